@@ -1,0 +1,137 @@
+"""Seeded synthetic checkpoints with the reference's ``state_dict`` layouts.
+
+There is no network on the build or GPU boxes, so every net on the hot path is exercised with
+deterministic random-init weights whose key names and shapes are exactly the ones the reference
+modules declare (checked with ``load_state_dict(strict=True)`` by ``tests/golden/make_golden.py``):
+
+* DB-ResNet18 ``DBModel``      -- /root/reference/src/pdftable/model/db_net/dbnet.py:715-728
+* ``CRNN``                     -- /root/reference/src/pdftable/model/crnn/modeling_crnn.py:36-90
+
+BatchNorm running statistics and affine terms are randomised (gamma, var in [0.5, 1.5]; beta, mean
+in [-0.1, 0.1]) so that BN folding in the weight packer is really exercised.
+numpy's Generator is used (not torch's RNG) so the stream does not depend on the torch build.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+__all__ = ["db_resnet18_state_dict", "crnn_state_dict", "CRNN_NUM_CLASSES"]
+
+CRNN_NUM_CLASSES = 7644  # crnn/modeling_crnn.py:90
+
+
+class _Gen:
+    def __init__(self, seed: int):
+        self.rng = np.random.default_rng(seed)
+        self.sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+
+    def put(self, name, arr):
+        self.sd[name] = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32))
+
+    def conv(self, name, cout, cin, kh, kw, bias=False, gain=2.0):
+        fan_in = cin * kh * kw
+        std = math.sqrt(gain / fan_in)
+        self.put(name + ".weight", self.rng.standard_normal((cout, cin, kh, kw)) * std)
+        if bias:
+            self.put(name + ".bias", self.rng.uniform(-0.1, 0.1, (cout,)))
+
+    def convT(self, name, cin, cout, kh, kw, gain=2.0):
+        # nn.ConvTranspose2d weight layout: [Cin, Cout, kh, kw]; always has a bias in the reference
+        std = math.sqrt(gain / cin)
+        self.put(name + ".weight", self.rng.standard_normal((cin, cout, kh, kw)) * std)
+        self.put(name + ".bias", self.rng.uniform(-0.1, 0.1, (cout,)))
+
+    def bn(self, name, c):
+        self.put(name + ".weight", self.rng.uniform(0.5, 1.5, (c,)))
+        self.put(name + ".bias", self.rng.uniform(-0.1, 0.1, (c,)))
+        self.put(name + ".running_mean", self.rng.uniform(-0.1, 0.1, (c,)))
+        self.put(name + ".running_var", self.rng.uniform(0.5, 1.5, (c,)))
+        self.sd[name + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+
+    def linear(self, name, cout, cin, bias=True):
+        k = 1.0 / math.sqrt(cin)
+        self.put(name + ".weight", self.rng.uniform(-k, k, (cout, cin)))
+        if bias:
+            self.put(name + ".bias", self.rng.uniform(-k, k, (cout,)))
+
+    def lstm(self, name, nin, nh):
+        k = 1.0 / math.sqrt(nh)
+        for sfx in ("", "_reverse"):
+            self.put(f"{name}.weight_ih_l0{sfx}", self.rng.uniform(-k, k, (4 * nh, nin)))
+            self.put(f"{name}.weight_hh_l0{sfx}", self.rng.uniform(-k, k, (4 * nh, nh)))
+            self.put(f"{name}.bias_ih_l0{sfx}", self.rng.uniform(-k, k, (4 * nh,)))
+            self.put(f"{name}.bias_hh_l0{sfx}", self.rng.uniform(-k, k, (4 * nh,)))
+
+
+def db_resnet18_state_dict(seed: int = 0, with_thresh_branch: bool = True):
+    """state_dict of ``DBModel`` (ResNet-18 backbone + ``SegDetector`` decoder, adaptive=True).
+
+    Key order follows module registration order in dbnet.py:260-336 (backbone) and :488-586
+    (decoder; the ``thresh`` branch exists in checkpoints but is never run in eval, :635-638).
+    """
+    g = _Gen(seed)
+    g.conv("backbone.conv1", 64, 3, 7, 7)
+    g.bn("backbone.bn1", 64)
+    inpl = 64
+    for li, planes in enumerate((64, 128, 256, 512), start=1):
+        for bi in range(2):
+            p = f"backbone.layer{li}.{bi}"
+            stride = 2 if (bi == 0 and li > 1) else 1
+            g.conv(p + ".conv1", planes, inpl, 3, 3)
+            g.bn(p + ".bn1", planes)
+            # residual branch scaled down a little so 8 blocks do not blow the dynamic range
+            g.conv(p + ".conv2", planes, planes, 3, 3, gain=1.0)
+            g.bn(p + ".bn2", planes)
+            if stride != 1 or inpl != planes:
+                g.conv(p + ".downsample.0", planes, inpl, 1, 1, gain=1.0)
+                g.bn(p + ".downsample.1", planes)
+            inpl = planes
+    # decoder (bias=False for the plain convs: SegDetector(..., bias=False) dbnet.py:494)
+    g.conv("decoder.in5", 256, 512, 1, 1)
+    g.conv("decoder.in4", 256, 256, 1, 1)
+    g.conv("decoder.in3", 256, 128, 1, 1)
+    g.conv("decoder.in2", 256, 64, 1, 1)
+    for n in ("out5.0", "out4.0", "out3.0", "out2"):
+        g.conv("decoder." + n, 64, 256, 3, 3)
+    g.conv("decoder.binarize.0", 64, 256, 3, 3)
+    g.bn("decoder.binarize.1", 64)
+    g.convT("decoder.binarize.3", 64, 64, 2, 2)
+    g.bn("decoder.binarize.4", 64)
+    # small gain on the last layer: logits with std ~5 (soft edges like a trained DB head) instead of ~50
+    g.convT("decoder.binarize.6", 64, 1, 2, 2, gain=0.02)
+    if with_thresh_branch:
+        g.conv("decoder.thresh.0", 64, 256, 3, 3)
+        g.bn("decoder.thresh.1", 64)
+        g.convT("decoder.thresh.3", 64, 64, 2, 2)
+        g.bn("decoder.thresh.4", 64)
+        g.convT("decoder.thresh.6", 64, 1, 2, 2)
+    return g.sd
+
+
+def crnn_state_dict(seed: int = 0, num_classes: int = CRNN_NUM_CLASSES):
+    """state_dict of ``CRNN`` (crnn/modeling_crnn.py:40-90); every conv has a bias."""
+    g = _Gen(seed)
+    g.conv("conv0.0", 64, 1, 3, 3, bias=True)
+    g.bn("conv0.1", 64)
+    g.conv("conv1.0", 128, 64, 3, 3, bias=True)
+    g.bn("conv1.1", 128)
+    g.conv("conv2.0", 256, 128, 3, 3, bias=True)
+    g.bn("conv2.1", 256)
+    g.conv("conv2.3", 256, 256, 3, 3, bias=True)
+    g.bn("conv2.4", 256)
+    g.conv("conv3.0", 512, 256, 3, 3, bias=True)
+    g.bn("conv3.1", 512)
+    g.conv("conv3.3", 512, 512, 3, 3, bias=True)
+    g.bn("conv3.4", 512)
+    g.conv("conv4.0", 512, 512, 2, 1, bias=True)
+    g.bn("conv4.1", 512)
+    g.lstm("rnn.0.rnn", 512, 256)
+    g.linear("rnn.0.embedding", 256, 512)
+    g.lstm("rnn.1.rnn", 256, 256)
+    g.linear("rnn.1.embedding", 512, 512)
+    g.linear("cls", num_classes, 512, bias=False)
+    return g.sd
