@@ -1,0 +1,138 @@
+/*
+ * pdftable_hip.h -- C ABI of libpdftable_hip.so, the MI355X (gfx950) engine behind pdf_table's
+ * four-stage page-vision path.
+ *
+ * The reference has NO FFI for this path: each stage is a Python ``BaseInferTask`` whose
+ * ``_run_model`` calls ``self.infer(...)`` which dispatches to PyTorch-eager or onnxruntime
+ * (reference: src/pdftable/model/ocr_pdf/base_infer_task.py:366-381).  The functions below are
+ * what a ``predictor_type == "hip"`` branch of that ``infer()`` binds (INTEGRATION.md shows the
+ * ctypes stub).  Conventions:
+ *   - plain pointers and sizes only; no torch / numpy types cross this boundary;
+ *   - every function returns an int status, 0 == PT_OK; pt_last_error() gives the message of the
+ *     last failure on the calling thread;
+ *   - pointers named d_* are DEVICE pointers on the engine's GPU, h_* are HOST pointers;
+ *   - weights, activations and scratch are engine-owned; inputs and outputs are caller-owned;
+ *   - one engine per GPU; calls on one engine must be serialised by the caller (the reference is
+ *     single-threaded, base_infer_task.py:311-315); distinct engines are independent;
+ *   - `stream` is a hipStream_t (0 = the null stream).  Calls are asynchronous on that stream
+ *     unless stated otherwise.
+ */
+#ifndef PDFTABLE_HIP_H
+#define PDFTABLE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_OK 0
+#define PT_ERR_INVALID 1   /* bad argument / shape */
+#define PT_ERR_HIP 2       /* a HIP runtime call failed */
+#define PT_ERR_STATE 3     /* e.g. weights for that model not loaded */
+#define PT_ERR_FORMAT 4    /* malformed weight blob */
+
+typedef struct pt_engine pt_engine;
+typedef void* pt_stream; /* hipStream_t */
+
+/* ---- lifetime (replaces DeployUtils.model_eval / prepare_onnx_model, utils/deploy_utils.py:227-280) ---- */
+int pt_engine_create(int device_id, pt_engine** out);
+void pt_engine_destroy(pt_engine* e);
+const char* pt_last_error(void);
+int pt_abi_version(void);
+
+/* Model kinds for pt_weights_load.  A blob is the "PTW1" container written by
+ * pdf_table_amd/weights.py (BN-folded, bf16 KRSC-tiled conv weights, fp32 biases). It replaces
+ * torch.load + load_state_dict of model/db_net/modeling_db_net.py:53-56 and
+ * model/ocr_recognition/modeling_ocr_recognition.py:102-132. */
+enum {
+  PT_MODEL_DB_RESNET18 = 1, /* db_net/dbnet.py:715-728 */
+  PT_MODEL_CRNN = 2,        /* crnn/modeling_crnn.py:36-113 */
+};
+int pt_weights_load(pt_engine* e, int model_kind, const void* h_blob, size_t nbytes);
+/* Same, but the blob already sits in device memory (e.g. after an RCCL broadcast from rank 0). */
+int pt_weights_load_device(pt_engine* e, int model_kind, const void* d_blob, size_t nbytes, pt_stream stream);
+
+/* ---- stage 2: DB text detection ------------------------------------------------------------- */
+
+/* Pre-process flavours: how a page is resized before the net. */
+#define PT_DET_PRE_DB_PP 0    /* max side <= 960, sides rounded to /32, ImageNet mean/std on BGR:
+                                 db_pp/image_operators.py:269-316,78-102; processor_ocr_db_pp.py:124 */
+#define PT_DET_PRE_DB_TORCH 1 /* short side 736, long side ceil to /32, (x - mean)/255 on BGR:
+                                 db_net/processor_ocr_dbnet.py:50-102 */
+#define PT_DET_PRE_NONE 2     /* no resize (h, w must be multiples of 32); db_pp normalisation */
+
+/* Resized (network) size the reference's pre-processor gives an h x w page. Pure host arithmetic. */
+int pt_det_plan(int h, int w, int pre_flavour, int* net_h, int* net_w);
+
+/* Full detection forward for n pages of identical size.
+ *   d_pages_rgb : uint8 [n, h, w, 3] RGB (as np.array(PIL.Image) gives; the BGR flip is done inside)
+ *   d_prob      : float32 [n, net_h, net_w]   sigmoid probability map   (may be NULL)
+ *   d_bitmap    : uint32  [n, net_h, net_w/32] bit x%32 of word x/32 = (prob > thresh), optionally
+ *                 2x2-dilated (DBPostProcess.__call__, db_pp/processor_ocr_db_pp.py:291-311) (may be NULL)
+ * Replaces OcrDetectionTask._preprocess + _run_model (ocr_detection_task.py:77-124) and the
+ * `pred > thresh` step of the post-processor. */
+int pt_det_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h, int w, int pre_flavour,
+                   float thresh, int use_dilation, float* d_prob, uint32_t* d_bitmap, pt_stream stream);
+
+/* Network only: d_input is bf16 NHWC4 [n, net_h, net_w, 4] (4th channel zero), already normalised.
+ * Used by parity tests to feed the net the exact tensor the oracle sees. d_logits (optional) gets the
+ * pre-sigmoid fp32 map. */
+int pt_det_forward_net(pt_engine* e, const uint16_t* d_input_bf16, int n, int net_h, int net_w,
+                       float* d_prob, float* d_logits, pt_stream stream);
+
+/* Pre-process only (tests / CPU-baseline inputs): writes bf16 NHWC4 [n, net_h, net_w, 4]. */
+int pt_det_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h, int w, int pre_flavour,
+                      uint16_t* d_out_bf16, pt_stream stream);
+
+/* prob -> bit-packed bitmap (see pt_det_forward). */
+int pt_det_bitmap(pt_engine* e, const float* d_prob, int n, int net_h, int net_w, float thresh,
+                  int use_dilation, uint32_t* d_bitmap, pt_stream stream);
+
+/* box_score_fast (db_pp/processor_ocr_db_pp.py:253-268) for nb quads on the device.
+ *   d_boxes : float32 [nb, 9] = (page index, x0,y0,x1,y1,x2,y2,x3,y3) in net-map pixels
+ *   d_scores: float32 [nb] mean probability inside the quad (cv2.fillPoly mask semantics) */
+int pt_det_box_scores(pt_engine* e, const float* d_prob, int n, int net_h, int net_w,
+                      const float* d_boxes, int nb, float* d_scores, pt_stream stream);
+
+/* Host side of DBPostProcess.boxes_from_bitmap (db_pp/processor_ocr_db_pp.py:174-251), split in the
+ * two halves that sit either side of pt_det_box_scores.  Pure CPU (C++), no GPU needed.
+ *
+ * pt_db_candidates: contour tracing (cv2.findContours RETR_LIST / CHAIN_APPROX_SIMPLE), first
+ *   max_candidates contours, min-area rectangle + get_mini_boxes ordering, drops sside < min_size.
+ *   h_bitmap: uint32 [net_h, net_w/32] of ONE page. h_boxes: float32 [cap, 8]; returns count in *n_out. */
+int pt_db_candidates(const uint32_t* h_bitmap, int net_h, int net_w, int max_candidates, float min_size,
+                     float* h_boxes, float* h_sside, int cap, int* n_out);
+/* pt_db_finalize: score gate, unclip (Clipper round-join offset by area*ratio/perimeter), second
+ *   min-area rectangle, sside gate (min_size + 2), rescale to the source page, round, clip.
+ *   Output h_out: int32 [cap, 8]; h_out_scores float32 [cap]. */
+int pt_db_finalize(const float* h_boxes, const float* h_scores, int nb, float box_thresh, float unclip_ratio,
+                   float min_size, int net_h, int net_w, int dest_h, int dest_w, int32_t* h_out,
+                   float* h_out_scores, int cap, int* n_out);
+
+/* ---- single operator (parity tests of the conv kernel variants) --------------------------------- */
+/* NHWC bf16 convolution on the MFMA implicit-GEMM kernel. d_w_tiled is [N/64][Cin/32][ks*ks][64][32] bf16
+ * (pdf_table_amd/weights.py:tile_conv_weight), d_bias fp32 [N]. ks in {1,3} (pad ks/2), stride in {1,2}.
+ * rep > 1: every output pixel is replicated rep x rep (fused nn.Upsample(nearest)); shuffle_cout > 0:
+ * N = 4*shuffle_cout and the output is the 2x up-sampled ConvTranspose2d(k=2,s=2) image;
+ * res_mode 1: + d_res (same shape as the un-replicated output); 2: + nearest-x2-upsampled d_res. */
+int pt_op_conv2d(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int Cin, const uint16_t* d_w_tiled,
+                 const float* d_bias, int N, int ks, int stride, uint16_t* d_out, int out_cstride, int out_coff,
+                 int rep, int shuffle_cout, const uint16_t* d_res, int res_mode, int relu, pt_stream stream);
+
+/* ---- introspection used by bench.py (HIP-event timing of the dominant kernel) ------------------ */
+/* When enabled, every conv launch inside pt_det_forward* is bracketed by hipEvents on `stream`.
+ * pt_profile_read returns accumulated milliseconds and launch count per kernel class. */
+#define PT_PROF_CONV3X3 0
+#define PT_PROF_CONV1X1 1
+#define PT_PROF_STEM 2
+#define PT_PROF_OTHER 3
+#define PT_PROF_NCLASS 4
+int pt_profile_enable(pt_engine* e, int on);
+int pt_profile_read(pt_engine* e, double* ms_per_class, long long* launches_per_class, double* flop_per_class);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDFTABLE_HIP_H */

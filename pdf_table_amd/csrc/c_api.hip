@@ -1,0 +1,302 @@
+// c_api.hip -- extern "C" surface of libpdftable_hip.so (declared in include/pdftable_hip.h).
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <cmath>
+
+#include "common.h"
+
+static thread_local char g_err[1024] = "";
+
+void pt_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" {
+
+const char* pt_last_error(void) { return g_err; }
+int pt_abi_version(void) { return 1; }
+
+int pt_engine_create(int device_id, pt_engine** out) {
+  PT_REQUIRE(out != nullptr, "pt_engine_create: out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  PT_HIP_CHECK(hipGetDeviceCount(&ndev));
+  PT_REQUIRE(device_id >= 0 && device_id < ndev, "pt_engine_create: device %d not in [0,%d)", device_id, ndev);
+  PT_HIP_CHECK(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  PT_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+  pt_engine* e = new pt_engine();
+  e->device = device_id;
+  e->num_cu = prop.multiProcessorCount;
+  *out = e;
+  return PT_OK;
+}
+
+void pt_engine_destroy(pt_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  (void)hipDeviceSynchronize();
+  for (auto& kv : e->models)
+    if (kv.second.d_blob) (void)hipFree(kv.second.d_blob);
+  if (e->arena.base) (void)hipFree(e->arena.base);
+  for (auto& p : e->prof.pending) {
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  delete e;
+}
+
+// ---- weights ---------------------------------------------------------------------------------------
+#pragma pack(push, 1)
+struct BlobEntry {
+  char name[96];
+  uint32_t dtype, ndim;
+  uint32_t dims[6];
+  uint64_t offset, nbytes;
+};
+#pragma pack(pop)
+
+static int register_blob(pt_engine* e, int kind, const uint8_t* h_head, size_t head_bytes, void* d_blob, size_t nbytes) {
+  if (head_bytes < 8 || memcmp(h_head, "PTW1", 4) != 0) {
+    pt_set_error("weight blob: bad magic");
+    return PT_ERR_FORMAT;
+  }
+  uint32_t nt;
+  memcpy(&nt, h_head + 4, 4);
+  if (8 + (size_t)nt * sizeof(BlobEntry) > head_bytes) {
+    pt_set_error("weight blob: truncated table (%u tensors)", nt);
+    return PT_ERR_FORMAT;
+  }
+  PtModel m;
+  m.d_blob = d_blob;
+  m.nbytes = nbytes;
+  for (uint32_t i = 0; i < nt; ++i) {
+    BlobEntry be;
+    memcpy(&be, h_head + 8 + (size_t)i * sizeof(BlobEntry), sizeof(be));
+    be.name[95] = 0;
+    if (be.offset + be.nbytes > nbytes || (be.offset & 255) || be.ndim > 6) {
+      pt_set_error("weight blob: tensor '%s' out of range", be.name);
+      return PT_ERR_FORMAT;
+    }
+    PtTensor t;
+    t.dtype = (int)be.dtype;
+    t.ndim = (int)be.ndim;
+    for (int k = 0; k < 6; ++k) t.dims[k] = be.dims[k];
+    t.nbytes = be.nbytes;
+    t.d_ptr = reinterpret_cast<const char*>(d_blob) + be.offset;
+    m.tensors[be.name] = t;
+  }
+  auto old = e->models.find(kind);
+  if (old != e->models.end()) {
+    (void)hipDeviceSynchronize();
+    (void)hipFree(old->second.d_blob);
+  }
+  e->models[kind] = m;
+  return PT_OK;
+}
+
+int pt_weights_load(pt_engine* e, int model_kind, const void* h_blob, size_t nbytes) {
+  PT_REQUIRE(e && h_blob && nbytes >= 8, "pt_weights_load: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  void* d = nullptr;
+  PT_HIP_CHECK(hipMalloc(&d, nbytes));
+  hipError_t he = hipMemcpy(d, h_blob, nbytes, hipMemcpyHostToDevice);
+  if (he != hipSuccess) {
+    (void)hipFree(d);
+    pt_set_error("hipMemcpy(weights) failed: %s", hipGetErrorString(he));
+    return PT_ERR_HIP;
+  }
+  uint32_t nt = 0;
+  memcpy(&nt, reinterpret_cast<const uint8_t*>(h_blob) + 4, 4);
+  size_t head = 8 + (size_t)nt * sizeof(BlobEntry);
+  if (head > nbytes) head = nbytes;
+  int rc = register_blob(e, model_kind, reinterpret_cast<const uint8_t*>(h_blob), head, d, nbytes);
+  if (rc != PT_OK) (void)hipFree(d);
+  return rc;
+}
+
+int pt_weights_load_device(pt_engine* e, int model_kind, const void* d_blob, size_t nbytes, pt_stream stream) {
+  PT_REQUIRE(e && d_blob && nbytes >= 8, "pt_weights_load_device: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  void* d = nullptr;
+  PT_HIP_CHECK(hipMalloc(&d, nbytes));
+  PT_HIP_CHECK(hipMemcpyAsync(d, d_blob, nbytes, hipMemcpyDeviceToDevice, s));
+  uint8_t h8[8];
+  PT_HIP_CHECK(hipMemcpyAsync(h8, d, 8, hipMemcpyDeviceToHost, s));
+  PT_HIP_CHECK(hipStreamSynchronize(s));
+  uint32_t nt = 0;
+  memcpy(&nt, h8 + 4, 4);
+  size_t head = 8 + (size_t)nt * sizeof(BlobEntry);
+  if (memcmp(h8, "PTW1", 4) != 0 || head > nbytes) {
+    (void)hipFree(d);
+    pt_set_error("weight blob: bad magic or table");
+    return PT_ERR_FORMAT;
+  }
+  std::vector<uint8_t> hh(head);
+  PT_HIP_CHECK(hipMemcpy(hh.data(), d, head, hipMemcpyDeviceToHost));
+  int rc = register_blob(e, model_kind, hh.data(), head, d, nbytes);
+  if (rc != PT_OK) (void)hipFree(d);
+  return rc;
+}
+
+// ---- detection ---------------------------------------------------------------------------------------
+int pt_det_plan(int h, int w, int pre_flavour, int* net_h, int* net_w) {
+  PT_REQUIRE(h > 0 && w > 0 && net_h && net_w, "pt_det_plan: bad arguments");
+  if (pre_flavour == PT_DET_PRE_DB_PP) {
+    // DetResizeForTest.resize_image_type0, limit_type 'max', limit_side_len 960 (image_operators.py:269-316)
+    const int limit = 960;
+    double ratio = 1.0;
+    if ((h > w ? h : w) > limit) ratio = (h > w) ? (double)limit / h : (double)limit / w;
+    int rh = (int)(h * ratio), rw = (int)(w * ratio);
+    // python round(): half to even
+    rh = (int)std::nearbyint(rh / 32.0) * 32;
+    rw = (int)std::nearbyint(rw / 32.0) * 32;
+    *net_h = rh < 32 ? 32 : rh;
+    *net_w = rw < 32 ? 32 : rw;
+  } else if (pre_flavour == PT_DET_PRE_DB_TORCH) {
+    // OCRDetectionPreprocessor.resize, short side 736 (processor_ocr_dbnet.py:50-60)
+    const int side = 736;
+    if (h < w) {
+      *net_h = side;
+      *net_w = (int)(std::ceil((double)side / h * w / 32.0) * 32);
+    } else {
+      *net_w = side;
+      *net_h = (int)(std::ceil((double)side / w * h / 32.0) * 32);
+    }
+  } else if (pre_flavour == PT_DET_PRE_NONE) {
+    PT_REQUIRE(h % 32 == 0 && w % 32 == 0, "PT_DET_PRE_NONE needs sizes that are multiples of 32");
+    *net_h = h;
+    *net_w = w;
+  } else {
+    pt_set_error("unknown pre-process flavour %d", pre_flavour);
+    return PT_ERR_INVALID;
+  }
+  return PT_OK;
+}
+
+int pt_det_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h, int w, int pre_flavour,
+                      uint16_t* d_out_bf16, pt_stream stream) {
+  PT_REQUIRE(e && d_pages_rgb && d_out_bf16 && n > 0, "pt_det_preprocess: bad arguments");
+  int nh, nw, rc;
+  if ((rc = pt_det_plan(h, w, pre_flavour, &nh, &nw)) != PT_OK) return rc;
+  return pt_launch_det_preprocess(d_pages_rgb, n, h, w, nh, nw, pre_flavour, d_out_bf16, reinterpret_cast<hipStream_t>(stream));
+}
+
+int pt_det_forward_net(pt_engine* e, const uint16_t* d_input_bf16, int n, int net_h, int net_w, float* d_prob,
+                       float* d_logits, pt_stream stream) {
+  PT_REQUIRE(e && d_input_bf16 && n > 0 && (d_prob || d_logits), "pt_det_forward_net: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  return pt_db_forward_net(e, d_input_bf16, n, net_h, net_w, d_prob, d_logits, reinterpret_cast<hipStream_t>(stream));
+}
+
+int pt_det_bitmap(pt_engine* e, const float* d_prob, int n, int net_h, int net_w, float thresh, int use_dilation,
+                  uint32_t* d_bitmap, pt_stream stream) {
+  PT_REQUIRE(e && d_prob && d_bitmap && n > 0, "pt_det_bitmap: bad arguments");
+  return pt_launch_bitmap(d_prob, n, net_h, net_w, thresh, use_dilation, d_bitmap, reinterpret_cast<hipStream_t>(stream));
+}
+
+static int microbatch() {
+  static int mb = -1;
+  if (mb < 0) {
+    const char* s = getenv("PT_DET_MICROBATCH");
+    mb = s ? atoi(s) : 8;
+    if (mb < 1) mb = 1;
+  }
+  return mb;
+}
+
+int pt_det_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h, int w, int pre_flavour, float thresh,
+                   int use_dilation, float* d_prob, uint32_t* d_bitmap, pt_stream stream) {
+  PT_REQUIRE(e && d_pages_rgb && n > 0 && d_prob, "pt_det_forward: bad arguments (d_prob is required)");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int nh, nw, rc;
+  if ((rc = pt_det_plan(h, w, pre_flavour, &nh, &nw)) != PT_OK) return rc;
+  const int mb = microbatch();
+  // the pre-processed pages live in their own engine-owned buffer (not the arena, which the net resets)
+  static thread_local void* xbuf = nullptr;
+  static thread_local size_t xcap = 0;
+  const size_t need = (size_t)(mb < n ? mb : n) * nh * nw * 4 * sizeof(bf16_t);
+  if (need > xcap) {
+    PT_HIP_CHECK(hipDeviceSynchronize());
+    if (xbuf) PT_HIP_CHECK(hipFree(xbuf));
+    xbuf = nullptr;
+    PT_HIP_CHECK(hipMalloc(&xbuf, need));
+    xcap = need;
+  }
+  for (int i0 = 0; i0 < n; i0 += mb) {
+    const int nb = (n - i0) < mb ? (n - i0) : mb;
+    {
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0);
+      rc = pt_launch_det_preprocess(d_pages_rgb + (size_t)i0 * h * w * 3, nb, h, w, nh, nw, pre_flavour,
+                                    reinterpret_cast<bf16_t*>(xbuf), s);
+      if (rc != PT_OK) return rc;
+    }
+    float* prob_i = d_prob + (size_t)i0 * nh * nw;
+    rc = pt_db_forward_net(e, reinterpret_cast<const bf16_t*>(xbuf), nb, nh, nw, prob_i, nullptr, s);
+    if (rc != PT_OK) return rc;
+    if (d_bitmap) {
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0);
+      rc = pt_launch_bitmap(prob_i, nb, nh, nw, thresh, use_dilation, d_bitmap + (size_t)i0 * nh * (nw / 32), s);
+      if (rc != PT_OK) return rc;
+    }
+  }
+  return PT_OK;
+}
+
+int pt_det_box_scores(pt_engine* e, const float* d_prob, int n, int net_h, int net_w, const float* d_boxes, int nb,
+                      float* d_scores, pt_stream stream) {
+  PT_REQUIRE(e && d_prob && (nb == 0 || (d_boxes && d_scores)), "pt_det_box_scores: bad arguments");
+  return pt_launch_box_scores(d_prob, n, net_h, net_w, d_boxes, nb, d_scores, reinterpret_cast<hipStream_t>(stream));
+}
+
+int pt_op_conv2d(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int Cin, const uint16_t* d_w_tiled,
+                 const float* d_bias, int N, int ks, int stride, uint16_t* d_out, int out_cstride, int out_coff,
+                 int rep, int shuffle_cout, const uint16_t* d_res, int res_mode, int relu, pt_stream stream) {
+  PT_REQUIRE(e != nullptr, "pt_op_conv2d: null engine");
+  ConvDesc d;
+  d.in = d_in; d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.w = d_w_tiled; d.bias = d_bias; d.N = N; d.ks = ks;
+  d.stride = stride; d.out = d_out; d.out_cstride = out_cstride; d.out_coff = out_coff; d.rep = rep;
+  d.shuffle_cout = shuffle_cout; d.res = d_res; d.res_mode = res_mode; d.relu = relu;
+  return pt_launch_conv(e, d, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ---- profiling ---------------------------------------------------------------------------------------
+int pt_profile_enable(pt_engine* e, int on) {
+  PT_REQUIRE(e != nullptr, "pt_profile_enable: null engine");
+  e->prof.on = on != 0;
+  return PT_OK;
+}
+
+int pt_profile_read(pt_engine* e, double* ms_per_class, long long* launches_per_class, double* flop_per_class) {
+  PT_REQUIRE(e != nullptr, "pt_profile_read: null engine");
+  PT_HIP_CHECK(hipDeviceSynchronize());
+  for (auto& p : e->prof.pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      e->prof.ms[p.cls] += ms;
+      e->prof.launches[p.cls] += 1;
+      e->prof.flop[p.cls] += p.flop;
+    }
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  e->prof.pending.clear();
+  for (int i = 0; i < PT_PROF_NCLASS; ++i) {
+    if (ms_per_class) ms_per_class[i] = e->prof.ms[i];
+    if (launches_per_class) launches_per_class[i] = e->prof.launches[i];
+    if (flop_per_class) flop_per_class[i] = e->prof.flop[i];
+    e->prof.ms[i] = 0;
+    e->prof.launches[i] = 0;
+    e->prof.flop[i] = 0;
+  }
+  return PT_OK;
+}
+
+}  // extern "C"

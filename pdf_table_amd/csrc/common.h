@@ -1,0 +1,159 @@
+// common.h -- engine internals shared by the HIP translation units of libpdftable_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pdftable_hip.h"
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+void pt_set_error(const char* fmt, ...);
+
+#define PT_HIP_CHECK(expr)                                                                  \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      pt_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return PT_ERR_HIP;                                                                    \
+    }                                                                                       \
+  } while (0)
+
+#define PT_REQUIRE(cond, ...)      \
+  do {                             \
+    if (!(cond)) {                 \
+      pt_set_error(__VA_ARGS__);   \
+      return PT_ERR_INVALID;       \
+    }                              \
+  } while (0)
+
+// ---- weight container ("PTW1") ----------------------------------------------------------------
+// header: char magic[4]="PTW1"; uint32 n_tensors; then n_tensors entries of
+//   char name[96]; uint32 dtype (0=bf16, 1=f32, 2=i32); uint32 ndim; uint32 dims[6]; uint64 offset; uint64 nbytes
+// data offsets are relative to the blob start and 256-byte aligned.
+struct PtTensor {
+  int dtype = 0;
+  int ndim = 0;
+  uint32_t dims[6] = {0, 0, 0, 0, 0, 0};
+  const void* d_ptr = nullptr;  // device pointer into the engine-owned copy of the blob
+  size_t nbytes = 0;
+};
+
+struct PtModel {
+  void* d_blob = nullptr;
+  size_t nbytes = 0;
+  std::map<std::string, PtTensor> tensors;
+  const PtTensor* find(const std::string& n) const {
+    auto it = tensors.find(n);
+    return it == tensors.end() ? nullptr : &it->second;
+  }
+};
+
+// ---- bump arena for activations ------------------------------------------------------------------
+struct PtArena {
+  char* base = nullptr;
+  size_t cap = 0;
+  size_t off = 0;
+  size_t high = 0;
+  void reset() { off = 0; }
+  // returns nullptr when out of space (caller grows and retries)
+  void* take(size_t n) {
+    size_t a = (off + 255) & ~size_t(255);
+    if (a + n > cap) {
+      high = a + n > high ? a + n : high;
+      off = a + n;
+      return nullptr;
+    }
+    off = a + n;
+    if (off > high) high = off;
+    return base + a;
+  }
+};
+
+struct PtProfile {
+  bool on = false;
+  double ms[PT_PROF_NCLASS] = {0, 0, 0, 0};
+  long long launches[PT_PROF_NCLASS] = {0, 0, 0, 0};
+  double flop[PT_PROF_NCLASS] = {0, 0, 0, 0};
+  struct Pending {
+    hipEvent_t a, b;
+    int cls;
+    double flop;
+  };
+  std::vector<Pending> pending;
+};
+
+struct pt_engine {
+  int device = 0;
+  int num_cu = 256;
+  PtArena arena;
+  std::map<int, PtModel> models;
+  PtProfile prof;
+};
+
+// ---- conv launcher (conv_igemm.hip) -----------------------------------------------------------------
+struct ConvDesc {
+  // input NHWC bf16
+  const bf16_t* in = nullptr;
+  int B = 0, H = 0, W = 0, Cin = 0;  // Cin multiple of 32 (channel stride == Cin)
+  // packed weights [N/64][Cin/32][taps][64][32] bf16, bias fp32 [N]
+  const bf16_t* w = nullptr;
+  const float* bias = nullptr;
+  int N = 0;       // GEMM N: Cout, or 4*Cout for a 2x2/s2 transposed conv
+  int ks = 3;      // 1 or 3 (square), padding = ks/2
+  int stride = 1;  // 1 or 2
+  // output
+  bf16_t* out = nullptr;
+  int out_cstride = 0;  // channels per pixel of the output buffer
+  int out_coff = 0;     // channel offset inside it (concat fusion)
+  int rep = 1;          // nearest-neighbour replicate factor (fused nn.Upsample)
+  int shuffle_cout = 0; // >0: pixel-shuffle epilogue of ConvTranspose2d(k=2,s=2) with this Cout
+  // residual
+  const bf16_t* res = nullptr;
+  int res_mode = 0;  // 0 none, 1 same resolution, 2 half resolution (fused nearest x2 upsample + add)
+  int relu = 0;
+};
+int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s);
+
+// stem: 7x7 s2 p3 conv on NHWC4 bf16 input, 64 outputs, bias + ReLU (conv_igemm.hip)
+int pt_launch_stem7x7(pt_engine* e, const bf16_t* in, int B, int H, int W, const bf16_t* w, const float* bias,
+                      bf16_t* out, hipStream_t s);
+
+// ---- misc kernels (det_kernels.hip) ---------------------------------------------------------------------
+int pt_launch_det_preprocess(const uint8_t* pages, int n, int h, int w, int nh, int nw, int flavour, bf16_t* out,
+                             hipStream_t s);
+int pt_launch_maxpool3x3s2(const bf16_t* in, int B, int H, int W, int C, bf16_t* out, hipStream_t s);
+int pt_launch_db_head_final(const bf16_t* in, int B, int H, int W, const bf16_t* w4x64, const float* bias, float* prob,
+                            float* logits, hipStream_t s);
+int pt_launch_bitmap(const float* prob, int n, int H, int W, float thresh, int dilate, uint32_t* bitmap,
+                     hipStream_t s);
+int pt_launch_box_scores(const float* prob, int n, int H, int W, const float* boxes, int nb, float* scores,
+                         hipStream_t s);
+
+// ---- models ---------------------------------------------------------------------------------------------
+int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* prob, float* logits, hipStream_t s);
+
+// profiling helper: bracket a launch with events when enabled
+struct PtProfScope {
+  pt_engine* e;
+  hipStream_t s;
+  int idx = -1;
+  PtProfScope(pt_engine* e_, hipStream_t s_, int cls, double flop) : e(e_), s(s_) {
+    if (e && e->prof.on) {
+      PtProfile::Pending p;
+      if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+      p.cls = cls;
+      p.flop = flop;
+      (void)hipEventRecord(p.a, s);
+      e->prof.pending.push_back(p);
+      idx = (int)e->prof.pending.size() - 1;
+    }
+  }
+  ~PtProfScope() {
+    if (idx >= 0) (void)hipEventRecord(e->prof.pending[idx].b, s);
+  }
+};

@@ -1,0 +1,423 @@
+// conv_igemm.hip -- implicit-GEMM convolution for gfx950 (MI355X), bf16 in / fp32 accumulate.
+//
+// Covers every dense conv of the hot-path nets (reference layer lists: SURVEY.md appendix A):
+//   3x3 s1/s2 and 1x1 s1/s2 convolutions of ResNet-18 / SegDetector (db_net/dbnet.py:102-171,
+//   260-336, 513-539) and the CRNN conv stack (crnn/modeling_crnn.py:40-87), plus
+//   ConvTranspose2d(k=2,s=2) as a 1x1 GEMM with N = 4*Cout and a pixel-shuffle epilogue.
+//
+// Design (DESIGN.md "conv kernel"):
+//   * activations NHWC bf16, weights pre-tiled [N/64][Cin/32][taps][64][32] bf16 (BN folded on host)
+//   * one workgroup = 4 waves = an 8x32 (stride 1) or 4x32 (stride 2) patch of output pixels x 64
+//     output channels; the input halo patch for a 32-channel slice is staged ONCE in LDS and all
+//     KSxKS taps read it from there (im2col never touches HBM/L2)
+//   * v_mfma_f32_32x32x16_bf16: the 32 MFMA rows are 32 consecutive output pixels of one image row,
+//     so an A fragment is one ds_read_b128 per lane at a fixed stride (80 B per pixel: 64 B of
+//     channels + 16 B pad => conflict-free across the 16-lane groups of ds_read_b128)
+//   * next K-slice is prefetched global->VGPR while the current one is multiplied (2 workgroups per
+//     CU cover the rest of the latency)
+//   * epilogue goes through LDS as fp32 so that bias + residual (+ fused nearest-x2 upsample of the
+//     residual) + ReLU + bf16 rounding + (replicated / pixel-shuffled / channel-offset) stores are
+//     all 16-byte, channel-contiguous accesses
+//   * blockIdx -> tile mapping is XCD-aware: consecutive logical tiles (all N-tiles of a patch, then
+//     the neighbouring patch) stay on one XCD so the halo and the weights hit that XCD's L2.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+struct ConvK {
+  const bf16_t* in;
+  const bf16_t* w;
+  const float* bias;
+  bf16_t* out;
+  const bf16_t* res;
+  int B, H, W, Cin, Ho, Wo, N;
+  int out_cstride, out_coff, rep, shuffle_cout, res_mode, relu;
+  int tiles_x, tiles_y, n_tiles;
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
+// round-to-nearest-even fp32 -> bf16 bits (inputs are finite on this path; NaN would become Inf/NaN-ish)
+__device__ __forceinline__ uint32_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+
+// XCD-aware bijective remap of the flat block id (8 XCDs; block b is observed to run on XCD b % 8)
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (id >> 3);
+}
+
+// Shared epilogue: fp32 tile [TH*32 pixels][64 ch] in LDS -> bias/residual/ReLU -> bf16 stores.
+template <int TH>
+__device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stage, int tid, int b, int oy0, int ox0,
+                                               int n0) {
+#pragma unroll
+  for (int j = 0; j < TH; ++j) {
+    const int idx = tid + j * 256;
+    const int pix = idx >> 3, cg = idx & 7;
+    const int ty = pix >> 5, tx = pix & 31;
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy >= p.Ho || ox >= p.Wo) continue;
+    const f32x4* sp = reinterpret_cast<const f32x4*>(stage + pix * 64 + cg * 8);
+    f32x4 v0 = sp[0], v1 = sp[1];
+    const int n = n0 + cg * 8;
+    const f32x4* bp = reinterpret_cast<const f32x4*>(p.bias + n);
+    f32x4 b0 = bp[0], b1 = bp[1];
+    float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
+    if (p.res_mode) {
+      size_t ro;
+      if (p.res_mode == 1)
+        ro = (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.N + n;
+      else
+        ro = (((size_t)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * p.N + n;
+      u32x4 r = *reinterpret_cast<const u32x4*>(p.res + ro);
+      v[0] += bf16_to_f32(r.x & 0xFFFFu); v[1] += bf16_to_f32(r.x >> 16);
+      v[2] += bf16_to_f32(r.y & 0xFFFFu); v[3] += bf16_to_f32(r.y >> 16);
+      v[4] += bf16_to_f32(r.z & 0xFFFFu); v[5] += bf16_to_f32(r.z >> 16);
+      v[6] += bf16_to_f32(r.w & 0xFFFFu); v[7] += bf16_to_f32(r.w >> 16);
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+    }
+    u32x4 o;
+    o.x = f32_to_bf16(v[0]) | (f32_to_bf16(v[1]) << 16);
+    o.y = f32_to_bf16(v[2]) | (f32_to_bf16(v[3]) << 16);
+    o.z = f32_to_bf16(v[4]) | (f32_to_bf16(v[5]) << 16);
+    o.w = f32_to_bf16(v[6]) | (f32_to_bf16(v[7]) << 16);
+    if (p.shuffle_cout) {
+      const int quad = n0 / p.shuffle_cout;
+      const int co = n0 - quad * p.shuffle_cout + cg * 8;
+      const int OH = p.Ho * 2, OW = p.Wo * 2;
+      const size_t oo = (((size_t)b * OH + 2 * oy + (quad >> 1)) * OW + 2 * ox + (quad & 1)) * p.out_cstride + p.out_coff + co;
+      *reinterpret_cast<u32x4*>(p.out + oo) = o;
+    } else {
+      const int f = p.rep;
+      const int OH = p.Ho * f, OW = p.Wo * f;
+      for (int fy = 0; fy < f; ++fy)
+        for (int fx = 0; fx < f; ++fx) {
+          const size_t oo = (((size_t)b * OH + oy * f + fy) * OW + ox * f + fx) * p.out_cstride + p.out_coff + n;
+          *reinterpret_cast<u32x4*>(p.out + oo) = o;
+        }
+    }
+  }
+}
+
+template <int KS, int STRIDE>
+struct ConvCfg {
+  static constexpr int TW = 32;
+  static constexpr int TH = (STRIDE == 1) ? 8 : 4;
+  static constexpr int MT = TH / 4;  // 1x32-pixel MFMA row-tiles per wave
+  static constexpr int THIN = (TH - 1) * STRIDE + KS;
+  static constexpr int TWIN = (TW - 1) * STRIDE + KS;
+  static constexpr int TAPS = KS * KS;
+  static constexpr int PIXB = 80;  // bytes per staged pixel / weight row: 32 bf16 + 16 B pad
+  static constexpr int IN_BYTES = THIN * TWIN * PIXB;
+  static constexpr int W_BYTES = TAPS * 64 * PIXB;
+  static constexpr int STAGE_BYTES = TH * TW * 64 * 4;
+  static constexpr int SMEM = (IN_BYTES + W_BYTES) > STAGE_BYTES ? (IN_BYTES + W_BYTES) : STAGE_BYTES;
+  static constexpr int NP_IN = THIN * TWIN * 4;  // 16-byte pieces of the input patch
+  static constexpr int NI = (NP_IN + 255) / 256;
+  static constexpr int NP_W = TAPS * 64 * 4;
+  static constexpr int NWP = NP_W / 256;
+  static_assert(NP_W % 256 == 0, "weight slice must be a whole number of 256-thread passes");
+};
+
+template <int KS, int STRIDE>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
+  using C = ConvCfg<KS, STRIDE>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_in = smem;
+  char* s_w = smem + C::IN_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, q = lane >> 5;
+
+  int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = L % p.n_tiles;
+  L /= p.n_tiles;
+  const int txi = L % p.tiles_x;
+  L /= p.tiles_x;
+  const int tyi = L % p.tiles_y;
+  const int b = L / p.tiles_y;
+  const int oy0 = tyi * C::TH, ox0 = txi * C::TW;
+  const int iy0 = oy0 * STRIDE - (KS / 2), ix0 = ox0 * STRIDE - (KS / 2);
+  const int nchunks = p.Cin >> 5;
+  const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * p.Cin;
+  const bf16_t* wt = p.w + (size_t)nt * nchunks * (C::TAPS * 64 * 32);
+
+  u32x4 rin[C::NI];
+  u32x4 rw[C::NWP];
+
+  auto prefetch = [&](int chunk) {
+    const int c0 = chunk << 5;
+#pragma unroll
+    for (int j = 0; j < C::NI; ++j) {
+      const int idx = tid + j * 256;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (idx < C::NP_IN) {
+        const int pix = idx >> 2, part = idx & 3;
+        const int iy = pix / C::TWIN, ix = pix - iy * C::TWIN;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+          v = *reinterpret_cast<const u32x4*>(in_b + ((size_t)gy * p.W + gx) * p.Cin + c0 + part * 8);
+      }
+      rin[j] = v;
+    }
+    const bf16_t* wc = wt + (size_t)chunk * (C::TAPS * 64 * 32);
+#pragma unroll
+    for (int j = 0; j < C::NWP; ++j) {
+      const int idx = tid + j * 256;
+      rw[j] = *reinterpret_cast<const u32x4*>(wc + idx * 8);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < C::NI; ++j) {
+      const int idx = tid + j * 256;
+      if (idx < C::NP_IN) *reinterpret_cast<u32x4*>(s_in + (idx >> 2) * C::PIXB + (idx & 3) * 16) = rin[j];
+    }
+#pragma unroll
+    for (int j = 0; j < C::NWP; ++j) {
+      const int idx = tid + j * 256;
+      *reinterpret_cast<u32x4*>(s_w + (idx >> 2) * C::PIXB + (idx & 3) * 16) = rw[j];
+    }
+  };
+
+  f32x16 acc[C::MT][2];
+#pragma unroll
+  for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  const char* a_base = s_in + (((wave * C::MT) * STRIDE) * C::TWIN + lx * STRIDE) * C::PIXB + q * 16;
+  const char* b_base = s_w + lx * C::PIXB + q * 16;
+
+  prefetch(0);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();  // everyone is done reading the previous slice
+    commit();
+    __syncthreads();
+    if (c + 1 < nchunks) prefetch(c + 1);
+#pragma unroll
+    for (int r = 0; r < KS; ++r) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int tap = r * KS + s;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(b_base + (tap * 64) * C::PIXB + kk * 32);
+          const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(b_base + (tap * 64 + 32) * C::PIXB + kk * 32);
+#pragma unroll
+          for (int m = 0; m < C::MT; ++m) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base + ((m * STRIDE + r) * C::TWIN + s) * C::PIXB + kk * 32);
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue through LDS (fp32 [pixel][64]) ----
+  __syncthreads();
+  float* stage = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int m = 0; m < C::MT; ++m) {
+    const int ty = wave * C::MT + m;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int tx = (r & 3) + 8 * (r >> 2) + 4 * q;
+        stage[(ty * 32 + tx) * 64 + n * 32 + lx] = acc[m][n][r];
+      }
+  }
+  __syncthreads();
+  epilogue_store<C::TH>(p, stage, tid, b, oy0, ox0, nt * 64);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Stem: 7x7 stride-2 pad-3 conv on a 4-channel (RGB0) bf16 image, 64 outputs, bias + ReLU.
+// K is laid out [r=7][s=8][c=4] = 224 (tap s=7 and channel 3 carry zero weights), so that one MFMA
+// k-step (16) = 4 horizontally adjacent pixels x 4 channels = 32 contiguous bytes of the image row.
+// ---------------------------------------------------------------------------------------------------
+struct StemCfg {
+  static constexpr int TH = 8, TW = 32;
+  static constexpr int THIN = (TH - 1) * 2 + 7;   // 21
+  static constexpr int TWIN = (TW - 1) * 2 + 8;   // 70
+  static constexpr int IN_BYTES = THIN * TWIN * 8;  // 11760
+  static constexpr int WROW = 464;                  // 224 bf16 = 448 B + 16 B pad (odd number of 16-B slots)
+  static constexpr int W_BYTES = 64 * WROW;
+  static constexpr int STAGE_BYTES = TH * TW * 64 * 4;
+  static constexpr int SMEM = STAGE_BYTES;  // > IN_BYTES + W_BYTES (41456)
+  static constexpr int NP_IN = THIN * (TWIN / 2);  // 735 pixel pairs
+  static constexpr int NI = (NP_IN + 255) / 256;   // 3
+  static constexpr int NP_W = 64 * 28;             // 1792 16-byte pieces
+  static constexpr int NWP = NP_W / 256;           // 7
+};
+
+__global__ __launch_bounds__(256, 2) void conv_stem7x7_kernel(ConvK p) {
+  using C = StemCfg;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_in = smem;
+  char* s_w = smem + C::IN_BYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, q = lane >> 5;
+
+  int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int txi = L % p.tiles_x;
+  L /= p.tiles_x;
+  const int tyi = L % p.tiles_y;
+  const int b = L / p.tiles_y;
+  const int oy0 = tyi * C::TH, ox0 = txi * C::TW;
+  const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+  const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * 4;
+
+#pragma unroll
+  for (int j = 0; j < C::NI; ++j) {
+    const int idx = tid + j * 256;
+    if (idx < C::NP_IN) {
+      const int iy = idx / 35, ip = idx - iy * 35;
+      const int gy = iy0 + iy, gx = ix0 + 2 * ip;
+      u32x2 v0 = {0u, 0u}, v1 = {0u, 0u};
+      if ((unsigned)gy < (unsigned)p.H) {
+        const bf16_t* rowp = in_b + (size_t)gy * p.W * 4;
+        if ((unsigned)gx < (unsigned)p.W) v0 = *reinterpret_cast<const u32x2*>(rowp + (size_t)gx * 4);
+        if ((unsigned)(gx + 1) < (unsigned)p.W) v1 = *reinterpret_cast<const u32x2*>(rowp + (size_t)(gx + 1) * 4);
+      }
+      u32x4 v = {v0.x, v0.y, v1.x, v1.y};
+      *reinterpret_cast<u32x4*>(s_in + (iy * C::TWIN + 2 * ip) * 8) = v;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < C::NWP; ++j) {
+    const int idx = tid + j * 256;
+    const int row = idx / 28, part = idx - row * 28;
+    *reinterpret_cast<u32x4*>(s_w + row * C::WROW + part * 16) = *reinterpret_cast<const u32x4*>(p.w + idx * 8);
+  }
+  __syncthreads();
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  const char* a_base = s_in + (((wave * 2) * 2) * C::TWIN + 2 * lx + 2 * q) * 8;
+  const char* b_base = s_w + lx * C::WROW + q * 16;
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ks = r * 2 + h;
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(b_base + ks * 32);
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(b_base + 32 * C::WROW + ks * 32);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base + ((m * 2 + r) * C::TWIN + 4 * h) * 8);
+        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
+        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();
+  float* stage = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int ty = wave * 2 + m;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int tx = (r & 3) + 8 * (r >> 2) + 4 * q;
+        stage[(ty * 32 + tx) * 64 + n * 32 + lx] = acc[m][n][r];
+      }
+  }
+  __syncthreads();
+  epilogue_store<C::TH>(p, stage, tid, b, oy0, ox0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <int KS, int STRIDE>
+static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
+  using C = ConvCfg<KS, STRIDE>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<KS, STRIDE>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
+    attr_done = true;
+  }
+  k.tiles_x = (k.Wo + C::TW - 1) / C::TW;
+  k.tiles_y = (k.Ho + C::TH - 1) / C::TH;
+  k.n_tiles = k.N / 64;
+  const long long nblk = (long long)k.B * k.tiles_x * k.tiles_y * k.n_tiles;
+  PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range (%lld blocks)", nblk);
+  PtProfScope prof(e, s, KS == 3 ? PT_PROF_CONV3X3 : PT_PROF_CONV1X1, flop);
+  hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
+  PT_REQUIRE(d.in && d.w && d.bias && d.out, "conv: null pointer");
+  PT_REQUIRE(d.Cin % 32 == 0 && d.Cin > 0, "conv: Cin=%d must be a positive multiple of 32", d.Cin);
+  PT_REQUIRE(d.N % 64 == 0 && d.N > 0, "conv: N=%d must be a positive multiple of 64", d.N);
+  PT_REQUIRE((d.ks == 1 || d.ks == 3) && (d.stride == 1 || d.stride == 2), "conv: ks=%d stride=%d unsupported", d.ks,
+             d.stride);
+  PT_REQUIRE(!(d.shuffle_cout && (d.rep != 1 || d.shuffle_cout % 64 != 0 || d.N != 4 * d.shuffle_cout)),
+             "conv: bad pixel-shuffle configuration");
+  PT_REQUIRE(d.rep >= 1 && d.out_cstride % 8 == 0 && d.out_coff % 8 == 0, "conv: bad output layout");
+  ConvK k;
+  k.in = d.in; k.w = d.w; k.bias = d.bias; k.out = d.out; k.res = d.res;
+  k.B = d.B; k.H = d.H; k.W = d.W; k.Cin = d.Cin; k.N = d.N;
+  const int pad = d.ks / 2;
+  k.Ho = (d.H + 2 * pad - d.ks) / d.stride + 1;
+  k.Wo = (d.W + 2 * pad - d.ks) / d.stride + 1;
+  k.out_cstride = d.out_cstride; k.out_coff = d.out_coff; k.rep = d.rep; k.shuffle_cout = d.shuffle_cout;
+  k.res_mode = d.res ? d.res_mode : 0; k.relu = d.relu;
+  if (k.res_mode == 2) PT_REQUIRE(k.Ho % 2 == 0 && k.Wo % 2 == 0, "conv: half-res residual needs even output size");
+  const double flop = 2.0 * k.B * k.Ho * k.Wo * (double)k.N * d.Cin * d.ks * d.ks;
+  if (d.ks == 3 && d.stride == 1) return launch_cfg<3, 1>(e, k, s, flop);
+  if (d.ks == 3 && d.stride == 2) return launch_cfg<3, 2>(e, k, s, flop);
+  if (d.ks == 1 && d.stride == 1) return launch_cfg<1, 1>(e, k, s, flop);
+  return launch_cfg<1, 2>(e, k, s, flop);
+}
+
+int pt_launch_stem7x7(pt_engine* e, const bf16_t* in, int B, int H, int W, const bf16_t* w, const float* bias,
+                      bf16_t* out, hipStream_t s) {
+  PT_REQUIRE(in && w && bias && out, "stem: null pointer");
+  PT_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: H, W must be even");
+  static bool attr_done = false;
+  if (!attr_done) {
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem7x7_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, StemCfg::SMEM));
+    attr_done = true;
+  }
+  ConvK k;
+  memset(&k, 0, sizeof(k));
+  k.in = in; k.w = w; k.bias = bias; k.out = out; k.res = nullptr;
+  k.B = B; k.H = H; k.W = W; k.Cin = 4; k.N = 64;
+  k.Ho = H / 2; k.Wo = W / 2;
+  k.out_cstride = 64; k.out_coff = 0; k.rep = 1; k.shuffle_cout = 0; k.res_mode = 0; k.relu = 1;
+  k.tiles_x = (k.Wo + 31) / 32; k.tiles_y = (k.Ho + 7) / 8; k.n_tiles = 1;
+  const long long nblk = (long long)B * k.tiles_x * k.tiles_y;
+  PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "stem grid out of range");
+  PtProfScope prof(e, s, PT_PROF_STEM, 2.0 * B * k.Ho * k.Wo * 64.0 * 147.0);
+  hipLaunchKernelGGL(conv_stem7x7_kernel, dim3((unsigned)nblk), dim3(256), StemCfg::SMEM, s, k);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}

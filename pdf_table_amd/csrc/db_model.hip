@@ -1,0 +1,190 @@
+// db_model.hip -- launch graph of the DB-ResNet18 text detector on the engine's kernels.
+//
+// Reference graph: DBModel.forward = SegDetector(ResNet(BasicBlock,[2,2,2,2]))
+//   model/db_net/dbnet.py:324-335 (backbone), :615-638 (decoder, eval branch), :533-539 (binarize head).
+// Fusions relative to the reference's op list (all arithmetic-preserving up to the bf16 contract in
+// DESIGN.md "numerics"): Conv+BN(+ReLU) folded; residual add + ReLU in the conv epilogue; the top-down
+// `up(x) + lateral` adds fused into the lateral 1x1 conv's epilogue (nearest x2 read of the residual);
+// the nn.Upsample(x8/x4/x2) + torch.cat fused into the out5/out4/out3/out2 conv epilogues (replicated
+// stores straight into the 256-channel concat buffer); ConvTranspose2d(2,2) as a GEMM with a
+// pixel-shuffle epilogue; the last ConvTranspose2d(64->1) + Sigmoid as one streaming kernel.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+struct DbWeights {
+  const PtTensor *stem_w, *stem_b;
+  struct Block {
+    const PtTensor *w1, *b1, *w2, *b2, *wd, *bd;
+  } blk[4][2];
+  const PtTensor *in_w[4], *in_b[4];    // in2..in5 (index 0 = in2)
+  const PtTensor *out_w[4], *out_b[4];  // out2..out5
+  const PtTensor *bin0_w, *bin0_b, *bin3_w, *bin3_b, *bin6_w, *bin6_b;
+};
+
+int get(const PtModel& m, const std::string& name, const PtTensor** out, bool optional = false) {
+  *out = m.find(name);
+  if (!*out && !optional) {
+    pt_set_error("weight blob lacks tensor '%s'", name.c_str());
+    return PT_ERR_FORMAT;
+  }
+  return PT_OK;
+}
+
+int bind(const PtModel& m, DbWeights& w) {
+  int rc;
+#define G(name, field) if ((rc = get(m, name, &w.field)) != PT_OK) return rc
+  G("stem.w", stem_w); G("stem.b", stem_b);
+  for (int l = 0; l < 4; ++l)
+    for (int b = 0; b < 2; ++b) {
+      const std::string p = "layer" + std::to_string(l + 1) + "." + std::to_string(b);
+      G(p + ".conv1.w", blk[l][b].w1); G(p + ".conv1.b", blk[l][b].b1);
+      G(p + ".conv2.w", blk[l][b].w2); G(p + ".conv2.b", blk[l][b].b2);
+      if ((rc = get(m, p + ".down.w", &w.blk[l][b].wd, true)) != PT_OK) return rc;
+      if ((rc = get(m, p + ".down.b", &w.blk[l][b].bd, true)) != PT_OK) return rc;
+    }
+  for (int i = 0; i < 4; ++i) {
+    const std::string k = std::to_string(i + 2);
+    G("in" + k + ".w", in_w[i]); G("in" + k + ".b", in_b[i]);
+    G("out" + k + ".w", out_w[i]); G("out" + k + ".b", out_b[i]);
+  }
+  G("bin0.w", bin0_w); G("bin0.b", bin0_b); G("bin3.w", bin3_w); G("bin3.b", bin3_b);
+  G("bin6.w", bin6_w); G("bin6.b", bin6_b);
+#undef G
+  return PT_OK;
+}
+
+inline const bf16_t* W(const PtTensor* t) { return reinterpret_cast<const bf16_t*>(t->d_ptr); }
+inline const float* Bv(const PtTensor* t) { return reinterpret_cast<const float*>(t->d_ptr); }
+
+struct Bufs {
+  bf16_t *s, *p, *t[4], *a[4], *c[4], *d[4], *in5, *o4, *o3, *o2, *fuse, *y0, *y1;
+};
+
+}  // namespace
+
+int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float* prob, float* logits, hipStream_t s) {
+  PT_REQUIRE(H % 32 == 0 && W_ % 32 == 0 && H > 0 && W_ > 0, "det net: input %dx%d must be multiples of 32", H, W_);
+  auto it = e->models.find(PT_MODEL_DB_RESNET18);
+  if (it == e->models.end()) {
+    pt_set_error("DB-ResNet18 weights not loaded (pt_weights_load(PT_MODEL_DB_RESNET18))");
+    return PT_ERR_STATE;
+  }
+  DbWeights w;
+  int rc = bind(it->second, w);
+  if (rc != PT_OK) return rc;
+
+  const int ch[4] = {64, 128, 256, 512};
+  Bufs bf;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    e->arena.reset();
+    bool ok = true;
+    auto take = [&](size_t elems) {
+      void* p = e->arena.take(elems * sizeof(bf16_t));
+      if (!p) ok = false;
+      return reinterpret_cast<bf16_t*>(p);
+    };
+    const size_t px2 = (size_t)n * (H / 2) * (W_ / 2), px4 = px2 / 4;
+    bf.s = take(px2 * 64);
+    bf.p = take(px4 * 64);
+    size_t px = px4;
+    for (int l = 0; l < 4; ++l) {
+      bf.t[l] = take(px * ch[l]); bf.a[l] = take(px * ch[l]); bf.c[l] = take(px * ch[l]);
+      bf.d[l] = l ? take(px * ch[l]) : nullptr;
+      px /= 4;
+    }
+    bf.in5 = take(px4 / 64 * 256); bf.o4 = take(px4 / 16 * 256); bf.o3 = take(px4 / 4 * 256); bf.o2 = take(px4 * 256);
+    bf.fuse = take(px4 * 256);
+    bf.y0 = take(px4 * 64);
+    bf.y1 = take(px2 * 64);
+    if (ok) break;
+    if (attempt == 1) {
+      pt_set_error("activation arena allocation failed");
+      return PT_ERR_HIP;
+    }
+    PT_HIP_CHECK(hipDeviceSynchronize());
+    if (e->arena.base) PT_HIP_CHECK(hipFree(e->arena.base));
+    e->arena.base = nullptr;
+    const size_t want = e->arena.high + (1u << 20);
+    PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arena.base), want));
+    e->arena.cap = want;
+  }
+
+#define RUN(call) do { if ((rc = (call)) != PT_OK) return rc; } while (0)
+  RUN(pt_launch_stem7x7(e, x, n, H, W_, W(w.stem_w), Bv(w.stem_b), bf.s, s));
+  {
+    PtProfScope ps(e, s, PT_PROF_OTHER, 0);
+    RUN(pt_launch_maxpool3x3s2(bf.s, n, H / 2, W_ / 2, 64, bf.p, s));
+  }
+  const bf16_t* cur = bf.p;
+  int ch_in = 64, hh = H / 4, ww = W_ / 4;
+  for (int l = 0; l < 4; ++l) {
+    for (int b = 0; b < 2; ++b) {
+      const int stride = (l > 0 && b == 0) ? 2 : 1;
+      const DbWeights::Block& bw = w.blk[l][b];
+      ConvDesc c1;
+      c1.in = cur; c1.B = n; c1.H = hh; c1.W = ww; c1.Cin = ch_in;
+      c1.w = W(bw.w1); c1.bias = Bv(bw.b1); c1.N = ch[l]; c1.ks = 3; c1.stride = stride;
+      c1.out = bf.t[l]; c1.out_cstride = ch[l]; c1.relu = 1;
+      RUN(pt_launch_conv(e, c1, s));
+      const bf16_t* res = cur;
+      if (bw.wd) {
+        ConvDesc cd;
+        cd.in = cur; cd.B = n; cd.H = hh; cd.W = ww; cd.Cin = ch_in;
+        cd.w = W(bw.wd); cd.bias = Bv(bw.bd); cd.N = ch[l]; cd.ks = 1; cd.stride = stride;
+        cd.out = bf.d[l]; cd.out_cstride = ch[l]; cd.relu = 0;
+        RUN(pt_launch_conv(e, cd, s));
+        res = bf.d[l];
+      }
+      hh /= stride; ww /= stride;
+      bf16_t* dst = (b == 0) ? bf.a[l] : bf.c[l];
+      ConvDesc c2;
+      c2.in = bf.t[l]; c2.B = n; c2.H = hh; c2.W = ww; c2.Cin = ch[l];
+      c2.w = W(bw.w2); c2.bias = Bv(bw.b2); c2.N = ch[l]; c2.ks = 3; c2.stride = 1;
+      c2.out = dst; c2.out_cstride = ch[l]; c2.res = res; c2.res_mode = 1; c2.relu = 1;
+      RUN(pt_launch_conv(e, c2, s));
+      cur = dst;
+      ch_in = ch[l];
+    }
+  }
+  // decoder: lateral 1x1 convs with the top-down add fused (in5 first, then in4 + up(in5), ...)
+  bf16_t* lat[4] = {bf.o2, bf.o3, bf.o4, bf.in5};  // index i <-> feature c[i]
+  for (int i = 3; i >= 0; --i) {
+    ConvDesc c;
+    c.in = bf.c[i]; c.B = n; c.H = H >> (2 + i); c.W = W_ >> (2 + i); c.Cin = ch[i];
+    c.w = W(w.in_w[i]); c.bias = Bv(w.in_b[i]); c.N = 256; c.ks = 1; c.stride = 1;
+    c.out = lat[i]; c.out_cstride = 256; c.relu = 0;
+    if (i < 3) { c.res = lat[i + 1]; c.res_mode = 2; }
+    RUN(pt_launch_conv(e, c, s));
+  }
+  // out5/out4/out3/out2: 3x3 256->64, nearest-upsampled x8/x4/x2/x1 and concatenated as (p5,p4,p3,p2)
+  for (int i = 3; i >= 0; --i) {
+    ConvDesc c;
+    c.in = lat[i]; c.B = n; c.H = H >> (2 + i); c.W = W_ >> (2 + i); c.Cin = 256;
+    c.w = W(w.out_w[i]); c.bias = Bv(w.out_b[i]); c.N = 64; c.ks = 3; c.stride = 1;
+    c.out = bf.fuse; c.out_cstride = 256; c.out_coff = (3 - i) * 64; c.rep = 1 << i; c.relu = 0;
+    RUN(pt_launch_conv(e, c, s));
+  }
+  {
+    ConvDesc c;
+    c.in = bf.fuse; c.B = n; c.H = H / 4; c.W = W_ / 4; c.Cin = 256;
+    c.w = W(w.bin0_w); c.bias = Bv(w.bin0_b); c.N = 64; c.ks = 3; c.stride = 1;
+    c.out = bf.y0; c.out_cstride = 64; c.relu = 1;
+    RUN(pt_launch_conv(e, c, s));
+  }
+  {
+    ConvDesc c;
+    c.in = bf.y0; c.B = n; c.H = H / 4; c.W = W_ / 4; c.Cin = 64;
+    c.w = W(w.bin3_w); c.bias = Bv(w.bin3_b); c.N = 256; c.ks = 1; c.stride = 1;
+    c.out = bf.y1; c.out_cstride = 64; c.shuffle_cout = 64; c.relu = 1;
+    RUN(pt_launch_conv(e, c, s));
+  }
+  {
+    PtProfScope ps(e, s, PT_PROF_OTHER, 0);
+    RUN(pt_launch_db_head_final(bf.y1, n, H / 2, W_ / 2, W(w.bin6_w), Bv(w.bin6_b), prob, logits, s));
+  }
+#undef RUN
+  return PT_OK;
+}

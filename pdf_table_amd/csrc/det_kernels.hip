@@ -1,0 +1,388 @@
+// det_kernels.hip -- HBM-bound kernels around the DB detector: page pre-process (resize + normalise),
+// 3x3/s2 max-pool, the 64->1 transposed-conv + sigmoid head, prob->bitmap, and box_score_fast.
+// Compiled with -ffp-contract=off: the float sequences below restate numpy/OpenCV op-by-op.
+#include <math.h>
+
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+__device__ __forceinline__ float bf2f(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
+__device__ __forceinline__ uint32_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Pre-process.  Restates, per output pixel:
+//   img[:, :, ::-1]                                    db_pp/processor_ocr_db_pp.py:124
+//   cv2.resize(img, (nw, nh))  (INTER_LINEAR, 8-bit)   db_pp/image_operators.py:310, db_net/processor_ocr_dbnet.py:58
+//   (x * (1/255) - mean) / std   [db_pp]               db_pp/image_operators.py:100-101
+//   (x - mean) / 255             [db torch]            db_net/processor_ocr_dbnet.py:62-65
+// OpenCV's 8-bit bilinear path is fixed point: 11-bit coefficients, horizontal pass in int32, vertical
+// pass ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2.  Exact 2x decimation switches to INTER_AREA.
+// ---------------------------------------------------------------------------------------------------
+struct ResizeCoef {
+  int s0, s1;
+  int a0, a1;
+};
+__device__ __forceinline__ ResizeCoef resize_coef(int d, double scale, int ssize, bool clamp_frac) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  ResizeCoef c;
+  if (clamp_frac) {  // horizontal direction: OpenCV pins fx at the borders
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+  }
+  c.a0 = (int)rintf((1.f - f) * 2048.f);
+  c.a1 = (int)rintf(f * 2048.f);
+  int t0 = s, t1 = s + 1;
+  t0 = t0 < 0 ? 0 : (t0 >= ssize ? ssize - 1 : t0);
+  t1 = t1 < 0 ? 0 : (t1 >= ssize ? ssize - 1 : t1);
+  c.s0 = t0;
+  c.s1 = t1;
+  return c;
+}
+
+__global__ __launch_bounds__(256) void det_preprocess_kernel(const uint8_t* __restrict__ pages, int n, int h, int w,
+                                                              int nh, int nw, int flavour, bf16_t* __restrict__ out) {
+  const long long total = (long long)n * nh * nw;
+  const double sx = (double)w / nw, sy = (double)h / nh;
+  const bool area2 = (w == 2 * nw) && (h == 2 * nh);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % nw);
+    const long long t = i / nw;
+    const int y = (int)(t % nh);
+    const int b = (int)(t / nh);
+    const uint8_t* src = pages + (size_t)b * h * w * 3;
+    int v[3];
+    if (w == nw && h == nh) {
+      const uint8_t* p = src + ((size_t)y * w + x) * 3;
+      v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+    } else if (area2) {
+      const uint8_t* p0 = src + ((size_t)(2 * y) * w + 2 * x) * 3;
+      const uint8_t* p1 = p0 + (size_t)w * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = (p0[c] + p0[3 + c] + p1[c] + p1[3 + c] + 2) >> 2;
+    } else {
+      const ResizeCoef cx = resize_coef(x, sx, w, true);
+      const ResizeCoef cy = resize_coef(y, sy, h, false);
+      const uint8_t* r0 = src + (size_t)cy.s0 * w * 3;
+      const uint8_t* r1 = src + (size_t)cy.s1 * w * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int S0 = r0[cx.s0 * 3 + c] * cx.a0 + r0[cx.s1 * 3 + c] * cx.a1;
+        const int S1 = r1[cx.s0 * 3 + c] * cx.a0 + r1[cx.s1 * 3 + c] * cx.a1;
+        v[c] = (((cy.a0 * (S0 >> 4)) >> 16) + ((cy.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
+        v[c] = v[c] < 0 ? 0 : (v[c] > 255 ? 255 : v[c]);
+      }
+    }
+    float o[3];
+    if (flavour == PT_DET_PRE_DB_TORCH) {
+      const float mean[3] = {123.68f, 116.78f, 103.94f};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o[c] = ((float)v[2 - c] - mean[c]) / 255.f;
+    } else {
+      const float scale = (float)(1.0 / 255.0);
+      const float mean[3] = {0.485f, 0.456f, 0.406f};
+      const float stdv[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o[c] = ((float)v[2 - c] * scale - mean[c]) / stdv[c];
+    }
+    u32x2 pk;
+    pk.x = f2bf(o[0]) | (f2bf(o[1]) << 16);
+    pk.y = f2bf(o[2]);
+    *reinterpret_cast<u32x2*>(out + (size_t)i * 4) = pk;
+  }
+}
+
+int pt_launch_det_preprocess(const uint8_t* pages, int n, int h, int w, int nh, int nw, int flavour, bf16_t* out,
+                             hipStream_t s) {
+  const long long total = (long long)n * nh * nw;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(det_preprocess_kernel, dim3(blocks), dim3(256), 0, s, pages, n, h, w, nh, nw, flavour, out);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// MaxPool2d(kernel 3, stride 2, padding 1) on NHWC bf16 (dbnet.py:276).  8 channels (16 B) per thread.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t bfmax2(uint32_t a, uint32_t b) {
+  const float al = bf2f(a & 0xFFFFu), bl = bf2f(b & 0xFFFFu);
+  const float ah = __uint_as_float(a & 0xFFFF0000u), bh = __uint_as_float(b & 0xFFFF0000u);
+  const uint32_t lo = (bl > al) ? (b & 0xFFFFu) : (a & 0xFFFFu);
+  const uint32_t hi = (bh > ah) ? (b & 0xFFFF0000u) : (a & 0xFFFF0000u);
+  return lo | hi;
+}
+
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const bf16_t* __restrict__ in, int B, int H, int W, int C,
+                                                            bf16_t* __restrict__ out) {
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int cg = C >> 3;
+  const long long total = (long long)B * Ho * Wo * cg;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cg);
+    long long t = i / cg;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    u32x4 m;
+    bool first = true;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = oy * 2 - 1 + dy;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ix = ox * 2 - 1 + dx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(in + (((size_t)b * H + iy) * W + ix) * C + g * 8);
+        if (first) {
+          m = v;
+          first = false;
+        } else {
+          m.x = bfmax2(m.x, v.x); m.y = bfmax2(m.y, v.y); m.z = bfmax2(m.z, v.z); m.w = bfmax2(m.w, v.w);
+        }
+      }
+    }
+    *reinterpret_cast<u32x4*>(out + (size_t)i * 8) = m;
+  }
+}
+
+int pt_launch_maxpool3x3s2(const bf16_t* in, int B, int H, int W, int C, bf16_t* out, hipStream_t s) {
+  PT_REQUIRE(C % 8 == 0, "maxpool: C must be a multiple of 8");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long total = (long long)B * Ho * Wo * (C / 8);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(blocks), dim3(256), 0, s, in, B, H, W, C, out);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// DB head tail: ConvTranspose2d(64 -> 1, k=2, s=2) + Sigmoid (dbnet.py:539).
+// in [B,H,W,64] bf16 -> prob fp32 [B,2H,2W].  8 lanes share one input pixel (16 B each, coalesced);
+// partial dot products are combined with a 3-step xor-shuffle; lanes 0..3 of the group store the
+// 2x2 output patch.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void db_head_final_kernel(const bf16_t* __restrict__ in, int B, int H, int W,
+                                                             const bf16_t* __restrict__ w4x64, const float* __restrict__ bias_p,
+                                                             float* __restrict__ prob, float* __restrict__ logits) {
+  const int sub = threadIdx.x & 7;
+  const float bias = bias_p[0];
+  float wq[4][8];
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    const u32x4 wv = *reinterpret_cast<const u32x4*>(w4x64 + qd * 64 + sub * 8);
+    wq[qd][0] = bf2f(wv.x & 0xFFFFu); wq[qd][1] = bf2f(wv.x >> 16);
+    wq[qd][2] = bf2f(wv.y & 0xFFFFu); wq[qd][3] = bf2f(wv.y >> 16);
+    wq[qd][4] = bf2f(wv.z & 0xFFFFu); wq[qd][5] = bf2f(wv.z >> 16);
+    wq[qd][6] = bf2f(wv.w & 0xFFFFu); wq[qd][7] = bf2f(wv.w >> 16);
+  }
+  const long long npix = (long long)B * H * W;
+  const long long gstride = ((long long)gridDim.x * blockDim.x) >> 3;
+  for (long long pix = (((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3); pix < npix; pix += gstride) {
+    const u32x4 xv = *reinterpret_cast<const u32x4*>(in + (size_t)pix * 64 + sub * 8);
+    float x[8] = {bf2f(xv.x & 0xFFFFu), bf2f(xv.x >> 16), bf2f(xv.y & 0xFFFFu), bf2f(xv.y >> 16),
+                  bf2f(xv.z & 0xFFFFu), bf2f(xv.z >> 16), bf2f(xv.w & 0xFFFFu), bf2f(xv.w >> 16)};
+    float acc[4];
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a = fmaf(x[k], wq[qd][k], a);
+      acc[qd] = a;
+    }
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      acc[qd] += __shfl_xor(acc[qd], 1);
+      acc[qd] += __shfl_xor(acc[qd], 2);
+      acc[qd] += __shfl_xor(acc[qd], 4);
+    }
+    if (sub < 4) {
+      const float lg = (sub == 0 ? acc[0] : sub == 1 ? acc[1] : sub == 2 ? acc[2] : acc[3]) + bias;
+      const int xx = (int)(pix % W);
+      const long long t = pix / W;
+      const int yy = (int)(t % H);
+      const int b = (int)(t / H);
+      const size_t o = ((size_t)b * (2 * H) + 2 * yy + (sub >> 1)) * (size_t)(2 * W) + 2 * xx + (sub & 1);
+      if (logits) logits[o] = lg;
+      if (prob) prob[o] = 1.f / (1.f + expf(-lg));
+    }
+  }
+}
+
+int pt_launch_db_head_final(const bf16_t* in, int B, int H, int W, const bf16_t* w4x64, const float* bias, float* prob,
+                            float* logits, hipStream_t s) {
+  const long long nthreads = (long long)B * H * W * 8;
+  int blocks = (int)((nthreads + 255) / 256);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(db_head_final_kernel, dim3(blocks), dim3(256), 0, s, in, B, H, W, w4x64, bias, prob, logits);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// prob > thresh -> bit-packed bitmap (DBPostProcess.__call__, processor_ocr_db_pp.py:296), with the
+// optional 2x2 all-ones cv2.dilate (anchor (1,1): out(x,y) = max over x-1..x, y-1..y; :301-304).
+// One lane per pixel, wave ballot -> two 32-bit words.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bitmap_kernel(const float* __restrict__ prob, int n, int H, int W, float thresh,
+                                                      int dilate, uint32_t* __restrict__ bitmap) {
+  const long long total = (long long)n * H * W;  // W % 32 == 0 -> total % 32 == 0
+  const long long rounded = (total + 63) & ~63ll;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += (long long)gridDim.x * blockDim.x) {
+    bool on = false;
+    if (i < total) {
+      if (!dilate) {
+        on = prob[i] > thresh;
+      } else {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        on = prob[i] > thresh;
+        if (x > 0) on = on || (prob[i - 1] > thresh);
+        if (y > 0) on = on || (prob[i - W] > thresh);
+        if (x > 0 && y > 0) on = on || (prob[i - W - 1] > thresh);
+      }
+    }
+    const unsigned long long m = __ballot(on);
+    const int lane = threadIdx.x & 63;
+    if (lane == 0 && i < total) bitmap[i >> 5] = (uint32_t)m;
+    if (lane == 32 && i < total) bitmap[i >> 5] = (uint32_t)(m >> 32);
+  }
+}
+
+int pt_launch_bitmap(const float* prob, int n, int H, int W, float thresh, int dilate, uint32_t* bitmap,
+                     hipStream_t s) {
+  PT_REQUIRE(W % 32 == 0, "bitmap: W must be a multiple of 32");
+  const long long total = (long long)n * H * W;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(bitmap_kernel, dim3(blocks), dim3(256), 0, s, prob, n, H, W, thresh, dilate, bitmap);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// box_score_fast (processor_ocr_db_pp.py:253-268): mean of prob over the cv2.fillPoly mask of the
+// quad inside its clipped bounding rectangle.  fillPoly semantics restated from OpenCV's drawing.cpp
+// (CollectPolyEdges + FillEdgeCollection, shift = 0, 8-connected): Bresenham outline of every edge
+// (iterated left-to-right, error term rounds exact halves toward the start point) united with the
+// scan-line interior x in [ (xa+0x8000)>>16 , (xb+0x8000)>>16 ] for ymin <= y < ymax, edges advanced
+// in 16.16 fixed point with a truncated slope.  One wave per box; double accumulation like cv2.mean.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool on_bresenham(int px, int py, int x0, int y0, int x1, int y1) {
+  // left-to-right start point
+  if (x1 < x0) { int t = x0; x0 = x1; x1 = t; t = y0; y0 = y1; y1 = t; }
+  const int dx = x1 - x0;
+  const int dyabs = y1 >= y0 ? y1 - y0 : y0 - y1;
+  const int sy = y1 >= y0 ? 1 : -1;
+  if (dyabs > dx) {  // y-major
+    const int j = (py - y0) * sy;
+    if (j < 0 || j > dyabs) return false;
+    const int m = (int)((2ll * dx * j + dyabs - 1) / (2ll * dyabs));
+    return px == x0 + m;
+  }
+  if (dx == 0) return px == x0 && py == y0;  // single point
+  const int j = px - x0;
+  if (j < 0 || j > dx) return false;
+  const int m = (int)((2ll * dyabs * j + dx - 1) / (2ll * dx));
+  return py == y0 + sy * m;
+}
+
+__global__ __launch_bounds__(64) void box_score_kernel(const float* __restrict__ prob, int n, int H, int W,
+                                                        const float* __restrict__ boxes, int nb,
+                                                        float* __restrict__ scores) {
+  const int bi = blockIdx.x;
+  if (bi >= nb) return;
+  const float* bx = boxes + (size_t)bi * 9;
+  const int page = (int)bx[0];
+  float fx[4], fy[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { fx[k] = bx[1 + 2 * k]; fy[k] = bx[2 + 2 * k]; }
+  const float mnx = fminf(fminf(fx[0], fx[1]), fminf(fx[2], fx[3]));
+  const float mxx = fmaxf(fmaxf(fx[0], fx[1]), fmaxf(fx[2], fx[3]));
+  const float mny = fminf(fminf(fy[0], fy[1]), fminf(fy[2], fy[3]));
+  const float mxy = fmaxf(fmaxf(fy[0], fy[1]), fmaxf(fy[2], fy[3]));
+  auto clampi = [](long long v, int lo, int hi) { return (int)(v < lo ? lo : (v > hi ? hi : v)); };
+  const int xmin = clampi((long long)floorf(mnx), 0, W - 1), xmax = clampi((long long)ceilf(mxx), 0, W - 1);
+  const int ymin = clampi((long long)floorf(mny), 0, H - 1), ymax = clampi((long long)ceilf(mxy), 0, H - 1);
+  const int mw = xmax - xmin + 1, mh = ymax - ymin + 1;
+  int vx[4], vy[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    vx[k] = (int)(fx[k] - (float)xmin);  // astype(int32): truncation toward zero
+    vy[k] = (int)(fy[k] - (float)ymin);
+  }
+  // polygon edges for the scan-line part
+  int ey0[4], ey1[4];
+  long long ex[4], edx[4];
+  int ne = 0;
+  int pymin = vy[0], pymax = vy[0];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    pymin = vy[k] < pymin ? vy[k] : pymin;
+    pymax = vy[k] > pymax ? vy[k] : pymax;
+    const int k0 = (k + 3) & 3;
+    const int ax = vx[k0], ay = vy[k0], cx = vx[k], cy = vy[k];
+    if (ay == cy) continue;
+    const long long X0 = (long long)ax << 16, X1 = (long long)cx << 16;
+    if (ay < cy) { ey0[ne] = ay; ey1[ne] = cy; ex[ne] = X0; } else { ey0[ne] = cy; ey1[ne] = ay; ex[ne] = X1; }
+    edx[ne] = (X1 - X0) / (cy - ay);
+    ++ne;
+  }
+  const float* pm = prob + (size_t)page * H * W;
+  double sum = 0.0;
+  int cnt = 0;
+  const int lane = threadIdx.x;
+  const int npx = mw * mh;
+  for (int t = lane; t < npx; t += 64) {
+    const int py = t / mw, px = t - py * mw;
+    bool in = false;
+    if (py >= pymin && py < pymax) {
+      long long xs[4];
+      int na = 0;
+      for (int k = 0; k < ne; ++k)
+        if (py >= ey0[k] && py < ey1[k]) xs[na++] = ex[k] + (long long)(py - ey0[k]) * edx[k];
+      // sort (na <= 4)
+      for (int a = 1; a < na; ++a)
+        for (int c = a; c > 0 && xs[c] < xs[c - 1]; --c) { long long tt = xs[c]; xs[c] = xs[c - 1]; xs[c - 1] = tt; }
+      for (int a = 0; a + 1 < na; a += 2) {
+        const int x1 = (int)((xs[a] + 32768) >> 16), x2 = (int)((xs[a + 1] + 32768) >> 16);
+        if (px >= x1 && px <= x2) in = true;
+      }
+    }
+    if (!in) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int k0 = (k + 3) & 3;
+        if (on_bresenham(px, py, vx[k0], vy[k0], vx[k], vy[k])) in = true;
+      }
+    }
+    if (in) {
+      sum += (double)pm[(size_t)(ymin + py) * W + (xmin + px)];
+      ++cnt;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    sum += __shfl_xor(sum, off);
+    cnt += __shfl_xor(cnt, off);
+  }
+  if (lane == 0) scores[bi] = cnt > 0 ? (float)(sum / (double)cnt) : 0.f;
+}
+
+int pt_launch_box_scores(const float* prob, int n, int H, int W, const float* boxes, int nb, float* scores,
+                         hipStream_t s) {
+  if (nb <= 0) return PT_OK;
+  hipLaunchKernelGGL(box_score_kernel, dim3(nb), dim3(64), 0, s, prob, n, H, W, boxes, nb, scores);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}

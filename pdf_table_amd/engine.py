@@ -1,0 +1,188 @@
+"""Python handle on one MI355X engine (one per GPU / per process).
+
+PyTorch is used here only as plumbing: it owns the caller-side device buffers (inputs / outputs) and
+the HIP stream; every compute call goes through the C ABI of libpdftable_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+__all__ = ["HipEngine"]
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class HipEngine:
+    def __init__(self, device: int = 0):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise L.PtError("no HIP device visible: the engine has no CPU fallback")
+        self.device = int(device)
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        L.check(self.lib.pt_engine_create(self.device, C.byref(h)), "pt_engine_create")
+        self._h = h
+        self._tdev = torch.device("cuda", self.device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.pt_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- plumbing -------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self._tdev).cuda_stream)
+
+    def _chk(self, t: torch.Tensor, dtype, name):
+        if not (t.is_cuda and t.device.index == self.device and t.dtype == dtype and t.is_contiguous()):
+            raise L.PtError(f"{name}: expected contiguous {dtype} tensor on cuda:{self.device}, got "
+                            f"{t.dtype} on {t.device} (contiguous={t.is_contiguous()})")
+
+    # ---- weights ----------------------------------------------------------------------------------
+    def load_weights(self, kind: int, blob: bytes):
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        L.check(self.lib.pt_weights_load(self._h, kind, C.cast(buf, C.c_void_p), len(blob)), "pt_weights_load")
+
+    def load_weights_device(self, kind: int, blob_u8: torch.Tensor):
+        self._chk(blob_u8, torch.uint8, "blob")
+        L.check(self.lib.pt_weights_load_device(self._h, kind, _ptr(blob_u8), blob_u8.numel(), self._stream()),
+                "pt_weights_load_device")
+
+    # ---- detection --------------------------------------------------------------------------------
+    def det_plan(self, h: int, w: int, flavour: int = L.PT_DET_PRE_DB_PP) -> Tuple[int, int]:
+        nh, nw = C.c_int(), C.c_int()
+        L.check(self.lib.pt_det_plan(h, w, flavour, C.byref(nh), C.byref(nw)), "pt_det_plan")
+        return nh.value, nw.value
+
+    def det_forward(self, pages: torch.Tensor, flavour: int = L.PT_DET_PRE_DB_PP, thresh: float = 0.3,
+                    use_dilation: bool = False, want_bitmap: bool = True, out_prob=None, out_bitmap=None):
+        """pages uint8 [n,h,w,3] RGB on the GPU -> (prob f32 [n,nh,nw], bitmap int32 [n,nh,nw/32] or None)."""
+        self._chk(pages, torch.uint8, "pages")
+        n, h, w, c = pages.shape
+        assert c == 3
+        nh, nw = self.det_plan(h, w, flavour)
+        prob = out_prob if out_prob is not None else torch.empty((n, nh, nw), dtype=torch.float32, device=self._tdev)
+        bitmap = None
+        if want_bitmap:
+            bitmap = out_bitmap if out_bitmap is not None else torch.empty((n, nh, nw // 32), dtype=torch.int32,
+                                                                             device=self._tdev)
+        L.check(self.lib.pt_det_forward(self._h, _ptr(pages), n, h, w, flavour, float(thresh), int(use_dilation),
+                                        _ptr(prob), _ptr(bitmap), self._stream()), "pt_det_forward")
+        return prob, bitmap
+
+    def det_preprocess(self, pages: torch.Tensor, flavour: int = L.PT_DET_PRE_DB_PP) -> torch.Tensor:
+        self._chk(pages, torch.uint8, "pages")
+        n, h, w, _ = pages.shape
+        nh, nw = self.det_plan(h, w, flavour)
+        out = torch.empty((n, nh, nw, 4), dtype=torch.bfloat16, device=self._tdev)
+        L.check(self.lib.pt_det_preprocess(self._h, _ptr(pages), n, h, w, flavour, _ptr(out), self._stream()),
+                "pt_det_preprocess")
+        return out
+
+    def det_forward_net(self, x: torch.Tensor, want_logits: bool = False):
+        """x bf16 NHWC4 [n,H,W,4] -> prob f32 [n,H,W] (and logits)."""
+        self._chk(x, torch.bfloat16, "x")
+        n, H, W, c = x.shape
+        assert c == 4
+        prob = torch.empty((n, H, W), dtype=torch.float32, device=self._tdev)
+        logits = torch.empty((n, H, W), dtype=torch.float32, device=self._tdev) if want_logits else None
+        L.check(self.lib.pt_det_forward_net(self._h, _ptr(x), n, H, W, _ptr(prob), _ptr(logits), self._stream()),
+                "pt_det_forward_net")
+        return (prob, logits) if want_logits else prob
+
+    def det_bitmap(self, prob: torch.Tensor, thresh: float, use_dilation: bool = False) -> torch.Tensor:
+        self._chk(prob, torch.float32, "prob")
+        n, H, W = prob.shape
+        bm = torch.empty((n, H, W // 32), dtype=torch.int32, device=self._tdev)
+        L.check(self.lib.pt_det_bitmap(self._h, _ptr(prob), n, H, W, float(thresh), int(use_dilation), _ptr(bm),
+                                       self._stream()), "pt_det_bitmap")
+        return bm
+
+    def det_box_scores(self, prob: torch.Tensor, boxes: torch.Tensor) -> torch.Tensor:
+        """boxes f32 [nb, 9] = (page, x0,y0,...,x3,y3) -> scores f32 [nb]."""
+        self._chk(prob, torch.float32, "prob")
+        self._chk(boxes, torch.float32, "boxes")
+        n, H, W = prob.shape
+        nb = boxes.shape[0]
+        scores = torch.empty((nb,), dtype=torch.float32, device=self._tdev)
+        if nb:
+            L.check(self.lib.pt_det_box_scores(self._h, _ptr(prob), n, H, W, _ptr(boxes), nb, _ptr(scores),
+                                               self._stream()), "pt_det_box_scores")
+        return scores
+
+    def op_conv2d(self, x: torch.Tensor, w_tiled: torch.Tensor, bias: torch.Tensor, ks: int, stride: int = 1,
+                  relu: bool = False, res: Optional[torch.Tensor] = None, res_mode: int = 0, rep: int = 1,
+                  shuffle_cout: int = 0, out: Optional[torch.Tensor] = None, out_coff: int = 0) -> torch.Tensor:
+        """Single conv on the MFMA kernel.  x bf16 [B,H,W,Cin]; w_tiled int16/bf16 bits; bias f32 [N]."""
+        self._chk(x, torch.bfloat16, "x")
+        self._chk(bias, torch.float32, "bias")
+        B, H, W, Cin = x.shape
+        N = bias.numel()
+        pad = ks // 2
+        Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+        if out is None:
+            if shuffle_cout:
+                out = torch.empty((B, 2 * Ho, 2 * Wo, shuffle_cout), dtype=torch.bfloat16, device=self._tdev)
+            else:
+                out = torch.empty((B, Ho * rep, Wo * rep, N), dtype=torch.bfloat16, device=self._tdev)
+        L.check(self.lib.pt_op_conv2d(self._h, _ptr(x), B, H, W, Cin, _ptr(w_tiled), _ptr(bias), N, ks, stride,
+                                      _ptr(out), out.shape[-1], out_coff, rep, shuffle_cout, _ptr(res), res_mode,
+                                      int(relu), self._stream()), "pt_op_conv2d")
+        return out
+
+    # ---- profiling ---------------------------------------------------------------------------------
+    def profile_enable(self, on: bool = True):
+        L.check(self.lib.pt_profile_enable(self._h, int(on)), "pt_profile_enable")
+
+    def profile_read(self):
+        ms = (C.c_double * 4)()
+        nl = (C.c_longlong * 4)()
+        fl = (C.c_double * 4)()
+        L.check(self.lib.pt_profile_read(self._h, ms, nl, fl), "pt_profile_read")
+        return {k: {"ms": ms[i], "launches": nl[i], "flop": fl[i]} for i, k in enumerate(L.PT_PROF_CLASSES)}
+
+
+# ---- host-side halves of the DB post-process (no GPU needed) -------------------------------------------
+def db_candidates(bitmap_words: np.ndarray, max_candidates: int = 1000, min_size: float = 3.0):
+    """bitmap uint32/int32 [H, W/32] of one page -> (boxes f32 [k,8] TL,TR,BR,BL ; sside f32 [k])."""
+    lib = L.load()
+    bm = np.ascontiguousarray(bitmap_words).view(np.uint32)
+    H, wpr = bm.shape
+    cap = max_candidates
+    boxes = np.empty((cap, 8), dtype=np.float32)
+    sside = np.empty((cap,), dtype=np.float32)
+    n = C.c_int()
+    L.check(lib.pt_db_candidates(bm.ctypes.data_as(C.c_void_p), H, wpr * 32, max_candidates, float(min_size),
+                                 boxes.ctypes.data_as(C.c_void_p), sside.ctypes.data_as(C.c_void_p), cap,
+                                 C.byref(n)), "pt_db_candidates")
+    return boxes[:n.value].copy(), sside[:n.value].copy()
+
+
+def db_finalize(boxes: np.ndarray, scores: np.ndarray, net_hw, dest_hw, box_thresh: float = 0.6,
+                unclip_ratio: float = 1.5, min_size: float = 3.0):
+    lib = L.load()
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 8)
+    scores = np.ascontiguousarray(scores, dtype=np.float32)
+    nb = boxes.shape[0]
+    out = np.empty((max(nb, 1), 8), dtype=np.int32)
+    osc = np.empty((max(nb, 1),), dtype=np.float32)
+    n = C.c_int()
+    L.check(lib.pt_db_finalize(boxes.ctypes.data_as(C.c_void_p), scores.ctypes.data_as(C.c_void_p), nb,
+                               float(box_thresh), float(unclip_ratio), float(min_size), int(net_hw[0]), int(net_hw[1]),
+                               int(dest_hw[0]), int(dest_hw[1]), out.ctypes.data_as(C.c_void_p),
+                               osc.ctypes.data_as(C.c_void_p), max(nb, 1), C.byref(n)), "pt_db_finalize")
+    return out[:n.value].copy(), osc[:n.value].copy()

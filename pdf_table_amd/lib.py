@@ -1,0 +1,78 @@
+"""ctypes binding of libpdftable_hip.so (C ABI: include/pdftable_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, an exception is
+raised.  ``import torch`` happens first so that the HIP runtime PyTorch ships (same soname,
+``libamdhip64.so.7``) is the one both share -- device pointers and streams then interoperate.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpdftable_hip.so")
+
+PT_MODEL_DB_RESNET18 = 1
+PT_MODEL_CRNN = 2
+PT_DET_PRE_DB_PP = 0
+PT_DET_PRE_DB_TORCH = 1
+PT_DET_PRE_NONE = 2
+PT_PROF_CLASSES = ("conv3x3", "conv1x1", "stem", "other")
+
+_lib = None
+
+
+class PtError(RuntimeError):
+    pass
+
+
+def _proto(lib):
+    vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    ip = C.POINTER(C.c_int)
+    P = {
+        "pt_engine_create": (i, [i, C.POINTER(vp)]),
+        "pt_engine_destroy": (None, [vp]),
+        "pt_last_error": (C.c_char_p, []),
+        "pt_abi_version": (i, []),
+        "pt_weights_load": (i, [vp, i, vp, sz]),
+        "pt_weights_load_device": (i, [vp, i, vp, sz, vp]),
+        "pt_det_plan": (i, [i, i, i, ip, ip]),
+        "pt_det_forward": (i, [vp, vp, i, i, i, i, f, i, vp, vp, vp]),
+        "pt_det_forward_net": (i, [vp, vp, i, i, i, vp, vp, vp]),
+        "pt_det_preprocess": (i, [vp, vp, i, i, i, i, vp, vp]),
+        "pt_det_bitmap": (i, [vp, vp, i, i, i, f, i, vp, vp]),
+        "pt_det_box_scores": (i, [vp, vp, i, i, i, vp, i, vp, vp]),
+        "pt_db_candidates": (i, [vp, i, i, i, f, vp, vp, i, ip]),
+        "pt_db_finalize": (i, [vp, vp, i, f, f, f, i, i, i, i, vp, vp, i, ip]),
+        "pt_op_conv2d": (i, [vp, vp, i, i, i, i, vp, vp, i, i, i, vp, i, i, i, i, vp, i, i, vp]),
+        "pt_profile_enable": (i, [vp, i]),
+        "pt_profile_read": (i, [vp, vp, vp, vp]),
+    }
+    for name, (res, args) in P.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    return P
+
+
+EXPORTS = None
+
+
+def load():
+    """Load the engine library (once).  Raises if it has not been built (python -m pdf_table_amd.build)."""
+    global _lib, EXPORTS
+    if _lib is None:
+        import torch  # noqa: F401  (must precede the CDLL: see module docstring)
+        if not os.path.exists(LIB_PATH):
+            raise PtError(f"{LIB_PATH} not found: run `python -m pdf_table_amd.build` (hipcc, gfx950). "
+                          "There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        EXPORTS = _proto(lib)
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().pt_last_error()
+        raise PtError(f"{what} failed (status {rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,133 @@
+"""Weight packer: reference ``state_dict`` layouts -> the engine's "PTW1" blobs.
+
+Host-side only (PyTorch CPU).  Replaces the reference's ``torch.load`` + ``load_state_dict`` +
+``model.half()`` (model/db_net/modeling_db_net.py:53-56, utils/deploy_utils.py:227-240) for the
+``predictor_type == "hip"`` path.
+
+What the packer does:
+  * folds eval-mode BatchNorm into the preceding conv (float64 fold; weight rounded to bf16 with
+    round-to-nearest-even, bias kept fp32) -- every backbone conv of the hot-path nets is Conv->BN->act;
+  * re-tiles conv weights to the layout the MFMA kernel streams: ``[N/64][Cin/32][kh*kw][64][32]`` bf16
+    (an LDS K-slice is one contiguous 16-byte-aligned run);
+  * rewrites ``ConvTranspose2d(k=2, s=2)`` as a 1x1 GEMM with ``N = 4*Cout`` (quadrant-major) for the
+    pixel-shuffle epilogue;
+  * pads the 7x7 stem to K = [7][8][4] (zero tap / zero channel).
+
+Blob format (little endian): ``b"PTW1"``, ``uint32 n``, then ``n`` records
+``name[96] | dtype u32 (0 bf16, 1 f32, 2 i32) | ndim u32 | dims[6] u32 | offset u64 | nbytes u64``,
+then 256-byte aligned payloads.
+"""
+from __future__ import annotations
+
+import struct
+from collections import OrderedDict
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+BN_EPS = 1e-5
+_DT = {"bf16": 0, "f32": 1, "i32": 2}
+
+__all__ = ["pack_db_resnet18", "pack_crnn", "write_blob", "fold_conv_bn", "to_bf16_bits"]
+
+
+def to_bf16_bits(t: torch.Tensor) -> np.ndarray:
+    """fp32 tensor -> uint16 array of bfloat16 bits (round to nearest even)."""
+    return t.detach().to(torch.float32).contiguous().to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+
+
+def fold_conv_bn(sd: Dict[str, torch.Tensor], conv: str, bn: Optional[str], transposed: bool = False
+                 ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(weight fp32 with BN scale folded in, bias fp32).  ``transposed``: weight is [Cin, Cout, kh, kw]."""
+    w = sd[conv + ".weight"].double()
+    cout = w.shape[1] if transposed else w.shape[0]
+    b = sd[conv + ".bias"].double() if (conv + ".bias") in sd else torch.zeros(cout, dtype=torch.float64)
+    if bn is not None:
+        scale = sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + BN_EPS)
+        shift = sd[bn + ".bias"].double() - sd[bn + ".running_mean"].double() * scale
+        w = w * (scale.view(1, -1, 1, 1) if transposed else scale.view(-1, 1, 1, 1))
+        b = b * scale + shift
+    return w.float(), b.float()
+
+
+def tile_conv_weight(w: torch.Tensor) -> np.ndarray:
+    """[N, Cin, kh, kw] fp32 -> bf16 bits [N/64][Cin/32][kh*kw][64][32]."""
+    n, cin, kh, kw = w.shape
+    assert n % 64 == 0 and cin % 32 == 0, (n, cin)
+    t = w.reshape(n // 64, 64, cin // 32, 32, kh, kw).permute(0, 2, 4, 5, 1, 3).contiguous()
+    return to_bf16_bits(t).reshape(n // 64, cin // 32, kh * kw, 64, 32)
+
+
+class _Blob:
+    def __init__(self):
+        self.items: "OrderedDict[str, Tuple[int, np.ndarray]]" = OrderedDict()
+
+    def add(self, name: str, arr: np.ndarray, dtype: str):
+        assert len(name) < 96 and arr.ndim <= 6
+        self.items[name] = (_DT[dtype], np.ascontiguousarray(arr))
+
+    def add_conv(self, name: str, w: torch.Tensor, b: torch.Tensor):
+        self.add(name + ".w", tile_conv_weight(w), "bf16")
+        self.add(name + ".b", b.numpy().astype(np.float32), "f32")
+
+    def tobytes(self) -> bytes:
+        return write_blob(self.items)
+
+
+def write_blob(items) -> bytes:
+    n = len(items)
+    head = 8 + n * 144
+    off = (head + 255) & ~255
+    table = []
+    payload = []
+    for name, (dt, arr) in items.items():
+        raw = arr.tobytes()
+        dims = list(arr.shape) + [0] * (6 - arr.ndim)
+        table.append(struct.pack("<96sII6IQQ", name.encode(), dt, arr.ndim, *dims, off, len(raw)))
+        payload.append((off, raw))
+        off = (off + len(raw) + 255) & ~255
+    out = bytearray(off)
+    out[0:4] = b"PTW1"
+    out[4:8] = struct.pack("<I", n)
+    for i, rec in enumerate(table):
+        out[8 + i * 144: 8 + (i + 1) * 144] = rec
+    for o, raw in payload:
+        out[o:o + len(raw)] = raw
+    return bytes(out)
+
+
+def pack_db_resnet18(sd: Dict[str, torch.Tensor]) -> bytes:
+    """``DBModel`` state_dict (db_net/dbnet.py:715-728) -> blob for PT_MODEL_DB_RESNET18."""
+    bl = _Blob()
+    # stem: [64,3,7,7] -> [64][r=7][s=8][c=4], tap s=7 / channel c=3 are zero
+    w, b = fold_conv_bn(sd, "backbone.conv1", "backbone.bn1")
+    stem = torch.zeros(64, 7, 8, 4)
+    stem[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+    bl.add("stem.w", to_bf16_bits(stem).reshape(64, 224), "bf16")
+    bl.add("stem.b", b.numpy(), "f32")
+    for li in range(1, 5):
+        for bi in range(2):
+            p = f"backbone.layer{li}.{bi}"
+            q = f"layer{li}.{bi}"
+            bl.add_conv(q + ".conv1", *fold_conv_bn(sd, p + ".conv1", p + ".bn1"))
+            bl.add_conv(q + ".conv2", *fold_conv_bn(sd, p + ".conv2", p + ".bn2"))
+            if (p + ".downsample.0.weight") in sd:
+                bl.add_conv(q + ".down", *fold_conv_bn(sd, p + ".downsample.0", p + ".downsample.1"))
+    for k in (2, 3, 4, 5):
+        bl.add_conv(f"in{k}", *fold_conv_bn(sd, f"decoder.in{k}", None))
+        oname = f"decoder.out{k}.0" if k > 2 else "decoder.out2"
+        bl.add_conv(f"out{k}", *fold_conv_bn(sd, oname, None))
+    bl.add_conv("bin0", *fold_conv_bn(sd, "decoder.binarize.0", "decoder.binarize.1"))
+    # ConvTranspose2d(64,64,2,2)+BN -> 1x1 GEMM, N index = (dy*2+dx)*64 + co
+    wt, bt = fold_conv_bn(sd, "decoder.binarize.3", "decoder.binarize.4", transposed=True)  # [ci, co, 2, 2]
+    wn = wt.permute(2, 3, 1, 0).reshape(4 * 64, 64, 1, 1)
+    bl.add_conv("bin3", wn, bt.repeat(4))
+    w6, b6 = fold_conv_bn(sd, "decoder.binarize.6", None, transposed=True)  # [64, 1, 2, 2]
+    bl.add("bin6.w", to_bf16_bits(w6[:, 0].permute(1, 2, 0).reshape(4, 64)), "bf16")
+    bl.add("bin6.b", b6.numpy().reshape(1), "f32")
+    return bl.tobytes()
+
+
+def pack_crnn(sd: Dict[str, torch.Tensor]) -> bytes:  # filled in by the recognition stage
+    raise NotImplementedError("CRNN packing lands with the recognition stage")

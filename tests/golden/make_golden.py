@@ -135,8 +135,103 @@ def gen_ctc():
     print("ctc", [r[0] for r in res])
 
 
+class _Stub(types.ModuleType):
+    """Stand-in for third-party modules that are not installed (cv2, pyclipper, shapely ...).  Only used
+    so that reference files IMPORT; any golden value below comes from reference code paths that do not
+    touch these stand-ins (except cv2.resize, which records the requested size and returns zeros)."""
+    calls = []
+
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return _Stub(self.__name__ + "." + k)
+
+    def __call__(self, *a, **k):
+        if self.__name__ == "cv2.resize":
+            w, h = a[1]
+            _Stub.calls.append((int(w), int(h)))
+            return np.zeros((int(h), int(w), 3), dtype=np.uint8)
+        return None
+
+
+def stub_env():
+    import logging
+    for m in ["cv2", "pyclipper", "shapely", "shapely.geometry", "fitz", "pdfminer", "dotenv"]:
+        sys.modules.setdefault(m, _Stub(m))
+    try:
+        import transformers.onnx  # noqa: F401  (removed in transformers 5; the reference subclasses OnnxConfig)
+    except Exception:
+        tm = types.ModuleType("transformers.onnx")
+        tm.OnnxConfig = type("OnnxConfig", (), {})
+        sys.modules["transformers.onnx"] = tm
+    if "pdftable.utils" not in sys.modules:
+        u = _pkg("pdftable", os.path.join(REF_SRC, "pdftable")) if "pdftable" not in sys.modules else None
+        pu = _pkg("pdftable.utils", os.path.join(REF_SRC, "pdftable", "utils"))
+        pu.logger = logging.getLogger("ref")
+        pu.BaseUtil = type("BaseUtil", (), {})
+        pu.FileUtils = _Stub("FileUtils")
+        pu.Constants = _Stub("Constants")
+        pu.TimeUtils = _Stub("TimeUtils")
+        pu.CommonUtils = _Stub("CommonUtils")
+        pu.MatchUtils = _Stub("MatchUtils")
+        # utils/ocr/__init__.py drags in pdfminer through pdftable.entity: load the one file we need instead
+        po = _pkg("pdftable.utils.ocr", os.path.join(REF_SRC, "pdftable", "utils", "ocr"))
+        po.OcrCommonUtils = importlib.import_module("pdftable.utils.ocr.ocr_common_utils").OcrCommonUtils
+        po.OcrInferUtils = _Stub("OcrInferUtils")
+
+
+def gen_db_host_numpy():
+    """Pure-numpy pieces of the detection path, produced by the reference's own code:
+    DetResizeForTest size arithmetic, filter_tag_det_res/order_points_clockwise, order_point, the
+    text_detection sort key."""
+    stub_env()
+    ops = ref_import("pdftable.model.db_pp.image_operators")
+    rz = ops.DetResizeForTest(limit_side_len=960, limit_type="max")
+    sizes = [(1024, 1024), (640, 640), (1000, 700), (333, 517), (2000, 1500), (31, 47), (960, 1280), (1920, 1920),
+             (975, 975), (976, 944)]
+    plan = []
+    for (h, w) in sizes:
+        _Stub.calls.clear()
+        _, (rh, rw) = rz.resize_image_type0(np.zeros((h, w, 3), np.uint8))
+        nw, nh = _Stub.calls[-1]
+        plan.append([h, w, nh, nw, rh, rw])
+    # (the torch-flavour OCRDetectionPreprocessor cannot be imported: its PretrainedConfig subclass breaks
+    #  under transformers 5 -- its size rule is pinned by hand-computed answers in the tests instead)
+    # DbPPConfig subclasses transformers.PretrainedConfig with a mutable class attribute, which transformers 5
+    # rejects at class creation; the post-processor methods used below never touch the config.
+    cm = types.ModuleType("pdftable.model.db_pp.configuration_db_pp")
+    cm.DbPPConfig = type("DbPPConfig", (), {})
+    cm.__all__ = ["DbPPConfig"]
+    sys.modules["pdftable.model.db_pp.configuration_db_pp"] = cm
+    post = ref_import("pdftable.model.db_pp.processor_ocr_db_pp")
+    pp = object.__new__(post.PPOcrDetectionPostProcessor)
+    rng = np.random.default_rng(104)
+    boxes = []
+    for bi in range(40):
+        c = rng.uniform(-20, 700, 2)
+        wh = rng.uniform(1, 8, 2) if bi < 12 else rng.uniform(1, 120, 2)
+        ang = rng.uniform(0, np.pi)
+        R = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+        q = np.array([[-1, -1], [1, -1], [1, 1], [-1, 1]]) * wh / 2 @ R.T + c
+        boxes.append(np.round(q[rng.permutation(4)]).astype(np.int16))
+    boxes = np.array(boxes, dtype=np.int16)
+    filt = pp.filter_tag_det_res(boxes.copy(), (640, 672, 3))
+    ocu = ref_import("pdftable.utils.ocr.ocr_common_utils")
+    op_in = rng.uniform(0, 500, (30, 8)).astype(np.float32)
+    op_out = np.stack([ocu.OcrCommonUtils.order_point(r) for r in op_in])
+    det = rng.integers(0, 900, (50, 8)).astype(np.float32)
+    lst = sorted(det.tolist(), key=lambda x: 0.01 * sum(x[::2]) / 4 + sum(x[1::2]) / 4)  # ocr_system_task.py:161
+    np.savez_compressed(os.path.join(HERE, "db_host_numpy.npz"), plan=np.array(plan, dtype=np.float64),
+                        boxes=boxes, filtered=filt.astype(np.float32),
+                        filter_shape=np.array([640, 672, 3]), order_point_in=op_in, order_point_out=op_out,
+                        sort_in=det, sort_out=np.array(lst, dtype=np.float32))
+    print("db_host_numpy.npz", len(filt), "of", len(boxes), "boxes kept")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["db", "crnn", "registry", "ctc"]
+    which = sys.argv[1:] or ["db", "crnn", "registry", "ctc", "host"]
+    if "host" in which:
+        gen_db_host_numpy()
     if "db" in which:
         gen_db_resnet18()
     if "crnn" in which:

@@ -1,0 +1,85 @@
+"""Product host post-process (C++ in libpdftable_hip.so) vs the oracle restatement: bit-exact boxes."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import db_post, db_pre
+from pdf_table_amd import engine as E
+from pdf_table_amd import lib as L
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    from pdf_table_amd.build import build
+    build(verbose=False)
+
+
+def pack_bits(bm):
+    h, w = bm.shape
+    assert w % 32 == 0
+    b = bm.reshape(h, w // 32, 32).astype(np.uint32)
+    return (b << np.arange(32, dtype=np.uint32)).sum(axis=2).astype(np.uint32)
+
+
+def blobs(seed, h=96, w=160, n=14):
+    rng = np.random.default_rng(seed)
+    prob = rng.uniform(0, 0.25, (h, w)).astype(np.float32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for _ in range(n):
+        cx, cy = rng.uniform(5, w - 5), rng.uniform(5, h - 5)
+        a, b = rng.uniform(2, 30), rng.uniform(1.5, 8)
+        th = rng.uniform(0, np.pi)
+        u = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th)
+        v = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+        inside = (np.abs(u) < a) & (np.abs(v) < b)
+        prob[inside] = rng.uniform(0.5, 1.0)
+    # a ring and single pixels
+    prob[10:22, 120:140] = 0.8
+    prob[14:18, 126:134] = 0.1
+    prob[50, 3] = 0.9
+    return prob
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_candidates_bit_exact(seed):
+    prob = blobs(seed)
+    bm = prob > 0.3
+    boxes, sside = E.db_candidates(pack_bits(bm), 1000, 3.0)
+    ref = db_post.candidates_from_bitmap(bm, 1000, 3)
+    assert len(ref) == len(boxes) and len(ref) >= 5
+    for (pts, ss), b, s in zip(ref, boxes, sside):
+        np.testing.assert_array_equal(pts.reshape(-1), b)
+        assert np.float32(ss) == s
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_finalize_bit_exact(seed):
+    prob = blobs(seed)
+    bm = prob > 0.3
+    boxes, _ = E.db_candidates(pack_bits(bm), 1000, 3.0)
+    scores = np.array([db_post.box_score_fast(prob, b.reshape(4, 2)) for b in boxes], np.float32)
+    out, osc = E.db_finalize(boxes, scores, prob.shape, (192, 320), 0.6, 1.5, 3.0)
+    ref_boxes, ref_scores = db_post.boxes_from_bitmap(prob, bm, 320, 192, 0.6, 1.5, 1000, 3, scores_override=scores)
+    np.testing.assert_array_equal(out.reshape(-1, 4, 2), ref_boxes.astype(np.int32))
+    assert len(out) >= 1
+    np.testing.assert_array_equal(osc, np.array(ref_scores, np.float32))
+
+
+def test_empty_and_full_bitmaps():
+    z = np.zeros((32, 64), bool)
+    boxes, _ = E.db_candidates(pack_bits(z))
+    assert len(boxes) == 0
+    o = np.ones((32, 64), bool)
+    boxes, sside = E.db_candidates(pack_bits(o))
+    ref = db_post.candidates_from_bitmap(o)
+    assert len(boxes) == len(ref) == 1
+    np.testing.assert_array_equal(ref[0][0].reshape(-1), boxes[0])
+
+
+def test_max_candidates_takes_last_found_first():
+    bm = np.zeros((64, 64), bool)
+    for i in range(6):
+        bm[4 + 10 * i: 9 + 10 * i, 5:40] = True
+    boxes, _ = E.db_candidates(pack_bits(bm), max_candidates=2)
+    assert len(boxes) == 2 and boxes[0][1] > boxes[1][1] > 40   # bottom-most components
