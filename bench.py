@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""bench.py -- pages/s of the hot path on N MI355X (one process per GPU, RCCL only for the weight broadcast).
+
+    python bench.py [--gpus 1] [--steps 10] [--warmup 3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic 1024x1024 pages per rank (inputs already
+resident in HBM).  Workload today (named in ``config.workload``): BASELINE.json configs[1], the batched DB
+text-detection stage -- resize + normalise, DB-ResNet18, prob -> bitmap, contour candidates, box scoring,
+unclip, final boxes.  Pages are sharded across ranks (weak scaling: fixed pages per rank); there is no
+collective in the timed region.
+
+Extra objects on the JSON line: ``roofline`` for the dominant kernel class (3x3 MFMA convolutions, HIP-event
+timed inside the timed region) and ``cpu_baseline`` (the oracle restatement of the same stage on the host
+cores, bounded sample, rank 0 at N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PAGE = 1024
+PAGES_PER_STEP = int(os.environ.get("PT_BENCH_PAGES", "64"))   # per rank
+DISTINCT = 8                     # distinct synthetic pages, tiled up to the batch
+MFMA_PEAK_TFLOPS = 2500.0        # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+DB_GFLOP_960 = 111.71            # DB-ResNet18 at the reference-preprocessed 960x960
+
+
+def cpu_baseline(sd, pages_np, cfg):
+    """The oracle (port of the reference CPU path: fp32 torch ops in the reference's op order + numpy/python
+    pre/post) on the host cores, batch 1 per call as the reference runs it."""
+    from oracle import db_net, db_post, db_pre
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n = len(pages_np)
+    t0 = time.time()
+    nboxes = 0
+    for img in pages_np:
+        chw, shape_list = db_pre.preprocess_db_pp(img)
+        with torch.no_grad():
+            prob = db_net.db_forward_fp32(sd, torch.from_numpy(np.ascontiguousarray(chw))[None])[0, 0].numpy()
+        boxes = db_post.db_postprocess(prob, shape_list, img.shape, cfg.thresh, cfg.box_thresh, cfg.unclip_ratio,
+                                       cfg.use_dilation, cfg.max_candidates)
+        nboxes += len(boxes)
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "pages/s", "cores": cores, "kind": "port",
+            "sample": f"{n} synthetic 1024x1024 pages, DB det stage (pre + DB-ResNet18 fp32 + post), batch 1, "
+                      f"torch.set_num_threads({cores}); {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-post", action="store_true", help="device half only (diagnostic; not a valid headline)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from pdf_table_amd import lib as L
+    from pdf_table_amd.det_stage import DetConfig, DetStage
+    from pdf_table_amd.engine import HipEngine
+    from pdf_table_amd.synth_pages import make_page
+    from pdf_table_amd.synth_weights import db_resnet18_state_dict
+    from pdf_table_amd.weights import pack_db_resnet18
+
+    eng = HipEngine(local_rank)
+    # weights: packed once on rank 0, broadcast over RCCL/xGMI, loaded from device memory everywhere
+    sd = db_resnet18_state_dict(seed=0) if rank == 0 or world == 1 else None
+    if world > 1:
+        if rank == 0:
+            blob = torch.frombuffer(bytearray(pack_db_resnet18(sd)), dtype=torch.uint8).to(dev)
+            size = torch.tensor([blob.numel()], dtype=torch.int64, device=dev)
+        else:
+            size = torch.zeros(1, dtype=torch.int64, device=dev)
+        dist.broadcast(size, 0)
+        if rank != 0:
+            blob = torch.empty(int(size.item()), dtype=torch.uint8, device=dev)
+        dist.broadcast(blob, 0)
+        eng.load_weights_device(L.PT_MODEL_DB_RESNET18, blob)
+    else:
+        eng.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(sd))
+
+    # pages: rank r owns pages [r*P, (r+1)*P) of the global batch (static contiguous shard)
+    base = [make_page(rank * DISTINCT + i, PAGE)[0] for i in range(DISTINCT)]
+    pages_np = np.stack([base[i % DISTINCT] for i in range(PAGES_PER_STEP)])
+    pages = torch.from_numpy(pages_np).to(dev)
+    cfg = DetConfig(flavour="db_pp", thresh=0.3, box_thresh=0.6, unclip_ratio=1.5)
+    stage = DetStage(eng, cfg)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    nboxes = 0
+
+    def run(steps, count=False):
+        """software pipeline: device half of step k+1 is enqueued before the host half of step k"""
+        nonlocal nboxes
+        prev = None
+        for k in range(steps):
+            cur = stage.forward(pages, slot=k & 1)
+            if prev is not None and not args.no_post:
+                res = stage.boxes(prev[0], prev[1], (PAGE, PAGE), prev[2])
+                if count:
+                    nboxes += sum(len(r) for r in res)
+            prev = cur
+        if prev is not None and not args.no_post:
+            res = stage.boxes(prev[0], prev[1], (PAGE, PAGE), prev[2])
+            if count:
+                nboxes += sum(len(r) for r in res)
+
+    run(args.warmup)
+    barrier()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    run(args.steps, count=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_pages = world * PAGES_PER_STEP * args.steps
+        value = total_pages / dt
+        c3 = prof["conv3x3"]
+        achieved = (c3["flop"] / (c3["ms"] * 1e-3)) / 1e12 if c3["ms"] > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<3,*> (3x3 implicit-GEMM convs of DB-ResNet18)",
+                "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
+                "traffic": None, "launches": c3["launches"], "avg_launch_ms": c3["ms"] / max(1, c3["launches"]),
+                "algorithmic_flop_per_launch": c3["flop"] / max(1, c3["launches"]),
+                "all_kernel_classes_ms": {k: v["ms"] for k, v in prof.items()},
+                "net_tflops_on_111.71_gflop_per_page": DB_GFLOP_960e9_per_page(total_pages, prof)}
+        out = {"metric": "pages/s", "value": value, "unit": "pages/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "BASELINE.json configs[1]: batched DB text detection (db_pp pre/post around "
+                                      "DB-ResNet18), 1024x1024 synthetic pages -> 960x960 net input, boxes out"
+                                      + (" [DEVICE HALF ONLY]" if args.no_post else ""),
+                          "pages_per_step_per_gpu": PAGES_PER_STEP, "page": [PAGE, PAGE],
+                          "stages": ["det"], "parallelism": f"page-shard x{world}",
+                          "boxes_per_page": nboxes / max(1, PAGES_PER_STEP * args.steps),
+                          "weights": "seeded random init (reference state_dict layout)"},
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, pages_np[:2], cfg)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def DB_GFLOP_960e9_per_page(total_pages, prof):
+    ms = sum(v["ms"] for k, v in prof.items() if k in ("conv3x3", "conv1x1", "stem"))
+    return (total_pages * DB_GFLOP_960 * 1e9 / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+
+
+if __name__ == "__main__":
+    main()

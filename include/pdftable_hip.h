@@ -108,8 +108,10 @@ int pt_db_candidates(const uint32_t* h_bitmap, int net_h, int net_w, int max_can
  *   min-area rectangle, sside gate (min_size + 2), rescale to the source page, round, clip.
  *   Output h_out: int32 [cap, 8]; h_out_scores float32 [cap]. */
 int pt_db_finalize(const float* h_boxes, const float* h_scores, int nb, float box_thresh, float unclip_ratio,
-                   float min_size, int net_h, int net_w, int dest_h, int dest_w, int32_t* h_out,
+                   float min_size, int net_h, int net_w, int dest_h, int dest_w, int post_flavour, int32_t* h_out,
                    float* h_out_scores, int cap, int* n_out);
+#define PT_DET_POST_DB_PP 0    /* float32 box / W * dest, round, clip, astype(int16): processor_ocr_db_pp.py:211-217 */
+#define PT_DET_POST_DB_TORCH 1 /* box.astype(int32) first, then the same in float64: ocr_detection_utils.py:198-206 */
 
 /* ---- single operator (parity tests of the conv kernel variants) --------------------------------- */
 /* NHWC bf16 convolution on the MFMA implicit-GEMM kernel. d_w_tiled is [N/64][Cin/32][ks*ks][64][32] bf16

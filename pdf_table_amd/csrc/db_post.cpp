@@ -425,8 +425,8 @@ int pt_db_candidates(const uint32_t* h_bitmap, int net_h, int net_w, int max_can
 }
 
 int pt_db_finalize(const float* h_boxes, const float* h_scores, int nb, float box_thresh, float unclip_ratio,
-                   float min_size, int net_h, int net_w, int dest_h, int dest_w, int32_t* h_out, float* h_out_scores,
-                   int cap, int* n_out) {
+                   float min_size, int net_h, int net_w, int dest_h, int dest_w, int post_flavour, int32_t* h_out,
+                   float* h_out_scores, int cap, int* n_out) {
   if ((nb > 0 && (!h_boxes || !h_scores)) || !h_out || !n_out) {
     pt_set_error("pt_db_finalize: bad arguments");
     return PT_ERR_INVALID;
@@ -461,12 +461,26 @@ int pt_db_finalize(const float* h_boxes, const float* h_scores, int nb, float bo
     for (int k = 0; k < 4; ++k) {
       // np.clip(np.round(box / width * dest_width), 0, dest_width): float32 divide, then double (numpy>=2
       // promotes float32 array * np.float64 scalar to float64), round half to even, astype(int16)
-      const float qx = box[k].x / (float)net_w, qy = box[k].y / (float)net_h;
-      double vx = nearbyint((double)qx * (double)dest_w), vy = nearbyint((double)qy * (double)dest_h);
+      double vx, vy;
+      if (post_flavour == PT_DET_POST_DB_TORCH) {
+        // np.array(box).astype(np.int32) first; int / int is float64 in numpy
+        const double ix = (double)(int32_t)box[k].x, iy = (double)(int32_t)box[k].y;
+        vx = nearbyint(ix / (double)net_w * (double)dest_w);
+        vy = nearbyint(iy / (double)net_h * (double)dest_h);
+      } else {
+        const float qx = box[k].x / (float)net_w, qy = box[k].y / (float)net_h;
+        vx = nearbyint((double)qx * (double)dest_w);
+        vy = nearbyint((double)qy * (double)dest_h);
+      }
       vx = vx < 0 ? 0 : (vx > dest_w ? dest_w : vx);
       vy = vy < 0 ? 0 : (vy > dest_h ? dest_h : vy);
-      h_out[(size_t)n * 8 + 2 * k] = (int32_t)(int16_t)(long long)vx;
-      h_out[(size_t)n * 8 + 2 * k + 1] = (int32_t)(int16_t)(long long)vy;
+      if (post_flavour == PT_DET_POST_DB_TORCH) {
+        h_out[(size_t)n * 8 + 2 * k] = (int32_t)(long long)vx;
+        h_out[(size_t)n * 8 + 2 * k + 1] = (int32_t)(long long)vy;
+      } else {
+        h_out[(size_t)n * 8 + 2 * k] = (int32_t)(int16_t)(long long)vx;
+        h_out[(size_t)n * 8 + 2 * k + 1] = (int32_t)(int16_t)(long long)vy;
+      }
     }
     if (h_out_scores) h_out_scores[n] = score;
     ++n;

@@ -173,7 +173,7 @@ def db_candidates(bitmap_words: np.ndarray, max_candidates: int = 1000, min_size
 
 
 def db_finalize(boxes: np.ndarray, scores: np.ndarray, net_hw, dest_hw, box_thresh: float = 0.6,
-                unclip_ratio: float = 1.5, min_size: float = 3.0):
+                unclip_ratio: float = 1.5, min_size: float = 3.0, post_flavour: int = L.PT_DET_POST_DB_PP):
     lib = L.load()
     boxes = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 8)
     scores = np.ascontiguousarray(scores, dtype=np.float32)
@@ -183,6 +183,6 @@ def db_finalize(boxes: np.ndarray, scores: np.ndarray, net_hw, dest_hw, box_thre
     n = C.c_int()
     L.check(lib.pt_db_finalize(boxes.ctypes.data_as(C.c_void_p), scores.ctypes.data_as(C.c_void_p), nb,
                                float(box_thresh), float(unclip_ratio), float(min_size), int(net_hw[0]), int(net_hw[1]),
-                               int(dest_hw[0]), int(dest_hw[1]), out.ctypes.data_as(C.c_void_p),
+                               int(dest_hw[0]), int(dest_hw[1]), int(post_flavour), out.ctypes.data_as(C.c_void_p),
                                osc.ctypes.data_as(C.c_void_p), max(nb, 1), C.byref(n)), "pt_db_finalize")
     return out[:n.value].copy(), osc[:n.value].copy()

@@ -17,6 +17,8 @@ PT_MODEL_CRNN = 2
 PT_DET_PRE_DB_PP = 0
 PT_DET_PRE_DB_TORCH = 1
 PT_DET_PRE_NONE = 2
+PT_DET_POST_DB_PP = 0
+PT_DET_POST_DB_TORCH = 1
 PT_PROF_CLASSES = ("conv3x3", "conv1x1", "stem", "other")
 
 _lib = None
@@ -43,7 +45,7 @@ def _proto(lib):
         "pt_det_bitmap": (i, [vp, vp, i, i, i, f, i, vp, vp]),
         "pt_det_box_scores": (i, [vp, vp, i, i, i, vp, i, vp, vp]),
         "pt_db_candidates": (i, [vp, i, i, i, f, vp, vp, i, ip]),
-        "pt_db_finalize": (i, [vp, vp, i, f, f, f, i, i, i, i, vp, vp, i, ip]),
+        "pt_db_finalize": (i, [vp, vp, i, f, f, f, i, i, i, i, i, vp, vp, i, ip]),
         "pt_op_conv2d": (i, [vp, vp, i, i, i, i, vp, vp, i, i, i, vp, i, i, i, i, vp, i, i, vp]),
         "pt_profile_enable": (i, [vp, i]),
         "pt_profile_read": (i, [vp, vp, vp, vp]),

@@ -1,0 +1,128 @@
+"""``OcrDetectionTask`` on the HIP engine -- drop-in for the reference's stage-2 plug-in.
+
+Reference: src/pdftable/model/ocr_pdf/ocr_detection_task.py:29-141.  Same constructor
+(``task, model in {"db","db_pp"}, backbone, thresh, **kwargs``), same five-method split, same result
+(``[np.ndarray (n, 8)]`` per input, x1,y1..x4,y4 in source pixels), same ``RuntimeError`` for an unknown
+model name (:58).  What changes is what runs: pages of equal size are batched, the network + bitmap run as
+HIP kernels, and the per-contour scoring runs on the device.
+
+Model availability (SURVEY.md finding F2): ``model="db"`` is the in-tree DB-ResNet18 -- fully served.
+``model="db_pp"`` selects PP-OCR ONNX graphs that exist neither in the reference tree nor offline; with
+``allow_stand_in=True`` the PP-OCR pre/post-processing is run around the DB-ResNet18 network (what the
+benchmark does); without it construction fails loudly, naming the hub id that would have been fetched.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import List
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .base_infer_task import BaseInferTask
+from .det_stage import DetConfig, DetStage
+from .engine import HipEngine
+from .weights import pack_db_resnet18
+
+__all__ = ["OcrDetectionTask"]
+
+
+class _DetCfg:
+    def __init__(self, backbone, thresh, lang="en"):
+        self.backbone = backbone
+        self.thresh = thresh
+        self.lang = lang
+        self.model_path = ""
+
+
+def _read_image(item) -> np.ndarray:
+    """str path / PIL image / RGB ndarray -> RGB uint8 ndarray (processor_ocr_db_pp.py:113-122)."""
+    if isinstance(item, np.ndarray):
+        return item
+    import PIL.Image
+    if isinstance(item, PIL.Image.Image):
+        return np.array(item.convert("RGB"))
+    if isinstance(item, str):
+        return np.array(PIL.Image.open(item).convert("RGB"))
+    raise TypeError(f"inputs should be either str, PIL.Image, np.array, but got {type(item)}")
+
+
+class OcrDetectionTask(BaseInferTask):
+    def __init__(self, task="ocr_detection", model="db", backbone: str = "resnet18", thresh: float = 0.2,
+                 engine: HipEngine = None, **kwargs):
+        super().__init__(task=task, model=model, **kwargs)
+        if model == "db":
+            self._config = _DetCfg(backbone, thresh)
+            self.model_provider = "model_scope"
+        elif model == "db_pp":
+            lang = self.lang if self.lang in ["ch", "en"] else "ml"
+            self._config = _DetCfg(backbone, thresh, lang)
+            self.model_provider = "PaddleOCR"
+        else:
+            raise RuntimeError(f"current model is not supported: {model}")
+        self._engine = engine
+        self._det_cfg = DetConfig(flavour=model, thresh=thresh,
+                                  box_thresh=kwargs.get("box_thresh", 0.6), unclip_ratio=kwargs.get("unclip_ratio", 1.5),
+                                  use_dilation=kwargs.get("use_dilation", False))
+        self._config.model_path = self.get_model_name_or_path()
+        self._get_inference_model()
+
+    def _construct_model(self, model):
+        if self._engine is None:
+            self._engine = HipEngine(int(str(self.device).split(":")[-1]) if ":" in str(self.device) else 0)
+        if model == "db_pp" and not self.kwargs.get("allow_stand_in", False):
+            raise RuntimeError(f"'{self._config.model_path}' is an ONNX graph that is not part of the reference tree; "
+                               "pass allow_stand_in=True to run the PP-OCR pre/post-processing around DB-ResNet18")
+        if model == "db" and self._config.backbone != "resnet18":
+            raise TypeError(f"detector backbone should be resnet18 on the HIP engine, but got {self._config.backbone}")
+        if self.synthetic_seed is not None:
+            from .synth_weights import db_resnet18_state_dict
+            sd = db_resnet18_state_dict(seed=int(self.synthetic_seed))
+        else:
+            path = os.path.join(self._config.model_path, "pytorch_model.pt")   # modeling_db_net.py:53-56
+            if not os.path.exists(path):
+                raise RuntimeError(f"no checkpoint at {path}: the reference would download "
+                                   f"'{self._config.model_path}' from the hub (no network here); pass task_path=<dir> "
+                                   "or synthetic_seed=<int>")
+            sd = torch.load(path, map_location="cpu", weights_only=True)
+        self._engine.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(sd))
+        self._model = self._predict
+
+    def _build_processor(self):
+        self._stage = DetStage(self._engine, self._det_cfg)
+
+    def _predict(self, pages: torch.Tensor):
+        return self._stage.forward(pages)
+
+    def _preprocess(self, inputs, **kwargs):
+        if not isinstance(inputs, list):
+            inputs = [inputs]
+        batch = []
+        for item in inputs:
+            img = _read_image(item)
+            batch.append({"image": img, "org_shape": img.shape, "inputs": item})
+        return {"inputs": batch}
+
+    def _run_model(self, inputs, **kwargs):
+        items = inputs["inputs"]
+        begin = time.time()
+        results = [None] * len(items)
+        # group pages of identical size into one device batch (the reference runs them one by one)
+        groups = {}
+        for i, it in enumerate(items):
+            groups.setdefault(it["image"].shape, []).append(i)
+        for shape, idxs in groups.items():
+            pages = torch.from_numpy(np.stack([items[i]["image"] for i in idxs])).to(self._engine._tdev)
+            (prob, bitmap, ev), elapse = self.infer({"pages": pages})
+            boxes = self._stage.boxes(prob, bitmap, shape[:2], ev)
+            for k, i in enumerate(idxs):
+                results[i] = {"results": boxes[k], "elapse": elapse, "org_shape": items[i]["org_shape"],
+                              "inputs": items[i]["inputs"]}
+        inputs["results"] = results
+        inputs["use_time"] = time.time() - begin
+        return inputs
+
+    def _postprocess(self, inputs, **kwargs) -> List[np.ndarray]:
+        return [r["results"] for r in inputs["results"]]

@@ -39,11 +39,19 @@ class _Gen:
         if bias:
             self.put(name + ".bias", self.rng.uniform(-0.1, 0.1, (cout,)))
 
-    def convT(self, name, cin, cout, kh, kw, gain=2.0):
-        # nn.ConvTranspose2d weight layout: [Cin, Cout, kh, kw]; always has a bias in the reference
+    def convT(self, name, cin, cout, kh, kw, gain=2.0, quad_noise=None, bias=None):
+        # nn.ConvTranspose2d weight layout: [Cin, Cout, kh, kw]; always has a bias in the reference.
+        # quad_noise: make the kh*kw sub-pixel kernels nearly equal (base * (1 + quad_noise * N(0,1))), like a
+        # trained up-sampling head, so that the output is blob-like instead of per-pixel speckle.
         std = math.sqrt(gain / cin)
-        self.put(name + ".weight", self.rng.standard_normal((cin, cout, kh, kw)) * std)
-        self.put(name + ".bias", self.rng.uniform(-0.1, 0.1, (cout,)))
+        if quad_noise is None:
+            w = self.rng.standard_normal((cin, cout, kh, kw)) * std
+        else:
+            base = self.rng.standard_normal((cin, cout, 1, 1)) * std
+            w = base * (1.0 + quad_noise * self.rng.standard_normal((cin, cout, kh, kw)))
+        self.put(name + ".weight", w)
+        b = self.rng.uniform(-0.1, 0.1, (cout,))
+        self.put(name + ".bias", b if bias is None else np.full((cout,), bias))
 
     def bn(self, name, c):
         self.put(name + ".weight", self.rng.uniform(0.5, 1.5, (c,)))
@@ -67,7 +75,7 @@ class _Gen:
             self.put(f"{name}.bias_hh_l0{sfx}", self.rng.uniform(-k, k, (4 * nh,)))
 
 
-def db_resnet18_state_dict(seed: int = 0, with_thresh_branch: bool = True):
+def db_resnet18_state_dict(seed: int = 0, with_thresh_branch: bool = True, head_bias: float = 6.0):
     """state_dict of ``DBModel`` (ResNet-18 backbone + ``SegDetector`` decoder, adaptive=True).
 
     Key order follows module registration order in dbnet.py:260-336 (backbone) and :488-586
@@ -99,10 +107,11 @@ def db_resnet18_state_dict(seed: int = 0, with_thresh_branch: bool = True):
         g.conv("decoder." + n, 64, 256, 3, 3)
     g.conv("decoder.binarize.0", 64, 256, 3, 3)
     g.bn("decoder.binarize.1", 64)
-    g.convT("decoder.binarize.3", 64, 64, 2, 2)
+    g.convT("decoder.binarize.3", 64, 64, 2, 2, quad_noise=0.05)
     g.bn("decoder.binarize.4", 64)
-    # small gain on the last layer: logits with std ~5 (soft edges like a trained DB head) instead of ~50
-    g.convT("decoder.binarize.6", 64, 1, 2, 2, gain=0.02)
+    # small gain on the last layer: logits with std ~5-8 (soft edges like a trained DB head) instead of ~50,
+    # and a bias calibrated on the synthetic pages so that ~6 % of a page is "text" (~150 blob components)
+    g.convT("decoder.binarize.6", 64, 1, 2, 2, gain=0.02, quad_noise=0.05, bias=head_bias)
     if with_thresh_branch:
         g.conv("decoder.thresh.0", 64, 256, 3, 3)
         g.bn("decoder.thresh.1", 64)
