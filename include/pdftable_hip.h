@@ -42,6 +42,16 @@ void pt_engine_destroy(pt_engine* e);
 const char* pt_last_error(void);
 int pt_abi_version(void);
 
+/* Arithmetic of the conv nets (DESIGN.md "numerics").  PT_PRECISION_BF16: bf16 activations/weights, fp32
+ * accumulate -- the throughput mode BASELINE.json's configs name.  PT_PRECISION_BF16X3: every activation and
+ * weight is a (hi, lo) bf16 pair and each product is three MFMA passes (hi*hi + lo*hi + hi*lo), fp32-class
+ * accuracy (~1e-5 relative) at ~1/3 of the throughput: the mode that meets the reference-fp32 parity tolerance.
+ * In BF16X3 mode every bf16 NHWC activation tensor of C channels crossing this ABI (pt_det_preprocess output,
+ * pt_det_forward_net input, pt_op_* tensors with split=1) has 2C channels laid out [hi(C) | lo(C)]. */
+#define PT_PRECISION_BF16 0
+#define PT_PRECISION_BF16X3 1
+int pt_engine_set_precision(pt_engine* e, int precision);
+
 /* Model kinds for pt_weights_load.  A blob is the "PTW1" container written by
  * pdf_table_amd/weights.py (BN-folded, bf16 KRSC-tiled conv weights, fp32 biases). It replaces
  * torch.load + load_state_dict of model/db_net/modeling_db_net.py:53-56 and
@@ -121,7 +131,22 @@ int pt_db_finalize(const float* h_boxes, const float* h_scores, int nb, float bo
  * res_mode 1: + d_res (same shape as the un-replicated output); 2: + nearest-x2-upsampled d_res. */
 int pt_op_conv2d(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int Cin, const uint16_t* d_w_tiled,
                  const float* d_bias, int N, int ks, int stride, uint16_t* d_out, int out_cstride, int out_coff,
-                 int rep, int shuffle_cout, const uint16_t* d_res, int res_mode, int relu, pt_stream stream);
+                 int rep, int shuffle_cout, const uint16_t* d_res, int res_mode, int relu, int split, int out_lo_off,
+                 pt_stream stream);
+/* split=1 (BF16X3): d_in/d_res/d_out carry (hi | lo) channel groups, d_w_tiled is [N/64][3*Cin/32][ks*ks][64][32]
+ * (K chunks: w_hi for x_hi, w_hi for x_lo, w_lo for x_hi), out_lo_off = channel distance hi -> lo in d_out. */
+
+/* Stem of the ResNet-18 backbone: 7x7 s2 p3 conv (BN folded) + ReLU on a bf16 NHWC4 image (dbnet.py:272-275).
+ * d_w is bf16 [64][7][8][4] (K padded: tap s=7 and channel 3 are zero), d_bias fp32 [64]; out bf16 [B,H/2,W/2,64]. */
+int pt_op_stem7x7(pt_engine* e, const uint16_t* d_in, int B, int H, int W, const uint16_t* d_w, const float* d_bias,
+                  uint16_t* d_out, int split, pt_stream stream);
+/* MaxPool2d(3, 2, 1) on bf16 NHWC (dbnet.py:276). */
+int pt_op_maxpool3x3s2(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int C, uint16_t* d_out, int split,
+                       pt_stream stream);
+/* ConvTranspose2d(64 -> 1, k=2, s=2) + Sigmoid (dbnet.py:539): in bf16 [B,H,W,64], d_w bf16 [4][64] (quadrant
+ * dy*2+dx major), d_bias fp32 [1]; d_prob / d_logits fp32 [B,2H,2W] (either may be NULL). */
+int pt_op_db_head_final(pt_engine* e, const uint16_t* d_in, int B, int H, int W, const void* d_w, const float* d_bias,
+                        float* d_prob, float* d_logits, int split, pt_stream stream);
 
 /* ---- introspection used by bench.py (HIP-event timing of the dominant kernel) ------------------ */
 /* When enabled, every conv launch inside pt_det_forward* is bracketed by hipEvents on `stream`.

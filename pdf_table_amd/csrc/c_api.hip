@@ -19,7 +19,13 @@ void pt_set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* pt_last_error(void) { return g_err; }
-int pt_abi_version(void) { return 1; }
+int pt_abi_version(void) { return 2; }
+
+int pt_engine_set_precision(pt_engine* e, int precision) {
+  PT_REQUIRE(e && (precision == PT_PRECISION_BF16 || precision == PT_PRECISION_BF16X3), "pt_engine_set_precision: bad arguments");
+  e->precision = precision;
+  return PT_OK;
+}
 
 int pt_engine_create(int device_id, pt_engine** out) {
   PT_REQUIRE(out != nullptr, "pt_engine_create: out is NULL");
@@ -185,7 +191,8 @@ int pt_det_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h, in
   PT_REQUIRE(e && d_pages_rgb && d_out_bf16 && n > 0, "pt_det_preprocess: bad arguments");
   int nh, nw, rc;
   if ((rc = pt_det_plan(h, w, pre_flavour, &nh, &nw)) != PT_OK) return rc;
-  return pt_launch_det_preprocess(d_pages_rgb, n, h, w, nh, nw, pre_flavour, d_out_bf16, reinterpret_cast<hipStream_t>(stream));
+  return pt_launch_det_preprocess(d_pages_rgb, n, h, w, nh, nw, pre_flavour, e->precision == PT_PRECISION_BF16X3, d_out_bf16,
+                                  reinterpret_cast<hipStream_t>(stream));
 }
 
 int pt_det_forward_net(pt_engine* e, const uint16_t* d_input_bf16, int n, int net_h, int net_w, float* d_prob,
@@ -222,7 +229,8 @@ int pt_det_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h, int w
   // the pre-processed pages live in their own engine-owned buffer (not the arena, which the net resets)
   static thread_local void* xbuf = nullptr;
   static thread_local size_t xcap = 0;
-  const size_t need = (size_t)(mb < n ? mb : n) * nh * nw * 4 * sizeof(bf16_t);
+  const int x3 = e->precision == PT_PRECISION_BF16X3;
+  const size_t need = (size_t)(mb < n ? mb : n) * nh * nw * (x3 ? 8 : 4) * sizeof(bf16_t);
   if (need > xcap) {
     PT_HIP_CHECK(hipDeviceSynchronize());
     if (xbuf) PT_HIP_CHECK(hipFree(xbuf));
@@ -234,7 +242,7 @@ int pt_det_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h, int w
     const int nb = (n - i0) < mb ? (n - i0) : mb;
     {
       PtProfScope ps(e, s, PT_PROF_OTHER, 0);
-      rc = pt_launch_det_preprocess(d_pages_rgb + (size_t)i0 * h * w * 3, nb, h, w, nh, nw, pre_flavour,
+      rc = pt_launch_det_preprocess(d_pages_rgb + (size_t)i0 * h * w * 3, nb, h, w, nh, nw, pre_flavour, x3,
                                     reinterpret_cast<bf16_t*>(xbuf), s);
       if (rc != PT_OK) return rc;
     }
@@ -258,13 +266,33 @@ int pt_det_box_scores(pt_engine* e, const float* d_prob, int n, int net_h, int n
 
 int pt_op_conv2d(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int Cin, const uint16_t* d_w_tiled,
                  const float* d_bias, int N, int ks, int stride, uint16_t* d_out, int out_cstride, int out_coff,
-                 int rep, int shuffle_cout, const uint16_t* d_res, int res_mode, int relu, pt_stream stream) {
+                 int rep, int shuffle_cout, const uint16_t* d_res, int res_mode, int relu, int split, int out_lo_off,
+                 pt_stream stream) {
   PT_REQUIRE(e != nullptr, "pt_op_conv2d: null engine");
   ConvDesc d;
   d.in = d_in; d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.w = d_w_tiled; d.bias = d_bias; d.N = N; d.ks = ks;
   d.stride = stride; d.out = d_out; d.out_cstride = out_cstride; d.out_coff = out_coff; d.rep = rep;
   d.shuffle_cout = shuffle_cout; d.res = d_res; d.res_mode = res_mode; d.relu = relu;
+  d.split = split; d.out_lo_off = out_lo_off;
   return pt_launch_conv(e, d, reinterpret_cast<hipStream_t>(stream));
+}
+
+int pt_op_stem7x7(pt_engine* e, const uint16_t* d_in, int B, int H, int W, const uint16_t* d_w, const float* d_bias,
+                  uint16_t* d_out, int split, pt_stream stream) {
+  PT_REQUIRE(e != nullptr, "pt_op_stem7x7: null engine");
+  return pt_launch_stem7x7(e, d_in, B, H, W, d_w, d_bias, d_out, split, reinterpret_cast<hipStream_t>(stream));
+}
+
+int pt_op_maxpool3x3s2(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int C, uint16_t* d_out, int split,
+                       pt_stream stream) {
+  PT_REQUIRE(e && d_in && d_out, "pt_op_maxpool3x3s2: bad arguments");
+  return pt_launch_maxpool3x3s2(d_in, B, H, W, C, d_out, split, reinterpret_cast<hipStream_t>(stream));
+}
+
+int pt_op_db_head_final(pt_engine* e, const uint16_t* d_in, int B, int H, int W, const void* d_w, const float* d_bias,
+                        float* d_prob, float* d_logits, int split, pt_stream stream) {
+  PT_REQUIRE(e && d_in && d_w && d_bias && (d_prob || d_logits), "pt_op_db_head_final: bad arguments");
+  return pt_launch_db_head_final(d_in, B, H, W, d_w, d_bias, d_prob, d_logits, split, reinterpret_cast<hipStream_t>(stream));
 }
 
 // ---- profiling ---------------------------------------------------------------------------------------

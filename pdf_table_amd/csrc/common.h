@@ -93,6 +93,7 @@ struct pt_engine {
   PtArena arena;
   std::map<int, PtModel> models;
   PtProfile prof;
+  int precision = 0;  // PT_PRECISION_*
 };
 
 // ---- conv launcher (conv_igemm.hip) -----------------------------------------------------------------
@@ -116,19 +117,22 @@ struct ConvDesc {
   const bf16_t* res = nullptr;
   int res_mode = 0;  // 0 none, 1 same resolution, 2 half resolution (fused nearest x2 upsample + add)
   int relu = 0;
+  // bf16x3 precision mode: in/res/out hold (hi | lo) channel groups; w is [N/64][3*Cin/32][taps][64][32]
+  int split = 0;
+  int out_lo_off = 0;  // channel distance between the hi and lo halves in the output buffer
 };
 int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s);
 
 // stem: 7x7 s2 p3 conv on NHWC4 bf16 input, 64 outputs, bias + ReLU (conv_igemm.hip)
 int pt_launch_stem7x7(pt_engine* e, const bf16_t* in, int B, int H, int W, const bf16_t* w, const float* bias,
-                      bf16_t* out, hipStream_t s);
+                      bf16_t* out, int split, hipStream_t s);
 
 // ---- misc kernels (det_kernels.hip) ---------------------------------------------------------------------
-int pt_launch_det_preprocess(const uint8_t* pages, int n, int h, int w, int nh, int nw, int flavour, bf16_t* out,
-                             hipStream_t s);
-int pt_launch_maxpool3x3s2(const bf16_t* in, int B, int H, int W, int C, bf16_t* out, hipStream_t s);
-int pt_launch_db_head_final(const bf16_t* in, int B, int H, int W, const bf16_t* w4x64, const float* bias, float* prob,
-                            float* logits, hipStream_t s);
+int pt_launch_det_preprocess(const uint8_t* pages, int n, int h, int w, int nh, int nw, int flavour, int split,
+                             bf16_t* out, hipStream_t s);
+int pt_launch_maxpool3x3s2(const bf16_t* in, int B, int H, int W, int C, bf16_t* out, int split, hipStream_t s);
+int pt_launch_db_head_final(const bf16_t* in, int B, int H, int W, const void* w4x64, const float* bias, float* prob,
+                            float* logits, int split, hipStream_t s);
 int pt_launch_bitmap(const float* prob, int n, int H, int W, float thresh, int dilate, uint32_t* bitmap,
                      hipStream_t s);
 int pt_launch_box_scores(const float* prob, int n, int H, int W, const float* boxes, int nb, float* scores,
@@ -136,6 +140,9 @@ int pt_launch_box_scores(const float* prob, int n, int H, int W, const float* bo
 
 // ---- models ---------------------------------------------------------------------------------------------
 int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* prob, float* logits, hipStream_t s);
+
+#define PT_PRECISION_BF16 0
+#define PT_PRECISION_BF16X3 1
 
 // profiling helper: bracket a launch with events when enabled
 struct PtProfScope {

@@ -37,6 +37,9 @@ struct ConvK {
   int B, H, W, Cin, Ho, Wo, N;
   int out_cstride, out_coff, rep, shuffle_cout, res_mode, relu;
   int tiles_x, tiles_y, n_tiles;
+  // bf16x3 ("split") precision mode: every activation is a (hi, lo) bf16 pair stored as two channel groups
+  // [hi(C) | lo(C)]; K runs over (x_hi, w_hi), (x_lo, w_hi), (x_hi, w_lo); out_lo_off = channel distance hi -> lo
+  int split, out_lo_off;
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
@@ -72,32 +75,47 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
     f32x4 b0 = bp[0], b1 = bp[1];
     float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
     if (p.res_mode) {
+      const int rcs = p.split ? 2 * p.N : p.N;
       size_t ro;
       if (p.res_mode == 1)
-        ro = (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.N + n;
+        ro = (((size_t)b * p.Ho + oy) * p.Wo + ox) * rcs + n;
       else
-        ro = (((size_t)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * p.N + n;
+        ro = (((size_t)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * rcs + n;
       u32x4 r = *reinterpret_cast<const u32x4*>(p.res + ro);
       v[0] += bf16_to_f32(r.x & 0xFFFFu); v[1] += bf16_to_f32(r.x >> 16);
       v[2] += bf16_to_f32(r.y & 0xFFFFu); v[3] += bf16_to_f32(r.y >> 16);
       v[4] += bf16_to_f32(r.z & 0xFFFFu); v[5] += bf16_to_f32(r.z >> 16);
       v[6] += bf16_to_f32(r.w & 0xFFFFu); v[7] += bf16_to_f32(r.w >> 16);
+      if (p.split) {
+        r = *reinterpret_cast<const u32x4*>(p.res + ro + p.N);
+        v[0] += bf16_to_f32(r.x & 0xFFFFu); v[1] += bf16_to_f32(r.x >> 16);
+        v[2] += bf16_to_f32(r.y & 0xFFFFu); v[3] += bf16_to_f32(r.y >> 16);
+        v[4] += bf16_to_f32(r.z & 0xFFFFu); v[5] += bf16_to_f32(r.z >> 16);
+        v[6] += bf16_to_f32(r.w & 0xFFFFu); v[7] += bf16_to_f32(r.w >> 16);
+      }
     }
     if (p.relu) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
     }
-    u32x4 o;
-    o.x = f32_to_bf16(v[0]) | (f32_to_bf16(v[1]) << 16);
-    o.y = f32_to_bf16(v[2]) | (f32_to_bf16(v[3]) << 16);
-    o.z = f32_to_bf16(v[4]) | (f32_to_bf16(v[5]) << 16);
-    o.w = f32_to_bf16(v[6]) | (f32_to_bf16(v[7]) << 16);
+    uint32_t hb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) hb[k] = f32_to_bf16(v[k]);
+    u32x4 o, ol;
+    o.x = hb[0] | (hb[1] << 16); o.y = hb[2] | (hb[3] << 16); o.z = hb[4] | (hb[5] << 16); o.w = hb[6] | (hb[7] << 16);
+    if (p.split) {
+      uint32_t lb[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) lb[k] = f32_to_bf16(v[k] - bf16_to_f32(hb[k]));
+      ol.x = lb[0] | (lb[1] << 16); ol.y = lb[2] | (lb[3] << 16); ol.z = lb[4] | (lb[5] << 16); ol.w = lb[6] | (lb[7] << 16);
+    }
     if (p.shuffle_cout) {
       const int quad = n0 / p.shuffle_cout;
       const int co = n0 - quad * p.shuffle_cout + cg * 8;
       const int OH = p.Ho * 2, OW = p.Wo * 2;
       const size_t oo = (((size_t)b * OH + 2 * oy + (quad >> 1)) * OW + 2 * ox + (quad & 1)) * p.out_cstride + p.out_coff + co;
       *reinterpret_cast<u32x4*>(p.out + oo) = o;
+      if (p.split) *reinterpret_cast<u32x4*>(p.out + oo + p.out_lo_off) = ol;
     } else {
       const int f = p.rep;
       const int OH = p.Ho * f, OW = p.Wo * f;
@@ -105,6 +123,7 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
         for (int fx = 0; fx < f; ++fx) {
           const size_t oo = (((size_t)b * OH + oy * f + fy) * OW + ox * f + fx) * p.out_cstride + p.out_coff + n;
           *reinterpret_cast<u32x4*>(p.out + oo) = o;
+          if (p.split) *reinterpret_cast<u32x4*>(p.out + oo + p.out_lo_off) = ol;
         }
     }
   }
@@ -150,15 +169,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
   const int b = L / p.tiles_y;
   const int oy0 = tyi * C::TH, ox0 = txi * C::TW;
   const int iy0 = oy0 * STRIDE - (KS / 2), ix0 = ox0 * STRIDE - (KS / 2);
-  const int nchunks = p.Cin >> 5;
-  const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * p.Cin;
+  const int nchunks = p.split ? 3 * (p.Cin >> 5) : (p.Cin >> 5);
+  const int in_cs = p.split ? 2 * p.Cin : p.Cin;   // channels per input pixel in memory
+  const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * in_cs;
   const bf16_t* wt = p.w + (size_t)nt * nchunks * (C::TAPS * 64 * 32);
 
   u32x4 rin[C::NI];
   u32x4 rw[C::NWP];
 
   auto prefetch = [&](int chunk) {
-    const int c0 = chunk << 5;
+    // split mode: K chunks walk [x_hi | x_lo] against w_hi, then x_hi again against w_lo
+    int c0 = chunk << 5;
+    if (c0 >= in_cs) c0 -= in_cs;
 #pragma unroll
     for (int j = 0; j < C::NI; ++j) {
       const int idx = tid + j * 256;
@@ -168,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         const int iy = pix / C::TWIN, ix = pix - iy * C::TWIN;
         const int gy = iy0 + iy, gx = ix0 + ix;
         if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-          v = *reinterpret_cast<const u32x4*>(in_b + ((size_t)gy * p.W + gx) * p.Cin + c0 + part * 8);
+          v = *reinterpret_cast<const u32x4*>(in_b + ((size_t)gy * p.W + gx) * in_cs + c0 + part * 8);
       }
       rin[j] = v;
     }
@@ -283,31 +305,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_kernel(ConvK p) {
   const int b = L / p.tiles_y;
   const int oy0 = tyi * C::TH, ox0 = txi * C::TW;
   const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
-  const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * 4;
-
-#pragma unroll
-  for (int j = 0; j < C::NI; ++j) {
-    const int idx = tid + j * 256;
-    if (idx < C::NP_IN) {
-      const int iy = idx / 35, ip = idx - iy * 35;
-      const int gy = iy0 + iy, gx = ix0 + 2 * ip;
-      u32x2 v0 = {0u, 0u}, v1 = {0u, 0u};
-      if ((unsigned)gy < (unsigned)p.H) {
-        const bf16_t* rowp = in_b + (size_t)gy * p.W * 4;
-        if ((unsigned)gx < (unsigned)p.W) v0 = *reinterpret_cast<const u32x2*>(rowp + (size_t)gx * 4);
-        if ((unsigned)(gx + 1) < (unsigned)p.W) v1 = *reinterpret_cast<const u32x2*>(rowp + (size_t)(gx + 1) * 4);
-      }
-      u32x4 v = {v0.x, v0.y, v1.x, v1.y};
-      *reinterpret_cast<u32x4*>(s_in + (iy * C::TWIN + 2 * ip) * 8) = v;
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < C::NWP; ++j) {
-    const int idx = tid + j * 256;
-    const int row = idx / 28, part = idx - row * 28;
-    *reinterpret_cast<u32x4*>(s_w + row * C::WROW + part * 16) = *reinterpret_cast<const u32x4*>(p.w + idx * 8);
-  }
-  __syncthreads();
+  const int ps = p.split ? 8 : 4;  // bf16 elements per input pixel: [r g b 0] or [hi rgb0 | lo rgb0]
+  const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * ps;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -319,18 +318,50 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_kernel(ConvK p) {
 
   const char* a_base = s_in + (((wave * 2) * 2) * C::TWIN + 2 * lx + 2 * q) * 8;
   const char* b_base = s_w + lx * C::WROW + q * 16;
+  // split mode: three passes (x_hi, w_hi), (x_lo, w_hi), (x_hi, w_lo) into the same accumulators
+  const int npass = p.split ? 3 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int po = (pass == 1) ? 4 : 0;
+    const bf16_t* wsrc = p.w + (pass == 2 ? 64 * 224 : 0);
+    if (pass) __syncthreads();
 #pragma unroll
-  for (int r = 0; r < 7; ++r) {
+    for (int j = 0; j < C::NI; ++j) {
+      const int idx = tid + j * 256;
+      if (idx < C::NP_IN) {
+        const int iy = idx / 35, ip = idx - iy * 35;
+        const int gy = iy0 + iy, gx = ix0 + 2 * ip;
+        u32x2 v0 = {0u, 0u}, v1 = {0u, 0u};
+        if ((unsigned)gy < (unsigned)p.H) {
+          const bf16_t* rowp = in_b + (size_t)gy * p.W * ps + po;
+          if ((unsigned)gx < (unsigned)p.W) v0 = *reinterpret_cast<const u32x2*>(rowp + (size_t)gx * ps);
+          if ((unsigned)(gx + 1) < (unsigned)p.W) v1 = *reinterpret_cast<const u32x2*>(rowp + (size_t)(gx + 1) * ps);
+        }
+        u32x4 v = {v0.x, v0.y, v1.x, v1.y};
+        *reinterpret_cast<u32x4*>(s_in + (iy * C::TWIN + 2 * ip) * 8) = v;
+      }
+    }
+    if (pass != 1) {  // pass 1 re-uses w_hi
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int ks = r * 2 + h;
-      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(b_base + ks * 32);
-      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(b_base + 32 * C::WROW + ks * 32);
+      for (int j = 0; j < C::NWP; ++j) {
+        const int idx = tid + j * 256;
+        const int row = idx / 28, part = idx - row * 28;
+        *reinterpret_cast<u32x4*>(s_w + row * C::WROW + part * 16) = *reinterpret_cast<const u32x4*>(wsrc + idx * 8);
+      }
+    }
+    __syncthreads();
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base + ((m * 2 + r) * C::TWIN + 4 * h) * 8);
-        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
-        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
+    for (int r = 0; r < 7; ++r) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ks = r * 2 + h;
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(b_base + ks * 32);
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(b_base + 32 * C::WROW + ks * 32);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base + ((m * 2 + r) * C::TWIN + 4 * h) * 8);
+          acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
+          acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
+        }
       }
     }
   }
@@ -389,8 +420,9 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   k.Wo = (d.W + 2 * pad - d.ks) / d.stride + 1;
   k.out_cstride = d.out_cstride; k.out_coff = d.out_coff; k.rep = d.rep; k.shuffle_cout = d.shuffle_cout;
   k.res_mode = d.res ? d.res_mode : 0; k.relu = d.relu;
+  k.split = d.split; k.out_lo_off = d.out_lo_off;
   if (k.res_mode == 2) PT_REQUIRE(k.Ho % 2 == 0 && k.Wo % 2 == 0, "conv: half-res residual needs even output size");
-  const double flop = 2.0 * k.B * k.Ho * k.Wo * (double)k.N * d.Cin * d.ks * d.ks;
+  const double flop = 2.0 * k.B * k.Ho * k.Wo * (double)k.N * d.Cin * d.ks * d.ks;  // algorithmic (not x3 in split mode)
   if (d.ks == 3 && d.stride == 1) return launch_cfg<3, 1>(e, k, s, flop);
   if (d.ks == 3 && d.stride == 2) return launch_cfg<3, 2>(e, k, s, flop);
   if (d.ks == 1 && d.stride == 1) return launch_cfg<1, 1>(e, k, s, flop);
@@ -398,7 +430,7 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
 }
 
 int pt_launch_stem7x7(pt_engine* e, const bf16_t* in, int B, int H, int W, const bf16_t* w, const float* bias,
-                      bf16_t* out, hipStream_t s) {
+                      bf16_t* out, int split, hipStream_t s) {
   PT_REQUIRE(in && w && bias && out, "stem: null pointer");
   PT_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: H, W must be even");
   static bool attr_done = false;
@@ -412,7 +444,8 @@ int pt_launch_stem7x7(pt_engine* e, const bf16_t* in, int B, int H, int W, const
   k.in = in; k.w = w; k.bias = bias; k.out = out; k.res = nullptr;
   k.B = B; k.H = H; k.W = W; k.Cin = 4; k.N = 64;
   k.Ho = H / 2; k.Wo = W / 2;
-  k.out_cstride = 64; k.out_coff = 0; k.rep = 1; k.shuffle_cout = 0; k.res_mode = 0; k.relu = 1;
+  k.out_cstride = split ? 128 : 64; k.out_coff = 0; k.rep = 1; k.shuffle_cout = 0; k.res_mode = 0; k.relu = 1;
+  k.split = split; k.out_lo_off = 64;
   k.tiles_x = (k.Wo + 31) / 32; k.tiles_y = (k.Ho + 7) / 8; k.n_tiles = 1;
   const long long nblk = (long long)B * k.tiles_x * k.tiles_y;
   PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "stem grid out of range");

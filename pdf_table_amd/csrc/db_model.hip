@@ -2,12 +2,17 @@
 //
 // Reference graph: DBModel.forward = SegDetector(ResNet(BasicBlock,[2,2,2,2]))
 //   model/db_net/dbnet.py:324-335 (backbone), :615-638 (decoder, eval branch), :533-539 (binarize head).
-// Fusions relative to the reference's op list (all arithmetic-preserving up to the bf16 contract in
-// DESIGN.md "numerics"): Conv+BN(+ReLU) folded; residual add + ReLU in the conv epilogue; the top-down
+// Fusions relative to the reference's op list (all arithmetic-preserving up to the numerics contract in
+// DESIGN.md): Conv+BN(+ReLU) folded; residual add + ReLU in the conv epilogue; the top-down
 // `up(x) + lateral` adds fused into the lateral 1x1 conv's epilogue (nearest x2 read of the residual);
 // the nn.Upsample(x8/x4/x2) + torch.cat fused into the out5/out4/out3/out2 conv epilogues (replicated
 // stores straight into the 256-channel concat buffer); ConvTranspose2d(2,2) as a GEMM with a
 // pixel-shuffle epilogue; the last ConvTranspose2d(64->1) + Sigmoid as one streaming kernel.
+//
+// Two precisions over the same graph and kernels (pt_engine_set_precision):
+//   PT_PRECISION_BF16   activations bf16, one MFMA pass                       (throughput mode)
+//   PT_PRECISION_BF16X3 activations (hi, lo) bf16 pairs, K = (x_hi,w_hi)+(x_lo,w_hi)+(x_hi,w_lo): ~2^-16
+//                       relative error per product, fp32 accumulate           (fp32-class parity mode)
 #include <stdlib.h>
 
 #include "common.h"
@@ -33,25 +38,26 @@ int get(const PtModel& m, const std::string& name, const PtTensor** out, bool op
   return PT_OK;
 }
 
-int bind(const PtModel& m, DbWeights& w) {
+int bind(const PtModel& m, DbWeights& w, bool x3) {
   int rc;
+  const std::string ws = x3 ? ".w3" : ".w";  // split-precision weight tiles carry the suffix .w3
 #define G(name, field) if ((rc = get(m, name, &w.field)) != PT_OK) return rc
-  G("stem.w", stem_w); G("stem.b", stem_b);
+  G("stem" + ws, stem_w); G("stem.b", stem_b);
   for (int l = 0; l < 4; ++l)
     for (int b = 0; b < 2; ++b) {
       const std::string p = "layer" + std::to_string(l + 1) + "." + std::to_string(b);
-      G(p + ".conv1.w", blk[l][b].w1); G(p + ".conv1.b", blk[l][b].b1);
-      G(p + ".conv2.w", blk[l][b].w2); G(p + ".conv2.b", blk[l][b].b2);
-      if ((rc = get(m, p + ".down.w", &w.blk[l][b].wd, true)) != PT_OK) return rc;
+      G(p + ".conv1" + ws, blk[l][b].w1); G(p + ".conv1.b", blk[l][b].b1);
+      G(p + ".conv2" + ws, blk[l][b].w2); G(p + ".conv2.b", blk[l][b].b2);
+      if ((rc = get(m, p + ".down" + ws, &w.blk[l][b].wd, true)) != PT_OK) return rc;
       if ((rc = get(m, p + ".down.b", &w.blk[l][b].bd, true)) != PT_OK) return rc;
     }
   for (int i = 0; i < 4; ++i) {
     const std::string k = std::to_string(i + 2);
-    G("in" + k + ".w", in_w[i]); G("in" + k + ".b", in_b[i]);
-    G("out" + k + ".w", out_w[i]); G("out" + k + ".b", out_b[i]);
+    G("in" + k + ws, in_w[i]); G("in" + k + ".b", in_b[i]);
+    G("out" + k + ws, out_w[i]); G("out" + k + ".b", out_b[i]);
   }
-  G("bin0.w", bin0_w); G("bin0.b", bin0_b); G("bin3.w", bin3_w); G("bin3.b", bin3_b);
-  G("bin6.w", bin6_w); G("bin6.b", bin6_b);
+  G("bin0" + ws, bin0_w); G("bin0.b", bin0_b); G("bin3" + ws, bin3_w); G("bin3.b", bin3_b);
+  G(x3 ? "bin6.wf32" : "bin6.w", bin6_w); G("bin6.b", bin6_b);
 #undef G
   return PT_OK;
 }
@@ -72,8 +78,10 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
     pt_set_error("DB-ResNet18 weights not loaded (pt_weights_load(PT_MODEL_DB_RESNET18))");
     return PT_ERR_STATE;
   }
+  const int x3 = e->precision == PT_PRECISION_BF16X3 ? 1 : 0;
+  const int m = x3 ? 2 : 1;  // channel-group multiplier of every activation buffer
   DbWeights w;
-  int rc = bind(it->second, w);
+  int rc = bind(it->second, w, x3 != 0);
   if (rc != PT_OK) return rc;
 
   const int ch[4] = {64, 128, 256, 512};
@@ -82,7 +90,7 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
     e->arena.reset();
     bool ok = true;
     auto take = [&](size_t elems) {
-      void* p = e->arena.take(elems * sizeof(bf16_t));
+      void* p = e->arena.take(elems * m * sizeof(bf16_t));
       if (!p) ok = false;
       return reinterpret_cast<bf16_t*>(p);
     };
@@ -113,10 +121,18 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
   }
 
 #define RUN(call) do { if ((rc = (call)) != PT_OK) return rc; } while (0)
-  RUN(pt_launch_stem7x7(e, x, n, H, W_, W(w.stem_w), Bv(w.stem_b), bf.s, s));
+  // every conv below: out buffer of C channels is laid out [hi(C) | lo(C)] in x3 mode
+  auto conv = [&](const bf16_t* in, int hh, int ww, int cin, const PtTensor* wt, const PtTensor* bs, int N, int ks,
+                  int stride, bf16_t* out, int out_c, int relu) {
+    ConvDesc c;
+    c.in = in; c.B = n; c.H = hh; c.W = ww; c.Cin = cin; c.w = W(wt); c.bias = Bv(bs); c.N = N; c.ks = ks;
+    c.stride = stride; c.out = out; c.out_cstride = out_c * m; c.relu = relu; c.split = x3; c.out_lo_off = out_c;
+    return c;
+  };
+  RUN(pt_launch_stem7x7(e, x, n, H, W_, W(w.stem_w), Bv(w.stem_b), bf.s, x3, s));
   {
     PtProfScope ps(e, s, PT_PROF_OTHER, 0);
-    RUN(pt_launch_maxpool3x3s2(bf.s, n, H / 2, W_ / 2, 64, bf.p, s));
+    RUN(pt_launch_maxpool3x3s2(bf.s, n, H / 2, W_ / 2, 64, bf.p, x3, s));
   }
   const bf16_t* cur = bf.p;
   int ch_in = 64, hh = H / 4, ww = W_ / 4;
@@ -124,26 +140,18 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
     for (int b = 0; b < 2; ++b) {
       const int stride = (l > 0 && b == 0) ? 2 : 1;
       const DbWeights::Block& bw = w.blk[l][b];
-      ConvDesc c1;
-      c1.in = cur; c1.B = n; c1.H = hh; c1.W = ww; c1.Cin = ch_in;
-      c1.w = W(bw.w1); c1.bias = Bv(bw.b1); c1.N = ch[l]; c1.ks = 3; c1.stride = stride;
-      c1.out = bf.t[l]; c1.out_cstride = ch[l]; c1.relu = 1;
+      ConvDesc c1 = conv(cur, hh, ww, ch_in, bw.w1, bw.b1, ch[l], 3, stride, bf.t[l], ch[l], 1);
       RUN(pt_launch_conv(e, c1, s));
       const bf16_t* res = cur;
       if (bw.wd) {
-        ConvDesc cd;
-        cd.in = cur; cd.B = n; cd.H = hh; cd.W = ww; cd.Cin = ch_in;
-        cd.w = W(bw.wd); cd.bias = Bv(bw.bd); cd.N = ch[l]; cd.ks = 1; cd.stride = stride;
-        cd.out = bf.d[l]; cd.out_cstride = ch[l]; cd.relu = 0;
+        ConvDesc cd = conv(cur, hh, ww, ch_in, bw.wd, bw.bd, ch[l], 1, stride, bf.d[l], ch[l], 0);
         RUN(pt_launch_conv(e, cd, s));
         res = bf.d[l];
       }
       hh /= stride; ww /= stride;
       bf16_t* dst = (b == 0) ? bf.a[l] : bf.c[l];
-      ConvDesc c2;
-      c2.in = bf.t[l]; c2.B = n; c2.H = hh; c2.W = ww; c2.Cin = ch[l];
-      c2.w = W(bw.w2); c2.bias = Bv(bw.b2); c2.N = ch[l]; c2.ks = 3; c2.stride = 1;
-      c2.out = dst; c2.out_cstride = ch[l]; c2.res = res; c2.res_mode = 1; c2.relu = 1;
+      ConvDesc c2 = conv(bf.t[l], hh, ww, ch[l], bw.w2, bw.b2, ch[l], 3, 1, dst, ch[l], 1);
+      c2.res = res; c2.res_mode = 1;
       RUN(pt_launch_conv(e, c2, s));
       cur = dst;
       ch_in = ch[l];
@@ -152,38 +160,28 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
   // decoder: lateral 1x1 convs with the top-down add fused (in5 first, then in4 + up(in5), ...)
   bf16_t* lat[4] = {bf.o2, bf.o3, bf.o4, bf.in5};  // index i <-> feature c[i]
   for (int i = 3; i >= 0; --i) {
-    ConvDesc c;
-    c.in = bf.c[i]; c.B = n; c.H = H >> (2 + i); c.W = W_ >> (2 + i); c.Cin = ch[i];
-    c.w = W(w.in_w[i]); c.bias = Bv(w.in_b[i]); c.N = 256; c.ks = 1; c.stride = 1;
-    c.out = lat[i]; c.out_cstride = 256; c.relu = 0;
+    ConvDesc c = conv(bf.c[i], H >> (2 + i), W_ >> (2 + i), ch[i], w.in_w[i], w.in_b[i], 256, 1, 1, lat[i], 256, 0);
     if (i < 3) { c.res = lat[i + 1]; c.res_mode = 2; }
     RUN(pt_launch_conv(e, c, s));
   }
   // out5/out4/out3/out2: 3x3 256->64, nearest-upsampled x8/x4/x2/x1 and concatenated as (p5,p4,p3,p2)
   for (int i = 3; i >= 0; --i) {
-    ConvDesc c;
-    c.in = lat[i]; c.B = n; c.H = H >> (2 + i); c.W = W_ >> (2 + i); c.Cin = 256;
-    c.w = W(w.out_w[i]); c.bias = Bv(w.out_b[i]); c.N = 64; c.ks = 3; c.stride = 1;
-    c.out = bf.fuse; c.out_cstride = 256; c.out_coff = (3 - i) * 64; c.rep = 1 << i; c.relu = 0;
+    ConvDesc c = conv(lat[i], H >> (2 + i), W_ >> (2 + i), 256, w.out_w[i], w.out_b[i], 64, 3, 1, bf.fuse, 256, 0);
+    c.out_coff = (3 - i) * 64; c.rep = 1 << i;
     RUN(pt_launch_conv(e, c, s));
   }
   {
-    ConvDesc c;
-    c.in = bf.fuse; c.B = n; c.H = H / 4; c.W = W_ / 4; c.Cin = 256;
-    c.w = W(w.bin0_w); c.bias = Bv(w.bin0_b); c.N = 64; c.ks = 3; c.stride = 1;
-    c.out = bf.y0; c.out_cstride = 64; c.relu = 1;
+    ConvDesc c = conv(bf.fuse, H / 4, W_ / 4, 256, w.bin0_w, w.bin0_b, 64, 3, 1, bf.y0, 64, 1);
     RUN(pt_launch_conv(e, c, s));
   }
   {
-    ConvDesc c;
-    c.in = bf.y0; c.B = n; c.H = H / 4; c.W = W_ / 4; c.Cin = 64;
-    c.w = W(w.bin3_w); c.bias = Bv(w.bin3_b); c.N = 256; c.ks = 1; c.stride = 1;
-    c.out = bf.y1; c.out_cstride = 64; c.shuffle_cout = 64; c.relu = 1;
+    ConvDesc c = conv(bf.y0, H / 4, W_ / 4, 64, w.bin3_w, w.bin3_b, 256, 1, 1, bf.y1, 64, 1);
+    c.shuffle_cout = 64;
     RUN(pt_launch_conv(e, c, s));
   }
   {
     PtProfScope ps(e, s, PT_PROF_OTHER, 0);
-    RUN(pt_launch_db_head_final(bf.y1, n, H / 2, W_ / 2, W(w.bin6_w), Bv(w.bin6_b), prob, logits, s));
+    RUN(pt_launch_db_head_final(bf.y1, n, H / 2, W_ / 2, w.bin6_w->d_ptr, Bv(w.bin6_b), prob, logits, x3, s));
   }
 #undef RUN
   return PT_OK;

@@ -48,7 +48,7 @@ __device__ __forceinline__ ResizeCoef resize_coef(int d, double scale, int ssize
 }
 
 __global__ __launch_bounds__(256) void det_preprocess_kernel(const uint8_t* __restrict__ pages, int n, int h, int w,
-                                                              int nh, int nw, int flavour, bf16_t* __restrict__ out) {
+                                                              int nh, int nw, int flavour, int split, bf16_t* __restrict__ out) {
   const long long total = (long long)n * nh * nw;
   const double sx = (double)w / nw, sy = (double)h / nh;
   const bool area2 = (w == 2 * nw) && (h == 2 * nh);
@@ -92,19 +92,29 @@ __global__ __launch_bounds__(256) void det_preprocess_kernel(const uint8_t* __re
 #pragma unroll
       for (int c = 0; c < 3; ++c) o[c] = ((float)v[2 - c] * scale - mean[c]) / stdv[c];
     }
-    u32x2 pk;
-    pk.x = f2bf(o[0]) | (f2bf(o[1]) << 16);
-    pk.y = f2bf(o[2]);
-    *reinterpret_cast<u32x2*>(out + (size_t)i * 4) = pk;
+    const uint32_t h0 = f2bf(o[0]), h1 = f2bf(o[1]), h2 = f2bf(o[2]);
+    if (!split) {
+      u32x2 pk;
+      pk.x = h0 | (h1 << 16);
+      pk.y = h2;
+      *reinterpret_cast<u32x2*>(out + (size_t)i * 4) = pk;
+    } else {  // (hi | lo) pairs for the bf16x3 precision mode: lo = bf16(x - hi)
+      u32x4 pk;
+      pk.x = h0 | (h1 << 16);
+      pk.y = h2;
+      pk.z = f2bf(o[0] - bf2f(h0)) | (f2bf(o[1] - bf2f(h1)) << 16);
+      pk.w = f2bf(o[2] - bf2f(h2));
+      *reinterpret_cast<u32x4*>(out + (size_t)i * 8) = pk;
+    }
   }
 }
 
-int pt_launch_det_preprocess(const uint8_t* pages, int n, int h, int w, int nh, int nw, int flavour, bf16_t* out,
-                             hipStream_t s) {
+int pt_launch_det_preprocess(const uint8_t* pages, int n, int h, int w, int nh, int nw, int flavour, int split,
+                             bf16_t* out, hipStream_t s) {
   const long long total = (long long)n * nh * nw;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL(det_preprocess_kernel, dim3(blocks), dim3(256), 0, s, pages, n, h, w, nh, nw, flavour, out);
+  hipLaunchKernelGGL(det_preprocess_kernel, dim3(blocks), dim3(256), 0, s, pages, n, h, w, nh, nw, flavour, split, out);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
@@ -118,6 +128,51 @@ __device__ __forceinline__ uint32_t bfmax2(uint32_t a, uint32_t b) {
   const uint32_t lo = (bl > al) ? (b & 0xFFFFu) : (a & 0xFFFFu);
   const uint32_t hi = (bh > ah) ? (b & 0xFFFF0000u) : (a & 0xFFFF0000u);
   return lo | hi;
+}
+
+// split mode: pixels hold [hi(C) | lo(C)]; the max is taken on hi + lo and the winning PAIR is copied
+__global__ __launch_bounds__(256) void maxpool3x3s2_split_kernel(const bf16_t* __restrict__ in, int B, int H, int W,
+                                                                  int C, bf16_t* __restrict__ out) {
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int cg = C >> 3;
+  const long long total = (long long)B * Ho * Wo * cg;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cg);
+    long long t = i / cg;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    uint32_t bh[8], bl[8];
+    float bv[8];
+    bool first = true;
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = oy * 2 - 1 + dy;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ix = ox * 2 - 1 + dx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const bf16_t* px = in + (((size_t)b * H + iy) * W + ix) * (2 * C) + g * 8;
+        const u32x4 vh = *reinterpret_cast<const u32x4*>(px);
+        const u32x4 vl = *reinterpret_cast<const u32x4*>(px + C);
+        const uint32_t hw[4] = {vh.x, vh.y, vh.z, vh.w}, lw[4] = {vl.x, vl.y, vl.z, vl.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t hb = (k & 1) ? (hw[k >> 1] >> 16) : (hw[k >> 1] & 0xFFFFu);
+          const uint32_t lb = (k & 1) ? (lw[k >> 1] >> 16) : (lw[k >> 1] & 0xFFFFu);
+          const float v = bf2f(hb) + bf2f(lb);
+          if (first || v > bv[k]) { bv[k] = v; bh[k] = hb; bl[k] = lb; }
+        }
+        first = false;
+      }
+    }
+    u32x4 oh, ol;
+    oh.x = bh[0] | (bh[1] << 16); oh.y = bh[2] | (bh[3] << 16); oh.z = bh[4] | (bh[5] << 16); oh.w = bh[6] | (bh[7] << 16);
+    ol.x = bl[0] | (bl[1] << 16); ol.y = bl[2] | (bl[3] << 16); ol.z = bl[4] | (bl[5] << 16); ol.w = bl[6] | (bl[7] << 16);
+    bf16_t* po = out + (((size_t)b * Ho + oy) * Wo + ox) * (2 * C) + g * 8;
+    *reinterpret_cast<u32x4*>(po) = oh;
+    *reinterpret_cast<u32x4*>(po + C) = ol;
+  }
 }
 
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const bf16_t* __restrict__ in, int B, int H, int W, int C,
@@ -155,13 +210,16 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const bf16_t* __restr
   }
 }
 
-int pt_launch_maxpool3x3s2(const bf16_t* in, int B, int H, int W, int C, bf16_t* out, hipStream_t s) {
+int pt_launch_maxpool3x3s2(const bf16_t* in, int B, int H, int W, int C, bf16_t* out, int split, hipStream_t s) {
   PT_REQUIRE(C % 8 == 0, "maxpool: C must be a multiple of 8");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const long long total = (long long)B * Ho * Wo * (C / 8);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(blocks), dim3(256), 0, s, in, B, H, W, C, out);
+  if (split)
+    hipLaunchKernelGGL(maxpool3x3s2_split_kernel, dim3(blocks), dim3(256), 0, s, in, B, H, W, C, out);
+  else
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(blocks), dim3(256), 0, s, in, B, H, W, C, out);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
@@ -219,12 +277,65 @@ __global__ __launch_bounds__(256) void db_head_final_kernel(const bf16_t* __rest
   }
 }
 
-int pt_launch_db_head_final(const bf16_t* in, int B, int H, int W, const bf16_t* w4x64, const float* bias, float* prob,
-                            float* logits, hipStream_t s) {
+// bf16x3 precision mode: in [B,H,W,128] = (hi | lo), weights fp32 [4][64]
+__global__ __launch_bounds__(256) void db_head_final_split_kernel(const bf16_t* __restrict__ in, int B, int H, int W,
+                                                                   const float* __restrict__ w4x64,
+                                                                   const float* __restrict__ bias_p,
+                                                                   float* __restrict__ prob, float* __restrict__ logits) {
+  const int sub = threadIdx.x & 7;
+  const float bias = bias_p[0];
+  float wq[4][8];
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wq[qd][k] = w4x64[qd * 64 + sub * 8 + k];
+  const long long npix = (long long)B * H * W;
+  const long long gstride = ((long long)gridDim.x * blockDim.x) >> 3;
+  for (long long pix = (((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3); pix < npix; pix += gstride) {
+    const u32x4 xh = *reinterpret_cast<const u32x4*>(in + (size_t)pix * 128 + sub * 8);
+    const u32x4 xl = *reinterpret_cast<const u32x4*>(in + (size_t)pix * 128 + 64 + sub * 8);
+    float x[8] = {bf2f(xh.x & 0xFFFFu) + bf2f(xl.x & 0xFFFFu), bf2f(xh.x >> 16) + bf2f(xl.x >> 16),
+                  bf2f(xh.y & 0xFFFFu) + bf2f(xl.y & 0xFFFFu), bf2f(xh.y >> 16) + bf2f(xl.y >> 16),
+                  bf2f(xh.z & 0xFFFFu) + bf2f(xl.z & 0xFFFFu), bf2f(xh.z >> 16) + bf2f(xl.z >> 16),
+                  bf2f(xh.w & 0xFFFFu) + bf2f(xl.w & 0xFFFFu), bf2f(xh.w >> 16) + bf2f(xl.w >> 16)};
+    float acc[4];
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a = fmaf(x[k], wq[qd][k], a);
+      acc[qd] = a;
+    }
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      acc[qd] += __shfl_xor(acc[qd], 1);
+      acc[qd] += __shfl_xor(acc[qd], 2);
+      acc[qd] += __shfl_xor(acc[qd], 4);
+    }
+    if (sub < 4) {
+      const float lg = (sub == 0 ? acc[0] : sub == 1 ? acc[1] : sub == 2 ? acc[2] : acc[3]) + bias;
+      const int xx = (int)(pix % W);
+      const long long t = pix / W;
+      const int yy = (int)(t % H);
+      const int b = (int)(t / H);
+      const size_t o = ((size_t)b * (2 * H) + 2 * yy + (sub >> 1)) * (size_t)(2 * W) + 2 * xx + (sub & 1);
+      if (logits) logits[o] = lg;
+      if (prob) prob[o] = 1.f / (1.f + expf(-lg));
+    }
+  }
+}
+
+int pt_launch_db_head_final(const bf16_t* in, int B, int H, int W, const void* w4x64, const float* bias, float* prob,
+                            float* logits, int split, hipStream_t s) {
   const long long nthreads = (long long)B * H * W * 8;
   int blocks = (int)((nthreads + 255) / 256);
   if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL(db_head_final_kernel, dim3(blocks), dim3(256), 0, s, in, B, H, W, w4x64, bias, prob, logits);
+  if (split)
+    hipLaunchKernelGGL(db_head_final_split_kernel, dim3(blocks), dim3(256), 0, s, in, B, H, W,
+                       reinterpret_cast<const float*>(w4x64), bias, prob, logits);
+  else
+    hipLaunchKernelGGL(db_head_final_kernel, dim3(blocks), dim3(256), 0, s, in, B, H, W,
+                       reinterpret_cast<const bf16_t*>(w4x64), bias, prob, logits);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }

@@ -31,6 +31,12 @@ class HipEngine:
         L.check(self.lib.pt_engine_create(self.device, C.byref(h)), "pt_engine_create")
         self._h = h
         self._tdev = torch.device("cuda", self.device)
+        self.precision = L.PT_PRECISION_BF16
+
+    def set_precision(self, precision: int):
+        """L.PT_PRECISION_BF16 (throughput) or L.PT_PRECISION_BF16X3 (fp32-class parity mode)."""
+        L.check(self.lib.pt_engine_set_precision(self._h, int(precision)), "pt_engine_set_precision")
+        self.precision = int(precision)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -88,16 +94,17 @@ class HipEngine:
         self._chk(pages, torch.uint8, "pages")
         n, h, w, _ = pages.shape
         nh, nw = self.det_plan(h, w, flavour)
-        out = torch.empty((n, nh, nw, 4), dtype=torch.bfloat16, device=self._tdev)
+        out = torch.empty((n, nh, nw, 8 if self.precision == L.PT_PRECISION_BF16X3 else 4), dtype=torch.bfloat16,
+                          device=self._tdev)
         L.check(self.lib.pt_det_preprocess(self._h, _ptr(pages), n, h, w, flavour, _ptr(out), self._stream()),
                 "pt_det_preprocess")
         return out
 
     def det_forward_net(self, x: torch.Tensor, want_logits: bool = False):
-        """x bf16 NHWC4 [n,H,W,4] -> prob f32 [n,H,W] (and logits)."""
+        """x bf16 NHWC4 [n,H,W,4] (BF16X3 mode: [n,H,W,8] = hi rgb0 | lo rgb0) -> prob f32 [n,H,W] (and logits)."""
         self._chk(x, torch.bfloat16, "x")
         n, H, W, c = x.shape
-        assert c == 4
+        assert c == (8 if self.precision == L.PT_PRECISION_BF16X3 else 4)
         prob = torch.empty((n, H, W), dtype=torch.float32, device=self._tdev)
         logits = torch.empty((n, H, W), dtype=torch.float32, device=self._tdev) if want_logits else None
         L.check(self.lib.pt_det_forward_net(self._h, _ptr(x), n, H, W, _ptr(prob), _ptr(logits), self._stream()),
@@ -126,23 +133,52 @@ class HipEngine:
 
     def op_conv2d(self, x: torch.Tensor, w_tiled: torch.Tensor, bias: torch.Tensor, ks: int, stride: int = 1,
                   relu: bool = False, res: Optional[torch.Tensor] = None, res_mode: int = 0, rep: int = 1,
-                  shuffle_cout: int = 0, out: Optional[torch.Tensor] = None, out_coff: int = 0) -> torch.Tensor:
+                  shuffle_cout: int = 0, out: Optional[torch.Tensor] = None, out_coff: int = 0,
+                  split: bool = False) -> torch.Tensor:
         """Single conv on the MFMA kernel.  x bf16 [B,H,W,Cin]; w_tiled int16/bf16 bits; bias f32 [N]."""
         self._chk(x, torch.bfloat16, "x")
         self._chk(bias, torch.float32, "bias")
         B, H, W, Cin = x.shape
+        m = 2 if split else 1
+        Cin //= m
         N = bias.numel()
         pad = ks // 2
         Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
         if out is None:
             if shuffle_cout:
-                out = torch.empty((B, 2 * Ho, 2 * Wo, shuffle_cout), dtype=torch.bfloat16, device=self._tdev)
+                out = torch.empty((B, 2 * Ho, 2 * Wo, shuffle_cout * m), dtype=torch.bfloat16, device=self._tdev)
             else:
-                out = torch.empty((B, Ho * rep, Wo * rep, N), dtype=torch.bfloat16, device=self._tdev)
+                out = torch.empty((B, Ho * rep, Wo * rep, N * m), dtype=torch.bfloat16, device=self._tdev)
         L.check(self.lib.pt_op_conv2d(self._h, _ptr(x), B, H, W, Cin, _ptr(w_tiled), _ptr(bias), N, ks, stride,
                                       _ptr(out), out.shape[-1], out_coff, rep, shuffle_cout, _ptr(res), res_mode,
-                                      int(relu), self._stream()), "pt_op_conv2d")
+                                      int(relu), int(split), out.shape[-1] // 2, self._stream()), "pt_op_conv2d")
         return out
+
+    def op_stem7x7(self, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, split: bool = False) -> torch.Tensor:
+        self._chk(x, torch.bfloat16, "x")
+        B, H, W, _ = x.shape
+        out = torch.empty((B, H // 2, W // 2, 128 if split else 64), dtype=torch.bfloat16, device=self._tdev)
+        L.check(self.lib.pt_op_stem7x7(self._h, _ptr(x), B, H, W, _ptr(w), _ptr(bias), _ptr(out), int(split), self._stream()),
+                "pt_op_stem7x7")
+        return out
+
+    def op_maxpool3x3s2(self, x: torch.Tensor, split: bool = False) -> torch.Tensor:
+        self._chk(x, torch.bfloat16, "x")
+        B, H, W, Cc = x.shape
+        out = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), dtype=torch.bfloat16, device=self._tdev)
+        L.check(self.lib.pt_op_maxpool3x3s2(self._h, _ptr(x), B, H, W, Cc // 2 if split else Cc, _ptr(out), int(split),
+                                            self._stream()),
+                "pt_op_maxpool3x3s2")
+        return out
+
+    def op_db_head_final(self, x: torch.Tensor, w4x64: torch.Tensor, bias: torch.Tensor, split: bool = False):
+        self._chk(x, torch.bfloat16, "x")
+        B, H, W, _ = x.shape
+        prob = torch.empty((B, 2 * H, 2 * W), dtype=torch.float32, device=self._tdev)
+        logits = torch.empty((B, 2 * H, 2 * W), dtype=torch.float32, device=self._tdev)
+        L.check(self.lib.pt_op_db_head_final(self._h, _ptr(x), B, H, W, _ptr(w4x64), _ptr(bias), _ptr(prob),
+                                             _ptr(logits), int(split), self._stream()), "pt_op_db_head_final")
+        return prob, logits
 
     # ---- profiling ---------------------------------------------------------------------------------
     def profile_enable(self, on: bool = True):

@@ -17,6 +17,8 @@ PT_MODEL_CRNN = 2
 PT_DET_PRE_DB_PP = 0
 PT_DET_PRE_DB_TORCH = 1
 PT_DET_PRE_NONE = 2
+PT_PRECISION_BF16 = 0
+PT_PRECISION_BF16X3 = 1
 PT_DET_POST_DB_PP = 0
 PT_DET_POST_DB_TORCH = 1
 PT_PROF_CLASSES = ("conv3x3", "conv1x1", "stem", "other")
@@ -36,6 +38,7 @@ def _proto(lib):
         "pt_engine_destroy": (None, [vp]),
         "pt_last_error": (C.c_char_p, []),
         "pt_abi_version": (i, []),
+        "pt_engine_set_precision": (i, [vp, i]),
         "pt_weights_load": (i, [vp, i, vp, sz]),
         "pt_weights_load_device": (i, [vp, i, vp, sz, vp]),
         "pt_det_plan": (i, [i, i, i, ip, ip]),
@@ -46,7 +49,10 @@ def _proto(lib):
         "pt_det_box_scores": (i, [vp, vp, i, i, i, vp, i, vp, vp]),
         "pt_db_candidates": (i, [vp, i, i, i, f, vp, vp, i, ip]),
         "pt_db_finalize": (i, [vp, vp, i, f, f, f, i, i, i, i, i, vp, vp, i, ip]),
-        "pt_op_conv2d": (i, [vp, vp, i, i, i, i, vp, vp, i, i, i, vp, i, i, i, i, vp, i, i, vp]),
+        "pt_op_conv2d": (i, [vp, vp, i, i, i, i, vp, vp, i, i, i, vp, i, i, i, i, vp, i, i, i, i, vp]),
+        "pt_op_stem7x7": (i, [vp, vp, i, i, i, vp, vp, vp, i, vp]),
+        "pt_op_maxpool3x3s2": (i, [vp, vp, i, i, i, i, vp, i, vp]),
+        "pt_op_db_head_final": (i, [vp, vp, i, i, i, vp, vp, vp, vp, i, vp]),
         "pt_profile_enable": (i, [vp, i]),
         "pt_profile_read": (i, [vp, vp, vp, vp]),
     }

@@ -59,9 +59,24 @@ def tile_conv_weight(w: torch.Tensor) -> np.ndarray:
     return to_bf16_bits(t).reshape(n // 64, cin // 32, kh * kw, 64, 32)
 
 
+def split_bf16(t: torch.Tensor):
+    """fp32 -> (hi, lo) with hi = bf16(t), lo = bf16(t - hi), both returned as fp32 tensors."""
+    hi = t.to(torch.bfloat16).to(torch.float32)
+    lo = (t - hi).to(torch.bfloat16).to(torch.float32)
+    return hi, lo
+
+
+def tile_conv_weight_x3(w: torch.Tensor) -> np.ndarray:
+    """BF16X3 tiles: K chunks are [w_hi (for x_hi) | w_hi (for x_lo) | w_lo (for x_hi)] -> [N/64][3*Cin/32][taps][64][32]."""
+    hi, lo = split_bf16(w)
+    th, tl = tile_conv_weight(hi), tile_conv_weight(lo)
+    return np.concatenate([th, th, tl], axis=1)
+
+
 class _Blob:
-    def __init__(self):
+    def __init__(self, x3: bool = True):
         self.items: "OrderedDict[str, Tuple[int, np.ndarray]]" = OrderedDict()
+        self.x3 = x3   # also emit the (hi, lo) tiles of the BF16X3 precision mode
 
     def add(self, name: str, arr: np.ndarray, dtype: str):
         assert len(name) < 96 and arr.ndim <= 6
@@ -69,6 +84,8 @@ class _Blob:
 
     def add_conv(self, name: str, w: torch.Tensor, b: torch.Tensor):
         self.add(name + ".w", tile_conv_weight(w), "bf16")
+        if self.x3:
+            self.add(name + ".w3", tile_conv_weight_x3(w), "bf16")
         self.add(name + ".b", b.numpy().astype(np.float32), "f32")
 
     def tobytes(self) -> bytes:
@@ -97,14 +114,18 @@ def write_blob(items) -> bytes:
     return bytes(out)
 
 
-def pack_db_resnet18(sd: Dict[str, torch.Tensor]) -> bytes:
-    """``DBModel`` state_dict (db_net/dbnet.py:715-728) -> blob for PT_MODEL_DB_RESNET18."""
-    bl = _Blob()
+def pack_db_resnet18(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
+    """``DBModel`` state_dict (db_net/dbnet.py:715-728) -> blob for PT_MODEL_DB_RESNET18.
+    ``x3``: also pack the (hi, lo) weight tiles that PT_PRECISION_BF16X3 uses (3x the conv weight bytes)."""
+    bl = _Blob(x3)
     # stem: [64,3,7,7] -> [64][r=7][s=8][c=4], tap s=7 / channel c=3 are zero
     w, b = fold_conv_bn(sd, "backbone.conv1", "backbone.bn1")
     stem = torch.zeros(64, 7, 8, 4)
     stem[:, :, :7, :3] = w.permute(0, 2, 3, 1)
     bl.add("stem.w", to_bf16_bits(stem).reshape(64, 224), "bf16")
+    if x3:
+        sh, sl = split_bf16(stem)
+        bl.add("stem.w3", np.stack([to_bf16_bits(sh).reshape(64, 224), to_bf16_bits(sl).reshape(64, 224)]), "bf16")
     bl.add("stem.b", b.numpy(), "f32")
     for li in range(1, 5):
         for bi in range(2):
@@ -125,6 +146,7 @@ def pack_db_resnet18(sd: Dict[str, torch.Tensor]) -> bytes:
     bl.add_conv("bin3", wn, bt.repeat(4))
     w6, b6 = fold_conv_bn(sd, "decoder.binarize.6", None, transposed=True)  # [64, 1, 2, 2]
     bl.add("bin6.w", to_bf16_bits(w6[:, 0].permute(1, 2, 0).reshape(4, 64)), "bf16")
+    bl.add("bin6.wf32", w6[:, 0].permute(1, 2, 0).reshape(4, 64).contiguous().numpy().astype(np.float32), "f32")
     bl.add("bin6.b", b6.numpy().reshape(1), "f32")
     return bl.tobytes()
 
