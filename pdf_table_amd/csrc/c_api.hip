@@ -241,7 +241,7 @@ int pt_det_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h, int w
   for (int i0 = 0; i0 < n; i0 += mb) {
     const int nb = (n - i0) < mb ? (n - i0) : mb;
     {
-      PtProfScope ps(e, s, PT_PROF_OTHER, 0);
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0, "preprocess");
       rc = pt_launch_det_preprocess(d_pages_rgb + (size_t)i0 * h * w * 3, nb, h, w, nh, nw, pre_flavour, x3,
                                     reinterpret_cast<bf16_t*>(xbuf), s);
       if (rc != PT_OK) return rc;
@@ -250,7 +250,7 @@ int pt_det_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h, int w
     rc = pt_db_forward_net(e, reinterpret_cast<const bf16_t*>(xbuf), nb, nh, nw, prob_i, nullptr, s);
     if (rc != PT_OK) return rc;
     if (d_bitmap) {
-      PtProfScope ps(e, s, PT_PROF_OTHER, 0);
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0, "bitmap");
       rc = pt_launch_bitmap(prob_i, nb, nh, nw, thresh, use_dilation, d_bitmap + (size_t)i0 * nh * (nw / 32), s);
       if (rc != PT_OK) return rc;
     }
@@ -305,9 +305,12 @@ int pt_profile_enable(pt_engine* e, int on) {
 int pt_profile_read(pt_engine* e, double* ms_per_class, long long* launches_per_class, double* flop_per_class) {
   PT_REQUIRE(e != nullptr, "pt_profile_read: null engine");
   PT_HIP_CHECK(hipDeviceSynchronize());
+  const bool verbose = getenv("PT_PROF_VERBOSE") != nullptr;
+  std::map<std::string, std::pair<double, int>> by_label;
   for (auto& p : e->prof.pending) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      if (verbose) { auto& r = by_label[p.label]; r.first += ms; r.second += 1; }
       e->prof.ms[p.cls] += ms;
       e->prof.launches[p.cls] += 1;
       e->prof.flop[p.cls] += p.flop;
@@ -316,6 +319,10 @@ int pt_profile_read(pt_engine* e, double* ms_per_class, long long* launches_per_
     (void)hipEventDestroy(p.b);
   }
   e->prof.pending.clear();
+  if (verbose)
+    for (auto& kv : by_label)
+      fprintf(stderr, "[pt_prof] %-40s n=%5d total=%9.3f ms avg=%8.4f ms\n", kv.first.c_str(), kv.second.second, kv.second.first,
+              kv.second.first / kv.second.second);
   for (int i = 0; i < PT_PROF_NCLASS; ++i) {
     if (ms_per_class) ms_per_class[i] = e->prof.ms[i];
     if (launches_per_class) launches_per_class[i] = e->prof.launches[i];

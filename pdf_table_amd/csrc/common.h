@@ -83,6 +83,7 @@ struct PtProfile {
     hipEvent_t a, b;
     int cls;
     double flop;
+    char label[48];
   };
   std::vector<Pending> pending;
 };
@@ -149,12 +150,14 @@ struct PtProfScope {
   pt_engine* e;
   hipStream_t s;
   int idx = -1;
-  PtProfScope(pt_engine* e_, hipStream_t s_, int cls, double flop) : e(e_), s(s_) {
+  PtProfScope(pt_engine* e_, hipStream_t s_, int cls, double flop, const char* label = "") : e(e_), s(s_) {
     if (e && e->prof.on) {
       PtProfile::Pending p;
       if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
       p.cls = cls;
       p.flop = flop;
+      strncpy(p.label, label, sizeof(p.label) - 1);
+      p.label[sizeof(p.label) - 1] = 0;
       (void)hipEventRecord(p.a, s);
       e->prof.pending.push_back(p);
       idx = (int)e->prof.pending.size() - 1;

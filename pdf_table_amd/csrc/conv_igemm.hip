@@ -20,6 +20,8 @@
 //     all 16-byte, channel-contiguous accesses
 //   * blockIdx -> tile mapping is XCD-aware: consecutive logical tiles (all N-tiles of a patch, then
 //     the neighbouring patch) stay on one XCD so the halo and the weights hit that XCD's L2.
+#include <stdio.h>
+
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -397,7 +399,9 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   k.n_tiles = k.N / 64;
   const long long nblk = (long long)k.B * k.tiles_x * k.tiles_y * k.n_tiles;
   PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range (%lld blocks)", nblk);
-  PtProfScope prof(e, s, KS == 3 ? PT_PROF_CONV3X3 : PT_PROF_CONV1X1, flop);
+  char label[48];
+  snprintf(label, sizeof(label), "conv%dx%d s%d %d->%d @%dx%d%s", KS, KS, STRIDE, k.Cin, k.N, k.Ho, k.Wo, k.split ? " x3" : "");
+  PtProfScope prof(e, s, KS == 3 ? PT_PROF_CONV3X3 : PT_PROF_CONV1X1, flop, label);
   hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
@@ -449,7 +453,7 @@ int pt_launch_stem7x7(pt_engine* e, const bf16_t* in, int B, int H, int W, const
   k.tiles_x = (k.Wo + 31) / 32; k.tiles_y = (k.Ho + 7) / 8; k.n_tiles = 1;
   const long long nblk = (long long)B * k.tiles_x * k.tiles_y;
   PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "stem grid out of range");
-  PtProfScope prof(e, s, PT_PROF_STEM, 2.0 * B * k.Ho * k.Wo * 64.0 * 147.0);
+  PtProfScope prof(e, s, PT_PROF_STEM, 2.0 * B * k.Ho * k.Wo * 64.0 * 147.0, "stem7x7");
   hipLaunchKernelGGL(conv_stem7x7_kernel, dim3((unsigned)nblk), dim3(256), StemCfg::SMEM, s, k);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;

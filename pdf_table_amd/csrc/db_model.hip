@@ -131,7 +131,7 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
   };
   RUN(pt_launch_stem7x7(e, x, n, H, W_, W(w.stem_w), Bv(w.stem_b), bf.s, x3, s));
   {
-    PtProfScope ps(e, s, PT_PROF_OTHER, 0);
+    PtProfScope ps(e, s, PT_PROF_OTHER, 0, "maxpool");
     RUN(pt_launch_maxpool3x3s2(bf.s, n, H / 2, W_ / 2, 64, bf.p, x3, s));
   }
   const bf16_t* cur = bf.p;
@@ -180,7 +180,7 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
     RUN(pt_launch_conv(e, c, s));
   }
   {
-    PtProfScope ps(e, s, PT_PROF_OTHER, 0);
+    PtProfScope ps(e, s, PT_PROF_OTHER, 0, "head_final");
     RUN(pt_launch_db_head_final(bf.y1, n, H / 2, W_ / 2, w.bin6_w->d_ptr, Bv(w.bin6_b), prob, logits, x3, s));
   }
 #undef RUN
