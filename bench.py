@@ -43,19 +43,30 @@ def cpu_baseline(sd, pages_np, cfg):
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     n = len(pages_np)
-    t0 = time.time()
+    with torch.no_grad():   # one un-timed warm-up forward (thread pool start-up, oneDNN primitive cache)
+        db_net.db_forward_fp32(sd, torch.zeros(1, 3, 960, 960))
+    t_pre = t_net = t_post = 0.0
     nboxes = 0
     for img in pages_np:
+        t0 = time.time()
         chw, shape_list = db_pre.preprocess_db_pp(img)
+        t1 = time.time()
         with torch.no_grad():
             prob = db_net.db_forward_fp32(sd, torch.from_numpy(np.ascontiguousarray(chw))[None])[0, 0].numpy()
+        t2 = time.time()
         boxes = db_post.db_postprocess(prob, shape_list, img.shape, cfg.thresh, cfg.box_thresh, cfg.unclip_ratio,
                                        cfg.use_dilation, cfg.max_candidates)
+        t3 = time.time()
+        t_pre += t1 - t0
+        t_net += t2 - t1
+        t_post += t3 - t2
         nboxes += len(boxes)
-    dt = time.time() - t0
+    dt = t_pre + t_net + t_post
     return {"value": n / dt, "unit": "pages/s", "cores": cores, "kind": "port",
-            "sample": f"{n} synthetic 1024x1024 pages, DB det stage (pre + DB-ResNet18 fp32 + post), batch 1, "
-                      f"torch.set_num_threads({cores}); {dt:.1f} s"}
+            "sample": f"{n} synthetic 1024x1024 pages, DB det stage, batch 1 per call as the reference runs it, "
+                      f"torch.set_num_threads({cores}); per page: pre (numpy) {t_pre / n:.2f} s, DB-ResNet18 fp32 "
+                      f"(torch CPU) {t_net / n:.2f} s, post (pure-Python restatement of cv2/pyclipper) {t_post / n:.2f} s",
+            "net_only_pages_per_s": n / t_net}
 
 
 def main():
@@ -91,20 +102,16 @@ def main():
     # weights: packed once on rank 0, broadcast over RCCL/xGMI, loaded from device memory everywhere
     sd = db_resnet18_state_dict(seed=0) if rank == 0 or world == 1 else None
     if world > 1:
-        if rank == 0:
-            blob = torch.frombuffer(bytearray(pack_db_resnet18(sd)), dtype=torch.uint8).to(dev)
-            size = torch.tensor([blob.numel()], dtype=torch.int64, device=dev)
-        else:
-            size = torch.zeros(1, dtype=torch.int64, device=dev)
-        dist.broadcast(size, 0)
-        if rank != 0:
-            blob = torch.empty(int(size.item()), dtype=torch.uint8, device=dev)
-        dist.broadcast(blob, 0)
+        from pdf_table_amd.dist_utils import broadcast_blob
+        blob = broadcast_blob(pack_db_resnet18(sd, x3=False) if rank == 0 else None, dev)
         eng.load_weights_device(L.PT_MODEL_DB_RESNET18, blob)
     else:
-        eng.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(sd))
+        eng.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(sd, x3=False))
 
-    # pages: rank r owns pages [r*P, (r+1)*P) of the global batch (static contiguous shard)
+    # pages: rank r owns pages [r*P, (r+1)*P) of the global batch (static contiguous shard, dist_utils.shard_range)
+    from pdf_table_amd.dist_utils import shard_range
+    lo, hi = shard_range(world * PAGES_PER_STEP, rank, world)
+    assert hi - lo == PAGES_PER_STEP
     base = [make_page(rank * DISTINCT + i, PAGE)[0] for i in range(DISTINCT)]
     pages_np = np.stack([base[i % DISTINCT] for i in range(PAGES_PER_STEP)])
     pages = torch.from_numpy(pages_np).to(dev)
@@ -154,9 +161,17 @@ def main():
         value = total_pages / dt
         c3 = prof["conv3x3"]
         achieved = (c3["flop"] / (c3["ms"] * 1e-3)) / 1e12 if c3["ms"] > 0 else 0.0
+        traffic = None
+        try:   # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_summary.py)
+            with open(os.path.join(REPO, "profiles", "pmc_latest.json")) as f:
+                traffic = json.load(f)["void conv_igemm_kernel<3, 1>"]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<3,*> (3x3 implicit-GEMM convs of DB-ResNet18)",
                 "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
-                "traffic": None, "launches": c3["launches"], "avg_launch_ms": c3["ms"] / max(1, c3["launches"]),
+                "traffic": traffic, "traffic_note": "bytes/launch, conv_igemm_kernel<3,1>, PMC passes of profiles/pmc_latest.json "
+                                                    "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
+                "launches": c3["launches"], "avg_launch_ms": c3["ms"] / max(1, c3["launches"]),
                 "algorithmic_flop_per_launch": c3["flop"] / max(1, c3["launches"]),
                 "all_kernel_classes_ms": {k: v["ms"] for k, v in prof.items()},
                 "net_tflops_on_111.71_gflop_per_page": DB_GFLOP_960e9_per_page(total_pages, prof)}

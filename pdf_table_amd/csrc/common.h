@@ -121,6 +121,11 @@ struct ConvDesc {
   // bf16x3 precision mode: in/res/out hold (hi | lo) channel groups; w is [N/64][3*Cin/32][taps][64][32]
   int split = 0;
   int out_lo_off = 0;  // channel distance between the hi and lo halves in the output buffer
+  // fused DB head: see ConvK in conv_igemm.hip (requires shuffle_cout == 64)
+  const void* head_w = nullptr;
+  const float* head_b = nullptr;
+  float* head_prob = nullptr;
+  float* head_logits = nullptr;
 };
 int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s);
 

@@ -42,6 +42,13 @@ struct ConvK {
   // bf16x3 ("split") precision mode: every activation is a (hi, lo) bf16 pair stored as two channel groups
   // [hi(C) | lo(C)]; K runs over (x_hi, w_hi), (x_lo, w_hi), (x_hi, w_lo); out_lo_off = channel distance hi -> lo
   int split, out_lo_off;
+  // fused DB head (dbnet.py:537-539): this conv is ConvTranspose2d(64,64,2,2)+BN+ReLU as a pixel-shuffle GEMM and
+  // the epilogue applies the last ConvTranspose2d(64->1,2,2) + Sigmoid on the rounded activations, so the
+  // 64-channel 1/2-resolution tensor never goes to HBM.  head_w: [4][64] bf16 (fp32 in split mode).
+  const void* head_w;
+  const float* head_b;
+  float* head_prob;
+  float* head_logits;
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
@@ -63,6 +70,24 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
 template <int TH>
 __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stage, int tid, int b, int oy0, int ox0,
                                                int n0) {
+  // fused-head weights of this thread's 8 channels (idx & 7 == tid & 7 for every j)
+  float hw[4][8];
+  if (p.head_w) {
+    const int cgw = tid & 7;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      if (p.split) {
+        const float* wf = reinterpret_cast<const float*>(p.head_w) + qd * 64 + cgw * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) hw[qd][k] = wf[k];
+      } else {
+        const u32x4 wv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.head_w) + qd * 64 + cgw * 8);
+        const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) hw[qd][k] = bf16_to_f32((k & 1) ? (ww[k >> 1] >> 16) : (ww[k >> 1] & 0xFFFFu));
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < TH; ++j) {
     const int idx = tid + j * 256;
@@ -111,7 +136,31 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
       for (int k = 0; k < 8; ++k) lb[k] = f32_to_bf16(v[k] - bf16_to_f32(hb[k]));
       ol.x = lb[0] | (lb[1] << 16); ol.y = lb[2] | (lb[3] << 16); ol.z = lb[4] | (lb[5] << 16); ol.w = lb[6] | (lb[7] << 16);
     }
-    if (p.shuffle_cout) {
+    if (p.head_w) {
+      // 8 consecutive lanes hold the 64 channels of one output pixel of quadrant `quad` (n0 == quad * 64)
+      float xs[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) xs[k] = p.split ? v[k] : bf16_to_f32(hb[k]);
+      float acc4[4];
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a = fmaf(xs[k], hw[qd][k], a);
+        a += __shfl_xor(a, 1);
+        a += __shfl_xor(a, 2);
+        a += __shfl_xor(a, 4);
+        acc4[qd] = a;
+      }
+      if (cg < 4) {
+        const int quad = n0 >> 6;
+        const float lg = (cg == 0 ? acc4[0] : cg == 1 ? acc4[1] : cg == 2 ? acc4[2] : acc4[3]) + p.head_b[0];
+        const int Y = 2 * oy + (quad >> 1), X = 2 * ox + (quad & 1);
+        const size_t o = ((size_t)b * (4 * p.Ho) + 2 * Y + (cg >> 1)) * (size_t)(4 * p.Wo) + 2 * X + (cg & 1);
+        if (p.head_logits) p.head_logits[o] = lg;
+        if (p.head_prob) p.head_prob[o] = 1.f / (1.f + expf(-lg));
+      }
+    } else if (p.shuffle_cout) {
       const int quad = n0 / p.shuffle_cout;
       const int co = n0 - quad * p.shuffle_cout + cg * 8;
       const int OH = p.Ho * 2, OW = p.Wo * 2;
@@ -134,7 +183,9 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
 template <int KS, int STRIDE>
 struct ConvCfg {
   static constexpr int TW = 32;
-  static constexpr int TH = (STRIDE == 1) ? 8 : 4;
+  // 3x3/s1: 8x32 patch (2 MFMA row-tiles per wave); 1x1 and stride-2: 4x32 (smaller LDS image -> more
+  // workgroups per CU, which is what the bandwidth-bound 1x1 layers need)
+  static constexpr int TH = (STRIDE == 1 && KS == 3) ? 8 : 4;
   static constexpr int MT = TH / 4;  // 1x32-pixel MFMA row-tiles per wave
   static constexpr int THIN = (TH - 1) * STRIDE + KS;
   static constexpr int TWIN = (TW - 1) * STRIDE + KS;
@@ -152,7 +203,7 @@ struct ConvCfg {
 };
 
 template <int KS, int STRIDE>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
+__global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_igemm_kernel(ConvK p) {
   using C = ConvCfg<KS, STRIDE>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_in = smem;
@@ -400,7 +451,7 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   const long long nblk = (long long)k.B * k.tiles_x * k.tiles_y * k.n_tiles;
   PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range (%lld blocks)", nblk);
   char label[48];
-  snprintf(label, sizeof(label), "conv%dx%d s%d %d->%d @%dx%d%s", KS, KS, STRIDE, k.Cin, k.N, k.Ho, k.Wo, k.split ? " x3" : "");
+  snprintf(label, sizeof(label), "conv%dx%d s%d %d->%d @%dx%d%s", KS, KS, STRIDE, k.Cin, k.N, k.Ho, k.Wo, k.head_w ? " +head" : (k.split ? " x3" : ""));
   PtProfScope prof(e, s, KS == 3 ? PT_PROF_CONV3X3 : PT_PROF_CONV1X1, flop, label);
   hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
   PT_HIP_CHECK(hipGetLastError());
@@ -408,7 +459,7 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
 }
 
 int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
-  PT_REQUIRE(d.in && d.w && d.bias && d.out, "conv: null pointer");
+  PT_REQUIRE(d.in && d.w && d.bias && (d.out || d.head_w), "conv: null pointer");
   PT_REQUIRE(d.Cin % 32 == 0 && d.Cin > 0, "conv: Cin=%d must be a positive multiple of 32", d.Cin);
   PT_REQUIRE(d.N % 64 == 0 && d.N > 0, "conv: N=%d must be a positive multiple of 64", d.N);
   PT_REQUIRE((d.ks == 1 || d.ks == 3) && (d.stride == 1 || d.stride == 2), "conv: ks=%d stride=%d unsupported", d.ks,
@@ -425,6 +476,8 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   k.out_cstride = d.out_cstride; k.out_coff = d.out_coff; k.rep = d.rep; k.shuffle_cout = d.shuffle_cout;
   k.res_mode = d.res ? d.res_mode : 0; k.relu = d.relu;
   k.split = d.split; k.out_lo_off = d.out_lo_off;
+  k.head_w = d.head_w; k.head_b = d.head_b; k.head_prob = d.head_prob; k.head_logits = d.head_logits;
+  if (d.head_w) PT_REQUIRE(d.shuffle_cout == 64 && d.head_b && (d.head_prob || d.head_logits), "conv: bad fused-head configuration");
   if (k.res_mode == 2) PT_REQUIRE(k.Ho % 2 == 0 && k.Wo % 2 == 0, "conv: half-res residual needs even output size");
   const double flop = 2.0 * k.B * k.Ho * k.Wo * (double)k.N * d.Cin * d.ks * d.ks;  // algorithmic (not x3 in split mode)
   if (d.ks == 3 && d.stride == 1) return launch_cfg<3, 1>(e, k, s, flop);

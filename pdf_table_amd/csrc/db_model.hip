@@ -175,13 +175,11 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
     RUN(pt_launch_conv(e, c, s));
   }
   {
+    // ConvTranspose2d(64,64,2,2)+BN+ReLU with the final ConvTranspose2d(64,1,2,2)+Sigmoid fused into its epilogue
     ConvDesc c = conv(bf.y0, H / 4, W_ / 4, 64, w.bin3_w, w.bin3_b, 256, 1, 1, bf.y1, 64, 1);
     c.shuffle_cout = 64;
+    c.head_w = w.bin6_w->d_ptr; c.head_b = Bv(w.bin6_b); c.head_prob = prob; c.head_logits = logits;
     RUN(pt_launch_conv(e, c, s));
-  }
-  {
-    PtProfScope ps(e, s, PT_PROF_OTHER, 0, "head_final");
-    RUN(pt_launch_db_head_final(bf.y1, n, H / 2, W_ / 2, w.bin6_w->d_ptr, Bv(w.bin6_b), prob, logits, x3, s));
   }
 #undef RUN
   return PT_OK;

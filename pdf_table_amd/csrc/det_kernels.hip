@@ -395,17 +395,19 @@ __device__ __forceinline__ bool on_bresenham(int px, int py, int x0, int y0, int
   const int dx = x1 - x0;
   const int dyabs = y1 >= y0 ? y1 - y0 : y0 - y1;
   const int sy = y1 >= y0 ? 1 : -1;
+  // minor-axis position after j major steps is floor((2*minor*j + major - 1) / (2*major)); the membership test
+  //   m == u  <=>  u*2*major <= 2*minor*j + major - 1 < (u+1)*2*major   needs no division (|coords| < 2^12)
   if (dyabs > dx) {  // y-major
-    const int j = (py - y0) * sy;
-    if (j < 0 || j > dyabs) return false;
-    const int m = (int)((2ll * dx * j + dyabs - 1) / (2ll * dyabs));
-    return px == x0 + m;
+    const int j = (py - y0) * sy, u = px - x0;
+    if (j < 0 || j > dyabs || u < 0) return false;
+    const int num = 2 * dx * j + dyabs - 1;
+    return u * 2 * dyabs <= num && num < (u + 1) * 2 * dyabs;
   }
   if (dx == 0) return px == x0 && py == y0;  // single point
-  const int j = px - x0;
-  if (j < 0 || j > dx) return false;
-  const int m = (int)((2ll * dyabs * j + dx - 1) / (2ll * dx));
-  return py == y0 + sy * m;
+  const int j = px - x0, u = (py - y0) * sy;
+  if (j < 0 || j > dx || u < 0) return false;
+  const int num = 2 * dyabs * j + dx - 1;
+  return u * 2 * dx <= num && num < (u + 1) * 2 * dx;
 }
 
 __global__ __launch_bounds__(64) void box_score_kernel(const float* __restrict__ prob, int n, int H, int W,
