@@ -123,6 +123,38 @@ int pt_db_finalize(const float* h_boxes, const float* h_scores, int nb, float bo
 #define PT_DET_POST_DB_PP 0    /* float32 box / W * dest, round, clip, astype(int16): processor_ocr_db_pp.py:211-217 */
 #define PT_DET_POST_DB_TORCH 1 /* box.astype(int32) first, then the same in float64: ocr_detection_utils.py:198-206 */
 
+/* ---- stage 3: text-line recognition (CRNN) -------------------------------------------------------- */
+#define PT_REC_H 32     /* OCRRecognitionConfig.img_height                                        */
+#define PT_REC_W 640    /* img_width for CRNN (configuration_ocr_document.py:47-48)                */
+#define PT_REC_T 160    /* time steps = W / 4 (crnn/modeling_crnn.py: two 2x2 pools)               */
+#define PT_REC_NCLS 7644 /* crnn/modeling_crnn.py:90                                               */
+
+/* One text line to cut out of a page: the INVERSE perspective matrix (row-major 3x3, destination -> source, what
+ * cv2.warpPerspective evaluates) of OcrCommonUtils.crop_image (utils/ocr/ocr_common_utils.py:214-266) and the
+ * crop size int(img_width) x int(img_height) computed there. */
+typedef struct pt_rec_line {
+  double minv[9];
+  int32_t page;
+  int32_t crop_w;
+  int32_t crop_h;
+  int32_t reserved;
+} pt_rec_line;
+
+/* Recognise n_lines text lines cut from n_pages pages (uint8 [n_pages,h,w,3] RGB, on the GPU).
+ *   d_lines   : device array of pt_rec_line;  h_crop_px: HOST array [n_lines] of crop_w*crop_h (sizes the crop
+ *               scratch without a device round trip)
+ *   d_ids     : int32 [n_lines, PT_REC_T] arg-max class per time step (0 = CTC blank); collapse on the host
+ *   d_maxlogit: float [n_lines, PT_REC_T] the winning logit (may be NULL)
+ * Replaces the per-line loop OcrSystemTask.text_recognition -> crop_image -> OcrRecognitionTask
+ * (ocr_system_task.py:296-336, ocr_recognition_task.py:81-136) and the arg-max of OCRRecognition.postprocess. */
+int pt_rec_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int h, int w, const pt_rec_line* d_lines,
+                   const int64_t* h_crop_px, int n_lines, int32_t* d_ids, float* d_maxlogit, pt_stream stream);
+/* Network only: d_gray bf16 [n, 32, 640] (BF16X3 mode: [n, 32, 640, 2] = hi, lo), values in [0, 1]. */
+int pt_rec_forward_net(pt_engine* e, const uint16_t* d_gray, int n, int32_t* d_ids, float* d_maxlogit, pt_stream stream);
+/* Crop + resize + gray only (tests): writes d_gray as above. */
+int pt_rec_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int h, int w, const pt_rec_line* d_lines,
+                      const int64_t* h_crop_px, int n_lines, uint16_t* d_gray, pt_stream stream);
+
 /* ---- single operator (parity tests of the conv kernel variants) --------------------------------- */
 /* NHWC bf16 convolution on the MFMA implicit-GEMM kernel. d_w_tiled is [N/64][Cin/32][ks*ks][64][32] bf16
  * (pdf_table_amd/weights.py:tile_conv_weight), d_bias fp32 [N]. ks in {1,3} (pad ks/2), stride in {1,2}.

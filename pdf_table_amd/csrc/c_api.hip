@@ -50,6 +50,9 @@ void pt_engine_destroy(pt_engine* e) {
   for (auto& kv : e->models)
     if (kv.second.d_blob) (void)hipFree(kv.second.d_blob);
   if (e->arena.base) (void)hipFree(e->arena.base);
+  if (e->rec_crops) (void)hipFree(e->rec_crops);
+  if (e->rec_gray) (void)hipFree(e->rec_gray);
+  if (e->rec_off) (void)hipFree(e->rec_off);
   for (auto& p : e->prof.pending) {
     (void)hipEventDestroy(p.a);
     (void)hipEventDestroy(p.b);
@@ -262,6 +265,99 @@ int pt_det_box_scores(pt_engine* e, const float* d_prob, int n, int net_h, int n
                       float* d_scores, pt_stream stream) {
   PT_REQUIRE(e && d_prob && (nb == 0 || (d_boxes && d_scores)), "pt_det_box_scores: bad arguments");
   return pt_launch_box_scores(d_prob, n, net_h, net_w, d_boxes, nb, d_scores, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ---- recognition ---------------------------------------------------------------------------------------
+static int ensure(void** buf, size_t* cap, size_t need) {
+  if (need <= *cap) return PT_OK;
+  PT_HIP_CHECK(hipDeviceSynchronize());
+  if (*buf) PT_HIP_CHECK(hipFree(*buf));
+  *buf = nullptr;
+  *cap = 0;
+  PT_HIP_CHECK(hipMalloc(buf, need));
+  *cap = need;
+  return PT_OK;
+}
+
+static int rec_microbatch() {
+  static int mb = -1;
+  if (mb < 0) {
+    const char* s = getenv("PT_REC_MICROBATCH");
+    mb = s ? atoi(s) : 512;
+    if (mb < 1) mb = 1;
+  }
+  return mb;
+}
+
+// crop + resize + gray for lines [i0, i0+nb) into d_gray (bf16 [nb,32,640] or hi/lo pairs)
+static int rec_pre_chunk(pt_engine* e, const uint8_t* d_pages, int n_pages, int h, int w, const pt_rec_line* d_lines,
+                         const int64_t* h_crop_px, int i0, int nb, bf16_t* d_gray, hipStream_t s) {
+  (void)n_pages;
+  std::vector<long long>& off = e->rec_off_host;
+  off.assign((size_t)nb + 1, 0);
+  long long maxpx = 0;
+  for (int i = 0; i < nb; ++i) {
+    const long long px = h_crop_px[i0 + i] > 0 ? h_crop_px[i0 + i] : 0;
+    off[i + 1] = off[i] + px;
+    if (px > maxpx) maxpx = px;
+  }
+  int rc;
+  if ((rc = ensure(&e->rec_off, &e->rec_off_cap, (size_t)(nb + 1) * sizeof(long long))) != PT_OK) return rc;
+  if ((rc = ensure(&e->rec_crops, &e->rec_crops_cap, (size_t)off[nb] * 3 + 16)) != PT_OK) return rc;
+  PT_HIP_CHECK(hipMemcpyAsync(e->rec_off, off.data(), (size_t)(nb + 1) * sizeof(long long), hipMemcpyHostToDevice, s));
+  PT_HIP_CHECK(hipStreamSynchronize(s));  // `off` is reused by the next chunk
+  const long long* d_off = reinterpret_cast<const long long*>(e->rec_off);
+  {
+    PtProfScope ps(e, s, PT_PROF_OTHER, 0, "rec warp");
+    rc = pt_launch_rec_warp(d_pages, h, w, d_lines + i0, nb, d_off, reinterpret_cast<uint8_t*>(e->rec_crops), (int)maxpx, s);
+    if (rc != PT_OK) return rc;
+  }
+  PtProfScope ps(e, s, PT_PROF_OTHER, 0, "rec resize+gray");
+  return pt_launch_rec_resize_gray(reinterpret_cast<const uint8_t*>(e->rec_crops), d_lines + i0, d_off, nb,
+                                   e->precision == PT_PRECISION_BF16X3, d_gray, s);
+}
+
+int pt_rec_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int h, int w, const pt_rec_line* d_lines,
+                      const int64_t* h_crop_px, int n_lines, uint16_t* d_gray, pt_stream stream) {
+  PT_REQUIRE(e && d_pages_rgb && d_lines && h_crop_px && d_gray && n_lines > 0, "pt_rec_preprocess: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  return rec_pre_chunk(e, d_pages_rgb, n_pages, h, w, d_lines, h_crop_px, 0, n_lines, d_gray, reinterpret_cast<hipStream_t>(stream));
+}
+
+int pt_rec_forward_net(pt_engine* e, const uint16_t* d_gray, int n, int32_t* d_ids, float* d_maxlogit, pt_stream stream) {
+  PT_REQUIRE(e && d_gray && d_ids && n > 0, "pt_rec_forward_net: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int mb = rec_microbatch();
+  const size_t per_line = (size_t)PT_REC_H * PT_REC_W * (e->precision == PT_PRECISION_BF16X3 ? 2 : 1);
+  for (int i0 = 0; i0 < n; i0 += mb) {
+    const int nb = (n - i0) < mb ? (n - i0) : mb;
+    int rc = pt_crnn_forward_net(e, d_gray + (size_t)i0 * per_line, nb, d_ids + (size_t)i0 * PT_REC_T,
+                                 d_maxlogit ? d_maxlogit + (size_t)i0 * PT_REC_T : nullptr, s);
+    if (rc != PT_OK) return rc;
+  }
+  return PT_OK;
+}
+
+int pt_rec_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int h, int w, const pt_rec_line* d_lines,
+                   const int64_t* h_crop_px, int n_lines, int32_t* d_ids, float* d_maxlogit, pt_stream stream) {
+  PT_REQUIRE(e && d_pages_rgb && d_lines && h_crop_px && d_ids && n_lines > 0, "pt_rec_forward: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int mb = rec_microbatch();
+  const size_t per_line = (size_t)PT_REC_H * PT_REC_W * (e->precision == PT_PRECISION_BF16X3 ? 2 : 1);
+  int rc;
+  if ((rc = ensure(&e->rec_gray, &e->rec_gray_cap, (size_t)(mb < n_lines ? mb : n_lines) * per_line * sizeof(bf16_t))) != PT_OK)
+    return rc;
+  for (int i0 = 0; i0 < n_lines; i0 += mb) {
+    const int nb = (n_lines - i0) < mb ? (n_lines - i0) : mb;
+    rc = rec_pre_chunk(e, d_pages_rgb, n_pages, h, w, d_lines, h_crop_px, i0, nb, reinterpret_cast<bf16_t*>(e->rec_gray), s);
+    if (rc != PT_OK) return rc;
+    rc = pt_crnn_forward_net(e, reinterpret_cast<const bf16_t*>(e->rec_gray), nb, d_ids + (size_t)i0 * PT_REC_T,
+                             d_maxlogit ? d_maxlogit + (size_t)i0 * PT_REC_T : nullptr, s);
+    if (rc != PT_OK) return rc;
+  }
+  return PT_OK;
 }
 
 int pt_op_conv2d(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int Cin, const uint16_t* d_w_tiled,

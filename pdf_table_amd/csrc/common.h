@@ -95,6 +95,11 @@ struct pt_engine {
   std::map<int, PtModel> models;
   PtProfile prof;
   int precision = 0;  // PT_PRECISION_*
+  // engine-owned scratch of the recognition stage (outside the arena, which every net forward resets)
+  void* rec_crops = nullptr; size_t rec_crops_cap = 0;
+  void* rec_gray = nullptr; size_t rec_gray_cap = 0;
+  void* rec_off = nullptr; size_t rec_off_cap = 0;
+  std::vector<long long> rec_off_host;
 };
 
 // ---- conv launcher (conv_igemm.hip) -----------------------------------------------------------------
@@ -126,6 +131,8 @@ struct ConvDesc {
   const float* head_b = nullptr;
   float* head_prob = nullptr;
   float* head_logits = nullptr;
+  // fused arg-max over N: float2 (max, index-as-bits) per (output row, 64-wide N tile); no activation tensor is written
+  float* argmax_part = nullptr;
 };
 int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s);
 
@@ -143,6 +150,19 @@ int pt_launch_bitmap(const float* prob, int n, int H, int W, float thresh, int d
                      hipStream_t s);
 int pt_launch_box_scores(const float* prob, int n, int H, int W, const float* boxes, int nb, float* scores,
                          hipStream_t s);
+
+// ---- recognition kernels (rec_kernels.hip) --------------------------------------------------------------
+int pt_launch_rec_warp(const uint8_t* pages, int ph, int pw, const pt_rec_line* lines, int n_lines,
+                       const long long* pix_off, uint8_t* crops, int max_crop_px, hipStream_t s);
+int pt_launch_rec_resize_gray(const uint8_t* crops, const pt_rec_line* lines, const long long* pix_off, int n_lines,
+                              int split, bf16_t* out, hipStream_t s);
+int pt_launch_crnn_conv0_pool(const bf16_t* in, int n, int H, int W, const float* w64x9, const float* bias, int split,
+                              bf16_t* out, hipStream_t s);
+int pt_launch_maxpool_kxk(const bf16_t* in, int n, int H, int W, int C, int kh, int kw, int h2c, int split, bf16_t* out,
+                          hipStream_t s);
+int pt_launch_lstm(const bf16_t* gx, const bf16_t* whh, bf16_t* hout, int B, int T, int split, hipStream_t s);
+int pt_launch_argmax_reduce(const float* part, long long rows, int ntiles, int* ids, float* maxv, hipStream_t s);
+int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, float* maxlogit, hipStream_t s);
 
 // ---- models ---------------------------------------------------------------------------------------------
 int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* prob, float* logits, hipStream_t s);

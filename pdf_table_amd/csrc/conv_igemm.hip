@@ -49,6 +49,8 @@ struct ConvK {
   const float* head_b;
   float* head_prob;
   float* head_logits;
+  // fused per-row arg-max over the N (class) dimension: partial (max, index) per 64-class tile -> [rows][N/64] float2
+  float* argmax_part;
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
@@ -67,7 +69,7 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
 }
 
 // Shared epilogue: fp32 tile [TH*32 pixels][64 ch] in LDS -> bias/residual/ReLU -> bf16 stores.
-template <int TH>
+template <int TH, int TW>
 __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stage, int tid, int b, int oy0, int ox0,
                                                int n0) {
   // fused-head weights of this thread's 8 channels (idx & 7 == tid & 7 for every j)
@@ -89,10 +91,10 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
     }
   }
 #pragma unroll
-  for (int j = 0; j < TH; ++j) {
+  for (int j = 0; j < TH * TW / 32; ++j) {
     const int idx = tid + j * 256;
     const int pix = idx >> 3, cg = idx & 7;
-    const int ty = pix >> 5, tx = pix & 31;
+    const int ty = pix / TW, tx = pix % TW;
     const int oy = oy0 + ty, ox = ox0 + tx;
     if (oy >= p.Ho || ox >= p.Wo) continue;
     const f32x4* sp = reinterpret_cast<const f32x4*>(stage + pix * 64 + cg * 8);
@@ -136,7 +138,28 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
       for (int k = 0; k < 8; ++k) lb[k] = f32_to_bf16(v[k] - bf16_to_f32(hb[k]));
       ol.x = lb[0] | (lb[1] << 16); ol.y = lb[2] | (lb[3] << 16); ol.z = lb[4] | (lb[5] << 16); ol.w = lb[6] | (lb[7] << 16);
     }
-    if (p.head_w) {
+    if (p.argmax_part) {
+      // fused arg-max over classes (CTC greedy decode, modeling_ocr_recognition.py:168-171): best (value, index)
+      // of this pixel's 64-class slice; ties keep the LOWEST class index, like torch.argmax
+      float bv = v[0];
+      int bi = n;
+#pragma unroll
+      for (int k = 1; k < 8; ++k)
+        if (v[k] > bv) { bv = v[k]; bi = n + k; }
+#pragma unroll
+      for (int off = 1; off < 8; off <<= 1) {
+        const float ov = __shfl_xor(bv, off);
+        const int oi = __shfl_xor(bi, off);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      if (cg == 0) {
+        const size_t row = ((size_t)b * p.Ho + oy) * p.Wo + ox;
+        float2 pr;
+        pr.x = bv;
+        pr.y = __int_as_float(bi);
+        reinterpret_cast<float2*>(p.argmax_part)[row * p.n_tiles + (n0 >> 6)] = pr;
+      }
+    } else if (p.head_w) {
       // 8 consecutive lanes hold the 64 channels of one output pixel of quadrant `quad` (n0 == quad * 64)
       float xs[8];
 #pragma unroll
@@ -180,13 +203,15 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
   }
 }
 
-template <int KS, int STRIDE>
+template <int KS, int STRIDE, int GEOM = 0>
 struct ConvCfg {
-  static constexpr int TW = 32;
-  // 3x3/s1: 8x32 patch (2 MFMA row-tiles per wave); 1x1 and stride-2: 4x32 (smaller LDS image -> more
-  // workgroups per CU, which is what the bandwidth-bound 1x1 layers need)
-  static constexpr int TH = (STRIDE == 1 && KS == 3) ? 8 : 4;
-  static constexpr int MT = TH / 4;  // 1x32-pixel MFMA row-tiles per wave
+  // GEOM 0: 3x3/s1: 8x32 patch (2 MFMA row-tiles per wave); 1x1 and stride-2: 4x32 (smaller LDS image -> more
+  //         workgroups per CU, which is what the bandwidth-bound 1x1 layers need)
+  // GEOM 1: 4x64 patch for feature maps that are only <= 4 rows high (CRNN conv3.*, crnn/modeling_crnn.py:66-77)
+  static constexpr int TW = GEOM ? 64 : 32;
+  static constexpr int TH = GEOM ? 4 : ((STRIDE == 1 && KS == 3) ? 8 : 4);
+  static constexpr int CT = TW / 32;            // 32-pixel MFMA row-tiles per patch row
+  static constexpr int MT = TH * CT / 4;        // row-tiles per wave
   static constexpr int THIN = (TH - 1) * STRIDE + KS;
   static constexpr int TWIN = (TW - 1) * STRIDE + KS;
   static constexpr int TAPS = KS * KS;
@@ -202,9 +227,9 @@ struct ConvCfg {
   static_assert(NP_W % 256 == 0, "weight slice must be a whole number of 256-thread passes");
 };
 
-template <int KS, int STRIDE>
+template <int KS, int STRIDE, int GEOM>
 __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_igemm_kernel(ConvK p) {
-  using C = ConvCfg<KS, STRIDE>;
+  using C = ConvCfg<KS, STRIDE, GEOM>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_in = smem;
   char* s_w = smem + C::IN_BYTES;
@@ -275,7 +300,13 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  const char* a_base = s_in + (((wave * C::MT) * STRIDE) * C::TWIN + lx * STRIDE) * C::PIXB + q * 16;
+  // MFMA row-tile t = wave * MT + m covers patch row t / CT, columns (t % CT) * 32 .. + 31
+  const char* a_base[C::MT];
+#pragma unroll
+  for (int m = 0; m < C::MT; ++m) {
+    const int t = wave * C::MT + m;
+    a_base[m] = s_in + ((((t / C::CT) * STRIDE) * C::TWIN + ((t % C::CT) * 32 + lx) * STRIDE) * C::PIXB) + q * 16;
+  }
   const char* b_base = s_w + lx * C::PIXB + q * 16;
 
   prefetch(0);
@@ -295,7 +326,7 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
           const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(b_base + (tap * 64 + 32) * C::PIXB + kk * 32);
 #pragma unroll
           for (int m = 0; m < C::MT; ++m) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base + ((m * STRIDE + r) * C::TWIN + s) * C::PIXB + kk * 32);
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base[m] + (r * C::TWIN + s) * C::PIXB + kk * 32);
             acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
             acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
           }
@@ -309,17 +340,18 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
   float* stage = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int m = 0; m < C::MT; ++m) {
-    const int ty = wave * C::MT + m;
+    const int t = wave * C::MT + m;
+    const int pbase = (t / C::CT) * C::TW + (t % C::CT) * 32;
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int tx = (r & 3) + 8 * (r >> 2) + 4 * q;
-        stage[(ty * 32 + tx) * 64 + n * 32 + lx] = acc[m][n][r];
+        stage[(pbase + tx) * 64 + n * 32 + lx] = acc[m][n][r];
       }
   }
   __syncthreads();
-  epilogue_store<C::TH>(p, stage, tid, b, oy0, ox0, nt * 64);
+  epilogue_store<C::TH, C::TW>(p, stage, tid, b, oy0, ox0, nt * 64);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -432,16 +464,16 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_kernel(ConvK p) {
       }
   }
   __syncthreads();
-  epilogue_store<C::TH>(p, stage, tid, b, oy0, ox0, 0);
+  epilogue_store<C::TH, C::TW>(p, stage, tid, b, oy0, ox0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <int KS, int STRIDE>
+template <int KS, int STRIDE, int GEOM = 0>
 static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
-  using C = ConvCfg<KS, STRIDE>;
+  using C = ConvCfg<KS, STRIDE, GEOM>;
   static bool attr_done = false;
   if (!attr_done) {
-    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<KS, STRIDE>),
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<KS, STRIDE, GEOM>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
     attr_done = true;
   }
@@ -453,13 +485,13 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   char label[48];
   snprintf(label, sizeof(label), "conv%dx%d s%d %d->%d @%dx%d%s", KS, KS, STRIDE, k.Cin, k.N, k.Ho, k.Wo, k.head_w ? " +head" : (k.split ? " x3" : ""));
   PtProfScope prof(e, s, KS == 3 ? PT_PROF_CONV3X3 : PT_PROF_CONV1X1, flop, label);
-  hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
+  hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, GEOM>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
 
 int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
-  PT_REQUIRE(d.in && d.w && d.bias && (d.out || d.head_w), "conv: null pointer");
+  PT_REQUIRE(d.in && d.w && d.bias && (d.out || d.head_w || d.argmax_part), "conv: null pointer");
   PT_REQUIRE(d.Cin % 32 == 0 && d.Cin > 0, "conv: Cin=%d must be a positive multiple of 32", d.Cin);
   PT_REQUIRE(d.N % 64 == 0 && d.N > 0, "conv: N=%d must be a positive multiple of 64", d.N);
   PT_REQUIRE((d.ks == 1 || d.ks == 3) && (d.stride == 1 || d.stride == 2), "conv: ks=%d stride=%d unsupported", d.ks,
@@ -477,9 +509,11 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   k.res_mode = d.res ? d.res_mode : 0; k.relu = d.relu;
   k.split = d.split; k.out_lo_off = d.out_lo_off;
   k.head_w = d.head_w; k.head_b = d.head_b; k.head_prob = d.head_prob; k.head_logits = d.head_logits;
+  k.argmax_part = d.argmax_part;
   if (d.head_w) PT_REQUIRE(d.shuffle_cout == 64 && d.head_b && (d.head_prob || d.head_logits), "conv: bad fused-head configuration");
   if (k.res_mode == 2) PT_REQUIRE(k.Ho % 2 == 0 && k.Wo % 2 == 0, "conv: half-res residual needs even output size");
   const double flop = 2.0 * k.B * k.Ho * k.Wo * (double)k.N * d.Cin * d.ks * d.ks;  // algorithmic (not x3 in split mode)
+  if (d.ks == 3 && d.stride == 1 && k.Ho <= 4 && k.Wo > 32) return launch_cfg<3, 1, 1>(e, k, s, flop);
   if (d.ks == 3 && d.stride == 1) return launch_cfg<3, 1>(e, k, s, flop);
   if (d.ks == 3 && d.stride == 2) return launch_cfg<3, 2>(e, k, s, flop);
   if (d.ks == 1 && d.stride == 1) return launch_cfg<1, 1>(e, k, s, flop);

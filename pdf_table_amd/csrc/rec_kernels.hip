@@ -1,0 +1,458 @@
+// rec_kernels.hip -- kernels of the text-line recognition stage that are not dense convolutions:
+//   * perspective crop of every detected quad straight from the page image (replaces the per-line host
+//     cv2.warpPerspective of OcrCommonUtils.crop_image, utils/ocr/ocr_common_utils.py:214-266)
+//   * keep-ratio resize to 32 x W, zero pad to 640, /255, RGB->gray (processor_ocr_recognition.py:44-62,111;
+//     crnn/modeling_crnn.py:94)
+//   * CRNN conv0 (1->64, 3x3) + BN + ReLU + 2x2 max-pool fused (crnn/modeling_crnn.py:40-47)
+//   * max-pools 2x2 / (2,1) on NHWC (:55,:68,:81), the last one also folding H into channels for the (2,1) conv
+//   * one direction of an LSTM layer for 32 text lines per workgroup (nn.LSTM equations; modeling_crnn.py:19-33)
+//   * arg-max reduction over the class tiles produced by the fused classifier GEMM epilogue
+// Compiled with -ffp-contract=off.
+#include <math.h>
+
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+__device__ __forceinline__ float rbf2f(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
+__device__ __forceinline__ uint32_t rf2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Perspective crop.  cv2.warpPerspective(img, M, (w, h)) semantics for 8-bit, INTER_LINEAR, constant border 0:
+// destination (x, y) -> (X, Y, W) = Minv * (x, y, 1) in double; X*32/W, Y*32/W rounded to nearest integer give
+// the source position in 1/32 pixel; the four neighbours are blended with 15-bit weights
+// (32-ay)(32-ax)*32 ... and the sum is rounded with +2^14 >> 15.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rec_warp_kernel(const uint8_t* __restrict__ pages, int ph, int pw,
+                                                        const pt_rec_line* __restrict__ lines, int n_lines,
+                                                        const long long* __restrict__ pix_off, uint8_t* __restrict__ crops) {
+  const int li = blockIdx.y;
+  if (li >= n_lines) return;
+  const pt_rec_line L = lines[li];
+  const int cw = L.crop_w, chh = L.crop_h;
+  const long long npx = (long long)cw * chh;
+  uint8_t* dst = crops + pix_off[li] * 3;
+  const uint8_t* src = pages + (size_t)L.page * ph * pw * 3;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % cw), y = (int)(i / cw);
+    const double X0 = L.minv[0] * x + L.minv[1] * y + L.minv[2];
+    const double Y0 = L.minv[3] * x + L.minv[4] * y + L.minv[5];
+    double W = L.minv[6] * x + L.minv[7] * y + L.minv[8];
+    W = W != 0. ? 32. / W : 0.;
+    const double fX = fmax(-2147483648., fmin(2147483647., X0 * W));
+    const double fY = fmax(-2147483648., fmin(2147483647., Y0 * W));
+    const long long Xi = (long long)rint(fX), Yi = (long long)rint(fY);
+    const long long sx = Xi >> 5, sy = Yi >> 5;
+    const int ax = (int)(Xi & 31), ay = (int)(Yi & 31);
+    const int w00 = (32 - ay) * (32 - ax) * 32, w01 = (32 - ay) * ax * 32, w10 = ay * (32 - ax) * 32, w11 = ay * ax * 32;
+    int acc[3] = {0, 0, 0};
+    auto tap = [&](long long yy, long long xx, int wgt) {
+      if (wgt && yy >= 0 && yy < ph && xx >= 0 && xx < pw) {
+        const uint8_t* p = src + ((size_t)yy * pw + xx) * 3;
+        acc[0] += p[0] * wgt; acc[1] += p[1] * wgt; acc[2] += p[2] * wgt;
+      }
+    };
+    tap(sy, sx, w00); tap(sy, sx + 1, w01); tap(sy + 1, sx, w10); tap(sy + 1, sx + 1, w11);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      int v = (acc[c] + (1 << 14)) >> 15;
+      dst[i * 3 + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+  }
+}
+
+int pt_launch_rec_warp(const uint8_t* pages, int ph, int pw, const pt_rec_line* lines, int n_lines,
+                       const long long* pix_off, uint8_t* crops, int max_crop_px, hipStream_t s) {
+  if (n_lines <= 0) return PT_OK;
+  int bx = (max_crop_px + 255) / 256;
+  bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
+  hipLaunchKernelGGL(rec_warp_kernel, dim3(bx, n_lines), dim3(256), 0, s, pages, ph, pw, lines, n_lines, pix_off, crops);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// keepratio_resize (cv2.resize 8-bit bilinear, see det_kernels.hip) + zero pad + /255 + gray.
+// out: bf16 [n, 32, 640] (split: [n, 32, 640, 2] = hi, lo)
+// ---------------------------------------------------------------------------------------------------
+struct RCoef {
+  int s0, s1, a0, a1;
+};
+__device__ __forceinline__ RCoef rcoef(int d, double scale, int ssize, bool clamp_frac) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (clamp_frac) {
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+  }
+  RCoef c;
+  c.a0 = (int)rintf((1.f - f) * 2048.f);
+  c.a1 = (int)rintf(f * 2048.f);
+  int t0 = s, t1 = s + 1;
+  c.s0 = t0 < 0 ? 0 : (t0 >= ssize ? ssize - 1 : t0);
+  c.s1 = t1 < 0 ? 0 : (t1 >= ssize ? ssize - 1 : t1);
+  return c;
+}
+
+__global__ __launch_bounds__(256) void rec_resize_gray_kernel(const uint8_t* __restrict__ crops,
+                                                               const pt_rec_line* __restrict__ lines,
+                                                               const long long* __restrict__ pix_off, int n_lines, int TH,
+                                                               int TWID, int split, bf16_t* __restrict__ out) {
+  const long long total = (long long)n_lines * TH * TWID;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % TWID);
+    const long long t = i / TWID;
+    const int y = (int)(t % TH);
+    const int li = (int)(t / TH);
+    const int cw = lines[li].crop_w, chh = lines[li].crop_h;
+    float gray = 0.f;
+    if (cw > 0 && chh > 0) {
+      // cur_ratio > target_w / target_h ? (32, 640) : (32, int(32 * ratio))   (python float arithmetic)
+      const double ratio = (double)cw / (double)chh;
+      const int nw = ratio > (double)TWID / (double)TH ? TWID : (int)((double)TH * ratio);
+      if (x < nw) {
+        const uint8_t* src = crops + pix_off[li] * 3;
+        int v[3];
+        if (cw == nw && chh == TH) {
+          const uint8_t* p = src + ((size_t)y * cw + x) * 3;
+          v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+        } else if (cw == 2 * nw && chh == 2 * TH) {
+          const uint8_t* p0 = src + ((size_t)(2 * y) * cw + 2 * x) * 3;
+          const uint8_t* p1 = p0 + (size_t)cw * 3;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) v[c] = (p0[c] + p0[3 + c] + p1[c] + p1[3 + c] + 2) >> 2;
+        } else {
+          const RCoef cx = rcoef(x, (double)cw / nw, cw, true);
+          const RCoef cy = rcoef(y, (double)chh / TH, chh, false);
+          const uint8_t* r0 = src + (size_t)cy.s0 * cw * 3;
+          const uint8_t* r1 = src + (size_t)cy.s1 * cw * 3;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const int S0 = r0[cx.s0 * 3 + c] * cx.a0 + r0[cx.s1 * 3 + c] * cx.a1;
+            const int S1 = r1[cx.s0 * 3 + c] * cx.a0 + r1[cx.s1 * 3 + c] * cx.a1;
+            int r = (((cy.a0 * (S0 >> 4)) >> 16) + ((cy.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
+            v[c] = r < 0 ? 0 : (r > 255 ? 255 : r);
+          }
+        }
+        const float R = (float)v[0] / 255.f, G = (float)v[1] / 255.f, B = (float)v[2] / 255.f;
+        gray = (R * 0.2989f + G * 0.5870f) + B * 0.1140f;  // modeling_crnn.py:94, left-to-right
+      }
+    }
+    const uint32_t hb = rf2bf(gray);
+    if (split) {
+      out[i * 2] = (bf16_t)hb;
+      out[i * 2 + 1] = (bf16_t)rf2bf(gray - rbf2f(hb));
+    } else {
+      out[i] = (bf16_t)hb;
+    }
+  }
+}
+
+int pt_launch_rec_resize_gray(const uint8_t* crops, const pt_rec_line* lines, const long long* pix_off, int n_lines,
+                              int split, bf16_t* out, hipStream_t s) {
+  if (n_lines <= 0) return PT_OK;
+  const long long total = (long long)n_lines * 32 * 640;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(rec_resize_gray_kernel, dim3(blocks), dim3(256), 0, s, crops, lines, pix_off, n_lines, 32, 640, split, out);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// CRNN conv0: Conv2d(1, 64, 3, pad 1) + BN + ReLU, then MaxPool2d(2, 2).  Direct fp32 convolution on the VALU
+// (K = 9 is far too thin for MFMA).  in: gray bf16 [n, H, W] (split: hi/lo pairs); w fp32 [64][9] (BN folded, rounded
+// to bf16 by the packer in bf16 mode), bias fp32 [64]; out bf16 [n, H/2, W/2, 64] (split: [hi(64) | lo(64)]).
+// One thread = one pooled pixel x 8 channels.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void crnn_conv0_pool_kernel(const bf16_t* __restrict__ in, int n, int H, int W,
+                                                               const float* __restrict__ w64x9,
+                                                               const float* __restrict__ bias, int split,
+                                                               bf16_t* __restrict__ out) {
+  __shared__ float sw[64 * 9 + 64];
+  for (int i = threadIdx.x; i < 64 * 9; i += blockDim.x) sw[i] = w64x9[i];
+  for (int i = threadIdx.x; i < 64; i += blockDim.x) sw[576 + i] = bias[i];
+  __syncthreads();
+  const int Ho = H / 2, Wo = W / 2;
+  const long long total = (long long)n * Ho * Wo * 8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i & 7);
+    long long t = i >> 3;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float win[4][4];
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 4; ++dx) {
+        const int yy = 2 * oy - 1 + dy, xx = 2 * ox - 1 + dx;
+        float v = 0.f;
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+          const size_t o = ((size_t)b * H + yy) * W + xx;
+          v = split ? rbf2f(in[o * 2]) + rbf2f(in[o * 2 + 1]) : rbf2f(in[o]);
+        }
+        win[dy][dx] = v;
+      }
+    float best[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = cg * 8 + k;
+      const float* wk = sw + c * 9;
+      float m = 0.f;
+#pragma unroll
+      for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+          float a = 0.f;
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2) a = fmaf(win[py + r][px + s2], wk[r * 3 + s2], a);
+          a = fmaxf(a + sw[576 + c], 0.f);
+          if (!split) a = rbf2f(rf2bf(a));  // bf16 contract: the conv output is stored in bf16 before pooling
+          m = (py == 0 && px == 0) ? a : fmaxf(m, a);
+        }
+      best[k] = m;
+    }
+    uint32_t hb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) hb[k] = rf2bf(best[k]);
+    u32x4 o;
+    o.x = hb[0] | (hb[1] << 16); o.y = hb[2] | (hb[3] << 16); o.z = hb[4] | (hb[5] << 16); o.w = hb[6] | (hb[7] << 16);
+    const size_t pix = ((size_t)b * Ho + oy) * Wo + ox;
+    if (!split) {
+      *reinterpret_cast<u32x4*>(out + pix * 64 + cg * 8) = o;
+    } else {
+      uint32_t lb[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) lb[k] = rf2bf(best[k] - rbf2f(hb[k]));
+      u32x4 ol;
+      ol.x = lb[0] | (lb[1] << 16); ol.y = lb[2] | (lb[3] << 16); ol.z = lb[4] | (lb[5] << 16); ol.w = lb[6] | (lb[7] << 16);
+      *reinterpret_cast<u32x4*>(out + pix * 128 + cg * 8) = o;
+      *reinterpret_cast<u32x4*>(out + pix * 128 + 64 + cg * 8) = ol;
+    }
+  }
+}
+
+int pt_launch_crnn_conv0_pool(const bf16_t* in, int n, int H, int W, const float* w64x9, const float* bias, int split,
+                              bf16_t* out, hipStream_t s) {
+  PT_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv0: H, W must be even");
+  const long long total = (long long)n * (H / 2) * (W / 2) * 8;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(crnn_conv0_pool_kernel, dim3(blocks), dim3(256), 0, s, in, n, H, W, w64x9, bias, split, out);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// MaxPool2d(kernel = stride = (kh, kw)) on NHWC bf16, kh in {2}, kw in {1, 2}.  h2c: the pooled rows are written
+// as extra channel groups ([n][Wo][Ho*C]) so that the following (Ho,1)-kernel conv is a plain 1x1 GEMM.
+// split: channels are [hi(C) | lo(C)] pairs and the max is taken on hi + lo.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_kxk_kernel(const bf16_t* __restrict__ in, int n, int H, int W, int C,
+                                                           int kh, int kw, int h2c, int split,
+                                                           bf16_t* __restrict__ out) {
+  const int Ho = H / kh, Wo = W / kw, cgn = C >> 3;
+  const int cs = split ? 2 * C : C;
+  const long long total = (long long)n * Ho * Wo * cgn;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cgn);
+    long long t = i / cgn;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    uint32_t bh[8], bl[8];
+    float bv[8];
+    bool first = true;
+    for (int dy = 0; dy < kh; ++dy)
+      for (int dx = 0; dx < kw; ++dx) {
+        const bf16_t* px = in + (((size_t)b * H + oy * kh + dy) * W + ox * kw + dx) * cs + g * 8;
+        const u32x4 vh = *reinterpret_cast<const u32x4*>(px);
+        u32x4 vl = {0u, 0u, 0u, 0u};
+        if (split) vl = *reinterpret_cast<const u32x4*>(px + C);
+        const uint32_t hw[4] = {vh.x, vh.y, vh.z, vh.w}, lw[4] = {vl.x, vl.y, vl.z, vl.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t hb = (k & 1) ? (hw[k >> 1] >> 16) : (hw[k >> 1] & 0xFFFFu);
+          const uint32_t lb = (k & 1) ? (lw[k >> 1] >> 16) : (lw[k >> 1] & 0xFFFFu);
+          const float v = rbf2f(hb) + rbf2f(lb);
+          if (first || v > bv[k]) { bv[k] = v; bh[k] = hb; bl[k] = lb; }
+        }
+        first = false;
+      }
+    u32x4 oh, ol;
+    oh.x = bh[0] | (bh[1] << 16); oh.y = bh[2] | (bh[3] << 16); oh.z = bh[4] | (bh[5] << 16); oh.w = bh[6] | (bh[7] << 16);
+    ol.x = bl[0] | (bl[1] << 16); ol.y = bl[2] | (bl[3] << 16); ol.z = bl[4] | (bl[5] << 16); ol.w = bl[6] | (bl[7] << 16);
+    size_t o;
+    int lo_off;
+    if (h2c) {
+      const int Ct = Ho * C;
+      o = ((size_t)b * Wo + ox) * (split ? 2 * Ct : Ct) + oy * C + g * 8;
+      lo_off = Ct;
+    } else {
+      o = (((size_t)b * Ho + oy) * Wo + ox) * cs + g * 8;
+      lo_off = C;
+    }
+    *reinterpret_cast<u32x4*>(out + o) = oh;
+    if (split) *reinterpret_cast<u32x4*>(out + o + lo_off) = ol;
+  }
+}
+
+int pt_launch_maxpool_kxk(const bf16_t* in, int n, int H, int W, int C, int kh, int kw, int h2c, int split, bf16_t* out,
+                          hipStream_t s) {
+  PT_REQUIRE(C % 8 == 0 && H % kh == 0 && W % kw == 0, "maxpool: bad shape");
+  const long long total = (long long)n * (H / kh) * (W / kw) * (C / 8);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(maxpool_kxk_kernel, dim3(blocks), dim3(256), 0, s, in, n, H, W, C, kh, kw, h2c, split, out);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LSTM, one direction, 32 text lines per workgroup, all T steps inside the kernel.
+//   gates_t = gx[line, t, dir] (input projection + both biases, computed beforehand by the 1x1 GEMM kernel)
+//             + h_{t-1} . W_hh^T                                   (MFMA: M = 32 lines, N = 1024, K = 256)
+//   i, f, g, o = split(gates);  c = sig(f) c + sig(i) tanh(g);  h = sig(o) tanh(c)
+// Wave w owns hidden units [64w, 64w+64): its 8 MFMA tiles are (gate 0..3) x (32-unit half 0..1), so the four
+// gate pre-activations of one (line, unit) sit in the same lane and register index and the cell update is
+// lane-local; c stays in registers (fp32) for the whole sequence; h goes through LDS (double-buffered, bf16 or
+// hi/lo pair) as next step's A operand and to HBM as the layer output.  W_hh fragments stream from L2.
+// ---------------------------------------------------------------------------------------------------
+template <int SPLIT>
+__global__ __launch_bounds__(256, 1) void lstm_dir_kernel(const bf16_t* __restrict__ gx, const bf16_t* __restrict__ whh,
+                                                           bf16_t* __restrict__ hout, int B, int T) {
+  constexpr int NP = SPLIT ? 2 : 1;
+  constexpr int HROW = 264;  // 256 + 8 bf16: 528-byte rows = 33 16-byte slots (odd) -> conflict-free b128 reads
+  __shared__ __attribute__((aligned(16))) bf16_t hbuf[NP][32][HROW];  // read by all waves (MFMA), then rewritten
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, q = lane >> 5;
+  const int line0 = blockIdx.x * 32, dir = blockIdx.y;
+  const int gcs = (SPLIT ? 2 : 1) * 2048;  // gx channels per (line, t): [dir0 1024 | dir1 1024] (x2 for hi|lo)
+  const int hcs = (SPLIT ? 2 : 1) * 512;   // hout channels per (line, t): [fw 256 | bw 256] (x2 for hi|lo)
+  const bf16_t* whh_d = whh + (size_t)dir * 1024 * 256;           // hi part; lo part at + 2*1024*256
+  for (int i = tid; i < NP * 32 * HROW; i += 256) (&hbuf[0][0][0])[i] = 0;
+  float c[2][16];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[h][r] = 0.f;
+  __syncthreads();
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? T - 1 - s : s;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][h][r] = 0.f;
+    constexpr int NPASS = SPLIT ? 3 : 1;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int pa = (pass == 1) ? 1 : 0;  // A part: h_hi, h_lo, h_hi
+      const bf16_t* wsrc = whh_d + (pass == 2 ? (size_t)2 * 1024 * 256 : 0);
+#pragma unroll 4
+      for (int k16 = 0; k16 < 16; ++k16) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(&hbuf[pa][lx][k16 * 16 + q * 8]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int ncol = g * 256 + wave * 64 + h * 32 + lx;
+            const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(wsrc + (size_t)ncol * 256 + k16 * 16 + q * 8);
+            acc[g][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag, acc[g][h], 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();  // every wave has finished reading h_{t-1}
+    // cell update (lane-local) + publish h
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int unit = wave * 64 + h * 32 + lx;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * q;
+        const int line = line0 + m;
+        const int lc = line < B ? line : B - 1;
+        const bf16_t* gp = gx + ((size_t)lc * T + t) * gcs + dir * 1024 + unit;
+        float gi = acc[0][h][r] + rbf2f(gp[0]);
+        float gf = acc[1][h][r] + rbf2f(gp[256]);
+        float gg = acc[2][h][r] + rbf2f(gp[512]);
+        float go = acc[3][h][r] + rbf2f(gp[768]);
+        if (SPLIT) {
+          gi += rbf2f(gp[2048]); gf += rbf2f(gp[2048 + 256]); gg += rbf2f(gp[2048 + 512]); go += rbf2f(gp[2048 + 768]);
+        }
+        const float si = 1.f / (1.f + expf(-gi)), sf = 1.f / (1.f + expf(-gf)), so = 1.f / (1.f + expf(-go));
+        const float cn = sf * c[h][r] + si * tanhf(gg);
+        c[h][r] = cn;
+        const float hn = so * tanhf(cn);
+        const uint32_t hb = rf2bf(hn);
+        hbuf[0][m][unit] = (bf16_t)hb;
+        uint32_t lb = 0;
+        if (SPLIT) {
+          lb = rf2bf(hn - rbf2f(hb));
+          hbuf[NP - 1][m][unit] = (bf16_t)lb;
+        }
+        if (line < B) {
+          bf16_t* hp = hout + ((size_t)line * T + t) * hcs + dir * 256 + unit;
+          hp[0] = (bf16_t)hb;
+          if (SPLIT) hp[512] = (bf16_t)lb;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+int pt_launch_lstm(const bf16_t* gx, const bf16_t* whh, bf16_t* hout, int B, int T, int split, hipStream_t s) {
+  if (B <= 0) return PT_OK;
+  dim3 grid((B + 31) / 32, 2);
+  if (split)
+    hipLaunchKernelGGL(lstm_dir_kernel<1>, grid, dim3(256), 0, s, gx, whh, hout, B, T);
+  else
+    hipLaunchKernelGGL(lstm_dir_kernel<0>, grid, dim3(256), 0, s, gx, whh, hout, B, T);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// arg-max over the per-tile partials written by the classifier GEMM epilogue: [rows][ntiles] float2(max, idx bits)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void argmax_reduce_kernel(const float2* __restrict__ part, long long rows, int ntiles,
+                                                             int* __restrict__ ids, float* __restrict__ maxv) {
+  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long long)gridDim.x * blockDim.x) {
+    const float2* p = part + r * ntiles;
+    float bv = p[0].x;
+    int bi = __float_as_int(p[0].y);
+    for (int k = 1; k < ntiles; ++k) {
+      const float v = p[k].x;
+      const int i = __float_as_int(p[k].y);
+      if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    }
+    ids[r] = bi;
+    if (maxv) maxv[r] = bv;
+  }
+}
+
+int pt_launch_argmax_reduce(const float* part, long long rows, int ntiles, int* ids, float* maxv, hipStream_t s) {
+  if (rows <= 0) return PT_OK;
+  int blocks = (int)((rows + 255) / 256);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(argmax_reduce_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float2*>(part), rows, ntiles,
+                     ids, maxv);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}

@@ -13,7 +13,11 @@ import torch
 
 from . import lib as L
 
-__all__ = ["HipEngine"]
+__all__ = ["HipEngine", "REC_LINE_DTYPE"]
+
+# mirrors struct pt_rec_line in include/pdftable_hip.h (88 bytes)
+REC_LINE_DTYPE = np.dtype([("minv", np.float64, (9,)), ("page", np.int32), ("crop_w", np.int32), ("crop_h", np.int32),
+                           ("reserved", np.int32)])
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -130,6 +134,49 @@ class HipEngine:
             L.check(self.lib.pt_det_box_scores(self._h, _ptr(prob), n, H, W, _ptr(boxes), nb, _ptr(scores),
                                                self._stream()), "pt_det_box_scores")
         return scores
+
+    # ---- recognition ------------------------------------------------------------------------------
+    def _lines_to_device(self, lines: np.ndarray):
+        """structured array (REC_LINE_DTYPE) -> (uint8 device tensor holding the pt_rec_line records, host crop px)."""
+        lines = np.ascontiguousarray(lines)
+        assert lines.dtype == REC_LINE_DTYPE
+        px = (lines["crop_w"].astype(np.int64) * lines["crop_h"].astype(np.int64)).clip(min=0)
+        d = torch.from_numpy(lines.view(np.uint8).reshape(-1).copy()).to(self._tdev)
+        return d, np.ascontiguousarray(px)
+
+    def rec_forward(self, pages: torch.Tensor, lines: np.ndarray, want_maxlogit: bool = True):
+        """pages uint8 [n,h,w,3] on the GPU, lines: REC_LINE_DTYPE records -> (ids int32 [L,160], maxlogit f32 [L,160])."""
+        self._chk(pages, torch.uint8, "pages")
+        n, h, w, _ = pages.shape
+        nl = len(lines)
+        ids = torch.empty((nl, L.PT_REC_T), dtype=torch.int32, device=self._tdev)
+        mx = torch.empty((nl, L.PT_REC_T), dtype=torch.float32, device=self._tdev) if want_maxlogit else None
+        if nl:
+            d, px = self._lines_to_device(lines)
+            L.check(self.lib.pt_rec_forward(self._h, _ptr(pages), n, h, w, _ptr(d), px.ctypes.data_as(C.c_void_p), nl,
+                                            _ptr(ids), _ptr(mx), self._stream()), "pt_rec_forward")
+        return ids, mx
+
+    def rec_preprocess(self, pages: torch.Tensor, lines: np.ndarray) -> torch.Tensor:
+        self._chk(pages, torch.uint8, "pages")
+        n, h, w, _ = pages.shape
+        nl = len(lines)
+        shape = (nl, L.PT_REC_H, L.PT_REC_W, 2) if self.precision == L.PT_PRECISION_BF16X3 else (nl, L.PT_REC_H, L.PT_REC_W)
+        gray = torch.empty(shape, dtype=torch.bfloat16, device=self._tdev)
+        d, px = self._lines_to_device(lines)
+        L.check(self.lib.pt_rec_preprocess(self._h, _ptr(pages), n, h, w, _ptr(d), px.ctypes.data_as(C.c_void_p), nl,
+                                           _ptr(gray), self._stream()), "pt_rec_preprocess")
+        return gray
+
+    def rec_forward_net(self, gray: torch.Tensor):
+        """gray bf16 [n,32,640] (BF16X3: [n,32,640,2]) -> (ids int32 [n,160], maxlogit f32 [n,160])."""
+        self._chk(gray, torch.bfloat16, "gray")
+        n = gray.shape[0]
+        ids = torch.empty((n, L.PT_REC_T), dtype=torch.int32, device=self._tdev)
+        mx = torch.empty((n, L.PT_REC_T), dtype=torch.float32, device=self._tdev)
+        L.check(self.lib.pt_rec_forward_net(self._h, _ptr(gray), n, _ptr(ids), _ptr(mx), self._stream()),
+                "pt_rec_forward_net")
+        return ids, mx
 
     def op_conv2d(self, x: torch.Tensor, w_tiled: torch.Tensor, bias: torch.Tensor, ks: int, stride: int = 1,
                   relu: bool = False, res: Optional[torch.Tensor] = None, res_mode: int = 0, rep: int = 1,

@@ -21,6 +21,7 @@ PT_PRECISION_BF16 = 0
 PT_PRECISION_BF16X3 = 1
 PT_DET_POST_DB_PP = 0
 PT_DET_POST_DB_TORCH = 1
+PT_REC_H, PT_REC_W, PT_REC_T, PT_REC_NCLS = 32, 640, 160, 7644
 PT_PROF_CLASSES = ("conv3x3", "conv1x1", "stem", "other")
 
 _lib = None
@@ -49,6 +50,9 @@ def _proto(lib):
         "pt_det_box_scores": (i, [vp, vp, i, i, i, vp, i, vp, vp]),
         "pt_db_candidates": (i, [vp, i, i, i, f, vp, vp, i, ip]),
         "pt_db_finalize": (i, [vp, vp, i, f, f, f, i, i, i, i, i, vp, vp, i, ip]),
+        "pt_rec_forward": (i, [vp, vp, i, i, i, vp, vp, i, vp, vp, vp]),
+        "pt_rec_forward_net": (i, [vp, vp, i, vp, vp, vp]),
+        "pt_rec_preprocess": (i, [vp, vp, i, i, i, vp, vp, i, vp, vp]),
         "pt_op_conv2d": (i, [vp, vp, i, i, i, i, vp, vp, i, i, i, vp, i, i, i, i, vp, i, i, i, i, vp]),
         "pt_op_stem7x7": (i, [vp, vp, i, i, i, vp, vp, vp, i, vp]),
         "pt_op_maxpool3x3s2": (i, [vp, vp, i, i, i, i, vp, i, vp]),

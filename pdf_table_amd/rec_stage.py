@@ -1,0 +1,145 @@
+"""Batched text-line recognition stage: quad geometry on the host (vectorised numpy), everything else on the GPU.
+
+Replaces the reference's per-line Python loop (ocr_system_task.py:296-336 / modeling_ocr_pdf.py:269-302):
+``order_point`` -> ``crop_image`` (cv2 perspective warp) -> ``OCRRecognitionPreprocessor`` -> ``CRNN`` ->
+arg-max -> CTC collapse.  Here the host only computes, for all quads of a page batch at once, the ordered corners, the
+crop size and the inverse perspective matrix (an 8x8 solve per quad); cropping, resizing, the network and the
+arg-max run in one ``pt_rec_forward`` call, and only ``int32 [lines, 160]`` token ids come back.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .engine import REC_LINE_DTYPE, HipEngine
+
+__all__ = ["order_points", "crop_geometry", "perspective_inverse", "build_lines", "ctc_collapse", "RecStage",
+           "synthetic_vocab"]
+
+
+def order_points(quads: np.ndarray) -> np.ndarray:
+    """OcrCommonUtils.order_point (utils/ocr/ocr_common_utils.py:287-304) for [n, 8] / [n, 4, 2] quads at once:
+    sort the corners by angle around the centroid; rotate so that the first one is left of the centroid."""
+    a = np.asarray(quads).reshape(-1, 4, 2)
+    cen = a.sum(1) / 4                                            # same dtype rules as np.sum(arr, 0) / 4
+    theta = np.arctan2(a[:, :, 1] - cen[:, None, 1], a[:, :, 0] - cen[:, None, 0])
+    idx = np.argsort(theta, axis=1)                               # default kind, like the reference
+    sp = np.take_along_axis(a, idx[:, :, None], axis=1)
+    rot = sp[:, 0, 0] > cen[:, 0]
+    sp[rot] = np.concatenate([sp[rot][:, 3:], sp[rot][:, :3]], axis=1)
+    return sp.astype("float32")
+
+
+def _cswap(p, i, j, cond):
+    pi, pj = p[:, i].copy(), p[:, j].copy()
+    p[:, i] = np.where(cond[:, None], pj, pi)
+    p[:, j] = np.where(cond[:, None], pi, pj)
+
+
+def crop_geometry(pts: np.ndarray):
+    """The pure-Python part of crop_image (ocr_common_utils.py:224-262), vectorised over quads.
+    pts f32 [n,4,2] -> (src f32 [n,4,2], dst f32 [n,4,2], out_w int [n], out_h int [n])."""
+    p = np.asarray(pts, dtype=np.float32).reshape(-1, 4, 2).astype(np.float64)   # .tolist() gives python floats
+    for i in range(4):                       # the reference's exchange sort on x (fixed compare-exchange sequence)
+        for j in range(i + 1, 4):
+            _cswap(p, i, j, p[:, i, 0] > p[:, j, 0])
+    _cswap(p, 0, 1, p[:, 0, 1] > p[:, 1, 1])
+    _cswap(p, 2, 3, p[:, 2, 1] > p[:, 3, 1])
+    x1, y1 = p[:, 0, 0], p[:, 0, 1]
+    x2, y2 = p[:, 2, 0], p[:, 2, 1]
+    x3, y3 = p[:, 3, 0], p[:, 3, 1]
+    x4, y4 = p[:, 1, 0], p[:, 1, 1]
+    src = np.stack([np.stack([x1, y1], 1), np.stack([x2, y2], 1), np.stack([x4, y4], 1), np.stack([x3, y3], 1)], 1)
+    src = src.astype(np.float32)
+
+    def dist(ax, ay, bx, by):
+        return np.sqrt((ax - bx) ** 2 + (ay - by) ** 2)
+    iw = dist((x1 + x4) / 2, (y1 + y4) / 2, (x2 + x3) / 2, (y2 + y3) / 2)
+    ih = dist((x1 + x2) / 2, (y1 + y2) / 2, (x4 + x3) / 2, (y4 + y3) / 2)
+    z = np.zeros_like(iw)
+    dst = np.stack([np.stack([z, z], 1), np.stack([iw - 1, z], 1), np.stack([z, ih - 1], 1), np.stack([iw - 1, ih - 1], 1)], 1)
+    return src, dst.astype(np.float32), iw.astype(np.int64), ih.astype(np.int64)      # int() truncates
+
+
+def perspective_inverse(src: np.ndarray, dst: np.ndarray) -> np.ndarray:
+    """cv2.getPerspectiveTransform(src, dst) (8x8 system, float64) and its 3x3 inverse, batched: -> [n, 9] float64.
+    Degenerate quads (singular system) yield all-zero matrices (their crops are empty or constant)."""
+    n = src.shape[0]
+    s = src.astype(np.float64)
+    d = dst.astype(np.float64)
+    a = np.zeros((n, 8, 8))
+    b = np.zeros((n, 8))
+    for i in range(4):
+        a[:, i, 0] = a[:, i + 4, 3] = s[:, i, 0]
+        a[:, i, 1] = a[:, i + 4, 4] = s[:, i, 1]
+        a[:, i, 2] = a[:, i + 4, 5] = 1
+        a[:, i, 6] = -s[:, i, 0] * d[:, i, 0]
+        a[:, i, 7] = -s[:, i, 1] * d[:, i, 0]
+        a[:, i + 4, 6] = -s[:, i, 0] * d[:, i, 1]
+        a[:, i + 4, 7] = -s[:, i, 1] * d[:, i, 1]
+        b[:, i] = d[:, i, 0]
+        b[:, i + 4] = d[:, i, 1]
+    out = np.zeros((n, 9))
+    for k in range(n):                     # per-quad so that one singular system does not poison the batch
+        try:
+            m = np.append(np.linalg.solve(a[k], b[k]), 1.0).reshape(3, 3)
+            out[k] = np.linalg.inv(m).reshape(-1)
+        except np.linalg.LinAlgError:
+            pass
+    return out
+
+
+def build_lines(boxes_per_page: Sequence[np.ndarray]) -> np.ndarray:
+    """Detection boxes ([k,8] per page, source pixels) -> pt_rec_line records for every line of the batch."""
+    counts = [len(b) for b in boxes_per_page]
+    tot = sum(counts)
+    lines = np.zeros(tot, dtype=REC_LINE_DTYPE)
+    if tot == 0:
+        return lines
+    allb = np.concatenate([np.asarray(b, dtype=np.float64).reshape(-1, 8) for b in boxes_per_page if len(b)], 0)
+    pts = order_points(allb)
+    src, dst, ow, oh = crop_geometry(pts)
+    lines["minv"] = perspective_inverse(src, dst)
+    lines["page"] = np.repeat(np.arange(len(counts)), counts)
+    lines["crop_w"] = np.clip(ow, 0, 1 << 20)
+    lines["crop_h"] = np.clip(oh, 0, 1 << 20)
+    return lines
+
+
+def ctc_collapse(ids: np.ndarray) -> List[List[int]]:
+    """OCRRecognition.postprocess after the arg-max (modeling_ocr_recognition.py:172-182): drop repeats, drop 0."""
+    ids = np.asarray(ids)
+    prev = np.concatenate([np.zeros((ids.shape[0], 1), ids.dtype), ids[:, :-1]], 1)
+    keep = (ids != prev) & (ids != 0)
+    return [row[k].tolist() for row, k in zip(ids, keep)]
+
+
+def synthetic_vocab(n: int = L.PT_REC_NCLS - 1) -> List[str]:
+    """Stand-in for vocab.txt (not available offline): n distinct CJK code points."""
+    return [chr(0x4E00 + i) for i in range(n)]
+
+
+class RecStage:
+    def __init__(self, eng: HipEngine, vocab: Optional[Sequence[str]] = None):
+        self.eng = eng
+        vocab = list(vocab) if vocab is not None else synthetic_vocab()
+        # labelMapping starts at 1 for CRNN (do_chunking False): modeling_ocr_recognition.py:119-132
+        self.label = {i + 1: ch for i, ch in enumerate(vocab)}
+
+    def ids(self, pages: torch.Tensor, boxes_per_page: Sequence[np.ndarray]):
+        lines = build_lines(boxes_per_page)
+        ids, _ = self.eng.rec_forward(pages, lines, want_maxlogit=False)
+        return ids, lines
+
+    def __call__(self, pages: torch.Tensor, boxes_per_page: Sequence[np.ndarray]) -> List[List[str]]:
+        ids, lines = self.ids(pages, boxes_per_page)
+        toks = ctc_collapse(ids.cpu().numpy()) if len(lines) else []
+        texts = ["".join(self.label.get(t, "") for t in row) for row in toks]
+        out, o = [], 0
+        for b in boxes_per_page:
+            out.append(texts[o:o + len(b)])
+            o += len(b)
+        return out

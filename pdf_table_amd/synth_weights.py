@@ -60,14 +60,14 @@ class _Gen:
         self.put(name + ".running_var", self.rng.uniform(0.5, 1.5, (c,)))
         self.sd[name + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
 
-    def linear(self, name, cout, cin, bias=True):
-        k = 1.0 / math.sqrt(cin)
+    def linear(self, name, cout, cin, bias=True, scale=1.0):
+        k = scale / math.sqrt(cin)
         self.put(name + ".weight", self.rng.uniform(-k, k, (cout, cin)))
         if bias:
             self.put(name + ".bias", self.rng.uniform(-k, k, (cout,)))
 
-    def lstm(self, name, nin, nh):
-        k = 1.0 / math.sqrt(nh)
+    def lstm(self, name, nin, nh, scale=1.0):
+        k = scale / math.sqrt(nh)
         for sfx in ("", "_reverse"):
             self.put(f"{name}.weight_ih_l0{sfx}", self.rng.uniform(-k, k, (4 * nh, nin)))
             self.put(f"{name}.weight_hh_l0{sfx}", self.rng.uniform(-k, k, (4 * nh, nh)))
@@ -138,9 +138,11 @@ def crnn_state_dict(seed: int = 0, num_classes: int = CRNN_NUM_CLASSES):
     g.bn("conv3.4", 512)
     g.conv("conv4.0", 512, 512, 2, 1, bias=True)
     g.bn("conv4.1", 512)
-    g.lstm("rnn.0.rnn", 512, 256)
-    g.linear("rnn.0.embedding", 256, 512)
-    g.lstm("rnn.1.rnn", 256, 256)
-    g.linear("rnn.1.embedding", 512, 512)
-    g.linear("cls", num_classes, 512, bias=False)
+    # larger-than-default scales so that the recurrent state really depends on the input and the logits are O(1)
+    # with a time-varying arg-max (default nn.LSTM/Linear init gives |logit| ~ 0.02 and a constant arg-max)
+    g.lstm("rnn.0.rnn", 512, 256, scale=2.0)
+    g.linear("rnn.0.embedding", 256, 512, scale=4.0)
+    g.lstm("rnn.1.rnn", 256, 256, scale=3.0)
+    g.linear("rnn.1.embedding", 512, 512, scale=4.0)
+    g.linear("cls", num_classes, 512, bias=False, scale=4.0)
     return g.sd

@@ -151,5 +151,40 @@ def pack_db_resnet18(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
     return bl.tobytes()
 
 
-def pack_crnn(sd: Dict[str, torch.Tensor]) -> bytes:  # filled in by the recognition stage
-    raise NotImplementedError("CRNN packing lands with the recognition stage")
+def pack_crnn(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
+    """``CRNN`` state_dict (crnn/modeling_crnn.py:40-90) -> blob for PT_MODEL_CRNN.
+
+    conv0 (K = 9) stays fp32 for the VALU kernel; conv4's (2,1) kernel is flattened to a 1x1 GEMM over
+    K = kh*512 + ci (the preceding pool writes H into channels); each LSTM's two directions share one input
+    projection GEMM (N = 2048, both biases folded in); W_hh is stored [hi|lo][dir][1024][256]; the classifier is
+    padded from 7644 to 7680 classes with zero weights and a -3e38 bias so that padding can never win the arg-max."""
+    bl = _Blob(x3)
+    w0, b0 = fold_conv_bn(sd, "conv0.0", "conv0.1")
+    bl.add("conv0.wf32", w0.reshape(64, 9).numpy().astype(np.float32), "f32")
+    bl.add("conv0.wbf", w0.reshape(64, 9).to(torch.bfloat16).float().numpy(), "f32")
+    bl.add("conv0.b", b0.numpy(), "f32")
+    for name, cv, bn in (("conv1", "conv1.0", "conv1.1"), ("conv2a", "conv2.0", "conv2.1"), ("conv2b", "conv2.3", "conv2.4"),
+                         ("conv3a", "conv3.0", "conv3.1"), ("conv3b", "conv3.3", "conv3.4")):
+        bl.add_conv(name, *fold_conv_bn(sd, cv, bn))
+    w4, b4 = fold_conv_bn(sd, "conv4.0", "conv4.1")            # [512, 512, 2, 1]
+    bl.add_conv("conv4", w4[:, :, :, 0].permute(0, 2, 1).reshape(512, 1024, 1, 1), b4)
+    for li, p in ((1, "rnn.0"), (2, "rnn.1")):
+        r = p + ".rnn."
+        wih = torch.cat([sd[r + "weight_ih_l0"], sd[r + "weight_ih_l0_reverse"]], 0)
+        bias = torch.cat([sd[r + "bias_ih_l0"] + sd[r + "bias_hh_l0"],
+                          sd[r + "bias_ih_l0_reverse"] + sd[r + "bias_hh_l0_reverse"]], 0)
+        bl.add_conv(f"lstm{li}.xproj", wih.reshape(2048, -1, 1, 1).float(), bias.float())
+        whh = torch.stack([sd[r + "weight_hh_l0"], sd[r + "weight_hh_l0_reverse"]], 0).float()   # [2, 1024, 256]
+        hi, lo = split_bf16(whh)
+        bl.add(f"lstm{li}.whh", np.stack([to_bf16_bits(hi), to_bf16_bits(lo)]), "bf16")
+        we = sd[p + ".embedding.weight"].float()
+        bl.add_conv(f"lstm{li}.emb", we.reshape(we.shape[0], we.shape[1], 1, 1), sd[p + ".embedding.bias"].float())
+    wc = sd["cls.weight"].float()
+    ncls = wc.shape[0]
+    npad = (ncls + 63) // 64 * 64
+    wpad = torch.zeros(npad, wc.shape[1])
+    wpad[:ncls] = wc
+    bpad = torch.zeros(npad)
+    bpad[ncls:] = -3.0e38
+    bl.add_conv("cls", wpad.reshape(npad, wc.shape[1], 1, 1), bpad)
+    return bl.tobytes()

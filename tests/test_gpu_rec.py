@@ -1,0 +1,147 @@
+"""GPU parity tests of the recognition stage (crop -> resize -> CRNN -> arg-max) through the C ABI.
+
+Integer work (crop/resize pixels, token ids) bit-exact; float work (winning logit) within 1e-3 of the oracle's fp32
+restatement in PT_PRECISION_BF16X3; token ids may differ from the oracle's only where the oracle's own top-2 margin
+is inside that tolerance."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import crnn as ocrnn
+from pdf_table_amd import lib as L
+from pdf_table_amd import rec_stage as R
+from pdf_table_amd.synth_pages import make_page
+from pdf_table_amd.synth_weights import crnn_state_dict
+from pdf_table_amd.weights import pack_crnn
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return crnn_state_dict(seed=12)
+
+
+@pytest.fixture(scope="module")
+def eng(sd):
+    from pdf_table_amd.engine import HipEngine
+    e = HipEngine(0)
+    e.load_weights(L.PT_MODEL_CRNN, pack_crnn(sd))
+    yield e
+    e.close()
+
+
+def _page_and_boxes(idx=3, k=12):
+    img, meta = make_page(idx)
+    rng = np.random.default_rng(idx)
+    boxes = []
+    for (x0, y0, x1, y1) in meta["lines"][:k]:
+        jit = rng.uniform(-1.5, 1.5, 8)
+        q = np.array([x0 - 2, y0 - 2, x1 + 2, y0 - 2, x1 + 2, y1 + 2, x0 - 2, y1 + 2], np.float64) + jit
+        boxes.append(np.round(q))
+    # one rotated quad and one tall (ratio < 1) quad
+    boxes.append(np.array([100, 400, 380, 430, 376, 462, 96, 432], np.float64))
+    boxes.append(np.array([500, 300, 520, 300, 520, 380, 500, 380], np.float64))
+    return img, np.array(boxes)
+
+
+def _oracle_gray(img, box):
+    crop = ocrnn.crop_image(img, ocrnn.order_point(box))
+    x = ocrnn.rec_preprocess(crop)                                        # [1,3,32,640] fp32
+    return (x[:, 0:1] * 0.2989 + x[:, 1:2] * 0.5870 + x[:, 2:3] * 0.1140)[0, 0], x
+
+
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+def test_rec_preprocess_bit_exact(eng, mode):
+    eng.set_precision(L.PT_PRECISION_BF16X3 if mode == "bf16x3" else L.PT_PRECISION_BF16)
+    try:
+        img, boxes = _page_and_boxes()
+        lines = R.build_lines([boxes])
+        gray = eng.rec_preprocess(torch.from_numpy(img[None]).cuda(), lines)
+        torch.cuda.synchronize()
+        g = gray.float().cpu()
+        for i, b in enumerate(boxes):
+            ref, _ = _oracle_gray(img, b)
+            if mode == "bf16":
+                want = ref.to(torch.bfloat16).float()
+                assert torch.equal(g[i], want), f"line {i}: {(g[i] - want).abs().max()}"
+            else:
+                hi = ref.to(torch.bfloat16).float()
+                lo = (ref - hi).to(torch.bfloat16).float()
+                assert torch.equal(g[i, :, :, 0], hi) and torch.equal(g[i, :, :, 1], lo)
+    finally:
+        eng.set_precision(L.PT_PRECISION_BF16)
+
+
+def test_rec_net_x3_matches_fp32_oracle(eng, sd):
+    eng.set_precision(L.PT_PRECISION_BF16X3)
+    try:
+        rng = np.random.default_rng(7)
+        x = rng.uniform(0, 1, (5, 3, 32, 640)).astype(np.float32)
+        x[1, :, :, 300:] = 0
+        x[2, :, :, 90:] = 0
+        x[4] = 0
+        xt = torch.from_numpy(x)
+        gray = xt[:, 0] * 0.2989 + xt[:, 1] * 0.5870 + xt[:, 2] * 0.1140
+        with torch.no_grad():
+            logits = ocrnn.crnn_forward_fp32(sd, xt)
+        top2 = torch.topk(logits, 2, dim=-1)
+        hi = gray.to(torch.bfloat16)
+        lo = (gray - hi.float()).to(torch.bfloat16)
+        ids, mx = eng.rec_forward_net(torch.stack([hi, lo], -1).contiguous().cuda())
+        torch.cuda.synchronize()
+        ids, mx = ids.cpu(), mx.cpu()
+        dmax = (mx - top2.values[..., 0]).abs().max().item()
+        margin = top2.values[..., 0] - top2.values[..., 1]
+        diff = ids != top2.indices[..., 0]
+        print(f"crnn x3: max|d max-logit| = {dmax:.2e}; {int(diff.sum())} of {ids.numel()} ids differ; "
+              f"min margin {margin.min().item():.2e}")
+        assert dmax <= TOL
+        assert bool((margin[diff] <= 2 * TOL).all())
+        assert float(diff.float().mean()) < 0.01
+        assert R.ctc_collapse(ids.numpy()) == ocrnn.ctc_greedy_ids(ids.numpy())
+    finally:
+        eng.set_precision(L.PT_PRECISION_BF16)
+
+
+def test_rec_net_bf16_close(eng, sd):
+    """Throughput mode: bf16-class drift on the winning logit; ids agree wherever the oracle's margin is clear."""
+    rng = np.random.default_rng(8)
+    x = rng.uniform(0, 1, (3, 3, 32, 640)).astype(np.float32)
+    xt = torch.from_numpy(x)
+    gray = (xt[:, 0] * 0.2989 + xt[:, 1] * 0.5870 + xt[:, 2] * 0.1140).to(torch.bfloat16)
+    with torch.no_grad():
+        logits = ocrnn.crnn_forward_fp32(sd, xt)
+    top2 = torch.topk(logits, 2, dim=-1)
+    ids, mx = eng.rec_forward_net(gray.contiguous().cuda())
+    ids, mx = ids.cpu(), mx.cpu()
+    scale = logits.abs().max().item()
+    dmax = (mx - top2.values[..., 0]).abs().max().item()
+    margin = top2.values[..., 0] - top2.values[..., 1]
+    diff = ids != top2.indices[..., 0]
+    print(f"crnn bf16: max|d max-logit| = {dmax:.2e} (scale {scale:.1f}); {int(diff.sum())} of {ids.numel()} ids differ")
+    assert dmax <= 0.06 * scale
+    assert bool((margin[diff] <= 0.12 * scale).all())
+
+
+def test_rec_end_to_end_x3(eng, sd):
+    """pages + quads -> pt_rec_forward (crop, resize, net, arg-max) vs the oracle run line by line like the reference."""
+    eng.set_precision(L.PT_PRECISION_BF16X3)
+    try:
+        img, boxes = _page_and_boxes(idx=4, k=6)
+        stage = R.RecStage(eng)
+        ids, lines = stage.ids(torch.from_numpy(img[None]).cuda(), [boxes])
+        ids = ids.cpu().numpy()
+        for i, b in enumerate(boxes):
+            _, x = _oracle_gray(img, b)
+            with torch.no_grad():
+                logits = ocrnn.crnn_forward_fp32(sd, x)[0]
+            top2 = torch.topk(logits, 2, dim=-1)
+            margin = (top2.values[:, 0] - top2.values[:, 1]).numpy()
+            d = ids[i] != top2.indices[:, 0].numpy()
+            assert (margin[d] <= 2 * TOL).all(), (i, margin[d])
+        texts = stage(torch.from_numpy(img[None]).cuda(), [boxes])
+        assert len(texts) == 1 and len(texts[0]) == len(boxes)
+    finally:
+        eng.set_precision(L.PT_PRECISION_BF16)
