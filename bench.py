@@ -36,7 +36,7 @@ MFMA_PEAK_TFLOPS = 2500.0        # dense bf16, /opt/skills/guides/MI355X_MICROAR
 DB_GFLOP_960 = 111.71            # DB-ResNet18 at the reference-preprocessed 960x960
 
 
-def cpu_baseline(sd, pages_np, cfg):
+def cpu_baseline(sd, pages_np, cfg, csd=None, quads=None, max_lines=12):
     """The oracle (port of the reference CPU path: fp32 torch ops in the reference's op order + numpy/python
     pre/post) on the host cores, batch 1 per call as the reference runs it."""
     from oracle import db_net, db_post, db_pre
@@ -62,10 +62,31 @@ def cpu_baseline(sd, pages_np, cfg):
         t_post += t3 - t2
         nboxes += len(boxes)
     dt = t_pre + t_net + t_post
+    rec_note = ""
+    if csd is not None:
+        # recognition: one call per text line like the reference (ocr_system_task.py:309-320); timed on a bounded
+        # number of lines and scaled to the page's line count
+        from oracle import crnn as ocrnn
+        t_rec, nl = 0.0, 0
+        lines_total = sum(len(q) for q in quads)
+        for img, qs in zip(pages_np, quads):
+            for q in qs[:max_lines]:
+                t0 = time.time()
+                crop = ocrnn.crop_image(img, ocrnn.order_point(q))
+                x = ocrnn.rec_preprocess(crop)
+                with torch.no_grad():
+                    ocrnn.ctc_greedy_ids(ocrnn.crnn_forward_fp32(csd, x).numpy())
+                t_rec += time.time() - t0
+                nl += 1
+        per_line = t_rec / max(1, nl)
+        dt += per_line * lines_total
+        rec_note = (f"; recognition {per_line:.3f} s/line measured on {nl} lines (crop + CRNN fp32 with a Python-loop LSTM "
+                    f"+ CTC), scaled to {lines_total / n:.0f} lines/page")
     return {"value": n / dt, "unit": "pages/s", "cores": cores, "kind": "port",
-            "sample": f"{n} synthetic 1024x1024 pages, DB det stage, batch 1 per call as the reference runs it, "
-                      f"torch.set_num_threads({cores}); per page: pre (numpy) {t_pre / n:.2f} s, DB-ResNet18 fp32 "
-                      f"(torch CPU) {t_net / n:.2f} s, post (pure-Python restatement of cv2/pyclipper) {t_post / n:.2f} s",
+            "sample": f"{n} synthetic 1024x1024 pages, batch 1 per call as the reference runs it, "
+                      f"torch.set_num_threads({cores}); per page: det pre (numpy) {t_pre / n:.2f} s, DB-ResNet18 fp32 "
+                      f"(torch CPU) {t_net / n:.2f} s, det post (pure-Python restatement of cv2/pyclipper) {t_post / n:.2f} s"
+                      + rec_note,
             "net_only_pages_per_s": n / t_net}
 
 
@@ -76,6 +97,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-post", action="store_true", help="device half only (diagnostic; not a valid headline)")
+    ap.add_argument("--stages", default=os.environ.get("PT_BENCH_STAGES", "det,rec"),
+                    help="comma list of stages in the timed step: det (configs[1]) and/or rec")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -96,7 +119,9 @@ def main():
     from pdf_table_amd.engine import HipEngine
     from pdf_table_amd.synth_pages import make_page
     from pdf_table_amd.synth_weights import db_resnet18_state_dict
-    from pdf_table_amd.weights import pack_db_resnet18
+    from pdf_table_amd.weights import pack_crnn, pack_db_resnet18
+    stages = [x for x in args.stages.split(",") if x]
+    assert set(stages) <= {"det", "rec"} and stages
 
     eng = HipEngine(local_rank)
     # weights: packed once on rank 0, broadcast over RCCL/xGMI, loaded from device memory everywhere
@@ -108,12 +133,32 @@ def main():
     else:
         eng.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(sd, x3=False))
 
+    rec = None
+    if "rec" in stages:
+        from pdf_table_amd.rec_stage import RecStage, build_lines
+        from pdf_table_amd.synth_weights import crnn_state_dict
+        csd = crnn_state_dict(seed=1) if rank == 0 or world == 1 else None
+        if world > 1:
+            from pdf_table_amd.dist_utils import broadcast_blob
+            eng.load_weights_device(L.PT_MODEL_CRNN, broadcast_blob(pack_crnn(csd, x3=False) if rank == 0 else None, dev))
+        else:
+            eng.load_weights(L.PT_MODEL_CRNN, pack_crnn(csd, x3=False))
+        rec = RecStage(eng)
+
     # pages: rank r owns pages [r*P, (r+1)*P) of the global batch (static contiguous shard, dist_utils.shard_range)
     from pdf_table_amd.dist_utils import shard_range
     lo, hi = shard_range(world * PAGES_PER_STEP, rank, world)
     assert hi - lo == PAGES_PER_STEP
-    base = [make_page(rank * DISTINCT + i, PAGE)[0] for i in range(DISTINCT)]
+    made = [make_page(rank * DISTINCT + i, PAGE) for i in range(DISTINCT)]
+    base = [m[0] for m in made]
     pages_np = np.stack([base[i % DISTINCT] for i in range(PAGES_PER_STEP)])
+    # Recognition input: the DB weights are random-init, so its boxes are not text.  The recogniser is fed the
+    # generator's own text-line rectangles (60-140 per page) as 4-point quads instead.
+    gt_quads = []
+    for i in range(PAGES_PER_STEP):
+        l = made[i % DISTINCT][1]["lines"].astype(np.float64)
+        gt_quads.append(np.stack([l[:, 0], l[:, 1], l[:, 2], l[:, 1], l[:, 2], l[:, 3], l[:, 0], l[:, 3]], 1))
+    lines_per_page = float(np.mean([len(q) for q in gt_quads]))
     pages = torch.from_numpy(pages_np).to(dev)
     cfg = DetConfig(flavour="db_pp", thresh=0.3, box_thresh=0.6, unclip_ratio=1.5)
     stage = DetStage(eng, cfg)
@@ -125,17 +170,26 @@ def main():
         torch.cuda.synchronize()
 
     nboxes = 0
+    ntok = 0
 
     def run(steps, count=False):
         """software pipeline: device half of step k+1 is enqueued before the host half of step k"""
-        nonlocal nboxes
+        nonlocal nboxes, ntok
         prev = None
         for k in range(steps):
-            cur = stage.forward(pages, slot=k & 1)
+            cur = stage.forward(pages, slot=k & 1) if "det" in stages else None
+            rec_ids = None
+            if rec is not None:
+                rec_ids, _ = rec.ids(pages, gt_quads)          # host quad geometry + one pt_rec_forward (async)
             if prev is not None and not args.no_post:
                 res = stage.boxes(prev[0], prev[1], (PAGE, PAGE), prev[2])
                 if count:
                     nboxes += sum(len(r) for r in res)
+            if rec_ids is not None:
+                from pdf_table_amd.rec_stage import ctc_collapse
+                toks = ctc_collapse(rec_ids.cpu().numpy())     # D2H of int32 [lines, 160] + host collapse
+                if count:
+                    ntok += sum(len(t) for t in toks)
             prev = cur
         if prev is not None and not args.no_post:
             res = stage.boxes(prev[0], prev[1], (PAGE, PAGE), prev[2])
@@ -178,16 +232,23 @@ def main():
         out = {"metric": "pages/s", "value": value, "unit": "pages/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": "BASELINE.json configs[1]: batched DB text detection (db_pp pre/post around "
-                                      "DB-ResNet18), 1024x1024 synthetic pages -> 960x960 net input, boxes out"
-                                      + (" [DEVICE HALF ONLY]" if args.no_post else ""),
+               "config": {"workload": ("BASELINE.json configs[1] batched DB text detection (db_pp pre/post around "
+                                       "DB-ResNet18, 1024x1024 synthetic pages -> 960x960 net input, boxes out)"
+                                       if "det" in stages else "")
+                                      + (" + CRNN text-line recognition of the page's text lines (crop, resize, CRNN, "
+                                         "arg-max, CTC collapse)" if "rec" in stages else "")
+                                      + (" [DEVICE HALF ONLY]" if args.no_post else "")
+                                      + "; layout (PicoDet) and TSR (Lore) stages are not built yet",
                           "pages_per_step_per_gpu": PAGES_PER_STEP, "page": [PAGE, PAGE],
-                          "stages": ["det"], "parallelism": f"page-shard x{world}",
+                          "stages": stages, "parallelism": f"page-shard x{world}",
+                          "text_lines_per_page": lines_per_page if "rec" in stages else 0,
+                          "tokens_per_page": ntok / max(1, PAGES_PER_STEP * args.steps),
                           "boxes_per_page": nboxes / max(1, PAGES_PER_STEP * args.steps),
                           "weights": "seeded random init (reference state_dict layout)"},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, pages_np[:2], cfg)
+            out["cpu_baseline"] = cpu_baseline(sd, pages_np[:2], cfg, csd if rec is not None else None,
+                                               gt_quads[:2] if rec is not None else None)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

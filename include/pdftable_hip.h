@@ -149,6 +149,11 @@ typedef struct pt_rec_line {
  * (ocr_system_task.py:296-336, ocr_recognition_task.py:81-136) and the arg-max of OCRRecognition.postprocess. */
 int pt_rec_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int h, int w, const pt_rec_line* d_lines,
                    const int64_t* h_crop_px, int n_lines, int32_t* d_ids, float* d_maxlogit, pt_stream stream);
+/* Same, for lines that are ALREADY cropped (what OcrRecognitionTask.__call__ receives, ocr_recognition_task.py:67-79):
+ * d_crops_rgb is the concatenation of the n_lines uint8 [crop_h, crop_w, 3] images; only crop_w / crop_h of d_lines
+ * are read.  Resize (OCRRecognitionPreprocessor.keepratio_resize) + CRNN + arg-max. */
+int pt_rec_forward_crops(pt_engine* e, const uint8_t* d_crops_rgb, const pt_rec_line* d_lines, const int64_t* h_crop_px,
+                         int n_lines, int32_t* d_ids, float* d_maxlogit, pt_stream stream);
 /* Network only: d_gray bf16 [n, 32, 640] (BF16X3 mode: [n, 32, 640, 2] = hi, lo), values in [0, 1]. */
 int pt_rec_forward_net(pt_engine* e, const uint16_t* d_gray, int n, int32_t* d_ids, float* d_maxlogit, pt_stream stream);
 /* Crop + resize + gray only (tests): writes d_gray as above. */

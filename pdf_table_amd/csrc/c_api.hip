@@ -283,7 +283,7 @@ static int rec_microbatch() {
   static int mb = -1;
   if (mb < 0) {
     const char* s = getenv("PT_REC_MICROBATCH");
-    mb = s ? atoi(s) : 512;
+    mb = s ? atoi(s) : 4096;  // many lines per launch: the LSTM kernel has only lines/32 x 2 workgroups
     if (mb < 1) mb = 1;
   }
   return mb;
@@ -334,6 +334,35 @@ int pt_rec_forward_net(pt_engine* e, const uint16_t* d_gray, int n, int32_t* d_i
     const int nb = (n - i0) < mb ? (n - i0) : mb;
     int rc = pt_crnn_forward_net(e, d_gray + (size_t)i0 * per_line, nb, d_ids + (size_t)i0 * PT_REC_T,
                                  d_maxlogit ? d_maxlogit + (size_t)i0 * PT_REC_T : nullptr, s);
+    if (rc != PT_OK) return rc;
+  }
+  return PT_OK;
+}
+
+int pt_rec_forward_crops(pt_engine* e, const uint8_t* d_crops_rgb, const pt_rec_line* d_lines, const int64_t* h_crop_px,
+                         int n_lines, int32_t* d_ids, float* d_maxlogit, pt_stream stream) {
+  PT_REQUIRE(e && d_crops_rgb && d_lines && h_crop_px && d_ids && n_lines > 0, "pt_rec_forward_crops: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int mb = rec_microbatch();
+  const int x3 = e->precision == PT_PRECISION_BF16X3;
+  const size_t per_line = (size_t)PT_REC_H * PT_REC_W * (x3 ? 2 : 1);
+  int rc;
+  if ((rc = ensure(&e->rec_gray, &e->rec_gray_cap, (size_t)(mb < n_lines ? mb : n_lines) * per_line * sizeof(bf16_t))) != PT_OK)
+    return rc;
+  std::vector<long long>& off = e->rec_off_host;
+  off.assign((size_t)n_lines + 1, 0);
+  for (int i = 0; i < n_lines; ++i) off[i + 1] = off[i] + (h_crop_px[i] > 0 ? h_crop_px[i] : 0);
+  if ((rc = ensure(&e->rec_off, &e->rec_off_cap, (size_t)(n_lines + 1) * sizeof(long long))) != PT_OK) return rc;
+  PT_HIP_CHECK(hipMemcpyAsync(e->rec_off, off.data(), (size_t)(n_lines + 1) * sizeof(long long), hipMemcpyHostToDevice, s));
+  PT_HIP_CHECK(hipStreamSynchronize(s));
+  const long long* d_off = reinterpret_cast<const long long*>(e->rec_off);
+  for (int i0 = 0; i0 < n_lines; i0 += mb) {
+    const int nb = (n_lines - i0) < mb ? (n_lines - i0) : mb;
+    rc = pt_launch_rec_resize_gray(d_crops_rgb, d_lines + i0, d_off + i0, nb, x3, reinterpret_cast<bf16_t*>(e->rec_gray), s);
+    if (rc != PT_OK) return rc;
+    rc = pt_crnn_forward_net(e, reinterpret_cast<const bf16_t*>(e->rec_gray), nb, d_ids + (size_t)i0 * PT_REC_T,
+                             d_maxlogit ? d_maxlogit + (size_t)i0 * PT_REC_T : nullptr, s);
     if (rc != PT_OK) return rc;
   }
   return PT_OK;

@@ -332,7 +332,7 @@ int pt_launch_maxpool_kxk(const bf16_t* in, int n, int H, int W, int C, int kh, 
 // hi/lo pair) as next step's A operand and to HBM as the layer output.  W_hh fragments stream from L2.
 // ---------------------------------------------------------------------------------------------------
 template <int SPLIT>
-__global__ __launch_bounds__(256, 1) void lstm_dir_kernel(const bf16_t* __restrict__ gx, const bf16_t* __restrict__ whh,
+__global__ __launch_bounds__(256, 2) void lstm_dir_kernel(const bf16_t* __restrict__ gx, const bf16_t* __restrict__ whh,
                                                            bf16_t* __restrict__ hout, int B, int T) {
   constexpr int NP = SPLIT ? 2 : 1;
   constexpr int HROW = 264;  // 256 + 8 bf16: 528-byte rows = 33 16-byte slots (odd) -> conflict-free b128 reads

@@ -6,7 +6,7 @@ the HIP stream; every compute call goes through the C ABI of libpdftable_hip.so.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -155,6 +155,23 @@ class HipEngine:
             d, px = self._lines_to_device(lines)
             L.check(self.lib.pt_rec_forward(self._h, _ptr(pages), n, h, w, _ptr(d), px.ctypes.data_as(C.c_void_p), nl,
                                             _ptr(ids), _ptr(mx), self._stream()), "pt_rec_forward")
+        return ids, mx
+
+    def rec_forward_crops(self, crops: Sequence[np.ndarray]):
+        """already-cropped RGB uint8 images (any sizes) -> (ids int32 [L,160], maxlogit f32 [L,160])."""
+        nl = len(crops)
+        lines = np.zeros(nl, dtype=REC_LINE_DTYPE)
+        lines["crop_w"] = [c.shape[1] for c in crops]
+        lines["crop_h"] = [c.shape[0] for c in crops]
+        flat = np.concatenate([np.ascontiguousarray(c[:, :, :3], dtype=np.uint8).reshape(-1) for c in crops]) if nl else \
+            np.zeros(0, np.uint8)
+        ids = torch.empty((nl, L.PT_REC_T), dtype=torch.int32, device=self._tdev)
+        mx = torch.empty((nl, L.PT_REC_T), dtype=torch.float32, device=self._tdev)
+        if nl:
+            d, px = self._lines_to_device(lines)
+            dc = torch.from_numpy(flat).to(self._tdev)
+            L.check(self.lib.pt_rec_forward_crops(self._h, _ptr(dc), _ptr(d), px.ctypes.data_as(C.c_void_p), nl, _ptr(ids),
+                                                  _ptr(mx), self._stream()), "pt_rec_forward_crops")
         return ids, mx
 
     def rec_preprocess(self, pages: torch.Tensor, lines: np.ndarray) -> torch.Tensor:

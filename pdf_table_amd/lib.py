@@ -51,6 +51,7 @@ def _proto(lib):
         "pt_db_candidates": (i, [vp, i, i, i, f, vp, vp, i, ip]),
         "pt_db_finalize": (i, [vp, vp, i, f, f, f, i, i, i, i, i, vp, vp, i, ip]),
         "pt_rec_forward": (i, [vp, vp, i, i, i, vp, vp, i, vp, vp, vp]),
+        "pt_rec_forward_crops": (i, [vp, vp, vp, vp, i, vp, vp, vp]),
         "pt_rec_forward_net": (i, [vp, vp, i, vp, vp, vp]),
         "pt_rec_preprocess": (i, [vp, vp, i, i, i, vp, vp, i, vp, vp]),
         "pt_op_conv2d": (i, [vp, vp, i, i, i, i, vp, vp, i, i, i, vp, i, i, i, i, vp, i, i, i, i, vp]),

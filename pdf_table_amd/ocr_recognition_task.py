@@ -1,0 +1,110 @@
+"""``OcrRecognitionTask`` on the HIP engine -- drop-in for the reference's stage-3 plug-in.
+
+Reference: src/pdftable/model/ocr_pdf/ocr_recognition_task.py:28-136.  Same constructor (``task, model, task_type``),
+same result (one string per input crop), same ``RuntimeError`` for an unknown model (:47).  ``model="CRNN"`` (the
+in-tree torch recogniser) is served; ``ConvNextViT`` / ``LightweightEdge`` and the PP-OCR ONNX recognisers are not
+built on the engine yet and fail loudly, naming the hub id the reference would have fetched.
+
+Two ways in:
+  * reference-shaped: ``task(crop_or_list_of_crops)`` -- every crop is an RGB image (path / PIL / ndarray) exactly as
+    ``OcrSystemTask.text_recognition`` passes it (ocr_system_task.py:309-320); all crops of the call go through one
+    ``pt_rec_forward_crops`` (ragged batch);
+  * batched: ``task.recognize_quads(pages_gpu, boxes_per_page)`` -- quads are cut out of the resident pages on the
+    device (no host crop at all); this is what ``OcrTablePipeline`` and ``bench.py`` use.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .base_infer_task import BaseInferTask
+from .engine import HipEngine
+from .ocr_detection_task import _read_image
+from .rec_stage import RecStage
+from .weights import pack_crnn
+
+__all__ = ["OcrRecognitionTask"]
+
+
+class _RecCfg:
+    def __init__(self, recognizer, task_type):
+        self.recognizer = recognizer
+        self.task_type = "general" if recognizer in ("CRNN", "LightweightEdge") else task_type
+        self.backbone = recognizer
+        self.model_path = ""
+
+
+class OcrRecognitionTask(BaseInferTask):
+    def __init__(self, task="ocr_recognition", model="CRNN", task_type="document", engine: HipEngine = None, **kwargs):
+        super().__init__(task=task, model=model, **kwargs)
+        if model in ["ConvNextViT", "CRNN", "LightweightEdge"]:
+            self._config = _RecCfg(model, task_type)
+            self.model_provider = "model_scope"
+        elif model in ["PP-OCRv4", "PP-OCRv3", "PP-Table"]:
+            self._config = _RecCfg(model, task_type)
+            self.model_provider = "PaddleOCR"
+        else:
+            raise RuntimeError(f"current model is not supported: {model}")
+        self._engine = engine
+        self._config.model_path = self.get_model_name_or_path()
+        self._get_inference_model()
+
+    def _construct_model(self, model):
+        if model != "CRNN":
+            raise RuntimeError(f"recogniser '{model}' ({self._config.model_path}) is not built on the HIP engine yet; "
+                               "only the in-tree CRNN is (SURVEY.md section 8f)")
+        if self._engine is None:
+            self._engine = HipEngine(int(str(self.device).split(":")[-1]) if ":" in str(self.device) else 0)
+        vocab = None
+        if self.synthetic_seed is not None:
+            from .synth_weights import crnn_state_dict
+            sd = crnn_state_dict(seed=int(self.synthetic_seed))
+        else:
+            mp = self._config.model_path
+            path = os.path.join(mp, "pytorch_model.bin")
+            if not os.path.exists(path):
+                path = os.path.join(mp, "pytorch_model.pt")          # modeling_ocr_recognition.py:102-105
+            if not os.path.exists(path):
+                raise RuntimeError(f"no checkpoint under {mp}: the reference would download it from the hub (no network "
+                                   "here); pass task_path=<dir> or synthetic_seed=<int>")
+            raw = torch.load(path, map_location="cpu", weights_only=True)
+            sd = {k.replace("recognizer.", "").replace("module.", ""): v for k, v in raw.items()}   # :108-111
+            with open(os.path.join(mp, "vocab.txt"), "r", encoding="utf-8") as f:
+                vocab = [ln.strip("\n") for ln in f.readlines()]
+        self._engine.load_weights(L.PT_MODEL_CRNN, pack_crnn(sd))
+        self._vocab = vocab
+        self._model = self._predict
+
+    def _build_processor(self):
+        self._stage = RecStage(self._engine, self._vocab)
+
+    def _predict(self, crops):
+        """already-cropped line images: resize + CRNN + arg-max on the device, CTC collapse + vocabulary on the host"""
+        from .rec_stage import ctc_collapse
+        ids, _ = self._engine.rec_forward_crops(crops)
+        toks = ctc_collapse(ids.cpu().numpy()) if len(crops) else []
+        return ["".join(self._stage.label.get(t, "") for t in row) for row in toks]
+
+    def recognize_quads(self, pages: torch.Tensor, boxes_per_page: Sequence[np.ndarray]) -> List[List[str]]:
+        return self._stage(pages, boxes_per_page)
+
+    def _preprocess(self, inputs, **kwargs):
+        if not isinstance(inputs, list):
+            inputs = [inputs]
+        return {"inputs": [{"image": _read_image(it)} for it in inputs]}
+
+    def _run_model(self, inputs, **kwargs):
+        begin = time.time()
+        crops = [it["image"] for it in inputs["inputs"]]
+        (texts), elapse = self.infer({"crops": crops})
+        inputs["results"] = [{"results": t, "elapse": elapse} for t in texts]
+        inputs["use_time"] = time.time() - begin
+        return inputs
+
+    def _postprocess(self, inputs, **kwargs) -> List[str]:
+        return [r["results"] for r in inputs["results"]]

@@ -1,0 +1,87 @@
+"""``OcrTablePipeline.predict()`` -- the batched page-inference façade named by BASELINE.json's north star.
+
+The reference has no class of this name (SURVEY.md finding F1); its semantics are those of
+``OcrSystemTask.__call__`` (src/pdftable/model/ocr_pdf/ocr_system_task.py:549-734) restricted to the vision path of
+an *image* page: text detection (:629, :148-166, incl. the reading-order sort) -> text recognition (:630, :296-336).
+Layout (PicoDet) and table structure (Lore) are SURVEY section 8 rows that are not built yet: asking for them raises.
+
+What is different from the reference, by design: pages are processed as a batch (the reference is batch 1 and
+synchronous), crops never leave the GPU, and a failed page/line follows the reference's containment rules
+(a failed crop yields ``""``: ocr_system_task.py:275-283).
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .det_stage import DetConfig, DetStage, sort_boxes_reading_order
+from .engine import HipEngine
+from .ocr_detection_task import OcrDetectionTask, _read_image
+from .ocr_recognition_task import OcrRecognitionTask
+
+__all__ = ["OcrTablePipeline", "PageResult"]
+
+
+@dataclass
+class PageResult:
+    """Subset of OcrSystemModelOutput (ocr_output.py:25-61) the built stages fill."""
+    det_result: np.ndarray                       # [n, 8] boxes in reading order (ocr_system_task.py:159-162)
+    ocr_result: List[Dict] = field(default_factory=list)   # [{"index", "text", "bbox"}] like modeling_ocr_pdf.py:286-291
+    layout_result: Optional[list] = None
+    table_structure_result: Optional[list] = None
+
+
+class OcrTablePipeline:
+    def __init__(self, device: int = 0, detect_model: str = "db", recognizer: str = "CRNN", thresh: float = 0.2,
+                 synthetic_seed: Optional[int] = None, det_task_path: Optional[str] = None,
+                 rec_task_path: Optional[str] = None, layout: bool = False, table_structure: bool = False, **kwargs):
+        if layout or table_structure:
+            raise NotImplementedError("layout (PicoDet) and table-structure (Lore) stages are not built on the HIP engine "
+                                      "yet (SURVEY.md section 8a rows 1 and 4)")
+        self.engine = HipEngine(device)
+        dk = dict(kwargs)
+        rk = dict(kwargs)
+        if synthetic_seed is not None:
+            dk["synthetic_seed"] = synthetic_seed
+            rk["synthetic_seed"] = synthetic_seed + 1
+        if det_task_path:
+            dk["task_path"] = det_task_path
+        if rec_task_path:
+            rk["task_path"] = rec_task_path
+        self.text_detector = OcrDetectionTask(model=detect_model, thresh=thresh, engine=self.engine, **dk)
+        self.text_recognizer = OcrRecognitionTask(model=recognizer, engine=self.engine, **rk)
+
+    def predict(self, pages: Sequence, **kwargs) -> List[PageResult]:
+        """pages: RGB images (paths / PIL / ndarrays).  Returns one PageResult per page, plus ``self.metric``."""
+        t0 = time.time()
+        imgs = [_read_image(p) for p in pages]
+        results: List[Optional[PageResult]] = [None] * len(imgs)
+        groups: Dict[tuple, List[int]] = {}
+        for i, im in enumerate(imgs):
+            groups.setdefault(im.shape, []).append(i)
+        t_det = t_rec = 0.0
+        for shape, idxs in groups.items():
+            batch = torch.from_numpy(np.stack([imgs[i] for i in idxs])).to(self.engine._tdev)
+            a = time.time()
+            stage: DetStage = self.text_detector._stage
+            prob, bitmap, ev = stage.forward(batch)
+            boxes = stage.boxes(prob, bitmap, shape[:2], ev)
+            boxes = [sort_boxes_reading_order(b) for b in boxes]
+            b_ = time.time()
+            try:
+                texts = self.text_recognizer.recognize_quads(batch, boxes)
+            except Exception:                      # reference: a failing recognition yields empty strings
+                texts = [[""] * len(b) for b in boxes]
+            c = time.time()
+            t_det += b_ - a
+            t_rec += c - b_
+            for k, i in enumerate(idxs):
+                ocr = [{"index": j + 1, "text": t, "bbox": boxes[k][j].reshape(4, 2)} for j, t in enumerate(texts[k])]
+                results[i] = PageResult(det_result=boxes[k], ocr_result=ocr)
+        self.metric = {"use_time": time.time() - t0, "text_detection": {"use_time": t_det},
+                       "text_recognition": {"use_time": t_rec, "total": sum(len(r.ocr_result) for r in results)}}
+        return results

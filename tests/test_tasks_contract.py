@@ -1,0 +1,78 @@
+"""Plug-in contract of the stage tasks (mirror of base_infer_task.py / ocr_*_task.py in the reference): registry,
+constructor errors, model-id resolution.  The registry hash is pinned to the reference's TABLE_MODEL_DICT."""
+import hashlib
+import json
+import os
+
+import pytest
+
+from pdf_table_amd.base_infer_task import BaseInferTask
+from pdf_table_amd.ocr_table_model_config import HIP_SUPPORTED, TABLE_MODEL_DICT
+
+
+def test_registry_equals_reference(golden_dir):
+    want = json.load(open(os.path.join(golden_dir, "registry_hash.json")))
+    blob = json.dumps(TABLE_MODEL_DICT, sort_keys=True, ensure_ascii=False).encode("utf-8")
+    assert hashlib.sha256(blob).hexdigest() == want["sha256"]
+    assert sorted(TABLE_MODEL_DICT) == want["providers"]
+    for prov, task, model in HIP_SUPPORTED:
+        assert model in TABLE_MODEL_DICT[prov][task]
+
+
+class _Dummy(BaseInferTask):
+    def _construct_model(self, model): self._model = lambda **kw: "ran"
+    def _build_processor(self): pass
+    def _preprocess(self, inputs, **kw): return {"inputs": [inputs]}
+    def _run_model(self, inputs, **kw):
+        r, el = self.infer({})
+        inputs["results"] = [r]
+        return inputs
+    def _postprocess(self, inputs, **kw): return inputs["results"]
+
+
+class _Cfg:
+    backbone = "resnet18"
+    recognizer = "CRNN"
+    task_type = "general"
+    model_name = "Lore"
+
+
+def test_base_task_call_chain_and_predictors():
+    t = _Dummy(model="db", task="ocr_detection")
+    t._config = _Cfg()
+    t._get_inference_model()
+    assert t("x") == ["ran"]
+    with pytest.raises(RuntimeError, match="TensorRt infer not supported"):
+        _Dummy(model="db", task="ocr_detection", predictor_type="trt")._get_inference_model()
+    for pt in ("pytorch", "onnx"):
+        with pytest.raises(RuntimeError, match="no fallback"):
+            _Dummy(model="db", task="ocr_detection", predictor_type=pt)._get_inference_model()
+
+
+def test_model_id_resolution_follows_reference_rules():
+    t = _Dummy(model="db", task="ocr_detection")
+    t._config = _Cfg()
+    assert t.get_model_name_or_path() == "cycloneboy/cv_resnet18_ocr-detection-db-line-level_damo"     # hf_model wins
+    t.use_modelscope_hub = True
+    assert t.get_model_name_or_path() == "damo/cv_resnet18_ocr-detection-db-line-level_damo"
+    r = _Dummy(model="CRNN", task="ocr_recognition")
+    r._config = _Cfg()
+    assert r.get_model_name_or_path() == "cycloneboy/cv_crnn_ocr-recognition-general_damo"
+    p = _Dummy(model="db_pp", task="ocr_detection", model_provider="PaddleOCR", lang="fr")
+    p._config = type("C", (), {"backbone": "PP-OCRv4"})()
+    assert p.get_model_name_or_path() == "cycloneboy/Multilingual_PP-OCRv3_det_infer"                   # lang -> "ml"
+    q = _Dummy(model="PP-OCRv4", task="ocr_recognition", model_provider="PaddleOCR", lang="ka")
+    q._config = type("C", (), {"backbone": "PP-OCRv4"})()
+    assert q.get_model_name_or_path() == "cycloneboy/en_PP-OCRv3_rec_infer"      # v4 -> v3 for non ch/en, then lang -> en
+    s = _Dummy(model="db_pp", task="ocr_detection", model_provider="PaddleOCR", lang="ch", server_model=True)
+    s._config = type("C", (), {"backbone": "PP-OCRv4"})()
+    assert s.get_model_name_or_path() == "cycloneboy/ch_PP-OCRv4_det_server_infer"
+
+
+def test_unknown_models_raise_like_the_reference():
+    from pdf_table_amd.ocr_detection_task import OcrDetectionTask
+    from pdf_table_amd.ocr_recognition_task import OcrRecognitionTask
+    with pytest.raises(RuntimeError, match="current model is not supported"):
+        OcrDetectionTask(model="yolo")
+    with pytest.raises(RuntimeError, match="current model is not supported"):
+        OcrRecognitionTask(model="tesseract")
