@@ -229,12 +229,19 @@ def main():
         traffic = None
         try:   # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_summary.py)
             with open(os.path.join(REPO, "profiles", "pmc_latest.json")) as f:
-                traffic = json.load(f)["void conv_igemm_kernel<3, 1>"]["hbm_bytes_per_launch"]
+                pm = json.load(f)
+            tot = nl = 0.0
+            for kname, rec_ in pm.items():       # every 3x3 conv kernel variant, launch-weighted
+                if ("conv_igemm_kernel<3," in kname or "conv3x3_dma_kernel" in kname) and "hbm_bytes_per_launch" in rec_:
+                    n_ = rec_["FETCH_SIZE"]["dispatches"]
+                    tot += rec_["hbm_bytes_per_launch"] * n_
+                    nl += n_
+            traffic = tot / nl if nl else None
         except Exception:
             traffic = None
         roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<3,*> (3x3 implicit-GEMM convs of DB-ResNet18)",
                 "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
-                "traffic": traffic, "traffic_note": "bytes/launch, conv_igemm_kernel<3,1>, PMC passes of profiles/pmc_latest.json "
+                "traffic": traffic, "traffic_note": "bytes/launch over the 3x3 conv kernels, PMC passes of profiles/pmc_latest.json "
                                                     "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
                 "launches": c3["launches"], "avg_launch_ms": c3["ms"] / max(1, c3["launches"]),
                 "algorithmic_flop_per_launch": c3["flop"] / max(1, c3["launches"]),

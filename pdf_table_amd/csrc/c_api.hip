@@ -53,6 +53,7 @@ void pt_engine_destroy(pt_engine* e) {
   if (e->rec_crops) (void)hipFree(e->rec_crops);
   if (e->rec_gray) (void)hipFree(e->rec_gray);
   if (e->rec_off) (void)hipFree(e->rec_off);
+  if (e->zero_page) (void)hipFree(e->zero_page);
   for (auto& p : e->prof.pending) {
     (void)hipEventDestroy(p.a);
     (void)hipEventDestroy(p.b);

@@ -100,6 +100,7 @@ struct pt_engine {
   void* rec_gray = nullptr; size_t rec_gray_cap = 0;
   void* rec_off = nullptr; size_t rec_off_cap = 0;
   std::vector<long long> rec_off_host;
+  void* zero_page = nullptr;  // 8 KiB of zeros: DMA source for halo pixels outside the image
 };
 
 // ---- conv launcher (conv_igemm.hip) -----------------------------------------------------------------

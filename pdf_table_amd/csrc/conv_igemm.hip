@@ -21,6 +21,7 @@
 //   * blockIdx -> tile mapping is XCD-aware: consecutive logical tiles (all N-tiles of a patch, then
 //     the neighbouring patch) stay on one XCD so the halo and the weights hit that XCD's L2.
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -69,7 +70,7 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
 }
 
 // Shared epilogue: fp32 tile [TH*32 pixels][64 ch] in LDS -> bias/residual/ReLU -> bf16 stores.
-template <int TH, int TW>
+template <int TH, int TW, int NTHR = 256>
 __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stage, int tid, int b, int oy0, int ox0,
                                                int n0) {
   // fused-head weights of this thread's 8 channels (idx & 7 == tid & 7 for every j)
@@ -91,8 +92,8 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
     }
   }
 #pragma unroll
-  for (int j = 0; j < TH * TW / 32; ++j) {
-    const int idx = tid + j * 256;
+  for (int j = 0; j < TH * TW * 8 / NTHR; ++j) {
+    const int idx = tid + j * NTHR;
     const int pix = idx >> 3, cg = idx & 7;
     const int ty = pix / TW, tx = pix % TW;
     const int oy = oy0 + ty, ox = ox0 + tx;
@@ -324,12 +325,18 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
         for (int kk = 0; kk < 2; ++kk) {
           const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(b_base + (tap * 64) * C::PIXB + kk * 32);
           const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(b_base + (tap * 64 + 32) * C::PIXB + kk * 32);
+#ifdef PT_SETPRIO
+          __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
           for (int m = 0; m < C::MT; ++m) {
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base[m] + (r * C::TWIN + s) * C::PIXB + kk * 32);
             acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
             acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
           }
+#ifdef PT_SETPRIO
+          __builtin_amdgcn_s_setprio(0);
+#endif
         }
       }
     }
@@ -352,6 +359,157 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
   }
   __syncthreads();
   epilogue_store<C::TH, C::TW>(p, stage, tid, b, oy0, ox0, nt * 64);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution, LDS-DMA pipeline ("v2").  Same math and epilogue as conv_igemm_kernel<3,1>, but
+//   * 8 waves / workgroup, 16x32 output patch x 64 channels: the 36 KB weight slice is shared by twice as many pixels
+//   * both operands go global -> LDS with global_load_lds (16 B per lane, no VGPR staging, no ds_write);
+//     the LDS images are un-padded 64-byte rows with the 16-byte slots XOR-swizzled by ((row >> 2) & 3), applied on
+//     the SOURCE address of the DMA and again on the ds_read address (conflict-free for any 16 lanes whose row indices
+//     are distinct mod 16)
+//   * two LDS buffers: the DMA of K-slice c+1 flies while slice c is multiplied; one barrier per slice
+//   * halo pixels outside the image read a zero page instead of being predicated
+// ---------------------------------------------------------------------------------------------------
+struct DmaCfg {
+  static constexpr int TH = 16, TW = 32, NTHR = 512;
+  static constexpr int THIN = TH + 2, TWIN = TW + 2;       // 18 x 34
+  static constexpr int NPIX = THIN * TWIN;                 // 612
+  static constexpr int IN_BYTES = NPIX * 64;               // 39168
+  static constexpr int W_BYTES = 9 * 64 * 64;              // 36864
+  static constexpr int BUF_BYTES = IN_BYTES + W_BYTES;     // 76032
+  static constexpr int STAGE_BYTES = TH * TW * 64 * 4;     // 131072
+  static constexpr int SMEM = 2 * BUF_BYTES;               // 152064 >= STAGE_BYTES
+  static constexpr int IN_UNITS = NPIX * 4;                // 2448 16-byte units
+  static constexpr int IN_INSTR = (IN_UNITS + 63) / 64;    // 39 wave-instructions
+  static constexpr int W_INSTR = 9 * 64 * 4 / 64;          // 36
+  static constexpr int IN_SLOTS = (IN_INSTR + 7) / 8;      // per wave: 5
+  static constexpr int W_SLOTS = (W_INSTR + 7) / 8;        // per wave: 5
+};
+
+__global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvK p, const bf16_t* __restrict__ zero_page) {
+  using C = DmaCfg;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lx = lane & 31, qh = lane >> 5;
+
+  int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = L % p.n_tiles;
+  L /= p.n_tiles;
+  const int txi = L % p.tiles_x;
+  L /= p.tiles_x;
+  const int tyi = L % p.tiles_y;
+  const int b = L / p.tiles_y;
+  const int oy0 = tyi * C::TH, ox0 = txi * C::TW;
+  const int nchunks = p.split ? 3 * (p.Cin >> 5) : (p.Cin >> 5);
+  const int in_cs = p.split ? 2 * p.Cin : p.Cin;
+  const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * in_cs;
+  const bf16_t* wt = p.w + (size_t)nt * nchunks * (9 * 64 * 32);
+
+  // per-wave DMA slots: input unit U = (wave + 8 j) * 64 + lane -> pixel U >> 2, LDS slot U & 3
+  const bf16_t* src_in[C::IN_SLOTS];
+  bool on_in[C::IN_SLOTS];
+#pragma unroll
+  for (int j = 0; j < C::IN_SLOTS; ++j) {
+    const int k = wave + 8 * j;
+    const int U = k * 64 + lane;
+    on_in[j] = (k < C::IN_INSTR) && (U < C::IN_UNITS);
+    const int pix = U >> 2;
+    const int q = (U & 3) ^ ((pix >> 2) & 3);
+    const int iy = pix / C::TWIN, ix = pix - iy * C::TWIN;
+    const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
+    const bool inside = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    src_in[j] = inside ? in_b + ((size_t)gy * p.W + gx) * in_cs + q * 8 : zero_page;
+  }
+  int src_w[C::W_SLOTS];
+#pragma unroll
+  for (int j = 0; j < C::W_SLOTS; ++j) {
+    const int U = (wave + 8 * j) * 64 + lane;   // row = U >> 2 (tap * 64 + n), slot = U & 3
+    const int row = U >> 2;
+    src_w[j] = row * 32 + (((U & 3) ^ ((row >> 2) & 3)) * 8);
+  }
+
+  auto issue = [&](int chunk, int buf) {
+    int c0 = chunk << 5;
+    if (c0 >= in_cs) c0 -= in_cs;
+    char* lds_in = smem + buf * C::BUF_BYTES;
+    char* lds_w = lds_in + C::IN_BYTES;
+    const bf16_t* wc = wt + (size_t)chunk * (9 * 64 * 32);
+#pragma unroll
+    for (int j = 0; j < C::IN_SLOTS; ++j) {
+      if (on_in[j])
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_in[j] + c0),
+                                         (__attribute__((address_space(3))) void*)(lds_in + (wave + 8 * j) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < C::W_SLOTS; ++j) {
+      if (wave + 8 * j < C::W_INSTR)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wc + src_w[j]),
+                                         (__attribute__((address_space(3))) void*)(lds_w + (wave + 8 * j) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  // A fragment of row-tile m, tap (r, s), k-half kk: pixel pa = (2 wave + m + r) * 34 + lx + s
+  const int pa0 = (2 * wave) * C::TWIN + lx;
+  const int gl = (lx >> 2) & 3;
+  const int boff0 = lx * 64 + (((0 + qh) ^ gl) << 4);   // kk = 0 : slot kk*2 + qh
+  const int boff1 = lx * 64 + (((2 + qh) ^ gl) << 4);   // kk = 1
+
+  issue(0, 0);
+  for (int c = 0; c < nchunks; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (c + 1 < nchunks) issue(c + 1, (c + 1) & 1);
+    const char* s_in = smem + (c & 1) * C::BUF_BYTES;
+    const char* s_w = s_in + C::IN_BYTES;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int tap = r * 3 + s;
+        const int pa[2] = {pa0 + r * C::TWIN + s, pa0 + (1 + r) * C::TWIN + s};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int bo = kk ? boff1 : boff0;
+          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(s_w + (tap * 64) * 64 + bo);
+          const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(s_w + (tap * 64 + 32) * 64 + bo);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const int pp = pa[m];
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(s_in + pp * 64 + (((kk * 2 + qh) ^ ((pp >> 2) & 3)) << 4));
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  __syncthreads();
+  float* stage = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int pbase = (2 * wave + m) * C::TW;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int tx = (r & 3) + 8 * (r >> 2) + 4 * qh;
+        stage[(pbase + tx) * 64 + n * 32 + lx] = acc[m][n][r];
+      }
+  }
+  __syncthreads();
+  epilogue_store<C::TH, C::TW, C::NTHR>(p, stage, tid, b, oy0, ox0, nt * 64);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -490,6 +648,41 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   return PT_OK;
 }
 
+static bool use_dma_kernel() {
+  static int v = -1;
+  if (v < 0) {
+    const char* s = getenv("PT_CONV_DMA");
+    v = s ? atoi(s) : 1;
+  }
+  return v != 0;
+}
+
+static int launch_dma(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
+  using C = DmaCfg;
+  static bool attr_done = false;
+  if (!attr_done) {
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
+    attr_done = true;
+  }
+  if (!e->zero_page) {
+    PT_HIP_CHECK(hipMalloc(&e->zero_page, 8192));
+    PT_HIP_CHECK(hipMemset(e->zero_page, 0, 8192));
+  }
+  k.tiles_x = (k.Wo + C::TW - 1) / C::TW;
+  k.tiles_y = (k.Ho + C::TH - 1) / C::TH;
+  k.n_tiles = k.N / 64;
+  const long long nblk = (long long)k.B * k.tiles_x * k.tiles_y * k.n_tiles;
+  PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range (%lld blocks)", nblk);
+  char label[48];
+  snprintf(label, sizeof(label), "conv3x3 dma %d->%d @%dx%d%s", k.Cin, k.N, k.Ho, k.Wo, k.split ? " x3" : "");
+  PtProfScope prof(e, s, PT_PROF_CONV3X3, flop, label);
+  hipLaunchKernelGGL(conv3x3_dma_kernel, dim3((unsigned)nblk), dim3(C::NTHR), C::SMEM, s, k,
+                     reinterpret_cast<const bf16_t*>(e->zero_page));
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
 int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   PT_REQUIRE(d.in && d.w && d.bias && (d.out || d.head_w || d.argmax_part), "conv: null pointer");
   PT_REQUIRE(d.Cin % 32 == 0 && d.Cin > 0, "conv: Cin=%d must be a positive multiple of 32", d.Cin);
@@ -513,6 +706,8 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   if (d.head_w) PT_REQUIRE(d.shuffle_cout == 64 && d.head_b && (d.head_prob || d.head_logits), "conv: bad fused-head configuration");
   if (k.res_mode == 2) PT_REQUIRE(k.Ho % 2 == 0 && k.Wo % 2 == 0, "conv: half-res residual needs even output size");
   const double flop = 2.0 * k.B * k.Ho * k.Wo * (double)k.N * d.Cin * d.ks * d.ks;  // algorithmic (not x3 in split mode)
+  // measured on MI355X (round 1): the DMA variant wins on wide-K layers over large maps, loses on short-K / small maps
+  if (d.ks == 3 && d.stride == 1 && k.Ho >= 60 && d.Cin >= 128 && use_dma_kernel()) return launch_dma(e, k, s, flop);
   if (d.ks == 3 && d.stride == 1 && k.Ho <= 4 && k.Wo > 32) return launch_cfg<3, 1, 1>(e, k, s, flop);
   if (d.ks == 3 && d.stride == 1) return launch_cfg<3, 1>(e, k, s, flop);
   if (d.ks == 3 && d.stride == 2) return launch_cfg<3, 2>(e, k, s, flop);

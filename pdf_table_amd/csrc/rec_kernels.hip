@@ -331,8 +331,16 @@ int pt_launch_maxpool_kxk(const bf16_t* in, int n, int H, int W, int C, int kh, 
 // lane-local; c stays in registers (fp32) for the whole sequence; h goes through LDS (double-buffered, bf16 or
 // hi/lo pair) as next step's A operand and to HBM as the layer output.  W_hh fragments stream from L2.
 // ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+  // 2 / (1 + 2^(-2 log2(e) x)) - 1 ; saturates cleanly for large |x| (exp2 -> 0 or inf)
+  return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.88539008177792681f * x)) - 1.f;
+}
+
 template <int SPLIT>
-__global__ __launch_bounds__(256, 2) void lstm_dir_kernel(const bf16_t* __restrict__ gx, const bf16_t* __restrict__ whh,
+__global__ __launch_bounds__(256, 1) void lstm_dir_kernel(const bf16_t* __restrict__ gx, const bf16_t* __restrict__ whh,
                                                            bf16_t* __restrict__ hout, int B, int T) {
   constexpr int NP = SPLIT ? 2 : 1;
   constexpr int HROW = 264;  // 256 + 8 bf16: 528-byte rows = 33 16-byte slots (odd) -> conflict-free b128 reads
@@ -352,6 +360,20 @@ __global__ __launch_bounds__(256, 2) void lstm_dir_kernel(const bf16_t* __restri
   __syncthreads();
   for (int s = 0; s < T; ++s) {
     const int t = dir ? T - 1 - s : s;
+    // input-projection terms of this step: gx is laid out [line][t][dir][unit][gate] (gate fastest, set up by the
+    // weight packer), so the four gates of a (line, unit) are one 8-byte load; issued before the MFMA phase
+    u32x2 gxv[2][16], gxl[2][16];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * q;
+        const int line = line0 + m;
+        const int lc = line < B ? line : B - 1;
+        const bf16_t* gp = gx + ((size_t)lc * T + t) * gcs + dir * 1024 + (wave * 64 + h * 32 + lx) * 4;
+        gxv[h][r] = *reinterpret_cast<const u32x2*>(gp);
+        if (SPLIT) gxl[h][r] = *reinterpret_cast<const u32x2*>(gp + 2048);
+      }
     f32x16 acc[4][2];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -364,17 +386,29 @@ __global__ __launch_bounds__(256, 2) void lstm_dir_kernel(const bf16_t* __restri
     for (int pass = 0; pass < NPASS; ++pass) {
       const int pa = (pass == 1) ? 1 : 0;  // A part: h_hi, h_lo, h_hi
       const bf16_t* wsrc = whh_d + (pass == 2 ? (size_t)2 * 1024 * 256 : 0);
-#pragma unroll 4
-      for (int k16 = 0; k16 < 16; ++k16) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(&hbuf[pa][lx][k16 * 16 + q * 8]);
+      // W_hh streams from L2 and the loop is latency-bound: issue the 32 fragment loads of a quarter step (128
+      // VGPRs) in one burst, then multiply -- four L2 round trips per pass instead of sixteen
+#pragma unroll 1
+      for (int half = 0; half < 4; ++half) {
+        bf16x8 bq[4][4][2];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int kq = 0; kq < 4; ++kq)
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int ncol = g * 256 + wave * 64 + h * 32 + lx;
-            const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(wsrc + (size_t)ncol * 256 + k16 * 16 + q * 8);
-            acc[g][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag, acc[g][h], 0, 0, 0);
-          }
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int ncol = g * 256 + wave * 64 + h * 32 + lx;
+              bq[kq][g][h] = *reinterpret_cast<const bf16x8*>(wsrc + (size_t)ncol * 256 + (half * 4 + kq) * 16 + q * 8);
+            }
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(&hbuf[pa][lx][(half * 4 + kq) * 16 + q * 8]);
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+              acc[g][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[kq][g][h], acc[g][h], 0, 0, 0);
+        }
       }
     }
     __syncthreads();  // every wave has finished reading h_{t-1}
@@ -386,19 +420,20 @@ __global__ __launch_bounds__(256, 2) void lstm_dir_kernel(const bf16_t* __restri
       for (int r = 0; r < 16; ++r) {
         const int m = (r & 3) + 8 * (r >> 2) + 4 * q;
         const int line = line0 + m;
-        const int lc = line < B ? line : B - 1;
-        const bf16_t* gp = gx + ((size_t)lc * T + t) * gcs + dir * 1024 + unit;
-        float gi = acc[0][h][r] + rbf2f(gp[0]);
-        float gf = acc[1][h][r] + rbf2f(gp[256]);
-        float gg = acc[2][h][r] + rbf2f(gp[512]);
-        float go = acc[3][h][r] + rbf2f(gp[768]);
+        float gi = acc[0][h][r] + rbf2f(gxv[h][r].x & 0xFFFFu);
+        float gf = acc[1][h][r] + rbf2f(gxv[h][r].x >> 16);
+        float gg = acc[2][h][r] + rbf2f(gxv[h][r].y & 0xFFFFu);
+        float go = acc[3][h][r] + rbf2f(gxv[h][r].y >> 16);
         if (SPLIT) {
-          gi += rbf2f(gp[2048]); gf += rbf2f(gp[2048 + 256]); gg += rbf2f(gp[2048 + 512]); go += rbf2f(gp[2048 + 768]);
+          gi += rbf2f(gxl[h][r].x & 0xFFFFu); gf += rbf2f(gxl[h][r].x >> 16);
+          gg += rbf2f(gxl[h][r].y & 0xFFFFu); go += rbf2f(gxl[h][r].y >> 16);
         }
-        const float si = 1.f / (1.f + expf(-gi)), sf = 1.f / (1.f + expf(-gf)), so = 1.f / (1.f + expf(-go));
-        const float cn = sf * c[h][r] + si * tanhf(gg);
+        // sigmoid / tanh through the hardware exp2 + reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp, far inside the 1e-3
+        // contract); tanh(x) = 2 sigmoid(2x) - 1
+        const float si = fast_sigmoid(gi), sf = fast_sigmoid(gf), so = fast_sigmoid(go);
+        const float cn = sf * c[h][r] + si * fast_tanh(gg);
         c[h][r] = cn;
-        const float hn = so * tanhf(cn);
+        const float hn = so * fast_tanh(cn);
         const uint32_t hb = rf2bf(hn);
         hbuf[0][m][unit] = (bf16_t)hb;
         uint32_t lb = 0;

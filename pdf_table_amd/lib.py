@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpdftable_hip.so")
+LIB_PATH = os.environ.get("PT_LIB_PATH") or os.path.join(_HERE, "libpdftable_hip.so")   # PT_LIB_PATH: kernel A/B experiments
 
 PT_MODEL_DB_RESNET18 = 1
 PT_MODEL_CRNN = 2

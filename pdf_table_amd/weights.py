@@ -173,7 +173,10 @@ def pack_crnn(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
         wih = torch.cat([sd[r + "weight_ih_l0"], sd[r + "weight_ih_l0_reverse"]], 0)
         bias = torch.cat([sd[r + "bias_ih_l0"] + sd[r + "bias_hh_l0"],
                           sd[r + "bias_ih_l0_reverse"] + sd[r + "bias_hh_l0_reverse"]], 0)
-        bl.add_conv(f"lstm{li}.xproj", wih.reshape(2048, -1, 1, 1).float(), bias.float())
+        # output columns re-ordered to [dir][unit][gate] (gate fastest) so that the LSTM kernel reads the four gate
+        # pre-activations of a (line, unit) with one 8-byte load
+        perm = torch.arange(2048).view(2, 4, 256).permute(0, 2, 1).reshape(-1)
+        bl.add_conv(f"lstm{li}.xproj", wih[perm].reshape(2048, -1, 1, 1).float(), bias[perm].float())
         whh = torch.stack([sd[r + "weight_hh_l0"], sd[r + "weight_hh_l0_reverse"]], 0).float()   # [2, 1024, 256]
         hi, lo = split_bf16(whh)
         bl.add(f"lstm{li}.whh", np.stack([to_bf16_bits(hi), to_bf16_bits(lo)]), "bf16")
