@@ -249,3 +249,40 @@ def rec_preprocess(crop, target_height=32, target_width=640):
     img = keepratio_resize(crop, target_height, target_width)
     data = torch.FloatTensor(img).view(1, target_height, target_width, 3) / 255.
     return data.permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------------------------------------
+# PP-OCR flavour: CTCLabelDecode (ocr_rec_pp/rec_postprocess.py:126-195), pinned by tests/golden/ctc_decode.*
+# ------------------------------------------------------------------------------------------------
+def ctc_label_decode(preds, characters, reverse=False):
+    """preds float [B,T,C]; characters = dict lines (+ ' '); -> [(text, conf)] exactly like CTCLabelDecode.__call__."""
+    import re
+    table = ["blank"] + list(characters)
+    preds = np.asarray(preds)
+    idx = preds.argmax(axis=2)
+    prob = preds.max(axis=2)
+    out = []
+    for b in range(len(idx)):
+        sel = np.ones(len(idx[b]), dtype=bool)
+        sel[1:] = idx[b][1:] != idx[b][:-1]
+        sel &= idx[b] != 0
+        chars = [table[t] for t in idx[b][sel]]
+        conf = prob[b][sel]
+        if len(conf) == 0:
+            conf = [0]
+        text = "".join(chars)
+        if reverse:
+            pred_re, cur = [], ""
+            for c in text:
+                if not bool(re.search("[a-zA-Z0-9 :*./%+-]", c)):
+                    if cur != "":
+                        pred_re.append(cur)
+                    pred_re.append(c)
+                    cur = ""
+                else:
+                    cur += c
+            if cur != "":
+                pred_re.append(cur)
+            text = "".join(pred_re[::-1])
+        out.append((text, np.mean(conf).tolist()))
+    return out

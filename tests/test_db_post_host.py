@@ -83,3 +83,16 @@ def test_max_candidates_takes_last_found_first():
         bm[4 + 10 * i: 9 + 10 * i, 5:40] = True
     boxes, _ = E.db_candidates(pack_bits(bm), max_candidates=2)
     assert len(boxes) == 2 and boxes[0][1] > boxes[1][1] > 40   # bottom-most components
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_finalize_torch_flavour_bit_exact(seed):
+    """db_net/ocr_detection_utils.py:167-210: score 0.3, unclip 1.5, int32 truncation before rescaling."""
+    prob = blobs(seed)
+    bm = prob > 0.2
+    boxes, _ = E.db_candidates(pack_bits(bm), 1000, 3.0)
+    scores = np.array([db_post.box_score_fast(prob, b.reshape(4, 2)) for b in boxes], np.float32)
+    out, _ = E.db_finalize(boxes, scores, prob.shape, (211, 333), 0.3, 1.5, 3.0, L.PT_DET_POST_DB_TORCH)
+    ref, _ = db_post.boxes_from_bitmap(prob, bm, 333, 211, 0.3, 1.5, 1000, 3, scores_override=scores, flavour="db")
+    np.testing.assert_array_equal(out.reshape(-1, 4, 2), ref)
+    assert len(out) >= 2
