@@ -1,0 +1,100 @@
+"""Full-size (BASELINE.json: 1024x1024 pages) checks through size-independent properties: determinism, batch
+invariance, bitmap/threshold consistency, integer post-processing vs the oracle on the engine's own map, ragged and
+empty inputs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import db_post
+from pdf_table_amd import engine as E
+from pdf_table_amd import lib as L
+from pdf_table_amd import rec_stage as R
+from pdf_table_amd.synth_pages import make_page
+from pdf_table_amd.synth_weights import crnn_state_dict, db_resnet18_state_dict
+from pdf_table_amd.weights import pack_crnn, pack_db_resnet18
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from pdf_table_amd.engine import HipEngine
+    e = HipEngine(0)
+    e.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(db_resnet18_state_dict(seed=0), x3=False))
+    e.load_weights(L.PT_MODEL_CRNN, pack_crnn(crnn_state_dict(seed=1), x3=False))
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def pages():
+    return [make_page(i) for i in range(3)]
+
+
+def test_det_fullsize_deterministic_and_batch_invariant(eng, pages):
+    imgs = np.stack([p[0] for p in pages])
+    a, bm_a = eng.det_forward(torch.from_numpy(imgs).cuda(), L.PT_DET_PRE_DB_PP, 0.3)
+    b, bm_b = eng.det_forward(torch.from_numpy(imgs).cuda(), L.PT_DET_PRE_DB_PP, 0.3)
+    assert a.shape == (3, 960, 960)
+    assert torch.equal(a, b) and torch.equal(bm_a, bm_b)                       # run-to-run identical
+    rev, _ = eng.det_forward(torch.from_numpy(imgs[::-1].copy()).cuda(), L.PT_DET_PRE_DB_PP, 0.3)
+    assert torch.equal(rev.flip(0), a)                                          # a page's map ignores its neighbours
+    one, _ = eng.det_forward(torch.from_numpy(imgs[1:2]).cuda(), L.PT_DET_PRE_DB_PP, 0.3)
+    assert torch.equal(one[0], a[1])                                            # ... and the batch size
+    p = a.cpu().numpy()
+    bits = ((bm_a.cpu().numpy().view(np.uint32)[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(p.shape).astype(bool)
+    np.testing.assert_array_equal(bits, p > 0.3)
+    assert np.isfinite(p).all() and p.min() >= 0 and p.max() <= 1
+
+
+def test_det_fullsize_integer_post_matches_oracle(eng, pages):
+    img = pages[0][0]
+    prob, bm = eng.det_forward(torch.from_numpy(img[None]).cuda(), L.PT_DET_PRE_DB_PP, 0.3)
+    p = prob[0].cpu().numpy()
+    bmh = bm[0].cpu().numpy().view(np.uint32)
+    cand, _ = E.db_candidates(bmh, 1000, 3.0)
+    ref_cand = db_post.candidates_from_bitmap(p > 0.3, 1000, 3)
+    assert len(cand) == len(ref_cand) > 10
+    for (pts, _), c in zip(ref_cand, cand):
+        np.testing.assert_array_equal(pts.reshape(-1), c)
+    cb = np.concatenate([np.zeros((len(cand), 1), np.float32), cand], 1)
+    sc = eng.det_box_scores(prob, torch.from_numpy(cb).cuda()).cpu().numpy()
+    ref_sc = np.array([db_post.box_score_fast(p, c.reshape(4, 2)) for c in cand], np.float32)
+    np.testing.assert_allclose(sc, ref_sc, rtol=0, atol=1e-6)
+    out, _ = E.db_finalize(cand, sc, p.shape, img.shape[:2], 0.05, 1.5, 3.0)      # low gate: keep many boxes
+    ref, _ = db_post.boxes_from_bitmap(p, p > 0.3, img.shape[1], img.shape[0], 0.05, 1.5, scores_override=sc)
+    np.testing.assert_array_equal(out.reshape(-1, 4, 2), ref.astype(np.int32))
+    assert len(out) > 10 and out.min() >= 0 and out.max() <= 1024
+
+
+def test_det_ragged_page_sizes(eng):
+    """pages of different sizes are grouped by shape by the task layer; every group keeps its own plan"""
+    from pdf_table_amd.det_stage import DetConfig, DetStage
+    st = DetStage(eng, DetConfig("db_pp"))
+    for (h, w) in ((1024, 1024), (640, 480), (37, 53), (2048, 1536)):
+        img = np.random.default_rng(h).integers(0, 256, (1, h, w, 3), dtype=np.uint8)
+        nh, nw = eng.det_plan(h, w, L.PT_DET_PRE_DB_PP)
+        assert nh % 32 == 0 and nw % 32 == 0 and max(nh, nw) <= 960
+        boxes = st(torch.from_numpy(img).cuda())
+        assert len(boxes) == 1 and boxes[0].shape[1:] == (8,)
+
+
+def test_rec_order_invariance_and_empty(eng, pages):
+    img, meta = pages[1]
+    l = meta["lines"].astype(np.float64)
+    quads = np.stack([l[:, 0], l[:, 1], l[:, 2], l[:, 1], l[:, 2], l[:, 3], l[:, 0], l[:, 3]], 1)
+    st = R.RecStage(eng)
+    dev = torch.from_numpy(img[None]).cuda()
+    ids, _ = st.ids(dev, [quads])
+    perm = np.random.default_rng(0).permutation(len(quads))
+    ids_p, _ = st.ids(dev, [quads[perm]])
+    assert torch.equal(ids_p, ids[torch.from_numpy(perm).cuda()])               # a line's ids ignore its neighbours
+    ids2, _ = st.ids(dev, [quads])
+    assert torch.equal(ids, ids2)
+    assert ids.min() >= 0 and ids.max() < L.PT_REC_NCLS                         # padded classes can never win
+    empty, lines = st.ids(dev, [np.zeros((0, 8))])
+    assert empty.shape == (0, L.PT_REC_T) and len(lines) == 0
+    assert st(dev, [np.zeros((0, 8))]) == [[]]
+    # degenerate quad (zero area): crop is empty -> all-padding input, still decodes without error
+    deg, _ = st.ids(dev, [np.array([[10, 10, 10, 10, 10, 10, 10, 10]], np.float64)])
+    assert deg.shape == (1, L.PT_REC_T)
