@@ -70,12 +70,12 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
 }
 
 // Shared epilogue: fp32 tile [TH*32 pixels][64 ch] in LDS -> bias/residual/ReLU -> bf16 stores.
-template <int TH, int TW, int NTHR = 256>
+template <int TH, int TW, int NTHR = 256, bool EXTRAS = true>
 __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stage, int tid, int b, int oy0, int ox0,
                                                int n0) {
   // fused-head weights of this thread's 8 channels (idx & 7 == tid & 7 for every j)
   float hw[4][8];
-  if (p.head_w) {
+  if (EXTRAS && p.head_w) {
     const int cgw = tid & 7;
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
@@ -139,7 +139,7 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
       for (int k = 0; k < 8; ++k) lb[k] = f32_to_bf16(v[k] - bf16_to_f32(hb[k]));
       ol.x = lb[0] | (lb[1] << 16); ol.y = lb[2] | (lb[3] << 16); ol.z = lb[4] | (lb[5] << 16); ol.w = lb[6] | (lb[7] << 16);
     }
-    if (p.argmax_part) {
+    if (EXTRAS && p.argmax_part) {
       // fused arg-max over classes (CTC greedy decode, modeling_ocr_recognition.py:168-171): best (value, index)
       // of this pixel's 64-class slice; ties keep the LOWEST class index, like torch.argmax
       float bv = v[0];
@@ -160,7 +160,7 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
         pr.y = __int_as_float(bi);
         reinterpret_cast<float2*>(p.argmax_part)[row * p.n_tiles + (n0 >> 6)] = pr;
       }
-    } else if (p.head_w) {
+    } else if (EXTRAS && p.head_w) {
       // 8 consecutive lanes hold the 64 channels of one output pixel of quadrant `quad` (n0 == quad * 64)
       float xs[8];
 #pragma unroll
@@ -513,6 +513,169 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvK p, const bf16
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution, LDS-DMA pipeline with 16-channel K-slices ("v3").
+// Fill traffic per FLOP is what limits v1/v2 (PMC analysis), so v3 makes the tile as large as two
+// K-slices in LDS allow:  NT == 1: 32x32 pixels x 64 channels;  NT == 2: 16x32 pixels x 128 channels.
+// 8 waves; each wave owns 4 MFMA row-tiles x 64 channels (acc 4x2, 6 ds_read_b128 per 8 MFMAs); a K-slice is
+// 16 channels (one MFMA k-step per tap), ~56 KB for both operands, double buffered; rows are 32 B with the two
+// 16-byte halves swapped on rows with bit 3 set (applied on the DMA source and on the ds_read address).
+// Weights are read straight from the 32-channel tiling of v1 (half of every 64-byte row per slice).
+// ---------------------------------------------------------------------------------------------------
+template <int NT>
+struct Dma16Cfg {
+  static constexpr int NTHR = 512;
+  static constexpr int TH = NT == 1 ? 32 : 16, TW = 32;
+  static constexpr int NW = 64 * NT;                          // output channels per workgroup
+  static constexpr int THIN = TH + 2, TWIN = TW + 2;
+  static constexpr int NPIX = THIN * TWIN;                    // 1156 / 612
+  static constexpr int IN_BYTES = NPIX * 32;
+  static constexpr int W_BYTES = 9 * NW * 32;
+  static constexpr int BUF_BYTES = IN_BYTES + W_BYTES;        // 55424 / 56448
+  static constexpr int STAGE_BYTES = 16 * 32 * 64 * 4;        // one epilogue pass: 512 pixels x 64 channels fp32
+  static constexpr int SMEM = 2 * BUF_BYTES > STAGE_BYTES ? 2 * BUF_BYTES : STAGE_BYTES;
+  static constexpr int IN_UNITS = NPIX * 2;
+  static constexpr int IN_INSTR = (IN_UNITS + 63) / 64;
+  static constexpr int W_UNITS = 9 * NW * 2;
+  static constexpr int W_INSTR = W_UNITS / 64;
+  static constexpr int IN_SLOTS = (IN_INSTR + 7) / 8;
+  static constexpr int W_SLOTS = (W_INSTR + 7) / 8;
+};
+
+template <int NT>
+__global__ __launch_bounds__(512, 2) void conv3x3_dma16_kernel(ConvK p, const bf16_t* __restrict__ zero_page) {
+  using C = Dma16Cfg<NT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lx = lane & 31, qh = lane >> 5;
+  const int wm = NT == 1 ? wave : (wave >> 1);   // which group of 4 patch rows
+  const int wn = NT == 1 ? 0 : (wave & 1);       // which 64-channel half
+
+  int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int nb = L % p.n_tiles;                  // n_tiles counts NW-wide blocks here
+  L /= p.n_tiles;
+  const int txi = L % p.tiles_x;
+  L /= p.tiles_x;
+  const int tyi = L % p.tiles_y;
+  const int b = L / p.tiles_y;
+  const int oy0 = tyi * C::TH, ox0 = txi * C::TW;
+  const int in_cs = p.split ? 2 * p.Cin : p.Cin;
+  const int nch32 = p.split ? 3 * (p.Cin >> 5) : (p.Cin >> 5);
+  const int nslices = nch32 * 2;
+  const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * in_cs;
+
+  const bf16_t* src_in[C::IN_SLOTS];
+  bool on_in[C::IN_SLOTS];
+#pragma unroll
+  for (int j = 0; j < C::IN_SLOTS; ++j) {
+    const int k = wave + 8 * j;
+    const int U = k * 64 + lane;
+    on_in[j] = (k < C::IN_INSTR) && (U < C::IN_UNITS);
+    const int pix = U >> 1;
+    const int q = (U & 1) ^ ((pix >> 3) & 1);
+    const int iy = pix / C::TWIN, ix = pix - iy * C::TWIN;
+    const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
+    const bool inside = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    src_in[j] = inside ? in_b + ((size_t)gy * p.W + gx) * in_cs + q * 8 : zero_page;
+  }
+  // weight unit U -> row = U >> 1 = tap * NW + n, half = (U & 1) ^ ((row >> 3) & 1); element offset inside one
+  // 32-channel chunk of the v1 tiling [N/64][Cin/32][9][64][32], relative to (nt64 = NT * nb, chunk32 = 0)
+  int src_w[C::W_SLOTS];
+#pragma unroll
+  for (int j = 0; j < C::W_SLOTS; ++j) {
+    const int U = (wave + 8 * j) * 64 + lane;
+    const int row = U >> 1;
+    const int tap = row / C::NW, n = row - tap * C::NW;
+    const int hq = (U & 1) ^ ((row >> 3) & 1);
+    src_w[j] = (n >> 6) * nch32 * (9 * 64 * 32) + (tap * 64 + (n & 63)) * 32 + hq * 8;
+  }
+  const bf16_t* wt = p.w + (size_t)(NT * nb) * nch32 * (9 * 64 * 32);
+
+  auto issue = [&](int slice, int buf) {
+    int c0 = slice << 4;
+    if (c0 >= in_cs) c0 -= in_cs;
+    if (c0 >= in_cs) c0 -= in_cs;
+    char* lds_in = smem + buf * C::BUF_BYTES;
+    char* lds_w = lds_in + C::IN_BYTES;
+    const bf16_t* wc = wt + (size_t)(slice >> 1) * (9 * 64 * 32) + (slice & 1) * 16;
+#pragma unroll
+    for (int j = 0; j < C::IN_SLOTS; ++j) {
+      if (on_in[j])
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_in[j] + c0),
+                                         (__attribute__((address_space(3))) void*)(lds_in + (wave + 8 * j) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < C::W_SLOTS; ++j) {
+      if (wave + 8 * j < C::W_INSTR)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wc + src_w[j]),
+                                         (__attribute__((address_space(3))) void*)(lds_w + (wave + 8 * j) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  const int pa0 = (4 * wm) * C::TWIN + lx;                              // pixel of row-tile 0, tap (0,0)
+  const int boff = (wn * 64 + lx) * 32 + ((qh ^ ((lx >> 3) & 1)) << 4);  // weight row n = wn*64 + nt*32 + lx
+
+  issue(0, 0);
+  for (int c = 0; c < nslices; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (c + 1 < nslices) issue(c + 1, (c + 1) & 1);
+    const char* s_in = smem + (c & 1) * C::BUF_BYTES;
+    const char* s_w = s_in + C::IN_BYTES;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int tap = r * 3 + s;
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(s_w + (tap * C::NW) * 32 + boff);
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(s_w + (tap * C::NW + 32) * 32 + boff);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int pp = pa0 + (m + r) * C::TWIN + s;
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(s_in + pp * 32 + ((qh ^ ((pp >> 3) & 1)) << 4));
+          acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
+          acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // epilogue in two passes of 512 pixels x 64 channels (fp32 in LDS)
+  float* stage = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+    const bool mine = NT == 1 ? ((wave >> 2) == pass) : (wn == pass);
+    if (mine) {
+      const int rbase = NT == 1 ? 4 * (wave & 3) : 4 * wm;   // local patch row inside this pass' 16 rows
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int tx = (r & 3) + 8 * (r >> 2) + 4 * qh;
+            stage[((rbase + m) * 32 + tx) * 64 + n * 32 + lx] = acc[m][n][r];
+          }
+    }
+    __syncthreads();
+    if (NT == 1)
+      epilogue_store<16, 32, C::NTHR, false>(p, stage, tid, b, oy0 + 16 * pass, ox0, nb * 64);
+    else
+      epilogue_store<16, 32, C::NTHR, false>(p, stage, tid, b, oy0, ox0, (nb * 2 + pass) * 64);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Stem: 7x7 stride-2 pad-3 conv on a 4-channel (RGB0) bf16 image, 64 outputs, bias + ReLU.
 // K is laid out [r=7][s=8][c=4] = 224 (tap s=7 and channel 3 carry zero weights), so that one MFMA
 // k-step (16) = 4 horizontally adjacent pixels x 4 channels = 32 contiguous bytes of the image row.
@@ -657,6 +820,45 @@ static bool use_dma_kernel() {
   return v != 0;
 }
 
+template <int NT>
+static int launch_dma16(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
+  using C = Dma16Cfg<NT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma16_kernel<NT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
+    attr_done = true;
+  }
+  if (!e->zero_page) {
+    PT_HIP_CHECK(hipMalloc(&e->zero_page, 8192));
+    PT_HIP_CHECK(hipMemset(e->zero_page, 0, 8192));
+  }
+  k.tiles_x = (k.Wo + C::TW - 1) / C::TW;
+  k.tiles_y = (k.Ho + C::TH - 1) / C::TH;
+  k.n_tiles = k.N / C::NW;
+  const long long nblk = (long long)k.B * k.tiles_x * k.tiles_y * k.n_tiles;
+  PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range (%lld blocks)", nblk);
+  char label[48];
+  snprintf(label, sizeof(label), "conv3x3 v3 %d->%d @%dx%d%s", k.Cin, k.N, k.Ho, k.Wo, k.split ? " x3" : "");
+  PtProfScope prof(e, s, PT_PROF_CONV3X3, flop, label);
+  hipLaunchKernelGGL((conv3x3_dma16_kernel<NT>), dim3((unsigned)nblk), dim3(C::NTHR), C::SMEM, s, k,
+                     reinterpret_cast<const bf16_t*>(e->zero_page));
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// PT_CONV_VARIANT: 0 = v1 only (default), 1 = micro-benchmark rule, 2 = v2 wherever it applies, 3 = v3 wherever it applies.
+// In the DB-ResNet18 graph on real (post-ReLU) activations at 8-page micro-batches v1-only measured fastest
+// (det-only, no post: 3836 pages/s vs 3764 with rule 1 and 3719 with v2), although rule 1 wins the randn micro-benchmark.
+static int conv_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* s = getenv("PT_CONV_VARIANT");
+    v = s ? atoi(s) : 0;
+  }
+  return v;
+}
+
 static int launch_dma(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   using C = DmaCfg;
   static bool attr_done = false;
@@ -706,8 +908,22 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   if (d.head_w) PT_REQUIRE(d.shuffle_cout == 64 && d.head_b && (d.head_prob || d.head_logits), "conv: bad fused-head configuration");
   if (k.res_mode == 2) PT_REQUIRE(k.Ho % 2 == 0 && k.Wo % 2 == 0, "conv: half-res residual needs even output size");
   const double flop = 2.0 * k.B * k.Ho * k.Wo * (double)k.N * d.Cin * d.ks * d.ks;  // algorithmic (not x3 in split mode)
-  // measured on MI355X (round 1): the DMA variant wins on wide-K layers over large maps, loses on short-K / small maps
-  if (d.ks == 3 && d.stride == 1 && k.Ho >= 60 && d.Cin >= 128 && use_dma_kernel()) return launch_dma(e, k, s, flop);
+  if (d.ks == 3 && d.stride == 1 && !d.head_w && !d.argmax_part && use_dma_kernel()) {
+    // steady-state A/B on MI355X (tools/ab3.sh, round 1): the 16-channel-slice DMA kernel (v3) wins on >= 120-row maps
+    // with K >= 128 channels, the 32-channel-slice DMA kernel (v2) on 60..119-row maps, the register-staged kernel
+    // (v1) on short-K layers and on small maps, where the big DMA tiles leave CUs idle
+    const int cv = conv_variant();
+    const bool v3ok = (d.N % 128 == 0) ? k.Ho >= 12 : k.Ho >= 24;
+    const bool v2ok = k.Ho >= 16;
+    const bool wide = d.Cin >= 128;
+    int pick = 0;
+    if (cv == 3 && v3ok) pick = 3;
+    else if (cv == 2 && v2ok) pick = 2;
+    else if (cv == 1 && wide && k.Ho >= 120) pick = 3;
+    else if (cv == 1 && wide && k.Ho >= 60) pick = 2;
+    if (pick == 3) return d.N % 128 == 0 ? launch_dma16<2>(e, k, s, flop) : launch_dma16<1>(e, k, s, flop);
+    if (pick == 2) return launch_dma(e, k, s, flop);
+  }
   if (d.ks == 3 && d.stride == 1 && k.Ho <= 4 && k.Wo > 32) return launch_cfg<3, 1, 1>(e, k, s, flop);
   if (d.ks == 3 && d.stride == 1) return launch_cfg<3, 1>(e, k, s, flop);
   if (d.ks == 3 && d.stride == 2) return launch_cfg<3, 2>(e, k, s, flop);

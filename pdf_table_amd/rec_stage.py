@@ -83,12 +83,18 @@ def perspective_inverse(src: np.ndarray, dst: np.ndarray) -> np.ndarray:
         b[:, i] = d[:, i, 0]
         b[:, i + 4] = d[:, i, 1]
     out = np.zeros((n, 9))
-    for k in range(n):                     # per-quad so that one singular system does not poison the batch
-        try:
-            m = np.append(np.linalg.solve(a[k], b[k]), 1.0).reshape(3, 3)
-            out[k] = np.linalg.inv(m).reshape(-1)
-        except np.linalg.LinAlgError:
-            pass
+    # batched LAPACK (gesv / getri per matrix, i.e. the same routine a per-quad call runs); singular systems are
+    # masked out first so that one degenerate quad does not poison the batch
+    with np.errstate(all="ignore"):
+        ok = np.abs(np.linalg.det(a)) > 0
+    if ok.any():
+        x = np.linalg.solve(a[ok], b[ok][:, :, None])[:, :, 0]
+        m = np.concatenate([x, np.ones((x.shape[0], 1))], 1).reshape(-1, 3, 3)
+        with np.errstate(all="ignore"):
+            good = np.abs(np.linalg.det(m)) > 0
+        inv = np.zeros_like(m)
+        inv[good] = np.linalg.inv(m[good])
+        out[ok] = inv.reshape(-1, 9)
     return out
 
 

@@ -29,4 +29,4 @@ ms = ev0.elapsed_time(ev1) / iters
 pad = ks // 2
 Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
 fl = 2.0 * B * Ho * Wo * N * Cin * ks * ks
-print(f"conv {ks}x{ks} s{stride} {Cin}->{N} @{H}x{W} B={B}: {ms*1e3:.1f} us  {fl/ms/1e9:.0f} TFLOP/s  (DMA={os.environ.get('PT_CONV_DMA','1')})")
+print(f"conv {ks}x{ks} s{stride} {Cin}->{N} @{H}x{W} B={B}: {ms*1e3:.1f} us  {fl/ms/1e9:.0f} TFLOP/s  (variant={os.environ.get('PT_CONV_VARIANT','0')})")
