@@ -19,7 +19,8 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-__all__ = ["db_resnet18_state_dict", "crnn_state_dict", "CRNN_NUM_CLASSES"]
+__all__ = ["db_resnet18_state_dict", "crnn_state_dict", "CRNN_NUM_CLASSES", "lore_dla34_state_dict",
+           "lore_processor_state_dict", "LORE_HEADS"]
 
 CRNN_NUM_CLASSES = 7644  # crnn/modeling_crnn.py:90
 
@@ -145,4 +146,146 @@ def crnn_state_dict(seed: int = 0, num_classes: int = CRNN_NUM_CLASSES):
     g.lstm("rnn.1.rnn", 256, 256, scale=3.0)
     g.linear("rnn.1.embedding", 512, 512, scale=4.0)
     g.linear("cls", num_classes, 512, bias=False, scale=4.0)
+    return g.sd
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Lore (table structure): DLA-34 + DCN detector and the logical-location processor
+# --------------------------------------------------------------------------------------------------------------------
+LORE_HEADS = {"hm": 2, "st": 8, "wh": 8, "ax": 256, "cr": 256, "reg": 2}     # lore/modeling_lore.py:89
+DLA34_LEVELS = [1, 1, 1, 2, 2, 1]                                            # center_net/modeling_centernet.py:405-409
+DLA34_CHANNELS = [16, 32, 64, 128, 256, 512]
+
+
+def lore_dla34_state_dict(seed: int = 0, hm_bias: float = -6.0, hm_gain: float = 0.5, cell_half=(10.0, 6.0)):
+    """state_dict of ``get_dla_dcn(34, heads)`` = ``DLASeg`` (lore/lore_dla_34.py:137-206) on ``dla34``
+    (center_net/modeling_centernet.py:274-409, incl. the unused 1000-way ``fc``).
+
+    Deformable convs get non-zero offset/mask weights (the reference initialises them to zero, dcnv2.py:66-67;
+    trained checkpoints are not) with offsets of about one pixel.  ``hm``/``wh`` biases are chosen so that a random
+    net yields a table-like number of cell centres with well-formed quads (corner i = centre - wh[2i:2i+2])."""
+    g = _Gen(seed)
+    ch = DLA34_CHANNELS
+    g.conv("base.base_layer.0", ch[0], 3, 7, 7)
+    g.bn("base.base_layer.1", ch[0])
+    g.conv("base.level0.0", ch[0], ch[0], 3, 3)
+    g.bn("base.level0.1", ch[0])
+    g.conv("base.level1.0", ch[1], ch[0], 3, 3)
+    g.bn("base.level1.1", ch[1])
+
+    def block(p, cin, cout):
+        g.conv(p + ".conv1", cout, cin, 3, 3)
+        g.bn(p + ".bn1", cout)
+        g.conv(p + ".conv2", cout, cout, 3, 3, gain=1.0)
+        g.bn(p + ".bn2", cout)
+
+    def tree(p, levels, cin, cout, level_root, root_dim=0):
+        if root_dim == 0:
+            root_dim = 2 * cout
+        if level_root:
+            root_dim += cin
+        if levels == 1:
+            block(p + ".tree1", cin, cout)
+            block(p + ".tree2", cout, cout)
+            g.conv(p + ".root.conv", cout, root_dim, 1, 1)
+            g.bn(p + ".root.bn", cout)
+        else:
+            tree(p + ".tree1", levels - 1, cin, cout, False, 0)
+            tree(p + ".tree2", levels - 1, cout, cout, False, root_dim + cout)
+        if cin != cout:
+            g.conv(p + ".project.0", cout, cin, 1, 1, gain=1.0)
+            g.bn(p + ".project.1", cout)
+
+    for lvl in range(2, 6):
+        tree(f"base.level{lvl}", DLA34_LEVELS[lvl], ch[lvl - 1], ch[lvl], lvl > 2)
+    g.conv("base.fc", 1000, ch[5], 1, 1, bias=True)
+
+    def dcn(p, cin, cout):
+        g.bn(p + ".actf.0", cout)
+        g.conv(p + ".conv", cout, cin, 3, 3, bias=True)
+        # 27 = 18 offsets + 9 mask logits; offsets ~ N(0, 1 px), mask logits ~ N(0, 1)
+        g.conv(p + ".conv.conv_offset_mask", 27, cin, 3, 3, bias=True, gain=1.0)
+
+    def up(p, c, f):
+        # fill_up_weights (lore_dla_34.py:53-62): bilinear kernel, same for every channel; perturbed per channel
+        # here so that the per-channel weights are really read
+        k = 2 * f
+        ff = math.ceil(k / 2)
+        cc = (2 * ff - 1 - ff % 2) / (2.0 * ff)
+        w = np.zeros((c, 1, k, k))
+        for i in range(k):
+            for j in range(k):
+                w[:, 0, i, j] = (1 - math.fabs(i / ff - cc)) * (1 - math.fabs(j / ff - cc))
+        w *= g.rng.uniform(0.9, 1.1, (c, 1, 1, 1))
+        g.put(p + ".weight", w)
+
+    def ida(p, o, channels, up_f):
+        for i in range(1, len(channels)):
+            dcn(f"{p}.proj_{i}", channels[i], o)
+            dcn(f"{p}.node_{i}", o, o)
+            up(f"{p}.up_{i}", o, int(up_f[i]))
+
+    # DLAUp.__init__ (lore_dla_34.py:115-126) with channels [64,128,256,512], scales [1,2,4,8]
+    channels = ch[2:]
+    in_channels = list(channels)
+    scales = np.array([1, 2, 4, 8])
+    for i in range(len(channels) - 1):
+        j = -i - 2
+        ida(f"dla_up.ida_{i}", channels[j], in_channels[j:], scales[j:] // scales[j])
+        scales[j + 1:] = scales[j]
+        in_channels[j + 1:] = [channels[j] for _ in channels[j + 1:]]
+    ida("ida_up", ch[2], ch[2:5], [1, 2, 4])
+
+    for h, k in LORE_HEADS.items():
+        g.conv(f"{h}.0", 256, ch[2], 3, 3, bias=True)
+        if h == "hm":
+            g.conv(f"{h}.2", k, 256, 1, 1, bias=False, gain=hm_gain)
+            g.put(f"{h}.2.bias", np.full((k,), hm_bias))
+        elif h in ("wh", "st"):
+            g.conv(f"{h}.2", k, 256, 1, 1, bias=False, gain=0.05)
+            hw, hh = cell_half
+            g.put(f"{h}.2.bias", np.array([hw, hh, -hw, hh, -hw, -hh, hw, -hh]))
+        elif h == "reg":
+            g.conv(f"{h}.2", k, 256, 1, 1, bias=False, gain=0.02)
+            g.put(f"{h}.2.bias", np.array([0.5, 0.5]))
+        else:
+            g.conv(f"{h}.2", k, 256, 1, 1, bias=True, gain=0.5)
+    return g.sd
+
+
+def lore_processor_state_dict(seed: int = 0, layers: int = 4, stacking_layers: int = 4):
+    """state_dict of ``LoreProcessModel`` (lore/lore_processor.py:399-437): stacker + tsfm_axis + 2 position tables."""
+    g = _Gen(seed)
+
+    def norm(p, d):
+        g.put(p + ".alpha", g.rng.uniform(0.8, 1.2, (d,)))
+        g.put(p + ".bias", g.rng.uniform(-0.1, 0.1, (d,)))
+
+    def transformer(p, in_size, hid, out_size, n):
+        g.linear(p + ".linear", hid, in_size)
+        # PositionalEncoder buffer (lore_processor.py:260-274) -- registered, never used in forward
+        pe = np.zeros((900, hid))
+        for pos in range(900):
+            for i in range(0, hid, 2):
+                pe[pos, i] = math.sin(pos / (10000 ** ((2 * i) / hid)))
+                pe[pos, i + 1] = math.cos(pos / (10000 ** ((2 * (i + 1)) / hid)))
+        g.put(p + ".encoder.pe.pe", pe[None])
+        for li in range(n):
+            q = f"{p}.encoder.layers.{li}"
+            norm(q + ".norm_1", hid)
+            norm(q + ".norm_2", hid)
+            for nm in ("q_linear", "v_linear", "k_linear", "out"):
+                g.linear(f"{q}.attn.{nm}", hid, hid, scale=2.0)
+            g.linear(q + ".ff.linear_1", 2048, hid, scale=1.5)
+            g.linear(q + ".ff.linear_2", hid, 2048, scale=1.5)
+        norm(p + ".encoder.norm", hid)
+        g.linear(p + ".decoder.linear.0", hid, hid, scale=2.0)
+        g.linear(p + ".decoder.linear.2", out_size, hid, scale=2.0)
+
+    g.linear("stacker.logi_encoder.0", 256, 4)
+    g.linear("stacker.logi_encoder.2", 256, 256)
+    transformer("stacker.tsfm", 512, 256, 4, stacking_layers)
+    transformer("tsfm_axis", 256, 256, 4, layers)
+    g.put("x_position_embeddings.weight", g.rng.standard_normal((256, 256)))
+    g.put("y_position_embeddings.weight", g.rng.standard_normal((256, 256)))
     return g.sd

@@ -228,8 +228,55 @@ def gen_db_host_numpy():
     print("db_host_numpy.npz", len(filt), "of", len(boxes), "boxes kept")
 
 
+def lore_env():
+    """Make lore/*.py importable: parent packages as empty stand-ins (their __init__ pull in transformers configs,
+    cv2 ...) and ``torchvision.ops.deform_conv2d`` -- torchvision is not installed -- provided by the oracle's
+    restatement, which is itself pinned against the reference's vendored DCNv2 C++ (tests/test_oracle_lore.py)."""
+    import transformers  # noqa: F401  (must be imported before the fake torchvision appears)
+    from oracle import lore_net
+    stub_env()
+    for sub in ("model", "model/center_net", "model/lore"):
+        name = "pdftable." + sub.replace("/", ".")
+        if name not in sys.modules:
+            _pkg(name, os.path.join(REF_SRC, "pdftable", sub))
+    if "torchvision" not in sys.modules:
+        tv = types.ModuleType("torchvision")
+        tvo = types.ModuleType("torchvision.ops")
+
+        def deform_conv2d(x, offset, weight, bias, stride, padding, dilation, mask):
+            return lore_net.deform_conv2d(x, offset, mask, weight, bias, stride[0], padding[0], dilation[0])
+        tvo.deform_conv2d = deform_conv2d
+        tv.ops = tvo
+        sys.modules["torchvision"] = tv
+        sys.modules["torchvision.ops"] = tvo
+
+
+def gen_lore_dla34():
+    """Outputs of the reference ``DLASeg`` (lore_dla_34.py:137-196) for seeded weights and inputs."""
+    from pdf_table_amd.synth_weights import LORE_HEADS, lore_dla34_state_dict
+    lore_env()
+    m = ref_import("pdftable.model.lore.lore_dla_34")
+    model = m.get_dla_dcn(34, dict(LORE_HEADS), head_conv=256).eval()
+    sd = lore_dla34_state_dict(seed=21)
+    model.load_state_dict(sd, strict=True)
+    rng = np.random.default_rng(105)
+    out = {"seed": np.array(21)}
+    for tag, (h, w) in {"a": (128, 160), "b": (64, 64)}.items():
+        x = rng.standard_normal((1, 3, h, w)).astype(np.float32)
+        with torch.no_grad():
+            z = model(torch.from_numpy(x))[0]
+        out[f"x_{tag}"] = x
+        for k, v in z.items():
+            v = v.numpy()
+            out[f"{k}_{tag}"] = v[:, ::8] if v.shape[1] == 256 else v     # every 8th channel of ax / cr
+    np.savez_compressed(os.path.join(HERE, "lore_dla34.npz"), **out)
+    print("lore_dla34.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["db", "crnn", "registry", "ctc", "host"]
+    which = sys.argv[1:] or ["db", "crnn", "registry", "ctc", "host", "lore_dla"]
+    if "lore_dla" in which:
+        gen_lore_dla34()
     if "host" in which:
         gen_db_host_numpy()
     if "db" in which:
