@@ -59,6 +59,7 @@ int pt_engine_set_precision(pt_engine* e, int precision);
 enum {
   PT_MODEL_DB_RESNET18 = 1, /* db_net/dbnet.py:715-728 */
   PT_MODEL_CRNN = 2,        /* crnn/modeling_crnn.py:36-113 */
+  PT_MODEL_LORE_DLA34 = 3,  /* lore/lore_dla_34.py:137-206 (DLASeg on dla34 + DCN), modeling_lore.py:88-95 */
 };
 int pt_weights_load(pt_engine* e, int model_kind, const void* h_blob, size_t nbytes);
 /* Same, but the blob already sits in device memory (e.g. after an RCCL broadcast from rank 0). */
@@ -159,6 +160,20 @@ int pt_rec_forward_net(pt_engine* e, const uint16_t* d_gray, int n, int32_t* d_i
 /* Crop + resize + gray only (tests): writes d_gray as above. */
 int pt_rec_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int h, int w, const pt_rec_line* d_lines,
                       const int64_t* h_crop_px, int n_lines, uint16_t* d_gray, pt_stream stream);
+
+/* ---- stage 4: table structure recognition (Lore) ------------------------------------------------- */
+/* Detector network only (LoreModel.forward's `self.detect_infer_model(pixel_values)`, lore/modeling_lore.py:147;
+ * DLASeg.forward lore/lore_dla_34.py:184-196).
+ *   d_input_bf16 : bf16 NHWC4 [n, H, W, 4] (4th channel zero; [hi rgb0 | lo rgb0] = 8 channels in BF16X3 mode),
+ *                  already warped + normalised (TableLorePreProcessor.process, lore/processer_lore.py:66-109);
+ *                  H, W multiples of 32
+ *   outputs      : fp32 NHWC head maps at H/4 x W/4, channel strides PT_TSR_CS_*: hm [.,8] (2 valid: cell centres,
+ *                  corners), st [.,8], wh [.,8], ax [.,256], cr [.,256], reg [.,8] (2 valid) -- the dict `z` of
+ *                  DLASeg.forward, pre-sigmoid */
+#define PT_TSR_CS_SMALL 8
+#define PT_TSR_CS_FEAT 256
+int pt_tsr_forward_net(pt_engine* e, const uint16_t* d_input_bf16, int n, int H, int W, float* d_hm, float* d_st,
+                       float* d_wh, float* d_ax, float* d_cr, float* d_reg, pt_stream stream);
 
 /* ---- single operator (parity tests of the conv kernel variants) --------------------------------- */
 /* NHWC bf16 convolution on the MFMA implicit-GEMM kernel. d_w_tiled is [N/64][Cin/32][ks*ks][64][32] bf16

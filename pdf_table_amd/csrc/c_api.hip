@@ -19,7 +19,7 @@ void pt_set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* pt_last_error(void) { return g_err; }
-int pt_abi_version(void) { return 2; }
+int pt_abi_version(void) { return 3; }
 
 int pt_engine_set_precision(pt_engine* e, int precision) {
   PT_REQUIRE(e && (precision == PT_PRECISION_BF16 || precision == PT_PRECISION_BF16X3), "pt_engine_set_precision: bad arguments");
@@ -204,6 +204,14 @@ int pt_det_forward_net(pt_engine* e, const uint16_t* d_input_bf16, int n, int ne
   PT_REQUIRE(e && d_input_bf16 && n > 0 && (d_prob || d_logits), "pt_det_forward_net: bad arguments");
   PT_HIP_CHECK(hipSetDevice(e->device));
   return pt_db_forward_net(e, d_input_bf16, n, net_h, net_w, d_prob, d_logits, reinterpret_cast<hipStream_t>(stream));
+}
+
+int pt_tsr_forward_net(pt_engine* e, const uint16_t* d_input_bf16, int n, int H, int W, float* d_hm, float* d_st,
+                       float* d_wh, float* d_ax, float* d_cr, float* d_reg, pt_stream stream) {
+  PT_REQUIRE(e && d_input_bf16 && n > 0, "pt_tsr_forward_net: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  return pt_lore_forward_net(e, d_input_bf16, n, H, W, d_hm, d_st, d_wh, d_ax, d_cr, d_reg,
+                             reinterpret_cast<hipStream_t>(stream));
 }
 
 int pt_det_bitmap(pt_engine* e, const float* d_prob, int n, int net_h, int net_w, float thresh, int use_dilation,

@@ -134,12 +134,16 @@ struct ConvDesc {
   float* head_logits = nullptr;
   // fused arg-max over N: float2 (max, index-as-bits) per (output row, 64-wide N tile); no activation tensor is written
   float* argmax_part = nullptr;
+  // only output channels [0, n_valid) are stored (0 = all N); out_f32: fp32 [pixel][out_cstride] output instead of bf16
+  int n_valid = 0;
+  float* out_f32 = nullptr;
 };
 int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s);
 
-// stem: 7x7 s2 p3 conv on NHWC4 bf16 input, 64 outputs, bias + ReLU (conv_igemm.hip)
+// stem: 7x7 p3 conv (stride 1 or 2) on NHWC4 bf16 input, 64 GEMM outputs of which the first n_valid (0 = 64) are
+// stored, bias + ReLU (conv_igemm.hip)
 int pt_launch_stem7x7(pt_engine* e, const bf16_t* in, int B, int H, int W, const bf16_t* w, const float* bias,
-                      bf16_t* out, int split, hipStream_t s);
+                      bf16_t* out, int split, hipStream_t s, int stride = 2, int n_valid = 0);
 
 // ---- misc kernels (det_kernels.hip) ---------------------------------------------------------------------
 int pt_launch_det_preprocess(const uint8_t* pages, int n, int h, int w, int nh, int nw, int flavour, int split,
@@ -167,6 +171,8 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
 
 // ---- models ---------------------------------------------------------------------------------------------
 int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* prob, float* logits, hipStream_t s);
+int pt_lore_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* hm, float* st, float* wh, float* ax,
+                        float* cr, float* reg, hipStream_t s);
 
 #define PT_PRECISION_BF16 0
 #define PT_PRECISION_BF16X3 1

@@ -52,6 +52,10 @@ struct ConvK {
   float* head_logits;
   // fused per-row arg-max over the N (class) dimension: partial (max, index) per 64-class tile -> [rows][N/64] float2
   float* argmax_part;
+  // n_valid > 0: only output channels [0, n_valid) are stored (N is padded to a multiple of 64 with zero weights);
+  // out_f32 != null: the plain store path writes fp32 [pixel][out_cstride] there instead of bf16 (network outputs)
+  int n_valid;
+  float* out_f32;
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
@@ -191,6 +195,13 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
       const size_t oo = (((size_t)b * OH + 2 * oy + (quad >> 1)) * OW + 2 * ox + (quad & 1)) * p.out_cstride + p.out_coff + co;
       *reinterpret_cast<u32x4*>(p.out + oo) = o;
       if (p.split) *reinterpret_cast<u32x4*>(p.out + oo + p.out_lo_off) = ol;
+    } else if (EXTRAS && p.n_valid && n >= p.n_valid) {
+      // padded output channel: nothing to store
+    } else if (EXTRAS && p.out_f32) {
+      const size_t oo = (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.out_cstride + p.out_coff + n;
+      f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+      *reinterpret_cast<f32x4*>(p.out_f32 + oo) = o0;
+      *reinterpret_cast<f32x4*>(p.out_f32 + oo + 4) = o1;
     } else {
       const int f = p.rep;
       const int OH = p.Ho * f, OW = p.Wo * f;
@@ -680,23 +691,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma16_kernel(ConvK p, const bf
 // K is laid out [r=7][s=8][c=4] = 224 (tap s=7 and channel 3 carry zero weights), so that one MFMA
 // k-step (16) = 4 horizontally adjacent pixels x 4 channels = 32 contiguous bytes of the image row.
 // ---------------------------------------------------------------------------------------------------
+template <int S>
 struct StemCfg {
   static constexpr int TH = 8, TW = 32;
-  static constexpr int THIN = (TH - 1) * 2 + 7;   // 21
-  static constexpr int TWIN = (TW - 1) * 2 + 8;   // 70
-  static constexpr int IN_BYTES = THIN * TWIN * 8;  // 11760
+  static constexpr int THIN = (TH - 1) * S + 7;         // 21 (S=2) / 14 (S=1)
+  static constexpr int TWIN = ((TW - 1) * S + 8 + 1) & ~1;  // 70 / 40 (even: staged as pixel pairs)
+  static constexpr int IN_BYTES = THIN * TWIN * 8;
   static constexpr int WROW = 464;                  // 224 bf16 = 448 B + 16 B pad (odd number of 16-B slots)
   static constexpr int W_BYTES = 64 * WROW;
   static constexpr int STAGE_BYTES = TH * TW * 64 * 4;
-  static constexpr int SMEM = STAGE_BYTES;  // > IN_BYTES + W_BYTES (41456)
-  static constexpr int NP_IN = THIN * (TWIN / 2);  // 735 pixel pairs
-  static constexpr int NI = (NP_IN + 255) / 256;   // 3
+  static constexpr int SMEM = STAGE_BYTES;  // > IN_BYTES + W_BYTES (41456 at S=2)
+  static constexpr int HP = TWIN / 2;              // pixel pairs per patch row
+  static constexpr int NP_IN = THIN * HP;
+  static constexpr int NI = (NP_IN + 255) / 256;
   static constexpr int NP_W = 64 * 28;             // 1792 16-byte pieces
   static constexpr int NWP = NP_W / 256;           // 7
 };
 
+// 7x7 pad-3 convolution of a 3-channel image stored NHWC4 ([r g b 0] bf16 per pixel), stride S, 64 GEMM outputs
+// (ResNet-18 stem: S=2, 64 channels, db_net/dbnet.py:272; DLA-34 base_layer: S=1, 16 channels + zero padding,
+// center_net/modeling_centernet.py:291-294).  K = [7 ky][8 kx][4 c] = 224: an A fragment is two horizontally
+// adjacent input pixels, so at S=1 fragments are only 8-byte aligned and are read as two ds_read_b64.
+template <int S>
 __global__ __launch_bounds__(256, 2) void conv_stem7x7_kernel(ConvK p) {
-  using C = StemCfg;
+  using C = StemCfg<S>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_in = smem;
   char* s_w = smem + C::IN_BYTES;
@@ -710,7 +728,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_kernel(ConvK p) {
   const int tyi = L % p.tiles_y;
   const int b = L / p.tiles_y;
   const int oy0 = tyi * C::TH, ox0 = txi * C::TW;
-  const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+  const int iy0 = oy0 * S - 3, ix0 = ox0 * S - 3;
   const int ps = p.split ? 8 : 4;  // bf16 elements per input pixel: [r g b 0] or [hi rgb0 | lo rgb0]
   const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * ps;
 
@@ -722,7 +740,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_kernel(ConvK p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  const char* a_base = s_in + (((wave * 2) * 2) * C::TWIN + 2 * lx + 2 * q) * 8;
+  const char* a_base = s_in + (((wave * 2) * S) * C::TWIN + S * lx + 2 * q) * 8;
   const char* b_base = s_w + lx * C::WROW + q * 16;
   // split mode: three passes (x_hi, w_hi), (x_lo, w_hi), (x_hi, w_lo) into the same accumulators
   const int npass = p.split ? 3 : 1;
@@ -734,7 +752,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_kernel(ConvK p) {
     for (int j = 0; j < C::NI; ++j) {
       const int idx = tid + j * 256;
       if (idx < C::NP_IN) {
-        const int iy = idx / 35, ip = idx - iy * 35;
+        const int iy = idx / C::HP, ip = idx - iy * C::HP;
         const int gy = iy0 + iy, gx = ix0 + 2 * ip;
         u32x2 v0 = {0u, 0u}, v1 = {0u, 0u};
         if ((unsigned)gy < (unsigned)p.H) {
@@ -764,7 +782,15 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_kernel(ConvK p) {
         const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(b_base + 32 * C::WROW + ks * 32);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base + ((m * 2 + r) * C::TWIN + 4 * h) * 8);
+          const char* ap = a_base + ((m * S + r) * C::TWIN + 4 * h) * 8;
+          bf16x8 a;
+          if (S == 2) {
+            a = *reinterpret_cast<const bf16x8*>(ap);
+          } else {
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(ap), hi = *reinterpret_cast<const u32x2*>(ap + 8);
+            const u32x4 av = {lo.x, lo.y, hi.x, hi.y};
+            a = __builtin_bit_cast(bf16x8, av);
+          }
           acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
           acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
         }
@@ -886,7 +912,7 @@ static int launch_dma(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
 }
 
 int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
-  PT_REQUIRE(d.in && d.w && d.bias && (d.out || d.head_w || d.argmax_part), "conv: null pointer");
+  PT_REQUIRE(d.in && d.w && d.bias && (d.out || d.out_f32 || d.head_w || d.argmax_part), "conv: null pointer");
   PT_REQUIRE(d.Cin % 32 == 0 && d.Cin > 0, "conv: Cin=%d must be a positive multiple of 32", d.Cin);
   PT_REQUIRE(d.N % 64 == 0 && d.N > 0, "conv: N=%d must be a positive multiple of 64", d.N);
   PT_REQUIRE((d.ks == 1 || d.ks == 3) && (d.stride == 1 || d.stride == 2), "conv: ks=%d stride=%d unsupported", d.ks,
@@ -895,6 +921,10 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
              "conv: bad pixel-shuffle configuration");
   PT_REQUIRE(d.rep >= 1 && d.out_cstride % 8 == 0 && d.out_coff % 8 == 0, "conv: bad output layout");
   ConvK k;
+  memset(&k, 0, sizeof(k));
+  k.n_valid = d.n_valid; k.out_f32 = d.out_f32;
+  PT_REQUIRE(d.n_valid % 8 == 0 && d.n_valid <= d.N, "conv: n_valid=%d must be a multiple of 8 and <= N", d.n_valid);
+  PT_REQUIRE(!(d.out_f32 && (d.rep != 1 || d.shuffle_cout)), "conv: fp32 output only on the plain store path");
   k.in = d.in; k.w = d.w; k.bias = d.bias; k.out = d.out; k.res = d.res;
   k.B = d.B; k.H = d.H; k.W = d.W; k.Cin = d.Cin; k.N = d.N;
   const int pad = d.ks / 2;
@@ -908,7 +938,7 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   if (d.head_w) PT_REQUIRE(d.shuffle_cout == 64 && d.head_b && (d.head_prob || d.head_logits), "conv: bad fused-head configuration");
   if (k.res_mode == 2) PT_REQUIRE(k.Ho % 2 == 0 && k.Wo % 2 == 0, "conv: half-res residual needs even output size");
   const double flop = 2.0 * k.B * k.Ho * k.Wo * (double)k.N * d.Cin * d.ks * d.ks;  // algorithmic (not x3 in split mode)
-  if (d.ks == 3 && d.stride == 1 && !d.head_w && !d.argmax_part && use_dma_kernel()) {
+  if (d.ks == 3 && d.stride == 1 && !d.head_w && !d.argmax_part && !d.n_valid && !d.out_f32 && use_dma_kernel()) {
     // steady-state A/B on MI355X (tools/ab3.sh, round 1): the 16-channel-slice DMA kernel (v3) wins on >= 120-row maps
     // with K >= 128 channels, the 32-channel-slice DMA kernel (v2) on 60..119-row maps, the register-staged kernel
     // (v1) on short-K layers and on small maps, where the big DMA tiles leave CUs idle
@@ -931,28 +961,36 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   return launch_cfg<1, 2>(e, k, s, flop);
 }
 
-int pt_launch_stem7x7(pt_engine* e, const bf16_t* in, int B, int H, int W, const bf16_t* w, const float* bias,
-                      bf16_t* out, int split, hipStream_t s) {
-  PT_REQUIRE(in && w && bias && out, "stem: null pointer");
-  PT_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: H, W must be even");
+template <int S>
+static int launch_stem(pt_engine* e, ConvK& k, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem7x7_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, StemCfg::SMEM));
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem7x7_kernel<S>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, StemCfg<S>::SMEM));
     attr_done = true;
   }
+  k.tiles_x = (k.Wo + 31) / 32; k.tiles_y = (k.Ho + 7) / 8; k.n_tiles = 1;
+  const long long nblk = (long long)k.B * k.tiles_x * k.tiles_y;
+  PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "stem grid out of range");
+  PtProfScope prof(e, s, PT_PROF_STEM, 2.0 * k.B * k.Ho * k.Wo * 64.0 * 147.0, S == 2 ? "stem7x7 s2" : "stem7x7 s1");
+  hipLaunchKernelGGL(conv_stem7x7_kernel<S>, dim3((unsigned)nblk), dim3(256), StemCfg<S>::SMEM, s, k);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_launch_stem7x7(pt_engine* e, const bf16_t* in, int B, int H, int W, const bf16_t* w, const float* bias,
+                      bf16_t* out, int split, hipStream_t s, int stride, int n_valid) {
+  PT_REQUIRE(in && w && bias && out, "stem: null pointer");
+  PT_REQUIRE(stride == 1 || stride == 2, "stem: stride %d unsupported", stride);
+  PT_REQUIRE(stride == 1 || (H % 2 == 0 && W % 2 == 0), "stem: H, W must be even");
+  PT_REQUIRE(n_valid % 8 == 0 && n_valid >= 0 && n_valid <= 64, "stem: bad n_valid");
+  const int nv = n_valid ? n_valid : 64;
   ConvK k;
   memset(&k, 0, sizeof(k));
   k.in = in; k.w = w; k.bias = bias; k.out = out; k.res = nullptr;
   k.B = B; k.H = H; k.W = W; k.Cin = 4; k.N = 64;
-  k.Ho = H / 2; k.Wo = W / 2;
-  k.out_cstride = split ? 128 : 64; k.out_coff = 0; k.rep = 1; k.shuffle_cout = 0; k.res_mode = 0; k.relu = 1;
-  k.split = split; k.out_lo_off = 64;
-  k.tiles_x = (k.Wo + 31) / 32; k.tiles_y = (k.Ho + 7) / 8; k.n_tiles = 1;
-  const long long nblk = (long long)B * k.tiles_x * k.tiles_y;
-  PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "stem grid out of range");
-  PtProfScope prof(e, s, PT_PROF_STEM, 2.0 * B * k.Ho * k.Wo * 64.0 * 147.0, "stem7x7");
-  hipLaunchKernelGGL(conv_stem7x7_kernel, dim3((unsigned)nblk), dim3(256), StemCfg::SMEM, s, k);
-  PT_HIP_CHECK(hipGetLastError());
-  return PT_OK;
+  k.Ho = H / stride; k.Wo = W / stride;
+  k.out_cstride = split ? 2 * nv : nv; k.out_coff = 0; k.rep = 1; k.shuffle_cout = 0; k.res_mode = 0; k.relu = 1;
+  k.split = split; k.out_lo_off = nv; k.n_valid = n_valid;
+  return stride == 2 ? launch_stem<2>(e, k, s) : launch_stem<1>(e, k, s);
 }

@@ -1,0 +1,239 @@
+// lore_model.hip -- launch graph of Lore's table-cell detector (DLA-34 backbone + DCN up-sampling + six heads).
+//
+// Reference graph: DLASeg.forward lore/lore_dla_34.py:184-196
+//   base    = dla34: DLA.forward center_net/modeling_centernet.py:382-402 (Tree.forward :259-271, Root :167-175,
+//             BasicBlock :58-72)
+//   dla_up  = DLAUp.forward :128-134 over IDAUp.forward :106-112; every proj/node is DeformConv :65-83 =
+//             DCN (lore/dcnv2.py:71-86) -> BN -> ReLU; every up is a depthwise ConvTranspose2d
+//   heads   = conv3x3(64->256)+ReLU+conv1x1 for hm, st, wh, ax, cr, reg (:159-182)
+// Engine mapping: Conv+BN(+ReLU) folded, residual add in the conv epilogue; Root's conv over a channel concat is
+// evaluated child by child, accumulating through the residual path (no concat tensor); DCN = offset/mask conv (fp32
+// out) -> dcn_im2col_kernel -> 1x1 GEMM over 9*C columns; the `up(x) + skip` add is fused into the up-sampler.
+// 16-channel tensors (base_layer, level0) are stored 32 wide with a zero upper half.
+#include <stdlib.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+int pt_launch_dcn_im2col(const bf16_t* x, const float* om, bf16_t* cols, int B, int H, int W, int C, int split,
+                         hipStream_t s);
+int pt_launch_dwconvt_up_add(const bf16_t* in, const float* w, const bf16_t* add, bf16_t* out, int B, int h, int wd,
+                             int C, int f, int split, hipStream_t s);
+
+namespace {
+
+struct T {
+  bf16_t* p = nullptr;
+  int H = 0, W = 0, C = 0;
+};
+
+struct Ctx {
+  pt_engine* e;
+  const PtModel* m;
+  hipStream_t s;
+  int n, x3, mul;
+  bool dry;      // planning pass: only arena accounting, no launches
+  bool ok;       // arena had room for everything so far
+  int rc;
+  bf16_t* cols = nullptr;   // shared DCN column scratch (largest site)
+  float* om = nullptr;      // shared offset/mask scratch, fp32 [pixel][32]
+
+  T alloc(int H, int W, int C) {
+    T t;
+    t.H = H; t.W = W; t.C = C;
+    t.p = reinterpret_cast<bf16_t*>(e->arena.take((size_t)n * H * W * C * mul * sizeof(bf16_t)));
+    if (!t.p) ok = false;
+    return t;
+  }
+  const PtTensor* get(const std::string& name) {
+    const PtTensor* t = m->find(name);
+    if (!t && rc == PT_OK) {
+      pt_set_error("Lore DLA-34 weight blob lacks tensor '%s'", name.c_str());
+      rc = PT_ERR_FORMAT;
+    }
+    return t;
+  }
+  // conv with folded bias; q = weight name prefix; N = GEMM width (multiple of 64), nv = channels stored (0 = N)
+  void conv(const T& in, const std::string& q, int N, int ks, int stride, const T& out, int relu, const T* res = nullptr,
+            int nv = 0, float* out_f32 = nullptr, int f32_cs = 0, int cin_override = 0) {
+    const PtTensor* w = get(q + (x3 ? ".w3" : ".w"));
+    const PtTensor* b = get(q + ".b");
+    if (rc != PT_OK || dry || !ok) return;
+    ConvDesc c;
+    c.in = in.p; c.B = n; c.H = in.H; c.W = in.W; c.Cin = cin_override ? cin_override : in.C;
+    c.w = reinterpret_cast<const bf16_t*>(w->d_ptr); c.bias = reinterpret_cast<const float*>(b->d_ptr);
+    c.N = N; c.ks = ks; c.stride = stride; c.relu = relu; c.split = x3; c.n_valid = nv;
+    if (out_f32) {
+      c.out_f32 = out_f32; c.out_cstride = f32_cs;
+    } else {
+      c.out = out.p; c.out_cstride = out.C * mul; c.out_lo_off = out.C;
+    }
+    if (res) { c.res = res->p; c.res_mode = 1; }
+    const int r = pt_launch_conv(e, c, s);
+    if (r != PT_OK) rc = r;
+  }
+  T maxpool2(const T& x) {
+    T o = alloc(x.H / 2, x.W / 2, x.C);
+    if (rc == PT_OK && !dry && ok) {
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0, "maxpool2x2");
+      const int r = pt_launch_maxpool_kxk(x.p, n, x.H, x.W, x.C, 2, 2, 0, x3, o.p, s);
+      if (r != PT_OK) rc = r;
+    }
+    return o;
+  }
+  T block(const std::string& q, const T& x, const T& residual, int stride, int cout) {
+    T t = alloc(x.H / stride, x.W / stride, cout);
+    conv(x, q + ".conv1", cout, 3, stride, t, 1);
+    T o = alloc(t.H, t.W, cout);
+    conv(t, q + ".conv2", cout, 3, 1, o, 1, &residual);
+    return o;
+  }
+  T tree(const std::string& q, int levels, const T& x, int cin, int cout, int stride, bool level_root,
+         std::vector<T> children) {
+    T bottom = stride > 1 ? maxpool2(x) : x;
+    if (level_root) children.push_back(bottom);
+    if (levels == 1) {
+      T residual = bottom;
+      if (cin != cout) {
+        residual = alloc(bottom.H, bottom.W, cout);
+        conv(bottom, q + ".project", cout, 1, 1, residual, 0);
+      }
+      T x1 = block(q + ".tree1", x, residual, stride, cout);
+      T x2 = block(q + ".tree2", x1, x1, 1, cout);
+      std::vector<T> ins = {x2, x1};
+      ins.insert(ins.end(), children.begin(), children.end());
+      T o = alloc(x1.H, x1.W, cout);
+      for (size_t i = 0; i < ins.size(); ++i)
+        conv(ins[i], q + ".root.c" + std::to_string(i), cout, 1, 1, o, i + 1 == ins.size() ? 1 : 0, i ? &o : nullptr);
+      return o;
+    }
+    T x1 = tree(q + ".tree1", levels - 1, x, cin, cout, stride, false, {});
+    children.push_back(x1);
+    return tree(q + ".tree2", levels - 1, x1, cout, cout, 1, false, children);
+  }
+  // DeformConv (lore_dla_34.py:65-83)
+  T dcn(const std::string& q, const T& x, int cout) {
+    T o = alloc(x.H, x.W, cout);
+    conv(x, q + ".om", 64, 3, 1, T(), 0, nullptr, 32, om, 32);
+    if (rc == PT_OK && !dry && ok) {
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0, "dcn im2col");
+      const int r = pt_launch_dcn_im2col(x.p, om, cols, n, x.H, x.W, x.C, x3, s);
+      if (r != PT_OK) rc = r;
+    }
+    T c;
+    c.p = cols; c.H = x.H; c.W = x.W; c.C = 9 * x.C;
+    conv(c, q + ".dcn", cout, 1, 1, o, 1);
+    return o;
+  }
+  // IDAUp.forward (lore_dla_34.py:106-112) on layers[startp .. endp)
+  void ida(const std::string& q, std::vector<T>& layers, int startp, int endp, int o_ch, const int* up_f) {
+    for (int i = startp + 1; i < endp; ++i) {
+      const int j = i - startp;
+      const std::string js = std::to_string(j);
+      T p = dcn(q + ".proj_" + js, layers[i], o_ch);
+      const int f = up_f[j];
+      T u = alloc(p.H * f, p.W * f, o_ch);
+      const PtTensor* wu = get(q + ".up_" + js + ".wf32");
+      if (rc == PT_OK && !dry && ok) {
+        PtProfScope ps(e, s, PT_PROF_OTHER, 0, "dw convT up + add");
+        const int r = pt_launch_dwconvt_up_add(p.p, reinterpret_cast<const float*>(wu->d_ptr), layers[i - 1].p, u.p, n,
+                                               p.H, p.W, o_ch, f, x3, s);
+        if (r != PT_OK) rc = r;
+      }
+      layers[i] = dcn(q + ".node_" + js, u, o_ch);
+    }
+  }
+};
+
+}  // namespace
+
+// x: NHWC4 bf16 [n, H, W, 4] ([hi rgb0 | lo rgb0] in BF16X3 mode); heads: fp32 NHWC at H/4 x W/4 with channel
+// strides 8 (hm: 2 valid), 8 (st), 8 (wh), 256 (ax), 256 (cr), 8 (reg: 2 valid)
+int pt_lore_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* hm, float* st, float* wh, float* ax,
+                        float* cr, float* reg, hipStream_t s) {
+  PT_REQUIRE(H % 32 == 0 && W % 32 == 0 && H > 0 && W > 0, "Lore net: input %dx%d must be multiples of 32", H, W);
+  PT_REQUIRE(x && hm && st && wh && ax && cr && reg && n > 0, "Lore net: null pointer");
+  auto it = e->models.find(PT_MODEL_LORE_DLA34);
+  if (it == e->models.end()) {
+    pt_set_error("Lore DLA-34 weights not loaded (pt_weights_load(PT_MODEL_LORE_DLA34))");
+    return PT_ERR_STATE;
+  }
+  Ctx c;
+  c.e = e; c.m = &it->second; c.s = s; c.n = n;
+  c.x3 = e->precision == PT_PRECISION_BF16X3 ? 1 : 0;
+  c.mul = c.x3 ? 2 : 1;
+  c.rc = PT_OK;
+  const int ch[6] = {16, 32, 64, 128, 256, 512};
+  const int lv[6] = {1, 1, 1, 2, 2, 1};
+  float* heads[6] = {hm, st, wh, ax, cr, reg};
+  const char* hname[6] = {"hm", "st", "wh", "ax", "cr", "reg"};
+  const int hcs[6] = {8, 8, 8, 256, 256, 8};
+
+  for (int pass = 0; pass < 2; ++pass) {
+    c.dry = pass == 0;     // pass 0 only plans the arena (and grows it if needed), pass 1 launches
+    c.ok = true;
+    e->arena.reset();
+    // shared DCN scratch: the largest site is 64 channels at H/4 x W/4 (9*64 columns); 128 ch at H/8 is half of it
+    const size_t px4 = (size_t)n * (H / 4) * (W / 4);
+    c.cols = reinterpret_cast<bf16_t*>(e->arena.take(px4 * 576 * c.mul * sizeof(bf16_t)));
+    c.om = reinterpret_cast<float*>(e->arena.take(px4 * 32 * sizeof(float)));
+    if (!c.cols || !c.om) c.ok = false;
+
+    T t0 = c.alloc(H, W, 32);
+    if (!c.dry && c.ok) {
+      const PtTensor* w = c.get(c.x3 ? "base_layer.w3" : "base_layer.w");
+      const PtTensor* b = c.get("base_layer.b");
+      if (c.rc == PT_OK) {
+        const int r = pt_launch_stem7x7(e, x, n, H, W, reinterpret_cast<const bf16_t*>(w->d_ptr),
+                                        reinterpret_cast<const float*>(b->d_ptr), t0.p, c.x3, s, 1, 32);
+        if (r != PT_OK) c.rc = r;
+      }
+    }
+    std::vector<T> layers(6);
+    layers[0] = c.alloc(H, W, 32);
+    c.conv(t0, "level0", 64, 3, 1, layers[0], 1, nullptr, 32);
+    layers[1] = c.alloc(H / 2, W / 2, 32);
+    c.conv(layers[0], "level1", 64, 3, 2, layers[1], 1, nullptr, 32);
+    for (int l = 2; l < 6; ++l)
+      layers[l] = c.tree("level" + std::to_string(l), lv[l], layers[l - 1], ch[l - 1], ch[l], 2, l > 2, {});
+
+    // DLAUp.forward (lore_dla_34.py:128-134): ida_0 on [4,6), ida_1 on [3,6), ida_2 on [2,6)
+    std::vector<T> out = {layers[5]};
+    const int f2[4] = {1, 2, 2, 2};
+    c.ida("dla_up.ida_0", layers, 4, 6, 256, f2);
+    out.insert(out.begin(), layers[5]);
+    c.ida("dla_up.ida_1", layers, 3, 6, 128, f2);
+    out.insert(out.begin(), layers[5]);
+    c.ida("dla_up.ida_2", layers, 2, 6, 64, f2);
+    out.insert(out.begin(), layers[5]);
+    // ida_up on clones of out[0..3) (strides 4, 8, 16): up factors 2 and 4
+    std::vector<T> y = {out[0], out[1], out[2]};
+    const int f24[3] = {1, 2, 4};
+    c.ida("ida_up", y, 0, 3, 64, f24);
+    const T feat = y[2];
+    T hid = c.alloc(feat.H, feat.W, 256);
+    for (int h = 0; h < 6; ++h) {
+      c.conv(feat, std::string(hname[h]) + ".0", 256, 3, 1, hid, 1);
+      c.conv(hid, std::string(hname[h]) + ".2", hcs[h] < 64 ? 64 : hcs[h], 1, 1, T(), 0, nullptr, hcs[h], heads[h], hcs[h]);
+    }
+    if (c.rc != PT_OK) return c.rc;
+    if (pass == 0) {
+      if (c.ok) continue;      // everything fits: next pass launches
+      PT_HIP_CHECK(hipDeviceSynchronize());
+      if (e->arena.base) PT_HIP_CHECK(hipFree(e->arena.base));
+      e->arena.base = nullptr;
+      const size_t want = e->arena.high + (1u << 20);
+      PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arena.base), want));
+      e->arena.cap = want;
+      continue;
+    }
+    if (!c.ok) {
+      pt_set_error("Lore net: activation arena allocation failed");
+      return PT_ERR_HIP;
+    }
+    break;
+  }
+  return PT_OK;
+}

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("PT_LIB_PATH") or os.path.join(_HERE, "libpdftable_hip
 
 PT_MODEL_DB_RESNET18 = 1
 PT_MODEL_CRNN = 2
+PT_MODEL_LORE_DLA34 = 3
 PT_DET_PRE_DB_PP = 0
 PT_DET_PRE_DB_TORCH = 1
 PT_DET_PRE_NONE = 2
@@ -54,6 +55,7 @@ def _proto(lib):
         "pt_rec_forward_crops": (i, [vp, vp, vp, vp, i, vp, vp, vp]),
         "pt_rec_forward_net": (i, [vp, vp, i, vp, vp, vp]),
         "pt_rec_preprocess": (i, [vp, vp, i, i, i, vp, vp, i, vp, vp]),
+        "pt_tsr_forward_net": (i, [vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp]),
         "pt_op_conv2d": (i, [vp, vp, i, i, i, i, vp, vp, i, i, i, vp, i, i, i, i, vp, i, i, i, i, vp]),
         "pt_op_stem7x7": (i, [vp, vp, i, i, i, vp, vp, vp, i, vp]),
         "pt_op_maxpool3x3s2": (i, [vp, vp, i, i, i, i, vp, i, vp]),

@@ -162,7 +162,7 @@ def lore_dla34_state_dict(seed: int = 0, hm_bias: float = -6.0, hm_gain: float =
     (center_net/modeling_centernet.py:274-409, incl. the unused 1000-way ``fc``).
 
     Deformable convs get non-zero offset/mask weights (the reference initialises them to zero, dcnv2.py:66-67;
-    trained checkpoints are not) with offsets of about one pixel.  ``hm``/``wh`` biases are chosen so that a random
+    trained checkpoints are not) with offsets of about a third of a pixel.  ``hm``/``wh`` biases are chosen so that a random
     net yields a table-like number of cell centres with well-formed quads (corner i = centre - wh[2i:2i+2])."""
     g = _Gen(seed)
     ch = DLA34_CHANNELS
@@ -203,8 +203,10 @@ def lore_dla34_state_dict(seed: int = 0, hm_bias: float = -6.0, hm_gain: float =
     def dcn(p, cin, cout):
         g.bn(p + ".actf.0", cout)
         g.conv(p + ".conv", cout, cin, 3, 3, bias=True)
-        # 27 = 18 offsets + 9 mask logits; offsets ~ N(0, 1 px), mask logits ~ N(0, 1)
-        g.conv(p + ".conv.conv_offset_mask", 27, cin, 3, 3, bias=True, gain=1.0)
+        # 27 = 18 offsets + 9 mask logits, ~N(0, 0.3): sub-pixel offsets, so the bilinear path is exercised.  Larger
+        # offsets make a RANDOM net ill-conditioned (its features are uncorrelated from pixel to pixel, so a 1e-5 px
+        # offset change moves the output by 1e-3 -- measured; trained features are smooth)
+        g.conv(p + ".conv.conv_offset_mask", 27, cin, 3, 3, bias=True, gain=0.1)
 
     def up(p, c, f):
         # fill_up_weights (lore_dla_34.py:53-62): bilinear kernel, same for every channel; perturbed per channel

@@ -29,7 +29,7 @@ import torch
 BN_EPS = 1e-5
 _DT = {"bf16": 0, "f32": 1, "i32": 2}
 
-__all__ = ["pack_db_resnet18", "pack_crnn", "write_blob", "fold_conv_bn", "to_bf16_bits"]
+__all__ = ["pack_db_resnet18", "pack_crnn", "pack_lore_dla34", "write_blob", "fold_conv_bn", "to_bf16_bits"]
 
 
 def to_bf16_bits(t: torch.Tensor) -> np.ndarray:
@@ -190,4 +190,98 @@ def pack_crnn(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
     bpad = torch.zeros(npad)
     bpad[ncls:] = -3.0e38
     bl.add_conv("cls", wpad.reshape(npad, wc.shape[1], 1, 1), bpad)
+    return bl.tobytes()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Lore: DLA-34 + DCN detector (lore/lore_dla_34.py:137-206 on center_net/modeling_centernet.py:274-409)
+# --------------------------------------------------------------------------------------------------------------------
+def _pad_conv(w: torch.Tensor, b: torch.Tensor, n_to: int, cin_to: int):
+    """zero-pad [N, Cin, kh, kw] / [N] to n_to outputs and cin_to inputs (thin DLA levels, 27-channel offset convs)."""
+    n, cin, kh, kw = w.shape
+    wp = torch.zeros(n_to, cin_to, kh, kw)
+    wp[:n, :cin] = w
+    bp = torch.zeros(n_to)
+    bp[:n] = b
+    return wp, bp
+
+
+def pack_lore_dla34(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
+    """``DLASeg`` state_dict -> blob for PT_MODEL_LORE_DLA34.
+
+    * every Conv->BN pair folded; 16-channel tensors are stored 32 wide (upper half zero), so the thin levels
+      pad Cin to 32 and N to 64 (the kernel stores only ``n_valid`` channels);
+    * Root 1x1 convs over a channel concat are split per child (``root.c<i>``): the engine accumulates them through
+      the residual path instead of materialising the concat;
+    * DCN: ``.om`` = the 27-channel offset/mask conv padded to 64 outputs (fp32 out), ``.dcn`` = the deformable conv
+      as a 1x1 GEMM over the 9*C sampled columns (tap-major K), with ``actf`` BN folded in;
+    * depthwise ConvTranspose2d up-samplers: fp32 ``[k*k][C]``."""
+    bl = _Blob(x3)
+    w, b = fold_conv_bn(sd, "base.base_layer.0", "base.base_layer.1")
+    stem = torch.zeros(64, 7, 8, 4)
+    stem[:16, :, :7, :3] = w.permute(0, 2, 3, 1)
+    bp = torch.zeros(64)
+    bp[:16] = b
+    bl.add("base_layer.w", to_bf16_bits(stem).reshape(64, 224), "bf16")
+    if x3:
+        sh, sl = split_bf16(stem)
+        bl.add("base_layer.w3", np.stack([to_bf16_bits(sh).reshape(64, 224), to_bf16_bits(sl).reshape(64, 224)]), "bf16")
+    bl.add("base_layer.b", bp.numpy(), "f32")
+    bl.add_conv("level0", *_pad_conv(*fold_conv_bn(sd, "base.level0.0", "base.level0.1"), 64, 32))
+    bl.add_conv("level1", *_pad_conv(*fold_conv_bn(sd, "base.level1.0", "base.level1.1"), 64, 32))
+
+    def block(p, q):
+        bl.add_conv(q + ".conv1", *fold_conv_bn(sd, p + ".conv1", p + ".bn1"))
+        bl.add_conv(q + ".conv2", *fold_conv_bn(sd, p + ".conv2", p + ".bn2"))
+
+    def tree(p, q, levels, cin, cout, level_root, inherited=()):
+        # Tree.forward (modeling_centernet.py:259-271): children = inherited (+ bottom if level_root); a leaf tree's
+        # root sees [x2, x1, *children]; an inner tree appends its tree1 output and hands the list to tree2
+        children = list(inherited) + ([cin] if level_root else [])
+        if levels == 1:
+            block(p + ".tree1", q + ".tree1")
+            block(p + ".tree2", q + ".tree2")
+            w, b = fold_conv_bn(sd, p + ".root.conv", p + ".root.bn")
+            widths = [cout, cout] + children
+            assert sum(widths) == w.shape[1], (p, widths, w.shape)
+            o = 0
+            for i, wd in enumerate(widths):
+                bl.add_conv(f"{q}.root.c{i}", w[:, o:o + wd].contiguous(), b if i == 0 else torch.zeros_like(b))
+                o += wd
+            if cin != cout:
+                bl.add_conv(q + ".project", *fold_conv_bn(sd, p + ".project.0", p + ".project.1"))
+        else:
+            tree(p + ".tree1", q + ".tree1", levels - 1, cin, cout, False)
+            tree(p + ".tree2", q + ".tree2", levels - 1, cout, cout, False, children + [cout])
+
+    lv = [1, 1, 1, 2, 2, 1]
+    ch = [16, 32, 64, 128, 256, 512]
+    for l in range(2, 6):
+        tree(f"base.level{l}", f"level{l}", lv[l], ch[l - 1], ch[l], l > 2)
+
+    def dcn(p, q):
+        w, b = fold_conv_bn(sd, p + ".conv.conv_offset_mask", None)
+        bl.add_conv(q + ".om", *_pad_conv(w, b, 64, w.shape[1]))
+        w, b = fold_conv_bn(sd, p + ".conv", p + ".actf.0")
+        o, c = w.shape[0], w.shape[1]
+        w1 = w.permute(0, 2, 3, 1).reshape(o, 9 * c, 1, 1).contiguous()       # K = tap * C + c
+        bl.add_conv(q + ".dcn", w1, b)
+
+    def ida(p, n):
+        for j in range(1, n + 1):
+            dcn(f"{p}.proj_{j}", f"{p}.proj_{j}")
+            dcn(f"{p}.node_{j}", f"{p}.node_{j}")
+            wu = sd[f"{p}.up_{j}.weight"]                                       # [C, 1, k, k]
+            k = wu.shape[2]
+            bl.add(f"{p}.up_{j}.wf32", wu[:, 0].permute(1, 2, 0).reshape(k * k, -1).contiguous().numpy(), "f32")
+
+    ida("dla_up.ida_0", 1)
+    ida("dla_up.ida_1", 2)
+    ida("dla_up.ida_2", 3)
+    ida("ida_up", 2)
+    for h, k in (("hm", 2), ("st", 8), ("wh", 8), ("ax", 256), ("cr", 256), ("reg", 2)):
+        bl.add_conv(f"{h}.0", *fold_conv_bn(sd, f"{h}.0", None))
+        w, b = fold_conv_bn(sd, f"{h}.2", None)
+        nt = (k + 63) // 64 * 64
+        bl.add_conv(f"{h}.2", *_pad_conv(w, b, nt, 256))
     return bl.tobytes()
