@@ -273,8 +273,98 @@ def gen_lore_dla34():
     print("lore_dla34.npz", {k: v.shape for k, v in out.items()})
 
 
+def gen_lore_decode():
+    """Outputs of the reference's own process_detect_output / process_logic_output (lineless_table_process.py:592-663)
+    on seeded head maps.  cv2.getAffineTransform and shapely are not installed: the oracle's stand-ins are injected
+    (those two stay PARITY UNPINNED); every other line that runs is the reference's."""
+    lore_env()
+    from oracle import lore_decode as od
+    sys.path.insert(0, os.path.dirname(HERE))
+    from lore_synth import synth_lore_heads          # tests/lore_synth.py: inputs are regenerated from the seed
+    cv2 = sys.modules["cv2"]
+    cv2.getAffineTransform = lambda s, d: od.get_affine_transform_3pt(np.asarray(s), np.asarray(d))
+
+    class Polygon:
+        def __init__(self, pts):
+            self.p = np.asarray(pts, dtype=np.float64).reshape(-1, 2)
+
+    class Point:
+        def __init__(self, xy):
+            self.x, self.y = float(xy[0]), float(xy[1])
+
+        def within(self, poly):
+            return od.point_strictly_in_polygon(self.x, self.y, poly.p)
+    sg = types.ModuleType("shapely.geometry")
+    sg.Polygon, sg.Point, sg.MultiPoint = Polygon, Point, object
+    sh = types.ModuleType("shapely")
+    sh.geometry = sg
+    sys.modules["shapely"] = sh
+    sys.modules["shapely.geometry"] = sg
+    torch.Tensor.cuda = lambda self, *a, **k: self            # the decode calls .cuda() on helper tensors
+    m = ref_import("pdftable.model.lore.lineless_table_process")
+    out = {}
+    # (K = 3000 cells / 5000 corners are hard-coded in the reference: maps need >= 5000 pixels)
+    for tag, (seed, H, W, src_h, src_w, rev) in {"a": (1, 80, 80, 300, 420, True), "b": (2, 72, 96, 777, 512, True),
+                                                 "c": (3, 80, 80, 256, 256, False)}.items():
+        heads = synth_lore_heads(seed, H, W)
+        _, meta = od.lore_preprocess_geometry(src_h, src_w, 4 * H, 4 * W)
+        hd = {k: torch.from_numpy(v.copy()) for k, v in heads.items()}
+        logi, ps, results, corner = m.process_detect_output(hd, torch.from_numpy(meta)[None], upper_left=False,
+                                                            wiz_rev=rev, vis_thresh=0.2)
+        n = logi.shape[1]
+        out[f"case_{tag}"] = np.array([seed, H, W, src_h, src_w, int(rev)])
+        out[f"meta_{tag}"] = meta
+        out[f"logi_{tag}"] = logi.numpy()
+        out[f"ps_{tag}"] = ps.numpy()
+        out[f"results_{tag}"] = results[1]
+        print("lore decode", tag, "cells", n)
+    lg = torch.from_numpy(np.random.default_rng(9).uniform(-1, 12, (1, 50, 4)).astype(np.float32))
+    lg[0, :4, 0] = torch.tensor([2.5, 3.5, 0.5, 7.500001])
+    out["logic_in"] = lg.numpy()
+    out["logic_out"] = m.process_logic_output(lg.clone()).numpy()
+    np.savez_compressed(os.path.join(HERE, "lore_decode.npz"), **out)
+
+
+def gen_lore_processor():
+    """Outputs of the reference LoreProcessModel (lore/lore_processor.py:399-514) for seeded weights and features."""
+    from pdf_table_amd.synth_weights import lore_processor_state_dict
+    lore_env()
+    # lore_processor.py imports these two by absolute name; only _tranpose_and_gather_feat & co. (training path) come from them
+    tp = types.ModuleType("pdftable.model.center_net.table_process")
+    tp._tranpose_and_gather_feat = None
+    sys.modules["pdftable.model.center_net.table_process"] = tp
+    cl = types.ModuleType("pdftable.model.lore.configuration_lore")
+    cl.LoreConfig = type("LoreConfig", (), {})
+    sys.modules["pdftable.model.lore.configuration_lore"] = cl
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    m = ref_import("pdftable.model.lore.lore_processor")
+    out = {}
+    rng = np.random.default_rng(106)
+    for tag, (L, n, with_dets) in {"wtw": (4, 137, False), "ptn": (3, 60, True)}.items():
+        cfg = types.SimpleNamespace(stacking_layers=L, tsfm_layers=L, wiz_stacking=True, wiz_2dpe=with_dets)
+        model = m.LoreProcessModel(cfg).eval()
+        sd = lore_processor_state_dict(seed=31, layers=L, stacking_layers=L)
+        model.load_state_dict(sd, strict=True)
+        feat = rng.standard_normal((1, n, 256)).astype(np.float32)
+        dets = rng.integers(0, 256, (1, n, 8)).astype(np.int64) if with_dets else None
+        with torch.no_grad():
+            logic, stacked = model(torch.from_numpy(feat), dets=None if dets is None else torch.from_numpy(dets))
+        out[f"feat_{tag}"] = feat
+        if dets is not None:
+            out[f"dets_{tag}"] = dets
+        out[f"logic_{tag}"] = logic.numpy()
+        out[f"stacked_{tag}"] = stacked.numpy()
+        out[f"layers_{tag}"] = np.array(L)
+        print("lore processor", tag, logic.shape, float(logic.abs().max()), float(stacked.abs().max()))
+    np.savez_compressed(os.path.join(HERE, "lore_processor.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["db", "crnn", "registry", "ctc", "host", "lore_dla"]
+    which = sys.argv[1:] or ["db", "crnn", "registry", "ctc", "host", "lore_dla", "lore_decode", "lore_processor"]
+    if "lore_processor" in which:
+        gen_lore_processor()
+    if "lore_decode" in which:
+        gen_lore_decode()
     if "lore_dla" in which:
         gen_lore_dla34()
     if "host" in which:

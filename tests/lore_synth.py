@@ -1,0 +1,28 @@
+"""Seeded synthetic Lore head maps shared by tests/golden/make_golden.py (inputs of the reference run) and the
+parity tests (inputs of the oracle / HIP run): data generators only."""
+import numpy as np
+
+
+def synth_lore_heads(seed, H=80, W=80):
+    """Seeded head maps that look like a table: cell-centre and corner peaks on a jittered grid, quads of about the
+    grid pitch, so that the wiz_rev vertex snapping really fires.  NCHW f32, 'hm' pre-sigmoid."""
+    rng = np.random.default_rng(seed)
+    hm = rng.normal(-6.0, 0.5, (1, 2, H, W)).astype(np.float32)
+    wh = np.zeros((1, 8, H, W), np.float32)
+    st = np.zeros((1, 8, H, W), np.float32)
+    pitch_x, pitch_y = 9, 7
+    for gy in range(3, H - 3, pitch_y):
+        for gx in range(4, W - 4, pitch_x):
+            if rng.uniform() < 0.85:
+                hm[0, 0, gy, gx] = rng.normal(1.5, 1.2)             # cell centre (some below the 0.2 threshold)
+            for (cy, cx) in ((gy - pitch_y // 2, gx - pitch_x // 2),):
+                if 0 <= cy < H and 0 <= cx < W and rng.uniform() < 0.9:
+                    hm[0, 1, cy, cx] = rng.normal(1.0, 1.0)         # corner point
+    hw, hh = pitch_x / 2.0, pitch_y / 2.0
+    base = np.array([hw, hh, -hw, hh, -hw, -hh, hw, -hh], np.float32).reshape(1, 8, 1, 1)
+    wh[:] = base + rng.normal(0, 0.6, (1, 8, H, W)).astype(np.float32)
+    st[:] = base + rng.normal(0, 0.6, (1, 8, H, W)).astype(np.float32)
+    reg = rng.uniform(0.2, 0.8, (1, 2, H, W)).astype(np.float32)
+    ax = rng.standard_normal((1, 256, H, W)).astype(np.float32)
+    cr = rng.standard_normal((1, 256, H, W)).astype(np.float32)
+    return {"hm": hm, "st": st, "wh": wh, "ax": ax, "cr": cr, "reg": reg}

@@ -67,3 +67,71 @@ def test_dlaseg_equals_reference_module():
             v = z[k].numpy()
             v = v[:, ::8] if v.shape[1] == 256 else v
             assert np.allclose(v, gold[f"{k}_{tag}"], atol=2e-5, rtol=1e-5), (tag, k, np.abs(v - gold[f"{k}_{tag}"]).max())
+
+
+# ---- decode: oracle/lore_decode.py against the reference's own process_detect_output -------------------------------
+def _decode_case(gold, tag):
+    import sys
+    sys.path.insert(0, HERE)
+    from lore_synth import synth_lore_heads
+    seed, H, W, src_h, src_w, rev = [int(v) for v in gold[f"case_{tag}"]]
+    heads = {k: torch.from_numpy(v) for k, v in synth_lore_heads(seed, H, W).items()}
+    return heads, gold[f"meta_{tag}"], bool(rev)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_decode_equals_reference(tag):
+    from oracle import lore_decode as od
+    gold = np.load(os.path.join(HERE, "golden", "lore_decode.npz"))
+    heads, meta, rev = _decode_case(gold, tag)
+    logi, ps, polys, results = od.process_detect_output(heads, meta, wiz_rev=rev, vis_thresh=0.2)
+    assert logi.shape[1] == gold[f"logi_{tag}"].shape[1] > 20
+    assert np.array_equal(logi.numpy(), gold[f"logi_{tag}"])
+    assert np.array_equal(ps.numpy(), gold[f"ps_{tag}"])
+    n = logi.shape[1]
+    assert np.array_equal(results[:n], gold[f"results_{tag}"][:n])          # valid cells: bit-exact, same order
+    # beyond the valid cells the reference's rows are zero-score peaks in torch.topk tie order: same multiset of rows
+    ours = results[np.lexsort(results.T[::-1])]
+    ref = gold[f"results_{tag}"]
+    assert np.array_equal(ours, ref[np.lexsort(ref.T[::-1])])
+
+
+def test_process_logic_output_equals_reference():
+    from oracle import lore_decode as od
+    gold = np.load(os.path.join(HERE, "golden", "lore_decode.npz"))
+    assert np.array_equal(od.process_logic_output(torch.from_numpy(gold["logic_in"])).numpy(), gold["logic_out"])
+
+
+def test_point_in_polygon_known_answers():
+    from oracle.lore_decode import point_strictly_in_polygon as pin
+    sq = np.array([[0, 0], [4, 0], [4, 4], [0, 4]], dtype=np.float64)
+    assert pin(2, 2, sq) and pin(0.001, 3.999, sq)
+    assert not pin(0, 2, sq) and not pin(4, 4, sq) and not pin(2, 0, sq)      # boundary is not "within"
+    assert not pin(5, 2, sq) and not pin(-1, -1, sq)
+    para = np.array([[0, 0], [6, 1], [8, 5], [2, 4]], dtype=np.float64)
+    assert pin(4, 2.5, para) and not pin(1, 3, para) and not pin(7, 1.2, para)
+
+
+def test_affine_geometry_known_answers():
+    from oracle import lore_decode as od
+    # 300 x 420 source into a 1024 x 1024 input: uniform scale 1024 / 420 about the centres
+    trans, meta = od.lore_preprocess_geometry(300, 420)
+    assert meta.tolist() == [210, 150, 420, 1024, 1024, 256, 256]
+    k = 1024 / 420
+    assert np.allclose(trans, [[k, 0, 512 - 210 * k], [0, k, 512 - 150 * k]], atol=1e-9)
+    back = od.transform_preds(np.array([[128.0, 128.0], [0.0, 0.0]], np.float32), meta[:2], meta[2], (256, 256))
+    assert np.allclose(back, [[210, 150], [210 - 128 * 420 / 256, 150 - 128 * 420 / 256]], atol=1e-9)
+
+
+@pytest.mark.parametrize("tag", ["wtw", "ptn"])
+def test_processor_equals_reference_module(tag):
+    from oracle import lore_processor as op
+    from pdf_table_amd.synth_weights import lore_processor_state_dict
+    gold = np.load(os.path.join(HERE, "golden", "lore_processor.npz"))
+    L = int(gold[f"layers_{tag}"])
+    sd = lore_processor_state_dict(seed=31, layers=L, stacking_layers=L)
+    dets = torch.from_numpy(gold[f"dets_{tag}"]) if f"dets_{tag}" in gold else None
+    with torch.no_grad():
+        logic, stacked = op.processor_forward(sd, torch.from_numpy(gold[f"feat_{tag}"]), dets, L, L)
+    assert np.allclose(logic.numpy(), gold[f"logic_{tag}"], atol=2e-5)
+    assert np.allclose(stacked.numpy(), gold[f"stacked_{tag}"], atol=2e-5)
