@@ -175,6 +175,19 @@ int pt_rec_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int
 int pt_tsr_forward_net(pt_engine* e, const uint16_t* d_input_bf16, int n, int H, int W, float* d_hm, float* d_st,
                        float* d_wh, float* d_ax, float* d_cr, float* d_reg, pt_stream stream);
 
+/* Heat-map + corner-point decode (process_detect_output, lore/lineless_table_process.py:592-655: corner_decode :97-124,
+ * ctdet_4ps_decode :127-267 incl. the wiz_rev vertex snapping :188-236, logi = ax + cr_feat :648) for n tables.
+ *   head maps   : as written by pt_tsr_forward_net (fp32 NHWC at h x w)
+ *   wiz_rev     : LoreConfig.wiz_rev (configuration_lore.py:79-92); vis_thresh: LoreConfig.vis_thresh
+ *   d_counts    : int32 [n]            cells with final score >= vis_thresh (= rows of slct_logi_feat, :568-571)
+ *   d_dets      : float32 [n, 3000, 9] x0,y0..x3,y3 in feature-map pixels + score, sorted like the reference's `dets`
+ *   d_logi      : float32 [n, 3000, 256] logic features of the same rows
+ * Only rows [0, number of peaks above vis_thresh) are written; rows past d_counts[i] are not part of the result. */
+#define PT_TSR_MAX_CELLS 3000
+int pt_tsr_decode(pt_engine* e, const float* d_hm, const float* d_st, const float* d_wh, const float* d_ax,
+                  const float* d_cr, const float* d_reg, int n, int h, int w, int wiz_rev, float vis_thresh,
+                  int32_t* d_counts, float* d_dets, float* d_logi, pt_stream stream);
+
 /* ---- single operator (parity tests of the conv kernel variants) --------------------------------- */
 /* NHWC bf16 convolution on the MFMA implicit-GEMM kernel. d_w_tiled is [N/64][Cin/32][ks*ks][64][32] bf16
  * (pdf_table_amd/weights.py:tile_conv_weight), d_bias fp32 [N]. ks in {1,3} (pad ks/2), stride in {1,2}.

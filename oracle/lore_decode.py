@@ -209,7 +209,7 @@ def transform_preds(coords: np.ndarray, center, scale, out_size) -> np.ndarray:
 
 
 def process_detect_output(output: Dict[str, torch.Tensor], meta: np.ndarray, wiz_rev: bool = True,
-                          vis_thresh: float = 0.2):
+                          vis_thresh: float = 0.2, return_raw: bool = False):
     """heads (NCHW f32; 'hm' pre-sigmoid) + meta [cx, cy, s, in_h, in_w, out_h, out_w] ->
     (slct_logi_feat f32 [1,n,256], slct_dets_feat i64 [1,n,8], polygons f32 [n,8] in source pixels, dets f32 [K,9])."""
     hm = torch.sigmoid(output["hm"])
@@ -227,6 +227,8 @@ def process_detect_output(output: Dict[str, torch.Tensor], meta: np.ndarray, wiz
     logi = (logi + crf)[:, :n].contiguous()
     ps = torch.from_numpy(raw[:n, :8].astype(np.int32).astype(np.float32))[None]      # filter(): int32 truncation
     ps = torch.round(ps).to(torch.int64).clamp(0, 255)                                 # normalized_ps(.., 256)
+    if return_raw:
+        return logi, ps, results[:n, :8], results, raw          # raw: [K,10] feature-map quads + score + class
     return logi, ps, results[:n, :8], results
 
 

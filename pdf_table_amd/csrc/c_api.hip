@@ -54,6 +54,7 @@ void pt_engine_destroy(pt_engine* e) {
   if (e->rec_gray) (void)hipFree(e->rec_gray);
   if (e->rec_off) (void)hipFree(e->rec_off);
   if (e->zero_page) (void)hipFree(e->zero_page);
+  if (e->tsr_scratch) (void)hipFree(e->tsr_scratch);
   for (auto& p : e->prof.pending) {
     (void)hipEventDestroy(p.a);
     (void)hipEventDestroy(p.b);
@@ -212,6 +213,15 @@ int pt_tsr_forward_net(pt_engine* e, const uint16_t* d_input_bf16, int n, int H,
   PT_HIP_CHECK(hipSetDevice(e->device));
   return pt_lore_forward_net(e, d_input_bf16, n, H, W, d_hm, d_st, d_wh, d_ax, d_cr, d_reg,
                              reinterpret_cast<hipStream_t>(stream));
+}
+
+int pt_tsr_decode(pt_engine* e, const float* d_hm, const float* d_st, const float* d_wh, const float* d_ax,
+                  const float* d_cr, const float* d_reg, int n, int h, int w, int wiz_rev, float vis_thresh,
+                  int32_t* d_counts, float* d_dets, float* d_logi, pt_stream stream) {
+  PT_REQUIRE(e && n > 0 && h > 0 && w > 0, "pt_tsr_decode: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  return pt_lore_decode(e, d_hm, d_st, d_wh, d_ax, d_cr, d_reg, n, h, w, wiz_rev, vis_thresh, d_counts, d_dets, d_logi,
+                        reinterpret_cast<hipStream_t>(stream));
 }
 
 int pt_det_bitmap(pt_engine* e, const float* d_prob, int n, int net_h, int net_w, float thresh, int use_dilation,

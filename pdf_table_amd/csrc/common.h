@@ -101,6 +101,7 @@ struct pt_engine {
   void* rec_off = nullptr; size_t rec_off_cap = 0;
   std::vector<long long> rec_off_host;
   void* zero_page = nullptr;  // 8 KiB of zeros: DMA source for halo pixels outside the image
+  void* tsr_scratch = nullptr; size_t tsr_scratch_cap = 0;   // candidate lists of the Lore decode
 };
 
 // ---- conv launcher (conv_igemm.hip) -----------------------------------------------------------------
@@ -171,6 +172,9 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
 
 // ---- models ---------------------------------------------------------------------------------------------
 int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* prob, float* logits, hipStream_t s);
+int pt_lore_decode(pt_engine* e, const float* hm, const float* st, const float* wh, const float* ax, const float* cr,
+                   const float* reg, int B, int H, int W, int wiz_rev, float vis_thresh, int* d_counts, float* d_dets,
+                   float* d_logi, hipStream_t s);
 int pt_lore_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* hm, float* st, float* wh, float* ax,
                         float* cr, float* reg, hipStream_t s);
 

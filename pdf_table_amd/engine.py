@@ -131,6 +131,26 @@ class HipEngine:
         bufs["reg"] = bufs["reg"][..., :2]
         return bufs
 
+    def tsr_decode(self, heads, wiz_rev: bool = True, vis_thresh: float = 0.2):
+        """heads: dict of fp32 NHWC maps (hm/st/wh/reg with 8-channel stride or their [..., :k] views, ax/cr 256)
+        -> (counts int32 [n] on the host, dets f32 [n,3000,9], logi f32 [n,3000,256] on the device)."""
+        def full(t, c):
+            if t.shape[-1] != c or not t.is_contiguous():
+                base = t._base if t._base is not None else t
+                assert base.shape[-1] == c and base.is_contiguous(), "head map must come from tsr_forward_net"
+                return base
+            return t
+        hm, st, wh, reg = (full(heads[k], 8) for k in ("hm", "st", "wh", "reg"))
+        ax, cr = full(heads["ax"], 256), full(heads["cr"], 256)
+        n, h, w, _ = ax.shape
+        counts = torch.zeros((n,), dtype=torch.int32, device=self._tdev)
+        dets = torch.empty((n, L.PT_TSR_MAX_CELLS, 9), dtype=torch.float32, device=self._tdev)
+        logi = torch.empty((n, L.PT_TSR_MAX_CELLS, 256), dtype=torch.float32, device=self._tdev)
+        L.check(self.lib.pt_tsr_decode(self._h, _ptr(hm), _ptr(st), _ptr(wh), _ptr(ax), _ptr(cr), _ptr(reg), n, h, w,
+                                       int(wiz_rev), float(vis_thresh), _ptr(counts), _ptr(dets), _ptr(logi),
+                                       self._stream()), "pt_tsr_decode")
+        return counts.cpu().numpy(), dets, logi
+
     def det_bitmap(self, prob: torch.Tensor, thresh: float, use_dilation: bool = False) -> torch.Tensor:
         self._chk(prob, torch.float32, "prob")
         n, H, W = prob.shape

@@ -22,6 +22,7 @@ PT_PRECISION_BF16 = 0
 PT_PRECISION_BF16X3 = 1
 PT_DET_POST_DB_PP = 0
 PT_DET_POST_DB_TORCH = 1
+PT_TSR_MAX_CELLS = 3000
 PT_REC_H, PT_REC_W, PT_REC_T, PT_REC_NCLS = 32, 640, 160, 7644
 PT_PROF_CLASSES = ("conv3x3", "conv1x1", "stem", "other")
 
@@ -56,6 +57,7 @@ def _proto(lib):
         "pt_rec_forward_net": (i, [vp, vp, i, vp, vp, vp]),
         "pt_rec_preprocess": (i, [vp, vp, i, i, i, vp, vp, i, vp, vp]),
         "pt_tsr_forward_net": (i, [vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp]),
+        "pt_tsr_decode": (i, [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, f, vp, vp, vp, vp]),
         "pt_op_conv2d": (i, [vp, vp, i, i, i, i, vp, vp, i, i, i, vp, i, i, i, i, vp, i, i, i, i, vp]),
         "pt_op_stem7x7": (i, [vp, vp, i, i, i, vp, vp, vp, i, vp]),
         "pt_op_maxpool3x3s2": (i, [vp, vp, i, i, i, i, vp, i, vp]),

@@ -103,3 +103,52 @@ def test_lore_net_bf16_drift(eng, lore_sd):
     got = eng.tsr_forward_net(_x4(x).cuda())
     torch.cuda.synchronize()
     assert _cmp(got, ref, "lore bf16") <= 0.1
+
+
+# ---- decode -----------------------------------------------------------------------------------------------------
+def _nhwc(t, cs):
+    """NCHW f32 -> NHWC with channel stride cs (zero padded), as pt_tsr_forward_net writes the head maps"""
+    n, c, h, w = t.shape
+    o = torch.zeros(n, h, w, cs)
+    o[..., :c] = t.permute(0, 2, 3, 1)
+    return o.cuda()
+
+
+@pytest.mark.parametrize("seed,H,W,rev", [(1, 80, 80, True), (2, 72, 96, True), (3, 80, 80, False), (4, 128, 128, True)])
+def test_tsr_decode_matches_oracle(eng, seed, H, W, rev):
+    """cells, their order, quads and logic features equal the oracle's restatement of process_detect_output (itself
+    bit-exact against the reference on the golden cases).  Scores go through expf on the device: 1e-6."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from lore_synth import synth_lore_heads
+    from oracle import lore_decode as od
+    heads = {k: torch.from_numpy(v) for k, v in synth_lore_heads(seed, H, W).items()}
+    _, meta = od.lore_preprocess_geometry(4 * H, 4 * W, 4 * H, 4 * W)
+    logi, ps, polys, results, raw = od.process_detect_output({k: v.clone() for k, v in heads.items()}, meta, wiz_rev=rev,
+                                                             vis_thresh=0.2, return_raw=True)
+    n_ref = logi.shape[1]
+    dev = {k: _nhwc(heads[k], 256 if k in ("ax", "cr") else 8) for k in heads}
+    counts, dets, lg = eng.tsr_decode(dev, wiz_rev=rev, vis_thresh=0.2)
+    torch.cuda.synchronize()
+    assert counts[0] == n_ref > 20, (counts, n_ref)
+    d = dets[0, :n_ref].cpu().numpy()
+    assert np.array_equal(d[:, :8], raw[:n_ref, :8]), np.abs(d[:, :8] - raw[:n_ref, :8]).max()
+    assert np.allclose(d[:, 8], raw[:n_ref, 8], atol=1e-6, rtol=0)
+    assert np.array_equal(lg[0, :n_ref].cpu().numpy(), logi[0].numpy())
+
+
+def test_tsr_decode_batch_and_empty(eng):
+    """two tables in one call == each alone; a map without peaks gives zero cells"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from lore_synth import synth_lore_heads
+    a = synth_lore_heads(5, 80, 80)
+    b = synth_lore_heads(6, 80, 80)
+    b["hm"][:] = -20.0                                          # nothing above any threshold
+    both = {k: _nhwc(torch.from_numpy(np.concatenate([a[k], b[k]])), 256 if k in ("ax", "cr") else 8) for k in a}
+    counts, dets, lg = eng.tsr_decode(both, wiz_rev=True, vis_thresh=0.2)
+    one = {k: _nhwc(torch.from_numpy(a[k]), 256 if k in ("ax", "cr") else 8) for k in a}
+    c1, d1, l1 = eng.tsr_decode(one, wiz_rev=True, vis_thresh=0.2)
+    assert counts[0] == c1[0] > 20 and counts[1] == 0
+    n = int(c1[0])
+    assert torch.equal(dets[0, :n], d1[0, :n]) and torch.equal(lg[0, :n], l1[0, :n])
