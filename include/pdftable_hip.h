@@ -60,6 +60,7 @@ enum {
   PT_MODEL_DB_RESNET18 = 1, /* db_net/dbnet.py:715-728 */
   PT_MODEL_CRNN = 2,        /* crnn/modeling_crnn.py:36-113 */
   PT_MODEL_LORE_DLA34 = 3,  /* lore/lore_dla_34.py:137-206 (DLASeg on dla34 + DCN), modeling_lore.py:88-95 */
+  PT_MODEL_LORE_PROCESSOR = 4, /* lore/lore_processor.py:399-514 (LoreProcessModel) */
 };
 int pt_weights_load(pt_engine* e, int model_kind, const void* h_blob, size_t nbytes);
 /* Same, but the blob already sits in device memory (e.g. after an RCCL broadcast from rank 0). */
@@ -187,6 +188,16 @@ int pt_tsr_forward_net(pt_engine* e, const uint16_t* d_input_bf16, int n, int H,
 int pt_tsr_decode(pt_engine* e, const float* d_hm, const float* d_st, const float* d_wh, const float* d_ax,
                   const float* d_cr, const float* d_reg, int n, int h, int w, int wiz_rev, float vis_thresh,
                   int32_t* d_counts, float* d_dets, float* d_logi, pt_stream stream);
+
+/* Logical-location processor (LoreProcessModel.forward, lore/lore_processor.py:465-514, evaluation branch) for the
+ * cells of n_tables tables at once.
+ *   d_logi, d_dets : as written by pt_tsr_decode;  h_counts : HOST int32 [n_tables] = its d_counts copied back
+ *   use_2dpe       : LoreConfig.wiz_2dpe -- add the x/y position embeddings of the (int-truncated, [0,255]-clamped)
+ *                    quad coordinates 0,1,2,5 (:486-491; lineless_table_process.py:576-589)
+ *   d_logic, d_stacked : float32 [n_tables, 3000, 4]: rows [0, h_counts[i]) = logic_axis / stacked_axis (post-ReLU,
+ *                    not yet rounded: process_logic_output, lineless_table_process.py:658-663, is host work) */
+int pt_tsr_process(pt_engine* e, const float* d_logi, const float* d_dets, const int32_t* h_counts, int n_tables,
+                   int use_2dpe, float* d_logic, float* d_stacked, pt_stream stream);
 
 /* ---- single operator (parity tests of the conv kernel variants) --------------------------------- */
 /* NHWC bf16 convolution on the MFMA implicit-GEMM kernel. d_w_tiled is [N/64][Cin/32][ks*ks][64][32] bf16

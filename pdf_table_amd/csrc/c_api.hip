@@ -224,6 +224,14 @@ int pt_tsr_decode(pt_engine* e, const float* d_hm, const float* d_st, const floa
                         reinterpret_cast<hipStream_t>(stream));
 }
 
+int pt_tsr_process(pt_engine* e, const float* d_logi, const float* d_dets, const int32_t* h_counts, int n_tables,
+                   int use_2dpe, float* d_logic, float* d_stacked, pt_stream stream) {
+  PT_REQUIRE(e, "pt_tsr_process: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  return pt_lore_process(e, d_logi, d_dets, h_counts, n_tables, use_2dpe, d_logic, d_stacked,
+                         reinterpret_cast<hipStream_t>(stream));
+}
+
 int pt_det_bitmap(pt_engine* e, const float* d_prob, int n, int net_h, int net_w, float thresh, int use_dilation,
                   uint32_t* d_bitmap, pt_stream stream) {
   PT_REQUIRE(e && d_prob && d_bitmap && n > 0, "pt_det_bitmap: bad arguments");

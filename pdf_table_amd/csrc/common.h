@@ -138,6 +138,7 @@ struct ConvDesc {
   // only output channels [0, n_valid) are stored (0 = all N); out_f32: fp32 [pixel][out_cstride] output instead of bf16
   int n_valid = 0;
   float* out_f32 = nullptr;
+  const float* res_f32 = nullptr;   // fp32 residual laid out like out_f32 (may alias it)
 };
 int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s);
 
@@ -175,6 +176,8 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float*
 int pt_lore_decode(pt_engine* e, const float* hm, const float* st, const float* wh, const float* ax, const float* cr,
                    const float* reg, int B, int H, int W, int wiz_rev, float vis_thresh, int* d_counts, float* d_dets,
                    float* d_logi, hipStream_t s);
+int pt_lore_process(pt_engine* e, const float* d_logi, const float* d_dets, const int32_t* h_counts, int n_tables,
+                    int use_2dpe, float* d_logic, float* d_stacked, hipStream_t s);
 int pt_lore_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* hm, float* st, float* wh, float* ax,
                         float* cr, float* reg, hipStream_t s);
 

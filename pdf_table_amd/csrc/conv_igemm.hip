@@ -56,6 +56,7 @@ struct ConvK {
   // out_f32 != null: the plain store path writes fp32 [pixel][out_cstride] there instead of bf16 (network outputs)
   int n_valid;
   float* out_f32;
+  const float* res_f32;   // fp32 residual with the layout of out_f32 (transformer residual stream), added before ReLU
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
@@ -127,6 +128,11 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
         v[4] += bf16_to_f32(r.z & 0xFFFFu); v[5] += bf16_to_f32(r.z >> 16);
         v[6] += bf16_to_f32(r.w & 0xFFFFu); v[7] += bf16_to_f32(r.w >> 16);
       }
+    }
+    if (EXTRAS && p.res_f32) {
+      const f32x4* rp = reinterpret_cast<const f32x4*>(p.res_f32 + (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.out_cstride + p.out_coff + n);
+      const f32x4 r0 = rp[0], r1 = rp[1];
+      v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
     }
     if (p.relu) {
 #pragma unroll
@@ -922,7 +928,8 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   PT_REQUIRE(d.rep >= 1 && d.out_cstride % 8 == 0 && d.out_coff % 8 == 0, "conv: bad output layout");
   ConvK k;
   memset(&k, 0, sizeof(k));
-  k.n_valid = d.n_valid; k.out_f32 = d.out_f32;
+  k.n_valid = d.n_valid; k.out_f32 = d.out_f32; k.res_f32 = d.res_f32;
+  PT_REQUIRE(!d.res_f32 || d.out_f32, "conv: fp32 residual needs the fp32 output path");
   PT_REQUIRE(d.n_valid % 8 == 0 && d.n_valid <= d.N, "conv: n_valid=%d must be a multiple of 8 and <= N", d.n_valid);
   PT_REQUIRE(!(d.out_f32 && (d.rep != 1 || d.shuffle_cout)), "conv: fp32 output only on the plain store path");
   k.in = d.in; k.w = d.w; k.bias = d.bias; k.out = d.out; k.res = d.res;
@@ -938,7 +945,7 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   if (d.head_w) PT_REQUIRE(d.shuffle_cout == 64 && d.head_b && (d.head_prob || d.head_logits), "conv: bad fused-head configuration");
   if (k.res_mode == 2) PT_REQUIRE(k.Ho % 2 == 0 && k.Wo % 2 == 0, "conv: half-res residual needs even output size");
   const double flop = 2.0 * k.B * k.Ho * k.Wo * (double)k.N * d.Cin * d.ks * d.ks;  // algorithmic (not x3 in split mode)
-  if (d.ks == 3 && d.stride == 1 && !d.head_w && !d.argmax_part && !d.n_valid && !d.out_f32 && use_dma_kernel()) {
+  if (d.ks == 3 && d.stride == 1 && !d.head_w && !d.argmax_part && !d.n_valid && !d.out_f32 && !d.res_f32 && use_dma_kernel()) {
     // steady-state A/B on MI355X (tools/ab3.sh, round 1): the 16-channel-slice DMA kernel (v3) wins on >= 120-row maps
     // with K >= 128 channels, the 32-channel-slice DMA kernel (v2) on 60..119-row maps, the register-staged kernel
     // (v1) on short-K layers and on small maps, where the big DMA tiles leave CUs idle

@@ -151,6 +151,19 @@ class HipEngine:
                                        self._stream()), "pt_tsr_decode")
         return counts.cpu().numpy(), dets, logi
 
+    def tsr_process(self, logi: torch.Tensor, dets: torch.Tensor, counts, use_2dpe: bool = False):
+        """logic features of pt_tsr_decode -> (logic_axis, stacked_axis) f32 [n,3000,4]; rows [0, counts[i]) valid."""
+        import numpy as np
+        self._chk(logi, torch.float32, "logi")
+        n = logi.shape[0]
+        hc = np.ascontiguousarray(counts, dtype=np.int32)
+        assert hc.shape == (n,)
+        logic = torch.zeros((n, L.PT_TSR_MAX_CELLS, 4), dtype=torch.float32, device=self._tdev)
+        stacked = torch.zeros((n, L.PT_TSR_MAX_CELLS, 4), dtype=torch.float32, device=self._tdev)
+        L.check(self.lib.pt_tsr_process(self._h, _ptr(logi), _ptr(dets), hc.ctypes.data, n, int(use_2dpe), _ptr(logic),
+                                        _ptr(stacked), self._stream()), "pt_tsr_process")
+        return logic, stacked
+
     def det_bitmap(self, prob: torch.Tensor, thresh: float, use_dilation: bool = False) -> torch.Tensor:
         self._chk(prob, torch.float32, "prob")
         n, H, W = prob.shape

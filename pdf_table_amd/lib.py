@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("PT_LIB_PATH") or os.path.join(_HERE, "libpdftable_hip
 PT_MODEL_DB_RESNET18 = 1
 PT_MODEL_CRNN = 2
 PT_MODEL_LORE_DLA34 = 3
+PT_MODEL_LORE_PROCESSOR = 4
 PT_DET_PRE_DB_PP = 0
 PT_DET_PRE_DB_TORCH = 1
 PT_DET_PRE_NONE = 2
@@ -58,6 +59,7 @@ def _proto(lib):
         "pt_rec_preprocess": (i, [vp, vp, i, i, i, vp, vp, i, vp, vp]),
         "pt_tsr_forward_net": (i, [vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp]),
         "pt_tsr_decode": (i, [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, f, vp, vp, vp, vp]),
+        "pt_tsr_process": (i, [vp, vp, vp, vp, i, i, vp, vp, vp]),
         "pt_op_conv2d": (i, [vp, vp, i, i, i, i, vp, vp, i, i, i, vp, i, i, i, i, vp, i, i, i, i, vp]),
         "pt_op_stem7x7": (i, [vp, vp, i, i, i, vp, vp, vp, i, vp]),
         "pt_op_maxpool3x3s2": (i, [vp, vp, i, i, i, i, vp, i, vp]),

@@ -29,7 +29,7 @@ import torch
 BN_EPS = 1e-5
 _DT = {"bf16": 0, "f32": 1, "i32": 2}
 
-__all__ = ["pack_db_resnet18", "pack_crnn", "pack_lore_dla34", "write_blob", "fold_conv_bn", "to_bf16_bits"]
+__all__ = ["pack_db_resnet18", "pack_crnn", "pack_lore_dla34", "pack_lore_processor", "write_blob", "fold_conv_bn", "to_bf16_bits"]
 
 
 def to_bf16_bits(t: torch.Tensor) -> np.ndarray:
@@ -284,4 +284,47 @@ def pack_lore_dla34(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
         w, b = fold_conv_bn(sd, f"{h}.2", None)
         nt = (k + 63) // 64 * 64
         bl.add_conv(f"{h}.2", *_pad_conv(w, b, nt, 256))
+    return bl.tobytes()
+
+
+def pack_lore_processor(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
+    """``LoreProcessModel`` state_dict (lore/lore_processor.py:399-437) -> blob for PT_MODEL_LORE_PROCESSOR.
+    Every nn.Linear becomes a 1x1 GEMM tile set; q/k/v projections are fused into one 256 -> 768 GEMM ([q; k; v]);
+    ``logi_encoder.0`` (4 inputs) and the 4-output decoders are zero-padded to 32 inputs / 64 outputs; Norm
+    parameters and the two position tables stay fp32.  ``meta`` = [tsfm layers, stacking layers]."""
+    bl = _Blob(x3)
+
+    def lin(name, key, n_to=None, cin_to=None):
+        w = sd[key + ".weight"].float()
+        b = sd[key + ".bias"].float() if (key + ".bias") in sd else torch.zeros(w.shape[0])
+        n_to = n_to or w.shape[0]
+        cin_to = cin_to or w.shape[1]
+        bl.add_conv(name, *_pad_conv(w.reshape(w.shape[0], w.shape[1], 1, 1), b, n_to, cin_to))
+
+    def transformer(p, q):
+        lin(q + ".linear", p + ".linear")
+        n = 0
+        while f"{p}.encoder.layers.{n}.norm_1.alpha" in sd:
+            lp, lq = f"{p}.encoder.layers.{n}", f"{q}.l{n}"
+            for nm in ("norm_1", "norm_2"):
+                bl.add(f"{lq}.{nm}.alpha", sd[f"{lp}.{nm}.alpha"].float().numpy(), "f32")
+                bl.add(f"{lq}.{nm}.bias", sd[f"{lp}.{nm}.bias"].float().numpy(), "f32")
+            wq = torch.cat([sd[f"{lp}.attn.{k}_linear.weight"] for k in ("q", "k", "v")], 0).float()
+            bq = torch.cat([sd[f"{lp}.attn.{k}_linear.bias"] for k in ("q", "k", "v")], 0).float()
+            bl.add_conv(lq + ".qkv", wq.reshape(768, 256, 1, 1), bq)
+            lin(lq + ".out", lp + ".attn.out")
+            lin(lq + ".ff1", lp + ".ff.linear_1")
+            lin(lq + ".ff2", lp + ".ff.linear_2")
+            n += 1
+        lin(q + ".dec0", p + ".decoder.linear.0")
+        lin(q + ".dec2", p + ".decoder.linear.2", n_to=64)
+        return n
+
+    n_axis = transformer("tsfm_axis", "axis")
+    lin("stk.le0", "stacker.logi_encoder.0", cin_to=32)
+    lin("stk.le2", "stacker.logi_encoder.2")
+    n_stack = transformer("stacker.tsfm", "stk")
+    bl.add("x_pe", sd["x_position_embeddings.weight"].float().numpy(), "f32")
+    bl.add("y_pe", sd["y_position_embeddings.weight"].float().numpy(), "f32")
+    bl.add("meta", np.array([n_axis, n_stack], dtype=np.int32), "i32")
     return bl.tobytes()

@@ -152,3 +152,61 @@ def test_tsr_decode_batch_and_empty(eng):
     assert counts[0] == c1[0] > 20 and counts[1] == 0
     n = int(c1[0])
     assert torch.equal(dets[0, :n], d1[0, :n]) and torch.equal(lg[0, :n], l1[0, :n])
+
+
+# ---- processor ----------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def proc_sd():
+    from pdf_table_amd.synth_weights import lore_processor_state_dict
+    return lore_processor_state_dict(seed=31)
+
+
+@pytest.fixture(scope="module")
+def eng_proc(eng, proc_sd):
+    from pdf_table_amd.weights import pack_lore_processor
+    eng.load_weights(L.PT_MODEL_LORE_PROCESSOR, pack_lore_processor(proc_sd))
+    return eng
+
+
+def _proc_case(eng_proc, proc_sd, counts, use_pe, seed):
+    from oracle import lore_processor as op
+    g = torch.Generator().manual_seed(seed)
+    n = len(counts)
+    logi = torch.zeros(n, L.PT_TSR_MAX_CELLS, 256)
+    dets = torch.zeros(n, L.PT_TSR_MAX_CELLS, 9)
+    refs = []
+    for t, c in enumerate(counts):
+        logi[t, :c] = torch.randn(c, 256, generator=g)
+        dets[t, :c, :8] = torch.rand(c, 8, generator=g) * 300 - 20           # some outside [0, 255]: clamp path
+        if c:
+            ps = dets[t, :c, :8].to(torch.int32).to(torch.float32).round().to(torch.int64).clamp(0, 255)[None]
+            with torch.no_grad():
+                refs.append(op.processor_forward(proc_sd, logi[t:t + 1, :c], ps if use_pe else None))
+        else:
+            refs.append(None)
+    logic, stacked = eng_proc.tsr_process(logi.cuda(), dets.cuda(), counts, use_2dpe=use_pe)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for t, c in enumerate(counts):
+        if not c:
+            continue
+        for got, ref in ((logic[t, :c].cpu(), refs[t][0][0]), (stacked[t, :c].cpu(), refs[t][1][0])):
+            worst = max(worst, (got - ref).abs().max().item() / max(1.0, ref.abs().max().item()))
+    return worst
+
+
+@pytest.mark.parametrize("counts,use_pe", [([137], False), ([60, 0, 200, 1], False), ([90, 33], True), ([700], False)])
+def test_tsr_processor_x3_matches_oracle(eng_proc, proc_sd, counts, use_pe):
+    eng_proc.set_precision(L.PT_PRECISION_BF16X3)
+    try:
+        w = _proc_case(eng_proc, proc_sd, counts, use_pe, seed=sum(counts))
+    finally:
+        eng_proc.set_precision(L.PT_PRECISION_BF16)
+    print("processor x3", counts, use_pe, w)
+    assert w <= TOL_REL, w
+
+
+def test_tsr_processor_bf16_drift(eng_proc, proc_sd):
+    w = _proc_case(eng_proc, proc_sd, [137, 50], False, seed=5)
+    print("processor bf16", w)
+    assert w <= 0.1, w
