@@ -163,6 +163,23 @@ int pt_rec_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int
                       const int64_t* h_crop_px, int n_lines, uint16_t* d_gray, pt_stream stream);
 
 /* ---- stage 4: table structure recognition (Lore) ------------------------------------------------- */
+/* One table crop of a resident page and the INVERSE (destination -> crop) affine map of
+ * TableLorePreProcessor.process (lore/processer_lore.py:66-90), i.e. cv::invertAffineTransform of
+ * get_affine_transform(c, s, 0, [inp_w, inp_h]) (lineless_table_process.py:403-438), computed on the host in float64.
+ * The crop is the integer box of crop_image_by_box (utils/ocr/ocr_common_utils.py:269-284). */
+typedef struct pt_tsr_table {
+  double minv[6];
+  int32_t page, x0, y0, crop_w, crop_h, reserved;
+} pt_tsr_table;
+
+/* Warp + normalise n table crops into the detector's input (cv2.warpAffine INTER_LINEAR fixed-point semantics, zero
+ * border, then ((x / 255) - mean) / std with Lore's constants).
+ *   d_pages_rgb : uint8 [n_pages, ph, pw, 3];  d_tables : pt_tsr_table [n];  bgr != 0: feed channels reversed, as the
+ *                 reference does for path / PIL inputs (processer_lore.py:48-64,152)
+ *   d_out_bf16  : bf16 NHWC4 [n, inp_h, inp_w, 4] (8 channels = hi | lo in BF16X3 mode) */
+int pt_tsr_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int ph, int pw, const pt_tsr_table* d_tables,
+                      int n, int inp_h, int inp_w, int bgr, uint16_t* d_out_bf16, pt_stream stream);
+
 /* Detector network only (LoreModel.forward's `self.detect_infer_model(pixel_values)`, lore/modeling_lore.py:147;
  * DLASeg.forward lore/lore_dla_34.py:184-196).
  *   d_input_bf16 : bf16 NHWC4 [n, H, W, 4] (4th channel zero; [hi rgb0 | lo rgb0] = 8 channels in BF16X3 mode),

@@ -162,6 +162,8 @@ def cell_decode(heat, wh, ax, cr, corners, reg, K: int = K_CELLS, wiz_rev: bool 
         _, order = torch.sort(scores, descending=True, dim=1)
         det = det.gather(1, order.expand(1, K, det.shape[2]))
         axg = axg.gather(1, order.expand(1, K, axg.shape[2]))
+        ind = ind.gather(1, order[:, :, 0])
+    cell_decode.last_inds = ind[0].numpy()        # centre pixel of every output row (tests only)
     return det, axg, cr_feat
 
 

@@ -55,6 +55,7 @@ void pt_engine_destroy(pt_engine* e) {
   if (e->rec_off) (void)hipFree(e->rec_off);
   if (e->zero_page) (void)hipFree(e->zero_page);
   if (e->tsr_scratch) (void)hipFree(e->tsr_scratch);
+  if (e->tsr_lut) (void)hipFree(e->tsr_lut);
   for (auto& p : e->prof.pending) {
     (void)hipEventDestroy(p.a);
     (void)hipEventDestroy(p.b);
@@ -205,6 +206,23 @@ int pt_det_forward_net(pt_engine* e, const uint16_t* d_input_bf16, int n, int ne
   PT_REQUIRE(e && d_input_bf16 && n > 0 && (d_prob || d_logits), "pt_det_forward_net: bad arguments");
   PT_HIP_CHECK(hipSetDevice(e->device));
   return pt_db_forward_net(e, d_input_bf16, n, net_h, net_w, d_prob, d_logits, reinterpret_cast<hipStream_t>(stream));
+}
+
+int pt_tsr_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int ph, int pw, const pt_tsr_table* d_tables,
+                      int n, int inp_h, int inp_w, int bgr, uint16_t* d_out_bf16, pt_stream stream) {
+  PT_REQUIRE(e && d_pages_rgb && d_tables && d_out_bf16 && n > 0 && n_pages > 0, "pt_tsr_preprocess: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  if (!e->tsr_lut) {
+    // ((x / 255.) - mean) / std in float64 then cast, as numpy evaluates processer_lore.py:67-70,90
+    const float mean[3] = {0.408f, 0.447f, 0.470f}, stdv[3] = {0.289f, 0.274f, 0.278f};
+    float lut[768];
+    for (int c = 0; c < 3; ++c)
+      for (int v = 0; v < 256; ++v) lut[c * 256 + v] = (float)(((double)v / 255.0 - (double)mean[c]) / (double)stdv[c]);
+    PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->tsr_lut), sizeof(lut)));
+    PT_HIP_CHECK(hipMemcpy(e->tsr_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
+  }
+  return pt_launch_tsr_preprocess(d_pages_rgb, ph, pw, d_tables, n, inp_h, inp_w, bgr, e->tsr_lut, d_out_bf16,
+                                  e->precision == PT_PRECISION_BF16X3, reinterpret_cast<hipStream_t>(stream));
 }
 
 int pt_tsr_forward_net(pt_engine* e, const uint16_t* d_input_bf16, int n, int H, int W, float* d_hm, float* d_st,

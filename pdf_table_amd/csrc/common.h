@@ -102,6 +102,7 @@ struct pt_engine {
   std::vector<long long> rec_off_host;
   void* zero_page = nullptr;  // 8 KiB of zeros: DMA source for halo pixels outside the image
   void* tsr_scratch = nullptr; size_t tsr_scratch_cap = 0;   // candidate lists of the Lore decode
+  float* tsr_lut = nullptr;                                  // [3][256] normalisation table of the Lore pre-process
 };
 
 // ---- conv launcher (conv_igemm.hip) -----------------------------------------------------------------
@@ -173,6 +174,8 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
 
 // ---- models ---------------------------------------------------------------------------------------------
 int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* prob, float* logits, hipStream_t s);
+int pt_launch_tsr_preprocess(const uint8_t* pages, int ph, int pw, const pt_tsr_table* tabs, int n, int H, int W, int bgr,
+                             const float* lut, bf16_t* out, int split, hipStream_t s);
 int pt_lore_decode(pt_engine* e, const float* hm, const float* st, const float* wh, const float* ax, const float* cr,
                    const float* reg, int B, int H, int W, int wiz_rev, float vis_thresh, int* d_counts, float* d_dets,
                    float* d_logi, hipStream_t s);

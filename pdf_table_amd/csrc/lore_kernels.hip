@@ -137,6 +137,59 @@ __global__ __launch_bounds__(256) void dwconvt_up_add_kernel(const bf16_t* __res
   }
 }
 
+// cv2.warpAffine(crop, M, (W, H), INTER_LINEAR, BORDER_CONSTANT 0) + (x/255 - mean)/std of TableLorePreProcessor.process
+// (lore/processer_lore.py:85-90), sampling the table crop straight from the resident page.  OpenCV's WarpAffineInvoker
+// arithmetic: inverse map in fp64, 10-bit fixed-point coordinates, 1/32-pixel positions, 15-bit weights.
+// lut[c][v] = float(((v / 255.) - mean[c]) / std[c]) evaluated in fp64 on the host like numpy does.
+__global__ __launch_bounds__(256) void tsr_preprocess_kernel(const uint8_t* __restrict__ pages, int ph, int pw,
+                                                              const pt_tsr_table* __restrict__ tabs, int H, int W, int bgr,
+                                                              const float* __restrict__ lut, bf16_t* __restrict__ out,
+                                                              int split) {
+  const int t = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= H * W) return;
+  const int y = i / W, x = i - y * W;
+  const pt_tsr_table tb = tabs[t];
+  auto sat = [](double v) { return (long long)fmin(fmax(rint(v), -2147483648.0), 2147483647.0); };
+  const long long adelta = sat(tb.minv[0] * x * 1024.0), bdelta = sat(tb.minv[3] * x * 1024.0);
+  const long long X0 = sat((tb.minv[1] * y + tb.minv[2]) * 1024.0) + 16, Y0 = sat((tb.minv[4] * y + tb.minv[5]) * 1024.0) + 16;
+  const long long X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+  long long sx = X >> 5, sy = Y >> 5;
+  sx = sx < -32768 ? -32768 : (sx > 32767 ? 32767 : sx);
+  sy = sy < -32768 ? -32768 : (sy > 32767 ? 32767 : sy);
+  const int ax = (int)(X & 31), ay = (int)(Y & 31);
+  const int wt[4] = {(32 - ay) * (32 - ax) * 32, (32 - ay) * ax * 32, ay * (32 - ax) * 32, ay * ax * 32};
+  int acc[3] = {0, 0, 0};
+  const uint8_t* pg = pages + (size_t)tb.page * ph * pw * 3;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long yy = sy + (k >> 1), xx = sx + (k & 1);
+    if (yy < 0 || yy >= tb.crop_h || xx < 0 || xx >= tb.crop_w) continue;
+    const long long py = tb.y0 + yy, px = tb.x0 + xx;
+    if (py < 0 || py >= ph || px < 0 || px >= pw) continue;
+    const uint8_t* s = pg + ((size_t)py * pw + px) * 3;
+    acc[0] += s[0] * wt[k]; acc[1] += s[1] * wt[k]; acc[2] += s[2] * wt[k];
+  }
+  float v[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int sc = bgr ? 2 - c : c;
+    int u = (acc[sc] + (1 << 14)) >> 15;
+    u = u < 0 ? 0 : (u > 255 ? 255 : u);
+    v[c] = lut[c * 256 + u];
+  }
+  bf16_t* o = out + ((size_t)t * H * W + i) * (split ? 8 : 4);
+  uint32_t hb[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { hb[c] = f2bf(v[c]); o[c] = (bf16_t)hb[c]; }
+  o[3] = 0;
+  if (split) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[4 + c] = (bf16_t)f2bf(v[c] - bf2f(hb[c]));
+    o[7] = 0;
+  }
+}
+
 inline int grid_for(long long total) {
   long long blocks = (total + 255) / 256;
   if (blocks > 256 * 64) blocks = 256 * 64;
@@ -159,6 +212,15 @@ int pt_launch_dwconvt_up_add(const bf16_t* in, const float* w, const bf16_t* add
   PT_REQUIRE(in && w && out && C % 8 == 0 && (f == 2 || f == 4), "dwconvT: bad arguments");
   hipLaunchKernelGGL(dwconvt_up_add_kernel, dim3(grid_for((long long)B * h * f * wd * f * (C / 8))), dim3(256), 0, s, in,
                      w, add, out, B, h, wd, C, f, split);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_launch_tsr_preprocess(const uint8_t* pages, int ph, int pw, const pt_tsr_table* tabs, int n, int H, int W, int bgr,
+                             const float* lut, bf16_t* out, int split, hipStream_t s) {
+  PT_REQUIRE(pages && tabs && lut && out && n > 0 && H > 0 && W > 0, "tsr preprocess: bad arguments");
+  hipLaunchKernelGGL(tsr_preprocess_kernel, dim3((H * W + 255) / 256, n), dim3(256), 0, s, pages, ph, pw, tabs, H, W, bgr, lut,
+                     out, split);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }

@@ -16,6 +16,8 @@ from . import lib as L
 __all__ = ["HipEngine", "REC_LINE_DTYPE"]
 
 # mirrors struct pt_rec_line in include/pdftable_hip.h (88 bytes)
+TSR_TABLE_DTYPE = np.dtype([("minv", "<f8", (6,)), ("page", "<i4"), ("x0", "<i4"), ("y0", "<i4"),
+                            ("crop_w", "<i4"), ("crop_h", "<i4"), ("reserved", "<i4")])   # struct pt_tsr_table
 REC_LINE_DTYPE = np.dtype([("minv", np.float64, (9,)), ("page", np.int32), ("crop_w", np.int32), ("crop_h", np.int32),
                            ("reserved", np.int32)])
 
@@ -114,6 +116,18 @@ class HipEngine:
         L.check(self.lib.pt_det_forward_net(self._h, _ptr(x), n, H, W, _ptr(prob), _ptr(logits), self._stream()),
                 "pt_det_forward_net")
         return (prob, logits) if want_logits else prob
+
+    def tsr_preprocess(self, pages: torch.Tensor, tables, inp_h: int = 1024, inp_w: int = 1024, bgr: bool = True):
+        """pages uint8 [np,h,w,3] on the device, tables: numpy array of TSR_TABLE_DTYPE -> bf16 NHWC4 [n,inp_h,inp_w,4|8]."""
+        self._chk(pages, torch.uint8, "pages")
+        npg, ph, pw, _ = pages.shape
+        n = len(tables)
+        tb = torch.from_numpy(tables.view(np.uint8).reshape(n, -1).copy()).to(self._tdev)
+        out = torch.empty((n, inp_h, inp_w, 8 if self.precision == L.PT_PRECISION_BF16X3 else 4), dtype=torch.bfloat16,
+                          device=self._tdev)
+        L.check(self.lib.pt_tsr_preprocess(self._h, _ptr(pages), npg, ph, pw, _ptr(tb), n, inp_h, inp_w, int(bgr), _ptr(out),
+                                           self._stream()), "pt_tsr_preprocess")
+        return out
 
     def tsr_forward_net(self, x: torch.Tensor):
         """Lore detector: x bf16 NHWC4 [n,H,W,4] (BF16X3: 8 channels) -> dict of fp32 NHWC head maps at H/4 x W/4

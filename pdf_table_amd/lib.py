@@ -57,6 +57,7 @@ def _proto(lib):
         "pt_rec_forward_crops": (i, [vp, vp, vp, vp, i, vp, vp, vp]),
         "pt_rec_forward_net": (i, [vp, vp, i, vp, vp, vp]),
         "pt_rec_preprocess": (i, [vp, vp, i, i, i, vp, vp, i, vp, vp]),
+        "pt_tsr_preprocess": (i, [vp, vp, i, i, i, vp, i, i, i, i, vp, vp]),
         "pt_tsr_forward_net": (i, [vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp]),
         "pt_tsr_decode": (i, [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, f, vp, vp, vp, vp]),
         "pt_tsr_process": (i, [vp, vp, vp, vp, i, i, vp, vp, vp]),

@@ -157,13 +157,14 @@ DLA34_LEVELS = [1, 1, 1, 2, 2, 1]                                            # c
 DLA34_CHANNELS = [16, 32, 64, 128, 256, 512]
 
 
-def lore_dla34_state_dict(seed: int = 0, hm_bias: float = -6.0, hm_gain: float = 0.5, cell_half=(10.0, 6.0)):
+def lore_dla34_state_dict(seed: int = 0, hm_bias=(-4.6, -3.5), hm_gain: float = 0.5, cell_half=(10.0, 6.0)):
     """state_dict of ``get_dla_dcn(34, heads)`` = ``DLASeg`` (lore/lore_dla_34.py:137-206) on ``dla34``
     (center_net/modeling_centernet.py:274-409, incl. the unused 1000-way ``fc``).
 
     Deformable convs get non-zero offset/mask weights (the reference initialises them to zero, dcnv2.py:66-67;
     trained checkpoints are not) with offsets of about a third of a pixel.  ``hm``/``wh`` biases are chosen so that a random
-    net yields a table-like number of cell centres with well-formed quads (corner i = centre - wh[2i:2i+2])."""
+    net yields a table-like number of cell centres and corner points (a few hundred each on a 256 x 256 map) with
+    well-formed quads (corner i = centre - wh[2i:2i+2])."""
     g = _Gen(seed)
     ch = DLA34_CHANNELS
     g.conv("base.base_layer.0", ch[0], 3, 7, 7)
@@ -242,7 +243,11 @@ def lore_dla34_state_dict(seed: int = 0, hm_bias: float = -6.0, hm_gain: float =
         g.conv(f"{h}.0", 256, ch[2], 3, 3, bias=True)
         if h == "hm":
             g.conv(f"{h}.2", k, 256, 1, 1, bias=False, gain=hm_gain)
-            g.put(f"{h}.2.bias", np.full((k,), hm_bias))
+            # zero-sum weights per output: the hidden units are post-ReLU (positive, similar means), so this centres
+            # both heat maps on the bias instead of on a random per-channel offset
+            w = g.sd[f"{h}.2.weight"]
+            g.sd[f"{h}.2.weight"] = w - w.mean(dim=1, keepdim=True)
+            g.put(f"{h}.2.bias", np.asarray(hm_bias, dtype=np.float64).reshape(k))   # (cell centres, corners)
         elif h in ("wh", "st"):
             g.conv(f"{h}.2", k, 256, 1, 1, bias=False, gain=0.05)
             hw, hh = cell_half

@@ -1,0 +1,186 @@
+"""Batched table-structure recognition stage (Lore): geometry and result shaping on the host, everything else on the GPU.
+
+Replaces, for a batch of table crops of resident pages, the reference's per-table chain
+``TableLorePreProcessor.process`` (lore/processer_lore.py:66-109) -> ``LoreModel.forward`` (lore/modeling_lore.py:125-194:
+DLASeg detector, ``process_detect_output``, ``LoreProcessModel``) -> ``TableLorePostProcessor.__call__``
+(processer_lore.py:163-188).  The host computes one 2x3 affine map per table (float64, like cv2.getAffineTransform)
+and, after the device decode, maps the cell quads back to source pixels and rounds the logical locations.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .engine import TSR_TABLE_DTYPE, HipEngine
+
+__all__ = ["LoreConfig", "TsrStage", "lore_geometry", "affine_from_center_scale", "invert_affine",
+           "transform_quads", "process_logic_output"]
+
+
+@dataclass
+class LoreConfig:
+    """The fields of lore/configuration_lore.py:29-116 that the inference path reads."""
+    task_type: str = "wtw"
+    backbone: str = "DLA-34"
+    resolution: Tuple[int, int] = (1024, 1024)
+    stacking_layers: int = 4
+    tsfm_layers: int = 4
+    upper_left: bool = False
+    wiz_2dpe: bool = False
+    wiz_stacking: bool = True
+    wiz_rev: bool = True
+    vis_thresh: float = 0.2
+
+    def __post_init__(self):
+        if self.task_type == "wireless":
+            raise NotImplementedError("Lore 'wireless' (ResNet-18 detector, lore/lore_detector.py) is not built on the HIP "
+                                      "engine yet; task_type 'wtw' and 'ptn' (DLA-34 + DCN) are")
+        if self.task_type == "wtw":                       # configuration_lore.py:79-92
+            self.backbone, self.resolution = "DLA-34", (1024, 1024)
+            self.stacking_layers = self.tsfm_layers = 4
+            self.upper_left, self.wiz_2dpe, self.wiz_rev, self.vis_thresh = False, False, True, 0.2
+        else:                                             # "ptn" and anything else (:94-108)
+            self.backbone, self.resolution = "DLA-34", (512, 512)
+            self.stacking_layers = self.tsfm_layers = 3
+            self.upper_left, self.wiz_2dpe, self.wiz_rev, self.vis_thresh = False, True, False, 0.35
+
+
+def _affine_3pt(src: np.ndarray, dst: np.ndarray) -> np.ndarray:
+    """the 2x3 map through three point pairs (what cv2.getAffineTransform solves), float64"""
+    a = np.zeros((6, 6))
+    b = np.zeros(6)
+    for i in range(3):
+        a[2 * i, 0:3] = (src[i, 0], src[i, 1], 1.0)
+        a[2 * i + 1, 3:6] = (src[i, 0], src[i, 1], 1.0)
+        b[2 * i], b[2 * i + 1] = dst[i, 0], dst[i, 1]
+    return np.linalg.solve(a, b).reshape(2, 3)
+
+
+def affine_from_center_scale(center, scale, out_size, inv: bool = False) -> np.ndarray:
+    """get_affine_transform(center, scale, 0, out_size, inv) of lineless_table_process.py:403-438 (rot = 0, no shift):
+    three float32 anchor points on each side -- centre, centre + (0, -scale/2), and their perpendicular third."""
+    s = np.float32(scale)
+    dst_w, dst_h = out_size
+    src = np.zeros((3, 2), np.float32)
+    dst = np.zeros((3, 2), np.float32)
+    src[0] = center
+    src[1] = np.asarray(center) + np.asarray([0.0, s * -0.5])
+    dst[0] = (dst_w * 0.5, dst_h * 0.5)
+    dst[1] = np.array([dst_w * 0.5, dst_h * 0.5], np.float32) + np.array([0, dst_w * -0.5], np.float32)
+    for p in (src, dst):
+        d = p[0] - p[1]
+        p[2] = p[1] + np.array([-d[1], d[0]], np.float32)
+    return _affine_3pt(dst, src) if inv else _affine_3pt(src, dst)
+
+
+def invert_affine(m: np.ndarray) -> np.ndarray:
+    """the inverse map cv2.warpAffine derives from M (float64, same operation order)"""
+    m = np.asarray(m, np.float64).reshape(6).copy()
+    d = m[0] * m[4] - m[1] * m[3]
+    d = 1.0 / d if d != 0 else 0.0
+    a11, a22 = m[4] * d, m[0] * d
+    m[0] = a11
+    m[1] *= -d
+    m[3] *= -d
+    m[4] = a22
+    b1 = -m[0] * m[2] - m[1] * m[5]
+    b2 = -m[3] * m[2] - m[4] * m[5]
+    m[2], m[5] = b1, b2
+    return m.reshape(2, 3)
+
+
+def lore_geometry(crop_h: int, crop_w: int, inp_h: int, inp_w: int):
+    """-> (minv 2x3 for pt_tsr_table, meta int64 [cx, cy, s, in_h, in_w, out_h, out_w]) -- processer_lore.py:74-126:
+    c = (w/2, h/2) float32, s = max(h, w); meta is cast to int64 (fractions of c are dropped, as in the reference)."""
+    c = np.array([crop_w / 2.0, crop_h / 2.0], dtype=np.float32)
+    s = max(crop_h, crop_w) * 1.0
+    trans = affine_from_center_scale(c, s, (inp_w, inp_h))
+    meta = np.array([c[0], c[1], s, inp_h, inp_w, inp_h // 4, inp_w // 4]).astype(np.int64)
+    return invert_affine(trans), meta
+
+
+def transform_quads(quads: np.ndarray, meta: np.ndarray) -> np.ndarray:
+    """ctdet_4ps_post_process (lineless_table_process.py:489-505): the four vertices of every quad through the inverse
+    centre/scale map built from the int64 meta; float64 matrix x float32 point, stored back as float32."""
+    t = affine_from_center_scale(meta[:2], meta[2], (meta[6], meta[5]), inv=True)
+    p = quads.astype(np.float32).astype(np.float64).reshape(-1, 4, 2)
+    out = np.empty_like(p)
+    out[..., 0] = t[0, 0] * p[..., 0] + t[0, 1] * p[..., 1] + t[0, 2]
+    out[..., 1] = t[1, 0] * p[..., 0] + t[1, 1] * p[..., 1] + t[1, 2]
+    return out.reshape(-1, 8).astype(np.float32)
+
+
+def process_logic_output(logi: np.ndarray) -> np.ndarray:
+    """lineless_table_process.py:658-663: fractional part > 0.5 rounds up, otherwise down."""
+    fl = np.floor(logi)
+    return np.where(logi - fl > 0.5, fl + 1, fl).astype(np.float32)
+
+
+class TsrStage:
+    def __init__(self, eng: HipEngine, config: Optional[LoreConfig] = None, micro_batch: int = 8, bgr: bool = True):
+        self.eng = eng
+        self.config = config or LoreConfig()
+        self.micro_batch = micro_batch
+        self.bgr = bgr
+
+    def tables(self, page_shape: Tuple[int, int], boxes_per_page: Sequence[np.ndarray]):
+        """integer table boxes [k,4] (x1,y1,x2,y2) per page, cropped like crop_image_by_box
+        (utils/ocr/ocr_common_utils.py:269-284: img[y1:y2, x1:x2]) -> (pt_tsr_table records, metas)."""
+        ph, pw = page_shape
+        inp_h, inp_w = self.config.resolution
+        recs, metas = [], []
+        for pi, boxes in enumerate(boxes_per_page):
+            for b in np.asarray(boxes).reshape(-1, 4):
+                x1, y1, x2, y2 = (int(v) for v in b)
+                x1, y1 = max(x1, 0), max(y1, 0)
+                x2, y2 = min(x2, pw), min(y2, ph)
+                cw, ch = x2 - x1, y2 - y1
+                if cw <= 0 or ch <= 0:
+                    raise ValueError(f"empty table crop {b.tolist()} on a {ph}x{pw} page")
+                minv, meta = lore_geometry(ch, cw, inp_h, inp_w)
+                r = np.zeros((), dtype=TSR_TABLE_DTYPE)
+                r["minv"], r["page"], r["x0"], r["y0"], r["crop_w"], r["crop_h"] = minv.reshape(6), pi, x1, y1, cw, ch
+                recs.append(r)
+                metas.append(meta)
+        return (np.array(recs, dtype=TSR_TABLE_DTYPE) if recs else np.zeros(0, dtype=TSR_TABLE_DTYPE)), metas
+
+    def run(self, pages: torch.Tensor, tables: np.ndarray, metas: List[np.ndarray]) -> List[Dict]:
+        """pages uint8 [np,h,w,3] on the device -> per table {'polygons' f32 [n,8], 'logi' f32 [n,4] (integer valued),
+        'logic_axis', 'stacked_axis' (unrounded), 'scores'} like TableLorePostProcessor's result dict."""
+        cfg = self.config
+        inp_h, inp_w = cfg.resolution
+        out: List[Dict] = []
+        for i in range(0, len(tables), self.micro_batch):
+            tb = tables[i:i + self.micro_batch]
+            x = self.eng.tsr_preprocess(pages, tb, inp_h, inp_w, bgr=self.bgr)
+            heads = self.eng.tsr_forward_net(x)
+            counts, dets, logi = self.eng.tsr_decode(heads, wiz_rev=cfg.wiz_rev, vis_thresh=cfg.vis_thresh)
+            logic, stacked = self.eng.tsr_process(logi, dets, counts, use_2dpe=cfg.wiz_2dpe)
+            dets_h = dets.cpu().numpy()
+            logic_h, stacked_h = logic.cpu().numpy(), stacked.cpu().numpy()
+            for k in range(len(tb)):
+                n = int(counts[k])
+                if n == 0:       # LoreModel.forward's empty case (modeling_lore.py:171-173)
+                    out.append({"polygons": np.zeros((1, 8), np.float32), "logi": np.zeros((1, 4), np.float32),
+                                "logic_axis": np.zeros((1, 4), np.float32), "stacked_axis": np.zeros((1, 4), np.float32),
+                                "scores": np.zeros((0,), np.float32)})
+                    continue
+                final = stacked_h[k, :n] if cfg.wiz_stacking else logic_h[k, :n]
+                out.append({"polygons": transform_quads(dets_h[k, :n, :8], metas[i + k]),
+                            "logi": process_logic_output(final), "logic_axis": logic_h[k, :n].copy(),
+                            "stacked_axis": stacked_h[k, :n].copy(), "scores": dets_h[k, :n, 8].copy()})
+        return out
+
+    def __call__(self, pages: torch.Tensor, boxes_per_page: Sequence[np.ndarray]) -> List[List[Dict]]:
+        tables, metas = self.tables(tuple(pages.shape[1:3]), boxes_per_page)
+        flat = self.run(pages, tables, metas) if len(tables) else []
+        res, o = [], 0
+        for b in boxes_per_page:
+            k = len(np.asarray(b).reshape(-1, 4))
+            res.append(flat[o:o + k])
+            o += k
+        return res

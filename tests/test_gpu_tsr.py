@@ -210,3 +210,99 @@ def test_tsr_processor_bf16_drift(eng_proc, proc_sd):
     w = _proc_case(eng_proc, proc_sd, [137, 50], False, seed=5)
     print("processor bf16", w)
     assert w <= 0.1, w
+
+
+# ---- pre-process and the whole stage -------------------------------------------------------------------------------
+def test_tsr_preprocess_matches_oracle(eng):
+    """pt_tsr_preprocess == oracle warpAffine + normalisation, bit for bit (fp32 values through the hi/lo pair)"""
+    from oracle import lore_pre
+    from pdf_table_amd.synth_pages import make_page
+    from pdf_table_amd.tsr_stage import LoreConfig, TsrStage
+    pages = np.stack([make_page(3, 1024)[0], make_page(4, 1024)[0]])
+    boxes = [np.array([[200, 100, 560, 420]]), np.array([[0, 0, 1024, 1024], [37, 500, 900, 777]])]
+    cfg = LoreConfig()
+    cfg.resolution = (320, 352)
+    st = TsrStage(eng, cfg)
+    tables, metas = st.tables((1024, 1024), boxes)
+    eng.set_precision(L.PT_PRECISION_BF16X3)
+    try:
+        x = eng.tsr_preprocess(torch.from_numpy(pages).cuda(), tables, 320, 352, bgr=True).float().cpu()
+    finally:
+        eng.set_precision(L.PT_PRECISION_BF16)
+    got = (x[..., :3] + x[..., 4:7]).permute(0, 3, 1, 2)
+    k = 0
+    for pi, bs in enumerate(boxes):
+        for (x1, y1, x2, y2) in bs:
+            crop = pages[pi][y1:y2, x1:x2][:, :, ::-1]
+            ref, meta = lore_pre.lore_preprocess(np.ascontiguousarray(crop), 320, 352)
+            assert np.array_equal(meta, metas[k])
+            d = (got[k] - ref[0]).abs().max().item()
+            assert d <= 2e-5, (k, d)            # hi + lo carries 16 mantissa bits of the fp32 value
+            k += 1
+
+
+def test_tsr_stage_matches_oracle_chain(eng_proc, lore_sd, proc_sd):
+    """Whole stage (pre-process, DLA-34+DCN, decode, processor, rounding) in the fp32-class mode against the oracle
+    chain on a 320 x 320 input: same cells in the same order, quads within 0.1 source px, logical locations equal except
+    where the oracle's own value sits within 2e-3 of the .5 rounding boundary."""
+    from oracle import lore_decode as od
+    from oracle import lore_net, lore_pre, lore_processor
+    from pdf_table_amd.synth_pages import make_page
+    from pdf_table_amd.synth_weights import lore_dla34_state_dict
+    from pdf_table_amd.tsr_stage import LoreConfig, TsrStage
+    sd = lore_dla34_state_dict(seed=21, hm_bias=(-3.6, -2.5))
+    eng_proc.load_weights(L.PT_MODEL_LORE_DLA34, pack_lore_dla34(sd))
+    page = make_page(3, 1024)[0]
+    box = np.array([[200, 100, 560, 420]])
+    cfg = LoreConfig()
+    cfg.resolution = (320, 320)
+    eng_proc.set_precision(L.PT_PRECISION_BF16X3)
+    try:
+        res = TsrStage(eng_proc, cfg)(torch.from_numpy(page[None]).cuda(), [box])[0][0]
+    finally:
+        eng_proc.set_precision(L.PT_PRECISION_BF16)
+        eng_proc.load_weights(L.PT_MODEL_LORE_DLA34, pack_lore_dla34(lore_sd))
+    crop = np.ascontiguousarray(page[100:420, 200:560][:, :, ::-1])
+    x, meta = lore_pre.lore_preprocess(crop, 320, 320)
+    with torch.no_grad():
+        z = lore_net.dlaseg_forward(sd, x)
+        logi, ps, polys, results, raw = od.process_detect_output(z, meta, wiz_rev=True, vis_thresh=0.2, return_raw=True)
+        logic, stacked = lore_processor.processor_forward(proc_sd, logi, None)
+    n = logi.shape[1]
+    assert n > 20
+    # Peak / threshold decisions sit on fp32-class (1e-3 in logit) differences of the heat map, so cells are matched by
+    # their quads, and a cell may be missing on either side only if the ORACLE's own decision was fragile: final score
+    # within 3e-3 of vis_thresh, x0.4 demotion boundary, or a 3x3 neighbour within 3e-3 of the peak.
+    sig = torch.sigmoid(z["hm"])[0, 0].numpy()
+    inds = od.cell_decode.last_inds[:n]
+    H, W = sig.shape
+
+    def fragile(k):
+        y, x0 = divmod(int(inds[k]), W)
+        nb = [sig[yy, xx] for yy in range(max(y - 1, 0), min(y + 2, H)) for xx in range(max(x0 - 1, 0), min(x0 + 2, W))
+              if (yy, xx) != (y, x0)]
+        s = raw[k, 8]
+        return abs(s - 0.2) < 3e-3 or abs(s / 0.4 - 0.2) < 3e-3 or abs(sig[y, x0] - 0.2) < 3e-3 or (sig[y, x0] - max(nb)) < 3e-3
+    got_p = res["polygons"]
+    used = np.zeros(len(got_p), bool)
+    pairs = []
+    for k in range(n):
+        d = np.abs(got_p - polys[k]).max(axis=1)
+        j = int(np.argmin(d))
+        if d[j] <= 0.1 and not used[j]:      # 1e-3 of the wh/st head scale (~12) x 4.5 source px per map px, x2
+            used[j] = True
+            pairs.append((k, j))
+        else:
+            assert fragile(k), (k, raw[k, 8], d[j])
+    assert len(pairs) >= n - 3 and (~used).sum() <= 3, (len(pairs), n, (~used).sum())
+    # matched cells keep their relative order unless their scores are within 3e-3 of each other
+    for (k1, j1), (k2, j2) in zip(pairs[:-1], pairs[1:]):
+        assert j1 < j2 or abs(raw[k1, 8] - raw[k2, 8]) < 3e-3
+    # logical locations: the processor attends over ALL cells of the table, so they are compared only when both sides
+    # hold exactly the same cell set
+    if len(pairs) == n == len(got_p) and all(k == j for k, j in pairs):
+        ref_st = stacked[0].numpy()
+        assert np.abs(res["stacked_axis"] - ref_st).max() <= 2 * TOL_REL * max(1.0, float(np.abs(ref_st).max()))
+        frac = ref_st - np.floor(ref_st)
+        safe = np.abs(frac - 0.5) > 5e-3
+        assert np.array_equal(res["logi"][safe], od.process_logic_output(stacked)[0].numpy()[safe])

@@ -135,3 +135,24 @@ def test_processor_equals_reference_module(tag):
         logic, stacked = op.processor_forward(sd, torch.from_numpy(gold[f"feat_{tag}"]), dets, L, L)
     assert np.allclose(logic.numpy(), gold[f"logic_{tag}"], atol=2e-5)
     assert np.allclose(stacked.numpy(), gold[f"stacked_{tag}"], atol=2e-5)
+
+
+def test_warp_affine_known_answers():
+    from oracle import lore_pre
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (20, 30, 3)).astype(np.uint8)
+    ident = np.array([[1, 0, 0], [0, 1, 0]], np.float64)
+    assert np.array_equal(lore_pre.warp_affine_u8(img, ident, 30, 20), img)
+    shift = np.array([[1, 0, 4], [0, 1, -3]], np.float64)            # dst(x, y) = src(x - 4, y + 3), zero outside
+    out = lore_pre.warp_affine_u8(img, shift, 30, 20)
+    exp = np.zeros_like(img)
+    exp[:17, 4:] = img[3:, :26]
+    assert np.array_equal(out, exp)
+    # dst = src / 2 about the origin: dst(x, y) samples src(2x, 2y) exactly
+    half = np.array([[0.5, 0, 0], [0, 0.5, 0]], np.float64)
+    assert np.array_equal(lore_pre.warp_affine_u8(img, half, 15, 10), img[::2, ::2])
+    # half-pixel shift: mean of horizontal neighbours, rounded half up ((a+b)*16384 + 16384) >> 15
+    hshift = np.array([[1, 0, 0.5], [0, 1, 0]], np.float64)
+    out = lore_pre.warp_affine_u8(img, hshift, 30, 20).astype(np.int64)
+    exp = (img[:, 1:].astype(np.int64) + img[:, :-1] + 1) >> 1
+    assert np.array_equal(out[:, 1:], exp)
