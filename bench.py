@@ -11,6 +11,9 @@ text-detection stage -- resize + normalise, DB-ResNet18, prob -> bitmap, contour
 unclip, final boxes.  Pages are sharded across ranks (weak scaling: fixed pages per rank); there is no
 collective in the timed region.
 
+Stages (--stages, default det,rec,tsr): DB text detection, CRNN recognition of the page's text lines, Lore table
+structure of the page's tables.
+
 Extra objects on the JSON line: ``roofline`` for the dominant kernel class (3x3 MFMA convolutions, HIP-event
 timed inside the timed region) and ``cpu_baseline`` (the oracle restatement of the same stage on the host
 cores, bounded sample, rank 0 at N=1 only).
@@ -108,8 +111,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-post", action="store_true", help="device half only (diagnostic; not a valid headline)")
-    ap.add_argument("--stages", default=os.environ.get("PT_BENCH_STAGES", "det,rec"),
-                    help="comma list of stages in the timed step: det (configs[1]) and/or rec")
+    ap.add_argument("--stages", default=os.environ.get("PT_BENCH_STAGES", "det,rec,tsr"),
+                    help="comma list of stages in the timed step: det (configs[1]), rec, tsr (Lore)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -132,7 +135,7 @@ def main():
     from pdf_table_amd.synth_weights import db_resnet18_state_dict
     from pdf_table_amd.weights import pack_crnn, pack_db_resnet18
     stages = [x for x in args.stages.split(",") if x]
-    assert set(stages) <= {"det", "rec"} and stages
+    assert set(stages) <= {"det", "rec", "tsr"} and stages
 
     eng = HipEngine(local_rank)
     # weights: packed once on rank 0, broadcast over RCCL/xGMI, loaded from device memory everywhere
@@ -156,6 +159,23 @@ def main():
             eng.load_weights(L.PT_MODEL_CRNN, pack_crnn(csd, x3=False))
         rec = RecStage(eng)
 
+    tsr = None
+    if "tsr" in stages:
+        from pdf_table_amd.synth_weights import lore_dla34_state_dict, lore_processor_state_dict
+        from pdf_table_amd.tsr_stage import LoreConfig, TsrStage
+        from pdf_table_amd.weights import pack_lore_dla34, pack_lore_processor
+        lsd = lore_dla34_state_dict(seed=2) if rank == 0 or world == 1 else None
+        psd = lore_processor_state_dict(seed=3) if rank == 0 or world == 1 else None
+        if world > 1:
+            from pdf_table_amd.dist_utils import broadcast_blob
+            eng.load_weights_device(L.PT_MODEL_LORE_DLA34, broadcast_blob(pack_lore_dla34(lsd, x3=False) if rank == 0 else None, dev))
+            eng.load_weights_device(L.PT_MODEL_LORE_PROCESSOR,
+                                    broadcast_blob(pack_lore_processor(psd, x3=False) if rank == 0 else None, dev))
+        else:
+            eng.load_weights(L.PT_MODEL_LORE_DLA34, pack_lore_dla34(lsd, x3=False))
+            eng.load_weights(L.PT_MODEL_LORE_PROCESSOR, pack_lore_processor(psd, x3=False))
+        tsr = TsrStage(eng, LoreConfig(task_type="wtw"), micro_batch=int(os.environ.get("PT_TSR_MICROBATCH", "8")))
+
     # pages: rank r owns pages [r*P, (r+1)*P) of the global batch (static contiguous shard, dist_utils.shard_range)
     from pdf_table_amd.dist_utils import shard_range
     lo, hi = shard_range(world * PAGES_PER_STEP, rank, world)
@@ -170,6 +190,15 @@ def main():
         l = made[i % DISTINCT][1]["lines"].astype(np.float64)
         gt_quads.append(np.stack([l[:, 0], l[:, 1], l[:, 2], l[:, 1], l[:, 2], l[:, 3], l[:, 0], l[:, 3]], 1))
     lines_per_page = float(np.mean([len(q) for q in gt_quads]))
+    # Table regions: the layout stage (PicoDet) is not built yet, so the table-structure stage is fed the generator's own
+    # table rectangles (1-2 per page) where the reference feeds it the layout boxes with label "table"
+    # (ocr_system_task.py:192-198), grown by 8 px like a detector's box
+    table_boxes = []
+    for i in range(PAGES_PER_STEP):
+        t = made[i % DISTINCT][1]["tables"].astype(np.int64).reshape(-1, 4)
+        table_boxes.append(np.stack([np.maximum(t[:, 0] - 8, 0), np.maximum(t[:, 1] - 8, 0), np.minimum(t[:, 2] + 8, PAGE),
+                                     np.minimum(t[:, 3] + 8, PAGE)], 1))
+    tables_per_page = float(np.mean([len(t) for t in table_boxes]))
     pages = torch.from_numpy(pages_np).to(dev)
     cfg = DetConfig(flavour="db_pp", thresh=0.3, box_thresh=0.6, unclip_ratio=1.5)
     stage = DetStage(eng, cfg)
@@ -182,10 +211,11 @@ def main():
 
     nboxes = 0
     ntok = 0
+    ncells = 0
 
     def run(steps, count=False):
         """software pipeline: device half of step k+1 is enqueued before the host half of step k"""
-        nonlocal nboxes, ntok
+        nonlocal nboxes, ntok, ncells
         prev = None
         for k in range(steps):
             cur = stage.forward(pages, slot=k & 1) if "det" in stages else None
@@ -196,6 +226,10 @@ def main():
                 res = stage.boxes(prev[0], prev[1], (PAGE, PAGE), prev[2])
                 if count:
                     nboxes += sum(len(r) for r in res)
+            if tsr is not None:
+                tres = tsr(pages, table_boxes)                 # warp, DLA-34+DCN, decode, processor; quads + logical locations
+                if count:
+                    ncells += sum(len(t["polygons"]) for pg in tres for t in pg)
             if rec_ids is not None:
                 from pdf_table_amd.rec_stage import ctc_collapse
                 toks = ctc_collapse(rec_ids.cpu().numpy())     # D2H of int32 [lines, 160] + host collapse
@@ -255,13 +289,19 @@ def main():
                                        if "det" in stages else "")
                                       + (" + CRNN text-line recognition of the page's text lines (crop, resize, CRNN, "
                                          "arg-max, CTC collapse)" if "rec" in stages else "")
+                                      + (" + Lore table-structure recognition of the page's tables (wtw: warp to 1024x1024, "
+                                         "DLA-34+DCN, heat-map/corner decode with vertex snapping, 2 x 4-layer processor, "
+                                         "quads + logical locations)" if "tsr" in stages else "")
                                       + (" [DEVICE HALF ONLY]" if args.no_post else "")
-                                      + "; layout (PicoDet) and TSR (Lore) stages are not built yet",
+                                      + "; the layout stage (PicoDet) is not built yet: table regions and text-line quads come "
+                                        "from the page generator",
                           "pages_per_step_per_gpu": PAGES_PER_STEP, "page": [PAGE, PAGE],
                           "stages": stages, "parallelism": f"page-shard x{world}",
                           "text_lines_per_page": lines_per_page if "rec" in stages else 0,
                           "tokens_per_page": ntok / max(1, PAGES_PER_STEP * args.steps),
                           "boxes_per_page": nboxes / max(1, PAGES_PER_STEP * args.steps),
+                          "tables_per_page": tables_per_page if "tsr" in stages else 0,
+                          "table_cells_per_page": ncells / max(1, PAGES_PER_STEP * args.steps),
                           "weights": "seeded random init (reference state_dict layout)"},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:

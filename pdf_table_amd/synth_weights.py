@@ -157,7 +157,7 @@ DLA34_LEVELS = [1, 1, 1, 2, 2, 1]                                            # c
 DLA34_CHANNELS = [16, 32, 64, 128, 256, 512]
 
 
-def lore_dla34_state_dict(seed: int = 0, hm_bias=(-4.6, -3.5), hm_gain: float = 0.5, cell_half=(10.0, 6.0)):
+def lore_dla34_state_dict(seed: int = 0, hm_bias=(-6.0, -5.0), hm_gain: float = 0.5, cell_half=(10.0, 6.0)):
     """state_dict of ``get_dla_dcn(34, heads)`` = ``DLASeg`` (lore/lore_dla_34.py:137-206) on ``dla34``
     (center_net/modeling_centernet.py:274-409, incl. the unused 1000-way ``fc``).
 
