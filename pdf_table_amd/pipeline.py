@@ -3,7 +3,9 @@
 The reference has no class of this name (SURVEY.md finding F1); its semantics are those of
 ``OcrSystemTask.__call__`` (src/pdftable/model/ocr_pdf/ocr_system_task.py:549-734) restricted to the vision path of
 an *image* page: text detection (:629, :148-166, incl. the reading-order sort) -> text recognition (:630, :296-336).
-Layout (PicoDet) and table structure (Lore) are SURVEY section 8 rows that are not built yet: asking for them raises.
+-> table structure (:192-198, Lore) on the page's table regions.  Layout (PicoDet) is the SURVEY section 8 row that is
+not built yet: asking for it raises, and the table regions the reference takes from the layout stage
+(``label == "table"``, pdf_table/table_common.py:1287-1301) are passed to ``predict(..., table_boxes=...)`` instead.
 
 What is different from the reference, by design: pages are processed as a batch (the reference is batch 1 and
 synchronous), crops never leave the GPU, and a failed page/line follows the reference's containment rules
@@ -22,6 +24,7 @@ from .det_stage import DetConfig, DetStage, sort_boxes_reading_order
 from .engine import HipEngine
 from .ocr_detection_task import OcrDetectionTask, _read_image
 from .ocr_recognition_task import OcrRecognitionTask
+from .ocr_table_structure_task import OcrTableStructureTask
 
 __all__ = ["OcrTablePipeline", "PageResult"]
 
@@ -38,10 +41,12 @@ class PageResult:
 class OcrTablePipeline:
     def __init__(self, device: int = 0, detect_model: str = "db", recognizer: str = "CRNN", thresh: float = 0.2,
                  synthetic_seed: Optional[int] = None, det_task_path: Optional[str] = None,
-                 rec_task_path: Optional[str] = None, layout: bool = False, table_structure: bool = False, **kwargs):
-        if layout or table_structure:
-            raise NotImplementedError("layout (PicoDet) and table-structure (Lore) stages are not built on the HIP engine "
-                                      "yet (SURVEY.md section 8a rows 1 and 4)")
+                 rec_task_path: Optional[str] = None, layout: bool = False, table_structure: bool = False,
+                 table_structure_model: str = "Lore", table_structure_task_type: str = "wtw",
+                 tsr_task_path: Optional[str] = None, **kwargs):
+        if layout:
+            raise NotImplementedError("the layout stage (PicoDet) is not built on the HIP engine yet (SURVEY.md section 8a "
+                                      "row 1); pass the table regions to predict(table_boxes=...)")
         self.engine = HipEngine(device)
         dk = dict(kwargs)
         rk = dict(kwargs)
@@ -54,16 +59,28 @@ class OcrTablePipeline:
             rk["task_path"] = rec_task_path
         self.text_detector = OcrDetectionTask(model=detect_model, thresh=thresh, engine=self.engine, **dk)
         self.text_recognizer = OcrRecognitionTask(model=recognizer, engine=self.engine, **rk)
+        self.table_structure_task = None
+        if table_structure:
+            tk = dict(kwargs)
+            if synthetic_seed is not None:
+                tk["synthetic_seed"] = synthetic_seed + 2
+            if tsr_task_path:
+                tk["task_path"] = tsr_task_path
+            self.table_structure_task = OcrTableStructureTask(model=table_structure_model, engine=self.engine,
+                                                              task_type=table_structure_task_type, **tk)
 
-    def predict(self, pages: Sequence, **kwargs) -> List[PageResult]:
-        """pages: RGB images (paths / PIL / ndarrays).  Returns one PageResult per page, plus ``self.metric``."""
+    def predict(self, pages: Sequence, table_boxes: Optional[Sequence[np.ndarray]] = None, **kwargs) -> List[PageResult]:
+        """pages: RGB images (paths / PIL / ndarrays); table_boxes: per page int [k,4] x1,y1,x2,y2 table regions (what the
+        layout stage would deliver).  Returns one PageResult per page, plus ``self.metric``."""
+        if self.table_structure_task is not None and table_boxes is None:
+            raise ValueError("table_structure=True needs predict(table_boxes=...) until the layout stage is built")
         t0 = time.time()
         imgs = [_read_image(p) for p in pages]
         results: List[Optional[PageResult]] = [None] * len(imgs)
         groups: Dict[tuple, List[int]] = {}
         for i, im in enumerate(imgs):
             groups.setdefault(im.shape, []).append(i)
-        t_det = t_rec = 0.0
+        t_det = t_rec = t_tsr = 0.0
         for shape, idxs in groups.items():
             batch = torch.from_numpy(np.stack([imgs[i] for i in idxs])).to(self.engine._tdev)
             a = time.time()
@@ -77,11 +94,18 @@ class OcrTablePipeline:
             except Exception:                      # reference: a failing recognition yields empty strings
                 texts = [[""] * len(b) for b in boxes]
             c = time.time()
+            tsr = None
+            if self.table_structure_task is not None:
+                tsr = self.table_structure_task.recognize_tables(batch, [np.asarray(table_boxes[i]).reshape(-1, 4) for i in idxs])
+            d_ = time.time()
             t_det += b_ - a
             t_rec += c - b_
+            t_tsr += d_ - c
             for k, i in enumerate(idxs):
                 ocr = [{"index": j + 1, "text": t, "bbox": boxes[k][j].reshape(4, 2)} for j, t in enumerate(texts[k])]
-                results[i] = PageResult(det_result=boxes[k], ocr_result=ocr)
+                results[i] = PageResult(det_result=boxes[k], ocr_result=ocr,
+                                        table_structure_result=None if tsr is None else tsr[k])
         self.metric = {"use_time": time.time() - t0, "text_detection": {"use_time": t_det},
-                       "text_recognition": {"use_time": t_rec, "total": sum(len(r.ocr_result) for r in results)}}
+                       "text_recognition": {"use_time": t_rec, "total": sum(len(r.ocr_result) for r in results)},
+                       "table_structure": {"use_time": t_tsr}}
         return results

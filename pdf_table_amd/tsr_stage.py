@@ -25,6 +25,8 @@ __all__ = ["LoreConfig", "TsrStage", "lore_geometry", "affine_from_center_scale"
 class LoreConfig:
     """The fields of lore/configuration_lore.py:29-116 that the inference path reads."""
     task_type: str = "wtw"
+    model_name: str = "Lore"
+    model_path: str = ""
     backbone: str = "DLA-34"
     resolution: Tuple[int, int] = (1024, 1024)
     stacking_layers: int = 4

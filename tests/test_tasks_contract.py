@@ -4,6 +4,7 @@ import hashlib
 import json
 import os
 
+import numpy as np
 import pytest
 
 from pdf_table_amd.base_infer_task import BaseInferTask
@@ -76,3 +77,25 @@ def test_unknown_models_raise_like_the_reference():
         OcrDetectionTask(model="yolo")
     with pytest.raises(RuntimeError, match="current model is not supported"):
         OcrRecognitionTask(model="tesseract")
+
+
+def test_lore_host_logic_matches_oracle():
+    """tsr_stage's host pieces (affine geometry, int64 meta, quad back-projection, logical rounding, config presets)
+    against the oracle restatements, which are pinned by the reference goldens."""
+    import torch
+    from oracle import lore_decode as od
+    from oracle import lore_pre
+    from pdf_table_amd import tsr_stage as ts
+    for (h, w, ih, iw) in [(320, 360, 1024, 1024), (300, 420, 1024, 1024), (777, 512, 512, 512), (51, 1999, 1024, 1024), (1024, 1024, 1024, 1024)]:
+        t1, m1 = od.lore_preprocess_geometry(h, w, ih, iw)
+        mi, m2 = ts.lore_geometry(h, w, ih, iw)
+        assert np.array_equal(m1, m2) and np.array_equal(lore_pre.invert_affine(t1), mi)
+        q = np.random.default_rng(h).uniform(-5, iw / 4 + 5, (40, 8)).astype(np.float32)
+        ref = np.concatenate([od.transform_preds(q[:, 2 * k:2 * k + 2], m1[:2], m1[2], (m1[6], m1[5])) for k in range(4)], 1)
+        assert np.array_equal(ts.transform_quads(q, m2), ref.astype(np.float32))
+    lg = np.random.default_rng(1).uniform(-1, 12, (50, 4)).astype(np.float32)
+    lg[:4, 0] = [2.5, 3.5, 0.5, 7.500001]
+    assert np.array_equal(ts.process_logic_output(lg), od.process_logic_output(torch.from_numpy(lg)).numpy())
+    wtw, ptn = ts.LoreConfig(task_type="wtw"), ts.LoreConfig(task_type="ptn")
+    assert (wtw.resolution, wtw.wiz_rev, wtw.wiz_2dpe, wtw.vis_thresh, wtw.tsfm_layers) == ((1024, 1024), True, False, 0.2, 4)
+    assert (ptn.resolution, ptn.wiz_rev, ptn.wiz_2dpe, ptn.vis_thresh, ptn.tsfm_layers) == ((512, 512), False, True, 0.35, 3)
