@@ -222,7 +222,7 @@ def main():
             rec_ids = None
             if rec is not None:
                 rec_ids, _ = rec.ids(pages, gt_quads)          # host quad geometry + one pt_rec_forward (async)
-            if prev is not None and not args.no_post:
+            if prev is not None and not args.no_post:          # host half of the previous step, under this step's GPU work
                 res = stage.boxes(prev[0], prev[1], (PAGE, PAGE), prev[2])
                 if count:
                     nboxes += sum(len(r) for r in res)

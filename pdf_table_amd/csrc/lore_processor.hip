@@ -94,50 +94,103 @@ __global__ __launch_bounds__(256) void cvt_logic_kernel(const float* __restrict_
   put(out + (size_t)t * (split ? 64 : 32) + c, 32, split, c < 4 ? x[(size_t)t * 8 + c] : 0.f);
 }
 
-// attention (:134-163) for one head and 64 queries of one table; tiles[3i..] = (first token of the table, query offset
-// inside it, cells in the table).  qkv [Npad, 768] = [q | k | v] (split: [hi 768 | lo 768]); out [Npad, 256].
+// attention (:134-163) for one head and 32 queries of one table, one wave, on the matrix cores.
+// tiles[3i..] = (first token of the table, query offset inside it, cells in the table).
+// qkv [Npad, 768] = [q | k | v] (split: [hi 768 | lo 768]); out [Npad, 256].
+//   S^T (32 keys x 32 queries) = K_tile Q^T: two v_mfma_f32_32x32x16_bf16 over d = 32 (A = key rows, B = query rows,
+//   both 16-byte row chunks straight from global).  In the D layout a lane owns ONE query (column lane & 31) and 16 of
+//   the 32 keys, so the online soft-max is in-lane plus one exchange with lane ^ 32.
+//   O^T (32 d x 32 queries) += V^T P^T: the B operand is exactly the 8 probabilities a lane already holds per
+//   k-step (keys taken in the D layout's own order -- a sum does not care), the A operand gathers V[key][d] in that
+//   same key order.  BF16X3 mode: three passes each (hi*hi + hi*lo + lo*hi), fp32 soft-max.
+typedef __attribute__((ext_vector_type(8))) __bf16 abf16x8;
+typedef __attribute__((ext_vector_type(16))) float af32x16;
+
+__device__ __forceinline__ abf16x8 ld8(const bf16_t* p) { return *reinterpret_cast<const abf16x8*>(p); }
+
+template <int SPLIT>
 __global__ __launch_bounds__(64) void attention_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ tiles,
-                                                        bf16_t* __restrict__ out, int split) {
-  __shared__ float ks[64][32];
-  __shared__ float vs[64][32];
+                                                        bf16_t* __restrict__ out) {
   const int tile = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
   const int tok0 = tiles[3 * tile], q0 = tiles[3 * tile + 1], nseg = tiles[3 * tile + 2];
-  const int cs = split ? 1536 : 768;
-  const int qi = q0 + lane;
-  const bool live = qi < nseg;
-  float q[32], acc[32];
-  const bf16_t* qp = qkv + (size_t)(tok0 + (live ? qi : 0)) * cs + head * 32;
+  constexpr int cs = SPLIT ? 1536 : 768;
+  const int col = lane & 31, half = lane >> 5;
+  const int qi = q0 + col;
+  const bf16_t* qrow = qkv + (size_t)(tok0 + (qi < nseg ? qi : nseg - 1)) * cs + head * 32 + half * 8;
+  abf16x8 qh[2], ql[2];
+  qh[0] = ld8(qrow); qh[1] = ld8(qrow + 16);
+  if (SPLIT) { ql[0] = ld8(qrow + 768); ql[1] = ld8(qrow + 768 + 16); }
+  af32x16 acc;
 #pragma unroll
-  for (int d = 0; d < 32; ++d) { q[d] = get(qp + d, 768, split); acc[d] = 0.f; }
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float m = -INFINITY, l = 0.f;
-  const float inv = 5.656854249492381f;   // math.sqrt(32): scores are DIVIDED by it (:135)
-  for (int k0 = 0; k0 < nseg; k0 += 64) {
-    const int kj = k0 + lane;
-    if (kj < nseg) {
-      const bf16_t* kp = qkv + (size_t)(tok0 + kj) * cs + 256 + head * 32;
+  for (int k0 = 0; k0 < nseg; k0 += 32) {
+    // ---- scores: rows = keys k0 + (r & 3) + 8 (r >> 2) + 4 half, column = this lane's query
+    const int krow = k0 + col;
+    const bf16_t* kp = qkv + (size_t)(tok0 + (krow < nseg ? krow : nseg - 1)) * cs + 256 + head * 32 + half * 8;
+    af32x16 sc;
 #pragma unroll
-      for (int d = 0; d < 32; ++d) { ks[lane][d] = get(kp + d, 768, split); vs[lane][d] = get(kp + 256 + d, 768, split); }
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+    {
+      const abf16x8 k0h = ld8(kp), k1h = ld8(kp + 16);
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0h, qh[0], sc, 0, 0, 0);
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1h, qh[1], sc, 0, 0, 0);
+      if (SPLIT) {
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0h, ql[0], sc, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1h, ql[1], sc, 0, 0, 0);
+        const abf16x8 k0l = ld8(kp + 768), k1l = ld8(kp + 768 + 16);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0l, qh[0], sc, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1l, qh[1], sc, 0, 0, 0);
+      }
     }
-    __syncthreads();
-    const int kn = min(64, nseg - k0);
-    for (int j = 0; j < kn; ++j) {
-      float s = 0.f;
+    float mt = -INFINITY;
 #pragma unroll
-      for (int d = 0; d < 32; ++d) s += q[d] * ks[j][d];
-      s = s / inv;
-      const float mn = fmaxf(m, s);
-      const float sc = expf(m - mn), p = expf(s - mn);
-      l = l * sc + p;
-#pragma unroll
-      for (int d = 0; d < 32; ++d) acc[d] = acc[d] * sc + p * vs[j][d];
-      m = mn;
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      sc[r] = key < nseg ? sc[r] / 5.656854249492381f : -INFINITY;      // scores / math.sqrt(32) (:135)
+      mt = fmaxf(mt, sc[r]);
     }
-    __syncthreads();
+    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    const float mn = fmaxf(m, mt);
+    const float scale = expf(m - mn);
+    float p[16], lt = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { p[r] = expf(sc[r] - mn); lt += p[r]; }
+    lt += __shfl_xor(lt, 32);
+    l = l * scale + lt;
+    m = mn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] *= scale;
+    // ---- O^T += V^T P^T; k-step s covers this half's registers 8s .. 8s+7, i.e. keys k0 + (j & 3) + 8 (2s + (j >> 2)) + 4 half
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      abf16x8 ph, pl, vh, vl;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float pv = p[8 * s2 + j];
+        const uint32_t hb = f2bf(pv);
+        ph[j] = __builtin_bit_cast(__bf16, (uint16_t)hb);
+        if (SPLIT) pl[j] = __builtin_bit_cast(__bf16, (uint16_t)f2bf(pv - bf2f(hb)));
+        int key = k0 + (j & 3) + 8 * (2 * s2 + (j >> 2)) + 4 * half;
+        if (key >= nseg) key = nseg - 1;                 // its probability is exactly 0
+        const bf16_t* vp = qkv + (size_t)(tok0 + key) * cs + 512 + head * 32 + col;     // A row = d = lane & 31
+        vh[j] = __builtin_bit_cast(__bf16, vp[0]);
+        if (SPLIT) vl[j] = __builtin_bit_cast(__bf16, vp[768]);
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, acc, 0, 0, 0);
+      if (SPLIT) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, acc, 0, 0, 0);
+      }
+    }
   }
-  if (live) {
-    bf16_t* op = out + (size_t)(tok0 + qi) * (split ? 512 : 256) + head * 32;
+  if (qi < nseg) {
+    bf16_t* op = out + (size_t)(tok0 + qi) * (SPLIT ? 512 : 256) + head * 32;
 #pragma unroll
-    for (int d = 0; d < 32; ++d) put(op + d, 256, split, acc[d] / l);
+    for (int r = 0; r < 16; ++r) {
+      const int d = (r & 3) + 8 * (r >> 2) + 4 * half;
+      put(op + d, 256, SPLIT, acc[r] / l);
+    }
   }
 }
 
@@ -199,7 +252,7 @@ int pt_lore_process(pt_engine* e, const float* d_logi, const float* d_dets, cons
   for (int t = 0; t < n_tables; ++t) {
     const int c = h_counts[t];
     PT_REQUIRE(c >= 0 && c <= PT_TSR_MAX_CELLS, "tsr process: bad cell count %d", c);
-    for (int q0 = 0; q0 < c; q0 += 64) { tiles.push_back(N); tiles.push_back(q0); tiles.push_back(c); }
+    for (int q0 = 0; q0 < c; q0 += 32) { tiles.push_back(N); tiles.push_back(q0); tiles.push_back(c); }
     for (int r = 0; r < c; ++r) { tok.push_back(t); tok.push_back(r); }
     N += c;
   }
@@ -274,7 +327,8 @@ int pt_lore_process(pt_engine* e, const float* d_logi, const float* d_dets, cons
       p.gemm(xb, 256, lq + ".qkv", 768, 0, qkv, 768, 0);
       if (p.rc == PT_OK) {
         PtProfScope ps(e, s, PT_PROF_OTHER, 0, "tsr attention");
-        hipLaunchKernelGGL(attention_kernel, dim3(ntiles, 8), dim3(64), 0, s, qkv, d_tiles, att, x3);
+        if (x3) hipLaunchKernelGGL(attention_kernel<1>, dim3(ntiles, 8), dim3(64), 0, s, qkv, d_tiles, att);
+        else hipLaunchKernelGGL(attention_kernel<0>, dim3(ntiles, 8), dim3(64), 0, s, qkv, d_tiles, att);
       }
       p.gemm(att, 256, lq + ".out", 256, 0, nullptr, 0, 0, x, 256, x);
       norm(lq + ".norm_2");
