@@ -174,7 +174,7 @@ def main():
         else:
             eng.load_weights(L.PT_MODEL_LORE_DLA34, pack_lore_dla34(lsd, x3=False))
             eng.load_weights(L.PT_MODEL_LORE_PROCESSOR, pack_lore_processor(psd, x3=False))
-        tsr = TsrStage(eng, LoreConfig(task_type="wtw"), micro_batch=int(os.environ.get("PT_TSR_MICROBATCH", "8")))
+        tsr = TsrStage(eng, LoreConfig(task_type="wtw"), micro_batch=int(os.environ.get("PT_TSR_MICROBATCH", "32")))
 
     # pages: rank r owns pages [r*P, (r+1)*P) of the global batch (static contiguous shard, dist_utils.shard_range)
     from pdf_table_amd.dist_utils import shard_range

@@ -8,6 +8,8 @@
 //                         (lore_dla_34.py:96-110) fused with the `+ layers[i-1]` of IDAUp.forward.
 // Activations are NHWC bf16; in the BF16X3 precision mode every tensor is [hi(C) | lo(C)] per pixel and values are
 // hi + lo in fp32.
+#include <stdio.h>
+
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -190,6 +192,358 @@ __global__ __launch_bounds__(256) void tsr_preprocess_kernel(const uint8_t* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused modulated deformable 3x3 convolution (+ folded BN + ReLU): the sampled columns never leave the CU.
+//   workgroup = 128 consecutive pixels x NB <= 128 output channels, 4 waves (32 pixels each); K = 9 taps x C channels
+//   walked in 32-channel chunks.  Per chunk every thread blends the 4 bilinear corners of ONE pixel for 16 channels
+//   (two 16-byte loads per corner, position / weights computed once per tap) into a bf16 [128][32] LDS tile (80-byte
+//   rows: conflict-free ds_read_b128), the weight chunk [NB][32] is staged next to it, and each wave issues
+//   2 x NB/32 v_mfma_f32_32x32x16_bf16.  Gathers of chunk c+1 are in flight while chunk c is multiplied.
+//   Same arithmetic as dcn_im2col_kernel + the 1x1 GEMM (columns rounded to bf16 / hi+lo), weights in the same
+//   [N/64][chunks][64][32] tiling (K = tap * C + c); BF16X3: chunks [w_hi | w_hi | w_lo], three MFMA passes.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 dbf16x8;
+typedef __attribute__((ext_vector_type(16))) float df32x16;
+typedef __attribute__((ext_vector_type(2))) float df2;
+typedef __attribute__((ext_vector_type(2))) __bf16 db2;
+
+template <int SPLIT, int NB>
+__global__ __launch_bounds__(256, (SPLIT || NB > 64) ? 2 : 4) void dcn_fused_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
+                                                            const bf16_t* __restrict__ w, const float* __restrict__ bias,
+                                                            bf16_t* __restrict__ out, long long npix, int H, int W, int C,
+                                                            int N, int relu) {
+#pragma clang fp contract(fast)
+  constexpr int ROW = 80;                       // bytes per staged row (32 bf16 + 16 B pad)
+  constexpr int NP = SPLIT ? 2 : 1;
+  constexpr int NT = NB / 32;                   // 32-wide MFMA column tiles
+  __shared__ __attribute__((aligned(16))) char s_a[NP][128 * ROW];
+  __shared__ __attribute__((aligned(16))) char s_w[NP][NB * ROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, q = lane >> 5;
+  const long long p0 = (long long)blockIdx.x * 128;
+  const int n0 = blockIdx.y * NB;
+  const int cs = SPLIT ? 2 * C : C;
+  const int nslice = C >> 5, nk = 9 * nslice;
+  // gather role: pixel gp, channels [16 * gh, 16 * gh + 16) of the current 32-channel slice
+  const int gp = tid & 127, gh = tid >> 7;
+  long long pix = p0 + gp;
+  const bool live = pix < npix;
+  if (!live) pix = npix - 1;
+  const int xw = (int)(pix % W), yh = (int)((pix / W) % H);
+  const bf16_t* xb = x + (size_t)(pix / ((long long)W * H)) * H * W * cs;
+  const float* omp = om + pix * 32;
+  // weight staging role: 16-byte piece `tid` (and tid + 256 ...) of the [NB][32] chunk
+  constexpr int WPIECES = NB * 4 / 256;         // per thread
+  const bf16_t* wbase = w + (size_t)(n0 >> 6) * (SPLIT ? 3 : 1) * nk * (64 * 32);
+
+  df32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  int coff[4];
+  float cwt[4], mask = 0.f;
+  u32x4 rc[NP][4][2];
+  u32x4 rw[NP][WPIECES];
+
+  auto geometry = [&](int tap) {
+    const float off_h = omp[2 * tap], off_w = omp[2 * tap + 1];
+    mask = 1.f / (1.f + expf(-omp[18 + tap]));
+    const float h_im = (float)(yh - 1 + tap / 3) + off_h;
+    const float w_im = (float)(xw - 1 + tap % 3) + off_w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { coff[k] = -1; cwt[k] = 0.f; }
+    if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+      const float hf = floorf(h_im), wf = floorf(w_im);
+      const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
+      const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+      cwt[0] = hh * hw; cwt[1] = hh * lw; cwt[2] = lh * hw; cwt[3] = lh * lw;
+      if (h_low >= 0 && w_low >= 0) coff[0] = (h_low * W + w_low) * cs;
+      if (h_low >= 0 && w_high <= W - 1) coff[1] = (h_low * W + w_high) * cs;
+      if (h_high <= H - 1 && w_low >= 0) coff[2] = (h_high * W + w_low) * cs;
+      if (h_high <= H - 1 && w_high <= W - 1) coff[3] = (h_high * W + w_high) * cs;
+    }
+  };
+  auto prefetch = [&](int kc) {
+    const int tap = kc / nslice, sl = kc - tap * nslice;
+    if (sl == 0) geometry(tap);
+    const int ch = sl * 32 + gh * 16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp) {
+        rc[pp][k][0] = z; rc[pp][k][1] = z;
+        if (coff[k] >= 0) {
+          const bf16_t* sp = xb + coff[k] + ch + pp * C;
+          rc[pp][k][0] = *reinterpret_cast<const u32x4*>(sp);
+          rc[pp][k][1] = *reinterpret_cast<const u32x4*>(sp + 8);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WPIECES; ++j) {
+      const int idx = tid + j * 256;            // row = idx >> 2 (0 .. NB-1), 16-byte part = idx & 3
+      const int row = idx >> 2, part = idx & 3;
+      const bf16_t* wc = wbase + (size_t)(row >> 6) * (SPLIT ? 3 : 1) * nk * (64 * 32) + (size_t)kc * (64 * 32) + (row & 63) * 32 + part * 8;
+      rw[0][j] = *reinterpret_cast<const u32x4*>(wc);
+      if (SPLIT) rw[1][j] = *reinterpret_cast<const u32x4*>(wc + (size_t)2 * nk * (64 * 32));
+    }
+  };
+  auto commit = [&]() {
+    // packed fp32 math (v_pk_fma_f32) and the hardware RNE bf16 conversion (v_cvt_pk_bf16_f32); FMA contraction is on
+    // in this kernel: ((w1 v1 + w2 v2) + w3 v3) + w4 v4 with fused roundings, then * mask
+    const df2 w0 = {cwt[0], cwt[0]}, w1 = {cwt[1], cwt[1]}, w2 = {cwt[2], cwt[2]}, w3 = {cwt[3], cwt[3]}, mk = {mask, mask};
+    uint32_t oh[8], ol[8];
+#pragma unroll
+    for (int hgrp = 0; hgrp < 2; ++hgrp) {
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        df2 c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t u = e2 == 0 ? rc[0][k][hgrp].x : e2 == 1 ? rc[0][k][hgrp].y : e2 == 2 ? rc[0][k][hgrp].z : rc[0][k][hgrp].w;
+          c[k] = df2{__uint_as_float(u << 16), __uint_as_float(u & 0xFFFF0000u)};
+          if (SPLIT) {
+            const uint32_t ul = e2 == 0 ? rc[NP - 1][k][hgrp].x : e2 == 1 ? rc[NP - 1][k][hgrp].y
+                                : e2 == 2 ? rc[NP - 1][k][hgrp].z : rc[NP - 1][k][hgrp].w;
+            c[k] += df2{__uint_as_float(ul << 16), __uint_as_float(ul & 0xFFFF0000u)};
+          }
+        }
+        df2 v = w0 * c[0];
+        v = w1 * c[1] + v;
+        v = w2 * c[2] + v;
+        v = w3 * c[3] + v;
+        v = v * mk;
+        const db2 hb = __builtin_convertvector(v, db2);
+        oh[hgrp * 4 + e2] = __builtin_bit_cast(uint32_t, hb);
+        if (SPLIT) {
+          const df2 back = __builtin_convertvector(hb, df2);
+          ol[hgrp * 4 + e2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - back, db2));
+        }
+      }
+    }
+    char* ap = s_a[0] + gp * ROW + gh * 32;
+    *reinterpret_cast<u32x4*>(ap) = u32x4{oh[0], oh[1], oh[2], oh[3]};
+    *reinterpret_cast<u32x4*>(ap + 16) = u32x4{oh[4], oh[5], oh[6], oh[7]};
+    if (SPLIT) {
+      char* al = s_a[NP - 1] + gp * ROW + gh * 32;
+      *reinterpret_cast<u32x4*>(al) = u32x4{ol[0], ol[1], ol[2], ol[3]};
+      *reinterpret_cast<u32x4*>(al + 16) = u32x4{ol[4], ol[5], ol[6], ol[7]};
+    }
+#pragma unroll
+    for (int j = 0; j < WPIECES; ++j) {
+      const int idx = tid + j * 256;
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp) *reinterpret_cast<u32x4*>(s_w[pp] + (idx >> 2) * ROW + (idx & 3) * 16) = rw[pp][j];
+    }
+  };
+
+  const char* a_rd = s_a[0] + (wave * 32 + lx) * ROW + q * 16;
+  const char* b_rd = s_w[0] + lx * ROW + q * 16;
+  constexpr int A_PLANE = 128 * ROW, W_PLANE = NB * ROW;
+  prefetch(0);
+  for (int kc = 0; kc < nk; ++kc) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (kc + 1 < nk) prefetch(kc + 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const dbf16x8 ah = *reinterpret_cast<const dbf16x8*>(a_rd + kk * 32);
+      dbf16x8 al;
+      if (SPLIT) al = *reinterpret_cast<const dbf16x8*>(a_rd + A_PLANE + kk * 32);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const dbf16x8 bh = *reinterpret_cast<const dbf16x8*>(b_rd + t * 32 * ROW + kk * 32);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+        if (SPLIT) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+          const dbf16x8 bl = *reinterpret_cast<const dbf16x8*>(b_rd + W_PLANE + t * 32 * ROW + kk * 32);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // epilogue: D[row = pixel (r & 3) + 8 (r >> 2) + 4 q][col = channel lx] -> + bias, ReLU, bf16 (hi | lo)
+  const int ocs = SPLIT ? 2 * N : N;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = n0 + t * 32 + lx;
+    const float bv = bias[n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long op = p0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
+      if (op >= npix) continue;
+      float v = acc[t][r] + bv;
+      if (relu) v = fmaxf(v, 0.f);
+      const uint32_t hb = f2bf(v);
+      out[(size_t)op * ocs + n] = (bf16_t)hb;
+      if (SPLIT) out[(size_t)op * ocs + N + n] = (bf16_t)f2bf(v - bf2f(hb));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 fast path of the fused deformable convolution.  The variant above gives every lane a different pixel, so one
+// 16-byte wave load touches 64 cache lines and the kernel runs at the L1 tag rate (measured: 0.246 ms for 64->64 @256^2
+// x 8 tables, whatever the VALU work or occupancy).  Here eight consecutive lanes read the eight 16-byte pieces of ONE
+// corner pixel's 64-channel run (a full 128-byte line): 8 lines per wave load.  K is walked in (tap, 64-channel) stages;
+// a thread blends 4 (pixel, piece) items per stage; LDS rows are 144 bytes (conflict-free ds_read_b128).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(256, 2) void dcn_fused64_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
+                                                              const bf16_t* __restrict__ w, const float* __restrict__ bias,
+                                                              bf16_t* __restrict__ out, long long npix, int H, int W,
+                                                              int C, int N, int relu) {
+#pragma clang fp contract(fast)
+  constexpr int ROW = 144;                      // 64 bf16 + 16 B pad
+  constexpr int NT = NB / 32;
+  constexpr int WP = NB * 8 / 256;              // 16-byte weight pieces per thread per stage
+  __shared__ __attribute__((aligned(16))) char s_a[128 * ROW];
+  __shared__ __attribute__((aligned(16))) char s_w[NB * ROW];
+  __shared__ float s_om[128 * 28];              // the tile's 27 offset / mask values per pixel, staged once (row pitch 28)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, q = lane >> 5;
+  const long long p0 = (long long)blockIdx.x * 128;
+  const int n0 = blockIdx.y * NB;
+  const int nss = C >> 6, nst = 9 * nss, nk = 9 * (C >> 5);
+  const int piece = tid & 7, prow = tid >> 3;   // items: pixels prow + 32 j, j = 0..3, 16-byte piece `piece`
+  for (int i = tid; i < 128 * 7; i += 256) {     // 7 float4 per pixel (channels 0..27; 27 is padding)
+    long long pix = p0 + i / 7;
+    if (pix >= npix) pix = npix - 1;
+    *reinterpret_cast<float4*>(s_om + (i / 7) * 28 + (i % 7) * 4) = *reinterpret_cast<const float4*>(om + pix * 32 + (i % 7) * 4);
+  }
+  int xw[4], yh[4];
+  const bf16_t* xb[4];
+  const float* omp[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    long long pix = p0 + prow + 32 * j;
+    if (pix >= npix) pix = npix - 1;
+    xw[j] = (int)(pix % W);
+    yh[j] = (int)((pix / W) % H);
+    xb[j] = x + (size_t)(pix / ((long long)W * H)) * H * W * C + piece * 8;
+    omp[j] = s_om + (prow + 32 * j) * 28;
+  }
+  __syncthreads();
+  const bf16_t* wbase = w + (size_t)(n0 >> 6) * nk * (64 * 32);
+
+  df32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  int coff[4][4];
+  float cwt[4][4], mask[4];
+  u32x4 rc[4][4];
+  u32x4 rw[WP];
+
+  auto geometry = [&](int tap) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float off_h = omp[j][2 * tap], off_w = omp[j][2 * tap + 1];
+      mask[j] = 1.f / (1.f + expf(-omp[j][18 + tap]));
+      const float h_im = (float)(yh[j] - 1 + tap / 3) + off_h;
+      const float w_im = (float)(xw[j] - 1 + tap % 3) + off_w;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { coff[j][k] = -1; cwt[j][k] = 0.f; }
+      if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+        const float hf = floorf(h_im), wf = floorf(w_im);
+        const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
+        const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+        cwt[j][0] = hh * hw; cwt[j][1] = hh * lw; cwt[j][2] = lh * hw; cwt[j][3] = lh * lw;
+        if (h_low >= 0 && w_low >= 0) coff[j][0] = (h_low * W + w_low) * C;
+        if (h_low >= 0 && w_high <= W - 1) coff[j][1] = (h_low * W + w_high) * C;
+        if (h_high <= H - 1 && w_low >= 0) coff[j][2] = (h_high * W + w_low) * C;
+        if (h_high <= H - 1 && w_high <= W - 1) coff[j][3] = (h_high * W + w_high) * C;
+      }
+    }
+  };
+  auto prefetch = [&](int st) {
+    const int tap = st / nss, ss = st - tap * nss;
+    if (ss == 0) geometry(tap);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        rc[j][k] = u32x4{0u, 0u, 0u, 0u};
+        if (coff[j][k] >= 0) rc[j][k] = *reinterpret_cast<const u32x4*>(xb[j] + coff[j][k] + ss * 64);
+      }
+    const int kc = tap * (C >> 5) + 2 * ss;     // the stage's two 32-channel weight chunks are adjacent
+#pragma unroll
+    for (int j = 0; j < WP; ++j) {
+      const int idx = tid + j * 256;            // row = idx >> 3, piece = idx & 7 (0..3: chunk kc, 4..7: chunk kc + 1)
+      const int row = idx >> 3, pc = idx & 7;
+      rw[j] = *reinterpret_cast<const u32x4*>(wbase + (size_t)(row >> 6) * nk * (64 * 32) + (size_t)(kc + (pc >> 2)) * (64 * 32) +
+                                              (row & 63) * 32 + (pc & 3) * 8);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const df2 w0 = {cwt[j][0], cwt[j][0]}, w1 = {cwt[j][1], cwt[j][1]}, w2 = {cwt[j][2], cwt[j][2]},
+                w3 = {cwt[j][3], cwt[j][3]}, mk = {mask[j], mask[j]};
+      uint32_t o[4];
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        df2 c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t u = e2 == 0 ? rc[j][k].x : e2 == 1 ? rc[j][k].y : e2 == 2 ? rc[j][k].z : rc[j][k].w;
+          c[k] = df2{__uint_as_float(u << 16), __uint_as_float(u & 0xFFFF0000u)};
+        }
+        df2 v = w0 * c[0];
+        v = w1 * c[1] + v;
+        v = w2 * c[2] + v;
+        v = w3 * c[3] + v;
+        v = v * mk;
+        o[e2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, db2));
+      }
+      *reinterpret_cast<u32x4*>(s_a + (prow + 32 * j) * ROW + piece * 16) = u32x4{o[0], o[1], o[2], o[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < WP; ++j) {
+      const int idx = tid + j * 256;
+      *reinterpret_cast<u32x4*>(s_w + (idx >> 3) * ROW + (idx & 7) * 16) = rw[j];
+    }
+  };
+
+  const char* a_rd = s_a + (wave * 32 + lx) * ROW + q * 16;
+  const char* b_rd = s_w + lx * ROW + q * 16;
+  prefetch(0);
+  for (int st = 0; st < nst; ++st) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (st + 1 < nst) prefetch(st + 1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const dbf16x8 a = *reinterpret_cast<const dbf16x8*>(a_rd + kk * 32);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const dbf16x8 b = *reinterpret_cast<const dbf16x8*>(b_rd + t * 32 * ROW + kk * 32);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = n0 + t * 32 + lx;
+    const float bv = bias[n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long op = p0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
+      if (op >= npix) continue;
+      float v = acc[t][r] + bv;
+      if (relu) v = fmaxf(v, 0.f);
+      out[(size_t)op * N + n] = (bf16_t)f2bf(v);
+    }
+  }
+}
+
 inline int grid_for(long long total) {
   long long blocks = (total + 255) / 256;
   if (blocks > 256 * 64) blocks = 256 * 64;
@@ -223,4 +577,38 @@ int pt_launch_tsr_preprocess(const uint8_t* pages, int ph, int pw, const pt_tsr_
                      out, split);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
+}
+
+template <int SPLIT, int NB>
+static int launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf16_t* w, const float* bias, bf16_t* out,
+                            int B, int H, int W, int C, int N, int relu, hipStream_t s) {
+  const long long npix = (long long)B * H * W;
+  char label[48];
+  snprintf(label, sizeof(label), "dcn fused %d->%d @%dx%d%s", C, N, H, W, SPLIT ? " x3" : "");
+  PtProfScope prof(e, s, PT_PROF_CONV3X3, 2.0 * npix * (double)N * C * 9, label);
+  hipLaunchKernelGGL((dcn_fused_kernel<SPLIT, NB>), dim3((unsigned)((npix + 127) / 128), N / NB), dim3(256), 0, s, x, om, w,
+                     bias, out, npix, H, W, C, N, relu);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// x NHWC bf16 [B,H,W,C], om fp32 [pixel][32], w tiled like a 1x1 conv over K = 9*C (".dcn" tensors), out [B,H,W,N]
+int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf16_t* w, const float* bias, bf16_t* out,
+                        int B, int H, int W, int C, int N, int split, int relu, hipStream_t s) {
+  PT_REQUIRE(x && om && w && bias && out && C % 32 == 0 && N % 64 == 0, "dcn fused: bad arguments (C=%d N=%d)", C, N);
+  PT_REQUIRE((long long)H * W * (split ? 2 * C : C) < (1ll << 31), "dcn fused: image too large for 32-bit offsets");
+  // (the hi/lo mode keeps 64-channel blocks: with 128 the corner registers of both halves spill)
+  if (split) return launch_dcn_fused<1, 64>(e, x, om, w, bias, out, B, H, W, C, N, relu, s);
+  if (C % 64 == 0) {
+    const long long npix = (long long)B * H * W;
+    char label[48];
+    snprintf(label, sizeof(label), "dcn fused %d->%d @%dx%d", C, N, H, W);
+    PtProfScope prof(e, s, PT_PROF_CONV3X3, 2.0 * npix * (double)N * C * 9, label);
+    hipLaunchKernelGGL((dcn_fused64_kernel<64>), dim3((unsigned)((npix + 127) / 128), N / 64), dim3(256), 0, s, x, om, w, bias,
+                       out, npix, H, W, C, N, relu);
+    PT_HIP_CHECK(hipGetLastError());
+    return PT_OK;
+  }
+  if (N % 128 == 0) return launch_dcn_fused<0, 128>(e, x, om, w, bias, out, B, H, W, C, N, relu, s);
+  return launch_dcn_fused<0, 64>(e, x, om, w, bias, out, B, H, W, C, N, relu, s);
 }

@@ -19,6 +19,8 @@
 
 int pt_launch_dcn_im2col(const bf16_t* x, const float* om, bf16_t* cols, int B, int H, int W, int C, int split,
                          hipStream_t s);
+int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf16_t* w, const float* bias, bf16_t* out,
+                        int B, int H, int W, int C, int N, int split, int relu, hipStream_t s);
 int pt_launch_dwconvt_up_add(const bf16_t* in, const float* w, const bf16_t* add, bf16_t* out, int B, int h, int wd,
                              int C, int f, int split, hipStream_t s);
 
@@ -117,6 +119,18 @@ struct Ctx {
   T dcn(const std::string& q, const T& x, int cout) {
     T o = alloc(x.H, x.W, cout);
     conv(x, q + ".om", 64, 3, 1, T(), 0, nullptr, 32, om, 32);
+    static const bool fused = !(getenv("PT_DCN_FUSED") && atoi(getenv("PT_DCN_FUSED")) == 0);
+    if (fused) {
+      const PtTensor* w = get(q + (x3 ? ".dcn.w3" : ".dcn.w"));
+      const PtTensor* b = get(q + ".dcn.b");
+      if (rc == PT_OK && !dry && ok) {
+        const int r = pt_launch_dcn_fused(e, x.p, om, reinterpret_cast<const bf16_t*>(w->d_ptr),
+                                          reinterpret_cast<const float*>(b->d_ptr), o.p, n, x.H, x.W, x.C, cout, x3, 1, s);
+        if (r != PT_OK) rc = r;
+      }
+      return o;
+    }
+    // two-kernel form (PT_DCN_FUSED=0): columns through HBM, then a 1x1 GEMM
     if (rc == PT_OK && !dry && ok) {
       PtProfScope ps(e, s, PT_PROF_OTHER, 0, "dcn im2col");
       const int r = pt_launch_dcn_im2col(x.p, om, cols, n, x.H, x.W, x.C, x3, s);
