@@ -39,7 +39,30 @@ MFMA_PEAK_TFLOPS = 2500.0        # dense bf16, /opt/skills/guides/MI355X_MICROAR
 DB_GFLOP_960 = 111.71            # DB-ResNet18 at the reference-preprocessed 960x960
 
 
-def cpu_baseline(sd, pages_np, cfg, csd=None, quads=None, max_lines=12):
+def cpu_baseline_tsr(lsd, psd, page, box):
+    """One table through the oracle chain (fp32 torch convs in the reference's op order, DCN restatement, the decode
+    with its Python vertex-snapping loop, processor) on the host cores -> seconds per table and a note."""
+    from oracle import lore_decode as od
+    from oracle import lore_net, lore_pre, lore_processor
+    x1, y1, x2, y2 = (int(v) for v in box)
+    crop = np.ascontiguousarray(page[y1:y2, x1:x2][:, :, ::-1])
+    t0 = time.time()
+    x, meta = lore_pre.lore_preprocess(crop, 1024, 1024)
+    t1 = time.time()
+    with torch.no_grad():
+        z = lore_net.dlaseg_forward(lsd, x)
+    t2 = time.time()
+    with torch.no_grad():
+        logi, ps, polys, results = od.process_detect_output(z, meta, wiz_rev=True, vis_thresh=0.2)
+    t3 = time.time()
+    with torch.no_grad():
+        lore_processor.processor_forward(psd, logi, None)
+    t4 = time.time()
+    return t4 - t0, (f"; table structure {t4 - t0:.2f} s/table measured on 1 table with {logi.shape[1]} cells (warp {t1 - t0:.2f}, "
+                     f"DLA-34+DCN fp32 {t2 - t1:.2f}, decode {t3 - t2:.2f}, processor {t4 - t3:.2f})")
+
+
+def cpu_baseline(sd, pages_np, cfg, csd=None, quads=None, max_lines=12, tsr=None):
     """The oracle (port of the reference CPU path: fp32 torch ops in the reference's op order + numpy/python
     pre/post) on the host cores, batch 1 per call as the reference runs it."""
     from oracle import db_net, db_post, db_pre
@@ -96,6 +119,11 @@ def cpu_baseline(sd, pages_np, cfg, csd=None, quads=None, max_lines=12):
         dt += per_line * lines_total
         rec_note = (f"; recognition {per_line:.3f} s/line measured on {nl} lines (crop + CRNN fp32 with a Python-loop LSTM "
                     f"+ CTC), scaled to {lines_total / n:.0f} lines/page")
+    if tsr is not None:
+        lsd, psd, boxes, tables_per_page = tsr
+        per_table, note = cpu_baseline_tsr(lsd, psd, pages_np[0], boxes[0][0])
+        dt += per_table * tables_per_page * n
+        rec_note += note + f", scaled to {tables_per_page:.2f} tables/page"
     return {"value": n / dt, "unit": "pages/s", "cores": cores, "kind": "port",
             "sample": f"{n} synthetic 1024x1024 pages, batch 1 per call as the reference runs it, "
                       f"torch.set_num_threads({cores}); per page: det pre (numpy) {t_pre / n:.2f} s, DB-ResNet18 fp32 "
@@ -306,7 +334,8 @@ def main():
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, pages_np[:2], cfg, csd if rec is not None else None,
-                                               gt_quads[:2] if rec is not None else None)
+                                               gt_quads[:2] if rec is not None else None,
+                                               tsr=(lsd, psd, table_boxes, tables_per_page) if tsr is not None else None)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
