@@ -585,7 +585,7 @@ static int launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, cons
   const long long npix = (long long)B * H * W;
   char label[48];
   snprintf(label, sizeof(label), "dcn fused %d->%d @%dx%d%s", C, N, H, W, SPLIT ? " x3" : "");
-  PtProfScope prof(e, s, PT_PROF_CONV3X3, 2.0 * npix * (double)N * C * 9, label);
+  PtProfScope prof(e, s, PT_PROF_OTHER, 0, label);   // gather-bound, kept out of the implicit-GEMM class
   hipLaunchKernelGGL((dcn_fused_kernel<SPLIT, NB>), dim3((unsigned)((npix + 127) / 128), N / NB), dim3(256), 0, s, x, om, w,
                      bias, out, npix, H, W, C, N, relu);
   PT_HIP_CHECK(hipGetLastError());
@@ -603,7 +603,7 @@ int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf
     const long long npix = (long long)B * H * W;
     char label[48];
     snprintf(label, sizeof(label), "dcn fused %d->%d @%dx%d", C, N, H, W);
-    PtProfScope prof(e, s, PT_PROF_CONV3X3, 2.0 * npix * (double)N * C * 9, label);
+    PtProfScope prof(e, s, PT_PROF_OTHER, 0, label);   // gather-bound, kept out of the implicit-GEMM class
     hipLaunchKernelGGL((dcn_fused64_kernel<64>), dim3((unsigned)((npix + 127) / 128), N / 64), dim3(256), 0, s, x, om, w, bias,
                        out, npix, H, W, C, N, relu);
     PT_HIP_CHECK(hipGetLastError());

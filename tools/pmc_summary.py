@@ -27,7 +27,7 @@ def main():
                     v = float(row.get("Counter_Value") or 0)
                 except ValueError:
                     continue
-                a = acc[name.split("(")[0]][cn]
+                a = acc[name.replace("(anonymous namespace)::", "").split("(")[0]][cn]
                 a[0] += v
                 a[1] += 1
     out = {}
