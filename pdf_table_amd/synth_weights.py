@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 __all__ = ["db_resnet18_state_dict", "crnn_state_dict", "CRNN_NUM_CLASSES", "lore_dla34_state_dict",
-           "lore_processor_state_dict", "LORE_HEADS"]
+           "lore_processor_state_dict", "LORE_HEADS", "picodet_state_dict", "LCNET_CONFIG", "PICODET_STANDIN"]
 
 CRNN_NUM_CLASSES = 7644  # crnn/modeling_crnn.py:90
 
@@ -295,4 +295,81 @@ def lore_processor_state_dict(seed: int = 0, layers: int = 4, stacking_layers: i
     transformer("tsfm_axis", 256, 256, 4, layers)
     g.put("x_position_embeddings.weight", g.rng.standard_normal((256, 256)))
     g.put("y_position_embeddings.weight", g.rng.standard_normal((256, 256)))
+    return g.sd
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# PicoDet layout detector: LCNet x1.0 backbone + 4-level CSP-PAN + PicoHead (shared cls/reg tower)
+# --------------------------------------------------------------------------------------------------------------------
+LCNET_CONFIG = {   # k, in_c, out_c, stride, use_se -- picodet/lcnet.py:25-46
+    "blocks2": [[3, 16, 32, 1, False]],
+    "blocks3": [[3, 32, 64, 2, False], [3, 64, 64, 1, False]],
+    "blocks4": [[3, 64, 128, 2, False], [3, 128, 128, 1, False]],
+    "blocks5": [[3, 128, 256, 2, False]] + [[5, 256, 256, 1, False]] * 5,
+    "blocks6": [[5, 256, 512, 2, True], [5, 512, 512, 1, True]],
+}
+PICODET_STANDIN = dict(neck_channels=128, num_convs=4, reg_max=7, strides=(8, 16, 32, 64))
+
+
+def picodet_state_dict(seed: int = 0, num_classes: int = 5, cls_bias: float = -4.0):
+    """state_dicts of the in-tree PicoDet parts, keys prefixed ``backbone.`` / ``neck.`` / ``head.`` like
+    ``PicoDet`` (picodet/modeling_picodet.py:31-36): ``LCNet(scale=1.0, feature_maps=[3,4,5])`` (lcnet.py:159-259),
+    ``CSPPAN(in_channels=[128,256,512], out_channels=128, kernel_size=5, num_features=4)`` (csp_pan.py:233-347) and
+    ``PicoHead(PicoFeat(128, 128, num_fpn_stride=4, num_convs=4, share_cls_reg=True), fpn_stride=[8,16,32,64],
+    reg_max=7)`` (pico_head.py:56-167,966-1072).  The reference runs an ONNX export whose exact hyper-parameters are
+    not in the tree: this configuration is the ASSUMED picodet_lcnet_x1_0 layout model."""
+    g = _Gen(seed)
+    nc = PICODET_STANDIN["neck_channels"]
+
+    def conv_bn(p, cout, cin, k, groups=1, norm="bn", gain=2.0):
+        g.conv(p + ".conv", cout, cin // groups, k, k, gain=gain)
+        g.bn(p + "." + norm, cout)
+
+    conv_bn("backbone.conv1", 16, 3, 3)
+    for blk in ("blocks2", "blocks3", "blocks4", "blocks5", "blocks6"):
+        for i, (k, cin, cout, s, se) in enumerate(LCNET_CONFIG[blk]):
+            p = f"backbone.{blk}.{i}"
+            conv_bn(p + ".dw_conv", cin, cin, k, groups=cin, gain=3.0)
+            if se:
+                g.conv(p + ".se.conv1", cin // 4, cin, 1, 1, bias=True)
+                g.conv(p + ".se.conv2", cin, cin // 4, 1, 1, bias=True)
+            conv_bn(p + ".pw_conv", cout, cin, 1)
+
+    def dp(p, c, k=5):       # DPModule (csp_pan.py:56-105)
+        g.conv(p + ".dwconv", c, 1, k, k, gain=3.0)
+        g.bn(p + ".bn1", c)
+        g.conv(p + ".pwconv", c, c, 1, 1)
+        g.bn(p + ".bn2", c)
+
+    def csp(p, cin, cout):   # CSPLayer with one depthwise DarknetBottleneck (csp_pan.py:160-209)
+        mid = cout // 2
+        conv_bn(p + ".main_conv", mid, cin, 1)
+        conv_bn(p + ".short_conv", mid, cin, 1)
+        conv_bn(p + ".final_conv", cout, 2 * mid, 1)
+        conv_bn(p + ".blocks.0.conv1", mid, mid, 1)
+        dp(p + ".blocks.0.conv2", mid)
+
+    for i, c in enumerate((128, 256, 512)):
+        conv_bn(f"neck.conv_t.convs.{i}", nc, c, 1)
+    dp("neck.first_top_conv", nc)
+    dp("neck.second_top_conv", nc)
+    for i in range(2):
+        csp(f"neck.top_down_blocks.{i}", 2 * nc, nc)
+    for i in range(2):
+        dp(f"neck.downsamples.{i}", nc)
+        csp(f"neck.bottom_up_blocks.{i}", 2 * nc, nc)
+
+    nout = num_classes + 4 * (PICODET_STANDIN["reg_max"] + 1)
+    for s in range(4):
+        for i in range(PICODET_STANDIN["num_convs"]):
+            conv_bn(f"head.conv_feat.cls_conv_dw{s}_{i}", nc, nc, 5, groups=nc, norm="norm", gain=3.0)
+            conv_bn(f"head.conv_feat.cls_conv_pw{s}_{i}", nc, nc, 1, norm="norm")
+    for lvl in (3, 4, 5, 6):
+        g.put(f"head.p{lvl}_feat.scale_reg", np.ones((1,)))
+    g.put("head.distribution_project.project", np.linspace(0, PICODET_STANDIN["reg_max"], PICODET_STANDIN["reg_max"] + 1))
+    for s in range(4):
+        g.conv(f"head.head_cls{s}", nout, nc, 1, 1, bias=False, gain=1.0)
+        b = g.rng.uniform(-0.5, 0.5, (nout,))
+        b[:num_classes] += cls_bias            # few positives, like a trained detector's prior (pico_head.py:1041)
+        g.put(f"head.head_cls{s}.bias", b)
     return g.sd

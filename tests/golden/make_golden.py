@@ -359,8 +359,84 @@ def gen_lore_processor():
     np.savez_compressed(os.path.join(HERE, "lore_processor.npz"), **out)
 
 
+def gen_picodet():
+    """(1) LCNet -> CSPPAN -> PicoHead.forward_eval(export_post_process=False) of the reference on seeded weights;
+    (2) the reference OCRPicodetPostProcessor on seeded head outputs."""
+    from pdf_table_amd.synth_weights import picodet_state_dict
+    import transformers  # noqa: F401
+    sys.path.insert(0, os.path.dirname(HERE))
+    from lore_synth import synth_pico_heads      # tests/lore_synth.py: inputs are regenerated from the seed
+    stub_env()
+    if "torchvision" not in sys.modules:      # pico_utils.py imports two names from torchvision.ops at module level
+        tv = types.ModuleType("torchvision")
+        tvo = types.ModuleType("torchvision.ops")
+        tvo.DeformConv2d = type("DeformConv2d", (torch.nn.Module,), {})
+        tvo.nms = None
+        tv.ops = tvo
+        sys.modules["torchvision"] = tv
+        sys.modules["torchvision.ops"] = tvo
+    else:
+        sys.modules["torchvision.ops"].DeformConv2d = type("DeformConv2d", (torch.nn.Module,), {})
+        sys.modules["torchvision.ops"].nms = None
+    for sub in ("model", "model/picodet"):
+        name = "pdftable." + sub.replace("/", ".")
+        if name not in sys.modules:
+            _pkg(name, os.path.join(REF_SRC, "pdftable", sub))
+    lc = ref_import("pdftable.model.picodet.lcnet")
+    cp = ref_import("pdftable.model.picodet.csp_pan")
+    ph = ref_import("pdftable.model.picodet.pico_head")
+    bb = lc.LCNet(scale=1.0, feature_maps=[3, 4, 5]).eval()
+    neck = cp.CSPPAN(in_channels=[128, 256, 512], out_channels=128, kernel_size=5, num_features=4, num_csp_blocks=1,
+                     use_depthwise=True, act="hard_swish", spatial_scales=[0.125, 0.0625, 0.03125]).eval()
+    head = ph.PicoHead(conv_feat=dict(feat_in=128, feat_out=128, num_fpn_stride=4, num_convs=4, norm_type="bn",
+                                      share_cls_reg=True, act="hard_swish", use_se=False),
+                       num_classes=5, fpn_stride=[8, 16, 32, 64], loss_class=dict(use_sigmoid=True, iou_weighted=True, loss_weight=1.0),
+                       nms=dict(nms_top_k=1000, keep_top_k=100, score_threshold=0.025, nms_threshold=0.6), reg_max=7,
+                       feat_in_chan=128, cell_offset=0.5).eval()
+    sd = picodet_state_dict(seed=41, num_classes=5)
+    for name, mod in (("backbone", bb), ("neck", neck), ("head", head)):
+        mod.load_state_dict({k[len(name) + 1:]: v for k, v in sd.items() if k.startswith(name + ".")}, strict=True)
+    rng = np.random.default_rng(107)
+    out = {"seed": np.array(41)}
+    for tag, (h, w) in {"a": (160, 128), "b": (224, 192)}.items():
+        x = rng.standard_normal((1, 3, h, w)).astype(np.float32)
+        with torch.no_grad():
+            f = bb(image=torch.from_numpy(x))
+            n = neck(f)
+            sc, bx = head(n, export_post_process=False)
+        out[f"x_{tag}"] = x
+        out[f"c5_{tag}"] = f[-1].numpy()
+        out[f"p3_{tag}"] = n[0].numpy()[:, ::4]
+        for i in range(4):
+            out[f"score{i}_{tag}"] = sc[i].numpy()
+            out[f"box{i}_{tag}"] = bx[i].numpy()
+    # post-processor: its config class subclasses transformers.PretrainedConfig with list defaults (rejected by
+    # transformers 5), so the instance is built without it and given the same attributes (processor_picodet.py:126-131)
+    cm = types.ModuleType("pdftable.model.picodet.configuration_picodet")
+    cm.PicodetConfig = type("PicodetConfig", (), {})
+    sys.modules["pdftable.model.picodet.configuration_picodet"] = cm
+    pp = ref_import("pdftable.model.picodet.processor_picodet")
+    labels = ["text", "title", "list", "table", "figure"]
+    post = object.__new__(pp.OCRPicodetPostProcessor)
+    post.config = types.SimpleNamespace(id2label=dict(enumerate(labels)))
+    post.strides, post.score_threshold, post.nms_threshold, post.nms_top_k, post.keep_top_k = [8, 16, 32, 64], 0.5, 0.5, 1000, 100
+    for tag, (seed, tgt, org) in {"p": (1, (160, 128), (1024, 1024)), "q": (2, (800, 608), (1100, 850))}.items():
+        sc, bx = synth_pico_heads(seed, tgt)
+        sf = [float(tgt[0]) / org[0], float(tgt[1]) / org[1]]
+        res = post({"boxes": sc, "boxes_num": bx, "org_shape": list(org), "scale_factor": sf, "target_shape": list(tgt)})
+        out[f"post_case_{tag}"] = np.array([seed, tgt[0], tgt[1], org[0], org[1]])
+        out[f"post_bbox_{tag}"] = np.array([r["bbox"] for r in res["bboxs"]], dtype=np.float64).reshape(-1, 4)
+        out[f"post_score_{tag}"] = np.array([r["score"] for r in res["bboxs"]], dtype=np.float64)
+        out[f"post_cls_{tag}"] = np.array([r["category_id"] for r in res["bboxs"]], dtype=np.int64)
+        print("picodet post", tag, len(res["bboxs"]), "boxes")
+    np.savez_compressed(os.path.join(HERE, "picodet.npz"), **out)
+    print("picodet.npz", os.path.getsize(os.path.join(HERE, "picodet.npz")))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["db", "crnn", "registry", "ctc", "host", "lore_dla", "lore_decode", "lore_processor"]
+    which = sys.argv[1:] or ["db", "crnn", "registry", "ctc", "host", "lore_dla", "lore_decode", "lore_processor", "picodet"]
+    if "picodet" in which:
+        gen_picodet()
     if "lore_processor" in which:
         gen_lore_processor()
     if "lore_decode" in which:

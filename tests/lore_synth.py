@@ -1,4 +1,4 @@
-"""Seeded synthetic Lore head maps shared by tests/golden/make_golden.py (inputs of the reference run) and the
+"""Seeded synthetic Lore head maps and PicoDet head outputs shared by tests/golden/make_golden.py (inputs of the reference run) and the
 parity tests (inputs of the oracle / HIP run): data generators only."""
 import numpy as np
 
@@ -26,3 +26,18 @@ def synth_lore_heads(seed, H=80, W=80):
     ax = rng.standard_normal((1, 256, H, W)).astype(np.float32)
     cr = rng.standard_normal((1, 256, H, W)).astype(np.float32)
     return {"hm": hm, "st": st, "wh": wh, "ax": ax, "cr": cr, "reg": reg}
+
+
+def synth_pico_heads(seed, target=(160, 128), ncls=5, reg_max=7, strides=(8, 16, 32, 64)):
+    """seeded head outputs of a layout-like page: a few strong, overlapping detections per class on every level"""
+    rng = np.random.default_rng(seed)
+    scores, boxes = [], []
+    for s in strides:
+        fh, fw = int(np.ceil(target[0] / s)), int(np.ceil(target[1] / s))
+        a = fh * fw
+        sc = rng.uniform(0.0, 0.3, (1, a, ncls)).astype(np.float32)
+        hot = rng.choice(a, max(2, a // 6), replace=False)
+        sc[0, hot, rng.integers(0, ncls, len(hot))] = rng.uniform(0.45, 0.99, len(hot)).astype(np.float32)
+        scores.append(sc)
+        boxes.append((rng.standard_normal((1, a, 4 * (reg_max + 1))) * 2.0).astype(np.float32))
+    return scores, boxes
