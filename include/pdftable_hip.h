@@ -61,10 +61,42 @@ enum {
   PT_MODEL_CRNN = 2,        /* crnn/modeling_crnn.py:36-113 */
   PT_MODEL_LORE_DLA34 = 3,  /* lore/lore_dla_34.py:137-206 (DLASeg on dla34 + DCN), modeling_lore.py:88-95 */
   PT_MODEL_LORE_PROCESSOR = 4, /* lore/lore_processor.py:399-514 (LoreProcessModel) */
+  PT_MODEL_PICODET = 5,     /* picodet/lcnet.py:159-259 + csp_pan.py:233-347 + pico_head.py:966-1160 (assumed config) */
 };
 int pt_weights_load(pt_engine* e, int model_kind, const void* h_blob, size_t nbytes);
 /* Same, but the blob already sits in device memory (e.g. after an RCCL broadcast from rank 0). */
 int pt_weights_load_device(pt_engine* e, int model_kind, const void* d_blob, size_t nbytes, pt_stream stream);
+
+/* ---- stage 1: layout detection (PicoDet) -------------------------------------------------------- */
+#define PT_LAYOUT_LEVELS 4
+#define PT_LAYOUT_HEAD_CS 40   /* fp32 values per anchor: ncls class logits, then 4 * (reg_max + 1) box logits, zero padded */
+#define PT_LAYOUT_CAND_FLOATS 48 /* candidate record: int32 level, int32 anchor, 40 head values, padding */
+
+/* Anchors of level l for an inp_h x inp_w input: strides 8, 16, 32 and the extra 5x5/s2 level (csp_pan.py:265-270). */
+int pt_layout_plan(int inp_h, int inp_w, int32_t fm_h[PT_LAYOUT_LEVELS], int32_t fm_w[PT_LAYOUT_LEVELS]);
+
+/* OCRPicodetPreProcessor.__call__ (picodet/processor_picodet.py:72-113): BGR flip, cv2.resize to inp_w x inp_h (8-bit
+ * bilinear, aspect not kept), (x * 1/255 - mean) / std  ->  bf16 NHWC4 [n, inp_h, inp_w, 4] (8 in BF16X3 mode). */
+int pt_layout_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h, int w, int inp_h, int inp_w,
+                         uint16_t* d_out_bf16, pt_stream stream);
+
+/* Network only: LCNet -> CSP-PAN -> PicoHead.forward_eval(export_post_process=False) before the sigmoid.
+ *   d_head[l] : float32 [n, fm_h[l] * fm_w[l], PT_LAYOUT_HEAD_CS] */
+int pt_layout_forward_net(pt_engine* e, const uint16_t* d_input_bf16, int n, int inp_h, int inp_w, float* d_head0,
+                          float* d_head1, float* d_head2, float* d_head3, pt_stream stream);
+
+/* Anchors whose best class score exceeds thr_lo, with their raw head values -- everything
+ * OCRPicodetPostProcessor.__call__ (processor_picodet.py:184-298) can keep when thr_lo <= its score_threshold.
+ *   d_counts : int32 [n] candidates found (may exceed max_cands: only the first max_cands records are stored)
+ *   d_cands  : float32 [n, max_cands, PT_LAYOUT_CAND_FLOATS] */
+int pt_layout_candidates(pt_engine* e, const float* d_head0, const float* d_head1, const float* d_head2,
+                         const float* d_head3, int n, int inp_h, int inp_w, int num_classes, float thr_lo, int max_cands,
+                         int32_t* d_counts, float* d_cands, pt_stream stream);
+
+/* pt_layout_preprocess + pt_layout_forward_net + pt_layout_candidates with engine-owned intermediates.
+ * Replaces OcrLayoutTask._preprocess + _run_model (ocr_layout_task.py:70-123). */
+int pt_layout_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h, int w, int inp_h, int inp_w, int num_classes,
+                      float thr_lo, int max_cands, int32_t* d_counts, float* d_cands, pt_stream stream);
 
 /* ---- stage 2: DB text detection ------------------------------------------------------------- */
 

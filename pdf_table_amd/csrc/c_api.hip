@@ -56,6 +56,7 @@ void pt_engine_destroy(pt_engine* e) {
   if (e->zero_page) (void)hipFree(e->zero_page);
   if (e->tsr_scratch) (void)hipFree(e->tsr_scratch);
   if (e->tsr_lut) (void)hipFree(e->tsr_lut);
+  if (e->layout_scratch) (void)hipFree(e->layout_scratch);
   for (auto& p : e->prof.pending) {
     (void)hipEventDestroy(p.a);
     (void)hipEventDestroy(p.b);
@@ -206,6 +207,80 @@ int pt_det_forward_net(pt_engine* e, const uint16_t* d_input_bf16, int n, int ne
   PT_REQUIRE(e && d_input_bf16 && n > 0 && (d_prob || d_logits), "pt_det_forward_net: bad arguments");
   PT_HIP_CHECK(hipSetDevice(e->device));
   return pt_db_forward_net(e, d_input_bf16, n, net_h, net_w, d_prob, d_logits, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ---- layout (PicoDet) ---------------------------------------------------------------------------------
+int pt_layout_plan(int inp_h, int inp_w, int32_t fm_h[PT_LAYOUT_LEVELS], int32_t fm_w[PT_LAYOUT_LEVELS]) {
+  PT_REQUIRE(inp_h > 0 && inp_w > 0 && inp_h % 32 == 0 && inp_w % 32 == 0 && fm_h && fm_w,
+             "pt_layout_plan: input %dx%d must be positive multiples of 32", inp_h, inp_w);
+  for (int l = 0; l < 3; ++l) { fm_h[l] = inp_h >> (3 + l); fm_w[l] = inp_w >> (3 + l); }
+  fm_h[3] = (fm_h[2] + 4 - 5) / 2 + 1;      // 5x5, stride 2, padding 2
+  fm_w[3] = (fm_w[2] + 4 - 5) / 2 + 1;
+  return PT_OK;
+}
+
+int pt_layout_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h, int w, int inp_h, int inp_w,
+                         uint16_t* d_out_bf16, pt_stream stream) {
+  PT_REQUIRE(e && d_pages_rgb && d_out_bf16 && n > 0, "pt_layout_preprocess: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  // same arithmetic as the PP-OCR detection pre-process (BGR flip, (x * 1/255 - mean) / std), fixed target size
+  return pt_launch_det_preprocess(d_pages_rgb, n, h, w, inp_h, inp_w, PT_DET_PRE_DB_PP, e->precision == PT_PRECISION_BF16X3,
+                                  d_out_bf16, reinterpret_cast<hipStream_t>(stream));
+}
+
+int pt_layout_forward_net(pt_engine* e, const uint16_t* d_input_bf16, int n, int inp_h, int inp_w, float* d_head0,
+                          float* d_head1, float* d_head2, float* d_head3, pt_stream stream) {
+  PT_REQUIRE(e && d_input_bf16 && n > 0, "pt_layout_forward_net: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  return pt_picodet_forward_net(e, d_input_bf16, n, inp_h, inp_w, d_head0, d_head1, d_head2, d_head3,
+                                reinterpret_cast<hipStream_t>(stream));
+}
+
+int pt_layout_candidates(pt_engine* e, const float* d_head0, const float* d_head1, const float* d_head2,
+                         const float* d_head3, int n, int inp_h, int inp_w, int num_classes, float thr_lo, int max_cands,
+                         int32_t* d_counts, float* d_cands, pt_stream stream) {
+  PT_REQUIRE(e && d_head0 && d_head1 && d_head2 && d_head3 && d_counts && d_cands && n > 0 && max_cands > 0 &&
+                 num_classes > 0 && num_classes <= 8, "pt_layout_candidates: bad arguments");
+  int32_t fh[4], fw[4];
+  int rc = pt_layout_plan(inp_h, inp_w, fh, fw);
+  if (rc != PT_OK) return rc;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  PT_HIP_CHECK(hipMemsetAsync(d_counts, 0, (size_t)n * 4, s));
+  const float* heads[4] = {d_head0, d_head1, d_head2, d_head3};
+  for (int l = 0; l < 4; ++l)
+    if ((rc = pt_launch_pico_candidates(heads[l], n, fh[l] * fw[l], num_classes, l, thr_lo, max_cands, d_cands, d_counts, s)) != PT_OK)
+      return rc;
+  return PT_OK;
+}
+
+int pt_layout_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h, int w, int inp_h, int inp_w, int num_classes,
+                      float thr_lo, int max_cands, int32_t* d_counts, float* d_cands, pt_stream stream) {
+  PT_REQUIRE(e && d_pages_rgb && n > 0, "pt_layout_forward: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  int32_t fh[4], fw[4];
+  int rc = pt_layout_plan(inp_h, inp_w, fh, fw);
+  if (rc != PT_OK) return rc;
+  const int m = e->precision == PT_PRECISION_BF16X3 ? 2 : 1;
+  size_t off = 0, o_head[4];
+  auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~size_t(255); return o; };
+  const size_t o_x = carve((size_t)n * inp_h * inp_w * 4 * m * sizeof(uint16_t));
+  for (int l = 0; l < 4; ++l) o_head[l] = carve((size_t)n * fh[l] * fw[l] * PT_LAYOUT_HEAD_CS * sizeof(float));
+  if (off > e->layout_scratch_cap) {
+    PT_HIP_CHECK(hipDeviceSynchronize());
+    if (e->layout_scratch) PT_HIP_CHECK(hipFree(e->layout_scratch));
+    e->layout_scratch = nullptr; e->layout_scratch_cap = 0;
+    PT_HIP_CHECK(hipMalloc(&e->layout_scratch, off));
+    e->layout_scratch_cap = off;
+  }
+  char* base = reinterpret_cast<char*>(e->layout_scratch);
+  uint16_t* x = reinterpret_cast<uint16_t*>(base + o_x);
+  float* hd[4];
+  for (int l = 0; l < 4; ++l) hd[l] = reinterpret_cast<float*>(base + o_head[l]);
+  if ((rc = pt_layout_preprocess(e, d_pages_rgb, n, h, w, inp_h, inp_w, x, stream)) != PT_OK) return rc;
+  if ((rc = pt_layout_forward_net(e, x, n, inp_h, inp_w, hd[0], hd[1], hd[2], hd[3], stream)) != PT_OK)
+    return rc;
+  return pt_layout_candidates(e, hd[0], hd[1], hd[2], hd[3], n, inp_h, inp_w, num_classes, thr_lo, max_cands, d_counts, d_cands,
+                              stream);
 }
 
 int pt_tsr_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int ph, int pw, const pt_tsr_table* d_tables,

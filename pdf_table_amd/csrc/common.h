@@ -102,6 +102,7 @@ struct pt_engine {
   std::vector<long long> rec_off_host;
   void* zero_page = nullptr;  // 8 KiB of zeros: DMA source for halo pixels outside the image
   void* tsr_scratch = nullptr; size_t tsr_scratch_cap = 0;   // candidate lists of the Lore decode
+  void* layout_scratch = nullptr; size_t layout_scratch_cap = 0;   // layout input + head maps (pt_layout_forward)
   float* tsr_lut = nullptr;                                  // [3][256] normalisation table of the Lore pre-process
 };
 
@@ -125,7 +126,7 @@ struct ConvDesc {
   // residual
   const bf16_t* res = nullptr;
   int res_mode = 0;  // 0 none, 1 same resolution, 2 half resolution (fused nearest x2 upsample + add)
-  int relu = 0;
+  int relu = 0;      // activation: 0 none, 1 ReLU, 2 hardswish
   // bf16x3 precision mode: in/res/out hold (hi | lo) channel groups; w is [N/64][3*Cin/32][taps][64][32]
   int split = 0;
   int out_lo_off = 0;  // channel distance between the hi and lo halves in the output buffer
@@ -176,6 +177,10 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
 int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* prob, float* logits, hipStream_t s);
 int pt_launch_tsr_preprocess(const uint8_t* pages, int ph, int pw, const pt_tsr_table* tabs, int n, int H, int W, int bgr,
                              const float* lut, bf16_t* out, int split, hipStream_t s);
+int pt_picodet_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* h0, float* h1, float* h2, float* h3,
+                          hipStream_t s);
+int pt_launch_pico_candidates(const float* head, int B, int A, int ncls, int level, float thr_lo, int max_cands, float* cands,
+                              int* counts, hipStream_t s);
 int pt_lore_decode(pt_engine* e, const float* hm, const float* st, const float* wh, const float* ax, const float* cr,
                    const float* reg, int B, int H, int W, int wiz_rev, float vis_thresh, int* d_counts, float* d_dets,
                    float* d_logi, hipStream_t s);

@@ -134,9 +134,12 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
       const f32x4 r0 = rp[0], r1 = rp[1];
       v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
     }
-    if (p.relu) {
+    if (p.relu == 1) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+    } else if (EXTRAS && p.relu == 2) {   // hardswish: x * relu6(x + 3) / 6 (PicoDet's LCNet / CSP-PAN / head)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = v[k] * fminf(fmaxf(v[k] + 3.f, 0.f), 6.f) / 6.f;
     }
     uint32_t hb[8];
 #pragma unroll
@@ -945,7 +948,7 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   if (d.head_w) PT_REQUIRE(d.shuffle_cout == 64 && d.head_b && (d.head_prob || d.head_logits), "conv: bad fused-head configuration");
   if (k.res_mode == 2) PT_REQUIRE(k.Ho % 2 == 0 && k.Wo % 2 == 0, "conv: half-res residual needs even output size");
   const double flop = 2.0 * k.B * k.Ho * k.Wo * (double)k.N * d.Cin * d.ks * d.ks;  // algorithmic (not x3 in split mode)
-  if (d.ks == 3 && d.stride == 1 && !d.head_w && !d.argmax_part && !d.n_valid && !d.out_f32 && !d.res_f32 && use_dma_kernel()) {
+  if (d.ks == 3 && d.stride == 1 && !d.head_w && !d.argmax_part && !d.n_valid && !d.out_f32 && !d.res_f32 && d.relu != 2 && use_dma_kernel()) {
     // steady-state A/B on MI355X (tools/ab3.sh, round 1): the 16-channel-slice DMA kernel (v3) wins on >= 120-row maps
     // with K >= 128 channels, the 32-channel-slice DMA kernel (v2) on 60..119-row maps, the register-staged kernel
     // (v1) on short-K layers and on small maps, where the big DMA tiles leave CUs idle

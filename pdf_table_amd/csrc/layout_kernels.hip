@@ -1,0 +1,265 @@
+// layout_kernels.hip -- the non-GEMM kernels of the PicoDet layout detector (all bandwidth-type work).
+//
+//   stem3x3s2_kernel   LCNet.conv1: conv 3x3 s2 (3 -> 16) + BN + hardswish (picodet/lcnet.py:165-170), direct VALU
+//   dwconv_kernel      depthwise k x k (3 / 5), stride 1 / 2, + BN + optional hardswish: DepthwiseSeparable.dw_conv
+//                      (lcnet.py:104-110), DPModule.dwconv (csp_pan.py:76-84), PicoFeat.cls_conv_dw (pico_head.py:98-107)
+//   se_gate_kernel     SEModule (lcnet.py:126-153): global average pool -> 1x1 (C/4) + ReLU -> 1x1 + hardsigmoid -> [B, C]
+//   se_scale_kernel    x * gate
+//   add_kernel         CSPPAN's `top_features = first_top_conv(..) + second_top_conv(..)` (csp_pan.py:338-340)
+//   pico_candidates_kernel  anchors whose best class score can pass the post-processor's threshold, with their raw head
+//                      outputs (processor_picodet.py:250-262 only ever looks at those)
+// NHWC bf16; BF16X3 mode: [hi(C) | lo(C)] per pixel, arithmetic on hi + lo in fp32.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+namespace {
+
+__device__ __forceinline__ float bf2f(uint32_t b) { return __uint_as_float(b << 16); }
+__device__ __forceinline__ uint32_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ float hswish(float v) { return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) / 6.f; }
+
+__device__ __forceinline__ void load8(const bf16_t* p, int lo_off, int split, float* v) {
+  const u32x4 h = *reinterpret_cast<const u32x4*>(p);
+  const uint32_t hw[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = bf2f((k & 1) ? (hw[k >> 1] >> 16) : (hw[k >> 1] & 0xFFFFu));
+  if (split) {
+    const u32x4 l = *reinterpret_cast<const u32x4*>(p + lo_off);
+    const uint32_t lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] += bf2f((k & 1) ? (lw[k >> 1] >> 16) : (lw[k >> 1] & 0xFFFFu));
+  }
+}
+__device__ __forceinline__ void store8(bf16_t* p, int lo_off, int split, const float* v) {
+  uint32_t hb[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) hb[k] = f2bf(v[k]);
+  u32x4 o = {hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16)};
+  *reinterpret_cast<u32x4*>(p) = o;
+  if (split) {
+    uint32_t lb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lb[k] = f2bf(v[k] - bf2f(hb[k]));
+    u32x4 l = {lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16), lb[4] | (lb[5] << 16), lb[6] | (lb[7] << 16)};
+    *reinterpret_cast<u32x4*>(p + lo_off) = l;
+  }
+}
+
+// in: NHWC4 [B,H,W,4] ([hi rgb0 | lo rgb0] when split); w fp32 [16][3][3][4]; out [B,Ho,Wo,32], channels 16..31 zero
+__global__ __launch_bounds__(256) void stem3x3s2_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w,
+                                                         const float* __restrict__ b, bf16_t* __restrict__ out, int B,
+                                                         int H, int W, int Ho, int Wo, int split) {
+  __shared__ float sw[16 * 36];
+  __shared__ float sb[16];
+  for (int i = threadIdx.x; i < 16 * 36; i += 256) sw[i] = w[i];
+  if (threadIdx.x < 16) sb[threadIdx.x] = b[threadIdx.x];
+  __syncthreads();
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * Ho * Wo) return;
+  const int ox = (int)(i % Wo), oy = (int)((i / Wo) % Ho), bi = (int)(i / ((long long)Wo * Ho));
+  const int ps = split ? 8 : 4;
+  float px[9][3];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
+      float* d = px[ky * 3 + kx];
+      d[0] = d[1] = d[2] = 0.f;
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+        const bf16_t* p = in + (((size_t)bi * H + iy) * W + ix) * ps;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) d[c] = bf2f(p[c]) + (split ? bf2f(p[4 + c]) : 0.f);
+      }
+    }
+  float o[16];
+#pragma unroll
+  for (int n = 0; n < 16; ++n) {
+    float a = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a += px[t][c] * sw[n * 36 + t * 4 + c];
+    o[n] = hswish(a + sb[n]);
+  }
+  bf16_t* op = out + (size_t)i * (split ? 64 : 32);
+  const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  store8(op, 32, split, o);
+  store8(op + 8, 32, split, o + 8);
+  store8(op + 16, 32, split, z);
+  store8(op + 24, 32, split, z);
+}
+
+// w fp32 [k*k][C] (BN scale folded), b fp32 [C]
+__global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w,
+                                                      const float* __restrict__ b, bf16_t* __restrict__ out, int B, int H,
+                                                      int W, int C, int k, int stride, int Ho, int Wo, int act, int split) {
+  const int cgn = C >> 3, cs = split ? 2 * C : C, pad = k / 2;
+  const long long total = (long long)B * Ho * Wo * cgn;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % cgn);
+    long long t = i / cgn;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int bi = (int)(t / Ho);
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    for (int ky = 0; ky < k; ++ky) {
+      const int iy = oy * stride - pad + ky;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        const int ix = ox * stride - pad + kx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        float v[8];
+        load8(in + (((size_t)bi * H + iy) * W + ix) * cs + cg * 8, C, split, v);
+        const float* wp = w + (size_t)(ky * k + kx) * C + cg * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += v[q] * wp[q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      acc[q] += b[cg * 8 + q];
+      if (act == 2) acc[q] = hswish(acc[q]);
+    }
+    store8(out + (((size_t)bi * Ho + oy) * Wo + ox) * cs + cg * 8, C, split, acc);
+  }
+}
+
+// one workgroup per image: gate[b][c] = hardsigmoid(W2 relu(W1 mean_hw(x) + b1) + b2); C <= 512, C/4 <= 128
+__global__ __launch_bounds__(256) void se_gate_kernel(const bf16_t* __restrict__ x, int HW, int C, const float* __restrict__ w1,
+                                                       const float* __restrict__ b1, const float* __restrict__ w2,
+                                                       const float* __restrict__ b2, float* __restrict__ gate, int split) {
+  __shared__ float s_mean[512];
+  __shared__ float s_hid[128];
+  const int bi = blockIdx.x, tid = threadIdx.x, cs = split ? 2 * C : C;
+  for (int c = tid; c < C; c += 256) {
+    float s = 0.f;
+    const bf16_t* p = x + (size_t)bi * HW * cs + c;
+    for (int i = 0; i < HW; ++i) s += bf2f(p[(size_t)i * cs]) + (split ? bf2f(p[(size_t)i * cs + C]) : 0.f);
+    s_mean[c] = s / (float)HW;
+  }
+  __syncthreads();
+  const int Ch = C >> 2;
+  for (int h = tid; h < Ch; h += 256) {
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a += w1[(size_t)h * C + c] * s_mean[c];
+    s_hid[h] = fmaxf(a + b1[h], 0.f);
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float a = 0.f;
+    for (int h = 0; h < Ch; ++h) a += w2[(size_t)c * Ch + h] * s_hid[h];
+    gate[(size_t)bi * C + c] = fminf(fmaxf(a + b2[c] + 3.f, 0.f), 6.f) / 6.f;      // nn.Hardsigmoid
+  }
+}
+
+__global__ __launch_bounds__(256) void se_scale_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gate,
+                                                        bf16_t* __restrict__ out, int B, int HW, int C, int split) {
+  const int cgn = C >> 3, cs = split ? 2 * C : C;
+  const long long total = (long long)B * HW * cgn;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cg = (int)(i % cgn);
+  const long long pix = i / cgn;
+  const int bi = (int)(pix / HW);
+  float v[8];
+  load8(x + (size_t)pix * cs + cg * 8, C, split, v);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] *= gate[(size_t)bi * C + cg * 8 + q];
+  store8(out + (size_t)pix * cs + cg * 8, C, split, v);
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                   bf16_t* __restrict__ out, long long npix, int C, int split) {
+  const int cgn = C >> 3, cs = split ? 2 * C : C;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npix * cgn) return;
+  const int cg = (int)(i % cgn);
+  const long long pix = i / cgn;
+  float va[8], vb[8];
+  load8(a + (size_t)pix * cs + cg * 8, C, split, va);
+  load8(b + (size_t)pix * cs + cg * 8, C, split, vb);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) va[q] += vb[q];
+  store8(out + (size_t)pix * cs + cg * 8, C, split, va);
+}
+
+// head: fp32 [B][A][40] of one level (ncls class logits, then 4 x (reg_max + 1) box logits).  An anchor whose best
+// sigmoid score exceeds thr_lo is appended to cands[b] as (level, anchor, 40 raw values) -- 48 floats per record.
+__global__ __launch_bounds__(256) void pico_candidates_kernel(const float* __restrict__ head, int B, int A, int ncls,
+                                                               int level, float thr_lo, int max_cands,
+                                                               float* __restrict__ cands, int* __restrict__ counts) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * A) return;
+  const int bi = (int)(i / A), a = (int)(i % A);
+  const float* h = head + (size_t)i * 40;
+  float mx = -INFINITY;
+  for (int c = 0; c < ncls; ++c) mx = fmaxf(mx, h[c]);
+  if (!(1.f / (1.f + expf(-mx)) > thr_lo)) return;
+  const int slot = atomicAdd(&counts[bi], 1);
+  if (slot >= max_cands) return;
+  float* o = cands + ((size_t)bi * max_cands + slot) * 48;
+  o[0] = __int_as_float(level);
+  o[1] = __int_as_float(a);
+  for (int c = 0; c < 40; ++c) o[2 + c] = h[c];
+}
+
+inline int blocks_for(long long total, int cap = 256 * 64) {
+  long long b = (total + 255) / 256;
+  if (b > cap) b = cap;
+  return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+int pt_launch_stem3x3s2(const bf16_t* in, const float* w, const float* b, bf16_t* out, int B, int H, int W, int split,
+                        hipStream_t s) {
+  PT_REQUIRE(in && w && b && out, "layout stem: null pointer");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(stem3x3s2_kernel, dim3((unsigned)(((long long)B * Ho * Wo + 255) / 256)), dim3(256), 0, s, in, w, b, out,
+                     B, H, W, Ho, Wo, split);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_launch_dwconv(const bf16_t* in, const float* w, const float* b, bf16_t* out, int B, int H, int W, int C, int k,
+                     int stride, int act, int split, hipStream_t s) {
+  PT_REQUIRE(in && w && b && out && C % 8 == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2), "dwconv: bad arguments");
+  const int pad = k / 2, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  hipLaunchKernelGGL(dwconv_kernel, dim3(blocks_for((long long)B * Ho * Wo * (C / 8))), dim3(256), 0, s, in, w, b, out, B, H,
+                     W, C, k, stride, Ho, Wo, act, split);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_launch_se(const bf16_t* x, const float* w1, const float* b1, const float* w2, const float* b2, float* gate,
+                 bf16_t* out, int B, int HW, int C, int split, hipStream_t s) {
+  PT_REQUIRE(x && w1 && b1 && w2 && b2 && gate && out && C <= 512 && C % 32 == 0, "SE: bad arguments");
+  hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), 0, s, x, HW, C, w1, b1, w2, b2, gate, split);
+  hipLaunchKernelGGL(se_scale_kernel, dim3((unsigned)(((long long)B * HW * (C / 8) + 255) / 256)), dim3(256), 0, s, x, gate, out, B,
+                     HW, C, split);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_launch_add(const bf16_t* a, const bf16_t* b, bf16_t* out, long long npix, int C, int split, hipStream_t s) {
+  hipLaunchKernelGGL(add_kernel, dim3((unsigned)((npix * (C / 8) + 255) / 256)), dim3(256), 0, s, a, b, out, npix, C, split);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_launch_pico_candidates(const float* head, int B, int A, int ncls, int level, float thr_lo, int max_cands, float* cands,
+                              int* counts, hipStream_t s) {
+  hipLaunchKernelGGL(pico_candidates_kernel, dim3((unsigned)(((long long)B * A + 255) / 256)), dim3(256), 0, s, head, B, A, ncls,
+                     level, thr_lo, max_cands, cands, counts);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}

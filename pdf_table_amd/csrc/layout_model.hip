@@ -1,0 +1,236 @@
+// layout_model.hip -- launch graph of the PicoDet layout detector: LCNet x1.0 -> 4-level CSP-PAN -> PicoHead.
+//
+// Reference graph: LCNet.forward picodet/lcnet.py:241-257, CSPPAN.forward csp_pan.py:305-345, PicoHead.forward_eval
+// pico_head.py:1108-1160 (export_post_process=False: per level sigmoid scores and raw box-distribution logits, which is
+// what the ONNX export the reference runs hands to OCRPicodetPostProcessor, ocr_layout_task.py:159-175).
+// Engine mapping: every Conv+BN folded; 1x1 convs on the MFMA kernel with a hardswish epilogue; depthwise convs, the
+// 3-channel stem, SE gates and the one tensor add are bandwidth kernels (layout_kernels.hip).  A 1x1 conv over
+// `cat(a, b)` is two GEMMs accumulating through the residual path; when `a` is a nearest x2 up-sample the first GEMM
+// runs at the low resolution and replicates its stores (1x1 conv and nearest up-sampling commute).
+// 16-channel tensors are stored 32 wide with a zero upper half.  Head outputs: fp32 [n, A_level, 40] (ncls class logits,
+// then 4 x (reg_max + 1) box logits, padded to 40).
+#include <stdlib.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+int pt_launch_stem3x3s2(const bf16_t* in, const float* w, const float* b, bf16_t* out, int B, int H, int W, int split,
+                        hipStream_t s);
+int pt_launch_dwconv(const bf16_t* in, const float* w, const float* b, bf16_t* out, int B, int H, int W, int C, int k,
+                     int stride, int act, int split, hipStream_t s);
+int pt_launch_se(const bf16_t* x, const float* w1, const float* b1, const float* w2, const float* b2, float* gate,
+                 bf16_t* out, int B, int HW, int C, int split, hipStream_t s);
+int pt_launch_add(const bf16_t* a, const bf16_t* b, bf16_t* out, long long npix, int C, int split, hipStream_t s);
+
+namespace {
+
+struct T {
+  bf16_t* p = nullptr;
+  int H = 0, W = 0, C = 0;
+};
+
+struct Ctx {
+  pt_engine* e;
+  const PtModel* m;
+  hipStream_t s;
+  int n, x3, mul;
+  bool dry, ok;
+  int rc;
+  float* gate = nullptr;
+
+  T alloc(int H, int W, int C) {
+    T t;
+    t.H = H; t.W = W; t.C = C;
+    t.p = reinterpret_cast<bf16_t*>(e->arena.take((size_t)n * H * W * C * mul * sizeof(bf16_t)));
+    if (!t.p) ok = false;
+    return t;
+  }
+  const PtTensor* get(const std::string& name) {
+    const PtTensor* t = m->find(name);
+    if (!t && rc == PT_OK) {
+      pt_set_error("PicoDet weight blob lacks tensor '%s'", name.c_str());
+      rc = PT_ERR_FORMAT;
+    }
+    return t;
+  }
+  bool go() const { return rc == PT_OK && !dry && ok; }
+  const float* F(const PtTensor* t) { return reinterpret_cast<const float*>(t->d_ptr); }
+
+  // 1x1 conv (+ folded BN) with activation act (0 none, 2 hardswish); rep: nearest replicate factor of the stores;
+  // res: added before the activation; nv: stored channels; out_f32: fp32 [.., f32_cs] output
+  void pw(const T& in, const std::string& q, int N, const T& out, int act, const T* res = nullptr, int rep = 1, int nv = 0,
+          float* out_f32 = nullptr, int f32_cs = 0) {
+    const PtTensor* w = get(q + (x3 ? ".w3" : ".w"));
+    const PtTensor* b = get(q + ".b");
+    if (!go()) return;
+    ConvDesc c;
+    c.in = in.p; c.B = n; c.H = in.H; c.W = in.W; c.Cin = in.C;
+    c.w = reinterpret_cast<const bf16_t*>(w->d_ptr); c.bias = F(b);
+    c.N = N; c.ks = 1; c.stride = 1; c.relu = act; c.split = x3; c.n_valid = nv; c.rep = rep;
+    if (out_f32) {
+      c.out_f32 = out_f32; c.out_cstride = f32_cs;
+    } else {
+      c.out = out.p; c.out_cstride = out.C * mul; c.out_lo_off = out.C;
+    }
+    if (res) { c.res = res->p; c.res_mode = 1; }
+    const int r = pt_launch_conv(e, c, s);
+    if (r != PT_OK) rc = r;
+  }
+  T dw(const T& in, const std::string& q, int k, int stride, int act) {
+    const int pad = k / 2;
+    T o = alloc((in.H + 2 * pad - k) / stride + 1, (in.W + 2 * pad - k) / stride + 1, in.C);
+    const PtTensor* w = get(q + ".wf32");
+    const PtTensor* b = get(q + ".b");
+    if (go()) {
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0, "layout dwconv");
+      const int r = pt_launch_dwconv(in.p, F(w), F(b), o.p, n, in.H, in.W, in.C, k, stride, act, x3, s);
+      if (r != PT_OK) rc = r;
+    }
+    return o;
+  }
+  // DPModule (csp_pan.py:56-105): dw k5 + BN + hswish, pw + BN + hswish
+  T dp(const T& in, const std::string& q, int stride) {
+    T d = dw(in, q + ".dw", 5, stride, 2);
+    T o = alloc(d.H, d.W, in.C);
+    pw(d, q + ".pw", in.C, o, 2);
+    return o;
+  }
+  // hswish(bn(conv1x1(cat(a', b)))) where a' = a (up == 1) or nearest-x2(a) (up == 2)
+  T cat_pw(const T& a, const T& b, const std::string& q, int N, int up) {
+    T o = alloc(b.H, b.W, N);
+    pw(a, q + ".a", N, o, 0, nullptr, up);
+    pw(b, q + ".b", N, o, 2, &o);
+    return o;
+  }
+  // CSPLayer (csp_pan.py:160-209) on cat(a', b)
+  T csp(const T& a, const T& b, const std::string& q, int up) {
+    T sh = cat_pw(a, b, q + ".short", 64, up);
+    T mn = cat_pw(a, b, q + ".main", 64, up);
+    T c1 = alloc(mn.H, mn.W, 64);
+    pw(mn, q + ".conv1", 64, c1, 2);
+    T d = dp(c1, q + ".dp", 1);
+    return cat_pw(d, sh, q + ".final", 128, 1);
+  }
+};
+
+}  // namespace
+
+// x: NHWC4 bf16 [n, H, W, 4] (8 channels in BF16X3 mode); heads[l]: fp32 [n, A_l, 40], A_l = ceil-chain of the strides
+int pt_picodet_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* h0, float* h1, float* h2, float* h3,
+                          hipStream_t s) {
+  PT_REQUIRE(x && h0 && h1 && h2 && h3 && n > 0, "layout net: null pointer");
+  PT_REQUIRE(H % 32 == 0 && W % 32 == 0 && H > 0 && W > 0, "layout net: input %dx%d must be multiples of 32", H, W);
+  auto it = e->models.find(PT_MODEL_PICODET);
+  if (it == e->models.end()) {
+    pt_set_error("PicoDet weights not loaded (pt_weights_load(PT_MODEL_PICODET))");
+    return PT_ERR_STATE;
+  }
+  Ctx c;
+  c.e = e; c.m = &it->second; c.s = s; c.n = n;
+  c.x3 = e->precision == PT_PRECISION_BF16X3 ? 1 : 0;
+  c.mul = c.x3 ? 2 : 1;
+  c.rc = PT_OK;
+  float* heads[4] = {h0, h1, h2, h3};
+  // k, cin, cout, stride, se -- picodet/lcnet.py:25-46
+  static const int cfg[][5] = {{3, 16, 32, 1, 0},
+                               {3, 32, 64, 2, 0}, {3, 64, 64, 1, 0},
+                               {3, 64, 128, 2, 0}, {3, 128, 128, 1, 0},
+                               {3, 128, 256, 2, 0}, {5, 256, 256, 1, 0}, {5, 256, 256, 1, 0}, {5, 256, 256, 1, 0},
+                               {5, 256, 256, 1, 0}, {5, 256, 256, 1, 0},
+                               {5, 256, 512, 2, 1}, {5, 512, 512, 1, 1}};
+  static const char* names[] = {"blocks2.0", "blocks3.0", "blocks3.1", "blocks4.0", "blocks4.1", "blocks5.0", "blocks5.1",
+                                "blocks5.2", "blocks5.3", "blocks5.4", "blocks5.5", "blocks6.0", "blocks6.1"};
+  for (int pass = 0; pass < 2; ++pass) {
+    c.dry = pass == 0;
+    c.ok = true;
+    e->arena.reset();
+    c.gate = reinterpret_cast<float*>(e->arena.take((size_t)n * 512 * sizeof(float)));
+    if (!c.gate) c.ok = false;
+    T t = c.alloc((H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1, 32);
+    {
+      const PtTensor* w = c.get("stem.wf32");
+      const PtTensor* b = c.get("stem.b");
+      if (c.go()) {
+        PtProfScope ps(e, s, PT_PROF_STEM, 0, "layout stem3x3");
+        const int r = pt_launch_stem3x3s2(x, c.F(w), c.F(b), t.p, n, H, W, c.x3, s);
+        if (r != PT_OK) c.rc = r;
+      }
+    }
+    T feats[3];
+    for (int i = 0; i < 13; ++i) {
+      const int k = cfg[i][0], cout = cfg[i][2], st = cfg[i][3], se = cfg[i][4];
+      const std::string q = names[i];
+      T d = c.dw(t, q + ".dw", k, st, 2);
+      if (se) {
+        const PtTensor *w1 = c.get(q + ".se.w1"), *b1 = c.get(q + ".se.b1"), *w2 = c.get(q + ".se.w2"), *b2 = c.get(q + ".se.b2");
+        T g = c.alloc(d.H, d.W, d.C);
+        if (c.go()) {
+          PtProfScope ps(e, s, PT_PROF_OTHER, 0, "layout SE");
+          const int r = pt_launch_se(d.p, c.F(w1), c.F(b1), c.F(w2), c.F(b2), c.gate, g.p, n, d.H * d.W, d.C, c.x3, s);
+          if (r != PT_OK) c.rc = r;
+        }
+        d = g;
+      }
+      const int cstore = cout < 32 ? 32 : cout;
+      T o = c.alloc(d.H, d.W, cstore);
+      c.pw(d, q + ".pw", cout < 64 ? 64 : cout, o, 2, nullptr, 1, cout < 64 ? cstore : 0);
+      t = o;
+      if (i == 4) feats[0] = t;
+      if (i == 10) feats[1] = t;
+      if (i == 12) feats[2] = t;
+    }
+    // ---- CSP-PAN (csp_pan.py:305-345)
+    T ins[3];
+    for (int i = 0; i < 3; ++i) {
+      ins[i] = c.alloc(feats[i].H, feats[i].W, 128);
+      c.pw(feats[i], "neck.t" + std::to_string(i), 128, ins[i], 2);
+    }
+    PT_REQUIRE(ins[1].H == 2 * ins[2].H && ins[1].W == 2 * ins[2].W && ins[0].H == 2 * ins[1].H && ins[0].W == 2 * ins[1].W,
+               "layout net: feature maps %dx%d / %dx%d / %dx%d are not exact halves", ins[0].H, ins[0].W, ins[1].H, ins[1].W,
+               ins[2].H, ins[2].W);
+    T inner1 = c.csp(ins[2], ins[1], "neck.td0", 2);
+    T inner0 = c.csp(inner1, ins[0], "neck.td1", 2);
+    T outs[4];
+    outs[0] = inner0;
+    outs[1] = c.csp(c.dp(outs[0], "neck.down0", 2), inner1, "neck.bu0", 1);
+    outs[2] = c.csp(c.dp(outs[1], "neck.down1", 2), ins[2], "neck.bu1", 1);
+    {
+      T a = c.dp(ins[2], "neck.top1", 2), b = c.dp(outs[2], "neck.top2", 2);
+      outs[3] = c.alloc(a.H, a.W, 128);
+      if (c.go()) {
+        const int r = pt_launch_add(a.p, b.p, outs[3].p, (long long)n * a.H * a.W, 128, c.x3, s);
+        if (r != PT_OK) c.rc = r;
+      }
+    }
+    // ---- PicoFeat towers + head_cls (pico_head.py:154-167, 1114-1140)
+    for (int l = 0; l < 4; ++l) {
+      T f = outs[l];
+      for (int i = 0; i < 4; ++i) {
+        const std::string q = "head." + std::to_string(l) + "." + std::to_string(i);
+        T d = c.dw(f, q + ".dw", 5, 1, 2);
+        T o = c.alloc(d.H, d.W, 128);
+        c.pw(d, q + ".pw", 128, o, 2);
+        f = o;
+      }
+      c.pw(f, "head." + std::to_string(l) + ".out", 64, T(), 0, nullptr, 1, 40, heads[l], 40);
+    }
+    if (c.rc != PT_OK) return c.rc;
+    if (pass == 0) {
+      if (c.ok) continue;
+      PT_HIP_CHECK(hipDeviceSynchronize());
+      if (e->arena.base) PT_HIP_CHECK(hipFree(e->arena.base));
+      e->arena.base = nullptr;
+      const size_t want = e->arena.high + (1u << 20);
+      PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arena.base), want));
+      e->arena.cap = want;
+      continue;
+    }
+    if (!c.ok) {
+      pt_set_error("layout net: activation arena allocation failed");
+      return PT_ERR_HIP;
+    }
+  }
+  return PT_OK;
+}

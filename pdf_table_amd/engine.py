@@ -117,6 +117,42 @@ class HipEngine:
                 "pt_det_forward_net")
         return (prob, logits) if want_logits else prob
 
+    # ---- layout (PicoDet) ----------------------------------------------------------------------------------------
+    def layout_plan(self, inp_h: int, inp_w: int):
+        fh, fw = (C.c_int * 4)(), (C.c_int * 4)()
+        L.check(self.lib.pt_layout_plan(inp_h, inp_w, fh, fw), "pt_layout_plan")
+        return list(fh), list(fw)
+
+    def layout_preprocess(self, pages: torch.Tensor, inp_h: int = 800, inp_w: int = 608) -> torch.Tensor:
+        self._chk(pages, torch.uint8, "pages")
+        n, h, w, _ = pages.shape
+        out = torch.empty((n, inp_h, inp_w, 8 if self.precision == L.PT_PRECISION_BF16X3 else 4), dtype=torch.bfloat16,
+                          device=self._tdev)
+        L.check(self.lib.pt_layout_preprocess(self._h, _ptr(pages), n, h, w, inp_h, inp_w, _ptr(out), self._stream()),
+                "pt_layout_preprocess")
+        return out
+
+    def layout_forward_net(self, x: torch.Tensor):
+        """x bf16 NHWC4 [n,H,W,4|8] -> 4 head maps f32 [n, A_l, 40] (class logits, then box-distribution logits)"""
+        self._chk(x, torch.bfloat16, "x")
+        n, H, W, _ = x.shape
+        fh, fw = self.layout_plan(H, W)
+        heads = [torch.empty((n, fh[l] * fw[l], L.PT_LAYOUT_HEAD_CS), dtype=torch.float32, device=self._tdev) for l in range(4)]
+        L.check(self.lib.pt_layout_forward_net(self._h, _ptr(x), n, H, W, *[_ptr(t) for t in heads], self._stream()),
+                "pt_layout_forward_net")
+        return heads
+
+    def layout_forward(self, pages: torch.Tensor, inp_h: int = 800, inp_w: int = 608, num_classes: int = 5,
+                       thr_lo: float = 0.45, max_cands: int = 2048):
+        """pages uint8 [n,h,w,3] -> (counts int32 [n] on the host, candidate records f32 [n, max_cands, 48] on the device)"""
+        self._chk(pages, torch.uint8, "pages")
+        n, h, w, _ = pages.shape
+        counts = torch.zeros((n,), dtype=torch.int32, device=self._tdev)
+        cands = torch.empty((n, max_cands, L.PT_LAYOUT_CAND_FLOATS), dtype=torch.float32, device=self._tdev)
+        L.check(self.lib.pt_layout_forward(self._h, _ptr(pages), n, h, w, inp_h, inp_w, num_classes, float(thr_lo), max_cands,
+                                           _ptr(counts), _ptr(cands), self._stream()), "pt_layout_forward")
+        return counts, cands
+
     def tsr_preprocess(self, pages: torch.Tensor, tables, inp_h: int = 1024, inp_w: int = 1024, bgr: bool = True):
         """pages uint8 [np,h,w,3] on the device, tables: numpy array of TSR_TABLE_DTYPE -> bf16 NHWC4 [n,inp_h,inp_w,4|8]."""
         self._chk(pages, torch.uint8, "pages")

@@ -16,6 +16,8 @@ PT_MODEL_DB_RESNET18 = 1
 PT_MODEL_CRNN = 2
 PT_MODEL_LORE_DLA34 = 3
 PT_MODEL_LORE_PROCESSOR = 4
+PT_MODEL_PICODET = 5
+PT_LAYOUT_HEAD_CS, PT_LAYOUT_CAND_FLOATS = 40, 48
 PT_DET_PRE_DB_PP = 0
 PT_DET_PRE_DB_TORCH = 1
 PT_DET_PRE_NONE = 2
@@ -57,6 +59,11 @@ def _proto(lib):
         "pt_rec_forward_crops": (i, [vp, vp, vp, vp, i, vp, vp, vp]),
         "pt_rec_forward_net": (i, [vp, vp, i, vp, vp, vp]),
         "pt_rec_preprocess": (i, [vp, vp, i, i, i, vp, vp, i, vp, vp]),
+        "pt_layout_plan": (i, [i, i, ip, ip]),
+        "pt_layout_preprocess": (i, [vp, vp, i, i, i, i, i, vp, vp]),
+        "pt_layout_forward_net": (i, [vp, vp, i, i, i, vp, vp, vp, vp, vp]),
+        "pt_layout_candidates": (i, [vp, vp, vp, vp, vp, i, i, i, i, f, i, vp, vp, vp]),
+        "pt_layout_forward": (i, [vp, vp, i, i, i, i, i, i, f, i, vp, vp, vp]),
         "pt_tsr_preprocess": (i, [vp, vp, i, i, i, vp, i, i, i, i, vp, vp]),
         "pt_tsr_forward_net": (i, [vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp]),
         "pt_tsr_decode": (i, [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, f, vp, vp, vp, vp]),

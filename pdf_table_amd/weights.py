@@ -29,7 +29,7 @@ import torch
 BN_EPS = 1e-5
 _DT = {"bf16": 0, "f32": 1, "i32": 2}
 
-__all__ = ["pack_db_resnet18", "pack_crnn", "pack_lore_dla34", "pack_lore_processor", "write_blob", "fold_conv_bn", "to_bf16_bits"]
+__all__ = ["pack_db_resnet18", "pack_crnn", "pack_lore_dla34", "pack_lore_processor", "pack_picodet", "write_blob", "fold_conv_bn", "to_bf16_bits"]
 
 
 def to_bf16_bits(t: torch.Tensor) -> np.ndarray:
@@ -327,4 +327,92 @@ def pack_lore_processor(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
     bl.add("x_pe", sd["x_position_embeddings.weight"].float().numpy(), "f32")
     bl.add("y_pe", sd["y_position_embeddings.weight"].float().numpy(), "f32")
     bl.add("meta", np.array([n_axis, n_stack], dtype=np.int32), "i32")
+    return bl.tobytes()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# PicoDet layout detector (picodet/lcnet.py, csp_pan.py, pico_head.py)
+# --------------------------------------------------------------------------------------------------------------------
+def _fold_named(sd, conv_key: str, bn_key: str):
+    """like fold_conv_bn, for modules whose conv / norm children have arbitrary names"""
+    w = sd[conv_key + ".weight"].double()
+    b = sd[conv_key + ".bias"].double() if (conv_key + ".bias") in sd else torch.zeros(w.shape[0], dtype=torch.float64)
+    scale = sd[bn_key + ".weight"].double() / torch.sqrt(sd[bn_key + ".running_var"].double() + BN_EPS)
+    shift = sd[bn_key + ".bias"].double() - sd[bn_key + ".running_mean"].double() * scale
+    return (w * scale.view(-1, 1, 1, 1)).float(), (b * scale + shift).float()
+
+
+def pack_picodet(sd: Dict[str, torch.Tensor], num_classes: int = 5, x3: bool = True) -> bytes:
+    """PicoDet state_dict (keys backbone. / neck. / head., pdf_table_amd.synth_weights.picodet_state_dict) -> blob for
+    PT_MODEL_PICODET.  BN folded everywhere; depthwise kernels fp32 ``[k*k][C]`` + bias; 1x1 convs tiled for the MFMA
+    kernel (16-channel tensors stored 32 wide; convs over a channel concat split per operand: ``.a`` / ``.b``);
+    SE fully-connected layers fp32; head convs padded to 64 outputs (``meta`` = [num_classes, reg_max])."""
+    from .synth_weights import LCNET_CONFIG, PICODET_STANDIN
+    bl = _Blob(x3)
+
+    def dw(name, conv_key, bn_key):
+        w, b = _fold_named(sd, conv_key, bn_key)                    # [C, 1, k, k]
+        c, _, k, _ = w.shape
+        cp = max(c, 32)
+        wp = torch.zeros(k * k, cp)
+        wp[:, :c] = w[:, 0].permute(1, 2, 0).reshape(k * k, c)
+        bp = torch.zeros(cp)
+        bp[:c] = b
+        bl.add(name + ".wf32", wp.numpy(), "f32")
+        bl.add(name + ".b", bp.numpy(), "f32")
+
+    def pw(name, conv_key, bn_key, split_at=None):
+        w, b = _fold_named(sd, conv_key, bn_key)
+        n, cin = w.shape[0], w.shape[1]
+        nt = (n + 63) // 64 * 64
+        if split_at is None:
+            bl.add_conv(name, *_pad_conv(w, b, nt, max(cin, 32)))
+        else:
+            bl.add_conv(name + ".a", *_pad_conv(w[:, :split_at].contiguous(), b, nt, split_at))
+            bl.add_conv(name + ".b", *_pad_conv(w[:, split_at:].contiguous(), torch.zeros_like(b), nt, cin - split_at))
+
+    # stem: conv 3x3 s2 3 -> 16 (+BN): fp32 [16][3][3][4] (channel 3 zero) for the direct kernel
+    w, b = _fold_named(sd, "backbone.conv1.conv", "backbone.conv1.bn")
+    st = torch.zeros(16, 3, 3, 4)
+    st[:, :, :, :3] = w.permute(0, 2, 3, 1)
+    bl.add("stem.wf32", st.numpy(), "f32")
+    bl.add("stem.b", b.numpy(), "f32")
+    for blk in ("blocks2", "blocks3", "blocks4", "blocks5", "blocks6"):
+        for i, (k, cin, cout, s, se) in enumerate(LCNET_CONFIG[blk]):
+            p, q = f"backbone.{blk}.{i}", f"{blk}.{i}"
+            dw(q + ".dw", p + ".dw_conv.conv", p + ".dw_conv.bn")
+            if se:
+                bl.add(q + ".se.w1", sd[p + ".se.conv1.weight"][:, :, 0, 0].float().numpy(), "f32")     # [C/4, C]
+                bl.add(q + ".se.b1", sd[p + ".se.conv1.bias"].float().numpy(), "f32")
+                bl.add(q + ".se.w2", sd[p + ".se.conv2.weight"][:, :, 0, 0].float().numpy(), "f32")     # [C, C/4]
+                bl.add(q + ".se.b2", sd[p + ".se.conv2.bias"].float().numpy(), "f32")
+            pw(q + ".pw", p + ".pw_conv.conv", p + ".pw_conv.bn")
+    nc = PICODET_STANDIN["neck_channels"]
+
+    def dp(q, p):
+        dw(q + ".dw", p + ".dwconv", p + ".bn1")
+        pw(q + ".pw", p + ".pwconv", p + ".bn2")
+
+    def csp(q, p):
+        pw(q + ".main", p + ".main_conv.conv", p + ".main_conv.bn", split_at=nc)
+        pw(q + ".short", p + ".short_conv.conv", p + ".short_conv.bn", split_at=nc)
+        pw(q + ".conv1", p + ".blocks.0.conv1.conv", p + ".blocks.0.conv1.bn")
+        dp(q + ".dp", p + ".blocks.0.conv2")
+        pw(q + ".final", p + ".final_conv.conv", p + ".final_conv.bn", split_at=nc // 2)
+
+    for i in range(3):
+        pw(f"neck.t{i}", f"neck.conv_t.convs.{i}.conv", f"neck.conv_t.convs.{i}.bn")
+    dp("neck.top1", "neck.first_top_conv")
+    dp("neck.top2", "neck.second_top_conv")
+    for i in range(2):
+        csp(f"neck.td{i}", f"neck.top_down_blocks.{i}")
+        dp(f"neck.down{i}", f"neck.downsamples.{i}")
+        csp(f"neck.bu{i}", f"neck.bottom_up_blocks.{i}")
+    for s in range(4):
+        for i in range(PICODET_STANDIN["num_convs"]):
+            dw(f"head.{s}.{i}.dw", f"head.conv_feat.cls_conv_dw{s}_{i}.conv", f"head.conv_feat.cls_conv_dw{s}_{i}.norm")
+            pw(f"head.{s}.{i}.pw", f"head.conv_feat.cls_conv_pw{s}_{i}.conv", f"head.conv_feat.cls_conv_pw{s}_{i}.norm")
+        w = sd[f"head.head_cls{s}.weight"].float()
+        bl.add_conv(f"head.{s}.out", *_pad_conv(w, sd[f"head.head_cls{s}.bias"].float(), 64, nc))
+    bl.add("meta", np.array([num_classes, PICODET_STANDIN["reg_max"]], dtype=np.int32), "i32")
     return bl.tobytes()

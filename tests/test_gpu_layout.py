@@ -1,0 +1,134 @@
+"""GPU parity tests of the layout stage (PicoDet), through the C ABI.  Float work: PT_PRECISION_BF16X3 within 1e-3
+(relative to the head's scale) of the oracle (itself pinned to the reference's LCNet / CSPPAN / PicoHead modules)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import picodet as op
+from pdf_table_amd import lib as L
+from pdf_table_amd.synth_weights import picodet_state_dict
+from pdf_table_amd.weights import pack_picodet
+
+pytestmark = pytest.mark.gpu
+TOL_REL = 1e-3
+
+
+def _x4(x, split=False):
+    n, _, H, W = x.shape
+    nhwc = x.permute(0, 2, 3, 1)
+    if not split:
+        x4 = torch.zeros(n, H, W, 4)
+        x4[..., :3] = nhwc
+        return x4.to(torch.bfloat16)
+    hi = nhwc.to(torch.bfloat16).float()
+    lo = (nhwc - hi).to(torch.bfloat16).float()
+    x8 = torch.zeros(n, H, W, 8)
+    x8[..., :3] = hi
+    x8[..., 4:7] = lo
+    return x8.to(torch.bfloat16)
+
+
+@pytest.fixture(scope="module")
+def pico_sd():
+    return picodet_state_dict(seed=41, num_classes=5)
+
+
+@pytest.fixture(scope="module")
+def eng(pico_sd):
+    from pdf_table_amd.engine import HipEngine
+    e = HipEngine(0)
+    e.load_weights(L.PT_MODEL_PICODET, pack_picodet(pico_sd, 5))
+    yield e
+    e.close()
+
+
+def _ref_logits(sd, x):
+    """oracle head outputs before the sigmoid: [n, A, 5 + 32] per level"""
+    with torch.no_grad():
+        sc, bx = op.picodet_forward(sd, x, 5)
+    return [torch.cat([torch.logit(s.double()).float(), b], 2) for s, b in zip(sc, bx)], sc, bx
+
+
+@pytest.mark.parametrize("shape", [(1, 160, 128), (2, 224, 192), (1, 320, 256)])
+def test_layout_net_x3_matches_oracle(eng, pico_sd, shape):
+    n, H, W = shape
+    g = torch.Generator().manual_seed(500 + H)
+    x = torch.randn(n, 3, H, W, generator=g)
+    with torch.no_grad():
+        sc, bx = op.picodet_forward(pico_sd, x, 5)
+    eng.set_precision(L.PT_PRECISION_BF16X3)
+    try:
+        heads = eng.layout_forward_net(_x4(x, split=True).cuda())
+        torch.cuda.synchronize()
+    finally:
+        eng.set_precision(L.PT_PRECISION_BF16)
+    for l in range(4):
+        h = heads[l].cpu()
+        assert h.shape[1] == sc[l].shape[1], (l, h.shape, sc[l].shape)
+        ds = (torch.sigmoid(h[..., :5]) - sc[l]).abs().max().item()
+        db = (h[..., 5:37] - bx[l]).abs().max().item()
+        print(f"layout x3 {shape} level {l}: max|dscore|={ds:.2e} max|dbox|={db:.2e} (scale {bx[l].abs().max().item():.1f})")
+        assert ds <= TOL_REL and db <= TOL_REL * max(1.0, bx[l].abs().max().item())
+
+
+def test_layout_net_matches_reference_golden(eng, golden_dir):
+    gold = np.load(os.path.join(golden_dir, "picodet.npz"))
+    eng.set_precision(L.PT_PRECISION_BF16X3)
+    try:
+        for tag in ("a", "b"):
+            heads = eng.layout_forward_net(_x4(torch.from_numpy(gold[f"x_{tag}"]), split=True).cuda())
+            for l in range(4):
+                h = heads[l].cpu()
+                assert (torch.sigmoid(h[..., :5]).numpy() - gold[f"score{l}_{tag}"]).__abs__().max() <= TOL_REL
+                assert np.abs(h[..., 5:37].numpy() - gold[f"box{l}_{tag}"]).max() <= TOL_REL * max(1.0, np.abs(gold[f"box{l}_{tag}"]).max())
+    finally:
+        eng.set_precision(L.PT_PRECISION_BF16)
+
+
+def test_layout_net_bf16_drift(eng, pico_sd):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, 3, 224, 192, generator=g).to(torch.bfloat16).float()
+    with torch.no_grad():
+        sc, bx = op.picodet_forward(pico_sd, x, 5)
+    heads = eng.layout_forward_net(_x4(x).cuda())
+    for l in range(4):
+        h = heads[l].cpu()
+        assert (h[..., 5:37] - bx[l]).abs().max().item() <= 0.1 * max(1.0, bx[l].abs().max().item())
+
+
+def test_layout_preprocess_and_candidates(eng):
+    """pt_layout_preprocess == the oracle's pre-process; candidates == every anchor above the threshold, with its raw values"""
+    from pdf_table_amd.synth_pages import make_page
+    page = make_page(5, 1024)[0]
+    eng.set_precision(L.PT_PRECISION_BF16X3)
+    try:
+        x = eng.layout_preprocess(torch.from_numpy(page[None]).cuda(), 800, 608).float().cpu()
+    finally:
+        eng.set_precision(L.PT_PRECISION_BF16)
+    ref, sf = op.picodet_preprocess(page)
+    got = (x[0, ..., :3] + x[0, ..., 4:7]).permute(2, 0, 1).numpy()
+    assert np.abs(got - ref).max() <= 2e-5
+    assert sf == [800 / 1024, 608 / 1024]
+    fh, fw = eng.layout_plan(800, 608)
+    assert [a * b for a, b in zip(fh, fw)] == [7600, 1900, 475, 130]
+    rng = np.random.default_rng(3)
+    heads = [torch.from_numpy((rng.standard_normal((2, fh[l] * fw[l], 40)) * 1.5 - 2.0).astype(np.float32)).cuda() for l in range(4)]
+    counts = torch.zeros(2, dtype=torch.int32, device="cuda")
+    cands = torch.zeros(2, 4096, 48, device="cuda")
+    from pdf_table_amd.engine import _ptr
+    L.check(eng.lib.pt_layout_candidates(eng._h, *[_ptr(h) for h in heads], 2, 800, 608, 5, 0.5, 4096, _ptr(counts), _ptr(cands),
+                                         eng._stream()), "pt_layout_candidates")
+    counts = counts.cpu().numpy()
+    for b in range(2):
+        want = set()
+        for l in range(4):
+            s = torch.sigmoid(heads[l][b, :, :5]).max(1).values.cpu().numpy()
+            want |= {(l, int(a)) for a in np.nonzero(s > 0.5)[0]}
+        rec = cands[b, :counts[b]].cpu().numpy()
+        got = {(int(r[:1].view(np.int32)[0]), int(r[1:2].view(np.int32)[0])) for r in rec}
+        assert counts[b] == len(want) > 50 and got == want
+        for r in rec[:20]:
+            l, a = int(r[:1].view(np.int32)[0]), int(r[1:2].view(np.int32)[0])
+            assert np.array_equal(r[2:42], heads[l][b, a].cpu().numpy())
