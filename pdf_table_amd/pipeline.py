@@ -23,6 +23,8 @@ import torch
 from .det_stage import DetConfig, DetStage, sort_boxes_reading_order
 from .engine import HipEngine
 from .ocr_detection_task import OcrDetectionTask, _read_image
+from .layout_stage import layout_tables
+from .ocr_layout_task import OcrLayoutTask
 from .ocr_recognition_task import OcrRecognitionTask
 from .ocr_table_structure_task import OcrTableStructureTask
 
@@ -43,10 +45,8 @@ class OcrTablePipeline:
                  synthetic_seed: Optional[int] = None, det_task_path: Optional[str] = None,
                  rec_task_path: Optional[str] = None, layout: bool = False, table_structure: bool = False,
                  table_structure_model: str = "Lore", table_structure_task_type: str = "wtw",
-                 tsr_task_path: Optional[str] = None, **kwargs):
-        if layout:
-            raise NotImplementedError("the layout stage (PicoDet) is not built on the HIP engine yet (SURVEY.md section 8a "
-                                      "row 1); pass the table regions to predict(table_boxes=...)")
+                 tsr_task_path: Optional[str] = None, layout_model: str = "picodet", layout_task_type: str = "en",
+                 layout_task_path: Optional[str] = None, **kwargs):
         self.engine = HipEngine(device)
         dk = dict(kwargs)
         rk = dict(kwargs)
@@ -59,6 +59,14 @@ class OcrTablePipeline:
             rk["task_path"] = rec_task_path
         self.text_detector = OcrDetectionTask(model=detect_model, thresh=thresh, engine=self.engine, **dk)
         self.text_recognizer = OcrRecognitionTask(model=recognizer, engine=self.engine, **rk)
+        self.layout_task = None
+        if layout:
+            lk = dict(kwargs)
+            if synthetic_seed is not None:
+                lk["synthetic_seed"] = synthetic_seed + 4
+            if layout_task_path:
+                lk["task_path"] = layout_task_path
+            self.layout_task = OcrLayoutTask(model=layout_model, engine=self.engine, task_type=layout_task_type, **lk)
         self.table_structure_task = None
         if table_structure:
             tk = dict(kwargs)
@@ -72,8 +80,8 @@ class OcrTablePipeline:
     def predict(self, pages: Sequence, table_boxes: Optional[Sequence[np.ndarray]] = None, **kwargs) -> List[PageResult]:
         """pages: RGB images (paths / PIL / ndarrays); table_boxes: per page int [k,4] x1,y1,x2,y2 table regions (what the
         layout stage would deliver).  Returns one PageResult per page, plus ``self.metric``."""
-        if self.table_structure_task is not None and table_boxes is None:
-            raise ValueError("table_structure=True needs predict(table_boxes=...) until the layout stage is built")
+        if self.table_structure_task is not None and table_boxes is None and self.layout_task is None:
+            raise ValueError("table_structure=True needs layout=True or predict(table_boxes=...)")
         t0 = time.time()
         imgs = [_read_image(p) for p in pages]
         results: List[Optional[PageResult]] = [None] * len(imgs)
@@ -94,16 +102,27 @@ class OcrTablePipeline:
             except Exception:                      # reference: a failing recognition yields empty strings
                 texts = [[""] * len(b) for b in boxes]
             c = time.time()
+            lay = self.layout_task.detect_pages(batch) if self.layout_task is not None else None
             tsr = None
             if self.table_structure_task is not None:
-                tsr = self.table_structure_task.recognize_tables(batch, [np.asarray(table_boxes[i]).reshape(-1, 4) for i in idxs])
+                if table_boxes is not None:
+                    tb = [np.asarray(table_boxes[i]).reshape(-1, 4) for i in idxs]
+                else:
+                    # layout regions labelled "table", score >= 0.2, top to bottom, cropped at rounded coordinates
+                    # (ocr_system_task.py:184-198, crop_image_by_box utils/ocr/ocr_common_utils.py:279-280)
+                    tb = []
+                    for k in range(len(idxs)):
+                        bx = [[round(float(v)) for v in t["bbox"]] for t in layout_tables(lay[k], "table", 0.2)]
+                        bx = [b for b in bx if b[2] > b[0] and b[3] > b[1]]
+                        tb.append(np.array(bx, dtype=np.int64).reshape(-1, 4))
+                tsr = self.table_structure_task.recognize_tables(batch, tb)
             d_ = time.time()
             t_det += b_ - a
             t_rec += c - b_
             t_tsr += d_ - c
             for k, i in enumerate(idxs):
                 ocr = [{"index": j + 1, "text": t, "bbox": boxes[k][j].reshape(4, 2)} for j, t in enumerate(texts[k])]
-                results[i] = PageResult(det_result=boxes[k], ocr_result=ocr,
+                results[i] = PageResult(det_result=boxes[k], ocr_result=ocr, layout_result=None if lay is None else lay[k],
                                         table_structure_result=None if tsr is None else tsr[k])
         self.metric = {"use_time": time.time() - t0, "text_detection": {"use_time": t_det},
                        "text_recognition": {"use_time": t_rec, "total": sum(len(r.ocr_result) for r in results)},

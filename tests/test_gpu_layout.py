@@ -132,3 +132,34 @@ def test_layout_preprocess_and_candidates(eng):
         for r in rec[:20]:
             l, a = int(r[:1].view(np.int32)[0]), int(r[1:2].view(np.int32)[0])
             assert np.array_equal(r[2:42], heads[l][b, a].cpu().numpy())
+
+
+def test_layout_stage_matches_oracle_chain(eng, pico_sd):
+    """pages -> detections through the device path (BF16X3) == the oracle chain (pre-process, net, post-process), up to
+    detections whose score sits within 2e-3 of the threshold / NMS boundary"""
+    from pdf_table_amd.layout_stage import LayoutStage, PicodetConfig
+    from pdf_table_amd.synth_pages import make_page
+    pages = np.stack([make_page(i, 1024)[0] for i in (0, 1, 2, 3)])
+    total = 0
+    eng.set_precision(L.PT_PRECISION_BF16X3)
+    try:
+        got = LayoutStage(eng, PicodetConfig(task_type="en"))(torch.from_numpy(pages).cuda())
+    finally:
+        eng.set_precision(L.PT_PRECISION_BF16)
+    for i in range(4):
+        x, sf = op.picodet_preprocess(pages[i])
+        with torch.no_grad():
+            sc, bx = op.picodet_forward(pico_sd, torch.from_numpy(x)[None], 5)
+        ref = op.picodet_postprocess([s.numpy() for s in sc], [b.numpy() for b in bx], [1024, 1024], sf, [800, 608], op.LABELS["en"])
+        total += len(ref)
+        rb = np.array([r["bbox"] for r in ref]).reshape(-1, 4)
+        gb = np.array([g["bbox"] for g in got[i]]).reshape(-1, 4)
+        matched = 0
+        for k, r in enumerate(ref):
+            d = np.abs(gb - rb[k]).max(1) if len(gb) else np.array([1e9])
+            j = int(np.argmin(d))
+            if d[j] <= 0.05 and got[i][j]["category_id"] == r["category_id"] and abs(got[i][j]["score"] - r["score"]) <= 2e-3:
+                matched += 1
+        print(f"layout page {i}: {len(ref)} reference detections, {len(got[i])} device detections, {matched} matched")
+        assert matched >= 0.9 * len(ref) and abs(len(got[i]) - len(ref)) <= max(2, len(ref) // 10)
+    assert total > 10

@@ -64,8 +64,11 @@ def test_pipeline_predict(pipe):
 
 def test_missing_stages_fail_loudly():
     from pdf_table_amd.pipeline import OcrTablePipeline
-    with pytest.raises(NotImplementedError):
-        OcrTablePipeline(device=0, synthetic_seed=0, layout=True)
+    from pdf_table_amd.ocr_layout_task import OcrLayoutTask
+    with pytest.raises(RuntimeError):
+        OcrLayoutTask(model="DocXLayout", synthetic_seed=0)
+    with pytest.raises(RuntimeError):
+        OcrLayoutTask(model="yolo", synthetic_seed=0)
     from pdf_table_amd.ocr_table_structure_task import OcrTableStructureTask
     with pytest.raises(RuntimeError):
         OcrTableStructureTask(model="SLANet", synthetic_seed=0)
@@ -97,3 +100,26 @@ def test_table_structure_task_and_pipeline(pipe):
     assert np.array_equal(t0["polygons"], r["polygons"]) and np.array_equal(t0["logi"], r["logi"])
     with pytest.raises(ValueError):
         p2.predict([page])
+
+
+def test_layout_task_and_full_pipeline(pipe):
+    """reference call shape of OcrLayoutTask, then the four-stage pipeline: layout -> det -> rec -> TSR on the layout's
+    "table" regions (ocr_system_task.py:184-198)"""
+    from pdf_table_amd.ocr_layout_task import OcrLayoutTask
+    from pdf_table_amd.pipeline import OcrTablePipeline
+    page = make_page(3)[0]
+    task = OcrLayoutTask(model="picodet", task_type="en", synthetic_seed=4, engine=pipe.engine)
+    out = task([page, page[:700, :900].copy()])
+    assert len(out) == 2
+    for dets in out:
+        for d in dets:
+            assert set(d) == {"bbox", "label", "score", "category_id"} and d["bbox"].shape == (4,)
+            assert d["label"] in ("text", "title", "list", "table", "figure") and d["score"] > 0.5
+    p4 = OcrTablePipeline(device=0, synthetic_seed=0, layout=True, table_structure=True)
+    res = p4.predict([page])
+    r = res[0]
+    assert r.layout_result is not None and r.table_structure_result is not None
+    ntab = len([d for d in r.layout_result if d["label"] == "table" and d["score"] >= 0.2])
+    assert len(r.table_structure_result) <= ntab
+    for t in r.table_structure_result:
+        assert t["polygons"].shape[1] == 8 and t["logi"].shape[1] == 4

@@ -99,3 +99,41 @@ def test_lore_host_logic_matches_oracle():
     wtw, ptn = ts.LoreConfig(task_type="wtw"), ts.LoreConfig(task_type="ptn")
     assert (wtw.resolution, wtw.wiz_rev, wtw.wiz_2dpe, wtw.vis_thresh, wtw.tsfm_layers) == ((1024, 1024), True, False, 0.2, 4)
     assert (ptn.resolution, ptn.wiz_rev, ptn.wiz_2dpe, ptn.vis_thresh, ptn.tsfm_layers) == ((512, 512), False, True, 0.35, 3)
+
+
+def test_layout_decode_matches_oracle_postprocess():
+    """LayoutStage.decode_page on the compacted candidates == the oracle's restatement of OCRPicodetPostProcessor on the
+    full head outputs (pinned bit-exactly to the reference): same boxes, labels, scores, order."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from lore_synth import synth_pico_heads
+    from oracle import picodet as op
+    from pdf_table_amd.layout_stage import LayoutStage, PicodetConfig, layout_tables
+    for seed, tgt, org in ((1, (160, 128), (1024, 1024)), (2, (800, 608), (1100, 850)), (7, (800, 608), (1024, 1024))):
+        sc, bx = synth_pico_heads(seed, tgt)
+        logits = [torch.logit(torch.from_numpy(s).double()).float().numpy() for s in sc]
+        sc = [torch.sigmoid(torch.from_numpy(l)).numpy() for l in logits]              # scores as the net would emit them
+        ref = op.picodet_postprocess(sc, bx, list(org), [float(tgt[0]) / org[0], float(tgt[1]) / org[1]], list(tgt), op.LABELS["en"])
+        cfg = PicodetConfig(task_type="en")
+        cfg.img_height, cfg.img_width = tgt
+        st = LayoutStage(None, cfg)
+        recs = []
+        for l in range(4):
+            keep = np.nonzero(sc[l][0].max(1) > cfg.score_threshold - 1e-3)[0]
+            r = np.zeros((len(keep), 48), np.float32)
+            r[:, 0] = np.full(len(keep), l, np.int32).view(np.float32)
+            r[:, 1] = keep.astype(np.int32).view(np.float32)
+            r[:, 2:7] = logits[l][0, keep]
+            r[:, 7:39] = bx[l][0, keep]
+            recs.append(r)
+        rng = np.random.default_rng(seed)
+        rec = np.concatenate(recs)[rng.permutation(sum(len(r) for r in recs))]         # device order is arbitrary
+        got = st.decode_page(rec, org)
+        assert len(got) == len(ref) > 10
+        assert [g["category_id"] for g in got] == [r["category_id"] for r in ref]
+        assert np.array_equal(np.array([g["bbox"] for g in got]), np.array([r["bbox"] for r in ref]))
+        assert np.array_equal(np.array([g["score"] for g in got]), np.array([r["score"] for r in ref]))
+    tabs = layout_tables(got, "table", 0.2)
+    assert all(t["label"] == "table" for t in tabs) and [t["bbox"][1] for t in tabs] == sorted(t["bbox"][1] for t in tabs)
