@@ -11,8 +11,8 @@ text-detection stage -- resize + normalise, DB-ResNet18, prob -> bitmap, contour
 unclip, final boxes.  Pages are sharded across ranks (weak scaling: fixed pages per rank); there is no
 collective in the timed region.
 
-Stages (--stages, default det,rec,tsr): DB text detection, CRNN recognition of the page's text lines, Lore table
-structure of the page's tables.
+Stages (--stages, default layout,det,rec,tsr): PicoDet layout detection, DB text detection, CRNN recognition of the
+page's text lines, Lore table structure of the page's tables.
 
 Extra objects on the JSON line: ``roofline`` for the dominant kernel class (3x3 MFMA convolutions, HIP-event
 timed inside the timed region) and ``cpu_baseline`` (the oracle restatement of the same stage on the host
@@ -62,7 +62,7 @@ def cpu_baseline_tsr(lsd, psd, page, box):
                      f"DLA-34+DCN fp32 {t2 - t1:.2f}, decode {t3 - t2:.2f}, processor {t4 - t3:.2f})")
 
 
-def cpu_baseline(sd, pages_np, cfg, csd=None, quads=None, max_lines=12, tsr=None):
+def cpu_baseline(sd, pages_np, cfg, csd=None, quads=None, max_lines=12, tsr=None, layout=None):
     """The oracle (port of the reference CPU path: fp32 torch ops in the reference's op order + numpy/python
     pre/post) on the host cores, batch 1 per call as the reference runs it."""
     from oracle import db_net, db_post, db_pre
@@ -119,6 +119,18 @@ def cpu_baseline(sd, pages_np, cfg, csd=None, quads=None, max_lines=12, tsr=None
         dt += per_line * lines_total
         rec_note = (f"; recognition {per_line:.3f} s/line measured on {nl} lines (crop + CRNN fp32 with a Python-loop LSTM "
                     f"+ CTC), scaled to {lines_total / n:.0f} lines/page")
+    if layout is not None:
+        from oracle import picodet as opico
+        t0 = time.time()
+        for img in pages_np[:n]:
+            xl, sf = opico.picodet_preprocess(img)
+            with torch.no_grad():
+                sc, bx = opico.picodet_forward(layout, torch.from_numpy(xl)[None], 5)
+            opico.picodet_postprocess([s_.numpy() for s_ in sc], [b_.numpy() for b_ in bx], list(img.shape[:2]), sf, [800, 608],
+                                      opico.LABELS["en"])
+        t_lay = (time.time() - t0) / n
+        dt += t_lay * n
+        rec_note += f"; layout (resize + LCNet/CSP-PAN/PicoHead fp32 + numpy NMS) {t_lay:.2f} s/page"
     if tsr is not None:
         lsd, psd, boxes, tables_per_page = tsr
         per_table, note = cpu_baseline_tsr(lsd, psd, pages_np[0], boxes[0][0])
@@ -139,8 +151,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-post", action="store_true", help="device half only (diagnostic; not a valid headline)")
-    ap.add_argument("--stages", default=os.environ.get("PT_BENCH_STAGES", "det,rec,tsr"),
-                    help="comma list of stages in the timed step: det (configs[1]), rec, tsr (Lore)")
+    ap.add_argument("--stages", default=os.environ.get("PT_BENCH_STAGES", "layout,det,rec,tsr"),
+                    help="comma list of stages in the timed step: layout (PicoDet), det (configs[1]), rec, tsr (Lore)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -163,7 +175,7 @@ def main():
     from pdf_table_amd.synth_weights import db_resnet18_state_dict
     from pdf_table_amd.weights import pack_crnn, pack_db_resnet18
     stages = [x for x in args.stages.split(",") if x]
-    assert set(stages) <= {"det", "rec", "tsr"} and stages
+    assert set(stages) <= {"layout", "det", "rec", "tsr"} and stages
 
     eng = HipEngine(local_rank)
     # weights: packed once on rank 0, broadcast over RCCL/xGMI, loaded from device memory everywhere
@@ -186,6 +198,19 @@ def main():
         else:
             eng.load_weights(L.PT_MODEL_CRNN, pack_crnn(csd, x3=False))
         rec = RecStage(eng)
+
+    layout = None
+    if "layout" in stages:
+        from pdf_table_amd.layout_stage import LayoutStage, PicodetConfig
+        from pdf_table_amd.synth_weights import picodet_state_dict
+        from pdf_table_amd.weights import pack_picodet
+        ysd = picodet_state_dict(seed=4, num_classes=5) if rank == 0 or world == 1 else None
+        if world > 1:
+            from pdf_table_amd.dist_utils import broadcast_blob
+            eng.load_weights_device(L.PT_MODEL_PICODET, broadcast_blob(pack_picodet(ysd, 5, x3=False) if rank == 0 else None, dev))
+        else:
+            eng.load_weights(L.PT_MODEL_PICODET, pack_picodet(ysd, 5, x3=False))
+        layout = LayoutStage(eng, PicodetConfig(task_type="en"))
 
     tsr = None
     if "tsr" in stages:
@@ -218,8 +243,8 @@ def main():
         l = made[i % DISTINCT][1]["lines"].astype(np.float64)
         gt_quads.append(np.stack([l[:, 0], l[:, 1], l[:, 2], l[:, 1], l[:, 2], l[:, 3], l[:, 0], l[:, 3]], 1))
     lines_per_page = float(np.mean([len(q) for q in gt_quads]))
-    # Table regions: the layout stage (PicoDet) is not built yet, so the table-structure stage is fed the generator's own
-    # table rectangles (1-2 per page) where the reference feeds it the layout boxes with label "table"
+    # Table regions: the layout net has random-init weights (its boxes are not tables), so the table-structure stage is fed
+    # the generator's own table rectangles (1-2 per page) where the reference feeds it the layout boxes with label "table"
     # (ocr_system_task.py:192-198), grown by 8 px like a detector's box
     table_boxes = []
     for i in range(PAGES_PER_STEP):
@@ -240,29 +265,56 @@ def main():
     nboxes = 0
     ntok = 0
     ncells = 0
+    nlayout = 0
+
+    trace = {} if os.environ.get("PT_BENCH_TRACE") else None
+
+    def tick(name, t0):
+        if trace is not None:
+            trace[name] = trace.get(name, 0.0) + time.perf_counter() - t0
 
     def run(steps, count=False):
-        """software pipeline: device half of step k+1 is enqueued before the host half of step k"""
-        nonlocal nboxes, ntok, ncells
+        """software pipeline: all device work of step k is enqueued before the host halves run (the detection
+        post-process of step k-1 first), so the GPU queue never drains while the host works"""
+        nonlocal nboxes, ntok, ncells, nlayout
         prev = None
         for k in range(steps):
+            t0 = time.perf_counter()
+            lay = layout.forward(pages) if layout is not None else None      # resize, LCNet/CSP-PAN/PicoHead, candidates (async)
             cur = stage.forward(pages, slot=k & 1) if "det" in stages else None
             rec_ids = None
             if rec is not None:
                 rec_ids, _ = rec.ids(pages, gt_quads)          # host quad geometry + one pt_rec_forward (async)
+            tpend = None
+            if tsr is not None:
+                tsr_tables, tsr_metas = tsr.tables((PAGE, PAGE), table_boxes)    # host: one affine map per table
+                tpend = tsr.start(pages, tsr_tables)           # warp, DLA-34+DCN, decode (async)
+            tick("enqueue", t0)
+            t0 = time.perf_counter()
             if prev is not None and not args.no_post:          # host half of the previous step, under this step's GPU work
                 res = stage.boxes(prev[0], prev[1], (PAGE, PAGE), prev[2])
                 if count:
                     nboxes += sum(len(r) for r in res)
-            if tsr is not None:
-                tres = tsr(pages, table_boxes)                 # warp, DLA-34+DCN, decode, processor; quads + logical locations
+            tick("det_post", t0)
+            t0 = time.perf_counter()
+            if lay is not None:
+                lres = layout.finish(lay[0], lay[1], (PAGE, PAGE))      # D2H of the candidates, decode + per-class hard NMS
                 if count:
-                    ncells += sum(len(t["polygons"]) for pg in tres for t in pg)
+                    nlayout += sum(len(r) for r in lres)
+            tick("layout_post", t0)
+            t0 = time.perf_counter()
+            if tsr is not None:
+                tres = tsr.finish(tpend, tsr_metas)            # cell counts D2H, processor, quads + logical locations
+                if count:
+                    ncells += sum(len(t["polygons"]) for t in tres)
+            tick("tsr_finish", t0)
+            t0 = time.perf_counter()
             if rec_ids is not None:
                 from pdf_table_amd.rec_stage import ctc_collapse
                 toks = ctc_collapse(rec_ids.cpu().numpy())     # D2H of int32 [lines, 160] + host collapse
                 if count:
                     ntok += sum(len(t) for t in toks)
+            tick("ctc", t0)
             prev = cur
         if prev is not None and not args.no_post:
             res = stage.boxes(prev[0], prev[1], (PAGE, PAGE), prev[2])
@@ -278,6 +330,8 @@ def main():
     dt = time.perf_counter() - t0
     prof = eng.profile_read()
     eng.profile_enable(False)
+    if trace is not None and rank == 0:
+        print("[bench trace] host seconds over warm-up + timed steps:", {k: round(v, 3) for k, v in trace.items()}, file=sys.stderr)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -312,7 +366,9 @@ def main():
         out = {"metric": "pages/s", "value": value, "unit": "pages/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": ("BASELINE.json configs[1] batched DB text detection (db_pp pre/post around "
+               "config": {"workload": ("PicoDet layout detection (resize to 800x608, LCNet + CSP-PAN + PicoHead, hard NMS) + "
+                                       if "layout" in stages else "")
+                                      + ("BASELINE.json configs[1] batched DB text detection (db_pp pre/post around "
                                        "DB-ResNet18, 1024x1024 synthetic pages -> 960x960 net input, boxes out)"
                                        if "det" in stages else "")
                                       + (" + CRNN text-line recognition of the page's text lines (crop, resize, CRNN, "
@@ -321,21 +377,23 @@ def main():
                                          "DLA-34+DCN, heat-map/corner decode with vertex snapping, 2 x 4-layer processor, "
                                          "quads + logical locations)" if "tsr" in stages else "")
                                       + (" [DEVICE HALF ONLY]" if args.no_post else "")
-                                      + "; the layout stage (PicoDet) is not built yet: table regions and text-line quads come "
-                                        "from the page generator",
+                                      + "; weights are random-init, so the stages are chained by the page generator's ground truth "
+                                        "(table regions for TSR, text-line quads for recognition) instead of each other's outputs",
                           "pages_per_step_per_gpu": PAGES_PER_STEP, "page": [PAGE, PAGE],
                           "stages": stages, "parallelism": f"page-shard x{world}",
                           "text_lines_per_page": lines_per_page if "rec" in stages else 0,
                           "tokens_per_page": ntok / max(1, PAGES_PER_STEP * args.steps),
                           "boxes_per_page": nboxes / max(1, PAGES_PER_STEP * args.steps),
                           "tables_per_page": tables_per_page if "tsr" in stages else 0,
+                          "layout_regions_per_page": nlayout / max(1, PAGES_PER_STEP * args.steps),
                           "table_cells_per_page": ncells / max(1, PAGES_PER_STEP * args.steps),
                           "weights": "seeded random init (reference state_dict layout)"},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, pages_np[:2], cfg, csd if rec is not None else None,
                                                gt_quads[:2] if rec is not None else None,
-                                               tsr=(lsd, psd, table_boxes, tables_per_page) if tsr is not None else None)
+                                               tsr=(lsd, psd, table_boxes, tables_per_page) if tsr is not None else None,
+                                               layout=ysd if layout is not None else None)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

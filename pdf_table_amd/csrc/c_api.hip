@@ -413,19 +413,18 @@ static int rec_microbatch() {
 static int rec_pre_chunk(pt_engine* e, const uint8_t* d_pages, int n_pages, int h, int w, const pt_rec_line* d_lines,
                          const int64_t* h_crop_px, int i0, int nb, bf16_t* d_gray, hipStream_t s) {
   (void)n_pages;
-  std::vector<long long>& off = e->rec_off_host;
-  off.assign((size_t)nb + 1, 0);
-  long long maxpx = 0;
+  long long maxpx = 0, total = 0;
   for (int i = 0; i < nb; ++i) {
     const long long px = h_crop_px[i0 + i] > 0 ? h_crop_px[i0 + i] : 0;
-    off[i + 1] = off[i] + px;
+    total += px;
     if (px > maxpx) maxpx = px;
   }
   int rc;
   if ((rc = ensure(&e->rec_off, &e->rec_off_cap, (size_t)(nb + 1) * sizeof(long long))) != PT_OK) return rc;
-  if ((rc = ensure(&e->rec_crops, &e->rec_crops_cap, (size_t)off[nb] * 3 + 16)) != PT_OK) return rc;
-  PT_HIP_CHECK(hipMemcpyAsync(e->rec_off, off.data(), (size_t)(nb + 1) * sizeof(long long), hipMemcpyHostToDevice, s));
-  PT_HIP_CHECK(hipStreamSynchronize(s));  // `off` is reused by the next chunk
+  if ((rc = ensure(&e->rec_crops, &e->rec_crops_cap, (size_t)total * 3 + 16)) != PT_OK) return rc;
+  // crop start offsets by a device scan over the line records: nothing is staged on the host, so the enqueue does not
+  // have to wait for the stream (a host staging vector would have to outlive the asynchronous copy)
+  if ((rc = pt_launch_rec_offsets(d_lines + i0, nb, reinterpret_cast<long long*>(e->rec_off), s)) != PT_OK) return rc;
   const long long* d_off = reinterpret_cast<const long long*>(e->rec_off);
   {
     PtProfScope ps(e, s, PT_PROF_OTHER, 0, "rec warp");

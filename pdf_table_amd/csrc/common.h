@@ -161,6 +161,7 @@ int pt_launch_box_scores(const float* prob, int n, int H, int W, const float* bo
                          hipStream_t s);
 
 // ---- recognition kernels (rec_kernels.hip) --------------------------------------------------------------
+int pt_launch_rec_offsets(const pt_rec_line* lines, int n, long long* off, hipStream_t s);
 int pt_launch_rec_warp(const uint8_t* pages, int ph, int pw, const pt_rec_line* lines, int n_lines,
                        const long long* pix_off, uint8_t* crops, int max_crop_px, hipStream_t s);
 int pt_launch_rec_resize_gray(const uint8_t* crops, const pt_rec_line* lines, const long long* pix_off, int n_lines,

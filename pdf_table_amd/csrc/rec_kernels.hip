@@ -68,6 +68,43 @@ __global__ __launch_bounds__(256) void rec_warp_kernel(const uint8_t* __restrict
   }
 }
 
+// off[i] = sum_{j < i} max(crop_w_j * crop_h_j, 0), i = 0 .. n: where line i's crop starts in the ragged crop buffer.
+// One workgroup, chunked Hillis-Steele scan in LDS with a running carry (n is a micro-batch: a few thousand lines).
+__global__ __launch_bounds__(1024) void rec_offsets_kernel(const pt_rec_line* __restrict__ lines, int n,
+                                                           long long* __restrict__ off) {
+  __shared__ long long sc[1024];
+  __shared__ long long carry;
+  const int tid = threadIdx.x;
+  if (tid == 0) { carry = 0; off[0] = 0; }
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    long long v = 0;
+    if (i < n) {
+      v = (long long)lines[i].crop_w * (long long)lines[i].crop_h;
+      if (v < 0) v = 0;
+    }
+    sc[tid] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const long long t = tid >= d ? sc[tid - d] : 0;
+      __syncthreads();
+      sc[tid] += t;
+      __syncthreads();
+    }
+    if (i < n) off[i + 1] = carry + sc[tid];
+    __syncthreads();
+    if (tid == 1023) carry += sc[1023];
+    __syncthreads();
+  }
+}
+
+int pt_launch_rec_offsets(const pt_rec_line* lines, int n, long long* off, hipStream_t s) {
+  hipLaunchKernelGGL(rec_offsets_kernel, dim3(1), dim3(1024), 0, s, lines, n, off);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
 int pt_launch_rec_warp(const uint8_t* pages, int ph, int pw, const pt_rec_line* lines, int n_lines,
                        const long long* pix_off, uint8_t* crops, int max_crop_px, hipStream_t s) {
   if (n_lines <= 0) return PT_OK;

@@ -22,6 +22,12 @@ REC_LINE_DTYPE = np.dtype([("minv", np.float64, (9,)), ("page", np.int32), ("cro
                            ("reserved", np.int32)])
 
 
+def _upload(arr: np.ndarray, device) -> torch.Tensor:
+    """small host array -> device through pinned memory, asynchronously: a pageable `.to(device)` would block the host
+    until everything already queued on the stream has run"""
+    return torch.from_numpy(np.ascontiguousarray(arr)).pin_memory().to(device, non_blocking=True)
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
@@ -158,7 +164,7 @@ class HipEngine:
         self._chk(pages, torch.uint8, "pages")
         npg, ph, pw, _ = pages.shape
         n = len(tables)
-        tb = torch.from_numpy(tables.view(np.uint8).reshape(n, -1).copy()).to(self._tdev)
+        tb = _upload(tables.view(np.uint8).reshape(n, -1), self._tdev)
         out = torch.empty((n, inp_h, inp_w, 8 if self.precision == L.PT_PRECISION_BF16X3 else 4), dtype=torch.bfloat16,
                           device=self._tdev)
         L.check(self.lib.pt_tsr_preprocess(self._h, _ptr(pages), npg, ph, pw, _ptr(tb), n, inp_h, inp_w, int(bgr), _ptr(out),
@@ -181,9 +187,10 @@ class HipEngine:
         bufs["reg"] = bufs["reg"][..., :2]
         return bufs
 
-    def tsr_decode(self, heads, wiz_rev: bool = True, vis_thresh: float = 0.2):
+    def tsr_decode(self, heads, wiz_rev: bool = True, vis_thresh: float = 0.2, sync: bool = True):
         """heads: dict of fp32 NHWC maps (hm/st/wh/reg with 8-channel stride or their [..., :k] views, ax/cr 256)
-        -> (counts int32 [n] on the host, dets f32 [n,3000,9], logi f32 [n,3000,256] on the device)."""
+        -> (counts int32 [n] on the host -- or still on the device when sync=False --, dets f32 [n,3000,9],
+        logi f32 [n,3000,256] on the device)."""
         def full(t, c):
             if t.shape[-1] != c or not t.is_contiguous():
                 base = t._base if t._base is not None else t
@@ -199,7 +206,7 @@ class HipEngine:
         L.check(self.lib.pt_tsr_decode(self._h, _ptr(hm), _ptr(st), _ptr(wh), _ptr(ax), _ptr(cr), _ptr(reg), n, h, w,
                                        int(wiz_rev), float(vis_thresh), _ptr(counts), _ptr(dets), _ptr(logi),
                                        self._stream()), "pt_tsr_decode")
-        return counts.cpu().numpy(), dets, logi
+        return (counts.cpu().numpy() if sync else counts), dets, logi
 
     def tsr_process(self, logi: torch.Tensor, dets: torch.Tensor, counts, use_2dpe: bool = False):
         """logic features of pt_tsr_decode -> (logic_axis, stacked_axis) f32 [n,3000,4]; rows [0, counts[i]) valid."""
@@ -240,7 +247,7 @@ class HipEngine:
         lines = np.ascontiguousarray(lines)
         assert lines.dtype == REC_LINE_DTYPE
         px = (lines["crop_w"].astype(np.int64) * lines["crop_h"].astype(np.int64)).clip(min=0)
-        d = torch.from_numpy(lines.view(np.uint8).reshape(-1).copy()).to(self._tdev)
+        d = _upload(lines.view(np.uint8).reshape(-1), self._tdev)
         return d, np.ascontiguousarray(px)
 
     def rec_forward(self, pages: torch.Tensor, lines: np.ndarray, want_maxlogit: bool = True):

@@ -91,11 +91,33 @@ class LayoutStage:
         self.eng = eng
         self.config = config or PicodetConfig()
         self.max_cands = max_cands
+        self._copy_stream = None
+        self._pinned = None
 
     def forward(self, pages: torch.Tensor):
+        """device half (asynchronous): network + candidate compaction on the current stream, then the D2H of the
+        records on a copy stream behind an event -- finish() waits for that copy only, not for whatever else has
+        been queued on the compute stream meanwhile"""
         cfg = self.config
-        return self.eng.layout_forward(pages, cfg.img_height, cfg.img_width, len(cfg.labels),
-                                       thr_lo=cfg.score_threshold - 1e-3, max_cands=self.max_cands)
+        counts, cands = self.eng.layout_forward(pages, cfg.img_height, cfg.img_width, len(cfg.labels),
+                                                thr_lo=cfg.score_threshold - 1e-3, max_cands=self.max_cands)
+        n = counts.shape[0]
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=counts.device)
+        if self._pinned is None or self._pinned[0].shape[0] < n:
+            self._pinned = (torch.empty((n,), dtype=torch.int32).pin_memory(),
+                            torch.empty((n, self.max_cands, L.PT_LAYOUT_CAND_FLOATS), dtype=torch.float32).pin_memory())
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(ready)
+            self._pinned[0][:n].copy_(counts, non_blocking=True)
+            self._pinned[1][:n].copy_(cands, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self._copy_stream)
+        counts.record_stream(self._copy_stream)
+        cands.record_stream(self._copy_stream)
+        return n, done
 
     def decode_page(self, rec: np.ndarray, org_shape) -> List[Dict]:
         """candidate records [k, 48] of one page -> the `bboxs` list of OCRPicodetPostProcessor.__call__"""
@@ -153,11 +175,15 @@ class LayoutStage:
                 for i, c in enumerate(labels)]
 
     def __call__(self, pages: torch.Tensor) -> List[List[Dict]]:
-        counts, cands = self.forward(pages)
-        counts = counts.cpu().numpy()
+        n, done = self.forward(pages)
+        return self.finish(n, done, tuple(pages.shape[1:3]))
+
+    def finish(self, n: int, done, org) -> List[List[Dict]]:
+        """host half: wait for the candidate copy, decode + NMS per page"""
+        done.synchronize()
+        counts = self._pinned[0][:n].numpy().copy()
         if (counts > self.max_cands).any():
             raise RuntimeError(f"layout: {int(counts.max())} candidate anchors on a page exceed max_cands={self.max_cands}")
         kmax = int(counts.max()) if len(counts) else 0
-        rec = cands[:, :max(kmax, 1)].cpu().numpy()
-        org = tuple(pages.shape[1:3])
+        rec = self._pinned[1][:n, :max(kmax, 1)].numpy()
         return [self.decode_page(rec[i, :counts[i]], org) for i in range(len(counts))]

@@ -150,21 +150,35 @@ class TsrStage:
                 metas.append(meta)
         return (np.array(recs, dtype=TSR_TABLE_DTYPE) if recs else np.zeros(0, dtype=TSR_TABLE_DTYPE)), metas
 
-    def run(self, pages: torch.Tensor, tables: np.ndarray, metas: List[np.ndarray]) -> List[Dict]:
-        """pages uint8 [np,h,w,3] on the device -> per table {'polygons' f32 [n,8], 'logi' f32 [n,4] (integer valued),
-        'logic_axis', 'stacked_axis' (unrounded), 'scores'} like TableLorePostProcessor's result dict."""
+    def start(self, pages: torch.Tensor, tables: np.ndarray):
+        """device half 1, nothing synchronises: per micro-batch warp -> DLA-34+DCN -> decode; returns the pending state"""
         cfg = self.config
         inp_h, inp_w = cfg.resolution
-        out: List[Dict] = []
+        pending = []
         for i in range(0, len(tables), self.micro_batch):
             tb = tables[i:i + self.micro_batch]
             x = self.eng.tsr_preprocess(pages, tb, inp_h, inp_w, bgr=self.bgr)
             heads = self.eng.tsr_forward_net(x)
-            counts, dets, logi = self.eng.tsr_decode(heads, wiz_rev=cfg.wiz_rev, vis_thresh=cfg.vis_thresh)
+            counts, dets, logi = self.eng.tsr_decode(heads, wiz_rev=cfg.wiz_rev, vis_thresh=cfg.vis_thresh, sync=False)
+            pending.append((i, len(tb), counts, dets, logi))
+        return pending
+
+    def finish(self, pending, metas: List[np.ndarray]) -> List[Dict]:
+        """device half 2 + host half: cell counts to the host (synchronises), the processor over all cells of a micro-batch,
+        quads back to source pixels, logical rounding -> per table {'polygons' f32 [n,8], 'logi' f32 [n,4] (integer
+        valued), 'logic_axis', 'stacked_axis' (unrounded), 'scores'} like TableLorePostProcessor's result dict."""
+        cfg = self.config
+        out: List[Dict] = []
+        staged = []
+        for (i, nt, counts_d, dets, logi) in pending:
+            counts = counts_d.cpu().numpy()
             logic, stacked = self.eng.tsr_process(logi, dets, counts, use_2dpe=cfg.wiz_2dpe)
-            dets_h = dets.cpu().numpy()
-            logic_h, stacked_h = logic.cpu().numpy(), stacked.cpu().numpy()
-            for k in range(len(tb)):
+            staged.append((i, nt, counts, dets, logic, stacked))
+        for (i, nt, counts, dets, logic, stacked) in staged:
+            nmax = max(1, int(counts.max()) if len(counts) else 1)
+            dets_h = dets[:, :nmax].cpu().numpy()
+            logic_h, stacked_h = logic[:, :nmax].cpu().numpy(), stacked[:, :nmax].cpu().numpy()
+            for k in range(nt):
                 n = int(counts[k])
                 if n == 0:       # LoreModel.forward's empty case (modeling_lore.py:171-173)
                     out.append({"polygons": np.zeros((1, 8), np.float32), "logi": np.zeros((1, 4), np.float32),
@@ -177,12 +191,18 @@ class TsrStage:
                             "stacked_axis": stacked_h[k, :n].copy(), "scores": dets_h[k, :n, 8].copy()})
         return out
 
-    def __call__(self, pages: torch.Tensor, boxes_per_page: Sequence[np.ndarray]) -> List[List[Dict]]:
-        tables, metas = self.tables(tuple(pages.shape[1:3]), boxes_per_page)
-        flat = self.run(pages, tables, metas) if len(tables) else []
+    def run(self, pages: torch.Tensor, tables: np.ndarray, metas: List[np.ndarray]) -> List[Dict]:
+        return self.finish(self.start(pages, tables), metas)
+
+    def regroup(self, flat: List[Dict], boxes_per_page: Sequence[np.ndarray]) -> List[List[Dict]]:
         res, o = [], 0
         for b in boxes_per_page:
             k = len(np.asarray(b).reshape(-1, 4))
             res.append(flat[o:o + k])
             o += k
         return res
+
+    def __call__(self, pages: torch.Tensor, boxes_per_page: Sequence[np.ndarray]) -> List[List[Dict]]:
+        tables, metas = self.tables(tuple(pages.shape[1:3]), boxes_per_page)
+        flat = self.run(pages, tables, metas) if len(tables) else []
+        return self.regroup(flat, boxes_per_page)
