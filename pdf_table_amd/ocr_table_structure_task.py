@@ -111,5 +111,9 @@ class OcrTableStructureTask(BaseInferTask):
             d = {"polygons": r["results"]["polygons"], "logi": r["results"]["logi"]}
             if r["inputs"] is not None:
                 d["inputs"] = r["inputs"]
+            # the reference adds these only when an output_dir is set (show_results, :262-268); they are cheap here
+            for k in ("table_cells", "structure_str_list"):
+                if k in r["results"]:
+                    d[k] = r["results"][k]
             out.append(d)
         return out

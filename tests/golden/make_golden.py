@@ -433,8 +433,55 @@ def gen_picodet():
     print("picodet.npz", os.path.getsize(os.path.join(HERE, "picodet.npz")))
 
 
+def gen_table_html():
+    """cells and structure HTML from the reference's own get_table_cell_from_table_logit / cell_to_html
+    (pdf_table/table_common.py:1643-1663, 578-669; entity/table_entity.py:569-657).  ``CommonUtils.sorted_dict`` (an
+    OrderedDict of ``sorted(items)``, utils/common_utils.py:53-65) is stood in because utils/__init__ cannot be imported."""
+    from collections import OrderedDict
+    import transformers  # noqa: F401
+    stub_env()
+    sys.path.insert(0, os.path.dirname(HERE))
+    from lore_synth import synth_table_grids
+    for sub in ("model", "model/pdf_table", "entity"):
+        name = "pdftable." + sub.replace("/", ".")
+        if name not in sys.modules:
+            _pkg(name, os.path.join(REF_SRC, "pdftable", sub))
+    sys.modules["pdftable.entity"].LineDirectionType = ref_import("pdftable.entity.enum_entity").LineDirectionType
+    pl = types.ModuleType("pdfminer.layout")
+    for nme in ("LTChar", "LTTextLineHorizontal", "LTAnno", "LTImage", "LTTextLineVertical", "LTTextLine"):
+        setattr(pl, nme, type(nme, (), {}))
+    sys.modules["pdfminer.layout"] = pl
+    pu = sys.modules["pdftable.utils"]
+    pu.MathUtils = _Stub("MathUtils")
+
+    class CU:
+        @staticmethod
+        def sorted_dict(label_dict, key=lambda x: x[1], reverse=True):
+            d = OrderedDict()
+            for k, v in sorted(label_dict.items(), key=key, reverse=reverse):
+                d[k] = v
+            return d
+    pu.CommonUtils = CU
+    T = ref_import("pdftable.model.pdf_table.table_common").TableProcessUtils
+    out = {"seed": 11, "cases": []}
+    for polys, logi in synth_table_grids(11):
+        cells = T.get_table_cell_from_table_logit(table_bboxs=polys, logits=logi, save_html_file=None)
+        html, _ = T.cell_to_html(table_cells=cells, first_header=False, add_width=False, add_text=False)
+        s_ = "".join(html)
+        s_ = f"<html><body>{s_}</body></html>".replace("<td >", "<td>").replace("<tbody>", "").replace("</tbody>", "")
+        out["cases"].append({"html": s_, "cells": [[float(c.row_index), float(c.col_index), float(c.row_span), float(c.col_span),
+                                                     float(c.x1), float(c.y1), float(c.x2), float(c.y2),
+                                                     float(c.width_ratio), float(c.height_ratio)] for c in cells]})
+    with open(os.path.join(HERE, "table_html.json"), "w") as f:
+        json.dump(out, f)
+    print("table_html.json", len(out["cases"]), "cases;", out["cases"][0]["html"][:120])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["db", "crnn", "registry", "ctc", "host", "lore_dla", "lore_decode", "lore_processor", "picodet"]
+    which = sys.argv[1:] or ["db", "crnn", "registry", "ctc", "host", "lore_dla", "lore_decode", "lore_processor", "picodet",
+                             "table_html"]
+    if "table_html" in which:
+        gen_table_html()
     if "picodet" in which:
         gen_picodet()
     if "lore_processor" in which:

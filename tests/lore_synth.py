@@ -41,3 +41,40 @@ def synth_pico_heads(seed, target=(160, 128), ncls=5, reg_max=7, strides=(8, 16,
         scores.append(sc)
         boxes.append((rng.standard_normal((1, a, 4 * (reg_max + 1))) * 2.0).astype(np.float32))
     return scores, boxes
+
+
+def synth_table_grids(seed, n_cases=6):
+    """seeded (polygons, logi) cases: regular grids with merged cells, shuffled, plus a few Lore-like irregular ones
+    (duplicate / overlapping logical locations, a row whose cells all span the same number of rows)"""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for ci in range(n_cases):
+        rows, cols = int(rng.integers(2, 7)), int(rng.integers(2, 6))
+        occ = np.zeros((rows, cols), bool)
+        polys, logi = [], []
+        xs = np.cumsum(np.concatenate([[10.0], rng.uniform(40, 120, cols)]))
+        ys = np.cumsum(np.concatenate([[20.0], rng.uniform(18, 40, rows)]))
+        for r in range(rows):
+            for c in range(cols):
+                if occ[r, c]:
+                    continue
+                rs = int(rng.integers(1, 3)) if rng.uniform() < 0.25 else 1
+                cs = int(rng.integers(1, 3)) if rng.uniform() < 0.25 else 1
+                rs, cs = min(rs, rows - r), min(cs, cols - c)
+                if occ[r:r + rs, c:c + cs].any():
+                    rs = cs = 1
+                occ[r:r + rs, c:c + cs] = True
+                x1, y1, x2, y2 = xs[c], ys[r], xs[c + cs], ys[r + rs]
+                j = rng.uniform(-1.5, 1.5, 8)
+                polys.append(np.array([x1, y1, x2, y1, x2, y2, x1, y2]) + j)
+                logi.append([c, c + cs - 1, r, r + rs - 1])
+        polys, logi = np.array(polys, np.float32), np.array(logi, np.float32)
+        if ci == n_cases - 2:                       # every cell of the first row spans two rows
+            m = logi[:, 2] == 0
+            logi[m, 3] = 1
+        if ci == n_cases - 1:                       # duplicated logical location
+            polys = np.concatenate([polys, polys[:2] + 3.0])
+            logi = np.concatenate([logi, logi[:2]])
+        perm = rng.permutation(len(polys))
+        cases.append((polys[perm], logi[perm]))
+    return cases

@@ -92,6 +92,9 @@ def test_table_structure_task_and_pipeline(pipe):
     r = out[0]
     assert r["polygons"].dtype == np.float32 and r["polygons"].shape[1] == 8 and r["logi"].shape == (len(r["polygons"]), 4)
     assert np.array_equal(r["logi"], np.round(r["logi"])) and (r["logi"] >= 0).all()
+    html = r["structure_str_list"][0]
+    assert html.startswith('<html><body><table border="1"><tr>') and html.endswith("</table></body></html>")
+    assert html.count("<td") == len(r["polygons"]) == len(r["table_cells"])
     p2 = OcrTablePipeline(device=0, synthetic_seed=0, table_structure=True)
     p2.table_structure_task = task
     res = p2.predict([page], table_boxes=[tb])

@@ -137,3 +137,22 @@ def test_layout_decode_matches_oracle_postprocess():
         assert np.array_equal(np.array([g["score"] for g in got]), np.array([r["score"] for r in ref]))
     tabs = layout_tables(got, "table", 0.2)
     assert all(t["label"] == "table" for t in tabs) and [t["bbox"][1] for t in tabs] == sorted(t["bbox"][1] for t in tabs)
+
+
+def test_table_html_equals_reference(golden_dir):
+    """cells (order, indices, spans, geometry ratios) and the structure HTML equal the reference's own
+    get_table_cell_from_table_logit + cell_to_html on seeded grids (tests/golden/table_html.json)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from lore_synth import synth_table_grids
+    from pdf_table_amd.table_html import cells_to_structure_html, table_cells_from_logits
+    with open(os.path.join(golden_dir, "table_html.json")) as f:
+        gold = json.load(f)
+    for (polys, logi), ref in zip(synth_table_grids(gold["seed"]), gold["cases"]):
+        cells = table_cells_from_logits(polys, logi)
+        got = [[float(c.row_index), float(c.col_index), float(c.row_span), float(c.col_span), float(c.x1), float(c.y1),
+                float(c.x2), float(c.y2), float(c.width_ratio), float(c.height_ratio)] for c in cells]
+        assert np.allclose(np.array(got), np.array(ref["cells"]), rtol=1e-6, atol=1e-6)
+        assert np.array_equal(np.array(got)[:, :4], np.array(ref["cells"])[:, :4])
+        assert cells_to_structure_html(cells) == ref["html"]
+    assert "colspan" in "".join(r["html"] for r in gold["cases"]) and "rowspan" in "".join(r["html"] for r in gold["cases"])
