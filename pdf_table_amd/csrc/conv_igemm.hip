@@ -721,7 +721,7 @@ struct StemCfg {
 // (ResNet-18 stem: S=2, 64 channels, db_net/dbnet.py:272; DLA-34 base_layer: S=1, 16 channels + zero padding,
 // center_net/modeling_centernet.py:291-294).  K = [7 ky][8 kx][4 c] = 224: an A fragment is two horizontally
 // adjacent input pixels, so at S=1 fragments are only 8-byte aligned and are read as two ds_read_b64.
-template <int S>
+template <int S, int NH>   // NH: 32-column halves of the 64 GEMM outputs that are computed (1 when n_valid <= 32)
 __global__ __launch_bounds__(256, 2) void conv_stem7x7_kernel(ConvK p) {
   using C = StemCfg<S>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -801,7 +801,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_kernel(ConvK p) {
             a = __builtin_bit_cast(bf16x8, av);
           }
           acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
-          acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
+          if (NH == 2) acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
         }
       }
     }
@@ -971,11 +971,11 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   return launch_cfg<1, 2>(e, k, s, flop);
 }
 
-template <int S>
+template <int S, int NH>
 static int launch_stem(pt_engine* e, ConvK& k, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem7x7_kernel<S>),
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem7x7_kernel<S, NH>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, StemCfg<S>::SMEM));
     attr_done = true;
   }
@@ -983,7 +983,7 @@ static int launch_stem(pt_engine* e, ConvK& k, hipStream_t s) {
   const long long nblk = (long long)k.B * k.tiles_x * k.tiles_y;
   PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "stem grid out of range");
   PtProfScope prof(e, s, PT_PROF_STEM, 2.0 * k.B * k.Ho * k.Wo * 64.0 * 147.0, S == 2 ? "stem7x7 s2" : "stem7x7 s1");
-  hipLaunchKernelGGL(conv_stem7x7_kernel<S>, dim3((unsigned)nblk), dim3(256), StemCfg<S>::SMEM, s, k);
+  hipLaunchKernelGGL((conv_stem7x7_kernel<S, NH>), dim3((unsigned)nblk), dim3(256), StemCfg<S>::SMEM, s, k);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
@@ -1002,5 +1002,6 @@ int pt_launch_stem7x7(pt_engine* e, const bf16_t* in, int B, int H, int W, const
   k.Ho = H / stride; k.Wo = W / stride;
   k.out_cstride = split ? 2 * nv : nv; k.out_coff = 0; k.rep = 1; k.shuffle_cout = 0; k.res_mode = 0; k.relu = 1;
   k.split = split; k.out_lo_off = nv; k.n_valid = n_valid;
-  return stride == 2 ? launch_stem<2>(e, k, s) : launch_stem<1>(e, k, s);
+  if (stride == 2) return launch_stem<2, 2>(e, k, s);
+  return (n_valid && n_valid <= 32) ? launch_stem<1, 1>(e, k, s) : launch_stem<1, 2>(e, k, s);
 }

@@ -544,6 +544,95 @@ __global__ __launch_bounds__(256, 2) void dcn_fused64_kernel(const bf16_t* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 convolution for 16 input channels (DLA-34 level0: 16 -> 16 at full resolution, level1: 16 -> 32 stride 2,
+// center_net/modeling_centernet.py:295-298,370-380) + folded BN + ReLU.  The general implicit-GEMM kernel would pad these
+// to 32 -> 64 (4-8x the work and twice the bytes at 1024 x 1024); here K = 9 taps x 16 channels = nine MFMA k-steps:
+//   * activations are stored with their real 16 channels ([hi16 | lo16] in BF16X3 mode)
+//   * the weights of all 9 taps live in registers as B fragments (lane = output channel, N <= 32), no LDS for them
+//   * the input patch of a (TH x 64)-pixel tile is staged in LDS with a 48-byte pixel pitch (conflict-free
+//     ds_read_b128 at stride 1); a wave owns TH/4 rows = two 32-pixel MFMA tiles per row
+// w: bf16 [9][32][16] (output channels >= N zero), [2][9][32][16] = (hi, lo) in BF16X3 mode; bias fp32 [32].
+// ---------------------------------------------------------------------------------------------------------------------
+template <int STRIDE, int SPLIT>
+__global__ __launch_bounds__(256) void conv3x3_c16_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ w,
+                                                           const float* __restrict__ bias, bf16_t* __restrict__ out,
+                                                           int B, int H, int W, int Ho, int Wo, int N, int tiles_x,
+                                                           int tiles_y) {
+  constexpr int TH = STRIDE == 1 ? 8 : 4, TW = (STRIDE == 2 && SPLIT) ? 32 : 64;   // (LDS: <= 64 KB static)
+  constexpr int RPW = TH / 4;                              // output rows per wave
+  constexpr int PH = (TH - 1) * STRIDE + 3, PW = (TW - 1) * STRIDE + 3;
+  constexpr int PITCH = 48;                                // bytes per staged pixel (32 data + 16 pad)
+  constexpr int NP = SPLIT ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) char s_in[NP][PH * PW * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lx = lane & 31, q = lane >> 5;
+  int L = blockIdx.x;
+  const int txi = L % tiles_x;
+  L /= tiles_x;
+  const int tyi = L % tiles_y;
+  const int b = L / tiles_y;
+  const int oy0 = tyi * TH, ox0 = txi * TW, iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
+  const int ics = SPLIT ? 32 : 16;
+  const bf16_t* in_b = in + (size_t)b * H * W * ics;
+  // stage the patch: 2 16-byte pieces per pixel (and per hi / lo plane)
+  for (int i = tid; i < PH * PW * 2 * NP; i += 256) {
+    const int plane = i / (PH * PW * 2), r = i - plane * (PH * PW * 2);
+    const int pix = r >> 1, part = r & 1;
+    const int py = pix / PW, px = pix - py * PW;
+    const int gy = iy0 + py, gx = ix0 + px;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+      v = *reinterpret_cast<const u32x4*>(in_b + ((size_t)gy * W + gx) * ics + plane * 16 + part * 8);
+    *reinterpret_cast<u32x4*>(s_in[plane] + pix * PITCH + part * 16) = v;
+  }
+  // B fragments: lane = output channel lx, k = channels 8q .. 8q+7 of tap t
+  dbf16x8 wh[9], wl[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    wh[t] = *reinterpret_cast<const dbf16x8*>(w + ((size_t)t * 32 + lx) * 16 + q * 8);
+    if (SPLIT) wl[t] = *reinterpret_cast<const dbf16x8*>(w + (size_t)9 * 32 * 16 + ((size_t)t * 32 + lx) * 16 + q * 8);
+  }
+  const float bv = bias[lx];
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int ty = wave * RPW + rr;
+#pragma unroll
+    for (int half = 0; half < TW / 32; ++half) {
+      df32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const int tx = half * 32 + lx;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int off = ((ty * STRIDE + t / 3) * PW + tx * STRIDE + t % 3) * PITCH + q * 16;
+        const dbf16x8 ah = *reinterpret_cast<const dbf16x8*>(s_in[0] + off);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh[t], acc, 0, 0, 0);
+        if (SPLIT) {
+          const dbf16x8 al = *reinterpret_cast<const dbf16x8*>(s_in[NP - 1] + off);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh[t], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl[t], acc, 0, 0, 0);
+        }
+      }
+      // D[row = pixel (r & 3) + 8 (r >> 2) + 4 q][col = channel lx]
+      const int oy = oy0 + ty;
+      if (oy < Ho && lx < N) {
+        const int ocs = SPLIT ? 2 * N : N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ox = ox0 + half * 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
+          if (ox >= Wo) continue;
+          const float v = fmaxf(acc[r] + bv, 0.f);
+          const uint32_t hb = f2bf(v);
+          bf16_t* op = out + (((size_t)b * Ho + oy) * Wo + ox) * ocs + lx;
+          op[0] = (bf16_t)hb;
+          if (SPLIT) op[N] = (bf16_t)f2bf(v - bf2f(hb));
+        }
+      }
+    }
+  }
+}
+
 inline int grid_for(long long total) {
   long long blocks = (total + 255) / 256;
   if (blocks > 256 * 64) blocks = 256 * 64;
@@ -611,4 +700,28 @@ int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf
   }
   if (N % 128 == 0) return launch_dcn_fused<0, 128>(e, x, om, w, bias, out, B, H, W, C, N, relu, s);
   return launch_dcn_fused<0, 64>(e, x, om, w, bias, out, B, H, W, C, N, relu, s);
+}
+
+// in [B,H,W,16] bf16 ([hi16|lo16] when split) -> out [B,Ho,Wo,N] (N = 16 or 32), 3x3 pad 1, stride 1 or 2, bias + ReLU
+int pt_launch_conv3x3_c16(pt_engine* e, const bf16_t* in, const bf16_t* w, const float* bias, bf16_t* out, int B, int H, int W,
+                          int N, int stride, int split, hipStream_t s) {
+  PT_REQUIRE(in && w && bias && out && (N == 16 || N == 32) && (stride == 1 || stride == 2), "conv3x3_c16: bad arguments");
+  const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  const int th = stride == 1 ? 8 : 4;
+  const int tw = (stride == 2 && split) ? 32 : 64;
+  const int tiles_x = (Wo + tw - 1) / tw, tiles_y = (Ho + th - 1) / th;
+  const long long nblk = (long long)B * tiles_x * tiles_y;
+  PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv3x3_c16: grid out of range");
+  char label[48];
+  snprintf(label, sizeof(label), "conv3x3 c16 s%d 16->%d @%dx%d%s", stride, N, Ho, Wo, split ? " x3" : "");
+  PtProfScope prof(e, s, PT_PROF_STEM, 2.0 * B * Ho * Wo * (double)N * 144, label);
+  if (stride == 1) {
+    if (split) hipLaunchKernelGGL((conv3x3_c16_kernel<1, 1>), dim3((unsigned)nblk), dim3(256), 0, s, in, w, bias, out, B, H, W, Ho, Wo, N, tiles_x, tiles_y);
+    else hipLaunchKernelGGL((conv3x3_c16_kernel<1, 0>), dim3((unsigned)nblk), dim3(256), 0, s, in, w, bias, out, B, H, W, Ho, Wo, N, tiles_x, tiles_y);
+  } else {
+    if (split) hipLaunchKernelGGL((conv3x3_c16_kernel<2, 1>), dim3((unsigned)nblk), dim3(256), 0, s, in, w, bias, out, B, H, W, Ho, Wo, N, tiles_x, tiles_y);
+    else hipLaunchKernelGGL((conv3x3_c16_kernel<2, 0>), dim3((unsigned)nblk), dim3(256), 0, s, in, w, bias, out, B, H, W, Ho, Wo, N, tiles_x, tiles_y);
+  }
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
 }

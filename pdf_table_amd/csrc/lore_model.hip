@@ -9,7 +9,7 @@
 // Engine mapping: Conv+BN(+ReLU) folded, residual add in the conv epilogue; Root's conv over a channel concat is
 // evaluated child by child, accumulating through the residual path (no concat tensor); DCN = offset/mask conv (fp32
 // out) -> dcn_im2col_kernel -> 1x1 GEMM over 9*C columns; the `up(x) + skip` add is fused into the up-sampler.
-// 16-channel tensors (base_layer, level0) are stored 32 wide with a zero upper half.
+// The 16-channel levels (base_layer, level0, level1) run on dedicated thin kernels and keep their real 16 channels.
 #include <stdlib.h>
 
 #include <string>
@@ -21,6 +21,8 @@ int pt_launch_dcn_im2col(const bf16_t* x, const float* om, bf16_t* cols, int B, 
                          hipStream_t s);
 int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf16_t* w, const float* bias, bf16_t* out,
                         int B, int H, int W, int C, int N, int split, int relu, hipStream_t s);
+int pt_launch_conv3x3_c16(pt_engine* e, const bf16_t* in, const bf16_t* w, const float* bias, bf16_t* out, int B, int H, int W,
+                          int N, int stride, int split, hipStream_t s);
 int pt_launch_dwconvt_up_add(const bf16_t* in, const float* w, const bf16_t* add, bf16_t* out, int B, int h, int wd,
                              int C, int f, int split, hipStream_t s);
 
@@ -195,21 +197,30 @@ int pt_lore_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, floa
     c.om = reinterpret_cast<float*>(e->arena.take(px4 * 32 * sizeof(float)));
     if (!c.cols || !c.om) c.ok = false;
 
-    T t0 = c.alloc(H, W, 32);
+    T t0 = c.alloc(H, W, 16);
     if (!c.dry && c.ok) {
       const PtTensor* w = c.get(c.x3 ? "base_layer.w3" : "base_layer.w");
       const PtTensor* b = c.get("base_layer.b");
       if (c.rc == PT_OK) {
         const int r = pt_launch_stem7x7(e, x, n, H, W, reinterpret_cast<const bf16_t*>(w->d_ptr),
-                                        reinterpret_cast<const float*>(b->d_ptr), t0.p, c.x3, s, 1, 32);
+                                        reinterpret_cast<const float*>(b->d_ptr), t0.p, c.x3, s, 1, 16);
         if (r != PT_OK) c.rc = r;
       }
     }
     std::vector<T> layers(6);
-    layers[0] = c.alloc(H, W, 32);
-    c.conv(t0, "level0", 64, 3, 1, layers[0], 1, nullptr, 32);
+    layers[0] = c.alloc(H, W, 16);
     layers[1] = c.alloc(H / 2, W / 2, 32);
-    c.conv(layers[0], "level1", 64, 3, 2, layers[1], 1, nullptr, 32);
+    for (int lv1 = 0; lv1 < 2; ++lv1) {
+      const std::string q = lv1 ? "level1" : "level0";
+      const PtTensor* w = c.get(q + (c.x3 ? ".wt3" : ".wt"));
+      const PtTensor* b = c.get(q + ".bt");
+      if (c.rc == PT_OK && !c.dry && c.ok) {
+        const int r = pt_launch_conv3x3_c16(e, lv1 ? layers[0].p : t0.p, reinterpret_cast<const bf16_t*>(w->d_ptr),
+                                            reinterpret_cast<const float*>(b->d_ptr), layers[lv1].p, n, H, W, lv1 ? 32 : 16,
+                                            lv1 ? 2 : 1, c.x3, s);
+        if (r != PT_OK) c.rc = r;
+      }
+    }
     for (int l = 2; l < 6; ++l)
       layers[l] = c.tree("level" + std::to_string(l), lv[l], layers[l - 1], ch[l - 1], ch[l], 2, l > 2, {});
 

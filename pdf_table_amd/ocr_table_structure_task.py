@@ -112,8 +112,9 @@ class OcrTableStructureTask(BaseInferTask):
             if r["inputs"] is not None:
                 d["inputs"] = r["inputs"]
             # the reference adds these only when an output_dir is set (show_results, :262-268); they are cheap here
-            for k in ("table_cells", "structure_str_list"):
-                if k in r["results"]:
-                    d[k] = r["results"][k]
+            if "structure_str_list" in r["results"]:
+                from .table_html import table_cells_from_logits
+                d["structure_str_list"] = r["results"]["structure_str_list"]
+                d["table_cells"] = table_cells_from_logits(d["polygons"], d["logi"])
             out.append(d)
         return out

@@ -92,4 +92,33 @@ def cells_to_structure_html(cells: List[TableCell]) -> str:
 
 
 def structure_html(polygons: np.ndarray, logi: np.ndarray) -> str:
-    return cells_to_structure_html(table_cells_from_logits(polygons, logi))
+    """same string as cells_to_structure_html(table_cells_from_logits(..)) without building the cell objects: the HTML
+    only needs the sorted (row, col, row_span, col_span) of every cell"""
+    lg = np.asarray(logi)
+    n = len(lg)
+    if n == 0:
+        return cells_to_structure_html([])
+    left, right, top, bottom = lg[:, 0], lg[:, 1], lg[:, 2], lg[:, 3]
+    order = np.lexsort((right, bottom, left, top))               # stable: (top, left, bottom, right)
+    row = (top + 1)[order]
+    col = (left + 1)[order]
+    rs = (bottom - top + 1)[order]
+    cs = (right - left + 1)[order]
+    o2 = np.lexsort((col, row))                                  # stable re-sort by (row_index, col_index)
+    row, rs, cs = row[o2], rs[o2].tolist(), cs[o2].tolist()
+    starts = np.flatnonzero(np.r_[True, row[1:] != row[:-1]]).tolist() + [n]
+    out = ['<html><body><table border="1">']
+    for a, b in zip(starts[:-1], starts[1:]):
+        spans = [x for x in rs[a:b] if x > 1]
+        drop = len(spans) == b - a and all(x == spans[0] for x in spans)
+        out.append("<tr>")
+        for k in range(a, b):
+            c_, r_ = cs[k], rs[k]
+            if c_ > 1 or (r_ > 1 and not drop):
+                out.append("<td " + (f'colspan="{int(c_)}" ' if c_ > 1 else "") + (f'rowspan="{int(r_)}" ' if r_ > 1 and not drop else "")
+                           + "></td>")
+            else:
+                out.append("<td></td>")
+        out.append("</tr>")
+    out.append("</table></body></html>")
+    return "".join(out)

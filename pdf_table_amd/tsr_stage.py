@@ -16,7 +16,7 @@ import torch
 
 from . import lib as L
 from .engine import TSR_TABLE_DTYPE, HipEngine
-from .table_html import cells_to_structure_html, table_cells_from_logits
+from .table_html import structure_html
 
 __all__ = ["LoreConfig", "TsrStage", "lore_geometry", "affine_from_center_scale", "invert_affine",
            "transform_quads", "process_logic_output"]
@@ -130,7 +130,7 @@ class TsrStage:
         self.config = config or LoreConfig()
         self.micro_batch = micro_batch
         self.bgr = bgr
-        self.with_html = with_html      # also emit 'table_cells' and 'structure_str_list' (show_results :292-303)
+        self.with_html = with_html      # also emit 'structure_str_list' (show_results :292-303)
 
     def tables(self, page_shape: Tuple[int, int], boxes_per_page: Sequence[np.ndarray]):
         """integer table boxes [k,4] (x1,y1,x2,y2) per page, cropped like crop_image_by_box
@@ -192,9 +192,8 @@ class TsrStage:
                 r = {"polygons": transform_quads(dets_h[k, :n, :8], metas[i + k]),
                      "logi": process_logic_output(final), "logic_axis": logic_h[k, :n].copy(),
                      "stacked_axis": stacked_h[k, :n].copy(), "scores": dets_h[k, :n, 8].copy()}
-                if self.with_html:
-                    r["table_cells"] = table_cells_from_logits(r["polygons"], r["logi"])
-                    r["structure_str_list"] = [cells_to_structure_html(r["table_cells"])]
+                if self.with_html:       # table_html.table_cells_from_logits(polygons, logi) gives the cell objects on demand
+                    r["structure_str_list"] = [structure_html(r["polygons"], r["logi"])]
                 out.append(r)
         return out
 

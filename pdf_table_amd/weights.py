@@ -209,8 +209,7 @@ def _pad_conv(w: torch.Tensor, b: torch.Tensor, n_to: int, cin_to: int):
 def pack_lore_dla34(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
     """``DLASeg`` state_dict -> blob for PT_MODEL_LORE_DLA34.
 
-    * every Conv->BN pair folded; 16-channel tensors are stored 32 wide (upper half zero), so the thin levels
-      pad Cin to 32 and N to 64 (the kernel stores only ``n_valid`` channels);
+    * every Conv->BN pair folded; the 16-input-channel levels (level0, level1) are packed tap-major for the thin kernel;
     * Root 1x1 convs over a channel concat are split per child (``root.c<i>``): the engine accumulates them through
       the residual path instead of materialising the concat;
     * DCN: ``.om`` = the 27-channel offset/mask conv padded to 64 outputs (fp32 out), ``.dcn`` = the deformable conv
@@ -227,8 +226,18 @@ def pack_lore_dla34(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
         sh, sl = split_bf16(stem)
         bl.add("base_layer.w3", np.stack([to_bf16_bits(sh).reshape(64, 224), to_bf16_bits(sl).reshape(64, 224)]), "bf16")
     bl.add("base_layer.b", bp.numpy(), "f32")
-    bl.add_conv("level0", *_pad_conv(*fold_conv_bn(sd, "base.level0.0", "base.level0.1"), 64, 32))
-    bl.add_conv("level1", *_pad_conv(*fold_conv_bn(sd, "base.level1.0", "base.level1.1"), 64, 32))
+    for name, key in (("level0", "base.level0"), ("level1", "base.level1")):
+        # thin 16-input-channel levels: [9 taps][32 outputs (zero padded)][16 channels] for conv3x3_c16_kernel
+        w, b = fold_conv_bn(sd, key + ".0", key + ".1")
+        wt = torch.zeros(9, 32, 16)
+        wt[:, :w.shape[0]] = w.permute(2, 3, 0, 1).reshape(9, w.shape[0], 16)
+        bt = torch.zeros(32)
+        bt[:w.shape[0]] = b
+        bl.add(name + ".wt", to_bf16_bits(wt), "bf16")
+        if x3:
+            hi, lo = split_bf16(wt)
+            bl.add(name + ".wt3", np.stack([to_bf16_bits(hi), to_bf16_bits(lo)]), "bf16")
+        bl.add(name + ".bt", bt.numpy(), "f32")
 
     def block(p, q):
         bl.add_conv(q + ".conv1", *fold_conv_bn(sd, p + ".conv1", p + ".bn1"))

@@ -145,7 +145,7 @@ def test_table_html_equals_reference(golden_dir):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from lore_synth import synth_table_grids
-    from pdf_table_amd.table_html import cells_to_structure_html, table_cells_from_logits
+    from pdf_table_amd.table_html import cells_to_structure_html, structure_html, table_cells_from_logits
     with open(os.path.join(golden_dir, "table_html.json")) as f:
         gold = json.load(f)
     for (polys, logi), ref in zip(synth_table_grids(gold["seed"]), gold["cases"]):
@@ -155,4 +155,5 @@ def test_table_html_equals_reference(golden_dir):
         assert np.allclose(np.array(got), np.array(ref["cells"]), rtol=1e-6, atol=1e-6)
         assert np.array_equal(np.array(got)[:, :4], np.array(ref["cells"])[:, :4])
         assert cells_to_structure_html(cells) == ref["html"]
+        assert structure_html(polys, logi) == ref["html"]          # the fast path used by TsrStage
     assert "colspan" in "".join(r["html"] for r in gold["cases"]) and "rowspan" in "".join(r["html"] for r in gold["cases"])
