@@ -57,6 +57,8 @@ struct ConvK {
   int n_valid;
   float* out_f32;
   const float* res_f32;   // fp32 residual with the layout of out_f32 (transformer residual stream), added before ReLU
+  int gemm_nt;            // gemm1x1_kernel: number of 128-wide column tiles (n_tiles stays N / 64 for the arg-max partials)
+  long long m_flat;       // > 0: the (Ho x 32) geometry is a flat list of m_flat pixels (gemm1x1_kernel); rows beyond it are skipped
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
@@ -103,6 +105,7 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
     const int ty = pix / TW, tx = pix % TW;
     const int oy = oy0 + ty, ox = ox0 + tx;
     if (oy >= p.Ho || ox >= p.Wo) continue;
+    if (EXTRAS && p.m_flat && (long long)oy * p.Wo + ox >= p.m_flat) continue;
     const f32x4* sp = reinterpret_cast<const f32x4*>(stage + pix * 64 + cg * 8);
     f32x4 v0 = sp[0], v1 = sp[1];
     const int n = n0 + cg * 8;
@@ -700,6 +703,115 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma16_kernel(ConvK p, const bf
 // K is laid out [r=7][s=8][c=4] = 224 (tap s=7 and channel 3 carry zero weights), so that one MFMA
 // k-step (16) = 4 horizontally adjacent pixels x 4 channels = 32 contiguous bytes of the image row.
 // ---------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------------------
+// 1x1 convolution as a plain GEMM over the flat pixel list, for large M: 256 pixels x 128 output channels per workgroup
+// (8 waves, each 64 x 64 = 2 x 2 MFMA tiles), K walked in 64-channel chunks (144-byte LDS rows), next chunk prefetched to
+// VGPRs.  Twice the arithmetic intensity of the 128 x 64 tiles of conv_igemm_kernel<1,1> (85 vs 43 FLOP per L2 byte), which
+// is what the CRNN classifier (M = lines x 160, K = 512, N = 7680), the LSTM input projections and the Lore / PicoDet
+// point-wise layers need.  Same weight tiling ([N/64][K/32][64][32]) and the same epilogue_store (two 64-column passes).
+// ---------------------------------------------------------------------------------------------------------------------
+struct GemmCfg {
+  static constexpr int TM = 256, TN = 128, NTHR = 512, ROW = 144;
+  static constexpr int A_BYTES = TM * ROW, W_BYTES = TN * ROW;      // 36864 + 18432
+  static constexpr int STAGE_BYTES = TM * 64 * 4;                   // 65536: one 64-column half of the tile in fp32
+  static constexpr int SMEM = STAGE_BYTES > (A_BYTES + W_BYTES) ? STAGE_BYTES : (A_BYTES + W_BYTES);
+};
+
+__global__ __launch_bounds__(512, 2) void gemm1x1_kernel(ConvK p) {
+  using C = GemmCfg;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_a = smem;
+  char* s_w = smem + C::A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, q = lane >> 5;
+  const int wm = wave & 3, wn = wave >> 2;
+  int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = L % p.gemm_nt;                 // 128-wide column tile
+  const long long m0 = (long long)(L / p.gemm_nt) * C::TM;
+  const int nchunks = p.split ? 3 * (p.Cin >> 6) : (p.Cin >> 6);
+  const int in_cs = p.split ? 2 * p.Cin : p.Cin;
+  const int nk32 = p.split ? 3 * (p.Cin >> 5) : (p.Cin >> 5);          // 32-channel weight chunks per 64-row tile
+  const bf16_t* wt = p.w + (size_t)(nt * 2) * nk32 * (64 * 32);
+
+  u32x4 ra[4], rw[2];
+  auto prefetch = [&](int chunk) {
+    int c0 = chunk << 6;
+    if (c0 >= in_cs) c0 -= in_cs;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = tid + j * 512, row = idx >> 3, part = idx & 7;
+      const long long m = m0 + row;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (m < p.m_flat) v = *reinterpret_cast<const u32x4*>(p.in + (size_t)m * in_cs + c0 + part * 8);
+      ra[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = tid + j * 512, row = idx >> 3, part = idx & 7;       // row 0..127, part 0..7 (0-3: chunk 2c, 4-7: 2c+1)
+      rw[j] = *reinterpret_cast<const u32x4*>(wt + (size_t)(row >> 6) * nk32 * (64 * 32) +
+                                              (size_t)(2 * chunk + (part >> 2)) * (64 * 32) + (row & 63) * 32 + (part & 3) * 8);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = tid + j * 512;
+      *reinterpret_cast<u32x4*>(s_a + (idx >> 3) * C::ROW + (idx & 7) * 16) = ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = tid + j * 512;
+      *reinterpret_cast<u32x4*>(s_w + (idx >> 3) * C::ROW + (idx & 7) * 16) = rw[j];
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  const char* a_rd = s_a + (wm * 64 + lx) * C::ROW + q * 16;
+  const char* b_rd = s_w + (wn * 64 + lx) * C::ROW + q * 16;
+  prefetch(0);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (c + 1 < nchunks) prefetch(c + 1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(a_rd + kk * 32);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(a_rd + 32 * C::ROW + kk * 32);
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(b_rd + kk * 32);
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(b_rd + 32 * C::ROW + kk * 32);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+  // ---- epilogue: the two 64-column halves one after the other through the fp32 stage [256 pixels][64]
+  float* stage = reinterpret_cast<float*>(smem);
+  const int oy0 = (int)(m0 >> 5);
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();
+    if (wn == h) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
+            stage[row * 64 + n * 32 + lx] = acc[m][n][r];
+          }
+    }
+    __syncthreads();
+    epilogue_store<8, 32, 512>(p, stage, tid, 0, oy0, 0, nt * 128 + h * 64);
+  }
+}
+
 template <int S>
 struct StemCfg {
   static constexpr int TH = 8, TW = 32;
@@ -920,6 +1032,43 @@ static int launch_dma(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   return PT_OK;
 }
 
+// PT_GEMM1X1=1 routes large 1x1 convolutions to gemm1x1_kernel.  Off by default: measured on MI355X it is no faster than
+// conv_igemm_kernel<1,1> (classifier 512 -> 7680, M = 655 k: 10.48 vs 10.55 ms; 512 -> 2048: 3.14 vs 2.69 ms) -- both sit
+// at ~500 TFLOP/s because one K-chunk of prefetch (~60 KB in flight per CU) does not cover the loaded L2 latency, not
+// because of bytes per FLOP; kept for the next round's deeper-pipelined version.
+static int gemm_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* s = getenv("PT_GEMM1X1");
+    v = s ? atoi(s) : 0;
+  }
+  return v;
+}
+
+static int launch_gemm1x1(pt_engine* e, ConvK k, hipStream_t s, double flop) {
+  using C = GemmCfg;
+  static bool attr_done = false;
+  if (!attr_done) {
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1x1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     C::SMEM));
+    attr_done = true;
+  }
+  const long long M = (long long)k.B * k.Ho * k.Wo;
+  char label[48];
+  snprintf(label, sizeof(label), "gemm1x1 %d->%d M=%lld%s", k.Cin, k.N, M, k.split ? " x3" : "");
+  // flat geometry for epilogue_store: one "image" of ceil(M / 32) rows x 32 pixels
+  k.m_flat = M;
+  k.B = 1; k.Ho = (int)((M + 31) / 32); k.Wo = 32;
+  k.n_tiles = k.N / 64;
+  k.gemm_nt = k.N / C::TN;
+  const long long nblk = ((M + C::TM - 1) / C::TM) * k.gemm_nt;
+  PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "gemm grid out of range (%lld blocks)", nblk);
+  PtProfScope prof(e, s, PT_PROF_CONV1X1, flop, label);
+  hipLaunchKernelGGL(gemm1x1_kernel, dim3((unsigned)nblk), dim3(C::NTHR), C::SMEM, s, k);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
 int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   PT_REQUIRE(d.in && d.w && d.bias && (d.out || d.out_f32 || d.head_w || d.argmax_part), "conv: null pointer");
   PT_REQUIRE(d.Cin % 32 == 0 && d.Cin > 0, "conv: Cin=%d must be a positive multiple of 32", d.Cin);
@@ -967,6 +1116,9 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   if (d.ks == 3 && d.stride == 1 && k.Ho <= 4 && k.Wo > 32) return launch_cfg<3, 1, 1>(e, k, s, flop);
   if (d.ks == 3 && d.stride == 1) return launch_cfg<3, 1>(e, k, s, flop);
   if (d.ks == 3 && d.stride == 2) return launch_cfg<3, 2>(e, k, s, flop);
+  if (d.ks == 1 && d.stride == 1 && gemm_variant() && d.Cin % 64 == 0 && d.N % 128 == 0 && d.rep == 1 && !d.shuffle_cout &&
+      !d.head_w && k.res_mode != 2 && (long long)k.B * k.Ho * k.Wo >= 16384)
+    return launch_gemm1x1(e, k, s, flop);
   if (d.ks == 1 && d.stride == 1) return launch_cfg<1, 1>(e, k, s, flop);
   return launch_cfg<1, 2>(e, k, s, flop);
 }
