@@ -57,6 +57,7 @@ struct ConvK {
   int n_valid;
   float* out_f32;
   const float* res_f32;   // fp32 residual with the layout of out_f32 (transformer residual stream), added before ReLU
+  int n_group;            // > 0: column tiles are walked in groups of n_group so that a group's weights stay in one XCD's L2
   int gemm_nt;            // gemm1x1_kernel: number of 128-wide column tiles (n_tiles stays N / 64 for the arg-max partials)
   long long m_flat;       // > 0: the (Ho x 32) geometry is a flat list of m_flat pixels (gemm1x1_kernel); rows beyond it are skipped
 };
@@ -74,6 +75,21 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + (id >> 3);
+}
+
+// Block order for wide-N layers: (column group, spatial tile, column inside the group).  With all N tiles of a spatial
+// tile consecutive, a 512 -> 7680 classifier streams its whole 7.8 MB weight matrix through every XCD's 4 MB L2 once per
+// spatial tile (20 GB per launch); walking the columns in groups whose weights fit L2 re-reads the activations a few
+// times instead (n_tiles / group) and keeps the weights resident.
+__device__ __forceinline__ void tile_order(int L, int n_tiles, int n_group, int& nt, int& sp) {
+  if (n_group <= 0 || n_group >= n_tiles) { nt = L % n_tiles; sp = L / n_tiles; return; }
+  const int spatial = gridDim.x / n_tiles;
+  const int per_group = n_group * spatial;
+  const int ng = L / per_group;
+  const int rem = L - ng * per_group;
+  const int gcur = min(n_group, n_tiles - ng * n_group);
+  sp = rem / gcur;
+  nt = ng * n_group + rem - sp * gcur;
 }
 
 // Shared epilogue: fp32 tile [TH*32 pixels][64 ch] in LDS -> bias/residual/ReLU -> bf16 stores.
@@ -262,9 +278,8 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
   const int lane = tid & 63, wave = tid >> 6;
   const int lx = lane & 31, q = lane >> 5;
 
-  int L = xcd_remap(blockIdx.x, gridDim.x);
-  const int nt = L % p.n_tiles;
-  L /= p.n_tiles;
+  int L = xcd_remap(blockIdx.x, gridDim.x), nt;
+  tile_order(L, p.n_tiles, p.n_group, nt, L);
   const int txi = L % p.tiles_x;
   L /= p.tiles_x;
   const int tyi = L % p.tiles_y;
@@ -725,9 +740,9 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_kernel(ConvK p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lx = lane & 31, q = lane >> 5;
   const int wm = wave & 3, wn = wave >> 2;
-  int L = xcd_remap(blockIdx.x, gridDim.x);
-  const int nt = L % p.gemm_nt;                 // 128-wide column tile
-  const long long m0 = (long long)(L / p.gemm_nt) * C::TM;
+  int L = xcd_remap(blockIdx.x, gridDim.x), nt;  // nt: 128-wide column tile
+  tile_order(L, p.gemm_nt, p.n_group, nt, L);
+  const long long m0 = (long long)L * C::TM;
   const int nchunks = p.split ? 3 * (p.Cin >> 6) : (p.Cin >> 6);
   const int in_cs = p.split ? 2 * p.Cin : p.Cin;
   const int nk32 = p.split ? 3 * (p.Cin >> 5) : (p.Cin >> 5);          // 32-channel weight chunks per 64-row tile
@@ -792,6 +807,121 @@ __global__ __launch_bounds__(512, 2) void gemm1x1_kernel(ConvK p) {
     }
   }
   // ---- epilogue: the two 64-column halves one after the other through the fp32 stage [256 pixels][64]
+  float* stage = reinterpret_cast<float*>(smem);
+  const int oy0 = (int)(m0 >> 5);
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();
+    if (wn == h) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
+            stage[row * 64 + n * 32 + lx] = acc[m][n][r];
+          }
+    }
+    __syncthreads();
+    epilogue_store<8, 32, 512>(p, stage, tid, 0, oy0, 0, nt * 128 + h * 64);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same 256 x 128 GEMM with an LDS-DMA ring: K in 32-channel chunks, each a 24 KB stage (A 256 x 64 B + W 128 x 64 B,
+// un-padded rows, 16-byte slots XOR-swizzled by (row >> 2) & 3 on the DMA source address and again on the ds_read
+// address), RING stages deep.  Every wave issues its 3 global_load_lds of stage c + RING - 1 right after the barrier of
+// iteration c, so RING - 1 stages (96 KB at RING = 5) are in flight while one is multiplied -- the register-staged
+// kernels keep one chunk in flight and are bound by the loaded L2 latency on K-short, 1x1-type layers.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int RING>
+__global__ __launch_bounds__(512, 1) void gemm1x1_dma_kernel(ConvK p, const bf16_t* __restrict__ zero_page) {
+  constexpr int STAGE = 24576;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lx = lane & 31, q = lane >> 5;
+  const int wm = wave & 3, wn = wave >> 2;
+  int L = xcd_remap(blockIdx.x, gridDim.x), nt;
+  tile_order(L, p.gemm_nt, p.n_group, nt, L);
+  const long long m0 = (long long)L * 256;
+  const int nchunks = p.split ? 3 * (p.Cin >> 5) : (p.Cin >> 5);
+  const int in_cs = p.split ? 2 * p.Cin : p.Cin;
+  const bf16_t* wt = p.w + (size_t)(nt * 2) * nchunks * (64 * 32);
+
+  // DMA instruction k = wave + 8 j (j = 0, 1: A rows 16 k .. 16 k + 15; j = 2: W rows 16 (k - 16) ..)
+  const bf16_t* src_a[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = 16 * (wave + 8 * j) + (lane >> 2);
+    const int slot = (lane & 3) ^ ((row >> 2) & 3);
+    const long long m = m0 + row;
+    src_a[j] = m < p.m_flat ? p.in + (size_t)m * in_cs + slot * 8 : zero_page;
+  }
+  const bool a_live[2] = {m0 + 16 * wave + (lane >> 2) < p.m_flat, m0 + 16 * (wave + 8) + (lane >> 2) < p.m_flat};
+  int src_w;
+  {
+    const int row = 16 * wave + (lane >> 2);              // 0 .. 127
+    const int slot = (lane & 3) ^ ((row >> 2) & 3);
+    src_w = (row >> 6) * nchunks * (64 * 32) + (row & 63) * 32 + slot * 8;
+  }
+  auto issue = [&](int chunk, int slot_i) {
+    int c0 = chunk << 5;
+    if (c0 >= in_cs) c0 -= in_cs;
+    char* st = smem + slot_i * STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_a[j] + (a_live[j] ? c0 : 0)),
+                                       (__attribute__((address_space(3))) void*)(st + (wave + 8 * j) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt + (size_t)chunk * (64 * 32) + src_w),
+                                     (__attribute__((address_space(3))) void*)(st + 16384 + wave * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  // fragment addresses inside a stage (row r, 16-byte slot s -> r * 64 + ((s ^ ((r >> 2) & 3)) << 4))
+  int a_off[2][2], b_off[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ra = wm * 64 + t * 32 + lx, rb = wn * 64 + t * 32 + lx;
+      a_off[t][kk] = ra * 64 + (((kk * 2 + q) ^ ((ra >> 2) & 3)) << 4);
+      b_off[t][kk] = 16384 + rb * 64 + (((kk * 2 + q) ^ ((rb >> 2) & 3)) << 4);
+    }
+
+#pragma unroll
+  for (int st = 0; st < RING - 1; ++st)
+    if (st < nchunks) issue(st, st);
+  for (int c = 0; c < nchunks; ++c) {
+    if (c + RING - 2 < nchunks) {
+      // stages c+1 .. c+RING-2 (3 DMA instructions each) may still be in flight
+      if (RING == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (RING == 5) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (c + RING - 1 < nchunks) issue(c + RING - 1, (c + RING - 1) % RING);
+    const char* st = smem + (c % RING) * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(st + a_off[0][kk]);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(st + a_off[1][kk]);
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(st + b_off[0][kk]);
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(st + b_off[1][kk]);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
   float* stage = reinterpret_cast<float*>(smem);
   const int oy0 = (int)(m0 >> 5);
   for (int h = 0; h < 2; ++h) {
@@ -1032,10 +1162,12 @@ static int launch_dma(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   return PT_OK;
 }
 
-// PT_GEMM1X1=1 routes large 1x1 convolutions to gemm1x1_kernel.  Off by default: measured on MI355X it is no faster than
-// conv_igemm_kernel<1,1> (classifier 512 -> 7680, M = 655 k: 10.48 vs 10.55 ms; 512 -> 2048: 3.14 vs 2.69 ms) -- both sit
-// at ~500 TFLOP/s because one K-chunk of prefetch (~60 KB in flight per CU) does not cover the loaded L2 latency, not
-// because of bytes per FLOP; kept for the next round's deeper-pipelined version.
+// PT_GEMM1X1=1 / 2 route large 1x1 convolutions to gemm1x1_kernel / gemm1x1_dma_kernel (256 x 128 tiles; register-staged or
+// a 5-stage LDS-DMA ring).  Off by default: on MI355X neither beats conv_igemm_kernel<1,1> (classifier 512 -> 7680,
+// M = 655 k: 10.5 / 11.7 ms vs 9.9 ms) -- all three sit at ~500 TFLOP/s.  Ablation of the ring kernel (timing only): without
+// DMA 9.3 ms, without epilogue 7.5 ms, without both 5.2 ms (ideal 2.7 ms): the fp32-through-LDS epilogue costs ~35 % of a
+// K = 512 tile and the fragment loop itself runs at ~60 %; a register-level bf16 epilogue is the next step, not more
+// prefetch.  The L2-aware column grouping (tile_order) is worth 4 % on the classifier and is on.
 static int gemm_variant() {
   static int v = -1;
   if (v < 0) {
@@ -1061,9 +1193,27 @@ static int launch_gemm1x1(pt_engine* e, ConvK k, hipStream_t s, double flop) {
   k.B = 1; k.Ho = (int)((M + 31) / 32); k.Wo = 32;
   k.n_tiles = k.N / 64;
   k.gemm_nt = k.N / C::TN;
+  k.n_group = k.n_group / 2;        // groups were sized in 64-column tiles
   const long long nblk = ((M + C::TM - 1) / C::TM) * k.gemm_nt;
   PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "gemm grid out of range (%lld blocks)", nblk);
   PtProfScope prof(e, s, PT_PROF_CONV1X1, flop, label);
+  if (gemm_variant() >= 2) {
+    constexpr int RING = 5;
+    static bool attr2 = false;
+    if (!attr2) {
+      PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1x1_dma_kernel<RING>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, RING * 24576));
+      attr2 = true;
+    }
+    if (!e->zero_page) {
+      PT_HIP_CHECK(hipMalloc(&e->zero_page, 8192));
+      PT_HIP_CHECK(hipMemset(e->zero_page, 0, 8192));
+    }
+    hipLaunchKernelGGL(gemm1x1_dma_kernel<RING>, dim3((unsigned)nblk), dim3(512), RING * 24576, s, k,
+                       reinterpret_cast<const bf16_t*>(e->zero_page));
+    PT_HIP_CHECK(hipGetLastError());
+    return PT_OK;
+  }
   hipLaunchKernelGGL(gemm1x1_kernel, dim3((unsigned)nblk), dim3(C::NTHR), C::SMEM, s, k);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
@@ -1116,6 +1266,15 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   if (d.ks == 3 && d.stride == 1 && k.Ho <= 4 && k.Wo > 32) return launch_cfg<3, 1, 1>(e, k, s, flop);
   if (d.ks == 3 && d.stride == 1) return launch_cfg<3, 1>(e, k, s, flop);
   if (d.ks == 3 && d.stride == 2) return launch_cfg<3, 2>(e, k, s, flop);
+  if (d.ks == 1) {
+    // column tiles per group: ~2 MB of weights (half of an XCD's L2); PT_N_GROUP overrides (0 = off)
+    static int ng_env = -2;
+    if (ng_env == -2) { const char* s_ = getenv("PT_N_GROUP"); ng_env = s_ ? atoi(s_) : -1; }
+    const long long tile_bytes = 64ll * d.Cin * 2 * (d.split ? 3 : 1);
+    int g = ng_env >= 0 ? ng_env : (int)((2ll << 20) / tile_bytes);
+    if (g < 1) g = ng_env == 0 ? 0 : 1;
+    k.n_group = g;
+  }
   if (d.ks == 1 && d.stride == 1 && gemm_variant() && d.Cin % 64 == 0 && d.N % 128 == 0 && d.rep == 1 && !d.shuffle_cout &&
       !d.head_w && k.res_mode != 2 && (long long)k.B * k.Ho * k.Wo >= 16384)
     return launch_gemm1x1(e, k, s, flop);
