@@ -61,6 +61,7 @@ enum {
   PT_MODEL_CRNN = 2,        /* crnn/modeling_crnn.py:36-113 */
   PT_MODEL_LORE_DLA34 = 3,  /* lore/lore_dla_34.py:137-206 (DLASeg on dla34 + DCN), modeling_lore.py:88-95 */
   PT_MODEL_LORE_PROCESSOR = 4, /* lore/lore_processor.py:399-514 (LoreProcessModel) */
+  PT_MODEL_LORE_RESNET18 = 6, /* lore/lore_detector.py:155-389 (LoreDetectModel, the 'wireless' detector) */
   PT_MODEL_PICODET = 5,     /* picodet/lcnet.py:159-259 + csp_pan.py:233-347 + pico_head.py:966-1160 (assumed config) */
 };
 int pt_weights_load(pt_engine* e, int model_kind, const void* h_blob, size_t nbytes);
@@ -224,6 +225,11 @@ int pt_tsr_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int
 #define PT_TSR_CS_FEAT 256
 int pt_tsr_forward_net(pt_engine* e, const uint16_t* d_input_bf16, int n, int H, int W, float* d_hm, float* d_st,
                        float* d_wh, float* d_ax, float* d_cr, float* d_reg, pt_stream stream);
+
+/* Same contract for the 'wireless' detector (LoreDetectModel.forward, lore/lore_detector.py:353-389; weights
+ * PT_MODEL_LORE_RESNET18); H, W multiples of 64. */
+int pt_tsr_forward_net_wireless(pt_engine* e, const uint16_t* d_input_bf16, int n, int H, int W, float* d_hm, float* d_st,
+                                float* d_wh, float* d_ax, float* d_cr, float* d_reg, pt_stream stream);
 
 /* Heat-map + corner-point decode (process_detect_output, lore/lineless_table_process.py:592-655: corner_decode :97-124,
  * ctdet_4ps_decode :127-267 incl. the wiz_rev vertex snapping :188-236, logi = ax + cr_feat :648) for n tables.

@@ -200,9 +200,32 @@ def affine_from_center_scale(center, scale, out_size, inv: bool = False) -> np.n
     return get_affine_transform_3pt(dst, src) if inv else get_affine_transform_3pt(src, dst)
 
 
-def transform_preds(coords: np.ndarray, center, scale, out_size) -> np.ndarray:
-    """[n,2] feature-map points -> source pixels: float64 matrix times float32 homogeneous point, per point (:471-476)."""
-    t = affine_from_center_scale(center, scale, out_size, inv=True)
+def affine_upper_left(center, scale, out_size, inv: bool = False) -> np.ndarray:
+    """get_affine_transform_upper_left (:441-468): anchors (cx, cy) -> (0, 0) and, when cx >= cy, (cx, scale) -> (0, out_w)
+    (otherwise (scale, cy) -> (out_w, 0)), third point perpendicular."""
+    sc = np.array([scale, scale], dtype=np.float32)
+    src = np.zeros((3, 2), np.float32)
+    dst = np.zeros((3, 2), np.float32)
+    src[0] = center
+    dst[0] = [0, 0]
+    if center[0] < center[1]:
+        src[1] = [sc[0], center[1]]
+        dst[1] = [out_size[0], 0]
+    else:
+        src[1] = [center[0], sc[0]]
+        dst[1] = [0, out_size[0]]
+
+    def third(a, b):
+        d = a - b
+        return b + np.array([-d[1], d[0]], dtype=np.float32)
+    src[2] = third(src[0], src[1])
+    dst[2] = third(dst[0], dst[1])
+    return get_affine_transform_3pt(dst, src) if inv else get_affine_transform_3pt(src, dst)
+
+
+def transform_preds(coords: np.ndarray, center, scale, out_size, upper_left: bool = False) -> np.ndarray:
+    """[n,2] feature-map points -> source pixels: float64 matrix times float32 homogeneous point, per point (:471-486)."""
+    t = (affine_upper_left if upper_left else affine_from_center_scale)(center, scale, out_size, inv=True)
     p = coords.astype(np.float32).astype(np.float64)
     out = np.zeros(coords.shape)
     out[:, 0] = t[0, 0] * p[:, 0] + t[0, 1] * p[:, 1] + t[0, 2]
@@ -211,7 +234,7 @@ def transform_preds(coords: np.ndarray, center, scale, out_size) -> np.ndarray:
 
 
 def process_detect_output(output: Dict[str, torch.Tensor], meta: np.ndarray, wiz_rev: bool = True,
-                          vis_thresh: float = 0.2, return_raw: bool = False):
+                          vis_thresh: float = 0.2, return_raw: bool = False, upper_left: bool = False):
     """heads (NCHW f32; 'hm' pre-sigmoid) + meta [cx, cy, s, in_h, in_w, out_h, out_w] ->
     (slct_logi_feat f32 [1,n,256], slct_dets_feat i64 [1,n,8], polygons f32 [n,8] in source pixels, dets f32 [K,9])."""
     hm = torch.sigmoid(output["hm"])
@@ -223,7 +246,7 @@ def process_detect_output(output: Dict[str, torch.Tensor], meta: np.ndarray, wiz
     c, s = meta[:2], meta[2]
     out_h, out_w = meta[5], meta[6]
     for k in range(4):
-        d[:, 2 * k:2 * k + 2] = transform_preds(d[:, 2 * k:2 * k + 2], c, s, (out_w, out_h))
+        d[:, 2 * k:2 * k + 2] = transform_preds(d[:, 2 * k:2 * k + 2], c, s, (out_w, out_h), upper_left)
     results = d[:, :9].astype(np.float32)
     n = int((results[:, 8] >= vis_thresh).sum())
     logi = (logi + crf)[:, :n].contiguous()
@@ -239,11 +262,15 @@ def process_logic_output(logi: torch.Tensor) -> torch.Tensor:
     return torch.where(logi - fl > 0.5, fl + 1, fl)
 
 
-def lore_preprocess_geometry(height: int, width: int, inp_h: int = 1024, inp_w: int = 1024):
-    """TableLorePreProcessor.process (processer_lore.py:66-109) with upper_left=False:
+def lore_preprocess_geometry(height: int, width: int, inp_h: int = 1024, inp_w: int = 1024, upper_left: bool = False):
+    """TableLorePreProcessor.process (processer_lore.py:66-109)
     -> (trans_input 2x3 float64 for cv2.warpAffine, meta int64 [cx, cy, s, in_h, in_w, out_h, out_w])."""
-    c = np.array([width / 2.0, height / 2.0], dtype=np.float32)
     s = max(height, width) * 1.0
-    trans = affine_from_center_scale(c, s, (inp_w, inp_h))
+    if upper_left:
+        c = np.array([0, 0], dtype=np.float32)
+        trans = affine_upper_left(c, s, (inp_w, inp_h))
+    else:
+        c = np.array([width / 2.0, height / 2.0], dtype=np.float32)
+        trans = affine_from_center_scale(c, s, (inp_w, inp_h))
     meta = np.array([c[0], c[1], s, inp_h, inp_w, inp_h // 4, inp_w // 4]).astype(np.int64)   # torch .long(): truncation
     return trans, meta

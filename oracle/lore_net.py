@@ -189,3 +189,43 @@ def ref_dcn_im2col(x: np.ndarray, offset: np.ndarray, mask: np.ndarray, k: int =
                                         B, C, H, W, Ho, Wo, k, k, pad, pad, stride, stride, dil, dil, 1,
                                         col.ctypes.data_as(fp))
     return col
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# 'wireless' detector: LoreDetectModel.forward, lore/lore_detector.py:353-389 (BasicBlock :57-88)
+# --------------------------------------------------------------------------------------------------------------------
+def lore_wireless_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor):
+    """x f32 [B,3,H,W] -> the six head maps at H/4 x W/4.  PINNED by tests/golden/lore_wireless.npz."""
+    def block(p, x, stride):
+        out = F.relu(_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], stride, 1)))
+        out = _bn(sd, p + ".bn2", F.conv2d(out, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], 1, 1))
+        res = x
+        if (p + ".downsample.0.weight") in sd:
+            res = _bn(sd, p + ".downsample.1", F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride))
+        return F.relu(out + res)
+
+    def deconv(i, x):
+        y = F.conv_transpose2d(x, sd[f"deconv_layers{i}.0.weight"], None, stride=2, padding=1)
+        return F.relu(_bn(sd, f"deconv_layers{i}.1", y))
+    x = F.relu(_bn(sd, "bn1", F.conv2d(x, sd["conv1.weight"], None, 2, 3)))
+    x0 = F.max_pool2d(x, 3, 2, 1)
+    feats = []
+    cur = x0
+    for li in range(1, 5):
+        cur = block(f"layer{li}.0", cur, 2)
+        cur = block(f"layer{li}.1", cur, 1)
+        feats.append(cur)
+    x1, x2, x3, x4 = feats
+    x3_ = F.conv2d(x3, sd["adaption3.weight"]) + deconv(1, x4)
+    x2_ = F.conv2d(x2, sd["adaption2.weight"]) + deconv(2, x3_)
+    x1_ = F.conv2d(x1, sd["adaption1.weight"]) + deconv(3, x2_)
+    x0_ = deconv(4, x1_) + F.conv2d(x0, sd["adaption0.weight"])
+    x0_ = F.conv2d(x0_, sd["adaptionU1.weight"])
+    z = {}
+    for h in HEADS:
+        n3 = 1 if h == "reg" else 4
+        t = x0_
+        for j in range(n3):
+            t = F.relu(F.conv2d(t, sd[f"{h}.{2 * j}.weight"], sd[f"{h}.{2 * j}.bias"], 1, 1))
+        z[h] = F.conv2d(t, sd[f"{h}.{2 * n3}.weight"], sd[f"{h}.{2 * n3}.bias"])
+    return z

@@ -65,11 +65,11 @@ def warp_affine_u8(img: np.ndarray, M: np.ndarray, out_w: int, out_h: int) -> np
     return out
 
 
-def lore_preprocess(img: np.ndarray, inp_h: int = 1024, inp_w: int = 1024):
+def lore_preprocess(img: np.ndarray, inp_h: int = 1024, inp_w: int = 1024, upper_left: bool = False):
     """img uint8 HxWx3 in the channel order the reference's ``process`` receives (BGR for path / PIL inputs)
     -> (pixel_values f32 [1,3,inp_h,inp_w], meta int64 [7])."""
     h, w = img.shape[:2]
-    trans, meta = lore_preprocess_geometry(h, w, inp_h, inp_w)
+    trans, meta = lore_preprocess_geometry(h, w, inp_h, inp_w, upper_left)
     # cv2.resize(img, (width, height)) to its own size is a copy
     warped = warp_affine_u8(img, trans, inp_w, inp_h)
     x = ((warped / 255.0 - MEAN.reshape(1, 1, 3)) / STD.reshape(1, 1, 3)).astype(np.float32)

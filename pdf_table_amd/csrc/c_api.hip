@@ -308,6 +308,14 @@ int pt_tsr_forward_net(pt_engine* e, const uint16_t* d_input_bf16, int n, int H,
                              reinterpret_cast<hipStream_t>(stream));
 }
 
+int pt_tsr_forward_net_wireless(pt_engine* e, const uint16_t* d_input_bf16, int n, int H, int W, float* d_hm, float* d_st,
+                                float* d_wh, float* d_ax, float* d_cr, float* d_reg, pt_stream stream) {
+  PT_REQUIRE(e && d_input_bf16 && n > 0, "pt_tsr_forward_net_wireless: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  return pt_lore_wireless_forward_net(e, d_input_bf16, n, H, W, d_hm, d_st, d_wh, d_ax, d_cr, d_reg,
+                                      reinterpret_cast<hipStream_t>(stream));
+}
+
 int pt_tsr_decode(pt_engine* e, const float* d_hm, const float* d_st, const float* d_wh, const float* d_ax,
                   const float* d_cr, const float* d_reg, int n, int h, int w, int wiz_rev, float vis_thresh,
                   int32_t* d_counts, float* d_dets, float* d_logi, pt_stream stream) {

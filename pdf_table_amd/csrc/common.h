@@ -185,6 +185,8 @@ int pt_launch_pico_candidates(const float* head, int B, int A, int ncls, int lev
 int pt_lore_decode(pt_engine* e, const float* hm, const float* st, const float* wh, const float* ax, const float* cr,
                    const float* reg, int B, int H, int W, int wiz_rev, float vis_thresh, int* d_counts, float* d_dets,
                    float* d_logi, hipStream_t s);
+int pt_lore_wireless_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* hm, float* st, float* wh,
+                                 float* ax, float* cr, float* reg, hipStream_t s);
 int pt_lore_process(pt_engine* e, const float* d_logi, const float* d_dets, const int32_t* h_counts, int n_tables,
                     int use_2dpe, float* d_logic, float* d_stacked, hipStream_t s);
 int pt_lore_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* hm, float* st, float* wh, float* ax,

@@ -262,3 +262,156 @@ int pt_lore_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, floa
   }
   return PT_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 'wireless' detector: LoreDetectModel.forward (lore/lore_detector.py:353-389) -- ResNet-18-style backbone whose every
+// stage is strided, four ConvTranspose2d(4x4, stride 2) + BN + ReLU up-samplers (run as 3x3 convolutions with 4 x 256
+// outputs and a pixel-shuffle epilogue), 1x1 lateral `adaption` convs added through the residual path, heads of
+// four 3x3 (-> 64) + ReLU and a 1x1.  Same head-map outputs as pt_lore_forward_net.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct WCtx {
+  pt_engine* e;
+  const PtModel* m;
+  hipStream_t s;
+  int n, x3, mul;
+  bool dry, ok;
+  int rc;
+  T alloc(int H, int W, int C) {
+    T t;
+    t.H = H; t.W = W; t.C = C;
+    t.p = reinterpret_cast<bf16_t*>(e->arena.take((size_t)n * H * W * C * mul * sizeof(bf16_t)));
+    if (!t.p) ok = false;
+    return t;
+  }
+  const PtTensor* get(const std::string& name) {
+    const PtTensor* t = m->find(name);
+    if (!t && rc == PT_OK) {
+      pt_set_error("Lore wireless weight blob lacks tensor '%s'", name.c_str());
+      rc = PT_ERR_FORMAT;
+    }
+    return t;
+  }
+  void conv(const T& in, const std::string& q, int N, int ks, int stride, const T& out, int relu, const T* res = nullptr,
+            int shuffle = 0, int nv = 0, float* out_f32 = nullptr, int f32_cs = 0) {
+    const PtTensor* w = get(q + (x3 ? ".w3" : ".w"));
+    const PtTensor* b = get(q + ".b");
+    if (rc != PT_OK || dry || !ok) return;
+    ConvDesc c;
+    c.in = in.p; c.B = n; c.H = in.H; c.W = in.W; c.Cin = in.C;
+    c.w = reinterpret_cast<const bf16_t*>(w->d_ptr); c.bias = reinterpret_cast<const float*>(b->d_ptr);
+    c.N = N; c.ks = ks; c.stride = stride; c.relu = relu; c.split = x3; c.n_valid = nv; c.shuffle_cout = shuffle;
+    if (out_f32) {
+      c.out_f32 = out_f32; c.out_cstride = f32_cs;
+    } else {
+      c.out = out.p; c.out_cstride = out.C * mul; c.out_lo_off = out.C;
+    }
+    if (res) { c.res = res->p; c.res_mode = 1; }
+    const int r = pt_launch_conv(e, c, s);
+    if (r != PT_OK) rc = r;
+  }
+};
+
+}  // namespace
+
+int pt_lore_wireless_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* hm, float* st, float* wh,
+                                 float* ax, float* cr, float* reg, hipStream_t s) {
+  PT_REQUIRE(H % 64 == 0 && W % 64 == 0 && H > 0 && W > 0, "Lore wireless net: input %dx%d must be multiples of 64", H, W);
+  PT_REQUIRE(x && hm && st && wh && ax && cr && reg && n > 0, "Lore wireless net: null pointer");
+  auto it = e->models.find(PT_MODEL_LORE_RESNET18);
+  if (it == e->models.end()) {
+    pt_set_error("Lore wireless weights not loaded (pt_weights_load(PT_MODEL_LORE_RESNET18))");
+    return PT_ERR_STATE;
+  }
+  WCtx c;
+  c.e = e; c.m = &it->second; c.s = s; c.n = n;
+  c.x3 = e->precision == PT_PRECISION_BF16X3 ? 1 : 0;
+  c.mul = c.x3 ? 2 : 1;
+  c.rc = PT_OK;
+  float* heads[6] = {hm, st, wh, ax, cr, reg};
+  const char* hname[6] = {"hm", "st", "wh", "ax", "cr", "reg"};
+  const int hcs[6] = {8, 8, 8, 256, 256, 8};
+  const int planes[4] = {64, 128, 256, 256};
+  for (int pass = 0; pass < 2; ++pass) {
+    c.dry = pass == 0;
+    c.ok = true;
+    e->arena.reset();
+    T s0 = c.alloc(H / 2, W / 2, 64);
+    if (!c.dry && c.ok) {
+      const PtTensor* w = c.get(c.x3 ? "stem.w3" : "stem.w");
+      const PtTensor* b = c.get("stem.b");
+      if (c.rc == PT_OK) {
+        const int r = pt_launch_stem7x7(e, x, n, H, W, reinterpret_cast<const bf16_t*>(w->d_ptr),
+                                        reinterpret_cast<const float*>(b->d_ptr), s0.p, c.x3, s, 2, 0);
+        if (r != PT_OK) c.rc = r;
+      }
+    }
+    T x0 = c.alloc(H / 4, W / 4, 64);
+    if (c.rc == PT_OK && !c.dry && c.ok) {
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0, "maxpool");
+      const int r = pt_launch_maxpool3x3s2(s0.p, n, H / 2, W / 2, 64, x0.p, c.x3, s);
+      if (r != PT_OK) c.rc = r;
+    }
+    T feat[4];
+    T cur = x0;
+    for (int l = 0; l < 4; ++l) {
+      for (int b = 0; b < 2; ++b) {
+        const std::string q = "layer" + std::to_string(l + 1) + "." + std::to_string(b);
+        const int stride = b == 0 ? 2 : 1;
+        T t = c.alloc(cur.H / stride, cur.W / stride, planes[l]);
+        c.conv(cur, q + ".conv1", planes[l], 3, stride, t, 1);
+        T res = cur;
+        if (b == 0) {
+          res = c.alloc(t.H, t.W, planes[l]);
+          c.conv(cur, q + ".down", planes[l], 1, 2, res, 0);
+        }
+        T o = c.alloc(t.H, t.W, planes[l]);
+        c.conv(t, q + ".conv2", planes[l], 3, 1, o, 1, &res);
+        cur = o;
+      }
+      feat[l] = cur;
+    }
+    // top-down: deconv (3x3 + pixel shuffle + BN + ReLU), then `adaption(lateral) + deconv`
+    T up = feat[3];
+    const T* lateral[4] = {&feat[2], &feat[1], &feat[0], &x0};
+    const char* adapt[4] = {"adaption3", "adaption2", "adaption1", "adaption0"};
+    for (int i = 0; i < 4; ++i) {
+      T d = c.alloc(up.H * 2, up.W * 2, 256);
+      c.conv(up, "deconv" + std::to_string(i + 1), 1024, 3, 1, d, 1, nullptr, 256);
+      T o = c.alloc(d.H, d.W, 256);
+      c.conv(*lateral[i], adapt[i], 256, 1, 1, o, 0, &d);
+      up = o;
+    }
+    T f = c.alloc(up.H, up.W, 256);
+    c.conv(up, "adaptionU1", 256, 1, 1, f, 0);
+    T h1 = c.alloc(f.H, f.W, 64), h2 = c.alloc(f.H, f.W, 64);
+    for (int h = 0; h < 6; ++h) {
+      const int n3 = h == 5 ? 1 : 4;
+      const T* in = &f;
+      for (int j = 0; j < n3; ++j) {
+        const T& o = (j & 1) ? h2 : h1;
+        c.conv(*in, std::string(hname[h]) + ".c" + std::to_string(j), 64, 3, 1, o, 1);
+        in = &o;
+      }
+      c.conv(*in, std::string(hname[h]) + ".out", hcs[h] < 64 ? 64 : hcs[h], 1, 1, T(), 0, nullptr, 0, hcs[h], heads[h], hcs[h]);
+    }
+    if (c.rc != PT_OK) return c.rc;
+    if (pass == 0) {
+      if (c.ok) continue;
+      PT_HIP_CHECK(hipDeviceSynchronize());
+      if (e->arena.base) PT_HIP_CHECK(hipFree(e->arena.base));
+      e->arena.base = nullptr;
+      const size_t want = e->arena.high + (1u << 20);
+      PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arena.base), want));
+      e->arena.cap = want;
+      continue;
+    }
+    if (!c.ok) {
+      pt_set_error("Lore wireless net: activation arena allocation failed");
+      return PT_ERR_HIP;
+    }
+  }
+  return PT_OK;
+}

@@ -171,18 +171,19 @@ class HipEngine:
                                            self._stream()), "pt_tsr_preprocess")
         return out
 
-    def tsr_forward_net(self, x: torch.Tensor):
-        """Lore detector: x bf16 NHWC4 [n,H,W,4] (BF16X3: 8 channels) -> dict of fp32 NHWC head maps at H/4 x W/4
-        ({'hm': [n,h,w,2], 'st': [.,8], 'wh': [.,8], 'ax': [.,256], 'cr': [.,256], 'reg': [.,2]})."""
+    def tsr_forward_net(self, x: torch.Tensor, wireless: bool = False):
+        """Lore detector (DLA-34 + DCN, or the ResNet-18 'wireless' one): x bf16 NHWC4 [n,H,W,4] (BF16X3: 8 channels) ->
+        dict of fp32 NHWC head maps at H/4 x W/4 ({'hm': [n,h,w,2], 'st': [.,8], 'wh': [.,8], 'ax': [.,256],
+        'cr': [.,256], 'reg': [.,2]})."""
         self._chk(x, torch.bfloat16, "x")
         n, H, W, c = x.shape
         assert c == (8 if self.precision == L.PT_PRECISION_BF16X3 else 4)
         h, w = H // 4, W // 4
         bufs = {k: torch.empty((n, h, w, 256 if k in ("ax", "cr") else 8), dtype=torch.float32, device=self._tdev)
                 for k in ("hm", "st", "wh", "ax", "cr", "reg")}
-        L.check(self.lib.pt_tsr_forward_net(self._h, _ptr(x), n, H, W, _ptr(bufs["hm"]), _ptr(bufs["st"]),
-                                            _ptr(bufs["wh"]), _ptr(bufs["ax"]), _ptr(bufs["cr"]), _ptr(bufs["reg"]),
-                                            self._stream()), "pt_tsr_forward_net")
+        fn = self.lib.pt_tsr_forward_net_wireless if wireless else self.lib.pt_tsr_forward_net
+        L.check(fn(self._h, _ptr(x), n, H, W, _ptr(bufs["hm"]), _ptr(bufs["st"]), _ptr(bufs["wh"]), _ptr(bufs["ax"]),
+                   _ptr(bufs["cr"]), _ptr(bufs["reg"]), self._stream()), "pt_tsr_forward_net")
         bufs["hm"] = bufs["hm"][..., :2]
         bufs["reg"] = bufs["reg"][..., :2]
         return bufs

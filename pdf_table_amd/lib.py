@@ -17,6 +17,7 @@ PT_MODEL_CRNN = 2
 PT_MODEL_LORE_DLA34 = 3
 PT_MODEL_LORE_PROCESSOR = 4
 PT_MODEL_PICODET = 5
+PT_MODEL_LORE_RESNET18 = 6
 PT_LAYOUT_HEAD_CS, PT_LAYOUT_CAND_FLOATS = 40, 48
 PT_DET_PRE_DB_PP = 0
 PT_DET_PRE_DB_TORCH = 1
@@ -66,6 +67,7 @@ def _proto(lib):
         "pt_layout_forward": (i, [vp, vp, i, i, i, i, i, i, f, i, vp, vp, vp]),
         "pt_tsr_preprocess": (i, [vp, vp, i, i, i, vp, i, i, i, i, vp, vp]),
         "pt_tsr_forward_net": (i, [vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp]),
+        "pt_tsr_forward_net_wireless": (i, [vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp]),
         "pt_tsr_decode": (i, [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, f, vp, vp, vp, vp]),
         "pt_tsr_process": (i, [vp, vp, vp, vp, i, i, vp, vp, vp]),
         "pt_op_conv2d": (i, [vp, vp, i, i, i, i, vp, vp, i, i, i, vp, i, i, i, i, vp, i, i, i, i, vp]),

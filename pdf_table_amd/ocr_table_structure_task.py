@@ -3,8 +3,8 @@
 Reference: src/pdftable/model/ocr_pdf/ocr_table_structure_task.py:47-271.  Same constructor (``task, model, task_type``,
 ``assert`` on the model name :53-54, ``PubTabNet`` -> ``ptn`` :66-67), same result list: one dict per input image with
 ``polygons`` float32 [n, 8] (cell quads in source pixels), ``logi`` [n, 4] (integer-valued logical locations) and
-``inputs`` (TableLorePostProcessor.__call__, lore/processer_lore.py:163-188).  Only ``model="Lore"`` with the DLA-34
-detector (``task_type`` wtw / ptn) is served; the other structure models the reference lists fail loudly.
+``inputs`` (TableLorePostProcessor.__call__, lore/processer_lore.py:163-188).  ``model="Lore"`` is served for all three
+task types (wtw / ptn: DLA-34 + DCN detector, wireless: ResNet-18 detector); the other structure models the reference lists fail loudly.
 
 Two ways in:
   * reference-shaped: ``task(image_or_list)`` -- path / PIL / ndarray, one table image each;
@@ -25,7 +25,7 @@ from .base_infer_task import BaseInferTask
 from .engine import HipEngine
 from .ocr_detection_task import _read_image
 from .tsr_stage import LoreConfig, TsrStage
-from .weights import pack_lore_dla34, pack_lore_processor
+from .weights import pack_lore_dla34, pack_lore_processor, pack_lore_wireless
 
 __all__ = ["OcrTableStructureTask"]
 
@@ -52,8 +52,8 @@ class OcrTableStructureTask(BaseInferTask):
             self._engine = HipEngine(int(str(self.device).split(":")[-1]) if ":" in str(self.device) else 0)
         cfg = self._config
         if self.synthetic_seed is not None:
-            from .synth_weights import lore_dla34_state_dict, lore_processor_state_dict
-            det_sd = lore_dla34_state_dict(seed=int(self.synthetic_seed))
+            from .synth_weights import lore_dla34_state_dict, lore_processor_state_dict, lore_wireless_state_dict
+            det_sd = (lore_wireless_state_dict if cfg.backbone == "ResNet-18" else lore_dla34_state_dict)(seed=int(self.synthetic_seed))
             proc_sd = lore_processor_state_dict(seed=int(self.synthetic_seed) + 1, layers=cfg.tsfm_layers,
                                                 stacking_layers=cfg.stacking_layers)
         else:
@@ -74,7 +74,10 @@ class OcrTableStructureTask(BaseInferTask):
             else:
                 raise RuntimeError(f"no Lore checkpoint under {mp}: the reference would download it from the hub (no "
                                    "network here); pass task_path=<dir> or synthetic_seed=<int>")
-        self._engine.load_weights(L.PT_MODEL_LORE_DLA34, pack_lore_dla34(det_sd))
+        if cfg.backbone == "ResNet-18":
+            self._engine.load_weights(L.PT_MODEL_LORE_RESNET18, pack_lore_wireless(det_sd))
+        else:
+            self._engine.load_weights(L.PT_MODEL_LORE_DLA34, pack_lore_dla34(det_sd))
         self._engine.load_weights(L.PT_MODEL_LORE_PROCESSOR, pack_lore_processor(proc_sd))
         self._model = self._predict
 

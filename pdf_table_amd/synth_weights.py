@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 __all__ = ["db_resnet18_state_dict", "crnn_state_dict", "CRNN_NUM_CLASSES", "lore_dla34_state_dict",
-           "lore_processor_state_dict", "LORE_HEADS", "picodet_state_dict", "LCNET_CONFIG", "PICODET_STANDIN"]
+           "lore_processor_state_dict", "LORE_HEADS", "picodet_state_dict", "LCNET_CONFIG", "PICODET_STANDIN", "lore_wireless_state_dict"]
 
 CRNN_NUM_CLASSES = 7644  # crnn/modeling_crnn.py:90
 
@@ -374,4 +374,55 @@ def picodet_state_dict(seed: int = 0, num_classes: int = 5, cls_bias: float = -6
         b = g.rng.uniform(-0.5, 0.5, (nout,))
         b[:num_classes] += cls_bias            # few positives, like a trained detector's prior (pico_head.py:1041)
         g.put(f"head.head_cls{s}.bias", b)
+    return g.sd
+
+
+def lore_wireless_state_dict(seed: int = 0, hm_bias=(-5.0, -4.5), cell_half=(10.0, 6.0)):
+    """state_dict of ``LoreDetectModel`` (lore/lore_detector.py:155-286): the ResNet-18-style 'wireless' detector --
+    7x7/s2 stem, max-pool, four 2-block stages (64, 128, 256, 256; every stage strided; block convs WITH bias), four
+    ConvTranspose2d(256, 256, 4, stride 2, padding 1, no bias) + BN up-samplers with 1x1 lateral ``adaption`` convs, and
+    heads of four 3x3 (->64) + ReLU then 1x1 (``reg``: one 3x3)."""
+    g = _Gen(seed)
+    g.conv("conv1", 64, 3, 7, 7)
+    g.bn("bn1", 64)
+    inpl = 64
+    for li, planes in enumerate((64, 128, 256, 256), start=1):
+        for bi in range(2):
+            p = f"layer{li}.{bi}"
+            g.conv(p + ".conv1", planes, inpl, 3, 3, bias=True)
+            g.bn(p + ".bn1", planes)
+            g.conv(p + ".conv2", planes, planes, 3, 3, bias=True, gain=1.0)
+            g.bn(p + ".bn2", planes)
+            if bi == 0:                                    # stride 2 in every stage (:181-188) -> always a downsample
+                g.conv(p + ".downsample.0", planes, inpl, 1, 1, gain=1.0)
+                g.bn(p + ".downsample.1", planes)
+            inpl = planes
+    for name, cin in (("adaption3", 256), ("adaption2", 128), ("adaption1", 64), ("adaption0", 64), ("adaptionU1", 256)):
+        g.conv(name, 256, cin, 1, 1, gain=1.0)
+    for i in range(1, 5):
+        # nn.ConvTranspose2d weight layout [Cin, Cout, 4, 4]; each output pixel sums 4 taps per input channel
+        std = math.sqrt(2.0 / (256 * 4))
+        g.put(f"deconv_layers{i}.0.weight", g.rng.standard_normal((256, 256, 4, 4)) * std)
+        g.bn(f"deconv_layers{i}.1", 256)
+    for h, k in LORE_HEADS.items():
+        n3 = 1 if h == "reg" else 4
+        cin = 256
+        for j in range(n3):
+            g.conv(f"{h}.{2 * j}", 64, cin, 3, 3, bias=True)
+            cin = 64
+        last = f"{h}.{2 * n3}"
+        if h == "hm":
+            g.conv(last, k, 64, 1, 1, bias=False, gain=0.5)
+            w = g.sd[last + ".weight"]
+            g.sd[last + ".weight"] = w - w.mean(dim=1, keepdim=True)
+            g.put(last + ".bias", np.asarray(hm_bias, dtype=np.float64).reshape(k))
+        elif h in ("wh", "st"):
+            g.conv(last, k, 64, 1, 1, bias=False, gain=0.05)
+            hw, hh = cell_half
+            g.put(last + ".bias", np.array([hw, hh, -hw, hh, -hw, -hh, hw, -hh]))
+        elif h == "reg":
+            g.conv(last, k, 64, 1, 1, bias=False, gain=0.02)
+            g.put(last + ".bias", np.array([0.5, 0.5]))
+        else:
+            g.conv(last, k, 64, 1, 1, bias=True, gain=0.5)
     return g.sd

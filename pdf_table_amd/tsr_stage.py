@@ -18,7 +18,7 @@ from . import lib as L
 from .engine import TSR_TABLE_DTYPE, HipEngine
 from .table_html import structure_html
 
-__all__ = ["LoreConfig", "TsrStage", "lore_geometry", "affine_from_center_scale", "invert_affine",
+__all__ = ["LoreConfig", "TsrStage", "lore_geometry", "affine_from_center_scale", "affine_upper_left", "invert_affine",
            "transform_quads", "process_logic_output"]
 
 
@@ -39,10 +39,11 @@ class LoreConfig:
     vis_thresh: float = 0.2
 
     def __post_init__(self):
-        if self.task_type == "wireless":
-            raise NotImplementedError("Lore 'wireless' (ResNet-18 detector, lore/lore_detector.py) is not built on the HIP "
-                                      "engine yet; task_type 'wtw' and 'ptn' (DLA-34 + DCN) are")
-        if self.task_type == "wtw":                       # configuration_lore.py:79-92
+        if self.task_type == "wireless":                  # configuration_lore.py:66-78
+            self.backbone, self.resolution = "ResNet-18", (768, 768)
+            self.stacking_layers = self.tsfm_layers = 4
+            self.upper_left, self.wiz_2dpe, self.wiz_rev, self.vis_thresh = True, True, False, 0.2
+        elif self.task_type == "wtw":                     # configuration_lore.py:79-92
             self.backbone, self.resolution = "DLA-34", (1024, 1024)
             self.stacking_layers = self.tsfm_layers = 4
             self.upper_left, self.wiz_2dpe, self.wiz_rev, self.vis_thresh = False, False, True, 0.2
@@ -80,6 +81,25 @@ def affine_from_center_scale(center, scale, out_size, inv: bool = False) -> np.n
     return _affine_3pt(dst, src) if inv else _affine_3pt(src, dst)
 
 
+def affine_upper_left(center, scale, out_size, inv: bool = False) -> np.ndarray:
+    """get_affine_transform_upper_left (lineless_table_process.py:441-468): the origin stays at the top-left corner;
+    (cx, scale) -> (0, out_w) when cx >= cy, else (scale, cy) -> (out_w, 0); third point perpendicular."""
+    s = np.float32(scale)
+    src = np.zeros((3, 2), np.float32)
+    dst = np.zeros((3, 2), np.float32)
+    src[0] = center
+    if center[0] < center[1]:
+        src[1] = (s, center[1])
+        dst[1] = (out_size[0], 0)
+    else:
+        src[1] = (center[0], s)
+        dst[1] = (0, out_size[0])
+    for p in (src, dst):
+        d = p[0] - p[1]
+        p[2] = p[1] + np.array([-d[1], d[0]], np.float32)
+    return _affine_3pt(dst, src) if inv else _affine_3pt(src, dst)
+
+
 def invert_affine(m: np.ndarray) -> np.ndarray:
     """the inverse map cv2.warpAffine derives from M (float64, same operation order)"""
     m = np.asarray(m, np.float64).reshape(6).copy()
@@ -96,20 +116,25 @@ def invert_affine(m: np.ndarray) -> np.ndarray:
     return m.reshape(2, 3)
 
 
-def lore_geometry(crop_h: int, crop_w: int, inp_h: int, inp_w: int):
+def lore_geometry(crop_h: int, crop_w: int, inp_h: int, inp_w: int, upper_left: bool = False):
     """-> (minv 2x3 for pt_tsr_table, meta int64 [cx, cy, s, in_h, in_w, out_h, out_w]) -- processer_lore.py:74-126:
-    c = (w/2, h/2) float32, s = max(h, w); meta is cast to int64 (fractions of c are dropped, as in the reference)."""
-    c = np.array([crop_w / 2.0, crop_h / 2.0], dtype=np.float32)
+    c = (w/2, h/2) float32 (or (0, 0) with upper_left), s = max(h, w); meta is cast to int64 (fractions of c are
+    dropped, as in the reference)."""
     s = max(crop_h, crop_w) * 1.0
-    trans = affine_from_center_scale(c, s, (inp_w, inp_h))
+    if upper_left:
+        c = np.array([0, 0], dtype=np.float32)
+        trans = affine_upper_left(c, s, (inp_w, inp_h))
+    else:
+        c = np.array([crop_w / 2.0, crop_h / 2.0], dtype=np.float32)
+        trans = affine_from_center_scale(c, s, (inp_w, inp_h))
     meta = np.array([c[0], c[1], s, inp_h, inp_w, inp_h // 4, inp_w // 4]).astype(np.int64)
     return invert_affine(trans), meta
 
 
-def transform_quads(quads: np.ndarray, meta: np.ndarray) -> np.ndarray:
-    """ctdet_4ps_post_process (lineless_table_process.py:489-505): the four vertices of every quad through the inverse
-    centre/scale map built from the int64 meta; float64 matrix x float32 point, stored back as float32."""
-    t = affine_from_center_scale(meta[:2], meta[2], (meta[6], meta[5]), inv=True)
+def transform_quads(quads: np.ndarray, meta: np.ndarray, upper_left: bool = False) -> np.ndarray:
+    """ctdet_4ps_post_process[_upper_left] (lineless_table_process.py:489-533): the four vertices of every quad through
+    the inverse map built from the int64 meta; float64 matrix x float32 point, stored back as float32."""
+    t = (affine_upper_left if upper_left else affine_from_center_scale)(meta[:2], meta[2], (meta[6], meta[5]), inv=True)
     p = quads.astype(np.float32).astype(np.float64).reshape(-1, 4, 2)
     out = np.empty_like(p)
     out[..., 0] = t[0, 0] * p[..., 0] + t[0, 1] * p[..., 1] + t[0, 2]
@@ -146,7 +171,7 @@ class TsrStage:
                 cw, ch = x2 - x1, y2 - y1
                 if cw <= 0 or ch <= 0:
                     raise ValueError(f"empty table crop {b.tolist()} on a {ph}x{pw} page")
-                minv, meta = lore_geometry(ch, cw, inp_h, inp_w)
+                minv, meta = lore_geometry(ch, cw, inp_h, inp_w, self.config.upper_left)
                 r = np.zeros((), dtype=TSR_TABLE_DTYPE)
                 r["minv"], r["page"], r["x0"], r["y0"], r["crop_w"], r["crop_h"] = minv.reshape(6), pi, x1, y1, cw, ch
                 recs.append(r)
@@ -161,7 +186,7 @@ class TsrStage:
         for i in range(0, len(tables), self.micro_batch):
             tb = tables[i:i + self.micro_batch]
             x = self.eng.tsr_preprocess(pages, tb, inp_h, inp_w, bgr=self.bgr)
-            heads = self.eng.tsr_forward_net(x)
+            heads = self.eng.tsr_forward_net(x, wireless=cfg.backbone == "ResNet-18")
             counts, dets, logi = self.eng.tsr_decode(heads, wiz_rev=cfg.wiz_rev, vis_thresh=cfg.vis_thresh, sync=False)
             pending.append((i, len(tb), counts, dets, logi))
         return pending
@@ -189,7 +214,7 @@ class TsrStage:
                                 "scores": np.zeros((0,), np.float32)})
                     continue
                 final = stacked_h[k, :n] if cfg.wiz_stacking else logic_h[k, :n]
-                r = {"polygons": transform_quads(dets_h[k, :n, :8], metas[i + k]),
+                r = {"polygons": transform_quads(dets_h[k, :n, :8], metas[i + k], cfg.upper_left),
                      "logi": process_logic_output(final), "logic_axis": logic_h[k, :n].copy(),
                      "stacked_axis": stacked_h[k, :n].copy(), "scores": dets_h[k, :n, 8].copy()}
                 if self.with_html:       # table_html.table_cells_from_logits(polygons, logi) gives the cell objects on demand

@@ -29,7 +29,7 @@ import torch
 BN_EPS = 1e-5
 _DT = {"bf16": 0, "f32": 1, "i32": 2}
 
-__all__ = ["pack_db_resnet18", "pack_crnn", "pack_lore_dla34", "pack_lore_processor", "pack_picodet", "write_blob", "fold_conv_bn", "to_bf16_bits"]
+__all__ = ["pack_db_resnet18", "pack_crnn", "pack_lore_dla34", "pack_lore_processor", "pack_picodet", "pack_lore_wireless", "write_blob", "fold_conv_bn", "to_bf16_bits"]
 
 
 def to_bf16_bits(t: torch.Tensor) -> np.ndarray:
@@ -424,4 +424,57 @@ def pack_picodet(sd: Dict[str, torch.Tensor], num_classes: int = 5, x3: bool = T
         w = sd[f"head.head_cls{s}.weight"].float()
         bl.add_conv(f"head.{s}.out", *_pad_conv(w, sd[f"head.head_cls{s}.bias"].float(), 64, nc))
     bl.add("meta", np.array([num_classes, PICODET_STANDIN["reg_max"]], dtype=np.int32), "i32")
+    return bl.tobytes()
+
+
+def deconv4x4s2_as_conv3x3(w: torch.Tensor) -> torch.Tensor:
+    """ConvTranspose2d(k=4, s=2, p=1) weight [Cin, Cout, 4, 4] -> the equivalent 3x3 convolution with 4*Cout outputs
+    (quadrant-major: q = 2*py + px feeds output pixel (2y+py, 2x+px)) for the pixel-shuffle epilogue.  Output row
+    2y+py takes input rows y+dy with kernel row ky: py=0: (dy=-1, ky=3), (0, 1); py=1: (0, 2), (+1, 0)."""
+    cin, cout = w.shape[0], w.shape[1]
+    taps = {0: ((-1, 3), (0, 1)), 1: ((0, 2), (1, 0))}
+    out = torch.zeros(4 * cout, cin, 3, 3, dtype=w.dtype)
+    for py in (0, 1):
+        for px in (0, 1):
+            q = 2 * py + px
+            for dy, ky in taps[py]:
+                for dx, kx in taps[px]:
+                    out[q * cout:(q + 1) * cout, :, dy + 1, dx + 1] = w[:, :, ky, kx].t()
+    return out
+
+
+def pack_lore_wireless(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
+    """``LoreDetectModel`` state_dict (lore/lore_detector.py:155-286) -> blob for PT_MODEL_LORE_RESNET18.  Conv+BN folded
+    (block convs carry a bias); the 4x4/s2 transposed convolutions become 3x3 convs with a pixel-shuffle epilogue."""
+    bl = _Blob(x3)
+    w, b = fold_conv_bn(sd, "conv1", "bn1")
+    stem = torch.zeros(64, 7, 8, 4)
+    stem[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+    bl.add("stem.w", to_bf16_bits(stem).reshape(64, 224), "bf16")
+    if x3:
+        sh, sl = split_bf16(stem)
+        bl.add("stem.w3", np.stack([to_bf16_bits(sh).reshape(64, 224), to_bf16_bits(sl).reshape(64, 224)]), "bf16")
+    bl.add("stem.b", b.numpy(), "f32")
+    for li in range(1, 5):
+        for bi in range(2):
+            p = f"layer{li}.{bi}"
+            bl.add_conv(p + ".conv1", *fold_conv_bn(sd, p + ".conv1", p + ".bn1"))
+            bl.add_conv(p + ".conv2", *fold_conv_bn(sd, p + ".conv2", p + ".bn2"))
+            if (p + ".downsample.0.weight") in sd:
+                bl.add_conv(p + ".down", *fold_conv_bn(sd, p + ".downsample.0", p + ".downsample.1"))
+    for name in ("adaption3", "adaption2", "adaption1", "adaption0", "adaptionU1"):
+        bl.add_conv(name, *fold_conv_bn(sd, name, None))
+    for i in range(1, 5):
+        wt = sd[f"deconv_layers{i}.0.weight"].double()
+        bn = f"deconv_layers{i}.1"
+        scale = sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + BN_EPS)
+        shift = sd[bn + ".bias"].double() - sd[bn + ".running_mean"].double() * scale
+        w3 = deconv4x4s2_as_conv3x3(wt * scale.view(1, -1, 1, 1))
+        bl.add_conv(f"deconv{i}", w3.float(), shift.repeat(4).float())
+    for h, k in (("hm", 2), ("st", 8), ("wh", 8), ("ax", 256), ("cr", 256), ("reg", 2)):
+        n3 = 1 if h == "reg" else 4
+        for j in range(n3):
+            bl.add_conv(f"{h}.c{j}", *fold_conv_bn(sd, f"{h}.{2 * j}", None))
+        w, b = fold_conv_bn(sd, f"{h}.{2 * n3}", None)
+        bl.add_conv(f"{h}.out", *_pad_conv(w, b, (k + 63) // 64 * 64, 64))
     return bl.tobytes()

@@ -273,6 +273,28 @@ def gen_lore_dla34():
     print("lore_dla34.npz", {k: v.shape for k, v in out.items()})
 
 
+def gen_lore_wireless():
+    """Outputs of the reference ``LoreDetectModel`` (lore_detector.py:155-389) for seeded weights and inputs."""
+    from pdf_table_amd.synth_weights import lore_wireless_state_dict
+    lore_env()
+    m = ref_import("pdftable.model.lore.lore_detector")
+    model = m.LoreDetectModel().eval()
+    sd = lore_wireless_state_dict(seed=23)
+    model.load_state_dict(sd, strict=True)
+    rng = np.random.default_rng(108)
+    out = {"seed": np.array(23)}
+    for tag, (h, w) in {"a": (128, 192), "b": (64, 128)}.items():   # sizes must be multiples of the total stride 64
+        x = rng.standard_normal((1, 3, h, w)).astype(np.float32)
+        with torch.no_grad():
+            z = model(torch.from_numpy(x))[0]
+        out[f"x_{tag}"] = x
+        for k, v in z.items():
+            v = v.numpy()
+            out[f"{k}_{tag}"] = v[:, ::8] if v.shape[1] == 256 else v
+    np.savez_compressed(os.path.join(HERE, "lore_wireless.npz"), **out)
+    print("lore_wireless.npz", sum(p_.numel() for p_ in model.parameters()), "parameters")
+
+
 def gen_lore_decode():
     """Outputs of the reference's own process_detect_output / process_logic_output (lineless_table_process.py:592-663)
     on seeded head maps.  cv2.getAffineTransform and shapely are not installed: the oracle's stand-ins are injected
@@ -305,14 +327,15 @@ def gen_lore_decode():
     out = {}
     # (K = 3000 cells / 5000 corners are hard-coded in the reference: maps need >= 5000 pixels)
     for tag, (seed, H, W, src_h, src_w, rev) in {"a": (1, 80, 80, 300, 420, True), "b": (2, 72, 96, 777, 512, True),
-                                                 "c": (3, 80, 80, 256, 256, False)}.items():
+                                                 "c": (3, 80, 80, 256, 256, False), "d": (4, 96, 96, 500, 333, False)}.items():
         heads = synth_lore_heads(seed, H, W)
-        _, meta = od.lore_preprocess_geometry(src_h, src_w, 4 * H, 4 * W)
+        ul = tag == "d"                             # the 'wireless' configuration: upper_left=True, wiz_rev=False
+        _, meta = od.lore_preprocess_geometry(src_h, src_w, 4 * H, 4 * W, upper_left=ul)
         hd = {k: torch.from_numpy(v.copy()) for k, v in heads.items()}
-        logi, ps, results, corner = m.process_detect_output(hd, torch.from_numpy(meta)[None], upper_left=False,
+        logi, ps, results, corner = m.process_detect_output(hd, torch.from_numpy(meta)[None], upper_left=ul,
                                                             wiz_rev=rev, vis_thresh=0.2)
         n = logi.shape[1]
-        out[f"case_{tag}"] = np.array([seed, H, W, src_h, src_w, int(rev)])
+        out[f"case_{tag}"] = np.array([seed, H, W, src_h, src_w, int(rev), int(ul)])
         out[f"meta_{tag}"] = meta
         out[f"logi_{tag}"] = logi.numpy()
         out[f"ps_{tag}"] = ps.numpy()
@@ -490,6 +513,8 @@ if __name__ == "__main__":
         gen_lore_decode()
     if "lore_dla" in which:
         gen_lore_dla34()
+    if "lore_wireless" in which or not sys.argv[1:]:
+        gen_lore_wireless()
     if "host" in which:
         gen_db_host_numpy()
     if "db" in which:

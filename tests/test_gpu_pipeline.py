@@ -74,8 +74,6 @@ def test_missing_stages_fail_loudly():
         OcrTableStructureTask(model="SLANet", synthetic_seed=0)
     with pytest.raises(AssertionError):
         OcrTableStructureTask(model="NoSuchModel", synthetic_seed=0)        # the reference asserts (:53-54)
-    with pytest.raises(NotImplementedError):
-        OcrTableStructureTask(model="Lore", task_type="wireless", synthetic_seed=0)
 
 
 def test_table_structure_task_and_pipeline(pipe):
@@ -126,3 +124,15 @@ def test_layout_task_and_full_pipeline(pipe):
     assert len(r.table_structure_result) <= ntab
     for t in r.table_structure_result:
         assert t["polygons"].shape[1] == 8 and t["logi"].shape[1] == 4
+
+
+def test_table_structure_task_wireless(pipe):
+    """task_type='wireless': ResNet-18 detector, upper-left geometry, 2-D position embeddings, no vertex snapping"""
+    from pdf_table_amd.ocr_table_structure_task import OcrTableStructureTask
+    page, meta = make_page(2)
+    x1, y1, x2, y2 = meta["tables"].reshape(-1, 4)[0]
+    task = OcrTableStructureTask(model="Lore", task_type="wireless", synthetic_seed=5, engine=pipe.engine)
+    assert task._config.resolution == (768, 768) and task._config.upper_left and task._config.wiz_2dpe and not task._config.wiz_rev
+    r = task(page[y1:y2, x1:x2].copy())[0]
+    assert r["polygons"].shape[1] == 8 and r["logi"].shape == (len(r["polygons"]), 4)
+    assert np.array_equal(r["logi"], np.round(r["logi"]))

@@ -306,3 +306,48 @@ def test_tsr_stage_matches_oracle_chain(eng_proc, lore_sd, proc_sd):
         frac = ref_st - np.floor(ref_st)
         safe = np.abs(frac - 0.5) > 5e-3
         assert np.array_equal(res["logi"][safe], od.process_logic_output(stacked)[0].numpy()[safe])
+
+
+# ---- 'wireless' detector (ResNet-18 backbone) ------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1, 128, 192), (2, 64, 128), (1, 256, 256)])
+def test_lore_wireless_net_x3_matches_oracle(eng, shape):
+    from pdf_table_amd.synth_weights import lore_wireless_state_dict
+    from pdf_table_amd.weights import pack_lore_wireless
+    sd = lore_wireless_state_dict(seed=23)
+    eng.load_weights(L.PT_MODEL_LORE_RESNET18, pack_lore_wireless(sd))
+    n, H, W = shape
+    g = torch.Generator().manual_seed(700 + W)
+    x = torch.randn(n, 3, H, W, generator=g)
+    with torch.no_grad():
+        ref = lore_net.lore_wireless_forward(sd, x)
+    eng.set_precision(L.PT_PRECISION_BF16X3)
+    try:
+        got = eng.tsr_forward_net(_x4(x, split=True).cuda(), wireless=True)
+        torch.cuda.synchronize()
+    finally:
+        eng.set_precision(L.PT_PRECISION_BF16)
+    assert _cmp(got, ref, f"lore wireless x3 {shape}") <= TOL_REL
+
+
+def test_lore_wireless_net_matches_reference_golden_and_bf16(eng, golden_dir):
+    from pdf_table_amd.synth_weights import lore_wireless_state_dict
+    from pdf_table_amd.weights import pack_lore_wireless
+    gold = np.load(os.path.join(golden_dir, "lore_wireless.npz"))
+    sd = lore_wireless_state_dict(int(gold["seed"]))
+    eng.load_weights(L.PT_MODEL_LORE_RESNET18, pack_lore_wireless(sd))
+    eng.set_precision(L.PT_PRECISION_BF16X3)
+    try:
+        for tag in ("a", "b"):
+            got = eng.tsr_forward_net(_x4(torch.from_numpy(gold[f"x_{tag}"]), split=True).cuda(), wireless=True)
+            for k in HEADS:
+                gk = got[k].cpu().permute(0, 3, 1, 2).numpy()
+                gk = gk[:, ::8] if gk.shape[1] == 256 else gk
+                r = gold[f"{k}_{tag}"]
+                assert np.abs(gk - r).max() / max(1.0, np.abs(r).max()) <= TOL_REL, (tag, k)
+    finally:
+        eng.set_precision(L.PT_PRECISION_BF16)
+    x = torch.from_numpy(gold["x_a"]).to(torch.bfloat16).float()
+    with torch.no_grad():
+        ref = lore_net.lore_wireless_forward(sd, x)
+    got = eng.tsr_forward_net(_x4(x).cuda(), wireless=True)
+    assert _cmp(got, ref, "lore wireless bf16") <= 0.1

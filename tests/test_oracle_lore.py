@@ -74,17 +74,20 @@ def _decode_case(gold, tag):
     import sys
     sys.path.insert(0, HERE)
     from lore_synth import synth_lore_heads
-    seed, H, W, src_h, src_w, rev = [int(v) for v in gold[f"case_{tag}"]]
+    seed, H, W, src_h, src_w, rev, ul = [int(v) for v in gold[f"case_{tag}"]]
     heads = {k: torch.from_numpy(v) for k, v in synth_lore_heads(seed, H, W).items()}
-    return heads, gold[f"meta_{tag}"], bool(rev)
+    from oracle import lore_decode as od
+    _, meta = od.lore_preprocess_geometry(src_h, src_w, 4 * H, 4 * W, upper_left=bool(ul))
+    assert np.array_equal(meta, gold[f"meta_{tag}"])
+    return heads, gold[f"meta_{tag}"], bool(rev), bool(ul)
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_decode_equals_reference(tag):
     from oracle import lore_decode as od
     gold = np.load(os.path.join(HERE, "golden", "lore_decode.npz"))
-    heads, meta, rev = _decode_case(gold, tag)
-    logi, ps, polys, results = od.process_detect_output(heads, meta, wiz_rev=rev, vis_thresh=0.2)
+    heads, meta, rev, ul = _decode_case(gold, tag)
+    logi, ps, polys, results = od.process_detect_output(heads, meta, wiz_rev=rev, vis_thresh=0.2, upper_left=ul)
     assert logi.shape[1] == gold[f"logi_{tag}"].shape[1] > 20
     assert np.array_equal(logi.numpy(), gold[f"logi_{tag}"])
     assert np.array_equal(ps.numpy(), gold[f"ps_{tag}"])
@@ -156,3 +159,16 @@ def test_warp_affine_known_answers():
     out = lore_pre.warp_affine_u8(img, hshift, 30, 20).astype(np.int64)
     exp = (img[:, 1:].astype(np.int64) + img[:, :-1] + 1) >> 1
     assert np.array_equal(out[:, 1:], exp)
+
+
+def test_wireless_detector_equals_reference_module():
+    from pdf_table_amd.synth_weights import lore_wireless_state_dict
+    gold = np.load(os.path.join(HERE, "golden", "lore_wireless.npz"))
+    sd = lore_wireless_state_dict(int(gold["seed"]))
+    for tag in ("a", "b"):
+        with torch.no_grad():
+            z = lore_net.lore_wireless_forward(sd, torch.from_numpy(gold[f"x_{tag}"]))
+        for k in lore_net.HEADS:
+            v = z[k].numpy()
+            v = v[:, ::8] if v.shape[1] == 256 else v
+            assert np.allclose(v, gold[f"{k}_{tag}"], atol=2e-5, rtol=1e-5), (tag, k, np.abs(v - gold[f"{k}_{tag}"]).max())

@@ -93,12 +93,21 @@ def test_lore_host_logic_matches_oracle():
         q = np.random.default_rng(h).uniform(-5, iw / 4 + 5, (40, 8)).astype(np.float32)
         ref = np.concatenate([od.transform_preds(q[:, 2 * k:2 * k + 2], m1[:2], m1[2], (m1[6], m1[5])) for k in range(4)], 1)
         assert np.array_equal(ts.transform_quads(q, m2), ref.astype(np.float32))
+    for (h, w, ih, iw) in [(500, 333, 768, 768), (300, 420, 768, 768)]:          # the 'wireless' upper-left geometry
+        t1, m1 = od.lore_preprocess_geometry(h, w, ih, iw, upper_left=True)
+        mi, m2 = ts.lore_geometry(h, w, ih, iw, upper_left=True)
+        assert np.array_equal(m1, m2) and np.array_equal(lore_pre.invert_affine(t1), mi) and m2[:3].tolist() == [0, 0, max(h, w)]
+        q = np.random.default_rng(w).uniform(-5, iw / 4 + 5, (40, 8)).astype(np.float32)
+        ref = np.concatenate([od.transform_preds(q[:, 2 * k:2 * k + 2], m1[:2], m1[2], (m1[6], m1[5]), True) for k in range(4)], 1)
+        assert np.array_equal(ts.transform_quads(q, m2, True), ref.astype(np.float32))
     lg = np.random.default_rng(1).uniform(-1, 12, (50, 4)).astype(np.float32)
     lg[:4, 0] = [2.5, 3.5, 0.5, 7.500001]
     assert np.array_equal(ts.process_logic_output(lg), od.process_logic_output(torch.from_numpy(lg)).numpy())
     wtw, ptn = ts.LoreConfig(task_type="wtw"), ts.LoreConfig(task_type="ptn")
     assert (wtw.resolution, wtw.wiz_rev, wtw.wiz_2dpe, wtw.vis_thresh, wtw.tsfm_layers) == ((1024, 1024), True, False, 0.2, 4)
     assert (ptn.resolution, ptn.wiz_rev, ptn.wiz_2dpe, ptn.vis_thresh, ptn.tsfm_layers) == ((512, 512), False, True, 0.35, 3)
+    wl = ts.LoreConfig(task_type="wireless")
+    assert (wl.backbone, wl.resolution, wl.upper_left, wl.wiz_rev, wl.wiz_2dpe) == ("ResNet-18", (768, 768), True, False, True)
 
 
 def test_layout_decode_matches_oracle_postprocess():
