@@ -277,7 +277,9 @@ def main():
         """software pipeline: all device work of step k is enqueued before the host halves run (the detection
         post-process of step k-1 first), so the GPU queue never drains while the host works"""
         nonlocal nboxes, ntok, ncells, nlayout
-        prev = None
+        prev = None          # detection maps of the previous step (host post-process pending)
+        tprev = None         # table-structure state of the previous step (cell counts, processor, host shaping pending)
+        tproc = None         # ... of two steps ago (processor queued, rows on their way to pinned memory)
         for k in range(steps):
             t0 = time.perf_counter()
             lay = layout.forward(pages) if layout is not None else None      # resize, LCNet/CSP-PAN/PicoHead, candidates (async)
@@ -288,7 +290,7 @@ def main():
             tpend = None
             if tsr is not None:
                 tsr_tables, tsr_metas = tsr.tables((PAGE, PAGE), table_boxes)    # host: one affine map per table
-                tpend = tsr.start(pages, tsr_tables)           # warp, DLA-34+DCN, decode (async)
+                tpend = (tsr.start(pages, tsr_tables), tsr_metas)                # warp, DLA-34+DCN, decode (async)
             tick("enqueue", t0)
             t0 = time.perf_counter()
             if prev is not None and not args.no_post:          # host half of the previous step, under this step's GPU work
@@ -303,23 +305,33 @@ def main():
                     nlayout += sum(len(r) for r in lres)
             tick("layout_post", t0)
             t0 = time.perf_counter()
-            if tsr is not None:
-                tres = tsr.finish(tpend, tsr_metas)            # cell counts D2H, processor, quads + logical locations
-                if count:
-                    ncells += sum(len(t["polygons"]) for t in tres)
-            tick("tsr_finish", t0)
-            t0 = time.perf_counter()
             if rec_ids is not None:
                 from pdf_table_amd.rec_stage import ctc_collapse
                 toks = ctc_collapse(rec_ids.cpu().numpy())     # D2H of int32 [lines, 160] + host collapse
                 if count:
                     ntok += sum(len(t) for t in toks)
             tick("ctc", t0)
+            t0 = time.perf_counter()
+            if tproc is not None:      # tables of two steps ago: their rows reached pinned memory during the last step
+                tres = tsr.collect(tproc[0], tproc[1])
+                if count:
+                    ncells += sum(len(t["polygons"]) for t in tres)
+            tproc = None
+            if tprev is not None:      # tables of the previous step: counts are ready, the processor and its D2H are queued
+                tproc = (tsr.process(tprev[0]), tprev[1])      # behind this step's work; nothing here blocks on this step
+            tick("tsr_finish", t0)
             prev = cur
+            tprev = tpend
         if prev is not None and not args.no_post:
             res = stage.boxes(prev[0], prev[1], (PAGE, PAGE), prev[2])
             if count:
                 nboxes += sum(len(r) for r in res)
+        for fin in ((lambda: tsr.collect(tproc[0], tproc[1])) if tproc is not None else None,
+                    (lambda: tsr.finish(tprev[0], tprev[1])) if tprev is not None else None):
+            if fin is not None:
+                tres = fin()
+                if count:
+                    ncells += sum(len(t["polygons"]) for t in tres)
 
     run(args.warmup)
     barrier()

@@ -156,6 +156,7 @@ class TsrStage:
         self.micro_batch = micro_batch
         self.bgr = bgr
         self.with_html = with_html      # also emit 'structure_str_list' (show_results :292-303)
+        self._copy_stream = None
 
     def tables(self, page_shape: Tuple[int, int], boxes_per_page: Sequence[np.ndarray]):
         """integer table boxes [k,4] (x1,y1,x2,y2) per page, cropped like crop_image_by_box
@@ -191,21 +192,48 @@ class TsrStage:
             pending.append((i, len(tb), counts, dets, logi))
         return pending
 
-    def finish(self, pending, metas: List[np.ndarray]) -> List[Dict]:
-        """device half 2 + host half: cell counts to the host (synchronises), the processor over all cells of a micro-batch,
-        quads back to source pixels, logical rounding -> per table {'polygons' f32 [n,8], 'logi' f32 [n,4] (integer
-        valued), 'logic_axis', 'stacked_axis' (unrounded), 'scores'} like TableLorePostProcessor's result dict."""
+    def process(self, pending):
+        """device half 2: cell counts to the host (waits for half 1 of these tables only when it is still running), the
+        processor over all cells of each micro-batch, then the valid rows to pinned host memory on a copy stream behind
+        an event -- nothing here waits for work queued after start()."""
         cfg = self.config
-        out: List[Dict] = []
         staged = []
         for (i, nt, counts_d, dets, logi) in pending:
             counts = counts_d.cpu().numpy()
             logic, stacked = self.eng.tsr_process(logi, dets, counts, use_2dpe=cfg.wiz_2dpe)
             staged.append((i, nt, counts, dets, logic, stacked))
-        for (i, nt, counts, dets, logic, stacked) in staged:
-            nmax = max(1, int(counts.max()) if len(counts) else 1)
-            dets_h = dets[:, :nmax].cpu().numpy()
-            logic_h, stacked_h = logic[:, :nmax].cpu().numpy(), stacked[:, :nmax].cpu().numpy()
+        if not staged:
+            return [], None
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=staged[0][3].device)
+        ready = torch.cuda.Event()
+        ready.record()
+        host = []
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(ready)
+            for (i, nt, counts, dets, logic, stacked) in staged:
+                nmax = max(1, int(counts.max()) if len(counts) else 1)
+                bufs = []
+                for src in (dets, logic, stacked):
+                    dst = torch.empty((src.shape[0], nmax, src.shape[2]), dtype=torch.float32, pin_memory=True)
+                    dst.copy_(src[:, :nmax], non_blocking=True)
+                    src.record_stream(self._copy_stream)
+                    bufs.append(dst)
+                host.append((i, nt, counts, bufs))
+            done = torch.cuda.Event()
+            done.record(self._copy_stream)
+        return host, done
+
+    def collect(self, processed, metas: List[np.ndarray]) -> List[Dict]:
+        """host half: quads back to source pixels, logical rounding -> per table {'polygons' f32 [n,8], 'logi' f32 [n,4]
+        (integer valued), 'logic_axis', 'stacked_axis' (unrounded), 'scores'} like TableLorePostProcessor's result dict."""
+        cfg = self.config
+        host, done = processed
+        if done is not None:
+            done.synchronize()
+        out: List[Dict] = []
+        for (i, nt, counts, bufs) in host:
+            dets_h, logic_h, stacked_h = (b.numpy() for b in bufs)
             for k in range(nt):
                 n = int(counts[k])
                 if n == 0:       # LoreModel.forward's empty case (modeling_lore.py:171-173)
@@ -221,6 +249,9 @@ class TsrStage:
                     r["structure_str_list"] = [structure_html(r["polygons"], r["logi"])]
                 out.append(r)
         return out
+
+    def finish(self, pending, metas: List[np.ndarray]) -> List[Dict]:
+        return self.collect(self.process(pending), metas)
 
     def run(self, pages: torch.Tensor, tables: np.ndarray, metas: List[np.ndarray]) -> List[Dict]:
         return self.finish(self.start(pages, tables), metas)
