@@ -62,6 +62,7 @@ enum {
   PT_MODEL_LORE_DLA34 = 3,  /* lore/lore_dla_34.py:137-206 (DLASeg on dla34 + DCN), modeling_lore.py:88-95 */
   PT_MODEL_LORE_PROCESSOR = 4, /* lore/lore_processor.py:399-514 (LoreProcessModel) */
   PT_MODEL_LORE_RESNET18 = 6, /* lore/lore_detector.py:155-389 (LoreDetectModel, the 'wireless' detector) */
+  PT_MODEL_DB_NAS = 7,        /* db_net/dbnet.py:693-712 (DBNasModel: ProxylessNAS backbone + LightSegDetector) */
   PT_MODEL_PICODET = 5,     /* picodet/lcnet.py:159-259 + csp_pan.py:233-347 + pico_head.py:966-1160 (assumed config) */
 };
 int pt_weights_load(pt_engine* e, int model_kind, const void* h_blob, size_t nbytes);
@@ -111,7 +112,9 @@ int pt_layout_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h, in
 /* Resized (network) size the reference's pre-processor gives an h x w page. Pure host arithmetic. */
 int pt_det_plan(int h, int w, int pre_flavour, int* net_h, int* net_w);
 
-/* Full detection forward for n pages of identical size.
+/* Full detection forward for n pages of identical size.  The detector network is the one loaded LAST with
+ * pt_weights_load: PT_MODEL_DB_RESNET18 (`DBModel`) or PT_MODEL_DB_NAS (`DBNasModel`), the two backbones
+ * modeling_db_net.py:47-52 chooses between.
  *   d_pages_rgb : uint8 [n, h, w, 3] RGB (as np.array(PIL.Image) gives; the BGR flip is done inside)
  *   d_prob      : float32 [n, net_h, net_w]   sigmoid probability map   (may be NULL)
  *   d_bitmap    : uint32  [n, net_h, net_w/32] bit x%32 of word x/32 = (prob > thresh), optionally

@@ -110,6 +110,7 @@ static int register_blob(pt_engine* e, int kind, const uint8_t* h_head, size_t h
     (void)hipFree(old->second.d_blob);
   }
   e->models[kind] = m;
+  if (kind == PT_MODEL_DB_RESNET18 || kind == PT_MODEL_DB_NAS) e->det_kind = kind;   // the active detector
   return PT_OK;
 }
 
@@ -159,6 +160,12 @@ int pt_weights_load_device(pt_engine* e, int model_kind, const void* d_blob, siz
 }
 
 // ---- detection ---------------------------------------------------------------------------------------
+// the detector network loaded last: `DBModel` or `DBNasModel` (modeling_db_net.py:47-52)
+static int det_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* prob, float* logits, hipStream_t s) {
+  if (e->det_kind == PT_MODEL_DB_NAS) return pt_dbnas_forward_net(e, x, n, H, W, prob, logits, s);
+  return pt_db_forward_net(e, x, n, H, W, prob, logits, s);
+}
+
 int pt_det_plan(int h, int w, int pre_flavour, int* net_h, int* net_w) {
   PT_REQUIRE(h > 0 && w > 0 && net_h && net_w, "pt_det_plan: bad arguments");
   if (pre_flavour == PT_DET_PRE_DB_PP) {
@@ -206,7 +213,7 @@ int pt_det_forward_net(pt_engine* e, const uint16_t* d_input_bf16, int n, int ne
                        float* d_logits, pt_stream stream) {
   PT_REQUIRE(e && d_input_bf16 && n > 0 && (d_prob || d_logits), "pt_det_forward_net: bad arguments");
   PT_HIP_CHECK(hipSetDevice(e->device));
-  return pt_db_forward_net(e, d_input_bf16, n, net_h, net_w, d_prob, d_logits, reinterpret_cast<hipStream_t>(stream));
+  return det_net(e, d_input_bf16, n, net_h, net_w, d_prob, d_logits, reinterpret_cast<hipStream_t>(stream));
 }
 
 // ---- layout (PicoDet) ---------------------------------------------------------------------------------
@@ -380,7 +387,7 @@ int pt_det_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h, int w
       if (rc != PT_OK) return rc;
     }
     float* prob_i = d_prob + (size_t)i0 * nh * nw;
-    rc = pt_db_forward_net(e, reinterpret_cast<const bf16_t*>(xbuf), nb, nh, nw, prob_i, nullptr, s);
+    rc = det_net(e, reinterpret_cast<const bf16_t*>(xbuf), nb, nh, nw, prob_i, nullptr, s);
     if (rc != PT_OK) return rc;
     if (d_bitmap) {
       PtProfScope ps(e, s, PT_PROF_OTHER, 0, "bitmap");

@@ -95,6 +95,7 @@ struct pt_engine {
   std::map<int, PtModel> models;
   PtProfile prof;
   int precision = 0;  // PT_PRECISION_*
+  int det_kind = PT_MODEL_DB_RESNET18;   // detector network pt_det_forward* runs: the one loaded last
   // engine-owned scratch of the recognition stage (outside the arena, which every net forward resets)
   void* rec_crops = nullptr; size_t rec_crops_cap = 0;
   void* rec_gray = nullptr; size_t rec_gray_cap = 0;
@@ -126,7 +127,8 @@ struct ConvDesc {
   // residual
   const bf16_t* res = nullptr;
   int res_mode = 0;  // 0 none, 1 same resolution, 2 half resolution (fused nearest x2 upsample + add)
-  int relu = 0;      // activation: 0 none, 1 ReLU, 2 hardswish
+  int relu = 0;      // activation: 0 none, 1 ReLU, 2 hardswish, 3 PReLU(slope)
+  const float* slope = nullptr;   // device pointer to the PReLU slope (relu == 3)
   // bf16x3 precision mode: in/res/out hold (hi | lo) channel groups; w is [N/64][3*Cin/32][taps][64][32]
   int split = 0;
   int out_lo_off = 0;  // channel distance between the hi and lo halves in the output buffer
@@ -159,6 +161,19 @@ int pt_launch_bitmap(const float* prob, int n, int H, int W, float thresh, int d
                      hipStream_t s);
 int pt_launch_box_scores(const float* prob, int n, int H, int W, const float* boxes, int nb, float* scores,
                          hipStream_t s);
+
+// ---- mobile-net kernels shared by PicoDet and DB-ProxylessNAS (layout_kernels.hip) ----------------------
+#define PT_SE_CHUNKS 64
+int pt_launch_stem3x3s2(const bf16_t* in, const float* w, const float* b, bf16_t* out, int B, int H, int W, int split,
+                        hipStream_t s, int variant);
+int pt_launch_dwconv(const bf16_t* in, const float* w, const float* b, bf16_t* out, int B, int H, int W, int C, int k,
+                     int stride, int act, int split, hipStream_t s, const float* slope);
+int pt_launch_se(const bf16_t* x, const float* w1, const float* b1, const float* w2, const float* b2, float* gate,
+                 bf16_t* out, int B, int HW, int C, int split, hipStream_t s, int hidden, int mode, float* part);
+int pt_launch_add(const bf16_t* a, const bf16_t* b, bf16_t* out, long long npix, int C, int split, hipStream_t s);
+int pt_launch_dbnas_tail(const bf16_t* y, const float* tw, int B, int H4, int W4, int split, float* prob, float* logits,
+                         hipStream_t s);
+int pt_dbnas_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* prob, float* logits, hipStream_t s);
 
 // ---- recognition kernels (rec_kernels.hip) --------------------------------------------------------------
 int pt_launch_rec_offsets(const pt_rec_line* lines, int n, long long* off, hipStream_t s);

@@ -59,6 +59,7 @@ struct ConvK {
   const float* res_f32;   // fp32 residual with the layout of out_f32 (transformer residual stream), added before ReLU
   int n_group;            // > 0: column tiles are walked in groups of n_group so that a group's weights stay in one XCD's L2
   int gemm_nt;            // gemm1x1_kernel: number of 128-wide column tiles (n_tiles stays N / 64 for the arg-max partials)
+  const float* slope;     // relu == 3: PReLU, slope[0] = the (single, layer-wide) negative slope, read on the device
   long long m_flat;       // > 0: the (Ho x 32) geometry is a flat list of m_flat pixels (gemm1x1_kernel); rows beyond it are skipped
 };
 
@@ -159,6 +160,10 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
     } else if (EXTRAS && p.relu == 2) {   // hardswish: x * relu6(x + 3) / 6 (PicoDet's LCNet / CSP-PAN / head)
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = v[k] * fminf(fmaxf(v[k] + 3.f, 0.f), 6.f) / 6.f;
+    } else if (EXTRAS && p.relu == 3) {   // nn.PReLU() with one shared slope (DB-ProxylessNAS, db_net/layers.py:696,722)
+      const float sl = p.slope[0];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : sl * v[k];
     }
     uint32_t hb[8];
 #pragma unroll
@@ -1240,14 +1245,15 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   k.Ho = (d.H + 2 * pad - d.ks) / d.stride + 1;
   k.Wo = (d.W + 2 * pad - d.ks) / d.stride + 1;
   k.out_cstride = d.out_cstride; k.out_coff = d.out_coff; k.rep = d.rep; k.shuffle_cout = d.shuffle_cout;
-  k.res_mode = d.res ? d.res_mode : 0; k.relu = d.relu;
+  k.res_mode = d.res ? d.res_mode : 0; k.relu = d.relu; k.slope = d.slope;
+  PT_REQUIRE(d.relu != 3 || d.slope, "conv: PReLU needs the slope tensor");
   k.split = d.split; k.out_lo_off = d.out_lo_off;
   k.head_w = d.head_w; k.head_b = d.head_b; k.head_prob = d.head_prob; k.head_logits = d.head_logits;
   k.argmax_part = d.argmax_part;
   if (d.head_w) PT_REQUIRE(d.shuffle_cout == 64 && d.head_b && (d.head_prob || d.head_logits), "conv: bad fused-head configuration");
   if (k.res_mode == 2) PT_REQUIRE(k.Ho % 2 == 0 && k.Wo % 2 == 0, "conv: half-res residual needs even output size");
   const double flop = 2.0 * k.B * k.Ho * k.Wo * (double)k.N * d.Cin * d.ks * d.ks;  // algorithmic (not x3 in split mode)
-  if (d.ks == 3 && d.stride == 1 && !d.head_w && !d.argmax_part && !d.n_valid && !d.out_f32 && !d.res_f32 && d.relu != 2 && use_dma_kernel()) {
+  if (d.ks == 3 && d.stride == 1 && !d.head_w && !d.argmax_part && !d.n_valid && !d.out_f32 && !d.res_f32 && d.relu < 2 && use_dma_kernel()) {
     // steady-state A/B on MI355X (tools/ab3.sh, round 1): the 16-channel-slice DMA kernel (v3) wins on >= 120-row maps
     // with K >= 128 channels, the 32-channel-slice DMA kernel (v2) on 60..119-row maps, the register-staged kernel
     // (v1) on short-K layers and on small maps, where the big DMA tiles leave CUs idle

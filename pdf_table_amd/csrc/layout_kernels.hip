@@ -1,4 +1,5 @@
-// layout_kernels.hip -- the non-GEMM kernels of the PicoDet layout detector (all bandwidth-type work).
+// layout_kernels.hip -- the non-GEMM kernels of the two mobile-style nets, the PicoDet layout detector and the
+// DB-ProxylessNAS text detector (all bandwidth-type work).
 //
 //   stem3x3s2_kernel   LCNet.conv1: conv 3x3 s2 (3 -> 16) + BN + hardswish (picodet/lcnet.py:165-170), direct VALU
 //   dwconv_kernel      depthwise k x k (3 / 5), stride 1 / 2, + BN + optional hardswish: DepthwiseSeparable.dw_conv
@@ -8,6 +9,11 @@
 //   add_kernel         CSPPAN's `top_features = first_top_conv(..) + second_top_conv(..)` (csp_pan.py:338-340)
 //   pico_candidates_kernel  anchors whose best class score can pass the post-processor's threshold, with their raw head
 //                      outputs (processor_picodet.py:250-262 only ever looks at those)
+// DB-ProxylessNAS (db_net/proxyless.py, layers.py, dbnet.py:338-481) re-uses the stem (32 outputs + ReLU), dwconv (PReLU
+// / ReLU) and SE kernels (sigmoid gate inside a residual block: x * (1 + gate), hidden width C / squeeze) and adds
+//   chan_partial_sum_kernel  deterministic two-level global average pool for SE at 1/4 .. 1/32 resolution
+//   dbnas_tail_kernel        everything after the 64->16 pointwise conv of LightSegDetector.binarize in one pass:
+//                            ConvT(dw 2x2 s2)+BN+ReLU, 1x1 16->16+BN+ReLU, ConvT(dw 2x2 s2)+BN+ReLU, 1x1 16->1, sigmoid
 // NHWC bf16; BF16X3 mode: [hi(C) | lo(C)] per pixel, arithmetic on hi + lo in fp32.
 #include "common.h"
 
@@ -50,14 +56,16 @@ __device__ __forceinline__ void store8(bf16_t* p, int lo_off, int split, const f
   }
 }
 
-// in: NHWC4 [B,H,W,4] ([hi rgb0 | lo rgb0] when split); w fp32 [16][3][3][4]; out [B,Ho,Wo,32], channels 16..31 zero
+// in: NHWC4 [B,H,W,4] ([hi rgb0 | lo rgb0] when split); w fp32 [NOUT][3][3][4]; out [B,Ho,Wo,OST], channels NOUT..OST-1
+// zero.  ACT 2: hardswish (LCNet.conv1), 1: ReLU (CompactDetBackbone.first_conv, proxyless.py:101-110)
+template <int NOUT, int OST, int ACT>
 __global__ __launch_bounds__(256) void stem3x3s2_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w,
                                                          const float* __restrict__ b, bf16_t* __restrict__ out, int B,
                                                          int H, int W, int Ho, int Wo, int split) {
-  __shared__ float sw[16 * 36];
-  __shared__ float sb[16];
-  for (int i = threadIdx.x; i < 16 * 36; i += 256) sw[i] = w[i];
-  if (threadIdx.x < 16) sb[threadIdx.x] = b[threadIdx.x];
+  __shared__ float sw[NOUT * 36];
+  __shared__ float sb[NOUT];
+  for (int i = threadIdx.x; i < NOUT * 36; i += 256) sw[i] = w[i];
+  if (threadIdx.x < NOUT) sb[threadIdx.x] = b[threadIdx.x];
   __syncthreads();
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long long)B * Ho * Wo) return;
@@ -77,29 +85,34 @@ __global__ __launch_bounds__(256) void stem3x3s2_kernel(const bf16_t* __restrict
         for (int c = 0; c < 3; ++c) d[c] = bf2f(p[c]) + (split ? bf2f(p[4 + c]) : 0.f);
       }
     }
-  float o[16];
+  bf16_t* op = out + (size_t)i * (split ? 2 * OST : OST);
 #pragma unroll
-  for (int n = 0; n < 16; ++n) {
-    float a = 0.f;
+  for (int n0 = 0; n0 < NOUT; n0 += 8) {
+    float o[8];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int n = 0; n < 8; ++n) {
+      float a = 0.f;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) a += px[t][c] * sw[n * 36 + t * 4 + c];
-    o[n] = hswish(a + sb[n]);
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a += px[t][c] * sw[(n0 + n) * 36 + t * 4 + c];
+      a += sb[n0 + n];
+      o[n] = ACT == 2 ? hswish(a) : fmaxf(a, 0.f);
+    }
+    store8(op + n0, OST, split, o);
   }
-  bf16_t* op = out + (size_t)i * (split ? 64 : 32);
   const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  store8(op, 32, split, o);
-  store8(op + 8, 32, split, o + 8);
-  store8(op + 16, 32, split, z);
-  store8(op + 24, 32, split, z);
+#pragma unroll
+  for (int n0 = NOUT; n0 < OST; n0 += 8) store8(op + n0, OST, split, z);
 }
 
 // w fp32 [k*k][C] (BN scale folded), b fp32 [C]
 __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w,
                                                       const float* __restrict__ b, bf16_t* __restrict__ out, int B, int H,
-                                                      int W, int C, int k, int stride, int Ho, int Wo, int act, int split) {
+                                                      int W, int C, int k, int stride, int Ho, int Wo, int act, int split,
+                                                      const float* __restrict__ slope) {
   const int cgn = C >> 3, cs = split ? 2 * C : C, pad = k / 2;
+  const float sl = act == 3 ? slope[0] : 0.f;
   const long long total = (long long)B * Ho * Wo * cgn;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int cg = (int)(i % cgn);
@@ -128,26 +141,61 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
     for (int q = 0; q < 8; ++q) {
       acc[q] += b[cg * 8 + q];
       if (act == 2) acc[q] = hswish(acc[q]);
+      else if (act == 1) acc[q] = fmaxf(acc[q], 0.f);
+      else if (act == 3) acc[q] = acc[q] > 0.f ? acc[q] : sl * acc[q];
     }
     store8(out + (((size_t)bi * Ho + oy) * Wo + ox) * cs + cg * 8, C, split, acc);
   }
 }
 
-// one workgroup per image: gate[b][c] = hardsigmoid(W2 relu(W1 mean_hw(x) + b1) + b2); C <= 512, C/4 <= 128
+// global-average-pool partial sums, deterministic: block (chunk, image) sums its pixel range per channel
+// part: fp32 [B][gridDim.x][C]
+__global__ __launch_bounds__(256) void chan_partial_sum_kernel(const bf16_t* __restrict__ x, int HW, int C, int split,
+                                                                float* __restrict__ part) {
+  __shared__ float s_acc[256][8];
+  const int cgn = C >> 3, cs = split ? 2 * C : C, nslot = 256 / cgn;
+  const int tid = threadIdx.x, cg = tid % cgn, slot = tid / cgn;
+  const int bi = blockIdx.y, nchunk = gridDim.x;
+  const int per = (HW + nchunk - 1) / nchunk, p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (slot < nslot)
+    for (int p = p0 + slot; p < p1; p += nslot) {
+      float v[8];
+      load8(x + ((size_t)bi * HW + p) * cs + cg * 8, C, split, v);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) a[q] += v[q];
+    }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) s_acc[tid][q] = a[q];
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float t = 0.f;
+    for (int sl = 0; sl < nslot; ++sl) t += s_acc[sl * cgn + (c >> 3)][c & 7];
+    part[((size_t)bi * nchunk + blockIdx.x) * C + c] = t;
+  }
+}
+
+// one workgroup per image: gate[b][c] = G(W2 relu(W1 mean_hw(x) + b1) + b2); C <= 512, hidden width Ch <= 128.
+// mode 0: G = hardsigmoid (LCNet SEModule); mode 1: G = 1 + sigmoid (SELayer inside an identity-shortcut block:
+// x + x * sigmoid(..), db_net/layers.py:480-489 + :50-57).  part != null: mean from nchunk partial sums.
 __global__ __launch_bounds__(256) void se_gate_kernel(const bf16_t* __restrict__ x, int HW, int C, const float* __restrict__ w1,
                                                        const float* __restrict__ b1, const float* __restrict__ w2,
-                                                       const float* __restrict__ b2, float* __restrict__ gate, int split) {
+                                                       const float* __restrict__ b2, float* __restrict__ gate, int split,
+                                                       int Ch, int mode, const float* __restrict__ part, int nchunk) {
   __shared__ float s_mean[512];
   __shared__ float s_hid[128];
   const int bi = blockIdx.x, tid = threadIdx.x, cs = split ? 2 * C : C;
   for (int c = tid; c < C; c += 256) {
     float s = 0.f;
-    const bf16_t* p = x + (size_t)bi * HW * cs + c;
-    for (int i = 0; i < HW; ++i) s += bf2f(p[(size_t)i * cs]) + (split ? bf2f(p[(size_t)i * cs + C]) : 0.f);
+    if (part) {
+      for (int i = 0; i < nchunk; ++i) s += part[((size_t)bi * nchunk + i) * C + c];
+    } else {
+      const bf16_t* p = x + (size_t)bi * HW * cs + c;
+      for (int i = 0; i < HW; ++i) s += bf2f(p[(size_t)i * cs]) + (split ? bf2f(p[(size_t)i * cs + C]) : 0.f);
+    }
     s_mean[c] = s / (float)HW;
   }
   __syncthreads();
-  const int Ch = C >> 2;
   for (int h = tid; h < Ch; h += 256) {
     float a = 0.f;
     for (int c = 0; c < C; ++c) a += w1[(size_t)h * C + c] * s_mean[c];
@@ -157,7 +205,9 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const bf16_t* __restrict__
   for (int c = tid; c < C; c += 256) {
     float a = 0.f;
     for (int h = 0; h < Ch; ++h) a += w2[(size_t)c * Ch + h] * s_hid[h];
-    gate[(size_t)bi * C + c] = fminf(fmaxf(a + b2[c] + 3.f, 0.f), 6.f) / 6.f;      // nn.Hardsigmoid
+    a += b2[c];
+    gate[(size_t)bi * C + c] = mode == 0 ? fminf(fmaxf(a + 3.f, 0.f), 6.f) / 6.f      // nn.Hardsigmoid
+                                         : 1.f + 1.f / (1.f + expf(-a));
   }
 }
 
@@ -212,6 +262,56 @@ __global__ __launch_bounds__(256) void pico_candidates_kernel(const float* __res
   for (int c = 0; c < 40; ++c) o[2 + c] = h[c];
 }
 
+// LightSegDetector.binarize after its first pointwise conv (dbnet.py:383-386 with DwPwConvTranspose :75-99), one thread
+// per 1/4-resolution pixel.  y: bf16 [B,H4,W4,16] (ReLU already applied); tw fp32, BN folded:
+//   [0,64) W1[q][c]  [64,80) B1[c]  [80,336) P1[j][c]  [336,352) pb1[j]  [352,416) W2[r][c]  [416,432) B2[c]
+//   [432,448) P2[c]  [448] pb2          (q, r = 2*dy + dx sub-pixel of the two transposed convs)
+// prob / logits: fp32 [B, 4*H4, 4*W4]
+__global__ __launch_bounds__(256) void dbnas_tail_kernel(const bf16_t* __restrict__ y, const float* __restrict__ tw, int B,
+                                                          int H4, int W4, int split, float* __restrict__ prob,
+                                                          float* __restrict__ logits) {
+  __shared__ float sw[449];
+  for (int i = threadIdx.x; i < 449; i += 256) sw[i] = tw[i];
+  __syncthreads();
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * H4 * W4) return;
+  const int x4 = (int)(i % W4), y4 = (int)((i / W4) % H4), bi = (int)(i / ((long long)W4 * H4));
+  float v[16];
+  const bf16_t* yp = y + (size_t)i * (split ? 32 : 16);
+  load8(yp, 16, split, v);
+  load8(yp + 8, 16, split, v + 8);
+  const int OH = 4 * H4, OW = 4 * W4;
+  float res[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float a[16], u[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = fmaxf(v[c] * sw[q * 16 + c] + sw[64 + c], 0.f);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float t = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) t += sw[80 + j * 16 + c] * a[c];
+      u[j] = fmaxf(t + sw[336 + j], 0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float t = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) t += sw[432 + c] * fmaxf(u[c] * sw[352 + r * 16 + c] + sw[416 + c], 0.f);
+      res[2 * (q >> 1) + (r >> 1)][2 * (q & 1) + (r & 1)] = t + sw[448];
+    }
+  }
+#pragma unroll
+  for (int ry = 0; ry < 4; ++ry) {
+    const size_t o = ((size_t)bi * OH + 4 * y4 + ry) * OW + 4 * x4;
+    if (logits) *reinterpret_cast<float4*>(logits + o) = make_float4(res[ry][0], res[ry][1], res[ry][2], res[ry][3]);
+    if (prob)
+      *reinterpret_cast<float4*>(prob + o) = make_float4(1.f / (1.f + expf(-res[ry][0])), 1.f / (1.f + expf(-res[ry][1])),
+                                                         1.f / (1.f + expf(-res[ry][2])), 1.f / (1.f + expf(-res[ry][3])));
+  }
+}
+
 inline int blocks_for(long long total, int cap = 256 * 64) {
   long long b = (total + 255) / 256;
   if (b > cap) b = cap;
@@ -221,31 +321,50 @@ inline int blocks_for(long long total, int cap = 256 * 64) {
 }  // namespace
 
 int pt_launch_stem3x3s2(const bf16_t* in, const float* w, const float* b, bf16_t* out, int B, int H, int W, int split,
-                        hipStream_t s) {
-  PT_REQUIRE(in && w && b && out, "layout stem: null pointer");
+                        hipStream_t s, int variant) {
+  PT_REQUIRE(in && w && b && out, "stem3x3: null pointer");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  hipLaunchKernelGGL(stem3x3s2_kernel, dim3((unsigned)(((long long)B * Ho * Wo + 255) / 256)), dim3(256), 0, s, in, w, b, out,
-                     B, H, W, Ho, Wo, split);
+  const dim3 grid((unsigned)(((long long)B * Ho * Wo + 255) / 256));
+  if (variant == 0)       // LCNet: 16 outputs stored 32 wide, hardswish
+    hipLaunchKernelGGL((stem3x3s2_kernel<16, 32, 2>), grid, dim3(256), 0, s, in, w, b, out, B, H, W, Ho, Wo, split);
+  else                    // ProxylessNAS: 32 outputs stored 64 wide, ReLU
+    hipLaunchKernelGGL((stem3x3s2_kernel<32, 64, 1>), grid, dim3(256), 0, s, in, w, b, out, B, H, W, Ho, Wo, split);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
 
 int pt_launch_dwconv(const bf16_t* in, const float* w, const float* b, bf16_t* out, int B, int H, int W, int C, int k,
-                     int stride, int act, int split, hipStream_t s) {
+                     int stride, int act, int split, hipStream_t s, const float* slope) {
   PT_REQUIRE(in && w && b && out && C % 8 == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2), "dwconv: bad arguments");
+  PT_REQUIRE(act != 3 || slope, "dwconv: PReLU needs the slope tensor");
   const int pad = k / 2, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   hipLaunchKernelGGL(dwconv_kernel, dim3(blocks_for((long long)B * Ho * Wo * (C / 8))), dim3(256), 0, s, in, w, b, out, B, H,
-                     W, C, k, stride, Ho, Wo, act, split);
+                     W, C, k, stride, Ho, Wo, act, split, slope);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
 
+// hidden: width of the squeeze layer; mode 0 hardsigmoid gate, 1: 1 + sigmoid (see se_gate_kernel); part: scratch of
+// PT_SE_CHUNKS * B * C floats for the two-level average pool, or null for the single-workgroup scan (tiny maps)
 int pt_launch_se(const bf16_t* x, const float* w1, const float* b1, const float* w2, const float* b2, float* gate,
-                 bf16_t* out, int B, int HW, int C, int split, hipStream_t s) {
-  PT_REQUIRE(x && w1 && b1 && w2 && b2 && gate && out && C <= 512 && C % 32 == 0, "SE: bad arguments");
-  hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), 0, s, x, HW, C, w1, b1, w2, b2, gate, split);
+                 bf16_t* out, int B, int HW, int C, int split, hipStream_t s, int hidden, int mode, float* part) {
+  PT_REQUIRE(x && w1 && b1 && w2 && b2 && gate && out && C <= 512 && C % 32 == 0 && hidden > 0 && hidden <= 128,
+             "SE: bad arguments");
+  if (part)
+    hipLaunchKernelGGL(chan_partial_sum_kernel, dim3(PT_SE_CHUNKS, B), dim3(256), 0, s, x, HW, C, split, part);
+  hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), 0, s, x, HW, C, w1, b1, w2, b2, gate, split, hidden, mode, part,
+                     PT_SE_CHUNKS);
   hipLaunchKernelGGL(se_scale_kernel, dim3((unsigned)(((long long)B * HW * (C / 8) + 255) / 256)), dim3(256), 0, s, x, gate, out, B,
                      HW, C, split);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_launch_dbnas_tail(const bf16_t* y, const float* tw, int B, int H4, int W4, int split, float* prob, float* logits,
+                         hipStream_t s) {
+  PT_REQUIRE(y && tw && (prob || logits), "dbnas tail: null pointer");
+  hipLaunchKernelGGL(dbnas_tail_kernel, dim3((unsigned)(((long long)B * H4 * W4 + 255) / 256)), dim3(256), 0, s, y, tw, B, H4, W4,
+                     split, prob, logits);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }

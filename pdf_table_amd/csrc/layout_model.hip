@@ -16,14 +16,6 @@
 
 #include "common.h"
 
-int pt_launch_stem3x3s2(const bf16_t* in, const float* w, const float* b, bf16_t* out, int B, int H, int W, int split,
-                        hipStream_t s);
-int pt_launch_dwconv(const bf16_t* in, const float* w, const float* b, bf16_t* out, int B, int H, int W, int C, int k,
-                     int stride, int act, int split, hipStream_t s);
-int pt_launch_se(const bf16_t* x, const float* w1, const float* b1, const float* w2, const float* b2, float* gate,
-                 bf16_t* out, int B, int HW, int C, int split, hipStream_t s);
-int pt_launch_add(const bf16_t* a, const bf16_t* b, bf16_t* out, long long npix, int C, int split, hipStream_t s);
-
 namespace {
 
 struct T {
@@ -85,7 +77,7 @@ struct Ctx {
     const PtTensor* b = get(q + ".b");
     if (go()) {
       PtProfScope ps(e, s, PT_PROF_OTHER, 0, "layout dwconv");
-      const int r = pt_launch_dwconv(in.p, F(w), F(b), o.p, n, in.H, in.W, in.C, k, stride, act, x3, s);
+      const int r = pt_launch_dwconv(in.p, F(w), F(b), o.p, n, in.H, in.W, in.C, k, stride, act, x3, s, nullptr);
       if (r != PT_OK) rc = r;
     }
     return o;
@@ -154,7 +146,7 @@ int pt_picodet_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, f
       const PtTensor* b = c.get("stem.b");
       if (c.go()) {
         PtProfScope ps(e, s, PT_PROF_STEM, 0, "layout stem3x3");
-        const int r = pt_launch_stem3x3s2(x, c.F(w), c.F(b), t.p, n, H, W, c.x3, s);
+        const int r = pt_launch_stem3x3s2(x, c.F(w), c.F(b), t.p, n, H, W, c.x3, s, 0);
         if (r != PT_OK) c.rc = r;
       }
     }
@@ -168,7 +160,7 @@ int pt_picodet_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, f
         T g = c.alloc(d.H, d.W, d.C);
         if (c.go()) {
           PtProfScope ps(e, s, PT_PROF_OTHER, 0, "layout SE");
-          const int r = pt_launch_se(d.p, c.F(w1), c.F(b1), c.F(w2), c.F(b2), c.gate, g.p, n, d.H * d.W, d.C, c.x3, s);
+          const int r = pt_launch_se(d.p, c.F(w1), c.F(b1), c.F(w2), c.F(b2), c.gate, g.p, n, d.H * d.W, d.C, c.x3, s, d.C / 4, 0, nullptr);
           if (r != PT_OK) c.rc = r;
         }
         d = g;

@@ -366,7 +366,8 @@ int pt_launch_maxpool_kxk(const bf16_t* in, int n, int H, int W, int C, int kh, 
 // Wave w owns hidden units [64w, 64w+64): its 8 MFMA tiles are (gate 0..3) x (32-unit half 0..1), so the four
 // gate pre-activations of one (line, unit) sit in the same lane and register index and the cell update is
 // lane-local; c stays in registers (fp32) for the whole sequence; h goes through LDS (double-buffered, bf16 or
-// hi/lo pair) as next step's A operand and to HBM as the layer output.  W_hh fragments stream from L2.
+// hi/lo pair) as next step's A operand and to HBM as the layer output.  W_hh streams from L2 in MFMA-fragment order
+// (packed that way by weights.pack_crnn), one contiguous 1 KB record per load instruction.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float fast_sigmoid(float x) {
   return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
@@ -376,6 +377,9 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.88539008177792681f * x)) - 1.f;
 }
 
+#ifndef PT_LSTM_ABL
+#define PT_LSTM_ABL 0
+#endif
 template <int SPLIT>
 __global__ __launch_bounds__(256, 1) void lstm_dir_kernel(const bf16_t* __restrict__ gx, const bf16_t* __restrict__ whh,
                                                            bf16_t* __restrict__ hout, int B, int T) {
@@ -408,8 +412,14 @@ __global__ __launch_bounds__(256, 1) void lstm_dir_kernel(const bf16_t* __restri
         const int line = line0 + m;
         const int lc = line < B ? line : B - 1;
         const bf16_t* gp = gx + ((size_t)lc * T + t) * gcs + dir * 1024 + (wave * 64 + h * 32 + lx) * 4;
+#if PT_LSTM_ABL == 3      /* ablation: no gx traffic (wrong results) */
+        gxv[h][r] = u32x2{(uint32_t)s, (uint32_t)r};
+        if (SPLIT) gxl[h][r] = gxv[h][r];
+        (void)gp;
+#else
         gxv[h][r] = *reinterpret_cast<const u32x2*>(gp);
         if (SPLIT) gxl[h][r] = *reinterpret_cast<const u32x2*>(gp + 2048);
+#endif
       }
     f32x16 acc[4][2];
 #pragma unroll
@@ -434,8 +444,14 @@ __global__ __launch_bounds__(256, 1) void lstm_dir_kernel(const bf16_t* __restri
           for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-              const int ncol = g * 256 + wave * 64 + h * 32 + lx;
-              bq[kq][g][h] = *reinterpret_cast<const bf16x8*>(wsrc + (size_t)ncol * 256 + (half * 4 + kq) * 16 + q * 8);
+              // fragment-ordered by the packer: [wave][half][kq][gate][h][lane][8] = column gate*256 + wave*64 +
+              // h*32 + lx, k = (half*4 + kq)*16 + q*8 ..+8
+#if PT_LSTM_ABL == 1      /* ablation: no W_hh traffic (wrong results) */
+              bq[kq][g][h] = *reinterpret_cast<const bf16x8*>(&hbuf[pa][lx][((kq * 4 + g) * 2 + h) * 8]);
+#else
+              bq[kq][g][h] = *reinterpret_cast<const bf16x8*>(
+                  wsrc + (size_t)(((((wave * 4 + half) * 4 + kq) * 4 + g) * 2 + h) * 64 + lane) * 8);
+#endif
             }
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq) {
@@ -467,10 +483,16 @@ __global__ __launch_bounds__(256, 1) void lstm_dir_kernel(const bf16_t* __restri
         }
         // sigmoid / tanh through the hardware exp2 + reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp, far inside the 1e-3
         // contract); tanh(x) = 2 sigmoid(2x) - 1
+#if PT_LSTM_ABL == 2      /* ablation: no transcendentals (wrong results) */
+        const float cn = gf * c[h][r] + gi * gg;
+        c[h][r] = cn;
+        const float hn = go * cn;
+#else
         const float si = fast_sigmoid(gi), sf = fast_sigmoid(gf), so = fast_sigmoid(go);
         const float cn = sf * c[h][r] + si * fast_tanh(gg);
         c[h][r] = cn;
         const float hn = so * fast_tanh(cn);
+#endif
         const uint32_t hb = rf2bf(hn);
         hbuf[0][m][unit] = (bf16_t)hb;
         uint32_t lb = 0;
@@ -478,7 +500,7 @@ __global__ __launch_bounds__(256, 1) void lstm_dir_kernel(const bf16_t* __restri
           lb = rf2bf(hn - rbf2f(hb));
           hbuf[NP - 1][m][unit] = (bf16_t)lb;
         }
-        if (line < B) {
+        if (line < B && PT_LSTM_ABL != 4) {
           bf16_t* hp = hout + ((size_t)line * T + t) * hcs + dir * 256 + unit;
           hp[0] = (bf16_t)hb;
           if (SPLIT) hp[512] = (bf16_t)lb;

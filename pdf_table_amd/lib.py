@@ -18,6 +18,7 @@ PT_MODEL_LORE_DLA34 = 3
 PT_MODEL_LORE_PROCESSOR = 4
 PT_MODEL_PICODET = 5
 PT_MODEL_LORE_RESNET18 = 6
+PT_MODEL_DB_NAS = 7
 PT_LAYOUT_HEAD_CS, PT_LAYOUT_CAND_FLOATS = 40, 48
 PT_DET_PRE_DB_PP = 0
 PT_DET_PRE_DB_TORCH = 1

@@ -24,7 +24,7 @@ from . import lib as L
 from .base_infer_task import BaseInferTask
 from .det_stage import DetConfig, DetStage
 from .engine import HipEngine
-from .weights import pack_db_resnet18
+from .weights import pack_db_nas, pack_db_resnet18
 
 __all__ = ["OcrDetectionTask"]
 
@@ -75,11 +75,12 @@ class OcrDetectionTask(BaseInferTask):
         if model == "db_pp" and not self.kwargs.get("allow_stand_in", False):
             raise RuntimeError(f"'{self._config.model_path}' is an ONNX graph that is not part of the reference tree; "
                                "pass allow_stand_in=True to run the PP-OCR pre/post-processing around DB-ResNet18")
-        if model == "db" and self._config.backbone != "resnet18":
-            raise TypeError(f"detector backbone should be resnet18 on the HIP engine, but got {self._config.backbone}")
+        nas = model == "db" and self._config.backbone == "proxylessnas"      # DBNasModel, modeling_db_net.py:47-49
+        if model == "db" and self._config.backbone not in ("resnet18", "proxylessnas"):
+            raise TypeError(f"detector backbone should be either resnet18, proxylessnas, but got {self._config.backbone}")
         if self.synthetic_seed is not None:
-            from .synth_weights import db_resnet18_state_dict
-            sd = db_resnet18_state_dict(seed=int(self.synthetic_seed))
+            from .synth_weights import db_nas_state_dict, db_resnet18_state_dict
+            sd = (db_nas_state_dict if nas else db_resnet18_state_dict)(seed=int(self.synthetic_seed))
         else:
             path = os.path.join(self._config.model_path, "pytorch_model.pt")   # modeling_db_net.py:53-56
             if not os.path.exists(path):
@@ -87,7 +88,10 @@ class OcrDetectionTask(BaseInferTask):
                                    f"'{self._config.model_path}' from the hub (no network here); pass task_path=<dir> "
                                    "or synthetic_seed=<int>")
             sd = torch.load(path, map_location="cpu", weights_only=True)
-        self._engine.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(sd))
+        if nas:
+            self._engine.load_weights(L.PT_MODEL_DB_NAS, pack_db_nas(sd))
+        else:
+            self._engine.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(sd))
         self._model = self._predict
 
     def _build_processor(self):

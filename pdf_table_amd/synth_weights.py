@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 __all__ = ["db_resnet18_state_dict", "crnn_state_dict", "CRNN_NUM_CLASSES", "lore_dla34_state_dict",
-           "lore_processor_state_dict", "LORE_HEADS", "picodet_state_dict", "LCNET_CONFIG", "PICODET_STANDIN", "lore_wireless_state_dict"]
+           "lore_processor_state_dict", "LORE_HEADS", "picodet_state_dict", "LCNET_CONFIG", "PICODET_STANDIN", "lore_wireless_state_dict", "db_nas_state_dict"]
 
 CRNN_NUM_CLASSES = 7644  # crnn/modeling_crnn.py:90
 
@@ -425,4 +425,69 @@ def lore_wireless_state_dict(seed: int = 0, hm_bias=(-5.0, -4.5), cell_half=(10.
             g.put(last + ".bias", np.array([0.5, 0.5]))
         else:
             g.conv(last, k, 64, 1, 1, bias=True, gain=0.5)
+    return g.sd
+
+
+def db_nas_state_dict(seed: int = 0, with_thresh_branch: bool = True, head_bias: float = -1.5):
+    """state_dict of ``DBNasModel`` (db_net/dbnet.py:693-712; blocks from pdf_table_amd.dbnas_arch).  Key order follows
+    module registration order (proxyless.py:99-161, layers.py:690-728 / :110-143 / :477-479, dbnet.py:370-391, 35-99)."""
+    from .dbnas_arch import dbnas_blocks, INNER_CHANNELS, DW_KERNEL, WIDTH_STAGES, INPUT_CHANNEL
+    g = _Gen(seed)
+
+    def prelu(name):
+        g.put(name + ".weight", g.rng.uniform(0.1, 0.4, (1,)))
+
+    def dwconv(name, c, k, gain=2.0):
+        g.put(name + ".weight", g.rng.standard_normal((c, 1, k, k)) * math.sqrt(gain / (k * k)))
+
+    g.conv("backbone.first_conv.0", INPUT_CHANNEL, 3, 3, 3)
+    g.bn("backbone.first_conv.1", INPUT_CHANNEL)
+    for bi, b in enumerate(dbnas_blocks()):
+        p = f"backbone.blocks.{bi}.mobile_inverted_conv"
+        if b["kind"] == "se":
+            g.conv(p + ".fc1", b["squeeze"], b["cin"], 1, 1, bias=True)
+            g.conv(p + ".fc2", b["cin"], b["squeeze"], 1, 1, bias=True)
+            continue
+        g.conv(p + ".inverted_bottleneck.conv", b["mid"], b["cin"], 1, 1, gain=1.0)
+        g.bn(p + ".inverted_bottleneck.bn", b["mid"])
+        prelu(p + ".inverted_bottleneck.act")
+        if b["kind"] == "rep":
+            for ri, k in enumerate(b["sizes"]):
+                dwconv(f"{p}.rep_conv.{ri}.conv", b["mid"], k, gain=2.0 / len(b["sizes"]))
+                g.bn(f"{p}.rep_conv.{ri}.bn", b["mid"])
+            prelu(p + ".act")
+        else:
+            dwconv(p + ".depth_conv.conv", b["mid"], b["sizes"][0])
+            g.bn(p + ".depth_conv.bn", b["mid"])
+            prelu(p + ".depth_conv.act")
+        # the projection is linear (no activation after its BN); a residual branch at half gain keeps 20 blocks in range
+        g.conv(p + ".point_conv.conv", b["cout"], b["mid"], 1, 1, gain=0.08 if b["shortcut"] else 0.3)
+        g.bn(p + ".point_conv.bn", b["cout"])
+    ic = INNER_CHANNELS
+    for name, cin in zip(("in5", "in4", "in3", "in2"), WIDTH_STAGES[::-1]):
+        g.conv("decoder." + name, ic, cin, 1, 1, gain=0.5)
+    q = ic // 4
+    dwconv("decoder.binarize.0.depthwise", ic, DW_KERNEL)
+    g.bn("decoder.binarize.0.bn1", ic)
+    g.conv("decoder.binarize.0.pointwise", q, ic, 1, 1)
+    g.bn("decoder.binarize.1", q)
+
+    def dwpw_t(name, cout, gain, bias=None):      # DwPwConvTranspose (dbnet.py:75-99): depthwise ConvT 2x2 s2 + BN + ReLU + 1x1
+        base = g.rng.standard_normal((q, 1, 1, 1)) * math.sqrt(2.0)
+        g.put(name + ".depthwise.weight", base * (1.0 + 0.05 * g.rng.standard_normal((q, 1, 2, 2))))
+        g.put(name + ".depthwise.bias", g.rng.uniform(-0.1, 0.1, (q,)))
+        g.bn(name + ".bn1", q)
+        g.conv(name + ".pointwise", cout, q, 1, 1, bias=True, gain=gain)
+        if bias is not None:
+            g.put(name + ".pointwise.bias", np.full((cout,), bias))
+
+    dwpw_t("decoder.binarize.3", q, 2.0)
+    g.bn("decoder.binarize.4", q)
+    dwpw_t("decoder.binarize.6", 1, 100.0, bias=head_bias)
+    if with_thresh_branch:     # exists in checkpoints (adaptive=True), never run in eval (dbnet.py:470-473)
+        g.conv("decoder.thresh.0", q, ic, DW_KERNEL, DW_KERNEL)
+        g.bn("decoder.thresh.1", q)
+        g.convT("decoder.thresh.3", q, q, 2, 2)
+        g.bn("decoder.thresh.4", q)
+        g.convT("decoder.thresh.6", q, 1, 2, 2)
     return g.sd

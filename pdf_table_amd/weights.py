@@ -29,7 +29,7 @@ import torch
 BN_EPS = 1e-5
 _DT = {"bf16": 0, "f32": 1, "i32": 2}
 
-__all__ = ["pack_db_resnet18", "pack_crnn", "pack_lore_dla34", "pack_lore_processor", "pack_picodet", "pack_lore_wireless", "write_blob", "fold_conv_bn", "to_bf16_bits"]
+__all__ = ["pack_db_resnet18", "pack_crnn", "pack_lore_dla34", "pack_lore_processor", "pack_picodet", "pack_lore_wireless", "pack_db_nas", "write_blob", "fold_conv_bn", "to_bf16_bits"]
 
 
 def to_bf16_bits(t: torch.Tensor) -> np.ndarray:
@@ -179,7 +179,12 @@ def pack_crnn(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
         bl.add_conv(f"lstm{li}.xproj", wih[perm].reshape(2048, -1, 1, 1).float(), bias[perm].float())
         whh = torch.stack([sd[r + "weight_hh_l0"], sd[r + "weight_hh_l0_reverse"]], 0).float()   # [2, 1024, 256]
         hi, lo = split_bf16(whh)
-        bl.add(f"lstm{li}.whh", np.stack([to_bf16_bits(hi), to_bf16_bits(lo)]), "bf16")
+        # MFMA-fragment order: the kernel's wave `wave` reads, for (half, kq, gate, h), one contiguous 1 KB record of
+        # 64 lanes x 8 k-values -- eight full 128-byte lines per load instead of 32 quarter-used ones
+        def frag(w):     # [2, 1024 = (gate 4, wave 4, h 2, lx 32), 256 = (half 4, kq 4, q 2, j 8)]
+            return (w.reshape(2, 4, 4, 2, 32, 4, 4, 2, 8).permute(0, 2, 5, 6, 1, 3, 7, 4, 8).contiguous()
+                    .reshape(2, 1024, 256))
+        bl.add(f"lstm{li}.whh", np.stack([to_bf16_bits(frag(hi)), to_bf16_bits(frag(lo))]), "bf16")
         we = sd[p + ".embedding.weight"].float()
         bl.add_conv(f"lstm{li}.emb", we.reshape(we.shape[0], we.shape[1], 1, 1), sd[p + ".embedding.bias"].float())
     wc = sd["cls.weight"].float()
@@ -477,4 +482,93 @@ def pack_lore_wireless(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
             bl.add_conv(f"{h}.c{j}", *fold_conv_bn(sd, f"{h}.{2 * j}", None))
         w, b = fold_conv_bn(sd, f"{h}.{2 * n3}", None)
         bl.add_conv(f"{h}.out", *_pad_conv(w, b, (k + 63) // 64 * 64, 64))
+    return bl.tobytes()
+
+
+def pack_db_nas(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
+    """``DBNasModel`` state_dict (db_net/dbnet.py:693-712) -> blob for PT_MODEL_DB_NAS (csrc/dbnas_model.hip).
+
+    * every BatchNorm folded (float64); channel counts padded to multiples of 64 with zero weights;
+    * a ``rep`` block's parallel depthwise branches (1x1 / 3x3 / 5x5, each + BN, summed: layers.py:732-745) become ONE
+      centred 5x5 depthwise kernel + bias -- convolution is linear, so the sum of the folded branches is exact;
+    * PReLU slopes (one scalar per activation) as 1-element fp32 tensors read on the device;
+    * ``dec.tail``: the two DwPwConvTranspose blocks + BN of LightSegDetector.binarize as the 449-float table
+      dbnas_tail_kernel documents."""
+    from .dbnas_arch import dbnas_blocks
+    bl = _Blob(x3)
+    p64 = lambda c: (c + 63) // 64 * 64
+
+    def bn_affine(bn):
+        scale = sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + BN_EPS)
+        return scale, sd[bn + ".bias"].double() - sd[bn + ".running_mean"].double() * scale
+
+    w, b = fold_conv_bn(sd, "backbone.first_conv.0", "backbone.first_conv.1")
+    st = torch.zeros(32, 3, 3, 4)
+    st[:, :, :, :3] = w.permute(0, 2, 3, 1)
+    bl.add("stem.wf32", st.numpy(), "f32")
+    bl.add("stem.b", b.numpy(), "f32")
+    for bi, blk in enumerate(dbnas_blocks()):
+        p, q = f"backbone.blocks.{bi}.mobile_inverted_conv", f"b{bi}"
+        if blk["kind"] == "se":
+            c, cp, hid = blk["cin"], p64(blk["cin"]), blk["squeeze"]
+            w1 = torch.zeros(hid, cp)
+            w1[:, :c] = sd[p + ".fc1.weight"][:, :, 0, 0].float()
+            w2 = torch.zeros(cp, hid)
+            w2[:c] = sd[p + ".fc2.weight"][:, :, 0, 0].float()
+            b2 = torch.zeros(cp)
+            b2[:c] = sd[p + ".fc2.bias"].float()
+            bl.add(q + ".se.w1", w1.numpy(), "f32")
+            bl.add(q + ".se.b1", sd[p + ".fc1.bias"].float().numpy(), "f32")
+            bl.add(q + ".se.w2", w2.numpy(), "f32")
+            bl.add(q + ".se.b2", b2.numpy(), "f32")
+            continue
+        mid, cin, cout = blk["mid"], blk["cin"], blk["cout"]
+        w, b = fold_conv_bn(sd, p + ".inverted_bottleneck.conv", p + ".inverted_bottleneck.bn")
+        bl.add_conv(q + ".exp", *_pad_conv(w, b, mid, p64(cin)))
+        bl.add(q + ".exp.slope", sd[p + ".inverted_bottleneck.act.weight"].float().numpy().reshape(1), "f32")
+        kmax = max(blk["sizes"])
+        wk = torch.zeros(mid, kmax, kmax, dtype=torch.float64)
+        bk = torch.zeros(mid, dtype=torch.float64)
+        if blk["kind"] == "rep":
+            branches = [(f"{p}.rep_conv.{ri}.conv", f"{p}.rep_conv.{ri}.bn", k) for ri, k in enumerate(blk["sizes"])]
+            slope = sd[p + ".act.weight"]
+        else:
+            branches = [(p + ".depth_conv.conv", p + ".depth_conv.bn", blk["sizes"][0])]
+            slope = sd[p + ".depth_conv.act.weight"]
+        for conv, bn, k in branches:
+            sc, sh = bn_affine(bn)
+            o = (kmax - k) // 2
+            wk[:, o:o + k, o:o + k] += sd[conv + ".weight"][:, 0].double() * sc.view(-1, 1, 1)
+            bk += sh
+        bl.add(q + ".dw.wf32", wk.permute(1, 2, 0).reshape(kmax * kmax, mid).float().numpy(), "f32")
+        bl.add(q + ".dw.b", bk.float().numpy(), "f32")
+        bl.add(q + ".dw.slope", slope.float().numpy().reshape(1), "f32")
+        w, b = fold_conv_bn(sd, p + ".point_conv.conv", p + ".point_conv.bn")
+        bl.add_conv(q + ".proj", *_pad_conv(w, b, p64(cout), mid))
+    for name in ("in5", "in4", "in3", "in2"):
+        w = sd[f"decoder.{name}.weight"].float()
+        bl.add_conv("dec." + name, *_pad_conv(w, torch.zeros(w.shape[0]), 64, p64(w.shape[1])))
+    sc, sh = bn_affine("decoder.binarize.0.bn1")
+    wd = sd["decoder.binarize.0.depthwise.weight"][:, 0].double() * sc.view(-1, 1, 1)          # [64, 5, 5]
+    k = wd.shape[-1]
+    bl.add("dec.dw.wf32", wd.permute(1, 2, 0).reshape(k * k, -1).float().numpy(), "f32")
+    bl.add("dec.dw.b", sh.float().numpy(), "f32")
+    w, b = fold_conv_bn(sd, "decoder.binarize.0.pointwise", "decoder.binarize.1")
+    bl.add_conv("dec.pw", *_pad_conv(w, b, 64, 64))
+    tail = np.zeros(449, dtype=np.float64)
+
+    def dwt(prefix, w_off, b_off):      # depthwise ConvTranspose2d(k=2, s=2) + BN: out[2y+dy, 2x+dx, c] = in[y, x, c] * W[2dy+dx][c] + B[c]
+        sc, sh = bn_affine(prefix + ".bn1")
+        wt = sd[prefix + ".depthwise.weight"][:, 0].double() * sc.view(-1, 1, 1)                # [16, 2, 2]
+        tail[w_off:w_off + 64] = wt.permute(1, 2, 0).reshape(-1).numpy()
+        tail[b_off:b_off + 16] = (sd[prefix + ".depthwise.bias"].double() * sc + sh).numpy()
+
+    dwt("decoder.binarize.3", 0, 64)
+    w, b = fold_conv_bn(sd, "decoder.binarize.3.pointwise", "decoder.binarize.4")
+    tail[80:336] = w[:, :, 0, 0].double().reshape(-1).numpy()
+    tail[336:352] = b.double().numpy()
+    dwt("decoder.binarize.6", 352, 416)
+    tail[432:448] = sd["decoder.binarize.6.pointwise.weight"][0, :, 0, 0].double().numpy()
+    tail[448] = float(sd["decoder.binarize.6.pointwise.bias"][0])
+    bl.add("dec.tail", tail.astype(np.float32), "f32")
     return bl.tobytes()

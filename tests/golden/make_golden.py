@@ -71,6 +71,34 @@ def gen_db_resnet18():
     print("db_resnet18.npz", {k: v.shape for k, v in out.items()})
 
 
+def gen_db_nas():
+    from pdf_table_amd.synth_weights import db_nas_state_dict
+    dbnet = ref_import("pdftable.model.db_net.dbnet")
+    torch.manual_seed(0)
+    model = dbnet.DBNasModel().eval()
+    sd = db_nas_state_dict(seed=13)
+    model.load_state_dict(sd, strict=True)
+    rng = np.random.default_rng(113)
+    out = {}
+    for tag, (h, w) in {"a": (64, 96), "b": (160, 128)}.items():
+        x = rng.standard_normal((1, 3, h, w)).astype(np.float32)
+        with torch.no_grad():
+            xt = torch.from_numpy(x)
+            c2, c3, c4, c5 = model.backbone(xt)
+            y = model(xt)
+        out[f"x_{tag}"] = x
+        out[f"prob_{tag}"] = y.numpy()
+        out[f"c2_{tag}"] = c2.numpy()
+        out[f"c5_{tag}"] = c5.numpy()
+    out["seed"] = np.array(13)
+    # the module's own parameter inventory: the synthetic checkpoint must have exactly these keys and shapes
+    ref_sd = dbnet.DBNasModel().state_dict()
+    out["keys"] = np.array(list(ref_sd.keys()))
+    out["shapes"] = np.array([",".join(str(d) for d in v.shape) for v in ref_sd.values()])
+    np.savez_compressed(os.path.join(HERE, "db_nas.npz"), **out)
+    print("db_nas.npz", {k: v.shape for k, v in out.items()})
+
+
 def gen_crnn():
     from pdf_table_amd.synth_weights import crnn_state_dict
     crnn = ref_import("pdftable.model.crnn.modeling_crnn")
@@ -519,6 +547,8 @@ if __name__ == "__main__":
         gen_db_host_numpy()
     if "db" in which:
         gen_db_resnet18()
+    if "db_nas" in which or not sys.argv[1:]:
+        gen_db_nas()
     if "crnn" in which:
         gen_crnn()
     if "registry" in which:
