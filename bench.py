@@ -65,7 +65,8 @@ def cpu_baseline_tsr(lsd, psd, page, box):
 def cpu_baseline(sd, pages_np, cfg, csd=None, quads=None, max_lines=12, tsr=None, layout=None):
     """The oracle (port of the reference CPU path: fp32 torch ops in the reference's op order + numpy/python
     pre/post) on the host cores, batch 1 per call as the reference runs it."""
-    from oracle import db_net, db_post, db_pre
+    from oracle import db_nas, db_net, db_post, db_pre
+    det_fwd = db_nas.dbnas_forward_fp32 if "backbone.first_conv.0.weight" in sd else db_net.db_forward_fp32
     # 32 threads: on the 256-thread GPU host, batch-1 convolutions and the per-step LSTM matmuls get SLOWER beyond a
     # few dozen threads (47 s for two pages at 256 threads vs ~3 s/page at 8); "cores" reports what was really used
     cores = min(os.cpu_count() or 1, 32)
@@ -73,7 +74,7 @@ def cpu_baseline(sd, pages_np, cfg, csd=None, quads=None, max_lines=12, tsr=None
     budget_t0 = time.time()
     n = len(pages_np)
     with torch.no_grad():   # one un-timed warm-up forward (thread pool start-up, oneDNN primitive cache)
-        db_net.db_forward_fp32(sd, torch.zeros(1, 3, 960, 960))
+        det_fwd(sd, torch.zeros(1, 3, 960, 960))
     t_pre = t_net = t_post = 0.0
     nboxes = 0
     done = 0
@@ -85,7 +86,7 @@ def cpu_baseline(sd, pages_np, cfg, csd=None, quads=None, max_lines=12, tsr=None
         chw, shape_list = db_pre.preprocess_db_pp(img)
         t1 = time.time()
         with torch.no_grad():
-            prob = db_net.db_forward_fp32(sd, torch.from_numpy(np.ascontiguousarray(chw))[None])[0, 0].numpy()
+            prob = det_fwd(sd, torch.from_numpy(np.ascontiguousarray(chw))[None])[0, 0].numpy()
         t2 = time.time()
         boxes = db_post.db_postprocess(prob, shape_list, img.shape, cfg.thresh, cfg.box_thresh, cfg.unclip_ratio,
                                        cfg.use_dilation, cfg.max_candidates)
@@ -150,6 +151,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--det-backbone", default="resnet18", choices=["resnet18", "proxylessnas"],
+                    help="DB detector network: DBModel (BASELINE.json's configuration) or DBNasModel (diagnostic variant)")
     ap.add_argument("--no-post", action="store_true", help="device half only (diagnostic; not a valid headline)")
     ap.add_argument("--stages", default=os.environ.get("PT_BENCH_STAGES", "layout,det,rec,tsr"),
                     help="comma list of stages in the timed step: layout (PicoDet), det (configs[1]), rec, tsr (Lore)")
@@ -179,13 +182,20 @@ def main():
 
     eng = HipEngine(local_rank)
     # weights: packed once on rank 0, broadcast over RCCL/xGMI, loaded from device memory everywhere
-    sd = db_resnet18_state_dict(seed=0) if rank == 0 or world == 1 else None
+    nas = args.det_backbone == "proxylessnas"
+    if nas:
+        from pdf_table_amd.synth_weights import db_nas_state_dict as det_state_dict
+        from pdf_table_amd.weights import pack_db_nas as pack_det
+    else:
+        det_state_dict, pack_det = db_resnet18_state_dict, pack_db_resnet18
+    det_kind = L.PT_MODEL_DB_NAS if nas else L.PT_MODEL_DB_RESNET18
+    sd = det_state_dict(seed=0) if rank == 0 or world == 1 else None
     if world > 1:
         from pdf_table_amd.dist_utils import broadcast_blob
-        blob = broadcast_blob(pack_db_resnet18(sd, x3=False) if rank == 0 else None, dev)
-        eng.load_weights_device(L.PT_MODEL_DB_RESNET18, blob)
+        blob = broadcast_blob(pack_det(sd, x3=False) if rank == 0 else None, dev)
+        eng.load_weights_device(det_kind, blob)
     else:
-        eng.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(sd, x3=False))
+        eng.load_weights(det_kind, pack_det(sd, x3=False))
 
     rec = None
     if "rec" in stages:
@@ -381,7 +391,8 @@ def main():
                "config": {"workload": ("PicoDet layout detection (resize to 800x608, LCNet + CSP-PAN + PicoHead, hard NMS) + "
                                        if "layout" in stages else "")
                                       + ("BASELINE.json configs[1] batched DB text detection (db_pp pre/post around "
-                                       "DB-ResNet18, 1024x1024 synthetic pages -> 960x960 net input, boxes out)"
+                                       + ("DB-ProxylessNAS [--det-backbone variant, not the BASELINE.json network]" if nas
+                                          else "DB-ResNet18") + ", 1024x1024 synthetic pages -> 960x960 net input, boxes out)"
                                        if "det" in stages else "")
                                       + (" + CRNN text-line recognition of the page's text lines (crop, resize, CRNN, "
                                          "arg-max, CTC collapse)" if "rec" in stages else "")
