@@ -272,7 +272,11 @@ struct ConvCfg {
   static_assert(NP_W % 256 == 0, "weight slice must be a whole number of 256-thread passes");
 };
 
-template <int KS, int STRIDE, int GEOM>
+// REGEPI: the plain layers (bias [+ residual] [+ activation], bf16 NHWC store) finish from registers: the MFMA runs with
+// its operands swapped (weights as A, pixels as B), so D is channel-major -- a lane owns ONE pixel (column lx) and its 16
+// registers are four runs of four consecutive channels -- and every lane stores 8-byte channel runs straight to HBM.
+// No fp32 staging image, no barrier, no second pass over LDS; the arithmetic per element is the LDS epilogue's.
+template <int KS, int STRIDE, int GEOM, bool REGEPI>
 __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_igemm_kernel(ConvK p) {
   using C = ConvCfg<KS, STRIDE, GEOM>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -374,8 +378,13 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
 #pragma unroll
           for (int m = 0; m < C::MT; ++m) {
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base[m] + (r * C::TWIN + s) * C::PIXB + kk * 32);
-            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
-            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
+            if (REGEPI) {   // D^T: rows = channels, columns = pixels
+              acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a, acc[m][0], 0, 0, 0);
+              acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a, acc[m][1], 0, 0, 0);
+            } else {
+              acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
+              acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
+            }
           }
 #ifdef PT_SETPRIO
           __builtin_amdgcn_s_setprio(0);
@@ -385,6 +394,63 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
     }
   }
 
+  if (REGEPI) {
+    const int n0 = nt * 64;
+    const float sl = p.relu == 3 ? p.slope[0] : 0.f;
+    const int rcs = p.split ? 2 * p.N : p.N;
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m) {
+      const int t = wave * C::MT + m;
+      const int oy = oy0 + t / C::CT, ox = ox0 + (t % C::CT) * 32 + lx;
+      if (oy >= p.Ho || ox >= p.Wo) continue;
+      const size_t pix = ((size_t)b * p.Ho + oy) * p.Wo + ox;
+      const size_t rpix = p.res_mode == 2 ? ((size_t)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1) : pix;
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int ch = n0 + n * 32 + rg * 8 + q * 4;
+          if (p.n_valid && ch >= p.n_valid) continue;
+          const f32x4 bs = *reinterpret_cast<const f32x4*>(p.bias + ch);
+          float v[4] = {acc[m][n][rg * 4 + 0] + bs.x, acc[m][n][rg * 4 + 1] + bs.y, acc[m][n][rg * 4 + 2] + bs.z,
+                        acc[m][n][rg * 4 + 3] + bs.w};
+          if (p.res_mode) {
+            u32x2 rr = *reinterpret_cast<const u32x2*>(p.res + rpix * rcs + ch);
+            v[0] += bf16_to_f32(rr.x & 0xFFFFu); v[1] += bf16_to_f32(rr.x >> 16);
+            v[2] += bf16_to_f32(rr.y & 0xFFFFu); v[3] += bf16_to_f32(rr.y >> 16);
+            if (p.split) {
+              rr = *reinterpret_cast<const u32x2*>(p.res + rpix * rcs + ch + p.N);
+              v[0] += bf16_to_f32(rr.x & 0xFFFFu); v[1] += bf16_to_f32(rr.x >> 16);
+              v[2] += bf16_to_f32(rr.y & 0xFFFFu); v[3] += bf16_to_f32(rr.y >> 16);
+            }
+          }
+          if (p.relu == 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+          } else if (p.relu == 2) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = v[k] * fminf(fmaxf(v[k] + 3.f, 0.f), 6.f) / 6.f;
+          } else if (p.relu == 3) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : sl * v[k];
+          }
+          uint32_t hb[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) hb[k] = f32_to_bf16(v[k]);
+          bf16_t* op = p.out + pix * p.out_cstride + p.out_coff + ch;
+          u32x2 o = {hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
+          *reinterpret_cast<u32x2*>(op) = o;
+          if (p.split) {
+            uint32_t lb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lb[k] = f32_to_bf16(v[k] - bf16_to_f32(hb[k]));
+            u32x2 ol = {lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16)};
+            *reinterpret_cast<u32x2*>(op + p.out_lo_off) = ol;
+          }
+        }
+    }
+    return;
+  }
   // ---- epilogue through LDS (fp32 [pixel][64]) ----
   __syncthreads();
   float* stage = reinterpret_cast<float*>(smem);
@@ -1071,15 +1137,31 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_kernel(ConvK p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// PT_REG_EPI=1 opts the plain layers into the register epilogue.  Measured on MI355X (four-stage bench, round 1): no gain --
+// 3x3 class 470.9 -> 473.1 ms, 1x1 class 244.3 -> 251.1 ms, det-only 3917 -> 3779 pages/s: the 8-byte channel-run stores
+// (32 partial lines per wave instruction) cost what the fp32 LDS round trip saved.  Default: LDS epilogue (16-byte stores).
+static bool use_reg_epilogue() {
+  static int v = -1;
+  if (v < 0) {
+    const char* s = getenv("PT_REG_EPI");
+    v = s ? atoi(s) : 0;
+  }
+  return v != 0;
+}
+
 template <int KS, int STRIDE, int GEOM = 0>
 static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   using C = ConvCfg<KS, STRIDE, GEOM>;
   static bool attr_done = false;
   if (!attr_done) {
-    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<KS, STRIDE, GEOM>),
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<KS, STRIDE, GEOM, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<KS, STRIDE, GEOM, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
     attr_done = true;
   }
+  // plain layer: bias [+ residual] [+ activation] -> bf16 NHWC, nothing fused behind it
+  const bool plain = !k.head_w && !k.argmax_part && !k.shuffle_cout && !k.out_f32 && !k.res_f32 && !k.m_flat && k.rep == 1;
   k.tiles_x = (k.Wo + C::TW - 1) / C::TW;
   k.tiles_y = (k.Ho + C::TH - 1) / C::TH;
   k.n_tiles = k.N / 64;
@@ -1088,7 +1170,10 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   char label[48];
   snprintf(label, sizeof(label), "conv%dx%d s%d %d->%d @%dx%d%s", KS, KS, STRIDE, k.Cin, k.N, k.Ho, k.Wo, k.head_w ? " +head" : (k.split ? " x3" : ""));
   PtProfScope prof(e, s, KS == 3 ? PT_PROF_CONV3X3 : PT_PROF_CONV1X1, flop, label);
-  hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, GEOM>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
+  if (plain && use_reg_epilogue())
+    hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, GEOM, true>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, GEOM, false>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
