@@ -392,6 +392,9 @@ __global__ __launch_bounds__(256, (SPLIT || NB > 64) ? 2 : 4) void dcn_fused_ker
 // corner pixel's 64-channel run (a full 128-byte line): 8 lines per wave load.  K is walked in (tap, 64-channel) stages;
 // a thread blends 4 (pixel, piece) items per stage; LDS rows are 144 bytes (conflict-free ds_read_b128).
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef PT_DCN_ABL
+#define PT_DCN_ABL 0
+#endif
 template <int NB>
 __global__ __launch_bounds__(256, 2) void dcn_fused64_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
                                                               const bf16_t* __restrict__ w, const float* __restrict__ bias,
@@ -401,33 +404,75 @@ __global__ __launch_bounds__(256, 2) void dcn_fused64_kernel(const bf16_t* __res
   constexpr int ROW = 144;                      // 64 bf16 + 16 B pad
   constexpr int NT = NB / 32;
   constexpr int WP = NB * 8 / 256;              // 16-byte weight pieces per thread per stage
-  __shared__ __attribute__((aligned(16))) char s_a[128 * ROW];
-  __shared__ __attribute__((aligned(16))) char s_w[NB * ROW];
-  __shared__ float s_om[128 * 28];              // the tile's 27 offset / mask values per pixel, staged once (row pitch 28)
+  // sampling geometry of the tile, computed ONCE per (pixel, tap) -- the eight lanes that share a pixel used to redo it
+  // every stage, which was half of the kernel's VALU time: element offsets of the four corners (-1 = outside the map),
+  // their bilinear weights, and the sigmoid mask
+  __shared__ __attribute__((aligned(16))) int s_goff[128 * 9][4];
+  __shared__ __attribute__((aligned(16))) float s_gwt[128 * 9][4];
+  __shared__ float s_gmask[128 * 9];
+  // the offset / mask values are only needed while the table is built: they share LDS with the operand images
+  __shared__ __attribute__((aligned(16))) char s_ab[128 * ROW + NB * ROW];
+  static_assert(128 * ROW + NB * ROW >= 128 * 28 * 4, "operand images must cover the staged offset/mask rows");
+  char* s_a = s_ab;
+  char* s_w = s_ab + 128 * ROW;
+  float* s_om = reinterpret_cast<float*>(s_ab);   // 27 offset / mask values per pixel (row pitch 28)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lx = lane & 31, q = lane >> 5;
-  const long long p0 = (long long)blockIdx.x * 128;
+  // the workgroup's 128 pixels are an 8-row x 16-column patch of one map: its 9-tap sampling footprint (~10 x 18 lines
+  // of 128 B) fits the 32 KB L1, where a 128-pixel row segment (3 x 130 lines) does not and every corner went to L2
+  const int tiles_x = (W + 15) >> 4, tiles_y = (H + 7) >> 3;
+  int Lb = blockIdx.x;
+  const int tx0 = (Lb % tiles_x) * 16;
+  Lb /= tiles_x;
+  const int ty0 = (Lb % tiles_y) * 8;
+  const long long img0 = (long long)(Lb / tiles_y) * H * W;     // first pixel of this tile's map
+  // local pixel pl -> (y, x), clamped into the map for loads; ok = inside the map
+  auto locate = [&](int pl, int& y, int& xq) -> bool {
+    y = ty0 + (pl >> 4);
+    xq = tx0 + (pl & 15);
+    const bool ok = y < H && xq < W;
+    y = y < H ? y : H - 1;
+    xq = xq < W ? xq : W - 1;
+    return ok;
+  };
   const int n0 = blockIdx.y * NB;
   const int nss = C >> 6, nst = 9 * nss, nk = 9 * (C >> 5);
   const int piece = tid & 7, prow = tid >> 3;   // items: pixels prow + 32 j, j = 0..3, 16-byte piece `piece`
   for (int i = tid; i < 128 * 7; i += 256) {     // 7 float4 per pixel (channels 0..27; 27 is padding)
-    long long pix = p0 + i / 7;
-    if (pix >= npix) pix = npix - 1;
+    int y, xq;
+    locate(i / 7, y, xq);
+    const long long pix = img0 + (long long)y * W + xq;
     *reinterpret_cast<float4*>(s_om + (i / 7) * 28 + (i % 7) * 4) = *reinterpret_cast<const float4*>(om + pix * 32 + (i % 7) * 4);
   }
-  int xw[4], yh[4];
   const bf16_t* xb[4];
-  const float* omp[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    long long pix = p0 + prow + 32 * j;
-    if (pix >= npix) pix = npix - 1;
-    xw[j] = (int)(pix % W);
-    yh[j] = (int)((pix / W) % H);
-    xb[j] = x + (size_t)(pix / ((long long)W * H)) * H * W * C + piece * 8;
-    omp[j] = s_om + (prow + 32 * j) * 28;
-  }
+  for (int j = 0; j < 4; ++j) xb[j] = x + (size_t)img0 * C + piece * 8;
   __syncthreads();
+  for (int i = tid; i < 128 * 9; i += 256) {
+    const int pl = i / 9, tap = i - pl * 9;
+    int yh, xw;
+    locate(pl, yh, xw);
+    const float* o = s_om + pl * 28;
+    const float off_h = o[2 * tap], off_w = o[2 * tap + 1];
+    s_gmask[i] = 1.f / (1.f + expf(-o[18 + tap]));
+    const float h_im = (float)(yh - 1 + tap / 3) + off_h;
+    const float w_im = (float)(xw - 1 + tap % 3) + off_w;
+    int co[4] = {-1, -1, -1, -1};
+    float cw[4] = {0.f, 0.f, 0.f, 0.f};
+    if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+      const float hf = floorf(h_im), wf = floorf(w_im);
+      const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
+      const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+      cw[0] = hh * hw; cw[1] = hh * lw; cw[2] = lh * hw; cw[3] = lh * lw;
+      if (h_low >= 0 && w_low >= 0) co[0] = (h_low * W + w_low) * C;
+      if (h_low >= 0 && w_high <= W - 1) co[1] = (h_low * W + w_high) * C;
+      if (h_high <= H - 1 && w_low >= 0) co[2] = (h_high * W + w_low) * C;
+      if (h_high <= H - 1 && w_high <= W - 1) co[3] = (h_high * W + w_high) * C;
+    }
+    *reinterpret_cast<int4*>(s_goff[i]) = make_int4(co[0], co[1], co[2], co[3]);
+    *reinterpret_cast<float4*>(s_gwt[i]) = make_float4(cw[0], cw[1], cw[2], cw[3]);
+  }
+  __syncthreads();     // table complete; s_om is dead from here on (s_a / s_w take its place at the first commit)
   const bf16_t* wbase = w + (size_t)(n0 >> 6) * nk * (64 * 32);
 
   df32x16 acc[NT];
@@ -444,22 +489,12 @@ __global__ __launch_bounds__(256, 2) void dcn_fused64_kernel(const bf16_t* __res
   auto geometry = [&](int tap) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float off_h = omp[j][2 * tap], off_w = omp[j][2 * tap + 1];
-      mask[j] = 1.f / (1.f + expf(-omp[j][18 + tap]));
-      const float h_im = (float)(yh[j] - 1 + tap / 3) + off_h;
-      const float w_im = (float)(xw[j] - 1 + tap % 3) + off_w;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { coff[j][k] = -1; cwt[j][k] = 0.f; }
-      if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
-        const float hf = floorf(h_im), wf = floorf(w_im);
-        const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
-        const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-        cwt[j][0] = hh * hw; cwt[j][1] = hh * lw; cwt[j][2] = lh * hw; cwt[j][3] = lh * lw;
-        if (h_low >= 0 && w_low >= 0) coff[j][0] = (h_low * W + w_low) * C;
-        if (h_low >= 0 && w_high <= W - 1) coff[j][1] = (h_low * W + w_high) * C;
-        if (h_high <= H - 1 && w_low >= 0) coff[j][2] = (h_high * W + w_low) * C;
-        if (h_high <= H - 1 && w_high <= W - 1) coff[j][3] = (h_high * W + w_high) * C;
-      }
+      const int gi = (prow + 32 * j) * 9 + tap;
+      const int4 o = *reinterpret_cast<const int4*>(s_goff[gi]);
+      const float4 wv = *reinterpret_cast<const float4*>(s_gwt[gi]);
+      coff[j][0] = o.x; coff[j][1] = o.y; coff[j][2] = o.z; coff[j][3] = o.w;
+      cwt[j][0] = wv.x; cwt[j][1] = wv.y; cwt[j][2] = wv.z; cwt[j][3] = wv.w;
+      mask[j] = s_gmask[gi];
     }
   };
   auto prefetch = [&](int st) {
@@ -470,7 +505,13 @@ __global__ __launch_bounds__(256, 2) void dcn_fused64_kernel(const bf16_t* __res
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         rc[j][k] = u32x4{0u, 0u, 0u, 0u};
+#if PT_DCN_ABL == 1     /* ablation: no gather traffic */
+        rc[j][k].x = (uint32_t)coff[j][k];
+#elif PT_DCN_ABL == 4   /* ablation: gather without the bounds predicate, always the pixel's own line */
+        rc[j][k] = *reinterpret_cast<const u32x4*>(xb[j] + ((size_t)(ty0 + ((prow + 32 * j) >> 4)) * W + tx0 + ((prow + 32 * j) & 15)) % ((size_t)H * W) * C + ss * 64);
+#else
         if (coff[j][k] >= 0) rc[j][k] = *reinterpret_cast<const u32x4*>(xb[j] + coff[j][k] + ss * 64);
+#endif
       }
     const int kc = tap * (C >> 5) + 2 * ss;     // the stage's two 32-channel weight chunks are adjacent
 #pragma unroll
@@ -484,6 +525,10 @@ __global__ __launch_bounds__(256, 2) void dcn_fused64_kernel(const bf16_t* __res
   auto commit = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+#if PT_DCN_ABL == 2     /* ablation: no blend arithmetic */
+      *reinterpret_cast<u32x4*>(s_a + (prow + 32 * j) * ROW + piece * 16) = rc[j][0] ^ rc[j][1] ^ rc[j][2] ^ rc[j][3];
+      continue;
+#endif
       const df2 w0 = {cwt[j][0], cwt[j][0]}, w1 = {cwt[j][1], cwt[j][1]}, w2 = {cwt[j][2], cwt[j][2]},
                 w3 = {cwt[j][3], cwt[j][3]}, mk = {mask[j], mask[j]};
       uint32_t o[4];
@@ -525,6 +570,9 @@ __global__ __launch_bounds__(256, 2) void dcn_fused64_kernel(const bf16_t* __res
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const dbf16x8 b = *reinterpret_cast<const dbf16x8*>(b_rd + t * 32 * ROW + kk * 32);
+#if PT_DCN_ABL == 3     /* ablation: one MFMA per stage instead of eight */
+        if (kk == 0 && t == 0)
+#endif
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
       }
     }
@@ -535,11 +583,11 @@ __global__ __launch_bounds__(256, 2) void dcn_fused64_kernel(const bf16_t* __res
     const float bv = bias[n];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const long long op = p0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
-      if (op >= npix) continue;
+      int y, xq;
+      if (!locate(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * q, y, xq)) continue;
       float v = acc[t][r] + bv;
       if (relu) v = fmaxf(v, 0.f);
-      out[(size_t)op * N + n] = (bf16_t)f2bf(v);
+      out[(size_t)(img0 + (long long)y * W + xq) * N + n] = (bf16_t)f2bf(v);
     }
   }
 }
@@ -693,7 +741,7 @@ int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf
     char label[48];
     snprintf(label, sizeof(label), "dcn fused %d->%d @%dx%d", C, N, H, W);
     PtProfScope prof(e, s, PT_PROF_OTHER, 0, label);   // gather-bound, kept out of the implicit-GEMM class
-    hipLaunchKernelGGL((dcn_fused64_kernel<64>), dim3((unsigned)((npix + 127) / 128), N / 64), dim3(256), 0, s, x, om, w, bias,
+    hipLaunchKernelGGL((dcn_fused64_kernel<64>), dim3((unsigned)((long long)B * ((H + 7) / 8) * ((W + 15) / 16)), N / 64), dim3(256), 0, s, x, om, w, bias,
                        out, npix, H, W, C, N, relu);
     PT_HIP_CHECK(hipGetLastError());
     return PT_OK;

@@ -1,0 +1,11 @@
+#!/bin/bash
+# tools/dcn_abl.sh <variants..>: dcn_fused64_kernel total time in the tsr-only bench under ablation builds (tools/scratch/lib_<v>.so)
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+for v in base "$@"; do
+  if [ $v != base ]; then export PT_LIB_PATH=$R/tools/scratch/lib_$v.so; fi
+  rm -rf /tmp/prof_$v
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$v -- python $R/bench.py --stages tsr --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2>&1
+  f=$(find /tmp/prof_$v -name "*kernel_stats.csv" | head -1)
+  if [ -n "$f" ]; then grep dcn_fused64 "$f" | sed "s/.*)\",//" | cut -d, -f1-3 | sed "s/^/$v: /"; else echo "$v: no stats"; fi
+done
