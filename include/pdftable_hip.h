@@ -63,6 +63,7 @@ enum {
   PT_MODEL_LORE_PROCESSOR = 4, /* lore/lore_processor.py:399-514 (LoreProcessModel) */
   PT_MODEL_LORE_RESNET18 = 6, /* lore/lore_detector.py:155-389 (LoreDetectModel, the 'wireless' detector) */
   PT_MODEL_DB_NAS = 7,        /* db_net/dbnet.py:693-712 (DBNasModel: ProxylessNAS backbone + LightSegDetector) */
+  PT_MODEL_PPLCNET = 8,       /* cls/cls_pp_lcnet.py:164-283 (PPLCNet classifier); kinds 8 .. 8 + PT_CLS_SLOTS - 1 = classifier slots */
   PT_MODEL_PICODET = 5,     /* picodet/lcnet.py:159-259 + csp_pan.py:233-347 + pico_head.py:966-1160 (assumed config) */
 };
 int pt_weights_load(pt_engine* e, int model_kind, const void* h_blob, size_t nbytes);
@@ -283,6 +284,37 @@ int pt_op_db_head_final(pt_engine* e, const uint16_t* d_in, int B, int H, int W,
                         float* d_prob, float* d_logits, int split, pt_stream stream);
 
 /* ---- introspection used by bench.py (HIP-event timing of the dominant kernel) ------------------ */
+/* ---- image classification (PP-LCNet) ------------------------------------------------------------
+ * Replaces ClsImagePulcTask._preprocess/_run_model (ocr_pdf/cls_image_pulc_task.py:48-84): PPLCNetImageProcessor
+ * (cls/image_processing_pplcnet.py:327-455: Pillow bilinear resize, * 1/255, ImageNet mean/std) and PPLCNet.forward
+ * (cls/cls_pp_lcnet.py:262-283).  The soft-max / top-k of the post-processor (:155-192) stays on the host.
+ * Up to PT_CLS_SLOTS classifiers are resident at once: load slot k with pt_weights_load(e, PT_MODEL_PPLCNET + k, ..).
+ * `textline`: the task's stride_list is [2,[2,1],[2,1],[2,1],[2,1]] (textline_orientation, language_classification;
+ * cls/configuration_cls_pulc.py:20-39). */
+#define PT_CLS_SLOTS 4
+#define PT_CLS_MAX_CLASSES 16
+typedef struct pt_cls_image {
+  int64_t offset; /* bytes from d_base to an RGB uint8 [h, w, 3] image */
+  int32_t h, w;
+} pt_cls_image;
+
+/* d_images: DEVICE array of n descriptors; max_h / max_w: upper bounds of their sizes (host-known);
+ * d_out_bf16: bf16 NHWC4 [n, out_h, out_w, 4] (8 channels [hi rgb0 | lo rgb0] in PT_PRECISION_BF16X3). */
+int pt_cls_preprocess(pt_engine* e, const uint8_t* d_base, const pt_cls_image* d_images, int n, int max_h, int max_w,
+                      int out_h, int out_w, uint16_t* d_out_bf16, pt_stream stream);
+/* d_logits: float32 [n, PT_CLS_MAX_CLASSES], the first *n_classes columns valid (n_classes may be NULL). */
+int pt_cls_forward_net(pt_engine* e, int slot, const uint16_t* d_input_bf16, int n, int in_h, int in_w, int textline,
+                       float* d_logits, int* n_classes, pt_stream stream);
+/* pre-process + network for n images. */
+int pt_cls_forward(pt_engine* e, int slot, const uint8_t* d_base, const pt_cls_image* d_images, int n, int max_h, int max_w,
+                   int out_h, int out_w, int textline, float* d_logits, int* n_classes, pt_stream stream);
+/* Text lines cut from resident pages (the per-line loop of OcrSystemTask.text_line_orientation,
+ * ocr_system_task.py:395-439: order_point -> crop_image -> classifier): d_lines / h_crop_px as for pt_rec_forward;
+ * max_crop_h / max_crop_w: upper bounds of the lines' crop sizes. */
+int pt_cls_forward_lines(pt_engine* e, int slot, const uint8_t* d_pages_rgb, int n_pages, int h, int w,
+                         const pt_rec_line* d_lines, const int64_t* h_crop_px, int n_lines, int max_crop_h, int max_crop_w,
+                         int out_h, int out_w, int textline, float* d_logits, int* n_classes, pt_stream stream);
+
 /* When enabled, every conv launch inside pt_det_forward* is bracketed by hipEvents on `stream`.
  * pt_profile_read returns accumulated milliseconds and launch count per kernel class. */
 #define PT_PROF_CONV3X3 0

@@ -1,0 +1,99 @@
+"""``ClsImagePulcTask`` on the HIP engine -- drop-in for the reference's PP-LCNet classification plug-in.
+
+Reference: src/pdftable/model/ocr_pdf/cls_image_pulc_task.py:25-100.  Same constructor (``task, model, task_type``) and
+result: for one input the post-processor's dict (``{"class_ids", "scores", "label_names"}`` or ``{"attributes",
+"output"}``), for a list one dict per image.  The reference runs one image per ``infer()``; here a list is one batched
+launch.  ``lines(pages, quads)`` is the batched form of OcrSystemTask.text_line_orientation's per-line loop
+(ocr_system_task.py:395-439)."""
+from __future__ import annotations
+
+import os
+import time
+from typing import List
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .base_infer_task import BaseInferTask
+from .cls_stage import CLS_TASKS, ClsStage
+from .engine import HipEngine
+from .ocr_detection_task import _read_image
+from .weights import pack_pplcnet
+
+__all__ = ["ClsImagePulcTask"]
+
+
+class ClsImagePulcTask(BaseInferTask):
+    def __init__(self, task="cls_image", model="PPLCNet", task_type="text_image_orientation", engine: HipEngine = None,
+                 slot: int = 0, **kwargs):
+        super().__init__(task=task, model=model, task_type=task_type, **kwargs)
+        if model != "PPLCNet":
+            raise RuntimeError(f"current model is not supported: {model}")
+        if task_type not in CLS_TASKS:
+            raise KeyError(task_type)                # CLS_PULC_TASK_CONFIG[self.task_type] in the reference
+        self.task_type = task_type
+        self.slot = slot
+        self.model_provider = "PaddleOCR"
+        self._engine = engine
+
+        class _Cfg:
+            backbone = model
+            model_path = ""
+        self._config = _Cfg()
+        self._config.model_path = self.get_model_name_or_path()
+        self._get_inference_model()
+
+    def _construct_model(self, model):
+        if self._engine is None:
+            self._engine = HipEngine(int(str(self.device).split(":")[-1]) if ":" in str(self.device) else 0)
+        ncls = CLS_TASKS[self.task_type]["class_num"]
+        if self.synthetic_seed is not None:
+            from .synth_weights import pplcnet_state_dict
+            sd = pplcnet_state_dict(seed=int(self.synthetic_seed), class_num=ncls)
+        else:
+            path = os.path.join(str(self._config.model_path), "pytorch_model.bin")
+            if not os.path.exists(path):
+                raise RuntimeError(f"no PP-LCNet checkpoint at {path}: the reference would download "
+                                   f"'{self._config.model_path}' from the hub (no network here); pass task_path=<dir> or "
+                                   "synthetic_seed=<int>")
+            sd = torch.load(path, map_location="cpu", weights_only=True)
+            sd = sd.get("state_dict", sd)
+        if sd["fc.weight"].shape[0] != ncls:
+            raise RuntimeError(f"checkpoint has {sd['fc.weight'].shape[0]} classes, task '{self.task_type}' needs {ncls}")
+        self._engine.load_weights(L.PT_MODEL_PPLCNET + self.slot, pack_pplcnet(sd))
+        self._model = self._predict
+
+    def _build_processor(self):
+        self._stage = ClsStage(self._engine, self.task_type, self.slot)
+
+    def _predict(self, images: List[np.ndarray]):
+        cfg = self._stage.cfg
+        return self._engine.cls_forward(images, cfg["size"], self.slot, cfg["textline"])
+
+    def _preprocess(self, inputs, **kwargs):
+        if not isinstance(inputs, list):
+            inputs = [inputs]
+        return {"inputs": [{"image": _read_image(item)} for item in inputs]}
+
+    def _run_model(self, inputs, **kwargs):
+        begin = time.time()
+        logits, elapse = self.infer({"images": [b["image"] for b in inputs["inputs"]]})
+        inputs["results"] = [{"results": logits, "elapse": elapse}]
+        inputs["use_time"] = time.time() - begin
+        return inputs
+
+    def _postprocess(self, inputs, **kwargs):
+        results = self._stage.post(inputs["results"][0]["results"])
+        return results[0] if len(results) == 1 else results
+
+    # ---- batched forms of the reference's per-item loops -------------------------------------------------------------
+    def pages(self, pages: torch.Tensor):
+        return self._stage.pages(pages)
+
+    def lines(self, pages: torch.Tensor, quads_per_page):
+        """quads_per_page: per page an array [k, 8] of detected text boxes -> (results per line, upright?)"""
+        from .rec_stage import build_lines
+        lines = build_lines(quads_per_page)
+        res = self._stage.lines(pages, lines)
+        return res, self._stage.orientation_vote(res)

@@ -19,7 +19,7 @@ void pt_set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* pt_last_error(void) { return g_err; }
-int pt_abi_version(void) { return 3; }
+int pt_abi_version(void) { return 4; }
 
 int pt_engine_set_precision(pt_engine* e, int precision) {
   PT_REQUIRE(e && (precision == PT_PRECISION_BF16 || precision == PT_PRECISION_BF16X3), "pt_engine_set_precision: bad arguments");
@@ -56,6 +56,8 @@ void pt_engine_destroy(pt_engine* e) {
   if (e->zero_page) (void)hipFree(e->zero_page);
   if (e->tsr_scratch) (void)hipFree(e->tsr_scratch);
   if (e->tsr_lut) (void)hipFree(e->tsr_lut);
+  if (e->cls_lut) (void)hipFree(e->cls_lut);
+  if (e->cls_scratch) (void)hipFree(e->cls_scratch);
   if (e->layout_scratch) (void)hipFree(e->layout_scratch);
   for (auto& p : e->prof.pending) {
     (void)hipEventDestroy(p.a);
@@ -520,6 +522,125 @@ int pt_rec_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int h,
     if (rc != PT_OK) return rc;
     rc = pt_crnn_forward_net(e, reinterpret_cast<const bf16_t*>(e->rec_gray), nb, d_ids + (size_t)i0 * PT_REC_T,
                              d_maxlogit ? d_maxlogit + (size_t)i0 * PT_REC_T : nullptr, s);
+    if (rc != PT_OK) return rc;
+  }
+  return PT_OK;
+}
+
+// ---- image classification (PP-LCNet) -----------------------------------------------------------------------------
+static int cls_microbatch() {
+  static int v = -1;
+  if (v < 0) {
+    const char* s = getenv("PT_CLS_MICROBATCH");
+    v = s ? atoi(s) : 1024;
+    if (v < 1) v = 1;
+  }
+  return v;
+}
+
+static int cls_lut(pt_engine* e) {
+  if (e->cls_lut) return PT_OK;
+  // transformers.image_transforms.rescale (fp64 product cast to fp32) then normalize in fp32 with
+  // IMAGENET_DEFAULT_MEAN / _STD (image_processing_pplcnet.py:267-268, 444-448)
+  static const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+  float lut[3 * 256];
+  for (int c = 0; c < 3; ++c)
+    for (int v = 0; v < 256; ++v) {
+      const float r = (float)((double)v * (1.0 / 255.0));
+      lut[c * 256 + v] = (r - mean[c]) / stdv[c];
+    }
+  PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->cls_lut), sizeof(lut)));
+  PT_HIP_CHECK(hipMemcpy(e->cls_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
+  return PT_OK;
+}
+
+int pt_cls_preprocess(pt_engine* e, const uint8_t* d_base, const pt_cls_image* d_images, int n, int max_h, int max_w,
+                      int out_h, int out_w, uint16_t* d_out_bf16, pt_stream stream) {
+  PT_REQUIRE(e && d_base && d_images && d_out_bf16 && n > 0, "pt_cls_preprocess: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  int rc;
+  if ((rc = cls_lut(e)) != PT_OK) return rc;
+  return pt_launch_cls_resize_norm(d_base, d_images, n, max_h, max_w, out_h, out_w, e->cls_lut,
+                                   e->precision == PT_PRECISION_BF16X3, d_out_bf16, reinterpret_cast<hipStream_t>(stream));
+}
+
+int pt_cls_forward_net(pt_engine* e, int slot, const uint16_t* d_input_bf16, int n, int in_h, int in_w, int textline,
+                       float* d_logits, int* n_classes, pt_stream stream) {
+  PT_REQUIRE(e && d_input_bf16 && d_logits && n > 0, "pt_cls_forward_net: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int mb = cls_microbatch();
+  const size_t per = (size_t)in_h * in_w * (e->precision == PT_PRECISION_BF16X3 ? 8 : 4);
+  for (int i0 = 0; i0 < n; i0 += mb) {
+    const int nb = (n - i0) < mb ? (n - i0) : mb;
+    const int rc = pt_pplcnet_forward_net(e, slot, d_input_bf16 + (size_t)i0 * per, nb, in_h, in_w, textline,
+                                          d_logits + (size_t)i0 * PT_CLS_MAX_CLASSES, n_classes, s);
+    if (rc != PT_OK) return rc;
+  }
+  return PT_OK;
+}
+
+int pt_cls_forward(pt_engine* e, int slot, const uint8_t* d_base, const pt_cls_image* d_images, int n, int max_h, int max_w,
+                   int out_h, int out_w, int textline, float* d_logits, int* n_classes, pt_stream stream) {
+  PT_REQUIRE(e && d_base && d_images && d_logits && n > 0, "pt_cls_forward: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int rc;
+  if ((rc = cls_lut(e)) != PT_OK) return rc;
+  const int mb = cls_microbatch(), x3 = e->precision == PT_PRECISION_BF16X3;
+  const size_t per = (size_t)out_h * out_w * (x3 ? 8 : 4);
+  if ((rc = ensure(&e->cls_scratch, &e->cls_scratch_cap, (size_t)(mb < n ? mb : n) * per * sizeof(bf16_t))) != PT_OK) return rc;
+  bf16_t* xin = reinterpret_cast<bf16_t*>(e->cls_scratch);
+  for (int i0 = 0; i0 < n; i0 += mb) {
+    const int nb = (n - i0) < mb ? (n - i0) : mb;
+    {
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0, "cls resize+norm");
+      rc = pt_launch_cls_resize_norm(d_base, d_images + i0, nb, max_h, max_w, out_h, out_w, e->cls_lut, x3, xin, s);
+      if (rc != PT_OK) return rc;
+    }
+    rc = pt_pplcnet_forward_net(e, slot, xin, nb, out_h, out_w, textline, d_logits + (size_t)i0 * PT_CLS_MAX_CLASSES, n_classes, s);
+    if (rc != PT_OK) return rc;
+  }
+  return PT_OK;
+}
+
+int pt_cls_forward_lines(pt_engine* e, int slot, const uint8_t* d_pages_rgb, int n_pages, int h, int w,
+                         const pt_rec_line* d_lines, const int64_t* h_crop_px, int n_lines, int max_crop_h, int max_crop_w,
+                         int out_h, int out_w, int textline, float* d_logits, int* n_classes, pt_stream stream) {
+  PT_REQUIRE(e && d_pages_rgb && d_lines && h_crop_px && d_logits && n_lines > 0 && n_pages > 0, "pt_cls_forward_lines: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int rc;
+  if ((rc = cls_lut(e)) != PT_OK) return rc;
+  const int mb = cls_microbatch(), x3 = e->precision == PT_PRECISION_BF16X3;
+  const size_t per = (size_t)out_h * out_w * (x3 ? 8 : 4);
+  const int cap = mb < n_lines ? mb : n_lines;
+  const size_t desc_bytes = ((size_t)cap * sizeof(pt_cls_image) + 255) & ~(size_t)255;
+  if ((rc = ensure(&e->cls_scratch, &e->cls_scratch_cap, desc_bytes + (size_t)cap * per * sizeof(bf16_t))) != PT_OK) return rc;
+  pt_cls_image* desc = reinterpret_cast<pt_cls_image*>(e->cls_scratch);
+  bf16_t* xin = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(e->cls_scratch) + desc_bytes);
+  for (int i0 = 0; i0 < n_lines; i0 += mb) {
+    const int nb = (n_lines - i0) < mb ? (n_lines - i0) : mb;
+    long long maxpx = 0, total = 0;
+    for (int i = 0; i < nb; ++i) {
+      const long long px = h_crop_px[i0 + i] > 0 ? h_crop_px[i0 + i] : 0;
+      total += px;
+      if (px > maxpx) maxpx = px;
+    }
+    if ((rc = ensure(&e->rec_off, &e->rec_off_cap, (size_t)(nb + 1) * sizeof(long long))) != PT_OK) return rc;
+    if ((rc = ensure(&e->rec_crops, &e->rec_crops_cap, (size_t)total * 3 + 16)) != PT_OK) return rc;
+    if ((rc = pt_launch_rec_offsets(d_lines + i0, nb, reinterpret_cast<long long*>(e->rec_off), s)) != PT_OK) return rc;
+    const long long* d_off = reinterpret_cast<const long long*>(e->rec_off);
+    {
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0, "cls warp");
+      rc = pt_launch_rec_warp(d_pages_rgb, h, w, d_lines + i0, nb, d_off, reinterpret_cast<uint8_t*>(e->rec_crops), (int)maxpx, s);
+      if (rc != PT_OK) return rc;
+      if ((rc = pt_launch_cls_desc_from_lines(d_lines + i0, d_off, nb, desc, s)) != PT_OK) return rc;
+      rc = pt_launch_cls_resize_norm(reinterpret_cast<const uint8_t*>(e->rec_crops), desc, nb, max_crop_h, max_crop_w, out_h,
+                                     out_w, e->cls_lut, x3, xin, s);
+      if (rc != PT_OK) return rc;
+    }
+    rc = pt_pplcnet_forward_net(e, slot, xin, nb, out_h, out_w, textline, d_logits + (size_t)i0 * PT_CLS_MAX_CLASSES, n_classes, s);
     if (rc != PT_OK) return rc;
   }
   return PT_OK;

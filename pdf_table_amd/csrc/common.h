@@ -105,6 +105,8 @@ struct pt_engine {
   void* tsr_scratch = nullptr; size_t tsr_scratch_cap = 0;   // candidate lists of the Lore decode
   void* layout_scratch = nullptr; size_t layout_scratch_cap = 0;   // layout input + head maps (pt_layout_forward)
   float* tsr_lut = nullptr;                                  // [3][256] normalisation table of the Lore pre-process
+  float* cls_lut = nullptr;                                  // [3][256] ... of the PP-LCNet pre-process
+  void* cls_scratch = nullptr; size_t cls_scratch_cap = 0;   // network input + image descriptors of pt_cls_forward*
 };
 
 // ---- conv launcher (conv_igemm.hip) -----------------------------------------------------------------
@@ -171,6 +173,12 @@ int pt_launch_dwconv(const bf16_t* in, const float* w, const float* b, bf16_t* o
 int pt_launch_se(const bf16_t* x, const float* w1, const float* b1, const float* w2, const float* b2, float* gate,
                  bf16_t* out, int B, int HW, int C, int split, hipStream_t s, int hidden, int mode, float* part);
 int pt_launch_add(const bf16_t* a, const bf16_t* b, bf16_t* out, long long npix, int C, int split, hipStream_t s);
+int pt_launch_chan_mean(const bf16_t* x, int B, int HW, int C, int split, float* part, bf16_t* mean, int rows, hipStream_t s);
+int pt_pplcnet_forward_net(pt_engine* e, int slot, const bf16_t* x, int n, int H, int W, int textline, float* logits,
+                           int* n_classes, hipStream_t s);
+int pt_launch_cls_resize_norm(const uint8_t* base, const pt_cls_image* images, int n, int max_h, int max_w, int OH, int OW,
+                              const float* lut, int split, bf16_t* out, hipStream_t s);
+int pt_launch_cls_desc_from_lines(const pt_rec_line* lines, const long long* off, int n, pt_cls_image* images, hipStream_t s);
 int pt_launch_dbnas_tail(const bf16_t* y, const float* tw, int B, int H4, int W4, int split, float* prob, float* logits,
                          hipStream_t s);
 int pt_dbnas_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* prob, float* logits, hipStream_t s);

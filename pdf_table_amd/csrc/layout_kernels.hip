@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void stem3x3s2_kernel(const bf16_t* __restrict
 // w fp32 [k*k][C] (BN scale folded), b fp32 [C]
 __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w,
                                                       const float* __restrict__ b, bf16_t* __restrict__ out, int B, int H,
-                                                      int W, int C, int k, int stride, int Ho, int Wo, int act, int split,
+                                                      int W, int C, int k, int sy, int sx, int Ho, int Wo, int act, int split,
                                                       const float* __restrict__ slope) {
   const int cgn = C >> 3, cs = split ? 2 * C : C, pad = k / 2;
   const float sl = act == 3 ? slope[0] : 0.f;
@@ -125,10 +125,10 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc[q] = 0.f;
     for (int ky = 0; ky < k; ++ky) {
-      const int iy = oy * stride - pad + ky;
+      const int iy = oy * sy - pad + ky;
       if ((unsigned)iy >= (unsigned)H) continue;
       for (int kx = 0; kx < k; ++kx) {
-        const int ix = ox * stride - pad + kx;
+        const int ix = ox * sx - pad + kx;
         if ((unsigned)ix >= (unsigned)W) continue;
         float v[8];
         load8(in + (((size_t)bi * H + iy) * W + ix) * cs + cg * 8, C, split, v);
@@ -312,6 +312,23 @@ __global__ __launch_bounds__(256) void dbnas_tail_kernel(const bf16_t* __restric
   }
 }
 
+// global average pool, second level: part [B][nchunk][C] -> mean bf16 [rows >= B][C] ([hi | lo] when split); rows B..rows-1
+// are written as zeros (the classifier GEMM works on whole 32-row tiles)
+__global__ __launch_bounds__(256) void chan_mean_kernel(const float* __restrict__ part, int B, int rows, int nchunk, int C,
+                                                        int HW, int split, bf16_t* __restrict__ mean) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)rows * C) return;
+  const int r = (int)(i / C), c = (int)(i % C);
+  float s = 0.f;
+  if (r < B)
+    for (int k = 0; k < nchunk; ++k) s += part[((size_t)r * nchunk + k) * C + c];
+  s /= (float)HW;
+  const uint32_t hb = f2bf(s);
+  const int cs = split ? 2 * C : C;
+  mean[(size_t)r * cs + c] = (bf16_t)hb;
+  if (split) mean[(size_t)r * cs + C + c] = (bf16_t)f2bf(s - bf2f(hb));
+}
+
 inline int blocks_for(long long total, int cap = 256 * 64) {
   long long b = (total + 255) / 256;
   if (b > cap) b = cap;
@@ -333,13 +350,16 @@ int pt_launch_stem3x3s2(const bf16_t* in, const float* w, const float* b, bf16_t
   return PT_OK;
 }
 
+// stride: s (both directions) or, for PP-LCNet's text-line classifiers, (sy << 8) | sx (cls_pp_lcnet.py:190-191)
 int pt_launch_dwconv(const bf16_t* in, const float* w, const float* b, bf16_t* out, int B, int H, int W, int C, int k,
                      int stride, int act, int split, hipStream_t s, const float* slope) {
-  PT_REQUIRE(in && w && b && out && C % 8 == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2), "dwconv: bad arguments");
+  const int sy = stride > 255 ? stride >> 8 : stride, sx = stride > 255 ? stride & 255 : stride;
+  PT_REQUIRE(in && w && b && out && C % 8 == 0 && (k == 3 || k == 5) && (sy == 1 || sy == 2) && (sx == 1 || sx == 2),
+             "dwconv: bad arguments");
   PT_REQUIRE(act != 3 || slope, "dwconv: PReLU needs the slope tensor");
-  const int pad = k / 2, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const int pad = k / 2, Ho = (H + 2 * pad - k) / sy + 1, Wo = (W + 2 * pad - k) / sx + 1;
   hipLaunchKernelGGL(dwconv_kernel, dim3(blocks_for((long long)B * Ho * Wo * (C / 8))), dim3(256), 0, s, in, w, b, out, B, H,
-                     W, C, k, stride, Ho, Wo, act, split, slope);
+                     W, C, k, sy, sx, Ho, Wo, act, split, slope);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
@@ -356,6 +376,16 @@ int pt_launch_se(const bf16_t* x, const float* w1, const float* b1, const float*
                      PT_SE_CHUNKS);
   hipLaunchKernelGGL(se_scale_kernel, dim3((unsigned)(((long long)B * HW * (C / 8) + 255) / 256)), dim3(256), 0, s, x, gate, out, B,
                      HW, C, split);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// x [B, HW, C] -> mean over HW as bf16 [rows, C]; part: scratch of PT_SE_CHUNKS * B * C floats
+int pt_launch_chan_mean(const bf16_t* x, int B, int HW, int C, int split, float* part, bf16_t* mean, int rows, hipStream_t s) {
+  PT_REQUIRE(x && part && mean && C % 8 == 0 && C <= 2048 && rows >= B, "channel mean: bad arguments");
+  hipLaunchKernelGGL(chan_partial_sum_kernel, dim3(PT_SE_CHUNKS, B), dim3(256), 0, s, x, HW, C, split, part);
+  hipLaunchKernelGGL(chan_mean_kernel, dim3((unsigned)(((long long)rows * C + 255) / 256)), dim3(256), 0, s, part, B, rows,
+                     PT_SE_CHUNKS, C, HW, split, mean);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }

@@ -1,4 +1,7 @@
-// layout_model.hip -- launch graph of the PicoDet layout detector: LCNet x1.0 -> 4-level CSP-PAN -> PicoHead.
+// layout_model.hip -- launch graphs over the LCNet x1.0 backbone: the PicoDet layout detector (LCNet -> 4-level CSP-PAN ->
+// PicoHead) and the PP-LCNet image classifiers (`PPLCNet`, model/cls/cls_pp_lcnet.py:164-283: the same backbone -> global
+// average pool -> 1x1 conv 512 -> 1280 + hardswish -> Linear; text-line variants run the first block of blocks3..6 with
+// stride (2, 1), configuration_cls_pulc.py:20-39).
 //
 // Reference graph: LCNet.forward picodet/lcnet.py:241-257, CSPPAN.forward csp_pan.py:305-345, PicoHead.forward_eval
 // pico_head.py:1108-1160 (export_post_process=False: per level sigmoid scores and raw box-distribution logits, which is
@@ -31,6 +34,7 @@ struct Ctx {
   bool dry, ok;
   int rc;
   float* gate = nullptr;
+  const char* what = "PicoDet";
 
   T alloc(int H, int W, int C) {
     T t;
@@ -42,7 +46,7 @@ struct Ctx {
   const PtTensor* get(const std::string& name) {
     const PtTensor* t = m->find(name);
     if (!t && rc == PT_OK) {
-      pt_set_error("PicoDet weight blob lacks tensor '%s'", name.c_str());
+      pt_set_error("%s weight blob lacks tensor '%s'", what, name.c_str());
       rc = PT_ERR_FORMAT;
     }
     return t;
@@ -70,9 +74,9 @@ struct Ctx {
     const int r = pt_launch_conv(e, c, s);
     if (r != PT_OK) rc = r;
   }
-  T dw(const T& in, const std::string& q, int k, int stride, int act) {
-    const int pad = k / 2;
-    T o = alloc((in.H + 2 * pad - k) / stride + 1, (in.W + 2 * pad - k) / stride + 1, in.C);
+  T dw(const T& in, const std::string& q, int k, int stride, int act) {     // stride: s or (sy << 8) | sx
+    const int pad = k / 2, sy = stride > 255 ? stride >> 8 : stride, sx = stride > 255 ? stride & 255 : stride;
+    T o = alloc((in.H + 2 * pad - k) / sy + 1, (in.W + 2 * pad - k) / sx + 1, in.C);
     const PtTensor* w = get(q + ".wf32");
     const PtTensor* b = get(q + ".b");
     if (go()) {
@@ -107,6 +111,57 @@ struct Ctx {
   }
 };
 
+// LCNet x1.0 (picodet/lcnet.py:241-257 == cls_pp_lcnet.py:262-273): conv1 3x3 s2 + 13 depthwise-separable blocks.
+// stage_stride[i]: stride of the first block of blocks3 + i -- 2, or (sy << 8) | sx.  feats: outputs of blocks4, 5, 6.
+T lcnet_backbone(Ctx& c, const bf16_t* x, int H, int W, const int* stage_stride, T* feats) {
+  // k, cin, cout, stage index of a stage's first block (-1: stride 1), se -- lcnet.py:25-46 / cls_pp_lcnet.py:54-66
+  static const int cfg[][5] = {{3, 16, 32, -1, 0},
+                               {3, 32, 64, 0, 0}, {3, 64, 64, -1, 0},
+                               {3, 64, 128, 1, 0}, {3, 128, 128, -1, 0},
+                               {3, 128, 256, 2, 0}, {5, 256, 256, -1, 0}, {5, 256, 256, -1, 0}, {5, 256, 256, -1, 0},
+                               {5, 256, 256, -1, 0}, {5, 256, 256, -1, 0},
+                               {5, 256, 512, 3, 1}, {5, 512, 512, -1, 1}};
+  static const char* names[] = {"blocks2.0", "blocks3.0", "blocks3.1", "blocks4.0", "blocks4.1", "blocks5.0", "blocks5.1",
+                                "blocks5.2", "blocks5.3", "blocks5.4", "blocks5.5", "blocks6.0", "blocks6.1"};
+  pt_engine* e = c.e;
+  hipStream_t s = c.s;
+  const int n = c.n;
+  T t = c.alloc((H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1, 32);
+  {
+    const PtTensor* w = c.get("stem.wf32");
+    const PtTensor* b = c.get("stem.b");
+    if (c.go()) {
+      PtProfScope ps(e, s, PT_PROF_STEM, 0, "lcnet stem3x3");
+      const int r = pt_launch_stem3x3s2(x, c.F(w), c.F(b), t.p, n, H, W, c.x3, s, 0);
+      if (r != PT_OK) c.rc = r;
+    }
+  }
+  for (int i = 0; i < 13; ++i) {
+    const int k = cfg[i][0], cout = cfg[i][2], se = cfg[i][4];
+    const int st = cfg[i][3] < 0 ? 1 : stage_stride[cfg[i][3]];
+    const std::string q = names[i];
+    T d = c.dw(t, q + ".dw", k, st, 2);
+    if (se) {
+      const PtTensor *w1 = c.get(q + ".se.w1"), *b1 = c.get(q + ".se.b1"), *w2 = c.get(q + ".se.w2"), *b2 = c.get(q + ".se.b2");
+      T g = c.alloc(d.H, d.W, d.C);
+      if (c.go()) {
+        PtProfScope ps(e, s, PT_PROF_OTHER, 0, "lcnet SE");
+        const int r = pt_launch_se(d.p, c.F(w1), c.F(b1), c.F(w2), c.F(b2), c.gate, g.p, n, d.H * d.W, d.C, c.x3, s, d.C / 4, 0, nullptr);
+        if (r != PT_OK) c.rc = r;
+      }
+      d = g;
+    }
+    const int cstore = cout < 32 ? 32 : cout;
+    T o = c.alloc(d.H, d.W, cstore);
+    c.pw(d, q + ".pw", cout < 64 ? 64 : cout, o, 2, nullptr, 1, cout < 64 ? cstore : 0);
+    t = o;
+    if (i == 4) feats[0] = t;
+    if (i == 10) feats[1] = t;
+    if (i == 12) feats[2] = t;
+  }
+  return t;
+}
+
 }  // namespace
 
 // x: NHWC4 bf16 [n, H, W, 4] (8 channels in BF16X3 mode); heads[l]: fp32 [n, A_l, 40], A_l = ceil-chain of the strides
@@ -125,54 +180,15 @@ int pt_picodet_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, f
   c.mul = c.x3 ? 2 : 1;
   c.rc = PT_OK;
   float* heads[4] = {h0, h1, h2, h3};
-  // k, cin, cout, stride, se -- picodet/lcnet.py:25-46
-  static const int cfg[][5] = {{3, 16, 32, 1, 0},
-                               {3, 32, 64, 2, 0}, {3, 64, 64, 1, 0},
-                               {3, 64, 128, 2, 0}, {3, 128, 128, 1, 0},
-                               {3, 128, 256, 2, 0}, {5, 256, 256, 1, 0}, {5, 256, 256, 1, 0}, {5, 256, 256, 1, 0},
-                               {5, 256, 256, 1, 0}, {5, 256, 256, 1, 0},
-                               {5, 256, 512, 2, 1}, {5, 512, 512, 1, 1}};
-  static const char* names[] = {"blocks2.0", "blocks3.0", "blocks3.1", "blocks4.0", "blocks4.1", "blocks5.0", "blocks5.1",
-                                "blocks5.2", "blocks5.3", "blocks5.4", "blocks5.5", "blocks6.0", "blocks6.1"};
+  static const int st22[4] = {2, 2, 2, 2};
   for (int pass = 0; pass < 2; ++pass) {
     c.dry = pass == 0;
     c.ok = true;
     e->arena.reset();
     c.gate = reinterpret_cast<float*>(e->arena.take((size_t)n * 512 * sizeof(float)));
     if (!c.gate) c.ok = false;
-    T t = c.alloc((H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1, 32);
-    {
-      const PtTensor* w = c.get("stem.wf32");
-      const PtTensor* b = c.get("stem.b");
-      if (c.go()) {
-        PtProfScope ps(e, s, PT_PROF_STEM, 0, "layout stem3x3");
-        const int r = pt_launch_stem3x3s2(x, c.F(w), c.F(b), t.p, n, H, W, c.x3, s, 0);
-        if (r != PT_OK) c.rc = r;
-      }
-    }
     T feats[3];
-    for (int i = 0; i < 13; ++i) {
-      const int k = cfg[i][0], cout = cfg[i][2], st = cfg[i][3], se = cfg[i][4];
-      const std::string q = names[i];
-      T d = c.dw(t, q + ".dw", k, st, 2);
-      if (se) {
-        const PtTensor *w1 = c.get(q + ".se.w1"), *b1 = c.get(q + ".se.b1"), *w2 = c.get(q + ".se.w2"), *b2 = c.get(q + ".se.b2");
-        T g = c.alloc(d.H, d.W, d.C);
-        if (c.go()) {
-          PtProfScope ps(e, s, PT_PROF_OTHER, 0, "layout SE");
-          const int r = pt_launch_se(d.p, c.F(w1), c.F(b1), c.F(w2), c.F(b2), c.gate, g.p, n, d.H * d.W, d.C, c.x3, s, d.C / 4, 0, nullptr);
-          if (r != PT_OK) c.rc = r;
-        }
-        d = g;
-      }
-      const int cstore = cout < 32 ? 32 : cout;
-      T o = c.alloc(d.H, d.W, cstore);
-      c.pw(d, q + ".pw", cout < 64 ? 64 : cout, o, 2, nullptr, 1, cout < 64 ? cstore : 0);
-      t = o;
-      if (i == 4) feats[0] = t;
-      if (i == 10) feats[1] = t;
-      if (i == 12) feats[2] = t;
-    }
+    lcnet_backbone(c, x, H, W, st22, feats);
     // ---- CSP-PAN (csp_pan.py:305-345)
     T ins[3];
     for (int i = 0; i < 3; ++i) {
@@ -221,6 +237,77 @@ int pt_picodet_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, f
     }
     if (!c.ok) {
       pt_set_error("layout net: activation arena allocation failed");
+      return PT_ERR_HIP;
+    }
+  }
+  return PT_OK;
+}
+
+// PP-LCNet classifier (`PPLCNet.forward`, cls_pp_lcnet.py:262-283).  x: NHWC4 bf16 [n, H, W, 4] (8 channels in BF16X3
+// mode); textline != 0: stride_list [2, [2,1], [2,1], [2,1], [2,1]] (textline_orientation / language_classification).
+// logits: fp32 [n, 16], the first *n_classes columns valid.  slot: which of the PT_CLS_SLOTS loaded classifiers
+// (model kind PT_MODEL_PPLCNET + slot) -- the reference keeps several alive at once (ocr_system_task.py:116-146).
+int pt_pplcnet_forward_net(pt_engine* e, int slot, const bf16_t* x, int n, int H, int W, int textline, float* logits,
+                           int* n_classes, hipStream_t s) {
+  PT_REQUIRE(x && logits && n > 0 && H > 0 && W > 0 && slot >= 0 && slot < PT_CLS_SLOTS, "PP-LCNet: bad arguments");
+  auto it = e->models.find(PT_MODEL_PPLCNET + slot);
+  if (it == e->models.end()) {
+    pt_set_error("PP-LCNet weights not loaded (pt_weights_load(PT_MODEL_PPLCNET + %d))", slot);
+    return PT_ERR_STATE;
+  }
+  Ctx c;
+  c.e = e; c.m = &it->second; c.s = s; c.n = n;
+  c.x3 = e->precision == PT_PRECISION_BF16X3 ? 1 : 0;
+  c.mul = c.x3 ? 2 : 1;
+  c.rc = PT_OK;
+  c.what = "PP-LCNet";
+  const PtTensor* nc = c.get("fc.nclass");
+  if (!nc) return c.rc;
+  if (n_classes) *n_classes = (int)nc->dims[0];
+  const int st22[4] = {2, 2, 2, 2}, st21[4] = {(2 << 8) | 1, (2 << 8) | 1, (2 << 8) | 1, (2 << 8) | 1};
+  const int rows = (n + 31) / 32 * 32;
+  for (int pass = 0; pass < 2; ++pass) {
+    c.dry = pass == 0;
+    c.ok = true;
+    e->arena.reset();
+    c.gate = reinterpret_cast<float*>(e->arena.take((size_t)n * 512 * sizeof(float)));
+    float* part = reinterpret_cast<float*>(e->arena.take((size_t)n * PT_SE_CHUNKS * 512 * sizeof(float)));
+    if (!c.gate || !part) c.ok = false;
+    T feats[3];
+    T t = lcnet_backbone(c, x, H, W, textline ? st21 : st22, feats);
+    // avg_pool -> last_conv (1x1, no bias) + hardswish -> fc: the pooled vectors form a [rows/32, 32] "image" of 512 channels
+    const int keep = c.n;
+    T mean;
+    mean.H = rows / 32; mean.W = 32; mean.C = 512;
+    mean.p = reinterpret_cast<bf16_t*>(e->arena.take((size_t)rows * 512 * c.mul * sizeof(bf16_t)));
+    T hid;
+    hid.H = rows / 32; hid.W = 32; hid.C = 1280;
+    hid.p = reinterpret_cast<bf16_t*>(e->arena.take((size_t)rows * 1280 * c.mul * sizeof(bf16_t)));
+    float* lg = reinterpret_cast<float*>(e->arena.take((size_t)rows * 16 * sizeof(float)));
+    if (!mean.p || !hid.p || !lg) c.ok = false;
+    if (c.go()) {
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0, "pplcnet avgpool");
+      const int r = pt_launch_chan_mean(t.p, n, t.H * t.W, 512, c.x3, part, mean.p, rows, s);
+      if (r != PT_OK) c.rc = r;
+    }
+    c.n = 1;     // the two head GEMMs see one [rows/32, 32] map
+    c.pw(mean, "last_conv", 1280, hid, 2);
+    c.pw(hid, "fc", 64, T(), 0, nullptr, 1, 16, lg, 16);
+    c.n = keep;
+    if (c.go()) PT_HIP_CHECK(hipMemcpyAsync(logits, lg, (size_t)n * 16 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (c.rc != PT_OK) return c.rc;
+    if (pass == 0) {
+      if (c.ok) continue;
+      PT_HIP_CHECK(hipDeviceSynchronize());
+      if (e->arena.base) PT_HIP_CHECK(hipFree(e->arena.base));
+      e->arena.base = nullptr;
+      const size_t want = e->arena.high + (1u << 20);
+      PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arena.base), want));
+      e->arena.cap = want;
+      continue;
+    }
+    if (!c.ok) {
+      pt_set_error("PP-LCNet: activation arena allocation failed");
       return PT_ERR_HIP;
     }
   }

@@ -13,11 +13,12 @@ import torch
 
 from . import lib as L
 
-__all__ = ["HipEngine", "REC_LINE_DTYPE"]
+__all__ = ["HipEngine", "REC_LINE_DTYPE", "CLS_IMAGE_DTYPE"]
 
 # mirrors struct pt_rec_line in include/pdftable_hip.h (88 bytes)
 TSR_TABLE_DTYPE = np.dtype([("minv", "<f8", (6,)), ("page", "<i4"), ("x0", "<i4"), ("y0", "<i4"),
                             ("crop_w", "<i4"), ("crop_h", "<i4"), ("reserved", "<i4")])   # struct pt_tsr_table
+CLS_IMAGE_DTYPE = np.dtype([("offset", "<i8"), ("h", "<i4"), ("w", "<i4")])      # pt_cls_image
 REC_LINE_DTYPE = np.dtype([("minv", np.float64, (9,)), ("page", np.int32), ("crop_w", np.int32), ("crop_h", np.int32),
                            ("reserved", np.int32)])
 
@@ -241,6 +242,80 @@ class HipEngine:
             L.check(self.lib.pt_det_box_scores(self._h, _ptr(prob), n, H, W, _ptr(boxes), nb, _ptr(scores),
                                                self._stream()), "pt_det_box_scores")
         return scores
+
+    # ---- image classification (PP-LCNet) ------------------------------------------------------------
+    def _cls_batch(self, images: Sequence[np.ndarray]):
+        """RGB uint8 images of any sizes -> (flat device bytes, device pt_cls_image records, max_h, max_w)"""
+        desc = np.zeros(len(images), dtype=CLS_IMAGE_DTYPE)
+        off = 0
+        parts = []
+        for k, im in enumerate(images):
+            im = np.ascontiguousarray(im[:, :, :3], dtype=np.uint8)
+            desc[k] = (off, im.shape[0], im.shape[1])
+            off += im.size
+            parts.append(im.reshape(-1))
+        flat = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+        return (_upload(flat, self._tdev), _upload(desc.view(np.uint8).reshape(-1), self._tdev),
+                int(desc["h"].max()), int(desc["w"].max()))
+
+    def cls_preprocess(self, images: Sequence[np.ndarray], out_hw) -> torch.Tensor:
+        """-> bf16 NHWC4 [n, out_h, out_w, 4] (8 channels in BF16X3 mode)"""
+        n = len(images)
+        base, desc, mh, mw = self._cls_batch(images)
+        ch = 8 if self.precision == L.PT_PRECISION_BF16X3 else 4
+        out = torch.empty((n, out_hw[0], out_hw[1], ch), dtype=torch.bfloat16, device=self._tdev)
+        L.check(self.lib.pt_cls_preprocess(self._h, _ptr(base), _ptr(desc), n, mh, mw, out_hw[0], out_hw[1], _ptr(out),
+                                           self._stream()), "pt_cls_preprocess")
+        return out
+
+    def cls_forward_net(self, x: torch.Tensor, slot: int = 0, textline: bool = False) -> torch.Tensor:
+        """x bf16 NHWC4 [n,H,W,4|8] -> logits f32 [n, class_num] (device)"""
+        self._chk(x, torch.bfloat16, "x")
+        n, H, W, _ = x.shape
+        logits = torch.empty((n, L.PT_CLS_MAX_CLASSES), dtype=torch.float32, device=self._tdev)
+        nc = C.c_int(0)
+        L.check(self.lib.pt_cls_forward_net(self._h, slot, _ptr(x), n, H, W, int(textline), _ptr(logits), C.byref(nc),
+                                            self._stream()), "pt_cls_forward_net")
+        return logits[:, :nc.value]
+
+    def cls_forward(self, images: Sequence[np.ndarray], out_hw, slot: int = 0, textline: bool = False) -> torch.Tensor:
+        """RGB uint8 images (any sizes, host) -> logits f32 [n, class_num] (device): resize + normalise + PP-LCNet"""
+        n = len(images)
+        base, desc, mh, mw = self._cls_batch(images)
+        logits = torch.empty((n, L.PT_CLS_MAX_CLASSES), dtype=torch.float32, device=self._tdev)
+        nc = C.c_int(0)
+        L.check(self.lib.pt_cls_forward(self._h, slot, _ptr(base), _ptr(desc), n, mh, mw, out_hw[0], out_hw[1], int(textline),
+                                        _ptr(logits), C.byref(nc), self._stream()), "pt_cls_forward")
+        return logits[:, :nc.value]
+
+    def cls_forward_pages(self, pages: torch.Tensor, out_hw, slot: int = 0, textline: bool = False) -> torch.Tensor:
+        """pages uint8 [n,h,w,3] resident on the device -> logits f32 [n, class_num]"""
+        self._chk(pages, torch.uint8, "pages")
+        n, h, w, _ = pages.shape
+        desc = np.zeros(n, dtype=CLS_IMAGE_DTYPE)
+        desc["offset"] = np.arange(n, dtype=np.int64) * (h * w * 3)
+        desc["h"], desc["w"] = h, w
+        d = _upload(desc.view(np.uint8).reshape(-1), self._tdev)
+        logits = torch.empty((n, L.PT_CLS_MAX_CLASSES), dtype=torch.float32, device=self._tdev)
+        nc = C.c_int(0)
+        L.check(self.lib.pt_cls_forward(self._h, slot, _ptr(pages), _ptr(d), n, h, w, out_hw[0], out_hw[1], int(textline),
+                                        _ptr(logits), C.byref(nc), self._stream()), "pt_cls_forward")
+        return logits[:, :nc.value]
+
+    def cls_forward_lines(self, pages: torch.Tensor, lines: np.ndarray, out_hw, slot: int = 0, textline: bool = True):
+        """text lines (REC_LINE_DTYPE records) cut from resident pages -> logits f32 [n_lines, class_num]"""
+        self._chk(pages, torch.uint8, "pages")
+        n, h, w, _ = pages.shape
+        nl = len(lines)
+        logits = torch.empty((nl, L.PT_CLS_MAX_CLASSES), dtype=torch.float32, device=self._tdev)
+        nc = C.c_int(0)
+        if nl:
+            d, px = self._lines_to_device(lines)
+            mh, mw = max(1, int(lines["crop_h"].max())), max(1, int(lines["crop_w"].max()))
+            L.check(self.lib.pt_cls_forward_lines(self._h, slot, _ptr(pages), n, h, w, _ptr(d), px.ctypes.data_as(C.c_void_p), nl,
+                                                  mh, mw, out_hw[0], out_hw[1], int(textline), _ptr(logits), C.byref(nc),
+                                                  self._stream()), "pt_cls_forward_lines")
+        return logits[:, :nc.value] if nl else logits[:, :0]
 
     # ---- recognition ------------------------------------------------------------------------------
     def _lines_to_device(self, lines: np.ndarray):

@@ -19,6 +19,9 @@ PT_MODEL_LORE_PROCESSOR = 4
 PT_MODEL_PICODET = 5
 PT_MODEL_LORE_RESNET18 = 6
 PT_MODEL_DB_NAS = 7
+PT_MODEL_PPLCNET = 8      # + slot (0 .. PT_CLS_SLOTS - 1)
+PT_CLS_SLOTS = 4
+PT_CLS_MAX_CLASSES = 16
 PT_LAYOUT_HEAD_CS, PT_LAYOUT_CAND_FLOATS = 40, 48
 PT_DET_PRE_DB_PP = 0
 PT_DET_PRE_DB_TORCH = 1
@@ -71,6 +74,10 @@ def _proto(lib):
         "pt_tsr_forward_net_wireless": (i, [vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp]),
         "pt_tsr_decode": (i, [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, f, vp, vp, vp, vp]),
         "pt_tsr_process": (i, [vp, vp, vp, vp, i, i, vp, vp, vp]),
+        "pt_cls_preprocess": (i, [vp, vp, vp, i, i, i, i, i, vp, vp]),
+        "pt_cls_forward_net": (i, [vp, i, vp, i, i, i, i, vp, ip, vp]),
+        "pt_cls_forward": (i, [vp, i, vp, vp, i, i, i, i, i, i, vp, ip, vp]),
+        "pt_cls_forward_lines": (i, [vp, i, vp, i, i, i, vp, vp, i, i, i, i, i, i, vp, ip, vp]),
         "pt_op_conv2d": (i, [vp, vp, i, i, i, i, vp, vp, i, i, i, vp, i, i, i, i, vp, i, i, i, i, vp]),
         "pt_op_stem7x7": (i, [vp, vp, i, i, i, vp, vp, vp, i, vp]),
         "pt_op_maxpool3x3s2": (i, [vp, vp, i, i, i, i, vp, i, vp]),

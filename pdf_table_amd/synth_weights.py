@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 __all__ = ["db_resnet18_state_dict", "crnn_state_dict", "CRNN_NUM_CLASSES", "lore_dla34_state_dict",
-           "lore_processor_state_dict", "LORE_HEADS", "picodet_state_dict", "LCNET_CONFIG", "PICODET_STANDIN", "lore_wireless_state_dict", "db_nas_state_dict"]
+           "lore_processor_state_dict", "LORE_HEADS", "picodet_state_dict", "LCNET_CONFIG", "PICODET_STANDIN", "lore_wireless_state_dict", "db_nas_state_dict", "pplcnet_state_dict"]
 
 CRNN_NUM_CLASSES = 7644  # crnn/modeling_crnn.py:90
 
@@ -490,4 +490,28 @@ def db_nas_state_dict(seed: int = 0, with_thresh_branch: bool = True, head_bias:
         g.convT("decoder.thresh.3", q, q, 2, 2)
         g.bn("decoder.thresh.4", q)
         g.convT("decoder.thresh.6", q, 1, 2, 2)
+    return g.sd
+
+
+def pplcnet_state_dict(seed: int = 0, class_num: int = 2, logit_gain: float = 4.0):
+    """state_dict of ``PPLCNet(scale=1.0, class_num=...)`` (model/cls/cls_pp_lcnet.py:164-260): conv1, blocks2..6 (the
+    LCNet x1.0 table LCNET_CONFIG == NET_CONFIG :54-66), last_conv (512 -> 1280, no bias), fc.  stride_list does not
+    change any shape."""
+    g = _Gen(seed)
+
+    def conv_bn(p, cout, cin, k, groups=1, gain=2.0):
+        g.conv(p + ".conv", cout, cin // groups, k, k, gain=gain)
+        g.bn(p + ".bn", cout)
+
+    conv_bn("conv1", 16, 3, 3)
+    for blk in ("blocks2", "blocks3", "blocks4", "blocks5", "blocks6"):
+        for i, (k, cin, cout, s, se) in enumerate(LCNET_CONFIG[blk]):
+            p = f"{blk}.{i}"
+            conv_bn(p + ".dw_conv", cin, cin, k, groups=cin, gain=2.0)
+            if se:
+                g.conv(p + ".se.conv1", cin // 4, cin, 1, 1, bias=True)
+                g.conv(p + ".se.conv2", cin, cin // 4, 1, 1, bias=True)
+            conv_bn(p + ".pw_conv", cout, cin, 1)
+    g.conv("last_conv", 1280, 512, 1, 1)
+    g.linear("fc", class_num, 1280, scale=logit_gain)
     return g.sd

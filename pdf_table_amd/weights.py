@@ -29,7 +29,7 @@ import torch
 BN_EPS = 1e-5
 _DT = {"bf16": 0, "f32": 1, "i32": 2}
 
-__all__ = ["pack_db_resnet18", "pack_crnn", "pack_lore_dla34", "pack_lore_processor", "pack_picodet", "pack_lore_wireless", "pack_db_nas", "write_blob", "fold_conv_bn", "to_bf16_bits"]
+__all__ = ["pack_db_resnet18", "pack_crnn", "pack_lore_dla34", "pack_lore_processor", "pack_picodet", "pack_lore_wireless", "pack_db_nas", "pack_pplcnet", "write_blob", "fold_conv_bn", "to_bf16_bits"]
 
 
 def to_bf16_bits(t: torch.Tensor) -> np.ndarray:
@@ -571,4 +571,49 @@ def pack_db_nas(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
     tail[432:448] = sd["decoder.binarize.6.pointwise.weight"][0, :, 0, 0].double().numpy()
     tail[448] = float(sd["decoder.binarize.6.pointwise.bias"][0])
     bl.add("dec.tail", tail.astype(np.float32), "f32")
+    return bl.tobytes()
+
+
+def pack_pplcnet(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
+    """``PPLCNet`` state_dict (model/cls/cls_pp_lcnet.py:164-260) -> blob for PT_MODEL_PPLCNET (+ slot).  The backbone
+    tensors have the names and layouts of pack_picodet's LCNet part (the same launch code runs both); ``last_conv`` and
+    ``fc`` are 1x1 GEMMs over the pooled vectors (fc padded to 64 outputs, 16 stored); ``fc.nclass`` carries the class
+    count in its length."""
+    from .synth_weights import LCNET_CONFIG
+    bl = _Blob(x3)
+
+    def dw(name, conv_key, bn_key):
+        w, b = _fold_named(sd, conv_key, bn_key)                    # [C, 1, k, k]
+        c, _, k, _ = w.shape
+        cp = max(c, 32)
+        wp = torch.zeros(k * k, cp)
+        wp[:, :c] = w[:, 0].permute(1, 2, 0).reshape(k * k, c)
+        bp = torch.zeros(cp)
+        bp[:c] = b
+        bl.add(name + ".wf32", wp.numpy(), "f32")
+        bl.add(name + ".b", bp.numpy(), "f32")
+
+    w, b = _fold_named(sd, "conv1.conv", "conv1.bn")
+    st = torch.zeros(16, 3, 3, 4)
+    st[:, :, :, :3] = w.permute(0, 2, 3, 1)
+    bl.add("stem.wf32", st.numpy(), "f32")
+    bl.add("stem.b", b.numpy(), "f32")
+    for blk in ("blocks2", "blocks3", "blocks4", "blocks5", "blocks6"):
+        for i, (k, cin, cout, s, se) in enumerate(LCNET_CONFIG[blk]):
+            p = f"{blk}.{i}"
+            dw(p + ".dw", p + ".dw_conv.conv", p + ".dw_conv.bn")
+            if se:
+                bl.add(p + ".se.w1", sd[p + ".se.conv1.weight"][:, :, 0, 0].float().numpy(), "f32")
+                bl.add(p + ".se.b1", sd[p + ".se.conv1.bias"].float().numpy(), "f32")
+                bl.add(p + ".se.w2", sd[p + ".se.conv2.weight"][:, :, 0, 0].float().numpy(), "f32")
+                bl.add(p + ".se.b2", sd[p + ".se.conv2.bias"].float().numpy(), "f32")
+            w, b = _fold_named(sd, p + ".pw_conv.conv", p + ".pw_conv.bn")
+            bl.add_conv(p + ".pw", *_pad_conv(w, b, (w.shape[0] + 63) // 64 * 64, max(w.shape[1], 32)))
+    wl = sd["last_conv.weight"].float()
+    bl.add_conv("last_conv", wl, torch.zeros(wl.shape[0]))
+    wf = sd["fc.weight"].float()
+    ncls = wf.shape[0]
+    assert ncls <= 16, "the classifier head stores 16 logits per image"
+    bl.add_conv("fc", *_pad_conv(wf.reshape(ncls, -1, 1, 1), sd["fc.bias"].float(), 64, wf.shape[1]))
+    bl.add("fc.nclass", np.zeros(ncls, dtype=np.float32), "f32")
     return bl.tobytes()

@@ -99,6 +99,47 @@ def gen_db_nas():
     print("db_nas.npz", {k: v.shape for k, v in out.items()})
 
 
+def gen_pplcnet():
+    """reference PPLCNet (model/cls/cls_pp_lcnet.py) logits, the reference's Topk / TableAttribute post-processors and its
+    PPLCNetImageProcessor (-> Pillow bilinear resize) on the seeded inputs of tests/cls_synth.py"""
+    import importlib.util
+    sys.path.insert(0, os.path.dirname(HERE))
+    from cls_synth import CLS_GOLDEN_TASKS, PIL_CASES, PRE_CASES, cls_inputs, u8_image
+    from pdf_table_amd.synth_weights import pplcnet_state_dict
+    stub_env()      # image_processing_pplcnet.py imports cv2 (only to read image paths)
+    spec = importlib.util.spec_from_file_location("cls_pp_lcnet", os.path.join(REF_SRC, "pdftable/model/cls/cls_pp_lcnet.py"))
+    net_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(net_mod)
+    spec = importlib.util.spec_from_file_location("image_processing_pplcnet",
+                                                  os.path.join(REF_SRC, "pdftable/model/cls/image_processing_pplcnet.py"))
+    ip = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ip)
+    out = {}
+    post = {}
+    for task, (cn, textline, hw, seed) in CLS_GOLDEN_TASKS.items():
+        strides = [2, [2, 1], [2, 1], [2, 1], [2, 1]] if textline else [2, 2, 2, 2, 2]
+        net = net_mod.PPLCNet(class_num=cn, stride_list=strides).eval()
+        net.load_state_dict(pplcnet_state_dict(seed, cn), strict=True)
+        with torch.no_grad():
+            y = net(torch.from_numpy(cls_inputs(seed, 5, hw)))
+        out[f"logits_{task}"] = y.numpy()
+        post[task] = ip.PPLCNetImagePostProcessor(task=task)({"results": y})
+    # pre-processor: uint8 RGB images of odd sizes through the reference's own processor (Pillow resize inside)
+    for i, (task, (h, w)) in enumerate(PRE_CASES):
+        pv = ip.PPLCNetImageProcessor(task=task)(u8_image(i, h, w))["pixel_values"][0]
+        out[f"pre_out_{i}"] = np.asarray(pv, dtype=np.float32)
+    # Pillow itself on more shapes (the resize is third-party code: pinned to the library in this image)
+    import PIL
+    from PIL import Image
+    for i, (h, w, oh, ow) in enumerate(PIL_CASES):
+        out[f"pil_out_{i}"] = np.array(Image.fromarray(u8_image(100 + i, h, w)).resize((ow, oh), resample=Image.BILINEAR))
+    out["pillow_version"] = np.array(PIL.__version__)
+    np.savez_compressed(os.path.join(HERE, "pplcnet.npz"), **out)
+    with open(os.path.join(HERE, "pplcnet_post.json"), "w") as f:
+        json.dump(post, f, indent=1)
+    print("pplcnet.npz", {k: v.shape for k, v in out.items()})
+
+
 def gen_crnn():
     from pdf_table_amd.synth_weights import crnn_state_dict
     crnn = ref_import("pdftable.model.crnn.modeling_crnn")
@@ -549,6 +590,8 @@ if __name__ == "__main__":
         gen_db_resnet18()
     if "db_nas" in which or not sys.argv[1:]:
         gen_db_nas()
+    if "pplcnet" in which or not sys.argv[1:]:
+        gen_pplcnet()
     if "crnn" in which:
         gen_crnn()
     if "registry" in which:
