@@ -178,7 +178,7 @@ def main():
     from pdf_table_amd.synth_weights import db_resnet18_state_dict
     from pdf_table_amd.weights import pack_crnn, pack_db_resnet18
     stages = [x for x in args.stages.split(",") if x]
-    assert set(stages) <= {"layout", "det", "rec", "tsr"} and stages
+    assert set(stages) <= {"layout", "det", "rec", "tsr", "cls"} and stages
 
     eng = HipEngine(local_rank)
     # weights: packed once on rank 0, broadcast over RCCL/xGMI, loaded from device memory everywhere
@@ -239,6 +239,20 @@ def main():
             eng.load_weights(L.PT_MODEL_LORE_PROCESSOR, pack_lore_processor(psd, x3=False))
         tsr = TsrStage(eng, LoreConfig(task_type="wtw"), micro_batch=int(os.environ.get("PT_TSR_MICROBATCH", "32")))
 
+    cls_line = cls_page = None
+    if "cls" in stages:      # SURVEY 8f-1 (not part of BASELINE.json's metric; opt-in): PP-LCNet text-line + page orientation
+        from pdf_table_amd.cls_stage import ClsStage
+        from pdf_table_amd.synth_weights import pplcnet_state_dict
+        from pdf_table_amd.weights import pack_pplcnet
+        for slot, (seed, ncls) in enumerate(((5, 2), (6, 4))):
+            csd_ = pplcnet_state_dict(seed, ncls) if rank == 0 or world == 1 else None
+            if world > 1:
+                from pdf_table_amd.dist_utils import broadcast_blob
+                eng.load_weights_device(L.PT_MODEL_PPLCNET + slot, broadcast_blob(pack_pplcnet(csd_, x3=False) if rank == 0 else None, dev))
+            else:
+                eng.load_weights(L.PT_MODEL_PPLCNET + slot, pack_pplcnet(csd_, x3=False))
+        cls_line, cls_page = ClsStage(eng, "textline_orientation", 0), ClsStage(eng, "text_image_orientation", 1)
+
     # pages: rank r owns pages [r*P, (r+1)*P) of the global batch (static contiguous shard, dist_utils.shard_range)
     from pdf_table_amd.dist_utils import shard_range
     lo, hi = shard_range(world * PAGES_PER_STEP, rank, world)
@@ -275,6 +289,7 @@ def main():
     nboxes = 0
     ntok = 0
     ncells = 0
+    ncls_lines = 0
     nlayout = 0
 
     trace = {} if os.environ.get("PT_BENCH_TRACE") else None
@@ -286,7 +301,7 @@ def main():
     def run(steps, count=False):
         """software pipeline: all device work of step k is enqueued before the host halves run (the detection
         post-process of step k-1 first), so the GPU queue never drains while the host works"""
-        nonlocal nboxes, ntok, ncells, nlayout
+        nonlocal nboxes, ntok, ncells, nlayout, ncls_lines
         prev = None          # detection maps of the previous step (host post-process pending)
         tprev = None         # table-structure state of the previous step (cell counts, processor, host shaping pending)
         tproc = None         # ... of two steps ago (processor queued, rows on their way to pinned memory)
@@ -301,6 +316,11 @@ def main():
             if tsr is not None:
                 tsr_tables, tsr_metas = tsr.tables((PAGE, PAGE), table_boxes)    # host: one affine map per table
                 tpend = (tsr.start(pages, tsr_tables), tsr_metas)                # warp, DLA-34+DCN, decode (async)
+            cls_out = None
+            if cls_line is not None:
+                from pdf_table_amd.rec_stage import build_lines
+                cls_out = (eng.cls_forward_lines(pages, build_lines(gt_quads), (80, 160), 0, True),
+                           eng.cls_forward_pages(pages, (224, 224), 1, False))
             tick("enqueue", t0)
             t0 = time.perf_counter()
             if prev is not None and not args.no_post:          # host half of the previous step, under this step's GPU work
@@ -321,6 +341,17 @@ def main():
                 if count:
                     ntok += sum(len(t) for t in toks)
             tick("ctc", t0)
+            if cls_out is not None:
+                t0 = time.perf_counter()
+                lid, lsc = cls_line.top1(cls_out[0])       # D2H of [lines, 2] logits, soft-max + top-1 (vectorised host)
+                o = 0
+                for q in gt_quads:                         # the reference's per-page upright / upside-down vote
+                    cls_line.vote_top1(lid[o:o + len(q)], lsc[o:o + len(q)])
+                    o += len(q)
+                cls_page.top1(cls_out[1])
+                if count:
+                    ncls_lines += len(lid)
+                tick("cls_post", t0)
             t0 = time.perf_counter()
             if tproc is not None:      # tables of two steps ago: their rows reached pinned memory during the last step
                 tres = tsr.collect(tproc[0], tproc[1])
@@ -399,6 +430,8 @@ def main():
                                       + (" + Lore table-structure recognition of the page's tables (wtw: warp to 1024x1024, "
                                          "DLA-34+DCN, heat-map/corner decode with vertex snapping, 2 x 4-layer processor, "
                                          "quads + logical locations)" if "tsr" in stages else "")
+                                      + (" + PP-LCNet text-line orientation of every text line and page orientation of every page "
+                                         "[opt-in stage, not part of BASELINE.json's metric]" if "cls" in stages else "")
                                       + (" [DEVICE HALF ONLY]" if args.no_post else "")
                                       + "; weights are random-init, so the stages are chained by the page generator's ground truth "
                                         "(table regions for TSR, text-line quads for recognition) instead of each other's outputs",
@@ -410,6 +443,7 @@ def main():
                           "tables_per_page": tables_per_page if "tsr" in stages else 0,
                           "layout_regions_per_page": nlayout / max(1, PAGES_PER_STEP * args.steps),
                           "table_cells_per_page": ncells / max(1, PAGES_PER_STEP * args.steps),
+                          "classified_lines_per_page": ncls_lines / max(1, PAGES_PER_STEP * args.steps),
                           "weights": "seeded random init (reference state_dict layout)"},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:

@@ -68,6 +68,17 @@ class ClsStage:
         x = logits.cpu().numpy()
         return table_attribute_postprocess(x) if self.task == "table_attribute" else topk_postprocess(x, self.task)
 
+    def top1(self, logits: torch.Tensor):
+        """vectorised Topk(topk=1) for large batches: (class ids int64 [n], scores f32 [n] rounded to 5 decimals)"""
+        p = torch.softmax(logits.float(), dim=-1).cpu().numpy()
+        ids = np.argsort(p, axis=1)[:, -1]          # same tie rule as Topk: the LAST of equal maxima in argsort order
+        return ids, np.around(p[np.arange(len(p)), ids], decimals=5)
+
+    def vote_top1(self, ids: np.ndarray, scores: np.ndarray, score_threshold: float = 0.9) -> bool:
+        """orientation_vote on top1() arrays (class 0 = "0_degree")"""
+        ok = scores > score_threshold
+        return int(np.sum(ok & (ids == 0))) > int(np.sum(ok & (ids != 0)))
+
     def images(self, images: Sequence[np.ndarray]) -> List[Dict]:
         """RGB uint8 host images of any sizes"""
         if not len(images):

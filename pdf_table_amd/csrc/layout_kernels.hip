@@ -106,45 +106,72 @@ __global__ __launch_bounds__(256) void stem3x3s2_kernel(const bf16_t* __restrict
   for (int n0 = NOUT; n0 < OST; n0 += 8) store8(op + n0, OST, split, z);
 }
 
-// w fp32 [k*k][C] (BN scale folded), b fp32 [C]
+// w fp32 [k*k][C] (BN scale folded), b fp32 [C].  One thread = 8 channels x PX consecutive output pixels of a row: the
+// input columns of a tap row are loaded once (16 B each) and shared by the PX outputs, the 8 weights of a tap once per
+// thread; per output pixel the taps are still accumulated in (ky, kx) order in fp32.
+template <int K, int SX>
 __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w,
                                                       const float* __restrict__ b, bf16_t* __restrict__ out, int B, int H,
-                                                      int W, int C, int k, int sy, int sx, int Ho, int Wo, int act, int split,
+                                                      int W, int C, int sy, int Ho, int Wo, int act, int split,
                                                       const float* __restrict__ slope) {
-  const int cgn = C >> 3, cs = split ? 2 * C : C, pad = k / 2;
+  constexpr int PX = 4, PAD = K / 2, NCOL = (PX - 1) * SX + K;
+  const int cgn = C >> 3, cs = split ? 2 * C : C, wq = (Wo + PX - 1) / PX;
   const float sl = act == 3 ? slope[0] : 0.f;
-  const long long total = (long long)B * Ho * Wo * cgn;
+  const long long total = (long long)B * Ho * wq * cgn;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int cg = (int)(i % cgn);
     long long t = i / cgn;
-    const int ox = (int)(t % Wo);
-    t /= Wo;
+    const int ox0 = (int)(t % wq) * PX;
+    t /= wq;
     const int oy = (int)(t % Ho);
     const int bi = (int)(t / Ho);
-    float acc[8];
+    float acc[PX][8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
-    for (int ky = 0; ky < k; ++ky) {
-      const int iy = oy * sy - pad + ky;
+    for (int p = 0; p < PX; ++p)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[p][q] = 0.f;
+    const int ix0 = ox0 * SX - PAD;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int iy = oy * sy - PAD + ky;
       if ((unsigned)iy >= (unsigned)H) continue;
-      for (int kx = 0; kx < k; ++kx) {
-        const int ix = ox * sx - pad + kx;
-        if ((unsigned)ix >= (unsigned)W) continue;
-        float v[8];
-        load8(in + (((size_t)bi * H + iy) * W + ix) * cs + cg * 8, C, split, v);
-        const float* wp = w + (size_t)(ky * k + kx) * C + cg * 8;
+      float col[NCOL][8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] += v[q] * wp[q];
+      for (int j = 0; j < NCOL; ++j) {
+        const int ix = ix0 + j;
+        if ((unsigned)ix < (unsigned)W) {
+          load8(in + (((size_t)bi * H + iy) * W + ix) * cs + cg * 8, C, split, col[j]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) col[j][q] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const float4 w0 = *reinterpret_cast<const float4*>(w + (size_t)(ky * K + kx) * C + cg * 8);
+        const float4 w1 = *reinterpret_cast<const float4*>(w + (size_t)(ky * K + kx) * C + cg * 8 + 4);
+        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int p = 0; p < PX; ++p)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc[p][q] += col[p * SX + kx][q] * wv[q];
       }
     }
+    const float4 b0 = *reinterpret_cast<const float4*>(b + cg * 8), b1 = *reinterpret_cast<const float4*>(b + cg * 8 + 4);
+    const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      acc[q] += b[cg * 8 + q];
-      if (act == 2) acc[q] = hswish(acc[q]);
-      else if (act == 1) acc[q] = fmaxf(acc[q], 0.f);
-      else if (act == 3) acc[q] = acc[q] > 0.f ? acc[q] : sl * acc[q];
+    for (int p = 0; p < PX; ++p) {
+      if (ox0 + p >= Wo) break;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float v = acc[p][q] + bv[q];
+        if (act == 2) v = hswish(v);
+        else if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 3) v = v > 0.f ? v : sl * v;
+        acc[p][q] = v;
+      }
+      store8(out + (((size_t)bi * Ho + oy) * Wo + ox0 + p) * cs + cg * 8, C, split, acc[p]);
     }
-    store8(out + (((size_t)bi * Ho + oy) * Wo + ox) * cs + cg * 8, C, split, acc);
   }
 }
 
@@ -358,8 +385,13 @@ int pt_launch_dwconv(const bf16_t* in, const float* w, const float* b, bf16_t* o
              "dwconv: bad arguments");
   PT_REQUIRE(act != 3 || slope, "dwconv: PReLU needs the slope tensor");
   const int pad = k / 2, Ho = (H + 2 * pad - k) / sy + 1, Wo = (W + 2 * pad - k) / sx + 1;
-  hipLaunchKernelGGL(dwconv_kernel, dim3(blocks_for((long long)B * Ho * Wo * (C / 8))), dim3(256), 0, s, in, w, b, out, B, H,
-                     W, C, k, sy, sx, Ho, Wo, act, split, slope);
+  const dim3 grid(blocks_for((long long)B * Ho * ((Wo + 3) / 4) * (C / 8)));
+#define PT_DW(KK, SS) hipLaunchKernelGGL((dwconv_kernel<KK, SS>), grid, dim3(256), 0, s, in, w, b, out, B, H, W, C, sy, Ho, Wo, act, split, slope)
+  if (k == 3 && sx == 1) PT_DW(3, 1);
+  else if (k == 3) PT_DW(3, 2);
+  else if (sx == 1) PT_DW(5, 1);
+  else PT_DW(5, 2);
+#undef PT_DW
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }

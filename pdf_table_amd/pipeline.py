@@ -38,6 +38,8 @@ class PageResult:
     ocr_result: List[Dict] = field(default_factory=list)   # [{"index", "text", "bbox"}] like modeling_ocr_pdf.py:286-291
     layout_result: Optional[list] = None
     table_structure_result: Optional[list] = None
+    text_upright: Optional[bool] = None          # text_line_orientation's vote (ocr_system_task.py:395-439); None = not run
+    text_line_orientation: Optional[list] = None  # per detected line: {"class_ids", "scores", "label_names"}
 
 
 class OcrTablePipeline:
@@ -46,7 +48,8 @@ class OcrTablePipeline:
                  rec_task_path: Optional[str] = None, layout: bool = False, table_structure: bool = False,
                  table_structure_model: str = "Lore", table_structure_task_type: str = "wtw",
                  tsr_task_path: Optional[str] = None, layout_model: str = "picodet", layout_task_type: str = "en",
-                 layout_task_path: Optional[str] = None, **kwargs):
+                 layout_task_path: Optional[str] = None, text_orientation: bool = False,
+                 orientation_task_path: Optional[str] = None, **kwargs):
         self.engine = HipEngine(device)
         dk = dict(kwargs)
         rk = dict(kwargs)
@@ -67,6 +70,15 @@ class OcrTablePipeline:
             if layout_task_path:
                 lk["task_path"] = layout_task_path
             self.layout_task = OcrLayoutTask(model=layout_model, engine=self.engine, task_type=layout_task_type, **lk)
+        self.orientation_task = None
+        if text_orientation:      # PP-LCNet text-line orientation over every detected line (ocr_system_task.py:116-146, 395-439)
+            from .cls_image_pulc_task import ClsImagePulcTask
+            ok = dict(kwargs)
+            if synthetic_seed is not None:
+                ok["synthetic_seed"] = synthetic_seed + 5
+            if orientation_task_path:
+                ok["task_path"] = orientation_task_path
+            self.orientation_task = ClsImagePulcTask(task_type="textline_orientation", engine=self.engine, slot=0, **ok)
         self.table_structure_task = None
         if table_structure:
             tk = dict(kwargs)
@@ -101,6 +113,15 @@ class OcrTablePipeline:
                 texts = self.text_recognizer.recognize_quads(batch, boxes)
             except Exception:                      # reference: a failing recognition yields empty strings
                 texts = [[""] * len(b) for b in boxes]
+            ori = None
+            if self.orientation_task is not None:
+                ori = []
+                flat, _ = self.orientation_task.lines(batch, boxes)
+                o = 0
+                for b in boxes:       # the reference votes per page; it then rotates a non-upright page by 180 degrees and
+                    res = flat[o:o + len(b)]      # detects again (:471-478) -- left to the caller, who holds the pages
+                    o += len(b)
+                    ori.append((res, self.orientation_task._stage.orientation_vote(res)))
             c = time.time()
             lay = self.layout_task.detect_pages(batch) if self.layout_task is not None else None
             tsr = None
@@ -123,7 +144,9 @@ class OcrTablePipeline:
             for k, i in enumerate(idxs):
                 ocr = [{"index": j + 1, "text": t, "bbox": boxes[k][j].reshape(4, 2)} for j, t in enumerate(texts[k])]
                 results[i] = PageResult(det_result=boxes[k], ocr_result=ocr, layout_result=None if lay is None else lay[k],
-                                        table_structure_result=None if tsr is None else tsr[k])
+                                        table_structure_result=None if tsr is None else tsr[k],
+                                        text_upright=None if ori is None else ori[k][1],
+                                        text_line_orientation=None if ori is None else ori[k][0])
         self.metric = {"use_time": time.time() - t0, "text_detection": {"use_time": t_det},
                        "text_recognition": {"use_time": t_rec, "total": sum(len(r.ocr_result) for r in results)},
                        "table_structure": {"use_time": t_tsr}}

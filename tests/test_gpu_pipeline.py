@@ -136,3 +136,17 @@ def test_table_structure_task_wireless(pipe):
     r = task(page[y1:y2, x1:x2].copy())[0]
     assert r["polygons"].shape[1] == 8 and r["logi"].shape == (len(r["polygons"]), 4)
     assert np.array_equal(r["logi"], np.round(r["logi"]))
+
+
+def test_pipeline_text_line_orientation():
+    """text_orientation=True: every detected line is classified in one batched call and each page gets the reference's
+    upright / upside-down vote (ocr_system_task.py:395-439)"""
+    from pdf_table_amd.pipeline import OcrTablePipeline
+    p = OcrTablePipeline(device=0, synthetic_seed=0, text_orientation=True)
+    pages = [make_page(i)[0] for i in (0, 1)]
+    res = p.predict(pages)
+    for r in res:
+        assert r.text_upright in (True, False)
+        assert len(r.text_line_orientation) == len(r.det_result)
+        for o in r.text_line_orientation:
+            assert o["label_names"][0] in ("0_degree", "180_degree") and 0.5 <= o["scores"][0] <= 1.0
