@@ -49,7 +49,7 @@ class OcrTablePipeline:
                  table_structure_model: str = "Lore", table_structure_task_type: str = "wtw",
                  tsr_task_path: Optional[str] = None, layout_model: str = "picodet", layout_task_type: str = "en",
                  layout_task_path: Optional[str] = None, text_orientation: bool = False,
-                 orientation_task_path: Optional[str] = None, **kwargs):
+                 orientation_task_path: Optional[str] = None, table_html: bool = False, **kwargs):
         self.engine = HipEngine(device)
         dk = dict(kwargs)
         rk = dict(kwargs)
@@ -70,6 +70,7 @@ class OcrTablePipeline:
             if layout_task_path:
                 lk["task_path"] = layout_task_path
             self.layout_task = OcrLayoutTask(model=layout_model, engine=self.engine, task_type=layout_task_type, **lk)
+        self.table_html = table_html      # structure + recognised text -> HTML per table (OcrTableToHtmlTask, section 8f-2)
         self.orientation_task = None
         if text_orientation:      # PP-LCNet text-line orientation over every detected line (ocr_system_task.py:116-146, 395-439)
             from .cls_image_pulc_task import ClsImagePulcTask
@@ -137,6 +138,20 @@ class OcrTablePipeline:
                         bx = [b for b in bx if b[2] > b[0] and b[3] > b[1]]
                         tb.append(np.array(bx, dtype=np.int64).reshape(-1, 4))
                 tsr = self.table_structure_task.recognize_tables(batch, tb)
+            if tsr is not None and self.table_html:
+                from .table_html import table_cells_from_logits
+                from .table_text_match import cells_to_html, match_table_cells_and_text, text_boxes, texts_in_table
+                for k in range(len(idxs)):
+                    tbx = text_boxes(boxes[k]) if len(boxes[k]) else np.zeros((0, 4))
+                    for ti, table in enumerate(tsr[k]):
+                        if len(table.get("scores", [])) == 0:
+                            table["table_html"], table["db_table_html"] = [], []
+                            continue
+                        cells = table_cells_from_logits(table["polygons"], table["logi"])
+                        inside = texts_in_table([float(v) for v in tb[k][ti]], tbx, diff=2) if len(tbx) else np.zeros(0, np.int64)
+                        # image pages: ocr_post_process=True (ocr_table_to_html_task.py:93)
+                        res = match_table_cells_and_text(cells, tbx[inside], [texts[k][i] for i in inside], post_process=True)
+                        table["table_html"], table["db_table_html"] = cells_to_html(res)
             d_ = time.time()
             t_det += b_ - a
             t_rec += c - b_

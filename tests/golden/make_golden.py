@@ -140,6 +140,86 @@ def gen_pplcnet():
     print("pplcnet.npz", {k: v.shape for k, v in out.items()})
 
 
+def _matcher_env():
+    """import environment for the reference's OcrTableToHtmlTask (third-party libraries stubbed, reference files real)"""
+    from collections import OrderedDict
+    import transformers  # noqa: F401
+    stub_env()
+    for m in ["pypdf", "PyPDF2", "pdf2image", "docx", "ghostscript", "requests", "tqdm", "xlsxwriter", "openpyxl", "bs4", "lxml",
+              "Levenshtein", "apted", "apted.helpers", "distance", "pdfminer.high_level", "pdfminer.pdfpage",
+              "pdfminer.pdfinterp", "pdfminer.converter", "pdfminer.pdfdocument", "pdfminer.pdfparser", "pdfminer.utils",
+              "pdfminer.image", "pdfminer.pdftypes", "pdfminer.psparser", "pdfminer.pdfdevice", "pdfminer.pdffont",
+              "pdfminer.pdfcolor", "skimage", "skimage.draw", "PIL.ImageDraw", "matplotlib", "matplotlib.pyplot",
+              "matplotlib.patches"]:
+        sys.modules.setdefault(m, _Stub(m))
+    for sub in ("model", "model/pdf_table", "entity", "model/ocr_pdf", "model/ocr_pdf/table", "utils/table"):
+        name = "pdftable." + sub.replace("/", ".")
+        if name not in sys.modules:
+            _pkg(name, os.path.join(REF_SRC, "pdftable", sub))
+    pl = types.ModuleType("pdfminer.layout")
+    for nme in ("LTChar", "LTTextLineHorizontal", "LTAnno", "LTImage", "LTTextLineVertical", "LTTextLine", "LTTextBoxHorizontal",
+                "LTFigure", "LTRect", "LTLine", "LTCurve", "LTTextBox", "LTPage", "LAParams", "LTContainer", "LTTextContainer"):
+        setattr(pl, nme, type(nme, (), {}))
+    sys.modules["pdfminer.layout"] = pl
+    ent = sys.modules["pdftable.entity"]
+    ee = ref_import("pdftable.entity.enum_entity")
+    for k in dir(ee):
+        if not k.startswith("_"):
+            setattr(ent, k, getattr(ee, k))
+    pu = sys.modules["pdftable.utils"]
+    pu.MathUtils = _Stub("MathUtils")
+    pu.Constants = ref_import("pdftable.utils.constant").Constants
+    pu.MatchUtils = ref_import("pdftable.utils.match_utils").MatchUtils
+    pu.CommonUtils = ref_import("pdftable.utils.common_utils").CommonUtils
+    ut = sys.modules["pdftable.utils.table"]
+    for nme in ("GhostscriptBackend", "PopplerBackend", "ImageConversionBackend"):
+        setattr(ut, nme, _Stub(nme))
+    te = ref_import("pdftable.entity.table_entity")
+    ref_import("pdftable.entity.ie_entity")
+    pu.PdfUtils = ref_import("pdftable.utils.pdf_utils").PdfUtils
+    tc = ref_import("pdftable.model.pdf_table.table_common")
+    core = ref_import("pdftable.model.pdf_table.table_core")
+    pm = sys.modules["pdftable.model"]
+    pm.Cell, pm.box_in_other_box, pm.distance, pm.compute_iou_v2 = core.Cell, tc.box_in_other_box, tc.distance, tc.compute_iou_v2
+    pm.TableProcessUtils = tc.TableProcessUtils
+    oo = types.ModuleType("pdftable.model.ocr_pdf.ocr_output")
+    oo.OcrSystemModelOutput = type("OcrSystemModelOutput", (), {})
+    sys.modules["pdftable.model.ocr_pdf.ocr_output"] = oo
+    sys.modules["pdftable.model.ocr_pdf.table"].TableMatch = lambda **k: None        # only constructed, never used on this path
+    tm = types.ModuleType("pdftable.model.ocr_pdf.table.table_master_match")
+    tm.TableMasterMatcher = lambda **k: None
+    sys.modules["pdftable.model.ocr_pdf.table.table_master_match"] = tm
+    t2h = ref_import("pdftable.model.ocr_pdf.ocr_table_to_html_task")
+    return t2h.OcrTableToHtmlTask, tc.TableProcessUtils, te.OcrCell
+
+
+def gen_table_text_match():
+    """the reference's own OcrTableToHtmlTask.match_table_cell_and_text_cell (ocr_table_to_html_task.py:178-243, with
+    find_top1_mach_box :48-77 and get_one_cell_text :297-330), get_text_in_table_bbox (table_common.py:1303-1325) and
+    cell_to_html with text and widths on the seeded tables / OCR lines of tests/lore_synth.py"""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from lore_synth import synth_table_grids, synth_table_texts
+    Task, T, OcrCell = _matcher_env()
+    task = Task(output_dir="/tmp/pt_golden_html")
+    out = {"seed": 17, "cases": []}
+    for ci, (polys, logi) in enumerate(synth_table_grids(17)):
+        boxes, texts = synth_table_texts(ci, polys)
+        for post in (False, True):
+            cells = T.get_table_cell_from_table_logit(table_bboxs=polys, logits=logi, save_html_file=None)
+            ocr = [OcrCell(raw_data={"index": i + 1, "text": t, "bbox": b}) for i, (b, t) in enumerate(zip(boxes, texts))]
+            bbox = [float(polys[:, 0::2].min()), float(polys[:, 1::2].min()), float(polys[:, 0::2].max()), float(polys[:, 1::2].max())]
+            inside, remain = T.get_text_in_table_bbox(bbox=bbox, ocr_results=ocr, diff=2)
+            top1 = [int(task.find_top1_mach_box(text_box=c.to_bbox(), table_bboxs=cells)) for c in inside]
+            res, html, metric, db_html = task.match_table_cell_and_text_cell(table_idx=0, table_cells=cells, text_bboxs=inside,
+                                                                             raw_filename="g", ocr_post_process=post)
+            out["cases"].append({"case": ci, "ocr_post_process": post, "bbox": bbox, "inside": [int(c.index) for c in inside],
+                                 "top1": top1, "html": html, "db_html": db_html,
+                                 "cells": [[float(c.row_index), float(c.col_index), c.text] for c in res]})
+    with open(os.path.join(HERE, "table_text_match.json"), "w") as f:
+        json.dump(out, f)
+    print("table_text_match.json", len(out["cases"]), "cases;", out["cases"][0]["html"][:6])
+
+
 def gen_crnn():
     from pdf_table_amd.synth_weights import crnn_state_dict
     crnn = ref_import("pdftable.model.crnn.modeling_crnn")
@@ -592,6 +672,8 @@ if __name__ == "__main__":
         gen_db_nas()
     if "pplcnet" in which or not sys.argv[1:]:
         gen_pplcnet()
+    if "table_text_match" in which or not sys.argv[1:]:
+        gen_table_text_match()
     if "crnn" in which:
         gen_crnn()
     if "registry" in which:

@@ -78,3 +78,39 @@ def synth_table_grids(seed, n_cases=6):
         perm = rng.permutation(len(polys))
         cases.append((polys[perm], logi[perm]))
     return cases
+
+
+def synth_table_texts(seed, polys):
+    """seeded OCR text lines for a table whose cells are `polys` [n,8] (TL,TR,BR,BL): most cells get 0-3 stacked lines
+    inside them (some poking over the border, some wider than the cell), a few lines lie between cells or outside the
+    table.  -> (boxes f32 [t,4,2] as OcrCell.bbox expects, texts list[str]); order shuffled like detector output."""
+    rng = np.random.default_rng(1000 + seed)
+    words = ["total", "0", "O", "1.2.3", "12.5", "n/a", "item", "Q1", "2024", "o", "1.000.000", "x y", "abc\n", "9,5", " lead"]
+    boxes, texts = [], []
+    p = np.asarray(polys, np.float64)
+    for k in range(len(p)):
+        x1, y1, x2, y2 = p[k, 0], p[k, 1], p[k, 4], p[k, 5]
+        n = int(rng.integers(0, 4))
+        h = (y2 - y1) / max(n, 1)
+        for i in range(n):
+            lx1 = x1 + rng.uniform(1, 0.3 * (x2 - x1))
+            lx2 = x2 - rng.uniform(1, 0.3 * (x2 - x1))
+            ly1 = y1 + i * h + rng.uniform(0.5, 0.2 * h)
+            ly2 = y1 + (i + 1) * h - rng.uniform(0.5, 0.2 * h)
+            u = rng.uniform()
+            if u < 0.15:        # pokes out of the cell
+                lx2 = x2 + rng.uniform(2.5, 12)
+            elif u < 0.25:
+                ly1 = y1 - rng.uniform(2.5, 6)
+            if i > 0 and rng.uniform() < 0.3:       # second fragment on the same text row
+                boxes.append([[lx2 + 2, ly1 + 1], [lx2 + 14, ly1 + 1], [lx2 + 14, ly2], [lx2 + 2, ly2]])
+                texts.append(str(words[int(rng.integers(len(words)))]))
+            boxes.append([[lx1, ly1], [lx2, ly1 + rng.uniform(-0.8, 0.8)], [lx2, ly2], [lx1, ly2 + rng.uniform(-0.8, 0.8)]])
+            texts.append(str(words[int(rng.integers(len(words)))]))
+    xmin, ymin, xmax, ymax = p[:, 0::2].min(), p[:, 1::2].min(), p[:, 0::2].max(), p[:, 1::2].max()
+    for _ in range(4):          # strays: just outside the table and far away
+        cx, cy = rng.uniform(xmin - 30, xmax + 30), rng.choice([ymin - rng.uniform(1, 30), ymax + rng.uniform(1, 30)])
+        boxes.append([[cx, cy], [cx + 30, cy], [cx + 30, cy + 10], [cx, cy + 10]])
+        texts.append("stray")
+    perm = rng.permutation(len(boxes))
+    return np.asarray(boxes, np.float32)[perm], [texts[i] for i in perm]

@@ -150,3 +150,19 @@ def test_pipeline_text_line_orientation():
         assert len(r.text_line_orientation) == len(r.det_result)
         for o in r.text_line_orientation:
             assert o["label_names"][0] in ("0_degree", "180_degree") and 0.5 <= o["scores"][0] <= 1.0
+
+
+def test_pipeline_table_html():
+    """table_html=True: every structured table comes back with the reference-format HTML rows (cells + matched text)"""
+    from pdf_table_amd.pipeline import OcrTablePipeline
+    p = OcrTablePipeline(device=0, synthetic_seed=0, table_structure=True, table_html=True)
+    page, gt = make_page(0)
+    t = gt["tables"].astype(np.int64).reshape(-1, 4)
+    res = p.predict([page], table_boxes=[t])
+    tables = res[0].table_structure_result
+    assert len(tables) == len(t)
+    for tb in tables:
+        assert tb["table_html"][0] == '<table border="1">' and tb["table_html"][-1] == "</table>"
+        ncell = sum(1 for r in tb["table_html"] if r.startswith("<td"))
+        assert ncell == len(tb["polygons"]) or len(tb["scores"]) == 0
+        assert tb["db_table_html"][0].startswith("<table class='pdf-table'")

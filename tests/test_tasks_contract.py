@@ -166,3 +166,39 @@ def test_table_html_equals_reference(golden_dir):
         assert cells_to_structure_html(cells) == ref["html"]
         assert structure_html(polys, logi) == ref["html"]          # the fast path used by TsrStage
     assert "colspan" in "".join(r["html"] for r in gold["cases"]) and "rowspan" in "".join(r["html"] for r in gold["cases"])
+
+
+# ---- text <-> cell matching and table HTML ------------------------------------------------------------
+def test_table_text_match_equals_reference(golden_dir):
+    """pdf_table_amd.table_text_match against the reference's own OcrTableToHtmlTask on seeded tables and OCR lines
+    (tests/golden/table_text_match.json, generator: tests/golden/make_golden.py table_text_match)"""
+    import json
+    import os
+    import numpy as np
+    from lore_synth import synth_table_grids, synth_table_texts
+    from pdf_table_amd import table_text_match as M
+    from pdf_table_amd.table_html import table_cells_from_logits
+    with open(os.path.join(golden_dir, "table_text_match.json")) as f:
+        gold = json.load(f)
+    grids = synth_table_grids(gold["seed"])
+    assert len(gold["cases"]) == 2 * len(grids)
+    for g in gold["cases"]:
+        polys, logi = grids[g["case"]]
+        boxes, texts = synth_table_texts(g["case"], polys)
+        cells = table_cells_from_logits(polys, logi)
+        tb = M.text_boxes(boxes)
+        inside = M.texts_in_table(g["bbox"], tb, diff=2)
+        assert [int(i) + 1 for i in inside] == g["inside"]
+        cb = np.array([[c.x1, c.y1, c.x2, c.y2] for c in cells], np.float64)
+        assert M.find_top1_match(tb[inside], cb).tolist() == g["top1"]
+        res = M.match_table_cells_and_text(cells, tb[inside], [texts[i] for i in inside], post_process=g["ocr_post_process"])
+        assert [[float(c.row_index), float(c.col_index), c.text] for c in res] == g["cells"]
+        html, db = M.cells_to_html(res)
+        assert html == g["html"] and db == g["db_html"]
+
+
+def test_ocr_post_process_known_answers():
+    from pdf_table_amd.table_text_match import ocr_post_process
+    assert ocr_post_process("o") == "0" and ocr_post_process(" O ") == "0"
+    assert ocr_post_process("1.000.000") == "1,000.000" and ocr_post_process("1.5") == "1.5"
+    assert ocr_post_process("total") == "total" and ocr_post_process("") == ""
