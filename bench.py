@@ -166,8 +166,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # PT_BENCH_FORCE_DIST=1: initialise RCCL and take the broadcast / barrier / all-reduce path even with one rank
+    # (exercises the N > 1 code on a single-GPU box; launch with torchrun --nproc-per-node 1 or set MASTER_PORT)
+    use_dist = world > 1 or os.environ.get("PT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -190,7 +194,7 @@ def main():
         det_state_dict, pack_det = db_resnet18_state_dict, pack_db_resnet18
     det_kind = L.PT_MODEL_DB_NAS if nas else L.PT_MODEL_DB_RESNET18
     sd = det_state_dict(seed=0) if rank == 0 or world == 1 else None
-    if world > 1:
+    if use_dist:
         from pdf_table_amd.dist_utils import broadcast_blob
         blob = broadcast_blob(pack_det(sd, x3=False) if rank == 0 else None, dev)
         eng.load_weights_device(det_kind, blob)
@@ -202,7 +206,7 @@ def main():
         from pdf_table_amd.rec_stage import RecStage, build_lines
         from pdf_table_amd.synth_weights import crnn_state_dict
         csd = crnn_state_dict(seed=1) if rank == 0 or world == 1 else None
-        if world > 1:
+        if use_dist:
             from pdf_table_amd.dist_utils import broadcast_blob
             eng.load_weights_device(L.PT_MODEL_CRNN, broadcast_blob(pack_crnn(csd, x3=False) if rank == 0 else None, dev))
         else:
@@ -215,7 +219,7 @@ def main():
         from pdf_table_amd.synth_weights import picodet_state_dict
         from pdf_table_amd.weights import pack_picodet
         ysd = picodet_state_dict(seed=4, num_classes=5) if rank == 0 or world == 1 else None
-        if world > 1:
+        if use_dist:
             from pdf_table_amd.dist_utils import broadcast_blob
             eng.load_weights_device(L.PT_MODEL_PICODET, broadcast_blob(pack_picodet(ysd, 5, x3=False) if rank == 0 else None, dev))
         else:
@@ -229,7 +233,7 @@ def main():
         from pdf_table_amd.weights import pack_lore_dla34, pack_lore_processor
         lsd = lore_dla34_state_dict(seed=2) if rank == 0 or world == 1 else None
         psd = lore_processor_state_dict(seed=3) if rank == 0 or world == 1 else None
-        if world > 1:
+        if use_dist:
             from pdf_table_amd.dist_utils import broadcast_blob
             eng.load_weights_device(L.PT_MODEL_LORE_DLA34, broadcast_blob(pack_lore_dla34(lsd, x3=False) if rank == 0 else None, dev))
             eng.load_weights_device(L.PT_MODEL_LORE_PROCESSOR,
@@ -246,7 +250,7 @@ def main():
         from pdf_table_amd.weights import pack_pplcnet
         for slot, (seed, ncls) in enumerate(((5, 2), (6, 4))):
             csd_ = pplcnet_state_dict(seed, ncls) if rank == 0 or world == 1 else None
-            if world > 1:
+            if use_dist:
                 from pdf_table_amd.dist_utils import broadcast_blob
                 eng.load_weights_device(L.PT_MODEL_PPLCNET + slot, broadcast_blob(pack_pplcnet(csd_, x3=False) if rank == 0 else None, dev))
             else:
