@@ -399,8 +399,22 @@ __global__ __launch_bounds__(256, 1) void lstm_dir_kernel(const bf16_t* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) c[h][r] = 0.f;
   __syncthreads();
+  // h_t goes to HBM from its LDS copy at the top of the NEXT step: 16-byte row pieces (4 per thread) instead of 32
+  // two-byte stores per lane from the MFMA layout; the copy is stable until this step's cell update (after the barrier)
+  auto flush_h = [&](int tt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256, m = idx >> 5, j = idx & 31;
+      const int line = line0 + m;
+      if (line >= B) continue;
+      bf16_t* hp = hout + ((size_t)line * T + tt) * hcs + dir * 256 + j * 8;
+      *reinterpret_cast<u32x4*>(hp) = *reinterpret_cast<const u32x4*>(&hbuf[0][m][j * 8]);
+      if (SPLIT) *reinterpret_cast<u32x4*>(hp + 512) = *reinterpret_cast<const u32x4*>(&hbuf[NP - 1][m][j * 8]);
+    }
+  };
   for (int s = 0; s < T; ++s) {
     const int t = dir ? T - 1 - s : s;
+    if (s > 0 && PT_LSTM_ABL != 4) flush_h(dir ? t + 1 : t - 1);
     // input-projection terms of this step: gx is laid out [line][t][dir][unit][gate] (gate fastest, set up by the
     // weight packer), so the four gates of a (line, unit) are one 8-byte load; issued before the MFMA phase
     u32x2 gxv[2][16], gxl[2][16];
@@ -500,24 +514,320 @@ __global__ __launch_bounds__(256, 1) void lstm_dir_kernel(const bf16_t* __restri
           lb = rf2bf(hn - rbf2f(hb));
           hbuf[NP - 1][m][unit] = (bf16_t)lb;
         }
-        if (line < B && PT_LSTM_ABL != 4) {
-          bf16_t* hp = hout + ((size_t)line * T + t) * hcs + dir * 256 + unit;
-          hp[0] = (bf16_t)hb;
-          if (SPLIT) hp[512] = (bf16_t)lb;
-        }
+        (void)line;
       }
     }
     __syncthreads();
+  }
+  if (T > 0 && PT_LSTM_ABL != 4) flush_h(dir ? 0 : T - 1);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bf16 fast path of the LSTM: the same step as lstm_dir_kernel<0>, but the gate pre-activations gx of step s + 1 are
+// pre-fetched into LDS (global_load_lds, 64 KB per step, two buffers) while step s runs.  In the register version every
+// workgroup of the chip asks HBM for its 128 scattered 256-byte gx rows at the same moment of every step and -- vector
+// loads return in order -- the first W_hh burst cannot be consumed before they have arrived (7.8 us of a 25 us step by
+// ablation).  Here the DMA of step s + 1 is issued right after the mid-step barrier of step s, has the cell update and
+// the four W_hh bursts of the next step to land, and is awaited (vmcnt(0), already satisfied) at the next mid-step
+// barrier.  Barriers are raw s_barrier + lgkmcnt(0): a __syncthreads() fence would wait for the DMA in flight.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void lstm_dir_dma_kernel(const bf16_t* __restrict__ gx, const bf16_t* __restrict__ whh,
+                                                               bf16_t* __restrict__ hout, int B, int T) {
+  constexpr int HROW = 264;
+  extern __shared__ __attribute__((aligned(16))) char lsm[];
+  bf16_t (*hbuf)[HROW] = reinterpret_cast<bf16_t (*)[HROW]>(lsm);                     // [32][HROW]
+  char* gxs = lsm + 32 * HROW * 2;                                                    // [2][32 lines][2048 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, q = lane >> 5;
+  const int line0 = blockIdx.x * 32, dir = blockIdx.y;
+  constexpr int gcs = 2048, hcs = 512;
+  const bf16_t* whh_d = whh + (size_t)dir * 1024 * 256;
+  for (int i = tid; i < 32 * HROW; i += 256) (&hbuf[0][0])[i] = 0;
+  float c[2][16];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[h][r] = 0.f;
+  // DMA of one step: 64 wave-instructions of 1 KB (line m = ii >> 1, half ii & 1), 16 per wave
+  auto issue_gx = [&](int tt, int buf) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int ii = wave * 16 + k, m = ii >> 1, part = ii & 1;
+      const int line = line0 + m;
+      const int lc = line < B ? line : B - 1;
+      const bf16_t* src = gx + ((size_t)lc * T + tt) * gcs + dir * 1024 + part * 512 + lane * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(gxs + buf * 65536 + m * 2048 + part * 1024), 16, 0, 0);
+    }
+  };
+  auto flush_h = [&](int tt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256, m = idx >> 5, j = idx & 31;
+      const int line = line0 + m;
+      if (line >= B) continue;
+      *reinterpret_cast<u32x4*>(hout + ((size_t)line * T + tt) * hcs + dir * 256 + j * 8) =
+          *reinterpret_cast<const u32x4*>(&hbuf[m][j * 8]);
+    }
+  };
+  if (T > 0) issue_gx(dir ? T - 1 : 0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? T - 1 - s : s;
+    if (s > 0) flush_h(dir ? t + 1 : t - 1);
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][h][r] = 0.f;
+#pragma unroll 1
+    for (int half = 0; half < 4; ++half) {
+      bf16x8 bq[4][4][2];
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            bq[kq][g][h] = *reinterpret_cast<const bf16x8*>(
+                whh_d + (size_t)(((((wave * 4 + half) * 4 + kq) * 4 + g) * 2 + h) * 64 + lane) * 8);
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(&hbuf[lx][(half * 4 + kq) * 16 + q * 8]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            acc[g][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[kq][g][h], acc[g][h], 0, 0, 0);
+      }
+    }
+    // every wave has finished reading h_{t-1}; this step's gx (issued one step ago) has landed
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (s + 1 < T) issue_gx(dir ? t - 1 : t + 1, (s + 1) & 1);
+    const char* gcur = gxs + (s & 1) * 65536;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int unit = wave * 64 + h * 32 + lx;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * q;
+        const u32x2 gv = *reinterpret_cast<const u32x2*>(gcur + m * 2048 + unit * 8);
+        const float gi = acc[0][h][r] + rbf2f(gv.x & 0xFFFFu);
+        const float gf = acc[1][h][r] + rbf2f(gv.x >> 16);
+        const float gg = acc[2][h][r] + rbf2f(gv.y & 0xFFFFu);
+        const float go = acc[3][h][r] + rbf2f(gv.y >> 16);
+        const float si = fast_sigmoid(gi), sf = fast_sigmoid(gf), so = fast_sigmoid(go);
+        const float cn = sf * c[h][r] + si * fast_tanh(gg);
+        c[h][r] = cn;
+        hbuf[m][unit] = (bf16_t)rf2bf(so * fast_tanh(cn));
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  if (T > 0) flush_h(dir ? 0 : T - 1);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Weight-stationary LSTM (bf16 mode).  lstm_dir_kernel streams the 512 KB W_hh of a direction from L2 in every one of
+// the T steps and every workgroup (128 MB per step over the chip: the step is bound by that traffic).
+// Here four workgroups ("members") share a block of 128 lines; member j keeps the W_hh columns of hidden units
+// [64 j, 64 j + 64) -- 128 KB, already contiguous in the packer's fragment order -- in LDS for the whole sequence,
+// computes those units' gates and cell update for all 128 lines, and publishes its quarter of h_t (bf16, in MFMA
+// A-fragment order) to an L2-resident exchange buffer; the members meet once per step on four step counters.
+//   * exchange: agent-scope relaxed atomic 8-byte stores / loads (global_* sc1: L1 bypassed, coherent across XCDs), the
+//     writer drains its stores (vmcnt(0)), barriers, then one lane bumps the member's counter; readers poll the four
+//     counters (one lane each), barrier, then load the fragments.  Two parities: a member can only be one step ahead.
+//   * wave w: 32-unit half h = w & 1, line tiles 2 (w >> 1) and 2 (w >> 1) + 1: a W fragment read from LDS feeds two MFMAs.
+//   * all workgroups of a launch must be co-resident (1 per CU, 144 KB of LDS): the launcher issues at most
+//     num_cu / 8 clusters per direction per launch; a member that waits > 2^22 polls gives up (sets *err) instead of hanging.
+// ---------------------------------------------------------------------------------------------------
+constexpr int CLL = 128;      // lines per cluster
+
+__global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(const bf16_t* __restrict__ gx, const bf16_t* __restrict__ whh,
+                                                               bf16_t* __restrict__ hout, int B, int T, int ncl,
+                                                               bf16_t* __restrict__ hx, int* __restrict__ flags,
+                                                               int* __restrict__ err) {
+  extern __shared__ __attribute__((aligned(16))) char lsm[];
+  char* wl = lsm;                                              // [16 ks][4 g][2 h][64 lanes][16 B] = 128 KB
+  constexpr int SROW = 72;                                     // 64 + 8 bf16: 144-byte rows
+  bf16_t* stage = reinterpret_cast<bf16_t*>(lsm + 131072);     // [128][SROW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, q = lane >> 5;
+  const int L = blockIdx.x, dir = blockIdx.y;
+  const int member = (L >> 3) & 3, cl = (L >> 5) * 8 + (L & 7);   // the 4 members of a cluster: ids b, b+8, b+16, b+24
+  if (cl >= ncl) return;
+  const int line0 = cl * CLL;
+  const int h = wave & 1, mp = wave >> 1;
+  {   // W slice of this member: one contiguous 128 KB block of the fragment-ordered tensor
+    const u32x4* src = reinterpret_cast<const u32x4*>(whh + (size_t)dir * 1024 * 256 + (size_t)member * 65536);
+    for (int i = tid; i < 8192; i += 256) reinterpret_cast<u32x4*>(wl)[i] = src[i];
+  }
+  unsigned long long* hxc = reinterpret_cast<unsigned long long*>(hx + (size_t)(dir * ncl + cl) * 2 * (CLL * 256));
+  int* fl = flags + (dir * ncl + cl) * 4;
+  float c[2][16];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[mi][r] = 0.f;
+  bool dead = false;
+  __syncthreads();
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? T - 1 - s : s;
+    // gate inputs of this step (independent of the other members): 8 bytes per (line, unit)
+    u32x2 gv[2][16];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (2 * mp + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
+        const int line = line0 + m;
+        const int lc = line < B ? line : B - 1;
+        gv[mi][r] = *reinterpret_cast<const u32x2*>(gx + ((size_t)lc * T + t) * 2048 + dir * 1024 + (member * 64 + h * 32 + lx) * 4);
+      }
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][g][r] = 0.f;
+    if (s > 0) {
+      if (tid < 4 && !dead) {
+        int spins = 0;
+        while (__hip_atomic_load(fl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < s) {
+          if (++spins > (1 << 22)) { dead = true; __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __syncthreads();
+      const unsigned long long* hp = hxc + (size_t)((s - 1) & 1) * (CLL * 256 / 4);
+      // A fragments of both line tiles, all 16 k-steps (2 x 16 x 16 B per lane), then the MFMAs
+      unsigned long long af[2][16][2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const unsigned long long* pp = hp + ((size_t)((2 * mp + mi) * 16 + ks) * 64 + lane) * 2;
+          af[mi][ks][0] = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          af[mi][ks][1] = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        bf16x8 a[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const unsigned long long two[2] = {af[mi][ks][0], af[mi][ks][1]};
+          a[mi] = __builtin_bit_cast(bf16x8, two);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const bf16x8 b = *reinterpret_cast<const bf16x8*>(wl + ((ks * 4 + g) * 2 + h) * 1024 + lane * 16);
+          acc[0][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b, acc[0][g], 0, 0, 0);
+          acc[1][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b, acc[1][g], 0, 0, 0);
+        }
+      }
+    }
+    // cell update (lane-local), h to the staging tile
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (2 * mp + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
+        const float gi = acc[mi][0][r] + rbf2f(gv[mi][r].x & 0xFFFFu);
+        const float gf = acc[mi][1][r] + rbf2f(gv[mi][r].x >> 16);
+        const float gg = acc[mi][2][r] + rbf2f(gv[mi][r].y & 0xFFFFu);
+        const float go = acc[mi][3][r] + rbf2f(gv[mi][r].y >> 16);
+        const float si = fast_sigmoid(gi), sf = fast_sigmoid(gf), so = fast_sigmoid(go);
+        const float cn = sf * c[mi][r] + si * fast_tanh(gg);
+        c[mi][r] = cn;
+        stage[m * SROW + h * 32 + lx] = (bf16_t)rf2bf(so * fast_tanh(cn));
+      }
+    __syncthreads();
+    // publish: 128 lines x 8 pieces of 16 B; piece i of line m = units 64 member + 8 i .. + 8
+    unsigned long long* hw = hxc + (size_t)(s & 1) * (CLL * 256 / 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256, m = idx >> 3, pc = idx & 7;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(stage + m * SROW + pc * 8);
+      const int ks = 4 * member + (pc >> 1), qq = pc & 1;
+      unsigned long long* dp = hw + ((size_t)((m >> 5) * 16 + ks) * 64 + qq * 32 + (m & 31)) * 2;
+      __hip_atomic_store(dp, (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dp + 1, (unsigned long long)v.z | ((unsigned long long)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int line = line0 + m;
+      if (line < B) *reinterpret_cast<u32x4*>(hout + ((size_t)line * T + t) * 512 + dir * 256 + member * 64 + pc * 8) = v;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(fl + member, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
 int pt_launch_lstm(const bf16_t* gx, const bf16_t* whh, bf16_t* hout, int B, int T, int split, hipStream_t s) {
   if (B <= 0) return PT_OK;
   dim3 grid((B + 31) / 32, 2);
-  if (split)
+  static int use_dma = -1;       // PT_LSTM_DMA=0: the register-staged kernel also in bf16 mode (A/B switch)
+  if (use_dma < 0) {
+    const char* ev = getenv("PT_LSTM_DMA");
+    use_dma = ev ? atoi(ev) : 0;      // measured 3.97 vs 3.89 ms: no gain (the step is bound by L2 traffic, not by gx latency)
+  }
+  static int use_cluster = -1;   // PT_LSTM_CLUSTER=0: the streaming kernel (A/B switch)
+  if (use_cluster < 0) {
+    const char* ev = getenv("PT_LSTM_CLUSTER");
+    use_cluster = ev ? atoi(ev) : 1;
+  }
+  if (!split && use_cluster) {
+    constexpr int SMEM = 131072 + CLL * 72 * 2;
+    static bool attr_done = false;
+    static void* scratch = nullptr;          // exchange buffers + step counters (one device per process)
+    static int* h_err = nullptr;             // pinned, device-visible: set by a member that gave up waiting for its peers
+    static int max_cl = 0;
+    if (!attr_done) {
+      PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_cluster_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+      int dev = 0, ncu = 0;
+      PT_HIP_CHECK(hipGetDevice(&dev));
+      PT_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+      max_cl = ncu / 8;                      // clusters per direction per launch: 2 dirs x 4 members x max_cl <= num_cu
+      if (max_cl < 1) max_cl = 1;
+      PT_HIP_CHECK(hipMalloc(&scratch, (size_t)2 * max_cl * 2 * CLL * 256 * sizeof(bf16_t) + (size_t)2 * max_cl * 4 * sizeof(int) + 256));
+      PT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_err), sizeof(int), hipHostMallocMapped));
+      *h_err = 0;
+      attr_done = true;
+    }
+    if (*h_err) {      // an EARLIER launch timed out (its output was wrong): fail loudly now and stop using the kernel
+      use_cluster = 0;
+      pt_set_error("lstm_cluster_kernel: a workgroup waited > 2^22 polls for its peers -- the launch was not co-resident "
+                   "(GPU shared with another process or stream?).  Results of that call are invalid; set PT_LSTM_CLUSTER=0");
+      return PT_ERR_HIP;
+    }
+    bf16_t* hx = reinterpret_cast<bf16_t*>(scratch);
+    int* flags = reinterpret_cast<int*>(reinterpret_cast<char*>(scratch) + (size_t)2 * max_cl * 2 * CLL * 256 * sizeof(bf16_t));
+    int* err = nullptr;
+    PT_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&err), h_err, 0));
+    for (int b0 = 0; b0 < B; b0 += max_cl * CLL) {
+      const int nb = (B - b0) < max_cl * CLL ? (B - b0) : max_cl * CLL;
+      const int ncl = (nb + CLL - 1) / CLL;
+      PT_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)(2 * max_cl * 4) * sizeof(int), s));
+      hipLaunchKernelGGL(lstm_cluster_kernel, dim3(((ncl + 7) / 8) * 32, 2), dim3(256), SMEM, s, gx + (size_t)b0 * T * 2048, whh,
+                         hout + (size_t)b0 * T * 512, nb, T, ncl, hx, flags, err);
+    }
+  } else if (split) {
     hipLaunchKernelGGL(lstm_dir_kernel<1>, grid, dim3(256), 0, s, gx, whh, hout, B, T);
-  else
+  } else if (use_dma) {
+    constexpr int SMEM = 32 * 264 * 2 + 2 * 65536;
+    static bool attr_done = false;
+    if (!attr_done) {
+      PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_dir_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(lstm_dir_dma_kernel, grid, dim3(256), SMEM, s, gx, whh, hout, B, T);
+  } else {
     hipLaunchKernelGGL(lstm_dir_kernel<0>, grid, dim3(256), 0, s, gx, whh, hout, B, T);
+  }
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
