@@ -194,6 +194,10 @@ int pt_launch_crnn_conv0_pool(const bf16_t* in, int n, int H, int W, const float
 int pt_launch_maxpool_kxk(const bf16_t* in, int n, int H, int W, int C, int kh, int kw, int h2c, int split, bf16_t* out,
                           hipStream_t s);
 int pt_launch_lstm(const bf16_t* gx, const bf16_t* whh, bf16_t* hout, int B, int T, int split, hipStream_t s);
+int pt_launch_gemm_argmax(const bf16_t* A, long long M, int K, const bf16_t* W, const float* bias, int N, int* ids, float* maxv,
+                          hipStream_t s);
+int pt_launch_gemm_rows(const bf16_t* A, long long M, int K, const bf16_t* W, const float* bias, int N, bf16_t* out, int relu,
+                        hipStream_t s);
 int pt_launch_argmax_reduce(const float* part, long long rows, int ntiles, int* ids, float* maxv, hipStream_t s);
 int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, float* maxlogit, hipStream_t s);
 

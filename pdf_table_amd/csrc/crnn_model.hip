@@ -116,6 +116,19 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
     c.stride = 1; c.out = out; c.out_cstride = N * m; c.relu = relu; c.split = x3; c.out_lo_off = N;
     return c;
   };
+  // [rows, K] x [N, K]^T GEMMs of the sequence head: streaming kernel in bf16 mode (PT_CLS_FUSED=0 or hi/lo mode: 1x1 conv kernel)
+  static int fused = -1;
+  if (fused < 0) {
+    const char* ev = getenv("PT_CLS_FUSED");
+    fused = ev ? atoi(ev) : 1;
+  }
+  auto rows_gemm = [&](const bf16_t* in, int cin, const ConvW& cw, int N, bf16_t* out, int relu, const char* label) -> int {
+    if (!x3 && fused && (cin == 512 || cin == 256)) {
+      PtProfScope ps(e, s, PT_PROF_CONV1X1, 2.0 * n * T * (double)cin * N, label);
+      return pt_launch_gemm_rows(in, (long long)n * T, cin, W(cw.w), Bv(cw.b), N, out, relu, s);
+    }
+    return pt_launch_conv(e, conv(in, 1, n, T, cin, cw, N, 1, out, relu), s);
+  };
   {
     PtProfScope ps(e, s, PT_PROF_OTHER, 0, "crnn conv0+pool");
     RUN(pt_launch_crnn_conv0_pool(gray, n, PT_REC_H, PT_REC_W, Bv(c0w), Bv(c0b), x3, bf.a0, s));
@@ -130,24 +143,29 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
   RUN(pt_launch_maxpool_kxk(bf.c3b, n, 4, 160, 512, 2, 1, /*h2c=*/1, x3, bf.p3, s));
   // from here on: [1, n, 160, C] views
   RUN(pt_launch_conv(e, conv(bf.p3, 1, n, T, 1024, c4, 512, 1, bf.f, 1), s));
-  RUN(pt_launch_conv(e, conv(bf.f, 1, n, T, 512, xp1, 2048, 1, bf.gx, 0), s));
+  RUN(rows_gemm(bf.f, 512, xp1, 2048, bf.gx, 0, "rows gemm 512->2048"));
   {
     PtProfScope ps(e, s, PT_PROF_OTHER, 0, "lstm1");
     RUN(pt_launch_lstm(bf.gx, W(whh1), bf.h, n, T, x3, s));
   }
-  RUN(pt_launch_conv(e, conv(bf.h, 1, n, T, 512, em1, 256, 1, bf.e1, 0), s));
-  RUN(pt_launch_conv(e, conv(bf.e1, 1, n, T, 256, xp2, 2048, 1, bf.gx, 0), s));
+  RUN(rows_gemm(bf.h, 512, em1, 256, bf.e1, 0, "rows gemm 512->256"));
+  RUN(rows_gemm(bf.e1, 256, xp2, 2048, bf.gx, 0, "rows gemm 256->2048"));
   {
     PtProfScope ps(e, s, PT_PROF_OTHER, 0, "lstm2");
     RUN(pt_launch_lstm(bf.gx, W(whh2), bf.h, n, T, x3, s));
   }
-  RUN(pt_launch_conv(e, conv(bf.h, 1, n, T, 512, em2, 512, 1, bf.e2, 0), s));
-  {
-    ConvDesc c = conv(bf.e2, 1, n, T, 512, cls, 7680, 1, nullptr, 0);
-    c.argmax_part = bf.part;
-    RUN(pt_launch_conv(e, c, s));
-  }
-  {
+  RUN(rows_gemm(bf.h, 512, em2, 512, bf.e2, 0, "rows gemm 512->512"));
+  // classifier + arg-max: fused kernel in bf16 mode (PT_CLS_FUSED=0: tiled GEMM with per-tile partials + reduce, which is
+  // also the hi/lo path)
+  if (!x3 && fused) {
+    PtProfScope ps(e, s, PT_PROF_CONV1X1, 2.0 * n * T * 512.0 * 7680.0, "classifier gemm+argmax");
+    RUN(pt_launch_gemm_argmax(bf.e2, (long long)n * T, 512, W(cls.w), Bv(cls.b), 7680, ids, maxlogit, s));
+  } else {
+    {
+      ConvDesc c = conv(bf.e2, 1, n, T, 512, cls, 7680, 1, nullptr, 0);
+      c.argmax_part = bf.part;
+      RUN(pt_launch_conv(e, c, s));
+    }
     PtProfScope ps(e, s, PT_PROF_OTHER, 0, "argmax");
     RUN(pt_launch_argmax_reduce(bf.part, (long long)n * T, NT, ids, maxlogit, s));
   }

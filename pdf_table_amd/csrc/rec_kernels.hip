@@ -851,6 +851,142 @@ __global__ __launch_bounds__(256) void argmax_reduce_kernel(const float2* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Classifier GEMM with the arg-max inside (bf16 mode): ids[row] = argmax_n (A[row, :] . W[n, :] + bias[n]).
+// The implicit-GEMM 1x1 kernel runs this layer (M = lines x 160, K = 512, N = 7680) at ~500 TFLOP/s: with four MFMAs per
+// K-slice and barrier it is bound by its own hand-over, and a third of every (128 x 64) tile goes to an fp32-through-LDS
+// epilogue that only feeds a compare.  Here the roles are turned around:
+//   * a wave keeps its 32 rows of A (all of K) in registers for the whole kernel: 32 k-steps x 16 B per lane;
+//   * W streams through LDS in 64-class stages (64 KB, next stage pre-fetched to registers, rows pitched K*2 + 16 bytes);
+//   * the MFMA runs with W as the A operand, so D is [class][row]: a lane owns ONE row and its 16 accumulators are 16
+//     classes in increasing order -- the running (max, index) is a compare/select per accumulator in the lane, no LDS,
+//     no partials; the two lanes that share a row meet once at the end (lane ^ 32).
+// Ties keep the lowest class index (torch.argmax); sums are the same MFMA sequence over K as the conv kernel's.
+// ---------------------------------------------------------------------------------------------------
+// MODE 1: the same streaming GEMM with a store epilogue instead (out bf16 [M][N] = A . W^T + bias, optional ReLU): a lane
+// writes its row's classes as 8-byte runs of four (the LSTM input projections and embeddings of the CRNN head).
+template <int KSTEPS, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __restrict__ A, long long M,
+                                                             const bf16_t* __restrict__ W, const float* __restrict__ bias,
+                                                             int N, int* __restrict__ ids, float* __restrict__ maxv,
+                                                             bf16_t* __restrict__ out, int relu) {
+  constexpr int K = KSTEPS * 16, NCH = K / 32, P = K * 2 + 16;     // P: LDS row pitch in bytes (odd number of 16-B slots)
+  constexpr int NPF = 64 * K * 2 / 16 / 256;                        // 16-byte pieces per thread per stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sw = smem;                                                  // [64 classes][P]
+  float* sb = reinterpret_cast<float*>(smem + 64 * P);              // [64] bias of the stage
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, q = lane >> 5;
+  const long long row = ((long long)blockIdx.x * 4 + wave) * 32 + lx;
+  const long long rc = row < M ? row : M - 1;
+  bf16x8 areg[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) areg[ks] = *reinterpret_cast<const bf16x8*>(A + rc * K + ks * 16 + q * 8);
+  u32x4 pf[NPF];
+  float pb = 0.f;
+  auto prefetch = [&](int t) {
+    const bf16_t* wt = W + (size_t)t * NCH * (64 * 32);
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) pf[j] = *reinterpret_cast<const u32x4*>(wt + (size_t)(tid + j * 256) * 8);
+    if (tid < 64) pb = bias[t * 64 + tid];
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+      const int idx = tid + j * 256, c = idx >> 8, r = (idx & 255) >> 2, part = idx & 3;    // chunk, class row, 16-B part
+      *reinterpret_cast<u32x4*>(sw + r * P + c * 64 + part * 16) = pf[j];
+    }
+    if (tid < 64) sb[tid] = pb;
+  };
+  float bv = -INFINITY;
+  int bi = 0;
+  const int NT = N / 64;
+  prefetch(0);
+  for (int t = 0; t < NT; ++t) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (t + 1 < NT) prefetch(t + 1);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const char* wr = sw + (half * 32 + lx) * P + q * 16;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wr + ks * 32);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, areg[ks], acc, 0, 0, 0);
+      }
+      if (MODE == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
+          const float v = acc[r] + sb[cl];
+          if (v > bv) { bv = v; bi = t * 64 + cl; }
+        }
+      } else if (row < M) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int cl = half * 32 + rg * 8 + 4 * q;
+          uint32_t hb[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float v = acc[rg * 4 + k] + sb[cl + k];
+            if (relu) v = fmaxf(v, 0.f);
+            hb[k] = rf2bf(v);
+          }
+          *reinterpret_cast<u32x2*>(out + row * N + t * 64 + cl) = u32x2{hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
+        }
+      }
+    }
+  }
+  if (MODE != 0) return;
+  const float ov = __shfl_xor(bv, 32);
+  const int oi = __shfl_xor(bi, 32);
+  if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  if (q == 0 && row < M) {
+    ids[row] = bi;
+    if (maxv) maxv[row] = bv;
+  }
+}
+
+// A: bf16 [M][K] row-major, W: conv-tiled [N/64][K/32][64][32], bias fp32 [N]; K == 512 only (returns PT_ERR_INVALID otherwise
+// so that the caller can fall back to the tiled kernel + reduce)
+int pt_launch_gemm_argmax(const bf16_t* A, long long M, int K, const bf16_t* W, const float* bias, int N, int* ids, float* maxv,
+                          hipStream_t s) {
+  if (K != 512 || N % 64 != 0 || M <= 0) return PT_ERR_INVALID;
+  constexpr int SMEM = 64 * (512 * 2 + 16) + 64 * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_argmax_kernel<32, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_argmax_kernel<32, 0>), dim3((unsigned)((M + 127) / 128)), dim3(256), SMEM, s, A, M, W, bias, N, ids, maxv,
+                     nullptr, 0);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// out bf16 [M][N] = A [M][K] . W^T + bias (+ ReLU); K in {256, 512}; PT_ERR_INVALID otherwise (caller falls back)
+int pt_launch_gemm_rows(const bf16_t* A, long long M, int K, const bf16_t* W, const float* bias, int N, bf16_t* out, int relu,
+                        hipStream_t s) {
+  if ((K != 512 && K != 256) || N % 64 != 0 || M <= 0) return PT_ERR_INVALID;
+  const int smem = 64 * (K * 2 + 16) + 64 * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_argmax_kernel<32, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (512 * 2 + 16) + 256));
+    attr_done = true;
+  }
+  const dim3 grid((unsigned)((M + 127) / 128));
+  if (K == 512)
+    hipLaunchKernelGGL((gemm_argmax_kernel<32, 1>), grid, dim3(256), smem, s, A, M, W, bias, N, nullptr, nullptr, out, relu);
+  else
+    hipLaunchKernelGGL((gemm_argmax_kernel<16, 1>), grid, dim3(256), smem, s, A, M, W, bias, N, nullptr, nullptr, out, relu);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
 int pt_launch_argmax_reduce(const float* part, long long rows, int ntiles, int* ids, float* maxv, hipStream_t s) {
   if (rows <= 0) return PT_OK;
   int blocks = (int)((rows + 255) / 256);
