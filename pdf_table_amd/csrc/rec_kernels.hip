@@ -782,22 +782,32 @@ int pt_launch_lstm(const bf16_t* gx, const bf16_t* whh, bf16_t* hout, int B, int
   }
   if (!split && use_cluster) {
     constexpr int SMEM = 131072 + CLL * 72 * 2;
+    struct ClusterState {        // per device: exchange buffers + step counters, pinned error word, clusters per launch
+      void* scratch = nullptr;
+      int* h_err = nullptr;      // pinned, device-visible: set by a member that gave up waiting for its peers
+      int max_cl = 0;
+    };
+    static ClusterState states[32];
     static bool attr_done = false;
-    static void* scratch = nullptr;          // exchange buffers + step counters (one device per process)
-    static int* h_err = nullptr;             // pinned, device-visible: set by a member that gave up waiting for its peers
-    static int max_cl = 0;
+    int dev = 0;
+    PT_HIP_CHECK(hipGetDevice(&dev));
+    PT_REQUIRE(dev >= 0 && dev < 32, "lstm: device index %d out of range", dev);
+    ClusterState& st = states[dev];
     if (!attr_done) {
       PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_cluster_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-      int dev = 0, ncu = 0;
-      PT_HIP_CHECK(hipGetDevice(&dev));
-      PT_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-      max_cl = ncu / 8;                      // clusters per direction per launch: 2 dirs x 4 members x max_cl <= num_cu
-      if (max_cl < 1) max_cl = 1;
-      PT_HIP_CHECK(hipMalloc(&scratch, (size_t)2 * max_cl * 2 * CLL * 256 * sizeof(bf16_t) + (size_t)2 * max_cl * 4 * sizeof(int) + 256));
-      PT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_err), sizeof(int), hipHostMallocMapped));
-      *h_err = 0;
       attr_done = true;
     }
+    if (!st.scratch) {
+      int ncu = 0;
+      PT_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+      st.max_cl = ncu / 8 < 1 ? 1 : ncu / 8;     // clusters per direction per launch: 2 dirs x 4 members x max_cl <= num_cu
+      PT_HIP_CHECK(hipMalloc(&st.scratch, (size_t)2 * st.max_cl * 2 * CLL * 256 * sizeof(bf16_t) + (size_t)2 * st.max_cl * 4 * sizeof(int) + 256));
+      PT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&st.h_err), sizeof(int), hipHostMallocMapped));
+      *st.h_err = 0;
+    }
+    void* scratch = st.scratch;
+    int* h_err = st.h_err;
+    const int max_cl = st.max_cl;
     if (*h_err) {      // an EARLIER launch timed out (its output was wrong): fail loudly now and stop using the kernel
       use_cluster = 0;
       pt_set_error("lstm_cluster_kernel: a workgroup waited > 2^22 polls for its peers -- the launch was not co-resident "
