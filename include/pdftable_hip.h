@@ -248,6 +248,14 @@ int pt_tsr_decode(pt_engine* e, const float* d_hm, const float* d_st, const floa
                   const float* d_cr, const float* d_reg, int n, int h, int w, int wiz_rev, float vis_thresh,
                   int32_t* d_counts, float* d_dets, float* d_logi, pt_stream stream);
 
+/* pt_tsr_forward_net + pt_tsr_decode in one call for the DLA-34 detector (PT_MODEL_LORE_DLA34), same outputs as
+ * pt_tsr_decode.  The decode reads the two 256-channel head maps `ax` and `cr` only at the kept cells' centres and corner
+ * pixels (lineless_table_process.py:254-263, _get_4ps_feat :39-63), so here those two heads run on 3x3-pixel patches
+ * around exactly these positions instead of on the whole map; every value that is read is produced by the same kernels
+ * in the same order as in the dense map (results are bit-identical to the two-call path). */
+int pt_tsr_forward_decode(pt_engine* e, const uint16_t* d_input_bf16, int n, int in_h, int in_w, int wiz_rev,
+                          float vis_thresh, int32_t* d_counts, float* d_dets, float* d_logi, pt_stream stream);
+
 /* Logical-location processor (LoreProcessModel.forward, lore/lore_processor.py:465-514, evaluation branch) for the
  * cells of n_tables tables at once.
  *   d_logi, d_dets : as written by pt_tsr_decode;  h_counts : HOST int32 [n_tables] = its d_counts copied back

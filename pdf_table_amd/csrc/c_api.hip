@@ -334,6 +334,14 @@ int pt_tsr_decode(pt_engine* e, const float* d_hm, const float* d_st, const floa
                         reinterpret_cast<hipStream_t>(stream));
 }
 
+int pt_tsr_forward_decode(pt_engine* e, const uint16_t* d_input_bf16, int n, int in_h, int in_w, int wiz_rev, float vis_thresh,
+                          int32_t* d_counts, float* d_dets, float* d_logi, pt_stream stream) {
+  PT_REQUIRE(e && d_input_bf16 && n > 0, "pt_tsr_forward_decode: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  return pt_lore_forward_decode(e, d_input_bf16, n, in_h, in_w, wiz_rev, vis_thresh, d_counts, d_dets, d_logi,
+                                reinterpret_cast<hipStream_t>(stream));
+}
+
 int pt_tsr_process(pt_engine* e, const float* d_logi, const float* d_dets, const int32_t* h_counts, int n_tables,
                    int use_2dpe, float* d_logic, float* d_stacked, pt_stream stream) {
   PT_REQUIRE(e, "pt_tsr_process: bad arguments");

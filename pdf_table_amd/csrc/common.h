@@ -131,6 +131,7 @@ struct ConvDesc {
   int res_mode = 0;  // 0 none, 1 same resolution, 2 half resolution (fused nearest x2 upsample + add)
   int relu = 0;      // activation: 0 none, 1 ReLU, 2 hardswish, 3 PReLU(slope)
   const float* slope = nullptr;   // device pointer to the PReLU slope (relu == 3)
+  const int* ylimit = nullptr;    // device int: output rows >= *ylimit are not computed (whole tiles; v1 kernel only)
   // bf16x3 precision mode: in/res/out hold (hi | lo) channel groups; w is [N/64][3*Cin/32][taps][64][32]
   int split = 0;
   int out_lo_off = 0;  // channel distance between the hi and lo halves in the output buffer
@@ -212,6 +213,16 @@ int pt_launch_pico_candidates(const float* head, int B, int A, int ncls, int lev
 int pt_lore_decode(pt_engine* e, const float* hm, const float* st, const float* wh, const float* ax, const float* cr,
                    const float* reg, int B, int H, int W, int wiz_rev, float vis_thresh, int* d_counts, float* d_dets,
                    float* d_logi, hipStream_t s);
+void pt_lore_mosaic_rows(int B, int* rows_ax, int* rows_cr);
+int pt_lore_decode_front(pt_engine* e, const float* hm, const float* st, const float* wh, const float* reg, int B, int H, int W,
+                         int wiz_rev, float vis_thresh, int* d_counts, const int** d_lim_ax, const int** d_lim_cr,
+                         hipStream_t s);
+int pt_lore_patch_gather(pt_engine* e, const bf16_t* feat, int B, int H, int W, int C, int split, bf16_t* mos_ax, bf16_t* mos_cr,
+                         hipStream_t s);
+int pt_lore_decode_sparse(pt_engine* e, const float* ax_mos, const float* cr_mos, int B, int H, int W, float vis_thresh,
+                          int* d_counts, float* d_dets, float* d_logi, hipStream_t s);
+int pt_lore_forward_decode(pt_engine* e, const bf16_t* x, int n, int H, int W, int wiz_rev, float vis_thresh, int* d_counts,
+                           float* d_dets, float* d_logi, hipStream_t s);
 int pt_lore_wireless_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* hm, float* st, float* wh,
                                  float* ax, float* cr, float* reg, hipStream_t s);
 int pt_lore_process(pt_engine* e, const float* d_logi, const float* d_dets, const int32_t* h_counts, int n_tables,

@@ -60,6 +60,7 @@ struct ConvK {
   int n_group;            // > 0: column tiles are walked in groups of n_group so that a group's weights stay in one XCD's L2
   int gemm_nt;            // gemm1x1_kernel: number of 128-wide column tiles (n_tiles stays N / 64 for the arg-max partials)
   const float* slope;     // relu == 3: PReLU, slope[0] = the (single, layer-wide) negative slope, read on the device
+  const int* ylimit;      // device int: tiles whose first output row is >= *ylimit do nothing (data-dependent extents)
   long long m_flat;       // > 0: the (Ho x 32) geometry is a flat list of m_flat pixels (gemm1x1_kernel); rows beyond it are skipped
 };
 
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
   const int tyi = L % p.tiles_y;
   const int b = L / p.tiles_y;
   const int oy0 = tyi * C::TH, ox0 = txi * C::TW;
+  if (p.ylimit && oy0 >= *p.ylimit) return;        // uniform over the workgroup, before any barrier
   const int iy0 = oy0 * STRIDE - (KS / 2), ix0 = ox0 * STRIDE - (KS / 2);
   const int nchunks = p.split ? 3 * (p.Cin >> 5) : (p.Cin >> 5);
   const int in_cs = p.split ? 2 * p.Cin : p.Cin;   // channels per input pixel in memory
@@ -1330,7 +1332,7 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   k.Ho = (d.H + 2 * pad - d.ks) / d.stride + 1;
   k.Wo = (d.W + 2 * pad - d.ks) / d.stride + 1;
   k.out_cstride = d.out_cstride; k.out_coff = d.out_coff; k.rep = d.rep; k.shuffle_cout = d.shuffle_cout;
-  k.res_mode = d.res ? d.res_mode : 0; k.relu = d.relu; k.slope = d.slope;
+  k.res_mode = d.res ? d.res_mode : 0; k.relu = d.relu; k.slope = d.slope; k.ylimit = d.ylimit;
   PT_REQUIRE(d.relu != 3 || d.slope, "conv: PReLU needs the slope tensor");
   k.split = d.split; k.out_lo_off = d.out_lo_off;
   k.head_w = d.head_w; k.head_b = d.head_b; k.head_prob = d.head_prob; k.head_logits = d.head_logits;
@@ -1338,7 +1340,7 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   if (d.head_w) PT_REQUIRE(d.shuffle_cout == 64 && d.head_b && (d.head_prob || d.head_logits), "conv: bad fused-head configuration");
   if (k.res_mode == 2) PT_REQUIRE(k.Ho % 2 == 0 && k.Wo % 2 == 0, "conv: half-res residual needs even output size");
   const double flop = 2.0 * k.B * k.Ho * k.Wo * (double)k.N * d.Cin * d.ks * d.ks;  // algorithmic (not x3 in split mode)
-  if (d.ks == 3 && d.stride == 1 && !d.head_w && !d.argmax_part && !d.n_valid && !d.out_f32 && !d.res_f32 && d.relu < 2 && use_dma_kernel()) {
+  if (d.ks == 3 && d.stride == 1 && !d.head_w && !d.argmax_part && !d.n_valid && !d.out_f32 && !d.res_f32 && d.relu < 2 && !d.ylimit && use_dma_kernel()) {
     // steady-state A/B on MI355X (tools/ab3.sh, round 1): the 16-channel-slice DMA kernel (v3) wins on >= 120-row maps
     // with K >= 128 channels, the 32-channel-slice DMA kernel (v2) on 60..119-row maps, the register-staged kernel
     // (v1) on short-K layers and on small maps, where the big DMA tiles leave CUs idle
@@ -1366,7 +1368,7 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
     if (g < 1) g = ng_env == 0 ? 0 : 1;
     k.n_group = g;
   }
-  if (d.ks == 1 && d.stride == 1 && gemm_variant() && d.Cin % 64 == 0 && d.N % 128 == 0 && d.rep == 1 && !d.shuffle_cout &&
+  if (d.ks == 1 && d.stride == 1 && gemm_variant() && !d.ylimit && d.Cin % 64 == 0 && d.N % 128 == 0 && d.rep == 1 && !d.shuffle_cout &&
       !d.head_w && k.res_mode != 2 && (long long)k.B * k.Ho * k.Wo >= 16384)
     return launch_gemm1x1(e, k, s, flop);
   if (d.ks == 1 && d.stride == 1) return launch_cfg<1, 1>(e, k, s, flop);

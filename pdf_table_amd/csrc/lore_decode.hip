@@ -220,6 +220,69 @@ __global__ __launch_bounds__(256) void lore_rekey_kernel(const float* __restrict
   keys[(size_t)b * stride + k] = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)k);
 }
 
+constexpr int MOS_PW = 256;        // patches per mosaic row (mosaic width = 3 * MOS_PW pixels)
+__device__ __forceinline__ size_t mosaic_centre(long long j) {
+  return (size_t)(3 * (j / MOS_PW) + 1) * (3 * MOS_PW) + 3 * (j % MOS_PW) + 1;
+}
+
+// exclusive prefix of the kept cell counts over the tables + the two row limits of the mosaics (one thread: B <= 64)
+// base[b] = sum_{b' < b} ncell[b'];  lim[0] / lim[1] = pixel rows of the ax / cr mosaic that hold patches
+__global__ void lore_sparse_base_kernel(const int* __restrict__ counts, int B, int* __restrict__ base, int* __restrict__ lim) {
+  if (threadIdx.x || blockIdx.x) return;
+  long long t = 0;
+  for (int b = 0; b < B; ++b) {
+    base[b] = (int)t;
+    t += counts[2 * b];
+  }
+  lim[0] = (int)(3 * ((t + MOS_PW - 1) / MOS_PW));
+  lim[1] = (int)(3 * ((4 * t + MOS_PW - 1) / MOS_PW));
+}
+
+// The 3x3 neighbourhoods (zero outside the map) of the five feature-map positions lore_gather_kernel reads for output
+// row p of table b -- the cell's centre for `ax`, its four corner pixels for `cr` -- copied into the two patch mosaics.
+// feat: bf16 [B,H,W,C] ([hi | lo] halves when split).  One workgroup per (p, b), 16-byte pieces.
+__global__ __launch_bounds__(256) void lore_patch_gather_kernel(const float* __restrict__ rev, const float* __restrict__ boxes,
+                                                                const unsigned long long* __restrict__ order,
+                                                                const int* __restrict__ counts, int stride, int H, int W,
+                                                                const bf16_t* __restrict__ feat, int C, int split,
+                                                                const int* __restrict__ sp_base, bf16_t* __restrict__ mos_ax,
+                                                                bf16_t* __restrict__ mos_cr) {
+  const int b = blockIdx.y, p = blockIdx.x;
+  const int ncell = counts[2 * b];
+  if (p >= ncell) return;
+  const int r = order ? (int)(0xFFFFFFFFu - (unsigned)(order[(size_t)b * stride + p] & 0xFFFFFFFFull)) : p;
+  const float* cellbox = boxes + ((size_t)(2 * b) * stride) * 12;
+  const float* here = rev ? rev + ((size_t)b * stride + p) * 12 : cellbox + (size_t)p * 12;
+  __shared__ int pos[5];
+  if (threadIdx.x < 5) {
+    const int m = (int)threadIdx.x - 1;
+    long long cc;
+    if (m < 0) {
+      cc = __float_as_int(cellbox[(size_t)r * 12 + 11]);
+    } else {
+      const float f = here[2 * m] + (float)W * rintf(here[2 * m + 1]);
+      cc = (long long)rintf(f);
+      if (!(cc < (long long)H * W)) cc = 0;
+      if (cc < 0) cc = 0;
+    }
+    pos[threadIdx.x] = (int)cc;
+  }
+  __syncthreads();
+  const int cs = split ? 2 * C : C, ppx = cs / 8;          // 16-byte pieces per pixel
+  const long long j = sp_base[b] + p;
+  for (int i = threadIdx.x; i < 5 * 9 * ppx; i += 256) {
+    const int piece = i % ppx, tap = (i / ppx) % 9, k = i / (9 * ppx);
+    const int y = pos[k] / W + tap / 3 - 1, x = pos[k] % W + tap % 3 - 1;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+      v = *reinterpret_cast<const uint4*>(feat + (((size_t)b * H + y) * W + x) * cs + piece * 8);
+    const long long pj = k == 0 ? j : 4 * j + (k - 1);
+    bf16_t* dst = (k == 0 ? mos_ax : mos_cr) +
+                  ((size_t)(3 * (pj / MOS_PW) + tap / 3) * (3 * MOS_PW) + 3 * (pj % MOS_PW) + tap % 3) * cs + piece * 8;
+    *reinterpret_cast<uint4*>(dst) = v;
+  }
+}
+
 // one workgroup per output row p of table b.  order[p] (or p itself when there was no snap pass) is the pre-sort rank
 // whose box / score / centre go to row p; the corner features use the box that sat at rank p BEFORE the re-sort.
 __global__ __launch_bounds__(256) void lore_gather_kernel(const float* __restrict__ rev, const float* __restrict__ boxes,
@@ -227,7 +290,8 @@ __global__ __launch_bounds__(256) void lore_gather_kernel(const float* __restric
                                                            const int* __restrict__ counts, int stride, int H, int W,
                                                            const float* __restrict__ ax, const float* __restrict__ cr,
                                                            float vis_thresh, float* __restrict__ dets,
-                                                           float* __restrict__ logi, int* __restrict__ n_valid) {
+                                                           float* __restrict__ logi, int* __restrict__ n_valid,
+                                                           const int* __restrict__ sp_base) {
   const int b = blockIdx.y, p = blockIdx.x, c = threadIdx.x;
   const int ncell = counts[2 * b];
   if (p >= ncell) return;
@@ -240,6 +304,17 @@ __global__ __launch_bounds__(256) void lore_gather_kernel(const float* __restric
   if (c == 8) {
     dets[((size_t)b * K_CELLS + p) * 9 + 8] = score;
     if (score >= vis_thresh) atomicAdd(&n_valid[b], 1);
+  }
+  if (sp_base) {
+    // sparse heads: ax / cr hold the head outputs of 3x3-pixel patches in a mosaic, 256 patches per mosaic row; the value
+    // of patch j is its centre pixel (mosaic_centre); patch (sp_base[b] + p) of ax, 4 (sp_base[b] + p) + m of cr
+    const long long j = sp_base[b] + p;
+    float v = ax[mosaic_centre(j) * 256 + c];
+    float crs = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) crs += cr[mosaic_centre(4 * j + m) * 256 + c];
+    logi[((size_t)b * K_CELLS + p) * 256 + c] = v + crs;
+    return;
   }
   const int centre = __float_as_int(cellbox[(size_t)r * 12 + 11]);
   const size_t fb = (size_t)b * H * W;
@@ -260,11 +335,16 @@ __global__ __launch_bounds__(256) void lore_gather_kernel(const float* __restric
 }  // namespace
 
 // Scratch layout (engine-owned): sig f32 [B*H*W*2] | counts int [4B] | keys u64 [2B*CAP] | sorted u64 [2B*CAP] |
-// boxes f32 [2B*CAP*12] | rev f32 [B*CAP*12] | keys2/sorted2 u64 [B*CAP] each
-int pt_lore_decode(pt_engine* e, const float* hm, const float* st, const float* wh, const float* ax, const float* cr,
-                   const float* reg, int B, int H, int W, int wiz_rev, float vis_thresh, int* d_counts, float* d_dets,
-                   float* d_logi, hipStream_t s) {
-  PT_REQUIRE(hm && st && wh && ax && cr && reg && d_counts && d_dets && d_logi && B > 0, "tsr decode: null pointer");
+// boxes f32 [2B*CAP*12] | rev f32 [B*CAP*12] | keys2/sorted2 u64 [B*CAP] each | sparse base int [B] + limits int [2]
+struct DecodeState {
+  int* cnt;
+  float *boxes, *rev;
+  unsigned long long* sorted2;
+  int *sp_base, *sp_lim;
+};
+
+static int decode_front(pt_engine* e, const float* hm, const float* st, const float* wh, const float* reg, int B, int H, int W,
+                        int wiz_rev, float vis_thresh, int* d_counts, DecodeState* ds, hipStream_t s) {
   PT_REQUIRE((long long)H * W < (1ll << 31), "tsr decode: map too large");
   const size_t npix = (size_t)B * H * W;
   size_t off = 0;
@@ -272,7 +352,7 @@ int pt_lore_decode(pt_engine* e, const float* hm, const float* st, const float* 
   const size_t o_sig = carve(npix * 2 * 4), o_cnt = carve((size_t)B * 5 * 4), o_keys = carve((size_t)2 * B * CAP * 8),
                o_sorted = carve((size_t)2 * B * CAP * 8), o_boxes = carve((size_t)2 * B * CAP * 12 * 4),
                o_rev = carve((size_t)B * CAP * 12 * 4), o_keys2 = carve((size_t)B * CAP * 8),
-               o_sorted2 = carve((size_t)B * CAP * 8);
+               o_sorted2 = carve((size_t)B * CAP * 8), o_sp = carve((size_t)(B + 2) * 4);
   if (off > e->tsr_scratch_cap) {
     PT_HIP_CHECK(hipDeviceSynchronize());
     if (e->tsr_scratch) PT_HIP_CHECK(hipFree(e->tsr_scratch));
@@ -295,7 +375,6 @@ int pt_lore_decode(pt_engine* e, const float* hm, const float* st, const float* 
                                      hipFuncAttributeMaxDynamicSharedMemorySize, CAP * 8));
     attr_done = true;
   }
-  PtProfScope ps(e, s, PT_PROF_OTHER, 0, "tsr decode");
   PT_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)B * 5 * 4, s));
   PT_HIP_CHECK(hipMemsetAsync(d_counts, 0, (size_t)B * 4, s));
   hipLaunchKernelGGL(lore_sigmoid_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, hm, sig, (long long)npix);
@@ -314,8 +393,71 @@ int pt_lore_decode(pt_engine* e, const float* hm, const float* st, const float* 
     hipLaunchKernelGGL(lore_sort_kernel, dim3(B), dim3(1024), CAP * 8, s, keys2, cnt + 2 * B, 2, CAP, K_CELLS, K_CELLS,
                        sorted2, CAP, cnt + 4 * B);
   }
-  hipLaunchKernelGGL(lore_gather_kernel, dim3(K_CELLS, B), dim3(256), 0, s, wiz_rev ? rev : nullptr, boxes,
-                     wiz_rev ? sorted2 : nullptr, cnt + 2 * B, CAP, H, W, ax, cr, vis_thresh, d_dets, d_logi, d_counts);
+  PT_HIP_CHECK(hipGetLastError());
+  ds->cnt = cnt; ds->boxes = boxes; ds->rev = wiz_rev ? rev : nullptr; ds->sorted2 = wiz_rev ? sorted2 : nullptr;
+  ds->sp_base = reinterpret_cast<int*>(base + o_sp); ds->sp_lim = ds->sp_base + B;
+  return PT_OK;
+}
+
+int pt_lore_decode(pt_engine* e, const float* hm, const float* st, const float* wh, const float* ax, const float* cr,
+                   const float* reg, int B, int H, int W, int wiz_rev, float vis_thresh, int* d_counts, float* d_dets,
+                   float* d_logi, hipStream_t s) {
+  PT_REQUIRE(hm && st && wh && ax && cr && reg && d_counts && d_dets && d_logi && B > 0, "tsr decode: null pointer");
+  PtProfScope ps(e, s, PT_PROF_OTHER, 0, "tsr decode");
+  DecodeState ds;
+  int rc = decode_front(e, hm, st, wh, reg, B, H, W, wiz_rev, vis_thresh, d_counts, &ds, s);
+  if (rc != PT_OK) return rc;
+  hipLaunchKernelGGL(lore_gather_kernel, dim3(K_CELLS, B), dim3(256), 0, s, ds.rev, ds.boxes, ds.sorted2, ds.cnt + 2 * B, CAP, H,
+                     W, ax, cr, vis_thresh, d_dets, d_logi, d_counts, (const int*)nullptr);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// ---- sparse `ax` / `cr` heads: the decode only ever reads those two 256-channel maps at the kept cells' centres and
+// corner pixels (<= 5 x 3000 positions of 65 536 per table), so the fused forward+decode evaluates the two heads on
+// 3x3-pixel patches around exactly those positions instead of on the whole map.  Three steps around the head launches:
+//   pt_lore_decode_front   everything up to the final cell order + the patch mosaics' row limits
+//   pt_lore_patch_gather   feature-map neighbourhoods -> mosaics [3 * rows][768][C]
+//   pt_lore_decode_sparse  dets + logic features from the head outputs on the mosaics
+// A patch's centre pixel sees only its own 3x3 pixels, through the same conv kernels in the same order as in the dense
+// map: the features are bit-identical to pt_lore_decode's (tests/test_gpu_tsr.py).
+void pt_lore_mosaic_rows(int B, int* rows_ax, int* rows_cr) {
+  *rows_ax = 3 * (((long long)B * K_CELLS + MOS_PW - 1) / MOS_PW);
+  *rows_cr = 3 * (((long long)B * K_CELLS * 4 + MOS_PW - 1) / MOS_PW);
+}
+
+static DecodeState g_ds;        // state of the front half, consumed by the two calls that follow it on the same stream
+
+int pt_lore_decode_front(pt_engine* e, const float* hm, const float* st, const float* wh, const float* reg, int B, int H, int W,
+                         int wiz_rev, float vis_thresh, int* d_counts, const int** d_lim_ax, const int** d_lim_cr,
+                         hipStream_t s) {
+  PT_REQUIRE(hm && st && wh && reg && d_counts && B > 0, "tsr decode front: null pointer");
+  PtProfScope ps(e, s, PT_PROF_OTHER, 0, "tsr decode");
+  int rc = decode_front(e, hm, st, wh, reg, B, H, W, wiz_rev, vis_thresh, d_counts, &g_ds, s);
+  if (rc != PT_OK) return rc;
+  hipLaunchKernelGGL(lore_sparse_base_kernel, dim3(1), dim3(1), 0, s, g_ds.cnt + 2 * B, B, g_ds.sp_base, g_ds.sp_lim);
+  PT_HIP_CHECK(hipGetLastError());
+  *d_lim_ax = g_ds.sp_lim;
+  *d_lim_cr = g_ds.sp_lim + 1;
+  return PT_OK;
+}
+
+int pt_lore_patch_gather(pt_engine* e, const bf16_t* feat, int B, int H, int W, int C, int split, bf16_t* mos_ax, bf16_t* mos_cr,
+                         hipStream_t s) {
+  PT_REQUIRE(feat && mos_ax && mos_cr && C % 8 == 0, "tsr patch gather: bad arguments");
+  PtProfScope ps(e, s, PT_PROF_OTHER, 0, "tsr patch gather");
+  hipLaunchKernelGGL(lore_patch_gather_kernel, dim3(K_CELLS, B), dim3(256), 0, s, g_ds.rev, g_ds.boxes, g_ds.sorted2,
+                     g_ds.cnt + 2 * B, CAP, H, W, feat, C, split, g_ds.sp_base, mos_ax, mos_cr);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_lore_decode_sparse(pt_engine* e, const float* ax_mos, const float* cr_mos, int B, int H, int W, float vis_thresh,
+                          int* d_counts, float* d_dets, float* d_logi, hipStream_t s) {
+  PT_REQUIRE(ax_mos && cr_mos && d_counts && d_dets && d_logi, "tsr decode sparse: null pointer");
+  PtProfScope ps(e, s, PT_PROF_OTHER, 0, "tsr decode");
+  hipLaunchKernelGGL(lore_gather_kernel, dim3(K_CELLS, B), dim3(256), 0, s, g_ds.rev, g_ds.boxes, g_ds.sorted2, g_ds.cnt + 2 * B,
+                     CAP, H, W, ax_mos, cr_mos, vis_thresh, d_dets, d_logi, d_counts, (const int*)g_ds.sp_base);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }

@@ -43,6 +43,7 @@ struct Ctx {
   int rc;
   bf16_t* cols = nullptr;   // shared DCN column scratch (largest site)
   float* om = nullptr;      // shared offset/mask scratch, fp32 [pixel][32]
+  const int* ylimit = nullptr;   // when set: convs skip output tiles at rows >= *ylimit (sparse-head mosaics)
 
   T alloc(int H, int W, int C) {
     T t;
@@ -68,7 +69,7 @@ struct Ctx {
     ConvDesc c;
     c.in = in.p; c.B = n; c.H = in.H; c.W = in.W; c.Cin = cin_override ? cin_override : in.C;
     c.w = reinterpret_cast<const bf16_t*>(w->d_ptr); c.bias = reinterpret_cast<const float*>(b->d_ptr);
-    c.N = N; c.ks = ks; c.stride = stride; c.relu = relu; c.split = x3; c.n_valid = nv;
+    c.N = N; c.ks = ks; c.stride = stride; c.relu = relu; c.split = x3; c.n_valid = nv; c.ylimit = ylimit;
     if (out_f32) {
       c.out_f32 = out_f32; c.out_cstride = f32_cs;
     } else {
@@ -167,10 +168,17 @@ struct Ctx {
 
 // x: NHWC4 bf16 [n, H, W, 4] ([hi rgb0 | lo rgb0] in BF16X3 mode); heads: fp32 NHWC at H/4 x W/4 with channel
 // strides 8 (hm: 2 valid), 8 (st), 8 (wh), 256 (ax), 256 (cr), 8 (reg: 2 valid)
-int pt_lore_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* hm, float* st, float* wh, float* ax,
-                        float* cr, float* reg, hipStream_t s) {
+struct SparseArgs {      // fused forward + decode: the ax / cr heads run on patch mosaics around the decoded positions
+  int wiz_rev;
+  float vis_thresh;
+  int* d_counts;
+  float *d_dets, *d_logi;
+};
+
+static int lore_dla_run(pt_engine* e, const bf16_t* x, int n, int H, int W, float* hm, float* st, float* wh, float* ax,
+                        float* cr, float* reg, const SparseArgs* sp, hipStream_t s) {
   PT_REQUIRE(H % 32 == 0 && W % 32 == 0 && H > 0 && W > 0, "Lore net: input %dx%d must be multiples of 32", H, W);
-  PT_REQUIRE(x && hm && st && wh && ax && cr && reg && n > 0, "Lore net: null pointer");
+  PT_REQUIRE(x && n > 0 && (sp || (hm && st && wh && ax && cr && reg)), "Lore net: null pointer");
   auto it = e->models.find(PT_MODEL_LORE_DLA34);
   if (it == e->models.end()) {
     pt_set_error("Lore DLA-34 weights not loaded (pt_weights_load(PT_MODEL_LORE_DLA34))");
@@ -239,9 +247,56 @@ int pt_lore_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, floa
     c.ida("ida_up", y, 0, 3, 64, f24);
     const T feat = y[2];
     T hid = c.alloc(feat.H, feat.W, 256);
+    if (sp) {      // the four small head maps live in the arena; ax / cr are not computed densely
+      for (int h = 0; h < 6; ++h)
+        if (h != 3 && h != 4) {
+          heads[h] = reinterpret_cast<float*>(e->arena.take((size_t)n * feat.H * feat.W * 8 * sizeof(float)));
+          if (!heads[h]) c.ok = false;
+        }
+    }
     for (int h = 0; h < 6; ++h) {
+      if (sp && (h == 3 || h == 4)) continue;
       c.conv(feat, std::string(hname[h]) + ".0", 256, 3, 1, hid, 1);
       c.conv(hid, std::string(hname[h]) + ".2", hcs[h] < 64 ? 64 : hcs[h], 1, 1, T(), 0, nullptr, hcs[h], heads[h], hcs[h]);
+    }
+    if (sp) {
+      // decode up to the final cell order, copy the 3x3 neighbourhoods of the positions it will read into two mosaics,
+      // run the ax / cr heads on the mosaics (tiles beyond the data-dependent row limit exit), finish the decode
+      int rows_ax = 0, rows_cr = 0;
+      pt_lore_mosaic_rows(n, &rows_ax, &rows_cr);
+      const int MW = 768;
+      auto take = [&](size_t bytes) { void* p_ = e->arena.take(bytes); if (!p_) c.ok = false; return p_; };
+      T max_, mcr_, mhid;
+      max_.H = rows_ax; max_.W = MW; max_.C = 64;
+      mcr_.H = rows_cr; mcr_.W = MW; mcr_.C = 64;
+      mhid.H = rows_cr; mhid.W = MW; mhid.C = 256;
+      max_.p = reinterpret_cast<bf16_t*>(take((size_t)rows_ax * MW * 64 * c.mul * sizeof(bf16_t)));
+      mcr_.p = reinterpret_cast<bf16_t*>(take((size_t)rows_cr * MW * 64 * c.mul * sizeof(bf16_t)));
+      mhid.p = reinterpret_cast<bf16_t*>(take((size_t)rows_cr * MW * 256 * c.mul * sizeof(bf16_t)));
+      float* oax = reinterpret_cast<float*>(take((size_t)rows_ax * MW * 256 * sizeof(float)));
+      float* ocr = reinterpret_cast<float*>(take((size_t)rows_cr * MW * 256 * sizeof(float)));
+      if (c.rc == PT_OK && !c.dry && c.ok) {
+        const int *lim_ax = nullptr, *lim_cr = nullptr;
+        int r = pt_lore_decode_front(e, heads[0], heads[1], heads[2], heads[5], n, feat.H, feat.W, sp->wiz_rev, sp->vis_thresh,
+                                     sp->d_counts, &lim_ax, &lim_cr, s);
+        if (r == PT_OK) r = pt_lore_patch_gather(e, feat.p, n, feat.H, feat.W, 64, c.x3, max_.p, mcr_.p, s);
+        if (r != PT_OK) return r;
+        const int keep = c.n;
+        c.n = 1;
+        T hax = mhid;
+        hax.H = rows_ax;
+        c.ylimit = lim_ax;
+        c.conv(max_, "ax.0", 256, 3, 1, hax, 1);
+        c.conv(hax, "ax.2", 256, 1, 1, T(), 0, nullptr, 256, oax, 256);
+        c.ylimit = lim_cr;
+        c.conv(mcr_, "cr.0", 256, 3, 1, mhid, 1);
+        c.conv(mhid, "cr.2", 256, 1, 1, T(), 0, nullptr, 256, ocr, 256);
+        c.ylimit = nullptr;
+        c.n = keep;
+        if (c.rc != PT_OK) return c.rc;
+        r = pt_lore_decode_sparse(e, oax, ocr, n, feat.H, feat.W, sp->vis_thresh, sp->d_counts, sp->d_dets, sp->d_logi, s);
+        if (r != PT_OK) return r;
+      }
     }
     if (c.rc != PT_OK) return c.rc;
     if (pass == 0) {
@@ -263,6 +318,20 @@ int pt_lore_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, floa
   return PT_OK;
 }
 
+
+int pt_lore_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* hm, float* st, float* wh, float* ax,
+                        float* cr, float* reg, hipStream_t s) {
+  PT_REQUIRE(hm && st && wh && ax && cr && reg, "Lore net: null pointer");
+  return lore_dla_run(e, x, n, H, W, hm, st, wh, ax, cr, reg, nullptr, s);
+}
+
+// DLA-34 forward and decode in one call with sparse ax / cr heads (see lore_decode.hip); outputs as pt_lore_decode
+int pt_lore_forward_decode(pt_engine* e, const bf16_t* x, int n, int H, int W, int wiz_rev, float vis_thresh, int* d_counts,
+                           float* d_dets, float* d_logi, hipStream_t s) {
+  PT_REQUIRE(d_counts && d_dets && d_logi, "Lore forward+decode: null pointer");
+  SparseArgs sp{wiz_rev, vis_thresh, d_counts, d_dets, d_logi};
+  return lore_dla_run(e, x, n, H, W, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &sp, s);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 'wireless' detector: LoreDetectModel.forward (lore/lore_detector.py:353-389) -- ResNet-18-style backbone whose every

@@ -8,6 +8,8 @@ and, after the device decode, maps the cell quads back to source pixels and roun
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -157,6 +159,7 @@ class TsrStage:
         self.bgr = bgr
         self.with_html = with_html      # also emit 'structure_str_list' (show_results :292-303)
         self._copy_stream = None
+        self.fused_decode = os.environ.get("PT_TSR_FUSED", "1") != "0"     # pt_tsr_forward_decode vs the two-call path
 
     def tables(self, page_shape: Tuple[int, int], boxes_per_page: Sequence[np.ndarray]):
         """integer table boxes [k,4] (x1,y1,x2,y2) per page, cropped like crop_image_by_box
@@ -187,8 +190,11 @@ class TsrStage:
         for i in range(0, len(tables), self.micro_batch):
             tb = tables[i:i + self.micro_batch]
             x = self.eng.tsr_preprocess(pages, tb, inp_h, inp_w, bgr=self.bgr)
-            heads = self.eng.tsr_forward_net(x, wireless=cfg.backbone == "ResNet-18")
-            counts, dets, logi = self.eng.tsr_decode(heads, wiz_rev=cfg.wiz_rev, vis_thresh=cfg.vis_thresh, sync=False)
+            if cfg.backbone != "ResNet-18" and self.fused_decode:      # one call, ax / cr heads only where the decode reads them
+                counts, dets, logi = self.eng.tsr_forward_decode(x, wiz_rev=cfg.wiz_rev, vis_thresh=cfg.vis_thresh, sync=False)
+            else:
+                heads = self.eng.tsr_forward_net(x, wireless=cfg.backbone == "ResNet-18")
+                counts, dets, logi = self.eng.tsr_decode(heads, wiz_rev=cfg.wiz_rev, vis_thresh=cfg.vis_thresh, sync=False)
             pending.append((i, len(tb), counts, dets, logi))
         return pending
 

@@ -351,3 +351,44 @@ def test_lore_wireless_net_matches_reference_golden_and_bf16(eng, golden_dir):
         ref = lore_net.lore_wireless_forward(sd, x)
     got = eng.tsr_forward_net(_x4(x).cuda(), wireless=True)
     assert _cmp(got, ref, "lore wireless bf16") <= 0.1
+
+
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("wiz_rev", [True, False])
+def test_forward_decode_fused_is_bit_identical(mode, wiz_rev):
+    """pt_tsr_forward_decode (ax / cr heads evaluated only on 3x3 patches around the positions the decode reads) gives
+    exactly the outputs of pt_tsr_forward_net + pt_tsr_decode: counts, boxes, scores and the 256 logic features"""
+    from pdf_table_amd.engine import HipEngine
+    from pdf_table_amd.synth_weights import lore_dla34_state_dict
+    from pdf_table_amd.weights import pack_lore_dla34
+    eng = HipEngine(0)
+    try:
+        # head biases near the thresholds: hundreds of cells and corners per table on noise input
+        eng.load_weights(L.PT_MODEL_LORE_DLA34, pack_lore_dla34(lore_dla34_state_dict(seed=2, hm_bias=(-1.2, -0.6))))
+        eng.set_precision(L.PT_PRECISION_BF16X3 if mode == "bf16x3" else L.PT_PRECISION_BF16)
+        g = torch.Generator().manual_seed(77)
+        n, H, W = 3, 256, 320
+        x = torch.randn(n, H, W, 3, generator=g) * 0.7
+        x4 = torch.zeros(n, H, W, 8 if mode == "bf16x3" else 4)
+        hi = x.to(torch.bfloat16).float()
+        x4[..., :3] = hi
+        if mode == "bf16x3":
+            x4[..., 4:7] = (x - hi).to(torch.bfloat16).float()
+        xd = x4.to(torch.bfloat16).cuda()
+        heads = eng.tsr_forward_net(xd)
+        c0, d0, l0 = eng.tsr_decode(heads, wiz_rev=wiz_rev, vis_thresh=0.2, sync=True)
+        d0, l0 = d0.cpu(), l0.cpu()
+        c1, d1, l1 = eng.tsr_forward_decode(xd, wiz_rev=wiz_rev, vis_thresh=0.2, sync=True)
+        print("fused decode: cells above vis_thresh per table", c0.tolist())
+        assert np.array_equal(c0, c1) and c0.sum() > 0, (c0, c1)
+        # rows beyond a table's count are unspecified in both paths
+        for b in range(n):
+            k = int(c0[b])
+            kk = int(max(k, 1))
+            assert torch.equal(d0[b, :kk], d1.cpu()[b, :kk])
+        # all kept cells (not only those above vis_thresh) carry features: compare where both wrote
+        ncell = [int((d0[b, :, 8] > 0).sum()) for b in range(n)]
+        for b in range(n):
+            assert torch.equal(l0[b, :int(c0[b])], l1.cpu()[b, :int(c0[b])]), b
+    finally:
+        eng.close()
