@@ -241,7 +241,7 @@ def main():
         else:
             eng.load_weights(L.PT_MODEL_LORE_DLA34, pack_lore_dla34(lsd, x3=False))
             eng.load_weights(L.PT_MODEL_LORE_PROCESSOR, pack_lore_processor(psd, x3=False))
-        tsr = TsrStage(eng, LoreConfig(task_type="wtw"), micro_batch=int(os.environ.get("PT_TSR_MICROBATCH", "32")))
+        tsr = TsrStage(eng, LoreConfig(task_type="wtw"), micro_batch=int(os.environ.get("PT_TSR_MICROBATCH", "80")))
 
     cls_line = cls_page = None
     if "cls" in stages:      # SURVEY 8f-1 (not part of BASELINE.json's metric; opt-in): PP-LCNet text-line + page orientation
