@@ -1139,6 +1139,94 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_kernel(ConvK p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Thin stride-1 stem (DLA-34 base_layer: 3 -> 16 channels at full resolution, bf16 mode).  conv_stem7x7_kernel<1,1> spends
+// most of its time around the MFMAs: every 8x32-pixel workgroup re-loads the 29 KB weight image from L2 (3.7 GB per
+// 32 tables) and sends 256 x 64 fp32 through LDS to store 16 channels.  Here a workgroup walks STEM_NT tiles of a row
+// strip with the 32 computed weight rows staged once, and the epilogue is done from the accumulators: lane = channel,
+// registers = 16 pixels, bias + ReLU, 2-byte stores (the 16 lanes of a pixel write its 32 contiguous bytes).
+// ---------------------------------------------------------------------------------------------------
+constexpr int STEM_NT = 8;
+
+__global__ __launch_bounds__(256, 2) void conv_stem7x7_thin_kernel(ConvK p) {
+  using C = StemCfg<1>;
+  __shared__ __attribute__((aligned(16))) char s_in[C::IN_BYTES];
+  __shared__ __attribute__((aligned(16))) char s_w[32 * C::WROW];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, q = lane >> 5;
+  const int strips_x = (p.tiles_x + STEM_NT - 1) / STEM_NT;
+  int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int sxi = L % strips_x;
+  L /= strips_x;
+  const int tyi = L % p.tiles_y;
+  const int b = L / p.tiles_y;
+  const int oy0 = tyi * C::TH, iy0 = oy0 - 3;
+  const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * 4;
+  for (int idx = tid; idx < 32 * 28; idx += 256) {        // weight rows 0..31 (channels >= n_valid are zero rows)
+    const int row = idx / 28, part = idx - row * 28;
+    *reinterpret_cast<u32x4*>(s_w + row * C::WROW + part * 16) = *reinterpret_cast<const u32x4*>(p.w + (size_t)idx * 8);
+  }
+  const float bv = lx < p.n_valid ? p.bias[lx] : 0.f;
+  const char* a_base = s_in + ((wave * 2) * C::TWIN + lx + 2 * q) * 8;
+  const char* b_base = s_w + lx * C::WROW + q * 16;
+  for (int it = 0; it < STEM_NT; ++it) {
+    const int txi = sxi * STEM_NT + it;
+    if (txi >= p.tiles_x) break;
+    const int ox0 = txi * C::TW, ix0 = ox0 - 3;
+    __syncthreads();                                      // previous tile's fragments have been read
+#pragma unroll
+    for (int j = 0; j < C::NI; ++j) {
+      const int idx = tid + j * 256;
+      if (idx < C::NP_IN) {
+        const int iy = idx / C::HP, ip = idx - iy * C::HP;
+        const int gy = iy0 + iy, gx = ix0 + 2 * ip;
+        u32x2 v0 = {0u, 0u}, v1 = {0u, 0u};
+        if ((unsigned)gy < (unsigned)p.H) {
+          const bf16_t* rowp = in_b + (size_t)gy * p.W * 4;
+          if ((unsigned)gx < (unsigned)p.W) v0 = *reinterpret_cast<const u32x2*>(rowp + (size_t)gx * 4);
+          if ((unsigned)(gx + 1) < (unsigned)p.W) v1 = *reinterpret_cast<const u32x2*>(rowp + (size_t)(gx + 1) * 4);
+        }
+        u32x4 v = {v0.x, v0.y, v1.x, v1.y};
+        *reinterpret_cast<u32x4*>(s_in + (iy * C::TWIN + 2 * ip) * 8) = v;
+      }
+    }
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(b_base + (r * 2 + h) * 32);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const char* ap = a_base + ((m + r) * C::TWIN + 4 * h) * 8;
+          const u32x2 lo = *reinterpret_cast<const u32x2*>(ap), hi = *reinterpret_cast<const u32x2*>(ap + 8);
+          const u32x4 av = {lo.x, lo.y, hi.x, hi.y};
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), b0, acc[m], 0, 0, 0);
+        }
+      }
+    }
+    if (lx < p.n_valid) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int oy = oy0 + wave * 2 + m;
+        if (oy >= p.Ho) continue;
+        bf16_t* orow = p.out + ((size_t)b * p.Ho + oy) * p.Wo * p.out_cstride + lx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * q;
+          if (ox < p.Wo) orow[(size_t)ox * p.out_cstride] = (bf16_t)f32_to_bf16(fmaxf(acc[m][r] + bv, 0.f));
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // PT_REG_EPI=1 opts the plain layers into the register epilogue.  Measured on MI355X (four-stage bench, round 1): no gain --
 // 3x3 class 470.9 -> 473.1 ms, 1x1 class 244.3 -> 251.1 ms, det-only 3917 -> 3779 pages/s: the 8-byte channel-run stores
 // (32 partial lines per wave instruction) cost what the fp32 LDS round trip saved.  Default: LDS epilogue (16-byte stores).
@@ -1407,5 +1495,19 @@ int pt_launch_stem7x7(pt_engine* e, const bf16_t* in, int B, int H, int W, const
   k.out_cstride = split ? 2 * nv : nv; k.out_coff = 0; k.rep = 1; k.shuffle_cout = 0; k.res_mode = 0; k.relu = 1;
   k.split = split; k.out_lo_off = nv; k.n_valid = n_valid;
   if (stride == 2) return launch_stem<2, 2>(e, k, s);
+  static int thin = -1;          // PT_STEM_THIN=0: the general kernel for the thin stride-1 stem too (A/B switch)
+  if (thin < 0) {
+    const char* ev = getenv("PT_STEM_THIN");
+    thin = ev ? atoi(ev) : 1;
+  }
+  if (thin && !split && n_valid && n_valid <= 32) {
+    k.tiles_x = (k.Wo + 31) / 32; k.tiles_y = (k.Ho + 7) / 8; k.n_tiles = 1;
+    const long long nblk = (long long)k.B * ((k.tiles_x + STEM_NT - 1) / STEM_NT) * k.tiles_y;
+    PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "stem grid out of range");
+    PtProfScope prof(e, s, PT_PROF_STEM, 2.0 * k.B * k.Ho * k.Wo * 64.0 * 147.0, "stem7x7 s1 thin");
+    hipLaunchKernelGGL(conv_stem7x7_thin_kernel, dim3((unsigned)nblk), dim3(256), 0, s, k);
+    PT_HIP_CHECK(hipGetLastError());
+    return PT_OK;
+  }
   return (n_valid && n_valid <= 32) ? launch_stem<1, 1>(e, k, s) : launch_stem<1, 2>(e, k, s);
 }
