@@ -60,6 +60,7 @@ struct ConvK {
   int n_group;            // > 0: column tiles are walked in groups of n_group so that a group's weights stay in one XCD's L2
   int gemm_nt;            // gemm1x1_kernel: number of 128-wide column tiles (n_tiles stays N / 64 for the arg-max partials)
   const float* slope;     // relu == 3: PReLU, slope[0] = the (single, layer-wide) negative slope, read on the device
+  int reps, total_tiles;  // reps > 1: a workgroup walks reps consecutive tiles of total_tiles (see the kernel)
   const int* ylimit;      // device int: tiles whose first output row is >= *ylimit do nothing (data-dependent extents)
   long long m_flat;       // > 0: the (Ho x 32) geometry is a flat list of m_flat pixels (gemm1x1_kernel); rows beyond it are skipped
 };
@@ -288,14 +289,27 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
   const int lane = tid & 63, wave = tid >> 6;
   const int lx = lane & 31, q = lane >> 5;
 
-  int L = xcd_remap(blockIdx.x, gridDim.x), nt;
-  tile_order(L, p.n_tiles, p.n_group, nt, L);
+  // reps > 1 (data-dependent extents, ConvDesc.ylimit): a workgroup walks `reps` consecutive tiles and stops at the first
+  // one beyond the row limit -- the worst-case grid of a mostly empty map is reps times smaller
+  const int reps = p.reps > 1 ? p.reps : 1;
+  for (int rep = 0; rep < reps; ++rep) {
+  int L, nt;
+  if (reps == 1) {
+    L = xcd_remap(blockIdx.x, gridDim.x);
+    tile_order(L, p.n_tiles, p.n_group, nt, L);
+  } else {
+    L = blockIdx.x * reps + rep;
+    if (L >= p.total_tiles) break;
+    nt = L % p.n_tiles;
+    L /= p.n_tiles;
+    if (rep) __syncthreads();                      // the previous tile's epilogue has finished with the LDS image
+  }
   const int txi = L % p.tiles_x;
   L /= p.tiles_x;
   const int tyi = L % p.tiles_y;
   const int b = L / p.tiles_y;
   const int oy0 = tyi * C::TH, ox0 = txi * C::TW;
-  if (p.ylimit && oy0 >= *p.ylimit) return;        // uniform over the workgroup, before any barrier
+  if (p.ylimit && oy0 >= *p.ylimit) break;         // uniform over the workgroup; later tiles of the walk are further down
   const int iy0 = oy0 * STRIDE - (KS / 2), ix0 = ox0 * STRIDE - (KS / 2);
   const int nchunks = p.split ? 3 * (p.Cin >> 5) : (p.Cin >> 5);
   const int in_cs = p.split ? 2 * p.Cin : p.Cin;   // channels per input pixel in memory
@@ -451,7 +465,7 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
           }
         }
     }
-    return;
+    continue;
   }
   // ---- epilogue through LDS (fp32 [pixel][64]) ----
   __syncthreads();
@@ -470,6 +484,7 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
   }
   __syncthreads();
   epilogue_store<C::TH, C::TW>(p, stage, tid, b, oy0, ox0, nt * 64);
+  }   // rep
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1255,8 +1270,14 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   k.tiles_x = (k.Wo + C::TW - 1) / C::TW;
   k.tiles_y = (k.Ho + C::TH - 1) / C::TH;
   k.n_tiles = k.N / 64;
-  const long long nblk = (long long)k.B * k.tiles_x * k.tiles_y * k.n_tiles;
+  long long nblk = (long long)k.B * k.tiles_x * k.tiles_y * k.n_tiles;
   PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range (%lld blocks)", nblk);
+  if (k.ylimit) {      // mostly empty worst-case extents: 16 tiles per workgroup
+    k.reps = 16;
+    k.total_tiles = (int)nblk;
+    k.n_group = 0;
+    nblk = (nblk + 15) / 16;
+  }
   char label[48];
   snprintf(label, sizeof(label), "conv%dx%d s%d %d->%d @%dx%d%s", KS, KS, STRIDE, k.Cin, k.N, k.Ho, k.Wo, k.head_w ? " +head" : (k.split ? " x3" : ""));
   PtProfScope prof(e, s, KS == 3 ? PT_PROF_CONV3X3 : PT_PROF_CONV1X1, flop, label);
