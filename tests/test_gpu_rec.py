@@ -145,3 +145,38 @@ def test_rec_end_to_end_x3(eng, sd):
         assert len(texts) == 1 and len(texts[0]) == len(boxes)
     finally:
         eng.set_precision(L.PT_PRECISION_BF16)
+
+
+def test_rec_bf16_fast_kernels_equal_tiled_kernels(tmp_path):
+    """bf16 mode: the weight-stationary LSTM (lstm_cluster_kernel) and the streaming row GEMMs / fused arg-max
+    (gemm_argmax_kernel) give bit-identical ids AND winning logits to the streaming LSTM + tiled 1x1 GEMM + arg-max reduce
+    they replaced (selected with PT_LSTM_CLUSTER=0 PT_CLS_FUSED=0 in a child process: the switches are read once).
+    300 lines = three 128-line clusters, the last one partial."""
+    import os
+    import subprocess
+    import sys
+    script = r'''
+import sys, numpy as np, torch
+from pdf_table_amd import lib as L
+from pdf_table_amd.engine import HipEngine
+from pdf_table_amd.synth_weights import crnn_state_dict
+from pdf_table_amd.weights import pack_crnn
+eng = HipEngine(0)
+eng.load_weights(L.PT_MODEL_CRNN, pack_crnn(crnn_state_dict(seed=1), x3=False))
+rng = np.random.default_rng(21)
+g = rng.uniform(0, 1, (300, 32, 640)).astype(np.float32)
+for i in range(0, 300, 7):
+    g[i, :, int(rng.integers(40, 600)):] = 0          # ragged right padding like real lines
+ids, mx = eng.rec_forward_net(torch.from_numpy(g).to(torch.bfloat16).cuda())
+np.savez(sys.argv[1], ids=ids.cpu().numpy(), mx=mx.cpu().numpy())
+'''
+    outs = []
+    for tag, env in (("fast", {}), ("tiled", {"PT_LSTM_CLUSTER": "0", "PT_CLS_FUSED": "0"})):
+        out = str(tmp_path / f"{tag}.npz")
+        e = dict(os.environ, **env)
+        e["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + e.get("PYTHONPATH", "")
+        subprocess.run([sys.executable, "-c", script, out], check=True, env=e, timeout=300)
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0]["ids"], outs[1]["ids"])
+    assert np.array_equal(outs[0]["mx"], outs[1]["mx"])
+    assert len(np.unique(outs[0]["ids"])) > 20           # not a degenerate output

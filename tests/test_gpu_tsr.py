@@ -392,3 +392,34 @@ def test_forward_decode_fused_is_bit_identical(mode, wiz_rev):
             assert torch.equal(l0[b, :int(c0[b])], l1.cpu()[b, :int(c0[b])]), b
     finally:
         eng.close()
+
+
+def test_thin_stem_kernel_equals_general_kernel(tmp_path):
+    """bf16 mode: conv_stem7x7_thin_kernel (DLA base_layer) gives bit-identical network outputs to the general stem kernel
+    (PT_STEM_THIN=0 in a child process: the switch is read once); odd tile counts in both directions"""
+    import os
+    import subprocess
+    import sys
+    script = r'''
+import sys, numpy as np, torch
+from pdf_table_amd import lib as L
+from pdf_table_amd.engine import HipEngine
+from pdf_table_amd.synth_weights import lore_dla34_state_dict
+from pdf_table_amd.weights import pack_lore_dla34
+eng = HipEngine(0)
+eng.load_weights(L.PT_MODEL_LORE_DLA34, pack_lore_dla34(lore_dla34_state_dict(seed=2), x3=False))
+g = torch.Generator().manual_seed(5)
+x = torch.zeros(2, 288, 352, 4)
+x[..., :3] = torch.randn(2, 288, 352, 3, generator=g)
+heads = eng.tsr_forward_net(x.to(torch.bfloat16).cuda())
+np.savez(sys.argv[1], **{k: v.float().cpu().numpy() for k, v in heads.items()})
+'''
+    outs = []
+    for tag, env in (("thin", {}), ("general", {"PT_STEM_THIN": "0"})):
+        out = str(tmp_path / f"{tag}.npz")
+        e = dict(os.environ, **env)
+        e["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + e.get("PYTHONPATH", "")
+        subprocess.run([sys.executable, "-c", script, out], check=True, env=e, timeout=300)
+        outs.append(np.load(out))
+    for k in outs[0].files:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
