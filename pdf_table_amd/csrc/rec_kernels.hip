@@ -281,9 +281,104 @@ __global__ __launch_bounds__(256) void crnn_conv0_pool_kernel(const bf16_t* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// bf16 fast path of conv0 + pool on the matrix cores.  The VALU kernel above already runs at ~85 % of the fp32 FMA
+// peak (57 GFMA per 4096 lines in 1.7 ms); as a GEMM the layer is [pixels] x [K = 9 taps, padded to 16] x [64]: one
+// v_mfma_f32_32x32x16_bf16 per 32 pixels and 32 channels.  The 32 rows of an M tile are 8 pooling windows x 4 pixels
+// (row m = 4 w + 2 dy + dx), so the four conv outputs of a window are the four accumulators (r & 3) of ONE lane and the
+// 2x2 max is in-lane; the weights are two B fragments held in registers; A fragments are gathered from a gray patch in
+// LDS (lane q = 0: taps 0..7, q = 1: tap 8 and zeros).  Same bf16 contract: bias, ReLU, round to bf16, then max.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void crnn_conv0_pool_mfma_kernel(const bf16_t* __restrict__ in, int n, int H, int W,
+                                                                    const float* __restrict__ w64x9,
+                                                                    const float* __restrict__ bias, bf16_t* __restrict__ out) {
+  constexpr int PR = 4, PC = 64;                  // pooled rows x cols per workgroup
+  constexpr int LW = 2 * PC + 2, LH = 2 * PR + 2; // gray patch with a 1-pixel halo
+  __shared__ bf16_t sg[LH * LW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, q = lane >> 5;
+  const int Ho = H / 2, Wo = W / 2;
+  const int tcx = (Wo + PC - 1) / PC, tcy = (Ho + PR - 1) / PR;
+  int L = blockIdx.x;
+  const int tx = L % tcx;
+  L /= tcx;
+  const int ty = L % tcy;
+  const int b = L / tcy;
+  const int oy0 = ty * PR, ox0 = tx * PC;
+  for (int i = tid; i < LH * LW; i += 256) {
+    const int yy = 2 * oy0 - 1 + i / LW, xx = 2 * ox0 - 1 + i % LW;
+    sg[i] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? in[((size_t)b * H + yy) * W + xx] : (bf16_t)0;
+  }
+  // B fragments: lane = output channel lx (+32), k = q*8 .. q*8+7 -> taps (weights already rounded to bf16 by the packer)
+  bf16x8 bw[2];
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh) {
+    uint32_t pk[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k0 = q * 8 + 2 * i, k1 = k0 + 1;
+      const uint32_t a0 = k0 < 9 ? rf2bf(w64x9[(nh * 32 + lx) * 9 + k0]) : 0u;
+      const uint32_t a1 = k1 < 9 ? rf2bf(w64x9[(nh * 32 + lx) * 9 + k1]) : 0u;
+      pk[i] = a0 | (a1 << 16);
+    }
+    const u32x4 v = {pk[0], pk[1], pk[2], pk[3]};
+    bw[nh] = __builtin_bit_cast(bf16x8, v);
+  }
+  const float bs[2] = {bias[lx], bias[32 + lx]};
+  __syncthreads();
+  // M tiles of this workgroup: PR row pairs x (PC / 8) groups of 8 windows; wave w takes tiles w, w + 4, ...
+  const int wnd = lx >> 2, dy = (lx >> 1) & 1, dx = lx & 1;      // this lane's A row: window, pixel inside it
+  for (int mt = wave; mt < PR * (PC / 8); mt += 4) {
+    const int pr = mt / (PC / 8), pc0 = (mt % (PC / 8)) * 8;
+    const int ly = 2 * pr + dy, lxx = 2 * (pc0 + wnd) + dx;       // conv pixel in patch coordinates minus the halo
+    uint32_t pk[4] = {0u, 0u, 0u, 0u};
+    if (q == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k0 = 2 * i, k1 = 2 * i + 1;
+        pk[i] = (uint32_t)sg[(ly + k0 / 3) * LW + lxx + k0 % 3] | ((uint32_t)sg[(ly + k1 / 3) * LW + lxx + k1 % 3] << 16);
+      }
+    } else {
+      pk[0] = (uint32_t)sg[(ly + 2) * LW + lxx + 2];
+    }
+    const u32x4 av = {pk[0], pk[1], pk[2], pk[3]};
+    const bf16x8 a = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[nh], acc, 0, 0, 0);
+      // accumulator r: row (r & 3) + 8 (r >> 2) + 4 q = window 2 (r >> 2) + q, pixel r & 3
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float m = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = rbf2f(rf2bf(fmaxf(acc[g * 4 + j] + bs[nh], 0.f)));
+          m = j == 0 ? v : fmaxf(m, v);
+        }
+        const int oy = oy0 + pr, ox = ox0 + pc0 + 2 * g + q;
+        if (oy < Ho && ox < Wo) out[(((size_t)b * Ho + oy) * Wo + ox) * 64 + nh * 32 + lx] = (bf16_t)rf2bf(m);
+      }
+    }
+  }
+}
+
 int pt_launch_crnn_conv0_pool(const bf16_t* in, int n, int H, int W, const float* w64x9, const float* bias, int split,
                               bf16_t* out, hipStream_t s) {
   PT_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv0: H, W must be even");
+  static int use_mfma = -1;      // PT_CONV0_MFMA=0: the VALU kernel in bf16 mode too (A/B switch)
+  if (use_mfma < 0) {
+    const char* ev = getenv("PT_CONV0_MFMA");
+    use_mfma = ev ? atoi(ev) : 1;
+  }
+  if (!split && use_mfma) {
+    const long long nb = (long long)n * ((H / 2 + 3) / 4) * ((W / 2 + 63) / 64);
+    hipLaunchKernelGGL(crnn_conv0_pool_mfma_kernel, dim3((unsigned)nb), dim3(256), 0, s, in, n, H, W, w64x9, bias, out);
+    PT_HIP_CHECK(hipGetLastError());
+    return PT_OK;
+  }
   const long long total = (long long)n * (H / 2) * (W / 2) * 8;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
