@@ -60,6 +60,7 @@ struct ConvK {
   int n_group;            // > 0: column tiles are walked in groups of n_group so that a group's weights stay in one XCD's L2
   int gemm_nt;            // gemm1x1_kernel: number of 128-wide column tiles (n_tiles stays N / 64 for the arg-max partials)
   const float* slope;     // relu == 3: PReLU, slope[0] = the (single, layer-wide) negative slope, read on the device
+  int pool;               // 1: MaxPool2d(2,2), 2: MaxPool2d((2,1)) fused behind bias + ReLU (bf16-rounded first, like the stored map)
   int reps, total_tiles;  // reps > 1: a workgroup walks reps consecutive tiles of total_tiles (see the kernel)
   const int* ylimit;      // device int: tiles whose first output row is >= *ylimit do nothing (data-dependent extents)
   long long m_flat;       // > 0: the (Ho x 32) geometry is a flat list of m_flat pixels (gemm1x1_kernel); rows beyond it are skipped
@@ -116,6 +117,50 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
         for (int k = 0; k < 8; ++k) hw[qd][k] = bf16_to_f32((k & 1) ? (ww[k >> 1] >> 16) : (ww[k >> 1] & 0xFFFFu));
       }
     }
+  }
+  if (EXTRAS && p.pool) {
+    // conv + BN + ReLU + max-pool in one pass: the pooled tile is (TH/2) x (TW/pw); every source value is biased, ReLU'd and
+    // rounded exactly as it would have been stored, then the maximum is stored (identical to conv -> store -> pool)
+    const int pw = p.pool == 1 ? 2 : 1;
+    const int PTW = TW / pw, PHo = p.Ho >> 1, PWo = p.Wo / pw;
+    for (int idx = tid; idx < (TH / 2) * PTW * 8; idx += NTHR) {
+      const int ppix = idx >> 3, cg = idx & 7;
+      const int py = ppix / PTW, px = ppix - py * PTW;
+      const int oy = (oy0 >> 1) + py, ox = ox0 / pw + px;
+      if (oy >= PHo || ox >= PWo) continue;
+      const int n = n0 + cg * 8;
+      const f32x4* bp = reinterpret_cast<const f32x4*>(p.bias + n);
+      const f32x4 b0 = bp[0], b1 = bp[1];
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      float m[8];
+      for (int dy = 0; dy < 2; ++dy)
+        for (int dx = 0; dx < pw; ++dx) {
+          const f32x4* sp = reinterpret_cast<const f32x4*>(stage + ((2 * py + dy) * TW + pw * px + dx) * 64 + cg * 8);
+          const f32x4 v0 = sp[0], v1 = sp[1];
+          const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            float v = vv[k] + bb[k];
+            if (p.relu == 1) v = fmaxf(v, 0.f);
+            if (!p.split) v = bf16_to_f32(f32_to_bf16(v));
+            m[k] = (dy == 0 && dx == 0) ? v : fmaxf(m[k], v);
+          }
+        }
+      uint32_t hb[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) hb[k] = f32_to_bf16(m[k]);
+      const u32x4 o = {hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16)};
+      const size_t oo = (((size_t)b * PHo + oy) * PWo + ox) * p.out_cstride + p.out_coff + n;
+      *reinterpret_cast<u32x4*>(p.out + oo) = o;
+      if (p.split) {
+        uint32_t lb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lb[k] = f32_to_bf16(m[k] - bf16_to_f32(hb[k]));
+        const u32x4 ol = {lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16), lb[4] | (lb[5] << 16), lb[6] | (lb[7] << 16)};
+        *reinterpret_cast<u32x4*>(p.out + oo + p.out_lo_off) = ol;
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int j = 0; j < TH * TW * 8 / NTHR; ++j) {
@@ -1266,7 +1311,7 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
     attr_done = true;
   }
   // plain layer: bias [+ residual] [+ activation] -> bf16 NHWC, nothing fused behind it
-  const bool plain = !k.head_w && !k.argmax_part && !k.shuffle_cout && !k.out_f32 && !k.res_f32 && !k.m_flat && k.rep == 1;
+  const bool plain = !k.head_w && !k.argmax_part && !k.shuffle_cout && !k.out_f32 && !k.res_f32 && !k.m_flat && k.rep == 1 && !k.pool;
   k.tiles_x = (k.Wo + C::TW - 1) / C::TW;
   k.tiles_y = (k.Ho + C::TH - 1) / C::TH;
   k.n_tiles = k.N / 64;
@@ -1441,7 +1486,9 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   k.Ho = (d.H + 2 * pad - d.ks) / d.stride + 1;
   k.Wo = (d.W + 2 * pad - d.ks) / d.stride + 1;
   k.out_cstride = d.out_cstride; k.out_coff = d.out_coff; k.rep = d.rep; k.shuffle_cout = d.shuffle_cout;
-  k.res_mode = d.res ? d.res_mode : 0; k.relu = d.relu; k.slope = d.slope; k.ylimit = d.ylimit;
+  k.res_mode = d.res ? d.res_mode : 0; k.relu = d.relu; k.slope = d.slope; k.ylimit = d.ylimit; k.pool = d.pool;
+  PT_REQUIRE(!d.pool || (d.ks == 3 && d.stride == 1 && !d.res && !d.shuffle_cout && d.rep == 1 && !d.out_f32 && !d.argmax_part && !d.head_w && !d.n_valid && d.relu <= 1 && k.Ho % 2 == 0 && (d.pool == 2 || k.Wo % 2 == 0)),
+             "conv: fused pooling needs a plain 3x3 stride-1 layer with even output size");
   PT_REQUIRE(d.relu != 3 || d.slope, "conv: PReLU needs the slope tensor");
   k.split = d.split; k.out_lo_off = d.out_lo_off;
   k.head_w = d.head_w; k.head_b = d.head_b; k.head_prob = d.head_prob; k.head_logits = d.head_logits;
@@ -1449,7 +1496,7 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   if (d.head_w) PT_REQUIRE(d.shuffle_cout == 64 && d.head_b && (d.head_prob || d.head_logits), "conv: bad fused-head configuration");
   if (k.res_mode == 2) PT_REQUIRE(k.Ho % 2 == 0 && k.Wo % 2 == 0, "conv: half-res residual needs even output size");
   const double flop = 2.0 * k.B * k.Ho * k.Wo * (double)k.N * d.Cin * d.ks * d.ks;  // algorithmic (not x3 in split mode)
-  if (d.ks == 3 && d.stride == 1 && !d.head_w && !d.argmax_part && !d.n_valid && !d.out_f32 && !d.res_f32 && d.relu < 2 && !d.ylimit && use_dma_kernel()) {
+  if (d.ks == 3 && d.stride == 1 && !d.head_w && !d.argmax_part && !d.n_valid && !d.out_f32 && !d.res_f32 && d.relu < 2 && !d.ylimit && !d.pool && use_dma_kernel()) {
     // steady-state A/B on MI355X (tools/ab3.sh, round 1): the 16-channel-slice DMA kernel (v3) wins on >= 120-row maps
     // with K >= 128 channels, the 32-channel-slice DMA kernel (v2) on 60..119-row maps, the register-staged kernel
     // (v1) on short-K layers and on small maps, where the big DMA tiles leave CUs idle

@@ -133,11 +133,29 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
     PtProfScope ps(e, s, PT_PROF_OTHER, 0, "crnn conv0+pool");
     RUN(pt_launch_crnn_conv0_pool(gray, n, PT_REC_H, PT_REC_W, Bv(c0w), Bv(c0b), x3, bf.a0, s));
   }
-  RUN(pt_launch_conv(e, conv(bf.a0, n, 16, 320, 64, c1, 128, 3, bf.a1, 1), s));
-  RUN(pt_launch_maxpool_kxk(bf.a1, n, 16, 320, 128, 2, 2, 0, x3, bf.p1, s));
+  // conv1 + pool(2,2) and conv2.3 + pool((2,1)): pooling in the conv epilogue (PT_POOL_FUSED=0: separate pool kernels)
+  static int pool_fused = -1;
+  if (pool_fused < 0) {
+    const char* ev = getenv("PT_POOL_FUSED");
+    pool_fused = ev ? atoi(ev) : 1;
+  }
+  if (pool_fused) {
+    ConvDesc c1d = conv(bf.a0, n, 16, 320, 64, c1, 128, 3, bf.p1, 1);
+    c1d.pool = 1;
+    RUN(pt_launch_conv(e, c1d, s));
+  } else {
+    RUN(pt_launch_conv(e, conv(bf.a0, n, 16, 320, 64, c1, 128, 3, bf.a1, 1), s));
+    RUN(pt_launch_maxpool_kxk(bf.a1, n, 16, 320, 128, 2, 2, 0, x3, bf.p1, s));
+  }
   RUN(pt_launch_conv(e, conv(bf.p1, n, 8, 160, 128, c2a, 256, 3, bf.c2a, 1), s));
-  RUN(pt_launch_conv(e, conv(bf.c2a, n, 8, 160, 256, c2b, 256, 3, bf.c2b, 1), s));
-  RUN(pt_launch_maxpool_kxk(bf.c2b, n, 8, 160, 256, 2, 1, 0, x3, bf.p2, s));
+  if (pool_fused) {
+    ConvDesc c2d = conv(bf.c2a, n, 8, 160, 256, c2b, 256, 3, bf.p2, 1);
+    c2d.pool = 2;
+    RUN(pt_launch_conv(e, c2d, s));
+  } else {
+    RUN(pt_launch_conv(e, conv(bf.c2a, n, 8, 160, 256, c2b, 256, 3, bf.c2b, 1), s));
+    RUN(pt_launch_maxpool_kxk(bf.c2b, n, 8, 160, 256, 2, 1, 0, x3, bf.p2, s));
+  }
   RUN(pt_launch_conv(e, conv(bf.p2, n, 4, 160, 256, c3a, 512, 3, bf.c3a, 1), s));
   RUN(pt_launch_conv(e, conv(bf.c3a, n, 4, 160, 512, c3b, 512, 3, bf.c3b, 1), s));
   RUN(pt_launch_maxpool_kxk(bf.c3b, n, 4, 160, 512, 2, 1, /*h2c=*/1, x3, bf.p3, s));

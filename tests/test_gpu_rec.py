@@ -150,7 +150,8 @@ def test_rec_end_to_end_x3(eng, sd):
 def test_rec_bf16_fast_kernels_equal_tiled_kernels(tmp_path):
     """bf16 mode: the weight-stationary LSTM (lstm_cluster_kernel) and the streaming row GEMMs / fused arg-max
     (gemm_argmax_kernel) give bit-identical ids AND winning logits to the streaming LSTM + tiled 1x1 GEMM + arg-max reduce
-    they replaced (selected with PT_LSTM_CLUSTER=0 PT_CLS_FUSED=0 in a child process: the switches are read once).
+    they replaced, and the max-pools fused into the conv epilogues to the separate pool kernels (selected with
+    PT_LSTM_CLUSTER=0 PT_CLS_FUSED=0 PT_POOL_FUSED=0 in a child process: the switches are read once).
     300 lines = three 128-line clusters, the last one partial."""
     import os
     import subprocess
@@ -171,7 +172,7 @@ ids, mx = eng.rec_forward_net(torch.from_numpy(g).to(torch.bfloat16).cuda())
 np.savez(sys.argv[1], ids=ids.cpu().numpy(), mx=mx.cpu().numpy())
 '''
     outs = []
-    for tag, env in (("fast", {}), ("tiled", {"PT_LSTM_CLUSTER": "0", "PT_CLS_FUSED": "0"})):
+    for tag, env in (("fast", {}), ("tiled", {"PT_LSTM_CLUSTER": "0", "PT_CLS_FUSED": "0", "PT_POOL_FUSED": "0"})):
         out = str(tmp_path / f"{tag}.npz")
         e = dict(os.environ, **env)
         e["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + e.get("PYTHONPATH", "")
