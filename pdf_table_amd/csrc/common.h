@@ -131,7 +131,7 @@ struct ConvDesc {
   int res_mode = 0;  // 0 none, 1 same resolution, 2 half resolution (fused nearest x2 upsample + add)
   int relu = 0;      // activation: 0 none, 1 ReLU, 2 hardswish, 3 PReLU(slope)
   const float* slope = nullptr;   // device pointer to the PReLU slope (relu == 3)
-  int pool = 0;                   // 1: MaxPool2d(2,2), 2: MaxPool2d((2,1)) fused behind bias + ReLU (plain 3x3 stride-1 layers)
+  int pool = 0;                   // 1: MaxPool2d(2,2), 2: MaxPool2d((2,1)), 3: (2,1) with rows -> channel groups; fused behind bias + ReLU (plain 3x3 stride-1 layers)
   const int* ylimit = nullptr;    // device int: output rows >= *ylimit are not computed (whole tiles; v1 kernel only)
   // bf16x3 precision mode: in/res/out hold (hi | lo) channel groups; w is [N/64][3*Cin/32][taps][64][32]
   int split = 0;

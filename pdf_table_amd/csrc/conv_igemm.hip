@@ -121,6 +121,8 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
   if (EXTRAS && p.pool) {
     // conv + BN + ReLU + max-pool in one pass: the pooled tile is (TH/2) x (TW/pw); every source value is biased, ReLU'd and
     // rounded exactly as it would have been stored, then the maximum is stored (identical to conv -> store -> pool)
+    // pool 3: (2,1) with the pooled rows written as channel groups, [n][Wo][Ho/2 * C] (the layout the (2,1)-kernel conv4 of
+    // the CRNN reads as a 1x1 GEMM, maxpool_kxk_kernel's h2c)
     const int pw = p.pool == 1 ? 2 : 1;
     const int PTW = TW / pw, PHo = p.Ho >> 1, PWo = p.Wo / pw;
     for (int idx = tid; idx < (TH / 2) * PTW * 8; idx += NTHR) {
@@ -150,14 +152,22 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
 #pragma unroll
       for (int k = 0; k < 8; ++k) hb[k] = f32_to_bf16(m[k]);
       const u32x4 o = {hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16)};
-      const size_t oo = (((size_t)b * PHo + oy) * PWo + ox) * p.out_cstride + p.out_coff + n;
+      size_t oo;
+      int lo_off = p.out_lo_off;
+      if (p.pool == 3) {
+        const int Ct = PHo * p.N;
+        oo = ((size_t)b * PWo + ox) * (p.split ? 2 * Ct : Ct) + oy * p.N + n;
+        lo_off = Ct;
+      } else {
+        oo = (((size_t)b * PHo + oy) * PWo + ox) * p.out_cstride + p.out_coff + n;
+      }
       *reinterpret_cast<u32x4*>(p.out + oo) = o;
       if (p.split) {
         uint32_t lb[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) lb[k] = f32_to_bf16(m[k] - bf16_to_f32(hb[k]));
         const u32x4 ol = {lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16), lb[4] | (lb[5] << 16), lb[6] | (lb[7] << 16)};
-        *reinterpret_cast<u32x4*>(p.out + oo + p.out_lo_off) = ol;
+        *reinterpret_cast<u32x4*>(p.out + oo + lo_off) = ol;
       }
     }
     return;
@@ -1487,7 +1497,7 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   k.Wo = (d.W + 2 * pad - d.ks) / d.stride + 1;
   k.out_cstride = d.out_cstride; k.out_coff = d.out_coff; k.rep = d.rep; k.shuffle_cout = d.shuffle_cout;
   k.res_mode = d.res ? d.res_mode : 0; k.relu = d.relu; k.slope = d.slope; k.ylimit = d.ylimit; k.pool = d.pool;
-  PT_REQUIRE(!d.pool || (d.ks == 3 && d.stride == 1 && !d.res && !d.shuffle_cout && d.rep == 1 && !d.out_f32 && !d.argmax_part && !d.head_w && !d.n_valid && d.relu <= 1 && k.Ho % 2 == 0 && (d.pool == 2 || k.Wo % 2 == 0)),
+  PT_REQUIRE(!d.pool || (d.ks == 3 && d.stride == 1 && !d.res && !d.shuffle_cout && d.rep == 1 && !d.out_f32 && !d.argmax_part && !d.head_w && !d.n_valid && d.relu <= 1 && k.Ho % 2 == 0 && (d.pool != 1 || k.Wo % 2 == 0)),
              "conv: fused pooling needs a plain 3x3 stride-1 layer with even output size");
   PT_REQUIRE(d.relu != 3 || d.slope, "conv: PReLU needs the slope tensor");
   k.split = d.split; k.out_lo_off = d.out_lo_off;

@@ -157,8 +157,14 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
     RUN(pt_launch_maxpool_kxk(bf.c2b, n, 8, 160, 256, 2, 1, 0, x3, bf.p2, s));
   }
   RUN(pt_launch_conv(e, conv(bf.p2, n, 4, 160, 256, c3a, 512, 3, bf.c3a, 1), s));
-  RUN(pt_launch_conv(e, conv(bf.c3a, n, 4, 160, 512, c3b, 512, 3, bf.c3b, 1), s));
-  RUN(pt_launch_maxpool_kxk(bf.c3b, n, 4, 160, 512, 2, 1, /*h2c=*/1, x3, bf.p3, s));
+  if (pool_fused) {
+    ConvDesc c3d = conv(bf.c3a, n, 4, 160, 512, c3b, 512, 3, bf.p3, 1);
+    c3d.pool = 3;          // (2,1) pool, rows -> channel groups: [n][160][2 * 512]
+    RUN(pt_launch_conv(e, c3d, s));
+  } else {
+    RUN(pt_launch_conv(e, conv(bf.c3a, n, 4, 160, 512, c3b, 512, 3, bf.c3b, 1), s));
+    RUN(pt_launch_maxpool_kxk(bf.c3b, n, 4, 160, 512, 2, 1, /*h2c=*/1, x3, bf.p3, s));
+  }
   // from here on: [1, n, 160, C] views
   RUN(pt_launch_conv(e, conv(bf.p3, 1, n, T, 1024, c4, 512, 1, bf.f, 1), s));
   RUN(rows_gemm(bf.f, 512, xp1, 2048, bf.gx, 0, "rows gemm 512->2048"));
