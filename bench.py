@@ -62,7 +62,7 @@ def cpu_baseline_tsr(lsd, psd, page, box):
                      f"DLA-34+DCN fp32 {t2 - t1:.2f}, decode {t3 - t2:.2f}, processor {t4 - t3:.2f})")
 
 
-def cpu_baseline(sd, pages_np, cfg, csd=None, quads=None, max_lines=12, tsr=None, layout=None):
+def cpu_baseline(sd, pages_np, cfg, csd=None, quads=None, max_lines=12, tsr=None, layout=None, lines_per_page=None):
     """The oracle (port of the reference CPU path: fp32 torch ops in the reference's op order + numpy/python
     pre/post) on the host cores, batch 1 per call as the reference runs it."""
     from oracle import db_nas, db_net, db_post, db_pre
@@ -103,7 +103,8 @@ def cpu_baseline(sd, pages_np, cfg, csd=None, quads=None, max_lines=12, tsr=None
         # number of lines and scaled to the page's line count
         from oracle import crnn as ocrnn
         t_rec, nl = 0.0, 0
-        lines_total = sum(len(q) for q in quads[:n])
+        # scaled to the WORKLOAD's mean line count per page (the sampled pages may have fewer or more)
+        lines_total = lines_per_page * n if lines_per_page else sum(len(q) for q in quads[:n])
         rec_t0 = time.time()
         for img, qs in zip(pages_np[:n], quads[:n]):
             for q in qs[:max_lines]:
@@ -454,7 +455,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sd, pages_np[:2], cfg, csd if rec is not None else None,
                                                gt_quads[:2] if rec is not None else None,
                                                tsr=(lsd, psd, table_boxes, tables_per_page) if tsr is not None else None,
-                                               layout=ysd if layout is not None else None)
+                                               layout=ysd if layout is not None else None,
+                                               lines_per_page=lines_per_page if rec is not None else None)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
