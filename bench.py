@@ -406,14 +406,14 @@ def main():
                 pm = json.load(f)
             tot = nl = 0.0
             for kname, rec_ in pm.items():       # every 3x3 conv kernel variant, launch-weighted
-                if ("conv_igemm_kernel<3," in kname or "conv3x3_dma_kernel" in kname) and "hbm_bytes_per_launch" in rec_:
+                if ("conv_igemm_kernel<3," in kname or "conv3x3_dma" in kname) and "hbm_bytes_per_launch" in rec_:
                     n_ = rec_["FETCH_SIZE"]["dispatches"]
                     tot += rec_["hbm_bytes_per_launch"] * n_
                     nl += n_
             traffic = tot / nl if nl else None
         except Exception:
             traffic = None
-        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<3,*> (3x3 implicit-GEMM convs of DB-ResNet18)",
+        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<3,*> / conv3x3_dma16_kernel (3x3 implicit-GEMM convolutions of all stages)",
                 "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
                 "traffic": traffic, "traffic_note": "bytes/launch over the 3x3 conv kernels, PMC passes of profiles/pmc_latest.json "
                                                     "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",

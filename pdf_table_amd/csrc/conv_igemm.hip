@@ -1380,14 +1380,16 @@ static int launch_dma16(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   return PT_OK;
 }
 
-// PT_CONV_VARIANT: 0 = v1 only (default), 1 = micro-benchmark rule, 2 = v2 wherever it applies, 3 = v3 wherever it applies.
-// In the DB-ResNet18 graph on real (post-ReLU) activations at 8-page micro-batches v1-only measured fastest
-// (det-only, no post: 3836 pages/s vs 3764 with rule 1 and 3719 with v2), although rule 1 wins the randn micro-benchmark.
+// PT_CONV_VARIANT: 0 = v1 only, 1 = micro-benchmark rule, 2 = v2 wherever it applies, 3 = v3 wherever it applies (default).
+// History: in the DB-ResNet18 graph at 8-page micro-batches v1-only measured fastest (det-only, no post: 3836 pages/s vs
+// 3764 with rule 1 and 3719 with v2) and was the default for most of round 1.  With 32-page det and 80-table Lore
+// micro-batches the 16-channel-slice DMA kernel wins where it applies (tools/ab_env.sh, two alternating runs each:
+// det-only 3503 / 3607 -> 3685 / 3647 pages/s, TSR-only 833 / 842 -> 845 / 859, four stages 354 / 358 -> 361 / 361).
 static int conv_variant() {
   static int v = -1;
   if (v < 0) {
     const char* s = getenv("PT_CONV_VARIANT");
-    v = s ? atoi(s) : 0;
+    v = s ? atoi(s) : 3;
   }
   return v;
 }

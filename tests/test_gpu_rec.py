@@ -175,6 +175,7 @@ np.savez(sys.argv[1], ids=ids.cpu().numpy(), mx=mx.cpu().numpy())
     for tag, env in (("fast", {}), ("tiled", {"PT_LSTM_CLUSTER": "0", "PT_CLS_FUSED": "0", "PT_POOL_FUSED": "0"})):
         out = str(tmp_path / f"{tag}.npz")
         e = dict(os.environ, **env)
+        e["PT_CONV_VARIANT"] = "0"     # one conv kernel family in both runs: the DMA variants sum K in another order
         e["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + e.get("PYTHONPATH", "")
         subprocess.run([sys.executable, "-c", script, out], check=True, env=e, timeout=300)
         outs.append(np.load(out))

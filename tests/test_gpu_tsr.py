@@ -353,45 +353,75 @@ def test_lore_wireless_net_matches_reference_golden_and_bf16(eng, golden_dir):
     assert _cmp(got, ref, "lore wireless bf16") <= 0.1
 
 
+_FUSED_SCRIPT = r'''
+import sys, numpy as np, torch
+from pdf_table_amd import lib as L
+from pdf_table_amd.engine import HipEngine
+from pdf_table_amd.synth_weights import lore_dla34_state_dict
+from pdf_table_amd.weights import pack_lore_dla34
+mode, wiz_rev, out = sys.argv[1], sys.argv[2] == "1", sys.argv[3]
+eng = HipEngine(0)
+# head biases near the thresholds: hundreds of cells and corners per table on noise input
+eng.load_weights(L.PT_MODEL_LORE_DLA34, pack_lore_dla34(lore_dla34_state_dict(seed=2, hm_bias=(-1.2, -0.6))))
+eng.set_precision(L.PT_PRECISION_BF16X3 if mode == "bf16x3" else L.PT_PRECISION_BF16)
+g = torch.Generator().manual_seed(77)
+n, H, W = 3, 256, 320
+x = torch.randn(n, H, W, 3, generator=g) * 0.7
+x4 = torch.zeros(n, H, W, 8 if mode == "bf16x3" else 4)
+hi = x.to(torch.bfloat16).float()
+x4[..., :3] = hi
+if mode == "bf16x3":
+    x4[..., 4:7] = (x - hi).to(torch.bfloat16).float()
+xd = x4.to(torch.bfloat16).cuda()
+heads = eng.tsr_forward_net(xd)
+c0, d0, l0 = eng.tsr_decode(heads, wiz_rev=wiz_rev, vis_thresh=0.2, sync=True)
+c1, d1, l1 = eng.tsr_forward_decode(xd, wiz_rev=wiz_rev, vis_thresh=0.2, sync=True)
+np.savez(out, c0=c0, c1=c1, d0=d0.cpu().numpy(), d1=d1.cpu().numpy(), l0=l0.cpu().numpy(), l1=l1.cpu().numpy())
+'''
+
+
+def _run_fused(tmp_path, mode, wiz_rev, variant):
+    import os
+    import subprocess
+    import sys
+    out = str(tmp_path / f"fused_{mode}_{int(wiz_rev)}_{variant}.npz")
+    e = dict(os.environ)
+    if variant is not None:
+        e["PT_CONV_VARIANT"] = str(variant)
+    e["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + e.get("PYTHONPATH", "")
+    subprocess.run([sys.executable, "-c", _FUSED_SCRIPT, mode, "1" if wiz_rev else "0", out], check=True, env=e, timeout=300)
+    return np.load(out)
+
+
 @pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
 @pytest.mark.parametrize("wiz_rev", [True, False])
-def test_forward_decode_fused_is_bit_identical(mode, wiz_rev):
+def test_forward_decode_fused_is_bit_identical(tmp_path, mode, wiz_rev):
     """pt_tsr_forward_decode (ax / cr heads evaluated only on 3x3 patches around the positions the decode reads) gives
-    exactly the outputs of pt_tsr_forward_net + pt_tsr_decode: counts, boxes, scores and the 256 logic features"""
-    from pdf_table_amd.engine import HipEngine
-    from pdf_table_amd.synth_weights import lore_dla34_state_dict
-    from pdf_table_amd.weights import pack_lore_dla34
-    eng = HipEngine(0)
-    try:
-        # head biases near the thresholds: hundreds of cells and corners per table on noise input
-        eng.load_weights(L.PT_MODEL_LORE_DLA34, pack_lore_dla34(lore_dla34_state_dict(seed=2, hm_bias=(-1.2, -0.6))))
-        eng.set_precision(L.PT_PRECISION_BF16X3 if mode == "bf16x3" else L.PT_PRECISION_BF16)
-        g = torch.Generator().manual_seed(77)
-        n, H, W = 3, 256, 320
-        x = torch.randn(n, H, W, 3, generator=g) * 0.7
-        x4 = torch.zeros(n, H, W, 8 if mode == "bf16x3" else 4)
-        hi = x.to(torch.bfloat16).float()
-        x4[..., :3] = hi
-        if mode == "bf16x3":
-            x4[..., 4:7] = (x - hi).to(torch.bfloat16).float()
-        xd = x4.to(torch.bfloat16).cuda()
-        heads = eng.tsr_forward_net(xd)
-        c0, d0, l0 = eng.tsr_decode(heads, wiz_rev=wiz_rev, vis_thresh=0.2, sync=True)
-        d0, l0 = d0.cpu(), l0.cpu()
-        c1, d1, l1 = eng.tsr_forward_decode(xd, wiz_rev=wiz_rev, vis_thresh=0.2, sync=True)
-        print("fused decode: cells above vis_thresh per table", c0.tolist())
-        assert np.array_equal(c0, c1) and c0.sum() > 0, (c0, c1)
-        # rows beyond a table's count are unspecified in both paths
-        for b in range(n):
-            k = int(c0[b])
-            kk = int(max(k, 1))
-            assert torch.equal(d0[b, :kk], d1.cpu()[b, :kk])
-        # all kept cells (not only those above vis_thresh) carry features: compare where both wrote
-        ncell = [int((d0[b, :, 8] > 0).sum()) for b in range(n)]
-        for b in range(n):
-            assert torch.equal(l0[b, :int(c0[b])], l1.cpu()[b, :int(c0[b])]), b
-    finally:
-        eng.close()
+    exactly the outputs of pt_tsr_forward_net + pt_tsr_decode -- counts, boxes, scores and the 256 logic features -- when
+    both run one conv kernel family (PT_CONV_VARIANT=0: the mosaic convs always use the register-staged kernel)"""
+    r = _run_fused(tmp_path, mode, wiz_rev, 0)
+    c0, c1 = r["c0"], r["c1"]
+    print("fused decode: cells above vis_thresh per table", c0.tolist())
+    assert np.array_equal(c0, c1) and c0.sum() > 0, (c0, c1)
+    for b in range(len(c0)):         # rows beyond a table's count are unspecified in both paths
+        k = int(c0[b])
+        assert np.array_equal(r["d0"][b, :max(k, 1)], r["d1"][b, :max(k, 1)])
+        assert np.array_equal(r["l0"][b, :k], r["l1"][b, :k]), b
+
+
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+def test_forward_decode_fused_default_dispatch(tmp_path, mode):
+    """with the default conv dispatch the dense map's 3x3 head convs run on the DMA kernel, which sums K in another order:
+    boxes and scores (from the dense hm / st / wh / reg heads in both paths) stay identical, the logic features agree to
+    fp32 summation noise (after one bf16 rounding of the hidden layer in bf16 mode)"""
+    r = _run_fused(tmp_path, mode, True, None)
+    assert np.array_equal(r["c0"], r["c1"]) and r["c0"].sum() > 0
+    for b in range(len(r["c0"])):
+        k = int(r["c0"][b])
+        assert np.array_equal(r["d0"][b, :max(k, 1)], r["d1"][b, :max(k, 1)])
+        scale = float(np.abs(r["l0"][b, :k]).max())
+        d = float(np.abs(r["l0"][b, :k] - r["l1"][b, :k]).max())
+        assert d <= (2e-2 if mode == "bf16" else 1e-4) * max(1.0, scale), (b, d, scale)
 
 
 def test_thin_stem_kernel_equals_general_kernel(tmp_path):
@@ -418,6 +448,7 @@ np.savez(sys.argv[1], **{k: v.float().cpu().numpy() for k, v in heads.items()})
     for tag, env in (("thin", {}), ("general", {"PT_STEM_THIN": "0"})):
         out = str(tmp_path / f"{tag}.npz")
         e = dict(os.environ, **env)
+        e["PT_CONV_VARIANT"] = "0"
         e["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + e.get("PYTHONPATH", "")
         subprocess.run([sys.executable, "-c", script, out], check=True, env=e, timeout=300)
         outs.append(np.load(out))
