@@ -166,6 +166,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:      # N ranks share the host: keep each rank's CPU-side torch / BLAS work inside its share of the cores
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
     dist = None
     # PT_BENCH_FORCE_DIST=1: initialise RCCL and take the broadcast / barrier / all-reduce path even with one rank
     # (exercises the N > 1 code on a single-GPU box; launch with torchrun --nproc-per-node 1 or set MASTER_PORT)
