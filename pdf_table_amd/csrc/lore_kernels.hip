@@ -741,8 +741,18 @@ int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf
     char label[48];
     snprintf(label, sizeof(label), "dcn fused %d->%d @%dx%d", C, N, H, W);
     PtProfScope prof(e, s, PT_PROF_OTHER, 0, label);   // gather-bound, kept out of the implicit-GEMM class
-    hipLaunchKernelGGL((dcn_fused64_kernel<64>), dim3((unsigned)((long long)B * ((H + 7) / 8) * ((W + 15) / 16)), N / 64), dim3(256), 0, s, x, om, w, bias,
-                       out, npix, H, W, C, N, relu);
+    // N >= 128: one workgroup computes 128 output channels from one gather + blend (the expensive half of the kernel)
+    // instead of two workgroups repeating it for 64 each (PT_DCN_NB=64: the 64-wide blocks everywhere)
+    static int nb128 = -1;
+    if (nb128 < 0) {
+      const char* ev = getenv("PT_DCN_NB");
+      nb128 = ev ? (atoi(ev) == 128) : 1;
+    }
+    const unsigned tiles = (unsigned)((long long)B * ((H + 7) / 8) * ((W + 15) / 16));
+    if (nb128 && N % 128 == 0)
+      hipLaunchKernelGGL((dcn_fused64_kernel<128>), dim3(tiles, N / 128), dim3(256), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
+    else
+      hipLaunchKernelGGL((dcn_fused64_kernel<64>), dim3(tiles, N / 64), dim3(256), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
     PT_HIP_CHECK(hipGetLastError());
     return PT_OK;
   }
