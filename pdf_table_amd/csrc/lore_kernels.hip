@@ -395,15 +395,20 @@ __global__ __launch_bounds__(256, (SPLIT || NB > 64) ? 2 : 4) void dcn_fused_ker
 #ifndef PT_DCN_ABL
 #define PT_DCN_ABL 0
 #endif
-template <int NB>
-__global__ __launch_bounds__(256, 2) void dcn_fused64_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
+// NTHR = 256 or 512 threads: with 512 a thread blends two (pixel, piece) items per stage instead of four and a wave owns
+// one 32-pixel x (NB / 2) block of the product -- the same arithmetic in the same order, ~100 VGPRs instead of ~190, so
+// that 16 waves per CU (instead of 8) keep gathers in flight.
+template <int NB, int NTHR>
+__global__ __launch_bounds__(NTHR, NTHR / 128) void dcn_fused64_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
                                                               const bf16_t* __restrict__ w, const float* __restrict__ bias,
                                                               bf16_t* __restrict__ out, long long npix, int H, int W,
                                                               int C, int N, int relu) {
 #pragma clang fp contract(fast)
   constexpr int ROW = 144;                      // 64 bf16 + 16 B pad
-  constexpr int NT = NB / 32;
-  constexpr int WP = NB * 8 / 256;              // 16-byte weight pieces per thread per stage
+  constexpr int IT = 1024 / NTHR;               // (pixel, 16-byte piece) items per thread per stage
+  constexpr int PSTEP = NTHR / 8;               // pixel distance between a thread's items
+  constexpr int WP = NB * 8 / NTHR;             // 16-byte weight pieces per thread per stage
+  constexpr int NT = NB * 8 / NTHR;             // 32-column tiles of the product per wave
   // sampling geometry of the tile, computed ONCE per (pixel, tap) -- the eight lanes that share a pixel used to redo it
   // every stage, which was half of the kernel's VALU time: element offsets of the four corners (-1 = outside the map),
   // their bilinear weights, and the sigmoid mask
@@ -438,17 +443,17 @@ __global__ __launch_bounds__(256, 2) void dcn_fused64_kernel(const bf16_t* __res
   const int n0 = blockIdx.y * NB;
   const int nss = C >> 6, nst = 9 * nss, nk = 9 * (C >> 5);
   const int piece = tid & 7, prow = tid >> 3;   // items: pixels prow + 32 j, j = 0..3, 16-byte piece `piece`
-  for (int i = tid; i < 128 * 7; i += 256) {     // 7 float4 per pixel (channels 0..27; 27 is padding)
+  for (int i = tid; i < 128 * 7; i += NTHR) {     // 7 float4 per pixel (channels 0..27; 27 is padding)
     int y, xq;
     locate(i / 7, y, xq);
     const long long pix = img0 + (long long)y * W + xq;
     *reinterpret_cast<float4*>(s_om + (i / 7) * 28 + (i % 7) * 4) = *reinterpret_cast<const float4*>(om + pix * 32 + (i % 7) * 4);
   }
-  const bf16_t* xb[4];
+  const bf16_t* xb[IT];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) xb[j] = x + (size_t)img0 * C + piece * 8;
+  for (int j = 0; j < IT; ++j) xb[j] = x + (size_t)img0 * C + piece * 8;
   __syncthreads();
-  for (int i = tid; i < 128 * 9; i += 256) {
+  for (int i = tid; i < 128 * 9; i += NTHR) {
     const int pl = i / 9, tap = i - pl * 9;
     int yh, xw;
     locate(pl, yh, xw);
@@ -481,15 +486,15 @@ __global__ __launch_bounds__(256, 2) void dcn_fused64_kernel(const bf16_t* __res
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  int coff[4][4];
-  float cwt[4][4], mask[4];
-  u32x4 rc[4][4];
+  int coff[IT][4];
+  float cwt[IT][4], mask[IT];
+  u32x4 rc[IT][4];
   u32x4 rw[WP];
 
   auto geometry = [&](int tap) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int gi = (prow + 32 * j) * 9 + tap;
+    for (int j = 0; j < IT; ++j) {
+      const int gi = (prow + PSTEP * j) * 9 + tap;
       const int4 o = *reinterpret_cast<const int4*>(s_goff[gi]);
       const float4 wv = *reinterpret_cast<const float4*>(s_gwt[gi]);
       coff[j][0] = o.x; coff[j][1] = o.y; coff[j][2] = o.z; coff[j][3] = o.w;
@@ -501,14 +506,14 @@ __global__ __launch_bounds__(256, 2) void dcn_fused64_kernel(const bf16_t* __res
     const int tap = st / nss, ss = st - tap * nss;
     if (ss == 0) geometry(tap);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < IT; ++j)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         rc[j][k] = u32x4{0u, 0u, 0u, 0u};
 #if PT_DCN_ABL == 1     /* ablation: no gather traffic */
         rc[j][k].x = (uint32_t)coff[j][k];
 #elif PT_DCN_ABL == 4   /* ablation: gather without the bounds predicate, always the pixel's own line */
-        rc[j][k] = *reinterpret_cast<const u32x4*>(xb[j] + ((size_t)(ty0 + ((prow + 32 * j) >> 4)) * W + tx0 + ((prow + 32 * j) & 15)) % ((size_t)H * W) * C + ss * 64);
+        rc[j][k] = *reinterpret_cast<const u32x4*>(xb[j] + ((size_t)(ty0 + ((prow + PSTEP * j) >> 4)) * W + tx0 + ((prow + PSTEP * j) & 15)) % ((size_t)H * W) * C + ss * 64);
 #else
         if (coff[j][k] >= 0) rc[j][k] = *reinterpret_cast<const u32x4*>(xb[j] + coff[j][k] + ss * 64);
 #endif
@@ -516,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void dcn_fused64_kernel(const bf16_t* __res
     const int kc = tap * (C >> 5) + 2 * ss;     // the stage's two 32-channel weight chunks are adjacent
 #pragma unroll
     for (int j = 0; j < WP; ++j) {
-      const int idx = tid + j * 256;            // row = idx >> 3, piece = idx & 7 (0..3: chunk kc, 4..7: chunk kc + 1)
+      const int idx = tid + j * NTHR;           // row = idx >> 3, piece = idx & 7 (0..3: chunk kc, 4..7: chunk kc + 1)
       const int row = idx >> 3, pc = idx & 7;
       rw[j] = *reinterpret_cast<const u32x4*>(wbase + (size_t)(row >> 6) * nk * (64 * 32) + (size_t)(kc + (pc >> 2)) * (64 * 32) +
                                               (row & 63) * 32 + (pc & 3) * 8);
@@ -524,9 +529,9 @@ __global__ __launch_bounds__(256, 2) void dcn_fused64_kernel(const bf16_t* __res
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < IT; ++j) {
 #if PT_DCN_ABL == 2     /* ablation: no blend arithmetic */
-      *reinterpret_cast<u32x4*>(s_a + (prow + 32 * j) * ROW + piece * 16) = rc[j][0] ^ rc[j][1] ^ rc[j][2] ^ rc[j][3];
+      *reinterpret_cast<u32x4*>(s_a + (prow + PSTEP * j) * ROW + piece * 16) = rc[j][0] ^ rc[j][1] ^ rc[j][2] ^ rc[j][3];
       continue;
 #endif
       const df2 w0 = {cwt[j][0], cwt[j][0]}, w1 = {cwt[j][1], cwt[j][1]}, w2 = {cwt[j][2], cwt[j][2]},
@@ -547,17 +552,18 @@ __global__ __launch_bounds__(256, 2) void dcn_fused64_kernel(const bf16_t* __res
         v = v * mk;
         o[e2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, db2));
       }
-      *reinterpret_cast<u32x4*>(s_a + (prow + 32 * j) * ROW + piece * 16) = u32x4{o[0], o[1], o[2], o[3]};
+      *reinterpret_cast<u32x4*>(s_a + (prow + PSTEP * j) * ROW + piece * 16) = u32x4{o[0], o[1], o[2], o[3]};
     }
 #pragma unroll
     for (int j = 0; j < WP; ++j) {
-      const int idx = tid + j * 256;
+      const int idx = tid + j * NTHR;
       *reinterpret_cast<u32x4*>(s_w + (idx >> 3) * ROW + (idx & 7) * 16) = rw[j];
     }
   };
 
-  const char* a_rd = s_a + (wave * 32 + lx) * ROW + q * 16;
-  const char* b_rd = s_w + lx * ROW + q * 16;
+  const int mt = wave & 3, ct0 = (wave >> 2) * NT;      // this wave's 32-pixel row tile and first 32-column tile
+  const char* a_rd = s_a + (mt * 32 + lx) * ROW + q * 16;
+  const char* b_rd = s_w + (ct0 * 32 + lx) * ROW + q * 16;
   prefetch(0);
   for (int st = 0; st < nst; ++st) {
     __syncthreads();
@@ -579,12 +585,12 @@ __global__ __launch_bounds__(256, 2) void dcn_fused64_kernel(const bf16_t* __res
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int n = n0 + t * 32 + lx;
+    const int n = n0 + (ct0 + t) * 32 + lx;
     const float bv = bias[n];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int y, xq;
-      if (!locate(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * q, y, xq)) continue;
+      if (!locate(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * q, y, xq)) continue;
       float v = acc[t][r] + bv;
       if (relu) v = fmaxf(v, 0.f);
       out[(size_t)(img0 + (long long)y * W + xq) * N + n] = (bf16_t)f2bf(v);
@@ -748,11 +754,20 @@ int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf
       const char* ev = getenv("PT_DCN_NB");
       nb128 = ev ? (atoi(ev) == 128) : 1;
     }
+    static int nthr = -1;          // PT_DCN_THREADS=256: four waves per workgroup (A/B switch)
+    if (nthr < 0) {
+      const char* ev = getenv("PT_DCN_THREADS");
+      nthr = ev ? atoi(ev) : 512;
+    }
     const unsigned tiles = (unsigned)((long long)B * ((H + 7) / 8) * ((W + 15) / 16));
-    if (nb128 && N % 128 == 0)
-      hipLaunchKernelGGL((dcn_fused64_kernel<128>), dim3(tiles, N / 128), dim3(256), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
-    else
-      hipLaunchKernelGGL((dcn_fused64_kernel<64>), dim3(tiles, N / 64), dim3(256), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
+    if (nb128 && N % 128 == 0) {     // 128-wide blocks stay at 4 waves: with 8 they need 136 VGPRs (> 128: spills), measured 1 % slower
+
+      hipLaunchKernelGGL((dcn_fused64_kernel<128, 256>), dim3(tiles, N / 128), dim3(256), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
+    } else if (nthr == 512) {
+      hipLaunchKernelGGL((dcn_fused64_kernel<64, 512>), dim3(tiles, N / 64), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
+    } else {
+      hipLaunchKernelGGL((dcn_fused64_kernel<64, 256>), dim3(tiles, N / 64), dim3(256), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
+    }
     PT_HIP_CHECK(hipGetLastError());
     return PT_OK;
   }
