@@ -1212,8 +1212,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_kernel(ConvK p) {
 // Thin stride-1 stem (DLA-34 base_layer: 3 -> 16 channels at full resolution, bf16 mode).  conv_stem7x7_kernel<1,1> spends
 // most of its time around the MFMAs: every 8x32-pixel workgroup re-loads the 29 KB weight image from L2 (3.7 GB per
 // 32 tables) and sends 256 x 64 fp32 through LDS to store 16 channels.  Here a workgroup walks STEM_NT tiles of a row
-// strip with the 32 computed weight rows staged once, and the epilogue is done from the accumulators: lane = channel,
-// registers = 16 pixels, bias + ReLU, 2-byte stores (the 16 lanes of a pixel write its 32 contiguous bytes).
+// strip with the 32 computed weight rows staged once, and the epilogue is done from the accumulators: the MFMA runs with
+// the weights as its A operand, so a lane owns one pixel and stores its channels as 8-byte runs of four.
 // ---------------------------------------------------------------------------------------------------
 constexpr int STEM_NT = 8;
 
@@ -1236,7 +1236,6 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_thin_kernel(ConvK p) {
     const int row = idx / 28, part = idx - row * 28;
     *reinterpret_cast<u32x4*>(s_w + row * C::WROW + part * 16) = *reinterpret_cast<const u32x4*>(p.w + (size_t)idx * 8);
   }
-  const float bv = lx < p.n_valid ? p.bias[lx] : 0.f;
   const char* a_base = s_in + ((wave * 2) * C::TWIN + lx + 2 * q) * 8;
   const char* b_base = s_w + lx * C::WROW + q * 16;
   for (int it = 0; it < STEM_NT; ++it) {
@@ -1266,6 +1265,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_thin_kernel(ConvK p) {
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    // weights as the A operand: D is [channel][pixel] -- a lane owns one pixel, its accumulators are 4-channel runs
 #pragma unroll
     for (int r = 0; r < 7; ++r) {
 #pragma unroll
@@ -1276,20 +1276,25 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_thin_kernel(ConvK p) {
           const char* ap = a_base + ((m + r) * C::TWIN + 4 * h) * 8;
           const u32x2 lo = *reinterpret_cast<const u32x2*>(ap), hi = *reinterpret_cast<const u32x2*>(ap + 8);
           const u32x4 av = {lo.x, lo.y, hi.x, hi.y};
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), b0, acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, __builtin_bit_cast(bf16x8, av), acc[m], 0, 0, 0);
         }
       }
     }
-    if (lx < p.n_valid) {
+    const int ox = ox0 + lx;
+    if (ox < p.Wo) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         const int oy = oy0 + wave * 2 + m;
         if (oy >= p.Ho) continue;
-        bf16_t* orow = p.out + ((size_t)b * p.Ho + oy) * p.Wo * p.out_cstride + lx;
+        bf16_t* op = p.out + (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.out_cstride;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * q;
-          if (ox < p.Wo) orow[(size_t)ox * p.out_cstride] = (bf16_t)f32_to_bf16(fmaxf(acc[m][r] + bv, 0.f));
+        for (int rg = 0; rg < 4; ++rg) {
+          const int ch = 8 * rg + 4 * q;
+          if (ch >= p.n_valid) continue;
+          const f32x4 bs = *reinterpret_cast<const f32x4*>(p.bias + ch);
+          const uint32_t h0 = f32_to_bf16(fmaxf(acc[m][rg * 4 + 0] + bs.x, 0.f)), h1 = f32_to_bf16(fmaxf(acc[m][rg * 4 + 1] + bs.y, 0.f)),
+                         h2 = f32_to_bf16(fmaxf(acc[m][rg * 4 + 2] + bs.z, 0.f)), h3 = f32_to_bf16(fmaxf(acc[m][rg * 4 + 3] + bs.w, 0.f));
+          *reinterpret_cast<u32x2*>(op + ch) = u32x2{h0 | (h1 << 16), h2 | (h3 << 16)};
         }
       }
     }

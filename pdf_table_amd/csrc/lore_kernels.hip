@@ -646,8 +646,10 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const bf16_t* __restri
     wh[t] = *reinterpret_cast<const dbf16x8*>(w + ((size_t)t * 32 + lx) * 16 + q * 8);
     if (SPLIT) wl[t] = *reinterpret_cast<const dbf16x8*>(w + (size_t)9 * 32 * 16 + ((size_t)t * 32 + lx) * 16 + q * 8);
   }
-  const float bv = bias[lx];
   __syncthreads();
+  // The MFMA runs with the weights as its A operand: D is [channel][pixel], i.e. a lane owns ONE pixel and its
+  // accumulators are runs of four consecutive channels (rows (r & 3) + 8 (r >> 2) + 4 q) -- 8-byte stores from every lane
+  // instead of 2-byte stores from the 16 or 32 lanes that hold a valid channel.
 #pragma unroll
   for (int rr = 0; rr < RPW; ++rr) {
     const int ty = wave * RPW + rr;
@@ -661,26 +663,34 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const bf16_t* __restri
       for (int t = 0; t < 9; ++t) {
         const int off = ((ty * STRIDE + t / 3) * PW + tx * STRIDE + t % 3) * PITCH + q * 16;
         const dbf16x8 ah = *reinterpret_cast<const dbf16x8*>(s_in[0] + off);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh[t], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[t], ah, acc, 0, 0, 0);
         if (SPLIT) {
           const dbf16x8 al = *reinterpret_cast<const dbf16x8*>(s_in[NP - 1] + off);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh[t], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl[t], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[t], al, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[t], ah, acc, 0, 0, 0);
         }
       }
-      // D[row = pixel (r & 3) + 8 (r >> 2) + 4 q][col = channel lx]
-      const int oy = oy0 + ty;
-      if (oy < Ho && lx < N) {
+      const int oy = oy0 + ty, ox = ox0 + tx;
+      if (oy < Ho && ox < Wo) {
         const int ocs = SPLIT ? 2 * N : N;
+        bf16_t* op = out + (((size_t)b * Ho + oy) * Wo + ox) * ocs;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ox = ox0 + half * 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
-          if (ox >= Wo) continue;
-          const float v = fmaxf(acc[r] + bv, 0.f);
-          const uint32_t hb = f2bf(v);
-          bf16_t* op = out + (((size_t)b * Ho + oy) * Wo + ox) * ocs + lx;
-          op[0] = (bf16_t)hb;
-          if (SPLIT) op[N] = (bf16_t)f2bf(v - bf2f(hb));
+        for (int rg = 0; rg < 4; ++rg) {
+          const int ch = 8 * rg + 4 * q;
+          if (ch >= N) continue;
+          const float4 bs = *reinterpret_cast<const float4*>(bias + ch);
+          const float v[4] = {fmaxf(acc[rg * 4 + 0] + bs.x, 0.f), fmaxf(acc[rg * 4 + 1] + bs.y, 0.f),
+                              fmaxf(acc[rg * 4 + 2] + bs.z, 0.f), fmaxf(acc[rg * 4 + 3] + bs.w, 0.f)};
+          uint32_t hb[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) hb[k] = f2bf(v[k]);
+          *reinterpret_cast<uint2*>(op + ch) = make_uint2(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16));
+          if (SPLIT) {
+            uint32_t lb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lb[k] = f2bf(v[k] - bf2f(hb[k]));
+            *reinterpret_cast<uint2*>(op + N + ch) = make_uint2(lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16));
+          }
         }
       }
     }
