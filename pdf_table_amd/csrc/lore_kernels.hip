@@ -579,22 +579,27 @@ __global__ __launch_bounds__(NTHR, NTHR / 128) void dcn_fused64_kernel(const bf1
 #if PT_DCN_ABL == 3     /* ablation: one MFMA per stage instead of eight */
         if (kk == 0 && t == 0)
 #endif
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc[t], 0, 0, 0);   // D = [channel][pixel]
       }
     }
   }
+  // weights were the MFMA's A operand: a lane owns pixel mt * 32 + lx, its accumulators are runs of four channels
+  int y, xq;
+  if (locate(mt * 32 + lx, y, xq)) {
+    bf16_t* op = out + (size_t)(img0 + (long long)y * W + xq) * N + n0 + ct0 * 32;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int n = n0 + (ct0 + t) * 32 + lx;
-    const float bv = bias[n];
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int y, xq;
-      if (!locate(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * q, y, xq)) continue;
-      float v = acc[t][r] + bv;
-      if (relu) v = fmaxf(v, 0.f);
-      out[(size_t)(img0 + (long long)y * W + xq) * N + n] = (bf16_t)f2bf(v);
-    }
+      for (int rg = 0; rg < 4; ++rg) {
+        const int ch = t * 32 + 8 * rg + 4 * q;
+        const float4 bs = *reinterpret_cast<const float4*>(bias + n0 + ct0 * 32 + ch);
+        float v[4] = {acc[t][rg * 4 + 0] + bs.x, acc[t][rg * 4 + 1] + bs.y, acc[t][rg * 4 + 2] + bs.z, acc[t][rg * 4 + 3] + bs.w};
+        if (relu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        *reinterpret_cast<uint2*>(op + ch) = make_uint2(f2bf(v[0]) | (f2bf(v[1]) << 16), f2bf(v[2]) | (f2bf(v[3]) << 16));
+      }
   }
 }
 
