@@ -36,23 +36,39 @@ __global__ __launch_bounds__(256) void lore_peaks_kernel(const float* __restrict
                                                           float thr_corner, unsigned long long* __restrict__ keys,
                                                           int* __restrict__ counts) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)B * H * W) return;
-  const int x = (int)(i % W), y = (int)((i / W) % H), b = (int)(i / ((long long)W * H));
+  const bool live = i < (long long)B * H * W;
+  const long long ic = live ? i : 0;
+  const int x = (int)(ic % W), y = (int)((ic / W) % H), b = (int)(ic / ((long long)W * H));
   const float* sb = sig + (size_t)b * H * W * 2;
+  const bool uniform = ((long long)H * W) % 64 == 0;      // a wave never straddles two tables: one counter per wave
   for (int cls = 0; cls < 2; ++cls) {
     const float s = sb[((size_t)y * W + x) * 2 + cls];
-    if (!(s >= (cls ? thr_corner : thr_cell))) continue;
-    bool peak = true;
-    for (int dy = -1; dy <= 1 && peak; ++dy)
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int yy = y + dy, xx = x + dx;
-        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-        if (sb[((size_t)yy * W + xx) * 2 + cls] > s) { peak = false; break; }
-      }
-    if (!peak) continue;
+    bool peak = live && (s >= (cls ? thr_corner : thr_cell));
+    if (peak) {
+      for (int dy = -1; dy <= 1 && peak; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int yy = y + dy, xx = x + dx;
+          if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+          if (sb[((size_t)yy * W + xx) * 2 + cls] > s) { peak = false; break; }
+        }
+    }
     const int list = b * 2 + cls;
-    const int slot = atomicAdd(&counts[list], 1);
-    if (slot < CAP)
+    int slot = -1;
+    if (uniform) {
+      // plateaus of equal scores make every pixel of them a peak: thousands of appends per list -- one atomic per
+      // wave instead of one per pixel (the order inside a list is irrelevant, it is sorted next)
+      const unsigned long long m = __ballot(peak);
+      if (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        int base = 0;
+        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&counts[list], __popcll(m));
+        base = __shfl(base, leader);
+        if (peak) slot = base + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+      }
+    } else if (peak) {
+      slot = atomicAdd(&counts[list], 1);
+    }
+    if (peak && slot < CAP)
       keys[(size_t)list * CAP + slot] = ((unsigned long long)__float_as_uint(s) << 32) |
                                         (unsigned long long)(0xFFFFFFFFu - (unsigned)(y * W + x));
   }
