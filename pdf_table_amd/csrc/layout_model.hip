@@ -34,6 +34,7 @@ struct Ctx {
   bool dry, ok;
   int rc;
   float* gate = nullptr;
+  float* part = nullptr;      // PT_SE_CHUNKS * n * 512 floats: two-level average pool of the SE blocks (null: single-workgroup scan)
   const char* what = "PicoDet";
 
   T alloc(int H, int W, int C) {
@@ -146,7 +147,7 @@ T lcnet_backbone(Ctx& c, const bf16_t* x, int H, int W, const int* stage_stride,
       T g = c.alloc(d.H, d.W, d.C);
       if (c.go()) {
         PtProfScope ps(e, s, PT_PROF_OTHER, 0, "lcnet SE");
-        const int r = pt_launch_se(d.p, c.F(w1), c.F(b1), c.F(w2), c.F(b2), c.gate, g.p, n, d.H * d.W, d.C, c.x3, s, d.C / 4, 0, nullptr);
+        const int r = pt_launch_se(d.p, c.F(w1), c.F(b1), c.F(w2), c.F(b2), c.gate, g.p, n, d.H * d.W, d.C, c.x3, s, d.C / 4, 0, c.part);
         if (r != PT_OK) c.rc = r;
       }
       d = g;
@@ -186,7 +187,8 @@ int pt_picodet_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, f
     c.ok = true;
     e->arena.reset();
     c.gate = reinterpret_cast<float*>(e->arena.take((size_t)n * 512 * sizeof(float)));
-    if (!c.gate) c.ok = false;
+    c.part = reinterpret_cast<float*>(e->arena.take((size_t)n * PT_SE_CHUNKS * 512 * sizeof(float)));
+    if (!c.gate || !c.part) c.ok = false;
     T feats[3];
     lcnet_backbone(c, x, H, W, st22, feats);
     // ---- CSP-PAN (csp_pan.py:305-345)
@@ -272,6 +274,7 @@ int pt_pplcnet_forward_net(pt_engine* e, int slot, const bf16_t* x, int n, int H
     e->arena.reset();
     c.gate = reinterpret_cast<float*>(e->arena.take((size_t)n * 512 * sizeof(float)));
     float* part = reinterpret_cast<float*>(e->arena.take((size_t)n * PT_SE_CHUNKS * 512 * sizeof(float)));
+    c.part = part;
     if (!c.gate || !part) c.ok = false;
     T feats[3];
     T t = lcnet_backbone(c, x, H, W, textline ? st21 : st22, feats);
