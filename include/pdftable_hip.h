@@ -249,10 +249,11 @@ int pt_tsr_decode(pt_engine* e, const float* d_hm, const float* d_st, const floa
                   int32_t* d_counts, float* d_dets, float* d_logi, pt_stream stream);
 
 /* pt_tsr_forward_net + pt_tsr_decode in one call for the DLA-34 detector (PT_MODEL_LORE_DLA34), same outputs as
- * pt_tsr_decode.  The decode reads the two 256-channel head maps `ax` and `cr` only at the kept cells' centres and corner
- * pixels (lineless_table_process.py:254-263, _get_4ps_feat :39-63), so here those two heads run on 3x3-pixel patches
- * around exactly these positions instead of on the whole map; every value that is read is produced by the same kernels
- * in the same order as in the dense map (results are bit-identical to the two-call path). */
+ * pt_tsr_decode.  Of the six head maps the decode needs only `hm` everywhere: `reg` / `wh` / `st` are read at the kept
+ * peaks (<= 3000 cells + 5000 corners per table, lineless_table_process.py:127-177), `ax` / `cr` at the final cells'
+ * centres and corner pixels (:254-263, _get_4ps_feat :39-63).  Here those five heads run on 3x3-pixel patches around
+ * exactly these positions instead of on the whole map; every value that is read is produced by the same kernels in the
+ * same order as in the dense map (bit-identical to the two-call path when both use one conv kernel family). */
 int pt_tsr_forward_decode(pt_engine* e, const uint16_t* d_input_bf16, int n, int in_h, int in_w, int wiz_rev,
                           float vis_thresh, int32_t* d_counts, float* d_dets, float* d_logi, pt_stream stream);
 

@@ -214,10 +214,13 @@ int pt_launch_pico_candidates(const float* head, int B, int A, int ncls, int lev
 int pt_lore_decode(pt_engine* e, const float* hm, const float* st, const float* wh, const float* ax, const float* cr,
                    const float* reg, int B, int H, int W, int wiz_rev, float vis_thresh, int* d_counts, float* d_dets,
                    float* d_logi, hipStream_t s);
-void pt_lore_mosaic_rows(int B, int* rows_ax, int* rows_cr);
-int pt_lore_decode_front(pt_engine* e, const float* hm, const float* st, const float* wh, const float* reg, int B, int H, int W,
-                         int wiz_rev, float vis_thresh, int* d_counts, const int** d_lim_ax, const int** d_lim_cr,
-                         hipStream_t s);
+void pt_lore_mosaic_rows(int B, int* rows_ax, int* rows_cr, int* rows_cell, int* rows_corner);
+int pt_lore_decode_peaks(pt_engine* e, const float* hm, int B, int H, int W, int wiz_rev, float vis_thresh, int* d_counts,
+                         const int** d_lim_cell, const int** d_lim_corner, hipStream_t s);
+int pt_lore_peak_patches(pt_engine* e, const bf16_t* feat, int B, int H, int W, int C, int split, bf16_t* mos_cell,
+                         bf16_t* mos_corner, hipStream_t s);
+int pt_lore_decode_boxes(pt_engine* e, const float* reg_cell, const float* wh, const float* reg_corner, const float* st, int B,
+                         int H, int W, const int** d_lim_ax, const int** d_lim_cr, hipStream_t s);
 int pt_lore_patch_gather(pt_engine* e, const bf16_t* feat, int B, int H, int W, int C, int split, bf16_t* mos_ax, bf16_t* mos_cr,
                          hipStream_t s);
 int pt_lore_decode_sparse(pt_engine* e, const float* ax_mos, const float* cr_mos, int B, int H, int W, float vis_thresh,

@@ -108,19 +108,25 @@ __global__ __launch_bounds__(1024) void lore_sort_kernel(const unsigned long lon
 }
 
 // boxes[(list, k)][0..7] = centre - offsets, [8] = score, [9] = centre x, [10] = centre y, [11] = pixel index
+__device__ __forceinline__ size_t mosaic_centre(long long j);
+
+// reg0 / reg1: the `reg` head for the cell / corner lists, wh, st: dense maps [B,H,W,8] -- or, when pk_base is given, the
+// head outputs on the peak-patch mosaics (patch pk_base[list] + k, value at its centre pixel)
 __global__ __launch_bounds__(256) void lore_boxes_kernel(const unsigned long long* __restrict__ sorted,
                                                           const int* __restrict__ counts, int stride, int B, int H, int W,
-                                                          const float* __restrict__ reg, const float* __restrict__ wh,
-                                                          const float* __restrict__ st, float* __restrict__ boxes) {
+                                                          const float* __restrict__ reg0, const float* __restrict__ reg1,
+                                                          const float* __restrict__ wh, const float* __restrict__ st,
+                                                          const int* __restrict__ pk_base, float* __restrict__ boxes) {
   const int list = blockIdx.y, b = list >> 1, cls = list & 1;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= counts[list]) return;
   const unsigned long long key = sorted[(size_t)list * stride + k];
   const int idx = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
   const float score = __uint_as_float((unsigned)(key >> 32));
-  const size_t pix = (size_t)b * H * W + idx;
-  const float xs = (float)(idx % W) + reg[pix * 8 + 0];
-  const float ys = (float)(idx / W) + reg[pix * 8 + 1];
+  const size_t pix = pk_base ? mosaic_centre((long long)pk_base[list] + k) : (size_t)b * H * W + idx;
+  const float* rg = (cls ? reg1 : reg0) + pix * 8;
+  const float xs = (float)(idx % W) + rg[0];
+  const float ys = (float)(idx / W) + rg[1];
   const float* off = (cls ? st : wh) + pix * 8;
   float* o = boxes + ((size_t)list * stride + k) * 12;
 #pragma unroll
@@ -254,6 +260,43 @@ __global__ void lore_sparse_base_kernel(const int* __restrict__ counts, int B, i
   lim[1] = (int)(3 * ((4 * t + MOS_PW - 1) / MOS_PW));
 }
 
+// the same for the kept peaks of the first sort: pk_base[2 b + cls] = number of kept peaks of class cls in the tables
+// before b; lim[0] / lim[1] = pixel rows of the cell / corner mosaic that hold patches
+__global__ void lore_peak_base_kernel(const int* __restrict__ kept, int B, int* __restrict__ pk_base, int* __restrict__ lim) {
+  if (threadIdx.x || blockIdx.x) return;
+  long long t0 = 0, t1 = 0;
+  for (int b = 0; b < B; ++b) {
+    pk_base[2 * b] = (int)t0;
+    pk_base[2 * b + 1] = (int)t1;
+    t0 += kept[2 * b];
+    t1 += kept[2 * b + 1];
+  }
+  lim[0] = (int)(3 * ((t0 + MOS_PW - 1) / MOS_PW));
+  lim[1] = (int)(3 * ((t1 + MOS_PW - 1) / MOS_PW));
+}
+
+// 3x3 neighbourhoods of the kept peaks (cells and corners, in sorted order) -> the cell / corner patch mosaics
+__global__ __launch_bounds__(64) void lore_peak_patch_kernel(const unsigned long long* __restrict__ sorted,
+                                                             const int* __restrict__ kept, int stride, int H, int W,
+                                                             const bf16_t* __restrict__ feat, int C, int split,
+                                                             const int* __restrict__ pk_base, bf16_t* __restrict__ mos_cell,
+                                                             bf16_t* __restrict__ mos_corner) {
+  const int list = blockIdx.y, b = list >> 1, cls = list & 1, k = blockIdx.x;
+  if (k >= kept[list]) return;
+  const int idx = (int)(0xFFFFFFFFu - (unsigned)(sorted[(size_t)list * stride + k] & 0xFFFFFFFFull));
+  const int cs = split ? 2 * C : C, ppx = cs / 8;
+  const long long pj = (long long)pk_base[list] + k;
+  bf16_t* mos = cls ? mos_corner : mos_cell;
+  for (int i = threadIdx.x; i < 9 * ppx; i += 64) {
+    const int piece = i % ppx, tap = i / ppx;
+    const int y = idx / W + tap / 3 - 1, x = idx % W + tap % 3 - 1;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+      v = *reinterpret_cast<const uint4*>(feat + (((size_t)b * H + y) * W + x) * cs + piece * 8);
+    *reinterpret_cast<uint4*>(mos + ((size_t)(3 * (pj / MOS_PW) + tap / 3) * (3 * MOS_PW) + 3 * (pj % MOS_PW) + tap % 3) * cs + piece * 8) = v;
+  }
+}
+
 // The 3x3 neighbourhoods (zero outside the map) of the five feature-map positions lore_gather_kernel reads for output
 // row p of table b -- the cell's centre for `ax`, its four corner pixels for `cr` -- copied into the two patch mosaics.
 // feat: bf16 [B,H,W,C] ([hi | lo] halves when split).  One workgroup per (p, b), 16-byte pieces.
@@ -350,17 +393,20 @@ __global__ __launch_bounds__(256) void lore_gather_kernel(const float* __restric
 
 }  // namespace
 
-// Scratch layout (engine-owned): sig f32 [B*H*W*2] | counts int [4B] | keys u64 [2B*CAP] | sorted u64 [2B*CAP] |
-// boxes f32 [2B*CAP*12] | rev f32 [B*CAP*12] | keys2/sorted2 u64 [B*CAP] each | sparse base int [B] + limits int [2]
+// Scratch layout (engine-owned): sig f32 [B*H*W*2] | counts int [5B] | keys u64 [2B*CAP] | sorted u64 [2B*CAP] |
+// boxes f32 [2B*CAP*12] | rev f32 [B*CAP*12] | keys2/sorted2 u64 [B*CAP] each | sparse bases / limits int [3B + 4]
 struct DecodeState {
   int* cnt;
+  unsigned long long *sorted, *keys2, *sorted2;
   float *boxes, *rev;
-  unsigned long long* sorted2;
-  int *sp_base, *sp_lim;
+  int *sp_base, *sp_lim;      // final-order cells: base per table, row limits of the ax / cr mosaics
+  int *pk_base, *pk_lim;      // kept peaks: base per (table, class), row limits of the cell / corner mosaics
+  int wiz_rev;
 };
 
-static int decode_front(pt_engine* e, const float* hm, const float* st, const float* wh, const float* reg, int B, int H, int W,
-                        int wiz_rev, float vis_thresh, int* d_counts, DecodeState* ds, hipStream_t s) {
+// sigmoid, peak test, first sort: the kept cells / corners of every table in score order
+static int decode_peaks(pt_engine* e, const float* hm, int B, int H, int W, int wiz_rev, float vis_thresh, int* d_counts,
+                        DecodeState* ds, hipStream_t s) {
   PT_REQUIRE((long long)H * W < (1ll << 31), "tsr decode: map too large");
   const size_t npix = (size_t)B * H * W;
   size_t off = 0;
@@ -368,7 +414,7 @@ static int decode_front(pt_engine* e, const float* hm, const float* st, const fl
   const size_t o_sig = carve(npix * 2 * 4), o_cnt = carve((size_t)B * 5 * 4), o_keys = carve((size_t)2 * B * CAP * 8),
                o_sorted = carve((size_t)2 * B * CAP * 8), o_boxes = carve((size_t)2 * B * CAP * 12 * 4),
                o_rev = carve((size_t)B * CAP * 12 * 4), o_keys2 = carve((size_t)B * CAP * 8),
-               o_sorted2 = carve((size_t)B * CAP * 8), o_sp = carve((size_t)(B + 2) * 4);
+               o_sorted2 = carve((size_t)B * CAP * 8), o_sp = carve((size_t)(3 * B + 4) * 4);
   if (off > e->tsr_scratch_cap) {
     PT_HIP_CHECK(hipDeviceSynchronize());
     if (e->tsr_scratch) PT_HIP_CHECK(hipFree(e->tsr_scratch));
@@ -380,11 +426,17 @@ static int decode_front(pt_engine* e, const float* hm, const float* st, const fl
   float* sig = reinterpret_cast<float*>(base + o_sig);
   int* cnt = reinterpret_cast<int*>(base + o_cnt);   // [0,2B): raw peak counts, [2B,4B): kept counts, [4B,5B): dump
   auto* keys = reinterpret_cast<unsigned long long*>(base + o_keys);
-  auto* sorted = reinterpret_cast<unsigned long long*>(base + o_sorted);
-  float* boxes = reinterpret_cast<float*>(base + o_boxes);
-  float* rev = reinterpret_cast<float*>(base + o_rev);
-  auto* keys2 = reinterpret_cast<unsigned long long*>(base + o_keys2);
-  auto* sorted2 = reinterpret_cast<unsigned long long*>(base + o_sorted2);
+  ds->cnt = cnt;
+  ds->sorted = reinterpret_cast<unsigned long long*>(base + o_sorted);
+  ds->boxes = reinterpret_cast<float*>(base + o_boxes);
+  ds->rev = wiz_rev ? reinterpret_cast<float*>(base + o_rev) : nullptr;
+  ds->keys2 = reinterpret_cast<unsigned long long*>(base + o_keys2);
+  ds->sorted2 = wiz_rev ? reinterpret_cast<unsigned long long*>(base + o_sorted2) : nullptr;
+  ds->sp_base = reinterpret_cast<int*>(base + o_sp);
+  ds->sp_lim = ds->sp_base + B;
+  ds->pk_base = ds->sp_lim + 2;
+  ds->pk_lim = ds->pk_base + 2 * B;
+  ds->wiz_rev = wiz_rev;
   static bool attr_done = false;
   if (!attr_done) {
     PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lore_sort_kernel),
@@ -398,20 +450,26 @@ static int decode_front(pt_engine* e, const float* hm, const float* st, const fl
   // vis_thresh can never reach the output, whatever the snap does
   hipLaunchKernelGGL(lore_peaks_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, sig, B, H, W, vis_thresh,
                      0.3f, keys, cnt);
-  hipLaunchKernelGGL(lore_sort_kernel, dim3(2 * B), dim3(1024), CAP * 8, s, keys, cnt, 1, CAP, K_CELLS, K_CORNERS, sorted,
+  hipLaunchKernelGGL(lore_sort_kernel, dim3(2 * B), dim3(1024), CAP * 8, s, keys, cnt, 1, CAP, K_CELLS, K_CORNERS, ds->sorted,
                      CAP, cnt + 2 * B);
-  hipLaunchKernelGGL(lore_boxes_kernel, dim3((K_CORNERS + 255) / 256, 2 * B), dim3(256), 0, s, sorted, cnt + 2 * B, CAP, B,
-                     H, W, reg, wh, st, boxes);
-  if (wiz_rev) {
-    hipLaunchKernelGGL(lore_snap_kernel, dim3(K_CELLS, B), dim3(64), 0, s, boxes, cnt + 2 * B, CAP, rev);
-    hipLaunchKernelGGL(lore_rekey_kernel, dim3((K_CELLS + 255) / 256, B), dim3(256), 0, s, rev, cnt + 2 * B, CAP, keys2);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// boxes from the reg / wh / st heads (dense maps, or their values on the peak-patch mosaics), vertex snapping, final order
+static int decode_boxes(const DecodeState* ds, const float* reg0, const float* reg1, const float* wh, const float* st,
+                        bool sparse, int B, int H, int W, hipStream_t s) {
+  int* cnt = ds->cnt;
+  hipLaunchKernelGGL(lore_boxes_kernel, dim3((K_CORNERS + 255) / 256, 2 * B), dim3(256), 0, s, ds->sorted, cnt + 2 * B, CAP, B,
+                     H, W, reg0, reg1, wh, st, sparse ? (const int*)ds->pk_base : (const int*)nullptr, ds->boxes);
+  if (ds->wiz_rev) {
+    hipLaunchKernelGGL(lore_snap_kernel, dim3(K_CELLS, B), dim3(64), 0, s, ds->boxes, cnt + 2 * B, CAP, ds->rev);
+    hipLaunchKernelGGL(lore_rekey_kernel, dim3((K_CELLS + 255) / 256, B), dim3(256), 0, s, ds->rev, cnt + 2 * B, CAP, ds->keys2);
     // one list per table; its length is the kept cell count (the even entries of the kept counts)
-    hipLaunchKernelGGL(lore_sort_kernel, dim3(B), dim3(1024), CAP * 8, s, keys2, cnt + 2 * B, 2, CAP, K_CELLS, K_CELLS,
-                       sorted2, CAP, cnt + 4 * B);
+    hipLaunchKernelGGL(lore_sort_kernel, dim3(B), dim3(1024), CAP * 8, s, ds->keys2, cnt + 2 * B, 2, CAP, K_CELLS, K_CELLS,
+                       ds->sorted2, CAP, cnt + 4 * B);
   }
   PT_HIP_CHECK(hipGetLastError());
-  ds->cnt = cnt; ds->boxes = boxes; ds->rev = wiz_rev ? rev : nullptr; ds->sorted2 = wiz_rev ? sorted2 : nullptr;
-  ds->sp_base = reinterpret_cast<int*>(base + o_sp); ds->sp_lim = ds->sp_base + B;
   return PT_OK;
 }
 
@@ -421,7 +479,8 @@ int pt_lore_decode(pt_engine* e, const float* hm, const float* st, const float* 
   PT_REQUIRE(hm && st && wh && ax && cr && reg && d_counts && d_dets && d_logi && B > 0, "tsr decode: null pointer");
   PtProfScope ps(e, s, PT_PROF_OTHER, 0, "tsr decode");
   DecodeState ds;
-  int rc = decode_front(e, hm, st, wh, reg, B, H, W, wiz_rev, vis_thresh, d_counts, &ds, s);
+  int rc = decode_peaks(e, hm, B, H, W, wiz_rev, vis_thresh, d_counts, &ds, s);
+  if (rc == PT_OK) rc = decode_boxes(&ds, reg, reg, wh, st, false, B, H, W, s);
   if (rc != PT_OK) return rc;
   hipLaunchKernelGGL(lore_gather_kernel, dim3(K_CELLS, B), dim3(256), 0, s, ds.rev, ds.boxes, ds.sorted2, ds.cnt + 2 * B, CAP, H,
                      W, ax, cr, vis_thresh, d_dets, d_logi, d_counts, (const int*)nullptr);
@@ -429,27 +488,54 @@ int pt_lore_decode(pt_engine* e, const float* hm, const float* st, const float* 
   return PT_OK;
 }
 
-// ---- sparse `ax` / `cr` heads: the decode only ever reads those two 256-channel maps at the kept cells' centres and
-// corner pixels (<= 5 x 3000 positions of 65 536 per table), so the fused forward+decode evaluates the two heads on
-// 3x3-pixel patches around exactly those positions instead of on the whole map.  Three steps around the head launches:
-//   pt_lore_decode_front   everything up to the final cell order + the patch mosaics' row limits
-//   pt_lore_patch_gather   feature-map neighbourhoods -> mosaics [3 * rows][768][C]
-//   pt_lore_decode_sparse  dets + logic features from the head outputs on the mosaics
+// ---- sparse heads.  Of the six head maps the decode needs only `hm` everywhere: `reg`, `wh`, `st` are read at the kept
+// peaks (<= 3000 cells + 5000 corners per table), `ax` / `cr` at the final cells' centres and corner pixels (<= 5 x 3000
+// positions).  The fused forward+decode therefore evaluates five heads on 3x3-pixel patches around exactly those
+// positions, in two rounds around the head launches (lore_model.hip):
+//   pt_lore_decode_peaks    sigmoid, peaks, first sort + row limits of the cell / corner mosaics
+//   pt_lore_peak_patches    feature-map neighbourhoods of the kept peaks -> mosaics [3 * rows][768][C]
+//   pt_lore_decode_boxes    boxes from the wh / st / reg outputs on the mosaics, snapping, final order + limits of round two
+//   pt_lore_patch_gather    neighbourhoods of the final cells' centres / corners -> the ax / cr mosaics
+//   pt_lore_decode_sparse   dets + logic features from the ax / cr outputs on the mosaics
 // A patch's centre pixel sees only its own 3x3 pixels, through the same conv kernels in the same order as in the dense
-// map: the features are bit-identical to pt_lore_decode's (tests/test_gpu_tsr.py).
-void pt_lore_mosaic_rows(int B, int* rows_ax, int* rows_cr) {
+// map: with one conv kernel family the results are bit-identical to pt_lore_decode's (tests/test_gpu_tsr.py).
+void pt_lore_mosaic_rows(int B, int* rows_ax, int* rows_cr, int* rows_cell, int* rows_corner) {
   *rows_ax = 3 * (((long long)B * K_CELLS + MOS_PW - 1) / MOS_PW);
   *rows_cr = 3 * (((long long)B * K_CELLS * 4 + MOS_PW - 1) / MOS_PW);
+  *rows_cell = *rows_ax;
+  *rows_corner = 3 * (((long long)B * K_CORNERS + MOS_PW - 1) / MOS_PW);
 }
 
-static DecodeState g_ds;        // state of the front half, consumed by the two calls that follow it on the same stream
+static DecodeState g_ds;        // state of the earlier steps, consumed by the calls that follow on the same stream
 
-int pt_lore_decode_front(pt_engine* e, const float* hm, const float* st, const float* wh, const float* reg, int B, int H, int W,
-                         int wiz_rev, float vis_thresh, int* d_counts, const int** d_lim_ax, const int** d_lim_cr,
-                         hipStream_t s) {
-  PT_REQUIRE(hm && st && wh && reg && d_counts && B > 0, "tsr decode front: null pointer");
+int pt_lore_decode_peaks(pt_engine* e, const float* hm, int B, int H, int W, int wiz_rev, float vis_thresh, int* d_counts,
+                         const int** d_lim_cell, const int** d_lim_corner, hipStream_t s) {
+  PT_REQUIRE(hm && d_counts && B > 0, "tsr decode peaks: null pointer");
   PtProfScope ps(e, s, PT_PROF_OTHER, 0, "tsr decode");
-  int rc = decode_front(e, hm, st, wh, reg, B, H, W, wiz_rev, vis_thresh, d_counts, &g_ds, s);
+  int rc = decode_peaks(e, hm, B, H, W, wiz_rev, vis_thresh, d_counts, &g_ds, s);
+  if (rc != PT_OK) return rc;
+  hipLaunchKernelGGL(lore_peak_base_kernel, dim3(1), dim3(1), 0, s, g_ds.cnt + 2 * B, B, g_ds.pk_base, g_ds.pk_lim);
+  PT_HIP_CHECK(hipGetLastError());
+  *d_lim_cell = g_ds.pk_lim;
+  *d_lim_corner = g_ds.pk_lim + 1;
+  return PT_OK;
+}
+
+int pt_lore_peak_patches(pt_engine* e, const bf16_t* feat, int B, int H, int W, int C, int split, bf16_t* mos_cell,
+                         bf16_t* mos_corner, hipStream_t s) {
+  PT_REQUIRE(feat && mos_cell && mos_corner && C % 8 == 0, "tsr peak patches: bad arguments");
+  PtProfScope ps(e, s, PT_PROF_OTHER, 0, "tsr patch gather");
+  hipLaunchKernelGGL(lore_peak_patch_kernel, dim3(K_CORNERS, 2 * B), dim3(64), 0, s, g_ds.sorted, g_ds.cnt + 2 * B, CAP, H, W, feat,
+                     C, split, g_ds.pk_base, mos_cell, mos_corner);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_lore_decode_boxes(pt_engine* e, const float* reg_cell, const float* wh, const float* reg_corner, const float* st, int B,
+                         int H, int W, const int** d_lim_ax, const int** d_lim_cr, hipStream_t s) {
+  PT_REQUIRE(reg_cell && wh && reg_corner && st, "tsr decode boxes: null pointer");
+  PtProfScope ps(e, s, PT_PROF_OTHER, 0, "tsr decode");
+  int rc = decode_boxes(&g_ds, reg_cell, reg_corner, wh, st, true, B, H, W, s);
   if (rc != PT_OK) return rc;
   hipLaunchKernelGGL(lore_sparse_base_kernel, dim3(1), dim3(1), 0, s, g_ds.cnt + 2 * B, B, g_ds.sp_base, g_ds.sp_lim);
   PT_HIP_CHECK(hipGetLastError());

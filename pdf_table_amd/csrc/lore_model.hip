@@ -247,52 +247,62 @@ static int lore_dla_run(pt_engine* e, const bf16_t* x, int n, int H, int W, floa
     c.ida("ida_up", y, 0, 3, 64, f24);
     const T feat = y[2];
     T hid = c.alloc(feat.H, feat.W, 256);
-    if (sp) {      // the four small head maps live in the arena; ax / cr are not computed densely
-      for (int h = 0; h < 6; ++h)
-        if (h != 3 && h != 4) {
-          heads[h] = reinterpret_cast<float*>(e->arena.take((size_t)n * feat.H * feat.W * 8 * sizeof(float)));
-          if (!heads[h]) c.ok = false;
-        }
+    if (sp) {      // only `hm` is needed everywhere: the other five heads run on patch mosaics (lore_decode.hip)
+      heads[0] = reinterpret_cast<float*>(e->arena.take((size_t)n * feat.H * feat.W * 8 * sizeof(float)));
+      if (!heads[0]) c.ok = false;
     }
     for (int h = 0; h < 6; ++h) {
-      if (sp && (h == 3 || h == 4)) continue;
+      if (sp && h != 0) continue;
       c.conv(feat, std::string(hname[h]) + ".0", 256, 3, 1, hid, 1);
       c.conv(hid, std::string(hname[h]) + ".2", hcs[h] < 64 ? 64 : hcs[h], 1, 1, T(), 0, nullptr, hcs[h], heads[h], hcs[h]);
     }
     if (sp) {
-      // decode up to the final cell order, copy the 3x3 neighbourhoods of the positions it will read into two mosaics,
-      // run the ax / cr heads on the mosaics (tiles beyond the data-dependent row limit exit), finish the decode
-      int rows_ax = 0, rows_cr = 0;
-      pt_lore_mosaic_rows(n, &rows_ax, &rows_cr);
+      int rows_ax = 0, rows_cr = 0, rows_cell = 0, rows_corner = 0;
+      pt_lore_mosaic_rows(n, &rows_ax, &rows_cr, &rows_cell, &rows_corner);
       const int MW = 768;
       auto take = [&](size_t bytes) { void* p_ = e->arena.take(bytes); if (!p_) c.ok = false; return p_; };
-      T max_, mcr_, mhid;
-      max_.H = rows_ax; max_.W = MW; max_.C = 64;
-      mcr_.H = rows_cr; mcr_.W = MW; mcr_.C = 64;
-      mhid.H = rows_cr; mhid.W = MW; mhid.C = 256;
-      max_.p = reinterpret_cast<bf16_t*>(take((size_t)rows_ax * MW * 64 * c.mul * sizeof(bf16_t)));
-      mcr_.p = reinterpret_cast<bf16_t*>(take((size_t)rows_cr * MW * 64 * c.mul * sizeof(bf16_t)));
-      mhid.p = reinterpret_cast<bf16_t*>(take((size_t)rows_cr * MW * 256 * c.mul * sizeof(bf16_t)));
+      auto mosaic = [&](int rows, int C) {
+        T t;
+        t.H = rows; t.W = MW; t.C = C;
+        t.p = reinterpret_cast<bf16_t*>(take((size_t)rows * MW * C * c.mul * sizeof(bf16_t)));
+        return t;
+      };
+      T mcell = mosaic(rows_cell, 64), mcorner = mosaic(rows_corner, 64), max_ = mosaic(rows_ax, 64), mcr_ = mosaic(rows_cr, 64);
+      T mhid = mosaic(rows_cr, 256);                 // hidden layer of whichever head is running (rows_cr is the largest)
+      float* o_wh = reinterpret_cast<float*>(take((size_t)rows_cell * MW * 8 * sizeof(float)));
+      float* o_regc = reinterpret_cast<float*>(take((size_t)rows_cell * MW * 8 * sizeof(float)));
+      float* o_st = reinterpret_cast<float*>(take((size_t)rows_corner * MW * 8 * sizeof(float)));
+      float* o_regk = reinterpret_cast<float*>(take((size_t)rows_corner * MW * 8 * sizeof(float)));
       float* oax = reinterpret_cast<float*>(take((size_t)rows_ax * MW * 256 * sizeof(float)));
       float* ocr = reinterpret_cast<float*>(take((size_t)rows_cr * MW * 256 * sizeof(float)));
       if (c.rc == PT_OK && !c.dry && c.ok) {
-        const int *lim_ax = nullptr, *lim_cr = nullptr;
-        int r = pt_lore_decode_front(e, heads[0], heads[1], heads[2], heads[5], n, feat.H, feat.W, sp->wiz_rev, sp->vis_thresh,
-                                     sp->d_counts, &lim_ax, &lim_cr, s);
+        const int keep = c.n;
+        // one head on one mosaic: 3x3 (64 -> 256) + ReLU, then 1x1 to nc channels, fp32 out; tiles below `lim` rows exit
+        auto head = [&](const T& mos, int rows, const char* name, int nc, float* outp, const int* lim) {
+          T hh = mhid;
+          hh.H = rows;
+          c.n = 1;
+          c.ylimit = lim;
+          c.conv(mos, std::string(name) + ".0", 256, 3, 1, hh, 1);
+          c.conv(hh, std::string(name) + ".2", nc < 64 ? 64 : nc, 1, 1, T(), 0, nullptr, nc, outp, nc);
+          c.ylimit = nullptr;
+          c.n = keep;
+        };
+        const int *lim_cell = nullptr, *lim_corner = nullptr, *lim_ax = nullptr, *lim_cr = nullptr;
+        int r = pt_lore_decode_peaks(e, heads[0], n, feat.H, feat.W, sp->wiz_rev, sp->vis_thresh, sp->d_counts, &lim_cell,
+                                     &lim_corner, s);
+        if (r == PT_OK) r = pt_lore_peak_patches(e, feat.p, n, feat.H, feat.W, 64, c.x3, mcell.p, mcorner.p, s);
+        if (r != PT_OK) return r;
+        head(mcell, rows_cell, "wh", 8, o_wh, lim_cell);
+        head(mcell, rows_cell, "reg", 8, o_regc, lim_cell);
+        head(mcorner, rows_corner, "st", 8, o_st, lim_corner);
+        head(mcorner, rows_corner, "reg", 8, o_regk, lim_corner);
+        if (c.rc != PT_OK) return c.rc;
+        r = pt_lore_decode_boxes(e, o_regc, o_wh, o_regk, o_st, n, feat.H, feat.W, &lim_ax, &lim_cr, s);
         if (r == PT_OK) r = pt_lore_patch_gather(e, feat.p, n, feat.H, feat.W, 64, c.x3, max_.p, mcr_.p, s);
         if (r != PT_OK) return r;
-        const int keep = c.n;
-        c.n = 1;
-        T hax = mhid;
-        hax.H = rows_ax;
-        c.ylimit = lim_ax;
-        c.conv(max_, "ax.0", 256, 3, 1, hax, 1);
-        c.conv(hax, "ax.2", 256, 1, 1, T(), 0, nullptr, 256, oax, 256);
-        c.ylimit = lim_cr;
-        c.conv(mcr_, "cr.0", 256, 3, 1, mhid, 1);
-        c.conv(mhid, "cr.2", 256, 1, 1, T(), 0, nullptr, 256, ocr, 256);
-        c.ylimit = nullptr;
-        c.n = keep;
+        head(max_, rows_ax, "ax", 256, oax, lim_ax);
+        head(mcr_, rows_cr, "cr", 256, ocr, lim_cr);
         if (c.rc != PT_OK) return c.rc;
         r = pt_lore_decode_sparse(e, oax, ocr, n, feat.H, feat.W, sp->vis_thresh, sp->d_counts, sp->d_dets, sp->d_logi, s);
         if (r != PT_OK) return r;

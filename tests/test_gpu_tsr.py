@@ -411,17 +411,21 @@ def test_forward_decode_fused_is_bit_identical(tmp_path, mode, wiz_rev):
 
 @pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
 def test_forward_decode_fused_default_dispatch(tmp_path, mode):
-    """with the default conv dispatch the dense map's 3x3 head convs run on the DMA kernel, which sums K in another order:
-    boxes and scores (from the dense hm / st / wh / reg heads in both paths) stay identical, the logic features agree to
-    fp32 summation noise (after one bf16 rounding of the hidden layer in bf16 mode)"""
+    """with the default conv dispatch the dense maps' 3x3 head convs run on the DMA kernel, which sums K in another order
+    than the register-staged kernel the mosaics use: the two paths agree to fp32 summation noise (after one bf16 rounding
+    of the hidden layer in bf16 mode) -- scores come from the dense `hm` map in both and are identical"""
     r = _run_fused(tmp_path, mode, True, None)
     assert np.array_equal(r["c0"], r["c1"]) and r["c0"].sum() > 0
+    tol_px, tol_f = (0.1, 2e-2) if mode == "bf16" else (1e-3, 1e-4)
     for b in range(len(r["c0"])):
         k = int(r["c0"][b])
-        assert np.array_equal(r["d0"][b, :max(k, 1)], r["d1"][b, :max(k, 1)])
+        assert np.array_equal(r["d0"][b, :k, 8], r["d1"][b, :k, 8])
+        dpx = float(np.abs(r["d0"][b, :k, :8] - r["d1"][b, :k, :8]).max())
         scale = float(np.abs(r["l0"][b, :k]).max())
         d = float(np.abs(r["l0"][b, :k] - r["l1"][b, :k]).max())
-        assert d <= (2e-2 if mode == "bf16" else 1e-4) * max(1.0, scale), (b, d, scale)
+        print(f"fused vs dense, default dispatch, {mode}, table {b}: max|dbox| {dpx:.3e} px, max|dfeat| {d:.3e} (scale {scale:.1f})")
+        assert dpx <= tol_px, (b, dpx)
+        assert d <= tol_f * max(1.0, scale), (b, d, scale)
 
 
 def test_thin_stem_kernel_equals_general_kernel(tmp_path):
