@@ -843,22 +843,29 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(const bf16_t* __re
         stage[m * SROW + h * 32 + lx] = (bf16_t)rf2bf(so * fast_tanh(cn));
       }
     __syncthreads();
-    // publish: 128 lines x 8 pieces of 16 B; piece i of line m = units 64 member + 8 i .. + 8
+    // publish: 128 lines x 8 pieces of 16 B; piece i of line m = units 64 member + 8 i .. + 8.  The exchange stores go
+    // first and only they are drained before the counter is bumped; the layer output (HBM) follows behind the counter,
+    // off the step's critical chain
     unsigned long long* hw = hxc + (size_t)(s & 1) * (CLL * 256 / 4);
+    u32x4 pv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + i * 256, m = idx >> 3, pc = idx & 7;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(stage + m * SROW + pc * 8);
+      pv[i] = *reinterpret_cast<const u32x4*>(stage + m * SROW + pc * 8);
       const int ks = 4 * member + (pc >> 1), qq = pc & 1;
       unsigned long long* dp = hw + ((size_t)((m >> 5) * 16 + ks) * 64 + qq * 32 + (m & 31)) * 2;
-      __hip_atomic_store(dp, (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(dp + 1, (unsigned long long)v.z | ((unsigned long long)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int line = line0 + m;
-      if (line < B) *reinterpret_cast<u32x4*>(hout + ((size_t)line * T + t) * 512 + dir * 256 + member * 64 + pc * 8) = v;
+      __hip_atomic_store(dp, (unsigned long long)pv[i].x | ((unsigned long long)pv[i].y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dp + 1, (unsigned long long)pv[i].z | ((unsigned long long)pv[i].w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_store(fl + member, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256, m = idx >> 3, pc = idx & 7;
+      const int line = line0 + m;
+      if (line < B) *reinterpret_cast<u32x4*>(hout + ((size_t)line * T + t) * 512 + dir * 256 + member * 64 + pc * 8) = pv[i];
+    }
   }
 }
 
