@@ -101,6 +101,14 @@ int pt_layout_candidates(pt_engine* e, const float* d_head0, const float* d_head
 int pt_layout_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h, int w, int inp_h, int inp_w, int num_classes,
                       float thr_lo, int max_cands, int32_t* d_counts, float* d_cands, pt_stream stream);
 
+/* Host: greedy per-class hard NMS of OCRPicodetPostProcessor (processor_picodet.py:301-348) for one page.
+ *   h_boxes    : float64 [n, 5] (x1, y1, x2, y2, score)
+ *   h_order    : per group (class) the candidate indices in ascending score order (numpy argsort()[-200:]);
+ *   h_group_off: int64 [n_groups + 1] offsets into h_order
+ *   h_picked   : int64 [len(h_order)] picked indices per group, in pick order;  h_n_picked: int32 [n_groups] */
+int pt_hard_nms(const double* h_boxes, const int64_t* h_order, const int64_t* h_group_off, int n_groups,
+                double iou_threshold, int top_k, int64_t* h_picked, int32_t* h_n_picked);
+
 /* ---- stage 2: DB text detection ------------------------------------------------------------- */
 
 /* Pre-process flavours: how a page is resized before the net. */

@@ -489,4 +489,53 @@ int pt_db_finalize(const float* h_boxes, const float* h_scores, int nb, float bo
   return PT_OK;
 }
 
+// ---- layout: greedy hard NMS of OCRPicodetPostProcessor (picodet/processor_picodet.py:301-348), host side ----------
+// One call per page: n_groups independent candidate lists (one per class).  boxes: float64 [n][5] (x1, y1, x2, y2, score);
+// order: for every group the candidate indices in ASCENDING score order as numpy's argsort()[-candidate_size:] gave them
+// (the tie order is numpy's, so it is computed there); group_off: [n_groups + 1] offsets into `order`.
+// picked: [sum of group sizes] indices in pick order, per group; n_picked: [n_groups].
+// iou_of in float64, same operation order: inter / ((a0 + a1) - inter + eps).
+int pt_hard_nms(const double* boxes, const int64_t* order, const int64_t* group_off, int n_groups, double iou_threshold,
+                int top_k, int64_t* picked, int32_t* n_picked) {
+  if (!boxes || !order || !group_off || !picked || !n_picked || n_groups < 0) {
+    pt_set_error("pt_hard_nms: bad arguments");
+    return PT_ERR_INVALID;
+  }
+  const double eps = 1e-5;
+  std::vector<int64_t> idx;
+  for (int g = 0; g < n_groups; ++g) {
+    idx.assign(order + group_off[g], order + group_off[g + 1]);
+    int64_t* out = picked + group_off[g];
+    int np = 0;
+    while (!idx.empty()) {
+      const int64_t cur = idx.back();
+      out[np++] = cur;
+      if ((top_k > 0 && np == top_k) || idx.size() == 1) break;
+      idx.pop_back();
+      const double* c = boxes + cur * 5;
+      double cw = c[2] - c[0], ch = c[3] - c[1];
+      if (cw < 0.0) cw = 0.0;
+      if (ch < 0.0) ch = 0.0;
+      const double a1 = cw * ch;
+      size_t keep = 0;
+      for (size_t k = 0; k < idx.size(); ++k) {
+        const double* b = boxes + idx[k] * 5;
+        double w = (b[2] < c[2] ? b[2] : c[2]) - (b[0] > c[0] ? b[0] : c[0]);
+        double h = (b[3] < c[3] ? b[3] : c[3]) - (b[1] > c[1] ? b[1] : c[1]);
+        if (w < 0.0) w = 0.0;
+        if (h < 0.0) h = 0.0;
+        const double inter = w * h;
+        double bw = b[2] - b[0], bh = b[3] - b[1];
+        if (bw < 0.0) bw = 0.0;
+        if (bh < 0.0) bh = 0.0;
+        const double iou = inter / (bw * bh + a1 - inter + eps);
+        if (iou <= iou_threshold) idx[keep++] = idx[k];
+      }
+      idx.resize(keep);
+    }
+    n_picked[g] = np;
+  }
+  return PT_OK;
+}
+
 }  // extern "C"

@@ -149,15 +149,34 @@ class LayoutStage:
             scores_l.append(sc[order])
         bboxes = np.concatenate(boxes_l, 0)
         conf = np.concatenate(scores_l, 0)
-        picked, labels = [], []
+        # per-class greedy NMS: candidate order by numpy (its tie order), the greedy loop on the host in C++ (pt_hard_nms)
+        groups, orders, labels_c = [], [], []
+        base = 0
         for c in range(ncls):
             probs = conf[:, c]
             mask = probs > cfg.score_threshold
             if not mask.any():
                 continue
-            bp = hard_nms(np.concatenate([bboxes[mask], probs[mask].reshape(-1, 1)], axis=1), cfg.nms_threshold, cfg.keep_top_k)
-            picked.append(bp)
-            labels.extend([c] * bp.shape[0])
+            bs = np.concatenate([bboxes[mask], probs[mask].reshape(-1, 1)], axis=1)
+            groups.append(bs)
+            orders.append(np.argsort(bs[:, -1])[-200:] + base)
+            labels_c.append(c)
+            base += len(bs)
+        picked, labels = [], []
+        if groups:
+            allb = np.ascontiguousarray(np.concatenate(groups, 0), dtype=np.float64)
+            order = np.ascontiguousarray(np.concatenate(orders), dtype=np.int64)
+            goff = np.zeros(len(groups) + 1, np.int64)
+            goff[1:] = np.cumsum([len(o) for o in orders])
+            out = np.empty(len(order), np.int64)
+            npk = np.zeros(len(groups), np.int32)
+            L.check(L.load().pt_hard_nms(allb.ctypes.data, order.ctypes.data, goff.ctypes.data, len(groups),
+                                             float(cfg.nms_threshold), int(cfg.keep_top_k), out.ctypes.data, npk.ctypes.data),
+                    "pt_hard_nms")
+            for g, c in enumerate(labels_c):
+                sel = out[goff[g]:goff[g] + npk[g]]
+                picked.append(allb[sel])
+                labels.extend([c] * len(sel))
         if not picked:
             return []
         pb = np.concatenate(picked)

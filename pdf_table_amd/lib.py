@@ -75,6 +75,7 @@ def _proto(lib):
         "pt_tsr_decode": (i, [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, f, vp, vp, vp, vp]),
         "pt_tsr_forward_decode": (i, [vp, vp, i, i, i, i, f, vp, vp, vp, vp]),
         "pt_tsr_process": (i, [vp, vp, vp, vp, i, i, vp, vp, vp]),
+        "pt_hard_nms": (i, [vp, vp, vp, i, C.c_double, i, vp, vp]),
         "pt_cls_preprocess": (i, [vp, vp, vp, i, i, i, i, i, vp, vp]),
         "pt_cls_forward_net": (i, [vp, i, vp, i, i, i, i, vp, ip, vp]),
         "pt_cls_forward": (i, [vp, i, vp, vp, i, i, i, i, i, i, vp, ip, vp]),
