@@ -410,7 +410,12 @@ __device__ __forceinline__ bool on_bresenham(int px, int py, int x0, int y0, int
   return u * 2 * dx <= num && num < (u + 1) * 2 * dx;
 }
 
-__global__ __launch_bounds__(64) void box_score_kernel(const float* __restrict__ prob, int n, int H, int W,
+// one workgroup per box: the waves take the rows of the bounding rectangle in turn (the scan-line spans of a row are
+// computed once, wave-uniform), the lanes its pixels; double sums, reduced through LDS.  One wave per box left the
+// largest box of a page batch (a ruled table is one connected component) as a 3 ms tail.
+constexpr int BS_THREADS = 256;
+
+__global__ __launch_bounds__(BS_THREADS) void box_score_kernel(const float* __restrict__ prob, int n, int H, int W,
                                                         const float* __restrict__ boxes, int nb,
                                                         float* __restrict__ scores) {
   const int bi = blockIdx.x;
@@ -454,11 +459,9 @@ __global__ __launch_bounds__(64) void box_score_kernel(const float* __restrict__
   const float* pm = prob + (size_t)page * H * W;
   double sum = 0.0;
   int cnt = 0;
-  const int lane = threadIdx.x;
-  const int npx = mw * mh;
-  for (int t = lane; t < npx; t += 64) {
-    const int py = t / mw, px = t - py * mw;
-    bool in = false;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int py = wave; py < mh; py += BS_THREADS / 64) {
+    int x1s[2] = {1, 1}, x2s[2] = {0, 0};      // up to two spans [x1, x2] of the row
     if (py >= pymin && py < pymax) {
       long long xs[4];
       int na = 0;
@@ -468,20 +471,24 @@ __global__ __launch_bounds__(64) void box_score_kernel(const float* __restrict__
       for (int a = 1; a < na; ++a)
         for (int c = a; c > 0 && xs[c] < xs[c - 1]; --c) { long long tt = xs[c]; xs[c] = xs[c - 1]; xs[c - 1] = tt; }
       for (int a = 0; a + 1 < na; a += 2) {
-        const int x1 = (int)((xs[a] + 32768) >> 16), x2 = (int)((xs[a + 1] + 32768) >> 16);
-        if (px >= x1 && px <= x2) in = true;
+        x1s[a >> 1] = (int)((xs[a] + 32768) >> 16);
+        x2s[a >> 1] = (int)((xs[a + 1] + 32768) >> 16);
       }
     }
-    if (!in) {
+    const float* prow = pm + (size_t)(ymin + py) * W + xmin;
+    for (int px = lane; px < mw; px += 64) {
+      bool in = (px >= x1s[0] && px <= x2s[0]) || (px >= x1s[1] && px <= x2s[1]);
+      if (!in) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int k0 = (k + 3) & 3;
-        if (on_bresenham(px, py, vx[k0], vy[k0], vx[k], vy[k])) in = true;
+        for (int k = 0; k < 4; ++k) {
+          const int k0 = (k + 3) & 3;
+          if (on_bresenham(px, py, vx[k0], vy[k0], vx[k], vy[k])) in = true;
+        }
       }
-    }
-    if (in) {
-      sum += (double)pm[(size_t)(ymin + py) * W + (xmin + px)];
-      ++cnt;
+      if (in) {
+        sum += (double)prow[px];
+        ++cnt;
+      }
     }
   }
 #pragma unroll
@@ -489,13 +496,20 @@ __global__ __launch_bounds__(64) void box_score_kernel(const float* __restrict__
     sum += __shfl_xor(sum, off);
     cnt += __shfl_xor(cnt, off);
   }
-  if (lane == 0) scores[bi] = cnt > 0 ? (float)(sum / (double)cnt) : 0.f;
+  __shared__ double s_sum[BS_THREADS / 64];
+  __shared__ int s_cnt[BS_THREADS / 64];
+  if (lane == 0) { s_sum[wave] = sum; s_cnt[wave] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < BS_THREADS / 64; ++k) { sum += s_sum[k]; cnt += s_cnt[k]; }
+    scores[bi] = cnt > 0 ? (float)(sum / (double)cnt) : 0.f;
+  }
 }
 
 int pt_launch_box_scores(const float* prob, int n, int H, int W, const float* boxes, int nb, float* scores,
                          hipStream_t s) {
   if (nb <= 0) return PT_OK;
-  hipLaunchKernelGGL(box_score_kernel, dim3(nb), dim3(64), 0, s, prob, n, H, W, boxes, nb, scores);
+  hipLaunchKernelGGL(box_score_kernel, dim3(nb), dim3(BS_THREADS), 0, s, prob, n, H, W, boxes, nb, scores);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
