@@ -345,6 +345,7 @@ def main():
             if rec_ids is not None:
                 from pdf_table_amd.rec_stage import ctc_collapse
                 toks = ctc_collapse(rec_ids.cpu().numpy())     # D2H of int32 [lines, 160] + host collapse
+                eng.check()
                 if count:
                     ntok += sum(len(t) for t in toks)
             tick("ctc", t0)

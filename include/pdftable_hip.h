@@ -13,7 +13,14 @@
  *   - pointers named d_* are DEVICE pointers on the engine's GPU, h_* are HOST pointers;
  *   - weights, activations and scratch are engine-owned; inputs and outputs are caller-owned;
  *   - one engine per GPU; calls on one engine must be serialised by the caller (the reference is
- *     single-threaded, base_infer_task.py:311-315); distinct engines are independent;
+ *     single-threaded, base_infer_task.py:311-315); distinct engines own all their state (weights,
+ *     arena, scratch, the decode state between the steps of pt_tsr_forward_decode) and are
+ *     independent, with ONE restriction per device: the bf16 recognition LSTM (pt_rec_forward*)
+ *     is a cluster kernel whose workgroups must all be resident at once, so two such launches may
+ *     not overlap in time on one GPU (two engines, streams or processes).  An overlap cannot hang:
+ *     a workgroup gives up after a bounded wait, pt_engine_check() (and the next rec call on that
+ *     engine) returns PT_ERR_HIP ("not co-resident"); PT_LSTM_CLUSTER=0 selects the streaming
+ *     kernel instead;
  *   - `stream` is a hipStream_t (0 = the null stream).  Calls are asynchronous on that stream
  *     unless stated otherwise.
  */
@@ -41,6 +48,10 @@ int pt_engine_create(int device_id, pt_engine** out);
 void pt_engine_destroy(pt_engine* e);
 const char* pt_last_error(void);
 int pt_abi_version(void);
+/* Failures the DEVICE detected in work already executed (today: the co-residency time-out of the recognition LSTM, see
+ * above).  Call it after synchronising the stream whose results are about to be consumed; PT_OK if nothing was flagged.
+ * No counterpart in the reference (a torch/onnxruntime call either returns or raises). */
+int pt_engine_check(pt_engine* e);
 
 /* Arithmetic of the conv nets (DESIGN.md "numerics").  PT_PRECISION_BF16: bf16 activations/weights, fp32
  * accumulate -- the throughput mode BASELINE.json's configs name.  PT_PRECISION_BF16X3: every activation and

@@ -21,6 +21,17 @@ extern "C" {
 const char* pt_last_error(void) { return g_err; }
 int pt_abi_version(void) { return 4; }
 
+int pt_engine_check(pt_engine* e) {
+  PT_REQUIRE(e, "pt_engine_check: null engine");
+  if (e->lstm_err && *e->lstm_err) {
+    pt_set_error("lstm_cluster_kernel: a workgroup waited > 2^22 polls for its peers -- the launch was not co-resident "
+                 "(GPU shared with another process or stream?).  The recognition results since the last check are invalid; "
+                 "set PT_LSTM_CLUSTER=0");
+    return PT_ERR_HIP;
+  }
+  return PT_OK;
+}
+
 int pt_engine_set_precision(pt_engine* e, int precision) {
   PT_REQUIRE(e && (precision == PT_PRECISION_BF16 || precision == PT_PRECISION_BF16X3), "pt_engine_set_precision: bad arguments");
   e->precision = precision;
@@ -59,6 +70,8 @@ void pt_engine_destroy(pt_engine* e) {
   if (e->cls_lut) (void)hipFree(e->cls_lut);
   if (e->cls_scratch) (void)hipFree(e->cls_scratch);
   if (e->layout_scratch) (void)hipFree(e->layout_scratch);
+  if (e->lstm_scratch) (void)hipFree(e->lstm_scratch);
+  if (e->lstm_err) (void)hipHostFree(e->lstm_err);
   for (auto& p : e->prof.pending) {
     (void)hipEventDestroy(p.a);
     (void)hipEventDestroy(p.b);

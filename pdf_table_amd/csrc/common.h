@@ -107,6 +107,10 @@ struct pt_engine {
   float* tsr_lut = nullptr;                                  // [3][256] normalisation table of the Lore pre-process
   float* cls_lut = nullptr;                                  // [3][256] ... of the PP-LCNet pre-process
   void* cls_scratch = nullptr; size_t cls_scratch_cap = 0;   // network input + image descriptors of pt_cls_forward*
+  alignas(8) unsigned char tsr_decode_state[128] = {};       // lore_decode.hip: DecodeState of the sparse-head decode in flight
+  void* lstm_scratch = nullptr;                              // rec_kernels.hip: h exchange buffers + step counters of the cluster LSTM
+  int* lstm_err = nullptr;                                   // pinned, device-visible: set by a cluster member that gave up waiting
+  int lstm_max_cl = 0;                                       // clusters per direction per launch (num_cu / 8)
 };
 
 // ---- conv launcher (conv_igemm.hip) -----------------------------------------------------------------
@@ -195,7 +199,7 @@ int pt_launch_crnn_conv0_pool(const bf16_t* in, int n, int H, int W, const float
                               bf16_t* out, hipStream_t s);
 int pt_launch_maxpool_kxk(const bf16_t* in, int n, int H, int W, int C, int kh, int kw, int h2c, int split, bf16_t* out,
                           hipStream_t s);
-int pt_launch_lstm(const bf16_t* gx, const bf16_t* whh, bf16_t* hout, int B, int T, int split, hipStream_t s);
+int pt_launch_lstm(pt_engine* e, const bf16_t* gx, const bf16_t* whh, bf16_t* hout, int B, int T, int split, hipStream_t s);
 int pt_launch_gemm_argmax(const bf16_t* A, long long M, int K, const bf16_t* W, const float* bias, int N, int* ids, float* maxv,
                           hipStream_t s);
 int pt_launch_gemm_rows(const bf16_t* A, long long M, int K, const bf16_t* W, const float* bias, int N, bf16_t* out, int relu,

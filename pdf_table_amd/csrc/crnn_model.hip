@@ -170,13 +170,13 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
   RUN(rows_gemm(bf.f, 512, xp1, 2048, bf.gx, 0, "rows gemm 512->2048"));
   {
     PtProfScope ps(e, s, PT_PROF_OTHER, 0, "lstm1");
-    RUN(pt_launch_lstm(bf.gx, W(whh1), bf.h, n, T, x3, s));
+    RUN(pt_launch_lstm(e, bf.gx, W(whh1), bf.h, n, T, x3, s));
   }
   RUN(rows_gemm(bf.h, 512, em1, 256, bf.e1, 0, "rows gemm 512->256"));
   RUN(rows_gemm(bf.e1, 256, xp2, 2048, bf.gx, 0, "rows gemm 256->2048"));
   {
     PtProfScope ps(e, s, PT_PROF_OTHER, 0, "lstm2");
-    RUN(pt_launch_lstm(bf.gx, W(whh2), bf.h, n, T, x3, s));
+    RUN(pt_launch_lstm(e, bf.gx, W(whh2), bf.h, n, T, x3, s));
   }
   RUN(rows_gemm(bf.h, 512, em2, 512, bf.e2, 0, "rows gemm 512->512"));
   // classifier + arg-max: fused kernel in bf16 mode (PT_CLS_FUSED=0: tiled GEMM with per-tile partials + reduce, which is

@@ -506,7 +506,10 @@ void pt_lore_mosaic_rows(int B, int* rows_ax, int* rows_cr, int* rows_cell, int*
   *rows_corner = 3 * (((long long)B * K_CORNERS + MOS_PW - 1) / MOS_PW);
 }
 
-static DecodeState g_ds;        // state of the earlier steps, consumed by the calls that follow on the same stream
+// state of the earlier steps, consumed by the calls that follow on the same stream: kept in the engine, so that two
+// engines can interleave their decodes
+static_assert(sizeof(DecodeState) <= sizeof(pt_engine::tsr_decode_state), "DecodeState outgrew its slot in pt_engine");
+#define g_ds (*reinterpret_cast<DecodeState*>(e->tsr_decode_state))
 
 int pt_lore_decode_peaks(pt_engine* e, const float* hm, int B, int H, int W, int wiz_rev, float vis_thresh, int* d_counts,
                          const int** d_lim_cell, const int** d_lim_corner, hipStream_t s) {

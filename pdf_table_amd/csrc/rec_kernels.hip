@@ -869,7 +869,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(const bf16_t* __re
   }
 }
 
-int pt_launch_lstm(const bf16_t* gx, const bf16_t* whh, bf16_t* hout, int B, int T, int split, hipStream_t s) {
+int pt_launch_lstm(pt_engine* e, const bf16_t* gx, const bf16_t* whh, bf16_t* hout, int B, int T, int split, hipStream_t s) {
   if (B <= 0) return PT_OK;
   dim3 grid((B + 31) / 32, 2);
   static int use_dma = -1;       // PT_LSTM_DMA=0: the register-staged kernel also in bf16 mode (A/B switch)
@@ -884,32 +884,20 @@ int pt_launch_lstm(const bf16_t* gx, const bf16_t* whh, bf16_t* hout, int B, int
   }
   if (!split && use_cluster) {
     constexpr int SMEM = 131072 + CLL * 72 * 2;
-    struct ClusterState {        // per device: exchange buffers + step counters, pinned error word, clusters per launch
-      void* scratch = nullptr;
-      int* h_err = nullptr;      // pinned, device-visible: set by a member that gave up waiting for its peers
-      int max_cl = 0;
-    };
-    static ClusterState states[32];
     static bool attr_done = false;
-    int dev = 0;
-    PT_HIP_CHECK(hipGetDevice(&dev));
-    PT_REQUIRE(dev >= 0 && dev < 32, "lstm: device index %d out of range", dev);
-    ClusterState& st = states[dev];
     if (!attr_done) {
       PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_cluster_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
       attr_done = true;
     }
-    if (!st.scratch) {
-      int ncu = 0;
-      PT_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-      st.max_cl = ncu / 8 < 1 ? 1 : ncu / 8;     // clusters per direction per launch: 2 dirs x 4 members x max_cl <= num_cu
-      PT_HIP_CHECK(hipMalloc(&st.scratch, (size_t)2 * st.max_cl * 2 * CLL * 256 * sizeof(bf16_t) + (size_t)2 * st.max_cl * 4 * sizeof(int) + 256));
-      PT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&st.h_err), sizeof(int), hipHostMallocMapped));
-      *st.h_err = 0;
+    if (!e->lstm_scratch) {     // per engine: exchange buffers + step counters, pinned error word, clusters per launch
+      e->lstm_max_cl = e->num_cu / 8 < 1 ? 1 : e->num_cu / 8;     // 2 dirs x 4 members x max_cl <= num_cu
+      PT_HIP_CHECK(hipMalloc(&e->lstm_scratch, (size_t)2 * e->lstm_max_cl * 2 * CLL * 256 * sizeof(bf16_t) + (size_t)2 * e->lstm_max_cl * 4 * sizeof(int) + 256));
+      PT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->lstm_err), sizeof(int), hipHostMallocMapped));
+      *e->lstm_err = 0;
     }
-    void* scratch = st.scratch;
-    int* h_err = st.h_err;
-    const int max_cl = st.max_cl;
+    void* scratch = e->lstm_scratch;
+    int* h_err = e->lstm_err;
+    const int max_cl = e->lstm_max_cl;
     if (*h_err) {      // an EARLIER launch timed out (its output was wrong): fail loudly now and stop using the kernel
       use_cluster = 0;
       pt_set_error("lstm_cluster_kernel: a workgroup waited > 2^22 polls for its peers -- the launch was not co-resident "

@@ -51,6 +51,11 @@ class HipEngine:
         L.check(self.lib.pt_engine_set_precision(self._h, int(precision)), "pt_engine_set_precision")
         self.precision = int(precision)
 
+    def check(self):
+        """Raise PtError if the device flagged a failure in work already executed (pt_engine_check): call after the
+        stream was synchronised, before consuming recognition results."""
+        L.check(self.lib.pt_engine_check(self._h), "pt_engine_check")
+
     def close(self):
         if getattr(self, "_h", None):
             self.lib.pt_engine_destroy(self._h)

@@ -49,6 +49,7 @@ def _proto(lib):
         "pt_engine_destroy": (None, [vp]),
         "pt_last_error": (C.c_char_p, []),
         "pt_abi_version": (i, []),
+        "pt_engine_check": (i, [vp]),
         "pt_engine_set_precision": (i, [vp, i]),
         "pt_weights_load": (i, [vp, i, vp, sz]),
         "pt_weights_load_device": (i, [vp, i, vp, sz, vp]),

@@ -143,6 +143,7 @@ class RecStage:
     def __call__(self, pages: torch.Tensor, boxes_per_page: Sequence[np.ndarray]) -> List[List[str]]:
         ids, lines = self.ids(pages, boxes_per_page)
         toks = ctc_collapse(ids.cpu().numpy()) if len(lines) else []
+        self.eng.check()          # the D2H copy synchronised the stream: surface device-side failures of this batch
         texts = ["".join(self.label.get(t, "") for t in row) for row in toks]
         out, o = [], 0
         for b in boxes_per_page:

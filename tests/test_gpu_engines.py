@@ -1,0 +1,69 @@
+"""Two engines on one GPU own their state (include/pdftable_hip.h, conventions): interleaving their calls gives each
+the results it gives alone -- bit-exact, the kernels are deterministic.  Covers the engine-owned scratch that is NOT in
+the per-call arena: the LSTM exchange buffers of the recognizer and the decode state of pt_tsr_forward_decode."""
+import numpy as np
+import pytest
+import torch
+
+from pdf_table_amd import lib as L
+from pdf_table_amd.synth_weights import crnn_state_dict, lore_dla34_state_dict
+from pdf_table_amd.weights import pack_crnn, pack_lore_dla34
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(seed):
+    from pdf_table_amd.engine import HipEngine
+    e = HipEngine(0)
+    e.load_weights(L.PT_MODEL_CRNN, pack_crnn(crnn_state_dict(seed=seed)))
+    e.load_weights(L.PT_MODEL_LORE_DLA34, pack_lore_dla34(lore_dla34_state_dict(seed=seed, hm_bias=(-1.2, -0.6))))
+    return e
+
+
+def test_two_engines_interleaved_equal_each_alone():
+    g = torch.Generator().manual_seed(5)
+    gray = (torch.rand(200, L.PT_REC_H, L.PT_REC_W, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    x4 = torch.zeros(2, 256, 256, 4)
+    x4[..., :3] = torch.randn(2, 256, 256, 3, generator=g) * 0.7
+    x4 = x4.to(torch.bfloat16).cuda()
+
+    def run(e):
+        ids, mx = e.rec_forward_net(gray)
+        c, d, l = e.tsr_forward_decode(x4, wiz_rev=True, vis_thresh=0.2, sync=True)
+        e.check()
+        return ids.cpu().numpy(), mx.cpu().numpy(), np.asarray(c), d.cpu().numpy(), l.cpu().numpy()
+
+    alone = []
+    for seed in (3, 4):
+        e = _engine(seed)
+        alone.append(run(e))
+        e.close()
+    assert not np.array_equal(alone[0][0], alone[1][0])          # different weights: different token ids
+    a, b = _engine(3), _engine(4)
+    try:
+        ia, _ = a.rec_forward_net(gray)                          # a and b alternate, results fetched at the end
+        ib, _ = b.rec_forward_net(gray)
+        ca, da, la = a.tsr_forward_decode(x4, wiz_rev=True, vis_thresh=0.2, sync=False)
+        cb, db, lb = b.tsr_forward_decode(x4, wiz_rev=True, vis_thresh=0.2, sync=False)
+        ia2, ma2 = a.rec_forward_net(gray)
+        torch.cuda.synchronize()
+        a.check()
+        b.check()
+        got_a = run(a)
+        got_b = run(b)
+    finally:
+        a.close()
+        b.close()
+    assert np.array_equal(ia.cpu().numpy(), alone[0][0]) and np.array_equal(ib.cpu().numpy(), alone[1][0])
+    assert np.array_equal(ia2.cpu().numpy(), alone[0][0]) and np.array_equal(ma2.cpu().numpy(), alone[0][1])
+    for got, ref in ((got_a, alone[0]), (got_b, alone[1])):
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+        assert np.array_equal(got[2], ref[2]) and got[2].sum() > 0
+        for t in range(len(ref[2])):
+            k = int(ref[2][t])
+            assert np.array_equal(got[3][t, :k], ref[3][t, :k]) and np.array_equal(got[4][t, :k], ref[4][t, :k])
+    for t in range(len(alone[0][2])):                            # the un-synchronised interleaved decodes too
+        k = int(alone[0][2][t])
+        assert np.array_equal(da.cpu().numpy()[t, :k], alone[0][3][t, :k])
+        k = int(alone[1][2][t])
+        assert np.array_equal(db.cpu().numpy()[t, :k], alone[1][3][t, :k])
