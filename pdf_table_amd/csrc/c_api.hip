@@ -443,7 +443,7 @@ static int rec_microbatch() {
   static int mb = -1;
   if (mb < 0) {
     const char* s = getenv("PT_REC_MICROBATCH");
-    mb = s ? atoi(s) : 4096;  // many lines per launch: the LSTM kernel has only lines/32 x 2 workgroups
+    mb = s ? atoi(s) : 6144;  // many lines per launch; 6144 = one launch of the cluster LSTM at 192 lines per cluster on 256 CUs
     if (mb < 1) mb = 1;
   }
   return mb;

@@ -104,13 +104,25 @@ __global__ __launch_bounds__(256) void dwconvt_up_add_kernel(const bf16_t* __res
   const int cs = split ? 2 * C : C;
   const int OH = h * f, OW = wd * f, p = f / 2, k = 2 * f;
   const long long total = (long long)B * OH * OW * cgn;
+  const bool small = total < (1ll << 31);      // 32-bit index arithmetic (the 64-bit divides were half of the kernel)
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int cg = (int)(i % cgn);
-    long long t = i / cgn;
-    const int ox = (int)(t % OW);
-    t /= OW;
-    const int oy = (int)(t % OH);
-    const int b = (int)(t / OH);
+    int cg, ox, oy, b;
+    if (small) {
+      const unsigned iu = (unsigned)i;
+      unsigned t = iu / (unsigned)cgn;
+      cg = (int)(iu - t * (unsigned)cgn);
+      const unsigned t2 = t / (unsigned)OW;
+      ox = (int)(t - t2 * (unsigned)OW);
+      b = (int)(t2 / (unsigned)OH);
+      oy = (int)(t2 - (unsigned)b * (unsigned)OH);
+    } else {
+      cg = (int)(i % cgn);
+      long long t = i / cgn;
+      ox = (int)(t % OW);
+      t /= OW;
+      oy = (int)(t % OH);
+      b = (int)(t / OH);
+    }
     float acc[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc[q] = 0.f;

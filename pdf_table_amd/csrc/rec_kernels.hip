@@ -741,16 +741,22 @@ __global__ __launch_bounds__(256, 1) void lstm_dir_dma_kernel(const bf16_t* __re
 //   * all workgroups of a launch must be co-resident (1 per CU, 144 KB of LDS): the launcher issues at most
 //     num_cu / 8 clusters per direction per launch; a member that waits > 2^22 polls gives up (sets *err) instead of hanging.
 // ---------------------------------------------------------------------------------------------------
-constexpr int CLL = 128;      // lines per cluster
+// MI = 32-line tiles per wave: 2 (128 lines per cluster, a W fragment read from LDS feeds two MFMAs) or 3 (192 lines per
+// cluster: the tiles go through the MFMAs one after the other so that the accumulators and the A fragments of one tile
+// are live at a time; 1.5x the LDS reads, but a launch holds 6144 lines instead of 4096 -- the step is latency-bound, so
+// a launch costs about the same whatever it holds).  Same sums in the same order for every MI.
+constexpr int CLL_MAX = 192;  // lines per cluster at MI = 3 (scratch is sized for it)
 
+template <int MI>
 __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(const bf16_t* __restrict__ gx, const bf16_t* __restrict__ whh,
                                                                bf16_t* __restrict__ hout, int B, int T, int ncl,
                                                                bf16_t* __restrict__ hx, int* __restrict__ flags,
                                                                int* __restrict__ err) {
+  constexpr int CLL = 64 * MI;                                 // lines per cluster
   extern __shared__ __attribute__((aligned(16))) char lsm[];
   char* wl = lsm;                                              // [16 ks][4 g][2 h][64 lanes][16 B] = 128 KB
   constexpr int SROW = 72;                                     // 64 + 8 bf16: 144-byte rows
-  bf16_t* stage = reinterpret_cast<bf16_t*>(lsm + 131072);     // [128][SROW]
+  bf16_t* stage = reinterpret_cast<bf16_t*>(lsm + 131072);     // [CLL][SROW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lx = lane & 31, q = lane >> 5;
   const int L = blockIdx.x, dir = blockIdx.y;
@@ -764,9 +770,9 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(const bf16_t* __re
   }
   unsigned long long* hxc = reinterpret_cast<unsigned long long*>(hx + (size_t)(dir * ncl + cl) * 2 * (CLL * 256));
   int* fl = flags + (dir * ncl + cl) * 4;
-  float c[2][16];
+  float c[MI][16];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int r = 0; r < 16; ++r) c[mi][r] = 0.f;
   bool dead = false;
@@ -774,23 +780,20 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(const bf16_t* __re
   for (int s = 0; s < T; ++s) {
     const int t = dir ? T - 1 - s : s;
     // gate inputs of this step (independent of the other members): 8 bytes per (line, unit)
-    u32x2 gv[2][16];
+    u32x2 gv[MI][16];
+    int last = B - 1;
+    asm volatile("" : "+v"(last));      // opaque per step: the 16 MI row addresses are recomputed (a min and a mad each) instead
+                                        // of living in 32 MI registers across the whole sequence
+    const bf16_t* gxt = gx + (size_t)t * 2048 + dir * 1024 + (member * 64 + h * 32 + lx) * 4;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = (2 * mp + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
+        const int m = (MI * mp + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
         const int line = line0 + m;
-        const int lc = line < B ? line : B - 1;
-        gv[mi][r] = *reinterpret_cast<const u32x2*>(gx + ((size_t)lc * T + t) * 2048 + dir * 1024 + (member * 64 + h * 32 + lx) * 4);
+        const int lc = line < last ? line : last;
+        gv[mi][r] = *reinterpret_cast<const u32x2*>(gxt + (size_t)lc * T * 2048);
       }
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][g][r] = 0.f;
     if (s > 0) {
       if (tid < 4 && !dead) {
         int spins = 0;
@@ -800,57 +803,109 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(const bf16_t* __re
         }
       }
       __syncthreads();
-      const unsigned long long* hp = hxc + (size_t)((s - 1) & 1) * (CLL * 256 / 4);
-      // A fragments of both line tiles, all 16 k-steps (2 x 16 x 16 B per lane), then the MFMAs
-      unsigned long long af[2][16][2];
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          const unsigned long long* pp = hp + ((size_t)((2 * mp + mi) * 16 + ks) * 64 + lane) * 2;
-          af[mi][ks][0] = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          af[mi][ks][1] = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        bf16x8 a[2];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          const unsigned long long two[2] = {af[mi][ks][0], af[mi][ks][1]};
-          a[mi] = __builtin_bit_cast(bf16x8, two);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const bf16x8 b = *reinterpret_cast<const bf16x8*>(wl + ((ks * 4 + g) * 2 + h) * 1024 + lane * 16);
-          acc[0][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b, acc[0][g], 0, 0, 0);
-          acc[1][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b, acc[1][g], 0, 0, 0);
-        }
-      }
     }
-    // cell update (lane-local), h to the staging tile
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    const unsigned long long* hp = hxc + (size_t)((s - 1) & 1) * (CLL * 256 / 4);
+    asm volatile("" : "+s"(hp));        // opaque per step, for the same reason: no per-fragment addresses kept across steps
+    // cell update of line tile mi (lane-local) from its four gate accumulators, h to the staging tile
+    auto cell = [&](int mi, const f32x16* acc) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = (2 * mp + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
-        const float gi = acc[mi][0][r] + rbf2f(gv[mi][r].x & 0xFFFFu);
-        const float gf = acc[mi][1][r] + rbf2f(gv[mi][r].x >> 16);
-        const float gg = acc[mi][2][r] + rbf2f(gv[mi][r].y & 0xFFFFu);
-        const float go = acc[mi][3][r] + rbf2f(gv[mi][r].y >> 16);
+        const int m = (MI * mp + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
+        const float gi = acc[0][r] + rbf2f(gv[mi][r].x & 0xFFFFu);
+        const float gf = acc[1][r] + rbf2f(gv[mi][r].x >> 16);
+        const float gg = acc[2][r] + rbf2f(gv[mi][r].y & 0xFFFFu);
+        const float go = acc[3][r] + rbf2f(gv[mi][r].y >> 16);
         const float si = fast_sigmoid(gi), sf = fast_sigmoid(gf), so = fast_sigmoid(go);
         const float cn = sf * c[mi][r] + si * fast_tanh(gg);
         c[mi][r] = cn;
         stage[m * SROW + h * 32 + lx] = (bf16_t)rf2bf(so * fast_tanh(cn));
       }
+    };
+    if constexpr (MI == 2) {
+      f32x16 acc[2][4];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mi][g][r] = 0.f;
+      if (s > 0) {
+        // A fragments of both line tiles, all 16 k-steps (2 x 16 x 16 B per lane), then the MFMAs
+        unsigned long long af[2][16][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) {
+            const unsigned long long* pp = hp + ((size_t)((2 * mp + mi) * 16 + ks) * 64 + lane) * 2;
+            af[mi][ks][0] = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            af[mi][ks][1] = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          bf16x8 a[2];
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            const unsigned long long two[2] = {af[mi][ks][0], af[mi][ks][1]};
+            a[mi] = __builtin_bit_cast(bf16x8, two);
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(wl + ((ks * 4 + g) * 2 + h) * 1024 + lane * 16);
+            acc[0][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b, acc[0][g], 0, 0, 0);
+            acc[1][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b, acc[1][g], 0, 0, 0);
+          }
+        }
+      }
+      cell(0, acc[0]);
+      cell(1, acc[1]);
+    } else {
+      // one tile at a time; the A fragments of the next tile are fetched under the MFMAs of this one (two buffers), and a
+      // scheduling barrier keeps the compiler from hoisting the third tile's loads on top (that spilled)
+      unsigned long long af[2][16][2];
+      auto fetch = [&](int mi, int buf) {
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const unsigned long long* pp = hp + ((size_t)((MI * mp + mi) * 16 + ks) * 64 + lane) * 2;
+          af[buf][ks][0] = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          af[buf][ks][1] = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      };
+      if (s > 0) fetch(0, 0);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+        if (s > 0) {
+          if (mi + 1 < MI) fetch(mi + 1, (mi + 1) & 1);
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) {
+            const unsigned long long two[2] = {af[mi & 1][ks][0], af[mi & 1][ks][1]};
+            const bf16x8 a = __builtin_bit_cast(bf16x8, two);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const bf16x8 b = *reinterpret_cast<const bf16x8*>(wl + ((ks * 4 + g) * 2 + h) * 1024 + lane * 16);
+              acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[g], 0, 0, 0);
+            }
+          }
+        }
+        cell(mi, acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     __syncthreads();
-    // publish: 128 lines x 8 pieces of 16 B; piece i of line m = units 64 member + 8 i .. + 8.  The exchange stores go
+    // publish: CLL lines x 8 pieces of 16 B; piece i of line m = units 64 member + 8 i .. + 8.  The exchange stores go
     // first and only they are drained before the counter is bumped; the layer output (HBM) follows behind the counter,
     // off the step's critical chain
     unsigned long long* hw = hxc + (size_t)(s & 1) * (CLL * 256 / 4);
-    u32x4 pv[4];
+    int tio = tid;
+    asm volatile("" : "+v"(tio));       // opaque per step: the store addresses below are recomputed, not kept (or spilled)
+    u32x4 pv[2 * MI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + i * 256, m = idx >> 3, pc = idx & 7;
+    for (int i = 0; i < 2 * MI; ++i) {
+      const int idx = tio + i * 256, m = idx >> 3, pc = idx & 7;
       pv[i] = *reinterpret_cast<const u32x4*>(stage + m * SROW + pc * 8);
       const int ks = 4 * member + (pc >> 1), qq = pc & 1;
       unsigned long long* dp = hw + ((size_t)((m >> 5) * 16 + ks) * 64 + qq * 32 + (m & 31)) * 2;
@@ -861,12 +916,35 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(const bf16_t* __re
     __syncthreads();
     if (tid == 0) __hip_atomic_store(fl + member, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + i * 256, m = idx >> 3, pc = idx & 7;
+    for (int i = 0; i < 2 * MI; ++i) {
+      const int idx = tio + i * 256, m = idx >> 3, pc = idx & 7;
       const int line = line0 + m;
       if (line < B) *reinterpret_cast<u32x4*>(hout + ((size_t)line * T + t) * 512 + dir * 256 + member * 64 + pc * 8) = pv[i];
     }
   }
+}
+
+template <int MI>
+static int launch_lstm_cluster(const bf16_t* gx, const bf16_t* whh, bf16_t* hout, int B, int T, int max_cl, bf16_t* hx, int* flags,
+                               int* err, hipStream_t s) {
+  constexpr int CLL = 64 * MI;
+  constexpr int SMEM = 131072 + CLL * 72 * 2;
+  static bool attr_done = false;
+  if (!attr_done) {
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_cluster_kernel<MI>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_done = true;
+  }
+  // equal chunks: a launch costs the same whatever it holds, so the last one should not be a sliver
+  const int nlaunch = (B + max_cl * CLL - 1) / (max_cl * CLL);
+  const int per = (((B + nlaunch - 1) / nlaunch) + CLL - 1) / CLL * CLL;
+  for (int b0 = 0; b0 < B; b0 += per) {
+    const int nb = (B - b0) < per ? (B - b0) : per;
+    const int ncl = (nb + CLL - 1) / CLL;
+    PT_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)(2 * max_cl * 4) * sizeof(int), s));
+    hipLaunchKernelGGL(lstm_cluster_kernel<MI>, dim3(((ncl + 7) / 8) * 32, 2), dim3(256), SMEM, s, gx + (size_t)b0 * T * 2048, whh,
+                       hout + (size_t)b0 * T * 512, nb, T, ncl, hx, flags, err);
+  }
+  return PT_OK;
 }
 
 int pt_launch_lstm(pt_engine* e, const bf16_t* gx, const bf16_t* whh, bf16_t* hout, int B, int T, int split, hipStream_t s) {
@@ -883,15 +961,9 @@ int pt_launch_lstm(pt_engine* e, const bf16_t* gx, const bf16_t* whh, bf16_t* ho
     use_cluster = ev ? atoi(ev) : 1;
   }
   if (!split && use_cluster) {
-    constexpr int SMEM = 131072 + CLL * 72 * 2;
-    static bool attr_done = false;
-    if (!attr_done) {
-      PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_cluster_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-      attr_done = true;
-    }
     if (!e->lstm_scratch) {     // per engine: exchange buffers + step counters, pinned error word, clusters per launch
       e->lstm_max_cl = e->num_cu / 8 < 1 ? 1 : e->num_cu / 8;     // 2 dirs x 4 members x max_cl <= num_cu
-      PT_HIP_CHECK(hipMalloc(&e->lstm_scratch, (size_t)2 * e->lstm_max_cl * 2 * CLL * 256 * sizeof(bf16_t) + (size_t)2 * e->lstm_max_cl * 4 * sizeof(int) + 256));
+      PT_HIP_CHECK(hipMalloc(&e->lstm_scratch, (size_t)2 * e->lstm_max_cl * 2 * CLL_MAX * 256 * sizeof(bf16_t) + (size_t)2 * e->lstm_max_cl * 4 * sizeof(int) + 256));
       PT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->lstm_err), sizeof(int), hipHostMallocMapped));
       *e->lstm_err = 0;
     }
@@ -905,16 +977,17 @@ int pt_launch_lstm(pt_engine* e, const bf16_t* gx, const bf16_t* whh, bf16_t* ho
       return PT_ERR_HIP;
     }
     bf16_t* hx = reinterpret_cast<bf16_t*>(scratch);
-    int* flags = reinterpret_cast<int*>(reinterpret_cast<char*>(scratch) + (size_t)2 * max_cl * 2 * CLL * 256 * sizeof(bf16_t));
+    int* flags = reinterpret_cast<int*>(reinterpret_cast<char*>(scratch) + (size_t)2 * max_cl * 2 * CLL_MAX * 256 * sizeof(bf16_t));
     int* err = nullptr;
     PT_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&err), h_err, 0));
-    for (int b0 = 0; b0 < B; b0 += max_cl * CLL) {
-      const int nb = (B - b0) < max_cl * CLL ? (B - b0) : max_cl * CLL;
-      const int ncl = (nb + CLL - 1) / CLL;
-      PT_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)(2 * max_cl * 4) * sizeof(int), s));
-      hipLaunchKernelGGL(lstm_cluster_kernel, dim3(((ncl + 7) / 8) * 32, 2), dim3(256), SMEM, s, gx + (size_t)b0 * T * 2048, whh,
-                         hout + (size_t)b0 * T * 512, nb, T, ncl, hx, flags, err);
-    }
+    // 192-line clusters when they save a launch (e.g. 4872 lines: 1 launch instead of 2); PT_LSTM_MI = 2 / 3 forces one
+    const char* ev = getenv("PT_LSTM_MI");
+    const int force = ev ? atoi(ev) : 0;
+    const int n2 = (B + max_cl * 128 - 1) / (max_cl * 128), n3 = (B + max_cl * 192 - 1) / (max_cl * 192);
+    const bool mi3 = force == 3 || (force != 2 && n3 < n2);
+    const int rc = mi3 ? launch_lstm_cluster<3>(gx, whh, hout, B, T, max_cl, hx, flags, err, s)
+                       : launch_lstm_cluster<2>(gx, whh, hout, B, T, max_cl, hx, flags, err, s);
+    if (rc != PT_OK) return rc;
   } else if (split) {
     hipLaunchKernelGGL(lstm_dir_kernel<1>, grid, dim3(256), 0, s, gx, whh, hout, B, T);
   } else if (use_dma) {

@@ -152,7 +152,8 @@ def test_rec_bf16_fast_kernels_equal_tiled_kernels(tmp_path):
     (gemm_argmax_kernel) give bit-identical ids AND winning logits to the streaming LSTM + tiled 1x1 GEMM + arg-max reduce
     they replaced, and the max-pools fused into the conv epilogues to the separate pool kernels (selected with
     PT_LSTM_CLUSTER=0 PT_CLS_FUSED=0 PT_POOL_FUSED=0 in a child process: the switches are read once).
-    300 lines = three 128-line clusters, the last one partial."""
+    300 lines = three 128-line clusters, the last one partial; with PT_LSTM_MI=3 two 192-line clusters (the variant a
+    launch of more than 4096 lines selects), the same sums in the same order."""
     import os
     import subprocess
     import sys
@@ -172,7 +173,8 @@ ids, mx = eng.rec_forward_net(torch.from_numpy(g).to(torch.bfloat16).cuda())
 np.savez(sys.argv[1], ids=ids.cpu().numpy(), mx=mx.cpu().numpy())
 '''
     outs = []
-    for tag, env in (("fast", {}), ("tiled", {"PT_LSTM_CLUSTER": "0", "PT_CLS_FUSED": "0", "PT_POOL_FUSED": "0"})):
+    for tag, env in (("fast", {}), ("tiled", {"PT_LSTM_CLUSTER": "0", "PT_CLS_FUSED": "0", "PT_POOL_FUSED": "0"}),
+                     ("fast192", {"PT_LSTM_MI": "3"})):
         out = str(tmp_path / f"{tag}.npz")
         e = dict(os.environ, **env)
         e["PT_CONV_VARIANT"] = "0"     # one conv kernel family in both runs: the DMA variants sum K in another order
@@ -181,4 +183,6 @@ np.savez(sys.argv[1], ids=ids.cpu().numpy(), mx=mx.cpu().numpy())
         outs.append(np.load(out))
     assert np.array_equal(outs[0]["ids"], outs[1]["ids"])
     assert np.array_equal(outs[0]["mx"], outs[1]["mx"])
+    assert np.array_equal(outs[0]["ids"], outs[2]["ids"])
+    assert np.array_equal(outs[0]["mx"], outs[2]["mx"])
     assert len(np.unique(outs[0]["ids"])) > 20           # not a degenerate output
