@@ -21,6 +21,7 @@ cores, bounded sample, rank 0 at N=1 only).
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -155,6 +156,9 @@ def main():
     ap.add_argument("--det-backbone", default="resnet18", choices=["resnet18", "proxylessnas"],
                     help="DB detector network: DBModel (BASELINE.json's configuration) or DBNasModel (diagnostic variant)")
     ap.add_argument("--no-post", action="store_true", help="device half only (diagnostic; not a valid headline)")
+    ap.add_argument("--overlap-rec", action="store_true",
+                    help="diagnostic: the recogniser runs on a second engine and stream, concurrently with the other stages "
+                         "(per-kernel HIP-event durations then include contention, so the roofline object reads low)")
     ap.add_argument("--stages", default=os.environ.get("PT_BENCH_STAGES", "layout,det,rec,tsr"),
                     help="comma list of stages in the timed step: layout (PicoDet), det (configs[1]), rec, tsr (Lore)")
     args = ap.parse_args()
@@ -188,6 +192,7 @@ def main():
     assert set(stages) <= {"layout", "det", "rec", "tsr", "cls"} and stages
 
     eng = HipEngine(local_rank)
+    eng_rec, rec_stream = None, None
     # weights: packed once on rank 0, broadcast over RCCL/xGMI, loaded from device memory everywhere
     nas = args.det_backbone == "proxylessnas"
     if nas:
@@ -215,6 +220,11 @@ def main():
         else:
             eng.load_weights(L.PT_MODEL_CRNN, pack_crnn(csd, x3=False))
         rec = RecStage(eng)
+        if args.overlap_rec:       # second engine (own arena and scratch) on its own stream
+            eng_rec = HipEngine(local_rank)
+            eng_rec.load_weights(L.PT_MODEL_CRNN, pack_crnn(crnn_state_dict(seed=1), x3=False))
+            rec = RecStage(eng_rec)
+            rec_stream = torch.cuda.Stream(device=dev)
 
     layout = None
     if "layout" in stages:
@@ -318,7 +328,8 @@ def main():
             cur = stage.forward(pages, slot=k & 1) if "det" in stages else None
             rec_ids = None
             if rec is not None:
-                rec_ids, _ = rec.ids(pages, gt_quads)          # host quad geometry + one pt_rec_forward (async)
+                with torch.cuda.stream(rec_stream) if rec_stream is not None else contextlib.nullcontext():
+                    rec_ids, _ = rec.ids(pages, gt_quads)      # host quad geometry + one pt_rec_forward (async)
             tpend = None
             if tsr is not None:
                 tsr_tables, tsr_metas = tsr.tables((PAGE, PAGE), table_boxes)    # host: one affine map per table
@@ -344,8 +355,9 @@ def main():
             t0 = time.perf_counter()
             if rec_ids is not None:
                 from pdf_table_amd.rec_stage import ctc_collapse
-                toks = ctc_collapse(rec_ids.cpu().numpy())     # D2H of int32 [lines, 160] + host collapse
-                eng.check()
+                with torch.cuda.stream(rec_stream) if rec_stream is not None else contextlib.nullcontext():
+                    toks = ctc_collapse(rec_ids.cpu().numpy())     # D2H of int32 [lines, 160] + host collapse
+                (eng_rec or eng).check()
                 if count:
                     ntok += sum(len(t) for t in toks)
             tick("ctc", t0)
@@ -382,15 +394,24 @@ def main():
                 if count:
                     ncells += sum(len(t["polygons"]) for t in tres)
 
+    if rec_stream is not None:
+        rec_stream.wait_stream(torch.cuda.current_stream(dev))      # the resident pages were uploaded on the default stream
     run(args.warmup)
     barrier()
     eng.profile_enable(True)
+    if eng_rec is not None:
+        eng_rec.profile_enable(True)
     t0 = time.perf_counter()
     run(args.steps, count=True)
     barrier()
     dt = time.perf_counter() - t0
     prof = eng.profile_read()
     eng.profile_enable(False)
+    if eng_rec is not None:
+        for k_, v_ in eng_rec.profile_read().items():
+            for f_ in v_:
+                prof[k_][f_] += v_[f_]
+        eng_rec.profile_enable(False)
     if trace is not None and rank == 0:
         print("[bench trace] host seconds over warm-up + timed steps:", {k: round(v, 3) for k, v in trace.items()}, file=sys.stderr)
     if dist is not None:
@@ -441,6 +462,7 @@ def main():
                                       + (" + PP-LCNet text-line orientation of every text line and page orientation of every page "
                                          "[opt-in stage, not part of BASELINE.json's metric]" if "cls" in stages else "")
                                       + (" [DEVICE HALF ONLY]" if args.no_post else "")
+                                      + (" [recogniser on a second engine and stream: --overlap-rec diagnostic]" if args.overlap_rec else "")
                                       + "; weights are random-init, so the stages are chained by the page generator's ground truth "
                                         "(table regions for TSR, text-line quads for recognition) instead of each other's outputs",
                           "pages_per_step_per_gpu": PAGES_PER_STEP, "page": [PAGE, PAGE],
