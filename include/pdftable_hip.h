@@ -343,8 +343,10 @@ int pt_cls_forward_lines(pt_engine* e, int slot, const uint8_t* d_pages_rgb, int
                          const pt_rec_line* d_lines, const int64_t* h_crop_px, int n_lines, int max_crop_h, int max_crop_w,
                          int out_h, int out_w, int textline, float* d_logits, int* n_classes, pt_stream stream);
 
-/* When enabled, every conv launch inside pt_det_forward* is bracketed by hipEvents on `stream`.
- * pt_profile_read returns accumulated milliseconds and launch count per kernel class. */
+/* on = 1: every kernel launch of the forward calls is bracketed by hipEvents on `stream`; on = 2 + class: only the
+ * launches of that kernel class (an event pair costs a few microseconds of idle GPU per launch, which adds up over the
+ * ~1000 launches of a four-stage step); 0: off.  pt_profile_read returns accumulated milliseconds, launch count and
+ * algorithmic FLOP per kernel class. */
 #define PT_PROF_CONV3X3 0
 #define PT_PROF_CONV1X1 1
 #define PT_PROF_STEM 2

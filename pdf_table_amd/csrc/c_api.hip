@@ -701,7 +701,8 @@ int pt_op_db_head_final(pt_engine* e, const uint16_t* d_in, int B, int H, int W,
 // ---- profiling ---------------------------------------------------------------------------------------
 int pt_profile_enable(pt_engine* e, int on) {
   PT_REQUIRE(e != nullptr, "pt_profile_enable: null engine");
-  e->prof.on = on != 0;
+  PT_REQUIRE(on >= 0 && on < 2 + PT_PROF_NCLASS, "pt_profile_enable: mode %d out of range", on);
+  e->prof.on = on;
   return PT_OK;
 }
 

@@ -75,7 +75,7 @@ struct PtArena {
 };
 
 struct PtProfile {
-  bool on = false;
+  int on = 0;         // 0 off, 1 every launch, 2 + class: only the launches of kernel class (on - 2)
   double ms[PT_PROF_NCLASS] = {0, 0, 0, 0};
   long long launches[PT_PROF_NCLASS] = {0, 0, 0, 0};
   double flop[PT_PROF_NCLASS] = {0, 0, 0, 0};
@@ -247,7 +247,7 @@ struct PtProfScope {
   hipStream_t s;
   int idx = -1;
   PtProfScope(pt_engine* e_, hipStream_t s_, int cls, double flop, const char* label = "") : e(e_), s(s_) {
-    if (e && e->prof.on) {
+    if (e && e->prof.on && (e->prof.on == 1 || e->prof.on - 2 == cls)) {
       PtProfile::Pending p;
       if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
       p.cls = cls;

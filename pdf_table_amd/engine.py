@@ -443,7 +443,8 @@ class HipEngine:
         return prob, logits
 
     # ---- profiling ---------------------------------------------------------------------------------
-    def profile_enable(self, on: bool = True):
+    def profile_enable(self, on=True):
+        """True / 1: HIP events around every launch; 2 + L.PT_PROF_CLASSES.index(name): only that kernel class; False: off"""
         L.check(self.lib.pt_profile_enable(self._h, int(on)), "pt_profile_enable")
 
     def profile_read(self):
