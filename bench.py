@@ -157,7 +157,7 @@ def main():
                     help="DB detector network: DBModel (BASELINE.json's configuration) or DBNasModel (diagnostic variant)")
     ap.add_argument("--no-post", action="store_true", help="device half only (diagnostic; not a valid headline)")
     ap.add_argument("--overlap-rec", action="store_true",
-                    help="diagnostic: the recogniser runs on a second engine and stream, concurrently with the other stages "
+                    help="diagnostic: the recogniser runs on a second stream, concurrently with the other stages "
                          "(per-kernel HIP-event durations then include contention, so the roofline object reads low)")
     ap.add_argument("--stages", default=os.environ.get("PT_BENCH_STAGES", "layout,det,rec,tsr"),
                     help="comma list of stages in the timed step: layout (PicoDet), det (configs[1]), rec, tsr (Lore)")
@@ -220,10 +220,7 @@ def main():
         else:
             eng.load_weights(L.PT_MODEL_CRNN, pack_crnn(csd, x3=False))
         rec = RecStage(eng)
-        if args.overlap_rec:       # second engine (own arena and scratch) on its own stream
-            eng_rec = HipEngine(local_rank)
-            eng_rec.load_weights(L.PT_MODEL_CRNN, pack_crnn(crnn_state_dict(seed=1), x3=False))
-            rec = RecStage(eng_rec)
+        if args.overlap_rec:       # same engine (every stage has its own activation arena and scratch), second stream
             rec_stream = torch.cuda.Stream(device=dev)
 
     layout = None
@@ -467,7 +464,7 @@ def main():
                                       + (" + PP-LCNet text-line orientation of every text line and page orientation of every page "
                                          "[opt-in stage, not part of BASELINE.json's metric]" if "cls" in stages else "")
                                       + (" [DEVICE HALF ONLY]" if args.no_post else "")
-                                      + (" [recogniser on a second engine and stream: --overlap-rec diagnostic]" if args.overlap_rec else "")
+                                      + (" [recogniser on a second stream: --overlap-rec diagnostic]" if args.overlap_rec else "")
                                       + "; weights are random-init, so the stages are chained by the page generator's ground truth "
                                         "(table regions for TSR, text-line quads for recognition) instead of each other's outputs",
                           "pages_per_step_per_gpu": PAGES_PER_STEP, "page": [PAGE, PAGE],

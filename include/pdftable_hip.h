@@ -12,8 +12,13 @@
  *     last failure on the calling thread;
  *   - pointers named d_* are DEVICE pointers on the engine's GPU, h_* are HOST pointers;
  *   - weights, activations and scratch are engine-owned; inputs and outputs are caller-owned;
- *   - one engine per GPU; calls on one engine must be serialised by the caller (the reference is
- *     single-threaded, base_infer_task.py:311-315); distinct engines own all their state (weights,
+ *   - one engine per GPU; calls on one engine must be issued by one host thread at a time (the
+ *     reference is single-threaded, base_infer_task.py:311-315).  Every stage (layout + cls, det,
+ *     rec, tsr) has its own activation arena and scratch inside the engine, so calls of DIFFERENT
+ *     stages may be in flight on different streams at the same time (measured: +10 % pages/s with
+ *     the recogniser on a second stream); two calls of the SAME stage -- and pt_cls_forward_lines
+ *     with pt_rec_forward*, which share the crop buffers -- must be stream-ordered.
+ *     Distinct engines own all their state (weights,
  *     arena, scratch, the decode state between the steps of pt_tsr_forward_decode) and are
  *     independent, with ONE restriction per device: the bf16 recognition LSTM (pt_rec_forward*)
  *     is a cluster kernel whose workgroups must all be resident at once, so two such launches may

@@ -8,6 +8,7 @@
 #include "common.h"
 
 static thread_local char g_err[1024] = "";
+static int ensure(void** buf, size_t* cap, size_t need);     // grow an engine-owned device buffer (defined below)
 
 void pt_set_error(const char* fmt, ...) {
   va_list ap;
@@ -60,7 +61,8 @@ void pt_engine_destroy(pt_engine* e) {
   (void)hipDeviceSynchronize();
   for (auto& kv : e->models)
     if (kv.second.d_blob) (void)hipFree(kv.second.d_blob);
-  if (e->arena.base) (void)hipFree(e->arena.base);
+  for (auto& a : e->arenas)
+    if (a.base) (void)hipFree(a.base);
   if (e->rec_crops) (void)hipFree(e->rec_crops);
   if (e->rec_gray) (void)hipFree(e->rec_gray);
   if (e->rec_off) (void)hipFree(e->rec_off);
@@ -70,6 +72,7 @@ void pt_engine_destroy(pt_engine* e) {
   if (e->cls_lut) (void)hipFree(e->cls_lut);
   if (e->cls_scratch) (void)hipFree(e->cls_scratch);
   if (e->layout_scratch) (void)hipFree(e->layout_scratch);
+  if (e->det_in) (void)hipFree(e->det_in);
   if (e->lstm_scratch) (void)hipFree(e->lstm_scratch);
   if (e->lstm_err) (void)hipHostFree(e->lstm_err);
   for (auto& p : e->prof.pending) {
@@ -390,17 +393,10 @@ int pt_det_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h, int w
   if ((rc = pt_det_plan(h, w, pre_flavour, &nh, &nw)) != PT_OK) return rc;
   const int mb = microbatch();
   // the pre-processed pages live in their own engine-owned buffer (not the arena, which the net resets)
-  static thread_local void* xbuf = nullptr;
-  static thread_local size_t xcap = 0;
   const int x3 = e->precision == PT_PRECISION_BF16X3;
   const size_t need = (size_t)(mb < n ? mb : n) * nh * nw * (x3 ? 8 : 4) * sizeof(bf16_t);
-  if (need > xcap) {
-    PT_HIP_CHECK(hipDeviceSynchronize());
-    if (xbuf) PT_HIP_CHECK(hipFree(xbuf));
-    xbuf = nullptr;
-    PT_HIP_CHECK(hipMalloc(&xbuf, need));
-    xcap = need;
-  }
+  if ((rc = ensure(&e->det_in, &e->det_in_cap, need)) != PT_OK) return rc;
+  void* xbuf = e->det_in;
   for (int i0 = 0; i0 < n; i0 += mb) {
     const int nb = (n - i0) < mb ? (n - i0) : mb;
     {

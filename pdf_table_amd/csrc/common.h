@@ -74,6 +74,8 @@ struct PtArena {
   }
 };
 
+enum { PT_ARENA_DET = 0, PT_ARENA_REC, PT_ARENA_TSR, PT_ARENA_LAYOUT, PT_ARENA_COUNT };
+
 struct PtProfile {
   int on = 0;         // 0 off, 1 every launch, 2 + class: only the launches of kernel class (on - 2)
   double ms[PT_PROF_NCLASS] = {0, 0, 0, 0};
@@ -91,7 +93,9 @@ struct PtProfile {
 struct pt_engine {
   int device = 0;
   int num_cu = 256;
-  PtArena arena;
+  // one activation arena per stage, so that calls of DIFFERENT stages may be in flight on different streams (two calls of
+  // one stage share its arena and must be stream-ordered); layout and the PP-LCNet classifiers share PT_ARENA_LAYOUT
+  PtArena arenas[PT_ARENA_COUNT];
   std::map<int, PtModel> models;
   PtProfile prof;
   int precision = 0;  // PT_PRECISION_*
@@ -101,6 +105,7 @@ struct pt_engine {
   void* rec_gray = nullptr; size_t rec_gray_cap = 0;
   void* rec_off = nullptr; size_t rec_off_cap = 0;
   std::vector<long long> rec_off_host;
+  void* det_in = nullptr; size_t det_in_cap = 0;             // pre-processed pages of pt_det_forward (one micro-batch)
   void* zero_page = nullptr;  // 8 KiB of zeros: DMA source for halo pixels outside the image
   void* tsr_scratch = nullptr; size_t tsr_scratch_cap = 0;   // candidate lists of the Lore decode
   void* layout_scratch = nullptr; size_t layout_scratch_cap = 0;   // layout input + head maps (pt_layout_forward)

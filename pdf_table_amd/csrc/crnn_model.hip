@@ -71,10 +71,10 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
     float* part;
   } bf;
   for (int attempt = 0; attempt < 2; ++attempt) {
-    e->arena.reset();
+    e->arenas[PT_ARENA_REC].reset();
     bool ok = true;
     auto take = [&](size_t elems) {
-      void* p = e->arena.take(elems * m * sizeof(bf16_t));
+      void* p = e->arenas[PT_ARENA_REC].take(elems * m * sizeof(bf16_t));
       if (!p) ok = false;
       return reinterpret_cast<bf16_t*>(p);
     };
@@ -93,7 +93,7 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
     bf.h = take(N * T * 512);
     bf.e1 = take(N * T * 256);
     bf.e2 = take(N * T * 512);
-    void* pp = e->arena.take(N * T * NT * 2 * sizeof(float));
+    void* pp = e->arenas[PT_ARENA_REC].take(N * T * NT * 2 * sizeof(float));
     if (!pp) ok = false;
     bf.part = reinterpret_cast<float*>(pp);
     if (ok) break;
@@ -102,11 +102,11 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
       return PT_ERR_HIP;
     }
     PT_HIP_CHECK(hipDeviceSynchronize());
-    if (e->arena.base) PT_HIP_CHECK(hipFree(e->arena.base));
-    e->arena.base = nullptr;
-    const size_t want = e->arena.high + (1u << 20);
-    PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arena.base), want));
-    e->arena.cap = want;
+    if (e->arenas[PT_ARENA_REC].base) PT_HIP_CHECK(hipFree(e->arenas[PT_ARENA_REC].base));
+    e->arenas[PT_ARENA_REC].base = nullptr;
+    const size_t want = e->arenas[PT_ARENA_REC].high + (1u << 20);
+    PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arenas[PT_ARENA_REC].base), want));
+    e->arenas[PT_ARENA_REC].cap = want;
   }
 
 #define RUN(call) do { if ((rc = (call)) != PT_OK) return rc; } while (0)

@@ -87,10 +87,10 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
   const int ch[4] = {64, 128, 256, 512};
   Bufs bf;
   for (int attempt = 0; attempt < 2; ++attempt) {
-    e->arena.reset();
+    e->arenas[PT_ARENA_DET].reset();
     bool ok = true;
     auto take = [&](size_t elems) {
-      void* p = e->arena.take(elems * m * sizeof(bf16_t));
+      void* p = e->arenas[PT_ARENA_DET].take(elems * m * sizeof(bf16_t));
       if (!p) ok = false;
       return reinterpret_cast<bf16_t*>(p);
     };
@@ -113,11 +113,11 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
       return PT_ERR_HIP;
     }
     PT_HIP_CHECK(hipDeviceSynchronize());
-    if (e->arena.base) PT_HIP_CHECK(hipFree(e->arena.base));
-    e->arena.base = nullptr;
-    const size_t want = e->arena.high + (1u << 20);
-    PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arena.base), want));
-    e->arena.cap = want;
+    if (e->arenas[PT_ARENA_DET].base) PT_HIP_CHECK(hipFree(e->arenas[PT_ARENA_DET].base));
+    e->arenas[PT_ARENA_DET].base = nullptr;
+    const size_t want = e->arenas[PT_ARENA_DET].high + (1u << 20);
+    PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arenas[PT_ARENA_DET].base), want));
+    e->arenas[PT_ARENA_DET].cap = want;
   }
 
 #define RUN(call) do { if ((rc = (call)) != PT_OK) return rc; } while (0)

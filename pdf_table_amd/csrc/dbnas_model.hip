@@ -51,7 +51,7 @@ struct Ctx {
   T alloc(int H, int W, int C) {
     T t;
     t.H = H; t.W = W; t.C = C;
-    t.p = reinterpret_cast<bf16_t*>(e->arena.take((size_t)n * H * W * C * mul * sizeof(bf16_t)));
+    t.p = reinterpret_cast<bf16_t*>(e->arenas[PT_ARENA_DET].take((size_t)n * H * W * C * mul * sizeof(bf16_t)));
     if (!t.p) ok = false;
     return t;
   }
@@ -116,9 +116,9 @@ int pt_dbnas_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, flo
   for (int pass = 0; pass < 2; ++pass) {
     c.dry = pass == 0;
     c.ok = true;
-    e->arena.reset();
-    float* gate = reinterpret_cast<float*>(e->arena.take((size_t)n * 512 * sizeof(float)));
-    float* part = reinterpret_cast<float*>(e->arena.take((size_t)n * PT_SE_CHUNKS * 512 * sizeof(float)));
+    e->arenas[PT_ARENA_DET].reset();
+    float* gate = reinterpret_cast<float*>(e->arenas[PT_ARENA_DET].take((size_t)n * 512 * sizeof(float)));
+    float* part = reinterpret_cast<float*>(e->arenas[PT_ARENA_DET].take((size_t)n * PT_SE_CHUNKS * 512 * sizeof(float)));
     if (!gate || !part) c.ok = false;
     T t = c.alloc(H / 2, W / 2, 64);
     {
@@ -181,11 +181,11 @@ int pt_dbnas_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, flo
     if (pass == 0) {
       if (c.ok) continue;
       PT_HIP_CHECK(hipDeviceSynchronize());
-      if (e->arena.base) PT_HIP_CHECK(hipFree(e->arena.base));
-      e->arena.base = nullptr;
-      const size_t want = e->arena.high + (1u << 20);
-      PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arena.base), want));
-      e->arena.cap = want;
+      if (e->arenas[PT_ARENA_DET].base) PT_HIP_CHECK(hipFree(e->arenas[PT_ARENA_DET].base));
+      e->arenas[PT_ARENA_DET].base = nullptr;
+      const size_t want = e->arenas[PT_ARENA_DET].high + (1u << 20);
+      PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arenas[PT_ARENA_DET].base), want));
+      e->arenas[PT_ARENA_DET].cap = want;
       continue;
     }
     if (!c.ok) {

@@ -40,7 +40,7 @@ struct Ctx {
   T alloc(int H, int W, int C) {
     T t;
     t.H = H; t.W = W; t.C = C;
-    t.p = reinterpret_cast<bf16_t*>(e->arena.take((size_t)n * H * W * C * mul * sizeof(bf16_t)));
+    t.p = reinterpret_cast<bf16_t*>(e->arenas[PT_ARENA_LAYOUT].take((size_t)n * H * W * C * mul * sizeof(bf16_t)));
     if (!t.p) ok = false;
     return t;
   }
@@ -185,9 +185,9 @@ int pt_picodet_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, f
   for (int pass = 0; pass < 2; ++pass) {
     c.dry = pass == 0;
     c.ok = true;
-    e->arena.reset();
-    c.gate = reinterpret_cast<float*>(e->arena.take((size_t)n * 512 * sizeof(float)));
-    c.part = reinterpret_cast<float*>(e->arena.take((size_t)n * PT_SE_CHUNKS * 512 * sizeof(float)));
+    e->arenas[PT_ARENA_LAYOUT].reset();
+    c.gate = reinterpret_cast<float*>(e->arenas[PT_ARENA_LAYOUT].take((size_t)n * 512 * sizeof(float)));
+    c.part = reinterpret_cast<float*>(e->arenas[PT_ARENA_LAYOUT].take((size_t)n * PT_SE_CHUNKS * 512 * sizeof(float)));
     if (!c.gate || !c.part) c.ok = false;
     T feats[3];
     lcnet_backbone(c, x, H, W, st22, feats);
@@ -230,11 +230,11 @@ int pt_picodet_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, f
     if (pass == 0) {
       if (c.ok) continue;
       PT_HIP_CHECK(hipDeviceSynchronize());
-      if (e->arena.base) PT_HIP_CHECK(hipFree(e->arena.base));
-      e->arena.base = nullptr;
-      const size_t want = e->arena.high + (1u << 20);
-      PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arena.base), want));
-      e->arena.cap = want;
+      if (e->arenas[PT_ARENA_LAYOUT].base) PT_HIP_CHECK(hipFree(e->arenas[PT_ARENA_LAYOUT].base));
+      e->arenas[PT_ARENA_LAYOUT].base = nullptr;
+      const size_t want = e->arenas[PT_ARENA_LAYOUT].high + (1u << 20);
+      PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arenas[PT_ARENA_LAYOUT].base), want));
+      e->arenas[PT_ARENA_LAYOUT].cap = want;
       continue;
     }
     if (!c.ok) {
@@ -271,9 +271,9 @@ int pt_pplcnet_forward_net(pt_engine* e, int slot, const bf16_t* x, int n, int H
   for (int pass = 0; pass < 2; ++pass) {
     c.dry = pass == 0;
     c.ok = true;
-    e->arena.reset();
-    c.gate = reinterpret_cast<float*>(e->arena.take((size_t)n * 512 * sizeof(float)));
-    float* part = reinterpret_cast<float*>(e->arena.take((size_t)n * PT_SE_CHUNKS * 512 * sizeof(float)));
+    e->arenas[PT_ARENA_LAYOUT].reset();
+    c.gate = reinterpret_cast<float*>(e->arenas[PT_ARENA_LAYOUT].take((size_t)n * 512 * sizeof(float)));
+    float* part = reinterpret_cast<float*>(e->arenas[PT_ARENA_LAYOUT].take((size_t)n * PT_SE_CHUNKS * 512 * sizeof(float)));
     c.part = part;
     if (!c.gate || !part) c.ok = false;
     T feats[3];
@@ -282,11 +282,11 @@ int pt_pplcnet_forward_net(pt_engine* e, int slot, const bf16_t* x, int n, int H
     const int keep = c.n;
     T mean;
     mean.H = rows / 32; mean.W = 32; mean.C = 512;
-    mean.p = reinterpret_cast<bf16_t*>(e->arena.take((size_t)rows * 512 * c.mul * sizeof(bf16_t)));
+    mean.p = reinterpret_cast<bf16_t*>(e->arenas[PT_ARENA_LAYOUT].take((size_t)rows * 512 * c.mul * sizeof(bf16_t)));
     T hid;
     hid.H = rows / 32; hid.W = 32; hid.C = 1280;
-    hid.p = reinterpret_cast<bf16_t*>(e->arena.take((size_t)rows * 1280 * c.mul * sizeof(bf16_t)));
-    float* lg = reinterpret_cast<float*>(e->arena.take((size_t)rows * 16 * sizeof(float)));
+    hid.p = reinterpret_cast<bf16_t*>(e->arenas[PT_ARENA_LAYOUT].take((size_t)rows * 1280 * c.mul * sizeof(bf16_t)));
+    float* lg = reinterpret_cast<float*>(e->arenas[PT_ARENA_LAYOUT].take((size_t)rows * 16 * sizeof(float)));
     if (!mean.p || !hid.p || !lg) c.ok = false;
     if (c.go()) {
       PtProfScope ps(e, s, PT_PROF_OTHER, 0, "pplcnet avgpool");
@@ -302,11 +302,11 @@ int pt_pplcnet_forward_net(pt_engine* e, int slot, const bf16_t* x, int n, int H
     if (pass == 0) {
       if (c.ok) continue;
       PT_HIP_CHECK(hipDeviceSynchronize());
-      if (e->arena.base) PT_HIP_CHECK(hipFree(e->arena.base));
-      e->arena.base = nullptr;
-      const size_t want = e->arena.high + (1u << 20);
-      PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arena.base), want));
-      e->arena.cap = want;
+      if (e->arenas[PT_ARENA_LAYOUT].base) PT_HIP_CHECK(hipFree(e->arenas[PT_ARENA_LAYOUT].base));
+      e->arenas[PT_ARENA_LAYOUT].base = nullptr;
+      const size_t want = e->arenas[PT_ARENA_LAYOUT].high + (1u << 20);
+      PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arenas[PT_ARENA_LAYOUT].base), want));
+      e->arenas[PT_ARENA_LAYOUT].cap = want;
       continue;
     }
     if (!c.ok) {

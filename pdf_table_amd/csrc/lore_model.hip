@@ -48,7 +48,7 @@ struct Ctx {
   T alloc(int H, int W, int C) {
     T t;
     t.H = H; t.W = W; t.C = C;
-    t.p = reinterpret_cast<bf16_t*>(e->arena.take((size_t)n * H * W * C * mul * sizeof(bf16_t)));
+    t.p = reinterpret_cast<bf16_t*>(e->arenas[PT_ARENA_TSR].take((size_t)n * H * W * C * mul * sizeof(bf16_t)));
     if (!t.p) ok = false;
     return t;
   }
@@ -198,11 +198,11 @@ static int lore_dla_run(pt_engine* e, const bf16_t* x, int n, int H, int W, floa
   for (int pass = 0; pass < 2; ++pass) {
     c.dry = pass == 0;     // pass 0 only plans the arena (and grows it if needed), pass 1 launches
     c.ok = true;
-    e->arena.reset();
+    e->arenas[PT_ARENA_TSR].reset();
     // shared DCN scratch: the largest site is 64 channels at H/4 x W/4 (9*64 columns); 128 ch at H/8 is half of it
     const size_t px4 = (size_t)n * (H / 4) * (W / 4);
-    c.cols = reinterpret_cast<bf16_t*>(e->arena.take(px4 * 576 * c.mul * sizeof(bf16_t)));
-    c.om = reinterpret_cast<float*>(e->arena.take(px4 * 32 * sizeof(float)));
+    c.cols = reinterpret_cast<bf16_t*>(e->arenas[PT_ARENA_TSR].take(px4 * 576 * c.mul * sizeof(bf16_t)));
+    c.om = reinterpret_cast<float*>(e->arenas[PT_ARENA_TSR].take(px4 * 32 * sizeof(float)));
     if (!c.cols || !c.om) c.ok = false;
 
     T t0 = c.alloc(H, W, 16);
@@ -248,7 +248,7 @@ static int lore_dla_run(pt_engine* e, const bf16_t* x, int n, int H, int W, floa
     const T feat = y[2];
     T hid = c.alloc(feat.H, feat.W, 256);
     if (sp) {      // only `hm` is needed everywhere: the other five heads run on patch mosaics (lore_decode.hip)
-      heads[0] = reinterpret_cast<float*>(e->arena.take((size_t)n * feat.H * feat.W * 8 * sizeof(float)));
+      heads[0] = reinterpret_cast<float*>(e->arenas[PT_ARENA_TSR].take((size_t)n * feat.H * feat.W * 8 * sizeof(float)));
       if (!heads[0]) c.ok = false;
     }
     for (int h = 0; h < 6; ++h) {
@@ -260,7 +260,7 @@ static int lore_dla_run(pt_engine* e, const bf16_t* x, int n, int H, int W, floa
       int rows_ax = 0, rows_cr = 0, rows_cell = 0, rows_corner = 0;
       pt_lore_mosaic_rows(n, &rows_ax, &rows_cr, &rows_cell, &rows_corner);
       const int MW = 768;
-      auto take = [&](size_t bytes) { void* p_ = e->arena.take(bytes); if (!p_) c.ok = false; return p_; };
+      auto take = [&](size_t bytes) { void* p_ = e->arenas[PT_ARENA_TSR].take(bytes); if (!p_) c.ok = false; return p_; };
       auto mosaic = [&](int rows, int C) {
         T t;
         t.H = rows; t.W = MW; t.C = C;
@@ -312,11 +312,11 @@ static int lore_dla_run(pt_engine* e, const bf16_t* x, int n, int H, int W, floa
     if (pass == 0) {
       if (c.ok) continue;      // everything fits: next pass launches
       PT_HIP_CHECK(hipDeviceSynchronize());
-      if (e->arena.base) PT_HIP_CHECK(hipFree(e->arena.base));
-      e->arena.base = nullptr;
-      const size_t want = e->arena.high + (1u << 20);
-      PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arena.base), want));
-      e->arena.cap = want;
+      if (e->arenas[PT_ARENA_TSR].base) PT_HIP_CHECK(hipFree(e->arenas[PT_ARENA_TSR].base));
+      e->arenas[PT_ARENA_TSR].base = nullptr;
+      const size_t want = e->arenas[PT_ARENA_TSR].high + (1u << 20);
+      PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arenas[PT_ARENA_TSR].base), want));
+      e->arenas[PT_ARENA_TSR].cap = want;
       continue;
     }
     if (!c.ok) {
@@ -361,7 +361,7 @@ struct WCtx {
   T alloc(int H, int W, int C) {
     T t;
     t.H = H; t.W = W; t.C = C;
-    t.p = reinterpret_cast<bf16_t*>(e->arena.take((size_t)n * H * W * C * mul * sizeof(bf16_t)));
+    t.p = reinterpret_cast<bf16_t*>(e->arenas[PT_ARENA_TSR].take((size_t)n * H * W * C * mul * sizeof(bf16_t)));
     if (!t.p) ok = false;
     return t;
   }
@@ -416,7 +416,7 @@ int pt_lore_wireless_forward_net(pt_engine* e, const bf16_t* x, int n, int H, in
   for (int pass = 0; pass < 2; ++pass) {
     c.dry = pass == 0;
     c.ok = true;
-    e->arena.reset();
+    e->arenas[PT_ARENA_TSR].reset();
     T s0 = c.alloc(H / 2, W / 2, 64);
     if (!c.dry && c.ok) {
       const PtTensor* w = c.get(c.x3 ? "stem.w3" : "stem.w");
@@ -480,11 +480,11 @@ int pt_lore_wireless_forward_net(pt_engine* e, const bf16_t* x, int n, int H, in
     if (pass == 0) {
       if (c.ok) continue;
       PT_HIP_CHECK(hipDeviceSynchronize());
-      if (e->arena.base) PT_HIP_CHECK(hipFree(e->arena.base));
-      e->arena.base = nullptr;
-      const size_t want = e->arena.high + (1u << 20);
-      PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arena.base), want));
-      e->arena.cap = want;
+      if (e->arenas[PT_ARENA_TSR].base) PT_HIP_CHECK(hipFree(e->arenas[PT_ARENA_TSR].base));
+      e->arenas[PT_ARENA_TSR].base = nullptr;
+      const size_t want = e->arenas[PT_ARENA_TSR].high + (1u << 20);
+      PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arenas[PT_ARENA_TSR].base), want));
+      e->arenas[PT_ARENA_TSR].cap = want;
       continue;
     }
     if (!c.ok) {

@@ -67,3 +67,38 @@ def test_two_engines_interleaved_equal_each_alone():
         assert np.array_equal(da.cpu().numpy()[t, :k], alone[0][3][t, :k])
         k = int(alone[1][2][t])
         assert np.array_equal(db.cpu().numpy()[t, :k], alone[1][3][t, :k])
+
+
+def test_stages_on_two_streams_equal_sequential():
+    """one engine, the recogniser on a second stream while the table-structure net runs on the first: every stage has its
+    own arena and scratch, so the results are those of the sequential calls (bit-exact)"""
+    g = torch.Generator().manual_seed(9)
+    gray = (torch.rand(700, L.PT_REC_H, L.PT_REC_W, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    x4 = torch.zeros(6, 512, 512, 4)
+    x4[..., :3] = torch.randn(6, 512, 512, 3, generator=g) * 0.7
+    x4 = x4.to(torch.bfloat16).cuda()
+    e = _engine(3)
+    try:
+        ids0, mx0 = e.rec_forward_net(gray)
+        c0, d0, l0 = e.tsr_forward_decode(x4, wiz_rev=True, vis_thresh=0.2, sync=True)
+        torch.cuda.synchronize()
+        s2 = torch.cuda.Stream()
+        s2.wait_stream(torch.cuda.current_stream())
+        for _ in range(3):
+            with torch.cuda.stream(s2):
+                ids1, mx1 = e.rec_forward_net(gray)
+            c1, d1, l1 = e.tsr_forward_decode(x4, wiz_rev=True, vis_thresh=0.2, sync=False)
+            with torch.cuda.stream(s2):
+                ids2, _ = e.rec_forward_net(gray)
+            torch.cuda.synchronize()
+            e.check()
+            assert np.array_equal(ids1.cpu().numpy(), ids0.cpu().numpy()) and np.array_equal(mx1.cpu().numpy(), mx0.cpu().numpy())
+            assert np.array_equal(ids2.cpu().numpy(), ids0.cpu().numpy())
+            c1h = c1.cpu().numpy()
+            assert np.array_equal(c1h, c0) and c0.sum() > 0
+            for t in range(len(c0)):
+                k = int(c0[t])
+                assert np.array_equal(d1.cpu().numpy()[t, :k], d0.cpu().numpy()[t, :k])
+                assert np.array_equal(l1.cpu().numpy()[t, :k], l0.cpu().numpy()[t, :k])
+    finally:
+        e.close()
