@@ -98,3 +98,67 @@ def test_rec_order_invariance_and_empty(eng, pages):
     # degenerate quad (zero area): crop is empty -> all-padding input, still decodes without error
     deg, _ = st.ids(dev, [np.array([[10, 10, 10, 10, 10, 10, 10, 10]], np.float64)])
     assert deg.shape == (1, L.PT_REC_T)
+
+
+# ---- table structure and layout at BASELINE.json's sizes: batch invariance -------------------------------------------
+@pytest.fixture(scope="module")
+def eng_tl():
+    from pdf_table_amd.engine import HipEngine
+    from pdf_table_amd.synth_weights import lore_dla34_state_dict, picodet_state_dict
+    from pdf_table_amd.weights import pack_lore_dla34, pack_picodet
+    e = HipEngine(0)
+    e.load_weights(L.PT_MODEL_LORE_DLA34, pack_lore_dla34(lore_dla34_state_dict(seed=2, hm_bias=(-1.2, -0.6)), x3=False))
+    e.load_weights(L.PT_MODEL_PICODET, pack_picodet(picodet_state_dict(seed=4, num_classes=5), 5, x3=False))
+    yield e
+    e.close()
+
+
+def test_tsr_fullsize_batch_invariant_and_deterministic(eng_tl):
+    """1024x1024 table images (the Lore input size of BASELINE.json's configs): a table's decoded cells, boxes and the 256
+    logic features do not depend on which other tables share its batch, nor on the run (bit-exact: every kernel tiles per
+    image or per patch; the sparse heads' mosaics pack patches of different tables side by side)"""
+    g = torch.Generator().manual_seed(31)
+    n = 5
+    x4 = torch.zeros(n, 1024, 1024, 4)
+    x4[..., :3] = torch.randn(n, 1024, 1024, 3, generator=g) * 0.7
+    x4 = x4.to(torch.bfloat16).cuda()
+    c0, d0, l0 = eng_tl.tsr_forward_decode(x4, wiz_rev=True, vis_thresh=0.2, sync=True)
+    c1, d1, l1 = eng_tl.tsr_forward_decode(x4, wiz_rev=True, vis_thresh=0.2, sync=True)
+    assert c0.sum() > 0 and np.array_equal(c0, c1)
+    d0, l0, d1, l1 = d0.cpu().numpy(), l0.cpu().numpy(), d1.cpu().numpy(), l1.cpu().numpy()
+    for t in range(n):
+        k = int(c0[t])
+        assert np.array_equal(d0[t, :k], d1[t, :k]) and np.array_equal(l0[t, :k], l1[t, :k])
+    for t in (0, 3):
+        cs, ds, ls = eng_tl.tsr_forward_decode(x4[t:t + 1].contiguous(), wiz_rev=True, vis_thresh=0.2, sync=True)
+        k = int(c0[t])
+        assert int(cs[0]) == k, (t, cs, c0)
+        assert np.array_equal(ds.cpu().numpy()[0, :k], d0[t, :k])
+        assert np.array_equal(ls.cpu().numpy()[0, :k], l0[t, :k])
+    print("tsr full size: cells per table", c0.tolist())
+
+
+def test_layout_fullsize_batch_invariant(eng_tl, pages):
+    """64-page batches of 1024x1024 pages through PicoDet at 800x608: a page's candidate records (the anchors above the
+    score floor with their raw head values) are the same set whether the page runs alone or inside the batch"""
+    imgs = np.stack([pages[i % 3][0] for i in range(64)])
+    imgs[5] = imgs[5][::-1].copy()                   # one page unlike the others
+    dev = torch.from_numpy(imgs).cuda()
+    counts, cands = eng_tl.layout_forward(dev, thr_lo=0.3)
+    counts = counts.cpu().numpy()
+    cands = cands.cpu().numpy()
+    assert counts.max() <= cands.shape[1]
+
+    def records(c, k):
+        r = c[:k, :2 + L.PT_LAYOUT_HEAD_CS]          # (level, anchor, 40 head values); the rest of a record is padding
+        key = r[:, :2].copy().view(np.int32)
+        order = np.lexsort((key[:, 1], key[:, 0]))
+        return r[order]
+
+    for p in (0, 5, 63):
+        c1, r1 = eng_tl.layout_forward(dev[p:p + 1].contiguous(), thr_lo=0.3)
+        k = int(c1.cpu().numpy()[0])
+        assert k == int(counts[p]), (p, k, counts[p])
+        assert np.array_equal(records(r1.cpu().numpy()[0], k), records(cands[p], k))
+    assert np.array_equal(records(cands[0], int(counts[0])), records(cands[3], int(counts[3])))    # same page, same records
+    print("layout full size: candidates per page", counts[:6].tolist())
