@@ -162,3 +162,22 @@ def test_layout_fullsize_batch_invariant(eng_tl, pages):
         assert np.array_equal(records(r1.cpu().numpy()[0], k), records(cands[p], k))
     assert np.array_equal(records(cands[0], int(counts[0])), records(cands[3], int(counts[3])))    # same page, same records
     print("layout full size: candidates per page", counts[:6].tolist())
+
+
+def test_rec_one_launch_lstm_equals_two_launches(eng):
+    """a step's worth of text lines (> 4096: the recognizer's LSTM then runs 192-line clusters in one launch) gives the ids
+    and winning logits of the 128-line clusters in two launches, bit for bit (PT_LSTM_MI is read at every call)"""
+    import os
+    g = torch.Generator().manual_seed(17)
+    gray = (torch.rand(4300, L.PT_REC_H, L.PT_REC_W, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    ids0, mx0 = eng.rec_forward_net(gray)
+    os.environ["PT_LSTM_MI"] = "2"
+    try:
+        ids1, mx1 = eng.rec_forward_net(gray)
+    finally:
+        del os.environ["PT_LSTM_MI"]
+    torch.cuda.synchronize()
+    eng.check()
+    assert np.array_equal(ids0.cpu().numpy(), ids1.cpu().numpy())
+    assert np.array_equal(mx0.cpu().numpy(), mx1.cpu().numpy())
+    assert len(np.unique(ids0.cpu().numpy())) > 20
