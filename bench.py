@@ -156,6 +156,9 @@ def main():
     ap.add_argument("--det-backbone", default="resnet18", choices=["resnet18", "proxylessnas"],
                     help="DB detector network: DBModel (BASELINE.json's configuration) or DBNasModel (diagnostic variant)")
     ap.add_argument("--no-post", action="store_true", help="device half only (diagnostic; not a valid headline)")
+    ap.add_argument("--aux-stream", type=int, default=0,
+                    help="1: the small-kernel work without 3x3 convolutions (PicoDet layout, the Lore processor and their "
+                         "D2H copies) runs on a second stream beside the conv-heavy nets")
     ap.add_argument("--overlap-rec", action="store_true",
                     help="diagnostic: the recogniser runs on a second stream, concurrently with the other stages "
                          "(per-kernel HIP-event durations then include contention, so the roofline object reads low)")
@@ -193,6 +196,10 @@ def main():
 
     eng = HipEngine(local_rank)
     eng_rec, rec_stream = None, None
+    aux = torch.cuda.Stream(device=dev) if args.aux_stream else None
+
+    def on_aux():
+        return torch.cuda.stream(aux) if aux is not None else contextlib.nullcontext()
     # weights: packed once on rank 0, broadcast over RCCL/xGMI, loaded from device memory everywhere
     nas = args.det_backbone == "proxylessnas"
     if nas:
@@ -321,7 +328,8 @@ def main():
         tproc = None         # ... of two steps ago (processor queued, rows on their way to pinned memory)
         for k in range(steps):
             t0 = time.perf_counter()
-            lay = layout.forward(pages) if layout is not None else None      # resize, LCNet/CSP-PAN/PicoHead, candidates (async)
+            with on_aux():
+                lay = layout.forward(pages) if layout is not None else None  # resize, LCNet/CSP-PAN/PicoHead, candidates (async)
             cur = stage.forward(pages, slot=k & 1) if "det" in stages else None
             rec_ids = None
             if rec is not None:
@@ -331,6 +339,13 @@ def main():
             if tsr is not None:
                 tsr_tables, tsr_metas = tsr.tables((PAGE, PAGE), table_boxes)    # host: one affine map per table
                 tpend = (tsr.start(pages, tsr_tables), tsr_metas)                # warp, DLA-34+DCN, decode (async)
+                if aux is not None:      # the processor of these tables will run on the auxiliary stream, behind this event
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    for (_, _, c_, d_, l_) in tpend[0]:
+                        for t_ in (c_, d_, l_):
+                            t_.record_stream(aux)
+                    tpend = tpend + (ev,)
             cls_out = None
             if cls_line is not None:
                 from pdf_table_amd.rec_stage import build_lines
@@ -376,7 +391,10 @@ def main():
                     ncells += sum(len(t["polygons"]) for t in tres)
             tproc = None
             if tprev is not None:      # tables of the previous step: counts are ready, the processor and its D2H are queued
-                tproc = (tsr.process(tprev[0]), tprev[1])      # behind this step's work; nothing here blocks on this step
+                with on_aux():
+                    if aux is not None:
+                        aux.wait_event(tprev[2])
+                    tproc = (tsr.process(tprev[0]), tprev[1])  # behind this step's work; nothing here blocks on this step
             tick("tsr_finish", t0)
             prev = cur
             tprev = tpend
@@ -391,8 +409,9 @@ def main():
                 if count:
                     ncells += sum(len(t["polygons"]) for t in tres)
 
-    if rec_stream is not None:
-        rec_stream.wait_stream(torch.cuda.current_stream(dev))      # the resident pages were uploaded on the default stream
+    for s_ in (rec_stream, aux):
+        if s_ is not None:
+            s_.wait_stream(torch.cuda.current_stream(dev))          # the resident pages were uploaded on the default stream
     run(args.warmup)
     barrier()
     # HIP events around the launches of the roofline's kernel class only (mode 2 + class 0 = the 3x3 convs): an event pair per
@@ -465,6 +484,7 @@ def main():
                                          "[opt-in stage, not part of BASELINE.json's metric]" if "cls" in stages else "")
                                       + (" [DEVICE HALF ONLY]" if args.no_post else "")
                                       + (" [recogniser on a second stream: --overlap-rec diagnostic]" if args.overlap_rec else "")
+                                      + (" [layout and the Lore processor on an auxiliary stream]" if args.aux_stream else "")
                                       + "; weights are random-init, so the stages are chained by the page generator's ground truth "
                                         "(table regions for TSR, text-line quads for recognition) instead of each other's outputs",
                           "pages_per_step_per_gpu": PAGES_PER_STEP, "page": [PAGE, PAGE],

@@ -14,7 +14,8 @@
  *   - weights, activations and scratch are engine-owned; inputs and outputs are caller-owned;
  *   - one engine per GPU; calls on one engine must be issued by one host thread at a time (the
  *     reference is single-threaded, base_infer_task.py:311-315).  Every stage (layout + cls, det,
- *     rec, tsr) has its own activation arena and scratch inside the engine, so calls of DIFFERENT
+ *     rec, the tsr detector pt_tsr_forward* / pt_tsr_decode, the tsr processor pt_tsr_process) has
+ *     its own activation arena and scratch inside the engine, so calls of DIFFERENT
  *     stages may be in flight on different streams at the same time (measured: +10 % pages/s with
  *     the recogniser on a second stream); two calls of the SAME stage -- and pt_cls_forward_lines
  *     with pt_rec_forward*, which share the crop buffers -- must be stream-ordered.

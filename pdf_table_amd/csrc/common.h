@@ -74,7 +74,7 @@ struct PtArena {
   }
 };
 
-enum { PT_ARENA_DET = 0, PT_ARENA_REC, PT_ARENA_TSR, PT_ARENA_LAYOUT, PT_ARENA_COUNT };
+enum { PT_ARENA_DET = 0, PT_ARENA_REC, PT_ARENA_TSR, PT_ARENA_TSRP, PT_ARENA_LAYOUT, PT_ARENA_COUNT };   // TSRP: the Lore processor
 
 struct PtProfile {
   int on = 0;         // 0 off, 1 every launch, 2 + class: only the launches of kernel class (on - 2)

@@ -278,14 +278,14 @@ int pt_lore_process(pt_engine* e, const float* d_logi, const float* d_dets, cons
                o_l32 = carve((size_t)Npad * 32 * be), o_le = carve((size_t)Npad * 256 * be),
                o_lg = carve((size_t)Npad * 8 * 4), o_sk = carve((size_t)Npad * 8 * 4),
                o_tok = carve(tok.size() * 4), o_tiles = carve(tiles.size() * 4);
-  if (off > e->arenas[PT_ARENA_TSR].cap) {
+  if (off > e->arenas[PT_ARENA_TSRP].cap) {
     PT_HIP_CHECK(hipDeviceSynchronize());
-    if (e->arenas[PT_ARENA_TSR].base) PT_HIP_CHECK(hipFree(e->arenas[PT_ARENA_TSR].base));
-    e->arenas[PT_ARENA_TSR].base = nullptr; e->arenas[PT_ARENA_TSR].cap = 0;
-    PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arenas[PT_ARENA_TSR].base), off + (1u << 20)));
-    e->arenas[PT_ARENA_TSR].cap = off + (1u << 20);
+    if (e->arenas[PT_ARENA_TSRP].base) PT_HIP_CHECK(hipFree(e->arenas[PT_ARENA_TSRP].base));
+    e->arenas[PT_ARENA_TSRP].base = nullptr; e->arenas[PT_ARENA_TSRP].cap = 0;
+    PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arenas[PT_ARENA_TSRP].base), off + (1u << 20)));
+    e->arenas[PT_ARENA_TSRP].cap = off + (1u << 20);
   }
-  char* base = e->arenas[PT_ARENA_TSR].base;
+  char* base = e->arenas[PT_ARENA_TSRP].base;
   float* x = reinterpret_cast<float*>(base + o_x);
   bf16_t* x0 = reinterpret_cast<bf16_t*>(base + o_x0);
   bf16_t* xb = reinterpret_cast<bf16_t*>(base + o_xb);
