@@ -9,6 +9,7 @@
 // Activations are NHWC bf16; in the BF16X3 precision mode every tensor is [hi(C) | lo(C)] per pixel and values are
 // hi + lo in fp32.
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -148,6 +149,71 @@ __global__ __launch_bounds__(256) void dwconvt_up_add_kernel(const bf16_t* __res
       for (int q = 0; q < 8; ++q) acc[q] += a[q];
     }
     store8(out + oo, C, split, acc);
+  }
+}
+
+// f = 2 (kernel 4, padding 1), the up-sampler of every IDAUp step but one: a thread owns a 2x2 output block of one 8-channel
+// group -- the four outputs read the same 3x3 input neighbourhood (9 loads instead of 16) and the 16 x C weight table comes
+// from LDS instead of 128 B per output through L1.  Per output the terms and their order are those of the kernel above
+// (dy = 0, 1 outer, dx = 0, 1 inner; terms outside the map skipped), so the results are bit-identical.
+__global__ __launch_bounds__(256) void dwconvt_up2_add_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w,
+                                                               const bf16_t* __restrict__ add, bf16_t* __restrict__ out,
+                                                               int B, int h, int wd, int C, int split) {
+  extern __shared__ float s_w[];                    // [16][C]
+  for (int i = threadIdx.x; i < 16 * C; i += 256) s_w[i] = w[i];
+  __syncthreads();
+  const int cgn = C >> 3;
+  const int cs = split ? 2 * C : C;
+  const int OW = wd * 2;
+  const unsigned total = (unsigned)B * h * wd * cgn;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    unsigned t = i / (unsigned)cgn;
+    const int cg = (int)(i - t * (unsigned)cgn);
+    const unsigned t2 = t / (unsigned)wd;
+    const int ax = (int)(t - t2 * (unsigned)wd);
+    const int b = (int)(t2 / (unsigned)h);
+    const int ay = (int)(t2 - (unsigned)b * (unsigned)h);
+    float v[3][3][8];
+    bool ok[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int iy = ay - 1 + r, ix = ax - 1 + c;
+        ok[r][c] = iy >= 0 && iy < h && ix >= 0 && ix < wd;
+        if (ok[r][c]) load8(in + (((size_t)b * h + iy) * wd + ix) * cs + cg * 8, C, split, v[r][c]);
+      }
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+        // output (2 ay + py, 2 ax + px): rows iy1 = ay + py (ky = 1 - py ... see the general kernel), then iy1 - 1
+        float acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+          const int r = py + 1 - dy;                 // neighbourhood row of iy = ay + py - dy
+          const int ky = py + 1 - 2 * (py - dy);     // oy + 1 - 2 iy with oy = 2 ay + py
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            const int c = px + 1 - dx;
+            const int kx = px + 1 - 2 * (px - dx);
+            if (!ok[r][c]) continue;
+            const float* wp = s_w + (ky * 4 + kx) * C + cg * 8;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] += v[r][c][q] * wp[q];
+          }
+        }
+        const size_t oo = (((size_t)b * (2 * h) + 2 * ay + py) * OW + 2 * ax + px) * cs + cg * 8;
+        if (add) {
+          float a[8];
+          load8(add + oo, C, split, a);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc[q] += a[q];
+        }
+        store8(out + oo, C, split, acc);
+      }
   }
 }
 
@@ -734,6 +800,14 @@ int pt_launch_dcn_im2col(const bf16_t* x, const float* om, bf16_t* cols, int B, 
 int pt_launch_dwconvt_up_add(const bf16_t* in, const float* w, const bf16_t* add, bf16_t* out, int B, int h, int wd,
                              int C, int f, int split, hipStream_t s) {
   PT_REQUIRE(in && w && out && C % 8 == 0 && (f == 2 || f == 4), "dwconvT: bad arguments");
+  const long long blocks2 = (long long)B * h * wd * (C / 8);
+  const char* sw = getenv("PT_DWCONVT2");       // PT_DWCONVT2=0: the general kernel also for f = 2 (A/B switch, read per call)
+  if (f == 2 && blocks2 < (1ll << 31) && C <= 512 && !(sw && sw[0] == '0')) {
+    hipLaunchKernelGGL(dwconvt_up2_add_kernel, dim3(grid_for(blocks2)), dim3(256), (size_t)16 * C * sizeof(float), s, in, w, add, out,
+                       B, h, wd, C, split);
+    PT_HIP_CHECK(hipGetLastError());
+    return PT_OK;
+  }
   hipLaunchKernelGGL(dwconvt_up_add_kernel, dim3(grid_for((long long)B * h * f * wd * f * (C / 8))), dim3(256), 0, s, in,
                      w, add, out, B, h, wd, C, f, split);
   PT_HIP_CHECK(hipGetLastError());

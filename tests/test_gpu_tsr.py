@@ -458,3 +458,27 @@ np.savez(sys.argv[1], **{k: v.float().cpu().numpy() for k, v in heads.items()})
         outs.append(np.load(out))
     for k in outs[0].files:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+def test_up_sampler_block_kernel_equals_general_kernel(eng, mode):
+    """dwconvt_up2_add_kernel (2x2 output block per thread, weights in LDS) gives the head maps of the general
+    depthwise-transposed-conv kernel bit for bit (PT_DWCONVT2 is read at every call); odd map sizes"""
+    import os
+    eng.set_precision(L.PT_PRECISION_BF16X3 if mode == "bf16x3" else L.PT_PRECISION_BF16)
+    try:
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(2, 3, 160, 224, generator=g) * 0.7
+        xd = _x4(x, split=mode == "bf16x3").cuda()
+        a = {k: t.cpu().numpy() for k, t in eng.tsr_forward_net(xd).items()}
+        os.environ["PT_DWCONVT2"] = "0"
+        try:
+            b = {k: t.cpu().numpy() for k, t in eng.tsr_forward_net(xd).items()}
+        finally:
+            del os.environ["PT_DWCONVT2"]
+        assert set(a) == set(b) and len(a) == 6
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+        assert float(np.abs(a["hm"]).max()) > 0
+    finally:
+        eng.set_precision(L.PT_PRECISION_BF16)
