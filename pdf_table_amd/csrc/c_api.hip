@@ -20,7 +20,7 @@ void pt_set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* pt_last_error(void) { return g_err; }
-int pt_abi_version(void) { return 4; }
+int pt_abi_version(void) { return 5; }   // 5: pt_engine_check, pt_profile_enable modes, pt_hard_nms
 
 int pt_engine_check(pt_engine* e) {
   PT_REQUIRE(e, "pt_engine_check: null engine");
