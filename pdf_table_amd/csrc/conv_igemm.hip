@@ -344,45 +344,37 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
   const int lane = tid & 63, wave = tid >> 6;
   const int lx = lane & 31, q = lane >> 5;
 
-  // reps > 1 (data-dependent extents, ConvDesc.ylimit; short-K layers): a workgroup walks `reps` consecutive tiles and stops
-  // at the first one beyond the row limit -- the worst-case grid of a mostly empty map is reps times smaller, and the first
-  // K-chunk of the NEXT tile is fetched into registers before this tile's epilogue, so that a short-K tile does not start
-  // with an exposed round trip to memory
+  // reps > 1 (data-dependent extents, ConvDesc.ylimit): a workgroup walks `reps` consecutive tiles and stops at the first
+  // one beyond the row limit -- the worst-case grid of a mostly empty map is reps times smaller
   const int reps = p.reps > 1 ? p.reps : 1;
+  for (int rep = 0; rep < reps; ++rep) {
+  int L, nt;
+  if (reps == 1) {
+    L = xcd_remap(blockIdx.x, gridDim.x);
+    tile_order(L, p.n_tiles, p.n_group, nt, L);
+  } else {
+    L = blockIdx.x * reps + rep;
+    if (L >= p.total_tiles) break;
+    nt = L % p.n_tiles;
+    L /= p.n_tiles;
+    if (rep) __syncthreads();                      // the previous tile's epilogue has finished with the LDS image
+  }
+  const int txi = L % p.tiles_x;
+  L /= p.tiles_x;
+  const int tyi = L % p.tiles_y;
+  const int b = L / p.tiles_y;
+  const int oy0 = tyi * C::TH, ox0 = txi * C::TW;
+  if (p.ylimit && oy0 >= *p.ylimit) break;         // uniform over the workgroup; later tiles of the walk are further down
+  const int iy0 = oy0 * STRIDE - (KS / 2), ix0 = ox0 * STRIDE - (KS / 2);
   const int nchunks = p.split ? 3 * (p.Cin >> 5) : (p.Cin >> 5);
   const int in_cs = p.split ? 2 * p.Cin : p.Cin;   // channels per input pixel in memory
-  struct Tile { int b, oy0, ox0, nt; bool valid; };
-  auto tile_at = [&](int rep) -> Tile {
-    Tile t{0, 0, 0, 0, false};
-    if (rep >= reps) return t;
-    int L, nt;
-    if (reps == 1) {
-      L = xcd_remap(blockIdx.x, gridDim.x);
-      tile_order(L, p.n_tiles, p.n_group, nt, L);
-    } else {
-      L = blockIdx.x * reps + rep;
-      if (L >= p.total_tiles) return t;
-      nt = L % p.n_tiles;
-      L /= p.n_tiles;
-    }
-    const int txi = L % p.tiles_x;
-    L /= p.tiles_x;
-    const int tyi = L % p.tiles_y;
-    t.b = L / p.tiles_y;
-    t.oy0 = tyi * C::TH;
-    t.ox0 = txi * C::TW;
-    t.nt = nt;
-    t.valid = !(p.ylimit && t.oy0 >= *p.ylimit);    // uniform over the workgroup; later tiles of the walk are further down
-    return t;
-  };
+  const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * in_cs;
+  const bf16_t* wt = p.w + (size_t)nt * nchunks * (C::TAPS * 64 * 32);
 
   u32x4 rin[C::NI];
   u32x4 rw[C::NWP];
 
-  auto prefetch = [&](const Tile& t, int chunk) {
-    const int iy0 = t.oy0 * STRIDE - (KS / 2), ix0 = t.ox0 * STRIDE - (KS / 2);
-    const bf16_t* in_b = p.in + (size_t)t.b * p.H * p.W * in_cs;
-    const bf16_t* wt = p.w + (size_t)t.nt * nchunks * (C::TAPS * 64 * 32);
+  auto prefetch = [&](int chunk) {
     // split mode: K chunks walk [x_hi | x_lo] against w_hi, then x_hi again against w_lo
     int c0 = chunk << 5;
     if (c0 >= in_cs) c0 -= in_cs;
@@ -419,13 +411,6 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
     }
   };
 
-  Tile cur = tile_at(0);
-  if (cur.valid) prefetch(cur, 0);
-  for (int rep = 0; rep < reps && cur.valid; ++rep) {
-  Tile nxt{0, 0, 0, 0, false};
-  if (rep) __syncthreads();                        // the previous tile's epilogue has finished with the LDS image
-  const int b = cur.b, oy0 = cur.oy0, ox0 = cur.ox0, nt = cur.nt;
-
   f32x16 acc[C::MT][2];
 #pragma unroll
   for (int m = 0; m < C::MT; ++m)
@@ -443,16 +428,12 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
   }
   const char* b_base = s_w + lx * C::PIXB + q * 16;
 
+  prefetch(0);
   for (int c = 0; c < nchunks; ++c) {
     __syncthreads();  // everyone is done reading the previous slice
     commit();
     __syncthreads();
-    if (c + 1 < nchunks) {
-      prefetch(cur, c + 1);
-    } else {
-      nxt = tile_at(rep + 1);
-      if (nxt.valid) prefetch(nxt, 0);              // travels under this tile's last MFMAs and its epilogue
-    }
+    if (c + 1 < nchunks) prefetch(c + 1);
 #pragma unroll
     for (int r = 0; r < KS; ++r) {
 #pragma unroll
@@ -539,7 +520,6 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
           }
         }
     }
-    cur = nxt;
     continue;
   }
   // ---- epilogue through LDS (fp32 [pixel][64]) ----
@@ -559,7 +539,6 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
   }
   __syncthreads();
   epilogue_store<C::TH, C::TW>(p, stage, tid, b, oy0, ox0, nt * 64);
-  cur = nxt;
   }   // rep
 }
 
@@ -1358,21 +1337,6 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
     k.total_tiles = (int)nblk;
     k.n_group = 0;
     nblk = (nblk + 15) / 16;
-  } else if (KS == 3) {
-    // short-K 3x3 layers (<= 8 K-chunks): the tile's fixed cost -- the first fetch, the epilogue -- is as long as its MFMAs;
-    // a workgroup walks PT_CONV_WALK consecutive tiles and fetches the next tile's first chunk under the current epilogue
-    static int walk = -1;
-    if (walk < 0) {
-      const char* ev = getenv("PT_CONV_WALK");
-      walk = ev ? atoi(ev) : 0;
-    }
-    const int nchunks = (k.split ? 3 : 1) * (k.Cin >> 5);
-    if (walk > 1 && nchunks <= 8 && nblk >= 8192) {
-      k.reps = walk;
-      k.total_tiles = (int)nblk;
-      k.n_group = 0;
-      nblk = (nblk + walk - 1) / walk;
-    }
   }
   char label[48];
   snprintf(label, sizeof(label), "conv%dx%d s%d %d->%d @%dx%d%s", KS, KS, STRIDE, k.Cin, k.N, k.Ho, k.Wo, k.head_w ? " +head" : (k.split ? " x3" : ""));
