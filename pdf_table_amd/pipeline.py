@@ -13,6 +13,7 @@ synchronous), crops never leave the GPU, and a failed page/line follows the refe
 """
 from __future__ import annotations
 
+import contextlib
 import time
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
@@ -49,8 +50,12 @@ class OcrTablePipeline:
                  table_structure_model: str = "Lore", table_structure_task_type: str = "wtw",
                  tsr_task_path: Optional[str] = None, layout_model: str = "picodet", layout_task_type: str = "en",
                  layout_task_path: Optional[str] = None, text_orientation: bool = False,
-                 orientation_task_path: Optional[str] = None, table_html: bool = False, **kwargs):
+                 orientation_task_path: Optional[str] = None, table_html: bool = False, overlap_rec: bool = True, **kwargs):
         self.engine = HipEngine(device)
+        # the recogniser of a page batch runs on a second stream beside the layout and table-structure stages of the same
+        # batch (every stage owns its arena inside the engine); the results do not depend on it
+        self.overlap_rec = overlap_rec
+        self._rec_stream = None
         dk = dict(kwargs)
         rk = dict(kwargs)
         if synthetic_seed is not None:
@@ -110,19 +115,48 @@ class OcrTablePipeline:
             boxes = stage.boxes(prob, bitmap, shape[:2], ev)
             boxes = [sort_boxes_reading_order(b) for b in boxes]
             b_ = time.time()
+            rec_stage = self.text_recognizer._stage
+            side = None
+            if self.overlap_rec and (self.layout_task is not None or self.table_structure_task is not None):
+                if self._rec_stream is None:
+                    self._rec_stream = torch.cuda.Stream(device=self.engine._tdev)
+                side = self._rec_stream
+                side.wait_stream(torch.cuda.current_stream(self.engine._tdev))
+                batch.record_stream(side)
+
+            def on_side():
+                return torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
+
+            rec_state, texts = None, None
             try:
-                texts = self.text_recognizer.recognize_quads(batch, boxes)
+                with on_side():
+                    rec_state = rec_stage.start(batch, boxes)        # asynchronous: crops, CRNN, arg-max
+                    if side is None:
+                        texts = rec_stage.finish(rec_state)
             except Exception:                      # reference: a failing recognition yields empty strings
-                texts = [[""] * len(b) for b in boxes]
-            ori = None
-            if self.orientation_task is not None:
-                ori = []
-                flat, _ = self.orientation_task.lines(batch, boxes)
+                rec_state, texts = None, [[""] * len(b) for b in boxes]
+
+            def finish_rec_and_orientation():
+                nonlocal texts
+                if texts is None:
+                    try:
+                        with on_side():
+                            texts = rec_stage.finish(rec_state)
+                    except Exception:
+                        texts = [[""] * len(b) for b in boxes]
+                if self.orientation_task is None:
+                    return None
+                res_all = []
+                with on_side():          # shares the crop buffers with the recogniser: same stream, behind it
+                    flat, _ = self.orientation_task.lines(batch, boxes)
                 o = 0
                 for b in boxes:       # the reference votes per page; it then rotates a non-upright page by 180 degrees and
                     res = flat[o:o + len(b)]      # detects again (:471-478) -- left to the caller, who holds the pages
                     o += len(b)
-                    ori.append((res, self.orientation_task._stage.orientation_vote(res)))
+                    res_all.append((res, self.orientation_task._stage.orientation_vote(res)))
+                return res_all
+
+            ori = finish_rec_and_orientation() if side is None else None
             c = time.time()
             lay = self.layout_task.detect_pages(batch) if self.layout_task is not None else None
             tsr = None
@@ -138,6 +172,8 @@ class OcrTablePipeline:
                         bx = [b for b in bx if b[2] > b[0] and b[3] > b[1]]
                         tb.append(np.array(bx, dtype=np.int64).reshape(-1, 4))
                 tsr = self.table_structure_task.recognize_tables(batch, tb)
+            if side is not None:
+                ori = finish_rec_and_orientation()
             if tsr is not None and self.table_html:
                 from .table_html import table_cells_from_logits
                 from .table_text_match import cells_to_html, match_table_cells_and_text, text_boxes, texts_in_table

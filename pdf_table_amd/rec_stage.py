@@ -140,13 +140,22 @@ class RecStage:
         ids, _ = self.eng.rec_forward(pages, lines, want_maxlogit=False)
         return ids, lines
 
-    def __call__(self, pages: torch.Tensor, boxes_per_page: Sequence[np.ndarray]) -> List[List[str]]:
+    def start(self, pages: torch.Tensor, boxes_per_page: Sequence[np.ndarray]):
+        """device half (asynchronous on the current stream): quad geometry on the host, one pt_rec_forward"""
         ids, lines = self.ids(pages, boxes_per_page)
-        toks = ctc_collapse(ids.cpu().numpy()) if len(lines) else []
+        return ids, len(lines), [len(b) for b in boxes_per_page]
+
+    def finish(self, state) -> List[List[str]]:
+        """host half: ids to the host (synchronises the stream it is called on), CTC collapse, vocabulary"""
+        ids, nl, per_page = state
+        toks = ctc_collapse(ids.cpu().numpy()) if nl else []
         self.eng.check()          # the D2H copy synchronised the stream: surface device-side failures of this batch
         texts = ["".join(self.label.get(t, "") for t in row) for row in toks]
         out, o = [], 0
-        for b in boxes_per_page:
-            out.append(texts[o:o + len(b)])
-            o += len(b)
+        for k in per_page:
+            out.append(texts[o:o + k])
+            o += k
         return out
+
+    def __call__(self, pages: torch.Tensor, boxes_per_page: Sequence[np.ndarray]) -> List[List[str]]:
+        return self.finish(self.start(pages, boxes_per_page))

@@ -166,3 +166,31 @@ def test_pipeline_table_html():
         ncell = sum(1 for r in tb["table_html"] if r.startswith("<td"))
         assert ncell == len(tb["polygons"]) or len(tb["scores"]) == 0
         assert tb["db_table_html"][0].startswith("<table class='pdf-table'")
+
+
+def test_pipeline_recogniser_on_second_stream_changes_nothing():
+    """OcrTablePipeline(overlap_rec=True) -- the default: the recogniser of a page batch runs on a second stream beside the
+    layout and table-structure stages -- gives exactly the results of the sequential pipeline, with text-line orientation
+    and table HTML switched on (every consumer of the recognised text waits for it)"""
+    from pdf_table_amd.pipeline import OcrTablePipeline
+    pages = [make_page(3)[0], make_page(5)[0]]
+    tb = [np.asarray(make_page(i)[1]["tables"]).reshape(-1, 4) for i in (3, 5)]
+    outs = []
+    for overlap in (False, True, True):
+        p = OcrTablePipeline(device=0, synthetic_seed=0, layout=True, table_structure=True, text_orientation=True,
+                             table_html=True, overlap_rec=overlap)
+        outs.append(p.predict(pages, table_boxes=tb))
+        p.engine.close()
+    ref = outs[0]
+    assert sum(len(r.ocr_result) for r in ref) >= 1 and sum(len(r.table_structure_result) for r in ref) >= 1
+    for got in outs[1:]:
+        for a, b in zip(ref, got):
+            assert np.array_equal(a.det_result, b.det_result)
+            assert [o["text"] for o in a.ocr_result] == [o["text"] for o in b.ocr_result]
+            assert a.text_upright == b.text_upright
+            assert [o["class_ids"] for o in a.text_line_orientation] == [o["class_ids"] for o in b.text_line_orientation]
+            assert len(a.layout_result) == len(b.layout_result)
+            assert len(a.table_structure_result) == len(b.table_structure_result)
+            for ta, tb_ in zip(a.table_structure_result, b.table_structure_result):
+                assert np.array_equal(ta["polygons"], tb_["polygons"]) and np.array_equal(ta["logi"], tb_["logi"])
+                assert ta.get("table_html") == tb_.get("table_html")
