@@ -1,0 +1,30 @@
+"""tools/pipeline_timing.py: wall time of OcrTablePipeline.predict (synchronous, stage after stage, one 32-page batch) with
+the recogniser on the main stream and on a second stream (GPU box)."""
+import time
+
+import numpy as np
+
+from pdf_table_amd.pipeline import OcrTablePipeline
+from pdf_table_amd.synth_pages import make_page
+
+made = [make_page(i) for i in range(8)]
+pages = [made[i % 8][0] for i in range(32)]
+tb = [np.asarray(made[i % 8][1]["tables"]).reshape(-1, 4) for i in range(32)]
+for overlap in (False, True, False, True):
+    p = OcrTablePipeline(device=0, synthetic_seed=0, layout=True, table_structure=True, overlap_rec=overlap)
+    # random-init detection finds almost no text: give the recogniser the generator's lines through a stub of the box stage
+    quads = []
+    for i in range(32):
+        l = made[i % 8][1]["lines"].astype(np.float64)
+        quads.append(np.stack([l[:, 0], l[:, 1], l[:, 2], l[:, 1], l[:, 2], l[:, 3], l[:, 0], l[:, 3]], 1))
+    stage = p.text_detector._stage
+    orig = stage.boxes
+    stage.boxes = lambda prob, bm, shape, ev, _o=orig, _q=quads: (_o(prob, bm, shape, ev), _q)[1]
+    p.predict(pages, table_boxes=tb)
+    ts = []
+    for _ in range(3):
+        t0 = time.time()
+        p.predict(pages, table_boxes=tb)
+        ts.append(time.time() - t0)
+    print(f"overlap_rec={overlap}: {min(ts) * 1e3:.0f} ms per 32-page predict() (best of 3), {32 / min(ts):.0f} pages/s")
+    p.engine.close()
