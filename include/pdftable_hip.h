@@ -24,9 +24,9 @@
  *     independent, with ONE restriction per device: the bf16 recognition LSTM (pt_rec_forward*)
  *     is a cluster kernel whose workgroups must all be resident at once, so two such launches may
  *     not overlap in time on one GPU (two engines, streams or processes).  An overlap cannot hang:
- *     a workgroup gives up after a bounded wait, pt_engine_check() (and the next rec call on that
- *     engine) returns PT_ERR_HIP ("not co-resident"); PT_LSTM_CLUSTER=0 selects the streaming
- *     kernel instead;
+ *     a workgroup gives up after a bounded wait, pt_engine_check() (or the next rec call on that
+ *     engine) returns PT_ERR_HIP ("not co-resident") once and switches the engine to the streaming
+ *     kernel; pt_engine_set_lstm_cluster(e, 0) selects it up front;
  *   - `stream` is a hipStream_t (0 = the null stream).  Calls are asynchronous on that stream
  *     unless stated otherwise.
  */
@@ -58,6 +58,12 @@ int pt_abi_version(void);
  * above).  Call it after synchronising the stream whose results are about to be consumed; PT_OK if nothing was flagged.
  * No counterpart in the reference (a torch/onnxruntime call either returns or raises). */
 int pt_engine_check(pt_engine* e);
+/* on = 1 (default; PT_LSTM_CLUSTER=0 in the environment changes the default): the bf16 recognition LSTM runs as the
+ * weight-stationary cluster kernel, whose workgroups must all be co-resident -- only safe when nothing else runs on the
+ * GPU beside the recogniser.  on = 0: the streaming kernel (about twice the LSTM time, no co-residency requirement):
+ * use it whenever pt_rec_forward* runs on a stream beside other work.  A failure pt_engine_check reports also
+ * switches the engine to 0 and clears the flag, so the failed batch can simply be submitted again. */
+int pt_engine_set_lstm_cluster(pt_engine* e, int on);
 
 /* Arithmetic of the conv nets (DESIGN.md "numerics").  PT_PRECISION_BF16: bf16 activations/weights, fp32
  * accumulate -- the throughput mode BASELINE.json's configs name.  PT_PRECISION_BF16X3: every activation and

@@ -20,16 +20,25 @@ void pt_set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* pt_last_error(void) { return g_err; }
-int pt_abi_version(void) { return 5; }   // 5: pt_engine_check, pt_profile_enable modes, pt_hard_nms
+int pt_abi_version(void) { return 6; }   // 6: pt_engine_set_lstm_cluster, pt_engine_check clears what it reports
 
 int pt_engine_check(pt_engine* e) {
   PT_REQUIRE(e, "pt_engine_check: null engine");
   if (e->lstm_err && *e->lstm_err) {
+    // reported ONCE: the flag is cleared and the engine switches to the streaming LSTM, so the caller can re-run the batch
+    *e->lstm_err = 0;
+    e->lstm_cluster = 0;
     pt_set_error("lstm_cluster_kernel: a workgroup waited > 2^22 polls for its peers -- the launch was not co-resident "
                  "(GPU shared with another process or stream?).  The recognition results since the last check are invalid; "
-                 "set PT_LSTM_CLUSTER=0");
+                 "this engine now uses the streaming LSTM kernel (pt_engine_set_lstm_cluster(e, 0)): run the batch again");
     return PT_ERR_HIP;
   }
+  return PT_OK;
+}
+
+int pt_engine_set_lstm_cluster(pt_engine* e, int on) {
+  PT_REQUIRE(e && (on == 0 || on == 1), "pt_engine_set_lstm_cluster: bad arguments");
+  e->lstm_cluster = on;
   return PT_OK;
 }
 
@@ -51,6 +60,10 @@ int pt_engine_create(int device_id, pt_engine** out) {
   pt_engine* e = new pt_engine();
   e->device = device_id;
   e->num_cu = prop.multiProcessorCount;
+  {
+    const char* ev = getenv("PT_LSTM_CLUSTER");     // default of pt_engine_set_lstm_cluster
+    e->lstm_cluster = ev ? (atoi(ev) != 0) : 1;
+  }
   *out = e;
   return PT_OK;
 }

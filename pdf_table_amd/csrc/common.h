@@ -116,6 +116,7 @@ struct pt_engine {
   void* lstm_scratch = nullptr;                              // rec_kernels.hip: h exchange buffers + step counters of the cluster LSTM
   int* lstm_err = nullptr;                                   // pinned, device-visible: set by a cluster member that gave up waiting
   int lstm_max_cl = 0;                                       // clusters per direction per launch (num_cu / 8)
+  int lstm_cluster = 1;                                      // 1: weight-stationary cluster kernel (bf16 mode); 0: streaming kernel
 };
 
 // ---- conv launcher (conv_igemm.hip) -----------------------------------------------------------------

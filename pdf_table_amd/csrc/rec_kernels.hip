@@ -955,12 +955,7 @@ int pt_launch_lstm(pt_engine* e, const bf16_t* gx, const bf16_t* whh, bf16_t* ho
     const char* ev = getenv("PT_LSTM_DMA");
     use_dma = ev ? atoi(ev) : 0;      // measured 3.97 vs 3.89 ms: no gain (the step is bound by L2 traffic, not by gx latency)
   }
-  static int use_cluster = -1;   // PT_LSTM_CLUSTER=0: the streaming kernel (A/B switch)
-  if (use_cluster < 0) {
-    const char* ev = getenv("PT_LSTM_CLUSTER");
-    use_cluster = ev ? atoi(ev) : 1;
-  }
-  if (!split && use_cluster) {
+  if (!split && e->lstm_cluster) {     // pt_engine_set_lstm_cluster / PT_LSTM_CLUSTER=0: the streaming kernel
     if (!e->lstm_scratch) {     // per engine: exchange buffers + step counters, pinned error word, clusters per launch
       e->lstm_max_cl = e->num_cu / 8 < 1 ? 1 : e->num_cu / 8;     // 2 dirs x 4 members x max_cl <= num_cu
       PT_HIP_CHECK(hipMalloc(&e->lstm_scratch, (size_t)2 * e->lstm_max_cl * 2 * CLL_MAX * 256 * sizeof(bf16_t) + (size_t)2 * e->lstm_max_cl * 4 * sizeof(int) + 256));
@@ -970,10 +965,12 @@ int pt_launch_lstm(pt_engine* e, const bf16_t* gx, const bf16_t* whh, bf16_t* ho
     void* scratch = e->lstm_scratch;
     int* h_err = e->lstm_err;
     const int max_cl = e->lstm_max_cl;
-    if (*h_err) {      // an EARLIER launch timed out (its output was wrong): fail loudly now and stop using the kernel
-      use_cluster = 0;
+    if (*h_err) {      // an EARLIER launch timed out (its output was wrong): fail loudly now, once, and stop using the kernel
+      *h_err = 0;
+      e->lstm_cluster = 0;
       pt_set_error("lstm_cluster_kernel: a workgroup waited > 2^22 polls for its peers -- the launch was not co-resident "
-                   "(GPU shared with another process or stream?).  Results of that call are invalid; set PT_LSTM_CLUSTER=0");
+                   "(GPU shared with another process or stream?).  Results of that call are invalid; this engine now uses "
+                   "the streaming LSTM kernel: run the batch again");
       return PT_ERR_HIP;
     }
     bf16_t* hx = reinterpret_cast<bf16_t*>(scratch);

@@ -51,6 +51,11 @@ class HipEngine:
         L.check(self.lib.pt_engine_set_precision(self._h, int(precision)), "pt_engine_set_precision")
         self.precision = int(precision)
 
+    def set_lstm_cluster(self, on: bool):
+        """False: the streaming LSTM kernel (no co-residency requirement) -- whenever the recogniser shares the GPU with
+        work on another stream; True (default): the weight-stationary cluster kernel."""
+        L.check(self.lib.pt_engine_set_lstm_cluster(self._h, 1 if on else 0), "pt_engine_set_lstm_cluster")
+
     def check(self):
         """Raise PtError if the device flagged a failure in work already executed (pt_engine_check): call after the
         stream was synchronised, before consuming recognition results."""

@@ -51,6 +51,7 @@ def _proto(lib):
         "pt_abi_version": (i, []),
         "pt_engine_check": (i, [vp]),
         "pt_engine_set_precision": (i, [vp, i]),
+        "pt_engine_set_lstm_cluster": (i, [vp, i]),
         "pt_weights_load": (i, [vp, i, vp, sz]),
         "pt_weights_load_device": (i, [vp, i, vp, sz, vp]),
         "pt_det_plan": (i, [i, i, i, ip, ip]),

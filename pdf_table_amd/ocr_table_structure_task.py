@@ -93,8 +93,11 @@ class OcrTableStructureTask(BaseInferTask):
             out.append(self._stage(page, [np.array([[0, 0, w, h]])])[0][0])
         return out
 
-    def recognize_tables(self, pages: torch.Tensor, boxes_per_page: Sequence[np.ndarray]) -> List[List[Dict]]:
-        return self._stage(pages, boxes_per_page)
+    def recognize_tables(self, pages: torch.Tensor, boxes_per_page: Sequence[np.ndarray], page_frame: bool = True) -> List[List[Dict]]:
+        """tables of resident pages; quads come back in PAGE pixels (page_frame=True), as the reference's system path
+        delivers them after shifting every per-crop result by the crop's rounded corner (ocr_system_task.py:190-199 ->
+        TableProcessUtils.convert_table_sep_to_merge, pdf_table/table_common.py:1811-1825)"""
+        return self._stage(pages, boxes_per_page, page_frame=page_frame)
 
     def _preprocess(self, inputs, **kwargs):
         if not isinstance(inputs, list):

@@ -2,18 +2,22 @@
 
 The reference has no class of this name (SURVEY.md finding F1); its semantics are those of
 ``OcrSystemTask.__call__`` (src/pdftable/model/ocr_pdf/ocr_system_task.py:549-734) restricted to the vision path of
-an *image* page: text detection (:629, :148-166, incl. the reading-order sort) -> text recognition (:630, :296-336).
--> table structure (:192-198, Lore) on the page's table regions.  Layout (PicoDet) is the SURVEY section 8 row that is
-not built yet: asking for it raises, and the table regions the reference takes from the layout stage
-(``label == "table"``, pdf_table/table_common.py:1287-1301) are passed to ``predict(..., table_boxes=...)`` instead.
+an *image* page: [text-line orientation vote -> 180 degree rotation + second detection (:441-491)] -> layout (PicoDet,
+:203-215) -> text detection (:629, :148-166, incl. the reading-order sort) -> text recognition (:630, :296-336) ->
+table structure (:184-199, Lore) on the layout regions labelled "table" (pdf_table/table_common.py:1287-1301; or on
+``predict(..., table_boxes=...)``), each table's quads shifted into page pixels (``convert_table_sep_to_merge``,
+table_common.py:1811-1825) -> cells + text -> HTML (``OcrTableToHtmlTask``).
 
 What is different from the reference, by design: pages are processed as a batch (the reference is batch 1 and
-synchronous), crops never leave the GPU, and a failed page/line follows the reference's containment rules
-(a failed crop yields ``""``: ocr_system_task.py:275-283).
+synchronous), crops never leave the GPU -- in particular the table crop is NOT written as a JPEG and read back
+(ocr_system_task.py:192-198: a lossy round trip through the file system) -- and a failed
+page/line follows the reference's containment rules (a failed crop yields ``""``: ocr_system_task.py:275-283) but is
+logged, never silent.
 """
 from __future__ import annotations
 
 import contextlib
+import logging
 import time
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
@@ -27,9 +31,12 @@ from .ocr_detection_task import OcrDetectionTask, _read_image
 from .layout_stage import layout_tables
 from .ocr_layout_task import OcrLayoutTask
 from .ocr_recognition_task import OcrRecognitionTask
+from .rec_stage import order_points
 from .ocr_table_structure_task import OcrTableStructureTask
 
 __all__ = ["OcrTablePipeline", "PageResult"]
+
+logger = logging.getLogger(__name__)
 
 
 @dataclass
@@ -40,6 +47,7 @@ class PageResult:
     layout_result: Optional[list] = None
     table_structure_result: Optional[list] = None
     text_upright: Optional[bool] = None          # text_line_orientation's vote (ocr_system_task.py:395-439); None = not run
+    rotated_180: bool = False                    # the page was voted upside-down and rotated before the stages ran (:471-478)
     text_line_orientation: Optional[list] = None  # per detected line: {"class_ids", "scores", "label_names"}
 
 
@@ -50,11 +58,17 @@ class OcrTablePipeline:
                  table_structure_model: str = "Lore", table_structure_task_type: str = "wtw",
                  tsr_task_path: Optional[str] = None, layout_model: str = "picodet", layout_task_type: str = "en",
                  layout_task_path: Optional[str] = None, text_orientation: bool = False,
-                 orientation_task_path: Optional[str] = None, table_html: bool = False, overlap_rec: bool = True, **kwargs):
+                 orientation_task_path: Optional[str] = None, table_html: bool = False, overlap_rec: bool = True,
+                 rotate_upside_down: bool = True, **kwargs):
         self.engine = HipEngine(device)
         # the recogniser of a page batch runs on a second stream beside the layout and table-structure stages of the same
-        # batch (every stage owns its arena inside the engine); the results do not depend on it
+        # batch (every stage owns its arena inside the engine); the results do not depend on it.  The weight-stationary
+        # cluster LSTM needs the whole GPU to itself (co-resident workgroups), so an overlapping pipeline runs the
+        # streaming LSTM kernel instead (pt_engine_set_lstm_cluster)
         self.overlap_rec = overlap_rec
+        # text_orientation=True: a page voted upside-down is rotated by 180 degrees and detected again, like
+        # OcrSystemTask.image_pre_process (ocr_system_task.py:471-478); every result of that page is in rotated pixels
+        self.rotate_upside_down = rotate_upside_down
         self._rec_stream = None
         dk = dict(kwargs)
         rk = dict(kwargs)
@@ -111,15 +125,37 @@ class OcrTablePipeline:
             batch = torch.from_numpy(np.stack([imgs[i] for i in idxs])).to(self.engine._tdev)
             a = time.time()
             stage: DetStage = self.text_detector._stage
-            prob, bitmap, ev = stage.forward(batch)
-            boxes = stage.boxes(prob, bitmap, shape[:2], ev)
-            boxes = [sort_boxes_reading_order(b) for b in boxes]
+
+            def detect(pages_t):
+                prob, bitmap, ev = stage.forward(pages_t)
+                return [sort_boxes_reading_order(b) for b in stage.boxes(prob, bitmap, shape[:2], ev)]
+
+            boxes = detect(batch)
+            ori = None
+            rotated = [False] * len(idxs)
+            if self.orientation_task is not None:
+                # per page: classify every detected line, vote (ocr_system_task.py:395-439); a page voted upside-down is
+                # rotated by 180 degrees and detected again (:471-478) -- the vote of the FIRST detection is what is kept
+                flat, _ = self.orientation_task.lines(batch, boxes)
+                ori, o = [], 0
+                for b in boxes:
+                    res = flat[o:o + len(b)]
+                    o += len(b)
+                    ori.append((res, self.orientation_task._stage.orientation_vote(res)))
+                down = [k for k, (_, up) in enumerate(ori) if not up] if self.rotate_upside_down else []
+                if down:
+                    sel = torch.tensor(down, device=batch.device)
+                    batch[sel] = torch.flip(batch[sel], dims=(1, 2))
+                    again = detect(batch[sel].contiguous())
+                    for k, bx in zip(down, again):
+                        boxes[k], rotated[k] = bx, True
             b_ = time.time()
             rec_stage = self.text_recognizer._stage
             side = None
             if self.overlap_rec and (self.layout_task is not None or self.table_structure_task is not None):
                 if self._rec_stream is None:
                     self._rec_stream = torch.cuda.Stream(device=self.engine._tdev)
+                    self.engine.set_lstm_cluster(False)      # the recogniser now shares the GPU with the other stages
                 side = self._rec_stream
                 side.wait_stream(torch.cuda.current_stream(self.engine._tdev))
                 batch.record_stream(side)
@@ -127,42 +163,47 @@ class OcrTablePipeline:
             def on_side():
                 return torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
 
-            rec_state, texts = None, None
-            try:
+            def recognise():
                 with on_side():
-                    rec_state = rec_stage.start(batch, boxes)        # asynchronous: crops, CRNN, arg-max
-                    if side is None:
-                        texts = rec_stage.finish(rec_state)
-            except Exception:                      # reference: a failing recognition yields empty strings
-                rec_state, texts = None, [[""] * len(b) for b in boxes]
+                    return rec_stage.start(batch, boxes)            # asynchronous: crops, CRNN, arg-max
 
-            def finish_rec_and_orientation():
-                nonlocal texts
-                if texts is None:
+            def finish_rec():
+                """-> texts; a device-side failure (PtError from pt_engine_check: the engine has switched to the streaming
+                LSTM and cleared the flag) is logged and the batch is run once more; only then the reference's containment
+                (empty strings, ocr_system_task.py:275-283) applies -- logged, never silent"""
+                from .lib import PtError
+                state = rec_state
+                for attempt in (0, 1):
                     try:
                         with on_side():
-                            texts = rec_stage.finish(rec_state)
-                    except Exception:
-                        texts = [[""] * len(b) for b in boxes]
-                if self.orientation_task is None:
-                    return None
-                res_all = []
-                with on_side():          # shares the crop buffers with the recogniser: same stream, behind it
-                    flat, _ = self.orientation_task.lines(batch, boxes)
-                o = 0
-                for b in boxes:       # the reference votes per page; it then rotates a non-upright page by 180 degrees and
-                    res = flat[o:o + len(b)]      # detects again (:471-478) -- left to the caller, who holds the pages
-                    o += len(b)
-                    res_all.append((res, self.orientation_task._stage.orientation_vote(res)))
-                return res_all
+                            if state is None:
+                                state = rec_stage.start(batch, boxes)
+                            return rec_stage.finish(state)
+                    except PtError as e:
+                        logger.warning("text recognition failed on the device (%s)%s", e, "; running the batch again" if attempt == 0 else "")
+                        state = None
+                    except Exception as e:     # noqa: BLE001 -- the reference contains every failure of a crop
+                        logger.warning("text recognition failed: %r", e)
+                        break
+                logger.error("text recognition of %d lines yields empty strings", sum(len(b) for b in boxes))
+                return [[""] * len(b) for b in boxes]
 
-            ori = finish_rec_and_orientation() if side is None else None
+            rec_state = None
+            try:
+                rec_state = recognise()
+            except Exception as e:                 # noqa: BLE001
+                logger.warning("text recognition could not be queued: %r", e)
+            texts = finish_rec() if side is None else None
             c = time.time()
             lay = self.layout_task.detect_pages(batch) if self.layout_task is not None else None
             tsr = None
             if self.table_structure_task is not None:
                 if table_boxes is not None:
                     tb = [np.asarray(table_boxes[i]).reshape(-1, 4) for i in idxs]
+                    for k in range(len(idxs)):      # boxes were given for the page as handed in: follow its rotation
+                        if rotated[k] and len(tb[k]):
+                            x1, y1, x2, y2 = tb[k].T
+                            tb[k] = np.stack([shape[1] - x2, shape[0] - y2, shape[1] - x1, shape[0] - y1], 1)
                 else:
                     # layout regions labelled "table", score >= 0.2, top to bottom, cropped at rounded coordinates
                     # (ocr_system_task.py:184-198, crop_image_by_box utils/ocr/ocr_common_utils.py:279-280)
@@ -173,28 +214,27 @@ class OcrTablePipeline:
                         tb.append(np.array(bx, dtype=np.int64).reshape(-1, 4))
                 tsr = self.table_structure_task.recognize_tables(batch, tb)
             if side is not None:
-                ori = finish_rec_and_orientation()
+                texts = finish_rec()
             if tsr is not None and self.table_html:
-                from .table_html import table_cells_from_logits
-                from .table_text_match import cells_to_html, match_table_cells_and_text, text_boxes, texts_in_table
+                from .table_text_match import page_table_html
                 for k in range(len(idxs)):
-                    tbx = text_boxes(boxes[k]) if len(boxes[k]) else np.zeros((0, 4))
                     for ti, table in enumerate(tsr[k]):
                         if len(table.get("scores", [])) == 0:
                             table["table_html"], table["db_table_html"] = [], []
                             continue
-                        cells = table_cells_from_logits(table["polygons"], table["logi"])
-                        inside = texts_in_table([float(v) for v in tb[k][ti]], tbx, diff=2) if len(tbx) else np.zeros(0, np.int64)
-                        # image pages: ocr_post_process=True (ocr_table_to_html_task.py:93)
-                        res = match_table_cells_and_text(cells, tbx[inside], [texts[k][i] for i in inside], post_process=True)
-                        table["table_html"], table["db_table_html"] = cells_to_html(res)
+                        # cells (page pixels since recognize_tables shifts them) x the page's text lines (page pixels)
+                        table["table_html"], table["db_table_html"] = page_table_html(
+                            table["polygons"], table["logi"], tb[k][ti], boxes[k], texts[k])
             d_ = time.time()
             t_det += b_ - a
             t_rec += c - b_
             t_tsr += d_ - c
             for k, i in enumerate(idxs):
-                ocr = [{"index": j + 1, "text": t, "bbox": boxes[k][j].reshape(4, 2)} for j, t in enumerate(texts[k])]
-                results[i] = PageResult(det_result=boxes[k], ocr_result=ocr, layout_result=None if lay is None else lay[k],
+                # bbox = OcrCommonUtils.order_point(det_result[j]) (ocr_system_task.py:311-320), what OcrCell.parse consumes
+                pts = order_points(boxes[k]) if len(boxes[k]) else np.zeros((0, 4, 2), np.float32)
+                ocr = [{"index": j + 1, "text": t, "bbox": pts[j]} for j, t in enumerate(texts[k])]
+                results[i] = PageResult(rotated_180=rotated[k],
+                                        det_result=boxes[k], ocr_result=ocr, layout_result=None if lay is None else lay[k],
                                         table_structure_result=None if tsr is None else tsr[k],
                                         text_upright=None if ori is None else ori[k][1],
                                         text_line_orientation=None if ori is None else ori[k][0])

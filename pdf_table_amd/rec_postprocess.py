@@ -61,7 +61,7 @@ class CTCLabelDecode:
             keep[1:] = row[1:] != row[:-1]
             keep &= row != 0
             text = "".join(self.character[int(t)] for t in row[keep])
-            conf = probs[b][keep] if probs is not None else np.ones(int(keep.sum()))
+            conf = probs[b][keep] if probs is not None else np.ones(len(row))      # reference: [1] * len(selection), never empty
             if len(conf) == 0:
                 conf = [0]
             if self.reverse:

@@ -23,7 +23,7 @@ import numpy as np
 from .table_html import TableCell
 
 __all__ = ["text_boxes", "texts_in_table", "find_top1_match", "one_cell_text", "ocr_post_process",
-           "match_table_cells_and_text", "cells_to_html"]
+           "match_table_cells_and_text", "cells_to_html", "page_table_html"]
 
 _NUM = re.compile(r"[-0-9\.,]")      # MatchUtils.PATTERN_OCR_TEXT_ZH_NUMBER (utils/match_utils.py:52)
 _ZERO = re.compile(r"[oO]")          # MatchUtils.PATTERN_OCR_TEXT_0 (:50)
@@ -174,3 +174,17 @@ def cells_to_html(cells: List[TableCell]) -> Tuple[List[str], List[str]]:
         db.append("".join(x.replace("<th ", "<td ").replace("</th>", "</td>") for x in r))
     db.append("</table>")
     return table_html, db
+
+
+def page_table_html(polygons: np.ndarray, logi: np.ndarray, table_box: Sequence[float], text_quads: np.ndarray,
+                    texts: Sequence[str], post_process: bool = True) -> Tuple[List[str], List[str]]:
+    """One table of a page -> (table_html, db_table_html).  EVERYTHING is in page pixels: ``polygons`` are the cell quads
+    after the reference's shift by the crop corner (convert_table_sep_to_merge, table_common.py:1811-1825), ``table_box``
+    the layout box the crop was cut from, ``text_quads`` [t,8] the page's detected lines with their ``texts``.  Lines whose
+    centre is in the table box are assigned to cells; image pages use ocr_post_process=True (ocr_table_to_html_task.py:93)."""
+    from .table_html import table_cells_from_logits
+    cells = table_cells_from_logits(polygons, logi)
+    tbx = text_boxes(text_quads) if len(text_quads) else np.zeros((0, 4))
+    inside = texts_in_table([float(v) for v in table_box], tbx, diff=2) if len(tbx) else np.zeros(0, np.int64)
+    res = match_table_cells_and_text(cells, tbx[inside], [texts[i] for i in inside], post_process=post_process)
+    return cells_to_html(res)

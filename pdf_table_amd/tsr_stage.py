@@ -230,9 +230,13 @@ class TsrStage:
             done.record(self._copy_stream)
         return host, done
 
-    def collect(self, processed, metas: List[np.ndarray]) -> List[Dict]:
+    def collect(self, processed, metas: List[np.ndarray], offsets: Optional[np.ndarray] = None) -> List[Dict]:
         """host half: quads back to source pixels, logical rounding -> per table {'polygons' f32 [n,8], 'logi' f32 [n,4]
-        (integer valued), 'logic_axis', 'stacked_axis' (unrounded), 'scores'} like TableLorePostProcessor's result dict."""
+        (integer valued), 'logic_axis', 'stacked_axis' (unrounded), 'scores'} like TableLorePostProcessor's result dict.
+        ``offsets`` int [tables, 2]: the crop's (x0, y0) on its page, added to every vertex so that the quads are in page
+        pixels -- what the reference's system path does after the per-crop call (convert_table_sep_to_merge ->
+        box_list_move_point, pdf_table/table_common.py:1811-1825); None keeps them relative to the crop (the task's own
+        result, processer_lore.py:175-182)."""
         cfg = self.config
         host, done = processed
         if done is not None:
@@ -248,7 +252,11 @@ class TsrStage:
                                 "scores": np.zeros((0,), np.float32)})
                     continue
                 final = stacked_h[k, :n] if cfg.wiz_stacking else logic_h[k, :n]
-                r = {"polygons": transform_quads(dets_h[k, :n, :8], metas[i + k], cfg.upper_left),
+                polys = transform_quads(dets_h[k, :n, :8], metas[i + k], cfg.upper_left)
+                if offsets is not None:
+                    # box_list_move_point works on .tolist() values: python floats + the rounded int corner -> float64
+                    polys = polys.astype(np.float64) + np.tile(np.asarray(offsets[i + k], np.float64), 4)[None]
+                r = {"polygons": polys,
                      "logi": process_logic_output(final), "logic_axis": logic_h[k, :n].copy(),
                      "stacked_axis": stacked_h[k, :n].copy(), "scores": dets_h[k, :n, 8].copy()}
                 if self.with_html:       # table_html.table_cells_from_logits(polygons, logi) gives the cell objects on demand
@@ -256,11 +264,11 @@ class TsrStage:
                 out.append(r)
         return out
 
-    def finish(self, pending, metas: List[np.ndarray]) -> List[Dict]:
-        return self.collect(self.process(pending), metas)
+    def finish(self, pending, metas: List[np.ndarray], offsets: Optional[np.ndarray] = None) -> List[Dict]:
+        return self.collect(self.process(pending), metas, offsets)
 
-    def run(self, pages: torch.Tensor, tables: np.ndarray, metas: List[np.ndarray]) -> List[Dict]:
-        return self.finish(self.start(pages, tables), metas)
+    def run(self, pages: torch.Tensor, tables: np.ndarray, metas: List[np.ndarray], offsets: Optional[np.ndarray] = None) -> List[Dict]:
+        return self.finish(self.start(pages, tables), metas, offsets)
 
     def regroup(self, flat: List[Dict], boxes_per_page: Sequence[np.ndarray]) -> List[List[Dict]]:
         res, o = [], 0
@@ -270,7 +278,9 @@ class TsrStage:
             o += k
         return res
 
-    def __call__(self, pages: torch.Tensor, boxes_per_page: Sequence[np.ndarray]) -> List[List[Dict]]:
+    def __call__(self, pages: torch.Tensor, boxes_per_page: Sequence[np.ndarray], page_frame: bool = False) -> List[List[Dict]]:
+        """page_frame=True: quads in page pixels (the crop's clamped x0, y0 added), like the reference's merged result"""
         tables, metas = self.tables(tuple(pages.shape[1:3]), boxes_per_page)
-        flat = self.run(pages, tables, metas) if len(tables) else []
+        offs = np.stack([tables["x0"], tables["y0"]], 1).astype(np.float32) if page_frame and len(tables) else None
+        flat = self.run(pages, tables, metas, offs) if len(tables) else []
         return self.regroup(flat, boxes_per_page)

@@ -97,8 +97,12 @@ def test_table_structure_task_and_pipeline(pipe):
     p2.table_structure_task = task
     res = p2.predict([page], table_boxes=[tb])
     t0 = res[0].table_structure_result[0]
-    # crop-relative (task) vs page-relative (pipeline) inputs see the same pixels: same cells, same quads
-    assert np.array_equal(t0["polygons"], r["polygons"]) and np.array_equal(t0["logi"], r["logi"])
+    # crop-relative (task) vs page-relative (pipeline) inputs see the same pixels: same cells; the pipeline's quads are in
+    # PAGE pixels -- the task's quads shifted by the crop corner (convert_table_sep_to_merge, table_common.py:1811-1825)
+    assert np.array_equal(t0["logi"], r["logi"])
+    assert np.array_equal(t0["polygons"], r["polygons"].astype(np.float64) + np.tile([x1, y1], 4)[None])
+    assert np.array_equal(task.recognize_tables(torch.from_numpy(page[None]).cuda(), [tb[:1]], page_frame=False)[0][0]["polygons"],
+                          r["polygons"])
     with pytest.raises(ValueError):
         p2.predict([page])
 
@@ -150,6 +154,26 @@ def test_pipeline_text_line_orientation():
         assert len(r.text_line_orientation) == len(r.det_result)
         for o in r.text_line_orientation:
             assert o["label_names"][0] in ("0_degree", "180_degree") and 0.5 <= o["scores"][0] <= 1.0
+
+
+def test_pipeline_rotates_upside_down_pages():
+    """text_orientation=True: a page whose lines are voted upside-down is rotated by 180 degrees and detected again
+    (ocr_system_task.py:471-478); its results equal those of the rotated page handed in directly"""
+    from pdf_table_amd.pipeline import OcrTablePipeline
+    p = OcrTablePipeline(device=0, synthetic_seed=0, text_orientation=True)
+    pages = [make_page(i)[0] for i in (0, 1, 2)]
+    res = p.predict(pages)
+    for r, pg in zip(res, pages):
+        assert r.rotated_180 == (not r.text_upright)
+        if r.rotated_180:
+            p2 = OcrTablePipeline(device=0, synthetic_seed=0)
+            p2.text_detector, p2.text_recognizer = p.text_detector, p.text_recognizer
+            direct = p2.predict([np.ascontiguousarray(pg[::-1, ::-1])])[0]
+            assert np.array_equal(direct.det_result, r.det_result)
+            assert [o["text"] for o in direct.ocr_result] == [o["text"] for o in r.ocr_result]
+    keep = OcrTablePipeline(device=0, synthetic_seed=0, text_orientation=True, rotate_upside_down=False)
+    keep.text_detector, keep.text_recognizer, keep.orientation_task = p.text_detector, p.text_recognizer, p.orientation_task
+    assert not any(r.rotated_180 for r in keep.predict(pages))
 
 
 def test_pipeline_table_html():

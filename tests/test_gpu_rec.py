@@ -186,3 +186,22 @@ np.savez(sys.argv[1], ids=ids.cpu().numpy(), mx=mx.cpu().numpy())
     assert np.array_equal(outs[0]["ids"], outs[2]["ids"])
     assert np.array_equal(outs[0]["mx"], outs[2]["mx"])
     assert len(np.unique(outs[0]["ids"])) > 20           # not a degenerate output
+
+
+def test_set_lstm_cluster_switches_kernels_in_process(eng, sd):
+    """pt_engine_set_lstm_cluster: the streaming LSTM (what an overlapping pipeline uses) and the cluster LSTM give the
+    same ids and winning logits; pt_engine_check has nothing to report after either"""
+    rng = np.random.default_rng(33)
+    g = torch.from_numpy(rng.uniform(0, 1, (70, 32, 640)).astype(np.float32)).to(torch.bfloat16).cuda()
+    outs = []
+    try:
+        for on in (True, False, True):
+            eng.set_lstm_cluster(on)
+            ids, mx = eng.rec_forward_net(g)
+            torch.cuda.synchronize()
+            eng.check()
+            outs.append((ids.cpu().numpy(), mx.cpu().numpy()))
+    finally:
+        eng.set_lstm_cluster(True)
+    for ids, mx in outs[1:]:
+        assert np.array_equal(ids, outs[0][0]) and np.array_equal(mx, outs[0][1])

@@ -202,3 +202,36 @@ def test_ocr_post_process_known_answers():
     assert ocr_post_process("o") == "0" and ocr_post_process(" O ") == "0"
     assert ocr_post_process("1.000.000") == "1,000.000" and ocr_post_process("1.5") == "1.5"
     assert ocr_post_process("total") == "total" and ocr_post_process("") == ""
+
+
+def test_page_table_html_uses_one_coordinate_frame():
+    """A 3x3 table whose crop starts at (300, 200) on the page: the structure stage's quads are relative to the crop,
+    the OCR lines are in page pixels.  After the reference's shift by the crop corner (convert_table_sep_to_merge,
+    pdf_table/table_common.py:1811-1825 -- what recognize_tables(page_frame=True) delivers) every line lands in the cell
+    that contains it; with crop-relative quads (the round-1 bug) it does not."""
+    import numpy as np
+    from pdf_table_amd.table_text_match import page_table_html
+    x0, y0, cw, ch = 300, 200, 100.0, 40.0
+    polys, logi = [], []
+    for r in range(3):
+        for c in range(3):
+            xa, ya, xb, yb = c * cw, r * ch, (c + 1) * cw, (r + 1) * ch
+            polys.append([xa, ya, xb, ya, xb, yb, xa, yb])           # TL, TR, BR, BL in crop pixels
+            logi.append([c, c, r, r])                                # left, right, top, bottom
+    polys, logi = np.array(polys, np.float32), np.array(logi, np.float32)
+    quads, texts = [], []
+    for r in range(3):
+        for c in range(3):
+            xa, ya = x0 + c * cw + 10, y0 + r * ch + 10              # one line inside every cell, page pixels
+            quads.append([xa, ya, xa + 60, ya, xa + 60, ya + 18, xa, ya + 18])
+            texts.append(f"r{r}c{c}")
+    quads = np.array(quads, np.float64)
+    box = [x0, y0, x0 + 3 * cw, y0 + 3 * ch]
+    page_polys = polys.astype(np.float64) + np.tile([x0, y0], 4)[None]
+    html, db = page_table_html(page_polys, logi, box, quads, texts)
+    tds = [row for row in html if row.startswith("<td")]
+    assert len(tds) == 9
+    for i, row in enumerate(tds):
+        assert row.endswith(f">test_textr{i // 3}c{i % 3}</td>"), row   # Cell.text appends to the structure stage's "test_text"
+    wrong, _ = page_table_html(polys, logi, box, quads, texts)          # crop-relative quads against page-frame text
+    assert [r for r in wrong if r.startswith("<td")] != tds
