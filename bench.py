@@ -1,22 +1,32 @@
 #!/usr/bin/env python
 """bench.py -- pages/s of the hot path on N MI355X (one process per GPU, RCCL only for the weight broadcast).
 
-    python bench.py [--gpus 1] [--steps 10] [--warmup 3]
+    python bench.py [--gpus N] [--steps 10] [--warmup 3]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic 1024x1024 pages per rank (inputs already
-resident in HBM).  Workload today (named in ``config.workload``): BASELINE.json configs[1], the batched DB
-text-detection stage -- resize + normalise, DB-ResNet18, prob -> bitmap, contour candidates, box scoring,
-unclip, final boxes.  Pages are sharded across ranks (weak scaling: fixed pages per rank); there is no
-collective in the timed region.
+``--gpus N`` with N > 1 and no WORLD_SIZE in the environment re-executes itself under ``torch.distributed.run`` with N
+ranks (and fails loudly when fewer than N devices are visible); under a launcher it checks WORLD_SIZE == N.
 
-Stages (--stages, default layout,det,rec,tsr): PicoDet layout detection, DB text detection, CRNN recognition of the
-page's text lines, Lore table structure of the page's tables.
+A "step" is one pass of the hot path -- BASELINE.json configs[2]: PicoDet layout + DB text detection + CRNN recognition
++ Lore table structure -- over one batch of synthetic 1024x1024 pages per rank (inputs already resident in HBM).
+Pages are sharded across ranks (weak scaling: fixed pages per rank); there is no collective in the timed region.
 
-Extra objects on the JSON line: ``roofline`` for the dominant kernel class (3x3 MFMA convolutions, HIP-event
-timed inside the timed region) and ``cpu_baseline`` (the oracle restatement of the same stage on the host
-cores, bounded sample, rank 0 at N=1 only).
+Chaining.  The detector's checkpoint is random-init except for one hand-built channel that detects the synthetic pages'
+text (synth_weights._db_text_signal), so detection yields ~75 boxes per page and THOSE boxes are what the recogniser
+crops and reads -- software-pipelined: the recogniser of step k works on the boxes whose host post-process finished
+during step k-1 (the bench's pages are the same every step).  The layout and Lore nets are plain random-init, so the
+table regions of the table-structure stage are the page generator's ground truth (said so in ``config``).
+
+Extra objects on the JSON line:
+  roofline        the dominant kernel class (3x3 MFMA convolutions of all stages), HIP-event timed inside the timed region,
+                  FLOP counted from real channel counts and the rows row-limited launches really computed;
+                  ``det_backbone``: BASELINE.md section 5's figure, 111.71 GFLOP x det-only pages/s / peak, from a det-only
+                  leg of the same run
+  tolerance_mode  the same step in PT_PRECISION_BF16X3 -- the arithmetic whose GPU tests assert the north-star tolerance
+                  (1e-3 on logits, ids exact outside the oracle's own ties) -- timed over a few steps
+  cpu_baseline    the oracle restatement of the same stages on the host cores (bounded sample, rank 0 at N = 1 only),
+                  plus BASELINE.json configs[0] (one 640x640 page, det + rec) on CPU and on the GPU
 """
 from __future__ import annotations
 
@@ -28,21 +38,86 @@ import sys
 import time
 
 import numpy as np
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PAGE = 1024
 PAGES_PER_STEP = int(os.environ.get("PT_BENCH_PAGES", "64"))   # per rank
-DISTINCT = 8                     # distinct synthetic pages, tiled up to the batch
+DISTINCT = int(os.environ.get("PT_BENCH_DISTINCT", str(PAGES_PER_STEP)))   # distinct synthetic pages per rank
 MFMA_PEAK_TFLOPS = 2500.0        # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 DB_GFLOP_960 = 111.71            # DB-ResNet18 at the reference-preprocessed 960x960
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# launch
+# ---------------------------------------------------------------------------------------------------------------------
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the det-only and BF16X3 legs (diagnostic runs)")
+    ap.add_argument("--det-backbone", default="resnet18", choices=["resnet18", "proxylessnas"],
+                    help="DB detector network: DBModel (BASELINE.json's configuration) or DBNasModel (diagnostic variant)")
+    ap.add_argument("--no-post", action="store_true", help="device half only (diagnostic; not a valid headline)")
+    ap.add_argument("--aux-stream", type=int, default=0,
+                    help="1: the small-kernel work without 3x3 convolutions (PicoDet layout, the Lore processor and their "
+                         "D2H copies) runs on a second stream beside the conv-heavy nets")
+    ap.add_argument("--overlap-rec", action="store_true",
+                    help="diagnostic: the recogniser runs on a second stream, concurrently with the other stages "
+                         "(per-kernel HIP-event durations then include contention, so the roofline object reads low)")
+    ap.add_argument("--gt-chain", action="store_true",
+                    help="diagnostic: feed the recogniser the generator's text-line rectangles (round-1 behaviour)")
+    ap.add_argument("--stages", default=os.environ.get("PT_BENCH_STAGES", "layout,det,rec,tsr"),
+                    help="comma list of stages in the timed step: layout (PicoDet), det (configs[1]), rec, tsr (Lore)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args, argv):
+    """--gpus N without a launcher: become N ranks under torch.distributed.run (one process per GPU)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    if os.environ.get("PT_BENCH_STUB") != "1":
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible -- refusing to report a "
+                             f"{args.gpus}-GPU number from fewer devices")
+    port = os.environ.get("MASTER_PORT", str(29500 + (os.getpid() % 2000)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + list(argv)
+    sys.stdout.flush()
+    os.execvp(sys.executable, cmd)
+
+
+def cpu_info():
+    """CPU model / sockets / cores / threads of the host (BASELINE.md section 4.3 asks for them beside the baseline)."""
+    model, phys, cores = "?", set(), set()
+    try:
+        cur = None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name") and model == "?":
+                    model = ln.split(":", 1)[1].strip()
+                elif ln.startswith("physical id"):
+                    cur = ln.split(":", 1)[1].strip()
+                    phys.add(cur)
+                elif ln.startswith("core id"):
+                    cores.add((cur, ln.split(":", 1)[1].strip()))
+    except OSError:
+        pass
+    return {"model": model, "sockets": max(1, len(phys)), "cores": len(cores) or None, "threads": os.cpu_count()}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the ONLY part of this file that touches oracle/)
+# ---------------------------------------------------------------------------------------------------------------------
 def cpu_baseline_tsr(lsd, psd, page, box):
     """One table through the oracle chain (fp32 torch convs in the reference's op order, DCN restatement, the decode
     with its Python vertex-snapping loop, processor) on the host cores -> seconds per table and a note."""
+    import torch
     from oracle import lore_decode as od
     from oracle import lore_net, lore_pre, lore_processor
     x1, y1, x2, y2 = (int(v) for v in box)
@@ -63,26 +138,27 @@ def cpu_baseline_tsr(lsd, psd, page, box):
                      f"DLA-34+DCN fp32 {t2 - t1:.2f}, decode {t3 - t2:.2f}, processor {t4 - t3:.2f})")
 
 
-def cpu_baseline(sd, pages_np, cfg, csd=None, quads=None, max_lines=12, tsr=None, layout=None, lines_per_page=None):
-    """The oracle (port of the reference CPU path: fp32 torch ops in the reference's op order + numpy/python
-    pre/post) on the host cores, batch 1 per call as the reference runs it."""
+def cpu_baseline(sd, pages_np, cfg, csd=None, tsr=None, layout=None, gpu=None):
+    """The oracle (port of the reference CPU path: fp32 torch ops in the reference's op order -- torch's own LSTM operator
+    for the CRNN, as the reference's nn.LSTM -- + numpy/python pre/post) on the host cores, batch 1 per call as the
+    reference runs it.  ``gpu``: engine outputs for the sampled page / lines, checked against the oracle here."""
+    import torch
+    from oracle import crnn as ocrnn
     from oracle import db_nas, db_net, db_post, db_pre
     det_fwd = db_nas.dbnas_forward_fp32 if "backbone.first_conv.0.weight" in sd else db_net.db_forward_fp32
-    # 32 threads: on the 256-thread GPU host, batch-1 convolutions and the per-step LSTM matmuls get SLOWER beyond a
-    # few dozen threads (47 s for two pages at 256 threads vs ~3 s/page at 8); "cores" reports what was really used
+    # 32 threads: on the 256-thread GPU host, batch-1 convolutions get SLOWER beyond a few dozen threads (47 s for two
+    # pages at 256 threads vs ~3 s/page at 8); "cores" reports what was really used
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     budget_t0 = time.time()
-    n = len(pages_np)
     with torch.no_grad():   # one un-timed warm-up forward (thread pool start-up, oneDNN primitive cache)
         det_fwd(sd, torch.zeros(1, 3, 960, 960))
     t_pre = t_net = t_post = 0.0
-    nboxes = 0
     done = 0
+    boxes_all, parity = [], {}
     for img in pages_np:
-        if done >= 1 and time.time() - budget_t0 > 15.0:      # bounded sample
+        if done >= 1 and time.time() - budget_t0 > 12.0:      # bounded sample
             break
-        done += 1
         t0 = time.time()
         chw, shape_list = db_pre.preprocess_db_pp(img)
         t1 = time.time()
@@ -92,36 +168,49 @@ def cpu_baseline(sd, pages_np, cfg, csd=None, quads=None, max_lines=12, tsr=None
         boxes = db_post.db_postprocess(prob, shape_list, img.shape, cfg.thresh, cfg.box_thresh, cfg.unclip_ratio,
                                        cfg.use_dilation, cfg.max_candidates)
         t3 = time.time()
+        if done == 0 and gpu is not None:
+            for mode in ("bf16", "bf16x3"):
+                if gpu.get("det_prob_" + mode) is not None:
+                    parity["det_max_abs_dprob_" + mode] = float(np.abs(gpu["det_prob_" + mode] - prob).max())
+            parity["det_boxes_oracle_vs_gpu_bf16"] = [int(len(boxes)), int(gpu.get("det_nboxes", -1))]
         t_pre += t1 - t0
         t_net += t2 - t1
         t_post += t3 - t2
-        nboxes += len(boxes)
+        boxes_all.append(boxes)
+        done += 1
     n = done
     dt = t_pre + t_net + t_post
-    rec_note = ""
+    lines_per_page = float(np.mean([len(b) for b in boxes_all]))
+    note = ""
     if csd is not None:
         # recognition: one call per text line like the reference (ocr_system_task.py:309-320); timed on a bounded
-        # number of lines and scaled to the page's line count
-        from oracle import crnn as ocrnn
+        # number of the oracle's own detected lines and scaled to the sampled pages' line count
         t_rec, nl = 0.0, 0
-        # scaled to the WORKLOAD's mean line count per page (the sampled pages may have fewer or more)
-        lines_total = lines_per_page * n if lines_per_page else sum(len(q) for q in quads[:n])
         rec_t0 = time.time()
-        for img, qs in zip(pages_np[:n], quads[:n]):
-            for q in qs[:max_lines]:
-                if nl >= 2 and time.time() - rec_t0 > 12.0:     # bounded sample
-                    break
-                t0 = time.time()
-                crop = ocrnn.crop_image(img, ocrnn.order_point(q))
-                x = ocrnn.rec_preprocess(crop)
-                with torch.no_grad():
-                    ocrnn.ctc_greedy_ids(ocrnn.crnn_forward_fp32(csd, x).numpy())
-                t_rec += time.time() - t0
-                nl += 1
+        ids_o = []
+        with torch.no_grad():
+            ocrnn.crnn_forward_fp32(csd, torch.zeros(1, 3, 32, 640), native_lstm=True)      # warm-up
+        for q in boxes_all[0]:
+            if nl >= 2 and time.time() - rec_t0 > 8.0:     # bounded sample
+                break
+            t0 = time.time()
+            crop = ocrnn.crop_image(pages_np[0], ocrnn.order_point(q))
+            x = ocrnn.rec_preprocess(crop)
+            with torch.no_grad():
+                lg = ocrnn.crnn_forward_fp32(csd, x, native_lstm=True)[0]
+            ids_o.append(lg.argmax(-1).numpy())
+            ocrnn.ctc_greedy_ids(ids_o[-1][None])
+            t_rec += time.time() - t0
+            nl += 1
         per_line = t_rec / max(1, nl)
-        dt += per_line * lines_total
-        rec_note = (f"; recognition {per_line:.3f} s/line measured on {nl} lines (crop + CRNN fp32 with a Python-loop LSTM "
-                    f"+ CTC), scaled to {lines_total / n:.0f} lines/page")
+        dt += per_line * lines_per_page * n
+        note += (f"; recognition {per_line:.3f} s/line measured on {nl} lines (crop + CRNN fp32 with torch's LSTM operator "
+                 f"+ CTC), scaled to {lines_per_page:.0f} lines/page")
+        if gpu is not None and nl:
+            for mode in ("bf16", "bf16x3"):
+                g = gpu.get("rec_ids_" + mode)
+                if g is not None and len(g) >= nl:
+                    parity["rec_token_ids_differing_" + mode] = [int(sum(int((g[i] != ids_o[i]).sum()) for i in range(nl))), int(nl * 160)]
     if layout is not None:
         from oracle import picodet as opico
         t0 = time.time()
@@ -133,46 +222,433 @@ def cpu_baseline(sd, pages_np, cfg, csd=None, quads=None, max_lines=12, tsr=None
                                       opico.LABELS["en"])
         t_lay = (time.time() - t0) / n
         dt += t_lay * n
-        rec_note += f"; layout (resize + LCNet/CSP-PAN/PicoHead fp32 + numpy NMS) {t_lay:.2f} s/page"
+        note += f"; layout (resize + LCNet/CSP-PAN/PicoHead fp32 + numpy NMS) {t_lay:.2f} s/page"
     if tsr is not None:
         lsd, psd, boxes, tables_per_page = tsr
-        per_table, note = cpu_baseline_tsr(lsd, psd, pages_np[0], boxes[0][0])
+        per_table, tnote = cpu_baseline_tsr(lsd, psd, pages_np[0], boxes[0][0])
         dt += per_table * tables_per_page * n
-        rec_note += note + f", scaled to {tables_per_page:.2f} tables/page"
-    return {"value": n / dt, "unit": "pages/s", "cores": cores, "kind": "port",
-            "sample": f"{n} synthetic 1024x1024 pages, batch 1 per call as the reference runs it, "
-                      f"torch.set_num_threads({cores}); per page: det pre (numpy) {t_pre / n:.2f} s, DB-ResNet18 fp32 "
-                      f"(torch CPU) {t_net / n:.2f} s, det post (pure-Python restatement of cv2/pyclipper) {t_post / n:.2f} s"
-                      + rec_note,
-            "net_only_pages_per_s": n / t_net}
+        note += tnote + f", scaled to {tables_per_page:.2f} tables/page"
+    # BASELINE.json configs[0]: one 640x640 page, DB-ResNet18 det + CRNN rec, CPU only (OcrDocument.__call__,
+    # model/ocr_pdf/modeling_ocr_pdf.py:313): detection, then one recogniser call per detected line
+    cfg0 = None
+    if csd is not None:
+        img = np.ascontiguousarray(pages_np[0][192:832, 192:832])
+        t0 = time.time()
+        chw, shape_list = db_pre.preprocess_db_pp(img)
+        with torch.no_grad():
+            prob = det_fwd(sd, torch.from_numpy(np.ascontiguousarray(chw))[None])[0, 0].numpy()
+        b0 = db_post.db_postprocess(prob, shape_list, img.shape, cfg.thresh, cfg.box_thresh, cfg.unclip_ratio,
+                                    cfg.use_dilation, cfg.max_candidates)
+        t1 = time.time()
+        for q in b0:
+            x = ocrnn.rec_preprocess(ocrnn.crop_image(img, ocrnn.order_point(q)))
+            with torch.no_grad():
+                ocrnn.ctc_greedy_ids(ocrnn.crnn_forward_fp32(csd, x, native_lstm=True).numpy())
+        t2 = time.time()
+        cfg0 = {"workload": "BASELINE.json configs[0]: one 640x640 page, DB-ResNet18 det + CRNN rec of every detected line",
+                "cpu_s_per_page": t2 - t0, "cpu_det_s": t1 - t0, "cpu_rec_s": t2 - t1, "lines": int(len(b0)),
+                "gpu_ms_per_page_bf16": None if gpu is None else gpu.get("config0_ms"),
+                "gpu_lines": None if gpu is None else gpu.get("config0_lines")}
+    info = cpu_info()
+    out = {"value": n / dt, "unit": "pages/s", "cores": cores, "kind": "port", "cpu": info,
+           "sample": f"{n} synthetic 1024x1024 page(s), batch 1 per call as the reference runs it, "
+                     f"torch.set_num_threads({cores}) on {info['model']} ({info['sockets']} socket(s), {info['cores']} cores, "
+                     f"{info['threads']} threads); per page: det pre (numpy) {t_pre / n:.2f} s, DB-ResNet18 fp32 "
+                     f"(torch CPU) {t_net / n:.2f} s, det post (pure-Python restatement of cv2/pyclipper) {t_post / n:.2f} s" + note
+                     + "; the reference's default ONNX models (PP-OCR, PicoDet) cannot be timed: neither onnxruntime nor the "
+                       "weights exist offline",
+           "net_only_pages_per_s": n / t_net}
+    if cfg0 is not None:
+        out["config0"] = cfg0
+    if parity:
+        out["gpu_vs_oracle_on_the_sample"] = parity
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--det-backbone", default="resnet18", choices=["resnet18", "proxylessnas"],
-                    help="DB detector network: DBModel (BASELINE.json's configuration) or DBNasModel (diagnostic variant)")
-    ap.add_argument("--no-post", action="store_true", help="device half only (diagnostic; not a valid headline)")
-    ap.add_argument("--aux-stream", type=int, default=0,
-                    help="1: the small-kernel work without 3x3 convolutions (PicoDet layout, the Lore processor and their "
-                         "D2H copies) runs on a second stream beside the conv-heavy nets")
-    ap.add_argument("--overlap-rec", action="store_true",
-                    help="diagnostic: the recogniser runs on a second stream, concurrently with the other stages "
-                         "(per-kernel HIP-event durations then include contention, so the roofline object reads low)")
-    ap.add_argument("--stages", default=os.environ.get("PT_BENCH_STAGES", "layout,det,rec,tsr"),
-                    help="comma list of stages in the timed step: layout (PicoDet), det (configs[1]), rec, tsr (Lore)")
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------------------------------
+# runners
+# ---------------------------------------------------------------------------------------------------------------------
+class StubRunner:
+    """PT_BENCH_STUB=1: no GPU, no engine -- a step is a fixed sleep.  Exercises the launch path (self-launch, rendezvous,
+    barrier, max-over-ranks timing, the JSON line) on CPU with gloo (tests/test_dist_gloo.py)."""
+
+    def __init__(self, args, rank, world):
+        self.args, self.rank, self.world = args, rank, world
+        self.stages = [x for x in args.stages.split(",") if x]
+
+    def sync(self):
+        pass
+
+    def run(self, steps, count=False):
+        time.sleep(0.01 * steps * (1 + self.rank))      # rank-dependent: the reported time must be the slowest rank's
+        return {}
+
+    def config(self, counts, steps):
+        return {"workload": "stub (PT_BENCH_STUB=1): no device work", "pages_per_step_per_gpu": PAGES_PER_STEP,
+                "stages": self.stages, "parallelism": f"page-shard x{self.world}"}
+
+
+class HipRunner:
+    def __init__(self, args, rank, local_rank, world, dist):
+        import torch
+        from pdf_table_amd import lib as L
+        from pdf_table_amd.det_stage import DetConfig, DetStage
+        from pdf_table_amd.dist_utils import shard_range
+        from pdf_table_amd.engine import HipEngine
+        from pdf_table_amd.synth_pages import make_page
+        self.torch, self.L = torch, L
+        self.args, self.rank, self.world, self.dist = args, rank, world, dist
+        torch.cuda.set_device(local_rank)
+        self.dev = dev = torch.device("cuda", local_rank)
+        self.stages = stages = [x for x in args.stages.split(",") if x]
+        assert set(stages) <= {"layout", "det", "rec", "tsr", "cls"} and stages
+        self.x3_leg = not args.no_extra_legs and args.det_backbone == "resnet18"
+        x3 = self.x3_leg            # blobs then also carry the (hi, lo) weight tiles of PT_PRECISION_BF16X3
+        self.eng = eng = HipEngine(local_rank)
+        self.aux = torch.cuda.Stream(device=dev) if args.aux_stream else None
+        self.rec_stream = None
+        first = rank == 0 or world == 1
+
+        def load(kind, make_blob):
+            """packed once on rank 0, broadcast over RCCL/xGMI, loaded from device memory everywhere"""
+            if dist is not None:
+                from pdf_table_amd.dist_utils import broadcast_blob
+                eng.load_weights_device(kind, broadcast_blob(make_blob() if rank == 0 else None, dev))
+            else:
+                eng.load_weights(kind, make_blob())
+
+        nas = args.det_backbone == "proxylessnas"
+        if nas:
+            from pdf_table_amd.synth_weights import db_nas_state_dict
+            from pdf_table_amd.weights import pack_db_nas as pack_det
+            self.sd = db_nas_state_dict(seed=0) if first else None
+        else:
+            from pdf_table_amd.synth_weights import db_resnet18_state_dict
+            from pdf_table_amd.weights import pack_db_resnet18 as pack_det
+            # random init + the hand-built text channel: the detector's own boxes feed the recogniser
+            self.sd = db_resnet18_state_dict(seed=0, text_signal=not args.gt_chain) if first else None
+        self.nas = nas
+        load(L.PT_MODEL_DB_NAS if nas else L.PT_MODEL_DB_RESNET18, lambda: pack_det(self.sd, x3=x3))
+
+        self.rec = self.csd = None
+        if "rec" in stages:
+            from pdf_table_amd.rec_stage import RecStage
+            from pdf_table_amd.synth_weights import crnn_state_dict
+            from pdf_table_amd.weights import pack_crnn
+            self.csd = crnn_state_dict(seed=1) if first else None
+            load(L.PT_MODEL_CRNN, lambda: pack_crnn(self.csd, x3=x3))
+            self.rec = RecStage(eng)
+            if args.overlap_rec:       # same engine (every stage has its own activation arena and scratch), second stream
+                self.rec_stream = torch.cuda.Stream(device=dev)
+                eng.set_lstm_cluster(False)       # the cluster LSTM needs the GPU to itself (pt_engine_set_lstm_cluster)
+
+        self.layout = self.ysd = None
+        if "layout" in stages:
+            from pdf_table_amd.layout_stage import LayoutStage, PicodetConfig
+            from pdf_table_amd.synth_weights import picodet_state_dict
+            from pdf_table_amd.weights import pack_picodet
+            self.ysd = picodet_state_dict(seed=4, num_classes=5) if first else None
+            load(L.PT_MODEL_PICODET, lambda: pack_picodet(self.ysd, 5, x3=x3))
+            self.layout = LayoutStage(eng, PicodetConfig(task_type="en"))
+
+        self.tsr = self.lsd = self.psd = None
+        if "tsr" in stages:
+            from pdf_table_amd.synth_weights import lore_dla34_state_dict, lore_processor_state_dict
+            from pdf_table_amd.tsr_stage import LoreConfig, TsrStage
+            from pdf_table_amd.weights import pack_lore_dla34, pack_lore_processor
+            self.lsd = lore_dla34_state_dict(seed=2) if first else None
+            self.psd = lore_processor_state_dict(seed=3) if first else None
+            load(L.PT_MODEL_LORE_DLA34, lambda: pack_lore_dla34(self.lsd, x3=x3))
+            load(L.PT_MODEL_LORE_PROCESSOR, lambda: pack_lore_processor(self.psd, x3=x3))
+            self.tsr = TsrStage(eng, LoreConfig(task_type="wtw"), micro_batch=int(os.environ.get("PT_TSR_MICROBATCH", "80")))
+
+        self.cls_line = self.cls_page = None
+        if "cls" in stages:      # SURVEY 8f-1 (not part of BASELINE.json's metric; opt-in): PP-LCNet text-line + page orientation
+            from pdf_table_amd.cls_stage import ClsStage
+            from pdf_table_amd.synth_weights import pplcnet_state_dict
+            from pdf_table_amd.weights import pack_pplcnet
+            for slot, (seed, ncls) in enumerate(((5, 2), (6, 4))):
+                csd_ = pplcnet_state_dict(seed, ncls) if first else None
+                load(L.PT_MODEL_PPLCNET + slot, lambda: pack_pplcnet(csd_, x3=x3))
+            self.cls_line, self.cls_page = ClsStage(eng, "textline_orientation", 0), ClsStage(eng, "text_image_orientation", 1)
+
+        # pages: rank r owns pages [r*P, (r+1)*P) of the global batch (static contiguous shard, dist_utils.shard_range)
+        lo, hi = shard_range(world * PAGES_PER_STEP, rank, world)
+        assert hi - lo == PAGES_PER_STEP
+        made = [make_page(rank * DISTINCT + i, PAGE) for i in range(DISTINCT)]
+        self.pages_np = np.stack([made[i % DISTINCT][0] for i in range(PAGES_PER_STEP)])
+        # ground truth of the generator: text-line rectangles (only with --gt-chain) and table rectangles.  The layout net
+        # has random-init weights (its boxes are not tables), so the table-structure stage is fed the generator's own table
+        # rectangles (1-2 per page) where the reference feeds it the layout boxes with label "table"
+        # (ocr_system_task.py:192-198), grown by 8 px like a detector's box
+        self.gt_quads, self.table_boxes = [], []
+        for i in range(PAGES_PER_STEP):
+            l = made[i % DISTINCT][1]["lines"].astype(np.float64)
+            self.gt_quads.append(np.stack([l[:, 0], l[:, 1], l[:, 2], l[:, 1], l[:, 2], l[:, 3], l[:, 0], l[:, 3]], 1))
+            t = made[i % DISTINCT][1]["tables"].astype(np.int64).reshape(-1, 4)
+            self.table_boxes.append(np.stack([np.maximum(t[:, 0] - 8, 0), np.maximum(t[:, 1] - 8, 0), np.minimum(t[:, 2] + 8, PAGE),
+                                              np.minimum(t[:, 3] + 8, PAGE)], 1))
+        self.gt_lines_per_page = float(np.mean([len(q) for q in self.gt_quads]))
+        self.tables_per_page = float(np.mean([len(t) for t in self.table_boxes]))
+        self.pages = torch.from_numpy(self.pages_np).to(dev)
+        self.cfg = DetConfig(flavour="db_pp", thresh=0.3, box_thresh=0.6, unclip_ratio=1.5)
+        # N ranks share the host: the contour / Clipper pool of each rank stays inside its share of the cores
+        workers = max(1, min(32, (os.cpu_count() or 8) // max(1, world)))
+        self.stage = DetStage(eng, self.cfg, workers=workers)
+        self.rec_boxes = None        # detection boxes of the last post-processed step: what the recogniser reads
+        self.trace = {} if os.environ.get("PT_BENCH_TRACE") else None
+        for s_ in (self.rec_stream, self.aux):
+            if s_ is not None:
+                s_.wait_stream(torch.cuda.current_stream(dev))          # the resident pages were uploaded on the default stream
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def _on(self, stream):
+        return self.torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+
+    def _tick(self, name, t0):
+        if self.trace is not None:
+            self.trace[name] = self.trace.get(name, 0.0) + time.perf_counter() - t0
+
+    def prime(self):
+        """pipeline fill (untimed): one synchronous detection so that the first step's recogniser has boxes to read"""
+        if "det" in self.stages and "rec" in self.stages and not self.args.gt_chain and self.rec_boxes is None:
+            cur = self.stage.forward(self.pages, slot=0)
+            self.rec_boxes = self.stage.boxes(cur[0], cur[1], (PAGE, PAGE), cur[2])
+
+    def run(self, steps, count=False, stages=None):
+        """software pipeline: all device work of step k is enqueued before the host halves run (the detection
+        post-process of step k-1 first), so the GPU queue never drains while the host works"""
+        torch, args, eng = self.torch, self.args, self.eng
+        stages = stages or self.stages
+        layout = self.layout if "layout" in stages else None
+        rec = self.rec if "rec" in stages else None
+        tsr = self.tsr if "tsr" in stages else None
+        cls_line = self.cls_line if "cls" in stages else None
+        c = {"boxes": 0, "tok": 0, "cells": 0, "layout": 0, "cls_lines": 0, "rec_lines": 0}
+        prev = None          # detection maps of the previous step (host post-process pending)
+        tprev = None         # table-structure state of the previous step (cell counts, processor, host shaping pending)
+        tproc = None         # ... of two steps ago (processor queued, rows on their way to pinned memory)
+        self.prime()
+        for k in range(steps):
+            t0 = time.perf_counter()
+            with self._on(self.aux):
+                lay = layout.forward(self.pages) if layout is not None else None  # resize, LCNet/CSP-PAN/PicoHead, candidates (async)
+            cur = self.stage.forward(self.pages, slot=k & 1) if "det" in stages else None
+            rec_ids = None
+            if rec is not None:
+                quads = self.gt_quads if (args.gt_chain or self.rec_boxes is None) else self.rec_boxes
+                with self._on(self.rec_stream):
+                    rec_ids, rec_lines = rec.ids(self.pages, quads)      # host quad geometry + one pt_rec_forward (async)
+                if count:
+                    c["rec_lines"] += len(rec_lines)
+            tpend = None
+            if tsr is not None:
+                tsr_tables, tsr_metas = tsr.tables((PAGE, PAGE), self.table_boxes)    # host: one affine map per table
+                tpend = (tsr.start(self.pages, tsr_tables), tsr_metas)                # warp, DLA-34+DCN, decode (async)
+                if self.aux is not None:      # the processor of these tables will run on the auxiliary stream, behind this event
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    for (_, _, c_, d_, l_) in tpend[0]:
+                        for t_ in (c_, d_, l_):
+                            t_.record_stream(self.aux)
+                    tpend = tpend + (ev,)
+            cls_out = None
+            if cls_line is not None:
+                from pdf_table_amd.rec_stage import build_lines
+                cls_quads = self.gt_quads if (args.gt_chain or self.rec_boxes is None) else self.rec_boxes
+                cls_out = (eng.cls_forward_lines(self.pages, build_lines(cls_quads), (80, 160), 0, True),
+                           eng.cls_forward_pages(self.pages, (224, 224), 1, False), cls_quads)
+            self._tick("enqueue", t0)
+            t0 = time.perf_counter()
+            if prev is not None and not args.no_post:          # host half of the previous step, under this step's GPU work
+                res = self.stage.boxes(prev[0], prev[1], (PAGE, PAGE), prev[2])
+                self.rec_boxes = res
+                if count:
+                    c["boxes"] += sum(len(r) for r in res)
+            self._tick("det_post", t0)
+            t0 = time.perf_counter()
+            if lay is not None:
+                lres = layout.finish(lay[0], lay[1], (PAGE, PAGE))      # D2H of the candidates, decode + per-class hard NMS
+                if count:
+                    c["layout"] += sum(len(r) for r in lres)
+            self._tick("layout_post", t0)
+            t0 = time.perf_counter()
+            if rec_ids is not None:
+                from pdf_table_amd.rec_stage import ctc_collapse
+                with self._on(self.rec_stream):
+                    toks = ctc_collapse(rec_ids.cpu().numpy())     # D2H of int32 [lines, 160] + host collapse
+                eng.check()
+                if count:
+                    c["tok"] += sum(len(t) for t in toks)
+            self._tick("ctc", t0)
+            if cls_out is not None:
+                t0 = time.perf_counter()
+                lid, lsc = cls_line.top1(cls_out[0])       # D2H of [lines, 2] logits, soft-max + top-1 (vectorised host)
+                o = 0
+                for q in cls_out[2]:                       # the reference's per-page upright / upside-down vote
+                    cls_line.vote_top1(lid[o:o + len(q)], lsc[o:o + len(q)])
+                    o += len(q)
+                self.cls_page.top1(cls_out[1])
+                if count:
+                    c["cls_lines"] += len(lid)
+                self._tick("cls_post", t0)
+            t0 = time.perf_counter()
+            if tproc is not None:      # tables of two steps ago: their rows reached pinned memory during the last step
+                tres = tsr.collect(tproc[0], tproc[1])
+                if count:
+                    c["cells"] += sum(len(t["polygons"]) for t in tres)
+            tproc = None
+            if tprev is not None:      # tables of the previous step: counts are ready, the processor and its D2H are queued
+                with self._on(self.aux):
+                    if self.aux is not None:
+                        self.aux.wait_event(tprev[2])
+                    tproc = (tsr.process(tprev[0]), tprev[1])  # behind this step's work; nothing here blocks on this step
+            self._tick("tsr_finish", t0)
+            prev = cur
+            tprev = tpend
+        if prev is not None and not args.no_post:
+            res = self.stage.boxes(prev[0], prev[1], (PAGE, PAGE), prev[2])
+            self.rec_boxes = res
+            if count:
+                c["boxes"] += sum(len(r) for r in res)
+        for fin in ((lambda: tsr.collect(tproc[0], tproc[1])) if tproc is not None else None,
+                    (lambda: tsr.finish(tprev[0], tprev[1])) if tprev is not None else None):
+            if fin is not None:
+                tres = fin()
+                if count:
+                    c["cells"] += sum(len(t["polygons"]) for t in tres)
+        return c
+
+    # ---- extra legs (after the timed region) ------------------------------------------------------------------------
+    def timed(self, steps, warm, stages=None):
+        self.run(warm, stages=stages)
+        self.sync()
+        t0 = time.perf_counter()
+        c = self.run(steps, count=True, stages=stages)
+        self.sync()
+        return time.perf_counter() - t0, c
+
+    def det_only_leg(self, steps=10, warm=2):
+        """BASELINE.json configs[1] in the same run: the det stage alone (pre, DB-ResNet18, bitmap, host post overlapped)"""
+        dt, c = self.timed(steps, warm, stages=["det"])
+        pps = PAGES_PER_STEP * steps / dt
+        return {"pages_per_s_det_only": pps, "steps": steps, "boxes_per_page": c["boxes"] / (PAGES_PER_STEP * steps),
+                "gflop_per_page": DB_GFLOP_960, "achieved_tflops": DB_GFLOP_960 * 1e9 * pps / 1e12,
+                "frac": DB_GFLOP_960 * 1e9 * pps / (MFMA_PEAK_TFLOPS * 1e12),
+                "definition": "BASELINE.md section 5: 111.71e9 x det-only pages/s / 2.5e15 (960x960 graph, whole det stage "
+                              "incl. pre-process, bitmap and the overlapped host post-process in the time)"}
+
+    def x3_leg_run(self, steps=3, warm=1):
+        """the same step in PT_PRECISION_BF16X3 (the mode whose tests assert 1e-3 / id-exact parity)"""
+        L = self.L
+        self.eng.set_precision(L.PT_PRECISION_BF16X3)
+        try:
+            dt, c = self.timed(steps, warm)
+        finally:
+            self.eng.set_precision(L.PT_PRECISION_BF16)
+        n = PAGES_PER_STEP * steps
+        return {"precision": "bf16x3 (hi/lo bf16 pairs, 3 MFMA passes, fp32 accumulate)", "pages_per_s": n / dt, "steps": steps,
+                "ms_per_step": dt / steps * 1e3, "boxes_per_page": c["boxes"] / n, "tokens_per_page": c["tok"] / n,
+                "table_cells_per_page": c["cells"] / n,
+                "asserted_by": "tests/test_gpu_fullsize.py::test_fullsize_*_oracle_parity (x3: <= 1e-3 of the logit scale at "
+                               "BASELINE sizes, token ids exact outside the oracle's own <= 2e-3 ties); bf16 drift recorded there"}
+
+    def parity_sample(self):
+        """engine outputs for the page / lines the CPU-baseline leg runs through the oracle (checked THERE)"""
+        torch, L, eng = self.torch, self.L, self.eng
+        out = {}
+        if self.nas:
+            return out
+        from pdf_table_amd.rec_stage import ctc_collapse
+        page0 = self.pages[:1]
+        for mode, prec in (("bf16", L.PT_PRECISION_BF16), ("bf16x3", L.PT_PRECISION_BF16X3)):
+            if mode == "bf16x3" and not self.x3_leg:
+                continue
+            eng.set_precision(prec)
+            try:
+                prob, bm = eng.det_forward(page0, L.PT_DET_PRE_DB_PP, self.cfg.thresh)
+                out["det_prob_" + mode] = prob[0].cpu().numpy()
+                boxes = self.stage.boxes(prob, bm, (PAGE, PAGE))
+                if mode == "bf16":
+                    out["det_nboxes"] = len(boxes[0])
+                    self._boxes0 = boxes
+                if self.rec is not None:
+                    # the ORACLE's boxes are not known here; the leg compares line by line, so both sides must read the
+                    # same quads: the bf16 boxes of page 0 (the oracle's boxes equal them unless a pixel sits on the threshold)
+                    ids, _ = self.rec.ids(page0, self._boxes0)
+                    out["rec_ids_" + mode] = ids.cpu().numpy()
+            finally:
+                eng.set_precision(L.PT_PRECISION_BF16)
+        if self.rec is not None:      # configs[0] on the GPU: one 640x640 page, det + rec, synchronous, bf16
+            p640 = self.pages[:1, 192:832, 192:832].contiguous()
+            st = self.stage
+            for it in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                b = st(p640)
+                ids, _ = self.rec.ids(p640, b)
+                ctc_collapse(ids.cpu().numpy())
+                torch.cuda.synchronize()
+                out["config0_ms"] = (time.perf_counter() - t0) * 1e3
+                out["config0_lines"] = int(len(b[0]))
+        return out
+
+    def config(self, c, steps):
+        nas, stages, args = self.nas, self.stages, self.args
+        n = max(1, PAGES_PER_STEP * steps)
+        chained = "det" in stages and "rec" in stages and not args.gt_chain
+        return {"workload": ("BASELINE.json configs[2], full pipeline: " if set(stages) >= {"layout", "det", "rec", "tsr"} else "")
+                            + ("PicoDet layout detection (resize to 800x608, LCNet + CSP-PAN + PicoHead, hard NMS) + "
+                               if "layout" in stages else "")
+                            + ("BASELINE.json configs[1] batched DB text detection (db_pp pre/post around "
+                               + ("DB-ProxylessNAS [--det-backbone variant, not the BASELINE.json network]" if nas
+                                  else "DB-ResNet18") + ", 1024x1024 synthetic pages -> 960x960 net input, boxes out)"
+                               if "det" in stages else "")
+                            + (" + CRNN text-line recognition (crop, resize, CRNN, arg-max, CTC collapse) of "
+                               + ("the boxes the detection stage produced (software-pipelined by one step)" if chained
+                                  else "the page generator's text-line rectangles") if "rec" in stages else "")
+                            + (" + Lore table-structure recognition of the page's tables (wtw: warp to 1024x1024, "
+                               "DLA-34+DCN, heat-map/corner decode with vertex snapping, 2 x 4-layer processor, "
+                               "quads + logical locations)" if "tsr" in stages else "")
+                            + (" + PP-LCNet text-line orientation of every text line and page orientation of every page "
+                               "[opt-in stage, not part of BASELINE.json's metric]" if "cls" in stages else "")
+                            + (" [DEVICE HALF ONLY]" if args.no_post else "")
+                            + (" [recogniser on a second stream: --overlap-rec diagnostic]" if args.overlap_rec else "")
+                            + (" [layout and the Lore processor on an auxiliary stream]" if args.aux_stream else "")
+                            + "; weights are seeded random init"
+                            + (" except one hand-built detector channel that finds the synthetic text (synth_weights._db_text_signal), "
+                               "so detection -> recognition is chained by the detector's own boxes" if chained else "")
+                            + ("; the layout and Lore nets are plain random init, so the table regions are the page generator's "
+                               "ground truth" if "tsr" in stages else ""),
+                "pages_per_step_per_gpu": PAGES_PER_STEP, "distinct_pages_per_gpu": DISTINCT, "page": [PAGE, PAGE],
+                "stages": stages, "parallelism": f"page-shard x{self.world}",
+                "text_lines_per_page_generated": self.gt_lines_per_page,
+                "text_lines_recognised_per_page": c["rec_lines"] / n,
+                "tokens_per_page": c["tok"] / n,
+                "boxes_per_page": c["boxes"] / n,
+                "tables_per_page": self.tables_per_page if "tsr" in stages else 0,
+                "layout_regions_per_page": c["layout"] / n,
+                "table_cells_per_page": c["cells"] / n,
+                "classified_lines_per_page": c["cls_lines"] / n,
+                "weights": "seeded random init (reference state_dict layout)" + (" + text-signal channel in the detector" if chained else "")}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    self_launch(args, argv)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python bench.py --gpus {args.gpus} does it itself)")
+    stub = os.environ.get("PT_BENCH_STUB") == "1"
+    import torch
     if world > 1:      # N ranks share the host: keep each rank's CPU-side torch / BLAS work inside its share of the cores
         torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
     dist = None
@@ -183,335 +659,102 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    from pdf_table_amd import lib as L
-    from pdf_table_amd.det_stage import DetConfig, DetStage
-    from pdf_table_amd.engine import HipEngine
-    from pdf_table_amd.synth_pages import make_page
-    from pdf_table_amd.synth_weights import db_resnet18_state_dict
-    from pdf_table_amd.weights import pack_crnn, pack_db_resnet18
-    stages = [x for x in args.stages.split(",") if x]
-    assert set(stages) <= {"layout", "det", "rec", "tsr", "cls"} and stages
-
-    eng = HipEngine(local_rank)
-    eng_rec, rec_stream = None, None
-    aux = torch.cuda.Stream(device=dev) if args.aux_stream else None
-
-    def on_aux():
-        return torch.cuda.stream(aux) if aux is not None else contextlib.nullcontext()
-    # weights: packed once on rank 0, broadcast over RCCL/xGMI, loaded from device memory everywhere
-    nas = args.det_backbone == "proxylessnas"
-    if nas:
-        from pdf_table_amd.synth_weights import db_nas_state_dict as det_state_dict
-        from pdf_table_amd.weights import pack_db_nas as pack_det
-    else:
-        det_state_dict, pack_det = db_resnet18_state_dict, pack_db_resnet18
-    det_kind = L.PT_MODEL_DB_NAS if nas else L.PT_MODEL_DB_RESNET18
-    sd = det_state_dict(seed=0) if rank == 0 or world == 1 else None
-    if use_dist:
-        from pdf_table_amd.dist_utils import broadcast_blob
-        blob = broadcast_blob(pack_det(sd, x3=False) if rank == 0 else None, dev)
-        eng.load_weights_device(det_kind, blob)
-    else:
-        eng.load_weights(det_kind, pack_det(sd, x3=False))
-
-    rec = None
-    if "rec" in stages:
-        from pdf_table_amd.rec_stage import RecStage, build_lines
-        from pdf_table_amd.synth_weights import crnn_state_dict
-        csd = crnn_state_dict(seed=1) if rank == 0 or world == 1 else None
-        if use_dist:
-            from pdf_table_amd.dist_utils import broadcast_blob
-            eng.load_weights_device(L.PT_MODEL_CRNN, broadcast_blob(pack_crnn(csd, x3=False) if rank == 0 else None, dev))
+        if stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            eng.load_weights(L.PT_MODEL_CRNN, pack_crnn(csd, x3=False))
-        rec = RecStage(eng)
-        if args.overlap_rec:       # same engine (every stage has its own activation arena and scratch), second stream
-            rec_stream = torch.cuda.Stream(device=dev)
+            if torch.cuda.device_count() <= local_rank:
+                raise SystemExit(f"rank {rank}: no GPU {local_rank} (visible: {torch.cuda.device_count()})")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    layout = None
-    if "layout" in stages:
-        from pdf_table_amd.layout_stage import LayoutStage, PicodetConfig
-        from pdf_table_amd.synth_weights import picodet_state_dict
-        from pdf_table_amd.weights import pack_picodet
-        ysd = picodet_state_dict(seed=4, num_classes=5) if rank == 0 or world == 1 else None
-        if use_dist:
-            from pdf_table_amd.dist_utils import broadcast_blob
-            eng.load_weights_device(L.PT_MODEL_PICODET, broadcast_blob(pack_picodet(ysd, 5, x3=False) if rank == 0 else None, dev))
-        else:
-            eng.load_weights(L.PT_MODEL_PICODET, pack_picodet(ysd, 5, x3=False))
-        layout = LayoutStage(eng, PicodetConfig(task_type="en"))
-
-    tsr = None
-    if "tsr" in stages:
-        from pdf_table_amd.synth_weights import lore_dla34_state_dict, lore_processor_state_dict
-        from pdf_table_amd.tsr_stage import LoreConfig, TsrStage
-        from pdf_table_amd.weights import pack_lore_dla34, pack_lore_processor
-        lsd = lore_dla34_state_dict(seed=2) if rank == 0 or world == 1 else None
-        psd = lore_processor_state_dict(seed=3) if rank == 0 or world == 1 else None
-        if use_dist:
-            from pdf_table_amd.dist_utils import broadcast_blob
-            eng.load_weights_device(L.PT_MODEL_LORE_DLA34, broadcast_blob(pack_lore_dla34(lsd, x3=False) if rank == 0 else None, dev))
-            eng.load_weights_device(L.PT_MODEL_LORE_PROCESSOR,
-                                    broadcast_blob(pack_lore_processor(psd, x3=False) if rank == 0 else None, dev))
-        else:
-            eng.load_weights(L.PT_MODEL_LORE_DLA34, pack_lore_dla34(lsd, x3=False))
-            eng.load_weights(L.PT_MODEL_LORE_PROCESSOR, pack_lore_processor(psd, x3=False))
-        tsr = TsrStage(eng, LoreConfig(task_type="wtw"), micro_batch=int(os.environ.get("PT_TSR_MICROBATCH", "80")))
-
-    cls_line = cls_page = None
-    if "cls" in stages:      # SURVEY 8f-1 (not part of BASELINE.json's metric; opt-in): PP-LCNet text-line + page orientation
-        from pdf_table_amd.cls_stage import ClsStage
-        from pdf_table_amd.synth_weights import pplcnet_state_dict
-        from pdf_table_amd.weights import pack_pplcnet
-        for slot, (seed, ncls) in enumerate(((5, 2), (6, 4))):
-            csd_ = pplcnet_state_dict(seed, ncls) if rank == 0 or world == 1 else None
-            if use_dist:
-                from pdf_table_amd.dist_utils import broadcast_blob
-                eng.load_weights_device(L.PT_MODEL_PPLCNET + slot, broadcast_blob(pack_pplcnet(csd_, x3=False) if rank == 0 else None, dev))
-            else:
-                eng.load_weights(L.PT_MODEL_PPLCNET + slot, pack_pplcnet(csd_, x3=False))
-        cls_line, cls_page = ClsStage(eng, "textline_orientation", 0), ClsStage(eng, "text_image_orientation", 1)
-
-    # pages: rank r owns pages [r*P, (r+1)*P) of the global batch (static contiguous shard, dist_utils.shard_range)
-    from pdf_table_amd.dist_utils import shard_range
-    lo, hi = shard_range(world * PAGES_PER_STEP, rank, world)
-    assert hi - lo == PAGES_PER_STEP
-    made = [make_page(rank * DISTINCT + i, PAGE) for i in range(DISTINCT)]
-    base = [m[0] for m in made]
-    pages_np = np.stack([base[i % DISTINCT] for i in range(PAGES_PER_STEP)])
-    # Recognition input: the DB weights are random-init, so its boxes are not text.  The recogniser is fed the
-    # generator's own text-line rectangles (60-140 per page) as 4-point quads instead.
-    gt_quads = []
-    for i in range(PAGES_PER_STEP):
-        l = made[i % DISTINCT][1]["lines"].astype(np.float64)
-        gt_quads.append(np.stack([l[:, 0], l[:, 1], l[:, 2], l[:, 1], l[:, 2], l[:, 3], l[:, 0], l[:, 3]], 1))
-    lines_per_page = float(np.mean([len(q) for q in gt_quads]))
-    # Table regions: the layout net has random-init weights (its boxes are not tables), so the table-structure stage is fed
-    # the generator's own table rectangles (1-2 per page) where the reference feeds it the layout boxes with label "table"
-    # (ocr_system_task.py:192-198), grown by 8 px like a detector's box
-    table_boxes = []
-    for i in range(PAGES_PER_STEP):
-        t = made[i % DISTINCT][1]["tables"].astype(np.int64).reshape(-1, 4)
-        table_boxes.append(np.stack([np.maximum(t[:, 0] - 8, 0), np.maximum(t[:, 1] - 8, 0), np.minimum(t[:, 2] + 8, PAGE),
-                                     np.minimum(t[:, 3] + 8, PAGE)], 1))
-    tables_per_page = float(np.mean([len(t) for t in table_boxes]))
-    pages = torch.from_numpy(pages_np).to(dev)
-    cfg = DetConfig(flavour="db_pp", thresh=0.3, box_thresh=0.6, unclip_ratio=1.5)
-    stage = DetStage(eng, cfg)
+    runner = StubRunner(args, rank, world) if stub else HipRunner(args, rank, local_rank, world, dist)
 
     def barrier():
-        torch.cuda.synchronize()
+        runner.sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        runner.sync()
 
-    nboxes = 0
-    ntok = 0
-    ncells = 0
-    ncls_lines = 0
-    nlayout = 0
-
-    trace = {} if os.environ.get("PT_BENCH_TRACE") else None
-
-    def tick(name, t0):
-        if trace is not None:
-            trace[name] = trace.get(name, 0.0) + time.perf_counter() - t0
-
-    def run(steps, count=False):
-        """software pipeline: all device work of step k is enqueued before the host halves run (the detection
-        post-process of step k-1 first), so the GPU queue never drains while the host works"""
-        nonlocal nboxes, ntok, ncells, nlayout, ncls_lines
-        prev = None          # detection maps of the previous step (host post-process pending)
-        tprev = None         # table-structure state of the previous step (cell counts, processor, host shaping pending)
-        tproc = None         # ... of two steps ago (processor queued, rows on their way to pinned memory)
-        for k in range(steps):
-            t0 = time.perf_counter()
-            with on_aux():
-                lay = layout.forward(pages) if layout is not None else None  # resize, LCNet/CSP-PAN/PicoHead, candidates (async)
-            cur = stage.forward(pages, slot=k & 1) if "det" in stages else None
-            rec_ids = None
-            if rec is not None:
-                with torch.cuda.stream(rec_stream) if rec_stream is not None else contextlib.nullcontext():
-                    rec_ids, _ = rec.ids(pages, gt_quads)      # host quad geometry + one pt_rec_forward (async)
-            tpend = None
-            if tsr is not None:
-                tsr_tables, tsr_metas = tsr.tables((PAGE, PAGE), table_boxes)    # host: one affine map per table
-                tpend = (tsr.start(pages, tsr_tables), tsr_metas)                # warp, DLA-34+DCN, decode (async)
-                if aux is not None:      # the processor of these tables will run on the auxiliary stream, behind this event
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    for (_, _, c_, d_, l_) in tpend[0]:
-                        for t_ in (c_, d_, l_):
-                            t_.record_stream(aux)
-                    tpend = tpend + (ev,)
-            cls_out = None
-            if cls_line is not None:
-                from pdf_table_amd.rec_stage import build_lines
-                cls_out = (eng.cls_forward_lines(pages, build_lines(gt_quads), (80, 160), 0, True),
-                           eng.cls_forward_pages(pages, (224, 224), 1, False))
-            tick("enqueue", t0)
-            t0 = time.perf_counter()
-            if prev is not None and not args.no_post:          # host half of the previous step, under this step's GPU work
-                res = stage.boxes(prev[0], prev[1], (PAGE, PAGE), prev[2])
-                if count:
-                    nboxes += sum(len(r) for r in res)
-            tick("det_post", t0)
-            t0 = time.perf_counter()
-            if lay is not None:
-                lres = layout.finish(lay[0], lay[1], (PAGE, PAGE))      # D2H of the candidates, decode + per-class hard NMS
-                if count:
-                    nlayout += sum(len(r) for r in lres)
-            tick("layout_post", t0)
-            t0 = time.perf_counter()
-            if rec_ids is not None:
-                from pdf_table_amd.rec_stage import ctc_collapse
-                with torch.cuda.stream(rec_stream) if rec_stream is not None else contextlib.nullcontext():
-                    toks = ctc_collapse(rec_ids.cpu().numpy())     # D2H of int32 [lines, 160] + host collapse
-                (eng_rec or eng).check()
-                if count:
-                    ntok += sum(len(t) for t in toks)
-            tick("ctc", t0)
-            if cls_out is not None:
-                t0 = time.perf_counter()
-                lid, lsc = cls_line.top1(cls_out[0])       # D2H of [lines, 2] logits, soft-max + top-1 (vectorised host)
-                o = 0
-                for q in gt_quads:                         # the reference's per-page upright / upside-down vote
-                    cls_line.vote_top1(lid[o:o + len(q)], lsc[o:o + len(q)])
-                    o += len(q)
-                cls_page.top1(cls_out[1])
-                if count:
-                    ncls_lines += len(lid)
-                tick("cls_post", t0)
-            t0 = time.perf_counter()
-            if tproc is not None:      # tables of two steps ago: their rows reached pinned memory during the last step
-                tres = tsr.collect(tproc[0], tproc[1])
-                if count:
-                    ncells += sum(len(t["polygons"]) for t in tres)
-            tproc = None
-            if tprev is not None:      # tables of the previous step: counts are ready, the processor and its D2H are queued
-                with on_aux():
-                    if aux is not None:
-                        aux.wait_event(tprev[2])
-                    tproc = (tsr.process(tprev[0]), tprev[1])  # behind this step's work; nothing here blocks on this step
-            tick("tsr_finish", t0)
-            prev = cur
-            tprev = tpend
-        if prev is not None and not args.no_post:
-            res = stage.boxes(prev[0], prev[1], (PAGE, PAGE), prev[2])
-            if count:
-                nboxes += sum(len(r) for r in res)
-        for fin in ((lambda: tsr.collect(tproc[0], tproc[1])) if tproc is not None else None,
-                    (lambda: tsr.finish(tprev[0], tprev[1])) if tprev is not None else None):
-            if fin is not None:
-                tres = fin()
-                if count:
-                    ncells += sum(len(t["polygons"]) for t in tres)
-
-    for s_ in (rec_stream, aux):
-        if s_ is not None:
-            s_.wait_stream(torch.cuda.current_stream(dev))          # the resident pages were uploaded on the default stream
-    run(args.warmup)
+    runner.run(args.warmup)
     barrier()
     # HIP events around the launches of the roofline's kernel class only (mode 2 + class 0 = the 3x3 convs): an event pair per
     # launch of every class (PT_BENCH_PROF=1, fills all_kernel_classes_ms) costs 1-3 % of the step in idle GPU time
     prof_mode = int(os.environ.get("PT_BENCH_PROF", "2"))
-    eng.profile_enable(prof_mode)
-    if eng_rec is not None:
-        eng_rec.profile_enable(prof_mode)
+    if not stub:
+        runner.eng.profile_enable(prof_mode)
     t0 = time.perf_counter()
-    run(args.steps, count=True)
+    counts = runner.run(args.steps, count=True)
     barrier()
     dt = time.perf_counter() - t0
-    prof = eng.profile_read()
-    eng.profile_enable(False)
-    if eng_rec is not None:
-        for k_, v_ in eng_rec.profile_read().items():
-            for f_ in v_:
-                prof[k_][f_] += v_[f_]
-        eng_rec.profile_enable(False)
-    if trace is not None and rank == 0:
-        print("[bench trace] host seconds over warm-up + timed steps:", {k: round(v, 3) for k, v in trace.items()}, file=sys.stderr)
+    prof = None
+    if not stub:
+        prof = runner.eng.profile_read()
+        runner.eng.profile_enable(False)
+        if runner.trace is not None and rank == 0:
+            print("[bench trace] host seconds over warm-up + timed steps:", {k: round(v, 3) for k, v in runner.trace.items()},
+                  file=sys.stderr)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=None if stub else runner.dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     if rank == 0:
         total_pages = world * PAGES_PER_STEP * args.steps
-        value = total_pages / dt
-        c3 = prof["conv3x3"]
-        achieved = (c3["flop"] / (c3["ms"] * 1e-3)) / 1e12 if c3["ms"] > 0 else 0.0
-        traffic = None
-        try:   # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_summary.py)
-            with open(os.path.join(REPO, "profiles", "pmc_latest.json")) as f:
-                pm = json.load(f)
-            tot = nl = 0.0
-            for kname, rec_ in pm.items():       # every 3x3 conv kernel variant, launch-weighted
-                if ("conv_igemm_kernel<3," in kname or "conv3x3_dma" in kname) and "hbm_bytes_per_launch" in rec_:
-                    n_ = rec_["FETCH_SIZE"]["dispatches"]
-                    tot += rec_["hbm_bytes_per_launch"] * n_
-                    nl += n_
-            traffic = tot / nl if nl else None
-        except Exception:
-            traffic = None
-        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<3,*> / conv3x3_dma16_kernel (3x3 implicit-GEMM convolutions of all stages)",
-                "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
-                "traffic": traffic, "traffic_note": "bytes/launch over the 3x3 conv kernels, PMC passes of profiles/pmc_latest.json "
-                                                    "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
-                "launches": c3["launches"], "avg_launch_ms": c3["ms"] / max(1, c3["launches"]),
-                "algorithmic_flop_per_launch": c3["flop"] / max(1, c3["launches"]),
-                "events": "3x3 class only" if prof_mode == 2 else "every launch"}
-        if prof_mode == 1:       # PT_BENCH_PROF=1: events around every launch
-            roof["all_kernel_classes_ms"] = {k: v["ms"] for k, v in prof.items()}
-            roof["net_tflops_on_111.71_gflop_per_page"] = DB_GFLOP_960e9_per_page(total_pages, prof)
-        out = {"metric": "pages/s", "value": value, "unit": "pages/s", "n_gpus": world, "steps": args.steps,
+        out = {"metric": "pages/s", "value": total_pages / dt, "unit": "pages/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": ("PicoDet layout detection (resize to 800x608, LCNet + CSP-PAN + PicoHead, hard NMS) + "
-                                       if "layout" in stages else "")
-                                      + ("BASELINE.json configs[1] batched DB text detection (db_pp pre/post around "
-                                       + ("DB-ProxylessNAS [--det-backbone variant, not the BASELINE.json network]" if nas
-                                          else "DB-ResNet18") + ", 1024x1024 synthetic pages -> 960x960 net input, boxes out)"
-                                       if "det" in stages else "")
-                                      + (" + CRNN text-line recognition of the page's text lines (crop, resize, CRNN, "
-                                         "arg-max, CTC collapse)" if "rec" in stages else "")
-                                      + (" + Lore table-structure recognition of the page's tables (wtw: warp to 1024x1024, "
-                                         "DLA-34+DCN, heat-map/corner decode with vertex snapping, 2 x 4-layer processor, "
-                                         "quads + logical locations)" if "tsr" in stages else "")
-                                      + (" + PP-LCNet text-line orientation of every text line and page orientation of every page "
-                                         "[opt-in stage, not part of BASELINE.json's metric]" if "cls" in stages else "")
-                                      + (" [DEVICE HALF ONLY]" if args.no_post else "")
-                                      + (" [recogniser on a second stream: --overlap-rec diagnostic]" if args.overlap_rec else "")
-                                      + (" [layout and the Lore processor on an auxiliary stream]" if args.aux_stream else "")
-                                      + "; weights are random-init, so the stages are chained by the page generator's ground truth "
-                                        "(table regions for TSR, text-line quads for recognition) instead of each other's outputs",
-                          "pages_per_step_per_gpu": PAGES_PER_STEP, "page": [PAGE, PAGE],
-                          "stages": stages, "parallelism": f"page-shard x{world}",
-                          "text_lines_per_page": lines_per_page if "rec" in stages else 0,
-                          "tokens_per_page": ntok / max(1, PAGES_PER_STEP * args.steps),
-                          "boxes_per_page": nboxes / max(1, PAGES_PER_STEP * args.steps),
-                          "tables_per_page": tables_per_page if "tsr" in stages else 0,
-                          "layout_regions_per_page": nlayout / max(1, PAGES_PER_STEP * args.steps),
-                          "table_cells_per_page": ncells / max(1, PAGES_PER_STEP * args.steps),
-                          "classified_lines_per_page": ncls_lines / max(1, PAGES_PER_STEP * args.steps),
-                          "weights": "seeded random init (reference state_dict layout)"},
-               "roofline": roof}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, pages_np[:2], cfg, csd if rec is not None else None,
-                                               gt_quads[:2] if rec is not None else None,
-                                               tsr=(lsd, psd, table_boxes, tables_per_page) if tsr is not None else None,
-                                               layout=ysd if layout is not None else None,
-                                               lines_per_page=lines_per_page if rec is not None else None)
+               "config": runner.config(counts, args.steps)}
+        if prof is not None:
+            c3 = prof["conv3x3"]
+            achieved = (c3["flop"] / (c3["ms"] * 1e-3)) / 1e12 if c3["ms"] > 0 else 0.0
+            traffic = None
+            try:   # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_summary.py)
+                with open(os.path.join(REPO, "profiles", "pmc_latest.json")) as f:
+                    pm = json.load(f)
+                tot = nl = 0.0
+                for kname, rec_ in pm.items():       # every 3x3 conv kernel variant, launch-weighted
+                    if ("conv_igemm_kernel<3," in kname or "conv3x3_dma" in kname) and "hbm_bytes_per_launch" in rec_:
+                        n_ = rec_["FETCH_SIZE"]["dispatches"]
+                        tot += rec_["hbm_bytes_per_launch"] * n_
+                        nl += n_
+                traffic = tot / nl if nl else None
+            except Exception:
+                traffic = None
+            roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<3,*> / conv3x3_dma16_kernel (3x3 implicit-GEMM convolutions of all stages)",
+                    "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
+                    "traffic": traffic, "traffic_note": "bytes/launch over the 3x3 conv kernels, PMC passes of profiles/pmc_latest.json "
+                                                        "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
+                    "launches": c3["launches"], "avg_launch_ms": c3["ms"] / max(1, c3["launches"]),
+                    "algorithmic_flop_per_launch": c3["flop"] / max(1, c3["launches"]),
+                    "flop_accounting": "2 x output pixels x REAL output channels x Cin x 9 per launch (padded GEMM columns are not "
+                                       "counted); row-limited sparse-head launches are credited the rows below the device limit "
+                                       "they read back, and 1/9 of those (a 3x3 patch yields one used pixel)",
+                    "events": "3x3 class only" if prof_mode == 2 else "every launch"}
+            if prof_mode == 1:       # PT_BENCH_PROF=1: events around every launch
+                roof["all_kernel_classes_ms"] = {k: v["ms"] for k, v in prof.items()}
+                roof["all_kernel_classes_flop"] = {k: v["flop"] for k, v in prof.items()}
+            out["roofline"] = roof
+    # extra legs: every rank runs them (they are outside the timed region; rank 0 reports its own)
+    if not stub and not args.no_extra_legs and world == 1:
+        if "det" in runner.stages and not runner.nas:
+            leg = runner.det_only_leg()
+            if rank == 0:
+                out["roofline"]["det_backbone"] = leg
+        if runner.x3_leg and not args.no_post:
+            leg = runner.x3_leg_run()
+            if rank == 0:
+                leg["bf16_pages_per_s"] = out["value"]
+                out["tolerance_mode"] = leg
+    if rank == 0:
+        if not stub and world == 1 and not args.no_cpu_baseline and "det" in runner.stages:
+            r = runner
+            gpu = r.parity_sample()
+            out["cpu_baseline"] = cpu_baseline(r.sd, r.pages_np[:2], r.cfg, r.csd if r.rec is not None else None,
+                                               tsr=(r.lsd, r.psd, r.table_boxes, r.tables_per_page) if r.tsr is not None else None,
+                                               layout=r.ysd if r.layout is not None else None, gpu=gpu)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
-
-
-def DB_GFLOP_960e9_per_page(total_pages, prof):
-    ms = sum(v["ms"] for k, v in prof.items() if k in ("conv3x3", "conv1x1", "stem"))
-    return (total_pages * DB_GFLOP_960 * 1e9 / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
 
 
 if __name__ == "__main__":

@@ -83,11 +83,34 @@ def crnn_features_fp32(sd, x):
     return f.squeeze(2).permute(2, 0, 1)
 
 
-def crnn_forward_fp32(sd, x):
+_NATIVE = {}
+
+
+def bilstm_native(sd, p, x):
+    """The same layer through torch's own LSTM operator -- what the reference runs (nn.LSTM inside BidirectionalLSTM,
+    crnn/modeling_crnn.py:16-33); used by the timed CPU-baseline leg so that the baseline is not slowed by a Python loop.
+    Equal to ``bilstm`` up to fp32 summation order (tests/test_oracle_db_net.py)."""
+    key = (id(sd), p)
+    m = _NATIVE.get(key)
+    if m is None:
+        w = sd[p + ".rnn.weight_hh_l0"]
+        m = torch.nn.LSTM(sd[p + ".rnn.weight_ih_l0"].shape[1], w.shape[1], bidirectional=True)
+        m.load_state_dict({k[len(p) + 5:]: v for k, v in sd.items() if k.startswith(p + ".rnn.")}, strict=True)
+        m.eval()
+        _NATIVE[key] = m
+    with torch.no_grad():
+        rec, _ = m(x)
+    T, B, Hh = rec.shape
+    out = rec.reshape(T * B, Hh) @ sd[p + ".embedding.weight"].t() + sd[p + ".embedding.bias"]
+    return out.view(T, B, -1)
+
+
+def crnn_forward_fp32(sd, x, native_lstm=False):
     """-> logits fp32 [B, W/4, 7644] (no softmax in the model)."""
     f = crnn_features_fp32(sd, x)
-    r = bilstm(sd, "rnn.0", f)
-    r = bilstm(sd, "rnn.1", r)
+    rnn = bilstm_native if native_lstm else bilstm
+    r = rnn(sd, "rnn.0", f)
+    r = rnn(sd, "rnn.1", r)
     out = r @ sd["cls.weight"].t()
     return out.permute(1, 0, 2)
 

@@ -88,6 +88,7 @@ void pt_engine_destroy(pt_engine* e) {
   if (e->det_in) (void)hipFree(e->det_in);
   if (e->lstm_scratch) (void)hipFree(e->lstm_scratch);
   if (e->lstm_err) (void)hipHostFree(e->lstm_err);
+  if (e->prof.h_lims) (void)hipHostFree(e->prof.h_lims);
   for (auto& p : e->prof.pending) {
     (void)hipEventDestroy(p.a);
     (void)hipEventDestroy(p.b);
@@ -711,6 +712,8 @@ int pt_op_db_head_final(pt_engine* e, const uint16_t* d_in, int B, int H, int W,
 int pt_profile_enable(pt_engine* e, int on) {
   PT_REQUIRE(e != nullptr, "pt_profile_enable: null engine");
   PT_REQUIRE(on >= 0 && on < 2 + PT_PROF_NCLASS, "pt_profile_enable: mode %d out of range", on);
+  if (on && !e->prof.h_lims)
+    PT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->prof.h_lims), PtProfile::MAX_LIMS * sizeof(int), hipHostMallocDefault));
   e->prof.on = on;
   return PT_OK;
 }
@@ -726,12 +729,18 @@ int pt_profile_read(pt_engine* e, double* ms_per_class, long long* launches_per_
       if (verbose) { auto& r = by_label[p.label]; r.first += ms; r.second += 1; }
       e->prof.ms[p.cls] += ms;
       e->prof.launches[p.cls] += 1;
-      e->prof.flop[p.cls] += p.flop;
+      double fl = p.flop;
+      if (p.lim_slot >= 0 && p.rows > 0) {      // row-limited launch: only the rows below the device limit were computed
+        const int lim = e->prof.h_lims[p.lim_slot];
+        fl *= (double)(lim < 0 ? 0 : (lim > p.rows ? p.rows : lim)) / p.rows;
+      }
+      e->prof.flop[p.cls] += fl;
     }
     (void)hipEventDestroy(p.a);
     (void)hipEventDestroy(p.b);
   }
   e->prof.pending.clear();
+  e->prof.n_lims = 0;
   if (verbose)
     for (auto& kv : by_label)
       fprintf(stderr, "[pt_prof] %-40s n=%5d total=%9.3f ms avg=%8.4f ms\n", kv.first.c_str(), kv.second.second, kv.second.first,

@@ -84,10 +84,15 @@ struct PtProfile {
   struct Pending {
     hipEvent_t a, b;
     int cls;
-    double flop;
+    double flop;          // algorithmic FLOP of the launch (for a row-limited launch: of its full extent)
+    int lim_slot = -1;    // >= 0: the launch was row-limited on the device (ConvDesc.ylimit); h_lims[lim_slot] receives the limit
+    int rows = 0;         // ... and this is the launch's full extent in output rows: credited flop * min(limit, rows) / rows
     char label[48];
   };
   std::vector<Pending> pending;
+  int* h_lims = nullptr;  // pinned: device row limits copied back behind their launches (only while profiling)
+  int n_lims = 0;
+  static constexpr int MAX_LIMS = 1 << 16;
 };
 
 struct pt_engine {
@@ -157,6 +162,10 @@ struct ConvDesc {
   int n_valid = 0;
   float* out_f32 = nullptr;
   const float* res_f32 = nullptr;   // fp32 residual laid out like out_f32 (may alias it)
+  // roofline accounting only (PtProfile): the layer's real output channels when N / n_valid are padded (0 = n_valid, else N),
+  // and the fraction of the launch's output pixels the algorithm needs (patch mosaics compute 9 pixels to use one)
+  int alg_n = 0;
+  double alg_scale = 1.0;
 };
 int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s);
 

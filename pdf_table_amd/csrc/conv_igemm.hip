@@ -1340,11 +1340,22 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   }
   char label[48];
   snprintf(label, sizeof(label), "conv%dx%d s%d %d->%d @%dx%d%s", KS, KS, STRIDE, k.Cin, k.N, k.Ho, k.Wo, k.head_w ? " +head" : (k.split ? " x3" : ""));
-  PtProfScope prof(e, s, KS == 3 ? PT_PROF_CONV3X3 : PT_PROF_CONV1X1, flop, label);
-  if (plain && use_reg_epilogue())
-    hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, GEOM, true>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
-  else
-    hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, GEOM, false>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
+  int lim_slot = -1;
+  {
+    PtProfScope prof(e, s, KS == 3 ? PT_PROF_CONV3X3 : PT_PROF_CONV1X1, flop, label);
+    if (plain && use_reg_epilogue())
+      hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, GEOM, true>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
+    else
+      hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, GEOM, false>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
+    if (k.ylimit && prof.idx >= 0 && e->prof.h_lims && e->prof.n_lims < PtProfile::MAX_LIMS) {
+      // the launch covers the worst case and stops at a device-side row limit: remember where the limit will land
+      auto& pd = e->prof.pending[prof.idx];
+      pd.lim_slot = lim_slot = e->prof.n_lims++;
+      pd.rows = k.Ho;
+    }
+  }
+  if (lim_slot >= 0)      // behind the launch (and outside its event pair): the limit the kernel saw, to pinned memory
+    (void)hipMemcpyAsync(e->prof.h_lims + lim_slot, k.ylimit, sizeof(int), hipMemcpyDeviceToHost, s);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
@@ -1512,7 +1523,11 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   k.argmax_part = d.argmax_part;
   if (d.head_w) PT_REQUIRE(d.shuffle_cout == 64 && d.head_b && (d.head_prob || d.head_logits), "conv: bad fused-head configuration");
   if (k.res_mode == 2) PT_REQUIRE(k.Ho % 2 == 0 && k.Wo % 2 == 0, "conv: half-res residual needs even output size");
-  const double flop = 2.0 * k.B * k.Ho * k.Wo * (double)k.N * d.Cin * d.ks * d.ks;  // algorithmic (not x3 in split mode)
+  // algorithmic FLOP (not x3 in split mode): the layer's real output channels, not the padded GEMM width; for a transposed
+  // conv run as a pixel-shuffle GEMM N = 4 * Cout IS the work.  Row-limited launches are credited at read-out with the rows
+  // the device limit let through (launch_cfg)
+  const int n_alg = d.alg_n ? d.alg_n : (d.n_valid ? d.n_valid : d.N);
+  const double flop = 2.0 * k.B * k.Ho * k.Wo * (double)n_alg * d.Cin * d.ks * d.ks * d.alg_scale;
   if (d.ks == 3 && d.stride == 1 && !d.head_w && !d.argmax_part && !d.n_valid && !d.out_f32 && !d.res_f32 && d.relu < 2 && !d.ylimit && !d.pool && use_dma_kernel()) {
     // steady-state A/B on MI355X (tools/ab3.sh, round 1): the 16-channel-slice DMA kernel (v3) wins on >= 120-row maps
     // with K >= 128 channels, the 32-channel-slice DMA kernel (v2) on 60..119-row maps, the register-staged kernel

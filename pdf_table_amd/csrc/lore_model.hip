@@ -44,6 +44,7 @@ struct Ctx {
   bf16_t* cols = nullptr;   // shared DCN column scratch (largest site)
   float* om = nullptr;      // shared offset/mask scratch, fp32 [pixel][32]
   const int* ylimit = nullptr;   // when set: convs skip output tiles at rows >= *ylimit (sparse-head mosaics)
+  double alg_scale = 1.0;        // roofline accounting: fraction of a launch's output pixels the algorithm needs
 
   T alloc(int H, int W, int C) {
     T t;
@@ -62,7 +63,7 @@ struct Ctx {
   }
   // conv with folded bias; q = weight name prefix; N = GEMM width (multiple of 64), nv = channels stored (0 = N)
   void conv(const T& in, const std::string& q, int N, int ks, int stride, const T& out, int relu, const T* res = nullptr,
-            int nv = 0, float* out_f32 = nullptr, int f32_cs = 0, int cin_override = 0) {
+            int nv = 0, float* out_f32 = nullptr, int f32_cs = 0, int cin_override = 0, int alg_n = 0) {
     const PtTensor* w = get(q + (x3 ? ".w3" : ".w"));
     const PtTensor* b = get(q + ".b");
     if (rc != PT_OK || dry || !ok) return;
@@ -70,6 +71,7 @@ struct Ctx {
     c.in = in.p; c.B = n; c.H = in.H; c.W = in.W; c.Cin = cin_override ? cin_override : in.C;
     c.w = reinterpret_cast<const bf16_t*>(w->d_ptr); c.bias = reinterpret_cast<const float*>(b->d_ptr);
     c.N = N; c.ks = ks; c.stride = stride; c.relu = relu; c.split = x3; c.n_valid = nv; c.ylimit = ylimit;
+    c.alg_n = alg_n; c.alg_scale = alg_scale;
     if (out_f32) {
       c.out_f32 = out_f32; c.out_cstride = f32_cs;
     } else {
@@ -121,7 +123,7 @@ struct Ctx {
   // DeformConv (lore_dla_34.py:65-83)
   T dcn(const std::string& q, const T& x, int cout) {
     T o = alloc(x.H, x.W, cout);
-    conv(x, q + ".om", 64, 3, 1, T(), 0, nullptr, 32, om, 32);
+    conv(x, q + ".om", 64, 3, 1, T(), 0, nullptr, 32, om, 32, 0, 27);     // 18 offsets + 9 masks are the layer's real outputs
     static const bool fused = !(getenv("PT_DCN_FUSED") && atoi(getenv("PT_DCN_FUSED")) == 0);
     if (fused) {
       const PtTensor* w = get(q + (x3 ? ".dcn.w3" : ".dcn.w"));
@@ -194,6 +196,7 @@ static int lore_dla_run(pt_engine* e, const bf16_t* x, int n, int H, int W, floa
   float* heads[6] = {hm, st, wh, ax, cr, reg};
   const char* hname[6] = {"hm", "st", "wh", "ax", "cr", "reg"};
   const int hcs[6] = {8, 8, 8, 256, 256, 8};
+  const int hreal[6] = {2, 8, 8, 256, 256, 2};     // the heads' real channel counts (roofline accounting)
 
   for (int pass = 0; pass < 2; ++pass) {
     c.dry = pass == 0;     // pass 0 only plans the arena (and grows it if needed), pass 1 launches
@@ -254,7 +257,7 @@ static int lore_dla_run(pt_engine* e, const bf16_t* x, int n, int H, int W, floa
     for (int h = 0; h < 6; ++h) {
       if (sp && h != 0) continue;
       c.conv(feat, std::string(hname[h]) + ".0", 256, 3, 1, hid, 1);
-      c.conv(hid, std::string(hname[h]) + ".2", hcs[h] < 64 ? 64 : hcs[h], 1, 1, T(), 0, nullptr, hcs[h], heads[h], hcs[h]);
+      c.conv(hid, std::string(hname[h]) + ".2", hcs[h] < 64 ? 64 : hcs[h], 1, 1, T(), 0, nullptr, hcs[h], heads[h], hcs[h], 0, hreal[h]);
     }
     if (sp) {
       int rows_ax = 0, rows_cr = 0, rows_cell = 0, rows_corner = 0;
@@ -278,14 +281,16 @@ static int lore_dla_run(pt_engine* e, const bf16_t* x, int n, int H, int W, floa
       if (c.rc == PT_OK && !c.dry && c.ok) {
         const int keep = c.n;
         // one head on one mosaic: 3x3 (64 -> 256) + ReLU, then 1x1 to nc channels, fp32 out; tiles below `lim` rows exit
-        auto head = [&](const T& mos, int rows, const char* name, int nc, float* outp, const int* lim) {
+        auto head = [&](const T& mos, int rows, const char* name, int nc, float* outp, const int* lim, int real_nc) {
           T hh = mhid;
           hh.H = rows;
           c.n = 1;
           c.ylimit = lim;
+          c.alg_scale = 1.0 / 9.0;     // a patch is 3x3 pixels of which the decode reads the centre: 1/9 of the mosaic is algorithmic
           c.conv(mos, std::string(name) + ".0", 256, 3, 1, hh, 1);
-          c.conv(hh, std::string(name) + ".2", nc < 64 ? 64 : nc, 1, 1, T(), 0, nullptr, nc, outp, nc);
+          c.conv(hh, std::string(name) + ".2", nc < 64 ? 64 : nc, 1, 1, T(), 0, nullptr, nc, outp, nc, 0, real_nc);
           c.ylimit = nullptr;
+          c.alg_scale = 1.0;
           c.n = keep;
         };
         const int *lim_cell = nullptr, *lim_corner = nullptr, *lim_ax = nullptr, *lim_cr = nullptr;
@@ -293,16 +298,16 @@ static int lore_dla_run(pt_engine* e, const bf16_t* x, int n, int H, int W, floa
                                      &lim_corner, s);
         if (r == PT_OK) r = pt_lore_peak_patches(e, feat.p, n, feat.H, feat.W, 64, c.x3, mcell.p, mcorner.p, s);
         if (r != PT_OK) return r;
-        head(mcell, rows_cell, "wh", 8, o_wh, lim_cell);
-        head(mcell, rows_cell, "reg", 8, o_regc, lim_cell);
-        head(mcorner, rows_corner, "st", 8, o_st, lim_corner);
-        head(mcorner, rows_corner, "reg", 8, o_regk, lim_corner);
+        head(mcell, rows_cell, "wh", 8, o_wh, lim_cell, 8);
+        head(mcell, rows_cell, "reg", 8, o_regc, lim_cell, 2);
+        head(mcorner, rows_corner, "st", 8, o_st, lim_corner, 8);
+        head(mcorner, rows_corner, "reg", 8, o_regk, lim_corner, 2);
         if (c.rc != PT_OK) return c.rc;
         r = pt_lore_decode_boxes(e, o_regc, o_wh, o_regk, o_st, n, feat.H, feat.W, &lim_ax, &lim_cr, s);
         if (r == PT_OK) r = pt_lore_patch_gather(e, feat.p, n, feat.H, feat.W, 64, c.x3, max_.p, mcr_.p, s);
         if (r != PT_OK) return r;
-        head(max_, rows_ax, "ax", 256, oax, lim_ax);
-        head(mcr_, rows_cr, "cr", 256, ocr, lim_cr);
+        head(max_, rows_ax, "ax", 256, oax, lim_ax, 256);
+        head(mcr_, rows_cr, "cr", 256, ocr, lim_cr, 256);
         if (c.rc != PT_OK) return c.rc;
         r = pt_lore_decode_sparse(e, oax, ocr, n, feat.H, feat.W, sp->vis_thresh, sp->d_counts, sp->d_dets, sp->d_logi, s);
         if (r != PT_OK) return r;
@@ -382,6 +387,7 @@ struct WCtx {
     c.in = in.p; c.B = n; c.H = in.H; c.W = in.W; c.Cin = in.C;
     c.w = reinterpret_cast<const bf16_t*>(w->d_ptr); c.bias = reinterpret_cast<const float*>(b->d_ptr);
     c.N = N; c.ks = ks; c.stride = stride; c.relu = relu; c.split = x3; c.n_valid = nv; c.shuffle_cout = shuffle;
+    if (shuffle && ks == 3) c.alg_scale = 16.0 / 36.0;   // ConvTranspose2d(k=4,s=2) has 16 taps per (input pixel, Cout); the 3x3 x 4-phase GEMM spends 36
     if (out_f32) {
       c.out_f32 = out_f32; c.out_cstride = f32_cs;
     } else {

@@ -76,7 +76,7 @@ class _Gen:
             self.put(f"{name}.bias_hh_l0{sfx}", self.rng.uniform(-k, k, (4 * nh,)))
 
 
-def db_resnet18_state_dict(seed: int = 0, with_thresh_branch: bool = True, head_bias: float = 6.0):
+def db_resnet18_state_dict(seed: int = 0, with_thresh_branch: bool = True, head_bias: float = 6.0, text_signal=False):
     """state_dict of ``DBModel`` (ResNet-18 backbone + ``SegDetector`` decoder, adaptive=True).
 
     Key order follows module registration order in dbnet.py:260-336 (backbone) and :488-586
@@ -119,7 +119,68 @@ def db_resnet18_state_dict(seed: int = 0, with_thresh_branch: bool = True, head_
         g.convT("decoder.thresh.3", 64, 64, 2, 2)
         g.bn("decoder.thresh.4", 64)
         g.convT("decoder.thresh.6", 64, 1, 2, 2)
+    if text_signal:
+        _db_text_signal(g.sd, *text_signal) if isinstance(text_signal, tuple) else _db_text_signal(g.sd)
     return g.sd
+
+
+def _db_text_signal(sd, gain: float = 24.0, level: float = 0.69, a1: float = 2.0, a2: float = 1.25):
+    """Turn channel 0 of a random-init DBModel checkpoint into a hand-built text-line detector for the synthetic pages
+    (dark glyph blobs on white), so that the detector's OWN boxes can feed the recogniser in bench.py and the box
+    post-process sees a realistic number of boxes per page (~75 on the synthetic pages, whose generator draws ~76 lines).
+    All other channels keep their random weights, so operand statistics, arithmetic and memory traffic of every layer are
+    what they were; only the rows that produce channel 0 (plus helper channel 1 between the two convs of layer1's
+    blocks), and the columns of the last layer, are set:
+
+      conv1 (7x7 s2) ch 0   x0 = 1 - mean gray / 255 over the window ("darkness"), BN as an affine identity; max-pool dilates
+      layer1.0              S1 = min(1, a1 * mean3x3(x0)): conv1 ch 0 -> u = relu(1 - a1 * mean3x3(x0)), ch 1 -> v = x0;
+                            conv2 ch 0 = 1 - u - v, and the block's residual adds x0 back.  Glyph holes and word gaps
+                            saturate to 1, 1-2 px table rules stay below 0.3
+      layer1.1              S2 = min(1, a2 * mean1x3(S1)) the same way: closes gaps of <= 2 cells (8 px) along a line
+      in2 -> out2 -> fuse[192] -> binarize   centre taps, BN identities, the two transposed convs replicate 2x2:
+                            logit = gain * (S2 - level) - logit(0.3), i.e. the DB bitmap threshold 0.3 cuts at S2 = level
+    """
+    import math as _m
+
+    def bn_identity(name, c, beta=0.0):
+        sd[name + ".weight"][c] = 1.0
+        sd[name + ".bias"][c] = beta
+        sd[name + ".running_mean"][c] = 0.0
+        sd[name + ".running_var"][c] = 1.0 - 1e-5      # sqrt(var + eps) == 1
+
+    mean = torch.tensor([0.485, 0.456, 0.406])
+    std = torch.tensor([0.229, 0.224, 0.225])
+    # sum over taps and channels of w * x with x = (pix/255 - mean_c) / std_c  ==  mean(mean_c) - gray/255
+    sd["backbone.conv1.weight"][0] = (-(std / 3.0 / 49.0)).view(3, 1, 1).expand(3, 7, 7)
+    bn_identity("backbone.bn1", 0, beta=1.0 - float(mean.mean()))
+    for bi, (a, taps) in enumerate(((a1, [(dy, dx) for dy in range(3) for dx in range(3)]), (a2, [(1, dx) for dx in range(3)]))):
+        p = f"backbone.layer1.{bi}"
+        w1, w2 = sd[p + ".conv1.weight"], sd[p + ".conv2.weight"]
+        w1[0] = 0.0
+        w1[1] = 0.0
+        for dy, dx in taps:
+            w1[0, 0, dy, dx] = -a / len(taps)
+        w1[1, 0, 1, 1] = 1.0
+        bn_identity(p + ".bn1", 0, beta=1.0)
+        bn_identity(p + ".bn1", 1)
+        w2[0] = 0.0
+        w2[0, 0, 1, 1] = -1.0
+        w2[0, 1, 1, 1] = -1.0
+        bn_identity(p + ".bn2", 0, beta=1.0)
+    for n in ("in5", "in4", "in3", "in2"):
+        sd[f"decoder.{n}.weight"][0] = 0.0
+    sd["decoder.in2.weight"][0, 0, 0, 0] = 1.0
+    for name, cin in (("decoder.out2.weight", 0), ("decoder.binarize.0.weight", 192)):
+        sd[name][0] = 0.0
+        sd[name][0, cin, 1, 1] = 1.0
+    bn_identity("decoder.binarize.1", 0)
+    sd["decoder.binarize.3.weight"][:, 0] = 0.0
+    sd["decoder.binarize.3.weight"][0, 0] = 1.0
+    sd["decoder.binarize.3.bias"][0] = 0.0
+    bn_identity("decoder.binarize.4", 0)
+    sd["decoder.binarize.6.weight"][:] = 0.0
+    sd["decoder.binarize.6.weight"][0, 0] = gain
+    sd["decoder.binarize.6.bias"][:] = -gain * level + _m.log(0.3 / 0.7)
 
 
 def crnn_state_dict(seed: int = 0, num_classes: int = CRNN_NUM_CLASSES):

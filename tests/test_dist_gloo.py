@@ -69,3 +69,35 @@ def test_broadcast_and_gather_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0][1] == res[1][1] and res[0][2] == res[1][2] > 1_000_000
+
+
+def _bench(argv, env_extra, timeout=300):
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PT_BENCH_STUB="1", MASTER_PORT=str(_free_port()), **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        if k not in env_extra:
+            env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + argv, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_gpus2_launches_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher re-executes under torch.distributed.run: two ranks rendezvous (gloo, stub
+    engine: a step is a sleep of 10 ms x (1 + rank)), the reported time is the SLOWEST rank's and n_gpus is 2"""
+    import json
+    r = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1"], {})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout          # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["ms_per_step"] >= 19.0         # rank 1 sleeps 20 ms per step: max over ranks, not rank 0's 10 ms
+    assert abs(out["value"] - 2 * out["config"]["pages_per_step_per_gpu"] * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    """a driver that exports WORLD_SIZE=1 and asks for --gpus 2 must not get a 1-GPU number labelled as 2"""
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
