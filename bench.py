@@ -190,7 +190,10 @@ def cpu_baseline(sd, pages_np, cfg, csd=None, tsr=None, layout=None, gpu=None):
         ids_o = []
         with torch.no_grad():
             ocrnn.crnn_forward_fp32(csd, torch.zeros(1, 3, 32, 640), native_lstm=True)      # warm-up
-        for q in boxes_all[0]:
+        # the lines: the GPU's own boxes of page 0 when given (both sides then read identical quads and the token ids can be
+        # compared line by line), else the oracle's
+        rec_quads = gpu["rec_quads"] if gpu is not None and gpu.get("rec_quads") is not None else boxes_all[0]
+        for q in rec_quads:
             if nl >= 2 and time.time() - rec_t0 > 8.0:     # bounded sample
                 break
             t0 = time.time()
@@ -574,9 +577,9 @@ class HipRunner:
                 if mode == "bf16":
                     out["det_nboxes"] = len(boxes[0])
                     self._boxes0 = boxes
+                    out["rec_quads"] = boxes[0]
                 if self.rec is not None:
-                    # the ORACLE's boxes are not known here; the leg compares line by line, so both sides must read the
-                    # same quads: the bf16 boxes of page 0 (the oracle's boxes equal them unless a pixel sits on the threshold)
+                    # both precisions (and the oracle, in the CPU leg) read the SAME quads: the bf16 boxes of page 0
                     ids, _ = self.rec.ids(page0, self._boxes0)
                     out["rec_ids_" + mode] = ids.cpu().numpy()
             finally:

@@ -230,6 +230,30 @@ int pt_rec_forward_net(pt_engine* e, const uint16_t* d_gray, int n, int32_t* d_i
 int pt_rec_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int h, int w, const pt_rec_line* d_lines,
                       const int64_t* h_crop_px, int n_lines, uint16_t* d_gray, pt_stream stream);
 
+/* PP-OCR recognition pre-processor -- PPOcrRecPreProcessor (model/ocr_rec_pp/processor_ocr_rec_pp.py:69-135,
+ * resize_norm_img :43-67), the pre-processing of the recogniser the reference's system path selects
+ * (fix_model_names, model/ocr_pdf/configuration_ocr_document.py:138-141).  The HOST orders the lines by aspect ratio and
+ * groups them into mini-batches of rec_batch_num (np.argsort, as the reference; pdf_table_amd/rec_pp_stage.py); one item =
+ * one line of that plan: which crop, the width it is resized to (height img_h = 48), the padded width img_w of its
+ * mini-batch and where its [3, img_h, img_w] fp32 block starts in d_out (float offset; a mini-batch's items are
+ * consecutive, which makes d_out the concatenation of the reference's [b, 3, 48, img_w] NCHW arrays).
+ * Pixels: cv2.resize 8-bit INTER_LINEAR semantics, then (x / 255 - 0.5) / 0.5 in fp32, zeros right of resized_w. */
+typedef struct pt_rec_pp_item {
+  int32_t line;
+  int32_t resized_w;
+  int32_t img_w;
+  int32_t reserved;
+  int64_t out_off;
+} pt_rec_pp_item;
+/* lines cut from resident pages (crop_image on the device, as pt_rec_forward) */
+int pt_rec_pp_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int h, int w, const pt_rec_line* d_lines,
+                         const int64_t* h_crop_px, int n_lines, const pt_rec_pp_item* d_items, int n_items, int img_h,
+                         int max_img_w, float* d_out, pt_stream stream);
+/* lines that are already cropped (what OcrRecognitionTask.__call__ receives); d_crops_rgb / d_lines as pt_rec_forward_crops */
+int pt_rec_pp_preprocess_crops(pt_engine* e, const uint8_t* d_crops_rgb, const pt_rec_line* d_lines, const int64_t* h_crop_px,
+                               int n_lines, const pt_rec_pp_item* d_items, int n_items, int img_h, int max_img_w, float* d_out,
+                               pt_stream stream);
+
 /* ---- stage 4: table structure recognition (Lore) ------------------------------------------------- */
 /* One table crop of a resident page and the INVERSE (destination -> crop) affine map of
  * TableLorePreProcessor.process (lore/processer_lore.py:66-90), i.e. cv::invertAffineTransform of

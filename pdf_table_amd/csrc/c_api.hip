@@ -20,7 +20,7 @@ void pt_set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* pt_last_error(void) { return g_err; }
-int pt_abi_version(void) { return 6; }   // 6: pt_engine_set_lstm_cluster, pt_engine_check clears what it reports
+int pt_abi_version(void) { return 7; }   // 7: pt_rec_pp_preprocess*; 6: pt_engine_set_lstm_cluster, pt_engine_check clears what it reports
 
 int pt_engine_check(pt_engine* e) {
   PT_REQUIRE(e, "pt_engine_check: null engine");
@@ -83,6 +83,7 @@ void pt_engine_destroy(pt_engine* e) {
   if (e->tsr_scratch) (void)hipFree(e->tsr_scratch);
   if (e->tsr_lut) (void)hipFree(e->tsr_lut);
   if (e->cls_lut) (void)hipFree(e->cls_lut);
+  if (e->rec_pp_lut) (void)hipFree(e->rec_pp_lut);
   if (e->cls_scratch) (void)hipFree(e->cls_scratch);
   if (e->layout_scratch) (void)hipFree(e->layout_scratch);
   if (e->det_in) (void)hipFree(e->det_in);
@@ -556,6 +557,62 @@ int pt_rec_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int h,
     if (rc != PT_OK) return rc;
   }
   return PT_OK;
+}
+
+// ---- PP-OCR recognition pre-processor --------------------------------------------------------------------------
+static int rec_pp_lut(pt_engine* e) {
+  if (e->rec_pp_lut) return PT_OK;
+  float lut[256];
+  for (int v = 0; v < 256; ++v) {      // resized.astype('float32') / 255; -= 0.5; /= 0.5  (fp32 at every step)
+    float x = (float)v / 255.0f;
+    x -= 0.5f;
+    x /= 0.5f;
+    lut[v] = x;
+  }
+  PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->rec_pp_lut), sizeof(lut)));
+  PT_HIP_CHECK(hipMemcpy(e->rec_pp_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
+  return PT_OK;
+}
+
+int pt_rec_pp_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int h, int w, const pt_rec_line* d_lines,
+                         const int64_t* h_crop_px, int n_lines, const pt_rec_pp_item* d_items, int n_items, int img_h,
+                         int max_img_w, float* d_out, pt_stream stream) {
+  PT_REQUIRE(e && d_pages_rgb && d_lines && h_crop_px && d_items && d_out && n_lines > 0 && n_items > 0 && img_h > 0 && max_img_w > 0,
+             "pt_rec_pp_preprocess: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  (void)n_pages;
+  long long maxpx = 0, total = 0;
+  for (int i = 0; i < n_lines; ++i) {
+    const long long px = h_crop_px[i] > 0 ? h_crop_px[i] : 0;
+    total += px;
+    if (px > maxpx) maxpx = px;
+  }
+  int rc;
+  if ((rc = rec_pp_lut(e)) != PT_OK) return rc;
+  if ((rc = ensure(&e->rec_off, &e->rec_off_cap, (size_t)(n_lines + 1) * sizeof(long long))) != PT_OK) return rc;
+  if ((rc = ensure(&e->rec_crops, &e->rec_crops_cap, (size_t)total * 3 + 16)) != PT_OK) return rc;
+  if ((rc = pt_launch_rec_offsets(d_lines, n_lines, reinterpret_cast<long long*>(e->rec_off), s)) != PT_OK) return rc;
+  const long long* d_off = reinterpret_cast<const long long*>(e->rec_off);
+  if ((rc = pt_launch_rec_warp(d_pages_rgb, h, w, d_lines, n_lines, d_off, reinterpret_cast<uint8_t*>(e->rec_crops), (int)maxpx, s)) != PT_OK)
+    return rc;
+  return pt_launch_rec_pp_resize_norm(reinterpret_cast<const uint8_t*>(e->rec_crops), d_lines, d_off, d_items, n_items, img_h, max_img_w,
+                                      e->rec_pp_lut, d_out, s);
+}
+
+int pt_rec_pp_preprocess_crops(pt_engine* e, const uint8_t* d_crops_rgb, const pt_rec_line* d_lines, const int64_t* h_crop_px,
+                               int n_lines, const pt_rec_pp_item* d_items, int n_items, int img_h, int max_img_w, float* d_out,
+                               pt_stream stream) {
+  PT_REQUIRE(e && d_crops_rgb && d_lines && h_crop_px && d_items && d_out && n_lines > 0 && n_items > 0 && img_h > 0 && max_img_w > 0,
+             "pt_rec_pp_preprocess_crops: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int rc;
+  if ((rc = rec_pp_lut(e)) != PT_OK) return rc;
+  if ((rc = ensure(&e->rec_off, &e->rec_off_cap, (size_t)(n_lines + 1) * sizeof(long long))) != PT_OK) return rc;
+  if ((rc = pt_launch_rec_offsets(d_lines, n_lines, reinterpret_cast<long long*>(e->rec_off), s)) != PT_OK) return rc;
+  return pt_launch_rec_pp_resize_norm(d_crops_rgb, d_lines, reinterpret_cast<const long long*>(e->rec_off), d_items, n_items, img_h,
+                                      max_img_w, e->rec_pp_lut, d_out, s);
 }
 
 // ---- image classification (PP-LCNet) -----------------------------------------------------------------------------

@@ -116,6 +116,7 @@ struct pt_engine {
   void* layout_scratch = nullptr; size_t layout_scratch_cap = 0;   // layout input + head maps (pt_layout_forward)
   float* tsr_lut = nullptr;                                  // [3][256] normalisation table of the Lore pre-process
   float* cls_lut = nullptr;                                  // [3][256] ... of the PP-LCNet pre-process
+  float* rec_pp_lut = nullptr;                               // [256] (v / 255 - 0.5) / 0.5 of the PP-OCR recognition pre-process
   void* cls_scratch = nullptr; size_t cls_scratch_cap = 0;   // network input + image descriptors of pt_cls_forward*
   alignas(8) unsigned char tsr_decode_state[128] = {};       // lore_decode.hip: DecodeState of the sparse-head decode in flight
   void* lstm_scratch = nullptr;                              // rec_kernels.hip: h exchange buffers + step counters of the cluster LSTM
@@ -210,6 +211,9 @@ int pt_launch_rec_warp(const uint8_t* pages, int ph, int pw, const pt_rec_line* 
                        const long long* pix_off, uint8_t* crops, int max_crop_px, hipStream_t s);
 int pt_launch_rec_resize_gray(const uint8_t* crops, const pt_rec_line* lines, const long long* pix_off, int n_lines,
                               int split, bf16_t* out, hipStream_t s);
+int pt_launch_rec_pp_resize_norm(const uint8_t* crops, const pt_rec_line* lines, const long long* pix_off,
+                                 const pt_rec_pp_item* items, int n_items, int img_h, int max_img_w, const float* lut, float* out,
+                                 hipStream_t s);
 int pt_launch_crnn_conv0_pool(const bf16_t* in, int n, int H, int W, const float* w64x9, const float* bias, int split,
                               bf16_t* out, hipStream_t s);
 int pt_launch_maxpool_kxk(const bf16_t* in, int n, int H, int W, int C, int kh, int kw, int h2c, int split, bf16_t* out,

@@ -205,6 +205,72 @@ int pt_launch_rec_resize_gray(const uint8_t* crops, const pt_rec_line* lines, co
 }
 
 // ---------------------------------------------------------------------------------------------------
+// PPOcrRecPreProcessor.resize_norm_img (ocr_rec_pp/processor_ocr_rec_pp.py:43-67) for every line of a width-sorted plan:
+// cv2.resize (8-bit bilinear, as above) of the crop to img_h x resized_w, (x / 255 - 0.5) / 0.5 through a 256-entry fp32
+// table built on the host with the reference's operation order, zeros right of resized_w up to the mini-batch width.
+// out: fp32, one [3, img_h, img_w] block per item at item.out_off (the reference's NCHW mini-batch layout).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rec_pp_resize_norm_kernel(const uint8_t* __restrict__ crops,
+                                                                  const pt_rec_line* __restrict__ lines,
+                                                                  const long long* __restrict__ pix_off,
+                                                                  const pt_rec_pp_item* __restrict__ items, int img_h,
+                                                                  const float* __restrict__ lut, float* __restrict__ out) {
+  __shared__ float slut[256];
+  slut[threadIdx.x] = lut[threadIdx.x];
+  __syncthreads();
+  const pt_rec_pp_item it = items[blockIdx.y];
+  const int li = it.line, nw = it.resized_w, iw = it.img_w;
+  const int cw = lines[li].crop_w, chh = lines[li].crop_h;
+  const uint8_t* src = crops + pix_off[li] * 3;
+  float* o = out + it.out_off;
+  const long long plane = (long long)img_h * iw;
+  const bool same = cw == nw && chh == img_h, half = cw == 2 * nw && chh == 2 * img_h;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % iw), y = (int)(i / iw);
+    float r[3] = {0.f, 0.f, 0.f};
+    if (x < nw && cw > 0 && chh > 0) {
+      int v[3];
+      if (same) {
+        const uint8_t* p = src + ((size_t)y * cw + x) * 3;
+        v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+      } else if (half) {
+        const uint8_t* p0 = src + ((size_t)(2 * y) * cw + 2 * x) * 3;
+        const uint8_t* p1 = p0 + (size_t)cw * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = (p0[c] + p0[3 + c] + p1[c] + p1[3 + c] + 2) >> 2;
+      } else {
+        const RCoef cx = rcoef(x, (double)cw / nw, cw, true);
+        const RCoef cy = rcoef(y, (double)chh / img_h, chh, false);
+        const uint8_t* r0 = src + (size_t)cy.s0 * cw * 3;
+        const uint8_t* r1 = src + (size_t)cy.s1 * cw * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int S0 = r0[cx.s0 * 3 + c] * cx.a0 + r0[cx.s1 * 3 + c] * cx.a1;
+          const int S1 = r1[cx.s0 * 3 + c] * cx.a0 + r1[cx.s1 * 3 + c] * cx.a1;
+          const int q = (((cy.a0 * (S0 >> 4)) >> 16) + ((cy.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
+          v[c] = q < 0 ? 0 : (q > 255 ? 255 : q);
+        }
+      }
+      r[0] = slut[v[0]]; r[1] = slut[v[1]]; r[2] = slut[v[2]];
+    }
+    o[i] = r[0];
+    o[plane + i] = r[1];
+    o[2 * plane + i] = r[2];
+  }
+}
+
+int pt_launch_rec_pp_resize_norm(const uint8_t* crops, const pt_rec_line* lines, const long long* pix_off,
+                                 const pt_rec_pp_item* items, int n_items, int img_h, int max_img_w, const float* lut, float* out,
+                                 hipStream_t s) {
+  if (n_items <= 0) return PT_OK;
+  int bx = (int)(((long long)img_h * max_img_w + 255) / 256);
+  bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
+  hipLaunchKernelGGL(rec_pp_resize_norm_kernel, dim3(bx, n_items), dim3(256), 0, s, crops, lines, pix_off, items, img_h, lut, out);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // CRNN conv0: Conv2d(1, 64, 3, pad 1) + BN + ReLU, then MaxPool2d(2, 2).  Direct fp32 convolution on the VALU
 // (K = 9 is far too thin for MFMA).  in: gray bf16 [n, H, W] (split: hi/lo pairs); w fp32 [64][9] (BN folded, rounded
 // to bf16 by the packer in bf16 mode), bias fp32 [64]; out bf16 [n, H/2, W/2, 64] (split: [hi(64) | lo(64)]).

@@ -13,7 +13,7 @@ import torch
 
 from . import lib as L
 
-__all__ = ["HipEngine", "REC_LINE_DTYPE", "CLS_IMAGE_DTYPE"]
+__all__ = ["HipEngine", "REC_LINE_DTYPE", "CLS_IMAGE_DTYPE", "REC_PP_ITEM_DTYPE"]
 
 # mirrors struct pt_rec_line in include/pdftable_hip.h (88 bytes)
 TSR_TABLE_DTYPE = np.dtype([("minv", "<f8", (6,)), ("page", "<i4"), ("x0", "<i4"), ("y0", "<i4"),
@@ -21,6 +21,10 @@ TSR_TABLE_DTYPE = np.dtype([("minv", "<f8", (6,)), ("page", "<i4"), ("x0", "<i4"
 CLS_IMAGE_DTYPE = np.dtype([("offset", "<i8"), ("h", "<i4"), ("w", "<i4")])      # pt_cls_image
 REC_LINE_DTYPE = np.dtype([("minv", np.float64, (9,)), ("page", np.int32), ("crop_w", np.int32), ("crop_h", np.int32),
                            ("reserved", np.int32)])
+
+
+REC_PP_ITEM_DTYPE = np.dtype([("line", "<i4"), ("resized_w", "<i4"), ("img_w", "<i4"), ("reserved", "<i4"),
+                              ("out_off", "<i8")])                               # struct pt_rec_pp_item (24 bytes)
 
 
 def _upload(arr: np.ndarray, device) -> torch.Tensor:
@@ -376,6 +380,29 @@ class HipEngine:
             L.check(self.lib.pt_rec_forward_crops(self._h, _ptr(dc), _ptr(d), px.ctypes.data_as(C.c_void_p), nl, _ptr(ids),
                                                   _ptr(mx), self._stream()), "pt_rec_forward_crops")
         return ids, mx
+
+    def rec_pp_preprocess(self, pages: Optional[torch.Tensor], lines: np.ndarray, items: np.ndarray, total_floats: int,
+                          img_h: int = 48, crops_flat: Optional[np.ndarray] = None) -> torch.Tensor:
+        """PPOcrRecPreProcessor on the device: ``items`` (REC_PP_ITEM_DTYPE, the host's width-sorted plan) -> one flat fp32
+        buffer holding every mini-batch's [b, 3, img_h, img_w] array.  Lines are cut from resident ``pages`` or, with
+        ``crops_flat`` (concatenated uint8 crops), are already cropped."""
+        assert items.dtype == REC_PP_ITEM_DTYPE and len(items) and len(lines)
+        out = torch.empty((int(total_floats),), dtype=torch.float32, device=self._tdev)
+        d, px = self._lines_to_device(lines)
+        di = _upload(np.ascontiguousarray(items).view(np.uint8).reshape(-1), self._tdev)
+        max_w = int(items["img_w"].max())
+        if crops_flat is None:
+            self._chk(pages, torch.uint8, "pages")
+            n, h, w, _ = pages.shape
+            L.check(self.lib.pt_rec_pp_preprocess(self._h, _ptr(pages), n, h, w, _ptr(d), px.ctypes.data_as(C.c_void_p), len(lines),
+                                                  _ptr(di), len(items), img_h, max_w, _ptr(out), self._stream()),
+                    "pt_rec_pp_preprocess")
+        else:
+            dc = torch.from_numpy(np.ascontiguousarray(crops_flat)).to(self._tdev)
+            L.check(self.lib.pt_rec_pp_preprocess_crops(self._h, _ptr(dc), _ptr(d), px.ctypes.data_as(C.c_void_p), len(lines),
+                                                        _ptr(di), len(items), img_h, max_w, _ptr(out), self._stream()),
+                    "pt_rec_pp_preprocess_crops")
+        return out
 
     def rec_preprocess(self, pages: torch.Tensor, lines: np.ndarray) -> torch.Tensor:
         self._chk(pages, torch.uint8, "pages")

@@ -218,7 +218,7 @@ DLA34_LEVELS = [1, 1, 1, 2, 2, 1]                                            # c
 DLA34_CHANNELS = [16, 32, 64, 128, 256, 512]
 
 
-def lore_dla34_state_dict(seed: int = 0, hm_bias=(-6.0, -5.0), hm_gain: float = 0.5, cell_half=(10.0, 6.0)):
+def lore_dla34_state_dict(seed: int = 0, hm_bias=(-6.0, -5.0), hm_gain: float = 0.5, cell_half=(10.0, 6.0), dcn_gain: float = 0.1):
     """state_dict of ``get_dla_dcn(34, heads)`` = ``DLASeg`` (lore/lore_dla_34.py:137-206) on ``dla34``
     (center_net/modeling_centernet.py:274-409, incl. the unused 1000-way ``fc``).
 
@@ -268,7 +268,7 @@ def lore_dla34_state_dict(seed: int = 0, hm_bias=(-6.0, -5.0), hm_gain: float = 
         # 27 = 18 offsets + 9 mask logits, ~N(0, 0.3): sub-pixel offsets, so the bilinear path is exercised.  Larger
         # offsets make a RANDOM net ill-conditioned (its features are uncorrelated from pixel to pixel, so a 1e-5 px
         # offset change moves the output by 1e-3 -- measured; trained features are smooth)
-        g.conv(p + ".conv.conv_offset_mask", 27, cin, 3, 3, bias=True, gain=0.1)
+        g.conv(p + ".conv.conv_offset_mask", 27, cin, 3, 3, bias=True, gain=dcn_gain)
 
     def up(p, c, f):
         # fill_up_weights (lore_dla_34.py:53-62): bilinear kernel, same for every channel; perturbed per channel

@@ -187,8 +187,11 @@ class TsrStage:
         cfg = self.config
         inp_h, inp_w = cfg.resolution
         pending = []
-        for i in range(0, len(tables), self.micro_batch):
-            tb = tables[i:i + self.micro_batch]
+        # balanced micro-batches (87 tables at micro_batch 80 -> 44 + 43, not 80 + 7: a 7-table launch leaves most CUs idle)
+        nmb = max(1, -(-len(tables) // self.micro_batch))
+        size = -(-len(tables) // nmb) if len(tables) else 1
+        for i in range(0, len(tables), size):
+            tb = tables[i:i + size]
             x = self.eng.tsr_preprocess(pages, tb, inp_h, inp_w, bgr=self.bgr)
             if cfg.backbone != "ResNet-18" and self.fused_decode:      # one call, ax / cr heads only where the decode reads them
                 counts, dets, logi = self.eng.tsr_forward_decode(x, wiz_rev=cfg.wiz_rev, vis_thresh=cfg.vis_thresh, sync=False)

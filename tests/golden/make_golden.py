@@ -284,6 +284,45 @@ def gen_ctc():
     print("ctc", [r[0] for r in res])
 
 
+def gen_rec_pp():
+    """The reference's PPOcrRecPreProcessor (model/ocr_rec_pp/processor_ocr_rec_pp.py) on seeded crops, one call with all
+    crops (mini-batches of 6, width-sorted) and one call per crop (how the system loop uses it).  cv2 is not installed: the
+    module's ``cv2.resize`` is this repository's restatement of OpenCV's 8-bit bilinear resize (oracle/db_pre.py) -- every
+    other line that runs is the reference's."""
+    from oracle.db_pre import cv2_resize_linear_u8
+    sys.path.insert(0, os.path.dirname(HERE))
+    from rec_synth import rec_pp_crops
+    stub_env()
+    cv2 = types.ModuleType("cv2")
+    cv2.resize = lambda img, size: cv2_resize_linear_u8(np.ascontiguousarray(img), int(size[0]), int(size[1]))
+    cv2.COLOR_GRAY2RGB = 8
+    sys.modules["cv2"] = cv2
+    # the module's config class cannot be defined under this image's transformers (PretrainedConfig is a dataclass there,
+    # and `attribute_map: Dict = {...}` is a mutable default): the pre-processor only reads four attributes of its config
+    cm = types.ModuleType("pdftable.model.ocr_rec_pp.configuration_ocr_recognition_pp")
+    cm.PPOcrRecognitionConfig = type("PPOcrRecognitionConfig", (), {})
+    for pk in ("pdftable", "pdftable.model", "pdftable.model.ocr_rec_pp"):
+        if pk not in sys.modules:
+            _pkg(pk, os.path.join(REF_SRC, *pk.split(".")))
+    sys.modules[cm.__name__] = cm
+    mod = ref_import("pdftable.model.ocr_rec_pp.processor_ocr_rec_pp")
+    mod.cv2 = cv2
+    cfg = types.SimpleNamespace(rec_image_shape=[3, 48, 320], rec_batch_num=6, limited_max_width=1280, limited_min_width=16)
+    pre = mod.PPOcrRecPreProcessor(cfg)
+    crops = rec_pp_crops()
+    out = {"seed": np.array(107)}
+    batches = pre(list(crops))
+    out["indices"] = np.asarray(batches[0]["indices"])
+    for b, d in enumerate(batches):
+        out[f"batch{b}"] = d["image"]
+        out[f"beg{b}"] = np.array(d["batch_beg_img_no"])
+    out["n_batches"] = np.array(len(batches))
+    for i in (0, 4, 5, 6):          # one crop per call: its own width, never padded beyond it
+        out[f"single{i}"] = pre(crops[i])[0]["image"]
+    np.savez_compressed(os.path.join(HERE, "rec_pp.npz"), **out)
+    print("rec_pp.npz", {k: v.shape for k, v in out.items()})
+
+
 class _Stub(types.ModuleType):
     """Stand-in for third-party modules that are not installed (cv2, pyclipper, shapely ...).  Only used
     so that reference files IMPORT; any golden value below comes from reference code paths that do not
@@ -652,6 +691,8 @@ def gen_table_html():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["db", "crnn", "registry", "ctc", "host", "lore_dla", "lore_decode", "lore_processor", "picodet",
                              "table_html"]
+    if "rec_pp" in which or not sys.argv[1:]:
+        gen_rec_pp()
     if "table_html" in which:
         gen_table_html()
     if "picodet" in which:

@@ -213,8 +213,13 @@ def eng_par():
     from pdf_table_amd.synth_weights import lore_dla34_state_dict, picodet_state_dict
     from pdf_table_amd.weights import pack_lore_dla34, pack_picodet
     e = HipEngine(0)
+    # Lore: dcn_gain=0.02 (DCN offsets of ~0.07 px instead of ~0.3 px).  A RANDOM DLA-34 + 16 stacked DCNs is chaotic in its
+    # offsets: with the default gain the fp32 oracle ITSELF moves by 1e-4 of the head scale when its input is perturbed by
+    # 1e-7 relative (one fp32 ulp) and by 1.2e-3 for 1e-5 (tools/lore_conditioning.py, 512x512) -- no arithmetic can then
+    # agree with it to 1e-3 at full size (measured: bf16x3 2e-3 .. 6e-3, bf16 0.4, growing with the map size).  With 0.02 the
+    # same perturbations move the oracle by 1e-5 / 6e-5, the conditioning of a trained net, and the comparison is meaningful.
     sds = {"db": db_resnet18_state_dict(seed=0), "crnn": crnn_state_dict(seed=1),
-           "lore": lore_dla34_state_dict(seed=2), "pico": picodet_state_dict(seed=4, num_classes=5)}
+           "lore": lore_dla34_state_dict(seed=2, dcn_gain=0.02), "pico": picodet_state_dict(seed=4, num_classes=5)}
     e.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(sds["db"]))
     e.load_weights(L.PT_MODEL_CRNN, pack_crnn(sds["crnn"]))
     e.load_weights(L.PT_MODEL_LORE_DLA34, pack_lore_dla34(sds["lore"]))

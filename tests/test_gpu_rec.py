@@ -205,3 +205,52 @@ def test_set_lstm_cluster_switches_kernels_in_process(eng, sd):
         eng.set_lstm_cluster(True)
     for ids, mx in outs[1:]:
         assert np.array_equal(ids, outs[0][0]) and np.array_equal(mx, outs[0][1])
+
+
+# ---- PP-OCR recognition pre-processor (PPOcrRecPreProcessor, ocr_rec_pp/processor_ocr_rec_pp.py:24-135) ---------------
+def test_rec_pp_preprocessor_crops_bit_exact(eng, golden_dir):
+    """already-cropped inputs (the reference call shape), all crops in one call and one crop per call: every mini-batch
+    array equals the oracle's AND the reference's own output (tests/golden/rec_pp.npz) bit for bit"""
+    import os
+    from oracle import rec_pp
+    from pdf_table_amd.rec_pp_stage import PPOcrRecPreProcessor
+    from rec_synth import rec_pp_crops
+    gold = np.load(os.path.join(golden_dir, "rec_pp.npz"))
+    crops = rec_pp_crops(int(gold["seed"]))
+    pre = PPOcrRecPreProcessor(engine=eng)
+    got = pre(list(crops))
+    ref = rec_pp.rec_pp_preprocess(crops)
+    assert len(got) == len(ref) == int(gold["n_batches"])
+    for b, (g, r) in enumerate(zip(got, ref)):
+        assert g["batch_beg_img_no"] == r["batch_beg_img_no"] and np.array_equal(g["indices"], r["indices"])
+        a = g["image"].cpu().numpy()
+        assert a.dtype == np.float32 and a.shape == r["image"].shape
+        assert np.array_equal(a, r["image"]) and np.array_equal(a, gold[f"batch{b}"])
+    for i in (0, 4, 5, 6):
+        one = pre(crops[i])
+        assert len(one) == 1 and np.array_equal(one[0]["image"].cpu().numpy(), gold[f"single{i}"])
+    gray = pre(crops[0][:, :, 0])                                  # a 2-D input is replicated to three channels (cv2.COLOR_GRAY2RGB)
+    want = rec_pp.rec_pp_preprocess([np.repeat(crops[0][:, :, :1], 3, 2)])
+    assert np.array_equal(gray[0]["image"].cpu().numpy(), want[0]["image"])
+    assert pre([]) == []
+    with pytest.raises(TypeError):
+        pre(3.14)
+
+
+def test_rec_pp_preprocessor_page_lines_bit_exact(eng):
+    """lines cut from a resident page on the device (order_point + crop_image, then the PP pre-processor) equal the oracle
+    run crop by crop: ~60 lines -> 10 width-sorted mini-batches"""
+    from oracle import rec_pp
+    from pdf_table_amd.rec_pp_stage import PPOcrRecPreProcessor
+    img, boxes = _page_and_boxes(idx=6, k=61)
+    pre = PPOcrRecPreProcessor(engine=eng)
+    got = pre.lines(torch.from_numpy(img[None]).cuda(), [boxes])
+    crops = [ocrnn.crop_image(img, ocrnn.order_point(b)) for b in boxes]
+    ref = rec_pp.rec_pp_preprocess(crops)
+    assert len(got) == len(ref) and len(ref) >= 3
+    widths = set()
+    for g, r in zip(got, ref):
+        assert np.array_equal(g["indices"], r["indices"]) and g["batch_beg_img_no"] == r["batch_beg_img_no"]
+        assert np.array_equal(g["image"].cpu().numpy(), r["image"])
+        widths.add(r["image"].shape[3])
+    assert len(widths) >= 2                                       # mini-batches of different padded widths
