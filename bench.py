@@ -421,8 +421,9 @@ class HipRunner:
             self.rec_boxes = self.stage.boxes(cur[0], cur[1], (PAGE, PAGE), cur[2])
 
     def run(self, steps, count=False, stages=None):
-        """software pipeline: all device work of step k is enqueued before the host halves run (the detection
-        post-process of step k-1 first), so the GPU queue never drains while the host works"""
+        """software pipeline: all device work of step k is enqueued, THEN the host halves of step k-1 run (detection
+        post-process, layout decode, CTC collapse) and the table results of steps k-1 / k-2 are advanced: the GPU queue never
+        drains while the host works, and the host never waits for work of the step it has just queued"""
         torch, args, eng = self.torch, self.args, self.eng
         stages = stages or self.stages
         layout = self.layout if "layout" in stages else None
@@ -431,9 +432,50 @@ class HipRunner:
         cls_line = self.cls_line if "cls" in stages else None
         c = {"boxes": 0, "tok": 0, "cells": 0, "layout": 0, "cls_lines": 0, "rec_lines": 0}
         prev = None          # detection maps of the previous step (host post-process pending)
+        lay_prev = None      # layout candidates of the previous step (D2H + decode + NMS pending)
+        rec_prev = None      # token ids of the previous step (D2H + CTC collapse pending)
+        cls_prev = None
         tprev = None         # table-structure state of the previous step (cell counts, processor, host shaping pending)
         tproc = None         # ... of two steps ago (processor queued, rows on their way to pinned memory)
         self.prime()
+
+        def host_half(prev, lay_prev, rec_prev, cls_prev):
+            """host halves of the PREVIOUS step: nothing here waits for work queued in the current step, so the GPU queue
+            always holds at least one step of work while the host decodes"""
+            t0 = time.perf_counter()
+            if prev is not None and not args.no_post:
+                res = self.stage.boxes(prev[0], prev[1], (PAGE, PAGE), prev[2])
+                self.rec_boxes = res
+                if count:
+                    c["boxes"] += sum(len(r) for r in res)
+            self._tick("det_post", t0)
+            t0 = time.perf_counter()
+            if lay_prev is not None:
+                lres = layout.finish(lay_prev[0], lay_prev[1], (PAGE, PAGE))      # D2H of the candidates, decode + per-class hard NMS
+                if count:
+                    c["layout"] += sum(len(r) for r in lres)
+            self._tick("layout_post", t0)
+            t0 = time.perf_counter()
+            if rec_prev is not None:
+                from pdf_table_amd.rec_stage import ctc_collapse
+                with self._on(self.rec_stream):
+                    toks = ctc_collapse(rec_prev.cpu().numpy())     # D2H of int32 [lines, 160] + host collapse
+                eng.check()
+                if count:
+                    c["tok"] += sum(len(t) for t in toks)
+            self._tick("ctc", t0)
+            if cls_prev is not None:
+                t0 = time.perf_counter()
+                lid, lsc = cls_line.top1(cls_prev[0])       # D2H of [lines, 2] logits, soft-max + top-1 (vectorised host)
+                o = 0
+                for q in cls_prev[2]:                       # the reference's per-page upright / upside-down vote
+                    cls_line.vote_top1(lid[o:o + len(q)], lsc[o:o + len(q)])
+                    o += len(q)
+                self.cls_page.top1(cls_prev[1])
+                if count:
+                    c["cls_lines"] += len(lid)
+                self._tick("cls_post", t0)
+
         for k in range(steps):
             t0 = time.perf_counter()
             with self._on(self.aux):
@@ -464,39 +506,7 @@ class HipRunner:
                 cls_out = (eng.cls_forward_lines(self.pages, build_lines(cls_quads), (80, 160), 0, True),
                            eng.cls_forward_pages(self.pages, (224, 224), 1, False), cls_quads)
             self._tick("enqueue", t0)
-            t0 = time.perf_counter()
-            if prev is not None and not args.no_post:          # host half of the previous step, under this step's GPU work
-                res = self.stage.boxes(prev[0], prev[1], (PAGE, PAGE), prev[2])
-                self.rec_boxes = res
-                if count:
-                    c["boxes"] += sum(len(r) for r in res)
-            self._tick("det_post", t0)
-            t0 = time.perf_counter()
-            if lay is not None:
-                lres = layout.finish(lay[0], lay[1], (PAGE, PAGE))      # D2H of the candidates, decode + per-class hard NMS
-                if count:
-                    c["layout"] += sum(len(r) for r in lres)
-            self._tick("layout_post", t0)
-            t0 = time.perf_counter()
-            if rec_ids is not None:
-                from pdf_table_amd.rec_stage import ctc_collapse
-                with self._on(self.rec_stream):
-                    toks = ctc_collapse(rec_ids.cpu().numpy())     # D2H of int32 [lines, 160] + host collapse
-                eng.check()
-                if count:
-                    c["tok"] += sum(len(t) for t in toks)
-            self._tick("ctc", t0)
-            if cls_out is not None:
-                t0 = time.perf_counter()
-                lid, lsc = cls_line.top1(cls_out[0])       # D2H of [lines, 2] logits, soft-max + top-1 (vectorised host)
-                o = 0
-                for q in cls_out[2]:                       # the reference's per-page upright / upside-down vote
-                    cls_line.vote_top1(lid[o:o + len(q)], lsc[o:o + len(q)])
-                    o += len(q)
-                self.cls_page.top1(cls_out[1])
-                if count:
-                    c["cls_lines"] += len(lid)
-                self._tick("cls_post", t0)
+            host_half(prev, lay_prev, rec_prev, cls_prev)
             t0 = time.perf_counter()
             if tproc is not None:      # tables of two steps ago: their rows reached pinned memory during the last step
                 tres = tsr.collect(tproc[0], tproc[1])
@@ -509,13 +519,8 @@ class HipRunner:
                         self.aux.wait_event(tprev[2])
                     tproc = (tsr.process(tprev[0]), tprev[1])  # behind this step's work; nothing here blocks on this step
             self._tick("tsr_finish", t0)
-            prev = cur
-            tprev = tpend
-        if prev is not None and not args.no_post:
-            res = self.stage.boxes(prev[0], prev[1], (PAGE, PAGE), prev[2])
-            self.rec_boxes = res
-            if count:
-                c["boxes"] += sum(len(r) for r in res)
+            prev, lay_prev, rec_prev, cls_prev, tprev = cur, lay, rec_ids, cls_out, tpend
+        host_half(prev, lay_prev, rec_prev, cls_prev)       # drain: the last step's host halves
         for fin in ((lambda: tsr.collect(tproc[0], tproc[1])) if tproc is not None else None,
                     (lambda: tsr.finish(tprev[0], tprev[1])) if tprev is not None else None):
             if fin is not None:

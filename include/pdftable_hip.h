@@ -190,6 +190,17 @@ int pt_db_candidates(const uint32_t* h_bitmap, int net_h, int net_w, int max_can
 int pt_db_finalize(const float* h_boxes, const float* h_scores, int nb, float box_thresh, float unclip_ratio,
                    float min_size, int net_h, int net_w, int dest_h, int dest_w, int post_flavour, int32_t* h_out,
                    float* h_out_scores, int cap, int* n_out);
+/* Batch forms of the two calls above: n pages in one call, walked by n_threads threads inside the library (0 = all
+ * hardware threads).  h_bitmaps uint32 [n, net_h, net_w/32]; h_boxes float32 [n, cap, 8] (page i's candidates at
+ * [i, 0 .. n_out[i])), h_sside float32 [n, cap] or NULL.  pt_db_finalize_batch: h_scores float32 [n, cap], nb int [n]
+ * candidates per page; h_out int32 [n, cap, 8]; filter != 0 additionally applies PPOcrDetectionPostProcessor.
+ * filter_tag_det_res (db_pp/processor_ocr_db_pp.py:344-386: clockwise order, clip to the page, drop boxes <= 3 px) and
+ * writes the surviving boxes as float32 [n, cap, 8] to h_out_f32 (n_out then counts those). */
+int pt_db_candidates_batch(const uint32_t* h_bitmaps, int n, int net_h, int net_w, int max_candidates, float min_size,
+                           int n_threads, float* h_boxes, float* h_sside, int cap, int* n_out);
+int pt_db_finalize_batch(const float* h_boxes, const float* h_scores, const int* nb, int n, int cap, float box_thresh,
+                         float unclip_ratio, float min_size, int net_h, int net_w, int dest_h, int dest_w, int post_flavour,
+                         int filter, int n_threads, int32_t* h_out, float* h_out_f32, float* h_out_scores, int* n_out);
 #define PT_DET_POST_DB_PP 0    /* float32 box / W * dest, round, clip, astype(int16): processor_ocr_db_pp.py:211-217 */
 #define PT_DET_POST_DB_TORCH 1 /* box.astype(int32) first, then the same in float64: ocr_detection_utils.py:198-206 */
 

@@ -15,6 +15,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "../../include/pdftable_hip.h"
@@ -487,6 +489,111 @@ int pt_db_finalize(const float* h_boxes, const float* h_scores, int nb, float bo
   }
   *n_out = n;
   return PT_OK;
+}
+
+// ---- batch forms: all pages of a batch in one call, spread over threads inside the library --------------------------
+// The per-page calls above are what DBPostProcess does for one image; a page batch used to go through a Python thread
+// pool that called them page by page (two pool.map rounds, per-page numpy glue under the GIL): 25 ms per 64 pages with ~80
+// boxes each, more than the GPU needs for the network.  Here one call walks the pages with an atomic counter.
+}  // extern "C"
+
+template <typename F>
+static void parallel_pages(int n, int n_threads, F f) {
+  int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+  if (nt > n) nt = n;
+  if (nt <= 1) {
+    for (int i = 0; i < n; ++i) f(i);
+    return;
+  }
+  std::atomic<int> next(0);
+  std::vector<std::thread> th;
+  th.reserve(nt);
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([&]() {
+      for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) f(i);
+    });
+  for (auto& t : th) t.join();
+}
+
+static int filter_tag(const int32_t* in, int n, int img_h, int img_w, float* out);
+
+extern "C" {
+
+int pt_db_candidates_batch(const uint32_t* h_bitmaps, int n, int net_h, int net_w, int max_candidates, float min_size,
+                           int n_threads, float* h_boxes, float* h_sside, int cap, int* n_out) {
+  if (!h_bitmaps || !h_boxes || !n_out || n < 0 || cap <= 0 || net_h <= 0 || net_w <= 0 || net_w % 32 != 0) {
+    pt_set_error("pt_db_candidates_batch: bad arguments");
+    return PT_ERR_INVALID;
+  }
+  const size_t words = (size_t)net_h * (net_w / 32);
+  std::atomic<int> bad(0);
+  parallel_pages(n, n_threads, [&](int i) {
+    const int rc = pt_db_candidates(h_bitmaps + (size_t)i * words, net_h, net_w, max_candidates, min_size,
+                                    h_boxes + (size_t)i * cap * 8, h_sside ? h_sside + (size_t)i * cap : nullptr, cap, n_out + i);
+    if (rc != PT_OK) bad.store(rc);
+  });
+  return bad.load();
+}
+
+}  // extern "C"
+
+// filter_tag_det_res of PPOcrDetectionPostProcessor (db_pp/processor_ocr_db_pp.py:344-386) on one page's int boxes, in
+// place: order_points_clockwise (sort by x -- numpy's argsort on 4 elements is an insertion sort, i.e. stable --, the two
+// left points and the two right points by y), clip to the page, drop boxes whose int(norm) width or height is <= 3.
+// boxes come in as int32 [n][8] and leave as float32 [n'][8] (the reference returns float32 points).
+static int filter_tag(const int32_t* in, int n, int img_h, int img_w, float* out) {
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    float px[4], py[4];
+    for (int k = 0; k < 4; ++k) {
+      px[k] = (float)in[(size_t)i * 8 + 2 * k];
+      py[k] = (float)in[(size_t)i * 8 + 2 * k + 1];
+    }
+    int o[4] = {0, 1, 2, 3};
+    std::stable_sort(o, o + 4, [&](int a, int b) { return px[a] < px[b]; });
+    int l0 = o[0], l1 = o[1], r0 = o[2], r1 = o[3];
+    if (py[l1] < py[l0]) std::swap(l0, l1);        // stable: equal y keeps the x order
+    if (py[r1] < py[r0]) std::swap(r0, r1);
+    const int ord[4] = {l0, r0, r1, l1};            // tl, tr, br, bl
+    float rx[4], ry[4];
+    for (int k = 0; k < 4; ++k) {
+      float x = px[ord[k]], y = py[ord[k]];
+      x = x < 0.f ? 0.f : (x > (float)(img_w - 1) ? (float)(img_w - 1) : x);
+      y = y < 0.f ? 0.f : (y > (float)(img_h - 1) ? (float)(img_h - 1) : y);
+      rx[k] = truncf(x);
+      ry[k] = truncf(y);
+    }
+    const float wx = rx[0] - rx[1], wy = ry[0] - ry[1], hx = rx[0] - rx[3], hy = ry[0] - ry[3];
+    const long long w = (long long)sqrtf(wx * wx + wy * wy), h = (long long)sqrtf(hx * hx + hy * hy);
+    if (w <= 3 || h <= 3) continue;
+    for (int k = 0; k < 4; ++k) {
+      out[(size_t)m * 8 + 2 * k] = rx[k];
+      out[(size_t)m * 8 + 2 * k + 1] = ry[k];
+    }
+    ++m;
+  }
+  return m;
+}
+
+extern "C" {
+
+int pt_db_finalize_batch(const float* h_boxes, const float* h_scores, const int* nb, int n, int cap, float box_thresh,
+                         float unclip_ratio, float min_size, int net_h, int net_w, int dest_h, int dest_w, int post_flavour,
+                         int filter, int n_threads, int32_t* h_out, float* h_out_f32, float* h_out_scores, int* n_out) {
+  if (!h_boxes || !h_scores || !nb || !h_out || !n_out || n < 0 || cap <= 0 || (filter && !h_out_f32)) {
+    pt_set_error("pt_db_finalize_batch: bad arguments");
+    return PT_ERR_INVALID;
+  }
+  std::atomic<int> bad(0);
+  parallel_pages(n, n_threads, [&](int i) {
+    int k = 0;
+    const int rc = pt_db_finalize(h_boxes + (size_t)i * cap * 8, h_scores + (size_t)i * cap, nb[i], box_thresh, unclip_ratio, min_size,
+                                  net_h, net_w, dest_h, dest_w, post_flavour, h_out + (size_t)i * cap * 8,
+                                  h_out_scores ? h_out_scores + (size_t)i * cap : nullptr, cap, &k);
+    if (rc != PT_OK) { bad.store(rc); n_out[i] = 0; return; }
+    n_out[i] = filter ? filter_tag(h_out + (size_t)i * cap * 8, k, dest_h, dest_w, h_out_f32 + (size_t)i * cap * 8) : k;
+  });
+  return bad.load();
 }
 
 // ---- layout: greedy hard NMS of OCRPicodetPostProcessor (picodet/processor_picodet.py:301-348), host side ----------

@@ -8,7 +8,6 @@ over the host cores while the GPU works on the next micro-batch.
 from __future__ import annotations
 
 import os
-from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -78,13 +77,12 @@ class DetStage:
     def __init__(self, eng: "E.HipEngine", cfg: Optional[DetConfig] = None, workers: Optional[int] = None):
         self.eng = eng
         self.cfg = (cfg or DetConfig()).resolved()
-        self.workers = workers or max(1, min(32, (os.cpu_count() or 8)))
-        self.pool = ThreadPoolExecutor(max_workers=self.workers)
+        self.workers = workers or max(1, min(32, (os.cpu_count() or 8)))     # threads of the batch host calls
         self._pin = {}
         self.side = None
 
     def close(self):
-        self.pool.shutdown(wait=False)
+        pass
 
     # ---- device half -----------------------------------------------------------------------------------
     def forward(self, pages: torch.Tensor, slot: int = 0):
@@ -130,30 +128,22 @@ class DetStage:
             hb.copy_(bitmap, non_blocking=True)
         self.side.synchronize()
         bm = hb.numpy()
-        cands = list(self.pool.map(lambda i: E.db_candidates(bm[i], cfg.max_candidates, cfg.min_size)[0], range(n)))
-        counts = [len(c) for c in cands]
-        tot = sum(counts)
+        # contour candidates of all pages: one call, pages on threads inside the library (no Python per page)
+        cand, counts = E.db_candidates_batch(bm, cfg.max_candidates, cfg.min_size, self.workers)
+        tot = int(counts.sum())
+        cap = cand.shape[1]
+        valid = np.arange(cap)[None, :] < counts[:, None]                 # [n, cap]
+        scores = np.zeros((n, cap), np.float32)
         if tot:
             allb = self._pinned("boxes", (tot, 9), torch.float32)
             ab = allb.numpy()
-            o = 0
-            for i, c in enumerate(cands):
-                ab[o:o + len(c), 0] = i
-                ab[o:o + len(c), 1:] = c
-                o += len(c)
+            ab[:, 0] = np.repeat(np.arange(n, dtype=np.float32), counts)
+            ab[:, 1:] = cand[valid]
             with torch.cuda.stream(self.side):
-                scores = self.eng.det_box_scores(prob, allb.to(prob.device, non_blocking=True)).cpu().numpy()
-        else:
-            scores = np.zeros((0,), np.float32)
-        offs = np.concatenate([[0], np.cumsum(counts)])
-
-        def fin(i):
-            out, _ = E.db_finalize(cands[i], scores[offs[i]:offs[i + 1]], (nh, nw), src_hw, cfg.box_thresh,
-                                   cfg.unclip_ratio, cfg.min_size, cfg.post)
-            if cfg.flavour == "db":
-                return out
-            return filter_tag_det_res(out, src_hw[0], src_hw[1]).reshape(-1, 8)
-        return list(self.pool.map(fin, range(n)))
+                scores[valid] = self.eng.det_box_scores(prob, allb.to(prob.device, non_blocking=True)).cpu().numpy()
+        # score gate, unclip, second rectangle, rescale (+ filter_tag_det_res for the db_pp flavour), again in one call
+        return E.db_finalize_batch(cand, scores, counts, (nh, nw), src_hw, cfg.box_thresh, cfg.unclip_ratio, cfg.min_size,
+                                   cfg.post, filter_tag=cfg.flavour != "db", n_threads=self.workers)
 
     def __call__(self, pages: torch.Tensor) -> List[np.ndarray]:
         prob, bitmap, ev = self.forward(pages)

@@ -503,6 +503,41 @@ def db_candidates(bitmap_words: np.ndarray, max_candidates: int = 1000, min_size
     return boxes[:n.value].copy(), sside[:n.value].copy()
 
 
+def db_candidates_batch(bitmaps: np.ndarray, max_candidates: int = 1000, min_size: float = 3.0, n_threads: int = 0):
+    """bitmaps uint32/int32 [n, H, W/32] -> (boxes f32 [n, cap, 8], counts int32 [n]); pages run on threads inside the library"""
+    lib = L.load()
+    bm = np.ascontiguousarray(bitmaps).view(np.uint32)
+    n, H, wpr = bm.shape
+    cap = max_candidates
+    boxes = np.empty((n, cap, 8), dtype=np.float32)
+    counts = np.zeros((n,), dtype=np.int32)
+    L.check(lib.pt_db_candidates_batch(bm.ctypes.data_as(C.c_void_p), n, H, wpr * 32, max_candidates, float(min_size), int(n_threads),
+                                       boxes.ctypes.data_as(C.c_void_p), None, cap, counts.ctypes.data_as(C.c_void_p)),
+            "pt_db_candidates_batch")
+    return boxes, counts
+
+
+def db_finalize_batch(boxes: np.ndarray, scores: np.ndarray, counts: np.ndarray, net_hw, dest_hw, box_thresh: float = 0.6,
+                      unclip_ratio: float = 1.5, min_size: float = 3.0, post_flavour: int = L.PT_DET_POST_DB_PP,
+                      filter_tag: bool = False, n_threads: int = 0):
+    """boxes f32 [n, cap, 8], scores f32 [n, cap], counts int32 [n] -> per page: int32 [k, 8] boxes, or, with filter_tag
+    (the db_pp flavour's filter_tag_det_res), float32 [k, 8]"""
+    lib = L.load()
+    n, cap, _ = boxes.shape
+    out = np.empty((n, cap, 8), dtype=np.int32)
+    outf = np.empty((n, cap, 8), dtype=np.float32) if filter_tag else None
+    nout = np.zeros((n,), dtype=np.int32)
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    L.check(lib.pt_db_finalize_batch(boxes.ctypes.data_as(C.c_void_p), scores.ctypes.data_as(C.c_void_p),
+                                     counts.ctypes.data_as(C.c_void_p), n, cap, float(box_thresh), float(unclip_ratio), float(min_size),
+                                     int(net_hw[0]), int(net_hw[1]), int(dest_hw[0]), int(dest_hw[1]), int(post_flavour),
+                                     1 if filter_tag else 0, int(n_threads), out.ctypes.data_as(C.c_void_p),
+                                     outf.ctypes.data_as(C.c_void_p) if filter_tag else None, None, nout.ctypes.data_as(C.c_void_p)),
+            "pt_db_finalize_batch")
+    src = outf if filter_tag else out
+    return [src[i, :nout[i]].copy() for i in range(n)]
+
+
 def db_finalize(boxes: np.ndarray, scores: np.ndarray, net_hw, dest_hw, box_thresh: float = 0.6,
                 unclip_ratio: float = 1.5, min_size: float = 3.0, post_flavour: int = L.PT_DET_POST_DB_PP):
     lib = L.load()

@@ -62,6 +62,8 @@ def _proto(lib):
         "pt_det_box_scores": (i, [vp, vp, i, i, i, vp, i, vp, vp]),
         "pt_db_candidates": (i, [vp, i, i, i, f, vp, vp, i, ip]),
         "pt_db_finalize": (i, [vp, vp, i, f, f, f, i, i, i, i, i, vp, vp, i, ip]),
+        "pt_db_candidates_batch": (i, [vp, i, i, i, i, f, i, vp, vp, i, vp]),
+        "pt_db_finalize_batch": (i, [vp, vp, vp, i, i, f, f, f, i, i, i, i, i, i, i, vp, vp, vp, vp]),
         "pt_rec_forward": (i, [vp, vp, i, i, i, vp, vp, i, vp, vp, vp]),
         "pt_rec_forward_crops": (i, [vp, vp, vp, vp, i, vp, vp, vp]),
         "pt_rec_forward_net": (i, [vp, vp, i, vp, vp, vp]),

@@ -96,3 +96,39 @@ def test_finalize_torch_flavour_bit_exact(seed):
     ref, _ = db_post.boxes_from_bitmap(prob, bm, 333, 211, 0.3, 1.5, 1000, 3, scores_override=scores, flavour="db")
     np.testing.assert_array_equal(out.reshape(-1, 4, 2), ref)
     assert len(out) >= 2
+
+
+def test_batch_host_calls_equal_the_per_page_calls():
+    """pt_db_candidates_batch / pt_db_finalize_batch (pages on threads inside the library, filter_tag_det_res in C++) give
+    exactly what the per-page calls + the numpy filter_tag_det_res give, for any thread count"""
+    import numpy as np
+    from pdf_table_amd import engine as E
+    from pdf_table_amd import lib as L
+    from pdf_table_amd.det_stage import filter_tag_det_res
+    rng = np.random.default_rng(5)
+    n, H, W = 7, 160, 192
+    bits = np.zeros((n, H, W), bool)
+    for i in range(n):
+        for _ in range(int(rng.integers(0, 40))):                      # random rectangles, some touching, some 1-2 px, some at the border
+            y, x = int(rng.integers(0, H - 2)), int(rng.integers(0, W - 2))
+            h, w = int(rng.integers(1, 14)), int(rng.integers(1, 60))
+            bits[i, y:y + h, x:x + w] = True
+    words = np.zeros((n, H, W // 32), np.uint32)
+    for k in range(32):
+        words |= bits[:, :, k::32].astype(np.uint32) << np.uint32(k)
+    for flavour, post, filt in (("db_pp", L.PT_DET_POST_DB_PP, True), ("db", L.PT_DET_POST_DB_TORCH, False)):
+        for nthr in (1, 3, 0):
+            cand, counts = E.db_candidates_batch(words, 1000, 3.0, nthr)
+            scores = np.zeros(cand.shape[:2], np.float32)
+            want = []
+            for i in range(n):
+                c1, _ = E.db_candidates(words[i], 1000, 3.0)
+                assert counts[i] == len(c1) and np.array_equal(cand[i, :counts[i]], c1)
+                sc = rng.uniform(0.3, 1.0, len(c1)).astype(np.float32)
+                scores[i, :len(c1)] = sc
+                out, _ = E.db_finalize(c1, sc, (H, W), (400, 500), 0.6, 1.5, 3.0, post)
+                want.append(filter_tag_det_res(out, 400, 500).reshape(-1, 8) if filt else out)
+            got = E.db_finalize_batch(cand, scores, counts, (H, W), (400, 500), 0.6, 1.5, 3.0, post, filter_tag=filt, n_threads=nthr)
+            assert sum(len(w) for w in want) > 20
+            for g, w in zip(got, want):
+                assert g.dtype == w.dtype and np.array_equal(g, w)
