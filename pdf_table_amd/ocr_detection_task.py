@@ -72,9 +72,23 @@ class OcrDetectionTask(BaseInferTask):
     def _construct_model(self, model):
         if self._engine is None:
             self._engine = HipEngine(int(str(self.device).split(":")[-1]) if ":" in str(self.device) else 0)
-        if model == "db_pp" and not self.kwargs.get("allow_stand_in", False):
-            raise RuntimeError(f"'{self._config.model_path}' is an ONNX graph that is not part of the reference tree; "
-                               "pass allow_stand_in=True to run the PP-OCR pre/post-processing around DB-ResNet18")
+        onnx_path = self._onnx_file()
+        if model == "db_pp" and onnx_path is None and not self.kwargs.get("allow_stand_in", False):
+            raise RuntimeError(f"'{self._config.model_path}' is an ONNX graph that is not part of the reference tree; pass "
+                               "task_path=<dir with model.onnx> (imported by pdf_table_amd.onnx_import when its architecture "
+                               "is one the engine runs) or allow_stand_in=True to run the PP-OCR pre/post-processing around "
+                               "DB-ResNet18")
+        if onnx_path is not None:
+            # the reference's ONNX mode (BaseInferTask._prepare_onnx_mode, base_infer_task.py:139-144 ->
+            # DeployUtils.prepare_onnx_model, utils/deploy_utils.py:243-280): parse the graph, map it to the engine's
+            # DB-ResNet18 launch graph, load its weights; any other architecture raises with the graph's inventory
+            from .onnx_import import UnsupportedOnnxGraph, load_onnx, recognise
+            arch, sd = recognise(load_onnx(onnx_path))
+            if arch != "db_resnet18":
+                raise UnsupportedOnnxGraph(f"{onnx_path} is a '{arch}' network, not a text detector the engine runs")
+            self._engine.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(sd))
+            self._model = self._predict
+            return
         nas = model == "db" and self._config.backbone == "proxylessnas"      # DBNasModel, modeling_db_net.py:47-49
         if model == "db" and self._config.backbone not in ("resnet18", "proxylessnas"):
             raise TypeError(f"detector backbone should be either resnet18, proxylessnas, but got {self._config.backbone}")
@@ -93,6 +107,18 @@ class OcrDetectionTask(BaseInferTask):
         else:
             self._engine.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(sd))
         self._model = self._predict
+
+    def _onnx_file(self):
+        """model.onnx / fp16_model.onnx under task_path (prepare_onnx_model's layout), or task_path itself if it is a file"""
+        tp = getattr(self, "_task_path", None)
+        if not tp or self.synthetic_seed is not None:
+            return None
+        if os.path.isfile(tp) and tp.endswith(".onnx"):
+            return tp
+        for cand in ("model.onnx", "fp16_model.onnx", "inference.onnx"):
+            if os.path.isfile(os.path.join(tp, cand)):
+                return os.path.join(tp, cand)
+        return None
 
     def _build_processor(self):
         self._stage = DetStage(self._engine, self._det_cfg)

@@ -64,6 +64,18 @@ class OcrRecognitionTask(BaseInferTask):
         if self.synthetic_seed is not None:
             from .synth_weights import crnn_state_dict
             sd = crnn_state_dict(seed=int(self.synthetic_seed))
+        elif any(os.path.isfile(os.path.join(self._config.model_path, c)) for c in ("model.onnx", "fp16_model.onnx")):
+            # an exported CRNN (DeployUtils.export_onnx -> torch.onnx.export, utils/deploy_utils.py:197-224): the importer
+            # restores the state_dict (ONNX LSTM gate order i, o, f, c -> torch's i, f, g, o) and the usual path takes over
+            from .onnx_import import UnsupportedOnnxGraph, load_onnx, recognise
+            mp = self._config.model_path
+            arch, sd = recognise(load_onnx(mp))
+            if arch != "crnn":
+                raise UnsupportedOnnxGraph(f"the ONNX graph under {mp} is a '{arch}' network, not a recogniser the engine runs")
+            vp = os.path.join(mp, "vocab.txt")
+            if os.path.exists(vp):
+                with open(vp, "r", encoding="utf-8") as f:
+                    vocab = [ln.strip("\n") for ln in f.readlines()]
         else:
             mp = self._config.model_path
             path = os.path.join(mp, "pytorch_model.bin")
