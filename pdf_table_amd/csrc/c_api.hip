@@ -63,6 +63,8 @@ int pt_engine_create(int device_id, pt_engine** out) {
   {
     const char* ev = getenv("PT_LSTM_CLUSTER");     // default of pt_engine_set_lstm_cluster
     e->lstm_cluster = ev ? (atoi(ev) != 0) : 1;
+    ev = getenv("PT_REC_RAGGED");                   // 0: the recogniser's conv stack also computes the padding (A/B switch)
+    e->rec_ragged = ev ? (atoi(ev) != 0) : 1;
   }
   *out = e;
   return PT_OK;
@@ -84,6 +86,9 @@ void pt_engine_destroy(pt_engine* e) {
   if (e->tsr_lut) (void)hipFree(e->tsr_lut);
   if (e->cls_lut) (void)hipFree(e->cls_lut);
   if (e->rec_pp_lut) (void)hipFree(e->rec_pp_lut);
+  if (e->rec_zero[0]) (void)hipFree(e->rec_zero[0]);
+  if (e->rec_zero[1]) (void)hipFree(e->rec_zero[1]);
+  if (e->rec_limits) (void)hipFree(e->rec_limits);
   if (e->cls_scratch) (void)hipFree(e->cls_scratch);
   if (e->layout_scratch) (void)hipFree(e->layout_scratch);
   if (e->det_in) (void)hipFree(e->det_in);
@@ -144,6 +149,7 @@ static int register_blob(pt_engine* e, int kind, const uint8_t* h_head, size_t h
   }
   e->models[kind] = m;
   if (kind == PT_MODEL_DB_RESNET18 || kind == PT_MODEL_DB_NAS) e->det_kind = kind;   // the active detector
+  if (kind == PT_MODEL_CRNN) e->rec_zero_valid[0] = e->rec_zero_valid[1] = false;     // cached all-padding-line activations
   return PT_OK;
 }
 
@@ -532,7 +538,7 @@ int pt_rec_forward_crops(pt_engine* e, const uint8_t* d_crops_rgb, const pt_rec_
     rc = pt_launch_rec_resize_gray(d_crops_rgb, d_lines + i0, d_off + i0, nb, x3, reinterpret_cast<bf16_t*>(e->rec_gray), s);
     if (rc != PT_OK) return rc;
     rc = pt_crnn_forward_net(e, reinterpret_cast<const bf16_t*>(e->rec_gray), nb, d_ids + (size_t)i0 * PT_REC_T,
-                             d_maxlogit ? d_maxlogit + (size_t)i0 * PT_REC_T : nullptr, s);
+                             d_maxlogit ? d_maxlogit + (size_t)i0 * PT_REC_T : nullptr, s, d_lines + i0);
     if (rc != PT_OK) return rc;
   }
   return PT_OK;
@@ -553,7 +559,7 @@ int pt_rec_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int h,
     rc = rec_pre_chunk(e, d_pages_rgb, n_pages, h, w, d_lines, h_crop_px, i0, nb, reinterpret_cast<bf16_t*>(e->rec_gray), s);
     if (rc != PT_OK) return rc;
     rc = pt_crnn_forward_net(e, reinterpret_cast<const bf16_t*>(e->rec_gray), nb, d_ids + (size_t)i0 * PT_REC_T,
-                             d_maxlogit ? d_maxlogit + (size_t)i0 * PT_REC_T : nullptr, s);
+                             d_maxlogit ? d_maxlogit + (size_t)i0 * PT_REC_T : nullptr, s, d_lines + i0);
     if (rc != PT_OK) return rc;
   }
   return PT_OK;

@@ -123,6 +123,12 @@ struct pt_engine {
   int* lstm_err = nullptr;                                   // pinned, device-visible: set by a cluster member that gave up waiting
   int lstm_max_cl = 0;                                       // clusters per direction per launch (num_cu / 8)
   int lstm_cluster = 1;                                      // 1: weight-stationary cluster kernel (bf16 mode); 0: streaming kernel
+  // crnn_model.hip: activations of an all-padding text line after every limited conv layer, per precision (bf16 / hi-lo);
+  // valid until the CRNN weights are loaded again
+  void* rec_zero[2] = {nullptr, nullptr};
+  bool rec_zero_valid[2] = {false, false};
+  void* rec_limits = nullptr; size_t rec_limits_cap = 0;     // per-line column limits of the call in flight
+  int rec_ragged = 1;                                        // PT_REC_RAGGED=0: compute the padding too (A/B switch)
 };
 
 // ---- conv launcher (conv_igemm.hip) -----------------------------------------------------------------
@@ -149,6 +155,11 @@ struct ConvDesc {
   const float* slope = nullptr;   // device pointer to the PReLU slope (relu == 3)
   int pool = 0;                   // 1: MaxPool2d(2,2), 2: MaxPool2d((2,1)), 3: (2,1) with rows -> channel groups; fused behind bias + ReLU (plain 3x3 stride-1 layers)
   const int* ylimit = nullptr;    // device int: output rows >= *ylimit are not computed (whole tiles; v1 kernel only)
+  // ragged images (text lines padded to a common width): device int [B], output COLUMNS >= xlimit[b] of image b are not
+  // computed (whole tiles; v1 kernel only) -- the caller fills them (pt_launch_crnn_fill).  xlimit_cols: device int, the
+  // number of columns below the limits summed over the images, tile-rounded (roofline accounting only)
+  const int* xlimit = nullptr;
+  const int* xlimit_cols = nullptr;
   // bf16x3 precision mode: in/res/out hold (hi | lo) channel groups; w is [N/64][3*Cin/32][taps][64][32]
   int split = 0;
   int out_lo_off = 0;  // channel distance between the hi and lo halves in the output buffer
@@ -214,6 +225,15 @@ int pt_launch_rec_resize_gray(const uint8_t* crops, const pt_rec_line* lines, co
 int pt_launch_rec_pp_resize_norm(const uint8_t* crops, const pt_rec_line* lines, const long long* pix_off,
                                  const pt_rec_pp_item* items, int n_items, int img_h, int max_img_w, const float* lut, float* out,
                                  hipStream_t s);
+// per-layer column limits of the ragged CRNN conv stack (crnn_model.hip) from the lines' crop sizes, and the fill of the
+// columns a limited conv skipped with the activations an all-padding line has there
+struct PtCrnnLimits {
+  int* lim[5];        // device int [n] each: conv1, conv2a, conv2b, conv3a, conv3b output-column limits
+  int* cols;          // device int [5]: sum over lines of the tile-rounded limits
+};
+int pt_launch_crnn_limits(const pt_rec_line* lines, int n, const PtCrnnLimits& L, hipStream_t s);
+int pt_launch_crnn_fill(bf16_t* out, const bf16_t* ref, const int* lim, int tile_w, int div, int n, int rows, int W, int cs,
+                        hipStream_t s);
 int pt_launch_crnn_conv0_pool(const bf16_t* in, int n, int H, int W, const float* w64x9, const float* bias, int split,
                               bf16_t* out, hipStream_t s);
 int pt_launch_maxpool_kxk(const bf16_t* in, int n, int H, int W, int C, int kh, int kw, int h2c, int split, bf16_t* out,
@@ -224,7 +244,10 @@ int pt_launch_gemm_argmax(const bf16_t* A, long long M, int K, const bf16_t* W, 
 int pt_launch_gemm_rows(const bf16_t* A, long long M, int K, const bf16_t* W, const float* bias, int N, bf16_t* out, int relu,
                         hipStream_t s);
 int pt_launch_argmax_reduce(const float* part, long long rows, int ntiles, int* ids, float* maxv, hipStream_t s);
-int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, float* maxlogit, hipStream_t s);
+// d_lines != null: the lines' crop sizes are known, so the conv stack does no work on the zero padding right of the text
+// (bit-identical results: skipped columns are filled with what an all-padding line has there)
+int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, float* maxlogit, hipStream_t s,
+                        const pt_rec_line* d_lines = nullptr);
 
 // ---- models ---------------------------------------------------------------------------------------------
 int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* prob, float* logits, hipStream_t s);

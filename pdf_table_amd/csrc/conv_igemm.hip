@@ -63,7 +63,9 @@ struct ConvK {
   int pool;               // 1: MaxPool2d(2,2), 2: MaxPool2d((2,1)) fused behind bias + ReLU (bf16-rounded first, like the stored map)
   int reps, total_tiles;  // reps > 1: a workgroup walks reps consecutive tiles of total_tiles (see the kernel)
   const int* ylimit;      // device int: tiles whose first output row is >= *ylimit do nothing (data-dependent extents)
+  const int* xlimit;      // device int [B]: tiles of image b whose first output column is >= xlimit[b] do nothing (ragged lines)
   long long m_flat;       // > 0: the (Ho x 32) geometry is a flat list of m_flat pixels (gemm1x1_kernel); rows beyond it are skipped
+  const int* xcols;       // host-side bookkeeping only (launch_cfg): ConvDesc.xlimit_cols
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
@@ -365,6 +367,7 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
   const int b = L / p.tiles_y;
   const int oy0 = tyi * C::TH, ox0 = txi * C::TW;
   if (p.ylimit && oy0 >= *p.ylimit) break;         // uniform over the workgroup; later tiles of the walk are further down
+  if (p.xlimit && ox0 >= p.xlimit[b]) continue;    // ragged image: this tile is all padding response, filled by the caller
   const int iy0 = oy0 * STRIDE - (KS / 2), ix0 = ox0 * STRIDE - (KS / 2);
   const int nchunks = p.split ? 3 * (p.Cin >> 5) : (p.Cin >> 5);
   const int in_cs = p.split ? 2 * p.Cin : p.Cin;   // channels per input pixel in memory
@@ -1347,15 +1350,16 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
       hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, GEOM, true>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
     else
       hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, GEOM, false>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
-    if (k.ylimit && prof.idx >= 0 && e->prof.h_lims && e->prof.n_lims < PtProfile::MAX_LIMS) {
-      // the launch covers the worst case and stops at a device-side row limit: remember where the limit will land
+    if ((k.ylimit || k.xcols) && prof.idx >= 0 && e->prof.h_lims && e->prof.n_lims < PtProfile::MAX_LIMS) {
+      // the launch covers the worst case and stops at a device-side row limit (or per-image column limits): remember
+      // where the limit will land
       auto& pd = e->prof.pending[prof.idx];
       pd.lim_slot = lim_slot = e->prof.n_lims++;
-      pd.rows = k.Ho;
+      pd.rows = k.ylimit ? k.Ho : k.B * k.Wo;
     }
   }
   if (lim_slot >= 0)      // behind the launch (and outside its event pair): the limit the kernel saw, to pinned memory
-    (void)hipMemcpyAsync(e->prof.h_lims + lim_slot, k.ylimit, sizeof(int), hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(e->prof.h_lims + lim_slot, k.ylimit ? k.ylimit : k.xcols, sizeof(int), hipMemcpyDeviceToHost, s);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
@@ -1515,6 +1519,8 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   k.Wo = (d.W + 2 * pad - d.ks) / d.stride + 1;
   k.out_cstride = d.out_cstride; k.out_coff = d.out_coff; k.rep = d.rep; k.shuffle_cout = d.shuffle_cout;
   k.res_mode = d.res ? d.res_mode : 0; k.relu = d.relu; k.slope = d.slope; k.ylimit = d.ylimit; k.pool = d.pool;
+  k.xlimit = d.xlimit; k.xcols = d.xlimit ? d.xlimit_cols : nullptr;
+  PT_REQUIRE(!d.xlimit || (d.ks == 3 && d.stride == 1 && !d.ylimit), "conv: column limits need a 3x3 stride-1 layer");
   PT_REQUIRE(!d.pool || (d.ks == 3 && d.stride == 1 && !d.res && !d.shuffle_cout && d.rep == 1 && !d.out_f32 && !d.argmax_part && !d.head_w && !d.n_valid && d.relu <= 1 && k.Ho % 2 == 0 && (d.pool != 1 || k.Wo % 2 == 0)),
              "conv: fused pooling needs a plain 3x3 stride-1 layer with even output size");
   PT_REQUIRE(d.relu != 3 || d.slope, "conv: PReLU needs the slope tensor");
@@ -1528,7 +1534,7 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   // the device limit let through (launch_cfg)
   const int n_alg = d.alg_n ? d.alg_n : (d.n_valid ? d.n_valid : d.N);
   const double flop = 2.0 * k.B * k.Ho * k.Wo * (double)n_alg * d.Cin * d.ks * d.ks * d.alg_scale;
-  if (d.ks == 3 && d.stride == 1 && !d.head_w && !d.argmax_part && !d.n_valid && !d.out_f32 && !d.res_f32 && d.relu < 2 && !d.ylimit && !d.pool && use_dma_kernel()) {
+  if (d.ks == 3 && d.stride == 1 && !d.head_w && !d.argmax_part && !d.n_valid && !d.out_f32 && !d.res_f32 && d.relu < 2 && !d.ylimit && !d.xlimit && !d.pool && use_dma_kernel()) {
     // steady-state A/B on MI355X (tools/ab3.sh, round 1): the 16-channel-slice DMA kernel (v3) wins on >= 120-row maps
     // with K >= 128 channels, the 32-channel-slice DMA kernel (v2) on 60..119-row maps, the register-staged kernel
     // (v1) on short-K layers and on small maps, where the big DMA tiles leave CUs idle

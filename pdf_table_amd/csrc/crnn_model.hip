@@ -40,7 +40,16 @@ inline const float* Bv(const PtTensor* t) { return reinterpret_cast<const float*
 
 }  // namespace
 
-int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, float* maxlogit, hipStream_t s) {
+// element offsets (per channel multiplier m) of the single-line tensors inside pt_engine::rec_zero[precision]
+namespace {
+struct ZeroLine {
+  static constexpr size_t GRAY = 0, A0 = GRAY + 32 * 640, P1 = A0 + 16 * 320 * 64, C2A = P1 + 8 * 160 * 128,
+                          P2 = C2A + 8 * 160 * 256, C3A = P2 + 4 * 160 * 256, P3 = C3A + 4 * 160 * 512, END = P3 + 160 * 1024;
+};
+}  // namespace
+
+int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, float* maxlogit, hipStream_t s,
+                        const pt_rec_line* d_lines) {
   PT_REQUIRE(e && gray && ids && n > 0, "crnn: bad arguments");
   auto it = e->models.find(PT_MODEL_CRNN);
   if (it == e->models.end()) {
@@ -129,42 +138,96 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
     }
     return pt_launch_conv(e, conv(in, 1, n, T, cin, cw, N, 1, out, relu), s);
   };
-  {
-    PtProfScope ps(e, s, PT_PROF_OTHER, 0, "crnn conv0+pool");
-    RUN(pt_launch_crnn_conv0_pool(gray, n, PT_REC_H, PT_REC_W, Bv(c0w), Bv(c0b), x3, bf.a0, s));
-  }
-  // conv1 + pool(2,2) and conv2.3 + pool((2,1)): pooling in the conv epilogue (PT_POOL_FUSED=0: separate pool kernels)
+  // conv0 .. conv3b (+ their pools) for nn lines; lim != null: no work right of every line's text (see crnn_limits_kernel),
+  // the skipped columns are filled from the all-padding line's activations `zl`
   static int pool_fused = -1;
   if (pool_fused < 0) {
     const char* ev = getenv("PT_POOL_FUSED");
     pool_fused = ev ? atoi(ev) : 1;
   }
-  if (pool_fused) {
-    ConvDesc c1d = conv(bf.a0, n, 16, 320, 64, c1, 128, 3, bf.p1, 1);
-    c1d.pool = 1;
-    RUN(pt_launch_conv(e, c1d, s));
-  } else {
-    RUN(pt_launch_conv(e, conv(bf.a0, n, 16, 320, 64, c1, 128, 3, bf.a1, 1), s));
-    RUN(pt_launch_maxpool_kxk(bf.a1, n, 16, 320, 128, 2, 2, 0, x3, bf.p1, s));
+  auto conv_stack = [&](const bf16_t* g, int nn, bf16_t* a0, bf16_t* a1, bf16_t* p1, bf16_t* c2a_o, bf16_t* c2b_o, bf16_t* p2,
+                        bf16_t* c3a_o, bf16_t* c3b_o, bf16_t* p3, const PtCrnnLimits* lim, const bf16_t* zl) -> int {
+    auto limited = [&](ConvDesc c, int k) {
+      if (lim) { c.xlimit = lim->lim[k]; c.xlimit_cols = lim->cols + k; }
+      return c;
+    };
+    auto fill = [&](bf16_t* out, size_t zoff, int k, int tile_w, int div, int rows, int Wd, int C) -> int {
+      if (!lim) return PT_OK;
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0, "crnn fill");
+      return pt_launch_crnn_fill(out, zl + zoff * m, lim->lim[k], tile_w, div, nn, rows, Wd, C * m, s);
+    };
+    {
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0, "crnn conv0+pool");
+      RUN(pt_launch_crnn_conv0_pool(g, nn, PT_REC_H, PT_REC_W, Bv(c0w), Bv(c0b), x3, a0, s));
+    }
+    // conv1 + pool(2,2) and conv2.3 + pool((2,1)): pooling in the conv epilogue (PT_POOL_FUSED=0: separate pool kernels,
+    // which need the full maps: no column limits then)
+    if (pool_fused) {
+      ConvDesc c1d = limited(conv(a0, nn, 16, 320, 64, c1, 128, 3, p1, 1), 0);
+      c1d.pool = 1;
+      RUN(pt_launch_conv(e, c1d, s));
+      RUN(fill(p1, ZeroLine::P1, 0, 32, 2, 8, 160, 128));
+    } else {
+      RUN(pt_launch_conv(e, conv(a0, nn, 16, 320, 64, c1, 128, 3, a1, 1), s));
+      RUN(pt_launch_maxpool_kxk(a1, nn, 16, 320, 128, 2, 2, 0, x3, p1, s));
+    }
+    RUN(pt_launch_conv(e, limited(conv(p1, nn, 8, 160, 128, c2a, 256, 3, c2a_o, 1), 1), s));
+    RUN(fill(c2a_o, ZeroLine::C2A, 1, 32, 1, 8, 160, 256));
+    if (pool_fused) {
+      ConvDesc c2d = limited(conv(c2a_o, nn, 8, 160, 256, c2b, 256, 3, p2, 1), 2);
+      c2d.pool = 2;
+      RUN(pt_launch_conv(e, c2d, s));
+      RUN(fill(p2, ZeroLine::P2, 2, 32, 1, 4, 160, 256));
+    } else {
+      RUN(pt_launch_conv(e, conv(c2a_o, nn, 8, 160, 256, c2b, 256, 3, c2b_o, 1), s));
+      RUN(pt_launch_maxpool_kxk(c2b_o, nn, 8, 160, 256, 2, 1, 0, x3, p2, s));
+    }
+    RUN(pt_launch_conv(e, limited(conv(p2, nn, 4, 160, 256, c3a, 512, 3, c3a_o, 1), 3), s));
+    RUN(fill(c3a_o, ZeroLine::C3A, 3, 64, 1, 4, 160, 512));
+    if (pool_fused) {
+      ConvDesc c3d = limited(conv(c3a_o, nn, 4, 160, 512, c3b, 512, 3, p3, 1), 4);
+      c3d.pool = 3;          // (2,1) pool, rows -> channel groups: [n][160][2 * 512]
+      RUN(pt_launch_conv(e, c3d, s));
+      RUN(fill(p3, ZeroLine::P3, 4, 64, 1, 1, 160, 1024));
+    } else {
+      RUN(pt_launch_conv(e, conv(c3a_o, nn, 4, 160, 512, c3b, 512, 3, c3b_o, 1), s));
+      RUN(pt_launch_maxpool_kxk(c3b_o, nn, 4, 160, 512, 2, 1, /*h2c=*/1, x3, p3, s));
+    }
+    return PT_OK;
+  };
+  // ragged path: the lines' sizes are known, the pools are fused (a limited conv never writes the full-resolution map)
+  const bool ragged = d_lines != nullptr && pool_fused && e->rec_ragged;
+  PtCrnnLimits lim;
+  const bf16_t* zl = nullptr;
+  if (ragged) {
+    if (!e->rec_zero_valid[x3]) {        // once per (weights, precision): an all-padding line through the conv stack, in full
+      const size_t bytes = ZeroLine::END * m * sizeof(bf16_t);
+      if (!e->rec_zero[x3]) PT_HIP_CHECK(hipMalloc(&e->rec_zero[x3], bytes));
+      PT_HIP_CHECK(hipMemsetAsync(e->rec_zero[x3], 0, bytes, s));
+      bf16_t* z = reinterpret_cast<bf16_t*>(e->rec_zero[x3]);
+      // full-resolution conv outputs are not kept with fused pools: a1 / c2b / c3b are unused there
+      RUN(conv_stack(z + ZeroLine::GRAY * m, 1, z + ZeroLine::A0 * m, nullptr, z + ZeroLine::P1 * m, z + ZeroLine::C2A * m, nullptr,
+                     z + ZeroLine::P2 * m, z + ZeroLine::C3A * m, nullptr, z + ZeroLine::P3 * m, nullptr, nullptr));
+      e->rec_zero_valid[x3] = true;
+    }
+    zl = reinterpret_cast<const bf16_t*>(e->rec_zero[x3]);
+    const size_t need = ((size_t)5 * n + 8) * sizeof(int);
+    if (need > e->rec_limits_cap) {
+      PT_HIP_CHECK(hipStreamSynchronize(s));
+      if (e->rec_limits) PT_HIP_CHECK(hipFree(e->rec_limits));
+      e->rec_limits = nullptr;
+      PT_HIP_CHECK(hipMalloc(&e->rec_limits, need * 2));
+      e->rec_limits_cap = need * 2;
+    }
+    int* base = reinterpret_cast<int*>(e->rec_limits);
+    for (int k = 0; k < 5; ++k) lim.lim[k] = base + (size_t)k * n;
+    lim.cols = base + (size_t)5 * n;
+    {
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0, "crnn limits");
+      RUN(pt_launch_crnn_limits(d_lines, n, lim, s));
+    }
   }
-  RUN(pt_launch_conv(e, conv(bf.p1, n, 8, 160, 128, c2a, 256, 3, bf.c2a, 1), s));
-  if (pool_fused) {
-    ConvDesc c2d = conv(bf.c2a, n, 8, 160, 256, c2b, 256, 3, bf.p2, 1);
-    c2d.pool = 2;
-    RUN(pt_launch_conv(e, c2d, s));
-  } else {
-    RUN(pt_launch_conv(e, conv(bf.c2a, n, 8, 160, 256, c2b, 256, 3, bf.c2b, 1), s));
-    RUN(pt_launch_maxpool_kxk(bf.c2b, n, 8, 160, 256, 2, 1, 0, x3, bf.p2, s));
-  }
-  RUN(pt_launch_conv(e, conv(bf.p2, n, 4, 160, 256, c3a, 512, 3, bf.c3a, 1), s));
-  if (pool_fused) {
-    ConvDesc c3d = conv(bf.c3a, n, 4, 160, 512, c3b, 512, 3, bf.p3, 1);
-    c3d.pool = 3;          // (2,1) pool, rows -> channel groups: [n][160][2 * 512]
-    RUN(pt_launch_conv(e, c3d, s));
-  } else {
-    RUN(pt_launch_conv(e, conv(bf.c3a, n, 4, 160, 512, c3b, 512, 3, bf.c3b, 1), s));
-    RUN(pt_launch_maxpool_kxk(bf.c3b, n, 4, 160, 512, 2, 1, /*h2c=*/1, x3, bf.p3, s));
-  }
+  RUN(conv_stack(gray, n, bf.a0, bf.a1, bf.p1, bf.c2a, bf.c2b, bf.p2, bf.c3a, bf.c3b, bf.p3, ragged ? &lim : nullptr, zl));
   // from here on: [1, n, 160, C] views
   RUN(pt_launch_conv(e, conv(bf.p3, 1, n, T, 1024, c4, 512, 1, bf.f, 1), s));
   RUN(rows_gemm(bf.f, 512, xp1, 2048, bf.gx, 0, "rows gemm 512->2048"));

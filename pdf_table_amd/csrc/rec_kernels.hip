@@ -205,6 +205,88 @@ int pt_launch_rec_resize_gray(const uint8_t* crops, const pt_rec_line* lines, co
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Ragged CRNN conv stack.  A text line is resized to height 32 and zero-padded to 640 columns (keepratio_resize,
+// processor_ocr_recognition.py:44-62); right of the text every conv layer produces what an ALL-padding line produces at
+// the same position (the kernels are position-independent and see the same zeros), so those columns need not be
+// computed: they are copied from the cached activations of an all-padding line.  crnn_limits_kernel derives, per line,
+// the first "clean" output column of each limited conv layer from the resized text width nw (the same formula as
+// rec_resize_gray_kernel):
+//   conv0 (3x3) + pool 2x2   clean from e0  = ceil((nw + 1) / 2)        (computed in full: K = 9, 1.6 ms per step)
+//   conv1 (3x3)              clean from e0 + 1;      after its 2x2 pool: e1 = ceil((e0 + 1) / 2)
+//   conv2a / conv2b (3x3)    e1 + 1 / e1 + 2         (the (2,1) pool keeps columns)
+//   conv3a / conv3b (3x3)    e1 + 3 / e1 + 4
+// lim[k][b] is that column (in the conv's own output columns); cols[k] sums the tile-rounded limits (roofline accounting).
+// ---------------------------------------------------------------------------------------------------
+__global__ void crnn_limits_kernel(const pt_rec_line* __restrict__ lines, int n, int* l1, int* l2a, int* l2b, int* l3a, int* l3b,
+                                   int* __restrict__ cols) {
+  __shared__ int sums[5];
+  if (threadIdx.x < 5) sums[threadIdx.x] = 0;
+  __syncthreads();
+  int acc[5] = {0, 0, 0, 0, 0};
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < n; b += gridDim.x * blockDim.x) {
+    const int cw = lines[b].crop_w, chh = lines[b].crop_h;
+    int nw = 0;
+    if (cw > 0 && chh > 0) {
+      const double ratio = (double)cw / (double)chh;
+      nw = ratio > 640.0 / 32.0 ? 640 : (int)(32.0 * ratio);
+    }
+    const int e0 = (nw + 2) >> 1;                 // ceil((nw + 1) / 2)
+    const int e1 = (e0 + 2) >> 1;                 // ceil((e0 + 1) / 2)
+    const int v[5] = {min(e0 + 1, 320), min(e1 + 1, 160), min(e1 + 2, 160), min(e1 + 3, 160), min(e1 + 4, 160)};
+    l1[b] = v[0]; l2a[b] = v[1]; l2b[b] = v[2]; l3a[b] = v[3]; l3b[b] = v[4];
+    const int tw[5] = {32, 32, 32, 64, 64}, wo[5] = {320, 160, 160, 160, 160};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) acc[k] += min(wo[k], (v[k] + tw[k] - 1) / tw[k] * tw[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) atomicAdd(&sums[k], acc[k]);
+  __syncthreads();
+  if (threadIdx.x < 5) atomicAdd(&cols[threadIdx.x], sums[threadIdx.x]);
+}
+
+int pt_launch_crnn_limits(const pt_rec_line* lines, int n, const PtCrnnLimits& L, hipStream_t s) {
+  PT_HIP_CHECK(hipMemsetAsync(L.cols, 0, 5 * sizeof(int), s));
+  int blocks = (n + 255) / 256;
+  if (blocks > 64) blocks = 64;
+  hipLaunchKernelGGL(crnn_limits_kernel, dim3(blocks), dim3(256), 0, s, lines, n, L.lim[0], L.lim[1], L.lim[2], L.lim[3], L.lim[4], L.cols);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// out [n][rows][W][cs] (bf16; cs = channels incl. the lo half in hi/lo mode), ref [rows][W][cs]: for every line b copy
+// ref -> out for the columns x >= xf(b) = (roundup(lim[b], tile_w)) / div -- the columns the limited conv left untouched
+// (div = 2 when a 2x2 pool follows the conv in its epilogue).  16-byte pieces; a block walks (row, column, piece) of one line.
+__global__ __launch_bounds__(256) void crnn_fill_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ ref,
+                                                         const int* __restrict__ lim, int tile_w, int div, int rows, int W, int cs) {
+  const int b = blockIdx.y;
+  const int xf = ((lim[b] + tile_w - 1) / tile_w * tile_w) / div;
+  if (xf >= W) return;
+  const int pc = cs >> 3, wcols = W - xf;
+  const long long total = (long long)rows * wcols * pc;
+  u32x4* o = reinterpret_cast<u32x4*>(out + (size_t)b * rows * W * cs);
+  const u32x4* r = reinterpret_cast<const u32x4*>(ref);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int piece = (int)(i % pc);
+    const long long t = i / pc;
+    const int x = xf + (int)(t % wcols), y = (int)(t / wcols);
+    const size_t idx = ((size_t)y * W + x) * pc + piece;
+    o[idx] = r[idx];
+  }
+}
+
+int pt_launch_crnn_fill(bf16_t* out, const bf16_t* ref, const int* lim, int tile_w, int div, int n, int rows, int W, int cs,
+                        hipStream_t s) {
+  if (n <= 0) return PT_OK;
+  PT_REQUIRE(cs % 8 == 0, "crnn fill: channel stride must be a multiple of 8");
+  long long per = (long long)rows * W * (cs >> 3);
+  int bx = (int)((per + 255) / 256);
+  bx = bx < 1 ? 1 : (bx > 16 ? 16 : bx);
+  hipLaunchKernelGGL(crnn_fill_kernel, dim3(bx, n), dim3(256), 0, s, out, ref, lim, tile_w, div, rows, W, cs);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // PPOcrRecPreProcessor.resize_norm_img (ocr_rec_pp/processor_ocr_rec_pp.py:43-67) for every line of a width-sorted plan:
 // cv2.resize (8-bit bilinear, as above) of the crop to img_h x resized_w, (x / 255 - 0.5) / 0.5 through a 256-entry fp32
 // table built on the host with the reference's operation order, zeros right of resized_w up to the mini-batch width.

@@ -254,3 +254,43 @@ def test_rec_pp_preprocessor_page_lines_bit_exact(eng):
         assert np.array_equal(g["image"].cpu().numpy(), r["image"])
         widths.add(r["image"].shape[3])
     assert len(widths) >= 2                                       # mini-batches of different padded widths
+
+
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+def test_ragged_conv_stack_is_bit_identical_to_the_full_one(sd, mode):
+    """pt_rec_forward knows every line's crop size, so the conv stack does no work right of the text (skipped columns are
+    filled with an all-padding line's activations): token ids AND winning logits equal the full computation bit for bit
+    (PT_REC_RAGGED=0, read when the engine is created), for short, long, over-long, tall and degenerate lines"""
+    import os
+    from pdf_table_amd.engine import HipEngine
+    img = make_page(7)[0]
+    rng = np.random.default_rng(11)
+    boxes = []
+    for k in range(150):
+        w = int(rng.choice([6, 17, 40, 90, 150, 260, 420, 700, 990]))
+        h = int(rng.choice([9, 14, 22, 31, 48]))
+        x0, y0 = int(rng.integers(0, 1024 - min(w, 1000))), int(rng.integers(0, 1024 - h))
+        boxes.append([x0, y0, x0 + w, y0, x0 + w, y0 + h, x0, y0 + h])
+    boxes.append([10, 10, 10, 10, 10, 10, 10, 10])                  # degenerate: empty crop, all padding
+    boxes.append([5, 100, 25, 100, 25, 400, 5, 400])                # tall: 20 x 300 -> two columns of text
+    boxes = np.array(boxes, np.float64)
+    outs = []
+    for ragged in ("1", "0"):
+        os.environ["PT_REC_RAGGED"] = ragged
+        try:
+            e = HipEngine(0)
+        finally:
+            del os.environ["PT_REC_RAGGED"]
+        e.load_weights(L.PT_MODEL_CRNN, pack_crnn(sd))
+        e.set_precision(L.PT_PRECISION_BF16X3 if mode == "bf16x3" else L.PT_PRECISION_BF16)
+        lines = R.build_lines([boxes])
+        pages = torch.from_numpy(img[None]).cuda()
+        ids, mx = e.rec_forward(pages, lines)
+        ids2, mx2 = e.rec_forward(pages, lines[::-1].copy())       # second call: cached all-padding line, other line order
+        torch.cuda.synchronize()
+        e.check()
+        assert torch.equal(ids2.flip(0), ids) and torch.equal(mx2.flip(0), mx)
+        outs.append((ids.cpu().numpy(), mx.cpu().numpy()))
+        e.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert len(np.unique(outs[0][0])) > 20
