@@ -192,6 +192,8 @@ int pt_launch_det_preprocess(const uint8_t* pages, int n, int h, int w, int nh, 
 int pt_launch_maxpool3x3s2(const bf16_t* in, int B, int H, int W, int C, bf16_t* out, int split, hipStream_t s);
 int pt_launch_db_head_final(const bf16_t* in, int B, int H, int W, const void* w4x64, const float* bias, float* prob,
                             float* logits, int split, hipStream_t s);
+int pt_launch_db_head_mfma(const bf16_t* in, int B, int H, int W, const bf16_t* w3, const float* b3, const bf16_t* w6,
+                           const float* b6, float* prob, float* logits, hipStream_t s);
 int pt_launch_bitmap(const float* prob, int n, int H, int W, float thresh, int dilate, uint32_t* bitmap,
                      hipStream_t s);
 int pt_launch_box_scores(const float* prob, int n, int H, int W, const float* boxes, int nb, float* scores,

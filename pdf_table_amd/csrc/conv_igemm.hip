@@ -319,6 +319,7 @@ struct ConvCfg {
   static constexpr int THIN = (TH - 1) * STRIDE + KS;
   static constexpr int TWIN = (TW - 1) * STRIDE + KS;
   static constexpr int TAPS = KS * KS;
+  static constexpr int XEVEN = (TWIN + 1) / 2;   // stride 2: number of even input columns of a patch row (stored first)
   static constexpr int PIXB = 80;  // bytes per staged pixel / weight row: 32 bf16 + 16 B pad
   static constexpr int IN_BYTES = THIN * TWIN * PIXB;
   static constexpr int W_BYTES = TAPS * 64 * PIXB;
@@ -405,7 +406,14 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
 #pragma unroll
     for (int j = 0; j < C::NI; ++j) {
       const int idx = tid + j * 256;
-      if (idx < C::NP_IN) *reinterpret_cast<u32x4*>(s_in + (idx >> 2) * C::PIXB + (idx & 3) * 16) = rin[j];
+      if (idx < C::NP_IN) {
+        int slot = idx >> 2;
+        if (STRIDE == 2) {      // even columns first, then the odd ones: the 32 pixels of an A fragment (input columns 2*lx + s)
+          const int iy = slot / C::TWIN, ix = slot - iy * C::TWIN;   // are then CONSECUTIVE 80-byte slots, as at stride 1 --
+          slot = iy * C::TWIN + (ix & 1) * C::XEVEN + (ix >> 1);      // no 2-pixel stride, no bank conflicts on ds_read_b128
+        }
+        *reinterpret_cast<u32x4*>(s_in + slot * C::PIXB + (idx & 3) * 16) = rin[j];
+      }
     }
 #pragma unroll
     for (int j = 0; j < C::NWP; ++j) {
@@ -427,7 +435,7 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
 #pragma unroll
   for (int m = 0; m < C::MT; ++m) {
     const int t = wave * C::MT + m;
-    a_base[m] = s_in + ((((t / C::CT) * STRIDE) * C::TWIN + ((t % C::CT) * 32 + lx) * STRIDE) * C::PIXB) + q * 16;
+    a_base[m] = s_in + ((((t / C::CT) * STRIDE) * C::TWIN + ((t % C::CT) * 32 + lx) * (STRIDE == 2 ? 1 : STRIDE)) * C::PIXB) + q * 16;
   }
   const char* b_base = s_w + lx * C::PIXB + q * 16;
 
@@ -451,7 +459,9 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
 #endif
 #pragma unroll
           for (int m = 0; m < C::MT; ++m) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base[m] + (r * C::TWIN + s) * C::PIXB + kk * 32);
+            // stride 2: tap s reads input column 2*lx + s = slot lx (s = 0), XEVEN + lx (s = 1), lx + 1 (s = 2)
+            const int soff = STRIDE == 2 ? ((s & 1) * C::XEVEN + (s >> 1)) : s;
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base[m] + (r * C::TWIN + soff) * C::PIXB + kk * 32);
             if (REGEPI) {   // D^T: rows = channels, columns = pixels
               acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a, acc[m][0], 0, 0, 0);
               acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a, acc[m][1], 0, 0, 0);

@@ -174,7 +174,16 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
     ConvDesc c = conv(bf.fuse, H / 4, W_ / 4, 256, w.bin0_w, w.bin0_b, 64, 3, 1, bf.y0, 64, 1);
     RUN(pt_launch_conv(e, c, s));
   }
-  {
+  static int head_mfma = -1;     // PT_DB_HEAD_MFMA=0: the head as an implicit-GEMM launch with the fused epilogue (A/B switch)
+  if (head_mfma < 0) {
+    const char* ev = getenv("PT_DB_HEAD_MFMA");
+    head_mfma = ev ? atoi(ev) : 1;
+  }
+  if (!x3 && head_mfma) {
+    // both transposed convs of the head in one streaming kernel (det_kernels.hip: db_head_mfma_kernel)
+    PtProfScope ps(e, s, PT_PROF_CONV1X1, 2.0 * n * (H / 4) * (W_ / 4) * (64.0 * 256 + 256 * 4), "db head (2 x convT) mfma");
+    RUN(pt_launch_db_head_mfma(bf.y0, n, H / 4, W_ / 4, W(w.bin3_w), Bv(w.bin3_b), W(w.bin6_w), Bv(w.bin6_b), prob, logits, s));
+  } else {
     // ConvTranspose2d(64,64,2,2)+BN+ReLU with the final ConvTranspose2d(64,1,2,2)+Sigmoid fused into its epilogue
     ConvDesc c = conv(bf.y0, H / 4, W_ / 4, 64, w.bin3_w, w.bin3_b, 256, 1, 1, bf.y1, 64, 1);
     c.shuffle_cout = 64;

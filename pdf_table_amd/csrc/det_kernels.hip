@@ -341,6 +341,137 @@ int pt_launch_db_head_final(const bf16_t* in, int B, int H, int W, const void* w
 }
 
 // ---------------------------------------------------------------------------------------------------
+// DB head in one streaming kernel (bf16 mode): ConvTranspose2d(64,64,2,2)+BN+ReLU and ConvTranspose2d(64,1,2,2)+Sigmoid
+// (dbnet.py:537-539) from the 64-channel map at 1/4 resolution straight to the full-resolution probability map.
+// The implicit-GEMM kernel ran this as four 64-column tiles with K = 64 -- two K-chunks of MFMA work per workgroup around
+// a full prologue / fp32-LDS epilogue, and 4-byte scattered stores: 0.6 ms per 32 pages for 355 MB of traffic.  Here a wave
+// owns 32 pixels at a time and never leaves its registers:
+//   GEMM 1  D^T[256 ch][32 px] = W3^T (A operand, from LDS) x X^T (B operand, 16-byte loads straight from HBM):
+//           a lane owns ONE pixel, its accumulators are that pixel's channels;
+//   bias + ReLU + bf16 rounding in the lane (the rounding the stored 64-channel map would have had);
+//   GEMM 2  per quadrant: D2[4 sub-pixels (of 32 rows)][32 px] = W6^T x h -- the accumulator registers of GEMM 1 ARE the B
+//           operand (the K order of a dot product is free: W6 is permuted to the accumulator order once);
+//   a pixel's 4x4 output block leaves as four 16-byte stores, 512 B contiguous per wave and output row.
+// ---------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 hbf16x8;
+typedef __attribute__((ext_vector_type(16))) float hf32x16;
+typedef __attribute__((ext_vector_type(4))) float hf32x4;
+
+__global__ __launch_bounds__(256, 4) void db_head_mfma_kernel(const bf16_t* __restrict__ in, long long npix, int H, int W,
+                                                               const bf16_t* __restrict__ w3, const float* __restrict__ b3,
+                                                               const bf16_t* __restrict__ w6, const float* __restrict__ b6,
+                                                               float* __restrict__ prob, float* __restrict__ logits) {
+  constexpr int PITCH = 144;                       // 64 k x 2 B + 16 B pad: conflict-free ds_read_b128 over 32 rows
+  __shared__ __attribute__((aligned(16))) char s_w[256 * PITCH];
+  __shared__ float s_b[256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, q = lane >> 5;
+  for (int idx = tid; idx < 256 * 8; idx += 256) {  // W3: packed [4 tiles of 64][2 chunks of 32 k][64 rows][32 k] -> [256 rows][64 k]
+    const int n = idx >> 3, piece = idx & 7;        // piece: 8 k-values
+    const int k = piece * 8;
+    const size_t src = ((size_t)((n >> 6) * 2 + (k >> 5)) * 64 + (n & 63)) * 32 + (k & 31);
+    *reinterpret_cast<u32x4*>(s_w + n * PITCH + piece * 16) = *reinterpret_cast<const u32x4*>(w3 + src);
+  }
+  s_b[tid] = b3[tid];
+  // W6^T fragments (A operand of GEMM 2), in the accumulator order of GEMM 1: k-slot (q, i) of step (tt, half) is channel
+  // tt*32 + 16*half + (i & 3) + 8*(i >> 2) + 4*q of the quadrant; rows >= 4 are zero
+  hbf16x8 w6f[2][2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      uint32_t pk[4];
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) {
+        uint32_t lo = 0, hi = 0;
+        if (lx < 4) {
+          lo = w6[lx * 64 + tt * 32 + 16 * half + (i & 3) + 8 * (i >> 2) + 4 * q];
+          hi = w6[lx * 64 + tt * 32 + 16 * half + ((i + 1) & 3) + 8 * ((i + 1) >> 2) + 4 * q];
+        }
+        pk[i >> 1] = lo | (hi << 16);
+      }
+      const u32x4 v = {pk[0], pk[1], pk[2], pk[3]};
+      w6f[tt][half] = __builtin_bit_cast(hbf16x8, v);
+    }
+  const float bias6 = b6[0];
+  __syncthreads();
+  const long long nbatch = (npix + 31) >> 5;
+  for (long long bt = (long long)blockIdx.x * 4 + wave; bt < nbatch; bt += (long long)gridDim.x * 4) {
+    const long long pix = bt * 32 + lx;
+    const long long pc = pix < npix ? pix : npix - 1;
+    hbf16x8 xf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const hbf16x8*>(in + (size_t)pc * 64 + j * 16 + q * 8);
+    // the weight fragments are re-read from LDS for every batch: hoisted out of the loop they would take 128 VGPRs and spill
+    const char* sw = s_w + lx * PITCH + q * 16;
+    const float* sb = s_b + 4 * q;
+    asm volatile("" : "+v"(sw), "+v"(sb));
+    float outv[4][4];                               // [quadrant][sub-pixel] of this lane's pixel (valid in the q == 0 lanes)
+#pragma unroll
+    for (int Q = 0; Q < 4; ++Q) {                   // quadrant by quadrant: 32 accumulators live, not 128
+      hf32x16 d2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d2[r] = 0.f;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * Q + tt;
+        hf32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const hbf16x8 a = *reinterpret_cast<const hbf16x8*>(sw + t * 32 * PITCH + j * 32);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[j], acc, 0, 0, 0);
+        }
+        uint32_t hb[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = fmaxf(acc[r] + sb[t * 32 + (r & 3) + 8 * (r >> 2)], 0.f);
+          hb[r] = f2bf(v);
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const u32x4 bv = {hb[8 * half + 0] | (hb[8 * half + 1] << 16), hb[8 * half + 2] | (hb[8 * half + 3] << 16),
+                            hb[8 * half + 4] | (hb[8 * half + 5] << 16), hb[8 * half + 6] | (hb[8 * half + 7] << 16)};
+          d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w6f[tt][half], __builtin_bit_cast(hbf16x8, bv), d2, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) outv[Q][sp] = d2[sp] + bias6;      // rows 0..3 live in registers 0..3 of the q == 0 lanes
+    }
+    if (q == 0 && pix < npix) {
+      const int ox = (int)(pix % W);
+      const long long tq = pix / W;
+      const int oy = (int)(tq % H);
+      const long long b = tq / H;
+      const size_t OW = (size_t)4 * W;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {              // output row 4*oy + rr: quadrant row a = rr >> 1, sub-pixel row c = rr & 1
+        const int a = rr >> 1, c = rr & 1;
+        const hf32x4 lg = {outv[2 * a][2 * c], outv[2 * a][2 * c + 1], outv[2 * a + 1][2 * c], outv[2 * a + 1][2 * c + 1]};
+        const size_t o = ((size_t)b * (4 * H) + 4 * oy + rr) * OW + (size_t)4 * ox;
+        if (logits) *reinterpret_cast<hf32x4*>(logits + o) = lg;
+        if (prob) {
+          const hf32x4 pr = {1.f / (1.f + expf(-lg.x)), 1.f / (1.f + expf(-lg.y)), 1.f / (1.f + expf(-lg.z)), 1.f / (1.f + expf(-lg.w))};
+          *reinterpret_cast<hf32x4*>(prob + o) = pr;
+        }
+      }
+    }
+  }
+}
+
+int pt_launch_db_head_mfma(const bf16_t* in, int B, int H, int W, const bf16_t* w3, const float* b3, const bf16_t* w6,
+                           const float* b6, float* prob, float* logits, hipStream_t s) {
+  const long long npix = (long long)B * H * W;
+  long long blocks = (npix / 32 + 4 * 12 - 1) / (4 * 12);     // ~12 batches per wave: the 37 KB weight image is staged once per workgroup
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(db_head_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, npix, H, W, w3, b3, w6, b6, prob, logits);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // prob > thresh -> bit-packed bitmap (DBPostProcess.__call__, processor_ocr_db_pp.py:296), with the
 // optional 2x2 all-ones cv2.dilate (anchor (1,1): out(x,y) = max over x-1..x, y-1..y; :301-304).
 // One lane per pixel, wave ballot -> two 32-bit words.
