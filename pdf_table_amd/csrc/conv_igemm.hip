@@ -336,7 +336,9 @@ struct ConvCfg {
 // its operands swapped (weights as A, pixels as B), so D is channel-major -- a lane owns ONE pixel (column lx) and its 16
 // registers are four runs of four consecutive channels -- and every lane stores 8-byte channel runs straight to HBM.
 // No fp32 staging image, no barrier, no second pass over LDS; the arithmetic per element is the LDS epilogue's.
-template <int KS, int STRIDE, int GEOM, bool REGEPI>
+// NHALF = 1: only the first 32 of the tile's 64 output columns are computed (layers with <= 32 real outputs, e.g. the
+// 27-channel offset / mask convs of the deformable layers): half the MFMAs and half the B-fragment reads.
+template <int KS, int STRIDE, int GEOM, bool REGEPI, int NHALF = 2>
 __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_igemm_kernel(ConvK p) {
   using C = ConvCfg<KS, STRIDE, GEOM>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -453,7 +455,8 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(b_base + (tap * 64) * C::PIXB + kk * 32);
-          const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(b_base + (tap * 64 + 32) * C::PIXB + kk * 32);
+          bf16x8 b1 = b0;
+          if (NHALF == 2) b1 = *reinterpret_cast<const bf16x8*>(b_base + (tap * 64 + 32) * C::PIXB + kk * 32);
 #ifdef PT_SETPRIO
           __builtin_amdgcn_s_setprio(1);
 #endif
@@ -464,10 +467,10 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base[m] + (r * C::TWIN + soff) * C::PIXB + kk * 32);
             if (REGEPI) {   // D^T: rows = channels, columns = pixels
               acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a, acc[m][0], 0, 0, 0);
-              acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a, acc[m][1], 0, 0, 0);
+              if (NHALF == 2) acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a, acc[m][1], 0, 0, 0);
             } else {
               acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
-              acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
+              if (NHALF == 2) acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
             }
           }
 #ifdef PT_SETPRIO
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
     const int t = wave * C::MT + m;
     const int pbase = (t / C::CT) * C::TW + (t % C::CT) * 32;
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < NHALF; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int tx = (r & 3) + 8 * (r >> 2) + 4 * q;
@@ -1327,6 +1330,17 @@ static bool use_reg_epilogue() {
   return v != 0;
 }
 
+static void launch_half(ConvK& k, unsigned nblk, hipStream_t s) {
+  using C = ConvCfg<3, 1, 0>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<3, 1, 0, false, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<3, 1, 0, false, 1>), dim3(nblk), dim3(256), C::SMEM, s, k);
+}
+
 template <int KS, int STRIDE, int GEOM = 0>
 static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   using C = ConvCfg<KS, STRIDE, GEOM>;
@@ -1356,7 +1370,9 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   int lim_slot = -1;
   {
     PtProfScope prof(e, s, KS == 3 ? PT_PROF_CONV3X3 : PT_PROF_CONV1X1, flop, label);
-    if (plain && use_reg_epilogue())
+    if (KS == 3 && STRIDE == 1 && GEOM == 0 && k.n_valid > 0 && k.n_valid <= 32 && k.N == 64 && !k.split && !k.pool && !k.head_w && !k.argmax_part)
+      launch_half(k, (unsigned)nblk, s);      // <= 32 real output channels: half-width variant
+    else if (plain && use_reg_epilogue())
       hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, GEOM, true>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
     else
       hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, GEOM, false>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
