@@ -242,9 +242,18 @@ __global__ __launch_bounds__(256) void lore_rekey_kernel(const float* __restrict
   keys[(size_t)b * stride + k] = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)k);
 }
 
-constexpr int MOS_PW = 256;        // patches per mosaic row (mosaic width = 3 * MOS_PW pixels)
-__device__ __forceinline__ size_t mosaic_centre(long long j) {
-  return (size_t)(3 * (j / MOS_PW) + 1) * (3 * MOS_PW) + 3 * (j % MOS_PW) + 1;
+// Patch rows.  The sparse heads are 3x3 (64 -> 256) + ReLU + 1x1 convolutions evaluated at single pixels: the 3x3
+// neighbourhood of such a pixel, laid out as ONE row of 9 * C values in the K order of the conv kernel -- [32-channel chunk]
+// [tap][32 channels], the (hi | lo) halves one after the other in hi/lo mode -- turns the 3x3 conv into a plain GEMM over
+// the patches whose K-chunks ARE the 3x3 layer's weight tiles in their packed order: same weights, same MFMA sequence, so
+// the same bits as the dense conv at that pixel, for 1/9 of the FLOPs a 3x3-pixel mosaic patch needs.  The rows form an
+// "image" of MOS_PW patches per row for the row-limited 1x1 launches.
+constexpr int MOS_PW = 32;         // patches per row of the patch image
+__device__ __forceinline__ size_t mosaic_centre(long long j) { return (size_t)j; }
+// element offset of (tap, channel ch of cs) inside a patch row; C = real channels (cs = C or 2C)
+__device__ __forceinline__ int patch_off(int tap, int ch, int C) {
+  const int half = ch >= C ? 1 : 0, cl = ch - half * C;
+  return half * 9 * C + ((cl >> 5) * 9 + tap) * 32 + (cl & 31);
 }
 
 // exclusive prefix of the kept cell counts over the tables + the two row limits of the mosaics (one thread: B <= 64)
@@ -256,8 +265,8 @@ __global__ void lore_sparse_base_kernel(const int* __restrict__ counts, int B, i
     base[b] = (int)t;
     t += counts[2 * b];
   }
-  lim[0] = (int)(3 * ((t + MOS_PW - 1) / MOS_PW));
-  lim[1] = (int)(3 * ((4 * t + MOS_PW - 1) / MOS_PW));
+  lim[0] = (int)((t + MOS_PW - 1) / MOS_PW);
+  lim[1] = (int)((4 * t + MOS_PW - 1) / MOS_PW);
 }
 
 // the same for the kept peaks of the first sort: pk_base[2 b + cls] = number of kept peaks of class cls in the tables
@@ -271,8 +280,8 @@ __global__ void lore_peak_base_kernel(const int* __restrict__ kept, int B, int* 
     t0 += kept[2 * b];
     t1 += kept[2 * b + 1];
   }
-  lim[0] = (int)(3 * ((t0 + MOS_PW - 1) / MOS_PW));
-  lim[1] = (int)(3 * ((t1 + MOS_PW - 1) / MOS_PW));
+  lim[0] = (int)((t0 + MOS_PW - 1) / MOS_PW);
+  lim[1] = (int)((t1 + MOS_PW - 1) / MOS_PW);
 }
 
 // 3x3 neighbourhoods of the kept peaks (cells and corners, in sorted order) -> the cell / corner patch mosaics
@@ -293,7 +302,7 @@ __global__ __launch_bounds__(64) void lore_peak_patch_kernel(const unsigned long
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
       v = *reinterpret_cast<const uint4*>(feat + (((size_t)b * H + y) * W + x) * cs + piece * 8);
-    *reinterpret_cast<uint4*>(mos + ((size_t)(3 * (pj / MOS_PW) + tap / 3) * (3 * MOS_PW) + 3 * (pj % MOS_PW) + tap % 3) * cs + piece * 8) = v;
+    *reinterpret_cast<uint4*>(mos + (size_t)pj * 9 * cs + patch_off(tap, piece * 8, C)) = v;
   }
 }
 
@@ -336,8 +345,7 @@ __global__ __launch_bounds__(256) void lore_patch_gather_kernel(const float* __r
     if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
       v = *reinterpret_cast<const uint4*>(feat + (((size_t)b * H + y) * W + x) * cs + piece * 8);
     const long long pj = k == 0 ? j : 4 * j + (k - 1);
-    bf16_t* dst = (k == 0 ? mos_ax : mos_cr) +
-                  ((size_t)(3 * (pj / MOS_PW) + tap / 3) * (3 * MOS_PW) + 3 * (pj % MOS_PW) + tap % 3) * cs + piece * 8;
+    bf16_t* dst = (k == 0 ? mos_ax : mos_cr) + (size_t)pj * 9 * cs + patch_off(tap, piece * 8, C);
     *reinterpret_cast<uint4*>(dst) = v;
   }
 }
@@ -500,10 +508,10 @@ int pt_lore_decode(pt_engine* e, const float* hm, const float* st, const float* 
 // A patch's centre pixel sees only its own 3x3 pixels, through the same conv kernels in the same order as in the dense
 // map: with one conv kernel family the results are bit-identical to pt_lore_decode's (tests/test_gpu_tsr.py).
 void pt_lore_mosaic_rows(int B, int* rows_ax, int* rows_cr, int* rows_cell, int* rows_corner) {
-  *rows_ax = 3 * (((long long)B * K_CELLS + MOS_PW - 1) / MOS_PW);
-  *rows_cr = 3 * (((long long)B * K_CELLS * 4 + MOS_PW - 1) / MOS_PW);
+  *rows_ax = (int)(((long long)B * K_CELLS + MOS_PW - 1) / MOS_PW);
+  *rows_cr = (int)(((long long)B * K_CELLS * 4 + MOS_PW - 1) / MOS_PW);
   *rows_cell = *rows_ax;
-  *rows_corner = 3 * (((long long)B * K_CORNERS + MOS_PW - 1) / MOS_PW);
+  *rows_corner = (int)(((long long)B * K_CORNERS + MOS_PW - 1) / MOS_PW);
 }
 
 // state of the earlier steps, consumed by the calls that follow on the same stream: kept in the engine, so that two

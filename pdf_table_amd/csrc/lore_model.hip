@@ -262,15 +262,15 @@ static int lore_dla_run(pt_engine* e, const bf16_t* x, int n, int H, int W, floa
     if (sp) {
       int rows_ax = 0, rows_cr = 0, rows_cell = 0, rows_corner = 0;
       pt_lore_mosaic_rows(n, &rows_ax, &rows_cr, &rows_cell, &rows_corner);
-      const int MW = 768;
+      const int MW = 32;          // patches per row of the patch image (lore_decode.hip: MOS_PW); a patch = one row of 9 * 64 values
       auto take = [&](size_t bytes) { void* p_ = e->arenas[PT_ARENA_TSR].take(bytes); if (!p_) c.ok = false; return p_; };
       auto mosaic = [&](int rows, int C) {
         T t;
         t.H = rows; t.W = MW; t.C = C;
-        t.p = reinterpret_cast<bf16_t*>(take((size_t)rows * MW * C * c.mul * sizeof(bf16_t)));
+        t.p = reinterpret_cast<bf16_t*>(take(((size_t)rows * MW * C * c.mul + 64) * sizeof(bf16_t)));
         return t;
       };
-      T mcell = mosaic(rows_cell, 64), mcorner = mosaic(rows_corner, 64), max_ = mosaic(rows_ax, 64), mcr_ = mosaic(rows_cr, 64);
+      T mcell = mosaic(rows_cell, 9 * 64), mcorner = mosaic(rows_corner, 9 * 64), max_ = mosaic(rows_ax, 9 * 64), mcr_ = mosaic(rows_cr, 9 * 64);
       T mhid = mosaic(rows_cr, 256);                 // hidden layer of whichever head is running (rows_cr is the largest)
       float* o_wh = reinterpret_cast<float*>(take((size_t)rows_cell * MW * 8 * sizeof(float)));
       float* o_regc = reinterpret_cast<float*>(take((size_t)rows_cell * MW * 8 * sizeof(float)));
@@ -286,11 +286,11 @@ static int lore_dla_run(pt_engine* e, const bf16_t* x, int n, int H, int W, floa
           hh.H = rows;
           c.n = 1;
           c.ylimit = lim;
-          c.alg_scale = 1.0 / 9.0;     // a patch is 3x3 pixels of which the decode reads the centre: 1/9 of the mosaic is algorithmic
-          c.conv(mos, std::string(name) + ".0", 256, 3, 1, hh, 1);
+          // the 3x3 layer as a GEMM over patch rows: K = 9 * 64 in the conv kernel's own (chunk, tap, channel) order, so the
+          // layer's packed 3x3 weight tiles are the 18 K-chunks of this 1x1 launch as they stand
+          c.conv(mos, std::string(name) + ".0", 256, 1, 1, hh, 1);
           c.conv(hh, std::string(name) + ".2", nc < 64 ? 64 : nc, 1, 1, T(), 0, nullptr, nc, outp, nc, 0, real_nc);
           c.ylimit = nullptr;
-          c.alg_scale = 1.0;
           c.n = keep;
         };
         const int *lim_cell = nullptr, *lim_corner = nullptr, *lim_ax = nullptr, *lim_cr = nullptr;
