@@ -70,7 +70,7 @@ class ClsStage:
 
     def top1(self, logits: torch.Tensor):
         """vectorised Topk(topk=1) for large batches: (class ids int64 [n], scores f32 [n] rounded to 5 decimals)"""
-        p = torch.softmax(logits.float(), dim=-1).cpu().numpy()
+        p = torch.softmax(logits.cpu().float(), dim=-1).numpy()      # host soft-max over <= 10 classes, like Topk (no device op here)
         ids = np.argsort(p, axis=1)[:, -1]          # same tie rule as Topk: the LAST of equal maxima in argsort order
         return ids, np.around(p[np.arange(len(p)), ids], decimals=5)
 

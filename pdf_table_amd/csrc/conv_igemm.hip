@@ -58,13 +58,11 @@ struct ConvK {
   float* out_f32;
   const float* res_f32;   // fp32 residual with the layout of out_f32 (transformer residual stream), added before ReLU
   int n_group;            // > 0: column tiles are walked in groups of n_group so that a group's weights stay in one XCD's L2
-  int gemm_nt;            // gemm1x1_kernel: number of 128-wide column tiles (n_tiles stays N / 64 for the arg-max partials)
   const float* slope;     // relu == 3: PReLU, slope[0] = the (single, layer-wide) negative slope, read on the device
   int pool;               // 1: MaxPool2d(2,2), 2: MaxPool2d((2,1)) fused behind bias + ReLU (bf16-rounded first, like the stored map)
   int reps, total_tiles;  // reps > 1: a workgroup walks reps consecutive tiles of total_tiles (see the kernel)
   const int* ylimit;      // device int: tiles whose first output row is >= *ylimit do nothing (data-dependent extents)
   const int* xlimit;      // device int [B]: tiles of image b whose first output column is >= xlimit[b] do nothing (ragged lines)
-  long long m_flat;       // > 0: the (Ho x 32) geometry is a flat list of m_flat pixels (gemm1x1_kernel); rows beyond it are skipped
   const int* xcols;       // host-side bookkeeping only (launch_cfg): ConvDesc.xlimit_cols
 };
 
@@ -181,7 +179,6 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
     const int ty = pix / TW, tx = pix % TW;
     const int oy = oy0 + ty, ox = ox0 + tx;
     if (oy >= p.Ho || ox >= p.Wo) continue;
-    if (EXTRAS && p.m_flat && (long long)oy * p.Wo + ox >= p.m_flat) continue;
     const f32x4* sp = reinterpret_cast<const f32x4*>(stage + pix * 64 + cg * 8);
     f32x4 v0 = sp[0], v1 = sp[1];
     const int n = n0 + cg * 8;
@@ -332,13 +329,9 @@ struct ConvCfg {
   static_assert(NP_W % 256 == 0, "weight slice must be a whole number of 256-thread passes");
 };
 
-// REGEPI: the plain layers (bias [+ residual] [+ activation], bf16 NHWC store) finish from registers: the MFMA runs with
-// its operands swapped (weights as A, pixels as B), so D is channel-major -- a lane owns ONE pixel (column lx) and its 16
-// registers are four runs of four consecutive channels -- and every lane stores 8-byte channel runs straight to HBM.
-// No fp32 staging image, no barrier, no second pass over LDS; the arithmetic per element is the LDS epilogue's.
 // NHALF = 1: only the first 32 of the tile's 64 output columns are computed (layers with <= 32 real outputs, e.g. the
 // 27-channel offset / mask convs of the deformable layers): half the MFMAs and half the B-fragment reads.
-template <int KS, int STRIDE, int GEOM, bool REGEPI, int NHALF = 2>
+template <int KS, int STRIDE, int GEOM, int NHALF = 2>
 __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_igemm_kernel(ConvK p) {
   using C = ConvCfg<KS, STRIDE, GEOM>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -465,13 +458,8 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
             // stride 2: tap s reads input column 2*lx + s = slot lx (s = 0), XEVEN + lx (s = 1), lx + 1 (s = 2)
             const int soff = STRIDE == 2 ? ((s & 1) * C::XEVEN + (s >> 1)) : s;
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base[m] + (r * C::TWIN + soff) * C::PIXB + kk * 32);
-            if (REGEPI) {   // D^T: rows = channels, columns = pixels
-              acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a, acc[m][0], 0, 0, 0);
-              if (NHALF == 2) acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a, acc[m][1], 0, 0, 0);
-            } else {
-              acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
-              if (NHALF == 2) acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
-            }
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
+            if (NHALF == 2) acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
           }
 #ifdef PT_SETPRIO
           __builtin_amdgcn_s_setprio(0);
@@ -481,63 +469,6 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
     }
   }
 
-  if (REGEPI) {
-    const int n0 = nt * 64;
-    const float sl = p.relu == 3 ? p.slope[0] : 0.f;
-    const int rcs = p.split ? 2 * p.N : p.N;
-#pragma unroll
-    for (int m = 0; m < C::MT; ++m) {
-      const int t = wave * C::MT + m;
-      const int oy = oy0 + t / C::CT, ox = ox0 + (t % C::CT) * 32 + lx;
-      if (oy >= p.Ho || ox >= p.Wo) continue;
-      const size_t pix = ((size_t)b * p.Ho + oy) * p.Wo + ox;
-      const size_t rpix = p.res_mode == 2 ? ((size_t)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1) : pix;
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int ch = n0 + n * 32 + rg * 8 + q * 4;
-          if (p.n_valid && ch >= p.n_valid) continue;
-          const f32x4 bs = *reinterpret_cast<const f32x4*>(p.bias + ch);
-          float v[4] = {acc[m][n][rg * 4 + 0] + bs.x, acc[m][n][rg * 4 + 1] + bs.y, acc[m][n][rg * 4 + 2] + bs.z,
-                        acc[m][n][rg * 4 + 3] + bs.w};
-          if (p.res_mode) {
-            u32x2 rr = *reinterpret_cast<const u32x2*>(p.res + rpix * rcs + ch);
-            v[0] += bf16_to_f32(rr.x & 0xFFFFu); v[1] += bf16_to_f32(rr.x >> 16);
-            v[2] += bf16_to_f32(rr.y & 0xFFFFu); v[3] += bf16_to_f32(rr.y >> 16);
-            if (p.split) {
-              rr = *reinterpret_cast<const u32x2*>(p.res + rpix * rcs + ch + p.N);
-              v[0] += bf16_to_f32(rr.x & 0xFFFFu); v[1] += bf16_to_f32(rr.x >> 16);
-              v[2] += bf16_to_f32(rr.y & 0xFFFFu); v[3] += bf16_to_f32(rr.y >> 16);
-            }
-          }
-          if (p.relu == 1) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
-          } else if (p.relu == 2) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = v[k] * fminf(fmaxf(v[k] + 3.f, 0.f), 6.f) / 6.f;
-          } else if (p.relu == 3) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : sl * v[k];
-          }
-          uint32_t hb[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) hb[k] = f32_to_bf16(v[k]);
-          bf16_t* op = p.out + pix * p.out_cstride + p.out_coff + ch;
-          u32x2 o = {hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
-          *reinterpret_cast<u32x2*>(op) = o;
-          if (p.split) {
-            uint32_t lb[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) lb[k] = f32_to_bf16(v[k] - bf16_to_f32(hb[k]));
-            u32x2 ol = {lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16)};
-            *reinterpret_cast<u32x2*>(op + p.out_lo_off) = ol;
-          }
-        }
-    }
-    continue;
-  }
   // ---- epilogue through LDS (fp32 [pixel][64]) ----
   __syncthreads();
   float* stage = reinterpret_cast<float*>(smem);
@@ -556,157 +487,6 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
   __syncthreads();
   epilogue_store<C::TH, C::TW>(p, stage, tid, b, oy0, ox0, nt * 64);
   }   // rep
-}
-
-// ---------------------------------------------------------------------------------------------------
-// 3x3 stride-1 convolution, LDS-DMA pipeline ("v2").  Same math and epilogue as conv_igemm_kernel<3,1>, but
-//   * 8 waves / workgroup, 16x32 output patch x 64 channels: the 36 KB weight slice is shared by twice as many pixels
-//   * both operands go global -> LDS with global_load_lds (16 B per lane, no VGPR staging, no ds_write);
-//     the LDS images are un-padded 64-byte rows with the 16-byte slots XOR-swizzled by ((row >> 2) & 3), applied on
-//     the SOURCE address of the DMA and again on the ds_read address (conflict-free for any 16 lanes whose row indices
-//     are distinct mod 16)
-//   * two LDS buffers: the DMA of K-slice c+1 flies while slice c is multiplied; one barrier per slice
-//   * halo pixels outside the image read a zero page instead of being predicated
-// ---------------------------------------------------------------------------------------------------
-struct DmaCfg {
-  static constexpr int TH = 16, TW = 32, NTHR = 512;
-  static constexpr int THIN = TH + 2, TWIN = TW + 2;       // 18 x 34
-  static constexpr int NPIX = THIN * TWIN;                 // 612
-  static constexpr int IN_BYTES = NPIX * 64;               // 39168
-  static constexpr int W_BYTES = 9 * 64 * 64;              // 36864
-  static constexpr int BUF_BYTES = IN_BYTES + W_BYTES;     // 76032
-  static constexpr int STAGE_BYTES = TH * TW * 64 * 4;     // 131072
-  static constexpr int SMEM = 2 * BUF_BYTES;               // 152064 >= STAGE_BYTES
-  static constexpr int IN_UNITS = NPIX * 4;                // 2448 16-byte units
-  static constexpr int IN_INSTR = (IN_UNITS + 63) / 64;    // 39 wave-instructions
-  static constexpr int W_INSTR = 9 * 64 * 4 / 64;          // 36
-  static constexpr int IN_SLOTS = (IN_INSTR + 7) / 8;      // per wave: 5
-  static constexpr int W_SLOTS = (W_INSTR + 7) / 8;        // per wave: 5
-};
-
-__global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(ConvK p, const bf16_t* __restrict__ zero_page) {
-  using C = DmaCfg;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lx = lane & 31, qh = lane >> 5;
-
-  int L = xcd_remap(blockIdx.x, gridDim.x);
-  const int nt = L % p.n_tiles;
-  L /= p.n_tiles;
-  const int txi = L % p.tiles_x;
-  L /= p.tiles_x;
-  const int tyi = L % p.tiles_y;
-  const int b = L / p.tiles_y;
-  const int oy0 = tyi * C::TH, ox0 = txi * C::TW;
-  const int nchunks = p.split ? 3 * (p.Cin >> 5) : (p.Cin >> 5);
-  const int in_cs = p.split ? 2 * p.Cin : p.Cin;
-  const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * in_cs;
-  const bf16_t* wt = p.w + (size_t)nt * nchunks * (9 * 64 * 32);
-
-  // per-wave DMA slots: input unit U = (wave + 8 j) * 64 + lane -> pixel U >> 2, LDS slot U & 3
-  const bf16_t* src_in[C::IN_SLOTS];
-  bool on_in[C::IN_SLOTS];
-#pragma unroll
-  for (int j = 0; j < C::IN_SLOTS; ++j) {
-    const int k = wave + 8 * j;
-    const int U = k * 64 + lane;
-    on_in[j] = (k < C::IN_INSTR) && (U < C::IN_UNITS);
-    const int pix = U >> 2;
-    const int q = (U & 3) ^ ((pix >> 2) & 3);
-    const int iy = pix / C::TWIN, ix = pix - iy * C::TWIN;
-    const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
-    const bool inside = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-    src_in[j] = inside ? in_b + ((size_t)gy * p.W + gx) * in_cs + q * 8 : zero_page;
-  }
-  int src_w[C::W_SLOTS];
-#pragma unroll
-  for (int j = 0; j < C::W_SLOTS; ++j) {
-    const int U = (wave + 8 * j) * 64 + lane;   // row = U >> 2 (tap * 64 + n), slot = U & 3
-    const int row = U >> 2;
-    src_w[j] = row * 32 + (((U & 3) ^ ((row >> 2) & 3)) * 8);
-  }
-
-  auto issue = [&](int chunk, int buf) {
-    int c0 = chunk << 5;
-    if (c0 >= in_cs) c0 -= in_cs;
-    char* lds_in = smem + buf * C::BUF_BYTES;
-    char* lds_w = lds_in + C::IN_BYTES;
-    const bf16_t* wc = wt + (size_t)chunk * (9 * 64 * 32);
-#pragma unroll
-    for (int j = 0; j < C::IN_SLOTS; ++j) {
-      if (on_in[j])
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_in[j] + c0),
-                                         (__attribute__((address_space(3))) void*)(lds_in + (wave + 8 * j) * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < C::W_SLOTS; ++j) {
-      if (wave + 8 * j < C::W_INSTR)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wc + src_w[j]),
-                                         (__attribute__((address_space(3))) void*)(lds_w + (wave + 8 * j) * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-
-  // A fragment of row-tile m, tap (r, s), k-half kk: pixel pa = (2 wave + m + r) * 34 + lx + s
-  const int pa0 = (2 * wave) * C::TWIN + lx;
-  const int gl = (lx >> 2) & 3;
-  const int boff0 = lx * 64 + (((0 + qh) ^ gl) << 4);   // kk = 0 : slot kk*2 + qh
-  const int boff1 = lx * 64 + (((2 + qh) ^ gl) << 4);   // kk = 1
-
-  issue(0, 0);
-  for (int c = 0; c < nchunks; ++c) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (c + 1 < nchunks) issue(c + 1, (c + 1) & 1);
-    const char* s_in = smem + (c & 1) * C::BUF_BYTES;
-    const char* s_w = s_in + C::IN_BYTES;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int tap = r * 3 + s;
-        const int pa[2] = {pa0 + r * C::TWIN + s, pa0 + (1 + r) * C::TWIN + s};
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const int bo = kk ? boff1 : boff0;
-          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(s_w + (tap * 64) * 64 + bo);
-          const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(s_w + (tap * 64 + 32) * 64 + bo);
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            const int pp = pa[m];
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(s_in + pp * 64 + (((kk * 2 + qh) ^ ((pp >> 2) & 3)) << 4));
-            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
-            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
-          }
-        }
-      }
-    }
-  }
-
-  __syncthreads();
-  float* stage = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int pbase = (2 * wave + m) * C::TW;
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int tx = (r & 3) + 8 * (r >> 2) + 4 * qh;
-        stage[(pbase + tx) * 64 + n * 32 + lx] = acc[m][n][r];
-      }
-  }
-  __syncthreads();
-  epilogue_store<C::TH, C::TW, C::NTHR>(p, stage, tid, b, oy0, ox0, nt * 64);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -877,230 +657,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma16_kernel(ConvK p, const bf
 // K is laid out [r=7][s=8][c=4] = 224 (tap s=7 and channel 3 carry zero weights), so that one MFMA
 // k-step (16) = 4 horizontally adjacent pixels x 4 channels = 32 contiguous bytes of the image row.
 // ---------------------------------------------------------------------------------------------------
-// ---------------------------------------------------------------------------------------------------------------------
-// 1x1 convolution as a plain GEMM over the flat pixel list, for large M: 256 pixels x 128 output channels per workgroup
-// (8 waves, each 64 x 64 = 2 x 2 MFMA tiles), K walked in 64-channel chunks (144-byte LDS rows), next chunk prefetched to
-// VGPRs.  Twice the arithmetic intensity of the 128 x 64 tiles of conv_igemm_kernel<1,1> (85 vs 43 FLOP per L2 byte), which
-// is what the CRNN classifier (M = lines x 160, K = 512, N = 7680), the LSTM input projections and the Lore / PicoDet
-// point-wise layers need.  Same weight tiling ([N/64][K/32][64][32]) and the same epilogue_store (two 64-column passes).
-// ---------------------------------------------------------------------------------------------------------------------
-struct GemmCfg {
-  static constexpr int TM = 256, TN = 128, NTHR = 512, ROW = 144;
-  static constexpr int A_BYTES = TM * ROW, W_BYTES = TN * ROW;      // 36864 + 18432
-  static constexpr int STAGE_BYTES = TM * 64 * 4;                   // 65536: one 64-column half of the tile in fp32
-  static constexpr int SMEM = STAGE_BYTES > (A_BYTES + W_BYTES) ? STAGE_BYTES : (A_BYTES + W_BYTES);
-};
-
-__global__ __launch_bounds__(512, 2) void gemm1x1_kernel(ConvK p) {
-  using C = GemmCfg;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* s_a = smem;
-  char* s_w = smem + C::A_BYTES;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lx = lane & 31, q = lane >> 5;
-  const int wm = wave & 3, wn = wave >> 2;
-  int L = xcd_remap(blockIdx.x, gridDim.x), nt;  // nt: 128-wide column tile
-  tile_order(L, p.gemm_nt, p.n_group, nt, L);
-  const long long m0 = (long long)L * C::TM;
-  const int nchunks = p.split ? 3 * (p.Cin >> 6) : (p.Cin >> 6);
-  const int in_cs = p.split ? 2 * p.Cin : p.Cin;
-  const int nk32 = p.split ? 3 * (p.Cin >> 5) : (p.Cin >> 5);          // 32-channel weight chunks per 64-row tile
-  const bf16_t* wt = p.w + (size_t)(nt * 2) * nk32 * (64 * 32);
-
-  u32x4 ra[4], rw[2];
-  auto prefetch = [&](int chunk) {
-    int c0 = chunk << 6;
-    if (c0 >= in_cs) c0 -= in_cs;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int idx = tid + j * 512, row = idx >> 3, part = idx & 7;
-      const long long m = m0 + row;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (m < p.m_flat) v = *reinterpret_cast<const u32x4*>(p.in + (size_t)m * in_cs + c0 + part * 8);
-      ra[j] = v;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int idx = tid + j * 512, row = idx >> 3, part = idx & 7;       // row 0..127, part 0..7 (0-3: chunk 2c, 4-7: 2c+1)
-      rw[j] = *reinterpret_cast<const u32x4*>(wt + (size_t)(row >> 6) * nk32 * (64 * 32) +
-                                              (size_t)(2 * chunk + (part >> 2)) * (64 * 32) + (row & 63) * 32 + (part & 3) * 8);
-    }
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int idx = tid + j * 512;
-      *reinterpret_cast<u32x4*>(s_a + (idx >> 3) * C::ROW + (idx & 7) * 16) = ra[j];
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int idx = tid + j * 512;
-      *reinterpret_cast<u32x4*>(s_w + (idx >> 3) * C::ROW + (idx & 7) * 16) = rw[j];
-    }
-  };
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-  const char* a_rd = s_a + (wm * 64 + lx) * C::ROW + q * 16;
-  const char* b_rd = s_w + (wn * 64 + lx) * C::ROW + q * 16;
-  prefetch(0);
-  for (int c = 0; c < nchunks; ++c) {
-    __syncthreads();
-    commit();
-    __syncthreads();
-    if (c + 1 < nchunks) prefetch(c + 1);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(a_rd + kk * 32);
-      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(a_rd + 32 * C::ROW + kk * 32);
-      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(b_rd + kk * 32);
-      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(b_rd + 32 * C::ROW + kk * 32);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-    }
-  }
-  // ---- epilogue: the two 64-column halves one after the other through the fp32 stage [256 pixels][64]
-  float* stage = reinterpret_cast<float*>(smem);
-  const int oy0 = (int)(m0 >> 5);
-  for (int h = 0; h < 2; ++h) {
-    __syncthreads();
-    if (wn == h) {
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
-            stage[row * 64 + n * 32 + lx] = acc[m][n][r];
-          }
-    }
-    __syncthreads();
-    epilogue_store<8, 32, 512>(p, stage, tid, 0, oy0, 0, nt * 128 + h * 64);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// The same 256 x 128 GEMM with an LDS-DMA ring: K in 32-channel chunks, each a 24 KB stage (A 256 x 64 B + W 128 x 64 B,
-// un-padded rows, 16-byte slots XOR-swizzled by (row >> 2) & 3 on the DMA source address and again on the ds_read
-// address), RING stages deep.  Every wave issues its 3 global_load_lds of stage c + RING - 1 right after the barrier of
-// iteration c, so RING - 1 stages (96 KB at RING = 5) are in flight while one is multiplied -- the register-staged
-// kernels keep one chunk in flight and are bound by the loaded L2 latency on K-short, 1x1-type layers.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int RING>
-__global__ __launch_bounds__(512, 1) void gemm1x1_dma_kernel(ConvK p, const bf16_t* __restrict__ zero_page) {
-  constexpr int STAGE = 24576;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lx = lane & 31, q = lane >> 5;
-  const int wm = wave & 3, wn = wave >> 2;
-  int L = xcd_remap(blockIdx.x, gridDim.x), nt;
-  tile_order(L, p.gemm_nt, p.n_group, nt, L);
-  const long long m0 = (long long)L * 256;
-  const int nchunks = p.split ? 3 * (p.Cin >> 5) : (p.Cin >> 5);
-  const int in_cs = p.split ? 2 * p.Cin : p.Cin;
-  const bf16_t* wt = p.w + (size_t)(nt * 2) * nchunks * (64 * 32);
-
-  // DMA instruction k = wave + 8 j (j = 0, 1: A rows 16 k .. 16 k + 15; j = 2: W rows 16 (k - 16) ..)
-  const bf16_t* src_a[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = 16 * (wave + 8 * j) + (lane >> 2);
-    const int slot = (lane & 3) ^ ((row >> 2) & 3);
-    const long long m = m0 + row;
-    src_a[j] = m < p.m_flat ? p.in + (size_t)m * in_cs + slot * 8 : zero_page;
-  }
-  const bool a_live[2] = {m0 + 16 * wave + (lane >> 2) < p.m_flat, m0 + 16 * (wave + 8) + (lane >> 2) < p.m_flat};
-  int src_w;
-  {
-    const int row = 16 * wave + (lane >> 2);              // 0 .. 127
-    const int slot = (lane & 3) ^ ((row >> 2) & 3);
-    src_w = (row >> 6) * nchunks * (64 * 32) + (row & 63) * 32 + slot * 8;
-  }
-  auto issue = [&](int chunk, int slot_i) {
-    int c0 = chunk << 5;
-    if (c0 >= in_cs) c0 -= in_cs;
-    char* st = smem + slot_i * STAGE;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_a[j] + (a_live[j] ? c0 : 0)),
-                                       (__attribute__((address_space(3))) void*)(st + (wave + 8 * j) * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt + (size_t)chunk * (64 * 32) + src_w),
-                                     (__attribute__((address_space(3))) void*)(st + 16384 + wave * 1024), 16, 0, 0);
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-  // fragment addresses inside a stage (row r, 16-byte slot s -> r * 64 + ((s ^ ((r >> 2) & 3)) << 4))
-  int a_off[2][2], b_off[2][2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int ra = wm * 64 + t * 32 + lx, rb = wn * 64 + t * 32 + lx;
-      a_off[t][kk] = ra * 64 + (((kk * 2 + q) ^ ((ra >> 2) & 3)) << 4);
-      b_off[t][kk] = 16384 + rb * 64 + (((kk * 2 + q) ^ ((rb >> 2) & 3)) << 4);
-    }
-
-#pragma unroll
-  for (int st = 0; st < RING - 1; ++st)
-    if (st < nchunks) issue(st, st);
-  for (int c = 0; c < nchunks; ++c) {
-    if (c + RING - 2 < nchunks) {
-      // stages c+1 .. c+RING-2 (3 DMA instructions each) may still be in flight
-      if (RING == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else if (RING == 5) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    if (c + RING - 1 < nchunks) issue(c + RING - 1, (c + RING - 1) % RING);
-    const char* st = smem + (c % RING) * STAGE;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(st + a_off[0][kk]);
-      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(st + a_off[1][kk]);
-      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(st + b_off[0][kk]);
-      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(st + b_off[1][kk]);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-    }
-  }
-  float* stage = reinterpret_cast<float*>(smem);
-  const int oy0 = (int)(m0 >> 5);
-  for (int h = 0; h < 2; ++h) {
-    __syncthreads();
-    if (wn == h) {
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
-            stage[row * 64 + n * 32 + lx] = acc[m][n][r];
-          }
-    }
-    __syncthreads();
-    epilogue_store<8, 32, 512>(p, stage, tid, 0, oy0, 0, nt * 128 + h * 64);
-  }
-}
-
 template <int S>
 struct StemCfg {
   static constexpr int TH = 8, TW = 32;
@@ -1317,28 +873,15 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_thin_kernel(ConvK p) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// PT_REG_EPI=1 opts the plain layers into the register epilogue.  Measured on MI355X (four-stage bench, round 1): no gain --
-// 3x3 class 470.9 -> 473.1 ms, 1x1 class 244.3 -> 251.1 ms, det-only 3917 -> 3779 pages/s: the 8-byte channel-run stores
-// (32 partial lines per wave instruction) cost what the fp32 LDS round trip saved.  Default: LDS epilogue (16-byte stores).
-static bool use_reg_epilogue() {
-  static int v = -1;
-  if (v < 0) {
-    const char* s = getenv("PT_REG_EPI");
-    v = s ? atoi(s) : 0;
-  }
-  return v != 0;
-}
-
 static void launch_half(ConvK& k, unsigned nblk, hipStream_t s) {
   using C = ConvCfg<3, 1, 0>;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<3, 1, 0, false, 1>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<3, 1, 0, 1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<3, 1, 0, false, 1>), dim3(nblk), dim3(256), C::SMEM, s, k);
+  hipLaunchKernelGGL((conv_igemm_kernel<3, 1, 0, 1>), dim3(nblk), dim3(256), C::SMEM, s, k);
 }
 
 template <int KS, int STRIDE, int GEOM = 0>
@@ -1346,14 +889,10 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   using C = ConvCfg<KS, STRIDE, GEOM>;
   static bool attr_done = false;
   if (!attr_done) {
-    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<KS, STRIDE, GEOM, false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
-    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<KS, STRIDE, GEOM, true>),
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<KS, STRIDE, GEOM>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
     attr_done = true;
   }
-  // plain layer: bias [+ residual] [+ activation] -> bf16 NHWC, nothing fused behind it
-  const bool plain = !k.head_w && !k.argmax_part && !k.shuffle_cout && !k.out_f32 && !k.res_f32 && !k.m_flat && k.rep == 1 && !k.pool;
   k.tiles_x = (k.Wo + C::TW - 1) / C::TW;
   k.tiles_y = (k.Ho + C::TH - 1) / C::TH;
   k.n_tiles = k.N / 64;
@@ -1372,10 +911,8 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
     PtProfScope prof(e, s, KS == 3 ? PT_PROF_CONV3X3 : PT_PROF_CONV1X1, flop, label);
     if (KS == 3 && STRIDE == 1 && GEOM == 0 && k.n_valid > 0 && k.n_valid <= 32 && k.N == 64 && !k.split && !k.pool && !k.head_w && !k.argmax_part)
       launch_half(k, (unsigned)nblk, s);      // <= 32 real output channels: half-width variant
-    else if (plain && use_reg_epilogue())
-      hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, GEOM, true>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
     else
-      hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, GEOM, false>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
+      hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, GEOM>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
     if ((k.ylimit || k.xcols) && prof.idx >= 0 && e->prof.h_lims && e->prof.n_lims < PtProfile::MAX_LIMS) {
       // the launch covers the worst case and stops at a device-side row limit (or per-image column limits): remember
       // where the limit will land
@@ -1440,89 +977,6 @@ static int conv_variant() {
   return v;
 }
 
-static int launch_dma(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
-  using C = DmaCfg;
-  static bool attr_done = false;
-  if (!attr_done) {
-    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
-    attr_done = true;
-  }
-  if (!e->zero_page) {
-    PT_HIP_CHECK(hipMalloc(&e->zero_page, 8192));
-    PT_HIP_CHECK(hipMemset(e->zero_page, 0, 8192));
-  }
-  k.tiles_x = (k.Wo + C::TW - 1) / C::TW;
-  k.tiles_y = (k.Ho + C::TH - 1) / C::TH;
-  k.n_tiles = k.N / 64;
-  const long long nblk = (long long)k.B * k.tiles_x * k.tiles_y * k.n_tiles;
-  PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range (%lld blocks)", nblk);
-  char label[48];
-  snprintf(label, sizeof(label), "conv3x3 dma %d->%d @%dx%d%s", k.Cin, k.N, k.Ho, k.Wo, k.split ? " x3" : "");
-  PtProfScope prof(e, s, PT_PROF_CONV3X3, flop, label);
-  hipLaunchKernelGGL(conv3x3_dma_kernel, dim3((unsigned)nblk), dim3(C::NTHR), C::SMEM, s, k,
-                     reinterpret_cast<const bf16_t*>(e->zero_page));
-  PT_HIP_CHECK(hipGetLastError());
-  return PT_OK;
-}
-
-// PT_GEMM1X1=1 / 2 route large 1x1 convolutions to gemm1x1_kernel / gemm1x1_dma_kernel (256 x 128 tiles; register-staged or
-// a 5-stage LDS-DMA ring).  Off by default: on MI355X neither beats conv_igemm_kernel<1,1> (classifier 512 -> 7680,
-// M = 655 k: 10.5 / 11.7 ms vs 9.9 ms) -- all three sit at ~500 TFLOP/s.  Ablation of the ring kernel (timing only): without
-// DMA 9.3 ms, without epilogue 7.5 ms, without both 5.2 ms (ideal 2.7 ms): the fp32-through-LDS epilogue costs ~35 % of a
-// K = 512 tile and the fragment loop itself runs at ~60 %; a register-level bf16 epilogue is the next step, not more
-// prefetch.  The L2-aware column grouping (tile_order) is worth 4 % on the classifier and is on.
-static int gemm_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* s = getenv("PT_GEMM1X1");
-    v = s ? atoi(s) : 0;
-  }
-  return v;
-}
-
-static int launch_gemm1x1(pt_engine* e, ConvK k, hipStream_t s, double flop) {
-  using C = GemmCfg;
-  static bool attr_done = false;
-  if (!attr_done) {
-    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1x1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     C::SMEM));
-    attr_done = true;
-  }
-  const long long M = (long long)k.B * k.Ho * k.Wo;
-  char label[48];
-  snprintf(label, sizeof(label), "gemm1x1 %d->%d M=%lld%s", k.Cin, k.N, M, k.split ? " x3" : "");
-  // flat geometry for epilogue_store: one "image" of ceil(M / 32) rows x 32 pixels
-  k.m_flat = M;
-  k.B = 1; k.Ho = (int)((M + 31) / 32); k.Wo = 32;
-  k.n_tiles = k.N / 64;
-  k.gemm_nt = k.N / C::TN;
-  k.n_group = k.n_group / 2;        // groups were sized in 64-column tiles
-  const long long nblk = ((M + C::TM - 1) / C::TM) * k.gemm_nt;
-  PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "gemm grid out of range (%lld blocks)", nblk);
-  PtProfScope prof(e, s, PT_PROF_CONV1X1, flop, label);
-  if (gemm_variant() >= 2) {
-    constexpr int RING = 5;
-    static bool attr2 = false;
-    if (!attr2) {
-      PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1x1_dma_kernel<RING>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, RING * 24576));
-      attr2 = true;
-    }
-    if (!e->zero_page) {
-      PT_HIP_CHECK(hipMalloc(&e->zero_page, 8192));
-      PT_HIP_CHECK(hipMemset(e->zero_page, 0, 8192));
-    }
-    hipLaunchKernelGGL(gemm1x1_dma_kernel<RING>, dim3((unsigned)nblk), dim3(512), RING * 24576, s, k,
-                       reinterpret_cast<const bf16_t*>(e->zero_page));
-    PT_HIP_CHECK(hipGetLastError());
-    return PT_OK;
-  }
-  hipLaunchKernelGGL(gemm1x1_kernel, dim3((unsigned)nblk), dim3(C::NTHR), C::SMEM, s, k);
-  PT_HIP_CHECK(hipGetLastError());
-  return PT_OK;
-}
-
 int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   PT_REQUIRE(d.in && d.w && d.bias && (d.out || d.out_f32 || d.head_w || d.argmax_part), "conv: null pointer");
   PT_REQUIRE(d.Cin % 32 == 0 && d.Cin > 0, "conv: Cin=%d must be a positive multiple of 32", d.Cin);
@@ -1566,15 +1020,11 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
     // (v1) on short-K layers and on small maps, where the big DMA tiles leave CUs idle
     const int cv = conv_variant();
     const bool v3ok = (d.N % 128 == 0) ? k.Ho >= 12 : k.Ho >= 24;
-    const bool v2ok = k.Ho >= 16;
     const bool wide = d.Cin >= 128;
     int pick = 0;
     if (cv == 3 && v3ok) pick = 3;
-    else if (cv == 2 && v2ok) pick = 2;
     else if (cv == 1 && wide && k.Ho >= 120) pick = 3;
-    else if (cv == 1 && wide && k.Ho >= 60) pick = 2;
     if (pick == 3) return d.N % 128 == 0 ? launch_dma16<2>(e, k, s, flop) : launch_dma16<1>(e, k, s, flop);
-    if (pick == 2) return launch_dma(e, k, s, flop);
   }
   if (d.ks == 3 && d.stride == 1 && k.Ho <= 4 && k.Wo > 32) return launch_cfg<3, 1, 1>(e, k, s, flop);
   if (d.ks == 3 && d.stride == 1) return launch_cfg<3, 1>(e, k, s, flop);
@@ -1588,9 +1038,6 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
     if (g < 1) g = ng_env == 0 ? 0 : 1;
     k.n_group = g;
   }
-  if (d.ks == 1 && d.stride == 1 && gemm_variant() && !d.ylimit && d.Cin % 64 == 0 && d.N % 128 == 0 && d.rep == 1 && !d.shuffle_cout &&
-      !d.head_w && k.res_mode != 2 && (long long)k.B * k.Ho * k.Wo >= 16384)
-    return launch_gemm1x1(e, k, s, flop);
   if (d.ks == 1 && d.stride == 1) return launch_cfg<1, 1>(e, k, s, flop);
   return launch_cfg<1, 2>(e, k, s, flop);
 }
