@@ -218,3 +218,26 @@ def test_pipeline_recogniser_on_second_stream_changes_nothing():
             for ta, tb_ in zip(a.table_structure_result, b.table_structure_result):
                 assert np.array_equal(ta["polygons"], tb_["polygons"]) and np.array_equal(ta["logi"], tb_["logi"])
                 assert ta.get("table_html") == tb_.get("table_html")
+
+
+def test_ocr_system_task_call_shape():
+    """OcrSystemTask(image) -> (OcrSystemModelOutput, metric) with the reference's field names (ocr_output.py:25-50); the
+    merged table-structure dict of convert_table_sep_to_merge; a PDF input raises"""
+    from pdf_table_amd.ocr_system_task import OcrSystemModelOutput, OcrSystemTask
+    task = OcrSystemTask(synthetic_seed=0)
+    page = make_page(4)[0]
+    out, metric = task(page, src_id=7, page=3)
+    assert isinstance(out, OcrSystemModelOutput) and out.src_id == 7 and out.page == 3 and out.is_pdf is False
+    assert list(out.image_shape) == [1024, 1024, 3] and isinstance(metric, dict) and "use_time" in metric
+    assert out.det_result.shape[1] == 8 and len(out.ocr_result) == len(out.det_result)
+    assert all(set(o) == {"index", "text", "bbox"} and o["bbox"].shape == (4, 2) for o in out.ocr_result)
+    assert isinstance(out.layout_result, list) and out.image_rotate in (True, False)
+    ts = out.table_structure_result
+    assert set(ts) >= {"polygons", "structure_str_list", "logi", "polygons_sep", "logi_sep"}
+    assert ts["polygons"].shape[1] == 8 and len(ts["polygons"]) == len(ts["logi"]) <= sum(len(p_) for p_ in ts["polygons_sep"])
+    bb = out.get_table_structure_bboxs()
+    assert bb is ts["polygons"]
+    both = task.predict_pages([page, make_page(5)[0]])
+    assert len(both) == 2 and np.array_equal(both[0][0].det_result, out.det_result)
+    with pytest.raises(RuntimeError):
+        task("some/file.pdf")
