@@ -224,13 +224,20 @@ class HipEngine:
                                        self._stream()), "pt_tsr_decode")
         return (counts.cpu().numpy() if sync else counts), dets, logi
 
-    def tsr_forward_decode(self, x: torch.Tensor, wiz_rev: bool = True, vis_thresh: float = 0.2, sync: bool = True):
-        """DLA-34 forward + decode in one call (sparse ax / cr heads): x bf16 NHWC4 [n,H,W,4|8] -> the outputs of tsr_decode"""
+    def tsr_forward_decode(self, x: torch.Tensor, wiz_rev: bool = True, vis_thresh: float = 0.2, sync: bool = True, out=None):
+        """DLA-34 forward + decode in one call (sparse ax / cr heads): x bf16 NHWC4 [n,H,W,4|8] -> the outputs of tsr_decode.
+        out: (counts i32 [n] zeroed, dets f32 [n,3000,9], logi f32 [n,3000,256]) contiguous device tensors to write into
+        (slices of a larger allocation: several micro-batches then feed ONE processor call)"""
         self._chk(x, torch.bfloat16, "x")
         n, H, W, _ = x.shape
-        counts = torch.zeros((n,), dtype=torch.int32, device=self._tdev)
-        dets = torch.empty((n, L.PT_TSR_MAX_CELLS, 9), dtype=torch.float32, device=self._tdev)
-        logi = torch.empty((n, L.PT_TSR_MAX_CELLS, 256), dtype=torch.float32, device=self._tdev)
+        if out is not None:
+            counts, dets, logi = out
+            assert counts.shape == (n,) and dets.shape == (n, L.PT_TSR_MAX_CELLS, 9) and logi.shape == (n, L.PT_TSR_MAX_CELLS, 256)
+            assert counts.is_contiguous() and dets.is_contiguous() and logi.is_contiguous()
+        else:
+            counts = torch.zeros((n,), dtype=torch.int32, device=self._tdev)
+            dets = torch.empty((n, L.PT_TSR_MAX_CELLS, 9), dtype=torch.float32, device=self._tdev)
+            logi = torch.empty((n, L.PT_TSR_MAX_CELLS, 256), dtype=torch.float32, device=self._tdev)
         L.check(self.lib.pt_tsr_forward_decode(self._h, _ptr(x), n, H, W, int(wiz_rev), float(vis_thresh), _ptr(counts),
                                                _ptr(dets), _ptr(logi), self._stream()), "pt_tsr_forward_decode")
         return (counts.cpu().numpy() if sync else counts), dets, logi

@@ -190,15 +190,27 @@ class TsrStage:
         # balanced micro-batches (87 tables at micro_batch 80 -> 44 + 43, not 80 + 7: a 7-table launch leaves most CUs idle)
         nmb = max(1, -(-len(tables) // self.micro_batch))
         size = -(-len(tables) // nmb) if len(tables) else 1
+        fused = cfg.backbone != "ResNet-18" and self.fused_decode
+        if fused and nmb > 1:
+            # all micro-batches decode into slices of one allocation, so that the processor (a chain of ~60 small launches)
+            # runs ONCE over all tables of the call instead of once per micro-batch
+            nt = len(tables)
+            dev = pages.device
+            counts_all = torch.zeros((nt,), dtype=torch.int32, device=dev)
+            dets_all = torch.empty((nt, L.PT_TSR_MAX_CELLS, 9), dtype=torch.float32, device=dev)
+            logi_all = torch.empty((nt, L.PT_TSR_MAX_CELLS, 256), dtype=torch.float32, device=dev)
         for i in range(0, len(tables), size):
             tb = tables[i:i + size]
             x = self.eng.tsr_preprocess(pages, tb, inp_h, inp_w, bgr=self.bgr)
-            if cfg.backbone != "ResNet-18" and self.fused_decode:      # one call, ax / cr heads only where the decode reads them
-                counts, dets, logi = self.eng.tsr_forward_decode(x, wiz_rev=cfg.wiz_rev, vis_thresh=cfg.vis_thresh, sync=False)
+            if fused:      # one call, ax / cr heads only where the decode reads them
+                out = (counts_all[i:i + len(tb)], dets_all[i:i + len(tb)], logi_all[i:i + len(tb)]) if nmb > 1 else None
+                counts, dets, logi = self.eng.tsr_forward_decode(x, wiz_rev=cfg.wiz_rev, vis_thresh=cfg.vis_thresh, sync=False, out=out)
             else:
                 heads = self.eng.tsr_forward_net(x, wireless=cfg.backbone == "ResNet-18")
                 counts, dets, logi = self.eng.tsr_decode(heads, wiz_rev=cfg.wiz_rev, vis_thresh=cfg.vis_thresh, sync=False)
             pending.append((i, len(tb), counts, dets, logi))
+        if fused and nmb > 1:
+            return [(0, len(tables), counts_all, dets_all, logi_all)]
         return pending
 
     def process(self, pending):
