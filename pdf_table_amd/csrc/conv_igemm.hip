@@ -317,7 +317,12 @@ struct ConvCfg {
   static constexpr int TWIN = (TW - 1) * STRIDE + KS;
   static constexpr int TAPS = KS * KS;
   static constexpr int XEVEN = (TWIN + 1) / 2;   // stride 2: number of even input columns of a patch row (stored first)
-  static constexpr int PIXB = 80;  // bytes per staged pixel / weight row: 32 bf16 + 16 B pad
+  // bytes per staged pixel / weight row: 32 bf16 + 16 B pad.  The stride-2 3x3 patch (9 x 65 pixels) plus its weight slice
+  // is 93 KB at that pitch -- ONE workgroup per CU, one wave per SIMD, nothing to hide the K-slice hand-over behind.  There
+  // the rows are un-padded (64 B) with the 16-byte slots XOR-swizzled by ((row >> 2) & 3) (conflict-free for 16 lanes on
+  // consecutive rows, like the DMA kernel's images): 74 KB, two workgroups per CU.
+  static constexpr bool SWZ = KS == 3 && STRIDE == 2;
+  static constexpr int PIXB = SWZ ? 64 : 80;
   static constexpr int IN_BYTES = THIN * TWIN * PIXB;
   static constexpr int W_BYTES = TAPS * 64 * PIXB;
   static constexpr int STAGE_BYTES = TH * TW * 64 * 4;
@@ -407,13 +412,13 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
           const int iy = slot / C::TWIN, ix = slot - iy * C::TWIN;   // are then CONSECUTIVE 80-byte slots, as at stride 1 --
           slot = iy * C::TWIN + (ix & 1) * C::XEVEN + (ix >> 1);      // no 2-pixel stride, no bank conflicts on ds_read_b128
         }
-        *reinterpret_cast<u32x4*>(s_in + slot * C::PIXB + (idx & 3) * 16) = rin[j];
+        *reinterpret_cast<u32x4*>(s_in + slot * C::PIXB + ((C::SWZ ? ((idx & 3) ^ ((slot >> 2) & 3)) : (idx & 3)) * 16)) = rin[j];
       }
     }
 #pragma unroll
     for (int j = 0; j < C::NWP; ++j) {
       const int idx = tid + j * 256;
-      *reinterpret_cast<u32x4*>(s_w + (idx >> 2) * C::PIXB + (idx & 3) * 16) = rw[j];
+      *reinterpret_cast<u32x4*>(s_w + (idx >> 2) * C::PIXB + ((C::SWZ ? ((idx & 3) ^ ((idx >> 4) & 3)) : (idx & 3)) * 16)) = rw[j];
     }
   };
 
@@ -427,12 +432,15 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
 
   // MFMA row-tile t = wave * MT + m covers patch row t / CT, columns (t % CT) * 32 .. + 31
   const char* a_base[C::MT];
+  int a_slot[C::MT];
 #pragma unroll
   for (int m = 0; m < C::MT; ++m) {
     const int t = wave * C::MT + m;
-    a_base[m] = s_in + ((((t / C::CT) * STRIDE) * C::TWIN + ((t % C::CT) * 32 + lx) * (STRIDE == 2 ? 1 : STRIDE)) * C::PIXB) + q * 16;
+    a_slot[m] = ((t / C::CT) * STRIDE) * C::TWIN + ((t % C::CT) * 32 + lx) * (STRIDE == 2 ? 1 : STRIDE);
+    a_base[m] = s_in + a_slot[m] * C::PIXB + (C::SWZ ? 0 : q * 16);
   }
-  const char* b_base = s_w + lx * C::PIXB + q * 16;
+  const char* b_base = s_w + lx * C::PIXB + (C::SWZ ? 0 : q * 16);
+  const int b_sw = (lx >> 2) & 3;      // SWZ: weight row tap * 64 (+ 32) + lx -> ((row >> 2) & 3) == ((lx >> 2) & 3) for every tap
 
   prefetch(0);
   for (int c = 0; c < nchunks; ++c) {
@@ -447,9 +455,10 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
         const int tap = r * KS + s;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(b_base + (tap * 64) * C::PIXB + kk * 32);
+          const int b_off = C::SWZ ? (((q + 2 * kk) ^ b_sw) * 16) : kk * 32;
+          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(b_base + (tap * 64) * C::PIXB + b_off);
           bf16x8 b1 = b0;
-          if (NHALF == 2) b1 = *reinterpret_cast<const bf16x8*>(b_base + (tap * 64 + 32) * C::PIXB + kk * 32);
+          if (NHALF == 2) b1 = *reinterpret_cast<const bf16x8*>(b_base + (tap * 64 + 32) * C::PIXB + b_off);
 #ifdef PT_SETPRIO
           __builtin_amdgcn_s_setprio(1);
 #endif
@@ -457,7 +466,8 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
           for (int m = 0; m < C::MT; ++m) {
             // stride 2: tap s reads input column 2*lx + s = slot lx (s = 0), XEVEN + lx (s = 1), lx + 1 (s = 2)
             const int soff = STRIDE == 2 ? ((s & 1) * C::XEVEN + (s >> 1)) : s;
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base[m] + (r * C::TWIN + soff) * C::PIXB + kk * 32);
+            const int a_off = C::SWZ ? (((q + 2 * kk) ^ (((a_slot[m] + r * C::TWIN + soff) >> 2) & 3)) * 16) : kk * 32;
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base[m] + (r * C::TWIN + soff) * C::PIXB + a_off);
             acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
             if (NHALF == 2) acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
           }
