@@ -160,6 +160,9 @@ struct ConvDesc {
   // number of columns below the limits summed over the images, tile-rounded (roofline accounting only)
   const int* xlimit = nullptr;
   const int* xlimit_cols = nullptr;
+  // the same for a [1, lines, T, C] view (1x1 GEMMs over the sequence): device int [H], limit of ROW oy; a tile of several
+  // rows is skipped when it lies right of all its rows' limits (rows with a smaller limit get values the caller overwrites)
+  const int* xlimit_rows = nullptr;
   // bf16x3 precision mode: in/res/out hold (hi | lo) channel groups; w is [N/64][3*Cin/32][taps][64][32]
   int split = 0;
   int out_lo_off = 0;  // channel distance between the hi and lo halves in the output buffer
@@ -230,21 +233,24 @@ int pt_launch_rec_pp_resize_norm(const uint8_t* crops, const pt_rec_line* lines,
 // per-layer column limits of the ragged CRNN conv stack (crnn_model.hip) from the lines' crop sizes, and the fill of the
 // columns a limited conv skipped with the activations an all-padding line has there
 struct PtCrnnLimits {
-  int* lim[5];        // device int [n] each: conv1, conv2a, conv2b, conv3a, conv3b output-column limits
-  int* cols;          // device int [5]: sum over lines of the tile-rounded limits
+  int* lim[6];        // device int [n] each: conv1, conv2a, conv2b, conv3a, conv3b output-column limits; [5]: conv0 (pooled columns)
+  int* cols;          // device int [8]: sum over lines of the tile-rounded limits ([5]: the sequence GEMMs, 32-step tiles)
 };
 int pt_launch_crnn_limits(const pt_rec_line* lines, int n, const PtCrnnLimits& L, hipStream_t s);
+// end_lim / end_tile: fill only up to column roundup(end_lim[b], end_tile) (inclusive: the halo column the next limited conv
+// reads); end_lim == null: to the end of the row
 int pt_launch_crnn_fill(bf16_t* out, const bf16_t* ref, const int* lim, int tile_w, int div, int n, int rows, int W, int cs,
-                        hipStream_t s);
+                        hipStream_t s, const int* end_lim = nullptr, int end_tile = 1);
 int pt_launch_crnn_conv0_pool(const bf16_t* in, int n, int H, int W, const float* w64x9, const float* bias, int split,
-                              bf16_t* out, hipStream_t s);
+                              bf16_t* out, hipStream_t s, const int* xlim = nullptr);
 int pt_launch_maxpool_kxk(const bf16_t* in, int n, int H, int W, int C, int kh, int kw, int h2c, int split, bf16_t* out,
                           hipStream_t s);
 int pt_launch_lstm(pt_engine* e, const bf16_t* gx, const bf16_t* whh, bf16_t* hout, int B, int T, int split, hipStream_t s);
 int pt_launch_gemm_argmax(const bf16_t* A, long long M, int K, const bf16_t* W, const float* bias, int N, int* ids, float* maxv,
                           hipStream_t s);
+// tlim != null: rows are (line, t) with T = 160 steps per line; 32-step groups at t0 >= tlim[line] are not computed
 int pt_launch_gemm_rows(const bf16_t* A, long long M, int K, const bf16_t* W, const float* bias, int N, bf16_t* out, int relu,
-                        hipStream_t s);
+                        hipStream_t s, const int* tlim = nullptr);
 int pt_launch_argmax_reduce(const float* part, long long rows, int ntiles, int* ids, float* maxv, hipStream_t s);
 // d_lines != null: the lines' crop sizes are known, so the conv stack does no work on the zero padding right of the text
 // (bit-identical results: skipped columns are filled with what an all-padding line has there)

@@ -63,6 +63,7 @@ struct ConvK {
   int reps, total_tiles;  // reps > 1: a workgroup walks reps consecutive tiles of total_tiles (see the kernel)
   const int* ylimit;      // device int: tiles whose first output row is >= *ylimit do nothing (data-dependent extents)
   const int* xlimit;      // device int [B]: tiles of image b whose first output column is >= xlimit[b] do nothing (ragged lines)
+  const int* xlimit_rows; // device int [Ho]: the same per output ROW (sequence views [1, lines, T, C])
   const int* xcols;       // host-side bookkeeping only (launch_cfg): ConvDesc.xlimit_cols
 };
 
@@ -369,6 +370,13 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
   const int oy0 = tyi * C::TH, ox0 = txi * C::TW;
   if (p.ylimit && oy0 >= *p.ylimit) break;         // uniform over the workgroup; later tiles of the walk are further down
   if (p.xlimit && ox0 >= p.xlimit[b]) continue;    // ragged image: this tile is all padding response, filled by the caller
+  if (p.xlimit_rows) {
+    int mx = 0;
+#pragma unroll
+    for (int r = 0; r < C::TH; ++r)
+      if (oy0 + r < p.Ho) mx = max(mx, p.xlimit_rows[oy0 + r]);
+    if (ox0 >= mx) continue;
+  }
   const int iy0 = oy0 * STRIDE - (KS / 2), ix0 = ox0 * STRIDE - (KS / 2);
   const int nchunks = p.split ? 3 * (p.Cin >> 5) : (p.Cin >> 5);
   const int in_cs = p.split ? 2 * p.Cin : p.Cin;   // channels per input pixel in memory
@@ -928,7 +936,7 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
       // where the limit will land
       auto& pd = e->prof.pending[prof.idx];
       pd.lim_slot = lim_slot = e->prof.n_lims++;
-      pd.rows = k.ylimit ? k.Ho : k.B * k.Wo;
+      pd.rows = k.ylimit ? k.Ho : (k.xlimit_rows ? k.Ho * k.Wo : k.B * k.Wo);
     }
   }
   if (lim_slot >= 0)      // behind the launch (and outside its event pair): the limit the kernel saw, to pinned memory
@@ -1009,7 +1017,8 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   k.Wo = (d.W + 2 * pad - d.ks) / d.stride + 1;
   k.out_cstride = d.out_cstride; k.out_coff = d.out_coff; k.rep = d.rep; k.shuffle_cout = d.shuffle_cout;
   k.res_mode = d.res ? d.res_mode : 0; k.relu = d.relu; k.slope = d.slope; k.ylimit = d.ylimit; k.pool = d.pool;
-  k.xlimit = d.xlimit; k.xcols = d.xlimit ? d.xlimit_cols : nullptr;
+  k.xlimit = d.xlimit; k.xlimit_rows = d.xlimit_rows; k.xcols = (d.xlimit || d.xlimit_rows) ? d.xlimit_cols : nullptr;
+  PT_REQUIRE(!d.xlimit_rows || (d.ks == 1 && d.stride == 1 && !d.ylimit && !d.xlimit), "conv: row-wise column limits need a 1x1 stride-1 layer");
   PT_REQUIRE(!d.xlimit || (d.ks == 3 && d.stride == 1 && !d.ylimit), "conv: column limits need a 3x3 stride-1 layer");
   PT_REQUIRE(!d.pool || (d.ks == 3 && d.stride == 1 && !d.res && !d.shuffle_cout && d.rep == 1 && !d.out_f32 && !d.argmax_part && !d.head_w && !d.n_valid && d.relu <= 1 && k.Ho % 2 == 0 && (d.pool != 1 || k.Wo % 2 == 0)),
              "conv: fused pooling needs a plain 3x3 stride-1 layer with even output size");

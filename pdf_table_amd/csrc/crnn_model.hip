@@ -44,7 +44,8 @@ inline const float* Bv(const PtTensor* t) { return reinterpret_cast<const float*
 namespace {
 struct ZeroLine {
   static constexpr size_t GRAY = 0, A0 = GRAY + 32 * 640, P1 = A0 + 16 * 320 * 64, C2A = P1 + 8 * 160 * 128,
-                          P2 = C2A + 8 * 160 * 256, C3A = P2 + 4 * 160 * 256, P3 = C3A + 4 * 160 * 512, END = P3 + 160 * 1024;
+                          P2 = C2A + 8 * 160 * 256, C3A = P2 + 4 * 160 * 256, P3 = C3A + 4 * 160 * 512, F = P3 + 160 * 1024,
+                          GX = F + 160 * 512, END = GX + 160 * 2048;
 };
 }  // namespace
 
@@ -146,19 +147,21 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
     pool_fused = ev ? atoi(ev) : 1;
   }
   auto conv_stack = [&](const bf16_t* g, int nn, bf16_t* a0, bf16_t* a1, bf16_t* p1, bf16_t* c2a_o, bf16_t* c2b_o, bf16_t* p2,
-                        bf16_t* c3a_o, bf16_t* c3b_o, bf16_t* p3, const PtCrnnLimits* lim, const bf16_t* zl) -> int {
+                        bf16_t* c3a_o, bf16_t* c3b_o, bf16_t* p3, bf16_t* f_o, bf16_t* gx_o, const PtCrnnLimits* lim,
+                        const bf16_t* zl) -> int {
     auto limited = [&](ConvDesc c, int k) {
       if (lim) { c.xlimit = lim->lim[k]; c.xlimit_cols = lim->cols + k; }
       return c;
     };
-    auto fill = [&](bf16_t* out, size_t zoff, int k, int tile_w, int div, int rows, int Wd, int C) -> int {
+    // fill the columns layer k left, up to the last column the NEXT limited layer (limit kn, tile tn) reads; kn < 0: to the end
+    auto fill = [&](bf16_t* out, size_t zoff, int k, int tile_w, int div, int rows, int Wd, int C, int kn, int tn) -> int {
       if (!lim) return PT_OK;
       PtProfScope ps(e, s, PT_PROF_OTHER, 0, "crnn fill");
-      return pt_launch_crnn_fill(out, zl + zoff * m, lim->lim[k], tile_w, div, nn, rows, Wd, C * m, s);
+      return pt_launch_crnn_fill(out, zl + zoff * m, lim->lim[k], tile_w, div, nn, rows, Wd, C * m, s, kn >= 0 ? lim->lim[kn] : nullptr, tn);
     };
     {
       PtProfScope ps(e, s, PT_PROF_OTHER, 0, "crnn conv0+pool");
-      RUN(pt_launch_crnn_conv0_pool(g, nn, PT_REC_H, PT_REC_W, Bv(c0w), Bv(c0b), x3, a0, s));
+      RUN(pt_launch_crnn_conv0_pool(g, nn, PT_REC_H, PT_REC_W, Bv(c0w), Bv(c0b), x3, a0, s, lim && !x3 ? lim->lim[5] : nullptr));
     }
     // conv1 + pool(2,2) and conv2.3 + pool((2,1)): pooling in the conv epilogue (PT_POOL_FUSED=0: separate pool kernels,
     // which need the full maps: no column limits then)
@@ -166,33 +169,49 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
       ConvDesc c1d = limited(conv(a0, nn, 16, 320, 64, c1, 128, 3, p1, 1), 0);
       c1d.pool = 1;
       RUN(pt_launch_conv(e, c1d, s));
-      RUN(fill(p1, ZeroLine::P1, 0, 32, 2, 8, 160, 128));
+      RUN(fill(p1, ZeroLine::P1, 0, 32, 2, 8, 160, 128, 1, 32));
     } else {
       RUN(pt_launch_conv(e, conv(a0, nn, 16, 320, 64, c1, 128, 3, a1, 1), s));
       RUN(pt_launch_maxpool_kxk(a1, nn, 16, 320, 128, 2, 2, 0, x3, p1, s));
     }
     RUN(pt_launch_conv(e, limited(conv(p1, nn, 8, 160, 128, c2a, 256, 3, c2a_o, 1), 1), s));
-    RUN(fill(c2a_o, ZeroLine::C2A, 1, 32, 1, 8, 160, 256));
+    RUN(fill(c2a_o, ZeroLine::C2A, 1, 32, 1, 8, 160, 256, 2, 32));
     if (pool_fused) {
       ConvDesc c2d = limited(conv(c2a_o, nn, 8, 160, 256, c2b, 256, 3, p2, 1), 2);
       c2d.pool = 2;
       RUN(pt_launch_conv(e, c2d, s));
-      RUN(fill(p2, ZeroLine::P2, 2, 32, 1, 4, 160, 256));
+      RUN(fill(p2, ZeroLine::P2, 2, 32, 1, 4, 160, 256, 3, 64));
     } else {
       RUN(pt_launch_conv(e, conv(c2a_o, nn, 8, 160, 256, c2b, 256, 3, c2b_o, 1), s));
       RUN(pt_launch_maxpool_kxk(c2b_o, nn, 8, 160, 256, 2, 1, 0, x3, p2, s));
     }
     RUN(pt_launch_conv(e, limited(conv(p2, nn, 4, 160, 256, c3a, 512, 3, c3a_o, 1), 3), s));
-    RUN(fill(c3a_o, ZeroLine::C3A, 3, 64, 1, 4, 160, 512));
+    RUN(fill(c3a_o, ZeroLine::C3A, 3, 64, 1, 4, 160, 512, 4, 64));
     if (pool_fused) {
       ConvDesc c3d = limited(conv(c3a_o, nn, 4, 160, 512, c3b, 512, 3, p3, 1), 4);
       c3d.pool = 3;          // (2,1) pool, rows -> channel groups: [n][160][2 * 512]
-      RUN(pt_launch_conv(e, c3d, s));
-      RUN(fill(p3, ZeroLine::P3, 4, 64, 1, 1, 160, 1024));
+      RUN(pt_launch_conv(e, c3d, s));      // p3 needs no fill: conv4 below is per position and limited the same way
     } else {
       RUN(pt_launch_conv(e, conv(c3a_o, nn, 4, 160, 512, c3b, 512, 3, c3b_o, 1), s));
       RUN(pt_launch_maxpool_kxk(c3b_o, nn, 4, 160, 512, 2, 1, /*h2c=*/1, x3, p3, s));
     }
+    // conv4 ((2,1) kernel = 1x1 GEMM over [1, nn, 160, 1024]) and the first LSTM's input projection: per time step, so right of
+    // the text they give the all-padding line's values too; computed in 32-step groups up to the conv3b limit, and only the
+    // projection's output -- which the recurrence reads at every step -- is filled
+    {
+      ConvDesc c4d = conv(p3, 1, nn, T, 1024, c4, 512, 1, f_o, 1);
+      if (lim) { c4d.xlimit_rows = lim->lim[4]; c4d.xlimit_cols = lim->cols + 5; }
+      RUN(pt_launch_conv(e, c4d, s));
+    }
+    if (!x3 && fused) {
+      PtProfScope ps(e, s, PT_PROF_CONV1X1, 2.0 * nn * T * 512.0 * 2048, "rows gemm 512->2048");
+      RUN(pt_launch_gemm_rows(f_o, (long long)nn * T, 512, W(xp1.w), Bv(xp1.b), 2048, gx_o, 0, s, lim ? lim->lim[4] : nullptr));
+    } else {
+      ConvDesc xd = conv(f_o, 1, nn, T, 512, xp1, 2048, 1, gx_o, 0);
+      if (lim) { xd.xlimit_rows = lim->lim[4]; xd.xlimit_cols = lim->cols + 5; }
+      RUN(pt_launch_conv(e, xd, s));
+    }
+    RUN(fill(gx_o, ZeroLine::GX, 4, 32, 1, 1, 160, 2048, -1, 1));
     return PT_OK;
   };
   // ragged path: the lines' sizes are known, the pools are fused (a limited conv never writes the full-resolution map)
@@ -207,11 +226,12 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
       bf16_t* z = reinterpret_cast<bf16_t*>(e->rec_zero[x3]);
       // full-resolution conv outputs are not kept with fused pools: a1 / c2b / c3b are unused there
       RUN(conv_stack(z + ZeroLine::GRAY * m, 1, z + ZeroLine::A0 * m, nullptr, z + ZeroLine::P1 * m, z + ZeroLine::C2A * m, nullptr,
-                     z + ZeroLine::P2 * m, z + ZeroLine::C3A * m, nullptr, z + ZeroLine::P3 * m, nullptr, nullptr));
+                     z + ZeroLine::P2 * m, z + ZeroLine::C3A * m, nullptr, z + ZeroLine::P3 * m, z + ZeroLine::F * m,
+                     z + ZeroLine::GX * m, nullptr, nullptr));
       e->rec_zero_valid[x3] = true;
     }
     zl = reinterpret_cast<const bf16_t*>(e->rec_zero[x3]);
-    const size_t need = ((size_t)5 * n + 8) * sizeof(int);
+    const size_t need = ((size_t)6 * n + 8) * sizeof(int);
     if (need > e->rec_limits_cap) {
       PT_HIP_CHECK(hipStreamSynchronize(s));
       if (e->rec_limits) PT_HIP_CHECK(hipFree(e->rec_limits));
@@ -220,17 +240,15 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
       e->rec_limits_cap = need * 2;
     }
     int* base = reinterpret_cast<int*>(e->rec_limits);
-    for (int k = 0; k < 5; ++k) lim.lim[k] = base + (size_t)k * n;
-    lim.cols = base + (size_t)5 * n;
+    for (int k = 0; k < 6; ++k) lim.lim[k] = base + (size_t)k * n;
+    lim.cols = base + (size_t)6 * n;
     {
       PtProfScope ps(e, s, PT_PROF_OTHER, 0, "crnn limits");
       RUN(pt_launch_crnn_limits(d_lines, n, lim, s));
     }
   }
-  RUN(conv_stack(gray, n, bf.a0, bf.a1, bf.p1, bf.c2a, bf.c2b, bf.p2, bf.c3a, bf.c3b, bf.p3, ragged ? &lim : nullptr, zl));
-  // from here on: [1, n, 160, C] views
-  RUN(pt_launch_conv(e, conv(bf.p3, 1, n, T, 1024, c4, 512, 1, bf.f, 1), s));
-  RUN(rows_gemm(bf.f, 512, xp1, 2048, bf.gx, 0, "rows gemm 512->2048"));
+  RUN(conv_stack(gray, n, bf.a0, bf.a1, bf.p1, bf.c2a, bf.c2b, bf.p2, bf.c3a, bf.c3b, bf.p3, bf.f, bf.gx, ragged ? &lim : nullptr, zl));
+  // from here on everything runs over all 160 steps of every line: the recurrences make padded steps line-dependent
   {
     PtProfScope ps(e, s, PT_PROF_OTHER, 0, "lstm1");
     RUN(pt_launch_lstm(e, bf.gx, W(whh1), bf.h, n, T, x3, s));

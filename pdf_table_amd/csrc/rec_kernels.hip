@@ -218,11 +218,11 @@ int pt_launch_rec_resize_gray(const uint8_t* crops, const pt_rec_line* lines, co
 // lim[k][b] is that column (in the conv's own output columns); cols[k] sums the tile-rounded limits (roofline accounting).
 // ---------------------------------------------------------------------------------------------------
 __global__ void crnn_limits_kernel(const pt_rec_line* __restrict__ lines, int n, int* l1, int* l2a, int* l2b, int* l3a, int* l3b,
-                                   int* __restrict__ cols) {
-  __shared__ int sums[5];
-  if (threadIdx.x < 5) sums[threadIdx.x] = 0;
+                                   int* l0, int* __restrict__ cols) {
+  __shared__ int sums[6];
+  if (threadIdx.x < 6) sums[threadIdx.x] = 0;
   __syncthreads();
-  int acc[5] = {0, 0, 0, 0, 0};
+  int acc[6] = {0, 0, 0, 0, 0, 0};
   for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < n; b += gridDim.x * blockDim.x) {
     const int cw = lines[b].crop_w, chh = lines[b].crop_h;
     int nw = 0;
@@ -234,21 +234,24 @@ __global__ void crnn_limits_kernel(const pt_rec_line* __restrict__ lines, int n,
     const int e1 = (e0 + 2) >> 1;                 // ceil((e0 + 1) / 2)
     const int v[5] = {min(e0 + 1, 320), min(e1 + 1, 160), min(e1 + 2, 160), min(e1 + 3, 160), min(e1 + 4, 160)};
     l1[b] = v[0]; l2a[b] = v[1]; l2b[b] = v[2]; l3a[b] = v[3]; l3b[b] = v[4];
+    // conv0 (computed in 64-column pooled tiles) must deliver the columns the limited conv1 reads: its tiles [0, R1) + the halo
+    l0[b] = min((v[0] + 31) / 32 * 32 + 1, 320);
     const int tw[5] = {32, 32, 32, 64, 64}, wo[5] = {320, 160, 160, 160, 160};
 #pragma unroll
     for (int k = 0; k < 5; ++k) acc[k] += min(wo[k], (v[k] + tw[k] - 1) / tw[k] * tw[k]);
+    acc[5] += min(160, (v[4] + 31) / 32 * 32);     // the sequence GEMMs (conv4, first LSTM projection): 32-step tiles
   }
 #pragma unroll
-  for (int k = 0; k < 5; ++k) atomicAdd(&sums[k], acc[k]);
+  for (int k = 0; k < 6; ++k) atomicAdd(&sums[k], acc[k]);
   __syncthreads();
-  if (threadIdx.x < 5) atomicAdd(&cols[threadIdx.x], sums[threadIdx.x]);
+  if (threadIdx.x < 6) atomicAdd(&cols[threadIdx.x], sums[threadIdx.x]);
 }
 
 int pt_launch_crnn_limits(const pt_rec_line* lines, int n, const PtCrnnLimits& L, hipStream_t s) {
-  PT_HIP_CHECK(hipMemsetAsync(L.cols, 0, 5 * sizeof(int), s));
+  PT_HIP_CHECK(hipMemsetAsync(L.cols, 0, 8 * sizeof(int), s));
   int blocks = (n + 255) / 256;
   if (blocks > 64) blocks = 64;
-  hipLaunchKernelGGL(crnn_limits_kernel, dim3(blocks), dim3(256), 0, s, lines, n, L.lim[0], L.lim[1], L.lim[2], L.lim[3], L.lim[4], L.cols);
+  hipLaunchKernelGGL(crnn_limits_kernel, dim3(blocks), dim3(256), 0, s, lines, n, L.lim[0], L.lim[1], L.lim[2], L.lim[3], L.lim[4], L.lim[5], L.cols);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
@@ -257,11 +260,14 @@ int pt_launch_crnn_limits(const pt_rec_line* lines, int n, const PtCrnnLimits& L
 // ref -> out for the columns x >= xf(b) = (roundup(lim[b], tile_w)) / div -- the columns the limited conv left untouched
 // (div = 2 when a 2x2 pool follows the conv in its epilogue).  16-byte pieces; a block walks (row, column, piece) of one line.
 __global__ __launch_bounds__(256) void crnn_fill_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ ref,
-                                                         const int* __restrict__ lim, int tile_w, int div, int rows, int W, int cs) {
+                                                         const int* __restrict__ lim, int tile_w, int div, int rows, int W, int cs,
+                                                         const int* __restrict__ end_lim, int end_tile) {
   const int b = blockIdx.y;
   const int xf = ((lim[b] + tile_w - 1) / tile_w * tile_w) / div;
-  if (xf >= W) return;
-  const int pc = cs >> 3, wcols = W - xf;
+  int xe = W;
+  if (end_lim) xe = min(W, (end_lim[b] + end_tile - 1) / end_tile * end_tile + 1);    // + 1: the next conv's halo column
+  if (xf >= xe) return;
+  const int pc = cs >> 3, wcols = xe - xf;
   const long long total = (long long)rows * wcols * pc;
   u32x4* o = reinterpret_cast<u32x4*>(out + (size_t)b * rows * W * cs);
   const u32x4* r = reinterpret_cast<const u32x4*>(ref);
@@ -275,13 +281,13 @@ __global__ __launch_bounds__(256) void crnn_fill_kernel(bf16_t* __restrict__ out
 }
 
 int pt_launch_crnn_fill(bf16_t* out, const bf16_t* ref, const int* lim, int tile_w, int div, int n, int rows, int W, int cs,
-                        hipStream_t s) {
+                        hipStream_t s, const int* end_lim, int end_tile) {
   if (n <= 0) return PT_OK;
   PT_REQUIRE(cs % 8 == 0, "crnn fill: channel stride must be a multiple of 8");
   long long per = (long long)rows * W * (cs >> 3);
   int bx = (int)((per + 255) / 256);
   bx = bx < 1 ? 1 : (bx > 16 ? 16 : bx);
-  hipLaunchKernelGGL(crnn_fill_kernel, dim3(bx, n), dim3(256), 0, s, out, ref, lim, tile_w, div, rows, W, cs);
+  hipLaunchKernelGGL(crnn_fill_kernel, dim3(bx, n), dim3(256), 0, s, out, ref, lim, tile_w, div, rows, W, cs, end_lim, end_tile);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
@@ -439,7 +445,8 @@ __global__ __launch_bounds__(256) void crnn_conv0_pool_kernel(const bf16_t* __re
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void crnn_conv0_pool_mfma_kernel(const bf16_t* __restrict__ in, int n, int H, int W,
                                                                     const float* __restrict__ w64x9,
-                                                                    const float* __restrict__ bias, bf16_t* __restrict__ out) {
+                                                                    const float* __restrict__ bias, bf16_t* __restrict__ out,
+                                                                    const int* __restrict__ xlim) {
   constexpr int PR = 4, PC = 64;                  // pooled rows x cols per workgroup
   constexpr int LW = 2 * PC + 2, LH = 2 * PR + 2; // gray patch with a 1-pixel halo
   __shared__ bf16_t sg[LH * LW];
@@ -453,6 +460,7 @@ __global__ __launch_bounds__(256) void crnn_conv0_pool_mfma_kernel(const bf16_t*
   const int ty = L % tcy;
   const int b = L / tcy;
   const int oy0 = ty * PR, ox0 = tx * PC;
+  if (xlim && ox0 >= xlim[b]) return;             // ragged line: nothing downstream reads these pooled columns
   for (int i = tid; i < LH * LW; i += 256) {
     const int yy = 2 * oy0 - 1 + i / LW, xx = 2 * ox0 - 1 + i % LW;
     sg[i] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? in[((size_t)b * H + yy) * W + xx] : (bf16_t)0;
@@ -514,7 +522,7 @@ __global__ __launch_bounds__(256) void crnn_conv0_pool_mfma_kernel(const bf16_t*
 }
 
 int pt_launch_crnn_conv0_pool(const bf16_t* in, int n, int H, int W, const float* w64x9, const float* bias, int split,
-                              bf16_t* out, hipStream_t s) {
+                              bf16_t* out, hipStream_t s, const int* xlim) {
   PT_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv0: H, W must be even");
   static int use_mfma = -1;      // PT_CONV0_MFMA=0: the VALU kernel in bf16 mode too (A/B switch)
   if (use_mfma < 0) {
@@ -523,7 +531,7 @@ int pt_launch_crnn_conv0_pool(const bf16_t* in, int n, int H, int W, const float
   }
   if (!split && use_mfma) {
     const long long nb = (long long)n * ((H / 2 + 3) / 4) * ((W / 2 + 63) / 64);
-    hipLaunchKernelGGL(crnn_conv0_pool_mfma_kernel, dim3((unsigned)nb), dim3(256), 0, s, in, n, H, W, w64x9, bias, out);
+    hipLaunchKernelGGL(crnn_conv0_pool_mfma_kernel, dim3((unsigned)nb), dim3(256), 0, s, in, n, H, W, w64x9, bias, out, xlim);
     PT_HIP_CHECK(hipGetLastError());
     return PT_OK;
   }
@@ -1187,7 +1195,7 @@ template <int KSTEPS, int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __restrict__ A, long long M,
                                                              const bf16_t* __restrict__ W, const float* __restrict__ bias,
                                                              int N, int* __restrict__ ids, float* __restrict__ maxv,
-                                                             bf16_t* __restrict__ out, int relu) {
+                                                             bf16_t* __restrict__ out, int relu, const int* __restrict__ tlim) {
   constexpr int K = KSTEPS * 16, NCH = K / 32, P = K * 2 + 16;     // P: LDS row pitch in bytes (odd number of 16-B slots)
   constexpr int NPF = 64 * K * 2 / 16 / 256;                        // 16-byte pieces per thread per stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1197,6 +1205,14 @@ __global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __res
   const int lx = lane & 31, q = lane >> 5;
   const long long row = ((long long)blockIdx.x * 4 + wave) * 32 + lx;
   const long long rc = row < M ? row : M - 1;
+  // ragged sequences (MODE 1): a wave's 32 rows are 32 consecutive time steps of ONE line (T = 160 = 5 x 32); groups at or
+  // beyond the line's limit are not computed (the caller fills them), a workgroup with no live wave leaves at once
+  bool live = true;
+  if (MODE == 1 && tlim) {
+    const long long r0 = ((long long)blockIdx.x * 4 + wave) * 32;
+    live = r0 < M && (int)(r0 % PT_REC_T) < tlim[r0 / PT_REC_T];
+    if (!__syncthreads_or(live ? 1 : 0)) return;
+  }
   bf16x8 areg[KSTEPS];
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) areg[ks] = *reinterpret_cast<const bf16x8*>(A + rc * K + ks * 16 + q * 8);
@@ -1231,6 +1247,7 @@ __global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __res
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       const char* wr = sw + (half * 32 + lx) * P + q * 16;
+      if (MODE == 1 && !live) continue;
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
         const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wr + ks * 32);
@@ -1281,14 +1298,14 @@ int pt_launch_gemm_argmax(const bf16_t* A, long long M, int K, const bf16_t* W, 
     attr_done = true;
   }
   hipLaunchKernelGGL((gemm_argmax_kernel<32, 0>), dim3((unsigned)((M + 127) / 128)), dim3(256), SMEM, s, A, M, W, bias, N, ids, maxv,
-                     nullptr, 0);
+                     nullptr, 0, nullptr);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
 
 // out bf16 [M][N] = A [M][K] . W^T + bias (+ ReLU); K in {256, 512}; PT_ERR_INVALID otherwise (caller falls back)
 int pt_launch_gemm_rows(const bf16_t* A, long long M, int K, const bf16_t* W, const float* bias, int N, bf16_t* out, int relu,
-                        hipStream_t s) {
+                        hipStream_t s, const int* tlim) {
   if ((K != 512 && K != 256) || N % 64 != 0 || M <= 0) return PT_ERR_INVALID;
   const int smem = 64 * (K * 2 + 16) + 64 * 4;
   static bool attr_done = false;
@@ -1298,9 +1315,9 @@ int pt_launch_gemm_rows(const bf16_t* A, long long M, int K, const bf16_t* W, co
   }
   const dim3 grid((unsigned)((M + 127) / 128));
   if (K == 512)
-    hipLaunchKernelGGL((gemm_argmax_kernel<32, 1>), grid, dim3(256), smem, s, A, M, W, bias, N, nullptr, nullptr, out, relu);
+    hipLaunchKernelGGL((gemm_argmax_kernel<32, 1>), grid, dim3(256), smem, s, A, M, W, bias, N, nullptr, nullptr, out, relu, tlim);
   else
-    hipLaunchKernelGGL((gemm_argmax_kernel<16, 1>), grid, dim3(256), smem, s, A, M, W, bias, N, nullptr, nullptr, out, relu);
+    hipLaunchKernelGGL((gemm_argmax_kernel<16, 1>), grid, dim3(256), smem, s, A, M, W, bias, N, nullptr, nullptr, out, relu, tlim);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
