@@ -75,6 +75,16 @@ __device__ __forceinline__ uint32_t f32_to_bf16(float f) {
   return u >> 16;
 }
 
+// two fp32 -> one dword of two bf16 (round-to-nearest-even): v_cvt_pk_bf16_f32, one instruction where the integer
+// rounding above takes nine -- the epilogues are VALU-bound (s_memtime phase stamps: 40 % of a short-K tile's time)
+typedef __attribute__((ext_vector_type(2))) float cf2;
+typedef __attribute__((ext_vector_type(2))) __bf16 cb2;
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(cf2{a, b}, cb2));
+}
+__device__ __forceinline__ float bf16lo_f32(uint32_t pk) { return __uint_as_float(pk << 16); }
+__device__ __forceinline__ float bf16hi_f32(uint32_t pk) { return __uint_as_float(pk & 0xFFFF0000u); }
+
 // XCD-aware bijective remap of the flat block id (8 XCDs; block b is observed to run on XCD b % 8)
 __device__ __forceinline__ int xcd_remap(int id, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
@@ -149,10 +159,7 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
             m[k] = (dy == 0 && dx == 0) ? v : fmaxf(m[k], v);
           }
         }
-      uint32_t hb[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) hb[k] = f32_to_bf16(m[k]);
-      const u32x4 o = {hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16)};
+      const u32x4 o = {pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3]), pack_bf16x2(m[4], m[5]), pack_bf16x2(m[6], m[7])};
       size_t oo;
       int lo_off = p.out_lo_off;
       if (p.pool == 3) {
@@ -164,27 +171,28 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
       }
       *reinterpret_cast<u32x4*>(p.out + oo) = o;
       if (p.split) {
-        uint32_t lb[8];
+        const uint32_t ow[4] = {o.x, o.y, o.z, o.w};
+        uint32_t lw[4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) lb[k] = f32_to_bf16(m[k] - bf16_to_f32(hb[k]));
-        const u32x4 ol = {lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16), lb[4] | (lb[5] << 16), lb[6] | (lb[7] << 16)};
+        for (int k = 0; k < 4; ++k) lw[k] = pack_bf16x2(m[2 * k] - bf16lo_f32(ow[k]), m[2 * k + 1] - bf16hi_f32(ow[k]));
+        const u32x4 ol = {lw[0], lw[1], lw[2], lw[3]};
         *reinterpret_cast<u32x4*>(p.out + oo + lo_off) = ol;
       }
     }
     return;
   }
+  static_assert(NTHR % 8 == 0, "a thread keeps its channel group over the passes");
+  const int cg = tid & 7, n = n0 + cg * 8;
+  // the thread's 8 bias values: once, not once per pixel (the compiler may not hoist the loads over the stores)
+  const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
 #pragma unroll
   for (int j = 0; j < TH * TW * 8 / NTHR; ++j) {
-    const int idx = tid + j * NTHR;
-    const int pix = idx >> 3, cg = idx & 7;
+    const int pix = (tid + j * NTHR) >> 3;
     const int ty = pix / TW, tx = pix % TW;
     const int oy = oy0 + ty, ox = ox0 + tx;
     if (oy >= p.Ho || ox >= p.Wo) continue;
     const f32x4* sp = reinterpret_cast<const f32x4*>(stage + pix * 64 + cg * 8);
     f32x4 v0 = sp[0], v1 = sp[1];
-    const int n = n0 + cg * 8;
-    const f32x4* bp = reinterpret_cast<const f32x4*>(p.bias + n);
-    f32x4 b0 = bp[0], b1 = bp[1];
     float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
     if (p.res_mode) {
       const int rcs = p.split ? 2 * p.N : p.N;
@@ -222,16 +230,13 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : sl * v[k];
     }
-    uint32_t hb[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) hb[k] = f32_to_bf16(v[k]);
     u32x4 o, ol;
-    o.x = hb[0] | (hb[1] << 16); o.y = hb[2] | (hb[3] << 16); o.z = hb[4] | (hb[5] << 16); o.w = hb[6] | (hb[7] << 16);
+    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
     if (p.split) {
-      uint32_t lb[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) lb[k] = f32_to_bf16(v[k] - bf16_to_f32(hb[k]));
-      ol.x = lb[0] | (lb[1] << 16); ol.y = lb[2] | (lb[3] << 16); ol.z = lb[4] | (lb[5] << 16); ol.w = lb[6] | (lb[7] << 16);
+      ol.x = pack_bf16x2(v[0] - bf16lo_f32(o.x), v[1] - bf16hi_f32(o.x));
+      ol.y = pack_bf16x2(v[2] - bf16lo_f32(o.y), v[3] - bf16hi_f32(o.y));
+      ol.z = pack_bf16x2(v[4] - bf16lo_f32(o.z), v[5] - bf16hi_f32(o.z));
+      ol.w = pack_bf16x2(v[6] - bf16lo_f32(o.w), v[7] - bf16hi_f32(o.w));
     }
     if (EXTRAS && p.argmax_part) {
       // fused arg-max over classes (CTC greedy decode, modeling_ocr_recognition.py:168-171): best (value, index)
@@ -258,7 +263,10 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
       // 8 consecutive lanes hold the 64 channels of one output pixel of quadrant `quad` (n0 == quad * 64)
       float xs[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) xs[k] = p.split ? v[k] : bf16_to_f32(hb[k]);
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t ow = k < 2 ? o.x : k < 4 ? o.y : k < 6 ? o.z : o.w;
+        xs[k] = p.split ? v[k] : ((k & 1) ? bf16hi_f32(ow) : bf16lo_f32(ow));
+      }
       float acc4[4];
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
@@ -511,34 +519,36 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
 // 3x3 stride-1 convolution, LDS-DMA pipeline with 16-channel K-slices ("v3").
 // Fill traffic per FLOP is what limits v1/v2 (PMC analysis), so v3 makes the tile as large as two
 // K-slices in LDS allow:  NT == 1: 32x32 pixels x 64 channels;  NT == 2: 16x32 pixels x 128 channels.
-// 8 waves; each wave owns 4 MFMA row-tiles x 64 channels (acc 4x2, 6 ds_read_b128 per 8 MFMAs); a K-slice is
+// NWV = 8 waves (or 4: a 16x32 x 64 tile, two workgroups per CU -- see the dispatch rule in pt_launch_conv); each wave owns
+// 4 MFMA row-tiles x 64 channels (acc 4x2, 6 ds_read_b128 per 8 MFMAs); a K-slice is
 // 16 channels (one MFMA k-step per tap), ~56 KB for both operands, double buffered; rows are 32 B with the two
 // 16-byte halves swapped on rows with bit 3 set (applied on the DMA source and on the ds_read address).
 // Weights are read straight from the 32-channel tiling of v1 (half of every 64-byte row per slice).
 // ---------------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, int NWV = 8>
 struct Dma16Cfg {
-  static constexpr int NTHR = 512;
-  static constexpr int TH = NT == 1 ? 32 : 16, TW = 32;
+  static constexpr int NTHR = 64 * NWV;
+  static constexpr int TH = NT == 1 ? 4 * NWV : 2 * NWV, TW = 32;
   static constexpr int NW = 64 * NT;                          // output channels per workgroup
   static constexpr int THIN = TH + 2, TWIN = TW + 2;
   static constexpr int NPIX = THIN * TWIN;                    // 1156 / 612
   static constexpr int IN_BYTES = NPIX * 32;
   static constexpr int W_BYTES = 9 * NW * 32;
   static constexpr int BUF_BYTES = IN_BYTES + W_BYTES;        // 55424 / 56448
-  static constexpr int STAGE_BYTES = 16 * 32 * 64 * 4;        // one epilogue pass: 512 pixels x 64 channels fp32
+  static constexpr int PASS_ROWS = 2 * NWV;                  // patch rows per epilogue pass (half of the waves)
+  static constexpr int STAGE_BYTES = PASS_ROWS * 32 * 64 * 4; // one epilogue pass: 64 channels fp32
   static constexpr int SMEM = 2 * BUF_BYTES > STAGE_BYTES ? 2 * BUF_BYTES : STAGE_BYTES;
   static constexpr int IN_UNITS = NPIX * 2;
   static constexpr int IN_INSTR = (IN_UNITS + 63) / 64;
   static constexpr int W_UNITS = 9 * NW * 2;
   static constexpr int W_INSTR = W_UNITS / 64;
-  static constexpr int IN_SLOTS = (IN_INSTR + 7) / 8;
-  static constexpr int W_SLOTS = (W_INSTR + 7) / 8;
+  static constexpr int IN_SLOTS = (IN_INSTR + NWV - 1) / NWV;
+  static constexpr int W_SLOTS = (W_INSTR + NWV - 1) / NWV;
 };
 
-template <int NT>
-__global__ __launch_bounds__(512, 2) void conv3x3_dma16_kernel(ConvK p, const bf16_t* __restrict__ zero_page) {
-  using C = Dma16Cfg<NT>;
+template <int NT, int NWV>
+__global__ __launch_bounds__(64 * NWV, 2) void conv3x3_dma16_kernel(ConvK p, const bf16_t* __restrict__ zero_page) {
+  using C = Dma16Cfg<NT, NWV>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -564,7 +574,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma16_kernel(ConvK p, const bf
   bool on_in[C::IN_SLOTS];
 #pragma unroll
   for (int j = 0; j < C::IN_SLOTS; ++j) {
-    const int k = wave + 8 * j;
+    const int k = wave + NWV * j;
     const int U = k * 64 + lane;
     on_in[j] = (k < C::IN_INSTR) && (U < C::IN_UNITS);
     const int pix = U >> 1;
@@ -579,7 +589,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma16_kernel(ConvK p, const bf
   int src_w[C::W_SLOTS];
 #pragma unroll
   for (int j = 0; j < C::W_SLOTS; ++j) {
-    const int U = (wave + 8 * j) * 64 + lane;
+    const int U = (wave + NWV * j) * 64 + lane;
     const int row = U >> 1;
     const int tap = row / C::NW, n = row - tap * C::NW;
     const int hq = (U & 1) ^ ((row >> 3) & 1);
@@ -598,13 +608,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma16_kernel(ConvK p, const bf
     for (int j = 0; j < C::IN_SLOTS; ++j) {
       if (on_in[j])
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_in[j] + c0),
-                                         (__attribute__((address_space(3))) void*)(lds_in + (wave + 8 * j) * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(lds_in + (wave + NWV * j) * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < C::W_SLOTS; ++j) {
-      if (wave + 8 * j < C::W_INSTR)
+      if (wave + NWV * j < C::W_INSTR)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wc + src_w[j]),
-                                         (__attribute__((address_space(3))) void*)(lds_w + (wave + 8 * j) * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(lds_w + (wave + NWV * j) * 1024), 16, 0, 0);
     }
   };
 
@@ -644,14 +654,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma16_kernel(ConvK p, const bf
     }
   }
 
-  // epilogue in two passes of 512 pixels x 64 channels (fp32 in LDS)
+  // epilogue in two passes of PASS_ROWS x 32 pixels x 64 channels (fp32 in LDS)
   float* stage = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     __syncthreads();
-    const bool mine = NT == 1 ? ((wave >> 2) == pass) : (wn == pass);
+    const bool mine = NT == 1 ? ((wave / (NWV / 2)) == pass) : (wn == pass);
     if (mine) {
-      const int rbase = NT == 1 ? 4 * (wave & 3) : 4 * wm;   // local patch row inside this pass' 16 rows
+      const int rbase = NT == 1 ? 4 * (wave % (NWV / 2)) : 4 * wm;   // local patch row inside this pass' rows
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -664,9 +674,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma16_kernel(ConvK p, const bf
     }
     __syncthreads();
     if (NT == 1)
-      epilogue_store<16, 32, C::NTHR, false>(p, stage, tid, b, oy0 + 16 * pass, ox0, nb * 64);
+      epilogue_store<C::PASS_ROWS, 32, C::NTHR, false>(p, stage, tid, b, oy0 + C::PASS_ROWS * pass, ox0, nb * 64);
     else
-      epilogue_store<16, 32, C::NTHR, false>(p, stage, tid, b, oy0, ox0, (nb * 2 + pass) * 64);
+      epilogue_store<C::PASS_ROWS, 32, C::NTHR, false>(p, stage, tid, b, oy0, ox0, (nb * 2 + pass) * 64);
   }
 }
 
@@ -954,12 +964,12 @@ static bool use_dma_kernel() {
   return v != 0;
 }
 
-template <int NT>
+template <int NT, int NWV>
 static int launch_dma16(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
-  using C = Dma16Cfg<NT>;
+  using C = Dma16Cfg<NT, NWV>;
   static bool attr_done = false;
   if (!attr_done) {
-    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma16_kernel<NT>),
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma16_kernel<NT, NWV>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
     attr_done = true;
   }
@@ -973,9 +983,9 @@ static int launch_dma16(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   const long long nblk = (long long)k.B * k.tiles_x * k.tiles_y * k.n_tiles;
   PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range (%lld blocks)", nblk);
   char label[48];
-  snprintf(label, sizeof(label), "conv3x3 v3 %d->%d @%dx%d%s", k.Cin, k.N, k.Ho, k.Wo, k.split ? " x3" : "");
+  snprintf(label, sizeof(label), "conv3x3 v3%s %d->%d @%dx%d%s", NWV == 4 ? "h" : "", k.Cin, k.N, k.Ho, k.Wo, k.split ? " x3" : "");
   PtProfScope prof(e, s, PT_PROF_CONV3X3, flop, label);
-  hipLaunchKernelGGL((conv3x3_dma16_kernel<NT>), dim3((unsigned)nblk), dim3(C::NTHR), C::SMEM, s, k,
+  hipLaunchKernelGGL((conv3x3_dma16_kernel<NT, NWV>), dim3((unsigned)nblk), dim3(C::NTHR), C::SMEM, s, k,
                      reinterpret_cast<const bf16_t*>(e->zero_page));
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
@@ -1043,7 +1053,20 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
     int pick = 0;
     if (cv == 3 && v3ok) pick = 3;
     else if (cv == 1 && wide && k.Ho >= 120) pick = 3;
-    if (pick == 3) return d.N % 128 == 0 ? launch_dma16<2>(e, k, s, flop) : launch_dma16<1>(e, k, s, flop);
+    // 4-wave workgroups (16x32 pixels x 64 channels, 74 KB of LDS: two per CU) where the 8-wave tile is mostly prologue and
+    // epilogue: short K (Cin <= 128: +3..8 % on 64->64 @240^2 / @256^2, 128->128 @120^2 / @128^2, 64->256 @256^2), and grids
+    // that leave the 8-wave tiling with a ragged last round (512->512 @32^2 x 44: +12 %); K >= 2304 layers whose grid is whole
+    // rounds stay on the 8-wave tiles (512->512 @30^2 x 32: -3 % as 4-wave).  PT_CONV_HALF = 0 / 1 forces one of them.
+    static int half = -2;
+    if (half == -2) { const char* ev = getenv("PT_CONV_HALF"); half = ev ? atoi(ev) : -1; }
+    bool use_half = half == 1;
+    if (half < 0 && pick == 3) {
+      const bool nt2 = d.N % 128 == 0;
+      const long long full = (long long)k.B * ((k.Ho + (nt2 ? 15 : 31)) / (nt2 ? 16 : 32)) * ((k.Wo + 31) / 32) * (d.N / (nt2 ? 128 : 64));
+      use_half = d.Cin <= 128 || (full < 2ll * e->num_cu && full % e->num_cu != 0);
+    }
+    if (pick == 3 && use_half) return launch_dma16<1, 4>(e, k, s, flop);
+    if (pick == 3) return d.N % 128 == 0 ? launch_dma16<2, 8>(e, k, s, flop) : launch_dma16<1, 8>(e, k, s, flop);
   }
   if (d.ks == 3 && d.stride == 1 && k.Ho <= 4 && k.Wo > 32) return launch_cfg<3, 1, 1>(e, k, s, flop);
   if (d.ks == 3 && d.stride == 1) return launch_cfg<3, 1>(e, k, s, flop);

@@ -92,7 +92,8 @@ class LayoutStage:
         self.config = config or PicodetConfig()
         self.max_cands = max_cands
         self._copy_stream = None
-        self._pinned = None
+        self._pinned = [None, None]          # two host landing buffers: a forward() may be queued while the previous finish() still reads
+        self._turn = 0
 
     def forward(self, pages: torch.Tensor):
         """device half (asynchronous): network + candidate compaction on the current stream, then the D2H of the
@@ -104,20 +105,23 @@ class LayoutStage:
         n = counts.shape[0]
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=counts.device)
-        if self._pinned is None or self._pinned[0].shape[0] < n:
-            self._pinned = (torch.empty((n,), dtype=torch.int32).pin_memory(),
-                            torch.empty((n, self.max_cands, L.PT_LAYOUT_CAND_FLOATS), dtype=torch.float32).pin_memory())
+        slot = self._turn
+        self._turn ^= 1
+        if self._pinned[slot] is None or self._pinned[slot][0].shape[0] < n:
+            self._pinned[slot] = (torch.empty((n,), dtype=torch.int32).pin_memory(),
+                                  torch.empty((n, self.max_cands, L.PT_LAYOUT_CAND_FLOATS), dtype=torch.float32).pin_memory())
+        host = self._pinned[slot]
         ready = torch.cuda.Event()
         ready.record()
         with torch.cuda.stream(self._copy_stream):
             self._copy_stream.wait_event(ready)
-            self._pinned[0][:n].copy_(counts, non_blocking=True)
-            self._pinned[1][:n].copy_(cands, non_blocking=True)
+            host[0][:n].copy_(counts, non_blocking=True)
+            host[1][:n].copy_(cands, non_blocking=True)
             done = torch.cuda.Event()
             done.record(self._copy_stream)
         counts.record_stream(self._copy_stream)
         cands.record_stream(self._copy_stream)
-        return n, done
+        return n, (done, host)
 
     def decode_page(self, rec: np.ndarray, org_shape) -> List[Dict]:
         """candidate records [k, 48] of one page -> the `bboxs` list of OCRPicodetPostProcessor.__call__"""
@@ -125,6 +129,9 @@ class LayoutStage:
         ncls = len(cfg.labels)
         if len(rec) == 0:
             return []
+        # the device appends candidates with an atomic counter: put them in the reference's dense order (level, anchor) so that
+        # ties in the argsorts below break as they do there and the result does not depend on the order of arrival
+        rec = rec[np.lexsort((rec[:, 1].view(np.int32), rec[:, 0].view(np.int32)))]
         level = rec[:, 0].view(np.int32)
         anchor = rec[:, 1].view(np.int32)
         logits = rec[:, 2:2 + ncls]
@@ -194,15 +201,17 @@ class LayoutStage:
                 for i, c in enumerate(labels)]
 
     def __call__(self, pages: torch.Tensor) -> List[List[Dict]]:
-        n, done = self.forward(pages)
-        return self.finish(n, done, tuple(pages.shape[1:3]))
+        n, ticket = self.forward(pages)
+        return self.finish(n, ticket, tuple(pages.shape[1:3]))
 
-    def finish(self, n: int, done, org) -> List[List[Dict]]:
-        """host half: wait for the candidate copy, decode + NMS per page"""
+    def finish(self, n: int, ticket, org) -> List[List[Dict]]:
+        """host half: wait for the candidate copy of that forward(), decode + NMS per page.  At most one newer forward() may
+        have been issued in between (two landing buffers)."""
+        done, host = ticket
         done.synchronize()
-        counts = self._pinned[0][:n].numpy().copy()
+        counts = host[0][:n].numpy().copy()
         if (counts > self.max_cands).any():
             raise RuntimeError(f"layout: {int(counts.max())} candidate anchors on a page exceed max_cands={self.max_cands}")
         kmax = int(counts.max()) if len(counts) else 0
-        rec = self._pinned[1][:n, :max(kmax, 1)].numpy()
+        rec = host[1][:n, :max(kmax, 1)].numpy()
         return [self.decode_page(rec[i, :counts[i]], org) for i in range(len(counts))]

@@ -168,25 +168,7 @@ class OcrTablePipeline:
                     return rec_stage.start(batch, boxes)            # asynchronous: crops, CRNN, arg-max
 
             def finish_rec():
-                """-> texts; a device-side failure (PtError from pt_engine_check: the engine has switched to the streaming
-                LSTM and cleared the flag) is logged and the batch is run once more; only then the reference's containment
-                (empty strings, ocr_system_task.py:275-283) applies -- logged, never silent"""
-                from .lib import PtError
-                state = rec_state
-                for attempt in (0, 1):
-                    try:
-                        with on_side():
-                            if state is None:
-                                state = rec_stage.start(batch, boxes)
-                            return rec_stage.finish(state)
-                    except PtError as e:
-                        logger.warning("text recognition failed on the device (%s)%s", e, "; running the batch again" if attempt == 0 else "")
-                        state = None
-                    except Exception as e:     # noqa: BLE001 -- the reference contains every failure of a crop
-                        logger.warning("text recognition failed: %r", e)
-                        break
-                logger.error("text recognition of %d lines yields empty strings", sum(len(b) for b in boxes))
-                return [[""] * len(b) for b in boxes]
+                return self._finish_rec(rec_stage, batch, boxes, rec_state, side)
 
             rec_state = None
             try:
@@ -205,26 +187,12 @@ class OcrTablePipeline:
                             x1, y1, x2, y2 = tb[k].T
                             tb[k] = np.stack([shape[1] - x2, shape[0] - y2, shape[1] - x1, shape[0] - y1], 1)
                 else:
-                    # layout regions labelled "table", score >= 0.2, top to bottom, cropped at rounded coordinates
-                    # (ocr_system_task.py:184-198, crop_image_by_box utils/ocr/ocr_common_utils.py:279-280)
-                    tb = []
-                    for k in range(len(idxs)):
-                        bx = [[round(float(v)) for v in t["bbox"]] for t in layout_tables(lay[k], "table", 0.2)]
-                        bx = [b for b in bx if b[2] > b[0] and b[3] > b[1]]
-                        tb.append(np.array(bx, dtype=np.int64).reshape(-1, 4))
+                    tb = self._layout_table_boxes(lay)
                 tsr = self.table_structure_task.recognize_tables(batch, tb)
             if side is not None:
                 texts = finish_rec()
             if tsr is not None and self.table_html:
-                from .table_text_match import page_table_html
-                for k in range(len(idxs)):
-                    for ti, table in enumerate(tsr[k]):
-                        if len(table.get("scores", [])) == 0:
-                            table["table_html"], table["db_table_html"] = [], []
-                            continue
-                        # cells (page pixels since recognize_tables shifts them) x the page's text lines (page pixels)
-                        table["table_html"], table["db_table_html"] = page_table_html(
-                            table["polygons"], table["logi"], tb[k][ti], boxes[k], texts[k])
+                self._attach_html(tsr, tb, boxes, texts)
             d_ = time.time()
             t_det += b_ - a
             t_rec += c - b_
@@ -242,3 +210,176 @@ class OcrTablePipeline:
                        "text_recognition": {"use_time": t_rec, "total": sum(len(r.ocr_result) for r in results)},
                        "table_structure": {"use_time": t_tsr}}
         return results
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _layout_table_boxes(self, lay_pages) -> List[np.ndarray]:
+        """layout regions labelled "table", score >= 0.2, top to bottom, at rounded coordinates
+        (ocr_system_task.py:184-198, crop_image_by_box utils/ocr/ocr_common_utils.py:279-280)"""
+        tb = []
+        for lay in lay_pages:
+            bx = [[round(float(v)) for v in t["bbox"]] for t in layout_tables(lay, "table", 0.2)]
+            bx = [b for b in bx if b[2] > b[0] and b[3] > b[1]]
+            tb.append(np.array(bx, dtype=np.int64).reshape(-1, 4))
+        return tb
+
+    def predict_stream(self, batches, table_boxes=None):
+        """``predict()`` over a stream of page batches, software-pipelined: a generator that takes an iterable of batches (each a
+        sequence of equally sized RGB pages, or a uint8 tensor [n, h, w, 3] already on the device) and yields one
+        ``List[PageResult]`` per batch, in order, with the results ``predict()`` gives for that batch.
+
+        The reference runs a page's stages back to back and waits for each (ocr_system_task.py:549-734); ``predict()`` keeps
+        that order per batch.  Here batch k's device work is queued while the host still works on batch k-1 and k-2:
+
+            step k:  queue layout(k) [auxiliary stream] and detection(k)
+                     host: boxes of batch k-1 (contours, unclip, reading order), layout decode + NMS of batch k-1
+                     queue recognition(k-1) [second stream] and table structure(k-1) on those boxes / regions
+                     host: texts and tables of batch k-2 (CTC collapse, processor, result shaping, HTML)  -> yield
+
+        so the GPU queue always holds at least one batch of work while the host decodes, and nothing the host waits for was
+        queued in the same step.  Results arrive two batches behind the input; the generator drains at the end.
+        ``table_boxes``: optional iterable aligned with ``batches`` (per batch: per-page int [k, 4] regions).  The text-line
+        orientation vote needs a second, dependent detection pass per page and is not pipelined: use ``predict()`` for it."""
+        if self.orientation_task is not None:
+            raise ValueError("predict_stream() does not run the text-line orientation vote; use predict()")
+        if self.table_structure_task is not None and table_boxes is None and self.layout_task is None:
+            raise ValueError("table_structure=True needs layout=True or predict_stream(table_boxes=...)")
+        dev = self.engine._tdev
+        main = torch.cuda.current_stream(dev)
+        if self._rec_stream is None:
+            self._rec_stream = torch.cuda.Stream(device=dev)
+            self.engine.set_lstm_cluster(False)      # the recogniser shares the GPU with the other stages (see __init__)
+        if getattr(self, "_aux_stream", None) is None:
+            self._aux_stream = torch.cuda.Stream(device=dev)
+        rec_s, aux = self._rec_stream, self._aux_stream
+        det: DetStage = self.text_detector._stage
+        rec_stage = self.text_recognizer._stage
+        lay_stage = self.layout_task._stage if self.layout_task is not None else None
+        tsr_stage = self.table_structure_task._stage if self.table_structure_task is not None else None
+        tb_iter = iter(table_boxes) if table_boxes is not None else None
+        t_start = time.time()
+        total_lines = 0
+
+        def queue_first(batch, k):
+            """layout(k) + detection(k)"""
+            if torch.is_tensor(batch):
+                pages_t = batch.to(dev)
+            else:
+                imgs = [_read_image(p) for p in batch]
+                if len({im.shape for im in imgs}) != 1:
+                    raise ValueError("predict_stream() needs equally sized pages inside a batch (predict() groups by size)")
+                pages_t = torch.from_numpy(np.stack(imgs)).to(dev)
+            st = {"pages": pages_t, "shape": tuple(pages_t.shape[1:3]), "n": pages_t.shape[0],
+                  "tb": [np.asarray(b).reshape(-1, 4) for b in next(tb_iter)] if tb_iter is not None else None}
+            up = torch.cuda.Event()
+            up.record(main)
+            st["uploaded"] = up
+            if lay_stage is not None:
+                with torch.cuda.stream(aux):
+                    aux.wait_event(up)
+                    st["lay"] = lay_stage.forward(pages_t)
+                pages_t.record_stream(aux)
+            st["det"] = det.forward(pages_t, slot=k & 1)
+            return st
+
+        def queue_second(st):
+            """host halves of detection / layout, then recognition + table structure on their results"""
+            prob, bitmap, ev = st["det"]
+            st["boxes"] = [sort_boxes_reading_order(b) for b in det.boxes(prob, bitmap, st["shape"], ev)]
+            st["layout"] = lay_stage.finish(st["lay"][0], st["lay"][1], st["shape"]) if lay_stage is not None else None
+            with torch.cuda.stream(rec_s):
+                rec_s.wait_event(st["uploaded"])
+                try:
+                    st["rec"] = rec_stage.start(st["pages"], st["boxes"])
+                except Exception as e:                 # noqa: BLE001
+                    logger.warning("text recognition could not be queued: %r", e)
+                    st["rec"] = None
+            st["pages"].record_stream(rec_s)
+            if tsr_stage is not None:
+                tb = st["tb"] if st["tb"] is not None else self._layout_table_boxes(st["layout"])
+                st["tb"] = tb
+                tables, metas = tsr_stage.tables(st["shape"], tb)
+                offs = np.stack([tables["x0"], tables["y0"]], 1).astype(np.float32) if len(tables) else None
+                pending = tsr_stage.start(st["pages"], tables) if len(tables) else None
+                ev = None
+                if pending is not None:      # the processor of these tables runs on the auxiliary stream, behind this event
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    for (_, _, c_, d_, l_) in pending:
+                        for t_ in (c_, d_, l_):
+                            t_.record_stream(aux)
+                st["tsr"] = (pending, metas, offs, ev)
+
+        def collect(st) -> List[PageResult]:
+            nonlocal total_lines
+            texts = self._finish_rec(rec_stage, st["pages"], st["boxes"], st["rec"], rec_s)
+            tsr = None
+            if tsr_stage is not None:
+                pending, metas, offs, ev = st["tsr"]
+                flat = []
+                if pending is not None:
+                    with torch.cuda.stream(aux):      # counts D2H + processor: behind the decode of THESE tables only
+                        aux.wait_event(ev)
+                        processed = tsr_stage.process(pending)
+                    flat = tsr_stage.collect(processed, metas, offs)
+                tsr = tsr_stage.regroup(flat, st["tb"])
+                if self.table_html:
+                    self._attach_html(tsr, st["tb"], st["boxes"], texts)
+            out = []
+            for k in range(st["n"]):
+                boxes = st["boxes"][k]
+                pts = order_points(boxes) if len(boxes) else np.zeros((0, 4, 2), np.float32)
+                ocr = [{"index": j + 1, "text": t, "bbox": pts[j]} for j, t in enumerate(texts[k])]
+                total_lines += len(ocr)
+                out.append(PageResult(det_result=boxes, ocr_result=ocr, layout_result=None if st["layout"] is None else st["layout"][k],
+                                      table_structure_result=None if tsr is None else tsr[k]))
+            return out
+
+        first = second = None          # batch k-1 (device halves of layout / detection queued), batch k-2 (recognition / tables queued)
+        k = 0
+        for batch in batches:
+            cur = queue_first(batch, k)
+            if first is not None:
+                queue_second(first)
+            if second is not None:
+                yield collect(second)
+            second, first = first, cur
+            k += 1
+        if first is not None:
+            queue_second(first)
+        if second is not None:
+            yield collect(second)
+        if first is not None:
+            yield collect(first)
+        self.metric = {"use_time": time.time() - t_start, "batches": k, "text_recognition": {"total": total_lines}}
+
+    def _attach_html(self, tsr, tb, boxes, texts):
+        """cells (page pixels since the stage shifts them) x the page's text lines (page pixels) -> HTML per table"""
+        from .table_text_match import page_table_html
+        for k in range(len(tsr)):
+            for ti, table in enumerate(tsr[k]):
+                if len(table.get("scores", [])) == 0:
+                    table["table_html"], table["db_table_html"] = [], []
+                    continue
+                table["table_html"], table["db_table_html"] = page_table_html(
+                    table["polygons"], table["logi"], tb[k][ti], boxes[k], texts[k])
+
+    def _finish_rec(self, rec_stage, pages_t, boxes, state, stream) -> List[List[str]]:
+        """-> texts; a device-side failure (PtError from pt_engine_check: the engine has switched to the streaming LSTM and
+        cleared the flag) is logged and the batch is run once more; only then the reference's containment (empty strings,
+        ocr_system_task.py:275-283) applies -- logged, never silent"""
+        from .lib import PtError
+        ctx = (lambda: torch.cuda.stream(stream)) if stream is not None else contextlib.nullcontext
+        for attempt in (0, 1):
+            try:
+                with ctx():
+                    if state is None:
+                        state = rec_stage.start(pages_t, boxes)
+                    return rec_stage.finish(state)
+            except PtError as e:
+                logger.warning("text recognition failed on the device (%s)%s", e, "; running the batch again" if attempt == 0 else "")
+                state = None
+            except Exception as e:     # noqa: BLE001 -- the reference contains every failure of a crop
+                logger.warning("text recognition failed: %r", e)
+                break
+        logger.error("text recognition of %d lines yields empty strings", sum(len(b) for b in boxes))
+        return [[""] * len(b) for b in boxes]

@@ -141,15 +141,26 @@ class RecStage:
         return ids, lines
 
     def start(self, pages: torch.Tensor, boxes_per_page: Sequence[np.ndarray]):
-        """device half (asynchronous on the current stream): quad geometry on the host, one pt_rec_forward"""
+        """device half (asynchronous on the current stream): quad geometry on the host, one pt_rec_forward, and the token ids
+        on their way to pinned host memory behind it -- finish() waits for THAT copy, not for whatever else has been queued
+        on the stream since (a pipelined caller queues the next batch before it collects this one)"""
         ids, lines = self.ids(pages, boxes_per_page)
-        return ids, len(lines), [len(b) for b in boxes_per_page]
+        host = done = None
+        if len(lines):
+            host = torch.empty(ids.shape, dtype=ids.dtype, pin_memory=True)
+            host.copy_(ids, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+        return ids, len(lines), [len(b) for b in boxes_per_page], host, done
 
     def finish(self, state) -> List[List[str]]:
-        """host half: ids to the host (synchronises the stream it is called on), CTC collapse, vocabulary"""
-        ids, nl, per_page = state
-        toks = ctc_collapse(ids.cpu().numpy()) if nl else []
-        self.eng.check()          # the D2H copy synchronised the stream: surface device-side failures of this batch
+        """host half: wait for the ids of that start(), CTC collapse, vocabulary"""
+        ids, nl, per_page, host, done = state
+        toks = []
+        if nl:
+            done.synchronize()
+            toks = ctc_collapse(host.numpy())
+        self.eng.check()          # the batch has executed: surface device-side failures of it
         texts = ["".join(self.label.get(t, "") for t in row) for row in toks]
         out, o = [], 0
         for k in per_page:

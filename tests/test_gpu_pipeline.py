@@ -241,3 +241,48 @@ def test_ocr_system_task_call_shape():
     assert len(both) == 2 and np.array_equal(both[0][0].det_result, out.det_result)
     with pytest.raises(RuntimeError):
         task("some/file.pdf")
+
+def test_predict_stream_equals_predict():
+    """OcrTablePipeline.predict_stream -- layout / detection of batch k queued while the host halves of batch k-1 and the
+    results of batch k-2 are worked on -- yields, batch by batch and in order, exactly what predict() returns for each batch
+    (four batches of two pages, with given table regions and with the layout stage's own regions, HTML on)"""
+    from pdf_table_amd.pipeline import OcrTablePipeline
+    made = [make_page(i) for i in range(8)]
+    batches = [[made[2 * k][0], made[2 * k + 1][0]] for k in range(4)]
+    tbs = [[np.asarray(made[2 * k + j][1]["tables"]).reshape(-1, 4) for j in (0, 1)] for k in range(4)]
+    for given in (True, False):
+        p = OcrTablePipeline(device=0, synthetic_seed=0, layout=True, table_structure=True, table_html=True)
+        ref = [p.predict(b, table_boxes=tbs[k] if given else None) for k, b in enumerate(batches)]
+        got = list(p.predict_stream(batches, table_boxes=tbs if given else None))
+        # a tensor batch already on the device, and a single batch (the pipeline drains after one step)
+        one = list(p.predict_stream([torch.from_numpy(np.stack(batches[1])).cuda()], table_boxes=[tbs[1]] if given else None))
+        p.engine.close()
+        assert len(got) == len(ref) == 4 and len(one) == 1
+        assert sum(len(t) for b in ref for r in b for t in [r.table_structure_result]) >= 1
+        for rb, gb in zip(ref + [ref[1]], got + one):
+            assert len(rb) == len(gb) == 2
+            for a, b in zip(rb, gb):
+                assert np.array_equal(a.det_result, b.det_result)
+                assert [o["text"] for o in a.ocr_result] == [o["text"] for o in b.ocr_result]
+                assert all(np.array_equal(x["bbox"], y["bbox"]) for x, y in zip(a.ocr_result, b.ocr_result))
+                assert len(a.layout_result) == len(b.layout_result)
+                for la, lb in zip(a.layout_result, b.layout_result):
+                    assert la["label"] == lb["label"] and np.array_equal(la["bbox"], lb["bbox"]) and la["score"] == lb["score"]
+                assert len(a.table_structure_result) == len(b.table_structure_result)
+                for ta, tb_ in zip(a.table_structure_result, b.table_structure_result):
+                    assert np.array_equal(ta["polygons"], tb_["polygons"]) and np.array_equal(ta["logi"], tb_["logi"])
+                    assert ta.get("table_html") == tb_.get("table_html")
+
+
+def test_predict_stream_refuses_what_it_does_not_pipeline():
+    from pdf_table_amd.pipeline import OcrTablePipeline
+    p = OcrTablePipeline(device=0, synthetic_seed=0, text_orientation=True)
+    with pytest.raises(ValueError, match="orientation"):
+        next(p.predict_stream([[make_page(0)[0]]]))
+    p.engine.close()
+    p = OcrTablePipeline(device=0, synthetic_seed=0, table_structure=True)
+    with pytest.raises(ValueError, match="table_boxes"):
+        next(p.predict_stream([[make_page(0)[0]]]))
+    with pytest.raises(ValueError, match="equally sized"):
+        list(p.predict_stream([[make_page(0)[0], make_page(1)[0][:700]]], table_boxes=[[np.zeros((0, 4)), np.zeros((0, 4))]]))
+    p.engine.close()

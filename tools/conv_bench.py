@@ -15,6 +15,9 @@ eng = HipEngine(0)
 g = torch.Generator().manual_seed(0)
 x = torch.randn(B, H, W, Cin, generator=g).to(torch.bfloat16).cuda()
 w = torch.randn(N, Cin, ks, ks, generator=g) * (2.0 / (Cin * ks * ks)) ** 0.5
+if os.environ.get("PT_BENCH_ZERO"):      # zero operands: the same instruction stream at the lowest switching power (DVFS probe)
+    x.zero_()
+    w.zero_()
 wt = torch.from_numpy(tile_conv_weight(w).view(np.int16)).cuda()
 b = torch.zeros(N).cuda()
 out = eng.op_conv2d(x, wt, b, ks, stride, relu=True)

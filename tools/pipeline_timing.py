@@ -1,8 +1,10 @@
 """tools/pipeline_timing.py: wall time of OcrTablePipeline.predict (synchronous, stage after stage, one 32-page batch) with
-the recogniser on the main stream and on a second stream (GPU box)."""
+the recogniser on the main stream and on a second stream, and of OcrTablePipeline.predict_stream over 64-page batches
+resident on the device (the product API next to bench.py's own loop; GPU box)."""
 import time
 
 import numpy as np
+import torch
 
 from pdf_table_amd.pipeline import OcrTablePipeline
 from pdf_table_amd.synth_pages import make_page
@@ -28,3 +30,28 @@ for overlap in (False, True, False, True):
         ts.append(time.time() - t0)
     print(f"overlap_rec={overlap}: {min(ts) * 1e3:.0f} ms per 32-page predict() (best of 3), {32 / min(ts):.0f} pages/s")
     p.engine.close()
+
+# predict_stream: ten 64-page batches already on the device, table regions given (bench.py's workload shape)
+p = OcrTablePipeline(device=0, synthetic_seed=0, layout=True, table_structure=True)
+quads64 = (quads + quads)
+stage = p.text_detector._stage
+orig = stage.boxes
+stage.boxes = lambda prob, bm, shape, ev, _o=orig, _q=quads64: (_o(prob, bm, shape, ev), _q)[1]
+batch = torch.from_numpy(np.stack(pages + pages)).cuda()
+tb64 = tb + tb
+for _ in p.predict_stream([batch] * 3, table_boxes=[tb64] * 3):
+    pass
+for rep in range(2):
+    torch.cuda.synchronize()
+    t0 = time.time()
+    n = sum(len(r) for r in p.predict_stream([batch] * 10, table_boxes=[tb64] * 10))
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    print(f"predict_stream: {n} pages in {dt * 1e3:.0f} ms = {n / dt:.0f} pages/s (64-page batches, 2-batch latency)")
+for rep in range(2):
+    t0 = time.time()
+    for _ in range(4):
+        p.predict(batch_pages := [pg for pg in (pages + pages)], table_boxes=tb64)
+    dt = time.time() - t0
+    print(f"predict (same pipeline, 64 host pages per call): {256 / dt:.0f} pages/s")
+p.engine.close()
