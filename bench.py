@@ -363,7 +363,7 @@ class HipRunner:
             self.psd = lore_processor_state_dict(seed=3) if first else None
             load(L.PT_MODEL_LORE_DLA34, lambda: pack_lore_dla34(self.lsd, x3=x3))
             load(L.PT_MODEL_LORE_PROCESSOR, lambda: pack_lore_processor(self.psd, x3=x3))
-            self.tsr = TsrStage(eng, LoreConfig(task_type="wtw"), micro_batch=int(os.environ.get("PT_TSR_MICROBATCH", "80")))
+            self.tsr = TsrStage(eng, LoreConfig(task_type="wtw"), micro_batch=int(os.environ.get("PT_TSR_MICROBATCH", "128")))
 
         self.cls_line = self.cls_page = None
         if "cls" in stages:      # SURVEY 8f-1 (not part of BASELINE.json's metric; opt-in): PP-LCNet text-line + page orientation

@@ -397,9 +397,10 @@ static int microbatch() {
   static int mb = -1;
   if (mb < 0) {
     const char* s = getenv("PT_DET_MICROBATCH");
-    // 32 pages per launch: the 30x30 / 60x60 layers of an 8-page batch are only 256-1000 workgroups, i.e. one (partial)
-    // round on 256 CUs x 2; measured det-only 3314 -> 3996 pages/s (8 -> 32), 4096 at 64; ~190 MB of activations per page
-    mb = s ? atoi(s) : 32;
+    // 64 pages per launch: the 30x30 / 60x60 layers of an 8-page batch are only 256-1000 workgroups, i.e. one (partial)
+    // round on 256 CUs x 2; measured det-only 3314 -> 3996 pages/s (8 -> 32), 4096 at 64; four stages 513 -> 519 pages/s
+    // (32 -> 64, with 128-table Lore micro-batches); ~190 MB of activations per page = 12 GB of the 288 GB at 64
+    mb = s ? atoi(s) : 64;
     if (mb < 1) mb = 1;
   }
   return mb;

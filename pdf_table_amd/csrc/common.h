@@ -136,6 +136,12 @@ struct ConvDesc {
   // input NHWC bf16
   const bf16_t* in = nullptr;
   int B = 0, H = 0, W = 0, Cin = 0;  // Cin multiple of 32 (channel stride == Cin)
+  // 1x1 stride-1 GEMM over a channel concatenation that is never materialised (DLA-34 `Root`: conv(torch.cat(children)),
+  // center_net/modeling_centernet.py:196-214): K walks `nseg` tensors of seg_c[i] channels each (multiples of 32, sum = Cin),
+  // `in` is segment 0, in_more[i - 1] segment i; every segment is its own NHWC tensor (channel stride seg_c[i])
+  const bf16_t* in_more[3] = {nullptr, nullptr, nullptr};
+  int seg_c[4] = {0, 0, 0, 0};
+  int nseg = 1;
   // packed weights [N/64][Cin/32][taps][64][32] bf16, bias fp32 [N]
   const bf16_t* w = nullptr;
   const float* bias = nullptr;

@@ -65,6 +65,11 @@ struct ConvK {
   const int* xlimit;      // device int [B]: tiles of image b whose first output column is >= xlimit[b] do nothing (ragged lines)
   const int* xlimit_rows; // device int [Ho]: the same per output ROW (sequence views [1, lines, T, C])
   const int* xcols;       // host-side bookkeeping only (launch_cfg): ConvDesc.xlimit_cols
+  // 1x1 stride-1 only: K over nseg > 1 tensors (ConvDesc.in_more / seg_c); `in` is segment 0
+  const bf16_t* in1;
+  const bf16_t* in2;
+  const bf16_t* in3;
+  int segc0, segc1, segc2, segc3, nseg;
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
@@ -398,6 +403,24 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
     // split mode: K chunks walk [x_hi | x_lo] against w_hi, then x_hi again against w_lo
     int c0 = chunk << 5;
     if (c0 >= in_cs) c0 -= in_cs;
+    const bf16_t* src = in_b;
+    int src_cs = in_cs;
+    if (KS == 1 && STRIDE == 1 && p.nseg > 1) {
+      // K over a concatenation of tensors: logical channel -> (segment, channel inside it); uniform over the workgroup
+      int cc = chunk << 5, lo = 0;
+      if (p.split) {
+        if (cc >= 2 * p.Cin) cc -= 2 * p.Cin;
+        else if (cc >= p.Cin) { cc -= p.Cin; lo = 1; }
+      }
+      const bf16_t* sp = p.in;
+      int sc = p.segc0;
+      if (cc >= sc) { cc -= sc; sp = p.in1; sc = p.segc1;
+        if (cc >= sc) { cc -= sc; sp = p.in2; sc = p.segc2;
+          if (cc >= sc) { cc -= sc; sp = p.in3; sc = p.segc3; } } }
+      src_cs = p.split ? 2 * sc : sc;
+      src = sp + (size_t)b * p.H * p.W * src_cs;
+      c0 = cc + (lo ? sc : 0);
+    }
 #pragma unroll
     for (int j = 0; j < C::NI; ++j) {
       const int idx = tid + j * 256;
@@ -407,7 +430,7 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
         const int iy = pix / C::TWIN, ix = pix - iy * C::TWIN;
         const int gy = iy0 + iy, gx = ix0 + ix;
         if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-          v = *reinterpret_cast<const u32x4*>(in_b + ((size_t)gy * p.W + gx) * in_cs + c0 + part * 8);
+          v = *reinterpret_cast<const u32x4*>(src + ((size_t)gy * p.W + gx) * src_cs + c0 + part * 8);
       }
       rin[j] = v;
     }
@@ -1021,6 +1044,18 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   PT_REQUIRE(d.n_valid % 8 == 0 && d.n_valid <= d.N, "conv: n_valid=%d must be a multiple of 8 and <= N", d.n_valid);
   PT_REQUIRE(!(d.out_f32 && (d.rep != 1 || d.shuffle_cout)), "conv: fp32 output only on the plain store path");
   k.in = d.in; k.w = d.w; k.bias = d.bias; k.out = d.out; k.res = d.res;
+  k.nseg = d.nseg;
+  if (d.nseg > 1) {
+    PT_REQUIRE(d.nseg <= 4 && d.ks == 1 && d.stride == 1, "conv: K over several tensors needs a 1x1 stride-1 layer and <= 4 segments");
+    int sum = 0;
+    for (int i = 0; i < d.nseg; ++i) {
+      PT_REQUIRE(d.seg_c[i] > 0 && d.seg_c[i] % 32 == 0 && (i == 0 || d.in_more[i - 1]), "conv: bad K segment %d", i);
+      sum += d.seg_c[i];
+    }
+    PT_REQUIRE(sum == d.Cin, "conv: K segments sum to %d channels, Cin is %d", sum, d.Cin);
+    k.in1 = d.in_more[0]; k.in2 = d.in_more[1]; k.in3 = d.in_more[2];
+    k.segc0 = d.seg_c[0]; k.segc1 = d.seg_c[1]; k.segc2 = d.seg_c[2]; k.segc3 = d.seg_c[3];
+  }
   k.B = d.B; k.H = d.H; k.W = d.W; k.Cin = d.Cin; k.N = d.N;
   const int pad = d.ks / 2;
   k.Ho = (d.H + 2 * pad - d.ks) / d.stride + 1;

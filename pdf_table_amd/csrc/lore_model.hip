@@ -81,6 +81,26 @@ struct Ctx {
     const int r = pt_launch_conv(e, c, s);
     if (r != PT_OK) rc = r;
   }
+  // 1x1 conv over the channel concatenation of `ins` (never materialised): one GEMM whose K walks the tensors
+  void conv_cat(const std::vector<T>& ins, const std::string& q, int N, const T& out, int relu) {
+    const PtTensor* w = get(q + (x3 ? ".w3" : ".w"));
+    const PtTensor* b = get(q + ".b");
+    if (rc != PT_OK || dry || !ok) return;
+    ConvDesc c;
+    c.in = ins[0].p; c.B = n; c.H = ins[0].H; c.W = ins[0].W;
+    c.nseg = (int)ins.size();
+    c.Cin = 0;
+    for (int i = 0; i < c.nseg; ++i) {
+      c.seg_c[i] = ins[i].C;
+      c.Cin += ins[i].C;
+      if (i) c.in_more[i - 1] = ins[i].p;
+    }
+    c.w = reinterpret_cast<const bf16_t*>(w->d_ptr); c.bias = reinterpret_cast<const float*>(b->d_ptr);
+    c.N = N; c.ks = 1; c.stride = 1; c.relu = relu; c.split = x3; c.alg_scale = alg_scale;
+    c.out = out.p; c.out_cstride = out.C * mul; c.out_lo_off = out.C;
+    const int r = pt_launch_conv(e, c, s);
+    if (r != PT_OK) rc = r;
+  }
   T maxpool2(const T& x) {
     T o = alloc(x.H / 2, x.W / 2, x.C);
     if (rc == PT_OK && !dry && ok) {
@@ -112,8 +132,7 @@ struct Ctx {
       std::vector<T> ins = {x2, x1};
       ins.insert(ins.end(), children.begin(), children.end());
       T o = alloc(x1.H, x1.W, cout);
-      for (size_t i = 0; i < ins.size(); ++i)
-        conv(ins[i], q + ".root.c" + std::to_string(i), cout, 1, 1, o, i + 1 == ins.size() ? 1 : 0, i ? &o : nullptr);
+      conv_cat(ins, q + ".root", cout, o, 1);      // Root: conv(cat(x2, x1, *children)) + BN + ReLU, one launch
       return o;
     }
     T x1 = tree(q + ".tree1", levels - 1, x, cin, cout, stride, false, {});

@@ -84,7 +84,7 @@ class OcrTableStructureTask(BaseInferTask):
     def _build_processor(self):
         # tables per DLA-34 launch chain: 8-table launches leave most of the 256 CUs idle in the coarse levels (measured
         # with the bench's 80); TsrStage balances the last micro-batch (87 tables -> 44 + 43)
-        self._stage = TsrStage(self._engine, self._config, micro_batch=int(os.environ.get("PT_TSR_MICROBATCH", "80")))
+        self._stage = TsrStage(self._engine, self._config, micro_batch=int(os.environ.get("PT_TSR_MICROBATCH", "128")))
 
     def _predict(self, images: List[np.ndarray]) -> List[Dict]:
         """one table image each (RGB ndarray): the whole image is the crop"""

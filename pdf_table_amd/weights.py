@@ -215,8 +215,8 @@ def pack_lore_dla34(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
     """``DLASeg`` state_dict -> blob for PT_MODEL_LORE_DLA34.
 
     * every Conv->BN pair folded; the 16-input-channel levels (level0, level1) are packed tap-major for the thin kernel;
-    * Root 1x1 convs over a channel concat are split per child (``root.c<i>``): the engine accumulates them through
-      the residual path instead of materialising the concat;
+    * Root 1x1 convs over a channel concat keep their weight (K in the order [x2, x1, *children] of the concat): the
+      engine's 1x1 GEMM walks K over the child tensors, the concat is never materialised;
     * DCN: ``.om`` = the 27-channel offset/mask conv padded to 64 outputs (fp32 out), ``.dcn`` = the deformable conv
       as a 1x1 GEMM over the 9*C sampled columns (tap-major K), with ``actf`` BN folded in;
     * depthwise ConvTranspose2d up-samplers: fp32 ``[k*k][C]``."""
@@ -258,10 +258,7 @@ def pack_lore_dla34(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
             w, b = fold_conv_bn(sd, p + ".root.conv", p + ".root.bn")
             widths = [cout, cout] + children
             assert sum(widths) == w.shape[1], (p, widths, w.shape)
-            o = 0
-            for i, wd in enumerate(widths):
-                bl.add_conv(f"{q}.root.c{i}", w[:, o:o + wd].contiguous(), b if i == 0 else torch.zeros_like(b))
-                o += wd
+            bl.add_conv(f"{q}.root", w, b)
             if cin != cout:
                 bl.add_conv(q + ".project", *fold_conv_bn(sd, p + ".project.0", p + ".project.1"))
         else:
