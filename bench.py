@@ -548,6 +548,25 @@ class HipRunner:
                 "definition": "BASELINE.md section 5: 111.71e9 x det-only pages/s / 2.5e15 (960x960 graph, whole det stage "
                               "incl. pre-process, bitmap and the overlapped host post-process in the time)"}
 
+    def overlap_leg(self, steps=8, warm=2):
+        """the same step with the recogniser on a second stream beside layout / detection / TSR (what OcrTablePipeline does by
+        default).  Not the driver's `value`: kernels of two streams share the CUs, so per-launch durations -- the roofline's
+        denominator -- would no longer be those of the kernel alone."""
+        torch = self.torch
+        if self.rec is None or self.rec_stream is not None:
+            return None
+        self.rec_stream = torch.cuda.Stream(device=self.dev)
+        self.rec_stream.wait_stream(torch.cuda.current_stream(self.dev))
+        self.eng.set_lstm_cluster(False)      # the cluster LSTM needs the GPU to itself (pt_engine_set_lstm_cluster)
+        try:
+            dt, _ = self.timed(steps, warm)
+        finally:
+            self.sync()
+            self.rec_stream = None
+            self.eng.set_lstm_cluster(os.environ.get("PT_LSTM_CLUSTER", "1") != "0")
+        return {"pages_per_s": PAGES_PER_STEP * steps / dt, "steps": steps,
+                "schedule": "recogniser on a second stream (streaming LSTM kernel), everything else as in the timed region"}
+
     def x3_leg_run(self, steps=3, warm=1):
         """the same step in PT_PRECISION_BF16X3 (the mode whose tests assert 1e-3 / id-exact parity)"""
         L = self.L
@@ -748,6 +767,10 @@ def main(argv=None):
             leg = runner.det_only_leg()
             if rank == 0:
                 out["roofline"]["det_backbone"] = leg
+        if len(runner.stages) > 1:
+            leg = runner.overlap_leg()
+            if rank == 0 and leg is not None:
+                out["overlap_rec"] = leg
         if runner.x3_leg and not args.no_post:
             leg = runner.x3_leg_run()
             if rank == 0:

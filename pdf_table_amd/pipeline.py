@@ -258,6 +258,7 @@ class OcrTablePipeline:
         tb_iter = iter(table_boxes) if table_boxes is not None else None
         t_start = time.time()
         total_lines = 0
+        host = {"queue_first": 0.0, "queue_second": 0.0, "collect": 0.0}      # host seconds per phase (self.metric)
 
         def queue_first(batch, k):
             """layout(k) + detection(k)"""
@@ -284,8 +285,12 @@ class OcrTablePipeline:
         def queue_second(st):
             """host halves of detection / layout, then recognition + table structure on their results"""
             prob, bitmap, ev = st["det"]
+            t0 = time.perf_counter()
             st["boxes"] = [sort_boxes_reading_order(b) for b in det.boxes(prob, bitmap, st["shape"], ev)]
+            t1 = time.perf_counter()
             st["layout"] = lay_stage.finish(st["lay"][0], st["lay"][1], st["shape"]) if lay_stage is not None else None
+            host["second.boxes"] = host.get("second.boxes", 0.0) + t1 - t0
+            host["second.layout"] = host.get("second.layout", 0.0) + time.perf_counter() - t1
             with torch.cuda.stream(rec_s):
                 rec_s.wait_event(st["uploaded"])
                 try:
@@ -311,7 +316,10 @@ class OcrTablePipeline:
 
         def collect(st) -> List[PageResult]:
             nonlocal total_lines
+            t0 = time.perf_counter()
             texts = self._finish_rec(rec_stage, st["pages"], st["boxes"], st["rec"], rec_s)
+            t1 = time.perf_counter()
+            host["collect.texts"] = host.get("collect.texts", 0.0) + t1 - t0
             tsr = None
             if tsr_stage is not None:
                 pending, metas, offs, ev = st["tsr"]
@@ -320,7 +328,10 @@ class OcrTablePipeline:
                     with torch.cuda.stream(aux):      # counts D2H + processor: behind the decode of THESE tables only
                         aux.wait_event(ev)
                         processed = tsr_stage.process(pending)
+                    t2 = time.perf_counter()
                     flat = tsr_stage.collect(processed, metas, offs)
+                    host["collect.tsr_process"] = host.get("collect.tsr_process", 0.0) + t2 - t1
+                    host["collect.tsr_collect"] = host.get("collect.tsr_collect", 0.0) + time.perf_counter() - t2
                 tsr = tsr_stage.regroup(flat, st["tb"])
                 if self.table_html:
                     self._attach_html(tsr, st["tb"], st["boxes"], texts)
@@ -334,23 +345,30 @@ class OcrTablePipeline:
                                       table_structure_result=None if tsr is None else tsr[k]))
             return out
 
+        def timed(name, fn, *a):
+            t0 = time.perf_counter()
+            r = fn(*a)
+            host[name] += time.perf_counter() - t0
+            return r
+
         first = second = None          # batch k-1 (device halves of layout / detection queued), batch k-2 (recognition / tables queued)
         k = 0
         for batch in batches:
-            cur = queue_first(batch, k)
+            cur = timed("queue_first", queue_first, batch, k)
             if first is not None:
-                queue_second(first)
+                timed("queue_second", queue_second, first)
             if second is not None:
-                yield collect(second)
+                yield timed("collect", collect, second)
             second, first = first, cur
             k += 1
         if first is not None:
-            queue_second(first)
+            timed("queue_second", queue_second, first)
         if second is not None:
-            yield collect(second)
+            yield timed("collect", collect, second)
         if first is not None:
-            yield collect(first)
-        self.metric = {"use_time": time.time() - t_start, "batches": k, "text_recognition": {"total": total_lines}}
+            yield timed("collect", collect, first)
+        self.metric = {"use_time": time.time() - t_start, "batches": k, "text_recognition": {"total": total_lines},
+                       "host_seconds": host}
 
     def _attach_html(self, tsr, tb, boxes, texts):
         """cells (page pixels since the stage shifts them) x the page's text lines (page pixels) -> HTML per table"""
