@@ -199,6 +199,8 @@ int pt_launch_stem7x7(pt_engine* e, const bf16_t* in, int B, int H, int W, const
 int pt_launch_det_preprocess(const uint8_t* pages, int n, int h, int w, int nh, int nw, int flavour, int split,
                              bf16_t* out, hipStream_t s);
 int pt_launch_maxpool3x3s2(const bf16_t* in, int B, int H, int W, int C, bf16_t* out, int split, hipStream_t s);
+int pt_launch_stem7x7_pool(pt_engine* e, const bf16_t* in, int B, int H, int W, const bf16_t* w, const float* bias, bf16_t* out,
+                           hipStream_t s);   // ResNet-18 stem + MaxPool2d(3,2,1) in one kernel (bf16 mode)
 int pt_launch_db_head_final(const bf16_t* in, int B, int H, int W, const void* w4x64, const float* bias, float* prob,
                             float* logits, int split, hipStream_t s);
 int pt_launch_db_head_mfma(const bf16_t* in, int B, int H, int W, const bf16_t* w3, const float* b3, const bf16_t* w6,

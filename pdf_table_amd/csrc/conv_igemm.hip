@@ -832,6 +832,143 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_kernel(ConvK p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// ResNet-18 stem + max-pool in one kernel (db_net/dbnet.py:272-275: conv 7x7/s2 + BN + ReLU, MaxPool2d(3, 2, 1)), bf16 mode.
+// conv_stem7x7_kernel<2,2> writes the 64-channel half-resolution map (29.5 MB per 960x960 page) and maxpool3x3s2_kernel
+// reads it back: 1.9 GB of the detector's traffic per 32 pages, and two latency-bound launches (one 8x32 tile per
+// workgroup, nothing overlapped).  Here a workgroup computes a 16x32 patch of the stem map (4 MFMA row-tiles per wave),
+// rounds it to bf16 exactly as the stored map would be, keeps it in LDS and writes the 7x15 pooled pixels it covers
+// (window rows 2py-1..2py+1: patch rows 2(py-py0)..+2): the stem map never exists in HBM.  1.22x the stem's MFMA work
+// (16/14 x 32/30 re-computed halo) against -1.9 GB.  Results are bit-identical to stem -> store -> pool: the conv sums
+// in the same order, the rounding is the same instruction, and a max over non-negative bf16 values is a max over their
+// bit patterns (positions outside the stem map hold 0, which never wins against the always-valid window centre).
+// The weights are the MFMA's A operand (D = [channel][pixel]): a lane owns a pixel and packs runs of four channels.
+// ---------------------------------------------------------------------------------------------------
+struct StemPoolCfg {
+  static constexpr int TH = 16, TW = 32, PH = 7, PW = 15;
+  static constexpr int THIN = (TH - 1) * 2 + 7;          // 37
+  static constexpr int TWIN = 70;                        // (TW - 1) * 2 + 8, as StemCfg<2>
+  static constexpr int IN_BYTES = THIN * TWIN * 8;       // 20 720
+  static constexpr int WROW = 464;
+  static constexpr int W_BYTES = 64 * WROW;              // 29 696
+  static constexpr int PIX = 136;                        // staged pixel: 64 bf16 + 8 B (conflict-free 8-byte writes of 16 lanes)
+  static constexpr int STAGE_BYTES = TH * TW * PIX;      // 69 632
+  static constexpr int SMEM = STAGE_BYTES;               // > IN_BYTES + W_BYTES
+  static constexpr int HP = TWIN / 2;
+  static constexpr int NP_IN = THIN * HP;                // 1295 pixel pairs
+  static constexpr int NI = (NP_IN + 255) / 256;         // 6
+  static constexpr int NWP = 64 * 28 / 256;              // 7
+};
+
+__global__ __launch_bounds__(256, 2) void conv_stem7x7_pool_kernel(ConvK p) {
+  using C = StemPoolCfg;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_in = smem;
+  char* s_w = smem + C::IN_BYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, q = lane >> 5;
+  // p.Ho x p.Wo is the STEM map (H/2 x W/2); tiles_x / tiles_y count pooled tiles of PH x PW
+  int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int txi = L % p.tiles_x;
+  L /= p.tiles_x;
+  const int tyi = L % p.tiles_y;
+  const int b = L / p.tiles_y;
+  const int py0 = tyi * C::PH, px0 = txi * C::PW;
+  const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;        // first stem row / column of the patch
+  const int iy0 = sy0 * 2 - 3, ix0 = sx0 * 2 - 3;
+  const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * 4;
+
+#pragma unroll
+  for (int j = 0; j < C::NI; ++j) {
+    const int idx = tid + j * 256;
+    if (idx < C::NP_IN) {
+      const int iy = idx / C::HP, ip = idx - iy * C::HP;
+      const int gy = iy0 + iy, gx = ix0 + 2 * ip;
+      u32x2 v0 = {0u, 0u}, v1 = {0u, 0u};
+      if ((unsigned)gy < (unsigned)p.H) {
+        const bf16_t* rowp = in_b + (size_t)gy * p.W * 4;
+        if ((unsigned)gx < (unsigned)p.W) v0 = *reinterpret_cast<const u32x2*>(rowp + (size_t)gx * 4);
+        if ((unsigned)(gx + 1) < (unsigned)p.W) v1 = *reinterpret_cast<const u32x2*>(rowp + (size_t)(gx + 1) * 4);
+      }
+      const u32x4 v = {v0.x, v0.y, v1.x, v1.y};
+      *reinterpret_cast<u32x4*>(s_in + (iy * C::TWIN + 2 * ip) * 8) = v;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < C::NWP; ++j) {
+    const int idx = tid + j * 256;
+    const int row = idx / 28, part = idx - row * 28;
+    *reinterpret_cast<u32x4*>(s_w + row * C::WROW + part * 16) = *reinterpret_cast<const u32x4*>(p.w + idx * 8);
+  }
+  __syncthreads();
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  const char* a_base = s_in + (((wave * 4) * 2) * C::TWIN + 2 * lx + 2 * q) * 8;
+  const char* b_base = s_w + lx * C::WROW + q * 16;
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ks = r * 2 + h;
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(b_base + ks * 32);
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(b_base + 32 * C::WROW + ks * 32);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base + ((m * 2 + r) * C::TWIN + 4 * h) * 8);
+        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a, acc[m][0], 0, 0, 0);     // D = [channel][pixel]
+        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a, acc[m][1], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();      // the operand images are dead: the patch takes their place
+  // lane (lx, q): stem pixel (sy0 + 4 wave + m, sx0 + lx); register r of block n = channel 32 n + (r & 3) + 8 (r >> 2) + 4 q
+  const bool col_ok = (unsigned)(sx0 + lx) < (unsigned)p.Wo;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int row = wave * 4 + m;
+    const bool ok = col_ok && (unsigned)(sy0 + row) < (unsigned)p.Ho;
+    char* dst = smem + (row * C::TW + lx) * C::PIX + 8 * q;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n * 32 + 8 * g + 4 * q);
+        u32x2 o = {0u, 0u};
+        if (ok) {
+          o.x = pack_bf16x2(fmaxf(acc[m][n][4 * g + 0] + bv.x, 0.f), fmaxf(acc[m][n][4 * g + 1] + bv.y, 0.f));
+          o.y = pack_bf16x2(fmaxf(acc[m][n][4 * g + 2] + bv.z, 0.f), fmaxf(acc[m][n][4 * g + 3] + bv.w, 0.f));
+        }
+        *reinterpret_cast<u32x2*>(dst + (n * 32 + 8 * g) * 2) = o;
+      }
+  }
+  __syncthreads();
+  // pooled pixel (py0 + py, px0 + px), channels 4 c .. 4 c + 3: max over the 3x3 window of bit patterns (all values >= +0)
+  const int PHo = p.Ho >> 1, PWo = p.Wo >> 1;
+  for (int idx = tid; idx < C::PH * C::PW * 16; idx += 256) {
+    const int c4 = idx & 15, pp = idx >> 4;
+    const int py = pp / C::PW, px = pp - py * C::PW;
+    const int oy = py0 + py, ox = px0 + px;
+    if (oy >= PHo || ox >= PWo) continue;
+    u32x2 mx = {0u, 0u};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(smem + ((2 * py + dy) * C::TW + 2 * px + dx) * C::PIX + c4 * 8);
+        mx.x = __builtin_elementwise_max(mx.x & 0xFFFFu, v.x & 0xFFFFu) | (__builtin_elementwise_max(mx.x >> 16, v.x >> 16) << 16);
+        mx.y = __builtin_elementwise_max(mx.y & 0xFFFFu, v.y & 0xFFFFu) | (__builtin_elementwise_max(mx.y >> 16, v.y >> 16) << 16);
+      }
+    *reinterpret_cast<u32x2*>(p.out + (((size_t)b * PHo + oy) * PWo + ox) * 64 + c4 * 4) = mx;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Thin stride-1 stem (DLA-34 base_layer: 3 -> 16 channels at full resolution, bf16 mode).  conv_stem7x7_kernel<1,1> spends
 // most of its time around the MFMAs: every 8x32-pixel workgroup re-loads the 29 KB weight image from L2 (3.7 GB per
 // 32 tables) and sends 256 x 64 fp32 through LDS to store 16 channels.  Here a workgroup walks STEM_NT tiles of a row
@@ -1132,6 +1269,33 @@ static int launch_stem(pt_engine* e, ConvK& k, hipStream_t s) {
   PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "stem grid out of range");
   PtProfScope prof(e, s, PT_PROF_STEM, 2.0 * k.B * k.Ho * k.Wo * 64.0 * 147.0, S == 2 ? "stem7x7 s2" : "stem7x7 s1");
   hipLaunchKernelGGL((conv_stem7x7_kernel<S, NH>), dim3((unsigned)nblk), dim3(256), StemCfg<S>::SMEM, s, k);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// ResNet-18 stem + MaxPool2d(3, 2, 1) fused (bf16 mode): in NHWC4 [B, H, W, 4], out [B, H/4, W/4, 64]
+int pt_launch_stem7x7_pool(pt_engine* e, const bf16_t* in, int B, int H, int W, const bf16_t* w, const float* bias, bf16_t* out,
+                           hipStream_t s) {
+  PT_REQUIRE(in && w && bias && out, "stem+pool: null pointer");
+  PT_REQUIRE(H % 4 == 0 && W % 4 == 0 && H > 0 && W > 0, "stem+pool: H, W must be multiples of 4");
+  static bool attr_done = false;
+  if (!attr_done) {
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem7x7_pool_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, StemPoolCfg::SMEM));
+    attr_done = true;
+  }
+  ConvK k;
+  memset(&k, 0, sizeof(k));
+  k.in = in; k.w = w; k.bias = bias; k.out = out;
+  k.B = B; k.H = H; k.W = W; k.Cin = 4; k.N = 64;
+  k.Ho = H / 2; k.Wo = W / 2;
+  k.tiles_x = (W / 4 + StemPoolCfg::PW - 1) / StemPoolCfg::PW;
+  k.tiles_y = (H / 4 + StemPoolCfg::PH - 1) / StemPoolCfg::PH;
+  const long long nblk = (long long)B * k.tiles_x * k.tiles_y;
+  PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "stem+pool grid out of range");
+  // FLOP of the layer (the re-computed halo is not algorithmic work)
+  PtProfScope prof(e, s, PT_PROF_STEM, 2.0 * B * k.Ho * k.Wo * 64.0 * 147.0, "stem7x7 s2 + maxpool");
+  hipLaunchKernelGGL(conv_stem7x7_pool_kernel, dim3((unsigned)nblk), dim3(256), StemPoolCfg::SMEM, s, k);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }

@@ -129,8 +129,13 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
     c.stride = stride; c.out = out; c.out_cstride = out_c * m; c.relu = relu; c.split = x3; c.out_lo_off = out_c;
     return c;
   };
-  RUN(pt_launch_stem7x7(e, x, n, H, W_, W(w.stem_w), Bv(w.stem_b), bf.s, x3, s));
-  {
+  // bf16 mode: stem + max-pool in one kernel (the 64-channel half-resolution map stays in LDS; bit-identical);
+  // PT_STEM_POOL=0 (read per call) keeps the two launches
+  const char* sp_env = getenv("PT_STEM_POOL");
+  if (!x3 && !(sp_env && atoi(sp_env) == 0)) {
+    RUN(pt_launch_stem7x7_pool(e, x, n, H, W_, W(w.stem_w), Bv(w.stem_b), bf.p, s));
+  } else {
+    RUN(pt_launch_stem7x7(e, x, n, H, W_, W(w.stem_w), Bv(w.stem_b), bf.s, x3, s));
     PtProfScope ps(e, s, PT_PROF_OTHER, 0, "maxpool");
     RUN(pt_launch_maxpool3x3s2(bf.s, n, H / 2, W_ / 2, 64, bf.p, x3, s));
   }

@@ -251,6 +251,24 @@ def test_det_net_bf16_drift_vs_oracle(eng_db, db_sd, shape):
     assert d32 <= 2.0 * o32 + 1e-3 * scale
 
 
+@pytest.mark.parametrize("shape", [(2, 96, 224), (1, 256, 288), (3, 960, 960)])
+def test_stem_pool_fused_is_bit_identical(eng_db, shape, monkeypatch):
+    """conv_stem7x7_pool_kernel (stem + BN + ReLU + MaxPool2d(3,2,1) with the half-resolution map kept in LDS) against the
+    two separate launches (PT_STEM_POOL=0, read per call): the same logits to the bit -- sizes whose pooled map is not a
+    whole number of 7x15 tiles, and the bench's 960x960"""
+    n, H, W = shape
+    g = torch.Generator().manual_seed(7 + H)
+    x = _x4(_bf16(torch.randn(n, 3, H, W, generator=g))).cuda()
+    monkeypatch.delenv("PT_STEM_POOL", raising=False)
+    _, fused = eng_db.det_forward_net(x, want_logits=True)
+    fused = fused.cpu()
+    monkeypatch.setenv("PT_STEM_POOL", "0")
+    _, two = eng_db.det_forward_net(x, want_logits=True)
+    two = two.cpu()
+    assert torch.isfinite(fused).all() and fused.abs().max() > 0
+    assert torch.equal(fused, two)
+
+
 def test_conv_x3_vs_torch_fp32(eng):
     """One 3x3 conv in BF16X3 mode against F.conv2d on UN-rounded fp32 operands."""
     from pdf_table_amd.weights import tile_conv_weight_x3

@@ -34,9 +34,12 @@ for overlap in (False, True, False, True):
 # predict_stream: ten 64-page batches already on the device, table regions given (bench.py's workload shape)
 # detect_model="db_pp": the PP-OCR pre/post flavour around DB-ResNet18 (1024^2 page -> 960^2 net input), bench.py's detection
 # workload; the "db" flavour of the runs above feeds the net 1024^2
-p = OcrTablePipeline(device=0, synthetic_seed=0, layout=True, table_structure=True, detect_model="db_pp", allow_stand_in=True)
+p = OcrTablePipeline(device=0, synthetic_seed=0, layout=True, table_structure=True)
 quads64 = (quads + quads)
 stage = p.text_detector._stage
+from pdf_table_amd.det_stage import DetConfig
+stage.cfg = DetConfig(flavour="db_pp", thresh=stage.cfg.thresh, box_thresh=stage.cfg.box_thresh, unclip_ratio=stage.cfg.unclip_ratio,
+                      use_dilation=stage.cfg.use_dilation)
 orig = stage.boxes
 stage.boxes = lambda prob, bm, shape, ev, _o=orig, _q=quads64: (_o(prob, bm, shape, ev), _q)[1]
 batch = torch.from_numpy(np.stack(pages + pages)).cuda()
