@@ -358,6 +358,29 @@ int pt_op_maxpool3x3s2(pt_engine* e, const uint16_t* d_in, int B, int H, int W, 
 int pt_op_db_head_final(pt_engine* e, const uint16_t* d_in, int B, int H, int W, const void* d_w, const float* d_bias,
                         float* d_prob, float* d_logits, int split, pt_stream stream);
 
+/* ---- single operators of the generic ONNX layer-list executor (pdf_table_amd/onnx_exec.py) --------------------
+ * Replaces: onnxruntime's execution of an arbitrary graph behind BaseInferTask.infer (model/ocr_pdf/base_infer_task.py:
+ * 366-370, sessions built by utils/deploy_utils.py:243-280).  bf16 NHWC, C a multiple of 8; convolutions go to
+ * pt_op_conv2d.  act: 0 none, 1 ReLU, 2 hardswish. */
+/* depthwise k x k (k 3 or 5, pad k/2, stride 1 or 2) + bias + act; d_w_taps fp32 [k*k][C], d_bias fp32 [C] */
+int pt_op_dwconv(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int C, const float* d_w_taps, const float* d_bias, int k,
+                 int stride, int act, uint16_t* d_out, pt_stream stream);
+/* element-wise a + b over npix pixels of C channels */
+int pt_op_add(pt_engine* e, const uint16_t* d_a, const uint16_t* d_b, uint16_t* d_out, long long npix, int C, pt_stream stream);
+/* MaxPool2d(3, 2, 1), or a non-overlapping k x k pool (stride k, no padding, H and W divisible by k) */
+int pt_op_maxpool(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int C, int k, int stride, int pad, uint16_t* d_out,
+                  pt_stream stream);
+/* GlobalAveragePool: [B, HW, C] -> bf16 [B, C]; d_scratch: pt_op_chan_mean_scratch_floats(B, C) floats */
+int pt_op_chan_mean(pt_engine* e, const uint16_t* d_in, int B, int HW, int C, float* d_scratch, uint16_t* d_mean, pt_stream stream);
+int pt_op_chan_mean_scratch_floats(int B, int C);
+/* x [B, HW, C] * gate [B, C] (the Mul of a squeeze-and-excitation block) */
+int pt_op_scale_channels(pt_engine* e, const uint16_t* d_in, const uint16_t* d_gate, int B, int HW, int C, uint16_t* d_out,
+                         pt_stream stream);
+/* stand-alone activation over n_elems (multiple of 8) values; kind: 1 ReLU, 2 hardswish, 4 sigmoid,
+ * 5 hardsigmoid = max(0, min(1, alpha x + beta)), 6 ReLU6 */
+int pt_op_act(pt_engine* e, const uint16_t* d_in, long long n_elems, int kind, float alpha, float beta, uint16_t* d_out,
+              pt_stream stream);
+
 /* ---- introspection used by bench.py (HIP-event timing of the dominant kernel) ------------------ */
 /* ---- image classification (PP-LCNet) ------------------------------------------------------------
  * Replaces ClsImagePulcTask._preprocess/_run_model (ocr_pdf/cls_image_pulc_task.py:48-84): PPLCNetImageProcessor

@@ -44,6 +44,17 @@ def run(model, feeds):
             y = F.batch_norm(x[0], x[3], x[4], x[1], x[2], False, 0.0, a.get("epsilon", 1e-5))
         elif t == "Relu":
             y = torch.relu(x[0])
+        elif t == "HardSigmoid":      # max(0, min(1, alpha x + beta)); ONNX defaults alpha 0.2, beta 0.5
+            y = torch.clamp(a.get("alpha", 0.2) * x[0] + a.get("beta", 0.5), 0.0, 1.0)
+        elif t == "HardSwish":
+            y = x[0] * torch.clamp(x[0] / 6.0 + 0.5, 0.0, 1.0)
+        elif t == "GlobalAveragePool":
+            y = x[0].mean(dim=(2, 3), keepdim=True)
+        elif t == "Flatten":
+            ax = a.get("axis", 1)
+            y = x[0].reshape(int(np.prod(x[0].shape[:ax])) if ax else 1, -1)
+        elif t == "Softmax":
+            y = torch.softmax(x[0], dim=a.get("axis", -1))
         elif t == "Sigmoid":
             y = torch.sigmoid(x[0])
         elif t == "MaxPool":

@@ -74,8 +74,12 @@ def sort_boxes_reading_order(det_result: np.ndarray) -> np.ndarray:
 
 
 class DetStage:
-    def __init__(self, eng: "E.HipEngine", cfg: Optional[DetConfig] = None, workers: Optional[int] = None):
+    def __init__(self, eng: "E.HipEngine", cfg: Optional[DetConfig] = None, workers: Optional[int] = None, net=None):
+        """net: optional callable bf16 NHWC4 [n, H, W, 4] -> probability map f32 [n, H, W] on the device, in place of the
+        engine's own detector networks (an imported ONNX graph run by onnx_exec.HipGraphExecutor); the pre-processing,
+        bitmap, box scores and the host post-process stay the engine's"""
         self.eng = eng
+        self.net = net
         self.cfg = (cfg or DetConfig()).resolved()
         self.workers = workers or max(1, min(32, (os.cpu_count() or 8)))     # threads of the batch host calls
         self._pin = {}
@@ -98,8 +102,16 @@ class DetStage:
             buf = (torch.empty((n, nh, nw), dtype=torch.float32, device=dev),
                    torch.empty((n, nh, nw // 32), dtype=torch.int32, device=dev))
             self._pin[key] = buf
-        prob, bitmap = self.eng.det_forward(pages, self.cfg.pre, self.cfg.thresh, self.cfg.use_dilation,
-                                            out_prob=buf[0], out_bitmap=buf[1])
+        if self.net is not None:
+            prob = self.net(self.eng.det_preprocess(pages, self.cfg.pre))
+            if tuple(prob.shape) != (n, nh, nw):
+                raise RuntimeError(f"the detector network returned a {tuple(prob.shape)} map for {n} pages of {nh}x{nw}")
+            buf[0].copy_(prob)
+            buf[1].copy_(self.eng.det_bitmap(buf[0], self.cfg.thresh, self.cfg.use_dilation))
+            prob, bitmap = buf
+        else:
+            prob, bitmap = self.eng.det_forward(pages, self.cfg.pre, self.cfg.thresh, self.cfg.use_dilation,
+                                                out_prob=buf[0], out_bitmap=buf[1])
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         return prob, bitmap, ev

@@ -452,7 +452,60 @@ class HipEngine:
                 out = torch.empty((B, Ho * rep, Wo * rep, N * m), dtype=torch.bfloat16, device=self._tdev)
         L.check(self.lib.pt_op_conv2d(self._h, _ptr(x), B, H, W, Cin, _ptr(w_tiled), _ptr(bias), N, ks, stride,
                                       _ptr(out), out.shape[-1], out_coff, rep, shuffle_cout, _ptr(res), res_mode,
-                                      int(relu), int(split), out.shape[-1] // 2, self._stream()), "pt_op_conv2d")
+                                      int(relu), int(split), out.shape[-1] // 2, self._stream()), "pt_op_conv2d")      # relu: bool, or the epilogue's activation code (0 none, 1 ReLU, 2 hardswish)
+        return out
+
+    # ---- single operators of the generic ONNX executor (pdf_table_amd/onnx_exec.py); bf16 NHWC, C a multiple of 8 -------
+    def op_dwconv(self, x: torch.Tensor, w_taps: torch.Tensor, bias: torch.Tensor, k: int, stride: int = 1, act: int = 0) -> torch.Tensor:
+        self._chk(x, torch.bfloat16, "x")
+        self._chk(w_taps, torch.float32, "w_taps")
+        self._chk(bias, torch.float32, "bias")
+        B, H, W, Cc = x.shape
+        pad = k // 2
+        out = torch.empty((B, (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1, Cc), dtype=torch.bfloat16, device=self._tdev)
+        L.check(self.lib.pt_op_dwconv(self._h, _ptr(x), B, H, W, Cc, _ptr(w_taps), _ptr(bias), k, stride, act, _ptr(out), self._stream()),
+                "pt_op_dwconv")
+        return out
+
+    def op_add(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        self._chk(a, torch.bfloat16, "a")
+        self._chk(b, torch.bfloat16, "b")
+        if a.shape != b.shape:
+            raise ValueError(f"op_add: shapes differ: {tuple(a.shape)} vs {tuple(b.shape)}")
+        out = torch.empty_like(a)
+        L.check(self.lib.pt_op_add(self._h, _ptr(a), _ptr(b), _ptr(out), a.numel() // a.shape[-1], a.shape[-1], self._stream()), "pt_op_add")
+        return out
+
+    def op_maxpool(self, x: torch.Tensor, k: int, stride: int, pad: int) -> torch.Tensor:
+        self._chk(x, torch.bfloat16, "x")
+        B, H, W, Cc = x.shape
+        out = torch.empty((B, (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1, Cc), dtype=torch.bfloat16, device=self._tdev)
+        L.check(self.lib.pt_op_maxpool(self._h, _ptr(x), B, H, W, Cc, k, stride, pad, _ptr(out), self._stream()), "pt_op_maxpool")
+        return out
+
+    def op_chan_mean(self, x: torch.Tensor) -> torch.Tensor:
+        """GlobalAveragePool: [B, H, W, C] -> [B, 1, 1, C]"""
+        self._chk(x, torch.bfloat16, "x")
+        B, H, W, Cc = x.shape
+        scratch = torch.empty((self.lib.pt_op_chan_mean_scratch_floats(B, Cc),), dtype=torch.float32, device=self._tdev)
+        out = torch.empty((B, 1, 1, Cc), dtype=torch.bfloat16, device=self._tdev)
+        L.check(self.lib.pt_op_chan_mean(self._h, _ptr(x), B, H * W, Cc, _ptr(scratch), _ptr(out), self._stream()), "pt_op_chan_mean")
+        return out
+
+    def op_scale_channels(self, x: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
+        self._chk(x, torch.bfloat16, "x")
+        self._chk(gate, torch.bfloat16, "gate")
+        B, H, W, Cc = x.shape
+        if gate.numel() != B * Cc:
+            raise ValueError(f"op_scale_channels: gate {tuple(gate.shape)} does not match [{B}, {Cc}]")
+        out = torch.empty_like(x)
+        L.check(self.lib.pt_op_scale_channels(self._h, _ptr(x), _ptr(gate), B, H * W, Cc, _ptr(out), self._stream()), "pt_op_scale_channels")
+        return out
+
+    def op_act(self, x: torch.Tensor, kind: int, alpha: float = 0.0, beta: float = 0.0) -> torch.Tensor:
+        self._chk(x, torch.bfloat16, "x")
+        out = torch.empty_like(x)
+        L.check(self.lib.pt_op_act(self._h, _ptr(x), x.numel(), kind, float(alpha), float(beta), _ptr(out), self._stream()), "pt_op_act")
         return out
 
     def op_stem7x7(self, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, split: bool = False) -> torch.Tensor:

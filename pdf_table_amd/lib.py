@@ -90,6 +90,13 @@ def _proto(lib):
         "pt_op_stem7x7": (i, [vp, vp, i, i, i, vp, vp, vp, i, vp]),
         "pt_op_maxpool3x3s2": (i, [vp, vp, i, i, i, i, vp, i, vp]),
         "pt_op_db_head_final": (i, [vp, vp, i, i, i, vp, vp, vp, vp, i, vp]),
+        "pt_op_dwconv": (i, [vp, vp, i, i, i, i, vp, vp, i, i, i, vp, vp]),
+        "pt_op_add": (i, [vp, vp, vp, vp, C.c_longlong, i, vp]),
+        "pt_op_maxpool": (i, [vp, vp, i, i, i, i, i, i, i, vp, vp]),
+        "pt_op_chan_mean": (i, [vp, vp, i, i, i, vp, vp, vp]),
+        "pt_op_chan_mean_scratch_floats": (i, [i, i]),
+        "pt_op_scale_channels": (i, [vp, vp, vp, i, i, i, vp, vp]),
+        "pt_op_act": (i, [vp, vp, C.c_longlong, i, C.c_float, C.c_float, vp, vp]),
         "pt_profile_enable": (i, [vp, i]),
         "pt_profile_read": (i, [vp, vp, vp, vp]),
     }

@@ -83,10 +83,30 @@ class OcrDetectionTask(BaseInferTask):
             # DeployUtils.prepare_onnx_model, utils/deploy_utils.py:243-280): parse the graph, map it to the engine's
             # DB-ResNet18 launch graph, load its weights; any other architecture raises with the graph's inventory
             from .onnx_import import UnsupportedOnnxGraph, load_onnx, recognise
-            arch, sd = recognise(load_onnx(onnx_path))
-            if arch != "db_resnet18":
+            graph = load_onnx(onnx_path)
+            try:
+                arch, sd = recognise(graph)
+            except UnsupportedOnnxGraph:
+                arch, sd = "generic", None
+            if arch == "db_resnet18":
+                self._engine.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(sd))
+            elif arch == "generic":
+                # an architecture without a dedicated launch graph (the real PP-OCR detectors: PP-LCNetV3 / MobileNetV3 +
+                # RSE-FPN + DB head): the layer list runs operator by operator between the engine's pre-processing and
+                # its bitmap / box-score kernels; an operator without a kernel is named when the first batch reaches it
+                from .onnx_exec import HipGraphExecutor
+                ex = HipGraphExecutor(graph, engine=self._engine)
+                if len(ex.outputs) != 1:
+                    raise UnsupportedOnnxGraph(f"{onnx_path}: a text detector returns one probability map, this graph returns {ex.outputs}")
+
+                def net(x4, _ex=ex):
+                    (a,) = _ex.run_device(x4, 3)
+                    if a.c != 1:
+                        raise UnsupportedOnnxGraph(f"{onnx_path}: the output has {a.c} channels, a probability map has one")
+                    return a.t[..., 0].float().contiguous()
+                self._net = net
+            else:
                 raise UnsupportedOnnxGraph(f"{onnx_path} is a '{arch}' network, not a text detector the engine runs")
-            self._engine.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(sd))
             self._model = self._predict
             return
         nas = model == "db" and self._config.backbone == "proxylessnas"      # DBNasModel, modeling_db_net.py:47-49
@@ -121,7 +141,7 @@ class OcrDetectionTask(BaseInferTask):
         return None
 
     def _build_processor(self):
-        self._stage = DetStage(self._engine, self._det_cfg)
+        self._stage = DetStage(self._engine, self._det_cfg, net=getattr(self, "_net", None))
 
     def _predict(self, pages: torch.Tensor):
         return self._stage.forward(pages)

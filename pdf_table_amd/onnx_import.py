@@ -15,10 +15,12 @@ prepare_onnx_model`` utils/deploy_utils.py:243-280; ``infer`` :366-370 calls ``p
     weights run through the SAME kernels and give the same numbers;
   * ``HipOnnxSession`` gives the imported detector the ``predictor.run(None, {"x": ...})`` surface.
 
-A graph of any other architecture (the real PP-OCRv4 / PicoDet exports: PP-LCNetV3 + RSE-FPN, SVTR-LCNet, ...) is parsed
-and listed but NOT executed: ``recognise`` raises ``UnsupportedOnnxGraph`` with the layer inventory and the operators that
-lack kernels -- there is no CPU execution path in the product (oracle/onnx_ref.py executes graphs on the CPU for the
-tests only).
+A graph of any other architecture is executed layer by layer by ``pdf_table_amd.onnx_exec.HipGraphExecutor`` -- one engine
+call per layer of the list -- as long as it is made of the operators that executor lists (convolutional networks:
+detection / layout / classification backbones, necks and heads); ``recognise`` still raises ``UnsupportedOnnxGraph`` with
+the layer inventory for such a graph, and the executor names the first operator it has no kernel for (sequence models:
+attention / LayerNorm blocks of SVTR-type recognisers).  There is no CPU execution path in the product (oracle/onnx_ref.py
+executes graphs on the CPU for the tests only).
 """
 from __future__ import annotations
 
@@ -174,6 +176,9 @@ class OnnxGraph:
                         lay.act = "relu6" if (lo, hi) == (0.0, 6.0) else f"clip({lo},{hi})"
                     else:
                         lay.act = _ACTS[a.op_type]
+                        if a.op_type == "HardSigmoid":      # ONNX defaults: alpha 0.2, beta 0.5 (torch exports 1/6, 0.5)
+                            lay.attrs["act_alpha"] = float(a.attrs.get("alpha", 0.2))
+                            lay.attrs["act_beta"] = float(a.attrs.get("beta", 0.5))
                         if a.op_type == "PRelu":
                             lay.extra["slope"] = np.asarray(self.init[a.inputs[1]], np.float32)
                     used.add(j)
@@ -206,7 +211,8 @@ class OnnxGraph:
                 out.append(Layer("concat", n.name or n.outputs[0], list(n.inputs), [n.outputs[0]], {"axis": int(n.attrs.get("axis", 1))}))
             elif t in _ACTS or t in ("Softmax", "Clip"):
                 out.append(Layer("act", n.name or n.outputs[0], [n.inputs[0]], [n.outputs[0]],
-                                 {"kind": _ACTS.get(t, t.lower()), "axis": int(n.attrs.get("axis", -1))}))
+                                 {"kind": _ACTS.get(t, t.lower()), "axis": int(n.attrs.get("axis", -1)),
+                                  "act_alpha": float(n.attrs.get("alpha", 0.2)), "act_beta": float(n.attrs.get("beta", 0.5))}))
             elif t == "LSTM":
                 out.append(Layer("lstm", n.name or n.outputs[0], [n.inputs[0]], [o for o in n.outputs if o],
                                  {"hidden_size": int(n.attrs["hidden_size"]), "direction": n.attrs.get("direction", "forward")},
@@ -417,21 +423,34 @@ class _IO:
 
 class HipOnnxSession:
     """the ``ort.InferenceSession`` surface the reference's ``infer`` uses (``run`` / ``get_inputs`` / ``get_providers``) over
-    the HIP engine, for graphs ``recognise`` maps to an engine network.  Only whole-network execution: DB-ResNet18
-    (input float [B, 3, H, W] with H, W multiples of 32 -> probability map [B, 1, H, W])."""
+    the HIP engine: a graph ``recognise`` maps to DB-ResNet18 runs on that launch graph (input float [B, 3, H, W] with H, W
+    multiples of 32 -> probability map [B, 1, H, W]); any other convolutional graph runs layer by layer through
+    ``pdf_table_amd.onnx_exec.HipGraphExecutor`` (``arch == "generic"``)."""
 
     def __init__(self, src, engine=None, device: int = 0):
         from . import lib as L
         from .engine import HipEngine
         from .weights import pack_db_resnet18
         self.graph = load_onnx(src)
-        self.arch, self.state_dict = recognise(self.graph)
-        if self.arch != "db_resnet18":
+        self._L = L
+        self._exec = None
+        try:
+            self.arch, self.state_dict = recognise(self.graph)
+        except UnsupportedOnnxGraph:
+            self.arch, self.state_dict = "generic", None
+        if self.arch == "db_resnet18":
+            self.engine = engine or HipEngine(device)
+            self.engine.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(self.state_dict))
+            return
+        if self.arch != "generic" and any(l.op == "lstm" for l in self.graph.layers()):
             raise UnsupportedOnnxGraph(f"'{self.arch}' imports as weights (see the task classes) but has no session surface: its "
                                        "engine path does not materialise the logits the ONNX graph returns")
+        # no dedicated launch graph: the layer list runs operator by operator (convolutional graphs; anything else is named
+        # by the executor when it is reached -- there is no CPU path)
+        from .onnx_exec import HipGraphExecutor
+        self.arch = "generic"
         self.engine = engine or HipEngine(device)
-        self.engine.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(self.state_dict))
-        self._L = L
+        self._exec = HipGraphExecutor(self.graph, engine=self.engine)
 
     def get_providers(self):
         return ["HipExecutionProvider"]
@@ -444,6 +463,11 @@ class HipOnnxSession:
 
     def run(self, output_names, input_dict):
         (x,) = [np.asarray(v) for v in input_dict.values()]
+        if self._exec is not None:
+            outs = self._exec.run(x.astype(np.float32))
+            if output_names:
+                outs = [outs[self._exec.outputs.index(o)] for o in output_names]
+            return [o.astype(np.float16) for o in outs] if x.dtype == np.float16 else outs
         if x.ndim != 4 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
             raise ValueError(f"input {x.shape}: expected [B, 3, H, W] with H, W multiples of 32")
         dev = self.engine._tdev
