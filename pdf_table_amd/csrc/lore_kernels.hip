@@ -476,8 +476,11 @@ __global__ __launch_bounds__(256, (SPLIT || NB > 64) ? 2 : 4) void dcn_fused_ker
 // NTHR = 256 or 512 threads: with 512 a thread blends two (pixel, piece) items per stage instead of four and a wave owns
 // one 32-pixel x (NB / 2) block of the product -- the same arithmetic in the same order, ~100 VGPRs instead of ~190, so
 // that 16 waves per CU (instead of 8) keep gathers in flight.
-template <int NB, int NTHR>
-__global__ __launch_bounds__(NTHR, NTHR / 128) void dcn_fused64_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
+// SPLIT = 1 (PT_PRECISION_BF16X3): x / out carry (hi | lo) channel groups, the corner lines of both halves are gathered and
+// summed in fp32 before the blend, the blended value is split again, and the product runs as three MFMA passes
+// (a_hi w_hi + a_lo w_hi + a_hi w_lo) -- the arithmetic of dcn_fused_kernel<1, .> on this kernel's gather / LDS layout.
+template <int NB, int NTHR, int SPLIT = 0>
+__global__ __launch_bounds__(NTHR, SPLIT ? 2 : NTHR / 128) void dcn_fused64_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
                                                               const bf16_t* __restrict__ w, const float* __restrict__ bias,
                                                               bf16_t* __restrict__ out, long long npix, int H, int W,
                                                               int C, int N, int relu) {
@@ -487,6 +490,7 @@ __global__ __launch_bounds__(NTHR, NTHR / 128) void dcn_fused64_kernel(const bf1
   constexpr int PSTEP = NTHR / 8;               // pixel distance between a thread's items
   constexpr int WP = NB * 8 / NTHR;             // 16-byte weight pieces per thread per stage
   constexpr int NT = NB * 8 / NTHR;             // 32-column tiles of the product per wave
+  constexpr int NP = SPLIT ? 2 : 1;             // operand planes in LDS (hi, lo)
   // sampling geometry of the tile, computed ONCE per (pixel, tap) -- the eight lanes that share a pixel used to redo it
   // every stage, which was half of the kernel's VALU time: element offsets of the four corners (-1 = outside the map),
   // their bilinear weights, and the sigmoid mask
@@ -494,10 +498,11 @@ __global__ __launch_bounds__(NTHR, NTHR / 128) void dcn_fused64_kernel(const bf1
   __shared__ __attribute__((aligned(16))) float s_gwt[128 * 9][4];
   __shared__ float s_gmask[128 * 9];
   // the offset / mask values are only needed while the table is built: they share LDS with the operand images
-  __shared__ __attribute__((aligned(16))) char s_ab[128 * ROW + NB * ROW];
+  __shared__ __attribute__((aligned(16))) char s_ab[NP * (128 * ROW + NB * ROW)];
   static_assert(128 * ROW + NB * ROW >= 128 * 28 * 4, "operand images must cover the staged offset/mask rows");
-  char* s_a = s_ab;
-  char* s_w = s_ab + 128 * ROW;
+  constexpr int A_PLANE = 128 * ROW, W_PLANE = NB * ROW;
+  char* s_a = s_ab;                              // plane p at + p * A_PLANE
+  char* s_w = s_ab + NP * A_PLANE;               // plane p at + p * W_PLANE
   float* s_om = reinterpret_cast<float*>(s_ab);   // 27 offset / mask values per pixel (row pitch 28)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lx = lane & 31, q = lane >> 5;
@@ -520,6 +525,7 @@ __global__ __launch_bounds__(NTHR, NTHR / 128) void dcn_fused64_kernel(const bf1
   };
   const int n0 = blockIdx.y * NB;
   const int nss = C >> 6, nst = 9 * nss, nk = 9 * (C >> 5);
+  const int cs = SPLIT ? 2 * C : C;             // channels per pixel in memory
   const int piece = tid & 7, prow = tid >> 3;   // items: pixels prow + 32 j, j = 0..3, 16-byte piece `piece`
   for (int i = tid; i < 128 * 7; i += NTHR) {     // 7 float4 per pixel (channels 0..27; 27 is padding)
     int y, xq;
@@ -529,7 +535,7 @@ __global__ __launch_bounds__(NTHR, NTHR / 128) void dcn_fused64_kernel(const bf1
   }
   const bf16_t* xb[IT];
 #pragma unroll
-  for (int j = 0; j < IT; ++j) xb[j] = x + (size_t)img0 * C + piece * 8;
+  for (int j = 0; j < IT; ++j) xb[j] = x + (size_t)img0 * cs + piece * 8;
   __syncthreads();
   for (int i = tid; i < 128 * 9; i += NTHR) {
     const int pl = i / 9, tap = i - pl * 9;
@@ -547,16 +553,16 @@ __global__ __launch_bounds__(NTHR, NTHR / 128) void dcn_fused64_kernel(const bf1
       const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
       const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
       cw[0] = hh * hw; cw[1] = hh * lw; cw[2] = lh * hw; cw[3] = lh * lw;
-      if (h_low >= 0 && w_low >= 0) co[0] = (h_low * W + w_low) * C;
-      if (h_low >= 0 && w_high <= W - 1) co[1] = (h_low * W + w_high) * C;
-      if (h_high <= H - 1 && w_low >= 0) co[2] = (h_high * W + w_low) * C;
-      if (h_high <= H - 1 && w_high <= W - 1) co[3] = (h_high * W + w_high) * C;
+      if (h_low >= 0 && w_low >= 0) co[0] = (h_low * W + w_low) * cs;
+      if (h_low >= 0 && w_high <= W - 1) co[1] = (h_low * W + w_high) * cs;
+      if (h_high <= H - 1 && w_low >= 0) co[2] = (h_high * W + w_low) * cs;
+      if (h_high <= H - 1 && w_high <= W - 1) co[3] = (h_high * W + w_high) * cs;
     }
     *reinterpret_cast<int4*>(s_goff[i]) = make_int4(co[0], co[1], co[2], co[3]);
     *reinterpret_cast<float4*>(s_gwt[i]) = make_float4(cw[0], cw[1], cw[2], cw[3]);
   }
   __syncthreads();     // table complete; s_om is dead from here on (s_a / s_w take its place at the first commit)
-  const bf16_t* wbase = w + (size_t)(n0 >> 6) * nk * (64 * 32);
+  const bf16_t* wbase = w + (size_t)(n0 >> 6) * (SPLIT ? 3 : 1) * nk * (64 * 32);
 
   df32x16 acc[NT];
 #pragma unroll
@@ -566,8 +572,8 @@ __global__ __launch_bounds__(NTHR, NTHR / 128) void dcn_fused64_kernel(const bf1
 
   int coff[IT][4];
   float cwt[IT][4], mask[IT];
-  u32x4 rc[IT][4];
-  u32x4 rw[WP];
+  u32x4 rc[IT][4], rcl[SPLIT ? IT : 1][4];
+  u32x4 rw[WP], rwl[SPLIT ? WP : 1];
 
   auto geometry = [&](int tap) {
 #pragma unroll
@@ -595,14 +601,20 @@ __global__ __launch_bounds__(NTHR, NTHR / 128) void dcn_fused64_kernel(const bf1
 #else
         if (coff[j][k] >= 0) rc[j][k] = *reinterpret_cast<const u32x4*>(xb[j] + coff[j][k] + ss * 64);
 #endif
+        if (SPLIT) {
+          rcl[j][k] = u32x4{0u, 0u, 0u, 0u};
+          if (coff[j][k] >= 0) rcl[j][k] = *reinterpret_cast<const u32x4*>(xb[j] + coff[j][k] + ss * 64 + C);
+        }
       }
     const int kc = tap * (C >> 5) + 2 * ss;     // the stage's two 32-channel weight chunks are adjacent
 #pragma unroll
     for (int j = 0; j < WP; ++j) {
       const int idx = tid + j * NTHR;           // row = idx >> 3, piece = idx & 7 (0..3: chunk kc, 4..7: chunk kc + 1)
       const int row = idx >> 3, pc = idx & 7;
-      rw[j] = *reinterpret_cast<const u32x4*>(wbase + (size_t)(row >> 6) * nk * (64 * 32) + (size_t)(kc + (pc >> 2)) * (64 * 32) +
-                                              (row & 63) * 32 + (pc & 3) * 8);
+      const bf16_t* wsrc = wbase + (size_t)(row >> 6) * (SPLIT ? 3 : 1) * nk * (64 * 32) + (size_t)(kc + (pc >> 2)) * (64 * 32) +
+                           (row & 63) * 32 + (pc & 3) * 8;
+      rw[j] = *reinterpret_cast<const u32x4*>(wsrc);
+      if (SPLIT) rwl[j] = *reinterpret_cast<const u32x4*>(wsrc + (size_t)2 * nk * (64 * 32));     // chunks [w_hi | w_hi | w_lo]
     }
   };
   auto commit = [&]() {
@@ -614,7 +626,7 @@ __global__ __launch_bounds__(NTHR, NTHR / 128) void dcn_fused64_kernel(const bf1
 #endif
       const df2 w0 = {cwt[j][0], cwt[j][0]}, w1 = {cwt[j][1], cwt[j][1]}, w2 = {cwt[j][2], cwt[j][2]},
                 w3 = {cwt[j][3], cwt[j][3]}, mk = {mask[j], mask[j]};
-      uint32_t o[4];
+      uint32_t o[4], ol[4];
 #pragma unroll
       for (int e2 = 0; e2 < 4; ++e2) {
         df2 c[4];
@@ -622,20 +634,28 @@ __global__ __launch_bounds__(NTHR, NTHR / 128) void dcn_fused64_kernel(const bf1
         for (int k = 0; k < 4; ++k) {
           const uint32_t u = e2 == 0 ? rc[j][k].x : e2 == 1 ? rc[j][k].y : e2 == 2 ? rc[j][k].z : rc[j][k].w;
           c[k] = df2{__uint_as_float(u << 16), __uint_as_float(u & 0xFFFF0000u)};
+          if (SPLIT) {
+            const uint32_t ul = e2 == 0 ? rcl[j][k].x : e2 == 1 ? rcl[j][k].y : e2 == 2 ? rcl[j][k].z : rcl[j][k].w;
+            c[k] += df2{__uint_as_float(ul << 16), __uint_as_float(ul & 0xFFFF0000u)};
+          }
         }
         df2 v = w0 * c[0];
         v = w1 * c[1] + v;
         v = w2 * c[2] + v;
         v = w3 * c[3] + v;
         v = v * mk;
-        o[e2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, db2));
+        const db2 hb = __builtin_convertvector(v, db2);
+        o[e2] = __builtin_bit_cast(uint32_t, hb);
+        if (SPLIT) ol[e2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - __builtin_convertvector(hb, df2), db2));
       }
       *reinterpret_cast<u32x4*>(s_a + (prow + PSTEP * j) * ROW + piece * 16) = u32x4{o[0], o[1], o[2], o[3]};
+      if (SPLIT) *reinterpret_cast<u32x4*>(s_a + A_PLANE + (prow + PSTEP * j) * ROW + piece * 16) = u32x4{ol[0], ol[1], ol[2], ol[3]};
     }
 #pragma unroll
     for (int j = 0; j < WP; ++j) {
       const int idx = tid + j * NTHR;
       *reinterpret_cast<u32x4*>(s_w + (idx >> 3) * ROW + (idx & 7) * 16) = rw[j];
+      if (SPLIT) *reinterpret_cast<u32x4*>(s_w + W_PLANE + (idx >> 3) * ROW + (idx & 7) * 16) = rwl[j];
     }
   };
 
@@ -651,6 +671,8 @@ __global__ __launch_bounds__(NTHR, NTHR / 128) void dcn_fused64_kernel(const bf1
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const dbf16x8 a = *reinterpret_cast<const dbf16x8*>(a_rd + kk * 32);
+      dbf16x8 al;
+      if (SPLIT) al = *reinterpret_cast<const dbf16x8*>(a_rd + A_PLANE + kk * 32);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const dbf16x8 b = *reinterpret_cast<const dbf16x8*>(b_rd + t * 32 * ROW + kk * 32);
@@ -658,13 +680,18 @@ __global__ __launch_bounds__(NTHR, NTHR / 128) void dcn_fused64_kernel(const bf1
         if (kk == 0 && t == 0)
 #endif
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc[t], 0, 0, 0);   // D = [channel][pixel]
+        if (SPLIT) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, al, acc[t], 0, 0, 0);
+          const dbf16x8 bl = *reinterpret_cast<const dbf16x8*>(b_rd + W_PLANE + t * 32 * ROW + kk * 32);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, a, acc[t], 0, 0, 0);
+        }
       }
     }
   }
   // weights were the MFMA's A operand: a lane owns pixel mt * 32 + lx, its accumulators are runs of four channels
   int y, xq;
   if (locate(mt * 32 + lx, y, xq)) {
-    bf16_t* op = out + (size_t)(img0 + (long long)y * W + xq) * N + n0 + ct0 * 32;
+    bf16_t* op = out + (size_t)(img0 + (long long)y * W + xq) * (SPLIT ? 2 * N : N) + n0 + ct0 * 32;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -676,7 +703,11 @@ __global__ __launch_bounds__(NTHR, NTHR / 128) void dcn_fused64_kernel(const bf1
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
         }
-        *reinterpret_cast<uint2*>(op + ch) = make_uint2(f2bf(v[0]) | (f2bf(v[1]) << 16), f2bf(v[2]) | (f2bf(v[3]) << 16));
+        const uint32_t h0 = f2bf(v[0]), h1 = f2bf(v[1]), h2 = f2bf(v[2]), h3 = f2bf(v[3]);
+        *reinterpret_cast<uint2*>(op + ch) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+        if (SPLIT)
+          *reinterpret_cast<uint2*>(op + N + ch) = make_uint2(f2bf(v[0] - bf2f(h0)) | (f2bf(v[1] - bf2f(h1)) << 16),
+                                                               f2bf(v[2] - bf2f(h2)) | (f2bf(v[3] - bf2f(h3)) << 16));
       }
   }
 }
@@ -842,6 +873,21 @@ int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf
   PT_REQUIRE(x && om && w && bias && out && C % 32 == 0 && N % 64 == 0, "dcn fused: bad arguments (C=%d N=%d)", C, N);
   PT_REQUIRE((long long)H * W * (split ? 2 * C : C) < (1ll << 31), "dcn fused: image too large for 32-bit offsets");
   // (the hi/lo mode keeps 64-channel blocks: with 128 the corner registers of both halves spill)
+  static int x3fast = -1;        // PT_DCN_X3_FAST=0: the hi/lo mode on dcn_fused_kernel<1, 64> (A/B switch)
+  if (x3fast < 0) {
+    const char* ev = getenv("PT_DCN_X3_FAST");
+    x3fast = ev ? atoi(ev) : 1;
+  }
+  if (split && C % 64 == 0 && x3fast) {
+    const long long npix = (long long)B * H * W;
+    char label[48];
+    snprintf(label, sizeof(label), "dcn fused %d->%d @%dx%d x3", C, N, H, W);
+    PtProfScope prof(e, s, PT_PROF_OTHER, 0, label);
+    const unsigned tiles = (unsigned)((long long)B * ((H + 7) / 8) * ((W + 15) / 16));
+    hipLaunchKernelGGL((dcn_fused64_kernel<64, 512, 1>), dim3(tiles, N / 64), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
+    PT_HIP_CHECK(hipGetLastError());
+    return PT_OK;
+  }
   if (split) return launch_dcn_fused<1, 64>(e, x, om, w, bias, out, B, H, W, C, N, relu, s);
   if (C % 64 == 0) {
     const long long npix = (long long)B * H * W;
