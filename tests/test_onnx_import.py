@@ -123,3 +123,37 @@ def test_unknown_architecture_fails_loudly_with_an_inventory():
     with pytest.raises(UnsupportedOnnxGraph) as e:
         recognise(g)
     assert "none of the architectures" in str(e.value) and "conv w[8, 3, 3, 3]" in str(e.value)
+
+
+def test_executor_layer_kinds_of_exported_cnns():
+    """the layer lists of PyTorch-exported CNNs (an LCNet-type classifier with SE blocks, an FPN-type detector) consist of the
+    kinds pdf_table_amd.onnx_exec executes -- conv (incl. depthwise) with a fused activation, convT, maxpool, gap, add, mul,
+    resize, concat, gemm, act, Flatten glue -- and carry what the executor reads (HardSigmoid's alpha / beta, Resize scales);
+    the executor itself needs the GPU (tests/test_gpu_onnx_exec.py)"""
+    import importlib.util
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "tools"))
+    spec = importlib.util.spec_from_file_location("gpu_onnx_exec_models", os.path.join(here, "test_gpu_onnx_exec.py"))
+    mods = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mods)
+    from onnx_export import torch_export
+    from pdf_table_amd.onnx_import import load_onnx
+    import pdf_table_amd.onnx_exec as ex
+    assert hasattr(ex, "HipGraphExecutor")
+    known = {"conv", "convT", "maxpool", "gap", "add", "mul", "resize", "concat", "gemm", "act", "glue"}
+    seen = set()
+    for m, x in ((mods.LcNetLike(), torch.randn(1, 3, 64, 96)), (mods.FpnLike(), torch.randn(1, 3, 64, 96))):
+        g = load_onnx(torch_export(mods._randomise(m, 1), x))
+        assert g.unsupported_ops() == []
+        for lay in g.layers():
+            assert lay.op in known, lay.describe()
+            seen.add(lay.op)
+            if lay.act == "hardsigmoid":
+                assert abs(lay.attrs["act_alpha"] - 1.0 / 6.0) < 1e-6 and lay.attrs["act_beta"] == 0.5
+            if lay.op == "resize":
+                assert lay.attrs["scale"] == [1.0, 1.0, 2.0, 2.0] and lay.attrs["mode"] == "nearest"
+            if lay.op == "glue":
+                assert lay.attrs["onnx_op"] == "Flatten"
+    assert seen == known
