@@ -370,6 +370,8 @@ int pt_op_add(pt_engine* e, const uint16_t* d_a, const uint16_t* d_b, uint16_t* 
 /* MaxPool2d(3, 2, 1), or a non-overlapping k x k pool (stride k, no padding, H and W divisible by k) */
 int pt_op_maxpool(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int C, int k, int stride, int pad, uint16_t* d_out,
                   pt_stream stream);
+/* AveragePool k x k, stride k, no padding (H and W divisible by k) */
+int pt_op_avgpool(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int C, int k, uint16_t* d_out, pt_stream stream);
 /* GlobalAveragePool: [B, HW, C] -> bf16 [B, C]; d_scratch: pt_op_chan_mean_scratch_floats(B, C) floats */
 int pt_op_chan_mean(pt_engine* e, const uint16_t* d_in, int B, int HW, int C, float* d_scratch, uint16_t* d_mean, pt_stream stream);
 int pt_op_chan_mean_scratch_floats(int B, int C);

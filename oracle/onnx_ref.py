@@ -55,6 +55,14 @@ def run(model, feeds):
             y = x[0].reshape(int(np.prod(x[0].shape[:ax])) if ax else 1, -1)
         elif t == "Softmax":
             y = torch.softmax(x[0], dim=a.get("axis", -1))
+        elif t == "Clip":
+            lo = float(x[1]) if len(x) > 1 and x[1] is not None else a.get("min", None)
+            hi = float(x[2]) if len(x) > 2 and x[2] is not None else a.get("max", None)
+            y = torch.clamp(x[0], min=lo, max=hi)
+        elif t == "AveragePool":
+            y = torch.nn.functional.avg_pool2d(x[0], tuple(a["kernel_shape"]), tuple(a.get("strides", a["kernel_shape"])),
+                                               tuple(a.get("pads", [0, 0, 0, 0])[:2]), ceil_mode=bool(a.get("ceil_mode", 0)),
+                                               count_include_pad=bool(a.get("count_include_pad", 0)))
         elif t == "Sigmoid":
             y = torch.sigmoid(x[0])
         elif t == "MaxPool":

@@ -20,7 +20,7 @@ void pt_set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* pt_last_error(void) { return g_err; }
-int pt_abi_version(void) { return 8; }   // 8: pt_op_dwconv / add / maxpool / chan_mean / scale_channels / act (generic ONNX executor); 7: pt_rec_pp_preprocess*; 6: pt_engine_set_lstm_cluster, pt_engine_check clears what it reports
+int pt_abi_version(void) { return 8; }   // 8: pt_op_dwconv / add / maxpool / avgpool / chan_mean / scale_channels / act (generic ONNX executor); 7: pt_rec_pp_preprocess*; 6: pt_engine_set_lstm_cluster, pt_engine_check clears what it reports
 
 int pt_engine_check(pt_engine* e) {
   PT_REQUIRE(e, "pt_engine_check: null engine");

@@ -65,6 +65,36 @@ __global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ x, 
   }
 }
 
+// AveragePool k x k, stride k, no padding: out [B, H/k, W/k, C]
+__global__ __launch_bounds__(256) void avgpool_kxk_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B, int H, int W, int C,
+                                                          int k) {
+  const int Ho = H / k, Wo = W / k, cg = C >> 3;
+  const long long total = (long long)B * Ho * Wo * cg;
+  const float inv = 1.f / (float)(k * k);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % cg);
+    long long t = i / cg;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho), b = (int)(t / Ho);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int dy = 0; dy < k; ++dy)
+      for (int dx = 0; dx < k; ++dx) {
+        const uint4 v = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + oy * k + dy) * W + ox * k + dx) * C + c8 * 8);
+        const uint32_t vs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[2 * q] += g_bf(vs[q] & 0xFFFFu);
+          acc[2 * q + 1] += g_bf(vs[q] >> 16);
+        }
+      }
+    uint32_t o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = g_f2bf(acc[2 * q] * inv) | (g_f2bf(acc[2 * q + 1] * inv) << 16);
+    *reinterpret_cast<uint4*>(out + i * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 inline unsigned grid_for(long long n) {
   const long long g = (n + 255) / 256;
   return (unsigned)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
@@ -96,6 +126,14 @@ int pt_op_maxpool(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int C
              "pt_op_maxpool: only MaxPool(3, 2, 1) and non-overlapping k x k pools on sizes divisible by k (got k=%d stride=%d pad=%d)", k,
              stride, pad);
   return pt_launch_maxpool_kxk(d_in, B, H, W, C, k, k, 0, 0, d_out, s);
+}
+
+int pt_op_avgpool(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int C, int k, uint16_t* d_out, pt_stream stream) {
+  PT_REQUIRE(e && d_in && d_out && C % 8 == 0 && k >= 2 && H % k == 0 && W % k == 0, "pt_op_avgpool: k x k / stride k on sizes divisible by k");
+  hipLaunchKernelGGL(avgpool_kxk_kernel, dim3(grid_for((long long)B * (H / k) * (W / k) * (C / 8))), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), d_in, d_out, B, H, W, C, k);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
 }
 
 int pt_op_chan_mean(pt_engine* e, const uint16_t* d_in, int B, int HW, int C, float* d_scratch, uint16_t* d_mean, pt_stream stream) {

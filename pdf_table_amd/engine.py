@@ -483,6 +483,13 @@ class HipEngine:
         L.check(self.lib.pt_op_maxpool(self._h, _ptr(x), B, H, W, Cc, k, stride, pad, _ptr(out), self._stream()), "pt_op_maxpool")
         return out
 
+    def op_avgpool(self, x: torch.Tensor, k: int) -> torch.Tensor:
+        self._chk(x, torch.bfloat16, "x")
+        B, H, W, Cc = x.shape
+        out = torch.empty((B, H // k, W // k, Cc), dtype=torch.bfloat16, device=self._tdev)
+        L.check(self.lib.pt_op_avgpool(self._h, _ptr(x), B, H, W, Cc, k, _ptr(out), self._stream()), "pt_op_avgpool")
+        return out
+
     def op_chan_mean(self, x: torch.Tensor) -> torch.Tensor:
         """GlobalAveragePool: [B, H, W, C] -> [B, 1, 1, C]"""
         self._chk(x, torch.bfloat16, "x")

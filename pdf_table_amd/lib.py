@@ -93,6 +93,7 @@ def _proto(lib):
         "pt_op_dwconv": (i, [vp, vp, i, i, i, i, vp, vp, i, i, i, vp, vp]),
         "pt_op_add": (i, [vp, vp, vp, vp, C.c_longlong, i, vp]),
         "pt_op_maxpool": (i, [vp, vp, i, i, i, i, i, i, i, vp, vp]),
+        "pt_op_avgpool": (i, [vp, vp, i, i, i, i, i, vp, vp]),
         "pt_op_chan_mean": (i, [vp, vp, i, i, i, vp, vp, vp]),
         "pt_op_chan_mean_scratch_floats": (i, [i, i]),
         "pt_op_scale_channels": (i, [vp, vp, vp, i, i, i, vp, vp]),

@@ -18,8 +18,9 @@ convolutional graph layer by layer:
 There is no CPU path: an operator outside this set raises ``UnsupportedOnnxGraph`` naming it (oracle/onnx_ref.py executes
 graphs on the CPU for the tests only).  Supported today: Conv (groups 1: 1x1 / 3x3; depthwise: 3x3 / 5x5; stride 1 / 2,
 "same" padding), ConvTranspose 2x2 / stride 2, BatchNormalization (folded), Relu / HardSwish / Sigmoid / HardSigmoid /
-Relu6, Add, Mul by a per-channel gate, MaxPool(3, 2, 1) and k x k / stride k, GlobalAveragePool, Resize / Upsample (nearest,
-integer factor), Concat over channels, Gemm / Flatten after a global pool.  Arithmetic is PT_PRECISION_BF16 (bf16
+Relu6, a BatchNormalization that stands alone, Add, Mul by a per-channel gate, MaxPool(3, 2, 1) and k x k / stride k,
+AveragePool k x k / stride k, GlobalAveragePool, Resize / Upsample (nearest, integer factor, by scales or sizes), Concat over
+channels, Gemm / Flatten after a global pool.  Arithmetic is PT_PRECISION_BF16 (bf16
 operands, fp32 accumulate); the hi/lo mode of the dedicated graphs is not wired here.
 """
 from __future__ import annotations
@@ -208,6 +209,26 @@ class HipGraphExecutor:
                 if kk[0] != kk[1] or st[0] != st[1] or len(set(pd)) != 1 or a.get("ceil_mode"):
                     raise UnsupportedOnnxGraph(f"{lay.name}: MaxPool {a}")
                 y = _Act(self.eng.op_maxpool(ins[0].t, kk[0], st[0], pd[0]), ins[0].c)
+            elif op == "avgpool":
+                a = lay.attrs
+                kk, st, pd = a["kernel"], a["strides"], a["pads"]
+                if kk[0] != kk[1] or st != kk or any(pd) or a.get("ceil_mode") or ins[0].t.shape[1] % kk[0] or ins[0].t.shape[2] % kk[0]:
+                    raise UnsupportedOnnxGraph(f"{lay.name}: AveragePool {a} (k x k / stride k without padding is built)")
+                y = _Act(self.eng.op_avgpool(ins[0].t, kk[0]), ins[0].c)
+            elif op == "bn":
+                # a BatchNormalization that could not be folded into a convolution: per-channel affine = a depthwise 3x3 whose only
+                # non-zero tap is the centre one
+                d = self._dev.get(k)
+                if d is None:
+                    e_ = lay.extra
+                    sc = e_["gamma"].astype(np.float64) / np.sqrt(e_["var"].astype(np.float64) + lay.attrs["epsilon"])
+                    cp = ins[0].t.shape[-1]
+                    wt = np.zeros((9, cp), np.float32)
+                    wt[4, :ins[0].c] = sc
+                    bt = np.zeros((cp,), np.float32)
+                    bt[:ins[0].c] = e_["beta"].astype(np.float64) - e_["mean"].astype(np.float64) * sc
+                    d = self._dev[k] = {"w": self._up(wt), "b": self._up(bt)}
+                y = _Act(self.eng.op_dwconv(ins[0].t, d["w"], d["b"], 3, 1, 0), ins[0].c)
             elif op == "gap":
                 y = _Act(self.eng.op_chan_mean(ins[0].t), ins[0].c)
             elif op == "add":
@@ -225,6 +246,10 @@ class HipGraphExecutor:
                 y = self._post_act(lay, ins[0], lay.attrs["kind"])
             elif op == "resize":
                 sc = lay.attrs.get("scale")
+                sz = lay.attrs.get("sizes")
+                if not sc and sz and len(sz) == 4:       # Resize given by target sizes (how some exporters write a x2 up-sampling)
+                    hh, ww = ins[0].t.shape[1], ins[0].t.shape[2]
+                    sc = [1.0, 1.0, sz[2] / hh, sz[3] / ww]
                 if lay.attrs.get("mode", "nearest") != "nearest" or not sc or sc[0] != 1 or sc[1] != 1 or sc[2] != sc[3] or sc[2] != int(sc[2]):
                     raise UnsupportedOnnxGraph(f"{lay.name}: Resize {lay.attrs} (nearest, integer factor)")
                 f = int(sc[2])

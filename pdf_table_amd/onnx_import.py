@@ -195,13 +195,15 @@ class OnnxGraph:
             elif t == "GlobalAveragePool" or (t == "ReduceMean" and sorted(n.attrs.get("axes", [])) in ([2, 3], [-2, -1])):
                 out.append(Layer("gap", n.name or n.outputs[0], [n.inputs[0]], [n.outputs[0]]))
             elif t in ("Resize", "Upsample"):
-                scale = None
+                scale = sizes = None
                 for i in n.inputs[1:]:
                     v = self.init.get(i)
                     if v is not None and v.size == 4 and v.dtype.kind == "f":
                         scale = [float(x) for x in np.asarray(v).reshape(-1)]
+                    elif v is not None and v.size == 4 and v.dtype.kind in "iu":
+                        sizes = [int(x) for x in np.asarray(v).reshape(-1)]
                 out.append(Layer("resize", n.name or n.outputs[0], [n.inputs[0]], [n.outputs[0]],
-                                 {"mode": n.attrs.get("mode", "nearest"), "scale": scale,
+                                 {"mode": n.attrs.get("mode", "nearest"), "scale": scale, "sizes": sizes,
                                   "coordinate_transformation_mode": n.attrs.get("coordinate_transformation_mode", "")}))
             elif t in ("Add", "Mul", "Sub", "Div"):
                 consts = {i: self.init[i] for i in n.inputs if i in self.init}

@@ -231,3 +231,27 @@ def test_detection_task_serves_an_unknown_onnx_detector(tmp_path, eng):
     d = float(np.abs(got - want).max())
     print(f"generic detector through OcrDetectionTask: max|dprob| = {d:.3e}")
     assert d <= 4e-2
+
+
+class VdLike(nn.Module):
+    """ResNet-vd style pieces: AvgPool(2, 2) in the shortcut, a BatchNorm that follows an Add (nothing to fold it into), ReLU6"""
+
+    def __init__(self):
+        super().__init__()
+        self.c1 = nn.Sequential(nn.Conv2d(3, 24, 3, 1, 1, bias=False), nn.BatchNorm2d(24), nn.ReLU6())
+        self.c2 = nn.Sequential(nn.Conv2d(24, 40, 3, 2, 1, bias=False), nn.BatchNorm2d(40))
+        self.short = nn.Sequential(nn.AvgPool2d(2, 2), nn.Conv2d(24, 40, 1, bias=False))
+        self.bn = nn.BatchNorm2d(40)
+        self.out = nn.Conv2d(40, 8, 1)
+
+    def forward(self, x):
+        x = self.c1(x)
+        y = self.bn(self.c2(x) + self.short(x))
+        return self.out(torch.relu(y))
+
+
+def test_vd_like_pieces(eng):
+    torch.manual_seed(0)
+    m = _randomise(VdLike(), 4)
+    ex = _check(m, torch.randn(2, 3, 32, 64), eng, 4e-2)
+    assert {"avgpool", "bn"} <= {l.op for l in ex.layers}
