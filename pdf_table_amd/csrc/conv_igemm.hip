@@ -318,6 +318,109 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
   }
 }
 
+// Register epilogue for kernels that run the MFMA with the WEIGHTS as its A operand (D = [channel][pixel]): lane (lx, q) owns
+// pixel lx of a 32-pixel row-tile, register r of 32-channel block nb holds channel nb*32 + (r & 3) + 8 * (r >> 2) + 4 * q.
+// bias / residual / activation / bf16 rounding happen where the accumulators are; one v_permlane32_swap per dword pair
+// then gives every lane two 16-byte channel runs per block (q = 0: channels 0-7 and 16-23, q = 1: 8-15 and 24-31).
+// Against the staged epilogue above (fp32 through LDS, two barriers per pass): no LDS, no barrier, ~1/3 of the
+// instructions.  Used by the 1x1 kernel (K is two to sixteen chunks there: a tile is mostly epilogue); plain layers only
+// (no split / pool / fused head / arg-max / pixel shuffle / fp32 output).
+struct DirectBias { f32x4 v[2][4]; };
+template <int NB>
+__device__ __forceinline__ DirectBias direct_bias(const ConvK& p, int n0, int q) {
+  DirectBias bs;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bs.v[nb][g] = *reinterpret_cast<const f32x4*>(p.bias + n0 + nb * 32 + 8 * g + 4 * q);
+  return bs;
+}
+// xp != null: the row-tile's 32 pixels x 64 channels go through a wave-private 4 KB LDS tile ([pixel][128 B], 16-byte pieces
+// XOR-swizzled by the pixel) so that the global stores are whole 128-byte lines, 8 per wave instruction -- stored straight
+// from the accumulator layout an instruction touches 32 lines with 16 bytes each.
+template <int NB>
+__device__ __forceinline__ void epilogue_direct_row(const ConvK& p, const f32x16 (&acc)[2], const DirectBias& bs, int b, int oy,
+                                                    int ox0, int lx, int n0, int q, char* xp) {
+  const int ox = ox0 + lx;
+  const bool inside = oy < p.Ho && ox < p.Wo;      // both lanes of a (pixel, q) pair agree
+  const bf16_t* rp = nullptr;
+  if (p.res_mode == 1)
+    rp = p.res + (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.N + n0 + 4 * q;
+  else if (p.res_mode == 2)
+    rp = p.res + (((size_t)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * p.N + n0 + 4 * q;
+  const int f = p.rep, OW = p.Wo * f;
+  const float sl = p.relu == 3 ? p.slope[0] : 0.f;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    float v[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      v[4 * g + 0] = acc[nb][4 * g + 0] + bs.v[nb][g].x;
+      v[4 * g + 1] = acc[nb][4 * g + 1] + bs.v[nb][g].y;
+      v[4 * g + 2] = acc[nb][4 * g + 2] + bs.v[nb][g].z;
+      v[4 * g + 3] = acc[nb][4 * g + 3] + bs.v[nb][g].w;
+    }
+    if (rp && inside) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const u32x2 rr = *reinterpret_cast<const u32x2*>(rp + nb * 32 + 8 * g);
+        v[4 * g + 0] += bf16lo_f32(rr.x); v[4 * g + 1] += bf16hi_f32(rr.x);
+        v[4 * g + 2] += bf16lo_f32(rr.y); v[4 * g + 3] += bf16hi_f32(rr.y);
+      }
+    }
+    if (p.relu == 1) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = fmaxf(v[k], 0.f);
+    } else if (p.relu == 2) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = v[k] * fminf(fmaxf(v[k] + 3.f, 0.f), 6.f) / 6.f;
+    } else if (p.relu == 3) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = v[k] > 0.f ? v[k] : sl * v[k];
+    }
+    uint32_t d[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+    // (d0, d1 | d2, d3) = channels 8g + 4q + (0..3) of g = 0, 1: swap the q = 1 half of (d0, d1) with the q = 0 half of (d2, d3)
+    const u32x2 s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+    const u32x2 s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+    const u32x2 s2 = __builtin_amdgcn_permlane32_swap(d[4], d[6], false, false);
+    const u32x2 s3 = __builtin_amdgcn_permlane32_swap(d[5], d[7], false, false);
+    const u32x4 run0 = {s0.x, s1.x, s0.y, s1.y};     // channels nb*32 + 8q .. + 7
+    const u32x4 run1 = {s2.x, s3.x, s2.y, s3.y};     // channels nb*32 + 16 + 8q .. + 7
+    if (xp) {
+      *reinterpret_cast<u32x4*>(xp + lx * 128 + (((nb * 4 + q) ^ (lx & 7)) << 4)) = run0;
+      *reinterpret_cast<u32x4*>(xp + lx * 128 + (((nb * 4 + 2 + q) ^ (lx & 7)) << 4)) = run1;
+    } else if (inside) {
+      bf16_t* op = p.out + (((size_t)b * p.Ho * f + oy * f) * OW + ox * f) * p.out_cstride + p.out_coff + n0 + 8 * q + nb * 32;
+      const bool ok0 = !p.n_valid || n0 + nb * 32 + 8 * q < p.n_valid;
+      const bool ok1 = !p.n_valid || n0 + nb * 32 + 16 + 8 * q < p.n_valid;
+      for (int fy = 0; fy < f; ++fy)
+        for (int fx = 0; fx < f; ++fx) {
+          bf16_t* o = op + ((size_t)fy * OW + fx) * p.out_cstride;
+          if (ok0) *reinterpret_cast<u32x4*>(o) = run0;
+          if (ok1) *reinterpret_cast<u32x4*>(o + 16) = run1;
+        }
+    }
+  }
+  if (xp) {
+    // wave-private tile: the wave's own writes are visible to it after lgkmcnt(0) (in-order LDS), no barrier
+    const int lane = q * 32 + lx, k = lane & 7;
+    const bool okc = k < NB * 4 && (!p.n_valid || n0 + 8 * k < p.n_valid);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int P = (lane >> 3) + 8 * i;
+      const u32x4 run = *reinterpret_cast<const u32x4*>(xp + P * 128 + ((k ^ (P & 7)) << 4));
+      const int oxp = ox0 + P;
+      if (okc && oy < p.Ho && oxp < p.Wo) {
+        bf16_t* op = p.out + (((size_t)b * p.Ho * f + oy * f) * OW + oxp * f) * p.out_cstride + p.out_coff + n0 + 8 * k;
+        for (int fy = 0; fy < f; ++fy)
+          for (int fx = 0; fx < f; ++fx) *reinterpret_cast<u32x4*>(op + ((size_t)fy * OW + fx) * p.out_cstride) = run;
+      }
+    }
+  }
+}
+
 template <int KS, int STRIDE, int GEOM = 0>
 struct ConvCfg {
   // GEOM 0: 3x3/s1: 8x32 patch (2 MFMA row-tiles per wave); 1x1 and stride-2: 4x32 (smaller LDS image -> more
@@ -350,7 +453,8 @@ struct ConvCfg {
 
 // NHALF = 1: only the first 32 of the tile's 64 output columns are computed (layers with <= 32 real outputs, e.g. the
 // 27-channel offset / mask convs of the deformable layers): half the MFMAs and half the B-fragment reads.
-template <int KS, int STRIDE, int GEOM, int NHALF = 2>
+// DIRECT: the weights are the MFMA's A operand and the epilogue runs from the accumulators (epilogue_direct_row)
+template <int KS, int STRIDE, int GEOM, int NHALF = 2, bool DIRECT = false>
 __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_igemm_kernel(ConvK p) {
   using C = ConvCfg<KS, STRIDE, GEOM>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -507,8 +611,13 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
             const int soff = STRIDE == 2 ? ((s & 1) * C::XEVEN + (s >> 1)) : s;
             const int a_off = C::SWZ ? (((q + 2 * kk) ^ (((a_slot[m] + r * C::TWIN + soff) >> 2) & 3)) * 16) : kk * 32;
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base[m] + (r * C::TWIN + soff) * C::PIXB + a_off);
-            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
-            if (NHALF == 2) acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
+            if (DIRECT) {
+              acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a, acc[m][0], 0, 0, 0);      // D = [channel][pixel]
+              if (NHALF == 2) acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a, acc[m][1], 0, 0, 0);
+            } else {
+              acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
+              if (NHALF == 2) acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
+            }
           }
 #ifdef PT_SETPRIO
           __builtin_amdgcn_s_setprio(0);
@@ -518,6 +627,16 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
     }
   }
 
+  if (DIRECT) {
+    // ---- epilogue from the accumulators: lane (lx, q) owns pixel lx of its row-tile ----
+    const DirectBias bs = direct_bias<NHALF>(p, nt * 64, q);
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m) {
+      const int t = wave * C::MT + m;
+      epilogue_direct_row<NHALF>(p, acc[m], bs, b, oy0 + t / C::CT, ox0 + (t % C::CT) * 32, lx, nt * 64, q, nullptr);
+    }
+    continue;      // next tile of a rep walk (none for the layers that take this path)
+  }
   // ---- epilogue through LDS (fp32 [pixel][64]) ----
   __syncthreads();
   float* stage = reinterpret_cast<float*>(smem);
@@ -1072,6 +1191,18 @@ static void launch_half(ConvK& k, unsigned nblk, hipStream_t s) {
   hipLaunchKernelGGL((conv_igemm_kernel<3, 1, 0, 1>), dim3(nblk), dim3(256), C::SMEM, s, k);
 }
 
+// 1x1 stride-1 layers with a plain epilogue: the register-epilogue instance
+static void launch_direct1(const ConvK& k, unsigned nblk, hipStream_t s) {
+  using C = ConvCfg<1, 1, 0>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<1, 1, 0, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              C::SMEM);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<1, 1, 0, 2, true>), dim3(nblk), dim3(256), C::SMEM, s, k);
+}
+
 template <int KS, int STRIDE, int GEOM = 0>
 static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   using C = ConvCfg<KS, STRIDE, GEOM>;
@@ -1097,8 +1228,13 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   int lim_slot = -1;
   {
     PtProfScope prof(e, s, KS == 3 ? PT_PROF_CONV3X3 : PT_PROF_CONV1X1, flop, label);
+    static int direct1 = -1;      // PT_CONV1_DIRECT=0: the staged epilogue for the 1x1 layers too (A/B switch)
+    if (direct1 < 0) { const char* ev = getenv("PT_CONV1_DIRECT"); direct1 = ev ? atoi(ev) : 1; }
     if (KS == 3 && STRIDE == 1 && GEOM == 0 && k.n_valid > 0 && k.n_valid <= 32 && k.N == 64 && !k.split && !k.pool && !k.head_w && !k.argmax_part)
       launch_half(k, (unsigned)nblk, s);      // <= 32 real output channels: half-width variant
+    else if (KS == 1 && STRIDE == 1 && GEOM == 0 && direct1 && !k.split && !k.pool && !k.head_w && !k.argmax_part && !k.out_f32 &&
+             !k.res_f32 && !k.shuffle_cout && !k.ylimit && !k.xlimit && !k.xlimit_rows)
+      launch_direct1(k, (unsigned)nblk, s);
     else
       hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, GEOM>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
     if ((k.ylimit || k.xcols) && prof.idx >= 0 && e->prof.h_lims && e->prof.n_lims < PtProfile::MAX_LIMS) {
