@@ -323,8 +323,8 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
 // bias / residual / activation / bf16 rounding happen where the accumulators are; one v_permlane32_swap per dword pair
 // then gives every lane two 16-byte channel runs per block (q = 0: channels 0-7 and 16-23, q = 1: 8-15 and 24-31).
 // Against the staged epilogue above (fp32 through LDS, two barriers per pass): no LDS, no barrier, ~1/3 of the
-// instructions.  Used by the 1x1 kernel (K is two to sixteen chunks there: a tile is mostly epilogue); plain layers only
-// (no split / pool / fused head / arg-max / pixel shuffle / fp32 output).
+// instructions.  Used by the register-staged kernel's 1x1, stride-2 and short 3x3 launches (K is two to sixteen chunks there: a
+// tile is mostly epilogue); plain layers only (no split / pool / fused head / arg-max / pixel shuffle / fp32 residual).
 struct DirectBias { f32x4 v[2][4]; };
 template <int NB>
 __device__ __forceinline__ DirectBias direct_bias(const ConvK& p, int n0, int q) {
@@ -377,6 +377,17 @@ __device__ __forceinline__ void epilogue_direct_row(const ConvK& p, const f32x16
     } else if (p.relu == 3) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) v[k] = v[k] > 0.f ? v[k] : sl * v[k];
+    }
+    if (p.out_f32) {
+      // fp32 output (network outputs, offset / mask maps): the lane's runs of four channels are 16-byte stores as they are
+      if (inside) {
+        float* of = p.out_f32 + (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.out_cstride + p.out_coff + n0 + nb * 32 + 4 * q;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (!p.n_valid || n0 + nb * 32 + 8 * g + 4 * q < p.n_valid)
+            *reinterpret_cast<f32x4*>(of + 8 * g) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+      }
+      continue;
     }
     uint32_t d[8];
 #pragma unroll
@@ -1191,16 +1202,17 @@ static void launch_half(ConvK& k, unsigned nblk, hipStream_t s) {
   hipLaunchKernelGGL((conv_igemm_kernel<3, 1, 0, 1>), dim3(nblk), dim3(256), C::SMEM, s, k);
 }
 
-// 1x1 stride-1 layers with a plain epilogue: the register-epilogue instance
-static void launch_direct1(const ConvK& k, unsigned nblk, hipStream_t s) {
-  using C = ConvCfg<1, 1, 0>;
+// layers with a plain epilogue: the register-epilogue instances of the kernel (1x1, stride-2 3x3, 3x3 at both widths)
+template <int KS, int STRIDE, int NHALF>
+static void launch_direct(const ConvK& k, unsigned nblk, hipStream_t s) {
+  using C = ConvCfg<KS, STRIDE, 0>;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<1, 1, 0, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              C::SMEM);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<KS, STRIDE, 0, NHALF, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<1, 1, 0, 2, true>), dim3(nblk), dim3(256), C::SMEM, s, k);
+  hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, 0, NHALF, true>), dim3(nblk), dim3(256), C::SMEM, s, k);
 }
 
 template <int KS, int STRIDE, int GEOM = 0>
@@ -1228,13 +1240,21 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   int lim_slot = -1;
   {
     PtProfScope prof(e, s, KS == 3 ? PT_PROF_CONV3X3 : PT_PROF_CONV1X1, flop, label);
-    static int direct1 = -1;      // PT_CONV1_DIRECT=0: the staged epilogue for the 1x1 layers too (A/B switch)
+    static int direct1 = -1;      // PT_CONV1_DIRECT=0: the staged epilogue for every launch of this kernel (A/B switch)
     if (direct1 < 0) { const char* ev = getenv("PT_CONV1_DIRECT"); direct1 = ev ? atoi(ev) : 1; }
-    if (KS == 3 && STRIDE == 1 && GEOM == 0 && k.n_valid > 0 && k.n_valid <= 32 && k.N == 64 && !k.split && !k.pool && !k.head_w && !k.argmax_part)
-      launch_half(k, (unsigned)nblk, s);      // <= 32 real output channels: half-width variant
-    else if (KS == 1 && STRIDE == 1 && GEOM == 0 && direct1 && !k.split && !k.pool && !k.head_w && !k.argmax_part && !k.out_f32 &&
-             !k.res_f32 && !k.shuffle_cout && !k.ylimit && !k.xlimit && !k.xlimit_rows)
-      launch_direct1(k, (unsigned)nblk, s);
+    const bool plain = direct1 && GEOM == 0 && !k.split && !k.pool && !k.head_w && !k.argmax_part && !k.res_f32 && !k.shuffle_cout;
+    const bool narrow = KS == 3 && STRIDE == 1 && GEOM == 0 && k.n_valid > 0 && k.n_valid <= 32 && k.N == 64 && !k.split && !k.pool &&
+                        !k.head_w && !k.argmax_part;      // <= 32 real output channels: half-width variant
+    if (narrow && plain)
+      launch_direct<3, 1, 1>(k, (unsigned)nblk, s);
+    else if (narrow)
+      launch_half(k, (unsigned)nblk, s);
+    else if (plain && KS == 1 && STRIDE == 1)
+      launch_direct<1, 1, 2>(k, (unsigned)nblk, s);
+    else if (plain && KS == 3 && STRIDE == 2)
+      launch_direct<3, 2, 2>(k, (unsigned)nblk, s);
+    else if (plain && KS == 3 && STRIDE == 1)
+      launch_direct<3, 1, 2>(k, (unsigned)nblk, s);
     else
       hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, GEOM>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
     if ((k.ylimit || k.xcols) && prof.idx >= 0 && e->prof.h_lims && e->prof.n_lims < PtProfile::MAX_LIMS) {
