@@ -496,7 +496,6 @@ __global__ __launch_bounds__(NTHR, SPLIT ? 2 : NTHR / 128) void dcn_fused64_kern
   // their bilinear weights, and the sigmoid mask
   __shared__ __attribute__((aligned(16))) int s_goff[128 * 9][4];
   __shared__ __attribute__((aligned(16))) float s_gwt[128 * 9][4];
-  __shared__ float s_gmask[128 * 9];
   // the offset / mask values are only needed while the table is built: they share LDS with the operand images
   __shared__ __attribute__((aligned(16))) char s_ab[NP * (128 * ROW + NB * ROW)];
   static_assert(128 * ROW + NB * ROW >= 128 * 28 * 4, "operand images must cover the staged offset/mask rows");
@@ -543,7 +542,8 @@ __global__ __launch_bounds__(NTHR, SPLIT ? 2 : NTHR / 128) void dcn_fused64_kern
     locate(pl, yh, xw);
     const float* o = s_om + pl * 28;
     const float off_h = o[2 * tap], off_w = o[2 * tap + 1];
-    s_gmask[i] = 1.f / (1.f + expf(-o[18 + tap]));
+    // the sigmoid mask is folded into the bilinear weights here: one multiply per (pixel, tap) instead of one per blended value
+    const float gm = 1.f / (1.f + expf(-o[18 + tap]));
     const float h_im = (float)(yh - 1 + tap / 3) + off_h;
     const float w_im = (float)(xw - 1 + tap % 3) + off_w;
     int co[4] = {-1, -1, -1, -1};
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(NTHR, SPLIT ? 2 : NTHR / 128) void dcn_fused64_kern
       const float hf = floorf(h_im), wf = floorf(w_im);
       const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
       const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-      cw[0] = hh * hw; cw[1] = hh * lw; cw[2] = lh * hw; cw[3] = lh * lw;
+      cw[0] = hh * hw * gm; cw[1] = hh * lw * gm; cw[2] = lh * hw * gm; cw[3] = lh * lw * gm;
       if (h_low >= 0 && w_low >= 0) co[0] = (h_low * W + w_low) * cs;
       if (h_low >= 0 && w_high <= W - 1) co[1] = (h_low * W + w_high) * cs;
       if (h_high <= H - 1 && w_low >= 0) co[2] = (h_high * W + w_low) * cs;
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(NTHR, SPLIT ? 2 : NTHR / 128) void dcn_fused64_kern
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   int coff[IT][4];
-  float cwt[IT][4], mask[IT];
+  float cwt[IT][4];
   u32x4 rc[IT][4], rcl[SPLIT ? IT : 1][4];
   u32x4 rw[WP], rwl[SPLIT ? WP : 1];
 
@@ -583,7 +583,6 @@ __global__ __launch_bounds__(NTHR, SPLIT ? 2 : NTHR / 128) void dcn_fused64_kern
       const float4 wv = *reinterpret_cast<const float4*>(s_gwt[gi]);
       coff[j][0] = o.x; coff[j][1] = o.y; coff[j][2] = o.z; coff[j][3] = o.w;
       cwt[j][0] = wv.x; cwt[j][1] = wv.y; cwt[j][2] = wv.z; cwt[j][3] = wv.w;
-      mask[j] = s_gmask[gi];
     }
   };
   auto prefetch = [&](int st) {
@@ -625,7 +624,7 @@ __global__ __launch_bounds__(NTHR, SPLIT ? 2 : NTHR / 128) void dcn_fused64_kern
       continue;
 #endif
       const df2 w0 = {cwt[j][0], cwt[j][0]}, w1 = {cwt[j][1], cwt[j][1]}, w2 = {cwt[j][2], cwt[j][2]},
-                w3 = {cwt[j][3], cwt[j][3]}, mk = {mask[j], mask[j]};
+                w3 = {cwt[j][3], cwt[j][3]};
       uint32_t o[4], ol[4];
 #pragma unroll
       for (int e2 = 0; e2 < 4; ++e2) {
@@ -643,7 +642,6 @@ __global__ __launch_bounds__(NTHR, SPLIT ? 2 : NTHR / 128) void dcn_fused64_kern
         v = w1 * c[1] + v;
         v = w2 * c[2] + v;
         v = w3 * c[3] + v;
-        v = v * mk;
         const db2 hb = __builtin_convertvector(v, db2);
         o[e2] = __builtin_bit_cast(uint32_t, hb);
         if (SPLIT) ol[e2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - __builtin_convertvector(hb, df2), db2));
