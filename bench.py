@@ -461,8 +461,11 @@ class HipRunner:
             t0 = time.perf_counter()
             if rec_prev is not None:
                 from pdf_table_amd.rec_stage import ctc_collapse
-                with self._on(self.rec_stream):
-                    toks = ctc_collapse(rec_prev.cpu().numpy())     # D2H of int32 [lines, 160] + host collapse
+                _, nl_, _, ids_h, ids_ev = rec_prev
+                toks = []
+                if nl_:
+                    ids_ev.synchronize()         # the copy of THAT step's ids: never waits for work queued since
+                    toks = ctc_collapse(ids_h.numpy())     # int32 [lines, 160], host collapse
                 eng.check()
                 if count:
                     c["tok"] += sum(len(t) for t in toks)
@@ -488,9 +491,9 @@ class HipRunner:
             if rec is not None:
                 quads = self.gt_quads if (args.gt_chain or self.rec_boxes is None) else self.rec_boxes
                 with self._on(self.rec_stream):
-                    rec_ids, rec_lines = rec.ids(self.pages, quads)      # host quad geometry + one pt_rec_forward (async)
+                    rec_ids = rec.start(self.pages, quads)      # host quad geometry + one pt_rec_forward + ids -> pinned memory (async)
                 if count:
-                    c["rec_lines"] += len(rec_lines)
+                    c["rec_lines"] += rec_ids[1]
             tpend = None
             if tsr is not None:
                 tsr_tables, tsr_metas = tsr.tables((PAGE, PAGE), self.table_boxes)    # host: one affine map per table
@@ -498,8 +501,8 @@ class HipRunner:
                 if self.aux is not None:      # the processor of these tables will run on the auxiliary stream, behind this event
                     ev = torch.cuda.Event()
                     ev.record()
-                    for (_, _, c_, d_, l_) in tpend[0]:
-                        for t_ in (c_, d_, l_):
+                    for p_ in tpend[0]:
+                        for t_ in p_[2:5]:
                             t_.record_stream(self.aux)
                     tpend = tpend + (ev,)
             cls_out = None

@@ -232,8 +232,9 @@ class OcrTablePipeline:
 
             step k:  queue layout(k) [auxiliary stream] and detection(k)
                      host: boxes of batch k-1 (contours, unclip, reading order), layout decode + NMS of batch k-1
-                     queue recognition(k-1) [second stream] and table structure(k-1) on those boxes / regions
+                     queue recognition(k-1) and table structure(k-1) on those boxes / regions
                      host: texts and tables of batch k-2 (CTC collapse, processor, result shaping, HTML)  -> yield
+                     (moving the host halves of batch k behind the collect of k-2 measured slower: 465 vs 500 pages/s)
 
         so the GPU queue always holds at least one batch of work while the host decodes, and nothing the host waits for was
         queued in the same step.  Results arrive two batches behind the input; the generator drains at the end.
@@ -245,12 +246,14 @@ class OcrTablePipeline:
             raise ValueError("table_structure=True needs layout=True or predict_stream(table_boxes=...)")
         dev = self.engine._tdev
         main = torch.cuda.current_stream(dev)
-        if self._rec_stream is None:
+        if self.overlap_rec and self._rec_stream is None:
             self._rec_stream = torch.cuda.Stream(device=dev)
             self.engine.set_lstm_cluster(False)      # the recogniser shares the GPU with the other stages (see __init__)
         if getattr(self, "_aux_stream", None) is None:
             self._aux_stream = torch.cuda.Stream(device=dev)
-        rec_s, aux = self._rec_stream, self._aux_stream
+        # overlap_rec=False: the recogniser stays on the main stream behind detection (weight-stationary cluster LSTM, the GPU
+        # to itself) -- with nothing in this schedule waiting on the newest work, that measures faster than sharing the CUs
+        rec_s, aux = (self._rec_stream if self.overlap_rec else main), self._aux_stream
         det: DetStage = self.text_detector._stage
         rec_stage = self.text_recognizer._stage
         lay_stage = self.layout_task._stage if self.layout_task is not None else None
@@ -258,7 +261,7 @@ class OcrTablePipeline:
         tb_iter = iter(table_boxes) if table_boxes is not None else None
         t_start = time.time()
         total_lines = 0
-        host = {"queue_first": 0.0, "queue_second": 0.0, "collect": 0.0}      # host seconds per phase (self.metric)
+        host = {"queue_first": 0.0, "queue_second": 0.0, "collect": 0.0, "host_halves": 0.0}      # host seconds per phase (self.metric)
 
         def queue_first(batch, k):
             """layout(k) + detection(k)"""
@@ -282,15 +285,19 @@ class OcrTablePipeline:
             st["det"] = det.forward(pages_t, slot=k & 1)
             return st
 
-        def queue_second(st):
-            """host halves of detection / layout, then recognition + table structure on their results"""
+        def host_halves(st):
+            """host halves of detection / layout of the batch queued one step ago"""
             prob, bitmap, ev = st["det"]
             t0 = time.perf_counter()
             st["boxes"] = [sort_boxes_reading_order(b) for b in det.boxes(prob, bitmap, st["shape"], ev)]
             t1 = time.perf_counter()
             st["layout"] = lay_stage.finish(st["lay"][0], st["lay"][1], st["shape"]) if lay_stage is not None else None
-            host["second.boxes"] = host.get("second.boxes", 0.0) + t1 - t0
-            host["second.layout"] = host.get("second.layout", 0.0) + time.perf_counter() - t1
+            host["halves.boxes"] = host.get("halves.boxes", 0.0) + t1 - t0
+            host["halves.layout"] = host.get("halves.layout", 0.0) + time.perf_counter() - t1
+
+        def queue_second(st):
+            """host halves of detection / layout, then recognition + table structure on their results"""
+            timed("host_halves", host_halves, st)
             with torch.cuda.stream(rec_s):
                 rec_s.wait_event(st["uploaded"])
                 try:
@@ -309,8 +316,8 @@ class OcrTablePipeline:
                 if pending is not None:      # the processor of these tables runs on the auxiliary stream, behind this event
                     ev = torch.cuda.Event()
                     ev.record(main)
-                    for (_, _, c_, d_, l_) in pending:
-                        for t_ in (c_, d_, l_):
+                    for p_ in pending:
+                        for t_ in p_[2:5]:
                             t_.record_stream(aux)
                 st["tsr"] = (pending, metas, offs, ev)
 

@@ -210,17 +210,28 @@ class TsrStage:
                 counts, dets, logi = self.eng.tsr_decode(heads, wiz_rev=cfg.wiz_rev, vis_thresh=cfg.vis_thresh, sync=False)
             pending.append((i, len(tb), counts, dets, logi))
         if fused and nmb > 1:
-            return [(0, len(tables), counts_all, dets_all, logi_all)]
-        return pending
+            pending = [(0, len(tables), counts_all, dets_all, logi_all)]
+        # the cell counts go to pinned host memory right behind the decode, with an event of their own: process() then waits
+        # for THESE tables' decode only -- a `.cpu()` there would wait for everything queued on the stream since (a pipelined
+        # caller has queued the next batch by then)
+        out = []
+        for (i, nt, counts, dets, logi) in pending:
+            host = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
+            host.copy_(counts, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            out.append((i, nt, counts, dets, logi, host, ev))
+        return out
 
     def process(self, pending):
-        """device half 2: cell counts to the host (waits for half 1 of these tables only when it is still running), the
+        """device half 2: cell counts from their pinned copy (waits for half 1 of these tables only when it is still running), the
         processor over all cells of each micro-batch, then the valid rows to pinned host memory on a copy stream behind
         an event -- nothing here waits for work queued after start()."""
         cfg = self.config
         staged = []
-        for (i, nt, counts_d, dets, logi) in pending:
-            counts = counts_d.cpu().numpy()
+        for (i, nt, counts_d, dets, logi, counts_h, counts_ev) in pending:
+            counts_ev.synchronize()
+            counts = counts_h.numpy().copy()
             logic, stacked = self.eng.tsr_process(logi, dets, counts, use_2dpe=cfg.wiz_2dpe)
             staged.append((i, nt, counts, dets, logic, stacked))
         if not staged:

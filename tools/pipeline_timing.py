@@ -34,7 +34,9 @@ for overlap in (False, True, False, True):
 # predict_stream: ten 64-page batches already on the device, table regions given (bench.py's workload shape)
 # detect_model="db_pp": the PP-OCR pre/post flavour around DB-ResNet18 (1024^2 page -> 960^2 net input), bench.py's detection
 # workload; the "db" flavour of the runs above feeds the net 1024^2
-p = OcrTablePipeline(device=0, synthetic_seed=0, layout=True, table_structure=True)
+import sys
+p = OcrTablePipeline(device=0, synthetic_seed=0, layout=True, table_structure=True, overlap_rec="--overlap-rec" in sys.argv)
+print("predict_stream with overlap_rec =", p.overlap_rec)
 quads64 = (quads + quads)
 stage = p.text_detector._stage
 from pdf_table_amd.det_stage import DetConfig
