@@ -308,7 +308,8 @@ class HipRunner:
         self.dev = dev = torch.device("cuda", local_rank)
         self.stages = stages = [x for x in args.stages.split(",") if x]
         assert set(stages) <= {"layout", "det", "rec", "tsr", "cls"} and stages
-        self.x3_leg = (not args.no_extra_legs or args.precision == "bf16x3") and args.det_backbone == "resnet18"
+        # the (hi, lo) weight tiles are only packed / broadcast when a BF16X3 leg will run (extra legs: one rank only)
+        self.x3_leg = ((not args.no_extra_legs and world == 1) or args.precision == "bf16x3") and args.det_backbone == "resnet18"
         x3 = self.x3_leg            # blobs then also carry the (hi, lo) weight tiles of PT_PRECISION_BF16X3
         self.eng = eng = HipEngine(local_rank)
         self.aux = torch.cuda.Stream(device=dev) if args.aux_stream else None
