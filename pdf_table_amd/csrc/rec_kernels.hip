@@ -631,15 +631,19 @@ __device__ __forceinline__ float fast_tanh(float x) {
 #ifndef PT_LSTM_ABL
 #define PT_LSTM_ABL 0
 #endif
-template <int SPLIT>
-__global__ __launch_bounds__(256, 1) void lstm_dir_kernel(const bf16_t* __restrict__ gx, const bf16_t* __restrict__ whh,
+// NG = 2: two independent groups of 32 lines per workgroup (waves 0-3 and 4-7, two waves per SIMD): while one group waits
+// for a W_hh burst from L2 the other multiplies -- with one group a SIMD holds one wave and every round trip is exposed --
+// and a launch needs half the workgroups (5082 lines x 2 directions: 160 instead of 318, one round on 256 CUs instead of two).
+template <int SPLIT, int NG = 1>
+__global__ __launch_bounds__(256 * NG, 1) void lstm_dir_kernel(const bf16_t* __restrict__ gx, const bf16_t* __restrict__ whh,
                                                            bf16_t* __restrict__ hout, int B, int T) {
   constexpr int NP = SPLIT ? 2 : 1;
   constexpr int HROW = 264;  // 256 + 8 bf16: 528-byte rows = 33 16-byte slots (odd) -> conflict-free b128 reads
-  __shared__ __attribute__((aligned(16))) bf16_t hbuf[NP][32][HROW];  // read by all waves (MFMA), then rewritten
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ __attribute__((aligned(16))) bf16_t hbuf_all[NG][NP][32][HROW];  // read by the group's waves (MFMA), then rewritten
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 8, tid = threadIdx.x & 255, wave = tid >> 6;
+  bf16_t (*hbuf)[32][HROW] = hbuf_all[grp];
   const int lx = lane & 31, q = lane >> 5;
-  const int line0 = blockIdx.x * 32, dir = blockIdx.y;
+  const int line0 = (blockIdx.x * NG + grp) * 32, dir = blockIdx.y;
   const int gcs = (SPLIT ? 2 : 1) * 2048;  // gx channels per (line, t): [dir0 1024 | dir1 1024] (x2 for hi|lo)
   const int hcs = (SPLIT ? 2 : 1) * 512;   // hout channels per (line, t): [fw 256 | bw 256] (x2 for hi|lo)
   const bf16_t* whh_d = whh + (size_t)dir * 1024 * 256;           // hi part; lo part at + 2*1024*256
@@ -668,9 +672,10 @@ __global__ __launch_bounds__(256, 1) void lstm_dir_kernel(const bf16_t* __restri
     if (s > 0 && PT_LSTM_ABL != 4) flush_h(dir ? t + 1 : t - 1);
     // input-projection terms of this step: gx is laid out [line][t][dir][unit][gate] (gate fastest, set up by the
     // weight packer), so the four gates of a (line, unit) are one 8-byte load; issued before the MFMA phase
+    // NG = 2 (256 registers per wave instead of 512): the gx terms are fetched per 32-unit half AFTER the MFMA phase (the
+    // other group's MFMAs cover the latency) and W_hh comes in bursts of two k-steps instead of four
     u32x2 gxv[2][16], gxl[2][16];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
+    auto load_gx = [&](int h) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = (r & 3) + 8 * (r >> 2) + 4 * q;
@@ -686,6 +691,11 @@ __global__ __launch_bounds__(256, 1) void lstm_dir_kernel(const bf16_t* __restri
         if (SPLIT) gxl[h][r] = *reinterpret_cast<const u32x2*>(gp + 2048);
 #endif
       }
+    };
+    if (NG == 1) {
+      load_gx(0);
+      load_gx(1);
+    }
     f32x16 acc[4][2];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -700,11 +710,12 @@ __global__ __launch_bounds__(256, 1) void lstm_dir_kernel(const bf16_t* __restri
       const bf16_t* wsrc = whh_d + (pass == 2 ? (size_t)2 * 1024 * 256 : 0);
       // W_hh streams from L2 and the loop is latency-bound: issue the 32 fragment loads of a quarter step (128
       // VGPRs) in one burst, then multiply -- four L2 round trips per pass instead of sixteen
+      constexpr int KQ = NG == 2 ? 2 : 4;      // k-steps per burst
 #pragma unroll 1
-      for (int half = 0; half < 4; ++half) {
-        bf16x8 bq[4][4][2];
+      for (int half = 0; half < 16 / KQ; ++half) {
+        bf16x8 bq[KQ][4][2];
 #pragma unroll
-        for (int kq = 0; kq < 4; ++kq)
+        for (int kq = 0; kq < KQ; ++kq)
 #pragma unroll
           for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -715,12 +726,12 @@ __global__ __launch_bounds__(256, 1) void lstm_dir_kernel(const bf16_t* __restri
               bq[kq][g][h] = *reinterpret_cast<const bf16x8*>(&hbuf[pa][lx][((kq * 4 + g) * 2 + h) * 8]);
 #else
               bq[kq][g][h] = *reinterpret_cast<const bf16x8*>(
-                  wsrc + (size_t)(((((wave * 4 + half) * 4 + kq) * 4 + g) * 2 + h) * 64 + lane) * 8);
+                  wsrc + (size_t)((((wave * 16 + half * KQ + kq) * 4 + g) * 2 + h) * 64 + lane) * 8);
 #endif
             }
 #pragma unroll
-        for (int kq = 0; kq < 4; ++kq) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(&hbuf[pa][lx][(half * 4 + kq) * 16 + q * 8]);
+        for (int kq = 0; kq < KQ; ++kq) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(&hbuf[pa][lx][(half * KQ + kq) * 16 + q * 8]);
 #pragma unroll
           for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -734,6 +745,7 @@ __global__ __launch_bounds__(256, 1) void lstm_dir_kernel(const bf16_t* __restri
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int unit = wave * 64 + h * 32 + lx;
+      if (NG == 2) load_gx(h);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = (r & 3) + 8 * (r >> 2) + 4 * q;
@@ -1106,6 +1118,11 @@ static int launch_lstm_cluster(const bf16_t* gx, const bf16_t* whh, bf16_t* hout
 int pt_launch_lstm(pt_engine* e, const bf16_t* gx, const bf16_t* whh, bf16_t* hout, int B, int T, int split, hipStream_t s) {
   if (B <= 0) return PT_OK;
   dim3 grid((B + 31) / 32, 2);
+  static int ng2 = -1;           // PT_LSTM_NG=1: one 32-line group per workgroup in the hi/lo kernel too (A/B switch)
+  if (ng2 < 0) {
+    const char* ev = getenv("PT_LSTM_NG");
+    ng2 = ev ? (atoi(ev) == 2) : 1;
+  }
   static int use_dma = -1;       // PT_LSTM_DMA=0: the register-staged kernel also in bf16 mode (A/B switch)
   if (use_dma < 0) {
     const char* ev = getenv("PT_LSTM_DMA");
@@ -1142,7 +1159,10 @@ int pt_launch_lstm(pt_engine* e, const bf16_t* gx, const bf16_t* whh, bf16_t* ho
                        : launch_lstm_cluster<2>(gx, whh, hout, B, T, max_cl, hx, flags, err, s);
     if (rc != PT_OK) return rc;
   } else if (split) {
-    hipLaunchKernelGGL(lstm_dir_kernel<1>, grid, dim3(256), 0, s, gx, whh, hout, B, T);
+    if (ng2)
+      hipLaunchKernelGGL((lstm_dir_kernel<1, 2>), dim3((B + 63) / 64, 2), dim3(512), 0, s, gx, whh, hout, B, T);
+    else
+      hipLaunchKernelGGL((lstm_dir_kernel<1, 1>), grid, dim3(256), 0, s, gx, whh, hout, B, T);
   } else if (use_dma) {
     constexpr int SMEM = 32 * 264 * 2 + 2 * 65536;
     static bool attr_done = false;
@@ -1152,7 +1172,7 @@ int pt_launch_lstm(pt_engine* e, const bf16_t* gx, const bf16_t* whh, bf16_t* ho
     }
     hipLaunchKernelGGL(lstm_dir_dma_kernel, grid, dim3(256), SMEM, s, gx, whh, hout, B, T);
   } else {
-    hipLaunchKernelGGL(lstm_dir_kernel<0>, grid, dim3(256), 0, s, gx, whh, hout, B, T);
+    hipLaunchKernelGGL((lstm_dir_kernel<0, 1>), grid, dim3(256), 0, s, gx, whh, hout, B, T);
   }
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
