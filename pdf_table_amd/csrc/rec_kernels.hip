@@ -1172,7 +1172,10 @@ int pt_launch_lstm(pt_engine* e, const bf16_t* gx, const bf16_t* whh, bf16_t* ho
     }
     hipLaunchKernelGGL(lstm_dir_dma_kernel, grid, dim3(256), SMEM, s, gx, whh, hout, B, T);
   } else {
-    hipLaunchKernelGGL((lstm_dir_kernel<0, 1>), grid, dim3(256), 0, s, gx, whh, hout, B, T);
+    if (ng2)
+      hipLaunchKernelGGL((lstm_dir_kernel<0, 2>), dim3((B + 63) / 64, 2), dim3(512), 0, s, gx, whh, hout, B, T);
+    else
+      hipLaunchKernelGGL((lstm_dir_kernel<0, 1>), grid, dim3(256), 0, s, gx, whh, hout, B, T);
   }
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
