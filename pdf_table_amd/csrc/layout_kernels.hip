@@ -178,6 +178,87 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
   }
 }
 
+// Stride-1 variant with TWO output rows per thread: the K + 1 input rows of the pair are loaded and unpacked once (6 x 8
+// column loads for 8 outputs at K = 5 instead of 2 x 5 x 8), every output still accumulates its taps in (ky, kx) order in
+// fp32 -- results identical to dwconv_kernel<K, 1>.  The layout net's 5x5 depthwise layers were its largest item
+// (4.9 ms per 64-page step: ~1200 VALU instructions and 90 loads per 32 outputs in the one-row kernel).
+template <int K>
+__global__ __launch_bounds__(256) void dwconv2_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w,
+                                                       const float* __restrict__ b, bf16_t* __restrict__ out, int B, int H, int W,
+                                                       int C, int Ho, int Wo, int act, int split, const float* __restrict__ slope) {
+#pragma clang fp contract(fast)
+  constexpr int PX = 4, PAD = K / 2, NCOL = PX - 1 + K;
+  const int cgn = C >> 3, cs = split ? 2 * C : C, wq = (Wo + PX - 1) / PX, hq = (Ho + 1) >> 1;
+  const float sl = act == 3 ? slope[0] : 0.f;
+  const long long total = (long long)B * hq * wq * cgn;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % cgn);
+    long long t = i / cgn;
+    const int ox0 = (int)(t % wq) * PX;
+    t /= wq;
+    const int oy0 = (int)(t % hq) * 2;
+    const int bi = (int)(t / hq);
+    float acc[2][PX][8];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int p = 0; p < PX; ++p)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[r][p][q] = 0.f;
+    const int ix0 = ox0 - PAD;
+#pragma unroll
+    for (int ir = 0; ir < K + 1; ++ir) {          // input row oy0 - PAD + ir feeds output row r with ky = ir - r
+      const int iy = oy0 - PAD + ir;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      float col[NCOL][8];
+#pragma unroll
+      for (int j = 0; j < NCOL; ++j) {
+        const int ix = ix0 + j;
+        if ((unsigned)ix < (unsigned)W) {
+          load8(in + (((size_t)bi * H + iy) * W + ix) * cs + cg * 8, C, split, col[j]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) col[j][q] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int ky = ir - r;
+        if (ky < 0 || ky >= K) continue;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          const float4 w0 = *reinterpret_cast<const float4*>(w + (size_t)(ky * K + kx) * C + cg * 8);
+          const float4 w1 = *reinterpret_cast<const float4*>(w + (size_t)(ky * K + kx) * C + cg * 8 + 4);
+          const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+          for (int p = 0; p < PX; ++p)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[r][p][q] += col[p + kx][q] * wv[q];
+        }
+      }
+    }
+    const float4 b0 = *reinterpret_cast<const float4*>(b + cg * 8), b1 = *reinterpret_cast<const float4*>(b + cg * 8 + 4);
+    const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (oy0 + r >= Ho) break;
+#pragma unroll
+      for (int p = 0; p < PX; ++p) {
+        if (ox0 + p >= Wo) break;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          float v = acc[r][p][q] + bv[q];
+          if (act == 2) v = hswish(v);
+          else if (act == 1) v = fmaxf(v, 0.f);
+          else if (act == 3) v = v > 0.f ? v : sl * v;
+          acc[r][p][q] = v;
+        }
+        store8(out + (((size_t)bi * Ho + oy0 + r) * Wo + ox0 + p) * cs + cg * 8, C, split, acc[r][p]);
+      }
+    }
+  }
+}
+
 // global-average-pool partial sums, deterministic: block (chunk, image) sums its pixel range per channel
 // part: fp32 [B][gridDim.x][C]
 __global__ __launch_bounds__(256) void chan_partial_sum_kernel(const bf16_t* __restrict__ x, int HW, int C, int split,
@@ -389,6 +470,20 @@ int pt_launch_dwconv(const bf16_t* in, const float* w, const float* b, bf16_t* o
   PT_REQUIRE(act != 3 || slope, "dwconv: PReLU needs the slope tensor");
   const int pad = k / 2, Ho = (H + 2 * pad - k) / sy + 1, Wo = (W + 2 * pad - k) / sx + 1;
   const dim3 grid(blocks_for((long long)B * Ho * ((Wo + 3) / 4) * (C / 8)));
+  static int two = -1;           // PT_DWCONV2=0: one output row per thread everywhere (A/B switch)
+  if (two < 0) {
+    const char* ev = getenv("PT_DWCONV2");
+    two = ev ? atoi(ev) : 1;
+  }
+  if (two && sy == 1 && sx == 1 && Ho >= 2) {
+    const dim3 grid2(blocks_for((long long)B * ((Ho + 1) / 2) * ((Wo + 3) / 4) * (C / 8)));
+    if (k == 3)
+      hipLaunchKernelGGL((dwconv2_kernel<3>), grid2, dim3(256), 0, s, in, w, b, out, B, H, W, C, Ho, Wo, act, split, slope);
+    else
+      hipLaunchKernelGGL((dwconv2_kernel<5>), grid2, dim3(256), 0, s, in, w, b, out, B, H, W, C, Ho, Wo, act, split, slope);
+    PT_HIP_CHECK(hipGetLastError());
+    return PT_OK;
+  }
 #define PT_DW(KK, SS) hipLaunchKernelGGL((dwconv_kernel<KK, SS>), grid, dim3(256), 0, s, in, w, b, out, B, H, W, C, sy, Ho, Wo, act, split, slope)
   if (k == 3 && sx == 1) PT_DW(3, 1);
   else if (k == 3) PT_DW(3, 2);
