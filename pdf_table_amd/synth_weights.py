@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 __all__ = ["db_resnet18_state_dict", "crnn_state_dict", "CRNN_NUM_CLASSES", "lore_dla34_state_dict",
-           "lore_processor_state_dict", "LORE_HEADS", "picodet_state_dict", "LCNET_CONFIG", "PICODET_STANDIN", "lore_wireless_state_dict", "db_nas_state_dict", "pplcnet_state_dict"]
+           "lore_processor_state_dict", "LORE_HEADS", "picodet_state_dict", "LCNET_CONFIG", "PICODET_STANDIN", "lore_wireless_state_dict", "db_nas_state_dict", "pplcnet_state_dict", "convnext_vit_state_dict"]
 
 CRNN_NUM_CLASSES = 7644  # crnn/modeling_crnn.py:90
 
@@ -207,6 +207,55 @@ def crnn_state_dict(seed: int = 0, num_classes: int = CRNN_NUM_CLASSES):
     g.lstm("rnn.1.rnn", 256, 256, scale=3.0)
     g.linear("rnn.1.embedding", 512, 512, scale=4.0)
     g.linear("cls", num_classes, 512, bias=False, scale=4.0)
+    return g.sd
+
+
+def convnext_vit_state_dict(seed: int = 0, num_labels: int = CRNN_NUM_CLASSES):
+    """state_dict of ``ConvNextViT`` (convnext_vit/modeling_convnext_vit.py:20-36: ConvNext depths [3, 3, 8, 3], widths
+    [96, 192, 256, 512], one input channel; ViT 12 x (192-d, 3 heads, 768 MLP) over 75 tokens; Linear(192 -> 7644)) in the
+    key names of the checkpoint era the reference was written for (transformers 4.x ``vit.encoder.layer.N.attention.attention
+    .query`` ...).  Layer-scale values are O(0.3) like a trained net (the 1e-6 initial value would make every block a no-op)."""
+    g = _Gen(seed)
+    r = g.rng
+
+    def ln(name, c):
+        g.put(name + ".weight", r.uniform(0.7, 1.3, (c,)))
+        g.put(name + ".bias", r.uniform(-0.1, 0.1, (c,)))
+
+    p = "cnn_model."
+    g.put(p + "embeddings.patch_embeddings.weight", r.standard_normal((96, 1, 4, 4)) * 1.5)
+    g.put(p + "embeddings.patch_embeddings.bias", r.uniform(-0.1, 0.1, (96,)))
+    ln(p + "embeddings.layernorm", 96)
+    dims, depths = (96, 192, 256, 512), (3, 3, 8, 3)
+    for i, (d, dep) in enumerate(zip(dims, depths)):
+        q = f"{p}encoder.stages.{i}."
+        if i > 0:
+            ln(q + "downsampling_layer.0", dims[i - 1])
+            g.conv(q + "downsampling_layer.1", d, dims[i - 1], 2, 1, bias=True, gain=1.0)
+        for j in range(dep):
+            lq = f"{q}layers.{j}."
+            g.put(lq + "layer_scale_parameter", r.uniform(0.2, 0.5, (d,)))
+            g.put(lq + "dwconv.weight", r.standard_normal((d, 1, 7, 7)) * (1.0 / 7.0))
+            g.put(lq + "dwconv.bias", r.uniform(-0.1, 0.1, (d,)))
+            ln(lq + "layernorm", d)
+            g.linear(lq + "pwconv1", 4 * d, d, scale=1.5)
+            g.linear(lq + "pwconv2", d, 4 * d, scale=1.5)
+    ln(p + "layernorm", 512)
+    p = "vitstr.vit."
+    g.put(p + "embeddings.cls_token", r.standard_normal((1, 1, 192)) * 0.02)
+    g.put(p + "embeddings.position_embeddings", r.standard_normal((1, 76, 192)) * 0.2)
+    g.conv(p + "embeddings.patch_embeddings.projection", 192, 512, 1, 1, bias=True, gain=1.0)
+    for l in range(12):
+        q = f"{p}encoder.layer.{l}."
+        for n in ("query", "key", "value"):
+            g.linear(q + "attention.attention." + n, 192, 192, scale=2.0)
+        g.linear(q + "attention.output.dense", 192, 192, scale=1.0)
+        ln(q + "layernorm_before", 192)
+        ln(q + "layernorm_after", 192)
+        g.linear(q + "intermediate.dense", 768, 192, scale=1.5)
+        g.linear(q + "output.dense", 192, 768, scale=1.0)
+    ln(p + "layernorm", 192)
+    g.linear("vitstr.classifier", num_labels, 192, scale=4.0)
     return g.sd
 
 

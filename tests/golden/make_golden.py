@@ -688,6 +688,68 @@ def gen_table_html():
     print("table_html.json", len(out["cases"]), "cases;", out["cases"][0]["html"][:120])
 
 
+def gen_convnext_vit():
+    """Outputs of the reference's ``ConvNextViT`` (convnext_vit/modeling_convnext_vit.py:20-45) for seeded weights and one
+    line (three 300-px chunks).  ``ViTForSTR.forward_features`` raises under the transformers 5.15 of this image
+    (``self.vit.get_head_mask`` is gone and ``ViTPatchEmbeddings.forward`` lost ``interpolate_pos_encoding``), so the fixture
+    drives the module's OWN sub-modules in the order that method does (modeling_vit.py:64-86: patch embeddings, position
+    embeddings [:, 1:], encoder layers, final LayerNorm) and then the stitching + classifier lines of ``forward``
+    (modeling_vit.py:131-143) on the module's own ``classifier``.  The CNN half is the reference's ``ConvNextModel`` called
+    as its forward calls it.  Weights: the synthetic 4.x-named state_dict renamed to the installed modules' 5.x names and
+    loaded with strict=True."""
+    import re
+    from pdf_table_amd.synth_weights import convnext_vit_state_dict
+    mod = ref_import("pdftable.model.convnext_vit.modeling_convnext_vit")
+    torch.manual_seed(0)
+    model = mod.ConvNextViT().eval()
+    v4_to_v5 = [
+        (r"vit\.encoder\.layer\.(\d+)\.attention\.attention\.query\.", r"vit.layers.\1.attention.q_proj."),
+        (r"vit\.encoder\.layer\.(\d+)\.attention\.attention\.key\.", r"vit.layers.\1.attention.k_proj."),
+        (r"vit\.encoder\.layer\.(\d+)\.attention\.attention\.value\.", r"vit.layers.\1.attention.v_proj."),
+        (r"vit\.encoder\.layer\.(\d+)\.attention\.output\.dense\.", r"vit.layers.\1.attention.o_proj."),
+        (r"vit\.encoder\.layer\.(\d+)\.intermediate\.dense\.", r"vit.layers.\1.mlp.fc1."),
+        (r"vit\.encoder\.layer\.(\d+)\.output\.dense\.", r"vit.layers.\1.mlp.fc2."),
+        (r"vit\.encoder\.layer\.(\d+)\.layernorm_", r"vit.layers.\1.layernorm_"),
+    ]
+    sd = {}
+    for k, v in convnext_vit_state_dict(seed=29).items():
+        for pat, rep in v4_to_v5:
+            k = re.sub(pat, rep, k)
+        sd[k] = v
+    if not any(k.startswith("vitstr.vit.layers.") for k in model.state_dict()):
+        sd = convnext_vit_state_dict(seed=29)            # an older transformers: the 4.x names are the module's own
+    model.load_state_dict(sd, strict=True)
+    rng = np.random.default_rng(131)
+    img = rng.integers(0, 256, (3, 32, 300, 3), dtype=np.uint8)       # three chunks of one line, RGB
+    img[:, :, 200:, :] //= 4
+    x = torch.from_numpy(img).float().div(255.).permute(0, 3, 1, 2)
+    with torch.no_grad():
+        gray = x[:, 0:1] * 0.2989 + x[:, 1:2] * 0.5870 + x[:, 2:3] * 0.1140          # modeling_convnext_vit.py:40
+        feats = model.cnn_model(gray).last_hidden_state                              # [3, 512, 1, 75]
+        vit = model.vitstr.vit
+        emb = vit.embeddings.patch_embeddings(feats)
+        emb = emb + vit.embeddings.position_embeddings[:, 1:, :]
+        hs = emb
+        layers = vit.layers if hasattr(vit, "layers") else vit.encoder.layer
+        for layer in layers:
+            hs = layer(hs)
+            hs = hs[0] if isinstance(hs, tuple) else hs
+        seq = vit.layernorm(hs)
+        b, s_, e = seq.shape
+        ap = seq.view(b // 3, 3, 75, e)
+        cat = torch.ones(b // 3, 201, e).type_as(seq)
+        cat[:, :69, :] = ap[:, 0, :69, :]
+        cat[:, 69:69 + 63, :] = ap[:, 1, 6:-6, :]
+        cat[:, 69 + 63:, :] = ap[:, 2, 6:, :]
+        logits = model.vitstr.classifier(cat.reshape(-1, e)).view(b // 3, 201, -1)
+    top2 = torch.topk(logits, 2, dim=-1)
+    out = {"img_u8": img, "seed": np.array(29), "feats_sub": feats[:, ::8, 0, ::5].numpy(), "seq_sub": seq[:, ::5, ::8].numpy(),
+           "logits_sub": logits[:, :, ::97].numpy(), "top2_val": top2.values.numpy(), "top2_idx": top2.indices.numpy().astype(np.int32),
+           "logits_abs_max": np.array(logits.abs().max().item(), np.float32)}
+    np.savez_compressed(os.path.join(HERE, "convnext_vit.npz"), **out)
+    print("convnext_vit.npz", {k: v.shape for k, v in out.items()}, "distinct ids", len(set(top2.indices[..., 0].flatten().tolist())))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["db", "crnn", "registry", "ctc", "host", "lore_dla", "lore_decode", "lore_processor", "picodet",
                              "table_html"]
@@ -721,3 +783,5 @@ if __name__ == "__main__":
         gen_registry_hash()
     if "ctc" in which:
         gen_ctc()
+    if "convnext_vit" in which or not sys.argv[1:]:
+        gen_convnext_vit()
