@@ -88,6 +88,7 @@ enum {
   PT_MODEL_DB_NAS = 7,        /* db_net/dbnet.py:693-712 (DBNasModel: ProxylessNAS backbone + LightSegDetector) */
   PT_MODEL_PPLCNET = 8,       /* cls/cls_pp_lcnet.py:164-283 (PPLCNet classifier); kinds 8 .. 8 + PT_CLS_SLOTS - 1 = classifier slots */
   PT_MODEL_PICODET = 5,     /* picodet/lcnet.py:159-259 + csp_pan.py:233-347 + pico_head.py:966-1160 (assumed config) */
+  PT_MODEL_CONVNEXT_VIT = 16, /* convnext_vit/modeling_convnext_vit.py:20-45 (ConvNextViT recogniser) */
 };
 int pt_weights_load(pt_engine* e, int model_kind, const void* h_blob, size_t nbytes);
 /* Same, but the blob already sits in device memory (e.g. after an RCCL broadcast from rank 0). */
@@ -240,6 +241,31 @@ int pt_rec_forward_net(pt_engine* e, const uint16_t* d_gray, int n, int32_t* d_i
 /* Crop + resize + gray only (tests): writes d_gray as above. */
 int pt_rec_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int h, int w, const pt_rec_line* d_lines,
                       const int64_t* h_crop_px, int n_lines, uint16_t* d_gray, pt_stream stream);
+
+/* ---- stage 3, ConvNextViT recogniser (OcrRecognitionTask(model="ConvNextViT"), BASELINE.json configs[4]) ---------
+ * OCRRecognitionPreprocessor with do_chunking (model/ocr_recognition/processor_ocr_recognition.py:44-62,94-113): keep-ratio
+ * resize to 32 x 804, three 300-px chunks at 252-px steps; ConvNextViT.forward (model/convnext_vit/modeling_convnext_vit.py:
+ * 38-45, modeling_convnext.py:29-131, modeling_vit.py:31-143): every chunk through the ConvNext CNN and the 12-layer ViT, the
+ * chunks' 75 tokens stitched to 201 per line, Linear(192 -> 7644); then the arg-max of OCRRecognitionPostProcessor (:147-150).
+ *   d_ids / d_maxlogit: [n_lines, PT_CVIT_T] arg-max class (0 = CTC blank, vocabulary from class 2) and its logit. */
+#define PT_CVIT_W 804          /* OCRRecognitionConfig.img_width with do_chunking (configuration_ocr_recognition.py:47) */
+#define PT_CVIT_CHUNK_W 300    /* processor_ocr_recognition.py:105-106 */
+#define PT_CVIT_CHUNK_STEP 252 /* 300 - 48 */
+#define PT_CVIT_T 201          /* modeling_vit.py:134 */
+#define PT_CVIT_NCLS 7644      /* modeling_convnext_vit.py:33 */
+/* lines cut from resident pages (as pt_rec_forward) */
+int pt_rec_cvit_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int h, int w, const pt_rec_line* d_lines,
+                        const int64_t* h_crop_px, int n_lines, int32_t* d_ids, float* d_maxlogit, pt_stream stream);
+/* lines that are already cropped (as pt_rec_forward_crops) */
+int pt_rec_cvit_forward_crops(pt_engine* e, const uint8_t* d_crops_rgb, const pt_rec_line* d_lines, const int64_t* h_crop_px,
+                              int n_lines, int32_t* d_ids, float* d_maxlogit, pt_stream stream);
+/* Network only.  d_gray fp32 in [0, 1]: layout 0 = chunks [3 n_lines, 32, 300] (the tensor the reference's model receives,
+ * gray), layout 1 = lines [n_lines, 32, 804] (chunk j = columns [252 j, 252 j + 300)). */
+int pt_rec_cvit_forward_net(pt_engine* e, const float* d_gray, int layout, int n_lines, int32_t* d_ids, float* d_maxlogit,
+                            pt_stream stream);
+/* Resize + gray only (tests): d_gray fp32 [n_lines, 32, 804]. */
+int pt_rec_cvit_preprocess_crops(pt_engine* e, const uint8_t* d_crops_rgb, const pt_rec_line* d_lines, const int64_t* h_crop_px,
+                                 int n_lines, float* d_gray, pt_stream stream);
 
 /* PP-OCR recognition pre-processor -- PPOcrRecPreProcessor (model/ocr_rec_pp/processor_ocr_rec_pp.py:69-135,
  * resize_norm_img :43-67), the pre-processing of the recogniser the reference's system path selects

@@ -20,7 +20,7 @@ void pt_set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* pt_last_error(void) { return g_err; }
-int pt_abi_version(void) { return 8; }   // 8: pt_op_dwconv / add / maxpool / avgpool / chan_mean / scale_channels / act (generic ONNX executor); 7: pt_rec_pp_preprocess*; 6: pt_engine_set_lstm_cluster, pt_engine_check clears what it reports
+int pt_abi_version(void) { return 9; }   // 9: pt_rec_cvit_* (ConvNextViT recogniser); 8: pt_op_dwconv / add / maxpool / avgpool / chan_mean / scale_channels / act (generic ONNX executor); 7: pt_rec_pp_preprocess*; 6: pt_engine_set_lstm_cluster, pt_engine_check clears what it reports
 
 int pt_engine_check(pt_engine* e) {
   PT_REQUIRE(e, "pt_engine_check: null engine");
@@ -561,6 +561,102 @@ int pt_rec_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int h,
     if (rc != PT_OK) return rc;
     rc = pt_crnn_forward_net(e, reinterpret_cast<const bf16_t*>(e->rec_gray), nb, d_ids + (size_t)i0 * PT_REC_T,
                              d_maxlogit ? d_maxlogit + (size_t)i0 * PT_REC_T : nullptr, s, d_lines + i0);
+    if (rc != PT_OK) return rc;
+  }
+  return PT_OK;
+}
+
+// ---- ConvNextViT recogniser ---------------------------------------------------------------------------------------
+static int cvit_microbatch() {
+  static int mb = -1;
+  if (mb < 0) {
+    const char* s = getenv("PT_CVIT_MICROBATCH");
+    mb = s ? atoi(s) : 512;
+    if (mb < 1) mb = 1;
+  }
+  return mb;
+}
+
+int pt_rec_cvit_forward_net(pt_engine* e, const float* d_gray, int layout, int n_lines, int32_t* d_ids, float* d_maxlogit,
+                            pt_stream stream) {
+  PT_REQUIRE(e && d_gray && d_ids && n_lines > 0, "pt_rec_cvit_forward_net: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  return pt_cvit_forward_net(e, d_gray, layout, n_lines, d_ids, d_maxlogit, reinterpret_cast<hipStream_t>(stream));
+}
+
+// crop offsets of already-cropped lines -> device (host prefix sum; the copy is waited for: `off` is reused by the next call)
+static int cvit_crop_offsets(pt_engine* e, const int64_t* h_crop_px, int n_lines, hipStream_t s) {
+  std::vector<long long>& off = e->rec_off_host;
+  off.assign((size_t)n_lines + 1, 0);
+  for (int i = 0; i < n_lines; ++i) off[i + 1] = off[i] + (h_crop_px[i] > 0 ? h_crop_px[i] : 0);
+  int rc;
+  if ((rc = ensure(&e->rec_off, &e->rec_off_cap, (size_t)(n_lines + 1) * sizeof(long long))) != PT_OK) return rc;
+  PT_HIP_CHECK(hipMemcpyAsync(e->rec_off, off.data(), (size_t)(n_lines + 1) * sizeof(long long), hipMemcpyHostToDevice, s));
+  PT_HIP_CHECK(hipStreamSynchronize(s));
+  return PT_OK;
+}
+
+int pt_rec_cvit_preprocess_crops(pt_engine* e, const uint8_t* d_crops_rgb, const pt_rec_line* d_lines, const int64_t* h_crop_px,
+                                 int n_lines, float* d_gray, pt_stream stream) {
+  PT_REQUIRE(e && d_crops_rgb && d_lines && h_crop_px && d_gray && n_lines > 0, "pt_rec_cvit_preprocess_crops: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int rc;
+  if ((rc = cvit_crop_offsets(e, h_crop_px, n_lines, s)) != PT_OK) return rc;
+  return pt_launch_rec_resize_gray_f32(d_crops_rgb, d_lines, reinterpret_cast<const long long*>(e->rec_off), n_lines, PT_CVIT_W, d_gray, s);
+}
+
+int pt_rec_cvit_forward_crops(pt_engine* e, const uint8_t* d_crops_rgb, const pt_rec_line* d_lines, const int64_t* h_crop_px,
+                              int n_lines, int32_t* d_ids, float* d_maxlogit, pt_stream stream) {
+  PT_REQUIRE(e && d_crops_rgb && d_lines && h_crop_px && d_ids && n_lines > 0, "pt_rec_cvit_forward_crops: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int mb = cvit_microbatch();
+  const size_t per_line = (size_t)PT_REC_H * PT_CVIT_W * sizeof(float);
+  int rc;
+  if ((rc = ensure(&e->rec_gray, &e->rec_gray_cap, (size_t)(mb < n_lines ? mb : n_lines) * per_line)) != PT_OK) return rc;
+  if ((rc = cvit_crop_offsets(e, h_crop_px, n_lines, s)) != PT_OK) return rc;
+  const long long* d_off = reinterpret_cast<const long long*>(e->rec_off);
+  for (int i0 = 0; i0 < n_lines; i0 += mb) {
+    const int nb = (n_lines - i0) < mb ? (n_lines - i0) : mb;
+    rc = pt_launch_rec_resize_gray_f32(d_crops_rgb, d_lines + i0, d_off + i0, nb, PT_CVIT_W, reinterpret_cast<float*>(e->rec_gray), s);
+    if (rc != PT_OK) return rc;
+    rc = pt_cvit_forward_net(e, reinterpret_cast<const float*>(e->rec_gray), 1, nb, d_ids + (size_t)i0 * PT_CVIT_T,
+                             d_maxlogit ? d_maxlogit + (size_t)i0 * PT_CVIT_T : nullptr, s);
+    if (rc != PT_OK) return rc;
+  }
+  return PT_OK;
+}
+
+int pt_rec_cvit_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int h, int w, const pt_rec_line* d_lines,
+                        const int64_t* h_crop_px, int n_lines, int32_t* d_ids, float* d_maxlogit, pt_stream stream) {
+  PT_REQUIRE(e && d_pages_rgb && d_lines && h_crop_px && d_ids && n_lines > 0, "pt_rec_cvit_forward: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  (void)n_pages;
+  const int mb = cvit_microbatch();
+  const size_t per_line = (size_t)PT_REC_H * PT_CVIT_W * sizeof(float);
+  int rc;
+  if ((rc = ensure(&e->rec_gray, &e->rec_gray_cap, (size_t)(mb < n_lines ? mb : n_lines) * per_line)) != PT_OK) return rc;
+  for (int i0 = 0; i0 < n_lines; i0 += mb) {
+    const int nb = (n_lines - i0) < mb ? (n_lines - i0) : mb;
+    long long maxpx = 0, total = 0;
+    for (int i = 0; i < nb; ++i) {
+      const long long px = h_crop_px[i0 + i] > 0 ? h_crop_px[i0 + i] : 0;
+      total += px;
+      if (px > maxpx) maxpx = px;
+    }
+    if ((rc = ensure(&e->rec_off, &e->rec_off_cap, (size_t)(nb + 1) * sizeof(long long))) != PT_OK) return rc;
+    if ((rc = ensure(&e->rec_crops, &e->rec_crops_cap, (size_t)total * 3 + 16)) != PT_OK) return rc;
+    if ((rc = pt_launch_rec_offsets(d_lines + i0, nb, reinterpret_cast<long long*>(e->rec_off), s)) != PT_OK) return rc;
+    const long long* d_off = reinterpret_cast<const long long*>(e->rec_off);
+    if ((rc = pt_launch_rec_warp(d_pages_rgb, h, w, d_lines + i0, nb, d_off, reinterpret_cast<uint8_t*>(e->rec_crops), (int)maxpx, s)) != PT_OK)
+      return rc;
+    rc = pt_launch_rec_resize_gray_f32(reinterpret_cast<const uint8_t*>(e->rec_crops), d_lines + i0, d_off, nb, PT_CVIT_W,
+                                       reinterpret_cast<float*>(e->rec_gray), s);
+    if (rc != PT_OK) return rc;
+    rc = pt_cvit_forward_net(e, reinterpret_cast<const float*>(e->rec_gray), 1, nb, d_ids + (size_t)i0 * PT_CVIT_T,
+                             d_maxlogit ? d_maxlogit + (size_t)i0 * PT_CVIT_T : nullptr, s);
     if (rc != PT_OK) return rc;
   }
   return PT_OK;

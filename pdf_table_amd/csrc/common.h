@@ -157,7 +157,7 @@ struct ConvDesc {
   // residual
   const bf16_t* res = nullptr;
   int res_mode = 0;  // 0 none, 1 same resolution, 2 half resolution (fused nearest x2 upsample + add)
-  int relu = 0;      // activation: 0 none, 1 ReLU, 2 hardswish, 3 PReLU(slope)
+  int relu = 0;      // activation: 0 none, 1 ReLU, 2 hardswish, 3 PReLU(slope), 4 GELU (erf)
   const float* slope = nullptr;   // device pointer to the PReLU slope (relu == 3)
   int pool = 0;                   // 1: MaxPool2d(2,2), 2: MaxPool2d((2,1)), 3: (2,1) with rows -> channel groups; fused behind bias + ReLU (plain 3x3 stride-1 layers)
   const int* ylimit = nullptr;    // device int: output rows >= *ylimit are not computed (whole tiles; v1 kernel only)
@@ -264,6 +264,11 @@ int pt_launch_argmax_reduce(const float* part, long long rows, int ntiles, int* 
 // (bit-identical results: skipped columns are filled with what an all-padding line has there)
 int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, float* maxlogit, hipStream_t s,
                         const pt_rec_line* d_lines = nullptr);
+
+// gray fp32, layout 0 = chunks [3 n, 32, 300], 1 = lines [n, 32, 804]; ids int32 [n, PT_CVIT_T] (cvit_model.hip)
+int pt_cvit_forward_net(pt_engine* e, const float* gray, int layout, int n, int32_t* ids, float* maxlogit, hipStream_t s);
+int pt_launch_rec_resize_gray_f32(const uint8_t* crops, const pt_rec_line* lines, const long long* pix_off, int n_lines, int tw,
+                                  float* out, hipStream_t s);
 
 // ---- models ---------------------------------------------------------------------------------------------
 int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* prob, float* logits, hipStream_t s);

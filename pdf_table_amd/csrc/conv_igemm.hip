@@ -234,6 +234,9 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
       const float sl = p.slope[0];
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : sl * v[k];
+    } else if (EXTRAS && p.relu == 4) {   // exact GELU, x * 0.5 * (1 + erf(x / sqrt(2))): ConvNext / ViT MLPs (cvit_model.hip)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = v[k] * 0.5f * (1.f + erff(v[k] * 0.70710678118654752f));
     }
     u32x4 o, ol;
     o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
@@ -377,6 +380,9 @@ __device__ __forceinline__ void epilogue_direct_row(const ConvK& p, const f32x16
     } else if (p.relu == 3) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) v[k] = v[k] > 0.f ? v[k] : sl * v[k];
+    } else if (p.relu == 4) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = v[k] * 0.5f * (1.f + erff(v[k] * 0.70710678118654752f));
     }
     if (p.out_f32) {
       // fp32 output (network outputs, offset / mask maps): the lane's runs of four channels are 16-byte stores as they are

@@ -1,0 +1,526 @@
+// cvit_model.hip -- the ConvNextViT text-line recogniser on the engine's kernels.
+//
+// Reference graph: ConvNextViT.forward (model/convnext_vit/modeling_convnext_vit.py:38-45) = RGB -> gray, ConvNextModel
+// (model/convnext_vit/modeling_convnext.py:29-131: patch embedding 4x4/4 + LayerNorm, four ConvNextStages of depths
+// 3/3/8/3 and widths 96/192/256/512, stages 1..3 preceded by LayerNorm + a (2,1)-kernel (2,1)-stride conv; each ConvNextLayer
+// = depthwise 7x7 -> LayerNorm -> Linear(C, 4C) -> GELU -> Linear(4C, C) -> layer scale -> + residual), then ViTForSTR
+// (model/convnext_vit/modeling_vit.py:31-143: 1x1 patch projection 512 -> 192, position embeddings [1:], twelve pre-norm ViT
+// layers with 3 heads of 64, final LayerNorm, the three 75-token chunks of a line stitched to 201 tokens, Linear(192 -> 7644))
+// and the arg-max of OCRRecognitionPostProcessor (model/ocr_recognition/processor_ocr_recognition.py:147-150).
+//
+// Mapping onto kernels.  A line is three 32 x 300 chunks (processor_ocr_recognition.py:103-109); every chunk is one image of
+// the CNN and one 75-token sequence of the ViT.  The residual stream is fp32 [pixels, C] for the whole network (the reference
+// is fp32; both precision modes round only the GEMM / attention operands), token-wise work runs over ALL pixels / tokens of a
+// micro-batch of lines at once:
+//   patch embedding + LayerNorm          cvit_embed_kernel (K = 16: VALU, one wave per output pixel)
+//   depthwise 7x7 + LayerNorm            cvit_dwconv_ln_kernel (a thread owns one channel of 8 consecutive pixels of a row: 7 x 14
+//                                        loads for 8 x 49 multiply-adds; the LayerNorm of those pixels inside the workgroup)
+//   Linear C->4C + GELU, 4C->C + scale   1x1 GEMMs on conv_igemm_kernel (MFMA); the layer scale is folded into the second
+//   + residual                           GEMM's weights and bias, its epilogue adds the fp32 residual in place
+//   down-sampler                         cvit_ln_kernel writes LayerNorm(x) of rows 2y / 2y+1 side by side: the (2,1) conv is a
+//                                        1x1 GEMM with K = 2C
+//   ViT LayerNorms, chunk stitching      cvit_ln_kernel (one wave per token; mode 2 drops the overlap tokens and orders the rest)
+//   q/k/v (one 192 -> 576 GEMM, 1/8 folded into q), out, MLP      1x1 GEMMs, fp32 residual epilogue
+//   attention                            cvit_attention_kernel: one wave = 32 queries x one head, all 75 keys, on the matrix
+//                                        cores (the Lore processor's scheme, lore_processor.hip, with d = 64)
+//   classifier + arg-max                 1x1 GEMM with the arg-max epilogue + argmax_reduce_kernel: no logits in HBM
+// PT_PRECISION_BF16X3: activations [hi | lo], weights [hi | hi | lo], three MFMA passes -- as everywhere in the engine.
+#include <math.h>
+#include <stdlib.h>
+
+#include <string>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 abf16x8;
+typedef __attribute__((ext_vector_type(16))) float af32x16;
+
+constexpr int CV_T = 75;          // tokens per chunk = 300 / 4
+constexpr int CV_PIX0 = 8 * CV_T; // pixels per chunk after the patch embedding (8 rows x 75)
+
+__device__ __forceinline__ float bf2f(uint32_t b) { return __uint_as_float(b << 16); }
+__device__ __forceinline__ uint32_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ void put(bf16_t* p, int lo_off, int split, float v) {
+  const uint32_t h = f2bf(v);
+  p[0] = (bf16_t)h;
+  if (split) p[lo_off] = (bf16_t)f2bf(v - bf2f(h));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+// ConvNextEmbeddings: Conv2d(1, 96, 4, stride 4) + LayerNorm(96, eps 1e-6) (HF modeling_convnext.py ConvNextEmbeddings).
+// gray fp32; chunk c = 3 * line + j starts at gray + line * lstride + j * jstride, rows `pitch` apart.  One wave per pixel.
+__global__ __launch_bounds__(256) void cvit_embed_kernel(const float* __restrict__ gray, int pitch, long long jstride, long long lstride,
+                                                         int nchunks, const float* __restrict__ w, const float* __restrict__ b,
+                                                         const float* __restrict__ g, const float* __restrict__ beta,
+                                                         float* __restrict__ x) {
+  const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (pix >= (long long)nchunks * CV_PIX0) return;
+  const int chunk = (int)(pix / CV_PIX0), r = (int)(pix % CV_PIX0), oy = r / CV_T, ox = r % CV_T;
+  const float* src = gray + (long long)(chunk / 3) * lstride + (long long)(chunk % 3) * jstride + (size_t)(oy * 4) * pitch + ox * 4;
+  float in[16];
+#pragma unroll
+  for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 4; ++dx) in[dy * 4 + dx] = src[dy * pitch + dx];
+  const bool two = lane < 32;
+  float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    v0 += w[lane * 16 + k] * in[k];
+    if (two) v1 += w[(64 + lane) * 16 + k] * in[k];
+  }
+  v0 += b[lane];
+  if (two) v1 += b[64 + lane];
+  const float mean = wave_sum(v0 + (two ? v1 : 0.f)) / 96.f;
+  const float d0 = v0 - mean, d1 = two ? v1 - mean : 0.f;
+  const float rstd = 1.f / sqrtf(wave_sum(d0 * d0 + d1 * d1) / 96.f + 1e-6f);
+  x[pix * 96 + lane] = d0 * rstd * g[lane] + beta[lane];
+  if (two) x[pix * 96 + 64 + lane] = d1 * rstd * g[64 + lane] + beta[64 + lane];
+}
+
+// ConvNextLayer, first half: depthwise Conv2d(C, C, 7, padding 3) + LayerNorm(C, eps 1e-6) over the fp32 stream
+// x [B, H, W, C] -> bf16 [pixel][C] ([hi C | lo C] in the hi/lo mode).  grid (ceil(W / 8), H, B), block = C rounded up to
+// waves; thread c owns channel c of 8 consecutive pixels.  wt: [49][C] (tap-major: coalesced over channels).
+constexpr int CV_TX = 8;
+__global__ __launch_bounds__(512) void cvit_dwconv_ln_kernel(const float* __restrict__ x, int H, int W, int C, const float* __restrict__ wt,
+                                                             const float* __restrict__ bias, const float* __restrict__ g,
+                                                             const float* __restrict__ beta, bf16_t* __restrict__ out, int split) {
+  __shared__ float red[8][CV_TX];
+  const int c = threadIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int x0 = blockIdx.x * CV_TX, y = blockIdx.y, b = blockIdx.z;
+  const bool active = c < C;
+  float acc[CV_TX];
+#pragma unroll
+  for (int j = 0; j < CV_TX; ++j) acc[j] = 0.f;
+  if (active) {
+    for (int dy = 0; dy < 7; ++dy) {
+      const int iy = y + dy - 3;
+      if (iy < 0 || iy >= H) continue;
+      float wv[7];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) wv[k] = wt[(dy * 7 + k) * C + c];
+      const float* row = x + ((size_t)b * H + iy) * W * C + c;
+#pragma unroll
+      for (int dx = 0; dx < CV_TX + 6; ++dx) {
+        const int ix = x0 + dx - 3;
+        const float v = (ix >= 0 && ix < W) ? row[(size_t)ix * C] : 0.f;
+#pragma unroll
+        for (int j = 0; j < CV_TX; ++j) {
+          const int k = dx - j;
+          if (k >= 0 && k < 7) acc[j] += wv[k] * v;
+        }
+      }
+    }
+    const float bb = bias[c];
+#pragma unroll
+    for (int j = 0; j < CV_TX; ++j) acc[j] += bb;
+  }
+  // LayerNorm over the C channels of each of the 8 pixels: two passes (mean, then squared deviations), fp32
+  float mean[CV_TX], rstd[CV_TX];
+#pragma unroll
+  for (int j = 0; j < CV_TX; ++j) {
+    const float s = wave_sum(active ? acc[j] : 0.f);
+    if (lane == 0) red[wave][j] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < CV_TX; ++j) {
+    float s = 0.f;
+    for (int k = 0; k < nw; ++k) s += red[k][j];
+    mean[j] = s / (float)C;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < CV_TX; ++j) {
+    const float d = active ? acc[j] - mean[j] : 0.f;
+    const float s = wave_sum(d * d);
+    if (lane == 0) red[wave][j] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < CV_TX; ++j) {
+    float s = 0.f;
+    for (int k = 0; k < nw; ++k) s += red[k][j];
+    rstd[j] = 1.f / sqrtf(s / (float)C + 1e-6f);
+  }
+  if (!active) return;
+  const float gg = g[c], be = beta[c];
+  const int mul = split ? 2 : 1;
+#pragma unroll
+  for (int j = 0; j < CV_TX; ++j) {
+    if (x0 + j >= W) break;
+    const size_t pix = ((size_t)b * H + y) * W + x0 + j;
+    put(out + pix * C * mul + c, C, split, (acc[j] - mean[j]) * rstd[j] * gg + be);
+  }
+}
+
+// LayerNorm (biased variance, eps inside the root: nn.LayerNorm) of fp32 rows [rows, C], C <= 512 -> bf16 (hi | lo).  One wave
+// per row.  g == null: conversion only.
+//   mode 0: out row = row
+//   mode 1: ConvNextStage down-sampler input: row = (b, y, x) of a [B, H, W] map goes to row (b, y / 2, x) of a [B, H/2, W]
+//           map with 2C channels, at channel offset (y & 1) * C -- the K layout of the (2,1)-kernel conv as a 1x1 GEMM
+//   mode 2: chunk stitching (modeling_vit.py:133-138): row = (chunk = 3 line + j, t); kept tokens go to row line * 201 + pos
+__global__ __launch_bounds__(256) void cvit_ln_kernel(const float* __restrict__ x, long long rows, int C, const float* __restrict__ g,
+                                                      const float* __restrict__ beta, float eps, bf16_t* __restrict__ out, int split,
+                                                      int mode, int H, int W) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  long long orow = row;
+  int ocs = C, coff = 0;
+  if (mode == 1) {
+    const int xx = (int)(row % W);
+    const long long t = row / W;
+    const int y = (int)(t % H);
+    const long long b = t / H;
+    orow = (b * (H >> 1) + (y >> 1)) * W + xx;
+    ocs = 2 * C;
+    coff = (y & 1) * C;
+  } else if (mode == 2) {
+    const long long chunk = row / CV_T;
+    const int t = (int)(row % CV_T), j = (int)(chunk % 3);
+    int pos;
+    if (j == 0) { if (t >= 69) return; pos = t; }
+    else if (j == 1) { if (t < 6 || t >= 69) return; pos = 69 + t - 6; }
+    else { if (t < 6) return; pos = 132 + t - 6; }
+    orow = (chunk / 3) * 201 + pos;
+  }
+  float v[8];
+  const int nk = (C + 63) >> 6;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = lane + 64 * k;
+    v[k] = (k < nk && c < C) ? x[row * C + c] : 0.f;
+    s += v[k];
+  }
+  float mean = 0.f, rstd = 1.f;
+  if (g) {
+    mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = lane + 64 * k;
+      const float d = (k < nk && c < C) ? v[k] - mean : 0.f;
+      q += d * d;
+    }
+    rstd = 1.f / sqrtf(wave_sum(q) / (float)C + eps);
+  }
+  bf16_t* op = out + orow * ocs * (split ? 2 : 1) + coff;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = lane + 64 * k;
+    if (k < nk && c < C) put(op + c, ocs, split, g ? (v[k] - mean) * rstd * g[c] + beta[c] : v[k]);
+  }
+}
+
+// x[row, c] += pos[row % 75, c]: embeddings + position_embeddings[:, 1:, :] (modeling_vit.py:78-79)
+__global__ __launch_bounds__(256) void cvit_add_pos_kernel(float* __restrict__ x, const float* __restrict__ pos, long long total, int C) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long long row = i / C;
+  x[i] += pos[(row % CV_T) * C + (i % C)];
+}
+
+// ViT self-attention for one head (d = 64) and 32 queries of one 75-token chunk: one wave, on the matrix cores.
+// qkv [tokens, 576] = [q | k | v] (hi/lo: [hi 576 | lo 576]), q already carries the 1/sqrt(64); out [tokens, 192].
+//   S^T (32 keys x 32 queries) = K_tile Q^T over d = 64: four v_mfma_f32_32x32x16_bf16.  In the D layout a lane owns ONE
+//   query and 16 of the 32 keys: the online soft-max is in-lane plus one exchange with lane ^ 32.
+//   O^T (64 d x 32 queries) += V^T P^T as two 32-row blocks; P is the B operand exactly as the lane holds it (keys in the D
+//   layout's own order), V is gathered in that key order.  Hi/lo mode: three passes each, fp32 soft-max.
+__device__ __forceinline__ abf16x8 ld8(const bf16_t* p) { return *reinterpret_cast<const abf16x8*>(p); }
+
+template <int SPLIT>
+__global__ __launch_bounds__(64) void cvit_attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out) {
+  const int q0 = blockIdx.x * 32, head = blockIdx.y, lane = threadIdx.x;
+  const long long tok0 = (long long)blockIdx.z * CV_T;
+  constexpr int E = 192, LO = 3 * E, cs = SPLIT ? 2 * LO : LO;
+  const int col = lane & 31, half = lane >> 5;
+  const int qi = q0 + col;
+  const bf16_t* qrow = qkv + (size_t)(tok0 + (qi < CV_T ? qi : CV_T - 1)) * cs + head * 64 + half * 8;
+  abf16x8 qh[4], ql[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    qh[s] = ld8(qrow + 16 * s);
+    if (SPLIT) ql[s] = ld8(qrow + LO + 16 * s);
+  }
+  af32x16 acc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+  float m = -INFINITY, l = 0.f;
+  for (int k0 = 0; k0 < CV_T; k0 += 32) {
+    const int krow = k0 + col;
+    const bf16_t* kp = qkv + (size_t)(tok0 + (krow < CV_T ? krow : CV_T - 1)) * cs + E + head * 64 + half * 8;
+    af32x16 sc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const abf16x8 kh = ld8(kp + 16 * s);
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[s], sc, 0, 0, 0);
+      if (SPLIT) {
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[s], sc, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(kp + LO + 16 * s), qh[s], sc, 0, 0, 0);
+      }
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (key >= CV_T) sc[r] = -INFINITY;
+      mt = fmaxf(mt, sc[r]);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    const float mn = fmaxf(m, mt);
+    const float scale = expf(m - mn);
+    float p[16], lt = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { p[r] = expf(sc[r] - mn); lt += p[r]; }
+    lt += __shfl_xor(lt, 32);
+    l = l * scale + lt;
+    m = mn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] *= scale; acc[1][r] *= scale; }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      abf16x8 ph, pl;
+      int keys[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float pv = p[8 * s2 + j];
+        const uint32_t hb = f2bf(pv);
+        ph[j] = __builtin_bit_cast(__bf16, (uint16_t)hb);
+        if (SPLIT) pl[j] = __builtin_bit_cast(__bf16, (uint16_t)f2bf(pv - bf2f(hb)));
+        const int key = k0 + (j & 3) + 8 * (2 * s2 + (j >> 2)) + 4 * half;
+        keys[j] = key < CV_T ? key : CV_T - 1;              // its probability is exactly 0
+      }
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        abf16x8 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bf16_t* vp = qkv + (size_t)(tok0 + keys[j]) * cs + 2 * E + head * 64 + db * 32 + col;     // A row = d
+          vh[j] = __builtin_bit_cast(__bf16, vp[0]);
+          if (SPLIT) vl[j] = __builtin_bit_cast(__bf16, vp[LO]);
+        }
+        acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, acc[db], 0, 0, 0);
+        if (SPLIT) {
+          acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, acc[db], 0, 0, 0);
+          acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, acc[db], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (qi < CV_T) {
+    bf16_t* op = out + (size_t)(tok0 + qi) * (SPLIT ? 2 * E : E) + head * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) put(op + db * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, E, SPLIT, acc[db][r] / l);
+  }
+}
+
+struct Net {
+  pt_engine* e;
+  const PtModel* m;
+  hipStream_t s;
+  int x3, mul, rc;
+  const PtTensor* get(const std::string& n) {
+    const PtTensor* t = m->find(n);
+    if (!t && rc == PT_OK) {
+      pt_set_error("ConvNextViT weight blob lacks tensor '%s'", n.c_str());
+      rc = PT_ERR_FORMAT;
+    }
+    return t;
+  }
+  const float* f32(const std::string& n) {
+    const PtTensor* t = get(n);
+    return t ? reinterpret_cast<const float*>(t->d_ptr) : nullptr;
+  }
+  // y = x W^T + b over `rows` (padded to 128) rows: x bf16 [rows, cin] -> bf16 [rows, N] (act: 0 none, 4 GELU), or the fp32
+  // stream [rows, f32_cs] (+ fp32 residual `res`, in place when res == out_f32); nv: real output channels when N is padded
+  void gemm(const bf16_t* x, long long rows, int cin, const std::string& q, int N, int act, bf16_t* out, float* out_f32 = nullptr,
+            int f32_cs = 0, const float* res = nullptr, int nv = 0, float* argmax_part = nullptr) {
+    const PtTensor* w = get(q + (x3 ? ".w3" : ".w"));
+    const PtTensor* b = get(q + ".b");
+    if (rc != PT_OK) return;
+    ConvDesc c;
+    c.in = x; c.B = 1; c.H = (int)(rows / 32); c.W = 32; c.Cin = cin;
+    c.w = reinterpret_cast<const bf16_t*>(w->d_ptr); c.bias = reinterpret_cast<const float*>(b->d_ptr);
+    c.N = N; c.ks = 1; c.stride = 1; c.relu = act; c.split = x3; c.n_valid = nv;
+    if (argmax_part) {
+      c.argmax_part = argmax_part;
+    } else if (out_f32) {
+      c.out_f32 = out_f32; c.out_cstride = f32_cs; c.res_f32 = res;
+    } else {
+      c.out = out; c.out_cstride = N * mul; c.out_coff = 0; c.out_lo_off = N;
+    }
+    const int r = pt_launch_conv(e, c, s);
+    if (r != PT_OK) rc = r;
+  }
+};
+
+inline long long pad128(long long r) { return (r + 127) / 128 * 128; }
+
+// lines [0, n) of one micro-batch
+int forward_batch(pt_engine* e, const PtModel& M, const float* gray, int pitch, long long jstride, long long lstride, int n, int32_t* ids,
+                  float* maxlogit, hipStream_t s) {
+  Net p;
+  p.e = e; p.m = &M; p.s = s; p.rc = PT_OK;
+  p.x3 = e->precision == PT_PRECISION_BF16X3 ? 1 : 0;
+  p.mul = p.x3 ? 2 : 1;
+  const int x3 = p.x3, mul = p.mul, nchunks = 3 * n, NT = 7680 / 64;
+  static const int DEPTH[4] = {3, 3, 8, 3}, DIM[4] = {96, 192, 256, 512};
+  const long long rows_cls = pad128((long long)n * 201), Tpad = pad128((long long)nchunks * CV_T);
+  // the stream / its bf16 image / the MLP hidden layer are reused by every stage: size them for the widest (rows are padded
+  // to 128 per stage, so a later, shorter stage can be the larger one)
+  long long xel = Tpad * 192;
+  for (int st = 0; st < 4; ++st) {
+    const long long el = pad128((long long)nchunks * (CV_PIX0 >> st)) * DIM[st];
+    if (el > xel) xel = el;
+  }
+  float* x = nullptr;
+  bf16_t *xb = nullptr, *hb = nullptr, *qkv = nullptr, *att = nullptr, *feat = nullptr;
+  float* part = nullptr;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    PtArena& A = e->arenas[PT_ARENA_REC];
+    A.reset();
+    bool ok = true;
+    auto take = [&](size_t bytes) { void* q = A.take(bytes); if (!q) ok = false; return q; };
+    x = reinterpret_cast<float*>(take((size_t)(xel + 128) * sizeof(float)));      // + 128: the padded-N epilogue reads up to 32 floats
+    xb = reinterpret_cast<bf16_t*>(take((size_t)xel * mul * sizeof(bf16_t)));      //   past the last 96-wide row
+    hb = reinterpret_cast<bf16_t*>(take((size_t)xel * 4 * mul * sizeof(bf16_t)));
+    qkv = reinterpret_cast<bf16_t*>(take((size_t)Tpad * 576 * mul * sizeof(bf16_t)));
+    att = reinterpret_cast<bf16_t*>(take((size_t)Tpad * 192 * mul * sizeof(bf16_t)));
+    feat = reinterpret_cast<bf16_t*>(take((size_t)rows_cls * 192 * mul * sizeof(bf16_t)));
+    part = reinterpret_cast<float*>(take((size_t)rows_cls * NT * 2 * sizeof(float)));
+    if (ok) break;
+    if (attempt == 1) {
+      pt_set_error("activation arena allocation failed");
+      return PT_ERR_HIP;
+    }
+    PT_HIP_CHECK(hipDeviceSynchronize());
+    if (A.base) PT_HIP_CHECK(hipFree(A.base));
+    A.base = nullptr;
+    const size_t want = A.high + (1u << 20);
+    PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&A.base), want));
+    A.cap = want;
+  }
+  // rows past the real ones are never written by the row kernels: clear once so that no NaN bit pattern reaches a GEMM
+  PT_HIP_CHECK(hipMemsetAsync(x, 0, (size_t)(xel + 128) * sizeof(float), s));
+  PT_HIP_CHECK(hipMemsetAsync(xb, 0, (size_t)xel * mul * sizeof(bf16_t), s));
+  PT_HIP_CHECK(hipMemsetAsync(att, 0, (size_t)Tpad * 192 * mul * sizeof(bf16_t), s));
+  PT_HIP_CHECK(hipMemsetAsync(feat, 0, (size_t)rows_cls * 192 * mul * sizeof(bf16_t), s));
+  {
+    const float *w = p.f32("embed.w"), *b = p.f32("embed.b"), *g = p.f32("embed.ln.g"), *be = p.f32("embed.ln.b");
+    if (p.rc != PT_OK) return p.rc;
+    PtProfScope ps(e, s, PT_PROF_OTHER, 0, "cvit embed");
+    const long long pix = (long long)nchunks * CV_PIX0;
+    hipLaunchKernelGGL(cvit_embed_kernel, dim3((unsigned)((pix + 3) / 4)), dim3(256), 0, s, gray, pitch, jstride, lstride, nchunks, w, b, g, be, x);
+  }
+  auto ln = [&](const std::string& q, long long rows, int C, float eps, bf16_t* out, int mode, int H, int W) {
+    const float* g = q.empty() ? nullptr : p.f32(q + ".g");
+    const float* be = q.empty() ? nullptr : p.f32(q + ".b");
+    if (p.rc != PT_OK) return;
+    PtProfScope ps(e, s, PT_PROF_OTHER, 0, "cvit layernorm");
+    hipLaunchKernelGGL(cvit_ln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, C, g, be, eps, out, x3, mode, H, W);
+  };
+  int H = 8;
+  for (int st = 0; st < 4; ++st) {
+    const int C = DIM[st];
+    const std::string sq = "s" + std::to_string(st);
+    if (st > 0) {
+      const int Cp = DIM[st - 1];
+      ln(sq + ".down.ln", (long long)nchunks * H * CV_T, Cp, 1e-6f, xb, 1, H, CV_T);
+      H >>= 1;
+      p.gemm(xb, pad128((long long)nchunks * H * CV_T), 2 * Cp, sq + ".down", C, 0, nullptr, x, C);
+    }
+    const long long rows = (long long)nchunks * H * CV_T, rp = pad128(rows);
+    const int Np = (C + 63) / 64 * 64;
+    for (int l = 0; l < DEPTH[st]; ++l) {
+      const std::string lq = sq + ".l" + std::to_string(l);
+      const float *w = p.f32(lq + ".dw.w"), *b = p.f32(lq + ".dw.b"), *g = p.f32(lq + ".ln.g"), *be = p.f32(lq + ".ln.b");
+      if (p.rc != PT_OK) return p.rc;
+      {
+        PtProfScope ps(e, s, PT_PROF_OTHER, 0, "cvit dwconv7+ln");
+        hipLaunchKernelGGL(cvit_dwconv_ln_kernel, dim3((CV_T + CV_TX - 1) / CV_TX, H, nchunks), dim3((C + 63) / 64 * 64), 0, s, x, H, CV_T, C,
+                           w, b, g, be, xb, x3);
+      }
+      p.gemm(xb, rp, C, lq + ".pw1", 4 * C, 4, hb);
+      p.gemm(hb, rp, 4 * C, lq + ".pw2", Np, 0, nullptr, x, C, x, Np != C ? C : 0);
+      if (p.rc != PT_OK) return p.rc;
+    }
+  }
+  // ---- ViT over [nchunks * 75, 192]; the CNN's last_hidden_state is the raw stream (modeling_convnext.py:117,127)
+  const long long T = (long long)nchunks * CV_T, Tp = Tpad;
+  ln("", T, 512, 0.f, xb, 0, 1, 1);
+  p.gemm(xb, Tp, 512, "vit.embed", 192, 0, nullptr, x, 192);
+  {
+    const float* pos = p.f32("vit.pos");
+    if (p.rc != PT_OK) return p.rc;
+    PtProfScope ps(e, s, PT_PROF_OTHER, 0, "cvit add pos");
+    hipLaunchKernelGGL(cvit_add_pos_kernel, dim3((unsigned)((T * 192 + 255) / 256)), dim3(256), 0, s, x, pos, T * 192, 192);
+  }
+  for (int l = 0; l < 12; ++l) {
+    const std::string lq = "vit.l" + std::to_string(l);
+    ln(lq + ".ln1", T, 192, 1e-12f, xb, 0, 1, 1);
+    p.gemm(xb, Tp, 192, lq + ".qkv", 576, 0, qkv);
+    if (p.rc != PT_OK) return p.rc;
+    {
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0, "cvit attention");
+      if (x3) hipLaunchKernelGGL(cvit_attention_kernel<1>, dim3(3, 3, nchunks), dim3(64), 0, s, qkv, att);
+      else hipLaunchKernelGGL(cvit_attention_kernel<0>, dim3(3, 3, nchunks), dim3(64), 0, s, qkv, att);
+    }
+    p.gemm(att, Tp, 192, lq + ".out", 192, 0, nullptr, x, 192, x);
+    ln(lq + ".ln2", T, 192, 1e-12f, xb, 0, 1, 1);
+    p.gemm(xb, Tp, 192, lq + ".fc1", 768, 4, hb);
+    p.gemm(hb, Tp, 768, lq + ".fc2", 192, 0, nullptr, x, 192, x);
+    if (p.rc != PT_OK) return p.rc;
+  }
+  ln("vit.ln", T, 192, 1e-12f, feat, 2, 1, 1);
+  p.gemm(feat, rows_cls, 192, "cls", 7680, 0, nullptr, nullptr, 0, nullptr, 0, part);
+  if (p.rc != PT_OK) return p.rc;
+  PT_HIP_CHECK(hipGetLastError());
+  PtProfScope ps(e, s, PT_PROF_OTHER, 0, "argmax");
+  return pt_launch_argmax_reduce(part, (long long)n * 201, NT, ids, maxlogit, s);
+}
+
+}  // namespace
+
+// gray fp32: layout 0 = chunks [3 n, 32, 300] (what the reference's model receives), 1 = lines [n, 32, 804] (what its
+// pre-processor cuts the chunks from: chunk j = columns [252 j, 252 j + 300))
+int pt_cvit_forward_net(pt_engine* e, const float* gray, int layout, int n, int32_t* ids, float* maxlogit, hipStream_t s) {
+  PT_REQUIRE(e && gray && ids && n > 0 && (layout == 0 || layout == 1), "convnext-vit: bad arguments");
+  auto it = e->models.find(PT_MODEL_CONVNEXT_VIT);
+  if (it == e->models.end()) {
+    pt_set_error("ConvNextViT weights not loaded (pt_weights_load(PT_MODEL_CONVNEXT_VIT))");
+    return PT_ERR_STATE;
+  }
+  static int mb = -1;
+  if (mb < 0) {
+    const char* ev = getenv("PT_CVIT_MICROBATCH");
+    mb = ev ? atoi(ev) : 512;
+    if (mb < 1) mb = 1;
+  }
+  const int pitch = layout ? PT_CVIT_W : PT_CVIT_CHUNK_W;
+  const long long jstride = layout ? PT_CVIT_CHUNK_STEP : (long long)PT_REC_H * PT_CVIT_CHUNK_W;
+  const long long lstride = layout ? (long long)PT_REC_H * PT_CVIT_W : 3ll * PT_REC_H * PT_CVIT_CHUNK_W;
+  for (int i0 = 0; i0 < n; i0 += mb) {
+    const int nb = (n - i0) < mb ? (n - i0) : mb;
+    const int rc = forward_batch(e, it->second, gray + (long long)i0 * lstride, pitch, jstride, lstride, nb, ids + (size_t)i0 * PT_CVIT_T,
+                                 maxlogit ? maxlogit + (size_t)i0 * PT_CVIT_T : nullptr, s);
+    if (rc != PT_OK) return rc;
+  }
+  return PT_OK;
+}

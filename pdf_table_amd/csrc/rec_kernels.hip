@@ -142,7 +142,8 @@ __device__ __forceinline__ RCoef rcoef(int d, double scale, int ssize, bool clam
 __global__ __launch_bounds__(256) void rec_resize_gray_kernel(const uint8_t* __restrict__ crops,
                                                                const pt_rec_line* __restrict__ lines,
                                                                const long long* __restrict__ pix_off, int n_lines, int TH,
-                                                               int TWID, int split, bf16_t* __restrict__ out) {
+                                                               int TWID, int split, bf16_t* __restrict__ out,
+                                                               float* __restrict__ out_f32) {
   const long long total = (long long)n_lines * TH * TWID;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int x = (int)(i % TWID);
@@ -183,6 +184,10 @@ __global__ __launch_bounds__(256) void rec_resize_gray_kernel(const uint8_t* __r
         gray = (R * 0.2989f + G * 0.5870f) + B * 0.1140f;  // modeling_crnn.py:94, left-to-right
       }
     }
+    if (out_f32) {                 // ConvNextViT (fp32 stream from the first layer on, cvit_model.hip)
+      out_f32[i] = gray;
+      continue;
+    }
     const uint32_t hb = rf2bf(gray);
     if (split) {
       out[i * 2] = (bf16_t)hb;
@@ -199,7 +204,21 @@ int pt_launch_rec_resize_gray(const uint8_t* crops, const pt_rec_line* lines, co
   const long long total = (long long)n_lines * 32 * 640;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL(rec_resize_gray_kernel, dim3(blocks), dim3(256), 0, s, crops, lines, pix_off, n_lines, 32, 640, split, out);
+  hipLaunchKernelGGL(rec_resize_gray_kernel, dim3(blocks), dim3(256), 0, s, crops, lines, pix_off, n_lines, 32, 640, split, out,
+                     static_cast<float*>(nullptr));
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// the same resize to 32 x tw (804 for the chunking ConvNextViT pre-processor, processor_ocr_recognition.py:38-62) as fp32 gray
+int pt_launch_rec_resize_gray_f32(const uint8_t* crops, const pt_rec_line* lines, const long long* pix_off, int n_lines, int tw,
+                                  float* out, hipStream_t s) {
+  if (n_lines <= 0) return PT_OK;
+  const long long total = (long long)n_lines * 32 * tw;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(rec_resize_gray_kernel, dim3(blocks), dim3(256), 0, s, crops, lines, pix_off, n_lines, 32, tw, 0,
+                     static_cast<bf16_t*>(nullptr), out);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }

@@ -432,6 +432,62 @@ class HipEngine:
                 "pt_rec_forward_net")
         return ids, mx
 
+    # ---- ConvNextViT recogniser ---------------------------------------------------------------
+    def _crops_to_device(self, crops: Sequence[np.ndarray]):
+        nl = len(crops)
+        lines = np.zeros(nl, dtype=REC_LINE_DTYPE)
+        lines["crop_w"] = [c.shape[1] for c in crops]
+        lines["crop_h"] = [c.shape[0] for c in crops]
+        flat = np.concatenate([np.ascontiguousarray(c[:, :, :3], dtype=np.uint8).reshape(-1) for c in crops])
+        d, px = self._lines_to_device(lines)
+        return d, px, torch.from_numpy(flat).to(self._tdev)
+
+    def rec_cvit_forward(self, pages: torch.Tensor, lines: np.ndarray):
+        """pages uint8 [n,h,w,3] on the GPU, lines: REC_LINE_DTYPE records -> (ids int32 [L,201], maxlogit f32 [L,201])."""
+        self._chk(pages, torch.uint8, "pages")
+        n, h, w, _ = pages.shape
+        nl = len(lines)
+        ids = torch.empty((nl, L.PT_CVIT_T), dtype=torch.int32, device=self._tdev)
+        mx = torch.empty((nl, L.PT_CVIT_T), dtype=torch.float32, device=self._tdev)
+        if nl:
+            d, px = self._lines_to_device(lines)
+            L.check(self.lib.pt_rec_cvit_forward(self._h, _ptr(pages), n, h, w, _ptr(d), px.ctypes.data_as(C.c_void_p), nl,
+                                                 _ptr(ids), _ptr(mx), self._stream()), "pt_rec_cvit_forward")
+        return ids, mx
+
+    def rec_cvit_forward_crops(self, crops: Sequence[np.ndarray]):
+        """already-cropped RGB uint8 images (any sizes) -> (ids int32 [L,201], maxlogit f32 [L,201])."""
+        nl = len(crops)
+        ids = torch.empty((nl, L.PT_CVIT_T), dtype=torch.int32, device=self._tdev)
+        mx = torch.empty((nl, L.PT_CVIT_T), dtype=torch.float32, device=self._tdev)
+        if nl:
+            d, px, dc = self._crops_to_device(crops)
+            L.check(self.lib.pt_rec_cvit_forward_crops(self._h, _ptr(dc), _ptr(d), px.ctypes.data_as(C.c_void_p), nl, _ptr(ids),
+                                                       _ptr(mx), self._stream()), "pt_rec_cvit_forward_crops")
+        return ids, mx
+
+    def rec_cvit_preprocess_crops(self, crops: Sequence[np.ndarray]) -> torch.Tensor:
+        """keep-ratio resize to 32 x 804 + gray of already-cropped lines -> fp32 [L,32,804]."""
+        nl = len(crops)
+        gray = torch.empty((nl, L.PT_REC_H, L.PT_CVIT_W), dtype=torch.float32, device=self._tdev)
+        d, px, dc = self._crops_to_device(crops)
+        L.check(self.lib.pt_rec_cvit_preprocess_crops(self._h, _ptr(dc), _ptr(d), px.ctypes.data_as(C.c_void_p), nl, _ptr(gray),
+                                                      self._stream()), "pt_rec_cvit_preprocess_crops")
+        return gray
+
+    def rec_cvit_forward_net(self, gray: torch.Tensor):
+        """gray fp32 [3n,32,300] (chunks) or [n,32,804] (lines) -> (ids int32 [n,201], maxlogit f32 [n,201])."""
+        self._chk(gray, torch.float32, "gray")
+        assert gray.dim() == 3 and gray.shape[1] == L.PT_REC_H and gray.shape[2] in (L.PT_CVIT_CHUNK_W, L.PT_CVIT_W)
+        layout = 1 if gray.shape[2] == L.PT_CVIT_W else 0
+        assert layout == 1 or gray.shape[0] % 3 == 0, "three chunks per line"
+        n = gray.shape[0] if layout else gray.shape[0] // 3
+        ids = torch.empty((n, L.PT_CVIT_T), dtype=torch.int32, device=self._tdev)
+        mx = torch.empty((n, L.PT_CVIT_T), dtype=torch.float32, device=self._tdev)
+        L.check(self.lib.pt_rec_cvit_forward_net(self._h, _ptr(gray), layout, n, _ptr(ids), _ptr(mx), self._stream()),
+                "pt_rec_cvit_forward_net")
+        return ids, mx
+
     def op_conv2d(self, x: torch.Tensor, w_tiled: torch.Tensor, bias: torch.Tensor, ks: int, stride: int = 1,
                   relu: bool = False, res: Optional[torch.Tensor] = None, res_mode: int = 0, rep: int = 1,
                   shuffle_cout: int = 0, out: Optional[torch.Tensor] = None, out_coff: int = 0,

@@ -29,7 +29,7 @@ import torch
 BN_EPS = 1e-5
 _DT = {"bf16": 0, "f32": 1, "i32": 2}
 
-__all__ = ["pack_db_resnet18", "pack_crnn", "pack_lore_dla34", "pack_lore_processor", "pack_picodet", "pack_lore_wireless", "pack_db_nas", "pack_pplcnet", "write_blob", "fold_conv_bn", "to_bf16_bits"]
+__all__ = ["pack_db_resnet18", "pack_crnn", "pack_lore_dla34", "pack_lore_processor", "pack_picodet", "pack_lore_wireless", "pack_db_nas", "pack_pplcnet", "pack_convnext_vit", "write_blob", "fold_conv_bn", "to_bf16_bits"]
 
 
 def to_bf16_bits(t: torch.Tensor) -> np.ndarray:
@@ -613,4 +613,101 @@ def pack_pplcnet(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
     assert ncls <= 16, "the classifier head stores 16 logits per image"
     bl.add_conv("fc", *_pad_conv(wf.reshape(ncls, -1, 1, 1), sd["fc.bias"].float(), 64, wf.shape[1]))
     bl.add("fc.nclass", np.zeros(ncls, dtype=np.float32), "f32")
+    return bl.tobytes()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# ConvNextViT recogniser (convnext_vit/modeling_convnext_vit.py:20-45; kernels: csrc/cvit_model.hip)
+# --------------------------------------------------------------------------------------------------------------------
+_CVIT_V5_TO_V4 = [
+    (r"vit\.layers\.(\d+)\.attention\.q_proj\.", r"vit.encoder.layer.\1.attention.attention.query."),
+    (r"vit\.layers\.(\d+)\.attention\.k_proj\.", r"vit.encoder.layer.\1.attention.attention.key."),
+    (r"vit\.layers\.(\d+)\.attention\.v_proj\.", r"vit.encoder.layer.\1.attention.attention.value."),
+    (r"vit\.layers\.(\d+)\.attention\.o_proj\.", r"vit.encoder.layer.\1.attention.output.dense."),
+    (r"vit\.layers\.(\d+)\.mlp\.fc1\.", r"vit.encoder.layer.\1.intermediate.dense."),
+    (r"vit\.layers\.(\d+)\.mlp\.fc2\.", r"vit.encoder.layer.\1.output.dense."),
+    (r"vit\.layers\.(\d+)\.layernorm_", r"vit.encoder.layer.\1.layernorm_"),
+]
+
+
+def pack_convnext_vit(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
+    """``ConvNextViT`` state_dict -> blob for PT_MODEL_CONVNEXT_VIT.  Key names of the reference's checkpoint era
+    (transformers 4.x, ``vitstr.vit.encoder.layer.N.attention.attention.query`` ...) or of transformers 5.x
+    (``vitstr.vit.layers.N.attention.q_proj`` ...), with or without the ``recognizer.`` / ``module.`` prefixes
+    (modeling_ocr_recognition.py:108-111).
+
+    Patch embedding and depthwise 7x7 weights stay fp32 (VALU kernels; taps-major ``[49][C]``); every Linear is a 1x1 GEMM
+    tile set; ``layer_scale_parameter`` is folded into ``pwconv2`` (scale * (W h + b) = (scale W) h + scale b, in fp64); the
+    (2,1)-kernel down-sampling convs become GEMMs over K = row * Cin + c; q/k/v are one 192 -> 576 GEMM with the attention's
+    1/sqrt(64) folded into q (a power of two: exact); position embeddings without the class-token slot; the classifier is
+    padded from 7644 to 7680 classes with a -3e38 bias."""
+    import re
+    csd = {}
+    for k, v in sd.items():
+        k = k.replace("recognizer.", "").replace("module.", "")
+        for pat, rep in _CVIT_V5_TO_V4:
+            k = re.sub(pat, rep, k)
+        csd[k] = v.detach().float()
+    sd = csd
+    bl = _Blob(x3)
+
+    def f32(name, t):
+        bl.add(name, t.contiguous().numpy().astype(np.float32), "f32")
+
+    def ln(name, key):
+        f32(name + ".g", sd[key + ".weight"])
+        f32(name + ".b", sd[key + ".bias"])
+
+    def lin(name, w, b, n_to=None):
+        n_to = n_to or w.shape[0]
+        bl.add_conv(name, *_pad_conv(w.reshape(w.shape[0], w.shape[1], 1, 1), b, n_to, w.shape[1]))
+
+    p = "cnn_model."
+    f32("embed.w", sd[p + "embeddings.patch_embeddings.weight"].reshape(96, 16))
+    f32("embed.b", sd[p + "embeddings.patch_embeddings.bias"])
+    ln("embed.ln", p + "embeddings.layernorm")
+    dims, depths = (96, 192, 256, 512), (3, 3, 8, 3)
+    for i, (d, dep) in enumerate(zip(dims, depths)):
+        q = f"{p}encoder.stages.{i}."
+        if i > 0:
+            ln(f"s{i}.down.ln", q + "downsampling_layer.0")
+            w = sd[q + "downsampling_layer.1.weight"]                       # [N, Cin, 2, 1]
+            lin(f"s{i}.down", w[:, :, :, 0].permute(0, 2, 1).reshape(d, 2 * dims[i - 1]), sd[q + "downsampling_layer.1.bias"])
+        for j in range(dep):
+            lq, o = f"{q}layers.{j}.", f"s{i}.l{j}"
+            f32(o + ".dw.w", sd[lq + "dwconv.weight"].reshape(d, 49).t())   # [49][C]
+            f32(o + ".dw.b", sd[lq + "dwconv.bias"])
+            ln(o + ".ln", lq + "layernorm")
+            lin(o + ".pw1", sd[lq + "pwconv1.weight"], sd[lq + "pwconv1.bias"])
+            g = sd[lq + "layer_scale_parameter"].double() if (lq + "layer_scale_parameter") in sd else torch.ones(d, dtype=torch.float64)
+            lin(o + ".pw2", (sd[lq + "pwconv2.weight"].double() * g[:, None]).float(), (sd[lq + "pwconv2.bias"].double() * g).float(),
+                n_to=(d + 63) // 64 * 64)
+    p = "vitstr.vit."
+    lin("vit.embed", sd[p + "embeddings.patch_embeddings.projection.weight"].reshape(192, 512), sd[p + "embeddings.patch_embeddings.projection.bias"])
+    f32("vit.pos", sd[p + "embeddings.position_embeddings"][0, 1:, :])
+    n = 0
+    while f"{p}encoder.layer.{n}.layernorm_before.weight" in sd:
+        q, o = f"{p}encoder.layer.{n}.", f"vit.l{n}"
+        ln(o + ".ln1", q + "layernorm_before")
+        ln(o + ".ln2", q + "layernorm_after")
+        a = q + "attention.attention."
+        wq = torch.cat([sd[a + "query.weight"] * 0.125, sd[a + "key.weight"], sd[a + "value.weight"]], 0)
+        bq = torch.cat([sd[a + "query.bias"] * 0.125, sd[a + "key.bias"], sd[a + "value.bias"]], 0)
+        lin(o + ".qkv", wq, bq)
+        lin(o + ".out", sd[q + "attention.output.dense.weight"], sd[q + "attention.output.dense.bias"])
+        lin(o + ".fc1", sd[q + "intermediate.dense.weight"], sd[q + "intermediate.dense.bias"])
+        lin(o + ".fc2", sd[q + "output.dense.weight"], sd[q + "output.dense.bias"])
+        n += 1
+    assert n == 12, f"ConvNextViT: {n} ViT layers in the checkpoint, the launch graph runs 12 (modeling_convnext_vit.py:28-35)"
+    ln("vit.ln", p + "layernorm")
+    wc, bc = sd["vitstr.classifier.weight"], sd["vitstr.classifier.bias"]
+    ncls = wc.shape[0]
+    npad = 7680
+    assert ncls <= npad
+    wpad = torch.zeros(npad, 192)
+    wpad[:ncls] = wc
+    bpad = torch.full((npad,), -3.0e38)
+    bpad[:ncls] = bc
+    bl.add_conv("cls", wpad.reshape(npad, 192, 1, 1), bpad)
+    bl.add("meta", np.array([ncls], dtype=np.int32), "i32")
     return bl.tobytes()

@@ -1,0 +1,141 @@
+"""GPU parity tests of the ConvNextViT recogniser through the C ABI.
+
+Integer work (resized pixels -> gray is fp32 arithmetic on integer pixels: bit-exact; token ids) and float work (winning
+logit within 1e-3 of the fp32 oracle / of the reference module's own output in PT_PRECISION_BF16X3; bf16 drift recorded);
+token ids may differ from the oracle's only where the oracle's own top-2 margin is inside the tolerance."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import convnext_vit as ocv
+from oracle.crnn import keepratio_resize
+from pdf_table_amd import lib as L
+from pdf_table_amd.synth_weights import convnext_vit_state_dict
+from pdf_table_amd.weights import pack_convnext_vit
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return convnext_vit_state_dict(seed=29)          # the seed of tests/golden/convnext_vit.npz
+
+
+@pytest.fixture(scope="module")
+def eng(sd):
+    from pdf_table_amd.engine import HipEngine
+    e = HipEngine(0)
+    e.load_weights(L.PT_MODEL_CONVNEXT_VIT, pack_convnext_vit(sd))
+    yield e
+    e.close()
+
+
+def _gray(x):
+    return x[:, 0] * 0.2989 + x[:, 1] * 0.5870 + x[:, 2] * 0.1140
+
+
+def _compare(tag, ids, mx, logits, tol_logit, tol_margin):
+    top2 = torch.topk(logits, 2, dim=-1)
+    dmax = (mx - top2.values[..., 0]).abs().max().item()
+    margin = top2.values[..., 0] - top2.values[..., 1]
+    diff = ids != top2.indices[..., 0]
+    print(f"convnext-vit {tag}: max|d max-logit| = {dmax:.2e} (scale {logits.abs().max().item():.1f}); "
+          f"{int(diff.sum())} of {ids.numel()} ids differ; min margin {margin.min().item():.2e}")
+    assert dmax <= tol_logit
+    assert bool((margin[diff] <= tol_margin).all())
+    return dmax
+
+
+def test_x3_matches_the_reference_modules_own_output(eng, golden_dir):
+    """the fixture the reference's ConvNextViT module produced (make_golden.py::gen_convnext_vit): three chunks of one line"""
+    g = np.load(os.path.join(golden_dir, "convnext_vit.npz"))
+    x = torch.from_numpy(g["img_u8"]).float().div(255.).permute(0, 3, 1, 2)
+    eng.set_precision(L.PT_PRECISION_BF16X3)
+    try:
+        ids, mx = eng.rec_cvit_forward_net(_gray(x).contiguous().cuda())
+        torch.cuda.synchronize()
+    finally:
+        eng.set_precision(L.PT_PRECISION_BF16)
+    ids, mx = ids.cpu(), mx.cpu()
+    val, idx = torch.from_numpy(g["top2_val"]), torch.from_numpy(g["top2_idx"]).long()
+    dmax = (mx - val[..., 0]).abs().max().item()
+    margin = val[..., 0] - val[..., 1]
+    diff = ids.long() != idx[..., 0]
+    print(f"convnext-vit x3 vs reference module: max|d max-logit| = {dmax:.2e} (scale {float(g['logits_abs_max']):.1f}); "
+          f"{int(diff.sum())} of {ids.numel()} ids differ")
+    assert dmax <= TOL
+    assert bool((margin[diff] <= 2 * TOL).all())
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_lines_match_fp32_oracle(eng, sd, mode):
+    """five 804-px lines (ragged text widths, one empty) in the line layout: chunks are cut by the kernel"""
+    rng = np.random.default_rng(17)
+    n = 5
+    img = rng.uniform(0, 1, (n, 3, 32, 804)).astype(np.float32)
+    img[1, :, :, 500:] = 0
+    img[2, :, :, 120:] = 0
+    img[4] = 0
+    xt = torch.from_numpy(img)
+    chunks = torch.stack([xt[:, :, :, 252 * j:252 * j + 300] for j in range(3)], 1).reshape(3 * n, 3, 32, 300)
+    with torch.no_grad():
+        logits = ocv.convnext_vit_forward_fp32(sd, chunks)
+    eng.set_precision(L.PT_PRECISION_BF16X3 if mode == "bf16x3" else L.PT_PRECISION_BF16)
+    try:
+        ids, mx = eng.rec_cvit_forward_net(_gray(xt).contiguous().cuda())
+        ids_c, mx_c = eng.rec_cvit_forward_net(_gray(chunks).contiguous().cuda())
+        ids_1, mx_1 = eng.rec_cvit_forward_net(_gray(xt[1:2]).contiguous().cuda())
+        torch.cuda.synchronize()
+    finally:
+        eng.set_precision(L.PT_PRECISION_BF16)
+    assert torch.equal(ids, ids_c) and torch.equal(mx, mx_c), "line layout and chunk layout are the same computation"
+    assert torch.equal(ids[1:2], ids_1) and torch.equal(mx[1:2], mx_1), "a line's result does not depend on its batch"
+    scale = logits.abs().max().item()
+    if mode == "bf16x3":
+        _compare("x3", ids.cpu().long(), mx.cpu(), logits, TOL, 2 * TOL)
+    else:
+        _compare("bf16", ids.cpu().long(), mx.cpu(), logits, 0.06 * scale, 0.12 * scale)
+
+
+def _crops():
+    rng = np.random.default_rng(23)
+    sizes = [(32, 804), (64, 1608), (40, 700), (25, 90), (48, 2000), (33, 60)]
+    return [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+
+
+def test_preprocess_bit_exact(eng):
+    crops = _crops()
+    gray = eng.rec_cvit_preprocess_crops(crops).cpu()
+    for i, c in enumerate(crops):
+        full = torch.from_numpy(keepratio_resize(c, 32, 804)).float().div(255.).permute(2, 0, 1)[None]
+        want = _gray(full)[0]
+        assert torch.equal(gray[i], want), f"crop {i}: {(gray[i] - want).abs().max()}"
+        d = ocv.chunk_preprocess(c)                                   # and the chunks the reference's processor makes
+        for j in range(3):
+            assert torch.equal(gray[i][:, 252 * j:252 * j + 300], _gray(d[j:j + 1])[0])
+
+
+def test_crops_end_to_end_x3(eng, sd):
+    crops = _crops()
+    eng.set_precision(L.PT_PRECISION_BF16X3)
+    try:
+        ids, mx = eng.rec_cvit_forward_crops(crops)
+        torch.cuda.synchronize()
+    finally:
+        eng.set_precision(L.PT_PRECISION_BF16)
+    with torch.no_grad():
+        logits = torch.cat([ocv.convnext_vit_forward_fp32(sd, ocv.chunk_preprocess(c)) for c in crops], 0)
+    _compare("crops x3", ids.cpu().long(), mx.cpu(), logits, TOL, 2 * TOL)
+
+
+def test_missing_weights_fail_loudly():
+    from pdf_table_amd.engine import HipEngine
+    e = HipEngine(0)
+    try:
+        with pytest.raises(L.PtError, match="ConvNextViT weights not loaded"):
+            e.rec_cvit_forward_net(torch.zeros((3, 32, 300), dtype=torch.float32, device="cuda"))
+    finally:
+        e.close()
