@@ -1,9 +1,11 @@
 """``OcrRecognitionTask`` on the HIP engine -- drop-in for the reference's stage-3 plug-in.
 
 Reference: src/pdftable/model/ocr_pdf/ocr_recognition_task.py:28-136.  Same constructor (``task, model, task_type``),
-same result (one string per input crop), same ``RuntimeError`` for an unknown model (:47).  ``model="CRNN"`` (the
-in-tree torch recogniser) is served; ``ConvNextViT`` / ``LightweightEdge`` and the PP-OCR ONNX recognisers are not
-built on the engine yet and fail loudly, naming the hub id the reference would have fetched.
+same result (one string per input crop), same ``RuntimeError`` for an unknown model (:47).  ``model="CRNN"`` and
+``model="ConvNextViT"`` (the two in-tree torch recognisers of BASELINE.json's configs; ConvNextViT with the chunking
+pre-processor: 32 x 804, three 300-px chunks, 201 tokens per line, vocabulary from class 2) are served; ``LightweightEdge``
+and the PP-OCR ONNX recognisers are not built on the engine yet and fail loudly, naming the hub id the reference would
+have fetched.
 
 Two ways in:
   * reference-shaped: ``task(crop_or_list_of_crops)`` -- every crop is an RGB image (path / PIL / ndarray) exactly as
@@ -26,7 +28,7 @@ from .base_infer_task import BaseInferTask
 from .engine import HipEngine
 from .ocr_detection_task import _read_image
 from .rec_stage import RecStage
-from .weights import pack_crnn
+from .weights import pack_convnext_vit, pack_crnn
 
 __all__ = ["OcrRecognitionTask"]
 
@@ -55,16 +57,16 @@ class OcrRecognitionTask(BaseInferTask):
         self._get_inference_model()
 
     def _construct_model(self, model):
-        if model != "CRNN":
+        if model not in ("CRNN", "ConvNextViT"):
             raise RuntimeError(f"recogniser '{model}' ({self._config.model_path}) is not built on the HIP engine yet; "
-                               "only the in-tree CRNN is (SURVEY.md section 8f)")
+                               "only the in-tree CRNN and ConvNextViT are (SURVEY.md section 8f)")
         if self._engine is None:
             self._engine = HipEngine(int(str(self.device).split(":")[-1]) if ":" in str(self.device) else 0)
         vocab = None
         if self.synthetic_seed is not None:
-            from .synth_weights import crnn_state_dict
-            sd = crnn_state_dict(seed=int(self.synthetic_seed))
-        elif any(os.path.isfile(os.path.join(self._config.model_path, c)) for c in ("model.onnx", "fp16_model.onnx")):
+            from .synth_weights import convnext_vit_state_dict, crnn_state_dict
+            sd = (convnext_vit_state_dict if model == "ConvNextViT" else crnn_state_dict)(seed=int(self.synthetic_seed))
+        elif model == "CRNN" and any(os.path.isfile(os.path.join(self._config.model_path, c)) for c in ("model.onnx", "fp16_model.onnx")):
             # an exported CRNN (DeployUtils.export_onnx -> torch.onnx.export, utils/deploy_utils.py:197-224): the importer
             # restores the state_dict (ONNX LSTM gate order i, o, f, c -> torch's i, f, g, o) and the usual path takes over
             from .onnx_import import UnsupportedOnnxGraph, load_onnx, recognise
@@ -88,17 +90,23 @@ class OcrRecognitionTask(BaseInferTask):
             sd = {k.replace("recognizer.", "").replace("module.", ""): v for k, v in raw.items()}   # :108-111
             with open(os.path.join(mp, "vocab.txt"), "r", encoding="utf-8") as f:
                 vocab = [ln.strip("\n") for ln in f.readlines()]
-        self._engine.load_weights(L.PT_MODEL_CRNN, pack_crnn(sd))
+        if model == "ConvNextViT":
+            self._engine.load_weights(L.PT_MODEL_CONVNEXT_VIT, pack_convnext_vit(sd))
+        else:
+            self._engine.load_weights(L.PT_MODEL_CRNN, pack_crnn(sd))
         self._vocab = vocab
         self._model = self._predict
 
     def _build_processor(self):
-        self._stage = RecStage(self._engine, self._vocab)
+        self._stage = RecStage(self._engine, self._vocab, recognizer=self._config.recognizer)
 
     def _predict(self, crops):
-        """already-cropped line images: resize + CRNN + arg-max on the device, CTC collapse + vocabulary on the host"""
+        """already-cropped line images: resize + network + arg-max on the device, CTC collapse + vocabulary on the host"""
         from .rec_stage import ctc_collapse
-        ids, _ = self._engine.rec_forward_crops(crops)
+        if self._config.recognizer == "ConvNextViT":
+            ids, _ = self._engine.rec_cvit_forward_crops(crops)
+        else:
+            ids, _ = self._engine.rec_forward_crops(crops)
         toks = ctc_collapse(ids.cpu().numpy()) if len(crops) else []
         return ["".join(self._stage.label.get(t, "") for t in row) for row in toks]
 

@@ -129,15 +129,22 @@ def synthetic_vocab(n: int = L.PT_REC_NCLS - 1) -> List[str]:
 
 
 class RecStage:
-    def __init__(self, eng: HipEngine, vocab: Optional[Sequence[str]] = None):
+    def __init__(self, eng: HipEngine, vocab: Optional[Sequence[str]] = None, recognizer: str = "CRNN"):
         self.eng = eng
-        vocab = list(vocab) if vocab is not None else synthetic_vocab()
-        # labelMapping starts at 1 for CRNN (do_chunking False): modeling_ocr_recognition.py:119-132
-        self.label = {i + 1: ch for i, ch in enumerate(vocab)}
+        self.recognizer = recognizer
+        chunking = recognizer == "ConvNextViT"
+        vocab = list(vocab) if vocab is not None else synthetic_vocab(L.PT_CVIT_NCLS - 2 if chunking else L.PT_REC_NCLS - 1)
+        # labelMapping starts at 1 for CRNN and at 2 for the chunking ConvNextViT: modeling_ocr_recognition.py:119-132,
+        # processor_ocr_recognition.py:131-145 (class 1 has no entry there either)
+        first = 2 if chunking else 1
+        self.label = {i + first: ch for i, ch in enumerate(vocab)}
 
     def ids(self, pages: torch.Tensor, boxes_per_page: Sequence[np.ndarray]):
         lines = build_lines(boxes_per_page)
-        ids, _ = self.eng.rec_forward(pages, lines, want_maxlogit=False)
+        if self.recognizer == "ConvNextViT":
+            ids, _ = self.eng.rec_cvit_forward(pages, lines)
+        else:
+            ids, _ = self.eng.rec_forward(pages, lines, want_maxlogit=False)
         return ids, lines
 
     def start(self, pages: torch.Tensor, boxes_per_page: Sequence[np.ndarray]):

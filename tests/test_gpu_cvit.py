@@ -139,3 +139,49 @@ def test_missing_weights_fail_loudly():
             e.rec_cvit_forward_net(torch.zeros((3, 32, 300), dtype=torch.float32, device="cuda"))
     finally:
         e.close()
+
+
+def test_recognition_task_serves_convnext_vit(tmp_path, sd):
+    """OcrRecognitionTask(model="ConvNextViT"): from a checkpoint directory (pytorch_model.pt in the transformers-5 key names
+    under the `recognizer.` prefix + vocab.txt, modeling_ocr_recognition.py:100-132) and from the seeded checkpoint: same
+    texts, and the texts of the oracle's greedy decode of the device ids (vocabulary from class 2)"""
+    from pdf_table_amd.ocr_recognition_task import OcrRecognitionTask
+    from pdf_table_amd.rec_stage import ctc_collapse
+    v5 = {}
+    for k, v in sd.items():
+        k = k.replace("vit.encoder.layer.", "vit.layers.").replace(".attention.attention.query.", ".attention.q_proj.")
+        k = k.replace(".attention.attention.key.", ".attention.k_proj.").replace(".attention.attention.value.", ".attention.v_proj.")
+        k = k.replace(".attention.output.dense.", ".attention.o_proj.").replace(".intermediate.dense.", ".mlp.fc1.")
+        if ".vit.layers." in k:
+            k = k.replace(".output.dense.", ".mlp.fc2.")
+        v5["recognizer." + k] = v
+    torch.save(v5, tmp_path / "pytorch_model.pt")
+    vocab = [chr(0x4E00 + i) for i in range(L.PT_CVIT_NCLS - 2)]
+    (tmp_path / "vocab.txt").write_text("\n".join(vocab) + "\n", encoding="utf-8")
+    task = OcrRecognitionTask(model="ConvNextViT", task_path=str(tmp_path))
+    crops = _crops()
+    texts = task(crops)
+    assert isinstance(texts, list) and len(texts) == len(crops) and all(isinstance(t, str) for t in texts)
+    ids, _ = task._engine.rec_cvit_forward_crops(crops)
+    want = ["".join(vocab[t - 2] for t in row if t >= 2) for row in ctc_collapse(ids.cpu().numpy())]
+    assert texts == want and any(len(t) > 3 for t in texts)
+    assert texts[0] == task(crops[0])[0]
+    seeded = OcrRecognitionTask(model="ConvNextViT", synthetic_seed=29, engine=task._engine)
+    assert seeded(crops) == texts
+
+
+def test_pipeline_with_convnext_vit_recogniser():
+    """OcrTablePipeline(recognizer="ConvNextViT"): detector boxes -> device crops -> chunked recogniser, one text per box;
+    the texts equal the task's on the same boxes cropped by the oracle's crop_image"""
+    from oracle import crnn as ocrnn
+    from pdf_table_amd.pipeline import OcrTablePipeline
+    from pdf_table_amd.synth_pages import make_page
+    pipe = OcrTablePipeline(device=0, recognizer="ConvNextViT", synthetic_seed=0)
+    pages = [make_page(i)[0] for i in range(2)]
+    res = pipe.predict(pages)
+    assert len(res) == 2
+    for page, r in zip(pages, res):
+        assert len(r.ocr_result) == len(r.det_result) and len(r.det_result) > 0
+        k = min(6, len(r.det_result))
+        crops = [ocrnn.crop_image(page, ocrnn.order_point(np.asarray(b, np.float64))) for b in r.det_result[:k]]
+        assert [o["text"] for o in r.ocr_result[:k]] == pipe.text_recognizer(crops)
