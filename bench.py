@@ -589,6 +589,37 @@ class HipRunner:
                 "asserted_by": "tests/test_gpu_fullsize.py::test_fullsize_*_oracle_parity (x3: <= 1e-3 of the logit scale at "
                                "BASELINE sizes, token ids exact outside the oracle's own <= 2e-3 ties); bf16 drift recorded there"}
 
+    def convnext_vit_leg(self, steps=3, warm=1):
+        """BASELINE.json configs[4], recogniser half: the SAME lines of the step (the detector's boxes on the 64 pages) through
+        the ConvNextViT recogniser (crop, 32 x 804 chunking pre-processor, ConvNext + ViT, arg-max), bf16 and BF16X3"""
+        torch, L, eng = self.torch, self.L, self.eng
+        if self.rec is None:
+            return None
+        from pdf_table_amd.rec_stage import build_lines
+        from pdf_table_amd.synth_weights import convnext_vit_state_dict
+        from pdf_table_amd.weights import pack_convnext_vit
+        eng.load_weights(L.PT_MODEL_CONVNEXT_VIT, pack_convnext_vit(convnext_vit_state_dict(seed=7)))
+        quads = self.gt_quads if (self.args.gt_chain or self.rec_boxes is None) else self.rec_boxes
+        lines = build_lines(quads)
+        out = {"lines_per_step": int(len(lines)), "steps": steps, "tokens_per_line": 201,
+               "gflop_per_line": 12.3, "asserted_by": "tests/test_gpu_cvit.py (x3: <= 1e-3 on the winning logit against the reference "
+                                                      "module's own output, ids exact outside <= 2e-3 ties; bf16 drift recorded there)"}
+        for name, prec in (("bf16", L.PT_PRECISION_BF16), ("bf16x3", L.PT_PRECISION_BF16X3)):
+            eng.set_precision(prec)
+            try:
+                for _ in range(warm):
+                    eng.rec_cvit_forward(self.pages, lines)
+                self.sync()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    eng.rec_cvit_forward(self.pages, lines)
+                self.sync()
+                dt = (time.perf_counter() - t0) / steps
+            finally:
+                eng.set_precision(L.PT_PRECISION_BF16)
+            out[name] = {"lines_per_s": len(lines) / dt, "ms_per_step": dt * 1e3, "pages_per_s_rec_only": PAGES_PER_STEP / dt}
+        return out
+
     def parity_sample(self):
         """engine outputs for the page / lines the CPU-baseline leg runs through the oracle (checked THERE)"""
         torch, L, eng = self.torch, self.L, self.eng
@@ -785,6 +816,10 @@ def main(argv=None):
             if rank == 0:
                 leg["bf16_pages_per_s"] = out["value"]
                 out["tolerance_mode"] = leg
+        if "rec" in runner.stages and not args.no_post:
+            leg = runner.convnext_vit_leg()
+            if rank == 0 and leg is not None:
+                out["convnext_vit_recogniser"] = leg
     if rank == 0:
         if not stub and world == 1 and not args.no_cpu_baseline and "det" in runner.stages:
             r = runner

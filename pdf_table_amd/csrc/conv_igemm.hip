@@ -327,7 +327,8 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
 // then gives every lane two 16-byte channel runs per block (q = 0: channels 0-7 and 16-23, q = 1: 8-15 and 24-31).
 // Against the staged epilogue above (fp32 through LDS, two barriers per pass): no LDS, no barrier, ~1/3 of the
 // instructions.  Used by the register-staged kernel's 1x1, stride-2 and short 3x3 launches (K is two to sixteen chunks there: a
-// tile is mostly epilogue); plain layers only (no split / pool / fused head / arg-max / pixel shuffle / fp32 residual).
+// tile is mostly epilogue); plain layers only (no split / pool / fused head / arg-max / pixel shuffle / fp32 residual: the staged epilogue's full-row
+// fp32 read-modify-write beats 16-byte pieces per lane, measured on the ConvNextViT residual GEMMs).
 struct DirectBias { f32x4 v[2][4]; };
 template <int NB>
 __device__ __forceinline__ DirectBias direct_bias(const ConvK& p, int n0, int q) {

@@ -58,13 +58,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ConvNextEmbeddings: Conv2d(1, 96, 4, stride 4) + LayerNorm(96, eps 1e-6) (HF modeling_convnext.py ConvNextEmbeddings).
-// gray fp32; chunk c = 3 * line + j starts at gray + line * lstride + j * jstride, rows `pitch` apart.  One wave per pixel.
+// gray fp32; chunk c = 3 * line + j starts at gray + line * lstride + j * jstride, rows `pitch` apart.  A LANE owns one output
+// pixel and all 96 channels of it: the weights are wave-uniform (scalar loads), the LayerNorm is in-lane -- no cross-lane step.
 __global__ __launch_bounds__(256) void cvit_embed_kernel(const float* __restrict__ gray, int pitch, long long jstride, long long lstride,
                                                          int nchunks, const float* __restrict__ w, const float* __restrict__ b,
                                                          const float* __restrict__ g, const float* __restrict__ beta,
                                                          float* __restrict__ x) {
-  const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
+  const long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= (long long)nchunks * CV_PIX0) return;
   const int chunk = (int)(pix / CV_PIX0), r = (int)(pix % CV_PIX0), oy = r / CV_T, ox = r % CV_T;
   const float* src = gray + (long long)(chunk / 3) * lstride + (long long)(chunk % 3) * jstride + (size_t)(oy * 4) * pitch + ox * 4;
@@ -73,96 +73,121 @@ __global__ __launch_bounds__(256) void cvit_embed_kernel(const float* __restrict
   for (int dy = 0; dy < 4; ++dy)
 #pragma unroll
     for (int dx = 0; dx < 4; ++dx) in[dy * 4 + dx] = src[dy * pitch + dx];
-  const bool two = lane < 32;
-  float v0 = 0.f, v1 = 0.f;
+  float v[96];
+  float sum = 0.f;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    v0 += w[lane * 16 + k] * in[k];
-    if (two) v1 += w[(64 + lane) * 16 + k] * in[k];
+  for (int c = 0; c < 96; ++c) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a += w[c * 16 + k] * in[k];
+    v[c] = a + b[c];
+    sum += v[c];
   }
-  v0 += b[lane];
-  if (two) v1 += b[64 + lane];
-  const float mean = wave_sum(v0 + (two ? v1 : 0.f)) / 96.f;
-  const float d0 = v0 - mean, d1 = two ? v1 - mean : 0.f;
-  const float rstd = 1.f / sqrtf(wave_sum(d0 * d0 + d1 * d1) / 96.f + 1e-6f);
-  x[pix * 96 + lane] = d0 * rstd * g[lane] + beta[lane];
-  if (two) x[pix * 96 + 64 + lane] = d1 * rstd * g[64 + lane] + beta[64 + lane];
+  const float mean = sum / 96.f;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < 96; ++c) {
+    v[c] -= mean;
+    q += v[c] * v[c];
+  }
+  const float rstd = 1.f / sqrtf(q / 96.f + 1e-6f);
+  float4* op = reinterpret_cast<float4*>(x + pix * 96);
+#pragma unroll
+  for (int c = 0; c < 96; c += 4)
+    op[c >> 2] = make_float4(v[c] * rstd * g[c] + beta[c], v[c + 1] * rstd * g[c + 1] + beta[c + 1], v[c + 2] * rstd * g[c + 2] + beta[c + 2],
+                             v[c + 3] * rstd * g[c + 3] + beta[c + 3]);
 }
 
 // ConvNextLayer, first half: depthwise Conv2d(C, C, 7, padding 3) + LayerNorm(C, eps 1e-6) over the fp32 stream
-// x [B, H, W, C] -> bf16 [pixel][C] ([hi C | lo C] in the hi/lo mode).  grid (ceil(W / 8), H, B), block = C rounded up to
-// waves; thread c owns channel c of 8 consecutive pixels.  wt: [49][C] (tap-major: coalesced over channels).
+// x [B, H, W, C] -> bf16 [pixel][C] ([hi C | lo C] in the hi/lo mode).  The maps are H <= 8 rows high, less than the kernel:
+// a workgroup owns ALL H rows of 8 consecutive columns of one chunk, thread c owns channel c of those H x 8 pixels, so every
+// input value is loaded once (H x 14 loads for up to H x 8 x 49 multiply-adds).  LayerNorm: the H x 8 pixels go through an LDS
+// tile [pixel][C]; a wave reduces whole pixels (two passes: mean, squared deviations), the statistics come back through LDS.
+// grid (ceil(W / 8), B), block = C rounded up to waves, dynamic LDS = (H * 8 * C + 2 * H * 8) floats.  wt: [49][C] (tap-major).
 constexpr int CV_TX = 8;
-__global__ __launch_bounds__(512) void cvit_dwconv_ln_kernel(const float* __restrict__ x, int H, int W, int C, const float* __restrict__ wt,
+template <int H>
+__global__ __launch_bounds__(512) void cvit_dwconv_ln_kernel(const float* __restrict__ x, int W, int C, const float* __restrict__ wt,
                                                              const float* __restrict__ bias, const float* __restrict__ g,
                                                              const float* __restrict__ beta, bf16_t* __restrict__ out, int split) {
-  __shared__ float red[8][CV_TX];
+  extern __shared__ float cv_lds[];
+  constexpr int NP = H * CV_TX;
+  float* tile = cv_lds;                 // [NP][C]
+  float* stats = cv_lds + NP * C;       // [NP][2] = (mean, rstd)
   const int c = threadIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-  const int x0 = blockIdx.x * CV_TX, y = blockIdx.y, b = blockIdx.z;
+  const int x0 = blockIdx.x * CV_TX, b = blockIdx.y;
   const bool active = c < C;
-  float acc[CV_TX];
+  float acc[H][CV_TX];
 #pragma unroll
-  for (int j = 0; j < CV_TX; ++j) acc[j] = 0.f;
+  for (int oy = 0; oy < H; ++oy)
+#pragma unroll
+    for (int j = 0; j < CV_TX; ++j) acc[oy][j] = 0.f;
   if (active) {
-    for (int dy = 0; dy < 7; ++dy) {
-      const int iy = y + dy - 3;
-      if (iy < 0 || iy >= H) continue;
-      float wv[7];
+    float wv[49];
 #pragma unroll
-      for (int k = 0; k < 7; ++k) wv[k] = wt[(dy * 7 + k) * C + c];
-      const float* row = x + ((size_t)b * H + iy) * W * C + c;
+    for (int k = 0; k < 49; ++k) wv[k] = wt[k * C + c];
+    const float* base = x + (size_t)b * H * W * C + c;
+#pragma unroll
+    for (int iy = 0; iy < H; ++iy) {
 #pragma unroll
       for (int dx = 0; dx < CV_TX + 6; ++dx) {
         const int ix = x0 + dx - 3;
-        const float v = (ix >= 0 && ix < W) ? row[(size_t)ix * C] : 0.f;
+        const float v = (ix >= 0 && ix < W) ? base[((size_t)iy * W + ix) * C] : 0.f;
 #pragma unroll
-        for (int j = 0; j < CV_TX; ++j) {
-          const int k = dx - j;
-          if (k >= 0 && k < 7) acc[j] += wv[k] * v;
+        for (int oy = 0; oy < H; ++oy) {
+          const int dy = iy - oy + 3;
+          if (dy < 0 || dy >= 7) continue;
+#pragma unroll
+          for (int j = 0; j < CV_TX; ++j) {
+            const int k = dx - j;
+            if (k >= 0 && k < 7) acc[oy][j] += wv[dy * 7 + k] * v;
+          }
         }
       }
     }
     const float bb = bias[c];
 #pragma unroll
-    for (int j = 0; j < CV_TX; ++j) acc[j] += bb;
-  }
-  // LayerNorm over the C channels of each of the 8 pixels: two passes (mean, then squared deviations), fp32
-  float mean[CV_TX], rstd[CV_TX];
+    for (int oy = 0; oy < H; ++oy)
 #pragma unroll
-  for (int j = 0; j < CV_TX; ++j) {
-    const float s = wave_sum(active ? acc[j] : 0.f);
-    if (lane == 0) red[wave][j] = s;
+      for (int j = 0; j < CV_TX; ++j) {
+        acc[oy][j] += bb;
+        tile[(oy * CV_TX + j) * C + c] = acc[oy][j];
+      }
   }
   __syncthreads();
+  for (int px = wave; px < NP; px += nw) {
+    float v[8], s = 0.f;
 #pragma unroll
-  for (int j = 0; j < CV_TX; ++j) {
-    float s = 0.f;
-    for (int k = 0; k < nw; ++k) s += red[k][j];
-    mean[j] = s / (float)C;
+    for (int k = 0; k < 8; ++k) {
+      const int cc = lane + 64 * k;
+      v[k] = cc < C ? tile[px * C + cc] : 0.f;
+      s += v[k];
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float d = (lane + 64 * k) < C ? v[k] - mean : 0.f;
+      q += d * d;
+    }
+    q = wave_sum(q);
+    if (lane == 0) {
+      stats[2 * px] = mean;
+      stats[2 * px + 1] = 1.f / sqrtf(q / (float)C + 1e-6f);
+    }
   }
   __syncthreads();
-#pragma unroll
-  for (int j = 0; j < CV_TX; ++j) {
-    const float d = active ? acc[j] - mean[j] : 0.f;
-    const float s = wave_sum(d * d);
-    if (lane == 0) red[wave][j] = s;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < CV_TX; ++j) {
-    float s = 0.f;
-    for (int k = 0; k < nw; ++k) s += red[k][j];
-    rstd[j] = 1.f / sqrtf(s / (float)C + 1e-6f);
-  }
   if (!active) return;
   const float gg = g[c], be = beta[c];
   const int mul = split ? 2 : 1;
 #pragma unroll
-  for (int j = 0; j < CV_TX; ++j) {
-    if (x0 + j >= W) break;
-    const size_t pix = ((size_t)b * H + y) * W + x0 + j;
-    put(out + pix * C * mul + c, C, split, (acc[j] - mean[j]) * rstd[j] * gg + be);
-  }
+  for (int oy = 0; oy < H; ++oy)
+#pragma unroll
+    for (int j = 0; j < CV_TX; ++j) {
+      if (x0 + j >= W) break;
+      const size_t pix = ((size_t)b * H + oy) * W + x0 + j;
+      const int px = oy * CV_TX + j;
+      put(out + pix * C * mul + c, C, split, (acc[oy][j] - stats[2 * px]) * stats[2 * px + 1] * gg + be);
+    }
 }
 
 // LayerNorm (biased variance, eps inside the root: nn.LayerNorm) of fp32 rows [rows, C], C <= 512 -> bf16 (hi | lo).  One wave
@@ -427,7 +452,7 @@ int forward_batch(pt_engine* e, const PtModel& M, const float* gray, int pitch, 
     if (p.rc != PT_OK) return p.rc;
     PtProfScope ps(e, s, PT_PROF_OTHER, 0, "cvit embed");
     const long long pix = (long long)nchunks * CV_PIX0;
-    hipLaunchKernelGGL(cvit_embed_kernel, dim3((unsigned)((pix + 3) / 4)), dim3(256), 0, s, gray, pitch, jstride, lstride, nchunks, w, b, g, be, x);
+    hipLaunchKernelGGL(cvit_embed_kernel, dim3((unsigned)((pix + 255) / 256)), dim3(256), 0, s, gray, pitch, jstride, lstride, nchunks, w, b, g, be, x);
   }
   auto ln = [&](const std::string& q, long long rows, int C, float eps, bf16_t* out, int mode, int H, int W) {
     const float* g = q.empty() ? nullptr : p.f32(q + ".g");
@@ -454,8 +479,12 @@ int forward_batch(pt_engine* e, const PtModel& M, const float* gray, int pitch, 
       if (p.rc != PT_OK) return p.rc;
       {
         PtProfScope ps(e, s, PT_PROF_OTHER, 0, "cvit dwconv7+ln");
-        hipLaunchKernelGGL(cvit_dwconv_ln_kernel, dim3((CV_T + CV_TX - 1) / CV_TX, H, nchunks), dim3((C + 63) / 64 * 64), 0, s, x, H, CV_T, C,
-                           w, b, g, be, xb, x3);
+        const dim3 grid((CV_T + CV_TX - 1) / CV_TX, nchunks), block((C + 63) / 64 * 64);
+        const size_t lds = ((size_t)H * CV_TX * C + 2 * H * CV_TX) * sizeof(float);
+        if (H == 8) hipLaunchKernelGGL(cvit_dwconv_ln_kernel<8>, grid, block, lds, s, x, CV_T, C, w, b, g, be, xb, x3);
+        else if (H == 4) hipLaunchKernelGGL(cvit_dwconv_ln_kernel<4>, grid, block, lds, s, x, CV_T, C, w, b, g, be, xb, x3);
+        else if (H == 2) hipLaunchKernelGGL(cvit_dwconv_ln_kernel<2>, grid, block, lds, s, x, CV_T, C, w, b, g, be, xb, x3);
+        else hipLaunchKernelGGL(cvit_dwconv_ln_kernel<1>, grid, block, lds, s, x, CV_T, C, w, b, g, be, xb, x3);
       }
       p.gemm(xb, rp, C, lq + ".pw1", 4 * C, 4, hb);
       p.gemm(hb, rp, 4 * C, lq + ".pw2", Np, 0, nullptr, x, C, x, Np != C ? C : 0);
