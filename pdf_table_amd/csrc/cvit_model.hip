@@ -356,6 +356,140 @@ __global__ __launch_bounds__(64) void cvit_attention_kernel(const bf16_t* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused MLP of a ConvNextLayer / ViTLayer (bf16 mode): x += W2 . GELU(W1 . xb + b1) + b2 without the [rows, 4C] hidden tensor
+// ever leaving the CU (unfused, it is written and read back once per layer: 16 of the 26 C bytes per row a layer moves).
+//   workgroup = 128 rows, a wave owns 32 of them and keeps their xb rows (K = C) in registers as MFMA B fragments for the
+//   whole kernel; the hidden layer is walked in chunks of 32 units.  Per chunk the W1 rows [32][C] and the W2 columns
+//   [C][32] sit in LDS (double-buffered, next chunk pre-fetched to registers while this one is multiplied):
+//     D1 [32 hidden][32 rows] = W1_chunk . xb^T        C / 16 v_mfma_f32_32x32x16_bf16, W1 as the A operand
+//     bias + GELU + bf16 in the lane: in the D layout a lane owns ONE row and 16 hidden units -- which is exactly a B operand
+//     of the second product if its K order is the D layout's own order (a sum does not care), so the hidden values go from
+//     accumulators to operands without leaving the lane; W2's columns are stored in that order (weights.py)
+//     D2 [C out][32 rows] += W2_chunk . H              2 x C / 32 MFMAs, W2 as the A operand
+//   An MFMA here reads 1 KB of LDS (the weight fragment; the row operand is in registers): LDS and matrix pipe are balanced,
+//   neither HBM (10 C bytes per row instead of 26 C) nor the launch count (one kernel instead of two) is the bound.
+//   Epilogue: the lane's 4-channel fp32 runs of its row are added to the residual stream in place.
+// GELU: erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, one exp, one reciprocal) -- the hidden value is rounded to bf16
+// right after, 2^-9 relative.  The hi/lo mode keeps the two-GEMM path with erff.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) uint32_t cu32x4;
+
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = 1.f - poly * __expf(-z * z);          // erf(|x| / sqrt 2)
+  return 0.5f * x * (1.f + copysignf(e, x)) ;
+}
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void cvit_mlp_kernel(const bf16_t* __restrict__ xb, const bf16_t* __restrict__ w1,
+                                                          const float* __restrict__ b1, const bf16_t* __restrict__ w2p,
+                                                          const float* __restrict__ b2, float* __restrict__ x) {
+  constexpr int KS = C / 16, NT = C / 32, NCH = 4 * C / 32;
+  constexpr int P1 = C * 2 + 16, P2 = 80;              // LDS row pitches in bytes: 16-byte skew, conflict-free ds_read_b128
+  constexpr int STAGE = 32 * P1 + C * P2;
+  constexpr int PIECES = C / 32;                       // 16-byte pieces per thread per chunk (4C of W1 + 4C of W2 over 256 threads)
+  extern __shared__ __attribute__((aligned(16))) char cv_mlp_lds[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
+  const long long row = (long long)blockIdx.x * 128 + wave * 32 + col;
+  abf16x8 xf[KS];
+  {
+    const bf16_t* xr = xb + row * C + half * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xf[s] = ld8(xr + 16 * s);
+  }
+  af32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  cu32x4 pre[PIECES];
+  auto load_chunk = [&](int hc) {
+    const char* g1 = reinterpret_cast<const char*>(w1 + (size_t)hc * 32 * C);      // 32 rows x C: 64 C contiguous bytes
+    const char* g2 = reinterpret_cast<const char*>(w2p + (size_t)hc * C * 32);     // C rows x 32 (permuted) k: 64 C bytes
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int idx = tid + i * 256;
+      pre[i] = *reinterpret_cast<const cu32x4*>(idx < 4 * C ? g1 + idx * 16 : g2 + (idx - 4 * C) * 16);
+    }
+  };
+  auto store_chunk = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int idx = tid + i * 256;
+      char* dst;
+      if (idx < 4 * C) {
+        dst = buf + (idx / (C / 8)) * P1 + (idx % (C / 8)) * 16;
+      } else {
+        const int j = idx - 4 * C;
+        dst = buf + 32 * P1 + (j >> 2) * P2 + (j & 3) * 16;
+      }
+      *reinterpret_cast<cu32x4*>(dst) = pre[i];
+    }
+  };
+  load_chunk(0);
+  store_chunk(cv_mlp_lds);
+  __syncthreads();
+  for (int hc = 0; hc < NCH; ++hc) {
+    const char* cur = cv_mlp_lds + (hc & 1) * STAGE;
+    if (hc + 1 < NCH) load_chunk(hc + 1);
+    af32x16 d1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d1[r] = 0.f;
+    const char* a1 = cur + col * P1 + half * 16;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a1 + s * 32), xf[s], d1, 0, 0, 0);
+    abf16x8 hf[2];
+    const float* bp = b1 + hc * 32 + 4 * half;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const float4 bb = *reinterpret_cast<const float4*>(bp + 8 * g4);
+      const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = 4 * g4 + k;
+        hf[r >> 3][r & 7] = __builtin_bit_cast(__bf16, (uint16_t)f2bf(gelu_fast(d1[r] + bv[k])));
+      }
+    }
+    const char* a2 = cur + 32 * P1 + col * P2 + half * 16;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a2 + t * 32 * P2), hf[0], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a2 + t * 32 * P2 + 32), hf[1], acc[t], 0, 0, 0);
+    }
+    if (hc + 1 < NCH) store_chunk(cv_mlp_lds + ((hc + 1) & 1) * STAGE);
+    __syncthreads();
+  }
+  float* xr = x + row * C + 4 * half;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int o = 32 * t + 8 * g4;
+      float4 r = *reinterpret_cast<const float4*>(xr + o);
+      const float4 bb = *reinterpret_cast<const float4*>(b2 + o + 4 * half);
+      r.x += acc[t][4 * g4] + bb.x; r.y += acc[t][4 * g4 + 1] + bb.y; r.z += acc[t][4 * g4 + 2] + bb.z; r.w += acc[t][4 * g4 + 3] + bb.w;
+      *reinterpret_cast<float4*>(xr + o) = r;
+    }
+}
+
+template <int C>
+int launch_mlp(const bf16_t* xb, const bf16_t* w1, const float* b1, const bf16_t* w2p, const float* b2, float* x, long long rows_pad,
+               hipStream_t s) {
+  constexpr int SMEM = 2 * (32 * (C * 2 + 16) + C * 80);
+  static bool attr_done = false;
+  if (!attr_done) {
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cvit_mlp_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(cvit_mlp_kernel<C>, dim3((unsigned)(rows_pad / 128)), dim3(256), SMEM, s, xb, w1, b1, w2p, b2, x);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
 struct Net {
   pt_engine* e;
   const PtModel* m;
@@ -397,6 +531,31 @@ struct Net {
 };
 
 inline long long pad128(long long r) { return (r + 127) / 128 * 128; }
+
+// the MLP of layer `q` (ConvNextLayer: pw1 / pw2 with the layer scale folded in; ViTLayer: fc1 / fc2) over the fp32 stream x:
+// one fused kernel in bf16 mode for C = 96 / 192 / 256 (PT_CVIT_FUSED_MLP=0: never), else two GEMMs through the hidden tensor
+void mlp(Net& p, const bf16_t* xb, bf16_t* hb, float* x, long long rows_pad, int C, const std::string& q, const char* n1, const char* n2) {
+  static int fused = -1;
+  if (fused < 0) {
+    const char* ev = getenv("PT_CVIT_FUSED_MLP");
+    fused = ev ? atoi(ev) : 1;
+  }
+  if (fused && !p.x3 && (C == 96 || C == 192 || C == 256)) {
+    const PtTensor *w1 = p.get(q + ".mlp.w1"), *w2 = p.get(q + ".mlp.w2p");
+    const float *b1 = p.f32(q + "." + n1 + ".b"), *b2 = p.f32(q + "." + n2 + ".b");
+    if (p.rc != PT_OK) return;
+    PtProfScope ps(p.e, p.s, PT_PROF_CONV1X1, 16.0 * rows_pad * (double)C * C, "cvit fused mlp");
+    const bf16_t* W1 = reinterpret_cast<const bf16_t*>(w1->d_ptr);
+    const bf16_t* W2 = reinterpret_cast<const bf16_t*>(w2->d_ptr);
+    int r = C == 96 ? launch_mlp<96>(xb, W1, b1, W2, b2, x, rows_pad, p.s)
+                    : (C == 192 ? launch_mlp<192>(xb, W1, b1, W2, b2, x, rows_pad, p.s) : launch_mlp<256>(xb, W1, b1, W2, b2, x, rows_pad, p.s));
+    if (r != PT_OK) p.rc = r;
+    return;
+  }
+  const int Np = (C + 63) / 64 * 64;
+  p.gemm(xb, rows_pad, C, q + "." + n1, 4 * C, 4, hb);
+  p.gemm(hb, rows_pad, 4 * C, q + "." + n2, Np, 0, nullptr, x, C, x, Np != C ? C : 0);
+}
 
 // lines [0, n) of one micro-batch
 int forward_batch(pt_engine* e, const PtModel& M, const float* gray, int pitch, long long jstride, long long lstride, int n, int32_t* ids,
@@ -472,7 +631,6 @@ int forward_batch(pt_engine* e, const PtModel& M, const float* gray, int pitch, 
       p.gemm(xb, pad128((long long)nchunks * H * CV_T), 2 * Cp, sq + ".down", C, 0, nullptr, x, C);
     }
     const long long rows = (long long)nchunks * H * CV_T, rp = pad128(rows);
-    const int Np = (C + 63) / 64 * 64;
     for (int l = 0; l < DEPTH[st]; ++l) {
       const std::string lq = sq + ".l" + std::to_string(l);
       const float *w = p.f32(lq + ".dw.w"), *b = p.f32(lq + ".dw.b"), *g = p.f32(lq + ".ln.g"), *be = p.f32(lq + ".ln.b");
@@ -486,8 +644,7 @@ int forward_batch(pt_engine* e, const PtModel& M, const float* gray, int pitch, 
         else if (H == 2) hipLaunchKernelGGL(cvit_dwconv_ln_kernel<2>, grid, block, lds, s, x, CV_T, C, w, b, g, be, xb, x3);
         else hipLaunchKernelGGL(cvit_dwconv_ln_kernel<1>, grid, block, lds, s, x, CV_T, C, w, b, g, be, xb, x3);
       }
-      p.gemm(xb, rp, C, lq + ".pw1", 4 * C, 4, hb);
-      p.gemm(hb, rp, 4 * C, lq + ".pw2", Np, 0, nullptr, x, C, x, Np != C ? C : 0);
+      mlp(p, xb, hb, x, rp, C, lq, "pw1", "pw2");
       if (p.rc != PT_OK) return p.rc;
     }
   }
@@ -513,8 +670,7 @@ int forward_batch(pt_engine* e, const PtModel& M, const float* gray, int pitch, 
     }
     p.gemm(att, Tp, 192, lq + ".out", 192, 0, nullptr, x, 192, x);
     ln(lq + ".ln2", T, 192, 1e-12f, xb, 0, 1, 1);
-    p.gemm(xb, Tp, 192, lq + ".fc1", 768, 4, hb);
-    p.gemm(hb, Tp, 768, lq + ".fc2", 192, 0, nullptr, x, 192, x);
+    mlp(p, xb, hb, x, Tp, 192, lq, "fc1", "fc2");
     if (p.rc != PT_OK) return p.rc;
   }
   ln("vit.ln", T, 192, 1e-12f, feat, 2, 1, 1);

@@ -662,6 +662,21 @@ def pack_convnext_vit(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
         n_to = n_to or w.shape[0]
         bl.add_conv(name, *_pad_conv(w.reshape(w.shape[0], w.shape[1], 1, 1), b, n_to, w.shape[1]))
 
+    # the fused MLP kernel (cvit_mlp_kernel, bf16 mode, C <= 256): W1 rows as they are ([4C][C]: a 32-unit chunk is
+    # contiguous); W2 [C][4C] with the K order of every 32-unit chunk permuted to the MFMA accumulator layout the hidden
+    # values are produced in: slot (s2, half, j) of chunk hc holds hidden unit hc * 32 + (j & 3) + 8 * (2 * s2 + (j >> 2)) +
+    # 4 * half; stored [chunk][C][32]
+    s2_, half_, j_ = np.meshgrid(np.arange(2), np.arange(2), np.arange(8), indexing="ij")
+    perm = torch.from_numpy(((j_ & 3) + 8 * (2 * s2_ + (j_ >> 2)) + 4 * half_).reshape(-1))
+
+    def mlp(name, w1, w2):
+        c = w1.shape[1]
+        if c > 256:
+            return
+        bl.add(name + ".mlp.w1", to_bf16_bits(w1), "bf16")
+        w2c = w2.reshape(c, 4 * c // 32, 32)[:, :, perm].permute(1, 0, 2).contiguous()          # [chunk][C][32]
+        bl.add(name + ".mlp.w2p", to_bf16_bits(w2c), "bf16")
+
     p = "cnn_model."
     f32("embed.w", sd[p + "embeddings.patch_embeddings.weight"].reshape(96, 16))
     f32("embed.b", sd[p + "embeddings.patch_embeddings.bias"])
@@ -680,8 +695,9 @@ def pack_convnext_vit(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
             ln(o + ".ln", lq + "layernorm")
             lin(o + ".pw1", sd[lq + "pwconv1.weight"], sd[lq + "pwconv1.bias"])
             g = sd[lq + "layer_scale_parameter"].double() if (lq + "layer_scale_parameter") in sd else torch.ones(d, dtype=torch.float64)
-            lin(o + ".pw2", (sd[lq + "pwconv2.weight"].double() * g[:, None]).float(), (sd[lq + "pwconv2.bias"].double() * g).float(),
-                n_to=(d + 63) // 64 * 64)
+            w2s = (sd[lq + "pwconv2.weight"].double() * g[:, None]).float()
+            lin(o + ".pw2", w2s, (sd[lq + "pwconv2.bias"].double() * g).float(), n_to=(d + 63) // 64 * 64)
+            mlp(o, sd[lq + "pwconv1.weight"], w2s)
     p = "vitstr.vit."
     lin("vit.embed", sd[p + "embeddings.patch_embeddings.projection.weight"].reshape(192, 512), sd[p + "embeddings.patch_embeddings.projection.bias"])
     f32("vit.pos", sd[p + "embeddings.position_embeddings"][0, 1:, :])
@@ -697,6 +713,7 @@ def pack_convnext_vit(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
         lin(o + ".out", sd[q + "attention.output.dense.weight"], sd[q + "attention.output.dense.bias"])
         lin(o + ".fc1", sd[q + "intermediate.dense.weight"], sd[q + "intermediate.dense.bias"])
         lin(o + ".fc2", sd[q + "output.dense.weight"], sd[q + "output.dense.bias"])
+        mlp(o, sd[q + "intermediate.dense.weight"], sd[q + "output.dense.weight"])
         n += 1
     assert n == 12, f"ConvNextViT: {n} ViT layers in the checkpoint, the launch graph runs 12 (modeling_convnext_vit.py:28-35)"
     ln("vit.ln", p + "layernorm")

@@ -185,3 +185,39 @@ def test_pipeline_with_convnext_vit_recogniser():
         k = min(6, len(r.det_result))
         crops = [ocrnn.crop_image(page, ocrnn.order_point(np.asarray(b, np.float64))) for b in r.det_result[:k]]
         assert [o["text"] for o in r.ocr_result[:k]] == pipe.text_recognizer(crops)
+
+
+def test_fused_mlp_agrees_with_the_two_gemm_path(tmp_path):
+    """bf16 mode: the fused MLP kernel (hidden layer never in HBM, cvit_mlp_kernel) against the two GEMMs through the hidden
+    tensor (PT_CVIT_FUSED_MLP=0 in a child process: the switch is read once).  Same bf16 operands and the same bf16 rounding of
+    the hidden values; the sum over the hidden units runs in another order and GELU's erf is the 1.5e-7 approximation, so
+    the winning logits agree to fp32-accumulation noise -- far inside bf16's own drift -- and the ids wherever the margin is
+    above that noise."""
+    import subprocess
+    import sys
+    script = r'''
+import sys, numpy as np, torch
+from pdf_table_amd import lib as L
+from pdf_table_amd.engine import HipEngine
+from pdf_table_amd.synth_weights import convnext_vit_state_dict
+from pdf_table_amd.weights import pack_convnext_vit
+eng = HipEngine(0)
+eng.load_weights(L.PT_MODEL_CONVNEXT_VIT, pack_convnext_vit(convnext_vit_state_dict(seed=29), x3=False))
+rng = np.random.default_rng(5)
+g = rng.uniform(0, 1, (7, 32, 804)).astype(np.float32)
+g[2, :, 300:] = 0
+ids, mx = eng.rec_cvit_forward_net(torch.from_numpy(g).cuda())
+np.savez(sys.argv[1], ids=ids.cpu().numpy(), mx=mx.cpu().numpy())
+'''
+    outs = []
+    for tag, env in (("fused", {}), ("gemms", {"PT_CVIT_FUSED_MLP": "0"})):
+        out = str(tmp_path / f"{tag}.npz")
+        e = dict(os.environ, **env)
+        e["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + e.get("PYTHONPATH", "")
+        subprocess.run([sys.executable, "-c", script, out], check=True, env=e, timeout=300)
+        outs.append(np.load(out))
+    d = np.abs(outs[0]["mx"] - outs[1]["mx"]).max()
+    same = (outs[0]["ids"] == outs[1]["ids"]).mean()
+    print(f"convnext-vit fused vs two-GEMM MLP: max|d max-logit| = {d:.2e}, {100 * same:.2f} % of the ids equal")
+    assert d <= 0.1 and same >= 0.95          # bf16-class agreement (logit scale ~ 11); the x3 tests carry the 1e-3 contract
+    assert len(np.unique(outs[0]["ids"])) > 3
