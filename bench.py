@@ -255,6 +255,19 @@ def cpu_baseline(sd, pages_np, cfg, csd=None, tsr=None, layout=None, gpu=None):
                 "cpu_s_per_page": t2 - t0, "cpu_det_s": t1 - t0, "cpu_rec_s": t2 - t1, "lines": int(len(b0)),
                 "gpu_ms_per_page_bf16": None if gpu is None else gpu.get("config0_ms"),
                 "gpu_lines": None if gpu is None else gpu.get("config0_lines")}
+    # BASELINE.json configs[4], recogniser half: the ConvNextViT oracle on a few of those lines (batch 1 per line as the reference)
+    cvit = None
+    if csd is not None and cfg0 is not None and len(b0):
+        from oracle import convnext_vit as ocv
+        from pdf_table_amd.synth_weights import convnext_vit_state_dict
+        vsd = ocv.canonical_state_dict(convnext_vit_state_dict(seed=7))
+        k = min(4, len(b0))
+        t0 = time.time()
+        for q in b0[:k]:
+            x = ocv.chunk_preprocess(ocrnn.crop_image(img, ocrnn.order_point(q)))
+            with torch.no_grad():
+                ocv.convnext_vit_forward_fp32(vsd, x).argmax(-1)
+        cvit = {"lines_per_s": k / (time.time() - t0), "sample": f"{k} lines of the configs[0] page, one line (three chunks) per call, fp32 torch CPU"}
     info = cpu_info()
     out = {"value": n / dt, "unit": "pages/s", "cores": cores, "kind": "port", "cpu": info,
            "sample": f"{n} synthetic 1024x1024 page(s), batch 1 per call as the reference runs it, "
@@ -266,6 +279,8 @@ def cpu_baseline(sd, pages_np, cfg, csd=None, tsr=None, layout=None, gpu=None):
            "net_only_pages_per_s": n / t_net}
     if cfg0 is not None:
         out["config0"] = cfg0
+    if cvit is not None:
+        out["convnext_vit"] = cvit
     if parity:
         out["gpu_vs_oracle_on_the_sample"] = parity
     return out
