@@ -383,15 +383,17 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return 0.5f * x * (1.f + copysignf(e, x)) ;
 }
 
-template <int C>
+template <int C, bool PIPE>
 __global__ __launch_bounds__(256, 2) void cvit_mlp_kernel(const bf16_t* __restrict__ xb, const bf16_t* __restrict__ w1,
                                                           const float* __restrict__ b1, const bf16_t* __restrict__ w2p,
                                                           const float* __restrict__ b2, float* __restrict__ x) {
   constexpr int KS = C / 16, NT = C / 32, NCH = 4 * C / 32;
   constexpr int P1 = C * 2 + 16, P2 = 80;              // LDS row pitches in bytes: 16-byte skew, conflict-free ds_read_b128
-  constexpr int STAGE = 32 * P1 + C * P2;
-  constexpr int PIECES = C / 32;                       // 16-byte pieces per thread per chunk (4C of W1 + 4C of W2 over 256 threads)
+  constexpr int S1 = 32 * P1, S2 = C * P2;             // one W1 chunk [32][C], one W2 chunk [C][32]
+  constexpr int PIECES = (4 * C + 255) / 256;          // 16-byte pieces per thread per chunk and matrix (4C pieces each)
   extern __shared__ __attribute__((aligned(16))) char cv_mlp_lds[];
+  char* const w1buf = cv_mlp_lds;                      // two W1 chunks, then two W2 chunks
+  char* const w2buf = cv_mlp_lds + 2 * S1;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
   const long long row = (long long)blockIdx.x * 128 + wave * 32 + col;
   abf16x8 xf[KS];
@@ -405,63 +407,101 @@ __global__ __launch_bounds__(256, 2) void cvit_mlp_kernel(const bf16_t* __restri
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  cu32x4 pre[PIECES];
-  auto load_chunk = [&](int hc) {
-    const char* g1 = reinterpret_cast<const char*>(w1 + (size_t)hc * 32 * C);      // 32 rows x C: 64 C contiguous bytes
-    const char* g2 = reinterpret_cast<const char*>(w2p + (size_t)hc * C * 32);     // C rows x 32 (permuted) k: 64 C bytes
+  cu32x4 pre1[PIECES], pre2[PIECES];
+  auto load1 = [&](int hc) {                            // W1 rows of chunk hc: 64 C contiguous bytes
+    const char* g = reinterpret_cast<const char*>(w1 + (size_t)hc * 32 * C);
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i)
+      if (tid + i * 256 < 4 * C) pre1[i] = *reinterpret_cast<const cu32x4*>(g + (tid + i * 256) * 16);
+  };
+  auto load2 = [&](int hc) {                            // W2 columns of chunk hc ([C][32], K permuted): 64 C contiguous bytes
+    const char* g = reinterpret_cast<const char*>(w2p + (size_t)hc * C * 32);
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i)
+      if (tid + i * 256 < 4 * C) pre2[i] = *reinterpret_cast<const cu32x4*>(g + (tid + i * 256) * 16);
+  };
+  auto store1 = [&](char* buf) {
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
       const int idx = tid + i * 256;
-      pre[i] = *reinterpret_cast<const cu32x4*>(idx < 4 * C ? g1 + idx * 16 : g2 + (idx - 4 * C) * 16);
+      if (idx < 4 * C) *reinterpret_cast<cu32x4*>(buf + (idx / (C / 8)) * P1 + (idx % (C / 8)) * 16) = pre1[i];
     }
   };
-  auto store_chunk = [&](char* buf) {
+  auto store2 = [&](char* buf) {
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
       const int idx = tid + i * 256;
-      char* dst;
-      if (idx < 4 * C) {
-        dst = buf + (idx / (C / 8)) * P1 + (idx % (C / 8)) * 16;
-      } else {
-        const int j = idx - 4 * C;
-        dst = buf + 32 * P1 + (j >> 2) * P2 + (j & 3) * 16;
-      }
-      *reinterpret_cast<cu32x4*>(dst) = pre[i];
+      if (idx < 4 * C) *reinterpret_cast<cu32x4*>(buf + (idx >> 2) * P2 + (idx & 3) * 16) = pre2[i];
     }
   };
-  load_chunk(0);
-  store_chunk(cv_mlp_lds);
-  __syncthreads();
-  for (int hc = 0; hc < NCH; ++hc) {
-    const char* cur = cv_mlp_lds + (hc & 1) * STAGE;
-    if (hc + 1 < NCH) load_chunk(hc + 1);
-    af32x16 d1;
+  auto gemm1 = [&](const char* buf) {
+    af32x16 d;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) d1[r] = 0.f;
-    const char* a1 = cur + col * P1 + half * 16;
+    for (int r = 0; r < 16; ++r) d[r] = 0.f;
+    const char* a1 = buf + col * P1 + half * 16;
 #pragma unroll
     for (int s = 0; s < KS; ++s)
-      d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a1 + s * 32), xf[s], d1, 0, 0, 0);
-    abf16x8 hf[2];
-    const float* bp = b1 + hc * 32 + 4 * half;
+      d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a1 + s * 32), xf[s], d, 0, 0, 0);
+    return d;
+  };
+  auto gelu16 = [&](const af32x16& d, const float* bp, abf16x8 (&h)[2], int r0, int r1) {
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const float4 bb = *reinterpret_cast<const float4*>(bp + 8 * g4);
-      const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int r = 4 * g4 + k;
-        hf[r >> 3][r & 7] = __builtin_bit_cast(__bf16, (uint16_t)f2bf(gelu_fast(d1[r] + bv[k])));
-      }
-    }
-    const char* a2 = cur + 32 * P1 + col * P2 + half * 16;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a2 + t * 32 * P2), hf[0], acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a2 + t * 32 * P2 + 32), hf[1], acc[t], 0, 0, 0);
-    }
-    if (hc + 1 < NCH) store_chunk(cv_mlp_lds + ((hc + 1) & 1) * STAGE);
+    for (int r = r0; r < r1; ++r) h[r >> 3][r & 7] = __builtin_bit_cast(__bf16, (uint16_t)f2bf(gelu_fast(d[r] + bp[8 * (r >> 2) + (r & 3)])));
+  };
+  abf16x8 hf[2];
+  if (PIPE) {
+    // software pipeline (C = 96 / 192): in iteration k the second product of chunk k (MFMA) and the bias + GELU of chunk k + 1
+    // (VALU) are independent instruction streams of the SAME wave, interleaved in program order so that the matrix pipe and
+    // the vector ALU work at the same time.  W1 is staged two chunks ahead, W2 one chunk ahead: two buffers each, one
+    // barrier per chunk.  (C = 256 would spill 140 bytes per lane this way: 664 us against 496 un-pipelined.)
+    load1(0);
+    load2(0);
+    store1(w1buf);
+    store2(w2buf);
+    load1(1);
+    store1(w1buf + S1);
     __syncthreads();
+    abf16x8 hn[2];
+    gelu16(gemm1(w1buf), b1 + 4 * half, hf, 0, 16);
+    for (int hc = 0; hc < NCH; ++hc) {
+      const bool more = hc + 1 < NCH;
+      if (hc + 2 < NCH) load1(hc + 2);
+      if (more) load2(hc + 1);
+      af32x16 d1;
+      const float* bp = b1 + (more ? hc + 1 : hc) * 32 + 4 * half;
+      if (more) d1 = gemm1(w1buf + ((hc + 1) & 1) * S1);
+      const char* a2 = w2buf + (hc & 1) * S2 + col * P2 + half * 16;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a2 + t * 32 * P2), hf[0], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a2 + t * 32 * P2 + 32), hf[1], acc[t], 0, 0, 0);
+        if (more) gelu16(d1, bp, hn, (16 * t) / NT, (16 * (t + 1)) / NT);
+      }
+      if (hc + 2 < NCH) store1(w1buf + (hc & 1) * S1);
+      if (more) store2(w2buf + ((hc + 1) & 1) * S2);
+      __syncthreads();
+      hf[0] = hn[0];
+      hf[1] = hn[1];
+    }
+  } else {
+    load1(0);
+    load2(0);
+    store1(w1buf);
+    store2(w2buf);
+    __syncthreads();
+    for (int hc = 0; hc < NCH; ++hc) {
+      const bool more = hc + 1 < NCH;
+      if (more) { load1(hc + 1); load2(hc + 1); }
+      gelu16(gemm1(w1buf + (hc & 1) * S1), b1 + hc * 32 + 4 * half, hf, 0, 16);
+      const char* a2 = w2buf + (hc & 1) * S2 + col * P2 + half * 16;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a2 + t * 32 * P2), hf[0], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a2 + t * 32 * P2 + 32), hf[1], acc[t], 0, 0, 0);
+      }
+      if (more) { store1(w1buf + ((hc + 1) & 1) * S1); store2(w2buf + ((hc + 1) & 1) * S2); }
+      __syncthreads();
+    }
   }
   float* xr = x + row * C + 4 * half;
 #pragma unroll
@@ -476,16 +516,16 @@ __global__ __launch_bounds__(256, 2) void cvit_mlp_kernel(const bf16_t* __restri
     }
 }
 
-template <int C>
+template <int C, bool PIPE>
 int launch_mlp(const bf16_t* xb, const bf16_t* w1, const float* b1, const bf16_t* w2p, const float* b2, float* x, long long rows_pad,
                hipStream_t s) {
   constexpr int SMEM = 2 * (32 * (C * 2 + 16) + C * 80);
   static bool attr_done = false;
   if (!attr_done) {
-    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cvit_mlp_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cvit_mlp_kernel<C, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_done = true;
   }
-  hipLaunchKernelGGL(cvit_mlp_kernel<C>, dim3((unsigned)(rows_pad / 128)), dim3(256), SMEM, s, xb, w1, b1, w2p, b2, x);
+  hipLaunchKernelGGL((cvit_mlp_kernel<C, PIPE>), dim3((unsigned)(rows_pad / 128)), dim3(256), SMEM, s, xb, w1, b1, w2p, b2, x);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
@@ -547,8 +587,10 @@ void mlp(Net& p, const bf16_t* xb, bf16_t* hb, float* x, long long rows_pad, int
     PtProfScope ps(p.e, p.s, PT_PROF_CONV1X1, 16.0 * rows_pad * (double)C * C, "cvit fused mlp");
     const bf16_t* W1 = reinterpret_cast<const bf16_t*>(w1->d_ptr);
     const bf16_t* W2 = reinterpret_cast<const bf16_t*>(w2->d_ptr);
-    int r = C == 96 ? launch_mlp<96>(xb, W1, b1, W2, b2, x, rows_pad, p.s)
-                    : (C == 192 ? launch_mlp<192>(xb, W1, b1, W2, b2, x, rows_pad, p.s) : launch_mlp<256>(xb, W1, b1, W2, b2, x, rows_pad, p.s));
+    int r;
+    if (C == 96) r = launch_mlp<96, true>(xb, W1, b1, W2, b2, x, rows_pad, p.s);
+    else if (C == 192) r = launch_mlp<192, true>(xb, W1, b1, W2, b2, x, rows_pad, p.s);
+    else r = launch_mlp<256, false>(xb, W1, b1, W2, b2, x, rows_pad, p.s);
     if (r != PT_OK) p.rc = r;
     return;
   }

@@ -63,3 +63,56 @@ def test_chunk_preprocess_layout_and_greedy_text():
     for t, c in enumerate([0, 3, 3, 0, 3, 2]):
         logits[0, t, c] = 1.0
     assert ocv.greedy_text(logits, ["a", "b", "c"]) == ["bba"]
+
+
+def _read_blob(raw):
+    """the PTW1 container of pdf_table_amd/weights.py: name -> ndarray"""
+    import struct
+    assert raw[:4] == b"PTW1"
+    n = struct.unpack("<I", raw[4:8])[0]
+    out = {}
+    for i in range(n):
+        name, dt, nd, *rest = struct.unpack("<96sII6IQQ", raw[8 + i * 144: 8 + (i + 1) * 144])
+        dims, off, nb = rest[:6][:nd], rest[6], rest[7]
+        dtype = {0: np.uint16, 1: np.float32, 2: np.int32}[dt]
+        out[name.rstrip(b"\0").decode()] = np.frombuffer(raw, dtype=dtype, count=nb // np.dtype(dtype).itemsize, offset=off).reshape(dims)
+    return out
+
+
+def test_packer_layouts_the_kernels_rely_on():
+    """pack_convnext_vit: layer scale folded into pwconv2, 1/8 folded into the query rows, the (2,1) down-sampler as K = 2C,
+    and the fused-MLP layouts -- W1 rows as they are, W2 columns per 32-unit chunk in the MFMA accumulator order."""
+    from pdf_table_amd.weights import pack_convnext_vit
+    sd = convnext_vit_state_dict(seed=3)
+    t = _read_blob(pack_convnext_vit(sd, x3=False))
+
+    def bf(a):
+        return torch.from_numpy(a.astype(np.int32) << 16).view(torch.float32) if False else \
+            torch.from_numpy((a.astype(np.uint32) << 16).view(np.float32))
+
+    q = "cnn_model.encoder.stages.1.layers.2."
+    w1, w2, g = sd[q + "pwconv1.weight"], sd[q + "pwconv2.weight"], sd[q + "layer_scale_parameter"]
+    assert torch.equal(bf(t["s1.l2.mlp.w1"]), w1.to(torch.bfloat16).float())
+    w2s = (w2.double() * g.double()[:, None]).float().to(torch.bfloat16).float()             # [192, 768]
+    got = bf(t["s1.l2.mlp.w2p"])                                                            # [24 chunks][192][32]
+    assert tuple(got.shape) == (24, 192, 32)
+    for s2 in range(2):
+        for half in range(2):
+            for j in range(8):
+                hidden = (j & 3) + 8 * (2 * s2 + (j >> 2)) + 4 * half
+                assert torch.equal(got[5, :, s2 * 16 + half * 8 + j], w2s[:, 5 * 32 + hidden])
+    np.testing.assert_allclose(t["s1.l2.pw2.b"], (sd[q + "pwconv2.bias"].double() * g.double()).float().numpy(), rtol=0, atol=0)
+    assert "s3.l0.mlp.w1" not in t and "s2.l7.mlp.w1" in t and "vit.l11.mlp.w2p" in t       # C = 512 keeps the two-GEMM path
+    # q rows carry 1/sqrt(64); biases too
+    a = "vitstr.vit.encoder.layer.4.attention.attention."
+    np.testing.assert_array_equal(t["vit.l4.qkv.b"][:192], (sd[a + "query.bias"] * 0.125).numpy())
+    np.testing.assert_array_equal(t["vit.l4.qkv.b"][192:384], sd[a + "key.bias"].numpy())
+    # tap-major depthwise weights, position table without the class-token slot, classifier padding
+    np.testing.assert_array_equal(t["s0.l0.dw.w"], sd["cnn_model.encoder.stages.0.layers.0.dwconv.weight"].reshape(96, 49).t().numpy())
+    np.testing.assert_array_equal(t["vit.pos"], sd["vitstr.vit.embeddings.position_embeddings"][0, 1:].numpy())
+    assert t["cls.b"].shape == (7680,) and (t["cls.b"][7644:] == np.float32(-3.0e38)).all()
+    # down-sampler: K index = row * Cin + c
+    wd = sd["cnn_model.encoder.stages.2.downsampling_layer.1.weight"]                         # [256, 192, 2, 1]
+    tiles = bf(t["s2.down.w"])                                                              # [N/64][K/32][1][64][32]
+    flat = tiles.permute(0, 3, 1, 2, 4).reshape(256, 384)
+    assert torch.equal(flat[:, :192], wd[:, :, 0, 0].to(torch.bfloat16).float()) and torch.equal(flat[:, 192:], wd[:, :, 1, 0].to(torch.bfloat16).float())
