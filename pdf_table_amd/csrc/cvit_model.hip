@@ -388,14 +388,48 @@ __global__ __launch_bounds__(256, 2) void cvit_mlp_kernel(const bf16_t* __restri
                                                           const float* __restrict__ b1, const bf16_t* __restrict__ w2p,
                                                           const float* __restrict__ b2, float* __restrict__ x) {
   constexpr int KS = C / 16, NT = C / 32, NCH = 4 * C / 32;
-  constexpr int P1 = C * 2 + 16, P2 = 80;              // LDS row pitches in bytes: 16-byte skew, conflict-free ds_read_b128
-  constexpr int S1 = 32 * P1, S2 = C * P2;             // one W1 chunk [32][C], one W2 chunk [C][32]
-  constexpr int PIECES = (4 * C + 255) / 256;          // 16-byte pieces per thread per chunk and matrix (4C pieces each)
+  constexpr int U1 = C / 8;                            // 16-byte units per W1 row
+  constexpr int S1 = 32 * C * 2, S2 = C * 64;          // one W1 chunk [32][C], one W2 chunk [C][32], bytes
+  constexpr int NI = C / 16;                           // DMA wave-instructions (64 units of 16 bytes) per chunk and matrix
+  constexpr int SLOTS = (NI + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) char cv_mlp_lds[];
-  char* const w1buf = cv_mlp_lds;                      // two W1 chunks, then two W2 chunks
+  char* const w1buf = cv_mlp_lds;                      // two W1 chunks, then two W2 chunks, then b1
   char* const w2buf = cv_mlp_lds + 2 * S1;
+  float* const b1s = reinterpret_cast<float*>(cv_mlp_lds + 2 * S1 + 2 * S2);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
   const long long row = (long long)blockIdx.x * 128 + wave * 32 + col;
+  for (int i = tid; i < 4 * C; i += 256) b1s[i] = b1[i];
+  // The weight chunks go global -> LDS by DMA (global_load_lds: no staging registers, no ds_write): a wave instruction
+  // fills 1 KB of LDS in lane order, the lane picks the SOURCE.  No row padding is possible that way, so the 16-byte units
+  // of a row are XOR-swizzled with the row number instead (rows are a multiple of 64 bytes apart): eight consecutive rows
+  // read at the same unit index then sit in eight different 16-byte bank groups -- conflict-free ds_read_b128.
+  const int sw1 = C == 96 ? ((col >> 1) & 3) : (col & 7);            // W1: row = the lane's hidden unit
+  const int sw2 = (col >> 1) & 3;                                     // W2: row = the lane's output channel
+  int src1[SLOTS], src2[SLOTS];
+#pragma unroll
+  for (int j = 0; j < SLOTS; ++j) {
+    const int U = (wave + 4 * j) * 64 + lane;
+    const int r1 = U / U1, u1 = U % U1;
+    src1[j] = r1 * (2 * C) + ((u1 ^ (C == 96 ? ((r1 >> 1) & 3) : (r1 & 7))) << 4);
+    const int r2 = U >> 2, u2 = U & 3;
+    src2[j] = r2 * 64 + ((u2 ^ ((r2 >> 1) & 3)) << 4);
+  }
+  auto issue1 = [&](int hc, char* buf) {
+    const char* g = reinterpret_cast<const char*>(w1) + (size_t)hc * S1;
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j)
+      if (wave + 4 * j < NI)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + src1[j]),
+                                         (__attribute__((address_space(3))) void*)(buf + (wave + 4 * j) * 1024), 16, 0, 0);
+  };
+  auto issue2 = [&](int hc, char* buf) {
+    const char* g = reinterpret_cast<const char*>(w2p) + (size_t)hc * S2;
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j)
+      if (wave + 4 * j < NI)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + src2[j]),
+                                         (__attribute__((address_space(3))) void*)(buf + (wave + 4 * j) * 1024), 16, 0, 0);
+  };
   abf16x8 xf[KS];
   {
     const bf16_t* xr = xb + row * C + half * 8;
@@ -407,42 +441,25 @@ __global__ __launch_bounds__(256, 2) void cvit_mlp_kernel(const bf16_t* __restri
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  cu32x4 pre1[PIECES], pre2[PIECES];
-  auto load1 = [&](int hc) {                            // W1 rows of chunk hc: 64 C contiguous bytes
-    const char* g = reinterpret_cast<const char*>(w1 + (size_t)hc * 32 * C);
-#pragma unroll
-    for (int i = 0; i < PIECES; ++i)
-      if (tid + i * 256 < 4 * C) pre1[i] = *reinterpret_cast<const cu32x4*>(g + (tid + i * 256) * 16);
-  };
-  auto load2 = [&](int hc) {                            // W2 columns of chunk hc ([C][32], K permuted): 64 C contiguous bytes
-    const char* g = reinterpret_cast<const char*>(w2p + (size_t)hc * C * 32);
-#pragma unroll
-    for (int i = 0; i < PIECES; ++i)
-      if (tid + i * 256 < 4 * C) pre2[i] = *reinterpret_cast<const cu32x4*>(g + (tid + i * 256) * 16);
-  };
-  auto store1 = [&](char* buf) {
-#pragma unroll
-    for (int i = 0; i < PIECES; ++i) {
-      const int idx = tid + i * 256;
-      if (idx < 4 * C) *reinterpret_cast<cu32x4*>(buf + (idx / (C / 8)) * P1 + (idx % (C / 8)) * 16) = pre1[i];
-    }
-  };
-  auto store2 = [&](char* buf) {
-#pragma unroll
-    for (int i = 0; i < PIECES; ++i) {
-      const int idx = tid + i * 256;
-      if (idx < 4 * C) *reinterpret_cast<cu32x4*>(buf + (idx >> 2) * P2 + (idx & 3) * 16) = pre2[i];
-    }
-  };
   auto gemm1 = [&](const char* buf) {
     af32x16 d;
 #pragma unroll
     for (int r = 0; r < 16; ++r) d[r] = 0.f;
-    const char* a1 = buf + col * P1 + half * 16;
+    const char* a1 = buf + col * (2 * C);
 #pragma unroll
     for (int s = 0; s < KS; ++s)
-      d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a1 + s * 32), xf[s], d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a1 + (((2 * s + half) ^ sw1) << 4)), xf[s], d, 0, 0, 0);
     return d;
+  };
+  // second product of one chunk: the two k-steps of a tile are dependent, so all first steps are issued before the second ones
+  auto gemm2 = [&](const char* buf, const abf16x8 (&h)[2]) {
+    const char* a2 = buf + col * 64;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a2 + t * 2048 + (((2 * s2 + half) ^ sw2) << 4)), h[s2],
+                                                          acc[t], 0, 0, 0);
   };
   auto gelu16 = [&](const af32x16& d, const float* bp, abf16x8 (&h)[2], int r0, int r1) {
 #pragma unroll
@@ -453,54 +470,47 @@ __global__ __launch_bounds__(256, 2) void cvit_mlp_kernel(const bf16_t* __restri
     // software pipeline (C = 96 / 192): in iteration k the second product of chunk k (MFMA) and the bias + GELU of chunk k + 1
     // (VALU) are independent instruction streams of the SAME wave, interleaved in program order so that the matrix pipe and
     // the vector ALU work at the same time.  W1 is staged two chunks ahead, W2 one chunk ahead: two buffers each, one
-    // barrier per chunk.  (C = 256 would spill 140 bytes per lane this way: 664 us against 496 un-pipelined.)
-    load1(0);
-    load2(0);
-    store1(w1buf);
-    store2(w2buf);
-    load1(1);
-    store1(w1buf + S1);
+    // barrier per chunk.  (C = 256 has no registers left for the second set of hidden values.)
+    issue1(0, w1buf);
+    issue2(0, w2buf);
+    issue1(1, w1buf + S1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     abf16x8 hn[2];
-    gelu16(gemm1(w1buf), b1 + 4 * half, hf, 0, 16);
+    gelu16(gemm1(w1buf), b1s + 4 * half, hf, 0, 16);
     for (int hc = 0; hc < NCH; ++hc) {
       const bool more = hc + 1 < NCH;
-      if (hc + 2 < NCH) load1(hc + 2);
-      if (more) load2(hc + 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();            // chunk hc's W2 and chunk hc + 1's W1 have landed; the buffers of hc - 1 are free
+      if (hc + 2 < NCH) issue1(hc + 2, w1buf + (hc & 1) * S1);
+      if (more) issue2(hc + 1, w2buf + ((hc + 1) & 1) * S2);
       af32x16 d1;
-      const float* bp = b1 + (more ? hc + 1 : hc) * 32 + 4 * half;
+      const float* bp = b1s + (more ? hc + 1 : hc) * 32 + 4 * half;
       if (more) d1 = gemm1(w1buf + ((hc + 1) & 1) * S1);
-      const char* a2 = w2buf + (hc & 1) * S2 + col * P2 + half * 16;
+      const char* a2 = w2buf + (hc & 1) * S2 + col * 64;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a2 + t * 32 * P2), hf[0], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a2 + t * 32 * P2 + 32), hf[1], acc[t], 0, 0, 0);
-        if (more) gelu16(d1, bp, hn, (16 * t) / NT, (16 * (t + 1)) / NT);
-      }
-      if (hc + 2 < NCH) store1(w1buf + (hc & 1) * S1);
-      if (more) store2(w2buf + ((hc + 1) & 1) * S2);
-      __syncthreads();
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a2 + t * 2048 + (((2 * s2 + half) ^ sw2) << 4)),
+                                                            hf[s2], acc[t], 0, 0, 0);
+          if (more) gelu16(d1, bp, hn, (16 * (s2 * NT + t)) / (2 * NT), (16 * (s2 * NT + t + 1)) / (2 * NT));
+        }
       hf[0] = hn[0];
       hf[1] = hn[1];
     }
   } else {
-    load1(0);
-    load2(0);
-    store1(w1buf);
-    store2(w2buf);
-    __syncthreads();
+    issue1(0, w1buf);
+    issue2(0, w2buf);
     for (int hc = 0; hc < NCH; ++hc) {
-      const bool more = hc + 1 < NCH;
-      if (more) { load1(hc + 1); load2(hc + 1); }
-      gelu16(gemm1(w1buf + (hc & 1) * S1), b1 + hc * 32 + 4 * half, hf, 0, 16);
-      const char* a2 = w2buf + (hc & 1) * S2 + col * P2 + half * 16;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a2 + t * 32 * P2), hf[0], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a2 + t * 32 * P2 + 32), hf[1], acc[t], 0, 0, 0);
-      }
-      if (more) { store1(w1buf + ((hc + 1) & 1) * S1); store2(w2buf + ((hc + 1) & 1) * S2); }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      if (hc + 1 < NCH) {
+        issue1(hc + 1, w1buf + ((hc + 1) & 1) * S1);
+        issue2(hc + 1, w2buf + ((hc + 1) & 1) * S2);
+      }
+      gelu16(gemm1(w1buf + (hc & 1) * S1), b1s + hc * 32 + 4 * half, hf, 0, 16);
+      gemm2(w2buf + (hc & 1) * S2, hf);
     }
   }
   float* xr = x + row * C + 4 * half;
@@ -519,7 +529,7 @@ __global__ __launch_bounds__(256, 2) void cvit_mlp_kernel(const bf16_t* __restri
 template <int C, bool PIPE>
 int launch_mlp(const bf16_t* xb, const bf16_t* w1, const float* b1, const bf16_t* w2p, const float* b2, float* x, long long rows_pad,
                hipStream_t s) {
-  constexpr int SMEM = 2 * (32 * (C * 2 + 16) + C * 80);
+  constexpr int SMEM = 2 * (32 * C * 2 + C * 64) + 4 * C * 4;
   static bool attr_done = false;
   if (!attr_done) {
     PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cvit_mlp_kernel<C, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
