@@ -374,6 +374,8 @@ __global__ __launch_bounds__(64) void cvit_attention_kernel(const bf16_t* __rest
 // right after, 2^-9 relative.  The hi/lo mode keeps the two-GEMM path with erff.
 // ---------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) uint32_t cu32x4;
+typedef __attribute__((ext_vector_type(2))) float mlp_f2;
+typedef __attribute__((ext_vector_type(2))) __bf16 mlp_b2;
 
 __device__ __forceinline__ float gelu_fast(float x) {
   const float z = fabsf(x) * 0.70710678118654752f;
@@ -461,9 +463,16 @@ __global__ __launch_bounds__(256, 2) void cvit_mlp_kernel(const bf16_t* __restri
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a2 + t * 2048 + (((2 * s2 + half) ^ sw2) << 4)), h[s2],
                                                           acc[t], 0, 0, 0);
   };
-  auto gelu16 = [&](const af32x16& d, const float* bp, abf16x8 (&h)[2], int r0, int r1) {
+  // bias + GELU + bf16 (v_cvt_pk_bf16_f32: round to nearest even, two values per instruction) of the value PAIRS [p0, p1)
+  auto gelu16 = [&](const af32x16& d, const float* bp, abf16x8 (&h)[2], int p0, int p1) {
 #pragma unroll
-    for (int r = r0; r < r1; ++r) h[r >> 3][r & 7] = __builtin_bit_cast(__bf16, (uint16_t)f2bf(gelu_fast(d[r] + bp[8 * (r >> 2) + (r & 3)])));
+    for (int q = p0; q < p1; ++q) {
+      const int r = 2 * q;
+      const mlp_f2 v = {gelu_fast(d[r] + bp[8 * (r >> 2) + (r & 3)]), gelu_fast(d[r + 1] + bp[8 * (r >> 2) + (r & 3) + 1])};
+      const mlp_b2 pk = __builtin_convertvector(v, mlp_b2);
+      h[r >> 3][r & 7] = pk[0];
+      h[r >> 3][(r & 7) + 1] = pk[1];
+    }
   };
   abf16x8 hf[2];
   if (PIPE) {
@@ -477,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void cvit_mlp_kernel(const bf16_t* __restri
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     abf16x8 hn[2];
-    gelu16(gemm1(w1buf), b1s + 4 * half, hf, 0, 16);
+    gelu16(gemm1(w1buf), b1s + 4 * half, hf, 0, 8);
     for (int hc = 0; hc < NCH; ++hc) {
       const bool more = hc + 1 < NCH;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -494,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void cvit_mlp_kernel(const bf16_t* __restri
         for (int t = 0; t < NT; ++t) {
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a2 + t * 2048 + (((2 * s2 + half) ^ sw2) << 4)),
                                                             hf[s2], acc[t], 0, 0, 0);
-          if (more) gelu16(d1, bp, hn, (16 * (s2 * NT + t)) / (2 * NT), (16 * (s2 * NT + t + 1)) / (2 * NT));
+          if (more) gelu16(d1, bp, hn, (8 * (s2 * NT + t)) / (2 * NT), (8 * (s2 * NT + t + 1)) / (2 * NT));
         }
       hf[0] = hn[0];
       hf[1] = hn[1];
@@ -509,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void cvit_mlp_kernel(const bf16_t* __restri
         issue1(hc + 1, w1buf + ((hc + 1) & 1) * S1);
         issue2(hc + 1, w2buf + ((hc + 1) & 1) * S2);
       }
-      gelu16(gemm1(w1buf + (hc & 1) * S1), b1s + hc * 32 + 4 * half, hf, 0, 16);
+      gelu16(gemm1(w1buf + (hc & 1) * S1), b1s + hc * 32 + 4 * half, hf, 0, 8);
       gemm2(w2buf + (hc & 1) * S2, hf);
     }
   }
