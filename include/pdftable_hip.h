@@ -247,7 +247,10 @@ int pt_rec_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int
  * resize to 32 x 804, three 300-px chunks at 252-px steps; ConvNextViT.forward (model/convnext_vit/modeling_convnext_vit.py:
  * 38-45, modeling_convnext.py:29-131, modeling_vit.py:31-143): every chunk through the ConvNext CNN and the 12-layer ViT, the
  * chunks' 75 tokens stitched to 201 per line, Linear(192 -> 7644); then the arg-max of OCRRecognitionPostProcessor (:147-150).
- *   d_ids / d_maxlogit: [n_lines, PT_CVIT_T] arg-max class (0 = CTC blank, vocabulary from class 2) and its logit. */
+ *   d_ids / d_maxlogit: [n_lines, PT_CVIT_T] arg-max class (0 = CTC blank, vocabulary from class 2) and its logit.
+ *   h_crop_wh (HOST int32 [n_lines][2] = crop_w, crop_h; may be NULL): with the crop sizes known on the host, the 300-px chunks
+ *   that hold no text (text width after the resize <= 252 j for chunk j) are not computed line by line: every all-padding
+ *   chunk yields the same 75 tokens, so ONE is computed per call and shared -- bit-identical results. */
 #define PT_CVIT_W 804          /* OCRRecognitionConfig.img_width with do_chunking (configuration_ocr_recognition.py:47) */
 #define PT_CVIT_CHUNK_W 300    /* processor_ocr_recognition.py:105-106 */
 #define PT_CVIT_CHUNK_STEP 252 /* 300 - 48 */
@@ -255,14 +258,16 @@ int pt_rec_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int
 #define PT_CVIT_NCLS 7644      /* modeling_convnext_vit.py:33 */
 /* lines cut from resident pages (as pt_rec_forward) */
 int pt_rec_cvit_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int h, int w, const pt_rec_line* d_lines,
-                        const int64_t* h_crop_px, int n_lines, int32_t* d_ids, float* d_maxlogit, pt_stream stream);
+                        const int64_t* h_crop_px, const int32_t* h_crop_wh, int n_lines, int32_t* d_ids, float* d_maxlogit,
+                        pt_stream stream);
 /* lines that are already cropped (as pt_rec_forward_crops) */
 int pt_rec_cvit_forward_crops(pt_engine* e, const uint8_t* d_crops_rgb, const pt_rec_line* d_lines, const int64_t* h_crop_px,
-                              int n_lines, int32_t* d_ids, float* d_maxlogit, pt_stream stream);
+                              const int32_t* h_crop_wh, int n_lines, int32_t* d_ids, float* d_maxlogit, pt_stream stream);
 /* Network only.  d_gray fp32 in [0, 1]: layout 0 = chunks [3 n_lines, 32, 300] (the tensor the reference's model receives,
- * gray), layout 1 = lines [n_lines, 32, 804] (chunk j = columns [252 j, 252 j + 300)). */
-int pt_rec_cvit_forward_net(pt_engine* e, const float* d_gray, int layout, int n_lines, int32_t* d_ids, float* d_maxlogit,
-                            pt_stream stream);
+ * gray), layout 1 = lines [n_lines, 32, 804] (chunk j = columns [252 j, 252 j + 300)).  h_text_w (HOST int32 [n_lines], may be
+ * NULL): columns >= h_text_w[i] of line i are zero padding (same chunk sharing as h_crop_wh above). */
+int pt_rec_cvit_forward_net(pt_engine* e, const float* d_gray, int layout, int n_lines, const int32_t* h_text_w, int32_t* d_ids,
+                            float* d_maxlogit, pt_stream stream);
 /* Resize + gray only (tests): d_gray fp32 [n_lines, 32, 804]. */
 int pt_rec_cvit_preprocess_crops(pt_engine* e, const uint8_t* d_crops_rgb, const pt_rec_line* d_lines, const int64_t* h_crop_px,
                                  int n_lines, float* d_gray, pt_stream stream);

@@ -577,11 +577,26 @@ static int cvit_microbatch() {
   return mb;
 }
 
-int pt_rec_cvit_forward_net(pt_engine* e, const float* d_gray, int layout, int n_lines, int32_t* d_ids, float* d_maxlogit,
-                            pt_stream stream) {
+int pt_rec_cvit_forward_net(pt_engine* e, const float* d_gray, int layout, int n_lines, const int32_t* h_text_w, int32_t* d_ids,
+                            float* d_maxlogit, pt_stream stream) {
   PT_REQUIRE(e && d_gray && d_ids && n_lines > 0, "pt_rec_cvit_forward_net: bad arguments");
   PT_HIP_CHECK(hipSetDevice(e->device));
-  return pt_cvit_forward_net(e, d_gray, layout, n_lines, d_ids, d_maxlogit, reinterpret_cast<hipStream_t>(stream));
+  return pt_cvit_forward_net(e, d_gray, layout, n_lines, d_ids, d_maxlogit, reinterpret_cast<hipStream_t>(stream), h_text_w);
+}
+
+// text width of every line after OCRRecognitionPreprocessor.keepratio_resize (processor_ocr_recognition.py:44-53), the formula
+// of rec_resize_gray_kernel in the same IEEE double arithmetic
+static void cvit_text_widths(const int32_t* h_crop_wh, int i0, int n, std::vector<int>& tw) {
+  tw.resize((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    const int cw = h_crop_wh[2 * (i0 + i)], ch = h_crop_wh[2 * (i0 + i) + 1];
+    int nw = 0;
+    if (cw > 0 && ch > 0) {
+      const double ratio = (double)cw / (double)ch;
+      nw = ratio > (double)PT_CVIT_W / (double)PT_REC_H ? PT_CVIT_W : (int)((double)PT_REC_H * ratio);
+    }
+    tw[(size_t)i] = nw;
+  }
 }
 
 // crop offsets of already-cropped lines -> device (host prefix sum; the copy is waited for: `off` is reused by the next call)
@@ -607,7 +622,7 @@ int pt_rec_cvit_preprocess_crops(pt_engine* e, const uint8_t* d_crops_rgb, const
 }
 
 int pt_rec_cvit_forward_crops(pt_engine* e, const uint8_t* d_crops_rgb, const pt_rec_line* d_lines, const int64_t* h_crop_px,
-                              int n_lines, int32_t* d_ids, float* d_maxlogit, pt_stream stream) {
+                              const int32_t* h_crop_wh, int n_lines, int32_t* d_ids, float* d_maxlogit, pt_stream stream) {
   PT_REQUIRE(e && d_crops_rgb && d_lines && h_crop_px && d_ids && n_lines > 0, "pt_rec_cvit_forward_crops: bad arguments");
   PT_HIP_CHECK(hipSetDevice(e->device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -621,15 +636,18 @@ int pt_rec_cvit_forward_crops(pt_engine* e, const uint8_t* d_crops_rgb, const pt
     const int nb = (n_lines - i0) < mb ? (n_lines - i0) : mb;
     rc = pt_launch_rec_resize_gray_f32(d_crops_rgb, d_lines + i0, d_off + i0, nb, PT_CVIT_W, reinterpret_cast<float*>(e->rec_gray), s);
     if (rc != PT_OK) return rc;
+    std::vector<int> tw;
+    if (h_crop_wh) cvit_text_widths(h_crop_wh, i0, nb, tw);
     rc = pt_cvit_forward_net(e, reinterpret_cast<const float*>(e->rec_gray), 1, nb, d_ids + (size_t)i0 * PT_CVIT_T,
-                             d_maxlogit ? d_maxlogit + (size_t)i0 * PT_CVIT_T : nullptr, s);
+                             d_maxlogit ? d_maxlogit + (size_t)i0 * PT_CVIT_T : nullptr, s, h_crop_wh ? tw.data() : nullptr);
     if (rc != PT_OK) return rc;
   }
   return PT_OK;
 }
 
 int pt_rec_cvit_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int h, int w, const pt_rec_line* d_lines,
-                        const int64_t* h_crop_px, int n_lines, int32_t* d_ids, float* d_maxlogit, pt_stream stream) {
+                        const int64_t* h_crop_px, const int32_t* h_crop_wh, int n_lines, int32_t* d_ids, float* d_maxlogit,
+                        pt_stream stream) {
   PT_REQUIRE(e && d_pages_rgb && d_lines && h_crop_px && d_ids && n_lines > 0, "pt_rec_cvit_forward: bad arguments");
   PT_HIP_CHECK(hipSetDevice(e->device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -655,8 +673,10 @@ int pt_rec_cvit_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, i
     rc = pt_launch_rec_resize_gray_f32(reinterpret_cast<const uint8_t*>(e->rec_crops), d_lines + i0, d_off, nb, PT_CVIT_W,
                                        reinterpret_cast<float*>(e->rec_gray), s);
     if (rc != PT_OK) return rc;
+    std::vector<int> tw;
+    if (h_crop_wh) cvit_text_widths(h_crop_wh, i0, nb, tw);
     rc = pt_cvit_forward_net(e, reinterpret_cast<const float*>(e->rec_gray), 1, nb, d_ids + (size_t)i0 * PT_CVIT_T,
-                             d_maxlogit ? d_maxlogit + (size_t)i0 * PT_CVIT_T : nullptr, s);
+                             d_maxlogit ? d_maxlogit + (size_t)i0 * PT_CVIT_T : nullptr, s, h_crop_wh ? tw.data() : nullptr);
     if (rc != PT_OK) return rc;
   }
   return PT_OK;

@@ -266,7 +266,9 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
                         const pt_rec_line* d_lines = nullptr);
 
 // gray fp32, layout 0 = chunks [3 n, 32, 300], 1 = lines [n, 32, 804]; ids int32 [n, PT_CVIT_T] (cvit_model.hip)
-int pt_cvit_forward_net(pt_engine* e, const float* gray, int layout, int n, int32_t* ids, float* maxlogit, hipStream_t s);
+// h_text_w (HOST, may be null): text width of every line after the keep-ratio resize -- all-padding chunks are then computed once
+int pt_cvit_forward_net(pt_engine* e, const float* gray, int layout, int n, int32_t* ids, float* maxlogit, hipStream_t s,
+                        const int* h_text_w = nullptr);
 int pt_launch_rec_resize_gray_f32(const uint8_t* crops, const pt_rec_line* lines, const long long* pix_off, int n_lines, int tw,
                                   float* out, hipStream_t s);
 

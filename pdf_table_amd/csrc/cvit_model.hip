@@ -29,6 +29,7 @@
 #include <stdlib.h>
 
 #include <string>
+#include <vector>
 
 #include "common.h"
 
@@ -61,18 +62,25 @@ __device__ __forceinline__ float wave_sum(float v) {
 // gray fp32; chunk c = 3 * line + j starts at gray + line * lstride + j * jstride, rows `pitch` apart.  A LANE owns one output
 // pixel and all 96 channels of it: the weights are wave-uniform (scalar loads), the LayerNorm is in-lane -- no cross-lane step.
 __global__ __launch_bounds__(256) void cvit_embed_kernel(const float* __restrict__ gray, int pitch, long long jstride, long long lstride,
-                                                         int nchunks, const float* __restrict__ w, const float* __restrict__ b,
-                                                         const float* __restrict__ g, const float* __restrict__ beta,
-                                                         float* __restrict__ x) {
+                                                         int nchunks, const int* __restrict__ csrc, const float* __restrict__ w,
+                                                         const float* __restrict__ b, const float* __restrict__ g,
+                                                         const float* __restrict__ beta, float* __restrict__ x) {
   const long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= (long long)nchunks * CV_PIX0) return;
-  const int chunk = (int)(pix / CV_PIX0), r = (int)(pix % CV_PIX0), oy = r / CV_T, ox = r % CV_T;
-  const float* src = gray + (long long)(chunk / 3) * lstride + (long long)(chunk % 3) * jstride + (size_t)(oy * 4) * pitch + ox * 4;
+  // csrc != null: the batch holds only the chunks with text in them; csrc[k] = 3 line + j of compact chunk k, -1 = the
+  // all-padding chunk (zeros)
+  const int k = (int)(pix / CV_PIX0), r = (int)(pix % CV_PIX0), oy = r / CV_T, ox = r % CV_T;
+  const int chunk = csrc ? csrc[k] : k;
   float in[16];
 #pragma unroll
-  for (int dy = 0; dy < 4; ++dy)
+  for (int i = 0; i < 16; ++i) in[i] = 0.f;
+  if (chunk >= 0) {
+    const float* src = gray + (long long)(chunk / 3) * lstride + (long long)(chunk % 3) * jstride + (size_t)(oy * 4) * pitch + ox * 4;
 #pragma unroll
-    for (int dx = 0; dx < 4; ++dx) in[dy * 4 + dx] = src[dy * pitch + dx];
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 4; ++dx) in[dy * 4 + dx] = src[dy * pitch + dx];
+  }
   float v[96];
   float sum = 0.f;
 #pragma unroll
@@ -195,11 +203,13 @@ __global__ __launch_bounds__(512) void cvit_dwconv_ln_kernel(const float* __rest
 //   mode 0: out row = row
 //   mode 1: ConvNextStage down-sampler input: row = (b, y, x) of a [B, H, W] map goes to row (b, y / 2, x) of a [B, H/2, W]
 //           map with 2C channels, at channel offset (y & 1) * C -- the K layout of the (2,1)-kernel conv as a 1x1 GEMM
-//   mode 2: chunk stitching (modeling_vit.py:133-138): row = (chunk = 3 line + j, t); kept tokens go to row line * 201 + pos
+//   mode 2: chunk stitching (modeling_vit.py:133-138), gather form: OUTPUT row = (line, pos) of the 201-token sequence takes
+//           token t of chunk j (pos < 69: chunk 0; < 132: chunk 1 from its token 6; else chunk 2 from its token 6); cmap != null:
+//           chunk 3 line + j of the line is compact chunk cmap[3 line + j] of the batch (all-padding chunks share one)
 __global__ __launch_bounds__(256) void cvit_ln_kernel(const float* __restrict__ x, long long rows, int C, const float* __restrict__ g,
                                                       const float* __restrict__ beta, float eps, bf16_t* __restrict__ out, int split,
-                                                      int mode, int H, int W) {
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                      int mode, int H, int W, const int* __restrict__ cmap) {
+  long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   long long orow = row;
@@ -213,13 +223,12 @@ __global__ __launch_bounds__(256) void cvit_ln_kernel(const float* __restrict__ 
     ocs = 2 * C;
     coff = (y & 1) * C;
   } else if (mode == 2) {
-    const long long chunk = row / CV_T;
-    const int t = (int)(row % CV_T), j = (int)(chunk % 3);
-    int pos;
-    if (j == 0) { if (t >= 69) return; pos = t; }
-    else if (j == 1) { if (t < 6 || t >= 69) return; pos = 69 + t - 6; }
-    else { if (t < 6) return; pos = 132 + t - 6; }
-    orow = (chunk / 3) * 201 + pos;
+    const long long line = row / 201;
+    const int pos = (int)(row % 201);
+    const int j = pos < 69 ? 0 : (pos < 132 ? 1 : 2);
+    const int t = j == 0 ? pos : (j == 1 ? pos - 69 + 6 : pos - 132 + 6);
+    const long long chunk = cmap ? cmap[3 * line + j] : 3 * line + j;
+    row = chunk * CV_T + t;                 // input row; orow stays (line, pos)
   }
   float v[8];
   const int nk = (C + 63) >> 6;
@@ -620,12 +629,33 @@ void mlp(Net& p, const bf16_t* xb, bf16_t* hb, float* x, long long rows_pad, int
 
 // lines [0, n) of one micro-batch
 int forward_batch(pt_engine* e, const PtModel& M, const float* gray, int pitch, long long jstride, long long lstride, int n, int32_t* ids,
-                  float* maxlogit, hipStream_t s) {
+                  float* maxlogit, hipStream_t s, const int* h_tw) {
   Net p;
   p.e = e; p.m = &M; p.s = s; p.rc = PT_OK;
   p.x3 = e->precision == PT_PRECISION_BF16X3 ? 1 : 0;
   p.mul = p.x3 ? 2 : 1;
-  const int x3 = p.x3, mul = p.mul, nchunks = 3 * n, NT = 7680 / 64;
+  const int x3 = p.x3, mul = p.mul, NT = 7680 / 64;
+  // h_tw != null: the lines' text widths after the keep-ratio resize are known.  Chunk j of a line is columns [252 j, 252 j +
+  // 300): with a text width <= 252 j it is all padding, and every all-padding chunk yields the same 75 tokens -- the CNN and
+  // the ViT never look across chunks.  The batch then holds the chunks with text plus ONE all-padding chunk; the stitching
+  // gathers through cmap.  Bit-identical to computing every chunk (a chunk's result does not depend on its batch).
+  std::vector<int> cmap, csrc;
+  if (h_tw) {
+    cmap.assign((size_t)3 * n, -1);
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < 3; ++j)
+        if (h_tw[i] > PT_CVIT_CHUNK_STEP * j) {
+          cmap[3 * i + j] = (int)csrc.size();
+          csrc.push_back(3 * i + j);
+        }
+    if ((int)csrc.size() < 3 * n) {
+      const int zero = (int)csrc.size();
+      csrc.push_back(-1);
+      for (int& c : cmap)
+        if (c < 0) c = zero;
+    }
+  }
+  const int nchunks = h_tw ? (int)csrc.size() : 3 * n;
   static const int DEPTH[4] = {3, 3, 8, 3}, DIM[4] = {96, 192, 256, 512};
   const long long rows_cls = pad128((long long)n * 201), Tpad = pad128((long long)nchunks * CV_T);
   // the stream / its bf16 image / the MLP hidden layer are reused by every stage: size them for the widest (rows are padded
@@ -638,6 +668,7 @@ int forward_batch(pt_engine* e, const PtModel& M, const float* gray, int pitch, 
   float* x = nullptr;
   bf16_t *xb = nullptr, *hb = nullptr, *qkv = nullptr, *att = nullptr, *feat = nullptr;
   float* part = nullptr;
+  int *d_cmap = nullptr, *d_csrc = nullptr;
   for (int attempt = 0; attempt < 2; ++attempt) {
     PtArena& A = e->arenas[PT_ARENA_REC];
     A.reset();
@@ -650,6 +681,10 @@ int forward_batch(pt_engine* e, const PtModel& M, const float* gray, int pitch, 
     att = reinterpret_cast<bf16_t*>(take((size_t)Tpad * 192 * mul * sizeof(bf16_t)));
     feat = reinterpret_cast<bf16_t*>(take((size_t)rows_cls * 192 * mul * sizeof(bf16_t)));
     part = reinterpret_cast<float*>(take((size_t)rows_cls * NT * 2 * sizeof(float)));
+    if (h_tw) {
+      d_cmap = reinterpret_cast<int*>(take(cmap.size() * sizeof(int)));
+      d_csrc = reinterpret_cast<int*>(take(csrc.size() * sizeof(int)));
+    }
     if (ok) break;
     if (attempt == 1) {
       pt_set_error("activation arena allocation failed");
@@ -662,6 +697,10 @@ int forward_batch(pt_engine* e, const PtModel& M, const float* gray, int pitch, 
     PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&A.base), want));
     A.cap = want;
   }
+  if (h_tw) {      // pageable sources: the copies are staged before the calls return
+    PT_HIP_CHECK(hipMemcpyAsync(d_cmap, cmap.data(), cmap.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    PT_HIP_CHECK(hipMemcpyAsync(d_csrc, csrc.data(), csrc.size() * sizeof(int), hipMemcpyHostToDevice, s));
+  }
   // rows past the real ones are never written by the row kernels: clear once so that no NaN bit pattern reaches a GEMM
   PT_HIP_CHECK(hipMemsetAsync(x, 0, (size_t)(xel + 128) * sizeof(float), s));
   PT_HIP_CHECK(hipMemsetAsync(xb, 0, (size_t)xel * mul * sizeof(bf16_t), s));
@@ -672,14 +711,14 @@ int forward_batch(pt_engine* e, const PtModel& M, const float* gray, int pitch, 
     if (p.rc != PT_OK) return p.rc;
     PtProfScope ps(e, s, PT_PROF_OTHER, 0, "cvit embed");
     const long long pix = (long long)nchunks * CV_PIX0;
-    hipLaunchKernelGGL(cvit_embed_kernel, dim3((unsigned)((pix + 255) / 256)), dim3(256), 0, s, gray, pitch, jstride, lstride, nchunks, w, b, g, be, x);
+    hipLaunchKernelGGL(cvit_embed_kernel, dim3((unsigned)((pix + 255) / 256)), dim3(256), 0, s, gray, pitch, jstride, lstride, nchunks, d_csrc, w, b, g, be, x);
   }
   auto ln = [&](const std::string& q, long long rows, int C, float eps, bf16_t* out, int mode, int H, int W) {
     const float* g = q.empty() ? nullptr : p.f32(q + ".g");
     const float* be = q.empty() ? nullptr : p.f32(q + ".b");
     if (p.rc != PT_OK) return;
     PtProfScope ps(e, s, PT_PROF_OTHER, 0, "cvit layernorm");
-    hipLaunchKernelGGL(cvit_ln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, C, g, be, eps, out, x3, mode, H, W);
+    hipLaunchKernelGGL(cvit_ln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, C, g, be, eps, out, x3, mode, H, W, d_cmap);
   };
   int H = 8;
   for (int st = 0; st < 4; ++st) {
@@ -734,7 +773,7 @@ int forward_batch(pt_engine* e, const PtModel& M, const float* gray, int pitch, 
     mlp(p, xb, hb, x, Tp, 192, lq, "fc1", "fc2");
     if (p.rc != PT_OK) return p.rc;
   }
-  ln("vit.ln", T, 192, 1e-12f, feat, 2, 1, 1);
+  ln("vit.ln", (long long)n * 201, 192, 1e-12f, feat, 2, 1, 1);
   p.gemm(feat, rows_cls, 192, "cls", 7680, 0, nullptr, nullptr, 0, nullptr, 0, part);
   if (p.rc != PT_OK) return p.rc;
   PT_HIP_CHECK(hipGetLastError());
@@ -746,27 +785,39 @@ int forward_batch(pt_engine* e, const PtModel& M, const float* gray, int pitch, 
 
 // gray fp32: layout 0 = chunks [3 n, 32, 300] (what the reference's model receives), 1 = lines [n, 32, 804] (what its
 // pre-processor cuts the chunks from: chunk j = columns [252 j, 252 j + 300))
-int pt_cvit_forward_net(pt_engine* e, const float* gray, int layout, int n, int32_t* ids, float* maxlogit, hipStream_t s) {
+int pt_cvit_forward_net(pt_engine* e, const float* gray, int layout, int n, int32_t* ids, float* maxlogit, hipStream_t s, const int* h_text_w) {
   PT_REQUIRE(e && gray && ids && n > 0 && (layout == 0 || layout == 1), "convnext-vit: bad arguments");
   auto it = e->models.find(PT_MODEL_CONVNEXT_VIT);
   if (it == e->models.end()) {
     pt_set_error("ConvNextViT weights not loaded (pt_weights_load(PT_MODEL_CONVNEXT_VIT))");
     return PT_ERR_STATE;
   }
-  static int mb = -1;
+  static int mb = -1, skip = -1;
   if (mb < 0) {
     const char* ev = getenv("PT_CVIT_MICROBATCH");
     mb = ev ? atoi(ev) : 512;
     if (mb < 1) mb = 1;
+    ev = getenv("PT_CVIT_SKIP_EMPTY");       // 0: compute the all-padding chunks too (A/B switch)
+    skip = ev ? atoi(ev) : 1;
   }
+  if (!skip) h_text_w = nullptr;
   const int pitch = layout ? PT_CVIT_W : PT_CVIT_CHUNK_W;
   const long long jstride = layout ? PT_CVIT_CHUNK_STEP : (long long)PT_REC_H * PT_CVIT_CHUNK_W;
   const long long lstride = layout ? (long long)PT_REC_H * PT_CVIT_W : 3ll * PT_REC_H * PT_CVIT_CHUNK_W;
-  for (int i0 = 0; i0 < n; i0 += mb) {
-    const int nb = (n - i0) < mb ? (n - i0) : mb;
+  // micro-batches of about 3 * mb chunks that are really computed (at most 4 * mb lines)
+  for (int i0 = 0; i0 < n;) {
+    int nb = 0, chunks = 0;
+    while (i0 + nb < n && nb < 4 * mb) {
+      int c = 3;
+      if (h_text_w) c = (h_text_w[i0 + nb] > 0) + (h_text_w[i0 + nb] > PT_CVIT_CHUNK_STEP) + (h_text_w[i0 + nb] > 2 * PT_CVIT_CHUNK_STEP);
+      if (nb > 0 && chunks + c > 3 * mb) break;
+      chunks += c;
+      ++nb;
+    }
     const int rc = forward_batch(e, it->second, gray + (long long)i0 * lstride, pitch, jstride, lstride, nb, ids + (size_t)i0 * PT_CVIT_T,
-                                 maxlogit ? maxlogit + (size_t)i0 * PT_CVIT_T : nullptr, s);
+                                 maxlogit ? maxlogit + (size_t)i0 * PT_CVIT_T : nullptr, s, h_text_w ? h_text_w + i0 : nullptr);
     if (rc != PT_OK) return rc;
+    i0 += nb;
   }
   return PT_OK;
 }

@@ -440,7 +440,12 @@ class HipEngine:
         lines["crop_h"] = [c.shape[0] for c in crops]
         flat = np.concatenate([np.ascontiguousarray(c[:, :, :3], dtype=np.uint8).reshape(-1) for c in crops])
         d, px = self._lines_to_device(lines)
-        return d, px, torch.from_numpy(flat).to(self._tdev)
+        return d, px, torch.from_numpy(flat).to(self._tdev), self._crop_wh(lines)
+
+    @staticmethod
+    def _crop_wh(lines: np.ndarray) -> np.ndarray:
+        """host int32 [n, 2] = (crop_w, crop_h): lets the engine share the all-padding chunks of short lines"""
+        return np.ascontiguousarray(np.stack([lines["crop_w"], lines["crop_h"]], 1).astype(np.int32))
 
     def rec_cvit_forward(self, pages: torch.Tensor, lines: np.ndarray):
         """pages uint8 [n,h,w,3] on the GPU, lines: REC_LINE_DTYPE records -> (ids int32 [L,201], maxlogit f32 [L,201])."""
@@ -451,8 +456,10 @@ class HipEngine:
         mx = torch.empty((nl, L.PT_CVIT_T), dtype=torch.float32, device=self._tdev)
         if nl:
             d, px = self._lines_to_device(lines)
-            L.check(self.lib.pt_rec_cvit_forward(self._h, _ptr(pages), n, h, w, _ptr(d), px.ctypes.data_as(C.c_void_p), nl,
-                                                 _ptr(ids), _ptr(mx), self._stream()), "pt_rec_cvit_forward")
+            wh = self._crop_wh(lines)
+            L.check(self.lib.pt_rec_cvit_forward(self._h, _ptr(pages), n, h, w, _ptr(d), px.ctypes.data_as(C.c_void_p),
+                                                 wh.ctypes.data_as(C.c_void_p), nl, _ptr(ids), _ptr(mx), self._stream()),
+                    "pt_rec_cvit_forward")
         return ids, mx
 
     def rec_cvit_forward_crops(self, crops: Sequence[np.ndarray]):
@@ -461,22 +468,24 @@ class HipEngine:
         ids = torch.empty((nl, L.PT_CVIT_T), dtype=torch.int32, device=self._tdev)
         mx = torch.empty((nl, L.PT_CVIT_T), dtype=torch.float32, device=self._tdev)
         if nl:
-            d, px, dc = self._crops_to_device(crops)
-            L.check(self.lib.pt_rec_cvit_forward_crops(self._h, _ptr(dc), _ptr(d), px.ctypes.data_as(C.c_void_p), nl, _ptr(ids),
-                                                       _ptr(mx), self._stream()), "pt_rec_cvit_forward_crops")
+            d, px, dc, wh = self._crops_to_device(crops)
+            L.check(self.lib.pt_rec_cvit_forward_crops(self._h, _ptr(dc), _ptr(d), px.ctypes.data_as(C.c_void_p),
+                                                       wh.ctypes.data_as(C.c_void_p), nl, _ptr(ids), _ptr(mx), self._stream()),
+                    "pt_rec_cvit_forward_crops")
         return ids, mx
 
     def rec_cvit_preprocess_crops(self, crops: Sequence[np.ndarray]) -> torch.Tensor:
         """keep-ratio resize to 32 x 804 + gray of already-cropped lines -> fp32 [L,32,804]."""
         nl = len(crops)
         gray = torch.empty((nl, L.PT_REC_H, L.PT_CVIT_W), dtype=torch.float32, device=self._tdev)
-        d, px, dc = self._crops_to_device(crops)
+        d, px, dc, _ = self._crops_to_device(crops)
         L.check(self.lib.pt_rec_cvit_preprocess_crops(self._h, _ptr(dc), _ptr(d), px.ctypes.data_as(C.c_void_p), nl, _ptr(gray),
                                                       self._stream()), "pt_rec_cvit_preprocess_crops")
         return gray
 
-    def rec_cvit_forward_net(self, gray: torch.Tensor):
-        """gray fp32 [3n,32,300] (chunks) or [n,32,804] (lines) -> (ids int32 [n,201], maxlogit f32 [n,201])."""
+    def rec_cvit_forward_net(self, gray: torch.Tensor, text_w: Optional[Sequence[int]] = None):
+        """gray fp32 [3n,32,300] (chunks) or [n,32,804] (lines) -> (ids int32 [n,201], maxlogit f32 [n,201]).
+        ``text_w`` (per line): columns >= text_w[i] are zero padding -- all-padding chunks are then computed once and shared."""
         self._chk(gray, torch.float32, "gray")
         assert gray.dim() == 3 and gray.shape[1] == L.PT_REC_H and gray.shape[2] in (L.PT_CVIT_CHUNK_W, L.PT_CVIT_W)
         layout = 1 if gray.shape[2] == L.PT_CVIT_W else 0
@@ -484,8 +493,10 @@ class HipEngine:
         n = gray.shape[0] if layout else gray.shape[0] // 3
         ids = torch.empty((n, L.PT_CVIT_T), dtype=torch.int32, device=self._tdev)
         mx = torch.empty((n, L.PT_CVIT_T), dtype=torch.float32, device=self._tdev)
-        L.check(self.lib.pt_rec_cvit_forward_net(self._h, _ptr(gray), layout, n, _ptr(ids), _ptr(mx), self._stream()),
-                "pt_rec_cvit_forward_net")
+        tw = None if text_w is None else np.ascontiguousarray(np.asarray(text_w, dtype=np.int32))
+        assert tw is None or len(tw) == n
+        L.check(self.lib.pt_rec_cvit_forward_net(self._h, _ptr(gray), layout, n, None if tw is None else tw.ctypes.data_as(C.c_void_p),
+                                                 _ptr(ids), _ptr(mx), self._stream()), "pt_rec_cvit_forward_net")
         return ids, mx
 
     def op_conv2d(self, x: torch.Tensor, w_tiled: torch.Tensor, bias: torch.Tensor, ks: int, stride: int = 1,

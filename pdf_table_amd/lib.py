@@ -70,9 +70,9 @@ def _proto(lib):
         "pt_rec_forward_crops": (i, [vp, vp, vp, vp, i, vp, vp, vp]),
         "pt_rec_forward_net": (i, [vp, vp, i, vp, vp, vp]),
         "pt_rec_preprocess": (i, [vp, vp, i, i, i, vp, vp, i, vp, vp]),
-        "pt_rec_cvit_forward": (i, [vp, vp, i, i, i, vp, vp, i, vp, vp, vp]),
-        "pt_rec_cvit_forward_crops": (i, [vp, vp, vp, vp, i, vp, vp, vp]),
-        "pt_rec_cvit_forward_net": (i, [vp, vp, i, i, vp, vp, vp]),
+        "pt_rec_cvit_forward": (i, [vp, vp, i, i, i, vp, vp, vp, i, vp, vp, vp]),
+        "pt_rec_cvit_forward_crops": (i, [vp, vp, vp, vp, vp, i, vp, vp, vp]),
+        "pt_rec_cvit_forward_net": (i, [vp, vp, i, i, vp, vp, vp, vp]),
         "pt_rec_cvit_preprocess_crops": (i, [vp, vp, vp, vp, i, vp, vp]),
         "pt_rec_pp_preprocess": (i, [vp, vp, i, i, i, vp, vp, i, vp, i, i, i, vp, vp]),
         "pt_rec_pp_preprocess_crops": (i, [vp, vp, vp, vp, i, vp, i, i, i, vp, vp]),

@@ -221,3 +221,42 @@ np.savez(sys.argv[1], ids=ids.cpu().numpy(), mx=mx.cpu().numpy())
     print(f"convnext-vit fused vs two-GEMM MLP: max|d max-logit| = {d:.2e}, {100 * same:.2f} % of the ids equal")
     assert d <= 0.1 and same >= 0.95          # bf16-class agreement (logit scale ~ 11); the x3 tests carry the 1e-3 contract
     assert len(np.unique(outs[0]["ids"])) > 3
+
+
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+def test_sharing_the_all_padding_chunks_is_bit_identical(eng, mode):
+    """with the text widths known, chunks without text are not computed per line (one all-padding chunk per batch is, and the
+    stitching gathers it): ids AND winning logits equal the computation of every chunk bit for bit -- widths on both sides of
+    the 252 / 504 chunk borders, an empty line, a full line"""
+    rng = np.random.default_rng(31)
+    tw = [804, 0, 1, 100, 252, 253, 300, 504, 505, 640, 30, 252, 804, 17]
+    g = np.zeros((len(tw), 32, 804), np.float32)
+    for i, w in enumerate(tw):
+        g[i, :, :w] = rng.uniform(0, 1, (32, w))
+    gt = torch.from_numpy(g).cuda()
+    eng.set_precision(L.PT_PRECISION_BF16X3 if mode == "bf16x3" else L.PT_PRECISION_BF16)
+    try:
+        ids_f, mx_f = eng.rec_cvit_forward_net(gt)
+        ids_s, mx_s = eng.rec_cvit_forward_net(gt, text_w=tw)
+        ids_1, mx_1 = eng.rec_cvit_forward_net(gt[1:3], text_w=tw[1:3])          # a batch with no text at all + one column
+        torch.cuda.synchronize()
+    finally:
+        eng.set_precision(L.PT_PRECISION_BF16)
+    assert torch.equal(ids_f, ids_s) and torch.equal(mx_f, mx_s)
+    assert torch.equal(ids_f[1:3], ids_1) and torch.equal(mx_f[1:3], mx_1)
+
+
+def test_crops_path_shares_chunks_and_matches_the_net_entry(eng):
+    """pt_rec_cvit_forward_crops derives the text widths from the crop sizes (the resize kernel's own formula): same ids and
+    logits as pre-processing + the net entry computing every chunk"""
+    crops = _crops()
+    ids_c, mx_c = eng.rec_cvit_forward_crops(crops)
+    gray = eng.rec_cvit_preprocess_crops(crops)
+    ids_n, mx_n = eng.rec_cvit_forward_net(gray)
+    torch.cuda.synchronize()
+    assert torch.equal(ids_c, ids_n) and torch.equal(mx_c, mx_n)
+    g = gray.cpu()
+    for i, c in enumerate(crops):          # the widths the sharing relies on: nothing but zeros right of the resized text
+        ratio = c.shape[1] / float(c.shape[0])
+        nw = 804 if ratio > 804 / 32 else int(32 * ratio)
+        assert bool((g[i, :, nw:] == 0).all()) and (nw == 0 or bool((g[i, :, :nw] != 0).any()))
