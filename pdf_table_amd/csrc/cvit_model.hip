@@ -26,6 +26,7 @@
 //   classifier + arg-max                 1x1 GEMM with the arg-max epilogue + argmax_reduce_kernel: no logits in HBM
 // PT_PRECISION_BF16X3: activations [hi | lo], weights [hi | hi | lo], three MFMA passes -- as everywhere in the engine.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <string>
@@ -379,37 +380,50 @@ __global__ __launch_bounds__(64) void cvit_attention_kernel(const bf16_t* __rest
 //   An MFMA here reads 1 KB of LDS (the weight fragment; the row operand is in registers): LDS and matrix pipe are balanced,
 //   neither HBM (10 C bytes per row instead of 26 C) nor the launch count (one kernel instead of two) is the bound.
 //   Epilogue: the lane's 4-channel fp32 runs of its row are added to the residual stream in place.
-// GELU: erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, one exp, one reciprocal) -- the hidden value is rounded to bf16
-// right after, 2^-9 relative.  The hi/lo mode keeps the two-GEMM path with erff.
+// GELU: a packed-fp32 polynomial (gelu_pair below, absolute error < 3e-6) -- the hidden value is rounded to bf16 right after,
+// 2^-9 relative.  The hi/lo mode keeps the two-GEMM path with erff.
 // ---------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) uint32_t cu32x4;
+
 typedef __attribute__((ext_vector_type(2))) float mlp_f2;
 typedef __attribute__((ext_vector_type(2))) __bf16 mlp_b2;
 
-__device__ __forceinline__ float gelu_fast(float x) {
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float e = 1.f - poly * __expf(-z * z);          // erf(|x| / sqrt 2)
-  return 0.5f * x * (1.f + copysignf(e, x)) ;
+// GELU of two values at once in packed fp32 (v_pk_fma_f32): x * Phi(x) with Phi(x) - 1/2 = x * Q(x^2), Q the degree-9 polynomial
+// of a Chebyshev fit on [-4, 4] (|error of Phi| < 8e-7 there); outside, x is clamped in Phi (Phi(4) = 1 - 3.2e-5) and, on the
+// negative side, in the product too (GELU(x < -4) = -1.3e-4 instead of -> 0).  Absolute error < 3e-6 on [-4, 4], relative error
+// < 5e-4 wherever |GELU| > 1e-3 -- the value is rounded to bf16 (2^-9) right after.  14 packed instructions per pair against
+// ~34 per value for the erf form (exp, reciprocal, unfused multiply-adds under -ffp-contract=off): the kernel is VALU-bound here.
+__device__ __forceinline__ mlp_f2 gelu_pair(mlp_f2 x) {
+  const mlp_f2 xp = __builtin_elementwise_max(x, (mlp_f2){-4.f, -4.f});
+  const mlp_f2 xc = __builtin_elementwise_min(xp, (mlp_f2){4.f, 4.f});
+  const mlp_f2 t = xc * xc;
+  constexpr float A[10] = {3.989380888e-01f, -6.647037283e-02f, 9.945140159e-03f, -1.168552637e-03f, 1.084709610e-04f,
+                           -7.841504780e-06f, 4.224180292e-07f, -1.572596130e-08f, 3.561182861e-10f, -3.658831230e-12f};
+  mlp_f2 q = {A[9], A[9]};
+#pragma unroll
+  for (int k = 8; k >= 0; --k) q = __builtin_elementwise_fma(q, t, (mlp_f2){A[k], A[k]});
+  return xp * __builtin_elementwise_fma(xc, q, (mlp_f2){0.5f, 0.5f});
 }
 
-template <int C, bool PIPE>
-__global__ __launch_bounds__(256, 2) void cvit_mlp_kernel(const bf16_t* __restrict__ xb, const bf16_t* __restrict__ w1,
-                                                          const float* __restrict__ b1, const bf16_t* __restrict__ w2p,
-                                                          const float* __restrict__ b2, float* __restrict__ x) {
+template <int C, bool PIPE, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void cvit_mlp_kernel(const bf16_t* __restrict__ xb, const bf16_t* __restrict__ w1,
+                                                                            const float* __restrict__ b1, const bf16_t* __restrict__ w2p,
+                                                                            const float* __restrict__ b2, float* __restrict__ x, long long rows) {
   constexpr int KS = C / 16, NT = C / 32, NCH = 4 * C / 32;
   constexpr int U1 = C / 8;                            // 16-byte units per W1 row
   constexpr int S1 = 32 * C * 2, S2 = C * 64;          // one W1 chunk [32][C], one W2 chunk [C][32], bytes
   constexpr int NI = C / 16;                           // DMA wave-instructions (64 units of 16 bytes) per chunk and matrix
-  constexpr int SLOTS = (NI + 3) / 4;
+  constexpr int SLOTS = (NI + NW - 1) / NW;
   extern __shared__ __attribute__((aligned(16))) char cv_mlp_lds[];
   char* const w1buf = cv_mlp_lds;                      // two W1 chunks, then two W2 chunks, then b1
   char* const w2buf = cv_mlp_lds + 2 * S1;
   float* const b1s = reinterpret_cast<float*>(cv_mlp_lds + 2 * S1 + 2 * S2);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
-  const long long row = (long long)blockIdx.x * 128 + wave * 32 + col;
-  for (int i = tid; i < 4 * C; i += 256) b1s[i] = b1[i];
+  // NW waves of 32 rows share one copy of the weight chunks (the DMA traffic per row halves from 4 to 8 waves); waves past the
+  // last row still take part in the DMA and the barriers
+  const long long row = (long long)blockIdx.x * (32 * NW) + wave * 32 + col;
+  const bool live = row < rows;
+  for (int i = tid; i < 4 * C; i += 64 * NW) b1s[i] = b1[i];
   // The weight chunks go global -> LDS by DMA (global_load_lds: no staging registers, no ds_write): a wave instruction
   // fills 1 KB of LDS in lane order, the lane picks the SOURCE.  No row padding is possible that way, so the 16-byte units
   // of a row are XOR-swizzled with the row number instead (rows are a multiple of 64 bytes apart): eight consecutive rows
@@ -419,31 +433,39 @@ __global__ __launch_bounds__(256, 2) void cvit_mlp_kernel(const bf16_t* __restri
   int src1[SLOTS], src2[SLOTS];
 #pragma unroll
   for (int j = 0; j < SLOTS; ++j) {
-    const int U = (wave + 4 * j) * 64 + lane;
+    const int U = (wave + NW * j) * 64 + lane;
     const int r1 = U / U1, u1 = U % U1;
     src1[j] = r1 * (2 * C) + ((u1 ^ (C == 96 ? ((r1 >> 1) & 3) : (r1 & 7))) << 4);
     const int r2 = U >> 2, u2 = U & 3;
     src2[j] = r2 * 64 + ((u2 ^ ((r2 >> 1) & 3)) << 4);
   }
+  // DMA addresses as (kernel-argument base in SGPRs) + (32-bit lane offset incl. the chunk offset): written as pointer + 64-bit
+  // chunk offset, the loop's chunk pointers become 64-bit per-lane induction variables -- sixteen more VGPRs in a kernel that
+  // has none to spare; they were spilled, and every reload waited (vmcnt, in order) for the DMA issued just before it: 3.8 k of
+  // the 8.9 k cycles a chunk took at C = 256 (s_memtime stamps)
   auto issue1 = [&](int hc, char* buf) {
-    const char* g = reinterpret_cast<const char*>(w1) + (size_t)hc * S1;
+    const char* g = reinterpret_cast<const char*>(w1);
+    unsigned base = (unsigned)hc * S1;
+    asm volatile("" : "+s"(base));        // opaque to loop strength reduction
 #pragma unroll
     for (int j = 0; j < SLOTS; ++j)
-      if (wave + 4 * j < NI)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + src1[j]),
-                                         (__attribute__((address_space(3))) void*)(buf + (wave + 4 * j) * 1024), 16, 0, 0);
+      if (wave + NW * j < NI)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (base + (unsigned)src1[j])),
+                                         (__attribute__((address_space(3))) void*)(buf + (wave + NW * j) * 1024), 16, 0, 0);
   };
   auto issue2 = [&](int hc, char* buf) {
-    const char* g = reinterpret_cast<const char*>(w2p) + (size_t)hc * S2;
+    const char* g = reinterpret_cast<const char*>(w2p);
+    unsigned base = (unsigned)hc * S2;
+    asm volatile("" : "+s"(base));
 #pragma unroll
     for (int j = 0; j < SLOTS; ++j)
-      if (wave + 4 * j < NI)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + src2[j]),
-                                         (__attribute__((address_space(3))) void*)(buf + (wave + 4 * j) * 1024), 16, 0, 0);
+      if (wave + NW * j < NI)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (base + (unsigned)src2[j])),
+                                         (__attribute__((address_space(3))) void*)(buf + (wave + NW * j) * 1024), 16, 0, 0);
   };
   abf16x8 xf[KS];
   {
-    const bf16_t* xr = xb + row * C + half * 8;
+    const bf16_t* xr = xb + (live ? row : 0) * C + half * 8;
 #pragma unroll
     for (int s = 0; s < KS; ++s) xf[s] = ld8(xr + 16 * s);
   }
@@ -477,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void cvit_mlp_kernel(const bf16_t* __restri
 #pragma unroll
     for (int q = p0; q < p1; ++q) {
       const int r = 2 * q;
-      const mlp_f2 v = {gelu_fast(d[r] + bp[8 * (r >> 2) + (r & 3)]), gelu_fast(d[r + 1] + bp[8 * (r >> 2) + (r & 3) + 1])};
+      const mlp_f2 v = gelu_pair((mlp_f2){d[r] + bp[8 * (r >> 2) + (r & 3)], d[r + 1] + bp[8 * (r >> 2) + (r & 3) + 1]});
       const mlp_b2 pk = __builtin_convertvector(v, mlp_b2);
       h[r >> 3][r & 7] = pk[0];
       h[r >> 3][(r & 7) + 1] = pk[1];
@@ -531,6 +553,7 @@ __global__ __launch_bounds__(256, 2) void cvit_mlp_kernel(const bf16_t* __restri
       gemm2(w2buf + (hc & 1) * S2, hf);
     }
   }
+  if (!live) return;
   float* xr = x + row * C + 4 * half;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -544,16 +567,17 @@ __global__ __launch_bounds__(256, 2) void cvit_mlp_kernel(const bf16_t* __restri
     }
 }
 
-template <int C, bool PIPE>
+template <int C, bool PIPE, int NW>
 int launch_mlp(const bf16_t* xb, const bf16_t* w1, const float* b1, const bf16_t* w2p, const float* b2, float* x, long long rows_pad,
                hipStream_t s) {
   constexpr int SMEM = 2 * (32 * C * 2 + C * 64) + 4 * C * 4;
   static bool attr_done = false;
   if (!attr_done) {
-    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cvit_mlp_kernel<C, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cvit_mlp_kernel<C, PIPE, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_done = true;
   }
-  hipLaunchKernelGGL((cvit_mlp_kernel<C, PIPE>), dim3((unsigned)(rows_pad / 128)), dim3(256), SMEM, s, xb, w1, b1, w2p, b2, x);
+  hipLaunchKernelGGL((cvit_mlp_kernel<C, PIPE, NW>), dim3((unsigned)((rows_pad + 32 * NW - 1) / (32 * NW))), dim3(64 * NW), SMEM, s, xb, w1, b1, w2p,
+                     b2, x, rows_pad);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
@@ -615,10 +639,12 @@ void mlp(Net& p, const bf16_t* xb, bf16_t* hb, float* x, long long rows_pad, int
     PtProfScope ps(p.e, p.s, PT_PROF_CONV1X1, 16.0 * rows_pad * (double)C * C, "cvit fused mlp");
     const bf16_t* W1 = reinterpret_cast<const bf16_t*>(w1->d_ptr);
     const bf16_t* W2 = reinterpret_cast<const bf16_t*>(w2->d_ptr);
+    // 128-row workgroups (NW = 4), two per CU; 256-row ones (NW = 8, one per CU, half the weight DMA per row) measured equal at
+    // C = 256 and 5-10 % slower at C = 96 / 192
     int r;
-    if (C == 96) r = launch_mlp<96, true>(xb, W1, b1, W2, b2, x, rows_pad, p.s);
-    else if (C == 192) r = launch_mlp<192, true>(xb, W1, b1, W2, b2, x, rows_pad, p.s);
-    else r = launch_mlp<256, false>(xb, W1, b1, W2, b2, x, rows_pad, p.s);
+    if (C == 96) r = launch_mlp<96, true, 4>(xb, W1, b1, W2, b2, x, rows_pad, p.s);
+    else if (C == 192) r = launch_mlp<192, true, 4>(xb, W1, b1, W2, b2, x, rows_pad, p.s);
+    else r = launch_mlp<256, false, 4>(xb, W1, b1, W2, b2, x, rows_pad, p.s);
     if (r != PT_OK) p.rc = r;
     return;
   }
