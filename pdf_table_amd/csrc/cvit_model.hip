@@ -649,7 +649,18 @@ void mlp(Net& p, const bf16_t* xb, bf16_t* hb, float* x, long long rows_pad, int
     return;
   }
   const int Np = (C + 63) / 64 * 64;
-  p.gemm(xb, rows_pad, C, q + "." + n1, 4 * C, 4, hb);
+  if (fused && !p.x3 && C == 512) {
+    // stage 3 (the fused kernel's accumulators do not fit at C = 512): the first product on the streaming row GEMM of the CRNN
+    // head (rows of A in registers, W through LDS; 2048-wide N: 0.64 -> 0.3x ms per 115 k rows) with the GELU in its epilogue
+    const PtTensor *w = p.get(q + "." + n1 + ".w"), *b = p.get(q + "." + n1 + ".b");
+    if (p.rc != PT_OK) return;
+    PtProfScope ps(p.e, p.s, PT_PROF_CONV1X1, 2.0 * rows_pad * (double)C * 4 * C, "cvit rows gemm + gelu");
+    const int r = pt_launch_gemm_rows(xb, rows_pad, C, reinterpret_cast<const bf16_t*>(w->d_ptr), reinterpret_cast<const float*>(b->d_ptr),
+                                      4 * C, hb, 4, p.s);
+    if (r != PT_OK) p.rc = r;
+  } else {
+    p.gemm(xb, rows_pad, C, q + "." + n1, 4 * C, 4, hb);
+  }
   p.gemm(hb, rows_pad, 4 * C, q + "." + n2, Np, 0, nullptr, x, C, x, Np != C ? C : 0);
 }
 
@@ -800,6 +811,20 @@ int forward_batch(pt_engine* e, const PtModel& M, const float* gray, int pitch, 
     if (p.rc != PT_OK) return p.rc;
   }
   ln("vit.ln", (long long)n * 201, 192, 1e-12f, feat, 2, 1, 1);
+  static int cls_fused = -1;      // PT_CLS_FUSED=0: tiled GEMM with per-tile arg-max partials + reduce in bf16 mode too (A/B switch)
+  if (cls_fused < 0) {
+    const char* ev = getenv("PT_CLS_FUSED");
+    cls_fused = ev ? atoi(ev) : 1;
+  }
+  if (!x3 && cls_fused) {
+    // bf16 mode: the streaming classifier of the CRNN head (gemm_argmax_kernel, K = 192 here): W as the MFMA A operand, the
+    // running arg-max in the lane, no partials
+    const PtTensor *w = p.get("cls.w"), *b = p.get("cls.b");
+    if (p.rc != PT_OK) return p.rc;
+    PtProfScope ps(e, s, PT_PROF_CONV1X1, 2.0 * n * 201 * 192.0 * 7680.0, "cvit classifier gemm+argmax");
+    return pt_launch_gemm_argmax(feat, (long long)n * 201, 192, reinterpret_cast<const bf16_t*>(w->d_ptr), reinterpret_cast<const float*>(b->d_ptr),
+                                 7680, ids, maxlogit, s);
+  }
   p.gemm(feat, rows_cls, 192, "cls", 7680, 0, nullptr, nullptr, 0, nullptr, 0, part);
   if (p.rc != PT_OK) return p.rc;
   PT_HIP_CHECK(hipGetLastError());

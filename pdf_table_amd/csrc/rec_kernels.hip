@@ -1233,6 +1233,18 @@ __global__ __launch_bounds__(256) void argmax_reduce_kernel(const float2* __rest
 // ---------------------------------------------------------------------------------------------------
 // MODE 1: the same streaming GEMM with a store epilogue instead (out bf16 [M][N] = A . W^T + bias, optional ReLU): a lane
 // writes its row's classes as 8-byte runs of four (the LSTM input projections and embeddings of the CRNN head).
+// GELU for the bf16 mode's row GEMM (ConvNextViT stage 3, cvit_model.hip): x * Phi(x), Phi - 1/2 = x * Q(x^2) with the degree-9
+// Q of a Chebyshev fit on [-4, 4] (the polynomial of cvit_model.hip's gelu_pair; |error| < 3e-6, clamped outside) -- the value
+// is rounded to bf16 right after
+__device__ __forceinline__ float gelu_poly(float x) {
+  const float xp = fmaxf(x, -4.f), xc = fminf(xp, 4.f), t = xc * xc;
+  float q = -3.658831230e-12f;
+  q = fmaf(q, t, 3.561182861e-10f); q = fmaf(q, t, -1.572596130e-08f); q = fmaf(q, t, 4.224180292e-07f);
+  q = fmaf(q, t, -7.841504780e-06f); q = fmaf(q, t, 1.084709610e-04f); q = fmaf(q, t, -1.168552637e-03f);
+  q = fmaf(q, t, 9.945140159e-03f); q = fmaf(q, t, -6.647037283e-02f); q = fmaf(q, t, 3.989380888e-01f);
+  return xp * fmaf(xc, q, 0.5f);
+}
+
 template <int KSTEPS, int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __restrict__ A, long long M,
                                                              const bf16_t* __restrict__ W, const float* __restrict__ bias,
@@ -1310,7 +1322,8 @@ __global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __res
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             float v = acc[rg * 4 + k] + sb[cl + k];
-            if (relu) v = fmaxf(v, 0.f);
+            if (relu == 1) v = fmaxf(v, 0.f);
+            else if (relu == 4) v = gelu_poly(v);
             hb[k] = rf2bf(v);
           }
           *reinterpret_cast<u32x2*>(out + row * N + t * 64 + cl) = u32x2{hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
@@ -1332,20 +1345,25 @@ __global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __res
 // so that the caller can fall back to the tiled kernel + reduce)
 int pt_launch_gemm_argmax(const bf16_t* A, long long M, int K, const bf16_t* W, const float* bias, int N, int* ids, float* maxv,
                           hipStream_t s) {
-  if (K != 512 || N % 64 != 0 || M <= 0) return PT_ERR_INVALID;
+  if ((K != 512 && K != 192) || N % 64 != 0 || M <= 0) return PT_ERR_INVALID;      // 512: CRNN head; 192: ConvNextViT head
   constexpr int SMEM = 64 * (512 * 2 + 16) + 64 * 4;
   static bool attr_done = false;
   if (!attr_done) {
     PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_argmax_kernel<32, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_argmax_kernel<12, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_argmax_kernel<32, 0>), dim3((unsigned)((M + 127) / 128)), dim3(256), SMEM, s, A, M, W, bias, N, ids, maxv,
-                     nullptr, 0, nullptr);
+  if (K == 192)
+    hipLaunchKernelGGL((gemm_argmax_kernel<12, 0>), dim3((unsigned)((M + 127) / 128)), dim3(256), 64 * (192 * 2 + 16) + 64 * 4, s, A, M, W, bias, N,
+                       ids, maxv, nullptr, 0, nullptr);
+  else
+    hipLaunchKernelGGL((gemm_argmax_kernel<32, 0>), dim3((unsigned)((M + 127) / 128)), dim3(256), SMEM, s, A, M, W, bias, N, ids, maxv,
+                       nullptr, 0, nullptr);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
 
-// out bf16 [M][N] = A [M][K] . W^T + bias (+ ReLU); K in {256, 512}; PT_ERR_INVALID otherwise (caller falls back)
+// out bf16 [M][N] = A [M][K] . W^T + bias (relu: 0 none, 1 ReLU, 4 GELU by gelu_poly); K in {256, 512}; PT_ERR_INVALID otherwise (caller falls back)
 int pt_launch_gemm_rows(const bf16_t* A, long long M, int K, const bf16_t* W, const float* bias, int N, bf16_t* out, int relu,
                         hipStream_t s, const int* tlim) {
   if ((K != 512 && K != 256) || N % 64 != 0 || M <= 0) return PT_ERR_INVALID;
