@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void cvit_embed_kernel(const float* __restrict
   for (int c = 0; c < 96; ++c) {
     float a = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) a += w[c * 16 + k] * in[k];
+    for (int k = 0; k < 16; ++k) a = fmaf(w[c * 16 + k], in[k], a);
     v[c] = a + b[c];
     sum += v[c];
   }
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(512) void cvit_dwconv_ln_kernel(const float* __rest
 #pragma unroll
           for (int j = 0; j < CV_TX; ++j) {
             const int k = dx - j;
-            if (k >= 0 && k < 7) acc[oy][j] += wv[dy * 7 + k] * v;
+            if (k >= 0 && k < 7) acc[oy][j] = fmaf(wv[dy * 7 + k], v, acc[oy][j]);      // explicit: the build runs with -ffp-contract=off
           }
         }
       }
