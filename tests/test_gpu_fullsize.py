@@ -355,3 +355,53 @@ def test_fullsize_crnn_64_lines_oracle_parity(eng_par, pages, mode):
         assert float(diff.float().mean()) < 0.01
     else:
         assert dmax <= 0.06 * scale and bool((margin[diff] <= 0.12 * scale).all())
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_fullsize_convnext_vit_64_lines_oracle_parity(eng_par, pages, mode):
+    """64 text lines of a synthetic 1024x1024 page through the WHOLE ConvNextViT path on the device -- perspective crop out of
+    the resident page, keep-ratio resize to 32x804, three chunks (the all-padding ones shared), ConvNext + ViT, stitching,
+    classifier, arg-max -- against the oracle run line by line like the reference (crop_image, chunking pre-processor, fp32
+    network): winning logit and token ids"""
+    from oracle import convnext_vit as ocv
+    from oracle import crnn as ocrnn
+    from pdf_table_amd import rec_stage as R
+    from pdf_table_amd.synth_weights import convnext_vit_state_dict
+    from pdf_table_amd.weights import pack_convnext_vit
+    eng, _ = eng_par
+    sd = convnext_vit_state_dict(seed=3)
+    eng.load_weights(L.PT_MODEL_CONVNEXT_VIT, pack_convnext_vit(sd))
+    img, meta = pages[1]
+    l = meta["lines"].astype(np.float64)
+    quads = np.stack([l[:, 0], l[:, 1], l[:, 2], l[:, 1], l[:, 2], l[:, 3], l[:, 0], l[:, 3]], 1)
+    quads = np.concatenate([quads, quads + 3.0])[:60]
+    wide = [(40, 100, 1000, 130), (40, 200, 600, 230), (40, 300, 340, 330), (500, 400, 1010, 420)]      # two and three chunks of text
+    quads = np.concatenate([quads, np.array([[x0, y0, x1, y0, x1, y1, x0, y1] for x0, y0, x1, y1 in wide], np.float64)])
+    with torch.no_grad():
+        logits = torch.cat([ocv.convnext_vit_forward_fp32(sd, ocv.chunk_preprocess(ocrnn.crop_image(img, ocrnn.order_point(q))))
+                            for q in quads])
+    top2 = torch.topk(logits, 2, dim=-1)
+    lines = R.build_lines([quads])
+    _mode(eng, mode)
+    try:
+        ids, mx = eng.rec_cvit_forward(torch.from_numpy(img[None]).cuda(), lines)
+        torch.cuda.synchronize()
+        eng.check()
+    finally:
+        _mode(eng, "bf16")
+    ids, mx = ids.cpu().long(), mx.cpu()
+    scale = logits.abs().max().item()
+    dmax = (mx - top2.values[..., 0]).abs().max().item()
+    margin = top2.values[..., 0] - top2.values[..., 1]
+    diff = ids != top2.indices[..., 0]
+    tw = np.minimum(804, (32 * lines["crop_w"] / np.maximum(lines["crop_h"], 1)).astype(int))
+    print(f"FULLSIZE convnext-vit 64 lines {mode}: max|d winning logit|={dmax:.3e} = {dmax / scale:.3e} of scale {scale:.1f}; "
+          f"{int(diff.sum())} of {ids.numel()} token ids differ (largest oracle margin among them "
+          f"{margin[diff].max().item() if diff.any() else 0.0:.3e}); {float(((tw > 0).astype(int) + (tw > 252) + (tw > 504)).mean()):.2f} chunks "
+          f"with text per line")
+    if mode == "bf16x3":
+        assert dmax <= X3_TOL * scale
+        assert bool((margin[diff] <= 2 * X3_TOL * scale).all())        # ids exact outside the oracle's own ties
+        assert float(diff.float().mean()) < 0.01
+    else:
+        assert dmax <= 0.06 * scale and bool((margin[diff] <= 0.12 * scale).all())
