@@ -129,6 +129,11 @@ struct pt_engine {
   bool rec_zero_valid[2] = {false, false};
   void* rec_limits = nullptr; size_t rec_limits_cap = 0;     // per-line column limits of the call in flight
   int rec_ragged = 1;                                        // PT_REC_RAGGED=0: compute the padding too (A/B switch)
+  // cvit_model.hip: host images of the chunk maps of the last 16 micro-batches.  They are the sources of asynchronous
+  // host-to-device copies: a stack vector could die before a deferred copy reads it; a slot is reused only 16 micro-batches
+  // (thousands of launches on the same stream) later
+  std::vector<int> cvit_maps[16][2];
+  int cvit_slot = 0;
 };
 
 // ---- conv launcher (conv_igemm.hip) -----------------------------------------------------------------

@@ -676,7 +676,10 @@ int forward_batch(pt_engine* e, const PtModel& M, const float* gray, int pitch, 
   // 300): with a text width <= 252 j it is all padding, and every all-padding chunk yields the same 75 tokens -- the CNN and
   // the ViT never look across chunks.  The batch then holds the chunks with text plus ONE all-padding chunk; the stitching
   // gathers through cmap.  Bit-identical to computing every chunk (a chunk's result does not depend on its batch).
-  std::vector<int> cmap, csrc;
+  std::vector<int>& cmap = e->cvit_maps[e->cvit_slot][0];
+  std::vector<int>& csrc = e->cvit_maps[e->cvit_slot][1];
+  e->cvit_slot = (e->cvit_slot + 1) & 15;
+  csrc.clear();
   if (h_tw) {
     cmap.assign((size_t)3 * n, -1);
     for (int i = 0; i < n; ++i)
@@ -734,7 +737,7 @@ int forward_batch(pt_engine* e, const PtModel& M, const float* gray, int pitch, 
     PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&A.base), want));
     A.cap = want;
   }
-  if (h_tw) {      // pageable sources: the copies are staged before the calls return
+  if (h_tw) {      // sources owned by the engine (see pt_engine::cvit_maps)
     PT_HIP_CHECK(hipMemcpyAsync(d_cmap, cmap.data(), cmap.size() * sizeof(int), hipMemcpyHostToDevice, s));
     PT_HIP_CHECK(hipMemcpyAsync(d_csrc, csrc.data(), csrc.size() * sizeof(int), hipMemcpyHostToDevice, s));
   }
