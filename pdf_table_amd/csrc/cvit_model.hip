@@ -12,18 +12,22 @@
 // the CNN and one 75-token sequence of the ViT.  The residual stream is fp32 [pixels, C] for the whole network (the reference
 // is fp32; both precision modes round only the GEMM / attention operands), token-wise work runs over ALL pixels / tokens of a
 // micro-batch of lines at once:
-//   patch embedding + LayerNorm          cvit_embed_kernel (K = 16: VALU, one wave per output pixel)
-//   depthwise 7x7 + LayerNorm            cvit_dwconv_ln_kernel (a thread owns one channel of 8 consecutive pixels of a row: 7 x 14
-//                                        loads for 8 x 49 multiply-adds; the LayerNorm of those pixels inside the workgroup)
-//   Linear C->4C + GELU, 4C->C + scale   1x1 GEMMs on conv_igemm_kernel (MFMA); the layer scale is folded into the second
-//   + residual                           GEMM's weights and bias, its epilogue adds the fp32 residual in place
+//   patch embedding + LayerNorm          cvit_embed_kernel (K = 16: VALU; a lane owns one output pixel and its 96 channels)
+//   depthwise 7x7 + LayerNorm            cvit_dwconv_ln_kernel<H> (a workgroup owns all H <= 8 rows of 8 columns of a chunk, a thread one
+//                                        channel of them: every input loaded once; LayerNorm statistics through an LDS tile)
+//   Linear C->4C + GELU, 4C->C + scale   bf16 mode, C <= 256 and the ViT MLP: ONE kernel, cvit_mlp_kernel (the hidden layer goes from
+//   + residual                           MFMA accumulators to MFMA operands inside the lane); C = 512: row GEMM + tiled GEMM; hi/lo
+//                                        mode: two 1x1 GEMMs on conv_igemm_kernel.  The layer scale is folded into the second
+//                                        product's weights and bias; its epilogue adds the fp32 residual in place
 //   down-sampler                         cvit_ln_kernel writes LayerNorm(x) of rows 2y / 2y+1 side by side: the (2,1) conv is a
 //                                        1x1 GEMM with K = 2C
-//   ViT LayerNorms, chunk stitching      cvit_ln_kernel (one wave per token; mode 2 drops the overlap tokens and orders the rest)
-//   q/k/v (one 192 -> 576 GEMM, 1/8 folded into q), out, MLP      1x1 GEMMs, fp32 residual epilogue
+//   ViT LayerNorms, chunk stitching      cvit_ln_kernel (one wave per token; mode 2 gathers the 201 tokens of a line from its chunks)
+//   q/k/v (one 192 -> 576 GEMM, 1/8 folded into q), attention output      1x1 GEMMs, fp32 residual epilogue
 //   attention                            cvit_attention_kernel: one wave = 32 queries x one head, all 75 keys, on the matrix
 //                                        cores (the Lore processor's scheme, lore_processor.hip, with d = 64)
-//   classifier + arg-max                 1x1 GEMM with the arg-max epilogue + argmax_reduce_kernel: no logits in HBM
+//   classifier + arg-max                 bf16 mode: gemm_argmax_kernel (rec_kernels.hip, K = 192); hi/lo mode: 1x1 GEMM with the
+//                                        arg-max epilogue + argmax_reduce_kernel.  No logits in HBM either way
+// Chunks that hold no text (the line's resized width ends before them) are computed once per micro-batch and shared (forward_batch).
 // PT_PRECISION_BF16X3: activations [hi | lo], weights [hi | hi | lo], three MFMA passes -- as everywhere in the engine.
 #include <math.h>
 #include <stdio.h>
