@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 __all__ = ["db_resnet18_state_dict", "crnn_state_dict", "CRNN_NUM_CLASSES", "lore_dla34_state_dict",
-           "lore_processor_state_dict", "LORE_HEADS", "picodet_state_dict", "LCNET_CONFIG", "PICODET_STANDIN", "lore_wireless_state_dict", "db_nas_state_dict", "pplcnet_state_dict", "convnext_vit_state_dict"]
+           "lore_processor_state_dict", "LORE_HEADS", "picodet_state_dict", "LCNET_CONFIG", "PICODET_STANDIN", "lore_wireless_state_dict", "db_nas_state_dict", "pplcnet_state_dict", "convnext_vit_state_dict", "mtl_tabnet_backbone_state_dict"]
 
 CRNN_NUM_CLASSES = 7644  # crnn/modeling_crnn.py:90
 
@@ -256,6 +256,43 @@ def convnext_vit_state_dict(seed: int = 0, num_labels: int = CRNN_NUM_CLASSES):
         g.linear(q + "output.dense", 192, 768, scale=1.0)
     ln(p + "layernorm", 192)
     g.linear("vitstr.classifier", num_labels, 192, scale=4.0)
+    return g.sd
+
+
+def mtl_tabnet_backbone_state_dict(seed: int = 0):
+    """state_dict of ``TableResNetExtra(layers=[1, 2, 5, 3], gcb_config=...)`` (table/mtl_tabnet/table_resnet_extra.py:205-247,
+    mtl_tabnet_config.py:41-53): the backbone of MtlTabNet / TableMaster.  Used by the oracle's golden only so far."""
+    g = _Gen(seed)
+    r = g.rng
+
+    def block(p, cin, planes, gcb):
+        g.conv(p + ".conv1", planes, cin, 3, 3)
+        g.bn(p + ".bn1", planes)
+        g.conv(p + ".conv2", planes, planes, 3, 3, gain=1.0)
+        g.bn(p + ".bn2", planes)
+        if gcb:
+            hid = int(planes * 0.0625)
+            q = p + ".context_block"
+            g.conv(q + ".conv_mask", 1, planes, 1, 1, bias=True, gain=4.0)
+            g.conv(q + ".channel_add_conv.0", hid, planes, 1, 1, bias=True)
+            g.put(q + ".channel_add_conv.1.weight", r.uniform(0.7, 1.3, (hid, 1, 1)))
+            g.put(q + ".channel_add_conv.1.bias", r.uniform(-0.1, 0.1, (hid, 1, 1)))
+            g.conv(q + ".channel_add_conv.3", planes, hid, 1, 1, bias=True)
+        if cin != planes:
+            g.conv(p + ".downsample.0", planes, cin, 1, 1, gain=1.0)
+            g.bn(p + ".downsample.1", planes)
+
+    g.conv("conv1", 64, 3, 3, 3)
+    g.bn("bn1", 64)
+    g.conv("conv2", 128, 64, 3, 3)
+    g.bn("bn2", 128)
+    inpl = 128
+    for i, (planes, n, gcb) in enumerate(zip((256, 256, 512, 512), (1, 2, 5, 3), (False, True, True, True)), start=1):
+        for j in range(n):
+            block(f"layer{i}.{j}", inpl, planes, gcb and j == 0)
+            inpl = planes
+        g.conv(f"conv{i + 2}", planes, planes, 3, 3)
+        g.bn(f"bn{i + 2}", planes)
     return g.sd
 
 

@@ -750,6 +750,26 @@ def gen_convnext_vit():
     print("convnext_vit.npz", {k: v.shape for k, v in out.items()}, "distinct ids", len(set(top2.indices[..., 0].flatten().tolist())))
 
 
+def gen_mtl_tabnet_backbone():
+    """Feature maps of the reference's own ``TableResNetExtra`` (table/mtl_tabnet/table_resnet_extra.py:205-318, configuration of
+    mtl_tabnet_config.py:41-53) for seeded weights (loaded strict=True) and a seeded 96x128 input."""
+    from pdf_table_amd.synth_weights import mtl_tabnet_backbone_state_dict
+    mod = ref_import("pdftable.model.table.mtl_tabnet.table_resnet_extra")
+    torch.manual_seed(0)
+    gcb = dict(ratio=0.0625, headers=1, att_scale=False, fusion_type="channel_add", layers=[False, True, True, True])
+    model = mod.TableResNetExtra(layers=[1, 2, 5, 3], input_dim=3, gcb_config=gcb).eval()
+    sd = mtl_tabnet_backbone_state_dict(seed=41)
+    model.load_state_dict(sd, strict=True)
+    rng = np.random.default_rng(141)
+    x = rng.standard_normal((1, 3, 96, 128)).astype(np.float32)
+    with torch.no_grad():
+        f = model(torch.from_numpy(x))
+    out = {"x": x, "seed": np.array(41), "f1_sub": f[0][:, ::8, ::3, ::3].numpy(), "f2_sub": f[1][:, ::4, ::2, ::2].numpy(), "f3": f[2][:, ::4].numpy(),
+           "shapes": np.array([list(t.shape) for t in f]), "n_params": np.array(sum(p.numel() for p in model.parameters()))}
+    np.savez_compressed(os.path.join(HERE, "mtl_tabnet_backbone.npz"), **out)
+    print("mtl_tabnet_backbone.npz", {k: v.shape for k, v in out.items()}, int(out["n_params"]), "parameters")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["db", "crnn", "registry", "ctc", "host", "lore_dla", "lore_decode", "lore_processor", "picodet",
                              "table_html"]
@@ -785,3 +805,5 @@ if __name__ == "__main__":
         gen_ctc()
     if "convnext_vit" in which or not sys.argv[1:]:
         gen_convnext_vit()
+    if "mtl_tabnet" in which or not sys.argv[1:]:
+        gen_mtl_tabnet_backbone()
