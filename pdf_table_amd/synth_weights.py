@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 __all__ = ["db_resnet18_state_dict", "crnn_state_dict", "CRNN_NUM_CLASSES", "lore_dla34_state_dict",
-           "lore_processor_state_dict", "LORE_HEADS", "picodet_state_dict", "LCNET_CONFIG", "PICODET_STANDIN", "lore_wireless_state_dict", "db_nas_state_dict", "pplcnet_state_dict", "convnext_vit_state_dict", "mtl_tabnet_backbone_state_dict"]
+           "lore_processor_state_dict", "LORE_HEADS", "picodet_state_dict", "LCNET_CONFIG", "PICODET_STANDIN", "lore_wireless_state_dict", "db_nas_state_dict", "pplcnet_state_dict", "convnext_vit_state_dict", "mtl_tabnet_backbone_state_dict", "mtl_tabnet_decoder_state_dict"]
 
 CRNN_NUM_CLASSES = 7644  # crnn/modeling_crnn.py:90
 
@@ -293,6 +293,39 @@ def mtl_tabnet_backbone_state_dict(seed: int = 0):
             inpl = planes
         g.conv(f"conv{i + 2}", planes, planes, 3, 3)
         g.bn(f"bn{i + 2}", planes)
+    return g.sd
+
+
+def mtl_tabnet_decoder_state_dict(seed: int = 0, num_classes: int = 43, num_classes_cell: int = 60, d_model: int = 512, d_ff: int = 2024,
+                                  n_layers: int = 3):
+    """state_dict of ``MtlTabNetDecoder`` (table/mtl_tabnet/master_decoder.py:194-262, configuration of mtl_tabnet_config.py:59-77:
+    N = 3, d_model 512, 8 heads, d_ff 2024) without the two ``pe`` buffers (position tables, recomputed).  Oracle golden only."""
+    g = _Gen(seed)
+    r = g.rng
+
+    def layer(p):
+        for a in ("self_attn", "src_attn"):
+            for i in range(4):
+                g.linear(f"{p}.{a}.linears.{i}", d_model, d_model, scale=1.5)
+        g.linear(p + ".feed_forward.w_1", d_ff, d_model, scale=1.5)
+        g.linear(p + ".feed_forward.w_2", d_model, d_ff, scale=1.0)
+        for i in range(3):
+            g.put(f"{p}.sublayer.{i}.norm.weight", r.uniform(0.7, 1.3, (d_model,)))
+            g.put(f"{p}.sublayer.{i}.norm.bias", r.uniform(-0.1, 0.1, (d_model,)))
+
+    for i in range(n_layers - 1):
+        layer(f"layers.{i}")
+    layer("cls_layer.0")
+    layer("bbox_layer.0")
+    layer("cell_layer.0")
+    g.linear("cls_fc", num_classes, d_model, scale=6.0)
+    g.linear("bbox_fc.0", 4, d_model, scale=2.0)
+    g.linear("cell_fc", num_classes_cell, d_model, scale=6.0)
+    g.put("norm.weight", r.uniform(0.7, 1.3, (d_model,)))
+    g.put("norm.bias", r.uniform(-0.1, 0.1, (d_model,)))
+    g.put("embedding.lut.weight", r.standard_normal((num_classes, d_model)) * 0.05)
+    g.put("embedding_cell.lut.weight", r.standard_normal((num_classes_cell, d_model)) * 0.05)
+    g.linear("cell_input_fc", d_model, 2 * d_model, scale=1.5)
     return g.sd
 
 

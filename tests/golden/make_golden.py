@@ -770,6 +770,48 @@ def gen_mtl_tabnet_backbone():
     print("mtl_tabnet_backbone.npz", {k: v.shape for k, v in out.items()}, int(out["n_params"]), "parameters")
 
 
+MTL_DEC_CFG = dict(N=3, sos=40, eos=41, pad=42, max_len=12, sos_cell=57, eos_cell=58, pad_cell=59, max_len_cell=6, idx_tag_cell=[3, 5],
+                   num_classes=43, num_classes_cell=60)
+
+
+def gen_mtl_tabnet_decoder():
+    """Greedy test-time decode of the reference's own ``MtlTabNetDecoder`` (table/mtl_tabnet/master_decoder.py:194-531; N = 3,
+    d_model 512, 8 heads, d_ff 2024 as mtl_tabnet_config.py:59-77; small vocabularies and sequence limits) for seeded weights
+    and a seeded feature sequence.  The nested config the reference builds from an mmcv ``ConfigDict`` (``decoder.size`` is read
+    as an attribute, :227) is a dict with attribute access here -- the only stand-in."""
+    from pdf_table_amd.synth_weights import mtl_tabnet_decoder_state_dict
+    mod = ref_import("pdftable.model.table.mtl_tabnet.master_decoder")
+
+    class AttrDict(dict):
+        __getattr__ = dict.__getitem__
+
+    c = MTL_DEC_CFG
+    att = dict(headers=8, d_model=512, dropout=0.)
+    dec = AttrDict(self_attn=dict(att), src_attn=dict(att), feed_forward=dict(d_model=512, d_ff=2024, dropout=0.), size=512, dropout=0.)
+    torch.manual_seed(0)
+    model = mod.MtlTabNetDecoder(N=c["N"], decoder=dec, d_model=512, num_classes=c["num_classes"], num_classes_cell=c["num_classes_cell"],
+                                 start_idx=c["sos"], padding_idx=c["pad"], end_idx=c["eos"], max_seq_len=c["max_len"],
+                                 start_idx_cell=c["sos_cell"], padding_idx_cell=c["pad_cell"], end_idx_cell=c["eos_cell"],
+                                 max_seq_len_cell=c["max_len_cell"], idx_tag_cell=c["idx_tag_cell"]).eval()
+    sd = mtl_tabnet_decoder_state_dict(seed=43, num_classes=c["num_classes"], num_classes_cell=c["num_classes_cell"])
+    full = dict(sd)
+    for k, v in model.state_dict().items():
+        if k.endswith(".pe"):
+            full[k] = v                       # the two position tables are buffers computed in __init__
+    model.load_state_dict(full, strict=True)
+    rng = np.random.default_rng(143)
+    fmap = rng.standard_normal((2, 512, 3, 8)).astype(np.float32)       # a backbone feature map, before the positional encoding
+    with torch.no_grad():
+        feature = mod.PositionalEncoding(d_model=512).eval()(torch.from_numpy(fmap))
+        out, box, cells = model(None, feature, None, None, train_mode=False)
+    res = {"fmap": fmap, "seed": np.array(43), "tag_logits": out.numpy(), "boxes": box.numpy(), "n_cells": np.array(len(cells)),
+           "feature_sub": feature[:, ::3, ::16].numpy()}
+    for i, cl in enumerate(cells):
+        res[f"cell_{i}"] = cl.numpy()
+    np.savez_compressed(os.path.join(HERE, "mtl_tabnet_decoder.npz"), **res)
+    print("mtl_tabnet_decoder.npz", {k: v.shape for k, v in res.items()}, "tags", out.argmax(-1).tolist())
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["db", "crnn", "registry", "ctc", "host", "lore_dla", "lore_decode", "lore_processor", "picodet",
                              "table_html"]
@@ -807,3 +849,5 @@ if __name__ == "__main__":
         gen_convnext_vit()
     if "mtl_tabnet" in which or not sys.argv[1:]:
         gen_mtl_tabnet_backbone()
+    if "mtl_tabnet_decoder" in which or not sys.argv[1:]:
+        gen_mtl_tabnet_decoder()
