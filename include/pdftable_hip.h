@@ -89,6 +89,7 @@ enum {
   PT_MODEL_PPLCNET = 8,       /* cls/cls_pp_lcnet.py:164-283 (PPLCNet classifier); kinds 8 .. 8 + PT_CLS_SLOTS - 1 = classifier slots */
   PT_MODEL_PICODET = 5,     /* picodet/lcnet.py:159-259 + csp_pan.py:233-347 + pico_head.py:966-1160 (assumed config) */
   PT_MODEL_CONVNEXT_VIT = 16, /* convnext_vit/modeling_convnext_vit.py:20-45 (ConvNextViT recogniser) */
+  PT_MODEL_MTL_BACKBONE = 17, /* table/mtl_tabnet/table_resnet_extra.py:205-318 (TableResNetExtra, backbone of MtlTabNet) */
 };
 int pt_weights_load(pt_engine* e, int model_kind, const void* h_blob, size_t nbytes);
 /* Same, but the blob already sits in device memory (e.g. after an RCCL broadcast from rank 0). */
@@ -271,6 +272,12 @@ int pt_rec_cvit_forward_net(pt_engine* e, const float* d_gray, int layout, int n
 /* Resize + gray only (tests): d_gray fp32 [n_lines, 32, 804]. */
 int pt_rec_cvit_preprocess_crops(pt_engine* e, const uint8_t* d_crops_rgb, const pt_rec_line* d_lines, const int64_t* h_crop_px,
                                  int n_lines, float* d_gray, pt_stream stream);
+
+/* ---- MtlTabNet backbone (second half; the decoders are not on the engine yet) ------------------
+ * TableResNetExtra.forward (model/table/mtl_tabnet/table_resnet_extra.py:268-318) of the configuration in
+ * mtl_tabnet_config.py:41-53: d_x bf16 [n, H, W, 32] NHWC (channels 0..2 = the normalised image, the rest zero; BF16X3:
+ * [hi 32 | lo 32]), H and W multiples of 8 -> d_f3 fp32 [n, H/8, W/8, 512], the feature map the decoders read (feat[-1]). */
+int pt_tsr_mtl_backbone_net(pt_engine* e, const uint16_t* d_x, int n, int H, int W, float* d_f3, pt_stream stream);
 
 /* PP-OCR recognition pre-processor -- PPOcrRecPreProcessor (model/ocr_rec_pp/processor_ocr_rec_pp.py:69-135,
  * resize_norm_img :43-67), the pre-processing of the recogniser the reference's system path selects

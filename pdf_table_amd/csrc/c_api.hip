@@ -682,6 +682,13 @@ int pt_rec_cvit_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, i
   return PT_OK;
 }
 
+// ---- MtlTabNet backbone ------------------------------------------------------------------------------------------
+int pt_tsr_mtl_backbone_net(pt_engine* e, const uint16_t* d_x, int n, int H, int W, float* d_f3, pt_stream stream) {
+  PT_REQUIRE(e && d_x && d_f3 && n > 0, "pt_tsr_mtl_backbone_net: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  return pt_mtl_backbone_forward_net(e, d_x, n, H, W, d_f3, reinterpret_cast<hipStream_t>(stream));
+}
+
 // ---- PP-OCR recognition pre-processor --------------------------------------------------------------------------
 static int rec_pp_lut(pt_engine* e) {
   if (e->rec_pp_lut) return PT_OK;

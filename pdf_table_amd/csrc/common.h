@@ -277,6 +277,8 @@ int pt_cvit_forward_net(pt_engine* e, const float* gray, int layout, int n, int3
 int pt_launch_rec_resize_gray_f32(const uint8_t* crops, const pt_rec_line* lines, const long long* pix_off, int n_lines, int tw,
                                   float* out, hipStream_t s);
 
+int pt_mtl_backbone_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* f3, hipStream_t s);
+
 // ---- models ---------------------------------------------------------------------------------------------
 int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* prob, float* logits, hipStream_t s);
 int pt_launch_tsr_preprocess(const uint8_t* pages, int ph, int pw, const pt_tsr_table* tabs, int n, int H, int W, int bgr,

@@ -499,6 +499,22 @@ class HipEngine:
                                                  _ptr(ids), _ptr(mx), self._stream()), "pt_rec_cvit_forward_net")
         return ids, mx
 
+    def mtl_backbone_forward(self, x: torch.Tensor) -> torch.Tensor:
+        """MtlTabNet backbone (TableResNetExtra): x fp32 [n, 3, H, W] (normalised image, on the GPU) -> the last feature map
+        fp32 [n, 512, H/8, W/8].  torch only moves data here (NCHW fp32 -> padded NHWC bf16, hi/lo in BF16X3)."""
+        self._chk(x, torch.float32, "x")
+        n, c, h, w = x.shape
+        assert c == 3 and h % 8 == 0 and w % 8 == 0
+        xp = torch.zeros((n, h, w, 32), dtype=torch.float32, device=self._tdev)
+        xp[..., :3] = x.permute(0, 2, 3, 1)
+        hi = xp.to(torch.bfloat16)
+        if self.precision == L.PT_PRECISION_BF16X3:
+            hi = torch.cat([hi, (xp - hi.float()).to(torch.bfloat16)], -1)
+        hi = hi.contiguous()
+        f3 = torch.empty((n, h // 8, w // 8, 512), dtype=torch.float32, device=self._tdev)
+        L.check(self.lib.pt_tsr_mtl_backbone_net(self._h, _ptr(hi), n, h, w, _ptr(f3), self._stream()), "pt_tsr_mtl_backbone_net")
+        return f3.permute(0, 3, 1, 2)
+
     def op_conv2d(self, x: torch.Tensor, w_tiled: torch.Tensor, bias: torch.Tensor, ks: int, stride: int = 1,
                   relu: bool = False, res: Optional[torch.Tensor] = None, res_mode: int = 0, rep: int = 1,
                   shuffle_cout: int = 0, out: Optional[torch.Tensor] = None, out_coff: int = 0,

@@ -29,7 +29,7 @@ import torch
 BN_EPS = 1e-5
 _DT = {"bf16": 0, "f32": 1, "i32": 2}
 
-__all__ = ["pack_db_resnet18", "pack_crnn", "pack_lore_dla34", "pack_lore_processor", "pack_picodet", "pack_lore_wireless", "pack_db_nas", "pack_pplcnet", "pack_convnext_vit", "write_blob", "fold_conv_bn", "to_bf16_bits"]
+__all__ = ["pack_db_resnet18", "pack_crnn", "pack_lore_dla34", "pack_lore_processor", "pack_picodet", "pack_lore_wireless", "pack_db_nas", "pack_pplcnet", "pack_convnext_vit", "pack_mtl_backbone", "write_blob", "fold_conv_bn", "to_bf16_bits"]
 
 
 def to_bf16_bits(t: torch.Tensor) -> np.ndarray:
@@ -727,4 +727,40 @@ def pack_convnext_vit(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
     bpad[:ncls] = bc
     bl.add_conv("cls", wpad.reshape(npad, 192, 1, 1), bpad)
     bl.add("meta", np.array([ncls], dtype=np.int32), "i32")
+    return bl.tobytes()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# MtlTabNet backbone (table/mtl_tabnet/table_resnet_extra.py:205-318; kernels: csrc/mtl_model.hip)
+# --------------------------------------------------------------------------------------------------------------------
+def pack_mtl_backbone(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
+    """``TableResNetExtra`` state_dict (layers [1, 2, 5, 3], context blocks in the first block of stages 2-4) -> blob for
+    PT_MODEL_MTL_BACKBONE.  Every conv with its BatchNorm folded in (conv1's 3 input channels zero-padded to 32); the context
+    blocks' small tensors stay fp32: mask conv ``wm [C]`` / ``bm``, ``w0 [hid][C]`` / ``b0``, LayerNorm ``lg`` / ``lb [hid]``,
+    ``w3 [C][hid]`` / ``b3``."""
+    bl = _Blob(x3)
+    w, b = fold_conv_bn(sd, "conv1", "bn1")
+    bl.add_conv("conv1", *_pad_conv(w, b, 64, 32))
+    for i in range(2, 7):
+        bl.add_conv(f"conv{i}", *fold_conv_bn(sd, f"conv{i}", f"bn{i}"))
+    for li, nblk in enumerate((1, 2, 5, 3), start=1):
+        for j in range(nblk):
+            p = f"layer{li}.{j}"
+            bl.add_conv(p + ".conv1", *fold_conv_bn(sd, p + ".conv1", p + ".bn1"))
+            bl.add_conv(p + ".conv2", *fold_conv_bn(sd, p + ".conv2", p + ".bn2"))
+            if (p + ".downsample.0.weight") in sd:
+                bl.add_conv(p + ".down", *fold_conv_bn(sd, p + ".downsample.0", p + ".downsample.1"))
+            q = p + ".context_block"
+            if (q + ".conv_mask.weight") in sd:
+                f = lambda t: t.detach().float().contiguous().numpy().astype(np.float32)
+                c = sd[q + ".conv_mask.weight"].shape[1]
+                hid = sd[q + ".channel_add_conv.0.weight"].shape[0]
+                bl.add(p + ".gc.wm", f(sd[q + ".conv_mask.weight"].reshape(c)), "f32")
+                bl.add(p + ".gc.bm", f(sd[q + ".conv_mask.bias"].reshape(1)), "f32")
+                bl.add(p + ".gc.w0", f(sd[q + ".channel_add_conv.0.weight"].reshape(hid, c)), "f32")
+                bl.add(p + ".gc.b0", f(sd[q + ".channel_add_conv.0.bias"]), "f32")
+                bl.add(p + ".gc.lg", f(sd[q + ".channel_add_conv.1.weight"].reshape(hid)), "f32")
+                bl.add(p + ".gc.lb", f(sd[q + ".channel_add_conv.1.bias"].reshape(hid)), "f32")
+                bl.add(p + ".gc.w3", f(sd[q + ".channel_add_conv.3.weight"].reshape(c, hid)), "f32")
+                bl.add(p + ".gc.b3", f(sd[q + ".channel_add_conv.3.bias"]), "f32")
     return bl.tobytes()
