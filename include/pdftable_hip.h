@@ -90,6 +90,7 @@ enum {
   PT_MODEL_PICODET = 5,     /* picodet/lcnet.py:159-259 + csp_pan.py:233-347 + pico_head.py:966-1160 (assumed config) */
   PT_MODEL_CONVNEXT_VIT = 16, /* convnext_vit/modeling_convnext_vit.py:20-45 (ConvNextViT recogniser) */
   PT_MODEL_MTL_BACKBONE = 17, /* table/mtl_tabnet/table_resnet_extra.py:205-318 (TableResNetExtra, backbone of MtlTabNet) */
+  PT_MODEL_MTL_DECODER = 18,  /* table/mtl_tabnet/master_decoder.py:194-531 (MtlTabNetDecoder: structure, box and cell-content decoders) */
 };
 int pt_weights_load(pt_engine* e, int model_kind, const void* h_blob, size_t nbytes);
 /* Same, but the blob already sits in device memory (e.g. after an RCCL broadcast from rank 0). */
@@ -272,12 +273,6 @@ int pt_rec_cvit_forward_net(pt_engine* e, const float* d_gray, int layout, int n
 /* Resize + gray only (tests): d_gray fp32 [n_lines, 32, 804]. */
 int pt_rec_cvit_preprocess_crops(pt_engine* e, const uint8_t* d_crops_rgb, const pt_rec_line* d_lines, const int64_t* h_crop_px,
                                  int n_lines, float* d_gray, pt_stream stream);
-
-/* ---- MtlTabNet backbone (second half; the decoders are not on the engine yet) ------------------
- * TableResNetExtra.forward (model/table/mtl_tabnet/table_resnet_extra.py:268-318) of the configuration in
- * mtl_tabnet_config.py:41-53: d_x bf16 [n, H, W, 32] NHWC (channels 0..2 = the normalised image, the rest zero; BF16X3:
- * [hi 32 | lo 32]), H and W multiples of 8 -> d_f3 fp32 [n, H/8, W/8, 512], the feature map the decoders read (feat[-1]). */
-int pt_tsr_mtl_backbone_net(pt_engine* e, const uint16_t* d_x, int n, int H, int W, float* d_f3, pt_stream stream);
 
 /* PP-OCR recognition pre-processor -- PPOcrRecPreProcessor (model/ocr_rec_pp/processor_ocr_rec_pp.py:69-135,
  * resize_norm_img :43-67), the pre-processing of the recogniser the reference's system path selects
@@ -464,6 +459,45 @@ int pt_cls_forward_lines(pt_engine* e, int slot, const uint8_t* d_pages_rgb, int
 #define PT_PROF_NCLASS 4
 int pt_profile_enable(pt_engine* e, int on);
 int pt_profile_read(pt_engine* e, double* ms_per_class, long long* launches_per_class, double* flop_per_class);
+
+/* ---- MtlTabNet (second half): backbone, then the decoders below -------------------------------
+ * TableResNetExtra.forward (model/table/mtl_tabnet/table_resnet_extra.py:268-318) of the configuration in
+ * mtl_tabnet_config.py:41-53: d_x bf16 [n, H, W, 32] NHWC (channels 0..2 = the normalised image, the rest zero; BF16X3:
+ * [hi 32 | lo 32]), H and W multiples of 8 -> d_f3 fp32 [n, H/8, W/8, 512], the feature map the decoders read (feat[-1]). */
+int pt_tsr_mtl_backbone_net(pt_engine* e, const uint16_t* d_x, int n, int H, int W, float* d_f3, pt_stream stream);
+
+/* MtlTabNet test-time pre-processing (mtl_tabnet_config.py:136-160: TableResize(keep_ratio, long_size = 480) -> TablePad(480 x 480,
+ * pad_val 0) -> ToTensorOCR -> NormalizeOCR(mean 0.5, std 0.5); model/table/lgpma/lgpma_preprocess.py:1067-1093, 1128-1152) of n
+ * table crops given as rectangles of resident pages (pt_tsr_table.page / x0 / y0 / w / h; the affine fields are not read).  The
+ * long side becomes `size`, the short side int(size / long * short) (cv2.resize INTER_LINEAR, 8-bit), the rest of the size x size
+ * canvas is 0 BEFORE the normalisation, i.e. -1 after it.  d_out bf16 [n, size, size, 32] (BF16X3: [hi 32 | lo 32]), channels
+ * 0..2 in the crop's own channel order (mean and std are the same for all three).  The resized size of crop i is what
+ * pt_tsr_mtl_resized_size returns (host arithmetic in double, as the reference's Python floats). */
+int pt_tsr_mtl_preprocess(pt_engine* e, const uint8_t* d_pages, int n_pages, int h, int w, const pt_tsr_table* d_tables, int n, int size,
+                          uint16_t* d_out, pt_stream stream);
+void pt_tsr_mtl_resized_size(int crop_w, int crop_h, int size, int32_t* out_w, int32_t* out_h);
+
+/* The three decoders of MtlTabNet (master_decoder.py:354-517: greedy_forward / decode_test) for a batch of tables, KV-cached.
+ * pt_weights_load(PT_MODEL_MTL_DECODER) first.  pt_tsr_mtl_decoder_config: the blob's 13 configuration integers (structure
+ * classes, cell classes, <SOS>, <EOS>, <PAD>, max_seq_len, the same three ids and the limit of the cell alphabet, the two
+ * structure ids that open a non-empty cell, padded d_ff).
+ * pt_tsr_mtl_structure: d_f3 fp32 [n, hw, 512] = the backbone's last map (pt_tsr_mtl_backbone_net; NHWC = flattened row-major
+ * like the reference's view + permute).  Every table is decoded as the reference decodes a batch of ONE: it stops at its own <EOS>
+ * (or after max_seq_len + 1 positions).  d_tag_logits fp32 [n, max_seq_len + 1, classes] (raw cls_fc outputs), d_boxes fp32 [n,
+ * max_seq_len + 1, 4] (sigmoid); h_lens[n] = positions written per table (the length of the reference's output), h_cell_counts[n] =
+ * positions whose arg-max is '<td></td>' or '<td' (decode_test :389-392).  Synchronous: the call polls the sequences' end flags.
+ * pt_tsr_mtl_cells: the cell-content decoder for those cells (ordered by table, then position; total = sum of h_cell_counts):
+ * d_cell_ids int32 / d_cell_prob fp32 [total, max_seq_len_cell + 1] = arg-max and its soft-max probability per position,
+ * d_cell_logits fp32 [total, max_seq_len_cell + 1, cell classes] or NULL; h_steps[n] = positions decoded per table (all cells of a
+ * table share it: the loop ends when every cell emitted <EOS> in the same step, :451-453; 0 = no cells).
+ * force_redecode = 1 runs the reference's own O(L^2) schedule (every step decodes the whole prefix again) instead of the cache:
+ * the engine switches to it by itself when a <PAD> token is emitted (the reference's padding mask is not causal); tests use the
+ * flag to show that both schedules agree. */
+int pt_tsr_mtl_decoder_config(pt_engine* e, int32_t out13[13]);
+int pt_tsr_mtl_structure(pt_engine* e, const float* d_f3, int n, int hw, float* d_tag_logits, float* d_boxes, int32_t* h_lens,
+                         int32_t* h_cell_counts, int force_redecode, pt_stream stream);
+int pt_tsr_mtl_cells(pt_engine* e, int total, int32_t* d_cell_ids, float* d_cell_prob, float* d_cell_logits, int32_t* h_steps,
+                     int force_redecode, pt_stream stream);
 
 #ifdef __cplusplus
 }

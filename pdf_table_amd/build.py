@@ -20,7 +20,7 @@ STAMP = LIB + ".stamp"
 
 HIP_SOURCES = ["conv_igemm.hip", "det_kernels.hip", "db_model.hip", "rec_kernels.hip", "crnn_model.hip",
                "lore_kernels.hip", "lore_model.hip", "lore_decode.hip", "lore_processor.hip", "layout_kernels.hip", "layout_model.hip", "dbnas_model.hip", "cls_kernels.hip",
-               "graph_ops.hip", "cvit_model.hip", "mtl_model.hip", "c_api.hip"]
+               "graph_ops.hip", "cvit_model.hip", "mtl_model.hip", "mtl_decoder.hip", "c_api.hip"]
 CPP_SOURCES = ["db_post.cpp"]
 HEADERS = ["common.h", os.path.join("..", "..", "include", "pdftable_hip.h")]
 

@@ -20,7 +20,7 @@ void pt_set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* pt_last_error(void) { return g_err; }
-int pt_abi_version(void) { return 9; }   // 9: pt_rec_cvit_* (ConvNextViT recogniser); 8: pt_op_dwconv / add / maxpool / avgpool / chan_mean / scale_channels / act (generic ONNX executor); 7: pt_rec_pp_preprocess*; 6: pt_engine_set_lstm_cluster, pt_engine_check clears what it reports
+int pt_abi_version(void) { return 10; }   // 10: pt_tsr_mtl_preprocess / decoder_config / structure / cells (MtlTabNet decoders); 9: pt_rec_cvit_* (ConvNextViT recogniser); 8: pt_op_dwconv / add / maxpool / avgpool / chan_mean / scale_channels / act (generic ONNX executor); 7: pt_rec_pp_preprocess*; 6: pt_engine_set_lstm_cluster, pt_engine_check clears what it reports
 
 int pt_engine_check(pt_engine* e) {
   PT_REQUIRE(e, "pt_engine_check: null engine");
@@ -92,6 +92,7 @@ void pt_engine_destroy(pt_engine* e) {
   if (e->cls_scratch) (void)hipFree(e->cls_scratch);
   if (e->layout_scratch) (void)hipFree(e->layout_scratch);
   if (e->det_in) (void)hipFree(e->det_in);
+  pt_mtl_release(e);
   if (e->lstm_scratch) (void)hipFree(e->lstm_scratch);
   if (e->lstm_err) (void)hipHostFree(e->lstm_err);
   if (e->prof.h_lims) (void)hipHostFree(e->prof.h_lims);
@@ -687,6 +688,34 @@ int pt_tsr_mtl_backbone_net(pt_engine* e, const uint16_t* d_x, int n, int H, int
   PT_REQUIRE(e && d_x && d_f3 && n > 0, "pt_tsr_mtl_backbone_net: bad arguments");
   PT_HIP_CHECK(hipSetDevice(e->device));
   return pt_mtl_backbone_forward_net(e, d_x, n, H, W, d_f3, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ---- MtlTabNet pre-processing + decoders (mtl_decoder.hip) ---------------------------------------------------------
+int pt_tsr_mtl_preprocess(pt_engine* e, const uint8_t* d_pages, int n_pages, int h, int w, const pt_tsr_table* d_tables, int n, int size,
+                          uint16_t* d_out, pt_stream stream) {
+  PT_REQUIRE(e && d_pages && d_tables && d_out && n_pages > 0 && n > 0 && h > 0 && w > 0 && size > 0 && size % 8 == 0, "pt_tsr_mtl_preprocess: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  return pt_mtl_preprocess(e, d_pages, h, w, d_tables, n, size, d_out, reinterpret_cast<hipStream_t>(stream));
+}
+
+int pt_tsr_mtl_decoder_config(pt_engine* e, int32_t out13[13]) {
+  PT_REQUIRE(e && out13, "pt_tsr_mtl_decoder_config: bad arguments");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  return pt_mtl_decoder_config(e, out13);
+}
+
+int pt_tsr_mtl_structure(pt_engine* e, const float* d_f3, int n, int hw, float* d_tag_logits, float* d_boxes, int32_t* h_lens,
+                         int32_t* h_cell_counts, int force_redecode, pt_stream stream) {
+  PT_REQUIRE(e, "pt_tsr_mtl_structure: null engine");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  return pt_mtl_structure(e, d_f3, n, hw, d_tag_logits, d_boxes, h_lens, h_cell_counts, force_redecode, reinterpret_cast<hipStream_t>(stream));
+}
+
+int pt_tsr_mtl_cells(pt_engine* e, int total, int32_t* d_cell_ids, float* d_cell_prob, float* d_cell_logits, int32_t* h_steps,
+                     int force_redecode, pt_stream stream) {
+  PT_REQUIRE(e, "pt_tsr_mtl_cells: null engine");
+  PT_HIP_CHECK(hipSetDevice(e->device));
+  return pt_mtl_cells(e, total, d_cell_ids, d_cell_prob, d_cell_logits, h_steps, force_redecode, reinterpret_cast<hipStream_t>(stream));
 }
 
 // ---- PP-OCR recognition pre-processor --------------------------------------------------------------------------

@@ -134,6 +134,7 @@ struct pt_engine {
   // (thousands of launches on the same stream) later
   std::vector<int> cvit_maps[16][2];
   int cvit_slot = 0;
+  void* mtl_state = nullptr;                                 // mtl_decoder.hip: buffers + cell lists between pt_tsr_mtl_structure and pt_tsr_mtl_cells
 };
 
 // ---- conv launcher (conv_igemm.hip) -----------------------------------------------------------------
@@ -278,6 +279,14 @@ int pt_launch_rec_resize_gray_f32(const uint8_t* crops, const pt_rec_line* lines
                                   float* out, hipStream_t s);
 
 int pt_mtl_backbone_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* f3, hipStream_t s);
+// mtl_decoder.hip
+void pt_mtl_release(pt_engine* e);
+int pt_mtl_preprocess(pt_engine* e, const uint8_t* pages, int ph, int pw, const pt_tsr_table* tabs, int n, int size, bf16_t* out, hipStream_t s);
+int pt_mtl_decoder_config(pt_engine* e, int32_t* out13);
+int pt_mtl_structure(pt_engine* e, const float* f3, int n, int hw, float* d_tag_logits, float* d_boxes, int32_t* h_lens, int32_t* h_cell_counts,
+                     int force_redecode, hipStream_t s);
+int pt_mtl_cells(pt_engine* e, int total, int32_t* d_cell_ids, float* d_cell_prob, float* d_cell_logits, int32_t* h_steps, int force_redecode,
+                 hipStream_t s);
 
 // ---- models ---------------------------------------------------------------------------------------------
 int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* prob, float* logits, hipStream_t s);

@@ -1,0 +1,1129 @@
+// mtl_decoder.hip -- the three autoregressive decoders of MtlTabNet (second half) as a KV-cached greedy
+// loop over a BATCH of tables.
+//
+// Reference (model/table/mtl_tabnet/master_decoder.py): MtlTabNetDecoder.forward_test :503-517 -> greedy_forward :463-491 ->
+// decode_test :354-461.  N = 3: two shared DecoderLayers (:99-114: x += self_attn(LN x); x += src_attn(LN x, feature);
+// x += FFN(LN x)), then one more layer + LayerNorm + Linear per head: structure tokens (cls_layer / cls_fc), cell boxes (bbox_layer /
+// bbox_fc + sigmoid), and -- after the structure loop ended -- the cell-content decoder (:387-459): every position whose structure
+// token is '<td></td>' or '<td' becomes a row [emb_cell(token) + pe | x2 of that position] -> cell_input_fc -> DecoderLayerCell
+// (keys / values of ONE table for all its cells, :117-144) -> LayerNorm -> cell_fc, greedy until ALL cells of the table emit
+// <EOS> in the same step.  The reference is called with ONE table (processor_mtl_tabnet.py:84-89) and decodes the WHOLE prefix
+// again at every step (O(L^2) layer passes).
+//
+// Here: rows are (position, sequence); a step computes only the NEW position of every sequence (tables in the structure loop,
+// cells in the content loop), the self-attention reads keys / values of earlier positions from a cache [position][sequence][q|k|v]
+// that the q/k/v GEMM of each step extends in place, and the source attention reads keys / values of the table's 3600 feature
+// vectors that ONE GEMM produced for all five layers before the loop (`kv`).  Per-table semantics are the reference's at batch 1:
+// a table stops at its own <EOS> (fin[]), the others go on.
+//
+// The one place where the reference is NOT causal: make_mask (:264-278) masks the QUERY rows of <PAD> tokens, so a <PAD> the
+// decoder emitted itself attends uniformly to the whole current prefix, future positions included.  A cache cannot express that;
+// the loop therefore watches for an emitted <PAD> (first_pad), rolls back to that step and continues in RE-DECODE mode, which runs
+// the same kernels over positions 0..t of every sequence at every step -- the reference's own schedule.  Trained checkpoints never
+// emit <PAD> (it is the loss's ignore_index); seeded random weights do, and tests/test_gpu_mtl.py covers both paths.
+//
+// Kernels: every Linear is a 1x1 GEMM on conv_igemm_kernel (fp32 residual stream, hi/lo operands in BF16X3 like the rest of the
+// engine); mtl_ln_kernel (nn.LayerNorm, one wave per row); mtl_self_attn_kernel (one wave per (row, head): lane = key for the
+// scores, lane = channel for the weighted sum; fp32); mtl_cross_attn_kernel (the MFMA flash scheme of lore_processor.hip /
+// cvit_model.hip with d = 64: a wave = up to 32 queries of ONE table x one head, the keys optionally split over several waves
+// whose partial (max, sum, acc) triples mtl_cross_combine_kernel merges -- with one query per table and step, the split is what
+// fills the chip); pick kernels (arg-max, soft-max probability, <EOS> / <PAD> bookkeeping, next-token embedding).
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 abf16x8;
+typedef __attribute__((ext_vector_type(16))) float af32x16;
+
+constexpr int D = 512, HEADS = 8, DK = 64, NL = 5;      // d_model, heads, d_k, decoder layers with a source attention
+constexpr int KVC = NL * 2 * D;                          // channels of the cross key / value tensor: [k_l | v_l] per layer
+constexpr int PE_ROWS = 4096;
+
+__device__ __forceinline__ float bf2f(uint32_t b) { return __uint_as_float(b << 16); }
+__device__ __forceinline__ uint32_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ void put(bf16_t* p, int lo_off, int split, float v) {
+  const uint32_t h = f2bf(v);
+  p[0] = (bf16_t)h;
+  if (split) p[lo_off] = (bf16_t)f2bf(v - bf2f(h));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+  return v;
+}
+__device__ __forceinline__ abf16x8 ld8(const bf16_t* p) { return *reinterpret_cast<const abf16x8*>(p); }
+
+// out_enc = PositionalEncoding(feat) (:182-188): f3 fp32 [n * hw, 512] (NHWC = the reference's view(b, c, h*w).permute(0, 2, 1))
+// + pe[token] -> bf16 (hi | lo) rows; rows >= rows_valid are zero.  One wave per row.
+__global__ __launch_bounds__(256) void mtl_feature_kernel(const float* __restrict__ f3, const float* __restrict__ pe, long long rows_valid,
+                                                          long long rows_pad, int hw, bf16_t* __restrict__ out, int split) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows_pad) return;
+  bf16_t* op = out + row * (split ? 2 * D : D);
+  const int t = (int)(row % hw);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = lane + 64 * k;
+    put(op + c, D, split, row < rows_valid ? f3[row * D + c] + pe[(size_t)t * D + c] : 0.f);
+  }
+}
+
+// Embeddings (* sqrt(d_model), folded into the table) + PositionalEncoding for positions [p0, p0 + npos) of every sequence.
+// Row r = (p - p0) * Mp + s.  xout != null: fp32 rows [rows, 512] (structure decoder).  cin != null (cell-content decoder): bf16
+// rows [rows, 1024] = [embedding + pe | x2 of the cell's structure position] -- the input of cell_input_fc (:417-418).
+__global__ __launch_bounds__(256) void mtl_embed_kernel(const int* __restrict__ tok, const float* __restrict__ emb, const float* __restrict__ pe, int p0,
+                                                        int npos, int Mp, int M, float* __restrict__ xout, bf16_t* __restrict__ cin,
+                                                        const float* __restrict__ x2keep, const int* __restrict__ src_row, int split) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= (long long)npos * Mp) return;
+  const int pi = (int)(row / Mp), s = (int)(row % Mp), p = p0 + pi;
+  const bool valid = s < M;
+  const int id = valid ? tok[(size_t)p * Mp + s] : 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = lane + 64 * k;
+    const float v = valid ? emb[(size_t)id * D + c] + pe[(size_t)p * D + c] : 0.f;
+    if (xout) xout[row * D + c] = v;
+    if (cin) {
+      bf16_t* op = cin + row * (split ? 4 * D : 2 * D);
+      put(op + c, 2 * D, split, v);
+      put(op + D + c, 2 * D, split, valid ? x2keep[(size_t)src_row[s] * D + c] : 0.f);
+    }
+  }
+}
+
+// nn.LayerNorm(512) (biased variance, eps = 1e-5 inside the root) of fp32 rows -> bf16 (hi | lo).  One wave per row.
+__global__ __launch_bounds__(256) void mtl_ln_kernel(const float* __restrict__ x, long long rows, const float* __restrict__ g,
+                                                     const float* __restrict__ b, bf16_t* __restrict__ out, int split) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float v[8], s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    v[k] = x[row * D + lane + 64 * k];
+    s += v[k];
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) q += (v[k] - mean) * (v[k] - mean);
+  const float rstd = 1.f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+  bf16_t* op = out + row * (split ? 2 * D : D);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = lane + 64 * k;
+    put(op + c, D, split, (v[k] - mean) * rstd * g[c] + b[c]);
+  }
+}
+
+// a [rows, 512] -> b, c (the cls and bbox layers start from the shared layers' output) and, for sequences still running at step
+// p1, -> keep[p][s] (x2 of every position: what the cell-content decoder reads, :399)
+__global__ __launch_bounds__(256) void mtl_fork_kernel(const float* __restrict__ a, float* __restrict__ b, float* __restrict__ c, float* __restrict__ keep,
+                                                       const int* __restrict__ fin, int p0, int p1, int Mp, int M) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)(p1 - p0 + 1) * Mp * (D / 4);
+  if (i >= total) return;
+  const float4 v = reinterpret_cast<const float4*>(a)[i];
+  reinterpret_cast<float4*>(b)[i] = v;
+  reinterpret_cast<float4*>(c)[i] = v;
+  const long long row = i / (D / 4);
+  const int pi = (int)(row / Mp), s = (int)(row % Mp);
+  if (s < M && fin[s] >= p1) reinterpret_cast<float4*>(keep)[((size_t)(p0 + pi) * Mp + s) * (D / 4) + (i % (D / 4))] = v;
+}
+
+// Self-attention of DecoderLayer (:109-110, self_attention :57-72) for one (row, head): the query is position p of sequence s, keys
+// and values are positions 0..p of the same sequence in the cache [position][Mp][q 512 | k 512 | v 512] (k already / 8, hi/lo:
+// [hi 1536 | lo 1536]).  make_mask (:264-278): a query whose own token is <PAD> has every score replaced by -6.55e4, i.e. attends
+// uniformly to ALL Lcur positions of the current prefix.  Scores: lane = key (64-term fp32 dot products); weighted sum: lane = channel.
+template <int SPLIT>
+__global__ __launch_bounds__(64) void mtl_self_attn_kernel(const bf16_t* __restrict__ cache, const int* __restrict__ tok, int pad, int p0, int Mp, int M,
+                                                           int Lcur, bf16_t* __restrict__ att) {
+  extern __shared__ float sc[];
+  const int pi = blockIdx.x / M, s = blockIdx.x % M, p = p0 + pi, head = blockIdx.y, lane = threadIdx.x;
+  constexpr int LO = 3 * D, cs = SPLIT ? 2 * LO : LO;
+  const bool is_pad = tok[(size_t)p * Mp + s] == pad;
+  const int nk = is_pad ? Lcur : p + 1;
+  float q[DK];
+  {
+    const bf16_t* qp = cache + ((size_t)p * Mp + s) * cs + head * DK;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const abf16x8 h = ld8(qp + 8 * k);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q[8 * k + j] = (float)h[j];
+      if (SPLIT) {
+        const abf16x8 l = ld8(qp + LO + 8 * k);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[8 * k + j] += (float)l[j];
+      }
+    }
+  }
+  float mx = -INFINITY;
+  for (int j = lane; j < nk; j += 64) {
+    const bf16_t* kp = cache + ((size_t)j * Mp + s) * cs + D + head * DK;
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const abf16x8 h = ld8(kp + 8 * k);
+      abf16x8 l;
+      if (SPLIT) l = ld8(kp + LO + 8 * k);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float kv = (float)h[i];
+        if (SPLIT) kv += (float)l[i];
+        a = fmaf(q[8 * k + i], kv, a);
+      }
+    }
+    if (is_pad) a = -6.55e4f;
+    sc[j] = a;
+    mx = fmaxf(mx, a);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < nk; j += 64) {
+    const float e = expf(sc[j] - mx);
+    sc[j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __syncthreads();
+  float o = 0.f;
+  const bf16_t* vp = cache + (size_t)s * cs + 2 * D + head * DK + lane;
+  for (int j = 0; j < nk; ++j) {
+    const bf16_t* r = vp + (size_t)j * Mp * cs;
+    float v = bf2f(r[0]);
+    if (SPLIT) v += bf2f(r[LO]);
+    o = fmaf(sc[j], v, o);
+  }
+  put(att + ((size_t)pi * Mp + s) * (SPLIT ? 2 * D : D) + head * DK + lane, D, SPLIT, o / sum);
+}
+
+// Source attention (:111-112; MultiHeadAttentionCell :117-144 for the cell decoder: same arithmetic, keys of ONE table) for a tile
+// of up to 32 queries of one table x one head x one slice of the keys, on the matrix cores.  tiles[i] = (table, first query row,
+// queries, row stride).  q [rows, 512] (hi | lo), kv [n * hw, KVC] with the layer's keys (already / 8) at channel koff and values at
+// koff + 512.  S^T (32 keys x 32 queries) = K Q^T over d = 64 (four v_mfma_f32_32x32x16_bf16); in the D layout a lane owns ONE
+// query and 16 keys, so the online soft-max is in-lane + one exchange with lane ^ 32; O^T (64 x 32) += V^T P^T with P fed from the
+// registers it is in.  nsplit == 1: normalised output rows -> att (hi | lo).  nsplit > 1: (max, sum) and the un-normalised
+// accumulator of this key slice -> mlpart / opart for mtl_cross_combine_kernel.
+template <int SPLIT>
+__global__ __launch_bounds__(64) void mtl_cross_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, int koff, const int4* __restrict__ tiles,
+                                                            int hw, int keys_per_split, int nsplit, long long R, float* __restrict__ opart,
+                                                            float* __restrict__ mlpart, bf16_t* __restrict__ att) {
+  const int4 tile = tiles[blockIdx.x];
+  const int head = blockIdx.y, z = blockIdx.z, lane = threadIdx.x;
+  const int tab = tile.x, row0 = tile.y, cnt = tile.z, rstride = tile.w;
+  constexpr int LOQ = D, qcs = SPLIT ? 2 * D : D, LOK = KVC, kcs = SPLIT ? 2 * KVC : KVC;
+  const int col = lane & 31, half = lane >> 5;
+  const long long qrow = row0 + (long long)(col < cnt ? col : cnt - 1) * rstride;
+  const bf16_t* qp = q + qrow * qcs + head * DK + half * 8;
+  abf16x8 qh[4], ql[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    qh[s] = ld8(qp + 16 * s);
+    if (SPLIT) ql[s] = ld8(qp + LOQ + 16 * s);
+  }
+  af32x16 acc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+  float m = -INFINITY, l = 0.f;
+  const int kbeg = z * keys_per_split, kend = min(hw, kbeg + keys_per_split);
+  const bf16_t* kbase = kv + (size_t)tab * hw * kcs + koff + head * DK;
+  for (int k0 = kbeg; k0 < kend; k0 += 32) {
+    const int krow = k0 + col;
+    const bf16_t* kp = kbase + (size_t)(krow < kend ? krow : kend - 1) * kcs + half * 8;
+    af32x16 sc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const abf16x8 kh = ld8(kp + 16 * s);
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[s], sc, 0, 0, 0);
+      if (SPLIT) {
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[s], sc, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(kp + LOK + 16 * s), qh[s], sc, 0, 0, 0);
+      }
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (key >= kend) sc[r] = -INFINITY;
+      mt = fmaxf(mt, sc[r]);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    const float mn = fmaxf(m, mt);
+    const float scale = expf(m - mn);
+    float p[16], lt = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { p[r] = expf(sc[r] - mn); lt += p[r]; }
+    lt += __shfl_xor(lt, 32);
+    l = l * scale + lt;
+    m = mn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] *= scale; acc[1][r] *= scale; }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      abf16x8 ph, pl;
+      int keys[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float pv = p[8 * s2 + j];
+        const uint32_t hb = f2bf(pv);
+        ph[j] = __builtin_bit_cast(__bf16, (uint16_t)hb);
+        if (SPLIT) pl[j] = __builtin_bit_cast(__bf16, (uint16_t)f2bf(pv - bf2f(hb)));
+        const int key = k0 + (j & 3) + 8 * (2 * s2 + (j >> 2)) + 4 * half;
+        keys[j] = key < kend ? key : kend - 1;              // its probability is exactly 0
+      }
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        abf16x8 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bf16_t* vp = kbase + (size_t)keys[j] * kcs + D + db * 32 + col;     // A row = d
+          vh[j] = __builtin_bit_cast(__bf16, vp[0]);
+          if (SPLIT) vl[j] = __builtin_bit_cast(__bf16, vp[LOK]);
+        }
+        acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, acc[db], 0, 0, 0);
+        if (SPLIT) {
+          acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, acc[db], 0, 0, 0);
+          acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, acc[db], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (col >= cnt) return;
+  if (nsplit == 1) {
+    bf16_t* op = att + qrow * qcs + head * DK;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) put(op + db * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, D, SPLIT, acc[db][r] / l);
+  } else {
+    const size_t slot = ((size_t)z * R + qrow) * HEADS + head;
+    float* op = opart + slot * DK;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) op[db * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = acc[db][r];
+    if (half == 0) {
+      mlpart[slot * 2] = m;
+      mlpart[slot * 2 + 1] = l;
+    }
+  }
+}
+
+// merges the key slices of mtl_cross_attn_kernel: out = sum_z e^(m_z - M) acc_z / sum_z e^(m_z - M) l_z.  thread = (row, channel)
+__global__ __launch_bounds__(512) void mtl_cross_combine_kernel(const float* __restrict__ opart, const float* __restrict__ mlpart, int nsplit, long long R, int Mp,
+                                                                int M, bf16_t* __restrict__ att, int split) {
+  const int pi = blockIdx.x / M, s = blockIdx.x % M, c = threadIdx.x, head = c >> 6;
+  const long long row = (long long)pi * Mp + s;
+  float mx = -INFINITY;
+  for (int z = 0; z < nsplit; ++z) mx = fmaxf(mx, mlpart[(((size_t)z * R + row) * HEADS + head) * 2]);
+  float num = 0.f, den = 0.f;
+  for (int z = 0; z < nsplit; ++z) {
+    const size_t slot = ((size_t)z * R + row) * HEADS + head;
+    const float w = expf(mlpart[slot * 2] - mx);
+    den += w * mlpart[slot * 2 + 1];
+    num += w * opart[slot * DK + (c & 63)];
+  }
+  put(att + row * (split ? 2 * D : D) + c, D, split, num / den);
+}
+
+// Structure heads of positions [p0, p1] (decode_test :372-380, 461 + greedy_forward :476-490), one thread per row.  For sequences
+// still running at step p1 (fin[s] >= p1): raw logits -> out_logits [M, T, ncls], sigmoid boxes -> out_boxes [M, T, 4], arg-max ->
+// ids; the row of position p1 decides: <EOS> or the length limit ends the sequence (fin[s] = p1, i.e. p1 + 1 output positions),
+// anything else is appended (tok[p1 + 1]); an appended <PAD> is reported through first_pad (see the header comment).
+__global__ __launch_bounds__(256) void mtl_tag_pick_kernel(const float* __restrict__ lg, const float* __restrict__ bx, int p0, int p1, int Mp, int M, int ncls,
+                                                           int ncls_p, int eos, int pad, int max_len, int T, int* __restrict__ tok, int* __restrict__ ids,
+                                                           int* __restrict__ fin, int* __restrict__ first_pad, float* __restrict__ out_logits,
+                                                           float* __restrict__ out_boxes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (p1 - p0 + 1) * M) return;
+  const int pi = i / M, s = i % M, p = p0 + pi;
+  const bool running = fin[s] >= p1;
+  if (!running) {
+    if (p == p1) tok[(size_t)(p1 + 1) * Mp + s] = eos;        // a valid id for the embedding of rows nobody reads
+    return;
+  }
+  const float* r = lg + ((size_t)pi * Mp + s) * ncls_p;
+  float best = r[0];
+  int bi = 0;
+  float* ol = out_logits + ((size_t)s * T + p) * ncls;
+  ol[0] = best;
+  for (int c = 1; c < ncls; ++c) {
+    const float v = r[c];
+    ol[c] = v;
+    if (v > best) { best = v; bi = c; }
+  }
+  ids[(size_t)p * Mp + s] = bi;
+  const float* b = bx + ((size_t)pi * Mp + s) * 8;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) out_boxes[((size_t)s * T + p) * 4 + k] = 1.f / (1.f + expf(-b[k]));
+  if (p == p1) {
+    if (bi == eos || p1 == max_len) {
+      fin[s] = p1;
+      tok[(size_t)(p1 + 1) * Mp + s] = eos;
+    } else {
+      tok[(size_t)(p1 + 1) * Mp + s] = bi;
+      if (bi == pad) atomicMin(first_pad, p1);
+    }
+  }
+}
+
+// Cell-content head of positions [p0, p1], one wave per row (cell): soft-max probability of the arg-max (what tensor2idx_cell reads,
+// master_convertor.py:551-584) -> cell_ids / cell_prob [Mc, Tc], raw logits -> cell_logits [Mc, Tc, ncell] when requested; the arg-max
+// of position p1 -> nxt[cell].  Written only for cells whose table is still running at step p1.
+__global__ __launch_bounds__(256) void mtl_cell_pick_kernel(const float* __restrict__ lg, int p0, int p1, int Mp, int M, int ncell, int ncell_p, int Tc,
+                                                            const int* __restrict__ cell_tab, const int* __restrict__ finc, int* __restrict__ nxt,
+                                                            int* __restrict__ cell_ids, float* __restrict__ cell_prob, float* __restrict__ cell_logits) {
+  const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (w >= (long long)(p1 - p0 + 1) * M) return;
+  const int pi = (int)(w / M), s = (int)(w % M), p = p0 + pi;
+  if (finc[cell_tab[s]] < p1) return;
+  const float* r = lg + ((size_t)pi * Mp + s) * ncell_p;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = lane; c < ncell; c += 64) {
+    const float v = r[c];
+    if (cell_logits) cell_logits[((size_t)s * Tc + p) * ncell + c] = v;
+    if (v > best) { best = v; bi = c; }
+  }
+#pragma unroll
+  for (int mm = 32; mm > 0; mm >>= 1) {
+    const float ob = __shfl_xor(best, mm);
+    const int oi = __shfl_xor(bi, mm);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  float sum = 0.f;
+  for (int c = lane; c < ncell; c += 64) sum += expf(r[c] - best);
+  sum = wave_sum(sum);
+  if (lane == 0) {
+    cell_ids[(size_t)s * Tc + p] = bi;
+    cell_prob[(size_t)s * Tc + p] = 1.f / sum;
+    if (p == p1) nxt[s] = bi;
+  }
+}
+
+// One workgroup per table after the pick of step p1 (:446-455): the content loop of a table ends when ALL its cells emitted <EOS> in
+// this step, or at the length limit; otherwise every cell's arg-max is appended.
+__global__ __launch_bounds__(256) void mtl_cell_next_kernel(const int* __restrict__ tab_first, const int* __restrict__ nxt, int p1, int Mp, int eos, int pad,
+                                                            int max_len, int* __restrict__ tok, int* __restrict__ finc, int* __restrict__ first_pad) {
+  __shared__ int cnt;
+  const int b = blockIdx.x, c0 = tab_first[b], c1 = tab_first[b + 1];
+  const bool running = finc[b] >= p1;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  if (running) {
+    int mine = 0;
+    for (int c = c0 + threadIdx.x; c < c1; c += blockDim.x) mine += nxt[c] == eos;
+    if (mine) atomicAdd(&cnt, mine);
+  }
+  __syncthreads();
+  const bool stop = !running || cnt == c1 - c0 || p1 == max_len;
+  for (int c = c0 + threadIdx.x; c < c1; c += blockDim.x) {
+    const int v = stop ? eos : nxt[c];
+    tok[(size_t)(p1 + 1) * Mp + c] = v;
+    if (!stop && v == pad) atomicMin(first_pad, p1);
+  }
+  if (running && stop && threadIdx.x == 0) finc[b] = p1;
+}
+
+__global__ void mtl_fill_kernel(int* __restrict__ p, int n, int v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// roll back to step `step`: sequences that ended later are running again
+__global__ void mtl_rollback_kernel(int* __restrict__ fin, int n, int step) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && fin[i] > step) fin[i] = INT_MAX;
+}
+
+// TableResize(keep_ratio, long_size) (lgpma_preprocess.py:1067-1093): Python floats = IEEE double; int() truncates
+__host__ __device__ inline void mtl_resized(int w, int h, int size, int* ow, int* oh) {
+  double fw = (double)w, fh = (double)h;
+  if (fw < fh) {
+    fw = (double)size / fh * fw;
+    fh = (double)size;
+  } else {
+    fh = (double)size / fw * fh;
+    fw = (double)size;
+  }
+  int iw = (int)fw, ih = (int)fh;
+  *ow = iw < 1 ? 1 : iw;       // cv2.resize raises on an empty size; a 1-pixel line is the nearest well-defined answer
+  *oh = ih < 1 ? 1 : ih;
+}
+
+struct RCoef {
+  int s0, s1, a0, a1;
+};
+// OpenCV's 8-bit INTER_LINEAR coefficients (see det_kernels.hip: resize_coef)
+__device__ __forceinline__ RCoef mtl_coef(int d, double scale, int ssize, bool clamp_frac) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  RCoef c;
+  if (clamp_frac) {
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+  }
+  c.a0 = (int)rintf((1.f - f) * 2048.f);
+  c.a1 = (int)rintf(f * 2048.f);
+  int t0 = s, t1 = s + 1;
+  c.s0 = t0 < 0 ? 0 : (t0 >= ssize ? ssize - 1 : t0);
+  c.s1 = t1 < 0 ? 0 : (t1 >= ssize ? ssize - 1 : t1);
+  return c;
+}
+
+// TableResize + TablePad + ToTensorOCR + NormalizeOCR of one table crop per blockIdx.y: out bf16 [n, size, size, 32] (hi | lo)
+__global__ __launch_bounds__(256) void mtl_preprocess_kernel(const uint8_t* __restrict__ pages, int ph, int pw, const pt_tsr_table* __restrict__ tabs, int size,
+                                                             bf16_t* __restrict__ out, int split) {
+  const int b = blockIdx.y;
+  const pt_tsr_table t = tabs[b];
+  int nw, nh;
+  mtl_resized(t.crop_w, t.crop_h, size, &nw, &nh);
+  const double sx = (double)t.crop_w / nw, sy = (double)t.crop_h / nh;
+  const bool area2 = (t.crop_w == 2 * nw) && (t.crop_h == 2 * nh);
+  const uint8_t* src = pages + ((size_t)t.page * ph + t.y0) * pw * 3 + (size_t)t.x0 * 3;
+  const size_t pitch = (size_t)pw * 3;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < size * size; i += gridDim.x * blockDim.x) {
+    const int x = i % size, y = i / size;
+    float o[3] = {-1.f, -1.f, -1.f};                      // pad value 0: (0 - 0.5) / 0.5
+    if (x < nw && y < nh) {
+      int v[3];
+      if (t.crop_w == nw && t.crop_h == nh) {
+        const uint8_t* p = src + y * pitch + x * 3;
+        v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+      } else if (area2) {
+        const uint8_t* p0 = src + (size_t)(2 * y) * pitch + 2 * x * 3;
+        const uint8_t* p1 = p0 + pitch;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = (p0[c] + p0[3 + c] + p1[c] + p1[3 + c] + 2) >> 2;
+      } else {
+        const RCoef cx = mtl_coef(x, sx, t.crop_w, true), cy = mtl_coef(y, sy, t.crop_h, false);
+        const uint8_t* r0 = src + (size_t)cy.s0 * pitch;
+        const uint8_t* r1 = src + (size_t)cy.s1 * pitch;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int S0 = r0[cx.s0 * 3 + c] * cx.a0 + r0[cx.s1 * 3 + c] * cx.a1;
+          const int S1 = r1[cx.s0 * 3 + c] * cx.a0 + r1[cx.s1 * 3 + c] * cx.a1;
+          int r = (((cy.a0 * (S0 >> 4)) >> 16) + ((cy.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
+          v[c] = r < 0 ? 0 : (r > 255 ? 255 : r);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o[c] = ((float)v[c] / 255.f - 0.5f) / 0.5f;       // to_tensor: / 255; normalize: (x - mean) / std
+    }
+    bf16_t* op = out + ((size_t)b * size * size + i) * (split ? 64 : 32);
+#pragma unroll
+    for (int c = 0; c < 32; ++c) put(op + c, 32, split, c < 3 ? o[c] : 0.f);
+  }
+}
+
+struct DevBuf {
+  char* base = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return PT_OK;
+    PT_HIP_CHECK(hipDeviceSynchronize());
+    if (base) PT_HIP_CHECK(hipFree(base));
+    base = nullptr;
+    cap = 0;
+    PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&base), bytes + (1u << 20)));
+    cap = bytes + (1u << 20);
+    return PT_OK;
+  }
+  void release() {
+    if (base) (void)hipFree(base);
+    base = nullptr;
+    cap = 0;
+  }
+};
+
+struct Carver {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    const size_t o = off;
+    off = (off + bytes + 255) & ~size_t(255);
+    return o;
+  }
+};
+
+// what survives between pt_tsr_mtl_structure and pt_tsr_mtl_cells
+struct MtlState {
+  DevBuf persist, work, cwork;
+  int n = 0, hw = 0, Mp = 0, T = 0, x3 = 0;
+  size_t o_kv = 0, o_keep = 0, o_tok = 0, o_ids = 0, o_fin = 0;
+  std::vector<int> lens;        // output positions per table
+  std::vector<int> cell_tab;    // table of every cell, cells ordered by (table, position)
+  std::vector<int> cell_src;    // row of x2keep ( = position * Mp + table) of every cell
+  std::vector<int> tab_first;   // [n + 1]
+  bool structure_done = false;
+  int* h_poll = nullptr;        // pinned
+};
+
+struct Ctx {
+  pt_engine* e;
+  const PtModel* m;
+  hipStream_t s;
+  int x3, mul, rc;
+  const PtTensor* get(const std::string& n) {
+    const PtTensor* t = m->find(n);
+    if (!t && rc == PT_OK) {
+      pt_set_error("MtlTabNet decoder weight blob lacks tensor '%s'", n.c_str());
+      rc = PT_ERR_FORMAT;
+    }
+    return t;
+  }
+  const float* F(const std::string& n) {
+    const PtTensor* t = get(n);
+    return t ? reinterpret_cast<const float*>(t->d_ptr) : nullptr;
+  }
+  // y = x W^T + b over `rows` rows (multiple of 128): x bf16 [rows, cin] (hi | lo) -> bf16 [rows, out_cs] or fp32 [rows, f32_cs]
+  void gemm(const bf16_t* x, long long rows, int cin, const std::string& q, int N, int relu, bf16_t* out, int out_cs, float* out_f32 = nullptr,
+            int f32_cs = 0, const float* res_f32 = nullptr, int nv = 0) {
+    const PtTensor* w = get(q + (x3 ? ".w3" : ".w"));
+    const PtTensor* b = get(q + ".b");
+    if (rc != PT_OK) return;
+    ConvDesc c;
+    c.in = x; c.B = 1; c.H = (int)(rows / 32); c.W = 32; c.Cin = cin;
+    c.w = reinterpret_cast<const bf16_t*>(w->d_ptr); c.bias = reinterpret_cast<const float*>(b->d_ptr);
+    c.N = N; c.ks = 1; c.stride = 1; c.relu = relu; c.split = x3; c.n_valid = nv;
+    if (out_f32) {
+      c.out_f32 = out_f32; c.out_cstride = f32_cs; c.res_f32 = res_f32;
+    } else {
+      c.out = out; c.out_cstride = out_cs * mul; c.out_coff = 0; c.out_lo_off = out_cs;
+    }
+    const int r = pt_launch_conv(e, c, s);
+    if (r != PT_OK) rc = r;
+  }
+  void ln(const float* x, long long rows, const std::string& q, bf16_t* out) {
+    const float *g = F(q + ".g"), *b = F(q + ".b");
+    if (rc != PT_OK) return;
+    hipLaunchKernelGGL(mtl_ln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, g, b, out, x3);
+  }
+};
+
+// work buffers of one decoding loop (structure or cells): R rows
+struct Work {
+  long long R = 0;
+  bf16_t *xb = nullptr, *qc = nullptr, *att = nullptr, *hb = nullptr;
+  float *opart = nullptr, *mlpart = nullptr;
+  int4* tiles = nullptr;
+  int ntiles = 0, nsplit = 1, kps = 0;
+};
+
+struct Seqs {          // the sequences of one loop
+  int M = 0, Mp = 0;   // sequences, padded to 128
+  const int* tok = nullptr;
+  int pad = 0;
+  int ffp = 2048;
+  int hw = 0;
+};
+
+// one DecoderLayer over positions [p0, p1] of all sequences.  x: fp32 residual rows of those positions ((p - p0) * Mp + s), updated in
+// place; cache: this layer's [position][Mp][1536] q/k/v cache; slot: the layer's place in the cross K / V tensor.
+void run_layer(Ctx& c, const std::string& q, int slot, float* x, bf16_t* cache, const bf16_t* kv, const Seqs& S, const Work& W, int p0, int p1) {
+  const int npos = p1 - p0 + 1;
+  const long long rows = (long long)npos * S.Mp;
+  const int mul = c.mul;
+  c.ln(x, rows, q + ".ln0", W.xb);
+  bf16_t* slab = cache + (size_t)p0 * S.Mp * 3 * D * mul;
+  c.gemm(W.xb, rows, D, q + ".qkv", 3 * D, 0, slab, 3 * D);
+  if (c.rc != PT_OK) return;
+  {
+    PtProfScope ps(c.e, c.s, PT_PROF_OTHER, 0, "mtl self attention");
+    const size_t lds = (size_t)(p1 + 1) * sizeof(float);
+    if (c.x3) hipLaunchKernelGGL(mtl_self_attn_kernel<1>, dim3(npos * S.M, HEADS), dim3(64), lds, c.s, cache, S.tok, S.pad, p0, S.Mp, S.M, p1 + 1, W.att);
+    else hipLaunchKernelGGL(mtl_self_attn_kernel<0>, dim3(npos * S.M, HEADS), dim3(64), lds, c.s, cache, S.tok, S.pad, p0, S.Mp, S.M, p1 + 1, W.att);
+  }
+  c.gemm(W.att, rows, D, q + ".so", D, 0, nullptr, 0, x, D, x);
+  c.ln(x, rows, q + ".ln1", W.xb);
+  c.gemm(W.xb, rows, D, q + ".cq", D, 0, W.qc, D);
+  if (c.rc != PT_OK) return;
+  {
+    PtProfScope ps(c.e, c.s, PT_PROF_OTHER, 0, "mtl source attention");
+    const dim3 grid(W.ntiles, HEADS, W.nsplit);
+    if (c.x3) hipLaunchKernelGGL(mtl_cross_attn_kernel<1>, grid, dim3(64), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.R, W.opart, W.mlpart, W.att);
+    else hipLaunchKernelGGL(mtl_cross_attn_kernel<0>, grid, dim3(64), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.R, W.opart, W.mlpart, W.att);
+    if (W.nsplit > 1)
+      hipLaunchKernelGGL(mtl_cross_combine_kernel, dim3(npos * S.M), dim3(512), 0, c.s, W.opart, W.mlpart, W.nsplit, W.R, S.Mp, S.M, W.att, c.x3);
+  }
+  c.gemm(W.att, rows, D, q + ".co", D, 0, nullptr, 0, x, D, x);
+  c.ln(x, rows, q + ".ln2", W.xb);
+  c.gemm(W.xb, rows, D, q + ".ff1", S.ffp, 1, W.hb, S.ffp);
+  c.gemm(W.hb, rows, S.ffp, q + ".ff2", D, 0, nullptr, 0, x, D, x);
+}
+
+MtlState* state_of(pt_engine* e) {
+  if (!e->mtl_state) e->mtl_state = new MtlState();
+  return reinterpret_cast<MtlState*>(e->mtl_state);
+}
+
+int upload_tiles(std::vector<int4>& host, int4* dev, hipStream_t s) {
+  PT_HIP_CHECK(hipMemcpyAsync(dev, host.data(), host.size() * sizeof(int4), hipMemcpyHostToDevice, s));
+  PT_HIP_CHECK(hipStreamSynchronize(s));      // `host` is a stack vector
+  return PT_OK;
+}
+
+int pick_split(int ntiles, int hw, int* kps) {
+  int ns = 2048 / (ntiles * HEADS > 0 ? ntiles * HEADS : 1);
+  if (ns < 1) ns = 1;
+  if (ns > 16) ns = 16;
+  int per = ((hw + ns - 1) / ns + 31) / 32 * 32;
+  ns = (hw + per - 1) / per;
+  *kps = per;
+  return ns;
+}
+
+struct Meta {
+  int ncls, ncell, sos, eos, pad, max_len, sos_c, eos_c, pad_c, max_len_c, tag0, tag1, ffp;
+};
+
+int read_meta(Ctx& c, Meta* mt) {
+  const PtTensor* t = c.get("meta");
+  if (c.rc != PT_OK) return c.rc;
+  PT_REQUIRE(t->nbytes >= sizeof(Meta), "MtlTabNet decoder blob: short meta tensor");
+  PT_HIP_CHECK(hipMemcpy(mt, t->d_ptr, sizeof(Meta), hipMemcpyDeviceToHost));
+  PT_REQUIRE(mt->ncls > 0 && mt->ncell > 0 && mt->max_len > 0 && mt->max_len + 2 <= PE_ROWS && mt->max_len_c > 0 && mt->max_len_c + 2 <= PE_ROWS &&
+                 mt->ffp % 64 == 0, "MtlTabNet decoder blob: bad meta");
+  return PT_OK;
+}
+
+}  // namespace
+
+void pt_tsr_mtl_resized_size(int crop_w, int crop_h, int size, int32_t* out_w, int32_t* out_h) {
+  int w = 0, h = 0;
+  mtl_resized(crop_w, crop_h, size, &w, &h);
+  *out_w = w;
+  *out_h = h;
+}
+
+int pt_mtl_preprocess(pt_engine* e, const uint8_t* pages, int ph, int pw, const pt_tsr_table* tabs, int n, int size, bf16_t* out, hipStream_t s) {
+  const int x3 = e->precision == PT_PRECISION_BF16X3 ? 1 : 0;
+  PtProfScope ps(e, s, PT_PROF_OTHER, 0, "mtl preprocess");
+  hipLaunchKernelGGL(mtl_preprocess_kernel, dim3((size * size + 255) / 256, n), dim3(256), 0, s, pages, ph, pw, tabs, size, out, x3);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+void pt_mtl_release(pt_engine* e) {
+  if (!e || !e->mtl_state) return;
+  MtlState* st = reinterpret_cast<MtlState*>(e->mtl_state);
+  st->persist.release();
+  st->work.release();
+  st->cwork.release();
+  if (st->h_poll) (void)hipHostFree(st->h_poll);
+  delete st;
+  e->mtl_state = nullptr;
+}
+
+int pt_mtl_decoder_config(pt_engine* e, int32_t* out13) {
+  auto it = e->models.find(PT_MODEL_MTL_DECODER);
+  if (it == e->models.end()) {
+    pt_set_error("MtlTabNet decoder weights not loaded (pt_weights_load(PT_MODEL_MTL_DECODER))");
+    return PT_ERR_STATE;
+  }
+  Ctx c{e, &it->second, nullptr, 0, 1, PT_OK};
+  Meta mt;
+  const int rc = read_meta(c, &mt);
+  if (rc != PT_OK) return rc;
+  memcpy(out13, &mt, sizeof(mt));
+  return PT_OK;
+}
+
+// Structure + box decoders.  f3 fp32 [n, hw, 512] (the backbone's last map, NHWC).  Outputs (device, caller-owned):
+// tag_logits [n, T, ncls], boxes [n, T, 4] with T = max_len + 1; host: lens[n] (positions written per table), cell_counts[n].
+int pt_mtl_structure(pt_engine* e, const float* f3, int n, int hw, float* d_tag_logits, float* d_boxes, int32_t* h_lens, int32_t* h_cell_counts,
+                     int force_redecode, hipStream_t s) {
+  PT_REQUIRE(e && f3 && n > 0 && hw > 0 && hw <= PE_ROWS && d_tag_logits && d_boxes && h_lens && h_cell_counts, "pt_tsr_mtl_structure: bad arguments");
+  auto it = e->models.find(PT_MODEL_MTL_DECODER);
+  if (it == e->models.end()) {
+    pt_set_error("MtlTabNet decoder weights not loaded (pt_weights_load(PT_MODEL_MTL_DECODER))");
+    return PT_ERR_STATE;
+  }
+  Ctx c{e, &it->second, s, e->precision == PT_PRECISION_BF16X3 ? 1 : 0, e->precision == PT_PRECISION_BF16X3 ? 2 : 1, PT_OK};
+  Meta mt;
+  int rc = read_meta(c, &mt);
+  if (rc != PT_OK) return rc;
+  PT_REQUIRE(mt.ncls <= 1024, "MtlTabNet decoder: %d structure classes", mt.ncls);
+  MtlState* st = state_of(e);
+  st->structure_done = false;
+  const int mul = c.mul, T = mt.max_len + 1, Mp = (n + 127) / 128 * 128, ncls_p = (mt.ncls + 63) / 64 * 64;
+  const long long Fr = ((long long)n * hw + 127) / 128 * 128;
+  st->n = n; st->hw = hw; st->Mp = Mp; st->T = T; st->x3 = c.x3;
+  if (!st->h_poll) PT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&st->h_poll), 4096 * sizeof(int)));
+  PT_REQUIRE(n + 1 <= 4096, "pt_tsr_mtl_structure: at most 4095 tables per call");
+
+  // ---- persistent buffers
+  {
+    Carver cv;
+    st->o_kv = cv.take((size_t)Fr * KVC * mul * sizeof(bf16_t));
+    st->o_keep = cv.take((size_t)T * Mp * D * sizeof(float));
+    st->o_tok = cv.take((size_t)(T + 1) * Mp * sizeof(int));
+    st->o_ids = cv.take((size_t)T * Mp * sizeof(int));
+    st->o_fin = cv.take((size_t)(Mp + 64) * sizeof(int));
+    if ((rc = st->persist.ensure(cv.off)) != PT_OK) return rc;
+  }
+  char* pb = st->persist.base;
+  bf16_t* kv = reinterpret_cast<bf16_t*>(pb + st->o_kv);
+  float* keep = reinterpret_cast<float*>(pb + st->o_keep);
+  int* tok = reinterpret_cast<int*>(pb + st->o_tok);
+  int* ids = reinterpret_cast<int*>(pb + st->o_ids);
+  int* fin = reinterpret_cast<int*>(pb + st->o_fin);
+  int* first_pad = fin + Mp;
+
+  // ---- work buffers: cached mode needs one position per buffer, re-decode mode all T
+  struct Lay { size_t x[3], cache, xb, qc, att, hb, lg, bx, opart, mlpart, tiles, featb, total; long long R; int nsplit_cap; };
+  auto plan = [&](bool all_positions) {
+    Lay L;
+    Carver cv;
+    const long long R = all_positions ? (long long)T * Mp : Mp;
+    L.R = R;
+    for (int i = 0; i < 3; ++i) L.x[i] = cv.take((size_t)R * D * sizeof(float));
+    L.cache = cv.take((size_t)4 * T * Mp * 3 * D * mul * sizeof(bf16_t));
+    L.xb = cv.take((size_t)R * D * mul * sizeof(bf16_t));
+    L.qc = cv.take((size_t)R * D * mul * sizeof(bf16_t));
+    L.att = cv.take((size_t)R * D * mul * sizeof(bf16_t));
+    L.hb = cv.take((size_t)R * mt.ffp * mul * sizeof(bf16_t));
+    L.lg = cv.take((size_t)R * ncls_p * sizeof(float));
+    L.bx = cv.take((size_t)R * 8 * sizeof(float));
+    L.nsplit_cap = 16;
+    L.opart = cv.take((size_t)L.nsplit_cap * R * D * sizeof(float));
+    L.mlpart = cv.take((size_t)L.nsplit_cap * R * HEADS * 2 * sizeof(float));
+    L.tiles = cv.take(((size_t)n * ((T + 31) / 32) + 16) * sizeof(int4));
+    L.featb = all_positions ? 0 : cv.take((size_t)Fr * D * mul * sizeof(bf16_t));
+    L.total = cv.off;
+    return L;
+  };
+  Lay L = plan(false);
+  if ((rc = st->work.ensure(L.total)) != PT_OK) return rc;
+
+  // ---- out_enc, then keys / values of the five source attentions in one GEMM
+  {
+    const float* pe = c.F("pe");
+    if (c.rc != PT_OK) return c.rc;
+    bf16_t* featb = reinterpret_cast<bf16_t*>(st->work.base + L.featb);
+    {
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0, "mtl feature + pe");
+      hipLaunchKernelGGL(mtl_feature_kernel, dim3((unsigned)((Fr + 3) / 4)), dim3(256), 0, s, f3, pe, (long long)n * hw, Fr, hw, featb, c.x3);
+    }
+    c.gemm(featb, Fr, D, "kv", KVC, 0, kv, KVC);
+    if (c.rc != PT_OK) return c.rc;
+  }
+  hipLaunchKernelGGL(mtl_fill_kernel, dim3((Mp + 255) / 256), dim3(256), 0, s, tok, Mp, mt.sos);
+  hipLaunchKernelGGL(mtl_fill_kernel, dim3((Mp + 64 + 255) / 256), dim3(256), 0, s, fin, Mp + 64, INT_MAX);
+
+  Seqs S;
+  S.M = n; S.Mp = Mp; S.tok = tok; S.pad = mt.pad; S.ffp = mt.ffp; S.hw = hw;
+  const float *emb = c.F("emb"), *pe = c.F("pe");
+  if (c.rc != PT_OK) return c.rc;
+  static const char* LN[4] = {"l0", "l1", "cls", "bbox"};
+  bool redecode = force_redecode != 0;
+  Work W;
+  auto bind = [&](const Lay& l) {
+    char* wb = st->work.base;
+    W.R = l.R;
+    W.xb = reinterpret_cast<bf16_t*>(wb + l.xb); W.qc = reinterpret_cast<bf16_t*>(wb + l.qc); W.att = reinterpret_cast<bf16_t*>(wb + l.att);
+    W.hb = reinterpret_cast<bf16_t*>(wb + l.hb); W.opart = reinterpret_cast<float*>(wb + l.opart); W.mlpart = reinterpret_cast<float*>(wb + l.mlpart);
+    W.tiles = reinterpret_cast<int4*>(wb + l.tiles);
+  };
+  auto enter_redecode = [&]() -> int {
+    PT_HIP_CHECK(hipStreamSynchronize(s));
+    L = plan(true);
+    int r = st->work.ensure(L.total);
+    if (r != PT_OK) return r;
+    bind(L);
+    PT_HIP_CHECK(hipMemsetAsync(W.att, 0, (size_t)L.R * D * mul * sizeof(bf16_t), s));
+    return PT_OK;
+  };
+  bind(L);
+  PT_HIP_CHECK(hipMemsetAsync(W.att, 0, (size_t)L.R * D * mul * sizeof(bf16_t), s));
+  if (redecode && (rc = enter_redecode()) != PT_OK) return rc;
+  if (!redecode) {           // one query per table and step
+    std::vector<int4> tl(n);
+    for (int b = 0; b < n; ++b) tl[b] = make_int4(b, b, 1, Mp);
+    W.ntiles = n;
+    W.nsplit = pick_split(n, hw, &W.kps);
+    if ((rc = upload_tiles(tl, W.tiles, s)) != PT_OK) return rc;
+  }
+  const int POLL = 16;
+  int t = 0;
+  while (t <= mt.max_len) {
+    const int p0 = redecode ? 0 : t, npos = t - p0 + 1;
+    const long long rows = (long long)npos * Mp;
+    char* wb = st->work.base;
+    float* xs = reinterpret_cast<float*>(wb + L.x[0]);
+    float* xc = reinterpret_cast<float*>(wb + L.x[1]);
+    float* xx = reinterpret_cast<float*>(wb + L.x[2]);
+    bf16_t* cache = reinterpret_cast<bf16_t*>(wb + L.cache);
+    const size_t cache_layer = (size_t)T * Mp * 3 * D * mul;
+    if (redecode) {           // tiles of up to 32 positions of one table
+      std::vector<int4> tl;
+      for (int b = 0; b < n; ++b)
+        for (int q0 = 0; q0 < npos; q0 += 32) tl.push_back(make_int4(b, q0 * Mp + b, npos - q0 < 32 ? npos - q0 : 32, Mp));
+      W.ntiles = (int)tl.size();
+      W.nsplit = pick_split(W.ntiles, hw, &W.kps);
+      if ((rc = upload_tiles(tl, W.tiles, s)) != PT_OK) return rc;
+    }
+    {
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0, "mtl embed");
+      hipLaunchKernelGGL(mtl_embed_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, tok, emb, pe, p0, npos, Mp, n, xs, (bf16_t*)nullptr,
+                         (const float*)nullptr, (const int*)nullptr, c.x3);
+    }
+    run_layer(c, LN[0], 0, xs, cache, kv, S, W, p0, t);
+    run_layer(c, LN[1], 1, xs, cache + cache_layer, kv, S, W, p0, t);
+    if (c.rc != PT_OK) return c.rc;
+    {
+      const long long tot = rows * (D / 4);
+      hipLaunchKernelGGL(mtl_fork_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, xs, xc, xx, keep, fin, p0, t, Mp, n);
+    }
+    run_layer(c, LN[2], 2, xc, cache + 2 * cache_layer, kv, S, W, p0, t);
+    run_layer(c, LN[3], 3, xx, cache + 3 * cache_layer, kv, S, W, p0, t);
+    float* lg = reinterpret_cast<float*>(wb + L.lg);
+    float* bx = reinterpret_cast<float*>(wb + L.bx);
+    c.ln(xc, rows, "norm", W.xb);
+    c.gemm(W.xb, rows, D, "cls_fc", ncls_p, 0, nullptr, 0, lg, ncls_p);
+    c.ln(xx, rows, "norm", W.xb);
+    c.gemm(W.xb, rows, D, "bbox_fc", 64, 0, nullptr, 0, bx, 8, nullptr, 8);
+    if (c.rc != PT_OK) return c.rc;
+    {
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0, "mtl tag pick");
+      hipLaunchKernelGGL(mtl_tag_pick_kernel, dim3((npos * n + 255) / 256), dim3(256), 0, s, lg, bx, p0, t, Mp, n, mt.ncls, ncls_p, mt.eos, mt.pad, mt.max_len, T,
+                         tok, ids, fin, first_pad, d_tag_logits, d_boxes);
+    }
+    ++t;
+    if (t % POLL == 0 || t > mt.max_len) {
+      PT_HIP_CHECK(hipMemcpyAsync(st->h_poll, fin, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+      PT_HIP_CHECK(hipMemcpyAsync(st->h_poll + n, first_pad, sizeof(int), hipMemcpyDeviceToHost, s));
+      PT_HIP_CHECK(hipStreamSynchronize(s));
+      const int fp = st->h_poll[n];
+      if (!redecode && fp != INT_MAX) {
+        // a <PAD> was appended at step fp: everything after it was computed with a causal cache the reference does not have
+        redecode = true;
+        hipLaunchKernelGGL(mtl_rollback_kernel, dim3((n + 255) / 256), dim3(256), 0, s, fin, n, fp);
+        if ((rc = enter_redecode()) != PT_OK) return rc;
+        t = fp + 1;
+        continue;
+      }
+      bool all = true;
+      for (int b = 0; b < n; ++b) all = all && st->h_poll[b] != INT_MAX;
+      if (all) break;
+    }
+  }
+  PT_HIP_CHECK(hipGetLastError());
+  // ---- lengths, cell positions (bbox_masks of decode_test :389-392 from the arg-max of the final logits)
+  std::vector<int> h_ids((size_t)T * Mp), h_fin(n);
+  PT_HIP_CHECK(hipMemcpyAsync(h_ids.data(), ids, h_ids.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+  PT_HIP_CHECK(hipMemcpyAsync(h_fin.data(), fin, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+  PT_HIP_CHECK(hipStreamSynchronize(s));
+  st->lens.assign(n, 0);
+  st->cell_tab.clear(); st->cell_src.clear(); st->tab_first.assign(n + 1, 0);
+  for (int b = 0; b < n; ++b) {
+    PT_REQUIRE(h_fin[b] != INT_MAX, "pt_tsr_mtl_structure: table %d did not finish (internal error)", b);
+    const int len = h_fin[b] + 1;
+    st->lens[b] = len;
+    h_lens[b] = len;
+    st->tab_first[b] = (int)st->cell_tab.size();
+    for (int p = 0; p < len; ++p) {
+      const int id = h_ids[(size_t)p * Mp + b];
+      if (id == mt.tag0 || id == mt.tag1) {
+        st->cell_tab.push_back(b);
+        st->cell_src.push_back(p * Mp + b);
+      }
+    }
+    h_cell_counts[b] = (int)st->cell_tab.size() - st->tab_first[b];
+  }
+  st->tab_first[n] = (int)st->cell_tab.size();
+  st->structure_done = true;
+  return PT_OK;
+}
+
+// Cell-content decoder for the cells pt_mtl_structure found (total = sum of its cell_counts, cells ordered by (table, position)).
+// Device outputs: cell_ids int32 / cell_prob fp32 [total, Tc] (Tc = max_len_cell + 1), cell_logits fp32 [total, Tc, ncell] or null;
+// host: steps[n] = positions decoded per table (0 for a table without cells: the reference returns torch.zeros(1) there, :395-398).
+int pt_mtl_cells(pt_engine* e, int total, int32_t* d_cell_ids, float* d_cell_prob, float* d_cell_logits, int32_t* h_steps, int force_redecode,
+                 hipStream_t s) {
+  PT_REQUIRE(e && h_steps, "pt_tsr_mtl_cells: bad arguments");
+  MtlState* st = e->mtl_state ? reinterpret_cast<MtlState*>(e->mtl_state) : nullptr;
+  if (!st || !st->structure_done) {
+    pt_set_error("pt_tsr_mtl_cells: call pt_tsr_mtl_structure first");
+    return PT_ERR_STATE;
+  }
+  auto it = e->models.find(PT_MODEL_MTL_DECODER);
+  if (it == e->models.end()) {
+    pt_set_error("MtlTabNet decoder weights not loaded (pt_weights_load(PT_MODEL_MTL_DECODER))");
+    return PT_ERR_STATE;
+  }
+  Ctx c{e, &it->second, s, st->x3, st->x3 ? 2 : 1, PT_OK};
+  PT_REQUIRE((e->precision == PT_PRECISION_BF16X3 ? 1 : 0) == st->x3, "pt_tsr_mtl_cells: the precision changed since pt_tsr_mtl_structure");
+  Meta mt;
+  int rc = read_meta(c, &mt);
+  if (rc != PT_OK) return rc;
+  const int n = st->n, Mc = (int)st->cell_tab.size();
+  PT_REQUIRE(total == Mc, "pt_tsr_mtl_cells: %d cells announced, the structure pass found %d", total, Mc);
+  for (int b = 0; b < n; ++b) h_steps[b] = 0;
+  if (Mc == 0) return PT_OK;
+  PT_REQUIRE(d_cell_ids && d_cell_prob, "pt_tsr_mtl_cells: null output");
+  const int mul = c.mul, Tc = mt.max_len_c + 1, Mp = (Mc + 127) / 128 * 128, ncell_p = (mt.ncell + 63) / 64 * 64, hw = st->hw;
+  char* pb = st->persist.base;
+  const bf16_t* kv = reinterpret_cast<const bf16_t*>(pb + st->o_kv);
+  const float* keep = reinterpret_cast<const float*>(pb + st->o_keep);
+
+  struct Lay { size_t x, cache, cin, xb, qc, att, hb, lg, tiles, total; long long R; };
+  const int max_tiles_pos = Mc / 32 + n + 1;
+  auto plan = [&](bool all_positions) {
+    Lay L;
+    Carver cv;
+    const long long R = all_positions ? (long long)Tc * Mp : Mp;
+    L.R = R;
+    L.x = cv.take((size_t)R * D * sizeof(float));
+    L.cache = cv.take((size_t)Tc * Mp * 3 * D * mul * sizeof(bf16_t));
+    L.cin = cv.take((size_t)R * 2 * D * mul * sizeof(bf16_t));
+    L.xb = cv.take((size_t)R * D * mul * sizeof(bf16_t));
+    L.qc = cv.take((size_t)R * D * mul * sizeof(bf16_t));
+    L.att = cv.take((size_t)R * D * mul * sizeof(bf16_t));
+    L.hb = cv.take((size_t)R * mt.ffp * mul * sizeof(bf16_t));
+    L.lg = cv.take((size_t)R * ncell_p * sizeof(float));
+    L.tiles = cv.take((size_t)max_tiles_pos * (all_positions ? Tc : 1) * sizeof(int4));
+    L.total = cv.off;
+    return L;
+  };
+  Lay L = plan(false);
+  if ((rc = st->cwork.ensure(L.total)) != PT_OK) return rc;
+  // bookkeeping lives in `work` (the structure loop is over, its buffers are free): growing `cwork` for the re-decode mode must not lose it
+  struct { size_t tok, nxt, tab, src, first, fin; } B;
+  {
+    Carver cv;
+    B.tok = cv.take((size_t)(Tc + 1) * Mp * sizeof(int));
+    B.nxt = cv.take((size_t)Mp * sizeof(int));
+    B.tab = cv.take((size_t)Mp * sizeof(int));
+    B.src = cv.take((size_t)Mp * sizeof(int));
+    B.first = cv.take((size_t)(n + 1) * sizeof(int));
+    B.fin = cv.take((size_t)(n + 64) * sizeof(int));
+    if ((rc = st->work.ensure(cv.off)) != PT_OK) return rc;
+  }
+  char* bk = st->work.base;
+  int* tok = reinterpret_cast<int*>(bk + B.tok);
+  int* nxt = reinterpret_cast<int*>(bk + B.nxt);
+  int* d_tab = reinterpret_cast<int*>(bk + B.tab);
+  int* d_src = reinterpret_cast<int*>(bk + B.src);
+  int* d_first = reinterpret_cast<int*>(bk + B.first);
+  int* finc = reinterpret_cast<int*>(bk + B.fin);
+  int* first_pad = finc + n;
+  PT_HIP_CHECK(hipMemcpyAsync(d_tab, st->cell_tab.data(), (size_t)Mc * sizeof(int), hipMemcpyHostToDevice, s));
+  PT_HIP_CHECK(hipMemcpyAsync(d_src, st->cell_src.data(), (size_t)Mc * sizeof(int), hipMemcpyHostToDevice, s));
+  PT_HIP_CHECK(hipMemcpyAsync(d_first, st->tab_first.data(), (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(mtl_fill_kernel, dim3((Mp + 255) / 256), dim3(256), 0, s, tok, Mp, mt.sos_c);
+  hipLaunchKernelGGL(mtl_fill_kernel, dim3((n + 64 + 255) / 256), dim3(256), 0, s, finc, n + 64, INT_MAX);
+  PT_HIP_CHECK(hipStreamSynchronize(s));       // the three vectors above belong to the state, but keep the copies simple
+
+  Seqs S;
+  S.M = Mc; S.Mp = Mp; S.tok = tok; S.pad = mt.pad_c; S.ffp = mt.ffp; S.hw = hw;
+  const float *emb = c.F("emb_cell"), *pe = c.F("pe");
+  if (c.rc != PT_OK) return c.rc;
+  Work W;
+  auto bind = [&](const Lay& l) {
+    char* wb = st->cwork.base;
+    W.R = l.R;
+    W.xb = reinterpret_cast<bf16_t*>(wb + l.xb); W.qc = reinterpret_cast<bf16_t*>(wb + l.qc); W.att = reinterpret_cast<bf16_t*>(wb + l.att);
+    W.hb = reinterpret_cast<bf16_t*>(wb + l.hb); W.tiles = reinterpret_cast<int4*>(wb + l.tiles);
+    W.opart = nullptr; W.mlpart = nullptr; W.nsplit = 1; W.kps = (hw + 31) / 32 * 32;
+  };
+  auto make_tiles = [&](int npos) -> int {
+    std::vector<int4> tl;
+    for (int pi = 0; pi < npos; ++pi)
+      for (int b = 0; b < n; ++b)
+        for (int c0 = st->tab_first[b]; c0 < st->tab_first[b + 1]; c0 += 32)
+          tl.push_back(make_int4(b, pi * Mp + c0, st->tab_first[b + 1] - c0 < 32 ? st->tab_first[b + 1] - c0 : 32, 1));
+    W.ntiles = (int)tl.size();
+    return upload_tiles(tl, W.tiles, s);
+  };
+  bool redecode = force_redecode != 0;
+  auto enter_redecode = [&]() -> int {
+    PT_HIP_CHECK(hipStreamSynchronize(s));
+    L = plan(true);
+    int r = st->cwork.ensure(L.total);
+    if (r != PT_OK) return r;
+    bind(L);
+    PT_HIP_CHECK(hipMemsetAsync(W.att, 0, (size_t)L.R * D * mul * sizeof(bf16_t), s));
+    return PT_OK;
+  };
+  bind(L);
+  PT_HIP_CHECK(hipMemsetAsync(W.att, 0, (size_t)L.R * D * mul * sizeof(bf16_t), s));
+  if (redecode && (rc = enter_redecode()) != PT_OK) return rc;
+  if (!redecode && (rc = make_tiles(1)) != PT_OK) return rc;
+  const int POLL = 8;
+  int t = 0;
+  while (t <= mt.max_len_c) {
+    const int p0 = redecode ? 0 : t, npos = t - p0 + 1;
+    const long long rows = (long long)npos * Mp;
+    char* wb = st->cwork.base;
+    float* x = reinterpret_cast<float*>(wb + L.x);
+    bf16_t* cache = reinterpret_cast<bf16_t*>(wb + L.cache);
+    bf16_t* cin = reinterpret_cast<bf16_t*>(wb + L.cin);
+    float* lg = reinterpret_cast<float*>(wb + L.lg);
+    if (redecode && (rc = make_tiles(npos)) != PT_OK) return rc;
+    {
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0, "mtl cell embed");
+      hipLaunchKernelGGL(mtl_embed_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, tok, emb, pe, p0, npos, Mp, Mc, (float*)nullptr, cin, keep, d_src, c.x3);
+    }
+    c.gemm(cin, rows, 2 * D, "cell_in", D, 0, nullptr, 0, x, D);
+    run_layer(c, "cell", 4, x, cache, kv, S, W, p0, t);
+    c.ln(x, rows, "norm", W.xb);
+    c.gemm(W.xb, rows, D, "cell_fc", ncell_p, 0, nullptr, 0, lg, ncell_p);
+    if (c.rc != PT_OK) return c.rc;
+    {
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0, "mtl cell pick");
+      const long long waves = (long long)npos * Mc;
+      hipLaunchKernelGGL(mtl_cell_pick_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, lg, p0, t, Mp, Mc, mt.ncell, ncell_p, Tc, d_tab, finc, nxt,
+                         d_cell_ids, d_cell_prob, d_cell_logits);
+      hipLaunchKernelGGL(mtl_cell_next_kernel, dim3(n), dim3(256), 0, s, d_first, nxt, t, Mp, mt.eos_c, mt.pad_c, mt.max_len_c, tok, finc, first_pad);
+    }
+    ++t;
+    if (t % POLL == 0 || t > mt.max_len_c) {
+      PT_HIP_CHECK(hipMemcpyAsync(st->h_poll, finc, (size_t)(n + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+      PT_HIP_CHECK(hipStreamSynchronize(s));
+      const int fp = st->h_poll[n];
+      if (!redecode && fp != INT_MAX) {
+        redecode = true;
+        hipLaunchKernelGGL(mtl_rollback_kernel, dim3((n + 255) / 256), dim3(256), 0, s, finc, n, fp);
+        if ((rc = enter_redecode()) != PT_OK) return rc;
+        t = fp + 1;
+        continue;
+      }
+      bool all = true;
+      for (int b = 0; b < n; ++b) all = all && (st->h_poll[b] != INT_MAX || st->tab_first[b + 1] == st->tab_first[b]);
+      if (all) break;
+    }
+  }
+  PT_HIP_CHECK(hipGetLastError());
+  PT_HIP_CHECK(hipMemcpyAsync(st->h_poll, finc, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+  PT_HIP_CHECK(hipStreamSynchronize(s));
+  for (int b = 0; b < n; ++b) {
+    const bool has = st->tab_first[b + 1] > st->tab_first[b];
+    PT_REQUIRE(!has || st->h_poll[b] != INT_MAX, "pt_tsr_mtl_cells: table %d did not finish (internal error)", b);
+    h_steps[b] = has ? st->h_poll[b] + 1 : 0;
+  }
+  return PT_OK;
+}

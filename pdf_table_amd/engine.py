@@ -515,6 +515,65 @@ class HipEngine:
         L.check(self.lib.pt_tsr_mtl_backbone_net(self._h, _ptr(hi), n, h, w, _ptr(f3), self._stream()), "pt_tsr_mtl_backbone_net")
         return f3.permute(0, 3, 1, 2)
 
+    def mtl_backbone_features(self, xin: torch.Tensor, size_hw: Tuple[int, int]) -> torch.Tensor:
+        """pre-processed input bf16 [n, H, W, 32 (x 2 in BF16X3)] (mtl_preprocess) -> f3 fp32 [n, H/8 * W/8, 512] (NHWC, flattened)"""
+        n = xin.shape[0]
+        h, w = size_hw
+        f3 = torch.empty((n, (h // 8) * (w // 8), 512), dtype=torch.float32, device=self._tdev)
+        L.check(self.lib.pt_tsr_mtl_backbone_net(self._h, _ptr(xin), n, h, w, _ptr(f3), self._stream()), "pt_tsr_mtl_backbone_net")
+        return f3
+
+    def mtl_preprocess(self, pages: torch.Tensor, tables: np.ndarray, size: int = 480) -> torch.Tensor:
+        """MtlTabNet test pipeline (TableResize keep-ratio long side `size`, TablePad, to_tensor, normalise) of table crops cut from
+        resident pages.  pages uint8 [n_pages, h, w, 3]; tables: TSR_TABLE_DTYPE records (page, x0, y0, crop_w, crop_h).
+        -> bf16 [n, size, size, 32] ([hi 32 | lo 32] in BF16X3), the backbone's input."""
+        self._chk(pages, torch.uint8, "pages")
+        assert tables.dtype == TSR_TABLE_DTYPE
+        n = len(tables)
+        d_tab = _upload(tables.view(np.uint8).reshape(-1), self._tdev)
+        m = 2 if self.precision == L.PT_PRECISION_BF16X3 else 1
+        out = torch.empty((n, size, size, 32 * m), dtype=torch.bfloat16, device=self._tdev)
+        L.check(self.lib.pt_tsr_mtl_preprocess(self._h, _ptr(pages), pages.shape[0], pages.shape[1], pages.shape[2], _ptr(d_tab), n, size,
+                                               _ptr(out), self._stream()), "pt_tsr_mtl_preprocess")
+        return out
+
+    def mtl_resized_size(self, crop_w: int, crop_h: int, size: int = 480) -> Tuple[int, int]:
+        ow, oh = C.c_int(), C.c_int()
+        self.lib.pt_tsr_mtl_resized_size(int(crop_w), int(crop_h), int(size), C.byref(ow), C.byref(oh))
+        return ow.value, oh.value
+
+    def mtl_decoder_config(self) -> dict:
+        v = (C.c_int * 13)()
+        L.check(self.lib.pt_tsr_mtl_decoder_config(self._h, v), "pt_tsr_mtl_decoder_config")
+        k = ("num_classes", "num_classes_cell", "sos", "eos", "pad", "max_len", "sos_cell", "eos_cell", "pad_cell", "max_len_cell", "tag0", "tag1", "d_ff_pad")
+        return dict(zip(k, [int(x) for x in v]))
+
+    def mtl_decode(self, f3: torch.Tensor, want_cell_logits: bool = False, force_redecode: bool = False) -> dict:
+        """The three MtlTabNet decoders for a batch of tables (pt_tsr_mtl_structure + pt_tsr_mtl_cells).  f3 fp32 [n, hw, 512].
+        -> dict: tag_logits fp32 [n, T, classes], boxes fp32 [n, T, 4] (device), lens [n], cell_counts [n], cell_steps [n] (numpy),
+        cell_ids int32 / cell_prob fp32 [total cells, Tc] (device; cells ordered by table, then position), cell_logits or None."""
+        self._chk(f3, torch.float32, "f3")
+        n, hw, d = f3.shape
+        assert d == 512
+        cfg = self.mtl_decoder_config()
+        T, Tc = cfg["max_len"] + 1, cfg["max_len_cell"] + 1
+        tag = torch.zeros((n, T, cfg["num_classes"]), dtype=torch.float32, device=self._tdev)
+        box = torch.zeros((n, T, 4), dtype=torch.float32, device=self._tdev)
+        lens = np.zeros(n, np.int32)
+        counts = np.zeros(n, np.int32)
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+        L.check(self.lib.pt_tsr_mtl_structure(self._h, _ptr(f3), n, hw, _ptr(tag), _ptr(box), ip(lens), ip(counts), 1 if force_redecode else 0,
+                                              self._stream()), "pt_tsr_mtl_structure")
+        total = int(counts.sum())
+        steps = np.zeros(n, np.int32)
+        ids = torch.zeros((max(total, 1), Tc), dtype=torch.int32, device=self._tdev)
+        prob = torch.zeros((max(total, 1), Tc), dtype=torch.float32, device=self._tdev)
+        logits = torch.zeros((max(total, 1), Tc, cfg["num_classes_cell"]), dtype=torch.float32, device=self._tdev) if want_cell_logits else None
+        L.check(self.lib.pt_tsr_mtl_cells(self._h, total, _ptr(ids), _ptr(prob), _ptr(logits), ip(steps), 1 if force_redecode else 0, self._stream()),
+                "pt_tsr_mtl_cells")
+        return dict(tag_logits=tag, boxes=box, lens=lens, cell_counts=counts, cell_steps=steps, cell_ids=ids[:total], cell_prob=prob[:total],
+                    cell_logits=None if logits is None else logits[:total], cfg=cfg)
+
     def op_conv2d(self, x: torch.Tensor, w_tiled: torch.Tensor, bias: torch.Tensor, ks: int, stride: int = 1,
                   relu: bool = False, res: Optional[torch.Tensor] = None, res_mode: int = 0, rep: int = 1,
                   shuffle_cout: int = 0, out: Optional[torch.Tensor] = None, out_coff: int = 0,

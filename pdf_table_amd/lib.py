@@ -22,6 +22,7 @@ PT_MODEL_DB_NAS = 7
 PT_MODEL_PPLCNET = 8      # + slot (0 .. PT_CLS_SLOTS - 1)
 PT_MODEL_CONVNEXT_VIT = 16
 PT_MODEL_MTL_BACKBONE = 17
+PT_MODEL_MTL_DECODER = 18
 PT_CVIT_W, PT_CVIT_CHUNK_W, PT_CVIT_CHUNK_STEP, PT_CVIT_T, PT_CVIT_NCLS = 804, 300, 252, 201, 7644
 PT_CLS_SLOTS = 4
 PT_CLS_MAX_CLASSES = 16
@@ -76,6 +77,11 @@ def _proto(lib):
         "pt_rec_cvit_forward_net": (i, [vp, vp, i, i, vp, vp, vp, vp]),
         "pt_rec_cvit_preprocess_crops": (i, [vp, vp, vp, vp, i, vp, vp]),
         "pt_tsr_mtl_backbone_net": (i, [vp, vp, i, i, i, vp, vp]),
+        "pt_tsr_mtl_preprocess": (i, [vp, vp, i, i, i, vp, i, i, vp, vp]),
+        "pt_tsr_mtl_resized_size": (None, [i, i, i, ip, ip]),
+        "pt_tsr_mtl_decoder_config": (i, [vp, ip]),
+        "pt_tsr_mtl_structure": (i, [vp, vp, i, i, vp, vp, ip, ip, i, vp]),
+        "pt_tsr_mtl_cells": (i, [vp, i, vp, vp, vp, ip, i, vp]),
         "pt_rec_pp_preprocess": (i, [vp, vp, i, i, i, vp, vp, i, vp, i, i, i, vp, vp]),
         "pt_rec_pp_preprocess_crops": (i, [vp, vp, vp, vp, i, vp, i, i, i, vp, vp]),
         "pt_layout_plan": (i, [i, i, ip, ip]),

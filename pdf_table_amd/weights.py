@@ -29,7 +29,7 @@ import torch
 BN_EPS = 1e-5
 _DT = {"bf16": 0, "f32": 1, "i32": 2}
 
-__all__ = ["pack_db_resnet18", "pack_crnn", "pack_lore_dla34", "pack_lore_processor", "pack_picodet", "pack_lore_wireless", "pack_db_nas", "pack_pplcnet", "pack_convnext_vit", "pack_mtl_backbone", "write_blob", "fold_conv_bn", "to_bf16_bits"]
+__all__ = ["pack_db_resnet18", "pack_crnn", "pack_lore_dla34", "pack_lore_processor", "pack_picodet", "pack_lore_wireless", "pack_db_nas", "pack_pplcnet", "pack_convnext_vit", "pack_mtl_backbone", "pack_mtl_decoder", "write_blob", "fold_conv_bn", "to_bf16_bits"]
 
 
 def to_bf16_bits(t: torch.Tensor) -> np.ndarray:
@@ -763,4 +763,84 @@ def pack_mtl_backbone(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
                 bl.add(p + ".gc.lb", f(sd[q + ".channel_add_conv.1.bias"].reshape(hid)), "f32")
                 bl.add(p + ".gc.w3", f(sd[q + ".channel_add_conv.3.weight"].reshape(c, hid)), "f32")
                 bl.add(p + ".gc.b3", f(sd[q + ".channel_add_conv.3.bias"]), "f32")
+    return bl.tobytes()
+
+
+MTL_LAYERS = ("l0", "l1", "cls", "bbox", "cell")      # slots of the five DecoderLayers in the blob and in the cross K / V tensor
+MTL_D = 512
+MTL_PE_ROWS = 4096
+
+
+def mtl_positional_table(rows: int = MTL_PE_ROWS, d_model: int = MTL_D) -> torch.Tensor:
+    """PositionalEncoding.pe (table/mtl_tabnet/master_decoder.py:166-180) -- computed with torch exactly as the reference does."""
+    import math
+    pe = torch.zeros(rows, d_model)
+    position = torch.arange(0, rows).unsqueeze(1).float()
+    div_term = torch.exp(torch.arange(0, d_model, 2).float() * -math.log(10000.0) / d_model)
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe
+
+
+def pack_mtl_decoder(sd: Dict[str, torch.Tensor], cfg: Dict, x3: bool = True) -> bytes:
+    """``MtlTabNetDecoder`` state_dict (table/mtl_tabnet/master_decoder.py:194-262; N = 3: two shared DecoderLayers, then the
+    structure, box and cell-content layers) -> blob for PT_MODEL_MTL_DECODER.  ``cfg``: sos / eos / pad / max_len, sos_cell /
+    eos_cell / pad_cell / max_len_cell, idx_tag_cell (master_convertor.py:541-549).
+
+    Every nn.Linear is a 1x1 GEMM tile set.  Per layer: ``qkv`` = [q; k / 8; v] of the self-attention (self_attention() scales
+    the KEYS by 1 / sqrt(d_k) = 1 / 8, :65 -- a power of two, folded exactly), ``so`` its output projection, ``cq`` / ``co`` the
+    query and output projections of the source attention, ``ff1`` / ``ff2`` with d_ff = 2024 zero-padded to 2048 (ReLU(0) = 0).
+    ``kv``: the key / value projections of the five source attentions as ONE 512 -> 5 x 1024 GEMM over the feature sequence
+    ([k_l / 8 | v_l] per layer, computed once per table).  ``cell_in`` = cell_input_fc (K = 1024: [embedding | x_i]); the three
+    classifiers zero-padded to multiples of 64 outputs; embeddings pre-multiplied by sqrt(d_model) in fp32 (the reference's own
+    fp32 product, :26); the position table as the reference computes it."""
+    import math
+    bl = _Blob(x3)
+    d = MTL_D
+
+    def W(key):
+        return sd[key + ".weight"].float(), sd[key + ".bias"].float()
+
+    def lin(name, w, b, n_to=None, cin_to=None):
+        n_to = n_to or w.shape[0]
+        cin_to = cin_to or w.shape[1]
+        bl.add_conv(name, *_pad_conv(w.reshape(w.shape[0], w.shape[1], 1, 1), b, n_to, cin_to))
+
+    n_shared = 0
+    while f"layers.{n_shared}.self_attn.linears.0.weight" in sd:
+        n_shared += 1
+    assert n_shared == 2, "the engine's MtlTabNet decoder is built for N = 3 (two shared layers)"
+    src = {"l0": "layers.0", "l1": "layers.1", "cls": "cls_layer.0", "bbox": "bbox_layer.0", "cell": "cell_layer.0"}
+    kv_w, kv_b = [], []
+    d_ff = sd["layers.0.feed_forward.w_1.weight"].shape[0]
+    ffp = (d_ff + 63) // 64 * 64
+    for q in MTL_LAYERS:
+        p = src[q]
+        (wq, bq), (wk, bk), (wv, bv), (wo, bo) = [W(f"{p}.self_attn.linears.{i}") for i in range(4)]
+        lin(q + ".qkv", torch.cat([wq, wk / 8.0, wv], 0), torch.cat([bq, bk / 8.0, bv], 0))
+        lin(q + ".so", wo, bo)
+        (wq, bq), (wk, bk), (wv, bv), (wo, bo) = [W(f"{p}.src_attn.linears.{i}") for i in range(4)]
+        lin(q + ".cq", wq, bq)
+        lin(q + ".co", wo, bo)
+        kv_w += [wk / 8.0, wv]
+        kv_b += [bk / 8.0, bv]
+        lin(q + ".ff1", *W(p + ".feed_forward.w_1"), n_to=ffp)
+        lin(q + ".ff2", *W(p + ".feed_forward.w_2"), cin_to=ffp)
+        for i in range(3):
+            bl.add(f"{q}.ln{i}.g", sd[f"{p}.sublayer.{i}.norm.weight"].float().numpy(), "f32")
+            bl.add(f"{q}.ln{i}.b", sd[f"{p}.sublayer.{i}.norm.bias"].float().numpy(), "f32")
+    lin("kv", torch.cat(kv_w, 0), torch.cat(kv_b, 0))
+    ncls, ncell = sd["cls_fc.weight"].shape[0], sd["cell_fc.weight"].shape[0]
+    lin("cls_fc", *W("cls_fc"), n_to=(ncls + 63) // 64 * 64)
+    lin("bbox_fc", *W("bbox_fc.0"), n_to=64)
+    lin("cell_fc", *W("cell_fc"), n_to=(ncell + 63) // 64 * 64)
+    lin("cell_in", *W("cell_input_fc"))
+    bl.add("norm.g", sd["norm.weight"].float().numpy(), "f32")
+    bl.add("norm.b", sd["norm.bias"].float().numpy(), "f32")
+    bl.add("emb", (sd["embedding.lut.weight"].float() * math.sqrt(d)).numpy(), "f32")
+    bl.add("emb_cell", (sd["embedding_cell.lut.weight"].float() * math.sqrt(d)).numpy(), "f32")
+    bl.add("pe", mtl_positional_table().numpy(), "f32")
+    tc = cfg["idx_tag_cell"]
+    bl.add("meta", np.array([ncls, ncell, cfg["sos"], cfg["eos"], cfg["pad"], cfg["max_len"], cfg["sos_cell"], cfg["eos_cell"],
+                             cfg["pad_cell"], cfg["max_len_cell"], tc[0], tc[1], ffp], dtype=np.int32), "i32")
     return bl.tobytes()

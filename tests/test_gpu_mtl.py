@@ -1,5 +1,5 @@
-"""GPU parity of the MtlTabNet backbone (second half) through the C ABI against the fp32 oracle, which is
-pinned to the reference's own TableResNetExtra (tests/test_oracle_mtl_tabnet.py).  The decoders are not on the engine yet."""
+"""GPU parity of MtlTabNet (second half: backbone + the three decoders) through the C ABI against the fp32 oracle, which is
+pinned to the reference's own TableResNetExtra / MtlTabNetDecoder (tests/test_oracle_mtl_tabnet.py)."""
 import os
 
 import numpy as np
@@ -55,5 +55,138 @@ def test_missing_weights_fail_loudly():
     try:
         with pytest.raises(L.PtError, match="MtlTabNet backbone weights not loaded"):
             e.mtl_backbone_forward(torch.zeros((1, 3, 32, 32), device="cuda"))
+    finally:
+        e.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The three decoders (pt_tsr_mtl_structure / pt_tsr_mtl_cells) against the oracle's greedy_decode run per table (the reference is
+# called with one table, processor_mtl_tabnet.py:84-89); the oracle is pinned to the reference's own MtlTabNetDecoder by
+# tests/test_oracle_mtl_tabnet.py.  The special ids are configuration, so the cases move <EOS> / <PAD> / the cell tags onto tokens
+# the seeded weights really emit: early stops at different lengths, tables without cells, an emitted <PAD> (the reference's
+# non-causal padding mask -> the engine's re-decode mode), the same for the cell alphabet.
+# ---------------------------------------------------------------------------------------------------------------------
+BASE_CFG = dict(N=3, sos=40, eos=41, pad=42, max_len=12, sos_cell=57, eos_cell=58, pad_cell=59, max_len_cell=6, idx_tag_cell=[3, 5])
+DEC_CASES = {
+    "golden_cfg": {},                                                   # nothing special is ever emitted: both tables run to max_len
+    "early_eos": dict(eos=7, idx_tag_cell=[12, 1]),                     # table 0 stops after 3 positions, table 1 runs on; many cells
+    "pad_emitted": dict(pad=15, idx_tag_cell=[12, 1]),                  # table 1 emits <PAD> at step 1 -> re-decode mode
+    "cell_eos_at_once": dict(idx_tag_cell=[12, 1], eos_cell=50),        # every cell emits <EOS> in step 0
+    "cell_pad_emitted": dict(idx_tag_cell=[12, 1], pad_cell=50),        # the cell decoder emits its <PAD>
+    "eos_and_pad": dict(eos=7, pad=1, idx_tag_cell=[12, 3]),            # table 0: <PAD> at step 1, <EOS> at step 2
+}
+
+
+def _decoder_inputs(golden_dir, n_extra=1):
+    g = np.load(os.path.join(golden_dir, "mtl_tabnet_decoder.npz"))
+    rng = np.random.default_rng(77)
+    fmap = np.concatenate([g["fmap"], rng.standard_normal((n_extra,) + g["fmap"].shape[1:]).astype(np.float32)])
+    return g, fmap
+
+
+def _oracle_decode(sd, fmap, cfg):
+    out = []
+    with torch.no_grad():
+        feature = omt.positional_encoding(torch.from_numpy(fmap))
+        for b in range(fmap.shape[0]):
+            tag, box, cells = omt.greedy_decode(sd, feature[b:b + 1], cfg)
+            out.append((tag[0].numpy(), box[0].numpy(), cells[0].numpy()))
+    return out
+
+
+@pytest.fixture(scope="module")
+def dec_eng():
+    from pdf_table_amd.engine import HipEngine
+    e = HipEngine(0)
+    yield e
+    e.close()
+
+
+def _run_case(dec_eng, golden_dir, case, mode, force_redecode=False):
+    from pdf_table_amd.synth_weights import mtl_tabnet_decoder_state_dict
+    from pdf_table_amd.weights import pack_mtl_decoder
+    cfg = dict(BASE_CFG, **DEC_CASES[case])
+    g, fmap = _decoder_inputs(golden_dir)
+    sd = mtl_tabnet_decoder_state_dict(seed=int(g["seed"]), num_classes=43, num_classes_cell=60)
+    dec_eng.load_weights(L.PT_MODEL_MTL_DECODER, pack_mtl_decoder(sd, cfg))
+    dec_eng.set_precision(L.PT_PRECISION_BF16X3 if mode == "bf16x3" else L.PT_PRECISION_BF16)
+    try:
+        f3 = torch.from_numpy(fmap).permute(0, 2, 3, 1).reshape(fmap.shape[0], -1, 512).contiguous().cuda()
+        out = dec_eng.mtl_decode(f3, want_cell_logits=True, force_redecode=force_redecode)
+        torch.cuda.synchronize()
+    finally:
+        dec_eng.set_precision(L.PT_PRECISION_BF16)
+    return cfg, sd, fmap, out
+
+
+@pytest.mark.parametrize("case", list(DEC_CASES))
+def test_decoders_match_oracle_bf16x3(dec_eng, golden_dir, case):
+    cfg, sd, fmap, out = _run_case(dec_eng, golden_dir, case, "bf16x3")
+    want = _oracle_decode(sd, fmap, cfg)
+    tag, box = out["tag_logits"].cpu().numpy(), out["boxes"].cpu().numpy()
+    ids, prob, logits = out["cell_ids"].cpu().numpy(), out["cell_prob"].cpu().numpy(), out["cell_logits"].cpu().numpy()
+    c0 = 0
+    worst = [0.0, 0.0, 0.0]
+    for b, (wt, wb, wc) in enumerate(want):
+        ln = int(out["lens"][b])
+        assert ln == wt.shape[0], (case, b, ln, wt.shape)
+        assert (tag[b, :ln].argmax(-1) == wt.argmax(-1)).all(), (case, b)
+        scale = np.abs(wt).max()
+        worst[0] = max(worst[0], np.abs(tag[b, :ln] - wt).max() / scale)
+        worst[1] = max(worst[1], np.abs(box[b, :ln] - wb).max())
+        nc = int(out["cell_counts"][b])
+        if wc.ndim == 1:                        # torch.zeros(1): no cell tags in this table
+            assert nc == 0 and out["cell_steps"][b] == 0
+            continue
+        assert nc == wc.shape[0] and out["cell_steps"][b] == wc.shape[1], (case, b, nc, out["cell_steps"][b], wc.shape)
+        st = wc.shape[1]
+        got = logits[c0:c0 + nc, :st]
+        worst[2] = max(worst[2], np.abs(got - wc).max() / max(1.0, np.abs(wc).max()))
+        assert (ids[c0:c0 + nc, :st] == wc.argmax(-1)).all(), (case, b)
+        wp = torch.softmax(torch.from_numpy(wc), -1).max(-1).values.numpy()
+        assert np.abs(prob[c0:c0 + nc, :st] - wp).max() <= 1e-3
+        c0 += nc
+    assert c0 == len(ids)
+    print(f"mtl decoders [{case}] bf16x3: tag logits {worst[0]:.2e} of scale, boxes {worst[1]:.2e}, cell logits {worst[2]:.2e} of scale; "
+          f"lens {out['lens'].tolist()} cells {out['cell_counts'].tolist()} steps {out['cell_steps'].tolist()}")
+    assert worst[0] <= 1e-3 and worst[1] <= 1e-3 and worst[2] <= 1e-3
+
+
+@pytest.mark.parametrize("case", ["golden_cfg", "early_eos"])
+def test_cache_and_redecode_schedules_agree(dec_eng, golden_dir, case):
+    """the KV-cached loop and the reference's own schedule (every step decodes the whole prefix again) run the same kernels on the
+    same rows: identical tokens, logits within fp32 summation noise"""
+    _, _, _, a = _run_case(dec_eng, golden_dir, case, "bf16x3")
+    _, _, _, b = _run_case(dec_eng, golden_dir, case, "bf16x3", force_redecode=True)
+    assert a["lens"].tolist() == b["lens"].tolist() and a["cell_counts"].tolist() == b["cell_counts"].tolist()
+    assert a["cell_steps"].tolist() == b["cell_steps"].tolist()
+    for n_, ln in enumerate(a["lens"]):
+        ta, tb = a["tag_logits"][n_, :ln], b["tag_logits"][n_, :ln]
+        assert (ta - tb).abs().max().item() <= 1e-4 * ta.abs().max().item()
+    assert torch.equal(a["cell_ids"], b["cell_ids"])
+
+
+def test_decoders_bf16_drift_is_recorded(dec_eng, golden_dir):
+    cfg, sd, fmap, out = _run_case(dec_eng, golden_dir, "early_eos", "bf16")
+    want = _oracle_decode(sd, fmap, cfg)
+    tag = out["tag_logits"].cpu().numpy()
+    drift, flips = 0.0, 0
+    for b, (wt, _, _) in enumerate(want):
+        ln = min(int(out["lens"][b]), wt.shape[0])
+        same = tag[b, :ln].argmax(-1) == wt[:ln].argmax(-1)
+        first = ln if same.all() else int(np.argmin(same))       # past the first different token the sequences are different inputs
+        flips += int(first < ln)
+        if first:
+            drift = max(drift, np.abs(tag[b, :first] - wt[:first]).max() / np.abs(wt).max())
+    print(f"mtl decoders bf16: tag-logit drift {drift:.2e} of scale up to the first differing token, {flips} of {len(want)} sequences diverge")
+    assert drift <= 0.1
+
+
+def test_decoder_needs_weights_and_structure_first():
+    from pdf_table_amd.engine import HipEngine
+    e = HipEngine(0)
+    try:
+        with pytest.raises(L.PtError, match="MtlTabNet decoder weights not loaded"):
+            e.mtl_decode(torch.zeros((1, 24, 512), device="cuda"))
     finally:
         e.close()
