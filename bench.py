@@ -641,6 +641,50 @@ class HipRunner:
             out[name] = {"lines_per_s": len(lines) / dt, "ms_per_step": dt * 1e3, "pages_per_s_rec_only": PAGES_PER_STEP / dt}
         return out
 
+    def mtl_tabnet_leg(self, steps=2, warm=1):
+        """BASELINE.json configs[4], table-structure half: the SAME table regions of the step through MtlTabNet (480 x 480 pre-processing
+        kernel, ResNet-GC backbone, KV-cached structure / box / cell-content decoders, label convertor + HTML post-processor on the
+        host) at the reference's sequence limits (500 structure tokens, 150 cell-content tokens), bf16 and BF16X3"""
+        torch, L, eng = self.torch, self.L, self.eng
+        if self.tsr is None:
+            return None
+        from pdf_table_amd.mtl_stage import MtlStage, MtlTabNetConvertor
+        from pdf_table_amd.synth_weights import mtl_tabnet_backbone_state_dict, mtl_tabnet_decoder_state_dict
+        from pdf_table_amd.weights import pack_mtl_backbone, pack_mtl_decoder
+        conv = MtlTabNetConvertor()
+        eng.load_weights(L.PT_MODEL_MTL_BACKBONE, pack_mtl_backbone(mtl_tabnet_backbone_state_dict(seed=41)))
+        eng.load_weights(L.PT_MODEL_MTL_DECODER, pack_mtl_decoder(mtl_tabnet_decoder_state_dict(seed=43, num_classes=conv.num_classes(),
+                                                                                             num_classes_cell=conv.num_classes_cell()), conv.decoder_cfg()))
+        n_tab = int(sum(len(t) for t in self.table_boxes))
+        out = {"tables_per_step": n_tab, "steps": steps, "max_seq_len": conv.max_seq_len, "max_seq_len_cell": conv.max_seq_len_cell,
+               "note": "random-init decoders do not emit <EOS>: every table decodes all max_seq_len + 1 structure positions and its cells all "
+                       "max_seq_len_cell + 1 content positions -- the worst case of the greedy loops (a trained model stops at </tbody>)",
+               "asserted_by": "tests/test_gpu_mtl.py (x3: tokens identical, boxes / tag / cell logits <= 1e-3 of scale against the oracle "
+                              "pinned to the reference's own MtlTabNetDecoder; task end to end against the composed oracle chain), "
+                              "tests/test_mtl_host.py (convertor + post-processor identical to the reference's own classes)"}
+        for name, prec in (("bf16", L.PT_PRECISION_BF16), ("bf16x3", L.PT_PRECISION_BF16X3)):
+            eng.set_precision(prec)
+            try:
+                stage = MtlStage(eng, conv, micro_batch=int(os.environ.get("PT_MTL_MICROBATCH", "128")))
+                for _ in range(warm):
+                    stage(self.pages, self.table_boxes)
+                self.sync()
+                stage.stats = {k: 0 for k in stage.stats}
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    res = stage(self.pages, self.table_boxes)
+                self.sync()
+                dt = (time.perf_counter() - t0) / steps
+            finally:
+                eng.set_precision(L.PT_PRECISION_BF16)
+            st = stage.stats
+            out[name] = {"tables_per_s": n_tab / dt, "ms_per_step": dt * 1e3, "pages_per_s_tsr_only": PAGES_PER_STEP / dt,
+                         "structure_tokens_per_table": st["tokens"] / max(1, st["tables"]), "cells_per_table": st["cells"] / max(1, st["tables"]),
+                         "cell_steps_per_table": st["cell_steps"] / max(1, st["tables"]),
+                         "structure_tokens_per_s": st["tokens"] / steps / dt,
+                         "boxes_per_table": float(sum(len(r["polygons"]) for pg in res for r in pg)) / max(1, n_tab)}
+        return out
+
     def parity_sample(self):
         """engine outputs for the page / lines the CPU-baseline leg runs through the oracle (checked THERE)"""
         torch, L, eng = self.torch, self.L, self.eng
@@ -841,6 +885,10 @@ def main(argv=None):
             leg = runner.convnext_vit_leg()
             if rank == 0 and leg is not None:
                 out["convnext_vit_recogniser"] = leg
+        if "tsr" in runner.stages and not args.no_post:
+            leg = runner.mtl_tabnet_leg()
+            if rank == 0 and leg is not None:
+                out["mtl_tabnet"] = leg
     if rank == 0:
         if not stub and world == 1 and not args.no_cpu_baseline and "det" in runner.stages:
             r = runner

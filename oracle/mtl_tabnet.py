@@ -191,3 +191,27 @@ def greedy_decode(sd, feature, cfg):
         if torch.equal(nxt, eos):
             return decode_step(sd, inp, feature, cfg, True)
         inp = torch.cat([inp, nxt], dim=1)
+
+
+def mtl_preprocess(img, size=480):
+    """The test pipeline of mtl_tabnet_config.py:136-160 on one uint8 HxWx3 image (taken as it is: mmcv's loader hands an ndarray on):
+    TableResize(keep_ratio, long_size) -- model/table/lgpma/lgpma_preprocess.py:1067-1093: the long side becomes `size`, the short side
+    int(size / long * short) in Python floats, cv2.resize INTER_LINEAR (restated in oracle/db_pre.py, parity unpinned like every cv2
+    call) -- TablePad(size x size, pad_val 0) :1128-1182, ToTensorOCR (/ 255, CHW) and NormalizeOCR(0.5, 0.5).
+    -> (fp32 [3, size, size], img_meta with the keys the label convertor reads)."""
+    import numpy as np
+    from . import db_pre
+    h, w = img.shape[:2]
+    fw, fh = float(w), float(h)
+    if fw < fh:
+        fw, fh = size / fh * fw, size
+    else:
+        fh, fw = size / fw * fh, size
+    nw, nh = int(fw), int(fh)
+    r = db_pre.cv2_resize_linear_u8(img, nw, nh)
+    pad = np.zeros((size, size, 3), dtype=np.uint8)
+    pad[:nh, :nw] = r
+    x = torch.from_numpy(pad).permute(2, 0, 1).float().div(255.0)
+    x = (x - 0.5) / 0.5
+    meta = {"scale_factor": (nh / h, nw / w), "pad_shape": (size, size, 3), "ori_shape": tuple(img.shape), "img_shape": (nh, nw, 3)}
+    return x, meta

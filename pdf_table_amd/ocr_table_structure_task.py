@@ -1,10 +1,14 @@
-"""``OcrTableStructureTask`` on the HIP engine -- drop-in for the reference's stage-4 plug-in (model="Lore").
+"""``OcrTableStructureTask`` on the HIP engine -- drop-in for the reference's stage-4 plug-in (model="Lore" and model="MtlTabNet").
 
 Reference: src/pdftable/model/ocr_pdf/ocr_table_structure_task.py:47-271.  Same constructor (``task, model, task_type``,
 ``assert`` on the model name :53-54, ``PubTabNet`` -> ``ptn`` :66-67), same result list: one dict per input image with
 ``polygons`` float32 [n, 8] (cell quads in source pixels), ``logi`` [n, 4] (integer-valued logical locations) and
 ``inputs`` (TableLorePostProcessor.__call__, lore/processer_lore.py:163-188).  ``model="Lore"`` is served for all three
-task types (wtw / ptn: DLA-34 + DCN detector, wireless: ResNet-18 detector); the other structure models the reference lists fail loudly.
+task types (wtw / ptn: DLA-34 + DCN detector, wireless: ResNet-18 detector).  ``model="MtlTabNet"`` (BASELINE.json configs[4], SURVEY.md
+section 8f-4: ResNet-GC backbone + three KV-cached decoders on the engine, label convertor + HTML post-processor on the host,
+``pdf_table_amd/mtl_stage.py``) returns what ``MtlTabNetPostProcessor.__call__`` returns (model/mtl_tabnet/processor_mtl_tabnet.py:108-131):
+``polygons`` int32 [n, 8], ``structure_str_list``, ``structure_str``, ``html_context``, ``inputs``.  The other structure models the
+reference lists fail loudly.
 
 Two ways in:
   * reference-shaped: ``task(image_or_list)`` -- path / PIL / ndarray, one table image each;
@@ -24,8 +28,9 @@ from . import lib as L
 from .base_infer_task import BaseInferTask
 from .engine import HipEngine
 from .ocr_detection_task import _read_image
+from .mtl_stage import MtlStage, MtlTabNetConvertor, MtlTabnetConfig
 from .tsr_stage import LoreConfig, TsrStage
-from .weights import pack_lore_dla34, pack_lore_processor, pack_lore_wireless
+from .weights import pack_lore_dla34, pack_lore_processor, pack_lore_wireless, pack_mtl_backbone, pack_mtl_decoder
 
 __all__ = ["OcrTableStructureTask"]
 
@@ -36,14 +41,23 @@ class OcrTableStructureTask(BaseInferTask):
     def __init__(self, task="ocr_table_structure", model="CenterNet", engine: HipEngine = None, **kwargs):
         super().__init__(task=task, model=model, **kwargs)
         assert model in _MODELS
-        if model != "Lore":
-            raise RuntimeError(f"table-structure model '{model}' is not built on the HIP engine; only 'Lore' is "
-                               "(SURVEY.md section 8a stage 4)")
+        if model not in ("Lore", "MtlTabNet"):
+            raise RuntimeError(f"table-structure model '{model}' is not built on the HIP engine; 'Lore' and 'MtlTabNet' are "
+                               "(SURVEY.md section 8a stage 4, 8f-4)")
+        self._engine = engine
+        if model == "MtlTabNet":
+            self._config = MtlTabnetConfig(model_name=model, task_type=self.task_type)
+            # sequence limits are configuration (mtl_tabnet_config.py:12-18); tests shorten them
+            self._config.max_seq_len = int(kwargs.get("max_seq_len", self._config.max_seq_len))
+            self._config.max_seq_len_cell = int(kwargs.get("max_seq_len_cell", self._config.max_seq_len_cell))
+            self.model_provider = self._config.model_provider
+            self._config.model_path = self.get_model_name_or_path()
+            self._get_inference_model()
+            return
         if self.task_type == "PubTabNet":
             self.task_type = "ptn"
         self._config = LoreConfig(task_type=self.task_type or "wtw")
         self.model_provider = "model_scope"
-        self._engine = engine
         self._config.model_path = self.get_model_name_or_path()
         self._get_inference_model()
 
@@ -51,6 +65,8 @@ class OcrTableStructureTask(BaseInferTask):
         if self._engine is None:
             self._engine = HipEngine(int(str(self.device).split(":")[-1]) if ":" in str(self.device) else 0)
         cfg = self._config
+        if model == "MtlTabNet":
+            return self._construct_mtl()
         if self.synthetic_seed is not None:
             from .synth_weights import lore_dla34_state_dict, lore_processor_state_dict, lore_wireless_state_dict
             det_sd = (lore_wireless_state_dict if cfg.backbone == "ResNet-18" else lore_dla34_state_dict)(seed=int(self.synthetic_seed))
@@ -81,7 +97,46 @@ class OcrTableStructureTask(BaseInferTask):
         self._engine.load_weights(L.PT_MODEL_LORE_PROCESSOR, pack_lore_processor(proc_sd))
         self._model = self._predict
 
+    def _construct_mtl(self):
+        """``build(model config) + load_checkpoint`` (ocr_table_structure_task.py:106-113): one mmcv-style checkpoint, keys ``backbone.*``
+        and ``decoder.*`` (``pytorch_model.bin`` in a directory, or a ``.pth`` / ``.bin`` file; ``state_dict`` entry if present --
+        table/lgpma/checkpoint.py:39-53).  The network was trained on cv2-read (BGR) images and this engine's pages are RGB: conv1's input
+        channels are swapped once at load time, which is exact."""
+        cfg = self._config
+        self._convertor = MtlTabNetConvertor(max_seq_len=cfg.max_seq_len, max_seq_len_cell=cfg.max_seq_len_cell)
+        if self.synthetic_seed is not None:
+            from .synth_weights import mtl_tabnet_backbone_state_dict, mtl_tabnet_decoder_state_dict
+            bb = mtl_tabnet_backbone_state_dict(seed=int(self.synthetic_seed))
+            dec = mtl_tabnet_decoder_state_dict(seed=int(self.synthetic_seed) + 1, num_classes=self._convertor.num_classes(),
+                                                num_classes_cell=self._convertor.num_classes_cell())
+        else:
+            mp = cfg.model_path
+            f = mp if str(mp).endswith((".pth", ".bin")) else os.path.join(mp, "pytorch_model.bin")
+            if not os.path.exists(f):
+                raise RuntimeError(f"no MtlTabNet checkpoint at {f}: the reference would download it from the hub (no network here); "
+                                   "pass task_path=<dir or file> or synthetic_seed=<int>")
+            ck = torch.load(f, map_location="cpu", weights_only=True)
+            sd = ck["state_dict"] if "state_dict" in ck else ck
+            sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+            bb = {k[9:]: v for k, v in sd.items() if k.startswith("backbone.")}
+            dec = {k[8:]: v for k, v in sd.items() if k.startswith("decoder.")}
+            if not bb or not dec:
+                raise RuntimeError(f"{f} holds no 'backbone.' / 'decoder.' tensors (an MtlTabNet checkpoint has both)")
+            if dec["cls_fc.weight"].shape[0] != self._convertor.num_classes() or dec["cell_fc.weight"].shape[0] != self._convertor.num_classes_cell():
+                raise RuntimeError("the checkpoint's class counts do not match the PubTabNet vocabularies "
+                                   f"({dec['cls_fc.weight'].shape[0]} / {dec['cell_fc.weight'].shape[0]} vs "
+                                   f"{self._convertor.num_classes()} / {self._convertor.num_classes_cell()})")
+        bb = dict(bb)
+        bb["conv1.weight"] = bb["conv1.weight"][:, [2, 1, 0]].contiguous()
+        self._engine.load_weights(L.PT_MODEL_MTL_BACKBONE, pack_mtl_backbone(bb))
+        self._engine.load_weights(L.PT_MODEL_MTL_DECODER, pack_mtl_decoder(dec, self._convertor.decoder_cfg()))
+        self._model = self._predict
+
     def _build_processor(self):
+        if self.model == "MtlTabNet":
+            # the reference-shaped door keeps the reference's IndexError for a table without a surviving box; the batched door does not
+            self._stage = MtlStage(self._engine, self._convertor, size=self._config.size, micro_batch=int(os.environ.get("PT_MTL_MICROBATCH", "32")))
+            return
         # tables per DLA-34 launch chain: 8-table launches leave most of the 256 CUs idle in the coarse levels (measured
         # with the bench's 80); TsrStage balances the last micro-batch (87 tables -> 44 + 43)
         self._stage = TsrStage(self._engine, self._config, micro_batch=int(os.environ.get("PT_TSR_MICROBATCH", "128")))
@@ -89,6 +144,15 @@ class OcrTableStructureTask(BaseInferTask):
     def _predict(self, images: List[np.ndarray]) -> List[Dict]:
         """one table image each (RGB ndarray): the whole image is the crop"""
         out = []
+        if self.model == "MtlTabNet":
+            self._stage.post.strict = True
+            try:
+                for img in images:
+                    page = torch.from_numpy(np.ascontiguousarray(img)[None]).to(self._engine._tdev)
+                    out.append(self._stage(page, [np.array([[0, 0, img.shape[1], img.shape[0]]])])[0][0])
+            finally:
+                self._stage.post.strict = False
+            return out
         for img in images:
             page = torch.from_numpy(np.ascontiguousarray(img)[None]).to(self._engine._tdev)
             h, w = img.shape[:2]
@@ -104,6 +168,11 @@ class OcrTableStructureTask(BaseInferTask):
     def _preprocess(self, inputs, **kwargs):
         if not isinstance(inputs, list):
             inputs = [inputs]
+        if self.model == "MtlTabNet":
+            # mmcv's imread hands an ndarray on AS IS and reads a file as BGR (table/lgpma/base_utils.py:689-739); the engine holds the
+            # network with conv1's channels swapped (it eats RGB), so an ndarray is flipped here and a file is read as RGB
+            return {"inputs": [{"image": np.ascontiguousarray(it[..., ::-1]) if isinstance(it, np.ndarray) else _read_image(it), "inputs": it}
+                               for it in inputs]}
         return {"inputs": [{"image": _read_image(it), "inputs": it} for it in inputs]}
 
     def _run_model(self, inputs, **kwargs):
@@ -115,6 +184,12 @@ class OcrTableStructureTask(BaseInferTask):
 
     def _postprocess(self, inputs, **kwargs) -> List[Dict]:
         out = []
+        if self.model == "MtlTabNet":
+            for r in inputs["results"]:
+                d = {k: r["results"][k] for k in ("polygons", "structure_str_list", "structure_str", "html_context")}
+                d["inputs"] = r["inputs"]
+                out.append(d)
+            return out
         for r in inputs["results"]:
             d = {"polygons": r["results"]["polygons"], "logi": r["results"]["logi"]}
             if r["inputs"] is not None:

@@ -812,6 +812,71 @@ def gen_mtl_tabnet_decoder():
     print("mtl_tabnet_decoder.npz", {k: v.shape for k, v in res.items()}, "tags", out.argmax(-1).tolist())
 
 
+def gen_mtl_alphabet():
+    """The two vocabularies MtlTabNet's checkpoints are trained against (table/mtl_tabnet/mtl_tabnet_constants.py: 39 structure
+    tokens, 277 cell-content tokens) as a DATA file of the package -- a checkpoint's class ids mean nothing without them -- plus
+    their sha256 in this directory."""
+    c = ref_import("pdftable.model.table.mtl_tabnet.mtl_tabnet_constants")
+    d = {"structure": list(c.STRUCTURE_ALPHABET_PUBTABNET), "cell": list(c.TEXTLINE_RECOGNITION_ALPHABET_PUBTABNET)}
+    os.makedirs(os.path.join(REPO, "pdf_table_amd", "data"), exist_ok=True)
+    blob = json.dumps(d, ensure_ascii=False, indent=0).encode("utf-8")
+    with open(os.path.join(REPO, "pdf_table_amd", "data", "mtl_tabnet_alphabet.json"), "wb") as f:
+        f.write(blob)
+    with open(os.path.join(HERE, "mtl_tabnet_alphabet_hash.json"), "w") as f:
+        json.dump({"sha256": hashlib.sha256(json.dumps(d, ensure_ascii=False, sort_keys=True).encode("utf-8")).hexdigest(),
+                   "structure": len(d["structure"]), "cell": len(d["cell"])}, f)
+    print("mtl_tabnet_alphabet.json", len(d["structure"]), len(d["cell"]))
+
+
+def gen_mtl_tabnet_host():
+    """The reference's own ``MtlTabNetConvertor.output_format`` (table/mtl_tabnet/master_convertor.py:756-784),
+    ``MasterPostProcessor.__call__`` (master_post_processor.py:360-401) and ``MtlTabNetPostProcessor.__call__``
+    (model/mtl_tabnet/processor_mtl_tabnet.py:108-131) on seeded decoder outputs (regenerated from the seed by the test: only the
+    case names, the seed and the EXPECTED results are stored)."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from mtl_synth import MTL_HOST_CASES, mtl_host_case_tensors
+    stub_env()
+    conv_mod = ref_import("pdftable.model.table.mtl_tabnet.master_convertor")
+    post_mod = ref_import("pdftable.model.table.mtl_tabnet.master_post_processor")
+    consts = ref_import("pdftable.model.table.mtl_tabnet.mtl_tabnet_constants")
+    ocu = sys.modules["pdftable.utils.ocr"].OcrCommonUtils
+    conv = conv_mod.MtlTabNetConvertor(dict_file=list(consts.STRUCTURE_ALPHABET_PUBTABNET), max_seq_len=500, start_end_same=False,
+                                       with_unknown=True, cell_dict_file=list(consts.TEXTLINE_RECOGNITION_ALPHABET_PUBTABNET),
+                                       max_seq_len_cell=150)
+    like = {"char2idx": conv.char2idx, "char2idx_cell": conv.char2idx_cell, "end_idx": conv.end_idx, "end_idx_cell": conv.end_idx_cell,
+            "padding_idx_cell": conv.padding_idx_cell}
+    ids = {k: int(getattr(conv, k)) for k in ("start_idx", "end_idx", "padding_idx", "unknown_idx", "start_idx_cell", "end_idx_cell",
+                                              "padding_idx_cell", "unknown_idx_cell")}
+    ids.update(num_classes=conv.num_classes(), num_classes_cell=conv.num_classes_cell(), idx_tag_cell=conv.idx_tag_cell())
+    out = {"seed": 5150, "convertor": ids, "cases": {}}
+    post = post_mod.MasterPostProcessor(output_dir=None)
+    for k, name in enumerate(MTL_HOST_CASES):
+        tag, box, cell, meta = mtl_host_case_tensors(name, like, out["seed"] + k)
+        strings, scores, bboxes, cell_strings, cell_scores = conv.output_format(torch.from_numpy(tag), torch.from_numpy(box),
+                                                                                [torch.from_numpy(cell)], [meta])
+        result = dict(text=strings[0], score=scores[0], bbox=bboxes[0], cell=cell_strings[0])
+        try:
+            pred = post(result, file_name=None)
+        except IndexError:
+            # no box survives `sum(item) > 1`: np.array([]) has no axis to index in box_transform (master_post_processor.py:360) --
+            # the reference raises; what it had computed up to there is recorded
+            out["cases"][name] = {"raises": "IndexError", "text": strings[0], "score": float(scores[0]), "cell": list(cell_strings[0]),
+                                  "pred_html": result["pred_html"], "html_context": result["html_context"],
+                                  "structure_str": result["structure_str"], "structure_str_list": result["structure_str_list"]}
+            print(name, "-> IndexError in box_transform")
+            continue
+        polygons = ocu.box_list_two_point_to_four_point(pred["new_bbox"])
+        out["cases"][name] = {"text": strings[0], "score": float(scores[0]), "bbox_decoded": np.asarray(bboxes[0]).tolist(),
+                              "cell": list(cell_strings[0]), "cell_scores": [float(v) for v in cell_scores[0]],
+                              "bbox_kept": np.asarray(pred["bbox"]).tolist(), "new_bbox": np.asarray(pred["new_bbox"]).tolist(),
+                              "polygons": np.asarray(polygons).tolist(), "pred_html": pred["pred_html"], "html_context": pred["html_context"],
+                              "structure_str": pred["structure_str"], "structure_str_list": pred["structure_str_list"]}
+        print(name, "->", pred["pred_html"][:100], len(pred["new_bbox"]), "boxes")
+    with open(os.path.join(HERE, "mtl_tabnet_host.json"), "w") as f:
+        json.dump(out, f, ensure_ascii=False)
+    print("mtl_tabnet_host.json", len(out["cases"]), "cases")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["db", "crnn", "registry", "ctc", "host", "lore_dla", "lore_decode", "lore_processor", "picodet",
                              "table_html"]
@@ -851,3 +916,6 @@ if __name__ == "__main__":
         gen_mtl_tabnet_backbone()
     if "mtl_tabnet_decoder" in which or not sys.argv[1:]:
         gen_mtl_tabnet_decoder()
+    if "mtl_tabnet_host" in which or not sys.argv[1:]:
+        gen_mtl_alphabet()
+        gen_mtl_tabnet_host()

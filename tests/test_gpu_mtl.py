@@ -190,3 +190,91 @@ def test_decoder_needs_weights_and_structure_first():
             e.mtl_decode(torch.zeros((1, 24, 512), device="cuda"))
     finally:
         e.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The whole stage: pre-processing kernel, backbone, decoders, label convertor, HTML post-processor behind
+# OcrTableStructureTask(model="MtlTabNet") against the composed oracle chain on the same table image (sequence limits reduced so
+# that the oracle's O(L^2) re-decode finishes in seconds; the vocabularies are the real ones: 43 / 281 classes).
+# ---------------------------------------------------------------------------------------------------------------------
+def _table_images():
+    from pdf_table_amd.synth_pages import make_page
+    page = make_page(3, 1024)[0]
+    return [np.ascontiguousarray(page[100:311, 60:700]), np.ascontiguousarray(page[200:680, 300:560]), np.ascontiguousarray(page[0:480, 0:480])]
+
+
+def test_mtl_preprocess_matches_oracle(dec_eng):
+    from pdf_table_amd.mtl_stage import MtlStage
+    imgs = _table_images()
+    dec_eng.set_precision(L.PT_PRECISION_BF16X3)
+    try:
+        for img in imgs:
+            st = MtlStage.__new__(MtlStage)
+            tb = MtlStage.tables(st, img.shape[:2], [np.array([[0, 0, img.shape[1], img.shape[0]]])])
+            x = dec_eng.mtl_preprocess(torch.from_numpy(img[None]).cuda(), tb, 480).float().cpu()
+            got = (x[0, :, :, :32] + x[0, :, :, 32:])[:, :, :3].permute(2, 0, 1)
+            want, meta = omt.mtl_preprocess(img, 480)
+            assert dec_eng.mtl_resized_size(img.shape[1], img.shape[0], 480) == (meta["img_shape"][1], meta["img_shape"][0])
+            assert (got - want).abs().max().item() <= 2e-5, img.shape          # hi + lo carries 16 mantissa bits of the fp32 value
+            assert float(x[0, :, :, 3:32].abs().max()) == 0.0
+    finally:
+        dec_eng.set_precision(L.PT_PRECISION_BF16)
+
+
+def test_task_mtltabnet_end_to_end_vs_oracle_chain():
+    """image -> engine (BF16X3) -> result dict  ==  image -> oracle pre-processing -> oracle backbone -> oracle greedy decode -> the
+    host half on the oracle's logits: structure string, cell strings, HTML identical; polygons identical (int32 after truncation,
+    one pixel allowed where a coordinate sits on an integer)."""
+    from pdf_table_amd.engine import HipEngine
+    from pdf_table_amd.mtl_stage import MasterPostProcessor, MtlTabNetConvertor
+    from pdf_table_amd.ocr_table_structure_task import OcrTableStructureTask
+    from pdf_table_amd.synth_weights import mtl_tabnet_decoder_state_dict
+    e = HipEngine(0)
+    try:
+        e.set_precision(L.PT_PRECISION_BF16X3)
+        task = OcrTableStructureTask(model="MtlTabNet", synthetic_seed=61, engine=e, max_seq_len=20, max_seq_len_cell=6)
+        conv = task._convertor
+        assert (conv.num_classes(), conv.num_classes_cell()) == (43, 281)
+        imgs = _table_images()[:2]
+        # the reference-shaped door takes an ndarray as the network's input as it is (mmcv imread), so the oracle sees the same array
+        try:
+            got = task(list(imgs))
+        except IndexError:
+            got = None                                  # the reference's own failure for a table without a surviving box
+        bb_sd = mtl_tabnet_backbone_state_dict(seed=61)
+        dec_sd = mtl_tabnet_decoder_state_dict(seed=62, num_classes=43, num_classes_cell=281)
+        cfg = conv.decoder_cfg()
+        want = []
+        raised = False
+        for img in imgs:
+            x, meta = omt.mtl_preprocess(img, 480)
+            with torch.no_grad():
+                f3 = omt.backbone_forward_fp32(bb_sd, x[None])[2]
+                tag, box, cells = omt.greedy_decode(dec_sd, omt.positional_encoding(f3), cfg)
+            s, sc, bbx, cs, css = conv.output_format(tag.numpy(), box.numpy(), [c.numpy() for c in cells], [meta])
+            try:
+                pred = MasterPostProcessor(strict=True)(dict(text=s[0], score=sc[0], bbox=bbx[0], cell=cs[0]))
+            except IndexError:
+                raised = True
+                break
+            want.append((s[0], cs[0], pred))
+        if raised:
+            assert got is None
+            return
+        assert got is not None and len(got) == len(want)
+        for g, (s, cs, pred), img in zip(got, want, imgs):
+            assert g["structure_str"] == pred["structure_str"] and g["structure_str_list"] == pred["structure_str_list"]
+            assert g["html_context"] == pred["html_context"]
+            wp = np.asarray(pred["new_bbox"])[:, [0, 1, 2, 1, 2, 3, 0, 3]]
+            assert g["polygons"].shape == wp.shape and np.abs(g["polygons"].astype(np.int64) - wp).max() <= 1
+            print(f"mtl task e2e: {len(s.split(','))} structure tokens, {len(cs)} cell strings, {len(wp)} boxes, html {len(pred['html_context'])} chars; "
+                  f"polygons differing by one pixel: {int((g['polygons'] != wp).sum())}")
+        # the batched door (tables of resident pages) gives the same tables
+        pages = torch.from_numpy(np.stack([np.pad(im, ((0, 480 - im.shape[0]), (0, 640 - im.shape[1]), (0, 0))) for im in imgs])).cuda()
+        boxes = [np.array([[0, 0, im.shape[1], im.shape[0]]]) for im in imgs]
+        # ... whose pages are RGB: the same arrays channel-flipped are what the ndarray door fed the network
+        res = task.recognize_tables(pages.flip(-1).contiguous(), boxes, page_frame=False)
+        for r, g in zip(res, got):
+            assert r[0]["html_context"] == g["html_context"] and np.array_equal(r[0]["polygons"], g["polygons"])
+    finally:
+        e.close()
