@@ -93,6 +93,7 @@ void pt_engine_destroy(pt_engine* e) {
   if (e->layout_scratch) (void)hipFree(e->layout_scratch);
   if (e->det_in) (void)hipFree(e->det_in);
   pt_mtl_release(e);
+  e->stage_ring.destroy();
   if (e->lstm_scratch) (void)hipFree(e->lstm_scratch);
   if (e->lstm_err) (void)hipHostFree(e->lstm_err);
   if (e->prof.h_lims) (void)hipHostFree(e->prof.h_lims);
@@ -502,6 +503,18 @@ int pt_rec_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int
   return rec_pre_chunk(e, d_pages_rgb, n_pages, h, w, d_lines, h_crop_px, 0, n_lines, d_gray, reinterpret_cast<hipStream_t>(stream));
 }
 
+// crop offsets of a recognition call -> e->rec_off through a pinned slot of the staging ring: no stream synchronise in the enqueue path
+// (a pipelined caller has the next batch's detection queued on s by now; waiting for it here stalled the host one detection per batch)
+static int upload_crop_offsets(pt_engine* e, const std::vector<long long>& off, hipStream_t s) {
+  const size_t nb = off.size() * sizeof(long long);
+  void* hs = e->stage_ring.acquire(nb);
+  PT_REQUIRE(hs, "recognition: pinned staging (%s)", hipGetErrorString(hipGetLastError()));
+  memcpy(hs, off.data(), nb);
+  PT_HIP_CHECK(hipMemcpyAsync(e->rec_off, hs, nb, hipMemcpyHostToDevice, s));
+  PT_REQUIRE(e->stage_ring.release(s) == 0, "recognition: event record failed");
+  return PT_OK;
+}
+
 int pt_rec_forward_net(pt_engine* e, const uint16_t* d_gray, int n, int32_t* d_ids, float* d_maxlogit, pt_stream stream) {
   PT_REQUIRE(e && d_gray && d_ids && n > 0, "pt_rec_forward_net: bad arguments");
   PT_HIP_CHECK(hipSetDevice(e->device));
@@ -532,8 +545,7 @@ int pt_rec_forward_crops(pt_engine* e, const uint8_t* d_crops_rgb, const pt_rec_
   off.assign((size_t)n_lines + 1, 0);
   for (int i = 0; i < n_lines; ++i) off[i + 1] = off[i] + (h_crop_px[i] > 0 ? h_crop_px[i] : 0);
   if ((rc = ensure(&e->rec_off, &e->rec_off_cap, (size_t)(n_lines + 1) * sizeof(long long))) != PT_OK) return rc;
-  PT_HIP_CHECK(hipMemcpyAsync(e->rec_off, off.data(), (size_t)(n_lines + 1) * sizeof(long long), hipMemcpyHostToDevice, s));
-  PT_HIP_CHECK(hipStreamSynchronize(s));
+  if ((rc = upload_crop_offsets(e, off, s)) != PT_OK) return rc;
   const long long* d_off = reinterpret_cast<const long long*>(e->rec_off);
   for (int i0 = 0; i0 < n_lines; i0 += mb) {
     const int nb = (n_lines - i0) < mb ? (n_lines - i0) : mb;
@@ -607,9 +619,7 @@ static int cvit_crop_offsets(pt_engine* e, const int64_t* h_crop_px, int n_lines
   for (int i = 0; i < n_lines; ++i) off[i + 1] = off[i] + (h_crop_px[i] > 0 ? h_crop_px[i] : 0);
   int rc;
   if ((rc = ensure(&e->rec_off, &e->rec_off_cap, (size_t)(n_lines + 1) * sizeof(long long))) != PT_OK) return rc;
-  PT_HIP_CHECK(hipMemcpyAsync(e->rec_off, off.data(), (size_t)(n_lines + 1) * sizeof(long long), hipMemcpyHostToDevice, s));
-  PT_HIP_CHECK(hipStreamSynchronize(s));
-  return PT_OK;
+  return upload_crop_offsets(e, off, s);
 }
 
 int pt_rec_cvit_preprocess_crops(pt_engine* e, const uint8_t* d_crops_rgb, const pt_rec_line* d_lines, const int64_t* h_crop_px,

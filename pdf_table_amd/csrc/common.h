@@ -47,6 +47,9 @@ struct PtModel {
   void* d_blob = nullptr;
   size_t nbytes = 0;
   std::map<std::string, PtTensor> tensors;
+  // host copies of small integer tensors (configuration words stored beside the weights), read from the device ONCE per loaded blob:
+  // a synchronous hipMemcpy per call runs on the null stream and waits for everything queued on the caller's default stream
+  std::map<std::string, std::vector<int32_t>> host_words;
   const PtTensor* find(const std::string& n) const {
     auto it = tensors.find(n);
     return it == tensors.end() ? nullptr : &it->second;
@@ -71,6 +74,52 @@ struct PtArena {
     off = a + n;
     if (off > high) high = off;
     return base + a;
+  }
+};
+
+// Pinned host staging for small per-call tables (token maps, tile lists) that are the SOURCE of an asynchronous host-to-device copy:
+// a stack vector dies before a deferred copy reads it, and waiting for the copy means a stream synchronise per call.  A slot is
+// re-used only after the event recorded behind its copy has completed (the wait is real only if the ring wrapped with work pending).
+struct PtPinnedRing {
+  static constexpr int SLOTS = 8;
+  void* buf[SLOTS] = {};
+  size_t cap[SLOTS] = {};
+  hipEvent_t ev[SLOTS] = {};
+  bool pending[SLOTS] = {};
+  int next = 0;
+  int cur = -1;
+  // -> pinned pointer of at least `bytes`, or nullptr (hip error left for the caller to report)
+  void* acquire(size_t bytes) {
+    cur = next;
+    next = (next + 1) % SLOTS;
+    if (pending[cur]) {
+      if (hipEventSynchronize(ev[cur]) != hipSuccess) return nullptr;
+      pending[cur] = false;
+    }
+    if (bytes > cap[cur]) {
+      if (buf[cur]) (void)hipHostFree(buf[cur]);
+      buf[cur] = nullptr;
+      cap[cur] = 0;
+      const size_t want = (bytes + 4095) & ~size_t(4095);
+      if (hipHostMalloc(&buf[cur], want) != hipSuccess) return nullptr;
+      cap[cur] = want;
+    }
+    return buf[cur];
+  }
+  // record "the copies out of the slot acquired last are queued on s"
+  int release(hipStream_t s) {
+    if (cur < 0) return 0;
+    if (!ev[cur] && hipEventCreateWithFlags(&ev[cur], hipEventDisableTiming) != hipSuccess) return 1;
+    if (hipEventRecord(ev[cur], s) != hipSuccess) return 1;
+    pending[cur] = true;
+    return 0;
+  }
+  void destroy() {
+    for (int i = 0; i < SLOTS; ++i) {
+      if (buf[i]) (void)hipHostFree(buf[i]);
+      if (ev[i]) (void)hipEventDestroy(ev[i]);
+      buf[i] = nullptr; cap[i] = 0; ev[i] = nullptr; pending[i] = false;
+    }
   }
 };
 
@@ -134,6 +183,7 @@ struct pt_engine {
   // (thousands of launches on the same stream) later
   std::vector<int> cvit_maps[16][2];
   int cvit_slot = 0;
+  PtPinnedRing stage_ring;                                   // pinned sources of small asynchronous uploads (Lore processor token maps, ConvNextViT chunk maps)
   void* mtl_state = nullptr;                                 // mtl_decoder.hip: buffers + cell lists between pt_tsr_mtl_structure and pt_tsr_mtl_cells
 };
 

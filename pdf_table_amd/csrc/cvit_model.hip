@@ -741,9 +741,16 @@ int forward_batch(pt_engine* e, const PtModel& M, const float* gray, int pitch, 
     PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&A.base), want));
     A.cap = want;
   }
-  if (h_tw) {      // sources owned by the engine (see pt_engine::cvit_maps)
-    PT_HIP_CHECK(hipMemcpyAsync(d_cmap, cmap.data(), cmap.size() * sizeof(int), hipMemcpyHostToDevice, s));
-    PT_HIP_CHECK(hipMemcpyAsync(d_csrc, csrc.data(), csrc.size() * sizeof(int), hipMemcpyHostToDevice, s));
+  if (h_tw) {
+    // sources of asynchronous copies: a pinned slot of the engine's staging ring, re-used only after the event recorded behind these
+    // copies has completed (a pageable vector in a fixed-depth ring could be rewritten by a host that runs far ahead of the GPU)
+    int* hs = static_cast<int*>(e->stage_ring.acquire((cmap.size() + csrc.size()) * sizeof(int)));
+    PT_REQUIRE(hs, "ConvNextViT: pinned staging (%s)", hipGetErrorString(hipGetLastError()));
+    memcpy(hs, cmap.data(), cmap.size() * sizeof(int));
+    memcpy(hs + cmap.size(), csrc.data(), csrc.size() * sizeof(int));
+    PT_HIP_CHECK(hipMemcpyAsync(d_cmap, hs, cmap.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    PT_HIP_CHECK(hipMemcpyAsync(d_csrc, hs + cmap.size(), csrc.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    PT_REQUIRE(e->stage_ring.release(s) == 0, "ConvNextViT: event record failed");
   }
   // rows past the real ones are never written by the row kernels: clear once so that no NaN bit pattern reaches a GEMM
   PT_HIP_CHECK(hipMemsetAsync(x, 0, (size_t)(xel + 128) * sizeof(float), s));

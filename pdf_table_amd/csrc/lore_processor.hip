@@ -266,7 +266,16 @@ int pt_lore_process(pt_engine* e, const float* d_logi, const float* d_dets, cons
   const PtTensor* meta = p.get("meta");
   if (p.rc != PT_OK) return p.rc;
   int layers[2];
-  PT_HIP_CHECK(hipMemcpy(layers, meta->d_ptr, 8, hipMemcpyDeviceToHost));
+  {
+    // the two layer counts: read from the blob once per loaded model (a per-call hipMemcpy would wait for the whole default stream)
+    std::vector<int32_t>& hw = it->second.host_words["meta"];
+    if (hw.size() != 2) {
+      hw.assign(2, 0);
+      PT_HIP_CHECK(hipMemcpy(hw.data(), meta->d_ptr, 8, hipMemcpyDeviceToHost));
+    }
+    layers[0] = hw[0];
+    layers[1] = hw[1];
+  }
 
   // activations from the arena (grown once if needed)
   const size_t be = sizeof(bf16_t) * p.mul;
@@ -299,9 +308,17 @@ int pt_lore_process(pt_engine* e, const float* d_logi, const float* d_dets, cons
   float* sk = reinterpret_cast<float*>(base + o_sk);
   int* d_tok = reinterpret_cast<int*>(base + o_tok);
   int* d_tiles = reinterpret_cast<int*>(base + o_tiles);
-  PT_HIP_CHECK(hipMemcpyAsync(d_tok, tok.data(), tok.size() * 4, hipMemcpyHostToDevice, s));
-  PT_HIP_CHECK(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, s));
-  PT_HIP_CHECK(hipStreamSynchronize(s));   // tok / tiles are stack vectors: the copies must finish before they die
+  {
+    // token and tile maps go through an engine-owned pinned slot (the vectors die with this call, and a stream synchronise here would
+    // make the host wait for everything queued on s)
+    char* hs = static_cast<char*>(e->stage_ring.acquire((tok.size() + tiles.size()) * 4));
+    PT_REQUIRE(hs, "tsr process: pinned staging (%s)", hipGetErrorString(hipGetLastError()));
+    memcpy(hs, tok.data(), tok.size() * 4);
+    memcpy(hs + tok.size() * 4, tiles.data(), tiles.size() * 4);
+    PT_HIP_CHECK(hipMemcpyAsync(d_tok, hs, tok.size() * 4, hipMemcpyHostToDevice, s));
+    PT_HIP_CHECK(hipMemcpyAsync(d_tiles, hs + tok.size() * 4, tiles.size() * 4, hipMemcpyHostToDevice, s));
+    PT_REQUIRE(e->stage_ring.release(s) == 0, "tsr process: event record failed");
+  }
 
   const PtTensor *xpe = p.get("x_pe"), *ype = p.get("y_pe");
   if (p.rc != PT_OK) return p.rc;

@@ -704,7 +704,14 @@ int read_meta(Ctx& c, Meta* mt) {
   const PtTensor* t = c.get("meta");
   if (c.rc != PT_OK) return c.rc;
   PT_REQUIRE(t->nbytes >= sizeof(Meta), "MtlTabNet decoder blob: short meta tensor");
-  PT_HIP_CHECK(hipMemcpy(mt, t->d_ptr, sizeof(Meta), hipMemcpyDeviceToHost));
+  {
+    std::vector<int32_t>& hw = const_cast<PtModel*>(c.m)->host_words["meta"];      // read from the device once per loaded blob
+    if (hw.size() != sizeof(Meta) / 4) {
+      hw.assign(sizeof(Meta) / 4, 0);
+      PT_HIP_CHECK(hipMemcpy(hw.data(), t->d_ptr, sizeof(Meta), hipMemcpyDeviceToHost));
+    }
+    memcpy(mt, hw.data(), sizeof(Meta));
+  }
   PT_REQUIRE(mt->ncls > 0 && mt->ncell > 0 && mt->max_len > 0 && mt->max_len + 2 <= PE_ROWS && mt->max_len_c > 0 && mt->max_len_c + 2 <= PE_ROWS &&
                  mt->ffp % 64 == 0, "MtlTabNet decoder blob: bad meta");
   return PT_OK;

@@ -59,8 +59,12 @@ class OcrTablePipeline:
                  tsr_task_path: Optional[str] = None, layout_model: str = "picodet", layout_task_type: str = "en",
                  layout_task_path: Optional[str] = None, text_orientation: bool = False,
                  orientation_task_path: Optional[str] = None, table_html: bool = False, overlap_rec: bool = True,
-                 rotate_upside_down: bool = True, **kwargs):
+                 rotate_upside_down: bool = True, aux_layout: bool = False, tsr_on_aux: bool = False, **kwargs):
         self.engine = HipEngine(device)
+        # predict_stream() schedule switches: layout / the Lore processor on an auxiliary stream beside the main one.  Off: ONE compute
+        # stream measured faster (the weight-stationary cluster LSTM wants the GPU to itself, and concurrent small kernels slowed the
+        # large ones: 500 vs 590 pages/s on 64-page batches), at the price of results arriving three batches behind instead of two
+        self.aux_layout, self.tsr_on_aux = aux_layout, tsr_on_aux
         # the recogniser of a page batch runs on a second stream beside the layout and table-structure stages of the same
         # batch (every stage owns its arena inside the engine); the results do not depend on it.  The weight-stationary
         # cluster LSTM needs the whole GPU to itself (co-resident workgroups), so an overlapping pipeline runs the
@@ -108,6 +112,23 @@ class OcrTablePipeline:
                 tk["task_path"] = tsr_task_path
             self.table_structure_task = OcrTableStructureTask(model=table_structure_model, engine=self.engine,
                                                               task_type=table_structure_task_type, **tk)
+
+    @classmethod
+    def from_engine(cls, engine: HipEngine, det_stage: DetStage, rec_stage, layout_stage=None, tsr_stage=None, table_html: bool = False,
+                    overlap_rec: bool = False, aux_layout: bool = False, tsr_on_aux: bool = False) -> "OcrTablePipeline":
+        """The façade over an engine whose weights are ALREADY loaded -- e.g. packed once on rank 0, broadcast over RCCL and loaded from
+        device memory on every rank (dist_utils.broadcast_blob, ``bench.py --gpus N``) -- and over stage objects the caller built on it.
+        ``predict()`` / ``predict_stream()`` are the same code as after the ordinary constructor."""
+        import types
+        self = cls.__new__(cls)
+        self.engine, self.overlap_rec, self.rotate_upside_down, self._rec_stream = engine, overlap_rec, True, None
+        self.table_html, self.orientation_task, self.aux_layout, self.tsr_on_aux = table_html, None, aux_layout, tsr_on_aux
+        self.text_detector = types.SimpleNamespace(_stage=det_stage)
+        self.text_recognizer = types.SimpleNamespace(_stage=rec_stage)
+        self.layout_task = None if layout_stage is None else types.SimpleNamespace(_stage=layout_stage, detect_pages=layout_stage)
+        self.table_structure_task = None if tsr_stage is None else types.SimpleNamespace(
+            _stage=tsr_stage, recognize_tables=lambda pages, boxes, page_frame=True: tsr_stage(pages, boxes, page_frame=page_frame))
+        return self
 
     def predict(self, pages: Sequence, table_boxes: Optional[Sequence[np.ndarray]] = None, **kwargs) -> List[PageResult]:
         """pages: RGB images (paths / PIL / ndarrays); table_boxes: per page int [k,4] x1,y1,x2,y2 table regions (what the
@@ -228,16 +249,19 @@ class OcrTablePipeline:
         ``List[PageResult]`` per batch, in order, with the results ``predict()`` gives for that batch.
 
         The reference runs a page's stages back to back and waits for each (ocr_system_task.py:549-734); ``predict()`` keeps
-        that order per batch.  Here batch k's device work is queued while the host still works on batch k-1 and k-2:
+        that order per batch.  Here batch k's device work is queued while the host still works on the batches before it:
 
-            step k:  queue layout(k) [auxiliary stream] and detection(k)
-                     host: boxes of batch k-1 (contours, unclip, reading order), layout decode + NMS of batch k-1
-                     queue recognition(k-1) and table structure(k-1) on those boxes / regions
-                     host: texts and tables of batch k-2 (CTC collapse, processor, result shaping, HTML)  -> yield
-                     (moving the host halves of batch k behind the collect of k-2 measured slower: 465 vs 500 pages/s)
+            step k:  queue layout(k) and detection(k); recognition(k-1) and the table detector + decode (k-1) on the boxes /
+                     regions the host produced at the end of step k-1
+                     batch k-2: cell counts from pinned memory -> queue the Lore processor over its cells
+                     host: texts and tables of batch k-3 (CTC collapse, result shaping, HTML)  -> yield
+                     host: boxes of batch k (contours, box scores, unclip, reading order), layout decode + NMS of batch k
 
-        so the GPU queue always holds at least one batch of work while the host decodes, and nothing the host waits for was
-        queued in the same step.  Results arrive two batches behind the input; the generator drains at the end.
+        on ONE compute stream (copies ride on their own streams behind events): the GPU queue always holds at least one batch of
+        work while the host decodes, and nothing the host waits for was queued in the same step.  Results arrive three batches
+        behind the input; the generator drains at the end.  ``tsr_on_aux=True`` (constructor) runs the processor on an auxiliary
+        stream in the collect step instead -- two batches of latency, but measured slower (concurrent small kernels beside the
+        cluster LSTM and the large convolutions); ``aux_layout=True`` does the same for the layout network.
         ``table_boxes``: optional iterable aligned with ``batches`` (per batch: per-page int [k, 4] regions).  The text-line
         orientation vote needs a second, dependent detection pass per page and is not pipelined: use ``predict()`` for it."""
         if self.orientation_task is not None:
@@ -261,7 +285,7 @@ class OcrTablePipeline:
         tb_iter = iter(table_boxes) if table_boxes is not None else None
         t_start = time.time()
         total_lines = 0
-        host = {"queue_first": 0.0, "queue_second": 0.0, "collect": 0.0, "host_halves": 0.0}      # host seconds per phase (self.metric)
+        host = {"queue_first": 0.0, "queue_second": 0.0, "process_tables": 0.0, "collect": 0.0, "host_halves": 0.0}      # host seconds per phase (self.metric)
 
         def queue_first(batch, k):
             """layout(k) + detection(k)"""
@@ -278,10 +302,13 @@ class OcrTablePipeline:
             up.record(main)
             st["uploaded"] = up
             if lay_stage is not None:
-                with torch.cuda.stream(aux):
-                    aux.wait_event(up)
+                if getattr(self, "aux_layout", False):
+                    with torch.cuda.stream(aux):
+                        aux.wait_event(up)
+                        st["lay"] = lay_stage.forward(pages_t)
+                    pages_t.record_stream(aux)
+                else:       # one compute stream: per-kernel durations are those of the kernel alone (what bench.py's roofline divides by)
                     st["lay"] = lay_stage.forward(pages_t)
-                pages_t.record_stream(aux)
             st["det"] = det.forward(pages_t, slot=k & 1)
             return st
 
@@ -296,8 +323,8 @@ class OcrTablePipeline:
             host["halves.layout"] = host.get("halves.layout", 0.0) + time.perf_counter() - t1
 
         def queue_second(st):
-            """host halves of detection / layout, then recognition + table structure on their results"""
-            timed("host_halves", host_halves, st)
+            """recognition + table detector / decode on the boxes and regions host_halves() produced one step ago"""
+            t0 = time.perf_counter()
             with torch.cuda.stream(rec_s):
                 rec_s.wait_event(st["uploaded"])
                 try:
@@ -306,20 +333,45 @@ class OcrTablePipeline:
                     logger.warning("text recognition could not be queued: %r", e)
                     st["rec"] = None
             st["pages"].record_stream(rec_s)
-            if tsr_stage is not None:
+            t1 = time.perf_counter()
+            host["second.rec_start"] = host.get("second.rec_start", 0.0) + t1 - t0
+            if staged_tsr:
                 tb = st["tb"] if st["tb"] is not None else self._layout_table_boxes(st["layout"])
                 st["tb"] = tb
                 tables, metas = tsr_stage.tables(st["shape"], tb)
                 offs = np.stack([tables["x0"], tables["y0"]], 1).astype(np.float32) if len(tables) else None
+                t2 = time.perf_counter()
                 pending = tsr_stage.start(st["pages"], tables) if len(tables) else None
+                host["second.tsr_tables"] = host.get("second.tsr_tables", 0.0) + t2 - t1
+                host["second.tsr_start"] = host.get("second.tsr_start", 0.0) + time.perf_counter() - t2
                 ev = None
                 if pending is not None:      # the processor of these tables runs on the auxiliary stream, behind this event
                     ev = torch.cuda.Event()
                     ev.record(main)
-                    for p_ in pending:
-                        for t_ in p_[2:5]:
-                            t_.record_stream(aux)
+                    # no record_stream() on the decode outputs: `st` keeps them alive until collect() has waited for the processor's
+                    # rows, i.e. past their last use on the auxiliary stream -- and a 267 MB block with a foreign-stream use recorded
+                    # cannot be re-used by the caching allocator when it is freed: every batch then paid a hipMalloc (a device-wide
+                    # synchronisation) for its successor (measured: 443-462 -> pages/s of the private loop)
                 st["tsr"] = (pending, metas, offs, ev)
+
+        staged_tsr = tsr_stage is not None and hasattr(tsr_stage, "start")      # Lore: start / process / collect; MtlTabNet: one synchronous call
+        tsr_on_aux = bool(getattr(self, "tsr_on_aux", False))
+
+        def process_tables(st):
+            """device half 2 of the table stage for a batch whose decode was queued one step ago: cell counts from pinned memory (waits
+            for THAT decode only), the processor over all its cells, rows on their way to pinned memory"""
+            st["processed"] = None
+            if not staged_tsr or st["tsr"][0] is None:
+                return
+            pending, ev = st["tsr"][0], st["tsr"][3]
+            w0 = getattr(tsr_stage, "wait_s", 0.0)
+            if tsr_on_aux:
+                with torch.cuda.stream(aux):      # behind the decode of THESE tables only, beside whatever the main stream runs
+                    aux.wait_event(ev)
+                    st["processed"] = tsr_stage.process(pending)
+            else:
+                st["processed"] = tsr_stage.process(pending)
+            host["tables.wait_decode"] = host.get("tables.wait_decode", 0.0) + getattr(tsr_stage, "wait_s", 0.0) - w0
 
         def collect(st) -> List[PageResult]:
             nonlocal total_lines
@@ -328,20 +380,21 @@ class OcrTablePipeline:
             t1 = time.perf_counter()
             host["collect.texts"] = host.get("collect.texts", 0.0) + t1 - t0
             tsr = None
-            if tsr_stage is not None:
+            if tsr_stage is not None and not staged_tsr:
+                tb = st["tb"] if st["tb"] is not None else self._layout_table_boxes(st["layout"])
+                st["tb"] = tb
+                tsr = tsr_stage(st["pages"], tb, page_frame=True)
+            elif tsr_stage is not None:
                 pending, metas, offs, ev = st["tsr"]
                 flat = []
                 if pending is not None:
-                    with torch.cuda.stream(aux):      # counts D2H + processor: behind the decode of THESE tables only
-                        aux.wait_event(ev)
-                        processed = tsr_stage.process(pending)
-                    t2 = time.perf_counter()
-                    flat = tsr_stage.collect(processed, metas, offs)
-                    host["collect.tsr_process"] = host.get("collect.tsr_process", 0.0) + t2 - t1
-                    host["collect.tsr_collect"] = host.get("collect.tsr_collect", 0.0) + time.perf_counter() - t2
+                    if "processed" not in st:
+                        process_tables(st)
+                    flat = tsr_stage.collect(st["processed"], metas, offs)
+                    host["collect.tsr_collect"] = host.get("collect.tsr_collect", 0.0) + time.perf_counter() - t1
                 tsr = tsr_stage.regroup(flat, st["tb"])
-                if self.table_html:
-                    self._attach_html(tsr, st["tb"], st["boxes"], texts)
+            if tsr is not None and self.table_html:
+                self._attach_html(tsr, st["tb"], st["boxes"], texts)
             out = []
             for k in range(st["n"]):
                 boxes = st["boxes"][k]
@@ -358,22 +411,37 @@ class OcrTablePipeline:
             host[name] += time.perf_counter() - t0
             return r
 
-        first = second = None          # batch k-1 (device halves of layout / detection queued), batch k-2 (recognition / tables queued)
+        # stages of the software pipeline a batch walks through, one per step: [0] layout + detection queued, [1] host halves done,
+        # recognition + table decode queued, [2] (single-stream schedule only) processor queued, then collected and yielded
+        depth = 2 if (tsr_on_aux or not staged_tsr) else 3
+        inflight: List[Optional[dict]] = [None] * depth
         k = 0
+
+        def advance(cur):
+            # every enqueue of the step first, then the host work that may have to wait for the GPU: the queue never runs dry
+            # while the host sits in the detection post-process (its box scores come back from a side stream)
+            if inflight[0] is not None:
+                timed("queue_second", queue_second, inflight[0])
+            if depth == 3 and inflight[1] is not None:
+                timed("process_tables", process_tables, inflight[1])
+            done = inflight[depth - 1]
+            res = timed("collect", collect, done) if done is not None else None
+            if cur is not None:
+                timed("host_halves", host_halves, cur)
+            inflight[1:] = inflight[:-1]
+            inflight[0] = cur
+            return res
+
         for batch in batches:
             cur = timed("queue_first", queue_first, batch, k)
-            if first is not None:
-                timed("queue_second", queue_second, first)
-            if second is not None:
-                yield timed("collect", collect, second)
-            second, first = first, cur
             k += 1
-        if first is not None:
-            timed("queue_second", queue_second, first)
-        if second is not None:
-            yield timed("collect", collect, second)
-        if first is not None:
-            yield timed("collect", collect, first)
+            res = advance(cur)
+            if res is not None:
+                yield res
+        for _ in range(depth):
+            res = advance(None)
+            if res is not None:
+                yield res
         self.metric = {"use_time": time.time() - t_start, "batches": k, "text_recognition": {"total": total_lines},
                        "host_seconds": host}
 

@@ -9,6 +9,7 @@ and, after the device decode, maps the cell quads back to source pixels and roun
 from __future__ import annotations
 
 import os
+import time
 
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -159,6 +160,7 @@ class TsrStage:
         self.bgr = bgr
         self.with_html = with_html      # also emit 'structure_str_list' (show_results :292-303)
         self._copy_stream = None
+        self.wait_s = 0.0
         self.fused_decode = os.environ.get("PT_TSR_FUSED", "1") != "0"     # pt_tsr_forward_decode vs the two-call path
 
     def tables(self, page_shape: Tuple[int, int], boxes_per_page: Sequence[np.ndarray]):
@@ -230,7 +232,9 @@ class TsrStage:
         cfg = self.config
         staged = []
         for (i, nt, counts_d, dets, logi, counts_h, counts_ev) in pending:
+            t0 = time.perf_counter()
             counts_ev.synchronize()
+            self.wait_s += time.perf_counter() - t0      # host seconds spent waiting for the decode (diagnostics: pipeline.metric)
             counts = counts_h.numpy().copy()
             logic, stacked = self.eng.tsr_process(logi, dets, counts, use_2dpe=cfg.wiz_2dpe)
             staged.append((i, nt, counts, dets, logic, stacked))

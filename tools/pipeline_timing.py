@@ -1,9 +1,13 @@
 """tools/pipeline_timing.py: wall time of OcrTablePipeline.predict (synchronous, stage after stage, one 32-page batch) with
 the recogniser on the main stream and on a second stream, and of OcrTablePipeline.predict_stream over 64-page batches
 resident on the device (the product API next to bench.py's own loop; GPU box)."""
+import os
+import sys
 import time
 
 import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from pdf_table_amd.pipeline import OcrTablePipeline
