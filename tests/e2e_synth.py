@@ -1,0 +1,19 @@
+"""Seeded inputs of the end-to-end fixture shared by tests/golden/make_golden.py::gen_e2e_page (the oracle chain's run) and
+tests/test_gpu_e2e.py (the engine's run): page indices, weights, table regions."""
+import numpy as np
+
+E2E_PAGES = (7, 3)          # synthetic page indices (pdf_table_amd.synth_pages.make_page)
+
+
+def e2e_state_dicts():
+    """the seeded weights of the end-to-end fixture: the detector carries the hand-built text channel (boxes come out), the Lore
+    detector the heat-map bias that yields cells and the small DCN offsets of the full-size parity test"""
+    from pdf_table_amd import synth_weights as sw
+    return {"db": sw.db_resnet18_state_dict(seed=0, text_signal=True), "crnn": sw.crnn_state_dict(seed=1),
+            "pico": sw.picodet_state_dict(seed=4, num_classes=5), "lore": sw.lore_dla34_state_dict(seed=2, dcn_gain=0.02, hm_bias=(-2.0, -2.0), hm_gain=0.25),
+            "proc": sw.lore_processor_state_dict(seed=3)}
+
+
+def e2e_table_boxes(meta):
+    t = np.asarray(meta["tables"]).astype(np.int64).reshape(-1, 4)
+    return np.stack([np.maximum(t[:, 0] - 8, 0), np.maximum(t[:, 1] - 8, 0), np.minimum(t[:, 2] + 8, 1024), np.minimum(t[:, 3] + 8, 1024)], 1)

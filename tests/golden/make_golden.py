@@ -877,6 +877,40 @@ def gen_mtl_tabnet_host():
     print("mtl_tabnet_host.json", len(out["cases"]), "cases")
 
 
+def gen_e2e_page():
+    """Two 1024 x 1024 synthetic pages through the composed oracle chain (oracle/e2e.py: fp32, one call per line / table like the
+    reference) -> tests/golden/e2e_page.npz: boxes, token ids + top-2 margins, cells + logical locations per table.  Minutes of CPU."""
+    import time
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from e2e_synth import E2E_PAGES, e2e_state_dicts, e2e_table_boxes
+    from oracle import e2e
+    from pdf_table_amd.synth_pages import make_page
+    torch.set_num_threads(os.cpu_count() or 1)
+    sds = e2e_state_dicts()
+    res = {"pages": np.array(E2E_PAGES)}
+    for pi, idx in enumerate(E2E_PAGES):
+        page, meta = make_page(idx, 1024)
+        tb = e2e_table_boxes(meta)
+        t0 = time.time()
+        r = e2e.page_chain(page, sds, tb)
+        print(f"page {idx}: {len(r['det_boxes'])} boxes, {len(r['layout'])} layout regions, tables {[t['n'] for t in r['tables']]} cells, "
+              f"{r['det_prob_near_thresh']} prob pixels within 1e-3 of the threshold, {time.time() - t0:.0f} s")
+        p = f"p{pi}_"
+        res[p + "table_boxes"] = tb
+        res[p + "det_boxes"] = r["det_boxes"].astype(np.float32)
+        res[p + "rec_ids"], res[p + "rec_margin"], res[p + "rec_win"] = r["rec_ids"], r["rec_margin"].astype(np.float32), r["rec_win"].astype(np.float32)
+        res[p + "layout_bbox"] = np.array([it["bbox"] for it in r["layout"]], np.float32).reshape(-1, 4)
+        res[p + "layout_score"] = np.array([it["score"] for it in r["layout"]], np.float32)
+        res[p + "layout_cat"] = np.array([it["category_id"] for it in r["layout"]], np.int32)
+        res[p + "n_tables"] = np.array(len(r["tables"]))
+        for ti, t in enumerate(r["tables"]):
+            for k in ("polys", "scores", "stacked", "logi", "fragile"):
+                if k in t:
+                    res[f"{p}t{ti}_{k}"] = t[k]
+    np.savez_compressed(os.path.join(HERE, "e2e_page.npz"), **res)
+    print("e2e_page.npz", os.path.getsize(os.path.join(HERE, "e2e_page.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["db", "crnn", "registry", "ctc", "host", "lore_dla", "lore_decode", "lore_processor", "picodet",
                              "table_html"]
@@ -916,6 +950,8 @@ if __name__ == "__main__":
         gen_mtl_tabnet_backbone()
     if "mtl_tabnet_decoder" in which or not sys.argv[1:]:
         gen_mtl_tabnet_decoder()
+    if "e2e" in which:           # minutes of CPU: only on request
+        gen_e2e_page()
     if "mtl_tabnet_host" in which or not sys.argv[1:]:
         gen_mtl_alphabet()
         gen_mtl_tabnet_host()
