@@ -73,7 +73,7 @@ def parse_args(argv=None):
                          "(per-kernel HIP-event durations then include contention, so the roofline object reads low)")
     ap.add_argument("--gt-chain", action="store_true",
                     help="diagnostic: feed the recogniser the generator's text-line rectangles (round-1 behaviour)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"],
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "f16x2"],
                     help="arithmetic mode of the TIMED region (bf16x3: the tolerance mode as the headline; the default line "
                          "reports it as tolerance_mode)")
     ap.add_argument("--stages", default=os.environ.get("PT_BENCH_STAGES", "layout,det,rec,tsr"),
@@ -327,7 +327,7 @@ class HipRunner:
         self.stages = stages = [x for x in args.stages.split(",") if x]
         assert set(stages) <= {"layout", "det", "rec", "tsr", "cls"} and stages
         # the (hi, lo) weight tiles are only packed / broadcast when a BF16X3 leg will run (extra legs: one rank only)
-        self.x3_leg = ((not args.no_extra_legs and world == 1) or args.precision == "bf16x3") and args.det_backbone == "resnet18"
+        self.x3_leg = ((not args.no_extra_legs and world == 1) or args.precision != "bf16") and args.det_backbone == "resnet18"
         x3 = self.x3_leg            # blobs then also carry the (hi, lo) weight tiles of PT_PRECISION_BF16X3
         self.eng = eng = HipEngine(local_rank)
         self.aux = torch.cuda.Stream(device=dev) if args.aux_stream else None
@@ -845,8 +845,8 @@ def main(argv=None):
             dist.barrier()
         runner.sync()
 
-    if not stub and args.precision == "bf16x3":
-        runner.eng.set_precision(runner.L.PT_PRECISION_BF16X3)
+    if not stub and args.precision != "bf16":
+        runner.eng.set_precision(runner.L.PT_PRECISION_BF16X3 if args.precision == "bf16x3" else runner.L.PT_PRECISION_F16X2)
     runner.run(args.warmup)
     barrier()
     # HIP events around the launches of the roofline's kernel class only (mode 2 + class 0 = the 3x3 convs): an event pair per
@@ -874,7 +874,7 @@ def main(argv=None):
         total_pages = world * PAGES_PER_STEP * args.steps
         out = {"metric": "pages/s", "value": total_pages / dt, "unit": "pages/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "bf16x3", "data": "synthetic",
+               "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
                "config": runner.config(counts, args.steps)}
         if prof is not None:
             c3 = prof["conv3x3"]

@@ -70,9 +70,14 @@ int pt_engine_set_lstm_cluster(pt_engine* e, int on);
  * weight is a (hi, lo) bf16 pair and each product is three MFMA passes (hi*hi + lo*hi + hi*lo), fp32-class
  * accuracy (~1e-5 relative) at ~1/3 of the throughput: the mode that meets the reference-fp32 parity tolerance.
  * In BF16X3 mode every bf16 NHWC activation tensor of C channels crossing this ABI (pt_det_preprocess output,
- * pt_det_forward_net input, pt_op_* tensors with split=1) has 2C channels laid out [hi(C) | lo(C)]. */
+ * pt_det_forward_net input, pt_op_* tensors with split=1) has 2C channels laid out [hi(C) | lo(C)].
+ * PT_PRECISION_F16X2: the same (hi, lo) bf16 activation pairs -- same tensors across this ABI -- but the convolutions and GEMMs of
+ * the DB / CRNN / Lore / PicoDet graphs multiply them with SINGLE fp16 weights in two fp16 MFMA passes (hi*w + lo*w; a bf16 value
+ * converts to fp16 exactly): rounding the WEIGHTS to 11 bits moves the logits by ~1.5e-4 of their scale (tools/x2_emulation.py) --
+ * inside the 1e-3 tolerance at 2/3 of BF16X3's matrix work; layers without the variant run as in BF16X3. */
 #define PT_PRECISION_BF16 0
 #define PT_PRECISION_BF16X3 1
+#define PT_PRECISION_F16X2 2
 int pt_engine_set_precision(pt_engine* e, int precision);
 
 /* Model kinds for pt_weights_load.  A blob is the "PTW1" container written by

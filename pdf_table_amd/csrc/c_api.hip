@@ -43,7 +43,7 @@ int pt_engine_set_lstm_cluster(pt_engine* e, int on) {
 }
 
 int pt_engine_set_precision(pt_engine* e, int precision) {
-  PT_REQUIRE(e && (precision == PT_PRECISION_BF16 || precision == PT_PRECISION_BF16X3), "pt_engine_set_precision: bad arguments");
+  PT_REQUIRE(e && (precision == PT_PRECISION_BF16 || precision == PT_PRECISION_BF16X3 || precision == PT_PRECISION_F16X2), "pt_engine_set_precision: bad arguments");
   e->precision = precision;
   return PT_OK;
 }
@@ -246,7 +246,7 @@ int pt_det_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h, in
   PT_REQUIRE(e && d_pages_rgb && d_out_bf16 && n > 0, "pt_det_preprocess: bad arguments");
   int nh, nw, rc;
   if ((rc = pt_det_plan(h, w, pre_flavour, &nh, &nw)) != PT_OK) return rc;
-  return pt_launch_det_preprocess(d_pages_rgb, n, h, w, nh, nw, pre_flavour, e->precision == PT_PRECISION_BF16X3, d_out_bf16,
+  return pt_launch_det_preprocess(d_pages_rgb, n, h, w, nh, nw, pre_flavour, pt_split(e), d_out_bf16,
                                   reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -272,7 +272,7 @@ int pt_layout_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h,
   PT_REQUIRE(e && d_pages_rgb && d_out_bf16 && n > 0, "pt_layout_preprocess: bad arguments");
   PT_HIP_CHECK(hipSetDevice(e->device));
   // same arithmetic as the PP-OCR detection pre-process (BGR flip, (x * 1/255 - mean) / std), fixed target size
-  return pt_launch_det_preprocess(d_pages_rgb, n, h, w, inp_h, inp_w, PT_DET_PRE_DB_PP, e->precision == PT_PRECISION_BF16X3,
+  return pt_launch_det_preprocess(d_pages_rgb, n, h, w, inp_h, inp_w, PT_DET_PRE_DB_PP, pt_split(e),
                                   d_out_bf16, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -308,7 +308,7 @@ int pt_layout_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h, in
   int32_t fh[4], fw[4];
   int rc = pt_layout_plan(inp_h, inp_w, fh, fw);
   if (rc != PT_OK) return rc;
-  const int m = e->precision == PT_PRECISION_BF16X3 ? 2 : 1;
+  const int m = pt_split(e) ? 2 : 1;
   size_t off = 0, o_head[4];
   auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~size_t(255); return o; };
   const size_t o_x = carve((size_t)n * inp_h * inp_w * 4 * m * sizeof(uint16_t));
@@ -345,7 +345,7 @@ int pt_tsr_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int
     PT_HIP_CHECK(hipMemcpy(e->tsr_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
   }
   return pt_launch_tsr_preprocess(d_pages_rgb, ph, pw, d_tables, n, inp_h, inp_w, bgr, e->tsr_lut, d_out_bf16,
-                                  e->precision == PT_PRECISION_BF16X3, reinterpret_cast<hipStream_t>(stream));
+                                  pt_split(e), reinterpret_cast<hipStream_t>(stream));
 }
 
 int pt_tsr_forward_net(pt_engine* e, const uint16_t* d_input_bf16, int n, int H, int W, float* d_hm, float* d_st,
@@ -417,7 +417,7 @@ int pt_det_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h, int w
   if ((rc = pt_det_plan(h, w, pre_flavour, &nh, &nw)) != PT_OK) return rc;
   const int mb = microbatch();
   // the pre-processed pages live in their own engine-owned buffer (not the arena, which the net resets)
-  const int x3 = e->precision == PT_PRECISION_BF16X3;
+  const int x3 = pt_split(e);
   const size_t need = (size_t)(mb < n ? mb : n) * nh * nw * (x3 ? 8 : 4) * sizeof(bf16_t);
   if ((rc = ensure(&e->det_in, &e->det_in_cap, need)) != PT_OK) return rc;
   void* xbuf = e->det_in;
@@ -493,7 +493,7 @@ static int rec_pre_chunk(pt_engine* e, const uint8_t* d_pages, int n_pages, int 
   }
   PtProfScope ps(e, s, PT_PROF_OTHER, 0, "rec resize+gray");
   return pt_launch_rec_resize_gray(reinterpret_cast<const uint8_t*>(e->rec_crops), d_lines + i0, d_off, nb,
-                                   e->precision == PT_PRECISION_BF16X3, d_gray, s);
+                                   pt_split(e), d_gray, s);
 }
 
 int pt_rec_preprocess(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int h, int w, const pt_rec_line* d_lines,
@@ -520,7 +520,7 @@ int pt_rec_forward_net(pt_engine* e, const uint16_t* d_gray, int n, int32_t* d_i
   PT_HIP_CHECK(hipSetDevice(e->device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int mb = rec_microbatch();
-  const size_t per_line = (size_t)PT_REC_H * PT_REC_W * (e->precision == PT_PRECISION_BF16X3 ? 2 : 1);
+  const size_t per_line = (size_t)PT_REC_H * PT_REC_W * (pt_split(e) ? 2 : 1);
   for (int i0 = 0; i0 < n; i0 += mb) {
     const int nb = (n - i0) < mb ? (n - i0) : mb;
     int rc = pt_crnn_forward_net(e, d_gray + (size_t)i0 * per_line, nb, d_ids + (size_t)i0 * PT_REC_T,
@@ -536,7 +536,7 @@ int pt_rec_forward_crops(pt_engine* e, const uint8_t* d_crops_rgb, const pt_rec_
   PT_HIP_CHECK(hipSetDevice(e->device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int mb = rec_microbatch();
-  const int x3 = e->precision == PT_PRECISION_BF16X3;
+  const int x3 = pt_split(e);
   const size_t per_line = (size_t)PT_REC_H * PT_REC_W * (x3 ? 2 : 1);
   int rc;
   if ((rc = ensure(&e->rec_gray, &e->rec_gray_cap, (size_t)(mb < n_lines ? mb : n_lines) * per_line * sizeof(bf16_t))) != PT_OK)
@@ -564,7 +564,7 @@ int pt_rec_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n_pages, int h,
   PT_HIP_CHECK(hipSetDevice(e->device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int mb = rec_microbatch();
-  const size_t per_line = (size_t)PT_REC_H * PT_REC_W * (e->precision == PT_PRECISION_BF16X3 ? 2 : 1);
+  const size_t per_line = (size_t)PT_REC_H * PT_REC_W * (pt_split(e) ? 2 : 1);
   int rc;
   if ((rc = ensure(&e->rec_gray, &e->rec_gray_cap, (size_t)(mb < n_lines ? mb : n_lines) * per_line * sizeof(bf16_t))) != PT_OK)
     return rc;
@@ -818,7 +818,7 @@ int pt_cls_preprocess(pt_engine* e, const uint8_t* d_base, const pt_cls_image* d
   int rc;
   if ((rc = cls_lut(e)) != PT_OK) return rc;
   return pt_launch_cls_resize_norm(d_base, d_images, n, max_h, max_w, out_h, out_w, e->cls_lut,
-                                   e->precision == PT_PRECISION_BF16X3, d_out_bf16, reinterpret_cast<hipStream_t>(stream));
+                                   pt_split(e), d_out_bf16, reinterpret_cast<hipStream_t>(stream));
 }
 
 int pt_cls_forward_net(pt_engine* e, int slot, const uint16_t* d_input_bf16, int n, int in_h, int in_w, int textline,
@@ -827,7 +827,7 @@ int pt_cls_forward_net(pt_engine* e, int slot, const uint16_t* d_input_bf16, int
   PT_HIP_CHECK(hipSetDevice(e->device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int mb = cls_microbatch();
-  const size_t per = (size_t)in_h * in_w * (e->precision == PT_PRECISION_BF16X3 ? 8 : 4);
+  const size_t per = (size_t)in_h * in_w * (pt_split(e) ? 8 : 4);
   for (int i0 = 0; i0 < n; i0 += mb) {
     const int nb = (n - i0) < mb ? (n - i0) : mb;
     const int rc = pt_pplcnet_forward_net(e, slot, d_input_bf16 + (size_t)i0 * per, nb, in_h, in_w, textline,
@@ -844,7 +844,7 @@ int pt_cls_forward(pt_engine* e, int slot, const uint8_t* d_base, const pt_cls_i
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc;
   if ((rc = cls_lut(e)) != PT_OK) return rc;
-  const int mb = cls_microbatch(), x3 = e->precision == PT_PRECISION_BF16X3;
+  const int mb = cls_microbatch(), x3 = pt_split(e);
   const size_t per = (size_t)out_h * out_w * (x3 ? 8 : 4);
   if ((rc = ensure(&e->cls_scratch, &e->cls_scratch_cap, (size_t)(mb < n ? mb : n) * per * sizeof(bf16_t))) != PT_OK) return rc;
   bf16_t* xin = reinterpret_cast<bf16_t*>(e->cls_scratch);
@@ -869,7 +869,7 @@ int pt_cls_forward_lines(pt_engine* e, int slot, const uint8_t* d_pages_rgb, int
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc;
   if ((rc = cls_lut(e)) != PT_OK) return rc;
-  const int mb = cls_microbatch(), x3 = e->precision == PT_PRECISION_BF16X3;
+  const int mb = cls_microbatch(), x3 = pt_split(e);
   const size_t per = (size_t)out_h * out_w * (x3 ? 8 : 4);
   const int cap = mb < n_lines ? mb : n_lines;
   const size_t desc_bytes = ((size_t)cap * sizeof(pt_cls_image) + 255) & ~(size_t)255;

@@ -227,6 +227,8 @@ struct ConvDesc {
   const int* xlimit_rows = nullptr;
   // bf16x3 precision mode: in/res/out hold (hi | lo) channel groups; w is [N/64][3*Cin/32][taps][64][32]
   int split = 0;
+  // split = 2 (PT_PRECISION_F16X2): same (hi | lo) tensors, but w holds fp16 tiles [N/64][2*Cin/32][taps][64][32] (blob suffix .wh: the
+  // same fp16 tile for the x_hi and the x_lo K chunks) and the launch takes the two-pass fp16 variant of conv_igemm_kernel
   int out_lo_off = 0;  // channel distance between the hi and lo halves in the output buffer
   // fused DB head: see ConvK in conv_igemm.hip (requires shuffle_cout == 64)
   const void* head_w = nullptr;
@@ -371,6 +373,12 @@ int pt_lore_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, floa
 
 #define PT_PRECISION_BF16 0
 #define PT_PRECISION_BF16X3 1
+#define PT_PRECISION_F16X2 2
+// storage: both tolerance modes keep every activation as a (hi | lo) bf16 pair ("split" layout)
+static inline int pt_split(const pt_engine* e) { return e->precision != PT_PRECISION_BF16; }
+// arithmetic: F16X2 = the conv / GEMM launches that have the variant multiply the pair (converted to fp16 while it is staged in LDS:
+// exact, a bf16 value has 8 significant bits) with SINGLE fp16 weights in two MFMA passes; every other kernel runs as in BF16X3
+static inline int pt_f16x2(const pt_engine* e) { return e->precision == PT_PRECISION_F16X2; }
 
 // profiling helper: bracket a launch with events when enabled
 struct PtProfScope {

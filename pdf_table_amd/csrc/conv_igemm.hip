@@ -26,6 +26,7 @@
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -89,6 +90,37 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
 }
 __device__ __forceinline__ float bf16lo_f32(uint32_t pk) { return __uint_as_float(pk << 16); }
 __device__ __forceinline__ float bf16hi_f32(uint32_t pk) { return __uint_as_float(pk & 0xFFFF0000u); }
+
+// PT_PRECISION_F16X2: two bf16 values -> two fp16 values.  Exact (a bf16 value has 8 significant bits, fp16 holds 11) inside fp16's
+// range, so the round-toward-zero pack is enough; the hi / lo halves of an activation pair are converted while the slice is staged.
+__device__ __forceinline__ uint32_t bf16x2_to_f16x2(uint32_t v) {
+  return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(v << 16), __uint_as_float(v & 0xFFFF0000u)));
+}
+__device__ __forceinline__ u32x4 bf16x8_to_f16x8(u32x4 v) {
+  u32x4 r;
+  r.x = bf16x2_to_f16x2(v.x); r.y = bf16x2_to_f16x2(v.y); r.z = bf16x2_to_f16x2(v.z); r.w = bf16x2_to_f16x2(v.w);
+  return r;
+}
+// The lo halves are ~2^-9 of their values: below 2^-14 they would be fp16 subnormals, which the matrix pipe flushes (measured: without
+// the scaling the mode read 1.2e-3 of the logit scale instead of 1.5e-4).  They are multiplied by 2^8 on the way in (exact), their K
+// chunks run FIRST, and the accumulators are multiplied by 2^-8 once before the hi chunks follow.
+#define PT_F16_LO_SCALE 256.0f
+__device__ __forceinline__ uint32_t bf16x2_to_f16x2_scaled(uint32_t v) {
+  return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(v << 16) * PT_F16_LO_SCALE, __uint_as_float(v & 0xFFFF0000u) * PT_F16_LO_SCALE));
+}
+__device__ __forceinline__ u32x4 bf16x8_to_f16x8_scaled(u32x4 v) {
+  u32x4 r;
+  r.x = bf16x2_to_f16x2_scaled(v.x); r.y = bf16x2_to_f16x2_scaled(v.y); r.z = bf16x2_to_f16x2_scaled(v.z); r.w = bf16x2_to_f16x2_scaled(v.w);
+  return r;
+}
+// one 32x32x16 MFMA on 16-bit operands held as bf16x8 bit patterns: bf16, or fp16 in the F16X2 kernels
+template <bool F16>
+__device__ __forceinline__ f32x16 mma16(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 
 // XCD-aware bijective remap of the flat block id (8 XCDs; block b is observed to run on XCD b % 8)
 __device__ __forceinline__ int xcd_remap(int id, int nwg) {
@@ -472,7 +504,9 @@ struct ConvCfg {
 // NHALF = 1: only the first 32 of the tile's 64 output columns are computed (layers with <= 32 real outputs, e.g. the
 // 27-channel offset / mask convs of the deformable layers): half the MFMAs and half the B-fragment reads.
 // DIRECT: the weights are the MFMA's A operand and the epilogue runs from the accumulators (epilogue_direct_row)
-template <int KS, int STRIDE, int GEOM, int NHALF = 2, bool DIRECT = false>
+// F16 (PT_PRECISION_F16X2, split layers only): K = (x_hi, w) + (x_lo, w) with fp16 weight tiles; the activation halves are converted to
+// fp16 on their way into LDS and the products run on v_mfma_f32_32x32x16_f16
+template <int KS, int STRIDE, int GEOM, int NHALF = 2, bool DIRECT = false, bool F16 = false>
 __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_igemm_kernel(ConvK p) {
   using C = ConvCfg<KS, STRIDE, GEOM>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -513,7 +547,7 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
     if (ox0 >= mx) continue;
   }
   const int iy0 = oy0 * STRIDE - (KS / 2), ix0 = ox0 * STRIDE - (KS / 2);
-  const int nchunks = p.split ? 3 * (p.Cin >> 5) : (p.Cin >> 5);
+  const int nchunks = p.split ? (F16 ? 2 : 3) * (p.Cin >> 5) : (p.Cin >> 5);
   const int in_cs = p.split ? 2 * p.Cin : p.Cin;   // channels per input pixel in memory
   const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * in_cs;
   const bf16_t* wt = p.w + (size_t)nt * nchunks * (C::TAPS * 64 * 32);
@@ -522,15 +556,19 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
   u32x4 rw[C::NWP];
 
   auto prefetch = [&](int chunk) {
-    // split mode: K chunks walk [x_hi | x_lo] against w_hi, then x_hi again against w_lo
+    // split mode: K chunks walk [x_hi | x_lo] against w_hi, then x_hi again against w_lo; F16: x_lo first, then x_hi, both against w
     int c0 = chunk << 5;
-    if (c0 >= in_cs) c0 -= in_cs;
+    if (F16) c0 = chunk < (p.Cin >> 5) ? p.Cin + c0 : c0 - p.Cin;
+    else if (c0 >= in_cs) c0 -= in_cs;
     const bf16_t* src = in_b;
     int src_cs = in_cs;
     if (KS == 1 && STRIDE == 1 && p.nseg > 1) {
       // K over a concatenation of tensors: logical channel -> (segment, channel inside it); uniform over the workgroup
       int cc = chunk << 5, lo = 0;
-      if (p.split) {
+      if (F16) {
+        if (cc < p.Cin) lo = 1;
+        else cc -= p.Cin;
+      } else if (p.split) {
         if (cc >= 2 * p.Cin) cc -= 2 * p.Cin;
         else if (cc >= p.Cin) { cc -= p.Cin; lo = 1; }
       }
@@ -563,7 +601,8 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
       rw[j] = *reinterpret_cast<const u32x4*>(wc + idx * 8);
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int chunk) {
+    const bool lo_half = F16 && chunk < (p.Cin >> 5);
 #pragma unroll
     for (int j = 0; j < C::NI; ++j) {
       const int idx = tid + j * 256;
@@ -573,7 +612,8 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
           const int iy = slot / C::TWIN, ix = slot - iy * C::TWIN;   // are then CONSECUTIVE 80-byte slots, as at stride 1 --
           slot = iy * C::TWIN + (ix & 1) * C::XEVEN + (ix >> 1);      // no 2-pixel stride, no bank conflicts on ds_read_b128
         }
-        *reinterpret_cast<u32x4*>(s_in + slot * C::PIXB + ((C::SWZ ? ((idx & 3) ^ ((slot >> 2) & 3)) : (idx & 3)) * 16)) = rin[j];
+        *reinterpret_cast<u32x4*>(s_in + slot * C::PIXB + ((C::SWZ ? ((idx & 3) ^ ((slot >> 2) & 3)) : (idx & 3)) * 16)) =
+            F16 ? (lo_half ? bf16x8_to_f16x8_scaled(rin[j]) : bf16x8_to_f16x8(rin[j])) : rin[j];
       }
     }
 #pragma unroll
@@ -606,9 +646,17 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
   prefetch(0);
   for (int c = 0; c < nchunks; ++c) {
     __syncthreads();  // everyone is done reading the previous slice
-    commit();
+    commit(c);
     __syncthreads();
     if (c + 1 < nchunks) prefetch(c + 1);
+    if (F16 && c == (p.Cin >> 5)) {      // the scaled lo chunks are in: back to the scale of the hi products
+#pragma unroll
+      for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NHALF; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][n][r] *= (1.0f / PT_F16_LO_SCALE);
+    }
 #pragma unroll
     for (int r = 0; r < KS; ++r) {
 #pragma unroll
@@ -630,11 +678,11 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
             const int a_off = C::SWZ ? (((q + 2 * kk) ^ (((a_slot[m] + r * C::TWIN + soff) >> 2) & 3)) * 16) : kk * 32;
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base[m] + (r * C::TWIN + soff) * C::PIXB + a_off);
             if (DIRECT) {
-              acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a, acc[m][0], 0, 0, 0);      // D = [channel][pixel]
-              if (NHALF == 2) acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a, acc[m][1], 0, 0, 0);
+              acc[m][0] = mma16<F16>(b0, a, acc[m][0]);      // D = [channel][pixel]
+              if (NHALF == 2) acc[m][1] = mma16<F16>(b1, a, acc[m][1]);
             } else {
-              acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
-              if (NHALF == 2) acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
+              acc[m][0] = mma16<F16>(a, b0, acc[m][0]);
+              if (NHALF == 2) acc[m][1] = mma16<F16>(a, b1, acc[m][1]);
             }
           }
 #ifdef PT_SETPRIO
@@ -1229,6 +1277,8 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   if (!attr_done) {
     PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<KS, STRIDE, GEOM>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<KS, STRIDE, GEOM, 2, false, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
     attr_done = true;
   }
   k.tiles_x = (k.Wo + C::TW - 1) / C::TW;
@@ -1243,7 +1293,7 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
     nblk = (nblk + 15) / 16;
   }
   char label[48];
-  snprintf(label, sizeof(label), "conv%dx%d s%d %d->%d @%dx%d%s", KS, KS, STRIDE, k.Cin, k.N, k.Ho, k.Wo, k.head_w ? " +head" : (k.split ? " x3" : ""));
+  snprintf(label, sizeof(label), "conv%dx%d s%d %d->%d @%dx%d%s", KS, KS, STRIDE, k.Cin, k.N, k.Ho, k.Wo, k.head_w ? " +head" : (k.split == 2 ? " h2" : (k.split ? " x3" : "")));
   int lim_slot = -1;
   {
     PtProfScope prof(e, s, KS == 3 ? PT_PROF_CONV3X3 : PT_PROF_CONV1X1, flop, label);
@@ -1262,6 +1312,8 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
       launch_direct<3, 2, 2>(k, (unsigned)nblk, s);
     else if (plain && KS == 3 && STRIDE == 1)
       launch_direct<3, 1, 2>(k, (unsigned)nblk, s);
+    else if (k.split == 2)
+      hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, GEOM, 2, false, true>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
     else
       hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, GEOM>), dim3((unsigned)nblk), dim3(256), C::SMEM, s, k);
     if ((k.ylimit || k.xcols) && prof.idx >= 0 && e->prof.h_lims && e->prof.n_lims < PtProfile::MAX_LIMS) {
@@ -1378,7 +1430,7 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   // the device limit let through (launch_cfg)
   const int n_alg = d.alg_n ? d.alg_n : (d.n_valid ? d.n_valid : d.N);
   const double flop = 2.0 * k.B * k.Ho * k.Wo * (double)n_alg * d.Cin * d.ks * d.ks * d.alg_scale;
-  if (d.ks == 3 && d.stride == 1 && !d.head_w && !d.argmax_part && !d.n_valid && !d.out_f32 && !d.res_f32 && d.relu < 2 && !d.ylimit && !d.xlimit && !d.pool && use_dma_kernel()) {
+  if (d.ks == 3 && d.stride == 1 && !d.head_w && !d.argmax_part && !d.n_valid && !d.out_f32 && !d.res_f32 && d.relu < 2 && !d.ylimit && !d.xlimit && !d.pool && d.split != 2 && use_dma_kernel()) {
     // steady-state A/B on MI355X (tools/ab3.sh, round 1): the 16-channel-slice DMA kernel (v3) wins on >= 120-row maps
     // with K >= 128 channels, the 32-channel-slice DMA kernel (v2) on 60..119-row maps, the register-staged kernel
     // (v1) on short-K layers and on small maps, where the big DMA tiles leave CUs idle
@@ -1410,7 +1462,7 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
     // column tiles per group: ~2 MB of weights (half of an XCD's L2); PT_N_GROUP overrides (0 = off)
     static int ng_env = -2;
     if (ng_env == -2) { const char* s_ = getenv("PT_N_GROUP"); ng_env = s_ ? atoi(s_) : -1; }
-    const long long tile_bytes = 64ll * d.Cin * 2 * (d.split ? 3 : 1);
+    const long long tile_bytes = 64ll * d.Cin * 2 * (d.split == 2 ? 2 : (d.split ? 3 : 1));
     int g = ng_env >= 0 ? ng_env : (int)((2ll << 20) / tile_bytes);
     if (g < 1) g = ng_env == 0 ? 0 : 1;
     k.n_group = g;

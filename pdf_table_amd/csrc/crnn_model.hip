@@ -58,7 +58,7 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
     return PT_ERR_STATE;
   }
   const PtModel& M = it->second;
-  const int x3 = e->precision == PT_PRECISION_BF16X3 ? 1 : 0;
+  const int x3 = pt_split(e) ? 1 : 0;
   const int m = x3 ? 2 : 1;
   int rc;
   ConvW c1, c2a, c2b, c3a, c3b, c4, xp1, em1, xp2, em2, cls;

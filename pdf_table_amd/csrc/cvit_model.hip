@@ -673,7 +673,7 @@ int forward_batch(pt_engine* e, const PtModel& M, const float* gray, int pitch, 
                   float* maxlogit, hipStream_t s, const int* h_tw) {
   Net p;
   p.e = e; p.m = &M; p.s = s; p.rc = PT_OK;
-  p.x3 = e->precision == PT_PRECISION_BF16X3 ? 1 : 0;
+  p.x3 = pt_split(e) ? 1 : 0;
   p.mul = p.x3 ? 2 : 1;
   const int x3 = p.x3, mul = p.mul, NT = 7680 / 64;
   // h_tw != null: the lines' text widths after the keep-ratio resize are known.  Chunk j of a line is columns [252 j, 252 j +

@@ -38,11 +38,12 @@ int get(const PtModel& m, const std::string& name, const PtTensor** out, bool op
   return PT_OK;
 }
 
-int bind(const PtModel& m, DbWeights& w, bool x3) {
+int bind(const PtModel& m, DbWeights& w, bool x3, bool f16) {
   int rc;
-  const std::string ws = x3 ? ".w3" : ".w";  // split-precision weight tiles carry the suffix .w3
+  const std::string ws3 = x3 ? ".w3" : ".w";  // split-precision weight tiles carry the suffix .w3
+  const std::string ws = f16 ? ".wh" : ws3;   // ... the fp16 tiles of PT_PRECISION_F16X2 .wh (implicit-GEMM layers only)
 #define G(name, field) if ((rc = get(m, name, &w.field)) != PT_OK) return rc
-  G("stem" + ws, stem_w); G("stem.b", stem_b);
+  G("stem" + ws3, stem_w); G("stem.b", stem_b);
   for (int l = 0; l < 4; ++l)
     for (int b = 0; b < 2; ++b) {
       const std::string p = "layer" + std::to_string(l + 1) + "." + std::to_string(b);
@@ -78,10 +79,11 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
     pt_set_error("DB-ResNet18 weights not loaded (pt_weights_load(PT_MODEL_DB_RESNET18))");
     return PT_ERR_STATE;
   }
-  const int x3 = e->precision == PT_PRECISION_BF16X3 ? 1 : 0;
+  const int x3 = pt_split(e) ? 1 : 0;
   const int m = x3 ? 2 : 1;  // channel-group multiplier of every activation buffer
   DbWeights w;
-  int rc = bind(it->second, w, x3 != 0);
+  const int f16 = pt_f16x2(e) && it->second.find("bin0.wh") ? 1 : 0;      // blobs packed without the fp16 tiles run as BF16X3
+  int rc = bind(it->second, w, x3 != 0, f16 != 0);
   if (rc != PT_OK) return rc;
 
   const int ch[4] = {64, 128, 256, 512};
@@ -126,7 +128,7 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
                   int stride, bf16_t* out, int out_c, int relu) {
     ConvDesc c;
     c.in = in; c.B = n; c.H = hh; c.W = ww; c.Cin = cin; c.w = W(wt); c.bias = Bv(bs); c.N = N; c.ks = ks;
-    c.stride = stride; c.out = out; c.out_cstride = out_c * m; c.relu = relu; c.split = x3; c.out_lo_off = out_c;
+    c.stride = stride; c.out = out; c.out_cstride = out_c * m; c.relu = relu; c.split = f16 ? 2 : x3; c.out_lo_off = out_c;
     return c;
   };
   // bf16 mode: stem + max-pool in one kernel (the 64-channel half-resolution map stays in LDS; bit-identical);

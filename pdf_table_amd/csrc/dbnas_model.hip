@@ -110,7 +110,7 @@ int pt_dbnas_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, flo
   }
   Ctx c;
   c.e = e; c.m = &it->second; c.s = s; c.n = n;
-  c.x3 = e->precision == PT_PRECISION_BF16X3 ? 1 : 0;
+  c.x3 = pt_split(e) ? 1 : 0;
   c.mul = c.x3 ? 2 : 1;
   c.rc = PT_OK;
   for (int pass = 0; pass < 2; ++pass) {

@@ -177,7 +177,7 @@ int pt_picodet_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, f
   }
   Ctx c;
   c.e = e; c.m = &it->second; c.s = s; c.n = n;
-  c.x3 = e->precision == PT_PRECISION_BF16X3 ? 1 : 0;
+  c.x3 = pt_split(e) ? 1 : 0;
   c.mul = c.x3 ? 2 : 1;
   c.rc = PT_OK;
   float* heads[4] = {h0, h1, h2, h3};
@@ -259,7 +259,7 @@ int pt_pplcnet_forward_net(pt_engine* e, int slot, const bf16_t* x, int n, int H
   }
   Ctx c;
   c.e = e; c.m = &it->second; c.s = s; c.n = n;
-  c.x3 = e->precision == PT_PRECISION_BF16X3 ? 1 : 0;
+  c.x3 = pt_split(e) ? 1 : 0;
   c.mul = c.x3 ? 2 : 1;
   c.rc = PT_OK;
   c.what = "PP-LCNet";

@@ -207,7 +207,7 @@ static int lore_dla_run(pt_engine* e, const bf16_t* x, int n, int H, int W, floa
   }
   Ctx c;
   c.e = e; c.m = &it->second; c.s = s; c.n = n;
-  c.x3 = e->precision == PT_PRECISION_BF16X3 ? 1 : 0;
+  c.x3 = pt_split(e) ? 1 : 0;
   c.mul = c.x3 ? 2 : 1;
   c.rc = PT_OK;
   const int ch[6] = {16, 32, 64, 128, 256, 512};
@@ -431,7 +431,7 @@ int pt_lore_wireless_forward_net(pt_engine* e, const bf16_t* x, int n, int H, in
   }
   WCtx c;
   c.e = e; c.m = &it->second; c.s = s; c.n = n;
-  c.x3 = e->precision == PT_PRECISION_BF16X3 ? 1 : 0;
+  c.x3 = pt_split(e) ? 1 : 0;
   c.mul = c.x3 ? 2 : 1;
   c.rc = PT_OK;
   float* heads[6] = {hm, st, wh, ax, cr, reg};

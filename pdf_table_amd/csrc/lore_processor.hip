@@ -259,7 +259,7 @@ int pt_lore_process(pt_engine* e, const float* d_logi, const float* d_dets, cons
   if (N == 0) return PT_OK;
   P p;
   p.e = e; p.m = &it->second; p.s = s; p.rc = PT_OK;
-  p.x3 = e->precision == PT_PRECISION_BF16X3 ? 1 : 0;
+  p.x3 = pt_split(e) ? 1 : 0;
   p.mul = p.x3 ? 2 : 1;
   p.Npad = (N + 127) / 128 * 128;
   const int Npad = p.Npad, x3 = p.x3;

@@ -727,7 +727,7 @@ void pt_tsr_mtl_resized_size(int crop_w, int crop_h, int size, int32_t* out_w, i
 }
 
 int pt_mtl_preprocess(pt_engine* e, const uint8_t* pages, int ph, int pw, const pt_tsr_table* tabs, int n, int size, bf16_t* out, hipStream_t s) {
-  const int x3 = e->precision == PT_PRECISION_BF16X3 ? 1 : 0;
+  const int x3 = pt_split(e) ? 1 : 0;
   PtProfScope ps(e, s, PT_PROF_OTHER, 0, "mtl preprocess");
   hipLaunchKernelGGL(mtl_preprocess_kernel, dim3((size * size + 255) / 256, n), dim3(256), 0, s, pages, ph, pw, tabs, size, out, x3);
   PT_HIP_CHECK(hipGetLastError());
@@ -769,7 +769,7 @@ int pt_mtl_structure(pt_engine* e, const float* f3, int n, int hw, float* d_tag_
     pt_set_error("MtlTabNet decoder weights not loaded (pt_weights_load(PT_MODEL_MTL_DECODER))");
     return PT_ERR_STATE;
   }
-  Ctx c{e, &it->second, s, e->precision == PT_PRECISION_BF16X3 ? 1 : 0, e->precision == PT_PRECISION_BF16X3 ? 2 : 1, PT_OK};
+  Ctx c{e, &it->second, s, pt_split(e) ? 1 : 0, pt_split(e) ? 2 : 1, PT_OK};
   Meta mt;
   int rc = read_meta(c, &mt);
   if (rc != PT_OK) return rc;
@@ -983,7 +983,7 @@ int pt_mtl_cells(pt_engine* e, int total, int32_t* d_cell_ids, float* d_cell_pro
     return PT_ERR_STATE;
   }
   Ctx c{e, &it->second, s, st->x3, st->x3 ? 2 : 1, PT_OK};
-  PT_REQUIRE((e->precision == PT_PRECISION_BF16X3 ? 1 : 0) == st->x3, "pt_tsr_mtl_cells: the precision changed since pt_tsr_mtl_structure");
+  PT_REQUIRE((pt_split(e) ? 1 : 0) == st->x3, "pt_tsr_mtl_cells: the precision changed since pt_tsr_mtl_structure");
   Meta mt;
   int rc = read_meta(c, &mt);
   if (rc != PT_OK) return rc;

@@ -157,7 +157,7 @@ int pt_mtl_backbone_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int
     return PT_ERR_STATE;
   }
   const PtModel& M = it->second;
-  const int x3 = e->precision == PT_PRECISION_BF16X3 ? 1 : 0, m = x3 ? 2 : 1;
+  const int x3 = pt_split(e) ? 1 : 0, m = x3 ? 2 : 1;
   int rc = PT_OK;
   auto get = [&](const std::string& name) -> const PtTensor* {
     const PtTensor* t = M.find(name);

@@ -51,7 +51,8 @@ class HipEngine:
         self.precision = L.PT_PRECISION_BF16
 
     def set_precision(self, precision: int):
-        """L.PT_PRECISION_BF16 (throughput) or L.PT_PRECISION_BF16X3 (fp32-class parity mode)."""
+        """L.PT_PRECISION_BF16 (throughput), L.PT_PRECISION_BF16X3 (fp32-class parity mode: three bf16 passes) or L.PT_PRECISION_F16X2 (the
+        same activation pairs against single fp16 weights: two fp16 passes, weight rounding ~1.5e-4 of the logit scale)."""
         L.check(self.lib.pt_engine_set_precision(self._h, int(precision)), "pt_engine_set_precision")
         self.precision = int(precision)
 
@@ -121,7 +122,7 @@ class HipEngine:
         self._chk(pages, torch.uint8, "pages")
         n, h, w, _ = pages.shape
         nh, nw = self.det_plan(h, w, flavour)
-        out = torch.empty((n, nh, nw, 8 if self.precision == L.PT_PRECISION_BF16X3 else 4), dtype=torch.bfloat16,
+        out = torch.empty((n, nh, nw, 8 if self.precision != L.PT_PRECISION_BF16 else 4), dtype=torch.bfloat16,
                           device=self._tdev)
         L.check(self.lib.pt_det_preprocess(self._h, _ptr(pages), n, h, w, flavour, _ptr(out), self._stream()),
                 "pt_det_preprocess")
@@ -131,7 +132,7 @@ class HipEngine:
         """x bf16 NHWC4 [n,H,W,4] (BF16X3 mode: [n,H,W,8] = hi rgb0 | lo rgb0) -> prob f32 [n,H,W] (and logits)."""
         self._chk(x, torch.bfloat16, "x")
         n, H, W, c = x.shape
-        assert c == (8 if self.precision == L.PT_PRECISION_BF16X3 else 4)
+        assert c == (8 if self.precision != L.PT_PRECISION_BF16 else 4)
         prob = torch.empty((n, H, W), dtype=torch.float32, device=self._tdev)
         logits = torch.empty((n, H, W), dtype=torch.float32, device=self._tdev) if want_logits else None
         L.check(self.lib.pt_det_forward_net(self._h, _ptr(x), n, H, W, _ptr(prob), _ptr(logits), self._stream()),
@@ -147,7 +148,7 @@ class HipEngine:
     def layout_preprocess(self, pages: torch.Tensor, inp_h: int = 800, inp_w: int = 608) -> torch.Tensor:
         self._chk(pages, torch.uint8, "pages")
         n, h, w, _ = pages.shape
-        out = torch.empty((n, inp_h, inp_w, 8 if self.precision == L.PT_PRECISION_BF16X3 else 4), dtype=torch.bfloat16,
+        out = torch.empty((n, inp_h, inp_w, 8 if self.precision != L.PT_PRECISION_BF16 else 4), dtype=torch.bfloat16,
                           device=self._tdev)
         L.check(self.lib.pt_layout_preprocess(self._h, _ptr(pages), n, h, w, inp_h, inp_w, _ptr(out), self._stream()),
                 "pt_layout_preprocess")
@@ -180,7 +181,7 @@ class HipEngine:
         npg, ph, pw, _ = pages.shape
         n = len(tables)
         tb = _upload(tables.view(np.uint8).reshape(n, -1), self._tdev)
-        out = torch.empty((n, inp_h, inp_w, 8 if self.precision == L.PT_PRECISION_BF16X3 else 4), dtype=torch.bfloat16,
+        out = torch.empty((n, inp_h, inp_w, 8 if self.precision != L.PT_PRECISION_BF16 else 4), dtype=torch.bfloat16,
                           device=self._tdev)
         L.check(self.lib.pt_tsr_preprocess(self._h, _ptr(pages), npg, ph, pw, _ptr(tb), n, inp_h, inp_w, int(bgr), _ptr(out),
                                            self._stream()), "pt_tsr_preprocess")
@@ -192,7 +193,7 @@ class HipEngine:
         'cr': [.,256], 'reg': [.,2]})."""
         self._chk(x, torch.bfloat16, "x")
         n, H, W, c = x.shape
-        assert c == (8 if self.precision == L.PT_PRECISION_BF16X3 else 4)
+        assert c == (8 if self.precision != L.PT_PRECISION_BF16 else 4)
         h, w = H // 4, W // 4
         bufs = {k: torch.empty((n, h, w, 256 if k in ("ax", "cr") else 8), dtype=torch.float32, device=self._tdev)
                 for k in ("hm", "st", "wh", "ax", "cr", "reg")}
@@ -294,7 +295,7 @@ class HipEngine:
         """-> bf16 NHWC4 [n, out_h, out_w, 4] (8 channels in BF16X3 mode)"""
         n = len(images)
         base, desc, mh, mw = self._cls_batch(images)
-        ch = 8 if self.precision == L.PT_PRECISION_BF16X3 else 4
+        ch = 8 if self.precision != L.PT_PRECISION_BF16 else 4
         out = torch.empty((n, out_hw[0], out_hw[1], ch), dtype=torch.bfloat16, device=self._tdev)
         L.check(self.lib.pt_cls_preprocess(self._h, _ptr(base), _ptr(desc), n, mh, mw, out_hw[0], out_hw[1], _ptr(out),
                                            self._stream()), "pt_cls_preprocess")
@@ -415,7 +416,7 @@ class HipEngine:
         self._chk(pages, torch.uint8, "pages")
         n, h, w, _ = pages.shape
         nl = len(lines)
-        shape = (nl, L.PT_REC_H, L.PT_REC_W, 2) if self.precision == L.PT_PRECISION_BF16X3 else (nl, L.PT_REC_H, L.PT_REC_W)
+        shape = (nl, L.PT_REC_H, L.PT_REC_W, 2) if self.precision != L.PT_PRECISION_BF16 else (nl, L.PT_REC_H, L.PT_REC_W)
         gray = torch.empty(shape, dtype=torch.bfloat16, device=self._tdev)
         d, px = self._lines_to_device(lines)
         L.check(self.lib.pt_rec_preprocess(self._h, _ptr(pages), n, h, w, _ptr(d), px.ctypes.data_as(C.c_void_p), nl,
@@ -508,7 +509,7 @@ class HipEngine:
         xp = torch.zeros((n, h, w, 32), dtype=torch.float32, device=self._tdev)
         xp[..., :3] = x.permute(0, 2, 3, 1)
         hi = xp.to(torch.bfloat16)
-        if self.precision == L.PT_PRECISION_BF16X3:
+        if self.precision != L.PT_PRECISION_BF16:
             hi = torch.cat([hi, (xp - hi.float()).to(torch.bfloat16)], -1)
         hi = hi.contiguous()
         f3 = torch.empty((n, h // 8, w // 8, 512), dtype=torch.float32, device=self._tdev)
@@ -531,7 +532,7 @@ class HipEngine:
         assert tables.dtype == TSR_TABLE_DTYPE
         n = len(tables)
         d_tab = _upload(tables.view(np.uint8).reshape(-1), self._tdev)
-        m = 2 if self.precision == L.PT_PRECISION_BF16X3 else 1
+        m = 2 if self.precision != L.PT_PRECISION_BF16 else 1
         out = torch.empty((n, size, size, 32 * m), dtype=torch.bfloat16, device=self._tdev)
         L.check(self.lib.pt_tsr_mtl_preprocess(self._h, _ptr(pages), pages.shape[0], pages.shape[1], pages.shape[2], _ptr(d_tab), n, size,
                                                _ptr(out), self._stream()), "pt_tsr_mtl_preprocess")
@@ -577,8 +578,9 @@ class HipEngine:
     def op_conv2d(self, x: torch.Tensor, w_tiled: torch.Tensor, bias: torch.Tensor, ks: int, stride: int = 1,
                   relu: bool = False, res: Optional[torch.Tensor] = None, res_mode: int = 0, rep: int = 1,
                   shuffle_cout: int = 0, out: Optional[torch.Tensor] = None, out_coff: int = 0,
-                  split: bool = False) -> torch.Tensor:
-        """Single conv on the MFMA kernel.  x bf16 [B,H,W,Cin]; w_tiled int16/bf16 bits; bias f32 [N]."""
+                  split: int = 0) -> torch.Tensor:
+        """Single conv on the MFMA kernel.  x bf16 [B,H,W,Cin]; w_tiled int16/bf16 bits; bias f32 [N].  split: 0 plain bf16, 1 (hi | lo)
+        tensors with the three-pass tiles, 2 the same tensors with the two-pass fp16 tiles (weights.tile_conv_weight_f16x2)."""
         self._chk(x, torch.bfloat16, "x")
         self._chk(bias, torch.float32, "bias")
         B, H, W, Cin = x.shape

@@ -32,6 +32,7 @@ PT_DET_PRE_DB_TORCH = 1
 PT_DET_PRE_NONE = 2
 PT_PRECISION_BF16 = 0
 PT_PRECISION_BF16X3 = 1
+PT_PRECISION_F16X2 = 2
 PT_DET_POST_DB_PP = 0
 PT_DET_POST_DB_TORCH = 1
 PT_TSR_MAX_CELLS = 3000

@@ -475,7 +475,7 @@ class HipOnnxSession:
         dev = self.engine._tdev
         t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev).permute(0, 2, 3, 1)
         n, h, w, _ = t.shape
-        if self.engine.precision == self._L.PT_PRECISION_BF16X3:
+        if self.engine.precision != self._L.PT_PRECISION_BF16:
             hi = t.to(torch.bfloat16)
             lo = (t - hi.float()).to(torch.bfloat16)
             x8 = torch.zeros((n, h, w, 8), dtype=torch.bfloat16, device=dev)

@@ -73,6 +73,16 @@ def tile_conv_weight_x3(w: torch.Tensor) -> np.ndarray:
     return np.concatenate([th, th, tl], axis=1)
 
 
+def tile_conv_weight_f16x2(w: torch.Tensor) -> np.ndarray:
+    """F16X2 tiles: ONE fp16 rounding of the weights (RNE), the same tile for the x_hi and the x_lo K chunks ->
+    fp16 bits [N/64][2*Cin/32][taps][64][32] (stored under the 16-bit tag of the container)."""
+    n, cin, kh, kw = w.shape
+    assert n % 64 == 0 and cin % 32 == 0, (n, cin)
+    t = w.reshape(n // 64, 64, cin // 32, 32, kh, kw).permute(0, 2, 4, 5, 1, 3).contiguous()
+    t = t.to(torch.float16).view(torch.int16).numpy().view(np.uint16).reshape(n // 64, cin // 32, kh * kw, 64, 32)
+    return np.concatenate([t, t], axis=1)
+
+
 class _Blob:
     def __init__(self, x3: bool = True):
         self.items: "OrderedDict[str, Tuple[int, np.ndarray]]" = OrderedDict()
@@ -86,6 +96,7 @@ class _Blob:
         self.add(name + ".w", tile_conv_weight(w), "bf16")
         if self.x3:
             self.add(name + ".w3", tile_conv_weight_x3(w), "bf16")
+            self.add(name + ".wh", tile_conv_weight_f16x2(w), "bf16")      # PT_PRECISION_F16X2 (fp16 bits)
         self.add(name + ".b", b.numpy().astype(np.float32), "f32")
 
     def tobytes(self) -> bytes:

@@ -229,10 +229,10 @@ def eng_par():
 
 
 def _mode(eng, mode):
-    eng.set_precision(L.PT_PRECISION_BF16X3 if mode == "bf16x3" else L.PT_PRECISION_BF16)
+    eng.set_precision({"bf16x3": L.PT_PRECISION_BF16X3, "f16x2": L.PT_PRECISION_F16X2}.get(mode, L.PT_PRECISION_BF16))
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2", "bf16"])
 def test_fullsize_det_oracle_parity(eng_par, pages, mode):
     """1024x1024 page -> db_pp pre-process (bit-exact with the oracle's) -> DB-ResNet18 at 960x960 vs the fp32 oracle"""
     from oracle import db_net, db_pre
@@ -255,7 +255,13 @@ def test_fullsize_det_oracle_parity(eng_par, pages, mode):
     flips = int(((prob[0].cpu() > 0.3) != (torch.sigmoid(ref) > 0.3)).sum())
     print(f"FULLSIZE det 960x960 {mode}: max|dlogit|={dl:.3e} = {dl / scale:.3e} of scale {scale:.1f}; max|dprob|={dp:.3e}; "
           f"{flips} of 921600 bitmap pixels differ")
-    if mode == "bf16x3":
+    if mode == "f16x2":
+        # the two-pass experiment: (hi, lo) activation pairs x SINGLE fp16 weights.  Every layer is exact against its
+        # fp16-rounded weights (5e-6 per layer), but rounding 21 layers' weights to 11 bits moves THIS random-init net's logits by 1.2e-3 of
+        # their scale (the CPU emulation tools/x2_emulation.py reads 1.4e-3 on the same page; 1.5e-4 on the text-signal checkpoint): outside
+        # the 1e-3 contract, so BF16X3 stays the tolerance mode and this bound only records the drift
+        assert dl <= 2e-3 * scale and dp <= 6e-3
+    elif mode == "bf16x3":
         assert dl <= X3_TOL * scale and dp <= X3_TOL
         near = (torch.sigmoid(ref) - 0.3).abs() <= X3_TOL          # a bitmap pixel may differ only on the threshold itself
         assert bool((((prob[0].cpu() > 0.3) != (torch.sigmoid(ref) > 0.3)) & ~near).sum() == 0)
