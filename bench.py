@@ -62,6 +62,9 @@ def parse_args(argv=None):
     ap.add_argument("--det-backbone", default="resnet18", choices=["resnet18", "proxylessnas"],
                     help="DB detector network: DBModel (BASELINE.json's configuration) or DBNasModel (diagnostic variant)")
     ap.add_argument("--no-post", action="store_true", help="device half only (diagnostic; not a valid headline)")
+    ap.add_argument("--host-share", type=int, default=0,
+                    help="(leg of the default run) re-run the timed region in a child process pinned with sched_setaffinity to 1/N of "
+                         "the host's cores: what every rank of an N-GPU node gets")
     ap.add_argument("--private-loop", action="store_true",
                     help="time bench.py's own software-pipelined loop (HipRunner.run_private) instead of OcrTablePipeline.predict_stream() "
                          "(diagnostic A/B: the product API is what `value` is measured on)")
@@ -289,6 +292,26 @@ def cpu_baseline(sd, pages_np, cfg, csd=None, tsr=None, layout=None, gpu=None):
     return out
 
 
+def one_eighth_host_leg(args, value):
+    """Multi-GPU readiness that one GPU can measure: eight ranks share the host, so the same timed region runs once
+    more in a child process pinned to 1/8 of the cores this process may use, its post-process pool sized for that share."""
+    import subprocess
+    cpus = sorted(os.sched_getaffinity(0))
+    share = cpus[:max(1, len(cpus) // 8)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline",
+           "--no-extra-legs", "--stages", args.stages, "--precision", args.precision]
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, preexec_fn=lambda: os.sched_setaffinity(0, share),
+                           env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+        d = json.loads(line)
+        return {"pages_per_s_at_one_eighth_host": d["value"], "ratio_to_value": d["value"] / value, "cores": len(share), "of_cores": len(cpus),
+                "note": "same timed region (OcrTablePipeline.predict_stream, 64-page batches), child process pinned to the first 1/8 of the "
+                        "cores, detection post-process pool capped to that share"}
+    except Exception as e:      # noqa: BLE001 -- a diagnostic leg must not take the bench line down
+        return {"error": repr(e)[:300]}
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # runners
 # ---------------------------------------------------------------------------------------------------------------------
@@ -418,7 +441,10 @@ class HipRunner:
         self.pages = torch.from_numpy(self.pages_np).to(dev)
         self.cfg = DetConfig(flavour="db_pp", thresh=0.3, box_thresh=0.6, unclip_ratio=1.5)
         # N ranks share the host: the contour / Clipper pool of each rank stays inside its share of the cores
-        workers = max(1, min(32, (os.cpu_count() or 8) // max(1, world)))
+        # (--host-share N: this process was pinned to 1/N of the cores -- the host an 8-rank job leaves each rank -- and sizes its pool so)
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+        workers = max(1, min(32, ncpu // max(1, world)))
+        self.host_cores, self.post_workers = ncpu, workers
         self.stage = DetStage(eng, self.cfg, workers=workers)
         # the product API under the clock: the timed loop is OcrTablePipeline.predict_stream() over these stages (weights already
         # loaded / broadcast above); bench.py's own loop stays for the single-stage legs and as the --private-loop A/B
@@ -929,6 +955,8 @@ def main(argv=None):
             leg = runner.mtl_tabnet_leg()
             if rank == 0 and leg is not None:
                 out["mtl_tabnet"] = leg
+        if rank == 0 and len(runner.stages) > 1 and not args.no_post:
+            out["one_eighth_host"] = one_eighth_host_leg(args, out["value"])
     if rank == 0:
         if not stub and world == 1 and not args.no_cpu_baseline and "det" in runner.stages:
             r = runner

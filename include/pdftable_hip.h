@@ -417,9 +417,26 @@ int pt_op_chan_mean_scratch_floats(int B, int C);
 int pt_op_scale_channels(pt_engine* e, const uint16_t* d_in, const uint16_t* d_gate, int B, int HW, int C, uint16_t* d_out,
                          pt_stream stream);
 /* stand-alone activation over n_elems (multiple of 8) values; kind: 1 ReLU, 2 hardswish, 4 sigmoid,
- * 5 hardsigmoid = max(0, min(1, alpha x + beta)), 6 ReLU6 */
+ * 5 hardsigmoid = max(0, min(1, alpha x + beta)), 6 ReLU6, 7 GELU (erf form), 8 swish x * sigmoid(x) */
 int pt_op_act(pt_engine* e, const uint16_t* d_in, long long n_elems, int kind, float alpha, float beta, uint16_t* d_out,
               pt_stream stream);
+/* Data movement of the executor (ONNX Concat / Slice / Split over channels, nearest Resize): dst[pix][dst_coff + c] = src[pix][src_coff + c] for
+ * c < n; nearest-neighbour up-sampling by an integer factor -> [B, H f, W f, C]; element-wise product of two equally shaped tensors */
+int pt_op_copy_channels(pt_engine* e, const uint16_t* d_src, long long npix, int src_cstride, int src_coff, uint16_t* d_dst, int dst_cstride, int dst_coff,
+                        int n, pt_stream stream);
+int pt_op_upsample_nearest(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int C, int factor, uint16_t* d_out, pt_stream stream);
+int pt_op_mul(pt_engine* e, const uint16_t* d_a, const uint16_t* d_b, uint16_t* d_out, long long n_elems, pt_stream stream);
+/* Sequence operators (the attention / LayerNorm / soft-max blocks of SVTR-type recognisers such as PP-OCRv4 rec, the recogniser
+ * fix_model_names() selects: model/ocr_pdf/configuration_ocr_document.py:138-141).  Token rows bf16 [rows, c_pad], the first c channels real.
+ * pt_op_layernorm: LayerNormalization over the channels (biased variance, eps inside the root), padded channels written as zeros.
+ * pt_op_softmax: Softmax over the channels -> fp32 [rows, c] (d_out_f32, network outputs) OR bf16 [rows, c_pad] (d_out_bf16); pass one.
+ * pt_op_attention: multi-head self-attention of rows holding [q | k | v], channel = part * heads * d + head * d + j (the fused-qkv layout of
+ * timm / PaddleOCR SVTR blocks): out[b, t, head * d + j] = softmax_k(scale q.k) v; T <= 1024, d <= 64. */
+int pt_op_layernorm(pt_engine* e, const uint16_t* d_in, long long rows, int c_pad, int c, const float* d_gamma, const float* d_beta, float eps,
+                    uint16_t* d_out, pt_stream stream);
+int pt_op_softmax(pt_engine* e, const uint16_t* d_in, long long rows, int c_pad, int c, float* d_out_f32, uint16_t* d_out_bf16, pt_stream stream);
+int pt_op_attention(pt_engine* e, const uint16_t* d_qkv, int B, int T, int heads, int d, int qkv_cstride, float scale, uint16_t* d_out, int out_cstride,
+                    pt_stream stream);
 
 /* ---- introspection used by bench.py (HIP-event timing of the dominant kernel) ------------------ */
 /* ---- image classification (PP-LCNet) ------------------------------------------------------------

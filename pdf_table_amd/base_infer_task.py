@@ -167,6 +167,19 @@ class BaseInferTask(metaclass=ABCMeta):
             return self.get_model_path_from_other()
         return self._task_path
 
+    def _onnx_file(self):
+        """model.onnx / fp16_model.onnx / inference.onnx under task_path (DeployUtils.prepare_onnx_model's layout, utils/deploy_utils.py:
+        243-280), or task_path itself if it is an .onnx file; None when the task was given seeded weights"""
+        tp = getattr(self, "_task_path", None)
+        if not tp or self.synthetic_seed is not None:
+            return None
+        if os.path.isfile(tp) and str(tp).endswith(".onnx"):
+            return tp
+        for cand in ("model.onnx", "fp16_model.onnx", "inference.onnx"):
+            if os.path.isfile(os.path.join(tp, cand)):
+                return os.path.join(tp, cand)
+        return None
+
     # ---- run -----------------------------------------------------------------------------------------
     def __call__(self, *args, **kwargs):
         inputs = self._preprocess(*args, **kwargs)

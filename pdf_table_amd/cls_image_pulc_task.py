@@ -48,10 +48,32 @@ class ClsImagePulcTask(BaseInferTask):
         if self._engine is None:
             self._engine = HipEngine(int(str(self.device).split(":")[-1]) if ":" in str(self.device) else 0)
         ncls = CLS_TASKS[self.task_type]["class_num"]
-        if self.synthetic_seed is not None:
+        self._exec, self._softmax_in_graph = None, False
+        onnx_path = self._onnx_file()
+        if onnx_path is not None:
+            # the reference's ONNX mode (DeployUtils.prepare_onnx_model, utils/deploy_utils.py:243-280): a PP-LCNet export the importer
+            # recognises runs on the dedicated launch graph, any other classifier layer by layer on the generic executor
+            from .onnx_import import UnsupportedOnnxGraph, load_onnx, recognise
+            graph = load_onnx(onnx_path)
+            sd = None
+            try:
+                arch, sd_ = recognise(graph)
+                if arch == "pplcnet":
+                    sd = sd_
+            except UnsupportedOnnxGraph:
+                pass
+            if sd is None:
+                from .onnx_exec import HipGraphExecutor
+                self._exec = HipGraphExecutor(graph, engine=self._engine)
+                if len(self._exec.outputs) != 1:
+                    raise UnsupportedOnnxGraph(f"{onnx_path}: a classifier returns one [B, classes] tensor, this graph returns {self._exec.outputs}")
+                self._softmax_in_graph = any(l.op == "act" and l.attrs.get("kind") == "softmax" for l in self._exec.layers[-2:])
+                self._model = self._predict_onnx
+                return
+        elif self.synthetic_seed is not None:
             from .synth_weights import pplcnet_state_dict
             sd = pplcnet_state_dict(seed=int(self.synthetic_seed), class_num=ncls)
-        else:
+        if onnx_path is None and self.synthetic_seed is None:
             path = os.path.join(str(self._config.model_path), "pytorch_model.bin")
             if not os.path.exists(path):
                 raise RuntimeError(f"no PP-LCNet checkpoint at {path}: the reference would download "
@@ -70,6 +92,22 @@ class ClsImagePulcTask(BaseInferTask):
     def _predict(self, images: List[np.ndarray]):
         cfg = self._stage.cfg
         return self._engine.cls_forward(images, cfg["size"], self.slot, cfg["textline"])
+
+    def _predict_onnx(self, images: List[np.ndarray]):
+        """generic executor behind the engine's Pillow-exact resize + normalise kernel -> logits (or log-probabilities when the graph ends in
+        its own Softmax, so that the post-processor's soft-max gives the graph's probabilities back)"""
+        cfg = self._stage.cfg
+        x = self._engine.cls_preprocess(images, cfg["size"])
+        ncls = CLS_TASKS[self.task_type]["class_num"]
+        rows = []
+        for i in range(x.shape[0]):              # one image per run: an export with static shapes has its batch size baked in (the reference
+            (a,) = self._exec.run_device(x[i:i + 1], 3)      # runs one image per infer() too, cls_image_pulc_task.py:70-84)
+            if not a.flat or a.c != ncls:
+                from .onnx_import import UnsupportedOnnxGraph
+                raise UnsupportedOnnxGraph(f"classifier output of shape {a.shape()}: [B, {ncls}] is expected for task '{self.task_type}'")
+            rows.append(a.t[:, 0, 0, :a.c].float())
+        y = torch.cat(rows, 0)
+        return torch.log(y.clamp_min(1e-30)) if self._softmax_in_graph and self.task_type != "table_attribute" else y
 
     def _preprocess(self, inputs, **kwargs):
         if not isinstance(inputs, list):

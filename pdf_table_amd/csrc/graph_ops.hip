@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void scale_channels_kernel(const bf16_t* __res
   }
 }
 
-// kind: 1 relu, 2 hardswish, 4 sigmoid, 5 hardsigmoid (max(0, min(1, alpha x + beta))), 6 relu6
+// kind: 1 relu, 2 hardswish, 4 sigmoid, 5 hardsigmoid (max(0, min(1, alpha x + beta))), 6 relu6, 7 GELU (erf), 8 swish
 __global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, long long total8, int kind,
                                                   float alpha, float beta) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (long long)gridDim.x * blockDim.x) {
@@ -57,6 +57,8 @@ __global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ x, 
         else if (kind == 4) t = 1.f / (1.f + expf(-t));
         else if (kind == 5) t = fmaxf(0.f, fminf(1.f, alpha * t + beta));
         else if (kind == 6) t = fminf(fmaxf(t, 0.f), 6.f);
+        else if (kind == 7) t = t * 0.5f * (1.f + erff(t * 0.70710678118654752f));      // GELU (erf form: nn.GELU())
+        else if (kind == 8) t = t / (1.f + expf(-t));                                      // swish / SiLU: x * sigmoid(x)
         v[j] = t;
       }
       o[k] = g_f2bf(v[0]) | (g_f2bf(v[1]) << 16);
@@ -92,6 +94,125 @@ __global__ __launch_bounds__(256) void avgpool_kxk_kernel(const bf16_t* __restri
 #pragma unroll
     for (int q = 0; q < 4; ++q) o[q] = g_f2bf(acc[2 * q] * inv) | (g_f2bf(acc[2 * q + 1] * inv) << 16);
     *reinterpret_cast<uint4*>(out + i * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+
+// ---- sequence operators (SVTR-type recognisers: LayerNorm / attention / soft-max blocks; rows = tokens, channels padded like every tensor here) ----
+// out[pix][dst_off + c] = src[pix][src_off + c], c < n: channel concat / slice without arithmetic
+__global__ __launch_bounds__(256) void copy_channels_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, long long npix, int scs, int soff,
+                                                            int dcs, int doff, int n) {
+  const long long total = npix * n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long pix = i / n;
+    const int c = (int)(i - pix * n);
+    dst[pix * dcs + doff + c] = src[pix * scs + soff + c];
+  }
+}
+
+// nearest-neighbour up-sampling by an integer factor: out [B, H f, W f, C]
+__global__ __launch_bounds__(256) void upsample_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B, int H, int W, int C, int f) {
+  const int cg = C >> 3, Wo = W * f, Ho = H * f;
+  const long long total = (long long)B * Ho * Wo * cg;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % cg);
+    long long t = i / cg;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho), b = (int)(t / Ho);
+    *reinterpret_cast<uint4*>(out + i * 8) = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + oy / f) * W + ox / f) * C + c8 * 8);
+  }
+}
+
+__global__ __launch_bounds__(256) void mul_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ out, long long total8) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (long long)gridDim.x * blockDim.x) {
+    const uint4 av = *reinterpret_cast<const uint4*>(a + i * 8), bv = *reinterpret_cast<const uint4*>(b + i * 8);
+    const uint32_t as[4] = {av.x, av.y, av.z, av.w}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      o[k] = g_f2bf(g_bf(as[k] & 0xFFFFu) * g_bf(bs[k] & 0xFFFFu)) | (g_f2bf(g_bf(as[k] >> 16) * g_bf(bs[k] >> 16)) << 16);
+    *reinterpret_cast<uint4*>(out + i * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// LayerNorm over the first C of Cp channels of every row (biased variance, eps inside the root: nn.LayerNorm); one wave per row, padded
+// channels are written as zeros
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, long long rows, int Cp, int C,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const bf16_t* xr = x + row * Cp;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += g_bf(xr[c]);
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+  for (int c = lane; c < C; c += 64) { const float d = g_bf(xr[c]) - mean; q += d * d; }
+  const float rstd = 1.f / sqrtf(wave_sum(q) / (float)C + eps);
+  bf16_t* orow = out + row * Cp;
+  for (int c = lane; c < Cp; c += 64) orow[c] = c < C ? (bf16_t)g_f2bf((g_bf(xr[c]) - mean) * rstd * gamma[c] + beta[c]) : (bf16_t)0;
+}
+
+// soft-max over the first C of Cp channels of every row -> fp32 probabilities [rows][C] (network outputs: CTC heads) or bf16 [rows][Cp]
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const bf16_t* __restrict__ x, long long rows, int Cp, int C, float* __restrict__ out_f32,
+                                                           bf16_t* __restrict__ out_bf) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const bf16_t* xr = x + row * Cp;
+  float m = -3.0e38f;
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, g_bf(xr[c]));
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += expf(g_bf(xr[c]) - m);
+  const float inv = 1.f / wave_sum(s);
+  for (int c = lane; c < (out_f32 ? C : Cp); c += 64) {
+    const float p = c < C ? expf(g_bf(xr[c]) - m) * inv : 0.f;
+    if (out_f32) out_f32[row * C + c] = p;
+    else out_bf[row * Cp + c] = (bf16_t)g_f2bf(p);
+  }
+}
+
+// Multi-head self-attention of token rows holding [q | k | v] (each heads * d channels; channel = part * heads * d + head * d + j): one wave per
+// (batch, head, query); scores of all T keys in LDS (T <= 1024), soft-max, weighted sum of the values; out[b, t, head * d + j].  d <= 64.
+__global__ __launch_bounds__(64) void attention_rows_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int T, int heads, int d, int qcs,
+                                                            int ocs, float scale) {
+  __shared__ float p[1024];
+  __shared__ float qs[64];
+  const int t = blockIdx.x, h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+  const int C = heads * d;
+  const bf16_t* base = qkv + (size_t)b * T * qcs;
+  if (lane < d) qs[lane] = g_bf(base[(size_t)t * qcs + h * d + lane]) * scale;
+  __syncthreads();
+  float m = -3.0e38f;
+  for (int k = lane; k < T; k += 64) {
+    const bf16_t* kr = base + (size_t)k * qcs + C + h * d;
+    float acc = 0.f;
+    for (int j = 0; j < d; ++j) acc += qs[j] * g_bf(kr[j]);
+    p[k] = acc;
+    m = fmaxf(m, acc);
+  }
+  m = wave_max(m);
+  float s = 0.f;
+  for (int k = lane; k < T; k += 64) { const float e_ = expf(p[k] - m); p[k] = e_; s += e_; }
+  const float inv = 1.f / wave_sum(s);
+  __syncthreads();
+  if (lane < d) {
+    float acc = 0.f;
+    for (int k = 0; k < T; ++k) acc += p[k] * g_bf(base[(size_t)k * qcs + 2 * C + h * d + lane]);
+    out[((size_t)b * T + t) * ocs + h * d + lane] = (bf16_t)g_f2bf(acc * inv);
   }
 }
 
@@ -156,9 +277,61 @@ int pt_op_scale_channels(pt_engine* e, const uint16_t* d_in, const uint16_t* d_g
 int pt_op_act(pt_engine* e, const uint16_t* d_in, long long n_elems, int kind, float alpha, float beta, uint16_t* d_out,
               pt_stream stream) {
   PT_REQUIRE(e && d_in && d_out && n_elems > 0 && n_elems % 8 == 0, "pt_op_act: bad arguments");
-  PT_REQUIRE(kind == 1 || kind == 2 || kind == 4 || kind == 5 || kind == 6, "pt_op_act: activation kind %d unsupported", kind);
+  PT_REQUIRE(kind == 1 || kind == 2 || (kind >= 4 && kind <= 8), "pt_op_act: activation kind %d unsupported", kind);
   hipLaunchKernelGGL(act_kernel, dim3(grid_for(n_elems / 8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_in, d_out,
                      n_elems / 8, kind, alpha, beta);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_op_copy_channels(pt_engine* e, const uint16_t* d_src, long long npix, int src_cstride, int src_coff, uint16_t* d_dst, int dst_cstride, int dst_coff,
+                        int n, pt_stream stream) {
+  PT_REQUIRE(e && d_src && d_dst && npix > 0 && n > 0 && src_coff >= 0 && dst_coff >= 0 && src_coff + n <= src_cstride && dst_coff + n <= dst_cstride,
+             "pt_op_copy_channels: bad arguments");
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(npix * n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_src, d_dst, npix, src_cstride,
+                     src_coff, dst_cstride, dst_coff, n);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_op_upsample_nearest(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int C, int factor, uint16_t* d_out, pt_stream stream) {
+  PT_REQUIRE(e && d_in && d_out && C % 8 == 0 && factor >= 1 && B > 0 && H > 0 && W > 0, "pt_op_upsample_nearest: bad arguments");
+  hipLaunchKernelGGL(upsample_kernel, dim3(grid_for((long long)B * H * factor * W * factor * (C / 8))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     d_in, d_out, B, H, W, C, factor);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_op_mul(pt_engine* e, const uint16_t* d_a, const uint16_t* d_b, uint16_t* d_out, long long n_elems, pt_stream stream) {
+  PT_REQUIRE(e && d_a && d_b && d_out && n_elems > 0 && n_elems % 8 == 0, "pt_op_mul: bad arguments");
+  hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n_elems / 8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_a, d_b, d_out, n_elems / 8);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_op_layernorm(pt_engine* e, const uint16_t* d_in, long long rows, int c_pad, int c, const float* d_gamma, const float* d_beta, float eps,
+                    uint16_t* d_out, pt_stream stream) {
+  PT_REQUIRE(e && d_in && d_gamma && d_beta && d_out && rows > 0 && c > 0 && c <= c_pad, "pt_op_layernorm: bad arguments");
+  hipLaunchKernelGGL(layernorm_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_in, d_out, rows, c_pad,
+                     c, d_gamma, d_beta, eps);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_op_softmax(pt_engine* e, const uint16_t* d_in, long long rows, int c_pad, int c, float* d_out_f32, uint16_t* d_out_bf16, pt_stream stream) {
+  PT_REQUIRE(e && d_in && rows > 0 && c > 0 && c <= c_pad && ((d_out_f32 != nullptr) != (d_out_bf16 != nullptr)), "pt_op_softmax: bad arguments (one output)");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_in, rows, c_pad, c,
+                     d_out_f32, d_out_bf16);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_op_attention(pt_engine* e, const uint16_t* d_qkv, int B, int T, int heads, int d, int qkv_cstride, float scale, uint16_t* d_out, int out_cstride,
+                    pt_stream stream) {
+  PT_REQUIRE(e && d_qkv && d_out && B > 0 && T > 0 && T <= 1024 && heads > 0 && d > 0 && d <= 64 && 3 * heads * d <= qkv_cstride && heads * d <= out_cstride,
+             "pt_op_attention: bad arguments (T <= 1024, head size <= 64)");
+  hipLaunchKernelGGL(attention_rows_kernel, dim3(T, heads, B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), d_qkv, d_out, T, heads, d, qkv_cstride,
+                     out_cstride, scale);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }

@@ -659,6 +659,60 @@ class HipEngine:
         L.check(self.lib.pt_op_act(self._h, _ptr(x), x.numel(), kind, float(alpha), float(beta), _ptr(out), self._stream()), "pt_op_act")
         return out
 
+    def op_copy_channels(self, src: torch.Tensor, dst: torch.Tensor, n: int, src_coff: int = 0, dst_coff: int = 0):
+        """dst[..., dst_coff : dst_coff + n] = src[..., src_coff : src_coff + n] (same pixel count; Concat / Slice / Split over channels)"""
+        self._chk(src, torch.bfloat16, "src")
+        self._chk(dst, torch.bfloat16, "dst")
+        npix = src.numel() // src.shape[-1]
+        assert npix == dst.numel() // dst.shape[-1]
+        L.check(self.lib.pt_op_copy_channels(self._h, _ptr(src), npix, src.shape[-1], src_coff, _ptr(dst), dst.shape[-1], dst_coff, n, self._stream()),
+                "pt_op_copy_channels")
+
+    def op_upsample(self, x: torch.Tensor, f: int) -> torch.Tensor:
+        self._chk(x, torch.bfloat16, "x")
+        B, H, W, Cc = x.shape
+        out = torch.empty((B, H * f, W * f, Cc), dtype=torch.bfloat16, device=self._tdev)
+        L.check(self.lib.pt_op_upsample_nearest(self._h, _ptr(x), B, H, W, Cc, int(f), _ptr(out), self._stream()), "pt_op_upsample_nearest")
+        return out
+
+    def op_mul(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        self._chk(a, torch.bfloat16, "a")
+        self._chk(b, torch.bfloat16, "b")
+        if a.shape != b.shape:
+            raise ValueError(f"op_mul: shapes differ: {tuple(a.shape)} vs {tuple(b.shape)}")
+        out = torch.empty_like(a)
+        L.check(self.lib.pt_op_mul(self._h, _ptr(a), _ptr(b), _ptr(out), a.numel(), self._stream()), "pt_op_mul")
+        return out
+
+    def op_layernorm(self, x: torch.Tensor, c: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
+        self._chk(x, torch.bfloat16, "x")
+        self._chk(gamma, torch.float32, "gamma")
+        self._chk(beta, torch.float32, "beta")
+        out = torch.empty_like(x)
+        L.check(self.lib.pt_op_layernorm(self._h, _ptr(x), x.numel() // x.shape[-1], x.shape[-1], int(c), _ptr(gamma), _ptr(beta), float(eps), _ptr(out),
+                                         self._stream()), "pt_op_layernorm")
+        return out
+
+    def op_softmax(self, x: torch.Tensor, c: int, f32: bool = False) -> torch.Tensor:
+        self._chk(x, torch.bfloat16, "x")
+        rows = x.numel() // x.shape[-1]
+        if f32:
+            out = torch.empty(x.shape[:-1] + (int(c),), dtype=torch.float32, device=self._tdev)
+            L.check(self.lib.pt_op_softmax(self._h, _ptr(x), rows, x.shape[-1], int(c), _ptr(out), None, self._stream()), "pt_op_softmax")
+        else:
+            out = torch.empty_like(x)
+            L.check(self.lib.pt_op_softmax(self._h, _ptr(x), rows, x.shape[-1], int(c), None, _ptr(out), self._stream()), "pt_op_softmax")
+        return out
+
+    def op_attention(self, qkv: torch.Tensor, heads: int, d: int, scale: float, out_c: int) -> torch.Tensor:
+        """qkv bf16 [B, 1, T, >= 3 heads d] rows of [q | k | v] -> bf16 [B, 1, T, out_c] (channels heads * d .. out_c are zero)"""
+        self._chk(qkv, torch.bfloat16, "qkv")
+        B, T = qkv.shape[0], qkv.shape[-2]
+        out = torch.zeros((B, 1, T, int(out_c)), dtype=torch.bfloat16, device=self._tdev)
+        L.check(self.lib.pt_op_attention(self._h, _ptr(qkv), B, T, int(heads), int(d), qkv.shape[-1], float(scale), _ptr(out), int(out_c), self._stream()),
+                "pt_op_attention")
+        return out
+
     def op_stem7x7(self, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, split: bool = False) -> torch.Tensor:
         self._chk(x, torch.bfloat16, "x")
         B, H, W, _ = x.shape

@@ -123,8 +123,26 @@ class LayoutStage:
         cands.record_stream(self._copy_stream)
         return n, (done, host)
 
-    def decode_page(self, rec: np.ndarray, org_shape) -> List[Dict]:
-        """candidate records [k, 48] of one page -> the `bboxs` list of OCRPicodetPostProcessor.__call__"""
+    def decode_outputs(self, scores: Sequence[np.ndarray], dists: Sequence[np.ndarray], org_shape) -> List[Dict]:
+        """One page's outputs of a PicoDet ONNX export -- per level class PROBABILITIES [A_l, ncls] and box-distribution logits [A_l, 32], the
+        two halves ``OcrLayoutTask.get_onnx_output_dict`` splits (ocr_layout_task.py:159-175) -- -> the same result list: anchors that can pass
+        the score threshold become the candidate records decode_page() reads from the engine's own graph"""
+        cfg = self.config
+        ncls = len(cfg.labels)
+        recs = []
+        for l, (sc, bd) in enumerate(zip(scores, dists)):
+            sc, bd = np.asarray(sc, np.float32).reshape(-1, ncls), np.asarray(bd, np.float32).reshape(-1, 32)
+            keep = np.nonzero(sc.max(1) > cfg.score_threshold - 1e-3)[0]
+            r = np.zeros((len(keep), 2 + ncls + 32), np.float32)
+            r[:, 0] = np.full(len(keep), l, np.int32).view(np.float32)
+            r[:, 1] = keep.astype(np.int32).view(np.float32)
+            r[:, 2:2 + ncls], r[:, 2 + ncls:] = sc[keep], bd[keep]
+            recs.append(r)
+        return self.decode_page(np.concatenate(recs, 0) if recs else np.zeros((0, 2 + ncls + 32), np.float32), org_shape, probs=True)
+
+    def decode_page(self, rec: np.ndarray, org_shape, probs: bool = False) -> List[Dict]:
+        """candidate records [k, 48] of one page -> the `bboxs` list of OCRPicodetPostProcessor.__call__ (probs: the class columns already
+        went through the sigmoid, as in an ONNX export's outputs)"""
         cfg = self.config
         ncls = len(cfg.labels)
         if len(rec) == 0:
@@ -135,7 +153,8 @@ class LayoutStage:
         level = rec[:, 0].view(np.int32)
         anchor = rec[:, 1].view(np.int32)
         logits = rec[:, 2:2 + ncls]
-        scores = torch.sigmoid(torch.from_numpy(np.ascontiguousarray(logits, dtype=np.float32))).numpy()   # F.sigmoid of forward_eval
+        scores = np.ascontiguousarray(logits, dtype=np.float32) if probs else \
+            torch.sigmoid(torch.from_numpy(np.ascontiguousarray(logits, dtype=np.float32))).numpy()   # F.sigmoid of forward_eval
         reg = rec[:, 2 + ncls:2 + ncls + 32].astype(np.float32)
         reg_max = 7
         th, tw = cfg.img_height, cfg.img_width

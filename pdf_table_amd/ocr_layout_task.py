@@ -5,6 +5,11 @@ result: one list per input image of ``{"bbox": ndarray [4] (x1, y1, x2, y2 in so
 "category_id"}`` (:125-141, picodet/processor_picodet.py:286-296).  The reference runs an ONNX export of PaddleDetection's
 picodet_lcnet_x1_0 layout model; here the in-tree LCNet + CSP-PAN + PicoHead graph (assumed hyper-parameters, see
 pdf_table_amd.synth_weights.picodet_state_dict) runs on the engine.  ``DocXLayout`` is not built and fails loudly.
+
+ONNX door (the reference's layout stage is ONNX-only: "pytorch model not support yet!", ocr_layout_task.py:82-123): a ``model.onnx`` /
+``inference.onnx`` under ``task_path`` (or ``task_path`` = the file) is parsed by ``pdf_table_amd.onnx_import`` and run layer by layer by
+``HipGraphExecutor`` behind the engine's own pre-processing kernel; its 2 L outputs are split like ``get_onnx_output_dict`` (:159-175: first
+half per-level scores [B, A_l, classes], second half box distributions [B, A_l, 32]) and decoded by the same host post-processor.
 """
 from __future__ import annotations
 
@@ -46,6 +51,17 @@ class OcrLayoutTask(BaseInferTask):
         if self._engine is None:
             self._engine = HipEngine(int(str(self.device).split(":")[-1]) if ":" in str(self.device) else 0)
         ncls = len(self._config.labels)
+        self._exec = None
+        onnx_path = self._onnx_file()
+        if onnx_path is not None:
+            from .onnx_exec import HipGraphExecutor
+            from .onnx_import import UnsupportedOnnxGraph
+            self._exec = HipGraphExecutor(onnx_path, engine=self._engine)      # raises UnsupportedOnnxGraph naming an operator without a kernel
+            if len(self._exec.outputs) % 2 or not self._exec.outputs:
+                raise UnsupportedOnnxGraph(f"{onnx_path}: a PicoDet export returns 2 L tensors (L score maps, then L box distributions), "
+                                           f"this graph returns {self._exec.outputs}")
+            self._model = self._predict_onnx
+            return
         if self.synthetic_seed is not None:
             from .synth_weights import picodet_state_dict
             sd = picodet_state_dict(seed=int(self.synthetic_seed), num_classes=ncls)
@@ -68,9 +84,41 @@ class OcrLayoutTask(BaseInferTask):
             out.append(self._stage(torch.from_numpy(np.ascontiguousarray(img)[None]).to(self._engine._tdev))[0])
         return out
 
+    def get_onnx_output_dict(self, outputs):
+        """ocr_layout_task.py:159-175: the first half of the graph outputs are the per-level scores, the second half the box distributions
+        (the reference's dict keys are kept: ``boxes`` holds the scores, ``boxes_num`` the distributions)"""
+        if self._exec is None:
+            return None
+        half = len(outputs) // 2
+        return dict(boxes=list(outputs[:half]), boxes_num=list(outputs[half:half * 2]))
+
+    def _predict_onnx(self, images: List[np.ndarray]) -> List[List[Dict]]:
+        out = []
+        for img in images:
+            out.extend(self.detect_pages(torch.from_numpy(np.ascontiguousarray(img)[None]).to(self._engine._tdev)))
+        return out
+
     def detect_pages(self, pages: torch.Tensor) -> List[List[Dict]]:
         """batched door: equally sized pages resident on the device"""
-        return self._stage(pages)
+        if getattr(self, "_exec", None) is None:
+            return self._stage(pages)
+        cfg = self._config
+        ncls = len(cfg.labels)
+        x = self._engine.layout_preprocess(pages, cfg.img_height, cfg.img_width)
+        acts = self._exec.run_device(x, 3)
+        outs = []
+        for a in acts:
+            if not a.seq:
+                from .onnx_import import UnsupportedOnnxGraph
+                raise UnsupportedOnnxGraph(f"layout graph output of shape {a.shape()}: [B, anchors, channels] tensors are expected")
+            outs.append(a.t[:, 0, :, :a.c].float().cpu().numpy())
+        d = self.get_onnx_output_dict(outs)
+        if any(s_.shape[-1] != ncls for s_ in d["boxes"]) or any(b_.shape[-1] != 32 for b_ in d["boxes_num"]):
+            from .onnx_import import UnsupportedOnnxGraph
+            raise UnsupportedOnnxGraph(f"layout graph outputs {[o.shape for o in outs]}: {ncls} class scores and 32 distribution bins per anchor "
+                                       f"are expected for task_type '{cfg.task_type}'")
+        return [self._stage.decode_outputs([s_[i] for s_ in d["boxes"]], [b_[i] for b_ in d["boxes_num"]], tuple(pages.shape[1:3]))
+                for i in range(pages.shape[0])]
 
     def _preprocess(self, inputs, **kwargs):
         if not isinstance(inputs, list):

@@ -15,6 +15,15 @@ convolutional graph layer by layer:
     want; zero weights keep the padding zero); PyTorch only owns the device memory and does the data MOVEMENT between
     layers that has no arithmetic in it (NCHW <-> NHWC, channel concat, nearest-neighbour up-sampling, the final cast).
 
+Sequence models (SVTR-type recognisers such as PP-OCRv4 rec: the recogniser ``fix_model_names()`` selects,
+model/ocr_pdf/configuration_ocr_document.py:138-141): token tensors [B, T, C] live as [B, 1, T, Cpad]; ``MatMul`` + bias with a constant
+weight is the 1x1 GEMM, LayerNormalization (native or decomposed), GELU / swish, Softmax and the fused-qkv multi-head attention run on
+``pt_op_layernorm`` / ``pt_op_act`` / ``pt_op_softmax`` / ``pt_op_attention``.  The shape plumbing between them (Shape / Slice / Concat /
+Reshape / Transpose / Gather / Split / Flatten) does not move data: it is evaluated on the host over INDEX arrays (``_View``: for every
+element of the logical tensor, which element of a materialised tensor it is), and a consumer accepts a view only if its index array is
+exactly one of the layouts its kernel reads -- NCHW map <-> token rows, a channel slice, the (B, heads, T, d) split of fused q / k / v rows.
+Anything else raises.
+
 There is no CPU path: an operator outside this set raises ``UnsupportedOnnxGraph`` naming it (oracle/onnx_ref.py executes
 graphs on the CPU for the tests only).  Supported today: Conv (groups 1: 1x1 / 3x3; depthwise: 3x3 / 5x5; stride 1 / 2,
 "same" padding), ConvTranspose 2x2 / stride 2, BatchNormalization (folded), Relu / HardSwish / Sigmoid / HardSigmoid /
@@ -38,7 +47,7 @@ from .weights import tile_conv_weight
 __all__ = ["HipGraphExecutor"]
 
 _ACT_CODE = {None: 0, "relu": 1, "hardswish": 2}             # fused into the conv / depthwise epilogue
-_ACT_KIND = {"relu": 1, "hardswish": 2, "sigmoid": 4, "hardsigmoid": 5, "relu6": 6}    # pt_op_act
+_ACT_KIND = {"relu": 1, "hardswish": 2, "sigmoid": 4, "hardsigmoid": 5, "relu6": 6, "gelu": 7, "swish": 8}    # pt_op_act
 
 
 def _pad64(c: int) -> int:
@@ -51,6 +60,35 @@ class _Act:
     t: torch.Tensor
     c: int
     flat: bool = False      # the ONNX tensor is [B, C] (after Flatten / Gemm), held here as [B, 1, 1, C]
+    seq: bool = False       # the ONNX tensor is [B, T, C] (token rows), held here as [B, 1, T, Cpad]
+
+    def shape(self):
+        """the ONNX (logical) shape"""
+        B, H, W = self.t.shape[:3]
+        if self.flat:
+            return (B, self.c)
+        if self.seq:
+            return (B, W, self.c)
+        return (B, self.c, H, W)
+
+
+@dataclass
+class _View:
+    """a logical tensor that is a re-indexing of a materialised one: idx has the logical shape and holds, per element, the flat position
+    in ``base.shape()`` (row-major); scale: a scalar the values are multiplied with (q * d ** -0.5 in front of an attention)"""
+    base: _Act
+    idx: np.ndarray
+    scale: float = 1.0
+
+
+@dataclass
+class _Scores:
+    """q k^T of a recognised fused-qkv attention (never materialised): soft-max and the product with v follow"""
+    base: _Act
+    heads: int
+    d: int
+    scale: float
+    soft: bool = False
 
 
 class HipGraphExecutor:
@@ -166,7 +204,7 @@ class HipGraphExecutor:
             return y
         if kind not in _ACT_KIND:
             raise UnsupportedOnnxGraph(f"{lay.name}: activation '{kind}'")
-        return _Act(self.eng.op_act(y.t, _ACT_KIND[kind], lay.attrs.get("act_alpha", 0.2), lay.attrs.get("act_beta", 0.5)), y.c, y.flat)
+        return _Act(self.eng.op_act(y.t, _ACT_KIND[kind], lay.attrs.get("act_alpha", 0.2), lay.attrs.get("act_beta", 0.5)), y.c, y.flat, y.seq)
 
     @staticmethod
     def _repad(t: torch.Tensor, c: int) -> torch.Tensor:
@@ -185,20 +223,211 @@ class HipGraphExecutor:
             raise ValueError(f"expected an NCHW batch, got shape {tuple(xt.shape)}")
         outs = []
         for a in self.run_device(xt.permute(0, 2, 3, 1).to(self.eng._tdev).to(torch.bfloat16), xt.shape[1]):
+            if a.seq:                                    # token rows: [B, T, C]
+                outs.append(a.t[:, 0, :, :a.c].float().contiguous().cpu().numpy())
+                continue
             o = a.t[..., :a.c].float().permute(0, 3, 1, 2).contiguous().cpu().numpy()
             outs.append(o.reshape(o.shape[0], -1) if a.flat else o)
         return outs
+
+    # ---- views: shape plumbing on index arrays ---------------------------------------------------------------------------
+    @staticmethod
+    def _as_view(v) -> _View:
+        if isinstance(v, _View):
+            return v
+        shp = v.shape()
+        return _View(v, np.arange(int(np.prod(shp)), dtype=np.int64).reshape(shp))
+
+    def _realize(self, v, what: str) -> _Act:
+        """a view -> an activation a kernel can read, without arithmetic: the same memory under another logical shape where the index
+        array says so, a channel slice through pt_op_copy_channels otherwise"""
+        if isinstance(v, _Act):
+            return v
+        if not isinstance(v, _View):
+            raise UnsupportedOnnxGraph(f"{what}: operand is a {type(v).__name__}, not a tensor on the device")
+        if v.scale != 1.0:
+            raise UnsupportedOnnxGraph(f"{what}: a scaled view is only consumed by the attention pattern")
+        b, idx = v.base, v.idx
+        bs = b.shape()
+        ident = np.arange(int(np.prod(bs)), dtype=np.int64)
+        if idx.size == ident.size and np.array_equal(idx.reshape(-1), ident):
+            # same element order: a pure reshape.  Token rows / maps share the [.., Cpad] memory only if the channel axis is kept
+            if idx.shape == bs:
+                return b
+            if len(idx.shape) == 3 and idx.shape[0] == bs[0] and idx.shape[2] == b.c and b.seq:
+                return _Act(b.t.reshape(bs[0], 1, idx.shape[1], b.t.shape[-1]), b.c, seq=True)
+            if len(idx.shape) == 2 and (b.flat or (b.seq and bs[1] == 1) or (not b.seq and b.t.shape[1] == 1 and b.t.shape[2] == 1)) and idx.shape[1] == b.c:
+                return _Act(b.t.reshape(bs[0], 1, 1, b.t.shape[-1]), b.c, flat=True)
+        if not b.seq and not b.flat and len(idx.shape) == 3 and len(bs) == 4:
+            # map [B, C, H, W] -> tokens [B, H W, C'] (flatten(2).transpose(1, 2)), optionally of a channel slice
+            B, C, H, W = bs
+            if idx.shape[0] == B and idx.shape[1] == H * W:
+                c0, cn = int(idx[0, 0, 0]) // (H * W), idx.shape[2]
+                want = (np.arange(B)[:, None, None] * C + (c0 + np.arange(cn))[None, None, :]) * (H * W) + np.arange(H * W)[None, :, None]
+                if c0 + cn <= C and np.array_equal(idx, want):
+                    src = b if (c0 == 0 and cn == C) else self._slice_channels(b, c0, cn)
+                    return _Act(src.t.reshape(B, 1, H * W, src.t.shape[-1]), cn, seq=True)
+        if not b.seq and not b.flat and len(idx.shape) == 4 and len(bs) == 4 and idx.shape[0] == bs[0] and idx.shape[2:] == bs[2:]:
+            B, C, H, W = bs                               # channel slice of a map
+            c0, cn = int(idx[0, 0, 0, 0]) // (H * W), idx.shape[1]
+            if c0 + cn <= C and np.array_equal(idx, np.arange(int(np.prod(bs))).reshape(bs)[:, c0:c0 + cn]):
+                return self._slice_channels(b, c0, cn)
+        if b.seq and len(idx.shape) == 4 and len(bs) == 3 and idx.shape[0] == bs[0] and idx.shape[1] == bs[2] and idx.shape[2] * idx.shape[3] == bs[1]:
+            B, T, C = bs                                  # tokens [B, T, C] -> map [B, C, H, W] (transpose(1, 2).reshape)
+            want = (np.arange(B)[:, None, None] * T + np.arange(T)[None, None, :]) * C + np.arange(C)[None, :, None]
+            if np.array_equal(idx.reshape(B, C, T), want):
+                return _Act(b.t.reshape(B, idx.shape[2], idx.shape[3], b.t.shape[-1]), C)
+        if b.seq and len(idx.shape) == 3 and len(bs) == 3 and idx.shape[:2] == bs[:2]:
+            B, T, C = bs                                  # channel slice of token rows
+            c0, cn = int(idx[0, 0, 0]), idx.shape[2]
+            if c0 + cn <= C and np.array_equal(idx, np.arange(int(np.prod(bs))).reshape(bs)[:, :, c0:c0 + cn]):
+                return self._slice_channels(b, c0, cn)
+        raise UnsupportedOnnxGraph(f"{what}: a tensor of logical shape {tuple(idx.shape)} re-indexing a {bs} tensor in a way no kernel reads "
+                                   "(built: map <-> token rows, channel slices, the head split of fused q / k / v rows)")
+
+    def _slice_channels(self, b: _Act, c0: int, cn: int) -> _Act:
+        out = torch.zeros(b.t.shape[:-1] + (_pad64(cn),), dtype=torch.bfloat16, device=self.eng._tdev)
+        self.eng.op_copy_channels(b.t, out, cn, src_coff=c0, dst_coff=0)
+        return _Act(out, cn, flat=b.flat, seq=b.seq)
+
+    def _glue(self, lay: Layer, env) -> list:
+        """Shape / Reshape / Transpose / Flatten / Squeeze / Unsqueeze / Gather / Slice / Split / Concat / Cast / Expand on host constants and
+        on views (index arrays): -> one value per output"""
+        op = lay.attrs.get("onnx_op", "Concat" if lay.op == "concat" else lay.op)
+        at = lay.attrs.get("node_attrs", {})
+        names = lay.attrs.get("all_inputs", lay.inputs)
+
+        def val(i):
+            nm = names[i] if i < len(names) else ""
+            if nm == "":
+                return None
+            return env[nm] if nm in env else self.graph.init.get(nm)
+        x = val(0)
+        is_c = isinstance(x, np.ndarray)
+
+        def ints(v):
+            return [int(q) for q in np.asarray(v).reshape(-1)]
+        if op == "Shape":
+            if is_c:
+                return [np.asarray(x.shape, np.int64)]
+            return [np.asarray(x.idx.shape if isinstance(x, _View) else x.shape(), np.int64)]
+        if op in ("Cast", "Identity"):
+            return [x]
+        if op == "Concat" and all(isinstance(val(i), np.ndarray) for i in range(len(names))):
+            return [np.concatenate([np.atleast_1d(val(i)) for i in range(len(names))], axis=int(at.get("axis", lay.attrs.get("axis", 0))))]
+        if op == "ConstantOfShape":
+            v = at.get("value")
+            return [np.full(ints(x), 0 if v is None else np.asarray(v).reshape(-1)[0])]
+        arr = x if is_c else self._as_view(x).idx
+
+        def wrap(a):
+            return a if is_c else _View(self._as_view(x).base, np.ascontiguousarray(a), self._as_view(x).scale)
+        if op == "Reshape":
+            shp = ints(val(1))
+            shp = [arr.shape[i] if d == 0 and not int(at.get("allowzero", 0)) else d for i, d in enumerate(shp)]
+            return [wrap(arr.reshape(shp))]
+        if op == "Flatten":
+            ax = int(at.get("axis", 1))
+            return [wrap(arr.reshape(int(np.prod(arr.shape[:ax])), -1))]
+        if op == "Transpose":
+            return [wrap(arr.transpose(at.get("perm", list(range(arr.ndim))[::-1])))]
+        if op in ("Squeeze", "Unsqueeze"):
+            axes = ints(at["axes"]) if "axes" in at else (ints(val(1)) if val(1) is not None else None)
+            if op == "Squeeze":
+                return [wrap(np.squeeze(arr, axis=None if axes is None else tuple(axes)))]
+            out = arr
+            for a_ in sorted(a_ if a_ >= 0 else a_ + arr.ndim + len(axes) for a_ in axes):
+                out = np.expand_dims(out, a_)
+            return [wrap(out)]
+        if op == "Gather":
+            ind = val(1)
+            if not isinstance(ind, np.ndarray):
+                raise UnsupportedOnnxGraph(f"{lay.name}: Gather with computed indices")
+            return [wrap(np.take(arr, ind.astype(np.int64), axis=int(at.get("axis", 0))))]
+        if op == "Slice":
+            if "starts" in at:
+                st, en, ax, sp = ints(at["starts"]), ints(at["ends"]), ints(at.get("axes", range(len(at["starts"])))), [1] * len(at["starts"])
+            else:
+                st, en = ints(val(1)), ints(val(2))
+                ax = ints(val(3)) if val(3) is not None else list(range(len(st)))
+                sp = ints(val(4)) if val(4) is not None else [1] * len(st)
+            sl = [slice(None)] * arr.ndim
+            for s_, e_, a_, p_ in zip(st, en, ax, sp):
+                sl[a_] = slice(s_, None if e_ > (1 << 60) else e_, p_)
+            return [wrap(arr[tuple(sl)])]
+        if op == "Split":
+            ax = int(at.get("axis", 0))
+            sizes = ints(at["split"]) if "split" in at else (ints(val(1)) if val(1) is not None else None)
+            parts = np.split(arr, len(lay.outputs), axis=ax) if sizes is None else np.split(arr, np.cumsum(sizes)[:-1], axis=ax)
+            return [wrap(p_) for p_ in parts]
+        if op == "Expand":
+            return [wrap(np.broadcast_to(arr, np.broadcast_shapes(arr.shape, tuple(ints(val(1))))))]
+        raise UnsupportedOnnxGraph(f"{lay.name}: {op} has no executor")
+
+    def _attention(self, lay: Layer, a, b):
+        """MatMul of two views: q k^T of a fused-qkv attention (-> _Scores), or soft-max(scores) v (-> the attention kernel)"""
+        if isinstance(a, _Scores) and a.soft and isinstance(b, _View):
+            base = a.base
+            B, T, C3 = base.shape()
+            C = a.heads * a.d
+            want = ((np.arange(B)[:, None, None, None] * T + np.arange(T)[None, None, :, None]) * C3 + 2 * C
+                    + np.arange(a.heads)[None, :, None, None] * a.d + np.arange(a.d)[None, None, None, :])
+            if b.base is not base or b.idx.shape != want.shape or not np.array_equal(b.idx, want) or b.scale != 1.0:
+                raise UnsupportedOnnxGraph(f"{lay.name}: the value operand is not the v part of the fused q / k / v rows")
+            out = _Act(self.eng.op_attention(base.t, a.heads, a.d, a.scale, _pad64(C)), C, seq=True)
+            idx = ((np.arange(B)[:, None, None, None] * T + np.arange(T)[None, None, :, None]) * C
+                   + np.arange(a.heads)[None, :, None, None] * a.d + np.arange(a.d)[None, None, None, :])
+            return _View(out, idx)
+        if isinstance(a, _View) and isinstance(b, _View) and a.base is b.base and a.base.seq and a.idx.ndim == 4 and b.idx.ndim == 4:
+            base = a.base
+            B, T, C3 = base.shape()
+            _, h, Tq, d = a.idx.shape
+            if Tq == T and C3 == 3 * h * d and b.idx.shape == (B, h, d, T):
+                C = h * d
+                q_want = ((np.arange(B)[:, None, None, None] * T + np.arange(T)[None, None, :, None]) * C3
+                          + np.arange(h)[None, :, None, None] * d + np.arange(d)[None, None, None, :])
+                if np.array_equal(a.idx, q_want) and np.array_equal(b.idx.transpose(0, 1, 3, 2), q_want + C):
+                    return _Scores(base, h, d, a.scale * b.scale)
+        raise UnsupportedOnnxGraph(f"{lay.name}: MatMul of two computed tensors outside the fused-qkv attention pattern "
+                                   "(q, k, v = qkv.reshape(B, T, 3, heads, d).permute(2, 0, 3, 1, 4))")
 
     def run_device(self, nhwc: torch.Tensor, c: int) -> List[_Act]:
         """bf16 NHWC batch on the device whose first ``c`` channels are the image (what pt_det_preprocess / pt_cls_preprocess
         write) -> the graph outputs as device activations (bf16 NHWC, ``.t[..., :.c]`` are the real channels): no host trip"""
         cp = (c + 31) // 32 * 32                         # the image itself: 32 channels are enough for the first GEMM's K
         first = torch.zeros(nhwc.shape[:-1] + (cp,), dtype=torch.bfloat16, device=self.eng._tdev)
-        first[..., :c] = nhwc[..., :c]
-        env: Dict[str, _Act] = {self.inputs[0].name: _Act(first, c)}
+        self.eng.op_copy_channels(nhwc.contiguous(), first, c)
+        env: Dict[str, object] = {self.inputs[0].name: _Act(first, c)}
+        R = self._realize
         for k, lay in enumerate(self.layers):
-            ins = [env[i] for i in lay.inputs if i in env]
             op = lay.op
+            if op == "glue" or (op == "concat" and all((i in self.graph.init or isinstance(env.get(i), np.ndarray)) for i in lay.inputs)):
+                for o, v in zip(lay.outputs, self._glue(lay, env)):
+                    env[o] = v
+                continue
+            raw = [env[i] for i in lay.inputs if i in env]
+            if op in ("add", "mul", "sub", "div") and lay.extra and all(np.asarray(v).size == 1 for v in lay.extra.values()) and len(raw) == 1 \
+                    and isinstance(raw[0], (_View, _Scores, np.ndarray)):
+                cst = float(np.asarray(next(iter(lay.extra.values()))).reshape(-1)[0])
+                v = raw[0]
+                if isinstance(v, np.ndarray):            # integer shape arithmetic
+                    first_is_const = lay.attrs["all_inputs"][0] not in env
+                    a_, b_ = (cst, v) if first_is_const else (v, cst)
+                    env[lay.outputs[0]] = {"add": np.add, "mul": np.multiply, "sub": np.subtract, "div": np.floor_divide if v.dtype.kind in "iu" else np.divide}[op](a_, b_)
+                    continue
+                if op in ("mul", "div"):                 # the 1 / sqrt(d) of an attention, on q or on the scores
+                    f = cst if op == "mul" else 1.0 / cst
+                    env[lay.outputs[0]] = _View(v.base, v.idx, v.scale * f) if isinstance(v, _View) else _Scores(v.base, v.heads, v.d, v.scale * f, v.soft)
+                    continue
+            if op == "matmul":
+                env[lay.outputs[0]] = self._attention(lay, raw[0], raw[1])
+                continue
+            if op == "act" and lay.attrs["kind"] == "softmax" and raw and isinstance(raw[0], _Scores):
+                if lay.attrs.get("axis", -1) not in (-1, 3):
+                    raise UnsupportedOnnxGraph(f"{lay.name}: attention soft-max over axis {lay.attrs.get('axis')}")
+                env[lay.outputs[0]] = _Scores(raw[0].base, raw[0].heads, raw[0].d, raw[0].scale, True)
+                continue
+            ins = [R(v, lay.name) for v in raw]
             if op == "conv":
                 y = self._conv(k, lay, ins[0])
             elif op == "convT":
@@ -231,19 +460,42 @@ class HipGraphExecutor:
                 y = _Act(self.eng.op_dwconv(ins[0].t, d["w"], d["b"], 3, 1, 0), ins[0].c)
             elif op == "gap":
                 y = _Act(self.eng.op_chan_mean(ins[0].t), ins[0].c)
+            elif op == "layernorm":
+                x = ins[0]
+                if not (x.seq or x.flat):
+                    raise UnsupportedOnnxGraph(f"{lay.name}: LayerNormalization of a feature map (token rows [B, T, C] are built)")
+                d = self._dev.get(k)
+                if d is None:
+                    g_, b_ = lay.extra.get("gamma"), lay.extra.get("beta")
+                    d = self._dev[k] = {"g": self._up(np.ones(x.c, np.float32) if g_ is None else g_.astype(np.float32)),
+                                        "b": self._up(np.zeros(x.c, np.float32) if b_ is None else b_.astype(np.float32))}
+                if d["g"].numel() != x.c:
+                    raise UnsupportedOnnxGraph(f"{lay.name}: LayerNormalization scale has {d['g'].numel()} entries, the rows {x.c} channels")
+                y = _Act(self.eng.op_layernorm(x.t, x.c, d["g"], d["b"], lay.attrs["epsilon"]), x.c, x.flat, x.seq)
             elif op == "add":
                 if len(ins) != 2 or lay.extra:
                     raise UnsupportedOnnxGraph(f"{lay.name}: Add with a constant operand")
-                y = _Act(self.eng.op_add(ins[0].t, ins[1].t), ins[0].c)
+                if ins[0].t.shape != ins[1].t.shape:
+                    raise UnsupportedOnnxGraph(f"{lay.name}: Add of {tuple(ins[0].t.shape)} and {tuple(ins[1].t.shape)} (broadcasting is not built)")
+                y = _Act(self.eng.op_add(ins[0].t, ins[1].t), ins[0].c, ins[0].flat, ins[0].seq)
             elif op == "mul":
                 if len(ins) != 2 or lay.extra:
                     raise UnsupportedOnnxGraph(f"{lay.name}: Mul with a constant operand")
-                big, gate = (ins[0], ins[1]) if ins[0].t.shape[1] * ins[0].t.shape[2] >= ins[1].t.shape[1] * ins[1].t.shape[2] else (ins[1], ins[0])
-                if gate.t.shape[1] != 1 or gate.t.shape[2] != 1:
-                    raise UnsupportedOnnxGraph(f"{lay.name}: Mul of two feature maps (a per-channel gate [B, C, 1, 1] is built)")
-                y = _Act(self.eng.op_scale_channels(big.t, gate.t), big.c)
+                if ins[0].t.shape == ins[1].t.shape:
+                    y = _Act(self.eng.op_mul(ins[0].t, ins[1].t), ins[0].c, ins[0].flat, ins[0].seq)
+                else:
+                    big, gate = (ins[0], ins[1]) if ins[0].t.shape[1] * ins[0].t.shape[2] >= ins[1].t.shape[1] * ins[1].t.shape[2] else (ins[1], ins[0])
+                    if gate.t.shape[1] != 1 or gate.t.shape[2] != 1:
+                        raise UnsupportedOnnxGraph(f"{lay.name}: Mul of two differently shaped feature maps (equal shapes and a per-channel gate [B, C, 1, 1] are built)")
+                    y = _Act(self.eng.op_scale_channels(big.t, gate.t), big.c)
             elif op == "act":
-                y = self._post_act(lay, ins[0], lay.attrs["kind"])
+                if lay.attrs["kind"] == "softmax":
+                    x = ins[0]
+                    if not (x.seq or x.flat) or lay.attrs.get("axis", -1) not in (-1, len(x.shape()) - 1):
+                        raise UnsupportedOnnxGraph(f"{lay.name}: Softmax over axis {lay.attrs.get('axis')} of a {x.shape()} tensor (the channel axis of token rows is built)")
+                    y = _Act(self.eng.op_softmax(x.t, x.c), x.c, x.flat, x.seq)
+                else:
+                    y = self._post_act(lay, ins[0], lay.attrs["kind"])
             elif op == "resize":
                 sc = lay.attrs.get("scale")
                 sz = lay.attrs.get("sizes")
@@ -252,31 +504,24 @@ class HipGraphExecutor:
                     sc = [1.0, 1.0, sz[2] / hh, sz[3] / ww]
                 if lay.attrs.get("mode", "nearest") != "nearest" or not sc or sc[0] != 1 or sc[1] != 1 or sc[2] != sc[3] or sc[2] != int(sc[2]):
                     raise UnsupportedOnnxGraph(f"{lay.name}: Resize {lay.attrs} (nearest, integer factor)")
-                f = int(sc[2])
-                y = _Act(ins[0].t.repeat_interleave(f, dim=1).repeat_interleave(f, dim=2).contiguous(), ins[0].c)      # data movement only
+                y = _Act(self.eng.op_upsample(ins[0].t, int(sc[2])), ins[0].c)
             elif op == "concat":
-                if lay.attrs["axis"] != 1:
+                if lay.attrs["axis"] != 1 or any(i.seq or i.flat for i in ins):
                     raise UnsupportedOnnxGraph(f"{lay.name}: Concat over axis {lay.attrs['axis']}")
-                cat = torch.cat([i.t[..., :i.c] for i in ins], dim=-1)
                 cc = sum(i.c for i in ins)
-                y = _Act(self._repad(cat, cc), cc)
+                out = torch.zeros(ins[0].t.shape[:-1] + (_pad64(cc),), dtype=torch.bfloat16, device=self.eng._tdev)
+                o_ = 0
+                for i in ins:
+                    self.eng.op_copy_channels(i.t, out, i.c, dst_coff=o_)
+                    o_ += i.c
+                y = _Act(out, cc)
             elif op == "gemm":
                 src = ins[0]
-                if src.t.shape[1] != 1 or src.t.shape[2] != 1:
-                    raise UnsupportedOnnxGraph(f"{lay.name}: Gemm on a {tuple(src.t.shape)} tensor (after a global pool only)")
+                if not src.seq and (src.t.shape[1] != 1 or src.t.shape[2] != 1):
+                    raise UnsupportedOnnxGraph(f"{lay.name}: Gemm on a {tuple(src.t.shape)} feature map (token rows and pooled vectors are built)")
                 lay2 = Layer("conv", lay.name, lay.inputs, lay.outputs, {}, weight=lay.weight.reshape(lay.weight.shape[0], -1, 1, 1), bias=lay.bias)
                 d = self._conv_operands(k, lay2, src.t.shape[-1], src.c)
-                y = _Act(self.eng.op_conv2d(src.t, d["w"], d["b"], 1, 1), d["n"], True)
-            elif op == "glue":
-                if lay.attrs.get("onnx_op") in ("Flatten", "Reshape", "Squeeze", "Unsqueeze", "Identity") and ins:
-                    y = ins[0]                               # [B, C, 1, 1] <-> [B, C]: the same NHWC tensor here
-                    if y.t.shape[1] != 1 or y.t.shape[2] != 1:
-                        raise UnsupportedOnnxGraph(f"{lay.name}: {lay.attrs.get('onnx_op')} of a feature map")
-                    y = _Act(y.t, y.c, lay.attrs.get("onnx_op") in ("Flatten", "Squeeze", "Reshape"))
-                elif not ins:
-                    continue                                 # shape arithmetic on constants
-                else:
-                    raise UnsupportedOnnxGraph(f"{lay.name}: {lay.attrs.get('onnx_op')} has no executor")
+                y = _Act(self.eng.op_conv2d(src.t, d["w"], d["b"], 1, 1), d["n"], not src.seq, src.seq)
             else:
                 raise UnsupportedOnnxGraph(f"{lay.name}: layer kind '{op}' has no executor")
             for o in lay.outputs:
@@ -284,4 +529,4 @@ class HipGraphExecutor:
         for name in self.outputs:
             if name not in env:
                 raise UnsupportedOnnxGraph(f"graph output '{name}' was not produced")
-        return [env[name] for name in self.outputs]
+        return [R(env[name], f"graph output '{name}'") for name in self.outputs]

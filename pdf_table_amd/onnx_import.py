@@ -39,7 +39,9 @@ __all__ = ["OnnxGraph", "Layer", "UnsupportedOnnxGraph", "load_onnx", "recognise
 ENGINE_OPS = {"Conv", "ConvTranspose", "BatchNormalization", "Relu", "Sigmoid", "HardSwish", "HardSigmoid", "PRelu", "Clip",
               "MaxPool", "AveragePool", "GlobalAveragePool", "ReduceMean", "Add", "Mul", "Concat", "Resize", "Upsample",
               "LSTM", "Gemm", "MatMul", "Softmax", "Flatten", "Reshape", "Transpose", "Squeeze", "Unsqueeze", "Identity",
-              "Constant", "ConstantOfShape", "Expand", "Shape", "Gather", "Slice", "Cast", "Div", "Sub"}
+              "Constant", "ConstantOfShape", "Expand", "Shape", "Gather", "Slice", "Cast", "Div", "Sub",
+              # sequence blocks (SVTR-type recognisers): native nodes, and the pieces LayerNorm / GELU decompose into below opset 17 / 20
+              "LayerNormalization", "Gelu", "Erf", "Pow", "Sqrt", "Split"}
 _ACTS = {"Relu": "relu", "HardSwish": "hardswish", "Sigmoid": "sigmoid", "HardSigmoid": "hardsigmoid", "PRelu": "prelu"}
 
 
@@ -129,6 +131,98 @@ class OnnxGraph:
             return None
         return c[0], c[1], b.outputs[0]
 
+    def _const_scalar(self, name: str) -> Optional[float]:
+        v = self.init.get(name)
+        return float(np.asarray(v).reshape(-1)[0]) if v is not None and np.asarray(v).size == 1 else None
+
+    def _only(self, tensor: str, op: str) -> Optional[int]:
+        """index of the ONLY consumer of `tensor` if it is an `op` node"""
+        return self._sole_consumer(tensor, (op,))
+
+    def _match_layernorm(self, k: int):
+        """ReduceMean(x, -1) -> Sub(x, .) -> Pow(., 2) -> ReduceMean(-1) -> Add(eps) -> Sqrt -> Div(sub, .) -> Mul(gamma) -> Add(beta): how
+        nn.LayerNorm exports below opset 17 (and from Paddle).  -> (used node indices, x, gamma, beta, eps, output) or None"""
+        n = self.nodes[k]
+        ax = n.attrs.get("axes")
+        if ax is None and len(n.inputs) > 1:
+            ax = self.init.get(n.inputs[1])
+        if n.op_type != "ReduceMean" or ax is None or [int(a) for a in np.asarray(ax).reshape(-1)] != [-1]:
+            return None
+        x = n.inputs[0]
+        j_sub = self._only(n.outputs[0], "Sub")
+        if j_sub is None or self.nodes[j_sub].inputs[0] != x:
+            return None
+        d = self.nodes[j_sub].outputs[0]
+        cons = self.consumers.get(d, [])
+        if len(cons) != 2:
+            return None
+        j_pow = next((c for c in cons if self.nodes[c].op_type in ("Pow", "Mul")), None)
+        j_div = next((c for c in cons if self.nodes[c].op_type == "Div"), None)
+        if j_pow is None or j_div is None:
+            return None
+        pw = self.nodes[j_pow]
+        if pw.op_type == "Pow" and self._const_scalar(pw.inputs[1]) != 2.0:
+            return None
+        if pw.op_type == "Mul" and list(pw.inputs) != [d, d]:
+            return None
+        j_m2 = self._only(pw.outputs[0], "ReduceMean")
+        if j_m2 is None:
+            return None
+        j_add = self._only(self.nodes[j_m2].outputs[0], "Add")
+        if j_add is None:
+            return None
+        eps = next((self._const_scalar(i) for i in self.nodes[j_add].inputs if i in self.init), None)
+        j_sqrt = self._only(self.nodes[j_add].outputs[0], "Sqrt")
+        if eps is None or j_sqrt is None or self.nodes[j_div].inputs != [d, self.nodes[j_sqrt].outputs[0]]:
+            return None
+        used = [k, j_sub, j_pow, j_m2, j_add, j_sqrt, j_div]
+        cur = self.nodes[j_div].outputs[0]
+        gamma = beta = None
+        j_mul = self._only(cur, "Mul")
+        if j_mul is not None:
+            g = [i for i in self.nodes[j_mul].inputs if i in self.init]
+            if len(g) == 1 and self.init[g[0]].ndim == 1:
+                gamma, cur = np.asarray(self.init[g[0]], np.float32), self.nodes[j_mul].outputs[0]
+                used.append(j_mul)
+                j_b = self._only(cur, "Add")
+                if j_b is not None:
+                    bb = [i for i in self.nodes[j_b].inputs if i in self.init]
+                    if len(bb) == 1 and self.init[bb[0]].ndim == 1:
+                        beta, cur = np.asarray(self.init[bb[0]], np.float32), self.nodes[j_b].outputs[0]
+                        used.append(j_b)
+        return used, x, gamma, beta, eps, cur
+
+    def _match_gelu(self, k: int):
+        """Div(x, sqrt 2) [or Mul(x, 1 / sqrt 2)] -> Erf -> Add(1) -> Mul(x, .) -> Mul(0.5): nn.GELU() below opset 20"""
+        n = self.nodes[k]
+        if n.op_type not in ("Div", "Mul") or len(n.inputs) != 2:
+            return None
+        c = self._const_scalar(n.inputs[1])
+        x = n.inputs[0]
+        if c is None or abs((c if n.op_type == "Div" else 1.0 / c) - 2.0 ** 0.5) > 1e-3:
+            return None
+        j_erf = self._only(n.outputs[0], "Erf")
+        if j_erf is None:
+            return None
+        j_add = self._only(self.nodes[j_erf].outputs[0], "Add")
+        if j_add is None or next((self._const_scalar(i) for i in self.nodes[j_add].inputs if i in self.init), None) != 1.0:
+            return None
+        j_mx = self._only(self.nodes[j_add].outputs[0], "Mul")
+        if j_mx is None or sorted(self.nodes[j_mx].inputs) != sorted([x, self.nodes[j_add].outputs[0]]):
+            return None
+        j_half = self._only(self.nodes[j_mx].outputs[0], "Mul")
+        if j_half is None or next((self._const_scalar(i) for i in self.nodes[j_half].inputs if i in self.init), None) != 0.5:
+            return None
+        return [k, j_erf, j_add, j_mx, j_half], x, self.nodes[j_half].outputs[0]
+
+    def _match_swish(self, k: int):
+        """Sigmoid(x) -> Mul(x, .): nn.SiLU / PaddleOCR's swish"""
+        n = self.nodes[k]
+        j = self._only(n.outputs[0], "Mul") if n.op_type == "Sigmoid" else None
+        if j is None or sorted(self.nodes[j].inputs) != sorted([n.inputs[0], n.outputs[0]]):
+            return None
+        return [k, j], n.inputs[0], self.nodes[j].outputs[0]
+
     # ---- the engine layer list ----------------------------------------------------------------------------------------
     def layers(self) -> List[Layer]:
         out: List[Layer] = []
@@ -137,6 +231,26 @@ class OnnxGraph:
             if k in used:
                 continue
             t = n.op_type
+            m = self._match_layernorm(k) if t == "ReduceMean" else None
+            if m is not None:
+                used.update(m[0])
+                out.append(Layer("layernorm", n.name or m[5], [m[1]], [m[5]], {"epsilon": float(m[4])}, extra={"gamma": m[2], "beta": m[3]}))
+                continue
+            if t == "LayerNormalization":
+                if int(n.attrs.get("axis", -1)) != -1:
+                    raise UnsupportedOnnxGraph(f"LayerNormalization '{n.name}' over axis {n.attrs.get('axis')} (the last axis is built)")
+                out.append(Layer("layernorm", n.name or n.outputs[0], [n.inputs[0]], [n.outputs[0]], {"epsilon": float(n.attrs.get("epsilon", 1e-5))},
+                                 extra={"gamma": np.asarray(self.init[n.inputs[1]], np.float32),
+                                        "beta": np.asarray(self.init[n.inputs[2]], np.float32) if len(n.inputs) > 2 and n.inputs[2] in self.init else None}))
+                continue
+            m = self._match_gelu(k) if t in ("Div", "Mul") else (self._match_swish(k) if t == "Sigmoid" else None)
+            if m is not None:
+                used.update(m[0])
+                out.append(Layer("act", n.name or m[2], [m[1]], [m[2]], {"kind": "gelu" if t != "Sigmoid" else "swish", "axis": -1}))
+                continue
+            if t == "Gelu":
+                out.append(Layer("act", n.name or n.outputs[0], [n.inputs[0]], [n.outputs[0]], {"kind": "gelu", "axis": -1}))
+                continue
             if t in ("Conv", "ConvTranspose"):
                 w = self.init.get(n.inputs[1])
                 if w is None:
@@ -207,7 +321,7 @@ class OnnxGraph:
                                   "coordinate_transformation_mode": n.attrs.get("coordinate_transformation_mode", "")}))
             elif t in ("Add", "Mul", "Sub", "Div"):
                 consts = {i: self.init[i] for i in n.inputs if i in self.init}
-                out.append(Layer(t.lower(), n.name or n.outputs[0], [i for i in n.inputs if i not in consts], [n.outputs[0]],
+                out.append(Layer(t.lower(), n.name or n.outputs[0], [i for i in n.inputs if i not in consts], [n.outputs[0]], {"all_inputs": list(n.inputs)},
                                  extra={f"const{q}": np.asarray(v) for q, v in enumerate(consts.values())}))
             elif t == "Concat":
                 out.append(Layer("concat", n.name or n.outputs[0], list(n.inputs), [n.outputs[0]], {"axis": int(n.attrs.get("axis", 1))}))
@@ -223,7 +337,7 @@ class OnnxGraph:
             elif t in ("Gemm", "MatMul"):
                 wname = next((i for i in n.inputs if i in self.init and self.init[i].ndim == 2), None)
                 if wname is None:
-                    out.append(Layer("matmul", n.name or n.outputs[0], list(n.inputs), [n.outputs[0]]))
+                    out.append(Layer("matmul", n.name or n.outputs[0], list(n.inputs), [n.outputs[0]], {"all_inputs": list(n.inputs)}))
                     continue
                 w = np.asarray(self.init[wname], np.float32)
                 if t == "MatMul" or not int(n.attrs.get("transB", 0)):
@@ -241,7 +355,7 @@ class OnnxGraph:
                 out.append(lay)
             else:
                 out.append(Layer("glue" if t in ENGINE_OPS else "unsupported", n.name or n.outputs[0], [i for i in n.inputs if i not in self.init],
-                                 list(n.outputs), {"onnx_op": t}))
+                                 list(n.outputs), {"onnx_op": t, "all_inputs": list(n.inputs), "node_attrs": dict(n.attrs)}))
         return out
 
     def summary(self) -> str:

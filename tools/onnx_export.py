@@ -243,3 +243,97 @@ if __name__ == "__main__":
     with open(path, "wb") as f:
         f.write(data)
     print(path, len(data), "bytes")
+
+
+# ---- sequence / multi-output stand-ins for the executor tests (tests/test_gpu_onnx_seq.py) --------------------------------------------
+class SvtrBlock(torch.nn.Module):
+    """one global-mixing block of an SVTR-type recogniser (PaddleOCR ppocr/modeling/backbones/rec_svtrnet.py: fused qkv, (B, heads, T, d)
+    attention, MLP), pre-norm"""
+
+    def __init__(self, dim=64, heads=4, mlp=2.0, act="gelu"):
+        super().__init__()
+        self.heads, self.hd = heads, dim // heads
+        self.norm1, self.norm2 = torch.nn.LayerNorm(dim, eps=1e-6), torch.nn.LayerNorm(dim, eps=1e-6)
+        self.qkv, self.proj = torch.nn.Linear(dim, 3 * dim), torch.nn.Linear(dim, dim)
+        self.fc1, self.fc2 = torch.nn.Linear(dim, int(dim * mlp)), torch.nn.Linear(int(dim * mlp), dim)
+        self.act = torch.nn.GELU() if act == "gelu" else torch.nn.SiLU()
+
+    def forward(self, x):
+        B, T, C = x.shape
+        qkv = self.qkv(self.norm1(x)).reshape(B, T, 3, self.heads, self.hd).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0] * (self.hd ** -0.5), qkv[1], qkv[2]
+        a = torch.softmax(q @ k.transpose(-2, -1), dim=-1)
+        x = x + self.proj((a @ v).transpose(1, 2).reshape(B, T, C))
+        return x + self.fc2(self.act(self.fc1(self.norm2(x))))
+
+
+class SvtrTiny(torch.nn.Module):
+    """conv stem -> tokens -> two SVTR blocks -> LayerNorm -> CTC head with its Softmax: the operator set of a PP-OCRv4-type recogniser"""
+
+    def __init__(self, dim=64, classes=97, act="gelu"):
+        super().__init__()
+        self.c1, self.b1 = torch.nn.Conv2d(3, 32, 3, 2, 1, bias=False), torch.nn.BatchNorm2d(32)
+        self.c2, self.b2 = torch.nn.Conv2d(32, dim, 3, 2, 1, bias=False), torch.nn.BatchNorm2d(dim)
+        self.blocks = torch.nn.ModuleList([SvtrBlock(dim, 4, 2.0, act), SvtrBlock(dim, 4, 2.0, act)])
+        self.norm = torch.nn.LayerNorm(dim, eps=1e-6)
+        self.head = torch.nn.Linear(dim, classes)
+
+    def forward(self, x):
+        x = torch.relu(self.b2(self.c2(torch.relu(self.b1(self.c1(x))))))
+        x = x.flatten(2).transpose(1, 2)                         # [B, H W, C]
+        for b in self.blocks:
+            x = b(x)
+        return torch.softmax(self.head(self.norm(x)), dim=-1)
+
+
+class PicoLike(torch.nn.Module):
+    """backbone -> levels -> per level one head conv whose channels are split into class scores (sigmoid) and box distributions, each
+    flattened to [B, anchors, C]: the output convention of the PicoDet export the reference's layout stage consumes
+    (ocr_layout_task.py:159-175: first half of the outputs = scores, second half = distributions).  levels = 3: strides 4 / 8 / 16 with a
+    top-down path (nearest x2 Resize + Add); levels = 4: strides 8 / 16 / 32 / 64 like picodet_lcnet_x1_0_layout, no top-down path (odd sizes)"""
+
+    def __init__(self, ncls=5, reg=32, levels=3):
+        super().__init__()
+        self.ncls, self.levels = ncls, levels
+        cbr = lambda i, o, s: torch.nn.Sequential(torch.nn.Conv2d(i, o, 3, s, 1, bias=False), torch.nn.BatchNorm2d(o), torch.nn.Hardswish())
+        self.s1, self.s2, self.s3, self.s4 = cbr(3, 32, 2), cbr(32, 64, 2), cbr(64, 96, 2), cbr(96, 128, 2)
+        chans = (64, 96, 128)
+        if levels == 4:
+            self.s5, self.s6 = cbr(128, 128, 2), cbr(128, 128, 2)
+            chans = (96, 128, 128, 128)
+        self.lat = torch.nn.ModuleList([torch.nn.Conv2d(c, 64, 1) for c in chans])
+        self.heads = torch.nn.ModuleList([torch.nn.Conv2d(64, ncls + reg, 1) for _ in chans])
+
+    def forward(self, x):
+        c2 = self.s2(self.s1(x))
+        c3 = self.s3(c2)
+        c4 = self.s4(c3)
+        if self.levels == 4:
+            c5 = self.s5(c4)
+            feats = [l(c) for l, c in zip(self.lat, (c3, c4, c5, self.s6(c5)))]
+        else:
+            p4 = self.lat[2](c4)
+            p3 = self.lat[1](c3) + torch.nn.functional.interpolate(p4, scale_factor=2.0, mode="nearest")
+            feats = [self.lat[0](c2) + torch.nn.functional.interpolate(p3, scale_factor=2.0, mode="nearest"), p3, p4]
+        scores, dists = [], []
+        for p, h in zip(feats, self.heads):
+            o = h(p)
+            scores.append(torch.sigmoid(o[:, :self.ncls]).flatten(2).permute(0, 2, 1))
+            dists.append(o[:, self.ncls:].flatten(2).permute(0, 2, 1))
+        return tuple(scores + dists)
+
+
+def seeded(module: torch.nn.Module, seed: int) -> torch.nn.Module:
+    """seeded parameters incl. non-trivial BatchNorm statistics"""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.3 if p.ndim == 1 else (2.0 / max(1, p[0].numel())) ** 0.5))
+            if n.endswith("norm1.weight") or n.endswith("norm2.weight") or n.endswith("norm.weight") or (p.ndim == 1 and "b" in n.split(".")[-2][:1] and n.endswith("weight")):
+                p.add_(1.0)
+        for n, b in module.named_buffers():
+            if n.endswith("running_var"):
+                b.copy_(torch.rand(b.shape, generator=g) + 0.5)
+            elif n.endswith("running_mean"):
+                b.copy_(torch.randn(b.shape, generator=g) * 0.1)
+    return module.eval()
