@@ -3,9 +3,12 @@
 Reference: src/pdftable/model/ocr_pdf/ocr_recognition_task.py:28-136.  Same constructor (``task, model, task_type``),
 same result (one string per input crop), same ``RuntimeError`` for an unknown model (:47).  ``model="CRNN"`` and
 ``model="ConvNextViT"`` (the two in-tree torch recognisers of BASELINE.json's configs; ConvNextViT with the chunking
-pre-processor: 32 x 804, three 300-px chunks, 201 tokens per line, vocabulary from class 2) are served; ``LightweightEdge``
-and the PP-OCR ONNX recognisers are not built on the engine yet and fail loudly, naming the hub id the reference would
-have fetched.
+pre-processor: 32 x 804, three 300-px chunks, 201 tokens per line, vocabulary from class 2) are served from checkpoints.
+``model="PP-OCRv4" / "PP-OCRv3" / "PP-Table"`` -- the ONNX recognisers ``fix_model_names()`` selects for every language
+(model/ocr_pdf/configuration_ocr_document.py:138-141) -- are served from a ``model.onnx`` / ``inference.onnx`` under ``task_path``: the
+engine's ``PPOcrRecPreProcessor`` kernel (48-px, width-sorted mini-batches), the generic graph executor (conv backbone, SVTR-type
+attention / LayerNorm neck, CTC head with its Softmax: pdf_table_amd/onnx_exec.py) and ``CTCLabelDecode``; without a file they fail
+loudly, naming the hub id the reference would have fetched.  ``LightweightEdge`` is not built.
 
 Two ways in:
   * reference-shaped: ``task(crop_or_list_of_crops)`` -- every crop is an RGB image (path / PIL / ndarray) exactly as
@@ -56,7 +59,55 @@ class OcrRecognitionTask(BaseInferTask):
         self._config.model_path = self.get_model_name_or_path()
         self._get_inference_model()
 
+    def _construct_pp(self):
+        """ONNX mode of the PP-OCR recognisers (ocr_recognition_task.py:81-116 -> DeployUtils.prepare_onnx_model)"""
+        from .onnx_exec import HipGraphExecutor
+        from .rec_postprocess import CTCLabelDecode
+        from .rec_pp_stage import PPOcrRecConfig, PPOcrRecPreProcessor
+        onnx_path = self._onnx_file()
+        if onnx_path is None:
+            raise RuntimeError(f"recogniser '{self.model}': no model.onnx / inference.onnx under {self._task_path!r} -- the reference would "
+                               f"download '{self._config.model_path}' from the hub (no network here); pass task_path=<dir or file>")
+        if self._engine is None:
+            self._engine = HipEngine(int(str(self.device).split(":")[-1]) if ":" in str(self.device) else 0)
+        self._exec = HipGraphExecutor(onnx_path, engine=self._engine)
+        if len(self._exec.outputs) != 1:
+            from .onnx_import import UnsupportedOnnxGraph
+            raise UnsupportedOnnxGraph(f"{onnx_path}: a CTC recogniser returns one [B, T, classes] tensor, this graph returns {self._exec.outputs}")
+        self._pp = PPOcrRecPreProcessor(PPOcrRecConfig(), engine=self._engine)
+        d = self.kwargs.get("character_dict_path")
+        if d is None:
+            base = onnx_path if os.path.isdir(onnx_path) else os.path.dirname(onnx_path)
+            d = next((os.path.join(base, c) for c in ("ppocr_keys_v1.txt", "en_dict.txt", "dict.txt", "vocab.txt") if os.path.isfile(os.path.join(base, c))), None)
+        self._ctc = CTCLabelDecode(d, use_space_char=bool(self.kwargs.get("use_space_char", True)))
+        self._vocab = None
+        self.last_scores: List[float] = []
+        self._model = self._predict_pp
+
+    def _predict_pp(self, crops):
+        """crops -> PPOcrRecPreProcessor mini-batches on the device -> graph -> CTCLabelDecode; results in the order of the crops (the
+        reference's PPOcrRecPostProcessor scatters correctly only for one crop per call, processor_ocr_rec_pp.py:149-171: not reproduced)"""
+        from .onnx_import import UnsupportedOnnxGraph
+        texts, scores = [""] * len(crops), [0.0] * len(crops)
+        for b in self._pp(list(crops)):
+            img = b["image"]                                     # f32 [n, 3, 48, imgW] on the device
+            for i in range(img.shape[0]):                        # one line per run: static exports have their batch size baked in
+                x = img[i:i + 1].permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
+                (a,) = self._exec.run_device(x, 3)
+                if not a.seq or a.c != len(self._ctc.character):
+                    raise UnsupportedOnnxGraph(f"recogniser output of shape {a.shape()}: [B, T, {len(self._ctc.character)}] (blank + dictionary"
+                                               " + space) is expected")
+                p = a.t[0, 0, :, :a.c].float()
+                conf, ids = p.max(-1)
+                (text, sc), = self._ctc.decode_ids(ids.cpu().numpy()[None], conf.cpu().numpy()[None])
+                k = int(b["indices"][b["batch_beg_img_no"] + i])
+                texts[k], scores[k] = text, float(sc)
+        self.last_scores = scores
+        return texts
+
     def _construct_model(self, model):
+        if model in ("PP-OCRv4", "PP-OCRv3", "PP-Table"):
+            return self._construct_pp()
         if model not in ("CRNN", "ConvNextViT"):
             raise RuntimeError(f"recogniser '{model}' ({self._config.model_path}) is not built on the HIP engine yet; "
                                "only the in-tree CRNN and ConvNextViT are (SURVEY.md section 8f)")
@@ -98,6 +149,9 @@ class OcrRecognitionTask(BaseInferTask):
         self._model = self._predict
 
     def _build_processor(self):
+        if self.model in ("PP-OCRv4", "PP-OCRv3", "PP-Table"):
+            self._stage = None
+            return
         self._stage = RecStage(self._engine, self._vocab, recognizer=self._config.recognizer)
 
     def _predict(self, crops):

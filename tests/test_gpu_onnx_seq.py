@@ -148,3 +148,34 @@ def test_classifier_task_onnx_door(eng, tmp_path):
         print("classifier ONNX door:", g, "module top-2", order[:2].tolist(), np.round(p[order[:2]], 4).tolist())
         assert len(g["class_ids"]) == 2 and abs(g["scores"][0] - float(p[g["class_ids"][0]])) <= 0.05
         assert g["class_ids"][0] == int(order[0]) or p[order[0]] - p[g["class_ids"][0]] <= 0.05
+
+
+def test_recognition_task_onnx_door(eng, tmp_path):
+    """OcrRecognitionTask(model="PP-OCRv4", task_path=<inference.onnx + dictionary>): PPOcrRecPreProcessor kernel -> executor (conv stem, two
+    attention blocks, CTC head with Softmax) -> CTCLabelDecode, against the exported module in fp32 on the oracle's pre-processing"""
+    import onnx_export as X
+    from oracle import rec_pp as orp
+    from pdf_table_amd.ocr_recognition_task import OcrRecognitionTask
+    from pdf_table_amd.rec_postprocess import CTCLabelDecode
+    from pdf_table_amd.synth_pages import make_page
+    chars = [chr(0x4E00 + i) for i in range(95)]
+    (tmp_path / "ppocr_keys_v1.txt").write_text("\n".join(chars) + "\n", encoding="utf-8")
+    m = X.seeded(X.SvtrTiny(classes=97), 31)                      # blank + 95 characters + space
+    (tmp_path / "inference.onnx").write_bytes(X.torch_export(m, torch.zeros(1, 3, 48, 320)))
+    task = OcrRecognitionTask(model="PP-OCRv4", task_type="ch", task_path=str(tmp_path), engine=eng)
+    page = make_page(4, 1024)[0]
+    crops = [page[100:130, 50:240].copy(), page[300:340, 400:600].copy(), page[500:520, 100:200].copy()]
+    got = task(crops)
+    assert isinstance(got, list) and len(got) == 3 and all(isinstance(t, str) for t in got)
+    ctc = CTCLabelDecode(str(tmp_path / "ppocr_keys_v1.txt"), use_space_char=True)
+    for c, g in zip(crops, got):
+        (b,) = orp.rec_pp_preprocess([c])
+        with torch.no_grad():
+            p = m(torch.from_numpy(np.ascontiguousarray(b["image"]))).numpy()
+        (want, _), = ctc(p)
+        import difflib
+        ratio = difflib.SequenceMatcher(None, g, want).ratio()
+        print(f"recogniser ONNX door: {len(g)} characters on the engine (bf16), {len(want)} from the module (fp32), similarity {ratio:.3f}")
+        assert len(want) > 5 and ratio >= 0.85              # a random-init head: a few near-tie tokens flip in bf16
+    with pytest.raises(RuntimeError, match="no model.onnx"):
+        OcrRecognitionTask(model="PP-OCRv4", task_type="ch", task_path=str(tmp_path / "missing"), engine=eng)
