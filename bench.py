@@ -303,8 +303,10 @@ def one_eighth_host_leg(args, value):
     try:
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, preexec_fn=lambda: os.sched_setaffinity(0, share),
                            env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
-        line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
-        d = json.loads(line)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if not lines:
+            return {"error": f"child exited with {p.returncode}: " + p.stderr[-400:]}
+        d = json.loads(lines[-1])
         return {"pages_per_s_at_one_eighth_host": d["value"], "ratio_to_value": d["value"] / value, "cores": len(share), "of_cores": len(cpus),
                 "note": "same timed region (OcrTablePipeline.predict_stream, 64-page batches), child process pinned to the first 1/8 of the "
                         "cores, detection post-process pool capped to that share"}
@@ -808,7 +810,7 @@ class HipRunner:
                             + (" + PP-LCNet text-line orientation of every text line and page orientation of every page "
                                "[opt-in stage, not part of BASELINE.json's metric]" if "cls" in stages else "")
                             + ("; timed loop = OcrTablePipeline.predict_stream() over device-resident 64-page batches (the product API: "
-                               "PageResult objects out, two batches behind the input, drained inside the timed region)" if self.uses_pipeline() else
+                               "PageResult objects out, three batches behind the input, drained inside the timed region)" if self.uses_pipeline() else
                                "; timed loop = bench.py's own schedule (run_private)")
                             + (" [DEVICE HALF ONLY]" if args.no_post else "")
                             + (" [recogniser on a second stream: --overlap-rec diagnostic]" if args.overlap_rec else "")

@@ -243,6 +243,9 @@ struct ConvDesc {
   const float* res_f32 = nullptr;   // fp32 residual laid out like out_f32 (may alias it)
   // roofline accounting only (PtProfile): the layer's real output channels when N / n_valid are padded (0 = n_valid, else N),
   // and the fraction of the launch's output pixels the algorithm needs (patch mosaics compute 9 pixels to use one)
+  // 3x3 stride-1 layers: bit (r * 3 + s) of tap_mask[t] set = tap (r, s) of the 64-channel output tile t has non-zero weights; 0 = all
+  // taps.  Tiles past the eighth use every tap.  (Phase convolutions of an up-sampled input: 4 of 9 taps per tile.)
+  unsigned tap_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int alg_n = 0;
   double alg_scale = 1.0;
 };

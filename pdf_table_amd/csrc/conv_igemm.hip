@@ -71,6 +71,7 @@ struct ConvK {
   const bf16_t* in2;
   const bf16_t* in3;
   int segc0, segc1, segc2, segc3, nseg;
+  unsigned tap_mask[8];   // ConvDesc.tap_mask (0 = every tap)
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
@@ -643,6 +644,7 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
   const char* b_base = s_w + lx * C::PIXB + (C::SWZ ? 0 : q * 16);
   const int b_sw = (lx >> 2) & 3;      // SWZ: weight row tap * 64 (+ 32) + lx -> ((row >> 2) & 3) == ((lx >> 2) & 3) for every tap
 
+  const unsigned tmask = (KS == 3 && STRIDE == 1 && nt < 8 && p.tap_mask[nt]) ? p.tap_mask[nt] : 0x1FFu;
   prefetch(0);
   for (int c = 0; c < nchunks; ++c) {
     __syncthreads();  // everyone is done reading the previous slice
@@ -662,6 +664,7 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const int tap = r * KS + s;
+        if (KS == 3 && STRIDE == 1 && !((tmask >> tap) & 1u)) continue;      // uniform: this tile's weights are zero on the tap
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           const int b_off = C::SWZ ? (((q + 2 * kk) ^ b_sw) * 16) : kk * 32;
@@ -837,6 +840,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_dma16_kernel(ConvK p, con
   const int pa0 = (4 * wm) * C::TWIN + lx;                              // pixel of row-tile 0, tap (0,0)
   const int boff = (wn * 64 + lx) * 32 + ((qh ^ ((lx >> 3) & 1)) << 4);  // weight row n = wn*64 + nt*32 + lx
 
+  const int t64 = NT * nb + (NT == 2 ? wn : 0);            // this wave's 64-channel output tile
+  const unsigned tmask = (t64 < 8 && p.tap_mask[t64]) ? p.tap_mask[t64] : 0x1FFu;
   issue(0, 0);
   for (int c = 0; c < nslices; ++c) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -849,6 +854,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_dma16_kernel(ConvK p, con
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
         const int tap = r * 3 + s;
+        if (!((tmask >> tap) & 1u)) continue;      // wave-uniform: this wave's 64 output channels have zero weights on the tap
         const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(s_w + (tap * C::NW) * 32 + boff);
         const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(s_w + (tap * C::NW + 32) * 32 + boff);
 #pragma unroll
@@ -1421,6 +1427,7 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
              "conv: fused pooling needs a plain 3x3 stride-1 layer with even output size");
   PT_REQUIRE(d.relu != 3 || d.slope, "conv: PReLU needs the slope tensor");
   k.split = d.split; k.out_lo_off = d.out_lo_off;
+  for (int i = 0; i < 8; ++i) k.tap_mask[i] = d.tap_mask[i];
   k.head_w = d.head_w; k.head_b = d.head_b; k.head_prob = d.head_prob; k.head_logits = d.head_logits;
   k.argmax_part = d.argmax_part;
   if (d.head_w) PT_REQUIRE(d.shuffle_cout == 64 && d.head_b && (d.head_prob || d.head_logits), "conv: bad fused-head configuration");

@@ -27,6 +27,7 @@ struct DbWeights {
   const PtTensor *in_w[4], *in_b[4];    // in2..in5 (index 0 = in2)
   const PtTensor *out_w[4], *out_b[4];  // out2..out5
   const PtTensor *bin0_w, *bin0_b, *bin3_w, *bin3_b, *bin6_w, *bin6_b;
+  const PtTensor *out2f_w = nullptr, *out2f_b = nullptr, *out2p_w = nullptr, *out2p_b = nullptr;
 };
 
 int get(const PtModel& m, const std::string& name, const PtTensor** out, bool optional = false) {
@@ -58,6 +59,11 @@ int bind(const PtModel& m, DbWeights& w, bool x3, bool f16) {
     G("out" + k + ws, out_w[i]); G("out" + k + ".b", out_b[i]);
   }
   G("bin0" + ws, bin0_w); G("bin0.b", bin0_b); G("bin3" + ws, bin3_w); G("bin3.b", bin3_b);
+  // fused out2 (packer: conv3x3(W_o . W_i, c2) + phase conv of o3); older blobs do not carry it
+  if ((rc = get(m, "out2f" + ws, &w.out2f_w, true)) != PT_OK) return rc;
+  if ((rc = get(m, "out2f.b", &w.out2f_b, true)) != PT_OK) return rc;
+  if ((rc = get(m, "out2p" + ws, &w.out2p_w, true)) != PT_OK) return rc;
+  if ((rc = get(m, "out2p.b", &w.out2p_b, true)) != PT_OK) return rc;
   G(x3 ? "bin6.wf32" : "bin6.w", bin6_w); G("bin6.b", bin6_b);
 #undef G
   return PT_OK;
@@ -166,16 +172,43 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
   }
   // decoder: lateral 1x1 convs with the top-down add fused (in5 first, then in4 + up(in5), ...)
   bf16_t* lat[4] = {bf.o2, bf.o3, bf.o4, bf.in5};  // index i <-> feature c[i]
-  for (int i = 3; i >= 0; --i) {
+  // out2 without its lateral (PT_DB_FUSE_OUT2=0: the layer-by-layer path; A/B switch): see the packer for the algebra
+  static int fuse_out2 = -1;
+  if (fuse_out2 < 0) {
+    const char* ev = getenv("PT_DB_FUSE_OUT2");
+    fuse_out2 = ev ? atoi(ev) : 1;
+  }
+  const bool fused2 = fuse_out2 && w.out2f_w && w.out2f_b && w.out2p_w && w.out2p_b;
+  for (int i = 3; i >= (fused2 ? 1 : 0); --i) {
     ConvDesc c = conv(bf.c[i], H >> (2 + i), W_ >> (2 + i), ch[i], w.in_w[i], w.in_b[i], 256, 1, 1, lat[i], 256, 0);
     if (i < 3) { c.res = lat[i + 1]; c.res_mode = 2; }
     RUN(pt_launch_conv(e, c, s));
   }
   // out5/out4/out3/out2: 3x3 256->64, nearest-upsampled x8/x4/x2/x1 and concatenated as (p5,p4,p3,p2)
-  for (int i = 3; i >= 0; --i) {
+  for (int i = 3; i >= (fused2 ? 1 : 0); --i) {
     ConvDesc c = conv(lat[i], H >> (2 + i), W_ >> (2 + i), 256, w.out_w[i], w.out_b[i], 64, 3, 1, bf.fuse, 256, 0);
     c.out_coff = (3 - i) * 64; c.rep = 1 << i;
     RUN(pt_launch_conv(e, c, s));
+  }
+  if (fused2) {
+    // (a) conv3x3(W_o, up2(o3)) as a phase convolution at 1/8 resolution: 4 x 64 outputs, pixel-shuffled to 1/4 resolution, 4 of 9 taps
+    //     per phase (bf.y0 is free until bin0 writes it)
+    ConvDesc cp = conv(lat[1], H >> 3, W_ >> 3, 256, w.out2p_w, w.out2p_b, 256, 3, 1, bf.y0, 64, 0);
+    cp.shuffle_cout = 64;
+    cp.alg_scale = 4.0 / 9.0;
+    for (int dy = 0; dy < 2; ++dy)
+      for (int dx = 0; dx < 2; ++dx) {
+        unsigned mk = 0;
+        for (int r = dy; r < dy + 2; ++r)
+          for (int q = dx; q < dx + 2; ++q) mk |= 1u << (r * 3 + q);
+        cp.tap_mask[dy * 2 + dx] = mk;
+      }
+    RUN(pt_launch_conv(e, cp, s));
+    // (b) + conv3x3(W_o . W_i, c2) with (a) as its residual, straight into the p2 slice of the concat
+    ConvDesc cf = conv(bf.c[0], H >> 2, W_ >> 2, 64, w.out2f_w, w.out2f_b, 64, 3, 1, bf.fuse, 256, 0);
+    cf.out_coff = 192;
+    cf.res = bf.y0; cf.res_mode = 1;
+    RUN(pt_launch_conv(e, cf, s));
   }
   {
     ConvDesc c = conv(bf.fuse, H / 4, W_ / 4, 256, w.bin0_w, w.bin0_b, 64, 3, 1, bf.y0, 64, 1);

@@ -150,6 +150,30 @@ def pack_db_resnet18(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
         bl.add_conv(f"in{k}", *fold_conv_bn(sd, f"decoder.in{k}", None))
         oname = f"decoder.out{k}.0" if k > 2 else "decoder.out2"
         bl.add_conv(f"out{k}", *fold_conv_bn(sd, oname, None))
+    # out2 = conv3x3(W_o, in2(c2) + up2(o3)) without the 256-channel lateral at 1/4 resolution (29.5 MB per page, the most expensive
+    # bandwidth-type tensor of the decoder):  conv3x3(W_o . W_i, c2)  +  conv3x3(W_o, up2(o3)).  The first term is a 64 -> 64 3x3 conv with
+    # the composed weights (in2 has no bias, so zero padding commutes with it); the second term reads a NEAREST-up-sampled map: output
+    # phase (dy, dx) of a 2x2 block sees only a 2x2 neighbourhood of o3 -- a 3x3 conv at HALF resolution with 4 x 64 outputs (pixel
+    # shuffle) whose kernel rows are {w[-1], w[0] + w[1], 0} for dy = 0 and {0, w[-1] + w[0], w[1]} for dy = 1 (columns alike): 4 of the 9
+    # taps are non-zero per phase and the kernels skip the others (ConvDesc.tap_mask).  Composed in float64.
+    wi, bi = fold_conv_bn(sd, "decoder.in2", None)
+    wo, bo = fold_conv_bn(sd, "decoder.out2", None)
+    if float(bi.abs().max()) == 0.0:
+        w1 = torch.einsum("okrs,kc->ocrs", wo.double(), wi.double()[:, :, 0, 0]).float()
+        bl.add_conv("out2f", w1, bo)
+        wd = wo.double()
+        rows = {0: (wd[:, :, 0], wd[:, :, 1] + wd[:, :, 2], torch.zeros_like(wd[:, :, 0])),
+                1: (torch.zeros_like(wd[:, :, 0]), wd[:, :, 0] + wd[:, :, 1], wd[:, :, 2])}          # [o, k, s] per low-res row offset
+        ph = torch.zeros(4, wo.shape[0], wo.shape[1], 3, 3, dtype=torch.float64)
+        for dy in range(2):
+            for dx in range(2):
+                for R in range(3):
+                    r_ = rows[dy][R]                                                                   # [o, k, 3 (s)]
+                    cols = (r_[:, :, 0], r_[:, :, 1] + r_[:, :, 2], torch.zeros_like(r_[:, :, 0])) if dx == 0 else \
+                           (torch.zeros_like(r_[:, :, 0]), r_[:, :, 0] + r_[:, :, 1], r_[:, :, 2])
+                    for S in range(3):
+                        ph[dy * 2 + dx, :, :, R, S] = cols[S]
+        bl.add_conv("out2p", ph.reshape(4 * wo.shape[0], wo.shape[1], 3, 3).float(), torch.zeros(4 * wo.shape[0]))
     bl.add_conv("bin0", *fold_conv_bn(sd, "decoder.binarize.0", "decoder.binarize.1"))
     # ConvTranspose2d(64,64,2,2)+BN -> 1x1 GEMM, N index = (dy*2+dx)*64 + co
     wt, bt = fold_conv_bn(sd, "decoder.binarize.3", "decoder.binarize.4", transposed=True)  # [ci, co, 2, 2]

@@ -5,7 +5,7 @@
 #   3. rocprofv3 --kernel-trace --stats of the default bench (timed legs only)      -> gpurun_out/<tag>/kernel_stats.csv, gaps.txt
 #   4. separate PMC passes: FETCH_SIZE, WRITE_SIZE (-> pmc_summary.json), MFMA busy (-> mfma_busy.json)
 set -x
-T=${1:-r02}
+T=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$T
 mkdir -p $O
