@@ -454,7 +454,8 @@ class HipRunner:
         if self.rec is not None and "det" in stages and "cls" not in stages:
             from pdf_table_amd.pipeline import OcrTablePipeline
             self.pipe = OcrTablePipeline.from_engine(eng, self.stage, self.rec, self.layout, self.tsr, overlap_rec=False,
-                                                     aux_layout=bool(args.aux_stream), tsr_on_aux=bool(args.aux_stream))
+                                                     aux_layout=bool(args.aux_stream), tsr_on_aux=bool(args.aux_stream),
+                                                     lookahead=int(os.environ.get("PT_PIPE_LOOKAHEAD", "1")))
         self.rec_boxes = None        # detection boxes of the last post-processed step: what the recogniser reads
         self.trace = {} if os.environ.get("PT_BENCH_TRACE") else None
         for s_ in (self.rec_stream, self.aux):
@@ -500,8 +501,17 @@ class HipRunner:
                     c["layout"] += len(r.layout_result or ())
                     c["cells"] += sum(len(t["polygons"]) for t in (r.table_structure_result or ()))
         if self.trace is not None:
+            try:
+                hs = self.torch.cuda.host_memory_stats()
+                self.trace["pinned_allocs_so_far"] = {k_: hs[k_] for k_ in hs if "num_host_alloc" in k_ or "num_host_free" in k_ or "host_alloc_time.total" in k_ or "allocated_bytes.current" in k_ or "reserved_bytes.current" in k_}
+            except Exception:      # noqa: BLE001
+                pass
             for k_, v_ in self.pipe.metric["host_seconds"].items():
                 self.trace[k_] = self.trace.get(k_, 0.0) + v_
+            self.trace["det_boxes_parts"] = {a: round(b, 3) for a, b in getattr(self.stage, "timing", {}).items()}
+            for key in ("gpu_ms_inside_phases", "gpu_ms_between_phases"):
+                if key in self.pipe.metric:
+                    self.trace[key + f"[{steps} steps]"] = {a: round(b, 1) for a, b in self.pipe.metric[key].items()}
         return c
 
     def run_private(self, steps, count=False, stages=None):
@@ -891,7 +901,7 @@ def main(argv=None):
         prof = runner.eng.profile_read()
         runner.eng.profile_enable(False)
         if runner.trace is not None and rank == 0:
-            print("[bench trace] host seconds over warm-up + timed steps:", {k: round(v, 3) for k, v in runner.trace.items()},
+            print("[bench trace] host seconds over warm-up + timed steps:", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in runner.trace.items()},
                   file=sys.stderr)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=None if stub else runner.dev)

@@ -114,7 +114,19 @@ class DetStage:
                                                 out_prob=buf[0], out_bitmap=buf[1])
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
-        return prob, bitmap, ev
+        # the bit-packed bitmap starts its way to pinned memory NOW, on the side stream behind the detector's last kernel: queued before
+        # any later copy of the compute stream.  Issued from boxes() (a step later) the copy could land behind the token-id / table-row
+        # copies of batches queued since -- the DMA engine serves its queue in order and those wait for kernels still to run: the host sat
+        # 15-50 ms per batch in that one 7 MB copy, bimodal from run to run (490 vs 580 pages/s through predict_stream)
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=pages.device, priority=-1)
+        hb = self._pinned(("bm", slot), bitmap.shape, torch.int32)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            hb.copy_(bitmap, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        return prob, bitmap, (ev, done, hb)
 
     def _pinned(self, key, shape, dtype):
         t = self._pin.get(key)
@@ -130,18 +142,33 @@ class DetStage:
         cfg = self.cfg
         n, nh, nw = prob.shape
         if self.side is None:
-            self.side = torch.cuda.Stream(device=prob.device)
-        hb = self._pinned("bm", bitmap.shape, torch.int32)
-        with torch.cuda.stream(self.side):
-            if ev is not None:
-                self.side.wait_event(ev)
-            else:
-                self.side.wait_stream(torch.cuda.current_stream())
-            hb.copy_(bitmap, non_blocking=True)
-        self.side.synchronize()
+            # HIGH priority: the bitmap copy and the box-score kernel are a few hundred microseconds of work the host WAITS for while the
+            # compute stream holds one or two batches of queued kernels; on a normal-priority stream they could land on a hardware queue
+            # shared with that backlog and sit behind it (measured: 20 ms vs 60 ms per 64 pages in this call, bimodal from run to run --
+            # the difference between 490 and 580 pages/s through predict_stream)
+            self.side = torch.cuda.Stream(device=prob.device, priority=-1)
+        import time as _t
+        tm = self.__dict__.setdefault("timing", {"copy": 0.0, "cand": 0.0, "score": 0.0, "final": 0.0})
+        t0 = _t.perf_counter()
+        if isinstance(ev, tuple):           # forward() already sent the bitmap on its way
+            ev, done, hb = ev
+            done.synchronize()
+        else:
+            hb = self._pinned("bm", bitmap.shape, torch.int32)
+            with torch.cuda.stream(self.side):
+                if ev is not None:
+                    self.side.wait_event(ev)
+                else:
+                    self.side.wait_stream(torch.cuda.current_stream())
+                hb.copy_(bitmap, non_blocking=True)
+            self.side.synchronize()
         bm = hb.numpy()
+        t1 = _t.perf_counter()
+        tm["copy"] += t1 - t0
         # contour candidates of all pages: one call, pages on threads inside the library (no Python per page)
         cand, counts = E.db_candidates_batch(bm, cfg.max_candidates, cfg.min_size, self.workers)
+        t2 = _t.perf_counter()
+        tm["cand"] += t2 - t1
         tot = int(counts.sum())
         cap = cand.shape[1]
         valid = np.arange(cap)[None, :] < counts[:, None]                 # [n, cap]
@@ -153,7 +180,16 @@ class DetStage:
             ab[:, 1:] = cand[valid]
             with torch.cuda.stream(self.side):
                 scores[valid] = self.eng.det_box_scores(prob, allb.to(prob.device, non_blocking=True)).cpu().numpy()
+        t3 = _t.perf_counter()
+        tm["score"] += t3 - t2
         # score gate, unclip, second rectangle, rescale (+ filter_tag_det_res for the db_pp flavour), again in one call
+        try:
+            return self._finalize(cand, scores, counts, nh, nw, src_hw)
+        finally:
+            tm["final"] += _t.perf_counter() - t3
+
+    def _finalize(self, cand, scores, counts, nh, nw, src_hw):
+        cfg = self.cfg
         return E.db_finalize_batch(cand, scores, counts, (nh, nw), src_hw, cfg.box_thresh, cfg.unclip_ratio, cfg.min_size,
                                    cfg.post, filter_tag=cfg.flavour != "db", n_threads=self.workers)
 

@@ -17,6 +17,7 @@ logged, never silent.
 from __future__ import annotations
 
 import contextlib
+import os
 import logging
 import time
 from dataclasses import dataclass, field
@@ -59,12 +60,12 @@ class OcrTablePipeline:
                  tsr_task_path: Optional[str] = None, layout_model: str = "picodet", layout_task_type: str = "en",
                  layout_task_path: Optional[str] = None, text_orientation: bool = False,
                  orientation_task_path: Optional[str] = None, table_html: bool = False, overlap_rec: bool = True,
-                 rotate_upside_down: bool = True, aux_layout: bool = False, tsr_on_aux: bool = False, **kwargs):
+                 rotate_upside_down: bool = True, aux_layout: bool = False, tsr_on_aux: bool = False, lookahead: int = 1, **kwargs):
         self.engine = HipEngine(device)
         # predict_stream() schedule switches: layout / the Lore processor on an auxiliary stream beside the main one.  Off: ONE compute
         # stream measured faster (the weight-stationary cluster LSTM wants the GPU to itself, and concurrent small kernels slowed the
         # large ones: 500 vs 590 pages/s on 64-page batches), at the price of results arriving three batches behind instead of two
-        self.aux_layout, self.tsr_on_aux = aux_layout, tsr_on_aux
+        self.aux_layout, self.tsr_on_aux, self.lookahead = aux_layout, tsr_on_aux, lookahead
         # the recogniser of a page batch runs on a second stream beside the layout and table-structure stages of the same
         # batch (every stage owns its arena inside the engine); the results do not depend on it.  The weight-stationary
         # cluster LSTM needs the whole GPU to itself (co-resident workgroups), so an overlapping pipeline runs the
@@ -115,7 +116,7 @@ class OcrTablePipeline:
 
     @classmethod
     def from_engine(cls, engine: HipEngine, det_stage: DetStage, rec_stage, layout_stage=None, tsr_stage=None, table_html: bool = False,
-                    overlap_rec: bool = False, aux_layout: bool = False, tsr_on_aux: bool = False) -> "OcrTablePipeline":
+                    overlap_rec: bool = False, aux_layout: bool = False, tsr_on_aux: bool = False, lookahead: int = 1) -> "OcrTablePipeline":
         """The façade over an engine whose weights are ALREADY loaded -- e.g. packed once on rank 0, broadcast over RCCL and loaded from
         device memory on every rank (dist_utils.broadcast_blob, ``bench.py --gpus N``) -- and over stage objects the caller built on it.
         ``predict()`` / ``predict_stream()`` are the same code as after the ordinary constructor."""
@@ -123,6 +124,7 @@ class OcrTablePipeline:
         self = cls.__new__(cls)
         self.engine, self.overlap_rec, self.rotate_upside_down, self._rec_stream = engine, overlap_rec, True, None
         self.table_html, self.orientation_task, self.aux_layout, self.tsr_on_aux = table_html, None, aux_layout, tsr_on_aux
+        self.lookahead = lookahead
         self.text_detector = types.SimpleNamespace(_stage=det_stage)
         self.text_recognizer = types.SimpleNamespace(_stage=rec_stage)
         self.layout_task = None if layout_stage is None else types.SimpleNamespace(_stage=layout_stage, detect_pages=layout_stage)
@@ -251,17 +253,17 @@ class OcrTablePipeline:
         The reference runs a page's stages back to back and waits for each (ocr_system_task.py:549-734); ``predict()`` keeps
         that order per batch.  Here batch k's device work is queued while the host still works on the batches before it:
 
-            step k:  queue layout(k) and detection(k); recognition(k-1) and the table detector + decode (k-1) on the boxes /
-                     regions the host produced at the end of step k-1
-                     batch k-2: cell counts from pinned memory -> queue the Lore processor over its cells
-                     host: texts and tables of batch k-3 (CTC collapse, result shaping, HTML)  -> yield
-                     host: boxes of batch k (contours, box scores, unclip, reading order), layout decode + NMS of batch k
+            step k:  queue layout(k) and detection(k); recognition(k-a) and the table detector + decode (k-a) on the boxes / regions
+                     the host produced for batch k-a
+                     batch k-2a: cell counts from pinned memory -> queue the Lore processor over its cells
+                     host: texts and tables of batch k-2a-1 (CTC collapse, result shaping, HTML)  -> yield
+                     host: boxes of batch k-a+1 (contours, box scores, unclip, reading order), its layout decode + NMS
 
-        on ONE compute stream (copies ride on their own streams behind events): the GPU queue always holds at least one batch of
-        work while the host decodes, and nothing the host waits for was queued in the same step.  Results arrive three batches
-        behind the input; the generator drains at the end.  ``tsr_on_aux=True`` (constructor) runs the processor on an auxiliary
-        stream in the collect step instead -- two batches of latency, but measured slower (concurrent small kernels beside the
-        cluster LSTM and the large convolutions); ``aux_layout=True`` does the same for the layout network.
+        on ONE compute stream (copies ride on their own streams behind events), with a = ``lookahead`` (constructor, default 1: results
+        arrive three batches behind the input; a = 2 lets the enqueue thread run two steps ahead of the GPU at five batches of latency);
+        the generator drains at the end.  ``tsr_on_aux=True`` runs the processor on an auxiliary stream in the collect step
+        instead (a = 1, two batches of latency, measured slower: concurrent small kernels beside the cluster LSTM and the large
+        convolutions); ``aux_layout=True`` does the same for the layout network.
         ``table_boxes``: optional iterable aligned with ``batches`` (per batch: per-page int [k, 4] regions).  The text-line
         orientation vote needs a second, dependent detection pass per page and is not pipelined: use ``predict()`` for it."""
         if self.orientation_task is not None:
@@ -405,45 +407,81 @@ class OcrTablePipeline:
                                       table_structure_result=None if tsr is None else tsr[k]))
             return out
 
+        gpu_marks = [] if os.environ.get("PT_PIPE_GPU_TRACE") else None      # diagnostics: (phase, begin event, end event) on the main stream
+
         def timed(name, fn, *a):
             t0 = time.perf_counter()
-            r = fn(*a)
+            if gpu_marks is not None and name in ("queue_first", "queue_second", "process_tables"):
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(main)
+                r = fn(*a)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(main)
+                gpu_marks.append((name, e0, e1))
+            else:
+                r = fn(*a)
             host[name] += time.perf_counter() - t0
             return r
 
         # stages of the software pipeline a batch walks through, one per step: [0] layout + detection queued, [1] host halves done,
         # recognition + table decode queued, [2] (single-stream schedule only) processor queued, then collected and yielded
         depth = 2 if (tsr_on_aux or not staged_tsr) else 3
-        inflight: List[Optional[dict]] = [None] * depth
+
+        # Schedule.  Batch j walks through: first (layout + detection queued) at step j, host halves at the END of step j + a - 1, second
+        # (recognition + table decode queued) at step j + a, processor at step j + 2a, collect at step j + 2a + 1, with a = self.lookahead.
+        # a = 1 (default): results three batches behind the input.  a = 2: every wait of the host targets device work queued two steps
+        # earlier, so the enqueue thread may run two steps ahead of the GPU (five batches of latency) -- built while hunting a 490-vs-580
+        # pages/s run-to-run bimodality; the cause turned out to be a late-issued 7 MB copy stuck behind other copies on the DMA engine
+        # (DetStage.forward), and with that fixed a = 1 measures 587-592 against 579-583 for a = 2 (one more drain step in 20).
+        a_ = max(1, int(getattr(self, "lookahead", 1)))
+        if tsr_on_aux or not staged_tsr:
+            a_ = 1
+        flight: Dict[int, dict] = {}
         k = 0
 
-        def advance(cur):
-            # every enqueue of the step first, then the host work that may have to wait for the GPU: the queue never runs dry
-            # while the host sits in the detection post-process (its box scores come back from a side stream)
-            if inflight[0] is not None:
-                timed("queue_second", queue_second, inflight[0])
-            if depth == 3 and inflight[1] is not None:
-                timed("process_tables", process_tables, inflight[1])
-            done = inflight[depth - 1]
-            res = timed("collect", collect, done) if done is not None else None
+        def step(j: int, cur):
+            """one step of the schedule at stream position j (cur: the batch that arrived, or None while draining)"""
             if cur is not None:
-                timed("host_halves", host_halves, cur)
-            inflight[1:] = inflight[:-1]
-            inflight[0] = cur
+                flight[j] = cur
+            st = flight.get(j - a_)
+            if st is not None:
+                timed("queue_second", queue_second, st)
+            if depth == 3:
+                st = flight.get(j - 2 * a_)
+                if st is not None:
+                    timed("process_tables", process_tables, st)
+            done = flight.pop(j - 2 * a_ - (1 if depth == 3 else 0), None)
+            res = timed("collect", collect, done) if done is not None else None
+            st = flight.get(j - (a_ - 1))
+            if st is not None and "boxes" not in st:
+                timed("host_halves", host_halves, st)
             return res
 
         for batch in batches:
             cur = timed("queue_first", queue_first, batch, k)
+            res = step(k, cur)
             k += 1
-            res = advance(cur)
             if res is not None:
                 yield res
-        for _ in range(depth):
-            res = advance(None)
+        j = k
+        while flight:
+            res = step(j, None)
+            j += 1
             if res is not None:
                 yield res
         self.metric = {"use_time": time.time() - t_start, "batches": k, "text_recognition": {"total": total_lines},
                        "host_seconds": host}
+        if gpu_marks:
+            torch.cuda.synchronize(dev)
+            busy: Dict[str, float] = {}
+            idle: Dict[str, float] = {}
+            for i, (name, e0, e1) in enumerate(gpu_marks):
+                busy[name] = busy.get(name, 0.0) + e0.elapsed_time(e1)
+                if i:
+                    key = gpu_marks[i - 1][0] + "->" + name
+                    idle[key] = idle.get(key, 0.0) + gpu_marks[i - 1][2].elapsed_time(e0)
+            self.metric["gpu_ms_inside_phases"] = busy         # device time between the first and the last launch of a phase
+            self.metric["gpu_ms_between_phases"] = idle        # device time between two phases' launches: the queue was empty (or copies ran)
 
     def _attach_html(self, tsr, tb, boxes, texts):
         """cells (page pixels since the stage shifts them) x the page's text lines (page pixels) -> HTML per table"""
