@@ -967,8 +967,6 @@ def main(argv=None):
             leg = runner.mtl_tabnet_leg()
             if rank == 0 and leg is not None:
                 out["mtl_tabnet"] = leg
-        if rank == 0 and len(runner.stages) > 1 and not args.no_post:
-            out["one_eighth_host"] = one_eighth_host_leg(args, out["value"])
     if rank == 0:
         if not stub and world == 1 and not args.no_cpu_baseline and "det" in runner.stages:
             r = runner
@@ -976,6 +974,14 @@ def main(argv=None):
             out["cpu_baseline"] = cpu_baseline(r.sd, r.pages_np[:2], r.cfg, r.csd if r.rec is not None else None,
                                                tsr=(r.lsd, r.psd, r.table_boxes, r.tables_per_page) if r.tsr is not None else None,
                                                layout=r.ysd if r.layout is not None else None, gpu=gpu)
+        if not stub and not args.no_extra_legs and world == 1 and len(runner.stages) > 1 and not args.no_post:
+            # last: the child needs the GPU's memory, so this process gives its engine (activation arenas, weights) and torch's cache back first
+            try:
+                runner.eng.close()
+                runner.torch.cuda.empty_cache()
+            except Exception:      # noqa: BLE001
+                pass
+            out["one_eighth_host"] = one_eighth_host_leg(args, out["value"])
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
