@@ -577,7 +577,7 @@ class HipRunner:
             t0 = time.perf_counter()
             with self._on(self.aux):
                 lay = layout.forward(self.pages) if layout is not None else None  # resize, LCNet/CSP-PAN/PicoHead, candidates (async)
-            cur = self.stage.forward(self.pages, slot=k & 1) if "det" in stages else None
+            cur = self.stage.forward(self.pages, slot=k & 1, early_copy=len(stages) > 1) if "det" in stages else None
             rec_ids = None
             if rec is not None:
                 quads = self.gt_quads if (args.gt_chain or self.rec_boxes is None) else self.rec_boxes

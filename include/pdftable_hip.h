@@ -426,6 +426,11 @@ int pt_op_copy_channels(pt_engine* e, const uint16_t* d_src, long long npix, int
                         int n, pt_stream stream);
 int pt_op_upsample_nearest(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int C, int factor, uint16_t* d_out, pt_stream stream);
 int pt_op_mul(pt_engine* e, const uint16_t* d_a, const uint16_t* d_b, uint16_t* d_out, long long n_elems, pt_stream stream);
+/* nbytes from src to dst (16-byte aligned) by a kernel on `stream`; either side may be PINNED HOST memory (hipHostMalloc / torch pin_memory: mapped into
+ * the device's address space).  For the few small transfers a host thread WAITS for while the compute stream holds a backlog: an asynchronous
+ * hipMemcpy goes through a DMA engine's in-order queue and can sit there behind copies of other streams that wait for kernels still to run
+ * (measured: 15-50 ms in a 7 MB copy); a kernel on a high-priority stream cannot.  Replaces nothing in the reference (torch's .cpu()). */
+int pt_copy_bytes(pt_engine* e, const void* src, void* dst, long long nbytes, pt_stream stream);
 /* Sequence operators (the attention / LayerNorm / soft-max blocks of SVTR-type recognisers such as PP-OCRv4 rec, the recogniser
  * fix_model_names() selects: model/ocr_pdf/configuration_ocr_document.py:138-141).  Token rows bf16 [rows, c_pad], the first c channels real.
  * pt_op_layernorm: LayerNormalization over the channels (biased variance, eps inside the root), padded channels written as zeros.

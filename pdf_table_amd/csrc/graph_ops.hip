@@ -216,6 +216,13 @@ __global__ __launch_bounds__(64) void attention_rows_kernel(const bf16_t* __rest
   }
 }
 
+// byte copy by the compute units; either pointer may be pinned host memory (mapped into the device's address space)
+__global__ __launch_bounds__(256) void copy_bytes_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long long n16, const unsigned char* __restrict__ src_tail,
+                                                         unsigned char* __restrict__ dst_tail, int tail) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
+  if (blockIdx.x == 0 && (int)threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+
 inline unsigned grid_for(long long n) {
   const long long g = (n + 255) / 256;
   return (unsigned)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
@@ -298,6 +305,18 @@ int pt_op_upsample_nearest(pt_engine* e, const uint16_t* d_in, int B, int H, int
   PT_REQUIRE(e && d_in && d_out && C % 8 == 0 && factor >= 1 && B > 0 && H > 0 && W > 0, "pt_op_upsample_nearest: bad arguments");
   hipLaunchKernelGGL(upsample_kernel, dim3(grid_for((long long)B * H * factor * W * factor * (C / 8))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      d_in, d_out, B, H, W, C, factor);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_copy_bytes(pt_engine* e, const void* src, void* dst, long long nbytes, pt_stream stream) {
+  PT_REQUIRE(e && src && dst && nbytes > 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "pt_copy_bytes: null or unaligned pointer");
+  const long long n16 = nbytes / 16;
+  const int tail = (int)(nbytes - n16 * 16);
+  long long g = (n16 + 255) / 256;
+  g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
+  hipLaunchKernelGGL(copy_bytes_kernel, dim3((unsigned)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const uint4*>(src),
+                     reinterpret_cast<uint4*>(dst), n16, reinterpret_cast<const unsigned char*>(src) + n16 * 16, reinterpret_cast<unsigned char*>(dst) + n16 * 16, tail);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }

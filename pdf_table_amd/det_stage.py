@@ -11,6 +11,8 @@ import os
 from dataclasses import dataclass
 from typing import List, Optional
 
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -89,7 +91,7 @@ class DetStage:
         pass
 
     # ---- device half -----------------------------------------------------------------------------------
-    def forward(self, pages: torch.Tensor, slot: int = 0):
+    def forward(self, pages: torch.Tensor, slot: int = 0, early_copy: bool = False):
         """pages uint8 [n,h,w,3] on the GPU -> (prob f32 [n,nh,nw], bitmap i32 [n,nh,nw/32], event).
         Asynchronous on the current stream; outputs live in per-slot buffers so that the host half of batch
         k (on the side stream) can overlap the device half of batch k+1."""
@@ -114,10 +116,18 @@ class DetStage:
                                                 out_prob=buf[0], out_bitmap=buf[1])
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
-        # the bit-packed bitmap starts its way to pinned memory NOW, on the side stream behind the detector's last kernel: queued before
-        # any later copy of the compute stream.  Issued from boxes() (a step later) the copy could land behind the token-id / table-row
-        # copies of batches queued since -- the DMA engine serves its queue in order and those wait for kernels still to run: the host sat
-        # 15-50 ms per batch in that one 7 MB copy, bimodal from run to run (490 vs 580 pages/s through predict_stream)
+        if not early_copy:
+            return prob, bitmap, ev
+        # early_copy (callers that queue OTHER stages' work behind this detection before they call boxes(): predict_stream, the four-stage
+        # bench loop): the bit-packed bitmap starts its way to pinned memory NOW, on the side stream behind the detector's last kernel --
+        # queued before any later copy.  Issued from boxes() (a step later) the 7 MB copy could land behind the token-id / table-row copies
+        # of batches queued since: a DMA engine serves its queue in order and those wait for kernels still to run; the host sat 15-50 ms
+        # per batch in that one copy, bimodal from run to run (490 vs 580 pages/s through predict_stream).  Which hardware queue a stream's
+        # work uses is the runtime's choice (4 by default for all streams of a process): a stream of its own for this copy, a third
+        # high-priority stream for the box scores and one shared copy stream per engine all measured SLOWER (525-560 pages/s) than riding
+        # on the box-score stream; a kernel copy into the mapped pinned buffer (pt_copy_bytes) never waits, but 7 MB of PCIe writes from
+        # high-priority workgroups slowed the compute stream by 10 %.  A detection-only loop calls boxes(k-1) AFTER forward(k): there the
+        # early copy of batch k would make the scores of batch k-1 wait for detection k, and nothing else is queued: early_copy=False.
         if self.side is None:
             self.side = torch.cuda.Stream(device=pages.device, priority=-1)
         hb = self._pinned(("bm", slot), bitmap.shape, torch.int32)
@@ -153,6 +163,8 @@ class DetStage:
         if isinstance(ev, tuple):           # forward() already sent the bitmap on its way
             ev, done, hb = ev
             done.synchronize()
+            if self.side is None:
+                self.side = torch.cuda.Stream(device=prob.device, priority=-1)
         else:
             hb = self._pinned("bm", bitmap.shape, torch.int32)
             with torch.cuda.stream(self.side):
@@ -179,6 +191,8 @@ class DetStage:
             ab[:, 0] = np.repeat(np.arange(n, dtype=np.float32), counts)
             ab[:, 1:] = cand[valid]
             with torch.cuda.stream(self.side):
+                if isinstance(ev, torch.cuda.Event):
+                    self.side.wait_event(ev)
                 scores[valid] = self.eng.det_box_scores(prob, allb.to(prob.device, non_blocking=True)).cpu().numpy()
         t3 = _t.perf_counter()
         tm["score"] += t3 - t2

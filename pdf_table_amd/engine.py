@@ -668,6 +668,12 @@ class HipEngine:
         L.check(self.lib.pt_op_copy_channels(self._h, _ptr(src), npix, src.shape[-1], src_coff, _ptr(dst), dst.shape[-1], dst_coff, n, self._stream()),
                 "pt_op_copy_channels")
 
+    def copy_bytes(self, src: torch.Tensor, dst: torch.Tensor):
+        """dst <- src (same byte count, contiguous) by a kernel on the current stream; either tensor may live in pinned host memory"""
+        nb = src.numel() * src.element_size()
+        assert nb == dst.numel() * dst.element_size() and src.is_contiguous() and dst.is_contiguous()
+        L.check(self.lib.pt_copy_bytes(self._h, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), nb, self._stream()), "pt_copy_bytes")
+
     def op_upsample(self, x: torch.Tensor, f: int) -> torch.Tensor:
         self._chk(x, torch.bfloat16, "x")
         B, H, W, Cc = x.shape

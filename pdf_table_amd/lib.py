@@ -116,6 +116,7 @@ def _proto(lib):
         "pt_op_copy_channels": (i, [vp, vp, C.c_longlong, i, i, vp, i, i, i, vp]),
         "pt_op_upsample_nearest": (i, [vp, vp, i, i, i, i, i, vp, vp]),
         "pt_op_mul": (i, [vp, vp, vp, vp, C.c_longlong, vp]),
+        "pt_copy_bytes": (i, [vp, vp, vp, C.c_longlong, vp]),
         "pt_op_layernorm": (i, [vp, vp, C.c_longlong, i, i, vp, vp, C.c_float, vp, vp]),
         "pt_op_softmax": (i, [vp, vp, C.c_longlong, i, i, vp, vp, vp]),
         "pt_op_attention": (i, [vp, vp, i, i, i, i, i, C.c_float, vp, i, vp]),

@@ -275,11 +275,12 @@ class OcrTablePipeline:
         if self.overlap_rec and self._rec_stream is None:
             self._rec_stream = torch.cuda.Stream(device=dev)
             self.engine.set_lstm_cluster(False)      # the recogniser shares the GPU with the other stages (see __init__)
-        if getattr(self, "_aux_stream", None) is None:
+        need_aux = bool(getattr(self, "aux_layout", False) or getattr(self, "tsr_on_aux", False))
+        if need_aux and getattr(self, "_aux_stream", None) is None:      # every extra stream competes for the few hardware queues
             self._aux_stream = torch.cuda.Stream(device=dev)
         # overlap_rec=False: the recogniser stays on the main stream behind detection (weight-stationary cluster LSTM, the GPU
         # to itself) -- with nothing in this schedule waiting on the newest work, that measures faster than sharing the CUs
-        rec_s, aux = (self._rec_stream if self.overlap_rec else main), self._aux_stream
+        rec_s, aux = (self._rec_stream if self.overlap_rec else main), getattr(self, "_aux_stream", None)
         det: DetStage = self.text_detector._stage
         rec_stage = self.text_recognizer._stage
         lay_stage = self.layout_task._stage if self.layout_task is not None else None
@@ -311,7 +312,7 @@ class OcrTablePipeline:
                     pages_t.record_stream(aux)
                 else:       # one compute stream: per-kernel durations are those of the kernel alone (what bench.py's roofline divides by)
                     st["lay"] = lay_stage.forward(pages_t)
-            st["det"] = det.forward(pages_t, slot=k & 1)
+            st["det"] = det.forward(pages_t, slot=k & 1, early_copy=True)
             return st
 
         def host_halves(st):

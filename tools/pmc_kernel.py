@@ -10,6 +10,7 @@ from collections import defaultdict
 
 acc = defaultdict(lambda: defaultdict(float))
 disp = defaultdict(set)
+passes = defaultdict(lambda: defaultdict(set))          # a counter that sits in several passes (GRBM_GUI_ACTIVE) is averaged over them
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
     with open(f, newline="") as fh:
         for r in csv.DictReader(fh):
@@ -18,14 +19,18 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), r
             k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][-60:]
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             disp[k].add(r["Dispatch_Id"])
+            passes[k][r["Counter_Name"]].add(f)
 out = {}
 for k, c in acc.items():
     n = len(disp[k])
-    d = {name: v / n for name, v in c.items()}
+    d = {name: v / n / len(passes[k][name]) for name, v in c.items()}
     d["dispatches"] = n
     gui = d.get("GRBM_GUI_ACTIVE", 0.0) / 8
     if gui and "SQ_ACTIVE_INST_VALU" in d:
-        d["valu_active_frac_of_simd_cycles"] = d["SQ_ACTIVE_INST_VALU"] / (gui * 1024)      # cycles a SIMD's VALU executes / available SIMD cycles
+        # SQ_ACTIVE_INST_* and SQ_WAVE_CYCLES count quad-cycles (4 clocks); cross-check: SQ_INSTS_VALU x 4 clocks per wave64 instruction
+        d["valu_active_frac_of_simd_cycles"] = 4.0 * d["SQ_ACTIVE_INST_VALU"] / (gui * 1024)
+        if "SQ_INSTS_VALU" in d:
+            d["valu_issue_frac_from_inst_count"] = 4.0 * d["SQ_INSTS_VALU"] / (gui * 1024)
     if d.get("SQ_WAVES") and "SQ_INSTS_VALU" in d:
         d["valu_insts_per_wave"] = d["SQ_INSTS_VALU"] / d["SQ_WAVES"]
     if d.get("SQ_WAVE_CYCLES") and "SQ_WAIT_INST_ANY" in d:
