@@ -687,7 +687,11 @@ int upload_tiles(std::vector<int4>& host, int4* dev, hipStream_t s) {
 }
 
 int pick_split(int ntiles, int hw, int* kps) {
-  int ns = 2048 / (ntiles * HEADS > 0 ? ntiles * HEADS : 1);
+  // single-wave workgroups that stream their key slice with a handful of loads in flight: ~10 of them per SIMD are needed to cover the
+  // HBM latency (PT_MTL_SPLIT_TARGET waves in flight; 2048 = two per SIMD measured 1.8 TB/s on the key / value stream)
+  static int target = -1;
+  if (target < 0) { const char* ev = getenv("PT_MTL_SPLIT_TARGET"); target = ev ? atoi(ev) : 16384; }
+  int ns = target / (ntiles * HEADS > 0 ? ntiles * HEADS : 1);
   if (ns < 1) ns = 1;
   if (ns > 16) ns = 16;
   int per = ((hw + ns - 1) / ns + 31) / 32 * 32;

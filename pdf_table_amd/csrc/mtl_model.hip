@@ -230,6 +230,13 @@ int pt_mtl_backbone_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int
                    *lb = get(q + ".gc.lb"), *w3 = get(q + ".gc.w3"), *b3 = get(q + ".gc.b3");
     if (rc != PT_OK) return t3;
     const int hid = (int)w0->dims[0];
+    // the context kernels hold ctx[512] / hidden[64] in LDS and launch `planes` threads: a checkpoint with another gcb ratio or width must fail here
+    if (!(hid > 0 && hid <= 64 && planes <= 512 && (int)w0->dims[1] == planes && (int)w3->dims[0] == planes && (int)w3->dims[1] == hid)) {
+      pt_set_error("MtlTabNet backbone: context block '%s' has hidden %d / %u x %u weights for %d planes (built: hidden <= 64, planes <= 512)", q.c_str(), hid,
+                   w0->dims[0], w0->dims[1], planes);
+      rc = PT_ERR_FORMAT;
+      return t3;
+    }
     auto F = [](const PtTensor* t) { return reinterpret_cast<const float*>(t->d_ptr); };
     {
       PtProfScope ps(e, s, PT_PROF_OTHER, 0, "mtl gc context");

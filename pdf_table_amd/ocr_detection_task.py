@@ -135,6 +135,10 @@ class OcrDetectionTask(BaseInferTask):
             return None
         if os.path.isfile(tp) and tp.endswith(".onnx"):
             return tp
+        # a directory: the ONNX route is the reference's for model="db_pp" (BaseInferTask._prepare_onnx_mode); for model="db" with a
+        # pytorch_model.pt beside an exported graph the checkpoint wins unless the caller asks (use_onnx=True)
+        if self.model == "db" and not self.kwargs.get("use_onnx", False) and os.path.isfile(os.path.join(tp, "pytorch_model.pt")):
+            return None
         for cand in ("model.onnx", "fp16_model.onnx", "inference.onnx"):
             if os.path.isfile(os.path.join(tp, cand)):
                 return os.path.join(tp, cand)

@@ -138,6 +138,7 @@ class RecStage:
         # processor_ocr_recognition.py:131-145 (class 1 has no entry there either)
         first = 2 if chunking else 1
         self.label = {i + first: ch for i, ch in enumerate(vocab)}
+        self._degenerate = {}       # id(pinned ids buffer) -> indices of lines whose crop resizes to width 0 (see start())
 
     def ids(self, pages: torch.Tensor, boxes_per_page: Sequence[np.ndarray]):
         lines = build_lines(boxes_per_page)
@@ -158,6 +159,11 @@ class RecStage:
             host.copy_(ids, non_blocking=True)
             done = torch.cuda.Event()
             done.record()
+            # a crop more than 32 times as high as wide resizes to width 0: cv2.resize raises in the reference and the system path turns that
+            # into '' (ocr_system_task.py:275-283); the engine decodes an all-padding line there, so finish() blanks these lines
+            bad = (lines["crop_w"].astype(np.int64) * 32 < lines["crop_h"]) | (lines["crop_w"] <= 0) | (lines["crop_h"] <= 0)
+            if bad.any():
+                self._degenerate[id(host)] = np.nonzero(bad)[0]
         return ids, len(lines), [len(b) for b in boxes_per_page], host, done
 
     def finish(self, state) -> List[List[str]]:
@@ -169,6 +175,8 @@ class RecStage:
             toks = ctc_collapse(host.numpy())
         self.eng.check()          # the batch has executed: surface device-side failures of it
         texts = ["".join(self.label.get(t, "") for t in row) for row in toks]
+        for i in self._degenerate.pop(id(host), ()):
+            texts[int(i)] = ""
         out, o = [], 0
         for k in per_page:
             out.append(texts[o:o + k])
