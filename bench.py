@@ -15,8 +15,11 @@ Pages are sharded across ranks (weak scaling: fixed pages per rank); there is no
 Chaining.  The detector's checkpoint is random-init except for one hand-built channel that detects the synthetic pages'
 text (synth_weights._db_text_signal), so detection yields ~75 boxes per page and THOSE boxes are what the recogniser
 crops and reads -- software-pipelined: the recogniser of step k works on the boxes whose host post-process finished
-during step k-1 (the bench's pages are the same every step).  The layout and Lore nets are plain random-init, so the
-table regions of the table-structure stage are the page generator's ground truth (said so in ``config``).
+during step k-1 (the bench's pages are the same every step).  Layout -> table structure is chained the same way: the
+layout checkpoint is the seeded random PicoDet with the stride-64 branch of its head fitted to the generator's pages
+(tools/fit_layout_head.py, picodet_state_dict(table_head=True): a workload device that memorises pages 0..511, not a
+detector), and the table-structure stage crops the regions the layout stage labels "table" with score >= 0.2
+(get_layout_by_type, ocr_system_task.py:184-198).  --gt-tables feeds it the generator's rectangles instead (rounds 1-2).
 
 Extra objects on the JSON line:
   roofline        the dominant kernel class (3x3 MFMA convolutions of all stages), HIP-event timed inside the timed region,
@@ -76,6 +79,9 @@ def parse_args(argv=None):
                          "(per-kernel HIP-event durations then include contention, so the roofline object reads low)")
     ap.add_argument("--gt-chain", action="store_true",
                     help="diagnostic: feed the recogniser the generator's text-line rectangles (round-1 behaviour)")
+    ap.add_argument("--gt-tables", action="store_true",
+                    help="diagnostic: feed the table-structure stage the generator's table rectangles (grown by 8 px) instead of the "
+                         "layout stage's own 'table' regions (rounds 1-2 behaviour)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "f16x2"],
                     help="arithmetic mode of the TIMED region (bf16x3: the tolerance mode as the headline; the default line "
                          "reports it as tolerance_mode)")
@@ -393,11 +399,14 @@ class HipRunner:
                 eng.set_lstm_cluster(False)       # the cluster LSTM needs the GPU to itself (pt_engine_set_lstm_cluster)
 
         self.layout = self.ysd = None
+        self.layout_chain = False
         if "layout" in stages:
             from pdf_table_amd.layout_stage import LayoutStage, PicodetConfig
             from pdf_table_amd.synth_weights import picodet_state_dict
             from pdf_table_amd.weights import pack_picodet
-            self.ysd = picodet_state_dict(seed=4, num_classes=5) if first else None
+            # layout -> table structure chained by the layout stage's own "table" regions: needs the fitted head (which knows pages 0..511)
+            self.layout_chain = "tsr" in stages and not args.gt_tables and (world * DISTINCT) <= 512 and PAGE == 1024
+            self.ysd = picodet_state_dict(seed=4, num_classes=5, table_head=self.layout_chain) if first else None
             load(L.PT_MODEL_PICODET, lambda: pack_picodet(self.ysd, 5, x3=x3))
             self.layout = LayoutStage(eng, PicodetConfig(task_type="en"))
 
@@ -491,7 +500,9 @@ class HipRunner:
             return self.run_private(steps, count, stages)
         import itertools
         c = {"boxes": 0, "tok": 0, "cells": 0, "layout": 0, "cls_lines": 0, "rec_lines": 0}
-        tb = itertools.repeat(self.table_boxes, steps) if self.tsr is not None else None
+        # table regions: the layout stage's own (table_boxes=None: OcrTablePipeline._layout_table_boxes) unless --gt-tables / no fitted head
+        tb = itertools.repeat(self.table_boxes, steps) if self.tsr is not None and not self.layout_chain else None
+        c["tables"] = 0
         for res in self.pipe.predict_stream(itertools.repeat(self.pages, steps), table_boxes=tb):
             if count:
                 for r in res:
@@ -500,6 +511,7 @@ class HipRunner:
                     c["tok"] += sum(len(o["text"]) for o in r.ocr_result)
                     c["layout"] += len(r.layout_result or ())
                     c["cells"] += sum(len(t["polygons"]) for t in (r.table_structure_result or ()))
+                    c["tables"] += len(r.table_structure_result or ())
         if self.trace is not None:
             try:
                 hs = self.torch.cuda.host_memory_stats()
@@ -828,15 +840,21 @@ class HipRunner:
                             + "; weights are seeded random init"
                             + (" except one hand-built detector channel that finds the synthetic text (synth_weights._db_text_signal), "
                                "so detection -> recognition is chained by the detector's own boxes" if chained else "")
-                            + ("; the layout and Lore nets are plain random init, so the table regions are the page generator's "
-                               "ground truth" if "tsr" in stages else ""),
+                            + (("; layout -> table structure is chained by the layout stage's own regions: label 'table', score >= 0.2, cropped "
+                                "(the seeded PicoDet's stride-64 head branch is fitted to the generator's pages by tools/fit_layout_head.py -- it "
+                                "memorises these pages, it is not a trained detector); the Lore nets are plain random init"
+                                if self.layout_chain and self.uses_pipeline() else
+                                "; the layout and Lore nets are plain random init, so the table regions are the page generator's ground truth")
+                               if "tsr" in stages else ""),
                 "pages_per_step_per_gpu": PAGES_PER_STEP, "distinct_pages_per_gpu": DISTINCT, "page": [PAGE, PAGE],
                 "stages": stages, "parallelism": f"page-shard x{self.world}",
                 "text_lines_per_page_generated": self.gt_lines_per_page,
                 "text_lines_recognised_per_page": c["rec_lines"] / n,
                 "tokens_per_page": c["tok"] / n,
                 "boxes_per_page": c["boxes"] / n,
-                "tables_per_page": self.tables_per_page if "tsr" in stages else 0,
+                "tables_per_page": (c["tables"] / n if "tables" in c else self.tables_per_page) if "tsr" in stages else 0,
+                "tables_per_page_generated": self.tables_per_page if "tsr" in stages else 0,
+                "table_regions_from": ("layout stage" if self.layout_chain and self.uses_pipeline() else "page generator") if "tsr" in stages else None,
                 "layout_regions_per_page": c["layout"] / n,
                 "table_cells_per_page": c["cells"] / n,
                 "classified_lines_per_page": c["cls_lines"] / n,

@@ -22,8 +22,10 @@
 // the same kernels over positions 0..t of every sequence at every step -- the reference's own schedule.  Trained checkpoints never
 // emit <PAD> (it is the loss's ignore_index); seeded random weights do, and tests/test_gpu_mtl.py covers both paths.
 //
-// Kernels: every Linear is a 1x1 GEMM on conv_igemm_kernel (fp32 residual stream, hi/lo operands in BF16X3 like the rest of the
-// engine); mtl_ln_kernel (nn.LayerNorm, one wave per row); mtl_self_attn_kernel (one wave per (row, head): lane = key for the
+// Kernels: a Linear over <= 512 rows (every step of the KV-cached loops) is mtl_rowgemm_kernel + mtl_rowgemm_finish_kernel (split-K, operands
+// straight into the MFMA registers), over more rows (the key / value projection of the feature map, the re-decode mode) a 1x1 GEMM on
+// conv_igemm_kernel -- fp32 residual stream, hi/lo operands in BF16X3 like the rest of the engine; mtl_cross_decode_kernel (one query per table: the
+// structure loop's source attention as a pure key / value stream, fp32 on the VALU); mtl_ln_kernel (nn.LayerNorm, one wave per row); mtl_self_attn_kernel (one wave per (row, head): lane = key for the
 // scores, lane = channel for the weighted sum; fp32); mtl_cross_attn_kernel (the MFMA flash scheme of lore_processor.hip /
 // cvit_model.hip with d = 64: a wave = up to 32 queries of ONE table x one head, the keys optionally split over several waves
 // whose partial (max, sum, acc) triples mtl_cross_combine_kernel merges -- with one query per table and step, the split is what
@@ -31,6 +33,8 @@
 #include <limits.h>
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
 
 #include <string>
 #include <vector>
@@ -68,6 +72,14 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 __device__ __forceinline__ abf16x8 ld8(const bf16_t* p) { return *reinterpret_cast<const abf16x8*>(p); }
+__device__ __forceinline__ uint4 ldu4(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+// eight bf16 values of a 16-byte load -> fp32, in memory order
+__device__ __forceinline__ void unpack8(const uint4 u, float* f) {
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
 
 // out_enc = PositionalEncoding(feat) (:182-188): f3 fp32 [n * hw, 512] (NHWC = the reference's view(b, c, h*w).permute(0, 2, 1))
 // + pe[token] -> bf16 (hi | lo) rows; rows >= rows_valid are zero.  One wave per row.
@@ -331,6 +343,128 @@ __global__ __launch_bounds__(64) void mtl_cross_attn_kernel(const bf16_t* __rest
   }
 }
 
+// Source attention of the KV-cached structure loop: ONE query per table and step, so the work is a stream over that table's keys and values and nothing
+// else.  A workgroup = the 8 heads of one (table, key slice): wave = head, so the eight waves read the same 1 KB key rows and 1 KB value rows (the
+// MFMA kernel above, launched per head, reads 128-byte pieces 10 KB apart, its values two bytes at a time).  lane = (g = key within an octet, c = 8-channel
+// piece): 16-byte loads, 8 lanes cover the 128 bytes of a key's head slice; fp32 arithmetic on the VALU -- q . k over the lane's 8 channels, summed over the
+// 8 lanes of the group; p * v accumulated per lane; hi + lo operands are added before the products in BF16X3 (exact in fp32) -- one independent online
+// soft-max stream per g, merged at the end.  Output as mtl_cross_attn_kernel's: normalised rows (nsplit == 1) or (max, sum, accumulator) per key slice.
+template <int SPLIT>
+__global__ __launch_bounds__(512) void mtl_cross_decode_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, int koff, const int4* __restrict__ tiles,
+                                                              int hw, int keys_per_split, int nsplit, long long R, float* __restrict__ opart,
+                                                              float* __restrict__ mlpart, bf16_t* __restrict__ att) {
+  const int4 tile = tiles[blockIdx.x];
+  const int head = threadIdx.x >> 6, lane = threadIdx.x & 63, z = blockIdx.y;
+  const int g = lane >> 3, c = lane & 7;
+  const int tab = tile.x;
+  const long long qrow = tile.y;
+  constexpr int LOQ = D, qcs = SPLIT ? 2 * D : D, LOK = KVC, kcs = SPLIT ? 2 * KVC : KVC;
+  float qf[8];
+  {
+    const bf16_t* qp = q + qrow * qcs + head * DK + 8 * c;
+    unpack8(ldu4(qp), qf);
+    if (SPLIT) {
+      float t[8];
+      unpack8(ldu4(qp + LOQ), t);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[j] += t[j];
+    }
+  }
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const int kbeg = z * keys_per_split, kend = min(hw, kbeg + keys_per_split);
+  const bf16_t* kbase = kv + (size_t)tab * hw * kcs + koff + head * DK + 8 * c;
+  for (int k0 = kbeg; k0 < kend; k0 += 64) {
+    uint4 kh[8], vh[8], kl[8], vl[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int key = k0 + 8 * i + g;
+      const bf16_t* kp = kbase + (size_t)(key < kend ? key : kend - 1) * kcs;
+      kh[i] = ldu4(kp);
+      vh[i] = ldu4(kp + D);
+      if (SPLIT) {
+        kl[i] = ldu4(kp + LOK);
+        vl[i] = ldu4(kp + LOK + D);
+      }
+    }
+    float sc[8], mt = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float kf[8];
+      unpack8(kh[i], kf);
+      if (SPLIT) {
+        float t[8];
+        unpack8(kl[i], t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kf[j] += t[j];
+      }
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d = fmaf(qf[j], kf[j], d);
+      d += __shfl_xor(d, 1);
+      d += __shfl_xor(d, 2);
+      d += __shfl_xor(d, 4);
+      sc[i] = k0 + 8 * i + g < kend ? d : -INFINITY;
+      mt = fmaxf(mt, sc[i]);
+    }
+    if (mt > -INFINITY) {                       // else: this group's keys of the chunk are all past the slice
+      const float mn = fmaxf(m, mt);
+      const float scale = expf(m - mn);         // m == -inf: 0
+      l *= scale;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] *= scale;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float pv = expf(sc[i] - mn);      // masked keys: exp(-inf) = 0
+        l += pv;
+        float vf[8];
+        unpack8(vh[i], vf);
+        if (SPLIT) {
+          float t[8];
+          unpack8(vl[i], t);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) vf[j] += t[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(pv, vf[j], acc[j]);
+      }
+      m = mn;
+    }
+  }
+  // merge the eight streams (lane bits 3..5)
+  float mx = m;
+  mx = fmaxf(mx, __shfl_xor(mx, 8));
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  const float w = m == -INFINITY ? 0.f : expf(m - mx);
+  l *= w;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] *= w;
+#pragma unroll
+  for (int sh = 8; sh < 64; sh <<= 1) {
+    l += __shfl_xor(l, sh);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], sh);
+  }
+  if (g != 0) return;
+  if (nsplit == 1) {
+    bf16_t* op = att + qrow * qcs + head * DK + 8 * c;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) put(op + j, D, SPLIT, acc[j] / l);
+  } else {
+    const size_t slot = ((size_t)z * R + qrow) * HEADS + head;
+    float* op = opart + slot * DK + 8 * c;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) op[j] = acc[j];
+    if (c == 0) {
+      mlpart[slot * 2] = mx;
+      mlpart[slot * 2 + 1] = l;
+    }
+  }
+}
+
 // merges the key slices of mtl_cross_attn_kernel: out = sum_z e^(m_z - M) acc_z / sum_z e^(m_z - M) l_z.  thread = (row, channel)
 __global__ __launch_bounds__(512) void mtl_cross_combine_kernel(const float* __restrict__ opart, const float* __restrict__ mlpart, int nsplit, long long R, int Mp,
                                                                 int M, bf16_t* __restrict__ att, int split) {
@@ -569,9 +703,100 @@ struct Carver {
   }
 };
 
+// ---- skinny GEMM of the decoding loops -------------------------------------------------------------------------------------------------
+// A decoding step multiplies M = 128 .. 256 rows (one per table / cell) by 512 x 512 .. 2048 x 512 weights: on conv_igemm_kernel that is 8 workgroups
+// walking 16 .. 192 K-chunks one global-load latency at a time (18 .. 55 us per Linear in bf16, 44 .. 146 us in BF16X3; four fifths of a step's GEMM time
+// is waiting).  mtl_rowgemm_kernel splits K instead: a workgroup = 128 rows x one 64-channel tile of the weights x ROWGEMM_CH K-chunks, every load of its
+// slice issued before the first MFMA (operands straight from global memory into the MFMA registers: no LDS, no barrier); fp32 partial tiles go to a
+// scratch buffer and mtl_rowgemm_finish_kernel adds them in a fixed order (deterministic), then bias, fp32 residual, ReLU and the store of Ctx::gemm's
+// contract (bf16 hi | lo rows or fp32 rows, n_valid).  Weights are read in conv_igemm's tiling ([N/64][chunks][64][32]; BF16X3: chunks = [hi | hi | lo]
+// against the activations' [hi | lo | hi]).  MFMA roles: A = weights (M = output channel), B = activations (N = row), so a lane owns four consecutive
+// channels of one row.
+constexpr int ROWGEMM_CH = 4;
+
+template <int SPLIT>
+__global__ __launch_bounds__(256) void mtl_rowgemm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, int cin, int N, long long rows,
+                                                         float* __restrict__ part) {
+  const int nt = blockIdx.x, z = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int col = lane & 31, half = lane >> 5;
+  const long long row = (long long)blockIdx.z * 128 + wave * 32 + col;
+  if ((long long)blockIdx.z * 128 + wave * 32 >= rows) return;
+  const int kc1 = cin >> 5, kc = SPLIT ? 3 * kc1 : kc1;
+  const int c0 = z * ROWGEMM_CH;
+  const bf16_t* xr = x + row * (SPLIT ? 2 * cin : cin) + 8 * half;
+  const bf16_t* wt = w + ((size_t)nt * kc + c0) * (64 * 32) + col * 32 + 8 * half;
+  abf16x8 a[ROWGEMM_CH][2][2], b[ROWGEMM_CH][2];
+#pragma unroll
+  for (int i = 0; i < ROWGEMM_CH; ++i) {
+    const int c = c0 + i;
+    if (c < kc) {
+      // activation chunk of weight chunk c: hi chunks, then (BF16X3) the lo chunks against w_hi, then the hi chunks again against w_lo
+      const int xc = !SPLIT ? c : (c < kc1 ? c : (c < 2 * kc1 ? c - kc1 + kc1 : c - 2 * kc1));      // [hi | lo] rows: lo chunk j sits at chunk kc1 + j
+      const bf16_t* xp = xr + xc * 32;
+      const bf16_t* wp = wt + (size_t)i * (64 * 32);
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        b[i][st] = ld8(xp + 16 * st);
+        a[i][0][st] = ld8(wp + 16 * st);
+        a[i][1][st] = ld8(wp + 32 * 32 + 16 * st);
+      }
+    }
+  }
+  af32x16 acc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < ROWGEMM_CH; ++i)
+    if (c0 + i < kc) {
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0][st], b[i][st], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1][st], b[i][st], acc[1], 0, 0, 0);
+      }
+    }
+  float* pp = part + ((size_t)z * rows + row) * N + nt * 64 + 4 * half;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 v = {acc[h][4 * g], acc[h][4 * g + 1], acc[h][4 * g + 2], acc[h][4 * g + 3]};
+      *reinterpret_cast<float4*>(pp + h * 32 + 8 * g) = v;
+    }
+}
+
+// thread = (row, four channels): sum of the K-slices in slice order + bias (+ fp32 residual) (ReLU) -> bf16 (hi | lo) or fp32 rows
+__global__ __launch_bounds__(256) void mtl_rowgemm_finish_kernel(const float* __restrict__ part, int nz, long long rows, int N, const float* __restrict__ bias,
+                                                                int relu, bf16_t* __restrict__ out, int out_cs, int split, float* __restrict__ out_f32,
+                                                                int f32_cs, const float* __restrict__ res_f32, int n_valid) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int q4 = N >> 2;
+  if (i >= rows * q4) return;
+  const long long row = i / q4;
+  const int n = (int)(i % q4) * 4;
+  if (n_valid && n >= n_valid) return;
+  float4 v = *reinterpret_cast<const float4*>(part + row * N + n);
+  for (int z = 1; z < nz; ++z) {
+    const float4 t = *reinterpret_cast<const float4*>(part + ((size_t)z * rows + row) * N + n);
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+  v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+  if (res_f32) {
+    const float4 r = *reinterpret_cast<const float4*>(res_f32 + row * f32_cs + n);
+    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+  }
+  if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  if (out_f32) {
+    *reinterpret_cast<float4*>(out_f32 + row * f32_cs + n) = v;
+  } else {
+    bf16_t* op = out + row * (split ? 2 * out_cs : out_cs) + n;
+    put(op, out_cs, split, v.x); put(op + 1, out_cs, split, v.y); put(op + 2, out_cs, split, v.z); put(op + 3, out_cs, split, v.w);
+  }
+}
+
 // what survives between pt_tsr_mtl_structure and pt_tsr_mtl_cells
 struct MtlState {
-  DevBuf persist, work, cwork;
+  DevBuf persist, work, cwork, part;      // part: K-slice partial tiles of mtl_rowgemm_kernel
   int n = 0, hw = 0, Mp = 0, T = 0, x3 = 0;
   size_t o_kv = 0, o_keep = 0, o_tok = 0, o_ids = 0, o_fin = 0;
   std::vector<int> lens;        // output positions per table
@@ -587,6 +812,7 @@ struct Ctx {
   const PtModel* m;
   hipStream_t s;
   int x3, mul, rc;
+  DevBuf* part = nullptr;      // scratch of the skinny GEMM (null: every Linear on conv_igemm_kernel)
   const PtTensor* get(const std::string& n) {
     const PtTensor* t = m->find(n);
     if (!t && rc == PT_OK) {
@@ -605,6 +831,23 @@ struct Ctx {
     const PtTensor* w = get(q + (x3 ? ".w3" : ".w"));
     const PtTensor* b = get(q + ".b");
     if (rc != PT_OK) return;
+    static const int skinny_rows = getenv("PT_MTL_ROWGEMM_MAX") ? atoi(getenv("PT_MTL_ROWGEMM_MAX")) : 512;
+    if (part && rows <= skinny_rows && rows % 32 == 0 && N % 64 == 0 && cin % 32 == 0 && (!out_f32 || f32_cs % 4 == 0) && (nv == 0 || nv % 4 == 0)) {
+      const int kc = (x3 ? 3 : 1) * (cin / 32), nz = (kc + ROWGEMM_CH - 1) / ROWGEMM_CH;
+      const size_t need = (size_t)nz * rows * N * sizeof(float);
+      const int r = part->ensure(need > ((size_t)64 << 20) ? need : ((size_t)64 << 20));      // one allocation for the usual shapes (growing synchronises)
+      if (r != PT_OK) { rc = r; return; }
+      float* pb = reinterpret_cast<float*>(part->base);
+      const bf16_t* wp = reinterpret_cast<const bf16_t*>(w->d_ptr);
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0, "mtl row gemm");
+      const dim3 grid(N / 64, nz, (unsigned)((rows + 127) / 128));
+      if (x3) hipLaunchKernelGGL(mtl_rowgemm_kernel<1>, grid, dim3(256), 0, s, x, wp, cin, N, rows, pb);
+      else hipLaunchKernelGGL(mtl_rowgemm_kernel<0>, grid, dim3(256), 0, s, x, wp, cin, N, rows, pb);
+      const long long thr = rows * (N / 4);
+      hipLaunchKernelGGL(mtl_rowgemm_finish_kernel, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, s, pb, nz, rows, N, reinterpret_cast<const float*>(b->d_ptr), relu,
+                         out, out_cs, x3, out_f32, f32_cs, res_f32, nv);
+      return;
+    }
     ConvDesc c;
     c.in = x; c.B = 1; c.H = (int)(rows / 32); c.W = 32; c.Cin = cin;
     c.w = reinterpret_cast<const bf16_t*>(w->d_ptr); c.bias = reinterpret_cast<const float*>(b->d_ptr);
@@ -631,6 +874,7 @@ struct Work {
   float *opart = nullptr, *mlpart = nullptr;
   int4* tiles = nullptr;
   int ntiles = 0, nsplit = 1, kps = 0;
+  bool single = false;      // every tile is ONE query (the KV-cached structure loop): mtl_cross_decode_kernel
 };
 
 struct Seqs {          // the sequences of one loop
@@ -663,8 +907,12 @@ void run_layer(Ctx& c, const std::string& q, int slot, float* x, bf16_t* cache, 
   if (c.rc != PT_OK) return;
   {
     PtProfScope ps(c.e, c.s, PT_PROF_OTHER, 0, "mtl source attention");
-    const dim3 grid(W.ntiles, HEADS, W.nsplit);
-    if (c.x3) hipLaunchKernelGGL(mtl_cross_attn_kernel<1>, grid, dim3(64), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.R, W.opart, W.mlpart, W.att);
+    const dim3 grid(W.ntiles, HEADS, W.nsplit), dgrid(W.ntiles, W.nsplit);
+    static const bool decode_kernel = !getenv("PT_MTL_CROSS_MFMA");
+    if (W.single && decode_kernel) {
+      if (c.x3) hipLaunchKernelGGL(mtl_cross_decode_kernel<1>, dgrid, dim3(512), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.R, W.opart, W.mlpart, W.att);
+      else hipLaunchKernelGGL(mtl_cross_decode_kernel<0>, dgrid, dim3(512), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.R, W.opart, W.mlpart, W.att);
+    } else if (c.x3) hipLaunchKernelGGL(mtl_cross_attn_kernel<1>, grid, dim3(64), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.R, W.opart, W.mlpart, W.att);
     else hipLaunchKernelGGL(mtl_cross_attn_kernel<0>, grid, dim3(64), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.R, W.opart, W.mlpart, W.att);
     if (W.nsplit > 1)
       hipLaunchKernelGGL(mtl_cross_combine_kernel, dim3(npos * S.M), dim3(512), 0, c.s, W.opart, W.mlpart, W.nsplit, W.R, S.Mp, S.M, W.att, c.x3);
@@ -687,10 +935,10 @@ int upload_tiles(std::vector<int4>& host, int4* dev, hipStream_t s) {
 }
 
 int pick_split(int ntiles, int hw, int* kps) {
-  // single-wave workgroups that stream their key slice with a handful of loads in flight: ~10 of them per SIMD are needed to cover the
-  // HBM latency (PT_MTL_SPLIT_TARGET waves in flight; 2048 = two per SIMD measured 1.8 TB/s on the key / value stream)
+  // waves that stream their key slice with a handful of loads in flight (PT_MTL_SPLIT_TARGET waves per launch).  Measured on 87 tables x 3600 keys,
+  // KV-cached loop: 2048 .. 16384 all within 3 % (1.43 .. 1.49 ms per step): at 641 MB per launch the stream runs at ~5 TB/s either way
   static int target = -1;
-  if (target < 0) { const char* ev = getenv("PT_MTL_SPLIT_TARGET"); target = ev ? atoi(ev) : 16384; }
+  if (target < 0) { const char* ev = getenv("PT_MTL_SPLIT_TARGET"); target = ev ? atoi(ev) : 4096; }
   int ns = target / (ntiles * HEADS > 0 ? ntiles * HEADS : 1);
   if (ns < 1) ns = 1;
   if (ns > 16) ns = 16;
@@ -744,6 +992,7 @@ void pt_mtl_release(pt_engine* e) {
   st->persist.release();
   st->work.release();
   st->cwork.release();
+  st->part.release();
   if (st->h_poll) (void)hipHostFree(st->h_poll);
   delete st;
   e->mtl_state = nullptr;
@@ -774,6 +1023,7 @@ int pt_mtl_structure(pt_engine* e, const float* f3, int n, int hw, float* d_tag_
     return PT_ERR_STATE;
   }
   Ctx c{e, &it->second, s, pt_split(e) ? 1 : 0, pt_split(e) ? 2 : 1, PT_OK};
+  if (!getenv("PT_MTL_NO_ROWGEMM")) c.part = &state_of(e)->part;
   Meta mt;
   int rc = read_meta(c, &mt);
   if (rc != PT_OK) return rc;
@@ -876,6 +1126,7 @@ int pt_mtl_structure(pt_engine* e, const float* f3, int n, int hw, float* d_tag_
     for (int b = 0; b < n; ++b) tl[b] = make_int4(b, b, 1, Mp);
     W.ntiles = n;
     W.nsplit = pick_split(n, hw, &W.kps);
+    W.single = true;
     if ((rc = upload_tiles(tl, W.tiles, s)) != PT_OK) return rc;
   }
   const int POLL = 16;
@@ -895,6 +1146,7 @@ int pt_mtl_structure(pt_engine* e, const float* f3, int n, int hw, float* d_tag_
         for (int q0 = 0; q0 < npos; q0 += 32) tl.push_back(make_int4(b, q0 * Mp + b, npos - q0 < 32 ? npos - q0 : 32, Mp));
       W.ntiles = (int)tl.size();
       W.nsplit = pick_split(W.ntiles, hw, &W.kps);
+      W.single = false;
       if ((rc = upload_tiles(tl, W.tiles, s)) != PT_OK) return rc;
     }
     {
@@ -987,6 +1239,7 @@ int pt_mtl_cells(pt_engine* e, int total, int32_t* d_cell_ids, float* d_cell_pro
     return PT_ERR_STATE;
   }
   Ctx c{e, &it->second, s, st->x3, st->x3 ? 2 : 1, PT_OK};
+  if (!getenv("PT_MTL_NO_ROWGEMM")) c.part = &st->part;
   PT_REQUIRE((pt_split(e) ? 1 : 0) == st->x3, "pt_tsr_mtl_cells: the precision changed since pt_tsr_mtl_structure");
   Meta mt;
   int rc = read_meta(c, &mt);

@@ -491,13 +491,18 @@ LCNET_CONFIG = {   # k, in_c, out_c, stride, use_se -- picodet/lcnet.py:25-46
 PICODET_STANDIN = dict(neck_channels=128, num_convs=4, reg_max=7, strides=(8, 16, 32, 64))
 
 
-def picodet_state_dict(seed: int = 0, num_classes: int = 5, cls_bias: float = -6.5, head_gain: float = 0.012):
+def picodet_state_dict(seed: int = 0, num_classes: int = 5, cls_bias: float = -6.5, head_gain: float = 0.012, table_head: bool = False):
     """state_dicts of the in-tree PicoDet parts, keys prefixed ``backbone.`` / ``neck.`` / ``head.`` like
     ``PicoDet`` (picodet/modeling_picodet.py:31-36): ``LCNet(scale=1.0, feature_maps=[3,4,5])`` (lcnet.py:159-259),
     ``CSPPAN(in_channels=[128,256,512], out_channels=128, kernel_size=5, num_features=4)`` (csp_pan.py:233-347) and
     ``PicoHead(PicoFeat(128, 128, num_fpn_stride=4, num_convs=4, share_cls_reg=True), fpn_stride=[8,16,32,64],
     reg_max=7)`` (pico_head.py:56-167,966-1072).  The reference runs an ONNX export whose exact hyper-parameters are
-    not in the tree: this configuration is the ASSUMED picodet_lcnet_x1_0 layout model."""
+    not in the tree: this configuration is the ASSUMED picodet_lcnet_x1_0 layout model.
+
+    ``table_head=True`` (seed 4, five classes: bench.py's layout checkpoint): the stride-64 branch of the head -- four depthwise / pointwise pairs and
+    ``head_cls3`` -- is replaced by the tensors of ``data/picodet_synth_table_head.npz``, fitted by ``tools/fit_layout_head.py`` on the features this very
+    backbone and neck give on pages 0..511 of ``synth_pages.make_page`` so that class "table" fires on those pages' tables (a workload device that memorises
+    its pages, not a layout detector -- see that script); the table logit of the other three levels is switched off."""
     g = _Gen(seed)
     nc = PICODET_STANDIN["neck_channels"]
 
@@ -554,6 +559,22 @@ def picodet_state_dict(seed: int = 0, num_classes: int = 5, cls_bias: float = -6
         b = g.rng.uniform(-0.5, 0.5, (nout,))
         b[:num_classes] += cls_bias            # few positives, like a trained detector's prior (pico_head.py:1041)
         g.put(f"head.head_cls{s}.bias", b)
+    if table_head:
+        import os
+        import torch
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "picodet_synth_table_head.npz"))
+        fit_seed, fit_ncls, table, level = (int(v) for v in z["meta"][:4])
+        if (seed, num_classes) != (fit_seed, fit_ncls):
+            raise ValueError(f"the fitted table head belongs to picodet_state_dict(seed={fit_seed}, num_classes={fit_ncls})")
+        for k in z.files:
+            if k != "meta":
+                if tuple(g.sd[k].shape) != tuple(z[k].shape):
+                    raise ValueError(f"picodet_synth_table_head.npz: {k} has shape {z[k].shape}, the checkpoint's is {tuple(g.sd[k].shape)}")
+                g.sd[k] = torch.from_numpy(np.ascontiguousarray(z[k])).to(g.sd[k].dtype)
+        for lvl in range(4):
+            if lvl != level:
+                g.sd[f"head.head_cls{lvl}.weight"][table] = 0.0
+                g.sd[f"head.head_cls{lvl}.bias"][table] = -12.0
     return g.sd
 
 

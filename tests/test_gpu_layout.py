@@ -163,3 +163,39 @@ def test_layout_stage_matches_oracle_chain(eng, pico_sd):
         print(f"layout page {i}: {len(ref)} reference detections, {len(got[i])} device detections, {matched} matched")
         assert matched >= 0.9 * len(ref) and abs(len(got[i]) - len(ref)) <= max(2, len(ref) // 10)
     assert total > 10
+
+
+def _iou(a, b):
+    ix = max(0.0, min(a[2], b[2]) - max(a[0], b[0]))
+    iy = max(0.0, min(a[3], b[3]) - max(a[1], b[1]))
+    return ix * iy / ((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - ix * iy)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_fitted_table_head_feeds_table_structure(precision):
+    """bench.py's layout -> table-structure chain: the seeded PicoDet with the fitted stride-64 head branch (tools/fit_layout_head.py) labels the tables of
+    the generator's pages "table" on the ENGINE, in both arithmetic modes, close enough to the generator's rectangles (grown by 8 px, the fit's target)
+    for the table-structure stage to see whole tables; OcrTablePipeline._layout_table_boxes (get_layout_by_type, score >= 0.2) is the hand-off"""
+    from pdf_table_amd.engine import HipEngine
+    from pdf_table_amd.layout_stage import LayoutStage, PicodetConfig, layout_tables
+    from pdf_table_amd.synth_pages import make_page
+    x3 = precision == "bf16x3"
+    e = HipEngine(0)
+    try:
+        e.set_precision(L.PT_PRECISION_BF16X3 if x3 else L.PT_PRECISION_BF16)
+        e.load_weights(L.PT_MODEL_PICODET, pack_picodet(picodet_state_dict(seed=4, num_classes=5, table_head=True), 5, x3=x3))
+        made = [make_page(i) for i in (0, 1, 2, 3, 100, 101, 300, 511)]
+        pages = torch.from_numpy(np.stack([m[0] for m in made])).cuda()
+        res = LayoutStage(e, PicodetConfig(task_type="en"))(pages)
+        worst, n = 1.0, 0
+        for m, lay in zip(made, res):
+            gt = np.asarray(m[1]["tables"], dtype=np.float64).reshape(-1, 4) + np.array([-8, -8, 8, 8])
+            tabs = layout_tables(lay, "table", 0.2)
+            assert len(tabs) == len(gt), (len(tabs), len(gt))
+            for g_, t in zip(sorted(gt.tolist(), key=lambda b: b[1]), tabs):      # layout_tables: top to bottom
+                worst = min(worst, _iou(g_, [float(v) for v in t["bbox"]]))
+                n += 1
+        print(f"fitted table head [{precision}]: {n} tables on 8 pages, worst IoU with the generator's rectangle {worst:.3f}")
+        assert worst >= 0.9
+    finally:
+        e.close()

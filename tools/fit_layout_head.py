@@ -1,0 +1,208 @@
+"""tools/fit_layout_head.py [n_pages] [iterations] [out.npz]: fits the stride-64 branch of the synthetic PicoDet head so that class "table" fires on the tables
+of pdf_table_amd.synth_pages (the bench chain layout -> table structure).
+
+A seeded random-init PicoDet (synth_weights.picodet_state_dict) finds no tables, so bench.py used to feed the table-structure stage the page generator's
+own rectangles.  This script keeps the seeded random backbone and neck, runs the CPU oracle (oracle/picodet.py) up to the neck's stride-64 output
+[128, 13, 10] on pages 0 .. n-1 of the generator (the pages bench.py's ranks 0 .. n/64-1 use), and trains, with Adam on the CPU (minutes), the four
+depthwise / pointwise pairs of the level-3 head tower and `head.head_cls3` to emit (i) the "table" logit: positive on the anchors inside the central 60 % of a
+table, ignored on the rest of its inside, negative elsewhere and for every other class; (ii) the four 8-bin distance distributions (stride 64: the only level
+whose 7 x 64 px reach covers a table's half width).  Levels 0-2 get a constant -12 on the table logit.
+
+What it is and is not: a WORKLOAD DEVICE.  A stride-64 tower over the features of a random backbone memorises the pages it was fitted on (all tables found, box
+edges within ~10 px) and generalises poorly to unseen pages of the generator (recall ~60 %, printed below) -- it makes the timed step's table regions the
+layout stage's own output (`get_layout_by_type`, score >= 0.2, crop), it is not a layout detector.  Output: pdf_table_amd/data/picodet_synth_table_head.npz
+(state_dict entries; picodet_state_dict(table_head=True) overlays them)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import picodet as P                                                   # noqa: E402
+from pdf_table_amd.synth_pages import make_page                                   # noqa: E402
+from pdf_table_amd.synth_weights import PICODET_STANDIN, picodet_state_dict       # noqa: E402
+
+SEED, NCLS, TABLE, LEVEL = 4, 5, 3, 3          # bench.py's layout checkpoint; LAYOUT_LABELS["en"].index("table"); the stride-64 level
+STR, FH, FW, H, W, GROW = 64, 13, 10, 800, 608, 8     # 800 x 608 net input
+REG = PICODET_STANDIN["reg_max"] + 1
+NC = PICODET_STANDIN["neck_channels"]
+CY, CX = np.meshgrid((np.arange(FH) + 0.5) * STR, (np.arange(FW) + 0.5) * STR, indexing="ij")
+
+
+def neck_features(lo, hi, cache):
+    """stride-64 neck output and the tables (net frame, x1 y1 x2 y2) of pages lo .. hi-1; cached as npz (about 1 s of CPU per page)"""
+    os.makedirs(cache, exist_ok=True)
+    sd = None
+    fs, ts = [], []
+    for i in range(lo, hi):
+        fn = os.path.join(cache, f"p{i}.npz")
+        if not os.path.exists(fn):
+            if sd is None:
+                sd = {k: torch.from_numpy(np.asarray(v)).float() for k, v in picodet_state_dict(seed=SEED, num_classes=NCLS).items()}
+            img, meta = make_page(i)
+            x, sf = P.picodet_preprocess(img)
+            with torch.no_grad():
+                f = P.csppan_forward(sd, P.lcnet_forward(sd, torch.from_numpy(x)[None]))
+            t = np.asarray(meta["tables"], dtype=np.float64).reshape(-1, 4) * np.array([sf[1], sf[0], sf[1], sf[0]])
+            np.savez(fn, f3=f[LEVEL][0].numpy(), t=t)
+        z = np.load(fn)
+        fs.append(z["f3"])
+        t = z["t"].copy()
+        if len(t):      # the rectangles a layout annotation would carry: the ruled grid grown by GROW page pixels (bench.py used to grow the generator's by 8)
+            gx, gy = GROW * W / 1024.0, GROW * H / 1024.0
+            t += np.array([-gx, -gy, gx, gy])
+            t = np.stack([t[:, 0].clip(0, W), t[:, 1].clip(0, H), t[:, 2].clip(0, W), t[:, 3].clip(0, H)], 1)
+        ts.append(t)
+    return np.stack(fs), ts
+
+
+def targets(ts, central=0.6):
+    n = len(ts)
+    cls, wcls = np.zeros((n, FH, FW), np.float32), np.ones((n, FH, FW), np.float32)
+    dist, reg = np.zeros((n, 4, FH, FW), np.float32), np.zeros((n, FH, FW), np.float32)
+    for p, t in enumerate(ts):
+        for x1, y1, x2, y2 in t:
+            inside = (CY > y1) & (CY < y2) & (CX > x1) & (CX < x2)
+            mx, my = (x1 + x2) / 2, (y1 + y2) / 2
+            cen = (np.abs(CX - mx) <= central * (x2 - x1) / 2) & (np.abs(CY - my) <= central * (y2 - y1) / 2) & inside
+            if not cen.any():            # a table thinner than the anchor pitch: its nearest anchor
+                d = (CY - my) ** 2 + (CX - mx) ** 2
+                cen = np.zeros((FH, FW), bool)
+                cen.flat[np.argmin(np.where(inside, d, np.inf)) if inside.any() else np.argmin(d)] = True
+            wcls[p][inside & ~cen] = 0
+            cls[p][cen] = 1
+            m = inside | cen
+            d4 = np.stack([CX - x1, CY - y1, x2 - CX, y2 - CY]) / STR
+            dist[p][:, m] = np.clip(d4[:, m], 0, REG - 1 - 1e-3)
+            reg[p][m] = 1
+    return [torch.from_numpy(a) for a in (cls, wcls, dist, reg)]
+
+
+class Tower(nn.Module):
+    """PicoFeat's level-3 tower + head_cls3 in the oracle's arithmetic (picohead_forward): BatchNorm as a per-channel affine map over unit statistics"""
+
+    def __init__(self, scale):
+        super().__init__()
+        self.register_buffer("scale", scale.view(1, -1, 1, 1))
+        self.dw = nn.ModuleList([nn.Conv2d(NC, NC, 5, padding=2, groups=NC, bias=False) for _ in range(4)])
+        self.pw = nn.ModuleList([nn.Conv2d(NC, NC, 1, bias=False) for _ in range(4)])
+        self.g = nn.ParameterList([nn.Parameter(torch.ones(NC)) for _ in range(8)])
+        self.b = nn.ParameterList([nn.Parameter(torch.zeros(NC)) for _ in range(8)])
+        self.head = nn.Conv2d(NC, NCLS + 4 * REG, 1)
+        nn.init.constant_(self.head.bias[:NCLS], -4.0)
+
+    def aff(self, x, i):
+        return x / np.sqrt(1 + 1e-5) * self.g[i].view(1, -1, 1, 1) + self.b[i].view(1, -1, 1, 1)
+
+    def forward(self, x):
+        x = x * self.scale
+        for i in range(4):
+            x = F.hardswish(self.aff(self.dw[i](x), 2 * i))
+            x = F.hardswish(self.aff(self.pw[i](x), 2 * i + 1))
+        return self.head(x)
+
+    def state_entries(self):
+        """the tensors under the names of PicoHead's state_dict; the input scale folded into the first depthwise filter"""
+        out = {}
+        for i in range(4):
+            w = self.dw[i].weight.detach().clone()
+            if i == 0:
+                w = w * self.scale.view(-1, 1, 1, 1)
+            for kind, wt, j in (("dw", w, 2 * i), ("pw", self.pw[i].weight.detach(), 2 * i + 1)):
+                p = f"head.conv_feat.cls_conv_{kind}{LEVEL}_{i}"
+                out[p + ".conv.weight"] = wt.numpy()
+                out[p + ".norm.weight"] = self.g[j].detach().numpy()
+                out[p + ".norm.bias"] = self.b[j].detach().numpy()
+                out[p + ".norm.running_mean"] = np.zeros(NC, np.float32)
+                out[p + ".norm.running_var"] = np.ones(NC, np.float32)
+        out[f"head.head_cls{LEVEL}.weight"] = self.head.weight.detach().numpy()
+        out[f"head.head_cls{LEVEL}.bias"] = self.head.bias.detach().numpy()
+        return out
+
+
+def evaluate(model, x, ts):
+    """(tables found at IoU > 0.7, missed, spurious, (mean, max) of the worst edge error of the found ones in net-frame px) after score > 0.5 and hard NMS"""
+    with torch.no_grad():
+        y = model(x)
+    sc = torch.sigmoid(y[:, TABLE]).numpy()
+    pb = y[:, NCLS:].reshape(-1, 4, REG, FH, FW).softmax(2)
+    d = (pb * torch.arange(REG).view(1, 1, REG, 1, 1)).sum(2).numpy() * STR
+    tp = fn = fp = 0
+    errs = []
+    for p, t in enumerate(ts):
+        boxes = np.stack([CX - d[p, 0], CY - d[p, 1], CX + d[p, 2], CY + d[p, 3]], -1).reshape(-1, 4)
+        s = sc[p].reshape(-1)
+        m = s > 0.5
+        det = P.hard_nms(np.concatenate([boxes[m], s[m, None]], 1), 0.5, 100) if m.any() else np.zeros((0, 5))
+        used = set()
+        for g in t:
+            bi, best = 0, -1
+            for k, b in enumerate(det):
+                ix = max(0, min(g[2], b[2]) - max(g[0], b[0]))
+                iy = max(0, min(g[3], b[3]) - max(g[1], b[1]))
+                iou = ix * iy / ((g[2] - g[0]) * (g[3] - g[1]) + (b[2] - b[0]) * (b[3] - b[1]) - ix * iy + 1e-9)
+                if iou > bi and k not in used:
+                    bi, best = iou, k
+            if best >= 0 and bi > 0.7:
+                tp += 1
+                used.add(best)
+                errs.append(np.abs(det[best, :4] - g).max())
+            else:
+                fn += 1
+        fp += len(det) - len(used)
+    return tp, fn, fp, ((round(float(np.mean(errs)), 1), round(float(np.max(errs)), 1)) if errs else None)
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 6000
+    out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pdf_table_amd", "data",
+                                                             "picodet_synth_table_head.npz")
+    cache = os.environ.get("PT_LAYFIT_CACHE", "/tmp/layfit/neck")
+    torch.manual_seed(0)
+    torch.set_num_threads(int(os.environ.get("PT_LAYFIT_THREADS", "6")))
+    xtr, ttr = neck_features(0, n, cache)
+    xte, tte = neck_features(n, n + 64, cache)              # unseen pages: the generalisation figure in the header
+    scale = torch.from_numpy(1.0 / (xtr.std((0, 2, 3)) + 1e-3)).float()
+    xtr, xte = torch.from_numpy(xtr).float(), torch.from_numpy(xte).float()
+    cls, wcls, dist, reg = targets(ttr)
+    model = Tower(scale)
+    opt = torch.optim.AdamW(model.parameters(), lr=3e-3, weight_decay=1e-4)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=5e-3, total_steps=iters)
+    bins = torch.arange(REG).view(1, 1, REG, 1, 1)
+    t0 = time.time()
+    for it in range(iters):
+        idx = torch.randperm(len(xtr))[:128]
+        y = model(xtr[idx])
+        tgt = torch.zeros_like(y[:, :NCLS])
+        tgt[:, TABLE] = cls[idx]
+        w = torch.ones_like(tgt)
+        w[:, TABLE] = wcls[idx]
+        lc = (F.binary_cross_entropy_with_logits(y[:, :NCLS], tgt, reduction="none") * w * (1 + 20 * tgt)).mean()
+        lg = y[:, NCLS:].reshape(-1, 4, REG, FH, FW).log_softmax(2)
+        dd = dist[idx]
+        k = dd.floor().long().clamp(max=REG - 2)
+        fr = dd - k
+        ce = -(lg.gather(2, k.unsqueeze(2)).squeeze(2) * (1 - fr) + lg.gather(2, (k + 1).unsqueeze(2)).squeeze(2) * fr)
+        ex = (lg.exp() * bins).sum(2)
+        m = reg[idx].unsqueeze(1)
+        lb = ((ce * 0.25 + (ex - dd).abs()) * m).sum() / m.sum().clamp(min=1) / 4
+        loss = lc * 10 + lb
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        sched.step()
+        if it % 500 == 499 or it == iters - 1:
+            print(it + 1, f"loss cls {lc.item():.4f} box {lb.item():.4f}; fitted pages (found, missed, spurious, edge error px):", evaluate(model, xtr, ttr),
+                  "unseen pages:", evaluate(model, xte, tte), f"{time.time() - t0:.0f} s", flush=True)
+    ent = {k: np.asarray(v, dtype=np.float32) for k, v in model.state_entries().items()}
+    np.savez_compressed(out, **ent, meta=np.array([SEED, NCLS, TABLE, LEVEL, n, iters]))
+    print("wrote", out, os.path.getsize(out), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -18,13 +18,24 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 87
 max_len = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 conv = MtlTabNetConvertor(max_seq_len=max_len)
 eng = HipEngine(0)
-eng.load_weights(L.PT_MODEL_MTL_DECODER, pack_mtl_decoder(mtl_tabnet_decoder_state_dict(seed=43, num_classes=conv.num_classes(), num_classes_cell=conv.num_classes_cell()),
-                                                          conv.decoder_cfg()))
+sd = mtl_tabnet_decoder_state_dict(seed=43, num_classes=conv.num_classes(), num_classes_cell=conv.num_classes_cell())
+if "--no-pad" in sys.argv:      # a trained model never emits <PAD>: keep the loops in their KV-cached mode (one query per table and step)
+    cfg = conv.decoder_cfg()
+    for key, pad in (("cls_fc.bias", cfg["pad"]), ("cell_fc.bias", cfg["pad_cell"])):
+        sd[key] = sd[key].clone()
+        sd[key][pad] = -1e4
+eng.load_weights(L.PT_MODEL_MTL_DECODER, pack_mtl_decoder(sd, conv.decoder_cfg()))
 f3 = torch.randn(n, 3600, 512, generator=torch.Generator().manual_seed(0)).cuda()
 for prec, name in ((L.PT_PRECISION_BF16, "bf16"), (L.PT_PRECISION_BF16X3, "bf16x3")):
     eng.set_precision(prec)
     eng.mtl_decode(f3)
     torch.cuda.synchronize()
+    if "--prof" in sys.argv:          # PT_PROF_VERBOSE=1: HIP-event time per launch label (serialises the launches: not a throughput figure)
+        eng.profile_enable(True)
+        eng.mtl_decode(f3)
+        print(f"-- per-label times, {name} --", file=sys.stderr, flush=True)
+        eng.profile_read()
+        eng.profile_enable(False)
     t0 = time.perf_counter()
     out = eng.mtl_decode(f3)
     torch.cuda.synchronize()
