@@ -749,8 +749,11 @@ class HipRunner:
                "asserted_by": "tests/test_gpu_mtl.py (x3: tokens identical, boxes / tag / cell logits <= 1e-3 of scale against the oracle "
                               "pinned to the reference's own MtlTabNetDecoder; task end to end against the composed oracle chain), "
                               "tests/test_mtl_host.py (convertor + post-processor identical to the reference's own classes)"}
-        for name, prec in (("bf16", L.PT_PRECISION_BF16), ("bf16x3", L.PT_PRECISION_BF16X3)):
+        # bf16_kv8: bf16 arithmetic, the structure loop's source-attention keys / values streamed as fp8 (pt_engine_set_mtl_kv_fp8: the fp8 of
+        # configs[4] where it pays on this path -- half the bytes of the loop's dominant HBM stream; drift recorded in tests/test_gpu_mtl.py)
+        for name, prec in (("bf16", L.PT_PRECISION_BF16), ("bf16_kv8", L.PT_PRECISION_BF16), ("bf16x3", L.PT_PRECISION_BF16X3)):
             eng.set_precision(prec)
+            eng.set_mtl_kv_fp8(name == "bf16_kv8")
             try:
                 stage = MtlStage(eng, conv, micro_batch=int(os.environ.get("PT_MTL_MICROBATCH", "128")))
                 for _ in range(warm):
@@ -764,6 +767,7 @@ class HipRunner:
                 dt = (time.perf_counter() - t0) / steps
             finally:
                 eng.set_precision(L.PT_PRECISION_BF16)
+                eng.set_mtl_kv_fp8(False)
             st = stage.stats
             out[name] = {"tables_per_s": n_tab / dt, "ms_per_step": dt * 1e3, "pages_per_s_tsr_only": PAGES_PER_STEP / dt,
                          "structure_tokens_per_table": st["tokens"] / max(1, st["tables"]), "cells_per_table": st["cells"] / max(1, st["tables"]),

@@ -64,6 +64,11 @@ int pt_engine_check(pt_engine* e);
  * use it whenever pt_rec_forward* runs on a stream beside other work.  A failure pt_engine_check reports also
  * switches the engine to 0 and clears the flag, so the failed batch can simply be submitted again. */
 int pt_engine_set_lstm_cluster(pt_engine* e, int on);
+/* MtlTabNet (pt_tsr_mtl_structure), PT_PRECISION_BF16 only: on = 1 keeps a second copy of the source-attention keys / values of the
+ * KV-cached structure loop as fp8 (e4m3, x 8) and streams THAT every step -- half the bytes of the loop's dominant HBM stream
+ * (BASELINE.json configs[4] names fp8; this is where fp8 pays on this path).  A throughput option with recorded drift
+ * (tests/test_gpu_mtl.py), off by default; ignored in PT_PRECISION_BF16X3.  Environment default: PT_MTL_KV_FP8. */
+int pt_engine_set_mtl_kv_fp8(pt_engine* e, int on);
 
 /* Arithmetic of the conv nets (DESIGN.md "numerics").  PT_PRECISION_BF16: bf16 activations/weights, fp32
  * accumulate -- the throughput mode BASELINE.json's configs name.  PT_PRECISION_BF16X3: every activation and

@@ -171,6 +171,7 @@ struct pt_engine {
   void* lstm_scratch = nullptr;                              // rec_kernels.hip: h exchange buffers + step counters of the cluster LSTM
   int* lstm_err = nullptr;                                   // pinned, device-visible: set by a cluster member that gave up waiting
   int lstm_max_cl = 0;                                       // clusters per direction per launch (num_cu / 8)
+  int mtl_kv_fp8 = 0;                                        // pt_engine_set_mtl_kv_fp8: MtlTabNet source-attention keys / values of the structure loop as fp8 (bf16 mode only)
   int lstm_cluster = 1;                                      // 1: weight-stationary cluster kernel (bf16 mode); 0: streaming kernel
   // crnn_model.hip: activations of an all-padding text line after every limited conv layer, per precision (bf16 / hi-lo);
   // valid until the CRNN weights are loaded again

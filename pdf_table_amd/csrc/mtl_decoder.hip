@@ -465,6 +465,132 @@ __global__ __launch_bounds__(512) void mtl_cross_decode_kernel(const bf16_t* __r
   }
 }
 
+// ---- fp8 keys / values (pt_engine_set_mtl_kv_fp8, bf16 mode) --------------------------------------------------------------------------
+// The KV-cached structure loop is a stream over the tables' keys and values (641 MB per layer and step for 87 tables at ~5 TB/s: 60 % of a
+// step).  mtl_kv_fp8_kernel writes a second copy of the projected [rows, 5120] tensor as e4m3 bytes (x KV8_SCALE: the projections of LayerNorm-ed
+// features are O(1), the scale keeps small values out of the subnormals), mtl_cross_decode8_kernel is mtl_cross_decode_kernel over that copy: 4 lanes
+// per key (16 channels = one 16-byte load each), 16 independent soft-max streams per wave, hardware conversions (v_cvt_pk_f32_fp8).  Half the bytes;
+// the drift against the bf16 keys / values is recorded in tests/test_gpu_mtl.py.  The cell loop and the re-decode mode read the bf16 tensor.
+constexpr float KV8_SCALE = 8.f;
+
+__global__ __launch_bounds__(256) void mtl_kv_fp8_kernel(const bf16_t* __restrict__ kv, long long n8, unsigned char* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  float f[8];
+  unpack8(ldu4(kv + i * 8), f);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = fminf(fmaxf(f[j] * KV8_SCALE, -448.f), 448.f);
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+  *reinterpret_cast<int2*>(out + i * 8) = make_int2(lo, hi);
+}
+
+// sixteen fp8 values of a 16-byte load -> fp32, in memory order
+__device__ __forceinline__ void unpack16_fp8(const uint4 u, float* f) {
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const auto a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[k], false);
+    const auto b = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[k], true);
+    f[4 * k] = a[0]; f[4 * k + 1] = a[1]; f[4 * k + 2] = b[0]; f[4 * k + 3] = b[1];
+  }
+}
+
+__global__ __launch_bounds__(512) void mtl_cross_decode8_kernel(const bf16_t* __restrict__ q, const unsigned char* __restrict__ kv8, int koff,
+                                                               const int4* __restrict__ tiles, int hw, int keys_per_split, int nsplit, long long R,
+                                                               float* __restrict__ opart, float* __restrict__ mlpart, bf16_t* __restrict__ att) {
+  const int4 tile = tiles[blockIdx.x];
+  const int head = threadIdx.x >> 6, lane = threadIdx.x & 63, z = blockIdx.y;
+  const int g = lane >> 2, c = lane & 3;
+  const int tab = tile.x;
+  const long long qrow = tile.y;
+  float qf[16];
+  {
+    const bf16_t* qp = q + qrow * D + head * DK + 16 * c;
+    unpack8(ldu4(qp), qf);
+    unpack8(ldu4(qp + 8), qf + 8);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) qf[j] *= 1.f / KV8_SCALE;
+  }
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const int kbeg = z * keys_per_split, kend = min(hw, kbeg + keys_per_split);
+  const unsigned char* kbase = kv8 + (size_t)tab * hw * KVC + koff + head * DK + 16 * c;
+  for (int k0 = kbeg; k0 < kend; k0 += 128) {
+    uint4 kr[8], vr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int key = k0 + 16 * i + g;
+      const unsigned char* kp = kbase + (size_t)(key < kend ? key : kend - 1) * KVC;
+      kr[i] = *reinterpret_cast<const uint4*>(kp);
+      vr[i] = *reinterpret_cast<const uint4*>(kp + D);
+    }
+    float sc[8], mt = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float kf[16];
+      unpack16_fp8(kr[i], kf);
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) d = fmaf(qf[j], kf[j], d);
+      d += __shfl_xor(d, 1);
+      d += __shfl_xor(d, 2);
+      sc[i] = k0 + 16 * i + g < kend ? d : -INFINITY;
+      mt = fmaxf(mt, sc[i]);
+    }
+    if (mt > -INFINITY) {
+      const float mn = fmaxf(m, mt);
+      const float scale = expf(m - mn);
+      l *= scale;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] *= scale;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float pv = expf(sc[i] - mn);
+        l += pv;
+        float vf[16];
+        unpack16_fp8(vr[i], vf);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = fmaf(pv, vf[j], acc[j]);
+      }
+      m = mn;
+    }
+  }
+  float mx = m;
+#pragma unroll
+  for (int sh = 4; sh < 64; sh <<= 1) mx = fmaxf(mx, __shfl_xor(mx, sh));
+  const float w = m == -INFINITY ? 0.f : expf(m - mx);
+  l *= w;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] *= w * (1.f / KV8_SCALE);
+#pragma unroll
+  for (int sh = 4; sh < 64; sh <<= 1) {
+    l += __shfl_xor(l, sh);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] += __shfl_xor(acc[j], sh);
+  }
+  if (g != 0) return;
+  if (nsplit == 1) {
+    bf16_t* op = att + qrow * D + head * DK + 16 * c;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) put(op + j, D, 0, acc[j] / l);
+  } else {
+    const size_t slot = ((size_t)z * R + qrow) * HEADS + head;
+    float* op = opart + slot * DK + 16 * c;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) op[j] = acc[j];
+    if (c == 0) {
+      mlpart[slot * 2] = mx;
+      mlpart[slot * 2 + 1] = l;
+    }
+  }
+}
+
 // merges the key slices of mtl_cross_attn_kernel: out = sum_z e^(m_z - M) acc_z / sum_z e^(m_z - M) l_z.  thread = (row, channel)
 __global__ __launch_bounds__(512) void mtl_cross_combine_kernel(const float* __restrict__ opart, const float* __restrict__ mlpart, int nsplit, long long R, int Mp,
                                                                 int M, bf16_t* __restrict__ att, int split) {
@@ -798,6 +924,7 @@ __global__ __launch_bounds__(256) void mtl_rowgemm_finish_kernel(const float* __
 struct MtlState {
   DevBuf persist, work, cwork, part;      // part: K-slice partial tiles of mtl_rowgemm_kernel
   int n = 0, hw = 0, Mp = 0, T = 0, x3 = 0;
+  size_t o_kv8 = 0;             // fp8 copy of the keys / values (0 bytes when the option is off)
   size_t o_kv = 0, o_keep = 0, o_tok = 0, o_ids = 0, o_fin = 0;
   std::vector<int> lens;        // output positions per table
   std::vector<int> cell_tab;    // table of every cell, cells ordered by (table, position)
@@ -883,6 +1010,7 @@ struct Seqs {          // the sequences of one loop
   int pad = 0;
   int ffp = 2048;
   int hw = 0;
+  const unsigned char* kv8 = nullptr;      // fp8 copy of the cross keys / values (pt_engine_set_mtl_kv_fp8; null: off)
 };
 
 // one DecoderLayer over positions [p0, p1] of all sequences.  x: fp32 residual rows of those positions ((p - p0) * Mp + s), updated in
@@ -909,7 +1037,9 @@ void run_layer(Ctx& c, const std::string& q, int slot, float* x, bf16_t* cache, 
     PtProfScope ps(c.e, c.s, PT_PROF_OTHER, 0, "mtl source attention");
     const dim3 grid(W.ntiles, HEADS, W.nsplit), dgrid(W.ntiles, W.nsplit);
     static const bool decode_kernel = !getenv("PT_MTL_CROSS_MFMA");
-    if (W.single && decode_kernel) {
+    if (W.single && S.kv8 && !c.x3) {
+      hipLaunchKernelGGL(mtl_cross_decode8_kernel, dgrid, dim3(512), 0, c.s, W.qc, S.kv8, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.R, W.opart, W.mlpart, W.att);
+    } else if (W.single && decode_kernel) {
       if (c.x3) hipLaunchKernelGGL(mtl_cross_decode_kernel<1>, dgrid, dim3(512), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.R, W.opart, W.mlpart, W.att);
       else hipLaunchKernelGGL(mtl_cross_decode_kernel<0>, dgrid, dim3(512), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.R, W.opart, W.mlpart, W.att);
     } else if (c.x3) hipLaunchKernelGGL(mtl_cross_attn_kernel<1>, grid, dim3(64), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.R, W.opart, W.mlpart, W.att);
@@ -1036,10 +1166,12 @@ int pt_mtl_structure(pt_engine* e, const float* f3, int n, int hw, float* d_tag_
   if (!st->h_poll) PT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&st->h_poll), 4096 * sizeof(int)));
   PT_REQUIRE(n + 1 <= 4096, "pt_tsr_mtl_structure: at most 4095 tables per call");
 
+  const bool kv_fp8 = e->mtl_kv_fp8 && !c.x3;
   // ---- persistent buffers
   {
     Carver cv;
     st->o_kv = cv.take((size_t)Fr * KVC * mul * sizeof(bf16_t));
+    st->o_kv8 = cv.take(kv_fp8 ? (size_t)Fr * KVC : 0);
     st->o_keep = cv.take((size_t)T * Mp * D * sizeof(float));
     st->o_tok = cv.take((size_t)(T + 1) * Mp * sizeof(int));
     st->o_ids = cv.take((size_t)T * Mp * sizeof(int));
@@ -1091,12 +1223,18 @@ int pt_mtl_structure(pt_engine* e, const float* f3, int n, int hw, float* d_tag_
     }
     c.gemm(featb, Fr, D, "kv", KVC, 0, kv, KVC);
     if (c.rc != PT_OK) return c.rc;
+    if (kv_fp8) {
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0, "mtl keys / values -> fp8");
+      const long long n8 = Fr * KVC / 8;
+      hipLaunchKernelGGL(mtl_kv_fp8_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, kv, n8, reinterpret_cast<unsigned char*>(pb + st->o_kv8));
+    }
   }
   hipLaunchKernelGGL(mtl_fill_kernel, dim3((Mp + 255) / 256), dim3(256), 0, s, tok, Mp, mt.sos);
   hipLaunchKernelGGL(mtl_fill_kernel, dim3((Mp + 64 + 255) / 256), dim3(256), 0, s, fin, Mp + 64, INT_MAX);
 
   Seqs S;
   S.M = n; S.Mp = Mp; S.tok = tok; S.pad = mt.pad; S.ffp = mt.ffp; S.hw = hw;
+  S.kv8 = kv_fp8 ? reinterpret_cast<const unsigned char*>(pb + st->o_kv8) : nullptr;
   const float *emb = c.F("emb"), *pe = c.F("pe");
   if (c.rc != PT_OK) return c.rc;
   static const char* LN[4] = {"l0", "l1", "cls", "bbox"};

@@ -56,6 +56,11 @@ class HipEngine:
         L.check(self.lib.pt_engine_set_precision(self._h, int(precision)), "pt_engine_set_precision")
         self.precision = int(precision)
 
+    def set_mtl_kv_fp8(self, on: bool):
+        """MtlTabNet, bf16 mode: stream the structure loop's source-attention keys / values as fp8 (half the bytes of the loop's dominant
+        HBM stream; a throughput option with recorded drift, off by default)"""
+        L.check(self.lib.pt_engine_set_mtl_kv_fp8(self._h, 1 if on else 0), "pt_engine_set_mtl_kv_fp8")
+
     def set_lstm_cluster(self, on: bool):
         """False: the streaming LSTM kernel (no co-residency requirement) -- whenever the recogniser shares the GPU with
         work on another stream; True (default): the weight-stationary cluster kernel."""

@@ -182,6 +182,39 @@ def test_decoders_bf16_drift_is_recorded(dec_eng, golden_dir):
     assert drift <= 0.1
 
 
+@pytest.mark.parametrize("case", ["golden_cfg", "early_eos"])
+def test_fp8_keys_values_drift_is_recorded(dec_eng, golden_dir, case):
+    """pt_engine_set_mtl_kv_fp8: the structure loop's source attention over an e4m3 copy of its keys / values (half the bytes of the loop's
+    dominant stream) -- a throughput option of the bf16 mode.  Recorded against the SAME run on bf16 keys / values (what the option changes) and
+    against the oracle: tag-logit drift up to the first differing token, sequences that diverge.  Ignored in BF16X3 (identical outputs)."""
+    cfg, sd, fmap, ref = _run_case(dec_eng, golden_dir, case, "bf16")
+    dec_eng.set_mtl_kv_fp8(True)
+    try:
+        _, _, _, out = _run_case(dec_eng, golden_dir, case, "bf16")
+        _, _, _, x3 = _run_case(dec_eng, golden_dir, case, "bf16x3")
+    finally:
+        dec_eng.set_mtl_kv_fp8(False)
+    _, _, _, x3_ref = _run_case(dec_eng, golden_dir, case, "bf16x3")
+    assert torch.equal(x3["tag_logits"], x3_ref["tag_logits"]) and torch.equal(x3["cell_ids"], x3_ref["cell_ids"])
+    want = _oracle_decode(sd, fmap, cfg)
+    a, b = out["tag_logits"].cpu().numpy(), ref["tag_logits"].cpu().numpy()
+    d_bf16 = d_orc = 0.0
+    flips_bf16 = flips_orc = 0
+    for n_, (wt, _, _) in enumerate(want):
+        for other, which in ((b[n_, :int(ref["lens"][n_])], "bf16"), (wt, "oracle")):
+            ln = min(int(out["lens"][n_]), other.shape[0])
+            same = a[n_, :ln].argmax(-1) == other[:ln].argmax(-1)
+            first = ln if same.all() else int(np.argmin(same))
+            d = np.abs(a[n_, :first] - other[:first]).max() / np.abs(wt).max() if first else 0.0
+            if which == "bf16":
+                d_bf16, flips_bf16 = max(d_bf16, d), flips_bf16 + int(first < ln)
+            else:
+                d_orc, flips_orc = max(d_orc, d), flips_orc + int(first < ln)
+    print(f"mtl fp8 keys / values [{case}]: tag-logit drift {d_bf16:.2e} of scale against the bf16 keys / values ({flips_bf16} of {len(want)} sequences "
+          f"diverge), {d_orc:.2e} against the oracle ({flips_orc} diverge)")
+    assert d_bf16 <= 0.1 and d_orc <= 0.15
+
+
 def test_decoder_needs_weights_and_structure_first():
     from pdf_table_amd.engine import HipEngine
     e = HipEngine(0)

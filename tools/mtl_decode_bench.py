@@ -26,8 +26,9 @@ if "--no-pad" in sys.argv:      # a trained model never emits <PAD>: keep the lo
         sd[key][pad] = -1e4
 eng.load_weights(L.PT_MODEL_MTL_DECODER, pack_mtl_decoder(sd, conv.decoder_cfg()))
 f3 = torch.randn(n, 3600, 512, generator=torch.Generator().manual_seed(0)).cuda()
-for prec, name in ((L.PT_PRECISION_BF16, "bf16"), (L.PT_PRECISION_BF16X3, "bf16x3")):
+for prec, name in ((L.PT_PRECISION_BF16, "bf16"), (L.PT_PRECISION_BF16, "bf16 + fp8 keys / values"), (L.PT_PRECISION_BF16X3, "bf16x3")):
     eng.set_precision(prec)
+    eng.set_mtl_kv_fp8("fp8" in name)
     eng.mtl_decode(f3)
     torch.cuda.synchronize()
     if "--prof" in sys.argv:          # PT_PROF_VERBOSE=1: HIP-event time per launch label (serialises the launches: not a throughput figure)
