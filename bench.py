@@ -94,7 +94,7 @@ def self_launch(args, argv):
     """--gpus N without a launcher: become N ranks under torch.distributed.run (one process per GPU)."""
     if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
         return
-    if os.environ.get("PT_BENCH_STUB") != "1":
+    if os.environ.get("PT_BENCH_STUB") not in ("1", "host"):
         import torch
         have = torch.cuda.device_count()
         if have < args.gpus:
@@ -330,17 +330,65 @@ class StubRunner:
     def __init__(self, args, rank, world):
         self.args, self.rank, self.world = args, rank, world
         self.stages = [x for x in args.stages.split(",") if x]
+        self.host = None
+        if os.environ.get("PT_BENCH_STUB") == "host":
+            self.init_host()
 
     def sync(self):
         pass
 
     def run(self, steps, count=False):
+        if self.host is not None:
+            return self.run_host(steps)
         time.sleep(0.01 * steps * (1 + self.rank))      # rank-dependent: the reported time must be the slowest rank's
         return {}
 
     def config(self, counts, steps):
+        if self.host is not None:
+            return {"workload": "stub (PT_BENCH_STUB=host): no device work; the REAL host halves of a step per rank on its own page shard -- contours, "
+                                "mini-boxes, unclip, filter (the library's thread pool, capped at cores / world), reading order, CTC collapse",
+                    "pages_per_step_per_gpu": self.host["pages"], "stages": self.stages, "parallelism": f"page-shard x{self.world}",
+                    "post_workers": self.host["workers"], "boxes_per_page": counts.get("boxes", 0) / max(1, self.host["pages"] * steps),
+                    "first_page_of_rank": self.host["first_page"]}
         return {"workload": "stub (PT_BENCH_STUB=1): no device work", "pages_per_step_per_gpu": PAGES_PER_STEP,
                 "stages": self.stages, "parallelism": f"page-shard x{self.world}"}
+
+    def init_host(self):
+        """PT_BENCH_STUB=host: what a rank's CPU does per step, with the device outputs replaced by what the generator knows: a bit-packed bitmap
+        with the text lines filled in (the detector's output on these pages), box scores of 0.9, random token ids.  PT_BENCH_STUB_PAGES pages per rank."""
+        import numpy as np
+        from pdf_table_amd.dist_utils import shard_range
+        from pdf_table_amd.synth_pages import make_page
+        pages = int(os.environ.get("PT_BENCH_STUB_PAGES", "8"))
+        lo, hi = shard_range(self.world * pages, self.rank, self.world)
+        assert hi - lo == pages
+        net = 960
+        bm = np.zeros((pages, net, net), dtype=bool)
+        for i in range(pages):
+            lines = make_page(lo + i, PAGE)[1]["lines"].astype(np.float64) * (net / PAGE)
+            for x0, y0, x1, y1 in lines:
+                bm[i, int(y0) + 2:int(y1) - 1, int(x0) + 1:int(x1) - 1] = True
+        words = np.packbits(bm.reshape(pages, net, net // 32, 32), axis=-1, bitorder="little").view(np.uint32).reshape(pages, net, net // 32)
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+        rng = np.random.default_rng(self.rank)
+        self.host = {"pages": pages, "first_page": lo, "words": words, "net": net, "workers": max(1, min(32, ncpu // max(1, self.world))),
+                     "ids": rng.integers(0, 40, (pages * 80, 160)).astype(np.int32)}
+
+    def run_host(self, steps):
+        import numpy as np
+        from pdf_table_amd.det_stage import sort_boxes_reading_order
+        from pdf_table_amd.engine import db_candidates_batch, db_finalize_batch
+        from pdf_table_amd.rec_stage import ctc_collapse
+        h = self.host
+        c = {"boxes": 0, "tok": 0}
+        for _ in range(steps):
+            boxes, counts = db_candidates_batch(h["words"], 1000, 3.0, n_threads=h["workers"])
+            scores = np.full(boxes.shape[:2], 0.9, dtype=np.float32)
+            out = db_finalize_batch(boxes, scores, counts, (h["net"], h["net"]), (PAGE, PAGE), 0.6, 1.5, 3.0, filter_tag=True, n_threads=h["workers"])
+            out = [sort_boxes_reading_order(b) for b in out]
+            c["boxes"] += sum(len(b) for b in out)
+            c["tok"] += sum(len(t) for t in ctc_collapse(h["ids"]))
+        return c
 
 
 class HipRunner:
@@ -877,7 +925,7 @@ def main(argv=None):
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python bench.py --gpus {args.gpus} does it itself)")
-    stub = os.environ.get("PT_BENCH_STUB") == "1"
+    stub = os.environ.get("PT_BENCH_STUB") in ("1", "host")
     import torch
     if world > 1:      # N ranks share the host: keep each rank's CPU-side torch / BLAS work inside its share of the cores
         torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
@@ -931,7 +979,7 @@ def main(argv=None):
         dt = float(t.item())
 
     if rank == 0:
-        total_pages = world * PAGES_PER_STEP * args.steps
+        total_pages = world * (runner.host["pages"] if getattr(runner, "host", None) else PAGES_PER_STEP) * args.steps
         out = {"metric": "pages/s", "value": total_pages / dt, "unit": "pages/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",

@@ -14,7 +14,7 @@ import torch
 
 def page_chain(page: np.ndarray, sds: Dict[str, dict], table_boxes: Sequence[Sequence[int]], thresh: float = 0.3, box_thresh: float = 0.6,
                unclip_ratio: float = 1.5, vis_thresh: float = 0.2, layout_classes: int = 5) -> Dict:
-    """page uint8 [h, w, 3] RGB; sds: state_dicts 'db', 'crnn', 'pico', 'lore', 'proc'; table_boxes: integer x1, y1, x2, y2 regions.
+    """page uint8 [h, w, 3] RGB; sds: state_dicts 'db', 'crnn', 'pico', 'lore', 'proc'; table_boxes: integer x1, y1, x2, y2 regions, or None: the layout stage's own "table" regions (the reference's flow).
     -> dict of numpy arrays / lists (see the keys below)."""
     from . import crnn as ocrnn
     from . import db_net, db_post, db_pre
@@ -29,6 +29,14 @@ def page_chain(page: np.ndarray, sds: Dict[str, dict], table_boxes: Sequence[Seq
         lay = opico.picodet_postprocess([s_.numpy() for s_ in sc], [b_.numpy() for b_ in bx], list(page.shape[:2]), sf, [800, 608],
                                         opico.LABELS["en"])
         out["layout"] = lay
+        if table_boxes is None:
+            # the reference's hand-off (ocr_system_task.py:184-198): TableProcessUtils.get_layout_by_type(layout, "table") -- score >= 0.2, top to
+            # bottom (pdf_table/table_common.py:1287-1300) --, each region cropped at its rounded coordinates (crop_image_by_box,
+            # utils/ocr/ocr_common_utils.py:279-280)
+            tabs = sorted((it for it in lay if it["label"].lower() == "table" and it["score"] >= 0.2), key=lambda it: it["bbox"][1])
+            table_boxes = [[round(float(v)) for v in it["bbox"]] for it in tabs]
+            table_boxes = [b for b in table_boxes if b[2] > b[0] and b[3] > b[1]]
+        out["table_boxes"] = np.asarray(table_boxes, dtype=np.int64).reshape(-1, 4)
         # ---- detection
         chw, shape_list = db_pre.preprocess_db_pp(page)
         logits = db_net.db_forward_fp32(sds["db"], torch.from_numpy(np.ascontiguousarray(chw))[None], return_logits=True)[0, 0]

@@ -890,9 +890,11 @@ def gen_e2e_page():
     res = {"pages": np.array(E2E_PAGES)}
     for pi, idx in enumerate(E2E_PAGES):
         page, meta = make_page(idx, 1024)
-        tb = e2e_table_boxes(meta)
         t0 = time.time()
-        r = e2e.page_chain(page, sds, tb)
+        r = e2e.page_chain(page, sds, None)          # table regions: the layout stage's own (the reference's flow)
+        tb = r["table_boxes"]
+        gen = e2e_table_boxes(meta)
+        print(f"page {idx}: layout tables {tb.tolist()}, the generator's rectangles grown by 8 px {gen.tolist()}")
         print(f"page {idx}: {len(r['det_boxes'])} boxes, {len(r['layout'])} layout regions, tables {[t['n'] for t in r['tables']]} cells, "
               f"{r['det_prob_near_thresh']} prob pixels within 1e-3 of the threshold, {time.time() - t0:.0f} s")
         p = f"p{pi}_"

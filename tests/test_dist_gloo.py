@@ -75,7 +75,7 @@ def _bench(argv, env_extra, timeout=300):
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PT_BENCH_STUB="1", MASTER_PORT=str(_free_port()), **env_extra)
+    env = dict(dict(os.environ, PT_BENCH_STUB="1", MASTER_PORT=str(_free_port())), **env_extra)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         if k not in env_extra:
             env.pop(k, None)
@@ -101,3 +101,25 @@ def test_bench_refuses_a_world_size_mismatch():
     """a driver that exports WORLD_SIZE=1 and asks for --gpus 2 must not get a 1-GPU number labelled as 2"""
     r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_bench_world8_runs_the_real_host_halves_per_rank():
+    """eight ranks on one host (gloo, no device): every rank runs the REAL host halves of a step on its own page shard -- the library's contour /
+    mini-box / unclip / filter pool capped at cores / 8, reading order, CTC collapse -- beside seven others; ONE line, n_gpus 8, and rank 0's
+    box count is what a single rank finds on the same pages (the shard of rank 0 is pages 0..3 in both runs)"""
+    import json
+    env = {"PT_BENCH_STUB": "host", "PT_BENCH_STUB_PAGES": "4"}
+    r8 = _bench(["--gpus", "8", "--steps", "2", "--warmup", "1"], env, timeout=600)
+    assert r8.returncode == 0, r8.stderr[-2000:]
+    lines = [ln for ln in r8.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r8.stdout
+    o8 = json.loads(lines[0])
+    r1 = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1"], env)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    o1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])
+    assert o8["n_gpus"] == 8 and o8["scaling"] == "weak" and o1["n_gpus"] == 1
+    c8, c1 = o8["config"], o1["config"]
+    assert c8["first_page_of_rank"] == c1["first_page_of_rank"] == 0 and c8["pages_per_step_per_gpu"] == 4
+    assert c8["boxes_per_page"] == c1["boxes_per_page"] > 20          # same pages, same host code: the same boxes with seven neighbours
+    assert c8["post_workers"] == max(1, min(32, len(os.sched_getaffinity(0)) // 8))
+    assert abs(o8["value"] - 8 * 4 * 2 / (o8["ms_per_step"] * 2e-3)) < 1e-6 * o8["value"]

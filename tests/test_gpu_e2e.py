@@ -42,13 +42,16 @@ def run(golden_dir):
                                         LayoutStage(eng, PicodetConfig(task_type="en")), TsrStage(eng, LoreConfig(task_type="wtw")), table_html=True)
     made = [make_page(i, 1024) for i in E2E_PAGES]
     pages = [m[0] for m in made]
-    tbs = [e2e_table_boxes(m[1]) for m in made]
-    for pi in range(len(pages)):
-        assert np.array_equal(tbs[pi], g[f"p{pi}_table_boxes"])
+    # table regions: the layout stage's own (label "table", score >= 0.2, rounded: ocr_system_task.py:184-198) -- no table_boxes argument.  The
+    # golden holds the regions the ORACLE's layout chain produced; the generator's rectangles only say that these are the pages' tables
+    tbs = [g[f"p{pi}_table_boxes"] for pi in range(len(pages))]
+    for pi, m in enumerate(made):
+        gen = e2e_table_boxes(m[1])
+        assert len(gen) == len(tbs[pi]) and np.abs(gen - tbs[pi]).max() <= 24, (gen.tolist(), tbs[pi].tolist())
     eng.set_precision(L.PT_PRECISION_BF16X3)
     try:
-        res = pipe.predict(pages, table_boxes=tbs)
-        stream = [r for batch in pipe.predict_stream([torch.from_numpy(np.stack(pages)).cuda()] * 2, table_boxes=[tbs] * 2) for r in batch]
+        res = pipe.predict(pages)
+        stream = [r for batch in pipe.predict_stream([torch.from_numpy(np.stack(pages)).cuda()] * 2) for r in batch]
     finally:
         eng.set_precision(L.PT_PRECISION_BF16)
     yield g, res, stream, pipe, tbs
@@ -118,6 +121,17 @@ def test_layout_regions(run):
         assert len(pairs) >= len(wb) - 3 and abs(len(gb) - len(wb)) <= 3
         for i, j in pairs:
             assert wc[i] == gc[j] and abs(ws[i] - gs[j]) <= 1e-3
+
+
+def test_layout_tables_feed_the_table_stage(run):
+    """the hand-off of the chain: the regions the pipeline crops for the table stage (OcrTablePipeline._layout_table_boxes over the ENGINE's layout
+    result) are, as integers, the regions the oracle chain derived from ITS layout result -- so the table comparisons below are on identical crops"""
+    g, res, _, pipe, tbs = run
+    got = pipe._layout_table_boxes([r.layout_result for r in res])
+    for pi in range(len(res)):
+        print(f"e2e page {E2E_PAGES[pi]}: table regions from the layout stage {got[pi].tolist()}")
+        assert np.array_equal(got[pi], tbs[pi]), (got[pi].tolist(), tbs[pi].tolist())
+        assert len(res[pi].table_structure_result) == len(tbs[pi])
 
 
 def _match_cells(want, got, tol=0.1):

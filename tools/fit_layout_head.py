@@ -5,7 +5,7 @@ A seeded random-init PicoDet (synth_weights.picodet_state_dict) finds no tables,
 own rectangles.  This script keeps the seeded random backbone and neck, runs the CPU oracle (oracle/picodet.py) up to the neck's stride-64 output
 [128, 13, 10] on pages 0 .. n-1 of the generator (the pages bench.py's ranks 0 .. n/64-1 use), and trains, with Adam on the CPU (minutes), the four
 depthwise / pointwise pairs of the level-3 head tower and `head.head_cls3` to emit (i) the "table" logit: positive on the anchors inside the central 60 % of a
-table, ignored on the rest of its inside, negative elsewhere and for every other class; (ii) the four 8-bin distance distributions (stride 64: the only level
+table (a quality score that peaks at the anchor nearest the centre), ignored on the rest of its inside, negative elsewhere and for every other class; (ii) the four 8-bin distance distributions (stride 64: the only level
 whose 7 x 64 px reach covers a table's half width).  Levels 0-2 get a constant -12 on the table logit.
 
 What it is and is not: a WORKLOAD DEVICE.  A stride-64 tower over the features of a random backbone memorises the pages it was fitted on (all tables found, box
@@ -74,7 +74,11 @@ def targets(ts, central=0.6):
                 cen = np.zeros((FH, FW), bool)
                 cen.flat[np.argmin(np.where(inside, d, np.inf)) if inside.any() else np.argmin(d)] = True
             wcls[p][inside & ~cen] = 0
-            cls[p][cen] = 1
+            # a quality score, as PicoDet's varifocal loss trains (score = IoU of the anchor's box): highest at the anchor nearest the centre and
+            # DISTINCT from its neighbours', so that NMS keeps the same anchor in every arithmetic -- logits pushed to +-inf by hard 0 / 1 targets
+            # saturate to 1.0 and leave the winner to the order of the candidates (the engine and the oracle then crop boxes a few pixels apart)
+            dn = np.maximum(np.abs(CX - mx) / max(central * (x2 - x1) / 2, STR / 2), np.abs(CY - my) / max(central * (y2 - y1) / 2, STR / 2))
+            cls[p][cen] = (0.95 - 0.45 * np.clip(dn, 0, 1))[cen]
             m = inside | cen
             d4 = np.stack([CX - x1, CY - y1, x2 - CX, y2 - CY]) / STR
             dist[p][:, m] = np.clip(d4[:, m], 0, REG - 1 - 1e-3)
@@ -182,7 +186,7 @@ def main():
         tgt[:, TABLE] = cls[idx]
         w = torch.ones_like(tgt)
         w[:, TABLE] = wcls[idx]
-        lc = (F.binary_cross_entropy_with_logits(y[:, :NCLS], tgt, reduction="none") * w * (1 + 20 * tgt)).mean()
+        lc = (F.binary_cross_entropy_with_logits(y[:, :NCLS], tgt, reduction="none") * w * (1 + 20 * (tgt > 0))).mean()
         lg = y[:, NCLS:].reshape(-1, 4, REG, FH, FW).log_softmax(2)
         dd = dist[idx]
         k = dd.floor().long().clamp(max=REG - 2)
