@@ -2,7 +2,7 @@
 tests/test_gpu_e2e.py (the engine's run): page indices, weights, table regions."""
 import numpy as np
 
-E2E_PAGES = (7, 3)          # synthetic page indices (pdf_table_amd.synth_pages.make_page)
+E2E_PAGES = (17, 6)         # synthetic page indices (pdf_table_amd.synth_pages.make_page): a two-table and a one-table page whose oracle logical locations keep clear of the .5 rounding boundary on two of the three tables, so that HTML strings get compared
 
 
 def e2e_state_dicts():
