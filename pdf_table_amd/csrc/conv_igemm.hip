@@ -895,6 +895,245 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_dma16_kernel(ConvK p, con
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution 64 -> 64, weight-stationary and persistent ("ws64", bf16 mode).
+// The five 64 -> 64 @240^2 layers of DB-ResNet18 (layer1 + the fused out2; db_net/dbnet.py:102-140, 615-638) are the detector's
+// largest item and the furthest from the matrix roofline (0.54 PF on the v3 4-wave tile): K is only 576, so a 16x32 tile
+// is four K-slices -- a DMA round trip of prologue, two fp32 passes through LDS of epilogue -- and every tile re-fetches the
+// layer's whole 72 KB weight matrix, which is HALF of its LDS fill traffic (73.7 KB weights against 78 KB of input patch).
+// Here ONE workgroup per CU (8 waves) keeps the whole weight matrix in LDS as ready-made MFMA fragments for the kernel's
+// lifetime and walks a contiguous run of 16x32-pixel tiles.  The input patches stream through two 32-channel slice buffers
+// (global_load_lds, 64-byte pixel rows with the 16-byte slots XOR-swizzled by ((pixel >> 2) & 3): conflict-free ds_read_b128
+// for 16 consecutive pixels); the slice pipeline runs ACROSS tile boundaries, so only the first tile of a workgroup pays a
+// prologue.  The MFMA takes the weights as its A operand (D = [channel][pixel]): a lane owns a pixel, the epilogue (bias,
+// residual, ReLU, bf16 packing, v_permlane32_swap into 16-byte channel runs) runs from the accumulators while the NEXT
+// tile's first slice is already in LDS, its stores drain under that slice's MFMAs, and the residual is fetched into
+// registers one slice ahead.  LDS: 72 KB weights + 2 x 39 KB slices = 150 KB.
+// ---------------------------------------------------------------------------------------------------
+#ifndef PT_WS_ABL
+#define PT_WS_ABL 0      // ablation bits (timing only): 1 no stores, 4 no epilogue, 8 no input DMA after the first tile, 16 no MFMA loop
+#endif
+struct Ws64Cfg {
+  static constexpr int NWV = 8, NTHR = 512;
+  static constexpr int TH = 16, TW = 32, THIN = TH + 2, TWIN = TW + 2;
+  static constexpr int NPIX = THIN * TWIN;                     // 612
+  static constexpr int W_FRAGS = 9 * 4 * 2;                    // (tap, 16-channel k-step, 32-output half): 1 KB each
+  static constexpr int W_BYTES = W_FRAGS * 1024;               // 73 728
+  static constexpr int IN_UNITS = NPIX * 4;                    // 16-byte units of a 32-channel slice
+  static constexpr int IN_INSTR = (IN_UNITS + 63) / 64;        // 39 wave-wide DMA instructions
+  static constexpr int IN_SLOTS = (IN_INSTR + NWV - 1) / NWV;  // 5 per wave
+  static constexpr int IN_BYTES = IN_INSTR * 1024;             // 39 936
+  static constexpr int SMEM = W_BYTES + 2 * IN_BYTES;          // 153 600
+};
+
+__global__ __launch_bounds__(512, 1) void conv3x3_ws64_kernel(ConvK p, const bf16_t* __restrict__ zero_page) {
+  using C = Ws64Cfg;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_w = smem;
+  char* s_in0 = smem + C::W_BYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lx = lane & 31, q = lane >> 5;
+
+  // this workgroup's run of tiles (tile = (image, tile row, tile column), x fastest)
+  const int G = gridDim.x;
+  const int Lw = xcd_remap(blockIdx.x, G);
+  const int t0 = (int)((long long)Lw * p.total_tiles / G), t1 = (int)((long long)(Lw + 1) * p.total_tiles / G);
+  if (t0 >= t1) return;
+  const int nsl = 2 * (t1 - t0);
+  const int tiles_img = p.tiles_x * p.tiles_y;
+
+  // weights -> LDS, once: fragment f = (tap * 4 + ks) * 2 + nh holds, for lane (lx, q), channels ks * 16 + 8 q .. + 7 of output
+  // nh * 32 + lx; source = the v1 tiling [Cin/32 = 2][9][64][32]
+#pragma unroll
+  for (int j = 0; j < C::W_FRAGS / C::NWV; ++j) {
+    const int f = wave + C::NWV * j;
+    const int tap = f >> 3, ks = (f >> 1) & 3, nh = f & 1;
+    const bf16_t* src = p.w + (((ks >> 1) * 9 + tap) * 64 + nh * 32 + lx) * 32 + (ks & 1) * 16 + q * 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(s_w + f * 1024), 16, 0, 0);
+  }
+
+  const bf16_t* src_in[C::IN_SLOTS];
+  bool on_in[C::IN_SLOTS];
+  auto issue = [&](int sl) {
+    if (!(sl & 1)) {      // first slice of a tile: where its patch lies
+      const int t = t0 + (sl >> 1);
+      const int b = t / tiles_img, r = t - b * tiles_img;
+      const int tyi = r / p.tiles_x, txi = r - tyi * p.tiles_x;
+      const int oy0 = tyi * C::TH, ox0 = txi * C::TW;
+      const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * 64;
+#pragma unroll
+      for (int j = 0; j < C::IN_SLOTS; ++j) {
+        const int k = wave + C::NWV * j;
+        const int U = k * 64 + lane;
+        on_in[j] = (k < C::IN_INSTR) && (U < C::IN_UNITS);
+        const int pix = U >> 2;
+        const int qq = (U & 3) ^ ((pix >> 2) & 3);
+        const int iy = pix / C::TWIN, ix = pix - iy * C::TWIN;
+        const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
+        const bool inside = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        src_in[j] = inside ? in_b + ((size_t)gy * p.W + gx) * 64 + qq * 8 : zero_page;
+      }
+    }
+    char* lds = s_in0 + (sl & 1) * C::IN_BYTES;
+    const int c0 = (sl & 1) * 32;
+#pragma unroll
+    for (int j = 0; j < C::IN_SLOTS; ++j) {
+      if (on_in[j])
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_in[j] + c0),
+                                         (__attribute__((address_space(3))) void*)(lds + (wave + C::NWV * j) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  u32x4 rres[2][2][2];                                   // residual of the tile in flight: [row][32-channel block][16-byte run]
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) rres[m][n][h] = u32x4{0u, 0u, 0u, 0u};
+
+  // bias in the accumulator layout: register r of block nb = channel nb * 32 + (r & 3) + 8 (r >> 2) + 4 q
+  f32x4 bs[2][4];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bs[nb][g] = *reinterpret_cast<const f32x4*>(p.bias + nb * 32 + 8 * g + 4 * q);
+
+  // pixel of this lane in tile t: -> (image, row of patch row 2 wave, column); false: outside the map
+  auto tile_pos = [&](int t, int& b, int& oy, int& ox) {
+    b = t / tiles_img;
+    const int r = t - b * tiles_img;
+    const int tyi = r / p.tiles_x, txi = r - tyi * p.tiles_x;
+    oy = tyi * C::TH + 2 * wave;
+    ox = txi * C::TW + lx;
+  };
+  auto load_res = [&](int t) {
+    int b, oy, ox;
+    tile_pos(t, b, oy, ox);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      if (oy + m < p.Ho && ox < p.Wo) {
+        const bf16_t* rp = p.res + (((size_t)b * p.Ho + oy + m) * p.Wo + ox) * 64 + 8 * q;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          rres[m][nb][0] = *reinterpret_cast<const u32x4*>(rp + nb * 32);
+          rres[m][nb][1] = *reinterpret_cast<const u32x4*>(rp + nb * 32 + 16);
+        }
+      }
+    }
+  };
+  auto epilogue = [&](int t) {
+    int b, oy, ox;
+    tile_pos(t, b, oy, ox);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const bool inside = oy + m < p.Ho && ox < p.Wo;
+      bf16_t* op = p.out + (((size_t)b * p.Ho + oy + m) * p.Wo + ox) * p.out_cstride + p.out_coff + 8 * q;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        float v[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          v[4 * g + 0] = acc[m][nb][4 * g + 0] + bs[nb][g].x;
+          v[4 * g + 1] = acc[m][nb][4 * g + 1] + bs[nb][g].y;
+          v[4 * g + 2] = acc[m][nb][4 * g + 2] + bs[nb][g].z;
+          v[4 * g + 3] = acc[m][nb][4 * g + 3] + bs[nb][g].w;
+        }
+        if (p.res_mode) {
+          // the 16-byte runs back into the accumulator layout: the swap of the store path is its own inverse
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const u32x4 rr = rres[m][nb][h];
+            const u32x2 a = __builtin_amdgcn_permlane32_swap(rr.x, rr.z, false, false);
+            const u32x2 c = __builtin_amdgcn_permlane32_swap(rr.y, rr.w, false, false);
+            v[8 * h + 0] += bf16lo_f32(a.x); v[8 * h + 1] += bf16hi_f32(a.x);
+            v[8 * h + 2] += bf16lo_f32(c.x); v[8 * h + 3] += bf16hi_f32(c.x);
+            v[8 * h + 4] += bf16lo_f32(a.y); v[8 * h + 5] += bf16hi_f32(a.y);
+            v[8 * h + 6] += bf16lo_f32(c.y); v[8 * h + 7] += bf16hi_f32(c.y);
+          }
+        }
+        if (p.relu == 1) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        uint32_t d[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+        const u32x2 s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+        const u32x2 s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+        const u32x2 s2 = __builtin_amdgcn_permlane32_swap(d[4], d[6], false, false);
+        const u32x2 s3 = __builtin_amdgcn_permlane32_swap(d[5], d[7], false, false);
+#if PT_WS_ABL & 1
+        if (inside && s0.x == 0x12345u) {
+#else
+        if (inside) {
+#endif
+          *reinterpret_cast<u32x4*>(op + nb * 32) = u32x4{s0.x, s1.x, s0.y, s1.y};
+          *reinterpret_cast<u32x4*>(op + nb * 32 + 16) = u32x4{s2.x, s3.x, s2.y, s3.y};
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][nb][r] = 0.f;
+      }
+    }
+  };
+
+  const int pa0 = (2 * wave) * C::TWIN + lx;
+  issue(0);
+  for (int sl = 0; sl < nsl; ++sl) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#if PT_WS_ABL & 8
+    if (sl + 1 < nsl && sl < 2) issue(sl + 1);
+#else
+    if (sl + 1 < nsl) issue(sl + 1);
+#endif
+    if (sl & 1) {
+#if !(PT_WS_ABL & 2)
+      if (p.res_mode) load_res(t0 + (sl >> 1));          // lands under this slice's MFMAs, used after the next barrier
+#endif
+    } else if (sl) {
+#if !(PT_WS_ABL & 4)
+      epilogue(t0 + (sl >> 1) - 1);                      // the stores drain under this slice's MFMAs
+#endif
+    }
+#if PT_WS_ABL & 16
+    if (sl > 1 && p.B != 12345) continue;
+#endif
+    const char* s_in = s_in0 + (sl & 1) * C::IN_BYTES;
+    const char* s_wc = s_w + (sl & 1) * 4096 + lane * 16;   // k-steps 2 c, 2 c + 1 of every tap
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int tap = r * 3 + s;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(s_wc + (tap * 8 + kk * 2) * 1024);
+          const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(s_wc + (tap * 8 + kk * 2 + 1) * 1024);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const int pp = pa0 + (m + r) * C::TWIN + s;
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(s_in + pp * 64 + (((kk * 2 + q) ^ ((pp >> 2) & 3)) << 4));
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a, acc[m][0], 0, 0, 0);      // D = [channel][pixel]
+            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a, acc[m][1], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  epilogue(t1 - 1);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Stem: 7x7 stride-2 pad-3 conv on a 4-channel (RGB0) bf16 image, 64 outputs, bias + ReLU.
 // K is laid out [r=7][s=8][c=4] = 224 (tap s=7 and channel 3 carry zero weights), so that one MFMA
 // k-step (16) = 4 horizontally adjacent pixels x 4 channels = 32 contiguous bytes of the image row.
@@ -1372,6 +1611,37 @@ static int launch_dma16(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   return PT_OK;
 }
 
+// weight-stationary persistent kernel for plain 64 -> 64 layers (bf16 mode): one workgroup per CU walks total_tiles / grid tiles
+static int launch_ws64(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
+  using C = Ws64Cfg;
+  static bool attr_done = false;
+  if (!attr_done) {
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ws64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
+    attr_done = true;
+  }
+  if (!e->zero_page) {
+    PT_HIP_CHECK(hipMalloc(&e->zero_page, 8192));
+    PT_HIP_CHECK(hipMemset(e->zero_page, 0, 8192));
+  }
+  k.tiles_x = (k.Wo + C::TW - 1) / C::TW;
+  k.tiles_y = (k.Ho + C::TH - 1) / C::TH;
+  k.n_tiles = 1;
+  const long long total = (long long)k.B * k.tiles_x * k.tiles_y;
+  PT_REQUIRE(total > 0 && total < (1ll << 30), "conv grid out of range (%lld tiles)", total);
+  k.total_tiles = (int)total;
+  unsigned nblk = (unsigned)(total < e->num_cu ? total : e->num_cu);
+  if (const char* gv = getenv("PT_CONV_WS64_GRID")) {      // tests: fewer workgroups, longer tile runs
+    const int g = atoi(gv);
+    if (g > 0 && (unsigned)g < nblk) nblk = (unsigned)g;
+  }
+  char label[48];
+  snprintf(label, sizeof(label), "conv3x3 ws %d->%d @%dx%d", k.Cin, k.N, k.Ho, k.Wo);
+  PtProfScope prof(e, s, PT_PROF_CONV3X3, flop, label);
+  hipLaunchKernelGGL(conv3x3_ws64_kernel, dim3(nblk), dim3(C::NTHR), C::SMEM, s, k, reinterpret_cast<const bf16_t*>(e->zero_page));
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
 // PT_CONV_VARIANT: 0 = v1 only, 1 = micro-benchmark rule, 2 = v2 wherever it applies, 3 = v3 wherever it applies (default).
 // History: in the DB-ResNet18 graph at 8-page micro-batches v1-only measured fastest (det-only, no post: 3836 pages/s vs
 // 3764 with rule 1 and 3719 with v2) and was the default for most of round 1.  With 32-page det and 80-table Lore
@@ -1442,6 +1712,15 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
     // with K >= 128 channels, the 32-channel-slice DMA kernel (v2) on 60..119-row maps, the register-staged kernel
     // (v1) on short-K layers and on small maps, where the big DMA tiles leave CUs idle
     const int cv = conv_variant();
+    // plain 64 -> 64 layers with enough tiles to give every CU a run of them: the weight-stationary persistent kernel
+    // (PT_CONV_WS64=0: the v3 tiles, A/B switch)
+    const char* ws_ev = getenv("PT_CONV_WS64");      // read per call: 2 forces the kernel for any tile count (tests)
+    const int ws64 = ws_ev ? atoi(ws_ev) : 1;
+    bool masked = false;
+    for (int i = 0; i < 8; ++i) masked = masked || d.tap_mask[i] != 0;
+    if (ws64 && cv == 3 && !d.split && d.Cin == 64 && d.N == 64 && d.rep == 1 && !d.shuffle_cout && d.res_mode <= 1 && !masked &&
+        (ws64 == 2 || (long long)k.B * ((k.Ho + 15) / 16) * ((k.Wo + 31) / 32) >= 4ll * e->num_cu))
+      return launch_ws64(e, k, s, flop);
     const bool v3ok = (d.N % 128 == 0) ? k.Ho >= 12 : k.Ho >= 24;
     const bool wide = d.Cin >= 128;
     int pick = 0;

@@ -96,6 +96,46 @@ def test_conv_variants_vs_torch_fp32(eng, case):
     _conv_case(eng, **case)
 
 
+@pytest.mark.parametrize("case", [
+    dict(B=1, H=16, W=64, Cin=64, N=64, ks=3, stride=1),                               # two tiles, two workgroups
+    dict(B=2, H=37, W=45, Cin=64, N=64, ks=3, stride=1, relu=True, res_mode=1),        # ragged tiles + residual
+    dict(B=3, H=50, W=70, Cin=64, N=64, ks=3, stride=1, relu=True, grid=5),            # 36 tiles walked by 5 workgroups
+    dict(B=2, H=64, W=96, Cin=64, N=64, ks=3, stride=1, res_mode=1, grid=7),           # runs of 3-4 tiles with the residual prefetch
+    dict(B=1, H=33, W=31, Cin=64, N=64, ks=3, stride=1, relu=True, grid=300),          # more workgroups asked for than tiles
+])
+def test_conv_ws64_vs_torch_fp32(eng, case, monkeypatch):
+    """conv3x3_ws64_kernel (weight-stationary persistent 64 -> 64 layers of DB-ResNet18's layer1, dbnet.py:102-140), forced for
+    any tile count; the default dispatch takes it from 4 tiles per CU up (test_conv_ws64_default_dispatch)."""
+    case = dict(case)
+    monkeypatch.setenv("PT_CONV_WS64", "2")
+    if "grid" in case:
+        monkeypatch.setenv("PT_CONV_WS64_GRID", str(case.pop("grid")))
+    _conv_case(eng, **case)
+
+
+def test_conv_ws64_default_dispatch(eng):
+    """9 feature maps of 240x240 (1080 tiles over 256 workgroups): the size at which pt_launch_conv picks the kernel itself."""
+    _conv_case(eng, B=9, H=240, W=240, Cin=64, N=64, ks=3, stride=1, relu=True, res_mode=1, seed=3)
+
+
+def test_conv_ws64_concat_offset(eng, monkeypatch):
+    """the fused out2 writes the p2 slice of the 256-channel concat buffer (db_model.hip: cf.out_coff = 192)."""
+    monkeypatch.setenv("PT_CONV_WS64", "2")
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(9)
+    x = _bf16(torch.randn(2, 64, 20, 40, generator=g))
+    wt = _bf16(torch.randn(64, 64, 3, 3, generator=g) * 0.06)
+    b = torch.randn(64, generator=g) * 0.1
+    fuse = torch.full((2, 20, 40, 256), 7.0, dtype=torch.bfloat16, device=dev)
+    eng.op_conv2d(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev), torch.from_numpy(tile_conv_weight(wt).view(np.int16)).to(dev),
+                  b.to(dev), 3, 1, out=fuse, out_coff=192)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x, wt, b, 1, 1)
+    got = fuse.float().cpu().permute(0, 3, 1, 2)
+    assert bool(((got[:, 192:] - ref).abs() <= ref.abs() * 2.0 ** -8 + 1e-3).all())
+    assert bool((got[:, :192] == 7.0).all())
+
+
 @pytest.mark.parametrize("hw", [(64, 64), (96, 160), (34, 70)])
 def test_stem_vs_torch_fp32(eng, hw):
     """7x7 s2 p3 conv + bias + ReLU on NHWC4 input vs F.conv2d on the same bf16-rounded operands."""
