@@ -481,8 +481,12 @@ struct ConvCfg {
   static constexpr int TH = GEOM ? 4 : ((STRIDE == 1 && KS == 3) ? 8 : 4);
   static constexpr int CT = TW / 32;            // 32-pixel MFMA row-tiles per patch row
   static constexpr int MT = TH * CT / 4;        // row-tiles per wave
-  static constexpr int THIN = (TH - 1) * STRIDE + KS;
-  static constexpr int TWIN = (TW - 1) * STRIDE + KS;
+  // a strided 1x1 conv reads only the pixels it samples: its patch is TH x TW pixels gathered at stride GS and laid out densely in LDS
+  // (SS = 1); the 7 x 63 window of a 4 x 32 stride-2 tile would stage 3.4x the pixels it uses
+  static constexpr int SS = KS == 1 ? 1 : STRIDE;      // pixel stride of an A fragment inside the LDS patch
+  static constexpr int GS = KS == 1 ? STRIDE : 1;      // stride of the patch's pixels in the input map
+  static constexpr int THIN = (TH - 1) * SS + KS;
+  static constexpr int TWIN = (TW - 1) * SS + KS;
   static constexpr int TAPS = KS * KS;
   static constexpr int XEVEN = (TWIN + 1) / 2;   // stride 2: number of even input columns of a patch row (stored first)
   // bytes per staged pixel / weight row: 32 bf16 + 16 B pad.  The stride-2 3x3 patch (9 x 65 pixels) plus its weight slice
@@ -508,7 +512,7 @@ struct ConvCfg {
 // F16 (PT_PRECISION_F16X2, split layers only): K = (x_hi, w) + (x_lo, w) with fp16 weight tiles; the activation halves are converted to
 // fp16 on their way into LDS and the products run on v_mfma_f32_32x32x16_f16
 template <int KS, int STRIDE, int GEOM, int NHALF = 2, bool DIRECT = false, bool F16 = false>
-__global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_igemm_kernel(ConvK p) {
+__global__ __launch_bounds__(256, KS == 1 ? 4 : 2) void conv_igemm_kernel(ConvK p) {
   using C = ConvCfg<KS, STRIDE, GEOM>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_in = smem;
@@ -589,7 +593,7 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
       if (idx < C::NP_IN) {
         const int pix = idx >> 2, part = idx & 3;
         const int iy = pix / C::TWIN, ix = pix - iy * C::TWIN;
-        const int gy = iy0 + iy, gx = ix0 + ix;
+        const int gy = iy0 + iy * C::GS, gx = ix0 + ix * C::GS;
         if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
           v = *reinterpret_cast<const u32x4*>(src + ((size_t)gy * p.W + gx) * src_cs + c0 + part * 8);
       }
@@ -609,7 +613,7 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
       const int idx = tid + j * 256;
       if (idx < C::NP_IN) {
         int slot = idx >> 2;
-        if (STRIDE == 2) {      // even columns first, then the odd ones: the 32 pixels of an A fragment (input columns 2*lx + s)
+        if (C::SS == 2) {       // even columns first, then the odd ones: the 32 pixels of an A fragment (input columns 2*lx + s)
           const int iy = slot / C::TWIN, ix = slot - iy * C::TWIN;   // are then CONSECUTIVE 80-byte slots, as at stride 1 --
           slot = iy * C::TWIN + (ix & 1) * C::XEVEN + (ix >> 1);      // no 2-pixel stride, no bank conflicts on ds_read_b128
         }
@@ -638,7 +642,7 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
 #pragma unroll
   for (int m = 0; m < C::MT; ++m) {
     const int t = wave * C::MT + m;
-    a_slot[m] = ((t / C::CT) * STRIDE) * C::TWIN + ((t % C::CT) * 32 + lx) * (STRIDE == 2 ? 1 : STRIDE);
+    a_slot[m] = ((t / C::CT) * C::SS) * C::TWIN + ((t % C::CT) * 32 + lx);      // SS = 2: even columns are stored first, consecutively
     a_base[m] = s_in + a_slot[m] * C::PIXB + (C::SWZ ? 0 : q * 16);
   }
   const char* b_base = s_w + lx * C::PIXB + (C::SWZ ? 0 : q * 16);
@@ -677,7 +681,7 @@ __global__ __launch_bounds__(256, (KS == 1 && STRIDE == 1) ? 4 : 2) void conv_ig
 #pragma unroll
           for (int m = 0; m < C::MT; ++m) {
             // stride 2: tap s reads input column 2*lx + s = slot lx (s = 0), XEVEN + lx (s = 1), lx + 1 (s = 2)
-            const int soff = STRIDE == 2 ? ((s & 1) * C::XEVEN + (s >> 1)) : s;
+            const int soff = C::SS == 2 ? ((s & 1) * C::XEVEN + (s >> 1)) : s;
             const int a_off = C::SWZ ? (((q + 2 * kk) ^ (((a_slot[m] + r * C::TWIN + soff) >> 2) & 3)) * 16) : kk * 32;
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base[m] + (r * C::TWIN + soff) * C::PIXB + a_off);
             if (DIRECT) {
@@ -1555,6 +1559,8 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
       launch_direct<1, 1, 2>(k, (unsigned)nblk, s);
     else if (plain && KS == 3 && STRIDE == 2)
       launch_direct<3, 2, 2>(k, (unsigned)nblk, s);
+    else if (plain && KS == 1 && STRIDE == 2)
+      launch_direct<1, 2, 2>(k, (unsigned)nblk, s);
     else if (plain && KS == 3 && STRIDE == 1)
       launch_direct<3, 1, 2>(k, (unsigned)nblk, s);
     else if (k.split == 2)

@@ -28,6 +28,7 @@ struct DbWeights {
   const PtTensor *out_w[4], *out_b[4];  // out2..out5
   const PtTensor *bin0_w, *bin0_b, *bin3_w, *bin3_b, *bin6_w, *bin6_b;
   const PtTensor *out2f_w = nullptr, *out2f_b = nullptr, *out2p_w = nullptr, *out2p_b = nullptr;
+  const PtTensor *bin0p_w = nullptr, *bin0p_b = nullptr, *bin0c_w = nullptr, *bin0c_b = nullptr;
 };
 
 int get(const PtModel& m, const std::string& name, const PtTensor** out, bool optional = false) {
@@ -64,6 +65,11 @@ int bind(const PtModel& m, DbWeights& w, bool x3, bool f16) {
   if ((rc = get(m, "out2f.b", &w.out2f_b, true)) != PT_OK) return rc;
   if ((rc = get(m, "out2p" + ws, &w.out2p_w, true)) != PT_OK) return rc;
   if ((rc = get(m, "out2p.b", &w.out2p_b, true)) != PT_OK) return rc;
+  // binarize.0 without the concat (packer: phase conv of the 1/8-resolution concat + 64 -> 64 conv of p2); older blobs do not carry it
+  if ((rc = get(m, "bin0p" + ws, &w.bin0p_w, true)) != PT_OK) return rc;
+  if ((rc = get(m, "bin0p.b", &w.bin0p_b, true)) != PT_OK) return rc;
+  if ((rc = get(m, "bin0c" + ws, &w.bin0c_w, true)) != PT_OK) return rc;
+  if ((rc = get(m, "bin0c.b", &w.bin0c_b, true)) != PT_OK) return rc;
   G(x3 ? "bin6.wf32" : "bin6.w", bin6_w); G("bin6.b", bin6_b);
 #undef G
   return PT_OK;
@@ -73,7 +79,7 @@ inline const bf16_t* W(const PtTensor* t) { return reinterpret_cast<const bf16_t
 inline const float* Bv(const PtTensor* t) { return reinterpret_cast<const float*>(t->d_ptr); }
 
 struct Bufs {
-  bf16_t *s, *p, *t[4], *a[4], *c[4], *d[4], *in5, *o4, *o3, *o2, *fuse, *y0, *y1;
+  bf16_t *s, *p, *t[4], *a[4], *c[4], *d[4], *in5, *o4, *o3, *o2, *fuse, *y0, *y1, *f8, *p2, *yb;
 };
 
 }  // namespace
@@ -93,6 +99,16 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
   if (rc != PT_OK) return rc;
 
   const int ch[4] = {64, 128, 256, 512};
+  // out2 without its lateral (PT_DB_FUSE_OUT2=0: the layer-by-layer path; A/B switch): see the packer for the algebra
+  static int fuse_out2 = -1;
+  if (fuse_out2 < 0) {
+    const char* ev = getenv("PT_DB_FUSE_OUT2");
+    fuse_out2 = ev ? atoi(ev) : 1;
+  }
+  const bool fused2 = fuse_out2 && w.out2f_w && w.out2f_b && w.out2p_w && w.out2p_b;
+  // binarize.0 without the 256-channel concat at 1/4 resolution (PT_DB_FUSE_BIN0=0: the concat path; A/B switch, read per call)
+  const char* fb_env = getenv("PT_DB_FUSE_BIN0");
+  const bool fused0 = fused2 && !(fb_env && atoi(fb_env) == 0) && w.bin0p_w && w.bin0p_b && w.bin0c_w && w.bin0c_b;
   Bufs bf;
   for (int attempt = 0; attempt < 2; ++attempt) {
     e->arenas[PT_ARENA_DET].reset();
@@ -111,10 +127,13 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
       bf.d[l] = l ? take(px * ch[l]) : nullptr;
       px /= 4;
     }
-    bf.in5 = take(px4 / 64 * 256); bf.o4 = take(px4 / 16 * 256); bf.o3 = take(px4 / 4 * 256); bf.o2 = take(px4 * 256);
-    bf.fuse = take(px4 * 256);
+    bf.in5 = take(px4 / 64 * 256); bf.o4 = take(px4 / 16 * 256); bf.o3 = take(px4 / 4 * 256);
+    bf.o2 = fused2 ? nullptr : take(px4 * 256);
+    bf.fuse = fused0 ? nullptr : take(px4 * 256);
     bf.y0 = take(px4 * 64);
     bf.y1 = take(px2 * 64);
+    bf.f8 = bf.p2 = bf.yb = nullptr;
+    if (fused0) { bf.f8 = take(px4 / 4 * 192); bf.p2 = take(px4 * 64); bf.yb = take(px4 * 64); }
     if (ok) break;
     if (attempt == 1) {
       pt_set_error("activation arena allocation failed");
@@ -172,45 +191,51 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
   }
   // decoder: lateral 1x1 convs with the top-down add fused (in5 first, then in4 + up(in5), ...)
   bf16_t* lat[4] = {bf.o2, bf.o3, bf.o4, bf.in5};  // index i <-> feature c[i]
-  // out2 without its lateral (PT_DB_FUSE_OUT2=0: the layer-by-layer path; A/B switch): see the packer for the algebra
-  static int fuse_out2 = -1;
-  if (fuse_out2 < 0) {
-    const char* ev = getenv("PT_DB_FUSE_OUT2");
-    fuse_out2 = ev ? atoi(ev) : 1;
-  }
-  const bool fused2 = fuse_out2 && w.out2f_w && w.out2f_b && w.out2p_w && w.out2p_b;
   for (int i = 3; i >= (fused2 ? 1 : 0); --i) {
     ConvDesc c = conv(bf.c[i], H >> (2 + i), W_ >> (2 + i), ch[i], w.in_w[i], w.in_b[i], 256, 1, 1, lat[i], 256, 0);
     if (i < 3) { c.res = lat[i + 1]; c.res_mode = 2; }
     RUN(pt_launch_conv(e, c, s));
   }
-  // out5/out4/out3/out2: 3x3 256->64, nearest-upsampled x8/x4/x2/x1 and concatenated as (p5,p4,p3,p2)
+  // phase masks of conv3x3(W, up2(x)) run at the resolution of x: output phase (dy, dx) uses taps (dy..dy+1) x (dx..dx+1)
+  auto phase_masks = [](ConvDesc& c) {
+    for (int dy = 0; dy < 2; ++dy)
+      for (int dx = 0; dx < 2; ++dx) {
+        unsigned mk = 0;
+        for (int r = dy; r < dy + 2; ++r)
+          for (int q = dx; q < dx + 2; ++q) mk |= 1u << (r * 3 + q);
+        c.tap_mask[dy * 2 + dx] = mk;
+      }
+    c.shuffle_cout = 64;
+    c.alg_scale = 4.0 / 9.0;
+  };
+  // out5/out4/out3/out2: 3x3 256->64, nearest-upsampled x8/x4/x2/x1 and concatenated as (p5,p4,p3,p2); with the fused binarize.0
+  // p5/p4/p3 are up-sampled x4/x2/x1 into a 192-channel concat at 1/8 resolution instead
   for (int i = 3; i >= (fused2 ? 1 : 0); --i) {
-    ConvDesc c = conv(lat[i], H >> (2 + i), W_ >> (2 + i), 256, w.out_w[i], w.out_b[i], 64, 3, 1, bf.fuse, 256, 0);
-    c.out_coff = (3 - i) * 64; c.rep = 1 << i;
+    ConvDesc c = conv(lat[i], H >> (2 + i), W_ >> (2 + i), 256, w.out_w[i], w.out_b[i], 64, 3, 1, fused0 ? bf.f8 : bf.fuse, fused0 ? 192 : 256, 0);
+    c.out_coff = (3 - i) * 64; c.rep = fused0 ? 1 << (i - 1) : 1 << i;
     RUN(pt_launch_conv(e, c, s));
   }
   if (fused2) {
     // (a) conv3x3(W_o, up2(o3)) as a phase convolution at 1/8 resolution: 4 x 64 outputs, pixel-shuffled to 1/4 resolution, 4 of 9 taps
     //     per phase (bf.y0 is free until bin0 writes it)
     ConvDesc cp = conv(lat[1], H >> 3, W_ >> 3, 256, w.out2p_w, w.out2p_b, 256, 3, 1, bf.y0, 64, 0);
-    cp.shuffle_cout = 64;
-    cp.alg_scale = 4.0 / 9.0;
-    for (int dy = 0; dy < 2; ++dy)
-      for (int dx = 0; dx < 2; ++dx) {
-        unsigned mk = 0;
-        for (int r = dy; r < dy + 2; ++r)
-          for (int q = dx; q < dx + 2; ++q) mk |= 1u << (r * 3 + q);
-        cp.tap_mask[dy * 2 + dx] = mk;
-      }
+    phase_masks(cp);
     RUN(pt_launch_conv(e, cp, s));
-    // (b) + conv3x3(W_o . W_i, c2) with (a) as its residual, straight into the p2 slice of the concat
-    ConvDesc cf = conv(bf.c[0], H >> 2, W_ >> 2, 64, w.out2f_w, w.out2f_b, 64, 3, 1, bf.fuse, 256, 0);
-    cf.out_coff = 192;
+    // (b) + conv3x3(W_o . W_i, c2) with (a) as its residual: p2, straight into its slice of the concat (or, fused binarize.0, on its own)
+    ConvDesc cf = conv(bf.c[0], H >> 2, W_ >> 2, 64, w.out2f_w, w.out2f_b, 64, 3, 1, fused0 ? bf.p2 : bf.fuse, fused0 ? 64 : 256, 0);
+    cf.out_coff = fused0 ? 0 : 192;
     cf.res = bf.y0; cf.res_mode = 1;
     RUN(pt_launch_conv(e, cf, s));
   }
-  {
+  if (fused0) {
+    // binarize.0 = conv3x3(W[:, :192], up2(concat at 1/8)) as a phase convolution + conv3x3(W[:, 192:], p2) + BN bias, ReLU
+    ConvDesc cb = conv(bf.f8, H >> 3, W_ >> 3, 192, w.bin0p_w, w.bin0p_b, 256, 3, 1, bf.yb, 64, 0);
+    phase_masks(cb);
+    RUN(pt_launch_conv(e, cb, s));
+    ConvDesc c = conv(bf.p2, H / 4, W_ / 4, 64, w.bin0c_w, w.bin0c_b, 64, 3, 1, bf.y0, 64, 1);
+    c.res = bf.yb; c.res_mode = 1;
+    RUN(pt_launch_conv(e, c, s));
+  } else {
     ConvDesc c = conv(bf.fuse, H / 4, W_ / 4, 256, w.bin0_w, w.bin0_b, 64, 3, 1, bf.y0, 64, 1);
     RUN(pt_launch_conv(e, c, s));
   }

@@ -125,6 +125,25 @@ def write_blob(items) -> bytes:
     return bytes(out)
 
 
+def _phase_conv_weights(w: torch.Tensor) -> torch.Tensor:
+    """conv3x3(w, up2(x)) as a convolution of x itself: [O, K, 3, 3] -> [4 O, K, 3, 3], output (dy * 2 + dx) * O + o = phase (dy, dx) of the
+    2x2 block an input pixel is up-sampled to (pixel-shuffle store).  Row kernels {w[-1], w[0] + w[1], 0} for dy = 0 and
+    {0, w[-1] + w[0], w[1]} for dy = 1, columns alike: 4 of the 9 taps are non-zero per phase.  Summed in float64."""
+    wd = w.double()
+    rows = {0: (wd[:, :, 0], wd[:, :, 1] + wd[:, :, 2], torch.zeros_like(wd[:, :, 0])),
+            1: (torch.zeros_like(wd[:, :, 0]), wd[:, :, 0] + wd[:, :, 1], wd[:, :, 2])}          # [o, k, s] per low-res row offset
+    ph = torch.zeros(4, w.shape[0], w.shape[1], 3, 3, dtype=torch.float64)
+    for dy in range(2):
+        for dx in range(2):
+            for R in range(3):
+                r_ = rows[dy][R]                                                                   # [o, k, 3 (s)]
+                cols = (r_[:, :, 0], r_[:, :, 1] + r_[:, :, 2], torch.zeros_like(r_[:, :, 0])) if dx == 0 else \
+                       (torch.zeros_like(r_[:, :, 0]), r_[:, :, 0] + r_[:, :, 1], r_[:, :, 2])
+                for S in range(3):
+                    ph[dy * 2 + dx, :, :, R, S] = cols[S]
+    return ph.reshape(4 * w.shape[0], w.shape[1], 3, 3).float()
+
+
 def pack_db_resnet18(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
     """``DBModel`` state_dict (db_net/dbnet.py:715-728) -> blob for PT_MODEL_DB_RESNET18.
     ``x3``: also pack the (hi, lo) weight tiles that PT_PRECISION_BF16X3 uses (3x the conv weight bytes)."""
@@ -161,20 +180,17 @@ def pack_db_resnet18(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
     if float(bi.abs().max()) == 0.0:
         w1 = torch.einsum("okrs,kc->ocrs", wo.double(), wi.double()[:, :, 0, 0]).float()
         bl.add_conv("out2f", w1, bo)
-        wd = wo.double()
-        rows = {0: (wd[:, :, 0], wd[:, :, 1] + wd[:, :, 2], torch.zeros_like(wd[:, :, 0])),
-                1: (torch.zeros_like(wd[:, :, 0]), wd[:, :, 0] + wd[:, :, 1], wd[:, :, 2])}          # [o, k, s] per low-res row offset
-        ph = torch.zeros(4, wo.shape[0], wo.shape[1], 3, 3, dtype=torch.float64)
-        for dy in range(2):
-            for dx in range(2):
-                for R in range(3):
-                    r_ = rows[dy][R]                                                                   # [o, k, 3 (s)]
-                    cols = (r_[:, :, 0], r_[:, :, 1] + r_[:, :, 2], torch.zeros_like(r_[:, :, 0])) if dx == 0 else \
-                           (torch.zeros_like(r_[:, :, 0]), r_[:, :, 0] + r_[:, :, 1], r_[:, :, 2])
-                    for S in range(3):
-                        ph[dy * 2 + dx, :, :, R, S] = cols[S]
-        bl.add_conv("out2p", ph.reshape(4 * wo.shape[0], wo.shape[1], 3, 3).float(), torch.zeros(4 * wo.shape[0]))
-    bl.add_conv("bin0", *fold_conv_bn(sd, "decoder.binarize.0", "decoder.binarize.1"))
+        bl.add_conv("out2p", _phase_conv_weights(wo), torch.zeros(4 * wo.shape[0]))
+    wb, bb = fold_conv_bn(sd, "decoder.binarize.0", "decoder.binarize.1")
+    bl.add_conv("bin0", wb, bb)
+    # binarize.0 without the 256-channel concat at 1/4 resolution (dbnet.py:631-633: fuse = cat(up8(p5), up4(p4), up2(p3), p2), 29.5 MB per
+    # page written and read back).  The conv is linear in its input channels, and up4 = up2 . up2, up8 = up2 . up4:
+    #   conv3x3(W, fuse) = conv3x3(W[:, 192:], p2) + conv3x3(W[:, :192], up2(cat(up4(p5), up2(p4), p3)))
+    # -- the second term is the phase convolution above on a 192-channel concat at 1/8 RESOLUTION (5.5 MB per page), the first a 64 -> 64
+    # conv that takes it as its residual and applies the folded BN bias + ReLU: 9.9 instead of 17.0 GFLOP per page.
+    if wb.shape[1] == 256 and wb.shape[0] == 64:
+        bl.add_conv("bin0p", _phase_conv_weights(wb[:, :192]), torch.zeros(4 * wb.shape[0]))
+        bl.add_conv("bin0c", wb[:, 192:].contiguous(), bb)
     # ConvTranspose2d(64,64,2,2)+BN -> 1x1 GEMM, N index = (dy*2+dx)*64 + co
     wt, bt = fold_conv_bn(sd, "decoder.binarize.3", "decoder.binarize.4", transposed=True)  # [ci, co, 2, 2]
     wn = wt.permute(2, 3, 1, 0).reshape(4 * 64, 64, 1, 1)
