@@ -801,14 +801,22 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_dma16_kernel(ConvK p, con
   }
   // weight unit U -> row = U >> 1 = tap * NW + n, half = (U & 1) ^ ((row >> 3) & 1); element offset inside one
   // 32-channel chunk of the v1 tiling [N/64][Cin/32][9][64][32], relative to (nt64 = NT * nb, chunk32 = 0)
+  // a DMA instruction moves 32 weight rows of ONE tap and ONE 64-channel output tile: instructions whose tap is masked out for that
+  // tile (phase convolutions: 5 of 9) are not issued -- their LDS rows are never read.  Weights are 36 of the 55 KB a 128-wide
+  // slice stages, and two workgroups per CU fill at ~54 B per clock against the ~64 the L2 delivers: the phase convs were fill-bound
   int src_w[C::W_SLOTS];
+  bool on_w[C::W_SLOTS];
 #pragma unroll
   for (int j = 0; j < C::W_SLOTS; ++j) {
-    const int U = (wave + NWV * j) * 64 + lane;
+    const int k = wave + NWV * j;
+    const int U = k * 64 + lane;
     const int row = U >> 1;
     const int tap = row / C::NW, n = row - tap * C::NW;
     const int hq = (U & 1) ^ ((row >> 3) & 1);
     src_w[j] = (n >> 6) * nch32 * (9 * 64 * 32) + (tap * 64 + (n & 63)) * 32 + hq * 8;
+    const int ktap = (k * 32) / C::NW, kt64 = NT * nb + (((k * 32) % C::NW) >> 6);      // wave-uniform
+    const unsigned km = (kt64 < 8 && p.tap_mask[kt64]) ? p.tap_mask[kt64] : 0x1FFu;
+    on_w[j] = k < C::W_INSTR && ((km >> ktap) & 1u);
   }
   const bf16_t* wt = p.w + (size_t)(NT * nb) * nch32 * (9 * 64 * 32);
 
@@ -827,7 +835,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_dma16_kernel(ConvK p, con
     }
 #pragma unroll
     for (int j = 0; j < C::W_SLOTS; ++j) {
-      if (wave + NWV * j < C::W_INSTR)
+      if (on_w[j])
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wc + src_w[j]),
                                          (__attribute__((address_space(3))) void*)(lds_w + (wave + NWV * j) * 1024), 16, 0, 0);
     }
@@ -1403,6 +1411,140 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_pool_kernel(ConvK p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The same stem + max-pool, persistent and weight-stationary.  conv_stem7x7_pool_kernel spends 85 % of a tile in latency: one
+// tile per workgroup, whose 29.7 KB weight image (more than its 20.7 KB input patch) and input are fetched, staged and
+// waited for before the first MFMA (0.86 ms per 64 pages for 3.6 k cycles of MFMA per tile and SIMD).  Here ONE workgroup
+// per CU (8 waves, two stem rows each) keeps the whole weight matrix in REGISTERS as the MFMA's A fragments (14 k-steps x
+// 2 x 16 B per lane: no weight traffic and no weight ds_reads after the first tile), walks a contiguous run of tiles, and
+// fetches the next tile's input patch into registers while the current one is multiplied and pooled.  Same MFMA sequence,
+// same rounding, same max: bit-identical to the kernel above (test_stem_pool_fused_is_bit_identical covers both).
+// ---------------------------------------------------------------------------------------------------
+struct StemPoolWsCfg {
+  static constexpr int NTHR = 512;
+  static constexpr int NI = (StemPoolCfg::NP_IN + NTHR - 1) / NTHR;      // 3 pixel pairs per thread
+};
+
+__global__ __launch_bounds__(512, 1) void conv_stem7x7_pool_ws_kernel(ConvK p) {
+  using C = StemPoolCfg;
+  using W = StemPoolWsCfg;
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // the input patch (20.7 KB), then the bf16 stem patch (69.6 KB) over it
+  char* s_in = smem;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, q = lane >> 5;
+  const int G = gridDim.x;
+  const int Lw = xcd_remap(blockIdx.x, G);
+  const int t0 = (int)((long long)Lw * p.total_tiles / G), t1 = (int)((long long)(Lw + 1) * p.total_tiles / G);
+  if (t0 >= t1) return;
+  const int tiles_img = p.tiles_x * p.tiles_y;
+
+  bf16x8 wreg[14][2];
+#pragma unroll
+  for (int ks = 0; ks < 14; ++ks)
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) wreg[ks][nh] = *reinterpret_cast<const bf16x8*>(p.w + (nh * 32 + lx) * 224 + ks * 16 + q * 8);
+  u32x4 rin[W::NI];
+  auto prefetch = [&](int t) {
+    const int b = t / tiles_img, r = t - b * tiles_img;
+    const int tyi = r / p.tiles_x, txi = r - tyi * p.tiles_x;
+    const int iy0 = (2 * tyi * C::PH - 1) * 2 - 3, ix0 = (2 * txi * C::PW - 1) * 2 - 3;
+    const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * 4;
+#pragma unroll
+    for (int j = 0; j < W::NI; ++j) {
+      const int idx = tid + j * W::NTHR;
+      u32x2 v0 = {0u, 0u}, v1 = {0u, 0u};
+      if (idx < C::NP_IN) {
+        const int iy = idx / C::HP, ip = idx - iy * C::HP;
+        const int gy = iy0 + iy, gx = ix0 + 2 * ip;
+        if ((unsigned)gy < (unsigned)p.H) {
+          const bf16_t* rowp = in_b + (size_t)gy * p.W * 4;
+          if ((unsigned)gx < (unsigned)p.W) v0 = *reinterpret_cast<const u32x2*>(rowp + (size_t)gx * 4);
+          if ((unsigned)(gx + 1) < (unsigned)p.W) v1 = *reinterpret_cast<const u32x2*>(rowp + (size_t)(gx + 1) * 4);
+        }
+      }
+      rin[j] = u32x4{v0.x, v0.y, v1.x, v1.y};
+    }
+  };
+  const char* a_base = s_in + (((wave * 2) * 2) * C::TWIN + 2 * lx + 2 * q) * 8;
+  const int PHo = p.Ho >> 1, PWo = p.Wo >> 1;
+  prefetch(t0);
+  for (int t = t0; t < t1; ++t) {
+#pragma unroll
+    for (int j = 0; j < W::NI; ++j) {
+      const int idx = tid + j * W::NTHR;
+      if (idx < C::NP_IN) {
+        const int iy = idx / C::HP, ip = idx - iy * C::HP;
+        *reinterpret_cast<u32x4*>(s_in + (iy * C::TWIN + 2 * ip) * 8) = rin[j];
+      }
+    }
+    __syncthreads();
+    if (t + 1 < t1) prefetch(t + 1);      // in flight under the MFMAs and the pooling of this tile
+    const int b = t / tiles_img, rr = t - b * tiles_img;
+    const int tyi = rr / p.tiles_x, txi = rr - tyi * p.tiles_x;
+    const int py0 = tyi * C::PH, px0 = txi * C::PW;
+    const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ks = r * 2 + h;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base + ((m * 2 + r) * C::TWIN + 4 * h) * 8);
+          acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[ks][0], a, acc[m][0], 0, 0, 0);     // D = [channel][pixel]
+          acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[ks][1], a, acc[m][1], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();      // the input patch is dead: the stem patch takes its place
+    const bool col_ok = (unsigned)(sx0 + lx) < (unsigned)p.Wo;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int row = wave * 2 + m;
+      const bool ok = col_ok && (unsigned)(sy0 + row) < (unsigned)p.Ho;
+      char* dst = smem + (row * C::TW + lx) * C::PIX + 8 * q;
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n * 32 + 8 * g + 4 * q);      // 256 B, cache-resident: not worth 32 registers
+          u32x2 o = {0u, 0u};
+          if (ok) {
+            o.x = pack_bf16x2(fmaxf(acc[m][n][4 * g + 0] + bv.x, 0.f), fmaxf(acc[m][n][4 * g + 1] + bv.y, 0.f));
+            o.y = pack_bf16x2(fmaxf(acc[m][n][4 * g + 2] + bv.z, 0.f), fmaxf(acc[m][n][4 * g + 3] + bv.w, 0.f));
+          }
+          *reinterpret_cast<u32x2*>(dst + (n * 32 + 8 * g) * 2) = o;
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < C::PH * C::PW * 16; idx += W::NTHR) {
+      const int c4 = idx & 15, pp = idx >> 4;
+      const int py = pp / C::PW, px = pp - py * C::PW;
+      const int oy = py0 + py, ox = px0 + px;
+      if (oy >= PHo || ox >= PWo) continue;
+      u32x2 mx = {0u, 0u};
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const u32x2 v = *reinterpret_cast<const u32x2*>(smem + ((2 * py + dy) * C::TW + 2 * px + dx) * C::PIX + c4 * 8);
+          mx.x = __builtin_elementwise_max(mx.x & 0xFFFFu, v.x & 0xFFFFu) | (__builtin_elementwise_max(mx.x >> 16, v.x >> 16) << 16);
+          mx.y = __builtin_elementwise_max(mx.y & 0xFFFFu, v.y & 0xFFFFu) | (__builtin_elementwise_max(mx.y >> 16, v.y >> 16) << 16);
+        }
+      *reinterpret_cast<u32x2*>(p.out + (((size_t)b * PHo + oy) * PWo + ox) * 64 + c4 * 4) = mx;
+    }
+    __syncthreads();      // the stem patch has been read: the next input patch may land on it
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Thin stride-1 stem (DLA-34 base_layer: 3 -> 16 channels at full resolution, bf16 mode).  conv_stem7x7_kernel<1,1> spends
 // most of its time around the MFMAs: every 8x32-pixel workgroup re-loads the 29 KB weight image from L2 (3.7 GB per
 // 32 tables) and sends 256 x 64 fp32 through LDS to store 16 channels.  Here a workgroup walks STEM_NT tiles of a row
@@ -1802,6 +1944,23 @@ int pt_launch_stem7x7_pool(pt_engine* e, const bf16_t* in, int B, int H, int W, 
   PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "stem+pool grid out of range");
   // FLOP of the layer (the re-computed halo is not algorithmic work)
   PtProfScope prof(e, s, PT_PROF_STEM, 2.0 * B * k.Ho * k.Wo * 64.0 * 147.0, "stem7x7 s2 + maxpool");
+  const char* ws_ev = getenv("PT_STEM_POOL_WS");      // 0: one tile per workgroup (A/B switch, read per call)
+  if (!(ws_ev && atoi(ws_ev) == 0)) {
+    static bool ws_attr = false;
+    if (!ws_attr) {
+      PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem7x7_pool_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, StemPoolCfg::SMEM));
+      ws_attr = true;
+    }
+    k.total_tiles = (int)nblk;
+    unsigned g = (unsigned)(nblk < e->num_cu ? nblk : e->num_cu);
+    if (const char* gv = getenv("PT_STEM_POOL_WS_GRID")) {      // tests: fewer workgroups, longer tile runs
+      const int gg = atoi(gv);
+      if (gg > 0 && (unsigned)gg < g) g = (unsigned)gg;
+    }
+    hipLaunchKernelGGL(conv_stem7x7_pool_ws_kernel, dim3(g), dim3(StemPoolWsCfg::NTHR), StemPoolCfg::SMEM, s, k);
+    PT_HIP_CHECK(hipGetLastError());
+    return PT_OK;
+  }
   hipLaunchKernelGGL(conv_stem7x7_pool_kernel, dim3((unsigned)nblk), dim3(256), StemPoolCfg::SMEM, s, k);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;

@@ -48,15 +48,16 @@ __device__ __forceinline__ ResizeCoef resize_coef(int d, double scale, int ssize
 }
 
 __global__ __launch_bounds__(256) void det_preprocess_kernel(const uint8_t* __restrict__ pages, int n, int h, int w,
-                                                              int nh, int nw, int flavour, int split, bf16_t* __restrict__ out) {
-  const long long total = (long long)n * nh * nw;
-  const double sx = (double)w / nw, sy = (double)h / nh;
+                                                              int nh, int nw, int flavour, int split, bf16_t* __restrict__ out,
+                                                              double sx, double sy) {
+  // grid (column blocks, output row, page): no 64-bit index division per pixel (three emulated divisions cost more than the resize), the
+  // row's vertical coefficients are uniform over the workgroup
+  // sx = (double)w / nw, sy = (double)h / nh come from the host (the same IEEE division): two fp64 divisions per thread were a third of
+  // the kernel's instructions
   const bool area2 = (w == 2 * nw) && (h == 2 * nh);
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int x = (int)(i % nw);
-    const long long t = i / nw;
-    const int y = (int)(t % nh);
-    const int b = (int)(t / nh);
+  const int y = blockIdx.y, b = blockIdx.z;
+  for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < nw; x += gridDim.x * blockDim.x) {
+    const long long i = ((long long)b * nh + y) * nw + x;
     const uint8_t* src = pages + (size_t)b * h * w * 3;
     int v[3];
     if (w == nw && h == nh) {
@@ -72,10 +73,25 @@ __global__ __launch_bounds__(256) void det_preprocess_kernel(const uint8_t* __re
       const ResizeCoef cy = resize_coef(y, sy, h, false);
       const uint8_t* r0 = src + (size_t)cy.s0 * w * 3;
       const uint8_t* r1 = src + (size_t)cy.s1 * w * 3;
+      // the two source pixels of a row are adjacent (or the same one at the clamped borders): ONE unaligned 8-byte load per row covers
+      // their 6 bytes, where twelve byte loads per output pixel made the kernel issue-bound on its memory instructions (1.9 TB/s);
+      // the last two pixels of a row take the byte loads (the window would end past the row -- past the buffer on the last one)
+      const int o0 = cx.s0 * 3, d1 = (cx.s1 - cx.s0) * 24;
+      unsigned long long q0, q1;
+      if (o0 + 8 <= w * 3) {
+        __builtin_memcpy(&q0, r0 + o0, 8);
+        __builtin_memcpy(&q1, r1 + o0, 8);
+      } else {
+        q0 = q1 = 0;
+        for (int k = 0; k < 3; ++k) {
+          q0 |= (unsigned long long)r0[o0 + k] << (8 * k) | (unsigned long long)r0[cx.s1 * 3 + k] << (d1 + 8 * k);
+          q1 |= (unsigned long long)r1[o0 + k] << (8 * k) | (unsigned long long)r1[cx.s1 * 3 + k] << (d1 + 8 * k);
+        }
+      }
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const int S0 = r0[cx.s0 * 3 + c] * cx.a0 + r0[cx.s1 * 3 + c] * cx.a1;
-        const int S1 = r1[cx.s0 * 3 + c] * cx.a0 + r1[cx.s1 * 3 + c] * cx.a1;
+        const int S0 = (int)((q0 >> (8 * c)) & 0xFF) * cx.a0 + (int)((q0 >> (d1 + 8 * c)) & 0xFF) * cx.a1;
+        const int S1 = (int)((q1 >> (8 * c)) & 0xFF) * cx.a0 + (int)((q1 >> (d1 + 8 * c)) & 0xFF) * cx.a1;
         v[c] = (((cy.a0 * (S0 >> 4)) >> 16) + ((cy.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
         v[c] = v[c] < 0 ? 0 : (v[c] > 255 ? 255 : v[c]);
       }
@@ -111,10 +127,9 @@ __global__ __launch_bounds__(256) void det_preprocess_kernel(const uint8_t* __re
 
 int pt_launch_det_preprocess(const uint8_t* pages, int n, int h, int w, int nh, int nw, int flavour, int split,
                              bf16_t* out, hipStream_t s) {
-  const long long total = (long long)n * nh * nw;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL(det_preprocess_kernel, dim3(blocks), dim3(256), 0, s, pages, n, h, w, nh, nw, flavour, split, out);
+  PT_REQUIRE(n > 0 && nh > 0 && nw > 0 && nh < 65536 && n < 65536, "det pre-process: bad extents %d x %d x %d", n, nh, nw);
+  hipLaunchKernelGGL(det_preprocess_kernel, dim3((nw + 255) / 256, nh, n), dim3(256), 0, s, pages, n, h, w, nh, nw, flavour, split, out,
+                     (double)w / nw, (double)h / nh);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }

@@ -304,13 +304,21 @@ def test_stem_pool_fused_is_bit_identical(eng_db, shape, monkeypatch):
     g = torch.Generator().manual_seed(7 + H)
     x = _x4(_bf16(torch.randn(n, 3, H, W, generator=g))).cuda()
     monkeypatch.delenv("PT_STEM_POOL", raising=False)
-    _, fused = eng_db.det_forward_net(x, want_logits=True)
+    monkeypatch.delenv("PT_STEM_POOL_WS", raising=False)
+    _, fused = eng_db.det_forward_net(x, want_logits=True)      # conv_stem7x7_pool_ws_kernel: persistent, weights in registers
     fused = fused.cpu()
+    monkeypatch.setenv("PT_STEM_POOL_WS_GRID", "3")              # ... with runs of many tiles per workgroup
+    _, fused3 = eng_db.det_forward_net(x, want_logits=True)
+    fused3 = fused3.cpu()
+    monkeypatch.delenv("PT_STEM_POOL_WS_GRID")
+    monkeypatch.setenv("PT_STEM_POOL_WS", "0")                   # conv_stem7x7_pool_kernel: one tile per workgroup
+    _, one = eng_db.det_forward_net(x, want_logits=True)
+    one = one.cpu()
     monkeypatch.setenv("PT_STEM_POOL", "0")
     _, two = eng_db.det_forward_net(x, want_logits=True)
     two = two.cpu()
     assert torch.isfinite(fused).all() and fused.abs().max() > 0
-    assert torch.equal(fused, two)
+    assert torch.equal(fused, two) and torch.equal(fused3, two) and torch.equal(one, two)
 
 
 def test_conv_x3_vs_torch_fp32(eng):

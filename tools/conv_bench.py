@@ -20,12 +20,16 @@ if os.environ.get("PT_BENCH_ZERO"):      # zero operands: the same instruction s
     w.zero_()
 wt = torch.from_numpy(tile_conv_weight(w).view(np.int16)).cuda()
 b = torch.zeros(N).cuda()
-out = eng.op_conv2d(x, wt, b, ks, stride, relu=True)
+res = None
+if os.environ.get("PT_BENCH_RES"):       # + residual of the output's shape (the second conv of a BasicBlock)
+    pad_ = ks // 2
+    res = torch.randn(B, (H + 2 * pad_ - ks) // stride + 1, (W + 2 * pad_ - ks) // stride + 1, N, generator=g).to(torch.bfloat16).cuda()
+out = eng.op_conv2d(x, wt, b, ks, stride, relu=True, res=res, res_mode=1 if res is not None else 0)
 torch.cuda.synchronize()
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 ev0.record()
 for _ in range(iters):
-    eng.op_conv2d(x, wt, b, ks, stride, relu=True, out=out)
+    eng.op_conv2d(x, wt, b, ks, stride, relu=True, out=out, res=res, res_mode=1 if res is not None else 0)
 ev1.record()
 torch.cuda.synchronize()
 ms = ev0.elapsed_time(ev1) / iters
