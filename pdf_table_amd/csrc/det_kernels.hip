@@ -47,80 +47,95 @@ __device__ __forceinline__ ResizeCoef resize_coef(int d, double scale, int ssize
   return c;
 }
 
+constexpr int PRE_ROWS = 8;      // output rows per workgroup
+
 __global__ __launch_bounds__(256) void det_preprocess_kernel(const uint8_t* __restrict__ pages, int n, int h, int w,
                                                               int nh, int nw, int flavour, int split, bf16_t* __restrict__ out,
                                                               double sx, double sy) {
-  // grid (column blocks, output row, page): no 64-bit index division per pixel (three emulated divisions cost more than the resize), the
-  // row's vertical coefficients are uniform over the workgroup
-  // sx = (double)w / nw, sy = (double)h / nh come from the host (the same IEEE division): two fp64 divisions per thread were a third of
-  // the kernel's instructions
-  const bool area2 = (w == 2 * nw) && (h == 2 * nh);
-  const int y = blockIdx.y, b = blockIdx.z;
-  for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < nw; x += gridDim.x * blockDim.x) {
-    const long long i = ((long long)b * nh + y) * nw + x;
-    const uint8_t* src = pages + (size_t)b * h * w * 3;
-    int v[3];
-    if (w == nw && h == nh) {
-      const uint8_t* p = src + ((size_t)y * w + x) * 3;
-      v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
-    } else if (area2) {
-      const uint8_t* p0 = src + ((size_t)(2 * y) * w + 2 * x) * 3;
-      const uint8_t* p1 = p0 + (size_t)w * 3;
+  // grid (column blocks, groups of PRE_ROWS output rows, page): no 64-bit index division per pixel, a thread keeps its column --
+  // the horizontal coefficients are computed once for PRE_ROWS pixels.  sx = (double)w / nw, sy = (double)h / nh come from the host
+  // (the same IEEE division).  The normalisation is a function of one byte: a [3][256] table of (bf16 hi | bf16 lo << 16) is built per
+  // workgroup with the per-pixel float sequence (-ffp-contract=off: the same bits) -- the fp32 division and the integer rounding were
+  // a third of the kernel's instructions, and the kernel is VALU-bound (190 instructions per 11 bytes moved).
+  __shared__ uint32_t lut[3][256];
+  {
+    const int u = threadIdx.x;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) v[c] = (p0[c] + p0[3 + c] + p1[c] + p1[3 + c] + 2) >> 2;
-    } else {
-      const ResizeCoef cx = resize_coef(x, sx, w, true);
-      const ResizeCoef cy = resize_coef(y, sy, h, false);
-      const uint8_t* r0 = src + (size_t)cy.s0 * w * 3;
-      const uint8_t* r1 = src + (size_t)cy.s1 * w * 3;
-      // the two source pixels of a row are adjacent (or the same one at the clamped borders): ONE unaligned 8-byte load per row covers
-      // their 6 bytes, where twelve byte loads per output pixel made the kernel issue-bound on its memory instructions (1.9 TB/s);
-      // the last two pixels of a row take the byte loads (the window would end past the row -- past the buffer on the last one)
-      const int o0 = cx.s0 * 3, d1 = (cx.s1 - cx.s0) * 24;
-      unsigned long long q0, q1;
-      if (o0 + 8 <= w * 3) {
-        __builtin_memcpy(&q0, r0 + o0, 8);
-        __builtin_memcpy(&q1, r1 + o0, 8);
+    for (int c = 0; c < 3; ++c) {
+      float o;
+      if (flavour == PT_DET_PRE_DB_TORCH) {
+        const float mean[3] = {123.68f, 116.78f, 103.94f};
+        o = ((float)u - mean[c]) / 255.f;
       } else {
-        q0 = q1 = 0;
-        for (int k = 0; k < 3; ++k) {
-          q0 |= (unsigned long long)r0[o0 + k] << (8 * k) | (unsigned long long)r0[cx.s1 * 3 + k] << (d1 + 8 * k);
-          q1 |= (unsigned long long)r1[o0 + k] << (8 * k) | (unsigned long long)r1[cx.s1 * 3 + k] << (d1 + 8 * k);
+        const float scale = (float)(1.0 / 255.0);
+        const float mean[3] = {0.485f, 0.456f, 0.406f};
+        const float stdv[3] = {0.229f, 0.224f, 0.225f};
+        o = ((float)u * scale - mean[c]) / stdv[c];
+      }
+      const uint32_t hi = f2bf(o);
+      lut[c][u] = hi | (f2bf(o - bf2f(hi)) << 16);
+    }
+  }
+  __syncthreads();
+  const bool area2 = (w == 2 * nw) && (h == 2 * nh);
+  const int b = blockIdx.z;
+  const uint8_t* src = pages + (size_t)b * h * w * 3;
+  for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < nw; x += gridDim.x * blockDim.x) {
+    const ResizeCoef cx = resize_coef(x, sx, w, true);
+    const int o0 = cx.s0 * 3, d1 = (cx.s1 - cx.s0) * 24;
+    for (int ry = 0; ry < PRE_ROWS; ++ry) {
+      const int y = blockIdx.y * PRE_ROWS + ry;
+      if (y >= nh) break;
+      const long long i = ((long long)b * nh + y) * nw + x;
+      int v[3];
+      if (w == nw && h == nh) {
+        const uint8_t* p = src + ((size_t)y * w + x) * 3;
+        v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+      } else if (area2) {
+        const uint8_t* p0 = src + ((size_t)(2 * y) * w + 2 * x) * 3;
+        const uint8_t* p1 = p0 + (size_t)w * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = (p0[c] + p0[3 + c] + p1[c] + p1[3 + c] + 2) >> 2;
+      } else {
+        const ResizeCoef cy = resize_coef(y, sy, h, false);
+        const uint8_t* r0 = src + (size_t)cy.s0 * w * 3;
+        const uint8_t* r1 = src + (size_t)cy.s1 * w * 3;
+        // the two source pixels of a row are adjacent (or the same one at the clamped borders): ONE unaligned 8-byte load per row covers
+        // their 6 bytes; the last two pixels of a row take byte loads (the window would end past the row -- past the buffer on the last one)
+        unsigned long long q0, q1;
+        if (o0 + 8 <= w * 3) {
+          __builtin_memcpy(&q0, r0 + o0, 8);
+          __builtin_memcpy(&q1, r1 + o0, 8);
+        } else {
+          q0 = q1 = 0;
+          for (int k = 0; k < 3; ++k) {
+            q0 |= (unsigned long long)r0[o0 + k] << (8 * k) | (unsigned long long)r0[cx.s1 * 3 + k] << (d1 + 8 * k);
+            q1 |= (unsigned long long)r1[o0 + k] << (8 * k) | (unsigned long long)r1[cx.s1 * 3 + k] << (d1 + 8 * k);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int S0 = (int)((q0 >> (8 * c)) & 0xFF) * cx.a0 + (int)((q0 >> (d1 + 8 * c)) & 0xFF) * cx.a1;
+          const int S1 = (int)((q1 >> (8 * c)) & 0xFF) * cx.a0 + (int)((q1 >> (d1 + 8 * c)) & 0xFF) * cx.a1;
+          v[c] = (((cy.a0 * (S0 >> 4)) >> 16) + ((cy.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
+          v[c] = v[c] < 0 ? 0 : (v[c] > 255 ? 255 : v[c]);
         }
       }
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int S0 = (int)((q0 >> (8 * c)) & 0xFF) * cx.a0 + (int)((q0 >> (d1 + 8 * c)) & 0xFF) * cx.a1;
-        const int S1 = (int)((q1 >> (8 * c)) & 0xFF) * cx.a0 + (int)((q1 >> (d1 + 8 * c)) & 0xFF) * cx.a1;
-        v[c] = (((cy.a0 * (S0 >> 4)) >> 16) + ((cy.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
-        v[c] = v[c] < 0 ? 0 : (v[c] > 255 ? 255 : v[c]);
+      // channel c of the output is channel 2 - c of the page (the BGR flip), through the table
+      const uint32_t e0 = lut[0][v[2]], e1 = lut[1][v[1]], e2 = lut[2][v[0]];
+      if (!split) {
+        u32x2 pk;
+        pk.x = (e0 & 0xFFFFu) | (e1 << 16);
+        pk.y = e2 & 0xFFFFu;
+        *reinterpret_cast<u32x2*>(out + (size_t)i * 4) = pk;
+      } else {  // (hi | lo) pairs for the bf16x3 precision mode: lo = bf16(x - hi)
+        u32x4 pk;
+        pk.x = (e0 & 0xFFFFu) | (e1 << 16);
+        pk.y = e2 & 0xFFFFu;
+        pk.z = (e0 >> 16) | (e1 & 0xFFFF0000u);
+        pk.w = e2 >> 16;
+        *reinterpret_cast<u32x4*>(out + (size_t)i * 8) = pk;
       }
-    }
-    float o[3];
-    if (flavour == PT_DET_PRE_DB_TORCH) {
-      const float mean[3] = {123.68f, 116.78f, 103.94f};
-#pragma unroll
-      for (int c = 0; c < 3; ++c) o[c] = ((float)v[2 - c] - mean[c]) / 255.f;
-    } else {
-      const float scale = (float)(1.0 / 255.0);
-      const float mean[3] = {0.485f, 0.456f, 0.406f};
-      const float stdv[3] = {0.229f, 0.224f, 0.225f};
-#pragma unroll
-      for (int c = 0; c < 3; ++c) o[c] = ((float)v[2 - c] * scale - mean[c]) / stdv[c];
-    }
-    const uint32_t h0 = f2bf(o[0]), h1 = f2bf(o[1]), h2 = f2bf(o[2]);
-    if (!split) {
-      u32x2 pk;
-      pk.x = h0 | (h1 << 16);
-      pk.y = h2;
-      *reinterpret_cast<u32x2*>(out + (size_t)i * 4) = pk;
-    } else {  // (hi | lo) pairs for the bf16x3 precision mode: lo = bf16(x - hi)
-      u32x4 pk;
-      pk.x = h0 | (h1 << 16);
-      pk.y = h2;
-      pk.z = f2bf(o[0] - bf2f(h0)) | (f2bf(o[1] - bf2f(h1)) << 16);
-      pk.w = f2bf(o[2] - bf2f(h2));
-      *reinterpret_cast<u32x4*>(out + (size_t)i * 8) = pk;
     }
   }
 }
@@ -128,7 +143,7 @@ __global__ __launch_bounds__(256) void det_preprocess_kernel(const uint8_t* __re
 int pt_launch_det_preprocess(const uint8_t* pages, int n, int h, int w, int nh, int nw, int flavour, int split,
                              bf16_t* out, hipStream_t s) {
   PT_REQUIRE(n > 0 && nh > 0 && nw > 0 && nh < 65536 && n < 65536, "det pre-process: bad extents %d x %d x %d", n, nh, nw);
-  hipLaunchKernelGGL(det_preprocess_kernel, dim3((nw + 255) / 256, nh, n), dim3(256), 0, s, pages, n, h, w, nh, nw, flavour, split, out,
+  hipLaunchKernelGGL(det_preprocess_kernel, dim3((nw + 255) / 256, (nh + PRE_ROWS - 1) / PRE_ROWS, n), dim3(256), 0, s, pages, n, h, w, nh, nw, flavour, split, out,
                      (double)w / nw, (double)h / nh);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
@@ -369,6 +384,12 @@ int pt_launch_db_head_final(const bf16_t* in, int B, int H, int W, const void* w
 //   a pixel's 4x4 output block leaves as four 16-byte stores, 512 B contiguous per wave and output row.
 // ---------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 hbf16x8;
+typedef __attribute__((ext_vector_type(2))) float hcf2;
+typedef __attribute__((ext_vector_type(2))) __bf16 hcb2;
+// two fp32 -> one dword of two bf16, round-to-nearest-even (v_cvt_pk_bf16_f32; equal to f2bf for finite values)
+__device__ __forceinline__ uint32_t pack2bf(float a, float b) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(hcf2{a, b}, hcb2));
+}
 typedef __attribute__((ext_vector_type(16))) float hf32x16;
 typedef __attribute__((ext_vector_type(4))) float hf32x4;
 
@@ -411,12 +432,28 @@ __global__ __launch_bounds__(256, 4) void db_head_mfma_kernel(const bf16_t* __re
   const float bias6 = b6[0];
   __syncthreads();
   const long long nbatch = (npix + 31) >> 5;
-  for (long long bt = (long long)blockIdx.x * 4 + wave; bt < nbatch; bt += (long long)gridDim.x * 4) {
+  // the next batch's pixels are fetched under this batch's arithmetic: with four waves per SIMD and a ~2.5 us load at the top of every
+  // ~1 us batch the kernel sat at 2 TB/s
+  const long long bstep = (long long)gridDim.x * 4;
+  hbf16x8 xn[4];
+  {
+    const long long bt0 = (long long)blockIdx.x * 4 + wave;
+    const long long p0 = bt0 * 32 + lx;
+    const long long pc0 = p0 < npix ? p0 : npix - 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xn[j] = *reinterpret_cast<const hbf16x8*>(in + (size_t)pc0 * 64 + j * 16 + q * 8);
+  }
+  for (long long bt = (long long)blockIdx.x * 4 + wave; bt < nbatch; bt += bstep) {
     const long long pix = bt * 32 + lx;
-    const long long pc = pix < npix ? pix : npix - 1;
     hbf16x8 xf[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const hbf16x8*>(in + (size_t)pc * 64 + j * 16 + q * 8);
+    for (int j = 0; j < 4; ++j) xf[j] = xn[j];
+    if (bt + bstep < nbatch) {
+      const long long pn = (bt + bstep) * 32 + lx;
+      const long long pcn = pn < npix ? pn : npix - 1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xn[j] = *reinterpret_cast<const hbf16x8*>(in + (size_t)pcn * 64 + j * 16 + q * 8);
+    }
     // the weight fragments are re-read from LDS for every batch: hoisted out of the loop they would take 128 VGPRs and spill
     const char* sw = s_w + lx * PITCH + q * 16;
     const float* sb = s_b + 4 * q;
@@ -438,16 +475,15 @@ __global__ __launch_bounds__(256, 4) void db_head_mfma_kernel(const bf16_t* __re
           const hbf16x8 a = *reinterpret_cast<const hbf16x8*>(sw + t * 32 * PITCH + j * 32);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[j], acc, 0, 0, 0);
         }
-        uint32_t hb[16];
+        // bias + ReLU + round-to-nearest-even to bf16, two values per v_cvt_pk_bf16_f32: the integer rounding (five instructions per
+        // value, 640 per 32-pixel batch against 48 MFMAs) had made this streaming kernel VALU-bound
+        float hv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = fmaxf(acc[r] + sb[t * 32 + (r & 3) + 8 * (r >> 2)], 0.f);
-          hb[r] = f2bf(v);
-        }
+        for (int r = 0; r < 16; ++r) hv[r] = fmaxf(acc[r] + sb[t * 32 + (r & 3) + 8 * (r >> 2)], 0.f);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-          const u32x4 bv = {hb[8 * half + 0] | (hb[8 * half + 1] << 16), hb[8 * half + 2] | (hb[8 * half + 3] << 16),
-                            hb[8 * half + 4] | (hb[8 * half + 5] << 16), hb[8 * half + 6] | (hb[8 * half + 7] << 16)};
+          const u32x4 bv = {pack2bf(hv[8 * half + 0], hv[8 * half + 1]), pack2bf(hv[8 * half + 2], hv[8 * half + 3]),
+                            pack2bf(hv[8 * half + 4], hv[8 * half + 5]), pack2bf(hv[8 * half + 6], hv[8 * half + 7])};
           d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w6f[tt][half], __builtin_bit_cast(hbf16x8, bv), d2, 0, 0, 0);
         }
       }
@@ -480,7 +516,7 @@ int pt_launch_db_head_mfma(const bf16_t* in, int B, int H, int W, const bf16_t* 
   const long long npix = (long long)B * H * W;
   long long blocks = (npix / 32 + 4 * 12 - 1) / (4 * 12);     // ~12 batches per wave: the 37 KB weight image is staged once per workgroup
   if (blocks < 1) blocks = 1;
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > 2048) blocks = 2048;                            // whole rounds of 256 CUs x 4 workgroups (2 400 were 2.3 rounds)
   hipLaunchKernelGGL(db_head_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, npix, H, W, w3, b3, w6, b6, prob, logits);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
