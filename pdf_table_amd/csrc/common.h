@@ -318,6 +318,8 @@ int pt_launch_maxpool_kxk(const bf16_t* in, int n, int H, int W, int C, int kh, 
 int pt_launch_lstm(pt_engine* e, const bf16_t* gx, const bf16_t* whh, bf16_t* hout, int B, int T, int split, hipStream_t s);
 int pt_launch_gemm_argmax(const bf16_t* A, long long M, int K, const bf16_t* W, const float* bias, int N, int* ids, float* maxv,
                           hipStream_t s);
+int pt_launch_gemm_argmax_x3(const bf16_t* A, long long M, int K, const bf16_t* W3, const float* bias, int N, int n_real, int* ids, float* maxv,
+                             void* scratch, hipStream_t s);
 // tlim != null: rows are (line, t) with T = 160 steps per line; 32-step groups at t0 >= tlim[line] are not computed
 int pt_launch_gemm_rows(const bf16_t* A, long long M, int K, const bf16_t* W, const float* bias, int N, bf16_t* out, int relu,
                         hipStream_t s, const int* tlim = nullptr);

@@ -265,6 +265,11 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
   if (!x3 && fused) {
     PtProfScope ps(e, s, PT_PROF_CONV1X1, 2.0 * n * T * 512.0 * 7680.0, "classifier gemm+argmax");
     RUN(pt_launch_gemm_argmax(bf.e2, (long long)n * T, 512, W(cls.w), Bv(cls.b), 7680, ids, maxlogit, s));
+  } else if (x3 && fused && !pt_f16x2(e) && !(getenv("PT_CLS_X3_REFINE") && atoi(getenv("PT_CLS_X3_REFINE")) == 0)) {
+    // hi/lo mode: two single-pass sweeps (maximum, then the classes within the rounding bound of it) + exact logits of those
+    // candidates (rec_kernels.hip: gemm_cand_kernel / cand_eval_kernel); PT_CLS_X3_REFINE=0: the tiled three-pass GEMM (A/B switch)
+    PtProfScope ps(e, s, PT_PROF_CONV1X1, 2.0 * n * T * 512.0 * 7680.0, "classifier bound+refine x3");
+    RUN(pt_launch_gemm_argmax_x3(bf.e2, (long long)n * T, 512, W(cls.w), Bv(cls.b), 7680, 7680, ids, maxlogit, bf.part, s));
   } else {
     {
       ConvDesc c = conv(bf.e2, 1, n, T, 512, cls, 7680, 1, nullptr, 0);

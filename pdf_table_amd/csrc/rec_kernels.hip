@@ -1249,7 +1249,10 @@ template <int KSTEPS, int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __restrict__ A, long long M,
                                                              const bf16_t* __restrict__ W, const float* __restrict__ bias,
                                                              int N, int* __restrict__ ids, float* __restrict__ maxv,
-                                                             bf16_t* __restrict__ out, int relu, const int* __restrict__ tlim) {
+                                                             bf16_t* __restrict__ out, int relu, const int* __restrict__ tlim,
+                                                             int lda, long long wts) {
+  // lda: elements between rows of A (K, or 2 K for the hi halves of (hi | lo) rows); wts: elements between 64-class tiles of W
+  // (NCH * 2048, or three times that for the first third -- the w_hi chunks -- of the three-pass tiling)
   constexpr int K = KSTEPS * 16, NCH = K / 32, P = K * 2 + 16;     // P: LDS row pitch in bytes (odd number of 16-B slots)
   constexpr int NPF = 64 * K * 2 / 16 / 256;                        // 16-byte pieces per thread per stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1269,11 +1272,11 @@ __global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __res
   }
   bf16x8 areg[KSTEPS];
 #pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks) areg[ks] = *reinterpret_cast<const bf16x8*>(A + rc * K + ks * 16 + q * 8);
+  for (int ks = 0; ks < KSTEPS; ++ks) areg[ks] = *reinterpret_cast<const bf16x8*>(A + rc * lda + ks * 16 + q * 8);
   u32x4 pf[NPF];
   float pb = 0.f;
   auto prefetch = [&](int t) {
-    const bf16_t* wt = W + (size_t)t * NCH * (64 * 32);
+    const bf16_t* wt = W + (size_t)t * wts;
 #pragma unroll
     for (int j = 0; j < NPF; ++j) pf[j] = *reinterpret_cast<const u32x4*>(wt + (size_t)(tid + j * 256) * 8);
     if (tid < 64) pb = bias[t * 64 + tid];
@@ -1341,6 +1344,285 @@ __global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Classifier arg-max of the hi/lo (BF16X3) mode by bound and refine.  The tiled three-pass GEMM with per-tile partials + reduce
+// spends 33 ms per 5 k lines (560 TF/s of three-pass work) to find ONE class per row.  With a = a_hi + a_lo, w = w_hi + w_lo:
+//     |a . w - a_hi . w_hi|  <=  |a_lo . w_hi| + |a . w_lo|  <=  2^-9 |a| |w_hi| + 2^-9 |a| |w| (1 + 2^-9)  <  2^-8 * 1.02 |a_hi| |w|
+// (bf16 rounding to nearest: |x_lo| <= 2^-9 |x| element-wise; Cauchy-Schwarz), plus the fp32 accumulation of the single-pass
+// product (<= 512 * 2^-24 |a| |w| = 2^-15 |a| |w|).  So with m = (2^-8 * 1.02 + 2^-14) |a_hi| max_n |w_n| the class that maximises the
+// exact logit has a single-pass logit within 2 m of the single-pass maximum: the kernel below sweeps the classes TWICE at the bf16
+// rate with the row's a_hi resident in registers -- first the maximum, then every class within 2 m of it into per-row slots (a lane
+// owns its row: no atomics) -- and cand_eval_kernel computes the exact four-term logits of those few classes (1.4 per row on
+// the bench's lines) in fp32 and takes their arg-max (lowest index on ties).  A row with more candidates than slots is evaluated
+// over all classes (rare: the margin is 0.18 standard deviations of a row's logits).  The result is the arg-max of the exact
+// (hi + lo) x (hi + lo) products: at least as close to the fp32 oracle as the three-pass sum it replaces.
+// ---------------------------------------------------------------------------------------------------
+constexpr int CAND_SLOTS = 8;      // per (row, half of the classes a lane pair splits): 16 per row
+
+__global__ __launch_bounds__(256) void wnorm_max_kernel(const bf16_t* __restrict__ W3, int N, int K, unsigned* __restrict__ out) {
+  // max over classes of |w_hi + w_lo|: a workgroup per 64-class tile of the [N/64][3 K/32][64][32] tensor (chunks: hi, hi, lo), a wave per
+  // class row, one atomic per workgroup
+  __shared__ float smax[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nch = K >> 5;
+  float best = 0.f;
+  for (int r = wave; r < 64; r += 4) {
+    const int n = blockIdx.x * 64 + r;
+    if (n >= N) break;
+    const bf16_t* wt = W3 + (size_t)blockIdx.x * 3 * nch * 2048 + r * 32;
+    float ss = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      const float v = rbf2f(wt[(size_t)(k >> 5) * 2048 + (k & 31)]) + rbf2f(wt[(size_t)(2 * nch + (k >> 5)) * 2048 + (k & 31)]);
+      ss += v * v;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+    best = fmaxf(best, sqrtf(ss) * 1.0001f);
+  }
+  if (lane == 0) smax[wave] = best;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicMax(out, __float_as_uint(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]))));      // non-negative floats order like their bit patterns
+}
+
+template <int KSTEPS>
+__global__ __launch_bounds__(256, 2) void gemm_cand_kernel(const bf16_t* __restrict__ A, long long M, int lda,
+                                                           const bf16_t* __restrict__ W, long long wts, const float* __restrict__ bias,
+                                                           int N, const float* __restrict__ wmax, const float* __restrict__ rowmax,
+                                                           int* __restrict__ cand) {
+  constexpr int K = KSTEPS * 16, P = K * 2 + 16;
+  constexpr int NPF = 64 * K * 2 / 16 / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sw = smem;
+  float* sb = reinterpret_cast<float*>(smem + 64 * P);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, q = lane >> 5;
+  const long long row = ((long long)blockIdx.x * 4 + wave) * 32 + lx;
+  const long long rc = row < M ? row : M - 1;
+  bf16x8 areg[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) areg[ks] = *reinterpret_cast<const bf16x8*>(A + rc * lda + ks * 16 + q * 8);
+  float thr;
+  {
+    float ss = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = (float)areg[ks][i];
+        ss += v * v;
+      }
+    ss += __shfl_xor(ss, 32);
+    thr = rowmax[rc] - 2.f * (0.00390625f * 1.02f + 6.103515625e-05f) * sqrtf(ss) * 1.0001f * wmax[0];
+  }
+  // [row][q][1 + CAND_SLOTS]: count (may exceed the slots: the row is then evaluated over all classes), class ids
+  int* cp = cand + (rc * 2 + q) * (1 + CAND_SLOTS);
+  int cnt = 0;
+  u32x4 pf[NPF];
+  float pb = 0.f;
+  auto prefetch = [&](int t) {
+    const bf16_t* wt = W + (size_t)t * wts;
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) pf[j] = *reinterpret_cast<const u32x4*>(wt + (size_t)(tid + j * 256) * 8);
+    if (tid < 64) pb = bias[t * 64 + tid];
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+      const int idx = tid + j * 256, c = idx >> 8, r = (idx & 255) >> 2, part = idx & 3;
+      *reinterpret_cast<u32x4*>(sw + r * P + c * 64 + part * 16) = pf[j];
+    }
+    if (tid < 64) sb[tid] = pb;
+  };
+  const int NT = N / 64;
+  prefetch(0);
+  for (int t = 0; t < NT; ++t) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (t + 1 < NT) prefetch(t + 1);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const char* wr = sw + (half * 32 + lx) * P + q * 16;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wr + ks * 32);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, areg[ks], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
+        if (acc[r] + sb[cl] >= thr) {      // rare (1.4 per row): straight to memory
+          if (cnt < CAND_SLOTS && row < M) cp[1 + cnt] = t * 64 + cl;
+          ++cnt;
+        }
+      }
+    }
+  }
+  if (row < M) cp[0] = cnt;
+}
+
+// exact logits (a_hi + a_lo) . (w_hi + w_lo) + bias of every row's candidate classes and their arg-max.  Sixteen lanes per row (four rows
+// per wave): lane l holds the 32 activations of K-chunk l and reads the 64 + 64 bytes of that chunk of a class's w_hi / w_lo rows; K = 512
+__global__ __launch_bounds__(256) void cand_eval_kernel(const bf16_t* __restrict__ A, long long M, int lda, int K, const bf16_t* __restrict__ W3,
+                                                        const float* __restrict__ bias, int N, int n_real, const int* __restrict__ cand,
+                                                        int* __restrict__ ids, float* __restrict__ maxv, int* __restrict__ ovf_count,
+                                                        int* __restrict__ ovf_rows) {
+  const int lane = threadIdx.x & 63, l = lane & 15;
+  const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  const long long rc = row < M ? row : M - 1;
+  const int nch = K >> 5;
+  float a[32];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const u32x4 ah = *reinterpret_cast<const u32x4*>(A + rc * lda + l * 32 + i * 8);
+    const u32x4 al = *reinterpret_cast<const u32x4*>(A + rc * lda + K + l * 32 + i * 8);
+    const uint32_t hw[4] = {ah.x, ah.y, ah.z, ah.w}, lw[4] = {al.x, al.y, al.z, al.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a[8 * i + 2 * j] = rbf2f(hw[j] & 0xFFFFu) + rbf2f(lw[j] & 0xFFFFu);
+      a[8 * i + 2 * j + 1] = rbf2f(hw[j] >> 16) + rbf2f(lw[j] >> 16);
+    }
+  }
+  auto logit = [&](int n) {
+    const bf16_t* wt = W3 + (size_t)(n >> 6) * 3 * nch * 2048 + ((size_t)l * 64 + (n & 63)) * 32;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u32x4 wh = *reinterpret_cast<const u32x4*>(wt + i * 8);
+      const u32x4 wl = *reinterpret_cast<const u32x4*>(wt + (size_t)2 * nch * 2048 + i * 8);
+      const uint32_t hw[4] = {wh.x, wh.y, wh.z, wh.w}, lw[4] = {wl.x, wl.y, wl.z, wl.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sum = fmaf(a[8 * i + 2 * j], rbf2f(hw[j] & 0xFFFFu) + rbf2f(lw[j] & 0xFFFFu), sum);
+        sum = fmaf(a[8 * i + 2 * j + 1], rbf2f(hw[j] >> 16) + rbf2f(lw[j] >> 16), sum);
+      }
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);      // inside the row's 16 lanes
+    return sum + bias[n];
+  };
+  const int* cp = cand + rc * 2 * (1 + CAND_SLOTS);
+  const int c0 = cp[0], c1 = cp[1 + CAND_SLOTS];
+  // more candidates than slots (a row whose logits lie closer together than the rounding bound): every class has to be evaluated -- 7 680
+  // dependent gathers would make one such row the kernel's tail (measured: 5-10 ms), so it goes to cand_full_kernel's list instead
+  const bool all = c0 > CAND_SLOTS || c1 > CAND_SLOTS;
+  if (all) {
+    if (l == 0 && row < M) ovf_rows[atomicAdd(ovf_count, 1)] = (int)row;
+  }
+  const int total = all ? 0 : c0 + c1;
+  float bv = -INFINITY;
+  int bi = 0x7FFFFFFF;
+  for (int i = 0; __any(i < total); ++i) {
+    if (i < total) {      // uniform over the row's 16 lanes
+      const int n = i < c0 ? cp[1 + i] : cp[(1 + CAND_SLOTS) + 1 + (i - c0)];
+      const float v = logit(n);
+      if (v > bv || (v == bv && n < bi)) { bv = v; bi = n; }
+    }
+  }
+  if (l == 0 && row < M && !all) {
+    ids[row] = bi;
+    if (maxv) maxv[row] = bv;
+  }
+}
+
+// the rows cand_eval_kernel could not settle from their slots: a workgroup per row, its 16 lane groups take the classes g, g + 16, ... in
+// ascending order (the first maximum of a group wins), then the groups meet in LDS (lowest class index on equal values)
+__global__ __launch_bounds__(256) void cand_full_kernel(const bf16_t* __restrict__ A, int lda, int K, const bf16_t* __restrict__ W3,
+                                                        const float* __restrict__ bias, int n_real, const int* __restrict__ ovf_count,
+                                                        const int* __restrict__ ovf_rows, int* __restrict__ ids, float* __restrict__ maxv) {
+  __shared__ float sv[16];
+  __shared__ int si[16];
+  const int lane = threadIdx.x & 63, l = lane & 15, g = threadIdx.x >> 4;
+  const int nch = K >> 5, count = ovf_count[0];
+  for (int o = blockIdx.x; o < count; o += gridDim.x) {
+    const long long row = ovf_rows[o];
+    float a[32];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u32x4 ah = *reinterpret_cast<const u32x4*>(A + row * lda + l * 32 + i * 8);
+      const u32x4 al = *reinterpret_cast<const u32x4*>(A + row * lda + K + l * 32 + i * 8);
+      const uint32_t hw[4] = {ah.x, ah.y, ah.z, ah.w}, lw[4] = {al.x, al.y, al.z, al.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a[8 * i + 2 * j] = rbf2f(hw[j] & 0xFFFFu) + rbf2f(lw[j] & 0xFFFFu);
+        a[8 * i + 2 * j + 1] = rbf2f(hw[j] >> 16) + rbf2f(lw[j] >> 16);
+      }
+    }
+    float bv = -INFINITY;
+    int bi = 0x7FFFFFFF;
+    for (int n = g; n < n_real; n += 16) {
+      const bf16_t* wt = W3 + (size_t)(n >> 6) * 3 * nch * 2048 + ((size_t)l * 64 + (n & 63)) * 32;
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32x4 wh = *reinterpret_cast<const u32x4*>(wt + i * 8);
+        const u32x4 wl = *reinterpret_cast<const u32x4*>(wt + (size_t)2 * nch * 2048 + i * 8);
+        const uint32_t hw[4] = {wh.x, wh.y, wh.z, wh.w}, lw[4] = {wl.x, wl.y, wl.z, wl.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sum = fmaf(a[8 * i + 2 * j], rbf2f(hw[j] & 0xFFFFu) + rbf2f(lw[j] & 0xFFFFu), sum);
+          sum = fmaf(a[8 * i + 2 * j + 1], rbf2f(hw[j] >> 16) + rbf2f(lw[j] >> 16), sum);
+        }
+      }
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+      const float v = sum + bias[n];
+      if (v > bv) { bv = v; bi = n; }
+    }
+    __syncthreads();      // the previous row's sv / si have been read
+    if (l == 0) { sv[g] = bv; si[g] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float b = sv[0];
+      int ix = si[0];
+      for (int k = 1; k < 16; ++k)
+        if (sv[k] > b || (sv[k] == b && si[k] < ix)) { b = sv[k]; ix = si[k]; }
+      ids[row] = ix;
+      if (maxv) maxv[row] = b;
+    }
+  }
+}
+
+// hi/lo mode: A bf16 [M][hi(K) | lo(K)], W3 the three-pass tiling [N/64][3 K/32][64][32]; scratch: >= 256 + M * (2 * (1 + CAND_SLOTS) + 2) * 4 bytes.
+// scratch additionally holds M floats (the first sweep's maxima).  n_real: classes below it carry weights.  K == 512 only (PT_ERR_INVALID otherwise: the caller falls back)
+int pt_launch_gemm_argmax_x3(const bf16_t* A, long long M, int K, const bf16_t* W3, const float* bias, int N, int n_real, int* ids, float* maxv,
+                             void* scratch, hipStream_t s) {
+  if (K != 512 || N % 64 != 0 || M <= 0) return PT_ERR_INVALID;
+  constexpr int SMEM = 64 * (512 * 2 + 16) + 64 * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_cand_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_done = true;
+  }
+  unsigned* wmax = reinterpret_cast<unsigned*>(scratch);
+  int* cand = reinterpret_cast<int*>(reinterpret_cast<char*>(scratch) + 256);
+  float* rowmax = reinterpret_cast<float*>(cand + (size_t)M * 2 * (1 + CAND_SLOTS));
+  int* ovf_count = reinterpret_cast<int*>(scratch) + 1;
+  int* ovf_rows = reinterpret_cast<int*>(rowmax + M);
+  static bool attr0 = false;
+  if (!attr0) {
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_argmax_kernel<32, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr0 = true;
+  }
+  PT_HIP_CHECK(hipMemsetAsync(wmax, 0, 8, s));
+  hipLaunchKernelGGL(wnorm_max_kernel, dim3(N / 64), dim3(256), 0, s, W3, N, K, wmax);
+  const long long wts = (long long)3 * (K / 32) * 2048;
+  // sweep 1: the single-pass maximum of every row (the bf16 mode's kernel on the hi halves); sweep 2: the classes within the bound of it
+  hipLaunchKernelGGL((gemm_argmax_kernel<32, 0>), dim3((unsigned)((M + 127) / 128)), dim3(256), SMEM, s, A, M, W3, bias, N, ids, rowmax, nullptr, 0,
+                     nullptr, 2 * K, wts);
+  hipLaunchKernelGGL((gemm_cand_kernel<32>), dim3((unsigned)((M + 127) / 128)), dim3(256), SMEM, s, A, M, 2 * K, W3, wts, bias, N,
+                     reinterpret_cast<const float*>(wmax), rowmax, cand);
+  hipLaunchKernelGGL(cand_eval_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, s, A, M, 2 * K, K, W3, bias, N, n_real, cand, ids, maxv, ovf_count,
+                     ovf_rows);
+  hipLaunchKernelGGL(cand_full_kernel, dim3(2048), dim3(256), 0, s, A, 2 * K, K, W3, bias, n_real, ovf_count, ovf_rows, ids, maxv);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
 // A: bf16 [M][K] row-major, W: conv-tiled [N/64][K/32][64][32], bias fp32 [N]; K == 512 only (returns PT_ERR_INVALID otherwise
 // so that the caller can fall back to the tiled kernel + reduce)
 int pt_launch_gemm_argmax(const bf16_t* A, long long M, int K, const bf16_t* W, const float* bias, int N, int* ids, float* maxv,
@@ -1355,10 +1637,10 @@ int pt_launch_gemm_argmax(const bf16_t* A, long long M, int K, const bf16_t* W, 
   }
   if (K == 192)
     hipLaunchKernelGGL((gemm_argmax_kernel<12, 0>), dim3((unsigned)((M + 127) / 128)), dim3(256), 64 * (192 * 2 + 16) + 64 * 4, s, A, M, W, bias, N,
-                       ids, maxv, nullptr, 0, nullptr);
+                       ids, maxv, nullptr, 0, nullptr, 192, 6ll * 2048);
   else
     hipLaunchKernelGGL((gemm_argmax_kernel<32, 0>), dim3((unsigned)((M + 127) / 128)), dim3(256), SMEM, s, A, M, W, bias, N, ids, maxv,
-                       nullptr, 0, nullptr);
+                       nullptr, 0, nullptr, 512, 16ll * 2048);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
@@ -1375,9 +1657,9 @@ int pt_launch_gemm_rows(const bf16_t* A, long long M, int K, const bf16_t* W, co
   }
   const dim3 grid((unsigned)((M + 127) / 128));
   if (K == 512)
-    hipLaunchKernelGGL((gemm_argmax_kernel<32, 1>), grid, dim3(256), smem, s, A, M, W, bias, N, nullptr, nullptr, out, relu, tlim);
+    hipLaunchKernelGGL((gemm_argmax_kernel<32, 1>), grid, dim3(256), smem, s, A, M, W, bias, N, nullptr, nullptr, out, relu, tlim, 512, 16ll * 2048);
   else
-    hipLaunchKernelGGL((gemm_argmax_kernel<16, 1>), grid, dim3(256), smem, s, A, M, W, bias, N, nullptr, nullptr, out, relu, tlim);
+    hipLaunchKernelGGL((gemm_argmax_kernel<16, 1>), grid, dim3(256), smem, s, A, M, W, bias, N, nullptr, nullptr, out, relu, tlim, 256, 8ll * 2048);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
