@@ -264,7 +264,7 @@ def test_det_net_x3_matches_reference_golden(eng_db_x3, golden_dir):
 # 20-layer graph is ~1 % of the logit scale, not 1e-3.  Per-operator tests above pin each kernel to half a bf16
 # ulp; this test bounds the end-to-end drift (measured: 2.5e-2 of scale / 4.4e-2 in prob at 128x160).
 # The MAXIMUM over a map is a tail statistic of that decorrelation, not a property of a kernel: on the two noise pages of
-# test_det_pipeline_boxes (profiles/r03/experiments.txt, tools/_drift.py) it reads 0.094 with the round-2 kernels, 0.107 when ONLY the
+# test_det_pipeline_boxes (profiles/r03/experiments.txt, tools/det_drift.py) it reads 0.094 with the round-2 kernels, 0.107 when ONLY the
 # summation order of the 64 -> 64 layers changes (conv3x3_ws64_kernel), 0.101 with binarize.0 evaluated without its concat and 0.111
 # with both, while the MEAN drift stays at 5.4e-3 in all four (and BF16X3 at 1.8e-4 max in all four).  Hence 0.12 since round 3.
 BF16_E2E_LOGIT_REL = 6e-2

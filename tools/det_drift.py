@@ -1,3 +1,5 @@
+"""bf16 / BF16X3 drift of the DB detector on the two noise pages of test_det_pipeline_boxes, for the four combinations of
+PT_CONV_WS64 and PT_DB_FUSE_BIN0 (profiles/r03/experiments.txt):  python tools/det_drift.py"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import db_net, db_pre
