@@ -695,8 +695,9 @@ class HipRunner:
         self.sync()
         return time.perf_counter() - t0, c
 
-    def det_only_leg(self, steps=10, warm=2):
-        """BASELINE.json configs[1] in the same run: the det stage alone (pre, DB-ResNet18, bitmap, host post overlapped)"""
+    def det_only_leg(self, steps=20, warm=5):
+        """BASELINE.json configs[1] in the same run: the det stage alone (pre, DB-ResNet18, bitmap, host post overlapped); steps / warm-up as
+        the stand-alone `bench.py --stages det` defaults (a 10-step leg read 2-3 % low: one software-pipeline fill + drain in 0.1 s)"""
         dt, c = self.timed(steps, warm, stages=["det"])
         pps = PAGES_PER_STEP * steps / dt
         return {"pages_per_s_det_only": pps, "steps": steps, "boxes_per_page": c["boxes"] / (PAGES_PER_STEP * steps),

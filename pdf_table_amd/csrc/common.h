@@ -247,6 +247,9 @@ struct ConvDesc {
   // 3x3 stride-1 layers: bit (r * 3 + s) of tap_mask[t] set = tap (r, s) of the 64-channel output tile t has non-zero weights; 0 = all
   // taps.  Tiles past the eighth use every tap.  (Phase convolutions of an up-sampled input: 4 of 9 taps per tile.)
   unsigned tap_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // register-epilogue launches: a row-tile's 32 pixels x 64 channels leave through a wave-private 4 KB LDS tile as whole 128-byte lines
+  // instead of 16-byte pieces per lane (one more barrier per tile: pays for large write-heavy layers, not for small GEMMs)
+  int xp_store = 0;
   int alg_n = 0;
   double alg_scale = 1.0;
 };

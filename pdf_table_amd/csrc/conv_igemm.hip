@@ -72,6 +72,7 @@ struct ConvK {
   const bf16_t* in3;
   int segc0, segc1, segc2, segc3, nseg;
   unsigned tap_mask[8];   // ConvDesc.tap_mask (0 = every tap)
+  int xp_store;           // register epilogue: rows leave through a wave-private LDS tile as whole 128-byte lines (PT_CONV_XP)
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
@@ -703,10 +704,15 @@ __global__ __launch_bounds__(256, KS == 1 ? 4 : 2) void conv_igemm_kernel(ConvK 
   if (DIRECT) {
     // ---- epilogue from the accumulators: lane (lx, q) owns pixel lx of its row-tile ----
     const DirectBias bs = direct_bias<NHALF>(p, nt * 64, q);
+    char* xp = nullptr;
+    if (p.xp_store) {      // uniform: the operand images are dead once every wave has left the K loop
+      __syncthreads();
+      xp = smem + wave * 4096;
+    }
 #pragma unroll
     for (int m = 0; m < C::MT; ++m) {
       const int t = wave * C::MT + m;
-      epilogue_direct_row<NHALF>(p, acc[m], bs, b, oy0 + t / C::CT, ox0 + (t % C::CT) * 32, lx, nt * 64, q, nullptr);
+      epilogue_direct_row<NHALF>(p, acc[m], bs, b, oy0 + t / C::CT, ox0 + (t % C::CT) * 32, lx, nt * 64, q, xp);
     }
     continue;      // next tile of a rep walk (none for the layers that take this path)
   }
@@ -1846,6 +1852,12 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   PT_REQUIRE(d.relu != 3 || d.slope, "conv: PReLU needs the slope tensor");
   k.split = d.split; k.out_lo_off = d.out_lo_off;
   for (int i = 0; i < 8; ++i) k.tap_mask[i] = d.tap_mask[i];
+  {
+    // the layer asks for it (ConvDesc.xp_store: the detector's graph, +0.9 % det-only; the layout net's many small hardswish GEMMs lose
+    // 1.9 % to the extra barrier, the table nets are indifferent); PT_CONV_XP=0 / 1 forces it off / on everywhere (A/B switch, read per call)
+    const char* xv = getenv("PT_CONV_XP");
+    k.xp_store = (xv ? atoi(xv) : d.xp_store) && !d.out_f32;
+  }
   k.head_w = d.head_w; k.head_b = d.head_b; k.head_prob = d.head_prob; k.head_logits = d.head_logits;
   k.argmax_part = d.argmax_part;
   if (d.head_w) PT_REQUIRE(d.shuffle_cout == 64 && d.head_b && (d.head_prob || d.head_logits), "conv: bad fused-head configuration");

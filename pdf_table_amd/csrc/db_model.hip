@@ -154,6 +154,7 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
     ConvDesc c;
     c.in = in; c.B = n; c.H = hh; c.W = ww; c.Cin = cin; c.w = W(wt); c.bias = Bv(bs); c.N = N; c.ks = ks;
     c.stride = stride; c.out = out; c.out_cstride = out_c * m; c.relu = relu; c.split = f16 ? 2 : x3; c.out_lo_off = out_c;
+    c.xp_store = 1;      // full-line stores where the launch takes the register epilogue (conv_igemm.hip: +0.9 % det-only)
     return c;
   };
   // bf16 mode: stem + max-pool in one kernel (the 64-channel half-resolution map stays in LDS; bit-identical);

@@ -144,7 +144,29 @@ class OcrTablePipeline:
         for i, im in enumerate(imgs):
             groups.setdefault(im.shape, []).append(i)
         t_det = t_rec = t_tsr = 0.0
+        # opt-in (PT_PREDICT_CHUNK=n or self.predict_chunk = n; default 0 = off): a group of >= 2 n equally sized pages goes through
+        # predict_stream() in chunks of n, so that the host halves of one chunk (contours, unclip, NMS, CTC collapse, result shaping) run
+        # while the device works on the next, where the loop below waits for every stage of the whole batch in turn.  Same per-page results
+        # (no kernel looks across pages: test_predict_in_chunks_equals_predict).  Measured on 64 host pages per call (tools/pipeline_timing.py):
+        # serial 315-332 pages/s, n = 32: 351, n = 16: 294-308, n = 8: 179 -- the stream's three steps of latency and the smaller launches
+        # eat what the overlap gives, which is why it is off by default and predict_stream() is the throughput API.
+        chunk = int(os.environ.get("PT_PREDICT_CHUNK", str(getattr(self, "predict_chunk", 0))))
+        streamed = {}
+        if chunk > 0 and self.orientation_task is None:
+            for shape, idxs in groups.items():
+                if len(idxs) < 2 * chunk:
+                    continue
+                parts = [idxs[j:j + chunk] for j in range(0, len(idxs), chunk)]
+                tbs = None if table_boxes is None else [[np.asarray(table_boxes[i]).reshape(-1, 4) for i in part] for part in parts]
+                a = time.time()
+                for part, res in zip(parts, self.predict_stream(([imgs[i] for i in part] for part in parts), table_boxes=tbs)):
+                    for i, r in zip(part, res):
+                        results[i] = r
+                t_det += time.time() - a      # the stages overlap: the group's wall time is booked here
+                streamed[shape] = True
         for shape, idxs in groups.items():
+            if shape in streamed:
+                continue
             batch = torch.from_numpy(np.stack([imgs[i] for i in idxs])).to(self.engine._tdev)
             a = time.time()
             stage: DetStage = self.text_detector._stage

@@ -274,6 +274,28 @@ def test_predict_stream_equals_predict():
                     assert ta.get("table_html") == tb_.get("table_html")
 
 
+def test_predict_in_chunks_equals_predict(monkeypatch):
+    """PT_PREDICT_CHUNK: predict() routes a large group of equally sized pages through predict_stream() in chunks -- the same PageResults
+    as the serial path (six pages in chunks of two, layout-chained tables, HTML on)"""
+    from pdf_table_amd.pipeline import OcrTablePipeline
+    pages = [make_page(i)[0] for i in range(6)]
+    p = OcrTablePipeline(device=0, synthetic_seed=0, layout=True, table_structure=True, table_html=True)
+    monkeypatch.setenv("PT_PREDICT_CHUNK", "0")
+    ref = p.predict(pages)
+    monkeypatch.setenv("PT_PREDICT_CHUNK", "2")
+    got = p.predict(pages)
+    p.engine.close()
+    assert len(ref) == len(got) == 6 and sum(len(r.table_structure_result) for r in ref) >= 1
+    for a, b in zip(ref, got):
+        assert np.array_equal(a.det_result, b.det_result)
+        assert [o["text"] for o in a.ocr_result] == [o["text"] for o in b.ocr_result]
+        assert len(a.layout_result) == len(b.layout_result)
+        assert len(a.table_structure_result) == len(b.table_structure_result)
+        for ta, tb_ in zip(a.table_structure_result, b.table_structure_result):
+            assert np.array_equal(ta["polygons"], tb_["polygons"]) and np.array_equal(ta["logi"], tb_["logi"])
+            assert ta.get("table_html") == tb_.get("table_html")
+
+
 def test_predict_stream_refuses_what_it_does_not_pipeline():
     from pdf_table_amd.pipeline import OcrTablePipeline
     p = OcrTablePipeline(device=0, synthetic_seed=0, text_orientation=True)

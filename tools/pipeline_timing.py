@@ -25,7 +25,7 @@ for overlap in (False, True, False, True):
         quads.append(np.stack([l[:, 0], l[:, 1], l[:, 2], l[:, 1], l[:, 2], l[:, 3], l[:, 0], l[:, 3]], 1))
     stage = p.text_detector._stage
     orig = stage.boxes
-    stage.boxes = lambda prob, bm, shape, ev, _o=orig, _q=quads: (_o(prob, bm, shape, ev), _q)[1]
+    stage.boxes = lambda prob, bm, shape, ev, _o=orig, _q=quads: (_o(prob, bm, shape, ev), _q)[1][:prob.shape[0]]      # pages repeat with period 8: a chunk's quads are the first n
     p.predict(pages, table_boxes=tb)
     ts = []
     for _ in range(3):
@@ -47,7 +47,7 @@ from pdf_table_amd.det_stage import DetConfig
 stage.cfg = DetConfig(flavour="db_pp", thresh=stage.cfg.thresh, box_thresh=stage.cfg.box_thresh, unclip_ratio=stage.cfg.unclip_ratio,
                       use_dilation=stage.cfg.use_dilation)
 orig = stage.boxes
-stage.boxes = lambda prob, bm, shape, ev, _o=orig, _q=quads64: (_o(prob, bm, shape, ev), _q)[1]
+stage.boxes = lambda prob, bm, shape, ev, _o=orig, _q=quads64: (_o(prob, bm, shape, ev), _q)[1][:prob.shape[0]]
 batch = torch.from_numpy(np.stack(pages + pages)).cuda()
 tb64 = tb + tb
 for _ in p.predict_stream([batch] * 3, table_boxes=[tb64] * 3):
@@ -63,10 +63,12 @@ for rep in range(2):
     steady = (len(stamps) - 1) * 64 / (stamps[-1] - stamps[0])      # between the first and the last result: no fill / drain
     print(f"predict_stream: 1280 pages in {dt * 1e3:.0f} ms = {1280 / dt:.0f} pages/s incl. the two-batch fill, {steady:.0f} pages/s "
           "between results (64-page batches); host s: " + ", ".join(f"{k} {v:.3f}" for k, v in p.metric["host_seconds"].items()))
-for rep in range(2):
+for ch in ("0", "32", "16", "0", "32"):      # PT_PREDICT_CHUNK: 0 = the serial path (stage after stage over the whole batch)
+    os.environ["PT_PREDICT_CHUNK"] = ch
+    p.predict(pages + pages, table_boxes=tb64)
     t0 = time.time()
     for _ in range(4):
         p.predict(batch_pages := [pg for pg in (pages + pages)], table_boxes=tb64)
     dt = time.time() - t0
-    print(f"predict (same pipeline, 64 host pages per call): {256 / dt:.0f} pages/s")
+    print(f"predict (same pipeline, 64 host pages per call, PT_PREDICT_CHUNK={ch}): {256 / dt:.0f} pages/s")
 p.engine.close()
