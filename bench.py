@@ -1001,7 +1001,7 @@ def main(argv=None):
                 traffic = tot / nl if nl else None
             except Exception:
                 traffic = None
-            roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<3,*> / conv3x3_dma16_kernel (3x3 implicit-GEMM convolutions of all stages)",
+            roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<3,*> / conv3x3_dma16_kernel / conv3x3_ws64_kernel (3x3 implicit-GEMM convolutions of all stages)",
                     "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
                     "traffic": traffic, "traffic_note": "bytes/launch over the 3x3 conv kernels, PMC passes of profiles/pmc_latest.json "
                                                         "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",

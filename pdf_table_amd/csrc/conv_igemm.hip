@@ -1559,10 +1559,14 @@ __global__ __launch_bounds__(512, 1) void conv_stem7x7_pool_ws_kernel(ConvK p) {
 // ---------------------------------------------------------------------------------------------------
 constexpr int STEM_NT = 8;
 
+// SPLIT (PT_PRECISION_BF16X3): pixels are [hi rgb0 | lo rgb0], the weights [hi | lo][64][224]; three passes (x_hi, w_hi), (x_lo, w_hi),
+// (x_hi, w_lo) into the same accumulators, in the general stem kernel's order (bit-identical to it), the 16 channels stored as (hi | lo) halves
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void conv_stem7x7_thin_kernel(ConvK p) {
   using C = StemCfg<1>;
-  __shared__ __attribute__((aligned(16))) char s_in[C::IN_BYTES];
-  __shared__ __attribute__((aligned(16))) char s_w[32 * C::WROW];
+  constexpr int NPL = SPLIT ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) char s_in[NPL][C::IN_BYTES];
+  __shared__ __attribute__((aligned(16))) char s_w[NPL][32 * C::WROW];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int lx = lane & 31, q = lane >> 5;
@@ -1573,13 +1577,16 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_thin_kernel(ConvK p) {
   const int tyi = L % p.tiles_y;
   const int b = L / p.tiles_y;
   const int oy0 = tyi * C::TH, iy0 = oy0 - 3;
-  const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * 4;
+  constexpr int PS = SPLIT ? 8 : 4;                       // bf16 elements per input pixel
+  const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * PS;
   for (int idx = tid; idx < 32 * 28; idx += 256) {        // weight rows 0..31 (channels >= n_valid are zero rows)
     const int row = idx / 28, part = idx - row * 28;
-    *reinterpret_cast<u32x4*>(s_w + row * C::WROW + part * 16) = *reinterpret_cast<const u32x4*>(p.w + (size_t)idx * 8);
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+      *reinterpret_cast<u32x4*>(s_w[pl] + row * C::WROW + part * 16) = *reinterpret_cast<const u32x4*>(p.w + (size_t)pl * 64 * 224 + (size_t)idx * 8);
   }
-  const char* a_base = s_in + ((wave * 2) * C::TWIN + lx + 2 * q) * 8;
-  const char* b_base = s_w + lx * C::WROW + q * 16;
+  const int a_off = ((wave * 2) * C::TWIN + lx + 2 * q) * 8;
+  const int b_off = lx * C::WROW + q * 16;
   for (int it = 0; it < STEM_NT; ++it) {
     const int txi = sxi * STEM_NT + it;
     if (txi >= p.tiles_x) break;
@@ -1591,14 +1598,17 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_thin_kernel(ConvK p) {
       if (idx < C::NP_IN) {
         const int iy = idx / C::HP, ip = idx - iy * C::HP;
         const int gy = iy0 + iy, gx = ix0 + 2 * ip;
-        u32x2 v0 = {0u, 0u}, v1 = {0u, 0u};
-        if ((unsigned)gy < (unsigned)p.H) {
-          const bf16_t* rowp = in_b + (size_t)gy * p.W * 4;
-          if ((unsigned)gx < (unsigned)p.W) v0 = *reinterpret_cast<const u32x2*>(rowp + (size_t)gx * 4);
-          if ((unsigned)(gx + 1) < (unsigned)p.W) v1 = *reinterpret_cast<const u32x2*>(rowp + (size_t)(gx + 1) * 4);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+          u32x2 v0 = {0u, 0u}, v1 = {0u, 0u};
+          if ((unsigned)gy < (unsigned)p.H) {
+            const bf16_t* rowp = in_b + (size_t)gy * p.W * PS + pl * 4;
+            if ((unsigned)gx < (unsigned)p.W) v0 = *reinterpret_cast<const u32x2*>(rowp + (size_t)gx * PS);
+            if ((unsigned)(gx + 1) < (unsigned)p.W) v1 = *reinterpret_cast<const u32x2*>(rowp + (size_t)(gx + 1) * PS);
+          }
+          u32x4 v = {v0.x, v0.y, v1.x, v1.y};
+          *reinterpret_cast<u32x4*>(s_in[pl] + (iy * C::TWIN + 2 * ip) * 8) = v;
         }
-        u32x4 v = {v0.x, v0.y, v1.x, v1.y};
-        *reinterpret_cast<u32x4*>(s_in + (iy * C::TWIN + 2 * ip) * 8) = v;
       }
     }
     __syncthreads();
@@ -1609,16 +1619,21 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_thin_kernel(ConvK p) {
       for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
     // weights as the A operand: D is [channel][pixel] -- a lane owns one pixel, its accumulators are 4-channel runs
 #pragma unroll
-    for (int r = 0; r < 7; ++r) {
+    for (int pass = 0; pass < (SPLIT ? 3 : 1); ++pass) {
+      const char* a_base = s_in[SPLIT && pass == 1 ? NPL - 1 : 0] + a_off;
+      const char* b_base = s_w[SPLIT && pass == 2 ? NPL - 1 : 0] + b_off;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(b_base + (r * 2 + h) * 32);
+      for (int r = 0; r < 7; ++r) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const char* ap = a_base + ((m + r) * C::TWIN + 4 * h) * 8;
-          const u32x2 lo = *reinterpret_cast<const u32x2*>(ap), hi = *reinterpret_cast<const u32x2*>(ap + 8);
-          const u32x4 av = {lo.x, lo.y, hi.x, hi.y};
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, __builtin_bit_cast(bf16x8, av), acc[m], 0, 0, 0);
+        for (int h = 0; h < 2; ++h) {
+          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(b_base + (r * 2 + h) * 32);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const char* ap = a_base + ((m + r) * C::TWIN + 4 * h) * 8;
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(ap), hi = *reinterpret_cast<const u32x2*>(ap + 8);
+            const u32x4 av = {lo.x, lo.y, hi.x, hi.y};
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, __builtin_bit_cast(bf16x8, av), acc[m], 0, 0, 0);
+          }
         }
       }
     }
@@ -1634,9 +1649,17 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_thin_kernel(ConvK p) {
           const int ch = 8 * rg + 4 * q;
           if (ch >= p.n_valid) continue;
           const f32x4 bs = *reinterpret_cast<const f32x4*>(p.bias + ch);
-          const uint32_t h0 = f32_to_bf16(fmaxf(acc[m][rg * 4 + 0] + bs.x, 0.f)), h1 = f32_to_bf16(fmaxf(acc[m][rg * 4 + 1] + bs.y, 0.f)),
-                         h2 = f32_to_bf16(fmaxf(acc[m][rg * 4 + 2] + bs.z, 0.f)), h3 = f32_to_bf16(fmaxf(acc[m][rg * 4 + 3] + bs.w, 0.f));
-          *reinterpret_cast<u32x2*>(op + ch) = u32x2{h0 | (h1 << 16), h2 | (h3 << 16)};
+          const float v0 = fmaxf(acc[m][rg * 4 + 0] + bs.x, 0.f), v1 = fmaxf(acc[m][rg * 4 + 1] + bs.y, 0.f),
+                      v2 = fmaxf(acc[m][rg * 4 + 2] + bs.z, 0.f), v3 = fmaxf(acc[m][rg * 4 + 3] + bs.w, 0.f);
+          if (SPLIT) {
+            const uint32_t h01 = pack_bf16x2(v0, v1), h23 = pack_bf16x2(v2, v3);
+            *reinterpret_cast<u32x2*>(op + ch) = u32x2{h01, h23};
+            *reinterpret_cast<u32x2*>(op + p.out_lo_off + ch) =
+                u32x2{pack_bf16x2(v0 - bf16lo_f32(h01), v1 - bf16hi_f32(h01)), pack_bf16x2(v2 - bf16lo_f32(h23), v3 - bf16hi_f32(h23))};
+          } else {
+            const uint32_t h0 = f32_to_bf16(v0), h1 = f32_to_bf16(v1), h2 = f32_to_bf16(v2), h3 = f32_to_bf16(v3);
+            *reinterpret_cast<u32x2*>(op + ch) = u32x2{h0 | (h1 << 16), h2 | (h3 << 16)};
+          }
         }
       }
     }
@@ -1998,12 +2021,20 @@ int pt_launch_stem7x7(pt_engine* e, const bf16_t* in, int B, int H, int W, const
     const char* ev = getenv("PT_STEM_THIN");
     thin = ev ? atoi(ev) : 1;
   }
-  if (thin && !split && n_valid && n_valid <= 32) {
+  static int thin_x3 = -1;       // PT_STEM_THIN_X3=0: the general kernel for the hi/lo mode's thin stem (A/B switch)
+  if (thin_x3 < 0) {
+    const char* ev = getenv("PT_STEM_THIN_X3");
+    thin_x3 = ev ? atoi(ev) : 1;
+  }
+  if (thin && (!split || (split == 1 && thin_x3)) && n_valid && n_valid <= 32) {
     k.tiles_x = (k.Wo + 31) / 32; k.tiles_y = (k.Ho + 7) / 8; k.n_tiles = 1;
     const long long nblk = (long long)k.B * ((k.tiles_x + STEM_NT - 1) / STEM_NT) * k.tiles_y;
     PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "stem grid out of range");
-    PtProfScope prof(e, s, PT_PROF_STEM, 2.0 * k.B * k.Ho * k.Wo * 64.0 * 147.0, "stem7x7 s1 thin");
-    hipLaunchKernelGGL(conv_stem7x7_thin_kernel, dim3((unsigned)nblk), dim3(256), 0, s, k);
+    PtProfScope prof(e, s, PT_PROF_STEM, 2.0 * k.B * k.Ho * k.Wo * 64.0 * 147.0, split ? "stem7x7 s1 thin x3" : "stem7x7 s1 thin");
+    if (split)
+      hipLaunchKernelGGL(conv_stem7x7_thin_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, k);
+    else
+      hipLaunchKernelGGL(conv_stem7x7_thin_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, k);
     PT_HIP_CHECK(hipGetLastError());
     return PT_OK;
   }
