@@ -103,6 +103,7 @@ void pt_engine_destroy(pt_engine* e) {
   pt_mtl_release(e);
   e->stage_ring.destroy();
   if (e->lstm_scratch) (void)hipFree(e->lstm_scratch);
+  if (e->lstm_scratch8) (void)hipFree(e->lstm_scratch8);
   if (e->lstm_err) (void)hipHostFree(e->lstm_err);
   if (e->prof.h_lims) (void)hipHostFree(e->prof.h_lims);
   for (auto& p : e->prof.pending) {

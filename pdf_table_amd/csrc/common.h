@@ -169,6 +169,7 @@ struct pt_engine {
   void* cls_scratch = nullptr; size_t cls_scratch_cap = 0;   // network input + image descriptors of pt_cls_forward*
   alignas(8) unsigned char tsr_decode_state[128] = {};       // lore_decode.hip: DecodeState of the sparse-head decode in flight
   void* lstm_scratch = nullptr;                              // rec_kernels.hip: h exchange buffers + step counters of the cluster LSTM
+  void* lstm_scratch8 = nullptr; size_t lstm_scratch8_cap = 0;   // ... of the eight-member hi/lo cluster LSTM
   int* lstm_err = nullptr;                                   // pinned, device-visible: set by a cluster member that gave up waiting
   int lstm_max_cl = 0;                                       // clusters per direction per launch (num_cu / 8)
   int mtl_kv_fp8 = 0;                                        // pt_engine_set_mtl_kv_fp8: MtlTabNet source-attention keys / values of the structure loop as fp8 (bf16 mode only)

@@ -1134,6 +1134,200 @@ static int launch_lstm_cluster(const bf16_t* gx, const bf16_t* whh, bf16_t* hout
   return PT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Weight-stationary LSTM of the hi/lo (BF16X3) mode: EIGHT workgroups share a block of lines.  The streaming kernel re-reads
+// the 1 MB of (hi, lo) W_hh of a direction from L2 in every step (94 us per step, 30 ms per 64-page step for the two layers); a
+// 64-unit slice of the pair is 256 KB and does not fit LDS, a 32-unit slice (64 KB hi + 64 KB lo) does.  Member j keeps the W_hh
+// columns of hidden units [32 j, 32 j + 32) for the whole sequence; its four waves take the cluster's 32-line tiles MI apiece,
+// compute gates = h_hi W_hi + h_lo W_hi + h_hi W_lo (per k-step, fp32 accumulate) + gx_hi + gx_lo and the lane-local cell update,
+// and publish their 32 units of h_t as (hi, lo) A fragments (k-steps 2 j, 2 j + 1 of every tile) to an L2-resident exchange buffer;
+// the members meet once per step on eight counters, exactly like lstm_cluster_kernel.  Members of a cluster sit on one XCD
+// (ids b, b + 8, ..., b + 56).  The packer's fragment order already has the 1 KB records this needs: member j = (wave j >> 1,
+// half j & 1) of the four-member layout.
+// ---------------------------------------------------------------------------------------------------
+template <int MI>
+__global__ __launch_bounds__(256, 1) void lstm_cluster8_x3_kernel(const bf16_t* __restrict__ gx, const bf16_t* __restrict__ whh,
+                                                                   bf16_t* __restrict__ hout, int B, int T, int ncl,
+                                                                   unsigned long long* __restrict__ hx, int* __restrict__ flags,
+                                                                   int* __restrict__ err) {
+  constexpr int CLL = 128 * MI, NTILE = 4 * MI;                // lines / 32-line tiles per cluster
+  extern __shared__ __attribute__((aligned(16))) char lsm[];
+  char* wl = lsm;                                              // [2 (hi, lo)][16 ks][4 g][64 lanes][16 B] = 128 KB
+  constexpr int SROW = 32;                                     // un-padded 64-byte rows: four consecutive lanes read a row's four 16-byte pieces
+  bf16_t* stage = reinterpret_cast<bf16_t*>(lsm + 131072);     // [2 (hi, lo)][CLL][SROW]: 32 KB at MI = 2 -- the 160 KB are full (MI = 3 does not fit)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, q = lane >> 5;
+  const int L = blockIdx.x, dir = blockIdx.y;
+  const int member = (L >> 3) & 7, cl = (L >> 6) * 8 + (L & 7);
+  if (cl >= ncl) return;
+  const int line0 = cl * CLL;
+  {   // W slice of this member: 64 + 64 records of 1 KB out of the fragment-ordered tensor [hi | lo][dir][wave 4][16 ks][4 g][2 h][64][8]
+    for (int i = tid; i < 2 * 64 * 64; i += 256) {
+      const int pl = i >> 12, rec = (i >> 6) & 63, ln = i & 63;
+      const bf16_t* src = whh + (size_t)pl * 2 * 1024 * 256 + (size_t)dir * 1024 * 256 + (size_t)(member >> 1) * 65536 +
+                          (size_t)(rec * 2 + (member & 1)) * 512 + ln * 8;
+      *reinterpret_cast<u32x4*>(wl + (size_t)pl * 65536 + rec * 1024 + ln * 16) = *reinterpret_cast<const u32x4*>(src);
+    }
+  }
+  // exchange buffer of the cluster: [2 buffers][NTILE][16 ks][2 (hi, lo)][64 lanes][2 u64]
+  constexpr size_t XBUF = (size_t)NTILE * 16 * 2 * 64 * 2;
+  unsigned long long* hxc = hx + (size_t)(dir * ncl + cl) * 2 * XBUF;
+  int* fl = flags + (dir * ncl + cl) * 8;
+  float c[MI][16];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[mi][r] = 0.f;
+  bool dead = false;
+  __syncthreads();
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? T - 1 - s : s;
+    int last = B - 1;
+    asm volatile("" : "+v"(last));      // opaque per step: row addresses are recomputed, not kept across the sequence
+    const bf16_t* gxt = gx + (size_t)t * 4096 + dir * 1024 + (member * 32 + lx) * 4;
+    if (s > 0) {
+      if (tid < 8 && !dead) {
+        int spins = 0;
+        while (__hip_atomic_load(fl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < s) {
+          if (++spins > (1 << 22)) { dead = true; __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __syncthreads();
+    }
+    const unsigned long long* hp = hxc + (size_t)((s - 1) & 1) * XBUF;
+    asm volatile("" : "+s"(hp));
+#pragma unroll 1
+    for (int mi = 0; mi < MI; ++mi) {
+      const int tile = wave * MI + mi;
+      // gate inputs of this tile (hi, lo): issued first, they land under the fragment fetch and the MFMAs
+      u32x2 gh[16], gl[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
+        const int line = line0 + m;
+        const int lc = line < last ? line : last;
+        const bf16_t* gp = gxt + (size_t)lc * T * 4096;
+        gh[r] = *reinterpret_cast<const u32x2*>(gp);
+        gl[r] = *reinterpret_cast<const u32x2*>(gp + 2048);
+      }
+      f32x16 acc[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+      if (s > 0) {
+        unsigned long long af[16][2][2];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+            const unsigned long long* pp = hp + ((size_t)((tile * 16 + ks) * 2 + pl) * 64 + lane) * 2;
+            af[ks][pl][0] = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            af[ks][pl][1] = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const unsigned long long th[2] = {af[ks][0][0], af[ks][0][1]}, tl[2] = {af[ks][1][0], af[ks][1][1]};
+          const bf16x8 ah = __builtin_bit_cast(bf16x8, th), al = __builtin_bit_cast(bf16x8, tl);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wl + (ks * 4 + g) * 1024 + lane * 16);
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wl + 65536 + (ks * 4 + g) * 1024 + lane * 16);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[g], 0, 0, 0);
+          }
+        }
+      }
+      // cell update (lane-local: the four gates of a (line, unit) share lane and register), h as a (hi, lo) pair to the staging tiles
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
+        const float gi = acc[0][r] + rbf2f(gh[r].x & 0xFFFFu) + rbf2f(gl[r].x & 0xFFFFu);
+        const float gf = acc[1][r] + rbf2f(gh[r].x >> 16) + rbf2f(gl[r].x >> 16);
+        const float gg = acc[2][r] + rbf2f(gh[r].y & 0xFFFFu) + rbf2f(gl[r].y & 0xFFFFu);
+        const float go = acc[3][r] + rbf2f(gh[r].y >> 16) + rbf2f(gl[r].y >> 16);
+        const float si = fast_sigmoid(gi), sf = fast_sigmoid(gf), so = fast_sigmoid(go);
+        const float cn = sf * c[mi][r] + si * fast_tanh(gg);
+        c[mi][r] = cn;
+        const float hn = so * fast_tanh(cn);
+        const uint32_t hb = rf2bf(hn);
+        stage[m * SROW + lx] = (bf16_t)hb;
+        stage[(CLL + m) * SROW + lx] = (bf16_t)rf2bf(hn - rbf2f(hb));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    // publish: CLL lines x 4 pieces of 16 B x (hi, lo); piece pc of line m = units 32 member + 8 pc .. + 8 = k-step 2 member + (pc >> 1),
+    // half q = pc & 1.  The exchange stores go first and only they are drained before the counter is bumped; the layer output follows
+    unsigned long long* hw = hxc + (size_t)(s & 1) * XBUF;
+    int tio = tid;
+    asm volatile("" : "+v"(tio));
+    u32x4 pv[2 * MI][2];
+#pragma unroll
+    for (int i = 0; i < 2 * MI; ++i) {
+      const int idx = tio + i * 256, m = idx >> 2, pc = idx & 3;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        pv[i][pl] = *reinterpret_cast<const u32x4*>(stage + (pl * CLL + m) * SROW + pc * 8);
+        unsigned long long* dp = hw + ((size_t)(((m >> 5) * 16 + 2 * member + (pc >> 1)) * 2 + pl) * 64 + (pc & 1) * 32 + (m & 31)) * 2;
+        __hip_atomic_store(dp, (unsigned long long)pv[i][pl].x | ((unsigned long long)pv[i][pl].y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dp + 1, (unsigned long long)pv[i][pl].z | ((unsigned long long)pv[i][pl].w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(fl + member, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int i = 0; i < 2 * MI; ++i) {
+      const int idx = tio + i * 256, m = idx >> 2, pc = idx & 3;
+      const int line = line0 + m;
+      if (line < B) {
+        bf16_t* ho = hout + ((size_t)line * T + t) * 1024 + dir * 256 + member * 32 + pc * 8;
+        *reinterpret_cast<u32x4*>(ho) = pv[i][0];
+        *reinterpret_cast<u32x4*>(ho + 512) = pv[i][1];
+      }
+    }
+  }
+}
+
+template <int MI>
+static int launch_lstm_cluster8_x3(pt_engine* e, const bf16_t* gx, const bf16_t* whh, bf16_t* hout, int B, int T, hipStream_t s) {
+  constexpr int CLL = 128 * MI;
+  constexpr int SMEM = 131072 + 2 * CLL * 32 * 2;
+  static_assert(SMEM <= 163840, "W slices + staging tiles must fit the 160 KB of LDS");
+  static bool attr_done = false;
+  if (!attr_done) {
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_cluster8_x3_kernel<MI>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_done = true;
+  }
+  const int max_cl = e->num_cu / 16 < 1 ? 1 : e->num_cu / 16;      // 2 dirs x 8 members x max_cl <= num_cu
+  const size_t xbuf = (size_t)4 * MI * 16 * 2 * 64 * 2 * sizeof(unsigned long long);
+  const size_t need = (size_t)2 * max_cl * 2 * xbuf + (size_t)2 * max_cl * 8 * sizeof(int) + 256;
+  if (need > e->lstm_scratch8_cap) {
+    PT_HIP_CHECK(hipStreamSynchronize(s));
+    if (e->lstm_scratch8) PT_HIP_CHECK(hipFree(e->lstm_scratch8));
+    e->lstm_scratch8 = nullptr; e->lstm_scratch8_cap = 0;
+    PT_HIP_CHECK(hipMalloc(&e->lstm_scratch8, need));
+    e->lstm_scratch8_cap = need;
+  }
+  unsigned long long* hx = reinterpret_cast<unsigned long long*>(e->lstm_scratch8);
+  int* flags = reinterpret_cast<int*>(reinterpret_cast<char*>(e->lstm_scratch8) + (size_t)2 * max_cl * 2 * xbuf);
+  int* err = nullptr;
+  PT_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&err), e->lstm_err, 0));
+  const int nlaunch = (B + max_cl * CLL - 1) / (max_cl * CLL);
+  const int per = (((B + nlaunch - 1) / nlaunch) + CLL - 1) / CLL * CLL;
+  for (int b0 = 0; b0 < B; b0 += per) {
+    const int nb = (B - b0) < per ? (B - b0) : per;
+    const int ncl = (nb + CLL - 1) / CLL;
+    PT_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)(2 * max_cl * 8) * sizeof(int), s));
+    hipLaunchKernelGGL(lstm_cluster8_x3_kernel<MI>, dim3(((ncl + 7) / 8) * 64, 2), dim3(256), SMEM, s, gx + (size_t)b0 * T * 4096, whh,
+                       hout + (size_t)b0 * T * 1024, nb, T, ncl, hx, flags, err);
+  }
+  return PT_OK;
+}
+
 int pt_launch_lstm(pt_engine* e, const bf16_t* gx, const bf16_t* whh, bf16_t* hout, int B, int T, int split, hipStream_t s) {
   if (B <= 0) return PT_OK;
   dim3 grid((B + 31) / 32, 2);
@@ -1176,6 +1370,22 @@ int pt_launch_lstm(pt_engine* e, const bf16_t* gx, const bf16_t* whh, bf16_t* ho
     const bool mi3 = force == 3 || (force != 2 && n3 < n2);
     const int rc = mi3 ? launch_lstm_cluster<3>(gx, whh, hout, B, T, max_cl, hx, flags, err, s)
                        : launch_lstm_cluster<2>(gx, whh, hout, B, T, max_cl, hx, flags, err, s);
+    if (rc != PT_OK) return rc;
+  } else if (split == 1 && e->lstm_cluster && !(getenv("PT_LSTM_CLUSTER_X3") && atoi(getenv("PT_LSTM_CLUSTER_X3")) == 0)) {
+    // hi/lo mode: the eight-member weight-stationary kernel (PT_LSTM_CLUSTER_X3=0: the streaming kernel; A/B switch, read per call)
+    if (!e->lstm_err) {
+      PT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->lstm_err), sizeof(int), hipHostMallocMapped));
+      *e->lstm_err = 0;
+    }
+    if (*e->lstm_err) {      // an EARLIER launch timed out (its output was wrong): fail loudly now, once, and stop using the kernels
+      *e->lstm_err = 0;
+      e->lstm_cluster = 0;
+      pt_set_error("lstm_cluster8_x3_kernel: a workgroup waited > 2^22 polls for its peers -- the launch was not co-resident "
+                   "(GPU shared with another process or stream?).  Results of that call are invalid; this engine now uses "
+                   "the streaming LSTM kernel: run the batch again");
+      return PT_ERR_HIP;
+    }
+    const int rc = launch_lstm_cluster8_x3<2>(e, gx, whh, hout, B, T, s);      // 256-line clusters (384 would need 176 KB of LDS)
     if (rc != PT_OK) return rc;
   } else if (split) {
     if (ng2)

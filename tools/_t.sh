@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_gpu_tsr.py tests/test_gpu_fullsize.py -m gpu -x -q -k "tsr or lore or Lore" 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gpu_rec.py -m gpu -x -q 2>&1 | tail -5
+timeout 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -x -q -k "rec or crnn" 2>&1 | tail -3
 for v in 0 1; do
-  PT_STEM_THIN_X3=$v PT_BENCH_PROF=1 PT_PROF_VERBOSE=1 timeout 600 python bench.py --stages tsr --precision bf16x3 --steps 4 --warmup 2 --no-cpu-baseline --no-extra-legs 2> /tmp/tsr_$v.err | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('tsr x3 thin=$v', round(d['value'],1), round(d['ms_per_step'],1))"
-  grep -E "stem7x7" /tmp/tsr_$v.err
+  PT_LSTM_CLUSTER_X3=$v PT_BENCH_PROF=1 PT_PROF_VERBOSE=1 timeout 600 python bench.py --stages rec --precision bf16x3 --steps 4 --warmup 2 --no-cpu-baseline --no-extra-legs 2> /tmp/rec_$v.err | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('rec x3 cluster=$v', round(d['value'],1), round(d['ms_per_step'],1))"
+  grep -E "lstm" /tmp/rec_$v.err
 done
