@@ -1154,7 +1154,9 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster8_x3_kernel(const bf16_t* 
   extern __shared__ __attribute__((aligned(16))) char lsm[];
   char* wl = lsm;                                              // [2 (hi, lo)][16 ks][4 g][64 lanes][16 B] = 128 KB
   constexpr int SROW = 32;                                     // un-padded 64-byte rows: four consecutive lanes read a row's four 16-byte pieces
-  bf16_t* stage = reinterpret_cast<bf16_t*>(lsm + 131072);     // [2 (hi, lo)][CLL][SROW]: 32 KB at MI = 2 -- the 160 KB are full (MI = 3 does not fit)
+  // wave-private staging tile [2 (hi, lo)][32 lines][SROW] = 4 KB: a wave publishes each of its tiles right after the cell update (its own
+  // LDS writes are visible to it in order: no barrier); staging whole clusters (2 x CLL x 64 B) would not fit beside the 128 KB of weights
+  bf16_t* stage = reinterpret_cast<bf16_t*>(lsm + 131072) + (threadIdx.x >> 6) * (2 * 32 * SROW);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lx = lane & 31, q = lane >> 5;
   const int L = blockIdx.x, dir = blockIdx.y;
@@ -1253,40 +1255,53 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster8_x3_kernel(const bf16_t* 
         c[mi][r] = cn;
         const float hn = so * fast_tanh(cn);
         const uint32_t hb = rf2bf(hn);
-        stage[m * SROW + lx] = (bf16_t)hb;
-        stage[(CLL + m) * SROW + lx] = (bf16_t)rf2bf(hn - rbf2f(hb));
+        const int ml = (r & 3) + 8 * (r >> 2) + 4 * q;
+        stage[ml * SROW + lx] = (bf16_t)hb;
+        stage[(32 + ml) * SROW + lx] = (bf16_t)rf2bf(hn - rbf2f(hb));
+        (void)m;
+      }
+      // publish the tile: 32 lines x 4 pieces of 16 B x (hi, lo); piece pc of a line = units 32 member + 8 pc .. + 8 = k-step 2 member + (pc >> 1),
+      // half q = pc & 1 of the consumers' A fragments
+      {
+        unsigned long long* hw = hxc + (size_t)(s & 1) * XBUF;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int idx = lane + i * 64, ml = idx >> 2, pc = idx & 3;
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+            const u32x4 pv = *reinterpret_cast<const u32x4*>(stage + (pl * 32 + ml) * SROW + pc * 8);
+            unsigned long long* dp = hw + ((size_t)((tile * 16 + 2 * member + (pc >> 1)) * 2 + pl) * 64 + (pc & 1) * 32 + ml) * 2;
+            __hip_atomic_store(dp, (unsigned long long)pv.x | ((unsigned long long)pv.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dp + 1, (unsigned long long)pv.z | ((unsigned long long)pv.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
-    // publish: CLL lines x 4 pieces of 16 B x (hi, lo); piece pc of line m = units 32 member + 8 pc .. + 8 = k-step 2 member + (pc >> 1),
-    // half q = pc & 1.  The exchange stores go first and only they are drained before the counter is bumped; the layer output follows
-    unsigned long long* hw = hxc + (size_t)(s & 1) * XBUF;
-    int tio = tid;
-    asm volatile("" : "+v"(tio));
-    u32x4 pv[2 * MI][2];
-#pragma unroll
-    for (int i = 0; i < 2 * MI; ++i) {
-      const int idx = tio + i * 256, m = idx >> 2, pc = idx & 3;
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) {
-        pv[i][pl] = *reinterpret_cast<const u32x4*>(stage + (pl * CLL + m) * SROW + pc * 8);
-        unsigned long long* dp = hw + ((size_t)(((m >> 5) * 16 + 2 * member + (pc >> 1)) * 2 + pl) * 64 + (pc & 1) * 32 + (m & 31)) * 2;
-        __hip_atomic_store(dp, (unsigned long long)pv[i][pl].x | ((unsigned long long)pv[i][pl].y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dp + 1, (unsigned long long)pv[i][pl].z | ((unsigned long long)pv[i][pl].w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
+    // only the exchange stores are outstanding here: drain them, meet, bump the counter; the layer output (HBM) follows behind the
+    // counter, off the step's critical chain -- copied from this member's own fragments in the exchange buffer (L2), which frees the
+    // registers a held copy would take
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_store(fl + member, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+      const unsigned long long* hr = hxc + (size_t)(s & 1) * XBUF;
+      int tio = tid;
+      asm volatile("" : "+v"(tio));
 #pragma unroll
-    for (int i = 0; i < 2 * MI; ++i) {
-      const int idx = tio + i * 256, m = idx >> 2, pc = idx & 3;
-      const int line = line0 + m;
-      if (line < B) {
-        bf16_t* ho = hout + ((size_t)line * T + t) * 1024 + dir * 256 + member * 32 + pc * 8;
-        *reinterpret_cast<u32x4*>(ho) = pv[i][0];
-        *reinterpret_cast<u32x4*>(ho + 512) = pv[i][1];
+      for (int i = 0; i < 2 * MI; ++i) {
+        const int idx = tio + i * 256, m = idx >> 2, pc = idx & 3;      // m: line inside the cluster
+        const int line = line0 + m;
+        if (line < B) {
+          bf16_t* ho = hout + ((size_t)line * T + t) * 1024 + dir * 256 + member * 32 + pc * 8;
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+            const unsigned long long* sp = hr + ((size_t)(((m >> 5) * 16 + 2 * member + (pc >> 1)) * 2 + pl) * 64 + (pc & 1) * 32 + (m & 31)) * 2;
+            const unsigned long long v0 = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long v1 = __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *reinterpret_cast<u32x4*>(ho + pl * 512) = u32x4{(uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1, (uint32_t)(v1 >> 32)};
+          }
+        }
       }
     }
   }
@@ -1295,8 +1310,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster8_x3_kernel(const bf16_t* 
 template <int MI>
 static int launch_lstm_cluster8_x3(pt_engine* e, const bf16_t* gx, const bf16_t* whh, bf16_t* hout, int B, int T, hipStream_t s) {
   constexpr int CLL = 128 * MI;
-  constexpr int SMEM = 131072 + 2 * CLL * 32 * 2;
-  static_assert(SMEM <= 163840, "W slices + staging tiles must fit the 160 KB of LDS");
+  constexpr int SMEM = 131072 + 4 * 2 * 32 * 32 * 2;      // W slices + four wave-private staging tiles
   static bool attr_done = false;
   if (!attr_done) {
     PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_cluster8_x3_kernel<MI>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -1385,7 +1399,13 @@ int pt_launch_lstm(pt_engine* e, const bf16_t* gx, const bf16_t* whh, bf16_t* ho
                    "the streaming LSTM kernel: run the batch again");
       return PT_ERR_HIP;
     }
-    const int rc = launch_lstm_cluster8_x3<2>(e, gx, whh, hout, B, T, s);      // 256-line clusters (384 would need 176 KB of LDS)
+    // 384-line clusters when they save a launch (e.g. 4 968 lines: 1 launch of 13 clusters instead of 2 of 10); PT_LSTM_MI = 2 / 3 forces one
+    const int max_cl = e->num_cu / 16 < 1 ? 1 : e->num_cu / 16;
+    const char* ev = getenv("PT_LSTM_MI");
+    const int force = ev ? atoi(ev) : 0;
+    const int n2 = (B + max_cl * 256 - 1) / (max_cl * 256), n3 = (B + max_cl * 384 - 1) / (max_cl * 384);
+    const bool mi3 = force == 3 || (force != 2 && n3 < n2);
+    const int rc = mi3 ? launch_lstm_cluster8_x3<3>(e, gx, whh, hout, B, T, s) : launch_lstm_cluster8_x3<2>(e, gx, whh, hout, B, T, s);
     if (rc != PT_OK) return rc;
   } else if (split) {
     if (ng2)
