@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256, (SPLIT || NB > 64) ? 2 : 4) void dcn_fused_ker
 // summed in fp32 before the blend, the blended value is split again, and the product runs as three MFMA passes
 // (a_hi w_hi + a_lo w_hi + a_hi w_lo) -- the arithmetic of dcn_fused_kernel<1, .> on this kernel's gather / LDS layout.
 template <int NB, int NTHR, int SPLIT = 0>
-__global__ __launch_bounds__(NTHR, SPLIT ? 2 : NTHR / 128) void dcn_fused64_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
+__global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) void dcn_fused64_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
                                                               const bf16_t* __restrict__ w, const float* __restrict__ bias,
                                                               bf16_t* __restrict__ out, long long npix, int H, int W,
                                                               int C, int N, int relu) {
@@ -882,7 +882,13 @@ int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf
     snprintf(label, sizeof(label), "dcn fused %d->%d @%dx%d x3", C, N, H, W);
     PtProfScope prof(e, s, PT_PROF_OTHER, 0, label);
     const unsigned tiles = (unsigned)((long long)B * ((H + 7) / 8) * ((W + 15) / 16));
-    hipLaunchKernelGGL((dcn_fused64_kernel<64, 512, 1>), dim3(tiles, N / 64), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
+    // N >= 128: one workgroup computes 128 output channels from one gather + blend, as in bf16 mode (PT_DCN_NB=64: 64-wide blocks everywhere).
+    // 110 KB of LDS for both operand planes: one workgroup of eight waves per CU, which the 64-wide hi/lo blocks (92 KB) are too
+    const char* nbv = getenv("PT_DCN_NB");
+    if (N % 128 == 0 && !(nbv && atoi(nbv) == 64))
+      hipLaunchKernelGGL((dcn_fused64_kernel<128, 512, 1>), dim3(tiles, N / 128), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
+    else
+      hipLaunchKernelGGL((dcn_fused64_kernel<64, 512, 1>), dim3(tiles, N / 64), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
     PT_HIP_CHECK(hipGetLastError());
     return PT_OK;
   }
