@@ -207,6 +207,94 @@ def test_set_lstm_cluster_switches_kernels_in_process(eng, sd):
         assert np.array_equal(ids, outs[0][0]) and np.array_equal(mx, outs[0][1])
 
 
+def _x3_input(n, seed):
+    rng = np.random.default_rng(seed)
+    g = torch.from_numpy(rng.uniform(0, 1, (n, 32, 640)).astype(np.float32))
+    g[n // 2, :, 200:] = 0
+    hi = g.to(torch.bfloat16)
+    return torch.stack([hi, (g - hi.float()).to(torch.bfloat16)], -1).contiguous().cuda()
+
+
+def test_x3_classifier_bound_and_refine_equals_the_tiled_classifier(eng, sd, monkeypatch):
+    """BF16X3 classifier: the arg-max from two single-pass sweeps + exact logits of the candidates (gemm_cand_kernel / cand_eval_kernel)
+    against the tiled three-pass GEMM with per-tile partials + reduce (PT_CLS_X3_REFINE=0, read per call): the same ids wherever the
+    three-term sum's top two are further apart than its own rounding, winning logits within 1e-3 of each other"""
+    eng.set_precision(L.PT_PRECISION_BF16X3)
+    try:
+        x = _x3_input(37, 5)
+        monkeypatch.delenv("PT_CLS_X3_REFINE", raising=False)
+        ids, mx = eng.rec_forward_net(x)
+        monkeypatch.setenv("PT_CLS_X3_REFINE", "0")
+        ids0, mx0 = eng.rec_forward_net(x)
+        torch.cuda.synchronize()
+        ids, mx, ids0, mx0 = ids.cpu(), mx.cpu(), ids0.cpu(), mx0.cpu()
+        assert float((mx - mx0).abs().max()) <= TOL
+        diff = ids != ids0
+        print(f"x3 classifier: {int(diff.sum())} of {ids.numel()} ids differ between bound-and-refine and the tiled GEMM")
+        assert float(diff.float().mean()) < 1e-3
+        assert len(np.unique(ids.numpy())) > 20
+    finally:
+        eng.set_precision(L.PT_PRECISION_BF16)
+
+
+def test_x3_classifier_rows_with_more_candidates_than_slots(monkeypatch):
+    """a classifier whose logits all coincide (zero weights; the CRNN's Linear has no bias): EVERY class is inside the rounding bound of the
+    maximum, the per-row slots overflow and cand_full_kernel evaluates all classes -- the lowest class index wins, as torch.argmax.  Then two
+    identical non-zero rows (classes 17 and 4321) over zeros: rows where they win tie between the two (slot path, 17 wins), the others fall
+    back to the all-zero tie (overflow path, 0 wins) -- in both cases what the tiled three-pass classifier answers"""
+    from pdf_table_amd.engine import HipEngine
+    base = crnn_state_dict(seed=3)
+    sd = dict(base)
+    sd["cls.weight"] = torch.zeros_like(base["cls.weight"])
+    e = HipEngine(0)
+    try:
+        e.load_weights(L.PT_MODEL_CRNN, pack_crnn(sd))
+        e.set_precision(L.PT_PRECISION_BF16X3)
+        x = _x3_input(3, 9)
+        ids, mx = e.rec_forward_net(x)
+        torch.cuda.synchronize()
+        assert int(ids.abs().max()) == 0 and float(mx.abs().max()) == 0.0
+        w = torch.zeros_like(base["cls.weight"])
+        w[17] = base["cls.weight"][5]
+        w[4321] = base["cls.weight"][5]
+        sd["cls.weight"] = w
+        e.load_weights(L.PT_MODEL_CRNN, pack_crnn(sd))
+        monkeypatch.delenv("PT_CLS_X3_REFINE", raising=False)
+        ids, mx = e.rec_forward_net(x)
+        monkeypatch.setenv("PT_CLS_X3_REFINE", "0")
+        ids0, mx0 = e.rec_forward_net(x)
+        torch.cuda.synchronize()
+        ids, ids0 = ids.cpu(), ids0.cpu()
+        assert set(np.unique(ids.numpy()).tolist()) <= {0, 17}
+        assert bool((ids == ids0).all()) and float((mx.cpu() - mx0.cpu()).abs().max()) <= TOL
+    finally:
+        e.close()
+
+
+def test_x3_cluster_lstm_equals_the_streaming_lstm(eng, sd, monkeypatch):
+    """lstm_cluster8_x3_kernel (eight members x 32 hidden units, (hi, lo) W_hh in LDS) against the streaming hi/lo kernel
+    (PT_LSTM_CLUSTER_X3=0): the same recurrence summed per k-step instead of per pass -- ids equal, winning logits within 1e-3; both
+    cluster sizes (PT_LSTM_MI = 2 / 3: 256- / 384-line clusters), a batch that does not fill its last cluster, nothing for
+    pt_engine_check to report"""
+    eng.set_precision(L.PT_PRECISION_BF16X3)
+    try:
+        x = _x3_input(300, 11)
+        monkeypatch.setenv("PT_LSTM_CLUSTER_X3", "0")
+        ids0, mx0 = eng.rec_forward_net(x)
+        torch.cuda.synchronize()
+        ids0, mx0 = ids0.cpu(), mx0.cpu()
+        monkeypatch.delenv("PT_LSTM_CLUSTER_X3")
+        for mi in ("2", "3"):
+            monkeypatch.setenv("PT_LSTM_MI", mi)
+            ids, mx = eng.rec_forward_net(x)
+            torch.cuda.synchronize()
+            eng.check()
+            assert float((mx.cpu() - mx0).abs().max()) <= TOL
+            assert float((ids.cpu() != ids0).float().mean()) < 1e-3
+    finally:
+        eng.set_precision(L.PT_PRECISION_BF16)
+
+
 # ---- PP-OCR recognition pre-processor (PPOcrRecPreProcessor, ocr_rec_pp/processor_ocr_rec_pp.py:24-135) ---------------
 def test_rec_pp_preprocessor_crops_bit_exact(eng, golden_dir):
     """already-cropped inputs (the reference call shape), all crops in one call and one crop per call: every mini-batch
