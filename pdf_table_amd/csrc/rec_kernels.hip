@@ -1145,12 +1145,14 @@ static int launch_lstm_cluster(const bf16_t* gx, const bf16_t* whh, bf16_t* hout
 // (ids b, b + 8, ..., b + 56).  The packer's fragment order already has the 1 KB records this needs: member j = (wave j >> 1,
 // half j & 1) of the four-member layout.
 // ---------------------------------------------------------------------------------------------------
-template <int MI>
-__global__ __launch_bounds__(256, 1) void lstm_cluster8_x3_kernel(const bf16_t* __restrict__ gx, const bf16_t* __restrict__ whh,
+// NW = 8 waves (two per SIMD, 256 registers each): while one wave waits for its tile's gate inputs and fragments the other multiplies --
+// with NW = 4 (one wave per SIMD) a tile's fetch, 192 MFMAs, cell update and publish run back to back (42.6 us per step at three tiles)
+template <int MI, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void lstm_cluster8_x3_kernel(const bf16_t* __restrict__ gx, const bf16_t* __restrict__ whh,
                                                                    bf16_t* __restrict__ hout, int B, int T, int ncl,
                                                                    unsigned long long* __restrict__ hx, int* __restrict__ flags,
                                                                    int* __restrict__ err) {
-  constexpr int CLL = 128 * MI, NTILE = 4 * MI;                // lines / 32-line tiles per cluster
+  constexpr int CLL = 32 * NW * MI, NTILE = NW * MI, NTHR = 64 * NW;      // lines / 32-line tiles per cluster
   extern __shared__ __attribute__((aligned(16))) char lsm[];
   char* wl = lsm;                                              // [2 (hi, lo)][16 ks][4 g][64 lanes][16 B] = 128 KB
   constexpr int SROW = 32;                                     // un-padded 64-byte rows: four consecutive lanes read a row's four 16-byte pieces
@@ -1164,7 +1166,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster8_x3_kernel(const bf16_t* 
   if (cl >= ncl) return;
   const int line0 = cl * CLL;
   {   // W slice of this member: 64 + 64 records of 1 KB out of the fragment-ordered tensor [hi | lo][dir][wave 4][16 ks][4 g][2 h][64][8]
-    for (int i = tid; i < 2 * 64 * 64; i += 256) {
+    for (int i = tid; i < 2 * 64 * 64; i += NTHR) {
       const int pl = i >> 12, rec = (i >> 6) & 63, ln = i & 63;
       const bf16_t* src = whh + (size_t)pl * 2 * 1024 * 256 + (size_t)dir * 1024 * 256 + (size_t)(member >> 1) * 65536 +
                           (size_t)(rec * 2 + (member & 1)) * 512 + ln * 8;
@@ -1219,27 +1221,34 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster8_x3_kernel(const bf16_t* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
       if (s > 0) {
-        unsigned long long af[16][2][2];
+        // NW = 8: the tile's fragments in two bursts of eight k-steps (64 registers instead of 128: the wave has 256, and its
+        // SIMD partner covers the second round trip)
+        constexpr int KH = NW == 8 ? 8 : 16;
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks)
+        for (int k0 = 0; k0 < 16; k0 += KH) {
+          unsigned long long af[KH][2][2];
 #pragma unroll
-          for (int pl = 0; pl < 2; ++pl) {
-            const unsigned long long* pp = hp + ((size_t)((tile * 16 + ks) * 2 + pl) * 64 + lane) * 2;
-            af[ks][pl][0] = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            af[ks][pl][1] = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int ks = 0; ks < KH; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+              const unsigned long long* pp = hp + ((size_t)((tile * 16 + k0 + ks) * 2 + pl) * 64 + lane) * 2;
+              af[ks][pl][0] = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              af[ks][pl][1] = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+          for (int ks = 0; ks < KH; ++ks) {
+            const unsigned long long th[2] = {af[ks][0][0], af[ks][0][1]}, tl[2] = {af[ks][1][0], af[ks][1][1]};
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, th), al = __builtin_bit_cast(bf16x8, tl);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wl + ((k0 + ks) * 4 + g) * 1024 + lane * 16);
+              const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wl + 65536 + ((k0 + ks) * 4 + g) * 1024 + lane * 16);
+              acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[g], 0, 0, 0);
+              acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[g], 0, 0, 0);
+              acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[g], 0, 0, 0);
+            }
           }
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          const unsigned long long th[2] = {af[ks][0][0], af[ks][0][1]}, tl[2] = {af[ks][1][0], af[ks][1][1]};
-          const bf16x8 ah = __builtin_bit_cast(bf16x8, th), al = __builtin_bit_cast(bf16x8, tl);
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wl + (ks * 4 + g) * 1024 + lane * 16);
-            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wl + 65536 + (ks * 4 + g) * 1024 + lane * 16);
-            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[g], 0, 0, 0);
-            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[g], 0, 0, 0);
-            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[g], 0, 0, 0);
-          }
+          if (NW == 8) __builtin_amdgcn_sched_barrier(0);      // the second burst's loads are not hoisted above the first burst's MFMAs
         }
       }
       // cell update (lane-local: the four gates of a (line, unit) share lane and register), h as a (hi, lo) pair to the staging tiles
@@ -1290,7 +1299,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster8_x3_kernel(const bf16_t* 
       asm volatile("" : "+v"(tio));
 #pragma unroll
       for (int i = 0; i < 2 * MI; ++i) {
-        const int idx = tio + i * 256, m = idx >> 2, pc = idx & 3;      // m: line inside the cluster
+        const int idx = tio + i * NTHR, m = idx >> 2, pc = idx & 3;      // m: line inside the cluster
         const int line = line0 + m;
         if (line < B) {
           bf16_t* ho = hout + ((size_t)line * T + t) * 1024 + dir * 256 + member * 32 + pc * 8;
@@ -1307,17 +1316,18 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster8_x3_kernel(const bf16_t* 
   }
 }
 
-template <int MI>
+template <int MI, int NW>
 static int launch_lstm_cluster8_x3(pt_engine* e, const bf16_t* gx, const bf16_t* whh, bf16_t* hout, int B, int T, hipStream_t s) {
-  constexpr int CLL = 128 * MI;
-  constexpr int SMEM = 131072 + 4 * 2 * 32 * 32 * 2;      // W slices + four wave-private staging tiles
+  constexpr int CLL = 32 * NW * MI;
+  constexpr int SMEM = 131072 + NW * 2 * 32 * 32 * 2;      // W slices + a wave-private staging tile per wave (160 KB exactly at eight waves)
+  static_assert(SMEM <= 163840, "LDS");
   static bool attr_done = false;
   if (!attr_done) {
-    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_cluster8_x3_kernel<MI>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_cluster8_x3_kernel<MI, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_done = true;
   }
   const int max_cl = e->num_cu / 16 < 1 ? 1 : e->num_cu / 16;      // 2 dirs x 8 members x max_cl <= num_cu
-  const size_t xbuf = (size_t)4 * MI * 16 * 2 * 64 * 2 * sizeof(unsigned long long);
+  const size_t xbuf = (size_t)NW * MI * 16 * 2 * 64 * 2 * sizeof(unsigned long long);
   const size_t need = (size_t)2 * max_cl * 2 * xbuf + (size_t)2 * max_cl * 8 * sizeof(int) + 256;
   if (need > e->lstm_scratch8_cap) {
     PT_HIP_CHECK(hipStreamSynchronize(s));
@@ -1336,7 +1346,7 @@ static int launch_lstm_cluster8_x3(pt_engine* e, const bf16_t* gx, const bf16_t*
     const int nb = (B - b0) < per ? (B - b0) : per;
     const int ncl = (nb + CLL - 1) / CLL;
     PT_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)(2 * max_cl * 8) * sizeof(int), s));
-    hipLaunchKernelGGL(lstm_cluster8_x3_kernel<MI>, dim3(((ncl + 7) / 8) * 64, 2), dim3(256), SMEM, s, gx + (size_t)b0 * T * 4096, whh,
+    hipLaunchKernelGGL((lstm_cluster8_x3_kernel<MI, NW>), dim3(((ncl + 7) / 8) * 64, 2), dim3(64 * NW), SMEM, s, gx + (size_t)b0 * T * 4096, whh,
                        hout + (size_t)b0 * T * 1024, nb, T, ncl, hx, flags, err);
   }
   return PT_OK;
@@ -1399,13 +1409,22 @@ int pt_launch_lstm(pt_engine* e, const bf16_t* gx, const bf16_t* whh, bf16_t* ho
                    "the streaming LSTM kernel: run the batch again");
       return PT_ERR_HIP;
     }
-    // 384-line clusters when they save a launch (e.g. 4 968 lines: 1 launch of 13 clusters instead of 2 of 10); PT_LSTM_MI = 2 / 3 forces one
+    // PT_LSTM_X3_WAVES=4: one wave per SIMD with 256- / 384-line clusters (PT_LSTM_MI = 2 / 3; 384 when it saves a launch); default: eight
+    // waves (two per SIMD, each hiding the other's fetches) with 256- / 512-line clusters (512 when it saves a launch or PT_LSTM_MI=2)
     const int max_cl = e->num_cu / 16 < 1 ? 1 : e->num_cu / 16;
     const char* ev = getenv("PT_LSTM_MI");
     const int force = ev ? atoi(ev) : 0;
-    const int n2 = (B + max_cl * 256 - 1) / (max_cl * 256), n3 = (B + max_cl * 384 - 1) / (max_cl * 384);
-    const bool mi3 = force == 3 || (force != 2 && n3 < n2);
-    const int rc = mi3 ? launch_lstm_cluster8_x3<3>(e, gx, whh, hout, B, T, s) : launch_lstm_cluster8_x3<2>(e, gx, whh, hout, B, T, s);
+    const char* wv = getenv("PT_LSTM_X3_WAVES");
+    int rc;
+    if (wv && atoi(wv) == 4) {
+      const int n2 = (B + max_cl * 256 - 1) / (max_cl * 256), n3 = (B + max_cl * 384 - 1) / (max_cl * 384);
+      const bool mi3 = force == 3 || (force != 2 && n3 < n2);
+      rc = mi3 ? launch_lstm_cluster8_x3<3, 4>(e, gx, whh, hout, B, T, s) : launch_lstm_cluster8_x3<2, 4>(e, gx, whh, hout, B, T, s);
+    } else {
+      const int n1 = (B + max_cl * 256 - 1) / (max_cl * 256), n2 = (B + max_cl * 512 - 1) / (max_cl * 512);
+      const bool mi2 = force == 2 || (force != 1 && n2 < n1);
+      rc = mi2 ? launch_lstm_cluster8_x3<2, 8>(e, gx, whh, hout, B, T, s) : launch_lstm_cluster8_x3<1, 8>(e, gx, whh, hout, B, T, s);
+    }
     if (rc != PT_OK) return rc;
   } else if (split) {
     if (ng2)

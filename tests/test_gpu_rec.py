@@ -273,8 +273,8 @@ def test_x3_classifier_rows_with_more_candidates_than_slots(monkeypatch):
 
 def test_x3_cluster_lstm_equals_the_streaming_lstm(eng, sd, monkeypatch):
     """lstm_cluster8_x3_kernel (eight members x 32 hidden units, (hi, lo) W_hh in LDS) against the streaming hi/lo kernel
-    (PT_LSTM_CLUSTER_X3=0): the same recurrence summed per k-step instead of per pass -- ids equal, winning logits within 1e-3; both
-    cluster sizes (PT_LSTM_MI = 2 / 3: 256- / 384-line clusters), a batch that does not fill its last cluster, nothing for
+    (PT_LSTM_CLUSTER_X3=0): the same recurrence summed per k-step instead of per pass -- ids equal, winning logits within 1e-3; eight and
+    four waves per member at both cluster sizes each (PT_LSTM_X3_WAVES, PT_LSTM_MI), a batch that does not fill its last cluster, nothing for
     pt_engine_check to report"""
     eng.set_precision(L.PT_PRECISION_BF16X3)
     try:
@@ -284,7 +284,8 @@ def test_x3_cluster_lstm_equals_the_streaming_lstm(eng, sd, monkeypatch):
         torch.cuda.synchronize()
         ids0, mx0 = ids0.cpu(), mx0.cpu()
         monkeypatch.delenv("PT_LSTM_CLUSTER_X3")
-        for mi in ("2", "3"):
+        for waves, mi in (("8", "1"), ("8", "2"), ("4", "2"), ("4", "3")):      # eight / four waves per member, tiles per wave
+            monkeypatch.setenv("PT_LSTM_X3_WAVES", waves)
             monkeypatch.setenv("PT_LSTM_MI", mi)
             ids, mx = eng.rec_forward_net(x)
             torch.cuda.synchronize()
