@@ -211,9 +211,11 @@ int pt_weights_load_device(pt_engine* e, int model_kind, const void* d_blob, siz
 
 // ---- detection ---------------------------------------------------------------------------------------
 // the detector network loaded last: `DBModel` or `DBNasModel` (modeling_db_net.py:47-52)
-static int det_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* prob, float* logits, hipStream_t s) {
+static int det_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* prob, float* logits, hipStream_t s, uint32_t* bitmap = nullptr,
+                   float thresh = 0.f, int* bitmap_done = nullptr) {
+  if (bitmap_done) *bitmap_done = 0;
   if (e->det_kind == PT_MODEL_DB_NAS) return pt_dbnas_forward_net(e, x, n, H, W, prob, logits, s);
-  return pt_db_forward_net(e, x, n, H, W, prob, logits, s);
+  return pt_db_forward_net(e, x, n, H, W, prob, logits, s, bitmap, thresh, bitmap_done);
 }
 
 int pt_det_plan(int h, int w, int pre_flavour, int* net_h, int* net_w) {
@@ -439,9 +441,12 @@ int pt_det_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h, int w
       if (rc != PT_OK) return rc;
     }
     float* prob_i = d_prob + (size_t)i0 * nh * nw;
-    rc = det_net(e, reinterpret_cast<const bf16_t*>(xbuf), nb, nh, nw, prob_i, nullptr, s);
+    // without dilation the DB-ResNet18 head thresholds its own output (bf16 mode): no second pass over the probability map
+    int bm_done = 0;
+    uint32_t* bm_i = d_bitmap ? d_bitmap + (size_t)i0 * nh * (nw / 32) : nullptr;
+    rc = det_net(e, reinterpret_cast<const bf16_t*>(xbuf), nb, nh, nw, prob_i, nullptr, s, use_dilation ? nullptr : bm_i, thresh, &bm_done);
     if (rc != PT_OK) return rc;
-    if (d_bitmap) {
+    if (d_bitmap && !bm_done) {
       PtProfScope ps(e, s, PT_PROF_OTHER, 0, "bitmap");
       rc = pt_launch_bitmap(prob_i, nb, nh, nw, thresh, use_dilation, d_bitmap + (size_t)i0 * nh * (nw / 32), s);
       if (rc != PT_OK) return rc;

@@ -269,8 +269,9 @@ int pt_launch_stem7x7_pool(pt_engine* e, const bf16_t* in, int B, int H, int W, 
                            hipStream_t s);   // ResNet-18 stem + MaxPool2d(3,2,1) in one kernel (bf16 mode)
 int pt_launch_db_head_final(const bf16_t* in, int B, int H, int W, const void* w4x64, const float* bias, float* prob,
                             float* logits, int split, hipStream_t s);
+// bitmap != null: prob > thresh bit-packed by the same kernel (pt_launch_bitmap's words, no dilation)
 int pt_launch_db_head_mfma(const bf16_t* in, int B, int H, int W, const bf16_t* w3, const float* b3, const bf16_t* w6,
-                           const float* b6, float* prob, float* logits, hipStream_t s);
+                           const float* b6, float* prob, float* logits, hipStream_t s, uint32_t* bitmap = nullptr, float thresh = 0.f);
 int pt_launch_bitmap(const float* prob, int n, int H, int W, float thresh, int dilate, uint32_t* bitmap,
                      hipStream_t s);
 int pt_launch_box_scores(const float* prob, int n, int H, int W, const float* boxes, int nb, float* scores,
@@ -351,7 +352,9 @@ int pt_mtl_cells(pt_engine* e, int total, int32_t* d_cell_ids, float* d_cell_pro
                  hipStream_t s);
 
 // ---- models ---------------------------------------------------------------------------------------------
-int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* prob, float* logits, hipStream_t s);
+// bitmap / bitmap_done (optional): where the head kernel can threshold its own output it writes the bit-packed map too and sets *bitmap_done = 1
+int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* prob, float* logits, hipStream_t s, uint32_t* bitmap = nullptr,
+                      float thresh = 0.f, int* bitmap_done = nullptr);
 int pt_launch_tsr_preprocess(const uint8_t* pages, int ph, int pw, const pt_tsr_table* tabs, int n, int H, int W, int bgr,
                              const float* lut, bf16_t* out, int split, hipStream_t s);
 int pt_picodet_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* h0, float* h1, float* h2, float* h3,

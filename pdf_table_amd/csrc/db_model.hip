@@ -84,7 +84,9 @@ struct Bufs {
 
 }  // namespace
 
-int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float* prob, float* logits, hipStream_t s) {
+int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float* prob, float* logits, hipStream_t s, uint32_t* bitmap, float thresh,
+                      int* bitmap_done) {
+  if (bitmap_done) *bitmap_done = 0;
   PT_REQUIRE(H % 32 == 0 && W_ % 32 == 0 && H > 0 && W_ > 0, "det net: input %dx%d must be multiples of 32", H, W_);
   auto it = e->models.find(PT_MODEL_DB_RESNET18);
   if (it == e->models.end()) {
@@ -248,7 +250,14 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
   if (!x3 && head_mfma) {
     // both transposed convs of the head in one streaming kernel (det_kernels.hip: db_head_mfma_kernel)
     PtProfScope ps(e, s, PT_PROF_CONV1X1, 2.0 * n * (H / 4) * (W_ / 4) * (64.0 * 256 + 256 * 4), "db head (2 x convT) mfma");
-    RUN(pt_launch_db_head_mfma(bf.y0, n, H / 4, W_ / 4, W(w.bin3_w), Bv(w.bin3_b), W(w.bin6_w), Bv(w.bin6_b), prob, logits, s));
+    static int fuse_bm = -1;      // PT_DB_FUSE_BITMAP=0: the separate bitmap pass (A/B switch)
+    if (fuse_bm < 0) {
+      const char* ev = getenv("PT_DB_FUSE_BITMAP");
+      fuse_bm = ev ? atoi(ev) : 1;
+    }
+    uint32_t* bm = (fuse_bm && bitmap && bitmap_done && prob) ? bitmap : nullptr;
+    RUN(pt_launch_db_head_mfma(bf.y0, n, H / 4, W_ / 4, W(w.bin3_w), Bv(w.bin3_b), W(w.bin6_w), Bv(w.bin6_b), prob, logits, s, bm, thresh));
+    if (bm) *bitmap_done = 1;
   } else {
     // ConvTranspose2d(64,64,2,2)+BN+ReLU with the final ConvTranspose2d(64,1,2,2)+Sigmoid fused into its epilogue
     ConvDesc c = conv(bf.y0, H / 4, W_ / 4, 64, w.bin3_w, w.bin3_b, 256, 1, 1, bf.y1, 64, 1);

@@ -396,7 +396,8 @@ typedef __attribute__((ext_vector_type(4))) float hf32x4;
 __global__ __launch_bounds__(256, 4) void db_head_mfma_kernel(const bf16_t* __restrict__ in, long long npix, int H, int W,
                                                                const bf16_t* __restrict__ w3, const float* __restrict__ b3,
                                                                const bf16_t* __restrict__ w6, const float* __restrict__ b6,
-                                                               float* __restrict__ prob, float* __restrict__ logits) {
+                                                               float* __restrict__ prob, float* __restrict__ logits,
+                                                               uint32_t* __restrict__ bitmap, float thresh) {
   constexpr int PITCH = 144;                       // 64 k x 2 B + 16 B pad: conflict-free ds_read_b128 over 32 rows
   __shared__ __attribute__((aligned(16))) char s_w[256 * PITCH];
   __shared__ float s_b[256];
@@ -505,6 +506,16 @@ __global__ __launch_bounds__(256, 4) void db_head_mfma_kernel(const bf16_t* __re
         if (prob) {
           const hf32x4 pr = {1.f / (1.f + expf(-lg.x)), 1.f / (1.f + expf(-lg.y)), 1.f / (1.f + expf(-lg.z)), 1.f / (1.f + expf(-lg.w))};
           *reinterpret_cast<hf32x4*>(prob + o) = pr;
+          if (bitmap) {
+            // prob > thresh, bit-packed (bitmap_kernel's words: bit k of word i = pixel 32 i + k): a lane holds 4 pixels of the row, the 8 lanes of
+            // an aligned group (W % 8 == 0, batches start at multiples of 32: the group is one 32-pixel word, all in or all out of the map) meet
+            // by three exchanges -- the separate pass re-read the 236 MB probability map of 64 pages for this
+            uint32_t wv = ((pr.x > thresh ? 1u : 0u) | (pr.y > thresh ? 2u : 0u) | (pr.z > thresh ? 4u : 0u) | (pr.w > thresh ? 8u : 0u)) << (4 * (lx & 7));
+            wv |= __shfl_xor(wv, 1);
+            wv |= __shfl_xor(wv, 2);
+            wv |= __shfl_xor(wv, 4);
+            if ((lx & 7) == 0) bitmap[o >> 5] = wv;
+          }
         }
       }
     }
@@ -512,12 +523,13 @@ __global__ __launch_bounds__(256, 4) void db_head_mfma_kernel(const bf16_t* __re
 }
 
 int pt_launch_db_head_mfma(const bf16_t* in, int B, int H, int W, const bf16_t* w3, const float* b3, const bf16_t* w6,
-                           const float* b6, float* prob, float* logits, hipStream_t s) {
+                           const float* b6, float* prob, float* logits, hipStream_t s, uint32_t* bitmap, float thresh) {
+  PT_REQUIRE(!bitmap || (prob && W % 8 == 0), "db head: the fused bitmap needs the probability map and a width that is a multiple of 8");
   const long long npix = (long long)B * H * W;
   long long blocks = (npix / 32 + 4 * 12 - 1) / (4 * 12);     // ~12 batches per wave: the 37 KB weight image is staged once per workgroup
   if (blocks < 1) blocks = 1;
   if (blocks > 2048) blocks = 2048;                            // whole rounds of 256 CUs x 4 workgroups (2 400 were 2.3 rounds)
-  hipLaunchKernelGGL(db_head_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, npix, H, W, w3, b3, w6, b6, prob, logits);
+  hipLaunchKernelGGL(db_head_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, npix, H, W, w3, b3, w6, b6, prob, logits, bitmap, thresh);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
