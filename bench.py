@@ -972,6 +972,7 @@ def main(argv=None):
         prof = runner.eng.profile_read()
         runner.eng.profile_enable(False)
         if runner.trace is not None and rank == 0:
+            runner.trace.setdefault("det_boxes_parts", {a: round(b, 3) for a, b in getattr(runner.stage, "timing", {}).items()})
             print("[bench trace] host seconds over warm-up + timed steps:", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in runner.trace.items()},
                   file=sys.stderr)
     if dist is not None:
