@@ -23,13 +23,22 @@ q = ab[:, 1:].reshape(-1, 4, 2)
 area = (q[..., 0].max(1) - q[..., 0].min(1) + 1) * (q[..., 1].max(1) - q[..., 1].min(1) + 1)
 print(f"{len(ab)} candidates on 64 pages; bounding rectangles: median {np.median(area):.0f} px, p90 {np.percentile(area, 90):.0f}, p99 {np.percentile(area, 99):.0f}, "
       f"max {area.max():.0f}, sum {area.sum() / 1e6:.1f} Mpx")
-d = torch.from_numpy(ab).cuda()
-eng.det_box_scores(prob, d)
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(20):
+def timed(sel, label):
+    d = torch.from_numpy(np.ascontiguousarray(ab[sel])).cuda()
     eng.det_box_scores(prob, d)
-e1.record()
-torch.cuda.synchronize()
-print(f"box_score_kernel alone: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per call")
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        eng.det_box_scores(prob, d)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"box_score_kernel alone, {label} ({int(np.count_nonzero(sel))} boxes, {area[sel].sum() / 1e6:.1f} Mpx): {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per call")
+
+
+timed(np.ones(len(ab), bool), "all candidates")
+timed(area <= 4096, "rectangles <= 4 096 px")
+timed((area > 4096) & (area <= 65536), "4 096 < px <= 65 536")
+timed(area > 65536, "> 65 536 px")
+order = np.argsort(-area)
+timed(np.isin(np.arange(len(ab)), order[:1]), "the largest one")
