@@ -389,6 +389,17 @@ int pt_op_conv2d(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int Ci
 /* split=1 (BF16X3): d_in/d_res/d_out carry (hi | lo) channel groups, d_w_tiled is [N/64][3*Cin/32][ks*ks][64][32]
  * (K chunks: w_hi for x_hi, w_hi for x_lo, w_lo for x_hi), out_lo_off = channel distance hi -> lo in d_out. */
 
+/* Fused modulated deformable 3x3 convolution (pad 1, stride 1, dilation 1, one deformable group) + bias (+ ReLU): the operator
+ * DCN.forward (model/lore/dcnv2.py:71-86) hands to torchvision.ops.deform_conv2d, sampling rule of
+ * model/lore/DCNv2_latest/src/cpu/dcn_v2_im2col_cpu.cpp:26-55,123-190 (bilinear, zero outside (-1,H)x(-1,W), per-corner bounds).
+ *   d_in  bf16 NHWC [B,H,W,C] ([hi(C) | lo(C)] when split), C % 32 == 0
+ *   d_om  fp32 [B*H*W][32]: channel 2k / 2k+1 = (dy, dx) of tap k, 18+k = mask LOGIT of tap k (the sigmoid is applied here), 27..31 unused
+ *   d_w_tiled: the [N, 9*C, 1, 1] weight (K = tap * C + c) tiled like a 1x1 convolution (weights.py:tile_conv_weight, or
+ *              tile_conv_weight_x3 when split), d_bias fp32 [N], N % 64 == 0
+ *   d_out bf16 [B,H,W,N] ([hi | lo] when split).  Since ABI 12. */
+int pt_op_dcn(pt_engine* e, const uint16_t* d_in, const float* d_om, int B, int H, int W, int C, const uint16_t* d_w_tiled,
+              const float* d_bias, int N, uint16_t* d_out, int relu, int split, pt_stream stream);
+
 /* Stem of the ResNet-18 backbone: 7x7 s2 p3 conv (BN folded) + ReLU on a bf16 NHWC4 image (dbnet.py:272-275).
  * d_w is bf16 [64][7][8][4] (K padded: tap s=7 and channel 3 are zero), d_bias fp32 [64]; out bf16 [B,H/2,W/2,64]. */
 int pt_op_stem7x7(pt_engine* e, const uint16_t* d_in, int B, int H, int W, const uint16_t* d_w, const float* d_bias,

@@ -20,7 +20,7 @@ void pt_set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* pt_last_error(void) { return g_err; }
-int pt_abi_version(void) { return 11; }   // 11: pt_engine_set_mtl_kv_fp8; 10: pt_tsr_mtl_preprocess / decoder_config / structure / cells (MtlTabNet decoders); 9: pt_rec_cvit_* (ConvNextViT recogniser); 8: pt_op_dwconv / add / maxpool / avgpool / chan_mean / scale_channels / act (generic ONNX executor); 7: pt_rec_pp_preprocess*; 6: pt_engine_set_lstm_cluster, pt_engine_check clears what it reports
+int pt_abi_version(void) { return 12; }   // 12: pt_op_dcn (the fused modulated deformable convolution as a single operator); 11: pt_engine_set_mtl_kv_fp8; 10: pt_tsr_mtl_preprocess / decoder_config / structure / cells (MtlTabNet decoders); 9: pt_rec_cvit_* (ConvNextViT recogniser); 8: pt_op_dwconv / add / maxpool / avgpool / chan_mean / scale_channels / act (generic ONNX executor); 7: pt_rec_pp_preprocess*; 6: pt_engine_set_lstm_cluster, pt_engine_check clears what it reports
 
 int pt_engine_check(pt_engine* e) {
   PT_REQUIRE(e, "pt_engine_check: null engine");
@@ -946,6 +946,13 @@ int pt_op_db_head_final(pt_engine* e, const uint16_t* d_in, int B, int H, int W,
                         float* d_prob, float* d_logits, int split, pt_stream stream) {
   PT_REQUIRE(e && d_in && d_w && d_bias && (d_prob || d_logits), "pt_op_db_head_final: bad arguments");
   return pt_launch_db_head_final(d_in, B, H, W, d_w, d_bias, d_prob, d_logits, split, reinterpret_cast<hipStream_t>(stream));
+}
+
+int pt_op_dcn(pt_engine* e, const uint16_t* d_in, const float* d_om, int B, int H, int W, int C, const uint16_t* d_w_tiled,
+              const float* d_bias, int N, uint16_t* d_out, int relu, int split, pt_stream stream) {
+  PT_REQUIRE(e && d_in && d_om && d_w_tiled && d_bias && d_out, "pt_op_dcn: null argument");
+  PT_REQUIRE(B > 0 && H > 0 && W > 0, "pt_op_dcn: empty map (B=%d H=%d W=%d)", B, H, W);
+  return pt_launch_dcn_fused(e, d_in, d_om, d_w_tiled, d_bias, d_out, B, H, W, C, N, split, relu, reinterpret_cast<hipStream_t>(stream));
 }
 
 // ---- profiling ---------------------------------------------------------------------------------------

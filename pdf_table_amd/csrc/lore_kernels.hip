@@ -494,7 +494,7 @@ __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) voi
   // sampling geometry of the tile, computed ONCE per (pixel, tap) -- the eight lanes that share a pixel used to redo it
   // every stage, which was half of the kernel's VALU time: element offsets of the four corners (-1 = outside the map),
   // their bilinear weights, and the sigmoid mask
-  __shared__ __attribute__((aligned(16))) int s_goff[128 * 9][4];
+  __shared__ __attribute__((aligned(16))) unsigned s_goff[128 * 9][4];
   __shared__ __attribute__((aligned(16))) float s_gwt[128 * 9][4];
   // the offset / mask values are only needed while the table is built: they share LDS with the operand images
   __shared__ __attribute__((aligned(16))) char s_ab[NP * (128 * ROW + NB * ROW)];
@@ -532,9 +532,7 @@ __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) voi
     const long long pix = img0 + (long long)y * W + xq;
     *reinterpret_cast<float4*>(s_om + (i / 7) * 28 + (i % 7) * 4) = *reinterpret_cast<const float4*>(om + pix * 32 + (i % 7) * 4);
   }
-  const bf16_t* xb[IT];
-#pragma unroll
-  for (int j = 0; j < IT; ++j) xb[j] = x + (size_t)img0 * cs + piece * 8;
+  const char* xmap = reinterpret_cast<const char*>(x + (size_t)img0 * cs);     // wave-uniform: the gathers are scalar base + 32-bit lane offset
   __syncthreads();
   for (int i = tid; i < 128 * 9; i += NTHR) {
     const int pl = i / 9, tap = i - pl * 9;
@@ -546,19 +544,21 @@ __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) voi
     const float gm = 1.f / (1.f + expf(-o[18 + tap]));
     const float h_im = (float)(yh - 1 + tap / 3) + off_h;
     const float w_im = (float)(xw - 1 + tap % 3) + off_w;
-    int co[4] = {-1, -1, -1, -1};
+    // A corner outside the map contributes zero (dcn_v2_im2col_cpu.cpp:26-55): its WEIGHT is zeroed here and its offset
+    // points at the map's first pixel, so that the stage loop gathers unconditionally -- no predicate, no zero-filled
+    // registers, no branch per corner (those were 40 % of the kernel's VALU instructions).  0 * finite = +-0: same sums.
+    unsigned co[4] = {0u, 0u, 0u, 0u};            // BYTE offsets from the map's first pixel (< 2^32, checked by the launcher)
     float cw[4] = {0.f, 0.f, 0.f, 0.f};
     if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
       const float hf = floorf(h_im), wf = floorf(w_im);
       const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
       const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-      cw[0] = hh * hw * gm; cw[1] = hh * lw * gm; cw[2] = lh * hw * gm; cw[3] = lh * lw * gm;
-      if (h_low >= 0 && w_low >= 0) co[0] = (h_low * W + w_low) * cs;
-      if (h_low >= 0 && w_high <= W - 1) co[1] = (h_low * W + w_high) * cs;
-      if (h_high <= H - 1 && w_low >= 0) co[2] = (h_high * W + w_low) * cs;
-      if (h_high <= H - 1 && w_high <= W - 1) co[3] = (h_high * W + w_high) * cs;
+      if (h_low >= 0 && w_low >= 0) { co[0] = (unsigned)(h_low * W + w_low) * (unsigned)(2 * cs); cw[0] = hh * hw * gm; }
+      if (h_low >= 0 && w_high <= W - 1) { co[1] = (unsigned)(h_low * W + w_high) * (unsigned)(2 * cs); cw[1] = hh * lw * gm; }
+      if (h_high <= H - 1 && w_low >= 0) { co[2] = (unsigned)(h_high * W + w_low) * (unsigned)(2 * cs); cw[2] = lh * hw * gm; }
+      if (h_high <= H - 1 && w_high <= W - 1) { co[3] = (unsigned)(h_high * W + w_high) * (unsigned)(2 * cs); cw[3] = lh * lw * gm; }
     }
-    *reinterpret_cast<int4*>(s_goff[i]) = make_int4(co[0], co[1], co[2], co[3]);
+    *reinterpret_cast<uint4*>(s_goff[i]) = make_uint4(co[0], co[1], co[2], co[3]);
     *reinterpret_cast<float4*>(s_gwt[i]) = make_float4(cw[0], cw[1], cw[2], cw[3]);
   }
   __syncthreads();     // table complete; s_om is dead from here on (s_a / s_w take its place at the first commit)
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) voi
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  int coff[IT][4];
+  unsigned coff[IT][4];
   float cwt[IT][4];
   u32x4 rc[IT][4], rcl[SPLIT ? IT : 1][4];
   u32x4 rw[WP], rwl[SPLIT ? WP : 1];
@@ -579,31 +579,26 @@ __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) voi
 #pragma unroll
     for (int j = 0; j < IT; ++j) {
       const int gi = (prow + PSTEP * j) * 9 + tap;
-      const int4 o = *reinterpret_cast<const int4*>(s_goff[gi]);
+      const uint4 o = *reinterpret_cast<const uint4*>(s_goff[gi]);
       const float4 wv = *reinterpret_cast<const float4*>(s_gwt[gi]);
-      coff[j][0] = o.x; coff[j][1] = o.y; coff[j][2] = o.z; coff[j][3] = o.w;
+      coff[j][0] = o.x + piece * 16; coff[j][1] = o.y + piece * 16; coff[j][2] = o.z + piece * 16; coff[j][3] = o.w + piece * 16;
       cwt[j][0] = wv.x; cwt[j][1] = wv.y; cwt[j][2] = wv.z; cwt[j][3] = wv.w;
     }
   };
   auto prefetch = [&](int st) {
     const int tap = st / nss, ss = st - tap * nss;
     if (ss == 0) geometry(tap);
+    const char* xs = xmap + ss * 128;             // this stage's 64-channel slice (uniform)
 #pragma unroll
     for (int j = 0; j < IT; ++j)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        rc[j][k] = u32x4{0u, 0u, 0u, 0u};
 #if PT_DCN_ABL == 1     /* ablation: no gather traffic */
-        rc[j][k].x = (uint32_t)coff[j][k];
-#elif PT_DCN_ABL == 4   /* ablation: gather without the bounds predicate, always the pixel's own line */
-        rc[j][k] = *reinterpret_cast<const u32x4*>(xb[j] + ((size_t)(ty0 + ((prow + PSTEP * j) >> 4)) * W + tx0 + ((prow + PSTEP * j) & 15)) % ((size_t)H * W) * C + ss * 64);
+        rc[j][k] = u32x4{coff[j][k], 0u, 0u, 0u};
 #else
-        if (coff[j][k] >= 0) rc[j][k] = *reinterpret_cast<const u32x4*>(xb[j] + coff[j][k] + ss * 64);
+        rc[j][k] = *reinterpret_cast<const u32x4*>(xs + coff[j][k]);
 #endif
-        if (SPLIT) {
-          rcl[j][k] = u32x4{0u, 0u, 0u, 0u};
-          if (coff[j][k] >= 0) rcl[j][k] = *reinterpret_cast<const u32x4*>(xb[j] + coff[j][k] + ss * 64 + C);
-        }
+        if (SPLIT) rcl[j][k] = *reinterpret_cast<const u32x4*>(xs + 2 * C + coff[j][k]);
       }
     const int kc = tap * (C >> 5) + 2 * ss;     // the stage's two 32-channel weight chunks are adjacent
 #pragma unroll

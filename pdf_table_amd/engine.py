@@ -604,6 +604,23 @@ class HipEngine:
                                       int(relu), int(split), out.shape[-1] // 2, self._stream()), "pt_op_conv2d")      # relu: bool, or the epilogue's activation code (0 none, 1 ReLU, 2 hardswish)
         return out
 
+    def op_dcn(self, x: torch.Tensor, om: torch.Tensor, w_tiled: torch.Tensor, bias: torch.Tensor, relu: bool = True, split: int = 0) -> torch.Tensor:
+        """Fused modulated deformable 3x3 convolution (lore/dcnv2.py:71-86) as a single operator.  x bf16 [B,H,W,C] ([hi | lo] when split),
+        om fp32 [B,H,W,32] (18 offsets, 9 mask logits, 5 unused), w_tiled = the [N, 9C, 1, 1] weight tiled as a 1x1 conv, bias fp32 [N]."""
+        self._chk(x, torch.bfloat16, "x")
+        self._chk(om, torch.float32, "om")
+        self._chk(bias, torch.float32, "bias")
+        B, H, W, Cc = x.shape
+        m = 2 if split else 1
+        Cc //= m
+        if tuple(om.shape) != (B, H, W, 32):
+            raise ValueError(f"op_dcn: om must be [B,H,W,32], got {tuple(om.shape)}")
+        N = bias.numel()
+        out = torch.empty((B, H, W, N * m), dtype=torch.bfloat16, device=self._tdev)
+        L.check(self.lib.pt_op_dcn(self._h, _ptr(x), _ptr(om), B, H, W, Cc, _ptr(w_tiled), _ptr(bias), N, _ptr(out), int(relu), int(split),
+                                   self._stream()), "pt_op_dcn")
+        return out
+
     # ---- single operators of the generic ONNX executor (pdf_table_amd/onnx_exec.py); bf16 NHWC, C a multiple of 8 -------
     def op_dwconv(self, x: torch.Tensor, w_taps: torch.Tensor, bias: torch.Tensor, k: int, stride: int = 1, act: int = 0) -> torch.Tensor:
         self._chk(x, torch.bfloat16, "x")

@@ -103,6 +103,7 @@ def _proto(lib):
         "pt_cls_forward": (i, [vp, i, vp, vp, i, i, i, i, i, i, vp, ip, vp]),
         "pt_cls_forward_lines": (i, [vp, i, vp, i, i, i, vp, vp, i, i, i, i, i, i, vp, ip, vp]),
         "pt_op_conv2d": (i, [vp, vp, i, i, i, i, vp, vp, i, i, i, vp, i, i, i, i, vp, i, i, i, i, vp]),
+        "pt_op_dcn": (i, [vp, vp, vp, i, i, i, i, vp, vp, i, vp, i, i, vp]),
         "pt_op_stem7x7": (i, [vp, vp, i, i, i, vp, vp, vp, i, vp]),
         "pt_op_maxpool3x3s2": (i, [vp, vp, i, i, i, i, vp, i, vp]),
         "pt_op_db_head_final": (i, [vp, vp, i, i, i, vp, vp, vp, vp, i, vp]),

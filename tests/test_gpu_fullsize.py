@@ -295,6 +295,39 @@ def test_fullsize_lore_oracle_parity(eng_par, pages, mode):
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_fullsize_lore_bench_weights_drift(pages, mode):
+    """The SAME table through the weights bench.py times (lore_dla34_state_dict(seed=2), dcn_gain = 0.1: offsets of ~0.3 px): recorded and
+    bounded in both modes.  The oracle itself is ill-conditioned on this random net (see eng_par: a 1e-5 relative input perturbation moves
+    the fp32 oracle by 1.2e-3 of the head scale at 512 x 512), so the BF16X3 bound here is NOT the 1e-3 contract -- that one is asserted on the
+    dcn_gain = 0.02 net above and, operator by operator with multi-pixel offsets, in tests/test_gpu_dcn_op.py -- but a recorded drift."""
+    from oracle import lore_net, lore_pre
+    from pdf_table_amd.engine import HipEngine
+    from pdf_table_amd.synth_weights import lore_dla34_state_dict
+    from pdf_table_amd.weights import pack_lore_dla34
+    sd = lore_dla34_state_dict(seed=2)
+    img, meta = pages[0]
+    x1, y1, x2, y2 = (int(v) for v in meta["tables"].reshape(-1, 4)[0])
+    xo, _ = lore_pre.lore_preprocess(np.ascontiguousarray(img[y1:y2, x1:x2][:, :, ::-1]), 1024, 1024)
+    with torch.no_grad():
+        ref = lore_net.dlaseg_forward(sd, xo)
+    eng = HipEngine(0)
+    try:
+        eng.load_weights(L.PT_MODEL_LORE_DLA34, pack_lore_dla34(sd))
+        _mode(eng, mode)
+        got = eng.tsr_forward_net(_x4(xo, split=mode == "bf16x3").cuda())
+        torch.cuda.synchronize()
+        got = {k: got[k].cpu().permute(0, 3, 1, 2) for k in ref}
+    finally:
+        eng.close()
+    worst = 0.0
+    for k in ref:
+        rel = (got[k] - ref[k]).abs().max().item() / max(1.0, ref[k].abs().max().item())
+        worst = max(worst, rel)
+        print(f"FULLSIZE lore 1024x1024 BENCH WEIGHTS (dcn_gain 0.1) {mode} head {k}: rel max err {rel:.3e} (scale {ref[k].abs().max().item():.2f})")
+    assert worst <= (2e-2 if mode == "bf16x3" else 0.6)      # r03 measured at this gain: bf16x3 2e-3 .. 6e-3, bf16 0.4
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
 def test_fullsize_picodet_oracle_parity(eng_par, pages, mode):
     """one 1024x1024 page -> 800x608 PicoDet input (the oracle's pre-process) -> LCNet + CSP-PAN + PicoHead vs the oracle"""
     from oracle import picodet as op
