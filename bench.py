@@ -65,6 +65,9 @@ def parse_args(argv=None):
     ap.add_argument("--det-backbone", default="resnet18", choices=["resnet18", "proxylessnas"],
                     help="DB detector network: DBModel (BASELINE.json's configuration) or DBNasModel (diagnostic variant)")
     ap.add_argument("--no-post", action="store_true", help="device half only (diagnostic; not a valid headline)")
+    ap.add_argument("--host-pages-leg", action="store_true",
+                    help="also run the host_pages leg (pinned host batches, H2D inside the timed region) when --no-extra-legs is given; "
+                         "the one_eighth_host child uses it")
     ap.add_argument("--host-share", type=int, default=0,
                     help="(leg of the default run) re-run the timed region in a child process pinned with sched_setaffinity to 1/N of "
                          "the host's cores: what every rank of an N-GPU node gets")
@@ -305,7 +308,7 @@ def one_eighth_host_leg(args, value):
     cpus = sorted(os.sched_getaffinity(0))
     share = cpus[:max(1, len(cpus) // 8)]
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline",
-           "--no-extra-legs", "--stages", args.stages, "--precision", args.precision]
+           "--no-extra-legs", "--host-pages-leg", "--stages", args.stages, "--precision", args.precision]
     try:
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, preexec_fn=lambda: os.sched_setaffinity(0, share),
                            env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
@@ -313,7 +316,10 @@ def one_eighth_host_leg(args, value):
         if not lines:
             return {"error": f"child exited with {p.returncode}: " + p.stderr[-400:]}
         d = json.loads(lines[-1])
+        hp = d.get("host_pages") or {}
         return {"pages_per_s_at_one_eighth_host": d["value"], "ratio_to_value": d["value"] / value, "cores": len(share), "of_cores": len(cpus),
+                "host_pages_pages_per_s_at_one_eighth_host": hp.get("pages_per_s"),
+                "host_pages_ratio_to_value": (hp["pages_per_s"] / value) if hp.get("pages_per_s") else None,
                 "note": "same timed region (OcrTablePipeline.predict_stream, 64-page batches), child process pinned to the first 1/8 of the "
                         "cores, detection post-process pool capped to that share"}
     except Exception as e:      # noqa: BLE001 -- a diagnostic leg must not take the bench line down
@@ -540,18 +546,19 @@ class HipRunner:
         return (self.pipe is not None and (stages is None or list(stages) == list(self.stages)) and self.rec_stream is None
                 and not (a.private_loop or a.gt_chain or a.no_post))
 
-    def run(self, steps, count=False, stages=None):
-        """`steps` 64-page batches through the four stages.  Default: the product API -- OcrTablePipeline.predict_stream() over a
+    def run(self, steps, count=False, stages=None, batch=None):
+        """`steps` 64-page batches through the four stages (`batch`: the tensor every step feeds; default the device-resident pages).  Default: the product API -- OcrTablePipeline.predict_stream() over a
         stream of device-resident batches (pdf_table_amd/pipeline.py; results arrive two batches behind the input and the
         generator drains inside the timed region).  Single-stage legs and --private-loop: run_private()."""
         if not self.uses_pipeline(stages):
+            assert batch is None
             return self.run_private(steps, count, stages)
         import itertools
         c = {"boxes": 0, "tok": 0, "cells": 0, "layout": 0, "cls_lines": 0, "rec_lines": 0}
         # table regions: the layout stage's own (table_boxes=None: OcrTablePipeline._layout_table_boxes) unless --gt-tables / no fitted head
         tb = itertools.repeat(self.table_boxes, steps) if self.tsr is not None and not self.layout_chain else None
         c["tables"] = 0
-        for res in self.pipe.predict_stream(itertools.repeat(self.pages, steps), table_boxes=tb):
+        for res in self.pipe.predict_stream(itertools.repeat(self.pages if batch is None else batch, steps), table_boxes=tb):
             if count:
                 for r in res:
                     c["boxes"] += len(r.det_result)
@@ -695,6 +702,24 @@ class HipRunner:
         self.sync()
         return time.perf_counter() - t0, c
 
+    def host_pages_leg(self, steps=10, warm=3):
+        """PCIe under the clock: the SAME step, but every batch starts in pinned HOST memory -- predict_stream() uploads it on a
+        copy stream (192 MiB per 64-page batch, queued as soon as the enqueue thread reaches the batch, i.e. while the GPU still computes the
+        batches before it) and the results come back as in the headline leg.  `value` keeps its definition (inputs resident in HBM); this is the
+        rate when they are not."""
+        if not self.uses_pipeline():
+            return None
+        host = self.torch.from_numpy(self.pages_np).pin_memory()
+        self.run(warm, batch=host)
+        self.sync()
+        t0 = time.perf_counter()
+        self.run(steps, count=True, batch=host)
+        self.sync()
+        dt = time.perf_counter() - t0
+        return {"pages_per_s": PAGES_PER_STEP * steps / dt, "steps": steps, "ms_per_step": dt / steps * 1e3,
+                "h2d_bytes_per_step": int(host.numel()), "source": "one pinned uint8 [64,1024,1024,3] host batch per step, H2D on a copy stream "
+                                                                   "inside the timed region (pipeline.py:predict_stream)"}
+
     def det_only_leg(self, steps=20, warm=5):
         """BASELINE.json configs[1] in the same run: the det stage alone (pre, DB-ResNet18, bitmap, host post overlapped); steps / warm-up as
         the stand-alone `bench.py --stages det` defaults (a 10-step leg read 2-3 % low: one software-pipeline fill + drain in 0.1 s)"""
@@ -823,6 +848,44 @@ class HipRunner:
                          "cell_steps_per_table": st["cell_steps"] / max(1, st["tables"]),
                          "structure_tokens_per_s": st["tokens"] / steps / dt,
                          "boxes_per_table": float(sum(len(r["polygons"]) for pg in res for r in pg)) / max(1, n_tab)}
+        return out
+
+    def e2e_agreement_leg(self):
+        """What the headline mode outputs, as fractions of the oracle chain's outputs: the two pages of the committed
+        end-to-end fixture (tests/golden/e2e_page.npz -- boxes, token ids, cells, logical locations of the composed fp32 oracle chain) through
+        OcrTablePipeline.predict() in bf16 (and BF16X3), compared by tests/e2e_agreement.py.  The fixture's nets are the bench's own except the
+        Lore detector (dcn_gain 0.02 and a heat-map bias that yields cells, tests/e2e_synth.py), which is loaded for this leg only.  A checker
+        outside every timed region, like cpu_baseline."""
+        L, eng = self.L, self.eng
+        if not (self.layout_chain and self.pipe is not None and self.tsr is not None and not self.nas):
+            return None
+        tdir = os.path.join(REPO, "tests")
+        if tdir not in sys.path:
+            sys.path.insert(0, tdir)
+        from e2e_agreement import agreement
+        from e2e_synth import E2E_PAGES, e2e_state_dicts
+        from pdf_table_amd.pipeline import OcrTablePipeline
+        from pdf_table_amd.synth_pages import make_page
+        from pdf_table_amd.tsr_stage import LoreConfig, TsrStage
+        from pdf_table_amd.weights import pack_lore_dla34
+        g = np.load(os.path.join(tdir, "golden", "e2e_page.npz"))
+        eng.load_weights(L.PT_MODEL_LORE_DLA34, pack_lore_dla34(e2e_state_dicts()["lore"], x3=self.x3_leg))
+        pipe = OcrTablePipeline.from_engine(eng, self.stage, self.rec, self.layout, TsrStage(eng, LoreConfig(task_type="wtw")), table_html=True)
+        pages = [make_page(i, PAGE)[0] for i in E2E_PAGES]
+        tbs = [g[f"p{pi}_table_boxes"] for pi in range(len(pages))]
+        out = {"fixture": "tests/golden/e2e_page.npz (2 pages, 236 text lines, 3 tables, 299 cells; oracle chain in fp32)",
+               "definition": "tests/e2e_agreement.py: fraction of the oracle's boxes / strings / cells / table HTML the engine reproduces"}
+        for mode, prec in (("bf16", L.PT_PRECISION_BF16), ("bf16x3", L.PT_PRECISION_BF16X3)):
+            if mode == "bf16x3" and not self.x3_leg:
+                continue
+            eng.set_precision(prec)
+            try:
+                a = agreement(g, pipe.predict(pages), self.rec.label, tbs)
+            finally:
+                eng.set_precision(L.PT_PRECISION_BF16)
+            out[mode] = a["frac"]
+            out[mode + "_counts"] = {k: v for k, v in a.items() if k != "frac"}
+        eng.load_weights(L.PT_MODEL_LORE_DLA34, pack_lore_dla34(self.lsd, x3=self.x3_leg))       # the bench's own Lore detector back
         return out
 
     def parity_sample(self):
@@ -1016,6 +1079,11 @@ def main(argv=None):
                 roof["all_kernel_classes_ms"] = {k: v["ms"] for k, v in prof.items()}
                 roof["all_kernel_classes_flop"] = {k: v["flop"] for k, v in prof.items()}
             out["roofline"] = roof
+    if not stub and world == 1 and (args.host_pages_leg or not args.no_extra_legs) and not args.no_post:
+        leg = runner.host_pages_leg()
+        if leg is not None:
+            leg["ratio_to_value"] = leg["pages_per_s"] / out["value"]
+            out["host_pages"] = leg
     # extra legs: every rank runs them (they are outside the timed region; rank 0 reports its own)
     if not stub and not args.no_extra_legs and world == 1:
         if "det" in runner.stages and not runner.nas:
@@ -1031,6 +1099,10 @@ def main(argv=None):
             if rank == 0:
                 leg["bf16_pages_per_s"] = out["value"]
                 out["tolerance_mode"] = leg
+        if rank == 0 and not args.no_post:
+            leg = runner.e2e_agreement_leg()
+            if leg is not None:
+                out.setdefault("tolerance_mode", {})["bf16_e2e_agreement"] = leg
         if "rec" in runner.stages and not args.no_post:
             leg = runner.convnext_vit_leg()
             if rank == 0 and leg is not None:

@@ -91,6 +91,7 @@ void pt_engine_destroy(pt_engine* e) {
   if (e->rec_off) (void)hipFree(e->rec_off);
   if (e->zero_page) (void)hipFree(e->zero_page);
   if (e->tsr_scratch) (void)hipFree(e->tsr_scratch);
+  if (e->dcn_list) (void)hipFree(e->dcn_list);
   if (e->tsr_lut) (void)hipFree(e->tsr_lut);
   if (e->cls_lut) (void)hipFree(e->cls_lut);
   if (e->rec_pp_lut) (void)hipFree(e->rec_pp_lut);

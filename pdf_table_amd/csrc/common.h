@@ -186,6 +186,8 @@ struct pt_engine {
   std::vector<int> cvit_maps[16][2];
   int cvit_slot = 0;
   PtPinnedRing stage_ring;                                   // pinned sources of small asynchronous uploads (Lore processor token maps, ConvNextViT chunk maps)
+  void* dcn_list = nullptr; size_t dcn_list_cap = 0;         // lore_kernels.hip: two append counters + the tile list dcn_win_kernel hands to dcn_fused64_kernel
+  unsigned dcn_calls = 0;                                    // ... parity of the counter in use
   void* mtl_state = nullptr;                                 // mtl_decoder.hip: buffers + cell lists between pt_tsr_mtl_structure and pt_tsr_mtl_cells
 };
 

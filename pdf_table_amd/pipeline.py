@@ -314,17 +314,28 @@ class OcrTablePipeline:
 
         def queue_first(batch, k):
             """layout(k) + detection(k)"""
-            if torch.is_tensor(batch):
+            up = torch.cuda.Event()
+            if torch.is_tensor(batch) and batch.device.type == "cpu":
+                # host batch: H2D on a copy stream, queued NOW -- the enqueue thread runs ahead of the GPU, so the transfer overlaps the
+                # compute of the batches before it (asynchronous when the batch is pinned; a pageable batch is staged by the runtime)
+                if getattr(self, "_copy_stream", None) is None:
+                    self._copy_stream = torch.cuda.Stream(device=dev)
+                with torch.cuda.stream(self._copy_stream):
+                    pages_t = batch.to(dev, non_blocking=batch.is_pinned())
+                up.record(self._copy_stream)
+                main.wait_event(up)
+                pages_t.record_stream(main)
+            elif torch.is_tensor(batch):
                 pages_t = batch.to(dev)
+                up.record(main)
             else:
                 imgs = [_read_image(p) for p in batch]
                 if len({im.shape for im in imgs}) != 1:
                     raise ValueError("predict_stream() needs equally sized pages inside a batch (predict() groups by size)")
                 pages_t = torch.from_numpy(np.stack(imgs)).to(dev)
+                up.record(main)
             st = {"pages": pages_t, "shape": tuple(pages_t.shape[1:3]), "n": pages_t.shape[0],
                   "tb": [np.asarray(b).reshape(-1, 4) for b in next(tb_iter)] if tb_iter is not None else None}
-            up = torch.cuda.Event()
-            up.record(main)
             st["uploaded"] = up
             if lay_stage is not None:
                 if getattr(self, "aux_layout", False):

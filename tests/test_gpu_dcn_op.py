@@ -33,7 +33,10 @@ def _bf16(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
 
-def _case(B, C, N, H, W, seed, sigma=3.0, rounded=True):
+def _case(B, C, N, H, W, seed, field="wide", rounded=True):
+    """field "wide": offsets ~ N(0, 3 px) + a 6 % tail of jumps beyond the map (most tiles leave dcn_win_kernel's LDS window and take the
+    tile-list path through dcn_fused64_kernel); "local": offsets ~ N(0, 0.6 px), no tail (every tile stays in the window kernel)."""
+    sigma = 3.0 if field == "wide" else 0.6
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, C, H, W, generator=g).abs()          # post-ReLU activations, as every DCN input in DLASeg is
     w = torch.randn(N, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5
@@ -42,7 +45,7 @@ def _case(B, C, N, H, W, seed, sigma=3.0, rounded=True):
         x, w = _bf16(x), _bf16(w)
     off = torch.randn(B, 18, H, W, generator=g) * sigma
     # a tail that leaves the map: 6 % of the taps get an offset of +-(0.5 .. 1.5) map sizes, some land exactly on -1 / H
-    far = torch.rand(B, 18, H, W, generator=g) < 0.06
+    far = torch.rand(B, 18, H, W, generator=g) < (0.06 if field == "wide" else 0.0)
     jump = (torch.rand(B, 18, H, W, generator=g) + 0.5) * max(H, W) * torch.sign(torch.randn(B, 18, H, W, generator=g))
     off = torch.where(far, jump, off)
     off[:, :, 0, 0] = torch.tensor([-1.0, 0.0] * 9)         # tap (0,0) of pixel (0,0): h_im = -2 (out); others at integer positions
@@ -76,13 +79,13 @@ SHAPES = [
 
 
 @pytest.mark.parametrize("C,N,H,W", SHAPES)
-@pytest.mark.parametrize("relu", [True, False])
-def test_dcn_op_bf16(eng, C, N, H, W, relu):
+@pytest.mark.parametrize("relu,field", [(True, "wide"), (False, "wide"), (True, "local")])
+def test_dcn_op_bf16(eng, C, N, H, W, relu, field):
     """bf16 mode: operands exactly representable; the kernel rounds every sampled column to bf16 before the product, so it is compared
     (a) with the oracle whose columns are rounded the same way -- difference = fp32 summation order + the output's own bf16 rounding --
     and (b) with the un-rounded oracle within the half-ulp-per-column bound."""
     B = 2
-    x, w, b, off, mlog = _case(B, C, N, H, W, seed=C * 1000 + N + H)
+    x, w, b, off, mlog = _case(B, C, N, H, W, seed=C * 1000 + N + H, field=field)
     mask = torch.sigmoid(mlog)
     cols = lore_net.deform_conv2d(x, off, mask, w, None, return_cols=True)          # [B,C,9,H,W] fp32
     ref = lore_net.deform_conv2d(x, off, mask, w, b)
@@ -105,7 +108,7 @@ def test_dcn_op_bf16(eng, C, N, H, W, relu):
     err_b = (got - ref).abs()
     tol_b = ref.abs() * 2.0 ** -8 + col_mag * 2.0 ** -9 + 1e-4
     assert bool((err_b <= tol_b).all()), f"vs oracle: max err {err_b.max().item()}"
-    print(f"dcn bf16 {C}->{N} @{H}x{W}: max err vs rounded-column oracle {err_a.max().item():.3e}, vs oracle {err_b.max().item():.3e}, scale {ref.abs().max().item():.2f}")
+    print(f"dcn bf16 {field} {C}->{N} @{H}x{W}: max err vs rounded-column oracle {err_a.max().item():.3e}, vs oracle {err_b.max().item():.3e}, scale {ref.abs().max().item():.2f}")
 
 
 @pytest.mark.parametrize("C,N,H,W", SHAPES)

@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 import torch
 
+from e2e_agreement import agreement, match_cells as _match_cells, match_rows as _match_rows
 from e2e_synth import E2E_PAGES, e2e_state_dicts, e2e_table_boxes
 from pdf_table_amd import lib as L
 from pdf_table_amd.synth_pages import make_page
@@ -54,24 +55,9 @@ def run(golden_dir):
         stream = [r for batch in pipe.predict_stream([torch.from_numpy(np.stack(pages)).cuda()] * 2) for r in batch]
     finally:
         eng.set_precision(L.PT_PRECISION_BF16)
+    pipe.res_bf16 = pipe.predict(pages)          # the SAME pages in the headline mode (PT_PRECISION_BF16): test_headline_mode_agreement
     yield g, res, stream, pipe, tbs
     eng.close()
-
-
-def _match_rows(want, got, tol):
-    """greedy one-to-one matching of rows by max |difference| <= tol -> list of (i_want, j_got)"""
-    used = np.zeros(len(got), bool)
-    pairs = []
-    for i, w in enumerate(want):
-        if not len(got):
-            break
-        d = np.abs(got - w).max(1)
-        d[used] = np.inf
-        j = int(np.argmin(d))
-        if d[j] <= tol:
-            used[j] = True
-            pairs.append((i, j))
-    return pairs
 
 
 def test_detection_boxes_and_reading_order(run):
@@ -134,26 +120,6 @@ def test_layout_tables_feed_the_table_stage(run):
         assert len(res[pi].table_structure_result) == len(tbs[pi])
 
 
-def _match_cells(want, got, tol=0.1):
-    """one-to-one matching of cell quads: a pair matches when at least three of its four vertices agree within tol (one vertex may have
-    been snapped to a different corner point) -> (pairs, indices of the pairs with a differing vertex)"""
-    used = np.zeros(len(got), bool)
-    pairs, odd = [], []
-    for i, w in enumerate(want):
-        if not len(got):
-            break
-        d = np.abs(got - w).reshape(len(got), 4, 2).max(2)          # per vertex
-        ok = (d <= tol).sum(1)
-        ok[used] = -1
-        j = int(np.argmax(ok))
-        if ok[j] >= 3:
-            used[j] = True
-            pairs.append((i, j))
-            if ok[j] < 4:
-                odd.append(len(pairs) - 1)
-    return pairs, odd
-
-
 def test_table_cells_logical_locations_and_html(run):
     """Cells: every oracle cell is found with its quad within 0.1 source px, except cells whose peak / score decision is fragile in the
     oracle itself; at most 2 % of the cells may carry ONE vertex that was snapped to a different corner point (the wiz_rev snapping takes
@@ -214,3 +180,24 @@ def test_predict_stream_yields_the_same_pages(run):
         assert len(s.table_structure_result) == len(r.table_structure_result)
         for a, b in zip(s.table_structure_result, r.table_structure_result):
             assert np.array_equal(a["polygons"], b["polygons"]) and np.array_equal(a["logi"], b["logi"]) and a["table_html"] == b["table_html"]
+
+
+def test_headline_mode_agreement(run):
+    """What the HEADLINE mode (PT_PRECISION_BF16, the arithmetic bench.py's `value` runs in) reproduces of the oracle chain's outputs end to
+    end, next to the tolerance mode's figures on the same pages: printed (profiles/r04/e2e_agreement.txt keeps the GPU run's lines) and
+    bounded from below so that a regression shows.  bf16 is NOT held to identity -- its per-stage tests assert drift bounds -- this test
+    says what those drifts do to the three outputs a user sees."""
+    import json
+    g, res, _, pipe, tbs = run
+    label = pipe.text_recognizer._stage.label
+    out = {}
+    for mode, r in (("bf16x3", res), ("bf16", pipe.res_bf16)):
+        a = agreement(g, r, label, tbs)
+        out[mode] = a
+        print(f"E2E AGREEMENT {mode}: " + json.dumps(a["frac"]))
+        print(f"E2E AGREEMENT {mode} counts: " + json.dumps({k: v for k, v in a.items() if k != "frac"}))
+    fx, fb = out["bf16x3"]["frac"], out["bf16"]["frac"]
+    # tolerance mode: what the tests above assert, as fractions
+    assert fx["boxes_identical"] >= 0.97 and fx["strings_identical_on_identical_quads"] >= 0.98 and fx["cells_matched_0p1px"] >= 0.95
+    # headline mode: recorded; floors well below the measured values (see DESIGN.md section 4)
+    assert fb["boxes_within_2px"] >= 0.9 and fb["strings_identical_on_2px_quads"] >= 0.5 and fb["cells_matched_1px"] >= 0.5
