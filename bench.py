@@ -49,6 +49,7 @@ PAGE = 1024
 PAGES_PER_STEP = int(os.environ.get("PT_BENCH_PAGES", "64"))   # per rank
 DISTINCT = int(os.environ.get("PT_BENCH_DISTINCT", str(PAGES_PER_STEP)))   # distinct synthetic pages per rank
 MFMA_PEAK_TFLOPS = 2500.0        # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_BYTES = 8.0e12          # HBM3E, bytes/s (same guide; ~6.3e12 achievable)
 DB_GFLOP_960 = 111.71            # DB-ResNet18 at the reference-preprocessed 960x960
 
 
@@ -720,6 +721,59 @@ class HipRunner:
                 "h2d_bytes_per_step": int(host.numel()), "source": "one pinned uint8 [64,1024,1024,3] host batch per step, H2D on a copy stream "
                                                                    "inside the timed region (pipeline.py:predict_stream)"}
 
+    # (label prefix, class) in match order: every launch label of the four stages falls into one class of roofline.by_class
+    BY_CLASS = (("conv3x3 c16", "thin DLA levels (3x3, 16 channels)"), ("conv3x3", "conv3x3 implicit GEMM"), ("conv1x1", "conv1x1 / row GEMM"),
+                ("rows gemm", "conv1x1 / row GEMM"), ("classifier", "classifier GEMM + arg-max"), ("cvit", "ConvNextViT"), ("db head", "DB head (2 x convT)"),
+                ("stem", "7x7 / 3x3 stems"), ("lcnet stem", "7x7 / 3x3 stems"), ("dcn", "deformable conv (gather + blend + GEMM)"),
+                ("dw convT", "depthwise convT up-sampler + add"), ("lstm", "BiLSTM recurrences"), ("layout dwconv", "depthwise convs (layout)"),
+                ("lcnet SE", "depthwise convs (layout)"), ("maxpool", "max-pools"), ("preprocess", "pre-processing (det / rec / tsr / layout)"),
+                ("rec ", "pre-processing (det / rec / tsr / layout)"), ("tsr pre", "pre-processing (det / rec / tsr / layout)"),
+                ("layout pre", "pre-processing (det / rec / tsr / layout)"), ("tsr attention", "Lore processor (attention, norms)"),
+                ("tsr norm", "Lore processor (attention, norms)"), ("tsr tok", "Lore processor (attention, norms)"), ("tsr cvt", "Lore processor (attention, norms)"),
+                ("tsr", "Lore decode (peaks, top-K, gathers, snapping)"), ("crnn", "CRNN fills / limits / conv0"), ("bitmap", "DB bitmap / box scores"),
+                ("box score", "DB bitmap / box scores"), ("argmax", "classifier GEMM + arg-max"))
+
+    def by_class_leg(self, steps=3, warm=1):
+        """roofline.by_class: the same step with HIP events around EVERY launch (pt_profile_enable(1); costs 1-3 % of the step in
+        idle GPU time, hence its own leg), the launches grouped into kernel classes: ms per step, launches, algorithmic FLOP and bytes per step
+        (what the launchers state: conv / GEMM FLOP = 2 x pixels x real N x K, bytes = inputs + outputs + residual + weights once), and the
+        fraction of the bf16 MFMA peak and of the 8 TB/s HBM peak that makes -- `bound` is the larger of the two.  Launches whose launcher
+        states neither are listed with their time only."""
+        if not self.uses_pipeline():
+            return None
+        eng = self.eng
+        self.run(warm)
+        self.sync()
+        eng.profile_enable(1)
+        t0 = time.perf_counter()
+        self.run(steps)
+        self.sync()
+        dt = (time.perf_counter() - t0) / steps
+        labels = eng.profile_read_labels()
+        eng.profile_enable(False)
+        cls = {}
+        for lab, r in labels.items():
+            name = next((c for p_, c in self.BY_CLASS if lab.startswith(p_)), "other")
+            d = cls.setdefault(name, {"ms": 0.0, "launches": 0, "flop": 0.0, "bytes": 0.0})
+            for k_ in d:
+                d[k_] += r[k_]
+        out = {}
+        for name, d in sorted(cls.items(), key=lambda kv: -kv[1]["ms"]):
+            ms = d["ms"] / steps
+            row = {"ms_per_step": round(ms, 3), "launches_per_step": round(d["launches"] / steps, 1)}
+            if d["flop"] > 0 and ms > 0:
+                row["gflop_per_step"] = round(d["flop"] / steps / 1e9, 1)
+                row["frac_mfma_peak"] = round(d["flop"] / steps / (ms * 1e-3) / (MFMA_PEAK_TFLOPS * 1e12), 4)
+            if d["bytes"] > 0 and ms > 0:
+                row["gbytes_per_step"] = round(d["bytes"] / steps / 1e9, 2)
+                row["frac_hbm_peak"] = round(d["bytes"] / steps / (ms * 1e-3) / HBM_PEAK_BYTES, 4)
+            if "frac_mfma_peak" in row or "frac_hbm_peak" in row:
+                row["bound"] = "mfma" if row.get("frac_mfma_peak", 0) >= row.get("frac_hbm_peak", 0) else "hbm"
+            out[name] = row
+        kern = sum(r["ms_per_step"] for r in out.values())
+        return {"ms_per_step_wall": round(dt * 1e3, 2), "ms_per_step_kernels": round(kern, 2), "steps": steps,
+                "peaks": {"mfma_tflops": MFMA_PEAK_TFLOPS, "hbm_tb_s": HBM_PEAK_BYTES / 1e12}, "classes": out}
+
     def det_only_leg(self, steps=20, warm=5):
         """BASELINE.json configs[1] in the same run: the det stage alone (pre, DB-ResNet18, bitmap, host post overlapped); steps / warm-up as
         the stand-alone `bench.py --stages det` defaults (a 10-step leg read 2-3 % low: one software-pipeline fill + drain in 0.1 s)"""
@@ -810,16 +864,21 @@ class HipRunner:
         if self.tsr is None:
             return None
         from pdf_table_amd.mtl_stage import MtlStage, MtlTabNetConvertor
-        from pdf_table_amd.synth_weights import mtl_tabnet_backbone_state_dict, mtl_tabnet_decoder_state_dict
+        from pdf_table_amd.synth_weights import mtl_table_signal_from, mtl_tabnet_backbone_state_dict, mtl_tabnet_decoder_state_dict
         from pdf_table_amd.weights import pack_mtl_backbone, pack_mtl_decoder
         conv = MtlTabNetConvertor()
         eng.load_weights(L.PT_MODEL_MTL_BACKBONE, pack_mtl_backbone(mtl_tabnet_backbone_state_dict(seed=41)))
-        eng.load_weights(L.PT_MODEL_MTL_DECODER, pack_mtl_decoder(mtl_tabnet_decoder_state_dict(seed=43, num_classes=conv.num_classes(),
-                                                                                             num_classes_cell=conv.num_classes_cell()), conv.decoder_cfg()))
+        # seeded random decoders + the hand-built table channels (synth_weights._mtl_table_signal): every table decodes <tbody>, 20 rows of
+        # <tr><td></td><td colspan="2"></td><eb></eb></tr>, </tbody>, <EOS> (163 structure positions) and its 40 content cells 8 characters + <EOS>
+        eng.load_weights(L.PT_MODEL_MTL_DECODER, pack_mtl_decoder(mtl_tabnet_decoder_state_dict(
+            seed=43, num_classes=conv.num_classes(), num_classes_cell=conv.num_classes_cell(), table_signal=mtl_table_signal_from(conv, rows_until=150)),
+            conv.decoder_cfg()))
         n_tab = int(sum(len(t) for t in self.table_boxes))
         out = {"tables_per_step": n_tab, "steps": steps, "max_seq_len": conv.max_seq_len, "max_seq_len_cell": conv.max_seq_len_cell,
-               "note": "random-init decoders do not emit <EOS>: every table decodes all max_seq_len + 1 structure positions and its cells all "
-                       "max_seq_len_cell + 1 content positions -- the worst case of the greedy loops (a trained model stops at </tbody>)",
+               "note": "seeded random decoders with hand-built table channels (synth_weights._mtl_table_signal: reserved residual dimensions carry the "
+                       "previous token and the position to the classifier): every table decodes 163 structure positions (20 rows, </tbody>, <EOS>) and "
+                       "40 content cells of 9 positions each -- structure loop, box head AND cell-content decoder are under the clock; sequence limits "
+                       "are the reference's (500 / 150), the loops stop at <EOS> like a trained model's",
                "asserted_by": "tests/test_gpu_mtl.py (x3: tokens identical, boxes / tag / cell logits <= 1e-3 of scale against the oracle "
                               "pinned to the reference's own MtlTabNetDecoder; task end to end against the composed oracle chain), "
                               "tests/test_mtl_host.py (convertor + post-processor identical to the reference's own classes)"}
@@ -1090,6 +1149,10 @@ def main(argv=None):
             leg = runner.det_only_leg()
             if rank == 0:
                 out["roofline"]["det_backbone"] = leg
+        if len(runner.stages) > 1 and not args.no_post:
+            leg = runner.by_class_leg()
+            if rank == 0 and leg is not None:
+                out["roofline"]["by_class"] = leg
         if len(runner.stages) > 1:
             leg = runner.overlap_leg()
             if rank == 0 and leg is not None:

@@ -502,6 +502,10 @@ int pt_cls_forward_lines(pt_engine* e, int slot, const uint8_t* d_pages_rgb, int
 #define PT_PROF_NCLASS 4
 int pt_profile_enable(pt_engine* e, int on);
 int pt_profile_read(pt_engine* e, double* ms_per_class, long long* launches_per_class, double* flop_per_class);
+/* Per-label readout of the launches recorded since the last read (pt_profile_enable(e, 1)): text lines
+ * "label<TAB>launches<TAB>ms<TAB>algorithmic FLOP<TAB>algorithmic bytes<NL>" into buf (NUL-terminated; PT_ERR_INVALID if cap is too small).
+ * Consumes the records like pt_profile_read.  bench.py's roofline.by_class is built from it.  Since ABI 12. */
+int pt_profile_read_labels(pt_engine* e, char* buf, int cap);
 
 /* ---- MtlTabNet (second half): backbone, then the decoders below -------------------------------
  * TableResNetExtra.forward (model/table/mtl_tabnet/table_resnet_extra.py:268-318) of the configuration in

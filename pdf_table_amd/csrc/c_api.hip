@@ -91,12 +91,13 @@ void pt_engine_destroy(pt_engine* e) {
   if (e->rec_off) (void)hipFree(e->rec_off);
   if (e->zero_page) (void)hipFree(e->zero_page);
   if (e->tsr_scratch) (void)hipFree(e->tsr_scratch);
-  if (e->dcn_list) (void)hipFree(e->dcn_list);
   if (e->tsr_lut) (void)hipFree(e->tsr_lut);
   if (e->cls_lut) (void)hipFree(e->cls_lut);
   if (e->rec_pp_lut) (void)hipFree(e->rec_pp_lut);
   if (e->rec_zero[0]) (void)hipFree(e->rec_zero[0]);
   if (e->rec_zero[1]) (void)hipFree(e->rec_zero[1]);
+  for (int i = 0; i < 2; ++i)
+    if (e->rec_zero_ready[i]) (void)hipEventDestroy(e->rec_zero_ready[i]);
   if (e->rec_limits) (void)hipFree(e->rec_limits);
   if (e->cls_scratch) (void)hipFree(e->cls_scratch);
   if (e->layout_scratch) (void)hipFree(e->layout_scratch);
@@ -963,6 +964,43 @@ int pt_profile_enable(pt_engine* e, int on) {
   if (on && !e->prof.h_lims)
     PT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->prof.h_lims), PtProfile::MAX_LIMS * sizeof(int), hipHostMallocDefault));
   e->prof.on = on;
+  return PT_OK;
+}
+
+// per-label readout of the launches recorded since the last read (PT profile mode 1): one line per label,
+// "label<TAB>launches<TAB>ms<TAB>flop<TAB>bytes<NL>", NUL-terminated; resets the records like pt_profile_read.  Returns PT_ERR_INVALID when the
+// text does not fit `cap` (nothing is consumed then).
+int pt_profile_read_labels(pt_engine* e, char* buf, int cap) {
+  PT_REQUIRE(e && buf && cap > 0, "pt_profile_read_labels: bad arguments");
+  PT_HIP_CHECK(hipDeviceSynchronize());
+  struct Row { double ms = 0, flop = 0, bytes = 0; long long n = 0; };
+  std::map<std::string, Row> rows;
+  for (auto& p : e->prof.pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) != hipSuccess) continue;
+    double fl = p.flop;
+    if (p.lim_slot >= 0 && p.rows > 0) {
+      const int lim = e->prof.h_lims[p.lim_slot];
+      fl *= (double)(lim < 0 ? 0 : (lim > p.rows ? p.rows : lim)) / p.rows;
+    }
+    Row& r = rows[p.label];
+    r.ms += ms; r.flop += fl; r.bytes += p.bytes; r.n += 1;
+  }
+  std::string text;
+  char line[160];
+  for (auto& kv : rows) {
+    snprintf(line, sizeof(line), "%s\t%lld\t%.6f\t%.6e\t%.6e\n", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.flop, kv.second.bytes);
+    text += line;
+  }
+  PT_REQUIRE((int)text.size() + 1 <= cap, "pt_profile_read_labels: %d bytes needed, %d given", (int)text.size() + 1, cap);
+  memcpy(buf, text.c_str(), text.size() + 1);
+  for (auto& p : e->prof.pending) {
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  e->prof.pending.clear();
+  e->prof.n_lims = 0;
+  for (int i = 0; i < PT_PROF_NCLASS; ++i) { e->prof.ms[i] = 0; e->prof.launches[i] = 0; e->prof.flop[i] = 0; }
   return PT_OK;
 }
 

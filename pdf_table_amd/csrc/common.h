@@ -134,11 +134,13 @@ struct PtProfile {
     hipEvent_t a, b;
     int cls;
     double flop;          // algorithmic FLOP of the launch (for a row-limited launch: of its full extent)
+    double bytes = 0;     // algorithmic HBM bytes of the launch (inputs once + outputs once + weights), 0 = not stated by the launcher
     int lim_slot = -1;    // >= 0: the launch was row-limited on the device (ConvDesc.ylimit); h_lims[lim_slot] receives the limit
     int rows = 0;         // ... and this is the launch's full extent in output rows: credited flop * min(limit, rows) / rows
     char label[48];
   };
   std::vector<Pending> pending;
+  double next_bytes = 0;  // set by a launcher right before it opens its PtProfScope, which takes (and clears) it
   int* h_lims = nullptr;  // pinned: device row limits copied back behind their launches (only while profiling)
   int n_lims = 0;
   static constexpr int MAX_LIMS = 1 << 16;
@@ -178,6 +180,7 @@ struct pt_engine {
   // valid until the CRNN weights are loaded again
   void* rec_zero[2] = {nullptr, nullptr};
   bool rec_zero_valid[2] = {false, false};
+  hipEvent_t rec_zero_ready[2] = {nullptr, nullptr};         // recorded behind the build of rec_zero[i]: calls on other streams wait for it
   void* rec_limits = nullptr; size_t rec_limits_cap = 0;     // per-line column limits of the call in flight
   int rec_ragged = 1;                                        // PT_REC_RAGGED=0: compute the padding too (A/B switch)
   // cvit_model.hip: host images of the chunk maps of the last 16 micro-batches.  They are the sources of asynchronous
@@ -186,8 +189,6 @@ struct pt_engine {
   std::vector<int> cvit_maps[16][2];
   int cvit_slot = 0;
   PtPinnedRing stage_ring;                                   // pinned sources of small asynchronous uploads (Lore processor token maps, ConvNextViT chunk maps)
-  void* dcn_list = nullptr; size_t dcn_list_cap = 0;         // lore_kernels.hip: two append counters + the tile list dcn_win_kernel hands to dcn_fused64_kernel
-  unsigned dcn_calls = 0;                                    // ... parity of the counter in use
   void* mtl_state = nullptr;                                 // mtl_decoder.hip: buffers + cell lists between pt_tsr_mtl_structure and pt_tsr_mtl_cells
 };
 
@@ -332,7 +333,7 @@ int pt_launch_gemm_argmax_x3(const bf16_t* A, long long M, int K, const bf16_t* 
                              void* scratch, hipStream_t s);
 // tlim != null: rows are (line, t) with T = 160 steps per line; 32-step groups at t0 >= tlim[line] are not computed
 int pt_launch_gemm_rows(const bf16_t* A, long long M, int K, const bf16_t* W, const float* bias, int N, bf16_t* out, int relu,
-                        hipStream_t s, const int* tlim = nullptr);
+                        hipStream_t s, const int* tlim = nullptr, const bf16_t* res = nullptr, int resH = 0, int resW = 0);
 int pt_launch_argmax_reduce(const float* part, long long rows, int ntiles, int* ids, float* maxv, hipStream_t s);
 // d_lines != null: the lines' crop sizes are known, so the conv stack does no work on the zero padding right of the text
 // (bit-identical results: skipped columns are filled with what an all-padding line has there)
@@ -404,8 +405,11 @@ struct PtProfScope {
   hipStream_t s;
   int idx = -1;
   PtProfScope(pt_engine* e_, hipStream_t s_, int cls, double flop, const char* label = "") : e(e_), s(s_) {
+    double bytes = 0;
+    if (e) { bytes = e->prof.next_bytes; e->prof.next_bytes = 0; }
     if (e && e->prof.on && (e->prof.on == 1 || e->prof.on - 2 == cls)) {
       PtProfile::Pending p;
+      p.bytes = bytes;
       if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
       p.cls = cls;
       p.flop = flop;

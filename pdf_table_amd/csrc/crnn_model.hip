@@ -229,6 +229,11 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
                      z + ZeroLine::P2 * m, z + ZeroLine::C3A * m, nullptr, z + ZeroLine::P3 * m, z + ZeroLine::F * m,
                      z + ZeroLine::GX * m, nullptr, nullptr));
       e->rec_zero_valid[x3] = true;
+      // later calls may run on ANOTHER stream (the pipeline's overlap recogniser): they wait for this build through the event
+      if (!e->rec_zero_ready[x3]) PT_HIP_CHECK(hipEventCreateWithFlags(&e->rec_zero_ready[x3], hipEventDisableTiming));
+      PT_HIP_CHECK(hipEventRecord(e->rec_zero_ready[x3], s));
+    } else if (e->rec_zero_ready[x3]) {
+      PT_HIP_CHECK(hipStreamWaitEvent(s, e->rec_zero_ready[x3], 0));       // a no-op once the build has completed
     }
     zl = reinterpret_cast<const bf16_t*>(e->rec_zero[x3]);
     const size_t need = ((size_t)6 * n + 8) * sizeof(int);

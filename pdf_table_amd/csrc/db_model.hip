@@ -13,6 +13,7 @@
 //   PT_PRECISION_BF16   activations bf16, one MFMA pass                       (throughput mode)
 //   PT_PRECISION_BF16X3 activations (hi, lo) bf16 pairs, K = (x_hi,w_hi)+(x_lo,w_hi)+(x_hi,w_lo): ~2^-16
 //                       relative error per product, fp32 accumulate           (fp32-class parity mode)
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -97,6 +98,14 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
   const int m = x3 ? 2 : 1;  // channel-group multiplier of every activation buffer
   DbWeights w;
   const int f16 = pt_f16x2(e) && it->second.find("bin0.wh") ? 1 : 0;      // blobs packed without the fp16 tiles run as BF16X3
+  if (pt_f16x2(e) && !f16) {
+    static bool said = false;      // once per process: the caller asked for F16X2 and gets BF16X3 numbers and speed
+    if (!said) {
+      said = true;
+      fprintf(stderr, "[pdftable_hip] PT_PRECISION_F16X2 requested but the detector blob has no '.wh' (fp16) tiles: running PT_PRECISION_BF16X3 "
+                      "(pack with x3=True to get them)\n");
+    }
+  }
   int rc = bind(it->second, w, x3 != 0, f16 != 0);
   if (rc != PT_OK) return rc;
 

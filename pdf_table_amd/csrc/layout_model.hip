@@ -81,6 +81,7 @@ struct Ctx {
     const PtTensor* w = get(q + ".wf32");
     const PtTensor* b = get(q + ".b");
     if (go()) {
+      e->prof.next_bytes = 2.0 * (x3 ? 2 : 1) * n * ((double)in.H * in.W + (double)o.H * o.W) * in.C;
       PtProfScope ps(e, s, PT_PROF_OTHER, 0, "layout dwconv");
       const int r = pt_launch_dwconv(in.p, F(w), F(b), o.p, n, in.H, in.W, in.C, k, stride, act, x3, s, nullptr);
       if (r != PT_OK) rc = r;

@@ -483,8 +483,7 @@ template <int NB, int NTHR, int SPLIT = 0>
 __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) void dcn_fused64_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
                                                               const bf16_t* __restrict__ w, const float* __restrict__ bias,
                                                               bf16_t* __restrict__ out, long long npix, int H, int W,
-                                                              int C, int N, int relu, const int* __restrict__ tile_list,
-                                                              const int* __restrict__ tile_count) {
+                                                              int C, int N, int relu) {
 #pragma clang fp contract(fast)
   constexpr int ROW = 144;                      // 64 bf16 + 16 B pad
   constexpr int IT = 1024 / NTHR;               // (pixel, 16-byte piece) items per thread per stage
@@ -509,13 +508,8 @@ __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) voi
   // the workgroup's 128 pixels are an 8-row x 16-column patch of one map: its 9-tap sampling footprint (~10 x 18 lines
   // of 128 B) fits the 32 KB L1, where a 128-pixel row segment (3 x 130 lines) does not and every corner went to L2
   const int tiles_x = (W + 15) >> 4, tiles_y = (H + 7) >> 3;
-  // tile_list != nullptr: this launch only computes the tiles dcn_win_kernel handed back (samples outside its LDS window);
-  // the grid covers every tile, a workgroup beyond the list's length has nothing to do
   int Lb = blockIdx.x;
-  if (tile_list) {
-    if (Lb >= *tile_count) return;
-    Lb = tile_list[Lb];
-  }
+  const int nblk = blockIdx.y;
   const int tx0 = (Lb % tiles_x) * 16;
   Lb /= tiles_x;
   const int ty0 = (Lb % tiles_y) * 8;
@@ -529,7 +523,7 @@ __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) voi
     xq = xq < W ? xq : W - 1;
     return ok;
   };
-  const int n0 = blockIdx.y * NB;
+  const int n0 = nblk * NB;
   const int nss = C >> 6, nst = 9 * nss, nk = 9 * (C >> 5);
   const int cs = SPLIT ? 2 * C : C;             // channels per pixel in memory
   const int piece = tid & 7, prow = tid >> 3;   // items: pixels prow + 32 j, j = 0..3, 16-byte piece `piece`
@@ -713,228 +707,6 @@ __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) voi
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Windowed variant of dcn_fused64_kernel (bf16 mode).  The gather of dcn_fused64_kernel asks the vector cache for 36 corner
-// lines per pixel and 64-channel slice -- 4608 line requests per 128-pixel tile -- although a tile whose offsets are a few
-// pixels long only ever touches the ~300 distinct pixels around it: the cache delivers them at its 64 B/clk, and that rate
-// (with the blend's VALU work behind it) is the kernel's time.  Here the tile's neighbourhood -- the 8 x 16 patch grown by
-// 1 (the 3 x 3 taps) + 1 (the bilinear neighbour) + R pixels on every side -- is staged ONCE per 64-channel slice in LDS
-// (128-byte rows, no padding: the four adjacent pixels a ds_read_b128 lane group touches then fall on disjoint banks), all
-// nine taps gather from it with ds_read_b128 (256 B/clk) and the cache sees 1/12 of the requests.
-//   * A tile with any in-map corner outside its window (|offset| > ~R px) is NOT computed here: the workgroup appends the
-//     tile to `fb_list` and returns; pt_launch_dcn_fused then runs dcn_fused64_kernel over that list (same arithmetic, gathers
-//     from global memory).  Results are therefore identical for every offset field; only the speed depends on it.
-//   * The sampling geometry of tap t+1 is computed by two waves while the workgroup multiplies tap t (a 4 KB double-buffered
-//     table instead of the 36 KB nine-tap table: two workgroups per CU fit the 160 KB LDS).
-//   * K is walked slice-major (for each 64-channel slice: nine taps): the fp32 sums are associated differently from
-//     dcn_fused64_kernel's tap-major walk -- both are "the" bf16-mode result within the operator test's bounds.
-// fb_count: appended-tiles counter of THIS call (zero on entry), zero_count: the counter the NEXT call will use (zeroed here).
-// ---------------------------------------------------------------------------------------------------------------------
-template <int NB, int R>
-__global__ __launch_bounds__(512, 2) void dcn_win_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
-                                                         const bf16_t* __restrict__ w, const float* __restrict__ bias,
-                                                         bf16_t* __restrict__ out, long long npix, int H, int W, int C, int N,
-                                                         int relu, int* __restrict__ fb_list, int* __restrict__ fb_count,
-                                                         int* __restrict__ zero_count) {
-#pragma clang fp contract(fast)
-  constexpr int ROW = 144;                      // operand images: 64 bf16 + 16 B pad
-  constexpr int NTHR = 512, IT = 2, PSTEP = 64;
-  constexpr int WP = NB * 8 / NTHR;             // 16-byte weight pieces per thread per stage
-  constexpr int NT = NB * 8 / NTHR;             // 32-column tiles of the product per wave
-  constexpr int WH = 10 + 2 * R, WW = 18 + 2 * R, WPIX = WH * WW;
-  constexpr int WLOADS = (WPIX * 8 + NTHR - 1) / NTHR;
-  __shared__ __attribute__((aligned(16))) char s_win[WPIX * 128];
-  __shared__ __attribute__((aligned(16))) unsigned s_goff[2][128][4];
-  __shared__ __attribute__((aligned(16))) float s_gwt[2][128][4];
-  __shared__ __attribute__((aligned(16))) char s_ab[128 * ROW + NB * ROW];
-  char* s_a = s_ab;
-  char* s_w = s_ab + 128 * ROW;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lx = lane & 31, q = lane >> 5;
-  const int tiles_x = (W + 15) >> 4, tiles_y = (H + 7) >> 3;
-  int Lb = blockIdx.x;
-  const int tx0 = (Lb % tiles_x) * 16;
-  Lb /= tiles_x;
-  const int ty0 = (Lb % tiles_y) * 8;
-  const long long img0 = (long long)(Lb / tiles_y) * H * W;
-  const int wy0 = ty0 - 1 - R, wx0 = tx0 - 1 - R;      // map position of the window's first pixel (may be negative)
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *zero_count = 0;
-  auto locate = [&](int pl, int& y, int& xq) -> bool {
-    y = ty0 + (pl >> 4);
-    xq = tx0 + (pl & 15);
-    const bool ok = y < H && xq < W;
-    y = y < H ? y : H - 1;
-    xq = xq < W ? xq : W - 1;
-    return ok;
-  };
-  // ---- pass 1: does every sample of this tile stay inside the window? ----
-  int bad = 0;
-  for (int i = tid; i < 128 * 9; i += NTHR) {
-    const int pl = i / 9, tap = i - pl * 9;
-    int yh, xw;
-    locate(pl, yh, xw);
-    const float* o = om + (img0 + (long long)yh * W + xw) * 32;
-    const float h_im = (float)(yh - 1 + tap / 3) + o[2 * tap];
-    const float w_im = (float)(xw - 1 + tap % 3) + o[2 * tap + 1];
-    if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
-      const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-      const int ha = h_low < 0 ? 0 : h_low, hb = h_low + 1 > H - 1 ? H - 1 : h_low + 1;     // rows of the in-map corners
-      const int wa = w_low < 0 ? 0 : w_low, wb = w_low + 1 > W - 1 ? W - 1 : w_low + 1;
-      if (ha < wy0 || hb > wy0 + WH - 1 || wa < wx0 || wb > wx0 + WW - 1) bad = 1;
-    }
-  }
-  if (__syncthreads_or(bad)) {
-    if (tid == 0 && blockIdx.y == 0) fb_list[atomicAdd(fb_count, 1)] = blockIdx.x;
-    return;
-  }
-  const int n0 = blockIdx.y * NB;
-  const int nss = C >> 6, nst = 9 * nss, nk = 9 * (C >> 5);
-  const int piece = tid & 7, prow = tid >> 3;
-  const char* xmap = reinterpret_cast<const char*>(x + (size_t)img0 * C);
-  const bf16_t* wbase = w + (size_t)(n0 >> 6) * nk * (64 * 32);
-
-  // sampling geometry of one tap for the tile's 128 pixels (threads 0..127): window byte offsets of the four corners, bilinear x mask weights;
-  // a corner outside the map carries weight zero and points at the window's first pixel
-  auto geometry = [&](int tap, int buf) {
-    if (tid >= 128) return;
-    int yh, xw;
-    locate(tid, yh, xw);
-    const float* o = om + (img0 + (long long)yh * W + xw) * 32;
-    const float off_h = o[2 * tap], off_w = o[2 * tap + 1];
-    const float gm = 1.f / (1.f + expf(-o[18 + tap]));
-    const float h_im = (float)(yh - 1 + tap / 3) + off_h;
-    const float w_im = (float)(xw - 1 + tap % 3) + off_w;
-    unsigned co[4] = {0u, 0u, 0u, 0u};
-    float cw[4] = {0.f, 0.f, 0.f, 0.f};
-    if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
-      const float hf = floorf(h_im), wf = floorf(w_im);
-      const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
-      const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-      const int r0 = (h_low - wy0) * WW, r1 = (h_high - wy0) * WW, c0 = w_low - wx0, c1 = w_high - wx0;
-      if (h_low >= 0 && w_low >= 0) { co[0] = (unsigned)(r0 + c0) * 128u; cw[0] = hh * hw * gm; }
-      if (h_low >= 0 && w_high <= W - 1) { co[1] = (unsigned)(r0 + c1) * 128u; cw[1] = hh * lw * gm; }
-      if (h_high <= H - 1 && w_low >= 0) { co[2] = (unsigned)(r1 + c0) * 128u; cw[2] = lh * hw * gm; }
-      if (h_high <= H - 1 && w_high <= W - 1) { co[3] = (unsigned)(r1 + c1) * 128u; cw[3] = lh * lw * gm; }
-    }
-    *reinterpret_cast<uint4*>(s_goff[buf][tid]) = make_uint4(co[0], co[1], co[2], co[3]);
-    *reinterpret_cast<float4*>(s_gwt[buf][tid]) = make_float4(cw[0], cw[1], cw[2], cw[3]);
-  };
-  // the window of one 64-channel slice: map pixel (wy0 + wy, wx0 + wx) clamped into the map (a clamped pixel is only ever
-  // referenced with weight zero), eight 16-byte pieces per pixel
-  auto load_window = [&](int ss) {
-    u32x4 v[WLOADS];
-#pragma unroll
-    for (int j = 0; j < WLOADS; ++j) {
-      const int i = tid + j * NTHR;
-      const int wp = i >> 3, pc = i & 7;
-      int gy = wy0 + wp / WW, gx = wx0 + wp % WW;
-      gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
-      gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
-      if (i < WPIX * 8) v[j] = *reinterpret_cast<const u32x4*>(xmap + ((size_t)(gy * W + gx) * C + ss * 64 + pc * 8) * 2);
-    }
-#pragma unroll
-    for (int j = 0; j < WLOADS; ++j) {
-      const int i = tid + j * NTHR;
-      if (i < WPIX * 8) *reinterpret_cast<u32x4*>(s_win + i * 16) = v[j];
-    }
-  };
-
-  df32x16 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  u32x4 rw[WP];
-  auto prefetch_w = [&](int st) {
-    const int ss = st / 9, tap = st - ss * 9;
-    const int kc = tap * (C >> 5) + 2 * ss;
-#pragma unroll
-    for (int j = 0; j < WP; ++j) {
-      const int idx = tid + j * NTHR;           // row = idx >> 3, piece = idx & 7 (0..3: chunk kc, 4..7: chunk kc + 1)
-      const int row = idx >> 3, pc = idx & 7;
-      rw[j] = *reinterpret_cast<const u32x4*>(wbase + (size_t)(row >> 6) * nk * (64 * 32) + (size_t)(kc + (pc >> 2)) * (64 * 32) +
-                                              (row & 63) * 32 + (pc & 3) * 8);
-    }
-  };
-  auto commit = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < IT; ++j) {
-      const int pl = prow + PSTEP * j;
-      const uint4 o = *reinterpret_cast<const uint4*>(s_goff[buf][pl]);
-      const float4 wv = *reinterpret_cast<const float4*>(s_gwt[buf][pl]);
-      const char* wb = s_win + piece * 16;
-      const u32x4 r0 = *reinterpret_cast<const u32x4*>(wb + o.x), r1 = *reinterpret_cast<const u32x4*>(wb + o.y),
-                  r2 = *reinterpret_cast<const u32x4*>(wb + o.z), r3 = *reinterpret_cast<const u32x4*>(wb + o.w);
-      const df2 w0 = {wv.x, wv.x}, w1 = {wv.y, wv.y}, w2 = {wv.z, wv.z}, w3 = {wv.w, wv.w};
-      uint32_t ob[4];
-#pragma unroll
-      for (int e2 = 0; e2 < 4; ++e2) {
-        const uint32_t u0 = e2 == 0 ? r0.x : e2 == 1 ? r0.y : e2 == 2 ? r0.z : r0.w;
-        const uint32_t u1 = e2 == 0 ? r1.x : e2 == 1 ? r1.y : e2 == 2 ? r1.z : r1.w;
-        const uint32_t u2 = e2 == 0 ? r2.x : e2 == 1 ? r2.y : e2 == 2 ? r2.z : r2.w;
-        const uint32_t u3 = e2 == 0 ? r3.x : e2 == 1 ? r3.y : e2 == 2 ? r3.z : r3.w;
-        df2 v = w0 * df2{__uint_as_float(u0 << 16), __uint_as_float(u0 & 0xFFFF0000u)};
-        v = w1 * df2{__uint_as_float(u1 << 16), __uint_as_float(u1 & 0xFFFF0000u)} + v;
-        v = w2 * df2{__uint_as_float(u2 << 16), __uint_as_float(u2 & 0xFFFF0000u)} + v;
-        v = w3 * df2{__uint_as_float(u3 << 16), __uint_as_float(u3 & 0xFFFF0000u)} + v;
-        ob[e2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, db2));
-      }
-      *reinterpret_cast<u32x4*>(s_a + pl * ROW + piece * 16) = u32x4{ob[0], ob[1], ob[2], ob[3]};
-    }
-#pragma unroll
-    for (int j = 0; j < WP; ++j) {
-      const int idx = tid + j * NTHR;
-      *reinterpret_cast<u32x4*>(s_w + (idx >> 3) * ROW + (idx & 7) * 16) = rw[j];
-    }
-  };
-
-  const int mt = wave & 3, ct0 = (wave >> 2) * NT;
-  const char* a_rd = s_a + (mt * 32 + lx) * ROW + q * 16;
-  const char* b_rd = s_w + (ct0 * 32 + lx) * ROW + q * 16;
-  prefetch_w(0);
-  load_window(0);
-  geometry(0, 0);
-  __syncthreads();
-  for (int st = 0; st < nst; ++st) {
-    const int ss = st / 9, tap = st - ss * 9;
-    commit(tap & 1);
-    __syncthreads();             // operand images complete; every read of the window and of table[tap & 1] for this stage is done
-    if (st + 1 < nst) {
-      prefetch_w(st + 1);
-      if (tap == 8) load_window(ss + 1);       // the next slice's neighbourhood replaces this one's
-      geometry(tap == 8 ? 0 : tap + 1, tap == 8 ? 0 : (tap + 1) & 1);
-    }
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const dbf16x8 a = *reinterpret_cast<const dbf16x8*>(a_rd + kk * 32);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const dbf16x8 b = *reinterpret_cast<const dbf16x8*>(b_rd + t * 32 * ROW + kk * 32);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc[t], 0, 0, 0);   // D = [channel][pixel]
-      }
-    }
-    __syncthreads();             // operand images free again; table / window of the next stage complete
-  }
-  int y, xq;
-  if (locate(mt * 32 + lx, y, xq)) {
-    bf16_t* op = out + (size_t)(img0 + (long long)y * W + xq) * N + n0 + ct0 * 32;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int ch = t * 32 + 8 * rg + 4 * q;
-        const float4 bs = *reinterpret_cast<const float4*>(bias + n0 + ct0 * 32 + ch);
-        float v[4] = {acc[t][rg * 4 + 0] + bs.x, acc[t][rg * 4 + 1] + bs.y, acc[t][rg * 4 + 2] + bs.z, acc[t][rg * 4 + 3] + bs.w};
-        if (relu) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-        }
-        const uint32_t h0 = f2bf(v[0]), h1 = f2bf(v[1]), h2 = f2bf(v[2]), h3 = f2bf(v[3]);
-        *reinterpret_cast<uint2*>(op + ch) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
-      }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // 3x3 convolution for 16 input channels (DLA-34 level0: 16 -> 16 at full resolution, level1: 16 -> 32 stride 2,
 // center_net/modeling_centernet.py:295-298,370-380) + folded BN + ReLU.  The general implicit-GEMM kernel would pad these
 // to 32 -> 64 (4-8x the work and twice the bytes at 1024 x 1024); here K = 9 taps x 16 channels = nine MFMA k-steps:
@@ -1094,6 +866,9 @@ int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf
                         int B, int H, int W, int C, int N, int split, int relu, hipStream_t s) {
   PT_REQUIRE(x && om && w && bias && out && C % 32 == 0 && N % 64 == 0, "dcn fused: bad arguments (C=%d N=%d)", C, N);
   PT_REQUIRE((long long)H * W * (split ? 2 * C : C) < (1ll << 31), "dcn fused: image too large for 32-bit offsets");
+  // algorithmic bytes: input map once, offsets / masks once, output once, weights once (the 36 corner lines per pixel are cache traffic)
+  const double dcn_bytes = (double)B * H * W * ((split ? 2.0 : 1.0) * 2.0 * (C + N) + 27 * 4.0) + (double)N * 9 * C * 2.0 * (split ? 3 : 1);
+  e->prof.next_bytes = dcn_bytes;
   // (the hi/lo mode keeps 64-channel blocks: with 128 the corner registers of both halves spill)
   static int x3fast = -1;        // PT_DCN_X3_FAST=0: the hi/lo mode on dcn_fused_kernel<1, 64> (A/B switch)
   if (x3fast < 0) {
@@ -1110,13 +885,13 @@ int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf
     // 110 KB of LDS for both operand planes: one workgroup of eight waves per CU, which the 64-wide hi/lo blocks (92 KB) are too
     const char* nbv = getenv("PT_DCN_NB");
     if (N % 128 == 0 && !(nbv && atoi(nbv) == 64))
-      hipLaunchKernelGGL((dcn_fused64_kernel<128, 512, 1>), dim3(tiles, N / 128), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu, nullptr, nullptr);
+      hipLaunchKernelGGL((dcn_fused64_kernel<128, 512, 1>), dim3(tiles, N / 128), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
     else
-      hipLaunchKernelGGL((dcn_fused64_kernel<64, 512, 1>), dim3(tiles, N / 64), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu, nullptr, nullptr);
+      hipLaunchKernelGGL((dcn_fused64_kernel<64, 512, 1>), dim3(tiles, N / 64), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
     PT_HIP_CHECK(hipGetLastError());
     return PT_OK;
   }
-  if (split) return launch_dcn_fused<1, 64>(e, x, om, w, bias, out, B, H, W, C, N, relu, s);
+  if (split) { e->prof.next_bytes = dcn_bytes; return launch_dcn_fused<1, 64>(e, x, om, w, bias, out, B, H, W, C, N, relu, s); }
   if (C % 64 == 0) {
     const long long npix = (long long)B * H * W;
     char label[48];
@@ -1135,48 +910,13 @@ int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf
       nthr = ev ? atoi(ev) : 512;
     }
     const unsigned tiles = (unsigned)((long long)B * ((H + 7) / 8) * ((W + 15) / 16));
-    // PT_DCN_WIN (default 1): the LDS-window kernel first; the tiles it hands back (a sample outside the window) go through
-    // dcn_fused64_kernel in tile-list mode.  Two alternating counters: call i appends to counter[i & 1] and zeroes the other one
-    // for call i + 1 (all DCN calls of an engine are stream-ordered: they share the TSR arena)
-    static int win = -1;
-    if (win < 0) {
-      const char* ev = getenv("PT_DCN_WIN");
-      win = ev ? atoi(ev) : 1;
-    }
-    if (win) {
-      const size_t need = 256 + (size_t)tiles * sizeof(int);
-      if (need > e->dcn_list_cap) {
-        PT_HIP_CHECK(hipStreamSynchronize(s));
-        if (e->dcn_list) PT_HIP_CHECK(hipFree(e->dcn_list));
-        e->dcn_list = nullptr; e->dcn_list_cap = 0;
-        const size_t cap = need + need / 2;
-        PT_HIP_CHECK(hipMalloc(&e->dcn_list, cap));
-        PT_HIP_CHECK(hipMemsetAsync(e->dcn_list, 0, 256, s));
-        e->dcn_list_cap = cap;
-        e->dcn_calls = 0;
-      }
-      int* cnt = reinterpret_cast<int*>(e->dcn_list);
-      int* list = cnt + 64;
-      int* mine = cnt + (e->dcn_calls & 1u) * 32;          // 128 bytes apart
-      int* next = cnt + ((e->dcn_calls + 1u) & 1u) * 32;
-      ++e->dcn_calls;
-      if (win == 3) hipLaunchKernelGGL((dcn_win_kernel<64, 3>), dim3(tiles, N / 64), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu, list, mine, next);
-      else hipLaunchKernelGGL((dcn_win_kernel<64, 2>), dim3(tiles, N / 64), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu, list, mine, next);
-      PT_HIP_CHECK(hipGetLastError());
-      if (N % 128 == 0)
-        hipLaunchKernelGGL((dcn_fused64_kernel<128, 256>), dim3(tiles, N / 128), dim3(256), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu, list, mine);
-      else
-        hipLaunchKernelGGL((dcn_fused64_kernel<64, 512>), dim3(tiles, N / 64), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu, list, mine);
-      PT_HIP_CHECK(hipGetLastError());
-      return PT_OK;
-    }
     if (nb128 && N % 128 == 0) {     // 128-wide blocks stay at 4 waves: with 8 they need 136 VGPRs (> 128: spills), measured 1 % slower
 
-      hipLaunchKernelGGL((dcn_fused64_kernel<128, 256>), dim3(tiles, N / 128), dim3(256), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu, nullptr, nullptr);
+      hipLaunchKernelGGL((dcn_fused64_kernel<128, 256>), dim3(tiles, N / 128), dim3(256), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
     } else if (nthr == 512) {
-      hipLaunchKernelGGL((dcn_fused64_kernel<64, 512>), dim3(tiles, N / 64), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu, nullptr, nullptr);
+      hipLaunchKernelGGL((dcn_fused64_kernel<64, 512>), dim3(tiles, N / 64), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
     } else {
-      hipLaunchKernelGGL((dcn_fused64_kernel<64, 256>), dim3(tiles, N / 64), dim3(256), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu, nullptr, nullptr);
+      hipLaunchKernelGGL((dcn_fused64_kernel<64, 256>), dim3(tiles, N / 64), dim3(256), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
     }
     PT_HIP_CHECK(hipGetLastError());
     return PT_OK;

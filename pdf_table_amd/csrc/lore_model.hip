@@ -104,6 +104,7 @@ struct Ctx {
   T maxpool2(const T& x) {
     T o = alloc(x.H / 2, x.W / 2, x.C);
     if (rc == PT_OK && !dry && ok) {
+      e->prof.next_bytes = (double)n * x.H * x.W * x.C * 2.0 * mul * 1.25;
       PtProfScope ps(e, s, PT_PROF_OTHER, 0, "maxpool2x2");
       const int r = pt_launch_maxpool_kxk(x.p, n, x.H, x.W, x.C, 2, 2, 0, x3, o.p, s);
       if (r != PT_OK) rc = r;
@@ -175,6 +176,7 @@ struct Ctx {
       T u = alloc(p.H * f, p.W * f, o_ch);
       const PtTensor* wu = get(q + ".up_" + js + ".wf32");
       if (rc == PT_OK && !dry && ok) {
+        e->prof.next_bytes = (double)n * p.H * p.W * o_ch * 2.0 * mul * (1.0 + 2.0 * f * f);      // in once, skip + out at f x f the pixels
         PtProfScope ps(e, s, PT_PROF_OTHER, 0, "dw convT up + add");
         const int r = pt_launch_dwconvt_up_add(p.p, reinterpret_cast<const float*>(wu->d_ptr), layers[i - 1].p, u.p, n,
                                                p.H, p.W, o_ch, f, x3, s);

@@ -997,6 +997,7 @@ struct Ctx {
 // work buffers of one decoding loop (structure or cells): R rows
 struct Work {
   long long R = 0;
+  long long Rs = 0;      // rows in use this step = stride between the key-split slices of opart / mlpart (<= R)
   bf16_t *xb = nullptr, *qc = nullptr, *att = nullptr, *hb = nullptr;
   float *opart = nullptr, *mlpart = nullptr;
   int4* tiles = nullptr;
@@ -1038,14 +1039,14 @@ void run_layer(Ctx& c, const std::string& q, int slot, float* x, bf16_t* cache, 
     const dim3 grid(W.ntiles, HEADS, W.nsplit), dgrid(W.ntiles, W.nsplit);
     static const bool decode_kernel = !getenv("PT_MTL_CROSS_MFMA");
     if (W.single && S.kv8 && !c.x3) {
-      hipLaunchKernelGGL(mtl_cross_decode8_kernel, dgrid, dim3(512), 0, c.s, W.qc, S.kv8, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.R, W.opart, W.mlpart, W.att);
+      hipLaunchKernelGGL(mtl_cross_decode8_kernel, dgrid, dim3(512), 0, c.s, W.qc, S.kv8, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.Rs, W.opart, W.mlpart, W.att);
     } else if (W.single && decode_kernel) {
-      if (c.x3) hipLaunchKernelGGL(mtl_cross_decode_kernel<1>, dgrid, dim3(512), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.R, W.opart, W.mlpart, W.att);
-      else hipLaunchKernelGGL(mtl_cross_decode_kernel<0>, dgrid, dim3(512), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.R, W.opart, W.mlpart, W.att);
-    } else if (c.x3) hipLaunchKernelGGL(mtl_cross_attn_kernel<1>, grid, dim3(64), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.R, W.opart, W.mlpart, W.att);
-    else hipLaunchKernelGGL(mtl_cross_attn_kernel<0>, grid, dim3(64), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.R, W.opart, W.mlpart, W.att);
+      if (c.x3) hipLaunchKernelGGL(mtl_cross_decode_kernel<1>, dgrid, dim3(512), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.Rs, W.opart, W.mlpart, W.att);
+      else hipLaunchKernelGGL(mtl_cross_decode_kernel<0>, dgrid, dim3(512), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.Rs, W.opart, W.mlpart, W.att);
+    } else if (c.x3) hipLaunchKernelGGL(mtl_cross_attn_kernel<1>, grid, dim3(64), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.Rs, W.opart, W.mlpart, W.att);
+    else hipLaunchKernelGGL(mtl_cross_attn_kernel<0>, grid, dim3(64), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.Rs, W.opart, W.mlpart, W.att);
     if (W.nsplit > 1)
-      hipLaunchKernelGGL(mtl_cross_combine_kernel, dim3(npos * S.M), dim3(512), 0, c.s, W.opart, W.mlpart, W.nsplit, W.R, S.Mp, S.M, W.att, c.x3);
+      hipLaunchKernelGGL(mtl_cross_combine_kernel, dim3(npos * S.M), dim3(512), 0, c.s, W.opart, W.mlpart, W.nsplit, W.Rs, S.Mp, S.M, W.att, c.x3);
   }
   c.gemm(W.att, rows, D, q + ".co", D, 0, nullptr, 0, x, D, x);
   c.ln(x, rows, q + ".ln2", W.xb);
@@ -1201,9 +1202,19 @@ int pt_mtl_structure(pt_engine* e, const float* f3, int n, int hw, float* d_tag_
     L.hb = cv.take((size_t)R * mt.ffp * mul * sizeof(bf16_t));
     L.lg = cv.take((size_t)R * ncls_p * sizeof(float));
     L.bx = cv.take((size_t)R * 8 * sizeof(float));
-    L.nsplit_cap = 16;
-    L.opart = cv.take((size_t)L.nsplit_cap * R * D * sizeof(float));
-    L.mlpart = cv.take((size_t)L.nsplit_cap * R * HEADS * 2 * sizeof(float));
+    // split-key partials: a step with `npos` positions in flight uses nsplit(npos) slices of npos * Mp rows each (stride = the rows in use,
+    // Work::Rs).  pick_split() shrinks as the tile count grows, so the product peaks around 32 positions -- sized for that peak instead of
+    // 16 x T x Mp rows (2.1 GB of fp32 for one 128-table micro-batch in re-decode mode)
+    long long prow = 0;
+    L.nsplit_cap = 1;
+    for (int np_ = 1; np_ <= (all_positions ? T : 1); ++np_) {
+      int kps_ = 0;
+      const int ns_ = pick_split(all_positions ? n * ((np_ + 31) / 32) : n, hw, &kps_);
+      if (ns_ > L.nsplit_cap) L.nsplit_cap = ns_;
+      if ((long long)ns_ * np_ * Mp > prow) prow = (long long)ns_ * np_ * Mp;
+    }
+    L.opart = cv.take((size_t)prow * D * sizeof(float));
+    L.mlpart = cv.take((size_t)prow * HEADS * 2 * sizeof(float));
     L.tiles = cv.take(((size_t)n * ((T + 31) / 32) + 16) * sizeof(int4));
     L.featb = all_positions ? 0 : cv.take((size_t)Fr * D * mul * sizeof(bf16_t));
     L.total = cv.off;
@@ -1272,6 +1283,7 @@ int pt_mtl_structure(pt_engine* e, const float* f3, int n, int hw, float* d_tag_
   while (t <= mt.max_len) {
     const int p0 = redecode ? 0 : t, npos = t - p0 + 1;
     const long long rows = (long long)npos * Mp;
+    W.Rs = rows;
     char* wb = st->work.base;
     float* xs = reinterpret_cast<float*>(wb + L.x[0]);
     float* xc = reinterpret_cast<float*>(wb + L.x[1]);

@@ -772,6 +772,16 @@ class HipEngine:
         """True / 1: HIP events around every launch; 2 + L.PT_PROF_CLASSES.index(name): only that kernel class; False: off"""
         L.check(self.lib.pt_profile_enable(self._h, int(on)), "pt_profile_enable")
 
+    def profile_read_labels(self):
+        """-> {label: {"launches", "ms", "flop", "bytes"}} of the launches recorded since the last read (profile_enable(1))"""
+        buf = C.create_string_buffer(1 << 18)
+        L.check(self.lib.pt_profile_read_labels(self._h, buf, len(buf)), "pt_profile_read_labels")
+        out = {}
+        for ln in buf.value.decode().splitlines():
+            lab, n, ms, fl, by = ln.split("\t")
+            out[lab] = {"launches": int(n), "ms": float(ms), "flop": float(fl), "bytes": float(by)}
+        return out
+
     def profile_read(self):
         ms = (C.c_double * 4)()
         nl = (C.c_longlong * 4)()

@@ -124,6 +124,7 @@ def _proto(lib):
         "pt_op_attention": (i, [vp, vp, i, i, i, i, i, C.c_float, vp, i, vp]),
         "pt_profile_enable": (i, [vp, i]),
         "pt_profile_read": (i, [vp, vp, vp, vp]),
+        "pt_profile_read_labels": (i, [vp, C.c_char_p, i]),
     }
     for name, (res, args) in P.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design

@@ -91,15 +91,19 @@ class OcrRecognitionTask(BaseInferTask):
         texts, scores = [""] * len(crops), [0.0] * len(crops)
         for b in self._pp(list(crops)):
             img = b["image"]                                     # f32 [n, 3, 48, imgW] on the device
+            confs, idss = [], []
             for i in range(img.shape[0]):                        # one line per run: static exports have their batch size baked in
                 x = img[i:i + 1].permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
                 (a,) = self._exec.run_device(x, 3)
                 if not a.seq or a.c != len(self._ctc.character):
                     raise UnsupportedOnnxGraph(f"recogniser output of shape {a.shape()}: [B, T, {len(self._ctc.character)}] (blank + dictionary"
                                                " + space) is expected")
-                p = a.t[0, 0, :, :a.c].float()
-                conf, ids = p.max(-1)
-                (text, sc), = self._ctc.decode_ids(ids.cpu().numpy()[None], conf.cpu().numpy()[None])
+                conf, ids = a.t[0, 0, :, :a.c].float().max(-1)    # fp32 probabilities (the executor keeps a final Softmax in fp32)
+                confs.append(conf)
+                idss.append(ids)
+            # one device -> host copy per mini-batch (all lines of a mini-batch share imgW, hence T)
+            conf_h, ids_h = torch.stack(confs).cpu().numpy(), torch.stack(idss).cpu().numpy()
+            for i, (text, sc) in enumerate(self._ctc.decode_ids(ids_h, conf_h)):
                 k = int(b["indices"][b["batch_beg_img_no"] + i])
                 texts[k], scores[k] = text, float(sc)
         self.last_scores = scores

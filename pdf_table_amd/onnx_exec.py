@@ -493,7 +493,9 @@ class HipGraphExecutor:
                     x = ins[0]
                     if not (x.seq or x.flat) or lay.attrs.get("axis", -1) not in (-1, len(x.shape()) - 1):
                         raise UnsupportedOnnxGraph(f"{lay.name}: Softmax over axis {lay.attrs.get('axis')} of a {x.shape()} tensor (the channel axis of token rows is built)")
-                    y = _Act(self.eng.op_softmax(x.t, x.c), x.c, x.flat, x.seq)
+                    # a Softmax that IS a graph output (the probabilities a CTC decoder / classifier reads) stays fp32 [.., c]: bf16 probabilities have 8
+                    # significant bits, so near-equal classes tie and the arg-max / confidence would differ from onnxruntime's fp32 ones
+                    y = _Act(self.eng.op_softmax(x.t, x.c, f32=lay.outputs[0] in self.outputs), x.c, x.flat, x.seq)
                 else:
                     y = self._post_act(lay, ins[0], lay.attrs["kind"])
             elif op == "resize":

@@ -138,7 +138,6 @@ class RecStage:
         # processor_ocr_recognition.py:131-145 (class 1 has no entry there either)
         first = 2 if chunking else 1
         self.label = {i + first: ch for i, ch in enumerate(vocab)}
-        self._degenerate = {}       # id(pinned ids buffer) -> indices of lines whose crop resizes to width 0 (see start())
 
     def ids(self, pages: torch.Tensor, boxes_per_page: Sequence[np.ndarray]):
         lines = build_lines(boxes_per_page)
@@ -154,6 +153,7 @@ class RecStage:
         on the stream since (a pipelined caller queues the next batch before it collects this one)"""
         ids, lines = self.ids(pages, boxes_per_page)
         host = done = None
+        degenerate = ()
         if len(lines):
             host = torch.empty(ids.shape, dtype=ids.dtype, pin_memory=True)
             host.copy_(ids, non_blocking=True)
@@ -163,19 +163,21 @@ class RecStage:
             # into '' (ocr_system_task.py:275-283); the engine decodes an all-padding line there, so finish() blanks these lines
             bad = (lines["crop_w"].astype(np.int64) * 32 < lines["crop_h"]) | (lines["crop_w"] <= 0) | (lines["crop_h"] <= 0)
             if bad.any():
-                self._degenerate[id(host)] = np.nonzero(bad)[0]
-        return ids, len(lines), [len(b) for b in boxes_per_page], host, done
+                degenerate = np.nonzero(bad)[0]
+        # the blank-out list travels IN the state: a table keyed by id(host) outlived a failed batch (finish() raising before the pop) and could
+        # match a later batch's buffer once CPython reused the id
+        return ids, len(lines), [len(b) for b in boxes_per_page], host, done, degenerate
 
     def finish(self, state) -> List[List[str]]:
         """host half: wait for the ids of that start(), CTC collapse, vocabulary"""
-        ids, nl, per_page, host, done = state
+        ids, nl, per_page, host, done, degenerate = state
         toks = []
         if nl:
             done.synchronize()
             toks = ctc_collapse(host.numpy())
         self.eng.check()          # the batch has executed: surface device-side failures of it
         texts = ["".join(self.label.get(t, "") for t in row) for row in toks]
-        for i in self._degenerate.pop(id(host), ()):
+        for i in degenerate:
             texts[int(i)] = ""
         out, o = [], 0
         for k in per_page:

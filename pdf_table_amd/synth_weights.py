@@ -297,7 +297,7 @@ def mtl_tabnet_backbone_state_dict(seed: int = 0):
 
 
 def mtl_tabnet_decoder_state_dict(seed: int = 0, num_classes: int = 43, num_classes_cell: int = 60, d_model: int = 512, d_ff: int = 2024,
-                                  n_layers: int = 3):
+                                  n_layers: int = 3, table_signal=None):
     """state_dict of ``MtlTabNetDecoder`` (table/mtl_tabnet/master_decoder.py:194-262, configuration of mtl_tabnet_config.py:59-77:
     N = 3, d_model 512, 8 heads, d_ff 2024) without the two ``pe`` buffers (position tables, recomputed).  Oracle golden only."""
     g = _Gen(seed)
@@ -326,7 +326,88 @@ def mtl_tabnet_decoder_state_dict(seed: int = 0, num_classes: int = 43, num_clas
     g.put("embedding.lut.weight", r.standard_normal((num_classes, d_model)) * 0.05)
     g.put("embedding_cell.lut.weight", r.standard_normal((num_classes_cell, d_model)) * 0.05)
     g.linear("cell_input_fc", d_model, 2 * d_model, scale=1.5)
+    if table_signal is not None:
+        _mtl_table_signal(g.sd, d_model, **table_signal)
     return g.sd
+
+
+def mtl_table_signal_from(conv, rows_until: int = 150, cell_text: str = "Varible%"):
+    """the ids ``mtl_tabnet_decoder_state_dict(table_signal=...)`` needs, taken from a label convertor (pdf_table_amd.mtl_stage.MtlTabNetConvertor):
+    one table row is ``<tr> <td></td> <td colspan="2" > </td> <eb></eb> </tr>`` (two cells with content, one empty), rows repeat until the decoded
+    position passes ``rows_until``, then ``</tbody>`` and <EOS>; every content cell reads ``cell_text`` (distinct characters) and <EOS>."""
+    c = conv.char2idx
+    row = [c["<tr>"], c["<td></td>"], c["<td"], c[' colspan="2"'] if ' colspan="2"' in c else c['colspan="2"'], c[">"], c["</td>"], c["<eb></eb>"], c["</tr>"]]
+    assert len(set(cell_text)) == len(cell_text), "the cell chain is first-order: characters must be distinct"
+    return dict(sos=conv.start_idx, eos=conv.end_idx, open_=c["<tbody>"], row=row, close=c["</tbody>"], rows_until=rows_until,
+                sos_cell=conv.start_idx_cell, eos_cell=conv.end_idx_cell, cell=[conv.char2idx_cell[ch] for ch in cell_text])
+
+
+def _mtl_table_signal(sd, d, sos, eos, open_, row, close, rows_until, sos_cell, eos_cell, cell):
+    """Hand-built channels that make the seeded MtlTabNet decoders emit a TABLE instead of noise (the analogue of _db_text_signal for the detector;
+    VERDICT r03: with plain random weights the structure decoder never emits a cell tag, so bench.py's mtl_tabnet leg never ran the cell-content
+    decoder).  A few residual-stream dimensions are reserved: no sub-layer writes to them (the rows of every attention / feed-forward OUTPUT
+    projection and their biases are zeroed there), so they carry ``embedding * sqrt(d) + positional encoding`` unchanged to the final LayerNorm:
+      * one dimension per token of the chain holds a one-hot of the PREVIOUS token (amplitude 64: it dominates the LayerNorm statistics); the
+        classifier row of the token that follows reads it -- a first-order chain <SOS> <tbody> (<tr> ... </tr>)* </tbody> <EOS>;
+      * after ``</tr>`` the choice between another ``<tr>`` and ``</tbody>`` reads the position: dimension 320 carries sin(pos / 316.2) (the model's
+        own positional encoding, monotone up to position 496) and dimension 510 a constant sin(rows_until / 316.2) every chain token embeds;
+        ``</tbody>`` wins once the first exceeds the second -- the LayerNorm's mean and variance cancel in that comparison, so every table closes at
+        the first row boundary past ``rows_until`` whatever its image;
+      * the cell-content decoder gets the same construction (its input projection passes the reserved dimensions of the character embedding
+        through): <SOS> c0 c1 ... <EOS>.
+    Everything else stays the seeded random network: the kernels see the same shapes and value ranges, attention over the source features included."""
+    import math
+    rt = math.sqrt(d)
+    chain = [sos, open_] + list(row) + [close]
+    cchain = [sos_cell] + list(cell)
+    assert len(set(chain)) == len(chain) and len(set(cchain)) == len(cchain)
+    tdim = {t: 384 + 2 * i for i, t in enumerate(chain)}            # even dimensions: the positional encoding there is sin(pos * 1e-3..) ~ 0
+    cdim = {t: 420 + 2 * i for i, t in enumerate(cchain)}
+    D_POS, D_REF = 320, 510
+    reserved = sorted(set(tdim.values()) | set(cdim.values()) | {D_POS, D_REF})
+    assert max(reserved) < d and len(reserved) == len(tdim) + len(cdim) + 2
+    layers = [k[:-len(".self_attn.linears.3.weight")] for k in sd if k.endswith(".self_attn.linears.3.weight")]
+    for p in layers:
+        for name in (".self_attn.linears.3", ".src_attn.linears.3", ".feed_forward.w_2"):
+            sd[p + name + ".weight"][reserved, :] = 0.0
+            sd[p + name + ".bias"][reserved] = 0.0
+    A, B, K = 64.0, 6.0, 4000.0
+    c0 = math.sin(rows_until / 316.2277660168379)                    # 1 / div_term of dimension 320: 10000 ** (320 / 512)
+    emb = sd["embedding.lut.weight"]
+    emb[:, reserved] = 0.0
+    for t in chain:
+        emb[t, tdim[t]] = A / rt
+        emb[t, D_REF] = c0 / rt
+    w, b = sd["cls_fc.weight"], sd["cls_fc.bias"]
+    w *= 0.25                                                        # the random logits stay, well below the chain's
+    w[:, reserved] = 0.0
+    nxt = {sos: open_, open_: row[0], close: eos}
+    for a_, b_ in zip(row[:-1], row[1:]):
+        nxt[a_] = b_
+    for prev, n in nxt.items():
+        w[n, tdim[prev]] += B
+    last = row[-1]
+    w[row[0], tdim[last]] += B                                       # after </tr>: <tr> ...
+    w[close, tdim[last]] += B                                        # ... or </tbody>, decided by the position:
+    g_, be = sd["norm.weight"], sd["norm.bias"]
+    w[close, D_POS] += K / float(g_[D_POS])                          # K * [(h[320] - beta) / gamma - (h[510] - beta') / gamma'] = K * (x[320] - x[510]) / std
+    w[close, D_REF] -= K / float(g_[D_REF])
+    b[close] += -K * float(be[D_POS]) / float(g_[D_POS]) + K * float(be[D_REF]) / float(g_[D_REF])
+    # cell-content decoder
+    cemb = sd["embedding_cell.lut.weight"]
+    cemb[:, reserved] = 0.0
+    for t in cchain:
+        cemb[t, cdim[t]] = A / rt
+    wi, bi = sd["cell_input_fc.weight"], sd["cell_input_fc.bias"]
+    wi[reserved, :] = 0.0
+    bi[reserved] = 0.0
+    for r_ in reserved:
+        wi[r_, r_] = 1.0                                             # from the character-embedding half of cat(embedding, structure state)
+    wc = sd["cell_fc.weight"]
+    wc *= 0.25
+    wc[:, reserved] = 0.0
+    for a_, b_ in zip(cchain, cchain[1:] + [eos_cell]):
+        wc[b_, cdim[a_]] += B
 
 
 # --------------------------------------------------------------------------------------------------------------------

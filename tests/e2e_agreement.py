@@ -6,8 +6,9 @@ tests/test_gpu_e2e.py (both modes) and by bench.py's `tolerance_mode.bf16_e2e_ag
 What is counted, per the reference's three outputs (north_star: text-box polygons, recognised strings, cell-adjacency HTML):
   boxes      oracle text boxes found by the engine: identical int16 quads / within 2 px on every coordinate
   strings    lines cut from a matched quad whose recognised string equals the oracle's (on identical quads; on quads within 2 px)
-  cells      oracle table cells found with >= 3 of 4 vertices within 0.1 px / within 1 px; logical locations equal on the matched ones
-  html       tables whose HTML string equals the one the host code builds from the ORACLE's cells, boxes and strings
+  cells      oracle table cells found with >= 3 of 4 vertices within 0.1 / 1 / 4 / 16 px; logical locations equal on the matched ones
+  html       tables whose HTML string equals the one the host code builds from the ORACLE's cells, boxes and strings (one differing token
+             anywhere in the table breaks it), and tables whose STRUCTURE string (rows, spans; no text) is equal
 """
 import numpy as np
 
@@ -57,9 +58,10 @@ def oracle_strings(g, pi, label):
 def agreement(g, results, label, table_boxes):
     """g: the loaded fixture; results: PageResult list of the fixture's pages (OcrTablePipeline.predict, table_html=True); label: the
     recogniser's id -> char map; table_boxes: per page int [t,4] regions the fixture's tables were cut from.  -> dict of counts and fractions."""
+    from pdf_table_amd.table_html import structure_html
     from pdf_table_amd.table_text_match import page_table_html
     c = dict(boxes=0, boxes_engine=0, boxes_identical=0, boxes_within_2px=0, lines_on_identical_quads=0, strings_identical_on_identical_quads=0,
-             lines_on_2px_quads=0, strings_identical_on_2px_quads=0, cells=0, cells_engine=0, cells_matched_0p1px=0, cells_matched_1px=0,
+             lines_on_2px_quads=0, strings_identical_on_2px_quads=0, chars=0, chars_equal=0, cells=0, cells_engine=0, cells_matched_0p1px=0, cells_matched_1px=0, cells_matched_4px=0, cells_matched_16px=0, tables_structure_identical=0,
              logi_rows_compared=0, logi_rows_equal=0, tables=0, tables_cells_and_logi_identical=0, tables_html_identical=0)
     for pi, r in enumerate(results):
         want = g[f"p{pi}_det_boxes"]
@@ -74,6 +76,10 @@ def agreement(g, results, label, table_boxes):
                               (near, "lines_on_2px_quads", "strings_identical_on_2px_quads")):
             c[kl] += len(pairs)
             c[ks] += sum(1 for i, j in pairs if r.ocr_result[j]["text"] == ref_txt[i])
+        for i, j in near:           # character level: positions that carry the oracle's character (a whole string fails on ONE flipped token)
+            a, b = r.ocr_result[j]["text"], ref_txt[i]
+            c["chars"] += max(len(a), len(b))
+            c["chars_equal"] += sum(1 for x, y in zip(a, b) if x == y)
         tbs = table_boxes[pi]
         tsr = r.table_structure_result or []
         c["tables"] += int(g[f"p{pi}_n_tables"])
@@ -92,6 +98,9 @@ def agreement(g, results, label, table_boxes):
             loose, _ = match_cells(polys, gp, 1.0)
             c["cells_matched_0p1px"] += len(tight)
             c["cells_matched_1px"] += len(loose)
+            c["cells_matched_4px"] += len(match_cells(polys, gp, 4.0)[0])
+            c["cells_matched_16px"] += len(match_cells(polys, gp, 16.0)[0])
+            c["tables_structure_identical"] += int(len(gp) > 0 and structure_html(polys + off, logi) == structure_html(gp + off, gl))
             if loose:
                 wi, gj = np.array([i for i, _ in loose]), np.array([j for _, j in loose])
                 eq = (gl[gj] == logi[wi]).all(1)
@@ -107,7 +116,10 @@ def agreement(g, results, label, table_boxes):
     c["frac"] = {"boxes_identical": fr("boxes_identical", "boxes"), "boxes_within_2px": fr("boxes_within_2px", "boxes"),
                  "strings_identical_on_identical_quads": fr("strings_identical_on_identical_quads", "lines_on_identical_quads"),
                  "strings_identical_on_2px_quads": fr("strings_identical_on_2px_quads", "lines_on_2px_quads"),
+                 "chars_equal_on_2px_quads": fr("chars_equal", "chars"),
                  "cells_matched_0p1px": fr("cells_matched_0p1px", "cells"), "cells_matched_1px": fr("cells_matched_1px", "cells"),
+                 "cells_matched_4px": fr("cells_matched_4px", "cells"), "cells_matched_16px": fr("cells_matched_16px", "cells"),
+                 "tables_structure_identical": fr("tables_structure_identical", "tables"),
                  "logi_rows_equal_on_matched_cells": fr("logi_rows_equal", "logi_rows_compared"),
                  "tables_html_identical": fr("tables_html_identical", "tables")}
     return c

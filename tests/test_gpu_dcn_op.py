@@ -34,8 +34,8 @@ def _bf16(t):
 
 
 def _case(B, C, N, H, W, seed, field="wide", rounded=True):
-    """field "wide": offsets ~ N(0, 3 px) + a 6 % tail of jumps beyond the map (most tiles leave dcn_win_kernel's LDS window and take the
-    tile-list path through dcn_fused64_kernel); "local": offsets ~ N(0, 0.6 px), no tail (every tile stays in the window kernel)."""
+    """field "wide": offsets ~ N(0, 3 px) + a 6 % tail of jumps beyond the map (what the bench's random-init Lore detector produces: |offset|
+    2 .. 9 px on average, up to 40 px); "local": offsets ~ N(0, 0.6 px), no tail (the sub-pixel regime of the parity nets)."""
     sigma = 3.0 if field == "wide" else 0.6
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, C, H, W, generator=g).abs()          # post-ReLU activations, as every DCN input in DLASeg is
