@@ -620,7 +620,7 @@ class HipRunner:
             t0 = time.perf_counter()
             if rec_prev is not None:
                 from pdf_table_amd.rec_stage import ctc_collapse
-                _, nl_, _, ids_h, ids_ev = rec_prev
+                _, nl_, _, ids_h, ids_ev = rec_prev[:5]
                 toks = []
                 if nl_:
                     ids_ev.synchronize()         # the copy of THAT step's ids: never waits for work queued since
@@ -722,7 +722,7 @@ class HipRunner:
                                                                    "inside the timed region (pipeline.py:predict_stream)"}
 
     # (label prefix, class) in match order: every launch label of the four stages falls into one class of roofline.by_class
-    BY_CLASS = (("conv3x3 c16", "thin DLA levels (3x3, 16 channels)"), ("conv3x3", "conv3x3 implicit GEMM"), ("conv1x1", "conv1x1 / row GEMM"),
+    BY_CLASS = (("conv3x3 c16", "thin DLA levels (7x7 stem + two 3x3, 16 channels)"), ("dla thin", "thin DLA levels (7x7 stem + two 3x3, 16 channels)"), ("conv3x3", "conv3x3 implicit GEMM"), ("conv1x1", "conv1x1 / row GEMM"),
                 ("rows gemm", "conv1x1 / row GEMM"), ("classifier", "classifier GEMM + arg-max"), ("cvit", "ConvNextViT"), ("db head", "DB head (2 x convT)"),
                 ("stem", "7x7 / 3x3 stems"), ("lcnet stem", "7x7 / 3x3 stems"), ("dcn", "deformable conv (gather + blend + GEMM)"),
                 ("dw convT", "depthwise convT up-sampler + add"), ("lstm", "BiLSTM recurrences"), ("layout dwconv", "depthwise convs (layout)"),
@@ -779,9 +779,29 @@ class HipRunner:
         the stand-alone `bench.py --stages det` defaults (a 10-step leg read 2-3 % low: one software-pipeline fill + drain in 0.1 s)"""
         dt, c = self.timed(steps, warm, stages=["det"])
         pps = PAGES_PER_STEP * steps / dt
+        # the same leg without the host post-process and its box-score kernel (device half only: pre-process, network, head + bitmap), and the
+        # FLOP the engine EXECUTES per page: the 111.71 GFLOP credit is the reference graph's; the exact out2 / binarize.0 refactorings
+        # (DESIGN.md section 3) run fewer -- both stated so that `frac` can be read either way (VERDICT r03 weak 4)
+        net = None
+        if not self.args.no_post:
+            self.args.no_post = True
+            try:
+                dtn, _ = self.timed(steps, warm, stages=["det"])
+                self.eng.profile_enable(1)
+                self.run(2, stages=["det"])
+                self.sync()
+                lab = self.eng.profile_read_labels()
+                self.eng.profile_enable(False)
+            finally:
+                self.args.no_post = False
+            ppsn = PAGES_PER_STEP * steps / dtn
+            ex = sum(r["flop"] for r in lab.values()) / (2 * PAGES_PER_STEP) / 1e9
+            net = {"pages_per_s": ppsn, "frac": DB_GFLOP_960 * 1e9 * ppsn / (MFMA_PEAK_TFLOPS * 1e12),
+                   "executed_gflop_per_page": ex, "frac_of_executed_flop": ex * 1e9 * ppsn / (MFMA_PEAK_TFLOPS * 1e12),
+                   "note": "device half only (--no-post): no contour / box-score / unclip work beside the network"}
         return {"pages_per_s_det_only": pps, "steps": steps, "boxes_per_page": c["boxes"] / (PAGES_PER_STEP * steps),
                 "gflop_per_page": DB_GFLOP_960, "achieved_tflops": DB_GFLOP_960 * 1e9 * pps / 1e12,
-                "frac": DB_GFLOP_960 * 1e9 * pps / (MFMA_PEAK_TFLOPS * 1e12),
+                "frac": DB_GFLOP_960 * 1e9 * pps / (MFMA_PEAK_TFLOPS * 1e12), "net_only": net,
                 "definition": "BASELINE.md section 5: 111.71e9 x det-only pages/s / 2.5e15 (960x960 graph, whole det stage "
                               "incl. pre-process, bitmap and the overlapped host post-process in the time)"}
 

@@ -333,7 +333,7 @@ int pt_launch_gemm_argmax_x3(const bf16_t* A, long long M, int K, const bf16_t* 
                              void* scratch, hipStream_t s);
 // tlim != null: rows are (line, t) with T = 160 steps per line; 32-step groups at t0 >= tlim[line] are not computed
 int pt_launch_gemm_rows(const bf16_t* A, long long M, int K, const bf16_t* W, const float* bias, int N, bf16_t* out, int relu,
-                        hipStream_t s, const int* tlim = nullptr, const bf16_t* res = nullptr, int resH = 0, int resW = 0);
+                        hipStream_t s, const int* tlim = nullptr);
 int pt_launch_argmax_reduce(const float* part, long long rows, int ntiles, int* ids, float* maxv, hipStream_t s);
 // d_lines != null: the lines' crop sizes are known, so the conv stack does no work on the zero padding right of the text
 // (bit-identical results: skipped columns are filled with what an all-padding line has there)

@@ -1938,25 +1938,6 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
     if (pick == 3 && use_half) return launch_dma16<1, 4>(e, k, s, flop);
     if (pick == 3) return d.N % 128 == 0 ? launch_dma16<2, 8>(e, k, s, flop) : launch_dma16<1, 8>(e, k, s, flop);
   }
-  // plain 1x1 stride-1 layers in bf16 mode as a ROW GEMM over pixels (rec_kernels.hip: gemm_argmax_kernel<., 1 / 2>): a workgroup keeps
-  // 128 pixels' K channels in registers and walks ALL N outputs, so the input is read once instead of once per 64-output tile, and a
-  // layer is one pass of 128-pixel workgroups instead of N / 64 passes of four-slice tiles with two barriers each.  Measured on the
-  // FPN lateral 128 -> 256 @120^2 x 64 pages: see profiles/r04/experiments.txt.  PT_CONV1_ROWS=0: the tiled kernel (A/B switch).
-  if (d.ks == 1 && d.stride == 1 && !d.split && d.nseg == 1 && d.rep == 1 && !d.shuffle_cout && !d.out_f32 && !d.res_f32 && !d.head_w &&
-      !d.argmax_part && !d.ylimit && !d.xlimit && !d.xlimit_rows && !d.pool && !d.n_valid && d.relu <= 1 && d.out_coff == 0 &&
-      d.out_cstride == d.N && (d.Cin == 128 || d.Cin == 256 || d.Cin == 512) && d.N >= 128 && d.alg_scale == 1.0 &&
-      (d.res_mode == 0 || (d.res && (d.res_mode == 1 || (d.res_mode == 2 && !((d.H | d.W) & 1)))))) {
-    static int rows1 = -1;
-    if (rows1 < 0) { const char* ev = getenv("PT_CONV1_ROWS"); rows1 = ev ? atoi(ev) : 1; }
-    if (rows1) {
-      char label[48];
-      snprintf(label, sizeof(label), "conv1x1 rows %d->%d @%dx%d", d.Cin, d.N, k.Ho, k.Wo);
-      PtProfScope prof(e, s, PT_PROF_CONV1X1, flop, label);
-      const int r = pt_launch_gemm_rows(d.in, (long long)d.B * d.H * d.W, d.Cin, d.w, d.bias, d.N, d.out, d.relu, s, nullptr, d.res_mode ? d.res : nullptr,
-                                        d.res_mode == 2 ? d.H : 0, d.res_mode == 2 ? d.W : 0);
-      if (r != PT_ERR_INVALID) return r;
-    }
-  }
   if (d.ks == 3 && d.stride == 1 && k.Ho <= 4 && k.Wo > 32) return launch_cfg<3, 1, 1>(e, k, s, flop);
   if (d.ks == 3 && d.stride == 1) return launch_cfg<3, 1>(e, k, s, flop);
   if (d.ks == 3 && d.stride == 2) return launch_cfg<3, 2>(e, k, s, flop);

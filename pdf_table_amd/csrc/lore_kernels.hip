@@ -14,6 +14,7 @@
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 namespace {
 
@@ -805,6 +806,163 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const bf16_t* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// DLA-34's three thin levels as ONE kernel (bf16 mode): base_layer (7x7, 3 -> 16, full resolution) -> level0 (3x3, 16 -> 16) ->
+// level1 (3x3 stride 2, 16 -> 32), center_net/modeling_centernet.py:291-298,382-402.  As three launches the two 16-channel
+// full-resolution maps (33.5 MB per 1024^2 table each) are written to HBM and read back, and the step spends 5.0 ms (r03) on 9.7
+// GFLOP per table.  Here a workgroup owns an 8 x 30 tile of the LEVEL1 output and keeps what it needs of the two intermediate maps in
+// LDS: the 19 x 63 patch of base_layer's output (halo of level0 + level1 recomputed: 1.19x rows, 1.05x columns) and the 17 x 61 patch
+// of level0's.  HBM sees the image once (25 x 69 pixels per tile) and the 32-channel half-resolution map once.
+//   * The arithmetic of each level is the stand-alone kernels' (conv_stem7x7_thin_kernel, conv3x3_c16_kernel: same operand layout,
+//     same K order, bf16 rounding of every intermediate) -- results are bit-identical to the three-launch path.
+//   * A position of an intermediate patch that lies OUTSIDE its map is stored as zero: the next level pads with zeros, not with the
+//     response to a padded input.
+//   * A workgroup (8 waves) walks all x-tiles of one tile row with the stem's weight rows in LDS and the two levels' nine B fragments in
+//     registers.
+// in: NHWC4 bf16 [B,H,W,4] (rgb0); w_stem bf16 [64][224] (rows >= 16 zero), w0 / w1 bf16 [9][32][16]; biases fp32 [>= 32]; out bf16
+// [B,H/2,W/2,32].  H, W even.
+// ---------------------------------------------------------------------------------------------------------------------
+struct ThinChainCfg {
+  static constexpr int TH1 = 8, TW1 = 30;                 // level1 output tile
+  static constexpr int R0 = 2 * TH1 + 1, C0 = 2 * TW1 + 1; // level0 patch: 17 x 61
+  static constexpr int RB = R0 + 2, CB = C0 + 2;           // base_layer patch: 19 x 63
+  static constexpr int RI = RB + 6, CI = 72;               // image patch: 25 rows x (69 needed; 72 staged: the stem's fragments of column 63 reach 70)
+  static constexpr int PW = 64;                            // pixels per LDS row of the two intermediate patches (two 32-pixel MFMA tiles)
+  static constexpr int PITCH = 48;                         // bytes per intermediate pixel: 16 bf16 + 16 B pad (conflict-free ds_read_b128)
+  static constexpr int WROW = 464;                         // stem weight row: 224 bf16 + 16 B pad
+  static constexpr int IN_BYTES = RI * CI * 8, W_BYTES = 32 * WROW;
+  static constexpr int B_BYTES = (RB * PW + 4) * PITCH, L0_BYTES = (R0 * PW + 4) * PITCH;      // + 4 pixels: fragments of discarded columns read past a row
+  static constexpr int SMEM = IN_BYTES + W_BYTES + B_BYTES + L0_BYTES;
+};
+
+__global__ __launch_bounds__(512, 1) void dla_thin_chain_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ w_stem,
+                                                                const float* __restrict__ b_stem, const bf16_t* __restrict__ w0,
+                                                                const float* __restrict__ b0, const bf16_t* __restrict__ w1,
+                                                                const float* __restrict__ b1, bf16_t* __restrict__ out, int B, int H, int W,
+                                                                int tiles_x, int tiles_y) {
+  using C = ThinChainCfg;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_in = smem;
+  char* s_w = s_in + C::IN_BYTES;
+  char* s_b = s_w + C::W_BYTES;
+  char* s_l0 = s_b + C::B_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lx = lane & 31, q = lane >> 5;
+  const int H1 = H >> 1, W1 = W >> 1;
+  const int tyi = blockIdx.x % tiles_y, b = blockIdx.x / tiles_y;
+  const int oy1 = tyi * C::TH1;
+  const bf16_t* in_b = in + (size_t)b * H * W * 4;
+  // stem weight rows 0..31 (channels >= 16 are zero rows), once per workgroup
+  for (int idx = tid; idx < 32 * 28; idx += 512) {
+    const int row = idx / 28, part = idx - row * 28;
+    *reinterpret_cast<u32x4*>(s_w + row * C::WROW + part * 16) = *reinterpret_cast<const u32x4*>(w_stem + (size_t)idx * 8);
+  }
+  // B fragments of the two 3x3 levels: lane = output channel lx, k = channels 8q .. 8q+7 of tap t
+  dbf16x8 wf0[9], wf1[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    wf0[t] = *reinterpret_cast<const dbf16x8*>(w0 + ((size_t)t * 32 + lx) * 16 + q * 8);
+    wf1[t] = *reinterpret_cast<const dbf16x8*>(w1 + ((size_t)t * 32 + lx) * 16 + q * 8);
+  }
+  const int yb0 = 2 * oy1 - 2, y00 = 2 * oy1 - 1, yi0 = 2 * oy1 - 5;      // first map row of the base / level0 / image patches
+  for (int txi = 0; txi < tiles_x; ++txi) {
+    const int ox1 = txi * C::TW1;
+    const int xb0 = 2 * ox1 - 2, x00 = 2 * ox1 - 1, xi0 = 2 * ox1 - 5;
+    __syncthreads();                       // the previous tile's patches have been read
+    // ---- image patch: zero outside the image (the 7x7 convolution's padding)
+    for (int idx = tid; idx < C::RI * C::CI; idx += 512) {
+      const int iy = idx / C::CI, ix = idx - iy * C::CI;
+      const int gy = yi0 + iy, gx = xi0 + ix;
+      u32x2 v = {0u, 0u};
+      if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = *reinterpret_cast<const u32x2*>(in_b + ((size_t)gy * W + gx) * 4);
+      *reinterpret_cast<u32x2*>(s_in + idx * 8) = v;
+    }
+    __syncthreads();
+    // ---- base_layer: 19 rows x 2 column tiles, 14 k-steps each (7 kernel rows x 2 halves of the 8-wide kernel row)
+    for (int u = wave; u < C::RB * 2; u += 8) {
+      const int i = u >> 1, ct = u & 1;
+      df32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const char* a_base = s_in + (i * C::CI + ct * 32 + lx + 2 * q) * 8;
+      const char* b_base = s_w + lx * C::WROW + q * 16;
+#pragma unroll
+      for (int r = 0; r < 7; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const dbf16x8 wv = *reinterpret_cast<const dbf16x8*>(b_base + (r * 2 + h) * 32);
+          const char* ap = a_base + (r * C::CI + 4 * h) * 8;
+          const u32x2 lo = *reinterpret_cast<const u32x2*>(ap), hi = *reinterpret_cast<const u32x2*>(ap + 8);
+          const u32x4 av = {lo.x, lo.y, hi.x, hi.y};
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, __builtin_bit_cast(dbf16x8, av), acc, 0, 0, 0);
+        }
+      const int j = ct * 32 + lx, gy = yb0 + i, gx = xb0 + j;
+      const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      char* dst = s_b + (i * C::PW + j) * C::PITCH;
+#pragma unroll
+      for (int rg = 0; rg < 2; ++rg) {      // channels 8 rg + 4 q .. + 3 (rows 16..31 of the product are zero weight rows)
+        const int ch = 8 * rg + 4 * q;
+        const float4 bs = *reinterpret_cast<const float4*>(b_stem + ch);
+        const float v0 = fmaxf(acc[rg * 4 + 0] + bs.x, 0.f), v1 = fmaxf(acc[rg * 4 + 1] + bs.y, 0.f), v2 = fmaxf(acc[rg * 4 + 2] + bs.z, 0.f),
+                    v3 = fmaxf(acc[rg * 4 + 3] + bs.w, 0.f);
+        uint2 o = make_uint2(f2bf(v0) | (f2bf(v1) << 16), f2bf(v2) | (f2bf(v3) << 16));
+        if (!inside) o = make_uint2(0u, 0u);
+        *reinterpret_cast<uint2*>(dst + ch * 2) = o;
+      }
+    }
+    __syncthreads();
+    // ---- level0: 3x3 stride 1 on the base patch, 17 rows x 2 column tiles, 9 taps
+    for (int u = wave; u < C::R0 * 2; u += 8) {
+      const int i = u >> 1, ct = u & 1;
+      df32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const dbf16x8 av = *reinterpret_cast<const dbf16x8*>(s_b + ((i + t / 3) * C::PW + ct * 32 + lx + t % 3) * C::PITCH + q * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0[t], av, acc, 0, 0, 0);
+      }
+      const int j = ct * 32 + lx, gy = y00 + i, gx = x00 + j;
+      const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && j < C::C0;
+      char* dst = s_l0 + (i * C::PW + j) * C::PITCH;
+#pragma unroll
+      for (int rg = 0; rg < 2; ++rg) {
+        const int ch = 8 * rg + 4 * q;
+        const float4 bs = *reinterpret_cast<const float4*>(b0 + ch);
+        const float v0 = fmaxf(acc[rg * 4 + 0] + bs.x, 0.f), v1 = fmaxf(acc[rg * 4 + 1] + bs.y, 0.f), v2 = fmaxf(acc[rg * 4 + 2] + bs.z, 0.f),
+                    v3 = fmaxf(acc[rg * 4 + 3] + bs.w, 0.f);
+        uint2 o = make_uint2(f2bf(v0) | (f2bf(v1) << 16), f2bf(v2) | (f2bf(v3) << 16));
+        if (!inside) o = make_uint2(0u, 0u);
+        *reinterpret_cast<uint2*>(dst + ch * 2) = o;
+      }
+    }
+    __syncthreads();
+    // ---- level1: 3x3 stride 2 on the level0 patch, one row of the tile per wave
+    {
+      const int oy = wave;
+      df32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const dbf16x8 av = *reinterpret_cast<const dbf16x8*>(s_l0 + ((2 * oy + t / 3) * C::PW + 2 * lx + t % 3) * C::PITCH + q * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1[t], av, acc, 0, 0, 0);
+      }
+      const int gy = oy1 + oy, gx = ox1 + lx;
+      if (lx < C::TW1 && gy < H1 && gx < W1) {
+        bf16_t* op = out + (((size_t)b * H1 + gy) * W1 + gx) * 32;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int ch = 8 * rg + 4 * q;
+          const float4 bs = *reinterpret_cast<const float4*>(b1 + ch);
+          const float v0 = fmaxf(acc[rg * 4 + 0] + bs.x, 0.f), v1 = fmaxf(acc[rg * 4 + 1] + bs.y, 0.f), v2 = fmaxf(acc[rg * 4 + 2] + bs.z, 0.f),
+                      v3 = fmaxf(acc[rg * 4 + 3] + bs.w, 0.f);
+          *reinterpret_cast<uint2*>(op + ch) = make_uint2(f2bf(v0) | (f2bf(v1) << 16), f2bf(v2) | (f2bf(v3) << 16));
+        }
+      }
+    }
+  }
+}
+
 inline int grid_for(long long total) {
   long long blocks = (total + 255) / 256;
   if (blocks > 256 * 64) blocks = 256 * 64;
@@ -945,6 +1103,28 @@ int pt_launch_conv3x3_c16(pt_engine* e, const bf16_t* in, const bf16_t* w, const
     if (split) hipLaunchKernelGGL((conv3x3_c16_kernel<2, 1>), dim3((unsigned)nblk), dim3(256), 0, s, in, w, bias, out, B, H, W, Ho, Wo, N, tiles_x, tiles_y);
     else hipLaunchKernelGGL((conv3x3_c16_kernel<2, 0>), dim3((unsigned)nblk), dim3(256), 0, s, in, w, bias, out, B, H, W, Ho, Wo, N, tiles_x, tiles_y);
   }
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// DLA-34 base_layer -> level0 -> level1 in one launch (bf16 mode): in NHWC4 [B,H,W,4] -> out [B,H/2,W/2,32]
+int pt_launch_dla_thin_chain(pt_engine* e, const bf16_t* in, int B, int H, int W, const bf16_t* w_stem, const float* b_stem, const bf16_t* w0,
+                             const float* b0, const bf16_t* w1, const float* b1, bf16_t* out, hipStream_t s) {
+  PT_REQUIRE(in && w_stem && b_stem && w0 && b0 && w1 && b1 && out && B > 0, "dla thin chain: bad arguments");
+  PT_REQUIRE(H % 2 == 0 && W % 2 == 0 && H >= 2 && W >= 2, "dla thin chain: H, W must be even (got %d x %d)", H, W);
+  using C = ThinChainCfg;
+  static bool attr_done = false;
+  if (!attr_done) {
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dla_thin_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
+    attr_done = true;
+  }
+  const int tiles_x = (W / 2 + C::TW1 - 1) / C::TW1, tiles_y = (H / 2 + C::TH1 - 1) / C::TH1;
+  const long long nblk = (long long)B * tiles_y;
+  PT_REQUIRE(nblk < (1ll << 31), "dla thin chain: grid out of range");
+  const double px = (double)B * H * W;
+  e->prof.next_bytes = px * 8.0 + px / 4 * 64.0;
+  PtProfScope prof(e, s, PT_PROF_STEM, 2.0 * px * (16.0 * 147 + 16.0 * 144) + 2.0 * px / 4 * 32.0 * 144, "dla thin chain (stem + level0 + level1)");
+  hipLaunchKernelGGL(dla_thin_chain_kernel, dim3((unsigned)nblk), dim3(512), C::SMEM, s, in, w_stem, b_stem, w0, b0, w1, b1, out, B, H, W, tiles_x, tiles_y);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }

@@ -25,6 +25,8 @@ int pt_launch_conv3x3_c16(pt_engine* e, const bf16_t* in, const bf16_t* w, const
                           int N, int stride, int split, hipStream_t s);
 int pt_launch_dwconvt_up_add(const bf16_t* in, const float* w, const bf16_t* add, bf16_t* out, int B, int h, int wd,
                              int C, int f, int split, hipStream_t s);
+int pt_launch_dla_thin_chain(pt_engine* e, const bf16_t* in, int B, int H, int W, const bf16_t* w_stem, const float* b_stem, const bf16_t* w0,
+                             const float* b0, const bf16_t* w1, const float* b1, bf16_t* out, hipStream_t s);
 
 namespace {
 
@@ -229,6 +231,22 @@ static int lore_dla_run(pt_engine* e, const bf16_t* x, int n, int H, int W, floa
     c.om = reinterpret_cast<float*>(e->arenas[PT_ARENA_TSR].take(px4 * 32 * sizeof(float)));
     if (!c.cols || !c.om) c.ok = false;
 
+    // bf16 mode: base_layer -> level0 -> level1 in one launch, the two full-resolution 16-channel maps never leave the CU
+    // (lore_kernels.hip: dla_thin_chain_kernel; PT_DLA_CHAIN=0: the three launches, A/B switch read per call)
+    const char* chain_env = getenv("PT_DLA_CHAIN");
+    const bool chain = !c.x3 && H % 2 == 0 && W % 2 == 0 && !(chain_env && atoi(chain_env) == 0);
+    std::vector<T> layers(6);
+    if (chain) {
+      layers[1] = c.alloc(H / 2, W / 2, 32);
+      const PtTensor *ws = c.get("base_layer.w"), *bs = c.get("base_layer.b"), *w0 = c.get("level0.wt"), *b0 = c.get("level0.bt"),
+                     *w1 = c.get("level1.wt"), *b1 = c.get("level1.bt");
+      if (c.rc == PT_OK && !c.dry && c.ok) {
+        const int r = pt_launch_dla_thin_chain(e, x, n, H, W, reinterpret_cast<const bf16_t*>(ws->d_ptr), reinterpret_cast<const float*>(bs->d_ptr),
+                                               reinterpret_cast<const bf16_t*>(w0->d_ptr), reinterpret_cast<const float*>(b0->d_ptr),
+                                               reinterpret_cast<const bf16_t*>(w1->d_ptr), reinterpret_cast<const float*>(b1->d_ptr), layers[1].p, s);
+        if (r != PT_OK) c.rc = r;
+      }
+    } else {
     T t0 = c.alloc(H, W, 16);
     if (!c.dry && c.ok) {
       const PtTensor* w = c.get(c.x3 ? "base_layer.w3" : "base_layer.w");
@@ -239,7 +257,6 @@ static int lore_dla_run(pt_engine* e, const bf16_t* x, int n, int H, int W, floa
         if (r != PT_OK) c.rc = r;
       }
     }
-    std::vector<T> layers(6);
     layers[0] = c.alloc(H, W, 16);
     layers[1] = c.alloc(H / 2, W / 2, 32);
     for (int lv1 = 0; lv1 < 2; ++lv1) {
@@ -252,6 +269,7 @@ static int lore_dla_run(pt_engine* e, const bf16_t* x, int n, int H, int W, floa
                                             lv1 ? 2 : 1, c.x3, s);
         if (r != PT_OK) c.rc = r;
       }
+    }
     }
     for (int l = 2; l < 6; ++l)
       layers[l] = c.tree("level" + std::to_string(l), lv[l], layers[l - 1], ch[l - 1], ch[l], 2, l > 2, {});

@@ -1499,11 +1499,7 @@ __global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __res
                                                              const bf16_t* __restrict__ W, const float* __restrict__ bias,
                                                              int N, int* __restrict__ ids, float* __restrict__ maxv,
                                                              bf16_t* __restrict__ out, int relu, const int* __restrict__ tlim,
-                                                             int lda, long long wts, const bf16_t* __restrict__ res = nullptr,
-                                                             int resH = 0, int resW = 0) {
-  // MODE 2 (a 1x1 convolution as a row GEMM over pixels, pt_launch_gemm_rows with a residual): MODE 1 + `res` added before the activation:
-  // resH == 0: res has the output's shape; else the rows are the pixels of [B, resH, resW] maps and res is the [B, resH/2, resW/2, N] map
-  // whose nearest x2 up-sampling is added (the top-down path of an FPN: SegDetector, db_net/dbnet.py:615-625)
+                                                             int lda, long long wts) {
   // lda: elements between rows of A (K, or 2 K for the hi halves of (hi | lo) rows); wts: elements between 64-class tiles of W
   // (NCH * 2048, or three times that for the first third -- the w_hi chunks -- of the three-pass tiling)
   constexpr int K = KSTEPS * 16, NCH = K / 32, P = K * 2 + 16;     // P: LDS row pitch in bytes (odd number of 16-B slots)
@@ -1518,7 +1514,7 @@ __global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __res
   // ragged sequences (MODE 1): a wave's 32 rows are 32 consecutive time steps of ONE line (T = 160 = 5 x 32); groups at or
   // beyond the line's limit are not computed (the caller fills them), a workgroup with no live wave leaves at once
   bool live = true;
-  if (MODE != 0 && tlim) {
+  if (MODE == 1 && tlim) {
     const long long r0 = ((long long)blockIdx.x * 4 + wave) * 32;
     live = r0 < M && (int)(r0 % PT_REC_T) < tlim[r0 / PT_REC_T];
     if (!__syncthreads_or(live ? 1 : 0)) return;
@@ -1557,7 +1553,7 @@ __global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __res
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       const char* wr = sw + (half * 32 + lx) * P + q * 16;
-      if (MODE != 0 && !live) continue;
+      if (MODE == 1 && !live) continue;
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
         const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wr + ks * 32);
@@ -1571,22 +1567,13 @@ __global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __res
           if (v > bv) { bv = v; bi = t * 64 + cl; }
         }
       } else if (row < M) {
-        long long rrow = row;
-        if (MODE == 2 && resH) {
-          const long long hw = (long long)resH * resW, b = row / hw, rem = row - b * hw;
-          const int y = (int)(rem / resW), xq = (int)(rem - (long long)y * resW);
-          rrow = (b * (resH >> 1) + (y >> 1)) * (resW >> 1) + (xq >> 1);
-        }
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int cl = half * 32 + rg * 8 + 4 * q;
           uint32_t hb[4];
-          u32x2 rv = {0u, 0u};
-          if (MODE == 2) rv = *reinterpret_cast<const u32x2*>(res + rrow * N + t * 64 + cl);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             float v = acc[rg * 4 + k] + sb[cl + k];
-            if (MODE == 2) v += rbf2f(k < 2 ? (k == 0 ? rv.x & 0xFFFFu : rv.x >> 16) : (k == 2 ? rv.y & 0xFFFFu : rv.y >> 16));
             if (relu == 1) v = fmaxf(v, 0.f);
             else if (relu == 4) v = gelu_poly(v);
             hb[k] = rf2bf(v);
@@ -1907,33 +1894,21 @@ int pt_launch_gemm_argmax(const bf16_t* A, long long M, int K, const bf16_t* W, 
   return PT_OK;
 }
 
-// out bf16 [M][N] = A [M][K] . W^T + bias (relu: 0 none, 1 ReLU, 4 GELU by gelu_poly); K in {128, 256, 512}; PT_ERR_INVALID otherwise (caller falls back).
-// res != nullptr: + res before the activation (resH == 0: [M][N]; else the rows are pixels of [B, resH, resW] maps and res is the half-resolution map
-// whose nearest x2 up-sampling is added) -- what lets a 1x1 convolution run here: the A rows are read ONCE for all N outputs
+// out bf16 [M][N] = A [M][K] . W^T + bias (relu: 0 none, 1 ReLU, 4 GELU by gelu_poly); K in {256, 512}; PT_ERR_INVALID otherwise (caller falls back)
 int pt_launch_gemm_rows(const bf16_t* A, long long M, int K, const bf16_t* W, const float* bias, int N, bf16_t* out, int relu,
-                        hipStream_t s, const int* tlim, const bf16_t* res, int resH, int resW) {
-  if ((K != 512 && K != 256 && K != 128) || N % 64 != 0 || M <= 0) return PT_ERR_INVALID;
-  if (res && resH && ((resH | resW) & 1)) return PT_ERR_INVALID;
+                        hipStream_t s, const int* tlim) {
+  if ((K != 512 && K != 256) || N % 64 != 0 || M <= 0) return PT_ERR_INVALID;
   const int smem = 64 * (K * 2 + 16) + 64 * 4;
   static bool attr_done = false;
   if (!attr_done) {
     PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_argmax_kernel<32, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (512 * 2 + 16) + 256));
-    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_argmax_kernel<32, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (512 * 2 + 16) + 256));
     attr_done = true;
   }
   const dim3 grid((unsigned)((M + 127) / 128));
-#define PT_ROWS_LAUNCH(KS, MODE) hipLaunchKernelGGL((gemm_argmax_kernel<KS, MODE>), grid, dim3(256), smem, s, A, M, W, bias, N, nullptr, nullptr, out, relu, tlim, K, \
-                                                    (long long)(K / 32) * 2048, res, resH, resW)
-  if (res) {
-    if (K == 512) PT_ROWS_LAUNCH(32, 2);
-    else if (K == 256) PT_ROWS_LAUNCH(16, 2);
-    else PT_ROWS_LAUNCH(8, 2);
-  } else {
-    if (K == 512) PT_ROWS_LAUNCH(32, 1);
-    else if (K == 256) PT_ROWS_LAUNCH(16, 1);
-    else PT_ROWS_LAUNCH(8, 1);
-  }
-#undef PT_ROWS_LAUNCH
+  if (K == 512)
+    hipLaunchKernelGGL((gemm_argmax_kernel<32, 1>), grid, dim3(256), smem, s, A, M, W, bias, N, nullptr, nullptr, out, relu, tlim, 512, 16ll * 2048);
+  else
+    hipLaunchKernelGGL((gemm_argmax_kernel<16, 1>), grid, dim3(256), smem, s, A, M, W, bias, N, nullptr, nullptr, out, relu, tlim, 256, 8ll * 2048);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }

@@ -91,7 +91,7 @@ def _conv_case(eng, B, H, W, Cin, N, ks, stride, relu=False, res_mode=0, rep=1, 
     dict(B=1, H=9, W=11, Cin=256, N=64, ks=3, stride=1, rep=4),                     # out4: conv + upsample x4
     dict(B=2, H=12, W=20, Cin=64, N=256, ks=1, stride=1, relu=True, shuffle=64),    # ConvTranspose2d(2,2)
     dict(B=1, H=1, W=1, Cin=32, N=64, ks=3, stride=1),                              # minimum size
-    # plain 1x1 layers with 128 / 256 / 512 input channels and >= 128 outputs take the row-GEMM path (conv_igemm.hip: PT_CONV1_ROWS)
+    # plain 1x1 layers with 128 / 256 / 512 input channels (the FPN laterals and their residual modes)
     dict(B=2, H=26, W=38, Cin=128, N=256, ks=1, stride=1, res_mode=2, seed=11),      # DB lateral in3 + up(in4); 1976 pixels: ragged last workgroup
     dict(B=1, H=15, W=17, Cin=512, N=256, ks=1, stride=1, seed=12),                   # in5: no residual
     dict(B=3, H=9, W=13, Cin=256, N=128, ks=1, stride=1, relu=True, res_mode=1, seed=13),

@@ -482,3 +482,25 @@ def test_up_sampler_block_kernel_equals_general_kernel(eng, mode):
         assert float(np.abs(a["hm"]).max()) > 0
     finally:
         eng.set_precision(L.PT_PRECISION_BF16)
+
+
+@pytest.mark.parametrize("hw", [(160, 224), (96, 64), (1024, 1024), (32, 1056)])
+def test_thin_chain_equals_three_launches(eng, hw):
+    """dla_thin_chain_kernel (base_layer -> level0 -> level1 in one launch, the two full-resolution maps in LDS; bf16 mode) gives the head
+    maps of the three stand-alone launches bit for bit (PT_DLA_CHAIN is read at every call): maps smaller than a tile, maps whose size is
+    not a multiple of the 8 x 30 level-1 tile (partial tiles, zero padding of the intermediate maps at every border), the bench's 1024^2."""
+    import os
+    H, W = hw
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = torch.randn(1 if H * W > 500000 else 2, 3, H, W, generator=g) * 0.7
+    xd = _x4(x).cuda()
+    a = {k: t.cpu().numpy() for k, t in eng.tsr_forward_net(xd).items()}
+    os.environ["PT_DLA_CHAIN"] = "0"
+    try:
+        b = {k: t.cpu().numpy() for k, t in eng.tsr_forward_net(xd).items()}
+    finally:
+        del os.environ["PT_DLA_CHAIN"]
+    assert set(a) == set(b) and len(a) == 6
+    for k in a:
+        assert np.array_equal(a[k], b[k]), (hw, k, float(np.abs(a[k].astype(np.float64) - b[k]).max()))
+    assert float(np.abs(a["hm"]).max()) > 0
