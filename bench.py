@@ -770,9 +770,14 @@ class HipRunner:
             if "frac_mfma_peak" in row or "frac_hbm_peak" in row:
                 row["bound"] = "mfma" if row.get("frac_mfma_peak", 0) >= row.get("frac_hbm_peak", 0) else "hbm"
             out[name] = row
+        top = sorted(labels.items(), key=lambda kv: -kv[1]["ms"])[:16]
+        top_labels = {lab: {"ms_per_step": round(r["ms"] / steps, 3), "launches_per_step": round(r["launches"] / steps, 1),
+                            **({"frac_mfma_peak": round(r["flop"] / (r["ms"] * 1e-3) / (MFMA_PEAK_TFLOPS * 1e12), 4)} if r["flop"] > 0 and r["ms"] > 0 else {}),
+                            **({"frac_hbm_peak": round(r["bytes"] / (r["ms"] * 1e-3) / HBM_PEAK_BYTES, 4)} if r["bytes"] > 0 and r["ms"] > 0 else {})}
+                      for lab, r in top}
         kern = sum(r["ms_per_step"] for r in out.values())
         return {"ms_per_step_wall": round(dt * 1e3, 2), "ms_per_step_kernels": round(kern, 2), "steps": steps,
-                "peaks": {"mfma_tflops": MFMA_PEAK_TFLOPS, "hbm_tb_s": HBM_PEAK_BYTES / 1e12}, "classes": out}
+                "peaks": {"mfma_tflops": MFMA_PEAK_TFLOPS, "hbm_tb_s": HBM_PEAK_BYTES / 1e12}, "classes": out, "top_labels": top_labels}
 
     def det_only_leg(self, steps=20, warm=5):
         """BASELINE.json configs[1] in the same run: the det stage alone (pre, DB-ResNet18, bitmap, host post overlapped); steps / warm-up as

@@ -419,7 +419,20 @@ class OcrTablePipeline:
             if tsr_stage is not None and not staged_tsr:
                 tb = st["tb"] if st["tb"] is not None else self._layout_table_boxes(st["layout"])
                 st["tb"] = tb
-                tsr = tsr_stage(st["pages"], tb, page_frame=True)
+                # a table stage without start / process / collect halves (MtlTabNet) decodes synchronously and polls its stream every few steps;
+                # on the main stream every poll would wait for the detection / recognition work of the NEXT batches already queued there and
+                # the software pipeline would run serially.  It gets its own stream behind this batch's upload instead.
+                if getattr(self, "_table_stream", None) is None:
+                    self._table_stream = torch.cuda.Stream(device=dev)
+                ts = self._table_stream
+                try:
+                    with torch.cuda.stream(ts):
+                        ts.wait_event(st["uploaded"])
+                        tsr = tsr_stage(st["pages"], tb, page_frame=True)
+                    st["pages"].record_stream(ts)
+                except ValueError as e:      # a degenerate layout box (empty crop): the reference contains a failed crop; logged, the batch goes on
+                    logger.warning("table structure skipped for a batch of %d pages: %s", st["n"], e)
+                    tsr = [[] for _ in range(st["n"])]
             elif tsr_stage is not None:
                 pending, metas, offs, ev = st["tsr"]
                 flat = []
