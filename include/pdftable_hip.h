@@ -415,33 +415,37 @@ int pt_op_db_head_final(pt_engine* e, const uint16_t* d_in, int B, int H, int W,
 /* ---- single operators of the generic ONNX layer-list executor (pdf_table_amd/onnx_exec.py) --------------------
  * Replaces: onnxruntime's execution of an arbitrary graph behind BaseInferTask.infer (model/ocr_pdf/base_infer_task.py:
  * 366-370, sessions built by utils/deploy_utils.py:243-280).  bf16 NHWC, C a multiple of 8; convolutions go to
- * pt_op_conv2d.  act: 0 none, 1 ReLU, 2 hardswish. */
+ * pt_op_conv2d.  act: 0 none, 1 ReLU, 2 hardswish.
+ * split (since ABI 12; every operator below except the pure data movers): 0 = plain bf16 tensors; 1 = the tolerance mode's (hi | lo) tensors --
+ * a pixel / token row holds [hi(C) | lo(C)], value = hi + lo, arithmetic in fp32 on the sum, result split again (the convention of
+ * PT_PRECISION_BF16X3).  pt_op_act / pt_op_mul then need C (channels of one half; n_elems counts VALUES, i.e. pixels x C); pt_op_copy_channels
+ * and pt_op_upsample_nearest move halves like any channels (the caller addresses them through the channel stride / offset). */
 /* depthwise k x k (k 3 or 5, pad k/2, stride 1 or 2) + bias + act; d_w_taps fp32 [k*k][C], d_bias fp32 [C] */
 int pt_op_dwconv(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int C, const float* d_w_taps, const float* d_bias, int k,
-                 int stride, int act, uint16_t* d_out, pt_stream stream);
+                 int stride, int act, uint16_t* d_out, int split, pt_stream stream);
 /* element-wise a + b over npix pixels of C channels */
-int pt_op_add(pt_engine* e, const uint16_t* d_a, const uint16_t* d_b, uint16_t* d_out, long long npix, int C, pt_stream stream);
+int pt_op_add(pt_engine* e, const uint16_t* d_a, const uint16_t* d_b, uint16_t* d_out, long long npix, int C, int split, pt_stream stream);
 /* MaxPool2d(3, 2, 1), or a non-overlapping k x k pool (stride k, no padding, H and W divisible by k) */
 int pt_op_maxpool(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int C, int k, int stride, int pad, uint16_t* d_out,
-                  pt_stream stream);
+                  int split, pt_stream stream);
 /* AveragePool k x k, stride k, no padding (H and W divisible by k) */
-int pt_op_avgpool(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int C, int k, uint16_t* d_out, pt_stream stream);
+int pt_op_avgpool(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int C, int k, uint16_t* d_out, int split, pt_stream stream);
 /* GlobalAveragePool: [B, HW, C] -> bf16 [B, C]; d_scratch: pt_op_chan_mean_scratch_floats(B, C) floats */
-int pt_op_chan_mean(pt_engine* e, const uint16_t* d_in, int B, int HW, int C, float* d_scratch, uint16_t* d_mean, pt_stream stream);
+int pt_op_chan_mean(pt_engine* e, const uint16_t* d_in, int B, int HW, int C, float* d_scratch, uint16_t* d_mean, int split, pt_stream stream);
 int pt_op_chan_mean_scratch_floats(int B, int C);
 /* x [B, HW, C] * gate [B, C] (the Mul of a squeeze-and-excitation block) */
 int pt_op_scale_channels(pt_engine* e, const uint16_t* d_in, const uint16_t* d_gate, int B, int HW, int C, uint16_t* d_out,
-                         pt_stream stream);
+                         int split, pt_stream stream);
 /* stand-alone activation over n_elems (multiple of 8) values; kind: 1 ReLU, 2 hardswish, 4 sigmoid,
  * 5 hardsigmoid = max(0, min(1, alpha x + beta)), 6 ReLU6, 7 GELU (erf form), 8 swish x * sigmoid(x) */
-int pt_op_act(pt_engine* e, const uint16_t* d_in, long long n_elems, int kind, float alpha, float beta, uint16_t* d_out,
+int pt_op_act(pt_engine* e, const uint16_t* d_in, long long n_elems, int kind, float alpha, float beta, uint16_t* d_out, int C, int split,
               pt_stream stream);
 /* Data movement of the executor (ONNX Concat / Slice / Split over channels, nearest Resize): dst[pix][dst_coff + c] = src[pix][src_coff + c] for
  * c < n; nearest-neighbour up-sampling by an integer factor -> [B, H f, W f, C]; element-wise product of two equally shaped tensors */
 int pt_op_copy_channels(pt_engine* e, const uint16_t* d_src, long long npix, int src_cstride, int src_coff, uint16_t* d_dst, int dst_cstride, int dst_coff,
                         int n, pt_stream stream);
 int pt_op_upsample_nearest(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int C, int factor, uint16_t* d_out, pt_stream stream);
-int pt_op_mul(pt_engine* e, const uint16_t* d_a, const uint16_t* d_b, uint16_t* d_out, long long n_elems, pt_stream stream);
+int pt_op_mul(pt_engine* e, const uint16_t* d_a, const uint16_t* d_b, uint16_t* d_out, long long n_elems, int C, int split, pt_stream stream);
 /* nbytes from src to dst (16-byte aligned) by a kernel on `stream`; either side may be PINNED HOST memory (hipHostMalloc / torch pin_memory: mapped into
  * the device's address space).  For the few small transfers a host thread WAITS for while the compute stream holds a backlog: an asynchronous
  * hipMemcpy goes through a DMA engine's in-order queue and can sit there behind copies of other streams that wait for kernels still to run
@@ -454,10 +458,10 @@ int pt_copy_bytes(pt_engine* e, const void* src, void* dst, long long nbytes, pt
  * pt_op_attention: multi-head self-attention of rows holding [q | k | v], channel = part * heads * d + head * d + j (the fused-qkv layout of
  * timm / PaddleOCR SVTR blocks): out[b, t, head * d + j] = softmax_k(scale q.k) v; T <= 1024, d <= 64. */
 int pt_op_layernorm(pt_engine* e, const uint16_t* d_in, long long rows, int c_pad, int c, const float* d_gamma, const float* d_beta, float eps,
-                    uint16_t* d_out, pt_stream stream);
-int pt_op_softmax(pt_engine* e, const uint16_t* d_in, long long rows, int c_pad, int c, float* d_out_f32, uint16_t* d_out_bf16, pt_stream stream);
+                    uint16_t* d_out, int split, pt_stream stream);
+int pt_op_softmax(pt_engine* e, const uint16_t* d_in, long long rows, int c_pad, int c, float* d_out_f32, uint16_t* d_out_bf16, int split, pt_stream stream);
 int pt_op_attention(pt_engine* e, const uint16_t* d_qkv, int B, int T, int heads, int d, int qkv_cstride, float scale, uint16_t* d_out, int out_cstride,
-                    pt_stream stream);
+                    int split, pt_stream stream);
 
 /* ---- introspection used by bench.py (HIP-event timing of the dominant kernel) ------------------ */
 /* ---- image classification (PP-LCNet) ------------------------------------------------------------

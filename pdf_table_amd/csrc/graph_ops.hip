@@ -17,60 +17,84 @@ __device__ __forceinline__ uint32_t g_f2bf(float f) {
   return u >> 16;
 }
 
+// (hi | lo) tensors of the executor's tolerance mode (PT_PRECISION_BF16X3 convention: a pixel / row holds [hi(C) | lo(C)], value = hi + lo,
+// arithmetic in fp32, result split again): lo = 0 reads / writes a plain bf16 tensor
+__device__ __forceinline__ void g_load8(const bf16_t* p, int lo, float* v) {
+  const uint4 h = *reinterpret_cast<const uint4*>(p);
+  const uint32_t hw[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { v[2 * k] = g_bf(hw[k] & 0xFFFFu); v[2 * k + 1] = g_bf(hw[k] >> 16); }
+  if (lo) {
+    const uint4 l = *reinterpret_cast<const uint4*>(p + lo);
+    const uint32_t lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[2 * k] += g_bf(lw[k] & 0xFFFFu); v[2 * k + 1] += g_bf(lw[k] >> 16); }
+  }
+}
+__device__ __forceinline__ void g_store8(bf16_t* p, int lo, const float* v) {
+  uint32_t h[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) h[k] = g_f2bf(v[k]);
+  *reinterpret_cast<uint4*>(p) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+  if (lo) {
+    uint32_t l[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) l[k] = g_f2bf(v[k] - g_bf(h[k]));
+    *reinterpret_cast<uint4*>(p + lo) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+  }
+}
+__device__ __forceinline__ float g_ld(const bf16_t* p, int lo) { return lo ? g_bf(p[0]) + g_bf(p[lo]) : g_bf(p[0]); }
+__device__ __forceinline__ void g_st(bf16_t* p, int lo, float v) {
+  const uint32_t h = g_f2bf(v);
+  p[0] = (bf16_t)h;
+  if (lo) p[lo] = (bf16_t)g_f2bf(v - g_bf(h));
+}
+
 // x [B, HW, C] *= gate [B, C] (the Mul of a squeeze-and-excitation block)
 __global__ __launch_bounds__(256) void scale_channels_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gate,
-                                                             bf16_t* __restrict__ out, long long total8, int HW, int C) {
-  const int cg = C >> 3;
+                                                             bf16_t* __restrict__ out, long long total8, int HW, int C, int split) {
+  const int cg = C >> 3, lo = split ? C : 0, cs = split ? 2 * C : C;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (long long)gridDim.x * blockDim.x) {
     const int c8 = (int)(i % cg);
     const long long pix = i / cg;
     const int b = (int)(pix / HW);
-    const uint4 xv = *reinterpret_cast<const uint4*>(x + i * 8);
-    const uint4 gv = *reinterpret_cast<const uint4*>(gate + ((size_t)b * C + c8 * 8));
-    const uint32_t xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
-    uint32_t o[4];
+    float xv[8], gv[8];
+    g_load8(x + pix * cs + c8 * 8, lo, xv);
+    g_load8(gate + (size_t)b * cs + c8 * 8, lo, gv);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float lo = g_bf(xs[k] & 0xFFFFu) * g_bf(gs[k] & 0xFFFFu);
-      const float hi = g_bf(xs[k] >> 16) * g_bf(gs[k] >> 16);
-      o[k] = g_f2bf(lo) | (g_f2bf(hi) << 16);
-    }
-    *reinterpret_cast<uint4*>(out + i * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    for (int k = 0; k < 8; ++k) xv[k] *= gv[k];
+    g_store8(out + pix * cs + c8 * 8, lo, xv);
   }
 }
 
 // kind: 1 relu, 2 hardswish, 4 sigmoid, 5 hardsigmoid (max(0, min(1, alpha x + beta))), 6 relu6, 7 GELU (erf), 8 swish
 __global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, long long total8, int kind,
-                                                  float alpha, float beta) {
+                                                  float alpha, float beta, int C, int split) {
+  const int cg = C >> 3, lo = split ? C : 0, cs = split ? 2 * C : C;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (long long)gridDim.x * blockDim.x) {
-    const uint4 xv = *reinterpret_cast<const uint4*>(x + i * 8);
-    const uint32_t xs[4] = {xv.x, xv.y, xv.z, xv.w};
-    uint32_t o[4];
+    const long long off = (i / cg) * cs + (i % cg) * 8;
+    float v[8];
+    g_load8(x + off, lo, v);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float v[2] = {g_bf(xs[k] & 0xFFFFu), g_bf(xs[k] >> 16)};
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        float t = v[j];
-        if (kind == 1) t = fmaxf(t, 0.f);
-        else if (kind == 2) t = t * fminf(fmaxf(t + 3.f, 0.f), 6.f) / 6.f;
-        else if (kind == 4) t = 1.f / (1.f + expf(-t));
-        else if (kind == 5) t = fmaxf(0.f, fminf(1.f, alpha * t + beta));
-        else if (kind == 6) t = fminf(fmaxf(t, 0.f), 6.f);
-        else if (kind == 7) t = t * 0.5f * (1.f + erff(t * 0.70710678118654752f));      // GELU (erf form: nn.GELU())
-        else if (kind == 8) t = t / (1.f + expf(-t));                                      // swish / SiLU: x * sigmoid(x)
-        v[j] = t;
-      }
-      o[k] = g_f2bf(v[0]) | (g_f2bf(v[1]) << 16);
+    for (int j = 0; j < 8; ++j) {
+      float t = v[j];
+      if (kind == 1) t = fmaxf(t, 0.f);
+      else if (kind == 2) t = t * fminf(fmaxf(t + 3.f, 0.f), 6.f) / 6.f;
+      else if (kind == 4) t = 1.f / (1.f + expf(-t));
+      else if (kind == 5) t = fmaxf(0.f, fminf(1.f, alpha * t + beta));
+      else if (kind == 6) t = fminf(fmaxf(t, 0.f), 6.f);
+      else if (kind == 7) t = t * 0.5f * (1.f + erff(t * 0.70710678118654752f));      // GELU (erf form: nn.GELU())
+      else if (kind == 8) t = t / (1.f + expf(-t));                                      // swish / SiLU: x * sigmoid(x)
+      v[j] = t;
     }
-    *reinterpret_cast<uint4*>(out + i * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    g_store8(out + off, lo, v);
   }
 }
 
 // AveragePool k x k, stride k, no padding: out [B, H/k, W/k, C]
 __global__ __launch_bounds__(256) void avgpool_kxk_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B, int H, int W, int C,
-                                                          int k) {
-  const int Ho = H / k, Wo = W / k, cg = C >> 3;
+                                                          int k, int split) {
+  const int Ho = H / k, Wo = W / k, cg = C >> 3, lo = split ? C : 0, cs = split ? 2 * C : C;
   const long long total = (long long)B * Ho * Wo * cg;
   const float inv = 1.f / (float)(k * k);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -82,18 +106,14 @@ __global__ __launch_bounds__(256) void avgpool_kxk_kernel(const bf16_t* __restri
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int dy = 0; dy < k; ++dy)
       for (int dx = 0; dx < k; ++dx) {
-        const uint4 v = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + oy * k + dy) * W + ox * k + dx) * C + c8 * 8);
-        const uint32_t vs[4] = {v.x, v.y, v.z, v.w};
+        float v[8];
+        g_load8(x + (((size_t)b * H + oy * k + dy) * W + ox * k + dx) * cs + c8 * 8, lo, v);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc[2 * q] += g_bf(vs[q] & 0xFFFFu);
-          acc[2 * q + 1] += g_bf(vs[q] >> 16);
-        }
+        for (int q = 0; q < 8; ++q) acc[q] += v[q];
       }
-    uint32_t o[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = g_f2bf(acc[2 * q] * inv) | (g_f2bf(acc[2 * q + 1] * inv) << 16);
-    *reinterpret_cast<uint4*>(out + i * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    for (int q = 0; q < 8; ++q) acc[q] *= inv;
+    g_store8(out + (i / cg) * cs + c8 * 8, lo, acc);
   }
 }
 
@@ -124,15 +144,17 @@ __global__ __launch_bounds__(256) void upsample_kernel(const bf16_t* __restrict_
   }
 }
 
-__global__ __launch_bounds__(256) void mul_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ out, long long total8) {
+__global__ __launch_bounds__(256) void mul_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ out, long long total8,
+                                                  int C, int split) {
+  const int cg = C >> 3, lo = split ? C : 0, cs = split ? 2 * C : C;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (long long)gridDim.x * blockDim.x) {
-    const uint4 av = *reinterpret_cast<const uint4*>(a + i * 8), bv = *reinterpret_cast<const uint4*>(b + i * 8);
-    const uint32_t as[4] = {av.x, av.y, av.z, av.w}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
-    uint32_t o[4];
+    const long long off = (i / cg) * cs + (i % cg) * 8;
+    float va[8], vb[8];
+    g_load8(a + off, lo, va);
+    g_load8(b + off, lo, vb);
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      o[k] = g_f2bf(g_bf(as[k] & 0xFFFFu) * g_bf(bs[k] & 0xFFFFu)) | (g_f2bf(g_bf(as[k] >> 16) * g_bf(bs[k] >> 16)) << 16);
-    *reinterpret_cast<uint4*>(out + i * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    for (int k = 0; k < 8; ++k) va[k] *= vb[k];
+    g_store8(out + off, lo, va);
   }
 }
 
@@ -148,59 +170,60 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // LayerNorm over the first C of Cp channels of every row (biased variance, eps inside the root: nn.LayerNorm); one wave per row, padded
-// channels are written as zeros
+// channels are written as zeros.  split: rows are [hi(Cp) | lo(Cp)]
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, long long rows, int Cp, int C,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps) {
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int split) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, lo = split ? Cp : 0, cs = split ? 2 * Cp : Cp;
   if (row >= rows) return;
-  const bf16_t* xr = x + row * Cp;
+  const bf16_t* xr = x + row * cs;
   float s = 0.f;
-  for (int c = lane; c < C; c += 64) s += g_bf(xr[c]);
+  for (int c = lane; c < C; c += 64) s += g_ld(xr + c, lo);
   const float mean = wave_sum(s) / (float)C;
   float q = 0.f;
-  for (int c = lane; c < C; c += 64) { const float d = g_bf(xr[c]) - mean; q += d * d; }
+  for (int c = lane; c < C; c += 64) { const float d = g_ld(xr + c, lo) - mean; q += d * d; }
   const float rstd = 1.f / sqrtf(wave_sum(q) / (float)C + eps);
-  bf16_t* orow = out + row * Cp;
-  for (int c = lane; c < Cp; c += 64) orow[c] = c < C ? (bf16_t)g_f2bf((g_bf(xr[c]) - mean) * rstd * gamma[c] + beta[c]) : (bf16_t)0;
+  bf16_t* orow = out + row * cs;
+  for (int c = lane; c < Cp; c += 64) g_st(orow + c, lo, c < C ? (g_ld(xr + c, lo) - mean) * rstd * gamma[c] + beta[c] : 0.f);
 }
 
-// soft-max over the first C of Cp channels of every row -> fp32 probabilities [rows][C] (network outputs: CTC heads) or bf16 [rows][Cp]
+// soft-max over the first C of Cp channels of every row -> fp32 probabilities [rows][C] (network outputs: CTC heads) or bf16 [rows][Cp] ([hi | lo] when split)
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const bf16_t* __restrict__ x, long long rows, int Cp, int C, float* __restrict__ out_f32,
-                                                           bf16_t* __restrict__ out_bf) {
+                                                           bf16_t* __restrict__ out_bf, int split) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, lo = split ? Cp : 0, cs = split ? 2 * Cp : Cp;
   if (row >= rows) return;
-  const bf16_t* xr = x + row * Cp;
+  const bf16_t* xr = x + row * cs;
   float m = -3.0e38f;
-  for (int c = lane; c < C; c += 64) m = fmaxf(m, g_bf(xr[c]));
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, g_ld(xr + c, lo));
   m = wave_max(m);
   float s = 0.f;
-  for (int c = lane; c < C; c += 64) s += expf(g_bf(xr[c]) - m);
+  for (int c = lane; c < C; c += 64) s += expf(g_ld(xr + c, lo) - m);
   const float inv = 1.f / wave_sum(s);
   for (int c = lane; c < (out_f32 ? C : Cp); c += 64) {
-    const float p = c < C ? expf(g_bf(xr[c]) - m) * inv : 0.f;
+    const float p = c < C ? expf(g_ld(xr + c, lo) - m) * inv : 0.f;
     if (out_f32) out_f32[row * C + c] = p;
-    else out_bf[row * Cp + c] = (bf16_t)g_f2bf(p);
+    else g_st(out_bf + row * cs + c, lo, p);
   }
 }
 
 // Multi-head self-attention of token rows holding [q | k | v] (each heads * d channels; channel = part * heads * d + head * d + j): one wave per
 // (batch, head, query); scores of all T keys in LDS (T <= 1024), soft-max, weighted sum of the values; out[b, t, head * d + j].  d <= 64.
+// split: rows are [hi(qcs) | lo(qcs)] / [hi(ocs) | lo(ocs)]; scores, soft-max and the weighted sum in fp32 on hi + lo
 __global__ __launch_bounds__(64) void attention_rows_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int T, int heads, int d, int qcs,
-                                                            int ocs, float scale) {
+                                                            int ocs, float scale, int split) {
   __shared__ float p[1024];
   __shared__ float qs[64];
   const int t = blockIdx.x, h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
-  const int C = heads * d;
-  const bf16_t* base = qkv + (size_t)b * T * qcs;
-  if (lane < d) qs[lane] = g_bf(base[(size_t)t * qcs + h * d + lane]) * scale;
+  const int C = heads * d, lo = split ? qcs : 0, rs = split ? 2 * qcs : qcs, olo = split ? ocs : 0, ors = split ? 2 * ocs : ocs;
+  const bf16_t* base = qkv + (size_t)b * T * rs;
+  if (lane < d) qs[lane] = g_ld(base + (size_t)t * rs + h * d + lane, lo) * scale;
   __syncthreads();
   float m = -3.0e38f;
   for (int k = lane; k < T; k += 64) {
-    const bf16_t* kr = base + (size_t)k * qcs + C + h * d;
+    const bf16_t* kr = base + (size_t)k * rs + C + h * d;
     float acc = 0.f;
-    for (int j = 0; j < d; ++j) acc += qs[j] * g_bf(kr[j]);
+    for (int j = 0; j < d; ++j) acc += qs[j] * g_ld(kr + j, lo);
     p[k] = acc;
     m = fmaxf(m, acc);
   }
@@ -211,8 +234,8 @@ __global__ __launch_bounds__(64) void attention_rows_kernel(const bf16_t* __rest
   __syncthreads();
   if (lane < d) {
     float acc = 0.f;
-    for (int k = 0; k < T; ++k) acc += p[k] * g_bf(base[(size_t)k * qcs + 2 * C + h * d + lane]);
-    out[((size_t)b * T + t) * ocs + h * d + lane] = (bf16_t)g_f2bf(acc * inv);
+    for (int k = 0; k < T; ++k) acc += p[k] * g_ld(base + (size_t)k * rs + 2 * C + h * d + lane, lo);
+    g_st(out + ((size_t)b * T + t) * ors + h * d + lane, olo, acc * inv);
   }
 }
 
@@ -233,60 +256,61 @@ inline unsigned grid_for(long long n) {
 extern "C" {
 
 int pt_op_dwconv(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int C, const float* d_w_taps, const float* d_bias, int k,
-                 int stride, int act, uint16_t* d_out, pt_stream stream) {
+                 int stride, int act, uint16_t* d_out, int split, pt_stream stream) {
   PT_REQUIRE(e && d_in && d_w_taps && d_bias && d_out, "pt_op_dwconv: null pointer");
   PT_REQUIRE((k == 3 || k == 5) && (stride == 1 || stride == 2) && C % 8 == 0 && act >= 0 && act <= 2,
              "pt_op_dwconv: k=%d stride=%d C=%d act=%d unsupported (k 3/5, stride 1/2, C multiple of 8, act 0/1/2)", k, stride, C, act);
-  return pt_launch_dwconv(d_in, d_w_taps, d_bias, d_out, B, H, W, C, k, stride, act, 0, reinterpret_cast<hipStream_t>(stream), nullptr);
+  return pt_launch_dwconv(d_in, d_w_taps, d_bias, d_out, B, H, W, C, k, stride, act, split ? 1 : 0, reinterpret_cast<hipStream_t>(stream), nullptr);
 }
 
-int pt_op_add(pt_engine* e, const uint16_t* d_a, const uint16_t* d_b, uint16_t* d_out, long long npix, int C, pt_stream stream) {
+int pt_op_add(pt_engine* e, const uint16_t* d_a, const uint16_t* d_b, uint16_t* d_out, long long npix, int C, int split, pt_stream stream) {
   PT_REQUIRE(e && d_a && d_b && d_out && npix > 0 && C % 8 == 0, "pt_op_add: bad arguments");
-  return pt_launch_add(d_a, d_b, d_out, npix, C, 0, reinterpret_cast<hipStream_t>(stream));
+  return pt_launch_add(d_a, d_b, d_out, npix, C, split ? 1 : 0, reinterpret_cast<hipStream_t>(stream));
 }
 
-int pt_op_maxpool(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int C, int k, int stride, int pad, uint16_t* d_out,
+int pt_op_maxpool(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int C, int k, int stride, int pad, uint16_t* d_out, int split,
                   pt_stream stream) {
   PT_REQUIRE(e && d_in && d_out && C % 8 == 0, "pt_op_maxpool: bad arguments");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (k == 3 && stride == 2 && pad == 1) return pt_launch_maxpool3x3s2(d_in, B, H, W, C, d_out, 0, s);
+  if (k == 3 && stride == 2 && pad == 1) return pt_launch_maxpool3x3s2(d_in, B, H, W, C, d_out, split ? 1 : 0, s);
   PT_REQUIRE(k == stride && pad == 0 && k >= 2 && H % k == 0 && W % k == 0,
              "pt_op_maxpool: only MaxPool(3, 2, 1) and non-overlapping k x k pools on sizes divisible by k (got k=%d stride=%d pad=%d)", k,
              stride, pad);
-  return pt_launch_maxpool_kxk(d_in, B, H, W, C, k, k, 0, 0, d_out, s);
+  return pt_launch_maxpool_kxk(d_in, B, H, W, C, k, k, 0, split ? 1 : 0, d_out, s);
 }
 
-int pt_op_avgpool(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int C, int k, uint16_t* d_out, pt_stream stream) {
+int pt_op_avgpool(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int C, int k, uint16_t* d_out, int split, pt_stream stream) {
   PT_REQUIRE(e && d_in && d_out && C % 8 == 0 && k >= 2 && H % k == 0 && W % k == 0, "pt_op_avgpool: k x k / stride k on sizes divisible by k");
   hipLaunchKernelGGL(avgpool_kxk_kernel, dim3(grid_for((long long)B * (H / k) * (W / k) * (C / 8))), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), d_in, d_out, B, H, W, C, k);
+                     reinterpret_cast<hipStream_t>(stream), d_in, d_out, B, H, W, C, k, split);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
 
-int pt_op_chan_mean(pt_engine* e, const uint16_t* d_in, int B, int HW, int C, float* d_scratch, uint16_t* d_mean, pt_stream stream) {
+int pt_op_chan_mean(pt_engine* e, const uint16_t* d_in, int B, int HW, int C, float* d_scratch, uint16_t* d_mean, int split, pt_stream stream) {
   PT_REQUIRE(e && d_in && d_scratch && d_mean, "pt_op_chan_mean: null pointer");
-  return pt_launch_chan_mean(d_in, B, HW, C, 0, d_scratch, d_mean, B, reinterpret_cast<hipStream_t>(stream));
+  return pt_launch_chan_mean(d_in, B, HW, C, split ? 1 : 0, d_scratch, d_mean, B, reinterpret_cast<hipStream_t>(stream));
 }
 
 int pt_op_chan_mean_scratch_floats(int B, int C) { return PT_SE_CHUNKS * B * C; }
 
-int pt_op_scale_channels(pt_engine* e, const uint16_t* d_in, const uint16_t* d_gate, int B, int HW, int C, uint16_t* d_out,
+int pt_op_scale_channels(pt_engine* e, const uint16_t* d_in, const uint16_t* d_gate, int B, int HW, int C, uint16_t* d_out, int split,
                          pt_stream stream) {
   PT_REQUIRE(e && d_in && d_gate && d_out && C % 8 == 0 && B > 0 && HW > 0, "pt_op_scale_channels: bad arguments");
   const long long total8 = (long long)B * HW * (C >> 3);
   hipLaunchKernelGGL(scale_channels_kernel, dim3(grid_for(total8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_in, d_gate,
-                     d_out, total8, HW, C);
+                     d_out, total8, HW, C, split);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
 
-int pt_op_act(pt_engine* e, const uint16_t* d_in, long long n_elems, int kind, float alpha, float beta, uint16_t* d_out,
+int pt_op_act(pt_engine* e, const uint16_t* d_in, long long n_elems, int kind, float alpha, float beta, uint16_t* d_out, int C, int split,
               pt_stream stream) {
   PT_REQUIRE(e && d_in && d_out && n_elems > 0 && n_elems % 8 == 0, "pt_op_act: bad arguments");
   PT_REQUIRE(kind == 1 || kind == 2 || (kind >= 4 && kind <= 8), "pt_op_act: activation kind %d unsupported", kind);
+  PT_REQUIRE(!split || (C > 0 && C % 8 == 0 && n_elems % C == 0), "pt_op_act: a (hi | lo) tensor needs its channel count (C=%d)", C);
   hipLaunchKernelGGL(act_kernel, dim3(grid_for(n_elems / 8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_in, d_out,
-                     n_elems / 8, kind, alpha, beta);
+                     n_elems / 8, kind, alpha, beta, split ? C : 8, split);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
@@ -321,36 +345,38 @@ int pt_copy_bytes(pt_engine* e, const void* src, void* dst, long long nbytes, pt
   return PT_OK;
 }
 
-int pt_op_mul(pt_engine* e, const uint16_t* d_a, const uint16_t* d_b, uint16_t* d_out, long long n_elems, pt_stream stream) {
+int pt_op_mul(pt_engine* e, const uint16_t* d_a, const uint16_t* d_b, uint16_t* d_out, long long n_elems, int C, int split, pt_stream stream) {
   PT_REQUIRE(e && d_a && d_b && d_out && n_elems > 0 && n_elems % 8 == 0, "pt_op_mul: bad arguments");
-  hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n_elems / 8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_a, d_b, d_out, n_elems / 8);
+  PT_REQUIRE(!split || (C > 0 && C % 8 == 0 && n_elems % C == 0), "pt_op_mul: a (hi | lo) tensor needs its channel count (C=%d)", C);
+  hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n_elems / 8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_a, d_b, d_out, n_elems / 8,
+                     split ? C : 8, split);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
 
 int pt_op_layernorm(pt_engine* e, const uint16_t* d_in, long long rows, int c_pad, int c, const float* d_gamma, const float* d_beta, float eps,
-                    uint16_t* d_out, pt_stream stream) {
+                    uint16_t* d_out, int split, pt_stream stream) {
   PT_REQUIRE(e && d_in && d_gamma && d_beta && d_out && rows > 0 && c > 0 && c <= c_pad, "pt_op_layernorm: bad arguments");
   hipLaunchKernelGGL(layernorm_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_in, d_out, rows, c_pad,
-                     c, d_gamma, d_beta, eps);
+                     c, d_gamma, d_beta, eps, split);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
 
-int pt_op_softmax(pt_engine* e, const uint16_t* d_in, long long rows, int c_pad, int c, float* d_out_f32, uint16_t* d_out_bf16, pt_stream stream) {
+int pt_op_softmax(pt_engine* e, const uint16_t* d_in, long long rows, int c_pad, int c, float* d_out_f32, uint16_t* d_out_bf16, int split, pt_stream stream) {
   PT_REQUIRE(e && d_in && rows > 0 && c > 0 && c <= c_pad && ((d_out_f32 != nullptr) != (d_out_bf16 != nullptr)), "pt_op_softmax: bad arguments (one output)");
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_in, rows, c_pad, c,
-                     d_out_f32, d_out_bf16);
+                     d_out_f32, d_out_bf16, split);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
 
 int pt_op_attention(pt_engine* e, const uint16_t* d_qkv, int B, int T, int heads, int d, int qkv_cstride, float scale, uint16_t* d_out, int out_cstride,
-                    pt_stream stream) {
+                    int split, pt_stream stream) {
   PT_REQUIRE(e && d_qkv && d_out && B > 0 && T > 0 && T <= 1024 && heads > 0 && d > 0 && d <= 64 && 3 * heads * d <= qkv_cstride && heads * d <= out_cstride,
              "pt_op_attention: bad arguments (T <= 1024, head size <= 64)");
   hipLaunchKernelGGL(attention_rows_kernel, dim3(T, heads, B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), d_qkv, d_out, T, heads, d, qkv_cstride,
-                     out_cstride, scale);
+                     out_cstride, scale, split);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }

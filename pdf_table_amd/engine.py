@@ -622,63 +622,69 @@ class HipEngine:
         return out
 
     # ---- single operators of the generic ONNX executor (pdf_table_amd/onnx_exec.py); bf16 NHWC, C a multiple of 8 -------
-    def op_dwconv(self, x: torch.Tensor, w_taps: torch.Tensor, bias: torch.Tensor, k: int, stride: int = 1, act: int = 0) -> torch.Tensor:
+    # (split=True: the tolerance mode's (hi | lo) tensors -- the last dimension holds [hi(C) | lo(C)], C = shape[-1] // 2)
+    def op_dwconv(self, x: torch.Tensor, w_taps: torch.Tensor, bias: torch.Tensor, k: int, stride: int = 1, act: int = 0, split: bool = False) -> torch.Tensor:
         self._chk(x, torch.bfloat16, "x")
         self._chk(w_taps, torch.float32, "w_taps")
         self._chk(bias, torch.float32, "bias")
         B, H, W, Cc = x.shape
         pad = k // 2
         out = torch.empty((B, (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1, Cc), dtype=torch.bfloat16, device=self._tdev)
-        L.check(self.lib.pt_op_dwconv(self._h, _ptr(x), B, H, W, Cc, _ptr(w_taps), _ptr(bias), k, stride, act, _ptr(out), self._stream()),
-                "pt_op_dwconv")
+        L.check(self.lib.pt_op_dwconv(self._h, _ptr(x), B, H, W, Cc // 2 if split else Cc, _ptr(w_taps), _ptr(bias), k, stride, act, _ptr(out), int(split),
+                                      self._stream()), "pt_op_dwconv")
         return out
 
-    def op_add(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    def op_add(self, a: torch.Tensor, b: torch.Tensor, split: bool = False) -> torch.Tensor:
         self._chk(a, torch.bfloat16, "a")
         self._chk(b, torch.bfloat16, "b")
         if a.shape != b.shape:
             raise ValueError(f"op_add: shapes differ: {tuple(a.shape)} vs {tuple(b.shape)}")
         out = torch.empty_like(a)
-        L.check(self.lib.pt_op_add(self._h, _ptr(a), _ptr(b), _ptr(out), a.numel() // a.shape[-1], a.shape[-1], self._stream()), "pt_op_add")
+        L.check(self.lib.pt_op_add(self._h, _ptr(a), _ptr(b), _ptr(out), a.numel() // a.shape[-1], a.shape[-1] // 2 if split else a.shape[-1], int(split),
+                                   self._stream()), "pt_op_add")
         return out
 
-    def op_maxpool(self, x: torch.Tensor, k: int, stride: int, pad: int) -> torch.Tensor:
+    def op_maxpool(self, x: torch.Tensor, k: int, stride: int, pad: int, split: bool = False) -> torch.Tensor:
         self._chk(x, torch.bfloat16, "x")
         B, H, W, Cc = x.shape
         out = torch.empty((B, (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1, Cc), dtype=torch.bfloat16, device=self._tdev)
-        L.check(self.lib.pt_op_maxpool(self._h, _ptr(x), B, H, W, Cc, k, stride, pad, _ptr(out), self._stream()), "pt_op_maxpool")
+        L.check(self.lib.pt_op_maxpool(self._h, _ptr(x), B, H, W, Cc // 2 if split else Cc, k, stride, pad, _ptr(out), int(split), self._stream()), "pt_op_maxpool")
         return out
 
-    def op_avgpool(self, x: torch.Tensor, k: int) -> torch.Tensor:
+    def op_avgpool(self, x: torch.Tensor, k: int, split: bool = False) -> torch.Tensor:
         self._chk(x, torch.bfloat16, "x")
         B, H, W, Cc = x.shape
         out = torch.empty((B, H // k, W // k, Cc), dtype=torch.bfloat16, device=self._tdev)
-        L.check(self.lib.pt_op_avgpool(self._h, _ptr(x), B, H, W, Cc, k, _ptr(out), self._stream()), "pt_op_avgpool")
+        L.check(self.lib.pt_op_avgpool(self._h, _ptr(x), B, H, W, Cc // 2 if split else Cc, k, _ptr(out), int(split), self._stream()), "pt_op_avgpool")
         return out
 
-    def op_chan_mean(self, x: torch.Tensor) -> torch.Tensor:
+    def op_chan_mean(self, x: torch.Tensor, split: bool = False) -> torch.Tensor:
         """GlobalAveragePool: [B, H, W, C] -> [B, 1, 1, C]"""
         self._chk(x, torch.bfloat16, "x")
         B, H, W, Cc = x.shape
-        scratch = torch.empty((self.lib.pt_op_chan_mean_scratch_floats(B, Cc),), dtype=torch.float32, device=self._tdev)
+        ch = Cc // 2 if split else Cc
+        scratch = torch.empty((self.lib.pt_op_chan_mean_scratch_floats(B, ch),), dtype=torch.float32, device=self._tdev)
         out = torch.empty((B, 1, 1, Cc), dtype=torch.bfloat16, device=self._tdev)
-        L.check(self.lib.pt_op_chan_mean(self._h, _ptr(x), B, H * W, Cc, _ptr(scratch), _ptr(out), self._stream()), "pt_op_chan_mean")
+        L.check(self.lib.pt_op_chan_mean(self._h, _ptr(x), B, H * W, ch, _ptr(scratch), _ptr(out), int(split), self._stream()), "pt_op_chan_mean")
         return out
 
-    def op_scale_channels(self, x: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
+    def op_scale_channels(self, x: torch.Tensor, gate: torch.Tensor, split: bool = False) -> torch.Tensor:
         self._chk(x, torch.bfloat16, "x")
         self._chk(gate, torch.bfloat16, "gate")
         B, H, W, Cc = x.shape
         if gate.numel() != B * Cc:
             raise ValueError(f"op_scale_channels: gate {tuple(gate.shape)} does not match [{B}, {Cc}]")
         out = torch.empty_like(x)
-        L.check(self.lib.pt_op_scale_channels(self._h, _ptr(x), _ptr(gate), B, H * W, Cc, _ptr(out), self._stream()), "pt_op_scale_channels")
+        L.check(self.lib.pt_op_scale_channels(self._h, _ptr(x), _ptr(gate), B, H * W, Cc // 2 if split else Cc, _ptr(out), int(split), self._stream()),
+                "pt_op_scale_channels")
         return out
 
-    def op_act(self, x: torch.Tensor, kind: int, alpha: float = 0.0, beta: float = 0.0) -> torch.Tensor:
+    def op_act(self, x: torch.Tensor, kind: int, alpha: float = 0.0, beta: float = 0.0, split: bool = False) -> torch.Tensor:
         self._chk(x, torch.bfloat16, "x")
         out = torch.empty_like(x)
-        L.check(self.lib.pt_op_act(self._h, _ptr(x), x.numel(), kind, float(alpha), float(beta), _ptr(out), self._stream()), "pt_op_act")
+        ch = x.shape[-1] // 2 if split else x.shape[-1]
+        L.check(self.lib.pt_op_act(self._h, _ptr(x), x.numel() // (2 if split else 1), kind, float(alpha), float(beta), _ptr(out), ch, int(split),
+                                   self._stream()), "pt_op_act")
         return out
 
     def op_copy_channels(self, src: torch.Tensor, dst: torch.Tensor, n: int, src_coff: int = 0, dst_coff: int = 0):
@@ -703,42 +709,47 @@ class HipEngine:
         L.check(self.lib.pt_op_upsample_nearest(self._h, _ptr(x), B, H, W, Cc, int(f), _ptr(out), self._stream()), "pt_op_upsample_nearest")
         return out
 
-    def op_mul(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    def op_mul(self, a: torch.Tensor, b: torch.Tensor, split: bool = False) -> torch.Tensor:
         self._chk(a, torch.bfloat16, "a")
         self._chk(b, torch.bfloat16, "b")
         if a.shape != b.shape:
             raise ValueError(f"op_mul: shapes differ: {tuple(a.shape)} vs {tuple(b.shape)}")
         out = torch.empty_like(a)
-        L.check(self.lib.pt_op_mul(self._h, _ptr(a), _ptr(b), _ptr(out), a.numel(), self._stream()), "pt_op_mul")
+        L.check(self.lib.pt_op_mul(self._h, _ptr(a), _ptr(b), _ptr(out), a.numel() // (2 if split else 1), a.shape[-1] // 2 if split else a.shape[-1], int(split),
+                                   self._stream()), "pt_op_mul")
         return out
 
-    def op_layernorm(self, x: torch.Tensor, c: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
+    def op_layernorm(self, x: torch.Tensor, c: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float, split: bool = False) -> torch.Tensor:
         self._chk(x, torch.bfloat16, "x")
         self._chk(gamma, torch.float32, "gamma")
         self._chk(beta, torch.float32, "beta")
         out = torch.empty_like(x)
-        L.check(self.lib.pt_op_layernorm(self._h, _ptr(x), x.numel() // x.shape[-1], x.shape[-1], int(c), _ptr(gamma), _ptr(beta), float(eps), _ptr(out),
+        cp = x.shape[-1] // 2 if split else x.shape[-1]
+        L.check(self.lib.pt_op_layernorm(self._h, _ptr(x), x.numel() // x.shape[-1], cp, int(c), _ptr(gamma), _ptr(beta), float(eps), _ptr(out), int(split),
                                          self._stream()), "pt_op_layernorm")
         return out
 
-    def op_softmax(self, x: torch.Tensor, c: int, f32: bool = False) -> torch.Tensor:
+    def op_softmax(self, x: torch.Tensor, c: int, f32: bool = False, split: bool = False) -> torch.Tensor:
         self._chk(x, torch.bfloat16, "x")
         rows = x.numel() // x.shape[-1]
+        cp = x.shape[-1] // 2 if split else x.shape[-1]
         if f32:
             out = torch.empty(x.shape[:-1] + (int(c),), dtype=torch.float32, device=self._tdev)
-            L.check(self.lib.pt_op_softmax(self._h, _ptr(x), rows, x.shape[-1], int(c), _ptr(out), None, self._stream()), "pt_op_softmax")
+            L.check(self.lib.pt_op_softmax(self._h, _ptr(x), rows, cp, int(c), _ptr(out), None, int(split), self._stream()), "pt_op_softmax")
         else:
             out = torch.empty_like(x)
-            L.check(self.lib.pt_op_softmax(self._h, _ptr(x), rows, x.shape[-1], int(c), None, _ptr(out), self._stream()), "pt_op_softmax")
+            L.check(self.lib.pt_op_softmax(self._h, _ptr(x), rows, cp, int(c), None, _ptr(out), int(split), self._stream()), "pt_op_softmax")
         return out
 
-    def op_attention(self, qkv: torch.Tensor, heads: int, d: int, scale: float, out_c: int) -> torch.Tensor:
-        """qkv bf16 [B, 1, T, >= 3 heads d] rows of [q | k | v] -> bf16 [B, 1, T, out_c] (channels heads * d .. out_c are zero)"""
+    def op_attention(self, qkv: torch.Tensor, heads: int, d: int, scale: float, out_c: int, split: bool = False) -> torch.Tensor:
+        """qkv bf16 [B, 1, T, >= 3 heads d] rows of [q | k | v] -> bf16 [B, 1, T, out_c] (channels heads * d .. out_c are zero); split: both tensors
+        carry [hi | lo] halves of that width"""
         self._chk(qkv, torch.bfloat16, "qkv")
         B, T = qkv.shape[0], qkv.shape[-2]
-        out = torch.zeros((B, 1, T, int(out_c)), dtype=torch.bfloat16, device=self._tdev)
-        L.check(self.lib.pt_op_attention(self._h, _ptr(qkv), B, T, int(heads), int(d), qkv.shape[-1], float(scale), _ptr(out), int(out_c), self._stream()),
-                "pt_op_attention")
+        m = 2 if split else 1
+        out = torch.zeros((B, 1, T, int(out_c) * m), dtype=torch.bfloat16, device=self._tdev)
+        L.check(self.lib.pt_op_attention(self._h, _ptr(qkv), B, T, int(heads), int(d), qkv.shape[-1] // m, float(scale), _ptr(out), int(out_c), int(split),
+                                         self._stream()), "pt_op_attention")
         return out
 
     def op_stem7x7(self, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, split: bool = False) -> torch.Tensor:

@@ -107,21 +107,21 @@ def _proto(lib):
         "pt_op_stem7x7": (i, [vp, vp, i, i, i, vp, vp, vp, i, vp]),
         "pt_op_maxpool3x3s2": (i, [vp, vp, i, i, i, i, vp, i, vp]),
         "pt_op_db_head_final": (i, [vp, vp, i, i, i, vp, vp, vp, vp, i, vp]),
-        "pt_op_dwconv": (i, [vp, vp, i, i, i, i, vp, vp, i, i, i, vp, vp]),
-        "pt_op_add": (i, [vp, vp, vp, vp, C.c_longlong, i, vp]),
-        "pt_op_maxpool": (i, [vp, vp, i, i, i, i, i, i, i, vp, vp]),
-        "pt_op_avgpool": (i, [vp, vp, i, i, i, i, i, vp, vp]),
-        "pt_op_chan_mean": (i, [vp, vp, i, i, i, vp, vp, vp]),
+        "pt_op_dwconv": (i, [vp, vp, i, i, i, i, vp, vp, i, i, i, vp, i, vp]),
+        "pt_op_add": (i, [vp, vp, vp, vp, C.c_longlong, i, i, vp]),
+        "pt_op_maxpool": (i, [vp, vp, i, i, i, i, i, i, i, vp, i, vp]),
+        "pt_op_avgpool": (i, [vp, vp, i, i, i, i, i, vp, i, vp]),
+        "pt_op_chan_mean": (i, [vp, vp, i, i, i, vp, vp, i, vp]),
         "pt_op_chan_mean_scratch_floats": (i, [i, i]),
-        "pt_op_scale_channels": (i, [vp, vp, vp, i, i, i, vp, vp]),
-        "pt_op_act": (i, [vp, vp, C.c_longlong, i, C.c_float, C.c_float, vp, vp]),
+        "pt_op_scale_channels": (i, [vp, vp, vp, i, i, i, vp, i, vp]),
+        "pt_op_act": (i, [vp, vp, C.c_longlong, i, C.c_float, C.c_float, vp, i, i, vp]),
         "pt_op_copy_channels": (i, [vp, vp, C.c_longlong, i, i, vp, i, i, i, vp]),
         "pt_op_upsample_nearest": (i, [vp, vp, i, i, i, i, i, vp, vp]),
-        "pt_op_mul": (i, [vp, vp, vp, vp, C.c_longlong, vp]),
+        "pt_op_mul": (i, [vp, vp, vp, vp, C.c_longlong, i, i, vp]),
         "pt_copy_bytes": (i, [vp, vp, vp, C.c_longlong, vp]),
-        "pt_op_layernorm": (i, [vp, vp, C.c_longlong, i, i, vp, vp, C.c_float, vp, vp]),
-        "pt_op_softmax": (i, [vp, vp, C.c_longlong, i, i, vp, vp, vp]),
-        "pt_op_attention": (i, [vp, vp, i, i, i, i, i, C.c_float, vp, i, vp]),
+        "pt_op_layernorm": (i, [vp, vp, C.c_longlong, i, i, vp, vp, C.c_float, vp, i, vp]),
+        "pt_op_softmax": (i, [vp, vp, C.c_longlong, i, i, vp, vp, i, vp]),
+        "pt_op_attention": (i, [vp, vp, i, i, i, i, i, C.c_float, vp, i, i, vp]),
         "pt_profile_enable": (i, [vp, i]),
         "pt_profile_read": (i, [vp, vp, vp, vp]),
         "pt_profile_read_labels": (i, [vp, C.c_char_p, i]),

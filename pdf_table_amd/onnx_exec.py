@@ -29,8 +29,13 @@ graphs on the CPU for the tests only).  Supported today: Conv (groups 1: 1x1 / 3
 "same" padding), ConvTranspose 2x2 / stride 2, BatchNormalization (folded), Relu / HardSwish / Sigmoid / HardSigmoid /
 Relu6, a BatchNormalization that stands alone, Add, Mul by a per-channel gate, MaxPool(3, 2, 1) and k x k / stride k,
 AveragePool k x k / stride k, GlobalAveragePool, Resize / Upsample (nearest, integer factor, by scales or sizes), Concat over
-channels, Gemm / Flatten after a global pool.  Arithmetic is PT_PRECISION_BF16 (bf16
-operands, fp32 accumulate); the hi/lo mode of the dedicated graphs is not wired here.
+channels, Gemm / Flatten after a global pool.
+
+Two arithmetic modes, like the dedicated launch graphs (``precision=`` of the constructor): ``"bf16"`` -- bf16 operands, fp32 accumulate, every
+activation rounded to bf16 (the throughput mode) -- and ``"bf16x3"``, the tolerance mode: every activation is a (hi | lo) pair of bf16 halves
+(``_Act.t[..., :Cp]`` and ``[..., Cp:]``, value = hi + lo: 16 significant bits), convolutions / GEMMs run as three MFMA passes over (hi, lo) weight
+tiles, every other operator computes on hi + lo in fp32 and splits its result again (``split`` of the pt_op_* entry points, ABI 12).  This is the
+mode whose outputs agree with an fp32 execution of the graph (oracle/onnx_ref.py; onnxruntime in the reference) to 1e-3.
 """
 from __future__ import annotations
 
@@ -42,7 +47,7 @@ import torch
 
 from .engine import HipEngine
 from .onnx_import import Layer, OnnxGraph, UnsupportedOnnxGraph, load_onnx
-from .weights import tile_conv_weight
+from .weights import split_bf16, tile_conv_weight, tile_conv_weight_x3
 
 __all__ = ["HipGraphExecutor"]
 
@@ -92,7 +97,12 @@ class _Scores:
 
 
 class HipGraphExecutor:
-    def __init__(self, src, engine: Optional[HipEngine] = None, device: int = 0):
+    def __init__(self, src, engine: Optional[HipEngine] = None, device: int = 0, precision: str = "bf16"):
+        if precision not in ("bf16", "bf16x3"):
+            raise ValueError(f"precision '{precision}': 'bf16' (throughput) or 'bf16x3' (tolerance mode, (hi | lo) activations)")
+        self.precision = precision
+        self.split = precision == "bf16x3"
+        self.m = 2 if self.split else 1                   # halves per activation: .t[..., :Cp] = hi, .t[..., Cp:] = lo
         self.graph: OnnxGraph = src if isinstance(src, OnnxGraph) else load_onnx(src)
         self.eng = engine or HipEngine(device)
         self.layers: List[Layer] = self.graph.layers()
@@ -125,9 +135,35 @@ class HipGraphExecutor:
         bp = torch.zeros(_pad64(n))
         if lay.bias is not None:
             bp[:n] = torch.from_numpy(lay.bias)
-        d = {"cin_pad": cin_pad, "w": self._up(tile_conv_weight(wp).view(np.int16)), "b": bp.to(self.eng._tdev), "n": n}
+        d = {"cin_pad": cin_pad, "w": self._up(self._tile(wp).view(np.int16)), "b": bp.to(self.eng._tdev), "n": n}
         self._dev[k] = d
         return d
+
+    def _tile(self, w: torch.Tensor) -> np.ndarray:
+        return tile_conv_weight_x3(w) if self.split else tile_conv_weight(w)
+
+    def _cp(self, x: _Act) -> int:
+        """padded channels of ONE half"""
+        return x.t.shape[-1] // self.m
+
+    def _zeros(self, lead, cp: int) -> torch.Tensor:
+        return torch.zeros(tuple(lead) + (cp * self.m,), dtype=torch.bfloat16, device=self.eng._tdev)
+
+    def _copy(self, src: torch.Tensor, dst: torch.Tensor, n: int, src_coff: int = 0, dst_coff: int = 0):
+        """channels [src_coff, src_coff + n) of src -> [dst_coff, ..) of dst, both halves in the tolerance mode"""
+        self.eng.op_copy_channels(src, dst, n, src_coff=src_coff, dst_coff=dst_coff)
+        if self.split:
+            self.eng.op_copy_channels(src, dst, n, src_coff=src.shape[-1] // 2 + src_coff, dst_coff=dst.shape[-1] // 2 + dst_coff)
+
+    def values(self, a: _Act) -> torch.Tensor:
+        """the real channels of an activation as fp32 (hi + lo in the tolerance mode); a final fp32 Softmax is returned as it is"""
+        if a.t.dtype == torch.float32:
+            return a.t[..., :a.c]
+        v = a.t[..., :a.c].float()
+        if self.split:
+            cp = a.t.shape[-1] // 2
+            v = v + a.t[..., cp:cp + a.c].float()
+        return v
 
     # ---- layers ----------------------------------------------------------------------------------------------------
     def _conv(self, k: int, lay: Layer, x: _Act) -> _Act:
@@ -152,28 +188,35 @@ class HipGraphExecutor:
                 if lay.bias is not None:
                     bp[:n0] = torch.from_numpy(lay.bias)
                 from .weights import to_bf16_bits
-                d = self._dev[k] = {"w": self._up(to_bf16_bits(stem).reshape(64, 224).view(np.int16)), "b": bp.to(self.eng._tdev), "n": n0}
+                if self.split:
+                    sh, sl = split_bf16(stem)
+                    wst = np.stack([to_bf16_bits(sh).reshape(64, 224), to_bf16_bits(sl).reshape(64, 224)])
+                else:
+                    wst = to_bf16_bits(stem).reshape(64, 224)
+                d = self._dev[k] = {"w": self._up(wst.view(np.int16)), "b": bp.to(self.eng._tdev), "n": n0}
             if x.t.shape[1] % 2 or x.t.shape[2] % 2:
                 raise UnsupportedOnnxGraph(f"{lay.name}: the 7x7 / stride-2 stem kernel needs even image sizes")
-            return _Act(self.eng.op_stem7x7(x.t[..., :4].contiguous(), d["w"], d["b"]), d["n"])
+            x4 = self._zeros(x.t.shape[:-1], 4)           # NHWC4 image ([hi rgb0 | lo rgb0] in the tolerance mode)
+            self._copy(x.t, x4, 3)
+            return _Act(self.eng.op_stem7x7(x4, d["w"], d["b"], split=self.split), d["n"])
         if a["group"] == 1:
             if kh not in (1, 3):
                 raise UnsupportedOnnxGraph(f"{lay.name}: {kh}x{kw} convolution (the MFMA kernel covers 1x1 and 3x3)")
-            d = self._conv_operands(k, lay, x.t.shape[-1], x.c)
-            y = _Act(self.eng.op_conv2d(x.t, d["w"], d["b"], kh, sh, relu=fused), d["n"])
+            d = self._conv_operands(k, lay, self._cp(x), x.c)
+            y = _Act(self.eng.op_conv2d(x.t, d["w"], d["b"], kh, sh, relu=fused, split=int(self.split)), d["n"])
         elif a["group"] == x.c and lay.weight.shape[0] == x.c and lay.weight.shape[1] == 1:
             if kh not in (3, 5):
                 raise UnsupportedOnnxGraph(f"{lay.name}: depthwise {kh}x{kw} (3x3 and 5x5 are built)")
             d = self._dev.get(k)
             if d is None:
-                cp = x.t.shape[-1]
+                cp = self._cp(x)
                 wt = np.zeros((kh * kw, cp), np.float32)
                 wt[:, :x.c] = lay.weight.reshape(x.c, kh * kw).T
                 bt = np.zeros((cp,), np.float32)
                 if lay.bias is not None:
                     bt[:x.c] = lay.bias
                 d = self._dev[k] = {"w": self._up(wt), "b": self._up(bt)}
-            y = _Act(self.eng.op_dwconv(x.t, d["w"], d["b"], kh, sh, fused), x.c)
+            y = _Act(self.eng.op_dwconv(x.t, d["w"], d["b"], kh, sh, fused, split=self.split), x.c)
         else:
             raise UnsupportedOnnxGraph(f"{lay.name}: grouped convolution (group {a['group']} of {x.c} channels)")
         return self._post_act(lay, y, post)
@@ -186,17 +229,17 @@ class HipGraphExecutor:
         if d is None:
             w = torch.from_numpy(lay.weight)                       # [ci, co, 2, 2]
             ci, co = w.shape[:2]
-            cop, cip = _pad64(co), x.t.shape[-1]
+            cop, cip = _pad64(co), self._cp(x)
             wq = torch.zeros(2, 2, cop, cip)
             wq[:, :, :co, :ci] = w.permute(2, 3, 1, 0)              # N index = (dy * 2 + dx) * cop + co: the pixel-shuffle epilogue
             bq = torch.zeros(cop)
             if lay.bias is not None:
                 bq[:co] = torch.from_numpy(lay.bias)
-            d = self._dev[k] = {"w": self._up(tile_conv_weight(wq.reshape(4 * cop, cip, 1, 1)).view(np.int16)),
+            d = self._dev[k] = {"w": self._up(self._tile(wq.reshape(4 * cop, cip, 1, 1)).view(np.int16)),
                                 "b": bq.repeat(4).to(self.eng._tdev), "n": co, "cop": cop}
         fused = _ACT_CODE.get(lay.act, None) if lay.act in _ACT_CODE else 0
         post = None if lay.act in _ACT_CODE else lay.act
-        y = _Act(self.eng.op_conv2d(x.t, d["w"], d["b"], 1, 1, relu=fused, shuffle_cout=d["cop"]), d["n"])
+        y = _Act(self.eng.op_conv2d(x.t, d["w"], d["b"], 1, 1, relu=fused, shuffle_cout=d["cop"], split=int(self.split)), d["n"])
         return self._post_act(lay, y, post)
 
     def _post_act(self, lay: Layer, y: _Act, kind: Optional[str]) -> _Act:
@@ -204,16 +247,7 @@ class HipGraphExecutor:
             return y
         if kind not in _ACT_KIND:
             raise UnsupportedOnnxGraph(f"{lay.name}: activation '{kind}'")
-        return _Act(self.eng.op_act(y.t, _ACT_KIND[kind], lay.attrs.get("act_alpha", 0.2), lay.attrs.get("act_beta", 0.5)), y.c, y.flat, y.seq)
-
-    @staticmethod
-    def _repad(t: torch.Tensor, c: int) -> torch.Tensor:
-        cp = _pad64(c)
-        if t.shape[-1] == cp:
-            return t.contiguous()
-        out = torch.zeros(t.shape[:-1] + (cp,), dtype=t.dtype, device=t.device)
-        out[..., :c] = t[..., :c]
-        return out
+        return _Act(self.eng.op_act(y.t, _ACT_KIND[kind], lay.attrs.get("act_alpha", 0.2), lay.attrs.get("act_beta", 0.5), split=self.split), y.c, y.flat, y.seq)
 
     # ---- the graph -------------------------------------------------------------------------------------------------
     def run(self, x) -> List[np.ndarray]:
@@ -222,11 +256,13 @@ class HipGraphExecutor:
         if xt.ndim != 4:
             raise ValueError(f"expected an NCHW batch, got shape {tuple(xt.shape)}")
         outs = []
-        for a in self.run_device(xt.permute(0, 2, 3, 1).to(self.eng._tdev).to(torch.bfloat16), xt.shape[1]):
+        nhwc = xt.permute(0, 2, 3, 1).to(self.eng._tdev)
+        for a in self.run_device(nhwc if self.split else nhwc.to(torch.bfloat16), xt.shape[1]):
+            v = self.values(a)
             if a.seq:                                    # token rows: [B, T, C]
-                outs.append(a.t[:, 0, :, :a.c].float().contiguous().cpu().numpy())
+                outs.append(v[:, 0].contiguous().cpu().numpy())
                 continue
-            o = a.t[..., :a.c].float().permute(0, 3, 1, 2).contiguous().cpu().numpy()
+            o = v.permute(0, 3, 1, 2).contiguous().cpu().numpy()
             outs.append(o.reshape(o.shape[0], -1) if a.flat else o)
         return outs
 
@@ -286,8 +322,8 @@ class HipGraphExecutor:
                                    "(built: map <-> token rows, channel slices, the head split of fused q / k / v rows)")
 
     def _slice_channels(self, b: _Act, c0: int, cn: int) -> _Act:
-        out = torch.zeros(b.t.shape[:-1] + (_pad64(cn),), dtype=torch.bfloat16, device=self.eng._tdev)
-        self.eng.op_copy_channels(b.t, out, cn, src_coff=c0, dst_coff=0)
+        out = self._zeros(b.t.shape[:-1], _pad64(cn))
+        self._copy(b.t, out, cn, src_coff=c0, dst_coff=0)
         return _Act(out, cn, flat=b.flat, seq=b.seq)
 
     def _glue(self, lay: Layer, env) -> list:
@@ -374,7 +410,7 @@ class HipGraphExecutor:
                     + np.arange(a.heads)[None, :, None, None] * a.d + np.arange(a.d)[None, None, None, :])
             if b.base is not base or b.idx.shape != want.shape or not np.array_equal(b.idx, want) or b.scale != 1.0:
                 raise UnsupportedOnnxGraph(f"{lay.name}: the value operand is not the v part of the fused q / k / v rows")
-            out = _Act(self.eng.op_attention(base.t, a.heads, a.d, a.scale, _pad64(C)), C, seq=True)
+            out = _Act(self.eng.op_attention(base.t, a.heads, a.d, a.scale, _pad64(C), split=self.split), C, seq=True)
             idx = ((np.arange(B)[:, None, None, None] * T + np.arange(T)[None, None, :, None]) * C
                    + np.arange(a.heads)[None, :, None, None] * a.d + np.arange(a.d)[None, None, None, :])
             return _View(out, idx)
@@ -393,10 +429,18 @@ class HipGraphExecutor:
 
     def run_device(self, nhwc: torch.Tensor, c: int) -> List[_Act]:
         """bf16 NHWC batch on the device whose first ``c`` channels are the image (what pt_det_preprocess / pt_cls_preprocess
-        write) -> the graph outputs as device activations (bf16 NHWC, ``.t[..., :.c]`` are the real channels): no host trip"""
+        write) -> the graph outputs as device activations (bf16 NHWC, ``.t[..., :.c]`` are the real channels; ``values()`` gives them as fp32 in
+        either mode): no host trip.  Tolerance mode: an fp32 batch is split into its (hi, lo) halves here (a cast: plumbing), a bf16 batch has lo = 0."""
         cp = (c + 31) // 32 * 32                         # the image itself: 32 channels are enough for the first GEMM's K
-        first = torch.zeros(nhwc.shape[:-1] + (cp,), dtype=torch.bfloat16, device=self.eng._tdev)
-        self.eng.op_copy_channels(nhwc.contiguous(), first, c)
+        first = self._zeros(nhwc.shape[:-1], cp)
+        if nhwc.dtype == torch.float32:
+            hi = nhwc[..., :c].to(torch.bfloat16)
+            self.eng.op_copy_channels(hi.contiguous(), first, c)
+            if self.split:
+                lo = (nhwc[..., :c] - hi.float()).to(torch.bfloat16)
+                self.eng.op_copy_channels(lo.contiguous(), first, c, dst_coff=cp)
+        else:
+            self.eng.op_copy_channels(nhwc.contiguous(), first, c)
         env: Dict[str, object] = {self.inputs[0].name: _Act(first, c)}
         R = self._realize
         for k, lay in enumerate(self.layers):
@@ -437,13 +481,13 @@ class HipGraphExecutor:
                 kk, st, pd = a["kernel"], a["strides"], a["pads"]
                 if kk[0] != kk[1] or st[0] != st[1] or len(set(pd)) != 1 or a.get("ceil_mode"):
                     raise UnsupportedOnnxGraph(f"{lay.name}: MaxPool {a}")
-                y = _Act(self.eng.op_maxpool(ins[0].t, kk[0], st[0], pd[0]), ins[0].c)
+                y = _Act(self.eng.op_maxpool(ins[0].t, kk[0], st[0], pd[0], split=self.split), ins[0].c)
             elif op == "avgpool":
                 a = lay.attrs
                 kk, st, pd = a["kernel"], a["strides"], a["pads"]
                 if kk[0] != kk[1] or st != kk or any(pd) or a.get("ceil_mode") or ins[0].t.shape[1] % kk[0] or ins[0].t.shape[2] % kk[0]:
                     raise UnsupportedOnnxGraph(f"{lay.name}: AveragePool {a} (k x k / stride k without padding is built)")
-                y = _Act(self.eng.op_avgpool(ins[0].t, kk[0]), ins[0].c)
+                y = _Act(self.eng.op_avgpool(ins[0].t, kk[0], split=self.split), ins[0].c)
             elif op == "bn":
                 # a BatchNormalization that could not be folded into a convolution: per-channel affine = a depthwise 3x3 whose only
                 # non-zero tap is the centre one
@@ -451,15 +495,15 @@ class HipGraphExecutor:
                 if d is None:
                     e_ = lay.extra
                     sc = e_["gamma"].astype(np.float64) / np.sqrt(e_["var"].astype(np.float64) + lay.attrs["epsilon"])
-                    cp = ins[0].t.shape[-1]
+                    cp = self._cp(ins[0])
                     wt = np.zeros((9, cp), np.float32)
                     wt[4, :ins[0].c] = sc
                     bt = np.zeros((cp,), np.float32)
                     bt[:ins[0].c] = e_["beta"].astype(np.float64) - e_["mean"].astype(np.float64) * sc
                     d = self._dev[k] = {"w": self._up(wt), "b": self._up(bt)}
-                y = _Act(self.eng.op_dwconv(ins[0].t, d["w"], d["b"], 3, 1, 0), ins[0].c)
+                y = _Act(self.eng.op_dwconv(ins[0].t, d["w"], d["b"], 3, 1, 0, split=self.split), ins[0].c)
             elif op == "gap":
-                y = _Act(self.eng.op_chan_mean(ins[0].t), ins[0].c)
+                y = _Act(self.eng.op_chan_mean(ins[0].t, split=self.split), ins[0].c)
             elif op == "layernorm":
                 x = ins[0]
                 if not (x.seq or x.flat):
@@ -471,23 +515,23 @@ class HipGraphExecutor:
                                         "b": self._up(np.zeros(x.c, np.float32) if b_ is None else b_.astype(np.float32))}
                 if d["g"].numel() != x.c:
                     raise UnsupportedOnnxGraph(f"{lay.name}: LayerNormalization scale has {d['g'].numel()} entries, the rows {x.c} channels")
-                y = _Act(self.eng.op_layernorm(x.t, x.c, d["g"], d["b"], lay.attrs["epsilon"]), x.c, x.flat, x.seq)
+                y = _Act(self.eng.op_layernorm(x.t, x.c, d["g"], d["b"], lay.attrs["epsilon"], split=self.split), x.c, x.flat, x.seq)
             elif op == "add":
                 if len(ins) != 2 or lay.extra:
                     raise UnsupportedOnnxGraph(f"{lay.name}: Add with a constant operand")
                 if ins[0].t.shape != ins[1].t.shape:
                     raise UnsupportedOnnxGraph(f"{lay.name}: Add of {tuple(ins[0].t.shape)} and {tuple(ins[1].t.shape)} (broadcasting is not built)")
-                y = _Act(self.eng.op_add(ins[0].t, ins[1].t), ins[0].c, ins[0].flat, ins[0].seq)
+                y = _Act(self.eng.op_add(ins[0].t, ins[1].t, split=self.split), ins[0].c, ins[0].flat, ins[0].seq)
             elif op == "mul":
                 if len(ins) != 2 or lay.extra:
                     raise UnsupportedOnnxGraph(f"{lay.name}: Mul with a constant operand")
                 if ins[0].t.shape == ins[1].t.shape:
-                    y = _Act(self.eng.op_mul(ins[0].t, ins[1].t), ins[0].c, ins[0].flat, ins[0].seq)
+                    y = _Act(self.eng.op_mul(ins[0].t, ins[1].t, split=self.split), ins[0].c, ins[0].flat, ins[0].seq)
                 else:
                     big, gate = (ins[0], ins[1]) if ins[0].t.shape[1] * ins[0].t.shape[2] >= ins[1].t.shape[1] * ins[1].t.shape[2] else (ins[1], ins[0])
                     if gate.t.shape[1] != 1 or gate.t.shape[2] != 1:
                         raise UnsupportedOnnxGraph(f"{lay.name}: Mul of two differently shaped feature maps (equal shapes and a per-channel gate [B, C, 1, 1] are built)")
-                    y = _Act(self.eng.op_scale_channels(big.t, gate.t), big.c)
+                    y = _Act(self.eng.op_scale_channels(big.t, gate.t, split=self.split), big.c)
             elif op == "act":
                 if lay.attrs["kind"] == "softmax":
                     x = ins[0]
@@ -495,7 +539,7 @@ class HipGraphExecutor:
                         raise UnsupportedOnnxGraph(f"{lay.name}: Softmax over axis {lay.attrs.get('axis')} of a {x.shape()} tensor (the channel axis of token rows is built)")
                     # a Softmax that IS a graph output (the probabilities a CTC decoder / classifier reads) stays fp32 [.., c]: bf16 probabilities have 8
                     # significant bits, so near-equal classes tie and the arg-max / confidence would differ from onnxruntime's fp32 ones
-                    y = _Act(self.eng.op_softmax(x.t, x.c, f32=lay.outputs[0] in self.outputs), x.c, x.flat, x.seq)
+                    y = _Act(self.eng.op_softmax(x.t, x.c, f32=lay.outputs[0] in self.outputs, split=self.split), x.c, x.flat, x.seq)
                 else:
                     y = self._post_act(lay, ins[0], lay.attrs["kind"])
             elif op == "resize":
@@ -511,10 +555,10 @@ class HipGraphExecutor:
                 if lay.attrs["axis"] != 1 or any(i.seq or i.flat for i in ins):
                     raise UnsupportedOnnxGraph(f"{lay.name}: Concat over axis {lay.attrs['axis']}")
                 cc = sum(i.c for i in ins)
-                out = torch.zeros(ins[0].t.shape[:-1] + (_pad64(cc),), dtype=torch.bfloat16, device=self.eng._tdev)
+                out = self._zeros(ins[0].t.shape[:-1], _pad64(cc))
                 o_ = 0
                 for i in ins:
-                    self.eng.op_copy_channels(i.t, out, i.c, dst_coff=o_)
+                    self._copy(i.t, out, i.c, dst_coff=o_)
                     o_ += i.c
                 y = _Act(out, cc)
             elif op == "gemm":
@@ -522,8 +566,8 @@ class HipGraphExecutor:
                 if not src.seq and (src.t.shape[1] != 1 or src.t.shape[2] != 1):
                     raise UnsupportedOnnxGraph(f"{lay.name}: Gemm on a {tuple(src.t.shape)} feature map (token rows and pooled vectors are built)")
                 lay2 = Layer("conv", lay.name, lay.inputs, lay.outputs, {}, weight=lay.weight.reshape(lay.weight.shape[0], -1, 1, 1), bias=lay.bias)
-                d = self._conv_operands(k, lay2, src.t.shape[-1], src.c)
-                y = _Act(self.eng.op_conv2d(src.t, d["w"], d["b"], 1, 1), d["n"], not src.seq, src.seq)
+                d = self._conv_operands(k, lay2, self._cp(src), src.c)
+                y = _Act(self.eng.op_conv2d(src.t, d["w"], d["b"], 1, 1, split=int(self.split)), d["n"], not src.seq, src.seq)
             else:
                 raise UnsupportedOnnxGraph(f"{lay.name}: layer kind '{op}' has no executor")
             for o in lay.outputs:

@@ -105,13 +105,13 @@ def eng():
     e.close()
 
 
-def _check(model, x, eng, tol_rel):
+def _check(model, x, eng, tol_rel, precision="bf16"):
     from onnx_export import torch_export
     from oracle import onnx_ref
     from pdf_table_amd.onnx_exec import HipGraphExecutor
     from pdf_table_amd.onnx_proto import parse_model
     blob = torch_export(model, x)
-    ex = HipGraphExecutor(blob, engine=eng)
+    ex = HipGraphExecutor(blob, engine=eng, precision=precision)
     (got,) = ex.run(x.numpy())
     (again,) = ex.run(x.numpy())                      # operands are cached after the first run
     with torch.no_grad():
@@ -122,7 +122,7 @@ def _check(model, x, eng, tol_rel):
     scale = float(np.abs(want).max())
     assert np.abs(ref - want).max() <= 1e-4 * max(scale, 1.0)        # the exported graph is the module
     d = float(np.abs(got - want).max())
-    print(f"{type(model).__name__}: max|d| = {d:.3e} on scale {scale:.2f} ({len(ex.layers)} layers)")
+    print(f"{type(model).__name__} [{precision}]: max|d| = {d:.3e} on scale {scale:.2f} ({len(ex.layers)} layers)")
     assert d <= tol_rel * scale + 1e-3
     return ex
 
@@ -135,6 +135,24 @@ def test_lcnet_like_classifier(eng):
     ex = _check(m, x, eng, 4e-2)
     kinds = {l.op for l in ex.layers}
     assert {"conv", "gap", "mul", "gemm"} <= kinds
+
+
+def test_lcnet_like_classifier_tolerance_mode(eng):
+    """the same graph in the executor's tolerance mode (precision="bf16x3": (hi | lo) activations, three-pass convolutions, every other operator on
+    hi + lo in fp32): within 1e-3 of the fp32 module (north_star's bound on float logits) -- depthwise, SE pool / gate / scale, hardswish /
+    hardsigmoid, Gemm"""
+    torch.manual_seed(0)
+    m = _randomise(LcNetLike(), 1)
+    x = torch.randn(3, 3, 64, 96)
+    _check(m, x, eng, 1e-3, precision="bf16x3")
+
+
+def test_fpn_like_detector_tolerance_mode(eng):
+    """MaxPool(3,2,1), residual Add, nearest x2 Resize, Concat, 2x2 transposed convs (pixel-shuffle GEMM), Sigmoid in the tolerance mode: 1e-3"""
+    torch.manual_seed(0)
+    m = _randomise(FpnLike(), 2)
+    x = torch.randn(2, 3, 64, 96)
+    _check(m, x, eng, 1e-3, precision="bf16x3")
 
 
 def test_fpn_like_detector(eng):

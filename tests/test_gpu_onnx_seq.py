@@ -48,6 +48,44 @@ def test_svtr_tiny_recogniser(eng, act):
     assert np.array_equal(got, again)
 
 
+@pytest.mark.parametrize("act", ["gelu", "silu"])
+def test_svtr_tiny_recogniser_tolerance_mode(eng, act):
+    """the SVTR-type recogniser in the executor's tolerance mode (precision="bf16x3"): LayerNorm, fused-qkv attention, GELU / swish, Softmax on
+    (hi | lo) token rows, three-pass GEMMs -- probabilities within 1e-3 of the fp32 module, arg-max identical outside its own <= 2e-3 ties"""
+    import onnx_export as X
+    from pdf_table_amd.onnx_exec import HipGraphExecutor
+    m = X.seeded(X.SvtrTiny(act=act), 11)
+    x = torch.randn(3, 3, 32, 64, generator=torch.Generator().manual_seed(5))
+    ex = HipGraphExecutor(X.torch_export(m, x), engine=eng, precision="bf16x3")
+    got = ex.run(x.numpy())[0]
+    with torch.no_grad():
+        want = m(x).numpy()
+    d = float(np.abs(got - want).max())
+    top2 = np.sort(want, -1)[..., -2:]
+    tie = (top2[..., 1] - top2[..., 0]) <= 2e-3
+    diff = got.argmax(-1) != want.argmax(-1)
+    print(f"SvtrTiny[{act}] bf16x3: max|d prob| = {d:.3e}; arg-max differs on {int(diff.sum())} tokens ({int((diff & ~tie).sum())} off a tie)")
+    assert d <= 1e-3 and not (diff & ~tie).any()
+    assert np.abs(got.sum(-1) - 1.0).max() <= 1e-4
+
+
+def test_picodet_shaped_outputs_tolerance_mode(eng):
+    import onnx_export as X
+    from pdf_table_amd.onnx_exec import HipGraphExecutor
+    m = X.seeded(X.PicoLike(), 12)
+    x = torch.randn(2, 3, 64, 96, generator=torch.Generator().manual_seed(6))
+    ex = HipGraphExecutor(X.torch_export(m, x), engine=eng, precision="bf16x3")
+    got = ex.run(x.numpy())
+    with torch.no_grad():
+        want = [w.numpy() for w in m(x)]
+    worst = 0.0
+    for g, w in zip(got, want):
+        assert g.shape == w.shape
+        worst = max(worst, float(np.abs(g - w).max()) / max(1.0, float(np.abs(w).max())))
+    print(f"PicoLike bf16x3: worst max|d| / scale over six outputs = {worst:.3e}")
+    assert worst <= 1e-3
+
+
 def test_picodet_shaped_outputs(eng):
     """three levels, per level scores = sigmoid(conv[:, :ncls]) and distributions = conv[:, ncls:], each flatten(2).permute(0, 2, 1): six outputs,
     first half scores, second half distributions -- what OcrLayoutTask.get_onnx_output_dict splits (ocr_layout_task.py:159-175)"""
