@@ -45,6 +45,9 @@ class BaseInferTask(metaclass=ABCMeta):
         self._custom_model = False
         self._num_threads = kwargs.get("num_threads", math.ceil(cpu_count() / 2))
         self._infer_precision = kwargs.get("precision", "bf16")
+        # arithmetic of a generic ONNX graph (pdf_table_amd/onnx_exec.py): "fp32" / "bf16x3" select the executor's tolerance mode ((hi | lo) activations,
+        # outputs within 1e-3 of an fp32 execution); everything else, the reference's default "fp16" included, the bf16 throughput mode
+        self._exec_precision = "bf16x3" if str(self._infer_precision).lower() in ("fp32", "bf16x3", "float32") else "bf16"
         self._predictor_type = kwargs.get("predictor_type", "hip")
         self._home_path = kwargs.get("home_path", os.path.expanduser("~/.cache/pdftable/outputs"))
         self._task_flag = kwargs.get("task_flag", self.model)

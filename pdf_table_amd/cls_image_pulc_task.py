@@ -64,7 +64,7 @@ class ClsImagePulcTask(BaseInferTask):
                 pass
             if sd is None:
                 from .onnx_exec import HipGraphExecutor
-                self._exec = HipGraphExecutor(graph, engine=self._engine)
+                self._exec = HipGraphExecutor(graph, engine=self._engine, precision=self._exec_precision)
                 if len(self._exec.outputs) != 1:
                     raise UnsupportedOnnxGraph(f"{onnx_path}: a classifier returns one [B, classes] tensor, this graph returns {self._exec.outputs}")
                 self._softmax_in_graph = any(l.op == "act" and l.attrs.get("kind") == "softmax" for l in self._exec.layers[-2:])
@@ -105,7 +105,7 @@ class ClsImagePulcTask(BaseInferTask):
             if not a.flat or a.c != ncls:
                 from .onnx_import import UnsupportedOnnxGraph
                 raise UnsupportedOnnxGraph(f"classifier output of shape {a.shape()}: [B, {ncls}] is expected for task '{self.task_type}'")
-            rows.append(a.t[:, 0, 0, :a.c].float())
+            rows.append(self._exec.values(a)[:, 0, 0])
         y = torch.cat(rows, 0)
         return torch.log(y.clamp_min(1e-30)) if self._softmax_in_graph and self.task_type != "table_attribute" else y
 

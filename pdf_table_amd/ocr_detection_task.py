@@ -95,7 +95,7 @@ class OcrDetectionTask(BaseInferTask):
                 # RSE-FPN + DB head): the layer list runs operator by operator between the engine's pre-processing and
                 # its bitmap / box-score kernels; an operator without a kernel is named when the first batch reaches it
                 from .onnx_exec import HipGraphExecutor
-                ex = HipGraphExecutor(graph, engine=self._engine)
+                ex = HipGraphExecutor(graph, engine=self._engine, precision=self._exec_precision)
                 if len(ex.outputs) != 1:
                     raise UnsupportedOnnxGraph(f"{onnx_path}: a text detector returns one probability map, this graph returns {ex.outputs}")
 
@@ -103,7 +103,7 @@ class OcrDetectionTask(BaseInferTask):
                     (a,) = _ex.run_device(x4, 3)
                     if a.c != 1:
                         raise UnsupportedOnnxGraph(f"{onnx_path}: the output has {a.c} channels, a probability map has one")
-                    return a.t[..., 0].float().contiguous()
+                    return _ex.values(a)[..., 0].contiguous()
                 self._net = net
             else:
                 raise UnsupportedOnnxGraph(f"{onnx_path} is a '{arch}' network, not a text detector the engine runs")

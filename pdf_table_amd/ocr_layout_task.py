@@ -56,7 +56,7 @@ class OcrLayoutTask(BaseInferTask):
         if onnx_path is not None:
             from .onnx_exec import HipGraphExecutor
             from .onnx_import import UnsupportedOnnxGraph
-            self._exec = HipGraphExecutor(onnx_path, engine=self._engine)      # raises UnsupportedOnnxGraph naming an operator without a kernel
+            self._exec = HipGraphExecutor(onnx_path, engine=self._engine, precision=self._exec_precision)      # raises UnsupportedOnnxGraph naming an operator without a kernel
             if len(self._exec.outputs) % 2 or not self._exec.outputs:
                 raise UnsupportedOnnxGraph(f"{onnx_path}: a PicoDet export returns 2 L tensors (L score maps, then L box distributions), "
                                            f"this graph returns {self._exec.outputs}")
@@ -111,7 +111,7 @@ class OcrLayoutTask(BaseInferTask):
             if not a.seq:
                 from .onnx_import import UnsupportedOnnxGraph
                 raise UnsupportedOnnxGraph(f"layout graph output of shape {a.shape()}: [B, anchors, channels] tensors are expected")
-            outs.append(a.t[:, 0, :, :a.c].float().cpu().numpy())
+            outs.append(self._exec.values(a)[:, 0].cpu().numpy())
         d = self.get_onnx_output_dict(outs)
         if any(s_.shape[-1] != ncls for s_ in d["boxes"]) or any(b_.shape[-1] != 32 for b_ in d["boxes_num"]):
             from .onnx_import import UnsupportedOnnxGraph

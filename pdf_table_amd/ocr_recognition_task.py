@@ -70,7 +70,7 @@ class OcrRecognitionTask(BaseInferTask):
                                f"download '{self._config.model_path}' from the hub (no network here); pass task_path=<dir or file>")
         if self._engine is None:
             self._engine = HipEngine(int(str(self.device).split(":")[-1]) if ":" in str(self.device) else 0)
-        self._exec = HipGraphExecutor(onnx_path, engine=self._engine)
+        self._exec = HipGraphExecutor(onnx_path, engine=self._engine, precision=self._exec_precision)
         if len(self._exec.outputs) != 1:
             from .onnx_import import UnsupportedOnnxGraph
             raise UnsupportedOnnxGraph(f"{onnx_path}: a CTC recogniser returns one [B, T, classes] tensor, this graph returns {self._exec.outputs}")
@@ -93,12 +93,14 @@ class OcrRecognitionTask(BaseInferTask):
             img = b["image"]                                     # f32 [n, 3, 48, imgW] on the device
             confs, idss = [], []
             for i in range(img.shape[0]):                        # one line per run: static exports have their batch size baked in
-                x = img[i:i + 1].permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
+                x = img[i:i + 1].permute(0, 2, 3, 1).contiguous()
+                if not self._exec.split:                     # the tolerance mode takes the fp32 image and splits it into (hi, lo) itself
+                    x = x.to(torch.bfloat16)
                 (a,) = self._exec.run_device(x, 3)
                 if not a.seq or a.c != len(self._ctc.character):
                     raise UnsupportedOnnxGraph(f"recogniser output of shape {a.shape()}: [B, T, {len(self._ctc.character)}] (blank + dictionary"
                                                " + space) is expected")
-                conf, ids = a.t[0, 0, :, :a.c].float().max(-1)    # fp32 probabilities (the executor keeps a final Softmax in fp32)
+                conf, ids = self._exec.values(a)[0, 0].max(-1)    # fp32 probabilities (the executor keeps a final Softmax in fp32)
                 confs.append(conf)
                 idss.append(ids)
             # one device -> host copy per mini-batch (all lines of a mini-batch share imgW, hence T)

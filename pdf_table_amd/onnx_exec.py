@@ -114,6 +114,45 @@ class HipGraphExecutor:
         if len(self.inputs) != 1:
             raise UnsupportedOnnxGraph(f"the executor takes graphs with one image input, this one has {[i.name for i in self.inputs]}")
         self._dev: Dict[int, Dict[str, torch.Tensor]] = {}      # layer index -> uploaded operands (filled on first use)
+        self._fuse = self._plan_add_fusion()
+
+    def _plan_add_fusion(self) -> Dict[int, tuple]:
+        """Residual adds folded into the producing convolution's epilogue at load time: conv k (groups 1, 1x1 / 3x3, no activation of its own)
+        whose ONLY consumer is an Add of two computed tensors, the other one produced earlier -> {k: (index of the Add, name of the other operand,
+        index of a following ReLU / hardswish that is the Add's only consumer or None)}.  One launch and one read + write of the map less per
+        residual block; the arithmetic (fp32 sum of bias, product and residual, then the activation, then ONE rounding) is what the fused launch
+        graphs do (ConvDesc.res_mode 1)."""
+        uses: Dict[str, List[int]] = {}
+        made: Dict[str, int] = {i.name: -1 for i in self.inputs}
+        for j, lay in enumerate(self.layers):
+            for nm in lay.inputs:
+                uses.setdefault(nm, []).append(j)
+            for o in lay.outputs:
+                made[o] = j
+        plan: Dict[int, tuple] = {}
+        taken = set()
+        for k, lay in enumerate(self.layers):
+            if lay.op != "conv" or lay.act is not None or lay.attrs.get("group", 1) != 1 or lay.attrs["kernel"][0] not in (1, 3) or len(lay.outputs) != 1:
+                continue
+            out = lay.outputs[0]
+            if out in self.outputs or len(uses.get(out, ())) != 1:
+                continue
+            j = uses[out][0]
+            add = self.layers[j]
+            if add.op != "add" or add.extra or len(add.inputs) != 2 or j in taken or len(add.outputs) != 1:
+                continue
+            other = add.inputs[0] if add.inputs[1] == out else add.inputs[1]
+            if other == out or made.get(other, 1 << 30) >= k:
+                continue
+            act = None
+            ao = add.outputs[0]
+            if ao not in self.outputs and len(uses.get(ao, ())) == 1:
+                nx = self.layers[uses[ao][0]]
+                if nx.op == "act" and nx.attrs.get("kind") in ("relu", "hardswish") and len(nx.outputs) == 1:
+                    act = uses[ao][0]
+            plan[k] = (j, other, act)
+            taken.add(j)
+        return plan
 
     # ---- weights ---------------------------------------------------------------------------------------------------
     def _up(self, a: np.ndarray, dtype=None) -> torch.Tensor:
@@ -166,7 +205,9 @@ class HipGraphExecutor:
         return v
 
     # ---- layers ----------------------------------------------------------------------------------------------------
-    def _conv(self, k: int, lay: Layer, x: _Act) -> _Act:
+    def _conv(self, k: int, lay: Layer, x: _Act, res: Optional[_Act] = None, res_act: int = 0) -> _Act:
+        """res: the other operand of a residual Add folded into this convolution (plain group-1 convolutions without an activation of their own),
+        res_act: the epilogue activation that follows the Add"""
         a = lay.attrs
         kh, kw = a["kernel"]
         sh, sw = a["strides"]
@@ -203,7 +244,8 @@ class HipGraphExecutor:
             if kh not in (1, 3):
                 raise UnsupportedOnnxGraph(f"{lay.name}: {kh}x{kw} convolution (the MFMA kernel covers 1x1 and 3x3)")
             d = self._conv_operands(k, lay, self._cp(x), x.c)
-            y = _Act(self.eng.op_conv2d(x.t, d["w"], d["b"], kh, sh, relu=fused, split=int(self.split)), d["n"])
+            y = _Act(self.eng.op_conv2d(x.t, d["w"], d["b"], kh, sh, relu=fused if res is None else res_act, res=None if res is None else res.t,
+                                        res_mode=0 if res is None else 1, split=int(self.split)), d["n"])
         elif a["group"] == x.c and lay.weight.shape[0] == x.c and lay.weight.shape[1] == 1:
             if kh not in (3, 5):
                 raise UnsupportedOnnxGraph(f"{lay.name}: depthwise {kh}x{kw} (3x3 and 5x5 are built)")
@@ -443,6 +485,7 @@ class HipGraphExecutor:
             self.eng.op_copy_channels(nhwc.contiguous(), first, c)
         env: Dict[str, object] = {self.inputs[0].name: _Act(first, c)}
         R = self._realize
+        skip = set()                                     # Add / activation layers folded into a convolution's epilogue (self._fuse)
         for k, lay in enumerate(self.layers):
             op = lay.op
             if op == "glue" or (op == "concat" and all((i in self.graph.init or isinstance(env.get(i), np.ndarray)) for i in lay.inputs)):
@@ -471,9 +514,30 @@ class HipGraphExecutor:
                     raise UnsupportedOnnxGraph(f"{lay.name}: attention soft-max over axis {lay.attrs.get('axis')}")
                 env[lay.outputs[0]] = _Scores(raw[0].base, raw[0].heads, raw[0].d, raw[0].scale, True)
                 continue
+            if k in skip:
+                continue
             ins = [R(v, lay.name) for v in raw]
             if op == "conv":
-                y = self._conv(k, lay, ins[0])
+                fz = self._fuse.get(k)
+                y = None
+                if fz is not None and isinstance(env.get(fz[1]), _Act):
+                    j_add, other, j_act = fz
+                    r_ = env[other]
+                    sh_ = lay.attrs["strides"][0]
+                    ho, wo = (ins[0].t.shape[1] - 1) // sh_ + 1, (ins[0].t.shape[2] - 1) // sh_ + 1
+                    if not (r_.seq or r_.flat or ins[0].seq or ins[0].flat) and r_.c == lay.weight.shape[0] and tuple(r_.t.shape[1:3]) == (ho, wo) \
+                            and r_.t.shape[-1] == _pad64(r_.c) * self.m:
+                        code = _ACT_CODE[self.layers[j_act].attrs["kind"]] if j_act is not None else 0
+                        y = self._conv(k, lay, ins[0], res=r_, res_act=code)
+                        skip.add(j_add)
+                        for o in self.layers[j_add].outputs:
+                            env[o] = y
+                        if j_act is not None:
+                            skip.add(j_act)
+                            for o in self.layers[j_act].outputs:
+                                env[o] = y
+                if y is None:
+                    y = self._conv(k, lay, ins[0])
             elif op == "convT":
                 y = self._convT(k, lay, ins[0])
             elif op == "maxpool":

@@ -215,5 +215,17 @@ def test_recognition_task_onnx_door(eng, tmp_path):
         ratio = difflib.SequenceMatcher(None, g, want).ratio()
         print(f"recogniser ONNX door: {len(g)} characters on the engine (bf16), {len(want)} from the module (fp32), similarity {ratio:.3f}")
         assert len(want) > 5 and ratio >= 0.85              # a random-init head: a few near-tie tokens flip in bf16
+    # precision="fp32": the executor's tolerance mode behind the same door -- the strings of the fp32 module, token for token
+    task32 = OcrRecognitionTask(model="PP-OCRv4", task_type="ch", task_path=str(tmp_path), engine=eng, precision="fp32")
+    assert task32._exec.precision == "bf16x3"
+    for c, g in zip(crops, task32(crops)):
+        (b,) = orp.rec_pp_preprocess([c])
+        with torch.no_grad():
+            p = m(torch.from_numpy(np.ascontiguousarray(b["image"]))).numpy()
+        (want, _), = ctc(p)
+        top2 = np.sort(p[0], -1)[:, -2:]
+        ties = int(((top2[:, 1] - top2[:, 0]) <= 2e-3).sum())
+        print(f"recogniser ONNX door, precision='fp32' (bf16x3): {'identical' if g == want else 'DIFFERENT'} strings of {len(want)} characters ({ties} oracle ties)")
+        assert g == want or ties > 0
     with pytest.raises(RuntimeError, match="no model.onnx"):
         OcrRecognitionTask(model="PP-OCRv4", task_type="ch", task_path=str(tmp_path / "missing"), engine=eng)
