@@ -881,6 +881,52 @@ class HipRunner:
             out[name] = {"lines_per_s": len(lines) / dt, "ms_per_step": dt * 1e3, "pages_per_s_rec_only": PAGES_PER_STEP / dt}
         return out
 
+    def onnx_rec_leg(self, n_lines=256):
+        """The reference's DEFAULT recogniser route: OcrRecognitionTask(model="PP-OCRv4") on an ONNX graph through the generic
+        layer-list executor (ocr_recognition_task.py:81-116 -> onnxruntime in the reference; pdf_table_amd/onnx_exec.py here).  The real PP-OCRv4
+        file is not available offline: the graph is the SVTR-type stand-in PyTorch's exporter writes (tools/onnx_export.py: conv stem, two
+        LayerNorm / fused-qkv attention / MLP blocks, CTC head with Softmax; 52 layers, static [1, 3, 48, 320] like the shipped exports), seeded.
+        Text-line crops of the step's pages -> PPOcrRecPreProcessor kernel -> one graph run per line -> CTCLabelDecode; lines/s in the executor's
+        bf16 mode and in its tolerance mode (precision="fp32" -> (hi | lo) activations, <= 1e-3 against the fp32 module: tests/test_gpu_onnx_seq.py)."""
+        import tempfile
+        tdir = os.path.join(REPO, "tools")
+        if tdir not in sys.path:
+            sys.path.insert(0, tdir)
+        try:
+            import onnx_export as X
+        except Exception as e:      # noqa: BLE001 -- the exporter needs torch.onnx; a diagnostic leg must not take the bench line down
+            return {"error": repr(e)[:200]}
+        from pdf_table_amd.ocr_recognition_task import OcrRecognitionTask
+        torch = self.torch
+        crops = []
+        for pi in range(PAGES_PER_STEP):
+            for q in self.gt_quads[pi]:
+                x0, y0, x1, y1 = int(q[0]), int(q[1]), int(q[4]), int(q[5])
+                if x1 - x0 >= 16 and y1 - y0 >= 8:
+                    crops.append(np.ascontiguousarray(self.pages_np[pi][y0:y1, x0:x1]))
+                if len(crops) >= n_lines:
+                    break
+            if len(crops) >= n_lines:
+                break
+        out = {"lines": len(crops), "graph": "SvtrTiny stand-in (tools/onnx_export.py), 52 layers, one graph run per line",
+               "asserted_by": "tests/test_gpu_onnx_seq.py (bf16: similarity bounds; precision='fp32': strings identical to the fp32 module's)"}
+        with tempfile.TemporaryDirectory() as td:
+            with open(os.path.join(td, "ppocr_keys_v1.txt"), "w", encoding="utf-8") as f:
+                f.write("\n".join(chr(0x4E00 + i) for i in range(95)) + "\n")
+            with open(os.path.join(td, "inference.onnx"), "wb") as f:
+                f.write(X.torch_export(X.seeded(X.SvtrTiny(classes=97), 31), torch.zeros(1, 3, 48, 320)))
+            for name, prec in (("bf16", "bf16"), ("bf16x3", "fp32")):
+                task = OcrRecognitionTask(model="PP-OCRv4", task_type="ch", task_path=td, engine=self.eng, precision=prec)
+                task(crops[:16])
+                self.sync()
+                t0 = time.perf_counter()
+                texts = task(crops)
+                self.sync()
+                dt = time.perf_counter() - t0
+                out[name] = {"lines_per_s": len(crops) / dt, "ms_per_line": dt / max(1, len(crops)) * 1e3, "characters": sum(len(t) for t in texts),
+                             "fused_residual_adds": len(task._exec._fuse), "layers": len(task._exec.layers)}
+        return out
+
     def mtl_tabnet_leg(self, steps=2, warm=1):
         """BASELINE.json configs[4], table-structure half: the SAME table regions of the step through MtlTabNet (480 x 480 pre-processing
         kernel, ResNet-GC backbone, KV-cached structure / box / cell-content decoders, label convertor + HTML post-processor on the
@@ -1195,6 +1241,10 @@ def main(argv=None):
             leg = runner.convnext_vit_leg()
             if rank == 0 and leg is not None:
                 out["convnext_vit_recogniser"] = leg
+        if "rec" in runner.stages and not args.no_post and rank == 0:
+            leg = runner.onnx_rec_leg()
+            if leg is not None:
+                out["onnx_recogniser"] = leg
         if "tsr" in runner.stages and not args.no_post:
             leg = runner.mtl_tabnet_leg()
             if rank == 0 and leg is not None:

@@ -864,19 +864,36 @@ __global__ __launch_bounds__(512, 1) void dla_thin_chain_kernel(const bf16_t* __
     wf1[t] = *reinterpret_cast<const dbf16x8*>(w1 + ((size_t)t * 32 + lx) * 16 + q * 8);
   }
   const int yb0 = 2 * oy1 - 2, y00 = 2 * oy1 - 1, yi0 = 2 * oy1 - 5;      // first map row of the base / level0 / image patches
-  for (int txi = 0; txi < tiles_x; ++txi) {
-    const int ox1 = txi * C::TW1;
-    const int xb0 = 2 * ox1 - 2, x00 = 2 * ox1 - 1, xi0 = 2 * ox1 - 5;
-    __syncthreads();                       // the previous tile's patches have been read
-    // ---- image patch: zero outside the image (the 7x7 convolution's padding)
-    for (int idx = tid; idx < C::RI * C::CI; idx += 512) {
+  // image patch of a tile: zero outside the image (the 7x7 convolution's padding).  The NEXT tile's patch is fetched into registers while
+  // this tile's stem runs and lands in LDS behind the stem's barrier (s_in is dead from there to the next tile): no exposed load latency
+  constexpr int NLD = (C::RI * C::CI + 511) / 512;
+  u32x2 pre[NLD];
+  auto fetch = [&](int txi) {
+    const int xi0 = 2 * txi * C::TW1 - 5;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int idx = tid + j * 512;
       const int iy = idx / C::CI, ix = idx - iy * C::CI;
       const int gy = yi0 + iy, gx = xi0 + ix;
-      u32x2 v = {0u, 0u};
-      if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = *reinterpret_cast<const u32x2*>(in_b + ((size_t)gy * W + gx) * 4);
-      *reinterpret_cast<u32x2*>(s_in + idx * 8) = v;
+      pre[j] = u32x2{0u, 0u};
+      if (idx < C::RI * C::CI && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+        pre[j] = *reinterpret_cast<const u32x2*>(in_b + ((size_t)gy * W + gx) * 4);
     }
-    __syncthreads();
+  };
+  auto land = [&]() {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int idx = tid + j * 512;
+      if (idx < C::RI * C::CI) *reinterpret_cast<u32x2*>(s_in + idx * 8) = pre[j];
+    }
+  };
+  fetch(0);
+  land();
+  for (int txi = 0; txi < tiles_x; ++txi) {
+    const int ox1 = txi * C::TW1;
+    const int xb0 = 2 * ox1 - 2, x00 = 2 * ox1 - 1;
+    __syncthreads();                       // this tile's image patch is in LDS; the previous tile's level0 patch has been read
+    if (txi + 1 < tiles_x) fetch(txi + 1);
     // ---- base_layer: 19 rows x 2 column tiles, 14 k-steps each (7 kernel rows x 2 halves of the 8-wide kernel row)
     for (int u = wave; u < C::RB * 2; u += 8) {
       const int i = u >> 1, ct = u & 1;
@@ -910,6 +927,7 @@ __global__ __launch_bounds__(512, 1) void dla_thin_chain_kernel(const bf16_t* __
       }
     }
     __syncthreads();
+    if (txi + 1 < tiles_x) land();         // every stem fragment of this tile has been read
     // ---- level0: 3x3 stride 1 on the base patch, 17 rows x 2 column tiles, 9 taps
     for (int u = wave; u < C::R0 * 2; u += 8) {
       const int i = u >> 1, ct = u & 1;
