@@ -1210,43 +1210,61 @@ def main(argv=None):
                 roof["all_kernel_classes_flop"] = {k: v["flop"] for k, v in prof.items()}
             out["roofline"] = roof
     if not stub and world == 1 and (args.host_pages_leg or not args.no_extra_legs) and not args.no_post:
-        leg = runner.host_pages_leg()
+        try:
+            leg = runner.host_pages_leg()
+        except Exception as e:      # noqa: BLE001 -- a diagnostic leg
+            leg = {"error": f"{type(e).__name__}: {e}"[:300]}
         if leg is not None:
-            leg["ratio_to_value"] = leg["pages_per_s"] / out["value"]
+            if "pages_per_s" in leg:
+                leg["ratio_to_value"] = leg["pages_per_s"] / out["value"]
             out["host_pages"] = leg
-    # extra legs: every rank runs them (they are outside the timed region; rank 0 reports its own)
+    # extra legs: every rank runs them (they are outside the timed region; rank 0 reports its own).  A diagnostic leg that raises is reported
+    # as {"error": ...} on the line and the engine goes back to the timed region's precision: it must never take the headline down with it
+    def guarded(fn):
+        try:
+            return fn()
+        except Exception as e:      # noqa: BLE001
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            try:
+                runner.eng.set_precision(runner.L.PT_PRECISION_BF16)
+                runner.torch.cuda.synchronize()
+            except Exception:       # noqa: BLE001
+                pass
+            return {"error": f"{type(e).__name__}: {e}"[:300]}
+
     if not stub and not args.no_extra_legs and world == 1:
         if "det" in runner.stages and not runner.nas:
-            leg = runner.det_only_leg()
+            leg = guarded(runner.det_only_leg)
             if rank == 0:
                 out["roofline"]["det_backbone"] = leg
         if len(runner.stages) > 1 and not args.no_post:
-            leg = runner.by_class_leg()
+            leg = guarded(runner.by_class_leg)
             if rank == 0 and leg is not None:
                 out["roofline"]["by_class"] = leg
         if len(runner.stages) > 1:
-            leg = runner.overlap_leg()
+            leg = guarded(runner.overlap_leg)
             if rank == 0 and leg is not None:
                 out["overlap_rec"] = leg
         if runner.x3_leg and not args.no_post:
-            leg = runner.x3_leg_run()
+            leg = guarded(runner.x3_leg_run)
             if rank == 0:
                 leg["bf16_pages_per_s"] = out["value"]
                 out["tolerance_mode"] = leg
         if rank == 0 and not args.no_post:
-            leg = runner.e2e_agreement_leg()
+            leg = guarded(runner.e2e_agreement_leg)
             if leg is not None:
                 out.setdefault("tolerance_mode", {})["bf16_e2e_agreement"] = leg
         if "rec" in runner.stages and not args.no_post:
-            leg = runner.convnext_vit_leg()
+            leg = guarded(runner.convnext_vit_leg)
             if rank == 0 and leg is not None:
                 out["convnext_vit_recogniser"] = leg
         if "rec" in runner.stages and not args.no_post and rank == 0:
-            leg = runner.onnx_rec_leg()
+            leg = guarded(runner.onnx_rec_leg)
             if leg is not None:
                 out["onnx_recogniser"] = leg
         if "tsr" in runner.stages and not args.no_post:
-            leg = runner.mtl_tabnet_leg()
+            leg = guarded(runner.mtl_tabnet_leg)
             if rank == 0 and leg is not None:
                 out["mtl_tabnet"] = leg
     if rank == 0:

@@ -74,7 +74,13 @@ class OcrRecognitionTask(BaseInferTask):
         if len(self._exec.outputs) != 1:
             from .onnx_import import UnsupportedOnnxGraph
             raise UnsupportedOnnxGraph(f"{onnx_path}: a CTC recogniser returns one [B, T, classes] tensor, this graph returns {self._exec.outputs}")
-        self._pp = PPOcrRecPreProcessor(PPOcrRecConfig(), engine=self._engine)
+        # a static export ([1, 3, 48, 320] like the shipped PP-OCR files) has its width baked into the Reshape constants: the pre-processor then
+        # runs PaddleOCR's static-shape setting of the same config fields (rec_image_shape = the graph's, limited_max_width = its width: lines
+        # wider than imgW are resized to imgW, resize_norm_img processor_ocr_rec_pp.py:43-58); a dynamic-width graph keeps the defaults
+        shp = list(getattr(self._exec.inputs[0], "shape", []) or [])
+        static = len(shp) == 4 and all(isinstance(d, int) and d > 0 for d in shp[1:])
+        cfg = PPOcrRecConfig(rec_image_shape=f"{shp[1]}, {shp[2]}, {shp[3]}", limited_max_width=int(shp[3])) if static else PPOcrRecConfig()
+        self._pp = PPOcrRecPreProcessor(cfg, engine=self._engine)
         d = self.kwargs.get("character_dict_path")
         if d is None:
             base = onnx_path if os.path.isdir(onnx_path) else os.path.dirname(onnx_path)
