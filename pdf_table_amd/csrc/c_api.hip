@@ -20,7 +20,7 @@ void pt_set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* pt_last_error(void) { return g_err; }
-int pt_abi_version(void) { return 12; }   // 12: pt_op_dcn (the fused modulated deformable convolution as a single operator); 11: pt_engine_set_mtl_kv_fp8; 10: pt_tsr_mtl_preprocess / decoder_config / structure / cells (MtlTabNet decoders); 9: pt_rec_cvit_* (ConvNextViT recogniser); 8: pt_op_dwconv / add / maxpool / avgpool / chan_mean / scale_channels / act (generic ONNX executor); 7: pt_rec_pp_preprocess*; 6: pt_engine_set_lstm_cluster, pt_engine_check clears what it reports
+int pt_abi_version(void) { return 13; }   // 13: pt_engine_set_dcn_mfma; 12: pt_op_dcn (the fused modulated deformable convolution as a single operator); 11: pt_engine_set_mtl_kv_fp8; 10: pt_tsr_mtl_preprocess / decoder_config / structure / cells (MtlTabNet decoders); 9: pt_rec_cvit_* (ConvNextViT recogniser); 8: pt_op_dwconv / add / maxpool / avgpool / chan_mean / scale_channels / act (generic ONNX executor); 7: pt_rec_pp_preprocess*; 6: pt_engine_set_lstm_cluster, pt_engine_check clears what it reports
 
 int pt_engine_check(pt_engine* e) {
   PT_REQUIRE(e, "pt_engine_check: null engine");
@@ -39,6 +39,12 @@ int pt_engine_check(pt_engine* e) {
 int pt_engine_set_lstm_cluster(pt_engine* e, int on) {
   PT_REQUIRE(e && (on == 0 || on == 1), "pt_engine_set_lstm_cluster: bad arguments");
   e->lstm_cluster = on;
+  return PT_OK;
+}
+
+int pt_engine_set_dcn_mfma(pt_engine* e, int on) {
+  PT_REQUIRE(e && (on == 0 || on == 1), "pt_engine_set_dcn_mfma: bad arguments");
+  e->dcn_mfma = on;
   return PT_OK;
 }
 
@@ -71,6 +77,8 @@ int pt_engine_create(int device_id, pt_engine** out) {
     e->lstm_cluster = ev ? (atoi(ev) != 0) : 1;
     ev = getenv("PT_MTL_KV_FP8");                   // default of pt_engine_set_mtl_kv_fp8
     e->mtl_kv_fp8 = ev ? (atoi(ev) != 0) : 0;
+    ev = getenv("PT_DCN_MFMA");                     // default of pt_engine_set_dcn_mfma
+    e->dcn_mfma = ev ? (atoi(ev) != 0) : 1;
     ev = getenv("PT_REC_RAGGED");                   // 0: the recogniser's conv stack also computes the padding (A/B switch)
     e->rec_ragged = ev ? (atoi(ev) != 0) : 1;
   }

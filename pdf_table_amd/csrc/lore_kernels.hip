@@ -708,6 +708,237 @@ __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) voi
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// dcn_mfma_kernel (bf16 mode): the bilinear blend of the deformable convolution on the matrix pipe.
+// dcn_fused64_kernel is VALU-bound on unpack -> fp32 blend -> repack (profiles/r03/dcn_counters.txt: 67 % VALU busy, matrix
+// pipe 10 %; profiles/r04/valu_rate_bench.txt: ~4 cycles per VALU instruction, v_pk_fma_f32 no faster than two v_fma_f32,
+// v_dot2_f32_bf16 half rate).  Here no gathered value passes through the VALU at all:
+//   * a wave owns 32 pixels x 32 channels of a (tap, 64-channel slice) stage.  The four corner lines of four pixels -- 16 rows
+//     of 64 bytes -- are ONE global_load_lds_dwordx4 (1 KB, lane-linear in LDS: lane 4 r + j moves piece j of row r =
+//     (pixel r >> 2, corner r & 3)); a ring of RING such slots per wave keeps RING - 1 gathers in flight, counted with
+//     s_waitcnt vmcnt (no VGPR holds gathered data, so the depth costs LDS only).
+//   * blend: D[channel][pixel] = G^T[channel][(pixel', corner)] x Wt[(pixel', corner)][pixel] as v_mfma_f32_32x32x16_bf16 --
+//     one slot is one K = 16 step.  G^T is read with ds_read_b64_tr_b16 (the 16-lane groups transpose a [4 rows][16 channels]
+//     block: lane = channel, registers = rows); Wt is block-diagonal and lives in registers: lane (pixel n, k-group) holds the
+//     four bilinear x mask weights of ITS pixel (bf16, rounded once) in the K slots of that pixel and zeros elsewhere -- one
+//     compare + four selects per step.  Corners outside the map carry weight zero and point at the map's first pixel.
+//   * product: a lane's 16 accumulators are 16 channels of one pixel; the tr-read hands channel sigma(m) to row m (4-channel
+//     pieces 1 and 2 of every 16 swapped), which makes accumulators [8 t, 8 t + 8) eight CONSECUTIVE channels: converted to
+//     bf16 in place they ARE the B operand of the 1x1 product (K = 32 channels of the wave; the weight fragment is a plain
+//     ds_read_b128 of the tiled weights, as in dcn_fused64_kernel).  No LDS round trip for the sampled columns.
+//   * the two waves that share a pixel tile (channel halves of the slice) add their partial sums through LDS once per tile.
+// The fp32 sums are associated differently from dcn_fused64_kernel (blend exact in fp32 there, bf16 weights here; K split in
+// halves): both are bf16-mode results within tests/test_gpu_dcn_op.py's bounds.  PT_DCN_MFMA=0 selects dcn_fused64_kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NB, int RING>
+struct DcnMfmaSmem {
+  static constexpr int BYTES = 128 * 9 * 24 + 2 * NB * 128 + 8 * RING * 1024;     // sampling table + two weight images + the waves' gather rings
+};
+template <int NB, int RING>
+__global__ __launch_bounds__(512, NB == 64 ? 2 : 1) void dcn_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
+                                                                            const bf16_t* __restrict__ w, const float* __restrict__ bias,
+                                                                            bf16_t* __restrict__ out, long long npix, int H, int W, int C,
+                                                                            int N, int relu) {
+#pragma clang fp contract(fast)
+  static_assert(RING == 4 || RING == 8, "ring slots must divide the eight steps of a stage");
+  constexpr int NT = NB / 32;                   // 32-column tiles of the product (every wave: all NB outputs over its 32 channels)
+  constexpr int WP = NB / 64;                   // weight DMAs per wave per stage (1 KB each)
+  constexpr int D = RING - 1;                   // gathers in flight ahead of the step being multiplied
+  constexpr int GOFF_BYTES = 128 * 9 * 16, GW_BYTES = 128 * 9 * 8, W_BYTES = NB * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_goff = smem;                          // [pixel * 9 + tap][4] byte offsets of the corners from the map's first pixel
+  char* s_gw = smem + GOFF_BYTES;               // [pixel * 9 + tap][2] the four weights as bf16 pairs (w0 | w1 << 16, w2 | w3 << 16)
+  char* s_w = s_gw + GW_BYTES;                  // two weight images
+  char* s_ring = s_w + 2 * W_BYTES;             // 8 waves x RING x 1 KB
+  float* s_om = reinterpret_cast<float*>(s_ring);   // offset / mask staging while the table is built (14 KB)
+  static_assert(8 * RING * 1024 >= 128 * 28 * 4, "ring must cover the staged offset / mask rows");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, q = lane >> 5;
+  const int pt = wave & 3, hh = wave >> 2;      // 32-pixel tile, channel half of the slice
+  const int tiles_x = (W + 15) >> 4, tiles_y = (H + 7) >> 3;
+  int Lb = blockIdx.x;
+  const int tx0 = (Lb % tiles_x) * 16;
+  Lb /= tiles_x;
+  const int ty0 = (Lb % tiles_y) * 8;
+  const long long img0 = (long long)(Lb / tiles_y) * H * W;
+  auto locate = [&](int pl, int& y, int& xq) -> bool {
+    y = ty0 + (pl >> 4);
+    xq = tx0 + (pl & 15);
+    const bool ok = y < H && xq < W;
+    y = y < H ? y : H - 1;
+    xq = xq < W ? xq : W - 1;
+    return ok;
+  };
+  const int n0 = blockIdx.y * NB;
+  const int nss = C >> 6, nst = 9 * nss, nk = 9 * (C >> 5);
+  for (int i = tid; i < 128 * 7; i += 512) {
+    int y, xq;
+    locate(i / 7, y, xq);
+    const long long pix = img0 + (long long)y * W + xq;
+    *reinterpret_cast<float4*>(s_om + (i / 7) * 28 + (i % 7) * 4) = *reinterpret_cast<const float4*>(om + pix * 32 + (i % 7) * 4);
+  }
+  __syncthreads();
+  for (int i = tid; i < 128 * 9; i += 512) {      // the sampling rule of dcn_fused64_kernel's table (dcn_v2_im2col_cpu.cpp:26-55)
+    const int pl = i / 9, tap = i - pl * 9;
+    int yh, xw;
+    locate(pl, yh, xw);
+    const float* o = s_om + pl * 28;
+    const float off_h = o[2 * tap], off_w = o[2 * tap + 1];
+    const float gm = 1.f / (1.f + expf(-o[18 + tap]));
+    const float h_im = (float)(yh - 1 + tap / 3) + off_h;
+    const float w_im = (float)(xw - 1 + tap % 3) + off_w;
+    unsigned co[4] = {0u, 0u, 0u, 0u};
+    float cw[4] = {0.f, 0.f, 0.f, 0.f};
+    if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+      const float hf = floorf(h_im), wf = floorf(w_im);
+      const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
+      const float lh = h_im - hf, lw = w_im - wf, hhh = 1.f - lh, hw = 1.f - lw;
+      if (h_low >= 0 && w_low >= 0) { co[0] = (unsigned)(h_low * W + w_low) * (unsigned)(2 * C); cw[0] = hhh * hw * gm; }
+      if (h_low >= 0 && w_high <= W - 1) { co[1] = (unsigned)(h_low * W + w_high) * (unsigned)(2 * C); cw[1] = hhh * lw * gm; }
+      if (h_high <= H - 1 && w_low >= 0) { co[2] = (unsigned)(h_high * W + w_low) * (unsigned)(2 * C); cw[2] = lh * hw * gm; }
+      if (h_high <= H - 1 && w_high <= W - 1) { co[3] = (unsigned)(h_high * W + w_high) * (unsigned)(2 * C); cw[3] = lh * lw * gm; }
+    }
+    *reinterpret_cast<uint4*>(s_goff + i * 16) = make_uint4(co[0], co[1], co[2], co[3]);
+    *reinterpret_cast<uint2*>(s_gw + i * 8) = make_uint2(f2bf(cw[0]) | (f2bf(cw[1]) << 16), f2bf(cw[2]) | (f2bf(cw[3]) << 16));
+  }
+  // weight image of a stage: NB rows x 128 bytes (the stage's 64 channels), moved by LDS-DMA too -- wave v moves rows [8 v, 8 v + 8) of every
+  // 64-row block: lane = (row, 16-byte slot), and the slot holds source piece slot ^ ((row >> 1) & 7): with rows 128 bytes apart that XOR
+  // puts the 16 rows a ds_read_b128 lane group touches on 16 different bank quads (no padding is possible in a lane-linear DMA image)
+  const bf16_t* wbase = w + (size_t)(n0 >> 6) * nk * (64 * 32);
+  const int w_row = wave * 8 + (lane >> 3), w_pc = (lane & 7) ^ ((w_row >> 1) & 7);
+  const unsigned w_lane = (unsigned)(((w_pc >> 2) * (64 * 32) + w_row * 32 + (w_pc & 3) * 8) * 2);   // bytes from (64-row block, first chunk of the stage)
+  auto issue_w = [&](int st) {
+    const int tap = st / nss, ss = st - tap * nss;
+    const int kc = tap * (C >> 5) + 2 * ss;
+#pragma unroll
+    for (int j = 0; j < WP; ++j) {
+      // scalar base + 32-bit lane offset, written out: hipcc folds the lane part of this one into a 64-bit vector address and then guards
+      // the next writes of those address registers with vmcnt(0) -- which drains the gather ring once per stage
+      const unsigned long long u = (unsigned long long)(wbase + ((size_t)j * nk + kc) * (64 * 32));
+      const unsigned long long ub = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(u >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)u);
+      const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_w + (st & 1) * W_BYTES + (j * 64 + wave * 8) * 128));
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(w_lane), "s"(ub), "s"(dst) : "memory");
+    }
+  };
+  issue_w(0);
+  __syncthreads();       // table complete; s_om (in the ring) is dead
+
+  // gather side: lane 4 r + j moves 16-byte piece j of row r of a step = corner (r & 3) of pixel 4 s + (r >> 2) of the wave's tile
+  const char* xmap = reinterpret_cast<const char*>(x + (size_t)img0 * C);
+  const int g_tab = ((pt * 32 + (lane >> 4)) * 9) * 16 + ((lane >> 2) & 3) * 4;     // this lane's entry of step 0, tap 0 in s_goff
+  const unsigned g_lane = (unsigned)(hh * 64 + (lane & 3) * 16);                     // bytes inside the 128-byte slice line
+  char* ring = s_ring + wave * (RING * 1024);
+  auto issue = [&](int s, int tap, int ss) {      // step s (0..7) of stage (tap, ss) -> slot s % RING
+    const unsigned off = *reinterpret_cast<const unsigned*>(s_goff + g_tab + (s * 36 + tap) * 16) + g_lane + (unsigned)(ss * 128);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xmap + off),
+                                     (__attribute__((address_space(3))) void*)(ring + (s % RING) * 1024), 16, 0, 0);
+  };
+  // blend side.  A operand (gathered, transposed): 16-lane group g = lane >> 4 reads rows 8 (g >> 1) + {0..3} (then + 4) x the 16
+  // channels 16 (g & 1) ..; lane a of the group SUPPLIES the address of row a >> 2, 4-channel piece swap(a & 3) (1 <-> 2) and
+  // RECEIVES column a: channel sigma(16 (g & 1) + a)
+  const int la = lane & 15, lg = lane >> 4;
+  const unsigned tr_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring + (unsigned)((8 * (lg >> 1) + (la >> 2)) * 64 + (lg & 1) * 32 + ((((la & 1) << 1) | ((la >> 1) & 1)) * 8));
+  const int key = (lx >> 1) - q;                // step s holds this lane's pixel in its K group iff key == 2 s
+  const bool odd = lx & 1;
+  const unsigned gw_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_gw + ((pt * 32 + lx) * 9) * 8);
+  const char* b_rd = s_w + lx * 128;           // + 16-byte slot (channel piece ^ ((row >> 1) & 7))
+  const int b_key = (lx >> 1) & 7;
+
+  df32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+#pragma unroll
+  for (int s = 0; s < D; ++s) issue(s, 0, 0);
+  for (int st = 0; st < nst; ++st) {
+    const int tap = st / nss, ss = st - tap * nss;
+    int tap_n = tap, ss_n = ss + 1;             // the stage after this one (the gathers run up to D steps ahead)
+    if (ss_n == nss) { ss_n = 0; tap_n = tap + 1; }
+    const bool last = st + 1 == nst;
+    // weight image st: every wave waits for its own piece (the newest D gathers were issued after it), then the barrier publishes all of them
+    // and frees image st - 1 for stage st + 1
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");
+    __builtin_amdgcn_s_barrier();              // (no fence: __syncthreads() would drain the gathers in flight with vmcnt(0))
+    if (!last) issue_w(st + 1);
+    u32x2 tw;                                   // (inline: hipcc puts a vmcnt(0) in front of a plain LDS load of this table here, draining the ring)
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(tw) : "v"(gw_addr + (unsigned)(tap * 8)) : "memory");
+    const uint32_t e01 = odd ? 0u : tw.x, e23 = odd ? 0u : tw.y, o01 = odd ? tw.x : 0u, o23 = odd ? tw.y : 0u;
+    df32x16 bl;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bl[r] = 0.f;
+    // one K = 16 step: issue the gather D steps ahead, wait for this step's slot (everything but the newest D gathers -- and, while they are
+    // younger than the slot, the WP weight loads of this stage -- has landed), transpose-read it, multiply by the block-diagonal weights
+#define PT_DCN_STEP(S)                                                                                                                   \
+    {                                                                                                                                    \
+      if (S + D < 8) issue(S + D, tap, ss);                                                                                              \
+      else if (!last) issue(S + D - 8, tap_n, ss_n);                                                                                     \
+      if (last) {                                                                                                                        \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S + D < 8 ? D : 7 - S) : "memory");                                                     \
+      } else {                                                                                                                           \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S < D ? D + WP : D) : "memory");                                                        \
+      }                                                                                                                                  \
+      u32x2 a_lo, a_hi;                                                                                                                  \
+      asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"                 \
+                   : "=&v"(a_lo), "=&v"(a_hi)                                                                                            \
+                   : "v"(tr_addr), "n"((S % RING) * 1024), "n"((S % RING) * 1024 + 256)                                                  \
+                   : "memory");                                                                                                          \
+      const bool mine = key == 2 * S;                                                                                                    \
+      const u32x4 bw = {mine ? e01 : 0u, mine ? e23 : 0u, mine ? o01 : 0u, mine ? o23 : 0u};                                             \
+      const u32x4 aw = {a_lo.x, a_lo.y, a_hi.x, a_hi.y};                                                                                 \
+      bl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dbf16x8, aw), __builtin_bit_cast(dbf16x8, bw), bl, 0, 0, 0);       \
+    }
+    PT_DCN_STEP(0) PT_DCN_STEP(1) PT_DCN_STEP(2) PT_DCN_STEP(3) PT_DCN_STEP(4) PT_DCN_STEP(5) PT_DCN_STEP(6) PT_DCN_STEP(7)
+#undef PT_DCN_STEP
+    // bl[8 t + e] = channel 32 hh + 16 t + 8 q + e of pixel lx: the product's B operand after one conversion
+    const char* wrd = b_rd + (st & 1) * W_BYTES;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      u32x4 cf;
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        const df2 v = {bl[8 * t + 2 * e2], bl[8 * t + 2 * e2 + 1]};
+        cf[e2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, db2));
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const dbf16x8 wf = *reinterpret_cast<const dbf16x8*>(wrd + nt * 32 * 128 + (((hh * 4 + t * 2 + q) ^ b_key) << 4));
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(dbf16x8, cf), acc[nt], 0, 0, 0);   // D = [channel][pixel]
+      }
+    }
+  }
+  // the two channel halves of a pixel tile meet in LDS: wave hh finishes the 32-column tiles [hh NT / 2, (hh + 1) NT / 2)
+  __syncthreads();
+  float* scr = reinterpret_cast<float*>(smem) + pt * (NT * 16 * 64);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+    if ((nt >= NT / 2) != (hh == 1)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) scr[(nt * 16 + r) * 64 + lane] = acc[nt][r];
+    }
+  __syncthreads();
+  int y, xq;
+  const bool ok = locate(pt * 32 + lx, y, xq);
+  bf16_t* op = out + (size_t)(img0 + (long long)y * W + xq) * N + n0;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+    if ((nt >= NT / 2) == (hh == 1)) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int ch = nt * 32 + 8 * rg + 4 * q;
+        const float4 bs = *reinterpret_cast<const float4*>(bias + n0 + ch);
+        float v[4] = {acc[nt][rg * 4 + 0] + scr[(nt * 16 + rg * 4 + 0) * 64 + lane] + bs.x, acc[nt][rg * 4 + 1] + scr[(nt * 16 + rg * 4 + 1) * 64 + lane] + bs.y,
+                      acc[nt][rg * 4 + 2] + scr[(nt * 16 + rg * 4 + 2) * 64 + lane] + bs.z, acc[nt][rg * 4 + 3] + scr[(nt * 16 + rg * 4 + 3) * 64 + lane] + bs.w};
+        if (relu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        if (ok) *reinterpret_cast<uint2*>(op + ch) = make_uint2(f2bf(v[0]) | (f2bf(v[1]) << 16), f2bf(v[2]) | (f2bf(v[3]) << 16));
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // 3x3 convolution for 16 input channels (DLA-34 level0: 16 -> 16 at full resolution, level1: 16 -> 32 stride 2,
 // center_net/modeling_centernet.py:295-298,370-380) + folded BN + ReLU.  The general implicit-GEMM kernel would pad these
 // to 32 -> 64 (4-8x the work and twice the bytes at 1024 x 1024); here K = 9 taps x 16 channels = nine MFMA k-steps:
@@ -1086,6 +1317,25 @@ int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf
       nthr = ev ? atoi(ev) : 512;
     }
     const unsigned tiles = (unsigned)((long long)B * ((H + 7) / 8) * ((W + 15) / 16));
+    // pt_engine_set_dcn_mfma (default on, PT_DCN_MFMA): the blend on the matrix pipe (dcn_mfma_kernel); off: dcn_fused64_kernel (VALU blend,
+    // fp32 weights); PT_DCN_MFMA_NB=64: 64-wide blocks for every layer
+    static int mfma_nb = -1;
+    if (mfma_nb < 0) {
+      const char* nv = getenv("PT_DCN_MFMA_NB");
+      PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_mfma_kernel<64, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, DcnMfmaSmem<64, 4>::BYTES));
+      PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_mfma_kernel<128, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, DcnMfmaSmem<128, 8>::BYTES));
+      mfma_nb = nv ? atoi(nv) : 128;
+    }
+    const int mfma = e ? e->dcn_mfma : 1;
+    if (mfma) {
+      constexpr int smem64 = DcnMfmaSmem<64, 4>::BYTES, smem128 = DcnMfmaSmem<128, 8>::BYTES;
+      if (N % 128 == 0 && mfma_nb == 128)
+        hipLaunchKernelGGL((dcn_mfma_kernel<128, 8>), dim3(tiles, N / 128), dim3(512), smem128, s, x, om, w, bias, out, npix, H, W, C, N, relu);
+      else
+        hipLaunchKernelGGL((dcn_mfma_kernel<64, 4>), dim3(tiles, N / 64), dim3(512), smem64, s, x, om, w, bias, out, npix, H, W, C, N, relu);
+      PT_HIP_CHECK(hipGetLastError());
+      return PT_OK;
+    }
     if (nb128 && N % 128 == 0) {     // 128-wide blocks stay at 4 waves: with 8 they need 136 VGPRs (> 128: spills), measured 1 % slower
 
       hipLaunchKernelGGL((dcn_fused64_kernel<128, 256>), dim3(tiles, N / 128), dim3(256), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);

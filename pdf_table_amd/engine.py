@@ -61,6 +61,11 @@ class HipEngine:
         HBM stream; a throughput option with recorded drift, off by default)"""
         L.check(self.lib.pt_engine_set_mtl_kv_fp8(self._h, 1 if on else 0), "pt_engine_set_mtl_kv_fp8")
 
+    def set_dcn_mfma(self, on: bool):
+        """Lore detector, bf16 mode: deformable convolutions with the bilinear blend on the matrix pipe (default on) or on the VALU with
+        fp32 weights (off); see include/pdftable_hip.h"""
+        L.check(self.lib.pt_engine_set_dcn_mfma(self._h, 1 if on else 0), "pt_engine_set_dcn_mfma")
+
     def set_lstm_cluster(self, on: bool):
         """False: the streaming LSTM kernel (no co-residency requirement) -- whenever the recogniser shares the GPU with
         work on another stream; True (default): the weight-stationary cluster kernel."""

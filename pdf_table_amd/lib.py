@@ -58,6 +58,7 @@ def _proto(lib):
         "pt_engine_set_precision": (i, [vp, i]),
         "pt_engine_set_lstm_cluster": (i, [vp, i]),
         "pt_engine_set_mtl_kv_fp8": (i, [vp, i]),
+        "pt_engine_set_dcn_mfma": (i, [vp, i]),
         "pt_weights_load": (i, [vp, i, vp, sz]),
         "pt_weights_load_device": (i, [vp, i, vp, sz, vp]),
         "pt_det_plan": (i, [i, i, i, ip, ip]),

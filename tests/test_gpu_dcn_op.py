@@ -80,11 +80,17 @@ SHAPES = [
 
 @pytest.mark.parametrize("C,N,H,W", SHAPES)
 @pytest.mark.parametrize("relu,field", [(True, "wide"), (False, "wide"), (True, "local")])
-def test_dcn_op_bf16(eng, C, N, H, W, relu, field):
+@pytest.mark.parametrize("blend", ["mfma", "valu"])
+def test_dcn_op_bf16(eng, C, N, H, W, relu, field, blend):
     """bf16 mode: operands exactly representable; the kernel rounds every sampled column to bf16 before the product, so it is compared
     (a) with the oracle whose columns are rounded the same way -- difference = fp32 summation order + the output's own bf16 rounding --
-    and (b) with the un-rounded oracle within the half-ulp-per-column bound."""
+    and (b) with the un-rounded oracle within the half-ulp-per-column bound.
+    blend "valu": dcn_fused64_kernel (fp32 bilinear x mask weights).  blend "mfma" (the default, pt_engine_set_dcn_mfma): dcn_mfma_kernel
+    blends on the matrix pipe against the four weights ROUNDED TO bf16 (2^-9 relative each): a column is then within 2^-9 of its magnitude
+    plus its own half ulp, so (a) and (b) carry one more column-ulp term; C % 64 != 0 shapes run dcn_fused_kernel in both settings."""
     B = 2
+    eng.set_dcn_mfma(blend == "mfma")
+    wq = 2.0 ** -8 if blend == "mfma" else 0.0      # extra column error of the bf16 weights, in units of the column magnitudes
     x, w, b, off, mlog = _case(B, C, N, H, W, seed=C * 1000 + N + H, field=field)
     mask = torch.sigmoid(mlog)
     cols = lore_net.deform_conv2d(x, off, mask, w, None, return_cols=True)          # [B,C,9,H,W] fp32
@@ -102,13 +108,14 @@ def test_dcn_op_bf16(eng, C, N, H, W, relu, field):
     # uses fused multiply-adds (<= 1 bf16 ulp of ONE column times its weight: bounded through the column magnitudes)
     col_mag = torch.einsum("ock,bckhw->bohw", w.reshape(N, C, 9).abs(), cols.abs())
     err_a = (got - ref_r).abs()
-    tol_a = ref_r.abs() * 2.0 ** -8 + col_mag * 2.0 ** -12 + 1e-4
+    tol_a = ref_r.abs() * 2.0 ** -8 + col_mag * (2.0 ** -12 + wq) + 1e-4
     assert bool((err_a <= tol_a).all()), f"vs rounded-column oracle: max err {err_a.max().item()} (tol there {tol_a.flatten()[err_a.argmax()].item()})"
     # (b) un-rounded oracle: every column within half a bf16 ulp
     err_b = (got - ref).abs()
-    tol_b = ref.abs() * 2.0 ** -8 + col_mag * 2.0 ** -9 + 1e-4
+    tol_b = ref.abs() * 2.0 ** -8 + col_mag * (2.0 ** -9 + wq) + 1e-4
     assert bool((err_b <= tol_b).all()), f"vs oracle: max err {err_b.max().item()}"
-    print(f"dcn bf16 {field} {C}->{N} @{H}x{W}: max err vs rounded-column oracle {err_a.max().item():.3e}, vs oracle {err_b.max().item():.3e}, scale {ref.abs().max().item():.2f}")
+    eng.set_dcn_mfma(True)
+    print(f"dcn bf16 [{blend}] {field} {C}->{N} @{H}x{W}: max err vs rounded-column oracle {err_a.max().item():.3e}, vs oracle {err_b.max().item():.3e}, scale {ref.abs().max().item():.2f}")
 
 
 @pytest.mark.parametrize("C,N,H,W", SHAPES)
