@@ -729,12 +729,18 @@ __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) voi
 // The fp32 sums are associated differently from dcn_fused64_kernel (blend exact in fp32 there, bf16 weights here; K split in
 // halves): both are bf16-mode results within tests/test_gpu_dcn_op.py's bounds.  PT_DCN_MFMA=0 selects dcn_fused64_kernel.
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef PT_DCN_MABL
+#define PT_DCN_MABL 0      /* ablations of dcn_mfma_kernel (tools/dcn_mfma_abl.sh): 1 no gathers, 2 no transpose-reads / blend products */
+#endif
+#ifndef PT_DCN_RING64
+#define PT_DCN_RING64 4    /* ring slots per wave of the 64-wide blocks: 4 -> two workgroups per CU, 8 -> one */
+#endif
 template <int NB, int RING>
 struct DcnMfmaSmem {
   static constexpr int BYTES = 128 * 9 * 24 + 2 * NB * 128 + 8 * RING * 1024;     // sampling table + two weight images + the waves' gather rings
 };
 template <int NB, int RING>
-__global__ __launch_bounds__(512, NB == 64 ? 2 : 1) void dcn_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
+__global__ __launch_bounds__(512, (NB == 64 && RING == 4) ? 2 : 1) void dcn_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
                                                                             const bf16_t* __restrict__ w, const float* __restrict__ bias,
                                                                             bf16_t* __restrict__ out, long long npix, int H, int W, int C,
                                                                             int N, int relu) {
@@ -806,37 +812,37 @@ __global__ __launch_bounds__(512, NB == 64 ? 2 : 1) void dcn_mfma_kernel(const b
   const bf16_t* wbase = w + (size_t)(n0 >> 6) * nk * (64 * 32);
   const int w_row = wave * 8 + (lane >> 3), w_pc = (lane & 7) ^ ((w_row >> 1) & 7);
   const unsigned w_lane = (unsigned)(((w_pc >> 2) * (64 * 32) + w_row * 32 + (w_pc & 3) * 8) * 2);   // bytes from (64-row block, first chunk of the stage)
-  auto issue_w = [&](int st) {
-    const int tap = st / nss, ss = st - tap * nss;
+  auto issue_w = [&](int st, int tap, int ss) {
     const int kc = tap * (C >> 5) + 2 * ss;
 #pragma unroll
     for (int j = 0; j < WP; ++j) {
       // scalar base + 32-bit lane offset, written out: hipcc folds the lane part of this one into a 64-bit vector address and then guards
       // the next writes of those address registers with vmcnt(0) -- which drains the gather ring once per stage
       const unsigned long long u = (unsigned long long)(wbase + ((size_t)j * nk + kc) * (64 * 32));
-      const unsigned long long ub = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(u >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)u);
+      const unsigned long long ub = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(u >> 32)) << 32) |
+                                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)u);     // (the builtin returns int: no sign extension)
       const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_w + (st & 1) * W_BYTES + (j * 64 + wave * 8) * 128));
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(w_lane), "s"(ub), "s"(dst) : "memory");
     }
   };
-  issue_w(0);
+  issue_w(0, 0, 0);
   __syncthreads();       // table complete; s_om (in the ring) is dead
 
   // gather side: lane 4 r + j moves 16-byte piece j of row r of a step = corner (r & 3) of pixel 4 s + (r >> 2) of the wave's tile
   const char* xmap = reinterpret_cast<const char*>(x + (size_t)img0 * C);
-  const int g_tab = ((pt * 32 + (lane >> 4)) * 9) * 16 + ((lane >> 2) & 3) * 4;     // this lane's entry of step 0, tap 0 in s_goff
-  const unsigned g_lane = (unsigned)(hh * 64 + (lane & 3) * 16);                     // bytes inside the 128-byte slice line
-  char* ring = s_ring + wave * (RING * 1024);
-  auto issue = [&](int s, int tap, int ss) {      // step s (0..7) of stage (tap, ss) -> slot s % RING
-    const unsigned off = *reinterpret_cast<const unsigned*>(s_goff + g_tab + (s * 36 + tap) * 16) + g_lane + (unsigned)(ss * 128);
+  const char* g_tab = s_goff + ((pt * 32 + (lane >> 4)) * 9) * 16 + ((lane >> 2) & 3) * 4;     // this lane's entry of step 0, tap 0
+  const unsigned g_lane = (unsigned)(hh * 64 + (lane & 3) * 16);                                // bytes inside the 128-byte slice line
+  // (wave-uniform values through readfirstlane: the ring's slot addresses then live in scalar registers -- one s_add + s_mov m0 per gather)
+  const unsigned ring_lds = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_ring + wave * (RING * 1024)));
+  auto issue = [&](unsigned off, int slot) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xmap + off),
-                                     (__attribute__((address_space(3))) void*)(ring + (s % RING) * 1024), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(size_t)(ring_lds + (unsigned)(slot * 1024)), 16, 0, 0);
   };
   // blend side.  A operand (gathered, transposed): 16-lane group g = lane >> 4 reads rows 8 (g >> 1) + {0..3} (then + 4) x the 16
   // channels 16 (g & 1) ..; lane a of the group SUPPLIES the address of row a >> 2, 4-channel piece swap(a & 3) (1 <-> 2) and
   // RECEIVES column a: channel sigma(16 (g & 1) + a)
   const int la = lane & 15, lg = lane >> 4;
-  const unsigned tr_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring + (unsigned)((8 * (lg >> 1) + (la >> 2)) * 64 + (lg & 1) * 32 + ((((la & 1) << 1) | ((la >> 1) & 1)) * 8));
+  const unsigned tr_addr = ring_lds + (unsigned)((8 * (lg >> 1) + (la >> 2)) * 64 + (lg & 1) * 32 + ((((la & 1) << 1) | ((la >> 1) & 1)) * 8));
   const int key = (lx >> 1) - q;                // step s holds this lane's pixel in its K group iff key == 2 s
   const bool odd = lx & 1;
   const unsigned gw_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_gw + ((pt * 32 + lx) * 9) * 8);
@@ -850,45 +856,56 @@ __global__ __launch_bounds__(512, NB == 64 ? 2 : 1) void dcn_mfma_kernel(const b
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
 #pragma unroll
-  for (int s = 0; s < D; ++s) issue(s, 0, 0);
+  for (int s = 0; s < D; ++s) issue(*reinterpret_cast<const unsigned*>(g_tab + s * 576) + g_lane, s);
+  int tap = 0, ss = 0;
   for (int st = 0; st < nst; ++st) {
-    const int tap = st / nss, ss = st - tap * nss;
-    int tap_n = tap, ss_n = ss + 1;             // the stage after this one (the gathers run up to D steps ahead)
+    int tap_n = tap, ss_n = ss + 1;             // the stage after this one (the gathers run D steps ahead)
     if (ss_n == nss) { ss_n = 0; tap_n = tap + 1; }
     const bool last = st + 1 == nst;
     // weight image st: every wave waits for its own piece (the newest D gathers were issued after it), then the barrier publishes all of them
     // and frees image st - 1 for stage st + 1
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");
     __builtin_amdgcn_s_barrier();              // (no fence: __syncthreads() would drain the gathers in flight with vmcnt(0))
-    if (!last) issue_w(st + 1);
+    if (!last) issue_w(st + 1, tap_n, ss_n);
     u32x2 tw;                                   // (inline: hipcc puts a vmcnt(0) in front of a plain LDS load of this table here, draining the ring)
     asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(tw) : "v"(gw_addr + (unsigned)(tap * 8)) : "memory");
     const uint32_t e01 = odd ? 0u : tw.x, e23 = odd ? 0u : tw.y, o01 = odd ? tw.x : 0u, o23 = odd ? tw.y : 0u;
+    // the eight table entries of the gathers this stage issues (steps D .. 7 of this stage, then 0 .. D - 1 of the next one)
+    const char* tb_c = g_tab + tap * 16;
+    const char* tb_n = g_tab + tap_n * 16;      // (tap_n = 9 in the last stage: read, never used)
+    const unsigned gc = g_lane + (unsigned)(ss * 128), gn = g_lane + (unsigned)(ss_n * 128);
+    unsigned gv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      gv[i] = (i + D < 8 ? *reinterpret_cast<const unsigned*>(tb_c + (i + D) * 576) + gc : *reinterpret_cast<const unsigned*>(tb_n + (i + D - 8) * 576) + gn);
     df32x16 bl;
 #pragma unroll
     for (int r = 0; r < 16; ++r) bl[r] = 0.f;
     // one K = 16 step: issue the gather D steps ahead, wait for this step's slot (everything but the newest D gathers -- and, while they are
-    // younger than the slot, the WP weight loads of this stage -- has landed), transpose-read it, multiply by the block-diagonal weights
-#define PT_DCN_STEP(S)                                                                                                                   \
+    // younger than the slot, the WP weight DMAs of this stage -- has landed), transpose-read it, multiply by the block-diagonal weights
+#define PT_DCN_STEP(S, LAST)                                                                                                             \
     {                                                                                                                                    \
-      if (S + D < 8) issue(S + D, tap, ss);                                                                                              \
-      else if (!last) issue(S + D - 8, tap_n, ss_n);                                                                                     \
-      if (last) {                                                                                                                        \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S + D < 8 ? D : 7 - S) : "memory");                                                     \
-      } else {                                                                                                                           \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S < D ? D + WP : D) : "memory");                                                        \
-      }                                                                                                                                  \
-      u32x2 a_lo, a_hi;                                                                                                                  \
-      asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"                 \
-                   : "=&v"(a_lo), "=&v"(a_hi)                                                                                            \
-                   : "v"(tr_addr), "n"((S % RING) * 1024), "n"((S % RING) * 1024 + 256)                                                  \
-                   : "memory");                                                                                                          \
+      if (PT_DCN_MABL != 1 && (S + D < 8 || !LAST)) issue(gv[S], (S + D) % RING);                                                        \
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LAST ? (S + D < 8 ? D : 7 - S) : (S < D ? D + WP : D)) : "memory");                       \
+      u32x2 a_lo = {gv[S], gc}, a_hi = {gn, gv[S]};                                                                                      \
+      if (PT_DCN_MABL != 2)                                                                                                              \
+        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"               \
+                     : "=&v"(a_lo), "=&v"(a_hi)                                                                                          \
+                     : "v"(tr_addr), "n"((S % RING) * 1024), "n"((S % RING) * 1024 + 256)                                                \
+                     : "memory");                                                                                                        \
       const bool mine = key == 2 * S;                                                                                                    \
       const u32x4 bw = {mine ? e01 : 0u, mine ? e23 : 0u, mine ? o01 : 0u, mine ? o23 : 0u};                                             \
       const u32x4 aw = {a_lo.x, a_lo.y, a_hi.x, a_hi.y};                                                                                 \
-      bl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dbf16x8, aw), __builtin_bit_cast(dbf16x8, bw), bl, 0, 0, 0);       \
+      if (PT_DCN_MABL != 2 || S == 0)                                                                                                    \
+        bl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dbf16x8, aw), __builtin_bit_cast(dbf16x8, bw), bl, 0, 0, 0);     \
     }
-    PT_DCN_STEP(0) PT_DCN_STEP(1) PT_DCN_STEP(2) PT_DCN_STEP(3) PT_DCN_STEP(4) PT_DCN_STEP(5) PT_DCN_STEP(6) PT_DCN_STEP(7)
+    if (!last) {
+      PT_DCN_STEP(0, false) PT_DCN_STEP(1, false) PT_DCN_STEP(2, false) PT_DCN_STEP(3, false)
+      PT_DCN_STEP(4, false) PT_DCN_STEP(5, false) PT_DCN_STEP(6, false) PT_DCN_STEP(7, false)
+    } else {
+      PT_DCN_STEP(0, true) PT_DCN_STEP(1, true) PT_DCN_STEP(2, true) PT_DCN_STEP(3, true)
+      PT_DCN_STEP(4, true) PT_DCN_STEP(5, true) PT_DCN_STEP(6, true) PT_DCN_STEP(7, true)
+    }
 #undef PT_DCN_STEP
     // bl[8 t + e] = channel 32 hh + 16 t + 8 q + e of pixel lx: the product's B operand after one conversion
     const char* wrd = b_rd + (st & 1) * W_BYTES;
@@ -906,6 +923,8 @@ __global__ __launch_bounds__(512, NB == 64 ? 2 : 1) void dcn_mfma_kernel(const b
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(dbf16x8, cf), acc[nt], 0, 0, 0);   // D = [channel][pixel]
       }
     }
+    tap = tap_n;
+    ss = ss_n;
   }
   // the two channel halves of a pixel tile meet in LDS: wave hh finishes the 32-column tiles [hh NT / 2, (hh + 1) NT / 2)
   __syncthreads();
@@ -1322,17 +1341,17 @@ int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf
     static int mfma_nb = -1;
     if (mfma_nb < 0) {
       const char* nv = getenv("PT_DCN_MFMA_NB");
-      PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_mfma_kernel<64, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, DcnMfmaSmem<64, 4>::BYTES));
+      PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_mfma_kernel<64, PT_DCN_RING64>), hipFuncAttributeMaxDynamicSharedMemorySize, DcnMfmaSmem<64, PT_DCN_RING64>::BYTES));
       PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_mfma_kernel<128, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, DcnMfmaSmem<128, 8>::BYTES));
       mfma_nb = nv ? atoi(nv) : 128;
     }
     const int mfma = e ? e->dcn_mfma : 1;
     if (mfma) {
-      constexpr int smem64 = DcnMfmaSmem<64, 4>::BYTES, smem128 = DcnMfmaSmem<128, 8>::BYTES;
+      constexpr int smem64 = DcnMfmaSmem<64, PT_DCN_RING64>::BYTES, smem128 = DcnMfmaSmem<128, 8>::BYTES;
       if (N % 128 == 0 && mfma_nb == 128)
         hipLaunchKernelGGL((dcn_mfma_kernel<128, 8>), dim3(tiles, N / 128), dim3(512), smem128, s, x, om, w, bias, out, npix, H, W, C, N, relu);
       else
-        hipLaunchKernelGGL((dcn_mfma_kernel<64, 4>), dim3(tiles, N / 64), dim3(512), smem64, s, x, om, w, bias, out, npix, H, W, C, N, relu);
+        hipLaunchKernelGGL((dcn_mfma_kernel<64, PT_DCN_RING64>), dim3(tiles, N / 64), dim3(512), smem64, s, x, om, w, bias, out, npix, H, W, C, N, relu);
       PT_HIP_CHECK(hipGetLastError());
       return PT_OK;
     }
