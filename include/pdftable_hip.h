@@ -69,12 +69,13 @@ int pt_engine_set_lstm_cluster(pt_engine* e, int on);
  * (BASELINE.json configs[4] names fp8; this is where fp8 pays on this path).  A throughput option with recorded drift
  * (tests/test_gpu_mtl.py), off by default; ignored in PT_PRECISION_BF16X3.  Environment default: PT_MTL_KV_FP8. */
 int pt_engine_set_mtl_kv_fp8(pt_engine* e, int on);
-/* Lore detector (pt_tsr_forward*, pt_op_dcn), PT_PRECISION_BF16 only: on = 1 (default) runs the modulated deformable convolutions
+/* Lore detector (pt_tsr_forward*, pt_op_dcn), PT_PRECISION_BF16 only: on = 1 runs the modulated deformable convolutions
  * (model/lore/dcnv2.py:71-86, DCNv2_latest/src/cuda/dcn_v2_im2col_cuda.cu:121-191) with the bilinear blend on the matrix pipe
- * (dcn_mfma_kernel: corner lines by LDS-DMA, blend = MFMA against block-diagonal bf16 weights); on = 0 keeps the VALU blend with fp32
- * weights (dcn_fused64_kernel).  Both are bf16-mode results: the sampled columns differ by the bf16 rounding of the four bilinear x mask
- * weights (<= 2^-9 of a column; tests/test_gpu_dcn_op.py holds both to the oracle).  Ignored in PT_PRECISION_BF16X3.
- * Environment default: PT_DCN_MFMA. */
+ * (dcn_mfma_kernel: corner lines by LDS-DMA, blend = MFMA against block-diagonal bf16 weights); on = 0 (default) keeps the VALU blend
+ * with fp32 weights (dcn_fused64_kernel).  Both are bf16-mode results: the sampled columns differ by the bf16 rounding of the four
+ * bilinear x mask weights (<= 2^-9 of a column; tests/test_gpu_dcn_op.py holds both to the oracle).  Measured equal in speed
+ * (profiles/r04/experiments.txt: both sit on the vector-memory path's gather rate), hence the exact weights by default.
+ * Ignored in PT_PRECISION_BF16X3.  Environment default: PT_DCN_MFMA. */
 int pt_engine_set_dcn_mfma(pt_engine* e, int on);
 
 /* Arithmetic of the conv nets (DESIGN.md "numerics").  PT_PRECISION_BF16: bf16 activations/weights, fp32

@@ -78,7 +78,7 @@ int pt_engine_create(int device_id, pt_engine** out) {
     ev = getenv("PT_MTL_KV_FP8");                   // default of pt_engine_set_mtl_kv_fp8
     e->mtl_kv_fp8 = ev ? (atoi(ev) != 0) : 0;
     ev = getenv("PT_DCN_MFMA");                     // default of pt_engine_set_dcn_mfma
-    e->dcn_mfma = ev ? (atoi(ev) != 0) : 1;
+    e->dcn_mfma = ev ? (atoi(ev) != 0) : 0;
     ev = getenv("PT_REC_RAGGED");                   // 0: the recogniser's conv stack also computes the padding (A/B switch)
     e->rec_ragged = ev ? (atoi(ev) != 0) : 1;
   }

@@ -174,7 +174,7 @@ struct pt_engine {
   void* lstm_scratch8 = nullptr; size_t lstm_scratch8_cap = 0;   // ... of the eight-member hi/lo cluster LSTM
   int* lstm_err = nullptr;                                   // pinned, device-visible: set by a cluster member that gave up waiting
   int lstm_max_cl = 0;                                       // clusters per direction per launch (num_cu / 8)
-  int dcn_mfma = 1;                                          // pt_engine_set_dcn_mfma: bf16-mode deformable convolutions blend on the matrix pipe (dcn_mfma_kernel)
+  int dcn_mfma = 0;                                          // pt_engine_set_dcn_mfma: bf16-mode deformable convolutions blend on the matrix pipe (dcn_mfma_kernel)
   int mtl_kv_fp8 = 0;                                        // pt_engine_set_mtl_kv_fp8: MtlTabNet source-attention keys / values of the structure loop as fp8 (bf16 mode only)
   int lstm_cluster = 1;                                      // 1: weight-stationary cluster kernel (bf16 mode); 0: streaming kernel
   // crnn_model.hip: activations of an all-padding text line after every limited conv layer, per precision (bf16 / hi-lo);

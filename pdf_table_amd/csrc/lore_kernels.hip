@@ -657,12 +657,7 @@ __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) voi
   const int mt = wave & 3, ct0 = (wave >> 2) * NT;      // this wave's 32-pixel row tile and first 32-column tile
   const char* a_rd = s_a + (mt * 32 + lx) * ROW + q * 16;
   const char* b_rd = s_w + (ct0 * 32 + lx) * ROW + q * 16;
-  prefetch(0);
-  for (int st = 0; st < nst; ++st) {
-    __syncthreads();
-    commit();
-    __syncthreads();
-    if (st + 1 < nst) prefetch(st + 1);
+  auto product = [&]() {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const dbf16x8 a = *reinterpret_cast<const dbf16x8*>(a_rd + kk * 32);
@@ -681,6 +676,16 @@ __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) voi
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, a, acc[t], 0, 0, 0);
         }
       }
+    }
+  };
+  {
+    prefetch(0);
+    for (int st = 0; st < nst; ++st) {
+      __syncthreads();
+      commit();
+      __syncthreads();
+      if (st + 1 < nst) prefetch(st + 1);
+      product();
     }
   }
   // weights were the MFMA's A operand: a lane owns pixel mt * 32 + lx, its accumulators are runs of four channels
@@ -727,7 +732,8 @@ __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) voi
 //     ds_read_b128 of the tiled weights, as in dcn_fused64_kernel).  No LDS round trip for the sampled columns.
 //   * the two waves that share a pixel tile (channel halves of the slice) add their partial sums through LDS once per tile.
 // The fp32 sums are associated differently from dcn_fused64_kernel (blend exact in fp32 there, bf16 weights here; K split in
-// halves): both are bf16-mode results within tests/test_gpu_dcn_op.py's bounds.  PT_DCN_MFMA=0 selects dcn_fused64_kernel.
+// halves): both are bf16-mode results within tests/test_gpu_dcn_op.py's bounds.  Opt-in (pt_engine_set_dcn_mfma / PT_DCN_MFMA=1): measured
+// equal in speed to dcn_fused64_kernel on the bench's offset fields (profiles/r04/experiments.txt).
 // ---------------------------------------------------------------------------------------------------------------------
 #ifndef PT_DCN_MABL
 #define PT_DCN_MABL 0      /* ablations of dcn_mfma_kernel (tools/dcn_mfma_abl.sh): 1 no gathers, 2 no transpose-reads / blend products */
@@ -1336,7 +1342,7 @@ int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf
       nthr = ev ? atoi(ev) : 512;
     }
     const unsigned tiles = (unsigned)((long long)B * ((H + 7) / 8) * ((W + 15) / 16));
-    // pt_engine_set_dcn_mfma (default on, PT_DCN_MFMA): the blend on the matrix pipe (dcn_mfma_kernel); off: dcn_fused64_kernel (VALU blend,
+    // pt_engine_set_dcn_mfma (default off, PT_DCN_MFMA): the blend on the matrix pipe (dcn_mfma_kernel); off: dcn_fused64_kernel (VALU blend,
     // fp32 weights); PT_DCN_MFMA_NB=64: 64-wide blocks for every layer
     static int mfma_nb = -1;
     if (mfma_nb < 0) {
@@ -1345,7 +1351,7 @@ int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf
       PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_mfma_kernel<128, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, DcnMfmaSmem<128, 8>::BYTES));
       mfma_nb = nv ? atoi(nv) : 128;
     }
-    const int mfma = e ? e->dcn_mfma : 1;
+    const int mfma = e ? e->dcn_mfma : 0;
     if (mfma) {
       constexpr int smem64 = DcnMfmaSmem<64, PT_DCN_RING64>::BYTES, smem128 = DcnMfmaSmem<128, 8>::BYTES;
       if (N % 128 == 0 && mfma_nb == 128)

@@ -62,8 +62,8 @@ class HipEngine:
         L.check(self.lib.pt_engine_set_mtl_kv_fp8(self._h, 1 if on else 0), "pt_engine_set_mtl_kv_fp8")
 
     def set_dcn_mfma(self, on: bool):
-        """Lore detector, bf16 mode: deformable convolutions with the bilinear blend on the matrix pipe (default on) or on the VALU with
-        fp32 weights (off); see include/pdftable_hip.h"""
+        """Lore detector, bf16 mode: deformable convolutions with the bilinear blend on the matrix pipe (on) or on the VALU with fp32
+        weights (off, the default); see include/pdftable_hip.h"""
         L.check(self.lib.pt_engine_set_dcn_mfma(self._h, 1 if on else 0), "pt_engine_set_dcn_mfma")
 
     def set_lstm_cluster(self, on: bool):

@@ -85,7 +85,7 @@ def test_dcn_op_bf16(eng, C, N, H, W, relu, field, blend):
     """bf16 mode: operands exactly representable; the kernel rounds every sampled column to bf16 before the product, so it is compared
     (a) with the oracle whose columns are rounded the same way -- difference = fp32 summation order + the output's own bf16 rounding --
     and (b) with the un-rounded oracle within the half-ulp-per-column bound.
-    blend "valu": dcn_fused64_kernel (fp32 bilinear x mask weights).  blend "mfma" (the default, pt_engine_set_dcn_mfma): dcn_mfma_kernel
+    blend "valu" (the default): dcn_fused64_kernel (fp32 bilinear x mask weights).  blend "mfma" (pt_engine_set_dcn_mfma): dcn_mfma_kernel
     blends on the matrix pipe against the four weights ROUNDED TO bf16 (2^-9 relative each): a column is then within 2^-9 of its magnitude
     plus its own half ulp, so (a) and (b) carry one more column-ulp term; C % 64 != 0 shapes run dcn_fused_kernel in both settings."""
     B = 2
@@ -114,7 +114,7 @@ def test_dcn_op_bf16(eng, C, N, H, W, relu, field, blend):
     err_b = (got - ref).abs()
     tol_b = ref.abs() * 2.0 ** -8 + col_mag * (2.0 ** -9 + wq) + 1e-4
     assert bool((err_b <= tol_b).all()), f"vs oracle: max err {err_b.max().item()}"
-    eng.set_dcn_mfma(True)
+    eng.set_dcn_mfma(False)
     print(f"dcn bf16 [{blend}] {field} {C}->{N} @{H}x{W}: max err vs rounded-column oracle {err_a.max().item():.3e}, vs oracle {err_b.max().item():.3e}, scale {ref.abs().max().item():.2f}")
 
 
