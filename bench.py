@@ -62,6 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--by-class-only", action="store_true", help="diagnostic: the timed region, then only the roofline.by_class leg")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the det-only and BF16X3 legs (diagnostic runs)")
     ap.add_argument("--det-backbone", default="resnet18", choices=["resnet18", "proxylessnas"],
                     help="DB detector network: DBModel (BASELINE.json's configuration) or DBNasModel (diagnostic variant)")
@@ -770,6 +771,11 @@ class HipRunner:
             if "frac_mfma_peak" in row or "frac_hbm_peak" in row:
                 row["bound"] = "mfma" if row.get("frac_mfma_peak", 0) >= row.get("frac_hbm_peak", 0) else "hbm"
             out[name] = row
+        if os.environ.get("PT_BENCH_LABELS_OUT"):     # every launch label of the step (diagnostic: tools read it to size a kernel class)
+            with open(os.environ["PT_BENCH_LABELS_OUT"], "w") as f:
+                for lab, r in sorted(labels.items(), key=lambda kv: -kv[1]["ms"]):
+                    f.write(f"{r['ms'] / steps:9.3f} ms  {r['launches'] / steps:6.1f} launches  {r['flop'] / steps / 1e9:10.1f} GFLOP  "
+                            f"{r['bytes'] / steps / 1e9:8.2f} GB  {lab}\n")
         top = sorted(labels.items(), key=lambda kv: -kv[1]["ms"])[:16]
         top_labels = {lab: {"ms_per_step": round(r["ms"] / steps, 3), "launches_per_step": round(r["launches"] / steps, 1),
                             **({"frac_mfma_peak": round(r["flop"] / (r["ms"] * 1e-3) / (MFMA_PEAK_TFLOPS * 1e12), 4)} if r["flop"] > 0 and r["ms"] > 0 else {}),
@@ -1209,7 +1215,7 @@ def main(argv=None):
                 roof["all_kernel_classes_ms"] = {k: v["ms"] for k, v in prof.items()}
                 roof["all_kernel_classes_flop"] = {k: v["flop"] for k, v in prof.items()}
             out["roofline"] = roof
-    if not stub and world == 1 and (args.host_pages_leg or not args.no_extra_legs) and not args.no_post:
+    if not stub and world == 1 and (args.host_pages_leg or not (args.no_extra_legs or args.by_class_only)) and not args.no_post:
         try:
             leg = runner.host_pages_leg()
         except Exception as e:      # noqa: BLE001 -- a diagnostic leg
@@ -1233,7 +1239,11 @@ def main(argv=None):
                 pass
             return {"error": f"{type(e).__name__}: {e}"[:300]}
 
-    if not stub and not args.no_extra_legs and world == 1:
+    if not stub and args.by_class_only and world == 1:
+        leg = guarded(runner.by_class_leg)
+        if rank == 0 and leg is not None:
+            out["roofline"]["by_class"] = leg
+    if not stub and not args.no_extra_legs and not args.by_class_only and world == 1:
         if "det" in runner.stages and not runner.nas:
             leg = guarded(runner.det_only_leg)
             if rank == 0:
@@ -1274,7 +1284,7 @@ def main(argv=None):
             out["cpu_baseline"] = cpu_baseline(r.sd, r.pages_np[:2], r.cfg, r.csd if r.rec is not None else None,
                                                tsr=(r.lsd, r.psd, r.table_boxes, r.tables_per_page) if r.tsr is not None else None,
                                                layout=r.ysd if r.layout is not None else None, gpu=gpu)
-        if not stub and not args.no_extra_legs and world == 1 and len(runner.stages) > 1 and not args.no_post:
+        if not stub and not args.no_extra_legs and not args.by_class_only and world == 1 and len(runner.stages) > 1 and not args.no_post:
             # last: the child needs the GPU's memory, so this process gives its engine (activation arenas, weights) and torch's cache back first
             try:
                 runner.eng.close()
