@@ -1494,6 +1494,9 @@ __device__ __forceinline__ float gelu_poly(float x) {
   return xp * fmaf(xc, q, 0.5f);
 }
 
+#ifndef PT_ROWS_ABL
+#define PT_ROWS_ABL 0
+#endif
 template <int KSTEPS, int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __restrict__ A, long long M,
                                                              const bf16_t* __restrict__ W, const float* __restrict__ bias,
@@ -1541,6 +1544,8 @@ __global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __res
   float bv = -INFINITY;
   int bi = 0;
   const int NT = N / 64;
+  // (walking the tiles from a per-workgroup start, to spread the stores' addresses over the memory channels, measured SLOWER: 1.02 -> 1.48 ms for
+  // K = 512 -- the workgroups then stream different weight tiles at the same time)
   prefetch(0);
   for (int t = 0; t < NT; ++t) {
     __syncthreads();
@@ -1556,6 +1561,9 @@ __global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __res
       if (MODE == 1 && !live) continue;
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
+#if PT_ROWS_ABL == 2     /* ablation: one MFMA per half stage */
+        if (MODE == 1 && ks) break;
+#endif
         const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wr + ks * 32);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, areg[ks], acc, 0, 0, 0);
       }
@@ -1566,7 +1574,11 @@ __global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __res
           const float v = acc[r] + sb[cl];
           if (v > bv) { bv = v; bi = t * 64 + cl; }
         }
-      } else if (row < M) {
+      } else {
+        // store epilogue through a wave-private LDS tile: a lane owns a ROW, so storing from the accumulators touches 64 lines with 8 bytes
+        // each per instruction (measured: the 256 -> 2048 projection took 1.76 ms with its stores and 0.23 ms without).  The half stage's
+        // 32 rows x 32 classes are transposed to 64-byte row segments instead: four lanes per row, 16 rows per 16-byte-per-lane store.
+        char* tile = smem + 64 * P + 256 + wave * (32 * 80);          // row pitch 80 bytes
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int cl = half * 32 + rg * 8 + 4 * q;
@@ -1578,8 +1590,20 @@ __global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __res
             else if (relu == 4) v = gelu_poly(v);
             hb[k] = rf2bf(v);
           }
-          *reinterpret_cast<u32x2*>(out + row * N + t * 64 + cl) = u32x2{hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
+          *reinterpret_cast<u32x2*>(tile + lx * 80 + (rg * 8 + 4 * q) * 2) = u32x2{hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the tile is wave-private: LDS operations of a wave complete in order
+        const long long row0 = ((long long)blockIdx.x * 4 + wave) * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = (lane >> 2) + 16 * i;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(tile + r * 80 + (lane & 3) * 16);
+#if PT_ROWS_ABL == 1     /* ablation: no stores */
+          if (v.x == 0x12345u)
+#endif
+          if (row0 + r < M) *reinterpret_cast<u32x4*>(out + (row0 + r) * N + t * 64 + half * 32 + (lane & 3) * 8) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // reads done before the next half overwrites the tile
       }
     }
   }
@@ -1898,10 +1922,10 @@ int pt_launch_gemm_argmax(const bf16_t* A, long long M, int K, const bf16_t* W, 
 int pt_launch_gemm_rows(const bf16_t* A, long long M, int K, const bf16_t* W, const float* bias, int N, bf16_t* out, int relu,
                         hipStream_t s, const int* tlim) {
   if ((K != 512 && K != 256) || N % 64 != 0 || M <= 0) return PT_ERR_INVALID;
-  const int smem = 64 * (K * 2 + 16) + 64 * 4;
+  const int smem = 64 * (K * 2 + 16) + 64 * 4 + 4 * 32 * 80;       // weight stage + bias + the waves' store tiles
   static bool attr_done = false;
   if (!attr_done) {
-    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_argmax_kernel<32, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (512 * 2 + 16) + 256));
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_argmax_kernel<32, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (512 * 2 + 16) + 256 + 4 * 32 * 80));
     attr_done = true;
   }
   const dim3 grid((unsigned)((M + 127) / 128));
