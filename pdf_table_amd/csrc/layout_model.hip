@@ -82,7 +82,9 @@ struct Ctx {
     const PtTensor* b = get(q + ".b");
     if (go()) {
       e->prof.next_bytes = 2.0 * (x3 ? 2 : 1) * n * ((double)in.H * in.W + (double)o.H * o.W) * in.C;
-      PtProfScope ps(e, s, PT_PROF_OTHER, 0, "layout dwconv");
+      char label[48];
+      snprintf(label, sizeof(label), "layout dwconv k%d s%d %d @%dx%d", k, stride, in.C, o.H, o.W);
+      PtProfScope ps(e, s, PT_PROF_OTHER, 0, label);
       const int r = pt_launch_dwconv(in.p, F(w), F(b), o.p, n, in.H, in.W, in.C, k, stride, act, x3, s, nullptr);
       if (r != PT_OK) rc = r;
     }
