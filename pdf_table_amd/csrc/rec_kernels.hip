@@ -1601,7 +1601,11 @@ __global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __res
 #if PT_ROWS_ABL == 1     /* ablation: no stores */
           if (v.x == 0x12345u)
 #endif
+#if PT_ROWS_ABL == 3     /* ablation (timing only, wrong layout): the wave's 32 x 32 half tile stored as 2 KB of consecutive bytes */
+          if (row0 + r < M) *reinterpret_cast<u32x4*>(out + ((row0 >> 5) * (N / 64) + t) * 2048 + half * 1024 + r * 32 + (lane & 3) * 8) = v;
+#else
           if (row0 + r < M) *reinterpret_cast<u32x4*>(out + (row0 + r) * N + t * 64 + half * 32 + (lane & 3) * 8) = v;
+#endif
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // reads done before the next half overwrites the tile
       }
