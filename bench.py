@@ -891,7 +891,7 @@ class HipRunner:
         """The reference's DEFAULT recogniser route: OcrRecognitionTask(model="PP-OCRv4") on an ONNX graph through the generic
         layer-list executor (ocr_recognition_task.py:81-116 -> onnxruntime in the reference; pdf_table_amd/onnx_exec.py here).  The real PP-OCRv4
         file is not available offline: the graph is the SVTR-type stand-in PyTorch's exporter writes (tools/onnx_export.py: conv stem, two
-        LayerNorm / fused-qkv attention / MLP blocks, CTC head with Softmax; 52 layers, static [1, 3, 48, 320] like the shipped exports), seeded.
+        LayerNorm / fused-qkv attention / MLP blocks, CTC head with Softmax; [batch, 3, 48, 320] with a symbolic batch like the shipped exports), seeded.
         Text-line crops of the step's pages -> PPOcrRecPreProcessor kernel -> one graph run per line -> CTCLabelDecode; lines/s in the executor's
         bf16 mode and in its tolerance mode (precision="fp32" -> (hi | lo) activations, <= 1e-3 against the fp32 module: tests/test_gpu_onnx_seq.py)."""
         import tempfile
@@ -914,13 +914,13 @@ class HipRunner:
                     break
             if len(crops) >= n_lines:
                 break
-        out = {"lines": len(crops), "graph": "SvtrTiny stand-in (tools/onnx_export.py), 52 layers, one graph run per line",
+        out = {"lines": len(crops), "graph": "SvtrTiny stand-in (tools/onnx_export.py), dynamic batch like the shipped exports (Shape / Gather / Concat glue), static 48 x 320 input: a six-line mini-batch is one walk, replayed from a captured HIP graph",
                "asserted_by": "tests/test_gpu_onnx_seq.py (bf16: similarity bounds; precision='fp32': strings identical to the fp32 module's)"}
         with tempfile.TemporaryDirectory() as td:
             with open(os.path.join(td, "ppocr_keys_v1.txt"), "w", encoding="utf-8") as f:
                 f.write("\n".join(chr(0x4E00 + i) for i in range(95)) + "\n")
             with open(os.path.join(td, "inference.onnx"), "wb") as f:
-                f.write(X.torch_export(X.seeded(X.SvtrTiny(classes=97), 31), torch.zeros(1, 3, 48, 320)))
+                f.write(X.torch_export(X.seeded(X.SvtrTiny(classes=97), 31), torch.zeros(2, 3, 48, 320), dynamic_batch=True))
             for name, prec in (("bf16", "bf16"), ("bf16x3", "fp32")):
                 task = OcrRecognitionTask(model="PP-OCRv4", task_type="ch", task_path=td, engine=self.eng, precision=prec)
                 task(crops[:16])

@@ -79,6 +79,7 @@ class OcrRecognitionTask(BaseInferTask):
         # wider than imgW are resized to imgW, resize_norm_img processor_ocr_rec_pp.py:43-58); a dynamic-width graph keeps the defaults
         shp = list(getattr(self._exec.inputs[0], "shape", []) or [])
         static = len(shp) == 4 and all(isinstance(d, int) and d > 0 for d in shp[1:])
+        self._batch1 = len(shp) == 4 and isinstance(shp[0], int) and shp[0] == 1       # batch size baked in: one walk per line
         cfg = PPOcrRecConfig(rec_image_shape=f"{shp[1]}, {shp[2]}, {shp[3]}", limited_max_width=int(shp[3])) if static else PPOcrRecConfig()
         self._pp = PPOcrRecPreProcessor(cfg, engine=self._engine)
         d = self.kwargs.get("character_dict_path")
@@ -97,20 +98,21 @@ class OcrRecognitionTask(BaseInferTask):
         texts, scores = [""] * len(crops), [0.0] * len(crops)
         for b in self._pp(list(crops)):
             img = b["image"]                                     # f32 [n, 3, 48, imgW] on the device
-            confs, idss = [], []
-            for i in range(img.shape[0]):                        # one line per run: static exports have their batch size baked in
-                x = img[i:i + 1].permute(0, 2, 3, 1).contiguous()
-                if not self._exec.split:                     # the tolerance mode takes the fp32 image and splits it into (hi, lo) itself
-                    x = x.to(torch.bfloat16)
-                (a,) = self._exec.run_device(x, 3)
+            # static exports have their batch size baked in: one graph walk per line, the mini-batch's walks captured into one HIP graph
+            x = img.permute(0, 2, 3, 1).contiguous()
+            if not self._exec.split:                         # the tolerance mode takes the fp32 image and splits it into (hi, lo) itself
+                x = x.to(torch.bfloat16)
+            outs = self._exec.run_lines_graphed(x, 3) if self._batch1 else [self._exec.run_device_graphed(x, 3)]    # dynamic batch: one walk
+            probs = []
+            for (a,) in outs:
                 if not a.seq or a.c != len(self._ctc.character):
                     raise UnsupportedOnnxGraph(f"recogniser output of shape {a.shape()}: [B, T, {len(self._ctc.character)}] (blank + dictionary"
                                                " + space) is expected")
-                conf, ids = self._exec.values(a)[0, 0].max(-1)    # fp32 probabilities (the executor keeps a final Softmax in fp32)
-                confs.append(conf)
-                idss.append(ids)
+                v = self._exec.values(a)                         # fp32 probabilities [b, 1, T, classes] (the executor keeps a final Softmax in fp32)
+                probs.append(v.reshape(v.shape[0], v.shape[-2], v.shape[-1]))
+            conf, ids = torch.cat(probs).max(-1)
             # one device -> host copy per mini-batch (all lines of a mini-batch share imgW, hence T)
-            conf_h, ids_h = torch.stack(confs).cpu().numpy(), torch.stack(idss).cpu().numpy()
+            conf_h, ids_h = conf.cpu().numpy(), ids.cpu().numpy()
             for i, (text, sc) in enumerate(self._ctc.decode_ids(ids_h, conf_h)):
                 k = int(b["indices"][b["batch_beg_img_no"] + i])
                 texts[k], scores[k] = text, float(sc)

@@ -42,6 +42,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
+import os
+
 import numpy as np
 import torch
 
@@ -114,6 +116,7 @@ class HipGraphExecutor:
         if len(self.inputs) != 1:
             raise UnsupportedOnnxGraph(f"the executor takes graphs with one image input, this one has {[i.name for i in self.inputs]}")
         self._dev: Dict[int, Dict[str, torch.Tensor]] = {}      # layer index -> uploaded operands (filled on first use)
+        self._graphs: Dict[tuple, object] = {}                  # input shape -> captured HIP graph (run_device_graphed)
         self._fuse = self._plan_add_fusion()
 
     def _plan_add_fusion(self) -> Dict[int, tuple]:
@@ -469,6 +472,56 @@ class HipGraphExecutor:
         raise UnsupportedOnnxGraph(f"{lay.name}: MatMul of two computed tensors outside the fused-qkv attention pattern "
                                    "(q, k, v = qkv.reshape(B, T, 3, heads, d).permute(2, 0, 3, 1, 4))")
 
+    def run_device_graphed(self, nhwc: torch.Tensor, c: int) -> List[_Act]:
+        """run_device() replayed from a captured HIP graph, one per input shape.  The layer list is walked from Python -- tens of launches of a
+        few microseconds each with the interpreter between them: a 52-layer recogniser spends 1.8 ms per line that way, most of it on the
+        host.  The first call for a shape runs eagerly (weights are uploaded, the engine's arenas sized), the second captures the same walk
+        into a graph (torch.cuda.graph: every pt_op_* launch goes to the capturing stream, activations come from the graph's pool), later
+        calls copy the input into the captured buffer and replay.  Same kernels, same arguments: same bits as run_device().  The returned
+        activations are the graph's own buffers -- read them before the next call.  PT_ONNX_GRAPH=0, or a shape after the first eight
+        distinct ones, runs eagerly."""
+        key = (tuple(nhwc.shape), nhwc.dtype, int(c))
+        ent = self._graphs.get(key)
+        if ent is None:
+            if os.environ.get("PT_ONNX_GRAPH", "1") == "0" or len(self._graphs) >= 8:
+                return self.run_device(nhwc, c)
+            self._graphs[key] = "warm"
+            return self.run_device(nhwc, c)
+        if ent == "warm":
+            torch.cuda.synchronize(self.eng._tdev)
+            static_in = nhwc.clone()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs = self.run_device(static_in, c)
+            ent = self._graphs[key] = (g, static_in, outs)
+        g, static_in, outs = ent
+        static_in.copy_(nhwc)
+        g.replay()
+        return outs
+
+    def run_lines_graphed(self, nhwc: torch.Tensor, c: int) -> List[List[_Act]]:
+        """a batch [n, H, W, c] through a graph whose batch size is baked in as 1 (static exports): the n single-image walks are captured
+        into ONE HIP graph, so that a mini-batch costs one copy and one replay -> per image the outputs of run_device().  Same rules as
+        run_device_graphed (first call eager, second captures; outputs are the graph's buffers)."""
+        n = int(nhwc.shape[0])
+        key = ("lines",) + tuple(nhwc.shape) + (nhwc.dtype, int(c))
+        ent = self._graphs.get(key)
+        if ent is None or os.environ.get("PT_ONNX_GRAPH", "1") == "0":
+            if ent is None and len(self._graphs) < 8 and os.environ.get("PT_ONNX_GRAPH", "1") != "0":
+                self._graphs[key] = "warm"
+            return [self.run_device(nhwc[i:i + 1], c) for i in range(n)]
+        if ent == "warm":
+            torch.cuda.synchronize(self.eng._tdev)
+            static_in = nhwc.clone()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs = [self.run_device(static_in[i:i + 1], c) for i in range(n)]
+            ent = self._graphs[key] = (g, static_in, outs)
+        g, static_in, outs = ent
+        static_in.copy_(nhwc)
+        g.replay()
+        return outs
+
     def run_device(self, nhwc: torch.Tensor, c: int) -> List[_Act]:
         """bf16 NHWC batch on the device whose first ``c`` channels are the image (what pt_det_preprocess / pt_cls_preprocess
         write) -> the graph outputs as device activations (bf16 NHWC, ``.t[..., :.c]`` are the real channels; ``values()`` gives them as fp32 in
@@ -490,7 +543,7 @@ class HipGraphExecutor:
             op = lay.op
             if op == "glue" or (op == "concat" and all((i in self.graph.init or isinstance(env.get(i), np.ndarray)) for i in lay.inputs)):
                 for o, v in zip(lay.outputs, self._glue(lay, env)):
-                    env[o] = v
+                    env[o] = np.asarray(v) if isinstance(v, (np.generic, int, float)) else v      # host constants stay ndarrays (0-d included)
                 continue
             raw = [env[i] for i in lay.inputs if i in env]
             if op in ("add", "mul", "sub", "div") and lay.extra and all(np.asarray(v).size == 1 for v in lay.extra.values()) and len(raw) == 1 \
@@ -500,7 +553,7 @@ class HipGraphExecutor:
                 if isinstance(v, np.ndarray):            # integer shape arithmetic
                     first_is_const = lay.attrs["all_inputs"][0] not in env
                     a_, b_ = (cst, v) if first_is_const else (v, cst)
-                    env[lay.outputs[0]] = {"add": np.add, "mul": np.multiply, "sub": np.subtract, "div": np.floor_divide if v.dtype.kind in "iu" else np.divide}[op](a_, b_)
+                    env[lay.outputs[0]] = np.asarray({"add": np.add, "mul": np.multiply, "sub": np.subtract, "div": np.floor_divide if v.dtype.kind in "iu" else np.divide}[op](a_, b_))
                     continue
                 if op in ("mul", "div"):                 # the 1 / sqrt(d) of an attention, on q or on the scores
                     f = cst if op == "mul" else 1.0 / cst

@@ -48,6 +48,49 @@ def test_svtr_tiny_recogniser(eng, act):
     assert np.array_equal(got, again)
 
 
+def test_dynamic_batch_export(eng):
+    """an export with a symbolic batch axis (the shipped PP-OCR files): the Reshape targets come out of Shape -> Gather -> Concat arithmetic the
+    executor folds on the host per input shape -- the same file runs batches of 2 and of 5, tolerance mode within 1e-3 of the fp32 module"""
+    import onnx_export as X
+    from pdf_table_amd.onnx_exec import HipGraphExecutor
+    m = X.seeded(X.SvtrTiny(act="gelu"), 17)
+    ex = HipGraphExecutor(X.torch_export(m, torch.zeros(2, 3, 32, 64), dynamic_batch=True), engine=eng, precision="bf16x3")
+    assert not isinstance(ex.inputs[0].shape[0], int)
+    g = torch.Generator().manual_seed(3)
+    for n in (2, 5):
+        x = torch.randn(n, 3, 32, 64, generator=g)
+        got = ex.run(x.numpy())[0]
+        with torch.no_grad():
+            want = m(x).numpy()
+        assert got.shape == want.shape == (n, 8 * 16, 97)
+        assert float(np.abs(got - want).max()) <= 1e-3
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_graph_replay_equals_the_eager_walk(eng, precision):
+    """run_device_graphed(): eager on the first call for a shape, captured on the second, replayed afterwards -- the same launches, so the same bits
+    as run_device() for every input; a second input shape gets its own graph"""
+    import onnx_export as X
+    from pdf_table_amd.onnx_exec import HipGraphExecutor
+    m = X.seeded(X.SvtrTiny(act="gelu"), 13)
+    ex = HipGraphExecutor(X.torch_export(m, torch.zeros(1, 3, 32, 64)), engine=eng, precision=precision)
+    g = torch.Generator().manual_seed(9)
+    dev = torch.device("cuda", 0)
+    dt = torch.float32 if precision == "bf16x3" else torch.bfloat16
+    xs = [torch.randn(1, 32, 64, 3, generator=g).to(dt).to(dev) for _ in range(5)]
+    want = [ex.values(ex.run_device(x, 3)[0]).clone() for x in xs]
+    got = [ex.values(ex.run_device_graphed(x, 3)[0]).clone() for x in xs]          # call 1 eager, call 2 captures, calls 3.. replay
+    assert len(ex._graphs) == 1 and not isinstance(next(iter(ex._graphs.values())), str)
+    for w, o in zip(want, got):
+        assert torch.equal(w, o)
+    # a mini-batch of single-image walks in ONE graph (what OcrRecognitionTask does with a static batch-1 export)
+    xb = torch.cat(xs[:3])
+    for _ in range(3):                                            # eager, capture, replay
+        outs = ex.run_lines_graphed(xb, 3)
+        for w, (a,) in zip(want[:3], outs):
+            assert torch.equal(w, ex.values(a))
+
+
 @pytest.mark.parametrize("act", ["gelu", "silu"])
 def test_svtr_tiny_recogniser_tolerance_mode(eng, act):
     """the SVTR-type recogniser in the executor's tolerance mode (precision="bf16x3"): LayerNorm, fused-qkv attention, GELU / swish, Softmax on

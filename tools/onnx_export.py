@@ -28,18 +28,21 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pdf_table_amd.onnx_proto import OnnxModel, OnnxNode, OnnxValueInfo, serialize_model  # noqa: E402
 
 
-def torch_export(module: torch.nn.Module, example: torch.Tensor, input_name="x", output_name="y", opset=13) -> bytes:
+def torch_export(module: torch.nn.Module, example: torch.Tensor, input_name="x", output_name="y", opset=13, dynamic_batch=False) -> bytes:
+    """dynamic_batch: axis 0 of the input and the output is symbolic (as in the shipped PP-OCR exports): the graph then carries its
+    Shape -> Gather -> Concat arithmetic instead of baked Reshape constants"""
     import torch.onnx
     from torch.onnx._internal.torchscript_exporter import utils as TU
     from torch.onnx._internal.torchscript_exporter._globals import GLOBALS
     module = module.eval()
+    dyn = {input_name: {0: "batch"}, output_name: {0: "batch"}} if dynamic_batch else {}
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         GLOBALS.export_onnx_opset_version = opset
         with torch.no_grad():
             graph, params, _ = TU._model_to_graph(module, (example,), False, [input_name], [output_name],
-                                                  torch.onnx.OperatorExportTypes.ONNX, True, dynamic_axes={})
-        proto = graph._export_onnx(params, opset, {}, False, torch.onnx.OperatorExportTypes.ONNX, True, True, {}, True, "", {})[0]
+                                                  torch.onnx.OperatorExportTypes.ONNX, True, dynamic_axes=dyn)
+        proto = graph._export_onnx(params, opset, dyn, False, torch.onnx.OperatorExportTypes.ONNX, True, True, {}, True, "", {})[0]
     return bytes(proto)
 
 
