@@ -1497,8 +1497,10 @@ __device__ __forceinline__ float gelu_poly(float x) {
 #ifndef PT_ROWS_ABL
 #define PT_ROWS_ABL 0
 #endif
-template <int KSTEPS, int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __restrict__ A, long long M,
+// NW: waves per workgroup (4 or 8).  Every workgroup streams ALL of W through its LDS stage: with eight waves on one stage instead of two
+// workgroups of four, a CU moves half the weight bytes (global -> registers -> ds_write at ~79 B/clk, which was 40 % of the MFMA time).
+template <int KSTEPS, int MODE, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 2) void gemm_argmax_kernel(const bf16_t* __restrict__ A, long long M,
                                                              const bf16_t* __restrict__ W, const float* __restrict__ bias,
                                                              int N, int* __restrict__ ids, float* __restrict__ maxv,
                                                              bf16_t* __restrict__ out, int relu, const int* __restrict__ tlim,
@@ -1506,19 +1508,20 @@ __global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __res
   // lda: elements between rows of A (K, or 2 K for the hi halves of (hi | lo) rows); wts: elements between 64-class tiles of W
   // (NCH * 2048, or three times that for the first third -- the w_hi chunks -- of the three-pass tiling)
   constexpr int K = KSTEPS * 16, NCH = K / 32, P = K * 2 + 16;     // P: LDS row pitch in bytes (odd number of 16-B slots)
-  constexpr int NPF = 64 * K * 2 / 16 / 256;                        // 16-byte pieces per thread per stage
+  constexpr int NTHR = NW * 64, NPF = 64 * K * 2 / 16 / NTHR;          // 16-byte pieces per thread per stage
+  static_assert(64 * K * 2 / 16 % NTHR == 0, "a stage is whole passes of the workgroup");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sw = smem;                                                  // [64 classes][P]
   float* sb = reinterpret_cast<float*>(smem + 64 * P);              // [64] bias of the stage
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lx = lane & 31, q = lane >> 5;
-  const long long row = ((long long)blockIdx.x * 4 + wave) * 32 + lx;
+  const long long row = ((long long)blockIdx.x * NW + wave) * 32 + lx;
   const long long rc = row < M ? row : M - 1;
   // ragged sequences (MODE 1): a wave's 32 rows are 32 consecutive time steps of ONE line (T = 160 = 5 x 32); groups at or
   // beyond the line's limit are not computed (the caller fills them), a workgroup with no live wave leaves at once
   bool live = true;
   if (MODE == 1 && tlim) {
-    const long long r0 = ((long long)blockIdx.x * 4 + wave) * 32;
+    const long long r0 = ((long long)blockIdx.x * NW + wave) * 32;
     live = r0 < M && (int)(r0 % PT_REC_T) < tlim[r0 / PT_REC_T];
     if (!__syncthreads_or(live ? 1 : 0)) return;
   }
@@ -1530,13 +1533,13 @@ __global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __res
   auto prefetch = [&](int t) {
     const bf16_t* wt = W + (size_t)t * wts;
 #pragma unroll
-    for (int j = 0; j < NPF; ++j) pf[j] = *reinterpret_cast<const u32x4*>(wt + (size_t)(tid + j * 256) * 8);
+    for (int j = 0; j < NPF; ++j) pf[j] = *reinterpret_cast<const u32x4*>(wt + (size_t)(tid + j * NTHR) * 8);
     if (tid < 64) pb = bias[t * 64 + tid];
   };
   auto commit = [&]() {
 #pragma unroll
     for (int j = 0; j < NPF; ++j) {
-      const int idx = tid + j * 256, c = idx >> 8, r = (idx & 255) >> 2, part = idx & 3;    // chunk, class row, 16-B part
+      const int idx = tid + j * NTHR, c = idx >> 8, r = (idx & 255) >> 2, part = idx & 3;    // chunk, class row, 16-B part
       *reinterpret_cast<u32x4*>(sw + r * P + c * 64 + part * 16) = pf[j];
     }
     if (tid < 64) sb[tid] = pb;
@@ -1593,7 +1596,7 @@ __global__ __launch_bounds__(256, 2) void gemm_argmax_kernel(const bf16_t* __res
           *reinterpret_cast<u32x2*>(tile + lx * 80 + (rg * 8 + 4 * q) * 2) = u32x2{hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the tile is wave-private: LDS operations of a wave complete in order
-        const long long row0 = ((long long)blockIdx.x * 4 + wave) * 32;
+        const long long row0 = ((long long)blockIdx.x * NW + wave) * 32;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int r = (lane >> 2) + 16 * i;
@@ -1902,6 +1905,18 @@ int pt_launch_gemm_argmax_x3(const bf16_t* A, long long M, int K, const bf16_t* 
 
 // A: bf16 [M][K] row-major, W: conv-tiled [N/64][K/32][64][32], bias fp32 [N]; K == 512 only (returns PT_ERR_INVALID otherwise
 // so that the caller can fall back to the tiled kernel + reduce)
+// Waves per workgroup of the streaming GEMMs.  Measured (rec-only bench, 5 082 lines): the K = 512 classifier 6.34 -> 5.68 ms with eight waves on
+// one weight stage; the store-epilogue GEMMs do not gain (512 -> 2048: 1.00 -> 1.03 ms) or lose (256 -> 2048: 1.48 -> 1.81 ms: half as many
+// workgroups hide each other's store tails), so they and the K = 192 head keep four.  PT_GEMM_NW=4 / 8 forces one size everywhere (A/B switch).
+static int gemm_nw(int dflt) {
+  static int nw = -1;
+  if (nw < 0) {
+    const char* ev = getenv("PT_GEMM_NW");
+    nw = ev ? (atoi(ev) == 8 ? 8 : 4) : 0;
+  }
+  return nw ? nw : dflt;
+}
+
 int pt_launch_gemm_argmax(const bf16_t* A, long long M, int K, const bf16_t* W, const float* bias, int N, int* ids, float* maxv,
                           hipStream_t s) {
   if ((K != 512 && K != 192) || N % 64 != 0 || M <= 0) return PT_ERR_INVALID;      // 512: CRNN head; 192: ConvNextViT head
@@ -1910,14 +1925,19 @@ int pt_launch_gemm_argmax(const bf16_t* A, long long M, int K, const bf16_t* W, 
   if (!attr_done) {
     PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_argmax_kernel<32, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_argmax_kernel<12, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_argmax_kernel<32, 0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_argmax_kernel<12, 0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_done = true;
   }
-  if (K == 192)
-    hipLaunchKernelGGL((gemm_argmax_kernel<12, 0>), dim3((unsigned)((M + 127) / 128)), dim3(256), 64 * (192 * 2 + 16) + 64 * 4, s, A, M, W, bias, N,
-                       ids, maxv, nullptr, 0, nullptr, 192, 6ll * 2048);
-  else
-    hipLaunchKernelGGL((gemm_argmax_kernel<32, 0>), dim3((unsigned)((M + 127) / 128)), dim3(256), SMEM, s, A, M, W, bias, N, ids, maxv,
-                       nullptr, 0, nullptr, 512, 16ll * 2048);
+  const int nw = gemm_nw(K == 512 ? 8 : 4);
+  const dim3 grid((unsigned)((M + nw * 32 - 1) / (nw * 32))), blk(nw * 64);
+  if (K == 192) {
+    if (nw == 8) hipLaunchKernelGGL((gemm_argmax_kernel<12, 0, 8>), grid, blk, 64 * (192 * 2 + 16) + 64 * 4, s, A, M, W, bias, N, ids, maxv, nullptr, 0, nullptr, 192, 6ll * 2048);
+    else hipLaunchKernelGGL((gemm_argmax_kernel<12, 0>), grid, blk, 64 * (192 * 2 + 16) + 64 * 4, s, A, M, W, bias, N, ids, maxv, nullptr, 0, nullptr, 192, 6ll * 2048);
+  } else {
+    if (nw == 8) hipLaunchKernelGGL((gemm_argmax_kernel<32, 0, 8>), grid, blk, SMEM, s, A, M, W, bias, N, ids, maxv, nullptr, 0, nullptr, 512, 16ll * 2048);
+    else hipLaunchKernelGGL((gemm_argmax_kernel<32, 0>), grid, blk, SMEM, s, A, M, W, bias, N, ids, maxv, nullptr, 0, nullptr, 512, 16ll * 2048);
+  }
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
@@ -1926,17 +1946,22 @@ int pt_launch_gemm_argmax(const bf16_t* A, long long M, int K, const bf16_t* W, 
 int pt_launch_gemm_rows(const bf16_t* A, long long M, int K, const bf16_t* W, const float* bias, int N, bf16_t* out, int relu,
                         hipStream_t s, const int* tlim) {
   if ((K != 512 && K != 256) || N % 64 != 0 || M <= 0) return PT_ERR_INVALID;
-  const int smem = 64 * (K * 2 + 16) + 64 * 4 + 4 * 32 * 80;       // weight stage + bias + the waves' store tiles
+  const int nw = gemm_nw(4);
+  const int smem = 64 * (K * 2 + 16) + 64 * 4 + nw * 32 * 80;       // weight stage + bias + the waves' store tiles
   static bool attr_done = false;
   if (!attr_done) {
     PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_argmax_kernel<32, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (512 * 2 + 16) + 256 + 4 * 32 * 80));
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_argmax_kernel<32, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (512 * 2 + 16) + 256 + 8 * 32 * 80));
     attr_done = true;
   }
-  const dim3 grid((unsigned)((M + 127) / 128));
-  if (K == 512)
-    hipLaunchKernelGGL((gemm_argmax_kernel<32, 1>), grid, dim3(256), smem, s, A, M, W, bias, N, nullptr, nullptr, out, relu, tlim, 512, 16ll * 2048);
-  else
-    hipLaunchKernelGGL((gemm_argmax_kernel<16, 1>), grid, dim3(256), smem, s, A, M, W, bias, N, nullptr, nullptr, out, relu, tlim, 256, 8ll * 2048);
+  const dim3 grid((unsigned)((M + nw * 32 - 1) / (nw * 32))), blk(nw * 64);
+  if (K == 512) {
+    if (nw == 8) hipLaunchKernelGGL((gemm_argmax_kernel<32, 1, 8>), grid, blk, smem, s, A, M, W, bias, N, nullptr, nullptr, out, relu, tlim, 512, 16ll * 2048);
+    else hipLaunchKernelGGL((gemm_argmax_kernel<32, 1>), grid, blk, smem, s, A, M, W, bias, N, nullptr, nullptr, out, relu, tlim, 512, 16ll * 2048);
+  } else {
+    if (nw == 8) hipLaunchKernelGGL((gemm_argmax_kernel<16, 1, 8>), grid, blk, smem, s, A, M, W, bias, N, nullptr, nullptr, out, relu, tlim, 256, 8ll * 2048);
+    else hipLaunchKernelGGL((gemm_argmax_kernel<16, 1>), grid, blk, smem, s, A, M, W, bias, N, nullptr, nullptr, out, relu, tlim, 256, 8ll * 2048);
+  }
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
