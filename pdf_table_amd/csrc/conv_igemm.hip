@@ -749,17 +749,23 @@ __global__ __launch_bounds__(256, KS == 1 ? 4 : 2) void conv_igemm_kernel(ConvK 
 // 16-byte halves swapped on rows with bit 3 set (applied on the DMA source and on the ds_read address).
 // Weights are read straight from the 32-channel tiling of v1 (half of every 64-byte row per slice).
 // ---------------------------------------------------------------------------------------------------
-template <int NT, int NWV = 8>
+// S = 2 (stride-2 layers with N % 128 == 0: the ResNet / DLA down-sampling convs): a wave owns TWO row-tiles, the workgroup 8 x 32 output pixels x 128
+// channels from a 17 x 65 input patch whose rows are stored even columns first (tap s of output pixel lx reads column 2 lx + s: slot lx,
+// 33 + lx, lx + 1 -- 32 consecutive slots per fragment, as at stride 1).  The register-staged stride-2 tile (4 x 32 x 64, a 37 KB weight slice
+// per 36 MFMAs of a wave) ran these layers at 16-25 % of the peak.
+template <int NT, int NWV = 8, int S = 1>
 struct Dma16Cfg {
   static constexpr int NTHR = 64 * NWV;
-  static constexpr int TH = NT == 1 ? 4 * NWV : 2 * NWV, TW = 32;
+  static constexpr int MT = S == 1 ? 4 : 2;                   // MFMA row-tiles (patch rows) per wave
+  static constexpr int TH = (NT == 1 ? NWV : NWV / 2) * MT, TW = 32;
   static constexpr int NW = 64 * NT;                          // output channels per workgroup
-  static constexpr int THIN = TH + 2, TWIN = TW + 2;
-  static constexpr int NPIX = THIN * TWIN;                    // 1156 / 612
+  static constexpr int THIN = (TH - 1) * S + 3, TWIN = (TW - 1) * S + 3;
+  static constexpr int XEVEN = (TWIN + 1) / 2;                // S = 2: even input columns of a patch row (stored first)
+  static constexpr int NPIX = THIN * TWIN;                    // 1156 / 612; S = 2: 1105
   static constexpr int IN_BYTES = NPIX * 32;
   static constexpr int W_BYTES = 9 * NW * 32;
   static constexpr int BUF_BYTES = IN_BYTES + W_BYTES;        // 55424 / 56448
-  static constexpr int PASS_ROWS = 2 * NWV;                  // patch rows per epilogue pass (half of the waves)
+  static constexpr int PASS_ROWS = NT == 1 ? TH / 2 : TH;    // patch rows per epilogue pass (half of the waves / one 64-channel half)
   static constexpr int STAGE_BYTES = PASS_ROWS * 32 * 64 * 4; // one epilogue pass: 64 channels fp32
   static constexpr int SMEM = 2 * BUF_BYTES > STAGE_BYTES ? 2 * BUF_BYTES : STAGE_BYTES;
   static constexpr int IN_UNITS = NPIX * 2;
@@ -770,9 +776,9 @@ struct Dma16Cfg {
   static constexpr int W_SLOTS = (W_INSTR + NWV - 1) / NWV;
 };
 
-template <int NT, int NWV>
+template <int NT, int NWV, int S = 1>
 __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_dma16_kernel(ConvK p, const bf16_t* __restrict__ zero_page) {
-  using C = Dma16Cfg<NT, NWV>;
+  using C = Dma16Cfg<NT, NWV, S>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -803,8 +809,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_dma16_kernel(ConvK p, con
     on_in[j] = (k < C::IN_INSTR) && (U < C::IN_UNITS);
     const int pix = U >> 1;
     const int q = (U & 1) ^ ((pix >> 3) & 1);
-    const int iy = pix / C::TWIN, ix = pix - iy * C::TWIN;
-    const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
+    const int iy = pix / C::TWIN, sx = pix - iy * C::TWIN;
+    const int ix = S == 1 ? sx : (sx < C::XEVEN ? 2 * sx : 2 * (sx - C::XEVEN) + 1);     // slot of the row -> input column of the patch
+    const int gy = oy0 * S - 1 + iy, gx = ox0 * S - 1 + ix;
     const bool inside = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
     src_in[j] = inside ? in_b + ((size_t)gy * p.W + gx) * in_cs + q * 8 : zero_page;
   }
@@ -850,15 +857,15 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_dma16_kernel(ConvK p, con
     }
   };
 
-  f32x16 acc[4][2];
+  f32x16 acc[C::MT][2];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < C::MT; ++m)
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  const int pa0 = (4 * wm) * C::TWIN + lx;                              // pixel of row-tile 0, tap (0,0)
+  const int pa0 = (S * C::MT * wm) * C::TWIN + lx;                      // pixel of row-tile 0, tap (0,0)
   const int boff = (wn * 64 + lx) * 32 + ((qh ^ ((lx >> 3) & 1)) << 4);  // weight row n = wn*64 + nt*32 + lx
 
   const int t64 = NT * nb + (NT == 2 ? wn : 0);            // this wave's 64-channel output tile
@@ -878,9 +885,10 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_dma16_kernel(ConvK p, con
         if (!((tmask >> tap) & 1u)) continue;      // wave-uniform: this wave's 64 output channels have zero weights on the tap
         const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(s_w + (tap * C::NW) * 32 + boff);
         const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(s_w + (tap * C::NW + 32) * 32 + boff);
+        const int soff = S == 1 ? s : ((s & 1) * C::XEVEN + (s >> 1));
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int pp = pa0 + (m + r) * C::TWIN + s;
+        for (int m = 0; m < C::MT; ++m) {
+          const int pp = pa0 + (S * m + r) * C::TWIN + soff;
           const bf16x8 a = *reinterpret_cast<const bf16x8*>(s_in + pp * 32 + ((qh ^ ((pp >> 3) & 1)) << 4));
           acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
           acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
@@ -896,9 +904,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_dma16_kernel(ConvK p, con
     __syncthreads();
     const bool mine = NT == 1 ? ((wave / (NWV / 2)) == pass) : (wn == pass);
     if (mine) {
-      const int rbase = NT == 1 ? 4 * (wave % (NWV / 2)) : 4 * wm;   // local patch row inside this pass' rows
+      const int rbase = NT == 1 ? C::MT * (wave % (NWV / 2)) : C::MT * wm;   // local patch row inside this pass' rows
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < C::MT; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -1764,12 +1772,12 @@ static bool use_dma_kernel() {
   return v != 0;
 }
 
-template <int NT, int NWV>
+template <int NT, int NWV, int S = 1>
 static int launch_dma16(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
-  using C = Dma16Cfg<NT, NWV>;
+  using C = Dma16Cfg<NT, NWV, S>;
   static bool attr_done = false;
   if (!attr_done) {
-    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma16_kernel<NT, NWV>),
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma16_kernel<NT, NWV, S>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
     attr_done = true;
   }
@@ -1783,9 +1791,9 @@ static int launch_dma16(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   const long long nblk = (long long)k.B * k.tiles_x * k.tiles_y * k.n_tiles;
   PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range (%lld blocks)", nblk);
   char label[48];
-  snprintf(label, sizeof(label), "conv3x3 v3%s %d->%d @%dx%d%s", NWV == 4 ? "h" : "", k.Cin, k.N, k.Ho, k.Wo, k.split ? " x3" : "");
+  snprintf(label, sizeof(label), "conv3x3 %s%s %d->%d @%dx%d%s", S == 2 ? "s2 v3" : "v3", NWV == 4 ? "h" : "", k.Cin, k.N, k.Ho, k.Wo, k.split ? " x3" : "");
   PtProfScope prof(e, s, PT_PROF_CONV3X3, flop, label);
-  hipLaunchKernelGGL((conv3x3_dma16_kernel<NT, NWV>), dim3((unsigned)nblk), dim3(C::NTHR), C::SMEM, s, k,
+  hipLaunchKernelGGL((conv3x3_dma16_kernel<NT, NWV, S>), dim3((unsigned)nblk), dim3(C::NTHR), C::SMEM, s, k,
                      reinterpret_cast<const bf16_t*>(e->zero_page));
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
@@ -1903,6 +1911,16 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
     if (d.res || d.res_f32) by += (double)k.B * k.Ho * k.Wo * nstore * (d.res_f32 ? 4.0 : 2.0 * mact) / (d.res_mode == 2 ? 4.0 : 1.0);
     by += (double)d.N * d.Cin * d.ks * d.ks * 2.0 * (d.split == 2 ? 2 : (d.split ? 3 : 1));
     e->prof.next_bytes = by;
+  }
+  // stride-2 3x3 layers with 128-wide output blocks (ResNet-18 / DLA-34 down-sampling convs): the 16-channel-slice DMA kernel on an 8 x 32 x 128 tile
+  // (PT_CONV_S2_DMA=0: the register-staged 4 x 32 x 64 tile, A/B switch)
+  if (d.ks == 3 && d.stride == 2 && !d.split && d.N % 128 == 0 && d.Cin % 32 == 0 && d.Cin >= 64 && k.Ho >= 8 && !d.head_w && !d.argmax_part && !d.n_valid &&
+      !d.out_f32 && !d.res_f32 && !d.res && d.relu < 2 && !d.ylimit && !d.xlimit && !d.xlimit_rows && !d.pool && d.rep == 1 && !d.shuffle_cout && use_dma_kernel()) {
+    static int s2 = -1;
+    if (s2 < 0) { const char* ev = getenv("PT_CONV_S2_DMA"); s2 = ev ? atoi(ev) : 1; }
+    bool masked = false;
+    for (int i = 0; i < 8; ++i) masked = masked || d.tap_mask[i] != 0;
+    if (s2 && !masked) return launch_dma16<2, 8, 2>(e, k, s, flop);
   }
   if (d.ks == 3 && d.stride == 1 && !d.head_w && !d.argmax_part && !d.n_valid && !d.out_f32 && !d.res_f32 && d.relu < 2 && !d.ylimit && !d.xlimit && !d.pool && d.split != 2 && use_dma_kernel()) {
     // steady-state A/B on MI355X (tools/ab3.sh, round 1): the 16-channel-slice DMA kernel (v3) wins on >= 120-row maps

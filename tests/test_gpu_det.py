@@ -86,6 +86,9 @@ def _conv_case(eng, B, H, W, Cin, N, ks, stride, relu=False, res_mode=0, rep=1, 
     dict(B=1, H=30, W=30, Cin=512, N=512, ks=3, stride=1, relu=True),               # layer4 shape @960
     dict(B=2, H=38, W=70, Cin=64, N=128, ks=3, stride=2, relu=True),
     dict(B=1, H=60, W=60, Cin=128, N=256, ks=3, stride=2),
+    dict(B=2, H=33, W=47, Cin=256, N=512, ks=3, stride=2, relu=True, seed=21),     # stride-2 DMA tile: odd map, ragged tiles in both directions
+    dict(B=3, H=16, W=130, Cin=64, N=128, ks=3, stride=2, seed=22),                 # exactly one tile row, three column tiles (the last one 1 px wide)
+    dict(B=1, H=14, W=40, Cin=128, N=128, ks=3, stride=2, seed=23),                 # Ho = 7: the register-staged stride-2 tile
     dict(B=2, H=24, W=40, Cin=256, N=256, ks=1, stride=1, res_mode=2),              # lateral + up(x2) add
     dict(B=1, H=38, W=70, Cin=64, N=128, ks=1, stride=2),                           # downsample branch
     dict(B=1, H=9, W=11, Cin=256, N=64, ks=3, stride=1, rep=4),                     # out4: conv + upsample x4
