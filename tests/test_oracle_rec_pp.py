@@ -51,3 +51,17 @@ def test_rec_pp_plan_matches_oracle_batching():
     for k, it in enumerate(items):
         h, w = crops[it["line"]].shape[:2]
         assert it["resized_w"] == min(it["img_w"], max(int(np.ceil(48 * (w / float(h)))), 16))
+
+
+def test_rec_pp_plan_static_width():
+    """a static export ([1, 3, 48, 320]) runs PaddleOCR's static-shape setting of the same config fields (rec_image_shape = the graph's,
+    limited_max_width = its width; ocr_recognition_task._construct_pp): every mini-batch is 320 wide, a line whose ratio exceeds 320 / 48 is
+    resized to the full width (resize_norm_img, processor_ocr_rec_pp.py:43-58), a narrower one keeps its ratio and is padded"""
+    from pdf_table_amd.rec_pp_stage import PPOcrRecConfig, rec_pp_plan
+    cfg = PPOcrRecConfig(rec_image_shape="3, 48, 320", limited_max_width=320)
+    cw, ch = np.array([300, 100, 600, 31, 2000]), np.array([24, 24, 20, 30, 25])
+    items, batches, total = rec_pp_plan(cw, ch, cfg)
+    assert all(b[2] == 320 for b in batches) and total == len(cw) * 3 * 48 * 320
+    for it in items:
+        w, h = int(cw[it["line"]]), int(ch[it["line"]])
+        assert it["img_w"] == 320 and it["resized_w"] == min(320, max(int(np.ceil(48 * w / float(h))), 16))
