@@ -101,11 +101,11 @@ class ClsImagePulcTask(BaseInferTask):
         ncls = CLS_TASKS[self.task_type]["class_num"]
         rows = []
         for i in range(x.shape[0]):              # one image per run: an export with static shapes has its batch size baked in (the reference
-            (a,) = self._exec.run_device(x[i:i + 1], 3)      # runs one image per infer() too, cls_image_pulc_task.py:70-84)
+            (a,) = self._exec.run_device_graphed(x[i:i + 1], 3)      # runs one image per infer() too, cls_image_pulc_task.py:70-84); replayed from a HIP graph
             if not a.flat or a.c != ncls:
                 from .onnx_import import UnsupportedOnnxGraph
                 raise UnsupportedOnnxGraph(f"classifier output of shape {a.shape()}: [B, {ncls}] is expected for task '{self.task_type}'")
-            rows.append(self._exec.values(a)[:, 0, 0])
+            rows.append(self._exec.values(a)[:, 0, 0].clone())      # (the activation is the graph's own buffer: the next replay overwrites it)
         y = torch.cat(rows, 0)
         return torch.log(y.clamp_min(1e-30)) if self._softmax_in_graph and self.task_type != "table_attribute" else y
 

@@ -100,10 +100,10 @@ class OcrDetectionTask(BaseInferTask):
                     raise UnsupportedOnnxGraph(f"{onnx_path}: a text detector returns one probability map, this graph returns {ex.outputs}")
 
                 def net(x4, _ex=ex):
-                    (a,) = _ex.run_device(x4, 3)
+                    (a,) = _ex.run_device_graphed(x4, 3)      # one captured HIP graph per input shape (eager beyond eight shapes)
                     if a.c != 1:
                         raise UnsupportedOnnxGraph(f"{onnx_path}: the output has {a.c} channels, a probability map has one")
-                    return _ex.values(a)[..., 0].contiguous()
+                    return _ex.values(a)[..., 0].clone()      # (the graph's own buffer: the next replay overwrites it)
                 self._net = net
             else:
                 raise UnsupportedOnnxGraph(f"{onnx_path} is a '{arch}' network, not a text detector the engine runs")

@@ -105,7 +105,7 @@ class OcrLayoutTask(BaseInferTask):
         cfg = self._config
         ncls = len(cfg.labels)
         x = self._engine.layout_preprocess(pages, cfg.img_height, cfg.img_width)
-        acts = self._exec.run_device(x, 3)
+        acts = self._exec.run_device_graphed(x, 3)      # the layer walk replayed from a captured HIP graph per batch shape
         outs = []
         for a in acts:
             if not a.seq:
