@@ -69,7 +69,8 @@ int pt_engine_set_lstm_cluster(pt_engine* e, int on);
  * (BASELINE.json configs[4] names fp8; this is where fp8 pays on this path).  A throughput option with recorded drift
  * (tests/test_gpu_mtl.py), off by default; ignored in PT_PRECISION_BF16X3.  Environment default: PT_MTL_KV_FP8. */
 int pt_engine_set_mtl_kv_fp8(pt_engine* e, int on);
-/* Lore detector (pt_tsr_forward*, pt_op_dcn), PT_PRECISION_BF16 only: on = 1 runs the modulated deformable convolutions
+/* Lore detector (pt_tsr_forward*, pt_op_dcn), PT_PRECISION_BF16 only: on = 1 (dcn_mfma_kernel) or 2 (dcn_mfma2_kernel: full-line gathers, one workgroup
+ * per CU; layers with 64 outputs, the others keep the VALU blend) runs the modulated deformable convolutions
  * (model/lore/dcnv2.py:71-86, DCNv2_latest/src/cuda/dcn_v2_im2col_cuda.cu:121-191) with the bilinear blend on the matrix pipe
  * (dcn_mfma_kernel: corner lines by LDS-DMA, blend = MFMA against block-diagonal bf16 weights); on = 0 (default) keeps the VALU blend
  * with fp32 weights (dcn_fused64_kernel).  Both are bf16-mode results: the sampled columns differ by the bf16 rounding of the four

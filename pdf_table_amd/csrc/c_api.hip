@@ -43,7 +43,7 @@ int pt_engine_set_lstm_cluster(pt_engine* e, int on) {
 }
 
 int pt_engine_set_dcn_mfma(pt_engine* e, int on) {
-  PT_REQUIRE(e && (on == 0 || on == 1), "pt_engine_set_dcn_mfma: bad arguments");
+  PT_REQUIRE(e && on >= 0 && on <= 2, "pt_engine_set_dcn_mfma: bad arguments");
   e->dcn_mfma = on;
   return PT_OK;
 }
@@ -78,7 +78,7 @@ int pt_engine_create(int device_id, pt_engine** out) {
     ev = getenv("PT_MTL_KV_FP8");                   // default of pt_engine_set_mtl_kv_fp8
     e->mtl_kv_fp8 = ev ? (atoi(ev) != 0) : 0;
     ev = getenv("PT_DCN_MFMA");                     // default of pt_engine_set_dcn_mfma
-    e->dcn_mfma = ev ? (atoi(ev) != 0) : 0;
+    e->dcn_mfma = ev ? (atoi(ev) < 0 || atoi(ev) > 2 ? 0 : atoi(ev)) : 0;
     ev = getenv("PT_REC_RAGGED");                   // 0: the recogniser's conv stack also computes the padding (A/B switch)
     e->rec_ragged = ev ? (atoi(ev) != 0) : 1;
   }

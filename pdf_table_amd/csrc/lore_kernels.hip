@@ -964,6 +964,237 @@ __global__ __launch_bounds__(512, (NB == 64 && RING == 4) ? 2 : 1) void dcn_mfma
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// dcn_mfma2_kernel (bf16 mode, 64 output channels per workgroup): dcn_mfma_kernel re-cut around what gather_rate_bench measured.
+//   * FULL 128-byte lines: a wave owns 32 pixels x the slice's 64 channels (two 32-channel M tiles share one block-diagonal weight operand),
+//     a K = 16 step is two LDS-DMA instructions (8 rows x 128 B each: 2 pixels x 4 corners) -- half-line rows cost the path 35 % at the bench's
+//     offsets.
+//   * ONE workgroup of eight waves per CU on a 16 x 16 pixel tile, an 8-step ring of 2 KB slots per wave: 7 steps = 14 KB per wave = 112 KB per
+//     CU in flight (the two-workgroup cut had 48 KB); LDS = 8 x 16 KB rings + two 8 KB weight images + 8 x 1 KB of corner offsets + ... = 160 KB.
+//   * every wave computes the sampling geometry of ITS pixels itself, one tap ahead (the 27 offset / mask values of a pixel sit in registers):
+//     no workgroup table, no table barrier; the only barrier per stage publishes the weight image.
+//   * a wave has all 64 channels of its pixels: the product needs no exchange between waves, the epilogue stores from the accumulators.
+// All DMAs are inline asm (scalar base + 32-bit lane offset): hipcc guards registers that served as the vector address of an LDS-DMA builtin with
+// vmcnt(0), which drains the ring.  Same arithmetic as dcn_mfma_kernel (bf16 bilinear x mask weights) with the K of the product in one piece.
+// ---------------------------------------------------------------------------------------------------------------------
+struct DcnMfma2Smem {
+  static constexpr int W_BYTES = 64 * 128, OFF_BYTES = 8 * 1024, RING_BYTES = 8 * 8 * 2048;
+  static constexpr int BYTES = 2 * W_BYTES + OFF_BYTES + RING_BYTES;       // 155 648
+};
+
+__global__ __launch_bounds__(512, 2) void dcn_mfma2_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om, const bf16_t* __restrict__ w,
+                                                            const float* __restrict__ bias, bf16_t* __restrict__ out, long long npix, int H, int W,
+                                                            int C, int N, int relu) {
+#pragma clang fp contract(fast)
+  constexpr int NT = 2, D = 7;                  // 32-column tiles of the product; K = 16 steps in flight ahead of the one being multiplied
+  constexpr int W_BYTES = DcnMfma2Smem::W_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_w = smem;                                            // two weight images (64 rows x 128 B, 16-byte slots XOR-swizzled by (row >> 1) & 7)
+  char* s_off = smem + 2 * W_BYTES;                            // per wave: [2 taps][32 pixels][4 corners] byte offsets from the map's first pixel
+  char* s_ring = s_off + DcnMfma2Smem::OFF_BYTES;              // per wave: 8 slots x 2 KB (16 rows x 128 B, 16-byte slots XOR 4 on rows with bit 1 set)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lx = lane & 31, q = lane >> 5;
+  const int tiles_x = (W + 15) >> 4, tiles_y = (H + 15) >> 4;
+  int Lb = blockIdx.x;
+  const int tx0 = (Lb % tiles_x) * 16;
+  Lb /= tiles_x;
+  const int ty0 = (Lb % tiles_y) * 16;
+  const long long img0 = (long long)(Lb / tiles_y) * H * W;
+  const int n0 = blockIdx.y * 64;
+  const int nss = C >> 6, nk = 9 * (C >> 5);
+  // this lane's pixel (lanes lx and lx + 32 share it): patch rows 2 wave, 2 wave + 1
+  int py = ty0 + 2 * wave + (lx >> 4), px = tx0 + (lx & 15);
+  const bool inside = py < H && px < W;
+  py = py < H ? py : H - 1;
+  px = px < W ? px : W - 1;
+  float omv[28];
+  {
+    const float* o = om + (img0 + (long long)py * W + px) * 32;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const float4 v = *reinterpret_cast<const float4*>(o + 4 * i);
+      omv[4 * i] = v.x; omv[4 * i + 1] = v.y; omv[4 * i + 2] = v.z; omv[4 * i + 3] = v.w;
+    }
+    // the 27 values pass through an asm statement: hipcc then knows they have landed.  It cannot see the inline-asm DMAs below, and where it still
+    // tracked one of these loads as outstanding it guarded the value's first use -- once per tap -- with vmcnt(0), draining the gather ring
+    asm volatile("" : "+v"(omv[0]), "+v"(omv[1]), "+v"(omv[2]), "+v"(omv[3]), "+v"(omv[4]), "+v"(omv[5]), "+v"(omv[6]), "+v"(omv[7]), "+v"(omv[8]),
+                 "+v"(omv[9]), "+v"(omv[10]), "+v"(omv[11]), "+v"(omv[12]), "+v"(omv[13]));
+    asm volatile("" : "+v"(omv[14]), "+v"(omv[15]), "+v"(omv[16]), "+v"(omv[17]), "+v"(omv[18]), "+v"(omv[19]), "+v"(omv[20]), "+v"(omv[21]),
+                 "+v"(omv[22]), "+v"(omv[23]), "+v"(omv[24]), "+v"(omv[25]), "+v"(omv[26]));
+  }
+  // scalar bases of the DMAs (readfirstlane returns int: no sign extension into the high half)
+  auto sbase = [](const void* p) -> unsigned long long {
+    const unsigned long long u = (unsigned long long)p;
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(u >> 32)) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)u);
+  };
+  const unsigned long long xbase = sbase(x + (size_t)img0 * C);
+  const bf16_t* wbase = w + (size_t)(n0 >> 6) * nk * (64 * 32);
+  const int w_row = wave * 8 + (lane >> 3), w_pc = (lane & 7) ^ ((w_row >> 1) & 7);
+  const unsigned w_lane = (unsigned)(((w_pc >> 2) * (64 * 32) + w_row * 32 + (w_pc & 3) * 8) * 2);
+  const unsigned w_dst = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_w + wave * 1024));
+  auto issue_w = [&](int buf, int tap, int ss) {
+    const unsigned long long ub = sbase(wbase + (size_t)(tap * (C >> 5) + 2 * ss) * (64 * 32));
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(w_lane), "s"(ub), "s"(w_dst + (unsigned)(buf * W_BYTES)) : "memory");
+  };
+  // sampling geometry of this lane's pixel for one tap (dcn_v2_im2col_cpu.cpp:26-55, as dcn_fused64_kernel's table): corner byte offsets -> the wave's
+  // offset table, the four bilinear x mask weights as bf16 pairs -> registers
+  char* my_off = s_off + wave * 1024;
+  const unsigned my_off_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)my_off;
+  auto geometry = [&](float off_h, float off_w, float mlogit, int tap, uint32_t& w01, uint32_t& w23) {
+    const float gm = 1.f / (1.f + expf(-mlogit));
+    const float h_im = (float)(py - 1 + tap / 3) + off_h;
+    const float w_im = (float)(px - 1 + tap % 3) + off_w;
+    unsigned co[4] = {0u, 0u, 0u, 0u};
+    float cw[4] = {0.f, 0.f, 0.f, 0.f};
+    if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+      const float hf = floorf(h_im), wf = floorf(w_im);
+      const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
+      const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+      if (h_low >= 0 && w_low >= 0) { co[0] = (unsigned)(h_low * W + w_low) * (unsigned)(2 * C); cw[0] = hh * hw * gm; }
+      if (h_low >= 0 && w_high <= W - 1) { co[1] = (unsigned)(h_low * W + w_high) * (unsigned)(2 * C); cw[1] = hh * lw * gm; }
+      if (h_high <= H - 1 && w_low >= 0) { co[2] = (unsigned)(h_high * W + w_low) * (unsigned)(2 * C); cw[2] = lh * hw * gm; }
+      if (h_high <= H - 1 && w_high <= W - 1) { co[3] = (unsigned)(h_high * W + w_high) * (unsigned)(2 * C); cw[3] = lh * lw * gm; }
+    }
+    if (q == 0) *reinterpret_cast<uint4*>(my_off + (tap & 1) * 512 + lx * 16) = make_uint4(co[0], co[1], co[2], co[3]);
+    w01 = f2bf(cw[0]) | (f2bf(cw[1]) << 16);
+    w23 = f2bf(cw[2]) | (f2bf(cw[3]) << 16);
+  };
+  // gather side: instruction h of a step moves pixels 4 s + 2 h, + 1 (lane >> 5) x corners ((lane >> 3) & 3) x eight 16-byte pieces; the slot a
+  // piece lands in is piece ^ 4 on rows with bit 1 set (two transposed reads of four rows then touch all 64 banks)
+  const unsigned g_tab = my_off_lds + (unsigned)((lane >> 5) * 16 + ((lane >> 3) & 3) * 4);
+  const unsigned g_piece = (unsigned)(((lane & 7) ^ (((lane >> 4) & 1) << 2)) * 16);
+  const unsigned ring_lds = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_ring + wave * 16384));
+  auto dma = [&](unsigned off, unsigned dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(xbase), "s"(dst) : "memory");
+  };
+  // blend side (see dcn_mfma_kernel): lane a of a 16-lane group supplies row 8 (g >> 1) + (a >> 2) (+ 4), 4-channel piece swap(a & 3) of the
+  // channels 32 mt + 16 (g & 1) .. + 15, and receives column a
+  const int la = lane & 15, lg = lane >> 4;
+  const int sw4 = ((la & 1) << 1) | ((la >> 1) & 1);
+  const unsigned tr_row = (unsigned)((8 * (lg >> 1) + (la >> 2)) * 128 + (sw4 & 1) * 8);
+  const unsigned tr_f = (unsigned)((la >> 3) & 1) << 2;             // the row's slot swizzle (bit 1 of the row)
+  const unsigned tr0 = ring_lds + tr_row + (((unsigned)(2 * (lg & 1) + (sw4 >> 1)) ^ tr_f) << 4);
+  const unsigned tr1 = ring_lds + tr_row + (((unsigned)(4 + 2 * (lg & 1) + (sw4 >> 1)) ^ tr_f) << 4);
+  const int key = (lx >> 1) - q;                // step s holds this lane's pixel in its K group iff key == 2 s
+  const bool odd = lx & 1;
+  const char* b_rd = s_w + lx * 128;
+  const int b_key = (lx >> 1) & 7;
+
+  df32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  uint32_t wc01, wc23, wn01 = 0, wn23 = 0;       // weights of the current / the next tap
+  geometry(omv[0], omv[1], omv[18], 0, wc01, wc23);
+  issue_w(0, 0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the wave's own offsets are in LDS (wave-private: no barrier)
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      unsigned o;
+      asm volatile("ds_read_b32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"(g_tab), "n"((4 * s + 2 * h) * 16) : "memory");
+      dma(o + g_piece, ring_lds + (unsigned)(s * 2048 + h * 1024));
+    }
+
+  // one stage = (tap, 64-channel slice).  GEO: the geometry of tap TAP + 1 is computed at the top (its gathers start in this stage)
+#define PT_DCN2_STEP(S, LAST)                                                                                                          \
+    {                                                                                                                                  \
+      if (S == 0 || !LAST) {                                                                                                           \
+        dma(gv[2 * S], ring_lds + (unsigned)(((S + D) % 8) * 2048));                                                                   \
+        dma(gv[2 * S + 1], ring_lds + (unsigned)(((S + D) % 8) * 2048 + 1024));                                                        \
+      }                                                                                                                                \
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LAST ? (S == 0 ? 2 * D : 2 * (7 - S)) : (S < D ? 2 * D + 1 : 2 * D)) : "memory");     \
+      u32x2 a0l, a0h, a1l, a1h;                                                                                                        \
+      asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%6\n\tds_read_b64_tr_b16 %1, %4 offset:%7\n\t"                                    \
+                   "ds_read_b64_tr_b16 %2, %5 offset:%6\n\tds_read_b64_tr_b16 %3, %5 offset:%7\n\ts_waitcnt lgkmcnt(0)"                \
+                   : "=&v"(a0l), "=&v"(a0h), "=&v"(a1l), "=&v"(a1h)                                                                    \
+                   : "v"(tr0), "v"(tr1), "n"(S * 2048), "n"(S * 2048 + 512)                                                            \
+                   : "memory");                                                                                                        \
+      const bool mine = key == 2 * S;                                                                                                  \
+      const u32x4 bw = {mine ? e01 : 0u, mine ? e23 : 0u, mine ? o01 : 0u, mine ? o23 : 0u};                                           \
+      const u32x4 aw0 = {a0l.x, a0l.y, a0h.x, a0h.y}, aw1 = {a1l.x, a1l.y, a1h.x, a1h.y};                                              \
+      bl0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dbf16x8, aw0), __builtin_bit_cast(dbf16x8, bw), bl0, 0, 0, 0);  \
+      bl1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dbf16x8, aw1), __builtin_bit_cast(dbf16x8, bw), bl1, 0, 0, 0);  \
+    }
+#define PT_DCN2_TAP(TAP)                                                                                                               \
+  for (int ss = 0; ss < nss; ++ss) {                                                                                                   \
+    const bool last = TAP == 8 && ss + 1 == nss;                                                                                       \
+    const bool geo = TAP < 8 && ss + 1 == nss;                                                                                         \
+    const int tap_n = geo ? TAP + 1 : TAP, ss_n = geo ? 0 : ss + 1;                                                                    \
+    const int st = TAP * nss + ss;                                                                                                     \
+    /* this wave's piece of weight image st has landed (14 gathers were issued after it); the barrier publishes all pieces */          \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * D) : "memory");                                                                       \
+    __builtin_amdgcn_s_barrier();                                                                                                      \
+    if (!last) issue_w((st + 1) & 1, tap_n, ss_n);                                                                                     \
+    if (geo) geometry(omv[2 * (TAP < 8 ? TAP + 1 : 0)], omv[2 * (TAP < 8 ? TAP + 1 : 0) + 1], omv[18 + (TAP < 8 ? TAP + 1 : 0)], TAP + 1, wn01, wn23); \
+    const uint32_t e01 = odd ? 0u : wc01, e23 = odd ? 0u : wc23, o01 = odd ? wc01 : 0u, o23 = odd ? wc23 : 0u;                         \
+    /* table entries of the gathers this stage issues: step 7 of this stage, then steps 0 .. 6 of the next one */                      \
+    unsigned gv[16];                                                                                                                   \
+    {                                                                                                                                  \
+      const unsigned tc = g_tab + (unsigned)((TAP & 1) * 512), tn = g_tab + (unsigned)((tap_n & 1) * 512);                             \
+      const unsigned gc = g_piece + (unsigned)(ss * 128), gn = g_piece + (unsigned)(ss_n * 128);                                       \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                               \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                                                 \
+        const int stp = i >> 1, h = i & 1;                                                                                             \
+        const unsigned a_ = (stp == 0 ? tc + (unsigned)((28 + 2 * h) * 16) : tn + (unsigned)((4 * (stp - 1) + 2 * h) * 16));           \
+        unsigned o_;                                                                                                                   \
+        asm volatile("ds_read_b32 %0, %1" : "=v"(o_) : "v"(a_) : "memory");                                                            \
+        gv[i] = o_;                                                                                                                    \
+      }                                                                                                                                \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                               \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) gv[i] += (i < 2 ? gc : gn);                                                       \
+    }                                                                                                                                  \
+    df32x16 bl0, bl1;                                                                                                                  \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) { bl0[r] = 0.f; bl1[r] = 0.f; }                                                     \
+    if (!last) {                                                                                                                       \
+      PT_DCN2_STEP(0, false) PT_DCN2_STEP(1, false) PT_DCN2_STEP(2, false) PT_DCN2_STEP(3, false)                                      \
+      PT_DCN2_STEP(4, false) PT_DCN2_STEP(5, false) PT_DCN2_STEP(6, false) PT_DCN2_STEP(7, false)                                      \
+    } else {                                                                                                                           \
+      PT_DCN2_STEP(0, true) PT_DCN2_STEP(1, true) PT_DCN2_STEP(2, true) PT_DCN2_STEP(3, true)                                          \
+      PT_DCN2_STEP(4, true) PT_DCN2_STEP(5, true) PT_DCN2_STEP(6, true) PT_DCN2_STEP(7, true)                                          \
+    }                                                                                                                                  \
+    /* bl<mt>[8 t + e] = channel 32 mt + 16 t + 8 q + e of pixel lx: after one conversion the B operand of the product's k-step 2 mt + t */ \
+    const char* wrd = b_rd + (st & 1) * W_BYTES;                                                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                                 \
+      u32x4 cf;                                                                                                                        \
+      _Pragma("unroll") for (int e2 = 0; e2 < 4; ++e2) {                                                                               \
+        const int r_ = 8 * (ks & 1) + 2 * e2;                                                                                          \
+        const df2 v = (ks < 2) ? df2{bl0[r_], bl0[r_ + 1]} : df2{bl1[r_], bl1[r_ + 1]};                                                \
+        cf[e2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, db2));                                                        \
+      }                                                                                                                                \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                                              \
+        const dbf16x8 wf = *reinterpret_cast<const dbf16x8*>(wrd + nt * 32 * 128 + (((ks * 2 + q) ^ b_key) << 4));                     \
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(dbf16x8, cf), acc[nt], 0, 0, 0);                      \
+      }                                                                                                                                \
+    }                                                                                                                                  \
+    if (geo) { wc01 = wn01; wc23 = wn23; }                                                                                             \
+  }
+  PT_DCN2_TAP(0) PT_DCN2_TAP(1) PT_DCN2_TAP(2) PT_DCN2_TAP(3) PT_DCN2_TAP(4) PT_DCN2_TAP(5) PT_DCN2_TAP(6) PT_DCN2_TAP(7) PT_DCN2_TAP(8)
+#undef PT_DCN2_TAP
+#undef PT_DCN2_STEP
+  // weights were the MFMA's A operand: a lane owns its pixel, the accumulators are runs of four channels
+  if (inside) {
+    bf16_t* op = out + (size_t)(img0 + (long long)py * W + px) * N + n0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int ch = nt * 32 + 8 * rg + 4 * q;
+        const float4 bs = *reinterpret_cast<const float4*>(bias + n0 + ch);
+        float v[4] = {acc[nt][rg * 4 + 0] + bs.x, acc[nt][rg * 4 + 1] + bs.y, acc[nt][rg * 4 + 2] + bs.z, acc[nt][rg * 4 + 3] + bs.w};
+        if (relu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        *reinterpret_cast<uint2*>(op + ch) = make_uint2(f2bf(v[0]) | (f2bf(v[1]) << 16), f2bf(v[2]) | (f2bf(v[3]) << 16));
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // 3x3 convolution for 16 input channels (DLA-34 level0: 16 -> 16 at full resolution, level1: 16 -> 32 stride 2,
 // center_net/modeling_centernet.py:295-298,370-380) + folded BN + ReLU.  The general implicit-GEMM kernel would pad these
 // to 32 -> 64 (4-8x the work and twice the bytes at 1024 x 1024); here K = 9 taps x 16 channels = nine MFMA k-steps:
@@ -1352,7 +1583,18 @@ int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf
       mfma_nb = nv ? atoi(nv) : 128;
     }
     const int mfma = e ? e->dcn_mfma : 0;
-    if (mfma) {
+    if (mfma == 2 && N == 64) {      // full-line gathers, one workgroup per CU (dcn_mfma2_kernel); wider layers keep dcn_fused64_kernel in this setting
+      static bool attr2 = false;
+      if (!attr2) {
+        PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_mfma2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DcnMfma2Smem::BYTES));
+        attr2 = true;
+      }
+      const unsigned tiles2 = (unsigned)((long long)B * ((H + 15) / 16) * ((W + 15) / 16));
+      hipLaunchKernelGGL(dcn_mfma2_kernel, dim3(tiles2, 1), dim3(512), DcnMfma2Smem::BYTES, s, x, om, w, bias, out, npix, H, W, C, N, relu);
+      PT_HIP_CHECK(hipGetLastError());
+      return PT_OK;
+    }
+    if (mfma == 1) {
       constexpr int smem64 = DcnMfmaSmem<64, PT_DCN_RING64>::BYTES, smem128 = DcnMfmaSmem<128, 8>::BYTES;
       if (N % 128 == 0 && mfma_nb == 128)
         hipLaunchKernelGGL((dcn_mfma_kernel<128, 8>), dim3(tiles, N / 128), dim3(512), smem128, s, x, om, w, bias, out, npix, H, W, C, N, relu);

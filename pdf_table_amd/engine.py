@@ -61,10 +61,10 @@ class HipEngine:
         HBM stream; a throughput option with recorded drift, off by default)"""
         L.check(self.lib.pt_engine_set_mtl_kv_fp8(self._h, 1 if on else 0), "pt_engine_set_mtl_kv_fp8")
 
-    def set_dcn_mfma(self, on: bool):
+    def set_dcn_mfma(self, on):
         """Lore detector, bf16 mode: deformable convolutions with the bilinear blend on the matrix pipe (on) or on the VALU with fp32
         weights (off, the default); see include/pdftable_hip.h"""
-        L.check(self.lib.pt_engine_set_dcn_mfma(self._h, 1 if on else 0), "pt_engine_set_dcn_mfma")
+        L.check(self.lib.pt_engine_set_dcn_mfma(self._h, int(on)), "pt_engine_set_dcn_mfma")      # 0 VALU blend, 1 dcn_mfma_kernel, 2 dcn_mfma2_kernel (64-output layers)
 
     def set_lstm_cluster(self, on: bool):
         """False: the streaming LSTM kernel (no co-residency requirement) -- whenever the recogniser shares the GPU with

@@ -80,7 +80,7 @@ SHAPES = [
 
 @pytest.mark.parametrize("C,N,H,W", SHAPES)
 @pytest.mark.parametrize("relu,field", [(True, "wide"), (False, "wide"), (True, "local")])
-@pytest.mark.parametrize("blend", ["mfma", "valu"])
+@pytest.mark.parametrize("blend", ["mfma", "mfma2", "valu"])
 def test_dcn_op_bf16(eng, C, N, H, W, relu, field, blend):
     """bf16 mode: operands exactly representable; the kernel rounds every sampled column to bf16 before the product, so it is compared
     (a) with the oracle whose columns are rounded the same way -- difference = fp32 summation order + the output's own bf16 rounding --
@@ -89,8 +89,8 @@ def test_dcn_op_bf16(eng, C, N, H, W, relu, field, blend):
     blends on the matrix pipe against the four weights ROUNDED TO bf16 (2^-9 relative each): a column is then within 2^-9 of its magnitude
     plus its own half ulp, so (a) and (b) carry one more column-ulp term; C % 64 != 0 shapes run dcn_fused_kernel in both settings."""
     B = 2
-    eng.set_dcn_mfma(blend == "mfma")
-    wq = 2.0 ** -8 if blend == "mfma" else 0.0      # extra column error of the bf16 weights, in units of the column magnitudes
+    eng.set_dcn_mfma({"valu": 0, "mfma": 1, "mfma2": 2}[blend])      # (mfma2: the 64-output shapes; the others run the VALU blend)
+    wq = 2.0 ** -8 if blend != "valu" else 0.0      # extra column error of the bf16 weights, in units of the column magnitudes
     x, w, b, off, mlog = _case(B, C, N, H, W, seed=C * 1000 + N + H, field=field)
     mask = torch.sigmoid(mlog)
     cols = lore_net.deform_conv2d(x, off, mask, w, None, return_cols=True)          # [B,C,9,H,W] fp32

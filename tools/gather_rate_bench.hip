@@ -24,7 +24,7 @@ __global__ __launch_bounds__(512, 2) void gather_kernel(const char* __restrict__
   __shared__ __attribute__((aligned(16))) char ring[8 * 4096];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile = blockIdx.x % tiles_per_map, map = blockIdx.x / tiles_per_map;
-  const int ty0 = 16 + (tile / 14) * 8, tx0 = 16 + (tile % 14) * 16;      // interior tiles: rows 16 .. 239, columns 16 .. 239
+  const int ty0 = 24 + (tile / 13) * 8, tx0 = 24 + (tile % 13) * 16;      // interior tiles: rows 24 .. 231, columns 24 .. 231 (no clamping up to R = 24)
   const char* xm = x + (size_t)map * 256 * 256 * 128;
   const int rows_per = MODE == 0 ? 16 : 8;                    // rows per instruction
   const int row = MODE == 0 ? lane >> 2 : lane >> 3;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(512, 2) void gather_kernel(const char* __restrict__
 
 template <int MODE, int DEPTH>
 static void run(const char* name, const char* x, uint32_t* out, int maps, int R) {
-  const int tiles_per_map = 28 * 14, steps = 72 * 2;      // 9 taps x 8 steps x 2 (a 128-channel layer's worth of instructions per wave)
+  const int tiles_per_map = 26 * 13, steps = 72 * 2;      // 9 taps x 8 steps x 2 (a 128-channel layer's worth of instructions per wave)
   const int grid = maps * tiles_per_map;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
@@ -95,7 +95,7 @@ int main() {
   CK(hipMalloc(&x, (size_t)maps * 256 * 256 * 128));
   CK(hipMemset(x, 1, (size_t)maps * 256 * 256 * 128));
   CK(hipMalloc(&out, (size_t)maps * 512 * 512 * 4));
-  for (int R : {2, 9}) {
+  for (int R : {2, 9, 16, 24}) {
     run<0, 3>("A  LDS-DMA, 16 x 64 B rows, 3 in flight per wave", x, out, maps, R);
     run<0, 7>("A  LDS-DMA, 16 x 64 B rows, 7 in flight (slots reused: rate only)", x, out, maps, R);
     run<0, 15>("A  LDS-DMA, 16 x 64 B rows, 15 in flight (rate only)", x, out, maps, R);
