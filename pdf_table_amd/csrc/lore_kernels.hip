@@ -480,7 +480,11 @@ __global__ __launch_bounds__(256, (SPLIT || NB > 64) ? 2 : 4) void dcn_fused_ker
 // SPLIT = 1 (PT_PRECISION_BF16X3): x / out carry (hi | lo) channel groups, the corner lines of both halves are gathered and
 // summed in fp32 before the blend, the blended value is split again, and the product runs as three MFMA passes
 // (a_hi w_hi + a_lo w_hi + a_hi w_lo) -- the arithmetic of dcn_fused_kernel<1, .> on this kernel's gather / LDS layout.
-template <int NB, int NTHR, int SPLIT = 0>
+// EARLY = 1 (bf16 mode): an item's corner loads for stage st + 1 are issued right after the item has been blended for stage st -- its registers are
+// free from then on -- instead of after the stage's second barrier: the loads then fly during the rest of the blend, the barrier and the product
+// (the kernel is bound by its phases -- gather wait, blend, barrier, product, barrier -- not by a resource: profiles/r04/dcn_op_bench.txt).  Same
+// arithmetic in the same order, no extra registers: same bits.
+template <int NB, int NTHR, int SPLIT = 0, int EARLY = 0>
 __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) void dcn_fused64_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
                                                               const bf16_t* __restrict__ w, const float* __restrict__ bias,
                                                               bf16_t* __restrict__ out, long long npix, int H, int W,
@@ -678,7 +682,62 @@ __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) voi
       }
     }
   };
-  {
+  if constexpr (EARLY && !SPLIT) {
+    prefetch(0);
+    for (int st = 0; st < nst; ++st) {
+      const bool more = st + 1 < nst;
+      const int tap_n = (st + 1) / nss, ss_n = (st + 1) - tap_n * nss;
+      const char* xs_n = xmap + ss_n * 128;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < IT; ++j) {
+        const df2 w0 = {cwt[j][0], cwt[j][0]}, w1 = {cwt[j][1], cwt[j][1]}, w2 = {cwt[j][2], cwt[j][2]}, w3 = {cwt[j][3], cwt[j][3]};
+        uint32_t o[4];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          df2 c[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t u = e2 == 0 ? rc[j][k].x : e2 == 1 ? rc[j][k].y : e2 == 2 ? rc[j][k].z : rc[j][k].w;
+            c[k] = df2{__uint_as_float(u << 16), __uint_as_float(u & 0xFFFF0000u)};
+          }
+          df2 v = w0 * c[0];
+          v = w1 * c[1] + v;
+          v = w2 * c[2] + v;
+          v = w3 * c[3] + v;
+          o[e2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, db2));
+        }
+        *reinterpret_cast<u32x4*>(s_a + (prow + PSTEP * j) * ROW + piece * 16) = u32x4{o[0], o[1], o[2], o[3]};
+        if (more) {          // this item's registers are free: its loads of the next stage go out now
+          if (ss_n == 0) {
+            const int gi = (prow + PSTEP * j) * 9 + tap_n;
+            const uint4 og = *reinterpret_cast<const uint4*>(s_goff[gi]);
+            const float4 wv = *reinterpret_cast<const float4*>(s_gwt[gi]);
+            coff[j][0] = og.x + piece * 16; coff[j][1] = og.y + piece * 16; coff[j][2] = og.z + piece * 16; coff[j][3] = og.w + piece * 16;
+            cwt[j][0] = wv.x; cwt[j][1] = wv.y; cwt[j][2] = wv.z; cwt[j][3] = wv.w;
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) rc[j][k] = *reinterpret_cast<const u32x4*>(xs_n + coff[j][k]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < WP; ++j) {
+        const int idx = tid + j * NTHR;
+        *reinterpret_cast<u32x4*>(s_w + (idx >> 3) * ROW + (idx & 7) * 16) = rw[j];
+      }
+      if (more) {
+        const int kc = tap_n * (C >> 5) + 2 * ss_n;
+#pragma unroll
+        for (int j = 0; j < WP; ++j) {
+          const int idx = tid + j * NTHR;
+          const int row = idx >> 3, pc = idx & 7;
+          rw[j] = *reinterpret_cast<const u32x4*>(wbase + (size_t)(row >> 6) * nk * (64 * 32) + (size_t)(kc + (pc >> 2)) * (64 * 32) + (row & 63) * 32 + (pc & 3) * 8);
+        }
+      }
+      __syncthreads();
+      product();
+    }
+  } else {
     prefetch(0);
     for (int st = 0; st < nst; ++st) {
       __syncthreads();
@@ -1607,7 +1666,13 @@ int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf
 
       hipLaunchKernelGGL((dcn_fused64_kernel<128, 256>), dim3(tiles, N / 128), dim3(256), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
     } else if (nthr == 512) {
-      hipLaunchKernelGGL((dcn_fused64_kernel<64, 512>), dim3(tiles, N / 64), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
+      static int early = -1;          // PT_DCN_EARLY=0: next-stage loads after the second barrier (A/B switch)
+      if (early < 0) {
+        const char* ev = getenv("PT_DCN_EARLY");
+        early = ev ? atoi(ev) : 1;
+      }
+      if (early) hipLaunchKernelGGL((dcn_fused64_kernel<64, 512, 0, 1>), dim3(tiles, N / 64), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
+      else hipLaunchKernelGGL((dcn_fused64_kernel<64, 512>), dim3(tiles, N / 64), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
     } else {
       hipLaunchKernelGGL((dcn_fused64_kernel<64, 256>), dim3(tiles, N / 64), dim3(256), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
     }
