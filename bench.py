@@ -59,8 +59,10 @@ DB_GFLOP_960 = 111.71            # DB-ResNet18 at the ref
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=8,
+                    help="untimed steps; the default covers the software pipeline's depth (3 batches) and the clock ramp of a GPU that idled "
+                         "while the process imported and packed weights (a first process on a fresh box read 554 pages/s at 3, 605 afterwards)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--by-class-only", action="store_true", help="diagnostic: the timed region, then only the roofline.by_class leg")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the det-only and BF16X3 legs (diagnostic runs)")
