@@ -1885,15 +1885,15 @@ int pt_launch_gemm_argmax_x3(const bf16_t* A, long long M, int K, const bf16_t* 
   int* ovf_rows = reinterpret_cast<int*>(rowmax + M);
   static bool attr0 = false;
   if (!attr0) {
-    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_argmax_kernel<32, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_argmax_kernel<32, 0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr0 = true;
   }
   PT_HIP_CHECK(hipMemsetAsync(wmax, 0, 8, s));
   hipLaunchKernelGGL(wnorm_max_kernel, dim3(N / 64), dim3(256), 0, s, W3, N, K, wmax);
   const long long wts = (long long)3 * (K / 32) * 2048;
   // sweep 1: the single-pass maximum of every row (the bf16 mode's kernel on the hi halves); sweep 2: the classes within the bound of it
-  hipLaunchKernelGGL((gemm_argmax_kernel<32, 0>), dim3((unsigned)((M + 127) / 128)), dim3(256), SMEM, s, A, M, W3, bias, N, ids, rowmax, nullptr, 0,
-                     nullptr, 2 * K, wts);
+  hipLaunchKernelGGL((gemm_argmax_kernel<32, 0, 8>), dim3((unsigned)((M + 255) / 256)), dim3(512), SMEM, s, A, M, W3, bias, N, ids, rowmax, nullptr, 0,
+                     nullptr, 2 * K, wts);      // eight waves per weight stage, as the bf16 mode's classifier
   hipLaunchKernelGGL((gemm_cand_kernel<32>), dim3((unsigned)((M + 127) / 128)), dim3(256), SMEM, s, A, M, 2 * K, W3, wts, bias, N,
                      reinterpret_cast<const float*>(wmax), rowmax, cand);
   hipLaunchKernelGGL(cand_eval_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, s, A, M, 2 * K, K, W3, bias, N, n_real, cand, ids, maxv, ovf_count,
