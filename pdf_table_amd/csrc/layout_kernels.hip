@@ -264,6 +264,96 @@ __global__ __launch_bounds__(256) void dwconv2_kernel(const bf16_t* __restrict__
   }
 }
 
+// Stride-1 depthwise convolution on an LDS tile (bf16 mode).  dwconv2_kernel is load-latency-bound (PMC, profiles/r04/experiments.txt: its waves wait 66 % of
+// their cycles, the VALU is busy 25 %: 240 registers -> two waves per SIMD, and a thread's 48 loads are issued a row at a time right before they are
+// needed).  Here a workgroup stages the (8 + K - 1) x (TW + K - 1) pixel neighbourhood of an 8 x TW output tile x CB channels in LDS -- every thread issues
+// its share of the 16-byte loads back to back --, and a thread then reads the K x (4 + K - 1) columns of its 4 output pixels x 8 channels from LDS.
+// A third of the registers, 30-40 KB of LDS: four to five workgroups per CU.  Per output the taps are accumulated in (ky, kx) order in fp32 with the
+// same fused multiply-adds: the results equal dwconv_kernel's / dwconv2_kernel's bit for bit.
+// CB = 64 channels per workgroup (TW = 16) or 32 (TW = 32); w fp32 [K * K][C], b fp32 [C].
+template <int K, int CB>
+__global__ __launch_bounds__(256, 4) void dwconv_tile_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w, const float* __restrict__ b,
+                                                          bf16_t* __restrict__ out, int B, int H, int W, int C, int act, const float* __restrict__ slope,
+                                                          int tiles_x, int tiles_y) {
+#pragma clang fp contract(fast)
+  constexpr int PAD = K / 2, CGN = CB / 8, TH = 8, TW = 16 * 64 / CB, TWIN = TW + K - 1, THIN = TH + K - 1, PX = 4, NCOL = PX + K - 1;
+  constexpr int PITCH = CB * 2 + 32;             // bytes per staged pixel: the 16 lanes of a ds_read_b128 group then fall on distinct bank quads
+  constexpr int NPIECE = THIN * TWIN * CGN;
+  __shared__ __attribute__((aligned(16))) char s_in[THIN * TWIN * PITCH];
+  __shared__ __attribute__((aligned(16))) float s_w[K * K * CB + CB];
+  const int tid = threadIdx.x;
+  int L = blockIdx.x;
+  const int cb = L % (C / CB);
+  L /= (C / CB);
+  const int txi = L % tiles_x;
+  L /= tiles_x;
+  const int tyi = L % tiles_y;
+  const int bi = L / tiles_y;
+  const int oy0 = tyi * TH, ox0 = txi * TW, c0 = cb * CB;
+  const bf16_t* in_b = in + (size_t)bi * H * W * C + c0;
+#pragma unroll
+  for (int j = 0; j < (NPIECE + 255) / 256; ++j) {
+    const int idx = tid + j * 256;
+    if (idx < NPIECE) {
+      const int pix = idx / CGN, c = idx - pix * CGN;
+      const int iy = pix / TWIN, ix = pix - iy * TWIN;
+      const int gy = oy0 - PAD + iy, gx = ox0 - PAD + ix;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = *reinterpret_cast<const u32x4*>(in_b + ((size_t)gy * W + gx) * C + c * 8);
+      *reinterpret_cast<u32x4*>(s_in + pix * PITCH + c * 16) = v;
+    }
+  }
+  for (int i = tid; i < K * K * CB; i += 256) s_w[i] = w[(size_t)(i / CB) * C + c0 + (i % CB)];
+  if (tid < CB) s_w[K * K * CB + tid] = b[c0 + tid];
+  __syncthreads();
+  const int cg = tid % CGN, g = tid / CGN;
+  const int colg = g % (TW / PX), row = g / (TW / PX);
+  float acc[PX][8];
+#pragma unroll
+  for (int p = 0; p < PX; ++p)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[p][q] = 0.f;
+#pragma unroll 1      // (one tap row at a time: unrolled, hipcc hoists every row's LDS reads and needs 256 registers)
+  for (int ky = 0; ky < K; ++ky) {
+    float col[NCOL][8];
+#pragma unroll
+    for (int j = 0; j < NCOL; ++j) {
+      const u32x4 h = *reinterpret_cast<const u32x4*>(s_in + ((row + ky) * TWIN + colg * PX + j) * PITCH + cg * 16);
+      const uint32_t hw[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) col[j][k] = bf2f((k & 1) ? (hw[k >> 1] >> 16) : (hw[k >> 1] & 0xFFFFu));
+    }
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const float4 w0 = *reinterpret_cast<const float4*>(s_w + (ky * K + kx) * CB + cg * 8);
+      const float4 w1 = *reinterpret_cast<const float4*>(s_w + (ky * K + kx) * CB + cg * 8 + 4);
+      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+      for (int p = 0; p < PX; ++p)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[p][q] += col[p + kx][q] * wv[q];
+    }
+  }
+  const int oy = oy0 + row;
+  if (oy >= H) return;
+  const float sl = act == 3 ? slope[0] : 0.f;
+  const float* bv = s_w + K * K * CB + cg * 8;
+#pragma unroll
+  for (int p = 0; p < PX; ++p) {
+    const int ox = ox0 + colg * PX + p;
+    if (ox >= W) break;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v = acc[p][q] + bv[q];
+      if (act == 2) v = hswish(v);
+      else if (act == 1) v = fmaxf(v, 0.f);
+      else if (act == 3) v = v > 0.f ? v : sl * v;
+      acc[p][q] = v;
+    }
+    store8(out + (((size_t)bi * H + oy) * W + ox) * C + c0 + cg * 8, C, 0, acc[p]);
+  }
+}
+
 // global-average-pool partial sums, deterministic: block (chunk, image) sums its pixel range per channel
 // part: fp32 [B][gridDim.x][C]
 __global__ __launch_bounds__(256) void chan_partial_sum_kernel(const bf16_t* __restrict__ x, int HW, int C, int split,
@@ -480,6 +570,25 @@ int pt_launch_dwconv(const bf16_t* in, const float* w, const float* b, bf16_t* o
   if (two < 0) {
     const char* ev = getenv("PT_DWCONV2");
     two = ev ? atoi(ev) : 1;
+  }
+  static int tile = -1;          // PT_DWCONV_TILE=0: the register kernels everywhere (A/B switch)
+  if (tile < 0) {
+    const char* ev = getenv("PT_DWCONV_TILE");
+    tile = ev ? atoi(ev) : 1;
+  }
+  if (tile && !split && sy == 1 && sx == 1 && C % 32 == 0) {      // stride 1, pad k / 2: Ho == H, Wo == W
+    const int cb = C % 64 == 0 ? 64 : 32, tw = cb == 64 ? 16 : 32;
+    const int tiles_x = (Wo + tw - 1) / tw, tiles_y = (Ho + 7) / 8;
+    const long long nblk = (long long)B * tiles_x * tiles_y * (C / cb);
+    PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "dwconv: grid out of range");
+#define PT_DWT(KK, CC) hipLaunchKernelGGL((dwconv_tile_kernel<KK, CC>), dim3((unsigned)nblk), dim3(256), 0, s, in, w, b, out, B, H, W, C, act, slope, tiles_x, tiles_y)
+    if (k == 3 && cb == 64) PT_DWT(3, 64);
+    else if (k == 3) PT_DWT(3, 32);
+    else if (cb == 64) PT_DWT(5, 64);
+    else PT_DWT(5, 32);
+#undef PT_DWT
+    PT_HIP_CHECK(hipGetLastError());
+    return PT_OK;
   }
   if (two && sy == 1 && sx == 1 && Ho >= 2) {
     const dim3 grid2(blocks_for((long long)B * ((Ho + 1) / 2) * ((Wo + 3) / 4) * (C / 8)));
