@@ -157,10 +157,14 @@ __global__ __launch_bounds__(256) void dwconvt_up_add_kernel(const bf16_t* __res
 // group -- the four outputs read the same 3x3 input neighbourhood (9 loads instead of 16) and the 16 x C weight table comes
 // from LDS instead of 128 B per output through L1.  Per output the terms and their order are those of the kernel above
 // (dy = 0, 1 outer, dx = 0, 1 inner; terms outside the map skipped), so the results are bit-identical.
+// PACKED (plain bf16 maps only): the 3x3 neighbourhood and the block's four `add` vectors stay packed in registers (52 instead of 72 + one add vector at a
+// time) and are all requested before the first multiply-add: ~90 registers instead of 122, and 13 loads in flight per thread instead of 9 + 1 + 1 + 1 + 1.
+// Same products, same order.
+template <int PACKED>
 __global__ __launch_bounds__(256) void dwconvt_up2_add_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w,
                                                                const bf16_t* __restrict__ add, bf16_t* __restrict__ out,
                                                                int B, int h, int wd, int C, int split) {
-  extern __shared__ float s_w[];                    // [16][C]
+  extern __shared__ __attribute__((aligned(16))) float s_w[];                    // [16][C]
   for (int i = threadIdx.x; i < 16 * C; i += 256) s_w[i] = w[i];
   __syncthreads();
   const int cgn = C >> 3;
@@ -174,7 +178,8 @@ __global__ __launch_bounds__(256) void dwconvt_up2_add_kernel(const bf16_t* __re
     const int ax = (int)(t - t2 * (unsigned)wd);
     const int b = (int)(t2 / (unsigned)h);
     const int ay = (int)(t2 - (unsigned)b * (unsigned)h);
-    float v[3][3][8];
+    float v[PACKED ? 1 : 3][PACKED ? 1 : 3][8];
+    u32x4 vraw[PACKED ? 3 : 1][PACKED ? 3 : 1], araw[2][2];
     bool ok[3][3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -182,8 +187,25 @@ __global__ __launch_bounds__(256) void dwconvt_up2_add_kernel(const bf16_t* __re
       for (int c = 0; c < 3; ++c) {
         const int iy = ay - 1 + r, ix = ax - 1 + c;
         ok[r][c] = iy >= 0 && iy < h && ix >= 0 && ix < wd;
-        if (ok[r][c]) load8(in + (((size_t)b * h + iy) * wd + ix) * cs + cg * 8, C, split, v[r][c]);
+        if (PACKED) {
+          // no branches: the clamped pixel is loaded and zeroed when it is outside the map -- its products are +-0, and an accumulator that started
+          // at +0 is never -0, so adding them changes no bit (the float variant skips those terms)
+          const int iyc = min(max(iy, 0), h - 1), ixc = min(max(ix, 0), wd - 1);
+          u32x4 rv = *reinterpret_cast<const u32x4*>(in + (((size_t)b * h + iyc) * wd + ixc) * cs + cg * 8);
+          const uint32_t m = ok[r][c] ? 0xFFFFFFFFu : 0u;
+          rv.x &= m; rv.y &= m; rv.z &= m; rv.w &= m;
+          vraw[PACKED ? r : 0][PACKED ? c : 0] = rv;
+        } else {
+          if (ok[r][c]) load8(in + (((size_t)b * h + iy) * wd + ix) * cs + cg * 8, C, split, v[PACKED ? 0 : r][PACKED ? 0 : c]);
+        }
       }
+    if (PACKED && add) {
+#pragma unroll
+      for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+          araw[py][px] = *reinterpret_cast<const u32x4*>(add + (((size_t)b * (2 * h) + 2 * ay + py) * OW + 2 * ax + px) * cs + cg * 8);
+    }
 #pragma unroll
     for (int py = 0; py < 2; ++py)
 #pragma unroll
@@ -200,20 +222,33 @@ __global__ __launch_bounds__(256) void dwconvt_up2_add_kernel(const bf16_t* __re
           for (int dx = 0; dx < 2; ++dx) {
             const int c = px + 1 - dx;
             const int kx = px + 1 - 2 * (px - dx);
-            if (!ok[r][c]) continue;
+            if (!PACKED && !ok[r][c]) continue;
             const float* wp = s_w + (ky * 4 + kx) * C + cg * 8;
+            if (PACKED) {
+              const u32x4 rv = vraw[PACKED ? r : 0][PACKED ? c : 0];
+              const uint32_t hw[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] += v[r][c][q] * wp[q];
+              for (int q = 0; q < 8; ++q) acc[q] += bf2f((q & 1) ? (hw[q >> 1] >> 16) : (hw[q >> 1] & 0xFFFFu)) * wp[q];
+            } else {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) acc[q] += v[PACKED ? 0 : r][PACKED ? 0 : c][q] * wp[q];
+            }
           }
         }
         const size_t oo = (((size_t)b * (2 * h) + 2 * ay + py) * OW + 2 * ax + px) * cs + cg * 8;
         if (add) {
           float a[8];
-          load8(add + oo, C, split, a);
+          if (PACKED) {
+            const uint32_t hw[4] = {araw[py][px].x, araw[py][px].y, araw[py][px].z, araw[py][px].w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = bf2f((k & 1) ? (hw[k >> 1] >> 16) : (hw[k >> 1] & 0xFFFFu));
+          } else {
+            load8(add + oo, C, split, a);
+          }
 #pragma unroll
           for (int q = 0; q < 8; ++q) acc[q] += a[q];
         }
-        store8(out + oo, C, split, acc);
+        store8(out + oo, C, PACKED ? 0 : split, acc);
       }
   }
 }
@@ -1550,8 +1585,17 @@ int pt_launch_dwconvt_up_add(const bf16_t* in, const float* w, const bf16_t* add
   const long long blocks2 = (long long)B * h * wd * (C / 8);
   const char* sw = getenv("PT_DWCONVT2");       // PT_DWCONVT2=0: the general kernel also for f = 2 (A/B switch, read per call)
   if (f == 2 && blocks2 < (1ll << 31) && C <= 512 && !(sw && sw[0] == '0')) {
-    hipLaunchKernelGGL(dwconvt_up2_add_kernel, dim3(grid_for(blocks2)), dim3(256), (size_t)16 * C * sizeof(float), s, in, w, add, out,
-                       B, h, wd, C, split);
+    static int packed = -1;                      // PT_DWCONVT2_PACKED=0: the float-register variant also for plain bf16 maps (A/B switch)
+    if (packed < 0) {
+      const char* ev = getenv("PT_DWCONVT2_PACKED");
+      packed = ev ? atoi(ev) : 1;
+    }
+    if (!split && packed)
+      hipLaunchKernelGGL(dwconvt_up2_add_kernel<1>, dim3(grid_for(blocks2)), dim3(256), (size_t)16 * C * sizeof(float), s, in, w, add, out,
+                         B, h, wd, C, 0);
+    else
+      hipLaunchKernelGGL(dwconvt_up2_add_kernel<0>, dim3(grid_for(blocks2)), dim3(256), (size_t)16 * C * sizeof(float), s, in, w, add, out,
+                         B, h, wd, C, split);
     PT_HIP_CHECK(hipGetLastError());
     return PT_OK;
   }

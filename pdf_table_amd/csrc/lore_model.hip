@@ -179,7 +179,9 @@ struct Ctx {
       const PtTensor* wu = get(q + ".up_" + js + ".wf32");
       if (rc == PT_OK && !dry && ok) {
         e->prof.next_bytes = (double)n * p.H * p.W * o_ch * 2.0 * mul * (1.0 + 2.0 * f * f);      // in once, skip + out at f x f the pixels
-        PtProfScope ps(e, s, PT_PROF_OTHER, 0, "dw convT up + add");
+        char label[48];
+        snprintf(label, sizeof(label), "dw convT up + add %d @%dx%d", o_ch, p.H * f, p.W * f);
+        PtProfScope ps(e, s, PT_PROF_OTHER, 0, label);
         const int r = pt_launch_dwconvt_up_add(p.p, reinterpret_cast<const float*>(wu->d_ptr), layers[i - 1].p, u.p, n,
                                                p.H, p.W, o_ch, f, x3, s);
         if (r != PT_OK) rc = r;
