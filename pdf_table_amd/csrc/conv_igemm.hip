@@ -414,7 +414,8 @@ __device__ __forceinline__ void epilogue_direct_row(const ConvK& p, const f32x16
       for (int k = 0; k < 16; ++k) v[k] = fmaxf(v[k], 0.f);
     } else if (p.relu == 2) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) v[k] = v[k] * fminf(fmaxf(v[k] + 3.f, 0.f), 6.f) / 6.f;
+      for (int k = 0; k < 16; ++k) v[k] = v[k] * fminf(fmaxf(v[k] + 3.f, 0.f), 6.f) * 0.16666667f;      // (the rounded reciprocal, like layout_kernels.hip's
+                                                                                                        // hswish: the IEEE division is ten instructions per value)
     } else if (p.relu == 3) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) v[k] = v[k] > 0.f ? v[k] : sl * v[k];
@@ -737,6 +738,118 @@ __global__ __launch_bounds__(256, KS == 1 ? 4 : 2) void conv_igemm_kernel(ConvK 
   __syncthreads();
   epilogue_store<C::TH, C::TW>(p, stage, tid, b, oy0, ox0, nt * 64);
   }   // rep
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 1x1 stride-1 layers with a plain epilogue, K staged KG 32-channel chunks at a time.  conv_igemm_kernel<1, 1> hands its 4 x 32 x 64 tile one
+// 32-channel chunk per barrier pair: 12 KB in flight per workgroup and four MFMAs per wave between two barriers -- a 128 -> 128 layer is four
+// load latencies in a row per tile and ran at 2.2 TB/s.  Here a stage is KG chunks (KG = 4: the whole K of a 128-channel layer is requested at
+// once, one barrier pair per tile); same tile, same chunk order inside the accumulators (bit-identical), same register epilogue.
+// ---------------------------------------------------------------------------------------------------
+template <int KG>
+struct Conv1WideCfg {
+  static constexpr int PIXB = 64 * KG + 16;       // 36 / 68 dwords: a quarter-wave's ds_read_b128 covers every bank twice
+  static constexpr int IN_BYTES = 128 * PIXB;
+  static constexpr int W_BYTES = 64 * PIXB;
+  static constexpr int SMEM = IN_BYTES + W_BYTES > 16384 ? IN_BYTES + W_BYTES : 16384;      // (16 KB: the xp_store tiles of the epilogue)
+};
+
+template <int KG>
+__global__ __launch_bounds__(256, KG == 4 ? 3 : 4) void conv1x1_wide_kernel(ConvK p) {
+  using C = Conv1WideCfg<KG>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_in = smem;
+  char* s_w = smem + C::IN_BYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, q = lane >> 5;
+  int L, nt;
+  L = xcd_remap(blockIdx.x, gridDim.x);
+  tile_order(L, p.n_tiles, p.n_group, nt, L);
+  const int txi = L % p.tiles_x;
+  L /= p.tiles_x;
+  const int tyi = L % p.tiles_y;
+  const int b = L / p.tiles_y;
+  const int oy0 = tyi * 4, ox0 = txi * 32;
+  if (p.xlimit && ox0 >= p.xlimit[b]) return;
+  if (p.xlimit_rows) {
+    int mx = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (oy0 + r < p.Ho) mx = max(mx, p.xlimit_rows[oy0 + r]);
+    if (ox0 >= mx) return;
+  }
+  const int nstages = (p.Cin >> 5) / KG;
+  const bf16_t* wt = p.w + (size_t)nt * (p.Cin >> 5) * (64 * 32);
+
+  u32x4 rin[2 * KG];
+  u32x4 rw[KG];
+  // piece idx = tid + j * 256 of a chunk: pixel idx >> 2 of the 4 x 32 patch, 16-byte part idx & 3
+  const int pix0 = tid >> 2, part = tid & 3;
+  const int gy0 = oy0 + (pix0 >> 5), gx = ox0 + (pix0 & 31);      // j = 1: two rows further down
+  const bool in0 = gy0 < p.H && gx < p.W, in1 = gy0 + 2 < p.H && gx < p.W;
+  auto prefetch = [&](int stage) {
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      int cc = (stage * KG + g) << 5;
+      const bf16_t* sp = p.in;
+      int sc = p.Cin;
+      if (p.nseg > 1) {      // K over a concatenation of tensors: logical channel -> (segment, channel inside it); uniform over the workgroup
+        sc = p.segc0;
+        if (cc >= sc) { cc -= sc; sp = p.in1; sc = p.segc1;
+          if (cc >= sc) { cc -= sc; sp = p.in2; sc = p.segc2;
+            if (cc >= sc) { cc -= sc; sp = p.in3; sc = p.segc3; } } }
+      }
+      const bf16_t* src = sp + ((size_t)b * p.H * p.W) * sc + cc + part * 8;
+      u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
+      if (in0) v0 = *reinterpret_cast<const u32x4*>(src + ((size_t)gy0 * p.W + gx) * sc);
+      if (in1) v1 = *reinterpret_cast<const u32x4*>(src + ((size_t)(gy0 + 2) * p.W + gx) * sc);
+      rin[2 * g] = v0;
+      rin[2 * g + 1] = v1;
+    }
+    const bf16_t* wc = wt + (size_t)stage * KG * (64 * 32);
+#pragma unroll
+    for (int g = 0; g < KG; ++g) rw[g] = *reinterpret_cast<const u32x4*>(wc + (g * 256 + tid) * 8);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      *reinterpret_cast<u32x4*>(s_in + pix0 * C::PIXB + g * 64 + part * 16) = rin[2 * g];
+      *reinterpret_cast<u32x4*>(s_in + (pix0 + 64) * C::PIXB + g * 64 + part * 16) = rin[2 * g + 1];
+      *reinterpret_cast<u32x4*>(s_w + pix0 * C::PIXB + g * 64 + part * 16) = rw[g];
+    }
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+  const char* a_base = s_in + (wave * 32 + lx) * C::PIXB + q * 16;
+  const char* b_base = s_w + lx * C::PIXB + q * 16;
+
+  prefetch(0);
+  for (int st = 0; st < nstages; ++st) {
+    if (st) __syncthreads();      // everyone is done reading the previous stage
+    commit();
+    __syncthreads();
+    if (st + 1 < nstages) prefetch(st + 1);
+#pragma unroll
+    for (int k = 0; k < 2 * KG; ++k) {
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(b_base + k * 32);
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(b_base + 32 * C::PIXB + k * 32);
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base + k * 32);
+      acc[0] = mma16<false>(b0, a, acc[0]);      // D = [channel][pixel]
+      acc[1] = mma16<false>(b1, a, acc[1]);
+    }
+  }
+  const DirectBias bs = direct_bias<2>(p, nt * 64, q);
+  char* xp = nullptr;
+  if (p.xp_store) {      // uniform: the operand images are dead once every wave has left the K loop
+    __syncthreads();
+    xp = smem + wave * 4096;
+  }
+  epilogue_direct_row<2>(p, acc, bs, b, oy0 + wave, ox0, lx, nt * 64, q, xp);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1701,6 +1814,21 @@ static void launch_direct(const ConvK& k, unsigned nblk, hipStream_t s) {
   hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, 0, NHALF, true>), dim3(nblk), dim3(256), C::SMEM, s, k);
 }
 
+static bool conv1_wide() {      // PT_CONV1_WIDE=0: conv_igemm_kernel<1, 1> (one 32-channel chunk per stage) for every plain 1x1 layer (A/B switch, read per call)
+  const char* ev = getenv("PT_CONV1_WIDE");
+  return !(ev && ev[0] == '0');
+}
+template <int KG>
+static void launch_wide1(const ConvK& k, unsigned nblk, hipStream_t s) {
+  using C = Conv1WideCfg<KG>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_wide_kernel<KG>), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv1x1_wide_kernel<KG>), dim3(nblk), dim3(256), C::SMEM, s, k);
+}
+
 template <int KS, int STRIDE, int GEOM = 0>
 static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   using C = ConvCfg<KS, STRIDE, GEOM>;
@@ -1737,6 +1865,10 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
       launch_direct<3, 1, 1>(k, (unsigned)nblk, s);
     else if (narrow)
       launch_half(k, (unsigned)nblk, s);
+    else if (plain && KS == 1 && STRIDE == 1 && !k.ylimit && k.Cin % 128 == 0 && conv1_wide())
+      launch_wide1<4>(k, (unsigned)nblk, s);
+    else if (plain && KS == 1 && STRIDE == 1 && !k.ylimit && k.Cin % 64 == 0 && conv1_wide())
+      launch_wide1<2>(k, (unsigned)nblk, s);
     else if (plain && KS == 1 && STRIDE == 1)
       launch_direct<1, 1, 2>(k, (unsigned)nblk, s);
     else if (plain && KS == 3 && STRIDE == 2)

@@ -105,6 +105,42 @@ def test_conv_variants_vs_torch_fp32(eng, case):
 
 
 @pytest.mark.parametrize("case", [
+    dict(B=2, H=26, W=38, Cin=128, N=256, res_mode=2),              # one 4-chunk stage, four output tiles, ragged last tile
+    dict(B=1, H=15, W=17, Cin=512, N=256),                          # four 4-chunk stages
+    dict(B=3, H=9, W=13, Cin=384, N=128, relu=True, res_mode=1),    # three 4-chunk stages
+    dict(B=2, H=21, W=35, Cin=64, N=128, relu=True),                # one 2-chunk stage
+    dict(B=1, H=7, W=70, Cin=192, N=64, res_mode=1),                # three 2-chunk stages
+    dict(B=1, H=3, W=5, Cin=128, N=192, relu=True),                 # fewer pixels than one workgroup
+])
+def test_conv1x1_wide_stages_equal_chunk_stages(eng, case, monkeypatch):
+    """conv1x1_wide_kernel (2 or 4 32-channel chunks per LDS stage) against conv_igemm_kernel<1, 1> (one chunk per stage; PT_CONV1_WIDE is read at
+    every call): same chunk order inside the accumulators, so every output bit is the same; and both against torch fp32 (_conv_case)."""
+    g = torch.Generator().manual_seed(case["Cin"] + case["N"])
+    B, H, W, Cin, N = case["B"], case["H"], case["W"], case["Cin"], case["N"]
+    dev = torch.device("cuda", 0)
+    x = torch.randn(B, H, W, Cin, generator=g).to(torch.bfloat16).to(dev)
+    w = _bf16(torch.randn(N, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5)
+    wt = torch.from_numpy(tile_conv_weight(w).view(np.int16)).to(dev)
+    bd = (torch.randn(N, generator=g) * 0.1).to(dev)
+    rm = case.get("res_mode", 0)
+    rd = None
+    if rm == 1:
+        rd = torch.randn(B, H, W, N, generator=g).to(torch.bfloat16).to(dev)
+    elif rm == 2:
+        rd = torch.randn(B, H // 2, W // 2, N, generator=g).to(torch.bfloat16).to(dev)
+    outs = []
+    for sw in ("1", "0"):
+        monkeypatch.setenv("PT_CONV1_WIDE", sw)
+        o = eng.op_conv2d(x, wt, bd, 1, 1, relu=case.get("relu", False), res=rd, res_mode=rm)
+        torch.cuda.synchronize()
+        outs.append(o.view(torch.int16).cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    assert float(np.abs(outs[0].astype(np.int32)).max()) > 0
+    monkeypatch.setenv("PT_CONV1_WIDE", "1")
+    _conv_case(eng, ks=1, stride=1, **case)
+
+
+@pytest.mark.parametrize("case", [
     dict(B=1, H=16, W=64, Cin=64, N=64, ks=3, stride=1),                               # two tiles, two workgroups
     dict(B=2, H=37, W=45, Cin=64, N=64, ks=3, stride=1, relu=True, res_mode=1),        # ragged tiles + residual
     dict(B=3, H=50, W=70, Cin=64, N=64, ks=3, stride=1, relu=True, grid=5),            # 36 tiles walked by 5 workgroups
