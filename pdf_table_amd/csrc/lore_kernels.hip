@@ -178,8 +178,9 @@ __global__ __launch_bounds__(256) void dwconvt_up2_add_kernel(const bf16_t* __re
     const int ax = (int)(t - t2 * (unsigned)wd);
     const int b = (int)(t2 / (unsigned)h);
     const int ay = (int)(t2 - (unsigned)b * (unsigned)h);
+    constexpr bool SP = PACKED == 2;      // PACKED 2: (hi | lo) maps, both halves packed
     float v[PACKED ? 1 : 3][PACKED ? 1 : 3][8];
-    u32x4 vraw[PACKED ? 3 : 1][PACKED ? 3 : 1], araw[2][2];
+    u32x4 vraw[PACKED ? 3 : 1][PACKED ? 3 : 1], vlo[SP ? 3 : 1][SP ? 3 : 1], araw[2][2], alo[SP ? 2 : 1][SP ? 2 : 1];
     bool ok[3][3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -191,10 +192,16 @@ __global__ __launch_bounds__(256) void dwconvt_up2_add_kernel(const bf16_t* __re
           // no branches: the clamped pixel is loaded and zeroed when it is outside the map -- its products are +-0, and an accumulator that started
           // at +0 is never -0, so adding them changes no bit (the float variant skips those terms)
           const int iyc = min(max(iy, 0), h - 1), ixc = min(max(ix, 0), wd - 1);
-          u32x4 rv = *reinterpret_cast<const u32x4*>(in + (((size_t)b * h + iyc) * wd + ixc) * cs + cg * 8);
+          const bf16_t* ip = in + (((size_t)b * h + iyc) * wd + ixc) * cs + cg * 8;
+          u32x4 rv = *reinterpret_cast<const u32x4*>(ip);
           const uint32_t m = ok[r][c] ? 0xFFFFFFFFu : 0u;
           rv.x &= m; rv.y &= m; rv.z &= m; rv.w &= m;
           vraw[PACKED ? r : 0][PACKED ? c : 0] = rv;
+          if (SP) {
+            u32x4 rl = *reinterpret_cast<const u32x4*>(ip + C);
+            rl.x &= m; rl.y &= m; rl.z &= m; rl.w &= m;
+            vlo[SP ? r : 0][SP ? c : 0] = rl;
+          }
         } else {
           if (ok[r][c]) load8(in + (((size_t)b * h + iy) * wd + ix) * cs + cg * 8, C, split, v[PACKED ? 0 : r][PACKED ? 0 : c]);
         }
@@ -203,8 +210,11 @@ __global__ __launch_bounds__(256) void dwconvt_up2_add_kernel(const bf16_t* __re
 #pragma unroll
       for (int py = 0; py < 2; ++py)
 #pragma unroll
-        for (int px = 0; px < 2; ++px)
-          araw[py][px] = *reinterpret_cast<const u32x4*>(add + (((size_t)b * (2 * h) + 2 * ay + py) * OW + 2 * ax + px) * cs + cg * 8);
+        for (int px = 0; px < 2; ++px) {
+          const bf16_t* ap = add + (((size_t)b * (2 * h) + 2 * ay + py) * OW + 2 * ax + px) * cs + cg * 8;
+          araw[py][px] = *reinterpret_cast<const u32x4*>(ap);
+          if (SP) alo[SP ? py : 0][SP ? px : 0] = *reinterpret_cast<const u32x4*>(ap + C);
+        }
     }
 #pragma unroll
     for (int py = 0; py < 2; ++py)
@@ -227,8 +237,16 @@ __global__ __launch_bounds__(256) void dwconvt_up2_add_kernel(const bf16_t* __re
             if (PACKED) {
               const u32x4 rv = vraw[PACKED ? r : 0][PACKED ? c : 0];
               const uint32_t hw[4] = {rv.x, rv.y, rv.z, rv.w};
+              if (SP) {      // the value is hi + lo (one rounding), as load8 forms it
+                const u32x4 rl = vlo[SP ? r : 0][SP ? c : 0];
+                const uint32_t lw[4] = {rl.x, rl.y, rl.z, rl.w};
 #pragma unroll
-              for (int q = 0; q < 8; ++q) acc[q] += bf2f((q & 1) ? (hw[q >> 1] >> 16) : (hw[q >> 1] & 0xFFFFu)) * wp[q];
+                for (int q = 0; q < 8; ++q)
+                  acc[q] += (bf2f((q & 1) ? (hw[q >> 1] >> 16) : (hw[q >> 1] & 0xFFFFu)) + bf2f((q & 1) ? (lw[q >> 1] >> 16) : (lw[q >> 1] & 0xFFFFu))) * wp[q];
+              } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] += bf2f((q & 1) ? (hw[q >> 1] >> 16) : (hw[q >> 1] & 0xFFFFu)) * wp[q];
+              }
             } else {
 #pragma unroll
               for (int q = 0; q < 8; ++q) acc[q] += v[PACKED ? 0 : r][PACKED ? 0 : c][q] * wp[q];
@@ -242,13 +260,19 @@ __global__ __launch_bounds__(256) void dwconvt_up2_add_kernel(const bf16_t* __re
             const uint32_t hw[4] = {araw[py][px].x, araw[py][px].y, araw[py][px].z, araw[py][px].w};
 #pragma unroll
             for (int k = 0; k < 8; ++k) a[k] = bf2f((k & 1) ? (hw[k >> 1] >> 16) : (hw[k >> 1] & 0xFFFFu));
+            if (SP) {
+              const u32x4 rl = alo[SP ? py : 0][SP ? px : 0];
+              const uint32_t lw[4] = {rl.x, rl.y, rl.z, rl.w};
+#pragma unroll
+              for (int k = 0; k < 8; ++k) a[k] += bf2f((k & 1) ? (lw[k >> 1] >> 16) : (lw[k >> 1] & 0xFFFFu));
+            }
           } else {
             load8(add + oo, C, split, a);
           }
 #pragma unroll
           for (int q = 0; q < 8; ++q) acc[q] += a[q];
         }
-        store8(out + oo, C, PACKED ? 0 : split, acc);
+        store8(out + oo, C, PACKED == 1 ? 0 : split, acc);
       }
   }
 }
@@ -1593,6 +1617,9 @@ int pt_launch_dwconvt_up_add(const bf16_t* in, const float* w, const bf16_t* add
     if (!split && packed)
       hipLaunchKernelGGL(dwconvt_up2_add_kernel<1>, dim3(grid_for(blocks2)), dim3(256), (size_t)16 * C * sizeof(float), s, in, w, add, out,
                          B, h, wd, C, 0);
+    else if (split && packed)
+      hipLaunchKernelGGL(dwconvt_up2_add_kernel<2>, dim3(grid_for(blocks2)), dim3(256), (size_t)16 * C * sizeof(float), s, in, w, add, out,
+                         B, h, wd, C, 1);
     else
       hipLaunchKernelGGL(dwconvt_up2_add_kernel<0>, dim3(grid_for(blocks2)), dim3(256), (size_t)16 * C * sizeof(float), s, in, w, add, out,
                          B, h, wd, C, split);
