@@ -161,7 +161,7 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
     };
     {
       PtProfScope ps(e, s, PT_PROF_OTHER, 0, "crnn conv0+pool");
-      RUN(pt_launch_crnn_conv0_pool(g, nn, PT_REC_H, PT_REC_W, Bv(c0w), Bv(c0b), x3, a0, s, lim && !x3 ? lim->lim[5] : nullptr));
+      RUN(pt_launch_crnn_conv0_pool(g, nn, PT_REC_H, PT_REC_W, Bv(c0w), Bv(c0b), x3, a0, s, lim ? lim->lim[5] : nullptr));
     }
     // conv1 + pool(2,2) and conv2.3 + pool((2,1)): pooling in the conv epilogue (PT_POOL_FUSED=0: separate pool kernels,
     // which need the full maps: no column limits then)

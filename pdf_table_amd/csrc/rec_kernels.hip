@@ -386,7 +386,7 @@ int pt_launch_rec_pp_resize_norm(const uint8_t* crops, const pt_rec_line* lines,
 __global__ __launch_bounds__(256) void crnn_conv0_pool_kernel(const bf16_t* __restrict__ in, int n, int H, int W,
                                                                const float* __restrict__ w64x9,
                                                                const float* __restrict__ bias, int split,
-                                                               bf16_t* __restrict__ out) {
+                                                               bf16_t* __restrict__ out, const int* __restrict__ xlim) {
   __shared__ float sw[64 * 9 + 64];
   for (int i = threadIdx.x; i < 64 * 9; i += blockDim.x) sw[i] = w64x9[i];
   for (int i = threadIdx.x; i < 64; i += blockDim.x) sw[576 + i] = bias[i];
@@ -400,6 +400,7 @@ __global__ __launch_bounds__(256) void crnn_conv0_pool_kernel(const bf16_t* __re
     t /= Wo;
     const int oy = (int)(t % Ho);
     const int b = (int)(t / Ho);
+    if (xlim && (ox & ~63) >= xlim[b]) continue;      // ragged line: the 64-column groups the MFMA kernel below skips (nothing downstream reads them)
     float win[4][4];
 #pragma unroll
     for (int dy = 0; dy < 4; ++dy)
@@ -557,7 +558,7 @@ int pt_launch_crnn_conv0_pool(const bf16_t* in, int n, int H, int W, const float
   const long long total = (long long)n * (H / 2) * (W / 2) * 8;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(crnn_conv0_pool_kernel, dim3(blocks), dim3(256), 0, s, in, n, H, W, w64x9, bias, split, out);
+  hipLaunchKernelGGL(crnn_conv0_pool_kernel, dim3(blocks), dim3(256), 0, s, in, n, H, W, w64x9, bias, split, out, xlim);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
