@@ -317,7 +317,9 @@ int pt_launch_rec_pp_resize_norm(const uint8_t* crops, const pt_rec_line* lines,
 struct PtCrnnLimits {
   int* lim[6];        // device int [n] each: conv1, conv2a, conv2b, conv3a, conv3b output-column limits; [5]: conv0 (pooled columns)
   int* cols;          // device int [8]: sum over lines of the tile-rounded limits ([5]: the sequence GEMMs, 32-step tiles)
+  int* glist;         // device int [1 + 5 n]: the live 32-step row groups of the sequence GEMMs, compacted (rows_live_list_kernel)
 };
+int pt_launch_rows_live_list(const int* lim, int n, int* glist, hipStream_t s);
 int pt_launch_crnn_limits(const pt_rec_line* lines, int n, const PtCrnnLimits& L, hipStream_t s);
 // end_lim / end_tile: fill only up to column roundup(end_lim[b], end_tile) (inclusive: the halo column the next limited conv
 // reads); end_lim == null: to the end of the row
@@ -332,7 +334,9 @@ int pt_launch_gemm_argmax(const bf16_t* A, long long M, int K, const bf16_t* W, 
                           hipStream_t s);
 int pt_launch_gemm_argmax_x3(const bf16_t* A, long long M, int K, const bf16_t* W3, const float* bias, int N, int n_real, int* ids, float* maxv,
                              void* scratch, hipStream_t s);
-// tlim != null: rows are (line, t) with T = 160 steps per line; 32-step groups at t0 >= tlim[line] are not computed
+// tlim != null: rows are (line, t) with T = 160 steps per line; only the 32-step row groups of the list are computed (PtCrnnLimits.glist)
+int pt_launch_gemm_rows_x3(const bf16_t* A, long long M, int K, const bf16_t* W3, const float* bias, int N, bf16_t* out, int relu, hipStream_t s,
+                           const int* tlim = nullptr);
 int pt_launch_gemm_rows(const bf16_t* A, long long M, int K, const bf16_t* W, const float* bias, int N, bf16_t* out, int relu,
                         hipStream_t s, const int* tlim = nullptr);
 int pt_launch_argmax_reduce(const float* part, long long rows, int ntiles, int* ids, float* maxv, hipStream_t s);

@@ -132,10 +132,21 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
     const char* ev = getenv("PT_CLS_FUSED");
     fused = ev ? atoi(ev) : 1;
   }
+  // hi/lo mode: the streaming three-pass kernel (gemm_rows_x3_kernel: the conv kernel's sums in its order; PT_ROWS_X3=0, read per call: the conv kernel)
+  auto rows_x3 = [&]() {
+    const char* ev = getenv("PT_ROWS_X3");
+    return x3 && fused && !pt_f16x2(e) && !(ev && ev[0] == '0');
+  };
   auto rows_gemm = [&](const bf16_t* in, int cin, const ConvW& cw, int N, bf16_t* out, int relu, const char* label) -> int {
     if (!x3 && fused && (cin == 512 || cin == 256)) {
       PtProfScope ps(e, s, PT_PROF_CONV1X1, 2.0 * n * T * (double)cin * N, label);
       return pt_launch_gemm_rows(in, (long long)n * T, cin, W(cw.w), Bv(cw.b), N, out, relu, s);
+    }
+    if (rows_x3() && (cin == 512 || cin == 256)) {
+      char lb[48];
+      snprintf(lb, sizeof(lb), "%s x3", label);
+      PtProfScope ps(e, s, PT_PROF_CONV1X1, 2.0 * n * T * (double)cin * N, lb);
+      return pt_launch_gemm_rows_x3(in, (long long)n * T, cin, W(cw.w), Bv(cw.b), N, out, relu, s);
     }
     return pt_launch_conv(e, conv(in, 1, n, T, cin, cw, N, 1, out, relu), s);
   };
@@ -203,9 +214,19 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
       if (lim) { c4d.xlimit_rows = lim->lim[4]; c4d.xlimit_cols = lim->cols + 5; }
       RUN(pt_launch_conv(e, c4d, s));
     }
-    if (!x3 && fused) {
-      PtProfScope ps(e, s, PT_PROF_CONV1X1, 2.0 * nn * T * 512.0 * 2048, "rows gemm 512->2048");
-      RUN(pt_launch_gemm_rows(f_o, (long long)nn * T, 512, W(xp1.w), Bv(xp1.b), 2048, gx_o, 0, s, lim ? lim->lim[4] : nullptr));
+    if ((!x3 && fused) || rows_x3()) {
+      int lim_slot = -1;
+      {
+        PtProfScope ps(e, s, PT_PROF_CONV1X1, 2.0 * nn * T * 512.0 * 2048, x3 ? "rows gemm 512->2048 x3" : "rows gemm 512->2048");
+        if (x3) RUN(pt_launch_gemm_rows_x3(f_o, (long long)nn * T, 512, W(xp1.w), Bv(xp1.b), 2048, gx_o, 0, s, lim ? lim->glist : nullptr));
+        else RUN(pt_launch_gemm_rows(f_o, (long long)nn * T, 512, W(xp1.w), Bv(xp1.b), 2048, gx_o, 0, s, lim ? lim->glist : nullptr));
+        if (lim && ps.idx >= 0 && e->prof.h_lims && e->prof.n_lims < PtProfile::MAX_LIMS) {      // credit the executed row groups, like the limited convs
+          auto& pd = e->prof.pending[ps.idx];
+          pd.lim_slot = lim_slot = e->prof.n_lims++;
+          pd.rows = nn * T;
+        }
+      }
+      if (lim_slot >= 0) (void)hipMemcpyAsync(e->prof.h_lims + lim_slot, lim->cols + 5, sizeof(int), hipMemcpyDeviceToHost, s);
     } else {
       ConvDesc xd = conv(f_o, 1, nn, T, 512, xp1, 2048, 1, gx_o, 0);
       if (lim) { xd.xlimit_rows = lim->lim[4]; xd.xlimit_cols = lim->cols + 5; }
@@ -236,7 +257,7 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
       PT_HIP_CHECK(hipStreamWaitEvent(s, e->rec_zero_ready[x3], 0));       // a no-op once the build has completed
     }
     zl = reinterpret_cast<const bf16_t*>(e->rec_zero[x3]);
-    const size_t need = ((size_t)6 * n + 8) * sizeof(int);
+    const size_t need = ((size_t)11 * n + 16) * sizeof(int);
     if (need > e->rec_limits_cap) {
       PT_HIP_CHECK(hipStreamSynchronize(s));
       if (e->rec_limits) PT_HIP_CHECK(hipFree(e->rec_limits));
@@ -247,9 +268,11 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
     int* base = reinterpret_cast<int*>(e->rec_limits);
     for (int k = 0; k < 6; ++k) lim.lim[k] = base + (size_t)k * n;
     lim.cols = base + (size_t)6 * n;
+    lim.glist = base + (size_t)6 * n + 8;
     {
       PtProfScope ps(e, s, PT_PROF_OTHER, 0, "crnn limits");
       RUN(pt_launch_crnn_limits(d_lines, n, lim, s));
+      RUN(pt_launch_rows_live_list(lim.lim[4], n, lim.glist, s));
     }
   }
   RUN(conv_stack(gray, n, bf.a0, bf.a1, bf.p1, bf.c2a, bf.c2b, bf.p2, bf.c3a, bf.c3b, bf.p3, bf.f, bf.gx, ragged ? &lim : nullptr, zl));

@@ -266,6 +266,36 @@ __global__ void crnn_limits_kernel(const pt_rec_line* __restrict__ lines, int n,
   if (threadIdx.x < 6) atomicAdd(&cols[threadIdx.x], sums[threadIdx.x]);
 }
 
+// The live 32-step row groups of the sequence GEMMs, compacted: glist[0] = their number, glist[1 + g] = row group (line * 5 + k) of the g-th,
+// in line order (k * 32 < lim[line]).  One workgroup: per-thread runs of lines, an exclusive scan of the runs' counts through LDS.
+__global__ __launch_bounds__(1024) void rows_live_list_kernel(const int* __restrict__ lim, int n, int* __restrict__ glist) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x, per = (n + 1023) / 1024, b0 = tid * per, b1 = min(n, b0 + per);
+  int cnt = 0;
+  for (int b = b0; b < b1; ++b) cnt += min(PT_REC_T / 32, (lim[b] + 31) / 32);
+  part[tid] = cnt;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int pos = part[tid] - cnt;
+  if (tid == 1023) glist[0] = part[1023];
+  for (int b = b0; b < b1; ++b) {
+    const int c = min(PT_REC_T / 32, (lim[b] + 31) / 32);
+    for (int k = 0; k < c; ++k) glist[1 + pos + k] = b * (PT_REC_T / 32) + k;
+    pos += c;
+  }
+}
+
+int pt_launch_rows_live_list(const int* lim, int n, int* glist, hipStream_t s) {
+  hipLaunchKernelGGL(rows_live_list_kernel, dim3(1), dim3(1024), 0, s, lim, n, glist);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
 int pt_launch_crnn_limits(const pt_rec_line* lines, int n, const PtCrnnLimits& L, hipStream_t s) {
   PT_HIP_CHECK(hipMemsetAsync(L.cols, 0, 8 * sizeof(int), s));
   int blocks = (n + 255) / 256;
@@ -1516,16 +1546,20 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_argmax_kernel(const bf16_t* _
   float* sb = reinterpret_cast<float*>(smem + 64 * P);              // [64] bias of the stage
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lx = lane & 31, q = lane >> 5;
-  const long long row = ((long long)blockIdx.x * NW + wave) * 32 + lx;
-  const long long rc = row < M ? row : M - 1;
-  // ragged sequences (MODE 1): a wave's 32 rows are 32 consecutive time steps of ONE line (T = 160 = 5 x 32); groups at or
-  // beyond the line's limit are not computed (the caller fills them), a workgroup with no live wave leaves at once
+  // ragged sequences (MODE 1, tlim = the list of rows_live_list_kernel): a wave's 32 rows are 32 consecutive time steps of ONE line
+  // (T = 160 = 5 x 32); only the groups in front of their line's limit are computed (the caller fills the others), and they are
+  // COMPACTED over the waves -- tlim[0] live groups, tlim[1 + g] = row group of the g-th -- so that no workgroup streams W for
+  // one live wave out of four (lines are ~ 1/4 text on the bench pages: skipping whole workgroups only left 70 % of them running)
+  long long row0 = ((long long)blockIdx.x * NW + wave) * 32;
   bool live = true;
   if (MODE == 1 && tlim) {
-    const long long r0 = ((long long)blockIdx.x * NW + wave) * 32;
-    live = r0 < M && (int)(r0 % PT_REC_T) < tlim[r0 / PT_REC_T];
-    if (!__syncthreads_or(live ? 1 : 0)) return;
+    const int total = tlim[0], g = blockIdx.x * NW + wave;
+    if ((int)blockIdx.x * NW >= total) return;
+    live = g < total;
+    row0 = live ? (long long)tlim[1 + g] * 32 : 0;
   }
+  const long long row = row0 + lx;
+  const long long rc = row < M ? row : M - 1;
   bf16x8 areg[KSTEPS];
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) areg[ks] = *reinterpret_cast<const bf16x8*>(A + rc * lda + ks * 16 + q * 8);
@@ -1597,7 +1631,6 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_argmax_kernel(const bf16_t* _
           *reinterpret_cast<u32x2*>(tile + lx * 80 + (rg * 8 + 4 * q) * 2) = u32x2{hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the tile is wave-private: LDS operations of a wave complete in order
-        const long long row0 = ((long long)blockIdx.x * NW + wave) * 32;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int r = (lane >> 2) + 16 * i;
@@ -1963,6 +1996,142 @@ int pt_launch_gemm_rows(const bf16_t* A, long long M, int K, const bf16_t* W, co
     if (nw == 8) hipLaunchKernelGGL((gemm_argmax_kernel<16, 1, 8>), grid, blk, smem, s, A, M, W, bias, N, nullptr, nullptr, out, relu, tlim, 256, 8ll * 2048);
     else hipLaunchKernelGGL((gemm_argmax_kernel<16, 1>), grid, blk, smem, s, A, M, W, bias, N, nullptr, nullptr, out, relu, tlim, 256, 8ll * 2048);
   }
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Row GEMM of the hi/lo (BF16X3) mode: out (hi | lo) [M][2 N] = A (hi | lo) [M][2 K] . W^T + bias over the three-pass tiling
+// [w_hi | w_hi | w_lo] of the 1x1 conv kernel, in that kernel's order -- all (a_hi, w_hi) k-steps, then (a_lo, w_hi), then (a_hi, w_lo)
+// -- so the accumulators hold the same sums.  The streaming shape of gemm_argmax_kernel<., 1>: a wave keeps BOTH halves of its 32
+// rows in registers for the whole kernel (2 x KSTEPS x 4: 256 of the 512 registers a lone wave of a SIMD may hold at K = 512; two
+// workgroups per CU at K = 256), W streams through LDS in 32-class stages of (w_hi, w_lo) rows (66 KB at K = 512, the next stage
+// pre-fetched to registers), 3 KSTEPS MFMAs per stage and wave, and the stage's 32 x 32 (hi, lo) values leave through wave-private
+// LDS tiles as 64-byte row segments.  The conv kernel ran these layers (the CRNN head's LSTM projections and embeddings) with a
+// 128 x 64 tile, twelve MFMAs per wave between two barriers and an fp32-through-LDS epilogue.
+// ---------------------------------------------------------------------------------------------------
+template <int KSTEPS>
+__global__ __launch_bounds__(256, KSTEPS == 32 ? 1 : 2) void gemm_rows_x3_kernel(const bf16_t* __restrict__ A, long long M, const bf16_t* __restrict__ W3,
+                                                                                 const float* __restrict__ bias, int N, bf16_t* __restrict__ out, int relu,
+                                                                                 const int* __restrict__ tlim) {
+  constexpr int K = KSTEPS * 16, NCH = K / 32, P = K * 2 + 16;
+  constexpr int NPF = NCH;                              // 16-byte pieces per thread per stage: 2 planes x 32 rows x K * 2 / 16 / 256
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sw = smem;                                      // [2 planes: w_hi, w_lo][32 classes][P]
+  float* sb = reinterpret_cast<float*>(smem + 64 * P);  // [32] bias of the stage
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, q = lane >> 5;
+  long long row0 = ((long long)blockIdx.x * 4 + wave) * 32;
+  bool live = row0 < M;
+  if (tlim) {      // ragged sequences: the compacted list of live row groups, as in gemm_argmax_kernel<., 1>
+    const int total = tlim[0], g = blockIdx.x * 4 + wave;
+    if ((int)blockIdx.x * 4 >= total) return;
+    live = g < total;
+    row0 = live ? (long long)tlim[1 + g] * 32 : 0;
+  }
+  const long long row = row0 + lx;
+  const long long rc = row < M ? row : M - 1;
+  bf16x8 ahi[KSTEPS], alo[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    ahi[ks] = *reinterpret_cast<const bf16x8*>(A + rc * (2 * K) + ks * 16 + q * 8);
+    alo[ks] = *reinterpret_cast<const bf16x8*>(A + rc * (2 * K) + K + ks * 16 + q * 8);
+  }
+  u32x4 pf[NPF];
+  float pb = 0.f;
+  // stage st = 32 classes: half st & 1 of the 64-class tile st >> 1; piece idx of the stage: plane idx / (NCH * 128), chunk, class row, 16-byte part
+  auto prefetch = [&](int st) {
+    const bf16_t* wt = W3 + (size_t)(st >> 1) * (3 * NCH * 2048) + (st & 1) * (32 * 32);
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+      const int idx = tid + j * 256, plane = idx / (NCH * 128), rem = idx - plane * (NCH * 128), c = rem >> 7, rp = rem & 127;
+      pf[j] = *reinterpret_cast<const u32x4*>(wt + (size_t)(plane * 2 * NCH + c) * 2048 + rp * 8);
+    }
+    if (tid < 32) pb = bias[st * 32 + tid];
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+      const int idx = tid + j * 256, plane = idx / (NCH * 128), rem = idx - plane * (NCH * 128), c = rem >> 7, r = (rem & 127) >> 2, part = rem & 3;
+      *reinterpret_cast<u32x4*>(sw + (plane * 32 + r) * P + c * 64 + part * 16) = pf[j];
+    }
+    if (tid < 32) sb[tid] = pb;
+  };
+  char* tile = smem + 64 * P + 128 + wave * (2 * 32 * 80);      // hi rows (pitch 80 bytes), then the lo rows
+  const int NS = N / 32;
+  prefetch(0);
+  for (int st = 0; st < NS; ++st) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (st + 1 < NS) prefetch(st + 1);
+    if (!live) continue;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const char* wh = sw + lx * P + q * 16;
+    const char* wl = sw + (32 + lx) * P + q * 16;
+    // (a scheduling barrier every eight k-steps: left alone, hipcc hoists a pass's 32 fragment reads in front of its MFMAs and spills the rows)
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(wh + ks * 32), ahi[ks], acc, 0, 0, 0);
+      if ((ks & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(wh + ks * 32), alo[ks], acc, 0, 0, 0);
+      if ((ks & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(wl + ks * 32), ahi[ks], acc, 0, 0, 0);
+      if ((ks & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+    // a lane owns a ROW: its 16 accumulators are classes (r & 3) + 8 (r >> 2) + 4 q of the stage; (hi, lo) through the wave's tiles
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int cl = rg * 8 + 4 * q;
+      uint32_t hb[4], lb[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float v = acc[rg * 4 + k] + sb[cl + k];
+        if (relu == 1) v = fmaxf(v, 0.f);
+        hb[k] = rf2bf(v);
+        lb[k] = rf2bf(v - rbf2f(hb[k]));
+      }
+      *reinterpret_cast<u32x2*>(tile + lx * 80 + cl * 2) = u32x2{hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
+      *reinterpret_cast<u32x2*>(tile + 32 * 80 + lx * 80 + cl * 2) = u32x2{lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16)};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the tiles are wave-private: LDS operations of a wave complete in order
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (lane >> 2) + 16 * i;
+      const u32x4 vh = *reinterpret_cast<const u32x4*>(tile + r * 80 + (lane & 3) * 16);
+      const u32x4 vl = *reinterpret_cast<const u32x4*>(tile + 32 * 80 + r * 80 + (lane & 3) * 16);
+      if (row0 + r < M) {
+        bf16_t* op = out + (row0 + r) * (2 * (long long)N) + st * 32 + (lane & 3) * 8;
+        *reinterpret_cast<u32x4*>(op) = vh;
+        *reinterpret_cast<u32x4*>(op + N) = vl;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // reads done before the next stage overwrites the tiles
+  }
+}
+
+// hi/lo rows (see the kernel); K in {256, 512}, N % 64 == 0; PT_ERR_INVALID otherwise (the caller falls back to the 1x1 conv kernel)
+int pt_launch_gemm_rows_x3(const bf16_t* A, long long M, int K, const bf16_t* W3, const float* bias, int N, bf16_t* out, int relu, hipStream_t s,
+                           const int* tlim) {
+  if ((K != 512 && K != 256) || N % 64 != 0 || M <= 0 || (relu != 0 && relu != 1)) return PT_ERR_INVALID;
+  const int smem = 64 * (K * 2 + 16) + 128 + 4 * 2 * 32 * 80;
+  static bool attr_done = false;
+  if (!attr_done) {
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_x3_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (512 * 2 + 16) + 128 + 4 * 2 * 32 * 80));
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_x3_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (256 * 2 + 16) + 128 + 4 * 2 * 32 * 80));
+    attr_done = true;
+  }
+  const dim3 grid((unsigned)((M + 127) / 128)), blk(256);
+  if (K == 512) hipLaunchKernelGGL((gemm_rows_x3_kernel<32>), grid, blk, smem, s, A, M, W3, bias, N, out, relu, tlim);
+  else hipLaunchKernelGGL((gemm_rows_x3_kernel<16>), grid, blk, smem, s, A, M, W3, bias, N, out, relu, tlim);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }

@@ -215,6 +215,25 @@ def _x3_input(n, seed):
     return torch.stack([hi, (g - hi.float()).to(torch.bfloat16)], -1).contiguous().cuda()
 
 
+def test_x3_row_gemm_equals_the_conv_kernel(eng, sd, monkeypatch):
+    """BF16X3 row GEMMs of the sequence head (LSTM input projections, embeddings): gemm_rows_x3_kernel against the three-pass 1x1 conv kernel
+    (PT_ROWS_X3=0, read per call) -- the same MFMA sequence per output, so ids AND winning logits are bit-identical; 37 lines (1.16 row blocks
+    of the last workgroup), one of them mostly padding (ragged first projection)"""
+    eng.set_precision(L.PT_PRECISION_BF16X3)
+    try:
+        x = _x3_input(37, 9)
+        monkeypatch.delenv("PT_ROWS_X3", raising=False)
+        ids, mx = eng.rec_forward_net(x)
+        monkeypatch.setenv("PT_ROWS_X3", "0")
+        ids0, mx0 = eng.rec_forward_net(x)
+        torch.cuda.synchronize()
+        assert np.array_equal(ids.cpu().numpy(), ids0.cpu().numpy())
+        assert np.array_equal(mx.cpu().numpy(), mx0.cpu().numpy())
+        assert len(np.unique(ids.cpu().numpy())) > 20
+    finally:
+        eng.set_precision(L.PT_PRECISION_BF16)
+
+
 def test_x3_classifier_bound_and_refine_equals_the_tiled_classifier(eng, sd, monkeypatch):
     """BF16X3 classifier: the arg-max from two single-pass sweeps + exact logits of the candidates (gemm_cand_kernel / cand_eval_kernel)
     against the tiled three-pass GEMM with per-tile partials + reduce (PT_CLS_X3_REFINE=0, read per call): the same ids wherever the
