@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void lore_sigmoid_kernel(const float* __restri
 
 // keys[(b * 2 + cls) * CAP + slot] = score_bits << 32 | (0xFFFFFFFF - pixel index): descending key order is
 // (score desc, index asc)
-__global__ __launch_bounds__(256) void lore_peaks_kernel(const float* __restrict__ sig, int B, int H, int W, float thr_cell,
+template <int NTHR>
+__global__ __launch_bounds__(NTHR) void lore_peaks_kernel(const float* __restrict__ sig, int B, int H, int W, float thr_cell,
                                                           float thr_corner, unsigned long long* __restrict__ keys,
                                                           int* __restrict__ counts) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -40,7 +41,12 @@ __global__ __launch_bounds__(256) void lore_peaks_kernel(const float* __restrict
   const long long ic = live ? i : 0;
   const int x = (int)(ic % W), y = (int)((ic / W) % H), b = (int)(ic / ((long long)W * H));
   const float* sb = sig + (size_t)b * H * W * 2;
-  const bool uniform = ((long long)H * W) % 64 == 0;      // a wave never straddles two tables: one counter per wave
+  // a workgroup never straddles two tables: one counter and ONE atomic per workgroup and class (the waves' counts meet in LDS).  With one
+  // atomic per wave a 256 x 256 map sent up to 1024 of them to the same address -- serialised in L2, 0.5 ms per 87 tables
+  const bool uniform = ((long long)H * W) % NTHR == 0;
+  __shared__ int s_cnt[2][NTHR / 64];
+  __shared__ int s_base[2];
+  const int wave = threadIdx.x >> 6;
   for (int cls = 0; cls < 2; ++cls) {
     const float s = sb[((size_t)y * W + x) * 2 + cls];
     bool peak = live && (s >= (cls ? thr_corner : thr_cell));
@@ -55,15 +61,21 @@ __global__ __launch_bounds__(256) void lore_peaks_kernel(const float* __restrict
     const int list = b * 2 + cls;
     int slot = -1;
     if (uniform) {
-      // plateaus of equal scores make every pixel of them a peak: thousands of appends per list -- one atomic per
-      // wave instead of one per pixel (the order inside a list is irrelevant, it is sorted next)
+      // plateaus of equal scores make every pixel of them a peak: thousands of appends per list (the order inside a list is
+      // irrelevant, it is sorted next)
       const unsigned long long m = __ballot(peak);
-      if (m) {
-        const int leader = __ffsll((long long)m) - 1;
-        int base = 0;
-        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&counts[list], __popcll(m));
-        base = __shfl(base, leader);
-        if (peak) slot = base + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+      if ((threadIdx.x & 63) == 0) s_cnt[cls][wave] = __popcll(m);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int k = 0; k < NTHR / 64; ++k) tot += s_cnt[cls][k];
+        s_base[cls] = tot ? atomicAdd(&counts[list], tot) : 0;
+      }
+      __syncthreads();
+      if (peak) {
+        int base = s_base[cls];
+        for (int k = 0; k < wave; ++k) base += s_cnt[cls][k];
+        slot = base + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
       }
     } else if (peak) {
       slot = atomicAdd(&counts[list], 1);
@@ -456,7 +468,7 @@ static int decode_peaks(pt_engine* e, const float* hm, int B, int H, int W, int 
   hipLaunchKernelGGL(lore_sigmoid_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, hm, sig, (long long)npix);
   // with wiz_rev the snap loop runs for cells >= 0.2 (:190) and the final filter is vis_thresh (:568-571): cells below
   // vis_thresh can never reach the output, whatever the snap does
-  hipLaunchKernelGGL(lore_peaks_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, sig, B, H, W, vis_thresh,
+  hipLaunchKernelGGL(lore_peaks_kernel<1024>, dim3((unsigned)((npix + 1023) / 1024)), dim3(1024), 0, s, sig, B, H, W, vis_thresh,
                      0.3f, keys, cnt);
   hipLaunchKernelGGL(lore_sort_kernel, dim3(2 * B), dim3(1024), CAP * 8, s, keys, cnt, 1, CAP, K_CELLS, K_CORNERS, ds->sorted,
                      CAP, cnt + 2 * B);
