@@ -571,11 +571,8 @@ int pt_launch_dwconv(const bf16_t* in, const float* w, const float* b, bf16_t* o
     const char* ev = getenv("PT_DWCONV2");
     two = ev ? atoi(ev) : 1;
   }
-  static int tile = -1;          // PT_DWCONV_TILE=0: the register kernels everywhere (A/B switch)
-  if (tile < 0) {
-    const char* ev = getenv("PT_DWCONV_TILE");
-    tile = ev ? atoi(ev) : 1;
-  }
+  const char* tile_ev = getenv("PT_DWCONV_TILE");      // PT_DWCONV_TILE=0: the register kernels everywhere (A/B switch, read per call)
+  const bool tile = !(tile_ev && tile_ev[0] == '0');
   if (tile && !split && sy == 1 && sx == 1 && C % 32 == 0) {      // stride 1, pad k / 2: Ho == H, Wo == W
     const int cb = C % 64 == 0 ? 64 : 32, tw = cb == 64 ? 16 : 32;
     const int tiles_x = (Wo + tw - 1) / tw, tiles_y = (Ho + 7) / 8;

@@ -51,6 +51,32 @@ def _ref_logits(sd, x):
     return [torch.cat([torch.logit(s.double()).float(), b], 2) for s, b in zip(sc, bx)], sc, bx
 
 
+@pytest.mark.parametrize("case", [(2, 37, 45, 64, 5, 2), (1, 8, 16, 128, 3, 1), (3, 19, 70, 32, 3, 2), (2, 25, 19, 256, 5, 2), (1, 13, 10, 96, 5, 0),
+                                  (2, 50, 38, 512, 5, 2), (1, 1, 1, 64, 5, 2)])
+def test_dwconv_tile_kernel_equals_register_kernel(eng, case, monkeypatch):
+    """dwconv_tile_kernel (stride-1 depthwise convs: the input tile + halo of 32 / 64 channels staged in LDS, four workgroups per CU) against the register
+    kernels (PT_DWCONV_TILE=0, read per call): every tap in the same (ky, kx) order per output, so every bit is the same; maps smaller than a tile, widths
+    that are not multiples of the 16- / 32-column tile, 96 channels (three 32-channel blocks), a single pixel; and both against torch fp32."""
+    import torch.nn.functional as F
+    B, H, W, C, k, act = case
+    g = torch.Generator().manual_seed(H * 131 + C)
+    x = torch.randn(B, H, W, C, generator=g).to(torch.bfloat16)
+    w = torch.randn(k * k, C, generator=g) * 0.2
+    b = torch.randn(C, generator=g) * 0.1
+    outs = []
+    for sw in ("1", "0"):
+        monkeypatch.setenv("PT_DWCONV_TILE", sw)
+        y = eng.op_dwconv(x.cuda(), w.cuda(), b.cuda(), k, 1, act)
+        torch.cuda.synchronize()
+        outs.append(y.view(torch.int16).cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.t().reshape(C, 1, k, k), b, 1, k // 2, groups=C)
+    ref = F.hardswish(ref) if act == 2 else (F.relu(ref) if act == 1 else ref)
+    got = torch.from_numpy(outs[0]).view(torch.bfloat16).float().permute(0, 3, 1, 2)
+    err = (got - ref).abs()
+    assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-3).all()), float(err.max())
+
+
 @pytest.mark.parametrize("shape", [(1, 160, 128), (2, 224, 192), (1, 320, 256)])
 def test_layout_net_x3_matches_oracle(eng, pico_sd, shape):
     n, H, W = shape
