@@ -1220,7 +1220,10 @@ def main(argv=None):
                     "algorithmic_flop_per_launch": c3["flop"] / max(1, c3["launches"]),
                     "flop_accounting": "2 x output pixels x REAL output channels x Cin x 9 per launch (padded GEMM columns are not "
                                        "counted); row-limited sparse-head launches are credited the rows below the device limit "
-                                       "they read back, and 1/9 of those (a 3x3 patch yields one used pixel)",
+                                       "they read back, and 1/9 of those (a 3x3 patch yields one used pixel); ragged CRNN launches are "
+                                       "credited the 32-column row-tiles they multiply (from the round-4 binary on the padding half of a line's "
+                                       "last 64-column conv3.* patch is neither multiplied nor credited: -3.9 of 31 TFLOP per step for -1.3 ms, "
+                                       "i.e. frac reads 0.30 where the whole-patch credit of the earlier rounds would read 0.34 on the same run)",
                     "events": "3x3 class only" if prof_mode == 2 else "every launch"}
             if prof_mode == 1:       # PT_BENCH_PROF=1: events around every launch
                 roof["all_kernel_classes_ms"] = {k: v["ms"] for k, v in prof.items()}

@@ -654,6 +654,11 @@ __global__ __launch_bounds__(256, KS == 1 ? 4 : 2) void conv_igemm_kernel(ConvK 
   const int b_sw = (lx >> 2) & 3;      // SWZ: weight row tap * 64 (+ 32) + lx -> ((row >> 2) & 3) == ((lx >> 2) & 3) for every tap
 
   const unsigned tmask = (KS == 3 && STRIDE == 1 && nt < 8 && p.tap_mask[nt]) ? p.tap_mask[nt] : 0x1FFu;
+  // ragged lines on the 4 x 64 patch: a wave's 32-column row-tile that starts at or behind the line's limit is not multiplied (the caller fills
+  // from the limit rounded up to 32 columns, not 64: lines are ~1/4 text, and the last tile of a line was half padding on average)
+  bool dead[C::MT];
+#pragma unroll
+  for (int m = 0; m < C::MT; ++m) dead[m] = GEOM == 1 && p.xlimit && ox0 + ((wave * C::MT + m) % C::CT) * 32 >= p.xlimit[b];
   prefetch(0);
   for (int c = 0; c < nchunks; ++c) {
     __syncthreads();  // everyone is done reading the previous slice
@@ -685,6 +690,7 @@ __global__ __launch_bounds__(256, KS == 1 ? 4 : 2) void conv_igemm_kernel(ConvK 
 #endif
 #pragma unroll
           for (int m = 0; m < C::MT; ++m) {
+            if (GEOM == 1 && dead[m]) continue;      // wave-uniform
             // stride 2: tap s reads input column 2*lx + s = slot lx (s = 0), XEVEN + lx (s = 1), lx + 1 (s = 2)
             const int soff = C::SS == 2 ? ((s & 1) * C::XEVEN + (s >> 1)) : s;
             const int a_off = C::SWZ ? (((q + 2 * kk) ^ (((a_slot[m] + r * C::TWIN + soff) >> 2) & 3)) * 16) : kk * 32;

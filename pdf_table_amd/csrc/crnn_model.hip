@@ -197,7 +197,7 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
       RUN(pt_launch_maxpool_kxk(c2b_o, nn, 8, 160, 256, 2, 1, 0, x3, p2, s));
     }
     RUN(pt_launch_conv(e, limited(conv(p2, nn, 4, 160, 256, c3a, 512, 3, c3a_o, 1), 3), s));
-    RUN(fill(c3a_o, ZeroLine::C3A, 3, 64, 1, 4, 160, 512, 4, 64));
+    RUN(fill(c3a_o, ZeroLine::C3A, 3, 32, 1, 4, 160, 512, 4, 64));      // (conv3.* multiply 32-column row-tiles up to the limit inside their 64-column patches)
     if (pool_fused) {
       ConvDesc c3d = limited(conv(c3a_o, nn, 4, 160, 512, c3b, 512, 3, p3, 1), 4);
       c3d.pool = 3;          // (2,1) pool, rows -> channel groups: [n][160][2 * 512]

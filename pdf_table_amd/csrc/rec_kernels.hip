@@ -255,7 +255,7 @@ __global__ void crnn_limits_kernel(const pt_rec_line* __restrict__ lines, int n,
     l1[b] = v[0]; l2a[b] = v[1]; l2b[b] = v[2]; l3a[b] = v[3]; l3b[b] = v[4];
     // conv0 (computed in 64-column pooled tiles) must deliver the columns the limited conv1 reads: its tiles [0, R1) + the halo
     l0[b] = min((v[0] + 31) / 32 * 32 + 1, 320);
-    const int tw[5] = {32, 32, 32, 64, 64}, wo[5] = {320, 160, 160, 160, 160};
+    const int tw[5] = {32, 32, 32, 32, 32}, wo[5] = {320, 160, 160, 160, 160};      // (conv3.*: 64-column patches, 32-column row-tiles)
 #pragma unroll
     for (int k = 0; k < 5; ++k) acc[k] += min(wo[k], (v[k] + tw[k] - 1) / tw[k] * tw[k]);
     acc[5] += min(160, (v[4] + 31) / 32 * 32);     // the sequence GEMMs (conv4, first LSTM projection): 32-step tiles
