@@ -231,6 +231,9 @@ struct ConvDesc {
   // the same for a [1, lines, T, C] view (1x1 GEMMs over the sequence): device int [H], limit of ROW oy; a tile of several
   // rows is skipped when it lies right of all its rows' limits (rows with a smaller limit get values the caller overwrites)
   const int* xlimit_rows = nullptr;
+  // with xlimit, maps <= 4 rows high (the 4 x 64 patch): the compacted list of live 32-column blocks (rows_live_list_kernel over the same limits:
+  // [0] = count, [1 + i] = image * (Wo / 32) + block); a workgroup multiplies two of them -- possibly of two images -- instead of one image's 64 columns
+  const int* block_list = nullptr;
   // bf16x3 precision mode: in/res/out hold (hi | lo) channel groups; w is [N/64][3*Cin/32][taps][64][32]
   int split = 0;
   // split = 2 (PT_PRECISION_F16X2): same (hi | lo) tensors, but w holds fp16 tiles [N/64][2*Cin/32][taps][64][32] (blob suffix .wh: the
@@ -317,7 +320,8 @@ int pt_launch_rec_pp_resize_norm(const uint8_t* crops, const pt_rec_line* lines,
 struct PtCrnnLimits {
   int* lim[6];        // device int [n] each: conv1, conv2a, conv2b, conv3a, conv3b output-column limits; [5]: conv0 (pooled columns)
   int* cols;          // device int [8]: sum over lines of the tile-rounded limits ([5]: the sequence GEMMs, 32-step tiles)
-  int* glist;         // device int [1 + 5 n]: the live 32-step row groups of the sequence GEMMs, compacted (rows_live_list_kernel)
+  int* glist;         // device int [1 + 5 n]: the live 32-step row groups of the sequence GEMMs, compacted (rows_live_list_kernel; = conv3b's block list)
+  int* blist3a;       // device int [1 + 5 n]: the live 32-column blocks of conv3a (limit lim[3])
 };
 int pt_launch_rows_live_list(const int* lim, int n, int* glist, hipStream_t s);
 int pt_launch_crnn_limits(const pt_rec_line* lines, int n, const PtCrnnLimits& L, hipStream_t s);

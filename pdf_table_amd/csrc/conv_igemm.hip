@@ -73,6 +73,7 @@ struct ConvK {
   int segc0, segc1, segc2, segc3, nseg;
   unsigned tap_mask[8];   // ConvDesc.tap_mask (0 = every tap)
   int xp_store;           // register epilogue: rows leave through a wave-private LDS tile as whole 128-byte lines (PT_CONV_XP)
+  const int* blist;       // 4 x 64 patch only (ConvDesc.block_list): blist[0] live 32-column blocks, blist[1 + i] = image * (Wo / 32) + block; a workgroup takes two
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
@@ -150,9 +151,11 @@ __device__ __forceinline__ void tile_order(int L, int n_tiles, int n_group, int&
 }
 
 // Shared epilogue: fp32 tile [TH*32 pixels][64 ch] in LDS -> bias/residual/ReLU -> bf16 stores.
+// b_second >= 0 (TW == 64, the 4 x 64 patch of conv_igemm_kernel<3, 1, 1>): the patch's columns 32 .. 63 are a 32-column block of image b_second at ox_second
+// (another text line's, from the compacted block list; ox_second = Wo: no second block)
 template <int TH, int TW, int NTHR = 256, bool EXTRAS = true>
-__device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stage, int tid, int b, int oy0, int ox0,
-                                               int n0) {
+__device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stage, int tid, int b_first, int oy0, int ox0,
+                                               int n0, int b_second = -1, int ox_second = 0) {
   // fused-head weights of this thread's 8 channels (idx & 7 == tid & 7 for every j)
   float hw[4][8];
   if (EXTRAS && p.head_w) {
@@ -181,7 +184,9 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
     for (int idx = tid; idx < (TH / 2) * PTW * 8; idx += NTHR) {
       const int ppix = idx >> 3, cg = idx & 7;
       const int py = ppix / PTW, px = ppix - py * PTW;
-      const int oy = (oy0 >> 1) + py, ox = ox0 / pw + px;
+      const bool second = b_second >= 0 && px >= 32 / pw;
+      const int b = second ? b_second : b_first;
+      const int oy = (oy0 >> 1) + py, ox = second ? ox_second / pw + px - 32 / pw : ox0 / pw + px;
       if (oy >= PHo || ox >= PWo) continue;
       const int n = n0 + cg * 8;
       const f32x4* bp = reinterpret_cast<const f32x4*>(p.bias + n);
@@ -231,7 +236,9 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
   for (int j = 0; j < TH * TW * 8 / NTHR; ++j) {
     const int pix = (tid + j * NTHR) >> 3;
     const int ty = pix / TW, tx = pix % TW;
-    const int oy = oy0 + ty, ox = ox0 + tx;
+    const bool second = b_second >= 0 && tx >= 32;
+    const int b = second ? b_second : b_first;
+    const int oy = oy0 + ty, ox = second ? ox_second + tx - 32 : ox0 + tx;
     if (oy >= p.Ho || ox >= p.Wo) continue;
     const f32x4* sp = reinterpret_cast<const f32x4*>(stage + pix * 64 + cg * 8);
     f32x4 v0 = sp[0], v1 = sp[1];
@@ -491,7 +498,8 @@ struct ConvCfg {
   static constexpr int SS = KS == 1 ? 1 : STRIDE;      // pixel stride of an A fragment inside the LDS patch
   static constexpr int GS = KS == 1 ? STRIDE : 1;      // stride of the patch's pixels in the input map
   static constexpr int THIN = (TH - 1) * SS + KS;
-  static constexpr int TWIN = (TW - 1) * SS + KS;
+  // GEOM 1: the patch is TWO 32-column blocks with their own halo columns (34 + 34), so that the blocks may come from different text lines
+  static constexpr int TWIN = GEOM == 1 ? 68 : (TW - 1) * SS + KS;
   static constexpr int TAPS = KS * KS;
   static constexpr int XEVEN = (TWIN + 1) / 2;   // stride 2: number of even input columns of a patch row (stored first)
   // bytes per staged pixel / weight row: 32 bf16 + 16 B pad.  The stride-2 3x3 patch (9 x 65 pixels) plus its weight slice
@@ -533,7 +541,9 @@ __global__ __launch_bounds__(256, KS == 1 ? 4 : 2) void conv_igemm_kernel(ConvK 
   for (int rep = 0; rep < reps; ++rep) {
   int L, nt;
   if (reps == 1) {
-    L = xcd_remap(blockIdx.x, gridDim.x);
+    // (block list: the live pairs are the FRONT of the walk -- the XCD remap would hand all of them to the first XCDs; in launch order every
+    // output-channel tile of a pair lands on another XCD instead)
+    L = (GEOM == 1 && p.blist) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     tile_order(L, p.n_tiles, p.n_group, nt, L);
   } else {
     L = blockIdx.x * reps + rep;
@@ -546,9 +556,28 @@ __global__ __launch_bounds__(256, KS == 1 ? 4 : 2) void conv_igemm_kernel(ConvK 
   L /= p.tiles_x;
   const int tyi = L % p.tiles_y;
   const int b = L / p.tiles_y;
-  const int oy0 = tyi * C::TH, ox0 = txi * C::TW;
+  const int oy0 = tyi * C::TH;
+  int ox0 = txi * C::TW;
+  // GEOM 1: the patch's two 32-column blocks, (image, first output column); column Wo = no block.  From the compacted list of live blocks
+  // (ragged text lines: a workgroup always has two full blocks to multiply, possibly of two lines), or the two halves of a 64-column tile
+  int blk_b[2] = {b, b}, blk_x[2] = {ox0, ox0 + 32};
+  if (GEOM == 1) {
+    if (p.blist) {
+      const int cnt = p.blist[0], bpl = p.Wo >> 5;
+      if (2 * txi >= cnt) continue;
+      const int e0 = p.blist[1 + 2 * txi], e1 = 2 * txi + 1 < cnt ? p.blist[2 + 2 * txi] : -1;
+      blk_b[0] = e0 / bpl; blk_x[0] = (e0 - blk_b[0] * bpl) * 32;
+      blk_b[1] = e1 >= 0 ? e1 / bpl : blk_b[0];
+      blk_x[1] = e1 >= 0 ? (e1 - blk_b[1] * bpl) * 32 : p.Wo;
+      ox0 = blk_x[0];
+    } else {
+      if (p.xlimit && ox0 >= p.xlimit[b]) continue;
+      if (blk_x[1] >= p.Wo || (p.xlimit && blk_x[1] >= p.xlimit[b])) blk_x[1] = p.Wo;      // the second half is beyond the map or all padding response
+    }
+  }
+  const int bq = GEOM == 1 ? blk_b[0] : b;         // image of the (first block of the) tile
   if (p.ylimit && oy0 >= *p.ylimit) break;         // uniform over the workgroup; later tiles of the walk are further down
-  if (p.xlimit && ox0 >= p.xlimit[b]) continue;    // ragged image: this tile is all padding response, filled by the caller
+  if (GEOM != 1 && p.xlimit && ox0 >= p.xlimit[b]) continue;    // ragged image: this tile is all padding response, filled by the caller
   if (p.xlimit_rows) {
     int mx = 0;
 #pragma unroll
@@ -559,7 +588,8 @@ __global__ __launch_bounds__(256, KS == 1 ? 4 : 2) void conv_igemm_kernel(ConvK 
   const int iy0 = oy0 * STRIDE - (KS / 2), ix0 = ox0 * STRIDE - (KS / 2);
   const int nchunks = p.split ? (F16 ? 2 : 3) * (p.Cin >> 5) : (p.Cin >> 5);
   const int in_cs = p.split ? 2 * p.Cin : p.Cin;   // channels per input pixel in memory
-  const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * in_cs;
+  const bf16_t* in_b = p.in + (size_t)bq * p.H * p.W * in_cs;
+  const bf16_t* in_b1 = p.in + (size_t)blk_b[1] * p.H * p.W * in_cs;      // GEOM 1: the second block's image
   const bf16_t* wt = p.w + (size_t)nt * nchunks * (C::TAPS * 64 * 32);
 
   u32x4 rin[C::NI];
@@ -598,9 +628,16 @@ __global__ __launch_bounds__(256, KS == 1 ? 4 : 2) void conv_igemm_kernel(ConvK 
       if (idx < C::NP_IN) {
         const int pix = idx >> 2, part = idx & 3;
         const int iy = pix / C::TWIN, ix = pix - iy * C::TWIN;
-        const int gy = iy0 + iy * C::GS, gx = ix0 + ix * C::GS;
+        int gy = iy0 + iy * C::GS, gx = ix0 + ix * C::GS;
+        const bf16_t* sp_ = src;
+        if (GEOM == 1) {       // sub-patch ix / 34 with its own halo: columns blk_x[j] - 1 .. blk_x[j] + 32 of image blk_b[j]
+          const int j = ix >= 34;
+          gx = blk_x[j] - 1 + ix - 34 * j;
+          if (blk_x[j] >= p.Wo) gx = -1;
+          if (j) sp_ = in_b1;
+        }
         if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-          v = *reinterpret_cast<const u32x4*>(src + ((size_t)gy * p.W + gx) * src_cs + c0 + part * 8);
+          v = *reinterpret_cast<const u32x4*>(sp_ + ((size_t)gy * p.W + gx) * src_cs + c0 + part * 8);
       }
       rin[j] = v;
     }
@@ -647,7 +684,7 @@ __global__ __launch_bounds__(256, KS == 1 ? 4 : 2) void conv_igemm_kernel(ConvK 
 #pragma unroll
   for (int m = 0; m < C::MT; ++m) {
     const int t = wave * C::MT + m;
-    a_slot[m] = ((t / C::CT) * C::SS) * C::TWIN + ((t % C::CT) * 32 + lx);      // SS = 2: even columns are stored first, consecutively
+    a_slot[m] = ((t / C::CT) * C::SS) * C::TWIN + ((t % C::CT) * (GEOM == 1 ? 34 : 32) + lx);      // SS = 2: even columns are stored first, consecutively
     a_base[m] = s_in + a_slot[m] * C::PIXB + (C::SWZ ? 0 : q * 16);
   }
   const char* b_base = s_w + lx * C::PIXB + (C::SWZ ? 0 : q * 16);
@@ -658,7 +695,7 @@ __global__ __launch_bounds__(256, KS == 1 ? 4 : 2) void conv_igemm_kernel(ConvK 
   // from the limit rounded up to 32 columns, not 64: lines are ~1/4 text, and the last tile of a line was half padding on average)
   bool dead[C::MT];
 #pragma unroll
-  for (int m = 0; m < C::MT; ++m) dead[m] = GEOM == 1 && p.xlimit && ox0 + ((wave * C::MT + m) % C::CT) * 32 >= p.xlimit[b];
+  for (int m = 0; m < C::MT; ++m) dead[m] = GEOM == 1 && blk_x[(wave * C::MT + m) % C::CT] >= p.Wo;
   prefetch(0);
   for (int c = 0; c < nchunks; ++c) {
     __syncthreads();  // everyone is done reading the previous slice
@@ -742,7 +779,8 @@ __global__ __launch_bounds__(256, KS == 1 ? 4 : 2) void conv_igemm_kernel(ConvK 
       }
   }
   __syncthreads();
-  epilogue_store<C::TH, C::TW>(p, stage, tid, b, oy0, ox0, nt * 64);
+  if (GEOM == 1) epilogue_store<C::TH, C::TW>(p, stage, tid, bq, oy0, ox0, nt * 64, blk_b[1], blk_x[1]);
+  else epilogue_store<C::TH, C::TW>(p, stage, tid, b, oy0, ox0, nt * 64);
   }   // rep
 }
 
@@ -1850,6 +1888,11 @@ static int launch_cfg(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   k.tiles_y = (k.Ho + C::TH - 1) / C::TH;
   k.n_tiles = k.N / 64;
   long long nblk = (long long)k.B * k.tiles_x * k.tiles_y * k.n_tiles;
+  if (GEOM == 1 && k.blist) {      // pairs of live 32-column blocks: the worst case is every block of every image
+    k.tiles_x = (int)(((long long)k.B * (k.Wo / 32) + 1) / 2);
+    k.tiles_y = 1;
+    nblk = (long long)k.tiles_x * k.n_tiles;
+  }
   PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range (%lld blocks)", nblk);
   if (k.ylimit) {      // mostly empty worst-case extents: 16 tiles per workgroup
     k.reps = 16;
@@ -2017,6 +2060,10 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   k.out_cstride = d.out_cstride; k.out_coff = d.out_coff; k.rep = d.rep; k.shuffle_cout = d.shuffle_cout;
   k.res_mode = d.res ? d.res_mode : 0; k.relu = d.relu; k.slope = d.slope; k.ylimit = d.ylimit; k.pool = d.pool;
   k.xlimit = d.xlimit; k.xlimit_rows = d.xlimit_rows; k.xcols = (d.xlimit || d.xlimit_rows) ? d.xlimit_cols : nullptr;
+  {
+    const char* bl = getenv("PT_CONV_BLOCK_LIST");      // PT_CONV_BLOCK_LIST=0: one image's 64 columns per workgroup (A/B switch, read per call)
+    k.blist = (d.xlimit && d.block_list && d.ks == 3 && d.stride == 1 && k.Ho <= 4 && k.Wo > 32 && k.Wo % 32 == 0 && !(bl && bl[0] == '0')) ? d.block_list : nullptr;
+  }
   PT_REQUIRE(!d.xlimit_rows || (d.ks == 1 && d.stride == 1 && !d.ylimit && !d.xlimit), "conv: row-wise column limits need a 1x1 stride-1 layer");
   PT_REQUIRE(!d.xlimit || (d.ks == 3 && d.stride == 1 && !d.ylimit), "conv: column limits need a 3x3 stride-1 layer");
   PT_REQUIRE(!d.pool || (d.ks == 3 && d.stride == 1 && !d.res && !d.shuffle_cout && d.rep == 1 && !d.out_f32 && !d.argmax_part && !d.head_w && !d.n_valid && d.relu <= 1 && k.Ho % 2 == 0 && (d.pool != 1 || k.Wo % 2 == 0)),

@@ -161,7 +161,11 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
                         bf16_t* c3a_o, bf16_t* c3b_o, bf16_t* p3, bf16_t* f_o, bf16_t* gx_o, const PtCrnnLimits* lim,
                         const bf16_t* zl) -> int {
     auto limited = [&](ConvDesc c, int k) {
-      if (lim) { c.xlimit = lim->lim[k]; c.xlimit_cols = lim->cols + k; }
+      if (lim) {
+        c.xlimit = lim->lim[k]; c.xlimit_cols = lim->cols + k;
+        if (k == 3) c.block_list = lim->blist3a;      // conv3.* (4-row maps): pairs of live 32-column blocks per workgroup
+        if (k == 4) c.block_list = lim->glist;
+      }
       return c;
     };
     // fill the columns layer k left, up to the last column the NEXT limited layer (limit kn, tile tn) reads; kn < 0: to the end
@@ -257,7 +261,7 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
       PT_HIP_CHECK(hipStreamWaitEvent(s, e->rec_zero_ready[x3], 0));       // a no-op once the build has completed
     }
     zl = reinterpret_cast<const bf16_t*>(e->rec_zero[x3]);
-    const size_t need = ((size_t)11 * n + 16) * sizeof(int);
+    const size_t need = ((size_t)16 * n + 24) * sizeof(int);
     if (need > e->rec_limits_cap) {
       PT_HIP_CHECK(hipStreamSynchronize(s));
       if (e->rec_limits) PT_HIP_CHECK(hipFree(e->rec_limits));
@@ -269,10 +273,12 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
     for (int k = 0; k < 6; ++k) lim.lim[k] = base + (size_t)k * n;
     lim.cols = base + (size_t)6 * n;
     lim.glist = base + (size_t)6 * n + 8;
+    lim.blist3a = base + (size_t)11 * n + 16;
     {
       PtProfScope ps(e, s, PT_PROF_OTHER, 0, "crnn limits");
       RUN(pt_launch_crnn_limits(d_lines, n, lim, s));
       RUN(pt_launch_rows_live_list(lim.lim[4], n, lim.glist, s));
+      RUN(pt_launch_rows_live_list(lim.lim[3], n, lim.blist3a, s));
     }
   }
   RUN(conv_stack(gray, n, bf.a0, bf.a1, bf.p1, bf.c2a, bf.c2b, bf.p2, bf.c3a, bf.c3b, bf.p3, bf.f, bf.gx, ragged ? &lim : nullptr, zl));
