@@ -1222,8 +1222,8 @@ def main(argv=None):
                                        "counted); row-limited sparse-head launches are credited the rows below the device limit "
                                        "they read back, and 1/9 of those (a 3x3 patch yields one used pixel); ragged CRNN launches are "
                                        "credited the 32-column row-tiles they multiply (from the round-4 binary on the padding half of a line's "
-                                       "last 64-column conv3.* patch is neither multiplied nor credited: -3.9 of 31 TFLOP per step for -1.3 ms, "
-                                       "i.e. frac reads 0.30 where the whole-patch credit of the earlier rounds would read 0.34 on the same run)",
+                                       "last 64-column conv3.* patch is neither multiplied nor credited: -3.9 of 31 TFLOP per step for -3.0 ms, "
+                                       "i.e. frac reads 0.31 where the whole-patch credit of the earlier rounds would read 0.35 on the same run)",
                     "events": "3x3 class only" if prof_mode == 2 else "every launch"}
             if prof_mode == 1:       # PT_BENCH_PROF=1: events around every launch
                 roof["all_kernel_classes_ms"] = {k: v["ms"] for k, v in prof.items()}
