@@ -645,7 +645,9 @@ __global__ __launch_bounds__(256, KS == 1 ? 4 : 2) void conv_igemm_kernel(ConvK 
 #pragma unroll
     for (int j = 0; j < C::NWP; ++j) {
       const int idx = tid + j * 256;
-      rw[j] = *reinterpret_cast<const u32x4*>(wc + idx * 8);
+      // NHALF = 1: the MFMAs read weight rows 0 .. 31 of every tap only -- rows 32 .. 63 (the second half of each 256-piece tap: threads 128 .. 255) are
+      // the zero padding of a <= 32-output layer and are neither fetched nor written to LDS
+      if (NHALF == 2 || tid < 128) rw[j] = *reinterpret_cast<const u32x4*>(wc + idx * 8);
     }
   };
   auto commit = [&](int chunk) {
@@ -666,7 +668,8 @@ __global__ __launch_bounds__(256, KS == 1 ? 4 : 2) void conv_igemm_kernel(ConvK 
 #pragma unroll
     for (int j = 0; j < C::NWP; ++j) {
       const int idx = tid + j * 256;
-      *reinterpret_cast<u32x4*>(s_w + (idx >> 2) * C::PIXB + ((C::SWZ ? ((idx & 3) ^ ((idx >> 4) & 3)) : (idx & 3)) * 16)) = rw[j];
+      if (NHALF == 2 || tid < 128)
+        *reinterpret_cast<u32x4*>(s_w + (idx >> 2) * C::PIXB + ((C::SWZ ? ((idx & 3) ^ ((idx >> 4) & 3)) : (idx & 3)) * 16)) = rw[j];
     }
   };
 
