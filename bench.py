@@ -1137,6 +1137,8 @@ def main(argv=None):
     # PT_BENCH_FORCE_DIST=1: initialise RCCL and take the broadcast / barrier / all-reduce path even with one rank
     # (exercises the N > 1 code on a single-GPU box; launch with torchrun --nproc-per-node 1 or set MASTER_PORT)
     use_dist = world > 1 or os.environ.get("PT_BENCH_FORCE_DIST") == "1"
+    saved_stdout = None
+    rccl_init_s = None
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -1147,7 +1149,16 @@ def main(argv=None):
             if torch.cuda.device_count() <= local_rank:
                 raise SystemExit(f"rank {rank}: no GPU {local_rank} (visible: {torch.cuda.device_count()})")
             torch.cuda.set_device(local_rank)
+            # librccl prints its version banner ("RCCL version : ...", five lines) on STDOUT when the first communicator is created (measured:
+            # profiles/r05/force_dist_1gpu.txt).  The contract is ONE JSON line on stdout, so file descriptor 1 points at stderr until rank 0 prints it
+            sys.stdout.flush()
+            saved_stdout = os.dup(1)
+            os.dup2(2, 1)
+            t_init = time.perf_counter()
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.barrier()          # the communicator is created lazily: by the first collective
+            torch.cuda.synchronize()
+            rccl_init_s = time.perf_counter() - t_init
 
     runner = StubRunner(args, rank, world) if stub else HipRunner(args, rank, local_rank, world, dist)
 
@@ -1306,7 +1317,13 @@ def main(argv=None):
             except Exception:      # noqa: BLE001
                 pass
             out["one_eighth_host"] = one_eighth_host_leg(args, out["value"])
+        if rccl_init_s is not None:
+            out["config"]["rccl_init_s"] = round(rccl_init_s, 3)
+        sys.stdout.flush()
+        if saved_stdout is not None:
+            os.dup2(saved_stdout, 1)
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 

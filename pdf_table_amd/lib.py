@@ -38,6 +38,7 @@ PT_DET_POST_DB_TORCH = 1
 PT_TSR_MAX_CELLS = 3000
 PT_REC_H, PT_REC_W, PT_REC_T, PT_REC_NCLS = 32, 640, 160, 7644
 PT_PROF_CLASSES = ("conv3x3", "conv1x1", "stem", "other")
+EXPECTED_ABI = 13         # pt_abi_version() of the library these prototypes were written against (include/pdftable_hip.h)
 
 _lib = None
 
@@ -147,6 +148,12 @@ def load():
                           "There is no CPU fallback.")
         lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
         EXPORTS = _proto(lib)
+        # ABI 12 / 13 inserted arguments into existing pt_op_* signatures: a stale library resolves every name and would take the stream pointer
+        # for `split` -- refuse it by version instead of faulting later
+        have = int(lib.pt_abi_version())
+        if have != EXPECTED_ABI:
+            raise PtError(f"{LIB_PATH} reports ABI {have}, this binding was written for ABI {EXPECTED_ABI}: rebuild it "
+                          "(`python -m pdf_table_amd.build --force`)")
         _lib = lib
     return _lib
 

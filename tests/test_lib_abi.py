@@ -45,7 +45,7 @@ def test_plan_and_error_reporting(built):
     assert (nh.value, nw.value) == (736, 736)
     assert lib.pt_det_plan(100, 100, 77, ctypes.byref(nh), ctypes.byref(nw)) != 0
     assert b"flavour" in lib.pt_last_error()
-    assert lib.pt_abi_version() == 13
+    assert lib.pt_abi_version() == L.EXPECTED_ABI
 
 
 def test_no_gpu_means_loud_failure(built):
