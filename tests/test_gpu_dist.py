@@ -27,7 +27,10 @@ def _run(code, env_extra=None, timeout=900):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-c", code], cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout)
-    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    if r.returncode != 0:
+        print(r.stdout[-3000:])
+        print(r.stderr[-6000:])
+    assert r.returncode == 0, "child process failed (its output is printed above)"
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert lines, r.stdout[-2000:]
     return json.loads(lines[-1])
@@ -41,7 +44,7 @@ import torch.distributed as dist
 from pdf_table_amd import lib as L
 from pdf_table_amd.dist_utils import broadcast_blob
 from pdf_table_amd.engine import HipEngine
-from pdf_table_amd.rec_stage import RecStage
+from pdf_table_amd.rec_stage import build_lines
 from pdf_table_amd.synth_pages import make_page
 from pdf_table_amd.synth_weights import crnn_state_dict, db_resnet18_state_dict
 from pdf_table_amd.weights import pack_crnn, pack_db_resnet18
@@ -77,8 +80,9 @@ quads = []
 for m in made:
     l = m[1]["lines"].astype(np.float64)
     quads.append(np.stack([l[:, 0], l[:, 1], l[:, 2], l[:, 1], l[:, 2], l[:, 3], l[:, 0], l[:, 3]], 1))
-ra = RecStage(a).forward_ids(pages, quads)
-rb = RecStage(b).forward_ids(pages, quads)
+lines = build_lines(quads)
+ra = a.rec_forward(pages, lines, want_maxlogit=True)
+rb = b.rec_forward(pages, lines, want_maxlogit=True)
 torch.cuda.synchronize()
 a.check(); b.check()
 ia, ib = ra[0].cpu().numpy(), rb[0].cpu().numpy()
