@@ -88,10 +88,17 @@ int pt_engine_set_dcn_mfma(pt_engine* e, int on);
  * PT_PRECISION_F16X2: the same (hi, lo) bf16 activation pairs -- same tensors across this ABI -- but the convolutions and GEMMs of
  * the DB / CRNN / Lore / PicoDet graphs multiply them with SINGLE fp16 weights in two fp16 MFMA passes (hi*w + lo*w; a bf16 value
  * converts to fp16 exactly): rounding the WEIGHTS to 11 bits moves the logits by ~1.5e-4 of their scale (tools/x2_emulation.py) --
- * inside the 1e-3 tolerance at 2/3 of BF16X3's matrix work; layers without the variant run as in BF16X3. */
+ * inside the 1e-3 tolerance at 2/3 of BF16X3's matrix work; layers without the variant run as in BF16X3.
+ * PT_PRECISION_F16 (ABI 14): single-pass IEEE half -- the reference's own GPU arithmetic (base_infer_task.py:56-57 precision="fp16",
+ * utils/deploy_utils.py:227-240 model.half()): every 16-bit tensor crossing this ABI (activations, the weight tiles of the blob) holds fp16
+ * bits instead of bf16 bits, products accumulate in fp32, stores round to nearest even and SATURATE at +-65504 (never Inf).  Same
+ * kernels, bytes and MFMA rate as PT_PRECISION_BF16 with 11 significant bits instead of 8.  The weight blobs must have been packed for
+ * it (weights.py fmt="f16"); a bf16 blob under this precision (or the reverse) is refused by every forward call.  The ONNX operator
+ * entry points (pt_op_*) follow the engine's precision the same way. */
 #define PT_PRECISION_BF16 0
 #define PT_PRECISION_BF16X3 1
 #define PT_PRECISION_F16X2 2
+#define PT_PRECISION_F16 3
 int pt_engine_set_precision(pt_engine* e, int precision);
 
 /* Model kinds for pt_weights_load.  A blob is the "PTW1" container written by

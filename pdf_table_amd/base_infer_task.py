@@ -13,7 +13,8 @@ Differences, all deliberate:
     model path (base_infer_task.py:81-83); ``synthetic_seed=<int>`` loads the seeded random-init checkpoint
     with the reference's state_dict layout; otherwise ``get_model_name_or_path()`` returns the hub id the
     reference would download and construction stops with a clear error.
-  * default ``precision`` is ``"bf16"`` (the reference's is ``"fp16"``, base_infer_task.py:56).
+  * default ``precision`` is ``"bf16"`` (the reference's is ``"fp16"``, base_infer_task.py:56); ``precision="fp16"`` selects the engine's
+    single-pass IEEE-half mode (PT_PRECISION_F16), ``"fp32"`` the three-pass pair mode (PT_PRECISION_BF16X3).
 """
 from __future__ import annotations
 
@@ -48,6 +49,12 @@ class BaseInferTask(metaclass=ABCMeta):
         # arithmetic of a generic ONNX graph (pdf_table_amd/onnx_exec.py): "fp32" / "bf16x3" select the executor's tolerance mode ((hi | lo) activations,
         # outputs within 1e-3 of an fp32 execution); everything else, the reference's default "fp16" included, the bf16 throughput mode
         self._exec_precision = "bf16x3" if str(self._infer_precision).lower() in ("fp32", "bf16x3", "float32") else "bf16"
+        # arithmetic of the in-tree networks on an engine this task creates itself (_new_engine): the reference's "fp16" (its default,
+        # base_infer_task.py:56-57 -> model.half(), utils/deploy_utils.py:227-240) is the engine's single-pass IEEE-half mode, "fp32" the
+        # three-pass pair mode that holds 1e-3 against an fp32 run, anything else bf16.  A shared engine keeps the precision its owner set.
+        _p = str(self._infer_precision).lower()
+        self._engine_precision = "f16" if _p in ("fp16", "f16", "half", "float16") else "bf16x3" if _p in ("fp32", "bf16x3", "float32") else "bf16"
+        self._exec_precision = self._engine_precision       # the generic ONNX executor computes in the engine's arithmetic
         self._predictor_type = kwargs.get("predictor_type", "hip")
         self._home_path = kwargs.get("home_path", os.path.expanduser("~/.cache/pdftable/outputs"))
         self._task_flag = kwargs.get("task_flag", self.model)
@@ -89,6 +96,15 @@ class BaseInferTask(metaclass=ABCMeta):
     @abstractmethod
     def _postprocess(self, inputs, **kwargs):
         """-> list of per-item results"""
+
+    def _new_engine(self):
+        """the task's own engine on ``self.device`` in the arithmetic ``precision=`` asked for; weight blobs are then packed for it
+        (``fmt=engine.weight_fmt``)"""
+        from . import lib as L
+        from .engine import HipEngine
+        eng = HipEngine(int(str(self.device).split(":")[-1]) if ":" in str(self.device) else 0)
+        eng.set_precision({"f16": L.PT_PRECISION_F16, "bf16x3": L.PT_PRECISION_BF16X3, "bf16": L.PT_PRECISION_BF16}[self._engine_precision])
+        return eng
 
     # ---- predictor preparation (base_infer_task.py:127-169) -----------------------------------------
     def _prepare_hip_mode(self):

@@ -46,7 +46,7 @@ class ClsImagePulcTask(BaseInferTask):
 
     def _construct_model(self, model):
         if self._engine is None:
-            self._engine = HipEngine(int(str(self.device).split(":")[-1]) if ":" in str(self.device) else 0)
+            self._engine = self._new_engine()
         ncls = CLS_TASKS[self.task_type]["class_num"]
         self._exec, self._softmax_in_graph = None, False
         onnx_path = self._onnx_file()
@@ -83,7 +83,7 @@ class ClsImagePulcTask(BaseInferTask):
             sd = sd.get("state_dict", sd)
         if sd["fc.weight"].shape[0] != ncls:
             raise RuntimeError(f"checkpoint has {sd['fc.weight'].shape[0]} classes, task '{self.task_type}' needs {ncls}")
-        self._engine.load_weights(L.PT_MODEL_PPLCNET + self.slot, pack_pplcnet(sd))
+        self._engine.load_weights(L.PT_MODEL_PPLCNET + self.slot, pack_pplcnet(sd, fmt=self._engine.weight_fmt))
         self._model = self._predict
 
     def _build_processor(self):

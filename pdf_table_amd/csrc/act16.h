@@ -1,0 +1,82 @@
+// act16.h -- the 16-bit storage format of activations and single-pass weights: a COMPILE-TIME parameter of every kernel.
+//
+// Every translation unit of the library is compiled twice (pdf_table_amd/build.py):
+//   namespace pt_bf16   bfloat16 (8 significant bits, fp32 range): PT_PRECISION_BF16, and the (hi | lo) pair modes BF16X3 / F16X2
+//   namespace pt_f16    IEEE half (11 significant bits, |x| <= 65504), -DPT_ACT_F16=1: PT_PRECISION_F16 -- the reference's own GPU
+//                       arithmetic (base_infer_task.py:56-57 precision="fp16", utils/deploy_utils.py:227-240 model.half())
+// Same kernels, same tiles, same bytes and the same MFMA rate (v_mfma_f32_32x32x16_f16 == ..._bf16); what changes is this file: how 16 stored
+// bits become an fp32 value, how an fp32 value is rounded for storage (round-to-nearest-even in both; the half format SATURATES at +-65504
+// instead of producing Inf), and which matrix instruction multiplies them.  The exported C functions (api_dispatch.cpp, generated from
+// include/pdftable_hip.h) pick the namespace from pt_engine::precision.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifndef PT_ACT_F16
+#define PT_ACT_F16 0
+#endif
+#if PT_ACT_F16
+#define PT_FMT_NS pt_f16
+#define PT_FMT_NAME "f16"
+#else
+#define PT_FMT_NS pt_bf16
+#define PT_FMT_NAME "bf16"
+#endif
+
+namespace PT_FMT_NS {
+
+typedef __attribute__((ext_vector_type(2))) float a16_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 a16_bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 a16_f16x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 a16_bf16x8;     // the kernels' 16-byte operand container (bit pattern only)
+typedef __attribute__((ext_vector_type(8))) _Float16 a16_f16x8;
+typedef __attribute__((ext_vector_type(16))) float a16_f32x16;
+
+#if PT_ACT_F16
+#define PT_A16_MAX 65504.0f
+// bits of 1.0 / -1.0 / the most negative finite value in the storage format (pool identities, canvas fills)
+#define PT_A16_ONE 0x3C00u
+#define PT_A16_LOWEST 0xFBFFu
+__device__ __forceinline__ float a16_sat(float f) { return __builtin_amdgcn_fmed3f(f, -PT_A16_MAX, PT_A16_MAX); }
+__device__ __forceinline__ float a16_to_f32(uint32_t bits16) { return (float)__builtin_bit_cast(_Float16, (uint16_t)bits16); }
+__device__ __forceinline__ float a16lo_f32(uint32_t pk) { return (float)__builtin_bit_cast(a16_f16x2, pk).x; }
+__device__ __forceinline__ float a16hi_f32(uint32_t pk) { return (float)__builtin_bit_cast(a16_f16x2, pk).y; }
+// round-to-nearest-even, saturating: an activation beyond 65504 is stored as 65504, never as Inf (tests/test_gpu_f16.py)
+__device__ __forceinline__ uint32_t f32_to_a16(float f) { return __builtin_bit_cast(uint16_t, (_Float16)a16_sat(f)); }
+// two values -> one dword: v_med3_f32 x 2 + v_cvt_pk_f16_f32
+__device__ __forceinline__ uint32_t pack_a16x2(float a, float b) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(a16_f32x2{a16_sat(a), a16_sat(b)}, a16_f16x2));
+}
+// non-negative inputs (behind a ReLU): the lower clamp is the ReLU itself
+__device__ __forceinline__ uint32_t pack_a16x2_relu(float a, float b) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(a16_f32x2{__builtin_amdgcn_fmed3f(a, 0.f, PT_A16_MAX), __builtin_amdgcn_fmed3f(b, 0.f, PT_A16_MAX)}, a16_f16x2));
+}
+__device__ __forceinline__ a16_f32x16 mfma_32x32x16_a16(a16_bf16x8 a, a16_bf16x8 b, a16_f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(a16_f16x8, a), __builtin_bit_cast(a16_f16x8, b), c, 0, 0, 0);
+}
+#else
+#define PT_A16_ONE 0x3F80u
+#define PT_A16_LOWEST 0xFF7Fu
+__device__ __forceinline__ float a16_sat(float f) { return f; }
+__device__ __forceinline__ float a16_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
+__device__ __forceinline__ float a16lo_f32(uint32_t pk) { return __uint_as_float(pk << 16); }
+__device__ __forceinline__ float a16hi_f32(uint32_t pk) { return __uint_as_float(pk & 0xFFFF0000u); }
+// round-to-nearest-even fp32 -> bf16 bits (inputs are finite on this path)
+__device__ __forceinline__ uint32_t f32_to_a16(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+// two values -> one dword: v_cvt_pk_bf16_f32 (equal to f32_to_a16 for finite values)
+__device__ __forceinline__ uint32_t pack_a16x2(float a, float b) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(a16_f32x2{a, b}, a16_bf16x2));
+}
+__device__ __forceinline__ uint32_t pack_a16x2_relu(float a, float b) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(a16_f32x2{__builtin_fmaxf(a, 0.f), __builtin_fmaxf(b, 0.f)}, a16_bf16x2));
+}
+__device__ __forceinline__ a16_f32x16 mfma_32x32x16_a16(a16_bf16x8 a, a16_bf16x8 b, a16_f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+#endif
+
+}  // namespace PT_FMT_NS

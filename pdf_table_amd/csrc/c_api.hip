@@ -1,4 +1,8 @@
-// c_api.hip -- extern "C" surface of libpdftable_hip.so (declared in include/pdftable_hip.h).
+// c_api.hip -- the entry points of libpdftable_hip.so (declared in include/pdftable_hip.h), once per activation format: this file is compiled
+// into namespace pt_bf16::api and, with -DPT_ACT_F16=1, into pt_f16::api (act16.h).  The exported C symbols are the thin dispatchers of
+// api_dispatch.cpp, which pdf_table_amd/build.py generates from the header's prototypes: an entry point whose first argument is the engine runs
+// the namespace of pt_engine::precision (PT_PRECISION_F16 -> pt_f16), every other entry point (plans, sizes) runs pt_bf16's copy.
+// pt_set_error / pt_last_error / pt_abi_version live in api_common.cpp (compiled once).
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -7,20 +11,10 @@
 
 #include "common.h"
 
-static thread_local char g_err[1024] = "";
+namespace PT_FMT_NS {
+namespace api {
+
 static int ensure(void** buf, size_t* cap, size_t need);     // grow an engine-owned device buffer (defined below)
-
-void pt_set_error(const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-}
-
-extern "C" {
-
-const char* pt_last_error(void) { return g_err; }
-int pt_abi_version(void) { return 13; }   // 13: pt_engine_set_dcn_mfma; 12: pt_op_dcn (the fused modulated deformable convolution as a single operator); 11: pt_engine_set_mtl_kv_fp8; 10: pt_tsr_mtl_preprocess / decoder_config / structure / cells (MtlTabNet decoders); 9: pt_rec_cvit_* (ConvNextViT recogniser); 8: pt_op_dwconv / add / maxpool / avgpool / chan_mean / scale_channels / act (generic ONNX executor); 7: pt_rec_pp_preprocess*; 6: pt_engine_set_lstm_cluster, pt_engine_check clears what it reports
 
 int pt_engine_check(pt_engine* e) {
   PT_REQUIRE(e, "pt_engine_check: null engine");
@@ -55,8 +49,9 @@ int pt_engine_set_mtl_kv_fp8(pt_engine* e, int on) {
 }
 
 int pt_engine_set_precision(pt_engine* e, int precision) {
-  PT_REQUIRE(e && (precision == PT_PRECISION_BF16 || precision == PT_PRECISION_BF16X3 || precision == PT_PRECISION_F16X2), "pt_engine_set_precision: bad arguments");
-  e->precision = precision;
+  PT_REQUIRE(e && (precision == PT_PRECISION_BF16 || precision == PT_PRECISION_BF16X3 || precision == PT_PRECISION_F16X2 || precision == PT_PRECISION_F16),
+             "pt_engine_set_precision: bad arguments");
+  e->precision = precision;      // the dispatchers read it on every call: PT_PRECISION_F16 runs namespace pt_f16 from the next call on
   return PT_OK;
 }
 
@@ -162,6 +157,7 @@ static int register_blob(pt_engine* e, int kind, const uint8_t* h_head, size_t h
     t.nbytes = be.nbytes;
     t.d_ptr = reinterpret_cast<const char*>(d_blob) + be.offset;
     m.tensors[be.name] = t;
+    if (strcmp(be.name, "__act_f16__") == 0) m.act_f16 = 1;       // weights.py fmt="f16": every 16-bit tensor of the blob holds IEEE-half bits
   }
   auto old = e->models.find(kind);
   if (old != e->models.end()) {
@@ -345,10 +341,10 @@ int pt_layout_forward(pt_engine* e, const uint8_t* d_pages_rgb, int n, int h, in
   uint16_t* x = reinterpret_cast<uint16_t*>(base + o_x);
   float* hd[4];
   for (int l = 0; l < 4; ++l) hd[l] = reinterpret_cast<float*>(base + o_head[l]);
-  if ((rc = pt_layout_preprocess(e, d_pages_rgb, n, h, w, inp_h, inp_w, x, stream)) != PT_OK) return rc;
-  if ((rc = pt_layout_forward_net(e, x, n, inp_h, inp_w, hd[0], hd[1], hd[2], hd[3], stream)) != PT_OK)
+  if ((rc = api::pt_layout_preprocess(e, d_pages_rgb, n, h, w, inp_h, inp_w, x, stream)) != PT_OK) return rc;
+  if ((rc = api::pt_layout_forward_net(e, x, n, inp_h, inp_w, hd[0], hd[1], hd[2], hd[3], stream)) != PT_OK)
     return rc;
-  return pt_layout_candidates(e, hd[0], hd[1], hd[2], hd[3], n, inp_h, inp_w, num_classes, thr_lo, max_cands, d_counts, d_cands,
+  return api::pt_layout_candidates(e, hd[0], hd[1], hd[2], hd[3], n, inp_h, inp_w, num_classes, thr_lo, max_cands, d_counts, d_cands,
                               stream);
 }
 
@@ -1050,4 +1046,5 @@ int pt_profile_read(pt_engine* e, double* ms_per_class, long long* launches_per_
   return PT_OK;
 }
 
-}  // extern "C"
+}  // namespace api
+}  // namespace PT_FMT_NS

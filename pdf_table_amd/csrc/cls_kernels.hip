@@ -14,16 +14,14 @@
 // recomputed for each output row that taps it (2-11 times) instead of staging a ragged intermediate image in HBM.
 #include "common.h"
 
+namespace PT_FMT_NS {
+
 namespace {
 
 constexpr int RT = 8;            // output rows per workgroup
 constexpr int PBITS = 22;        // PRECISION_BITS = 32 - 8 - 2
 
-__device__ __forceinline__ uint32_t f2bf_(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return u >> 16;
-}
+__device__ __forceinline__ uint32_t f2bf_(float f) { return f32_to_a16(f); }      // act16.h: the storage format of this namespace
 
 // precompute_coeffs + normalize_coeffs_8bpc for output coordinate xx; k must hold ksize ints
 __device__ void coeffs(int in_size, int out_size, int xx, int ksize, int* xmin_out, int* n_out, int* k) {
@@ -131,7 +129,7 @@ __global__ __launch_bounds__(256) void cls_resize_norm_kernel(const uint8_t* __r
       const float f = lut[c * 256 + v[c]];
       const uint32_t hb = f2bf_(f);
       o[c] = (bf16_t)hb;
-      if (split) o[4 + c] = (bf16_t)f2bf_(f - __uint_as_float(hb << 16));
+      if (split) o[4 + c] = (bf16_t)f2bf_(f - a16_to_f32(hb));
     }
     o[3] = 0;
     if (split) o[7] = 0;
@@ -177,3 +175,5 @@ int pt_launch_cls_desc_from_lines(const pt_rec_line* lines, const long long* off
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
+
+}  // namespace PT_FMT_NS

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/pdftable_hip.h"
+#include "act16.h"
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits
 
@@ -50,6 +51,7 @@ struct PtModel {
   // host copies of small integer tensors (configuration words stored beside the weights), read from the device ONCE per loaded blob:
   // a synchronous hipMemcpy per call runs on the null stream and waits for everything queued on the caller's default stream
   std::map<std::string, std::vector<int32_t>> host_words;
+  int act_f16 = 0;   // 1: the blob's 16-bit tensors are IEEE half (packed for PT_PRECISION_F16), 0: bfloat16
   const PtTensor* find(const std::string& n) const {
     auto it = tensors.find(n);
     return it == tensors.end() ? nullptr : &it->second;
@@ -154,7 +156,7 @@ struct pt_engine {
   PtArena arenas[PT_ARENA_COUNT];
   std::map<int, PtModel> models;
   PtProfile prof;
-  int precision = 0;  // PT_PRECISION_*
+  int precision = 0;  // PT_PRECISION_* (PT_PRECISION_F16: the exported functions run namespace pt_f16, every other value pt_bf16)
   int det_kind = PT_MODEL_DB_RESNET18;   // detector network pt_det_forward* runs: the one loaded last
   // engine-owned scratch of the recognition stage (outside the arena, which every net forward resets)
   void* rec_crops = nullptr; size_t rec_crops_cap = 0;
@@ -192,6 +194,9 @@ struct pt_engine {
   PtPinnedRing stage_ring;                                   // pinned sources of small asynchronous uploads (Lore processor token maps, ConvNextViT chunk maps)
   void* mtl_state = nullptr;                                 // mtl_decoder.hip: buffers + cell lists between pt_tsr_mtl_structure and pt_tsr_mtl_cells
 };
+
+// Everything below exists once per activation format (act16.h): the launchers and the model drivers of namespace pt_bf16 and of namespace pt_f16.
+namespace PT_FMT_NS {
 
 // ---- conv launcher (conv_igemm.hip) -----------------------------------------------------------------
 struct ConvDesc {
@@ -399,11 +404,9 @@ int pt_lore_process(pt_engine* e, const float* d_logi, const float* d_dets, cons
 int pt_lore_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, float* hm, float* st, float* wh, float* ax,
                         float* cr, float* reg, hipStream_t s);
 
-#define PT_PRECISION_BF16 0
-#define PT_PRECISION_BF16X3 1
-#define PT_PRECISION_F16X2 2
-// storage: both tolerance modes keep every activation as a (hi | lo) bf16 pair ("split" layout)
-static inline int pt_split(const pt_engine* e) { return e->precision != PT_PRECISION_BF16; }
+// storage: both tolerance modes keep every activation as a (hi | lo) bf16 pair ("split" layout); PT_PRECISION_F16 (namespace pt_f16 only) is
+// single-pass like PT_PRECISION_BF16
+static inline int pt_split(const pt_engine* e) { return e->precision == PT_PRECISION_BF16X3 || e->precision == PT_PRECISION_F16X2; }
 // arithmetic: F16X2 = the conv / GEMM launches that have the variant multiply the pair (converted to fp16 while it is staged in LDS:
 // exact, a bf16 value has 8 significant bits) with SINGLE fp16 weights in two MFMA passes; every other kernel runs as in BF16X3
 static inline int pt_f16x2(const pt_engine* e) { return e->precision == PT_PRECISION_F16X2; }
@@ -433,3 +436,15 @@ struct PtProfScope {
     if (idx >= 0) (void)hipEventRecord(e->prof.pending[idx].b, s);
   }
 };
+
+// a weight blob is packed for ONE storage format (weights.py: the "__act_format__" word; absent = bf16): refuse the other one loudly
+static inline int pt_model_format_ok(const PtModel& m, const char* what) {
+  if (m.act_f16 != PT_ACT_F16) {
+    pt_set_error("%s: the loaded weight blob holds %s tiles but the engine computes in %s (pack it with fmt=\"%s\" / set the matching precision)", what,
+                 m.act_f16 ? "fp16" : "bf16", PT_FMT_NAME, PT_FMT_NAME);
+    return 0;
+  }
+  return 1;
+}
+
+}  // namespace PT_FMT_NS

@@ -25,6 +25,8 @@
 
 #include "common.h"
 
+namespace PT_FMT_NS {
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -76,23 +78,14 @@ struct ConvK {
   const int* blist;       // 4 x 64 patch only (ConvDesc.block_list): blist[0] live 32-column blocks, blist[1 + i] = image * (Wo / 32) + block; a workgroup takes two
 };
 
-__device__ __forceinline__ float bf16_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
-// round-to-nearest-even fp32 -> bf16 bits (inputs are finite on this path; NaN would become Inf/NaN-ish)
-__device__ __forceinline__ uint32_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return u >> 16;
-}
-
-// two fp32 -> one dword of two bf16 (round-to-nearest-even): v_cvt_pk_bf16_f32, one instruction where the integer
-// rounding above takes nine -- the epilogues are VALU-bound (s_memtime phase stamps: 40 % of a short-K tile's time)
-typedef __attribute__((ext_vector_type(2))) float cf2;
-typedef __attribute__((ext_vector_type(2))) __bf16 cb2;
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(cf2{a, b}, cb2));
-}
-__device__ __forceinline__ float bf16lo_f32(uint32_t pk) { return __uint_as_float(pk << 16); }
-__device__ __forceinline__ float bf16hi_f32(uint32_t pk) { return __uint_as_float(pk & 0xFFFF0000u); }
+// The storage format of activations and single-pass weights is act16.h's (bf16 in namespace pt_bf16, IEEE half in pt_f16); these are this
+// file's names for its conversions.  pack_bf16x2 is ONE instruction (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 behind two v_med3_f32 clamps) where
+// an integer rounding takes nine -- the epilogues are VALU-bound (s_memtime phase stamps: 40 % of a short-K tile's time)
+__device__ __forceinline__ float bf16_to_f32(uint32_t bits16) { return a16_to_f32(bits16); }
+__device__ __forceinline__ uint32_t f32_to_bf16(float f) { return f32_to_a16(f); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) { return pack_a16x2(a, b); }
+__device__ __forceinline__ float bf16lo_f32(uint32_t pk) { return a16lo_f32(pk); }
+__device__ __forceinline__ float bf16hi_f32(uint32_t pk) { return a16hi_f32(pk); }
 
 // PT_PRECISION_F16X2: two bf16 values -> two fp16 values.  Exact (a bf16 value has 8 significant bits, fp16 holds 11) only inside fp16's
 // NORMAL range 2^-14 <= |x| <= 65504: v_cvt_pkrtz clamps larger magnitudes to 65504 and truncates smaller ones toward zero (subnormals
@@ -125,7 +118,7 @@ __device__ __forceinline__ f32x16 mma16(bf16x8 a, bf16x8 b, f32x16 c) {
   if constexpr (F16)
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   else
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    return mfma_32x32x16_a16(a, b, c);
 }
 
 // XCD-aware bijective remap of the flat block id (8 XCDs; block b is observed to run on XCD b % 8)
@@ -1050,8 +1043,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_dma16_kernel(ConvK p, con
         for (int m = 0; m < C::MT; ++m) {
           const int pp = pa0 + (S * m + r) * C::TWIN + soff;
           const bf16x8 a = *reinterpret_cast<const bf16x8*>(s_in + pp * 32 + ((qh ^ ((pp >> 3) & 1)) << 4));
-          acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
-          acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
+          acc[m][0] = mfma_32x32x16_a16(a, b0, acc[m][0]);
+          acc[m][1] = mfma_32x32x16_a16(a, b1, acc[m][1]);
         }
       }
     }
@@ -1312,8 +1305,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws64_kernel(ConvK p, const bf1
           for (int m = 0; m < 2; ++m) {
             const int pp = pa0 + (m + r) * C::TWIN + s;
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(s_in + pp * 64 + (((kk * 2 + q) ^ ((pp >> 2) & 3)) << 4));
-            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a, acc[m][0], 0, 0, 0);      // D = [channel][pixel]
-            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a, acc[m][1], 0, 0, 0);
+            acc[m][0] = mfma_32x32x16_a16(w0, a, acc[m][0]);      // D = [channel][pixel]
+            acc[m][1] = mfma_32x32x16_a16(w1, a, acc[m][1]);
           }
         }
       }
@@ -1427,8 +1420,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_kernel(ConvK p) {
             const u32x4 av = {lo.x, lo.y, hi.x, hi.y};
             a = __builtin_bit_cast(bf16x8, av);
           }
-          acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[m][0], 0, 0, 0);
-          if (NH == 2) acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[m][1], 0, 0, 0);
+          acc[m][0] = mfma_32x32x16_a16(a, b0, acc[m][0]);
+          if (NH == 2) acc[m][1] = mfma_32x32x16_a16(a, b1, acc[m][1]);
         }
       }
     }
@@ -1540,8 +1533,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_pool_kernel(ConvK p) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base + ((m * 2 + r) * C::TWIN + 4 * h) * 8);
-        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a, acc[m][0], 0, 0, 0);     // D = [channel][pixel]
-        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a, acc[m][1], 0, 0, 0);
+        acc[m][0] = mfma_32x32x16_a16(b0, a, acc[m][0]);     // D = [channel][pixel]
+        acc[m][1] = mfma_32x32x16_a16(b1, a, acc[m][1]);
       }
     }
   }
@@ -1675,8 +1668,8 @@ __global__ __launch_bounds__(512, 1) void conv_stem7x7_pool_ws_kernel(ConvK p) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
           const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_base + ((m * 2 + r) * C::TWIN + 4 * h) * 8);
-          acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[ks][0], a, acc[m][0], 0, 0, 0);     // D = [channel][pixel]
-          acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[ks][1], a, acc[m][1], 0, 0, 0);
+          acc[m][0] = mfma_32x32x16_a16(wreg[ks][0], a, acc[m][0]);     // D = [channel][pixel]
+          acc[m][1] = mfma_32x32x16_a16(wreg[ks][1], a, acc[m][1]);
         }
       }
     }
@@ -1803,7 +1796,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_thin_kernel(ConvK p) {
             const char* ap = a_base + ((m + r) * C::TWIN + 4 * h) * 8;
             const u32x2 lo = *reinterpret_cast<const u32x2*>(ap), hi = *reinterpret_cast<const u32x2*>(ap + 8);
             const u32x4 av = {lo.x, lo.y, hi.x, hi.y};
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, __builtin_bit_cast(bf16x8, av), acc[m], 0, 0, 0);
+            acc[m] = mfma_32x32x16_a16(b0, __builtin_bit_cast(bf16x8, av), acc[m]);
           }
         }
       }
@@ -2260,3 +2253,5 @@ int pt_launch_stem7x7(pt_engine* e, const bf16_t* in, int B, int H, int W, const
   }
   return (n_valid && n_valid <= 32) ? launch_stem<1, 1>(e, k, s) : launch_stem<1, 2>(e, k, s);
 }
+
+}  // namespace PT_FMT_NS

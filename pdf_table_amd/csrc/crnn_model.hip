@@ -19,6 +19,8 @@
 
 #include "common.h"
 
+namespace PT_FMT_NS {
+
 namespace {
 
 struct ConvW {
@@ -57,6 +59,7 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
     pt_set_error("CRNN weights not loaded (pt_weights_load(PT_MODEL_CRNN))");
     return PT_ERR_STATE;
   }
+  if (!pt_model_format_ok(it->second, "PT_MODEL_CRNN")) return PT_ERR_STATE;
   const PtModel& M = it->second;
   const int x3 = pt_split(e) ? 1 : 0;
   const int m = x3 ? 2 : 1;
@@ -316,3 +319,5 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
 #undef RUN
   return PT_OK;
 }
+
+}  // namespace PT_FMT_NS

@@ -38,6 +38,8 @@
 
 #include "common.h"
 
+namespace PT_FMT_NS {
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 abf16x8;
@@ -46,12 +48,9 @@ typedef __attribute__((ext_vector_type(16))) float af32x16;
 constexpr int CV_T = 75;          // tokens per chunk = 300 / 4
 constexpr int CV_PIX0 = 8 * CV_T; // pixels per chunk after the patch embedding (8 rows x 75)
 
-__device__ __forceinline__ float bf2f(uint32_t b) { return __uint_as_float(b << 16); }
-__device__ __forceinline__ uint32_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return u >> 16;
-}
+// 16 stored bits <-> fp32 in the storage format of this namespace (act16.h: bf16, or IEEE half in pt_f16)
+__device__ __forceinline__ float bf2f(uint32_t b) { return a16_to_f32(b); }
+__device__ __forceinline__ uint32_t f2bf(float f) { return f32_to_a16(f); }
 __device__ __forceinline__ void put(bf16_t* p, int lo_off, int split, float v) {
   const uint32_t h = f2bf(v);
   p[0] = (bf16_t)h;
@@ -307,10 +306,10 @@ __global__ __launch_bounds__(64) void cvit_attention_kernel(const bf16_t* __rest
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const abf16x8 kh = ld8(kp + 16 * s);
-      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[s], sc, 0, 0, 0);
+      sc = mfma_32x32x16_a16(kh, qh[s], sc);
       if (SPLIT) {
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[s], sc, 0, 0, 0);
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(kp + LO + 16 * s), qh[s], sc, 0, 0, 0);
+        sc = mfma_32x32x16_a16(kh, ql[s], sc);
+        sc = mfma_32x32x16_a16(ld8(kp + LO + 16 * s), qh[s], sc);
       }
     }
     float mt = -INFINITY;
@@ -353,10 +352,10 @@ __global__ __launch_bounds__(64) void cvit_attention_kernel(const bf16_t* __rest
           vh[j] = __builtin_bit_cast(__bf16, vp[0]);
           if (SPLIT) vl[j] = __builtin_bit_cast(__bf16, vp[LO]);
         }
-        acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, acc[db], 0, 0, 0);
+        acc[db] = mfma_32x32x16_a16(vh, ph, acc[db]);
         if (SPLIT) {
-          acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, acc[db], 0, 0, 0);
-          acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, acc[db], 0, 0, 0);
+          acc[db] = mfma_32x32x16_a16(vh, pl, acc[db]);
+          acc[db] = mfma_32x32x16_a16(vl, ph, acc[db]);
         }
       }
     }
@@ -485,7 +484,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void cvit_mlp_kernel(cons
     const char* a1 = buf + col * (2 * C);
 #pragma unroll
     for (int s = 0; s < KS; ++s)
-      d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a1 + (((2 * s + half) ^ sw1) << 4)), xf[s], d, 0, 0, 0);
+      d = mfma_32x32x16_a16(*reinterpret_cast<const abf16x8*>(a1 + (((2 * s + half) ^ sw1) << 4)), xf[s], d);
     return d;
   };
   // second product of one chunk: the two k-steps of a tile are dependent, so all first steps are issued before the second ones
@@ -495,8 +494,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void cvit_mlp_kernel(cons
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int t = 0; t < NT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a2 + t * 2048 + (((2 * s2 + half) ^ sw2) << 4)), h[s2],
-                                                          acc[t], 0, 0, 0);
+        acc[t] = mfma_32x32x16_a16(*reinterpret_cast<const abf16x8*>(a2 + t * 2048 + (((2 * s2 + half) ^ sw2) << 4)), h[s2],
+                                                          acc[t]);
   };
   // bias + GELU + bf16 (v_cvt_pk_bf16_f32: round to nearest even, two values per instruction) of the value PAIRS [p0, p1)
   auto gelu16 = [&](const af32x16& d, const float* bp, abf16x8 (&h)[2], int p0, int p1) {
@@ -504,7 +503,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void cvit_mlp_kernel(cons
     for (int q = p0; q < p1; ++q) {
       const int r = 2 * q;
       const mlp_f2 v = gelu_pair((mlp_f2){d[r] + bp[8 * (r >> 2) + (r & 3)], d[r + 1] + bp[8 * (r >> 2) + (r & 3) + 1]});
-      const mlp_b2 pk = __builtin_convertvector(v, mlp_b2);
+      const mlp_b2 pk = __builtin_bit_cast(mlp_b2, pack_a16x2(v[0], v[1]));      // bit containers: the storage format is act16.h's
       h[r >> 3][r & 7] = pk[0];
       h[r >> 3][(r & 7) + 1] = pk[1];
     }
@@ -536,8 +535,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void cvit_mlp_kernel(cons
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const abf16x8*>(a2 + t * 2048 + (((2 * s2 + half) ^ sw2) << 4)),
-                                                            hf[s2], acc[t], 0, 0, 0);
+          acc[t] = mfma_32x32x16_a16(*reinterpret_cast<const abf16x8*>(a2 + t * 2048 + (((2 * s2 + half) ^ sw2) << 4)),
+                                                            hf[s2], acc[t]);
           if (more) gelu16(d1, bp, hn, (8 * (s2 * NT + t)) / (2 * NT), (8 * (s2 * NT + t + 1)) / (2 * NT));
         }
       hf[0] = hn[0];
@@ -857,6 +856,7 @@ int pt_cvit_forward_net(pt_engine* e, const float* gray, int layout, int n, int3
     pt_set_error("ConvNextViT weights not loaded (pt_weights_load(PT_MODEL_CONVNEXT_VIT))");
     return PT_ERR_STATE;
   }
+  if (!pt_model_format_ok(it->second, "PT_MODEL_CONVNEXT_VIT")) return PT_ERR_STATE;
   static int mb = -1, skip = -1;
   if (mb < 0) {
     const char* ev = getenv("PT_CVIT_MICROBATCH");
@@ -886,3 +886,5 @@ int pt_cvit_forward_net(pt_engine* e, const float* gray, int layout, int n, int3
   }
   return PT_OK;
 }
+
+}  // namespace PT_FMT_NS

@@ -18,6 +18,8 @@
 
 #include "common.h"
 
+namespace PT_FMT_NS {
+
 namespace {
 
 struct DbWeights {
@@ -94,6 +96,7 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
     pt_set_error("DB-ResNet18 weights not loaded (pt_weights_load(PT_MODEL_DB_RESNET18))");
     return PT_ERR_STATE;
   }
+  if (!pt_model_format_ok(it->second, "PT_MODEL_DB_RESNET18")) return PT_ERR_STATE;
   const int x3 = pt_split(e) ? 1 : 0;
   const int m = x3 ? 2 : 1;  // channel-group multiplier of every activation buffer
   DbWeights w;
@@ -277,3 +280,5 @@ int pt_db_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W_, float
 #undef RUN
   return PT_OK;
 }
+
+}  // namespace PT_FMT_NS

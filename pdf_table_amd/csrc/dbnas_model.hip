@@ -18,6 +18,8 @@
 
 #include "common.h"
 
+namespace PT_FMT_NS {
+
 namespace {
 
 struct T {
@@ -108,6 +110,7 @@ int pt_dbnas_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, flo
     pt_set_error("DB-NAS weights not loaded (pt_weights_load(PT_MODEL_DB_NAS))");
     return PT_ERR_STATE;
   }
+  if (!pt_model_format_ok(it->second, "PT_MODEL_DB_NAS")) return PT_ERR_STATE;
   Ctx c;
   c.e = e; c.m = &it->second; c.s = s; c.n = n;
   c.x3 = pt_split(e) ? 1 : 0;
@@ -195,3 +198,5 @@ int pt_dbnas_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, flo
   }
   return PT_OK;
 }
+
+}  // namespace PT_FMT_NS

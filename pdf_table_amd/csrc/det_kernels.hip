@@ -5,15 +5,14 @@
 
 #include "common.h"
 
+namespace PT_FMT_NS {
+
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
-__device__ __forceinline__ float bf2f(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
-__device__ __forceinline__ uint32_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return u >> 16;
-}
+// 16 stored bits <-> fp32 in the storage format of this namespace (act16.h: bf16, or IEEE half in pt_f16)
+__device__ __forceinline__ float bf2f(uint32_t bits16) { return a16_to_f32(bits16); }
+__device__ __forceinline__ uint32_t f2bf(float f) { return f32_to_a16(f); }
 
 // ---------------------------------------------------------------------------------------------------
 // Pre-process.  Restates, per output pixel:
@@ -153,8 +152,8 @@ int pt_launch_det_preprocess(const uint8_t* pages, int n, int h, int w, int nh, 
 // MaxPool2d(kernel 3, stride 2, padding 1) on NHWC bf16 (dbnet.py:276).  8 channels (16 B) per thread.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t bfmax2(uint32_t a, uint32_t b) {
-  const float al = bf2f(a & 0xFFFFu), bl = bf2f(b & 0xFFFFu);
-  const float ah = __uint_as_float(a & 0xFFFF0000u), bh = __uint_as_float(b & 0xFFFF0000u);
+  const float al = a16lo_f32(a), bl = a16lo_f32(b);
+  const float ah = a16hi_f32(a), bh = a16hi_f32(b);
   const uint32_t lo = (bl > al) ? (b & 0xFFFFu) : (a & 0xFFFFu);
   const uint32_t hi = (bh > ah) ? (b & 0xFFFF0000u) : (a & 0xFFFF0000u);
   return lo | hi;
@@ -386,10 +385,8 @@ int pt_launch_db_head_final(const bf16_t* in, int B, int H, int W, const void* w
 typedef __attribute__((ext_vector_type(8))) __bf16 hbf16x8;
 typedef __attribute__((ext_vector_type(2))) float hcf2;
 typedef __attribute__((ext_vector_type(2))) __bf16 hcb2;
-// two fp32 -> one dword of two bf16, round-to-nearest-even (v_cvt_pk_bf16_f32; equal to f2bf for finite values)
-__device__ __forceinline__ uint32_t pack2bf(float a, float b) {
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(hcf2{a, b}, hcb2));
-}
+// two fp32 -> one dword of two stored values, round-to-nearest-even (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32; equal to f2bf for finite values)
+__device__ __forceinline__ uint32_t pack2bf(float a, float b) { return pack_a16x2(a, b); }
 typedef __attribute__((ext_vector_type(16))) float hf32x16;
 typedef __attribute__((ext_vector_type(4))) float hf32x4;
 
@@ -474,7 +471,7 @@ __global__ __launch_bounds__(256, 4) void db_head_mfma_kernel(const bf16_t* __re
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const hbf16x8 a = *reinterpret_cast<const hbf16x8*>(sw + t * 32 * PITCH + j * 32);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[j], acc, 0, 0, 0);
+          acc = mfma_32x32x16_a16(a, xf[j], acc);
         }
         // bias + ReLU + round-to-nearest-even to bf16, two values per v_cvt_pk_bf16_f32: the integer rounding (five instructions per
         // value, 640 per 32-pixel batch against 48 MFMAs) had made this streaming kernel VALU-bound
@@ -485,7 +482,7 @@ __global__ __launch_bounds__(256, 4) void db_head_mfma_kernel(const bf16_t* __re
         for (int half = 0; half < 2; ++half) {
           const u32x4 bv = {pack2bf(hv[8 * half + 0], hv[8 * half + 1]), pack2bf(hv[8 * half + 2], hv[8 * half + 3]),
                             pack2bf(hv[8 * half + 4], hv[8 * half + 5]), pack2bf(hv[8 * half + 6], hv[8 * half + 7])};
-          d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w6f[tt][half], __builtin_bit_cast(hbf16x8, bv), d2, 0, 0, 0);
+          d2 = mfma_32x32x16_a16(w6f[tt][half], __builtin_bit_cast(hbf16x8, bv), d2);
         }
       }
 #pragma unroll
@@ -707,3 +704,5 @@ int pt_launch_box_scores(const float* prob, int n, int H, int W, const float* bo
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
+
+}  // namespace PT_FMT_NS

@@ -8,14 +8,13 @@
 // here except sigmoid / hardsigmoid, whose padded lanes the caller never reads).
 #include "common.h"
 
+namespace PT_FMT_NS {
+
 namespace {
 
-__device__ __forceinline__ float g_bf(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
-__device__ __forceinline__ uint32_t g_f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return u >> 16;
-}
+// 16 stored bits <-> fp32 in the storage format of this namespace (act16.h: bf16, or IEEE half in pt_f16)
+__device__ __forceinline__ float g_bf(uint32_t bits16) { return a16_to_f32(bits16); }
+__device__ __forceinline__ uint32_t g_f2bf(float f) { return f32_to_a16(f); }
 
 // (hi | lo) tensors of the executor's tolerance mode (PT_PRECISION_BF16X3 convention: a pixel / row holds [hi(C) | lo(C)], value = hi + lo,
 // arithmetic in fp32, result split again): lo = 0 reads / writes a plain bf16 tensor
@@ -253,7 +252,7 @@ inline unsigned grid_for(long long n) {
 
 }  // namespace
 
-extern "C" {
+namespace api {
 
 int pt_op_dwconv(pt_engine* e, const uint16_t* d_in, int B, int H, int W, int C, const float* d_w_taps, const float* d_bias, int k,
                  int stride, int act, uint16_t* d_out, int split, pt_stream stream) {
@@ -381,4 +380,5 @@ int pt_op_attention(pt_engine* e, const uint16_t* d_qkv, int B, int T, int heads
   return PT_OK;
 }
 
-}  // extern "C"
+}  // namespace api
+}  // namespace PT_FMT_NS

@@ -17,16 +17,15 @@
 // NHWC bf16; BF16X3 mode: [hi(C) | lo(C)] per pixel, arithmetic on hi + lo in fp32.
 #include "common.h"
 
+namespace PT_FMT_NS {
+
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 namespace {
 
-__device__ __forceinline__ float bf2f(uint32_t b) { return __uint_as_float(b << 16); }
-__device__ __forceinline__ uint32_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return u >> 16;
-}
+// 16 stored bits <-> fp32 in the storage format of this namespace (act16.h: bf16, or IEEE half in pt_f16)
+__device__ __forceinline__ float bf2f(uint32_t b) { return a16_to_f32(b); }
+__device__ __forceinline__ uint32_t f2bf(float f) { return f32_to_a16(f); }
 // x * relu6(x + 3) / 6 with the division as a multiplication by the rounded reciprocal (<= 1 ulp from the quotient): the IEEE division was ten
 // instructions per value -- a fifth of the depthwise kernels' VALU work
 __device__ __forceinline__ float hswish(float v) { return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * 0.16666667f; }
@@ -654,3 +653,5 @@ int pt_launch_pico_candidates(const float* head, int B, int A, int ncls, int lev
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
+
+}  // namespace PT_FMT_NS

@@ -19,6 +19,8 @@
 
 #include "common.h"
 
+namespace PT_FMT_NS {
+
 namespace {
 
 struct T {
@@ -178,6 +180,7 @@ int pt_picodet_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, f
     pt_set_error("PicoDet weights not loaded (pt_weights_load(PT_MODEL_PICODET))");
     return PT_ERR_STATE;
   }
+  if (!pt_model_format_ok(it->second, "PT_MODEL_PICODET")) return PT_ERR_STATE;
   Ctx c;
   c.e = e; c.m = &it->second; c.s = s; c.n = n;
   c.x3 = pt_split(e) ? 1 : 0;
@@ -260,6 +263,7 @@ int pt_pplcnet_forward_net(pt_engine* e, int slot, const bf16_t* x, int n, int H
     pt_set_error("PP-LCNet weights not loaded (pt_weights_load(PT_MODEL_PPLCNET + %d))", slot);
     return PT_ERR_STATE;
   }
+  if (!pt_model_format_ok(it->second, "PT_MODEL_PPLCNET")) return PT_ERR_STATE;
   Ctx c;
   c.e = e; c.m = &it->second; c.s = s; c.n = n;
   c.x3 = pt_split(e) ? 1 : 0;
@@ -319,3 +323,5 @@ int pt_pplcnet_forward_net(pt_engine* e, int slot, const bf16_t* x, int n, int H
   }
   return PT_OK;
 }
+
+}  // namespace PT_FMT_NS

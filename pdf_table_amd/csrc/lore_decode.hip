@@ -17,6 +17,8 @@
 //                         the 4 corner pixels -- with the reference's quirk that cr_feat is NOT re-sorted (:254-263)
 #include "common.h"
 
+namespace PT_FMT_NS {
+
 namespace {
 
 constexpr int CAP = 16384;         // candidate capacity per (table, class)
@@ -586,3 +588,5 @@ int pt_lore_decode_sparse(pt_engine* e, const float* ax_mos, const float* cr_mos
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
+
+}  // namespace PT_FMT_NS

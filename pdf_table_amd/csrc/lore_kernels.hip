@@ -13,17 +13,16 @@
 
 #include "common.h"
 
+namespace PT_FMT_NS {
+
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 namespace {
 
-__device__ __forceinline__ float bf2f(uint32_t b) { return __uint_as_float(b << 16); }
-__device__ __forceinline__ uint32_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return u >> 16;
-}
+// 16 stored bits <-> fp32 in the storage format of this namespace (act16.h: bf16, or IEEE half in pt_f16)
+__device__ __forceinline__ float bf2f(uint32_t b) { return a16_to_f32(b); }
+__device__ __forceinline__ uint32_t f2bf(float f) { return f32_to_a16(f); }
 
 __device__ __forceinline__ void load8(const bf16_t* p, int lo_off, int split, float* v) {
   const u32x4 h = *reinterpret_cast<const u32x4*>(p);
@@ -343,7 +342,9 @@ __global__ __launch_bounds__(256) void tsr_preprocess_kernel(const uint8_t* __re
 typedef __attribute__((ext_vector_type(8))) __bf16 dbf16x8;
 typedef __attribute__((ext_vector_type(16))) float df32x16;
 typedef __attribute__((ext_vector_type(2))) float df2;
-typedef __attribute__((ext_vector_type(2))) __bf16 db2;
+// two fp32 -> one dword of two stored values (act16.h: v_cvt_pk_bf16_f32, or clamp + v_cvt_pk_f16_f32 in pt_f16), and back
+__device__ __forceinline__ uint32_t pack_df2(df2 v) { return pack_a16x2(v.x, v.y); }
+__device__ __forceinline__ df2 unpack_df2(uint32_t pk) { return df2{a16lo_f32(pk), a16hi_f32(pk)}; }
 
 template <int SPLIT, int NB>
 __global__ __launch_bounds__(256, (SPLIT || NB > 64) ? 2 : 4) void dcn_fused_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
@@ -442,11 +443,11 @@ __global__ __launch_bounds__(256, (SPLIT || NB > 64) ? 2 : 4) void dcn_fused_ker
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const uint32_t u = e2 == 0 ? rc[0][k][hgrp].x : e2 == 1 ? rc[0][k][hgrp].y : e2 == 2 ? rc[0][k][hgrp].z : rc[0][k][hgrp].w;
-          c[k] = df2{__uint_as_float(u << 16), __uint_as_float(u & 0xFFFF0000u)};
+          c[k] = df2{a16lo_f32(u), a16hi_f32(u)};
           if (SPLIT) {
             const uint32_t ul = e2 == 0 ? rc[NP - 1][k][hgrp].x : e2 == 1 ? rc[NP - 1][k][hgrp].y
                                 : e2 == 2 ? rc[NP - 1][k][hgrp].z : rc[NP - 1][k][hgrp].w;
-            c[k] += df2{__uint_as_float(ul << 16), __uint_as_float(ul & 0xFFFF0000u)};
+            c[k] += df2{a16lo_f32(ul), a16hi_f32(ul)};
           }
         }
         df2 v = w0 * c[0];
@@ -454,12 +455,9 @@ __global__ __launch_bounds__(256, (SPLIT || NB > 64) ? 2 : 4) void dcn_fused_ker
         v = w2 * c[2] + v;
         v = w3 * c[3] + v;
         v = v * mk;
-        const db2 hb = __builtin_convertvector(v, db2);
-        oh[hgrp * 4 + e2] = __builtin_bit_cast(uint32_t, hb);
-        if (SPLIT) {
-          const df2 back = __builtin_convertvector(hb, df2);
-          ol[hgrp * 4 + e2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - back, db2));
-        }
+        const uint32_t hb = pack_df2(v);
+        oh[hgrp * 4 + e2] = hb;
+        if (SPLIT) ol[hgrp * 4 + e2] = pack_df2(v - unpack_df2(hb));
       }
     }
     char* ap = s_a[0] + gp * ROW + gh * 32;
@@ -495,11 +493,11 @@ __global__ __launch_bounds__(256, (SPLIT || NB > 64) ? 2 : 4) void dcn_fused_ker
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const dbf16x8 bh = *reinterpret_cast<const dbf16x8*>(b_rd + t * 32 * ROW + kk * 32);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+        acc[t] = mfma_32x32x16_a16(ah, bh, acc[t]);
         if (SPLIT) {
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+          acc[t] = mfma_32x32x16_a16(al, bh, acc[t]);
           const dbf16x8 bl = *reinterpret_cast<const dbf16x8*>(b_rd + W_PLANE + t * 32 * ROW + kk * 32);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+          acc[t] = mfma_32x32x16_a16(ah, bl, acc[t]);
         }
       }
     }
@@ -692,19 +690,19 @@ __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) voi
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const uint32_t u = e2 == 0 ? rc[j][k].x : e2 == 1 ? rc[j][k].y : e2 == 2 ? rc[j][k].z : rc[j][k].w;
-          c[k] = df2{__uint_as_float(u << 16), __uint_as_float(u & 0xFFFF0000u)};
+          c[k] = df2{a16lo_f32(u), a16hi_f32(u)};
           if (SPLIT) {
             const uint32_t ul = e2 == 0 ? rcl[j][k].x : e2 == 1 ? rcl[j][k].y : e2 == 2 ? rcl[j][k].z : rcl[j][k].w;
-            c[k] += df2{__uint_as_float(ul << 16), __uint_as_float(ul & 0xFFFF0000u)};
+            c[k] += df2{a16lo_f32(ul), a16hi_f32(ul)};
           }
         }
         df2 v = w0 * c[0];
         v = w1 * c[1] + v;
         v = w2 * c[2] + v;
         v = w3 * c[3] + v;
-        const db2 hb = __builtin_convertvector(v, db2);
-        o[e2] = __builtin_bit_cast(uint32_t, hb);
-        if (SPLIT) ol[e2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - __builtin_convertvector(hb, df2), db2));
+        const uint32_t hb = pack_df2(v);
+        o[e2] = hb;
+        if (SPLIT) ol[e2] = pack_df2(v - unpack_df2(hb));
       }
       *reinterpret_cast<u32x4*>(s_a + (prow + PSTEP * j) * ROW + piece * 16) = u32x4{o[0], o[1], o[2], o[3]};
       if (SPLIT) *reinterpret_cast<u32x4*>(s_a + A_PLANE + (prow + PSTEP * j) * ROW + piece * 16) = u32x4{ol[0], ol[1], ol[2], ol[3]};
@@ -732,11 +730,11 @@ __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) voi
 #if PT_DCN_ABL == 3     /* ablation: one MFMA per stage instead of eight */
         if (kk == 0 && t == 0)
 #endif
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc[t], 0, 0, 0);   // D = [channel][pixel]
+        acc[t] = mfma_32x32x16_a16(b, a, acc[t]);   // D = [channel][pixel]
         if (SPLIT) {
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, al, acc[t], 0, 0, 0);
+          acc[t] = mfma_32x32x16_a16(b, al, acc[t]);
           const dbf16x8 bl = *reinterpret_cast<const dbf16x8*>(b_rd + W_PLANE + t * 32 * ROW + kk * 32);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, a, acc[t], 0, 0, 0);
+          acc[t] = mfma_32x32x16_a16(bl, a, acc[t]);
         }
       }
     }
@@ -758,13 +756,13 @@ __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) voi
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const uint32_t u = e2 == 0 ? rc[j][k].x : e2 == 1 ? rc[j][k].y : e2 == 2 ? rc[j][k].z : rc[j][k].w;
-            c[k] = df2{__uint_as_float(u << 16), __uint_as_float(u & 0xFFFF0000u)};
+            c[k] = df2{a16lo_f32(u), a16hi_f32(u)};
           }
           df2 v = w0 * c[0];
           v = w1 * c[1] + v;
           v = w2 * c[2] + v;
           v = w3 * c[3] + v;
-          o[e2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, db2));
+          o[e2] = pack_df2(v);
         }
         *reinterpret_cast<u32x4*>(s_a + (prow + PSTEP * j) * ROW + piece * 16) = u32x4{o[0], o[1], o[2], o[3]};
         if (more) {          // this item's registers are free: its loads of the next stage go out now
@@ -1021,7 +1019,7 @@ __global__ __launch_bounds__(512, (NB == 64 && RING == 4) ? 2 : 1) void dcn_mfma
       const u32x4 bw = {mine ? e01 : 0u, mine ? e23 : 0u, mine ? o01 : 0u, mine ? o23 : 0u};                                             \
       const u32x4 aw = {a_lo.x, a_lo.y, a_hi.x, a_hi.y};                                                                                 \
       if (PT_DCN_MABL != 2 || S == 0)                                                                                                    \
-        bl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dbf16x8, aw), __builtin_bit_cast(dbf16x8, bw), bl, 0, 0, 0);     \
+        bl = mfma_32x32x16_a16(__builtin_bit_cast(dbf16x8, aw), __builtin_bit_cast(dbf16x8, bw), bl);     \
     }
     if (!last) {
       PT_DCN_STEP(0, false) PT_DCN_STEP(1, false) PT_DCN_STEP(2, false) PT_DCN_STEP(3, false)
@@ -1039,12 +1037,12 @@ __global__ __launch_bounds__(512, (NB == 64 && RING == 4) ? 2 : 1) void dcn_mfma
 #pragma unroll
       for (int e2 = 0; e2 < 4; ++e2) {
         const df2 v = {bl[8 * t + 2 * e2], bl[8 * t + 2 * e2 + 1]};
-        cf[e2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, db2));
+        cf[e2] = pack_df2(v);
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const dbf16x8 wf = *reinterpret_cast<const dbf16x8*>(wrd + nt * 32 * 128 + (((hh * 4 + t * 2 + q) ^ b_key) << 4));
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(dbf16x8, cf), acc[nt], 0, 0, 0);   // D = [channel][pixel]
+        acc[nt] = mfma_32x32x16_a16(wf, __builtin_bit_cast(dbf16x8, cf), acc[nt]);   // D = [channel][pixel]
       }
     }
     tap = tap_n;
@@ -1234,8 +1232,8 @@ __global__ __launch_bounds__(512, 2) void dcn_mfma2_kernel(const bf16_t* __restr
       const bool mine = key == 2 * S;                                                                                                  \
       const u32x4 bw = {mine ? e01 : 0u, mine ? e23 : 0u, mine ? o01 : 0u, mine ? o23 : 0u};                                           \
       const u32x4 aw0 = {a0l.x, a0l.y, a0h.x, a0h.y}, aw1 = {a1l.x, a1l.y, a1h.x, a1h.y};                                              \
-      bl0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dbf16x8, aw0), __builtin_bit_cast(dbf16x8, bw), bl0, 0, 0, 0);  \
-      bl1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dbf16x8, aw1), __builtin_bit_cast(dbf16x8, bw), bl1, 0, 0, 0);  \
+      bl0 = mfma_32x32x16_a16(__builtin_bit_cast(dbf16x8, aw0), __builtin_bit_cast(dbf16x8, bw), bl0);  \
+      bl1 = mfma_32x32x16_a16(__builtin_bit_cast(dbf16x8, aw1), __builtin_bit_cast(dbf16x8, bw), bl1);  \
     }
 #define PT_DCN2_TAP(TAP)                                                                                                               \
   for (int ss = 0; ss < nss; ++ss) {                                                                                                   \
@@ -1281,11 +1279,11 @@ __global__ __launch_bounds__(512, 2) void dcn_mfma2_kernel(const bf16_t* __restr
       _Pragma("unroll") for (int e2 = 0; e2 < 4; ++e2) {                                                                               \
         const int r_ = 8 * (ks & 1) + 2 * e2;                                                                                          \
         const df2 v = (ks < 2) ? df2{bl0[r_], bl0[r_ + 1]} : df2{bl1[r_], bl1[r_ + 1]};                                                \
-        cf[e2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, db2));                                                        \
+        cf[e2] = pack_df2(v);                                                        \
       }                                                                                                                                \
       _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                                              \
         const dbf16x8 wf = *reinterpret_cast<const dbf16x8*>(wrd + nt * 32 * 128 + (((ks * 2 + q) ^ b_key) << 4));                     \
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(dbf16x8, cf), acc[nt], 0, 0, 0);                      \
+        acc[nt] = mfma_32x32x16_a16(wf, __builtin_bit_cast(dbf16x8, cf), acc[nt]);                      \
       }                                                                                                                                \
     }                                                                                                                                  \
     if (geo) { wc01 = wn01; wc23 = wn23; }                                                                                             \
@@ -1377,11 +1375,11 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const bf16_t* __restri
       for (int t = 0; t < 9; ++t) {
         const int off = ((ty * STRIDE + t / 3) * PW + tx * STRIDE + t % 3) * PITCH + q * 16;
         const dbf16x8 ah = *reinterpret_cast<const dbf16x8*>(s_in[0] + off);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[t], ah, acc, 0, 0, 0);
+        acc = mfma_32x32x16_a16(wh[t], ah, acc);
         if (SPLIT) {
           const dbf16x8 al = *reinterpret_cast<const dbf16x8*>(s_in[NP - 1] + off);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[t], al, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[t], ah, acc, 0, 0, 0);
+          acc = mfma_32x32x16_a16(wh[t], al, acc);
+          acc = mfma_32x32x16_a16(wl[t], ah, acc);
         }
       }
       const int oy = oy0 + ty, ox = ox0 + tx;
@@ -1515,7 +1513,7 @@ __global__ __launch_bounds__(512, 1) void dla_thin_chain_kernel(const bf16_t* __
           const char* ap = a_base + (r * C::CI + 4 * h) * 8;
           const u32x2 lo = *reinterpret_cast<const u32x2*>(ap), hi = *reinterpret_cast<const u32x2*>(ap + 8);
           const u32x4 av = {lo.x, lo.y, hi.x, hi.y};
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, __builtin_bit_cast(dbf16x8, av), acc, 0, 0, 0);
+          acc = mfma_32x32x16_a16(wv, __builtin_bit_cast(dbf16x8, av), acc);
         }
       const int j = ct * 32 + lx, gy = yb0 + i, gx = xb0 + j;
       const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
@@ -1542,7 +1540,7 @@ __global__ __launch_bounds__(512, 1) void dla_thin_chain_kernel(const bf16_t* __
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const dbf16x8 av = *reinterpret_cast<const dbf16x8*>(s_b + ((i + t / 3) * C::PW + ct * 32 + lx + t % 3) * C::PITCH + q * 16);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0[t], av, acc, 0, 0, 0);
+        acc = mfma_32x32x16_a16(wf0[t], av, acc);
       }
       const int j = ct * 32 + lx, gy = y00 + i, gx = x00 + j;
       const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && j < C::C0;
@@ -1568,7 +1566,7 @@ __global__ __launch_bounds__(512, 1) void dla_thin_chain_kernel(const bf16_t* __
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const dbf16x8 av = *reinterpret_cast<const dbf16x8*>(s_l0 + ((2 * oy + t / 3) * C::PW + 2 * lx + t % 3) * C::PITCH + q * 16);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1[t], av, acc, 0, 0, 0);
+        acc = mfma_32x32x16_a16(wf1[t], av, acc);
       }
       const int gy = oy1 + oy, gx = ox1 + lx;
       if (lx < C::TW1 && gy < H1 && gx < W1) {
@@ -1799,3 +1797,5 @@ int pt_launch_dla_thin_chain(pt_engine* e, const bf16_t* in, int B, int H, int W
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
+
+}  // namespace PT_FMT_NS

@@ -17,6 +17,8 @@
 
 #include "common.h"
 
+namespace PT_FMT_NS {
+
 int pt_launch_dcn_im2col(const bf16_t* x, const float* om, bf16_t* cols, int B, int H, int W, int C, int split,
                          hipStream_t s);
 int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf16_t* w, const float* bias, bf16_t* out,
@@ -211,6 +213,7 @@ static int lore_dla_run(pt_engine* e, const bf16_t* x, int n, int H, int W, floa
     pt_set_error("Lore DLA-34 weights not loaded (pt_weights_load(PT_MODEL_LORE_DLA34))");
     return PT_ERR_STATE;
   }
+  if (!pt_model_format_ok(it->second, "PT_MODEL_LORE_DLA34")) return PT_ERR_STATE;
   Ctx c;
   c.e = e; c.m = &it->second; c.s = s; c.n = n;
   c.x3 = pt_split(e) ? 1 : 0;
@@ -451,6 +454,7 @@ int pt_lore_wireless_forward_net(pt_engine* e, const bf16_t* x, int n, int H, in
     pt_set_error("Lore wireless weights not loaded (pt_weights_load(PT_MODEL_LORE_RESNET18))");
     return PT_ERR_STATE;
   }
+  if (!pt_model_format_ok(it->second, "PT_MODEL_LORE_RESNET18")) return PT_ERR_STATE;
   WCtx c;
   c.e = e; c.m = &it->second; c.s = s; c.n = n;
   c.x3 = pt_split(e) ? 1 : 0;
@@ -541,3 +545,5 @@ int pt_lore_wireless_forward_net(pt_engine* e, const bf16_t* x, int n, int H, in
   }
   return PT_OK;
 }
+
+}  // namespace PT_FMT_NS

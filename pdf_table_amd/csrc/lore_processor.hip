@@ -15,16 +15,15 @@
 
 #include "common.h"
 
+namespace PT_FMT_NS {
+
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 namespace {
 
-__device__ __forceinline__ float bf2f(uint32_t b) { return __uint_as_float(b << 16); }
-__device__ __forceinline__ uint32_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return u >> 16;
-}
+// 16 stored bits <-> fp32 in the storage format of this namespace (act16.h: bf16, or IEEE half in pt_f16)
+__device__ __forceinline__ float bf2f(uint32_t b) { return a16_to_f32(b); }
+__device__ __forceinline__ uint32_t f2bf(float f) { return f32_to_a16(f); }
 __device__ __forceinline__ void put(bf16_t* p, int lo_off, int split, float v) {
   const uint32_t h = f2bf(v);
   p[0] = (bf16_t)h;
@@ -133,14 +132,14 @@ __global__ __launch_bounds__(64) void attention_kernel(const bf16_t* __restrict_
     for (int r = 0; r < 16; ++r) sc[r] = 0.f;
     {
       const abf16x8 k0h = ld8(kp), k1h = ld8(kp + 16);
-      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0h, qh[0], sc, 0, 0, 0);
-      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1h, qh[1], sc, 0, 0, 0);
+      sc = mfma_32x32x16_a16(k0h, qh[0], sc);
+      sc = mfma_32x32x16_a16(k1h, qh[1], sc);
       if (SPLIT) {
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0h, ql[0], sc, 0, 0, 0);
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1h, ql[1], sc, 0, 0, 0);
+        sc = mfma_32x32x16_a16(k0h, ql[0], sc);
+        sc = mfma_32x32x16_a16(k1h, ql[1], sc);
         const abf16x8 k0l = ld8(kp + 768), k1l = ld8(kp + 768 + 16);
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0l, qh[0], sc, 0, 0, 0);
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1l, qh[1], sc, 0, 0, 0);
+        sc = mfma_32x32x16_a16(k0l, qh[0], sc);
+        sc = mfma_32x32x16_a16(k1l, qh[1], sc);
       }
     }
     float mt = -INFINITY;
@@ -177,10 +176,10 @@ __global__ __launch_bounds__(64) void attention_kernel(const bf16_t* __restrict_
         vh[j] = __builtin_bit_cast(__bf16, vp[0]);
         if (SPLIT) vl[j] = __builtin_bit_cast(__bf16, vp[768]);
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, acc, 0, 0, 0);
+      acc = mfma_32x32x16_a16(vh, ph, acc);
       if (SPLIT) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, acc, 0, 0, 0);
+        acc = mfma_32x32x16_a16(vh, pl, acc);
+        acc = mfma_32x32x16_a16(vl, ph, acc);
       }
     }
   }
@@ -247,6 +246,7 @@ int pt_lore_process(pt_engine* e, const float* d_logi, const float* d_dets, cons
     pt_set_error("Lore processor weights not loaded (pt_weights_load(PT_MODEL_LORE_PROCESSOR))");
     return PT_ERR_STATE;
   }
+  if (!pt_model_format_ok(it->second, "PT_MODEL_LORE_PROCESSOR")) return PT_ERR_STATE;
   std::vector<int> tok, tiles;
   int N = 0;
   for (int t = 0; t < n_tables; ++t) {
@@ -372,3 +372,5 @@ int pt_lore_process(pt_engine* e, const float* d_logi, const float* d_dets, cons
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
+
+}  // namespace PT_FMT_NS

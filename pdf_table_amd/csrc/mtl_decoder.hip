@@ -41,6 +41,8 @@
 
 #include "common.h"
 
+namespace PT_FMT_NS {
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 abf16x8;
@@ -50,12 +52,9 @@ constexpr int D = 512, HEADS = 8, DK = 64, NL = 5;      // d_model, heads, d_k, 
 constexpr int KVC = NL * 2 * D;                          // channels of the cross key / value tensor: [k_l | v_l] per layer
 constexpr int PE_ROWS = 4096;
 
-__device__ __forceinline__ float bf2f(uint32_t b) { return __uint_as_float(b << 16); }
-__device__ __forceinline__ uint32_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return u >> 16;
-}
+// 16 stored bits <-> fp32 in the storage format of this namespace (act16.h: bf16, or IEEE half in pt_f16)
+__device__ __forceinline__ float bf2f(uint32_t b) { return a16_to_f32(b); }
+__device__ __forceinline__ uint32_t f2bf(float f) { return f32_to_a16(f); }
 __device__ __forceinline__ void put(bf16_t* p, int lo_off, int split, float v) {
   const uint32_t h = f2bf(v);
   p[0] = (bf16_t)h;
@@ -75,10 +74,10 @@ __device__ __forceinline__ abf16x8 ld8(const bf16_t* p) { return *reinterpret_ca
 __device__ __forceinline__ uint4 ldu4(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
 // eight bf16 values of a 16-byte load -> fp32, in memory order
 __device__ __forceinline__ void unpack8(const uint4 u, float* f) {
-  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
-  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
-  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
-  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+  f[0] = a16lo_f32(u.x); f[1] = a16hi_f32(u.x);
+  f[2] = a16lo_f32(u.y); f[3] = a16hi_f32(u.y);
+  f[4] = a16lo_f32(u.z); f[5] = a16hi_f32(u.z);
+  f[6] = a16lo_f32(u.w); f[7] = a16hi_f32(u.w);
 }
 
 // out_enc = PositionalEncoding(feat) (:182-188): f3 fp32 [n * hw, 512] (NHWC = the reference's view(b, c, h*w).permute(0, 2, 1))
@@ -268,10 +267,10 @@ __global__ __launch_bounds__(64) void mtl_cross_attn_kernel(const bf16_t* __rest
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const abf16x8 kh = ld8(kp + 16 * s);
-      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[s], sc, 0, 0, 0);
+      sc = mfma_32x32x16_a16(kh, qh[s], sc);
       if (SPLIT) {
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[s], sc, 0, 0, 0);
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(kp + LOK + 16 * s), qh[s], sc, 0, 0, 0);
+        sc = mfma_32x32x16_a16(kh, ql[s], sc);
+        sc = mfma_32x32x16_a16(ld8(kp + LOK + 16 * s), qh[s], sc);
       }
     }
     float mt = -INFINITY;
@@ -314,10 +313,10 @@ __global__ __launch_bounds__(64) void mtl_cross_attn_kernel(const bf16_t* __rest
           vh[j] = __builtin_bit_cast(__bf16, vp[0]);
           if (SPLIT) vl[j] = __builtin_bit_cast(__bf16, vp[LOK]);
         }
-        acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, acc[db], 0, 0, 0);
+        acc[db] = mfma_32x32x16_a16(vh, ph, acc[db]);
         if (SPLIT) {
-          acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, acc[db], 0, 0, 0);
-          acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, acc[db], 0, 0, 0);
+          acc[db] = mfma_32x32x16_a16(vh, pl, acc[db]);
+          acc[db] = mfma_32x32x16_a16(vl, ph, acc[db]);
         }
       }
     }
@@ -876,8 +875,8 @@ __global__ __launch_bounds__(256) void mtl_rowgemm_kernel(const bf16_t* __restri
     if (c0 + i < kc) {
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0][st], b[i][st], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1][st], b[i][st], acc[1], 0, 0, 0);
+        acc[0] = mfma_32x32x16_a16(a[i][0][st], b[i][st], acc[0]);
+        acc[1] = mfma_32x32x16_a16(a[i][1][st], b[i][st], acc[1]);
       }
     }
   float* pp = part + ((size_t)z * rows + row) * N + nt * 64 + 4 * half;
@@ -1102,12 +1101,14 @@ int read_meta(Ctx& c, Meta* mt) {
 
 }  // namespace
 
+namespace api {      // an entry point of include/pdftable_hip.h (reached through api_dispatch.cpp)
 void pt_tsr_mtl_resized_size(int crop_w, int crop_h, int size, int32_t* out_w, int32_t* out_h) {
   int w = 0, h = 0;
   mtl_resized(crop_w, crop_h, size, &w, &h);
   *out_w = w;
   *out_h = h;
 }
+}  // namespace api
 
 int pt_mtl_preprocess(pt_engine* e, const uint8_t* pages, int ph, int pw, const pt_tsr_table* tabs, int n, int size, bf16_t* out, hipStream_t s) {
   const int x3 = pt_split(e) ? 1 : 0;
@@ -1135,6 +1136,7 @@ int pt_mtl_decoder_config(pt_engine* e, int32_t* out13) {
     pt_set_error("MtlTabNet decoder weights not loaded (pt_weights_load(PT_MODEL_MTL_DECODER))");
     return PT_ERR_STATE;
   }
+  if (!pt_model_format_ok(it->second, "PT_MODEL_MTL_DECODER")) return PT_ERR_STATE;
   Ctx c{e, &it->second, nullptr, 0, 1, PT_OK};
   Meta mt;
   const int rc = read_meta(c, &mt);
@@ -1153,6 +1155,7 @@ int pt_mtl_structure(pt_engine* e, const float* f3, int n, int hw, float* d_tag_
     pt_set_error("MtlTabNet decoder weights not loaded (pt_weights_load(PT_MODEL_MTL_DECODER))");
     return PT_ERR_STATE;
   }
+  if (!pt_model_format_ok(it->second, "PT_MODEL_MTL_DECODER")) return PT_ERR_STATE;
   Ctx c{e, &it->second, s, pt_split(e) ? 1 : 0, pt_split(e) ? 2 : 1, PT_OK};
   if (!getenv("PT_MTL_NO_ROWGEMM")) c.part = &state_of(e)->part;
   Meta mt;
@@ -1388,6 +1391,7 @@ int pt_mtl_cells(pt_engine* e, int total, int32_t* d_cell_ids, float* d_cell_pro
     pt_set_error("MtlTabNet decoder weights not loaded (pt_weights_load(PT_MODEL_MTL_DECODER))");
     return PT_ERR_STATE;
   }
+  if (!pt_model_format_ok(it->second, "PT_MODEL_MTL_DECODER")) return PT_ERR_STATE;
   Ctx c{e, &it->second, s, st->x3, st->x3 ? 2 : 1, PT_OK};
   if (!getenv("PT_MTL_NO_ROWGEMM")) c.part = &st->part;
   PT_REQUIRE((pt_split(e) ? 1 : 0) == st->x3, "pt_tsr_mtl_cells: the precision changed since pt_tsr_mtl_structure");
@@ -1541,3 +1545,5 @@ int pt_mtl_cells(pt_engine* e, int total, int32_t* d_cell_ids, float* d_cell_pro
   }
   return PT_OK;
 }
+
+}  // namespace PT_FMT_NS

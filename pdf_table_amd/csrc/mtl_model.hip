@@ -15,14 +15,13 @@
 
 #include "common.h"
 
+namespace PT_FMT_NS {
+
 namespace {
 
-__device__ __forceinline__ float mbf2f(uint32_t b) { return __uint_as_float(b << 16); }
-__device__ __forceinline__ uint32_t mf2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return u >> 16;
-}
+// 16 stored bits <-> fp32 in the storage format of this namespace (act16.h: bf16, or IEEE half in pt_f16)
+__device__ __forceinline__ float mbf2f(uint32_t b) { return a16_to_f32(b); }
+__device__ __forceinline__ uint32_t mf2bf(float f) { return f32_to_a16(f); }
 __device__ __forceinline__ float mget(const bf16_t* p, int lo_off, int split) {
   float v = mbf2f(p[0]);
   if (split) v += mbf2f(p[lo_off]);
@@ -156,6 +155,7 @@ int pt_mtl_backbone_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int
     pt_set_error("MtlTabNet backbone weights not loaded (pt_weights_load(PT_MODEL_MTL_BACKBONE))");
     return PT_ERR_STATE;
   }
+  if (!pt_model_format_ok(it->second, "PT_MODEL_MTL_BACKBONE")) return PT_ERR_STATE;
   const PtModel& M = it->second;
   const int x3 = pt_split(e) ? 1 : 0, m = x3 ? 2 : 1;
   int rc = PT_OK;
@@ -287,3 +287,5 @@ int pt_mtl_backbone_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int
   PT_HIP_CHECK(hipGetLastError());
   return rc;
 }
+
+}  // namespace PT_FMT_NS

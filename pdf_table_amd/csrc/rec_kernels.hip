@@ -12,17 +12,16 @@
 
 #include "common.h"
 
+namespace PT_FMT_NS {
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
-__device__ __forceinline__ float rbf2f(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
-__device__ __forceinline__ uint32_t rf2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return u >> 16;
-}
+// 16 stored bits <-> fp32 in the storage format of this namespace (act16.h: bf16, or IEEE half in pt_f16)
+__device__ __forceinline__ float rbf2f(uint32_t bits16) { return a16_to_f32(bits16); }
+__device__ __forceinline__ uint32_t rf2bf(float f) { return f32_to_a16(f); }
 
 // ---------------------------------------------------------------------------------------------------
 // Perspective crop.  cv2.warpPerspective(img, M, (w, h)) semantics for 8-bit, INTER_LINEAR, constant border 0:
@@ -554,7 +553,7 @@ __global__ __launch_bounds__(256) void crnn_conv0_pool_mfma_kernel(const bf16_t*
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[nh], acc, 0, 0, 0);
+      acc = mfma_32x32x16_a16(a, bw[nh], acc);
       // accumulator r: row (r & 3) + 8 (r >> 2) + 4 q = window 2 (r >> 2) + q, pixel r & 3
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -786,7 +785,7 @@ __global__ __launch_bounds__(256 * NG, 1) void lstm_dir_kernel(const bf16_t* __r
           for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
-              acc[g][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[kq][g][h], acc[g][h], 0, 0, 0);
+              acc[g][h] = mfma_32x32x16_a16(a, bq[kq][g][h], acc[g][h]);
         }
       }
     }
@@ -914,7 +913,7 @@ __global__ __launch_bounds__(256, 1) void lstm_dir_dma_kernel(const bf16_t* __re
         for (int g = 0; g < 4; ++g)
 #pragma unroll
           for (int h = 0; h < 2; ++h)
-            acc[g][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[kq][g][h], acc[g][h], 0, 0, 0);
+            acc[g][h] = mfma_32x32x16_a16(a, bq[kq][g][h], acc[g][h]);
       }
     }
     // every wave has finished reading h_{t-1}; this step's gx (issued one step ago) has landed
@@ -1069,8 +1068,8 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(const bf16_t* __re
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const bf16x8 b = *reinterpret_cast<const bf16x8*>(wl + ((ks * 4 + g) * 2 + h) * 1024 + lane * 16);
-            acc[0][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b, acc[0][g], 0, 0, 0);
-            acc[1][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b, acc[1][g], 0, 0, 0);
+            acc[0][g] = mfma_32x32x16_a16(a[0], b, acc[0][g]);
+            acc[1][g] = mfma_32x32x16_a16(a[1], b, acc[1][g]);
           }
         }
       }
@@ -1105,7 +1104,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(const bf16_t* __re
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const bf16x8 b = *reinterpret_cast<const bf16x8*>(wl + ((ks * 4 + g) * 2 + h) * 1024 + lane * 16);
-              acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[g], 0, 0, 0);
+              acc[g] = mfma_32x32x16_a16(a, b, acc[g]);
             }
           }
         }
@@ -1274,9 +1273,9 @@ __global__ __launch_bounds__(64 * NW, 1) void lstm_cluster8_x3_kernel(const bf16
             for (int g = 0; g < 4; ++g) {
               const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wl + ((k0 + ks) * 4 + g) * 1024 + lane * 16);
               const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wl + 65536 + ((k0 + ks) * 4 + g) * 1024 + lane * 16);
-              acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[g], 0, 0, 0);
-              acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[g], 0, 0, 0);
-              acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[g], 0, 0, 0);
+              acc[g] = mfma_32x32x16_a16(ah, bh, acc[g]);
+              acc[g] = mfma_32x32x16_a16(al, bh, acc[g]);
+              acc[g] = mfma_32x32x16_a16(ah, bl, acc[g]);
             }
           }
           if (NW == 8) __builtin_amdgcn_sched_barrier(0);      // the second burst's loads are not hoisted above the first burst's MFMAs
@@ -1603,7 +1602,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_argmax_kernel(const bf16_t* _
         if (MODE == 1 && ks) break;
 #endif
         const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wr + ks * 32);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, areg[ks], acc, 0, 0, 0);
+        acc = mfma_32x32x16_a16(wf, areg[ks], acc);
       }
       if (MODE == 0) {
 #pragma unroll
@@ -1764,7 +1763,7 @@ __global__ __launch_bounds__(256, 2) void gemm_cand_kernel(const bf16_t* __restr
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
         const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wr + ks * 32);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, areg[ks], acc, 0, 0, 0);
+        acc = mfma_32x32x16_a16(wf, areg[ks], acc);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -2074,17 +2073,17 @@ __global__ __launch_bounds__(256, KSTEPS == 32 ? 1 : 2) void gemm_rows_x3_kernel
     // (a scheduling barrier every eight k-steps: left alone, hipcc hoists a pass's 32 fragment reads in front of its MFMAs and spills the rows)
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(wh + ks * 32), ahi[ks], acc, 0, 0, 0);
+      acc = mfma_32x32x16_a16(*reinterpret_cast<const bf16x8*>(wh + ks * 32), ahi[ks], acc);
       if ((ks & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(wh + ks * 32), alo[ks], acc, 0, 0, 0);
+      acc = mfma_32x32x16_a16(*reinterpret_cast<const bf16x8*>(wh + ks * 32), alo[ks], acc);
       if ((ks & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(wl + ks * 32), ahi[ks], acc, 0, 0, 0);
+      acc = mfma_32x32x16_a16(*reinterpret_cast<const bf16x8*>(wl + ks * 32), ahi[ks], acc);
       if ((ks & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
     // a lane owns a ROW: its 16 accumulators are classes (r & 3) + 8 (r >> 2) + 4 q of the stage; (hi, lo) through the wave's tiles
@@ -2145,3 +2144,5 @@ int pt_launch_argmax_reduce(const float* part, long long rows, int ntiles, int* 
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
+
+}  // namespace PT_FMT_NS

@@ -51,10 +51,27 @@ class HipEngine:
         self.precision = L.PT_PRECISION_BF16
 
     def set_precision(self, precision: int):
-        """L.PT_PRECISION_BF16 (throughput), L.PT_PRECISION_BF16X3 (fp32-class parity mode: three bf16 passes) or L.PT_PRECISION_F16X2 (the
-        same activation pairs against single fp16 weights: two fp16 passes, weight rounding ~1.5e-4 of the logit scale)."""
+        """L.PT_PRECISION_BF16 (throughput), L.PT_PRECISION_BF16X3 (fp32-class parity mode: three bf16 passes), L.PT_PRECISION_F16X2 (the
+        same activation pairs against single fp16 weights: two fp16 passes, weight rounding ~1.5e-4 of the logit scale) or L.PT_PRECISION_F16
+        (single-pass IEEE half, the reference's own GPU arithmetic: same speed as BF16 with 11 significant bits instead of 8; the weight blobs
+        must be packed with ``fmt="f16"`` -- ``weight_fmt`` -- and the 16-bit tensors of the API are torch.float16)."""
         L.check(self.lib.pt_engine_set_precision(self._h, int(precision)), "pt_engine_set_precision")
         self.precision = int(precision)
+
+    @property
+    def split(self) -> bool:
+        """activations cross the ABI as (hi | lo) bf16 pairs (twice the channels): the two pair modes"""
+        return self.precision in (L.PT_PRECISION_BF16X3, L.PT_PRECISION_F16X2)
+
+    @property
+    def act_dtype(self):
+        """torch dtype of the 16-bit activation tensors of the current precision (csrc/act16.h): float16 under PT_PRECISION_F16, else bfloat16"""
+        return torch.float16 if self.precision == L.PT_PRECISION_F16 else torch.bfloat16
+
+    @property
+    def weight_fmt(self) -> str:
+        """the ``fmt`` argument weights.pack_* need for blobs this engine will accept under its current precision"""
+        return "f16" if self.precision == L.PT_PRECISION_F16 else "bf16"
 
     def set_mtl_kv_fp8(self, on: bool):
         """MtlTabNet, bf16 mode: stream the structure loop's source-attention keys / values as fp8 (half the bytes of the loop's dominant
@@ -132,7 +149,7 @@ class HipEngine:
         self._chk(pages, torch.uint8, "pages")
         n, h, w, _ = pages.shape
         nh, nw = self.det_plan(h, w, flavour)
-        out = torch.empty((n, nh, nw, 8 if self.precision != L.PT_PRECISION_BF16 else 4), dtype=torch.bfloat16,
+        out = torch.empty((n, nh, nw, 8 if self.split else 4), dtype=self.act_dtype,
                           device=self._tdev)
         L.check(self.lib.pt_det_preprocess(self._h, _ptr(pages), n, h, w, flavour, _ptr(out), self._stream()),
                 "pt_det_preprocess")
@@ -140,9 +157,9 @@ class HipEngine:
 
     def det_forward_net(self, x: torch.Tensor, want_logits: bool = False):
         """x bf16 NHWC4 [n,H,W,4] (BF16X3 mode: [n,H,W,8] = hi rgb0 | lo rgb0) -> prob f32 [n,H,W] (and logits)."""
-        self._chk(x, torch.bfloat16, "x")
+        self._chk(x, self.act_dtype, "x")
         n, H, W, c = x.shape
-        assert c == (8 if self.precision != L.PT_PRECISION_BF16 else 4)
+        assert c == (8 if self.split else 4)
         prob = torch.empty((n, H, W), dtype=torch.float32, device=self._tdev)
         logits = torch.empty((n, H, W), dtype=torch.float32, device=self._tdev) if want_logits else None
         L.check(self.lib.pt_det_forward_net(self._h, _ptr(x), n, H, W, _ptr(prob), _ptr(logits), self._stream()),
@@ -158,7 +175,7 @@ class HipEngine:
     def layout_preprocess(self, pages: torch.Tensor, inp_h: int = 800, inp_w: int = 608) -> torch.Tensor:
         self._chk(pages, torch.uint8, "pages")
         n, h, w, _ = pages.shape
-        out = torch.empty((n, inp_h, inp_w, 8 if self.precision != L.PT_PRECISION_BF16 else 4), dtype=torch.bfloat16,
+        out = torch.empty((n, inp_h, inp_w, 8 if self.split else 4), dtype=self.act_dtype,
                           device=self._tdev)
         L.check(self.lib.pt_layout_preprocess(self._h, _ptr(pages), n, h, w, inp_h, inp_w, _ptr(out), self._stream()),
                 "pt_layout_preprocess")
@@ -166,7 +183,7 @@ class HipEngine:
 
     def layout_forward_net(self, x: torch.Tensor):
         """x bf16 NHWC4 [n,H,W,4|8] -> 4 head maps f32 [n, A_l, 40] (class logits, then box-distribution logits)"""
-        self._chk(x, torch.bfloat16, "x")
+        self._chk(x, self.act_dtype, "x")
         n, H, W, _ = x.shape
         fh, fw = self.layout_plan(H, W)
         heads = [torch.empty((n, fh[l] * fw[l], L.PT_LAYOUT_HEAD_CS), dtype=torch.float32, device=self._tdev) for l in range(4)]
@@ -191,7 +208,7 @@ class HipEngine:
         npg, ph, pw, _ = pages.shape
         n = len(tables)
         tb = _upload(tables.view(np.uint8).reshape(n, -1), self._tdev)
-        out = torch.empty((n, inp_h, inp_w, 8 if self.precision != L.PT_PRECISION_BF16 else 4), dtype=torch.bfloat16,
+        out = torch.empty((n, inp_h, inp_w, 8 if self.split else 4), dtype=self.act_dtype,
                           device=self._tdev)
         L.check(self.lib.pt_tsr_preprocess(self._h, _ptr(pages), npg, ph, pw, _ptr(tb), n, inp_h, inp_w, int(bgr), _ptr(out),
                                            self._stream()), "pt_tsr_preprocess")
@@ -201,9 +218,9 @@ class HipEngine:
         """Lore detector (DLA-34 + DCN, or the ResNet-18 'wireless' one): x bf16 NHWC4 [n,H,W,4] (BF16X3: 8 channels) ->
         dict of fp32 NHWC head maps at H/4 x W/4 ({'hm': [n,h,w,2], 'st': [.,8], 'wh': [.,8], 'ax': [.,256],
         'cr': [.,256], 'reg': [.,2]})."""
-        self._chk(x, torch.bfloat16, "x")
+        self._chk(x, self.act_dtype, "x")
         n, H, W, c = x.shape
-        assert c == (8 if self.precision != L.PT_PRECISION_BF16 else 4)
+        assert c == (8 if self.split else 4)
         h, w = H // 4, W // 4
         bufs = {k: torch.empty((n, h, w, 256 if k in ("ax", "cr") else 8), dtype=torch.float32, device=self._tdev)
                 for k in ("hm", "st", "wh", "ax", "cr", "reg")}
@@ -239,7 +256,7 @@ class HipEngine:
         """DLA-34 forward + decode in one call (sparse ax / cr heads): x bf16 NHWC4 [n,H,W,4|8] -> the outputs of tsr_decode.
         out: (counts i32 [n] zeroed, dets f32 [n,3000,9], logi f32 [n,3000,256]) contiguous device tensors to write into
         (slices of a larger allocation: several micro-batches then feed ONE processor call)"""
-        self._chk(x, torch.bfloat16, "x")
+        self._chk(x, self.act_dtype, "x")
         n, H, W, _ = x.shape
         if out is not None:
             counts, dets, logi = out
@@ -305,15 +322,15 @@ class HipEngine:
         """-> bf16 NHWC4 [n, out_h, out_w, 4] (8 channels in BF16X3 mode)"""
         n = len(images)
         base, desc, mh, mw = self._cls_batch(images)
-        ch = 8 if self.precision != L.PT_PRECISION_BF16 else 4
-        out = torch.empty((n, out_hw[0], out_hw[1], ch), dtype=torch.bfloat16, device=self._tdev)
+        ch = 8 if self.split else 4
+        out = torch.empty((n, out_hw[0], out_hw[1], ch), dtype=self.act_dtype, device=self._tdev)
         L.check(self.lib.pt_cls_preprocess(self._h, _ptr(base), _ptr(desc), n, mh, mw, out_hw[0], out_hw[1], _ptr(out),
                                            self._stream()), "pt_cls_preprocess")
         return out
 
     def cls_forward_net(self, x: torch.Tensor, slot: int = 0, textline: bool = False) -> torch.Tensor:
         """x bf16 NHWC4 [n,H,W,4|8] -> logits f32 [n, class_num] (device)"""
-        self._chk(x, torch.bfloat16, "x")
+        self._chk(x, self.act_dtype, "x")
         n, H, W, _ = x.shape
         logits = torch.empty((n, L.PT_CLS_MAX_CLASSES), dtype=torch.float32, device=self._tdev)
         nc = C.c_int(0)
@@ -426,8 +443,8 @@ class HipEngine:
         self._chk(pages, torch.uint8, "pages")
         n, h, w, _ = pages.shape
         nl = len(lines)
-        shape = (nl, L.PT_REC_H, L.PT_REC_W, 2) if self.precision != L.PT_PRECISION_BF16 else (nl, L.PT_REC_H, L.PT_REC_W)
-        gray = torch.empty(shape, dtype=torch.bfloat16, device=self._tdev)
+        shape = (nl, L.PT_REC_H, L.PT_REC_W, 2) if self.split else (nl, L.PT_REC_H, L.PT_REC_W)
+        gray = torch.empty(shape, dtype=self.act_dtype, device=self._tdev)
         d, px = self._lines_to_device(lines)
         L.check(self.lib.pt_rec_preprocess(self._h, _ptr(pages), n, h, w, _ptr(d), px.ctypes.data_as(C.c_void_p), nl,
                                            _ptr(gray), self._stream()), "pt_rec_preprocess")
@@ -435,7 +452,7 @@ class HipEngine:
 
     def rec_forward_net(self, gray: torch.Tensor):
         """gray bf16 [n,32,640] (BF16X3: [n,32,640,2]) -> (ids int32 [n,160], maxlogit f32 [n,160])."""
-        self._chk(gray, torch.bfloat16, "gray")
+        self._chk(gray, self.act_dtype, "gray")
         n = gray.shape[0]
         ids = torch.empty((n, L.PT_REC_T), dtype=torch.int32, device=self._tdev)
         mx = torch.empty((n, L.PT_REC_T), dtype=torch.float32, device=self._tdev)
@@ -518,9 +535,9 @@ class HipEngine:
         assert c == 3 and h % 8 == 0 and w % 8 == 0
         xp = torch.zeros((n, h, w, 32), dtype=torch.float32, device=self._tdev)
         xp[..., :3] = x.permute(0, 2, 3, 1)
-        hi = xp.to(torch.bfloat16)
-        if self.precision != L.PT_PRECISION_BF16:
-            hi = torch.cat([hi, (xp - hi.float()).to(torch.bfloat16)], -1)
+        hi = xp.to(self.act_dtype)
+        if self.split:
+            hi = torch.cat([hi, (xp - hi.float()).to(self.act_dtype)], -1)
         hi = hi.contiguous()
         f3 = torch.empty((n, h // 8, w // 8, 512), dtype=torch.float32, device=self._tdev)
         L.check(self.lib.pt_tsr_mtl_backbone_net(self._h, _ptr(hi), n, h, w, _ptr(f3), self._stream()), "pt_tsr_mtl_backbone_net")
@@ -542,8 +559,8 @@ class HipEngine:
         assert tables.dtype == TSR_TABLE_DTYPE
         n = len(tables)
         d_tab = _upload(tables.view(np.uint8).reshape(-1), self._tdev)
-        m = 2 if self.precision != L.PT_PRECISION_BF16 else 1
-        out = torch.empty((n, size, size, 32 * m), dtype=torch.bfloat16, device=self._tdev)
+        m = 2 if self.split else 1
+        out = torch.empty((n, size, size, 32 * m), dtype=self.act_dtype, device=self._tdev)
         L.check(self.lib.pt_tsr_mtl_preprocess(self._h, _ptr(pages), pages.shape[0], pages.shape[1], pages.shape[2], _ptr(d_tab), n, size,
                                                _ptr(out), self._stream()), "pt_tsr_mtl_preprocess")
         return out
@@ -591,7 +608,7 @@ class HipEngine:
                   split: int = 0) -> torch.Tensor:
         """Single conv on the MFMA kernel.  x bf16 [B,H,W,Cin]; w_tiled int16/bf16 bits; bias f32 [N].  split: 0 plain bf16, 1 (hi | lo)
         tensors with the three-pass tiles, 2 the same tensors with the two-pass fp16 tiles (weights.tile_conv_weight_f16x2)."""
-        self._chk(x, torch.bfloat16, "x")
+        self._chk(x, self.act_dtype, "x")
         self._chk(bias, torch.float32, "bias")
         B, H, W, Cin = x.shape
         m = 2 if split else 1
@@ -601,9 +618,9 @@ class HipEngine:
         Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
         if out is None:
             if shuffle_cout:
-                out = torch.empty((B, 2 * Ho, 2 * Wo, shuffle_cout * m), dtype=torch.bfloat16, device=self._tdev)
+                out = torch.empty((B, 2 * Ho, 2 * Wo, shuffle_cout * m), dtype=self.act_dtype, device=self._tdev)
             else:
-                out = torch.empty((B, Ho * rep, Wo * rep, N * m), dtype=torch.bfloat16, device=self._tdev)
+                out = torch.empty((B, Ho * rep, Wo * rep, N * m), dtype=self.act_dtype, device=self._tdev)
         L.check(self.lib.pt_op_conv2d(self._h, _ptr(x), B, H, W, Cin, _ptr(w_tiled), _ptr(bias), N, ks, stride,
                                       _ptr(out), out.shape[-1], out_coff, rep, shuffle_cout, _ptr(res), res_mode,
                                       int(relu), int(split), out.shape[-1] // 2, self._stream()), "pt_op_conv2d")      # relu: bool, or the epilogue's activation code (0 none, 1 ReLU, 2 hardswish)
@@ -612,7 +629,7 @@ class HipEngine:
     def op_dcn(self, x: torch.Tensor, om: torch.Tensor, w_tiled: torch.Tensor, bias: torch.Tensor, relu: bool = True, split: int = 0) -> torch.Tensor:
         """Fused modulated deformable 3x3 convolution (lore/dcnv2.py:71-86) as a single operator.  x bf16 [B,H,W,C] ([hi | lo] when split),
         om fp32 [B,H,W,32] (18 offsets, 9 mask logits, 5 unused), w_tiled = the [N, 9C, 1, 1] weight tiled as a 1x1 conv, bias fp32 [N]."""
-        self._chk(x, torch.bfloat16, "x")
+        self._chk(x, self.act_dtype, "x")
         self._chk(om, torch.float32, "om")
         self._chk(bias, torch.float32, "bias")
         B, H, W, Cc = x.shape
@@ -621,7 +638,7 @@ class HipEngine:
         if tuple(om.shape) != (B, H, W, 32):
             raise ValueError(f"op_dcn: om must be [B,H,W,32], got {tuple(om.shape)}")
         N = bias.numel()
-        out = torch.empty((B, H, W, N * m), dtype=torch.bfloat16, device=self._tdev)
+        out = torch.empty((B, H, W, N * m), dtype=self.act_dtype, device=self._tdev)
         L.check(self.lib.pt_op_dcn(self._h, _ptr(x), _ptr(om), B, H, W, Cc, _ptr(w_tiled), _ptr(bias), N, _ptr(out), int(relu), int(split),
                                    self._stream()), "pt_op_dcn")
         return out
@@ -629,19 +646,19 @@ class HipEngine:
     # ---- single operators of the generic ONNX executor (pdf_table_amd/onnx_exec.py); bf16 NHWC, C a multiple of 8 -------
     # (split=True: the tolerance mode's (hi | lo) tensors -- the last dimension holds [hi(C) | lo(C)], C = shape[-1] // 2)
     def op_dwconv(self, x: torch.Tensor, w_taps: torch.Tensor, bias: torch.Tensor, k: int, stride: int = 1, act: int = 0, split: bool = False) -> torch.Tensor:
-        self._chk(x, torch.bfloat16, "x")
+        self._chk(x, self.act_dtype, "x")
         self._chk(w_taps, torch.float32, "w_taps")
         self._chk(bias, torch.float32, "bias")
         B, H, W, Cc = x.shape
         pad = k // 2
-        out = torch.empty((B, (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1, Cc), dtype=torch.bfloat16, device=self._tdev)
+        out = torch.empty((B, (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1, Cc), dtype=self.act_dtype, device=self._tdev)
         L.check(self.lib.pt_op_dwconv(self._h, _ptr(x), B, H, W, Cc // 2 if split else Cc, _ptr(w_taps), _ptr(bias), k, stride, act, _ptr(out), int(split),
                                       self._stream()), "pt_op_dwconv")
         return out
 
     def op_add(self, a: torch.Tensor, b: torch.Tensor, split: bool = False) -> torch.Tensor:
-        self._chk(a, torch.bfloat16, "a")
-        self._chk(b, torch.bfloat16, "b")
+        self._chk(a, self.act_dtype, "a")
+        self._chk(b, self.act_dtype, "b")
         if a.shape != b.shape:
             raise ValueError(f"op_add: shapes differ: {tuple(a.shape)} vs {tuple(b.shape)}")
         out = torch.empty_like(a)
@@ -650,32 +667,32 @@ class HipEngine:
         return out
 
     def op_maxpool(self, x: torch.Tensor, k: int, stride: int, pad: int, split: bool = False) -> torch.Tensor:
-        self._chk(x, torch.bfloat16, "x")
+        self._chk(x, self.act_dtype, "x")
         B, H, W, Cc = x.shape
-        out = torch.empty((B, (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1, Cc), dtype=torch.bfloat16, device=self._tdev)
+        out = torch.empty((B, (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1, Cc), dtype=self.act_dtype, device=self._tdev)
         L.check(self.lib.pt_op_maxpool(self._h, _ptr(x), B, H, W, Cc // 2 if split else Cc, k, stride, pad, _ptr(out), int(split), self._stream()), "pt_op_maxpool")
         return out
 
     def op_avgpool(self, x: torch.Tensor, k: int, split: bool = False) -> torch.Tensor:
-        self._chk(x, torch.bfloat16, "x")
+        self._chk(x, self.act_dtype, "x")
         B, H, W, Cc = x.shape
-        out = torch.empty((B, H // k, W // k, Cc), dtype=torch.bfloat16, device=self._tdev)
+        out = torch.empty((B, H // k, W // k, Cc), dtype=self.act_dtype, device=self._tdev)
         L.check(self.lib.pt_op_avgpool(self._h, _ptr(x), B, H, W, Cc // 2 if split else Cc, k, _ptr(out), int(split), self._stream()), "pt_op_avgpool")
         return out
 
     def op_chan_mean(self, x: torch.Tensor, split: bool = False) -> torch.Tensor:
         """GlobalAveragePool: [B, H, W, C] -> [B, 1, 1, C]"""
-        self._chk(x, torch.bfloat16, "x")
+        self._chk(x, self.act_dtype, "x")
         B, H, W, Cc = x.shape
         ch = Cc // 2 if split else Cc
         scratch = torch.empty((self.lib.pt_op_chan_mean_scratch_floats(B, ch),), dtype=torch.float32, device=self._tdev)
-        out = torch.empty((B, 1, 1, Cc), dtype=torch.bfloat16, device=self._tdev)
+        out = torch.empty((B, 1, 1, Cc), dtype=self.act_dtype, device=self._tdev)
         L.check(self.lib.pt_op_chan_mean(self._h, _ptr(x), B, H * W, ch, _ptr(scratch), _ptr(out), int(split), self._stream()), "pt_op_chan_mean")
         return out
 
     def op_scale_channels(self, x: torch.Tensor, gate: torch.Tensor, split: bool = False) -> torch.Tensor:
-        self._chk(x, torch.bfloat16, "x")
-        self._chk(gate, torch.bfloat16, "gate")
+        self._chk(x, self.act_dtype, "x")
+        self._chk(gate, self.act_dtype, "gate")
         B, H, W, Cc = x.shape
         if gate.numel() != B * Cc:
             raise ValueError(f"op_scale_channels: gate {tuple(gate.shape)} does not match [{B}, {Cc}]")
@@ -685,7 +702,7 @@ class HipEngine:
         return out
 
     def op_act(self, x: torch.Tensor, kind: int, alpha: float = 0.0, beta: float = 0.0, split: bool = False) -> torch.Tensor:
-        self._chk(x, torch.bfloat16, "x")
+        self._chk(x, self.act_dtype, "x")
         out = torch.empty_like(x)
         ch = x.shape[-1] // 2 if split else x.shape[-1]
         L.check(self.lib.pt_op_act(self._h, _ptr(x), x.numel() // (2 if split else 1), kind, float(alpha), float(beta), _ptr(out), ch, int(split),
@@ -694,8 +711,8 @@ class HipEngine:
 
     def op_copy_channels(self, src: torch.Tensor, dst: torch.Tensor, n: int, src_coff: int = 0, dst_coff: int = 0):
         """dst[..., dst_coff : dst_coff + n] = src[..., src_coff : src_coff + n] (same pixel count; Concat / Slice / Split over channels)"""
-        self._chk(src, torch.bfloat16, "src")
-        self._chk(dst, torch.bfloat16, "dst")
+        self._chk(src, self.act_dtype, "src")
+        self._chk(dst, self.act_dtype, "dst")
         npix = src.numel() // src.shape[-1]
         assert npix == dst.numel() // dst.shape[-1]
         L.check(self.lib.pt_op_copy_channels(self._h, _ptr(src), npix, src.shape[-1], src_coff, _ptr(dst), dst.shape[-1], dst_coff, n, self._stream()),
@@ -708,15 +725,15 @@ class HipEngine:
         L.check(self.lib.pt_copy_bytes(self._h, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), nb, self._stream()), "pt_copy_bytes")
 
     def op_upsample(self, x: torch.Tensor, f: int) -> torch.Tensor:
-        self._chk(x, torch.bfloat16, "x")
+        self._chk(x, self.act_dtype, "x")
         B, H, W, Cc = x.shape
-        out = torch.empty((B, H * f, W * f, Cc), dtype=torch.bfloat16, device=self._tdev)
+        out = torch.empty((B, H * f, W * f, Cc), dtype=self.act_dtype, device=self._tdev)
         L.check(self.lib.pt_op_upsample_nearest(self._h, _ptr(x), B, H, W, Cc, int(f), _ptr(out), self._stream()), "pt_op_upsample_nearest")
         return out
 
     def op_mul(self, a: torch.Tensor, b: torch.Tensor, split: bool = False) -> torch.Tensor:
-        self._chk(a, torch.bfloat16, "a")
-        self._chk(b, torch.bfloat16, "b")
+        self._chk(a, self.act_dtype, "a")
+        self._chk(b, self.act_dtype, "b")
         if a.shape != b.shape:
             raise ValueError(f"op_mul: shapes differ: {tuple(a.shape)} vs {tuple(b.shape)}")
         out = torch.empty_like(a)
@@ -725,7 +742,7 @@ class HipEngine:
         return out
 
     def op_layernorm(self, x: torch.Tensor, c: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float, split: bool = False) -> torch.Tensor:
-        self._chk(x, torch.bfloat16, "x")
+        self._chk(x, self.act_dtype, "x")
         self._chk(gamma, torch.float32, "gamma")
         self._chk(beta, torch.float32, "beta")
         out = torch.empty_like(x)
@@ -735,7 +752,7 @@ class HipEngine:
         return out
 
     def op_softmax(self, x: torch.Tensor, c: int, f32: bool = False, split: bool = False) -> torch.Tensor:
-        self._chk(x, torch.bfloat16, "x")
+        self._chk(x, self.act_dtype, "x")
         rows = x.numel() // x.shape[-1]
         cp = x.shape[-1] // 2 if split else x.shape[-1]
         if f32:
@@ -749,33 +766,33 @@ class HipEngine:
     def op_attention(self, qkv: torch.Tensor, heads: int, d: int, scale: float, out_c: int, split: bool = False) -> torch.Tensor:
         """qkv bf16 [B, 1, T, >= 3 heads d] rows of [q | k | v] -> bf16 [B, 1, T, out_c] (channels heads * d .. out_c are zero); split: both tensors
         carry [hi | lo] halves of that width"""
-        self._chk(qkv, torch.bfloat16, "qkv")
+        self._chk(qkv, self.act_dtype, "qkv")
         B, T = qkv.shape[0], qkv.shape[-2]
         m = 2 if split else 1
-        out = torch.zeros((B, 1, T, int(out_c) * m), dtype=torch.bfloat16, device=self._tdev)
+        out = torch.zeros((B, 1, T, int(out_c) * m), dtype=self.act_dtype, device=self._tdev)
         L.check(self.lib.pt_op_attention(self._h, _ptr(qkv), B, T, int(heads), int(d), qkv.shape[-1] // m, float(scale), _ptr(out), int(out_c), int(split),
                                          self._stream()), "pt_op_attention")
         return out
 
     def op_stem7x7(self, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, split: bool = False) -> torch.Tensor:
-        self._chk(x, torch.bfloat16, "x")
+        self._chk(x, self.act_dtype, "x")
         B, H, W, _ = x.shape
-        out = torch.empty((B, H // 2, W // 2, 128 if split else 64), dtype=torch.bfloat16, device=self._tdev)
+        out = torch.empty((B, H // 2, W // 2, 128 if split else 64), dtype=self.act_dtype, device=self._tdev)
         L.check(self.lib.pt_op_stem7x7(self._h, _ptr(x), B, H, W, _ptr(w), _ptr(bias), _ptr(out), int(split), self._stream()),
                 "pt_op_stem7x7")
         return out
 
     def op_maxpool3x3s2(self, x: torch.Tensor, split: bool = False) -> torch.Tensor:
-        self._chk(x, torch.bfloat16, "x")
+        self._chk(x, self.act_dtype, "x")
         B, H, W, Cc = x.shape
-        out = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), dtype=torch.bfloat16, device=self._tdev)
+        out = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), dtype=self.act_dtype, device=self._tdev)
         L.check(self.lib.pt_op_maxpool3x3s2(self._h, _ptr(x), B, H, W, Cc // 2 if split else Cc, _ptr(out), int(split),
                                             self._stream()),
                 "pt_op_maxpool3x3s2")
         return out
 
     def op_db_head_final(self, x: torch.Tensor, w4x64: torch.Tensor, bias: torch.Tensor, split: bool = False):
-        self._chk(x, torch.bfloat16, "x")
+        self._chk(x, self.act_dtype, "x")
         B, H, W, _ = x.shape
         prob = torch.empty((B, 2 * H, 2 * W), dtype=torch.float32, device=self._tdev)
         logits = torch.empty((B, 2 * H, 2 * W), dtype=torch.float32, device=self._tdev)

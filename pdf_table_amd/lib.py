@@ -33,12 +33,13 @@ PT_DET_PRE_NONE = 2
 PT_PRECISION_BF16 = 0
 PT_PRECISION_BF16X3 = 1
 PT_PRECISION_F16X2 = 2
+PT_PRECISION_F16 = 3          # single-pass IEEE half (ABI 14): fp16 activations and weight tiles, saturating stores
 PT_DET_POST_DB_PP = 0
 PT_DET_POST_DB_TORCH = 1
 PT_TSR_MAX_CELLS = 3000
 PT_REC_H, PT_REC_W, PT_REC_T, PT_REC_NCLS = 32, 640, 160, 7644
 PT_PROF_CLASSES = ("conv3x3", "conv1x1", "stem", "other")
-EXPECTED_ABI = 13         # pt_abi_version() of the library these prototypes were written against (include/pdftable_hip.h)
+EXPECTED_ABI = 14         # pt_abi_version() of the library these prototypes were written against (include/pdftable_hip.h)
 
 _lib = None
 

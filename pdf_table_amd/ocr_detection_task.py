@@ -71,7 +71,7 @@ class OcrDetectionTask(BaseInferTask):
 
     def _construct_model(self, model):
         if self._engine is None:
-            self._engine = HipEngine(int(str(self.device).split(":")[-1]) if ":" in str(self.device) else 0)
+            self._engine = self._new_engine()
         onnx_path = self._onnx_file()
         if model == "db_pp" and onnx_path is None and not self.kwargs.get("allow_stand_in", False):
             raise RuntimeError(f"'{self._config.model_path}' is an ONNX graph that is not part of the reference tree; pass "
@@ -89,7 +89,7 @@ class OcrDetectionTask(BaseInferTask):
             except UnsupportedOnnxGraph:
                 arch, sd = "generic", None
             if arch == "db_resnet18":
-                self._engine.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(sd))
+                self._engine.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(sd, fmt=self._engine.weight_fmt))
             elif arch == "generic":
                 # an architecture without a dedicated launch graph (the real PP-OCR detectors: PP-LCNetV3 / MobileNetV3 +
                 # RSE-FPN + DB head): the layer list runs operator by operator between the engine's pre-processing and
@@ -123,9 +123,9 @@ class OcrDetectionTask(BaseInferTask):
                                    "or synthetic_seed=<int>")
             sd = torch.load(path, map_location="cpu", weights_only=True)
         if nas:
-            self._engine.load_weights(L.PT_MODEL_DB_NAS, pack_db_nas(sd))
+            self._engine.load_weights(L.PT_MODEL_DB_NAS, pack_db_nas(sd, fmt=self._engine.weight_fmt))
         else:
-            self._engine.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(sd))
+            self._engine.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(sd, fmt=self._engine.weight_fmt))
         self._model = self._predict
 
     def _onnx_file(self):

@@ -49,7 +49,7 @@ class OcrLayoutTask(BaseInferTask):
 
     def _construct_model(self, model):
         if self._engine is None:
-            self._engine = HipEngine(int(str(self.device).split(":")[-1]) if ":" in str(self.device) else 0)
+            self._engine = self._new_engine()
         ncls = len(self._config.labels)
         self._exec = None
         onnx_path = self._onnx_file()
@@ -72,7 +72,7 @@ class OcrLayoutTask(BaseInferTask):
                                    "export from the hub (no network here, and the ONNX importer is SURVEY.md section 8f-3); pass "
                                    "task_path=<dir with a PicoDet state_dict> or synthetic_seed=<int>")
             sd = torch.load(path, map_location="cpu", weights_only=True)
-        self._engine.load_weights(L.PT_MODEL_PICODET, pack_picodet(sd, ncls))
+        self._engine.load_weights(L.PT_MODEL_PICODET, pack_picodet(sd, ncls, fmt=self._engine.weight_fmt))
         self._model = self._predict
 
     def _build_processor(self):

@@ -69,7 +69,7 @@ class OcrRecognitionTask(BaseInferTask):
             raise RuntimeError(f"recogniser '{self.model}': no model.onnx / inference.onnx under {self._task_path!r} -- the reference would "
                                f"download '{self._config.model_path}' from the hub (no network here); pass task_path=<dir or file>")
         if self._engine is None:
-            self._engine = HipEngine(int(str(self.device).split(":")[-1]) if ":" in str(self.device) else 0)
+            self._engine = self._new_engine()
         self._exec = HipGraphExecutor(onnx_path, engine=self._engine, precision=self._exec_precision)
         if len(self._exec.outputs) != 1:
             from .onnx_import import UnsupportedOnnxGraph
@@ -101,7 +101,7 @@ class OcrRecognitionTask(BaseInferTask):
             # static exports have their batch size baked in: one graph walk per line, the mini-batch's walks captured into one HIP graph
             x = img.permute(0, 2, 3, 1).contiguous()
             if not self._exec.split:                         # the tolerance mode takes the fp32 image and splits it into (hi, lo) itself
-                x = x.to(torch.bfloat16)
+                x = x.to(self._exec.adt)
             outs = self._exec.run_lines_graphed(x, 3) if self._batch1 else [self._exec.run_device_graphed(x, 3)]    # dynamic batch: one walk
             probs = []
             for (a,) in outs:
@@ -126,7 +126,7 @@ class OcrRecognitionTask(BaseInferTask):
             raise RuntimeError(f"recogniser '{model}' ({self._config.model_path}) is not built on the HIP engine yet; "
                                "only the in-tree CRNN and ConvNextViT are (SURVEY.md section 8f)")
         if self._engine is None:
-            self._engine = HipEngine(int(str(self.device).split(":")[-1]) if ":" in str(self.device) else 0)
+            self._engine = self._new_engine()
         vocab = None
         if self.synthetic_seed is not None:
             from .synth_weights import convnext_vit_state_dict, crnn_state_dict
@@ -156,9 +156,9 @@ class OcrRecognitionTask(BaseInferTask):
             with open(os.path.join(mp, "vocab.txt"), "r", encoding="utf-8") as f:
                 vocab = [ln.strip("\n") for ln in f.readlines()]
         if model == "ConvNextViT":
-            self._engine.load_weights(L.PT_MODEL_CONVNEXT_VIT, pack_convnext_vit(sd))
+            self._engine.load_weights(L.PT_MODEL_CONVNEXT_VIT, pack_convnext_vit(sd, fmt=self._engine.weight_fmt))
         else:
-            self._engine.load_weights(L.PT_MODEL_CRNN, pack_crnn(sd))
+            self._engine.load_weights(L.PT_MODEL_CRNN, pack_crnn(sd, fmt=self._engine.weight_fmt))
         self._vocab = vocab
         self._model = self._predict
 

@@ -63,7 +63,7 @@ class OcrTableStructureTask(BaseInferTask):
 
     def _construct_model(self, model):
         if self._engine is None:
-            self._engine = HipEngine(int(str(self.device).split(":")[-1]) if ":" in str(self.device) else 0)
+            self._engine = self._new_engine()
         cfg = self._config
         if model == "MtlTabNet":
             return self._construct_mtl()
@@ -91,10 +91,10 @@ class OcrTableStructureTask(BaseInferTask):
                 raise RuntimeError(f"no Lore checkpoint under {mp}: the reference would download it from the hub (no "
                                    "network here); pass task_path=<dir> or synthetic_seed=<int>")
         if cfg.backbone == "ResNet-18":
-            self._engine.load_weights(L.PT_MODEL_LORE_RESNET18, pack_lore_wireless(det_sd))
+            self._engine.load_weights(L.PT_MODEL_LORE_RESNET18, pack_lore_wireless(det_sd, fmt=self._engine.weight_fmt))
         else:
-            self._engine.load_weights(L.PT_MODEL_LORE_DLA34, pack_lore_dla34(det_sd))
-        self._engine.load_weights(L.PT_MODEL_LORE_PROCESSOR, pack_lore_processor(proc_sd))
+            self._engine.load_weights(L.PT_MODEL_LORE_DLA34, pack_lore_dla34(det_sd, fmt=self._engine.weight_fmt))
+        self._engine.load_weights(L.PT_MODEL_LORE_PROCESSOR, pack_lore_processor(proc_sd, fmt=self._engine.weight_fmt))
         self._model = self._predict
 
     def _construct_mtl(self):
@@ -128,8 +128,8 @@ class OcrTableStructureTask(BaseInferTask):
                                    f"{self._convertor.num_classes()} / {self._convertor.num_classes_cell()})")
         bb = dict(bb)
         bb["conv1.weight"] = bb["conv1.weight"][:, [2, 1, 0]].contiguous()
-        self._engine.load_weights(L.PT_MODEL_MTL_BACKBONE, pack_mtl_backbone(bb))
-        self._engine.load_weights(L.PT_MODEL_MTL_DECODER, pack_mtl_decoder(dec, self._convertor.decoder_cfg()))
+        self._engine.load_weights(L.PT_MODEL_MTL_BACKBONE, pack_mtl_backbone(bb, fmt=self._engine.weight_fmt))
+        self._engine.load_weights(L.PT_MODEL_MTL_DECODER, pack_mtl_decoder(dec, self._convertor.decoder_cfg(), fmt=self._engine.weight_fmt))
         self._model = self._predict
 
     def _build_processor(self):

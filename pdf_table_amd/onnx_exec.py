@@ -47,6 +47,7 @@ import os
 import numpy as np
 import torch
 
+from . import lib as L
 from .engine import HipEngine
 from .onnx_import import Layer, OnnxGraph, UnsupportedOnnxGraph, load_onnx
 from .weights import split_bf16, tile_conv_weight, tile_conv_weight_x3
@@ -100,13 +101,24 @@ class _Scores:
 
 class HipGraphExecutor:
     def __init__(self, src, engine: Optional[HipEngine] = None, device: int = 0, precision: str = "bf16"):
-        if precision not in ("bf16", "bf16x3"):
-            raise ValueError(f"precision '{precision}': 'bf16' (throughput) or 'bf16x3' (tolerance mode, (hi | lo) activations)")
+        if precision not in ("bf16", "bf16x3", "f16"):
+            raise ValueError(f"precision '{precision}': 'bf16' (throughput), 'f16' (single-pass IEEE half, the reference's fp16) or 'bf16x3' "
+                             "(tolerance mode, (hi | lo) activations)")
         self.precision = precision
         self.split = precision == "bf16x3"
         self.m = 2 if self.split else 1                   # halves per activation: .t[..., :Cp] = hi, .t[..., Cp:] = lo
+        self.fmt = "f16" if precision == "f16" else "bf16"       # 16-bit storage format of activations and weight tiles (csrc/act16.h)
+        self.adt = torch.float16 if precision == "f16" else torch.bfloat16
         self.graph: OnnxGraph = src if isinstance(src, OnnxGraph) else load_onnx(src)
-        self.eng = engine or HipEngine(device)
+        want = {"bf16": L.PT_PRECISION_BF16, "bf16x3": L.PT_PRECISION_BF16X3, "f16": L.PT_PRECISION_F16}[precision]
+        if engine is None:
+            engine = HipEngine(device)
+            engine.set_precision(want)
+        elif (engine.precision == L.PT_PRECISION_F16) != (precision == "f16"):
+            # the operator entry points interpret 16-bit tensors in the ENGINE's storage format: a mismatch would read fp16 bits as bf16
+            raise ValueError(f"executor precision '{precision}' on an engine whose precision is {engine.precision}: set the engine's precision "
+                             "(HipEngine.set_precision) to the executor's before building it")
+        self.eng = engine
         self.layers: List[Layer] = self.graph.layers()
         bad = [f"{l.name} ({l.attrs.get('onnx_op', l.op)})" for l in self.layers if l.op == "unsupported"]
         if bad:
@@ -182,14 +194,14 @@ class HipGraphExecutor:
         return d
 
     def _tile(self, w: torch.Tensor) -> np.ndarray:
-        return tile_conv_weight_x3(w) if self.split else tile_conv_weight(w)
+        return tile_conv_weight_x3(w) if self.split else tile_conv_weight(w, self.fmt)
 
     def _cp(self, x: _Act) -> int:
         """padded channels of ONE half"""
         return x.t.shape[-1] // self.m
 
     def _zeros(self, lead, cp: int) -> torch.Tensor:
-        return torch.zeros(tuple(lead) + (cp * self.m,), dtype=torch.bfloat16, device=self.eng._tdev)
+        return torch.zeros(tuple(lead) + (cp * self.m,), dtype=self.adt, device=self.eng._tdev)
 
     def _copy(self, src: torch.Tensor, dst: torch.Tensor, n: int, src_coff: int = 0, dst_coff: int = 0):
         """channels [src_coff, src_coff + n) of src -> [dst_coff, ..) of dst, both halves in the tolerance mode"""
@@ -236,7 +248,7 @@ class HipGraphExecutor:
                     sh, sl = split_bf16(stem)
                     wst = np.stack([to_bf16_bits(sh).reshape(64, 224), to_bf16_bits(sl).reshape(64, 224)])
                 else:
-                    wst = to_bf16_bits(stem).reshape(64, 224)
+                    wst = to_bf16_bits(stem, self.fmt).reshape(64, 224)
                 d = self._dev[k] = {"w": self._up(wst.view(np.int16)), "b": bp.to(self.eng._tdev), "n": n0}
             if x.t.shape[1] % 2 or x.t.shape[2] % 2:
                 raise UnsupportedOnnxGraph(f"{lay.name}: the 7x7 / stride-2 stem kernel needs even image sizes")
@@ -302,7 +314,7 @@ class HipGraphExecutor:
             raise ValueError(f"expected an NCHW batch, got shape {tuple(xt.shape)}")
         outs = []
         nhwc = xt.permute(0, 2, 3, 1).to(self.eng._tdev)
-        for a in self.run_device(nhwc if self.split else nhwc.to(torch.bfloat16), xt.shape[1]):
+        for a in self.run_device(nhwc if self.split else nhwc.to(self.adt), xt.shape[1]):
             v = self.values(a)
             if a.seq:                                    # token rows: [B, T, C]
                 outs.append(v[:, 0].contiguous().cpu().numpy())
@@ -529,13 +541,23 @@ class HipGraphExecutor:
         cp = (c + 31) // 32 * 32                         # the image itself: 32 channels are enough for the first GEMM's K
         first = self._zeros(nhwc.shape[:-1], cp)
         if nhwc.dtype == torch.float32:
-            hi = nhwc[..., :c].to(torch.bfloat16)
+            hi = nhwc[..., :c].to(self.adt)
             self.eng.op_copy_channels(hi.contiguous(), first, c)
             if self.split:
-                lo = (nhwc[..., :c] - hi.float()).to(torch.bfloat16)
+                lo = (nhwc[..., :c] - hi.float()).to(self.adt)
                 self.eng.op_copy_channels(lo.contiguous(), first, c, dst_coff=cp)
         else:
-            self.eng.op_copy_channels(nhwc.contiguous(), first, c)
+            if nhwc.dtype != self.adt:
+                raise ValueError(f"run_device: a {nhwc.dtype} batch for a '{self.precision}' executor (expected {self.adt} or float32)")
+            nhwc = nhwc.contiguous()
+            self.eng.op_copy_channels(nhwc, first, c)
+            if self.split:
+                # the engine's pre-processing kernels in PT_PRECISION_BF16X3 write [hi (c4) | lo (c4)]: the lo half travels too (without it the
+                # normalised image is rounded to 8 significant bits before the first conv and the 1e-3 contract of this mode is not met --
+                # ADVICE r04); a plain 16-bit batch (c4 channels, an engine in PT_PRECISION_BF16) has lo = 0
+                half = nhwc.shape[-1] // 2
+                if nhwc.shape[-1] % 2 == 0 and half >= c and self.eng.split:
+                    self.eng.op_copy_channels(nhwc, first, c, src_coff=half, dst_coff=cp)
         env: Dict[str, object] = {self.inputs[0].name: _Act(first, c)}
         R = self._realize
         skip = set()                                     # Add / activation layers folded into a convolution's epilogue (self._fuse)

@@ -556,7 +556,7 @@ class HipOnnxSession:
             self.arch, self.state_dict = "generic", None
         if self.arch == "db_resnet18":
             self.engine = engine or HipEngine(device)
-            self.engine.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(self.state_dict))
+            self.engine.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(self.state_dict, fmt=self.engine.weight_fmt))
             return
         if self.arch != "generic" and any(l.op == "lstm" for l in self.graph.layers()):
             raise UnsupportedOnnxGraph(f"'{self.arch}' imports as weights (see the task classes) but has no session surface: its "
@@ -589,15 +589,16 @@ class HipOnnxSession:
         dev = self.engine._tdev
         t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev).permute(0, 2, 3, 1)
         n, h, w, _ = t.shape
-        if self.engine.precision != self._L.PT_PRECISION_BF16:
-            hi = t.to(torch.bfloat16)
-            lo = (t - hi.float()).to(torch.bfloat16)
-            x8 = torch.zeros((n, h, w, 8), dtype=torch.bfloat16, device=dev)
+        adt = self.engine.act_dtype                  # torch.float16 under PT_PRECISION_F16, else torch.bfloat16
+        if self.engine.split:
+            hi = t.to(adt)
+            lo = (t - hi.float()).to(adt)
+            x8 = torch.zeros((n, h, w, 8), dtype=adt, device=dev)
             x8[..., :3], x8[..., 4:7] = hi, lo
             xin = x8
         else:
-            xin = torch.zeros((n, h, w, 4), dtype=torch.bfloat16, device=dev)
-            xin[..., :3] = t.to(torch.bfloat16)
+            xin = torch.zeros((n, h, w, 4), dtype=adt, device=dev)
+            xin[..., :3] = t.to(adt)
         prob = self.engine.det_forward_net(xin.contiguous())
         out = prob.cpu().numpy()[:, None]
         return [out.astype(x.dtype) if x.dtype == np.float16 else out]

@@ -60,8 +60,19 @@ class OcrTablePipeline:
                  tsr_task_path: Optional[str] = None, layout_model: str = "picodet", layout_task_type: str = "en",
                  layout_task_path: Optional[str] = None, text_orientation: bool = False,
                  orientation_task_path: Optional[str] = None, table_html: bool = False, overlap_rec: bool = True,
-                 rotate_upside_down: bool = True, aux_layout: bool = False, tsr_on_aux: bool = False, lookahead: int = 1, **kwargs):
+                 rotate_upside_down: bool = True, aux_layout: bool = False, tsr_on_aux: bool = False, lookahead: int = 1,
+                 precision: str = "bf16", **kwargs):
         self.engine = HipEngine(device)
+        # arithmetic of every stage on this engine: "bf16" (BASELINE.json's), "fp16" (the reference's own default precision,
+        # base_infer_task.py:56-57: the engine's single-pass IEEE-half mode, same speed, 8x finer rounding) or "fp32" (three-pass pair mode)
+        _p = str(precision).lower()
+        if _p in ("fp16", "f16", "half", "float16"):
+            self.engine.set_precision(L.PT_PRECISION_F16)
+        elif _p in ("fp32", "bf16x3", "float32"):
+            self.engine.set_precision(L.PT_PRECISION_BF16X3)
+        elif _p != "bf16":
+            raise ValueError(f"precision={precision!r}: expected 'bf16', 'fp16' or 'fp32'")
+        kwargs = dict(kwargs, precision=precision)
         # predict_stream() schedule switches: layout / the Lore processor on an auxiliary stream beside the main one.  Off: ONE compute
         # stream measured faster (the weight-stationary cluster LSTM wants the GPU to itself, and concurrent small kernels slowed the
         # large ones: 500 vs 590 pages/s on 64-page batches), at the price of results arriving three batches behind instead of two

@@ -32,9 +32,16 @@ _DT = {"bf16": 0, "f32": 1, "i32": 2}
 __all__ = ["pack_db_resnet18", "pack_crnn", "pack_lore_dla34", "pack_lore_processor", "pack_picodet", "pack_lore_wireless", "pack_db_nas", "pack_pplcnet", "pack_convnext_vit", "pack_mtl_backbone", "pack_mtl_decoder", "write_blob", "fold_conv_bn", "to_bf16_bits"]
 
 
-def to_bf16_bits(t: torch.Tensor) -> np.ndarray:
-    """fp32 tensor -> uint16 array of bfloat16 bits (round to nearest even)."""
-    return t.detach().to(torch.float32).contiguous().to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+FORMATS = {"bf16": torch.bfloat16, "f16": torch.float16}      # 16-bit storage formats of the engine (csrc/act16.h): PT_PRECISION_BF16* / PT_PRECISION_F16
+
+
+def to_bf16_bits(t: torch.Tensor, fmt: str = "bf16") -> np.ndarray:
+    """fp32 tensor -> uint16 array of the bits of its 16-bit rounding (round to nearest even): bfloat16, or IEEE half for
+    ``fmt="f16"`` (saturating at +-65504 like the engine's stores; folded weights are nowhere near)."""
+    t = t.detach().to(torch.float32).contiguous()
+    if fmt == "f16":
+        t = t.clamp(-65504.0, 65504.0)
+    return t.to(FORMATS[fmt]).view(torch.int16).numpy().view(np.uint16)
 
 
 def fold_conv_bn(sd: Dict[str, torch.Tensor], conv: str, bn: Optional[str], transposed: bool = False
@@ -51,18 +58,19 @@ def fold_conv_bn(sd: Dict[str, torch.Tensor], conv: str, bn: Optional[str], tran
     return w.float(), b.float()
 
 
-def tile_conv_weight(w: torch.Tensor) -> np.ndarray:
-    """[N, Cin, kh, kw] fp32 -> bf16 bits [N/64][Cin/32][kh*kw][64][32]."""
+def tile_conv_weight(w: torch.Tensor, fmt: str = "bf16") -> np.ndarray:
+    """[N, Cin, kh, kw] fp32 -> 16-bit tiles [N/64][Cin/32][kh*kw][64][32] (bf16 bits, or fp16 bits for ``fmt="f16"``)."""
     n, cin, kh, kw = w.shape
     assert n % 64 == 0 and cin % 32 == 0, (n, cin)
     t = w.reshape(n // 64, 64, cin // 32, 32, kh, kw).permute(0, 2, 4, 5, 1, 3).contiguous()
-    return to_bf16_bits(t).reshape(n // 64, cin // 32, kh * kw, 64, 32)
+    return to_bf16_bits(t, fmt).reshape(n // 64, cin // 32, kh * kw, 64, 32)
 
 
-def split_bf16(t: torch.Tensor):
-    """fp32 -> (hi, lo) with hi = bf16(t), lo = bf16(t - hi), both returned as fp32 tensors."""
-    hi = t.to(torch.bfloat16).to(torch.float32)
-    lo = (t - hi).to(torch.bfloat16).to(torch.float32)
+def split_bf16(t: torch.Tensor, fmt: str = "bf16"):
+    """fp32 -> (hi, lo) with hi = round16(t), lo = round16(t - hi), both returned as fp32 tensors."""
+    dt = FORMATS[fmt]
+    hi = t.to(dt).to(torch.float32)
+    lo = (t - hi).to(dt).to(torch.float32)
     return hi, lo
 
 
@@ -84,16 +92,30 @@ def tile_conv_weight_f16x2(w: torch.Tensor) -> np.ndarray:
 
 
 class _Blob:
-    def __init__(self, x3: bool = True):
+    """One packed model.  ``fmt``: the 16-bit storage format every "bf16"-tagged tensor of the blob is rounded to -- "bf16" (PT_PRECISION_BF16 and,
+    with ``x3``, the pair modes) or "f16" (PT_PRECISION_F16: single-pass IEEE half, no pair tiles).  An f16 blob carries the marker tensor
+    ``__act_f16__``; the engine refuses a blob whose format is not the one its precision computes in (csrc/common.h pt_model_format_ok)."""
+
+    def __init__(self, x3: bool = True, fmt: str = "bf16"):
+        assert fmt in FORMATS, fmt
         self.items: "OrderedDict[str, Tuple[int, np.ndarray]]" = OrderedDict()
-        self.x3 = x3   # also emit the (hi, lo) tiles of the BF16X3 precision mode
+        self.fmt = fmt
+        self.x3 = x3 and fmt == "bf16"   # also emit the (hi, lo) tiles of the BF16X3 precision mode
+        if fmt == "f16":
+            self.add("__act_f16__", np.ones(1, np.int32), "i32")
+
+    def bits(self, t: torch.Tensor) -> np.ndarray:
+        return to_bf16_bits(t, self.fmt)
+
+    def split(self, t: torch.Tensor):
+        return split_bf16(t, self.fmt)
 
     def add(self, name: str, arr: np.ndarray, dtype: str):
         assert len(name) < 96 and arr.ndim <= 6
         self.items[name] = (_DT[dtype], np.ascontiguousarray(arr))
 
     def add_conv(self, name: str, w: torch.Tensor, b: torch.Tensor):
-        self.add(name + ".w", tile_conv_weight(w), "bf16")
+        self.add(name + ".w", tile_conv_weight(w, self.fmt), "bf16")
         if self.x3:
             self.add(name + ".w3", tile_conv_weight_x3(w), "bf16")
             self.add(name + ".wh", tile_conv_weight_f16x2(w), "bf16")      # PT_PRECISION_F16X2 (fp16 bits)
@@ -144,18 +166,19 @@ def _phase_conv_weights(w: torch.Tensor) -> torch.Tensor:
     return ph.reshape(4 * w.shape[0], w.shape[1], 3, 3).float()
 
 
-def pack_db_resnet18(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
+def pack_db_resnet18(sd: Dict[str, torch.Tensor], x3: bool = True, fmt: str = "bf16") -> bytes:
     """``DBModel`` state_dict (db_net/dbnet.py:715-728) -> blob for PT_MODEL_DB_RESNET18.
     ``x3``: also pack the (hi, lo) weight tiles that PT_PRECISION_BF16X3 uses (3x the conv weight bytes)."""
-    bl = _Blob(x3)
+    bl = _Blob(x3, fmt)
+    x3 = bl.x3
     # stem: [64,3,7,7] -> [64][r=7][s=8][c=4], tap s=7 / channel c=3 are zero
     w, b = fold_conv_bn(sd, "backbone.conv1", "backbone.bn1")
     stem = torch.zeros(64, 7, 8, 4)
     stem[:, :, :7, :3] = w.permute(0, 2, 3, 1)
-    bl.add("stem.w", to_bf16_bits(stem).reshape(64, 224), "bf16")
+    bl.add("stem.w", bl.bits(stem).reshape(64, 224), "bf16")
     if x3:
-        sh, sl = split_bf16(stem)
-        bl.add("stem.w3", np.stack([to_bf16_bits(sh).reshape(64, 224), to_bf16_bits(sl).reshape(64, 224)]), "bf16")
+        sh, sl = bl.split(stem)
+        bl.add("stem.w3", np.stack([bl.bits(sh).reshape(64, 224), bl.bits(sl).reshape(64, 224)]), "bf16")
     bl.add("stem.b", b.numpy(), "f32")
     for li in range(1, 5):
         for bi in range(2):
@@ -196,23 +219,24 @@ def pack_db_resnet18(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
     wn = wt.permute(2, 3, 1, 0).reshape(4 * 64, 64, 1, 1)
     bl.add_conv("bin3", wn, bt.repeat(4))
     w6, b6 = fold_conv_bn(sd, "decoder.binarize.6", None, transposed=True)  # [64, 1, 2, 2]
-    bl.add("bin6.w", to_bf16_bits(w6[:, 0].permute(1, 2, 0).reshape(4, 64)), "bf16")
+    bl.add("bin6.w", bl.bits(w6[:, 0].permute(1, 2, 0).reshape(4, 64)), "bf16")
     bl.add("bin6.wf32", w6[:, 0].permute(1, 2, 0).reshape(4, 64).contiguous().numpy().astype(np.float32), "f32")
     bl.add("bin6.b", b6.numpy().reshape(1), "f32")
     return bl.tobytes()
 
 
-def pack_crnn(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
+def pack_crnn(sd: Dict[str, torch.Tensor], x3: bool = True, fmt: str = "bf16") -> bytes:
     """``CRNN`` state_dict (crnn/modeling_crnn.py:40-90) -> blob for PT_MODEL_CRNN.
 
     conv0 (K = 9) stays fp32 for the VALU kernel; conv4's (2,1) kernel is flattened to a 1x1 GEMM over
     K = kh*512 + ci (the preceding pool writes H into channels); each LSTM's two directions share one input
     projection GEMM (N = 2048, both biases folded in); W_hh is stored [hi|lo][dir][1024][256]; the classifier is
     padded from 7644 to 7680 classes with zero weights and a -3e38 bias so that padding can never win the arg-max."""
-    bl = _Blob(x3)
+    bl = _Blob(x3, fmt)
+    x3 = bl.x3
     w0, b0 = fold_conv_bn(sd, "conv0.0", "conv0.1")
     bl.add("conv0.wf32", w0.reshape(64, 9).numpy().astype(np.float32), "f32")
-    bl.add("conv0.wbf", w0.reshape(64, 9).to(torch.bfloat16).float().numpy(), "f32")
+    bl.add("conv0.wbf", w0.reshape(64, 9).to(FORMATS[fmt]).float().numpy(), "f32")     # the 16-bit rounding of the single-pass modes, held in fp32
     bl.add("conv0.b", b0.numpy(), "f32")
     for name, cv, bn in (("conv1", "conv1.0", "conv1.1"), ("conv2a", "conv2.0", "conv2.1"), ("conv2b", "conv2.3", "conv2.4"),
                          ("conv3a", "conv3.0", "conv3.1"), ("conv3b", "conv3.3", "conv3.4")):
@@ -229,13 +253,13 @@ def pack_crnn(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
         perm = torch.arange(2048).view(2, 4, 256).permute(0, 2, 1).reshape(-1)
         bl.add_conv(f"lstm{li}.xproj", wih[perm].reshape(2048, -1, 1, 1).float(), bias[perm].float())
         whh = torch.stack([sd[r + "weight_hh_l0"], sd[r + "weight_hh_l0_reverse"]], 0).float()   # [2, 1024, 256]
-        hi, lo = split_bf16(whh)
+        hi, lo = bl.split(whh)
         # MFMA-fragment order: the kernel's wave `wave` reads, for (half, kq, gate, h), one contiguous 1 KB record of
         # 64 lanes x 8 k-values -- eight full 128-byte lines per load instead of 32 quarter-used ones
         def frag(w):     # [2, 1024 = (gate 4, wave 4, h 2, lx 32), 256 = (half 4, kq 4, q 2, j 8)]
             return (w.reshape(2, 4, 4, 2, 32, 4, 4, 2, 8).permute(0, 2, 5, 6, 1, 3, 7, 4, 8).contiguous()
                     .reshape(2, 1024, 256))
-        bl.add(f"lstm{li}.whh", np.stack([to_bf16_bits(frag(hi)), to_bf16_bits(frag(lo))]), "bf16")
+        bl.add(f"lstm{li}.whh", np.stack([bl.bits(frag(hi)), bl.bits(frag(lo))]), "bf16")
         we = sd[p + ".embedding.weight"].float()
         bl.add_conv(f"lstm{li}.emb", we.reshape(we.shape[0], we.shape[1], 1, 1), sd[p + ".embedding.bias"].float())
     wc = sd["cls.weight"].float()
@@ -262,7 +286,7 @@ def _pad_conv(w: torch.Tensor, b: torch.Tensor, n_to: int, cin_to: int):
     return wp, bp
 
 
-def pack_lore_dla34(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
+def pack_lore_dla34(sd: Dict[str, torch.Tensor], x3: bool = True, fmt: str = "bf16") -> bytes:
     """``DLASeg`` state_dict -> blob for PT_MODEL_LORE_DLA34.
 
     * every Conv->BN pair folded; the 16-input-channel levels (level0, level1) are packed tap-major for the thin kernel;
@@ -271,16 +295,17 @@ def pack_lore_dla34(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
     * DCN: ``.om`` = the 27-channel offset/mask conv padded to 64 outputs (fp32 out), ``.dcn`` = the deformable conv
       as a 1x1 GEMM over the 9*C sampled columns (tap-major K), with ``actf`` BN folded in;
     * depthwise ConvTranspose2d up-samplers: fp32 ``[k*k][C]``."""
-    bl = _Blob(x3)
+    bl = _Blob(x3, fmt)
+    x3 = bl.x3
     w, b = fold_conv_bn(sd, "base.base_layer.0", "base.base_layer.1")
     stem = torch.zeros(64, 7, 8, 4)
     stem[:16, :, :7, :3] = w.permute(0, 2, 3, 1)
     bp = torch.zeros(64)
     bp[:16] = b
-    bl.add("base_layer.w", to_bf16_bits(stem).reshape(64, 224), "bf16")
+    bl.add("base_layer.w", bl.bits(stem).reshape(64, 224), "bf16")
     if x3:
-        sh, sl = split_bf16(stem)
-        bl.add("base_layer.w3", np.stack([to_bf16_bits(sh).reshape(64, 224), to_bf16_bits(sl).reshape(64, 224)]), "bf16")
+        sh, sl = bl.split(stem)
+        bl.add("base_layer.w3", np.stack([bl.bits(sh).reshape(64, 224), bl.bits(sl).reshape(64, 224)]), "bf16")
     bl.add("base_layer.b", bp.numpy(), "f32")
     for name, key in (("level0", "base.level0"), ("level1", "base.level1")):
         # thin 16-input-channel levels: [9 taps][32 outputs (zero padded)][16 channels] for conv3x3_c16_kernel
@@ -289,10 +314,10 @@ def pack_lore_dla34(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
         wt[:, :w.shape[0]] = w.permute(2, 3, 0, 1).reshape(9, w.shape[0], 16)
         bt = torch.zeros(32)
         bt[:w.shape[0]] = b
-        bl.add(name + ".wt", to_bf16_bits(wt), "bf16")
+        bl.add(name + ".wt", bl.bits(wt), "bf16")
         if x3:
-            hi, lo = split_bf16(wt)
-            bl.add(name + ".wt3", np.stack([to_bf16_bits(hi), to_bf16_bits(lo)]), "bf16")
+            hi, lo = bl.split(wt)
+            bl.add(name + ".wt3", np.stack([bl.bits(hi), bl.bits(lo)]), "bf16")
         bl.add(name + ".bt", bt.numpy(), "f32")
 
     def block(p, q):
@@ -349,12 +374,13 @@ def pack_lore_dla34(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
     return bl.tobytes()
 
 
-def pack_lore_processor(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
+def pack_lore_processor(sd: Dict[str, torch.Tensor], x3: bool = True, fmt: str = "bf16") -> bytes:
     """``LoreProcessModel`` state_dict (lore/lore_processor.py:399-437) -> blob for PT_MODEL_LORE_PROCESSOR.
     Every nn.Linear becomes a 1x1 GEMM tile set; q/k/v projections are fused into one 256 -> 768 GEMM ([q; k; v]);
     ``logi_encoder.0`` (4 inputs) and the 4-output decoders are zero-padded to 32 inputs / 64 outputs; Norm
     parameters and the two position tables stay fp32.  ``meta`` = [tsfm layers, stacking layers]."""
-    bl = _Blob(x3)
+    bl = _Blob(x3, fmt)
+    x3 = bl.x3
 
     def lin(name, key, n_to=None, cin_to=None):
         w = sd[key + ".weight"].float()
@@ -404,13 +430,14 @@ def _fold_named(sd, conv_key: str, bn_key: str):
     return (w * scale.view(-1, 1, 1, 1)).float(), (b * scale + shift).float()
 
 
-def pack_picodet(sd: Dict[str, torch.Tensor], num_classes: int = 5, x3: bool = True) -> bytes:
+def pack_picodet(sd: Dict[str, torch.Tensor], num_classes: int = 5, x3: bool = True, fmt: str = "bf16") -> bytes:
     """PicoDet state_dict (keys backbone. / neck. / head., pdf_table_amd.synth_weights.picodet_state_dict) -> blob for
     PT_MODEL_PICODET.  BN folded everywhere; depthwise kernels fp32 ``[k*k][C]`` + bias; 1x1 convs tiled for the MFMA
     kernel (16-channel tensors stored 32 wide; convs over a channel concat split per operand: ``.a`` / ``.b``);
     SE fully-connected layers fp32; head convs padded to 64 outputs (``meta`` = [num_classes, reg_max])."""
     from .synth_weights import LCNET_CONFIG, PICODET_STANDIN
-    bl = _Blob(x3)
+    bl = _Blob(x3, fmt)
+    x3 = bl.x3
 
     def dw(name, conv_key, bn_key):
         w, b = _fold_named(sd, conv_key, bn_key)                    # [C, 1, k, k]
@@ -496,17 +523,18 @@ def deconv4x4s2_as_conv3x3(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def pack_lore_wireless(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
+def pack_lore_wireless(sd: Dict[str, torch.Tensor], x3: bool = True, fmt: str = "bf16") -> bytes:
     """``LoreDetectModel`` state_dict (lore/lore_detector.py:155-286) -> blob for PT_MODEL_LORE_RESNET18.  Conv+BN folded
     (block convs carry a bias); the 4x4/s2 transposed convolutions become 3x3 convs with a pixel-shuffle epilogue."""
-    bl = _Blob(x3)
+    bl = _Blob(x3, fmt)
+    x3 = bl.x3
     w, b = fold_conv_bn(sd, "conv1", "bn1")
     stem = torch.zeros(64, 7, 8, 4)
     stem[:, :, :7, :3] = w.permute(0, 2, 3, 1)
-    bl.add("stem.w", to_bf16_bits(stem).reshape(64, 224), "bf16")
+    bl.add("stem.w", bl.bits(stem).reshape(64, 224), "bf16")
     if x3:
-        sh, sl = split_bf16(stem)
-        bl.add("stem.w3", np.stack([to_bf16_bits(sh).reshape(64, 224), to_bf16_bits(sl).reshape(64, 224)]), "bf16")
+        sh, sl = bl.split(stem)
+        bl.add("stem.w3", np.stack([bl.bits(sh).reshape(64, 224), bl.bits(sl).reshape(64, 224)]), "bf16")
     bl.add("stem.b", b.numpy(), "f32")
     for li in range(1, 5):
         for bi in range(2):
@@ -533,7 +561,7 @@ def pack_lore_wireless(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
     return bl.tobytes()
 
 
-def pack_db_nas(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
+def pack_db_nas(sd: Dict[str, torch.Tensor], x3: bool = True, fmt: str = "bf16") -> bytes:
     """``DBNasModel`` state_dict (db_net/dbnet.py:693-712) -> blob for PT_MODEL_DB_NAS (csrc/dbnas_model.hip).
 
     * every BatchNorm folded (float64); channel counts padded to multiples of 64 with zero weights;
@@ -543,7 +571,8 @@ def pack_db_nas(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
     * ``dec.tail``: the two DwPwConvTranspose blocks + BN of LightSegDetector.binarize as the 449-float table
       dbnas_tail_kernel documents."""
     from .dbnas_arch import dbnas_blocks
-    bl = _Blob(x3)
+    bl = _Blob(x3, fmt)
+    x3 = bl.x3
     p64 = lambda c: (c + 63) // 64 * 64
 
     def bn_affine(bn):
@@ -622,13 +651,14 @@ def pack_db_nas(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
     return bl.tobytes()
 
 
-def pack_pplcnet(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
+def pack_pplcnet(sd: Dict[str, torch.Tensor], x3: bool = True, fmt: str = "bf16") -> bytes:
     """``PPLCNet`` state_dict (model/cls/cls_pp_lcnet.py:164-260) -> blob for PT_MODEL_PPLCNET (+ slot).  The backbone
     tensors have the names and layouts of pack_picodet's LCNet part (the same launch code runs both); ``last_conv`` and
     ``fc`` are 1x1 GEMMs over the pooled vectors (fc padded to 64 outputs, 16 stored); ``fc.nclass`` carries the class
     count in its length."""
     from .synth_weights import LCNET_CONFIG
-    bl = _Blob(x3)
+    bl = _Blob(x3, fmt)
+    x3 = bl.x3
 
     def dw(name, conv_key, bn_key):
         w, b = _fold_named(sd, conv_key, bn_key)                    # [C, 1, k, k]
@@ -681,7 +711,7 @@ _CVIT_V5_TO_V4 = [
 ]
 
 
-def pack_convnext_vit(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
+def pack_convnext_vit(sd: Dict[str, torch.Tensor], x3: bool = True, fmt: str = "bf16") -> bytes:
     """``ConvNextViT`` state_dict -> blob for PT_MODEL_CONVNEXT_VIT.  Key names of the reference's checkpoint era
     (transformers 4.x, ``vitstr.vit.encoder.layer.N.attention.attention.query`` ...) or of transformers 5.x
     (``vitstr.vit.layers.N.attention.q_proj`` ...), with or without the ``recognizer.`` / ``module.`` prefixes
@@ -700,7 +730,8 @@ def pack_convnext_vit(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
             k = re.sub(pat, rep, k)
         csd[k] = v.detach().float()
     sd = csd
-    bl = _Blob(x3)
+    bl = _Blob(x3, fmt)
+    x3 = bl.x3
 
     def f32(name, t):
         bl.add(name, t.contiguous().numpy().astype(np.float32), "f32")
@@ -724,9 +755,9 @@ def pack_convnext_vit(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
         c = w1.shape[1]
         if c > 256:
             return
-        bl.add(name + ".mlp.w1", to_bf16_bits(w1), "bf16")
+        bl.add(name + ".mlp.w1", bl.bits(w1), "bf16")
         w2c = w2.reshape(c, 4 * c // 32, 32)[:, :, perm].permute(1, 0, 2).contiguous()          # [chunk][C][32]
-        bl.add(name + ".mlp.w2p", to_bf16_bits(w2c), "bf16")
+        bl.add(name + ".mlp.w2p", bl.bits(w2c), "bf16")
 
     p = "cnn_model."
     f32("embed.w", sd[p + "embeddings.patch_embeddings.weight"].reshape(96, 16))
@@ -784,12 +815,13 @@ def pack_convnext_vit(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
 # --------------------------------------------------------------------------------------------------------------------
 # MtlTabNet backbone (table/mtl_tabnet/table_resnet_extra.py:205-318; kernels: csrc/mtl_model.hip)
 # --------------------------------------------------------------------------------------------------------------------
-def pack_mtl_backbone(sd: Dict[str, torch.Tensor], x3: bool = True) -> bytes:
+def pack_mtl_backbone(sd: Dict[str, torch.Tensor], x3: bool = True, fmt: str = "bf16") -> bytes:
     """``TableResNetExtra`` state_dict (layers [1, 2, 5, 3], context blocks in the first block of stages 2-4) -> blob for
     PT_MODEL_MTL_BACKBONE.  Every conv with its BatchNorm folded in (conv1's 3 input channels zero-padded to 32); the context
     blocks' small tensors stay fp32: mask conv ``wm [C]`` / ``bm``, ``w0 [hid][C]`` / ``b0``, LayerNorm ``lg`` / ``lb [hid]``,
     ``w3 [C][hid]`` / ``b3``."""
-    bl = _Blob(x3)
+    bl = _Blob(x3, fmt)
+    x3 = bl.x3
     w, b = fold_conv_bn(sd, "conv1", "bn1")
     bl.add_conv("conv1", *_pad_conv(w, b, 64, 32))
     for i in range(2, 7):
@@ -833,7 +865,7 @@ def mtl_positional_table(rows: int = MTL_PE_ROWS, d_model: int = MTL_D) -> torch
     return pe
 
 
-def pack_mtl_decoder(sd: Dict[str, torch.Tensor], cfg: Dict, x3: bool = True) -> bytes:
+def pack_mtl_decoder(sd: Dict[str, torch.Tensor], cfg: Dict, x3: bool = True, fmt: str = "bf16") -> bytes:
     """``MtlTabNetDecoder`` state_dict (table/mtl_tabnet/master_decoder.py:194-262; N = 3: two shared DecoderLayers, then the
     structure, box and cell-content layers) -> blob for PT_MODEL_MTL_DECODER.  ``cfg``: sos / eos / pad / max_len, sos_cell /
     eos_cell / pad_cell / max_len_cell, idx_tag_cell (master_convertor.py:541-549).
@@ -846,7 +878,8 @@ def pack_mtl_decoder(sd: Dict[str, torch.Tensor], cfg: Dict, x3: bool = True) ->
     classifiers zero-padded to multiples of 64 outputs; embeddings pre-multiplied by sqrt(d_model) in fp32 (the reference's own
     fp32 product, :26); the position table as the reference computes it."""
     import math
-    bl = _Blob(x3)
+    bl = _Blob(x3, fmt)
+    x3 = bl.x3
     d = MTL_D
 
     def W(key):
