@@ -87,7 +87,7 @@ def test_store_saturates_instead_of_inf(eng16):
     B, H, W, C = 1, 8, 32, 64
     x = torch.full((B, C, H, W), 30.0)
     w = torch.zeros(64, C, 1, 1)
-    w[torch.arange(64), torch.arange(64), 0, 0] = torch.linspace(-4096.0, 4096.0, 64)     # outputs -122 880 .. 122 880
+    w[torch.arange(64), torch.arange(64), 0, 0] = _h(torch.linspace(-4096.0, 4096.0, 64))     # outputs -122 880 .. 122 880
     b = torch.zeros(64)
     ref = F.conv2d(x, w, b)
     for relu in (False, True):
