@@ -183,8 +183,14 @@ def _db_text_signal(sd, gain: float = 24.0, level: float = 0.69, a1: float = 2.0
     sd["decoder.binarize.6.bias"][:] = -gain * level + _m.log(0.3 / 0.7)
 
 
-def crnn_state_dict(seed: int = 0, num_classes: int = CRNN_NUM_CLASSES):
-    """state_dict of ``CRNN`` (crnn/modeling_crnn.py:40-90); every conv has a bias."""
+def crnn_state_dict(seed: int = 0, num_classes: int = CRNN_NUM_CLASSES, conditioned: bool = False):
+    """state_dict of ``CRNN`` (crnn/modeling_crnn.py:40-90); every conv has a bias.
+
+    ``conditioned=True`` (seed 1: bench.py's and the end-to-end fixture's recogniser): the classifier ``cls.weight`` is replaced by the rows of
+    ``data/crnn_synth_classifier.npz``, fitted by ``tools/fit_crnn_classifier.py`` on this very net's BiLSTM features of the generator's text lines
+    (k-means clusters of the frames as classes, the largest one as CTC blank; every other row zero).  A random 7644-way classifier has near-tied
+    logits on every frame -- any 16-bit arithmetic flips token ids there --, the fitted one has the margin distribution of a trained recogniser
+    (the file keeps both distributions).  A workload device that memorises its pages, not a recogniser."""
     g = _Gen(seed)
     g.conv("conv0.0", 64, 1, 3, 3, bias=True)
     g.bn("conv0.1", 64)
@@ -207,6 +213,14 @@ def crnn_state_dict(seed: int = 0, num_classes: int = CRNN_NUM_CLASSES):
     g.lstm("rnn.1.rnn", 256, 256, scale=3.0)
     g.linear("rnn.1.embedding", 512, 512, scale=4.0)
     g.linear("cls", num_classes, 512, bias=False, scale=4.0)
+    if conditioned:
+        import os
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "crnn_synth_classifier.npz"))
+        if int(z["seed"]) != seed or num_classes != CRNN_NUM_CLASSES:
+            raise ValueError(f"crnn_synth_classifier.npz was fitted on crnn_state_dict(seed={int(z['seed'])}), not seed={seed}")
+        w = torch.zeros(num_classes, 512, dtype=g.sd["cls.weight"].dtype)
+        w[torch.from_numpy(z["ids"].astype(np.int64))] = torch.from_numpy(z["rows"]).to(w.dtype)
+        g.sd["cls.weight"] = w
     return g.sd
 
 
@@ -797,3 +811,14 @@ def pplcnet_state_dict(seed: int = 0, class_num: int = 2, logit_gain: float = 4.
     g.conv("last_conv", 1280, 512, 1, 1)
     g.linear("fc", class_num, 1280, scale=logit_gain)
     return g.sd
+
+
+def conditioned_state_dicts():
+    """THE synthetic checkpoint set of bench.py's timed step and of the end-to-end fixture (tests/golden/e2e_page.npz) -- one set, so that what is
+    timed is what the parity assertions run on: the detector with the hand-built text channel (its boxes feed the recogniser),
+    the recogniser with the fitted classifier (trained-like arg-max margins), the layout net with the head branch fitted to the generator's pages (its
+    "table" regions feed the table stage), the Lore detector with the heat-map bias that yields cells and DCN offsets of ~0.07 px (a random DLA-34
+    with 16 stacked DCNs at the default ~0.3 px is chaotic in fp32 itself: DESIGN.md numerics), the seeded Lore processor."""
+    return {"db": db_resnet18_state_dict(seed=0, text_signal=True), "crnn": crnn_state_dict(seed=1, conditioned=True),
+            "pico": picodet_state_dict(seed=4, num_classes=5, table_head=True),
+            "lore": lore_dla34_state_dict(seed=2, dcn_gain=0.02, hm_bias=(-2.0, -2.0), hm_gain=0.25), "proc": lore_processor_state_dict(seed=3)}

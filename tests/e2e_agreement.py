@@ -7,8 +7,9 @@ What is counted, per the reference's three outputs (north_star: text-box polygon
   boxes      oracle text boxes found by the engine: identical int16 quads / within 2 px on every coordinate
   strings    lines cut from a matched quad whose recognised string equals the oracle's (on identical quads; on quads within 2 px)
   cells      oracle table cells found with >= 3 of 4 vertices within 0.1 / 1 / 4 / 16 px; logical locations equal on the matched ones
-  html       tables whose HTML string equals the one the host code builds from the ORACLE's cells, boxes and strings (one differing token
-             anywhere in the table breaks it), and tables whose STRUCTURE string (rows, spans; no text) is equal
+  html       tables whose HTML equals the ORACLE CHAIN's -- the reference's own structure + text -> HTML functions run over the oracle's cells, boxes
+             and strings when the fixture was generated (one differing token anywhere in the table breaks it) --, and tables whose STRUCTURE
+             string (rows, spans; no text) is equal
 """
 import numpy as np
 
@@ -52,7 +53,10 @@ def match_cells(want, got, tol=0.1):
 def oracle_strings(g, pi, label):
     from pdf_table_amd.rec_stage import ctc_collapse
     ids = g[f"p{pi}_rec_ids"]
-    return ["".join(label.get(t, "") for t in row) for row in ctc_collapse(ids)]
+    out = ["".join(label.get(t, "") for t in row) for row in ctc_collapse(ids)]
+    if f"p{pi}_rec_text" in g:          # the strings the fixture's HTML was built from (make_golden.py: the oracle's own greedy decode)
+        assert out == [str(x) for x in g[f"p{pi}_rec_text"]]
+    return out
 
 
 def agreement(g, results, label, table_boxes):
@@ -108,8 +112,10 @@ def agreement(g, results, label, table_boxes):
                 c["logi_rows_equal"] += int(eq.sum())
             same_cells = len(tight) == len(polys) == len(gp) and all(i == j for i, j in tight) and np.array_equal(gl, logi)
             c["tables_cells_and_logi_identical"] += int(same_cells)
-            ref_html, _ = page_table_html(polys + off, logi, tbs[ti], want, ref_txt)
-            c["tables_html_identical"] += int(t.get("table_html") == ref_html)
+            # the ORACLE CHAIN's HTML: the reference's own OcrTableToHtmlTask code over the oracle's cells, boxes and strings, stored in the fixture
+            # (make_golden.py::gen_e2e_page) -- nothing of the product on this side of the comparison
+            ref_html = [str(x) for x in g[k + "html"]]
+            c["tables_html_identical"] += int(list(t.get("table_html") or []) == ref_html)
 
     def fr(a, b):
         return round(c[a] / c[b], 4) if c[b] else None

@@ -6,13 +6,12 @@ E2E_PAGES = (17, 6)         # synthetic page indices (pdf_table_amd.synth_pages.
 
 
 def e2e_state_dicts():
-    """the seeded weights of the end-to-end fixture: the detector carries the hand-built text channel (boxes come out), the Lore
-    detector the heat-map bias that yields cells and the small DCN offsets of the full-size parity test, the layout net the head
-    branch fitted to the generator's pages (tools/fit_layout_head.py): its "table" regions are what the table stage crops, as in the reference"""
+    """the seeded weights of the end-to-end fixture = bench.py's timed checkpoint set (pdf_table_amd.synth_weights.conditioned_state_dicts): the
+    detector carries the hand-built text channel (boxes come out), the recogniser the fitted classifier (tools/fit_crnn_classifier.py), the Lore
+    detector the heat-map bias that yields cells and the small DCN offsets of the full-size parity test, the layout net the head branch fitted to the
+    generator's pages (tools/fit_layout_head.py): its "table" regions are what the table stage crops, as in the reference"""
     from pdf_table_amd import synth_weights as sw
-    return {"db": sw.db_resnet18_state_dict(seed=0, text_signal=True), "crnn": sw.crnn_state_dict(seed=1),
-            "pico": sw.picodet_state_dict(seed=4, num_classes=5, table_head=True), "lore": sw.lore_dla34_state_dict(seed=2, dcn_gain=0.02, hm_bias=(-2.0, -2.0), hm_gain=0.25),
-            "proc": sw.lore_processor_state_dict(seed=3)}
+    return sw.conditioned_state_dicts()
 
 
 def e2e_table_boxes(meta):

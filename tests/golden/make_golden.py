@@ -888,6 +888,12 @@ def gen_e2e_page():
     torch.set_num_threads(os.cpu_count() or 1)
     sds = e2e_state_dicts()
     res = {"pages": np.array(E2E_PAGES)}
+    # the reference's OWN structure + text -> HTML code over the oracle chain's cells, boxes and strings: what the engine's
+    # table_html is compared with in tests/test_gpu_e2e.py / tests/e2e_agreement.py -- no product code on this side of the comparison
+    Task, T, OcrCell = _matcher_env()
+    task = Task(output_dir="/tmp/pt_golden_html")
+    from oracle.crnn import ctc_greedy_ids
+    vocab = {i + 1: chr(0x4E00 + i) for i in range(7643)}       # pdf_table_amd.rec_stage.synthetic_vocab: id k -> the k-th CJK code point (no vocab.txt offline)
     for pi, idx in enumerate(E2E_PAGES):
         page, meta = make_page(idx, 1024)
         t0 = time.time()
@@ -905,10 +911,26 @@ def gen_e2e_page():
         res[p + "layout_score"] = np.array([it["score"] for it in r["layout"]], np.float32)
         res[p + "layout_cat"] = np.array([it["category_id"] for it in r["layout"]], np.int32)
         res[p + "n_tables"] = np.array(len(r["tables"]))
+        texts = ["".join(vocab.get(int(t_), "") for t_ in row) for row in ctc_greedy_ids(r["rec_ids"])]
+        res[p + "rec_text"] = np.array(texts)
         for ti, t in enumerate(r["tables"]):
             for k in ("polys", "scores", "stacked", "logi", "fragile"):
                 if k in t:
                     res[f"{p}t{ti}_{k}"] = t[k]
+            if not t["n"]:
+                continue
+            # ocr_system_task.py:192-199 -> OcrTableToHtmlTask (ocr_table_to_html_task.py:79-176): cells in page pixels (shifted by the crop corner,
+            # table_common.py:1811-1825), the page's lines whose centre lies in the layout box, image pages with ocr_post_process=True (:93)
+            off = np.tile(tb[ti][:2].astype(np.float64), 4)[None]
+            cells = T.get_table_cell_from_table_logit(table_bboxs=t["polys"].astype(np.float64) + off, logits=t["logi"], save_html_file=None)
+            ocr = [OcrCell(raw_data={"index": i + 1, "text": tx, "bbox": np.asarray(q, np.float64).reshape(4, 2).tolist()}) for i, (q, tx) in enumerate(zip(r["det_boxes"], texts))]
+            inside, _ = T.get_text_in_table_bbox(bbox=[float(v) for v in tb[ti]], ocr_results=ocr, diff=2)
+            _, html, _, db_html = task.match_table_cell_and_text_cell(table_idx=ti, table_cells=cells, text_bboxs=inside, raw_filename="g",
+                                                                      ocr_post_process=True)
+            res[f"{p}t{ti}_html"] = np.array(list(html))
+            fr = t["stacked"] - np.floor(t["stacked"])
+            print(f"   table {ti}: {t['n']} cells, {len(inside)} lines inside, HTML {sum(len(x) for x in html)} characters; closest logical location to the "
+                  f".5 boundary {float(np.abs(fr - 0.5).min()):.2e}; {int(t['fragile'].sum())} fragile peaks")
     np.savez_compressed(os.path.join(HERE, "e2e_page.npz"), **res)
     print("e2e_page.npz", os.path.getsize(os.path.join(HERE, "e2e_page.npz")) // 1024, "KiB")
 

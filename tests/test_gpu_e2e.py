@@ -56,6 +56,24 @@ def run(golden_dir):
     finally:
         eng.set_precision(L.PT_PRECISION_BF16)
     pipe.res_bf16 = pipe.predict(pages)          # the SAME pages in the headline mode (PT_PRECISION_BF16): test_headline_mode_agreement
+    # ... and in PT_PRECISION_F16 (single-pass IEEE half, the reference's own GPU arithmetic): a second engine, the same state dicts as fp16 tiles
+    e16 = HipEngine(0)
+    e16.set_precision(L.PT_PRECISION_F16)
+    e16.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(sds["db"], fmt="f16"))
+    e16.load_weights(L.PT_MODEL_CRNN, pack_crnn(sds["crnn"], fmt="f16"))
+    e16.load_weights(L.PT_MODEL_PICODET, pack_picodet(sds["pico"], 5, fmt="f16"))
+    e16.load_weights(L.PT_MODEL_LORE_DLA34, pack_lore_dla34(sds["lore"], fmt="f16"))
+    e16.load_weights(L.PT_MODEL_LORE_PROCESSOR, pack_lore_processor(sds["proc"], fmt="f16"))
+    pipe16 = OcrTablePipeline.from_engine(e16, DetStage(e16, DetConfig(flavour="db_pp", thresh=0.3, box_thresh=0.6, unclip_ratio=1.5)), RecStage(e16),
+                                          LayoutStage(e16, PicodetConfig(task_type="en")), TsrStage(e16, LoreConfig(task_type="wtw")), table_html=True)
+    pipe.res_f16 = pipe16.predict(pages)
+    # the table stage alone: the SAME crops as the oracle chain's (its layout regions handed in), so that a one-pixel difference of a rounded
+    # layout box -- a different crop, hence a different input to a random-init net -- does not count against the table-structure arithmetic
+    pipe.res_f16_tb = pipe16.predict(pages, table_boxes=[np.asarray(t) for t in tbs])
+    pipe.res_bf16_tb = pipe.predict(pages, table_boxes=[np.asarray(t) for t in tbs])
+    pipe.layout_boxes = {m: [[np.asarray(it["bbox"]).round().tolist() for it in (r.layout_result or []) if str(it.get("label", "")).lower() == "table"] for r in rr]
+                         for m, rr in (("bf16x3", res), ("f16", pipe.res_f16), ("bf16", pipe.res_bf16))}
+    e16.close()
     yield g, res, stream, pipe, tbs
     eng.close()
 
@@ -158,17 +176,23 @@ def test_table_cells_logical_locations_and_html(run):
             print(f"   logical locations: {int(neq.sum())} of {neq.size} entries differ outside the oracle's .5 boundary")
             if len(pairs) == len(polys) == len(got) and same_order and not odd:
                 assert not neq.any()
-                # every entry equal, the .5-boundary ones included: the host code got the same input from both sides
-                if safe.all() or np.array_equal(np.asarray(t["logi"])[gj], logi[wi]):
-                    texts = [o["text"] for o in r.ocr_result]
-                    ref_html, _ = page_table_html(polys + off, logi, tbs[pi][ti], np.asarray(r.det_result), texts)
-                    assert t["table_html"] == ref_html
+                # every entry equal, the .5-boundary ones included, and every string of the page equal: the engine's HTML must then be the ORACLE CHAIN's --
+                # the fixture's string, which make_golden.py built with the reference's own OcrTableToHtmlTask code over the oracle's cells, boxes and
+                # strings (no product code on the reference side of this comparison)
+                texts = [o["text"] for o in r.ocr_result]
+                same_text = np.array_equal(np.asarray(r.det_result, np.float32).reshape(-1, 8), g[f"p{pi}_det_boxes"]) and texts == [str(x) for x in g[f"p{pi}_rec_text"]]
+                if np.array_equal(np.asarray(t["logi"])[gj], logi[wi]) and same_text:
+                    ref_html = [str(x) for x in g[k + "html"]]
+                    assert list(t["table_html"]) == ref_html
                     html_checked += 1
-                    print(f"   HTML identical ({sum(len(x) for x in ref_html)} characters)")
+                    print(f"   HTML identical to the oracle chain's ({sum(len(x) for x in ref_html)} characters)")
+                    # and the product's host code over the ORACLE's inputs gives the same string (table_text_match.py is pinned to the reference functions)
+                    mine, _ = page_table_html(polys + off, logi, tbs[pi][ti], g[f"p{pi}_det_boxes"], [str(x) for x in g[f"p{pi}_rec_text"]])
+                    assert list(mine) == ref_html
             else:
                 assert neq.sum() <= max(2, neq.size // 50)
     print(f"e2e tables: HTML compared for {html_checked} table(s)")
-    assert html_checked >= 1, "the fixture's pages are chosen so that at least one table is identical cell for cell"
+    assert html_checked >= 1, "the fixture's pages are chosen so that at least one table's HTML equals the oracle chain's"
 
 
 def test_predict_stream_yields_the_same_pages(run):
@@ -191,12 +215,18 @@ def test_headline_mode_agreement(run):
     g, res, _, pipe, tbs = run
     label = pipe.text_recognizer._stage.label
     out = {}
-    for mode, r in (("bf16x3", res), ("bf16", pipe.res_bf16)):
+    print("E2E layout table boxes (rounded): fixture", [np.asarray(t).tolist() for t in tbs], pipe.layout_boxes)
+    for mode, r in (("bf16x3", res), ("f16", pipe.res_f16), ("bf16", pipe.res_bf16), ("f16_oracle_crops", pipe.res_f16_tb), ("bf16_oracle_crops", pipe.res_bf16_tb)):
         a = agreement(g, r, label, tbs)
         out[mode] = a
         print(f"E2E AGREEMENT {mode}: " + json.dumps(a["frac"]))
         print(f"E2E AGREEMENT {mode} counts: " + json.dumps({k: v for k, v in a.items() if k != "frac"}))
-    fx, fb = out["bf16x3"]["frac"], out["bf16"]["frac"]
+    fx, fb, fh, fhc = out["bf16x3"]["frac"], out["bf16"]["frac"], out["f16"]["frac"], out["f16_oracle_crops"]["frac"]
+    assert fx["tables_html_identical"] >= 0.33          # at least one table whose HTML is the oracle chain's own string
+    # PT_PRECISION_F16: floors under the measured values (profiles/r05/e2e_agreement.txt).  The chained cell figure is dominated by ONE decision: a layout
+    # box that rounds a pixel differently is a different crop, and a random-init Lore net is not shift-robust -- given the oracle's crops f16 finds its cells
+    assert fh["boxes_within_2px"] >= 0.98 and fh["strings_identical_on_2px_quads"] >= 0.8
+    assert fhc["cells_matched_1px"] >= 0.85
     # tolerance mode: what the tests above assert, as fractions
     assert fx["boxes_identical"] >= 0.97 and fx["strings_identical_on_identical_quads"] >= 0.98 and fx["cells_matched_0p1px"] >= 0.95
     # headline mode: recorded; floors below the measured values (r04: boxes 0.98, strings 0.54).  The table cells carry NO floor:
