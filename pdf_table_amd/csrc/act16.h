@@ -6,7 +6,7 @@
 //                       arithmetic (base_infer_task.py:56-57 precision="fp16", utils/deploy_utils.py:227-240 model.half())
 // Same kernels, same tiles, same bytes and the same MFMA rate (v_mfma_f32_32x32x16_f16 == ..._bf16); what changes is this file: how 16 stored
 // bits become an fp32 value, how an fp32 value is rounded for storage (round-to-nearest-even in both; the half format SATURATES at +-65504
-// instead of producing Inf), and which matrix instruction multiplies them.  The exported C functions (api_dispatch.cpp, generated from
+// instead of producing Inf: MODE.FP16_OVFL, set by a16_kernel_enter() at the top of every kernel), and which matrix instruction multiplies them.  The exported C functions (api_dispatch.cpp, generated from
 // include/pdftable_hip.h) pick the namespace from pt_engine::precision.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -34,22 +34,25 @@ typedef __attribute__((ext_vector_type(16))) float a16_f32x16;
 
 #if PT_ACT_F16
 #define PT_A16_MAX 65504.0f
-// bits of 1.0 / -1.0 / the most negative finite value in the storage format (pool identities, canvas fills)
+// bits of 1.0 / the most negative finite value in the storage format (pool identities, canvas fills)
 #define PT_A16_ONE 0x3C00u
 #define PT_A16_LOWEST 0xFBFFu
-__device__ __forceinline__ float a16_sat(float f) { return __builtin_amdgcn_fmed3f(f, -PT_A16_MAX, PT_A16_MAX); }
+// First statement of EVERY kernel of this namespace: MODE.FP16_OVFL = 1 -- "an overflowed FP16 VALU result is clamped to +/- MAX_FP16 regardless of the
+// round mode" (the bit exists for exactly this) -- so v_cvt_f16_f32 / v_cvt_pk_f16_f32 SATURATE at +-65504 instead of producing Inf, at no instruction per
+// stored value (two v_med3_f32 clamps per pair cost 3 % of the four-stage step: 674 -> pages/s in profiles/r05/f16_ovfl.txt).  Measured on gfx950
+// (tools/scratch/ovfl.hip, recorded in the same file): 70000 -> 0x7bff, -1e9 -> 0xfbff, 65520 -> 0x7bff with the bit, Inf without.  MODE is per wave and
+// starts from the kernel descriptor (bit clear), so a kernel that skips this call would store Inf again: tests/test_gpu_f16.py drives the stores of every
+// kernel family over the edge.
+__device__ __forceinline__ void a16_kernel_enter() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
+__device__ __forceinline__ float a16_sat(float f) { return __builtin_amdgcn_fmed3f(f, -PT_A16_MAX, PT_A16_MAX); }      // explicit clamp (fp32 side), where one is wanted
 __device__ __forceinline__ float a16_to_f32(uint32_t bits16) { return (float)__builtin_bit_cast(_Float16, (uint16_t)bits16); }
 __device__ __forceinline__ float a16lo_f32(uint32_t pk) { return (float)__builtin_bit_cast(a16_f16x2, pk).x; }
 __device__ __forceinline__ float a16hi_f32(uint32_t pk) { return (float)__builtin_bit_cast(a16_f16x2, pk).y; }
-// round-to-nearest-even, saturating: an activation beyond 65504 is stored as 65504, never as Inf (tests/test_gpu_f16.py)
-__device__ __forceinline__ uint32_t f32_to_a16(float f) { return __builtin_bit_cast(uint16_t, (_Float16)a16_sat(f)); }
-// two values -> one dword: v_med3_f32 x 2 + v_cvt_pk_f16_f32
+// round-to-nearest-even; saturating through MODE.FP16_OVFL (a16_kernel_enter): an activation beyond 65504 is stored as 65504, never as Inf
+__device__ __forceinline__ uint32_t f32_to_a16(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+// two values -> one dword: v_cvt_pk_f16_f32
 __device__ __forceinline__ uint32_t pack_a16x2(float a, float b) {
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(a16_f32x2{a16_sat(a), a16_sat(b)}, a16_f16x2));
-}
-// non-negative inputs (behind a ReLU): the lower clamp is the ReLU itself
-__device__ __forceinline__ uint32_t pack_a16x2_relu(float a, float b) {
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(a16_f32x2{__builtin_amdgcn_fmed3f(a, 0.f, PT_A16_MAX), __builtin_amdgcn_fmed3f(b, 0.f, PT_A16_MAX)}, a16_f16x2));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(a16_f32x2{a, b}, a16_f16x2));
 }
 __device__ __forceinline__ a16_f32x16 mfma_32x32x16_a16(a16_bf16x8 a, a16_bf16x8 b, a16_f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(a16_f16x8, a), __builtin_bit_cast(a16_f16x8, b), c, 0, 0, 0);
@@ -57,6 +60,7 @@ __device__ __forceinline__ a16_f32x16 mfma_32x32x16_a16(a16_bf16x8 a, a16_bf16x8
 #else
 #define PT_A16_ONE 0x3F80u
 #define PT_A16_LOWEST 0xFF7Fu
+__device__ __forceinline__ void a16_kernel_enter() {}       // bf16 has the fp32 range: nothing to set up (see the pt_f16 side)
 __device__ __forceinline__ float a16_sat(float f) { return f; }
 __device__ __forceinline__ float a16_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
 __device__ __forceinline__ float a16lo_f32(uint32_t pk) { return __uint_as_float(pk << 16); }
@@ -70,9 +74,6 @@ __device__ __forceinline__ uint32_t f32_to_a16(float f) {
 // two values -> one dword: v_cvt_pk_bf16_f32 (equal to f32_to_a16 for finite values)
 __device__ __forceinline__ uint32_t pack_a16x2(float a, float b) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(a16_f32x2{a, b}, a16_bf16x2));
-}
-__device__ __forceinline__ uint32_t pack_a16x2_relu(float a, float b) {
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(a16_f32x2{__builtin_fmaxf(a, 0.f), __builtin_fmaxf(b, 0.f)}, a16_bf16x2));
 }
 __device__ __forceinline__ a16_f32x16 mfma_32x32x16_a16(a16_bf16x8 a, a16_bf16x8 b, a16_f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void cls_resize_norm_kernel(const uint8_t* __r
                                                               const pt_cls_image* __restrict__ images, int OH, int OW,
                                                               int ksx, int ksy, const float* __restrict__ lut, int split,
                                                               bf16_t* __restrict__ out) {
+  a16_kernel_enter();
   extern __shared__ int s_tab[];
   int* kx = s_tab;                      // [OW][ksx]
   int* bx = kx + OW * ksx;              // [OW][2] xmin, count
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(256) void cls_resize_norm_kernel(const uint8_t* __r
 // text-line crops of the recognition stage (ragged uint8 RGB, pixel offsets off[]) -> image descriptors
 __global__ void cls_desc_from_lines_kernel(const pt_rec_line* __restrict__ lines, const long long* __restrict__ off, int n,
                                            pt_cls_image* __restrict__ images) {
+  a16_kernel_enter();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   pt_cls_image d;

@@ -519,6 +519,7 @@ struct ConvCfg {
 // fp16 on their way into LDS and the products run on v_mfma_f32_32x32x16_f16
 template <int KS, int STRIDE, int GEOM, int NHALF = 2, bool DIRECT = false, bool F16 = false>
 __global__ __launch_bounds__(256, KS == 1 ? 4 : 2) void conv_igemm_kernel(ConvK p) {
+  a16_kernel_enter();
   using C = ConvCfg<KS, STRIDE, GEOM>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_in = smem;
@@ -796,6 +797,7 @@ struct Conv1WideCfg {
 
 template <int KG>
 __global__ __launch_bounds__(256, KG == 4 ? 3 : 4) void conv1x1_wide_kernel(ConvK p) {
+  a16_kernel_enter();
   using C = Conv1WideCfg<KG>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_in = smem;
@@ -931,6 +933,7 @@ struct Dma16Cfg {
 
 template <int NT, int NWV, int S = 1>
 __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_dma16_kernel(ConvK p, const bf16_t* __restrict__ zero_page) {
+  a16_kernel_enter();
   using C = Dma16Cfg<NT, NWV, S>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -1108,6 +1111,7 @@ struct Ws64Cfg {
 };
 
 __global__ __launch_bounds__(512, 1) void conv3x3_ws64_kernel(ConvK p, const bf16_t* __restrict__ zero_page) {
+  a16_kernel_enter();
   using C = Ws64Cfg;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_w = smem;
@@ -1343,6 +1347,7 @@ struct StemCfg {
 // adjacent input pixels, so at S=1 fragments are only 8-byte aligned and are read as two ds_read_b64.
 template <int S, int NH>   // NH: 32-column halves of the 64 GEMM outputs that are computed (1 when n_valid <= 32)
 __global__ __launch_bounds__(256, 2) void conv_stem7x7_kernel(ConvK p) {
+  a16_kernel_enter();
   using C = StemCfg<S>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_in = smem;
@@ -1472,6 +1477,7 @@ struct StemPoolCfg {
 };
 
 __global__ __launch_bounds__(256, 2) void conv_stem7x7_pool_kernel(ConvK p) {
+  a16_kernel_enter();
   using C = StemPoolCfg;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_in = smem;
@@ -1595,6 +1601,7 @@ struct StemPoolWsCfg {
 };
 
 __global__ __launch_bounds__(512, 1) void conv_stem7x7_pool_ws_kernel(ConvK p) {
+  a16_kernel_enter();
   using C = StemPoolCfg;
   using W = StemPoolWsCfg;
   extern __shared__ __attribute__((aligned(16))) char smem[];      // the input patch (20.7 KB), then the bf16 stem patch (69.6 KB) over it
@@ -1727,6 +1734,7 @@ constexpr int STEM_NT = 8;
 // (x_hi, w_lo) into the same accumulators, in the general stem kernel's order (bit-identical to it), the 16 channels stored as (hi | lo) halves
 template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void conv_stem7x7_thin_kernel(ConvK p) {
+  a16_kernel_enter();
   using C = StemCfg<1>;
   constexpr int NPL = SPLIT ? 2 : 1;
   __shared__ __attribute__((aligned(16))) char s_in[NPL][C::IN_BYTES];

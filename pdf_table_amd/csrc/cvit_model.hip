@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void cvit_embed_kernel(const float* __restrict
                                                          int nchunks, const int* __restrict__ csrc, const float* __restrict__ w,
                                                          const float* __restrict__ b, const float* __restrict__ g,
                                                          const float* __restrict__ beta, float* __restrict__ x) {
+  a16_kernel_enter();
   const long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= (long long)nchunks * CV_PIX0) return;
   // csrc != null: the batch holds only the chunks with text in them; csrc[k] = 3 line + j of compact chunk k, -1 = the
@@ -121,6 +122,7 @@ template <int H>
 __global__ __launch_bounds__(512) void cvit_dwconv_ln_kernel(const float* __restrict__ x, int W, int C, const float* __restrict__ wt,
                                                              const float* __restrict__ bias, const float* __restrict__ g,
                                                              const float* __restrict__ beta, bf16_t* __restrict__ out, int split) {
+  a16_kernel_enter();
   extern __shared__ float cv_lds[];
   constexpr int NP = H * CV_TX;
   float* tile = cv_lds;                 // [NP][C]
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(512) void cvit_dwconv_ln_kernel(const float* __rest
 __global__ __launch_bounds__(256) void cvit_ln_kernel(const float* __restrict__ x, long long rows, int C, const float* __restrict__ g,
                                                       const float* __restrict__ beta, float eps, bf16_t* __restrict__ out, int split,
                                                       int mode, int H, int W, const int* __restrict__ cmap) {
+  a16_kernel_enter();
   long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -265,6 +268,7 @@ __global__ __launch_bounds__(256) void cvit_ln_kernel(const float* __restrict__ 
 
 // x[row, c] += pos[row % 75, c]: embeddings + position_embeddings[:, 1:, :] (modeling_vit.py:78-79)
 __global__ __launch_bounds__(256) void cvit_add_pos_kernel(float* __restrict__ x, const float* __restrict__ pos, long long total, int C) {
+  a16_kernel_enter();
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const long long row = i / C;
@@ -281,6 +285,7 @@ __device__ __forceinline__ abf16x8 ld8(const bf16_t* p) { return *reinterpret_ca
 
 template <int SPLIT>
 __global__ __launch_bounds__(64) void cvit_attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out) {
+  a16_kernel_enter();
   const int q0 = blockIdx.x * 32, head = blockIdx.y, lane = threadIdx.x;
   const long long tok0 = (long long)blockIdx.z * CV_T;
   constexpr int E = 192, LO = 3 * E, cs = SPLIT ? 2 * LO : LO;
@@ -412,6 +417,7 @@ template <int C, bool PIPE, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void cvit_mlp_kernel(const bf16_t* __restrict__ xb, const bf16_t* __restrict__ w1,
                                                                             const float* __restrict__ b1, const bf16_t* __restrict__ w2p,
                                                                             const float* __restrict__ b2, float* __restrict__ x, long long rows) {
+  a16_kernel_enter();
   constexpr int KS = C / 16, NT = C / 32, NCH = 4 * C / 32;
   constexpr int U1 = C / 8;                            // 16-byte units per W1 row
   constexpr int S1 = 32 * C * 2, S2 = C * 64;          // one W1 chunk [32][C], one W2 chunk [C][32], bytes

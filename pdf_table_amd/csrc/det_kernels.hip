@@ -51,6 +51,7 @@ constexpr int PRE_ROWS = 8;      // output rows per workgroup
 __global__ __launch_bounds__(256) void det_preprocess_kernel(const uint8_t* __restrict__ pages, int n, int h, int w,
                                                               int nh, int nw, int flavour, int split, bf16_t* __restrict__ out,
                                                               double sx, double sy) {
+  a16_kernel_enter();
   // grid (column blocks, groups of PRE_ROWS output rows, page): no 64-bit index division per pixel, a thread keeps its column --
   // the horizontal coefficients are computed once for PRE_ROWS pixels.  sx = (double)w / nw, sy = (double)h / nh come from the host
   // (the same IEEE division).  The normalisation is a function of one byte: a [3][256] table of (bf16 hi | bf16 lo << 16) is built per
@@ -162,6 +163,7 @@ __device__ __forceinline__ uint32_t bfmax2(uint32_t a, uint32_t b) {
 // split mode: pixels hold [hi(C) | lo(C)]; the max is taken on hi + lo and the winning PAIR is copied
 __global__ __launch_bounds__(256) void maxpool3x3s2_split_kernel(const bf16_t* __restrict__ in, int B, int H, int W,
                                                                   int C, bf16_t* __restrict__ out) {
+  a16_kernel_enter();
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const int cg = C >> 3;
   const long long total = (long long)B * Ho * Wo * cg;
@@ -206,6 +208,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_split_kernel(const bf16_t* _
 
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const bf16_t* __restrict__ in, int B, int H, int W, int C,
                                                             bf16_t* __restrict__ out) {
+  a16_kernel_enter();
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const int cg = C >> 3;
   const long long total = (long long)B * Ho * Wo * cg;
@@ -262,6 +265,7 @@ int pt_launch_maxpool3x3s2(const bf16_t* in, int B, int H, int W, int C, bf16_t*
 __global__ __launch_bounds__(256) void db_head_final_kernel(const bf16_t* __restrict__ in, int B, int H, int W,
                                                              const bf16_t* __restrict__ w4x64, const float* __restrict__ bias_p,
                                                              float* __restrict__ prob, float* __restrict__ logits) {
+  a16_kernel_enter();
   const int sub = threadIdx.x & 7;
   const float bias = bias_p[0];
   float wq[4][8];
@@ -311,6 +315,7 @@ __global__ __launch_bounds__(256) void db_head_final_split_kernel(const bf16_t* 
                                                                    const float* __restrict__ w4x64,
                                                                    const float* __restrict__ bias_p,
                                                                    float* __restrict__ prob, float* __restrict__ logits) {
+  a16_kernel_enter();
   const int sub = threadIdx.x & 7;
   const float bias = bias_p[0];
   float wq[4][8];
@@ -395,6 +400,7 @@ __global__ __launch_bounds__(256, 4) void db_head_mfma_kernel(const bf16_t* __re
                                                                const bf16_t* __restrict__ w6, const float* __restrict__ b6,
                                                                float* __restrict__ prob, float* __restrict__ logits,
                                                                uint32_t* __restrict__ bitmap, float thresh) {
+  a16_kernel_enter();
   constexpr int PITCH = 144;                       // 64 k x 2 B + 16 B pad: conflict-free ds_read_b128 over 32 rows
   __shared__ __attribute__((aligned(16))) char s_w[256 * PITCH];
   __shared__ float s_b[256];
@@ -538,6 +544,7 @@ int pt_launch_db_head_mfma(const bf16_t* in, int B, int H, int W, const bf16_t* 
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bitmap_kernel(const float* __restrict__ prob, int n, int H, int W, float thresh,
                                                       int dilate, uint32_t* __restrict__ bitmap) {
+  a16_kernel_enter();
   const long long total = (long long)n * H * W;  // W % 32 == 0 -> total % 32 == 0
   const long long rounded = (total + 63) & ~63ll;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += (long long)gridDim.x * blockDim.x) {
@@ -609,6 +616,7 @@ constexpr int BS_THREADS = 256;
 __global__ __launch_bounds__(BS_THREADS) void box_score_kernel(const float* __restrict__ prob, int n, int H, int W,
                                                         const float* __restrict__ boxes, int nb,
                                                         float* __restrict__ scores) {
+  a16_kernel_enter();
   const int bi = blockIdx.x;
   if (bi >= nb) return;
   const float* bx = boxes + (size_t)bi * 9;

@@ -52,6 +52,7 @@ __device__ __forceinline__ void g_st(bf16_t* p, int lo, float v) {
 // x [B, HW, C] *= gate [B, C] (the Mul of a squeeze-and-excitation block)
 __global__ __launch_bounds__(256) void scale_channels_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gate,
                                                              bf16_t* __restrict__ out, long long total8, int HW, int C, int split) {
+  a16_kernel_enter();
   const int cg = C >> 3, lo = split ? C : 0, cs = split ? 2 * C : C;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (long long)gridDim.x * blockDim.x) {
     const int c8 = (int)(i % cg);
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(256) void scale_channels_kernel(const bf16_t* __res
 // kind: 1 relu, 2 hardswish, 4 sigmoid, 5 hardsigmoid (max(0, min(1, alpha x + beta))), 6 relu6, 7 GELU (erf), 8 swish
 __global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, long long total8, int kind,
                                                   float alpha, float beta, int C, int split) {
+  a16_kernel_enter();
   const int cg = C >> 3, lo = split ? C : 0, cs = split ? 2 * C : C;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (long long)gridDim.x * blockDim.x) {
     const long long off = (i / cg) * cs + (i % cg) * 8;
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ x, 
 // AveragePool k x k, stride k, no padding: out [B, H/k, W/k, C]
 __global__ __launch_bounds__(256) void avgpool_kxk_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B, int H, int W, int C,
                                                           int k, int split) {
+  a16_kernel_enter();
   const int Ho = H / k, Wo = W / k, cg = C >> 3, lo = split ? C : 0, cs = split ? 2 * C : C;
   const long long total = (long long)B * Ho * Wo * cg;
   const float inv = 1.f / (float)(k * k);
@@ -121,6 +124,7 @@ __global__ __launch_bounds__(256) void avgpool_kxk_kernel(const bf16_t* __restri
 // out[pix][dst_off + c] = src[pix][src_off + c], c < n: channel concat / slice without arithmetic
 __global__ __launch_bounds__(256) void copy_channels_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, long long npix, int scs, int soff,
                                                             int dcs, int doff, int n) {
+  a16_kernel_enter();
   const long long total = npix * n;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long pix = i / n;
@@ -131,6 +135,7 @@ __global__ __launch_bounds__(256) void copy_channels_kernel(const bf16_t* __rest
 
 // nearest-neighbour up-sampling by an integer factor: out [B, H f, W f, C]
 __global__ __launch_bounds__(256) void upsample_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B, int H, int W, int C, int f) {
+  a16_kernel_enter();
   const int cg = C >> 3, Wo = W * f, Ho = H * f;
   const long long total = (long long)B * Ho * Wo * cg;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -145,6 +150,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const bf16_t* __restrict_
 
 __global__ __launch_bounds__(256) void mul_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ out, long long total8,
                                                   int C, int split) {
+  a16_kernel_enter();
   const int cg = C >> 3, lo = split ? C : 0, cs = split ? 2 * C : C;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (long long)gridDim.x * blockDim.x) {
     const long long off = (i / cg) * cs + (i % cg) * 8;
@@ -172,6 +178,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // channels are written as zeros.  split: rows are [hi(Cp) | lo(Cp)]
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, long long rows, int Cp, int C,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int split) {
+  a16_kernel_enter();
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63, lo = split ? Cp : 0, cs = split ? 2 * Cp : Cp;
   if (row >= rows) return;
@@ -189,6 +196,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const bf16_t* __res
 // soft-max over the first C of Cp channels of every row -> fp32 probabilities [rows][C] (network outputs: CTC heads) or bf16 [rows][Cp] ([hi | lo] when split)
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const bf16_t* __restrict__ x, long long rows, int Cp, int C, float* __restrict__ out_f32,
                                                            bf16_t* __restrict__ out_bf, int split) {
+  a16_kernel_enter();
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63, lo = split ? Cp : 0, cs = split ? 2 * Cp : Cp;
   if (row >= rows) return;
@@ -211,6 +219,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const bf16_t* __restr
 // split: rows are [hi(qcs) | lo(qcs)] / [hi(ocs) | lo(ocs)]; scores, soft-max and the weighted sum in fp32 on hi + lo
 __global__ __launch_bounds__(64) void attention_rows_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int T, int heads, int d, int qcs,
                                                             int ocs, float scale, int split) {
+  a16_kernel_enter();
   __shared__ float p[1024];
   __shared__ float qs[64];
   const int t = blockIdx.x, h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
@@ -241,6 +250,7 @@ __global__ __launch_bounds__(64) void attention_rows_kernel(const bf16_t* __rest
 // byte copy by the compute units; either pointer may be pinned host memory (mapped into the device's address space)
 __global__ __launch_bounds__(256) void copy_bytes_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long long n16, const unsigned char* __restrict__ src_tail,
                                                          unsigned char* __restrict__ dst_tail, int tail) {
+  a16_kernel_enter();
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
   if (blockIdx.x == 0 && (int)threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
 }

@@ -63,6 +63,7 @@ template <int NOUT, int OST, int ACT>
 __global__ __launch_bounds__(256) void stem3x3s2_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w,
                                                          const float* __restrict__ b, bf16_t* __restrict__ out, int B,
                                                          int H, int W, int Ho, int Wo, int split) {
+  a16_kernel_enter();
   __shared__ float sw[NOUT * 36];
   __shared__ float sb[NOUT];
   for (int i = threadIdx.x; i < NOUT * 36; i += 256) sw[i] = w[i];
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
   // fused multiply-adds for the tap sums (the library is built with -ffp-contract=off for the bit-exact pre-processing
   // arithmetic; here mul + add as two VALU operations was half of the kernel's time)
 #pragma clang fp contract(fast)
+  a16_kernel_enter();
   constexpr int PX = 4, PAD = K / 2, NCOL = (PX - 1) * SX + K;
   const int cgn = C >> 3, cs = split ? 2 * C : C, wq = (Wo + PX - 1) / PX;
   const float sl = act == 3 ? slope[0] : 0.f;
@@ -190,6 +192,7 @@ __global__ __launch_bounds__(256) void dwconv2_kernel(const bf16_t* __restrict__
                                                        const float* __restrict__ b, bf16_t* __restrict__ out, int B, int H, int W,
                                                        int C, int Ho, int Wo, int act, int split, const float* __restrict__ slope) {
 #pragma clang fp contract(fast)
+  a16_kernel_enter();
   constexpr int PX = 4, PAD = K / 2, NCOL = PX - 1 + K;
   const int cgn = C >> 3, cs = split ? 2 * C : C, wq = (Wo + PX - 1) / PX, hq = (Ho + 1) >> 1;
   const float sl = act == 3 ? slope[0] : 0.f;
@@ -275,6 +278,7 @@ __global__ __launch_bounds__(256, 4) void dwconv_tile_kernel(const bf16_t* __res
                                                           bf16_t* __restrict__ out, int B, int H, int W, int C, int act, const float* __restrict__ slope,
                                                           int tiles_x, int tiles_y) {
 #pragma clang fp contract(fast)
+  a16_kernel_enter();
   constexpr int PAD = K / 2, CGN = CB / 8, TH = 8, TW = 16 * 64 / CB, TWIN = TW + K - 1, THIN = TH + K - 1, PX = 4, NCOL = PX + K - 1;
   constexpr int PITCH = CB * 2 + 32;             // bytes per staged pixel: the 16 lanes of a ds_read_b128 group then fall on distinct bank quads
   constexpr int NPIECE = THIN * TWIN * CGN;
@@ -357,6 +361,7 @@ __global__ __launch_bounds__(256, 4) void dwconv_tile_kernel(const bf16_t* __res
 // part: fp32 [B][gridDim.x][C]
 __global__ __launch_bounds__(256) void chan_partial_sum_kernel(const bf16_t* __restrict__ x, int HW, int C, int split,
                                                                 float* __restrict__ part) {
+  a16_kernel_enter();
   __shared__ float s_acc[256][8];
   const int cgn = C >> 3, cs = split ? 2 * C : C, nslot = 256 / cgn;
   const int tid = threadIdx.x, cg = tid % cgn, slot = tid / cgn;
@@ -387,6 +392,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const bf16_t* __restrict__
                                                        const float* __restrict__ b1, const float* __restrict__ w2,
                                                        const float* __restrict__ b2, float* __restrict__ gate, int split,
                                                        int Ch, int mode, const float* __restrict__ part, int nchunk) {
+  a16_kernel_enter();
   __shared__ float s_mean[512];
   __shared__ float s_hid[128];
   const int bi = blockIdx.x, tid = threadIdx.x, cs = split ? 2 * C : C;
@@ -418,6 +424,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const bf16_t* __restrict__
 
 __global__ __launch_bounds__(256) void se_scale_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gate,
                                                         bf16_t* __restrict__ out, int B, int HW, int C, int split) {
+  a16_kernel_enter();
   const int cgn = C >> 3, cs = split ? 2 * C : C;
   const long long total = (long long)B * HW * cgn;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -434,6 +441,7 @@ __global__ __launch_bounds__(256) void se_scale_kernel(const bf16_t* __restrict_
 
 __global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
                                                    bf16_t* __restrict__ out, long long npix, int C, int split) {
+  a16_kernel_enter();
   const int cgn = C >> 3, cs = split ? 2 * C : C;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= npix * cgn) return;
@@ -452,6 +460,7 @@ __global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a, 
 __global__ __launch_bounds__(256) void pico_candidates_kernel(const float* __restrict__ head, int B, int A, int ncls,
                                                                int level, float thr_lo, int max_cands,
                                                                float* __restrict__ cands, int* __restrict__ counts) {
+  a16_kernel_enter();
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long long)B * A) return;
   const int bi = (int)(i / A), a = (int)(i % A);
@@ -475,6 +484,7 @@ __global__ __launch_bounds__(256) void pico_candidates_kernel(const float* __res
 __global__ __launch_bounds__(256) void dbnas_tail_kernel(const bf16_t* __restrict__ y, const float* __restrict__ tw, int B,
                                                           int H4, int W4, int split, float* __restrict__ prob,
                                                           float* __restrict__ logits) {
+  a16_kernel_enter();
   __shared__ float sw[449];
   for (int i = threadIdx.x; i < 449; i += 256) sw[i] = tw[i];
   __syncthreads();
@@ -521,6 +531,7 @@ __global__ __launch_bounds__(256) void dbnas_tail_kernel(const bf16_t* __restric
 // are written as zeros (the classifier GEMM works on whole 32-row tiles)
 __global__ __launch_bounds__(256) void chan_mean_kernel(const float* __restrict__ part, int B, int rows, int nchunk, int C,
                                                         int HW, int split, bf16_t* __restrict__ mean) {
+  a16_kernel_enter();
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long long)rows * C) return;
   const int r = (int)(i / C), c = (int)(i % C);

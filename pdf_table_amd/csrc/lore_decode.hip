@@ -26,6 +26,7 @@ constexpr int K_CELLS = 3000, K_CORNERS = 5000;
 
 __global__ __launch_bounds__(256) void lore_sigmoid_kernel(const float* __restrict__ hm, float* __restrict__ sig,
                                                             long long npix) {
+  a16_kernel_enter();
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npix) return;
   sig[2 * i] = 1.f / (1.f + expf(-hm[8 * i]));
@@ -38,6 +39,7 @@ template <int NTHR>
 __global__ __launch_bounds__(NTHR) void lore_peaks_kernel(const float* __restrict__ sig, int B, int H, int W, float thr_cell,
                                                           float thr_corner, unsigned long long* __restrict__ keys,
                                                           int* __restrict__ counts) {
+  a16_kernel_enter();
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < (long long)B * H * W;
   const long long ic = live ? i : 0;
@@ -94,6 +96,7 @@ __global__ __launch_bounds__(1024) void lore_sort_kernel(const unsigned long lon
                                                           int stride_in, int kmax_even, int kmax_odd,
                                                           unsigned long long* __restrict__ out, int stride_out,
                                                           int* __restrict__ out_counts) {
+  a16_kernel_enter();
   extern __shared__ unsigned long long sk[];
   const int list = blockIdx.x;
   int n = counts[list * count_stride];
@@ -131,6 +134,7 @@ __global__ __launch_bounds__(256) void lore_boxes_kernel(const unsigned long lon
                                                           const float* __restrict__ reg0, const float* __restrict__ reg1,
                                                           const float* __restrict__ wh, const float* __restrict__ st,
                                                           const int* __restrict__ pk_base, float* __restrict__ boxes) {
+  a16_kernel_enter();
   const int list = blockIdx.y, b = list >> 1, cls = list & 1;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= counts[list]) return;
@@ -178,6 +182,7 @@ __device__ bool point_in_quad(double px, double py, const float* q) {
 // one wave per cell (cells with score >= 0.2 only, lineless_table_process.py:190); rev[(b, k)][0..7], new score [8]
 __global__ __launch_bounds__(64) void lore_snap_kernel(const float* __restrict__ boxes, const int* __restrict__ counts,
                                                         int stride, float* __restrict__ rev) {
+  a16_kernel_enter();
   const int b = blockIdx.y, k = blockIdx.x, lane = threadIdx.x;
   const int ncell = counts[2 * b], ncorner = counts[2 * b + 1];
   if (k >= ncell) return;
@@ -250,6 +255,7 @@ __global__ __launch_bounds__(64) void lore_snap_kernel(const float* __restrict__
 // key of cell k after the snap: (new score desc, previous rank asc)
 __global__ __launch_bounds__(256) void lore_rekey_kernel(const float* __restrict__ rev, const int* __restrict__ counts,
                                                           int stride, unsigned long long* __restrict__ keys) {
+  a16_kernel_enter();
   const int b = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= counts[2 * b]) return;
   const float s = rev[((size_t)b * stride + k) * 12 + 8];
@@ -273,6 +279,7 @@ __device__ __forceinline__ int patch_off(int tap, int ch, int C) {
 // exclusive prefix of the kept cell counts over the tables + the two row limits of the mosaics (one thread: B <= 64)
 // base[b] = sum_{b' < b} ncell[b'];  lim[0] / lim[1] = pixel rows of the ax / cr mosaic that hold patches
 __global__ void lore_sparse_base_kernel(const int* __restrict__ counts, int B, int* __restrict__ base, int* __restrict__ lim) {
+  a16_kernel_enter();
   if (threadIdx.x || blockIdx.x) return;
   long long t = 0;
   for (int b = 0; b < B; ++b) {
@@ -286,6 +293,7 @@ __global__ void lore_sparse_base_kernel(const int* __restrict__ counts, int B, i
 // the same for the kept peaks of the first sort: pk_base[2 b + cls] = number of kept peaks of class cls in the tables
 // before b; lim[0] / lim[1] = pixel rows of the cell / corner mosaic that hold patches
 __global__ void lore_peak_base_kernel(const int* __restrict__ kept, int B, int* __restrict__ pk_base, int* __restrict__ lim) {
+  a16_kernel_enter();
   if (threadIdx.x || blockIdx.x) return;
   long long t0 = 0, t1 = 0;
   for (int b = 0; b < B; ++b) {
@@ -304,6 +312,7 @@ __global__ __launch_bounds__(64) void lore_peak_patch_kernel(const unsigned long
                                                              const bf16_t* __restrict__ feat, int C, int split,
                                                              const int* __restrict__ pk_base, bf16_t* __restrict__ mos_cell,
                                                              bf16_t* __restrict__ mos_corner) {
+  a16_kernel_enter();
   const int list = blockIdx.y, b = list >> 1, cls = list & 1, k = blockIdx.x;
   if (k >= kept[list]) return;
   const int idx = (int)(0xFFFFFFFFu - (unsigned)(sorted[(size_t)list * stride + k] & 0xFFFFFFFFull));
@@ -329,6 +338,7 @@ __global__ __launch_bounds__(256) void lore_patch_gather_kernel(const float* __r
                                                                 const bf16_t* __restrict__ feat, int C, int split,
                                                                 const int* __restrict__ sp_base, bf16_t* __restrict__ mos_ax,
                                                                 bf16_t* __restrict__ mos_cr) {
+  a16_kernel_enter();
   const int b = blockIdx.y, p = blockIdx.x;
   const int ncell = counts[2 * b];
   if (p >= ncell) return;
@@ -373,6 +383,7 @@ __global__ __launch_bounds__(256) void lore_gather_kernel(const float* __restric
                                                            float vis_thresh, float* __restrict__ dets,
                                                            float* __restrict__ logi, int* __restrict__ n_valid,
                                                            const int* __restrict__ sp_base) {
+  a16_kernel_enter();
   const int b = blockIdx.y, p = blockIdx.x, c = threadIdx.x;
   const int ncell = counts[2 * b];
   if (p >= ncell) return;

@@ -57,6 +57,7 @@ __device__ __forceinline__ void store8(bf16_t* p, int lo_off, int split, const f
 __global__ __launch_bounds__(256) void dcn_im2col_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
                                                           bf16_t* __restrict__ cols, int B, int H, int W, int C,
                                                           int split) {
+  a16_kernel_enter();
   const int cgn = C >> 3;
   const int cs = split ? 2 * C : C;
   const int kc = 9 * C;
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const bf16_t* __restric
 __global__ __launch_bounds__(256) void dwconvt_up_add_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w,
                                                               const bf16_t* __restrict__ add, bf16_t* __restrict__ out,
                                                               int B, int h, int wd, int C, int f, int split) {
+  a16_kernel_enter();
   const int cgn = C >> 3;
   const int cs = split ? 2 * C : C;
   const int OH = h * f, OW = wd * f, p = f / 2, k = 2 * f;
@@ -163,6 +165,7 @@ template <int PACKED>
 __global__ __launch_bounds__(256) void dwconvt_up2_add_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w,
                                                                const bf16_t* __restrict__ add, bf16_t* __restrict__ out,
                                                                int B, int h, int wd, int C, int split) {
+  a16_kernel_enter();
   extern __shared__ __attribute__((aligned(16))) float s_w[];                    // [16][C]
   for (int i = threadIdx.x; i < 16 * C; i += 256) s_w[i] = w[i];
   __syncthreads();
@@ -284,6 +287,7 @@ __global__ __launch_bounds__(256) void tsr_preprocess_kernel(const uint8_t* __re
                                                               const pt_tsr_table* __restrict__ tabs, int H, int W, int bgr,
                                                               const float* __restrict__ lut, bf16_t* __restrict__ out,
                                                               int split) {
+  a16_kernel_enter();
   const int t = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= H * W) return;
@@ -352,6 +356,7 @@ __global__ __launch_bounds__(256, (SPLIT || NB > 64) ? 2 : 4) void dcn_fused_ker
                                                             bf16_t* __restrict__ out, long long npix, int H, int W, int C,
                                                             int N, int relu) {
 #pragma clang fp contract(fast)
+  a16_kernel_enter();
   constexpr int ROW = 80;                       // bytes per staged row (32 bf16 + 16 B pad)
   constexpr int NP = SPLIT ? 2 : 1;
   constexpr int NT = NB / 32;                   // 32-wide MFMA column tiles
@@ -547,6 +552,7 @@ __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) voi
                                                               bf16_t* __restrict__ out, long long npix, int H, int W,
                                                               int C, int N, int relu) {
 #pragma clang fp contract(fast)
+  a16_kernel_enter();
   constexpr int ROW = 144;                      // 64 bf16 + 16 B pad
   constexpr int IT = 1024 / NTHR;               // (pixel, 16-byte piece) items per thread per stage
   constexpr int PSTEP = NTHR / 8;               // pixel distance between a thread's items
@@ -867,6 +873,7 @@ __global__ __launch_bounds__(512, (NB == 64 && RING == 4) ? 2 : 1) void dcn_mfma
                                                                             bf16_t* __restrict__ out, long long npix, int H, int W, int C,
                                                                             int N, int relu) {
 #pragma clang fp contract(fast)
+  a16_kernel_enter();
   static_assert(RING == 4 || RING == 8, "ring slots must divide the eight steps of a stage");
   constexpr int NT = NB / 32;                   // 32-column tiles of the product (every wave: all NB outputs over its 32 channels)
   constexpr int WP = NB / 64;                   // weight DMAs per wave per stage (1 KB each)
@@ -1101,6 +1108,7 @@ __global__ __launch_bounds__(512, 2) void dcn_mfma2_kernel(const bf16_t* __restr
                                                             const float* __restrict__ bias, bf16_t* __restrict__ out, long long npix, int H, int W,
                                                             int C, int N, int relu) {
 #pragma clang fp contract(fast)
+  a16_kernel_enter();
   constexpr int NT = 2, D = 7;                  // 32-column tiles of the product; K = 16 steps in flight ahead of the one being multiplied
   constexpr int W_BYTES = DcnMfma2Smem::W_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1325,6 +1333,7 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const bf16_t* __restri
                                                            const float* __restrict__ bias, bf16_t* __restrict__ out,
                                                            int B, int H, int W, int Ho, int Wo, int N, int tiles_x,
                                                            int tiles_y) {
+  a16_kernel_enter();
   constexpr int TH = STRIDE == 1 ? 8 : 4, TW = (STRIDE == 2 && SPLIT) ? 32 : 64;   // (LDS: <= 64 KB static)
   constexpr int RPW = TH / 4;                              // output rows per wave
   constexpr int PH = (TH - 1) * STRIDE + 3, PW = (TW - 1) * STRIDE + 3;
@@ -1443,6 +1452,7 @@ __global__ __launch_bounds__(512, 1) void dla_thin_chain_kernel(const bf16_t* __
                                                                 const float* __restrict__ b0, const bf16_t* __restrict__ w1,
                                                                 const float* __restrict__ b1, bf16_t* __restrict__ out, int B, int H, int W,
                                                                 int tiles_x, int tiles_y) {
+  a16_kernel_enter();
   using C = ThinChainCfg;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_in = smem;

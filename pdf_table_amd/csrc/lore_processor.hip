@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void tok_prepare_kernel(const float* __restric
                                                            const int* __restrict__ tok, int N, int use_pe,
                                                            const float* __restrict__ x_pe, const float* __restrict__ y_pe,
                                                            bf16_t* __restrict__ x0, bf16_t* __restrict__ cat, int split) {
+  a16_kernel_enter();
   const int t = blockIdx.x, c = threadIdx.x;
   float v = 0.f;
   if (t < N) {
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(256) void tok_prepare_kernel(const float* __restric
 __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
                                                     const float* __restrict__ bias, bf16_t* __restrict__ out, int Npad,
                                                     int split) {
+  a16_kernel_enter();
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (t >= Npad) return;
   const float4 v = *reinterpret_cast<const float4*>(x + (size_t)t * 256 + lane * 4);
@@ -87,6 +89,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
 // fp32 [Npad, 8] (4 valid) -> bf16 [Npad, 32] zero padded: the stacker's logi_encoder input (:383)
 __global__ __launch_bounds__(256) void cvt_logic_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int Npad,
                                                          int split) {
+  a16_kernel_enter();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Npad * 32) return;
   const int t = i >> 5, c = i & 31;
@@ -110,6 +113,7 @@ __device__ __forceinline__ abf16x8 ld8(const bf16_t* p) { return *reinterpret_ca
 template <int SPLIT>
 __global__ __launch_bounds__(64) void attention_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ tiles,
                                                         bf16_t* __restrict__ out) {
+  a16_kernel_enter();
   const int tile = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
   const int tok0 = tiles[3 * tile], q0 = tiles[3 * tile + 1], nseg = tiles[3 * tile + 2];
   constexpr int cs = SPLIT ? 1536 : 768;
@@ -196,6 +200,7 @@ __global__ __launch_bounds__(64) void attention_kernel(const bf16_t* __restrict_
 // fp32 [Npad, 8] token rows -> out[table][row][4]
 __global__ __launch_bounds__(256) void scatter4_kernel(const float* __restrict__ x, const int* __restrict__ tok, int N,
                                                         float* __restrict__ out) {
+  a16_kernel_enter();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * 4) return;
   const int t = i >> 2, c = i & 3;

@@ -84,6 +84,7 @@ __device__ __forceinline__ void unpack8(const uint4 u, float* f) {
 // + pe[token] -> bf16 (hi | lo) rows; rows >= rows_valid are zero.  One wave per row.
 __global__ __launch_bounds__(256) void mtl_feature_kernel(const float* __restrict__ f3, const float* __restrict__ pe, long long rows_valid,
                                                           long long rows_pad, int hw, bf16_t* __restrict__ out, int split) {
+  a16_kernel_enter();
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows_pad) return;
@@ -102,6 +103,7 @@ __global__ __launch_bounds__(256) void mtl_feature_kernel(const float* __restric
 __global__ __launch_bounds__(256) void mtl_embed_kernel(const int* __restrict__ tok, const float* __restrict__ emb, const float* __restrict__ pe, int p0,
                                                         int npos, int Mp, int M, float* __restrict__ xout, bf16_t* __restrict__ cin,
                                                         const float* __restrict__ x2keep, const int* __restrict__ src_row, int split) {
+  a16_kernel_enter();
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= (long long)npos * Mp) return;
@@ -124,6 +126,7 @@ __global__ __launch_bounds__(256) void mtl_embed_kernel(const int* __restrict__ 
 // nn.LayerNorm(512) (biased variance, eps = 1e-5 inside the root) of fp32 rows -> bf16 (hi | lo).  One wave per row.
 __global__ __launch_bounds__(256) void mtl_ln_kernel(const float* __restrict__ x, long long rows, const float* __restrict__ g,
                                                      const float* __restrict__ b, bf16_t* __restrict__ out, int split) {
+  a16_kernel_enter();
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -150,6 +153,7 @@ __global__ __launch_bounds__(256) void mtl_ln_kernel(const float* __restrict__ x
 // p1, -> keep[p][s] (x2 of every position: what the cell-content decoder reads, :399)
 __global__ __launch_bounds__(256) void mtl_fork_kernel(const float* __restrict__ a, float* __restrict__ b, float* __restrict__ c, float* __restrict__ keep,
                                                        const int* __restrict__ fin, int p0, int p1, int Mp, int M) {
+  a16_kernel_enter();
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)(p1 - p0 + 1) * Mp * (D / 4);
   if (i >= total) return;
@@ -168,6 +172,7 @@ __global__ __launch_bounds__(256) void mtl_fork_kernel(const float* __restrict__
 template <int SPLIT>
 __global__ __launch_bounds__(64) void mtl_self_attn_kernel(const bf16_t* __restrict__ cache, const int* __restrict__ tok, int pad, int p0, int Mp, int M,
                                                            int Lcur, bf16_t* __restrict__ att) {
+  a16_kernel_enter();
   extern __shared__ float sc[];
   const int pi = blockIdx.x / M, s = blockIdx.x % M, p = p0 + pi, head = blockIdx.y, lane = threadIdx.x;
   constexpr int LO = 3 * D, cs = SPLIT ? 2 * LO : LO;
@@ -239,6 +244,7 @@ template <int SPLIT>
 __global__ __launch_bounds__(64) void mtl_cross_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, int koff, const int4* __restrict__ tiles,
                                                             int hw, int keys_per_split, int nsplit, long long R, float* __restrict__ opart,
                                                             float* __restrict__ mlpart, bf16_t* __restrict__ att) {
+  a16_kernel_enter();
   const int4 tile = tiles[blockIdx.x];
   const int head = blockIdx.y, z = blockIdx.z, lane = threadIdx.x;
   const int tab = tile.x, row0 = tile.y, cnt = tile.z, rstride = tile.w;
@@ -352,6 +358,7 @@ template <int SPLIT>
 __global__ __launch_bounds__(512) void mtl_cross_decode_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, int koff, const int4* __restrict__ tiles,
                                                               int hw, int keys_per_split, int nsplit, long long R, float* __restrict__ opart,
                                                               float* __restrict__ mlpart, bf16_t* __restrict__ att) {
+  a16_kernel_enter();
   const int4 tile = tiles[blockIdx.x];
   const int head = threadIdx.x >> 6, lane = threadIdx.x & 63, z = blockIdx.y;
   const int g = lane >> 3, c = lane & 7;
@@ -473,6 +480,7 @@ __global__ __launch_bounds__(512) void mtl_cross_decode_kernel(const bf16_t* __r
 constexpr float KV8_SCALE = 8.f;
 
 __global__ __launch_bounds__(256) void mtl_kv_fp8_kernel(const bf16_t* __restrict__ kv, long long n8, unsigned char* __restrict__ out) {
+  a16_kernel_enter();
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n8) return;
   float f[8];
@@ -501,6 +509,7 @@ __device__ __forceinline__ void unpack16_fp8(const uint4 u, float* f) {
 __global__ __launch_bounds__(512) void mtl_cross_decode8_kernel(const bf16_t* __restrict__ q, const unsigned char* __restrict__ kv8, int koff,
                                                                const int4* __restrict__ tiles, int hw, int keys_per_split, int nsplit, long long R,
                                                                float* __restrict__ opart, float* __restrict__ mlpart, bf16_t* __restrict__ att) {
+  a16_kernel_enter();
   const int4 tile = tiles[blockIdx.x];
   const int head = threadIdx.x >> 6, lane = threadIdx.x & 63, z = blockIdx.y;
   const int g = lane >> 2, c = lane & 3;
@@ -593,6 +602,7 @@ __global__ __launch_bounds__(512) void mtl_cross_decode8_kernel(const bf16_t* __
 // merges the key slices of mtl_cross_attn_kernel: out = sum_z e^(m_z - M) acc_z / sum_z e^(m_z - M) l_z.  thread = (row, channel)
 __global__ __launch_bounds__(512) void mtl_cross_combine_kernel(const float* __restrict__ opart, const float* __restrict__ mlpart, int nsplit, long long R, int Mp,
                                                                 int M, bf16_t* __restrict__ att, int split) {
+  a16_kernel_enter();
   const int pi = blockIdx.x / M, s = blockIdx.x % M, c = threadIdx.x, head = c >> 6;
   const long long row = (long long)pi * Mp + s;
   float mx = -INFINITY;
@@ -615,6 +625,7 @@ __global__ __launch_bounds__(256) void mtl_tag_pick_kernel(const float* __restri
                                                            int ncls_p, int eos, int pad, int max_len, int T, int* __restrict__ tok, int* __restrict__ ids,
                                                            int* __restrict__ fin, int* __restrict__ first_pad, float* __restrict__ out_logits,
                                                            float* __restrict__ out_boxes) {
+  a16_kernel_enter();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (p1 - p0 + 1) * M) return;
   const int pi = i / M, s = i % M, p = p0 + pi;
@@ -654,6 +665,7 @@ __global__ __launch_bounds__(256) void mtl_tag_pick_kernel(const float* __restri
 __global__ __launch_bounds__(256) void mtl_cell_pick_kernel(const float* __restrict__ lg, int p0, int p1, int Mp, int M, int ncell, int ncell_p, int Tc,
                                                             const int* __restrict__ cell_tab, const int* __restrict__ finc, int* __restrict__ nxt,
                                                             int* __restrict__ cell_ids, float* __restrict__ cell_prob, float* __restrict__ cell_logits) {
+  a16_kernel_enter();
   const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (w >= (long long)(p1 - p0 + 1) * M) return;
@@ -687,6 +699,7 @@ __global__ __launch_bounds__(256) void mtl_cell_pick_kernel(const float* __restr
 // this step, or at the length limit; otherwise every cell's arg-max is appended.
 __global__ __launch_bounds__(256) void mtl_cell_next_kernel(const int* __restrict__ tab_first, const int* __restrict__ nxt, int p1, int Mp, int eos, int pad,
                                                             int max_len, int* __restrict__ tok, int* __restrict__ finc, int* __restrict__ first_pad) {
+  a16_kernel_enter();
   __shared__ int cnt;
   const int b = blockIdx.x, c0 = tab_first[b], c1 = tab_first[b + 1];
   const bool running = finc[b] >= p1;
@@ -708,12 +721,14 @@ __global__ __launch_bounds__(256) void mtl_cell_next_kernel(const int* __restric
 }
 
 __global__ void mtl_fill_kernel(int* __restrict__ p, int n, int v) {
+  a16_kernel_enter();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
 }
 
 // roll back to step `step`: sequences that ended later are running again
 __global__ void mtl_rollback_kernel(int* __restrict__ fin, int n, int step) {
+  a16_kernel_enter();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && fin[i] > step) fin[i] = INT_MAX;
 }
@@ -757,6 +772,7 @@ __device__ __forceinline__ RCoef mtl_coef(int d, double scale, int ssize, bool c
 // TableResize + TablePad + ToTensorOCR + NormalizeOCR of one table crop per blockIdx.y: out bf16 [n, size, size, 32] (hi | lo)
 __global__ __launch_bounds__(256) void mtl_preprocess_kernel(const uint8_t* __restrict__ pages, int ph, int pw, const pt_tsr_table* __restrict__ tabs, int size,
                                                              bf16_t* __restrict__ out, int split) {
+  a16_kernel_enter();
   const int b = blockIdx.y;
   const pt_tsr_table t = tabs[b];
   int nw, nh;
@@ -842,6 +858,7 @@ constexpr int ROWGEMM_CH = 4;
 template <int SPLIT>
 __global__ __launch_bounds__(256) void mtl_rowgemm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, int cin, int N, long long rows,
                                                          float* __restrict__ part) {
+  a16_kernel_enter();
   const int nt = blockIdx.x, z = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int col = lane & 31, half = lane >> 5;
   const long long row = (long long)blockIdx.z * 128 + wave * 32 + col;
@@ -893,6 +910,7 @@ __global__ __launch_bounds__(256) void mtl_rowgemm_kernel(const bf16_t* __restri
 __global__ __launch_bounds__(256) void mtl_rowgemm_finish_kernel(const float* __restrict__ part, int nz, long long rows, int N, const float* __restrict__ bias,
                                                                 int relu, bf16_t* __restrict__ out, int out_cs, int split, float* __restrict__ out_f32,
                                                                 int f32_cs, const float* __restrict__ res_f32, int n_valid) {
+  a16_kernel_enter();
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const int q4 = N >> 2;
   if (i >= rows * q4) return;

@@ -58,6 +58,7 @@ constexpr int GC_CHUNK = 128;
 
 __global__ __launch_bounds__(256) void gc_logits_kernel(const bf16_t* __restrict__ x, long long npix, int C, const float* __restrict__ wm,
                                                         const float* __restrict__ bm, float* __restrict__ logit, int split) {
+  a16_kernel_enter();
   const long long px = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (px >= npix) return;
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(256) void gc_logits_kernel(const bf16_t* __restrict
 }
 
 __global__ __launch_bounds__(512) void gc_softmax_kernel(float* __restrict__ logit, int HW) {
+  a16_kernel_enter();
   __shared__ float red[8];
   float* l = logit + (size_t)blockIdx.x * HW;
   float mx = -INFINITY;
@@ -88,6 +90,7 @@ __global__ __launch_bounds__(512) void gc_softmax_kernel(float* __restrict__ log
 
 __global__ __launch_bounds__(512) void gc_pool_kernel(const bf16_t* __restrict__ x, const float* __restrict__ p, int HW, int C, int nchunk,
                                                       float* __restrict__ part, int split) {
+  a16_kernel_enter();
   const int b = blockIdx.y, ch = blockIdx.x, c = threadIdx.x;
   if (c >= C) return;
   const int cs = split ? 2 * C : C;
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(512) void gc_pool_kernel(const bf16_t* __restrict__
 __global__ __launch_bounds__(512) void gc_mlp_kernel(const float* __restrict__ part, int nchunk, int C, int hid, const float* __restrict__ w0,
                                                      const float* __restrict__ b0, const float* __restrict__ lg, const float* __restrict__ lb,
                                                      const float* __restrict__ w3, const float* __restrict__ b3, float* __restrict__ t) {
+  a16_kernel_enter();
   __shared__ float ctx[512];
   __shared__ float hbuf[64];
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -136,6 +140,7 @@ __global__ __launch_bounds__(512) void gc_mlp_kernel(const float* __restrict__ p
 // out = ReLU(x + t[image][c] + res)   (BasicBlock.forward :191-200 with the context block's broadcast add)
 __global__ __launch_bounds__(256) void gc_add_relu_kernel(const bf16_t* __restrict__ x, const float* __restrict__ t, const bf16_t* __restrict__ res,
                                                           bf16_t* __restrict__ out, long long total, int HW, int C, int split) {
+  a16_kernel_enter();
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     const long long px = i / C;

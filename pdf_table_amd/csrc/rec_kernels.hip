@@ -32,6 +32,7 @@ __device__ __forceinline__ uint32_t rf2bf(float f) { return f32_to_a16(f); }
 __global__ __launch_bounds__(256) void rec_warp_kernel(const uint8_t* __restrict__ pages, int ph, int pw,
                                                         const pt_rec_line* __restrict__ lines, int n_lines,
                                                         const long long* __restrict__ pix_off, uint8_t* __restrict__ crops) {
+  a16_kernel_enter();
   const int li = blockIdx.y;
   if (li >= n_lines) return;
   const pt_rec_line L = lines[li];
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(256) void rec_warp_kernel(const uint8_t* __restrict
 // One workgroup, chunked Hillis-Steele scan in LDS with a running carry (n is a micro-batch: a few thousand lines).
 __global__ __launch_bounds__(1024) void rec_offsets_kernel(const pt_rec_line* __restrict__ lines, int n,
                                                            long long* __restrict__ off) {
+  a16_kernel_enter();
   __shared__ long long sc[1024];
   __shared__ long long carry;
   const int tid = threadIdx.x;
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(256) void rec_resize_gray_kernel(const uint8_t* __r
                                                                const long long* __restrict__ pix_off, int n_lines, int TH,
                                                                int TWID, int split, bf16_t* __restrict__ out,
                                                                float* __restrict__ out_f32) {
+  a16_kernel_enter();
   const long long total = (long long)n_lines * TH * TWID;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int x = (int)(i % TWID);
@@ -237,6 +240,7 @@ int pt_launch_rec_resize_gray_f32(const uint8_t* crops, const pt_rec_line* lines
 // ---------------------------------------------------------------------------------------------------
 __global__ void crnn_limits_kernel(const pt_rec_line* __restrict__ lines, int n, int* l1, int* l2a, int* l2b, int* l3a, int* l3b,
                                    int* l0, int* __restrict__ cols) {
+  a16_kernel_enter();
   __shared__ int sums[6];
   if (threadIdx.x < 6) sums[threadIdx.x] = 0;
   __syncthreads();
@@ -268,6 +272,7 @@ __global__ void crnn_limits_kernel(const pt_rec_line* __restrict__ lines, int n,
 // The live 32-step row groups of the sequence GEMMs, compacted: glist[0] = their number, glist[1 + g] = row group (line * 5 + k) of the g-th,
 // in line order (k * 32 < lim[line]).  One workgroup: per-thread runs of lines, an exclusive scan of the runs' counts through LDS.
 __global__ __launch_bounds__(1024) void rows_live_list_kernel(const int* __restrict__ lim, int n, int* __restrict__ glist) {
+  a16_kernel_enter();
   __shared__ int part[1024];
   const int tid = threadIdx.x, per = (n + 1023) / 1024, b0 = tid * per, b1 = min(n, b0 + per);
   int cnt = 0;
@@ -310,6 +315,7 @@ int pt_launch_crnn_limits(const pt_rec_line* lines, int n, const PtCrnnLimits& L
 __global__ __launch_bounds__(256) void crnn_fill_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ ref,
                                                          const int* __restrict__ lim, int tile_w, int div, int rows, int W, int cs,
                                                          const int* __restrict__ end_lim, int end_tile) {
+  a16_kernel_enter();
   const int b = blockIdx.y;
   const int xf = ((lim[b] + tile_w - 1) / tile_w * tile_w) / div;
   int xe = W;
@@ -351,6 +357,7 @@ __global__ __launch_bounds__(256) void rec_pp_resize_norm_kernel(const uint8_t* 
                                                                   const long long* __restrict__ pix_off,
                                                                   const pt_rec_pp_item* __restrict__ items, int img_h,
                                                                   const float* __restrict__ lut, float* __restrict__ out) {
+  a16_kernel_enter();
   __shared__ float slut[256];
   slut[threadIdx.x] = lut[threadIdx.x];
   __syncthreads();
@@ -416,6 +423,7 @@ __global__ __launch_bounds__(256) void crnn_conv0_pool_kernel(const bf16_t* __re
                                                                const float* __restrict__ w64x9,
                                                                const float* __restrict__ bias, int split,
                                                                bf16_t* __restrict__ out, const int* __restrict__ xlim) {
+  a16_kernel_enter();
   __shared__ float sw[64 * 9 + 64];
   for (int i = threadIdx.x; i < 64 * 9; i += blockDim.x) sw[i] = w64x9[i];
   for (int i = threadIdx.x; i < 64; i += blockDim.x) sw[576 + i] = bias[i];
@@ -496,6 +504,7 @@ __global__ __launch_bounds__(256) void crnn_conv0_pool_mfma_kernel(const bf16_t*
                                                                     const float* __restrict__ w64x9,
                                                                     const float* __restrict__ bias, bf16_t* __restrict__ out,
                                                                     const int* __restrict__ xlim) {
+  a16_kernel_enter();
   constexpr int PR = 4, PC = 64;                  // pooled rows x cols per workgroup
   constexpr int LW = 2 * PC + 2, LH = 2 * PR + 2; // gray patch with a 1-pixel halo
   __shared__ bf16_t sg[LH * LW];
@@ -600,6 +609,7 @@ int pt_launch_crnn_conv0_pool(const bf16_t* in, int n, int H, int W, const float
 __global__ __launch_bounds__(256) void maxpool_kxk_kernel(const bf16_t* __restrict__ in, int n, int H, int W, int C,
                                                            int kh, int kw, int h2c, int split,
                                                            bf16_t* __restrict__ out) {
+  a16_kernel_enter();
   const int Ho = H / kh, Wo = W / kw, cgn = C >> 3;
   const int cs = split ? 2 * C : C;
   const long long total = (long long)n * Ho * Wo * cgn;
@@ -686,6 +696,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
 template <int SPLIT, int NG = 1>
 __global__ __launch_bounds__(256 * NG, 1) void lstm_dir_kernel(const bf16_t* __restrict__ gx, const bf16_t* __restrict__ whh,
                                                            bf16_t* __restrict__ hout, int B, int T) {
+  a16_kernel_enter();
   constexpr int NP = SPLIT ? 2 : 1;
   constexpr int HROW = 264;  // 256 + 8 bf16: 528-byte rows = 33 16-byte slots (odd) -> conflict-free b128 reads
   __shared__ __attribute__((aligned(16))) bf16_t hbuf_all[NG][NP][32][HROW];  // read by the group's waves (MFMA), then rewritten
@@ -845,6 +856,7 @@ __global__ __launch_bounds__(256 * NG, 1) void lstm_dir_kernel(const bf16_t* __r
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 1) void lstm_dir_dma_kernel(const bf16_t* __restrict__ gx, const bf16_t* __restrict__ whh,
                                                                bf16_t* __restrict__ hout, int B, int T) {
+  a16_kernel_enter();
   constexpr int HROW = 264;
   extern __shared__ __attribute__((aligned(16))) char lsm[];
   bf16_t (*hbuf)[HROW] = reinterpret_cast<bf16_t (*)[HROW]>(lsm);                     // [32][HROW]
@@ -969,6 +981,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(const bf16_t* __re
                                                                bf16_t* __restrict__ hout, int B, int T, int ncl,
                                                                bf16_t* __restrict__ hx, int* __restrict__ flags,
                                                                int* __restrict__ err) {
+  a16_kernel_enter();
   constexpr int CLL = 64 * MI;                                 // lines per cluster
   extern __shared__ __attribute__((aligned(16))) char lsm[];
   char* wl = lsm;                                              // [16 ks][4 g][2 h][64 lanes][16 B] = 128 KB
@@ -1182,6 +1195,7 @@ __global__ __launch_bounds__(64 * NW, 1) void lstm_cluster8_x3_kernel(const bf16
                                                                    bf16_t* __restrict__ hout, int B, int T, int ncl,
                                                                    unsigned long long* __restrict__ hx, int* __restrict__ flags,
                                                                    int* __restrict__ err) {
+  a16_kernel_enter();
   constexpr int CLL = 32 * NW * MI, NTILE = NW * MI, NTHR = 64 * NW;      // lines / 32-line tiles per cluster
   extern __shared__ __attribute__((aligned(16))) char lsm[];
   char* wl = lsm;                                              // [2 (hi, lo)][16 ks][4 g][64 lanes][16 B] = 128 KB
@@ -1484,6 +1498,7 @@ int pt_launch_lstm(pt_engine* e, const bf16_t* gx, const bf16_t* whh, bf16_t* ho
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void argmax_reduce_kernel(const float2* __restrict__ part, long long rows, int ntiles,
                                                              int* __restrict__ ids, float* __restrict__ maxv) {
+  a16_kernel_enter();
   for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long long)gridDim.x * blockDim.x) {
     const float2* p = part + r * ntiles;
     float bv = p[0].x;
@@ -1535,6 +1550,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_argmax_kernel(const bf16_t* _
                                                              int N, int* __restrict__ ids, float* __restrict__ maxv,
                                                              bf16_t* __restrict__ out, int relu, const int* __restrict__ tlim,
                                                              int lda, long long wts) {
+  a16_kernel_enter();
   // lda: elements between rows of A (K, or 2 K for the hi halves of (hi | lo) rows); wts: elements between 64-class tiles of W
   // (NCH * 2048, or three times that for the first third -- the w_hi chunks -- of the three-pass tiling)
   constexpr int K = KSTEPS * 16, NCH = K / 32, P = K * 2 + 16;     // P: LDS row pitch in bytes (odd number of 16-B slots)
@@ -1673,6 +1689,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_argmax_kernel(const bf16_t* _
 constexpr int CAND_SLOTS = 8;      // per (row, half of the classes a lane pair splits): 16 per row
 
 __global__ __launch_bounds__(256) void wnorm_max_kernel(const bf16_t* __restrict__ W3, int N, int K, unsigned* __restrict__ out) {
+  a16_kernel_enter();
   // max over classes of |w_hi + w_lo|: a workgroup per 64-class tile of the [N/64][3 K/32][64][32] tensor (chunks: hi, hi, lo), a wave per
   // class row, one atomic per workgroup
   __shared__ float smax[4];
@@ -1703,6 +1720,7 @@ __global__ __launch_bounds__(256, 2) void gemm_cand_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ W, long long wts, const float* __restrict__ bias,
                                                            int N, const float* __restrict__ wmax, const float* __restrict__ rowmax,
                                                            int* __restrict__ cand) {
+  a16_kernel_enter();
   constexpr int K = KSTEPS * 16, P = K * 2 + 16;
   constexpr int NPF = 64 * K * 2 / 16 / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1784,6 +1802,7 @@ __global__ __launch_bounds__(256) void cand_eval_kernel(const bf16_t* __restrict
                                                         const float* __restrict__ bias, int N, int n_real, const int* __restrict__ cand,
                                                         int* __restrict__ ids, float* __restrict__ maxv, int* __restrict__ ovf_count,
                                                         int* __restrict__ ovf_rows) {
+  a16_kernel_enter();
   const int lane = threadIdx.x & 63, l = lane & 15;
   const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
   const long long rc = row < M ? row : M - 1;
@@ -1847,6 +1866,7 @@ __global__ __launch_bounds__(256) void cand_eval_kernel(const bf16_t* __restrict
 __global__ __launch_bounds__(256) void cand_full_kernel(const bf16_t* __restrict__ A, int lda, int K, const bf16_t* __restrict__ W3,
                                                         const float* __restrict__ bias, int n_real, const int* __restrict__ ovf_count,
                                                         const int* __restrict__ ovf_rows, int* __restrict__ ids, float* __restrict__ maxv) {
+  a16_kernel_enter();
   __shared__ float sv[16];
   __shared__ int si[16];
   const int lane = threadIdx.x & 63, l = lane & 15, g = threadIdx.x >> 4;
@@ -2013,6 +2033,7 @@ template <int KSTEPS>
 __global__ __launch_bounds__(256, KSTEPS == 32 ? 1 : 2) void gemm_rows_x3_kernel(const bf16_t* __restrict__ A, long long M, const bf16_t* __restrict__ W3,
                                                                                  const float* __restrict__ bias, int N, bf16_t* __restrict__ out, int relu,
                                                                                  const int* __restrict__ tlim) {
+  a16_kernel_enter();
   constexpr int K = KSTEPS * 16, NCH = K / 32, P = K * 2 + 16;
   constexpr int NPF = NCH;                              // 16-byte pieces per thread per stage: 2 planes x 32 rows x K * 2 / 16 / 256
   extern __shared__ __attribute__((aligned(16))) char smem[];

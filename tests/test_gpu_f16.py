@@ -110,6 +110,16 @@ def test_store_saturates_instead_of_inf(eng16):
     s = eng16.op_add(-a, -a)
     torch.cuda.synchronize()
     assert float(s.float().min()) == -F16_MAX
+    # the other kernel families' stores (the saturation is MODE.FP16_OVFL, set at the top of EVERY kernel: csrc/act16.h a16_kernel_enter)
+    m = torch.full((1, 4, 4, 32), 300.0, dtype=torch.float16, device=dev)
+    s = eng16.op_mul(m, m)                                                  # 90 000 (graph_ops.hip)
+    torch.cuda.synchronize()
+    assert float(s.float().max()) == F16_MAX == float(s.float().min())
+    wt = torch.zeros(9, 32, device=dev)
+    wt[4] = 3.0
+    s = eng16.op_dwconv(torch.full((1, 8, 8, 32), 30000.0, dtype=torch.float16, device=dev), wt, torch.zeros(32, device=dev), 3)      # depthwise: 90 000 (layout_kernels.hip)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(s.float()).all()) and float(s.float().max()) == F16_MAX
 
 
 def test_blob_format_guard(eng16):
