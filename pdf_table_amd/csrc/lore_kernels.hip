@@ -1665,7 +1665,7 @@ static int launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, cons
 // x NHWC bf16 [B,H,W,C], om fp32 [pixel][32], w tiled like a 1x1 conv over K = 9*C (".dcn" tensors), out [B,H,W,N]
 int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf16_t* w, const float* bias, bf16_t* out,
                         int B, int H, int W, int C, int N, int split, int relu, hipStream_t s) {
-  PT_REQUIRE(x && om && w && bias && out && C % 32 == 0 && N % 64 == 0, "dcn fused: bad arguments (C=%d N=%d)", C, N);
+  PT_REQUIRE(e && x && om && w && bias && out && C % 32 == 0 && N % 64 == 0, "dcn fused: bad arguments (C=%d N=%d)", C, N);      // e: every path below reads it
   PT_REQUIRE((long long)H * W * (split ? 2 * C : C) < (1ll << 31), "dcn fused: image too large for 32-bit offsets");
   // algorithmic bytes: input map once, offsets / masks once, output once, weights once (the 36 corner lines per pixel are cache traffic)
   const double dcn_bytes = (double)B * H * W * ((split ? 2.0 : 1.0) * 2.0 * (C + N) + 27 * 4.0) + (double)N * 9 * C * 2.0 * (split ? 3 : 1);
@@ -1720,7 +1720,7 @@ int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf
       PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_mfma_kernel<128, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, DcnMfmaSmem<128, 8>::BYTES));
       mfma_nb = nv ? atoi(nv) : 128;
     }
-    const int mfma = e ? e->dcn_mfma : 0;
+    const int mfma = e->dcn_mfma;
     if (mfma == 2 && N == 64) {      // full-line gathers, one workgroup per CU (dcn_mfma2_kernel); wider layers keep dcn_fused64_kernel in this setting
       static bool attr2 = false;
       if (!attr2) {

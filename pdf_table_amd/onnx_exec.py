@@ -43,6 +43,7 @@ from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
 import os
+import threading
 
 import numpy as np
 import torch
@@ -99,6 +100,9 @@ class _Scores:
     soft: bool = False
 
 
+_CAPTURE_LOCK = threading.Lock()      # graph capture is serialised across executors and host threads (see HipGraphExecutor._graphed)
+
+
 class HipGraphExecutor:
     def __init__(self, src, engine: Optional[HipEngine] = None, device: int = 0, precision: str = "bf16"):
         if precision not in ("bf16", "bf16x3", "f16"):
@@ -128,7 +132,9 @@ class HipGraphExecutor:
         if len(self.inputs) != 1:
             raise UnsupportedOnnxGraph(f"the executor takes graphs with one image input, this one has {[i.name for i in self.inputs]}")
         self._dev: Dict[int, Dict[str, torch.Tensor]] = {}      # layer index -> uploaded operands (filled on first use)
-        self._graphs: Dict[tuple, object] = {}                  # input shape -> captured HIP graph (run_device_graphed)
+        self._graphs: Dict[tuple, object] = {}                  # input shape -> captured HIP graph (run_device_graphed), least recently used first
+        self._seen: set = set()                                 # shapes that ran once eagerly (the next call captures)
+        self._bad: set = set()                                  # shapes whose capture raised: eager from then on
         self._fuse = self._plan_add_fusion()
 
     def _plan_add_fusion(self) -> Dict[int, tuple]:
@@ -484,55 +490,60 @@ class HipGraphExecutor:
         raise UnsupportedOnnxGraph(f"{lay.name}: MatMul of two computed tensors outside the fused-qkv attention pattern "
                                    "(q, k, v = qkv.reshape(B, T, 3, heads, d).permute(2, 0, 3, 1, 4))")
 
-    def run_device_graphed(self, nhwc: torch.Tensor, c: int) -> List[_Act]:
-        """run_device() replayed from a captured HIP graph, one per input shape.  The layer list is walked from Python -- tens of launches of a
-        few microseconds each with the interpreter between them: a 52-layer recogniser spends 1.8 ms per line that way, most of it on the
-        host.  The first call for a shape runs eagerly (weights are uploaded, the engine's arenas sized), the second captures the same walk
-        into a graph (torch.cuda.graph: every pt_op_* launch goes to the capturing stream, activations come from the graph's pool), later
-        calls copy the input into the captured buffer and replay.  Same kernels, same arguments: same bits as run_device().  The returned
-        activations are the graph's own buffers -- read them before the next call.  PT_ONNX_GRAPH=0, or a shape after the first eight
-        distinct ones, runs eagerly."""
-        key = (tuple(nhwc.shape), nhwc.dtype, int(c))
+    # ---- captured HIP graphs -------------------------------------------------------------------------------------------
+    MAX_GRAPHS = 8          # captured graphs kept per executor (each pins a private pool of its peak activations): least recently used goes first
+
+    def _graphed(self, key, nhwc: torch.Tensor, walk):
+        """walk(static_input) replayed from a captured HIP graph, one per key.  A shape's first call runs eagerly (weights are uploaded, the engine's
+        arenas sized) and is only remembered (`_seen`, bounded); the second captures; later calls copy the input into the captured buffer and replay.
+        Only CAPTURED graphs count against MAX_GRAPHS, and the least recently used one is dropped for a new shape -- a dynamic-shape detector does not
+        run eagerly for the rest of the process after its first eight page sizes.  Capture is serialised (one lock for all executors:
+        capture is a property of the device's allocator) in thread-local capture mode, so allocations of other host threads (the pipeline's
+        enqueue / collect threads) do not invalidate it; a capture that raises anyway falls back to the eager walk for that shape."""
+        if os.environ.get("PT_ONNX_GRAPH", "1") == "0":
+            return walk(nhwc)
         ent = self._graphs.get(key)
         if ent is None:
-            if os.environ.get("PT_ONNX_GRAPH", "1") == "0" or len(self._graphs) >= 8:
-                return self.run_device(nhwc, c)
-            self._graphs[key] = "warm"
-            return self.run_device(nhwc, c)
-        if ent == "warm":
+            if key in self._bad or key not in self._seen:
+                if len(self._seen) >= 64:
+                    self._seen.clear()
+                self._seen.add(key)
+                return walk(nhwc)
             torch.cuda.synchronize(self.eng._tdev)
             static_in = nhwc.clone()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                outs = self.run_device(static_in, c)
-            ent = self._graphs[key] = (g, static_in, outs)
+            try:
+                with _CAPTURE_LOCK:
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        outs = walk(static_in)
+            except Exception:      # noqa: BLE001 -- the capture is an optimisation: the eager walk is always available
+                torch.cuda.synchronize(self.eng._tdev)
+                self._bad.add(key)
+                return walk(nhwc)
+            while len(self._graphs) >= self.MAX_GRAPHS:
+                self._graphs.pop(next(iter(self._graphs)))          # dicts keep insertion order: the first key is the least recently used
+            ent = (g, static_in, outs)
+        else:
+            self._graphs.pop(key)                                   # re-inserted below as the most recently used
+        self._graphs[key] = ent
         g, static_in, outs = ent
         static_in.copy_(nhwc)
         g.replay()
         return outs
 
+    def run_device_graphed(self, nhwc: torch.Tensor, c: int) -> List[_Act]:
+        """run_device() replayed from a captured HIP graph, one per input shape.  The layer list is walked from Python -- tens of launches of a
+        few microseconds each with the interpreter between them: a 52-layer recogniser spends 1.8 ms per line that way, most of it on the
+        host.  Same kernels, same arguments: same bits as run_device().  The returned activations are the graph's own buffers -- read them
+        before the next call.  PT_ONNX_GRAPH=0 runs eagerly (see _graphed for the cache's rules)."""
+        return self._graphed((tuple(nhwc.shape), nhwc.dtype, int(c)), nhwc, lambda x: self.run_device(x, c))
+
     def run_lines_graphed(self, nhwc: torch.Tensor, c: int) -> List[List[_Act]]:
         """a batch [n, H, W, c] through a graph whose batch size is baked in as 1 (static exports): the n single-image walks are captured
         into ONE HIP graph, so that a mini-batch costs one copy and one replay -> per image the outputs of run_device().  Same rules as
-        run_device_graphed (first call eager, second captures; outputs are the graph's buffers)."""
+        run_device_graphed."""
         n = int(nhwc.shape[0])
-        key = ("lines",) + tuple(nhwc.shape) + (nhwc.dtype, int(c))
-        ent = self._graphs.get(key)
-        if ent is None or os.environ.get("PT_ONNX_GRAPH", "1") == "0":
-            if ent is None and len(self._graphs) < 8 and os.environ.get("PT_ONNX_GRAPH", "1") != "0":
-                self._graphs[key] = "warm"
-            return [self.run_device(nhwc[i:i + 1], c) for i in range(n)]
-        if ent == "warm":
-            torch.cuda.synchronize(self.eng._tdev)
-            static_in = nhwc.clone()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                outs = [self.run_device(static_in[i:i + 1], c) for i in range(n)]
-            ent = self._graphs[key] = (g, static_in, outs)
-        g, static_in, outs = ent
-        static_in.copy_(nhwc)
-        g.replay()
-        return outs
+        return self._graphed(("lines",) + tuple(nhwc.shape) + (nhwc.dtype, int(c)), nhwc, lambda x: [self.run_device(x[i:i + 1], c) for i in range(n)])
 
     def run_device(self, nhwc: torch.Tensor, c: int) -> List[_Act]:
         """bf16 NHWC batch on the device whose first ``c`` channels are the image (what pt_det_preprocess / pt_cls_preprocess

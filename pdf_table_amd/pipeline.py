@@ -278,6 +278,23 @@ class OcrTablePipeline:
             tb.append(np.array(bx, dtype=np.int64).reshape(-1, 4))
         return tb
 
+    @staticmethod
+    def _drop_empty_crops(tb: Sequence[np.ndarray], shape) -> List[np.ndarray]:
+        """table boxes whose crop is empty once clamped to the page are dropped ONE BY ONE, each with a log line -- the reference contains a failed
+        crop the same way (ocr_system_task.py:275-283 turns a failing line crop into ''); every other error of the table stage propagates
+        (an ``except ValueError`` around the whole batch used to swallow the engine wrappers' own shape errors: ADVICE r04)"""
+        ph, pw = int(shape[0]), int(shape[1])
+        out = []
+        for pi, boxes in enumerate(tb):
+            b = np.asarray(boxes).reshape(-1, 4)
+            if len(b):
+                ok = (np.minimum(b[:, 2], pw) > np.maximum(b[:, 0], 0)) & (np.minimum(b[:, 3], ph) > np.maximum(b[:, 1], 0))
+                for bad in b[~ok]:
+                    logger.warning("table region %s of page %d of the batch is empty on a %dx%d page: skipped", bad.tolist(), pi, ph, pw)
+                b = b[ok]
+            out.append(b)
+        return out
+
     def predict_stream(self, batches, table_boxes=None):
         """``predict()`` over a stream of page batches, software-pipelined: a generator that takes an iterable of batches (each a
         sequence of equally sized RGB pages, or a uint8 tensor [n, h, w, 3] already on the device) and yields one
@@ -383,7 +400,7 @@ class OcrTablePipeline:
             t1 = time.perf_counter()
             host["second.rec_start"] = host.get("second.rec_start", 0.0) + t1 - t0
             if staged_tsr:
-                tb = st["tb"] if st["tb"] is not None else self._layout_table_boxes(st["layout"])
+                tb = self._drop_empty_crops(st["tb"] if st["tb"] is not None else self._layout_table_boxes(st["layout"]), st["shape"])
                 st["tb"] = tb
                 tables, metas = tsr_stage.tables(st["shape"], tb)
                 offs = np.stack([tables["x0"], tables["y0"]], 1).astype(np.float32) if len(tables) else None
@@ -428,7 +445,7 @@ class OcrTablePipeline:
             host["collect.texts"] = host.get("collect.texts", 0.0) + t1 - t0
             tsr = None
             if tsr_stage is not None and not staged_tsr:
-                tb = st["tb"] if st["tb"] is not None else self._layout_table_boxes(st["layout"])
+                tb = self._drop_empty_crops(st["tb"] if st["tb"] is not None else self._layout_table_boxes(st["layout"]), st["shape"])
                 st["tb"] = tb
                 # a table stage without start / process / collect halves (MtlTabNet) decodes synchronously and polls its stream every few steps;
                 # on the main stream every poll would wait for the detection / recognition work of the NEXT batches already queued there and
@@ -436,14 +453,10 @@ class OcrTablePipeline:
                 if getattr(self, "_table_stream", None) is None:
                     self._table_stream = torch.cuda.Stream(device=dev)
                 ts = self._table_stream
-                try:
-                    with torch.cuda.stream(ts):
-                        ts.wait_event(st["uploaded"])
-                        tsr = tsr_stage(st["pages"], tb, page_frame=True)
-                    st["pages"].record_stream(ts)
-                except ValueError as e:      # a degenerate layout box (empty crop): the reference contains a failed crop; logged, the batch goes on
-                    logger.warning("table structure skipped for a batch of %d pages: %s", st["n"], e)
-                    tsr = [[] for _ in range(st["n"])]
+                with torch.cuda.stream(ts):
+                    ts.wait_event(st["uploaded"])
+                    tsr = tsr_stage(st["pages"], tb, page_frame=True)
+                st["pages"].record_stream(ts)
             elif tsr_stage is not None:
                 pending, metas, offs, ev = st["tsr"]
                 flat = []
