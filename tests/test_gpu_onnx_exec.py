@@ -259,6 +259,39 @@ def test_detection_task_serves_an_unknown_onnx_detector(tmp_path, eng):
     assert d <= 4e-2
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("fp16", 6e-3)])
+def test_detection_task_route_in_the_tolerance_and_half_modes(tmp_path, precision, tol):
+    """The PRODUCT route of an unknown ONNX detector -- OcrDetectionTask(precision=...) on its own engine: pt_det_preprocess -> generic executor ->
+    probability map -- against the fp32 PyTorch module on the ORACLE's pre-processed pixels (oracle/db_pre.py, fp32): precision="fp32" must hold the
+    executor's 1e-3 contract THROUGH THE TASK (the (hi | lo) pre-process output used to lose its lo half on the way into the graph, i.e.
+    the image was rounded to 8 significant bits first); precision="fp16" is the reference's own default arithmetic (PT_PRECISION_F16)."""
+    from onnx_export import torch_export
+    from oracle import db_pre
+    from pdf_table_amd import lib as L
+    from pdf_table_amd.ocr_detection_task import OcrDetectionTask
+    from pdf_table_amd.synth_pages import make_page
+    torch.manual_seed(0)
+    m = _randomise(FpnLike(), 5)
+    (tmp_path / "model.onnx").write_bytes(torch_export(m, torch.randn(1, 3, 64, 64)))
+    task = OcrDetectionTask(model="db_pp", task_path=str(tmp_path), thresh=0.3, precision=precision)
+    try:
+        assert task._engine.precision == {"fp32": L.PT_PRECISION_BF16X3, "fp16": L.PT_PRECISION_F16}[precision]
+        page = make_page(2)[0][:480, :640].copy()
+        chw, _ = db_pre.preprocess_db_pp(page)
+        with torch.no_grad():
+            want = m(torch.from_numpy(np.ascontiguousarray(chw))[None])[:, 0].numpy()
+        prob, _, _ = task._stage.forward(torch.from_numpy(page[None]).cuda())
+        got = prob.cpu().numpy()
+        assert got.shape == want.shape
+        d = float(np.abs(got - want).max())
+        print(f"generic detector through OcrDetectionTask(precision={precision!r}): max|dprob| = {d:.3e}")
+        assert d <= tol
+        out = task(page)
+        assert len(out) == 1 and out[0].ndim == 2 and out[0].shape[1] == 8
+    finally:
+        task._engine.close()
+
+
 class VdLike(nn.Module):
     """ResNet-vd style pieces: AvgPool(2, 2) in the shortcut, a BatchNorm that follows an Add (nothing to fold it into), ReLU6"""
 
