@@ -277,8 +277,10 @@ int pt_launch_stem7x7(pt_engine* e, const bf16_t* in, int B, int H, int W, const
 int pt_launch_det_preprocess(const uint8_t* pages, int n, int h, int w, int nh, int nw, int flavour, int split,
                              bf16_t* out, hipStream_t s);
 // fused modulated deformable 3x3 convolution (lore_kernels.hip): x NHWC bf16, om fp32 [pixel][32], w tiled as a 1x1 conv over K = 9C
+// omw / omb != null (allowed when pt_dcn_fuses_om): the layer's 27-channel offset / mask conv runs in the kernel's prologue from its `.om` weight tiles; om is not read
 int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf16_t* w, const float* bias, bf16_t* out,
-                        int B, int H, int W, int C, int N, int split, int relu, hipStream_t s);
+                        int B, int H, int W, int C, int N, int split, int relu, hipStream_t s, const bf16_t* omw = nullptr, const float* omb = nullptr);
+bool pt_dcn_fuses_om(const pt_engine* e, int C, int split);
 int pt_launch_maxpool3x3s2(const bf16_t* in, int B, int H, int W, int C, bf16_t* out, int split, hipStream_t s);
 int pt_launch_stem7x7_pool(pt_engine* e, const bf16_t* in, int B, int H, int W, const bf16_t* w, const float* bias, bf16_t* out,
                            hipStream_t s);   // ResNet-18 stem + MaxPool2d(3,2,1) in one kernel (bf16 mode)

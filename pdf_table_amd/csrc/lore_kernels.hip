@@ -546,11 +546,18 @@ __global__ __launch_bounds__(256, (SPLIT || NB > 64) ? 2 : 4) void dcn_fused_ker
 // free from then on -- instead of after the stage's second barrier: the loads then fly during the rest of the blend, the barrier and the product
 // (the kernel is bound by its phases -- gather wait, blend, barrier, product, barrier -- not by a resource: profiles/r04/dcn_op_bench.txt).  Same
 // arithmetic in the same order, no extra registers: same bits.
-template <int NB, int NTHR, int SPLIT = 0, int EARLY = 0>
+// OMF = 1: the layer's 27-channel offset / mask convolution (3x3, C -> 18 offsets + 9 mask logits, lore/dcnv2.py:71-75) runs in THIS kernel's prologue
+// instead of as a launch of its own whose fp32 output travels through HBM (8.4 MB per 256 x 256 map out and back in; sixteen launches per table batch):
+// the (8 + 2) x (16 + 2) halo of the tile is staged 32 channels at a time in the LDS the sampling tables will occupy, each of the first four waves multiplies
+// one 32-pixel row tile against the `.om` weight tiles (32 of their 64 rows: the rest is zero padding) straight from L2, chunk -> tap -> k-step like
+// conv_igemm_kernel<3, 1, 0, NHALF = 1> (same sums in the same order), and the 27 values per pixel land in s_om where the table build reads them.  With
+// eight waves the taps are split between two wave groups and summed through s_om.  SPLIT: K walks (x_hi, w_hi), (x_lo, w_hi), (x_hi, w_lo) over the `.om.w3` tiles.
+template <int NB, int NTHR, int SPLIT = 0, int EARLY = 0, int OMF = 0>
 __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) void dcn_fused64_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
                                                               const bf16_t* __restrict__ w, const float* __restrict__ bias,
                                                               bf16_t* __restrict__ out, long long npix, int H, int W,
-                                                              int C, int N, int relu) {
+                                                              int C, int N, int relu, const bf16_t* __restrict__ omw = nullptr,
+                                                              const float* __restrict__ omb = nullptr) {
 #pragma clang fp contract(fast)
   a16_kernel_enter();
   constexpr int ROW = 144;                      // 64 bf16 + 16 B pad
@@ -595,13 +602,100 @@ __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) voi
   const int nss = C >> 6, nst = 9 * nss, nk = 9 * (C >> 5);
   const int cs = SPLIT ? 2 * C : C;             // channels per pixel in memory
   const int piece = tid & 7, prow = tid >> 3;   // items: pixels prow + 32 j, j = 0..3, 16-byte piece `piece`
-  for (int i = tid; i < 128 * 7; i += NTHR) {     // 7 float4 per pixel (channels 0..27; 27 is padding)
-    int y, xq;
-    locate(i / 7, y, xq);
-    const long long pix = img0 + (long long)y * W + xq;
-    *reinterpret_cast<float4*>(s_om + (i / 7) * 28 + (i % 7) * 4) = *reinterpret_cast<const float4*>(om + pix * 32 + (i % 7) * 4);
-  }
   const char* xmap = reinterpret_cast<const char*>(x + (size_t)img0 * cs);     // wave-uniform: the gathers are scalar base + 32-bit lane offset
+  if constexpr (OMF) {
+    constexpr int HP = 180, HROW = 80;            // halo pixels (10 rows x 18 columns); bytes per staged pixel: 32 channels + 16 B pad (conflict-free ds_read_b128)
+    constexpr int HIT = (HP * 4 + NTHR - 1) / NTHR;   // 16-byte halo pieces per thread per chunk
+    constexpr int NG = NTHR / 256;                // wave groups that share the taps
+    static_assert(sizeof(s_goff) >= HP * HROW && sizeof(s_gwt) >= HP * HROW, "a halo buffer must fit each table's space");
+    char* s_h = reinterpret_cast<char*>(&s_goff[0][0]);     // the two sampling tables' space holds the two halo buffers: the tables are built after the last use
+    char* s_h2 = reinterpret_cast<char*>(&s_gwt[0][0]);
+    const int nch = (SPLIT ? 3 : 1) * (C >> 5);
+    const int grp = wave >> 2, mt_o = wave & 3;
+    const int t_lo = NG == 2 ? (grp ? 5 : 0) : 0, t_hi = NG == 2 ? (grp ? 9 : 5) : 9;
+    // halo piece i -> pixel i >> 2 (row hy, column hx of the halo), 16-byte part i & 3; outside the map: zeros (the conv's padding)
+    u32x4 hreg[HIT];
+    auto halo_load = [&](int kc) {
+      int c0 = kc * 32;                           // element offset into a pixel's [hi(C) | lo(C)] channels
+      if (SPLIT && kc >= 2 * (C >> 5)) c0 -= 2 * C;      // third pass: x_hi again (against w_lo)
+#pragma unroll
+      for (int j = 0; j < HIT; ++j) {
+        const int i = tid + j * NTHR;
+        const int hp = i >> 2, hy = hp / 18, hx = hp - hy * 18;
+        const int y = ty0 - 1 + hy, xq = tx0 - 1 + hx;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (i < HP * 4 && (unsigned)y < (unsigned)H && (unsigned)xq < (unsigned)W)
+          v = *reinterpret_cast<const u32x4*>(xmap + ((size_t)y * W + xq) * (2 * cs) + (size_t)c0 * 2 + (i & 3) * 16);
+        hreg[j] = v;
+      }
+    };
+    auto halo_store = [&](char* buf) {
+#pragma unroll
+      for (int j = 0; j < HIT; ++j) {
+        const int i = tid + j * NTHR;
+        if (i < HP * 4) *reinterpret_cast<u32x4*>(buf + (i >> 2) * HROW + (i & 3) * 16) = hreg[j];
+      }
+    };
+    df32x16 oacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+    const int pl_o = mt_o * 32 + lx;              // this lane's pixel of the A fragment: row pl_o >> 4, column pl_o & 15 of the tile
+    const int a_off = ((pl_o >> 4) * 18 + (pl_o & 15)) * HROW + q * 16;
+    const bf16_t* wl = omw + (size_t)lx * 32 + q * 8;     // row lx (< 32) of a [64][32] tile, k-half q
+    // B fragments (rows lx of the weight tiles) of ALL the group's taps of a chunk live in registers and are re-loaded for the next chunk right behind
+    // their last use: every load has a whole chunk (halo store, barrier, the other taps' MFMAs) to arrive -- under the gathers of the co-resident
+    // workgroups an L2 hit takes a microsecond, and a tap-by-tap prefetch made the prologue a chain of nine of them per chunk
+    constexpr int NTAP = NG == 2 ? 5 : 9;
+    dbf16x8 bfr[NTAP][2];
+    auto load_b = [&](int kc, int t) {
+      const bf16_t* wt = wl + ((size_t)kc * 9 + (t_lo + t)) * 2048;
+      bfr[t][0] = *reinterpret_cast<const dbf16x8*>(wt);
+      bfr[t][1] = *reinterpret_cast<const dbf16x8*>(wt + 16);
+    };
+    halo_load(0);
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+      if (t_lo + t < t_hi) load_b(0, t);
+    for (int kc = 0; kc < nch; ++kc) {
+      char* buf = (kc & 1) ? s_h2 : s_h;
+      halo_store(buf);
+      if (kc + 1 < nch) halo_load(kc + 1);
+      __syncthreads();            // buffer kc & 1 is complete; its previous readers (chunk kc - 2) passed the barrier of chunk kc - 1
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) {
+        const int tap = t_lo + t;
+        if (tap < t_hi) {         // wave-uniform
+          const char* ap = buf + a_off + ((tap / 3) * 18 + (tap % 3)) * HROW;
+          const dbf16x8 a0 = *reinterpret_cast<const dbf16x8*>(ap);
+          const dbf16x8 a1 = *reinterpret_cast<const dbf16x8*>(ap + 32);
+          oacc = mfma_32x32x16_a16(a0, bfr[t][0], oacc);      // D = [pixel][offset / mask channel]
+          oacc = mfma_32x32x16_a16(a1, bfr[t][1], oacc);
+          if (kc + 1 < nch) load_b(kc + 1, t);
+        }
+      }
+    }
+    // s_om aliases the operand images, not the halo buffers: no barrier needed before it is written.  A lane holds channel lx of 16 pixels: group 0 stores
+    // (+ bias), group 1 adds its taps' share
+    if (wave < 4 && lx < 27) {
+      const float bo = omb[lx];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_om[(mt_o * 32 + (r & 3) + 8 * (r >> 2) + 4 * q) * 28 + lx] = oacc[r] + bo;
+    }
+    if (NG == 2) {
+      __syncthreads();
+      if (wave >= 4 && lx < 27) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_om[(mt_o * 32 + (r & 3) + 8 * (r >> 2) + 4 * q) * 28 + lx] += oacc[r];
+      }
+    }
+  } else {
+    for (int i = tid; i < 128 * 7; i += NTHR) {     // 7 float4 per pixel (channels 0..27; 27 is padding)
+      int y, xq;
+      locate(i / 7, y, xq);
+      const long long pix = img0 + (long long)y * W + xq;
+      *reinterpret_cast<float4*>(s_om + (i / 7) * 28 + (i % 7) * 4) = *reinterpret_cast<const float4*>(om + pix * 32 + (i % 7) * 4);
+    }
+  }
   __syncthreads();
   for (int i = tid; i < 128 * 9; i += NTHR) {
     const int pl = i / 9, tap = i - pl * 9;
@@ -1663,9 +1757,26 @@ static int launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, cons
 }
 
 // x NHWC bf16 [B,H,W,C], om fp32 [pixel][32], w tiled like a 1x1 conv over K = 9*C (".dcn" tensors), out [B,H,W,N]
+// omw / omb != null (pt_dcn_fuses_om says when): the offset / mask convolution runs in the kernel's prologue from the layer's `.om` tiles and `om` is not read
+bool pt_dcn_fuses_om(const pt_engine* e, int C, int split) {
+  // PT_DCN_FUSE_OM: 0 = the offset conv as its own launch everywhere; 1 (default) = inside the DCN kernel where that measured faster -- single-pass modes,
+  // C <= 128: the 64 -> 64 @256^2 layers 10.68 -> 9.59 ms per step, the C = 128 layers 5.95 -> 5.63 (profiles/r05/dcn_offset_conv_fusion.txt); at C >= 256
+  // the prologue's 8+ chunk barriers cost what the launch did, and in the pair modes (one or two workgroups per CU: nobody to hide behind) it measured
+  // equal; 2 = everywhere it can run (tests).  Read at every call: tests flip it.
+  const char* ev = getenv("PT_DCN_FUSE_OM");
+  const int on = ev ? atoi(ev) : 1;
+  const char* nt = getenv("PT_DCN_THREADS");
+  const char* ea = getenv("PT_DCN_EARLY");
+  const char* xf = getenv("PT_DCN_X3_FAST");
+  const bool defaults = !(nt && atoi(nt) != 512) && !(ea && atoi(ea) == 0) && !(xf && atoi(xf) == 0);
+  if (!on || !e || C % 64 != 0 || !defaults || (!split && e->dcn_mfma != 0)) return false;
+  return on == 2 || (!split && C <= 128);
+}
+
 int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf16_t* w, const float* bias, bf16_t* out,
-                        int B, int H, int W, int C, int N, int split, int relu, hipStream_t s) {
-  PT_REQUIRE(e && x && om && w && bias && out && C % 32 == 0 && N % 64 == 0, "dcn fused: bad arguments (C=%d N=%d)", C, N);      // e: every path below reads it
+                        int B, int H, int W, int C, int N, int split, int relu, hipStream_t s, const bf16_t* omw, const float* omb) {
+  PT_REQUIRE(e && x && (om || (omw && omb)) && w && bias && out && C % 32 == 0 && N % 64 == 0, "dcn fused: bad arguments (C=%d N=%d)", C, N);      // e: every path below reads it
+  PT_REQUIRE(!omw || pt_dcn_fuses_om(e, C, split), "dcn fused: the offset conv can only be fused on the default fused64 paths (C=%d)", C);
   PT_REQUIRE((long long)H * W * (split ? 2 * C : C) < (1ll << 31), "dcn fused: image too large for 32-bit offsets");
   // algorithmic bytes: input map once, offsets / masks once, output once, weights once (the 36 corner lines per pixel are cache traffic)
   const double dcn_bytes = (double)B * H * W * ((split ? 2.0 : 1.0) * 2.0 * (C + N) + 27 * 4.0) + (double)N * 9 * C * 2.0 * (split ? 3 : 1);
@@ -1685,10 +1796,13 @@ int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf
     // N >= 128: one workgroup computes 128 output channels from one gather + blend, as in bf16 mode (PT_DCN_NB=64: 64-wide blocks everywhere).
     // 110 KB of LDS for both operand planes: one workgroup of eight waves per CU, which the 64-wide hi/lo blocks (92 KB) are too
     const char* nbv = getenv("PT_DCN_NB");
-    if (N % 128 == 0 && !(nbv && atoi(nbv) == 64))
-      hipLaunchKernelGGL((dcn_fused64_kernel<128, 512, 1>), dim3(tiles, N / 128), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
-    else
-      hipLaunchKernelGGL((dcn_fused64_kernel<64, 512, 1>), dim3(tiles, N / 64), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
+    if (N % 128 == 0 && !(nbv && atoi(nbv) == 64)) {
+      if (omw) hipLaunchKernelGGL((dcn_fused64_kernel<128, 512, 1, 0, 1>), dim3(tiles, N / 128), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu, omw, omb);
+      else hipLaunchKernelGGL((dcn_fused64_kernel<128, 512, 1>), dim3(tiles, N / 128), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu, omw, omb);
+    } else {
+      if (omw) hipLaunchKernelGGL((dcn_fused64_kernel<64, 512, 1, 0, 1>), dim3(tiles, N / 64), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu, omw, omb);
+      else hipLaunchKernelGGL((dcn_fused64_kernel<64, 512, 1>), dim3(tiles, N / 64), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu, omw, omb);
+    }
     PT_HIP_CHECK(hipGetLastError());
     return PT_OK;
   }
@@ -1743,17 +1857,19 @@ int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf
     }
     if (nb128 && N % 128 == 0) {     // 128-wide blocks stay at 4 waves: with 8 they need 136 VGPRs (> 128: spills), measured 1 % slower
 
-      hipLaunchKernelGGL((dcn_fused64_kernel<128, 256>), dim3(tiles, N / 128), dim3(256), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
+      if (omw) hipLaunchKernelGGL((dcn_fused64_kernel<128, 256, 0, 0, 1>), dim3(tiles, N / 128), dim3(256), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu, omw, omb);
+      else hipLaunchKernelGGL((dcn_fused64_kernel<128, 256>), dim3(tiles, N / 128), dim3(256), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu, omw, omb);
     } else if (nthr == 512) {
       static int early = -1;          // PT_DCN_EARLY=0: next-stage loads after the second barrier (A/B switch)
       if (early < 0) {
         const char* ev = getenv("PT_DCN_EARLY");
         early = ev ? atoi(ev) : 1;
       }
-      if (early) hipLaunchKernelGGL((dcn_fused64_kernel<64, 512, 0, 1>), dim3(tiles, N / 64), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
-      else hipLaunchKernelGGL((dcn_fused64_kernel<64, 512>), dim3(tiles, N / 64), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
+      if (early && omw) hipLaunchKernelGGL((dcn_fused64_kernel<64, 512, 0, 1, 1>), dim3(tiles, N / 64), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu, omw, omb);
+      else if (early) hipLaunchKernelGGL((dcn_fused64_kernel<64, 512, 0, 1>), dim3(tiles, N / 64), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu, omw, omb);
+      else hipLaunchKernelGGL((dcn_fused64_kernel<64, 512>), dim3(tiles, N / 64), dim3(512), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu, omw, omb);
     } else {
-      hipLaunchKernelGGL((dcn_fused64_kernel<64, 256>), dim3(tiles, N / 64), dim3(256), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu);
+      hipLaunchKernelGGL((dcn_fused64_kernel<64, 256>), dim3(tiles, N / 64), dim3(256), 0, s, x, om, w, bias, out, npix, H, W, C, N, relu, omw, omb);
     }
     PT_HIP_CHECK(hipGetLastError());
     return PT_OK;

@@ -21,8 +21,6 @@ namespace PT_FMT_NS {
 
 int pt_launch_dcn_im2col(const bf16_t* x, const float* om, bf16_t* cols, int B, int H, int W, int C, int split,
                          hipStream_t s);
-int pt_launch_dcn_fused(pt_engine* e, const bf16_t* x, const float* om, const bf16_t* w, const float* bias, bf16_t* out,
-                        int B, int H, int W, int C, int N, int split, int relu, hipStream_t s);
 int pt_launch_conv3x3_c16(pt_engine* e, const bf16_t* in, const bf16_t* w, const float* bias, bf16_t* out, int B, int H, int W,
                           int N, int stride, int split, hipStream_t s);
 int pt_launch_dwconvt_up_add(const bf16_t* in, const float* w, const bf16_t* add, bf16_t* out, int B, int h, int wd,
@@ -147,14 +145,20 @@ struct Ctx {
   // DeformConv (lore_dla_34.py:65-83)
   T dcn(const std::string& q, const T& x, int cout) {
     T o = alloc(x.H, x.W, cout);
-    conv(x, q + ".om", 64, 3, 1, T(), 0, nullptr, 32, om, 32, 0, 27);     // 18 offsets + 9 masks are the layer's real outputs
     static const bool fused = !(getenv("PT_DCN_FUSED") && atoi(getenv("PT_DCN_FUSED")) == 0);
+    // the 27-channel offset / mask conv: inside the deformable conv's kernel where that kernel can (dcn_fused64_kernel<..., OMF = 1>: no launch, no fp32 map
+    // through HBM), else as a launch of its own writing `om`
+    const bool om_inside = fused && pt_dcn_fuses_om(e, x.C, x3);
+    if (!om_inside) conv(x, q + ".om", 64, 3, 1, T(), 0, nullptr, 32, om, 32, 0, 27);     // 18 offsets + 9 masks are the layer's real outputs
     if (fused) {
       const PtTensor* w = get(q + (x3 ? ".dcn.w3" : ".dcn.w"));
       const PtTensor* b = get(q + ".dcn.b");
+      const PtTensor* ow = om_inside ? get(q + (x3 ? ".om.w3" : ".om.w")) : nullptr;
+      const PtTensor* ob = om_inside ? get(q + ".om.b") : nullptr;
       if (rc == PT_OK && !dry && ok) {
         const int r = pt_launch_dcn_fused(e, x.p, om, reinterpret_cast<const bf16_t*>(w->d_ptr),
-                                          reinterpret_cast<const float*>(b->d_ptr), o.p, n, x.H, x.W, x.C, cout, x3, 1, s);
+                                          reinterpret_cast<const float*>(b->d_ptr), o.p, n, x.H, x.W, x.C, cout, x3, 1, s,
+                                          ow ? reinterpret_cast<const bf16_t*>(ow->d_ptr) : nullptr, ob ? reinterpret_cast<const float*>(ob->d_ptr) : nullptr);
         if (r != PT_OK) rc = r;
       }
       return o;

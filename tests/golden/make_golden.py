@@ -935,6 +935,22 @@ def gen_e2e_page():
     print("e2e_page.npz", os.path.getsize(os.path.join(HERE, "e2e_page.npz")) // 1024, "KiB")
 
 
+def gen_mtl_lengths():
+    """the oracle's greedy decode at the reference's configured sequence limits (500 structure / 150 cell positions) for the two tables of
+    tests/test_gpu_mtl.py::test_decoders_at_the_configured_lengths_bf16x3 -> mtl_tabnet_lengths.npz (tag logits, boxes, cell logits).  ~3 minutes of CPU."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import test_gpu_mtl as T
+    torch.set_num_threads(os.cpu_count() or 1)
+    g, fmap, cfg, sd = T.lengths_case(HERE)
+    want = T._oracle_decode(sd, fmap, cfg)
+    res = {"seed": np.array(int(g["seed"])), "fmap_digest": T._digest(fmap)}
+    for b, (tag, box, cells) in enumerate(want):
+        res[f"tag{b}"], res[f"box{b}"], res[f"cells{b}"] = tag.astype(np.float32), box.astype(np.float32), cells.astype(np.float32)
+        print(f"table {b}: {tag.shape[0]} structure positions, {cells.shape[0]} cells x {cells.shape[1]} positions")
+    np.savez_compressed(os.path.join(HERE, "mtl_tabnet_lengths.npz"), **res)
+    print("mtl_tabnet_lengths.npz", os.path.getsize(os.path.join(HERE, "mtl_tabnet_lengths.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["db", "crnn", "registry", "ctc", "host", "lore_dla", "lore_decode", "lore_processor", "picodet",
                              "table_html"]
@@ -974,6 +990,8 @@ if __name__ == "__main__":
         gen_mtl_tabnet_backbone()
     if "mtl_tabnet_decoder" in which or not sys.argv[1:]:
         gen_mtl_tabnet_decoder()
+    if "mtl_lengths" in which:   # minutes of CPU: only on request
+        gen_mtl_lengths()
     if "e2e" in which:           # minutes of CPU: only on request
         gen_e2e_page()
     if "mtl_tabnet_host" in which or not sys.argv[1:]:

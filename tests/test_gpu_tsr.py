@@ -80,6 +80,39 @@ def test_lore_net_x3_matches_fp32_oracle(eng_x3, lore_sd, shape):
     assert _cmp(got, ref, f"lore x3 {shape}") <= TOL_REL
 
 
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("shape", [(2, 96, 160), (1, 200, 136)])          # 1/4-resolution maps of 24 x 40 and 50 x 34: ragged 8 x 16 tiles in both directions
+def test_offset_conv_inside_the_dcn_kernel_equals_its_own_launch(eng, lore_sd, mode, shape, monkeypatch):
+    """dcn_fused64_kernel<..., OMF = 1> (the 27-channel offset / mask conv of a deformable conv in the kernel's prologue, lore/dcnv2.py:71-75; the default)
+    in ALL sixteen layers (PT_DCN_FUSE_OM=2) against the two-launch form (PT_DCN_FUSE_OM=0: conv_igemm_kernel writes the fp32 `om` map, the DCN kernel reads it) through the whole DLA-34 + 16 DCN
+    net: same tiles, same chunk -> tap -> k-step order; with eight waves the taps are summed in two groups, so the fp32 offsets may differ in the last bit --
+    the heads agree to 1e-5 of their scale in the pair mode (the oracle bound on this net is 1e-3) and to bf16-drift level in bf16."""
+    n, H, W = shape
+    g = torch.Generator().manual_seed(900 + W)
+    x = torch.randn(n, 3, H, W, generator=g)
+    eng.set_precision(L.PT_PRECISION_BF16X3 if mode == "bf16x3" else L.PT_PRECISION_BF16)
+    try:
+        xin = _x4(x, split=mode == "bf16x3").cuda()
+        monkeypatch.setenv("PT_DCN_FUSE_OM", "0")
+        two = {k: v.cpu().clone() for k, v in eng.tsr_forward_net(xin).items()}
+        monkeypatch.setenv("PT_DCN_FUSE_OM", "2")         # 2: every layer that can (the default, 1, fuses the single-pass modes' C <= 128 layers)
+        one = {k: v.cpu().clone() for k, v in eng.tsr_forward_net(xin).items()}
+        torch.cuda.synchronize()
+    finally:
+        eng.set_precision(L.PT_PRECISION_BF16)
+    worst = 0.0
+    for k in HEADS:
+        rel = (one[k] - two[k]).abs().max().item() / max(1.0, two[k].abs().max().item())
+        worst = max(worst, rel)
+    print(f"offset conv inside the DCN kernel vs its own launch [{mode}, {shape}]: worst head difference {worst:.3e} of scale")
+    assert bool(torch.isfinite(one["hm"]).all())
+    assert worst <= (1e-4 if mode == "bf16x3" else 2e-2)      # measured 1.6e-5 / 5e-3: last-bit differences of the offsets, amplified by 16 stacked deformable convs
+    if mode == "bf16x3":
+        with torch.no_grad():
+            ref = lore_net.dlaseg_forward(lore_sd, x)
+        assert _cmp({k: v.cuda() for k, v in one.items()}, ref, f"lore x3 fused offset conv {shape}") <= TOL_REL
+
+
 def test_lore_net_x3_matches_reference_golden(eng_x3, golden_dir):
     gold = np.load(os.path.join(golden_dir, "lore_dla34.npz"))
     for tag in ("a", "b"):
