@@ -218,8 +218,10 @@ def eng_par():
     # 1e-7 relative (one fp32 ulp) and by 1.2e-3 for 1e-5 (tools/lore_conditioning.py, 512x512) -- no arithmetic can then
     # agree with it to 1e-3 at full size (measured: bf16x3 2e-3 .. 6e-3, bf16 0.4, growing with the map size).  With 0.02 the
     # same perturbations move the oracle by 1e-5 / 6e-5, the conditioning of a trained net, and the comparison is meaningful.
-    sds = {"db": db_resnet18_state_dict(seed=0), "crnn": crnn_state_dict(seed=1),
-           "lore": lore_dla34_state_dict(seed=2, dcn_gain=0.02), "pico": picodet_state_dict(seed=4, num_classes=5)}
+    # THE checkpoint set bench.py times and the end-to-end fixture runs on (synth_weights.conditioned_state_dicts): what is asserted here at BASELINE
+    # sizes is what is timed -- text-signal detector, fitted CRNN classifier, fitted layout head, Lore with dcn_gain = 0.02
+    from pdf_table_amd.synth_weights import conditioned_state_dicts
+    sds = dict(conditioned_state_dicts())
     e.load_weights(L.PT_MODEL_DB_RESNET18, pack_db_resnet18(sds["db"]))
     e.load_weights(L.PT_MODEL_CRNN, pack_crnn(sds["crnn"]))
     e.load_weights(L.PT_MODEL_LORE_DLA34, pack_lore_dla34(sds["lore"]))
@@ -322,10 +324,10 @@ def test_fullsize_lore_oracle_parity(eng_par, pages, mode):
     assert worst <= (X3_TOL if mode == "bf16x3" else 0.03 if mode == "f16" else 0.2)      # bf16: measured 0.04 .. 0.13 of the head scale (reg, the smallest head)
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
-def test_fullsize_lore_bench_weights_drift(pages, mode):
-    """The SAME table through the weights bench.py times (lore_dla34_state_dict(seed=2), dcn_gain = 0.1: offsets of ~0.3 px): recorded and
-    bounded in both modes.  The oracle itself is ill-conditioned on this random net (see eng_par: a 1e-5 relative input perturbation moves
+@pytest.mark.parametrize("mode", ["bf16x3"])
+def test_fullsize_lore_default_gain_drift(pages, mode):
+    """The SAME table through the UNCONDITIONED synthetic net (lore_dla34_state_dict(seed=2), dcn_gain = 0.1: offsets of ~0.3 px -- what bench.py timed
+    until round 4; it now times the conditioned net asserted above): recorded and bounded.  The oracle itself is ill-conditioned on this random net (see eng_par: a 1e-5 relative input perturbation moves
     the fp32 oracle by 1.2e-3 of the head scale at 512 x 512), so the BF16X3 bound here is NOT the 1e-3 contract -- that one is asserted on the
     dcn_gain = 0.02 net above and, operator by operator with multi-pixel offsets, in tests/test_gpu_dcn_op.py -- but a recorded drift."""
     from oracle import lore_net, lore_pre
@@ -351,7 +353,7 @@ def test_fullsize_lore_bench_weights_drift(pages, mode):
     for k in ref:
         rel = (got[k] - ref[k]).abs().max().item() / max(1.0, ref[k].abs().max().item())
         worst = max(worst, rel)
-        print(f"FULLSIZE lore 1024x1024 BENCH WEIGHTS (dcn_gain 0.1) {mode} head {k}: rel max err {rel:.3e} (scale {ref[k].abs().max().item():.2f})")
+        print(f"FULLSIZE lore 1024x1024 DEFAULT GAIN (dcn_gain 0.1) {mode} head {k}: rel max err {rel:.3e} (scale {ref[k].abs().max().item():.2f})")
     assert worst <= (2e-2 if mode == "bf16x3" else 0.6)      # r03 measured at this gain: bf16x3 2e-3 .. 6e-3, bf16 0.4
 
 
