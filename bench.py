@@ -1320,7 +1320,9 @@ def main(argv=None):
             out["roofline"] = roof
     if not stub and world == 1 and (args.host_pages_leg or not (args.no_extra_legs or args.by_class_only)) and not args.no_post:
         try:
-            leg = runner.host_pages_leg()
+            # as many timed steps as the headline region: a 10-step leg reads ~3 % lower than a 20-step one on the SAME resident input (one pipeline fill + drain
+            # in half the time), which is most of the 0.96 the round-4 driver line showed for this ratio
+            leg = runner.host_pages_leg(steps=max(10, args.steps), warm=5)
         except Exception as e:      # noqa: BLE001 -- a diagnostic leg
             leg = {"error": f"{type(e).__name__}: {e}"[:300]}
         if leg is not None:
