@@ -57,6 +57,26 @@ __device__ __forceinline__ uint32_t pack_a16x2(float a, float b) {
 __device__ __forceinline__ a16_f32x16 mfma_32x32x16_a16(a16_bf16x8 a, a16_bf16x8 b, a16_f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(a16_f16x8, a), __builtin_bit_cast(a16_f16x8, b), c, 0, 0, 0);
 }
+// Weighted sum of four stored dwords (two values each) with fp32 weights, fp32 accumulation, one rounding: ((w0 c0 + w1 c1) + w2 c2) + w3 c3, fused.
+// The half format has mixed-precision FMAs that read a 16-bit half of a register directly (v_fma_mix_f32, op_sel picks the half) and write a rounded half
+// of the result (v_fma_mixlo / mixhi_f16): eight instructions per dword where unpack + packed fp32 FMA + pack takes thirteen -- the deformable conv's blend
+// is bound by exactly this instruction count (profiles/r05/experiments.txt).  Saturation: MODE.FP16_OVFL covers the mixlo / mixhi results like any VALU half.
+#define PT_A16_HAS_MIX_BLEND 1
+__device__ __forceinline__ uint32_t a16_blend4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, float w0, float w1, float w2, float w3) {
+  float lo, hi;
+  uint32_t o;
+  asm("v_fma_mix_f32 %0, %3, %7, 0 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %1, %3, %7, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %0, %4, %8, %0 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %1, %4, %8, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %0, %5, %9, %0 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %1, %5, %9, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %2, %6, %10, %0 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %2, %6, %10, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(lo), "=&v"(hi), "=&v"(o)
+      : "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+  return o;
+}
 #else
 #define PT_A16_ONE 0x3F80u
 #define PT_A16_LOWEST 0xFF7Fu
@@ -78,6 +98,8 @@ __device__ __forceinline__ uint32_t pack_a16x2(float a, float b) {
 __device__ __forceinline__ a16_f32x16 mfma_32x32x16_a16(a16_bf16x8 a, a16_bf16x8 b, a16_f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+#define PT_A16_HAS_MIX_BLEND 0      // no mixed-precision FMA reads bf16: callers keep their unpack / packed-FMA / pack sequence
+__device__ __forceinline__ uint32_t a16_blend4(uint32_t, uint32_t, uint32_t, uint32_t, float, float, float, float) { return 0u; }
 #endif
 
 }  // namespace PT_FMT_NS

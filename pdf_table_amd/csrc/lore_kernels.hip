@@ -786,6 +786,10 @@ __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) voi
       uint32_t o[4], ol[4];
 #pragma unroll
       for (int e2 = 0; e2 < 4; ++e2) {
+        if constexpr (PT_A16_HAS_MIX_BLEND && !SPLIT) {      // half storage: eight mixed-precision FMAs per dword, no unpack, no pack (act16.h)
+          o[e2] = a16_blend4(rc[j][0][e2], rc[j][1][e2], rc[j][2][e2], rc[j][3][e2], cwt[j][0], cwt[j][1], cwt[j][2], cwt[j][3]);
+          continue;
+        }
         df2 c[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -852,6 +856,10 @@ __global__ __launch_bounds__(NTHR, SPLIT ? (NB == 128 ? 1 : 2) : NTHR / 128) voi
         uint32_t o[4];
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2) {
+          if constexpr (PT_A16_HAS_MIX_BLEND) {
+            o[e2] = a16_blend4(rc[j][0][e2], rc[j][1][e2], rc[j][2][e2], rc[j][3][e2], cwt[j][0], cwt[j][1], cwt[j][2], cwt[j][3]);
+            continue;
+          }
           df2 c[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {

@@ -169,3 +169,35 @@ def test_bits_helper_matches_torch_half():
     bits = to_bf16_bits(t, "f16")
     back = torch.from_numpy(bits.view(np.int16)).view(torch.float16).float()
     assert torch.equal(back, t.clamp(-F16_MAX, F16_MAX).to(torch.float16).float())
+
+
+@pytest.mark.parametrize("C,N,H,W", [(64, 64, 13, 21), (128, 64, 37, 50), (128, 128, 19, 33), (256, 256, 16, 16), (96, 64, 11, 23)])
+@pytest.mark.parametrize("relu,field", [(True, "wide"), (False, "local")])
+def test_dcn_op_f16(eng16, C, N, H, W, relu, field):
+    """pt_op_dcn in PT_PRECISION_F16 against oracle.lore_net.deform_conv2d on fp16-exact operands, with the offset fields of tests/test_gpu_dcn_op.py
+    (multi-pixel, out-of-map, sub-pixel): the blend of namespace pt_f16 runs on mixed-precision FMAs (v_fma_mix_f32 / v_fma_mixlo|hi_f16, act16.h) -- fp32
+    accumulation, ONE fp16 rounding per sampled column -- so the bounds are test_dcn_op_bf16's with the half ulp of fp16 (2^-11) in place of bf16's (2^-8)."""
+    from oracle import lore_net
+    from test_gpu_dcn_op import _case, _om
+    B = 2
+    x, w, b, off, mlog = _case(B, C, N, H, W, seed=C * 1000 + N + H, field=field, rounded=False)
+    x, w = _h(x), _h(w)
+    mask = torch.sigmoid(mlog)
+    cols = lore_net.deform_conv2d(x, off, mask, w, None, return_cols=True)
+    ref = lore_net.deform_conv2d(x, off, mask, w, b)
+    ref_r = torch.einsum("ock,bckhw->bohw", w.reshape(N, C, 9).double(), _h(cols).double()).float() + b.view(1, N, 1, 1)
+    if relu:
+        ref, ref_r = torch.relu(ref), torch.relu(ref_r)
+    dev = torch.device("cuda", 0)
+    w1 = w.permute(0, 2, 3, 1).reshape(N, 9 * C, 1, 1).contiguous()
+    out = eng16.op_dcn(x.permute(0, 2, 3, 1).contiguous().to(torch.float16).to(dev), _om(off, mlog).to(dev),
+                       torch.from_numpy(tile_conv_weight(w1, "f16").view(np.int16)).to(dev), b.to(dev), relu=relu)
+    torch.cuda.synchronize()
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    col_mag = torch.einsum("ock,bckhw->bohw", w.reshape(N, C, 9).abs(), cols.abs())
+    err_a, err_b = (got - ref_r).abs(), (got - ref).abs()
+    tol_a = ref_r.abs() * 2.0 ** -11 + col_mag * 2.0 ** -15 + 1e-4
+    tol_b = ref.abs() * 2.0 ** -11 + col_mag * 2.0 ** -12 + 1e-4
+    print(f"dcn f16 {field} {C}->{N} @{H}x{W}: max err vs rounded-column oracle {err_a.max().item():.3e}, vs oracle {err_b.max().item():.3e}, scale {ref.abs().max().item():.2f}")
+    assert bool((err_a <= tol_a).all()), f"vs rounded-column oracle: max err {err_a.max().item()} (tol there {tol_a.flatten()[err_a.argmax()].item()})"
+    assert bool((err_b <= tol_b).all()), f"vs oracle: max err {err_b.max().item()}"
