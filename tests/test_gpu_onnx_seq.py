@@ -48,6 +48,33 @@ def test_svtr_tiny_recogniser(eng, act):
     assert np.array_equal(got, again)
 
 
+@pytest.mark.parametrize("act", ["gelu", "silu"])
+def test_svtr_tiny_recogniser_f16(act):
+    """the same SVTR-type graph with precision="f16" (PT_PRECISION_F16; the executor makes its own engine in that precision): the sequence operators of
+    graph_ops.hip -- LayerNorm, fused-qkv attention, GELU / swish, Softmax -- in their IEEE-half instantiation, bounds 5x tighter than the bf16 case's"""
+    import onnx_export as X
+    from pdf_table_amd import lib as L
+    from pdf_table_amd.onnx_exec import HipGraphExecutor
+    m = X.seeded(X.SvtrTiny(act=act), 11)
+    x = torch.randn(3, 3, 32, 64, generator=torch.Generator().manual_seed(5))
+    ex = HipGraphExecutor(X.torch_export(m, x), precision="f16")
+    try:
+        assert ex.eng.precision == L.PT_PRECISION_F16 and ex.adt == torch.float16
+        got = ex.run(x.numpy())[0]
+        with torch.no_grad():
+            want = m(x).numpy()
+        d = float(np.abs(got - want).max())
+        same = float((got.argmax(-1) == want.argmax(-1)).mean())
+        print(f"SvtrTiny[{act}] f16: max|d prob| = {d:.3e}, arg-max equal on {same * 100:.1f} % of {got.shape[0] * got.shape[1]} tokens")
+        assert d <= 6e-3 and same >= 0.99
+        a = ex.run_device_graphed(torch.from_numpy(x.numpy()).permute(0, 2, 3, 1).contiguous().to(torch.float16).cuda(), 3)      # eager
+        b = ex.run_device_graphed(torch.from_numpy(x.numpy()).permute(0, 2, 3, 1).contiguous().to(torch.float16).cuda(), 3)      # captured
+        assert a[0].t.dtype == torch.float16 or a[0].t.dtype == torch.float32
+        assert torch.equal(ex.values(a[0]), ex.values(b[0]))
+    finally:
+        ex.eng.close()
+
+
 def test_dynamic_batch_export(eng):
     """an export with a symbolic batch axis (the shipped PP-OCR files): the Reshape targets come out of Shape -> Gather -> Concat arithmetic the
     executor folds on the host per input shape -- the same file runs batches of 2 and of 5, tolerance mode within 1e-3 of the fp32 module"""
