@@ -1100,6 +1100,33 @@ class HipRunner:
             out[mode] = a["frac"]
             out[mode + "_oracle_crops"] = {k: v for k, v in b["frac"].items() if k.startswith(("cells", "logi", "tables"))}
             out[mode + "_counts"] = {k: v for k, v in a.items() if k != "frac"}
+        # The constructive form of `*_oracle_crops`: the layout net ALONE in the pair mode (LayoutStage.precision = BF16X3; OcrTablePipeline(layout_precision=
+        # "fp32")) under an engine that otherwise computes in 16 bits -- the table crops are then the oracle chain's own, chained, at the price of
+        # the layout stage's three passes.  f16 engine: its PicoDet blob is reloaded as a bf16 blob with the pair tiles (blobs carry their format per model).
+        from pdf_table_amd.layout_stage import LayoutStage, PicodetConfig
+        from pdf_table_amd.weights import pack_picodet
+        mixed = [("bf16_layout_fp32", eng, (self.stage, self.rec), None)] if self.x3_leg else []
+        if getattr(self, "_f16", None) is not None:
+            f = self._f16
+            f["eng"].load_weights(L.PT_MODEL_PICODET, pack_picodet(self.ysd, 5, x3=True))
+            mixed.append(("f16_layout_fp32", f["eng"], (f["stage"], f["rec"]), f))
+        for mode, e, st, other in mixed:
+            lay = LayoutStage(e, PicodetConfig(task_type="en"), precision=L.PT_PRECISION_BF16X3)
+            pipe = OcrTablePipeline.from_engine(e, st[0], st[1], lay, TsrStage(e, LoreConfig(task_type="wtw")), table_html=True)
+            a = agreement(g, pipe.predict(pages), self.rec.label, tbs)
+            out[mode] = {k: v for k, v in a["frac"].items() if k.startswith(("boxes_within", "strings_identical_on_2px", "cells", "logi", "tables"))}
+            if other is not None:          # and what it costs: the same timed loop with that layout stage
+                keep = other["layout"], other["pipe"]
+                other["layout"] = lay
+                other["pipe"] = OcrTablePipeline.from_engine(e, other["stage"], other["rec"], lay, other["tsr"], overlap_rec=False,
+                                                             aux_layout=bool(self.args.aux_stream), tsr_on_aux=bool(self.args.aux_stream),
+                                                             lookahead=int(os.environ.get("PT_PIPE_LOOKAHEAD", "1")))
+                try:
+                    with self.on_engine(other):
+                        dt, _ = self.timed(8, 3)
+                    out[mode]["pages_per_s"] = PAGES_PER_STEP * 8 / dt
+                finally:
+                    other["layout"], other["pipe"] = keep
         return out
 
     def parity_sample(self):
@@ -1428,6 +1455,10 @@ def main(argv=None):
                                              "cells_1px": ag[mode].get("cells_matched_1px"),
                                              "cells_1px_oracle_crops": (ag.get(mode + "_oracle_crops") or {}).get("cells_matched_1px"),
                                              "tables_html_identical": ag[mode].get("tables_html_identical")}
+        for mode in ("f16_layout_fp32", "bf16_layout_fp32"):
+            if mode in ag:
+                summ["agreement_" + mode] = {"cells_1px": ag[mode].get("cells_matched_1px"), "strings": ag[mode].get("strings_identical_on_2px_quads"),
+                                             "tables_html_identical": ag[mode].get("tables_html_identical"), "pages_per_s": dig(ag[mode], "pages_per_s")}
         out["summary"] = summ
         sys.stdout.flush()
         if saved_stdout is not None:

@@ -10,7 +10,7 @@ reference's numpy arithmetic (float32 soft-max, float64 boxes), so the result eq
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Dict, List, Sequence
+from typing import Optional, Dict, List, Sequence
 
 import numpy as np
 import torch
@@ -87,8 +87,14 @@ def layout_tables(layout_result: List[Dict], label: str = "table", score_thresho
 
 
 class LayoutStage:
-    def __init__(self, eng: HipEngine, config: PicodetConfig = None, max_cands: int = 2048):
+    def __init__(self, eng: HipEngine, config: PicodetConfig = None, max_cands: int = 2048, precision: Optional[int] = None):
+        """``precision``: an L.PT_PRECISION_* for THIS stage's network, whatever the engine's is (None: the engine's).  The layout net is the
+        pipeline's smallest (3 % of a step) and its output is a DECISION the table stage inherits -- the crop of every table at the box's ROUNDED
+        coordinates (ocr_system_task.py:184-198): in a 16-bit mode an edge that rounds one pixel differently is a different input to the table
+        net.  ``precision=L.PT_PRECISION_BF16X3`` runs just this stage in the pair mode (its blob must then be a bf16 blob with the pair tiles,
+        also on an engine that otherwise computes in PT_PRECISION_F16: blobs carry their format per model)."""
         self.eng = eng
+        self.precision = precision
         self.config = config or PicodetConfig()
         self.max_cands = max_cands
         self._copy_stream = None
@@ -100,8 +106,15 @@ class LayoutStage:
         records on a copy stream behind an event -- finish() waits for that copy only, not for whatever else has
         been queued on the compute stream meanwhile"""
         cfg = self.config
-        counts, cands = self.eng.layout_forward(pages, cfg.img_height, cfg.img_width, len(cfg.labels),
-                                                thr_lo=cfg.score_threshold - 1e-3, max_cands=self.max_cands)
+        keep = self.eng.precision
+        if self.precision is not None and self.precision != keep:
+            self.eng.set_precision(self.precision)        # host state read when a call is queued: the launches below carry it, later calls do not
+        try:
+            counts, cands = self.eng.layout_forward(pages, cfg.img_height, cfg.img_width, len(cfg.labels),
+                                                    thr_lo=cfg.score_threshold - 1e-3, max_cands=self.max_cands)
+        finally:
+            if self.eng.precision != keep:
+                self.eng.set_precision(keep)
         n = counts.shape[0]
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=counts.device)

@@ -72,11 +72,20 @@ class OcrLayoutTask(BaseInferTask):
                                    "export from the hub (no network here, and the ONNX importer is SURVEY.md section 8f-3); pass "
                                    "task_path=<dir with a PicoDet state_dict> or synthetic_seed=<int>")
             sd = torch.load(path, map_location="cpu", weights_only=True)
-        self._engine.load_weights(L.PT_MODEL_PICODET, pack_picodet(sd, ncls, fmt=self._engine.weight_fmt))
+        # stage_precision="fp32": this stage alone in the pair mode (LayoutStage.precision) -- its blob is then a bf16 blob with the pair tiles whatever
+        # the engine's own precision is
+        sp = str(self.kwargs.get("stage_precision") or "").lower()
+        self._stage_precision = L.PT_PRECISION_BF16X3 if sp in ("fp32", "bf16x3", "float32") else None
+        if sp and self._stage_precision is None:
+            raise ValueError(f"stage_precision={sp!r}: only 'fp32' (the pair mode for this stage alone) is supported")
+        if self._stage_precision is not None:
+            self._engine.load_weights(L.PT_MODEL_PICODET, pack_picodet(sd, ncls, x3=True, fmt="bf16"))
+        else:
+            self._engine.load_weights(L.PT_MODEL_PICODET, pack_picodet(sd, ncls, fmt=self._engine.weight_fmt))
         self._model = self._predict
 
     def _build_processor(self):
-        self._stage = LayoutStage(self._engine, self._config)
+        self._stage = LayoutStage(self._engine, self._config, precision=getattr(self, "_stage_precision", None))
 
     def _predict(self, images: List[np.ndarray]) -> List[List[Dict]]:
         out = []

@@ -61,7 +61,7 @@ class OcrTablePipeline:
                  layout_task_path: Optional[str] = None, text_orientation: bool = False,
                  orientation_task_path: Optional[str] = None, table_html: bool = False, overlap_rec: bool = True,
                  rotate_upside_down: bool = True, aux_layout: bool = False, tsr_on_aux: bool = False, lookahead: int = 1,
-                 precision: str = "bf16", **kwargs):
+                 precision: str = "bf16", layout_precision: Optional[str] = None, **kwargs):
         self.engine = HipEngine(device)
         # arithmetic of every stage on this engine: "bf16" (BASELINE.json's), "fp16" (the reference's own default precision,
         # base_infer_task.py:56-57: the engine's single-pass IEEE-half mode, same speed, 8x finer rounding) or "fp32" (three-pass pair mode)
@@ -104,6 +104,8 @@ class OcrTablePipeline:
                 lk["synthetic_seed"] = synthetic_seed + 4
             if layout_task_path:
                 lk["task_path"] = layout_task_path
+            if layout_precision:      # the layout net alone in the pair mode ("fp32"): exact table crops under a 16-bit engine (LayoutStage.precision)
+                lk["stage_precision"] = layout_precision
             self.layout_task = OcrLayoutTask(model=layout_model, engine=self.engine, task_type=layout_task_type, **lk)
         self.table_html = table_html      # structure + recognised text -> HTML per table (OcrTableToHtmlTask, section 8f-2)
         self.orientation_task = None

@@ -73,6 +73,14 @@ def run(golden_dir):
     pipe.res_bf16_tb = pipe.predict(pages, table_boxes=[np.asarray(t) for t in tbs])
     pipe.layout_boxes = {m: [[np.asarray(it["bbox"]).round().tolist() for it in (r.layout_result or []) if str(it.get("label", "")).lower() == "table"] for r in rr]
                          for m, rr in (("bf16x3", res), ("f16", pipe.res_f16), ("bf16", pipe.res_bf16))}
+    # ... and the constructive form of "the oracle's crops": the layout net ALONE in the pair mode on the f16 engine (LayoutStage.precision; its blob a
+    # bf16 blob with the pair tiles -- blobs carry their format per model), everything else in f16, table regions the layout stage's own
+    e16.load_weights(L.PT_MODEL_PICODET, pack_picodet(sds["pico"], 5, x3=True))
+    pipe16m = OcrTablePipeline.from_engine(e16, DetStage(e16, DetConfig(flavour="db_pp", thresh=0.3, box_thresh=0.6, unclip_ratio=1.5)), RecStage(e16),
+                                           LayoutStage(e16, PicodetConfig(task_type="en"), precision=L.PT_PRECISION_BF16X3),
+                                           TsrStage(e16, LoreConfig(task_type="wtw")), table_html=True)
+    pipe.res_f16_layout_fp32 = pipe16m.predict(pages)
+    assert e16.precision == L.PT_PRECISION_F16          # the stage restores the engine's precision behind its call
     e16.close()
     yield g, res, stream, pipe, tbs
     eng.close()
@@ -216,7 +224,8 @@ def test_headline_mode_agreement(run):
     label = pipe.text_recognizer._stage.label
     out = {}
     print("E2E layout table boxes (rounded): fixture", [np.asarray(t).tolist() for t in tbs], pipe.layout_boxes)
-    for mode, r in (("bf16x3", res), ("f16", pipe.res_f16), ("bf16", pipe.res_bf16), ("f16_oracle_crops", pipe.res_f16_tb), ("bf16_oracle_crops", pipe.res_bf16_tb)):
+    for mode, r in (("bf16x3", res), ("f16", pipe.res_f16), ("bf16", pipe.res_bf16), ("f16_oracle_crops", pipe.res_f16_tb), ("bf16_oracle_crops", pipe.res_bf16_tb),
+                    ("f16_layout_fp32", pipe.res_f16_layout_fp32)):
         a = agreement(g, r, label, tbs)
         out[mode] = a
         print(f"E2E AGREEMENT {mode}: " + json.dumps(a["frac"]))
@@ -227,6 +236,9 @@ def test_headline_mode_agreement(run):
     # box that rounds a pixel differently is a different crop, and a random-init Lore net is not shift-robust -- given the oracle's crops f16 finds its cells
     assert fh["boxes_within_2px"] >= 0.98 and fh["strings_identical_on_2px_quads"] >= 0.8
     assert fhc["cells_matched_1px"] >= 0.85
+    # chained, with only the layout net in the pair mode: the crops are the oracle chain's, so the f16 table stage finds its cells without being handed them
+    fm = out["f16_layout_fp32"]["frac"]
+    assert fm["cells_matched_1px"] >= 0.85 and fm["boxes_within_2px"] >= 0.98
     # tolerance mode: what the tests above assert, as fractions
     assert fx["boxes_identical"] >= 0.97 and fx["strings_identical_on_identical_quads"] >= 0.98 and fx["cells_matched_0p1px"] >= 0.95
     # headline mode: recorded; floors below the measured values (r04: boxes 0.98, strings 0.54).  The table cells carry NO floor:
