@@ -188,11 +188,19 @@ np.savez(sys.argv[1], ids=ids.cpu().numpy(), mx=mx.cpu().numpy())
     assert len(np.unique(outs[0]["ids"])) > 20           # not a degenerate output
 
 
-def test_set_lstm_cluster_switches_kernels_in_process(eng, sd):
+@pytest.mark.parametrize("fmt", ["bf16", "f16"])
+def test_set_lstm_cluster_switches_kernels_in_process(eng, sd, fmt):
     """pt_engine_set_lstm_cluster: the streaming LSTM (what an overlapping pipeline uses) and the cluster LSTM give the
-    same ids and winning logits; pt_engine_check has nothing to report after either"""
+    same ids and winning logits; pt_engine_check has nothing to report after either (f16: the same pair in namespace pt_f16)"""
     rng = np.random.default_rng(33)
-    g = torch.from_numpy(rng.uniform(0, 1, (70, 32, 640)).astype(np.float32)).to(torch.bfloat16).cuda()
+    g = torch.from_numpy(rng.uniform(0, 1, (70, 32, 640)).astype(np.float32))
+    own = None
+    if fmt == "f16":
+        from pdf_table_amd.engine import HipEngine
+        eng = own = HipEngine(0)
+        eng.set_precision(L.PT_PRECISION_F16)
+        eng.load_weights(L.PT_MODEL_CRNN, pack_crnn(sd, fmt="f16"))
+    g = g.to(eng.act_dtype).cuda()
     outs = []
     try:
         for on in (True, False, True):
@@ -203,6 +211,8 @@ def test_set_lstm_cluster_switches_kernels_in_process(eng, sd):
             outs.append((ids.cpu().numpy(), mx.cpu().numpy()))
     finally:
         eng.set_lstm_cluster(True)
+        if own is not None:
+            own.close()
     for ids, mx in outs[1:]:
         assert np.array_equal(ids, outs[0][0]) and np.array_equal(mx, outs[0][1])
 
@@ -364,7 +374,7 @@ def test_rec_pp_preprocessor_page_lines_bit_exact(eng):
     assert len(widths) >= 2                                       # mini-batches of different padded widths
 
 
-@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("mode", ["bf16", "f16", "bf16x3"])
 def test_ragged_conv_stack_is_bit_identical_to_the_full_one(sd, mode):
     """pt_rec_forward knows every line's crop size, so the conv stack does no work right of the text (skipped columns are
     filled with an all-padding line's activations): token ids AND winning logits equal the full computation bit for bit
@@ -389,8 +399,8 @@ def test_ragged_conv_stack_is_bit_identical_to_the_full_one(sd, mode):
             e = HipEngine(0)
         finally:
             del os.environ["PT_REC_RAGGED"]
-        e.load_weights(L.PT_MODEL_CRNN, pack_crnn(sd))
-        e.set_precision(L.PT_PRECISION_BF16X3 if mode == "bf16x3" else L.PT_PRECISION_BF16)
+        e.set_precision({"bf16x3": L.PT_PRECISION_BF16X3, "f16": L.PT_PRECISION_F16}.get(mode, L.PT_PRECISION_BF16))
+        e.load_weights(L.PT_MODEL_CRNN, pack_crnn(sd, fmt=e.weight_fmt))          # f16: the pt_f16 instantiation of the same kernels on fp16 tiles
         lines = R.build_lines([boxes])
         pages = torch.from_numpy(img[None]).cuda()
         ids, mx = e.rec_forward(pages, lines)
