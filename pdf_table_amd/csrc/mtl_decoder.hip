@@ -171,9 +171,11 @@ __global__ __launch_bounds__(256) void mtl_fork_kernel(const float* __restrict__
 // uniformly to ALL Lcur positions of the current prefix.  Scores: lane = key (64-term fp32 dot products); weighted sum: lane = channel.
 template <int SPLIT>
 __global__ __launch_bounds__(64) void mtl_self_attn_kernel(const bf16_t* __restrict__ cache, const int* __restrict__ tok, int pad, int p0, int Mp, int M,
-                                                           int Lcur, bf16_t* __restrict__ att) {
+                                                           int Lcur, bf16_t* __restrict__ att, long long cache_bs, long long att_bs) {
   a16_kernel_enter();
   extern __shared__ float sc[];
+  cache += blockIdx.z * cache_bs;      // blockIdx.z: the layer of a pair run in one launch (branch strides in elements)
+  att += blockIdx.z * att_bs;
   const int pi = blockIdx.x / M, s = blockIdx.x % M, p = p0 + pi, head = blockIdx.y, lane = threadIdx.x;
   constexpr int LO = 3 * D, cs = SPLIT ? 2 * LO : LO;
   const bool is_pad = tok[(size_t)p * Mp + s] == pad;
@@ -357,8 +359,11 @@ __global__ __launch_bounds__(64) void mtl_cross_attn_kernel(const bf16_t* __rest
 template <int SPLIT>
 __global__ __launch_bounds__(512) void mtl_cross_decode_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, int koff, const int4* __restrict__ tiles,
                                                               int hw, int keys_per_split, int nsplit, long long R, float* __restrict__ opart,
-                                                              float* __restrict__ mlpart, bf16_t* __restrict__ att) {
+                                                              float* __restrict__ mlpart, bf16_t* __restrict__ att, long long q_bs, long long part_bs,
+                                                              long long ml_bs) {
   a16_kernel_enter();
+  q += blockIdx.z * q_bs; att += blockIdx.z * q_bs; koff += blockIdx.z * 2 * D;      // blockIdx.z: second layer of a pair (the next key / value slot)
+  opart += blockIdx.z * part_bs; mlpart += blockIdx.z * ml_bs;
   const int4 tile = tiles[blockIdx.x];
   const int head = threadIdx.x >> 6, lane = threadIdx.x & 63, z = blockIdx.y;
   const int g = lane >> 3, c = lane & 7;
@@ -508,8 +513,11 @@ __device__ __forceinline__ void unpack16_fp8(const uint4 u, float* f) {
 
 __global__ __launch_bounds__(512) void mtl_cross_decode8_kernel(const bf16_t* __restrict__ q, const unsigned char* __restrict__ kv8, int koff,
                                                                const int4* __restrict__ tiles, int hw, int keys_per_split, int nsplit, long long R,
-                                                               float* __restrict__ opart, float* __restrict__ mlpart, bf16_t* __restrict__ att) {
+                                                               float* __restrict__ opart, float* __restrict__ mlpart, bf16_t* __restrict__ att,
+                                                               long long q_bs, long long part_bs, long long ml_bs) {
   a16_kernel_enter();
+  q += blockIdx.z * q_bs; att += blockIdx.z * q_bs; koff += blockIdx.z * 2 * D;
+  opart += blockIdx.z * part_bs; mlpart += blockIdx.z * ml_bs;
   const int4 tile = tiles[blockIdx.x];
   const int head = threadIdx.x >> 6, lane = threadIdx.x & 63, z = blockIdx.y;
   const int g = lane >> 2, c = lane & 3;
@@ -601,8 +609,10 @@ __global__ __launch_bounds__(512) void mtl_cross_decode8_kernel(const bf16_t* __
 
 // merges the key slices of mtl_cross_attn_kernel: out = sum_z e^(m_z - M) acc_z / sum_z e^(m_z - M) l_z.  thread = (row, channel)
 __global__ __launch_bounds__(512) void mtl_cross_combine_kernel(const float* __restrict__ opart, const float* __restrict__ mlpart, int nsplit, long long R, int Mp,
-                                                                int M, bf16_t* __restrict__ att, int split) {
+                                                                int M, bf16_t* __restrict__ att, int split, long long att_bs, long long part_bs,
+                                                                long long ml_bs) {
   a16_kernel_enter();
+  att += blockIdx.z * att_bs; opart += blockIdx.z * part_bs; mlpart += blockIdx.z * ml_bs;
   const int pi = blockIdx.x / M, s = blockIdx.x % M, c = threadIdx.x, head = c >> 6;
   const long long row = (long long)pi * Mp + s;
   float mx = -INFINITY;
@@ -937,6 +947,204 @@ __global__ __launch_bounds__(256) void mtl_rowgemm_finish_kernel(const float* __
   }
 }
 
+// ---- the same Linear in ONE launch (round 5; the KV-cached loops are a chain of dependent few-microsecond kernels, so the launch count IS the step time).
+// Workgroup = 32 rows x one 64-channel weight tile; its four waves split K (a wave = kc / 4 chunks, in groups of ROWGEMM_CH with the next group's loads in
+// flight), their fp32 partial tiles meet in LDS and are added in wave order (deterministic; for K = 512 the very sums of mtl_rowgemm_finish_kernel), then
+// bias, fp32 residual, ReLU and Ctx::gemm's store contract.  LNIN: the rows come as the fp32 residual stream and nn.LayerNorm(512) runs in the prologue --
+// a wave owns the 128-channel slice its K-share needs, so the values are read once and normalised in registers (two-pass variance like mtl_ln_kernel; row
+// statistics cross the waves through LDS); BF16X3 builds the hi and lo operands there.  Every weight tile of the layer recomputes the statistics of its
+// 32 rows (64 KB from L2) -- cheaper than the launch it replaces.
+constexpr int RF_LD = 68;      // floats per row of the partial tiles in LDS
+
+// one Linear's operands; the kernel takes two sets and blockIdx.z picks (the structure-token and the box layer of a step are independent and equal in
+// shape: one launch per Linear for both)
+struct RowB {
+  const bf16_t* x; const float* xf; const float* lng; const float* lnb; const bf16_t* w; const float* bias;
+  bf16_t* out; float* out_f32; const float* res_f32; int f32_cs; int n_valid;
+};
+
+template <int SPLIT, int LNIN>
+__global__ __launch_bounds__(256) void mtl_rowfused_kernel(const RowB pa, const RowB pb, int cin, int N, int relu, int out_cs) {
+#define RB(f) (blockIdx.z ? pb.f : pa.f)
+  const bf16_t* __restrict__ x = RB(x);
+  const float* __restrict__ xf = RB(xf);
+  const float* __restrict__ lng = RB(lng);
+  const float* __restrict__ lnb = RB(lnb);
+  const bf16_t* __restrict__ w = RB(w);
+  const float* __restrict__ bias = RB(bias);
+  bf16_t* __restrict__ out = RB(out);
+  float* out_f32 = RB(out_f32);
+  const float* res_f32 = RB(res_f32);
+  const int f32_cs = RB(f32_cs), n_valid = RB(n_valid);
+#undef RB
+  a16_kernel_enter();
+  __shared__ float s_red[4][32][RF_LD];
+  __shared__ float s_stat[2][4][32];
+  const int nt = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int col = lane & 31, half = lane >> 5;
+  const long long row = (long long)blockIdx.y * 32 + col;
+  const int kc1 = cin >> 5, kc = SPLIT ? 3 * kc1 : kc1;
+  const bf16_t* wt = w + (size_t)nt * kc * (64 * 32) + col * 32 + 8 * half;
+  af32x16 acc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+  auto load_a = [&](abf16x8 (&a)[ROWGEMM_CH][2][2], int wc0) {
+#pragma unroll
+    for (int i = 0; i < ROWGEMM_CH; ++i) {
+      const bf16_t* wp = wt + (size_t)(wc0 + i) * (64 * 32);
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        a[i][0][st] = ld8(wp + 16 * st);
+        a[i][1][st] = ld8(wp + 32 * 32 + 16 * st);
+      }
+    }
+  };
+  auto mma = [&](const abf16x8 (&a)[ROWGEMM_CH][2][2], const abf16x8 (&b)[ROWGEMM_CH][2]) {
+#pragma unroll
+    for (int i = 0; i < ROWGEMM_CH; ++i)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        acc[0] = mfma_32x32x16_a16(a[i][0][st], b[i][st], acc[0]);
+        acc[1] = mfma_32x32x16_a16(a[i][1][st], b[i][st], acc[1]);
+      }
+  };
+  abf16x8 a0[ROWGEMM_CH][2][2], a1[ROWGEMM_CH][2][2];
+  if constexpr (LNIN) {
+    // cin == D: chunks 4 * wave .. 4 * wave + 3 of every pass
+    load_a(a0, 4 * wave);
+    float v[ROWGEMM_CH][2][8];
+    const float* xr = xf + row * D + 128 * wave + 8 * half;
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < ROWGEMM_CH; ++i)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const float4 p = *reinterpret_cast<const float4*>(xr + 32 * i + 16 * st), q = *reinterpret_cast<const float4*>(xr + 32 * i + 16 * st + 4);
+        float* vv = v[i][st];
+        vv[0] = p.x; vv[1] = p.y; vv[2] = p.z; vv[3] = p.w; vv[4] = q.x; vv[5] = q.y; vv[6] = q.z; vv[7] = q.w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sm += vv[e];
+      }
+    sm += __shfl_xor(sm, 32);
+    if (half == 0) s_stat[0][wave][col] = sm;
+    __syncthreads();
+    const float mean = (((s_stat[0][0][col] + s_stat[0][1][col]) + s_stat[0][2][col]) + s_stat[0][3][col]) / (float)D;
+    float qd = 0.f;
+#pragma unroll
+    for (int i = 0; i < ROWGEMM_CH; ++i)
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qd += (v[i][st][e] - mean) * (v[i][st][e] - mean);
+    qd += __shfl_xor(qd, 32);
+    if (half == 0) s_stat[1][wave][col] = qd;
+    __syncthreads();
+    const float rstd = 1.f / sqrtf((((s_stat[1][0][col] + s_stat[1][1][col]) + s_stat[1][2][col]) + s_stat[1][3][col]) / (float)D + 1e-5f);
+    abf16x8 bh[ROWGEMM_CH][2], bl[ROWGEMM_CH][2];
+#pragma unroll
+    for (int i = 0; i < ROWGEMM_CH; ++i)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const int c0 = 128 * wave + 32 * i + 16 * st + 8 * half;
+        const float4 g0 = *reinterpret_cast<const float4*>(lng + c0), g1 = *reinterpret_cast<const float4*>(lng + c0 + 4);
+        const float4 e0 = *reinterpret_cast<const float4*>(lnb + c0), e1 = *reinterpret_cast<const float4*>(lnb + c0 + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, ee[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = (v[i][st][e] - mean) * rstd * gg[e] + ee[e];
+        uint4 hi = {pack_a16x2(y[0], y[1]), pack_a16x2(y[2], y[3]), pack_a16x2(y[4], y[5]), pack_a16x2(y[6], y[7])};
+        bh[i][st] = __builtin_bit_cast(abf16x8, hi);
+        if constexpr (SPLIT) {
+          uint4 lo = {pack_a16x2(y[0] - a16lo_f32(hi.x), y[1] - a16hi_f32(hi.x)), pack_a16x2(y[2] - a16lo_f32(hi.y), y[3] - a16hi_f32(hi.y)),
+                      pack_a16x2(y[4] - a16lo_f32(hi.z), y[5] - a16hi_f32(hi.z)), pack_a16x2(y[6] - a16lo_f32(hi.w), y[7] - a16hi_f32(hi.w))};
+          bl[i][st] = __builtin_bit_cast(abf16x8, lo);
+        }
+      }
+    if constexpr (SPLIT) {      // weights [hi | hi | lo] against the row's [hi | lo | hi]
+      load_a(a1, kc1 + 4 * wave);
+      mma(a0, bh);
+      load_a(a0, 2 * kc1 + 4 * wave);
+      mma(a1, bl);
+      mma(a0, bh);
+    } else {
+      mma(a0, bh);
+    }
+  } else {
+    const int cpw = kc >> 2, ng = cpw / ROWGEMM_CH;      // host: kc % 16 == 0
+    const bf16_t* xr = x + row * (SPLIT ? 2 * cin : cin) + 8 * half;
+    abf16x8 b0[ROWGEMM_CH][2], b1[ROWGEMM_CH][2];
+    auto load_b = [&](abf16x8 (&b)[ROWGEMM_CH][2], int c0) {
+#pragma unroll
+      for (int i = 0; i < ROWGEMM_CH; ++i) {
+        const int c = c0 + i;
+        const int xc = !SPLIT ? c : (c < 2 * kc1 ? c : c - 2 * kc1);      // [hi | lo] rows against weight chunks [hi | hi | lo]
+#pragma unroll
+        for (int st = 0; st < 2; ++st) b[i][st] = ld8(xr + xc * 32 + 16 * st);
+      }
+    };
+    const int cw = wave * cpw;
+    load_a(a0, cw); load_b(b0, cw);
+    for (int g = 0; g < ng; g += 2) {
+      if (g + 1 < ng) { load_a(a1, cw + (g + 1) * ROWGEMM_CH); load_b(b1, cw + (g + 1) * ROWGEMM_CH); }
+      mma(a0, b0);
+      if (g + 2 < ng) { load_a(a0, cw + (g + 2) * ROWGEMM_CH); load_b(b0, cw + (g + 2) * ROWGEMM_CH); }
+      if (g + 1 < ng) mma(a1, b1);
+    }
+  }
+  // partial tiles -> LDS ([wave][row][channel]), summed in wave order by (row, eight channels) threads
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 t = {acc[h][4 * g], acc[h][4 * g + 1], acc[h][4 * g + 2], acc[h][4 * g + 3]};
+      *reinterpret_cast<float4*>(&s_red[wave][col][h * 32 + 8 * g + 4 * half]) = t;
+    }
+  __syncthreads();
+  const int r = threadIdx.x >> 3, c8 = (threadIdx.x & 7) * 8, n0 = nt * 64 + c8;
+  if (n_valid && n0 >= n_valid) return;
+  const long long grow = (long long)blockIdx.y * 32 + r;
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = s_red[0][r][c8 + e];
+#pragma unroll
+  for (int z = 1; z < 4; ++z)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] += s_red[z][r][c8 + e];
+  const bool second = !n_valid || n0 + 4 < n_valid;      // n_valid % 4 == 0
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] += bias[n0 + e];
+  if (second)
+#pragma unroll
+    for (int e = 4; e < 8; ++e) o[e] += bias[n0 + e];
+  if (res_f32) {
+    const float* rp = res_f32 + grow * f32_cs + n0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] += rp[e];
+    if (second)
+#pragma unroll
+      for (int e = 4; e < 8; ++e) o[e] += rp[e];
+  }
+  if (relu)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = fmaxf(o[e], 0.f);
+  if (out_f32) {
+    float* op = out_f32 + grow * f32_cs + n0;
+    *reinterpret_cast<float4*>(op) = float4{o[0], o[1], o[2], o[3]};
+    if (second) *reinterpret_cast<float4*>(op + 4) = float4{o[4], o[5], o[6], o[7]};
+  } else {
+    bf16_t* op = out + grow * (SPLIT ? 2 * out_cs : out_cs) + n0;
+    const uint4 hi = {pack_a16x2(o[0], o[1]), pack_a16x2(o[2], o[3]), pack_a16x2(o[4], o[5]), pack_a16x2(o[6], o[7])};
+    *reinterpret_cast<uint2*>(op) = uint2{hi.x, hi.y};
+    if (second) *reinterpret_cast<uint2*>(op + 4) = uint2{hi.z, hi.w};
+    if constexpr (SPLIT) {
+      const uint2 l0 = {pack_a16x2(o[0] - a16lo_f32(hi.x), o[1] - a16hi_f32(hi.x)), pack_a16x2(o[2] - a16lo_f32(hi.y), o[3] - a16hi_f32(hi.y))};
+      const uint2 l1 = {pack_a16x2(o[4] - a16lo_f32(hi.z), o[5] - a16hi_f32(hi.z)), pack_a16x2(o[6] - a16lo_f32(hi.w), o[7] - a16hi_f32(hi.w))};
+      *reinterpret_cast<uint2*>(op + out_cs) = l0;
+      if (second) *reinterpret_cast<uint2*>(op + out_cs + 4) = l1;
+    }
+  }
+}
+
 // what survives between pt_tsr_mtl_structure and pt_tsr_mtl_cells
 struct MtlState {
   DevBuf persist, work, cwork, part;      // part: K-slice partial tiles of mtl_rowgemm_kernel
@@ -976,6 +1184,11 @@ struct Ctx {
     const PtTensor* b = get(q + ".b");
     if (rc != PT_OK) return;
     static const int skinny_rows = getenv("PT_MTL_ROWGEMM_MAX") ? atoi(getenv("PT_MTL_ROWGEMM_MAX")) : 512;
+    if (fusable(rows, cin, N, out_f32, f32_cs, nv, out_cs)) {
+      Lin l{x, nullptr, "", q, out, out_f32, res_f32, f32_cs, nv};
+      lin(1, &l, rows, cin, N, relu, out_cs, nullptr);
+      return;
+    }
     if (part && rows <= skinny_rows && rows % 32 == 0 && N % 64 == 0 && cin % 32 == 0 && (!out_f32 || f32_cs % 4 == 0) && (nv == 0 || nv % 4 == 0)) {
       const int kc = (x3 ? 3 : 1) * (cin / 32), nz = (kc + ROWGEMM_CH - 1) / ROWGEMM_CH;
       const size_t need = (size_t)nz * rows * N * sizeof(float);
@@ -1004,6 +1217,59 @@ struct Ctx {
     const int r = pt_launch_conv(e, c, s);
     if (r != PT_OK) rc = r;
   }
+  // one Linear: bf16 rows `x`, or (xf != null) LayerNorm `lnq` of the fp32 rows xf [rows, 512]; weights `q`; bf16 rows `out` or fp32 rows `out_f32` (+ res)
+  struct Lin {
+    const bf16_t* x; const float* xf; std::string lnq, q;
+    bf16_t* out; float* out_f32; const float* res; int f32_cs, nv;
+  };
+  // nb (1 or 2) Linears of one shape: ONE mtl_rowfused_kernel launch when the shape allows, else one after the other on the general kernels
+  void lin(int nb, const Lin* l, long long rows, int cin, int N, int relu, int out_cs, bf16_t* xb) {
+    bool fuse = true;
+    for (int b = 0; b < nb; ++b) fuse = fuse && fusable(rows, cin, N, l[b].out_f32, l[b].f32_cs, l[b].nv, out_cs) && (l[b].xf != nullptr) == (l[0].xf != nullptr);
+    if (!fuse) {
+      for (int b = 0; b < nb; ++b) {
+        if (l[b].xf) gemm_ln(l[b].xf, rows, l[b].lnq, xb, l[b].q, N, relu, l[b].out, out_cs, l[b].out_f32, l[b].f32_cs, l[b].nv);
+        else gemm(l[b].x, rows, cin, l[b].q, N, relu, l[b].out, out_cs, l[b].out_f32, l[b].f32_cs, l[b].res, l[b].nv);
+      }
+      return;
+    }
+    RowB rb[2];
+    for (int b = 0; b < nb; ++b) {
+      const PtTensor* w = get(l[b].q + (x3 ? ".w3" : ".w"));
+      const PtTensor* bi = get(l[b].q + ".b");
+      const float *g = nullptr, *be = nullptr;
+      if (l[b].xf) { g = F(l[b].lnq + ".g"); be = F(l[b].lnq + ".b"); }
+      if (rc != PT_OK) return;
+      rb[b] = RowB{l[b].x, l[b].xf, g, be, reinterpret_cast<const bf16_t*>(w->d_ptr), reinterpret_cast<const float*>(bi->d_ptr), l[b].out, l[b].out_f32,
+                   l[b].res, l[b].f32_cs, l[b].nv};
+    }
+    if (nb == 1) rb[1] = rb[0];
+    PtProfScope ps(e, s, PT_PROF_OTHER, 0, "mtl row gemm");
+    const dim3 grid(N / 64, (unsigned)(rows / 32), nb);
+    const bool lnin = l[0].xf != nullptr;
+    if (x3 && lnin) hipLaunchKernelGGL((mtl_rowfused_kernel<1, 1>), grid, dim3(256), 0, s, rb[0], rb[1], cin, N, relu, out_cs);
+    else if (x3) hipLaunchKernelGGL((mtl_rowfused_kernel<1, 0>), grid, dim3(256), 0, s, rb[0], rb[1], cin, N, relu, out_cs);
+    else if (lnin) hipLaunchKernelGGL((mtl_rowfused_kernel<0, 1>), grid, dim3(256), 0, s, rb[0], rb[1], cin, N, relu, out_cs);
+    else hipLaunchKernelGGL((mtl_rowfused_kernel<0, 0>), grid, dim3(256), 0, s, rb[0], rb[1], cin, N, relu, out_cs);
+  }
+  // one launch per Linear (mtl_rowfused_kernel) for the KV-cached loops' row counts; PT_MTL_ROWFUSED=0: the split-K pair of kernels + mtl_ln_kernel
+  bool fusable(long long rows, int cin, int N, const float* out_f32, int f32_cs, int nv, int out_cs) const {
+    static const bool on = !(getenv("PT_MTL_ROWFUSED") && atoi(getenv("PT_MTL_ROWFUSED")) == 0);
+    static const int skinny_rows = getenv("PT_MTL_ROWGEMM_MAX") ? atoi(getenv("PT_MTL_ROWGEMM_MAX")) : 512;
+    return on && part && rows <= skinny_rows && rows % 32 == 0 && N % 64 == 0 && ((x3 ? 3 : 1) * (cin / 32)) % 16 == 0 && cin % 32 == 0 &&
+           (out_f32 ? f32_cs % 4 == 0 : out_cs % 8 == 0) && (nv == 0 || nv % 4 == 0);
+  }
+  // y = LayerNorm(x; lnq) W^T + b: x fp32 [rows, 512] (the residual stream).  `xb`: where the normalised rows go when the two cannot share a launch
+  void gemm_ln(const float* x, long long rows, const std::string& lnq, bf16_t* xb, const std::string& q, int N, int relu, bf16_t* out, int out_cs,
+               float* out_f32 = nullptr, int f32_cs = 0, int nv = 0) {
+    if (fusable(rows, D, N, out_f32, f32_cs, nv, out_cs)) {
+      Lin l{nullptr, x, lnq, q, out, out_f32, nullptr, f32_cs, nv};
+      lin(1, &l, rows, D, N, relu, out_cs, xb);
+      return;
+    }
+    ln(x, rows, lnq, xb);
+    gemm(xb, rows, D, q, N, relu, out, out_cs, out_f32, f32_cs, nullptr, nv);
+  }
   void ln(const float* x, long long rows, const std::string& q, bf16_t* out) {
     const float *g = F(q + ".g"), *b = F(q + ".b");
     if (rc != PT_OK) return;
@@ -1020,6 +1286,8 @@ struct Work {
   int4* tiles = nullptr;
   int ntiles = 0, nsplit = 1, kps = 0;
   bool single = false;      // every tile is ONE query (the KV-cached structure loop): mtl_cross_decode_kernel
+  // buffers of a second layer run in the same launches (structure-token + box layer of a KV-cached step): element strides from the first one's (0: none)
+  long long bs_row = 0, bs_hb = 0, bs_opart = 0, bs_ml = 0;
 };
 
 struct Seqs {          // the sequences of one loop
@@ -1031,44 +1299,62 @@ struct Seqs {          // the sequences of one loop
   const unsigned char* kv8 = nullptr;      // fp8 copy of the cross keys / values (pt_engine_set_mtl_kv_fp8; null: off)
 };
 
-// one DecoderLayer over positions [p0, p1] of all sequences.  x: fp32 residual rows of those positions ((p - p0) * Mp + s), updated in
-// place; cache: this layer's [position][Mp][1536] q/k/v cache; slot: the layer's place in the cross K / V tensor.
-void run_layer(Ctx& c, const std::string& q, int slot, float* x, bf16_t* cache, const bf16_t* kv, const Seqs& S, const Work& W, int p0, int p1) {
+// One DecoderLayer over positions [p0, p1] of all sequences -- or (nb == 2) two independent layers of one shape in the same launches: the structure-token
+// and the box layer of a KV-cached step.  Per layer: weights `q`, its place `slot` in the cross K / V tensor (the second layer's = slot + 1), x_in: the
+// fp32 residual rows of those positions ((p - p0) * Mp + s) the layer starts from, x: where its residual stream lives from the first residual on
+// (x == x_in: in place).  cache: the first layer's [position][Mp][1536] q/k/v cache, the second's cache_bs elements behind it.
+struct LayerB { std::string q; const float* x_in; float* x; };
+
+void run_layer(Ctx& c, int nb, const LayerB* lb, int slot, bf16_t* cache, long long cache_bs, const bf16_t* kv, const Seqs& S, const Work& W, int p0, int p1) {
   const int npos = p1 - p0 + 1;
   const long long rows = (long long)npos * S.Mp;
   const int mul = c.mul;
-  c.ln(x, rows, q + ".ln0", W.xb);
-  bf16_t* slab = cache + (size_t)p0 * S.Mp * 3 * D * mul;
-  c.gemm(W.xb, rows, D, q + ".qkv", 3 * D, 0, slab, 3 * D);
+  const size_t slab_off = (size_t)p0 * S.Mp * 3 * D * mul;
+  Ctx::Lin l[2];
+  for (int b = 0; b < nb; ++b) l[b] = Ctx::Lin{nullptr, lb[b].x_in, lb[b].q + ".ln0", lb[b].q + ".qkv", cache + b * cache_bs + slab_off, nullptr, nullptr, 0, 0};
+  c.lin(nb, l, rows, D, 3 * D, 0, 3 * D, W.xb);
   if (c.rc != PT_OK) return;
   {
     PtProfScope ps(c.e, c.s, PT_PROF_OTHER, 0, "mtl self attention");
     const size_t lds = (size_t)(p1 + 1) * sizeof(float);
-    if (c.x3) hipLaunchKernelGGL(mtl_self_attn_kernel<1>, dim3(npos * S.M, HEADS), dim3(64), lds, c.s, cache, S.tok, S.pad, p0, S.Mp, S.M, p1 + 1, W.att);
-    else hipLaunchKernelGGL(mtl_self_attn_kernel<0>, dim3(npos * S.M, HEADS), dim3(64), lds, c.s, cache, S.tok, S.pad, p0, S.Mp, S.M, p1 + 1, W.att);
+    const dim3 grid(npos * S.M, HEADS, nb);
+    if (c.x3) hipLaunchKernelGGL(mtl_self_attn_kernel<1>, grid, dim3(64), lds, c.s, cache, S.tok, S.pad, p0, S.Mp, S.M, p1 + 1, W.att, cache_bs, W.bs_row);
+    else hipLaunchKernelGGL(mtl_self_attn_kernel<0>, grid, dim3(64), lds, c.s, cache, S.tok, S.pad, p0, S.Mp, S.M, p1 + 1, W.att, cache_bs, W.bs_row);
   }
-  c.gemm(W.att, rows, D, q + ".so", D, 0, nullptr, 0, x, D, x);
-  c.ln(x, rows, q + ".ln1", W.xb);
-  c.gemm(W.xb, rows, D, q + ".cq", D, 0, W.qc, D);
+  for (int b = 0; b < nb; ++b) l[b] = Ctx::Lin{W.att + b * W.bs_row, nullptr, "", lb[b].q + ".so", nullptr, lb[b].x, lb[b].x_in, D, 0};
+  c.lin(nb, l, rows, D, D, 0, 0, nullptr);
+  for (int b = 0; b < nb; ++b) l[b] = Ctx::Lin{nullptr, lb[b].x, lb[b].q + ".ln1", lb[b].q + ".cq", W.qc + b * W.bs_row, nullptr, nullptr, 0, 0};
+  c.lin(nb, l, rows, D, D, 0, D, W.xb);
   if (c.rc != PT_OK) return;
   {
     PtProfScope ps(c.e, c.s, PT_PROF_OTHER, 0, "mtl source attention");
-    const dim3 grid(W.ntiles, HEADS, W.nsplit), dgrid(W.ntiles, W.nsplit);
+    const dim3 grid(W.ntiles, HEADS, W.nsplit), dgrid(W.ntiles, W.nsplit, nb);
     static const bool decode_kernel = !getenv("PT_MTL_CROSS_MFMA");
     if (W.single && S.kv8 && !c.x3) {
-      hipLaunchKernelGGL(mtl_cross_decode8_kernel, dgrid, dim3(512), 0, c.s, W.qc, S.kv8, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.Rs, W.opart, W.mlpart, W.att);
-    } else if (W.single && decode_kernel) {
-      if (c.x3) hipLaunchKernelGGL(mtl_cross_decode_kernel<1>, dgrid, dim3(512), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.Rs, W.opart, W.mlpart, W.att);
-      else hipLaunchKernelGGL(mtl_cross_decode_kernel<0>, dgrid, dim3(512), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.Rs, W.opart, W.mlpart, W.att);
+      hipLaunchKernelGGL(mtl_cross_decode8_kernel, dgrid, dim3(512), 0, c.s, W.qc, S.kv8, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.Rs, W.opart, W.mlpart, W.att,
+                         W.bs_row, W.bs_opart, W.bs_ml);
+    } else if (W.single && (decode_kernel || nb > 1)) {
+      if (c.x3) hipLaunchKernelGGL(mtl_cross_decode_kernel<1>, dgrid, dim3(512), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.Rs, W.opart, W.mlpart, W.att,
+                                   W.bs_row, W.bs_opart, W.bs_ml);
+      else hipLaunchKernelGGL(mtl_cross_decode_kernel<0>, dgrid, dim3(512), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.Rs, W.opart, W.mlpart, W.att,
+                              W.bs_row, W.bs_opart, W.bs_ml);
     } else if (c.x3) hipLaunchKernelGGL(mtl_cross_attn_kernel<1>, grid, dim3(64), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.Rs, W.opart, W.mlpart, W.att);
     else hipLaunchKernelGGL(mtl_cross_attn_kernel<0>, grid, dim3(64), 0, c.s, W.qc, kv, slot * 2 * D, W.tiles, S.hw, W.kps, W.nsplit, W.Rs, W.opart, W.mlpart, W.att);
     if (W.nsplit > 1)
-      hipLaunchKernelGGL(mtl_cross_combine_kernel, dim3(npos * S.M), dim3(512), 0, c.s, W.opart, W.mlpart, W.nsplit, W.Rs, S.Mp, S.M, W.att, c.x3);
+      hipLaunchKernelGGL(mtl_cross_combine_kernel, dim3(npos * S.M, 1, nb), dim3(512), 0, c.s, W.opart, W.mlpart, W.nsplit, W.Rs, S.Mp, S.M, W.att, c.x3, W.bs_row,
+                         W.bs_opart, W.bs_ml);
   }
-  c.gemm(W.att, rows, D, q + ".co", D, 0, nullptr, 0, x, D, x);
-  c.ln(x, rows, q + ".ln2", W.xb);
-  c.gemm(W.xb, rows, D, q + ".ff1", S.ffp, 1, W.hb, S.ffp);
-  c.gemm(W.hb, rows, S.ffp, q + ".ff2", D, 0, nullptr, 0, x, D, x);
+  for (int b = 0; b < nb; ++b) l[b] = Ctx::Lin{W.att + b * W.bs_row, nullptr, "", lb[b].q + ".co", nullptr, lb[b].x, lb[b].x, D, 0};
+  c.lin(nb, l, rows, D, D, 0, 0, nullptr);
+  for (int b = 0; b < nb; ++b) l[b] = Ctx::Lin{nullptr, lb[b].x, lb[b].q + ".ln2", lb[b].q + ".ff1", W.hb + b * W.bs_hb, nullptr, nullptr, 0, 0};
+  c.lin(nb, l, rows, D, S.ffp, 1, S.ffp, W.xb);
+  for (int b = 0; b < nb; ++b) l[b] = Ctx::Lin{W.hb + b * W.bs_hb, nullptr, "", lb[b].q + ".ff2", nullptr, lb[b].x, lb[b].x, D, 0};
+  c.lin(nb, l, rows, S.ffp, D, 0, 0, nullptr);
+}
+
+void run_layer(Ctx& c, const std::string& q, int slot, float* x, bf16_t* cache, const bf16_t* kv, const Seqs& S, const Work& W, int p0, int p1) {
+  const LayerB lb{q, x, x};
+  run_layer(c, 1, &lb, slot, cache, 0, kv, S, W, p0, p1);
 }
 
 MtlState* state_of(pt_engine* e) {
@@ -1209,18 +1495,20 @@ int pt_mtl_structure(pt_engine* e, const float* f3, int n, int hw, float* d_tag_
   int* first_pad = fin + Mp;
 
   // ---- work buffers: cached mode needs one position per buffer, re-decode mode all T
-  struct Lay { size_t x[3], cache, xb, qc, att, hb, lg, bx, opart, mlpart, tiles, featb, total; long long R; int nsplit_cap; };
+  struct Lay { size_t x[3], cache, xb, qc, att, hb, lg, bx, opart, mlpart, tiles, featb, total; long long R, prow; int nsplit_cap; bool pair; };
   auto plan = [&](bool all_positions) {
     Lay L;
     Carver cv;
     const long long R = all_positions ? (long long)T * Mp : Mp;
     L.R = R;
+    L.pair = !all_positions;
     for (int i = 0; i < 3; ++i) L.x[i] = cv.take((size_t)R * D * sizeof(float));
     L.cache = cv.take((size_t)4 * T * Mp * 3 * D * mul * sizeof(bf16_t));
+    const int nbuf = all_positions ? 1 : 2;      // KV-cached mode: the structure-token and the box layer of a step share their launches (run_layer, nb = 2)
     L.xb = cv.take((size_t)R * D * mul * sizeof(bf16_t));
-    L.qc = cv.take((size_t)R * D * mul * sizeof(bf16_t));
-    L.att = cv.take((size_t)R * D * mul * sizeof(bf16_t));
-    L.hb = cv.take((size_t)R * mt.ffp * mul * sizeof(bf16_t));
+    L.qc = cv.take((size_t)nbuf * R * D * mul * sizeof(bf16_t));
+    L.att = cv.take((size_t)nbuf * R * D * mul * sizeof(bf16_t));
+    L.hb = cv.take((size_t)nbuf * R * mt.ffp * mul * sizeof(bf16_t));
     L.lg = cv.take((size_t)R * ncls_p * sizeof(float));
     L.bx = cv.take((size_t)R * 8 * sizeof(float));
     // split-key partials: a step with `npos` positions in flight uses nsplit(npos) slices of npos * Mp rows each (stride = the rows in use,
@@ -1234,8 +1522,9 @@ int pt_mtl_structure(pt_engine* e, const float* f3, int n, int hw, float* d_tag_
       if (ns_ > L.nsplit_cap) L.nsplit_cap = ns_;
       if ((long long)ns_ * np_ * Mp > prow) prow = (long long)ns_ * np_ * Mp;
     }
-    L.opart = cv.take((size_t)prow * D * sizeof(float));
-    L.mlpart = cv.take((size_t)prow * HEADS * 2 * sizeof(float));
+    L.prow = prow;
+    L.opart = cv.take((size_t)nbuf * prow * D * sizeof(float));
+    L.mlpart = cv.take((size_t)nbuf * prow * HEADS * 2 * sizeof(float));
     L.tiles = cv.take(((size_t)n * ((T + 31) / 32) + 16) * sizeof(int4));
     L.featb = all_positions ? 0 : cv.take((size_t)Fr * D * mul * sizeof(bf16_t));
     L.total = cv.off;
@@ -1278,6 +1567,8 @@ int pt_mtl_structure(pt_engine* e, const float* f3, int n, int hw, float* d_tag_
     W.xb = reinterpret_cast<bf16_t*>(wb + l.xb); W.qc = reinterpret_cast<bf16_t*>(wb + l.qc); W.att = reinterpret_cast<bf16_t*>(wb + l.att);
     W.hb = reinterpret_cast<bf16_t*>(wb + l.hb); W.opart = reinterpret_cast<float*>(wb + l.opart); W.mlpart = reinterpret_cast<float*>(wb + l.mlpart);
     W.tiles = reinterpret_cast<int4*>(wb + l.tiles);
+    W.bs_row = l.pair ? l.R * D * mul : 0; W.bs_hb = l.pair ? l.R * mt.ffp * mul : 0;
+    W.bs_opart = l.pair ? l.prow * D : 0; W.bs_ml = l.pair ? l.prow * HEADS * 2 : 0;
   };
   auto enter_redecode = [&]() -> int {
     PT_HIP_CHECK(hipStreamSynchronize(s));
@@ -1289,7 +1580,7 @@ int pt_mtl_structure(pt_engine* e, const float* f3, int n, int hw, float* d_tag_
     return PT_OK;
   };
   bind(L);
-  PT_HIP_CHECK(hipMemsetAsync(W.att, 0, (size_t)L.R * D * mul * sizeof(bf16_t), s));
+  PT_HIP_CHECK(hipMemsetAsync(W.att, 0, (size_t)2 * L.R * D * mul * sizeof(bf16_t), s));
   if (redecode && (rc = enter_redecode()) != PT_OK) return rc;
   if (!redecode) {           // one query per table and step
     std::vector<int4> tl(n);
@@ -1320,6 +1611,11 @@ int pt_mtl_structure(pt_engine* e, const float* f3, int n, int hw, float* d_tag_
       W.single = false;
       if ((rc = upload_tiles(tl, W.tiles, s)) != PT_OK) return rc;
     }
+    // KV-cached step: the shared layers work in place on keep[t] (x2 of every position, what the cell-content decoder reads: no copy; rows of finished
+    // sequences are past their length and never read), then the structure-token and the box layer run as ONE chain of launches (nb = 2)
+    static const bool pair_on = !(getenv("PT_MTL_PAIR") && atoi(getenv("PT_MTL_PAIR")) == 0);
+    const bool pair = !redecode && pair_on && L.pair && W.single && c.fusable(rows, D, D, xc, D, 0, 0);
+    if (pair) xs = keep + (size_t)t * Mp * D;
     {
       PtProfScope ps(e, s, PT_PROF_OTHER, 0, "mtl embed");
       hipLaunchKernelGGL(mtl_embed_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, tok, emb, pe, p0, npos, Mp, n, xs, (bf16_t*)nullptr,
@@ -1328,18 +1624,24 @@ int pt_mtl_structure(pt_engine* e, const float* f3, int n, int hw, float* d_tag_
     run_layer(c, LN[0], 0, xs, cache, kv, S, W, p0, t);
     run_layer(c, LN[1], 1, xs, cache + cache_layer, kv, S, W, p0, t);
     if (c.rc != PT_OK) return c.rc;
-    {
-      const long long tot = rows * (D / 4);
-      hipLaunchKernelGGL(mtl_fork_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, xs, xc, xx, keep, fin, p0, t, Mp, n);
-    }
-    run_layer(c, LN[2], 2, xc, cache + 2 * cache_layer, kv, S, W, p0, t);
-    run_layer(c, LN[3], 3, xx, cache + 3 * cache_layer, kv, S, W, p0, t);
     float* lg = reinterpret_cast<float*>(wb + L.lg);
     float* bx = reinterpret_cast<float*>(wb + L.bx);
-    c.ln(xc, rows, "norm", W.xb);
-    c.gemm(W.xb, rows, D, "cls_fc", ncls_p, 0, nullptr, 0, lg, ncls_p);
-    c.ln(xx, rows, "norm", W.xb);
-    c.gemm(W.xb, rows, D, "bbox_fc", 64, 0, nullptr, 0, bx, 8, nullptr, 8);
+    if (pair) {
+      const LayerB lb[2] = {{LN[2], xs, xc}, {LN[3], xs, xx}};
+      run_layer(c, 2, lb, 2, cache + 2 * cache_layer, (long long)cache_layer, kv, S, W, p0, t);
+      const Ctx::Lin heads[2] = {{nullptr, xc, "norm", "cls_fc", nullptr, lg, nullptr, ncls_p, 0}, {nullptr, xx, "norm", "bbox_fc", nullptr, bx, nullptr, 8, 8}};
+      if (ncls_p == 64) c.lin(2, heads, rows, D, 64, 0, 0, W.xb);
+      else { c.lin(1, &heads[0], rows, D, ncls_p, 0, 0, W.xb); c.lin(1, &heads[1], rows, D, 64, 0, 0, W.xb); }
+    } else {
+      {
+        const long long tot = rows * (D / 4);
+        hipLaunchKernelGGL(mtl_fork_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, xs, xc, xx, keep, fin, p0, t, Mp, n);
+      }
+      run_layer(c, LN[2], 2, xc, cache + 2 * cache_layer, kv, S, W, p0, t);
+      run_layer(c, LN[3], 3, xx, cache + 3 * cache_layer, kv, S, W, p0, t);
+      c.gemm_ln(xc, rows, "norm", W.xb, "cls_fc", ncls_p, 0, nullptr, 0, lg, ncls_p);
+      c.gemm_ln(xx, rows, "norm", W.xb, "bbox_fc", 64, 0, nullptr, 0, bx, 8, 8);
+    }
     if (c.rc != PT_OK) return c.rc;
     {
       PtProfScope ps(e, s, PT_PROF_OTHER, 0, "mtl tag pick");
@@ -1526,8 +1828,7 @@ int pt_mtl_cells(pt_engine* e, int total, int32_t* d_cell_ids, float* d_cell_pro
     }
     c.gemm(cin, rows, 2 * D, "cell_in", D, 0, nullptr, 0, x, D);
     run_layer(c, "cell", 4, x, cache, kv, S, W, p0, t);
-    c.ln(x, rows, "norm", W.xb);
-    c.gemm(W.xb, rows, D, "cell_fc", ncell_p, 0, nullptr, 0, lg, ncell_p);
+    c.gemm_ln(x, rows, "norm", W.xb, "cell_fc", ncell_p, 0, nullptr, 0, lg, ncell_p);
     if (c.rc != PT_OK) return c.rc;
     {
       PtProfScope ps(e, s, PT_PROF_OTHER, 0, "mtl cell pick");

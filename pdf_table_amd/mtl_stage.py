@@ -109,16 +109,13 @@ class MtlTabNetConvertor:
     # -- test-time formatting of ONE table (the reference always runs a batch of one, processor_mtl_tabnet.py:84-89) -------------------
     @staticmethod
     def _kept(ids: Sequence[int], probs: Sequence[float], pad: int, eos: int):
-        keep_i, keep_p = [], []
-        for i, p in zip(ids, probs):
-            i = int(i)
-            if i == pad:
-                continue
-            if i == eos:
-                break
-            keep_i.append(i)
-            keep_p.append(float(p))
-        return keep_i, keep_p
+        """ids / probabilities up to the first <EOS>, <PAD> positions dropped (the reference's per-element loop, as two array operations)"""
+        ids, probs = np.asarray(ids), np.asarray(probs)
+        stop = np.flatnonzero(ids == eos)
+        if len(stop):
+            ids, probs = ids[:stop[0]], probs[:stop[0]]
+        keep = ids != pad
+        return ids[keep].tolist(), probs[keep].astype(np.float64).tolist()
 
     @staticmethod
     def _mean(v: List[float]) -> float:
@@ -153,10 +150,16 @@ class MtlTabNetConvertor:
         dec = dec[:len(parts), :]
         cell_strings, cell_scores = [], []
         if cell_ids is not None and len(cell_ids) > 1:      # size(0) == 1 is the no-cells placeholder AND a single real cell
-            for ci, cp in zip(cell_ids, cell_prob):
-                k, p = self._kept(ci, cp, self.padding_idx_cell, self.end_idx_cell)
-                cell_strings.append("".join(self.idx2char_cell[i] for i in k))
-                cell_scores.append(self._mean(p))
+            # _kept for every cell at once: positions before the row's first <EOS> that are not <PAD>; the score is the reference's left-to-right
+            # float64 sum of the kept probabilities (a cumulative sum adds them in that order, and + 0.0 for a dropped position is exact)
+            ci, cp = np.asarray(cell_ids), np.asarray(cell_prob, dtype=np.float64)
+            keep = (np.cumsum(ci == self.end_idx_cell, axis=1) == 0) & (ci != self.padding_idx_cell)
+            cnt = keep.sum(1)
+            tot = np.cumsum(np.where(keep, cp, 0.0), axis=1)[:, -1] if ci.shape[1] else np.zeros(len(ci))
+            table = self.idx2char_cell
+            for row, km, n_kept, t in zip(ci.tolist(), keep.tolist(), cnt.tolist(), tot.tolist()):
+                cell_strings.append("".join([table[i] for i, k in zip(row, km) if k]))
+                cell_scores.append(t / n_kept if n_kept > 0 else 0.0)
         return string, score, dec, cell_strings, cell_scores
 
     def output_format(self, outputs, out_bbox, out_cell, img_metas=None):
@@ -223,6 +226,8 @@ def merge_span_token(toks: List[str]) -> List[str]:
 
 
 def deal_eb_token(tok: str) -> str:
+    if "<eb" not in tok:
+        return tok
     for a, b in _EMPTY_BOX_TOKENS:
         tok = tok.replace(a, b)
     return tok
@@ -312,12 +317,17 @@ class MasterPostProcessor:
 
     def __call__(self, result: Dict, file_name=None) -> Dict:
         text, cells = result["text"], result.get("cell", None)
-        result["bbox"] = np.array([row for row in result["bbox"] if sum(row) > 1])
+        bb = np.asarray(result["bbox"])
+        # rows whose coordinates sum to more than 1 (the reference filters row by row with Python's sum: the same left-to-right float64 additions)
+        kept = bb[((bb[:, 0] + bb[:, 1]) + bb[:, 2]) + bb[:, 3] > 1] if bb.ndim == 2 and bb.shape[1] == 4 and len(bb) else \
+            np.array([row for row in result["bbox"] if sum(row) > 1])
+        result["bbox"] = kept if len(kept) else np.array([])      # no surviving box: the reference's empty 1-D array (box_transform then raises)
         html = insert_text_to_token(text_to_list(text), cells)
         html = deal_bb(deal_bb(html, "thead"), "tbody")
         result["pred_html"], result["html_context"] = html, html_post_process(html)
-        result["structure_str"] = self.get_table_structure(text)
-        result["structure_str_list"] = self.get_table_structure_list(text)
+        toks = self._structure_tokens(text)      # once for both forms (get_table_structure / get_table_structure_list)
+        result["structure_str"] = html_post_process(deal_bb(deal_bb("".join(toks), "thead"), "tbody"))
+        result["structure_str_list"] = ["<html>", "<body>", "<table>"] + toks + ["</table>", "</body>", "</html>"]
         result["new_bbox"] = self.box_transform(result["bbox"])
         return result
 
