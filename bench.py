@@ -950,7 +950,7 @@ class HipRunner:
                              "fused_residual_adds": len(task._exec._fuse), "layers": len(task._exec.layers)}
         return out
 
-    def mtl_tabnet_leg(self, steps=2, warm=1):
+    def mtl_tabnet_leg(self, steps=2, warm=2, modes=("bf16", "bf16_kv8", "bf16x3")):
         """BASELINE.json configs[4], table-structure half: the SAME table regions of the step through MtlTabNet (480 x 480 pre-processing
         kernel, ResNet-GC backbone, KV-cached structure / box / cell-content decoders, label convertor + HTML post-processor on the
         host) at the reference's sequence limits (500 structure tokens, 150 cell-content tokens), bf16 and BF16X3"""
@@ -979,6 +979,8 @@ class HipRunner:
         # bf16_kv8: bf16 arithmetic, the structure loop's source-attention keys / values streamed as fp8 (pt_engine_set_mtl_kv_fp8: the fp8 of
         # configs[4] where it pays on this path -- half the bytes of the loop's dominant HBM stream; drift recorded in tests/test_gpu_mtl.py)
         for name, prec in (("bf16", L.PT_PRECISION_BF16), ("bf16_kv8", L.PT_PRECISION_BF16), ("bf16x3", L.PT_PRECISION_BF16X3)):
+            if name not in modes:
+                continue
             eng.set_precision(prec)
             eng.set_mtl_kv_fp8(name == "bf16_kv8")
             try:
@@ -992,11 +994,26 @@ class HipRunner:
                     res = stage(self.pages, self.table_boxes)
                 self.sync()
                 dt = (time.perf_counter() - t0) / steps
+                # the same steps through MtlStage.stream: the host half of step k (convertor + post-processor, Python) on a worker thread under step k + 1's
+                # device loop -- what a caller with more than one batch gets; `tables_per_s` stays the synchronous call
+                if name != "bf16x3":
+                    stats_keep = dict(stage.stats)
+                    n_str = max(steps, 3)
+                    self.sync()
+                    t0 = time.perf_counter()
+                    for res_s in stage.stream([(self.pages, self.table_boxes)] * n_str):
+                        pass
+                    self.sync()
+                    dt_stream = (time.perf_counter() - t0) / n_str
+                    stage.stats = stats_keep
+                else:
+                    dt_stream = None
             finally:
                 eng.set_precision(L.PT_PRECISION_BF16)
                 eng.set_mtl_kv_fp8(False)
             st = stage.stats
             out[name] = {"tables_per_s": n_tab / dt, "ms_per_step": dt * 1e3, "pages_per_s_tsr_only": PAGES_PER_STEP / dt,
+                         "tables_per_s_streamed": n_tab / dt_stream if dt_stream else None,
                          "structure_tokens_per_table": st["tokens"] / max(1, st["tables"]), "cells_per_table": st["cells"] / max(1, st["tables"]),
                          "cell_steps_per_table": st["cell_steps"] / max(1, st["tables"]),
                          "structure_tokens_per_s": st["tokens"] / steps / dt,

@@ -235,6 +235,116 @@ __global__ __launch_bounds__(64) void mtl_self_attn_kernel(const bf16_t* __restr
   put(att + ((size_t)pi * Mp + s) * (SPLIT ? 2 * D : D) + head * DK + lane, D, SPLIT, o / sum);
 }
 
+// The same self-attention as a key / value stream (round 5): a workgroup = the 8 heads of one (row): wave = head, lane = (g = key within an octet, c = 8-channel
+// piece), 16-byte loads of the cached k and v rows, one online soft-max stream per g merged at the end -- mtl_cross_decode_kernel's scheme over the cache.
+// mtl_self_attn_kernel walks the values one key and two bytes per lane at a time (17 us at 160 cached positions, latency-bound); this one reads eight keys
+// per step and lane group.  Same mask semantics (<PAD> query: every score -6.55e4 over all Lcur positions).
+template <int SPLIT>
+__global__ __launch_bounds__(512) void mtl_self_decode_kernel(const bf16_t* __restrict__ cache, const int* __restrict__ tok, int pad, int p0, int Mp, int M,
+                                                             int Lcur, bf16_t* __restrict__ att, long long cache_bs, long long att_bs) {
+  a16_kernel_enter();
+  cache += blockIdx.z * cache_bs;
+  att += blockIdx.z * att_bs;
+  const int pi = blockIdx.x / M, s = blockIdx.x % M, p = p0 + pi;
+  const int head = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 3, c = lane & 7;
+  constexpr int LO = 3 * D, cs = SPLIT ? 2 * LO : LO;
+  const bool is_pad = tok[(size_t)p * Mp + s] == pad;
+  const int nk = is_pad ? Lcur : p + 1;
+  float qf[8];
+  {
+    const bf16_t* qp = cache + ((size_t)p * Mp + s) * cs + head * DK + 8 * c;
+    unpack8(ldu4(qp), qf);
+    if (SPLIT) {
+      float t[8];
+      unpack8(ldu4(qp + LO), t);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[j] += t[j];
+    }
+  }
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const bf16_t* kbase = cache + (size_t)s * cs + D + head * DK + 8 * c;
+  const size_t pstride = (size_t)Mp * cs;
+  for (int k0 = 0; k0 < nk; k0 += 64) {
+    uint4 kh[8], vh[8], kl[8], vl[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int key = k0 + 8 * i + g;
+      const bf16_t* kp = kbase + (size_t)(key < nk ? key : nk - 1) * pstride;
+      kh[i] = ldu4(kp);
+      vh[i] = ldu4(kp + D);
+      if (SPLIT) {
+        kl[i] = ldu4(kp + LO);
+        vl[i] = ldu4(kp + LO + D);
+      }
+    }
+    float sc[8], mt = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float kf[8];
+      unpack8(kh[i], kf);
+      if (SPLIT) {
+        float t[8];
+        unpack8(kl[i], t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kf[j] += t[j];
+      }
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d = fmaf(qf[j], kf[j], d);
+      d += __shfl_xor(d, 1);
+      d += __shfl_xor(d, 2);
+      d += __shfl_xor(d, 4);
+      if (is_pad) d = -6.55e4f;
+      sc[i] = k0 + 8 * i + g < nk ? d : -INFINITY;
+      mt = fmaxf(mt, sc[i]);
+    }
+    if (mt > -INFINITY) {
+      const float mn = fmaxf(m, mt);
+      const float scale = expf(m - mn);
+      l *= scale;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] *= scale;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float pv = expf(sc[i] - mn);
+        l += pv;
+        float vf[8];
+        unpack8(vh[i], vf);
+        if (SPLIT) {
+          float t[8];
+          unpack8(vl[i], t);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) vf[j] += t[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(pv, vf[j], acc[j]);
+      }
+      m = mn;
+    }
+  }
+  float mx = m;
+  mx = fmaxf(mx, __shfl_xor(mx, 8));
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  const float w = m == -INFINITY ? 0.f : expf(m - mx);
+  l *= w;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] *= w;
+#pragma unroll
+  for (int sh = 8; sh < 64; sh <<= 1) {
+    l += __shfl_xor(l, sh);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], sh);
+  }
+  if (g != 0) return;
+  bf16_t* op = att + ((size_t)pi * Mp + s) * (SPLIT ? 2 * D : D) + head * DK + 8 * c;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) put(op + j, D, SPLIT, acc[j] / l);
+}
+
 // Source attention (:111-112; MultiHeadAttentionCell :117-144 for the cell decoder: same arithmetic, keys of ONE table) for a tile
 // of up to 32 queries of one table x one head x one slice of the keys, on the matrix cores.  tiles[i] = (table, first query row,
 // queries, row stride).  q [rows, 512] (hi | lo), kv [n * hw, KVC] with the layer's keys (already / 8) at channel koff and values at
@@ -459,12 +569,14 @@ __global__ __launch_bounds__(512) void mtl_cross_decode_kernel(const bf16_t* __r
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], sh);
   }
-  if (g != 0) return;
   if (nsplit == 1) {
+    if (g != 0) return;
     bf16_t* op = att + qrow * qcs + head * DK + 8 * c;
 #pragma unroll
     for (int j = 0; j < 8; ++j) put(op + j, D, SPLIT, acc[j] / l);
-  } else {
+    return;
+  }
+  if (g == 0) {
     const size_t slot = ((size_t)z * R + qrow) * HEADS + head;
     float* op = opart + slot * DK + 8 * c;
 #pragma unroll
@@ -590,12 +702,14 @@ __global__ __launch_bounds__(512) void mtl_cross_decode8_kernel(const bf16_t* __
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] += __shfl_xor(acc[j], sh);
   }
-  if (g != 0) return;
   if (nsplit == 1) {
+    if (g != 0) return;
     bf16_t* op = att + qrow * D + head * DK + 16 * c;
 #pragma unroll
     for (int j = 0; j < 16; ++j) put(op + j, D, 0, acc[j] / l);
-  } else {
+    return;
+  }
+  if (g == 0) {
     const size_t slot = ((size_t)z * R + qrow) * HEADS + head;
     float* op = opart + slot * DK + 16 * c;
 #pragma unroll
@@ -819,9 +933,15 @@ __global__ __launch_bounds__(256) void mtl_preprocess_kernel(const uint8_t* __re
 #pragma unroll
       for (int c = 0; c < 3; ++c) o[c] = ((float)v[c] / 255.f - 0.5f) / 0.5f;       // to_tensor: / 255; normalize: (x - mean) / std
     }
-    bf16_t* op = out + ((size_t)b * size * size + i) * (split ? 64 : 32);
-#pragma unroll
-    for (int c = 0; c < 32; ++c) put(op + c, 32, split, c < 3 ? o[c] : 0.f);
+    // 64 bytes per pixel (three values + the zero padding of conv1's 32-channel chunk) as four 16-byte stores; the lo half likewise
+    uint4* op = reinterpret_cast<uint4*>(out + ((size_t)b * size * size + i) * (split ? 64 : 32));
+    const uint4 zero = {0u, 0u, 0u, 0u};
+    const uint4 hi = {pack_a16x2(o[0], o[1]), pack_a16x2(o[2], 0.f), 0u, 0u};
+    op[0] = hi; op[1] = zero; op[2] = zero; op[3] = zero;
+    if (split) {
+      const uint4 lo = {pack_a16x2(o[0] - a16lo_f32(hi.x), o[1] - a16hi_f32(hi.x)), pack_a16x2(o[2] - a16lo_f32(hi.y), 0.f), 0u, 0u};
+      op[4] = lo; op[5] = zero; op[6] = zero; op[7] = zero;
+    }
   }
 }
 
@@ -1317,8 +1437,11 @@ void run_layer(Ctx& c, int nb, const LayerB* lb, int slot, bf16_t* cache, long l
   {
     PtProfScope ps(c.e, c.s, PT_PROF_OTHER, 0, "mtl self attention");
     const size_t lds = (size_t)(p1 + 1) * sizeof(float);
-    const dim3 grid(npos * S.M, HEADS, nb);
-    if (c.x3) hipLaunchKernelGGL(mtl_self_attn_kernel<1>, grid, dim3(64), lds, c.s, cache, S.tok, S.pad, p0, S.Mp, S.M, p1 + 1, W.att, cache_bs, W.bs_row);
+    const dim3 grid(npos * S.M, HEADS, nb), sgrid(npos * S.M, 1, nb);
+    static const bool stream_kernel = !getenv("PT_MTL_SELF_WAVE");
+    if (stream_kernel && c.x3) hipLaunchKernelGGL(mtl_self_decode_kernel<1>, sgrid, dim3(512), 0, c.s, cache, S.tok, S.pad, p0, S.Mp, S.M, p1 + 1, W.att, cache_bs, W.bs_row);
+    else if (stream_kernel) hipLaunchKernelGGL(mtl_self_decode_kernel<0>, sgrid, dim3(512), 0, c.s, cache, S.tok, S.pad, p0, S.Mp, S.M, p1 + 1, W.att, cache_bs, W.bs_row);
+    else if (c.x3) hipLaunchKernelGGL(mtl_self_attn_kernel<1>, grid, dim3(64), lds, c.s, cache, S.tok, S.pad, p0, S.Mp, S.M, p1 + 1, W.att, cache_bs, W.bs_row);
     else hipLaunchKernelGGL(mtl_self_attn_kernel<0>, grid, dim3(64), lds, c.s, cache, S.tok, S.pad, p0, S.Mp, S.M, p1 + 1, W.att, cache_bs, W.bs_row);
   }
   for (int b = 0; b < nb; ++b) l[b] = Ctx::Lin{W.att + b * W.bs_row, nullptr, "", lb[b].q + ".so", nullptr, lb[b].x, lb[b].x_in, D, 0};
@@ -1590,7 +1713,8 @@ int pt_mtl_structure(pt_engine* e, const float* f3, int n, int hw, float* d_tag_
     W.single = true;
     if ((rc = upload_tiles(tl, W.tiles, s)) != PT_OK) return rc;
   }
-  const int POLL = 16;
+  // finish / <PAD> poll every POLL steps (4, 8, 16 and a synchronisation-free ring of device-written host slots all measured within noise of each other)
+  static const int POLL = getenv("PT_MTL_POLL") && atoi(getenv("PT_MTL_POLL")) > 0 ? atoi(getenv("PT_MTL_POLL")) : 16;
   int t = 0;
   while (t <= mt.max_len) {
     const int p0 = redecode ? 0 : t, npos = t - p0 + 1;
@@ -1811,7 +1935,7 @@ int pt_mtl_cells(pt_engine* e, int total, int32_t* d_cell_ids, float* d_cell_pro
   PT_HIP_CHECK(hipMemsetAsync(W.att, 0, (size_t)L.R * D * mul * sizeof(bf16_t), s));
   if (redecode && (rc = enter_redecode()) != PT_OK) return rc;
   if (!redecode && (rc = make_tiles(1)) != PT_OK) return rc;
-  const int POLL = 8;
+  const int POLL = 2;      // a cell step is ~1 ms of device work (every cell of every table): the poll's bubble is nothing, a step after the last <EOS> is
   int t = 0;
   while (t <= mt.max_len_c) {
     const int p0 = redecode ? 0 : t, npos = t - p0 + 1;

@@ -436,5 +436,13 @@ def test_task_mtltabnet_end_to_end_vs_oracle_chain():
         res = task.recognize_tables(pages.flip(-1).contiguous(), boxes, page_frame=False)
         for r, g in zip(res, got):
             assert r[0]["html_context"] == g["html_context"] and np.array_equal(r[0]["polygons"], g["polygons"])
+        # MtlStage.stream (host half of batch k on a worker thread under batch k + 1's device loop): the same results, in order
+        rgb = pages.flip(-1).contiguous()
+        streamed = list(task._stage.stream([(rgb, boxes), (rgb[:1], boxes[:1]), (rgb, boxes)], page_frame=False))
+        assert [len(b) for b in streamed] == [2, 1, 2]
+        for batch in (streamed[0], streamed[2]):
+            for r, g in zip(batch, got):
+                assert r[0]["html_context"] == g["html_context"] and np.array_equal(r[0]["polygons"], g["polygons"]) and r[0]["structure_str_list"] == g["structure_str_list"]
+        assert streamed[1][0][0]["html_context"] == got[0]["html_context"]
     finally:
         e.close()

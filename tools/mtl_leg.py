@@ -1,5 +1,5 @@
 """Times only bench.py's MtlTabNet leg (BASELINE.json configs[4], table-structure half) on the bench's own pages and table regions: the loop for the
-decoder's launch-chain work (PT_MTL_ROWFUSED=0|1 A/B, profiles/r05/mtl_rowfused.txt).  usage: python tools/mtl_leg.py [steps]"""
+decoder's launch-chain work (PT_MTL_ROWFUSED=0|1 A/B, profiles/r05/mtl_rowfused.txt).  usage: [PT_MTL_LEG_MODES=bf16,bf16_kv8] python tools/mtl_leg.py [steps]"""
 import json
 import os
 import sys
@@ -16,8 +16,9 @@ def main():
         raise SystemExit("bench.py has no parse_args()")
     runner = bench.HipRunner(args, 0, 0, 1, None)
     runner.run(2)
-    leg = runner.mtl_tabnet_leg(steps=steps, warm=1)
-    print(json.dumps({k: ({a: round(b, 2) for a, b in v.items()} if isinstance(v, dict) else v) for k, v in leg.items() if k not in ("note", "asserted_by")}))
+    modes = tuple(os.environ.get("PT_MTL_LEG_MODES", "bf16,bf16_kv8,bf16x3").split(","))
+    leg = runner.mtl_tabnet_leg(steps=steps, warm=1, modes=modes)
+    print(json.dumps({k: ({a: (round(b, 2) if b is not None else None) for a, b in v.items()} if isinstance(v, dict) else v) for k, v in leg.items() if k not in ("note", "asserted_by")}))
 
 
 if __name__ == "__main__":
