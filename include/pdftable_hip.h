@@ -559,7 +559,12 @@ void pt_tsr_mtl_resized_size(int crop_w, int crop_h, int size, int32_t* out_w, i
  * table share it: the loop ends when every cell emitted <EOS> in the same step, :451-453; 0 = no cells).
  * force_redecode = 1 runs the reference's own O(L^2) schedule (every step decodes the whole prefix again) instead of the cache:
  * the engine switches to it by itself when a <PAD> token is emitted (the reference's padding mask is not causal); tests use the
- * flag to show that both schedules agree. */
+ * flag to show that both schedules agree.
+ * TableMasterDecoder (master_decoder.py:532-645, model="TableMaster" of ocr_table_structure_task.py:71) is the same decoder without the
+ * cell-content layer: a blob that says "0 cell classes" (pdf_table_amd/weights.py::pack_mtl_decoder on a state_dict without cell tensors).
+ * pt_tsr_mtl_structure then reports zero cells for every table and pt_tsr_mtl_cells(total = 0) is a no-op.  Its greedy_forward (:599-608)
+ * never stops at <EOS> (the output is the last of max_seq_len + 1 passes; the convertor cuts at <EOS>): the KV-cached loop's stop at
+ * <EOS> is that output's prefix, and a table still running when a <PAD> appears runs on to the length limit as the reference's does. */
 int pt_tsr_mtl_decoder_config(pt_engine* e, int32_t out13[13]);
 int pt_tsr_mtl_structure(pt_engine* e, const float* d_f3, int n, int hw, float* d_tag_logits, float* d_boxes, int32_t* h_lens,
                          int32_t* h_cell_counts, int force_redecode, pt_stream stream);

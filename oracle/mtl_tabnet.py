@@ -16,7 +16,10 @@ What it restates (reference file:line):
                                (decode_test, greedy_forward, forward_test: structure tokens, cell boxes, cell content)
 Pinned by ``tests/golden/mtl_tabnet_backbone.npz`` / ``mtl_tabnet_decoder.npz`` (the reference's own ``TableResNetExtra`` and
 ``MtlTabNetDecoder`` modules on seeded weights, ``tests/golden/make_golden.py::gen_mtl_tabnet_*``).  Not restated: the label
-convertor / post-processor (master_convertor.py, master_post_processor.py).  No engine path exists for MtlTabNet yet.
+convertor / post-processor (master_convertor.py, master_post_processor.py).
+  TableMasterDecoder (test time) master_decoder.py:532-645: the same two shared layers + structure-token / box layers WITHOUT the cell-content
+                               decoder; greedy_forward :599-608 always runs max_seq_len + 1 steps (no <EOS> stop).  ``table_master_decode``,
+                               pinned by ``tests/golden/table_master_decoder.npz`` (the reference's own module, ``gen_table_master``).
 """
 from __future__ import annotations
 
@@ -191,6 +194,19 @@ def greedy_decode(sd, feature, cfg):
         if torch.equal(nxt, eos):
             return decode_step(sd, inp, feature, cfg, True)
         inp = torch.cat([inp, nxt], dim=1)
+
+
+def table_master_decode(sd, feature, cfg):
+    """TableMasterDecoder.forward_test / greedy_forward (master_decoder.py:599-632): max_len + 1 decode steps whatever is emitted (the convertor cuts
+    at the first <EOS>), every step over the whole prefix; -> (structure logits [b, max_len + 1, classes], boxes [b, max_len + 1, 4])."""
+    b = feature.shape[0]
+    inp = torch.full((b, 1), cfg["sos"], dtype=torch.long)
+    out = box = None
+    for _ in range(cfg["max_len"] + 1):
+        out, box, _ = decode_step(sd, inp, feature, cfg, False)
+        nxt = torch.max(F.softmax(out, dim=-1), dim=-1)[1][:, -1:]
+        inp = torch.cat([inp, nxt], dim=1)
+    return out, box
 
 
 def mtl_preprocess(img, size=480):

@@ -22,14 +22,15 @@
 // the same kernels over positions 0..t of every sequence at every step -- the reference's own schedule.  Trained checkpoints never
 // emit <PAD> (it is the loss's ignore_index); seeded random weights do, and tests/test_gpu_mtl.py covers both paths.
 //
-// Kernels: a Linear over <= 512 rows (every step of the KV-cached loops) is mtl_rowgemm_kernel + mtl_rowgemm_finish_kernel (split-K, operands
-// straight into the MFMA registers), over more rows (the key / value projection of the feature map, the re-decode mode) a 1x1 GEMM on
-// conv_igemm_kernel -- fp32 residual stream, hi/lo operands in BF16X3 like the rest of the engine; mtl_cross_decode_kernel (one query per table: the
-// structure loop's source attention as a pure key / value stream, fp32 on the VALU); mtl_ln_kernel (nn.LayerNorm, one wave per row); mtl_self_attn_kernel (one wave per (row, head): lane = key for the
-// scores, lane = channel for the weighted sum; fp32); mtl_cross_attn_kernel (the MFMA flash scheme of lore_processor.hip /
-// cvit_model.hip with d = 64: a wave = up to 32 queries of ONE table x one head, the keys optionally split over several waves
-// whose partial (max, sum, acc) triples mtl_cross_combine_kernel merges -- with one query per table and step, the split is what
-// fills the chip); pick kernels (arg-max, soft-max probability, <EOS> / <PAD> bookkeeping, next-token embedding).
+// Kernels: a Linear over <= 512 rows (every step of the KV-cached loops) is ONE launch of mtl_rowfused_kernel (LayerNorm in the prologue where the layer
+// has one, K split over the waves of a workgroup, operands straight into the MFMA registers), over more rows (the key / value projection of the feature
+// map, the re-decode mode) mtl_ln_kernel + a 1x1 GEMM on conv_igemm_kernel -- fp32 residual stream, hi/lo operands in BF16X3 like the rest of the engine;
+// mtl_self_decode_kernel / mtl_cross_decode_kernel (one query per sequence: self- and source attention of the KV-cached loops as pure key / value
+// streams, fp32 on the VALU); mtl_cross_attn_kernel (many queries per table -- re-decode mode, cell loop: the MFMA flash scheme of lore_processor.hip /
+// cvit_model.hip with d = 64: a wave = up to 32 queries of ONE table x one head, the keys optionally split over several waves whose partial (max, sum,
+// acc) triples mtl_cross_combine_kernel merges -- with one query per table and step, the split is what fills the chip); pick kernels (arg-max, soft-max
+// probability, <EOS> / <PAD> bookkeeping, next-token embedding).  The structure-token and the box layer of a KV-cached step share every launch
+// (run_layer, nb = 2: blockIdx.z picks the layer).
 #include <limits.h>
 #include <math.h>
 #include <stdlib.h>
@@ -165,80 +166,12 @@ __global__ __launch_bounds__(256) void mtl_fork_kernel(const float* __restrict__
   if (s < M && fin[s] >= p1) reinterpret_cast<float4*>(keep)[((size_t)(p0 + pi) * Mp + s) * (D / 4) + (i % (D / 4))] = v;
 }
 
-// Self-attention of DecoderLayer (:109-110, self_attention :57-72) for one (row, head): the query is position p of sequence s, keys
-// and values are positions 0..p of the same sequence in the cache [position][Mp][q 512 | k 512 | v 512] (k already / 8, hi/lo:
-// [hi 1536 | lo 1536]).  make_mask (:264-278): a query whose own token is <PAD> has every score replaced by -6.55e4, i.e. attends
-// uniformly to ALL Lcur positions of the current prefix.  Scores: lane = key (64-term fp32 dot products); weighted sum: lane = channel.
-template <int SPLIT>
-__global__ __launch_bounds__(64) void mtl_self_attn_kernel(const bf16_t* __restrict__ cache, const int* __restrict__ tok, int pad, int p0, int Mp, int M,
-                                                           int Lcur, bf16_t* __restrict__ att, long long cache_bs, long long att_bs) {
-  a16_kernel_enter();
-  extern __shared__ float sc[];
-  cache += blockIdx.z * cache_bs;      // blockIdx.z: the layer of a pair run in one launch (branch strides in elements)
-  att += blockIdx.z * att_bs;
-  const int pi = blockIdx.x / M, s = blockIdx.x % M, p = p0 + pi, head = blockIdx.y, lane = threadIdx.x;
-  constexpr int LO = 3 * D, cs = SPLIT ? 2 * LO : LO;
-  const bool is_pad = tok[(size_t)p * Mp + s] == pad;
-  const int nk = is_pad ? Lcur : p + 1;
-  float q[DK];
-  {
-    const bf16_t* qp = cache + ((size_t)p * Mp + s) * cs + head * DK;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const abf16x8 h = ld8(qp + 8 * k);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) q[8 * k + j] = (float)h[j];
-      if (SPLIT) {
-        const abf16x8 l = ld8(qp + LO + 8 * k);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) q[8 * k + j] += (float)l[j];
-      }
-    }
-  }
-  float mx = -INFINITY;
-  for (int j = lane; j < nk; j += 64) {
-    const bf16_t* kp = cache + ((size_t)j * Mp + s) * cs + D + head * DK;
-    float a = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const abf16x8 h = ld8(kp + 8 * k);
-      abf16x8 l;
-      if (SPLIT) l = ld8(kp + LO + 8 * k);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float kv = (float)h[i];
-        if (SPLIT) kv += (float)l[i];
-        a = fmaf(q[8 * k + i], kv, a);
-      }
-    }
-    if (is_pad) a = -6.55e4f;
-    sc[j] = a;
-    mx = fmaxf(mx, a);
-  }
-  mx = wave_max(mx);
-  float sum = 0.f;
-  for (int j = lane; j < nk; j += 64) {
-    const float e = expf(sc[j] - mx);
-    sc[j] = e;
-    sum += e;
-  }
-  sum = wave_sum(sum);
-  __syncthreads();
-  float o = 0.f;
-  const bf16_t* vp = cache + (size_t)s * cs + 2 * D + head * DK + lane;
-  for (int j = 0; j < nk; ++j) {
-    const bf16_t* r = vp + (size_t)j * Mp * cs;
-    float v = bf2f(r[0]);
-    if (SPLIT) v += bf2f(r[LO]);
-    o = fmaf(sc[j], v, o);
-  }
-  put(att + ((size_t)pi * Mp + s) * (SPLIT ? 2 * D : D) + head * DK + lane, D, SPLIT, o / sum);
-}
-
-// The same self-attention as a key / value stream (round 5): a workgroup = the 8 heads of one (row): wave = head, lane = (g = key within an octet, c = 8-channel
-// piece), 16-byte loads of the cached k and v rows, one online soft-max stream per g merged at the end -- mtl_cross_decode_kernel's scheme over the cache.
-// mtl_self_attn_kernel walks the values one key and two bytes per lane at a time (17 us at 160 cached positions, latency-bound); this one reads eight keys
-// per step and lane group.  Same mask semantics (<PAD> query: every score -6.55e4 over all Lcur positions).
+// Self-attention of DecoderLayer (:109-110, self_attention :57-72) as a key / value stream: the query is position p of sequence s, keys and values are
+// positions 0..p of the same sequence in the cache [position][Mp][q 512 | k 512 | v 512] (k already / 8, hi/lo: [hi 1536 | lo 1536]).  make_mask
+// (:264-278): a query whose own token is <PAD> has every score replaced by -6.55e4, i.e. attends uniformly to ALL Lcur positions of the current prefix.
+// A workgroup = the 8 heads of one row: wave = head, lane = (g = key within an octet, c = 8-channel piece), 16-byte loads of the cached k and v rows, one
+// online soft-max stream per g merged at the end -- mtl_cross_decode_kernel's scheme over the cache (10 us at 160 cached positions; a wave per (row, head)
+// walking the values one key and two bytes per lane at a time took 17).
 template <int SPLIT>
 __global__ __launch_bounds__(512) void mtl_self_decode_kernel(const bf16_t* __restrict__ cache, const int* __restrict__ tok, int pad, int p0, int Mp, int M,
                                                              int Lcur, bf16_t* __restrict__ att, long long cache_bs, long long att_bs) {
@@ -976,104 +909,17 @@ struct Carver {
 
 // ---- skinny GEMM of the decoding loops -------------------------------------------------------------------------------------------------
 // A decoding step multiplies M = 128 .. 256 rows (one per table / cell) by 512 x 512 .. 2048 x 512 weights: on conv_igemm_kernel that is 8 workgroups
-// walking 16 .. 192 K-chunks one global-load latency at a time (18 .. 55 us per Linear in bf16, 44 .. 146 us in BF16X3; four fifths of a step's GEMM time
-// is waiting).  mtl_rowgemm_kernel splits K instead: a workgroup = 128 rows x one 64-channel tile of the weights x ROWGEMM_CH K-chunks, every load of its
-// slice issued before the first MFMA (operands straight from global memory into the MFMA registers: no LDS, no barrier); fp32 partial tiles go to a
-// scratch buffer and mtl_rowgemm_finish_kernel adds them in a fixed order (deterministic), then bias, fp32 residual, ReLU and the store of Ctx::gemm's
-// contract (bf16 hi | lo rows or fp32 rows, n_valid).  Weights are read in conv_igemm's tiling ([N/64][chunks][64][32]; BF16X3: chunks = [hi | hi | lo]
-// against the activations' [hi | lo | hi]).  MFMA roles: A = weights (M = output channel), B = activations (N = row), so a lane owns four consecutive
-// channels of one row.
+// walking 16 .. 192 K-chunks one global-load latency at a time (18 .. 55 us per Linear in bf16), and the KV-cached loops are a chain of dependent
+// few-microsecond kernels, so the launch count IS the step time.  mtl_rowfused_kernel does a Linear in ONE launch: workgroup = 32 rows x one 64-channel
+// weight tile; its four waves split K (a wave = kc / 4 chunks, in groups of ROWGEMM_CH with the next group's loads in flight; operands straight from global
+// memory into the MFMA registers), their fp32 partial tiles meet in LDS and are added in wave order (deterministic), then bias, fp32 residual, ReLU and
+// the store of Ctx::gemm's contract (bf16 hi | lo rows or fp32 rows, n_valid).  Weights are read in conv_igemm's tiling ([N/64][chunks][64][32]; BF16X3:
+// chunks = [hi | hi | lo] against the activations' [hi | lo | hi]).  MFMA roles: A = weights (M = output channel), B = activations (N = row), so a lane
+// owns four consecutive channels of one row.  LNIN: the rows come as the fp32 residual stream and nn.LayerNorm(512) runs in the prologue -- a wave owns the
+// 128-channel slice its K-share needs, so the values are read once and normalised in registers (two-pass variance; row statistics cross the waves through
+// LDS); BF16X3 builds the hi and lo operands there.  Every weight tile of the layer recomputes the statistics of its 32 rows (64 KB from L2) -- cheaper than
+// the launch it replaces.  (Round 4's split-K pair of kernels + mtl_ln_kernel: 85 launches per step; this: 43; with the layer pairing of run_layer: 31.)
 constexpr int ROWGEMM_CH = 4;
-
-template <int SPLIT>
-__global__ __launch_bounds__(256) void mtl_rowgemm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, int cin, int N, long long rows,
-                                                         float* __restrict__ part) {
-  a16_kernel_enter();
-  const int nt = blockIdx.x, z = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int col = lane & 31, half = lane >> 5;
-  const long long row = (long long)blockIdx.z * 128 + wave * 32 + col;
-  if ((long long)blockIdx.z * 128 + wave * 32 >= rows) return;
-  const int kc1 = cin >> 5, kc = SPLIT ? 3 * kc1 : kc1;
-  const int c0 = z * ROWGEMM_CH;
-  const bf16_t* xr = x + row * (SPLIT ? 2 * cin : cin) + 8 * half;
-  const bf16_t* wt = w + ((size_t)nt * kc + c0) * (64 * 32) + col * 32 + 8 * half;
-  abf16x8 a[ROWGEMM_CH][2][2], b[ROWGEMM_CH][2];
-#pragma unroll
-  for (int i = 0; i < ROWGEMM_CH; ++i) {
-    const int c = c0 + i;
-    if (c < kc) {
-      // activation chunk of weight chunk c: hi chunks, then (BF16X3) the lo chunks against w_hi, then the hi chunks again against w_lo
-      const int xc = !SPLIT ? c : (c < kc1 ? c : (c < 2 * kc1 ? c - kc1 + kc1 : c - 2 * kc1));      // [hi | lo] rows: lo chunk j sits at chunk kc1 + j
-      const bf16_t* xp = xr + xc * 32;
-      const bf16_t* wp = wt + (size_t)i * (64 * 32);
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        b[i][st] = ld8(xp + 16 * st);
-        a[i][0][st] = ld8(wp + 16 * st);
-        a[i][1][st] = ld8(wp + 32 * 32 + 16 * st);
-      }
-    }
-  }
-  af32x16 acc[2];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-#pragma unroll
-  for (int i = 0; i < ROWGEMM_CH; ++i)
-    if (c0 + i < kc) {
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        acc[0] = mfma_32x32x16_a16(a[i][0][st], b[i][st], acc[0]);
-        acc[1] = mfma_32x32x16_a16(a[i][1][st], b[i][st], acc[1]);
-      }
-    }
-  float* pp = part + ((size_t)z * rows + row) * N + nt * 64 + 4 * half;
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float4 v = {acc[h][4 * g], acc[h][4 * g + 1], acc[h][4 * g + 2], acc[h][4 * g + 3]};
-      *reinterpret_cast<float4*>(pp + h * 32 + 8 * g) = v;
-    }
-}
-
-// thread = (row, four channels): sum of the K-slices in slice order + bias (+ fp32 residual) (ReLU) -> bf16 (hi | lo) or fp32 rows
-__global__ __launch_bounds__(256) void mtl_rowgemm_finish_kernel(const float* __restrict__ part, int nz, long long rows, int N, const float* __restrict__ bias,
-                                                                int relu, bf16_t* __restrict__ out, int out_cs, int split, float* __restrict__ out_f32,
-                                                                int f32_cs, const float* __restrict__ res_f32, int n_valid) {
-  a16_kernel_enter();
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int q4 = N >> 2;
-  if (i >= rows * q4) return;
-  const long long row = i / q4;
-  const int n = (int)(i % q4) * 4;
-  if (n_valid && n >= n_valid) return;
-  float4 v = *reinterpret_cast<const float4*>(part + row * N + n);
-  for (int z = 1; z < nz; ++z) {
-    const float4 t = *reinterpret_cast<const float4*>(part + ((size_t)z * rows + row) * N + n);
-    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-  }
-  const float4 bv = *reinterpret_cast<const float4*>(bias + n);
-  v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-  if (res_f32) {
-    const float4 r = *reinterpret_cast<const float4*>(res_f32 + row * f32_cs + n);
-    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-  }
-  if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-  if (out_f32) {
-    *reinterpret_cast<float4*>(out_f32 + row * f32_cs + n) = v;
-  } else {
-    bf16_t* op = out + row * (split ? 2 * out_cs : out_cs) + n;
-    put(op, out_cs, split, v.x); put(op + 1, out_cs, split, v.y); put(op + 2, out_cs, split, v.z); put(op + 3, out_cs, split, v.w);
-  }
-}
-
-// ---- the same Linear in ONE launch (round 5; the KV-cached loops are a chain of dependent few-microsecond kernels, so the launch count IS the step time).
-// Workgroup = 32 rows x one 64-channel weight tile; its four waves split K (a wave = kc / 4 chunks, in groups of ROWGEMM_CH with the next group's loads in
-// flight), their fp32 partial tiles meet in LDS and are added in wave order (deterministic; for K = 512 the very sums of mtl_rowgemm_finish_kernel), then
-// bias, fp32 residual, ReLU and Ctx::gemm's store contract.  LNIN: the rows come as the fp32 residual stream and nn.LayerNorm(512) runs in the prologue --
-// a wave owns the 128-channel slice its K-share needs, so the values are read once and normalised in registers (two-pass variance like mtl_ln_kernel; row
-// statistics cross the waves through LDS); BF16X3 builds the hi and lo operands there.  Every weight tile of the layer recomputes the statistics of its
-// 32 rows (64 KB from L2) -- cheaper than the launch it replaces.
 constexpr int RF_LD = 68;      // floats per row of the partial tiles in LDS
 
 // one Linear's operands; the kernel takes two sets and blockIdx.z picks (the structure-token and the box layer of a step are independent and equal in
@@ -1267,7 +1113,7 @@ __global__ __launch_bounds__(256) void mtl_rowfused_kernel(const RowB pa, const 
 
 // what survives between pt_tsr_mtl_structure and pt_tsr_mtl_cells
 struct MtlState {
-  DevBuf persist, work, cwork, part;      // part: K-slice partial tiles of mtl_rowgemm_kernel
+  DevBuf persist, work, cwork;
   int n = 0, hw = 0, Mp = 0, T = 0, x3 = 0;
   size_t o_kv8 = 0;             // fp8 copy of the keys / values (0 bytes when the option is off)
   size_t o_kv = 0, o_keep = 0, o_tok = 0, o_ids = 0, o_fin = 0;
@@ -1284,7 +1130,7 @@ struct Ctx {
   const PtModel* m;
   hipStream_t s;
   int x3, mul, rc;
-  DevBuf* part = nullptr;      // scratch of the skinny GEMM (null: every Linear on conv_igemm_kernel)
+  bool rowfused = true;        // false: every Linear on conv_igemm_kernel + mtl_ln_kernel
   const PtTensor* get(const std::string& n) {
     const PtTensor* t = m->find(n);
     if (!t && rc == PT_OK) {
@@ -1303,26 +1149,9 @@ struct Ctx {
     const PtTensor* w = get(q + (x3 ? ".w3" : ".w"));
     const PtTensor* b = get(q + ".b");
     if (rc != PT_OK) return;
-    static const int skinny_rows = getenv("PT_MTL_ROWGEMM_MAX") ? atoi(getenv("PT_MTL_ROWGEMM_MAX")) : 512;
     if (fusable(rows, cin, N, out_f32, f32_cs, nv, out_cs)) {
       Lin l{x, nullptr, "", q, out, out_f32, res_f32, f32_cs, nv};
       lin(1, &l, rows, cin, N, relu, out_cs, nullptr);
-      return;
-    }
-    if (part && rows <= skinny_rows && rows % 32 == 0 && N % 64 == 0 && cin % 32 == 0 && (!out_f32 || f32_cs % 4 == 0) && (nv == 0 || nv % 4 == 0)) {
-      const int kc = (x3 ? 3 : 1) * (cin / 32), nz = (kc + ROWGEMM_CH - 1) / ROWGEMM_CH;
-      const size_t need = (size_t)nz * rows * N * sizeof(float);
-      const int r = part->ensure(need > ((size_t)64 << 20) ? need : ((size_t)64 << 20));      // one allocation for the usual shapes (growing synchronises)
-      if (r != PT_OK) { rc = r; return; }
-      float* pb = reinterpret_cast<float*>(part->base);
-      const bf16_t* wp = reinterpret_cast<const bf16_t*>(w->d_ptr);
-      PtProfScope ps(e, s, PT_PROF_OTHER, 0, "mtl row gemm");
-      const dim3 grid(N / 64, nz, (unsigned)((rows + 127) / 128));
-      if (x3) hipLaunchKernelGGL(mtl_rowgemm_kernel<1>, grid, dim3(256), 0, s, x, wp, cin, N, rows, pb);
-      else hipLaunchKernelGGL(mtl_rowgemm_kernel<0>, grid, dim3(256), 0, s, x, wp, cin, N, rows, pb);
-      const long long thr = rows * (N / 4);
-      hipLaunchKernelGGL(mtl_rowgemm_finish_kernel, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, s, pb, nz, rows, N, reinterpret_cast<const float*>(b->d_ptr), relu,
-                         out, out_cs, x3, out_f32, f32_cs, res_f32, nv);
       return;
     }
     ConvDesc c;
@@ -1372,11 +1201,11 @@ struct Ctx {
     else if (lnin) hipLaunchKernelGGL((mtl_rowfused_kernel<0, 1>), grid, dim3(256), 0, s, rb[0], rb[1], cin, N, relu, out_cs);
     else hipLaunchKernelGGL((mtl_rowfused_kernel<0, 0>), grid, dim3(256), 0, s, rb[0], rb[1], cin, N, relu, out_cs);
   }
-  // one launch per Linear (mtl_rowfused_kernel) for the KV-cached loops' row counts; PT_MTL_ROWFUSED=0: the split-K pair of kernels + mtl_ln_kernel
+  // one launch per Linear (mtl_rowfused_kernel) for the KV-cached loops' row counts; PT_MTL_ROWFUSED=0: conv_igemm_kernel + mtl_ln_kernel
   bool fusable(long long rows, int cin, int N, const float* out_f32, int f32_cs, int nv, int out_cs) const {
     static const bool on = !(getenv("PT_MTL_ROWFUSED") && atoi(getenv("PT_MTL_ROWFUSED")) == 0);
     static const int skinny_rows = getenv("PT_MTL_ROWGEMM_MAX") ? atoi(getenv("PT_MTL_ROWGEMM_MAX")) : 512;
-    return on && part && rows <= skinny_rows && rows % 32 == 0 && N % 64 == 0 && ((x3 ? 3 : 1) * (cin / 32)) % 16 == 0 && cin % 32 == 0 &&
+    return on && rowfused && rows <= skinny_rows && rows % 32 == 0 && N % 64 == 0 && ((x3 ? 3 : 1) * (cin / 32)) % 16 == 0 && cin % 32 == 0 &&
            (out_f32 ? f32_cs % 4 == 0 : out_cs % 8 == 0) && (nv == 0 || nv % 4 == 0);
   }
   // y = LayerNorm(x; lnq) W^T + b: x fp32 [rows, 512] (the residual stream).  `xb`: where the normalised rows go when the two cannot share a launch
@@ -1436,13 +1265,9 @@ void run_layer(Ctx& c, int nb, const LayerB* lb, int slot, bf16_t* cache, long l
   if (c.rc != PT_OK) return;
   {
     PtProfScope ps(c.e, c.s, PT_PROF_OTHER, 0, "mtl self attention");
-    const size_t lds = (size_t)(p1 + 1) * sizeof(float);
-    const dim3 grid(npos * S.M, HEADS, nb), sgrid(npos * S.M, 1, nb);
-    static const bool stream_kernel = !getenv("PT_MTL_SELF_WAVE");
-    if (stream_kernel && c.x3) hipLaunchKernelGGL(mtl_self_decode_kernel<1>, sgrid, dim3(512), 0, c.s, cache, S.tok, S.pad, p0, S.Mp, S.M, p1 + 1, W.att, cache_bs, W.bs_row);
-    else if (stream_kernel) hipLaunchKernelGGL(mtl_self_decode_kernel<0>, sgrid, dim3(512), 0, c.s, cache, S.tok, S.pad, p0, S.Mp, S.M, p1 + 1, W.att, cache_bs, W.bs_row);
-    else if (c.x3) hipLaunchKernelGGL(mtl_self_attn_kernel<1>, grid, dim3(64), lds, c.s, cache, S.tok, S.pad, p0, S.Mp, S.M, p1 + 1, W.att, cache_bs, W.bs_row);
-    else hipLaunchKernelGGL(mtl_self_attn_kernel<0>, grid, dim3(64), lds, c.s, cache, S.tok, S.pad, p0, S.Mp, S.M, p1 + 1, W.att, cache_bs, W.bs_row);
+    const dim3 sgrid(npos * S.M, 1, nb);
+    if (c.x3) hipLaunchKernelGGL(mtl_self_decode_kernel<1>, sgrid, dim3(512), 0, c.s, cache, S.tok, S.pad, p0, S.Mp, S.M, p1 + 1, W.att, cache_bs, W.bs_row);
+    else hipLaunchKernelGGL(mtl_self_decode_kernel<0>, sgrid, dim3(512), 0, c.s, cache, S.tok, S.pad, p0, S.Mp, S.M, p1 + 1, W.att, cache_bs, W.bs_row);
   }
   for (int b = 0; b < nb; ++b) l[b] = Ctx::Lin{W.att + b * W.bs_row, nullptr, "", lb[b].q + ".so", nullptr, lb[b].x, lb[b].x_in, D, 0};
   c.lin(nb, l, rows, D, D, 0, 0, nullptr);
@@ -1521,8 +1346,9 @@ int read_meta(Ctx& c, Meta* mt) {
     }
     memcpy(mt, hw.data(), sizeof(Meta));
   }
-  PT_REQUIRE(mt->ncls > 0 && mt->ncell > 0 && mt->max_len > 0 && mt->max_len + 2 <= PE_ROWS && mt->max_len_c > 0 && mt->max_len_c + 2 <= PE_ROWS &&
-                 mt->ffp % 64 == 0, "MtlTabNet decoder blob: bad meta");
+  // ncell == 0: a TableMasterDecoder blob (no cell-content decoder: pt_tsr_mtl_structure reports zero cells)
+  PT_REQUIRE(mt->ncls > 0 && mt->ncell >= 0 && mt->max_len > 0 && mt->max_len + 2 <= PE_ROWS &&
+                 (mt->ncell == 0 || (mt->max_len_c > 0 && mt->max_len_c + 2 <= PE_ROWS)) && mt->ffp % 64 == 0, "MtlTabNet decoder blob: bad meta");
   return PT_OK;
 }
 
@@ -1551,7 +1377,6 @@ void pt_mtl_release(pt_engine* e) {
   st->persist.release();
   st->work.release();
   st->cwork.release();
-  st->part.release();
   if (st->h_poll) (void)hipHostFree(st->h_poll);
   delete st;
   e->mtl_state = nullptr;
@@ -1584,7 +1409,6 @@ int pt_mtl_structure(pt_engine* e, const float* f3, int n, int hw, float* d_tag_
   }
   if (!pt_model_format_ok(it->second, "PT_MODEL_MTL_DECODER")) return PT_ERR_STATE;
   Ctx c{e, &it->second, s, pt_split(e) ? 1 : 0, pt_split(e) ? 2 : 1, PT_OK};
-  if (!getenv("PT_MTL_NO_ROWGEMM")) c.part = &state_of(e)->part;
   Meta mt;
   int rc = read_meta(c, &mt);
   if (rc != PT_OK) return rc;
@@ -1769,7 +1593,11 @@ int pt_mtl_structure(pt_engine* e, const float* f3, int n, int hw, float* d_tag_
     if (c.rc != PT_OK) return c.rc;
     {
       PtProfScope ps(e, s, PT_PROF_OTHER, 0, "mtl tag pick");
-      hipLaunchKernelGGL(mtl_tag_pick_kernel, dim3((npos * n + 255) / 256), dim3(256), 0, s, lg, bx, p0, t, Mp, n, mt.ncls, ncls_p, mt.eos, mt.pad, mt.max_len, T,
+      // TableMasterDecoder.greedy_forward (:599-608) has no <EOS> stop: its output is the LAST of max_len + 1 passes over the whole prefix.  For the
+      // causal rows that equals stopping at <EOS>; once a <PAD> was emitted (re-decode mode: its row attends to ALL positions of the prefix, later ones
+      // included) it does not, so a table still running then goes on to the length limit like the reference's -- the convertor cuts at <EOS> either way
+      const int eos_eff = (mt.ncell == 0 && redecode) ? -1 : mt.eos;
+      hipLaunchKernelGGL(mtl_tag_pick_kernel, dim3((npos * n + 255) / 256), dim3(256), 0, s, lg, bx, p0, t, Mp, n, mt.ncls, ncls_p, eos_eff, mt.pad, mt.max_len, T,
                          tok, ids, fin, first_pad, d_tag_logits, d_boxes);
     }
     ++t;
@@ -1807,7 +1635,7 @@ int pt_mtl_structure(pt_engine* e, const float* f3, int n, int hw, float* d_tag_
     st->tab_first[b] = (int)st->cell_tab.size();
     for (int p = 0; p < len; ++p) {
       const int id = h_ids[(size_t)p * Mp + b];
-      if (id == mt.tag0 || id == mt.tag1) {
+      if (mt.ncell > 0 && (id == mt.tag0 || id == mt.tag1)) {
         st->cell_tab.push_back(b);
         st->cell_src.push_back(p * Mp + b);
       }
@@ -1837,7 +1665,6 @@ int pt_mtl_cells(pt_engine* e, int total, int32_t* d_cell_ids, float* d_cell_pro
   }
   if (!pt_model_format_ok(it->second, "PT_MODEL_MTL_DECODER")) return PT_ERR_STATE;
   Ctx c{e, &it->second, s, st->x3, st->x3 ? 2 : 1, PT_OK};
-  if (!getenv("PT_MTL_NO_ROWGEMM")) c.part = &st->part;
   PT_REQUIRE((pt_split(e) ? 1 : 0) == st->x3, "pt_tsr_mtl_cells: the precision changed since pt_tsr_mtl_structure");
   Meta mt;
   int rc = read_meta(c, &mt);

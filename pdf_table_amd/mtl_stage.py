@@ -80,6 +80,7 @@ class MtlTabNetConvertor:
         self.unknown_idx_cell, self.start_idx_cell, self.end_idx_cell, self.padding_idx_cell = sp
         self.char2idx = {c: i for i, c in enumerate(self.idx2char)}
         self.char2idx_cell = {c: i for i, c in enumerate(self.idx2char_cell)}
+        self.has_cell = True
 
     @staticmethod
     def _vocabulary(lines: Sequence[str], with_unknown: bool):
@@ -103,6 +104,8 @@ class MtlTabNetConvertor:
 
     def decoder_cfg(self) -> Dict:
         """the integers pack_mtl_decoder stores beside the weights (update_decoder_config, table_master.py:321-340)"""
+        if not self.has_cell:
+            return dict(N=3, sos=self.start_idx, eos=self.end_idx, pad=self.padding_idx, max_len=self.max_seq_len, idx_tag_cell=self.idx_tag_cell())
         return dict(N=3, sos=self.start_idx, eos=self.end_idx, pad=self.padding_idx, max_len=self.max_seq_len, sos_cell=self.start_idx_cell,
                     eos_cell=self.end_idx_cell, pad_cell=self.padding_idx_cell, max_len_cell=self.max_seq_len_cell, idx_tag_cell=self.idx_tag_cell())
 
@@ -175,6 +178,27 @@ class MtlTabNetConvertor:
             s, sc, bb, cs, css = self.format_ids(ti, tp, np.asarray(out_bbox[b]), ci, cp, img_metas[b])
             strings.append(s), scores.append(sc), bboxes.append(bb), cells.append(cs), cell_scores.append(css)
         return strings, scores, bboxes, cells, cell_scores
+
+
+class TableMasterConvertor(MtlTabNetConvertor):
+    """``TableMasterConvertor`` (table/mtl_tabnet/master_convertor.py:787-1070): the structure vocabulary only -- TableMaster has no cell-content decoder
+    (master_decoder.py:532-563), so ``output_format`` returns (strings, scores, boxes) and the post-processor gets no cell texts."""
+
+    def __init__(self, dict_file: Optional[Sequence[str]] = None, max_seq_len: int = 500, with_unknown: bool = True, start_end_same: bool = False, **kwargs):
+        super().__init__(dict_file=dict_file, cell_dict_file=[], max_seq_len=max_seq_len, max_seq_len_cell=0, with_unknown=with_unknown,
+                         start_end_same=start_end_same)
+        self.has_cell = False
+
+    def num_classes_cell(self) -> int:
+        return 0
+
+    def output_format(self, outputs, out_bbox, img_metas=None):
+        strings, scores, bboxes = [], [], []
+        for b in range(len(outputs)):
+            ti, tp = _softmax_max(np.asarray(outputs[b]))
+            s, sc, bb, _, _ = self.format_ids(ti, tp, np.asarray(out_bbox[b]), None, None, img_metas[b])
+            strings.append(s), scores.append(sc), bboxes.append(bb)
+        return strings, scores, bboxes
 
 
 # ----------------------------------------------------------------------------------------------------------------------------------
@@ -344,7 +368,9 @@ def mtl_result(convertor: MtlTabNetConvertor, post: MasterPostProcessor, tag_ids
                inputs=None) -> Dict:
     """decoder outputs of one table -> the reference's result dict (``MtlTabNet.simple_test`` -> ``MtlTabNetPostProcessor.__call__``)"""
     s, sc, bb, cs, _ = convertor.format_ids(tag_ids, tag_prob, boxes, cell_ids, cell_prob, img_meta)
-    pred = post(dict(text=s, score=sc, bbox=bb, cell=cs))
+    if not getattr(convertor, "has_cell", True):
+        cs = None                                    # TableMaster.simple_test (table_master.py:692-694): dict(text, score, bbox), no 'cell' entry
+    pred = post(dict(text=s, score=sc, bbox=bb, cell=cs) if cs is not None else dict(text=s, score=sc, bbox=bb))
     return {"polygons": two_point_to_four_point(pred["new_bbox"]), "structure_str_list": pred["structure_str_list"],
             "structure_str": pred["structure_str"], "html_context": pred["html_context"], "inputs": inputs,
             "text": s, "score": sc, "cell": cs}

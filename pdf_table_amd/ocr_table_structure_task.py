@@ -1,4 +1,4 @@
-"""``OcrTableStructureTask`` on the HIP engine -- drop-in for the reference's stage-4 plug-in (model="Lore" and model="MtlTabNet").
+"""``OcrTableStructureTask`` on the HIP engine -- drop-in for the reference's stage-4 plug-in (model="Lore", "MtlTabNet", "TableMaster").
 
 Reference: src/pdftable/model/ocr_pdf/ocr_table_structure_task.py:47-271.  Same constructor (``task, model, task_type``,
 ``assert`` on the model name :53-54, ``PubTabNet`` -> ``ptn`` :66-67), same result list: one dict per input image with
@@ -7,8 +7,9 @@ Reference: src/pdftable/model/ocr_pdf/ocr_table_structure_task.py:47-271.  Same 
 task types (wtw / ptn: DLA-34 + DCN detector, wireless: ResNet-18 detector).  ``model="MtlTabNet"`` (BASELINE.json configs[4], SURVEY.md
 section 8f-4: ResNet-GC backbone + three KV-cached decoders on the engine, label convertor + HTML post-processor on the host,
 ``pdf_table_amd/mtl_stage.py``) returns what ``MtlTabNetPostProcessor.__call__`` returns (model/mtl_tabnet/processor_mtl_tabnet.py:108-131):
-``polygons`` int32 [n, 8], ``structure_str_list``, ``structure_str``, ``html_context``, ``inputs``.  The other structure models the
-reference lists fail loudly.
+``polygons`` int32 [n, 8], ``structure_str_list``, ``structure_str``, ``html_context``, ``inputs``.  ``model="TableMaster"`` (table_master_config.py,
+``TableMasterDecoder`` master_decoder.py:532-645): the same backbone, layers and host half without the cell-content decoder (the blob says "0 cell
+classes"; ``TableMasterConvertor``).  The other structure models the reference lists fail loudly.
 
 Two ways in:
   * reference-shaped: ``task(image_or_list)`` -- path / PIL / ndarray, one table image each;
@@ -28,7 +29,7 @@ from . import lib as L
 from .base_infer_task import BaseInferTask
 from .engine import HipEngine
 from .ocr_detection_task import _read_image
-from .mtl_stage import MtlStage, MtlTabNetConvertor, MtlTabnetConfig
+from .mtl_stage import MtlStage, MtlTabNetConvertor, MtlTabnetConfig, TableMasterConvertor
 from .tsr_stage import LoreConfig, TsrStage
 from .weights import pack_lore_dla34, pack_lore_processor, pack_lore_wireless, pack_mtl_backbone, pack_mtl_decoder
 
@@ -41,11 +42,11 @@ class OcrTableStructureTask(BaseInferTask):
     def __init__(self, task="ocr_table_structure", model="CenterNet", engine: HipEngine = None, **kwargs):
         super().__init__(task=task, model=model, **kwargs)
         assert model in _MODELS
-        if model not in ("Lore", "MtlTabNet"):
-            raise RuntimeError(f"table-structure model '{model}' is not built on the HIP engine; 'Lore' and 'MtlTabNet' are "
+        if model not in ("Lore", "MtlTabNet", "TableMaster"):
+            raise RuntimeError(f"table-structure model '{model}' is not built on the HIP engine; 'Lore', 'MtlTabNet' and 'TableMaster' are "
                                "(SURVEY.md section 8a stage 4, 8f-4)")
         self._engine = engine
-        if model == "MtlTabNet":
+        if model in ("MtlTabNet", "TableMaster"):
             self._config = MtlTabnetConfig(model_name=model, task_type=self.task_type)
             # sequence limits are configuration (mtl_tabnet_config.py:12-18); tests shorten them
             self._config.max_seq_len = int(kwargs.get("max_seq_len", self._config.max_seq_len))
@@ -65,7 +66,7 @@ class OcrTableStructureTask(BaseInferTask):
         if self._engine is None:
             self._engine = self._new_engine()
         cfg = self._config
-        if model == "MtlTabNet":
+        if model in ("MtlTabNet", "TableMaster"):
             return self._construct_mtl()
         if self.synthetic_seed is not None:
             from .synth_weights import lore_dla34_state_dict, lore_processor_state_dict, lore_wireless_state_dict
@@ -103,12 +104,15 @@ class OcrTableStructureTask(BaseInferTask):
         table/lgpma/checkpoint.py:39-53).  The network was trained on cv2-read (BGR) images and this engine's pages are RGB: conv1's input
         channels are swapped once at load time, which is exact."""
         cfg = self._config
-        self._convertor = MtlTabNetConvertor(max_seq_len=cfg.max_seq_len, max_seq_len_cell=cfg.max_seq_len_cell)
+        master = self.model == "TableMaster"      # table_master_config.py: the same backbone and layers, TableMasterDecoder (no cell-content decoder)
+        self._convertor = TableMasterConvertor(max_seq_len=cfg.max_seq_len) if master else \
+            MtlTabNetConvertor(max_seq_len=cfg.max_seq_len, max_seq_len_cell=cfg.max_seq_len_cell)
         if self.synthetic_seed is not None:
-            from .synth_weights import mtl_tabnet_backbone_state_dict, mtl_tabnet_decoder_state_dict
+            from .synth_weights import mtl_tabnet_backbone_state_dict, mtl_tabnet_decoder_state_dict, table_master_decoder_state_dict
             bb = mtl_tabnet_backbone_state_dict(seed=int(self.synthetic_seed))
-            dec = mtl_tabnet_decoder_state_dict(seed=int(self.synthetic_seed) + 1, num_classes=self._convertor.num_classes(),
-                                                num_classes_cell=self._convertor.num_classes_cell())
+            dec = table_master_decoder_state_dict(seed=int(self.synthetic_seed) + 1, num_classes=self._convertor.num_classes()) if master else \
+                mtl_tabnet_decoder_state_dict(seed=int(self.synthetic_seed) + 1, num_classes=self._convertor.num_classes(),
+                                              num_classes_cell=self._convertor.num_classes_cell())
         else:
             mp = cfg.model_path
             f = mp if str(mp).endswith((".pth", ".bin")) else os.path.join(mp, "pytorch_model.bin")
@@ -122,9 +126,13 @@ class OcrTableStructureTask(BaseInferTask):
             dec = {k[8:]: v for k, v in sd.items() if k.startswith("decoder.")}
             if not bb or not dec:
                 raise RuntimeError(f"{f} holds no 'backbone.' / 'decoder.' tensors (an MtlTabNet checkpoint has both)")
-            if dec["cls_fc.weight"].shape[0] != self._convertor.num_classes() or dec["cell_fc.weight"].shape[0] != self._convertor.num_classes_cell():
+            if master == ("cell_fc.weight" in dec):
+                raise RuntimeError(f"{f} is {'an MtlTabNet' if master else 'a TableMaster'} checkpoint (cell-content decoder "
+                                   f"{'present' if master else 'absent'}); model='{self.model}' was asked for")
+            ncell = dec["cell_fc.weight"].shape[0] if not master else 0
+            if dec["cls_fc.weight"].shape[0] != self._convertor.num_classes() or ncell != self._convertor.num_classes_cell():
                 raise RuntimeError("the checkpoint's class counts do not match the PubTabNet vocabularies "
-                                   f"({dec['cls_fc.weight'].shape[0]} / {dec['cell_fc.weight'].shape[0]} vs "
+                                   f"({dec['cls_fc.weight'].shape[0]} / {ncell} vs "
                                    f"{self._convertor.num_classes()} / {self._convertor.num_classes_cell()})")
         bb = dict(bb)
         bb["conv1.weight"] = bb["conv1.weight"][:, [2, 1, 0]].contiguous()
@@ -133,7 +141,7 @@ class OcrTableStructureTask(BaseInferTask):
         self._model = self._predict
 
     def _build_processor(self):
-        if self.model == "MtlTabNet":
+        if self.model in ("MtlTabNet", "TableMaster"):
             # the reference-shaped door keeps the reference's IndexError for a table without a surviving box; the batched door does not
             self._stage = MtlStage(self._engine, self._convertor, size=self._config.size, micro_batch=int(os.environ.get("PT_MTL_MICROBATCH", "32")))
             return
@@ -144,7 +152,7 @@ class OcrTableStructureTask(BaseInferTask):
     def _predict(self, images: List[np.ndarray]) -> List[Dict]:
         """one table image each (RGB ndarray): the whole image is the crop"""
         out = []
-        if self.model == "MtlTabNet":
+        if self.model in ("MtlTabNet", "TableMaster"):
             self._stage.post.strict = True
             try:
                 for img in images:
@@ -168,7 +176,7 @@ class OcrTableStructureTask(BaseInferTask):
     def _preprocess(self, inputs, **kwargs):
         if not isinstance(inputs, list):
             inputs = [inputs]
-        if self.model == "MtlTabNet":
+        if self.model in ("MtlTabNet", "TableMaster"):
             # mmcv's imread hands an ndarray on AS IS and reads a file as BGR (table/lgpma/base_utils.py:689-739); the engine holds the
             # network with conv1's channels swapped (it eats RGB), so an ndarray is flipped here and a file is read as RGB
             return {"inputs": [{"image": np.ascontiguousarray(it[..., ::-1]) if isinstance(it, np.ndarray) else _read_image(it), "inputs": it}
@@ -184,7 +192,7 @@ class OcrTableStructureTask(BaseInferTask):
 
     def _postprocess(self, inputs, **kwargs) -> List[Dict]:
         out = []
-        if self.model == "MtlTabNet":
+        if self.model in ("MtlTabNet", "TableMaster"):
             for r in inputs["results"]:
                 d = {k: r["results"][k] for k in ("polygons", "structure_str_list", "structure_str", "html_context")}
                 d["inputs"] = r["inputs"]

@@ -345,6 +345,14 @@ def mtl_tabnet_decoder_state_dict(seed: int = 0, num_classes: int = 43, num_clas
     return g.sd
 
 
+def table_master_decoder_state_dict(seed: int = 0, num_classes: int = 43, table_signal=None):
+    """state_dict of ``TableMasterDecoder`` (table/mtl_tabnet/master_decoder.py:532-563, table_master_config.py:45-64): MtlTabNetDecoder's tensors without
+    the cell-content decoder (cell_layer, cell_fc, cell_input_fc, embedding_cell) -- the same seeded values as ``mtl_tabnet_decoder_state_dict``."""
+    ncc = 8 if table_signal is None else max([table_signal["sos_cell"], table_signal["eos_cell"]] + list(table_signal["cell"])) + 2
+    sd = mtl_tabnet_decoder_state_dict(seed=seed, num_classes=num_classes, num_classes_cell=ncc, table_signal=table_signal)
+    return {k: v for k, v in sd.items() if not k.startswith(("cell_", "embedding_cell."))}
+
+
 def mtl_table_signal_from(conv, rows_until: int = 150, cell_text: str = "Varible%"):
     """the ids ``mtl_tabnet_decoder_state_dict(table_signal=...)`` needs, taken from a label convertor (pdf_table_amd.mtl_stage.MtlTabNetConvertor):
     one table row is ``<tr> <td></td> <td colspan="2" > </td> <eb></eb> </tr>`` (two cells with content, one empty), rows repeat until the decoded

@@ -895,10 +895,17 @@ def pack_mtl_decoder(sd: Dict[str, torch.Tensor], cfg: Dict, x3: bool = True, fm
         n_shared += 1
     assert n_shared == 2, "the engine's MtlTabNet decoder is built for N = 3 (two shared layers)"
     src = {"l0": "layers.0", "l1": "layers.1", "cls": "cls_layer.0", "bbox": "bbox_layer.0", "cell": "cell_layer.0"}
+    # TableMasterDecoder (master_decoder.py:532-563) is this decoder without the cell-content layer: its slot of the key / value projection stays (zero
+    # weights: the tensor's channel layout is the engine's), its tensors are absent and the meta tensor says "0 cell classes"
+    has_cell = "cell_layer.0.self_attn.linears.0.weight" in sd
     kv_w, kv_b = [], []
     d_ff = sd["layers.0.feed_forward.w_1.weight"].shape[0]
     ffp = (d_ff + 63) // 64 * 64
     for q in MTL_LAYERS:
+        if q == "cell" and not has_cell:
+            kv_w += [torch.zeros(d, d), torch.zeros(d, d)]
+            kv_b += [torch.zeros(d), torch.zeros(d)]
+            continue
         p = src[q]
         (wq, bq), (wk, bk), (wv, bv), (wo, bo) = [W(f"{p}.self_attn.linears.{i}") for i in range(4)]
         lin(q + ".qkv", torch.cat([wq, wk / 8.0, wv], 0), torch.cat([bq, bk / 8.0, bv], 0))
@@ -914,17 +921,19 @@ def pack_mtl_decoder(sd: Dict[str, torch.Tensor], cfg: Dict, x3: bool = True, fm
             bl.add(f"{q}.ln{i}.g", sd[f"{p}.sublayer.{i}.norm.weight"].float().numpy(), "f32")
             bl.add(f"{q}.ln{i}.b", sd[f"{p}.sublayer.{i}.norm.bias"].float().numpy(), "f32")
     lin("kv", torch.cat(kv_w, 0), torch.cat(kv_b, 0))
-    ncls, ncell = sd["cls_fc.weight"].shape[0], sd["cell_fc.weight"].shape[0]
+    ncls, ncell = sd["cls_fc.weight"].shape[0], sd["cell_fc.weight"].shape[0] if has_cell else 0
     lin("cls_fc", *W("cls_fc"), n_to=(ncls + 63) // 64 * 64)
     lin("bbox_fc", *W("bbox_fc.0"), n_to=64)
-    lin("cell_fc", *W("cell_fc"), n_to=(ncell + 63) // 64 * 64)
-    lin("cell_in", *W("cell_input_fc"))
+    if has_cell:
+        lin("cell_fc", *W("cell_fc"), n_to=(ncell + 63) // 64 * 64)
+        lin("cell_in", *W("cell_input_fc"))
+        bl.add("emb_cell", (sd["embedding_cell.lut.weight"].float() * math.sqrt(d)).numpy(), "f32")
     bl.add("norm.g", sd["norm.weight"].float().numpy(), "f32")
     bl.add("norm.b", sd["norm.bias"].float().numpy(), "f32")
     bl.add("emb", (sd["embedding.lut.weight"].float() * math.sqrt(d)).numpy(), "f32")
-    bl.add("emb_cell", (sd["embedding_cell.lut.weight"].float() * math.sqrt(d)).numpy(), "f32")
     bl.add("pe", mtl_positional_table().numpy(), "f32")
-    tc = cfg["idx_tag_cell"]
-    bl.add("meta", np.array([ncls, ncell, cfg["sos"], cfg["eos"], cfg["pad"], cfg["max_len"], cfg["sos_cell"], cfg["eos_cell"],
-                             cfg["pad_cell"], cfg["max_len_cell"], tc[0], tc[1], ffp], dtype=np.int32), "i32")
+    tc = cfg.get("idx_tag_cell", [0, 0])
+    cc = [cfg.get(k, 0) if has_cell else 0 for k in ("sos_cell", "eos_cell", "pad_cell", "max_len_cell")]
+    bl.add("meta", np.array([ncls, ncell, cfg["sos"], cfg["eos"], cfg["pad"], cfg["max_len"], cc[0], cc[1], cc[2], cc[3], tc[0], tc[1], ffp],
+                            dtype=np.int32), "i32")
     return bl.tobytes()

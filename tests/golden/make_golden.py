@@ -812,6 +812,61 @@ def gen_mtl_tabnet_decoder():
     print("mtl_tabnet_decoder.npz", {k: v.shape for k, v in res.items()}, "tags", out.argmax(-1).tolist())
 
 
+def gen_table_master():
+    """The reference's own ``TableMasterDecoder`` (table/mtl_tabnet/master_decoder.py:532-645; configuration of table_master_config.py:45-64 with a
+    small sequence limit) on seeded weights (strict=True) and seeded feature maps, then ITS host half on those outputs: ``TableMasterConvertor.output_format``
+    (master_convertor.py:1000-1030) and ``MasterPostProcessor.__call__`` on ``dict(text, score, bbox)`` as ``TableMaster.simple_test`` builds it
+    (table_master.py:669-697) -- logits, boxes and the expected strings / HTML in one fixture."""
+    from pdf_table_amd.synth_weights import table_master_decoder_state_dict
+    stub_env()
+    mod = ref_import("pdftable.model.table.mtl_tabnet.master_decoder")
+    conv_mod = ref_import("pdftable.model.table.mtl_tabnet.master_convertor")
+    post_mod = ref_import("pdftable.model.table.mtl_tabnet.master_post_processor")
+    consts = ref_import("pdftable.model.table.mtl_tabnet.mtl_tabnet_constants")
+
+    class AttrDict(dict):
+        __getattr__ = dict.__getitem__
+
+    conv = conv_mod.TableMasterConvertor(dict_file=list(consts.STRUCTURE_ALPHABET_PUBTABNET), max_seq_len=500, start_end_same=False, with_unknown=True)
+    ncls, max_len = conv.num_classes(), 14
+    att = dict(headers=8, d_model=512, dropout=0.)
+    dec = AttrDict(self_attn=dict(att), src_attn=dict(att), feed_forward=dict(d_model=512, d_ff=2024, dropout=0.), size=512, dropout=0.)
+    torch.manual_seed(0)
+    model = mod.TableMasterDecoder(N=3, decoder=dec, d_model=512, num_classes=ncls, start_idx=conv.start_idx, padding_idx=conv.padding_idx,
+                                   max_seq_len=max_len).eval()
+    sd = table_master_decoder_state_dict(seed=47, num_classes=ncls)
+    full = dict(sd)
+    for k, v in model.state_dict().items():
+        if k.endswith(".pe"):
+            full[k] = v
+    model.load_state_dict(full, strict=True)
+    rng = np.random.default_rng(147)
+    fmap = rng.standard_normal((3, 512, 3, 8)).astype(np.float32)
+    with torch.no_grad():
+        feature = mod.PositionalEncoding(d_model=512).eval()(torch.from_numpy(fmap))
+        out, box = model(None, feature, None, None, train_mode=False)
+    metas = [{"scale_factor": (0.75, 0.75), "pad_shape": (480, 480, 3), "ori_shape": (400, 640, 3), "img_shape": (300, 480, 3)} for _ in range(3)]
+    # one sample per call, as the reference runs it (processor_mtl_tabnet.py:84-89; _get_pred_bbox_mask builds a ragged array for a mixed batch)
+    strings, scores, bboxes = [], [], []
+    for b in range(out.shape[0]):
+        s1, c1, b1 = conv.output_format(out[b:b + 1], box[b:b + 1], metas[b:b + 1])
+        strings.append(s1[0]), scores.append(c1[0]), bboxes.append(b1[0])
+    host = []
+    post = post_mod.MasterPostProcessor(output_dir=None)
+    for s_, sc, bb in zip(strings, scores, bboxes):
+        result = dict(text=s_, score=sc, bbox=bb)
+        try:
+            pred = post(result, file_name=None)
+            host.append({"text": s_, "score": float(sc), "bbox_decoded": np.asarray(bb).tolist(), "new_bbox": np.asarray(pred["new_bbox"]).tolist(),
+                         "html_context": pred["html_context"], "structure_str": pred["structure_str"], "structure_str_list": pred["structure_str_list"]})
+        except IndexError:
+            host.append({"raises": "IndexError", "text": s_, "score": float(sc), "bbox_decoded": np.asarray(bb).tolist()})
+    res = {"fmap": fmap, "seed": np.array(47), "max_len": np.array(max_len), "tag_logits": out.numpy(), "boxes": box.numpy(),
+           "ids": np.array([conv.start_idx, conv.end_idx, conv.padding_idx, ncls]), "host_json": np.array(json.dumps(host, ensure_ascii=False))}
+    np.savez_compressed(os.path.join(HERE, "table_master_decoder.npz"), **res)
+    print("table_master_decoder.npz", {k: getattr(v, "shape", None) for k, v in res.items()}, "tags", out.argmax(-1).tolist(), [h.get("raises", "ok") for h in host])
+
+
 def gen_mtl_alphabet():
     """The two vocabularies MtlTabNet's checkpoints are trained against (table/mtl_tabnet/mtl_tabnet_constants.py: 39 structure
     tokens, 277 cell-content tokens) as a DATA file of the package -- a checkpoint's class ids mean nothing without them -- plus
@@ -990,6 +1045,8 @@ if __name__ == "__main__":
         gen_mtl_tabnet_backbone()
     if "mtl_tabnet_decoder" in which or not sys.argv[1:]:
         gen_mtl_tabnet_decoder()
+    if "table_master" in which or not sys.argv[1:]:
+        gen_table_master()
     if "mtl_lengths" in which:   # minutes of CPU: only on request
         gen_mtl_lengths()
     if "e2e" in which:           # minutes of CPU: only on request

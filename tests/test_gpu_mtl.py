@@ -342,6 +342,97 @@ def test_fp8_keys_values_drift_is_recorded(dec_eng, golden_dir, case):
     assert d_bf16 <= 0.1 and d_orc <= 0.15
 
 
+@pytest.mark.parametrize("case", ["golden_ids", "eos_on_an_emitted_token"])
+def test_table_master_decoder_matches_the_reference_bf16x3(dec_eng, golden_dir, case):
+    """TableMasterDecoder (master_decoder.py:532-645; no cell-content decoder) on the engine against the REFERENCE module's own outputs
+    (tests/golden/table_master_decoder.npz): a blob without cell tensors, zero cells reported, every position up to a table's length within 1e-3 with
+    identical ids.  The fixture's tables emit <PAD> (re-decode mode); with <EOS> moved onto an emitted token a table that finished before the first <PAD>
+    stops there (causal rows: equal to the reference's last pass), the others run to the length limit like the reference's loop."""
+    from pdf_table_amd.synth_weights import table_master_decoder_state_dict
+    from pdf_table_amd.weights import pack_mtl_decoder
+    g = np.load(os.path.join(golden_dir, "table_master_decoder.npz"))
+    sos, eos, pad, ncls = (int(v) for v in g["ids"])
+    want = g["tag_logits"].argmax(-1)
+    if case == "eos_on_an_emitted_token":
+        eos = int(want[0, 1])                                   # table 0 emits it at position 1: before any <PAD>
+        assert (want == pad).any() and not (want[0, :2] == pad).any()
+    cfg = dict(N=3, sos=sos, eos=eos, pad=pad, max_len=int(g["max_len"]), idx_tag_cell=[0, 0])
+    sd = table_master_decoder_state_dict(seed=int(g["seed"]), num_classes=ncls)
+    dec_eng.load_weights(L.PT_MODEL_MTL_DECODER, pack_mtl_decoder(sd, cfg))
+    dec_eng.set_precision(L.PT_PRECISION_BF16X3)
+    try:
+        fmap = g["fmap"]
+        f3 = torch.from_numpy(fmap).permute(0, 2, 3, 1).reshape(fmap.shape[0], -1, 512).contiguous().cuda()
+        out = dec_eng.mtl_decode(f3)
+        torch.cuda.synchronize()
+    finally:
+        dec_eng.set_precision(L.PT_PRECISION_BF16)
+    assert out["cfg"]["num_classes_cell"] == 0 and not out["cell_counts"].any() and len(out["cell_ids"]) == 0
+    tag, box = out["tag_logits"].cpu().numpy(), out["boxes"].cpu().numpy()
+    T = cfg["max_len"] + 1
+    worst = [0.0, 0.0]
+    for b in range(fmap.shape[0]):
+        ln = int(out["lens"][b])
+        hit = np.flatnonzero(want[b] == eos)
+        first_pad = np.flatnonzero(want[b] == pad)
+        stops = len(hit) and (not len(first_pad) or hit[0] < first_pad[0]) and not (case == "eos_on_an_emitted_token" and b != 0 and
+                                                                                    (want[:, :hit[0] + 1] == pad).any())
+        if case == "golden_ids":
+            assert ln == T
+        elif b == 0:
+            assert ln == 2, ln                                   # <EOS> at position 1, no <PAD> anywhere before: the KV-cached loop's stop
+        assert ln == T or stops, (b, ln)
+        assert (tag[b, :ln].argmax(-1) == want[b, :ln]).all(), (case, b)
+        worst[0] = max(worst[0], np.abs(tag[b, :ln] - g["tag_logits"][b, :ln]).max() / np.abs(g["tag_logits"][b]).max())
+        worst[1] = max(worst[1], np.abs(box[b, :ln] - g["boxes"][b, :ln]).max())
+    print(f"TableMaster decoder [{case}] bf16x3 vs the reference module: tag logits {worst[0]:.2e} of scale, boxes {worst[1]:.2e}; lens {out['lens'].tolist()}")
+    assert worst[0] <= 1e-3 and worst[1] <= 1e-3
+
+
+def test_task_table_master_end_to_end_vs_oracle_chain():
+    """OcrTableStructureTask(model="TableMaster"): image -> engine (BF16X3) -> result dict == oracle pre-processing -> oracle backbone ->
+    oracle table_master_decode -> TableMasterConvertor + MasterPostProcessor on the oracle's logits (dict(text, score, bbox): no cell texts)."""
+    from pdf_table_amd.engine import HipEngine
+    from pdf_table_amd.mtl_stage import MasterPostProcessor, TableMasterConvertor
+    from pdf_table_amd.ocr_table_structure_task import OcrTableStructureTask
+    from pdf_table_amd.synth_weights import table_master_decoder_state_dict
+    e = HipEngine(0)
+    try:
+        e.set_precision(L.PT_PRECISION_BF16X3)
+        task = OcrTableStructureTask(model="TableMaster", synthetic_seed=65, engine=e, max_seq_len=16)      # seed: one table with cell tags, one without
+        conv = task._convertor
+        assert isinstance(conv, TableMasterConvertor) and conv.num_classes() == 43
+        imgs = _table_images()[:2]
+        bb_sd = mtl_tabnet_backbone_state_dict(seed=65)
+        dec_sd = table_master_decoder_state_dict(seed=66, num_classes=43)
+        cfg = conv.decoder_cfg()
+        n_ok = 0
+        for img in imgs:
+            x, meta = omt.mtl_preprocess(img, 480)
+            with torch.no_grad():
+                f3 = omt.backbone_forward_fp32(bb_sd, x[None])[2]
+                tag, box = omt.table_master_decode(dec_sd, omt.positional_encoding(f3), cfg)
+            s, sc, bbx = conv.output_format(tag.numpy(), box.numpy(), [meta])
+            try:
+                pred = MasterPostProcessor(strict=True)(dict(text=s[0], score=sc[0], bbox=bbx[0]))
+            except IndexError:
+                with pytest.raises(IndexError):
+                    task([img])
+                continue
+            got = task([img])[0]
+            assert set(got) == {"polygons", "structure_str_list", "structure_str", "html_context", "inputs"}
+            assert got["structure_str"] == pred["structure_str"] and got["structure_str_list"] == pred["structure_str_list"]
+            assert got["html_context"] == pred["html_context"]
+            wp = np.asarray(pred["new_bbox"])[:, [0, 1, 2, 1, 2, 3, 0, 3]]
+            assert got["polygons"].shape == wp.shape and np.abs(got["polygons"].astype(np.int64) - wp).max() <= 1
+            n_ok += 1
+            print(f"TableMaster task e2e: {len(s[0].split(','))} structure tokens, {len(wp)} boxes, html {len(pred['html_context'])} chars")
+        print(f"TableMaster task e2e: {n_ok} of {len(imgs)} tables with a surviving box")
+        assert 1 <= n_ok < len(imgs)          # both outcomes of the reference: a result dict, and its IndexError for a table without a surviving box
+    finally:
+        e.close()
+
+
 def test_decoder_needs_weights_and_structure_first():
     from pdf_table_amd.engine import HipEngine
     e = HipEngine(0)
