@@ -1018,6 +1018,29 @@ class HipRunner:
                          "cell_steps_per_table": st["cell_steps"] / max(1, st["tables"]),
                          "structure_tokens_per_s": st["tokens"] / steps / dt,
                          "boxes_per_table": float(sum(len(r["polygons"]) for pg in res for r in pg)) / max(1, n_tab)}
+        # model="TableMaster" (table_master_config.py: TableMasterDecoder = the same layers without the cell-content decoder): the same tables, the same
+        # hand-built structure chain, bf16 -- what the cell-content decoder and its formatting cost is the difference to `bf16` above
+        if "bf16" in modes:
+            from pdf_table_amd.mtl_stage import TableMasterConvertor
+            from pdf_table_amd.synth_weights import table_master_decoder_state_dict
+            tconv = TableMasterConvertor()
+            eng.load_weights(L.PT_MODEL_MTL_DECODER, pack_mtl_decoder(table_master_decoder_state_dict(
+                seed=43, num_classes=tconv.num_classes(), table_signal=mtl_table_signal_from(conv, rows_until=150)), tconv.decoder_cfg()))
+            stage = MtlStage(eng, tconv, micro_batch=int(os.environ.get("PT_MTL_MICROBATCH", "128")))
+            stage(self.pages, self.table_boxes)
+            self.sync()
+            stage.stats = {k: 0 for k in stage.stats}
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                res = stage(self.pages, self.table_boxes)
+            self.sync()
+            dt = (time.perf_counter() - t0) / steps
+            st = stage.stats
+            out["table_master_bf16"] = {"tables_per_s": n_tab / dt, "ms_per_step": dt * 1e3, "structure_tokens_per_table": st["tokens"] / max(1, st["tables"]),
+                                        "cells_per_table": st["cells"] / max(1, st["tables"]),
+                                        "boxes_per_table": float(sum(len(r["polygons"]) for pg in res for r in pg)) / max(1, n_tab),
+                                        "asserted_by": "tests/test_table_master.py, tests/test_gpu_mtl.py::test_table_master_* (the reference's own TableMasterDecoder / "
+                                                       "TableMasterConvertor outputs)"}
         return out
 
     def second_engine(self, precision):

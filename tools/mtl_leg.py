@@ -18,7 +18,7 @@ def main():
     runner.run(2)
     modes = tuple(os.environ.get("PT_MTL_LEG_MODES", "bf16,bf16_kv8,bf16x3").split(","))
     leg = runner.mtl_tabnet_leg(steps=steps, warm=1, modes=modes)
-    print(json.dumps({k: ({a: (round(b, 2) if b is not None else None) for a, b in v.items()} if isinstance(v, dict) else v) for k, v in leg.items() if k not in ("note", "asserted_by")}))
+    print(json.dumps({k: ({a: (round(b, 2) if isinstance(b, float) else b) for a, b in v.items() if a != "asserted_by"} if isinstance(v, dict) else v) for k, v in leg.items() if k not in ("note", "asserted_by")}))
 
 
 if __name__ == "__main__":
