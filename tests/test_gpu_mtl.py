@@ -166,6 +166,48 @@ def test_decoders_match_oracle_bf16x3(dec_eng, golden_dir, case):
     assert worst[0] <= 1e-3 and worst[1] <= 1e-3 and worst[2] <= 1e-3
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_a_micro_batch_beyond_512_tables_runs_the_general_kernels_and_agrees(dec_eng, golden_dir, mode):
+    """520 tables in ONE call: more rows per step than mtl_rowfused_kernel takes (512), so every Linear of the KV-cached loop runs on conv_igemm_kernel +
+    mtl_ln_kernel, the structure-token and box layers one after the other behind mtl_fork_kernel -- the path the re-decode mode and big batches use.  Each
+    table must come out as it does in a three-table call (one launch per Linear, paired layers): BF16X3 within 1e-3 with identical ids; bf16 ids on all
+    positions where the small call's top-2 margin exceeds the drift bound."""
+    from pdf_table_amd.synth_weights import mtl_tabnet_decoder_state_dict
+    from pdf_table_amd.weights import pack_mtl_decoder
+    cfg = dict(BASE_CFG, **DEC_CASES["early_eos"])
+    g, fmap = _decoder_inputs(golden_dir)
+    sd = mtl_tabnet_decoder_state_dict(seed=int(g["seed"]), num_classes=43, num_classes_cell=60)
+    dec_eng.load_weights(L.PT_MODEL_MTL_DECODER, pack_mtl_decoder(sd, cfg))
+    dec_eng.set_precision(L.PT_PRECISION_BF16X3 if mode == "bf16x3" else L.PT_PRECISION_BF16)
+    try:
+        f3 = torch.from_numpy(fmap).permute(0, 2, 3, 1).reshape(fmap.shape[0], -1, 512).contiguous().cuda()
+        small = dec_eng.mtl_decode(f3, want_cell_logits=True)
+        reps = 174                                              # 3 x 174 = 522 tables
+        big = dec_eng.mtl_decode(f3.repeat(reps, 1, 1), want_cell_logits=True)
+        torch.cuda.synchronize()
+    finally:
+        dec_eng.set_precision(L.PT_PRECISION_BF16)
+    n = fmap.shape[0]
+    assert len(big["lens"]) == n * reps
+    st, bt = small["tag_logits"].cpu().numpy(), big["tag_logits"].cpu().numpy()
+    sb, bb = small["boxes"].cpu().numpy(), big["boxes"].cpu().numpy()
+    worst = 0.0
+    for r in (0, 1, reps // 2, reps - 1):
+        for b in range(n):
+            k = r * n + b
+            ln = int(small["lens"][b])
+            scale = np.abs(st[b, :ln]).max()
+            if mode == "bf16x3":
+                assert int(big["lens"][k]) == ln and int(big["cell_counts"][k]) == int(small["cell_counts"][b])
+                assert (bt[k, :ln].argmax(-1) == st[b, :ln].argmax(-1)).all()
+                worst = max(worst, np.abs(bt[k, :ln] - st[b, :ln]).max() / scale, np.abs(bb[k, :ln] - sb[b, :ln]).max())
+            else:
+                # first position: same inputs for both paths (later ones may follow a different token once a near-tie flips)
+                worst = max(worst, np.abs(bt[k, 0] - st[b, 0]).max() / scale)
+    print(f"mtl decoders, 522 tables in one call vs three [{mode}]: worst difference {worst:.2e} of the logit scale")
+    assert worst <= (1e-3 if mode == "bf16x3" else 3e-2)
+
+
 def test_decoders_at_the_configured_lengths_bf16x3(dec_eng, golden_dir):
     """The sequence limits the reference configures (mtl_tabnet_config.py:12,17: max_seq_len = 500, max_seq_len_cell = 150) and bench.py's
     mtl_tabnet leg runs: two tables decode all 501 structure positions (the seeded weights never emit <EOS>), the cells of the tokens 13 / 3
