@@ -23,6 +23,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace PT_FMT_NS {
@@ -119,6 +121,15 @@ __device__ __forceinline__ f32x16 mma16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   else
     return mfma_32x32x16_a16(a, b, c);
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(f);
+  }
 }
 
 // XCD-aware bijective remap of the flat block id (8 XCDs; block b is observed to run on XCD b % 8)
@@ -1080,6 +1091,264 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_dma16_kernel(ConvK p, con
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution, LDS-DMA pipeline with 16-channel K-slices and a SOFTWARE-PIPELINED tap loop ("v4").
+// Same tiles, same K order inside the accumulators (bit-identical results) and the same two-buffer slice ring as conv3x3_dma16_kernel; what
+// changes is what the matrix pipe waits for.  Counters on v3 (profiles/r06/conv3x3_stalls.txt): 37-42 % MFMA-busy.  Its ISA shows why: the
+// per-tap mask test makes every tap a basic block, so a tap is {4 ds_read_b128, lgkmcnt(0), 4 MFMA, 2 ds_read_b128, lgkmcnt(0), 4 MFMA} --
+// two exposed LDS round trips per 8 MFMAs -- and the seven LDS-DMA instructions of the next slice are issued in one burst behind the barrier
+// while neither wave of the SIMD feeds the pipe.  Here:
+//   * the slice body is straight-line code (no tap masks: masked layers stay on v3): the fragments of tap t+1 are requested before the
+//     MFMAs of tap t are issued, so a read has eight MFMAs (256 cycles of the pipe) to come back;
+//   * the image's 16-byte halves are swizzled by the patch COLUMN instead of the linear pixel index: a fragment address is one of three
+//     per-lane bases (tap column s) plus an immediate (78 address VGPRs in v3, 4 here);
+//   * every wave issues exactly SLOTS DMA instructions per slice, one behind each of the first taps' MFMA groups (the input and weight
+//     instructions are one list; a slot past its end repeats the last instruction), out-of-image lanes read the zero page: no exec masks,
+//     no branches between the MFMAs.
+// ---------------------------------------------------------------------------------------------------
+template <int NT, int NWV>
+struct PipeCfg {
+  static constexpr int NTHR = 64 * NWV;
+  static constexpr int MT = 4;                                // MFMA row-tiles (patch rows) per wave
+  static constexpr int TH = (NT == 1 ? NWV : NWV / 2) * MT, TW = 32;
+  static constexpr int NW = 64 * NT;                          // output channels per workgroup
+  static constexpr int THIN = TH + 2, TWIN = TW + 2;
+  static constexpr int NPIX = THIN * TWIN;
+  static constexpr int IN_UNITS = NPIX * 2;
+  static constexpr int IN_INSTR = (IN_UNITS + 63) / 64;
+  static constexpr int W_INSTR = 9 * NW * 2 / 64;
+  static constexpr int T_INSTR = IN_INSTR + W_INSTR;
+  static constexpr int SLOTS = (T_INSTR + NWV - 1) / NWV;
+  static constexpr int IN_BYTES = IN_INSTR * 1024;            // (the last instruction's tail lanes land in padding)
+  static constexpr int W_BYTES = W_INSTR * 1024;
+  static constexpr int BUF_BYTES = IN_BYTES + W_BYTES;
+  static constexpr int PASS_ROWS = NT == 1 ? TH / 2 : TH;
+  static constexpr int STAGE_BYTES = PASS_ROWS * 32 * 64 * 4;
+  static constexpr int SMEM = 2 * BUF_BYTES > STAGE_BYTES ? 2 * BUF_BYTES : STAGE_BYTES;
+  static_assert(SLOTS <= 18, "at most two DMA instructions per tap");
+  static_assert(SMEM <= 163840, "LDS budget");
+};
+
+template <int NT, int NWV, bool SKEW>
+__global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, const bf16_t* __restrict__ zero_page) {
+  // (device pass only: the buffer-resource builtins do not exist for the host target, and a kernel template whose body fails to instantiate there
+  // silently loses its launch stub -- "undefined symbol ... conv3x3_pipe_kernel" at dlopen)
+#if defined(__HIP_DEVICE_COMPILE__)
+  a16_kernel_enter();
+  using C = PipeCfg<NT, NWV>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lx = lane & 31, qh = lane >> 5;
+  const int wm = NT == 1 ? wave : (wave >> 1);   // which group of 4 patch rows
+  const int wn = NT == 1 ? 0 : (wave & 1);       // which 64-channel half
+
+  int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int nb = L % p.n_tiles;                  // n_tiles counts NW-wide blocks here
+  L /= p.n_tiles;
+  const int txi = L % p.tiles_x;
+  L /= p.tiles_x;
+  const int tyi = L % p.tiles_y;
+  const int b = L / p.tiles_y;
+  const int oy0 = tyi * C::TH, ox0 = txi * C::TW;
+  const int in_cs = p.split ? 2 * p.Cin : p.Cin;
+  const int nch32 = p.split ? 3 * (p.Cin >> 5) : (p.Cin >> 5);
+  const int nslices = nch32 * 2;
+  const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * in_cs;
+  const bf16_t* wt = p.w + (size_t)(NT * nb) * nch32 * (9 * 64 * 32);
+
+  // DMA slot j of this wave = instruction k = wave + NWV * j of the list [IN_INSTR input | W_INSTR weight]; lane -> 16-byte unit k * 64 + lane.
+  // Input unit U: pixel U >> 1 of the patch, stored half U & 1 holds channel half (U & 1) ^ ((column >> 3) & 1).
+  // Weight unit U: row = U >> 1 = tap * NW + n, channel half (U & 1) ^ ((row >> 3) & 1); source = the v1 tiling [N/64][Cin/32][9][64][32].
+  // The requests are MUBUF (buffer_load_dwordx4 ... offen lds), not global_load_lds: a FLAT-encoded LDS load in flight makes hipcc's wait-count
+  // pass treat every later LDS dependency as out of order (s_waitcnt lgkmcnt(0) in front of each tap: the prefetched fragments of the NEXT tap
+  // were waited for too -- seen in the ISA of the first build of this kernel); a buffer load does not.  It also zero-fills by itself: a lane
+  // whose byte offset is beyond num_records writes zeros (halo pixels outside the image; no zero page).
+  constexpr int OOB = 0x7FFFF000;                 // == num_records of both descriptors
+  const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(in_b), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(wt), 0, OOB, 0x00020000);
+  int voff[C::SLOTS];                             // byte offset of the lane's unit at slice 0
+  bool is_in[C::SLOTS];
+  int dst[C::SLOTS];
+#pragma unroll
+  for (int j = 0; j < C::SLOTS; ++j) {
+    int k = wave + NWV * j;
+    if (k >= C::T_INSTR) k = C::T_INSTR - 1;
+    is_in[j] = k < C::IN_INSTR;                  // wave-uniform
+    dst[j] = k * 1024;
+    if (is_in[j]) {
+      const int U = k * 64 + lane;
+      const int pix = U >> 1;
+      const int iy = pix / C::TWIN, ix = pix - iy * C::TWIN;
+      const int q = (U & 1) ^ ((ix >> 3) & 1);
+      const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
+      const bool inside = U < C::IN_UNITS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+      voff[j] = inside ? (int)((((size_t)gy * p.W + gx) * in_cs + q * 8) * 2) : OOB;
+    } else {
+      const int U = (k - C::IN_INSTR) * 64 + lane;
+      const int row = U >> 1;
+      const int tap = row / C::NW, n = row - tap * C::NW;
+      const int hq = (U & 1) ^ ((row >> 3) & 1);
+      voff[j] = (int)((((size_t)(n >> 6) * nch32 * (9 * 64 * 32)) + (tap * 64 + (n & 63)) * 32 + hq * 8) * 2);
+    }
+  }
+  // element offsets of slice c: input channels (split mode: [x_hi | x_lo] against w_hi, then x_hi again against w_lo), weight chunk + half
+  auto in_off = [&](int slice) {
+    int c0 = slice << 4;
+    if (c0 >= in_cs) c0 -= in_cs;
+    if (c0 >= in_cs) c0 -= in_cs;
+    return c0;
+  };
+  auto w_off = [&](int slice) { return (slice >> 1) * (9 * 64 * 32) + (slice & 1) * 16; };
+  auto issue_one = [&](int j, int oi, int ow, int buf) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(is_in[j] ? r_in : r_w, (__attribute__((address_space(3))) void*)(smem + buf * C::BUF_BYTES + dst[j]), 16,
+                                             voff[j], (is_in[j] ? oi : ow) * 2, 0, 0);
+  };
+
+  f32x16 acc[C::MT][2];
+#pragma unroll
+  for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  // fragment addresses: A(tap (r, s), row-tile m) = a_lane[s] + ((m + r) * TWIN) * 32; B(tap, half) = b_lane + (tap * NW + half * 32) * 32
+  int a_lane[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+    a_lane[s] = ((C::MT * wm) * C::TWIN + lx + s) * 32 + ((qh ^ (((lx + s) >> 3) & 1)) << 4);
+  const int b_lane = C::IN_BYTES + (wn * 64 + lx) * 32 + ((qh ^ ((lx >> 3) & 1)) << 4);
+
+  bf16x8 fa[2][C::MT], fb[2][2];
+  auto load_frags = [&](const char* sb, int tap, int slot) {
+    const int r = tap / 3, s = tap - 3 * r;
+    fb[slot][0] = *reinterpret_cast<const bf16x8*>(sb + b_lane + (tap * C::NW) * 32);
+    fb[slot][1] = *reinterpret_cast<const bf16x8*>(sb + b_lane + (tap * C::NW + 32) * 32);
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m)
+      fa[slot][m] = *reinterpret_cast<const bf16x8*>(sb + a_lane[s] + ((m + r) * C::TWIN) * 32);
+  };
+  auto mma_tap = [&](int slot) {
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m) {
+      acc[m][0] = mfma_32x32x16_a16(fa[slot][m], fb[slot][0], acc[m][0]);
+      acc[m][1] = mfma_32x32x16_a16(fa[slot][m], fb[slot][1], acc[m][1]);
+    }
+  };
+
+#pragma unroll
+  for (int j = 0; j < C::SLOTS; ++j) issue_one(j, in_off(0), w_off(0), 0);
+  // one slice: wait for its data, then nine taps with the next tap's fragments and (MORE) the next slice's DMA requests between the MFMA groups
+  auto slice_body = [&](int c, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const char* sb = smem + (c & 1) * C::BUF_BYTES;
+    const int oi = in_off(c + 1), ow = w_off(c + 1), nbuf = (c + 1) & 1;
+    load_frags(sb, 0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap < 8) load_frags(sb, tap + 1, (tap + 1) & 1);
+      mma_tap(tap & 1);
+      if constexpr (MORE) {
+#pragma unroll
+        for (int j = tap; j < C::SLOTS; j += 9) issue_one(j, oi, ow, nbuf);
+      }
+    }
+    // pin the order the source asks for (left alone, the scheduler sinks every ds_read to just above its first use and waits lgkmcnt(0) there):
+    // 6 reads of tap 0, then per tap {6 reads of the next tap, 8 MFMAs, this tap's DMA requests}
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 + C::MT, 0);
+    static_for<9>([&](auto tap_c) {
+      constexpr int tap = decltype(tap_c)::value;
+      if constexpr (tap < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2 + C::MT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * C::MT, 0);
+      if constexpr (MORE) {
+        constexpr int nd = (C::SLOTS > tap ? 1 : 0) + (C::SLOTS > tap + 9 ? 1 : 0);
+        if constexpr (nd > 0) __builtin_amdgcn_sched_group_barrier(0x020, nd, 0);
+      }
+    });
+  };
+  // SKEW: the hand-over barrier sits in front of tap 8 instead of behind it.  Tap 8's fragments are in registers by then (so every read of
+  // slice c is complete: the barrier still frees its buffer), the next slice's own DMA pieces were requested during taps 0 .. 3, and the first
+  // fragments of slice c + 1 are requested right behind the barrier -- barrier skew and that first LDS round trip run under tap 8's eight MFMAs
+  // instead of an idle pipe.  Fragment slot of (slice parity P, tap t) = (P + t) & 1, so two slices make one loop iteration.
+  auto skew_slice = [&](int c, auto par_tag, auto more_tag) {
+    constexpr int P = decltype(par_tag)::value;
+    constexpr bool MORE = decltype(more_tag)::value;
+    const char* sb = smem + P * C::BUF_BYTES;
+    const int oi = in_off(c + 1), ow = w_off(c + 1);
+    static_for<8>([&](auto tap_c) {
+      constexpr int tap = decltype(tap_c)::value;
+      load_frags(sb, tap + 1, (P + tap + 1) & 1);
+      mma_tap((P + tap) & 1);
+      if constexpr (MORE) {
+#pragma unroll
+        for (int j = 2 * tap; j < 2 * tap + 2 && j < C::SLOTS; ++j) issue_one(j, oi, ow, P ^ 1);
+        static_assert(C::SLOTS <= 16, "two DMA requests per tap over taps 0 .. 7");
+      }
+    });
+    static_for<8>([&](auto tap_c) {
+      constexpr int tap = decltype(tap_c)::value;
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + C::MT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * C::MT, 0);
+      if constexpr (MORE) {
+        constexpr int nd = (C::SLOTS > 2 * tap ? 1 : 0) + (C::SLOTS > 2 * tap + 1 ? 1 : 0);
+        if constexpr (nd > 0) __builtin_amdgcn_sched_group_barrier(0x020, nd, 0);
+      }
+    });
+    if constexpr (MORE) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      load_frags(smem + (P ^ 1) * C::BUF_BYTES, 0, (P + 1) & 1);
+    }
+    mma_tap((P + 8) & 1);
+    if constexpr (MORE) __builtin_amdgcn_sched_group_barrier(0x100, 2 + C::MT, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * C::MT, 0);
+  };
+  if constexpr (SKEW) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    load_frags(smem, 0, 0);
+    for (int c = 0; c + 2 < nslices; c += 2) {
+      skew_slice(c, std::integral_constant<int, 0>{}, std::true_type{});
+      skew_slice(c + 1, std::integral_constant<int, 1>{}, std::true_type{});
+    }
+    skew_slice(nslices - 2, std::integral_constant<int, 0>{}, std::true_type{});
+    skew_slice(nslices - 1, std::integral_constant<int, 1>{}, std::false_type{});
+  } else {
+    for (int c = 0; c + 1 < nslices; ++c) slice_body(c, std::true_type{});
+    slice_body(nslices - 1, std::false_type{});
+  }
+
+  // epilogue in two passes of PASS_ROWS x 32 pixels x 64 channels (fp32 in LDS)
+  float* stage = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+    const bool mine = NT == 1 ? ((wave / (NWV / 2)) == pass) : (wn == pass);
+    if (mine) {
+      const int rbase = NT == 1 ? C::MT * (wave % (NWV / 2)) : C::MT * wm;   // local patch row inside this pass' rows
+#pragma unroll
+      for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int tx = (r & 3) + 8 * (r >> 2) + 4 * qh;
+            stage[((rbase + m) * 32 + tx) * 64 + n * 32 + lx] = acc[m][n][r];
+          }
+    }
+    __syncthreads();
+    if (NT == 1)
+      epilogue_store<C::PASS_ROWS, 32, C::NTHR, false>(p, stage, tid, b, oy0 + C::PASS_ROWS * pass, ox0, nb * 64);
+    else
+      epilogue_store<C::PASS_ROWS, 32, C::NTHR, false>(p, stage, tid, b, oy0, ox0, (nb * 2 + pass) * 64);
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 3x3 stride-1 convolution 64 -> 64, weight-stationary and persistent ("ws64", bf16 mode).
 // The five 64 -> 64 @240^2 layers of DB-ResNet18 (layer1 + the fused out2; db_net/dbnet.py:102-140, 615-638) are the detector's
 // largest item and the furthest from the matrix roofline (0.54 PF on the v3 4-wave tile): K is only 576, so a 16x32 tile
@@ -1984,6 +2253,32 @@ static int launch_dma16(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   return PT_OK;
 }
 
+// v4: the software-pipelined tap loop (conv3x3_pipe_kernel); same tiling arithmetic and labels as launch_dma16
+template <int NT, int NWV, bool SKEW>
+static int launch_pipe(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
+  using C = PipeCfg<NT, NWV>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pipe_kernel<NT, NWV, SKEW>), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
+    attr_done = true;
+  }
+  if (!e->zero_page) {
+    PT_HIP_CHECK(hipMalloc(&e->zero_page, 8192));
+    PT_HIP_CHECK(hipMemset(e->zero_page, 0, 8192));
+  }
+  k.tiles_x = (k.Wo + C::TW - 1) / C::TW;
+  k.tiles_y = (k.Ho + C::TH - 1) / C::TH;
+  k.n_tiles = k.N / C::NW;
+  const long long nblk = (long long)k.B * k.tiles_x * k.tiles_y * k.n_tiles;
+  PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range (%lld blocks)", nblk);
+  char label[48];
+  snprintf(label, sizeof(label), "conv3x3 v4%s %d->%d @%dx%d%s", NWV == 4 ? "h" : "", k.Cin, k.N, k.Ho, k.Wo, k.split ? " x3" : "");
+  PtProfScope prof(e, s, PT_PROF_CONV3X3, flop, label);
+  hipLaunchKernelGGL((conv3x3_pipe_kernel<NT, NWV, SKEW>), dim3((unsigned)nblk), dim3(C::NTHR), C::SMEM, s, k, reinterpret_cast<const bf16_t*>(e->zero_page));
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
 // weight-stationary persistent kernel for plain 64 -> 64 layers (bf16 mode): one workgroup per CU walks total_tiles / grid tiles
 static int launch_ws64(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   using C = Ws64Cfg;
@@ -2141,6 +2436,17 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
       const bool nt2 = d.N % 128 == 0;
       const long long full = (long long)k.B * ((k.Ho + (nt2 ? 15 : 31)) / (nt2 ? 16 : 32)) * ((k.Wo + 31) / 32) * (d.N / (nt2 ? 128 : 64));
       use_half = d.Cin <= 128 || (full < 2ll * e->num_cu && full % e->num_cu != 0);
+    }
+    // v4 (software-pipelined tap loop) for the unmasked layers; PT_CONV_PIPE=0: v3 everywhere (A/B switch, read per call)
+    const char* pv = getenv("PT_CONV_PIPE");
+    const int pipe = masked ? 0 : (pv ? atoi(pv) : 2);      // 1: barrier behind tap 8, 2: in front of it (SKEW)
+    if (pick == 3 && pipe == 1) {
+      if (use_half) return launch_pipe<1, 4, false>(e, k, s, flop);
+      return d.N % 128 == 0 ? launch_pipe<2, 8, false>(e, k, s, flop) : launch_pipe<1, 8, false>(e, k, s, flop);
+    }
+    if (pick == 3 && pipe >= 2) {
+      if (use_half) return launch_pipe<1, 4, true>(e, k, s, flop);
+      return d.N % 128 == 0 ? launch_pipe<2, 8, true>(e, k, s, flop) : launch_pipe<1, 8, true>(e, k, s, flop);
     }
     if (pick == 3 && use_half) return launch_dma16<1, 4>(e, k, s, flop);
     if (pick == 3) return d.N % 128 == 0 ? launch_dma16<2, 8>(e, k, s, flop) : launch_dma16<1, 8>(e, k, s, flop);

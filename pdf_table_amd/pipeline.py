@@ -33,6 +33,7 @@ from .layout_stage import layout_tables
 from .ocr_layout_task import OcrLayoutTask
 from .ocr_recognition_task import OcrRecognitionTask
 from .rec_stage import order_points
+from .trace_ranges import stage_range
 from .ocr_table_structure_task import OcrTableStructureTask
 
 __all__ = ["OcrTablePipeline", "PageResult"]
@@ -188,7 +189,8 @@ class OcrTablePipeline:
                 prob, bitmap, ev = stage.forward(pages_t)
                 return [sort_boxes_reading_order(b) for b in stage.boxes(prob, bitmap, shape[:2], ev)]
 
-            boxes = detect(batch)
+            with stage_range("text_detection"):
+                boxes = detect(batch)
             ori = None
             rotated = [False] * len(idxs)
             if self.orientation_task is not None:
@@ -229,13 +231,15 @@ class OcrTablePipeline:
                 return self._finish_rec(rec_stage, batch, boxes, rec_state, side)
 
             rec_state = None
-            try:
-                rec_state = recognise()
-            except Exception as e:                 # noqa: BLE001
-                logger.warning("text recognition could not be queued: %r", e)
-            texts = finish_rec() if side is None else None
+            with stage_range("text_recognition"):
+                try:
+                    rec_state = recognise()
+                except Exception as e:                 # noqa: BLE001
+                    logger.warning("text recognition could not be queued: %r", e)
+                texts = finish_rec() if side is None else None
             c = time.time()
-            lay = self.layout_task.detect_pages(batch) if self.layout_task is not None else None
+            with stage_range("layout"):
+                lay = self.layout_task.detect_pages(batch) if self.layout_task is not None else None
             tsr = None
             if self.table_structure_task is not None:
                 if table_boxes is not None:
@@ -246,9 +250,11 @@ class OcrTablePipeline:
                             tb[k] = np.stack([shape[1] - x2, shape[0] - y2, shape[1] - x1, shape[0] - y1], 1)
                 else:
                     tb = self._layout_table_boxes(lay)
-                tsr = self.table_structure_task.recognize_tables(batch, tb)
+                with stage_range("table_structure"):
+                    tsr = self.table_structure_task.recognize_tables(batch, tb)
             if side is not None:
-                texts = finish_rec()
+                with stage_range("text_recognition"):
+                    texts = finish_rec()
             if tsr is not None and self.table_html:
                 self._attach_html(tsr, tb, boxes, texts)
             d_ = time.time()
@@ -374,8 +380,10 @@ class OcrTablePipeline:
                         st["lay"] = lay_stage.forward(pages_t)
                     pages_t.record_stream(aux)
                 else:       # one compute stream: per-kernel durations are those of the kernel alone (what bench.py's roofline divides by)
-                    st["lay"] = lay_stage.forward(pages_t)
-            st["det"] = det.forward(pages_t, slot=k & 1, early_copy=True)
+                    with stage_range("layout"):
+                        st["lay"] = lay_stage.forward(pages_t)
+            with stage_range("text_detection"):
+                st["det"] = det.forward(pages_t, slot=k & 1, early_copy=True)
             return st
 
         def host_halves(st):
@@ -391,7 +399,7 @@ class OcrTablePipeline:
         def queue_second(st):
             """recognition + table detector / decode on the boxes and regions host_halves() produced one step ago"""
             t0 = time.perf_counter()
-            with torch.cuda.stream(rec_s):
+            with torch.cuda.stream(rec_s), stage_range("text_recognition"):
                 rec_s.wait_event(st["uploaded"])
                 try:
                     st["rec"] = rec_stage.start(st["pages"], st["boxes"])
@@ -407,7 +415,8 @@ class OcrTablePipeline:
                 tables, metas = tsr_stage.tables(st["shape"], tb)
                 offs = np.stack([tables["x0"], tables["y0"]], 1).astype(np.float32) if len(tables) else None
                 t2 = time.perf_counter()
-                pending = tsr_stage.start(st["pages"], tables) if len(tables) else None
+                with stage_range("table_structure"):
+                    pending = tsr_stage.start(st["pages"], tables) if len(tables) else None
                 host["second.tsr_tables"] = host.get("second.tsr_tables", 0.0) + t2 - t1
                 host["second.tsr_start"] = host.get("second.tsr_start", 0.0) + time.perf_counter() - t2
                 ev = None
@@ -436,7 +445,8 @@ class OcrTablePipeline:
                     aux.wait_event(ev)
                     st["processed"] = tsr_stage.process(pending)
             else:
-                st["processed"] = tsr_stage.process(pending)
+                with stage_range("table_structure.processor"):
+                    st["processed"] = tsr_stage.process(pending)
             host["tables.wait_decode"] = host.get("tables.wait_decode", 0.0) + getattr(tsr_stage, "wait_s", 0.0) - w0
 
         def collect(st) -> List[PageResult]:
@@ -483,6 +493,10 @@ class OcrTablePipeline:
         gpu_marks = [] if os.environ.get("PT_PIPE_GPU_TRACE") else None      # diagnostics: (phase, begin event, end event) on the main stream
 
         def timed(name, fn, *a):
+            with stage_range("predict_stream." + name):      # roctx span of the phase (rocprofv3 --marker-trace); the stages inside name their own
+                return timed_(name, fn, *a)
+
+        def timed_(name, fn, *a):
             t0 = time.perf_counter()
             if gpu_marks is not None and name in ("queue_first", "queue_second", "process_tables"):
                 e0 = torch.cuda.Event(enable_timing=True)

@@ -141,6 +141,49 @@ def test_conv1x1_wide_stages_equal_chunk_stages(eng, case, monkeypatch):
 
 
 @pytest.mark.parametrize("case", [
+    dict(B=2, H=37, W=45, Cin=64, N=128, relu=True, res_mode=1),     # 4-wave tile (Cin <= 128), ragged tiles in both directions + residual
+    dict(B=1, H=30, W=30, Cin=512, N=512, relu=True),                 # 8-wave 16 x 32 x 128 tile, 32 K-slices
+    dict(B=3, H=33, W=65, Cin=256, N=256, res_mode=1),                # 8-wave tile, three column tiles (the last one 1 px wide)
+    dict(B=2, H=40, W=40, Cin=256, N=192, relu=True),                 # N % 128 != 0: the 32 x 32 x 64 8-wave tile
+    dict(B=1, H=24, W=33, Cin=160, N=64),                             # odd slice count per 32-channel chunk pair, 64 outputs
+    dict(B=2, H=21, W=37, Cin=64, N=128, relu=True, res_mode=1, split=True),   # BF16X3: K walks [x_hi | x_lo] x w_hi, then x_hi x w_lo
+])
+def test_conv_v4_equals_v3(eng, case, monkeypatch):
+    """conv3x3_pipe_kernel (v4: software-pipelined tap loop, MUBUF LDS-DMA, column-swizzled image) against conv3x3_dma16_kernel (v3) on the
+    same tiles: same K order inside the accumulators, so every output bit is the same (PT_CONV_PIPE is read at every call); the torch-fp32
+    comparison of both is test_conv_variants_vs_torch_fp32 / test_conv_x3_vs_torch_fp32."""
+    from pdf_table_amd.weights import tile_conv_weight_x3
+    g = torch.Generator().manual_seed(case["Cin"] * 7 + case["N"])
+    B, H, W, Cin, N = case["B"], case["H"], case["W"], case["Cin"], case["N"]
+    split = case.get("split", False)
+    dev = torch.device("cuda", 0)
+
+    def nhwc(t):
+        if not split:
+            return t.to(torch.bfloat16).to(dev)
+        hi = t.to(torch.bfloat16)
+        return torch.cat([hi, (t - hi.float()).to(torch.bfloat16)], -1).contiguous().to(dev)
+    x = nhwc(torch.randn(B, H, W, Cin, generator=g))
+    w = torch.randn(N, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    wt = torch.from_numpy((tile_conv_weight_x3(w) if split else tile_conv_weight(_bf16(w))).view(np.int16)).to(dev)
+    bd = (torch.randn(N, generator=g) * 0.1).to(dev)
+    rm = case.get("res_mode", 0)
+    rd = nhwc(torch.randn(B, H, W, N, generator=g)) if rm else None
+    outs = []
+    for v in ("0", "1"):
+        monkeypatch.setenv("PT_CONV_PIPE", v)
+        eng.profile_enable(1)
+        outs.append(eng.op_conv2d(x, wt, bd, 3, 1, relu=case.get("relu", False), res=rd, res_mode=rm, split=split).clone())
+        torch.cuda.synchronize()
+        labels = list(eng.profile_read_labels())
+        eng.profile_enable(False)
+        # the launcher's label says which kernel ran
+        assert labels and all(k.startswith("conv3x3") and ((" v4" in k) == (v == "1")) for k in labels), labels
+    assert torch.isfinite(outs[0].float()).all() and outs[0].float().abs().max() > 0
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
+@pytest.mark.parametrize("case", [
     dict(B=1, H=16, W=64, Cin=64, N=64, ks=3, stride=1),                               # two tiles, two workgroups
     dict(B=2, H=37, W=45, Cin=64, N=64, ks=3, stride=1, relu=True, res_mode=1),        # ragged tiles + residual
     dict(B=3, H=50, W=70, Cin=64, N=64, ks=3, stride=1, relu=True, grid=5),            # 36 tiles walked by 5 workgroups
