@@ -329,6 +329,8 @@ struct PtCrnnLimits {
   int* cols;          // device int [8]: sum over lines of the tile-rounded limits ([5]: the sequence GEMMs, 32-step tiles)
   int* glist;         // device int [1 + 5 n]: the live 32-step row groups of the sequence GEMMs, compacted (rows_live_list_kernel; = conv3b's block list)
   int* blist3a;       // device int [1 + 5 n]: the live 32-column blocks of conv3a (limit lim[3])
+  int* blist2a;       // the same for conv2a (lim[1]) and conv2b (lim[2]): the 8-row maps' tiles of the blocked DMA kernel (conv3x3_pipe_kernel<.., 8>)
+  int* blist2b;
 };
 int pt_launch_rows_live_list(const int* lim, int n, int* glist, hipStream_t s);
 int pt_launch_crnn_limits(const pt_rec_line* lines, int n, const PtCrnnLimits& L, hipStream_t s);

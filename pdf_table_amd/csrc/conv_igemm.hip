@@ -157,12 +157,12 @@ __device__ __forceinline__ void tile_order(int L, int n_tiles, int n_group, int&
 // Shared epilogue: fp32 tile [TH*32 pixels][64 ch] in LDS -> bias/residual/ReLU -> bf16 stores.
 // b_second >= 0 (TW == 64, the 4 x 64 patch of conv_igemm_kernel<3, 1, 1>): the patch's columns 32 .. 63 are a 32-column block of image b_second at ox_second
 // (another text line's, from the compacted block list; ox_second = Wo: no second block)
-template <int TH, int TW, int NTHR = 256, bool EXTRAS = true>
+template <int TH, int TW, int NTHR = 256, int EXTRAS = 1>      // EXTRAS: 0 plain stores only, 1 every fused epilogue, 2 plain + fused pooling
 __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stage, int tid, int b_first, int oy0, int ox0,
                                                int n0, int b_second = -1, int ox_second = 0) {
   // fused-head weights of this thread's 8 channels (idx & 7 == tid & 7 for every j)
   float hw[4][8];
-  if (EXTRAS && p.head_w) {
+  if (EXTRAS == 1 && p.head_w) {
     const int cgw = tid & 7;
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
@@ -178,7 +178,7 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
       }
     }
   }
-  if (EXTRAS && p.pool) {
+  if (EXTRAS != 0 && p.pool) {
     // conv + BN + ReLU + max-pool in one pass: the pooled tile is (TH/2) x (TW/pw); every source value is biased, ReLU'd and
     // rounded exactly as it would have been stored, then the maximum is stored (identical to conv -> store -> pool)
     // pool 3: (2,1) with the pooled rows written as channel groups, [n][Wo][Ho/2 * C] (the layout the (2,1)-kernel conv4 of
@@ -267,7 +267,7 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
         v[6] += bf16_to_f32(r.w & 0xFFFFu); v[7] += bf16_to_f32(r.w >> 16);
       }
     }
-    if (EXTRAS && p.res_f32) {
+    if (EXTRAS == 1 && p.res_f32) {
       const f32x4* rp = reinterpret_cast<const f32x4*>(p.res_f32 + (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.out_cstride + p.out_coff + n);
       const f32x4 r0 = rp[0], r1 = rp[1];
       v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
@@ -275,14 +275,14 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
     if (p.relu == 1) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-    } else if (EXTRAS && p.relu == 2) {   // hardswish: x * relu6(x + 3) / 6 (PicoDet's LCNet / CSP-PAN / head)
+    } else if (EXTRAS == 1 && p.relu == 2) {   // hardswish: x * relu6(x + 3) / 6 (PicoDet's LCNet / CSP-PAN / head)
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = v[k] * fminf(fmaxf(v[k] + 3.f, 0.f), 6.f) / 6.f;
-    } else if (EXTRAS && p.relu == 3) {   // nn.PReLU() with one shared slope (DB-ProxylessNAS, db_net/layers.py:696,722)
+    } else if (EXTRAS == 1 && p.relu == 3) {   // nn.PReLU() with one shared slope (DB-ProxylessNAS, db_net/layers.py:696,722)
       const float sl = p.slope[0];
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : sl * v[k];
-    } else if (EXTRAS && p.relu == 4) {   // exact GELU, x * 0.5 * (1 + erf(x / sqrt(2))): ConvNext / ViT MLPs (cvit_model.hip)
+    } else if (EXTRAS == 1 && p.relu == 4) {   // exact GELU, x * 0.5 * (1 + erf(x / sqrt(2))): ConvNext / ViT MLPs (cvit_model.hip)
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = v[k] * 0.5f * (1.f + erff(v[k] * 0.70710678118654752f));
     }
@@ -294,7 +294,7 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
       ol.z = pack_bf16x2(v[4] - bf16lo_f32(o.z), v[5] - bf16hi_f32(o.z));
       ol.w = pack_bf16x2(v[6] - bf16lo_f32(o.w), v[7] - bf16hi_f32(o.w));
     }
-    if (EXTRAS && p.argmax_part) {
+    if (EXTRAS == 1 && p.argmax_part) {
       // fused arg-max over classes (CTC greedy decode, modeling_ocr_recognition.py:168-171): best (value, index)
       // of this pixel's 64-class slice; ties keep the LOWEST class index, like torch.argmax
       float bv = v[0];
@@ -315,7 +315,7 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
         pr.y = __int_as_float(bi);
         reinterpret_cast<float2*>(p.argmax_part)[row * p.n_tiles + (n0 >> 6)] = pr;
       }
-    } else if (EXTRAS && p.head_w) {
+    } else if (EXTRAS == 1 && p.head_w) {
       // 8 consecutive lanes hold the 64 channels of one output pixel of quadrant `quad` (n0 == quad * 64)
       float xs[8];
 #pragma unroll
@@ -349,9 +349,9 @@ __device__ __forceinline__ void epilogue_store(const ConvK& p, const float* stag
       const size_t oo = (((size_t)b * OH + 2 * oy + (quad >> 1)) * OW + 2 * ox + (quad & 1)) * p.out_cstride + p.out_coff + co;
       *reinterpret_cast<u32x4*>(p.out + oo) = o;
       if (p.split) *reinterpret_cast<u32x4*>(p.out + oo + p.out_lo_off) = ol;
-    } else if (EXTRAS && p.n_valid && n >= p.n_valid) {
+    } else if (EXTRAS == 1 && p.n_valid && n >= p.n_valid) {
       // padded output channel: nothing to store
-    } else if (EXTRAS && p.out_f32) {
+    } else if (EXTRAS == 1 && p.out_f32) {
       const size_t oo = (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.out_cstride + p.out_coff + n;
       f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
       *reinterpret_cast<f32x4*>(p.out_f32 + oo) = o0;
@@ -1084,9 +1084,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_dma16_kernel(ConvK p, con
     }
     __syncthreads();
     if (NT == 1)
-      epilogue_store<C::PASS_ROWS, 32, C::NTHR, false>(p, stage, tid, b, oy0 + C::PASS_ROWS * pass, ox0, nb * 64);
+      epilogue_store<C::PASS_ROWS, 32, C::NTHR, 0>(p, stage, tid, b, oy0 + C::PASS_ROWS * pass, ox0, nb * 64);
     else
-      epilogue_store<C::PASS_ROWS, 32, C::NTHR, false>(p, stage, tid, b, oy0, ox0, (nb * 2 + pass) * 64);
+      epilogue_store<C::PASS_ROWS, 32, C::NTHR, 0>(p, stage, tid, b, oy0, ox0, (nb * 2 + pass) * 64);
   }
 }
 
@@ -1105,13 +1105,43 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_dma16_kernel(ConvK p, con
 //     instructions are one list; a slot past its end repeats the last instruction), out-of-image lanes read the zero page: no exec masks,
 //     no branches between the MFMAs.
 // ---------------------------------------------------------------------------------------------------
-template <int NT, int NWV>
+#ifndef PT_PIPE_INTERLEAVE
+#define PT_PIPE_INTERLEAVE 1
+#endif
+// Scheduling groups of one tap of the pipelined loop: NM MFMAs of this tap, NR ds_reads (the NEXT tap's fragments) and ND LDS-DMA requests, in
+// the order M R M R ... M [D] M: every read and every DMA request is issued in the shadow of an MFMA that is already in the pipe (a wave that
+// issues its six reads and a DMA request back to back leaves the pipe ~100 cycles without work unless its SIMD partner happens to be out of phase)
+template <int NR, int NM, int ND>
+__device__ __forceinline__ void tap_groups() {
+#if PT_PIPE_INTERLEAVE
+  static_for<NM>([&](auto i_c) {
+    constexpr int i = decltype(i_c)::value;
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    if constexpr (i < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    if constexpr (i >= NR && i - NR < ND) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+  });
+  static_assert(NR + ND <= NM, "more memory requests than MFMAs to hide them behind");
+#else
+  if constexpr (NR > 0) __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+  __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+  if constexpr (ND > 0) __builtin_amdgcn_sched_group_barrier(0x020, ND, 0);
+#endif
+}
+
+// BR (block rows): the tile's TH x 32 output pixels are NBLK = TH / BR blocks of BR rows x 32 columns, each with its own halo ((BR + 2) x 34 input
+// pixels) and its own (image, first column).  BR == TH (0 = default) is the ordinary tile.  BR = 4 / 8 serve maps that are exactly BR rows high --
+// the CRNN conv stack's 4 x 160 and 8 x 160 maps (crnn/modeling_crnn.py:66-77), K = 1 152 ... 4 608 -- whose blocks come from the compacted list of
+// live 32-column blocks of the ragged text lines (ConvDesc.block_list), or from NBLK consecutive column blocks of one line.
+template <int NT, int NWV, int BR_ = 0>
 struct PipeCfg {
   static constexpr int NTHR = 64 * NWV;
   static constexpr int MT = 4;                                // MFMA row-tiles (patch rows) per wave
   static constexpr int TH = (NT == 1 ? NWV : NWV / 2) * MT, TW = 32;
+  static constexpr int BR = BR_ ? BR_ : TH;
+  static constexpr int NBLK = TH / BR, PR = BR + 2;           // blocks per tile, patch rows per block
+  static_assert(TH % BR == 0 && BR % MT == 0, "a wave's four rows lie inside one block");
   static constexpr int NW = 64 * NT;                          // output channels per workgroup
-  static constexpr int THIN = TH + 2, TWIN = TW + 2;
+  static constexpr int THIN = NBLK * PR, TWIN = TW + 2;
   static constexpr int NPIX = THIN * TWIN;
   static constexpr int IN_UNITS = NPIX * 2;
   static constexpr int IN_INSTR = (IN_UNITS + 63) / 64;
@@ -1128,13 +1158,13 @@ struct PipeCfg {
   static_assert(SMEM <= 163840, "LDS budget");
 };
 
-template <int NT, int NWV, bool SKEW>
+template <int NT, int NWV, bool SKEW, int BR = 0>
 __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, const bf16_t* __restrict__ zero_page) {
   // (device pass only: the buffer-resource builtins do not exist for the host target, and a kernel template whose body fails to instantiate there
   // silently loses its launch stub -- "undefined symbol ... conv3x3_pipe_kernel" at dlopen)
 #if defined(__HIP_DEVICE_COMPILE__)
   a16_kernel_enter();
-  using C = PipeCfg<NT, NWV>;
+  using C = PipeCfg<NT, NWV, BR>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1143,18 +1173,50 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, cons
   const int wm = NT == 1 ? wave : (wave >> 1);   // which group of 4 patch rows
   const int wn = NT == 1 ? 0 : (wave & 1);       // which 64-channel half
 
-  int L = xcd_remap(blockIdx.x, gridDim.x);
-  const int nb = L % p.n_tiles;                  // n_tiles counts NW-wide blocks here
-  L /= p.n_tiles;
-  const int txi = L % p.tiles_x;
-  L /= p.tiles_x;
-  const int tyi = L % p.tiles_y;
-  const int b = L / p.tiles_y;
-  const int oy0 = tyi * C::TH, ox0 = txi * C::TW;
+  // the tile's blocks: (image, first output column); column Wo = no block (nothing fetched, nothing stored)
+  int blk_b[C::NBLK], blk_x[C::NBLK];
+  int nb, oy0 = 0;
+  if constexpr (C::NBLK == 1) {
+    int L = xcd_remap(blockIdx.x, gridDim.x);
+    nb = L % p.n_tiles;                          // n_tiles counts NW-wide blocks here
+    L /= p.n_tiles;
+    const int txi = L % p.tiles_x;
+    L /= p.tiles_x;
+    const int tyi = L % p.tiles_y;
+    blk_b[0] = L / p.tiles_y;
+    blk_x[0] = txi * C::TW;
+    oy0 = tyi * C::TH;
+  } else {
+    // (launch order, no XCD remap: with a block list the live tiles are the FRONT of the walk -- the remap would hand all of them to the first XCDs)
+    const int L = blockIdx.x;
+    nb = L % p.n_tiles;
+    const int ti = L / p.n_tiles;
+    if (p.blist) {
+      const int cnt = p.blist[0], bpl = p.Wo >> 5, first = ti * C::NBLK;
+      if (first >= cnt) return;
+#pragma unroll
+      for (int j = 0; j < C::NBLK; ++j) {
+        const int e = first + j < cnt ? p.blist[1 + first + j] : -1;
+        blk_b[j] = e >= 0 ? e / bpl : 0;
+        blk_x[j] = e >= 0 ? (e - blk_b[j] * bpl) * 32 : p.Wo;
+        if (e < 0) blk_b[j] = blk_b[0];
+      }
+    } else {
+      const int txi = ti % p.tiles_x, bb = ti / p.tiles_x, x0 = txi * C::NBLK * 32;
+      if (p.xlimit && x0 >= p.xlimit[bb]) return;      // ragged line: this tile is all padding response, filled by the caller
+#pragma unroll
+      for (int j = 0; j < C::NBLK; ++j) {
+        const int x = x0 + 32 * j;
+        blk_b[j] = bb;
+        blk_x[j] = (x < p.Wo && (!p.xlimit || x < p.xlimit[bb])) ? x : p.Wo;
+      }
+    }
+  }
+  const int b = blk_b[0], ox0 = blk_x[0];
   const int in_cs = p.split ? 2 * p.Cin : p.Cin;
   const int nch32 = p.split ? 3 * (p.Cin >> 5) : (p.Cin >> 5);
   const int nslices = nch32 * 2;
-  const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * in_cs;
+  const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * in_cs;      // (every block's image is at or behind the first block's: offsets stay non-negative)
   const bf16_t* wt = p.w + (size_t)(NT * nb) * nch32 * (9 * 64 * 32);
 
   // DMA slot j of this wave = instruction k = wave + NWV * j of the list [IN_INSTR input | W_INSTR weight]; lane -> 16-byte unit k * 64 + lane.
@@ -1179,11 +1241,16 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, cons
     if (is_in[j]) {
       const int U = k * 64 + lane;
       const int pix = U >> 1;
-      const int iy = pix / C::TWIN, ix = pix - iy * C::TWIN;
+      const int pr = pix / C::TWIN, ix = pix - pr * C::TWIN;
       const int q = (U & 1) ^ ((ix >> 3) & 1);
-      const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
-      const bool inside = U < C::IN_UNITS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-      voff[j] = inside ? (int)((((size_t)gy * p.W + gx) * in_cs + q * 8) * 2) : OOB;
+      const int bk = pr / C::PR, iy = pr - bk * C::PR;      // block of the patch row, row inside the block's (BR + 2)-row patch
+      int bj = blk_b[0], xj = blk_x[0];
+#pragma unroll
+      for (int t = 1; t < C::NBLK; ++t)
+        if (bk == t) { bj = blk_b[t]; xj = blk_x[t]; }
+      const int gy = oy0 - 1 + iy, gx = xj - 1 + ix;
+      const bool inside = U < C::IN_UNITS && xj < p.Wo && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+      voff[j] = inside ? (int)(((((size_t)(bj - b) * p.H + gy) * p.W + gx) * in_cs + q * 8) * 2) : OOB;
     } else {
       const int U = (k - C::IN_INSTR) * 64 + lane;
       const int row = U >> 1;
@@ -1217,7 +1284,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, cons
   int a_lane[3];
 #pragma unroll
   for (int s = 0; s < 3; ++s)
-    a_lane[s] = ((C::MT * wm) * C::TWIN + lx + s) * 32 + ((qh ^ (((lx + s) >> 3) & 1)) << 4);
+    a_lane[s] = ((((C::MT * wm) / C::BR) * C::PR + (C::MT * wm) % C::BR) * C::TWIN + lx + s) * 32 + ((qh ^ (((lx + s) >> 3) & 1)) << 4);
   const int b_lane = C::IN_BYTES + (wn * 64 + lx) * 32 + ((qh ^ ((lx >> 3) & 1)) << 4);
 
   bf16x8 fa[2][C::MT], fb[2][2];
@@ -1261,12 +1328,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, cons
     __builtin_amdgcn_sched_group_barrier(0x100, 2 + C::MT, 0);
     static_for<9>([&](auto tap_c) {
       constexpr int tap = decltype(tap_c)::value;
-      if constexpr (tap < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2 + C::MT, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * C::MT, 0);
-      if constexpr (MORE) {
-        constexpr int nd = (C::SLOTS > tap ? 1 : 0) + (C::SLOTS > tap + 9 ? 1 : 0);
-        if constexpr (nd > 0) __builtin_amdgcn_sched_group_barrier(0x020, nd, 0);
-      }
+      constexpr int nd = MORE ? (C::SLOTS > tap ? 1 : 0) + (C::SLOTS > tap + 9 ? 1 : 0) : 0;
+      tap_groups<tap < 8 ? 2 + C::MT : 0, 2 * C::MT, nd>();
     });
   };
   // SKEW: the hand-over barrier sits in front of tap 8 instead of behind it.  Tap 8's fragments are in registers by then (so every read of
@@ -1290,12 +1353,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, cons
     });
     static_for<8>([&](auto tap_c) {
       constexpr int tap = decltype(tap_c)::value;
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 + C::MT, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * C::MT, 0);
-      if constexpr (MORE) {
-        constexpr int nd = (C::SLOTS > 2 * tap ? 1 : 0) + (C::SLOTS > 2 * tap + 1 ? 1 : 0);
-        if constexpr (nd > 0) __builtin_amdgcn_sched_group_barrier(0x020, nd, 0);
-      }
+      constexpr int nd = MORE ? (C::SLOTS > 2 * tap ? 1 : 0) + (C::SLOTS > 2 * tap + 1 ? 1 : 0) : 0;
+      tap_groups<2 + C::MT, 2 * C::MT, nd>();
     });
     if constexpr (MORE) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1303,8 +1362,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, cons
       load_frags(smem + (P ^ 1) * C::BUF_BYTES, 0, (P + 1) & 1);
     }
     mma_tap((P + 8) & 1);
-    if constexpr (MORE) __builtin_amdgcn_sched_group_barrier(0x100, 2 + C::MT, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 2 * C::MT, 0);
+    tap_groups<MORE ? 2 + C::MT : 0, 2 * C::MT, 0>();
   };
   if constexpr (SKEW) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1340,10 +1398,21 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, cons
           }
     }
     __syncthreads();
-    if (NT == 1)
-      epilogue_store<C::PASS_ROWS, 32, C::NTHR, false>(p, stage, tid, b, oy0 + C::PASS_ROWS * pass, ox0, nb * 64);
-    else
-      epilogue_store<C::PASS_ROWS, 32, C::NTHR, false>(p, stage, tid, b, oy0, ox0, (nb * 2 + pass) * 64);
+    if constexpr (C::NBLK > 1) {
+      static_assert(NT == 2 || C::NBLK == 1, "blocked tiles: one pass = all rows of one 64-channel half");
+#pragma unroll 1
+      for (int j = 0; j < C::NBLK; ++j) {      // (uniform: a dead block stores nothing)
+        int bj = blk_b[0], xj = blk_x[0];
+#pragma unroll
+        for (int t = 1; t < C::NBLK; ++t)
+          if (j == t) { bj = blk_b[t]; xj = blk_x[t]; }
+        if (xj < p.Wo) epilogue_store<C::BR, 32, C::NTHR, 2>(p, stage + j * C::BR * 32 * 64, tid, bj, 0, xj, (nb * 2 + pass) * 64);
+      }
+    } else if (NT == 1) {
+      epilogue_store<C::PASS_ROWS, 32, C::NTHR, 0>(p, stage, tid, b, oy0 + C::PASS_ROWS * pass, ox0, nb * 64);
+    } else {
+      epilogue_store<C::PASS_ROWS, 32, C::NTHR, 0>(p, stage, tid, b, oy0, ox0, (nb * 2 + pass) * 64);
+    }
   }
 #endif
 }
@@ -2254,27 +2323,45 @@ static int launch_dma16(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
 }
 
 // v4: the software-pipelined tap loop (conv3x3_pipe_kernel); same tiling arithmetic and labels as launch_dma16
-template <int NT, int NWV, bool SKEW>
+template <int NT, int NWV, bool SKEW, int BR = 0>
 static int launch_pipe(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
-  using C = PipeCfg<NT, NWV>;
+  using C = PipeCfg<NT, NWV, BR>;
   static bool attr_done = false;
   if (!attr_done) {
-    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pipe_kernel<NT, NWV, SKEW>), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pipe_kernel<NT, NWV, SKEW, BR>), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
     attr_done = true;
   }
-  if (!e->zero_page) {
-    PT_HIP_CHECK(hipMalloc(&e->zero_page, 8192));
-    PT_HIP_CHECK(hipMemset(e->zero_page, 0, 8192));
-  }
-  k.tiles_x = (k.Wo + C::TW - 1) / C::TW;
-  k.tiles_y = (k.Ho + C::TH - 1) / C::TH;
   k.n_tiles = k.N / C::NW;
-  const long long nblk = (long long)k.B * k.tiles_x * k.tiles_y * k.n_tiles;
+  long long nblk;
+  if (C::NBLK == 1) {
+    k.tiles_x = (k.Wo + C::TW - 1) / C::TW;
+    k.tiles_y = (k.Ho + C::TH - 1) / C::TH;
+    nblk = (long long)k.B * k.tiles_x * k.tiles_y * k.n_tiles;
+  } else if (k.blist) {      // NBLK live 32-column blocks per workgroup: the worst case is every block of every image
+    k.tiles_x = (int)(((long long)k.B * (k.Wo / 32) + C::NBLK - 1) / C::NBLK);
+    k.tiles_y = 1;
+    nblk = (long long)k.tiles_x * k.n_tiles;
+  } else {                   // NBLK consecutive column blocks of one image
+    k.tiles_x = (k.Wo + C::NBLK * 32 - 1) / (C::NBLK * 32);
+    k.tiles_y = 1;
+    nblk = (long long)k.B * k.tiles_x * k.n_tiles;
+  }
   PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range (%lld blocks)", nblk);
   char label[48];
-  snprintf(label, sizeof(label), "conv3x3 v4%s %d->%d @%dx%d%s", NWV == 4 ? "h" : "", k.Cin, k.N, k.Ho, k.Wo, k.split ? " x3" : "");
-  PtProfScope prof(e, s, PT_PROF_CONV3X3, flop, label);
-  hipLaunchKernelGGL((conv3x3_pipe_kernel<NT, NWV, SKEW>), dim3((unsigned)nblk), dim3(C::NTHR), C::SMEM, s, k, reinterpret_cast<const bf16_t*>(e->zero_page));
+  if (C::NBLK == 1) snprintf(label, sizeof(label), "conv3x3 v4%s %d->%d @%dx%d%s", NWV == 4 ? "h" : "", k.Cin, k.N, k.Ho, k.Wo, k.split ? " x3" : "");
+  else snprintf(label, sizeof(label), "conv3x3 v4b %d->%d @%dx%d%s", k.Cin, k.N, k.Ho, k.Wo, k.split ? " x3" : "");
+  int lim_slot = -1;
+  {
+    PtProfScope prof(e, s, PT_PROF_CONV3X3, flop, label);
+    hipLaunchKernelGGL((conv3x3_pipe_kernel<NT, NWV, SKEW, BR>), dim3((unsigned)nblk), dim3(C::NTHR), C::SMEM, s, k, reinterpret_cast<const bf16_t*>(e->zero_page));
+    if (k.xcols && prof.idx >= 0 && e->prof.h_lims && e->prof.n_lims < PtProfile::MAX_LIMS) {
+      // per-image column limits: the launch covers the worst case; remember where the limit will land (credited at read-out, like launch_cfg)
+      auto& pd = e->prof.pending[prof.idx];
+      pd.lim_slot = lim_slot = e->prof.n_lims++;
+      pd.rows = k.B * k.Wo;
+    }
+  }
+  if (lim_slot >= 0) (void)hipMemcpyAsync(e->prof.h_lims + lim_slot, k.xcols, sizeof(int), hipMemcpyDeviceToHost, s);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }
@@ -2450,6 +2537,21 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
     }
     if (pick == 3 && use_half) return launch_dma16<1, 4>(e, k, s, flop);
     if (pick == 3) return d.N % 128 == 0 ? launch_dma16<2, 8>(e, k, s, flop) : launch_dma16<1, 8>(e, k, s, flop);
+  }
+  // maps that are exactly 4 or 8 rows high with K >= 1152 and 128-wide output blocks (the CRNN conv2.* / conv3.* layers): the pipelined DMA kernel on
+  // tiles of four 4 x 32 / two 8 x 32 blocks -- from the compacted list of live blocks when the layer has one (PT_CONV_PIPE_BLOCKS=0: the
+  // register-staged kernels, A/B switch read per call)
+  if (d.ks == 3 && d.stride == 1 && (k.Ho == 4 || k.Ho == 8) && k.H == k.Ho && k.Wo % 32 == 0 && k.Wo > 32 && d.N % 128 == 0 && d.Cin >= 128 && !d.head_w &&
+      !d.argmax_part && !d.n_valid && !d.out_f32 && !d.res_f32 && !d.res && d.relu < 2 && !d.ylimit && !d.xlimit_rows && d.rep == 1 && !d.shuffle_cout &&
+      d.split != 2 && use_dma_kernel()) {
+    const char* pb = getenv("PT_CONV_PIPE_BLOCKS");
+    const char* pv = getenv("PT_CONV_PIPE");
+    bool masked = false;
+    for (int i = 0; i < 8; ++i) masked = masked || d.tap_mask[i] != 0;
+    if (!masked && !(pb && pb[0] == '0') && !(pv && pv[0] == '0')) {
+      if (d.xlimit && d.block_list) k.blist = d.block_list;      // (8-row maps too: the GEOM 1 rule above only takes lists for <= 4 rows)
+      return k.Ho == 4 ? launch_pipe<2, 8, true, 4>(e, k, s, flop) : launch_pipe<2, 8, true, 8>(e, k, s, flop);
+    }
   }
   if (d.ks == 3 && d.stride == 1 && k.Ho <= 4 && k.Wo > 32) return launch_cfg<3, 1, 1>(e, k, s, flop);
   if (d.ks == 3 && d.stride == 1) return launch_cfg<3, 1>(e, k, s, flop);

@@ -168,6 +168,8 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
         c.xlimit = lim->lim[k]; c.xlimit_cols = lim->cols + k;
         if (k == 3) c.block_list = lim->blist3a;      // conv3.* (4-row maps): pairs of live 32-column blocks per workgroup
         if (k == 4) c.block_list = lim->glist;
+        if (k == 1) c.block_list = lim->blist2a;      // conv2.* (8-row maps): taken by the blocked DMA kernel only (pt_launch_conv)
+        if (k == 2) c.block_list = lim->blist2b;
       }
       return c;
     };
@@ -264,7 +266,7 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
       PT_HIP_CHECK(hipStreamWaitEvent(s, e->rec_zero_ready[x3], 0));       // a no-op once the build has completed
     }
     zl = reinterpret_cast<const bf16_t*>(e->rec_zero[x3]);
-    const size_t need = ((size_t)16 * n + 24) * sizeof(int);
+    const size_t need = ((size_t)26 * n + 40) * sizeof(int);
     if (need > e->rec_limits_cap) {
       PT_HIP_CHECK(hipStreamSynchronize(s));
       if (e->rec_limits) PT_HIP_CHECK(hipFree(e->rec_limits));
@@ -277,11 +279,15 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
     lim.cols = base + (size_t)6 * n;
     lim.glist = base + (size_t)6 * n + 8;
     lim.blist3a = base + (size_t)11 * n + 16;
+    lim.blist2a = base + (size_t)16 * n + 24;
+    lim.blist2b = base + (size_t)21 * n + 32;
     {
       PtProfScope ps(e, s, PT_PROF_OTHER, 0, "crnn limits");
       RUN(pt_launch_crnn_limits(d_lines, n, lim, s));
       RUN(pt_launch_rows_live_list(lim.lim[4], n, lim.glist, s));
       RUN(pt_launch_rows_live_list(lim.lim[3], n, lim.blist3a, s));
+      RUN(pt_launch_rows_live_list(lim.lim[1], n, lim.blist2a, s));
+      RUN(pt_launch_rows_live_list(lim.lim[2], n, lim.blist2b, s));
     }
   }
   RUN(conv_stack(gray, n, bf.a0, bf.a1, bf.p1, bf.c2a, bf.c2b, bf.p2, bf.c3a, bf.c3b, bf.p3, bf.f, bf.gx, ragged ? &lim : nullptr, zl));
