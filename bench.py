@@ -1535,7 +1535,7 @@ def main(argv=None):
                 leg["bf16_pages_per_s"] = out["value"]
                 out["tolerance_mode"] = leg
         if rank == 0 and not args.no_post and "tsr" in runner.stages and "layout" in runner.stages:
-            leg = guarded(lambda: runner.f16_leg_run(steps=max(8, args.steps)))
+            leg = guarded(lambda: runner.f16_leg_run(steps=max(8, args.steps), warm=max(3, args.warmup)))      # a fresh engine: as many untimed steps as the headline's
             if leg is not None:
                 leg["ratio_to_bf16"] = leg["pages_per_s"] / out["value"] if "pages_per_s" in leg else None
                 out.setdefault("tolerance_mode", {})["f16"] = leg

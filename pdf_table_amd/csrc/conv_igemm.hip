@@ -1158,7 +1158,10 @@ struct PipeCfg {
   static_assert(SMEM <= 163840, "LDS budget");
 };
 
-template <int NT, int NWV, bool SKEW, int BR = 0>
+// DIRECT (plain layers: no hi/lo pairs, no fused pooling): the weights are the MFMA's A operand (D = [channel][pixel], the same sums in the same order)
+// and the epilogue runs from the accumulators (epilogue_direct_row: bias, residual, activation, rounding, v_permlane32_swap into 16-byte channel
+// runs) -- no fp32 round trip through LDS, no barrier behind the K loop
+template <int NT, int NWV, bool SKEW, int BR = 0, bool DIRECT = false>
 __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, const bf16_t* __restrict__ zero_page) {
   // (device pass only: the buffer-resource builtins do not exist for the host target, and a kernel template whose body fails to instantiate there
   // silently loses its launch stub -- "undefined symbol ... conv3x3_pipe_kernel" at dlopen)
@@ -1299,8 +1302,13 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, cons
   auto mma_tap = [&](int slot) {
 #pragma unroll
     for (int m = 0; m < C::MT; ++m) {
-      acc[m][0] = mfma_32x32x16_a16(fa[slot][m], fb[slot][0], acc[m][0]);
-      acc[m][1] = mfma_32x32x16_a16(fa[slot][m], fb[slot][1], acc[m][1]);
+      if constexpr (DIRECT) {
+        acc[m][0] = mfma_32x32x16_a16(fb[slot][0], fa[slot][m], acc[m][0]);
+        acc[m][1] = mfma_32x32x16_a16(fb[slot][1], fa[slot][m], acc[m][1]);
+      } else {
+        acc[m][0] = mfma_32x32x16_a16(fa[slot][m], fb[slot][0], acc[m][0]);
+        acc[m][1] = mfma_32x32x16_a16(fa[slot][m], fb[slot][1], acc[m][1]);
+      }
     }
   };
 
@@ -1379,6 +1387,19 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, cons
     slice_body(nslices - 1, std::false_type{});
   }
 
+  if constexpr (DIRECT) {
+    const int n0 = (NT == 1 ? nb : nb * 2 + wn) * 64;
+    const DirectBias bs = direct_bias<2>(p, n0, qh);
+    // the wave's four rows lie in block (MT wm) / BR of the tile, from row (MT wm) % BR of that block's map
+    int bj = blk_b[0], xj = blk_x[0];
+#pragma unroll
+    for (int t = 1; t < C::NBLK; ++t)
+      if ((C::MT * wm) / C::BR == t) { bj = blk_b[t]; xj = blk_x[t]; }
+    if (xj >= p.Wo) return;      // (wave-uniform) no block
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m) epilogue_direct_row<2>(p, acc[m], bs, bj, oy0 + (C::MT * wm) % C::BR + m, xj, lx, n0, qh, nullptr);
+    return;
+  }
   // epilogue in two passes of PASS_ROWS x 32 pixels x 64 channels (fp32 in LDS)
   float* stage = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -1449,6 +1470,7 @@ struct Ws64Cfg {
 };
 
 __global__ __launch_bounds__(512, 1) void conv3x3_ws64_kernel(ConvK p, const bf16_t* __restrict__ zero_page) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (buffer-resource builtins: device pass only, see conv3x3_pipe_kernel)
   a16_kernel_enter();
   using C = Ws64Cfg;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1469,44 +1491,49 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws64_kernel(ConvK p, const bf1
 
   // weights -> LDS, once: fragment f = (tap * 4 + ks) * 2 + nh holds, for lane (lx, q), channels ks * 16 + 8 q .. + 7 of output
   // nh * 32 + lx; source = the v1 tiling [Cin/32 = 2][9][64][32]
+  // LDS-DMA requests are MUBUF (buffer_load ... lds), like conv3x3_pipe_kernel's: a FLAT-encoded LDS load in flight makes hipcc wait lgkmcnt(0) in front of
+  // every dependent ds_read result (no read could stay in flight across an MFMA group), and a lane beyond num_records writes zeros (no zero page)
+  constexpr int OOB = 0x7FFFF000;
+  const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.w), 0, OOB, 0x00020000);
 #pragma unroll
   for (int j = 0; j < C::W_FRAGS / C::NWV; ++j) {
     const int f = wave + C::NWV * j;
     const int tap = f >> 3, ks = (f >> 1) & 3, nh = f & 1;
-    const bf16_t* src = p.w + (((ks >> 1) * 9 + tap) * 64 + nh * 32 + lx) * 32 + (ks & 1) * 16 + q * 8;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(s_w + f * 1024), 16, 0, 0);
+    const int off = ((((ks >> 1) * 9 + tap) * 64 + nh * 32 + lx) * 32 + (ks & 1) * 16 + q * 8) * 2;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (__attribute__((address_space(3))) void*)(s_w + f * 1024), 16, off, 0, 0, 0);
   }
 
-  const bf16_t* src_in[C::IN_SLOTS];
-  bool on_in[C::IN_SLOTS];
+  // input units: 16-byte slot U & 3 of pixel U >> 2 holds channel quarter (U & 3) ^ ((patch column >> 2) & 3): conflict-free ds_read_b128 for 16 lanes on
+  // consecutive columns, and a fragment address is (per tap column, per k-step) base + row * immediate
+  int voff[C::IN_SLOTS];
+  const bf16_t* in_b = p.in;
   auto issue = [&](int sl) {
     if (!(sl & 1)) {      // first slice of a tile: where its patch lies
       const int t = t0 + (sl >> 1);
       const int b = t / tiles_img, r = t - b * tiles_img;
       const int tyi = r / p.tiles_x, txi = r - tyi * p.tiles_x;
       const int oy0 = tyi * C::TH, ox0 = txi * C::TW;
-      const bf16_t* in_b = p.in + (size_t)b * p.H * p.W * 64;
+      in_b = p.in + (size_t)b * p.H * p.W * 64;
 #pragma unroll
       for (int j = 0; j < C::IN_SLOTS; ++j) {
-        const int k = wave + C::NWV * j;
+        int k = wave + C::NWV * j;
+        if (k >= C::IN_INSTR) k = C::IN_INSTR - 1;      // (a slot past the list repeats the last instruction: no branch in the issue path)
         const int U = k * 64 + lane;
-        on_in[j] = (k < C::IN_INSTR) && (U < C::IN_UNITS);
         const int pix = U >> 2;
-        const int qq = (U & 3) ^ ((pix >> 2) & 3);
         const int iy = pix / C::TWIN, ix = pix - iy * C::TWIN;
+        const int qq = (U & 3) ^ ((ix >> 2) & 3);
         const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
-        const bool inside = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-        src_in[j] = inside ? in_b + ((size_t)gy * p.W + gx) * 64 + qq * 8 : zero_page;
+        const bool inside = U < C::IN_UNITS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        voff[j] = inside ? (int)((((size_t)gy * p.W + gx) * 64 + qq * 8) * 2) : OOB;
       }
     }
+    const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(in_b), 0, OOB, 0x00020000);
     char* lds = s_in0 + (sl & 1) * C::IN_BYTES;
-    const int c0 = (sl & 1) * 32;
 #pragma unroll
     for (int j = 0; j < C::IN_SLOTS; ++j) {
-      if (on_in[j])
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_in[j] + c0),
-                                         (__attribute__((address_space(3))) void*)(lds + (wave + C::NWV * j) * 1024), 16, 0, 0);
+      int k = wave + C::NWV * j;
+      if (k >= C::IN_INSTR) k = C::IN_INSTR - 1;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_in, (__attribute__((address_space(3))) void*)(lds + k * 1024), 16, voff[j], (sl & 1) * 64, 0, 0);
     }
   };
 
@@ -1610,7 +1637,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws64_kernel(ConvK p, const bf1
     }
   };
 
-  const int pa0 = (2 * wave) * C::TWIN + lx;
+  int a_lane[3][2];      // fragment base of (tap column s, k-step kk): pixel (2 wave, lx + s) of the patch, 16-byte slot (kk * 2 + q) ^ ((column >> 2) & 3)
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) a_lane[s][kk] = ((2 * wave) * C::TWIN + lx + s) * 64 + (((kk * 2 + q) ^ (((lx + s) >> 2) & 3)) << 4);
   issue(0);
   for (int sl = 0; sl < nsl; ++sl) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1634,27 +1665,34 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws64_kernel(ConvK p, const bf1
 #endif
     const char* s_in = s_in0 + (sl & 1) * C::IN_BYTES;
     const char* s_wc = s_w + (sl & 1) * 4096 + lane * 16;   // k-steps 2 c, 2 c + 1 of every tap
+    // 18 steps (tap, k-step) of {2 weight + 2 image fragments, 4 MFMAs}; the fragments of step i + 1 are requested between the MFMAs of step i
+    // (M R M R M R M R, pinned with scheduling groups: left alone the reads sink to just above their use and every step waits for LDS)
+    bf16x8 fw[2][2], fa[2][2];
+    auto load_step = [&](int st, int slot) {
+      const int tap = st >> 1, kk = st & 1, r = tap / 3, s = tap - 3 * r;
+      fw[slot][0] = *reinterpret_cast<const bf16x8*>(s_wc + (tap * 8 + kk * 2) * 1024);
+      fw[slot][1] = *reinterpret_cast<const bf16x8*>(s_wc + (tap * 8 + kk * 2 + 1) * 1024);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+      for (int m = 0; m < 2; ++m) fa[slot][m] = *reinterpret_cast<const bf16x8*>(s_in + a_lane[s][kk] + ((m + r) * C::TWIN) * 64);
+    };
+    load_step(0, 0);
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int tap = r * 3 + s;
+    for (int st = 0; st < 18; ++st) {
+      if (st < 17) load_step(st + 1, (st + 1) & 1);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(s_wc + (tap * 8 + kk * 2) * 1024);
-          const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(s_wc + (tap * 8 + kk * 2 + 1) * 1024);
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            const int pp = pa0 + (m + r) * C::TWIN + s;
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(s_in + pp * 64 + (((kk * 2 + q) ^ ((pp >> 2) & 3)) << 4));
-            acc[m][0] = mfma_32x32x16_a16(w0, a, acc[m][0]);      // D = [channel][pixel]
-            acc[m][1] = mfma_32x32x16_a16(w1, a, acc[m][1]);
-          }
-        }
+      for (int m = 0; m < 2; ++m) {
+        acc[m][0] = mfma_32x32x16_a16(fw[st & 1][0], fa[st & 1][m], acc[m][0]);      // D = [channel][pixel]
+        acc[m][1] = mfma_32x32x16_a16(fw[st & 1][1], fa[st & 1][m], acc[m][1]);
       }
     }
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    static_for<18>([&](auto st_c) {
+      constexpr int st = decltype(st_c)::value;
+      tap_groups<st < 17 ? 4 : 0, 4, 0>();
+    });
   }
   epilogue(t1 - 1);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2323,12 +2361,12 @@ static int launch_dma16(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
 }
 
 // v4: the software-pipelined tap loop (conv3x3_pipe_kernel); same tiling arithmetic and labels as launch_dma16
-template <int NT, int NWV, bool SKEW, int BR = 0>
+template <int NT, int NWV, bool SKEW, int BR = 0, bool DIRECT = false>
 static int launch_pipe(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   using C = PipeCfg<NT, NWV, BR>;
   static bool attr_done = false;
   if (!attr_done) {
-    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pipe_kernel<NT, NWV, SKEW, BR>), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pipe_kernel<NT, NWV, SKEW, BR, DIRECT>), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
     attr_done = true;
   }
   k.n_tiles = k.N / C::NW;
@@ -2353,7 +2391,7 @@ static int launch_pipe(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   int lim_slot = -1;
   {
     PtProfScope prof(e, s, PT_PROF_CONV3X3, flop, label);
-    hipLaunchKernelGGL((conv3x3_pipe_kernel<NT, NWV, SKEW, BR>), dim3((unsigned)nblk), dim3(C::NTHR), C::SMEM, s, k, reinterpret_cast<const bf16_t*>(e->zero_page));
+    hipLaunchKernelGGL((conv3x3_pipe_kernel<NT, NWV, SKEW, BR, DIRECT>), dim3((unsigned)nblk), dim3(C::NTHR), C::SMEM, s, k, reinterpret_cast<const bf16_t*>(e->zero_page));
     if (k.xcols && prof.idx >= 0 && e->prof.h_lims && e->prof.n_lims < PtProfile::MAX_LIMS) {
       // per-image column limits: the launch covers the worst case; remember where the limit will land (credited at read-out, like launch_cfg)
       auto& pd = e->prof.pending[prof.idx];
@@ -2526,12 +2564,18 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
     }
     // v4 (software-pipelined tap loop) for the unmasked layers; PT_CONV_PIPE=0: v3 everywhere (A/B switch, read per call)
     const char* pv = getenv("PT_CONV_PIPE");
-    const int pipe = masked ? 0 : (pv ? atoi(pv) : 2);      // 1: barrier behind tap 8, 2: in front of it (SKEW)
+    const int pipe = masked ? 0 : (pv ? atoi(pv) : 3);      // 1: barrier behind tap 8, 2: in front of it (SKEW), 3: + register epilogue on plain layers
     if (pick == 3 && pipe == 1) {
       if (use_half) return launch_pipe<1, 4, false>(e, k, s, flop);
       return d.N % 128 == 0 ? launch_pipe<2, 8, false>(e, k, s, flop) : launch_pipe<1, 8, false>(e, k, s, flop);
     }
     if (pick == 3 && pipe >= 2) {
+      // register epilogue for the plain layers (PT_CONV_PIPE=2: the staged fp32 epilogue everywhere, A/B switch)
+      const bool direct = pipe >= 3 && !k.split && !k.pool && !k.shuffle_cout;
+      if (direct) {
+        if (use_half) return launch_pipe<1, 4, true, 0, true>(e, k, s, flop);
+        return d.N % 128 == 0 ? launch_pipe<2, 8, true, 0, true>(e, k, s, flop) : launch_pipe<1, 8, true, 0, true>(e, k, s, flop);
+      }
       if (use_half) return launch_pipe<1, 4, true>(e, k, s, flop);
       return d.N % 128 == 0 ? launch_pipe<2, 8, true>(e, k, s, flop) : launch_pipe<1, 8, true>(e, k, s, flop);
     }
@@ -2550,6 +2594,8 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
     for (int i = 0; i < 8; ++i) masked = masked || d.tap_mask[i] != 0;
     if (!masked && !(pb && pb[0] == '0') && !(pv && pv[0] == '0')) {
       if (d.xlimit && d.block_list) k.blist = d.block_list;      // (8-row maps too: the GEOM 1 rule above only takes lists for <= 4 rows)
+      if (!k.split && !k.pool && !(pv && atoi(pv) < 3))           // plain layer: register epilogue
+        return k.Ho == 4 ? launch_pipe<2, 8, true, 4, true>(e, k, s, flop) : launch_pipe<2, 8, true, 8, true>(e, k, s, flop);
       return k.Ho == 4 ? launch_pipe<2, 8, true, 4>(e, k, s, flop) : launch_pipe<2, 8, true, 8>(e, k, s, flop);
     }
   }

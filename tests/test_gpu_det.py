@@ -170,7 +170,7 @@ def test_conv_v4_equals_v3(eng, case, monkeypatch):
     rm = case.get("res_mode", 0)
     rd = nhwc(torch.randn(B, H, W, N, generator=g)) if rm else None
     outs = []
-    for v in ("0", "1"):
+    for v in ("0", "1", "2", "3"):      # v3; v4 with the barrier behind tap 8; in front of it; + the register epilogue on plain layers (the default)
         monkeypatch.setenv("PT_CONV_PIPE", v)
         eng.profile_enable(1)
         outs.append(eng.op_conv2d(x, wt, bd, 3, 1, relu=case.get("relu", False), res=rd, res_mode=rm, split=split).clone())
@@ -178,9 +178,10 @@ def test_conv_v4_equals_v3(eng, case, monkeypatch):
         labels = list(eng.profile_read_labels())
         eng.profile_enable(False)
         # the launcher's label says which kernel ran
-        assert labels and all(k.startswith("conv3x3") and ((" v4" in k) == (v == "1")) for k in labels), labels
+        assert labels and all(k.startswith("conv3x3") and ((" v4" in k) == (v != "0")) for k in labels), labels
     assert torch.isfinite(outs[0].float()).all() and outs[0].float().abs().max() > 0
-    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    for o in outs[1:]:
+        assert torch.equal(outs[0].view(torch.int16), o.view(torch.int16))
 
 
 @pytest.mark.parametrize("case", [
