@@ -1308,8 +1308,9 @@ def compact_line(out):
                                    if full else "stages " + "+".join(stages) + " ")
                                   + f"over {cfg.get('pages_per_step_per_gpu')} device-resident synthetic {PAGE}x{PAGE} pages per GPU per step, "
                                   + "OcrTablePipeline.predict_stream(), seeded synthetic checkpoints",
-                      **_pick(cfg, "pages_per_step_per_gpu", "page", "stages", "parallelism", "boxes_per_page", "text_lines_recognised_per_page",
-                              "tokens_per_page", "tables_per_page", "table_cells_per_page", "layout_regions_per_page", "rccl_init_s")}
+                      # every short entry of the full config (numbers, short lists / strings); the prose stays in bench_detail.json
+                      **{k: v for k, v in cfg.items() if k != "workload" and v is not None and
+                         (isinstance(v, (int, float, bool)) or (isinstance(v, (list, tuple)) and len(v) <= 8) or (isinstance(v, str) and len(v) <= 40))}}
     roof = out.get("roofline")
     if roof:
         r = _pick(roof, "bound", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms", "algorithmic_flop_per_launch")
@@ -1361,7 +1362,11 @@ def compact_line(out):
         s["overlap_rec_pages_per_s"] = out["overlap_rec"].get("pages_per_s")
     s["detail"] = "bench_detail.json (every leg, notes, count tables); side legs: --legs all"
     line["summary"] = s
-    return _r(line)
+    line = _r(line)
+    for k in ("value", "ms_per_step"):      # the contract's own numbers keep every digit (value == pages / time to the last bit)
+        if k in out:
+            line[k] = out[k]
+    return line
 
 
 def main(argv=None):

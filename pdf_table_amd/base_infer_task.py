@@ -46,9 +46,6 @@ class BaseInferTask(metaclass=ABCMeta):
         self._custom_model = False
         self._num_threads = kwargs.get("num_threads", math.ceil(cpu_count() / 2))
         self._infer_precision = kwargs.get("precision", "bf16")
-        # arithmetic of a generic ONNX graph (pdf_table_amd/onnx_exec.py): "fp32" / "bf16x3" select the executor's tolerance mode ((hi | lo) activations,
-        # outputs within 1e-3 of an fp32 execution); everything else, the reference's default "fp16" included, the bf16 throughput mode
-        self._exec_precision = "bf16x3" if str(self._infer_precision).lower() in ("fp32", "bf16x3", "float32") else "bf16"
         # arithmetic of the in-tree networks on an engine this task creates itself (_new_engine): the reference's "fp16" (its default,
         # base_infer_task.py:56-57 -> model.half(), utils/deploy_utils.py:227-240) is the engine's single-pass IEEE-half mode, "fp32" the
         # three-pass pair mode that holds 1e-3 against an fp32 run, anything else bf16.  A shared engine keeps the precision its owner set.

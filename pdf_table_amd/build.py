@@ -49,7 +49,46 @@ def _digest() -> str:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
     h.update(repr(FORMATS).encode())
+    # this file generates api_dispatch.cpp (dispatch_source) and decides flags and sources: a change here must rebuild the library too
+    with open(os.path.abspath(__file__), "rb") as fh:
+        h.update(fh.read())
     return h.hexdigest()
+
+
+def lint_kernel_enter() -> None:
+    """Every __global__ kernel must open with a16_kernel_enter() (csrc/act16.h: MODE.FP16_OVFL for the half format's saturating stores).  Nothing in the
+    language enforces it, so the build does: per translation unit, as many a16_kernel_enter() calls as __global__ definitions."""
+    import re
+    bad = []
+    for src in HIP_SOURCES:
+        path = os.path.join(CSRC, src)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            txt = re.sub(r"//[^\n]*", "", f.read())
+        n_k = len(re.findall(r"\b__global__\b", txt))
+        n_e = len(re.findall(r"\ba16_kernel_enter\s*\(\s*\)\s*;", txt))
+        if n_k != n_e:
+            bad.append(f"{src}: {n_k} __global__ kernels, {n_e} a16_kernel_enter() calls")
+    if bad:
+        raise RuntimeError("kernels without a16_kernel_enter() (csrc/act16.h): " + "; ".join(bad))
+
+
+def lint_dispatch() -> None:
+    """Every pt_* entry point the Python binding declares (lib.py) must have an exported definition: a generated dispatcher (the regex parser in
+    _prototypes() silently skips a header declaration it cannot match) or a compile-once definition in CPP_SOURCES."""
+    import re
+    with open(os.path.join(HERE, "lib.py")) as f:
+        wanted = set(re.findall(r"\b(pt_[a-z0-9_]+)\b", f.read()))
+    have = {name for _, name, _ in _prototypes()}
+    for src in CPP_SOURCES:
+        with open(os.path.join(CSRC, src)) as f:
+            have |= set(re.findall(r"^(?:int|void|const char\*)\s+(pt_[a-z0-9_]+)\s*\(", f.read(), flags=re.M))
+    with open(os.path.join(CSRC, HEADERS[-1])) as f:
+        declared = set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", f.read()))
+    missing = sorted(n for n in wanted & declared if n not in have)
+    if missing:
+        raise RuntimeError("entry points declared in include/pdftable_hip.h and bound in lib.py but without a dispatcher: " + ", ".join(missing))
 
 
 def _prototypes():
@@ -94,6 +133,8 @@ def dispatch_source() -> str:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    lint_kernel_enter()
+    lint_dispatch()
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(STAMP):
         with open(STAMP) as f:

@@ -441,7 +441,7 @@ struct PtProfScope {
   }
 };
 
-// a weight blob is packed for ONE storage format (weights.py: the "__act_format__" word; absent = bf16): refuse the other one loudly
+// a weight blob is packed for ONE storage format (weights.py: the "__act_f16__" tensor; absent = bf16): refuse the other one loudly
 static inline int pt_model_format_ok(const PtModel& m, const char* what) {
   if (m.act_f16 != PT_ACT_F16) {
     pt_set_error("%s: the loaded weight blob holds %s tiles but the engine computes in %s (pack it with fmt=\"%s\" / set the matching precision)", what,

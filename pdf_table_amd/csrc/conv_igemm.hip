@@ -81,7 +81,7 @@ struct ConvK {
 };
 
 // The storage format of activations and single-pass weights is act16.h's (bf16 in namespace pt_bf16, IEEE half in pt_f16); these are this
-// file's names for its conversions.  pack_bf16x2 is ONE instruction (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 behind two v_med3_f32 clamps) where
+// file's names for its conversions.  pack_bf16x2 is ONE instruction (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32; the half format saturates through MODE.FP16_OVFL, act16.h) where
 // an integer rounding takes nine -- the epilogues are VALU-bound (s_memtime phase stamps: 40 % of a short-K tile's time)
 __device__ __forceinline__ float bf16_to_f32(uint32_t bits16) { return a16_to_f32(bits16); }
 __device__ __forceinline__ uint32_t f32_to_bf16(float f) { return f32_to_a16(f); }

@@ -5,7 +5,10 @@ the HIP stream; every compute call goes through the C ABI of libpdftable_hip.so.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import functools
+import threading
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
@@ -49,6 +52,25 @@ class HipEngine:
         self._h = h
         self._tdev = torch.device("cuda", self.device)
         self.precision = L.PT_PRECISION_BF16
+        # Precision is engine-wide HOST state that every call reads when it is queued (the dispatcher picks the pt_bf16 / pt_f16 namespace and the
+        # pair layout from it).  The C ABI leaves serialising calls on one engine to the caller; this handle does it: every public method takes
+        # this re-entrant lock, and precision_scope() holds it across {set, queue the stage's calls, restore}, so that a call from another host
+        # thread (MtlStage.stream's worker, a user's own) can never be queued in somebody else's temporary precision.
+        self._lock = threading.RLock()
+
+    @contextlib.contextmanager
+    def precision_scope(self, precision: Optional[int]):
+        """``with eng.precision_scope(L.PT_PRECISION_BF16X3): eng.layout_forward(...)`` -- the calls QUEUED inside run in `precision` (None: no
+        change), the engine's own precision is back afterwards; other threads' engine calls wait outside the scope."""
+        with self._lock:
+            keep = self.precision
+            if precision is not None and int(precision) != keep:
+                self.set_precision(int(precision))
+            try:
+                yield
+            finally:
+                if self.precision != keep:
+                    self.set_precision(keep)
 
     def set_precision(self, precision: int):
         """L.PT_PRECISION_BF16 (throughput), L.PT_PRECISION_BF16X3 (fp32-class parity mode: three bf16 passes), L.PT_PRECISION_F16X2 (the
@@ -821,6 +843,21 @@ class HipEngine:
         fl = (C.c_double * 4)()
         L.check(self.lib.pt_profile_read(self._h, ms, nl, fl), "pt_profile_read")
         return {k: {"ms": ms[i], "launches": nl[i], "flop": fl[i]} for i, k in enumerate(L.PT_PROF_CLASSES)}
+
+
+
+def _serialised(fn):
+    @functools.wraps(fn)
+    def call(self, *a, **kw):
+        with self._lock:
+            return fn(self, *a, **kw)
+    return call
+
+
+# every public method of the handle queues its pt_* calls under the engine's lock (see HipEngine.__init__); close() / __del__ stay free of it
+for _name, _fn in list(vars(HipEngine).items()):
+    if callable(_fn) and not _name.startswith("_") and _name not in ("close", "precision_scope") and not isinstance(_fn, (property, staticmethod, classmethod)):
+        setattr(HipEngine, _name, _serialised(_fn))
 
 
 # ---- host-side halves of the DB post-process (no GPU needed) -------------------------------------------

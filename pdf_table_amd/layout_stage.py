@@ -106,15 +106,11 @@ class LayoutStage:
         records on a copy stream behind an event -- finish() waits for that copy only, not for whatever else has
         been queued on the compute stream meanwhile"""
         cfg = self.config
-        keep = self.eng.precision
-        if self.precision is not None and self.precision != keep:
-            self.eng.set_precision(self.precision)        # host state read when a call is queued: the launches below carry it, later calls do not
-        try:
+        # the stage's precision is host state read when a call is QUEUED: the launches below carry it, later calls do not; the scope holds the
+        # engine's lock, so no other host thread can queue a call in this stage's precision meanwhile
+        with self.eng.precision_scope(self.precision):
             counts, cands = self.eng.layout_forward(pages, cfg.img_height, cfg.img_width, len(cfg.labels),
                                                     thr_lo=cfg.score_threshold - 1e-3, max_cands=self.max_cands)
-        finally:
-            if self.eng.precision != keep:
-                self.eng.set_precision(keep)
         n = counts.shape[0]
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=counts.device)

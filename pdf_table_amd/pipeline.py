@@ -287,20 +287,41 @@ class OcrTablePipeline:
         return tb
 
     @staticmethod
-    def _drop_empty_crops(tb: Sequence[np.ndarray], shape) -> List[np.ndarray]:
+    def _drop_empty_crops(tb: Sequence[np.ndarray], shape, kept: Optional[list] = None) -> List[np.ndarray]:
         """table boxes whose crop is empty once clamped to the page are dropped ONE BY ONE, each with a log line -- the reference contains a failed
         crop the same way (ocr_system_task.py:275-283 turns a failing line crop into ''); every other error of the table stage propagates
-        (an ``except ValueError`` around the whole batch used to swallow the engine wrappers' own shape errors: ADVICE r04)"""
+        (an ``except ValueError`` around the whole batch used to swallow the engine wrappers' own shape errors: ADVICE r04).
+        ``kept`` (a list to fill): per page, the indices of the boxes that stay -- _realign_tables() uses them to hand CALLER-supplied
+        ``table_boxes`` their results index-aligned, with None where a box was dropped."""
         ph, pw = int(shape[0]), int(shape[1])
         out = []
         for pi, boxes in enumerate(tb):
             b = np.asarray(boxes).reshape(-1, 4)
+            idx, n_in = np.arange(len(b)), len(b)
             if len(b):
                 ok = (np.minimum(b[:, 2], pw) > np.maximum(b[:, 0], 0)) & (np.minimum(b[:, 3], ph) > np.maximum(b[:, 1], 0))
                 for bad in b[~ok]:
                     logger.warning("table region %s of page %d of the batch is empty on a %dx%d page: skipped", bad.tolist(), pi, ph, pw)
-                b = b[ok]
+                b, idx = b[ok], idx[ok]
             out.append(b)
+            if kept is not None:
+                kept.append((idx, n_in))
+        return out
+
+    @staticmethod
+    def _realign_tables(tsr, kept):
+        """per-page table results -> lists as long as the caller's ``table_boxes[page]``, result j at the position of box j, None for a dropped box"""
+        if tsr is None or kept is None:
+            return tsr
+        out = []
+        for page_res, (idx, n_in) in zip(tsr, kept):
+            if len(idx) == n_in:
+                out.append(page_res)
+                continue
+            row = [None] * n_in
+            for j, res in zip(idx.tolist(), page_res):
+                row[j] = res
+            out.append(row)
         return out
 
     def predict_stream(self, batches, table_boxes=None):
@@ -410,7 +431,8 @@ class OcrTablePipeline:
             t1 = time.perf_counter()
             host["second.rec_start"] = host.get("second.rec_start", 0.0) + t1 - t0
             if staged_tsr:
-                tb = self._drop_empty_crops(st["tb"] if st["tb"] is not None else self._layout_table_boxes(st["layout"]), st["shape"])
+                st["kept"] = [] if st["tb"] is not None else None      # caller-supplied boxes: results go back index-aligned (collect)
+                tb = self._drop_empty_crops(st["tb"] if st["tb"] is not None else self._layout_table_boxes(st["layout"]), st["shape"], st["kept"])
                 st["tb"] = tb
                 tables, metas = tsr_stage.tables(st["shape"], tb)
                 offs = np.stack([tables["x0"], tables["y0"]], 1).astype(np.float32) if len(tables) else None
@@ -457,7 +479,8 @@ class OcrTablePipeline:
             host["collect.texts"] = host.get("collect.texts", 0.0) + t1 - t0
             tsr = None
             if tsr_stage is not None and not staged_tsr:
-                tb = self._drop_empty_crops(st["tb"] if st["tb"] is not None else self._layout_table_boxes(st["layout"]), st["shape"])
+                st["kept"] = [] if st["tb"] is not None else None
+                tb = self._drop_empty_crops(st["tb"] if st["tb"] is not None else self._layout_table_boxes(st["layout"]), st["shape"], st["kept"])
                 st["tb"] = tb
                 # a table stage without start / process / collect halves (MtlTabNet) decodes synchronously and polls its stream every few steps;
                 # on the main stream every poll would wait for the detection / recognition work of the NEXT batches already queued there and
@@ -480,6 +503,7 @@ class OcrTablePipeline:
                 tsr = tsr_stage.regroup(flat, st["tb"])
             if tsr is not None and self.table_html:
                 self._attach_html(tsr, st["tb"], st["boxes"], texts)
+            tsr = self._realign_tables(tsr, st.get("kept"))
             out = []
             for k in range(st["n"]):
                 boxes = st["boxes"][k]

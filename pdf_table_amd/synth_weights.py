@@ -14,6 +14,7 @@ numpy's Generator is used (not torch's RNG) so the stream does not depend on the
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -543,8 +544,11 @@ def lore_dla34_state_dict(seed: int = 0, hm_bias=(-6.0, -5.0), hm_gain: float = 
     return g.sd
 
 
-def lore_processor_state_dict(seed: int = 0, layers: int = 4, stacking_layers: int = 4):
-    """state_dict of ``LoreProcessModel`` (lore/lore_processor.py:399-437): stacker + tsfm_axis + 2 position tables."""
+def lore_processor_state_dict(seed: int = 0, layers: int = 4, stacking_layers: int = 4, conditioned: bool = False):
+    """state_dict of ``LoreProcessModel`` (lore/lore_processor.py:399-437): stacker + tsfm_axis + 2 position tables.
+    ``conditioned`` (seed 3 only): the stacker's last Linear(256 -> 4) comes from ``data/lore_synth_processor_head.npz``, fitted by
+    ``tools/fit_lore_processor.py`` so that the logical locations of the end-to-end fixture's tables are near-integers like a trained model's (a seeded
+    random layer emits arbitrary reals: two of the fixture's three tables had a location 5.6e-5 from the .5 rounding boundary) -- a workload device."""
     g = _Gen(seed)
 
     def norm(p, d):
@@ -578,6 +582,12 @@ def lore_processor_state_dict(seed: int = 0, layers: int = 4, stacking_layers: i
     transformer("tsfm_axis", 256, 256, 4, layers)
     g.put("x_position_embeddings.weight", g.rng.standard_normal((256, 256)))
     g.put("y_position_embeddings.weight", g.rng.standard_normal((256, 256)))
+    if conditioned:
+        if seed != 3 or layers != 4 or stacking_layers != 4:
+            raise ValueError("lore_synth_processor_head.npz was fitted on lore_processor_state_dict(seed=3) with 4 + 4 layers")
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "lore_synth_processor_head.npz"))
+        g.sd["stacker.tsfm.decoder.linear.2.weight"] = torch.from_numpy(z["weight"].astype(np.float32))
+        g.sd["stacker.tsfm.decoder.linear.2.bias"] = torch.from_numpy(z["bias"].astype(np.float32))
     return g.sd
 
 
@@ -826,7 +836,8 @@ def conditioned_state_dicts():
     timed is what the parity assertions run on: the detector with the hand-built text channel (its boxes feed the recogniser),
     the recogniser with the fitted classifier (trained-like arg-max margins), the layout net with the head branch fitted to the generator's pages (its
     "table" regions feed the table stage), the Lore detector with the heat-map bias that yields cells and DCN offsets of ~0.07 px (a random DLA-34
-    with 16 stacked DCNs at the default ~0.3 px is chaotic in fp32 itself: DESIGN.md numerics), the seeded Lore processor."""
+    with 16 stacked DCNs at the default ~0.3 px is chaotic in fp32 itself: DESIGN.md numerics), the Lore processor with the last Linear fitted to
+    near-integer logical locations on the fixture's tables (tools/fit_lore_processor.py)."""
     return {"db": db_resnet18_state_dict(seed=0, text_signal=True), "crnn": crnn_state_dict(seed=1, conditioned=True),
             "pico": picodet_state_dict(seed=4, num_classes=5, table_head=True),
-            "lore": lore_dla34_state_dict(seed=2, dcn_gain=0.02, hm_bias=(-2.0, -2.0), hm_gain=0.25), "proc": lore_processor_state_dict(seed=3)}
+            "lore": lore_dla34_state_dict(seed=2, dcn_gain=0.02, hm_bias=(-2.0, -2.0), hm_gain=0.25), "proc": lore_processor_state_dict(seed=3, conditioned=True)}

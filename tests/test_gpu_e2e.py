@@ -200,7 +200,9 @@ def test_table_cells_logical_locations_and_html(run):
             else:
                 assert neq.sum() <= max(2, neq.size // 50)
     print(f"e2e tables: HTML compared for {html_checked} table(s)")
-    assert html_checked >= 1, "the fixture's pages are chosen so that at least one table's HTML equals the oracle chain's"
+    # all three tables: since round 6 the processor's last Linear is fitted to near-integer logical locations (tools/fit_lore_processor.py: the closest
+    # location sits 0.25 from the .5 rounding boundary; a seeded random layer had two tables 5.6e-5 from it), so the 1e-3 mode must give the oracle's HTML
+    assert html_checked == 3, f"HTML identical to the oracle chain's for {html_checked} of 3 tables"
 
 
 def test_predict_stream_yields_the_same_pages(run):
@@ -231,7 +233,7 @@ def test_headline_mode_agreement(run):
         print(f"E2E AGREEMENT {mode}: " + json.dumps(a["frac"]))
         print(f"E2E AGREEMENT {mode} counts: " + json.dumps({k: v for k, v in a.items() if k != "frac"}))
     fx, fb, fh, fhc = out["bf16x3"]["frac"], out["bf16"]["frac"], out["f16"]["frac"], out["f16_oracle_crops"]["frac"]
-    assert fx["tables_html_identical"] >= 0.33          # at least one table whose HTML is the oracle chain's own string
+    assert fx["tables_html_identical"] == 1.0           # every table's HTML is the oracle chain's own string
     # PT_PRECISION_F16: floors under the measured values (profiles/r05/e2e_agreement.txt).  The chained cell figure is dominated by ONE decision: a layout
     # box that rounds a pixel differently is a different crop, and a random-init Lore net is not shift-robust -- given the oracle's crops f16 finds its cells
     assert fh["boxes_within_2px"] >= 0.98 and fh["strings_identical_on_2px_quads"] >= 0.8

@@ -102,3 +102,43 @@ def test_stages_on_two_streams_equal_sequential():
                 assert np.array_equal(l1.cpu().numpy()[t, :k], l0.cpu().numpy()[t, :k])
     finally:
         e.close()
+
+
+def test_precision_scope_serialises_other_threads_calls():
+    """A stage may run in its own precision for the calls IT queues (LayoutStage.precision -> HipEngine.precision_scope).  Precision is engine-wide host
+    state: while one host thread holds a scope, another thread's engine calls must wait -- never be queued in the temporary precision (ADVICE r05:
+    wrong kernel namespace / (hi | lo) layout at best a format-guard error, at worst 4-channel tensors read as 8-channel).  Here a second thread flips
+    the precision in a tight loop while this thread runs the recogniser: every result equals the undisturbed one bit for bit."""
+    import threading
+    import time
+    g = torch.Generator().manual_seed(9)
+    gray = (torch.rand(64, L.PT_REC_H, L.PT_REC_W, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    e = _engine(6)
+    try:
+        ids0, mx0 = e.rec_forward_net(gray)
+        torch.cuda.synchronize()
+        ids0, mx0 = ids0.cpu().numpy(), mx0.cpu().numpy()
+        stop = threading.Event()
+        flips = [0]
+
+        def flipper():
+            while not stop.is_set():
+                with e.precision_scope(L.PT_PRECISION_BF16X3):
+                    assert e.precision == L.PT_PRECISION_BF16X3
+                    time.sleep(0.0005)       # another stage's calls would be queued here
+                    flips[0] += 1
+        th = threading.Thread(target=flipper, daemon=True)
+        th.start()
+        try:
+            for _ in range(20):
+                assert e.precision in (L.PT_PRECISION_BF16, L.PT_PRECISION_BF16X3)
+                ids, mx = e.rec_forward_net(gray)      # takes the engine's lock: runs in the engine's own precision
+                torch.cuda.synchronize()
+                assert np.array_equal(ids.cpu().numpy(), ids0) and np.array_equal(mx.cpu().numpy(), mx0)
+        finally:
+            stop.set()
+            th.join(timeout=10)
+        assert flips[0] > 0 and e.precision == L.PT_PRECISION_BF16
+        e.check()
+    finally:
+        e.close()

@@ -324,7 +324,7 @@ def test_fullsize_lore_oracle_parity(eng_par, pages, mode):
     assert worst <= (X3_TOL if mode == "bf16x3" else 0.03 if mode == "f16" else 0.2)      # bf16: measured 0.04 .. 0.13 of the head scale (reg, the smallest head)
 
 
-@pytest.mark.parametrize("mode", ["bf16x3"])
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])      # bf16: a loose bound (0.6 of the head scale; r03 measured 0.4) keeps the stressier net under a test
 def test_fullsize_lore_default_gain_drift(pages, mode):
     """The SAME table through the UNCONDITIONED synthetic net (lore_dla34_state_dict(seed=2), dcn_gain = 0.1: offsets of ~0.3 px -- what bench.py timed
     until round 4; it now times the conditioned net asserted above): recorded and bounded.  The oracle itself is ill-conditioned on this random net (see eng_par: a 1e-5 relative input perturbation moves

@@ -235,3 +235,17 @@ def test_page_table_html_uses_one_coordinate_frame():
         assert row.endswith(f">test_textr{i // 3}c{i % 3}</td>"), row   # Cell.text appends to the structure stage's "test_text"
     wrong, _ = page_table_html(polys, logi, box, quads, texts)          # crop-relative quads against page-frame text
     assert [r for r in wrong if r.startswith("<td")] != tds
+
+
+def test_dropped_table_boxes_keep_the_callers_indexing():
+    """A degenerate caller-supplied table box is skipped with a log line; the page's table results stay index-aligned with the caller's list
+    (None at the dropped position) instead of silently shifting."""
+    import numpy as np
+    from pdf_table_amd.pipeline import OcrTablePipeline
+    tb = [np.array([[10, 10, 200, 120], [300, 50, 300, 90], [40, 400, 500, 700]]), np.zeros((0, 4), np.int64), np.array([[5, 5, 60, 60]])]
+    kept = []
+    out = OcrTablePipeline._drop_empty_crops(tb, (1024, 1024), kept)
+    assert [len(b) for b in out] == [2, 0, 1]
+    tsr = [["t0", "t2"], [], ["u0"]]
+    assert OcrTablePipeline._realign_tables(tsr, kept) == [["t0", None, "t2"], [], ["u0"]]
+    assert OcrTablePipeline._realign_tables(tsr, None) is tsr

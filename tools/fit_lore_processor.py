@@ -1,0 +1,125 @@
+"""tools/fit_lore_processor.py [ridge] [out.npz]: conditions the LAST Linear(256 -> 4) of the synthetic Lore processor's stacker so that its logical
+locations look like a trained model's -- near-integers.
+
+A seeded random processor emits arbitrary reals; `process_logic_output` rounds them at .5 (lineless_table_process.py:658-663), and on the end-to-end
+fixture two of three tables carried a location 5.6e-5 from the oracle's own boundary: no arithmetic, however close to fp32, can be asserted to give the
+oracle's HTML there.  A trained LORE regresses integer row / column indices, i.e. values that sit far from .5.  This script keeps everything else of
+lore_processor_state_dict(seed=3) -- both transformers, the logic encoder, the decoder's first Linear -- runs the fp32 CPU oracle chain over the tables
+of the fixture's pages (tests/e2e_synth.E2E_PAGES, the layout stage's own regions) up to the decoder's hidden layer h = relu(linear.0(x)) [n, 256], and
+fits (W [4, 256], b [4]) to targets = the integers the UNFITTED processor's outputs round to (the table structure the fixture already has):
+squared error where the integer is positive, one-sided where it is 0 (a ReLU follows), ridge on W; L-BFGS, seconds after the oracle's DLA-34 passes.
+
+What it is: a WORKLOAD DEVICE, like tools/fit_crnn_classifier.py and tools/fit_layout_head.py -- it memorises these tables.  What it buys: the distance
+of every logical location to the rounding boundary (printed: before / after), which is what decides whether a 1e-3 difference changes a table's HTML.
+Output: pdf_table_amd/data/lore_synth_processor_head.npz; lore_processor_state_dict(conditioned=True) overlays it."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+from oracle import lore_decode as od, lore_net, lore_pre, lore_processor as lp    # noqa: E402
+from oracle import picodet as opico                                                 # noqa: E402
+import torch.nn.functional as F                                                     # noqa: E402
+from pdf_table_amd.synth_pages import make_page                                      # noqa: E402
+from pdf_table_amd.synth_weights import conditioned_state_dicts, lore_processor_state_dict   # noqa: E402
+
+
+def table_regions(page, sds):
+    """the layout stage's own 'table' regions of a page, as oracle/e2e.page_chain derives them"""
+    xl, sf = opico.picodet_preprocess(page)
+    with torch.no_grad():
+        sc, bd = opico.picodet_forward(sds["pico"], torch.from_numpy(xl)[None], 5)
+    lay = opico.picodet_postprocess([s.numpy() for s in sc], [b.numpy() for b in bd], list(page.shape[:2]), sf, [800, 608], opico.LABELS["en"])
+    tabs = sorted((it for it in lay if it["label"].lower() == "table" and it["score"] >= 0.2), key=lambda it: it["bbox"][1])
+    tb = [[round(float(v)) for v in it["bbox"]] for it in tabs]
+    return [b for b in tb if b[2] > b[0] and b[3] > b[1]]
+
+
+def hidden(psd, logi):
+    """decoder hidden layer of the stacker's transformer (oracle/lore_processor.py:48-65): relu(decoder.linear.0(.)) [n, 256], and its 4 outputs"""
+    logic = lp.transformer(psd, "tsfm_axis", logi, 4)
+    le = F.relu(lp._lin(psd, "stacker.logi_encoder.2", F.relu(lp._lin(psd, "stacker.logi_encoder.0", logic))))
+    x = torch.cat((le, logi), dim=2)
+    p = "stacker.tsfm"
+    x = lp._lin(psd, p + ".linear", x)
+    for i in range(4):
+        x = lp.encoder_layer(psd, f"{p}.encoder.layers.{i}", x)
+    h = F.relu(lp._lin(psd, p + ".decoder.linear.0", x))
+    return h[0], F.relu(lp._lin(psd, p + ".decoder.linear.2", h))[0]
+
+
+def main():
+    from e2e_synth import E2E_PAGES
+    ridge = float(sys.argv[1]) if len(sys.argv) > 1 else 1e-4
+    out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(REPO, "pdf_table_amd", "data", "lore_synth_processor_head.npz")
+    torch.set_num_threads(os.cpu_count() or 1)
+    sds = conditioned_state_dicts()
+    psd = lore_processor_state_dict(seed=3)            # the UNFITTED processor: its outputs define the targets
+    hs, ys = [], []
+    cache = os.environ.get("PT_FIT_CACHE")             # optional: the oracle's hidden layers of a previous run (ridge sweeps)
+    if cache and os.path.exists(cache):
+        c = np.load(cache)
+        hs, ys = [c["H"]], [c["Y"]]
+    with torch.no_grad():
+        for idx in ([] if hs else E2E_PAGES):
+            page = make_page(idx, 1024)[0]
+            for b in table_regions(page, sds):
+                x1, y1, x2, y2 = (int(v) for v in b)
+                x, meta = lore_pre.lore_preprocess(np.ascontiguousarray(page[y1:y2, x1:x2][:, :, ::-1]), 1024, 1024)
+                z = lore_net.dlaseg_forward(sds["lore"], x)
+                logi = od.process_detect_output(z, meta, wiz_rev=True, vis_thresh=0.2, return_raw=True)[0]
+                if logi.shape[1] == 0:
+                    continue
+                h, y = hidden(psd, logi)
+                hs.append(h.double().numpy())
+                ys.append(y.double().numpy())
+                print(f"page {idx} table {b}: {logi.shape[1]} cells")
+    H, Y = np.concatenate(hs), np.concatenate(ys)
+    if cache and not os.path.exists(cache):
+        np.savez(cache, H=H, Y=Y)
+    frac = Y - np.floor(Y)
+    T = np.where(frac > 0.5, np.floor(Y) + 1, np.floor(Y))                 # process_logic_output's integers: the structure the fixture has
+    dist0 = np.abs(frac - 0.5)
+    # Fit (W [4, 256], b [4]) on standardised features: squared error to the integer where the target is positive, a one-sided penalty
+    # relu(pre + 0.25)^2 where it is 0 (the ReLU behind this layer makes every negative pre-activation a 0), plus `ridge` on W.  The hidden
+    # layer has rank 217 over these 299 cells, so an exact interpolation of every integer does not exist; L-BFGS in float64, seconds.
+    n = len(H)
+    Ht, Tt = torch.tensor(H), torch.tensor(T)
+    mu, sd = Ht.mean(0), Ht.std(0) + 1e-6
+    Hn, pos = (Ht - mu) / sd, Tt > 0
+    Wn = torch.zeros(4, H.shape[1], dtype=torch.float64, requires_grad=True)
+    bn = torch.zeros(4, dtype=torch.float64, requires_grad=True)
+    opt = torch.optim.LBFGS([Wn, bn], lr=1.0, max_iter=2000, history_size=100, line_search_fn="strong_wolfe", tolerance_grad=1e-12, tolerance_change=1e-14)
+
+    def closure():
+        opt.zero_grad()
+        pre = Hn @ Wn.T + bn
+        loss = torch.where(pos, (pre - Tt) ** 2, torch.relu(pre + 0.25) ** 2).mean() + ridge * (Wn ** 2).mean()
+        loss.backward()
+        return loss
+    for _ in range(5):
+        opt.step(closure)
+    W = (Wn.detach() / sd).numpy()                                        # on the raw hidden layer
+    b = (bn.detach() - (Wn.detach() / sd) @ mu).numpy()
+    P = np.maximum(H @ W.T + b, 0.0)
+    fp = P - np.floor(P)
+    dist1 = np.abs(fp - 0.5)
+    same = (np.where(fp > 0.5, np.floor(P) + 1, np.floor(P)) == T).all()
+    w0 = psd["stacker.tsfm.decoder.linear.2.weight"].numpy()
+    print(f"{n} cells, ridge {ridge:g}: distance of a logical location to the .5 boundary  before: min {dist0.min():.2e} 5th pct {np.percentile(dist0, 5):.3f}"
+          f"   after: min {dist1.min():.3f} 5th pct {np.percentile(dist1, 5):.3f}; max |fit - integer| {np.abs(P - T).max():.3f}; same integers: {same}")
+    rng = np.random.default_rng(0)
+    moved = np.abs((H * (1e-3 * rng.standard_normal(H.shape))) @ W.T).max()
+    print(f"|W| fitted {np.linalg.norm(W):.2f} (seeded {np.linalg.norm(w0):.2f}); a 1e-3 relative Gaussian perturbation of h moves an output by <= {moved:.3f}")
+    assert same, "the fit changed a logical location: lower the ridge"
+    np.savez(out, weight=W.astype(np.float32), bias=b.astype(np.float32), ridge=np.float64(ridge), cells=np.int64(n),
+             min_dist_before=np.float64(dist0.min()), min_dist_after=np.float64(dist1.min()))
+    print("wrote", out)
+
+
+if __name__ == "__main__":
+    main()
