@@ -79,6 +79,9 @@ struct PtArena {
   }
 };
 
+// Capacity an arena is (re)allocated with: its high-water mark plus 1 MiB of slack
+static inline size_t pt_arena_round(size_t high) { return high + (1u << 20); }
+
 // Pinned host staging for small per-call tables (token maps, tile lists) that are the SOURCE of an asynchronous host-to-device copy:
 // a stack vector dies before a deferred copy reads it, and waiting for the copy means a stream synchronise per call.  A slot is
 // re-used only after the event recorded behind its copy has completed (the wait is real only if the ring wrapped with work pending).

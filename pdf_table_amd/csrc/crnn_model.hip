@@ -117,7 +117,7 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
     PT_HIP_CHECK(hipDeviceSynchronize());
     if (e->arenas[PT_ARENA_REC].base) PT_HIP_CHECK(hipFree(e->arenas[PT_ARENA_REC].base));
     e->arenas[PT_ARENA_REC].base = nullptr;
-    const size_t want = e->arenas[PT_ARENA_REC].high + (1u << 20);
+    const size_t want = pt_arena_round(e->arenas[PT_ARENA_REC].high);
     PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arenas[PT_ARENA_REC].base), want));
     e->arenas[PT_ARENA_REC].cap = want;
   }

@@ -742,7 +742,7 @@ int forward_batch(pt_engine* e, const PtModel& M, const float* gray, int pitch, 
     PT_HIP_CHECK(hipDeviceSynchronize());
     if (A.base) PT_HIP_CHECK(hipFree(A.base));
     A.base = nullptr;
-    const size_t want = A.high + (1u << 20);
+    const size_t want = pt_arena_round(A.high);
     PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&A.base), want));
     A.cap = want;
   }

@@ -186,7 +186,7 @@ int pt_dbnas_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, flo
       PT_HIP_CHECK(hipDeviceSynchronize());
       if (e->arenas[PT_ARENA_DET].base) PT_HIP_CHECK(hipFree(e->arenas[PT_ARENA_DET].base));
       e->arenas[PT_ARENA_DET].base = nullptr;
-      const size_t want = e->arenas[PT_ARENA_DET].high + (1u << 20);
+      const size_t want = pt_arena_round(e->arenas[PT_ARENA_DET].high);
       PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arenas[PT_ARENA_DET].base), want));
       e->arenas[PT_ARENA_DET].cap = want;
       continue;

@@ -238,7 +238,7 @@ int pt_picodet_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, f
       PT_HIP_CHECK(hipDeviceSynchronize());
       if (e->arenas[PT_ARENA_LAYOUT].base) PT_HIP_CHECK(hipFree(e->arenas[PT_ARENA_LAYOUT].base));
       e->arenas[PT_ARENA_LAYOUT].base = nullptr;
-      const size_t want = e->arenas[PT_ARENA_LAYOUT].high + (1u << 20);
+      const size_t want = pt_arena_round(e->arenas[PT_ARENA_LAYOUT].high);
       PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arenas[PT_ARENA_LAYOUT].base), want));
       e->arenas[PT_ARENA_LAYOUT].cap = want;
       continue;
@@ -311,7 +311,7 @@ int pt_pplcnet_forward_net(pt_engine* e, int slot, const bf16_t* x, int n, int H
       PT_HIP_CHECK(hipDeviceSynchronize());
       if (e->arenas[PT_ARENA_LAYOUT].base) PT_HIP_CHECK(hipFree(e->arenas[PT_ARENA_LAYOUT].base));
       e->arenas[PT_ARENA_LAYOUT].base = nullptr;
-      const size_t want = e->arenas[PT_ARENA_LAYOUT].high + (1u << 20);
+      const size_t want = pt_arena_round(e->arenas[PT_ARENA_LAYOUT].high);
       PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arenas[PT_ARENA_LAYOUT].base), want));
       e->arenas[PT_ARENA_LAYOUT].cap = want;
       continue;

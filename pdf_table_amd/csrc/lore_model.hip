@@ -367,7 +367,7 @@ static int lore_dla_run(pt_engine* e, const bf16_t* x, int n, int H, int W, floa
       PT_HIP_CHECK(hipDeviceSynchronize());
       if (e->arenas[PT_ARENA_TSR].base) PT_HIP_CHECK(hipFree(e->arenas[PT_ARENA_TSR].base));
       e->arenas[PT_ARENA_TSR].base = nullptr;
-      const size_t want = e->arenas[PT_ARENA_TSR].high + (1u << 20);
+      const size_t want = pt_arena_round(e->arenas[PT_ARENA_TSR].high);
       PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arenas[PT_ARENA_TSR].base), want));
       e->arenas[PT_ARENA_TSR].cap = want;
       continue;
@@ -537,7 +537,7 @@ int pt_lore_wireless_forward_net(pt_engine* e, const bf16_t* x, int n, int H, in
       PT_HIP_CHECK(hipDeviceSynchronize());
       if (e->arenas[PT_ARENA_TSR].base) PT_HIP_CHECK(hipFree(e->arenas[PT_ARENA_TSR].base));
       e->arenas[PT_ARENA_TSR].base = nullptr;
-      const size_t want = e->arenas[PT_ARENA_TSR].high + (1u << 20);
+      const size_t want = pt_arena_round(e->arenas[PT_ARENA_TSR].high);
       PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->arenas[PT_ARENA_TSR].base), want));
       e->arenas[PT_ARENA_TSR].cap = want;
       continue;

@@ -195,7 +195,7 @@ int pt_mtl_backbone_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int
     PT_HIP_CHECK(hipDeviceSynchronize());
     if (A.base) PT_HIP_CHECK(hipFree(A.base));
     A.base = nullptr;
-    const size_t want = A.high + (1u << 20);
+    const size_t want = pt_arena_round(A.high);
     PT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&A.base), want));
     A.cap = want;
   }

@@ -15,6 +15,7 @@ import ctypes as C
 
 import numpy as np
 import torch
+from .streams import shared_stream
 
 from . import engine as E
 from . import lib as L
@@ -129,7 +130,7 @@ class DetStage:
         # high-priority workgroups slowed the compute stream by 10 %.  A detection-only loop calls boxes(k-1) AFTER forward(k): there the
         # early copy of batch k would make the scores of batch k-1 wait for detection k, and nothing else is queued: early_copy=False.
         if self.side is None:
-            self.side = torch.cuda.Stream(device=pages.device, priority=-1)
+            self.side = shared_stream(pages.device, "det_side", priority=-1)
         hb = self._pinned(("bm", slot), bitmap.shape, torch.int32)
         with torch.cuda.stream(self.side):
             self.side.wait_event(ev)
@@ -156,7 +157,7 @@ class DetStage:
             # compute stream holds one or two batches of queued kernels; on a normal-priority stream they could land on a hardware queue
             # shared with that backlog and sit behind it (measured: 20 ms vs 60 ms per 64 pages in this call, bimodal from run to run --
             # the difference between 490 and 580 pages/s through predict_stream)
-            self.side = torch.cuda.Stream(device=prob.device, priority=-1)
+            self.side = shared_stream(prob.device, "det_side", priority=-1)
         import time as _t
         tm = self.__dict__.setdefault("timing", {"copy": 0.0, "cand": 0.0, "score": 0.0, "final": 0.0})
         t0 = _t.perf_counter()
@@ -164,7 +165,7 @@ class DetStage:
             ev, done, hb = ev
             done.synchronize()
             if self.side is None:
-                self.side = torch.cuda.Stream(device=prob.device, priority=-1)
+                self.side = shared_stream(prob.device, "det_side", priority=-1)
         else:
             hb = self._pinned("bm", bitmap.shape, torch.int32)
             with torch.cuda.stream(self.side):

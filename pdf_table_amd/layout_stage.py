@@ -14,6 +14,7 @@ from typing import Optional, Dict, List, Sequence
 
 import numpy as np
 import torch
+from .streams import shared_stream
 
 from . import lib as L
 from .engine import HipEngine
@@ -113,7 +114,7 @@ class LayoutStage:
                                                     thr_lo=cfg.score_threshold - 1e-3, max_cands=self.max_cands)
         n = counts.shape[0]
         if self._copy_stream is None:
-            self._copy_stream = torch.cuda.Stream(device=counts.device)
+            self._copy_stream = shared_stream(counts.device, "layout_copy")
         slot = self._turn
         self._turn ^= 1
         if self._pinned[slot] is None or self._pinned[slot][0].shape[0] < n:

@@ -25,6 +25,7 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
+from .streams import shared_stream
 
 from .det_stage import DetConfig, DetStage, sort_boxes_reading_order
 from .engine import HipEngine
@@ -214,7 +215,7 @@ class OcrTablePipeline:
             side = None
             if self.overlap_rec and (self.layout_task is not None or self.table_structure_task is not None):
                 if self._rec_stream is None:
-                    self._rec_stream = torch.cuda.Stream(device=self.engine._tdev)
+                    self._rec_stream = shared_stream(self.engine._tdev, "rec")
                     self.engine.set_lstm_cluster(False)      # the recogniser now shares the GPU with the other stages
                 side = self._rec_stream
                 side.wait_stream(torch.cuda.current_stream(self.engine._tdev))
@@ -352,11 +353,11 @@ class OcrTablePipeline:
         dev = self.engine._tdev
         main = torch.cuda.current_stream(dev)
         if self.overlap_rec and self._rec_stream is None:
-            self._rec_stream = torch.cuda.Stream(device=dev)
+            self._rec_stream = shared_stream(dev, "rec")
             self.engine.set_lstm_cluster(False)      # the recogniser shares the GPU with the other stages (see __init__)
         need_aux = bool(getattr(self, "aux_layout", False) or getattr(self, "tsr_on_aux", False))
         if need_aux and getattr(self, "_aux_stream", None) is None:      # every extra stream competes for the few hardware queues
-            self._aux_stream = torch.cuda.Stream(device=dev)
+            self._aux_stream = shared_stream(dev, "aux")
         # overlap_rec=False: the recogniser stays on the main stream behind detection (weight-stationary cluster LSTM, the GPU
         # to itself) -- with nothing in this schedule waiting on the newest work, that measures faster than sharing the CUs
         rec_s, aux = (self._rec_stream if self.overlap_rec else main), getattr(self, "_aux_stream", None)
@@ -376,7 +377,7 @@ class OcrTablePipeline:
                 # host batch: H2D on a copy stream, queued NOW -- the enqueue thread runs ahead of the GPU, so the transfer overlaps the
                 # compute of the batches before it (asynchronous when the batch is pinned; a pageable batch is staged by the runtime)
                 if getattr(self, "_copy_stream", None) is None:
-                    self._copy_stream = torch.cuda.Stream(device=dev)
+                    self._copy_stream = shared_stream(dev, "h2d")
                 with torch.cuda.stream(self._copy_stream):
                     pages_t = batch.to(dev, non_blocking=batch.is_pinned())
                 up.record(self._copy_stream)
@@ -486,7 +487,7 @@ class OcrTablePipeline:
                 # on the main stream every poll would wait for the detection / recognition work of the NEXT batches already queued there and
                 # the software pipeline would run serially.  It gets its own stream behind this batch's upload instead.
                 if getattr(self, "_table_stream", None) is None:
-                    self._table_stream = torch.cuda.Stream(device=dev)
+                    self._table_stream = shared_stream(dev, "table")
                 ts = self._table_stream
                 with torch.cuda.stream(ts):
                     ts.wait_event(st["uploaded"])

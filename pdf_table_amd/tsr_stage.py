@@ -16,6 +16,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
+from .streams import shared_stream
 
 from . import lib as L
 from .engine import TSR_TABLE_DTYPE, HipEngine
@@ -241,7 +242,7 @@ class TsrStage:
         if not staged:
             return [], None
         if self._copy_stream is None:
-            self._copy_stream = torch.cuda.Stream(device=staged[0][3].device)
+            self._copy_stream = shared_stream(staged[0][3].device, "tsr_copy")
         ready = torch.cuda.Event()
         ready.record()
         host = []
