@@ -1314,7 +1314,7 @@ def compact_line(out):
     roof = out.get("roofline")
     if roof:
         r = _pick(roof, "bound", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms", "algorithmic_flop_per_launch")
-        r["kernel"] = "3x3 implicit-GEMM convs (conv_igemm_kernel<3,*>, conv3x3_dma16_kernel, conv3x3_ws64_kernel)"
+        r["kernel"] = "3x3 implicit-GEMM convs (conv3x3_pipe_kernel, conv3x3_ws64_kernel, conv3x3_dma16_kernel, conv_igemm_kernel<3,*>)"
         db = roof.get("det_backbone")
         if isinstance(db, dict):
             r["det_backbone"] = {**_pick(db, "frac", "pages_per_s_det_only", "gflop_per_page", "error"),
@@ -1467,14 +1467,14 @@ def main(argv=None):
                     pm = json.load(f)
                 tot = nl = 0.0
                 for kname, rec_ in pm.items():       # every 3x3 conv kernel variant, launch-weighted
-                    if ("conv_igemm_kernel<3," in kname or "conv3x3_dma" in kname) and "hbm_bytes_per_launch" in rec_:
+                    if ("conv_igemm_kernel<3," in kname or "conv3x3_dma" in kname or "conv3x3_pipe" in kname or "conv3x3_ws64" in kname) and "hbm_bytes_per_launch" in rec_:
                         n_ = rec_["FETCH_SIZE"]["dispatches"]
                         tot += rec_["hbm_bytes_per_launch"] * n_
                         nl += n_
                 traffic = tot / nl if nl else None
             except Exception:
                 traffic = None
-            roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<3,*> / conv3x3_dma16_kernel / conv3x3_ws64_kernel (3x3 implicit-GEMM convolutions of all stages)",
+            roof = {"bound": "mfma", "kernel": "conv3x3_pipe_kernel / conv3x3_ws64_kernel / conv3x3_dma16_kernel / conv_igemm_kernel<3,*> (3x3 implicit-GEMM convolutions of all stages)",
                     "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
                     "traffic": traffic, "traffic_note": "bytes/launch over the 3x3 conv kernels, PMC passes of profiles/pmc_latest.json "
                                                         "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",

@@ -1120,7 +1120,9 @@ __device__ __forceinline__ void tap_groups() {
     if constexpr (i < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     if constexpr (i >= NR && i - NR < ND) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
   });
-  static_assert(NR + ND <= NM, "more memory requests than MFMAs to hide them behind");
+  // (more requests than MFMAs to hide them behind -- the stride-2 tile's 4 MFMAs per tap: the rest follow the last MFMA)
+  if constexpr (NR > NM) __builtin_amdgcn_sched_group_barrier(0x100, NR - NM, 0);
+  if constexpr (NR + ND > NM) __builtin_amdgcn_sched_group_barrier(0x020, NR >= NM ? ND : NR + ND - NM, 0);
 #else
   if constexpr (NR > 0) __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
   __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
@@ -1132,16 +1134,21 @@ __device__ __forceinline__ void tap_groups() {
 // pixels) and its own (image, first column).  BR == TH (0 = default) is the ordinary tile.  BR = 4 / 8 serve maps that are exactly BR rows high --
 // the CRNN conv stack's 4 x 160 and 8 x 160 maps (crnn/modeling_crnn.py:66-77), K = 1 152 ... 4 608 -- whose blocks come from the compacted list of
 // live 32-column blocks of the ragged text lines (ConvDesc.block_list), or from NBLK consecutive column blocks of one line.
-template <int NT, int NWV, int BR_ = 0>
+template <int NT, int NWV, int BR_ = 0, int S_ = 1>
 struct PipeCfg {
   static constexpr int NTHR = 64 * NWV;
-  static constexpr int MT = 4;                                // MFMA row-tiles (patch rows) per wave
+  static constexpr int S = S_;                                // stride (2: the ResNet / DLA down-sampling convs; ordinary tiles only)
+  static constexpr int MT = S == 1 ? 4 : 2;                   // MFMA row-tiles (patch rows) per wave
   static constexpr int TH = (NT == 1 ? NWV : NWV / 2) * MT, TW = 32;
   static constexpr int BR = BR_ ? BR_ : TH;
-  static constexpr int NBLK = TH / BR, PR = BR + 2;           // blocks per tile, patch rows per block
-  static_assert(TH % BR == 0 && BR % MT == 0, "a wave's four rows lie inside one block");
+  static constexpr int NBLK = TH / BR, PR = (BR - 1) * S + 3; // blocks per tile, patch rows per block
+  static_assert(TH % BR == 0 && BR % MT == 0, "a wave's rows lie inside one block");
+  static_assert(S == 1 || NBLK == 1, "stride 2: ordinary tiles");
   static constexpr int NW = 64 * NT;                          // output channels per workgroup
-  static constexpr int THIN = NBLK * PR, TWIN = TW + 2;
+  static constexpr int THIN = NBLK * PR, TWIN = (TW - 1) * S + 3;
+  // stride 2: a patch row is stored even input columns first (XEVEN of them), then the odd ones: tap s of output pixel lx reads input column 2 lx + s,
+  // i.e. slot lx (s = 0), XEVEN + lx (s = 1), lx + 1 (s = 2) -- 32 consecutive slots per fragment, as at stride 1
+  static constexpr int XEVEN = (TWIN + 1) / 2;
   static constexpr int NPIX = THIN * TWIN;
   static constexpr int IN_UNITS = NPIX * 2;
   static constexpr int IN_INSTR = (IN_UNITS + 63) / 64;
@@ -1161,19 +1168,19 @@ struct PipeCfg {
 // DIRECT (plain layers: no hi/lo pairs, no fused pooling): the weights are the MFMA's A operand (D = [channel][pixel], the same sums in the same order)
 // and the epilogue runs from the accumulators (epilogue_direct_row: bias, residual, activation, rounding, v_permlane32_swap into 16-byte channel
 // runs) -- no fp32 round trip through LDS, no barrier behind the K loop
-template <int NT, int NWV, bool SKEW, int BR = 0, bool DIRECT = false>
+template <int NT, int NWV, bool SKEW, int BR = 0, bool DIRECT = false, int S = 1>
 __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, const bf16_t* __restrict__ zero_page) {
   // (device pass only: the buffer-resource builtins do not exist for the host target, and a kernel template whose body fails to instantiate there
   // silently loses its launch stub -- "undefined symbol ... conv3x3_pipe_kernel" at dlopen)
 #if defined(__HIP_DEVICE_COMPILE__)
   a16_kernel_enter();
-  using C = PipeCfg<NT, NWV, BR>;
+  using C = PipeCfg<NT, NWV, BR, S>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lx = lane & 31, qh = lane >> 5;
-  const int wm = NT == 1 ? wave : (wave >> 1);   // which group of 4 patch rows
+  const int wm = NT == 1 ? wave : (wave >> 1);   // which group of MT output rows
   const int wn = NT == 1 ? 0 : (wave & 1);       // which 64-channel half
 
   // the tile's blocks: (image, first output column); column Wo = no block (nothing fetched, nothing stored)
@@ -1244,14 +1251,15 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, cons
     if (is_in[j]) {
       const int U = k * 64 + lane;
       const int pix = U >> 1;
-      const int pr = pix / C::TWIN, ix = pix - pr * C::TWIN;
-      const int q = (U & 1) ^ ((ix >> 3) & 1);
-      const int bk = pr / C::PR, iy = pr - bk * C::PR;      // block of the patch row, row inside the block's (BR + 2)-row patch
+      const int pr = pix / C::TWIN, sx = pix - pr * C::TWIN;      // patch row, SLOT inside the row
+      const int q = (U & 1) ^ ((sx >> 3) & 1);
+      const int ix = S == 1 ? sx : (sx < C::XEVEN ? 2 * sx : 2 * (sx - C::XEVEN) + 1);      // slot -> input column of the patch
+      const int bk = pr / C::PR, iy = pr - bk * C::PR;      // block of the patch row, row inside the block's patch
       int bj = blk_b[0], xj = blk_x[0];
 #pragma unroll
       for (int t = 1; t < C::NBLK; ++t)
         if (bk == t) { bj = blk_b[t]; xj = blk_x[t]; }
-      const int gy = oy0 - 1 + iy, gx = xj - 1 + ix;
+      const int gy = oy0 * S - 1 + iy, gx = xj * S - 1 + ix;
       const bool inside = U < C::IN_UNITS && xj < p.Wo && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
       voff[j] = inside ? (int)(((((size_t)(bj - b) * p.H + gy) * p.W + gx) * in_cs + q * 8) * 2) : OOB;
     } else {
@@ -1287,7 +1295,10 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, cons
   int a_lane[3];
 #pragma unroll
   for (int s = 0; s < 3; ++s)
-    a_lane[s] = ((((C::MT * wm) / C::BR) * C::PR + (C::MT * wm) % C::BR) * C::TWIN + lx + s) * 32 + ((qh ^ (((lx + s) >> 3) & 1)) << 4);
+  {
+    const int soff = S == 1 ? s : ((s & 1) * C::XEVEN + (s >> 1));      // slot offset of tap column s
+    a_lane[s] = ((((C::MT * wm) / C::BR) * C::PR + ((C::MT * wm) % C::BR) * S) * C::TWIN + lx + soff) * 32 + ((qh ^ (((lx + soff) >> 3) & 1)) << 4);
+  }
   const int b_lane = C::IN_BYTES + (wn * 64 + lx) * 32 + ((qh ^ ((lx >> 3) & 1)) << 4);
 
   bf16x8 fa[2][C::MT], fb[2][2];
@@ -1297,7 +1308,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, cons
     fb[slot][1] = *reinterpret_cast<const bf16x8*>(sb + b_lane + (tap * C::NW + 32) * 32);
 #pragma unroll
     for (int m = 0; m < C::MT; ++m)
-      fa[slot][m] = *reinterpret_cast<const bf16x8*>(sb + a_lane[s] + ((m + r) * C::TWIN) * 32);
+      fa[slot][m] = *reinterpret_cast<const bf16x8*>(sb + a_lane[s] + ((S * m + r) * C::TWIN) * 32);
   };
   auto mma_tap = [&](int slot) {
 #pragma unroll
@@ -2361,12 +2372,12 @@ static int launch_dma16(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
 }
 
 // v4: the software-pipelined tap loop (conv3x3_pipe_kernel); same tiling arithmetic and labels as launch_dma16
-template <int NT, int NWV, bool SKEW, int BR = 0, bool DIRECT = false>
+template <int NT, int NWV, bool SKEW, int BR = 0, bool DIRECT = false, int S = 1>
 static int launch_pipe(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
-  using C = PipeCfg<NT, NWV, BR>;
+  using C = PipeCfg<NT, NWV, BR, S>;
   static bool attr_done = false;
   if (!attr_done) {
-    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pipe_kernel<NT, NWV, SKEW, BR, DIRECT>), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pipe_kernel<NT, NWV, SKEW, BR, DIRECT, S>), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
     attr_done = true;
   }
   k.n_tiles = k.N / C::NW;
@@ -2386,12 +2397,12 @@ static int launch_pipe(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   }
   PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range (%lld blocks)", nblk);
   char label[48];
-  if (C::NBLK == 1) snprintf(label, sizeof(label), "conv3x3 v4%s %d->%d @%dx%d%s", NWV == 4 ? "h" : "", k.Cin, k.N, k.Ho, k.Wo, k.split ? " x3" : "");
+  if (C::NBLK == 1) snprintf(label, sizeof(label), "conv3x3 %sv4%s %d->%d @%dx%d%s", S == 2 ? "s2 " : "", NWV == 4 ? "h" : "", k.Cin, k.N, k.Ho, k.Wo, k.split ? " x3" : "");
   else snprintf(label, sizeof(label), "conv3x3 v4b %d->%d @%dx%d%s", k.Cin, k.N, k.Ho, k.Wo, k.split ? " x3" : "");
   int lim_slot = -1;
   {
     PtProfScope prof(e, s, PT_PROF_CONV3X3, flop, label);
-    hipLaunchKernelGGL((conv3x3_pipe_kernel<NT, NWV, SKEW, BR, DIRECT>), dim3((unsigned)nblk), dim3(C::NTHR), C::SMEM, s, k, reinterpret_cast<const bf16_t*>(e->zero_page));
+    hipLaunchKernelGGL((conv3x3_pipe_kernel<NT, NWV, SKEW, BR, DIRECT, S>), dim3((unsigned)nblk), dim3(C::NTHR), C::SMEM, s, k, reinterpret_cast<const bf16_t*>(e->zero_page));
     if (k.xcols && prof.idx >= 0 && e->prof.h_lims && e->prof.n_lims < PtProfile::MAX_LIMS) {
       // per-image column limits: the launch covers the worst case; remember where the limit will land (credited at read-out, like launch_cfg)
       auto& pd = e->prof.pending[prof.idx];
@@ -2529,6 +2540,8 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
     if (s2 < 0) { const char* ev = getenv("PT_CONV_S2_DMA"); s2 = ev ? atoi(ev) : 1; }
     bool masked = false;
     for (int i = 0; i < 8; ++i) masked = masked || d.tap_mask[i] != 0;
+    const char* pv2 = getenv("PT_CONV_PIPE");      // 0: the v3 stride-2 tile (A/B switch, read per call)
+    if (s2 && !masked && !(pv2 && pv2[0] == '0')) return launch_pipe<2, 8, true, 0, true, 2>(e, k, s, flop);
     if (s2 && !masked) return launch_dma16<2, 8, 2>(e, k, s, flop);
   }
   if (d.ks == 3 && d.stride == 1 && !d.head_w && !d.argmax_part && !d.n_valid && !d.out_f32 && !d.res_f32 && d.relu < 2 && !d.ylimit && !d.xlimit && !d.pool && d.split != 2 && use_dma_kernel()) {

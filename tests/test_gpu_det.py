@@ -147,6 +147,8 @@ def test_conv1x1_wide_stages_equal_chunk_stages(eng, case, monkeypatch):
     dict(B=2, H=40, W=40, Cin=256, N=192, relu=True),                 # N % 128 != 0: the 32 x 32 x 64 8-wave tile
     dict(B=1, H=24, W=33, Cin=160, N=64),                             # odd slice count per 32-channel chunk pair, 64 outputs
     dict(B=2, H=21, W=37, Cin=64, N=128, relu=True, res_mode=1, split=True),   # BF16X3: K walks [x_hi | x_lo] x w_hi, then x_hi x w_lo
+    dict(B=2, H=33, W=47, Cin=256, N=512, relu=True, stride=2),       # stride 2: 8 x 32 x 128 tile from a 17 x 65 patch (even columns first), odd map
+    dict(B=3, H=16, W=130, Cin=64, N=128, stride=2),                  # stride 2: one tile row, three column tiles (the last one 1 px wide)
 ])
 def test_conv_v4_equals_v3(eng, case, monkeypatch):
     """conv3x3_pipe_kernel (v4: software-pipelined tap loop, MUBUF LDS-DMA, column-swizzled image) against conv3x3_dma16_kernel (v3) on the
@@ -168,12 +170,13 @@ def test_conv_v4_equals_v3(eng, case, monkeypatch):
     wt = torch.from_numpy((tile_conv_weight_x3(w) if split else tile_conv_weight(_bf16(w))).view(np.int16)).to(dev)
     bd = (torch.randn(N, generator=g) * 0.1).to(dev)
     rm = case.get("res_mode", 0)
+    stride = case.get("stride", 1)
     rd = nhwc(torch.randn(B, H, W, N, generator=g)) if rm else None
     outs = []
     for v in ("0", "1", "2", "3"):      # v3; v4 with the barrier behind tap 8; in front of it; + the register epilogue on plain layers (the default)
         monkeypatch.setenv("PT_CONV_PIPE", v)
         eng.profile_enable(1)
-        outs.append(eng.op_conv2d(x, wt, bd, 3, 1, relu=case.get("relu", False), res=rd, res_mode=rm, split=split).clone())
+        outs.append(eng.op_conv2d(x, wt, bd, 3, stride, relu=case.get("relu", False), res=rd, res_mode=rm, split=split).clone())
         torch.cuda.synchronize()
         labels = list(eng.profile_read_labels())
         eng.profile_enable(False)
