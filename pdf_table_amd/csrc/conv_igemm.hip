@@ -1168,7 +1168,10 @@ struct PipeCfg {
 // DIRECT (plain layers: no hi/lo pairs, no fused pooling): the weights are the MFMA's A operand (D = [channel][pixel], the same sums in the same order)
 // and the epilogue runs from the accumulators (epilogue_direct_row: bias, residual, activation, rounding, v_permlane32_swap into 16-byte channel
 // runs) -- no fp32 round trip through LDS, no barrier behind the K loop
-template <int NT, int NWV, bool SKEW, int BR = 0, bool DIRECT = false, int S = 1>
+// PHASE (N = 4 x 64, the phase convolutions of conv3x3(W, up2(x)) run at the resolution of x: db_model.hip phase_masks): 64-channel output tile ph = (dy, dx)
+// has non-zero weights on taps (dy .. dy + 1) x (dx .. dx + 1) only -- a wave multiplies those four taps (runtime fragment bases, the same immediates),
+// the weight rows of the other five are neither fetched (out-of-range DMA lanes) nor read
+template <int NT, int NWV, bool SKEW, int BR = 0, bool DIRECT = false, int S = 1, bool PHASE = false>
 __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, const bf16_t* __restrict__ zero_page) {
   // (device pass only: the buffer-resource builtins do not exist for the host target, and a kernel template whose body fails to instantiate there
   // silently loses its launch stub -- "undefined symbol ... conv3x3_pipe_kernel" at dlopen)
@@ -1268,6 +1271,10 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, cons
       const int tap = row / C::NW, n = row - tap * C::NW;
       const int hq = (U & 1) ^ ((row >> 3) & 1);
       voff[j] = (int)((((size_t)(n >> 6) * nch32 * (9 * 64 * 32)) + (tap * 64 + (n & 63)) * 32 + hq * 8) * 2);
+      if constexpr (PHASE) {      // the tile's phase (dy, dx) = its index among the four 64-channel tiles: taps outside its 2 x 2 window are not fetched
+        const int ph = NT * nb + (n >> 6), dr = tap / 3 - (ph >> 1), dc = tap % 3 - (ph & 1);
+        if ((unsigned)dr > 1u || (unsigned)dc > 1u) voff[j] = OOB;
+      }
     }
   }
   // element offsets of slice c: input channels (split mode: [x_hi | x_lo] against w_hi, then x_hi again against w_lo), weight chunk + half
@@ -1301,14 +1308,32 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, cons
   }
   const int b_lane = C::IN_BYTES + (wn * 64 + lx) * 32 + ((qh ^ ((lx >> 3) & 1)) << 4);
 
+  // PHASE: this wave's 64-channel tile is phase (dy, dx); its tap t4 = (a, b) is tap (dy + a, dx + b) of the 3 x 3 kernel
+  constexpr int NTAP = PHASE ? 4 : 9;
+  int a_ph[2] = {0, 0}, b_ph = 0;
+  if constexpr (PHASE) {
+    const int ph = NT * nb + wn, dy = ph >> 1, dx = ph & 1;
+    a_ph[0] = (dx ? a_lane[1] : a_lane[0]) + dy * C::TWIN * 32;
+    a_ph[1] = (dx ? a_lane[2] : a_lane[1]) + dy * C::TWIN * 32;
+    b_ph = b_lane + ((dy * 3 + dx) * C::NW) * 32;
+  }
   bf16x8 fa[2][C::MT], fb[2][2];
   auto load_frags = [&](const char* sb, int tap, int slot) {
-    const int r = tap / 3, s = tap - 3 * r;
-    fb[slot][0] = *reinterpret_cast<const bf16x8*>(sb + b_lane + (tap * C::NW) * 32);
-    fb[slot][1] = *reinterpret_cast<const bf16x8*>(sb + b_lane + (tap * C::NW + 32) * 32);
+    if constexpr (PHASE) {
+      const int a = tap >> 1, b = tap & 1;
+      fb[slot][0] = *reinterpret_cast<const bf16x8*>(sb + b_ph + ((a * 3 + b) * C::NW) * 32);
+      fb[slot][1] = *reinterpret_cast<const bf16x8*>(sb + b_ph + ((a * 3 + b) * C::NW + 32) * 32);
 #pragma unroll
-    for (int m = 0; m < C::MT; ++m)
-      fa[slot][m] = *reinterpret_cast<const bf16x8*>(sb + a_lane[s] + ((S * m + r) * C::TWIN) * 32);
+      for (int m = 0; m < C::MT; ++m)
+        fa[slot][m] = *reinterpret_cast<const bf16x8*>(sb + a_ph[b] + ((S * m + a) * C::TWIN) * 32);
+    } else {
+      const int r = tap / 3, s = tap - 3 * r;
+      fb[slot][0] = *reinterpret_cast<const bf16x8*>(sb + b_lane + (tap * C::NW) * 32);
+      fb[slot][1] = *reinterpret_cast<const bf16x8*>(sb + b_lane + (tap * C::NW + 32) * 32);
+#pragma unroll
+      for (int m = 0; m < C::MT; ++m)
+        fa[slot][m] = *reinterpret_cast<const bf16x8*>(sb + a_lane[s] + ((S * m + r) * C::TWIN) * 32);
+    }
   };
   auto mma_tap = [&](int slot) {
 #pragma unroll
@@ -1358,29 +1383,31 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, cons
   auto skew_slice = [&](int c, auto par_tag, auto more_tag) {
     constexpr int P = decltype(par_tag)::value;
     constexpr bool MORE = decltype(more_tag)::value;
+    constexpr int DPT = (C::SLOTS + NTAP - 2) / (NTAP - 1) > 2 ? (C::SLOTS + NTAP - 2) / (NTAP - 1) : 2;      // DMA requests per tap, over the first taps
     const char* sb = smem + P * C::BUF_BYTES;
     const int oi = in_off(c + 1), ow = w_off(c + 1);
-    static_for<8>([&](auto tap_c) {
+    static_for<NTAP - 1>([&](auto tap_c) {
       constexpr int tap = decltype(tap_c)::value;
-      load_frags(sb, tap + 1, (P + tap + 1) & 1);
-      mma_tap((P + tap) & 1);
+      load_frags(sb, tap + 1, (P * NTAP + tap + 1) & 1);
+      mma_tap((P * NTAP + tap) & 1);
       if constexpr (MORE) {
 #pragma unroll
-        for (int j = 2 * tap; j < 2 * tap + 2 && j < C::SLOTS; ++j) issue_one(j, oi, ow, P ^ 1);
-        static_assert(C::SLOTS <= 16, "two DMA requests per tap over taps 0 .. 7");
+        for (int j = DPT * tap; j < DPT * tap + DPT && j < C::SLOTS; ++j) issue_one(j, oi, ow, P ^ 1);
+        static_assert(C::SLOTS <= DPT * (NTAP - 1), "every DMA request has a tap");
       }
     });
-    static_for<8>([&](auto tap_c) {
+    static_for<NTAP - 1>([&](auto tap_c) {
       constexpr int tap = decltype(tap_c)::value;
-      constexpr int nd = MORE ? (C::SLOTS > 2 * tap ? 1 : 0) + (C::SLOTS > 2 * tap + 1 ? 1 : 0) : 0;
+      constexpr int left = C::SLOTS - DPT * tap;
+      constexpr int nd = MORE ? (left > DPT ? DPT : (left > 0 ? left : 0)) : 0;
       tap_groups<2 + C::MT, 2 * C::MT, nd>();
     });
     if constexpr (MORE) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      load_frags(smem + (P ^ 1) * C::BUF_BYTES, 0, (P + 1) & 1);
+      load_frags(smem + (P ^ 1) * C::BUF_BYTES, 0, ((P + 1) * NTAP) & 1);
     }
-    mma_tap((P + 8) & 1);
+    mma_tap((P * NTAP + NTAP - 1) & 1);
     tap_groups<MORE ? 2 + C::MT : 0, 2 * C::MT, 0>();
   };
   if constexpr (SKEW) {
@@ -1394,6 +1421,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, cons
     skew_slice(nslices - 2, std::integral_constant<int, 0>{}, std::true_type{});
     skew_slice(nslices - 1, std::integral_constant<int, 1>{}, std::false_type{});
   } else {
+    static_assert(!PHASE, "phase convolutions: the SKEW loop only");
     for (int c = 0; c + 1 < nslices; ++c) slice_body(c, std::true_type{});
     slice_body(nslices - 1, std::false_type{});
   }
@@ -2372,12 +2400,12 @@ static int launch_dma16(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
 }
 
 // v4: the software-pipelined tap loop (conv3x3_pipe_kernel); same tiling arithmetic and labels as launch_dma16
-template <int NT, int NWV, bool SKEW, int BR = 0, bool DIRECT = false, int S = 1>
+template <int NT, int NWV, bool SKEW, int BR = 0, bool DIRECT = false, int S = 1, bool PHASE = false>
 static int launch_pipe(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   using C = PipeCfg<NT, NWV, BR, S>;
   static bool attr_done = false;
   if (!attr_done) {
-    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pipe_kernel<NT, NWV, SKEW, BR, DIRECT, S>), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pipe_kernel<NT, NWV, SKEW, BR, DIRECT, S, PHASE>), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
     attr_done = true;
   }
   k.n_tiles = k.N / C::NW;
@@ -2397,12 +2425,12 @@ static int launch_pipe(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   }
   PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range (%lld blocks)", nblk);
   char label[48];
-  if (C::NBLK == 1) snprintf(label, sizeof(label), "conv3x3 %sv4%s %d->%d @%dx%d%s", S == 2 ? "s2 " : "", NWV == 4 ? "h" : "", k.Cin, k.N, k.Ho, k.Wo, k.split ? " x3" : "");
+  if (C::NBLK == 1) snprintf(label, sizeof(label), "conv3x3 %sv4%s%s %d->%d @%dx%d%s", S == 2 ? "s2 " : "", NWV == 4 ? "h" : "", PHASE ? "p" : "", k.Cin, k.N, k.Ho, k.Wo, k.split ? " x3" : "");
   else snprintf(label, sizeof(label), "conv3x3 v4b %d->%d @%dx%d%s", k.Cin, k.N, k.Ho, k.Wo, k.split ? " x3" : "");
   int lim_slot = -1;
   {
     PtProfScope prof(e, s, PT_PROF_CONV3X3, flop, label);
-    hipLaunchKernelGGL((conv3x3_pipe_kernel<NT, NWV, SKEW, BR, DIRECT, S>), dim3((unsigned)nblk), dim3(C::NTHR), C::SMEM, s, k, reinterpret_cast<const bf16_t*>(e->zero_page));
+    hipLaunchKernelGGL((conv3x3_pipe_kernel<NT, NWV, SKEW, BR, DIRECT, S, PHASE>), dim3((unsigned)nblk), dim3(C::NTHR), C::SMEM, s, k, reinterpret_cast<const bf16_t*>(e->zero_page));
     if (k.xcols && prof.idx >= 0 && e->prof.h_lims && e->prof.n_lims < PtProfile::MAX_LIMS) {
       // per-image column limits: the launch covers the worst case; remember where the limit will land (credited at read-out, like launch_cfg)
       auto& pd = e->prof.pending[prof.idx];
@@ -2577,6 +2605,16 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
     }
     // v4 (software-pipelined tap loop) for the unmasked layers; PT_CONV_PIPE=0: v3 everywhere (A/B switch, read per call)
     const char* pv = getenv("PT_CONV_PIPE");
+    // the phase convolutions (db_model.hip phase_masks: four 64-channel tiles, taps (dy .. dy + 1) x (dx .. dx + 1)) have their own v4 variant
+    bool phase = masked && d.N == 256;
+    for (int i = 0; i < 8 && phase; ++i) {
+      unsigned mk = 0;
+      if (i < 4)
+        for (int r = i >> 1; r < (i >> 1) + 2; ++r)
+          for (int q = i & 1; q < (i & 1) + 2; ++q) mk |= 1u << (r * 3 + q);
+      phase = d.tap_mask[i] == mk;
+    }
+    if (phase && cv == 3 && v3ok && !(pv && atoi(pv) < 3)) return launch_pipe<2, 8, true, 0, false, 1, true>(e, k, s, flop);
     const int pipe = masked ? 0 : (pv ? atoi(pv) : 3);      // 1: barrier behind tap 8, 2: in front of it (SKEW), 3: + register epilogue on plain layers
     if (pick == 3 && pipe == 1) {
       if (use_half) return launch_pipe<1, 4, false>(e, k, s, flop);

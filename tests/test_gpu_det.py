@@ -528,3 +528,29 @@ def _pipeline_boxes(eng_db, db_sd, mode):
         out, _ = E.db_finalize(cand, sc, prob_h[b].shape, (160, 224), 0.6, 1.5, 3.0)
         ref_boxes, _ = db_post.boxes_from_bitmap(prob_h[b], bits, 224, 160, 0.6, 1.5)
         np.testing.assert_array_equal(out.reshape(-1, 4, 2), ref_boxes.astype(np.int32))
+
+
+@pytest.mark.parametrize("shape", [(2, 512, 544), (2, 960, 960)])
+def test_db_net_v4_kernels_equal_v3(eng_db, shape, monkeypatch):
+    """The whole DB-ResNet18 graph with the round-6 conv kernels -- conv3x3_pipe_kernel in every variant the detector uses (4-wave and 8-wave tiles,
+    register epilogue with residual, stride 2, the four-tap phase convolutions of the fused out2 / binarize.0 with their pixel-shuffle epilogue) and the
+    MUBUF ws64 -- against PT_CONV_PIPE=0 (conv3x3_dma16_kernel, read at every call): same K order inside the accumulators, so the logits are the
+    same to the bit.  (ws64 changed its DMA and read order, not its sums: it stays on in both runs.)"""
+    n, H, W = shape
+    g = torch.Generator().manual_seed(11 + H)
+    x = _x4(_bf16(torch.randn(n, 3, H, W, generator=g))).cuda()
+    monkeypatch.delenv("PT_CONV_PIPE", raising=False)
+    eng_db.profile_enable(1)
+    _, new = eng_db.det_forward_net(x, want_logits=True)
+    torch.cuda.synchronize()
+    labels = list(eng_db.profile_read_labels())
+    eng_db.profile_enable(False)
+    new = new.cpu()
+    monkeypatch.setenv("PT_CONV_PIPE", "0")
+    _, old = eng_db.det_forward_net(x, want_logits=True)
+    old = old.cpu()
+    assert torch.isfinite(new).all() and new.abs().max() > 0
+    assert torch.equal(new, old)
+    if H >= 960:      # the bench's size: every variant is on the path
+        for mark in ("conv3x3 v4h ", "conv3x3 s2 v4 ", "conv3x3 v4p "):      # (two pages: the dispatch takes the 4-wave tiles; the 8-wave ones are test_conv_v4_equals_v3's)
+            assert any(k.startswith(mark) for k in labels), (mark, labels)
