@@ -1478,6 +1478,174 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, cons
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 1x1 stride-1 layers with K >= 256 as a pipelined GEMM: out [M][N] = A [M][K] . W^T (+ bias, residual, activation), single-pass modes.
+// These layers -- the CRNN's conv4 (K = 1024) and sequence-head projections (512 -> 2048, 256 -> 2048, 512 -> 512 / 256), Lore's wide 1x1 convs --
+// ran on conv_igemm_kernel<1, 1> / conv1x1_wide_kernel (4 x 32 x 64 tiles, two barriers per 32 or 128 channels) or on the streaming row GEMM
+// (gemm_argmax_kernel<., 1>: a wave's 32 rows x the whole W through LDS, one ds_read per MFMA, 64-byte store segments) at 0.14-0.24 of the
+// matrix peak and 0.27-0.41 of HBM.  Here: conv3x3_pipe_kernel's structure on a GEMM tile --
+//   * 512 rows (16 groups of 32 consecutive rows: an MFMA row-tile each) x 128 output channels per 8-wave workgroup, a wave 4 row-tiles x 64 channels;
+//   * K in 64-channel slices, two LDS buffers of (64 KB of A + 16 KB of W), requested by MUBUF LDS-DMA (ten instructions per wave and slice) between
+//     the MFMA groups of the slice before; rows are 128 bytes with the 16-byte slots XOR-swizzled by ((row >> 1) & 7) on the DMA source and on
+//     the read address (conflict-free ds_read_b128 for any 16 rows of a fragment);
+//   * four k-steps per slice, the next k-step's six fragments requested between this one's eight MFMAs, the hand-over barrier in front of the
+//     last k-step (SKEW);
+//   * the weights are the MFMA's A operand: bias / residual / activation / rounding from the accumulators, 16-byte channel runs.
+// LIST (ragged sequence views: ConvDesc.xlimit_rows + block_list): the tile's row groups come from the compacted list of live 32-step groups.
+// ---------------------------------------------------------------------------------------------------
+struct GemmPipeCfg {
+  static constexpr int NWV = 8, NTHR = 512, MT = 4, NG = 16;       // row groups (MFMA row-tiles) per workgroup
+  static constexpr int KS = 64, NW = 128;
+  static constexpr int A_BYTES = NG * 32 * KS * 2, W_BYTES = NW * KS * 2, BUF_BYTES = A_BYTES + W_BYTES;      // 65 536 + 16 384
+  static constexpr int A_INSTR = A_BYTES / 1024, W_INSTR = W_BYTES / 1024, SLOTS = (A_INSTR + W_INSTR) / NWV;  // 64 + 16 -> 10 per wave
+  static constexpr int SMEM = 2 * BUF_BYTES;                       // 163 840: the whole LDS of a CU
+  static_assert(A_INSTR % NWV == 0 && W_INSTR % NWV == 0, "a slot is an A or a W request for every wave alike");
+};
+
+template <bool LIST>
+__global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(ConvK p) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (buffer-resource builtins: device pass only, see conv3x3_pipe_kernel)
+  a16_kernel_enter();
+  using C = GemmPipeCfg;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lx = lane & 31, qh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;       // which four row groups, which 64-channel half
+
+  // tile -> (128-channel block, 16 row groups); consecutive workgroups = the channel blocks of one row tile (its A slices come from that XCD's L2)
+  const int L = LIST ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+  const int nb = L % p.n_tiles, ti = L / p.n_tiles;
+  const long long M = (long long)p.B * p.H * p.W;
+  const int n_groups = (int)(M >> 5);
+  int cnt = n_groups;
+  if (LIST) {
+    cnt = p.blist[0];
+    if (ti * C::NG >= cnt) return;
+  }
+  // row group of the tile's j-th MFMA row-tile (-1: none)
+  auto group_of = [&](int j) {
+    const int i = ti * C::NG + j;
+    if (i >= cnt) return -1;
+    return LIST ? p.blist[1 + i] : i;
+  };
+  const int K = p.Cin, nslices = K >> 6;
+  const bf16_t* wt = p.w + (size_t)(2 * nb) * (K >> 5) * 2048;
+  constexpr int OOB = 0x7FFFF000;
+  // A rows can lie anywhere in a > 2 GB tensor: the descriptor starts at the tile's first group, offsets are relative to it (a list is ascending)
+  const int g0 = group_of(0);
+  const __amdgpu_buffer_rsrc_t r_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.in + (size_t)g0 * 32 * K), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(wt), 0, OOB, 0x00020000);
+  int voff[C::SLOTS];
+#pragma unroll
+  for (int j = 0; j < C::SLOTS; ++j) {
+    const int k = wave + C::NWV * j;
+    if (j < C::A_INSTR / C::NWV) {
+      // A unit U = k * 64 + lane: row r = U >> 3 of the tile, stored slot U & 7 holds channel run (U & 7) ^ ((r >> 1) & 7) of the slice
+      const int U = k * 64 + lane, r = U >> 3, c = (U & 7) ^ ((r >> 1) & 7);
+      const int g = group_of(r >> 5);            // (r >> 5 is uniform over an instruction: 8 rows of one group)
+      const long long off = ((long long)(g - g0) * 32 + (r & 31)) * K + c * 8;
+      voff[j] = (g >= 0 && off * 2 < OOB) ? (int)(off * 2) : OOB;
+    } else {
+      // W unit: row n = U >> 3 of the 128, slot U & 7 holds channel run (U & 7) ^ ((n >> 1) & 7); source = the 1x1 tiling [N/64][K/32][64][32]
+      const int U = (k - C::A_INSTR) * 64 + lane, n = U >> 3, c = (U & 7) ^ ((n >> 1) & 7);
+      voff[j] = (int)((((size_t)(n >> 6) * (K >> 5) + (c >> 2)) * 2048 + (n & 63) * 32 + (c & 3) * 8) * 2);
+    }
+  }
+  auto issue_one = [&](int j, int slice, int buf) {
+    const bool is_a = j < C::A_INSTR / C::NWV;      // compile-time per slot
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(is_a ? r_a : r_w, (__attribute__((address_space(3))) void*)(smem + buf * C::BUF_BYTES + (wave + C::NWV * j) * 1024), 16,
+                                             voff[j], is_a ? slice * 128 : slice * 2 * 2048 * 2, 0, 0);
+  };
+
+  f32x16 acc[C::MT][2];
+#pragma unroll
+  for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  // fragment addresses of k-step kk: A(row-tile m) = a_lane[kk] + (4 wm + m) * 4096; W(half h) = b_lane[kk] + h * 4096
+  int a_lane[4], b_lane[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int slot = ((kk * 2 + qh) ^ ((lx >> 1) & 7)) << 4;
+    a_lane[kk] = (C::MT * wm) * 4096 + lx * 128 + slot;
+    b_lane[kk] = C::A_BYTES + (wn * 64 + lx) * 128 + slot;
+  }
+  bf16x8 fa[2][C::MT], fb[2][2];
+  auto load_frags = [&](const char* sb, int kk, int slot) {
+    fb[slot][0] = *reinterpret_cast<const bf16x8*>(sb + b_lane[kk]);
+    fb[slot][1] = *reinterpret_cast<const bf16x8*>(sb + b_lane[kk] + 4096);
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m) fa[slot][m] = *reinterpret_cast<const bf16x8*>(sb + a_lane[kk] + m * 4096);
+  };
+  auto mma_step = [&](int slot) {
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m) {
+      acc[m][0] = mfma_32x32x16_a16(fb[slot][0], fa[slot][m], acc[m][0]);      // D = [channel][row]
+      acc[m][1] = mfma_32x32x16_a16(fb[slot][1], fa[slot][m], acc[m][1]);
+    }
+  };
+
+#pragma unroll
+  for (int j = 0; j < C::SLOTS; ++j) issue_one(j, 0, 0);
+  // one slice: three k-steps with the next k-step's fragments and (MORE) the next slice's DMA requests between the MFMAs, the hand-over barrier,
+  // the next slice's first fragments, the fourth k-step.  Four k-steps per slice: the fragment slot of k-step kk is kk & 1 in every slice.
+  auto slice = [&](int c, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    const char* sb = smem + (c & 1) * C::BUF_BYTES;
+    static_for<3>([&](auto kk_c) {
+      constexpr int kk = decltype(kk_c)::value;
+      load_frags(sb, kk + 1, (kk + 1) & 1);
+      mma_step(kk & 1);
+      if constexpr (MORE) {
+#pragma unroll
+        for (int j = 4 * kk; j < 4 * kk + 4 && j < C::SLOTS; ++j) issue_one(j, c + 1, (c + 1) & 1);
+      }
+    });
+    static_for<3>([&](auto kk_c) {
+      constexpr int kk = decltype(kk_c)::value;
+      constexpr int nd = MORE ? (C::SLOTS - 4 * kk > 4 ? 4 : (C::SLOTS - 4 * kk > 0 ? C::SLOTS - 4 * kk : 0)) : 0;
+      tap_groups<2 + C::MT, 2 * C::MT, nd>();
+    });
+    if constexpr (MORE) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      load_frags(smem + ((c + 1) & 1) * C::BUF_BYTES, 0, 0);
+    }
+    mma_step(1);
+    tap_groups<MORE ? 2 + C::MT : 0, 2 * C::MT, 0>();
+  };
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  load_frags(smem, 0, 0);
+  for (int c = 0; c + 1 < nslices; ++c) slice(c, std::true_type{});
+  slice(nslices - 1, std::false_type{});
+
+  // epilogue from the accumulators: lane (lx, q) owns row lx of its row-tile; the map is addressed as [1][M / 32][32] (oy = row group, ox = lx)
+  const int n0 = (nb * 2 + wn) * 64;
+  const DirectBias bs = direct_bias<2>(p, n0, qh);
+  ConvK q = p;
+  q.B = 1; q.Ho = n_groups; q.Wo = 32;
+  // bf16 outputs leave as whole 128-byte lines through a wave-private 4 KB LDS tile (epilogue_direct_row's xp path): the operand buffers are dead once
+  // every wave has left the K loop.  Straight from the accumulator layout a store instruction touches 32 rows with 32 bytes each -- the 2048-wide
+  // projections wrote at 2.0 TB/s that way
+  char* xp = nullptr;
+  if (!p.out_f32 && p.xp_store) {
+    __syncthreads();
+    xp = smem + wave * 4096;
+  }
+#pragma unroll
+  for (int m = 0; m < C::MT; ++m) {
+    const int g = group_of(C::MT * wm + m);
+    if (g >= 0) epilogue_direct_row<2>(q, acc[m], bs, 0, g, 0, lx, n0, qh, xp);
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 3x3 stride-1 convolution 64 -> 64, weight-stationary and persistent ("ws64", bf16 mode).
 // The five 64 -> 64 @240^2 layers of DB-ResNet18 (layer1 + the fused out2; db_net/dbnet.py:102-140, 615-638) are the detector's
 // largest item and the furthest from the matrix roofline (0.54 PF on the v3 4-wave tile): K is only 576, so a 16x32 tile
@@ -2443,6 +2611,43 @@ static int launch_pipe(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   return PT_OK;
 }
 
+// 1x1 stride-1 plain layers with K >= 256, N % 128 == 0, M % 32 == 0 in the single-pass modes: the pipelined GEMM (gemm_pipe_kernel)
+static int launch_gemm_pipe(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
+  using C = GemmPipeCfg;
+  static bool attr_done = false;
+  if (!attr_done) {
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
+    attr_done = true;
+  }
+  const long long M = (long long)k.B * k.H * k.W, groups = M / 32;
+  {
+    const char* xv = getenv("PT_GEMM_XP");      // 0: 16-byte runs straight from the accumulators (A/B switch, read per call)
+    k.xp_store = !(xv && xv[0] == '0') && !k.out_f32;
+  }
+  k.n_tiles = k.N / C::NW;
+  k.tiles_x = (int)((groups + C::NG - 1) / C::NG);      // worst case with a list: every group live
+  k.tiles_y = 1;
+  const long long nblk = (long long)k.tiles_x * k.n_tiles;
+  PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "gemm grid out of range (%lld blocks)", nblk);
+  char label[48];
+  snprintf(label, sizeof(label), "gemm %d->%d @%dx%d", k.Cin, k.N, k.Ho, k.Wo);
+  int lim_slot = -1;
+  {
+    PtProfScope prof(e, s, PT_PROF_CONV1X1, flop, label);
+    if (k.blist) hipLaunchKernelGGL((gemm_pipe_kernel<true>), dim3((unsigned)nblk), dim3(C::NTHR), C::SMEM, s, k);
+    else hipLaunchKernelGGL((gemm_pipe_kernel<false>), dim3((unsigned)nblk), dim3(C::NTHR), C::SMEM, s, k);
+    if (k.xcols && prof.idx >= 0 && e->prof.h_lims && e->prof.n_lims < PtProfile::MAX_LIMS) {      // ragged rows: credited at read-out, like launch_cfg
+      auto& pd = e->prof.pending[prof.idx];
+      pd.lim_slot = lim_slot = e->prof.n_lims++;
+      pd.rows = k.xlimit_rows ? k.Ho * k.Wo : k.B * k.Wo;
+    }
+  }
+  if (lim_slot >= 0) (void)hipMemcpyAsync(e->prof.h_lims + lim_slot, k.xcols, sizeof(int), hipMemcpyDeviceToHost, s);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
 // weight-stationary persistent kernel for plain 64 -> 64 layers (bf16 mode): one workgroup per CU walks total_tiles / grid tiles
 static int launch_ws64(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   using C = Ws64Cfg;
@@ -2653,6 +2858,17 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   if (d.ks == 3 && d.stride == 1 && k.Ho <= 4 && k.Wo > 32) return launch_cfg<3, 1, 1>(e, k, s, flop);
   if (d.ks == 3 && d.stride == 1) return launch_cfg<3, 1>(e, k, s, flop);
   if (d.ks == 3 && d.stride == 2) return launch_cfg<3, 2>(e, k, s, flop);
+  // (K >= 512: at K = 256 a tile is four slices -- mostly prologue and epilogue of a workgroup that has the CU to itself -- and the 2048-wide
+  // projection measured 1.65 ms against the streaming row GEMM's 1.42; K = 512 ... 1024: 1.43 -> 1.35, 0.70 -> 0.60, 0.42 -> 0.34, 1.17 -> 0.63 ms)
+  if (d.ks == 1 && d.stride == 1 && !d.split && d.nseg <= 1 && d.Cin >= 512 && d.Cin % 64 == 0 && d.N % 128 == 0 && ((long long)d.B * d.H * d.W) % 32 == 0 &&
+      !d.head_w && !d.argmax_part && !d.res_f32 && !d.shuffle_cout && !d.pool && !d.ylimit && !d.xlimit && d.rep == 1 && (!d.res || d.res_mode == 1) &&
+      (!d.xlimit_rows || (d.block_list && d.W % 32 == 0)) && use_dma_kernel()) {
+    const char* gv = getenv("PT_GEMM_PIPE");      // 0: the 4 x 32 x 64 tile kernels (A/B switch, read per call)
+    if (!(gv && gv[0] == '0')) {
+      k.blist = d.xlimit_rows ? d.block_list : nullptr;
+      return launch_gemm_pipe(e, k, s, flop);
+    }
+  }
   if (d.ks == 1) {
     // column tiles per group: ~2 MB of weights (half of an XCD's L2); PT_N_GROUP overrides (0 = off)
     static int ng_env = -2;

@@ -140,8 +140,13 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
     const char* ev = getenv("PT_ROWS_X3");
     return x3 && fused && !pt_f16x2(e) && !(ev && ev[0] == '0');
   };
+  // single-pass modes: the pipelined GEMM of pt_launch_conv (gemm_pipe_kernel) takes these layers; PT_GEMM_PIPE=0 (read per call): the streaming kernel
+  auto gemm_pipe = [&]() {
+    const char* ev = getenv("PT_GEMM_PIPE");
+    return !x3 && !(ev && ev[0] == '0');
+  };
   auto rows_gemm = [&](const bf16_t* in, int cin, const ConvW& cw, int N, bf16_t* out, int relu, const char* label) -> int {
-    if (!x3 && fused && (cin == 512 || cin == 256)) {
+    if (!x3 && fused && (cin == 256 || (cin == 512 && !gemm_pipe()))) {      // (K = 256 stays on the streaming kernel: pt_launch_conv's rule)
       PtProfScope ps(e, s, PT_PROF_CONV1X1, 2.0 * n * T * (double)cin * N, label);
       return pt_launch_gemm_rows(in, (long long)n * T, cin, W(cw.w), Bv(cw.b), N, out, relu, s);
     }
@@ -220,10 +225,10 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
     // projection's output -- which the recurrence reads at every step -- is filled
     {
       ConvDesc c4d = conv(p3, 1, nn, T, 1024, c4, 512, 1, f_o, 1);
-      if (lim) { c4d.xlimit_rows = lim->lim[4]; c4d.xlimit_cols = lim->cols + 5; }
+      if (lim) { c4d.xlimit_rows = lim->lim[4]; c4d.xlimit_cols = lim->cols + 5; c4d.block_list = lim->glist; }      // (the list: gemm_pipe_kernel's live row groups)
       RUN(pt_launch_conv(e, c4d, s));
     }
-    if ((!x3 && fused) || rows_x3()) {
+    if ((!x3 && fused && !gemm_pipe()) || rows_x3()) {
       int lim_slot = -1;
       {
         PtProfScope ps(e, s, PT_PROF_CONV1X1, 2.0 * nn * T * 512.0 * 2048, x3 ? "rows gemm 512->2048 x3" : "rows gemm 512->2048");
@@ -238,7 +243,7 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
       if (lim_slot >= 0) (void)hipMemcpyAsync(e->prof.h_lims + lim_slot, lim->cols + 5, sizeof(int), hipMemcpyDeviceToHost, s);
     } else {
       ConvDesc xd = conv(f_o, 1, nn, T, 512, xp1, 2048, 1, gx_o, 0);
-      if (lim) { xd.xlimit_rows = lim->lim[4]; xd.xlimit_cols = lim->cols + 5; }
+      if (lim) { xd.xlimit_rows = lim->lim[4]; xd.xlimit_cols = lim->cols + 5; xd.block_list = lim->glist; }
       RUN(pt_launch_conv(e, xd, s));
     }
     RUN(fill(gx_o, ZeroLine::GX, 4, 32, 1, 1, 160, 2048, -1, 1));

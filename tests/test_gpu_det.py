@@ -554,3 +554,45 @@ def test_db_net_v4_kernels_equal_v3(eng_db, shape, monkeypatch):
     if H >= 960:      # the bench's size: every variant is on the path
         for mark in ("conv3x3 v4h ", "conv3x3 s2 v4 ", "conv3x3 v4p "):      # (two pages: the dispatch takes the 4-wave tiles; the 8-wave ones are test_conv_v4_equals_v3's)
             assert any(k.startswith(mark) for k in labels), (mark, labels)
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=1, H=40, W=160, Cin=1024, N=512, relu=True),              # the CRNN's conv4 as a sequence view [1, lines, 160, 1024]: 200 row groups, 13 tiles (the last one partial)
+    dict(B=1, H=33, W=160, Cin=512, N=2048),                          # first LSTM projection: 16 channel blocks per row tile
+    dict(B=2, H=24, W=40, Cin=512, N=256, relu=True, res_mode=1),     # a lateral with a residual; 60 row groups
+    dict(B=3, H=16, W=16, Cin=576, N=128),                            # K = 9 slices, one channel block
+    dict(B=1, H=1, W=32, Cin=512, N=128, relu=True),                  # a single row group
+])
+def test_gemm_pipe_equals_tile_kernels(eng, case, monkeypatch):
+    """gemm_pipe_kernel (1x1 layers with K >= 256 as a pipelined 512 x 128 GEMM, register epilogue) against the 4 x 32 x 64 tile kernels
+    (PT_GEMM_PIPE=0, read per call): the 16-channel k-steps enter every accumulator in the same ascending order, so the outputs are the same to the
+    bit; and both against torch fp32."""
+    g = torch.Generator().manual_seed(case["Cin"] + case["N"] + case["H"])
+    B, H, W, Cin, N = case["B"], case["H"], case["W"], case["Cin"], case["N"]
+    dev = torch.device("cuda", 0)
+    xf = _bf16(torch.randn(B, H, W, Cin, generator=g))
+    x = xf.to(torch.bfloat16).to(dev)
+    w = _bf16(torch.randn(N, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5)
+    wt = torch.from_numpy(tile_conv_weight(w).view(np.int16)).to(dev)
+    b = torch.randn(N, generator=g) * 0.1
+    rm = case.get("res_mode", 0)
+    rf = _bf16(torch.randn(B, H, W, N, generator=g)) if rm else None
+    rd = rf.to(torch.bfloat16).to(dev) if rm else None
+    outs = []
+    for v in ("0", "1"):
+        monkeypatch.setenv("PT_GEMM_PIPE", v)
+        eng.profile_enable(1)
+        outs.append(eng.op_conv2d(x, wt, b.to(dev), 1, 1, relu=case.get("relu", False), res=rd, res_mode=rm).clone())
+        torch.cuda.synchronize()
+        labels = list(eng.profile_read_labels())
+        eng.profile_enable(False)
+        assert labels and all(k.startswith("gemm ") == (v == "1") for k in labels), labels
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    ref = xf.reshape(-1, Cin) @ w[:, :, 0, 0].t() + b
+    if rm:
+        ref = ref + rf.reshape(-1, N)
+    if case.get("relu", False):
+        ref = F.relu(ref)
+    got = outs[1].float().cpu().reshape(-1, N)
+    err = (got - ref).abs()
+    assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-3).all()), err.max().item()
