@@ -273,15 +273,20 @@ __global__ __launch_bounds__(256) void dwconv2_kernel(const bf16_t* __restrict__
 // A third of the registers, 30-40 KB of LDS: four to five workgroups per CU.  Per output the taps are accumulated in (ky, kx) order in fp32 with the
 // same fused multiply-adds: the results equal dwconv_kernel's / dwconv2_kernel's bit for bit.
 // CB = 64 channels per workgroup (TW = 16) or 32 (TW = 32); w fp32 [K * K][C], b fp32 [C].
-template <int K, int CB>
-__global__ __launch_bounds__(256, 4) void dwconv_tile_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w, const float* __restrict__ b,
+template <int K, int CB, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? 128 : 256, 4) void dwconv_tile_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w, const float* __restrict__ b,
                                                           bf16_t* __restrict__ out, int B, int H, int W, int C, int act, const float* __restrict__ slope,
                                                           int tiles_x, int tiles_y) {
 #pragma clang fp contract(fast)
   a16_kernel_enter();
-  constexpr int PAD = K / 2, CGN = CB / 8, TH = 8, TW = 16 * 64 / CB, TWIN = TW + K - 1, THIN = TH + K - 1, PX = 4, NCOL = PX + K - 1;
-  constexpr int PITCH = CB * 2 + 32;             // bytes per staged pixel: the 16 lanes of a ds_read_b128 group then fall on distinct bank quads
+  // SPLIT (the pair modes: a pixel is [hi(C) | lo(C)], the value hi + lo): the staged tile holds the fp32 SUMS (256 + 32 bytes per pixel at CB = 64), four
+  // output rows per workgroup of 128 threads instead of eight / 256 (the static LDS limit), the same taps in the same (ky, kx) order on the same fp32
+  // values as dwconv_kernel / dwconv2_kernel in their split mode: bit-identical results
+  constexpr int PAD = K / 2, CGN = CB / 8, TH = SPLIT ? 4 : 8, TW = 16 * 64 / CB, TWIN = TW + K - 1, THIN = TH + K - 1, PX = 4, NCOL = PX + K - 1;
+  constexpr int NTHR = SPLIT ? 128 : 256;
+  constexpr int PITCH = SPLIT ? CB * 4 + 32 : CB * 2 + 32;             // bytes per staged pixel: the 16 lanes of a ds_read_b128 group then fall on distinct bank quads
   constexpr int NPIECE = THIN * TWIN * CGN;
+  static_assert(TH * (TW / PX) * CGN == NTHR, "one thread per (row, 4-pixel column group, 8-channel group)");
   __shared__ __attribute__((aligned(16))) char s_in[THIN * TWIN * PITCH];
   __shared__ __attribute__((aligned(16))) float s_w[K * K * CB + CB];
   const int tid = threadIdx.x;
@@ -293,20 +298,30 @@ __global__ __launch_bounds__(256, 4) void dwconv_tile_kernel(const bf16_t* __res
   const int tyi = L % tiles_y;
   const int bi = L / tiles_y;
   const int oy0 = tyi * TH, ox0 = txi * TW, c0 = cb * CB;
-  const bf16_t* in_b = in + (size_t)bi * H * W * C + c0;
+  const int cs = SPLIT ? 2 * C : C;               // channels per pixel in memory
+  const bf16_t* in_b = in + (size_t)bi * H * W * cs + c0;
 #pragma unroll
-  for (int j = 0; j < (NPIECE + 255) / 256; ++j) {
-    const int idx = tid + j * 256;
+  for (int j = 0; j < (NPIECE + NTHR - 1) / NTHR; ++j) {
+    const int idx = tid + j * NTHR;
     if (idx < NPIECE) {
       const int pix = idx / CGN, c = idx - pix * CGN;
       const int iy = pix / TWIN, ix = pix - iy * TWIN;
       const int gy = oy0 - PAD + iy, gx = ox0 - PAD + ix;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = *reinterpret_cast<const u32x4*>(in_b + ((size_t)gy * W + gx) * C + c * 8);
-      *reinterpret_cast<u32x4*>(s_in + pix * PITCH + c * 16) = v;
+      const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      if (SPLIT) {
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (inside) load8(in_b + ((size_t)gy * W + gx) * cs + c * 8, C, 1, v);
+        float4* d = reinterpret_cast<float4*>(s_in + pix * PITCH + c * 32);
+        d[0] = make_float4(v[0], v[1], v[2], v[3]);
+        d[1] = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (inside) v = *reinterpret_cast<const u32x4*>(in_b + ((size_t)gy * W + gx) * cs + c * 8);
+        *reinterpret_cast<u32x4*>(s_in + pix * PITCH + c * 16) = v;
+      }
     }
   }
-  for (int i = tid; i < K * K * CB; i += 256) s_w[i] = w[(size_t)(i / CB) * C + c0 + (i % CB)];
+  for (int i = tid; i < K * K * CB; i += NTHR) s_w[i] = w[(size_t)(i / CB) * C + c0 + (i % CB)];
   if (tid < CB) s_w[K * K * CB + tid] = b[c0 + tid];
   __syncthreads();
   const int cg = tid % CGN, g = tid / CGN;
@@ -321,10 +336,17 @@ __global__ __launch_bounds__(256, 4) void dwconv_tile_kernel(const bf16_t* __res
     float col[NCOL][8];
 #pragma unroll
     for (int j = 0; j < NCOL; ++j) {
-      const u32x4 h = *reinterpret_cast<const u32x4*>(s_in + ((row + ky) * TWIN + colg * PX + j) * PITCH + cg * 16);
-      const uint32_t hw[4] = {h.x, h.y, h.z, h.w};
+      const char* sp = s_in + ((row + ky) * TWIN + colg * PX + j) * PITCH;
+      if (SPLIT) {
+        const float4 f0 = *reinterpret_cast<const float4*>(sp + cg * 32), f1 = *reinterpret_cast<const float4*>(sp + cg * 32 + 16);
+        col[j][0] = f0.x; col[j][1] = f0.y; col[j][2] = f0.z; col[j][3] = f0.w;
+        col[j][4] = f1.x; col[j][5] = f1.y; col[j][6] = f1.z; col[j][7] = f1.w;
+      } else {
+        const u32x4 h = *reinterpret_cast<const u32x4*>(sp + cg * 16);
+        const uint32_t hw[4] = {h.x, h.y, h.z, h.w};
 #pragma unroll
-      for (int k = 0; k < 8; ++k) col[j][k] = bf2f((k & 1) ? (hw[k >> 1] >> 16) : (hw[k >> 1] & 0xFFFFu));
+        for (int k = 0; k < 8; ++k) col[j][k] = bf2f((k & 1) ? (hw[k >> 1] >> 16) : (hw[k >> 1] & 0xFFFFu));
+      }
     }
 #pragma unroll
     for (int kx = 0; kx < K; ++kx) {
@@ -353,7 +375,7 @@ __global__ __launch_bounds__(256, 4) void dwconv_tile_kernel(const bf16_t* __res
       else if (act == 3) v = v > 0.f ? v : sl * v;
       acc[p][q] = v;
     }
-    store8(out + (((size_t)bi * H + oy) * W + ox) * C + c0 + cg * 8, C, 0, acc[p]);
+    store8(out + (((size_t)bi * H + oy) * W + ox) * cs + c0 + cg * 8, C, SPLIT ? 1 : 0, acc[p]);
   }
 }
 
@@ -583,16 +605,23 @@ int pt_launch_dwconv(const bf16_t* in, const float* w, const float* b, bf16_t* o
   }
   const char* tile_ev = getenv("PT_DWCONV_TILE");      // PT_DWCONV_TILE=0: the register kernels everywhere (A/B switch, read per call)
   const bool tile = !(tile_ev && tile_ev[0] == '0');
-  if (tile && !split && sy == 1 && sx == 1 && C % 32 == 0) {      // stride 1, pad k / 2: Ho == H, Wo == W
-    const int cb = C % 64 == 0 ? 64 : 32, tw = cb == 64 ? 16 : 32;
-    const int tiles_x = (Wo + tw - 1) / tw, tiles_y = (Ho + 7) / 8;
+  if (tile && sy == 1 && sx == 1 && C % 32 == 0) {      // stride 1, pad k / 2: Ho == H, Wo == W; the pair modes take the fp32-staged instantiation
+    const int cb = C % 64 == 0 ? 64 : 32, tw = cb == 64 ? 16 : 32, th = split ? 4 : 8;
+    const int tiles_x = (Wo + tw - 1) / tw, tiles_y = (Ho + th - 1) / th;
     const long long nblk = (long long)B * tiles_x * tiles_y * (C / cb);
     PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "dwconv: grid out of range");
-#define PT_DWT(KK, CC) hipLaunchKernelGGL((dwconv_tile_kernel<KK, CC>), dim3((unsigned)nblk), dim3(256), 0, s, in, w, b, out, B, H, W, C, act, slope, tiles_x, tiles_y)
-    if (k == 3 && cb == 64) PT_DWT(3, 64);
-    else if (k == 3) PT_DWT(3, 32);
-    else if (cb == 64) PT_DWT(5, 64);
-    else PT_DWT(5, 32);
+#define PT_DWT(KK, CC, SP) hipLaunchKernelGGL((dwconv_tile_kernel<KK, CC, SP>), dim3((unsigned)nblk), dim3(SP ? 128 : 256), 0, s, in, w, b, out, B, H, W, C, act, slope, tiles_x, tiles_y)
+    if (split) {
+      if (k == 3 && cb == 64) PT_DWT(3, 64, true);
+      else if (k == 3) PT_DWT(3, 32, true);
+      else if (cb == 64) PT_DWT(5, 64, true);
+      else PT_DWT(5, 32, true);
+    } else {
+      if (k == 3 && cb == 64) PT_DWT(3, 64, false);
+      else if (k == 3) PT_DWT(3, 32, false);
+      else if (cb == 64) PT_DWT(5, 64, false);
+      else PT_DWT(5, 32, false);
+    }
 #undef PT_DWT
     PT_HIP_CHECK(hipGetLastError());
     return PT_OK;

@@ -75,6 +75,24 @@ def test_dwconv_tile_kernel_equals_register_kernel(eng, case, monkeypatch):
     got = torch.from_numpy(outs[0]).view(torch.bfloat16).float().permute(0, 3, 1, 2)
     err = (got - ref).abs()
     assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-3).all()), float(err.max())
+    # the pair modes' instantiation (fp32 sums staged in LDS, four output rows per workgroup): the same comparison on (hi | lo) tensors, and against
+    # torch fp32 on the UN-rounded values (the pair carries 16 mantissa bits)
+    xf = torch.randn(B, H, W, C, generator=g)
+    hi = xf.to(torch.bfloat16)
+    xs = torch.cat([hi, (xf - hi.float()).to(torch.bfloat16)], -1).contiguous()
+    outs = []
+    for sw in ("1", "0"):
+        monkeypatch.setenv("PT_DWCONV_TILE", sw)
+        y = eng.op_dwconv(xs.cuda(), w.cuda(), b.cuda(), k, 1, act, split=True)
+        torch.cuda.synchronize()
+        outs.append(y.view(torch.int16).cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    o = torch.from_numpy(outs[0]).view(torch.bfloat16).float()
+    got = (o[..., :C] + o[..., C:]).permute(0, 3, 1, 2)
+    xv = (xs[..., :C].float() + xs[..., C:].float()).permute(0, 3, 1, 2)
+    ref = F.conv2d(xv, w.t().reshape(C, 1, k, k), b, 1, k // 2, groups=C)
+    ref = F.hardswish(ref) if act == 2 else (F.relu(ref) if act == 1 else ref)
+    assert float((got - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max()))
 
 
 @pytest.mark.parametrize("shape", [(1, 160, 128), (2, 224, 192), (1, 320, 256)])
