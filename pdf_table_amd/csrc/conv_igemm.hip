@@ -1632,6 +1632,38 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(ConvK p) {
   // bf16 outputs leave as whole 128-byte lines through a wave-private 4 KB LDS tile (epilogue_direct_row's xp path): the operand buffers are dead once
   // every wave has left the K loop.  Straight from the accumulator layout a store instruction touches 32 rows with 32 bytes each -- the 2048-wide
   // projections wrote at 2.0 TB/s that way
+  if (p.argmax_part) {
+    // fused arg-max over classes (CTC greedy decode, modeling_ocr_recognition.py:168-171): best (value, index) of every row's 64-class slice from the
+    // accumulators -- lane (lx, q) holds 32 of the 64 logits of row lx: register r of block nb = class n0 + nb * 32 + (r & 3) + 8 (r >> 2) + 4 q --,
+    // then the two lanes of a row; ties keep the LOWEST class index, like torch.argmax.  Partial results [row][N / 64] float2, as epilogue_store writes them
+    const int nt64 = p.N >> 6;
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m) {
+      const int g = group_of(C::MT * wm + m);
+      if (g < 0) continue;
+      float bv = -INFINITY;
+      int bi = 0x7FFFFFFF;
+#pragma unroll
+      for (int nbk = 0; nbk < 2; ++nbk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float bias = r < 4 ? bs.v[nbk][0][r & 3] : r < 8 ? bs.v[nbk][1][r & 3] : r < 12 ? bs.v[nbk][2][r & 3] : bs.v[nbk][3][r & 3];
+          const float v = acc[m][nbk][r] + bias;
+          const int ci = n0 + nbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * qh;
+          if (v > bv || (v == bv && ci < bi)) { bv = v; bi = ci; }
+        }
+      const float ov = __shfl_xor(bv, 32);
+      const int oi = __shfl_xor(bi, 32);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      if (qh == 0) {
+        float2 pr;
+        pr.x = bv;
+        pr.y = __int_as_float(bi);
+        reinterpret_cast<float2*>(p.argmax_part)[((size_t)g * 32 + lx) * nt64 + (n0 >> 6)] = pr;
+      }
+    }
+    return;
+  }
   char* xp = nullptr;
   if (!p.out_f32 && p.xp_store) {
     __syncthreads();
@@ -2631,7 +2663,8 @@ static int launch_gemm_pipe(pt_engine* e, ConvK& k, hipStream_t s, double flop) 
   const long long nblk = (long long)k.tiles_x * k.n_tiles;
   PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "gemm grid out of range (%lld blocks)", nblk);
   char label[48];
-  snprintf(label, sizeof(label), "gemm %d->%d @%dx%d", k.Cin, k.N, k.Ho, k.Wo);
+  if (k.argmax_part) snprintf(label, sizeof(label), "classifier gemm+argmax");      // (the label bench.py's by_class files the CTC classifier under)
+  else snprintf(label, sizeof(label), "gemm %d->%d @%dx%d", k.Cin, k.N, k.Ho, k.Wo);
   int lim_slot = -1;
   {
     PtProfScope prof(e, s, PT_PROF_CONV1X1, flop, label);
@@ -2861,7 +2894,7 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   // (K >= 512: at K = 256 a tile is four slices -- mostly prologue and epilogue of a workgroup that has the CU to itself -- and the 2048-wide
   // projection measured 1.65 ms against the streaming row GEMM's 1.42; K = 512 ... 1024: 1.43 -> 1.35, 0.70 -> 0.60, 0.42 -> 0.34, 1.17 -> 0.63 ms)
   if (d.ks == 1 && d.stride == 1 && !d.split && d.nseg <= 1 && d.Cin >= 512 && d.Cin % 64 == 0 && d.N % 128 == 0 && ((long long)d.B * d.H * d.W) % 32 == 0 &&
-      !d.head_w && !d.argmax_part && !d.res_f32 && !d.shuffle_cout && !d.pool && !d.ylimit && !d.xlimit && d.rep == 1 && (!d.res || d.res_mode == 1) &&
+      !d.head_w && (!d.argmax_part || (!d.res && !d.relu)) && !d.res_f32 && !d.shuffle_cout && !d.pool && !d.ylimit && !d.xlimit && d.rep == 1 && (!d.res || d.res_mode == 1) &&
       (!d.xlimit_rows || (d.block_list && d.W % 32 == 0)) && use_dma_kernel()) {
     const char* gv = getenv("PT_GEMM_PIPE");      // 0: the 4 x 32 x 64 tile kernels (A/B switch, read per call)
     if (!(gv && gv[0] == '0')) {

@@ -310,7 +310,12 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
   RUN(rows_gemm(bf.h, 512, em2, 512, bf.e2, 0, "rows gemm 512->512"));
   // classifier + arg-max: fused kernel in bf16 mode (PT_CLS_FUSED=0: tiled GEMM with per-tile partials + reduce, which is
   // also the hi/lo path)
-  if (!x3 && fused) {
+  // (PT_CLS_PIPE=1, read per call: the pipelined GEMM with the arg-max in its register epilogue + the partial reduce -- the conv path below.  Measured
+  // SLOWER for this shape, 6.87 + 1.57 ms against the streaming kernel's 5.02: with N = 7680 a row tile is sixty 8-slice tiles that re-stream A and
+  // write 780 MB of partial maxima, where the streaming kernel keeps a wave's rows in registers and sweeps W once)
+  const char* cp_ev = getenv("PT_CLS_PIPE");
+  const bool cls_pipe = gemm_pipe() && cp_ev && cp_ev[0] == '1';
+  if (!x3 && fused && !cls_pipe) {
     PtProfScope ps(e, s, PT_PROF_CONV1X1, 2.0 * n * T * 512.0 * 7680.0, "classifier gemm+argmax");
     RUN(pt_launch_gemm_argmax(bf.e2, (long long)n * T, 512, W(cls.w), Bv(cls.b), 7680, ids, maxlogit, s));
   } else if (x3 && fused && !pt_f16x2(e) && !(getenv("PT_CLS_X3_REFINE") && atoi(getenv("PT_CLS_X3_REFINE")) == 0)) {
