@@ -270,6 +270,9 @@ struct ConvDesc {
   double alg_scale = 1.0;
 };
 int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s);
+// depthwise k x k + pointwise 1x1 in one launch (conv_igemm.hip: dwpw_kernel); PT_ERR_INVALID: outside its shapes, run the two launches
+int pt_launch_dwpw(pt_engine* e, const bf16_t* in, int B, int H, int W, int C, const float* dw_w, const float* dw_b, int k, int stride, int dw_act,
+                   const ConvDesc& pw, hipStream_t s);
 
 // stem: 7x7 p3 conv (stride 1 or 2) on NHWC4 bf16 input, 64 GEMM outputs of which the first n_valid (0 = 64) are
 // stored, bias + ReLU (conv_igemm.hip)

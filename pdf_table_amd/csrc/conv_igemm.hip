@@ -1678,6 +1678,155 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(ConvK p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Depthwise k x k (+ BN + activation) -> pointwise 1x1 (+ BN + activation) in ONE kernel: LCNet's DepthwiseSeparable (picodet/lcnet.py:64-90), CSP-PAN's
+// DPModule (csp_pan.py:56-105) and the PicoFeat towers (pico_head.py:98-107), single-pass modes.  Run as two launches, every block writes its depthwise
+// output to HBM for the pointwise conv to read back -- half of the pair's traffic -- and the layout net is ~130 launches of 50-150 us.  Here a
+// workgroup (four waves) owns 4 x 32 output pixels and ALL output channels: per 32-channel chunk it stages the input halo in LDS, computes the
+// depthwise taps on the VALU (fp32, the same (ky, kx) order and the same fused multiply-adds as dwconv_tile_kernel, bias, activation, rounded to the
+// storage format), writes that 128 x 32 tile to LDS as the MFMA's pixel operand (64-byte rows, slots XOR-swizzled by ((pixel >> 2) & 3)) and multiplies
+// it with the chunk's pointwise weights (fragments straight from global memory / L2, requested before the taps are computed); a wave keeps its 32
+// pixels x Cout accumulators, the epilogue is epilogue_direct_row.  The depthwise tensor never exists in HBM; every output bit equals the two launches'.
+// ---------------------------------------------------------------------------------------------------
+struct DwPwK {
+  const bf16_t* in;      // [B, H, W, C]
+  const float* dw_w;     // fp32 [K * K][C]
+  const float* dw_b;     // fp32 [C]
+  int dw_act;            // 0 none, 1 ReLU, 2 hardswish
+  int B, H, W, C, Ho, Wo, tiles_x, tiles_y;
+  ConvK pw;              // the pointwise layer as a 1x1 ConvK on the depthwise output map (w, bias, out, out_cstride, out_coff, relu, N, n_valid, Ho, Wo)
+};
+
+template <int K, int NB>      // NB: 32-channel blocks of the pointwise output (Cout / 32); stride 1 (a stride-2 halo of 11 x 67 pixels is 70 KB per chunk)
+__global__ __launch_bounds__(256, 2) void dwpw_kernel(DwPwK p) {
+#pragma clang fp contract(fast)
+  a16_kernel_enter();
+  constexpr int PAD = K / 2, TH = 4, TW = 32, PX = 2, CB = 32, CGN = CB / 8, S = 1;
+  constexpr int THIN = (TH - 1) * S + K, TWIN = (TW - 1) * S + K, NCOL = (PX - 1) * S + K;
+  constexpr int PITCH = CB * 2 + 32;             // 96 bytes per staged pixel (dwconv_tile_kernel's pitch at 32 channels)
+  constexpr int NPIECE = THIN * TWIN * CGN;
+  __shared__ __attribute__((aligned(16))) char s_in[THIN * TWIN * PITCH];
+  __shared__ __attribute__((aligned(16))) char s_a[TH * TW * 64];          // depthwise output tile: [pixel][32 channels], swizzled 16-byte slots
+  __shared__ __attribute__((aligned(16))) float s_w[K * K * CB + CB];
+  __shared__ __attribute__((aligned(16))) char s_pw[NB * 32 * 64];         // the chunk's pointwise weights: [output][32 channels], the same swizzle
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, q = lane >> 5;
+  int L = blockIdx.x;
+  const int txi = L % p.tiles_x;
+  L /= p.tiles_x;
+  const int tyi = L % p.tiles_y;
+  const int bi = L / p.tiles_y;
+  const int oy0 = tyi * TH, ox0 = txi * TW;
+  const bf16_t* in_b = p.in + (size_t)bi * p.H * p.W * p.C;
+  const int nchunks = p.C >> 5;
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+
+  // depthwise work item of this thread: 8 channels x 2 horizontally adjacent output pixels
+  const int cg = tid & (CGN - 1), g = tid >> 2;
+  const int row = g >> 4, colp = g & 15;
+
+  for (int c = 0; c < nchunks; ++c) {
+    // the chunk's pointwise weights, 16-byte pieces: output n = piece >> 2 (tile n >> 6 of the 1x1 tiling [N/64][C/32][64][32]), channel run piece & 3;
+    // requested now, stored to LDS behind the barrier below -- the loads fly while the halo is staged
+    constexpr int WP = NB * 32 * 4 / 256;          // pieces per thread
+    u32x4 wreg[WP];
+#pragma unroll
+    for (int j = 0; j < WP; ++j) {
+      const int piece = tid + j * 256, n = piece >> 2, cr = piece & 3;
+      wreg[j] = *reinterpret_cast<const u32x4*>(p.pw.w + ((size_t)(n >> 6) * nchunks + c) * 2048 + (n & 63) * 32 + cr * 8);
+    }
+    if (c) __syncthreads();      // the previous chunk's taps have been read (s_in, s_w) and its A tile multiplied (s_a)
+#pragma unroll
+    for (int j = 0; j < (NPIECE + 255) / 256; ++j) {
+      const int idx = tid + j * 256;
+      if (idx < NPIECE) {
+        const int pix = idx / CGN, cc = idx - pix * CGN;
+        const int iy = pix / TWIN, ix = pix - iy * TWIN;
+        const int gy = oy0 * S - PAD + iy, gx = ox0 * S - PAD + ix;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) v = *reinterpret_cast<const u32x4*>(in_b + ((size_t)gy * p.W + gx) * p.C + c * CB + cc * 8);
+        *reinterpret_cast<u32x4*>(s_in + pix * PITCH + cc * 16) = v;
+      }
+    }
+    for (int i = tid; i < K * K * CB; i += 256) s_w[i] = p.dw_w[(size_t)(i / CB) * p.C + c * CB + (i % CB)];
+    if (tid < CB) s_w[K * K * CB + tid] = p.dw_b[c * CB + tid];
+#pragma unroll
+    for (int j = 0; j < WP; ++j) {
+      const int piece = tid + j * 256, n = piece >> 2, cr = piece & 3;
+      *reinterpret_cast<u32x4*>(s_pw + n * 64 + ((cr ^ ((n >> 2) & 3)) << 4)) = wreg[j];
+    }
+    __syncthreads();
+    float a2[PX][8];
+#pragma unroll
+    for (int px = 0; px < PX; ++px)
+#pragma unroll
+      for (int k8 = 0; k8 < 8; ++k8) a2[px][k8] = 0.f;
+#pragma unroll 1
+    for (int ky = 0; ky < K; ++ky) {
+      float col[NCOL][8];
+#pragma unroll
+      for (int j = 0; j < NCOL; ++j) {
+        const u32x4 h = *reinterpret_cast<const u32x4*>(s_in + ((row * S + ky) * TWIN + colp * PX * S + j) * PITCH + cg * 16);
+        const uint32_t hw[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) col[j][k8] = bf16_to_f32((k8 & 1) ? (hw[k8 >> 1] >> 16) : (hw[k8 >> 1] & 0xFFFFu));
+      }
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const float4 w0 = *reinterpret_cast<const float4*>(s_w + (ky * K + kx) * CB + cg * 8);
+        const float4 w1 = *reinterpret_cast<const float4*>(s_w + (ky * K + kx) * CB + cg * 8 + 4);
+        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int px = 0; px < PX; ++px)
+#pragma unroll
+          for (int k8 = 0; k8 < 8; ++k8) a2[px][k8] += col[px * S + kx][k8] * wv[k8];
+      }
+    }
+    {
+      const float* bv = s_w + K * K * CB + cg * 8;
+#pragma unroll
+      for (int px = 0; px < PX; ++px) {
+        uint32_t hb[8];
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) {
+          float v = a2[px][k8] + bv[k8];
+          if (p.dw_act == 2) v = v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * 0.16666667f;      // (layout_kernels.hip's hswish)
+          else if (p.dw_act == 1) v = fmaxf(v, 0.f);
+          hb[k8] = f32_to_bf16(v);
+        }
+        const int P = row * TW + colp * PX + px;
+        const u32x4 o = {hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16)};
+        *reinterpret_cast<u32x4*>(s_a + P * 64 + ((cg ^ ((P >> 2) & 3)) << 4)) = o;
+      }
+    }
+    __syncthreads();
+    // pointwise: wave w multiplies row-tile w (pixels 32 w .. 32 w + 31) with every output block; D = [channel][pixel]
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int P = wave * TW + lx;
+      const bf16x8 fa = *reinterpret_cast<const bf16x8*>(s_a + P * 64 + (((kk * 2 + q) ^ ((P >> 2) & 3)) << 4));
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = nb * 32 + lx;
+        const bf16x8 fb = *reinterpret_cast<const bf16x8*>(s_pw + n * 64 + (((kk * 2 + q) ^ ((n >> 2) & 3)) << 4));
+        acc[nb] = mfma_32x32x16_a16(fb, fa, acc[nb]);
+      }
+    }
+  }
+  // epilogue from the accumulators, 64 output channels at a time
+  const int oy = oy0 + wave;
+#pragma unroll
+  for (int j = 0; j < NB / 2; ++j) {
+    const DirectBias bs = direct_bias<2>(p.pw, 64 * j, q);
+    epilogue_direct_row<2>(p.pw, *reinterpret_cast<const f32x16(*)[2]>(&acc[2 * j]), bs, bi, oy, ox0, lx, 64 * j, q, nullptr);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 3x3 stride-1 convolution 64 -> 64, weight-stationary and persistent ("ws64", bf16 mode).
 // The five 64 -> 64 @240^2 layers of DB-ResNet18 (layer1 + the fused out2; db_net/dbnet.py:102-140, 615-638) are the detector's
 // largest item and the furthest from the matrix roofline (0.54 PF on the v3 4-wave tile): K is only 576, so a 16x32 tile
@@ -2913,6 +3062,39 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   }
   if (d.ks == 1 && d.stride == 1) return launch_cfg<1, 1>(e, k, s, flop);
   return launch_cfg<1, 2>(e, k, s, flop);
+}
+
+// depthwise k x k (stride 1 / 2) + pointwise 1x1 in one launch (dwpw_kernel); returns PT_ERR_INVALID when the pair is outside the kernel's
+// shapes (the caller then runs the two launches).  pw: the pointwise layer's ConvDesc on the depthwise OUTPUT map (its `in` is ignored).
+int pt_launch_dwpw(pt_engine* e, const bf16_t* in, int B, int H, int W, int C, const float* dw_w, const float* dw_b, int k, int stride, int dw_act,
+                   const ConvDesc& pw, hipStream_t s) {
+  if (!(k == 3 || k == 5) || stride != 1 || C % 32 != 0 || pw.N % 64 != 0 || pw.N > 256 || pw.split || pw.res || pw.rep != 1 ||
+      pw.shuffle_cout || pw.out_f32 || pw.relu > 2 || dw_act > 2 || pw.Cin != C)
+    return PT_ERR_INVALID;
+  const int pad = k / 2, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  if (pw.H != Ho || pw.W != Wo || pw.B != B) return PT_ERR_INVALID;
+  DwPwK p;
+  memset(&p, 0, sizeof(p));
+  p.in = in; p.dw_w = dw_w; p.dw_b = dw_b; p.dw_act = dw_act;
+  p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo;
+  p.tiles_x = (Wo + 31) / 32; p.tiles_y = (Ho + 3) / 4;
+  ConvK& q = p.pw;
+  q.w = pw.w; q.bias = pw.bias; q.out = pw.out; q.B = B; q.H = Ho; q.W = Wo; q.Ho = Ho; q.Wo = Wo; q.Cin = C; q.N = pw.N;
+  q.out_cstride = pw.out_cstride; q.out_coff = pw.out_coff; q.rep = 1; q.relu = pw.relu; q.n_valid = pw.n_valid;
+  const long long nblk = (long long)B * p.tiles_x * p.tiles_y;
+  PT_REQUIRE(nblk > 0 && nblk < (1ll << 31), "dwpw grid out of range");
+  char label[48];
+  snprintf(label, sizeof(label), "dw%d s%d + pw %d->%d @%dx%d", k, stride, C, pw.n_valid ? pw.n_valid : pw.N, Ho, Wo);
+  e->prof.next_bytes = 2.0 * B * ((double)H * W * C + (double)Ho * Wo * (pw.n_valid ? pw.n_valid : pw.N));
+  PtProfScope prof(e, s, PT_PROF_CONV1X1, 2.0 * B * Ho * Wo * (double)C * (pw.n_valid ? pw.n_valid : pw.N), label);
+#define PT_DWPW(KK, NN) hipLaunchKernelGGL((dwpw_kernel<KK, NN>), dim3((unsigned)nblk), dim3(256), 0, s, p)
+#define PT_DWPW_N(KK) do { if (pw.N == 64) PT_DWPW(KK, 2); else if (pw.N == 128) PT_DWPW(KK, 4); else if (pw.N == 192) PT_DWPW(KK, 6); else PT_DWPW(KK, 8); } while (0)
+  if (k == 3) PT_DWPW_N(3);
+  else PT_DWPW_N(5);
+#undef PT_DWPW_N
+#undef PT_DWPW
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
 }
 
 template <int S, int NH>

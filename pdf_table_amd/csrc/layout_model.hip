@@ -92,8 +92,37 @@ struct Ctx {
     }
     return o;
   }
+  // depthwise k x k (stride 1) + pointwise 1x1 as ONE launch (conv_igemm.hip: dwpw_kernel) in the single-pass modes; false: not taken (pair mode, stride 2,
+  // more than 256 outputs, PT_DWPW=0 -- read per call), the caller runs the two launches
+  bool dwpw(const T& in, const std::string& qd, int k, int stride, int act_dw, const std::string& qp, int N, const T& out, int act_pw, int nv = 0) {
+    // Measured (MI355X, 64 pages, profiles/r06/dwpw_ab.txt): the fused launch wins where the depthwise conv is 3 x 3 (32 -> 32 @400x304: 0.74 -> 0.61 ms,
+    // 64 -> 64 @200x152: 0.32 -> 0.25, 128 -> 128 @100x76: 0.18 -> 0.16) and LOSES at 5 x 5 (256 -> 256 @50x38 x 5: 0.81 -> 1.15 ms, 128 -> 128 @100x76 x 4:
+    // 0.94 -> 1.02): 25 taps per value are VALU / LDS work that two workgroups of 210-256 registers per CU hide worse than the depthwise tile kernel's
+    // four to five, and these maps sit in the Infinity Cache -- the traffic the fusion removes was not what the pair waited for.  PT_DWPW=0: never,
+    // PT_DWPW=2: every stride-1 pair (A/B switch, read per call)
+    const char* ev = getenv("PT_DWPW");
+    const int mode = ev ? atoi(ev) : 1;
+    if (x3 || stride != 1 || N > 256 || mode == 0 || (mode == 1 && k != 3)) return false;
+    const PtTensor* dww = get(qd + ".wf32");
+    const PtTensor* dwb = get(qd + ".b");
+    const PtTensor* w = get(qp + ".w");
+    const PtTensor* b = get(qp + ".b");
+    if (!go()) return true;
+    ConvDesc c;
+    c.B = n; c.H = in.H; c.W = in.W; c.Cin = in.C;
+    c.w = reinterpret_cast<const bf16_t*>(w->d_ptr); c.bias = F(b);
+    c.N = N; c.ks = 1; c.stride = 1; c.relu = act_pw; c.n_valid = nv;
+    c.out = out.p; c.out_cstride = out.C; c.out_lo_off = out.C;
+    const int r = pt_launch_dwpw(e, in.p, n, in.H, in.W, in.C, F(dww), F(dwb), k, 1, act_dw, c, s);
+    if (r != PT_OK) rc = r;
+    return true;
+  }
   // DPModule (csp_pan.py:56-105): dw k5 + BN + hswish, pw + BN + hswish
   T dp(const T& in, const std::string& q, int stride) {
+    if (stride == 1 && !x3) {
+      T o = alloc(in.H, in.W, in.C);
+      if (dwpw(in, q + ".dw", 5, 1, 2, q + ".pw", in.C, o, 2)) return o;
+    }
     T d = dw(in, q + ".dw", 5, stride, 2);
     T o = alloc(d.H, d.W, in.C);
     pw(d, q + ".pw", in.C, o, 2);
@@ -146,6 +175,17 @@ T lcnet_backbone(Ctx& c, const bf16_t* x, int H, int W, const int* stage_stride,
     const int k = cfg[i][0], cout = cfg[i][2], se = cfg[i][4];
     const int st = cfg[i][3] < 0 ? 1 : stage_stride[cfg[i][3]];
     const std::string q = names[i];
+    if (!se && st == 1 && !c.x3) {      // plain DepthwiseSeparable block at stride 1: one launch
+      const int cstore = cout < 32 ? 32 : cout;
+      T o = c.alloc(t.H, t.W, cstore);
+      if (c.dwpw(t, q + ".dw", k, 1, 2, q + ".pw", cout < 64 ? 64 : cout, o, 2, cout < 64 ? cstore : 0)) {
+        t = o;
+        if (i == 4) feats[0] = t;
+        if (i == 10) feats[1] = t;
+        if (i == 12) feats[2] = t;
+        continue;
+      }
+    }
     T d = c.dw(t, q + ".dw", k, st, 2);
     if (se) {
       const PtTensor *w1 = c.get(q + ".se.w1"), *b1 = c.get(q + ".se.b1"), *w2 = c.get(q + ".se.w2"), *b2 = c.get(q + ".se.b2");
@@ -225,9 +265,11 @@ int pt_picodet_forward_net(pt_engine* e, const bf16_t* x, int n, int H, int W, f
       T f = outs[l];
       for (int i = 0; i < 4; ++i) {
         const std::string q = "head." + std::to_string(l) + "." + std::to_string(i);
-        T d = c.dw(f, q + ".dw", 5, 1, 2);
-        T o = c.alloc(d.H, d.W, 128);
-        c.pw(d, q + ".pw", 128, o, 2);
+        T o = c.alloc(f.H, f.W, 128);
+        if (!c.dwpw(f, q + ".dw", 5, 1, 2, q + ".pw", 128, o, 2)) {
+          T d = c.dw(f, q + ".dw", 5, 1, 2);
+          c.pw(d, q + ".pw", 128, o, 2);
+        }
         f = o;
       }
       c.pw(f, "head." + std::to_string(l) + ".out", 64, T(), 0, nullptr, 1, 40, heads[l], 40);

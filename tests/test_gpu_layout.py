@@ -243,3 +243,29 @@ def test_fitted_table_head_feeds_table_structure(precision):
         assert worst >= 0.9
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("shape", [(2, 160, 128), (1, 800, 608), (3, 96, 224)])
+def test_fused_depthwise_pointwise_is_bit_identical(eng, shape, monkeypatch):
+    """dwpw_kernel (depthwise k x k + pointwise 1x1 of a DepthwiseSeparable / DPModule / PicoFeat block in ONE launch: the depthwise tile goes to the MFMA
+    through LDS, never to HBM) against the two launches (PT_DWPW=0, read per call): the same taps in the same order, the same rounding of the depthwise
+    output, the same K order in the pointwise sums -- every head value the same to the bit; sizes whose maps are not whole 4 x 32 tiles, and the bench's
+    800 x 608."""
+    n, H, W = shape
+    g = torch.Generator().manual_seed(41 + H)
+    x = _x4(torch.randn(n, 3, H, W, generator=g)).cuda()
+    monkeypatch.setenv("PT_DWPW", "2")      # every stride-1 pair (the default fuses the 3 x 3 pairs only: the 5 x 5 ones measured slower fused)
+    eng.profile_enable(1)
+    fused = [h.clone() for h in eng.layout_forward_net(x)]
+    torch.cuda.synchronize()
+    labels = list(eng.profile_read_labels())
+    eng.profile_enable(False)
+    assert any(k.startswith("dw5 s1 + pw") for k in labels) and any(k.startswith("dw3 s1 + pw") for k in labels), labels
+    monkeypatch.setenv("PT_DWPW", "0")
+    two = [h.clone() for h in eng.layout_forward_net(x)]
+    monkeypatch.delenv("PT_DWPW")
+    dflt = eng.layout_forward_net(x)
+    torch.cuda.synchronize()
+    for a, b, c in zip(fused, two, dflt):
+        assert torch.isfinite(a).all() and a.abs().max() > 0
+        assert torch.equal(a, b) and torch.equal(c, b)
