@@ -270,6 +270,9 @@ struct ConvDesc {
   double alg_scale = 1.0;
 };
 int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s);
+// CRNN conv0 + pool + conv1 + pool in one launch (conv_igemm.hip: crnn_conv01_kernel), single-pass modes
+int pt_launch_crnn_conv01(pt_engine* e, const bf16_t* gray, int n, const float* w64x9, const float* b0, const bf16_t* w1, const float* b1, bf16_t* p1,
+                          const int* xlimit, const int* xlimit_cols, hipStream_t s);
 // depthwise k x k + pointwise 1x1 in one launch (conv_igemm.hip: dwpw_kernel); PT_ERR_INVALID: outside its shapes, run the two launches
 int pt_launch_dwpw(pt_engine* e, const bf16_t* in, int B, int H, int W, int C, const float* dw_w, const float* dw_b, int k, int stride, int dw_act,
                    const ConvDesc& pw, hipStream_t s);

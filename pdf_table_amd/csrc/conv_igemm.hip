@@ -1678,6 +1678,281 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(ConvK p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// CRNN conv0 (3x3, 1 -> 64, + BN + ReLU) + MaxPool2d(2) + conv1 (3x3, 64 -> 128, + BN + ReLU) + MaxPool2d(2) in ONE kernel (crnn/modeling_crnn.py:44-55),
+// single-pass modes.  As two launches the 64-channel 16 x 320 map of every text line went to HBM and came back; conv1 (pool in a staged epilogue) sat on the
+// register-staged kernel at 0.23 of the matrix peak and conv0 + pool was a launch of its own.  The map is cheap to RE-COMPUTE where it is needed: a 16 x 32
+// conv1 tile reads an 18 x 34 patch of it = 77 MFMA row tiles of conv0 (K = 9 taps padded to 16) beside the tile's 2 304 MFMAs.  A workgroup
+//   1. stages a 38 x 72 gray patch in LDS and computes conv0 + bias + ReLU + 2x2 max + rounding for the patch (crnn_conv0_pool_mfma_kernel's operands: the
+//      32 rows of an M tile are 8 pooling windows x 4 pixels, the max is in-lane), writing the result -- zero outside the 16 x 320 map, which is conv1's
+//      padding -- straight into the four 16-channel slice images of conv3x3_pipe_kernel's layout, resident for the whole K loop;
+//   2. runs conv1's K loop on those images with the weights streamed through a two-buffer ring by MUBUF LDS-DMA (software-pipelined taps, hand-over
+//      barrier in front of the last tap), 16 x 32 pixels x 128 channels per 8-wave workgroup, weights as the MFMA's A operand;
+//   3. pools in registers (the lane's two rows, the neighbouring lane's column by DPP) and stores 16-byte runs -- no LDS stage.
+// K order = conv3x3_pipe_kernel's (16-channel slices outer, taps inner): every bit equals conv0+pool -> the v4 conv -> MaxPool2d(2) as three launches
+// (PT_CONV01=0 PT_POOL_FUSED=0; tests/test_gpu_rec.py).  Measured on the recognition stage alone (2 227 lines): 3.86 ms (0.93 + 2.93) -> 2.24 ms, of which
+// 1.0 ms is the K loop, 0.85 ms the conv0 phase (VALU-bound: ~100 instructions per row tile, two waves per SIMD) and 0.2 ms the epilogue.
+// ConvK: in = gray [n][32][640] (16 bit), head_w = conv0 weights fp32 [64][9], head_b = conv0 bias fp32 [64]; w / bias / out / xlimit = conv1's.
+// ---------------------------------------------------------------------------------------------------
+struct Conv01Cfg {
+  static constexpr int NWV = 8, NTHR = 512, MT = 4, TH = 16, TW = 32, NW = 128;
+  static constexpr int THIN = TH + 2, TWIN = TW + 2, NPIX = THIN * TWIN;           // 18 x 34 pooled-conv0 pixels
+  static constexpr int NMT = (NPIX + 7) / 8;                                       // conv0 M tiles (8 pooling windows each)
+  static constexpr int IMG_BYTES = NPIX * 32 + 64;                                 // one 16-channel slice image; + 64: the two slices a conv0 store touches lie in different banks
+  static constexpr int W_INSTR = 9 * NW * 2 / 64, W_BYTES = W_INSTR * 1024;        // 36 KB of weights per slice
+  static constexpr int SLOTS = (W_INSTR + NWV - 1) / NWV;                          // 5 DMA requests per wave and slice
+  static constexpr int GH = 2 * THIN + 2, GW = 72, GQ = GW / 4;                    // gray patch: 38 rows x 72 columns from column 64 tile - 4 (8-byte aligned quads)
+  static constexpr int OFF_W = ((4 * IMG_BYTES + 1023) / 1024) * 1024, OFF_G = OFF_W + 2 * W_BYTES;
+  static constexpr int SMEM = OFF_G + GH * GW * 2;
+  static_assert(SMEM <= 163840, "LDS budget");
+};
+
+__device__ __forceinline__ float dpp_xor1(float v) {      // the value of lane ^ 1 (quad_perm [1, 0, 3, 2])
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+}
+
+__global__ __launch_bounds__(512, 2) void crnn_conv01_kernel(ConvK p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  a16_kernel_enter();
+  using C = Conv01Cfg;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lx = lane & 31, qh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int txi = blockIdx.x % p.tiles_x, b = blockIdx.x / p.tiles_x;
+  const int ox0 = txi * C::TW;
+  if (p.xlimit && ox0 >= p.xlimit[b]) return;      // ragged line: this tile is all padding response, filled by the caller
+  const int GHI = 2 * p.H, GWI = 2 * p.W;            // gray image (32 x 640): the conv0 map is p.H x p.W = 16 x 320 after its pool
+
+  // ---- weights: MUBUF LDS-DMA ring (conv3x3_pipe_kernel's weight half)
+  constexpr int OOB = 0x7FFFF000;
+  const int nch32 = p.Cin >> 5, nslices = nch32 * 2;      // 64 input channels: 4 slices
+  const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.w), 0, OOB, 0x00020000);
+  int voff[C::SLOTS], dst[C::SLOTS];
+#pragma unroll
+  for (int j = 0; j < C::SLOTS; ++j) {
+    int k = wave + C::NWV * j;
+    if (k >= C::W_INSTR) k = C::W_INSTR - 1;
+    dst[j] = k * 1024;
+    const int U = k * 64 + lane, row = U >> 1;
+    const int tap = row / C::NW, n = row - tap * C::NW;
+    const int hq = (U & 1) ^ ((row >> 3) & 1);
+    voff[j] = (int)((((size_t)(n >> 6) * nch32 * (9 * 64 * 32)) + (tap * 64 + (n & 63)) * 32 + hq * 8) * 2);
+  }
+  auto w_off = [&](int slice) { return (slice >> 1) * (9 * 64 * 32) + (slice & 1) * 16; };
+  auto issue_one = [&](int j, int slice, int buf) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (__attribute__((address_space(3))) void*)(smem + C::OFF_W + buf * C::W_BYTES + dst[j]), 16, voff[j],
+                                             w_off(slice) * 2, 0, 0);
+  };
+#pragma unroll
+  for (int j = 0; j < C::SLOTS; ++j) issue_one(j, 0, 0);      // slice 0's weights fly while conv0 is computed
+
+  // ---- conv0 + pool into the slice images
+  {
+    // gray patch: rows -3 .. 34, columns 64 tile - 4 .. + 67 of the line's image as aligned quads of pixels (zeros outside the image: conv0's padding)
+    const bf16_t* gin = p.in + (size_t)b * GHI * GWI;
+#pragma unroll
+    for (int it = 0; it < (C::GH * C::GQ + C::NTHR - 1) / C::NTHR; ++it) {
+      const int i = tid + it * C::NTHR;
+      if (i < C::GH * C::GQ) {
+        const int yy = -3 + i / C::GQ, xx = 2 * ox0 - 4 + 4 * (i % C::GQ);
+        u32x2 v = {0u, 0u};
+        if ((unsigned)yy < (unsigned)GHI && (unsigned)xx < (unsigned)GWI) v = *reinterpret_cast<const u32x2*>(gin + (size_t)yy * GWI + xx);
+        *reinterpret_cast<u32x2*>(smem + C::OFF_G + i * 8) = v;
+      }
+    }
+    const float* w64x9 = reinterpret_cast<const float*>(p.head_w);
+    bf16x8 bw[2];
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      uint32_t pk[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k0 = qh * 8 + 2 * i, k1 = k0 + 1;
+        const uint32_t a0 = k0 < 9 ? f32_to_bf16(w64x9[(nh * 32 + lx) * 9 + k0]) : 0u;
+        const uint32_t a1 = k1 < 9 ? f32_to_bf16(w64x9[(nh * 32 + lx) * 9 + k1]) : 0u;
+        pk[i] = a0 | (a1 << 16);
+      }
+      const u32x4 v = {pk[0], pk[1], pk[2], pk[3]};
+      bw[nh] = __builtin_bit_cast(bf16x8, v);
+    }
+    const float bs0[2] = {p.head_b[lx], p.head_b[32 + lx]};
+    __syncthreads();
+    // M tile mt = pooled pixels 8 mt .. 8 mt + 7 of the 18 x 34 patch (linear index P); MFMA row 4 w + 2 dy + dx = conv0 pixel (dy, dx) of window w.
+    // A fragment: k = tap 3 r + s.  A lane reads, per tap row, the two dwords that hold its three taps (patch columns 2 px + 1 + dx + s; the pair starts at
+    // column 2 (px + dx)) and shifts them into place; the upper half of the wave (k = 8 ..) keeps tap 8 only.
+    const int wnd = lx >> 2, dy = (lx >> 1) & 1, dx = lx & 1, odd = lx & 1;
+    const uint32_t* sgd = reinterpret_cast<const uint32_t*>(smem + C::OFF_G);
+    auto conv0_tile = [&](int mt) {
+      const int Pm = min(mt * 8 + wnd, C::NPIX - 1);
+      const int py = Pm / C::TWIN, pxx = Pm - py * C::TWIN;
+      const uint32_t* gp = sgd + (2 * py + dy) * (C::GW / 2) + pxx + dx;
+      uint32_t L[3], H[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const uint32_t d0 = gp[r * (C::GW / 2)], d1 = gp[r * (C::GW / 2) + 1];
+        L[r] = dx ? d0 : __builtin_amdgcn_alignbit(d1, d0, 16);
+        H[r] = dx ? (d1 & 0xFFFFu) : (d1 >> 16);
+      }
+      const u32x4 av = {qh ? H[2] : L[0], qh ? 0u : (H[0] | (L[1] << 16)), qh ? 0u : ((L[1] >> 16) | (H[1] << 16)), qh ? 0u : L[2]};
+      const bf16x8 a = __builtin_bit_cast(bf16x8, av);
+      f32x16 c0[2];
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c0[nh][r] = 0.f;
+        c0[nh] = mfma_32x32x16_a16(a, bw[nh], c0[nh]);
+      }
+      // the lane's two store positions (windows g = odd, 2 + odd): pixel P of the patch -> slot, in the map or conv1's zero padding
+      int soff[2];
+      bool in_map[2];
+#pragma unroll
+      for (int gp2 = 0; gp2 < 2; ++gp2) {
+        const int P = min(mt * 8 + 2 * (2 * gp2 + odd) + qh, C::NPIX - 1);      // (past the end: the last pixel once more -- only in the last tile, whose
+        const int qy = P / C::TWIN, qx = P - qy * C::TWIN;                       //  lanes of the clamped windows hold that pixel's values: Pm is clamped alike)
+        in_map[gp2] = (unsigned)(qy - 1) < (unsigned)p.H && (unsigned)(ox0 - 1 + qx) < (unsigned)p.W;
+        soff[gp2] = P * 32 + (((qx >> 3) & 1) << 4);
+      }
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+        // accumulator r: row (r & 3) + 8 (r >> 2) + 4 q = window 2 (r >> 2) + q, pixel r & 3; lane lx = channel nh * 32 + lx.
+        // + bias on the sums, then max(window, 0): the rounding is monotonic, so round(max(..)) == max(round(..)) bit for bit (and the additions come
+        // first because a maximum of raw MFMA results costs a canonicalising instruction per operand)
+        float mv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float t0 = c0[nh][g * 4] + bs0[nh], t1 = c0[nh][g * 4 + 1] + bs0[nh], t2 = c0[nh][g * 4 + 2] + bs0[nh], t3 = c0[nh][g * 4 + 3] + bs0[nh];
+          mv[g] = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(t0, t1), t2), __builtin_fmaxf(t3, 0.f));
+        }
+        // lane pairs (channel 2 c, 2 c + 1) trade windows so that each stores dwords: the even lane windows g = 0, 2, the odd lane g = 1, 3
+        const int ch = nh * 32 + (lx & ~1), sl = ch >> 4, kq = (ch >> 3) & 1, e = ch & 7;
+#pragma unroll
+        for (int gp2 = 0; gp2 < 2; ++gp2) {
+          const float keep = odd ? mv[2 * gp2 + 1] : mv[2 * gp2], send = odd ? mv[2 * gp2] : mv[2 * gp2 + 1];
+          const float recv = dpp_xor1(send);
+          const uint32_t dw = pack_bf16x2(odd ? recv : keep, odd ? keep : recv);
+          *reinterpret_cast<uint32_t*>(smem + sl * C::IMG_BYTES + (soff[gp2] ^ (kq << 4)) + e * 2) = in_map[gp2] ? dw : 0u;
+        }
+      }
+    };
+    for (int mt = wave; mt < C::NMT; mt += 2 * C::NWV) {      // two tiles per turn: independent chains (two waves per SIMD hide nothing)
+      conv0_tile(mt);
+      conv0_tile(min(mt + C::NWV, C::NMT - 1));               // (past the end: the last tile once more, same values)
+    }
+  }
+
+  // ---- conv1: K loop over the resident images; the weights are the MFMA's A operand: D = [channel][pixel]
+  f32x16 acc[C::MT][2];
+#pragma unroll
+  for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  int a_lane[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) a_lane[s] = ((C::MT * wm) * C::TWIN + lx + s) * 32 + ((qh ^ (((lx + s) >> 3) & 1)) << 4);
+  const int b_lane = (wn * 64 + lx) * 32 + ((qh ^ ((lx >> 3) & 1)) << 4);
+  bf16x8 fa[2][C::MT], fb[2][2];
+  auto load_frags = [&](int c, int tap, int slot) {
+    const char* sa = smem + c * C::IMG_BYTES;
+    const char* sw = smem + C::OFF_W + (c & 1) * C::W_BYTES;
+    const int r = tap / 3, s = tap - 3 * r;
+    fb[slot][0] = *reinterpret_cast<const bf16x8*>(sw + b_lane + (tap * C::NW) * 32);
+    fb[slot][1] = *reinterpret_cast<const bf16x8*>(sw + b_lane + (tap * C::NW + 32) * 32);
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m) fa[slot][m] = *reinterpret_cast<const bf16x8*>(sa + a_lane[s] + ((m + r) * C::TWIN) * 32);
+  };
+  auto mma_tap = [&](int slot) {
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m) {
+      acc[m][0] = mfma_32x32x16_a16(fb[slot][0], fa[slot][m], acc[m][0]);
+      acc[m][1] = mfma_32x32x16_a16(fb[slot][1], fa[slot][m], acc[m][1]);
+    }
+  };
+  auto slice = [&](int c, auto par_tag, auto more_tag) {
+    constexpr int P = decltype(par_tag)::value;
+    constexpr bool MORE = decltype(more_tag)::value;
+    static_for<8>([&](auto tap_c) {
+      constexpr int tap = decltype(tap_c)::value;
+      load_frags(c, tap + 1, (P + tap + 1) & 1);
+      mma_tap((P + tap) & 1);
+      if constexpr (MORE) {
+#pragma unroll
+        for (int j = 2 * tap; j < 2 * tap + 2 && j < C::SLOTS; ++j) issue_one(j, c + 1, (c + 1) & 1);
+      }
+    });
+    static_for<8>([&](auto tap_c) {
+      constexpr int tap = decltype(tap_c)::value;
+      constexpr int nd = MORE ? (C::SLOTS > 2 * tap ? 1 : 0) + (C::SLOTS > 2 * tap + 1 ? 1 : 0) : 0;
+      tap_groups<2 + C::MT, 2 * C::MT, nd>();
+    });
+    if constexpr (MORE) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      load_frags(c + 1, 0, (P + 1) & 1);
+    }
+    mma_tap((P + 8) & 1);
+    tap_groups<MORE ? 2 + C::MT : 0, 2 * C::MT, 0>();
+  };
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();            // the images are written, slice 0's weights have landed
+  load_frags(0, 0, 0);
+  for (int c = 0; c + 2 < nslices; c += 2) {
+    slice(c, std::integral_constant<int, 0>{}, std::true_type{});
+    slice(c + 1, std::integral_constant<int, 1>{}, std::true_type{});
+  }
+  slice(nslices - 2, std::integral_constant<int, 0>{}, std::true_type{});
+  slice(nslices - 1, std::integral_constant<int, 1>{}, std::false_type{});
+
+  // ---- epilogue from the accumulators: MaxPool2d(2) = the lane's two rows (in-lane) and the neighbouring lane's column (DPP), taken on the raw sums --
+  // bias, ReLU and the rounding are monotonic, the result equals pooling the stored map bit for bit.  Of a lane pair the even lane keeps the wave's first
+  // 32 channels, the odd lane the second 32: every lane stores.
+  {
+    const int odd = lx & 1;
+    const int n0 = wn * 64 + odd * 32;
+    f32x4 bsv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bsv[g] = *reinterpret_cast<const f32x4*>(p.bias + n0 + 8 * g + 4 * qh);
+    const int PHo = p.Ho >> 1, PWo = p.Wo >> 1;
+#pragma unroll
+    for (int rp = 0; rp < C::MT / 2; ++rp) {
+      float v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const float t0 = fmaxf(acc[2 * rp][0][k], acc[2 * rp + 1][0][k]), t1 = fmaxf(acc[2 * rp][1][k], acc[2 * rp + 1][1][k]);
+        const float keep = odd ? t1 : t0, send = odd ? t0 : t1;
+        v[k] = fmaxf(keep, dpp_xor1(send));
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        v[4 * g + 0] = fmaxf(v[4 * g + 0] + bsv[g].x, 0.f);
+        v[4 * g + 1] = fmaxf(v[4 * g + 1] + bsv[g].y, 0.f);
+        v[4 * g + 2] = fmaxf(v[4 * g + 2] + bsv[g].z, 0.f);
+        v[4 * g + 3] = fmaxf(v[4 * g + 3] + bsv[g].w, 0.f);
+      }
+      uint32_t d[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) d[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+      const u32x2 s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+      const u32x2 s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+      const u32x2 s2 = __builtin_amdgcn_permlane32_swap(d[4], d[6], false, false);
+      const u32x2 s3 = __builtin_amdgcn_permlane32_swap(d[5], d[7], false, false);
+      const u32x4 run0 = {s0.x, s1.x, s0.y, s1.y};     // channels n0 + 8 q .. + 7
+      const u32x4 run1 = {s2.x, s3.x, s2.y, s3.y};     // channels n0 + 16 + 8 q .. + 7
+      const int oy = (C::MT * wm) / 2 + rp, ox = (ox0 + lx) >> 1;
+      if (oy < PHo && ox < PWo) {
+        bf16_t* op = p.out + (((size_t)b * PHo + oy) * PWo + ox) * p.out_cstride + p.out_coff + n0 + 8 * qh;
+        *reinterpret_cast<u32x4*>(op) = run0;
+        *reinterpret_cast<u32x4*>(op + 16) = run1;
+      }
+    }
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Depthwise k x k (+ BN + activation) -> pointwise 1x1 (+ BN + activation) in ONE kernel: LCNet's DepthwiseSeparable (picodet/lcnet.py:64-90), CSP-PAN's
 // DPModule (csp_pan.py:56-105) and the PicoFeat towers (pico_head.py:98-107), single-pass modes.  Run as two launches, every block writes its depthwise
 // output to HBM for the pointwise conv to read back -- half of the pair's traffic -- and the layout net is ~130 launches of 50-150 us.  Here a
@@ -3062,6 +3337,39 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
   }
   if (d.ks == 1 && d.stride == 1) return launch_cfg<1, 1>(e, k, s, flop);
   return launch_cfg<1, 2>(e, k, s, flop);
+}
+
+// CRNN conv0 + pool + conv1 + pool in one launch (crnn_conv01_kernel): gray [n][32][640] -> p1 [n][8][160][128]; xlimit: conv1's per-line column limits
+int pt_launch_crnn_conv01(pt_engine* e, const bf16_t* gray, int n, const float* w64x9, const float* b0, const bf16_t* w1, const float* b1, bf16_t* p1,
+                          const int* xlimit, const int* xlimit_cols, hipStream_t s) {
+  using C = Conv01Cfg;
+  static bool attr_done = false;
+  if (!attr_done) {
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&crnn_conv01_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
+    attr_done = true;
+  }
+  ConvK k;
+  memset(&k, 0, sizeof(k));
+  k.in = gray; k.head_w = w64x9; k.head_b = b0; k.w = w1; k.bias = b1; k.out = p1;
+  k.B = n; k.H = 16; k.W = 320; k.Ho = 16; k.Wo = 320; k.Cin = 64; k.N = 128;
+  k.out_cstride = 128; k.out_coff = 0; k.rep = 1; k.relu = 1; k.pool = 1;
+  k.xlimit = xlimit; k.xcols = xlimit ? xlimit_cols : nullptr;
+  k.tiles_x = 10; k.tiles_y = 1; k.n_tiles = 1;
+  const double flop = 2.0 * n * 16 * 320 * 128.0 * 64 * 9;
+  e->prof.next_bytes = 2.0 * n * (32.0 * 640 + 8.0 * 160 * 128);
+  int lim_slot = -1;
+  {
+    PtProfScope prof(e, s, PT_PROF_CONV3X3, flop, "conv0+pool+conv1+pool 1->64->128 @16x320");
+    hipLaunchKernelGGL(crnn_conv01_kernel, dim3((unsigned)(n * 10)), dim3(C::NTHR), C::SMEM, s, k);
+    if (k.xcols && prof.idx >= 0 && e->prof.h_lims && e->prof.n_lims < PtProfile::MAX_LIMS) {
+      auto& pd = e->prof.pending[prof.idx];
+      pd.lim_slot = lim_slot = e->prof.n_lims++;
+      pd.rows = k.B * k.Wo;
+    }
+  }
+  if (lim_slot >= 0) (void)hipMemcpyAsync(e->prof.h_lims + lim_slot, k.xcols, sizeof(int), hipMemcpyDeviceToHost, s);
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
 }
 
 // depthwise k x k (stride 1 / 2) + pointwise 1x1 in one launch (dwpw_kernel); returns PT_ERR_INVALID when the pair is outside the kernel's

@@ -160,10 +160,10 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
   };
   // conv0 .. conv3b (+ their pools) for nn lines; lim != null: no work right of every line's text (see crnn_limits_kernel),
   // the skipped columns are filled from the all-padding line's activations `zl`
-  static int pool_fused = -1;
-  if (pool_fused < 0) {
+  int pool_fused = 1;      // (read per call: tests switch it in process)
+  {
     const char* ev = getenv("PT_POOL_FUSED");
-    pool_fused = ev ? atoi(ev) : 1;
+    if (ev) pool_fused = atoi(ev);
   }
   auto conv_stack = [&](const bf16_t* g, int nn, bf16_t* a0, bf16_t* a1, bf16_t* p1, bf16_t* c2a_o, bf16_t* c2b_o, bf16_t* p2,
                         bf16_t* c3a_o, bf16_t* c3b_o, bf16_t* p3, bf16_t* f_o, bf16_t* gx_o, const PtCrnnLimits* lim,
@@ -184,13 +184,21 @@ int pt_crnn_forward_net(pt_engine* e, const bf16_t* gray, int n, int32_t* ids, f
       PtProfScope ps(e, s, PT_PROF_OTHER, 0, "crnn fill");
       return pt_launch_crnn_fill(out, zl + zoff * m, lim->lim[k], tile_w, div, nn, rows, Wd, C * m, s, kn >= 0 ? lim->lim[kn] : nullptr, tn);
     };
-    {
+    // single-pass modes: conv0 + pool + conv1 + pool in ONE launch, the 64-channel map never leaves the CU (crnn_conv01_kernel; PT_CONV01=0, read per
+    // call: the two launches below -- same values, tests/test_gpu_rec.py)
+    const char* ev01 = getenv("PT_CONV01");
+    const bool conv01 = pool_fused && !x3 && !(ev01 && atoi(ev01) == 0);
+    if (conv01) {
+      RUN(pt_launch_crnn_conv01(e, g, nn, Bv(c0w), Bv(c0b), W(c1.w), Bv(c1.b), p1, lim ? lim->lim[0] : nullptr, lim ? lim->cols + 0 : nullptr, s));
+      RUN(fill(p1, ZeroLine::P1, 0, 32, 2, 8, 160, 128, 1, 32));
+    } else {
       PtProfScope ps(e, s, PT_PROF_OTHER, 0, "crnn conv0+pool");
       RUN(pt_launch_crnn_conv0_pool(g, nn, PT_REC_H, PT_REC_W, Bv(c0w), Bv(c0b), x3, a0, s, lim ? lim->lim[5] : nullptr));
     }
     // conv1 + pool(2,2) and conv2.3 + pool((2,1)): pooling in the conv epilogue (PT_POOL_FUSED=0: separate pool kernels,
     // which need the full maps: no column limits then)
-    if (pool_fused) {
+    if (conv01) {
+    } else if (pool_fused) {
       ConvDesc c1d = limited(conv(a0, nn, 16, 320, 64, c1, 128, 3, p1, 1), 0);
       c1d.pool = 1;
       RUN(pt_launch_conv(e, c1d, s));

@@ -178,6 +178,7 @@ np.savez(sys.argv[1], ids=ids.cpu().numpy(), mx=mx.cpu().numpy())
         out = str(tmp_path / f"{tag}.npz")
         e = dict(os.environ, **env)
         e["PT_CONV_VARIANT"] = "0"     # one conv kernel family in both runs: the DMA variants sum K in another order
+        e["PT_CONV01"] = "0"           # (and so does the fused conv0 + conv1 kernel: test_conv0_conv1_in_one_launch_equals_the_separate_launches)
         e["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + e.get("PYTHONPATH", "")
         subprocess.run([sys.executable, "-c", script, out], check=True, env=e, timeout=300)
         outs.append(np.load(out))
@@ -412,3 +413,62 @@ def test_ragged_conv_stack_is_bit_identical_to_the_full_one(sd, mode):
         e.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert len(np.unique(outs[0][0])) > 20
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_conv0_conv1_in_one_launch_equals_the_separate_launches(sd, mode, monkeypatch):
+    """crnn_conv01_kernel (conv0 + pool + conv1 + pool in one launch; the 64-channel 16 x 320 map is recomputed per tile in LDS and never stored) is the
+    kernel that runs in the single-pass modes, and its token ids and winning logits equal conv0+pool -> the v4 conv kernel -> MaxPool2d(2) as three launches
+    (PT_CONV01=0 PT_POOL_FUSED=0, read per call: the same K order -- 16-channel slices outer, taps inner) bit for bit; so does the ragged run (column limits
+    per line) of the fused kernel.  (Against PT_CONV01=0 alone the logits differ by bf16 noise: that path's conv1 is the register-staged kernel, whose K loop
+    runs taps outer over 32-channel chunks.)"""
+    import os
+    from pdf_table_amd.engine import HipEngine
+    img = make_page(5)[0]
+    rng = np.random.default_rng(23)
+    boxes = []
+    for k in range(90):
+        w = int(rng.choice([6, 17, 40, 90, 150, 260, 420, 700, 990]))
+        h = int(rng.choice([9, 14, 22, 31, 48]))
+        x0, y0 = int(rng.integers(0, 1024 - min(w, 1000))), int(rng.integers(0, 1024 - h))
+        boxes.append([x0, y0, x0 + w, y0, x0 + w, y0 + h, x0, y0 + h])
+    boxes.append([10, 10, 10, 10, 10, 10, 10, 10])
+    boxes = np.array(boxes, np.float64)
+    pages = torch.from_numpy(img[None]).cuda()
+    lines = R.build_lines([boxes])
+
+    def run(e):
+        e.profile_enable(True)
+        ids, mx = e.rec_forward(pages, lines)
+        torch.cuda.synchronize()
+        labels = list(e.profile_read_labels())
+        e.profile_enable(False)
+        e.check()
+        return (ids.cpu().numpy(), mx.cpu().numpy()), labels
+
+    outs = {}
+    for ragged in ("0", "1"):
+        os.environ["PT_REC_RAGGED"] = ragged
+        try:
+            e = HipEngine(0)
+        finally:
+            del os.environ["PT_REC_RAGGED"]
+        e.set_precision({"f16": L.PT_PRECISION_F16}.get(mode, L.PT_PRECISION_BF16))
+        e.load_weights(L.PT_MODEL_CRNN, pack_crnn(sd, fmt=e.weight_fmt))
+        outs["fused" + ragged], labels = run(e)
+        assert any(l.startswith("conv0+pool+conv1+pool") for l in labels) and not any(l.startswith("crnn conv0+pool") for l in labels), labels
+        if ragged == "0":
+            monkeypatch.setenv("PT_CONV01", "0")
+            outs["two"], labels = run(e)
+            assert any(l.startswith("crnn conv0+pool") for l in labels) and any(l.startswith("conv3x3 s1 64->128") for l in labels), labels
+            monkeypatch.setenv("PT_POOL_FUSED", "0")
+            outs["three"], labels = run(e)
+            assert any(l.startswith("crnn conv0+pool") for l in labels) and any(l.startswith("conv3x3 v4") and "64->128" in l for l in labels), labels
+            monkeypatch.delenv("PT_CONV01")
+            monkeypatch.delenv("PT_POOL_FUSED")
+        e.close()
+    for k in ("three", "fused1"):
+        assert np.array_equal(outs["fused0"][0], outs[k][0]) and np.array_equal(outs["fused0"][1], outs[k][1]), k
+    # the register-staged conv1 of the two-launch path: another summation order, same network
+    assert (outs["fused0"][0] != outs["two"][0]).mean() < 0.01 and np.abs(outs["fused0"][1] - outs["two"][1]).max() < 0.25
+    assert len(np.unique(outs["fused0"][0])) > 20
