@@ -31,6 +31,7 @@ typedef __attribute__((ext_vector_type(2))) _Float16 a16_f16x2;
 typedef __attribute__((ext_vector_type(8))) __bf16 a16_bf16x8;     // the kernels' 16-byte operand container (bit pattern only)
 typedef __attribute__((ext_vector_type(8))) _Float16 a16_f16x8;
 typedef __attribute__((ext_vector_type(16))) float a16_f32x16;
+typedef __attribute__((ext_vector_type(4))) float a16_f32x4;
 
 #if PT_ACT_F16
 #define PT_A16_MAX 65504.0f
@@ -60,6 +61,10 @@ __device__ __forceinline__ uint32_t pack_a16x2(float a, float b) {
 }
 __device__ __forceinline__ a16_f32x16 mfma_32x32x16_a16(a16_bf16x8 a, a16_bf16x8 b, a16_f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(a16_f16x8, a), __builtin_bit_cast(a16_f16x8, b), c, 0, 0, 0);
+}
+// 16 x 16 outputs, K = 32 (lane l: row / column l & 15, k = 8 (l >> 4) .. + 7; D: column l & 15, rows 4 (l >> 4) .. + 3): thin layers with 16 output channels
+__device__ __forceinline__ a16_f32x4 mfma_16x16x32_a16(a16_bf16x8 a, a16_bf16x8 b, a16_f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(a16_f16x8, a), __builtin_bit_cast(a16_f16x8, b), c, 0, 0, 0);
 }
 // Weighted sum of four stored dwords (two values each) with fp32 weights, fp32 accumulation, one rounding: ((w0 c0 + w1 c1) + w2 c2) + w3 c3, fused.
 // The half format has mixed-precision FMAs that read a 16-bit half of a register directly (v_fma_mix_f32, op_sel picks the half) and write a rounded half
@@ -101,6 +106,9 @@ __device__ __forceinline__ uint32_t pack_a16x2(float a, float b) {
 }
 __device__ __forceinline__ a16_f32x16 mfma_32x32x16_a16(a16_bf16x8 a, a16_bf16x8 b, a16_f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ a16_f32x4 mfma_16x16x32_a16(a16_bf16x8 a, a16_bf16x8 b, a16_f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 #define PT_A16_HAS_MIX_BLEND 0      // no mixed-precision FMA reads bf16: callers keep their unpack / packed-FMA / pack sequence
 __device__ __forceinline__ uint32_t a16_blend4(uint32_t, uint32_t, uint32_t, uint32_t, float, float, float, float) { return 0u; }

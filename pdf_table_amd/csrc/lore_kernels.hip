@@ -1696,6 +1696,176 @@ __global__ __launch_bounds__(512, 1) void dla_thin_chain_kernel(const bf16_t* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same chain on the 16 x 16 x 32 MFMA ("v2", the default).  Counters of the kernel above (profiles/r06/thin_chain_stalls.txt): matrix pipe 43 % busy, LDS
+// port 44 %, and SIX VALU instructions per LDS instruction -- base_layer and level0 have 16 output channels, the 32 x 32 x 16 MFMA computes 32 rows, so half of
+// the matrix time and half of every epilogue (bias, ReLU, rounding of 16 accumulators per lane) is spent on rows of zeros.  Here those two levels run on
+// v_mfma_f32_16x16x32: A = the 16 channels' weights (K = 32: one 8-tap kernel row of the 7x7, two taps of the 3x3), B = 16 pixels, D = 4 accumulators
+// per lane (four consecutive channels of one pixel: one 8-byte LDS store).  Per 32 pixels: 14 MFMAs of half the cycles for base_layer, 10 (nine taps
+// paired, the tenth half zero) against 9 full ones for level0; the epilogue's VALU work halves.  level1 (32 channels) keeps the 32 x 32 x 16 MFMA.
+// K is summed in another association than in the stand-alone kernels (32 products per instruction, taps paired): results agree with the three launches
+// to fp32 rounding, not bit for bit (tests/test_gpu_tsr.py bounds it; the kernel above stays selectable: PT_DLA_CHAIN=1).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void dla_thin_chain16_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ w_stem,
+                                                                  const float* __restrict__ b_stem, const bf16_t* __restrict__ w0,
+                                                                  const float* __restrict__ b0, const bf16_t* __restrict__ w1,
+                                                                  const float* __restrict__ b1, bf16_t* __restrict__ out, int B, int H, int W,
+                                                                  int tiles_x, int tiles_y) {
+  a16_kernel_enter();
+  using C = ThinChainCfg;
+  typedef a16_f32x4 df32x4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_in = smem;
+  char* s_b = s_in + C::IN_BYTES + C::W_BYTES;      // (the layout of the kernel above; its weight rows are unused here)
+  char* s_l0 = s_b + C::B_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lx = lane & 31, q = lane >> 5;
+  const int c16 = lane & 15, kb = lane >> 4;        // 16-wide MFMA: row / column, k-block (= the lane's four output channels 4 kb .. + 3)
+  const int H1 = H >> 1, W1 = W >> 1;
+  const int tyi = blockIdx.x % tiles_y, b = blockIdx.x / tiles_y;
+  const int oy1 = tyi * C::TH1;
+  const bf16_t* in_b = in + (size_t)b * H * W * 4;
+  // A fragments.  base_layer: kernel row r = K block r of the [7][8][4] row: lane (channel c16, k-block kb) holds taps 2 kb, 2 kb + 1 (x 4 channels)
+  // (which eight K indices a k-block means is ours to choose, the same for both operands: lanes l and l + 32 -- k-blocks kb and kb + 2 -- are given
+  // ADJACENT 16-byte pieces of LDS, as the q halves of the 32-wide kernels are)
+  const int tp = (kb & 1) * 2 + (kb >> 1);          // base_layer: the lane's pair of taps (2 tp, 2 tp + 1) of a kernel row
+  dbf16x8 wst[7];
+#pragma unroll
+  for (int r = 0; r < 7; ++r) wst[r] = *reinterpret_cast<const dbf16x8*>(w_stem + (size_t)c16 * 224 + r * 32 + tp * 8);
+  // level0: K block p = taps 2 p, 2 p + 1 (tap 9 does not exist: zero weights); k-block kb = tap 2 p + (kb & 1), channels 8 (kb >> 1) .. + 7
+  dbf16x8 wl0[5];
+  int toff[5];                                      // the lane's pixel fragment of K block p, relative to the unit's first pixel
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    const int t = 2 * p + (kb & 1);
+    const int tc = t < 9 ? t : 8;
+    const dbf16x8 wv = *reinterpret_cast<const dbf16x8*>(w0 + ((size_t)tc * 32 + c16) * 16 + (kb >> 1) * 8);
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    wl0[p] = t < 9 ? wv : __builtin_bit_cast(dbf16x8, z);
+    toff[p] = ((tc / 3) * C::PW + tc % 3) * C::PITCH + (kb >> 1) * 16;
+  }
+  dbf16x8 wf1[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wf1[t] = *reinterpret_cast<const dbf16x8*>(w1 + ((size_t)t * 32 + lx) * 16 + q * 8);
+  const float4 bsv = *reinterpret_cast<const float4*>(b_stem + 4 * kb), b0v = *reinterpret_cast<const float4*>(b0 + 4 * kb);
+  const int yb0 = 2 * oy1 - 2, y00 = 2 * oy1 - 1, yi0 = 2 * oy1 - 5;      // first map row of the base / level0 / image patches
+  constexpr int NLD = (C::RI * C::CI + 511) / 512;
+  u32x2 pre[NLD];
+  auto fetch = [&](int txi) {
+    const int xi0 = 2 * txi * C::TW1 - 5;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int idx = tid + j * 512;
+      const int iy = idx / C::CI, ix = idx - iy * C::CI;
+      const int gy = yi0 + iy, gx = xi0 + ix;
+      pre[j] = u32x2{0u, 0u};
+      if (idx < C::RI * C::CI && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+        pre[j] = *reinterpret_cast<const u32x2*>(in_b + ((size_t)gy * W + gx) * 4);
+    }
+  };
+  auto land = [&]() {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int idx = tid + j * 512;
+      if (idx < C::RI * C::CI) *reinterpret_cast<u32x2*>(s_in + idx * 8) = pre[j];
+    }
+  };
+  // bias + ReLU + rounding of a lane's four channels of one pixel -> the 8 bytes it stores (zero outside the map: the next level's padding)
+  auto finish = [&](const df32x4& acc, const float4& bv, bool inside) {
+    uint2 o = make_uint2(pack_a16x2(fmaxf(acc[0] + bv.x, 0.f), fmaxf(acc[1] + bv.y, 0.f)), pack_a16x2(fmaxf(acc[2] + bv.z, 0.f), fmaxf(acc[3] + bv.w, 0.f)));
+    if (!inside) o = make_uint2(0u, 0u);
+    return o;
+  };
+  fetch(0);
+  land();
+  for (int txi = 0; txi < tiles_x; ++txi) {
+    const int ox1 = txi * C::TW1;
+    const int xb0 = 2 * ox1 - 2, x00 = 2 * ox1 - 1;
+    __syncthreads();                       // this tile's image patch is in LDS; the previous tile's level0 patch has been read
+    if (txi + 1 < tiles_x) fetch(txi + 1);
+    // ---- base_layer: 19 rows x 2 halves of 32 columns = two 16-pixel blocks each (two accumulator chains), 7 K blocks
+    for (int u = wave; u < C::RB * 2; u += 8) {
+      const int i = u >> 1, ct = u & 1;
+      df32x4 acc[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) acc[k] = df32x4{0.f, 0.f, 0.f, 0.f};
+      const char* a_base = s_in + (i * C::CI + ct * 32 + c16 + 2 * tp) * 8;
+      // the unit's 14 fragments are requested up front (pinned below: left alone hipcc sinks each read to its MFMA and waits for it there)
+      u32x4 fr[7][2];
+#pragma unroll
+      for (int r = 0; r < 7; ++r)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const char* ap = a_base + (r * C::CI + 16 * k) * 8;
+          const u32x2 lo = *reinterpret_cast<const u32x2*>(ap), hi = *reinterpret_cast<const u32x2*>(ap + 8);
+          fr[r][k] = u32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+#pragma unroll
+      for (int r = 0; r < 7; ++r)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) acc[k] = mfma_16x16x32_a16(wst[r], __builtin_bit_cast(dbf16x8, fr[r][k]), acc[k]);
+      __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 14, 0);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int j = ct * 32 + 16 * k + c16, gy = yb0 + i, gx = xb0 + j;
+        const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        *reinterpret_cast<uint2*>(s_b + (i * C::PW + j) * C::PITCH + kb * 8) = finish(acc[k], bsv, inside);
+      }
+    }
+    __syncthreads();
+    if (txi + 1 < tiles_x) land();         // every stem fragment of this tile has been read
+    // ---- level0: 3x3 stride 1 on the base patch, 17 rows x 2 halves, 5 K blocks of two taps
+    for (int u = wave; u < C::R0 * 2; u += 8) {
+      const int i = u >> 1, ct = u & 1;
+      df32x4 acc[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) acc[k] = df32x4{0.f, 0.f, 0.f, 0.f};
+      const char* a_base = s_b + (i * C::PW + ct * 32 + c16) * C::PITCH;
+      dbf16x8 fr[5][2];
+#pragma unroll
+      for (int p = 0; p < 5; ++p)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) fr[p][k] = *reinterpret_cast<const dbf16x8*>(a_base + toff[p] + 16 * k * C::PITCH);
+#pragma unroll
+      for (int p = 0; p < 5; ++p)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) acc[k] = mfma_16x16x32_a16(wl0[p], fr[p][k], acc[k]);
+      __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int j = ct * 32 + 16 * k + c16, gy = y00 + i, gx = x00 + j;
+        const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && j < C::C0;
+        *reinterpret_cast<uint2*>(s_l0 + (i * C::PW + j) * C::PITCH + kb * 8) = finish(acc[k], b0v, inside);
+      }
+    }
+    __syncthreads();
+    // ---- level1: 3x3 stride 2 on the level0 patch, one row of the tile per wave (32 channels: the 32 x 32 x 16 MFMA, as above)
+    {
+      const int oy = wave;
+      df32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const dbf16x8 av = *reinterpret_cast<const dbf16x8*>(s_l0 + ((2 * oy + t / 3) * C::PW + 2 * lx + t % 3) * C::PITCH + q * 16);
+        acc = mfma_32x32x16_a16(wf1[t], av, acc);
+      }
+      const int gy = oy1 + oy, gx = ox1 + lx;
+      if (lx < C::TW1 && gy < H1 && gx < W1) {
+        bf16_t* op = out + (((size_t)b * H1 + gy) * W1 + gx) * 32;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int ch = 8 * rg + 4 * q;
+          const float4 bs = *reinterpret_cast<const float4*>(b1 + ch);
+          *reinterpret_cast<uint2*>(op + ch) = make_uint2(pack_a16x2(fmaxf(acc[rg * 4 + 0] + bs.x, 0.f), fmaxf(acc[rg * 4 + 1] + bs.y, 0.f)),
+                                                          pack_a16x2(fmaxf(acc[rg * 4 + 2] + bs.z, 0.f), fmaxf(acc[rg * 4 + 3] + bs.w, 0.f)));
+        }
+      }
+    }
+  }
+}
+
 inline int grid_for(long long total) {
   long long blocks = (total + 255) / 256;
   if (blocks > 256 * 64) blocks = 256 * 64;
@@ -1919,6 +2089,7 @@ int pt_launch_dla_thin_chain(pt_engine* e, const bf16_t* in, int B, int H, int W
   static bool attr_done = false;
   if (!attr_done) {
     PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dla_thin_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dla_thin_chain16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
     attr_done = true;
   }
   const int tiles_x = (W / 2 + C::TW1 - 1) / C::TW1, tiles_y = (H / 2 + C::TH1 - 1) / C::TH1;
@@ -1927,7 +2098,11 @@ int pt_launch_dla_thin_chain(pt_engine* e, const bf16_t* in, int B, int H, int W
   const double px = (double)B * H * W;
   e->prof.next_bytes = px * 8.0 + px / 4 * 64.0;
   PtProfScope prof(e, s, PT_PROF_STEM, 2.0 * px * (16.0 * 147 + 16.0 * 144) + 2.0 * px / 4 * 32.0 * 144, "dla thin chain (stem + level0 + level1)");
-  hipLaunchKernelGGL(dla_thin_chain_kernel, dim3((unsigned)nblk), dim3(512), C::SMEM, s, in, w_stem, b_stem, w0, b0, w1, b1, out, B, H, W, tiles_x, tiles_y);
+  const char* cv = getenv("PT_DLA_CHAIN");      // 1: the 32 x 32 x 16 kernel (bit-identical to the three launches); default: the 16 x 16 x 32 one (read per call)
+  if (cv && atoi(cv) == 1)
+    hipLaunchKernelGGL(dla_thin_chain_kernel, dim3((unsigned)nblk), dim3(512), C::SMEM, s, in, w_stem, b_stem, w0, b0, w1, b1, out, B, H, W, tiles_x, tiles_y);
+  else
+    hipLaunchKernelGGL(dla_thin_chain16_kernel, dim3((unsigned)nblk), dim3(512), C::SMEM, s, in, w_stem, b_stem, w0, b0, w1, b1, out, B, H, W, tiles_x, tiles_y);
   PT_HIP_CHECK(hipGetLastError());
   return PT_OK;
 }

@@ -519,21 +519,39 @@ def test_up_sampler_block_kernel_equals_general_kernel(eng, mode):
 
 @pytest.mark.parametrize("hw", [(160, 224), (96, 64), (1024, 1024), (32, 1056)])
 def test_thin_chain_equals_three_launches(eng, hw):
-    """dla_thin_chain_kernel (base_layer -> level0 -> level1 in one launch, the two full-resolution maps in LDS; bf16 mode) gives the head
-    maps of the three stand-alone launches bit for bit (PT_DLA_CHAIN is read at every call): maps smaller than a tile, maps whose size is
-    not a multiple of the 8 x 30 level-1 tile (partial tiles, zero padding of the intermediate maps at every border), the bench's 1024^2."""
+    """dla_thin_chain_kernel (base_layer -> level0 -> level1 in one launch, the two full-resolution maps in LDS; bf16 mode; PT_DLA_CHAIN=1) gives the
+    head maps of the three stand-alone launches (PT_DLA_CHAIN=0) bit for bit (the switch is read at every call): maps smaller than a tile, maps whose
+    size is not a multiple of the 8 x 30 level-1 tile (partial tiles, zero padding of the intermediate maps at every border), the bench's 1024^2.
+    The default kernel (dla_thin_chain16_kernel: the two 16-channel levels on the 16 x 16 x 32 MFMA, taps paired into K = 32 blocks) sums K in another
+    association.  A few roundings of stored 16-bit values flip and the network behind
+    (34 layers, deformable sampling) spreads them to its own bf16 noise level -- so the claim is made against the BF16X3 evaluation of the same net:
+    the default kernel's head maps are as close to it as the three launches' are."""
     import os
     H, W = hw
     g = torch.Generator().manual_seed(H * 7 + W)
     x = torch.randn(1 if H * W > 500000 else 2, 3, H, W, generator=g) * 0.7
     xd = _x4(x).cuda()
-    a = {k: t.cpu().numpy() for k, t in eng.tsr_forward_net(xd).items()}
-    os.environ["PT_DLA_CHAIN"] = "0"
-    try:
-        b = {k: t.cpu().numpy() for k, t in eng.tsr_forward_net(xd).items()}
-    finally:
-        del os.environ["PT_DLA_CHAIN"]
-    assert set(a) == set(b) and len(a) == 6
+    outs = {}
+    for sw in ("2", "1", "0"):
+        os.environ["PT_DLA_CHAIN"] = sw
+        try:
+            outs[sw] = {k: t.cpu().numpy() for k, t in eng.tsr_forward_net(xd).items()}
+        finally:
+            del os.environ["PT_DLA_CHAIN"]
+    a, b, c = outs["1"], outs["0"], outs["2"]
+    assert set(a) == set(b) == set(c) and len(a) == 6
     for k in a:
         assert np.array_equal(a[k], b[k]), (hw, k, float(np.abs(a[k].astype(np.float64) - b[k]).max()))
     assert float(np.abs(a["hm"]).max()) > 0
+    eng.set_precision(L.PT_PRECISION_BF16X3)
+    try:
+        ref = {k: t.cpu().numpy().astype(np.float64) for k, t in eng.tsr_forward_net(_x4(x, True).cuda()).items()}
+    finally:
+        eng.set_precision(L.PT_PRECISION_BF16)
+    for k in a:
+        scale = float(np.abs(ref[k]).max())
+        d1, d2 = np.abs(b[k] - ref[k]), np.abs(c[k] - ref[k])
+        print(f"thin chain {hw} {k}: |three launches - x3| max {d1.max() / scale:.4f} mean {d1.mean() / scale:.5f}; |16x16x32 chain - x3| max {d2.max() / scale:.4f} "
+              f"mean {d2.mean() / scale:.5f}; identical to the three launches: {np.array_equal(b[k], c[k])}")
+        # (the smallest case has 1 536 values per head: the ratio of two such means scatters by tens of per cent; on 1024^2 it reads 0.98 - 1.00)
+        assert d2.mean() <= 1.5 * d1.mean() + 2e-4 * scale and d2.max() <= 2.0 * d1.max() + 1e-3 * scale, (hw, k)
