@@ -1972,7 +1972,7 @@ struct DwPwK {
 };
 
 template <int K, int NB>      // NB: 32-channel blocks of the pointwise output (Cout / 32); stride 1 (a stride-2 halo of 11 x 67 pixels is 70 KB per chunk)
-__global__ __launch_bounds__(256, 2) void dwpw_kernel(DwPwK p) {
+__global__ __launch_bounds__(256, (NB == 2 && K == 3) ? 4 : 2) void dwpw_kernel(DwPwK p) {
 #pragma clang fp contract(fast)
   a16_kernel_enter();
   constexpr int PAD = K / 2, TH = 4, TW = 32, PX = 2, CB = 32, CGN = CB / 8, S = 1;
@@ -2499,6 +2499,11 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_kernel(ConvK p) {
 // bit patterns (positions outside the stem map hold 0, which never wins against the always-valid window centre).
 // The weights are the MFMA's A operand (D = [channel][pixel]): a lane owns a pixel and packs runs of four channels.
 // ---------------------------------------------------------------------------------------------------
+// max of the two 16-bit halves of a dword as unsigned integers, one instruction (v_pk_max_u16): the order of non-negative 16-bit floats is the order of their bits
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2_t;
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b)));
+}
 struct StemPoolCfg {
   static constexpr int TH = 16, TW = 32, PH = 7, PW = 15;
   static constexpr int THIN = (TH - 1) * 2 + 7;          // 37
@@ -2618,8 +2623,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem7x7_pool_kernel(ConvK p) {
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         const u32x2 v = *reinterpret_cast<const u32x2*>(smem + ((2 * py + dy) * C::TW + 2 * px + dx) * C::PIX + c4 * 8);
-        mx.x = __builtin_elementwise_max(mx.x & 0xFFFFu, v.x & 0xFFFFu) | (__builtin_elementwise_max(mx.x >> 16, v.x >> 16) << 16);
-        mx.y = __builtin_elementwise_max(mx.y & 0xFFFFu, v.y & 0xFFFFu) | (__builtin_elementwise_max(mx.y >> 16, v.y >> 16) << 16);
+        mx.x = pk_max_u16(mx.x, v.x);
+        mx.y = pk_max_u16(mx.y, v.y);
       }
     *reinterpret_cast<u32x2*>(p.out + (((size_t)b * PHo + oy) * PWo + ox) * 64 + c4 * 4) = mx;
   }
@@ -2751,8 +2756,8 @@ __global__ __launch_bounds__(512, 1) void conv_stem7x7_pool_ws_kernel(ConvK p) {
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
           const u32x2 v = *reinterpret_cast<const u32x2*>(smem + ((2 * py + dy) * C::TW + 2 * px + dx) * C::PIX + c4 * 8);
-          mx.x = __builtin_elementwise_max(mx.x & 0xFFFFu, v.x & 0xFFFFu) | (__builtin_elementwise_max(mx.x >> 16, v.x >> 16) << 16);
-          mx.y = __builtin_elementwise_max(mx.y & 0xFFFFu, v.y & 0xFFFFu) | (__builtin_elementwise_max(mx.y >> 16, v.y >> 16) << 16);
+          mx.x = pk_max_u16(mx.x, v.x);
+          mx.y = pk_max_u16(mx.y, v.y);
         }
       *reinterpret_cast<u32x2*>(p.out + (((size_t)b * PHo + oy) * PWo + ox) * 64 + c4 * 4) = mx;
     }
