@@ -1478,6 +1478,204 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_kernel(ConvK p, cons
 }
 
 // ---------------------------------------------------------------------------------------------------
+// conv3x3_pipe_kernel<NT, NWV, SKEW, 0, DIRECT, S> as a PERSISTENT kernel ("v5"): a workgroup walks a contiguous run of tiles and the slice pipeline
+// runs across the tile boundary.  One tile per workgroup pays, per tile, the launch of the workgroup, the address arithmetic of its DMA requests, a DMA
+// round trip with nothing to multiply, and the epilogue with nothing in flight: T(tile) = 3.48 us x slices + 9.1 us on the 8-wave tile (r06) -- 14 % of
+// a 256-channel layer, 25 % of a 128-channel one.  Here the first slice of tile i + 1 is requested during the LAST slice of tile i (into the buffer
+// that slice does not use: the slice count is even), the hand-over barrier in front of tile i's last tap is also tile i + 1's first one, its first
+// fragments are read behind it, and the epilogue of tile i (registers -> global, nothing staged) runs while that slice is already in LDS.
+// Per tile the per-lane DMA offsets are eight integer operations per slot from the slot's (row, column, half) in the patch, kept packed in a register.
+// Same tiles, same K order, same epilogue: every output bit equals conv3x3_pipe_kernel's (tests/test_gpu_det.py).
+// ---------------------------------------------------------------------------------------------------
+template <int NT, int NWV, int S>
+__global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pipe_persist_kernel(ConvK p) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (buffer-resource builtins: device pass only, see conv3x3_pipe_kernel)
+  a16_kernel_enter();
+  using C = PipeCfg<NT, NWV, 0, S>;
+  static_assert(C::NBLK == 1, "ordinary tiles");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lx = lane & 31, qh = lane >> 5;
+  const int wm = NT == 1 ? wave : (wave >> 1);   // which group of MT output rows
+  const int wn = NT == 1 ? 0 : (wave & 1);       // which 64-channel half
+  const int G = gridDim.x;
+  const int Lw = xcd_remap(blockIdx.x, G);
+  const int t0 = (int)((long long)Lw * p.total_tiles / G), t1 = (int)((long long)(Lw + 1) * p.total_tiles / G);
+  if (t0 >= t1) return;
+  const int in_cs = p.Cin;
+  const int nch32 = p.Cin >> 5, nslices = nch32 * 2;
+
+  // DMA slot j of this wave = instruction k = wave + NWV * j of the list [IN_INSTR input | W_INSTR weight] (conv3x3_pipe_kernel's list and LDS layout).
+  // Tile-independent part of a slot: an input unit's (patch row, input column of the patch, stored half), packed; a weight unit's byte offset.
+  constexpr int OOB = 0x7FFFF000;
+  int meta[C::SLOTS];
+  bool is_in[C::SLOTS];
+  int dst[C::SLOTS];
+#pragma unroll
+  for (int j = 0; j < C::SLOTS; ++j) {
+    int k = wave + NWV * j;
+    if (k >= C::T_INSTR) k = C::T_INSTR - 1;
+    is_in[j] = k < C::IN_INSTR;                  // wave-uniform
+    dst[j] = k * 1024;
+    if (is_in[j]) {
+      const int U = k * 64 + lane;
+      const int pix = U >> 1;
+      const int pr = pix / C::TWIN, sx = pix - pr * C::TWIN;
+      const int q = (U & 1) ^ ((sx >> 3) & 1);
+      const int ix = S == 1 ? sx : (sx < C::XEVEN ? 2 * sx : 2 * (sx - C::XEVEN) + 1);
+      meta[j] = U < C::IN_UNITS ? (pr | (ix << 8) | (q << 16)) : -1;
+    } else {
+      const int U = (k - C::IN_INSTR) * 64 + lane;
+      const int row = U >> 1;
+      const int tap = row / C::NW, n = row - tap * C::NW;
+      const int hq = (U & 1) ^ ((row >> 3) & 1);
+      meta[j] = (int)((((size_t)(n >> 6) * nch32 * (9 * 64 * 32)) + (tap * 64 + (n & 63)) * 32 + hq * 8) * 2);
+    }
+  }
+  struct Tile { int b, oy0, ox0, nb; };
+  auto decode = [&](int L) {
+    Tile t;
+    t.nb = L % p.n_tiles;
+    L /= p.n_tiles;
+    const int txi = L % p.tiles_x;
+    L /= p.tiles_x;
+    const int tyi = L % p.tiles_y;
+    t.b = L / p.tiles_y;
+    t.ox0 = txi * C::TW;
+    t.oy0 = tyi * C::TH;
+    return t;
+  };
+  auto offsets = [&](const Tile& t, int (&vo)[C::SLOTS]) {
+#pragma unroll
+    for (int j = 0; j < C::SLOTS; ++j) {
+      if (is_in[j]) {
+        const int m = meta[j];
+        const int gy = t.oy0 * S - 1 + (m & 0xFF), gx = t.ox0 * S - 1 + ((m >> 8) & 0xFF);
+        const bool inside = m >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        vo[j] = inside ? ((gy * p.W + gx) * in_cs + ((m >> 16) & 1) * 8) * 2 : OOB;
+      } else {
+        vo[j] = meta[j];
+      }
+    }
+  };
+  auto rsrc_in = [&](const Tile& t) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.in + (size_t)t.b * p.H * p.W * in_cs), 0, OOB, 0x00020000); };
+  auto rsrc_w = [&](const Tile& t) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.w + (size_t)(NT * t.nb) * nch32 * (9 * 64 * 32)), 0, OOB, 0x00020000); };
+  auto in_off = [&](int slice) { return slice << 4; };
+  auto w_off = [&](int slice) { return (slice >> 1) * (9 * 64 * 32) + (slice & 1) * 16; };
+
+  f32x16 acc[C::MT][2];
+#pragma unroll
+  for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  int a_lane[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const int soff = S == 1 ? s : ((s & 1) * C::XEVEN + (s >> 1));      // slot offset of tap column s
+    a_lane[s] = ((C::MT * wm * S) * C::TWIN + lx + soff) * 32 + ((qh ^ (((lx + soff) >> 3) & 1)) << 4);
+  }
+  const int b_lane = C::IN_BYTES + (wn * 64 + lx) * 32 + ((qh ^ ((lx >> 3) & 1)) << 4);
+  bf16x8 fa[2][C::MT], fb[2][2];
+  auto load_frags = [&](const char* sb, int tap, int slot) {
+    const int r = tap / 3, s = tap - 3 * r;
+    fb[slot][0] = *reinterpret_cast<const bf16x8*>(sb + b_lane + (tap * C::NW) * 32);
+    fb[slot][1] = *reinterpret_cast<const bf16x8*>(sb + b_lane + (tap * C::NW + 32) * 32);
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m) fa[slot][m] = *reinterpret_cast<const bf16x8*>(sb + a_lane[s] + ((S * m + r) * C::TWIN) * 32);
+  };
+  auto mma_tap = [&](int slot) {
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m) {
+      acc[m][0] = mfma_32x32x16_a16(fb[slot][0], fa[slot][m], acc[m][0]);
+      acc[m][1] = mfma_32x32x16_a16(fb[slot][1], fa[slot][m], acc[m][1]);
+    }
+  };
+
+  Tile cur = decode(t0);
+  int vo[C::SLOTS];
+  offsets(cur, vo);
+  __amdgpu_buffer_rsrc_t r_in = rsrc_in(cur), r_w = rsrc_w(cur);
+#pragma unroll
+  for (int j = 0; j < C::SLOTS; ++j)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(is_in[j] ? r_in : r_w, (__attribute__((address_space(3))) void*)(smem + dst[j]), 16, vo[j], 0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  load_frags(smem, 0, 0);
+
+  for (int ti = t0; ti < t1; ++ti) {
+    // one slice of the K loop (conv3x3_pipe_kernel's skew_slice): the DMA requests of the slice after it go out behind the first taps' MFMAs.
+    // LAST (the tile's last slice): the requests are slice 0 of the NEXT tile (of the last tile: all out of range -- the buffer is zero-filled and
+    // never read), and the first fragments of that slice are read after the epilogue, not before it (they would be 24 live registers across it)
+    auto skew_slice = [&](int c, auto par_tag, auto last_tag, int oi, int ow) {
+      constexpr int P = decltype(par_tag)::value;
+      constexpr bool LAST = decltype(last_tag)::value;
+      constexpr int NTAP = 9;
+      constexpr int DPT = (C::SLOTS + NTAP - 2) / (NTAP - 1) > 2 ? (C::SLOTS + NTAP - 2) / (NTAP - 1) : 2;
+      const char* sb = smem + P * C::BUF_BYTES;
+      static_for<NTAP - 1>([&](auto tap_c) {
+        constexpr int tap = decltype(tap_c)::value;
+        load_frags(sb, tap + 1, (P * NTAP + tap + 1) & 1);
+        mma_tap((P * NTAP + tap) & 1);
+#pragma unroll
+        for (int j = DPT * tap; j < DPT * tap + DPT && j < C::SLOTS; ++j)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(is_in[j] ? r_in : r_w, (__attribute__((address_space(3))) void*)(smem + (P ^ 1) * C::BUF_BYTES + dst[j]), 16, vo[j],
+                                                   (is_in[j] ? oi : ow) * 2, 0, 0);
+        static_assert(C::SLOTS <= DPT * (NTAP - 1), "every DMA request has a tap");
+      });
+      static_for<NTAP - 1>([&](auto tap_c) {
+        constexpr int tap = decltype(tap_c)::value;
+        constexpr int left = C::SLOTS - DPT * tap;
+        constexpr int nd = left > DPT ? DPT : (left > 0 ? left : 0);
+        tap_groups<2 + C::MT, 2 * C::MT, nd>();
+      });
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if constexpr (!LAST) load_frags(smem + (P ^ 1) * C::BUF_BYTES, 0, ((P + 1) * NTAP) & 1);
+      mma_tap((P * NTAP + NTAP - 1) & 1);
+      tap_groups<LAST ? 0 : 2 + C::MT, 2 * C::MT, 0>();
+    };
+    for (int c = 0; c + 2 < nslices; c += 2) {
+      skew_slice(c, std::integral_constant<int, 0>{}, std::false_type{}, in_off(c + 1), w_off(c + 1));
+      skew_slice(c + 1, std::integral_constant<int, 1>{}, std::false_type{}, in_off(c + 2), w_off(c + 2));
+    }
+    skew_slice(nslices - 2, std::integral_constant<int, 0>{}, std::false_type{}, in_off(nslices - 1), w_off(nslices - 1));
+    // this tile's requests are all out: the offsets and descriptors become the next tile's
+    const Tile done = cur;
+    {
+      const bool has_next = ti + 1 < t1;
+      cur = decode(has_next ? ti + 1 : ti);
+      offsets(cur, vo);
+      if (!has_next) {
+#pragma unroll
+        for (int j = 0; j < C::SLOTS; ++j) vo[j] = OOB;
+      }
+      r_in = rsrc_in(cur);
+      r_w = rsrc_w(cur);
+    }
+    skew_slice(nslices - 1, std::integral_constant<int, 1>{}, std::true_type{}, 0, 0);
+    // epilogue from the accumulators; the next tile's first slice is in LDS
+    {
+      const int n0 = (NT == 1 ? done.nb : done.nb * 2 + wn) * 64;
+      const DirectBias bs = direct_bias<2>(p, n0, qh);
+#pragma unroll
+      for (int m = 0; m < C::MT; ++m) {
+        epilogue_direct_row<2>(p, acc[m], bs, done.b, done.oy0 + C::MT * wm + m, done.ox0, lx, n0, qh, nullptr);
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+      }
+    }
+    load_frags(smem, 0, 0);
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 1x1 stride-1 layers with K >= 256 as a pipelined GEMM: out [M][N] = A [M][K] . W^T (+ bias, residual, activation), single-pass modes.
 // These layers -- the CRNN's conv4 (K = 1024) and sequence-head projections (512 -> 2048, 256 -> 2048, 512 -> 512 / 256), Lore's wide 1x1 convs --
 // ran on conv_igemm_kernel<1, 1> / conv1x1_wide_kernel (4 x 32 x 64 tiles, two barriers per 32 or 128 channels) or on the streaming row GEMM
@@ -3072,6 +3270,38 @@ static int launch_pipe(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   return PT_OK;
 }
 
+// the persistent form of launch_pipe<NT, NWV, true, 0, true, S> (conv3x3_pipe_persist_kernel): as many workgroups as fit the chip, a contiguous run of tiles each
+template <int NT, int NWV, int S>
+static int launch_pipe_persist(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
+  using C = PipeCfg<NT, NWV, 0, S>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pipe_persist_kernel<NT, NWV, S>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::BUF_BYTES));
+    attr_done = true;
+  }
+  k.n_tiles = k.N / C::NW;
+  k.tiles_x = (k.Wo + C::TW - 1) / C::TW;
+  k.tiles_y = (k.Ho + C::TH - 1) / C::TH;
+  const long long total = (long long)k.B * k.tiles_x * k.tiles_y * k.n_tiles;
+  PT_REQUIRE(total > 0 && total < (1ll << 31), "conv grid out of range (%lld tiles)", total);
+  k.total_tiles = (int)total;
+  const int per_cu = 2 * C::BUF_BYTES <= 80 * 1024 ? 2 : 1;      // workgroups that fit a CU's LDS
+  long long grid = (long long)e->num_cu * per_cu;
+  if (const char* gv = getenv("PT_CONV_PERSIST_GRID")) {          // tests: fewer workgroups, longer runs
+    const int gg = atoi(gv);
+    if (gg > 0) grid = gg;
+  }
+  if (grid > total) grid = total;
+  char label[48];
+  snprintf(label, sizeof(label), "conv3x3 %sv5%s %d->%d @%dx%d", S == 2 ? "s2 " : "", NWV == 4 ? "h" : "", k.Cin, k.N, k.Ho, k.Wo);
+  {
+    PtProfScope prof(e, s, PT_PROF_CONV3X3, flop, label);
+    hipLaunchKernelGGL((conv3x3_pipe_persist_kernel<NT, NWV, S>), dim3((unsigned)grid), dim3(C::NTHR), 2 * C::BUF_BYTES, s, k);
+  }
+  PT_HIP_CHECK(hipGetLastError());
+  return PT_OK;
+}
+
 // 1x1 stride-1 plain layers with K >= 256, N % 128 == 0, M % 32 == 0 in the single-pass modes: the pipelined GEMM (gemm_pipe_kernel)
 static int launch_gemm_pipe(pt_engine* e, ConvK& k, hipStream_t s, double flop) {
   using C = GemmPipeCfg;
@@ -3282,7 +3512,7 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
       phase = d.tap_mask[i] == mk;
     }
     if (phase && cv == 3 && v3ok && !(pv && atoi(pv) < 3)) return launch_pipe<2, 8, true, 0, false, 1, true>(e, k, s, flop);
-    const int pipe = masked ? 0 : (pv ? atoi(pv) : 3);      // 1: barrier behind tap 8, 2: in front of it (SKEW), 3: + register epilogue on plain layers
+    const int pipe = masked ? 0 : (pv ? atoi(pv) : 4);      // 1: barrier behind tap 8, 2: in front of it (SKEW), 3: + register epilogue on plain layers, 4: + persistent workgroups
     if (pick == 3 && pipe == 1) {
       if (use_half) return launch_pipe<1, 4, false>(e, k, s, flop);
       return d.N % 128 == 0 ? launch_pipe<2, 8, false>(e, k, s, flop) : launch_pipe<1, 8, false>(e, k, s, flop);
@@ -3290,6 +3520,15 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
     if (pick == 3 && pipe >= 2) {
       // register epilogue for the plain layers (PT_CONV_PIPE=2: the staged fp32 epilogue everywhere, A/B switch)
       const bool direct = pipe >= 3 && !k.split && !k.pool && !k.shuffle_cout;
+      // 4: the persistent form for the 8-wave tiles where a workgroup gets at least two tiles (interleaved A/B, tools/conv_ab.py: 256 -> 256 @64^2 1305 -> 1327
+      // TF/s, @60^2 1174 -> 1198, 512 -> 512 @32^2 1379 -> 1404, @30^2 1267 -> 1275; the 4-wave tile LOSES 14 % as a persistent kernel -- 128 -> 128 @128^2
+      // 1134 -> 975: two of its workgroups per CU already cover each other's prologues, and the run's bookkeeping costs it registers it does not have)
+      if (direct && pipe >= 4 && (!use_half || pipe >= 5) && !k.xlimit && !k.xlimit_rows && !k.blist) {
+        const bool nt2 = d.N % 128 == 0;
+        const long long tiles = (long long)k.B * ((k.Ho + (nt2 ? 15 : 31)) / (nt2 ? 16 : 32)) * ((k.Wo + 31) / 32) * (d.N / (nt2 ? 128 : 64));
+        if (tiles >= 2ll * e->num_cu || pipe >= 5)      // (5: whatever the tile count -- tests)
+          return nt2 ? launch_pipe_persist<2, 8, 1>(e, k, s, flop) : launch_pipe_persist<1, 8, 1>(e, k, s, flop);
+      }
       if (direct) {
         if (use_half) return launch_pipe<1, 4, true, 0, true>(e, k, s, flop);
         return d.N % 128 == 0 ? launch_pipe<2, 8, true, 0, true>(e, k, s, flop) : launch_pipe<1, 8, true, 0, true>(e, k, s, flop);

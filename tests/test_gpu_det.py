@@ -173,15 +173,22 @@ def test_conv_v4_equals_v3(eng, case, monkeypatch):
     stride = case.get("stride", 1)
     rd = nhwc(torch.randn(B, H, W, N, generator=g)) if rm else None
     outs = []
-    for v in ("0", "1", "2", "3"):      # v3; v4 with the barrier behind tap 8; in front of it; + the register epilogue on plain layers (the default)
+    # v3; v4 with the barrier behind tap 8; in front of it; + the register epilogue on plain layers; + persistent workgroups (v5: forced here whatever the
+    # tile count -- the default takes it from two tiles per workgroup up -- with 3 and with 7 workgroups: runs of several tiles, the last one shorter)
+    for v, grid in (("0", None), ("1", None), ("2", None), ("3", None), ("5", "3"), ("5", "7")):
         monkeypatch.setenv("PT_CONV_PIPE", v)
+        if grid:
+            monkeypatch.setenv("PT_CONV_PERSIST_GRID", grid)
         eng.profile_enable(1)
         outs.append(eng.op_conv2d(x, wt, bd, 3, stride, relu=case.get("relu", False), res=rd, res_mode=rm, split=split).clone())
         torch.cuda.synchronize()
         labels = list(eng.profile_read_labels())
         eng.profile_enable(False)
-        # the launcher's label says which kernel ran
-        assert labels and all(k.startswith("conv3x3") and ((" v4" in k) == (v != "0")) for k in labels), labels
+        monkeypatch.delenv("PT_CONV_PERSIST_GRID", raising=False)
+        # the launcher's label says which kernel ran (v5 only where it exists: plain stride-1 layers in the single-pass modes)
+        assert labels and all(k.startswith("conv3x3") and ((" v4" in k or " v5" in k) == (v != "0")) for k in labels), labels
+        if v == "5" and not split and stride == 1:      # (5 also forces the 8-wave tile: the 4-wave one has no persistent form)
+            assert all(" v5" in k for k in labels), labels
     assert torch.isfinite(outs[0].float()).all() and outs[0].float().abs().max() > 0
     for o in outs[1:]:
         assert torch.equal(outs[0].view(torch.int16), o.view(torch.int16))
