@@ -1674,6 +1674,123 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_argmax_kernel(const bf16_t* _
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The K = 512 classifier arg-max (gemm_argmax_kernel<32, 0, 8>: a wave's 32 rows resident in registers, the class tiles streamed through LDS) with the
+// weight stream on LDS-DMA and a pinned inner loop.  In that kernel's ISA every pair of MFMAs waits for an LDS round trip requested just in front of
+// it (read, read, wait, MFMA, wait, MFMA: hipcc sinks the reads to their uses), all 64 MFMAs of a class tile hang on ONE accumulator chain, the next
+// tile travels global -> 32 registers -> ds_write, and a tile costs two barriers: matrix pipe 51 % busy, LDS port 42 % (profiles/r06).  Here
+//   * the next tile is requested by MUBUF LDS-DMA (one 1 KB class row per instruction, eight per wave) into the other of two LDS buffers: no staging
+//     registers, no ds_writes, ONE barrier per tile;
+//   * both 32-class halves of a tile are multiplied together (two accumulator chains: an MFMA never waits for the one in front of it), the
+//     fragments of step ks + 2 are requested between the MFMAs of step ks (pinned with scheduling groups).
+// Same operands, same K order per (row, class), same visiting order of the classes in the arg-max: ids and maxima equal gemm_argmax_kernel's bit for bit.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void cls_argmax_dma_kernel(const bf16_t* __restrict__ A, long long M, const bf16_t* __restrict__ W,
+                                                                const float* __restrict__ bias, int N, int* __restrict__ ids, float* __restrict__ maxv,
+                                                                int lda, long long wts) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (buffer-resource builtins: device pass only)
+  a16_kernel_enter();
+  constexpr int KSTEPS = 32, K = 512, P = K * 2 + 16, TILE = 64 * P, D = 2;      // P: LDS row pitch (odd number of 16-byte slots); D: fragment prefetch distance
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sb = reinterpret_cast<float*>(smem + 2 * TILE);            // [2][64] bias of the tile in each buffer
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lx = lane & 31, q = lane >> 5;
+  const long long row0 = ((long long)blockIdx.x * 8 + wave) * 32;
+  const long long row = row0 + lx;
+  const long long rc = row < M ? row : M - 1;
+  bf16x8 areg[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) areg[ks] = *reinterpret_cast<const bf16x8*>(A + rc * lda + ks * 16 + q * 8);
+  // DMA slot j of this wave = class row r = wave + 8 j of the tile; lane L fetches 16-byte part L & 3 of 32-channel chunk L >> 2 (tiling [K/32][64][32])
+  constexpr int OOB = 0x7FFFF000;
+  const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W), 0, OOB, 0x00020000);
+  int voff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) voff[j] = ((((lane >> 2) * 64 + wave + 8 * j) * 32) + (lane & 3) * 8) * 2;
+  const int NT = N / 64;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (__attribute__((address_space(3))) void*)(smem + (wave + 8 * j) * P), 16, voff[j], 0, 0, 0);
+  if (tid < 64) sb[tid] = bias[tid];
+  float bv = -INFINITY;
+  int bi = 0;
+  for (int t = 0; t < NT; ++t) {
+    const int b = t & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // tile t is in buffer b (every wave's rows), tile t - 1 has been read
+    const bool more = t + 1 < NT;
+    const int soff = more ? (int)((long long)(t + 1) * wts * 2) : 0;
+    if (tid < 64) sb[(b ^ 1) * 64 + tid] = bias[(more ? t + 1 : t) * 64 + tid];
+    const char* wr = smem + b * TILE + lx * P + q * 16;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    bf16x8 f0[D + 1], f1[D + 1];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      f0[d] = *reinterpret_cast<const bf16x8*>(wr + d * 32);
+      f1[d] = *reinterpret_cast<const bf16x8*>(wr + 32 * P + d * 32);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      if (ks + D < KSTEPS) {
+        f0[(ks + D) % (D + 1)] = *reinterpret_cast<const bf16x8*>(wr + (ks + D) * 32);
+        f1[(ks + D) % (D + 1)] = *reinterpret_cast<const bf16x8*>(wr + 32 * P + (ks + D) * 32);
+      }
+      acc0 = mfma_32x32x16_a16(f0[ks % (D + 1)], areg[ks], acc0);
+      acc1 = mfma_32x32x16_a16(f1[ks % (D + 1)], areg[ks], acc1);
+      if ((ks & 3) == 0)      // the next tile's eight rows of this wave, one request every four steps (the last tile: out of range, zero-filled, never read)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (__attribute__((address_space(3))) void*)(smem + (b ^ 1) * TILE + (wave + 8 * (ks >> 2)) * P), 16,
+                                                 more ? voff[ks >> 2] : OOB, soff, 0, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * D, 0);
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (ks + D < KSTEPS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (ks + D < KSTEPS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if ((ks & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    const float* sbt = sb + b * 64;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cl = (r & 3) + 8 * (r >> 2) + 4 * q;
+      const float v = acc0[r] + sbt[cl];
+      if (v > bv) { bv = v; bi = t * 64 + cl; }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cl = 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
+      const float v = acc1[r] + sbt[cl];
+      if (v > bv) { bv = v; bi = t * 64 + cl; }
+    }
+  }
+  const float ov = __shfl_xor(bv, 32);
+  const int oi = __shfl_xor(bi, 32);
+  if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  if (q == 0 && row < M) {
+    ids[row] = bi;
+    if (maxv) maxv[row] = bv;
+  }
+#endif
+}
+
+static bool cls_dma() {      // PT_CLS_DMA=0: gemm_argmax_kernel<32, 0, 8> for the K = 512 classifier (A/B switch, read per call)
+  const char* ev = getenv("PT_CLS_DMA");
+  return !(ev && ev[0] == '0');
+}
+constexpr int CLS_DMA_SMEM = 2 * 64 * (512 * 2 + 16) + 2 * 64 * 4;
+static int cls_dma_attr() {
+  static bool done = false;
+  if (!done) {
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cls_argmax_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CLS_DMA_SMEM));
+    done = true;
+  }
+  return PT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Classifier arg-max of the hi/lo (BF16X3) mode by bound and refine.  The tiled three-pass GEMM with per-tile partials + reduce
 // spends 33 ms per 5 k lines (560 TF/s of three-pass work) to find ONE class per row.  With a = a_hi + a_lo, w = w_hi + w_lo:
 //     |a . w - a_hi . w_hi|  <=  |a_lo . w_hi| + |a . w_lo|  <=  2^-9 |a| |w_hi| + 2^-9 |a| |w| (1 + 2^-9)  <  2^-8 * 1.02 |a_hi| |w|
@@ -1945,8 +2062,13 @@ int pt_launch_gemm_argmax_x3(const bf16_t* A, long long M, int K, const bf16_t* 
   hipLaunchKernelGGL(wnorm_max_kernel, dim3(N / 64), dim3(256), 0, s, W3, N, K, wmax);
   const long long wts = (long long)3 * (K / 32) * 2048;
   // sweep 1: the single-pass maximum of every row (the bf16 mode's kernel on the hi halves); sweep 2: the classes within the bound of it
-  hipLaunchKernelGGL((gemm_argmax_kernel<32, 0, 8>), dim3((unsigned)((M + 255) / 256)), dim3(512), SMEM, s, A, M, W3, bias, N, ids, rowmax, nullptr, 0,
-                     nullptr, 2 * K, wts);      // eight waves per weight stage, as the bf16 mode's classifier
+  if (cls_dma()) {
+    if (cls_dma_attr() != PT_OK) return PT_ERR_HIP;
+    hipLaunchKernelGGL(cls_argmax_dma_kernel, dim3((unsigned)((M + 255) / 256)), dim3(512), CLS_DMA_SMEM, s, A, M, W3, bias, N, ids, rowmax, 2 * K, wts);
+  } else {
+    hipLaunchKernelGGL((gemm_argmax_kernel<32, 0, 8>), dim3((unsigned)((M + 255) / 256)), dim3(512), SMEM, s, A, M, W3, bias, N, ids, rowmax, nullptr, 0,
+                       nullptr, 2 * K, wts);      // eight waves per weight stage, as the bf16 mode's classifier
+  }
   hipLaunchKernelGGL((gemm_cand_kernel<32>), dim3((unsigned)((M + 127) / 128)), dim3(256), SMEM, s, A, M, 2 * K, W3, wts, bias, N,
                      reinterpret_cast<const float*>(wmax), rowmax, cand);
   hipLaunchKernelGGL(cand_eval_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, s, A, M, 2 * K, K, W3, bias, N, n_real, cand, ids, maxv, ovf_count,
@@ -1988,7 +2110,10 @@ int pt_launch_gemm_argmax(const bf16_t* A, long long M, int K, const bf16_t* W, 
     if (nw == 8) hipLaunchKernelGGL((gemm_argmax_kernel<12, 0, 8>), grid, blk, 64 * (192 * 2 + 16) + 64 * 4, s, A, M, W, bias, N, ids, maxv, nullptr, 0, nullptr, 192, 6ll * 2048);
     else hipLaunchKernelGGL((gemm_argmax_kernel<12, 0>), grid, blk, 64 * (192 * 2 + 16) + 64 * 4, s, A, M, W, bias, N, ids, maxv, nullptr, 0, nullptr, 192, 6ll * 2048);
   } else {
-    if (nw == 8) hipLaunchKernelGGL((gemm_argmax_kernel<32, 0, 8>), grid, blk, SMEM, s, A, M, W, bias, N, ids, maxv, nullptr, 0, nullptr, 512, 16ll * 2048);
+    if (nw == 8 && cls_dma()) {
+      if (cls_dma_attr() != PT_OK) return PT_ERR_HIP;
+      hipLaunchKernelGGL(cls_argmax_dma_kernel, grid, blk, CLS_DMA_SMEM, s, A, M, W, bias, N, ids, maxv, 512, 16ll * 2048);
+    } else if (nw == 8) hipLaunchKernelGGL((gemm_argmax_kernel<32, 0, 8>), grid, blk, SMEM, s, A, M, W, bias, N, ids, maxv, nullptr, 0, nullptr, 512, 16ll * 2048);
     else hipLaunchKernelGGL((gemm_argmax_kernel<32, 0>), grid, blk, SMEM, s, A, M, W, bias, N, ids, maxv, nullptr, 0, nullptr, 512, 16ll * 2048);
   }
   PT_HIP_CHECK(hipGetLastError());

@@ -472,3 +472,36 @@ def test_conv0_conv1_in_one_launch_equals_the_separate_launches(sd, mode, monkey
     # the register-staged conv1 of the two-launch path: another summation order, same network
     assert (outs["fused0"][0] != outs["two"][0]).mean() < 0.01 and np.abs(outs["fused0"][1] - outs["two"][1]).max() < 0.25
     assert len(np.unique(outs["fused0"][0])) > 20
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f16", "bf16x3"])
+def test_classifier_dma_kernel_equals_the_register_staged_one(eng, sd, mode, monkeypatch):
+    """cls_argmax_dma_kernel (class tiles by LDS-DMA into two buffers, both 32-class halves multiplied together, fragment reads pinned two steps ahead) gives
+    the ids and maxima of gemm_argmax_kernel<32, 0, 8> (PT_CLS_DMA=0, read per call) bit for bit; in the hi/lo mode it is the first sweep of the
+    bound-and-refine arg-max.  600 rows x 160 steps: several workgroups, the last one partial."""
+    from pdf_table_amd.engine import HipEngine
+    rng = np.random.default_rng(31)
+    g = rng.uniform(0, 1, (77, 32, 640)).astype(np.float32)
+    for i in range(0, 77, 5):
+        g[i, :, int(rng.integers(40, 600)):] = 0
+    e = HipEngine(0)
+    try:
+        e.set_precision({"bf16x3": L.PT_PRECISION_BF16X3, "f16": L.PT_PRECISION_F16}.get(mode, L.PT_PRECISION_BF16))
+        e.load_weights(L.PT_MODEL_CRNN, pack_crnn(sd, fmt=e.weight_fmt))
+        gt = torch.from_numpy(g)
+        if mode == "bf16x3":
+            hi = gt.to(torch.bfloat16)
+            x = torch.stack([hi, (gt - hi.float()).to(torch.bfloat16)], -1).contiguous().cuda()
+        else:
+            x = gt.to(torch.float16 if mode == "f16" else torch.bfloat16).cuda()
+        outs = {}
+        for sw in ("1", "0"):
+            monkeypatch.setenv("PT_CLS_DMA", sw)
+            ids, mx = e.rec_forward_net(x)
+            torch.cuda.synchronize()
+            e.check()
+            outs[sw] = (ids.cpu().numpy(), mx.cpu().numpy())
+    finally:
+        e.close()
+    assert np.array_equal(outs["1"][0], outs["0"][0]) and np.array_equal(outs["1"][1], outs["0"][1])
+    assert len(np.unique(outs["1"][0])) > 20
