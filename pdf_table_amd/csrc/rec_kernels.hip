@@ -1684,9 +1684,13 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_argmax_kernel(const bf16_t* _
 //     fragments of step ks + 2 are requested between the MFMAs of step ks (pinned with scheduling groups).
 // Same operands, same K order per (row, class), same visiting order of the classes in the arg-max: ids and maxima equal gemm_argmax_kernel's bit for bit.
 // ---------------------------------------------------------------------------------------------------
+constexpr int CAND_SLOTS = 8;      // candidate slots per (row, half of the classes a lane pair splits): 16 per row (the hi/lo mode's bound-and-refine arg-max below)
+
+template <int MODE>      // 0: arg-max (ids, maxv); 1: the hi/lo mode's second sweep -- every class within the bound of the row's maximum into cand (gemm_cand_kernel's lists)
 __global__ __launch_bounds__(512, 1) void cls_argmax_dma_kernel(const bf16_t* __restrict__ A, long long M, const bf16_t* __restrict__ W,
                                                                 const float* __restrict__ bias, int N, int* __restrict__ ids, float* __restrict__ maxv,
-                                                                int lda, long long wts) {
+                                                                int lda, long long wts, const float* __restrict__ wmax, const float* __restrict__ rowmax,
+                                                                int* __restrict__ cand) {
 #if defined(__HIP_DEVICE_COMPILE__)      // (buffer-resource builtins: device pass only)
   a16_kernel_enter();
   constexpr int KSTEPS = 32, K = 512, P = K * 2 + 16, TILE = 64 * P, D = 2;      // P: LDS row pitch (odd number of 16-byte slots); D: fragment prefetch distance
@@ -1701,6 +1705,22 @@ __global__ __launch_bounds__(512, 1) void cls_argmax_dma_kernel(const bf16_t* __
   bf16x8 areg[KSTEPS];
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) areg[ks] = *reinterpret_cast<const bf16x8*>(A + rc * lda + ks * 16 + q * 8);
+  float thr = 0.f;
+  int* cp = nullptr;
+  int cnt = 0;
+  if (MODE == 1) {      // (gemm_cand_kernel's bound: see the derivation above it)
+    float ss = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = (float)areg[ks][i];
+        ss += v * v;
+      }
+    ss += __shfl_xor(ss, 32);
+    thr = rowmax[rc] - 2.f * (0.00390625f * 1.02f + 6.103515625e-05f) * sqrtf(ss) * 1.0001f * wmax[0];
+    cp = cand + (rc * 2 + q) * (1 + CAND_SLOTS);
+  }
   // DMA slot j of this wave = class row r = wave + 8 j of the tile; lane L fetches 16-byte part L & 3 of 32-channel chunk L >> 2 (tiling [K/32][64][32])
   constexpr int OOB = 0x7FFFF000;
   const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W), 0, OOB, 0x00020000);
@@ -1754,17 +1774,22 @@ __global__ __launch_bounds__(512, 1) void cls_argmax_dma_kernel(const bf16_t* __
     }
     const float* sbt = sb + b * 64;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int cl = (r & 3) + 8 * (r >> 2) + 4 * q;
-      const float v = acc0[r] + sbt[cl];
-      if (v > bv) { bv = v; bi = t * 64 + cl; }
-    }
+    for (int half = 0; half < 2; ++half)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int cl = 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
-      const float v = acc1[r] + sbt[cl];
-      if (v > bv) { bv = v; bi = t * 64 + cl; }
-    }
+      for (int r = 0; r < 16; ++r) {
+        const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
+        const float v = (half ? acc1[r] : acc0[r]) + sbt[cl];
+        if (MODE == 0) {
+          if (v > bv) { bv = v; bi = t * 64 + cl; }
+        } else if (v >= thr) {      // rare (1.4 per row): straight to memory
+          if (cnt < CAND_SLOTS && row < M) cp[1 + cnt] = t * 64 + cl;
+          ++cnt;
+        }
+      }
+  }
+  if (MODE == 1) {
+    if (row < M) cp[0] = cnt;
+    return;
   }
   const float ov = __shfl_xor(bv, 32);
   const int oi = __shfl_xor(bi, 32);
@@ -1784,7 +1809,8 @@ constexpr int CLS_DMA_SMEM = 2 * 64 * (512 * 2 + 16) + 2 * 64 * 4;
 static int cls_dma_attr() {
   static bool done = false;
   if (!done) {
-    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cls_argmax_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CLS_DMA_SMEM));
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cls_argmax_dma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, CLS_DMA_SMEM));
+    PT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cls_argmax_dma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, CLS_DMA_SMEM));
     done = true;
   }
   return PT_OK;
@@ -1803,7 +1829,6 @@ static int cls_dma_attr() {
 // over all classes (rare: the margin is 0.18 standard deviations of a row's logits).  The result is the arg-max of the exact
 // (hi + lo) x (hi + lo) products: at least as close to the fp32 oracle as the three-pass sum it replaces.
 // ---------------------------------------------------------------------------------------------------
-constexpr int CAND_SLOTS = 8;      // per (row, half of the classes a lane pair splits): 16 per row
 
 __global__ __launch_bounds__(256) void wnorm_max_kernel(const bf16_t* __restrict__ W3, int N, int K, unsigned* __restrict__ out) {
   a16_kernel_enter();
@@ -2064,13 +2089,17 @@ int pt_launch_gemm_argmax_x3(const bf16_t* A, long long M, int K, const bf16_t* 
   // sweep 1: the single-pass maximum of every row (the bf16 mode's kernel on the hi halves); sweep 2: the classes within the bound of it
   if (cls_dma()) {
     if (cls_dma_attr() != PT_OK) return PT_ERR_HIP;
-    hipLaunchKernelGGL(cls_argmax_dma_kernel, dim3((unsigned)((M + 255) / 256)), dim3(512), CLS_DMA_SMEM, s, A, M, W3, bias, N, ids, rowmax, 2 * K, wts);
+    hipLaunchKernelGGL(cls_argmax_dma_kernel<0>, dim3((unsigned)((M + 255) / 256)), dim3(512), CLS_DMA_SMEM, s, A, M, W3, bias, N, ids, rowmax, 2 * K, wts, nullptr, nullptr, nullptr);
   } else {
     hipLaunchKernelGGL((gemm_argmax_kernel<32, 0, 8>), dim3((unsigned)((M + 255) / 256)), dim3(512), SMEM, s, A, M, W3, bias, N, ids, rowmax, nullptr, 0,
                        nullptr, 2 * K, wts);      // eight waves per weight stage, as the bf16 mode's classifier
   }
-  hipLaunchKernelGGL((gemm_cand_kernel<32>), dim3((unsigned)((M + 127) / 128)), dim3(256), SMEM, s, A, M, 2 * K, W3, wts, bias, N,
-                     reinterpret_cast<const float*>(wmax), rowmax, cand);
+  if (cls_dma())
+    hipLaunchKernelGGL(cls_argmax_dma_kernel<1>, dim3((unsigned)((M + 255) / 256)), dim3(512), CLS_DMA_SMEM, s, A, M, W3, bias, N, nullptr, nullptr, 2 * K, wts,
+                       reinterpret_cast<const float*>(wmax), rowmax, cand);
+  else
+    hipLaunchKernelGGL((gemm_cand_kernel<32>), dim3((unsigned)((M + 127) / 128)), dim3(256), SMEM, s, A, M, 2 * K, W3, wts, bias, N,
+                       reinterpret_cast<const float*>(wmax), rowmax, cand);
   hipLaunchKernelGGL(cand_eval_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, s, A, M, 2 * K, K, W3, bias, N, n_real, cand, ids, maxv, ovf_count,
                      ovf_rows);
   hipLaunchKernelGGL(cand_full_kernel, dim3(2048), dim3(256), 0, s, A, 2 * K, K, W3, bias, n_real, ovf_count, ovf_rows, ids, maxv);
@@ -2112,7 +2141,7 @@ int pt_launch_gemm_argmax(const bf16_t* A, long long M, int K, const bf16_t* W, 
   } else {
     if (nw == 8 && cls_dma()) {
       if (cls_dma_attr() != PT_OK) return PT_ERR_HIP;
-      hipLaunchKernelGGL(cls_argmax_dma_kernel, grid, blk, CLS_DMA_SMEM, s, A, M, W, bias, N, ids, maxv, 512, 16ll * 2048);
+      hipLaunchKernelGGL(cls_argmax_dma_kernel<0>, grid, blk, CLS_DMA_SMEM, s, A, M, W, bias, N, ids, maxv, 512, 16ll * 2048, nullptr, nullptr, nullptr);
     } else if (nw == 8) hipLaunchKernelGGL((gemm_argmax_kernel<32, 0, 8>), grid, blk, SMEM, s, A, M, W, bias, N, ids, maxv, nullptr, 0, nullptr, 512, 16ll * 2048);
     else hipLaunchKernelGGL((gemm_argmax_kernel<32, 0>), grid, blk, SMEM, s, A, M, W, bias, N, ids, maxv, nullptr, 0, nullptr, 512, 16ll * 2048);
   }
