@@ -976,6 +976,10 @@ __global__ __launch_bounds__(256, 1) void lstm_dir_dma_kernel(const bf16_t* __re
 // a launch costs about the same whatever it holds).  Same sums in the same order for every MI.
 constexpr int CLL_MAX = 192;  // lines per cluster at MI = 3 (scratch is sized for it)
 
+// (global, not generic: the opaque per-step pointers below would otherwise make every h fragment load a FLAT instruction, and with FLAT loads in flight hipcc
+// waits lgkmcnt(0) in front of every LDS-fed MFMA)
+typedef const __attribute__((address_space(1))) unsigned long long* gptr_u64;
+
 template <int MI>
 __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(const bf16_t* __restrict__ gx, const bf16_t* __restrict__ whh,
                                                                bf16_t* __restrict__ hout, int B, int T, int ncl,
@@ -1066,10 +1070,15 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(const bf16_t* __re
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int ks = 0; ks < 16; ++ks) {
-            const unsigned long long* pp = hp + ((size_t)((2 * mp + mi) * 16 + ks) * 64 + lane) * 2;
+            const gptr_u64 pp = (gptr_u64)hp + ((size_t)((2 * mp + mi) * 16 + ks) * 64 + lane) * 2;
             af[mi][ks][0] = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             af[mi][ks][1] = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
+        // the four gate fragments of k-step ks + 1 are requested between the eight MFMAs of k-step ks (pinned: left alone, with ONE wave per SIMD,
+        // hipcc emits read, wait, MFMA, MFMA on one fragment register -- 64 exposed LDS round trips per step)
+        bf16x8 wf[2][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) wf[0][g] = *reinterpret_cast<const bf16x8*>(wl + (g * 2 + h) * 1024 + lane * 16);
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
           bf16x8 a[2];
@@ -1080,11 +1089,21 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(const bf16_t* __re
           }
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(wl + ((ks * 4 + g) * 2 + h) * 1024 + lane * 16);
-            acc[0][g] = mfma_32x32x16_a16(a[0], b, acc[0][g]);
-            acc[1][g] = mfma_32x32x16_a16(a[1], b, acc[1][g]);
+            if (ks + 1 < 16) wf[(ks + 1) & 1][g] = *reinterpret_cast<const bf16x8*>(wl + (((ks + 1) * 4 + g) * 2 + h) * 1024 + lane * 16);
+            acc[0][g] = mfma_32x32x16_a16(a[0], wf[ks & 1][g], acc[0][g]);
+            acc[1][g] = mfma_32x32x16_a16(a[1], wf[ks & 1][g], acc[1][g]);
           }
         }
+        __builtin_amdgcn_sched_group_barrier(0x020, 64, 0);      // both tiles' A fragments (global loads) first
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (ks + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          }
       }
       cell(0, acc[0]);
       cell(1, acc[1]);
@@ -1095,7 +1114,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(const bf16_t* __re
       auto fetch = [&](int mi, int buf) {
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-          const unsigned long long* pp = hp + ((size_t)((MI * mp + mi) * 16 + ks) * 64 + lane) * 2;
+          const gptr_u64 pp = (gptr_u64)hp + ((size_t)((MI * mp + mi) * 16 + ks) * 64 + lane) * 2;
           af[buf][ks][0] = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           af[buf][ks][1] = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1110,16 +1129,27 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(const bf16_t* __re
           for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
         if (s > 0) {
           if (mi + 1 < MI) fetch(mi + 1, (mi + 1) & 1);
+          bf16x8 wf[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) wf[g] = *reinterpret_cast<const bf16x8*>(wl + (g * 2 + h) * 1024 + lane * 16);
 #pragma unroll
           for (int ks = 0; ks < 16; ++ks) {
             const unsigned long long two[2] = {af[mi & 1][ks][0], af[mi & 1][ks][1]};
             const bf16x8 a = __builtin_bit_cast(bf16x8, two);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-              const bf16x8 b = *reinterpret_cast<const bf16x8*>(wl + ((ks * 4 + g) * 2 + h) * 1024 + lane * 16);
-              acc[g] = mfma_32x32x16_a16(a, b, acc[g]);
+              acc[g] = mfma_32x32x16_a16(a, wf[g], acc[g]);
+              if (ks + 1 < 16) wf[g] = *reinterpret_cast<const bf16x8*>(wl + (((ks + 1) * 4 + g) * 2 + h) * 1024 + lane * 16);
             }
           }
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              if (ks + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
         }
         cell(mi, acc);
         __builtin_amdgcn_sched_barrier(0);
