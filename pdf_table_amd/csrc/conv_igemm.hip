@@ -3523,9 +3523,12 @@ int pt_launch_conv(pt_engine* e, const ConvDesc& d, hipStream_t s) {
       // 4: the persistent form for the 8-wave tiles where a workgroup gets at least two tiles (interleaved A/B, tools/conv_ab.py: 256 -> 256 @64^2 1305 -> 1327
       // TF/s, @60^2 1174 -> 1198, 512 -> 512 @32^2 1379 -> 1404, @30^2 1267 -> 1275; the 4-wave tile LOSES 14 % as a persistent kernel -- 128 -> 128 @128^2
       // 1134 -> 975: two of its workgroups per CU already cover each other's prologues, and the run's bookkeeping costs it registers it does not have)
+      const bool nt2 = d.N % 128 == 0;
+      const long long tiles = (long long)k.B * ((k.Ho + (nt2 ? 15 : 31)) / (nt2 ? 16 : 32)) * ((k.Wo + 31) / 32) * (d.N / (nt2 ? 128 : 64));
+      // (a four-slice layer without a residual is better off on the persistent 8-wave tile than on the 4-wave one: 64 -> 256 @256^2 900 -> 955 TF/s; with
+      // eight slices the two are level -- 128 -> 128 @128^2 1101 / 1120 -- and with a residual the 4-wave tile wins, 922 against 862)
+      if (use_half && half < 0 && direct && pipe >= 4 && d.Cin == 64 && nt2 && !d.res && tiles >= 2ll * e->num_cu) use_half = false;
       if (direct && pipe >= 4 && (!use_half || pipe >= 5) && !k.xlimit && !k.xlimit_rows && !k.blist) {
-        const bool nt2 = d.N % 128 == 0;
-        const long long tiles = (long long)k.B * ((k.Ho + (nt2 ? 15 : 31)) / (nt2 ? 16 : 32)) * ((k.Wo + 31) / 32) * (d.N / (nt2 ? 128 : 64));
         if (tiles >= 2ll * e->num_cu || pipe >= 5)      // (5: whatever the tile count -- tests)
           return nt2 ? launch_pipe_persist<2, 8, 1>(e, k, s, flop) : launch_pipe_persist<1, 8, 1>(e, k, s, flop);
       }
