@@ -40,5 +40,5 @@ seen = set()
 for name, mf, w in sorted(rows, key=lambda r: -r[2] / r[1]):
     if mf >= 16 and keep in name and name not in seen:
         seen.add(name)
-        dem = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip().split("(")[0]
+        dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().split("(")[0]
         print(f"{w / mf:5.2f}  {mf:4d} MFMAs  {dem[-100:]}")
