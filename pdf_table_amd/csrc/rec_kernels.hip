@@ -1305,7 +1305,7 @@ __global__ __launch_bounds__(64 * NW, 1) void lstm_cluster8_x3_kernel(const bf16
           for (int ks = 0; ks < KH; ++ks)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
-              const unsigned long long* pp = hp + ((size_t)((tile * 16 + k0 + ks) * 2 + pl) * 64 + lane) * 2;
+              const gptr_u64 pp = (gptr_u64)hp + ((size_t)((tile * 16 + k0 + ks) * 2 + pl) * 64 + lane) * 2;
               af[ks][pl][0] = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               af[ks][pl][1] = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -1379,7 +1379,7 @@ __global__ __launch_bounds__(64 * NW, 1) void lstm_cluster8_x3_kernel(const bf16
           bf16_t* ho = hout + ((size_t)line * T + t) * 1024 + dir * 256 + member * 32 + pc * 8;
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl) {
-            const unsigned long long* sp = hr + ((size_t)(((m >> 5) * 16 + 2 * member + (pc >> 1)) * 2 + pl) * 64 + (pc & 1) * 32 + (m & 31)) * 2;
+            const gptr_u64 sp = (gptr_u64)hr + ((size_t)(((m >> 5) * 16 + 2 * member + (pc >> 1)) * 2 + pl) * 64 + (pc & 1) * 32 + (m & 31)) * 2;
             const unsigned long long v0 = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long v1 = __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *reinterpret_cast<u32x4*>(ho + pl * 512) = u32x4{(uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1, (uint32_t)(v1 >> 32)};
