@@ -459,8 +459,12 @@ __global__ __launch_bounds__(256, 4) void db_head_mfma_kernel(const bf16_t* __re
       for (int j = 0; j < 4; ++j) xn[j] = *reinterpret_cast<const hbf16x8*>(in + (size_t)pcn * 64 + j * 16 + q * 8);
     }
     // the weight fragments are re-read from LDS for every batch: hoisted out of the loop they would take 128 VGPRs and spill
-    const char* sw = s_w + lx * PITCH + q * 16;
-    const float* sb = s_b + 4 * q;
+    // (LDS-typed pointers: made opaque as generic pointers, every one of the 48 fragment reads of a batch was a FLAT load -- slower than ds_read, and with
+    // FLAT loads in flight hipcc waits lgkmcnt(0) / vmcnt(0) in front of each MFMA)
+    typedef __attribute__((address_space(3))) const char* lds_cptr;
+    typedef __attribute__((address_space(3))) const float* lds_fptr;
+    lds_cptr sw = (lds_cptr)(s_w + lx * PITCH + q * 16);
+    lds_fptr sb = (lds_fptr)(s_b + 4 * q);
     asm volatile("" : "+v"(sw), "+v"(sb));
     float outv[4][4];                               // [quadrant][sub-pixel] of this lane's pixel (valid in the q == 0 lanes)
 #pragma unroll
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(256, 4) void db_head_mfma_kernel(const bf16_t* __re
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const hbf16x8 a = *reinterpret_cast<const hbf16x8*>(sw + t * 32 * PITCH + j * 32);
+          const hbf16x8 a = *reinterpret_cast<__attribute__((address_space(3))) const hbf16x8*>(sw + t * 32 * PITCH + j * 32);
           acc = mfma_32x32x16_a16(a, xf[j], acc);
         }
         // bias + ReLU + round-to-nearest-even to bf16, two values per v_cvt_pk_bf16_f32: the integer rounding (five instructions per
