@@ -837,8 +837,11 @@ __global__ __launch_bounds__(256, KG == 4 ? 3 : 4) void conv1x1_wide_kernel(Conv
 
   u32x4 rin[2 * KG];
   u32x4 rw[KG];
-  // piece idx = tid + j * 256 of a chunk: pixel idx >> 2 of the 4 x 32 patch, 16-byte part idx & 3
-  const int pix0 = tid >> 2, part = tid & 3;
+  // a thread's piece of a chunk: 16-byte part tid & 3 of pixel (row) pix0.  Consecutive groups of four lanes take pixels p and p + 4, not p and p + 1: a
+  // ds_write_b128 is served eight lanes at a time, a pixel row is 68 (36) dwords -- four banks further than its neighbour -- so neighbours overlap in 12 of
+  // their 16 banks and rows four apart do not (the 1x1 kernels spent a third of their LDS cycles in bank conflicts: profiles/r06/lds_activity_all_kernels.txt)
+  const int t4 = tid >> 2, part = tid & 3;
+  const int pix0 = (t4 & ~7) | ((t4 & 1) << 2) | ((t4 >> 1) & 3);
   const int gy0 = oy0 + (pix0 >> 5), gx = ox0 + (pix0 & 31);      // j = 1: two rows further down
   const bool in0 = gy0 < p.H && gx < p.W, in1 = gy0 + 2 < p.H && gx < p.W;
   auto prefetch = [&](int stage) {
@@ -862,7 +865,7 @@ __global__ __launch_bounds__(256, KG == 4 ? 3 : 4) void conv1x1_wide_kernel(Conv
     }
     const bf16_t* wc = wt + (size_t)stage * KG * (64 * 32);
 #pragma unroll
-    for (int g = 0; g < KG; ++g) rw[g] = *reinterpret_cast<const u32x4*>(wc + (g * 256 + tid) * 8);
+    for (int g = 0; g < KG; ++g) rw[g] = *reinterpret_cast<const u32x4*>(wc + (g * 256 + pix0 * 4 + part) * 8);
   };
   auto commit = [&]() {
 #pragma unroll
