@@ -1836,7 +1836,10 @@ __global__ __launch_bounds__(512, 1) void dla_thin_chain16_kernel(const bf16_t* 
       for (int k = 0; k < 2; ++k) {
         const int j = ct * 32 + 16 * k + c16, gy = y00 + i, gx = x00 + j;
         const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && j < C::C0;
-        *reinterpret_cast<uint2*>(s_l0 + (i * C::PW + j) * C::PITCH + kb * 8) = finish(acc[k], b0v, inside);
+        // a level0 row is stored even columns first (32 slots), then the odd ones: level1's stride-2 fragments then read 32 CONSECUTIVE slots (column
+        // 2 lx + s = slot lx, 32 + lx, lx + 1 for s = 0, 1, 2) -- read at a stride of two 48-byte pixels they hit every bank quad twice
+        const int slot = (j & 1) * 32 + (j >> 1);
+        *reinterpret_cast<uint2*>(s_l0 + (i * C::PW + slot) * C::PITCH + kb * 8) = finish(acc[k], b0v, inside);
       }
     }
     __syncthreads();
@@ -1848,7 +1851,8 @@ __global__ __launch_bounds__(512, 1) void dla_thin_chain16_kernel(const bf16_t* 
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        const dbf16x8 av = *reinterpret_cast<const dbf16x8*>(s_l0 + ((2 * oy + t / 3) * C::PW + 2 * lx + t % 3) * C::PITCH + q * 16);
+        const int sl = (t % 3 == 1 ? 32 : 0) + lx + (t % 3 == 2 ? 1 : 0);      // slot of column 2 lx + t % 3
+        const dbf16x8 av = *reinterpret_cast<const dbf16x8*>(s_l0 + ((2 * oy + t / 3) * C::PW + sl) * C::PITCH + q * 16);
         acc = mfma_32x32x16_a16(wf1[t], av, acc);
       }
       const int gy = oy1 + oy, gx = ox1 + lx;
