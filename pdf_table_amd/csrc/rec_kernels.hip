@@ -978,6 +978,9 @@ constexpr int CLL_MAX = 192;  // lines per cluster at MI = 3 (scratch is sized f
 
 // (global, not generic: the opaque per-step pointers below would otherwise make every h fragment load a FLAT instruction, and with FLAT loads in flight hipcc
 // waits lgkmcnt(0) in front of every LDS-fed MFMA)
+#ifndef PT_CL_ABL
+#define PT_CL_ABL 0      // ablation bits of lstm_cluster_kernel (timing only, results wrong): 1 no MFMA loop, 2 no transcendentals in the cell update, 4 no waiting for the other members
+#endif
 typedef const __attribute__((address_space(1))) unsigned long long* gptr_u64;
 
 template <int MI>
@@ -1028,7 +1031,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(const bf16_t* __re
         const int lc = line < last ? line : last;
         gv[mi][r] = *reinterpret_cast<const u32x2*>(gxt + (size_t)lc * T * 2048);
       }
-    if (s > 0) {
+    if (s > 0 && !(PT_CL_ABL & 4)) {
       if (tid < 4 && !dead) {
         int spins = 0;
         while (__hip_atomic_load(fl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < s) {
@@ -1049,10 +1052,17 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(const bf16_t* __re
         const float gf = acc[1][r] + rbf2f(gv[mi][r].x >> 16);
         const float gg = acc[2][r] + rbf2f(gv[mi][r].y & 0xFFFFu);
         const float go = acc[3][r] + rbf2f(gv[mi][r].y >> 16);
+#if PT_CL_ABL & 2
+        const float si = gi * 0.25f, sf = gf * 0.25f, so = go * 0.25f;
+        const float cn = sf * c[mi][r] + si * gg;
+        c[mi][r] = cn;
+        stage[m * SROW + h * 32 + lx] = (bf16_t)rf2bf(so * cn);
+#else
         const float si = fast_sigmoid(gi), sf = fast_sigmoid(gf), so = fast_sigmoid(go);
         const float cn = sf * c[mi][r] + si * fast_tanh(gg);
         c[mi][r] = cn;
         stage[m * SROW + h * 32 + lx] = (bf16_t)rf2bf(so * fast_tanh(cn));
+#endif
       }
     };
     if constexpr (MI == 2) {
@@ -1127,7 +1137,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(const bf16_t* __re
         for (int g = 0; g < 4; ++g)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
-        if (s > 0) {
+        if (s > 0 && !(PT_CL_ABL & 1)) {
           if (mi + 1 < MI) fetch(mi + 1, (mi + 1) & 1);
           bf16x8 wf[4];
 #pragma unroll
